@@ -1,0 +1,1214 @@
+/*
+ * oracle/rapier_oracle.c — TEST INFRASTRUCTURE ONLY (never linked into the product).
+ *
+ * Single-threaded scalar CPU restatement of rapier3d/f32 `PhysicsPipeline::step()`
+ * (reference v0.35.2).  Every function cites the reference lines it follows; paths are
+ * relative to /root/reference/src.  See rapier_oracle.h for the parity-pinning statement.
+ *
+ * Ordering rules that are part of the numerical contract and are
+ * reproduced here exactly:
+ *   1. pair colour = greedy first-fit over per-body u128 masks on begin-touch pairs sorted by
+ *      (min body index, max body index, edge)  — geometry/narrow_phase/contacts.rs:369-385,
+ *      geometry/narrow_phase/mod.rs:90-154;
+ *   2. sweep order = colours with >= 32 four-lane chunks ascending, then the smaller colours
+ *      ascending, then the overflow colour — dynamics/solver/staged_island_solver/init.rs:163-254;
+ *   3. per substep: increment(+gyro) -> per colour update+warmstart -> biased solve (no friction)
+ *      -> integrate -> refreshed unbiased solve with friction — worker.rs:207-650.
+ * Deliberate simplification (documented in DESIGN.md): the overflow colour is swept in bucket
+ * order instead of the body-mask regrouped order of interaction_groups.rs:240-355 (it only
+ * fills when a body has >120 simultaneous dynamic neighbours).
+ */
+#include "rapier_oracle.h"
+#include "ro_shapes.h"
+#include <stdio.h>
+#include <stdlib.h>
+
+#define RO_NUM_COLORS 129
+#define RO_COLOR_OVERFLOW 128
+#define RO_COLOR_UNCOLORED 255
+#define RO_DYNAMIC_COLOR_COUNT 120 /* contact_pair.rs:167 */
+#define RO_NO_BODY 0xffffffffu
+
+typedef struct { uint64_t lo, hi; } u128;
+
+typedef struct {
+    int body_type;
+    pose position, next_position;
+    v3 linvel, angvel;
+    /* local mass properties (parry MassProperties) */
+    v3 local_com; float inv_mass; v3 inv_principal_inertia; quat principal_frame;
+    /* world mass properties — rigid_body_components.rs:528-578 */
+    v3 world_com; v3 effective_inv_mass; sym3 effective_world_inv_inertia;
+    v3 force, torque, user_force, user_torque;
+    float linear_damping, angular_damping, gravity_scale, additional_mass;
+    int dominance, gyroscopic, allow_fast_rotation;
+    int ncolliders, first_collider;
+    uint32_t solver_id; /* active_set_id, RO_NO_BODY for non-dynamic */
+} Body;
+
+typedef struct { v3 mins, maxs; } Aabb;
+
+typedef struct {
+    int parent; pose pos_wrt_parent, pos;
+    int shape; v3 he; float radius;
+    float density, friction, restitution; int friction_rule, restitution_rule;
+    uint32_t memberships, filter;
+    Aabb fat; int has_fat;
+} Collider;
+
+/* SolverContact — contact_pair.rs:617-629 */
+typedef struct { v3 anchor1, anchor2; float dist; v3 tangent_velocity; int cid; } SolverContact;
+
+typedef struct {
+    int c1, c2;
+    int alive;
+    Manifold m;
+    /* ContactManifoldData */
+    v3 normal; float friction, restitution; int relative_dominance;
+    SolverContact sc[4]; int nsc;
+    uint32_t solver_body_ids[2];
+    /* recycle state — contact_pair.rs:262-278 */
+    int has_recycle; pose rec_pos12; quat rec_rot1, rec_rot2; float rec_max_extent, rec_max_drift;
+    uint8_t color; uint32_t color_bodies[2];
+} Pair;
+
+/* ContactWithTwistFriction + builder, one lane — contact_with_twist_friction.rs:18-55,600-630 */
+typedef struct {
+    v3 torque_dir1, torque_dir2, ii_torque_dir1, ii_torque_dir2;
+    float rhs, rhs_wo_bias, impulse, impulse_accumulator, r, cfm_factor;
+} NormalPart;
+typedef struct {
+    v3 dir1, im1, im2; sym3 ii1, ii2; float cfm_factor, limit; v3 tangent1;
+    NormalPart normal_part[4];
+    struct { v3 dp1, dp2, torque_dir1[2], torque_dir2[2], ii_torque_dir1[2], ii_torque_dir2[2];
+             float rhs[2], rhs_wo_bias[2], impulse[2], impulse_accumulator[2], r[3]; } tangent_part;
+    struct { float rhs, impulse, impulse_accumulator, r; } twist_part;
+    float twist_dists[4];
+    uint32_t solver_vel1, solver_vel2; int pair; int num_contacts; int contact_id[4];
+    /* builder */
+    struct { float restitution_seed; v3 local_p1, local_p2; float dist; } infos[4];
+    v3 local_friction_center1, local_friction_center2, tangent_vel, local_n1; float restitution;
+} Constraint;
+
+typedef struct { v3 linear, angular; } SolverVel;
+typedef struct { quat rotation; v3 translation; sym3 ii; v3 im; } SolverPose;
+typedef struct { int enabled; v3 principal_inertia, inv_principal_inertia; quat principal_frame; } Gyro;
+
+struct ro_world {
+    ro_params params; v3 gravity;
+    Body *bodies; int nbodies, cap_bodies;
+    Collider *colliders; int ncolliders, cap_colliders;
+    Pair *pairs; int npairs, cap_pairs;
+    /* open-addressing map (c1,c2) -> pair index */
+    int64_t *map_keys; int *map_vals; int map_cap;
+    u128 *color_masks; int cap_masks;
+    int bp_dirty;
+    /* solver scratch */
+    SolverVel *vels, *incr; SolverPose *poses; Gyro *gyro; uint8_t *flags; int *dyn_bodies; int ndyn;
+    Constraint *cons; int ncons, cap_cons;
+    int bucket_begin[RO_NUM_COLORS + 1];
+    int stage_color[RO_NUM_COLORS]; int nstages;
+    ro_stats stats;
+};
+
+/* ------------------------------------------------------------------------------------ */
+void ro_default_params(ro_params *p) {
+    /* integration_parameters.rs:379-408 */
+    p->dt = 1.0f / 60.0f;
+    p->contact_natural_frequency = 30.0f; p->contact_damping_ratio = 10.0f;
+    p->static_contact_natural_frequency = 60.0f; p->static_contact_damping_ratio = 10.0f;
+    p->joint_natural_frequency = 1.0e6f; p->joint_damping_ratio = 1.0f;
+    p->warmstart_coefficient = 1.0f;
+    p->normalized_allowed_linear_error = 0.005f;
+    p->normalized_max_corrective_velocity = 3.0f;
+    p->normalized_prediction_distance = 0.02f;
+    p->normalized_max_linear_velocity = 400.0f;
+    p->normalized_contact_recycle_distance = 0.05f;
+    p->length_unit = 1.0f;
+    p->num_solver_iterations = 4;
+    p->num_internal_pgs_iterations = 1;
+    p->num_internal_stabilization_iterations = 1;
+    p->contact_recycling = 1;
+    p->friction_in_bias_pass = 0;
+    p->warmstart_joints = 0;
+    p->max_ccd_substeps = 1;
+}
+
+/* SpringCoefficients — integration_parameters.rs:86-149 */
+static float spring_erp_inv_dt(float freq, float damping, float dt) {
+    float ang_freq = freq * 6.283185307179586f; /* simd_two_pi */
+    return ang_freq / (dt * ang_freq + 2.0f * damping);
+}
+static float spring_cfm_factor(float freq, float damping, float dt) {
+    float erp = dt * spring_erp_inv_dt(freq, damping, dt);
+    float cfm_coeff = 0.0f;
+    if (erp != 0.0f) {
+        float inv_erp_minus_one = 1.0f / erp - 1.0f;
+        cfm_coeff = inv_erp_minus_one * inv_erp_minus_one / ((1.0f + inv_erp_minus_one) * 4.0f * damping * damping);
+    }
+    return 1.0f / (1.0f + cfm_coeff);
+}
+
+float ro_combine_coefficient(float a, float b, int32_t ra, int32_t rb) {
+    /* coefficient_combine_rule.rs:58-86 */
+    int rule = ra > rb ? ra : rb;
+    switch (rule) {
+    case RO_RULE_AVERAGE: return (a + b) / 2.0f;
+    case RO_RULE_MIN: return fabsf(a < b ? a : b);
+    case RO_RULE_MULTIPLY: return a * b;
+    case RO_RULE_MAX: return a > b ? a : b;
+    case RO_RULE_CLAMPED_SUM: return ro_clampf(a + b, 0.0f, 1.0f);
+    default: return sqrtf(ro_maxf(a, 0.0f) * ro_maxf(b, 0.0f));
+    }
+}
+
+ro_world *ro_world_new(const ro_params *params, const float gravity[3]) {
+    ro_world *w = (ro_world *)calloc(1, sizeof(ro_world));
+    w->params = *params;
+    w->gravity = V3(gravity[0], gravity[1], gravity[2]);
+    w->map_cap = 1 << 12;
+    w->map_keys = (int64_t *)malloc(sizeof(int64_t) * w->map_cap);
+    w->map_vals = (int *)malloc(sizeof(int) * w->map_cap);
+    for (int i = 0; i < w->map_cap; ++i) w->map_keys[i] = -1;
+    w->bp_dirty = 1;
+    return w;
+}
+void ro_world_free(ro_world *w) {
+    if (!w) return;
+    free(w->bodies); free(w->colliders); free(w->pairs); free(w->map_keys); free(w->map_vals);
+    free(w->color_masks); free(w->vels); free(w->incr); free(w->poses); free(w->gyro); free(w->flags);
+    free(w->dyn_bodies); free(w->cons); free(w);
+}
+
+/* parry MassProperties::world_inv_inertia */
+static sym3 world_inv_inertia(v3 inv_pi, quat frame, quat rot) {
+    sym3 r = {0, 0, 0, 0, 0, 0};
+    if (inv_pi.x == 0.0f && inv_pi.y == 0.0f && inv_pi.z == 0.0f) return r;
+    float m[3][3]; quat_to_mat(qmul(rot, frame), m);
+    float d[3] = {inv_pi.x, inv_pi.y, inv_pi.z};
+#define E(i, j) (m[i][0] * d[0] * m[j][0] + m[i][1] * d[1] * m[j][1] + m[i][2] * d[2] * m[j][2])
+    r.m11 = E(0, 0); r.m12 = E(0, 1); r.m13 = E(0, 2); r.m22 = E(1, 1); r.m23 = E(1, 2); r.m33 = E(2, 2);
+#undef E
+    return r;
+}
+/* RigidBodyMassProps::update_world_mass_properties — rigid_body_components.rs:528-578 */
+static void update_world_mass_properties(Body *b) {
+    b->world_com = pose_tp(b->position, b->local_com);
+    if (b->body_type == RO_BODY_DYNAMIC) {
+        b->effective_inv_mass = V3(b->inv_mass, b->inv_mass, b->inv_mass);
+        b->effective_world_inv_inertia = world_inv_inertia(b->inv_principal_inertia, b->principal_frame, b->position.r);
+    } else {
+        b->effective_inv_mass = V3(0, 0, 0);
+        sym3 z = {0, 0, 0, 0, 0, 0}; b->effective_world_inv_inertia = z;
+    }
+}
+
+/* parry Shape::mass_properties (cuboid / ball), SURVEY Appendix C */
+static void shape_mass_props(const Collider *c, float density, float *mass, v3 *principal_inertia) {
+    if (c->shape == RO_SHAPE_CUBOID) {
+        float vol = c->he.x * c->he.y * c->he.z * 8.0f;
+        float m = vol * density;
+        float ix = (c->he.y * c->he.y + c->he.z * c->he.z) / 3.0f;
+        float iy = (c->he.x * c->he.x + c->he.z * c->he.z) / 3.0f;
+        float iz = (c->he.x * c->he.x + c->he.y * c->he.y) / 3.0f;
+        *mass = m; *principal_inertia = V3(ix * m, iy * m, iz * m);
+    } else {
+        float r = c->radius;
+        float vol = 3.14159265358979323846f * r * r * r * 4.0f / 3.0f;
+        float m = vol * density;
+        float i = r * r * 0.4f;
+        *mass = m; *principal_inertia = V3(i * m, i * m, i * m);
+    }
+}
+
+/* RigidBodyMassProps::recompute_mass_properties_from_colliders — rigid_body_components.rs:421-489.
+ * Scope: one collider per body attached at the body origin (all benchmark scenes). */
+static void recompute_mass_properties(ro_world *w, Body *b) {
+    float mass = 0.0f; v3 pi = V3(0, 0, 0);
+    const Collider *c0 = NULL;
+    for (int i = 0; i < w->ncolliders; ++i)
+        if (w->colliders[i].parent == (int)(b - w->bodies)) { c0 = &w->colliders[i]; break; }
+    if (c0) shape_mass_props(c0, c0->density, &mass, &pi);
+    if (b->additional_mass != 0.0f) {
+        if (mass > 0.0f) {
+            /* MassProperties::set_mass(prev + add, adjust_angular_inertia = true) */
+            float nm = mass + b->additional_mass;
+            float k = nm / mass; pi = vmul(pi, k); mass = nm;
+        } else if (c0) {
+            float um; v3 upi; shape_mass_props(c0, 1.0f, &um, &upi);
+            if (um > 0.0f) { float k = b->additional_mass / um; pi = vmul(upi, k); }
+            mass = b->additional_mass;
+        } else {
+            mass = b->additional_mass;
+        }
+    }
+    b->local_com = V3(0, 0, 0);
+    b->inv_mass = ro_inv(mass);
+    b->inv_principal_inertia = V3(ro_inv(pi.x), ro_inv(pi.y), ro_inv(pi.z));
+    b->principal_frame = qident();
+    update_world_mass_properties(b);
+}
+
+int32_t ro_add_body(ro_world *w, const ro_body_desc *d) {
+    if (w->nbodies == w->cap_bodies) {
+        w->cap_bodies = w->cap_bodies ? w->cap_bodies * 2 : 1024;
+        w->bodies = (Body *)realloc(w->bodies, sizeof(Body) * w->cap_bodies);
+    }
+    Body *b = &w->bodies[w->nbodies];
+    memset(b, 0, sizeof(*b));
+    b->body_type = d->body_type;
+    b->position.t = V3(d->translation[0], d->translation[1], d->translation[2]);
+    b->position.r = qnormalize(Q(d->rotation[0], d->rotation[1], d->rotation[2], d->rotation[3]));
+    b->next_position = b->position;
+    b->linvel = V3(d->linvel[0], d->linvel[1], d->linvel[2]);
+    b->angvel = V3(d->angvel[0], d->angvel[1], d->angvel[2]);
+    b->linear_damping = d->linear_damping; b->angular_damping = d->angular_damping;
+    b->gravity_scale = d->gravity_scale; b->additional_mass = d->additional_mass;
+    b->dominance = d->dominance; b->gyroscopic = d->gyroscopic; b->allow_fast_rotation = d->allow_fast_rotation;
+    b->principal_frame = qident();
+    b->solver_id = RO_NO_BODY;
+    recompute_mass_properties(w, b);
+    return w->nbodies++;
+}
+
+int32_t ro_add_collider(ro_world *w, const ro_collider_desc *d, int32_t parent) {
+    if (w->ncolliders == w->cap_colliders) {
+        w->cap_colliders = w->cap_colliders ? w->cap_colliders * 2 : 1024;
+        w->colliders = (Collider *)realloc(w->colliders, sizeof(Collider) * w->cap_colliders);
+    }
+    Collider *c = &w->colliders[w->ncolliders];
+    memset(c, 0, sizeof(*c));
+    c->parent = parent;
+    c->shape = d->shape;
+    c->he = V3(d->half_extents[0], d->half_extents[1], d->half_extents[2]);
+    c->radius = d->half_extents[0];
+    c->pos_wrt_parent.t = V3(d->translation[0], d->translation[1], d->translation[2]);
+    c->pos_wrt_parent.r = qnormalize(Q(d->rotation[0], d->rotation[1], d->rotation[2], d->rotation[3]));
+    c->density = d->density; c->friction = d->friction; c->restitution = d->restitution;
+    c->friction_rule = d->friction_rule; c->restitution_rule = d->restitution_rule;
+    c->memberships = d->collision_memberships; c->filter = d->collision_filter;
+    if (parent >= 0) c->pos = pose_mul(w->bodies[parent].position, c->pos_wrt_parent);
+    else c->pos = c->pos_wrt_parent;
+    int idx = w->ncolliders++;
+    if (parent >= 0) recompute_mass_properties(w, &w->bodies[parent]);
+    w->bp_dirty = 1;
+    return idx;
+}
+
+int32_t ro_num_bodies(const ro_world *w) { return w->nbodies; }
+void ro_read_bodies(const ro_world *w, float *pos7, float *vel6) {
+    for (int i = 0; i < w->nbodies; ++i) {
+        const Body *b = &w->bodies[i];
+        if (pos7) {
+            float *p = pos7 + 7 * i;
+            p[0] = b->position.t.x; p[1] = b->position.t.y; p[2] = b->position.t.z;
+            p[3] = b->position.r.x; p[4] = b->position.r.y; p[5] = b->position.r.z; p[6] = b->position.r.w;
+        }
+        if (vel6) {
+            float *v = vel6 + 6 * i;
+            v[0] = b->linvel.x; v[1] = b->linvel.y; v[2] = b->linvel.z;
+            v[3] = b->angvel.x; v[4] = b->angvel.y; v[5] = b->angvel.z;
+        }
+    }
+}
+void ro_set_body_vel(ro_world *w, int32_t body, const float lv[3], const float av[3]) {
+    w->bodies[body].linvel = V3(lv[0], lv[1], lv[2]);
+    w->bodies[body].angvel = V3(av[0], av[1], av[2]);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Broad phase.  Contract = the pair SET of the reference's fat-AABB BVH
+ * (geometry/broad_phase_bvh/mod.rs:171-263, update.rs:35-602): each leaf keeps an AABB
+ * fattened by CHANGE_DETECTION_FACTOR (0.04) that is only rewritten when the tight
+ * collision AABB (shape AABB loosened by contact_skin + prediction/2, collider.rs:553-557)
+ * leaves it; a pair exists exactly while the two fat AABBs intersect and the pair passes the
+ * filters of update.rs:334-396.  The tree itself is free to differ: here a
+ * sort-and-sweep over fat AABBs, re-run only when some fat AABB changed. */
+static Aabb collider_collision_aabb(const Collider *c, float loosen) {
+    Aabb a;
+    if (c->shape == RO_SHAPE_CUBOID) {
+        float m[3][3]; quat_to_mat(c->pos.r, m);
+        v3 h = V3(fabsf(m[0][0]) * c->he.x + fabsf(m[0][1]) * c->he.y + fabsf(m[0][2]) * c->he.z,
+                  fabsf(m[1][0]) * c->he.x + fabsf(m[1][1]) * c->he.y + fabsf(m[1][2]) * c->he.z,
+                  fabsf(m[2][0]) * c->he.x + fabsf(m[2][1]) * c->he.y + fabsf(m[2][2]) * c->he.z);
+        a.mins = vsub(c->pos.t, h); a.maxs = vadd(c->pos.t, h);
+    } else {
+        v3 h = V3(c->radius, c->radius, c->radius);
+        a.mins = vsub(c->pos.t, h); a.maxs = vadd(c->pos.t, h);
+    }
+    v3 l = V3(loosen, loosen, loosen);
+    a.mins = vsub(a.mins, l); a.maxs = vadd(a.maxs, l);
+    return a;
+}
+static int aabb_contains(const Aabb *o, const Aabb *i) {
+    return o->mins.x <= i->mins.x && o->mins.y <= i->mins.y && o->mins.z <= i->mins.z &&
+           o->maxs.x >= i->maxs.x && o->maxs.y >= i->maxs.y && o->maxs.z >= i->maxs.z;
+}
+static int aabb_intersects(const Aabb *a, const Aabb *b) {
+    return a->mins.x <= b->maxs.x && b->mins.x <= a->maxs.x && a->mins.y <= b->maxs.y && b->mins.y <= a->maxs.y &&
+           a->mins.z <= b->maxs.z && b->mins.z <= a->maxs.z;
+}
+/* BroadPhaseBvh::set_aabb / insert_with_change_detection */
+static void bp_set_aabb(ro_world *w, Collider *c) {
+    float prediction = w->params.normalized_prediction_distance * w->params.length_unit;
+    Aabb tight = collider_collision_aabb(c, prediction / 2.0f);
+    if (c->has_fat && aabb_contains(&c->fat, &tight)) return;
+    float skin = 4.0e-2f * w->params.length_unit;
+    v3 l = V3(skin, skin, skin);
+    c->fat.mins = vsub(tight.mins, l); c->fat.maxs = vadd(tight.maxs, l);
+    c->has_fat = 1;
+    w->bp_dirty = 1;
+}
+
+static uint64_t hash64(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x; }
+static int map_find(const ro_world *w, int64_t key) {
+    uint64_t h = hash64((uint64_t)key) & (uint64_t)(w->map_cap - 1);
+    while (w->map_keys[h] != -1) { if (w->map_keys[h] == key) return w->map_vals[h]; h = (h + 1) & (uint64_t)(w->map_cap - 1); }
+    return -1;
+}
+static void map_insert_raw(int64_t *keys, int *vals, int cap, int64_t key, int val) {
+    uint64_t h = hash64((uint64_t)key) & (uint64_t)(cap - 1);
+    while (keys[h] != -1) h = (h + 1) & (uint64_t)(cap - 1);
+    keys[h] = key; vals[h] = val;
+}
+static void map_rebuild(ro_world *w) {
+    int need = 1 << 12; while (need < 4 * (w->npairs + 16)) need <<= 1;
+    if (need != w->map_cap) {
+        w->map_cap = need;
+        w->map_keys = (int64_t *)realloc(w->map_keys, sizeof(int64_t) * need);
+        w->map_vals = (int *)realloc(w->map_vals, sizeof(int) * need);
+    }
+    for (int i = 0; i < w->map_cap; ++i) w->map_keys[i] = -1;
+    for (int i = 0; i < w->npairs; ++i)
+        map_insert_raw(w->map_keys, w->map_vals, w->map_cap, ((int64_t)w->pairs[i].c1 << 32) | (uint32_t)w->pairs[i].c2, i);
+}
+
+static int body_is_dynamic(const ro_world *w, int parent) { return parent >= 0 && w->bodies[parent].body_type == RO_BODY_DYNAMIC; }
+
+/* update.rs:334-396 pair filter (same parent, collision types, groups) */
+static int bp_pair_allowed(const ro_world *w, const Collider *a, const Collider *b) {
+    if (a->parent >= 0 && a->parent == b->parent) return 0;
+    if (!body_is_dynamic(w, a->parent) && !body_is_dynamic(w, b->parent)) return 0; /* ActiveCollisionTypes::default */
+    if (!((a->memberships & b->filter) != 0 && (b->memberships & a->filter) != 0)) return 0;
+    return 1;
+}
+
+typedef struct { float minx; int idx; } SweepItem;
+static int sweep_cmp(const void *a, const void *b) {
+    const SweepItem *x = (const SweepItem *)a, *y = (const SweepItem *)b;
+    if (x->minx < y->minx) return -1; if (x->minx > y->minx) return 1; return x->idx - y->idx;
+}
+static void clear_pair_solver_color(ro_world *w, Pair *p);
+
+static void broad_phase_update(ro_world *w) {
+    for (int i = 0; i < w->ncolliders; ++i) if (!w->colliders[i].has_fat) bp_set_aabb(w, &w->colliders[i]);
+    w->stats.bp_rebuilt = 0;
+    if (!w->bp_dirty) return;
+    w->bp_dirty = 0; w->stats.bp_rebuilt = 1;
+    int n = w->ncolliders;
+    SweepItem *items = (SweepItem *)malloc(sizeof(SweepItem) * (n + 1));
+    for (int i = 0; i < n; ++i) { items[i].minx = w->colliders[i].fat.mins.x; items[i].idx = i; }
+    qsort(items, n, sizeof(SweepItem), sweep_cmp);
+    for (int i = 0; i < w->npairs; ++i) w->pairs[i].alive = 0;
+    for (int a = 0; a < n; ++a) {
+        const Collider *ca = &w->colliders[items[a].idx];
+        for (int b = a + 1; b < n && items[b].minx <= ca->fat.maxs.x; ++b) {
+            const Collider *cb = &w->colliders[items[b].idx];
+            if (!aabb_intersects(&ca->fat, &cb->fat)) continue;
+            if (!bp_pair_allowed(w, ca, cb)) continue;
+            int c1 = items[a].idx < items[b].idx ? items[a].idx : items[b].idx;
+            int c2 = items[a].idx < items[b].idx ? items[b].idx : items[a].idx;
+            int64_t key = ((int64_t)c1 << 32) | (uint32_t)c2;
+            int pi = map_find(w, key);
+            if (pi >= 0) { w->pairs[pi].alive = 1; continue; }
+            if (w->npairs == w->cap_pairs) {
+                w->cap_pairs = w->cap_pairs ? w->cap_pairs * 2 : 4096;
+                w->pairs = (Pair *)realloc(w->pairs, sizeof(Pair) * w->cap_pairs);
+            }
+            Pair *p = &w->pairs[w->npairs];
+            memset(p, 0, sizeof(*p));
+            p->c1 = c1; p->c2 = c2; p->alive = 1; p->color = RO_COLOR_UNCOLORED;
+            p->color_bodies[0] = p->color_bodies[1] = RO_NO_BODY;
+            p->solver_body_ids[0] = p->solver_body_ids[1] = RO_NO_BODY;
+            w->npairs++;
+            if (4 * (w->npairs + 16) > w->map_cap) map_rebuild(w);
+            else map_insert_raw(w->map_keys, w->map_vals, w->map_cap, key, w->npairs - 1);
+        }
+    }
+    free(items);
+    /* DeletePair: NarrowPhase::remove_pair (pair_management.rs:382) frees the colour and drops the edge. */
+    int out = 0, removed = 0;
+    for (int i = 0; i < w->npairs; ++i) {
+        if (!w->pairs[i].alive) { clear_pair_solver_color(w, &w->pairs[i]); removed = 1; continue; }
+        if (out != i) w->pairs[out] = w->pairs[i];
+        out++;
+    }
+    w->npairs = out;
+    if (removed) map_rebuild(w);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Pair colouring — geometry/narrow_phase/mod.rs:90-172 */
+static void masks_reserve(ro_world *w, int n) {
+    if (n <= w->cap_masks) return;
+    int nc = w->cap_masks ? w->cap_masks : 1024; while (nc < n) nc *= 2;
+    w->color_masks = (u128 *)realloc(w->color_masks, sizeof(u128) * nc);
+    memset(w->color_masks + w->cap_masks, 0, sizeof(u128) * (nc - w->cap_masks));
+    w->cap_masks = nc;
+}
+static int u128_test(u128 m, int bit) { return bit < 64 ? (int)((m.lo >> bit) & 1) : (int)((m.hi >> (bit - 64)) & 1); }
+static void u128_set(u128 *m, int bit) { if (bit < 64) m->lo |= 1ULL << bit; else m->hi |= 1ULL << (bit - 64); }
+static void u128_clear(u128 *m, int bit) { if (bit < 64) m->lo &= ~(1ULL << bit); else m->hi &= ~(1ULL << (bit - 64)); }
+
+static void clear_pair_solver_color(ro_world *w, Pair *p) {
+    if (p->color < RO_COLOR_OVERFLOW)
+        for (int k = 0; k < 2; ++k)
+            if (p->color_bodies[k] != RO_NO_BODY && (int)p->color_bodies[k] < w->cap_masks)
+                u128_clear(&w->color_masks[p->color_bodies[k]], p->color);
+    p->color = RO_COLOR_UNCOLORED;
+    p->color_bodies[0] = p->color_bodies[1] = RO_NO_BODY;
+}
+static void assign_pair_solver_color(ro_world *w, Pair *p, int body1, int body2) {
+    if (p->color != RO_COLOR_UNCOLORED) return;
+    uint32_t i1 = (body1 >= 0 && w->bodies[body1].body_type != RO_BODY_FIXED) ? (uint32_t)body1 : RO_NO_BODY;
+    uint32_t i2 = (body2 >= 0 && w->bodies[body2].body_type != RO_BODY_FIXED) ? (uint32_t)body2 : RO_NO_BODY;
+    masks_reserve(w, w->nbodies + 1);
+    int color; uint32_t cb[2];
+    if (i1 != RO_NO_BODY && i2 != RO_NO_BODY) {
+        u128 a = w->color_masks[i1], b = w->color_masks[i2];
+        u128 m = {a.lo | b.lo, a.hi | b.hi};
+        color = 128;
+        for (int c = 0; c < RO_DYNAMIC_COLOR_COUNT; ++c) if (!u128_test(m, c)) { color = c; break; }
+        cb[0] = i1; cb[1] = i2;
+    } else if (i1 != RO_NO_BODY || i2 != RO_NO_BODY) {
+        uint32_t i = i1 != RO_NO_BODY ? i1 : i2;
+        u128 m = w->color_masks[i];
+        color = 128;
+        for (int c = 127; c >= 0; --c) if (!u128_test(m, c)) { color = c; break; }
+        cb[0] = i; cb[1] = RO_NO_BODY;
+    } else {
+        p->color = RO_COLOR_OVERFLOW; p->color_bodies[0] = p->color_bodies[1] = RO_NO_BODY; return;
+    }
+    if (color >= 128) { p->color = RO_COLOR_OVERFLOW; p->color_bodies[0] = p->color_bodies[1] = RO_NO_BODY; return; }
+    for (int k = 0; k < 2; ++k) if (cb[k] != RO_NO_BODY) u128_set(&w->color_masks[cb[k]], color);
+    p->color = (uint8_t)color; p->color_bodies[0] = cb[0]; p->color_bodies[1] = cb[1];
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Narrow phase: pair_update::process_pair — geometry/narrow_phase/pair_update.rs:67-680 */
+static float relative_rot_cos(quat base, quat cur) { float c = qdot(base, cur); return 2.0f * c * c - 1.0f; }
+static float relative_pose_drift(pose base, pose cur, float max_extent) {
+    float trans = vlen(vsub(cur.t, base.t));
+    quat d = qmul(cur.r, qconj(base.r));
+    float chord = 2.0f * vlen(V3(d.x, d.y, d.z)) * max_extent;
+    return trans + chord;
+}
+static float collider_origin_radius(const Collider *c) {
+    if (c->shape == RO_SHAPE_CUBOID) return vlen(c->he); /* max(|mins|,|maxs|) of the local AABB */
+    return vlen(V3(c->radius, c->radius, c->radius));
+}
+
+/* manifold_reduction::reduce_manifold_naive — geometry/manifold_reduction.rs:4-84 */
+static void reduce_manifold_naive(const Manifold *m, int selected[4], int *num_selected, float prediction) {
+    if (m->npoints <= 4) return;
+    selected[0] = selected[1] = selected[2] = selected[3] = -1;
+    float deepest = FLT_MAX;
+    for (int i = 0; i < m->npoints; ++i) if (m->points[i].dist < deepest) { deepest = m->points[i].dist; selected[0] = i; }
+    if (selected[0] < 0) { *num_selected = 0; return; }
+    v3 a = m->points[selected[0]].local_p1;
+    float furthest = -FLT_MAX;
+    for (int i = 0; i < m->npoints; ++i) {
+        float d = vlen2(vsub(m->points[i].local_p1, a));
+        if (i != selected[0] && m->points[i].dist <= prediction && d > furthest) { furthest = d; selected[1] = i; }
+    }
+    if (selected[1] < 0) { *num_selected = 1; return; }
+    v3 b = m->points[selected[1]].local_p1;
+    if (a.x == b.x && a.y == b.y && a.z == b.z) { *num_selected = 1; return; }
+    v3 tangent = vcross(vsub(b, a), m->local_n1);
+    float min_dot = FLT_MAX, max_dot = -FLT_MAX;
+    for (int i = 0; i < m->npoints; ++i) {
+        if (i == selected[0] || i == selected[1] || m->points[i].dist > prediction) continue;
+        float dot = vdot(vsub(m->points[i].local_p1, a), tangent);
+        if (dot < min_dot) { min_dot = dot; selected[2] = i; }
+        if (dot > max_dot) { max_dot = dot; selected[3] = i; }
+    }
+    if (selected[2] < 0) *num_selected = 2;
+    else if (selected[2] == selected[3]) *num_selected = 3;
+    else *num_selected = 4;
+}
+
+typedef struct { int pair; int body1, body2; int touching; } Transition;
+
+static int effective_dominance_group(const ro_world *w, int body) {
+    /* RigidBodyDominance::effective_group — rigid_body_components.rs:1269-1275 */
+    if (body >= 0 && w->bodies[body].body_type == RO_BODY_DYNAMIC) return w->bodies[body].dominance;
+    return 128;
+}
+
+static void process_pair(ro_world *w, int pair_idx, Transition *transitions, int *ntransitions) {
+    Pair *p = &w->pairs[pair_idx];
+    const Collider *co1 = &w->colliders[p->c1], *co2 = &w->colliders[p->c2];
+    const ro_params *prm = &w->params;
+    float prediction = prm->normalized_prediction_distance * prm->length_unit;
+    float recycle_dist = prm->contact_recycling ? prm->normalized_contact_recycle_distance * prm->length_unit : 0.0f;
+    /* :98-106 — neither body awake (non-dynamic): skipped */
+    if (!body_is_dynamic(w, co1->parent) && !body_is_dynamic(w, co2->parent)) return;
+
+    /* :111-171 contact recycling */
+    if (recycle_dist > 0.0f && p->has_recycle) {
+        pose pos12 = pose_inv_mul(co1->pos, co2->pos);
+        float drift = relative_pose_drift(p->rec_pos12, pos12, p->rec_max_extent);
+        float rot_cos = ro_minf(relative_rot_cos(p->rec_rot1, co1->pos.r), relative_rot_cos(p->rec_rot2, co2->pos.r));
+        if (drift <= p->rec_max_drift && rot_cos > 0.98f) { w->stats.num_recycled++; return; }
+    }
+    int had = p->nsc > 0;
+    w->stats.num_full_updates++;
+    int rb1 = co1->parent, rb2 = co2->parent;
+    /* filters (:179-252) were applied when the pair was created (static in this scope) */
+    pose pos12 = pose_inv_mul(co1->pos, co2->pos);
+    float eff_prediction = prediction; /* contact_skin = 0, no soft-ccd */
+
+    /* :323-330 parry DefaultQueryDispatcher::contact_manifolds */
+    if (co1->shape == RO_SHAPE_CUBOID && co2->shape == RO_SHAPE_CUBOID) manifold_cuboid_cuboid(pos12, co1->he, co2->he, eff_prediction, &p->m);
+    else if (co1->shape == RO_SHAPE_BALL && co2->shape == RO_SHAPE_BALL) manifold_ball_ball(pos12, co1->radius, co2->radius, eff_prediction, &p->m);
+    else if (co1->shape == RO_SHAPE_CUBOID) manifold_cuboid_ball(pos12, co1->he, co2->radius, eff_prediction, &p->m, 0);
+    else manifold_cuboid_ball(pose_inv(pos12), co2->he, co1->radius, eff_prediction, &p->m, 1);
+
+    p->friction = ro_combine_coefficient(co1->friction, co2->friction, co1->friction_rule, co2->friction_rule);
+    p->restitution = ro_combine_coefficient(co1->restitution, co2->restitution, co1->restitution_rule, co2->restitution_rule);
+    p->relative_dominance = effective_dominance_group(w, rb1) - effective_dominance_group(w, rb2);
+    p->normal = qrot(co1->pos.r, p->m.local_n1);
+    p->nsc = 0;
+
+    Manifold *m = &p->m;
+    if (m->npoints > 0) {
+        int selected[4] = {0, 1, 2, 3};
+        int num_selected = m->npoints < 4 ? m->npoints : 4;
+        reduce_manifold_naive(m, selected, &num_selected, prediction);
+        /* :430-457 lexicographic sort in the contact plane */
+        if (num_selected > 1) {
+            v3 basis[2]; orthonormal_basis(m->local_n1, basis);
+            float k0[4], k1[4]; int ks[4];
+            for (int i = 0; i < num_selected; ++i) {
+                v3 lp = m->points[selected[i]].local_p1;
+                k0[i] = vdot(lp, basis[0]); k1[i] = vdot(lp, basis[1]); ks[i] = selected[i];
+            }
+            for (int i = 1; i < num_selected; ++i) {
+                float a0 = k0[i], a1 = k1[i]; int as = ks[i]; int j = i;
+                while (j > 0 && (k0[j - 1] > a0 || (k0[j - 1] == a0 && k1[j - 1] > a1))) {
+                    k0[j] = k0[j - 1]; k1[j] = k1[j - 1]; ks[j] = ks[j - 1]; j--;
+                }
+                k0[j] = a0; k1[j] = a1; ks[j] = as;
+            }
+            for (int i = 0; i < num_selected; ++i) selected[i] = ks[i];
+        }
+        /* :459-498 solver contacts */
+        for (int s = 0; s < num_selected; ++s) {
+            int cid = selected[s];
+            TrackedContact *c = &m->points[cid];
+            float eff_dist = c->dist; /* - skins (0) */
+            v3 world_pt1 = pose_tp(co1->pos, c->local_p1);
+            v3 world_pt2 = pose_tp(co2->pos, c->local_p2);
+            int keep = eff_dist < prediction;
+            if (!keep) {
+                v3 vel1 = V3(0, 0, 0), vel2 = V3(0, 0, 0);
+                if (rb1 >= 0) { const Body *b = &w->bodies[rb1]; vel1 = vadd(b->linvel, vcross(b->angvel, vsub(world_pt1, b->world_com))); }
+                if (rb2 >= 0) { const Body *b = &w->bodies[rb2]; vel2 = vadd(b->linvel, vcross(b->angvel, vsub(world_pt2, b->world_com))); }
+                keep = eff_dist + vdot(vsub(vel2, vel1), p->normal) * prm->dt < prediction;
+            }
+            if (keep) {
+                SolverContact *sc = &p->sc[p->nsc++];
+                sc->anchor1 = world_pt1; sc->anchor2 = world_pt2; sc->dist = eff_dist;
+                sc->tangent_velocity = V3(0, 0, 0); sc->cid = cid;
+            }
+        }
+        /* :536-577 localise anchors and freeze the solver lever arms */
+        {
+            v3 normal = p->normal; int rel_dom = p->relative_dominance;
+            int has1 = rb1 >= 0 && rel_dom <= 0, has2 = rb2 >= 0 && rel_dom >= 0;
+            pose com1 = pose_ident(), com2 = pose_ident();
+            if (has1) { const Body *b = &w->bodies[rb1]; com1.r = b->position.r; com1.t = pose_tp(b->position, b->local_com); }
+            if (has2) { const Body *b = &w->bodies[rb2]; com2.r = b->position.r; com2.t = pose_tp(b->position, b->local_com); }
+            for (int s = 0; s < p->nsc; ++s) {
+                SolverContact *sc = &p->sc[s];
+                float shift = vdot(vsub(sc->anchor2, sc->anchor1), normal) - sc->dist;
+                v3 p1 = vadd(sc->anchor1, vmul(normal, shift));
+                v3 point = vmul(vadd(p1, sc->anchor2), 0.5f);
+                ContactData *pd = &m->points[sc->cid].data;
+                pd->solver_dp1 = has1 ? vsub(point, com1.t) : point;
+                pd->solver_dp2 = has2 ? vsub(point, com2.t) : point;
+                sc->anchor1 = has1 ? pose_itp(com1, p1) : p1;
+                if (has2) sc->anchor2 = pose_itp(com2, sc->anchor2);
+            }
+        }
+    }
+    /* :582-613 recycle state */
+    if (recycle_dist > 0.0f) {
+        float max_extent = p->has_recycle ? p->rec_max_extent : ro_maxf(collider_origin_radius(co1), collider_origin_radius(co2));
+        p->rec_max_drift = p->nsc > 0 ? recycle_dist : ro_minf(recycle_dist, prediction);
+        p->rec_pos12 = pos12; p->rec_rot1 = co1->pos.r; p->rec_rot2 = co2->pos.r; p->rec_max_extent = max_extent;
+        p->has_recycle = 1;
+    }
+    /* :622-629 begin/end-touch transition */
+    int has = p->nsc > 0;
+    if (has != had) {
+        Transition *t = &transitions[(*ntransitions)++];
+        t->pair = pair_idx; t->body1 = rb1; t->body2 = rb2; t->touching = has;
+    }
+}
+
+typedef struct { uint64_t key; int pair; int b1, b2; } ColorTodo;
+static int todo_cmp(const void *a, const void *b) {
+    const ColorTodo *x = (const ColorTodo *)a, *y = (const ColorTodo *)b;
+    if (x->key < y->key) return -1; if (x->key > y->key) return 1; return x->pair - y->pair;
+}
+/* NarrowPhase::compute_contacts + apply_pair_transitions — contacts.rs:22-385 */
+static void narrow_phase_compute_contacts(ro_world *w) {
+    Transition *tr = (Transition *)malloc(sizeof(Transition) * (w->npairs + 1));
+    int ntr = 0;
+    w->stats.num_full_updates = 0; w->stats.num_recycled = 0;
+    for (int i = 0; i < w->npairs; ++i) process_pair(w, i, tr, &ntr);
+    /* transitions are visited in edge order (already ascending); end-touch frees its colour first */
+    ColorTodo *todo = (ColorTodo *)malloc(sizeof(ColorTodo) * (ntr + 1));
+    int ntodo = 0;
+    for (int i = 0; i < ntr; ++i) {
+        Pair *p = &w->pairs[tr[i].pair];
+        if (!tr[i].touching) { clear_pair_solver_color(w, p); continue; }
+        uint32_t a = tr[i].body1 >= 0 ? (uint32_t)tr[i].body1 : RO_NO_BODY;
+        uint32_t b = tr[i].body2 >= 0 ? (uint32_t)tr[i].body2 : RO_NO_BODY;
+        uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+        todo[ntodo].key = ((uint64_t)lo << 32) | hi; todo[ntodo].pair = tr[i].pair;
+        todo[ntodo].b1 = tr[i].body1; todo[ntodo].b2 = tr[i].body2; ntodo++;
+    }
+    /* apply_deferred_solver_coloring — contacts.rs:369-385 */
+    qsort(todo, ntodo, sizeof(ColorTodo), todo_cmp);
+    for (int i = 0; i < ntodo; ++i) assign_pair_solver_color(w, &w->pairs[todo[i].pair], todo[i].b1, todo[i].b2);
+    free(todo); free(tr);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Solver */
+static void solver_reserve(ro_world *w, int nb, int nc) {
+    static int cap_b = 0; (void)cap_b;
+    w->vels = (SolverVel *)realloc(w->vels, sizeof(SolverVel) * (nb + 1));
+    w->incr = (SolverVel *)realloc(w->incr, sizeof(SolverVel) * (nb + 1));
+    w->poses = (SolverPose *)realloc(w->poses, sizeof(SolverPose) * (nb + 1));
+    w->gyro = (Gyro *)realloc(w->gyro, sizeof(Gyro) * (nb + 1));
+    w->flags = (uint8_t *)realloc(w->flags, nb + 1);
+    w->dyn_bodies = (int *)realloc(w->dyn_bodies, sizeof(int) * (nb + 1));
+    if (nc > w->cap_cons) { w->cap_cons = nc * 2 + 64; w->cons = (Constraint *)realloc(w->cons, sizeof(Constraint) * w->cap_cons); }
+}
+
+static void gather_vel(const ro_world *w, uint32_t id, SolverVel *v) {
+    if (id == RO_NO_BODY) { v->linear = V3(0, 0, 0); v->angular = V3(0, 0, 0); } else *v = w->vels[id];
+}
+static void gather_pose(const ro_world *w, uint32_t id, SolverPose *p) {
+    if (id == RO_NO_BODY) { memset(p, 0, sizeof(*p)); p->rotation = qident(); } else *p = w->poses[id];
+}
+static void scatter_vel(ro_world *w, uint32_t id, const SolverVel *v) { if (id != RO_NO_BODY) w->vels[id] = *v; }
+static v3 spose_tp(const SolverPose *p, v3 x) { return vadd(qrot(p->rotation, x), p->translation); }
+static v3 spose_itp(const SolverPose *p, v3 x) { return qrot_inv(p->rotation, vsub(x, p->translation)); }
+
+/* ContactWithTwistFrictionBuilder::generate — contact_with_twist_friction.rs:58-424 (one lane) */
+static void constraint_generate(ro_world *w, int pair_idx, Constraint *c) {
+    const Pair *p = &w->pairs[pair_idx];
+    memset(c, 0, sizeof(*c));
+    uint32_t ids1 = p->relative_dominance <= 0 ? p->solver_body_ids[0] : RO_NO_BODY;
+    uint32_t ids2 = p->relative_dominance >= 0 ? p->solver_body_ids[1] : RO_NO_BODY;
+    SolverVel vels1, vels2; SolverPose poses1, poses2;
+    gather_vel(w, ids1, &vels1); gather_vel(w, ids2, &vels2);
+    gather_pose(w, ids1, &poses1); gather_pose(w, ids2, &poses2);
+    v3 world_com1 = poses1.translation, world_com2 = poses2.translation;
+    v3 force_dir1 = vneg(p->normal);
+    int count = p->nsc < 4 ? p->nsc : 4;
+    v3 tangents1[2];
+    tangents1[0] = orthonormal_vector(force_dir1);           /* contact_constraint/mod.rs:27-46 */
+    tangents1[1] = vcross(force_dir1, tangents1[0]);
+    float inv_num_points = 1.0f / (float)count;
+
+    c->dir1 = force_dir1; c->im1 = poses1.im; c->im2 = poses2.im; c->ii1 = poses1.ii; c->ii2 = poses2.ii;
+    c->local_n1 = qrot_inv(poses1.rotation, force_dir1);
+    c->restitution = p->restitution;
+    c->solver_vel1 = ids1; c->solver_vel2 = ids2; c->pair = pair_idx; c->num_contacts = count;
+    c->tangent1 = tangents1[0];
+    c->limit = p->friction;
+
+    v3 friction_center = V3(0, 0, 0), friction_center2 = V3(0, 0, 0), tangent_vel = V3(0, 0, 0);
+    float twist_warmstart = 0.0f, tangent_warmstart[2] = {0, 0};
+    v3 points[4];
+    for (int k = 0; k < count; ++k) {
+        float weight = inv_num_points;
+        const SolverContact *sc = &p->sc[k];
+        const ContactData *pd = &p->m.points[sc->cid].data;
+        float warmstart_impulse = pd->warmstart_impulse;
+        v3 wt = pd->warmstart_tangent_world;
+        float wti[2] = {vdot(wt, tangents1[0]), vdot(wt, tangents1[1])};
+        float warmstart_twist_impulse = pd->warmstart_twist_impulse;
+        int is_new = pd->impulse == 0.0f;
+        float is_bouncy = is_new ? (p->restitution > 0.0f ? 1.0f : 0.0f) : (p->restitution >= 1.0f ? 1.0f : 0.0f);
+
+        v3 p1 = spose_tp(&poses1, sc->anchor1);
+        v3 p2 = spose_tp(&poses2, sc->anchor2);
+        float dist = vdot(vsub(p1, p2), force_dir1);
+        v3 dp1 = pd->solver_dp1, dp2 = pd->solver_dp2;
+        v3 point = vadd(world_com1, dp1);
+        points[k] = point;
+        friction_center = vadd(friction_center, vmul(point, weight));
+        friction_center2 = vadd(friction_center2, vmul(vadd(world_com2, dp2), weight));
+        v3 vel1 = vadd(vels1.linear, vcross(vels1.angular, dp1));
+        v3 vel2 = vadd(vels2.linear, vcross(vels2.angular, dp2));
+        twist_warmstart += warmstart_twist_impulse * weight;
+        tangent_warmstart[0] += wti[0] * weight; tangent_warmstart[1] += wti[1] * weight;
+        tangent_vel = vadd(tangent_vel, vmul(sc->tangent_velocity, weight));
+        c->contact_id[k] = sc->cid;
+        {
+            v3 torque_dir1 = vcross(dp1, force_dir1);
+            v3 torque_dir2 = vcross(dp2, vneg(force_dir1));
+            v3 ii_torque_dir1 = sym3_mul(poses1.ii, torque_dir1);
+            v3 ii_torque_dir2 = sym3_mul(poses2.ii, torque_dir2);
+            v3 imsum = vadd(poses1.im, poses2.im);
+            float projected_mass = ro_inv(vdot(force_dir1, vcmul(imsum, force_dir1)) + vdot(ii_torque_dir1, torque_dir1) +
+                                          vdot(ii_torque_dir2, torque_dir2));
+            float projected_velocity = vdot(vsub(vel1, vel2), force_dir1);
+            float restitution_seed = is_bouncy * p->restitution * projected_velocity;
+            NormalPart *n = &c->normal_part[k];
+            n->torque_dir1 = torque_dir1; n->torque_dir2 = torque_dir2;
+            n->ii_torque_dir1 = ii_torque_dir1; n->ii_torque_dir2 = ii_torque_dir2;
+            n->impulse = warmstart_impulse; n->impulse_accumulator = -n->impulse; n->r = projected_mass;
+            c->infos[k].local_p1 = spose_itp(&poses1, point);
+            c->infos[k].local_p2 = spose_itp(&poses2, vadd(world_com2, dp2));
+            c->infos[k].dist = dist - vdot(vsub(point, vadd(world_com2, dp2)), force_dir1);
+            c->infos[k].restitution_seed = restitution_seed;
+        }
+    }
+    c->tangent_part.impulse[0] = tangent_warmstart[0]; c->tangent_part.impulse[1] = tangent_warmstart[1];
+    c->tangent_part.impulse_accumulator[0] = -tangent_warmstart[0]; c->tangent_part.impulse_accumulator[1] = -tangent_warmstart[1];
+    c->twist_part.impulse = count > 1 ? twist_warmstart : 0.0f;
+    c->twist_part.impulse_accumulator = -c->twist_part.impulse;
+    c->local_friction_center1 = spose_itp(&poses1, friction_center);
+    c->local_friction_center2 = spose_itp(&poses2, friction_center2);
+    c->tangent_vel = tangent_vel;
+    v3 dp1 = vsub(friction_center, world_com1), dp2 = vsub(friction_center2, world_com2);
+    if (count > 1) {
+        for (int k = 0; k < count; ++k) c->twist_dists[k] = vlen(vsub(friction_center, points[k]));
+        v3 ii_twist_dir1 = sym3_mul(poses1.ii, force_dir1);
+        v3 ii_twist_dir2 = sym3_mul(poses2.ii, vneg(force_dir1));
+        c->twist_part.rhs = 0.0f;
+        c->twist_part.r = ro_inv(vdot(ii_twist_dir1, force_dir1) + vdot(ii_twist_dir2, vneg(force_dir1)));
+    }
+    c->tangent_part.dp1 = dp1; c->tangent_part.dp2 = dp2;
+    for (int j = 0; j < 2; ++j) {
+        v3 torque_dir1 = vcross(dp1, tangents1[j]);
+        v3 torque_dir2 = vcross(dp2, vneg(tangents1[j]));
+        v3 ii_torque_dir1 = sym3_mul(poses1.ii, torque_dir1);
+        v3 ii_torque_dir2 = sym3_mul(poses2.ii, torque_dir2);
+        v3 imsum = vadd(poses1.im, poses2.im);
+        float r = vdot(tangents1[j], vcmul(imsum, tangents1[j])) + vdot(ii_torque_dir1, torque_dir1) + vdot(ii_torque_dir2, torque_dir2);
+        float rhs_wo_bias = vdot(tangent_vel, tangents1[j]);
+        c->tangent_part.torque_dir1[j] = torque_dir1; c->tangent_part.torque_dir2[j] = torque_dir2;
+        c->tangent_part.ii_torque_dir1[j] = ii_torque_dir1; c->tangent_part.ii_torque_dir2[j] = ii_torque_dir2;
+        c->tangent_part.rhs_wo_bias[j] = rhs_wo_bias; c->tangent_part.rhs[j] = rhs_wo_bias; c->tangent_part.r[j] = r;
+    }
+    c->tangent_part.r[2] = 2.0f * (vdot(c->tangent_part.ii_torque_dir1[0], c->tangent_part.torque_dir1[1]) +
+                                   vdot(c->tangent_part.ii_torque_dir2[0], c->tangent_part.torque_dir2[1]));
+}
+
+typedef struct { quat rotation; v3 translation; } Xform;
+static void gather_xform(const ro_world *w, uint32_t id, Xform *x) {
+    if (id == RO_NO_BODY) { x->rotation = qident(); x->translation = V3(0, 0, 0); }
+    else { x->rotation = w->poses[id].rotation; x->translation = w->poses[id].translation; }
+}
+static v3 xform_tp(const Xform *x, v3 p) { return vadd(qrot(x->rotation, p), x->translation); }
+
+/* ContactWithTwistFrictionBuilder::update — contact_with_twist_friction.rs:426-522; `dt` = substep dt */
+static void constraint_update(const ro_world *w, Constraint *c, float dt, float solved_dt) {
+    const ro_params *prm = &w->params;
+    int is_static = c->solver_vel1 == RO_NO_BODY || c->solver_vel2 == RO_NO_BODY;
+    float dyn_cfm = spring_cfm_factor(prm->contact_natural_frequency, prm->contact_damping_ratio, dt);
+    float static_cfm = spring_cfm_factor(prm->static_contact_natural_frequency, prm->static_contact_damping_ratio, dt);
+    float dyn_erp = spring_erp_inv_dt(prm->contact_natural_frequency, prm->contact_damping_ratio, dt);
+    float static_erp = spring_erp_inv_dt(prm->static_contact_natural_frequency, prm->static_contact_damping_ratio, dt);
+    float fstatic = is_static ? 1.0f : 0.0f;
+    float cfm_factor = dyn_cfm + fstatic * (static_cfm - dyn_cfm);
+    float inv_dt = dt == 0.0f ? 0.0f : 1.0f / dt;
+    float erp_inv_dt = dyn_erp + fstatic * (static_erp - dyn_erp);
+    float max_corrective_velocity = prm->normalized_max_corrective_velocity * prm->length_unit;
+    float warmstart_coeff = prm->warmstart_coefficient;
+    Xform poses1, poses2; gather_xform(w, c->solver_vel1, &poses1); gather_xform(w, c->solver_vel2, &poses2);
+    v3 tangents1[2] = {c->tangent1, vcross(c->dir1, c->tangent1)};
+    v3 tangent_delta = vmul(c->tangent_vel, solved_dt);
+    for (int k = 0; k < c->num_contacts; ++k) {
+        NormalPart *n = &c->normal_part[k];
+        v3 p1 = vadd(xform_tp(&poses1, c->infos[k].local_p1), tangent_delta);
+        v3 p2 = xform_tp(&poses2, c->infos[k].local_p2);
+        float dist = c->infos[k].dist + vdot(vsub(p1, p2), c->dir1);
+        float rhs_wo_bias = ro_maxf(dist, 0.0f) * inv_dt;
+        float rhs_bias = ro_clampf(dist * erp_inv_dt, -max_corrective_velocity, 0.0f);
+        n->rhs_wo_bias = rhs_wo_bias; n->rhs = rhs_wo_bias + rhs_bias;
+        n->cfm_factor = dist <= 0.0f ? cfm_factor : 1.0f;
+        n->impulse_accumulator += n->impulse;
+        n->impulse *= warmstart_coeff;
+    }
+    {
+        v3 p1 = vadd(xform_tp(&poses1, c->local_friction_center1), tangent_delta);
+        v3 p2 = xform_tp(&poses2, c->local_friction_center2);
+        for (int j = 0; j < 2; ++j) {
+            float bias = vdot(vsub(p1, p2), tangents1[j]) * inv_dt;
+            c->tangent_part.rhs[j] = c->tangent_part.rhs_wo_bias[j] + bias;
+        }
+        for (int j = 0; j < 2; ++j) { c->tangent_part.impulse_accumulator[j] += c->tangent_part.impulse[j]; c->tangent_part.impulse[j] *= warmstart_coeff; }
+        c->twist_part.impulse_accumulator += c->twist_part.impulse;
+        c->twist_part.impulse *= warmstart_coeff;
+    }
+    c->cfm_factor = cfm_factor;
+}
+
+/* refresh_rhs_wo_bias — contact_with_twist_friction.rs:529-554 */
+static void constraint_refresh_rhs_wo_bias(const ro_world *w, Constraint *c, float dt, float solved_dt) {
+    float inv_dt = dt == 0.0f ? 0.0f : 1.0f / dt;
+    Xform poses1, poses2; gather_xform(w, c->solver_vel1, &poses1); gather_xform(w, c->solver_vel2, &poses2);
+    v3 tangent_delta = vmul(c->tangent_vel, solved_dt);
+    for (int k = 0; k < c->num_contacts; ++k) {
+        v3 p1 = vadd(xform_tp(&poses1, c->infos[k].local_p1), tangent_delta);
+        v3 p2 = xform_tp(&poses2, c->infos[k].local_p2);
+        float dist = c->infos[k].dist + vdot(vsub(p1, p2), c->dir1);
+        c->normal_part[k].rhs = ro_maxf(dist, 0.0f) * inv_dt;
+        c->normal_part[k].cfm_factor = 1.0f;
+    }
+    c->cfm_factor = 1.0f;
+    c->tangent_part.rhs[0] = c->tangent_part.rhs_wo_bias[0];
+    c->tangent_part.rhs[1] = c->tangent_part.rhs_wo_bias[1];
+}
+
+/* warmstart — contact_with_twist_friction.rs:633-678; elements contact_constraint_element.rs:465-478,627-647,720-732 */
+static void constraint_warmstart(ro_world *w, Constraint *c) {
+    SolverVel v1, v2; gather_vel(w, c->solver_vel1, &v1); gather_vel(w, c->solver_vel2, &v2);
+    for (int k = 0; k < c->num_contacts; ++k) {
+        NormalPart *n = &c->normal_part[k];
+        v1.linear = vadd(v1.linear, vmul(vcmul(c->dir1, c->im1), n->impulse));
+        v1.angular = vadd(v1.angular, vmul(n->ii_torque_dir1, n->impulse));
+        v2.linear = vadd(v2.linear, vmul(vcmul(c->dir1, c->im2), -n->impulse));
+        v2.angular = vadd(v2.angular, vmul(n->ii_torque_dir2, n->impulse));
+    }
+    v3 t0 = c->tangent1, t1 = vcross(c->dir1, c->tangent1);
+    float i0 = c->tangent_part.impulse[0], i1 = c->tangent_part.impulse[1];
+    v1.linear = vadd(v1.linear, vcmul(vadd(vmul(t0, i0), vmul(t1, i1)), c->im1));
+    v1.angular = vadd(v1.angular, vadd(vmul(c->tangent_part.ii_torque_dir1[0], i0), vmul(c->tangent_part.ii_torque_dir1[1], i1)));
+    v2.linear = vadd(v2.linear, vcmul(vadd(vmul(t0, -i0), vmul(t1, -i1)), c->im2));
+    v2.angular = vadd(v2.angular, vadd(vmul(c->tangent_part.ii_torque_dir2[0], i0), vmul(c->tangent_part.ii_torque_dir2[1], i1)));
+    if (c->num_contacts > 1) {
+        v3 a = sym3_mul(c->ii1, c->dir1), b = sym3_mul(c->ii2, c->dir1);
+        v1.angular = vadd(v1.angular, vmul(a, c->twist_part.impulse));
+        v2.angular = vsub(v2.angular, vmul(b, c->twist_part.impulse));
+    }
+    scatter_vel(w, c->solver_vel1, &v1); scatter_vel(w, c->solver_vel2, &v2);
+}
+
+/* solve — contact_with_twist_friction.rs:680-781; elements contact_constraint_element.rs:481-504,650-705,735-755 */
+static void constraint_solve(ro_world *w, Constraint *c, int solve_friction) {
+    SolverVel v1, v2; gather_vel(w, c->solver_vel1, &v1); gather_vel(w, c->solver_vel2, &v2);
+    for (int k = 0; k < c->num_contacts; ++k) {
+        NormalPart *n = &c->normal_part[k];
+        float dvel = vdot(c->dir1, v1.linear) + vdot(n->torque_dir1, v1.angular) - vdot(c->dir1, v2.linear) +
+                     vdot(n->torque_dir2, v2.angular) + n->rhs;
+        float new_impulse = n->cfm_factor * ro_maxf(n->impulse - n->r * dvel, 0.0f);
+        float dlambda = new_impulse - n->impulse;
+        n->impulse = new_impulse;
+        v1.linear = vadd(v1.linear, vmul(vcmul(c->dir1, c->im1), dlambda));
+        v1.angular = vadd(v1.angular, vmul(n->ii_torque_dir1, dlambda));
+        v2.linear = vadd(v2.linear, vmul(vcmul(c->dir1, c->im2), -dlambda));
+        v2.angular = vadd(v2.angular, vmul(n->ii_torque_dir2, dlambda));
+    }
+    if (solve_friction) {
+        v3 t0 = c->tangent1, t1 = vcross(c->dir1, c->tangent1);
+        float tangent_limit = 0.0f, twist_limit = 0.0f;
+        for (int k = 0; k < c->num_contacts; ++k) {
+            tangent_limit += c->normal_part[k].impulse;
+            twist_limit += c->normal_part[k].impulse * c->twist_dists[k];
+        }
+        tangent_limit *= c->limit; twist_limit *= c->limit;
+        if (c->num_contacts > 1) {
+            v3 a = sym3_mul(c->ii1, c->dir1), b = sym3_mul(c->ii2, c->dir1);
+            float dvel = vdot(c->dir1, vsub(v1.angular, v2.angular)) + c->twist_part.rhs;
+            float new_impulse = ro_clampf(c->twist_part.impulse - c->twist_part.r * dvel, -twist_limit, twist_limit);
+            float dlambda = new_impulse - c->twist_part.impulse;
+            c->twist_part.impulse = new_impulse;
+            v1.angular = vadd(v1.angular, vmul(a, dlambda));
+            v2.angular = vsub(v2.angular, vmul(b, dlambda));
+        }
+        {
+            float dvel_0 = vdot(t0, v1.linear) + vdot(c->tangent_part.torque_dir1[0], v1.angular) - vdot(t0, v2.linear) +
+                           vdot(c->tangent_part.torque_dir2[0], v2.angular) + c->tangent_part.rhs[0];
+            float dvel_1 = vdot(t1, v1.linear) + vdot(c->tangent_part.torque_dir1[1], v1.angular) - vdot(t1, v2.linear) +
+                           vdot(c->tangent_part.torque_dir2[1], v2.angular) + c->tangent_part.rhs[1];
+            float k11 = c->tangent_part.r[0], k22 = c->tangent_part.r[1], k12 = c->tangent_part.r[2] * 0.5f;
+            float inv_det = ro_inv(k11 * k22 - k12 * k12);
+            float d0 = (k22 * dvel_0 - k12 * dvel_1) * inv_det;
+            float d1 = (k11 * dvel_1 - k12 * dvel_0) * inv_det;
+            float n0 = c->tangent_part.impulse[0] - d0, n1 = c->tangent_part.impulse[1] - d1;
+            /* nalgebra simd_cap_magnitude(limit) */
+            float len = sqrtf(n0 * n0 + n1 * n1);
+            if (len > tangent_limit) { float s = tangent_limit / len; n0 *= s; n1 *= s; }
+            float dl0 = n0 - c->tangent_part.impulse[0], dl1 = n1 - c->tangent_part.impulse[1];
+            c->tangent_part.impulse[0] = n0; c->tangent_part.impulse[1] = n1;
+            v1.linear = vadd(v1.linear, vcmul(vadd(vmul(t0, dl0), vmul(t1, dl1)), c->im1));
+            v1.angular = vadd(v1.angular, vadd(vmul(c->tangent_part.ii_torque_dir1[0], dl0), vmul(c->tangent_part.ii_torque_dir1[1], dl1)));
+            v2.linear = vadd(v2.linear, vcmul(vadd(vmul(t0, -dl0), vmul(t1, -dl1)), c->im2));
+            v2.angular = vadd(v2.angular, vadd(vmul(c->tangent_part.ii_torque_dir2[0], dl0), vmul(c->tangent_part.ii_torque_dir2[1], dl1)));
+        }
+    }
+    scatter_vel(w, c->solver_vel1, &v1); scatter_vel(w, c->solver_vel2, &v2);
+}
+
+/* apply_restitution — contact_with_twist_friction.rs:568-597; solve_restitution contact_constraint_element.rs:508-534 */
+static void constraint_apply_restitution(ro_world *w, Constraint *c) {
+    int any = 0;
+    for (int k = 0; k < c->num_contacts; ++k) any |= c->infos[k].restitution_seed < 0.0f;
+    if (!any) return;
+    SolverVel v1, v2; gather_vel(w, c->solver_vel1, &v1); gather_vel(w, c->solver_vel2, &v2);
+    for (int k = 0; k < c->num_contacts; ++k) {
+        NormalPart *n = &c->normal_part[k];
+        float seed = c->infos[k].restitution_seed;
+        float dvel = vdot(c->dir1, v1.linear) + vdot(n->torque_dir1, v1.angular) - vdot(c->dir1, v2.linear) +
+                     vdot(n->torque_dir2, v2.angular) + seed;
+        int gate = seed < 0.0f && (n->impulse_accumulator + n->impulse) > 0.0f;
+        float new_impulse = gate ? ro_maxf(n->impulse - n->r * dvel, 0.0f) : n->impulse;
+        float dlambda = new_impulse - n->impulse;
+        n->impulse = new_impulse;
+        v1.linear = vadd(v1.linear, vmul(vcmul(c->dir1, c->im1), dlambda));
+        v1.angular = vadd(v1.angular, vmul(n->ii_torque_dir1, dlambda));
+        v2.linear = vadd(v2.linear, vmul(vcmul(c->dir1, c->im2), -dlambda));
+        v2.angular = vadd(v2.angular, vmul(n->ii_torque_dir2, dlambda));
+    }
+    scatter_vel(w, c->solver_vel1, &v1); scatter_vel(w, c->solver_vel2, &v2);
+}
+
+/* writeback_impulses — contact_with_twist_friction.rs:783-829 */
+static void constraint_writeback(ro_world *w, const Constraint *c) {
+    Pair *p = &w->pairs[c->pair];
+    v3 tangent2 = vcross(c->dir1, c->tangent1);
+    v3 wtw = vadd(vmul(c->tangent1, c->tangent_part.impulse[0]), vmul(tangent2, c->tangent_part.impulse[1]));
+    for (int k = 0; k < c->num_contacts; ++k) {
+        ContactData *pd = &p->m.points[c->contact_id[k]].data;
+        pd->warmstart_impulse = c->normal_part[k].impulse;
+        pd->impulse = c->normal_part[k].impulse_accumulator + c->normal_part[k].impulse;
+        pd->warmstart_tangent_world = wtw;
+        pd->warmstart_twist_impulse = c->twist_part.impulse;
+    }
+}
+
+/* gyroscopic_corrected_angvel — dynamics/rigid_body.rs:2023-2046 */
+static v3 gyroscopic_corrected_angvel(v3 angvel, quat principal_axes, v3 pi, v3 inv_pi, float dt) {
+    v3 wl = qrot_inv(principal_axes, angvel);
+    v3 curr = vcmul(pi, wl);
+    v3 explicit_gyro = vmul(vneg(vcross(wl, curr)), dt);
+    v3 total = vadd(curr, explicit_gyro);
+    float sq = vlen2(total);
+    if (sq != 0.0f) {
+        v3 capped = vmul(total, sqrtf(vlen2(curr) / sq));
+        return qrot(principal_axes, vcmul(inv_pi, capped));
+    }
+    return angvel;
+}
+
+/* StagedIslandSolver::init_and_solve + run_worker — staged_island_solver/init.rs:30-545, worker.rs:32-898 */
+static void solve_velocity_constraints(ro_world *w) {
+    const ro_params *prm = &w->params;
+    int num_substeps = prm->num_solver_iterations;
+    float dt_s = prm->dt / (float)num_substeps;
+
+    /* active set = dynamic bodies in arena order (never-sleeping scope), manager.rs:20-39 */
+    int nd = 0;
+    for (int i = 0; i < w->nbodies; ++i) if (w->bodies[i].body_type == RO_BODY_DYNAMIC) nd++;
+    /* maintain_solver_contact_graph — solver_graph.rs:129-361: buckets of active manifolds per colour,
+     * full-rebuild order = ascending (edge, manifold) */
+    int counts[RO_NUM_COLORS]; memset(counts, 0, sizeof(counts));
+    int M = 0, nsc = 0;
+    for (int i = 0; i < w->npairs; ++i) {
+        Pair *p = &w->pairs[i];
+        if (p->nsc == 0 || p->color == RO_COLOR_UNCOLORED) continue;
+        counts[p->color]++; M++; nsc += p->nsc;
+    }
+    solver_reserve(w, nd, M);
+    nd = 0;
+    for (int i = 0; i < w->nbodies; ++i) {
+        Body *b = &w->bodies[i];
+        if (b->body_type == RO_BODY_DYNAMIC) { b->solver_id = (uint32_t)nd; w->dyn_bodies[nd++] = i; } else b->solver_id = RO_NO_BODY;
+    }
+    w->ndyn = nd;
+    w->bucket_begin[0] = 0;
+    for (int c = 0; c < RO_NUM_COLORS; ++c) w->bucket_begin[c + 1] = w->bucket_begin[c] + counts[c];
+    int cursor[RO_NUM_COLORS]; memcpy(cursor, w->bucket_begin, sizeof(cursor));
+    int *order = (int *)malloc(sizeof(int) * (M + 1));
+    for (int i = 0; i < w->npairs; ++i) {
+        Pair *p = &w->pairs[i];
+        if (p->nsc == 0 || p->color == RO_COLOR_UNCOLORED) continue;
+        /* qualify_manifold_bqi — solver_contact_graph.rs:101-124 */
+        int b1 = w->colliders[p->c1].parent, b2 = w->colliders[p->c2].parent;
+        p->solver_body_ids[0] = b1 >= 0 ? w->bodies[b1].solver_id : RO_NO_BODY;
+        p->solver_body_ids[1] = b2 >= 0 ? w->bodies[b2].solver_id : RO_NO_BODY;
+        order[cursor[p->color]++] = i;
+    }
+    /* chunk layout — init.rs:163-254: colours with >= 32 four-lane chunks first (ascending),
+     * then the smaller colours (ascending), then the overflow colour. */
+    w->nstages = 0; int nparallel = 0, nused = 0;
+    for (int c = 0; c < RO_NUM_COLORS - 1; ++c) if ((counts[c] + 3) / 4 >= 32) { w->stage_color[w->nstages++] = c; nparallel++; }
+    for (int c = 0; c < RO_NUM_COLORS - 1; ++c) if (counts[c] > 0 && (counts[c] + 3) / 4 < 32) w->stage_color[w->nstages++] = c;
+    if (counts[RO_COLOR_OVERFLOW] > 0) w->stage_color[w->nstages++] = RO_COLOR_OVERFLOW;
+    for (int c = 0; c < RO_NUM_COLORS; ++c) if (counts[c] > 0) nused++;
+    w->stats.num_active_manifolds = M; w->stats.num_solver_contacts = nsc;
+    w->stats.num_colors_used = nused; w->stats.num_parallel_colors = nparallel; w->stats.num_pairs = w->npairs;
+    w->ncons = M;
+
+    /* S0: solver bodies + increments — worker.rs:46-104, solver_body.rs:82-121 */
+    for (int i = 0; i < nd; ++i) {
+        Body *rb = &w->bodies[w->dyn_bodies[i]];
+        w->flags[i] = rb->allow_fast_rotation ? 1 : 0;
+        w->vels[i].angular = rb->angvel; w->vels[i].linear = rb->linvel;
+        w->poses[i].rotation = rb->position.r;
+        w->poses[i].translation = pose_tp(rb->position, rb->local_com);
+        w->poses[i].ii = rb->effective_world_inv_inertia;
+        w->poses[i].im = rb->effective_inv_mass;
+        w->incr[i].angular = vmul(sym3_mul(rb->effective_world_inv_inertia, rb->torque), dt_s);
+        w->incr[i].linear = vmul(vcmul(rb->force, rb->effective_inv_mass), dt_s);
+        Gyro *g = &w->gyro[i];
+        if (rb->gyroscopic) {
+            g->inv_principal_inertia = rb->inv_principal_inertia;
+            g->principal_inertia = V3(ro_inv(rb->inv_principal_inertia.x), ro_inv(rb->inv_principal_inertia.y), ro_inv(rb->inv_principal_inertia.z));
+            g->principal_frame = rb->principal_frame; g->enabled = 1;
+        } else g->enabled = 0;
+    }
+    /* S1: generate — worker.rs:109-190.  Constraint i lives at bucket position i. */
+    int any_bouncy = 0;
+    for (int i = 0; i < M; ++i) {
+        constraint_generate(w, order[i], &w->cons[i]);
+        for (int k = 0; k < w->cons[i].num_contacts; ++k) any_bouncy |= w->cons[i].infos[k].restitution_seed < 0.0f;
+    }
+    free(order);
+
+    int solve_friction_in_bias = prm->friction_in_bias_pass || prm->num_internal_stabilization_iterations == 0;
+    float max_lin = prm->normalized_max_linear_velocity * prm->length_unit;
+    float max_ang = 0.78539816339744830962f * (prm->dt == 0.0f ? 0.0f : 1.0f / prm->dt);
+    for (int s = 0; s < num_substeps; ++s) {
+        float solved_dt = (float)s * dt_s;
+        /* S2 increments + gyroscopic — worker.rs:235-284 */
+        for (int i = 0; i < nd; ++i) {
+            w->vels[i].linear = vadd(w->vels[i].linear, w->incr[i].linear);
+            w->vels[i].angular = vadd(w->vels[i].angular, w->incr[i].angular);
+            if (w->gyro[i].enabled) {
+                quat axes = qmul(w->poses[i].rotation, w->gyro[i].principal_frame);
+                w->vels[i].angular = gyroscopic_corrected_angvel(w->vels[i].angular, axes, w->gyro[i].principal_inertia,
+                                                                 w->gyro[i].inv_principal_inertia, dt_s);
+            }
+        }
+        /* S4 fused update + warmstart per colour — worker.rs:438-538 (non-fused when coefficient == 0) */
+        for (int st = 0; st < w->nstages; ++st) {
+            int c = w->stage_color[st];
+            for (int i = w->bucket_begin[c]; i < w->bucket_begin[c + 1]; ++i) {
+                constraint_update(w, &w->cons[i], dt_s, solved_dt);
+                if (prm->warmstart_coefficient != 0.0f) constraint_warmstart(w, &w->cons[i]);
+            }
+        }
+        /* S5 biased pass — worker.rs:544-561, staged_island_solver/solve.rs:12-209 */
+        for (int it = 0; it < prm->num_internal_pgs_iterations; ++it)
+            for (int st = 0; st < w->nstages; ++st) {
+                int c = w->stage_color[st];
+                for (int i = w->bucket_begin[c]; i < w->bucket_begin[c + 1]; ++i) constraint_solve(w, &w->cons[i], solve_friction_in_bias);
+            }
+        /* S6 integrate — worker.rs:568-631, rigid_body_components.rs:884-898 */
+        for (int i = 0; i < nd; ++i) {
+            SolverVel *v = &w->vels[i];
+            if (max_lin != FLT_MAX) { float n = vlen(v->linear); if (n > max_lin) v->linear = vmul(v->linear, max_lin / n); }
+            if (!(w->flags[i] & 1)) { float n = vlen(v->angular); if (n > max_ang) v->angular = vmul(v->angular, max_ang / n); }
+            v3 hang = vmul(v->angular, dt_s * 0.5f);
+            quat q = qmul(Q(hang.x, hang.y, hang.z, 1.0f), w->poses[i].rotation);
+            w->poses[i].rotation = qnormalize(q);
+            w->poses[i].translation = vadd(w->poses[i].translation, vmul(v->linear, dt_s));
+        }
+        /* S7 unbiased pass with refreshed rhs — worker.rs:636-649 */
+        for (int it = 0; it < prm->num_internal_stabilization_iterations; ++it)
+            for (int st = 0; st < w->nstages; ++st) {
+                int c = w->stage_color[st];
+                for (int i = w->bucket_begin[c]; i < w->bucket_begin[c + 1]; ++i) {
+                    constraint_refresh_rhs_wo_bias(w, &w->cons[i], dt_s, solved_dt + dt_s);
+                    constraint_solve(w, &w->cons[i], 1);
+                }
+            }
+    }
+    /* S8 restitution — worker.rs:657-734 */
+    if (any_bouncy)
+        for (int st = 0; st < w->nstages; ++st) {
+            int c = w->stage_color[st];
+            for (int i = w->bucket_begin[c]; i < w->bucket_begin[c + 1]; ++i) constraint_apply_restitution(w, &w->cons[i]);
+        }
+    /* S9 impulse writeback — worker.rs:742-802 */
+    for (int i = 0; i < M; ++i) constraint_writeback(w, &w->cons[i]);
+    /* S10 body writeback — worker.rs:809-897 */
+    for (int i = 0; i < nd; ++i) {
+        Body *rb = &w->bodies[w->dyn_bodies[i]];
+        rb->linvel = vmul(w->vels[i].linear, 1.0f / (1.0f + prm->dt * rb->linear_damping));
+        rb->angvel = vmul(w->vels[i].angular, 1.0f / (1.0f + prm->dt * rb->angular_damping));
+        pose sp; sp.r = w->poses[i].rotation; sp.t = w->poses[i].translation;
+        /* pose.prepend_translation(-local_com) */
+        rb->next_position.r = sp.r;
+        rb->next_position.t = vadd(sp.t, qrot(sp.r, vneg(rb->local_com)));
+    }
+}
+
+/* PhysicsPipeline::step_inner — pipeline/physics_pipeline/substep.rs:267-581 */
+static void step_once(ro_world *w) {
+    /* detect_collisions — solve.rs:45-157 */
+    broad_phase_update(w);
+    narrow_phase_compute_contacts(w);
+    /* fused body pass — solve.rs:234-291; compute_effective_force_and_torque rigid_body_components.rs:1030-1033 */
+    for (int i = 0; i < w->nbodies; ++i) {
+        Body *b = &w->bodies[i];
+        if (b->body_type != RO_BODY_DYNAMIC) continue;
+        v3 mass = V3(ro_inv(b->effective_inv_mass.x), ro_inv(b->effective_inv_mass.y), ro_inv(b->effective_inv_mass.z));
+        b->force = vadd(b->user_force, vmul(vcmul(w->gravity, mass), b->gravity_scale));
+        b->torque = b->user_torque;
+    }
+    solve_velocity_constraints(w);
+    /* advance_to_final_positions — substep.rs:84-224; refresh_moved_collider_aabbs :229-240 */
+    for (int i = 0; i < w->nbodies; ++i) {
+        Body *b = &w->bodies[i];
+        if (b->body_type != RO_BODY_DYNAMIC) continue;
+        b->position = b->next_position;
+        update_world_mass_properties(b);
+    }
+    for (int i = 0; i < w->ncolliders; ++i) {
+        Collider *c = &w->colliders[i];
+        if (c->parent < 0 || w->bodies[c->parent].body_type != RO_BODY_DYNAMIC) continue;
+        c->pos = pose_mul(w->bodies[c->parent].position, c->pos_wrt_parent);
+        bp_set_aabb(w, c);
+    }
+}
+
+void ro_step(ro_world *w, int32_t nsteps) { for (int i = 0; i < nsteps; ++i) step_once(w); }
+void ro_get_stats(const ro_world *w, ro_stats *out) { *out = w->stats; }
+
+float ro_total_contact_impulse(const ro_world *w) {
+    float total = 0.0f;
+    for (int i = 0; i < w->npairs; ++i) {
+        const Pair *p = &w->pairs[i];
+        float s = 0.0f;
+        for (int k = 0; k < p->m.npoints; ++k) s += p->m.points[k].data.impulse;
+        total += s;
+    }
+    return total;
+}
+int32_t ro_dump_manifolds(const ro_world *w, int32_t cap, int32_t *meta, float *normal3, float *impulses4) {
+    int n = 0;
+    for (int i = 0; i < w->npairs; ++i) {
+        const Pair *p = &w->pairs[i];
+        if (p->nsc == 0) continue;
+        if (n < cap) {
+            if (meta) { meta[4 * n] = p->c1; meta[4 * n + 1] = p->c2; meta[4 * n + 2] = p->color; meta[4 * n + 3] = p->nsc; }
+            if (normal3) { normal3[3 * n] = p->normal.x; normal3[3 * n + 1] = p->normal.y; normal3[3 * n + 2] = p->normal.z; }
+            if (impulses4) for (int k = 0; k < 4; ++k) impulses4[4 * n + k] = k < p->nsc ? p->m.points[p->sc[k].cid].data.impulse : 0.0f;
+        }
+        n++;
+    }
+    return n;
+}
+int32_t ro_add_joint(ro_world *w, const ro_joint_desc *d) { (void)w; (void)d; return -1; }

@@ -1,0 +1,124 @@
+/*
+ * oracle/rapier_oracle.h — TEST INFRASTRUCTURE ONLY.
+ *
+ * Public (ctypes-friendly) interface of the CPU oracle: a single-threaded, scalar C
+ * restatement of rapier3d/f32 `PhysicsPipeline::step()` (reference v0.35.2,
+ * /root/reference/src/pipeline/physics_pipeline/substep.rs:267-581) restricted to the
+ * hot-path scope of SURVEY.md §8: fat-AABB broad phase pair set, cuboid/ball contact
+ * manifolds, persistent greedy pair colouring, colour-ordered TGS-soft contact solver with
+ * twist friction, spherical/fixed impulse joints, linearised integrator.
+ *
+ * PARITY PINNING: the Rust reference cannot be built in this environment (no cargo) and
+ * parry3d's manifold generator is not in /root/reference.  The oracle is therefore pinned
+ * by the reference's own outcome-level known-answer tests (tests/test_oracle_kat.py):
+ * total_contact_impulse.rs:13-75, broad_phase_bvh/mod.rs:281-329, test_staged.rs:86-148,
+ * coefficient_combine_rule.rs:60-96.  Manifold-level (parry-internal) parity is UNPINNED.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+ */
+#ifndef RAPIER_ORACLE_H
+#define RAPIER_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* IntegrationParameters — /root/reference/src/dynamics/integration_parameters.rs:181-304,
+ * defaults :379-408. */
+typedef struct ro_params {
+    float dt;
+    float contact_natural_frequency, contact_damping_ratio;               /* 30, 10 */
+    float static_contact_natural_frequency, static_contact_damping_ratio; /* 60, 10 */
+    float joint_natural_frequency, joint_damping_ratio;                   /* 1e6, 1 */
+    float warmstart_coefficient;                                          /* 1 */
+    float normalized_allowed_linear_error;                                /* 0.005 */
+    float normalized_max_corrective_velocity;                             /* 3 */
+    float normalized_prediction_distance;                                 /* 0.02 */
+    float normalized_max_linear_velocity;                                 /* 400 */
+    float normalized_contact_recycle_distance;                            /* 0.05 */
+    float length_unit;                                                    /* 1 */
+    int32_t num_solver_iterations;                                        /* 4 (substeps) */
+    int32_t num_internal_pgs_iterations;                                  /* 1 */
+    int32_t num_internal_stabilization_iterations;                        /* 1 */
+    int32_t contact_recycling;                                            /* 1 */
+    int32_t friction_in_bias_pass;                                        /* 0 */
+    int32_t warmstart_joints;                                             /* 0 */
+    int32_t max_ccd_substeps;                                             /* 1 (flag only) */
+} ro_params;
+
+enum { RO_BODY_DYNAMIC = 0, RO_BODY_FIXED = 1 };
+enum { RO_SHAPE_BALL = 0, RO_SHAPE_CUBOID = 1 };
+/* CoefficientCombineRule — coefficient_combine_rule.rs:37-57 */
+enum { RO_RULE_AVERAGE = 0, RO_RULE_MIN = 1, RO_RULE_MULTIPLY = 2, RO_RULE_MAX = 3,
+       RO_RULE_CLAMPED_SUM = 4, RO_RULE_GEOMETRIC_MEAN = 5 };
+
+typedef struct ro_body_desc {
+    int32_t body_type;
+    float translation[3];
+    float rotation[4]; /* x,y,z,w */
+    float linvel[3], angvel[3];
+    float linear_damping, angular_damping;
+    float gravity_scale;
+    float additional_mass;  /* RigidBodyBuilder::additional_mass */
+    int32_t dominance;      /* i8 group */
+    int32_t gyroscopic;     /* default 1 — rigid_body.rs:1579 */
+    int32_t allow_fast_rotation;
+} ro_body_desc;
+
+typedef struct ro_collider_desc {
+    int32_t shape;
+    float half_extents[3]; /* cuboid; ball: radius in [0] */
+    float translation[3];  /* pos_wrt_parent (or world pose when parent < 0) */
+    float rotation[4];
+    float density, friction, restitution;
+    int32_t friction_rule, restitution_rule;
+    uint32_t collision_memberships, collision_filter; /* InteractionGroups */
+} ro_collider_desc;
+
+/* GenericJoint restricted to lock rows (spherical = LIN_X|LIN_Y|LIN_Z, fixed = all six). */
+typedef struct ro_joint_desc {
+    int32_t body1, body2;
+    float local_anchor1[3], local_anchor2[3];
+    float local_basis1[4], local_basis2[4];
+    uint32_t locked_axes; /* bit0..2 lin x,y,z ; bit3..5 ang x,y,z */
+    int32_t contacts_enabled;
+} ro_joint_desc;
+
+typedef struct ro_world ro_world;
+
+void ro_default_params(ro_params *out);
+ro_world *ro_world_new(const ro_params *params, const float gravity[3]);
+void ro_world_free(ro_world *w);
+int32_t ro_add_body(ro_world *w, const ro_body_desc *d);
+int32_t ro_add_collider(ro_world *w, const ro_collider_desc *d, int32_t parent_body);
+int32_t ro_add_joint(ro_world *w, const ro_joint_desc *d);
+void ro_step(ro_world *w, int32_t nsteps);
+int32_t ro_num_bodies(const ro_world *w);
+/* pos7 = (tx,ty,tz, qx,qy,qz,qw) per body, vel6 = (lin, ang) per body, arena order. */
+void ro_read_bodies(const ro_world *w, float *pos7, float *vel6);
+void ro_set_body_vel(ro_world *w, int32_t body, const float linvel[3], const float angvel[3]);
+
+/* Statistics of the last step (for DESIGN/bench: M and colour histogram). */
+typedef struct ro_stats {
+    int32_t num_pairs;          /* broad-phase pairs in the pair table */
+    int32_t num_active_manifolds; /* M: solver manifolds */
+    int32_t num_solver_contacts;
+    int32_t num_colors_used;
+    int32_t num_parallel_colors; /* colours with >= 32 four-lane chunks */
+    int32_t num_full_updates;   /* pairs that took the full narrow-phase path */
+    int32_t num_recycled;
+    int32_t bp_rebuilt;
+} ro_stats;
+void ro_get_stats(const ro_world *w, ro_stats *out);
+/* Sum over contact pairs of |sum_k impulse_k * normal| — ContactPair::total_impulse_magnitude. */
+float ro_total_contact_impulse(const ro_world *w);
+/* Dump active manifolds: per manifold (c1,c2,color,count) and per point impulse.  Returns M. */
+int32_t ro_dump_manifolds(const ro_world *w, int32_t cap, int32_t *c1c2_color_count,
+                          float *normal3, float *impulses4);
+float ro_combine_coefficient(float a, float b, int32_t rule_a, int32_t rule_b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,2 @@
+"""rapier_amd — MI355X-native `PhysicsPipeline::step()` hot path for rapier3d scenes."""
+from . import scenes  # noqa: F401

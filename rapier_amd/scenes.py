@@ -1,0 +1,246 @@
+"""Closed-form scene generators for the hot-path configs.
+
+Each generator restates the formulas of the reference example it is named after and
+returns a :class:`Scene` of plain numpy descriptor arrays (the same layouts the C ABI in
+``include/rapier_hip.h`` takes).  No RNG anywhere: the scenes are closed-form.
+
+* ``many_pyramids``  — /root/reference/examples3d/b3d_many_pyramids.rs:9-64
+* ``large_pyramid``  — /root/reference/examples3d/b3d_large_pyramid.rs:15-36
+* ``joint_grid``     — /root/reference/examples3d/b3d_joint_grid.rs:17-53
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+BODY_DYNAMIC, BODY_FIXED = 0, 1
+SHAPE_BALL, SHAPE_CUBOID = 0, 1
+RULE_AVERAGE, RULE_MIN, RULE_MULTIPLY, RULE_MAX, RULE_CLAMPED_SUM, RULE_GEOMETRIC_MEAN = range(6)
+
+# Field-for-field mirrors of rp_body_desc / rp_collider_desc / rp_joint_desc / rp_integration_params.
+BODY_DTYPE = np.dtype([
+    ("body_type", "<i4"), ("translation", "<f4", 3), ("rotation", "<f4", 4),
+    ("linvel", "<f4", 3), ("angvel", "<f4", 3),
+    ("linear_damping", "<f4"), ("angular_damping", "<f4"), ("gravity_scale", "<f4"),
+    ("additional_mass", "<f4"), ("dominance", "<i4"), ("gyroscopic", "<i4"),
+    ("allow_fast_rotation", "<i4"),
+], align=False)
+COLLIDER_DTYPE = np.dtype([
+    ("shape", "<i4"), ("half_extents", "<f4", 3), ("translation", "<f4", 3), ("rotation", "<f4", 4),
+    ("density", "<f4"), ("friction", "<f4"), ("restitution", "<f4"),
+    ("friction_rule", "<i4"), ("restitution_rule", "<i4"),
+    ("collision_memberships", "<u4"), ("collision_filter", "<u4"),
+], align=False)
+JOINT_DTYPE = np.dtype([
+    ("body1", "<i4"), ("body2", "<i4"), ("local_anchor1", "<f4", 3), ("local_anchor2", "<f4", 3),
+    ("local_basis1", "<f4", 4), ("local_basis2", "<f4", 4), ("locked_axes", "<u4"),
+    ("contacts_enabled", "<i4"),
+], align=False)
+PARAMS_DTYPE = np.dtype([
+    ("dt", "<f4"),
+    ("contact_natural_frequency", "<f4"), ("contact_damping_ratio", "<f4"),
+    ("static_contact_natural_frequency", "<f4"), ("static_contact_damping_ratio", "<f4"),
+    ("joint_natural_frequency", "<f4"), ("joint_damping_ratio", "<f4"),
+    ("warmstart_coefficient", "<f4"),
+    ("normalized_allowed_linear_error", "<f4"), ("normalized_max_corrective_velocity", "<f4"),
+    ("normalized_prediction_distance", "<f4"), ("normalized_max_linear_velocity", "<f4"),
+    ("normalized_contact_recycle_distance", "<f4"), ("length_unit", "<f4"),
+    ("num_solver_iterations", "<i4"), ("num_internal_pgs_iterations", "<i4"),
+    ("num_internal_stabilization_iterations", "<i4"), ("contact_recycling", "<i4"),
+    ("friction_in_bias_pass", "<i4"), ("warmstart_joints", "<i4"), ("max_ccd_substeps", "<i4"),
+], align=False)
+
+LOCK_LIN = 0b000111
+LOCK_ALL = 0b111111
+
+
+def default_params() -> np.ndarray:
+    """IntegrationParameters::default() — integration_parameters.rs:379-408."""
+    p = np.zeros((), dtype=PARAMS_DTYPE)
+    p["dt"] = np.float32(1.0) / np.float32(60.0)
+    p["contact_natural_frequency"], p["contact_damping_ratio"] = 30.0, 10.0
+    p["static_contact_natural_frequency"], p["static_contact_damping_ratio"] = 60.0, 10.0
+    p["joint_natural_frequency"], p["joint_damping_ratio"] = 1.0e6, 1.0
+    p["warmstart_coefficient"] = 1.0
+    p["normalized_allowed_linear_error"] = 0.005
+    p["normalized_max_corrective_velocity"] = 3.0
+    p["normalized_prediction_distance"] = 0.02
+    p["normalized_max_linear_velocity"] = 400.0
+    p["normalized_contact_recycle_distance"] = 0.05
+    p["length_unit"] = 1.0
+    p["num_solver_iterations"] = 4
+    p["num_internal_pgs_iterations"] = 1
+    p["num_internal_stabilization_iterations"] = 1
+    p["contact_recycling"] = 1
+    p["friction_in_bias_pass"] = 0
+    p["warmstart_joints"] = 0
+    p["max_ccd_substeps"] = 1
+    return p
+
+
+def body_desc(body_type=BODY_DYNAMIC, translation=(0, 0, 0), rotation=(0, 0, 0, 1), linvel=(0, 0, 0),
+              angvel=(0, 0, 0), linear_damping=0.0, angular_damping=0.0, gravity_scale=1.0,
+              additional_mass=0.0, dominance=0, gyroscopic=1, allow_fast_rotation=0) -> np.ndarray:
+    """RigidBodyBuilder defaults — /root/reference/src/dynamics/rigid_body.rs:1560-1600."""
+    b = np.zeros((), dtype=BODY_DTYPE)
+    b["body_type"] = body_type
+    b["translation"] = translation
+    b["rotation"] = rotation
+    b["linvel"], b["angvel"] = linvel, angvel
+    b["linear_damping"], b["angular_damping"] = linear_damping, angular_damping
+    b["gravity_scale"], b["additional_mass"] = gravity_scale, additional_mass
+    b["dominance"], b["gyroscopic"], b["allow_fast_rotation"] = dominance, gyroscopic, allow_fast_rotation
+    return b
+
+
+def collider_desc(shape=SHAPE_CUBOID, half_extents=(0.5, 0.5, 0.5), translation=(0, 0, 0),
+                  rotation=(0, 0, 0, 1), density=1.0, friction=0.5, restitution=0.0,
+                  friction_rule=RULE_AVERAGE, restitution_rule=RULE_AVERAGE,
+                  memberships=0xFFFFFFFF, filter=0xFFFFFFFF) -> np.ndarray:
+    """ColliderBuilder defaults — /root/reference/src/geometry/collider.rs:1125-1127 (friction 0.5,
+    restitution 0, density 1, rule Average)."""
+    c = np.zeros((), dtype=COLLIDER_DTYPE)
+    c["shape"] = shape
+    he = np.zeros(3, np.float32)
+    he[: len(np.atleast_1d(half_extents))] = np.atleast_1d(half_extents)
+    c["half_extents"] = he
+    c["translation"], c["rotation"] = translation, rotation
+    c["density"], c["friction"], c["restitution"] = density, friction, restitution
+    c["friction_rule"], c["restitution_rule"] = friction_rule, restitution_rule
+    c["collision_memberships"], c["collision_filter"] = memberships, filter
+    return c
+
+
+@dataclass
+class Scene:
+    name: str
+    gravity: tuple = (0.0, -10.0, 0.0)
+    params: np.ndarray = field(default_factory=default_params)
+    bodies: list = field(default_factory=list)
+    colliders: list = field(default_factory=list)
+    collider_parents: list = field(default_factory=list)
+    joints: list = field(default_factory=list)
+
+    def add_body(self, **kw) -> int:
+        self.bodies.append(body_desc(**kw))
+        return len(self.bodies) - 1
+
+    def add_collider(self, parent: int, **kw) -> int:
+        self.colliders.append(collider_desc(**kw))
+        self.collider_parents.append(parent)
+        return len(self.colliders) - 1
+
+    def add_joint(self, body1, body2, anchor1, anchor2, locked_axes=LOCK_LIN, contacts_enabled=1) -> int:
+        j = np.zeros((), dtype=JOINT_DTYPE)
+        j["body1"], j["body2"] = body1, body2
+        j["local_anchor1"], j["local_anchor2"] = anchor1, anchor2
+        j["local_basis1"] = (0, 0, 0, 1)
+        j["local_basis2"] = (0, 0, 0, 1)
+        j["locked_axes"], j["contacts_enabled"] = locked_axes, contacts_enabled
+        self.joints.append(j)
+        return len(self.joints) - 1
+
+    # Packed arrays ---------------------------------------------------------------------
+    def body_array(self) -> np.ndarray:
+        return np.array(self.bodies, dtype=BODY_DTYPE) if self.bodies else np.zeros(0, BODY_DTYPE)
+
+    def collider_array(self) -> np.ndarray:
+        return np.array(self.colliders, dtype=COLLIDER_DTYPE) if self.colliders else np.zeros(0, COLLIDER_DTYPE)
+
+    def parent_array(self) -> np.ndarray:
+        return np.array(self.collider_parents, dtype=np.int32)
+
+    def joint_array(self) -> np.ndarray:
+        return np.array(self.joints, dtype=JOINT_DTYPE) if self.joints else np.zeros(0, JOINT_DTYPE)
+
+    @property
+    def num_dynamic(self) -> int:
+        return int(sum(int(b["body_type"]) == BODY_DYNAMIC for b in self.bodies))
+
+
+def _f(x):
+    return np.float32(x)
+
+
+def _small_pyramid(scene: Scene, base_count: int, extent, center_x, base_z):
+    """create_small_pyramid — b3d_many_pyramids.rs:9-29 (f32 arithmetic, same op order)."""
+    extent = _f(extent)
+    for i in range(base_count):
+        y = (_f(2.0) * _f(i) + _f(1.0)) * extent
+        for j in range(i, base_count):
+            x = (_f(i) + _f(1.0)) * extent + _f(2.0) * _f(j - i) * extent + _f(center_x) - _f(0.5)
+            b = scene.add_body(translation=(x, y, _f(base_z)))
+            scene.add_collider(b, half_extents=(extent, extent, extent), density=100.0)
+
+
+def many_pyramids(rows: int = 14, cols: int = 14, base_count: int = 10, col_range=None) -> Scene:
+    """b3d_many_pyramids.rs:36-64.  ``col_range=(lo, hi)`` keeps only pyramid columns lo..hi-1 (the
+    multi-GPU island shard; the ground is replicated)."""
+    s = Scene(name=f"b3d_many_pyramids_{rows}x{cols}")
+    extent = _f(0.5)
+    ground_extent = extent * _f(cols) * (_f(base_count) + _f(1.0))
+    g = s.add_body(body_type=BODY_FIXED, translation=(0.0, -1.0, 0.0))
+    s.add_collider(g, half_extents=(ground_extent, 1.0, ground_extent))
+    base_width = _f(2.0) * extent * _f(base_count)
+    base_z = -ground_extent + _f(2.0) * extent
+    delta_z = _f(2.0) * (ground_extent - _f(2.0) * extent) / (_f(rows) - _f(1.0)) if rows > 1 else _f(0.0)
+    lo, hi = col_range if col_range is not None else (0, cols)
+    for _ in range(rows):
+        for j in range(cols):
+            center_x = -ground_extent + _f(j) * (base_width + _f(2.0) * extent) + _f(2.0) * extent
+            if lo <= j < hi:
+                _small_pyramid(s, base_count, extent, center_x, base_z)
+        base_z = base_z + delta_z
+    return s
+
+
+def pyramid10() -> Scene:
+    """C1 plumbing scene: one 10-base pyramid."""
+    s = many_pyramids(rows=1, cols=1)
+    s.name = "pyramid10"
+    return s
+
+
+def large_pyramid(base_count: int = 200) -> Scene:
+    """b3d_large_pyramid.rs:15-36."""
+    s = Scene(name=f"b3d_large_pyramid_{base_count}")
+    g = s.add_body(body_type=BODY_FIXED, translation=(0.0, -1.0, 0.0))
+    s.add_collider(g, half_extents=(400.0, 1.0, 400.0))
+    extent = _f(0.5)
+    for i in range(base_count):
+        y = (_f(2.0) * _f(i) + _f(1.0)) * extent
+        for j in range(i, base_count):
+            x = (_f(i) + _f(1.0)) * extent + _f(2.0) * _f(j - i) * extent - _f(base_count) * extent
+            b = s.add_body(translation=(x, y, 0.0))
+            s.add_collider(b, half_extents=(extent, extent, extent), density=100.0)
+    return s
+
+
+def joint_grid(n: int = 100) -> Scene:
+    """b3d_joint_grid.rs:17-53: n x n balls (r 0.4), spherical joints, row i == 0 fixed."""
+    s = Scene(name=f"b3d_joint_grid_{n}")
+    ids = [-1] * (n * n)
+    index = 0
+    for k in range(n):
+        for i in range(n):
+            b = s.add_body(body_type=BODY_FIXED if i == 0 else BODY_DYNAMIC, translation=(_f(k), -_f(i), 0.0))
+            s.add_collider(b, shape=SHAPE_BALL, half_extents=(0.4, 0.0, 0.0), density=1.0)
+            if i > 0:
+                s.add_joint(ids[index - 1], b, (0.0, -0.5, 0.0), (0.0, 0.5, 0.0))
+            if k > 0:
+                s.add_joint(ids[index - n], b, (0.5, 0.0, 0.0), (-0.5, 0.0, 0.0))
+            ids[index] = b
+            index += 1
+    return s
+
+
+def box_stack(height: int = 3, gap: float = 0.0) -> Scene:
+    """Small cube stack on a slab (the 3-cube stack of test_staged.rs:86-148)."""
+    s = Scene(name=f"box_stack_{height}", gravity=(0.0, -9.81, 0.0))
+    g = s.add_body(body_type=BODY_FIXED, translation=(0.0, -0.5, 0.0))
+    s.add_collider(g, half_extents=(10.0, 0.5, 10.0))
+    for i in range(height):
+        b = s.add_body(translation=(0.0, 0.5 + i * (1.0 + gap), 0.0))
+        s.add_collider(b, half_extents=(0.5, 0.5, 0.5))
+    return s

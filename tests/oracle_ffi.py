@@ -1,0 +1,111 @@
+"""ctypes binding of the CPU oracle (oracle/librapier_oracle.so) — test infrastructure only."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from rapier_amd import scenes as S
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_ORACLE_DIR = os.path.join(_ROOT, "oracle")
+_LIB = None
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "num_pairs", "num_active_manifolds", "num_solver_contacts", "num_colors_used",
+        "num_parallel_colors", "num_full_updates", "num_recycled", "bp_rebuilt")]
+
+
+def build_oracle() -> str:
+    subprocess.run(["make", "-s", "-C", _ORACLE_DIR], check=True)
+    return os.path.join(_ORACLE_DIR, "librapier_oracle.so")
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_ORACLE_DIR, "librapier_oracle.so")
+        src = os.path.join(_ORACLE_DIR, "rapier_oracle.c")
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            build_oracle()
+        L = C.CDLL(path)
+        L.ro_world_new.restype = C.c_void_p
+        L.ro_world_new.argtypes = [C.c_void_p, C.c_void_p]
+        L.ro_world_free.argtypes = [C.c_void_p]
+        L.ro_add_body.argtypes = [C.c_void_p, C.c_void_p]
+        L.ro_add_collider.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        L.ro_add_joint.argtypes = [C.c_void_p, C.c_void_p]
+        L.ro_step.argtypes = [C.c_void_p, C.c_int32]
+        L.ro_num_bodies.argtypes = [C.c_void_p]
+        L.ro_read_bodies.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ro_get_stats.argtypes = [C.c_void_p, C.c_void_p]
+        L.ro_total_contact_impulse.argtypes = [C.c_void_p]
+        L.ro_total_contact_impulse.restype = C.c_float
+        L.ro_dump_manifolds.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ro_combine_coefficient.argtypes = [C.c_float, C.c_float, C.c_int32, C.c_int32]
+        L.ro_combine_coefficient.restype = C.c_float
+        L.ro_set_body_vel.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+class OracleWorld:
+    """The oracle stepped through the same Scene descriptors as the product."""
+
+    def __init__(self, scene: S.Scene):
+        L = lib()
+        params = np.ascontiguousarray(scene.params)
+        grav = np.asarray(scene.gravity, dtype=np.float32)
+        self._w = L.ro_world_new(params.ctypes.data, grav.ctypes.data)
+        bodies = scene.body_array()
+        for i in range(len(bodies)):
+            L.ro_add_body(self._w, bodies[i:i + 1].ctypes.data)
+        cols = scene.collider_array()
+        parents = scene.parent_array()
+        for i in range(len(cols)):
+            L.ro_add_collider(self._w, cols[i:i + 1].ctypes.data, int(parents[i]))
+        joints = scene.joint_array()
+        for i in range(len(joints)):
+            L.ro_add_joint(self._w, joints[i:i + 1].ctypes.data)
+        self.n = len(bodies)
+
+    def step(self, n: int = 1):
+        lib().ro_step(self._w, n)
+
+    def read(self):
+        pos = np.zeros((self.n, 7), np.float32)
+        vel = np.zeros((self.n, 6), np.float32)
+        lib().ro_read_bodies(self._w, pos.ctypes.data, vel.ctypes.data)
+        return pos, vel
+
+    def stats(self) -> dict:
+        s = Stats()
+        lib().ro_get_stats(self._w, C.byref(s))
+        return {n: getattr(s, n) for n, _ in Stats._fields_}
+
+    def total_contact_impulse(self) -> float:
+        return float(lib().ro_total_contact_impulse(self._w))
+
+    def manifolds(self):
+        L = lib()
+        m = L.ro_dump_manifolds(self._w, 0, None, None, None)
+        meta = np.zeros((m, 4), np.int32)
+        nrm = np.zeros((m, 3), np.float32)
+        imp = np.zeros((m, 4), np.float32)
+        L.ro_dump_manifolds(self._w, m, meta.ctypes.data, nrm.ctypes.data, imp.ctypes.data)
+        return meta, nrm, imp
+
+    def set_vel(self, body, linvel, angvel=(0, 0, 0)):
+        lv = np.asarray(linvel, np.float32)
+        av = np.asarray(angvel, np.float32)
+        lib().ro_set_body_vel(self._w, body, lv.ctypes.data, av.ctypes.data)
+
+    def __del__(self):
+        try:
+            lib().ro_world_free(self._w)
+        except Exception:
+            pass
