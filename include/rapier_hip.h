@@ -1,0 +1,169 @@
+/*
+ * rapier_hip.h — C ABI of librapier_hip.so, the MI355X-native drop-in for the rapier3d (f32)
+ * `PhysicsPipeline::step()` hot path.
+ *
+ * The reference has no FFI around this path (everything is Rust); the seam this
+ * ABI replaces is B1/B2 of SURVEY §8(b):
+ *   PhysicsPipeline::step      /root/reference/src/pipeline/physics_pipeline/mod.rs:196-246
+ *   PhysicsWorld (owner of the ten sets)   /root/reference/src/pipeline/physics_world.rs:61-157
+ *   RigidBodySet::insert       /root/reference/src/dynamics/rigid_body_set.rs:70
+ *   ColliderSet::insert_with_parent  /root/reference/src/geometry/collider_set.rs:49
+ *   ImpulseJointSet::insert    /root/reference/src/dynamics/joint/impulse_joint/impulse_joint_set.rs
+ *   Index{index,generation}    /root/reference/src/data/arena.rs:58-90  (handles)
+ *   Counters                   /root/reference/src/counters/mod.rs:18
+ * A Rust shim binding these gives RigidBodySet/ColliderSet/PhysicsPipeline
+ * newtypes with the reference's method names.
+ *
+ * Conventions: C linkage, no exceptions cross the boundary, every call returns int32 status
+ * (0 = ok, <0 = error; text via rp_last_error).  The opaque rp_world owns all host and device
+ * memory; the caller owns every array it passes.  One thread per world at a time; different
+ * worlds may be stepped concurrently on different devices.  All state lives in HBM between
+ * calls; rp_step enqueues on the world's HIP stream and returns without host sync unless
+ * stated.  There is NO CPU fallback: if no HIP device is usable rp_world_create fails.
+ */
+#ifndef RAPIER_HIP_H
+#define RAPIER_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RP_OK 0
+#define RP_ERR_INVALID (-1)
+#define RP_ERR_DEVICE (-2)
+#define RP_ERR_CAPACITY (-3)
+#define RP_ERR_NONFINITE (-4)
+
+/* IntegrationParameters, field for field — integration_parameters.rs:181-304 (defaults :379-408) */
+typedef struct rp_integration_params {
+    float dt;
+    float contact_natural_frequency, contact_damping_ratio;
+    float static_contact_natural_frequency, static_contact_damping_ratio;
+    float joint_natural_frequency, joint_damping_ratio;
+    float warmstart_coefficient;
+    float normalized_allowed_linear_error;
+    float normalized_max_corrective_velocity;
+    float normalized_prediction_distance;
+    float normalized_max_linear_velocity;
+    float normalized_contact_recycle_distance;
+    float length_unit;
+    int32_t num_solver_iterations;
+    int32_t num_internal_pgs_iterations;
+    int32_t num_internal_stabilization_iterations;
+    int32_t contact_recycling;
+    int32_t friction_in_bias_pass;
+    int32_t warmstart_joints;
+    int32_t max_ccd_substeps;
+} rp_integration_params;
+
+enum { RP_BODY_DYNAMIC = 0, RP_BODY_FIXED = 1 };
+enum { RP_SHAPE_BALL = 0, RP_SHAPE_CUBOID = 1 };
+enum { RP_RULE_AVERAGE = 0, RP_RULE_MIN, RP_RULE_MULTIPLY, RP_RULE_MAX, RP_RULE_CLAMPED_SUM, RP_RULE_GEOMETRIC_MEAN };
+
+/* RigidBodyBuilder — /root/reference/src/dynamics/rigid_body.rs:1560-1900 */
+typedef struct rp_body_desc {
+    int32_t body_type;
+    float translation[3];
+    float rotation[4]; /* unit quaternion x,y,z,w */
+    float linvel[3], angvel[3];
+    float linear_damping, angular_damping;
+    float gravity_scale;
+    float additional_mass;
+    int32_t dominance;
+    int32_t gyroscopic;
+    int32_t allow_fast_rotation;
+} rp_body_desc;
+
+/* ColliderBuilder — /root/reference/src/geometry/collider.rs:600-1130 */
+typedef struct rp_collider_desc {
+    int32_t shape;
+    float half_extents[3]; /* cuboid half extents; ball radius in [0] */
+    float translation[3];  /* pos_wrt_parent (world pose when parent handle is RP_INVALID_HANDLE) */
+    float rotation[4];
+    float density, friction, restitution;
+    int32_t friction_rule, restitution_rule;
+    uint32_t collision_memberships, collision_filter;
+} rp_collider_desc;
+
+/* GenericJoint restricted to locked axes — /root/reference/src/dynamics/joint/generic_joint.rs:341-355 */
+typedef struct rp_joint_desc {
+    int32_t body1, body2; /* dense body indices (handle low 32 bits) */
+    float local_anchor1[3], local_anchor2[3];
+    float local_basis1[4], local_basis2[4];
+    uint32_t locked_axes; /* JointAxesMask: bit0..2 LIN_X,Y,Z ; bit3..5 ANG_X,Y,Z */
+    int32_t contacts_enabled;
+} rp_joint_desc;
+
+/* Counters mirror (ms, from hipEvents) — /root/reference/src/counters/{mod,stages_counters,
+ * collision_detection_counters,solver_counters}.rs; plus device-side scene statistics. */
+typedef struct rp_counters {
+    float step_time_ms;            /* Counters::step_time (last rp_step call, per step) */
+    float collision_detection_ms;  /* StagesCounters::collision_detection_time */
+    float broad_phase_ms;          /* CollisionDetectionCounters::broad_phase_time */
+    float narrow_phase_ms;         /* CollisionDetectionCounters::narrow_phase_time */
+    float island_construction_ms;  /* StagesCounters::island_construction_time (colouring + buckets) */
+    float solver_ms;               /* StagesCounters::solver_time */
+    float velocity_assembly_ms;    /* SolverCounters::velocity_assembly_time */
+    float velocity_resolution_ms;  /* SolverCounters::velocity_resolution_time (the TGS loop) */
+    float velocity_update_ms;      /* SolverCounters::velocity_update_time (writeback + advance) */
+    int32_t num_pairs;             /* CollisionDetectionCounters::ncontact_pairs */
+    int32_t num_manifolds;         /* SolverCounters::nconstraints (solver manifolds M) */
+    int32_t num_solver_contacts;   /* SolverCounters::ncontacts */
+    int32_t num_colors;            /* colours in use */
+    int32_t num_parallel_stages;   /* colours with >= 32 four-lane chunks (init.rs:169) */
+    int32_t num_dynamic_bodies;
+    int32_t bp_rebuilds;           /* broad-phase pair-set rebuilds so far */
+    int32_t full_updates;          /* narrow-phase full updates in the last step */
+    int32_t overflow_flags;        /* nonzero = a device buffer overflowed (see rp_last_error) */
+    int32_t quarantined;           /* bodies with non-finite state detected (Quarantine) */
+} rp_counters;
+
+#define RP_INVALID_HANDLE 0xffffffffffffffffull
+
+typedef struct rp_world rp_world;
+
+/* PhysicsWorld::new + the device to live on.  Fails (RP_ERR_DEVICE) when no HIP device. */
+int32_t rp_world_create(const rp_integration_params *params, const float gravity[3], int32_t device, rp_world **out);
+int32_t rp_world_destroy(rp_world *w);
+const char *rp_last_error(const rp_world *w);
+void rp_default_params(rp_integration_params *out);            /* IntegrationParameters::default() */
+int32_t rp_params_get(const rp_world *w, rp_integration_params *out);
+int32_t rp_params_set(rp_world *w, const rp_integration_params *in);
+
+/* RigidBodySet::insert ×n; handles = generation<<32 | index (arena.rs:58-90). */
+int32_t rp_bodies_insert(rp_world *w, int32_t n, const rp_body_desc *descs, uint64_t *handles_out);
+/* ColliderSet::insert_with_parent ×n (parent RP_INVALID_HANDLE = ColliderSet::insert). */
+int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider_desc *descs, const uint64_t *parents, uint64_t *handles_out);
+/* ImpulseJointSet::insert ×n. */
+int32_t rp_impulse_joints_insert(rp_world *w, int32_t n, const rp_joint_desc *descs, uint64_t *handles_out);
+
+/* PhysicsWorld::step() × nsteps with hooks = &(), events = &() (physics_world.rs:120-157). */
+int32_t rp_step(rp_world *w, uint32_t nsteps);
+/* Block until every enqueued step has finished (hipStreamSynchronize). */
+int32_t rp_sync(rp_world *w);
+
+/* RigidBody::position()/linvel()/angvel() for n handles (NULL handles = all bodies in arena order):
+ * pos7 = tx,ty,tz,qx,qy,qz,qw ; vel6 = linvel, angvel.  Synchronises. */
+int32_t rp_bodies_read(rp_world *w, int32_t n, const uint64_t *handles, float *pos7_out, float *vel6_out);
+/* RigidBody::set_linvel/set_angvel/set_position (user changes).  NULL arrays are left untouched. */
+int32_t rp_bodies_write(rp_world *w, int32_t n, const uint64_t *handles, const float *pos7, const float *vel6);
+int32_t rp_num_bodies(const rp_world *w);
+
+/* NarrowPhase::contact_pairs() analogue: for each active solver manifold: (collider1, collider2,
+ * colour, num solver contacts), world normal, total normal impulse per solver contact.
+ * Returns the number of active manifolds (may exceed cap; only cap are written). */
+int32_t rp_contacts_read(rp_world *w, int32_t cap, int32_t *c1_c2_color_count, float *normal3, float *impulse4);
+
+/* PhysicsPipeline::counters; `enable_timers` != 0 turns on hipEvent stage timing (off = no events). */
+int32_t rp_counters_enable(rp_world *w, int32_t enable_timers);
+int32_t rp_counters_read(rp_world *w, rp_counters *out);
+
+/* Average device time (ms) of the TGS velocity-solve loop kernels over the steps since the last
+ * call, measured with hipEvents on the world's stream (bench.py roofline leg). */
+int32_t rp_solver_loop_time_ms(rp_world *w, float *avg_ms_per_step, int32_t *steps_measured);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

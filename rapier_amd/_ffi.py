@@ -1,0 +1,76 @@
+"""ctypes loader for librapier_hip.so (the C ABI of include/rapier_hip.h).
+
+There is no CPU fallback: if the HIP library is missing or no HIP device is usable the
+import / world creation fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librapier_hip.so")
+
+RP_OK = 0
+RP_INVALID_HANDLE = 0xFFFFFFFFFFFFFFFF
+
+# every symbol include/rapier_hip.h declares
+SYMBOLS = [
+    "rp_world_create", "rp_world_destroy", "rp_last_error", "rp_default_params", "rp_params_get",
+    "rp_params_set", "rp_bodies_insert", "rp_colliders_insert", "rp_impulse_joints_insert", "rp_step",
+    "rp_sync", "rp_bodies_read", "rp_bodies_write", "rp_num_bodies", "rp_contacts_read",
+    "rp_counters_enable", "rp_counters_read", "rp_solver_loop_time_ms",
+]
+
+
+class Counters(C.Structure):
+    """rp_counters — mirror of the reference's Counters (src/counters/mod.rs:18)."""
+    _fields_ = [(n, C.c_float) for n in (
+        "step_time_ms", "collision_detection_ms", "broad_phase_ms", "narrow_phase_ms",
+        "island_construction_ms", "solver_ms", "velocity_assembly_ms", "velocity_resolution_ms",
+        "velocity_update_ms")] + [(n, C.c_int32) for n in (
+        "num_pairs", "num_manifolds", "num_solver_contacts", "num_colors", "num_parallel_stages",
+        "num_dynamic_bodies", "bp_rebuilds", "full_updates", "overflow_flags", "quarantined")]
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"rapier_amd: HIP library not built ({LIB_PATH} missing). Run __graft_entry__.build() "
+            "or `make -C rapier_amd/csrc`. There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, u32, f32 = C.c_void_p, C.c_int32, C.c_uint32, C.c_float
+    L.rp_world_create.argtypes = [vp, vp, i32, C.POINTER(vp)]
+    L.rp_world_create.restype = i32
+    L.rp_world_destroy.argtypes = [vp]
+    L.rp_world_destroy.restype = i32
+    L.rp_last_error.argtypes = [vp]
+    L.rp_last_error.restype = C.c_char_p
+    L.rp_default_params.argtypes = [vp]
+    L.rp_default_params.restype = None
+    L.rp_params_get.argtypes = [vp, vp]
+    L.rp_params_set.argtypes = [vp, vp]
+    L.rp_bodies_insert.argtypes = [vp, i32, vp, vp]
+    L.rp_colliders_insert.argtypes = [vp, i32, vp, vp, vp]
+    L.rp_impulse_joints_insert.argtypes = [vp, i32, vp, vp]
+    L.rp_step.argtypes = [vp, u32]
+    L.rp_sync.argtypes = [vp]
+    L.rp_bodies_read.argtypes = [vp, i32, vp, vp, vp]
+    L.rp_bodies_write.argtypes = [vp, i32, vp, vp, vp]
+    L.rp_num_bodies.argtypes = [vp]
+    L.rp_contacts_read.argtypes = [vp, i32, vp, vp, vp]
+    L.rp_counters_enable.argtypes = [vp, i32]
+    L.rp_counters_read.argtypes = [vp, vp]
+    L.rp_solver_loop_time_ms.argtypes = [vp, C.POINTER(f32), C.POINTER(i32)]
+    for name in SYMBOLS:
+        fn = getattr(L, name)
+        if name not in ("rp_last_error", "rp_default_params"):
+            fn.restype = i32
+    _LIB = L
+    return L

@@ -1,0 +1,660 @@
+// rp_api.hip — the C ABI of librapier_hip.so (include/rapier_hip.h) and the per-step launch driver.
+//
+// Mirrors PhysicsWorld / PhysicsPipeline::step (physics_world.rs:61-157, physics_pipeline/mod.rs:196-246,
+// substep.rs:267-581): detect_collisions -> build_islands_and_solve_velocity_constraints ->
+// advance_to_final_positions -> refresh_moved_collider_aabbs.  A step is a fixed sequence of kernel
+// launches on the world's HIP stream, captured once into a hipGraph and replayed (the reference's
+// per-colour spin barriers become kernel boundaries; graph replay removes the host launch cost).
+// The host never needs device-side counts to be correct: kernels size themselves from device
+// scalars and the solver's single-workgroup tail absorbs any colour stage the host did not launch.
+// Layout hints (parallel colour count, largest stage) are read lazily from pinned memory.
+#include "rp_world.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+void rp_launch_collider_update(const DevWorld &w, hipStream_t st);
+void rp_launch_broadphase(const DevWorld &w, hipStream_t st);
+void rp_launch_narrowphase(const DevWorld &w, hipStream_t st);
+void rp_launch_init_bodies(const DevWorld &w, hipStream_t st);
+void rp_launch_solver_assembly(const DevWorld &w, hipStream_t st);
+void rp_launch_solver_loop(const DevWorld &w, hipStream_t st, int parallel_stages, int stage_blocks, int has_restitution);
+void rp_launch_solver_writeback(const DevWorld &w, hipStream_t st);
+
+struct HostBody { rp_body_desc d; float inv_mass; float inv_pi[3]; float lcom[3]; int ncolliders; };
+
+struct rp_world {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    rp_integration_params params;
+    float gravity[3];
+    std::vector<HostBody> bodies;
+    std::vector<rp_collider_desc> colliders;
+    std::vector<int> collider_parent;
+    std::vector<rp_joint_desc> joints;
+    bool finalized = false;
+    bool hints_valid = false;
+    std::vector<void *> allocs;
+    DevWorld dw;
+    int *pinned_flags = nullptr; // FL_COUNT ints, written by an async D2H copy at the end of each step
+    // launch plan + graph
+    int plan_stages = 0, plan_blocks = 1;
+    bool has_restitution = false;
+    hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;
+    hipGraph_t g_col = nullptr, g_asm = nullptr, g_loop = nullptr, g_fin = nullptr;
+    hipGraphExec_t ge_col = nullptr, ge_asm = nullptr, ge_loop = nullptr, ge_fin = nullptr;
+    int graph_stages = -1, graph_blocks = -1;
+    bool use_graph = true;
+    // timers
+    bool timers = false;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double acc_loop_ms = 0.0, acc_col_ms = 0.0, acc_asm_ms = 0.0, acc_fin_ms = 0.0, acc_step_ms = 0.0;
+    int acc_steps = 0;
+    double loop_ms_since_read = 0.0; int loop_steps_since_read = 0;
+    std::string err;
+};
+
+#define HIPCHK(w, expr)                                                                                   \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) {                                                                           \
+            (w)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                                 \
+            return RP_ERR_DEVICE;                                                                         \
+        }                                                                                                 \
+    } while (0)
+
+extern "C" void rp_default_params(rp_integration_params *p) {
+    // IntegrationParameters::default() — integration_parameters.rs:379-408
+    p->dt = 1.0f / 60.0f;
+    p->contact_natural_frequency = 30.0f; p->contact_damping_ratio = 10.0f;
+    p->static_contact_natural_frequency = 60.0f; p->static_contact_damping_ratio = 10.0f;
+    p->joint_natural_frequency = 1.0e6f; p->joint_damping_ratio = 1.0f;
+    p->warmstart_coefficient = 1.0f;
+    p->normalized_allowed_linear_error = 0.005f;
+    p->normalized_max_corrective_velocity = 3.0f;
+    p->normalized_prediction_distance = 0.02f;
+    p->normalized_max_linear_velocity = 400.0f;
+    p->normalized_contact_recycle_distance = 0.05f;
+    p->length_unit = 1.0f;
+    p->num_solver_iterations = 4;
+    p->num_internal_pgs_iterations = 1;
+    p->num_internal_stabilization_iterations = 1;
+    p->contact_recycling = 1;
+    p->friction_in_bias_pass = 0;
+    p->warmstart_joints = 0;
+    p->max_ccd_substeps = 1;
+}
+
+// SpringCoefficients::{erp_inv_dt, cfm_factor} — integration_parameters.rs:86-149 (f32, no FMA)
+static float spring_erp_inv_dt(float freq, float damping, float dt) {
+    volatile float ang_freq = freq * 6.283185307179586f;
+    volatile float a = dt * ang_freq;
+    volatile float b = 2.0f * damping;
+    volatile float den = a + b;
+    return ang_freq / den;
+}
+static float spring_cfm_factor(float freq, float damping, float dt) {
+    volatile float erp = dt * spring_erp_inv_dt(freq, damping, dt);
+    volatile float cfm_coeff = 0.0f;
+    if (erp != 0.0f) {
+        volatile float q = 1.0f / erp;
+        volatile float iem1 = q - 1.0f;
+        volatile float num = iem1 * iem1;
+        volatile float d0 = 1.0f + iem1;
+        volatile float d1 = d0 * 4.0f;
+        volatile float d2 = d1 * damping;
+        volatile float d3 = d2 * damping;
+        cfm_coeff = num / d3;
+    }
+    volatile float den = 1.0f + cfm_coeff;
+    return 1.0f / den;
+}
+
+static void fill_sim_params(rp_world *w, SimParams &sp, float cell) {
+    const rp_integration_params &p = w->params;
+    sp.p = p;
+    for (int k = 0; k < 3; ++k) sp.gravity[k] = w->gravity[k];
+    sp.num_substeps = p.num_solver_iterations;
+    volatile float dts = p.dt / (float)sp.num_substeps;
+    sp.dt_sub = dts;
+    sp.inv_dt_sub = dts == 0.0f ? 0.0f : 1.0f / dts;
+    sp.dyn_cfm = spring_cfm_factor(p.contact_natural_frequency, p.contact_damping_ratio, dts);
+    sp.static_cfm = spring_cfm_factor(p.static_contact_natural_frequency, p.static_contact_damping_ratio, dts);
+    sp.dyn_erp_inv_dt = spring_erp_inv_dt(p.contact_natural_frequency, p.contact_damping_ratio, dts);
+    sp.static_erp_inv_dt = spring_erp_inv_dt(p.static_contact_natural_frequency, p.static_contact_damping_ratio, dts);
+    sp.prediction = p.normalized_prediction_distance * p.length_unit;
+    sp.recycle_distance = p.contact_recycling ? p.normalized_contact_recycle_distance * p.length_unit : 0.0f;
+    sp.max_corrective_velocity = p.normalized_max_corrective_velocity * p.length_unit;
+    sp.max_lin = p.normalized_max_linear_velocity * p.length_unit;
+    volatile float inv_dt = p.dt == 0.0f ? 0.0f : 1.0f / p.dt;
+    sp.max_ang = 0.78539816339744830962f * inv_dt; // MAX_ROTATION * inv_dt, worker.rs:29,575
+    sp.bp_skin = 4.0e-2f * p.length_unit;           // CHANGE_DETECTION_FACTOR, broad_phase_bvh/mod.rs:175
+    sp.cell_size = cell;
+    sp.inv_cell_size = 1.0f / cell;
+}
+
+extern "C" int32_t rp_world_create(const rp_integration_params *params, const float gravity[3], int32_t device, rp_world **out) {
+    if (!out) return RP_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RP_ERR_DEVICE; // no CPU fallback
+    if (device < 0 || device >= ndev) return RP_ERR_DEVICE;
+    rp_world *w = new rp_world();
+    w->device = device;
+    if (params) w->params = *params; else rp_default_params(&w->params);
+    for (int k = 0; k < 3; ++k) w->gravity[k] = gravity ? gravity[k] : 0.0f;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) { delete w; return RP_ERR_DEVICE; }
+    const char *g = getenv("RP_NO_GRAPH");
+    if (g && g[0] == '1') w->use_graph = false;
+    memset(&w->dw, 0, sizeof(w->dw));
+    *out = w;
+    return RP_OK;
+}
+
+static void destroy_graphs(rp_world *w) {
+    hipGraphExec_t *ex[] = {&w->graph_exec, &w->ge_col, &w->ge_asm, &w->ge_loop, &w->ge_fin};
+    hipGraph_t *gr[] = {&w->graph, &w->g_col, &w->g_asm, &w->g_loop, &w->g_fin};
+    for (auto e : ex) if (*e) { hipGraphExecDestroy(*e); *e = nullptr; }
+    for (auto g : gr) if (*g) { hipGraphDestroy(*g); *g = nullptr; }
+    w->graph_stages = -1; w->graph_blocks = -1;
+}
+static void free_device(rp_world *w) {
+    destroy_graphs(w);
+    for (void *p : w->allocs) hipFree(p);
+    w->allocs.clear();
+    if (w->pinned_flags) { hipHostFree(w->pinned_flags); w->pinned_flags = nullptr; }
+    w->finalized = false;
+}
+
+extern "C" int32_t rp_world_destroy(rp_world *w) {
+    if (!w) return RP_ERR_INVALID;
+    hipSetDevice(w->device);
+    if (w->stream) hipStreamSynchronize(w->stream);
+    free_device(w);
+    for (auto &e : w->ev) if (e) hipEventDestroy(e);
+    if (w->stream) hipStreamDestroy(w->stream);
+    delete w;
+    return RP_OK;
+}
+extern "C" const char *rp_last_error(const rp_world *w) { return w ? w->err.c_str() : "null world"; }
+extern "C" int32_t rp_params_get(const rp_world *w, rp_integration_params *out) { if (!w || !out) return RP_ERR_INVALID; *out = w->params; return RP_OK; }
+extern "C" int32_t rp_params_set(rp_world *w, const rp_integration_params *in) {
+    if (!w || !in) return RP_ERR_INVALID;
+    w->params = *in;
+    if (w->finalized) { fill_sim_params(w, w->dw.prm, w->dw.prm.cell_size); destroy_graphs(w); }
+    return RP_OK;
+}
+extern "C" int32_t rp_num_bodies(const rp_world *w) { return w ? (int32_t)w->bodies.size() : 0; }
+
+// parry Shape::mass_properties for cuboid / ball
+static void shape_mass_props(const rp_collider_desc &c, float density, float &mass, float pi[3]) {
+    if (c.shape == RP_SHAPE_CUBOID) {
+        const float *he = c.half_extents;
+        volatile float vol = he[0] * he[1] * he[2] * 8.0f;
+        volatile float m = vol * density;
+        volatile float ix = (he[1] * he[1] + he[2] * he[2]) / 3.0f;
+        volatile float iy = (he[0] * he[0] + he[2] * he[2]) / 3.0f;
+        volatile float iz = (he[0] * he[0] + he[1] * he[1]) / 3.0f;
+        mass = m; pi[0] = ix * m; pi[1] = iy * m; pi[2] = iz * m;
+    } else {
+        float r = c.half_extents[0];
+        volatile float vol = 3.14159265358979323846f * r * r * r * 4.0f / 3.0f;
+        volatile float m = vol * density;
+        volatile float i = r * r * 0.4f;
+        mass = m; pi[0] = pi[1] = pi[2] = i * m;
+    }
+}
+static float h_inv(float x) { return (x > -1.0e-20f && x < 1.0e-20f) ? 0.0f : 1.0f / x; }
+
+// RigidBodyMassProps::recompute_mass_properties_from_colliders — rigid_body_components.rs:421-489.
+// Scope: one collider per body attached at the body origin (all the hot-path scenes).
+static void recompute_mass(rp_world *w, int body) {
+    HostBody &b = w->bodies[body];
+    float mass = 0.0f, pi[3] = {0, 0, 0};
+    const rp_collider_desc *c0 = nullptr;
+    for (size_t i = 0; i < w->colliders.size(); ++i) if (w->collider_parent[i] == body) { c0 = &w->colliders[i]; break; }
+    if (c0) shape_mass_props(*c0, c0->density, mass, pi);
+    float add = b.d.additional_mass;
+    if (add != 0.0f) {
+        if (mass > 0.0f) { volatile float nm = mass + add; volatile float k = nm / mass; for (int q = 0; q < 3; ++q) pi[q] = pi[q] * k; mass = nm; }
+        else if (c0) {
+            float um, upi[3]; shape_mass_props(*c0, 1.0f, um, upi);
+            if (um > 0.0f) { volatile float k = add / um; for (int q = 0; q < 3; ++q) pi[q] = upi[q] * k; }
+            mass = add;
+        } else mass = add;
+    }
+    b.inv_mass = h_inv(mass);
+    for (int q = 0; q < 3; ++q) { b.inv_pi[q] = h_inv(pi[q]); b.lcom[q] = 0.0f; }
+}
+
+extern "C" int32_t rp_bodies_insert(rp_world *w, int32_t n, const rp_body_desc *descs, uint64_t *handles_out) {
+    if (!w || n < 0 || (n > 0 && !descs)) return RP_ERR_INVALID;
+    if (w->finalized) { hipSetDevice(w->device); hipStreamSynchronize(w->stream); free_device(w); }
+    for (int i = 0; i < n; ++i) {
+        HostBody b; b.d = descs[i]; b.ncolliders = 0; b.inv_mass = 0; b.inv_pi[0] = b.inv_pi[1] = b.inv_pi[2] = 0; b.lcom[0] = b.lcom[1] = b.lcom[2] = 0;
+        w->bodies.push_back(b);
+        recompute_mass(w, (int)w->bodies.size() - 1);
+        if (handles_out) handles_out[i] = (uint64_t)(w->bodies.size() - 1);
+    }
+    return RP_OK;
+}
+extern "C" int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider_desc *descs, const uint64_t *parents, uint64_t *handles_out) {
+    if (!w || n < 0 || (n > 0 && !descs)) return RP_ERR_INVALID;
+    if (w->finalized) { hipSetDevice(w->device); hipStreamSynchronize(w->stream); free_device(w); }
+    for (int i = 0; i < n; ++i) {
+        int parent = -1;
+        if (parents && parents[i] != RP_INVALID_HANDLE) {
+            parent = (int)(parents[i] & 0xffffffffull);
+            if (parent < 0 || parent >= (int)w->bodies.size()) { w->err = "rp_colliders_insert: invalid parent handle"; return RP_ERR_INVALID; }
+        }
+        w->colliders.push_back(descs[i]);
+        w->collider_parent.push_back(parent);
+        if (parent >= 0) { w->bodies[parent].ncolliders++; recompute_mass(w, parent); }
+        if (descs[i].restitution > 0.0f) w->has_restitution = true;
+        if (handles_out) handles_out[i] = (uint64_t)(w->colliders.size() - 1);
+    }
+    return RP_OK;
+}
+extern "C" int32_t rp_impulse_joints_insert(rp_world *w, int32_t n, const rp_joint_desc *descs, uint64_t *handles_out) {
+    if (!w || n < 0 || (n > 0 && !descs)) return RP_ERR_INVALID;
+    if (n > 0) { w->err = "rp_impulse_joints_insert: impulse joints are not implemented on the device path yet"; return RP_ERR_INVALID; }
+    (void)handles_out;
+    return RP_OK;
+}
+
+template <typename T>
+static int dalloc(rp_world *w, T *&p, size_t count, int fill_byte = 0) {
+    void *q = nullptr;
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    if (hipMalloc(&q, bytes) != hipSuccess) { w->err = "hipMalloc failed"; return RP_ERR_DEVICE; }
+    if (hipMemsetAsync(q, fill_byte, bytes, w->stream) != hipSuccess) { w->err = "hipMemset failed"; return RP_ERR_DEVICE; }
+    w->allocs.push_back(q);
+    p = (T *)q;
+    return RP_OK;
+}
+#define DA(ptr, count) do { int r_ = dalloc(w, ptr, (size_t)(count)); if (r_ != RP_OK) return r_; } while (0)
+#define DAF(ptr, count, fill) do { int r_ = dalloc(w, ptr, (size_t)(count), fill); if (r_ != RP_OK) return r_; } while (0)
+
+template <typename T>
+static int upload(rp_world *w, T *dst, const std::vector<T> &src) {
+    if (src.empty()) return RP_OK;
+    if (hipMemcpyAsync(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, w->stream) != hipSuccess) { w->err = "upload failed"; return RP_ERR_DEVICE; }
+    return RP_OK;
+}
+#define UP(dst, vec) do { int r_ = upload(w, dst, vec); if (r_ != RP_OK) return r_; } while (0)
+
+static int next_pow2(long long x) { long long p = 1; while (p < x) p <<= 1; return (int)p; }
+static float4 mk4(float x, float y, float z, float w_) { float4 r; r.x = x; r.y = y; r.z = z; r.w = w_; return r; }
+
+// Upload the host mirrors into the SoA device world (the "upload = resume" path of SURVEY §5).
+static int finalize(rp_world *w) {
+    HIPCHK(w, hipSetDevice(w->device));
+    DevWorld &d = w->dw;
+    memset(&d, 0, sizeof(d));
+    int nb = (int)w->bodies.size(), nc = (int)w->colliders.size();
+    d.n_bodies = nb; d.n_colliders = nc;
+    const char *env_pool = getenv("RP_PAIRS_PER_COLLIDER");
+    int ppc = env_pool ? atoi(env_pool) : 8;
+    d.pool_cap = ppc * nc + 1024;
+    d.hash_cap = next_pow2(4LL * d.pool_cap);
+    d.grid_cap = std::min(next_pow2(8LL * std::max(nc, 1)), 1 << 20);
+    d.grid_cap = std::max(d.grid_cap, 1024);
+    d.entries_cap = 27 * nc + 64;
+    d.large_cap = std::min(std::max(nc, 1), 4096);
+    d.cons_cap = d.pool_cap;
+    // grid cell size: 90th percentile of the collider bounding extents (+ fat margins)
+    float pred = w->params.normalized_prediction_distance * w->params.length_unit;
+    float margin = 2.0f * (pred * 0.5f + 4.0e-2f * w->params.length_unit);
+    std::vector<float> ext;
+    for (auto &c : w->colliders) {
+        float r = c.shape == RP_SHAPE_CUBOID ? std::sqrt(c.half_extents[0] * c.half_extents[0] + c.half_extents[1] * c.half_extents[1] + c.half_extents[2] * c.half_extents[2]) : c.half_extents[0];
+        ext.push_back(2.0f * r + margin);
+    }
+    float cell = 1.0f;
+    if (!ext.empty()) { std::sort(ext.begin(), ext.end()); cell = ext[(size_t)((ext.size() - 1) * 0.9)]; }
+    if (!(cell > 1.0e-6f)) cell = 1.0f;
+    fill_sim_params(w, d.prm, cell);
+
+    DA(d.flags, FL_COUNT);
+    DA(d.b_pos, nb); DA(d.b_rot, nb); DA(d.b_linvel, nb); DA(d.b_angvel, nb); DA(d.b_lcom_invm, nb); DA(d.b_invpi, nb);
+    DA(d.b_pframe, nb); DA(d.b_wcom, nb); DA(d.b_eim, nb); DA(d.b_eii0, nb); DA(d.b_eii1, nb); DA(d.b_damp, nb);
+    DA(d.b_uforce, nb); DA(d.b_utorque, nb); DA(d.b_flags, nb);
+    DA(d.s_lin, nb); DA(d.s_ang, nb); DA(d.s_rot, nb); DA(d.s_trans, nb); DA(d.s_incl, nb); DA(d.s_inca, nb);
+    DA(d.b_cmask, 4 * (size_t)nb); DAF(d.b_min, nb, 0xff);
+    DA(d.c_parent, nc); DA(d.c_shape, nc); DA(d.c_lpos, nc); DA(d.c_lrot, nc); DA(d.c_pos, nc); DA(d.c_rot, nc); DA(d.c_he, nc);
+    DA(d.c_mat, nc); DA(d.c_rules, nc); DA(d.c_groups, nc); DA(d.c_fatmin, nc); DA(d.c_fatmax, nc);
+    DA(d.cell_count, d.grid_cap); DA(d.cell_start, d.grid_cap + 1); DA(d.cell_fill, d.grid_cap); DA(d.scan_block, 1024);
+    DA(d.e_key, d.entries_cap); DA(d.e_col, d.entries_cap); DA(d.large_list, d.large_cap);
+    DAF(d.h_key[0], d.hash_cap, 0xff); DAF(d.h_key[1], d.hash_cap, 0xff); DA(d.h_slot[0], d.hash_cap); DA(d.h_slot[1], d.hash_cap);
+    DA(d.free_stack, d.pool_cap);
+    size_t P = (size_t)d.pool_cap;
+    DAF(d.p_c1, P, 0xff); DA(d.p_c2, P); DA(d.p_stamp, P); DA(d.p_color, P); DA(d.p_nsc, P); DA(d.p_npts, P); DA(d.p_pflags, P); DA(d.p_reldom, P);
+    DA(d.p_colorb, P); DA(d.p_ln1, P); DA(d.p_ln2, P); DA(d.p_normal, P); DA(d.p_misc, P);
+    DA(d.r_t, P); DA(d.r_r, P); DA(d.r_rot1, P); DA(d.r_rot2, P);
+    DA(d.pt_lp1d, RP_MAX_PTS * P); DA(d.pt_lp2f, RP_MAX_PTS * P); DA(d.pt_imp, RP_MAX_PTS * P); DA(d.pt_wst, RP_MAX_PTS * P);
+    DA(d.pt_dp1, RP_MAX_PTS * P); DA(d.pt_dp2, RP_MAX_PTS * P);
+    DA(d.sc_a1, 4 * P); DA(d.sc_a2, 4 * P);
+    DA(d.todo_slot, P); DA(d.todo_key, P); DA(d.todo_tmp, P);
+    DA(d.color_count, RP_NUM_COLORS + 1); DA(d.color_begin, RP_NUM_COLORS + 1); DA(d.color_cursor, RP_NUM_COLORS + 1);
+    DA(d.stage_color, RP_NUM_COLORS + 1); DA(d.stage_begin, RP_NUM_COLORS + 1); DA(d.stage_count, RP_NUM_COLORS + 1);
+    DA(d.cons_pair, d.cons_cap); DAF(d.p_conspos, P, 0xff);
+    DA(d.C, (size_t)CP_COUNT * d.cons_cap);
+    DA(d.k_b1, d.cons_cap); DA(d.k_b2, d.cons_cap); DA(d.k_n, d.cons_cap); DA(d.k_cid, d.cons_cap);
+
+    // host SoA staging
+    std::vector<float4> pos(nb), rot(nb), lv(nb), av(nb), lci(nb), ipi(nb), pfr(nb), damp(nb);
+    std::vector<int> bfl(nb);
+    for (int i = 0; i < nb; ++i) {
+        const HostBody &b = w->bodies[i];
+        const rp_body_desc &bd = b.d;
+        float qn = std::sqrt(bd.rotation[0] * bd.rotation[0] + bd.rotation[1] * bd.rotation[1] + bd.rotation[2] * bd.rotation[2] + bd.rotation[3] * bd.rotation[3]);
+        float qi = qn > 0.0f ? 1.0f / qn : 1.0f;
+        pos[i] = mk4(bd.translation[0], bd.translation[1], bd.translation[2], 0);
+        rot[i] = mk4(bd.rotation[0] * qi, bd.rotation[1] * qi, bd.rotation[2] * qi, qn > 0.0f ? bd.rotation[3] * qi : 1.0f);
+        lv[i] = mk4(bd.linvel[0], bd.linvel[1], bd.linvel[2], 0); av[i] = mk4(bd.angvel[0], bd.angvel[1], bd.angvel[2], 0);
+        lci[i] = mk4(b.lcom[0], b.lcom[1], b.lcom[2], b.inv_mass);
+        ipi[i] = mk4(b.inv_pi[0], b.inv_pi[1], b.inv_pi[2], 0);
+        pfr[i] = mk4(0, 0, 0, 1);
+        damp[i] = mk4(bd.linear_damping, bd.angular_damping, bd.gravity_scale, 0);
+        int fl = (bd.body_type & RP_BF_TYPE_MASK);
+        if (bd.gyroscopic) fl |= RP_BF_GYRO;
+        if (bd.allow_fast_rotation) fl |= RP_BF_FASTROT;
+        fl |= ((int)(bd.dominance & 0xff)) << RP_BF_DOM_SHIFT;
+        bfl[i] = fl;
+    }
+    UP(d.b_pos, pos); UP(d.b_rot, rot); UP(d.b_linvel, lv); UP(d.b_angvel, av); UP(d.b_lcom_invm, lci); UP(d.b_invpi, ipi);
+    UP(d.b_pframe, pfr); UP(d.b_damp, damp); UP(d.b_flags, bfl);
+    std::vector<int> cpar(nc), csh(nc);
+    std::vector<float4> clp(nc), clr(nc), che(nc), cmat(nc), fmn(nc), fmx(nc);
+    std::vector<int2> crul(nc); std::vector<uint2> cgrp(nc);
+    for (int i = 0; i < nc; ++i) {
+        const rp_collider_desc &c = w->colliders[i];
+        cpar[i] = w->collider_parent[i]; csh[i] = c.shape;
+        float qn = std::sqrt(c.rotation[0] * c.rotation[0] + c.rotation[1] * c.rotation[1] + c.rotation[2] * c.rotation[2] + c.rotation[3] * c.rotation[3]);
+        float qi = qn > 0.0f ? 1.0f / qn : 1.0f;
+        clp[i] = mk4(c.translation[0], c.translation[1], c.translation[2], 0);
+        clr[i] = mk4(c.rotation[0] * qi, c.rotation[1] * qi, c.rotation[2] * qi, qn > 0.0f ? c.rotation[3] * qi : 1.0f);
+        che[i] = mk4(c.half_extents[0], c.half_extents[1], c.half_extents[2], 0);
+        cmat[i] = mk4(c.friction, c.restitution, c.density, 0);
+        crul[i].x = c.friction_rule; crul[i].y = c.restitution_rule;
+        cgrp[i].x = c.collision_memberships; cgrp[i].y = c.collision_filter;
+        // an "inverted" AABB: the first k_collider_update always rewrites it
+        fmn[i] = mk4(1.0f, 1.0f, 1.0f, 0); fmx[i] = mk4(-1.0f, -1.0f, -1.0f, 0);
+    }
+    UP(d.c_parent, cpar); UP(d.c_shape, csh); UP(d.c_lpos, clp); UP(d.c_lrot, clr); UP(d.c_he, che); UP(d.c_mat, cmat);
+    UP(d.c_rules, crul); UP(d.c_groups, cgrp); UP(d.c_fatmin, fmn); UP(d.c_fatmax, fmx);
+    std::vector<int> fl(FL_COUNT, 0);
+    fl[FL_BP_DIRTY] = 1; fl[FL_LAYOUT_DIRTY] = 1;
+    UP(d.flags, fl);
+    HIPCHK(w, hipHostMalloc((void **)&w->pinned_flags, FL_COUNT * sizeof(int), hipHostMallocDefault));
+    memset(w->pinned_flags, 0, FL_COUNT * sizeof(int));
+    rp_launch_init_bodies(d, w->stream);
+    rp_launch_collider_update(d, w->stream);
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    HIPCHK(w, hipGetLastError());
+    w->finalized = true; w->hints_valid = false;
+    return RP_OK;
+}
+
+static void enqueue_collision(rp_world *w) {
+    rp_launch_broadphase(w->dw, w->stream);
+    rp_launch_narrowphase(w->dw, w->stream);
+}
+static void enqueue_assembly(rp_world *w) { rp_launch_solver_assembly(w->dw, w->stream); }
+static void enqueue_loop(rp_world *w) { rp_launch_solver_loop(w->dw, w->stream, w->plan_stages, w->plan_blocks, w->has_restitution ? 1 : 0); }
+static void enqueue_finish(rp_world *w) {
+    rp_launch_solver_writeback(w->dw, w->stream);
+    rp_launch_collider_update(w->dw, w->stream);
+    hipMemcpyAsync(w->pinned_flags, w->dw.flags, FL_COUNT * sizeof(int), hipMemcpyDeviceToHost, w->stream);
+}
+
+static void plan_from_hints(rp_world *w, const int *fl) {
+    int npar = fl[FL_N_PARALLEL];
+    int maxs = fl[FL_MAX_STAGE];
+    w->plan_stages = npar;
+    int blocks = (maxs + 255) / 256;
+    // round up to a power of two so small changes of the stage size do not force a re-capture
+    int b = 1; while (b < blocks) b <<= 1;
+    w->plan_blocks = std::min(std::max(b, 1), 4096);
+}
+
+static int capture(rp_world *w, hipGraph_t *g, hipGraphExec_t *ge, void (*fn)(rp_world *)) {
+    HIPCHK(w, hipStreamBeginCapture(w->stream, hipStreamCaptureModeThreadLocal));
+    fn(w);
+    HIPCHK(w, hipStreamEndCapture(w->stream, g));
+    HIPCHK(w, hipGraphInstantiate(ge, *g, nullptr, nullptr, 0));
+    return RP_OK;
+}
+static void enqueue_whole(rp_world *w) { enqueue_collision(w); enqueue_assembly(w); enqueue_loop(w); enqueue_finish(w); }
+
+static int check_overflow(rp_world *w, const int *fl) {
+    if (fl[FL_OVERFLOW]) {
+        char buf[256];
+        snprintf(buf, sizeof(buf), "device buffer overflow (flags 0x%x: 1=pair pool 2=pair hash 4=grid cells 8=large list 16=constraints); "
+                 "raise RP_PAIRS_PER_COLLIDER", fl[FL_OVERFLOW]);
+        w->err = buf;
+        return RP_ERR_CAPACITY;
+    }
+    return RP_OK;
+}
+
+static int step_once(rp_world *w) {
+    if (!w->hints_valid) {
+        // First step after (re)building the world: run collision detection eagerly and read the
+        // colour layout once so the solver launch plan is right from the start.
+        enqueue_collision(w);
+        int fl[FL_COUNT];
+        HIPCHK(w, hipMemcpyAsync(fl, w->dw.flags, sizeof(fl), hipMemcpyDeviceToHost, w->stream));
+        HIPCHK(w, hipStreamSynchronize(w->stream));
+        int r = check_overflow(w, fl);
+        if (r != RP_OK) return r;
+        plan_from_hints(w, fl);
+        memcpy(w->pinned_flags, fl, sizeof(fl));
+        enqueue_assembly(w); enqueue_loop(w); enqueue_finish(w);
+        w->hints_valid = true;
+        HIPCHK(w, hipGetLastError());
+        return RP_OK;
+    }
+    // lazy hint refresh (values from some already finished step; correctness never depends on them)
+    {
+        int fl[FL_COUNT];
+        memcpy(fl, w->pinned_flags, sizeof(fl));
+        int old_s = w->plan_stages, old_b = w->plan_blocks;
+        plan_from_hints(w, fl);
+        if (w->plan_blocks < old_b && w->plan_blocks * 2 >= old_b) w->plan_blocks = old_b; // hysteresis
+        (void)old_s;
+    }
+    if (w->timers) {
+        // four sub-graphs with events in between (Counters from hipEvents)
+        if (!w->ge_col || w->graph_stages != w->plan_stages || w->graph_blocks != w->plan_blocks) {
+            destroy_graphs(w);
+            int r;
+            if ((r = capture(w, &w->g_col, &w->ge_col, enqueue_collision)) != RP_OK) return r;
+            if ((r = capture(w, &w->g_asm, &w->ge_asm, enqueue_assembly)) != RP_OK) return r;
+            if ((r = capture(w, &w->g_loop, &w->ge_loop, enqueue_loop)) != RP_OK) return r;
+            if ((r = capture(w, &w->g_fin, &w->ge_fin, enqueue_finish)) != RP_OK) return r;
+            w->graph_stages = w->plan_stages; w->graph_blocks = w->plan_blocks;
+        }
+        HIPCHK(w, hipEventRecord(w->ev[0], w->stream));
+        HIPCHK(w, hipGraphLaunch(w->ge_col, w->stream));
+        HIPCHK(w, hipEventRecord(w->ev[1], w->stream));
+        HIPCHK(w, hipGraphLaunch(w->ge_asm, w->stream));
+        HIPCHK(w, hipEventRecord(w->ev[2], w->stream));
+        HIPCHK(w, hipGraphLaunch(w->ge_loop, w->stream));
+        HIPCHK(w, hipEventRecord(w->ev[3], w->stream));
+        HIPCHK(w, hipGraphLaunch(w->ge_fin, w->stream));
+        HIPCHK(w, hipEventRecord(w->ev[4], w->stream));
+        HIPCHK(w, hipEventSynchronize(w->ev[4]));
+        float a = 0, b = 0, c = 0, d = 0;
+        hipEventElapsedTime(&a, w->ev[0], w->ev[1]); hipEventElapsedTime(&b, w->ev[1], w->ev[2]);
+        hipEventElapsedTime(&c, w->ev[2], w->ev[3]); hipEventElapsedTime(&d, w->ev[3], w->ev[4]);
+        w->acc_col_ms += a; w->acc_asm_ms += b; w->acc_loop_ms += c; w->acc_fin_ms += d; w->acc_step_ms += a + b + c + d; w->acc_steps++;
+        w->loop_ms_since_read += c; w->loop_steps_since_read++;
+        return RP_OK;
+    }
+    if (!w->use_graph) { enqueue_whole(w); HIPCHK(w, hipGetLastError()); return RP_OK; }
+    if (!w->graph_exec || w->graph_stages != w->plan_stages || w->graph_blocks != w->plan_blocks) {
+        destroy_graphs(w);
+        int r = capture(w, &w->graph, &w->graph_exec, enqueue_whole);
+        if (r != RP_OK) return r;
+        w->graph_stages = w->plan_stages; w->graph_blocks = w->plan_blocks;
+    }
+    HIPCHK(w, hipGraphLaunch(w->graph_exec, w->stream));
+    return RP_OK;
+}
+
+extern "C" int32_t rp_step(rp_world *w, uint32_t nsteps) {
+    if (!w) return RP_ERR_INVALID;
+    HIPCHK(w, hipSetDevice(w->device));
+    if (!w->finalized) { int r = finalize(w); if (r != RP_OK) return r; }
+    for (uint32_t i = 0; i < nsteps; ++i) { int r = step_once(w); if (r != RP_OK) return r; }
+    return RP_OK;
+}
+extern "C" int32_t rp_sync(rp_world *w) {
+    if (!w) return RP_ERR_INVALID;
+    HIPCHK(w, hipSetDevice(w->device));
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    if (w->finalized) return check_overflow(w, w->pinned_flags);
+    return RP_OK;
+}
+
+extern "C" int32_t rp_bodies_read(rp_world *w, int32_t n, const uint64_t *handles, float *pos7_out, float *vel6_out) {
+    if (!w) return RP_ERR_INVALID;
+    HIPCHK(w, hipSetDevice(w->device));
+    if (!w->finalized) { int r = finalize(w); if (r != RP_OK) return r; }
+    int nb = w->dw.n_bodies;
+    std::vector<float4> pos(nb), rot(nb), lv(nb), av(nb);
+    HIPCHK(w, hipMemcpyAsync(pos.data(), w->dw.b_pos, nb * sizeof(float4), hipMemcpyDeviceToHost, w->stream));
+    HIPCHK(w, hipMemcpyAsync(rot.data(), w->dw.b_rot, nb * sizeof(float4), hipMemcpyDeviceToHost, w->stream));
+    HIPCHK(w, hipMemcpyAsync(lv.data(), w->dw.b_linvel, nb * sizeof(float4), hipMemcpyDeviceToHost, w->stream));
+    HIPCHK(w, hipMemcpyAsync(av.data(), w->dw.b_angvel, nb * sizeof(float4), hipMemcpyDeviceToHost, w->stream));
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    int count = handles ? n : nb;
+    for (int i = 0; i < count; ++i) {
+        int b = handles ? (int)(handles[i] & 0xffffffffull) : i;
+        if (b < 0 || b >= nb) { w->err = "rp_bodies_read: invalid handle"; return RP_ERR_INVALID; }
+        if (pos7_out) { float *p = pos7_out + 7 * i; p[0] = pos[b].x; p[1] = pos[b].y; p[2] = pos[b].z; p[3] = rot[b].x; p[4] = rot[b].y; p[5] = rot[b].z; p[6] = rot[b].w; }
+        if (vel6_out) { float *v = vel6_out + 6 * i; v[0] = lv[b].x; v[1] = lv[b].y; v[2] = lv[b].z; v[3] = av[b].x; v[4] = av[b].y; v[5] = av[b].z; }
+    }
+    return check_overflow(w, w->pinned_flags);
+}
+
+extern "C" int32_t rp_bodies_write(rp_world *w, int32_t n, const uint64_t *handles, const float *pos7, const float *vel6) {
+    if (!w || n < 0 || !handles) return RP_ERR_INVALID;
+    HIPCHK(w, hipSetDevice(w->device));
+    if (!w->finalized) { int r = finalize(w); if (r != RP_OK) return r; }
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    for (int i = 0; i < n; ++i) {
+        int b = (int)(handles[i] & 0xffffffffull);
+        if (b < 0 || b >= w->dw.n_bodies) { w->err = "rp_bodies_write: invalid handle"; return RP_ERR_INVALID; }
+        if (vel6) {
+            float4 l = mk4(vel6[6 * i], vel6[6 * i + 1], vel6[6 * i + 2], 0), a = mk4(vel6[6 * i + 3], vel6[6 * i + 4], vel6[6 * i + 5], 0);
+            HIPCHK(w, hipMemcpy(w->dw.b_linvel + b, &l, sizeof(l), hipMemcpyHostToDevice));
+            HIPCHK(w, hipMemcpy(w->dw.b_angvel + b, &a, sizeof(a), hipMemcpyHostToDevice));
+        }
+        if (pos7) {
+            float4 t = mk4(pos7[7 * i], pos7[7 * i + 1], pos7[7 * i + 2], 0), q = mk4(pos7[7 * i + 3], pos7[7 * i + 4], pos7[7 * i + 5], pos7[7 * i + 6]);
+            HIPCHK(w, hipMemcpy(w->dw.b_pos + b, &t, sizeof(t), hipMemcpyHostToDevice));
+            HIPCHK(w, hipMemcpy(w->dw.b_rot + b, &q, sizeof(q), hipMemcpyHostToDevice));
+        }
+    }
+    if (pos7) { // user_changes.rs: moved bodies refresh world mass properties, collider poses and AABBs
+        rp_launch_init_bodies(w->dw, w->stream);
+        rp_launch_collider_update(w->dw, w->stream);
+    }
+    return RP_OK;
+}
+
+extern "C" int32_t rp_contacts_read(rp_world *w, int32_t cap, int32_t *meta, float *normal3, float *impulse4) {
+    if (!w) return RP_ERR_INVALID;
+    HIPCHK(w, hipSetDevice(w->device));
+    if (!w->finalized) return 0;
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    int fl[FL_COUNT];
+    HIPCHK(w, hipMemcpy(fl, w->dw.flags, sizeof(fl), hipMemcpyDeviceToHost));
+    int top = std::min(fl[FL_POOL_TOP], w->dw.pool_cap);
+    size_t P = (size_t)w->dw.pool_cap;
+    std::vector<int> c1(top), c2(top), col(top), nsc(top);
+    std::vector<float4> nrm(top), imp(RP_MAX_PTS * (size_t)top), a2(4 * (size_t)top);
+    if (top > 0) {
+        HIPCHK(w, hipMemcpy(c1.data(), w->dw.p_c1, top * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(w, hipMemcpy(c2.data(), w->dw.p_c2, top * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(w, hipMemcpy(col.data(), w->dw.p_color, top * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(w, hipMemcpy(nsc.data(), w->dw.p_nsc, top * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(w, hipMemcpy(nrm.data(), w->dw.p_normal, top * sizeof(float4), hipMemcpyDeviceToHost));
+        for (int k = 0; k < RP_MAX_PTS; ++k) HIPCHK(w, hipMemcpy(imp.data() + (size_t)k * top, w->dw.pt_imp + k * P, top * sizeof(float4), hipMemcpyDeviceToHost));
+        for (int k = 0; k < 4; ++k) HIPCHK(w, hipMemcpy(a2.data() + (size_t)k * top, w->dw.sc_a2 + k * P, top * sizeof(float4), hipMemcpyDeviceToHost));
+    }
+    int m = 0;
+    for (int s = 0; s < top; ++s) {
+        if (c1[s] < 0 || nsc[s] == 0) continue;
+        if (m < cap) {
+            if (meta) { meta[4 * m] = c1[s]; meta[4 * m + 1] = c2[s]; meta[4 * m + 2] = col[s]; meta[4 * m + 3] = nsc[s]; }
+            if (normal3) { normal3[3 * m] = nrm[s].x; normal3[3 * m + 1] = nrm[s].y; normal3[3 * m + 2] = nrm[s].z; }
+            if (impulse4) for (int k = 0; k < 4; ++k) {
+                float v = 0.0f;
+                if (k < nsc[s]) { int cid; float f = a2[(size_t)k * top + s].w; memcpy(&cid, &f, 4); v = imp[(size_t)cid * top + s].x; }
+                impulse4[4 * m + k] = v;
+            }
+        }
+        m++;
+    }
+    return m;
+}
+
+extern "C" int32_t rp_counters_enable(rp_world *w, int32_t enable) {
+    if (!w) return RP_ERR_INVALID;
+    HIPCHK(w, hipSetDevice(w->device));
+    if (enable && !w->ev[0]) for (auto &e : w->ev) HIPCHK(w, hipEventCreate(&e));
+    if ((enable != 0) != w->timers) { if (w->stream) hipStreamSynchronize(w->stream); destroy_graphs(w); }
+    w->timers = enable != 0;
+    w->acc_loop_ms = w->acc_col_ms = w->acc_asm_ms = w->acc_fin_ms = w->acc_step_ms = 0.0; w->acc_steps = 0;
+    w->loop_ms_since_read = 0.0; w->loop_steps_since_read = 0;
+    return RP_OK;
+}
+
+extern "C" int32_t rp_counters_read(rp_world *w, rp_counters *out) {
+    if (!w || !out) return RP_ERR_INVALID;
+    memset(out, 0, sizeof(*out));
+    HIPCHK(w, hipSetDevice(w->device));
+    if (!w->finalized) return RP_OK;
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    int fl[FL_COUNT];
+    HIPCHK(w, hipMemcpy(fl, w->dw.flags, sizeof(fl), hipMemcpyDeviceToHost));
+    double n = w->acc_steps > 0 ? (double)w->acc_steps : 1.0;
+    out->step_time_ms = (float)(w->acc_step_ms / n);
+    out->collision_detection_ms = (float)(w->acc_col_ms / n);
+    out->solver_ms = (float)((w->acc_asm_ms + w->acc_loop_ms + w->acc_fin_ms) / n);
+    out->velocity_assembly_ms = (float)(w->acc_asm_ms / n);
+    out->velocity_resolution_ms = (float)(w->acc_loop_ms / n);
+    out->velocity_update_ms = (float)(w->acc_fin_ms / n);
+    int live = 0;
+    {
+        int top = std::min(fl[FL_POOL_TOP], w->dw.pool_cap);
+        live = top - fl[FL_FREE_TOP];
+    }
+    out->num_pairs = live;
+    out->num_manifolds = fl[FL_N_CONS];
+    out->num_solver_contacts = fl[FL_N_SC];
+    out->num_colors = fl[FL_N_COLORS];
+    out->num_parallel_stages = fl[FL_N_PARALLEL];
+    int nd = 0; for (auto &b : w->bodies) nd += b.d.body_type == RP_BODY_DYNAMIC;
+    out->num_dynamic_bodies = nd;
+    out->bp_rebuilds = fl[FL_BP_REBUILDS];
+    out->full_updates = fl[FL_FULL_UPDATES];
+    out->overflow_flags = fl[FL_OVERFLOW];
+    out->quarantined = fl[FL_QUARANTINE];
+    return RP_OK;
+}
+
+extern "C" int32_t rp_solver_loop_time_ms(rp_world *w, float *avg, int32_t *steps) {
+    if (!w) return RP_ERR_INVALID;
+    if (avg) *avg = w->loop_steps_since_read > 0 ? (float)(w->loop_ms_since_read / w->loop_steps_since_read) : 0.0f;
+    if (steps) *steps = w->loop_steps_since_read;
+    w->loop_ms_since_read = 0.0; w->loop_steps_since_read = 0;
+    return RP_OK;
+}

@@ -1,0 +1,316 @@
+// rp_broadphase.hip — broad phase on device.
+//
+// Contract: the pair SET of the reference's fat-AABB BVH
+// (/root/reference/src/geometry/broad_phase_bvh/mod.rs:171-263, update.rs:35-602):
+//   * every collider keeps an AABB fattened by CHANGE_DETECTION_FACTOR (0.04) that is rewritten only
+//     when its tight collision AABB (shape AABB loosened by prediction/2, collider.rs:553-557) leaves it;
+//   * a pair exists exactly while the two fat AABBs intersect and it passes the filters of
+//     update.rs:334-396 (same parent, collision types, interaction groups);
+//   * AddPair creates an empty ContactPair, DeletePair frees its solver colour (pair_management.rs:382).
+// The tree is free to differ: here a hashed uniform grid built by counting sort (HBM-bound integer
+// work, one thread per collider, wave-coalesced SoA loads) plus a brute-force list for colliders
+// spanning more than 3 cells.  Like the reference's change detection the whole rebuild is skipped
+// (every kernel early-exits on FL_BP_DIRTY == 0) while no fat AABB changed.
+#include "rp_world.h"
+
+__device__ __forceinline__ unsigned long long rp_hash64(unsigned long long x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return x;
+}
+__device__ __forceinline__ unsigned long long cell_key(int cx, int cy, int cz) {
+    const int off = 1 << 20;
+    return ((unsigned long long)((cx + off) & 0x1fffff)) | ((unsigned long long)((cy + off) & 0x1fffff) << 21) |
+           ((unsigned long long)((cz + off) & 0x1fffff) << 42);
+}
+__device__ __forceinline__ int cell_coord(float x, float inv_cell) { return (int)floorf(x * inv_cell); }
+
+struct CellRange { int lo[3], hi[3]; bool large; };
+__device__ __forceinline__ CellRange cell_range(const DevWorld &w, int i) {
+    float4 mn = w.c_fatmin[i], mx = w.c_fatmax[i];
+    CellRange r;
+    float ic = w.prm.inv_cell_size;
+    r.lo[0] = cell_coord(mn.x, ic); r.lo[1] = cell_coord(mn.y, ic); r.lo[2] = cell_coord(mn.z, ic);
+    r.hi[0] = cell_coord(mx.x, ic); r.hi[1] = cell_coord(mx.y, ic); r.hi[2] = cell_coord(mx.z, ic);
+    r.large = (r.hi[0] - r.lo[0] > 2) || (r.hi[1] - r.lo[1] > 2) || (r.hi[2] - r.lo[2] > 2);
+    return r;
+}
+
+// Collider world pose + fat AABB maintenance (BroadPhaseBvh::set_aabb; advance_to_final_positions
+// substep.rs:103-119).  One thread per collider.
+__global__ void k_collider_update(DevWorld w) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= w.n_colliders) return;
+    int parent = w.c_parent[i];
+    Pose lp; lp.r = q4(w.c_lrot[i]); lp.t = v3(w.c_lpos[i]);
+    Pose pos = lp;
+    if (parent >= 0) { Pose bp; bp.r = q4(w.b_rot[parent]); bp.t = v3(w.b_pos[parent]); pos = pose_mul(bp, lp); }
+    bool finite = isfinite(pos.t.x) && isfinite(pos.t.y) && isfinite(pos.t.z) && isfinite(pos.r.x) && isfinite(pos.r.y) &&
+                  isfinite(pos.r.z) && isfinite(pos.r.w);
+    if (!finite) { atomicAdd(&w.flags[FL_QUARANTINE], 1); return; }
+    w.c_pos[i] = f4(pos.t, 0.0f);
+    w.c_rot[i] = f4(pos.r);
+    float4 he = w.c_he[i];
+    V3 h;
+    if (w.c_shape[i] == RP_SHAPE_CUBOID) {
+        float m[3][3]; quat_to_mat(pos.r, m);
+        h = v3(fabsf(m[0][0]) * he.x + fabsf(m[0][1]) * he.y + fabsf(m[0][2]) * he.z,
+               fabsf(m[1][0]) * he.x + fabsf(m[1][1]) * he.y + fabsf(m[1][2]) * he.z,
+               fabsf(m[2][0]) * he.x + fabsf(m[2][1]) * he.y + fabsf(m[2][2]) * he.z);
+    } else {
+        h = v3(he.x, he.x, he.x);
+    }
+    float loosen = w.prm.prediction / 2.0f;
+    V3 mn = pos.t - h - v3(loosen, loosen, loosen);
+    V3 mx = pos.t + h + v3(loosen, loosen, loosen);
+    float4 fmn = w.c_fatmin[i], fmx = w.c_fatmax[i];
+    bool inside = fmn.x <= mn.x && fmn.y <= mn.y && fmn.z <= mn.z && fmx.x >= mx.x && fmx.y >= mx.y && fmx.z >= mx.z;
+    if (!inside) {
+        float s = w.prm.bp_skin;
+        w.c_fatmin[i] = f4(mn - v3(s, s, s), 0.0f);
+        w.c_fatmax[i] = f4(mx + v3(s, s, s), 0.0f);
+        w.flags[FL_BP_DIRTY] = 1;
+    }
+}
+
+__global__ void k_bp_clear(DevWorld w) {
+    if (!w.flags[FL_BP_DIRTY]) return;
+    int nxt = (w.flags[FL_BP_EPOCH] & 1) ^ 1;
+    int stride = gridDim.x * blockDim.x;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < w.grid_cap; i += stride) { w.cell_count[i] = 0; w.cell_fill[i] = 0; }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < w.hash_cap; i += stride) w.h_key[nxt][i] = RP_EMPTY_KEY;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { w.flags[FL_N_LARGE] = 0; w.flags[FL_N_ENTRIES] = 0; }
+}
+
+__global__ void k_bp_count(DevWorld w) {
+    if (!w.flags[FL_BP_DIRTY]) return;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= w.n_colliders) return;
+    CellRange r = cell_range(w, i);
+    if (r.large) {
+        int k = atomicAdd(&w.flags[FL_N_LARGE], 1);
+        if (k < w.large_cap) w.large_list[k] = i; else atomicOr(&w.flags[FL_OVERFLOW], RP_OVF_LARGE);
+        return;
+    }
+    for (int z = r.lo[2]; z <= r.hi[2]; ++z)
+        for (int y = r.lo[1]; y <= r.hi[1]; ++y)
+            for (int x = r.lo[0]; x <= r.hi[0]; ++x) {
+                unsigned long long key = cell_key(x, y, z);
+                int h = (int)(rp_hash64(key) & (unsigned long long)(w.grid_cap - 1));
+                atomicAdd(&w.cell_count[h], 1);
+            }
+}
+
+// ---- exclusive scan of cell_count -> cell_start (three small launches, 1024 items per block) ----
+__global__ void k_scan_blocks(DevWorld w) {
+    if (!w.flags[FL_BP_DIRTY]) return;
+    __shared__ int s[1024];
+    int gid = blockIdx.x * 1024 + threadIdx.x;
+    int v = gid < w.grid_cap ? w.cell_count[gid] : 0;
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int t = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+        __syncthreads();
+        s[threadIdx.x] += t;
+        __syncthreads();
+    }
+    if (gid < w.grid_cap) w.cell_start[gid] = s[threadIdx.x] - v;
+    if (threadIdx.x == 1023) w.scan_block[blockIdx.x] = s[1023];
+}
+__global__ void k_scan_sums(DevWorld w, int nblocks) {
+    if (!w.flags[FL_BP_DIRTY]) return;
+    __shared__ int s[1024];
+    int v = threadIdx.x < nblocks ? w.scan_block[threadIdx.x] : 0;
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int t = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+        __syncthreads();
+        s[threadIdx.x] += t;
+        __syncthreads();
+    }
+    if (threadIdx.x < nblocks) w.scan_block[threadIdx.x] = s[threadIdx.x] - v;
+    if (threadIdx.x == 1023) {
+        w.flags[FL_N_ENTRIES] = s[1023];
+        if (s[1023] > w.entries_cap) atomicOr(&w.flags[FL_OVERFLOW], RP_OVF_CELLS);
+    }
+}
+__global__ void k_scan_add(DevWorld w) {
+    if (!w.flags[FL_BP_DIRTY]) return;
+    int gid = blockIdx.x * 1024 + threadIdx.x;
+    if (gid < w.grid_cap) w.cell_start[gid] += w.scan_block[blockIdx.x];
+}
+
+__global__ void k_bp_fill(DevWorld w) {
+    if (!w.flags[FL_BP_DIRTY]) return;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= w.n_colliders) return;
+    CellRange r = cell_range(w, i);
+    if (r.large) return;
+    for (int z = r.lo[2]; z <= r.hi[2]; ++z)
+        for (int y = r.lo[1]; y <= r.hi[1]; ++y)
+            for (int x = r.lo[0]; x <= r.hi[0]; ++x) {
+                unsigned long long key = cell_key(x, y, z);
+                int h = (int)(rp_hash64(key) & (unsigned long long)(w.grid_cap - 1));
+                int pos = w.cell_start[h] + atomicAdd(&w.cell_fill[h], 1);
+                if (pos < w.entries_cap) { w.e_key[pos] = key; w.e_col[pos] = i; }
+            }
+}
+
+__device__ __forceinline__ bool fat_overlap(const DevWorld &w, int a, int b, V3 &imin) {
+    float4 amn = w.c_fatmin[a], amx = w.c_fatmax[a], bmn = w.c_fatmin[b], bmx = w.c_fatmax[b];
+    bool ov = amn.x <= bmx.x && bmn.x <= amx.x && amn.y <= bmx.y && bmn.y <= amx.y && amn.z <= bmx.z && bmn.z <= amx.z;
+    imin = v3(fmaxf(amn.x, bmn.x), fmaxf(amn.y, bmn.y), fmaxf(amn.z, bmn.z));
+    return ov;
+}
+// update.rs:334-396: same parent / ActiveCollisionTypes::default() / InteractionGroups::test
+__device__ __forceinline__ bool pair_allowed(const DevWorld &w, int a, int b) {
+    int pa = w.c_parent[a], pb = w.c_parent[b];
+    if (pa >= 0 && pa == pb) return false;
+    bool da = pa >= 0 && (w.b_flags[pa] & RP_BF_TYPE_MASK) == RP_BODY_DYNAMIC;
+    bool db = pb >= 0 && (w.b_flags[pb] & RP_BF_TYPE_MASK) == RP_BODY_DYNAMIC;
+    if (!da && !db) return false;
+    uint2 ga = w.c_groups[a], gb = w.c_groups[b];
+    return (ga.x & gb.y) != 0 && (gb.x & ga.y) != 0;
+}
+
+__device__ __forceinline__ int hash_find(const unsigned long long *keys, const int *slots, int cap, unsigned long long key) {
+    int h = (int)(rp_hash64(key) & (unsigned long long)(cap - 1));
+    for (int probe = 0; probe < cap; ++probe) {
+        unsigned long long k = keys[h];
+        if (k == key) return slots[h];
+        if (k == RP_EMPTY_KEY) return -1;
+        h = (h + 1) & (cap - 1);
+    }
+    return -1;
+}
+
+// AddPair (NarrowPhase::add_pair, pair_management.rs:572): find-or-create the pair slot and
+// register it in the next-epoch table.  Each unordered pair reaches this exactly once per rebuild.
+__device__ void bp_insert_pair(DevWorld &w, int c1, int c2) {
+    int epoch = w.flags[FL_BP_EPOCH];
+    int cur = epoch & 1, nxt = cur ^ 1;
+    unsigned long long key = ((unsigned long long)(unsigned)c1 << 32) | (unsigned)c2;
+    int slot = hash_find(w.h_key[cur], w.h_slot[cur], w.hash_cap, key);
+    if (slot < 0) {
+        int t = atomicSub(&w.flags[FL_FREE_TOP], 1);
+        if (t > 0) slot = w.free_stack[t - 1];
+        else { atomicAdd(&w.flags[FL_FREE_TOP], 1); slot = atomicAdd(&w.flags[FL_POOL_TOP], 1); }
+        if (slot >= w.pool_cap) { atomicOr(&w.flags[FL_OVERFLOW], RP_OVF_POOL); return; }
+        w.p_c1[slot] = c1; w.p_c2[slot] = c2;
+        w.p_color[slot] = RP_COLOR_UNCOLORED; w.p_nsc[slot] = 0; w.p_npts[slot] = 0; w.p_pflags[slot] = 0;
+        w.p_reldom[slot] = 0; w.p_colorb[slot] = make_int2(-1, -1); w.p_conspos[slot] = -1;
+    }
+    w.p_stamp[slot] = epoch + 1;
+    int h = (int)(rp_hash64(key) & (unsigned long long)(w.hash_cap - 1));
+    for (int probe = 0; probe < w.hash_cap; ++probe) {
+        unsigned long long prev = atomicCAS(&w.h_key[nxt][h], RP_EMPTY_KEY, key);
+        if (prev == RP_EMPTY_KEY) { w.h_slot[nxt][h] = slot; return; }
+        h = (h + 1) & (w.hash_cap - 1);
+    }
+    atomicOr(&w.flags[FL_OVERFLOW], RP_OVF_HASH);
+}
+
+__global__ void k_bp_pairs(DevWorld w) {
+    if (!w.flags[FL_BP_DIRTY]) return;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= w.n_colliders) return;
+    CellRange r = cell_range(w, i);
+    if (r.large) return;
+    float ic = w.prm.inv_cell_size;
+    for (int z = r.lo[2]; z <= r.hi[2]; ++z)
+        for (int y = r.lo[1]; y <= r.hi[1]; ++y)
+            for (int x = r.lo[0]; x <= r.hi[0]; ++x) {
+                unsigned long long key = cell_key(x, y, z);
+                int h = (int)(rp_hash64(key) & (unsigned long long)(w.grid_cap - 1));
+                int beg = w.cell_start[h], end = beg + w.cell_count[h];
+                if (end > w.entries_cap) end = w.entries_cap;
+                for (int e = beg; e < end; ++e) {
+                    if (w.e_key[e] != key) continue;
+                    int j = w.e_col[e];
+                    if (j <= i) continue;
+                    V3 imin;
+                    if (!fat_overlap(w, i, j, imin)) continue;
+                    // report only in the cell that holds the min corner of the intersection
+                    if (cell_coord(imin.x, ic) != x || cell_coord(imin.y, ic) != y || cell_coord(imin.z, ic) != z) continue;
+                    if (!pair_allowed(w, i, j)) continue;
+                    bp_insert_pair(w, i, j);
+                }
+            }
+}
+
+// Colliders spanning > 3 cells (ground slabs, walls) against everything: one thread per collider,
+// looping over the (short) large list.
+__global__ void k_bp_pairs_large(DevWorld w) {
+    if (!w.flags[FL_BP_DIRTY]) return;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= w.n_colliders) return;
+    int nl = w.flags[FL_N_LARGE];
+    if (nl > w.large_cap) nl = w.large_cap;
+    if (nl == 0) return;
+    bool i_large = cell_range(w, i).large;
+    for (int k = 0; k < nl; ++k) {
+        int L = w.large_list[k];
+        if (L == i) continue;
+        if (i_large && i > L) continue; // large-large pairs reported from the lower index
+        V3 imin;
+        if (!fat_overlap(w, i, L, imin)) continue;
+        if (!pair_allowed(w, i, L)) continue;
+        bp_insert_pair(w, i < L ? i : L, i < L ? L : i);
+    }
+}
+
+// DeletePair: slots not re-stamped by this rebuild are dead (NarrowPhase::remove_pair,
+// pair_management.rs:382): free the colour, drop from the solver graph, recycle the slot.
+__global__ void k_bp_finish_pairs(DevWorld w) {
+    if (!w.flags[FL_BP_DIRTY]) return;
+    int epoch = w.flags[FL_BP_EPOCH];
+    int top = w.flags[FL_POOL_TOP];
+    if (top > w.pool_cap) top = w.pool_cap;
+    int stride = gridDim.x * blockDim.x;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < top; s += stride) {
+        if (w.p_c1[s] < 0) continue;
+        if (w.p_stamp[s] == epoch + 1) continue;
+        int color = w.p_color[s];
+        if (color < RP_COLOR_OVERFLOW) {
+            int2 cb = w.p_colorb[s];
+            unsigned bit = 1u << (color & 31);
+            if (cb.x >= 0) atomicAnd(&w.b_cmask[4 * cb.x + (color >> 5)], ~bit);
+            if (cb.y >= 0) atomicAnd(&w.b_cmask[4 * cb.y + (color >> 5)], ~bit);
+        }
+        if (w.p_nsc[s] > 0) w.flags[FL_LAYOUT_DIRTY] = 1;
+        w.p_c1[s] = -1; w.p_nsc[s] = 0; w.p_npts[s] = 0; w.p_color[s] = RP_COLOR_UNCOLORED;
+        int t = atomicAdd(&w.flags[FL_FREE_TOP], 1);
+        w.free_stack[t] = s;
+    }
+}
+__global__ void k_bp_finish(DevWorld w) {
+    if (!w.flags[FL_BP_DIRTY]) return;
+    w.flags[FL_BP_EPOCH] += 1;
+    w.flags[FL_BP_DIRTY] = 0;
+    w.flags[FL_BP_REBUILDS] += 1;
+}
+
+void rp_launch_collider_update(const DevWorld &w, hipStream_t st) {
+    if (w.n_colliders == 0) return;
+    hipLaunchKernelGGL(k_collider_update, dim3((w.n_colliders + 255) / 256), dim3(256), 0, st, w);
+}
+
+void rp_launch_broadphase(const DevWorld &w, hipStream_t st) {
+    if (w.n_colliders == 0) return;
+    int nb = (w.n_colliders + 255) / 256;
+    int clear_n = w.grid_cap > w.hash_cap ? w.grid_cap : w.hash_cap;
+    int clear_blocks = (clear_n + 255) / 256; if (clear_blocks > 2048) clear_blocks = 2048;
+    int scan_blocks = (w.grid_cap + 1023) / 1024;
+    hipLaunchKernelGGL(k_bp_clear, dim3(clear_blocks), dim3(256), 0, st, w);
+    hipLaunchKernelGGL(k_bp_count, dim3(nb), dim3(256), 0, st, w);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(scan_blocks), dim3(1024), 0, st, w);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, w, scan_blocks);
+    hipLaunchKernelGGL(k_scan_add, dim3(scan_blocks), dim3(1024), 0, st, w);
+    hipLaunchKernelGGL(k_bp_fill, dim3(nb), dim3(256), 0, st, w);
+    hipLaunchKernelGGL(k_bp_pairs, dim3(nb), dim3(256), 0, st, w);
+    hipLaunchKernelGGL(k_bp_pairs_large, dim3(nb), dim3(256), 0, st, w);
+    int fin_blocks = (w.pool_cap + 255) / 256; if (fin_blocks > 1024) fin_blocks = 1024;
+    hipLaunchKernelGGL(k_bp_finish_pairs, dim3(fin_blocks), dim3(256), 0, st, w);
+    hipLaunchKernelGGL(k_bp_finish, dim3(1), dim3(1), 0, st, w);
+}

@@ -1,0 +1,636 @@
+// rp_narrowphase.hip — contact manifold generation and pair bookkeeping on device.
+//
+// One thread per live contact pair (NarrowPhase::compute_contacts, contacts.rs:22-251 dispatches
+// pair_update::process_pair per edge; here the "rayon broadcast + atomic cursor" becomes a grid).
+// Per pair (pair_update.rs:67-680): recycle test -> [full update: parry contact_manifolds ->
+// combine friction/restitution -> 4-point reduction -> plane sort -> solver contacts -> anchor
+// localisation / lever-arm freezing -> recycle state] -> begin/end-touch transition.
+// The parry3d pieces (cuboid SAT + face clipping, ball cases, try_update_contacts, match_contacts)
+// are not in /root/reference; they are implemented from the crate's published algorithm.
+//
+// Then (contacts.rs:300-385, narrow_phase/mod.rs:90-172) begin-touch pairs get a persistent colour by
+// first-fit over per-body 128-bit masks in (min body, max body) order.  The serial greedy loop is
+// reproduced exactly by a dependency-round scheme inside ONE workgroup (k_color_pairs): a pair is
+// coloured in the round where it is the smallest uncoloured key at both of its dynamic bodies, so
+// it sees precisely the masks the serial order would have produced.
+#include "rp_world.h"
+#include <float.h>
+
+#define PT(plane, k, s) plane[(size_t)(k) * w.pool_cap + (s)]
+
+struct LocalManifold {
+    V3 lp1[RP_MAX_PTS], lp2[RP_MAX_PTS];
+    float dist[RP_MAX_PTS];
+    unsigned fid[RP_MAX_PTS]; // fid1 | fid2 << 16
+    int src[RP_MAX_PTS];      // old point index whose ContactData this point inherits (-1 = fresh)
+    int n;
+    V3 ln1, ln2;
+};
+
+struct Face { V3 v[4]; unsigned vid[4], eid[4], fid; };
+
+RP_DEV V3 cuboid_support_point(V3 he, V3 d) { return v3(copysignf(he.x, d.x), copysignf(he.y, d.y), copysignf(he.z, d.z)); }
+RP_DEV unsigned cuboid_vid(V3 v) { return (unsigned)((v.x < 0.0f) | ((v.y < 0.0f) << 1) | ((v.z < 0.0f) << 2)); }
+
+__device__ Face cuboid_support_face(V3 he, V3 dir) {
+    Face f;
+    float ax = fabsf(dir.x), ay = fabsf(dir.y), az = fabsf(dir.z);
+    int iamax = 0; float best = ax;
+    if (ay > best) { best = ay; iamax = 1; }
+    if (az > best) { best = az; iamax = 2; }
+    float sign = copysignf(1.0f, comp(dir, iamax));
+    if (iamax == 0) {
+        f.v[0] = v3(he.x * sign, he.y, he.z); f.v[1] = v3(he.x * sign, -he.y, he.z);
+        f.v[2] = v3(he.x * sign, -he.y, -he.z); f.v[3] = v3(he.x * sign, he.y, -he.z);
+    } else if (iamax == 1) {
+        f.v[0] = v3(he.x, he.y * sign, he.z); f.v[1] = v3(-he.x, he.y * sign, he.z);
+        f.v[2] = v3(-he.x, he.y * sign, -he.z); f.v[3] = v3(he.x, he.y * sign, -he.z);
+    } else {
+        f.v[0] = v3(he.x, he.y, he.z * sign); f.v[1] = v3(he.x, -he.y, he.z * sign);
+        f.v[2] = v3(-he.x, -he.y, he.z * sign); f.v[3] = v3(-he.x, he.y, he.z * sign);
+    }
+    for (int i = 0; i < 4; ++i) f.vid[i] = cuboid_vid(f.v[i]);
+    for (int i = 0; i < 4; ++i) {
+        unsigned a = f.vid[i], b = f.vid[(i + 1) & 3];
+        unsigned lo = a < b ? a : b, hi = a < b ? b : a;
+        f.eid[i] = 8u + 8u * lo + hi;
+    }
+    f.fid = 100u + 2u * (unsigned)iamax + (sign < 0.0f ? 1u : 0u);
+    return f;
+}
+
+__device__ float sat_normal_oneway(V3 he1, V3 he2, Pose pos12, V3 &out_dir) {
+    float best = -FLT_MAX; V3 best_dir = v3(0, 0, 0);
+    for (int i = 0; i < 3; ++i) {
+        float sign = copysignf(1.0f, comp(pos12.t, i));
+        V3 axis1 = v3(i == 0 ? sign : 0.0f, i == 1 ? sign : 0.0f, i == 2 ? sign : 0.0f);
+        V3 axis2 = qrot_inv(pos12.r, -axis1);
+        V3 pt2 = pose_tp(pos12, cuboid_support_point(he2, axis2));
+        float sep = comp(pt2, i) * sign - comp(he1, i);
+        if (sep > best) { best = sep; best_dir = axis1; }
+    }
+    out_dir = best_dir;
+    return best;
+}
+__device__ float sat_edge_twoway(V3 he1, V3 he2, Pose pos12, V3 &out_dir) {
+    float best = -FLT_MAX; V3 best_dir = v3(0, 0, 0);
+    V3 c[3] = {qrot(pos12.r, v3(1, 0, 0)), qrot(pos12.r, v3(0, 1, 0)), qrot(pos12.r, v3(0, 0, 1))};
+    for (int k = 0; k < 9; ++k) {
+        V3 e = c[k / 3];
+        int a = k % 3;
+        V3 axis = a == 0 ? v3(0, -e.z, e.y) : (a == 1 ? v3(e.z, 0, -e.x) : v3(-e.y, e.x, 0));
+        float n = len(axis);
+        if (n > FLT_EPSILON) {
+            V3 axis1 = axis * (1.0f / n);
+            float signum = copysignf(1.0f, dot(pos12.t, axis1));
+            axis1 = axis1 * signum;
+            V3 axis2 = qrot_inv(pos12.r, -axis1);
+            V3 lp1 = cuboid_support_point(he1, axis1);
+            V3 pt2 = pose_tp(pos12, cuboid_support_point(he2, axis2));
+            float sep = dot(pt2 - lp1, axis1);
+            if (sep > best) { best = sep; best_dir = axis1; }
+        }
+    }
+    out_dir = best_dir;
+    return best;
+}
+
+RP_DEV bool ulps_eq(float a, float b) {
+    if (fabsf(a - b) <= FLT_EPSILON) return true;
+    if ((a < 0) != (b < 0)) return false;
+    int ia = __float_as_int(a), ib = __float_as_int(b);
+    int d = ia > ib ? ia - ib : ib - ia;
+    return d <= 4;
+}
+__device__ bool closest_points_line2d(float a0x, float a0y, float a1x, float a1y, float b0x, float b0y, float b1x, float b1y,
+                                      float &s_out, float &t_out) {
+    float d1x = a1x - a0x, d1y = a1y - a0y, d2x = b1x - b0x, d2y = b1y - b0y;
+    float rx = a0x - b0x, ry = a0y - b0y;
+    float a = d1x * d1x + d1y * d1y, e = d2x * d2x + d2y * d2y, f = d2x * rx + d2y * ry;
+    const float eps = FLT_EPSILON;
+    if (a <= eps && e <= eps) { s_out = 0; t_out = 0; return true; }
+    if (a <= eps) { s_out = 0; t_out = f / e; return true; }
+    float c = d1x * rx + d1y * ry;
+    if (e <= eps) { s_out = -c / a; t_out = 0; return true; }
+    float b = d1x * d2x + d1y * d2y;
+    float ae = a * e, bb = b * b, denom = ae - bb;
+    bool parallel = denom <= eps || ulps_eq(ae, bb);
+    if (parallel) return false;
+    float s = (b * f - c * e) / denom;
+    s_out = s; t_out = (b * s + f) / e;
+    return true;
+}
+
+RP_DEV void lm_push(LocalManifold &m, V3 p1, V3 p2, unsigned f1, unsigned f2, float dist) {
+    if (m.n >= RP_MAX_PTS) return;
+    int i = m.n++;
+    m.lp1[i] = p1; m.lp2[i] = p2; m.dist[i] = dist; m.fid[i] = f1 | (f2 << 16); m.src[i] = -1;
+}
+
+#define PERP(ax, ay, bx, by) ((ax) * (by) - (ay) * (bx))
+__device__ void contacts_face_face(Pose pos12, const Face &f1, V3 sep, const Face &f2, LocalManifold &m) {
+    V3 b0, b1; orthonormal_basis(sep, b0, b1);
+    float p1x[4], p1y[4], p2x[4], p2y[4];
+    for (int i = 0; i < 4; ++i) { p1x[i] = dot(f1.v[i], b0); p1y[i] = dot(f1.v[i], b1); p2x[i] = dot(f2.v[i], b0); p2y[i] = dot(f2.v[i], b1); }
+    {
+        V3 normal2_1 = cross(f2.v[2] - f2.v[1], f2.v[0] - f2.v[1]);
+        float denom = dot(normal2_1, sep);
+        if (!(fabsf(denom) <= FLT_EPSILON)) {
+            for (int i = 0; i < 4; ++i) {
+                float px = p1x[i], py = p1y[i];
+                float sign = PERP(p2x[0] - p2x[3], p2y[0] - p2y[3], px - p2x[3], py - p2y[3]);
+                bool outside = false;
+                for (int j = 0; j < 3; ++j) {
+                    float ns = PERP(p2x[j + 1] - p2x[j], p2y[j + 1] - p2y[j], px - p2x[j], py - p2y[j]);
+                    if (sign == 0.0f) sign = ns; else if (sign * ns < 0.0f) { outside = true; break; }
+                }
+                if (outside) continue;
+                float dist = dot(f2.v[0] - f1.v[i], normal2_1) / denom;
+                V3 lp2_1 = f1.v[i] + sep * dist;
+                lm_push(m, f1.v[i], pose_itp(pos12, lp2_1), f1.vid[i], f2.fid, dist);
+            }
+        }
+    }
+    {
+        V3 normal1 = cross(f1.v[2] - f1.v[1], f1.v[0] - f1.v[1]);
+        float denom = -dot(normal1, sep);
+        if (!(fabsf(denom) <= FLT_EPSILON)) {
+            for (int i = 0; i < 4; ++i) {
+                float px = p2x[i], py = p2y[i];
+                float sign = PERP(p1x[0] - p1x[3], p1y[0] - p1y[3], px - p1x[3], py - p1y[3]);
+                bool outside = false;
+                for (int j = 0; j < 3; ++j) {
+                    float ns = PERP(p1x[j + 1] - p1x[j], p1y[j + 1] - p1y[j], px - p1x[j], py - p1y[j]);
+                    if (sign == 0.0f) sign = ns; else if (sign * ns < 0.0f) { outside = true; break; }
+                }
+                if (outside) continue;
+                float dist = dot(f1.v[0] - f2.v[i], normal1) / denom;
+                V3 lp1 = f2.v[i] - sep * dist;
+                lm_push(m, lp1, pose_itp(pos12, f2.v[i]), f1.fid, f2.vid[i], dist);
+            }
+        }
+    }
+    for (int j = 0; j < 4; ++j) {
+        int j1 = (j + 1) & 3;
+        for (int i = 0; i < 4; ++i) {
+            int i1 = (i + 1) & 3;
+            float s, t;
+            if (closest_points_line2d(p1x[i], p1y[i], p1x[i1], p1y[i1], p2x[j], p2y[j], p2x[j1], p2y[j1], s, t)) {
+                if (s > 0.0f && s < 1.0f && t > 0.0f && t < 1.0f) {
+                    V3 lp1 = f1.v[i] * (1.0f - s) + f1.v[i1] * s;
+                    V3 lp2_1 = f2.v[j] * (1.0f - t) + f2.v[j1] * t;
+                    float dist = dot(lp2_1 - lp1, sep);
+                    lm_push(m, lp1, pose_itp(pos12, lp2_1), f1.eid[i], f2.eid[j], dist);
+                }
+            }
+        }
+    }
+}
+#undef PERP
+
+// ContactManifold::try_update_contacts (cos 1 degree, 1e-6 squared distance)
+__device__ bool try_update_contacts(LocalManifold &m, Pose pos12) {
+    if (m.n == 0) return false;
+    V3 ln2 = qrot(pos12.r, m.ln2);
+    if (-dot(m.ln1, ln2) < 0.99984769515f) return false;
+    V3 nlp1[RP_MAX_PTS]; float nd[RP_MAX_PTS];
+    for (int i = 0; i < m.n; ++i) {
+        V3 lp2 = pose_tp(pos12, m.lp2[i]);
+        float dist = dot(lp2 - m.lp1[i], m.ln1);
+        if (dist * m.dist[i] < 0.0f) return false;
+        V3 np1 = lp2 - m.ln1 * dist;
+        if (len2(m.lp1[i] - np1) > 1.0e-6f) return false;
+        nlp1[i] = np1; nd[i] = dist;
+    }
+    for (int i = 0; i < m.n; ++i) { m.lp1[i] = nlp1[i]; m.dist[i] = nd[i]; }
+    return true;
+}
+
+__device__ void manifold_cuboid_cuboid(Pose pos12, V3 he1, V3 he2, float prediction, LocalManifold &m) {
+    if (try_update_contacts(m, pos12)) return;
+    Pose pos21 = pose_inv(pos12);
+    V3 d1, d2, d3;
+    float s1 = sat_normal_oneway(he1, he2, pos12, d1);
+    if (s1 > prediction) { m.n = 0; return; }
+    float s2 = sat_normal_oneway(he2, he1, pos21, d2);
+    if (s2 > prediction) { m.n = 0; return; }
+    float s3 = sat_edge_twoway(he1, he2, pos12, d3);
+    if (s3 > prediction) { m.n = 0; return; }
+    V3 best = d1;
+    if (s2 > s1 && s2 > s3) best = qrot(pos12.r, -d2);
+    else if (s3 > s1) best = d3;
+    V3 ln2 = qrot(pos21.r, -best);
+    Face f1 = cuboid_support_face(he1, best);
+    Face f2 = cuboid_support_face(he2, ln2);
+    for (int i = 0; i < 4; ++i) f2.v[i] = pose_tp(pos12, f2.v[i]);
+    unsigned oldfid[RP_MAX_PTS]; int nold = m.n;
+    for (int i = 0; i < nold; ++i) oldfid[i] = m.fid[i];
+    m.n = 0;
+    contacts_face_face(pos12, f1, best, f2, m);
+    m.ln1 = best; m.ln2 = ln2;
+    // match_contacts: inherit tracked data by (fid1, fid2); the LAST matching old point wins
+    for (int i = 0; i < m.n; ++i)
+        for (int j = 0; j < nold; ++j)
+            if (m.fid[i] == oldfid[j]) m.src[i] = j;
+}
+
+__device__ void manifold_ball_ball(Pose pos12, float r1, float r2, float prediction, LocalManifold &m) {
+    float l = len(pos12.t);
+    float dist = l - r1 - r2;
+    if (dist < prediction) {
+        V3 n1 = l > 0.0f ? pos12.t * (1.0f / l) : v3(0, 1, 0);
+        V3 n2 = qrot_inv(pos12.r, -n1);
+        int keep = m.n != 0 ? 0 : -1;
+        m.n = 1; m.lp1[0] = n1 * r1; m.lp2[0] = n2 * r2; m.dist[0] = dist; m.fid[0] = 0; m.src[0] = keep;
+        m.ln1 = n1; m.ln2 = n2;
+    } else m.n = 0;
+}
+// contact_manifold_convex_ball with shape1 = cuboid (solid projection); flipped = ball is collider 1
+__device__ void manifold_cuboid_ball(Pose pos12, V3 he1, float r2, float prediction, LocalManifold &m, bool flipped) {
+    V3 pt = pos12.t;
+    V3 shift = v3(rp_max(-he1.x - pt.x, 0.0f) - rp_max(pt.x - he1.x, 0.0f), rp_max(-he1.y - pt.y, 0.0f) - rp_max(pt.y - he1.y, 0.0f),
+                  rp_max(-he1.z - pt.z, 0.0f) - rp_max(pt.z - he1.z, 0.0f));
+    bool inside = shift.x == 0.0f && shift.y == 0.0f && shift.z == 0.0f;
+    V3 proj = inside ? pt : pt + shift;
+    V3 dpos = pt - proj;
+    float dist = len(dpos);
+    if (!(dist > 0.0f)) return;
+    V3 n1 = dpos * (1.0f / dist);
+    if (dist <= r2 + prediction) {
+        V3 n2 = qrot_inv(pos12.r, -n1);
+        V3 p2 = n2 * r2;
+        int keep = m.n == 1 ? 0 : -1;
+        m.n = 1;
+        m.lp1[0] = flipped ? p2 : proj; m.lp2[0] = flipped ? proj : p2; m.dist[0] = dist - r2;
+        if (keep < 0) m.fid[0] = RP_FID_UNKNOWN | (RP_FID_UNKNOWN << 16);
+        m.src[0] = keep;
+        if (flipped) { m.ln1 = n2; m.ln2 = n1; } else { m.ln1 = n1; m.ln2 = n2; }
+    } else m.n = 0;
+}
+
+// manifold_reduction::reduce_manifold_naive — geometry/manifold_reduction.rs:4-84
+__device__ void reduce_manifold(const LocalManifold &m, int sel[4], int &nsel, float prediction) {
+    if (m.n <= 4) return;
+    sel[0] = sel[1] = sel[2] = sel[3] = -1;
+    float deepest = FLT_MAX;
+    for (int i = 0; i < m.n; ++i) if (m.dist[i] < deepest) { deepest = m.dist[i]; sel[0] = i; }
+    if (sel[0] < 0) { nsel = 0; return; }
+    V3 a = m.lp1[sel[0]];
+    float furthest = -FLT_MAX;
+    for (int i = 0; i < m.n; ++i) {
+        float d = len2(m.lp1[i] - a);
+        if (i != sel[0] && m.dist[i] <= prediction && d > furthest) { furthest = d; sel[1] = i; }
+    }
+    if (sel[1] < 0) { nsel = 1; return; }
+    V3 b = m.lp1[sel[1]];
+    if (a.x == b.x && a.y == b.y && a.z == b.z) { nsel = 1; return; }
+    V3 tangent = cross(b - a, m.ln1);
+    float mind = FLT_MAX, maxd = -FLT_MAX;
+    for (int i = 0; i < m.n; ++i) {
+        if (i == sel[0] || i == sel[1] || m.dist[i] > prediction) continue;
+        float d = dot(m.lp1[i] - a, tangent);
+        if (d < mind) { mind = d; sel[2] = i; }
+        if (d > maxd) { maxd = d; sel[3] = i; }
+    }
+    if (sel[2] < 0) nsel = 2; else if (sel[2] == sel[3]) nsel = 3; else nsel = 4;
+}
+
+RP_DEV float combine_coeff(float a, float b, int ra, int rb) {
+    int rule = ra > rb ? ra : rb; // coefficient_combine_rule.rs:58-86
+    switch (rule) {
+    case RP_RULE_AVERAGE: return (a + b) / 2.0f;
+    case RP_RULE_MIN: return fabsf(a < b ? a : b);
+    case RP_RULE_MULTIPLY: return a * b;
+    case RP_RULE_MAX: return a > b ? a : b;
+    case RP_RULE_CLAMPED_SUM: return rp_clamp(a + b, 0.0f, 1.0f);
+    default: return sqrtf(rp_max(a, 0.0f) * rp_max(b, 0.0f));
+    }
+}
+RP_DEV int effective_dominance(const DevWorld &w, int body) {
+    if (body >= 0) { int f = w.b_flags[body]; if ((f & RP_BF_TYPE_MASK) == RP_BODY_DYNAMIC) return (int)(signed char)((f >> RP_BF_DOM_SHIFT) & 0xff); }
+    return 128;
+}
+RP_DEV bool body_dynamic(const DevWorld &w, int body) { return body >= 0 && (w.b_flags[body] & RP_BF_TYPE_MASK) == RP_BODY_DYNAMIC; }
+
+// The full narrow-phase update of one pair (pair_update.rs:173-613).
+__device__ __noinline__ void pair_full_update(DevWorld &w, int s, int c1, int c2, Pose pc1, Pose pc2, Pose pos12) {
+    const float prediction = w.prm.prediction;
+    int rb1 = w.c_parent[c1], rb2 = w.c_parent[c2];
+    int sh1 = w.c_shape[c1], sh2 = w.c_shape[c2];
+    float4 he1 = w.c_he[c1], he2 = w.c_he[c2];
+    int had = w.p_nsc[s] > 0;
+
+    LocalManifold m;
+    m.n = w.p_npts[s];
+    m.ln1 = v3(w.p_ln1[s]); m.ln2 = v3(w.p_ln2[s]);
+    for (int k = 0; k < m.n; ++k) {
+        float4 a = PT(w.pt_lp1d, k, s), b = PT(w.pt_lp2f, k, s);
+        m.lp1[k] = v3(a); m.dist[k] = a.w; m.lp2[k] = v3(b); m.fid[k] = __float_as_uint(b.w); m.src[k] = k;
+    }
+    int nold = m.n;
+    // pair_update.rs:323-330 -> parry DefaultQueryDispatcher::contact_manifolds
+    if (sh1 == RP_SHAPE_CUBOID && sh2 == RP_SHAPE_CUBOID) manifold_cuboid_cuboid(pos12, v3(he1), v3(he2), prediction, m);
+    else if (sh1 == RP_SHAPE_BALL && sh2 == RP_SHAPE_BALL) manifold_ball_ball(pos12, he1.x, he2.x, prediction, m);
+    else if (sh1 == RP_SHAPE_CUBOID) manifold_cuboid_ball(pos12, v3(he1), he2.x, prediction, m, false);
+    else manifold_cuboid_ball(pose_inv(pos12), v3(he2), he1.x, prediction, m, true);
+
+    // carry ContactData (impulse, warm starts) to the new point order
+    float4 oimp[RP_MAX_PTS], owst[RP_MAX_PTS];
+    for (int k = 0; k < nold; ++k) { oimp[k] = PT(w.pt_imp, k, s); owst[k] = PT(w.pt_wst, k, s); }
+    float impulse_of[RP_MAX_PTS];
+    for (int k = 0; k < m.n; ++k) {
+        int j = m.src[k];
+        float4 im = j >= 0 ? oimp[j] : make_float4(0, 0, 0, 0);
+        float4 ws = j >= 0 ? owst[j] : make_float4(0, 0, 0, 0);
+        PT(w.pt_imp, k, s) = im; PT(w.pt_wst, k, s) = ws;
+        PT(w.pt_lp1d, k, s) = f4(m.lp1[k], m.dist[k]);
+        PT(w.pt_lp2f, k, s) = f4(m.lp2[k], __uint_as_float(m.fid[k]));
+        impulse_of[k] = im.x;
+    }
+    (void)impulse_of;
+    w.p_npts[s] = m.n;
+    w.p_ln1[s] = f4(m.ln1, 0.0f); w.p_ln2[s] = f4(m.ln2, 0.0f);
+
+    float4 mat1 = w.c_mat[c1], mat2 = w.c_mat[c2];
+    int2 ru1 = w.c_rules[c1], ru2 = w.c_rules[c2];
+    float friction = combine_coeff(mat1.x, mat2.x, ru1.x, ru2.x);
+    float restitution = combine_coeff(mat1.y, mat2.y, ru1.y, ru2.y);
+    int rel_dom = effective_dominance(w, rb1) - effective_dominance(w, rb2);
+    V3 normal = qrot(pc1.r, m.ln1);
+    w.p_normal[s] = f4(normal, friction);
+    w.p_reldom[s] = rel_dom;
+
+    int nsc = 0;
+    if (m.n > 0) {
+        int sel[4] = {0, 1, 2, 3};
+        int nsel = m.n < 4 ? m.n : 4;
+        reduce_manifold(m, sel, nsel, prediction);
+        if (nsel > 1) { // pair_update.rs:430-457
+            V3 b0, b1; orthonormal_basis(m.ln1, b0, b1);
+            float k0[4], k1[4]; int ks[4];
+            for (int i = 0; i < nsel; ++i) { V3 lp = m.lp1[sel[i]]; k0[i] = dot(lp, b0); k1[i] = dot(lp, b1); ks[i] = sel[i]; }
+            for (int i = 1; i < nsel; ++i) {
+                float a0 = k0[i], a1 = k1[i]; int as = ks[i]; int j = i;
+                while (j > 0 && (k0[j - 1] > a0 || (k0[j - 1] == a0 && k1[j - 1] > a1))) { k0[j] = k0[j - 1]; k1[j] = k1[j - 1]; ks[j] = ks[j - 1]; j--; }
+                k0[j] = a0; k1[j] = a1; ks[j] = as;
+            }
+            for (int i = 0; i < nsel; ++i) sel[i] = ks[i];
+        }
+        bool has1 = rb1 >= 0 && rel_dom <= 0, has2 = rb2 >= 0 && rel_dom >= 0;
+        Pose com1, com2;
+        com1.r = q4(0, 0, 0, 1); com1.t = v3(0, 0, 0); com2 = com1;
+        V3 lv1 = v3(0, 0, 0), av1 = lv1, wc1 = lv1, lv2 = lv1, av2 = lv1, wc2 = lv1;
+        if (rb1 >= 0) { lv1 = v3(w.b_linvel[rb1]); av1 = v3(w.b_angvel[rb1]); wc1 = v3(w.b_wcom[rb1]); }
+        if (rb2 >= 0) { lv2 = v3(w.b_linvel[rb2]); av2 = v3(w.b_angvel[rb2]); wc2 = v3(w.b_wcom[rb2]); }
+        if (has1) { Pose bp; bp.r = q4(w.b_rot[rb1]); bp.t = v3(w.b_pos[rb1]); com1.r = bp.r; com1.t = pose_tp(bp, v3(w.b_lcom_invm[rb1])); }
+        if (has2) { Pose bp; bp.r = q4(w.b_rot[rb2]); bp.t = v3(w.b_pos[rb2]); com2.r = bp.r; com2.t = pose_tp(bp, v3(w.b_lcom_invm[rb2])); }
+        for (int q = 0; q < nsel; ++q) { // pair_update.rs:459-498 + :536-577
+            int cid = sel[q];
+            float eff_dist = m.dist[cid];
+            V3 wp1 = pose_tp(pc1, m.lp1[cid]);
+            V3 wp2 = pose_tp(pc2, m.lp2[cid]);
+            bool keep = eff_dist < prediction;
+            if (!keep) {
+                V3 vel1 = rb1 >= 0 ? lv1 + cross(av1, wp1 - wc1) : v3(0, 0, 0);
+                V3 vel2 = rb2 >= 0 ? lv2 + cross(av2, wp2 - wc2) : v3(0, 0, 0);
+                keep = eff_dist + dot(vel2 - vel1, normal) * w.prm.p.dt < prediction;
+            }
+            if (!keep) continue;
+            float shift = dot(wp2 - wp1, normal) - eff_dist;
+            V3 p1 = wp1 + normal * shift;
+            V3 point = (p1 + wp2) * 0.5f;
+            PT(w.pt_dp1, cid, s) = f4(has1 ? point - com1.t : point, 0.0f);
+            PT(w.pt_dp2, cid, s) = f4(has2 ? point - com2.t : point, 0.0f);
+            V3 a1 = has1 ? pose_itp(com1, p1) : p1;
+            V3 a2 = has2 ? pose_itp(com2, wp2) : wp2;
+            PT(w.sc_a1, nsc, s) = f4(a1, eff_dist);
+            PT(w.sc_a2, nsc, s) = f4(a2, __int_as_float(cid));
+            nsc++;
+        }
+    }
+    w.p_nsc[s] = nsc;
+    // recycle state — pair_update.rs:582-613
+    float recycle = w.prm.recycle_distance;
+    if (recycle > 0.0f) {
+        float max_extent;
+        if (w.p_pflags[s] & RP_PF_RECYCLE) max_extent = w.p_misc[s].y;
+        else {
+            float e1 = sh1 == RP_SHAPE_CUBOID ? len(v3(he1)) : len(v3(he1.x, he1.x, he1.x));
+            float e2 = sh2 == RP_SHAPE_CUBOID ? len(v3(he2)) : len(v3(he2.x, he2.x, he2.x));
+            max_extent = rp_max(e1, e2);
+        }
+        float max_drift = nsc > 0 ? recycle : rp_min(recycle, prediction);
+        w.p_misc[s] = make_float4(restitution, max_extent, max_drift, 0.0f);
+        w.r_t[s] = f4(pos12.t, 0.0f); w.r_r[s] = f4(pos12.r); w.r_rot1[s] = f4(pc1.r); w.r_rot2[s] = f4(pc2.r);
+        w.p_pflags[s] |= RP_PF_RECYCLE;
+    } else {
+        w.p_misc[s] = make_float4(restitution, 0.0f, 0.0f, 0.0f);
+    }
+    atomicAdd(&w.flags[FL_FULL_UPDATES], 1);
+    // begin/end-touch transition — pair_update.rs:622-629, contacts.rs:300-364
+    int has = nsc > 0;
+    if (has != had) {
+        w.flags[FL_LAYOUT_DIRTY] = 1;
+        if (!has) { // end touch: free the colour now (clear_pair_solver_color, mod.rs:157-172)
+            int color = w.p_color[s];
+            if (color < RP_COLOR_OVERFLOW) {
+                int2 cb = w.p_colorb[s];
+                unsigned bit = 1u << (color & 31);
+                if (cb.x >= 0) atomicAnd(&w.b_cmask[4 * cb.x + (color >> 5)], ~bit);
+                if (cb.y >= 0) atomicAnd(&w.b_cmask[4 * cb.y + (color >> 5)], ~bit);
+            }
+            w.p_color[s] = RP_COLOR_UNCOLORED; w.p_colorb[s] = make_int2(-1, -1);
+        } else { // begin touch: queue for the sorted greedy colouring
+            int t = atomicAdd(&w.flags[FL_TODO_COUNT], 1);
+            unsigned a = rb1 >= 0 ? (unsigned)rb1 : 0x1fffffu, b = rb2 >= 0 ? (unsigned)rb2 : 0x1fffffu;
+            unsigned lo = a < b ? a : b, hi = a < b ? b : a;
+            w.todo_slot[t] = s;
+            w.todo_key[t] = ((unsigned long long)lo << 43) | ((unsigned long long)hi << 22) | (unsigned long long)(s & 0x3fffff);
+        }
+    }
+}
+
+__global__ void k_np_begin(DevWorld w) {
+    w.flags[FL_FULL_UPDATES] = 0;
+    w.flags[FL_TODO_COUNT] = 0;
+}
+
+__global__ void k_np_pairs(DevWorld w) {
+    int top = w.flags[FL_POOL_TOP];
+    if (top > w.pool_cap) top = w.pool_cap;
+    int stride = gridDim.x * blockDim.x;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < top; s += stride) {
+        int c1 = w.p_c1[s];
+        if (c1 < 0) continue;
+        int c2 = w.p_c2[s];
+        Pose pc1, pc2;
+        pc1.r = q4(w.c_rot[c1]); pc1.t = v3(w.c_pos[c1]);
+        pc2.r = q4(w.c_rot[c2]); pc2.t = v3(w.c_pos[c2]);
+        Pose pos12 = pose_inv_mul(pc1, pc2);
+        // contact recycling — pair_update.rs:111-171, contact_pair.rs:284-325
+        if (w.prm.recycle_distance > 0.0f && (w.p_pflags[s] & RP_PF_RECYCLE)) {
+            Pose base; base.t = v3(w.r_t[s]); base.r = q4(w.r_r[s]);
+            float4 misc = w.p_misc[s];
+            float trans = len(pos12.t - base.t);
+            Q4 d = qmul(pos12.r, qconj(base.r));
+            float drift = trans + 2.0f * len(v3(d.x, d.y, d.z)) * misc.y;
+            float ca = qdot(q4(w.r_rot1[s]), pc1.r), cb = qdot(q4(w.r_rot2[s]), pc2.r);
+            float rot_cos = rp_min(2.0f * ca * ca - 1.0f, 2.0f * cb * cb - 1.0f);
+            if (drift <= misc.z && rot_cos > 0.98f) continue;
+        }
+        pair_full_update(w, s, c1, c2, pc1, pc2, pos12);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Deferred greedy colouring (apply_deferred_solver_coloring, contacts.rs:369-385 +
+// assign_pair_solver_color, narrow_phase/mod.rs:90-154) — ONE workgroup, dependency rounds.
+RP_DEV unsigned long long ld_u64(unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+RP_DEV unsigned ld_u32(unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ void __launch_bounds__(1024) k_color_pairs(DevWorld w) {
+    int T = w.flags[FL_TODO_COUNT];
+    if (T == 0) return;
+    __shared__ int remaining;
+    // todo_tmp[t] = 1 while uncoloured
+    for (int t = threadIdx.x; t < T; t += blockDim.x) w.todo_tmp[t] = 1;
+    __syncthreads();
+    for (int round = 0; round < (1 << 24); ++round) {
+        if (threadIdx.x == 0) remaining = 0;
+        __syncthreads();
+        // phase A: each uncoloured pair bids its key at its dynamic bodies
+        for (int t = threadIdx.x; t < T; t += blockDim.x) {
+            if (!w.todo_tmp[t]) continue;
+            int s = w.todo_slot[t];
+            unsigned long long key = w.todo_key[t];
+            int b1 = w.c_parent[w.p_c1[s]], b2 = w.c_parent[w.p_c2[s]];
+            if (body_dynamic(w, b1)) atomicMin(&w.b_min[b1], key);
+            if (body_dynamic(w, b2)) atomicMin(&w.b_min[b2], key);
+        }
+        __threadfence();
+        __syncthreads();
+        // phase B: winners at both bodies take the first free colour
+        for (int t = threadIdx.x; t < T; t += blockDim.x) {
+            if (!w.todo_tmp[t]) continue;
+            int s = w.todo_slot[t];
+            unsigned long long key = w.todo_key[t];
+            int b1 = w.c_parent[w.p_c1[s]], b2 = w.c_parent[w.p_c2[s]];
+            bool d1 = body_dynamic(w, b1), d2 = body_dynamic(w, b2);
+            bool win = (!d1 || ld_u64(&w.b_min[b1]) == key) && (!d2 || ld_u64(&w.b_min[b2]) == key);
+            if (!win) { atomicAdd(&remaining, 1); continue; }
+            // a non-fixed side conflicts (mod.rs:104-105); only dynamic bodies exist besides fixed here
+            int color = 128;
+            unsigned m[4] = {0, 0, 0, 0};
+            if (d1) for (int q = 0; q < 4; ++q) m[q] |= ld_u32(&w.b_cmask[4 * b1 + q]);
+            if (d2) for (int q = 0; q < 4; ++q) m[q] |= ld_u32(&w.b_cmask[4 * b2 + q]);
+            if (d1 && d2) {
+                for (int c = 0; c < RP_DYNAMIC_COLOR_COUNT; ++c) if (!((m[c >> 5] >> (c & 31)) & 1u)) { color = c; break; }
+            } else if (d1 || d2) {
+                for (int c = 127; c >= 0; --c) if (!((m[c >> 5] >> (c & 31)) & 1u)) { color = c; break; }
+            }
+            if (color >= 128) { w.p_color[s] = RP_COLOR_OVERFLOW; w.p_colorb[s] = make_int2(-1, -1); }
+            else {
+                unsigned bit = 1u << (color & 31);
+                if (d1) atomicOr(&w.b_cmask[4 * b1 + (color >> 5)], bit);
+                if (d2) atomicOr(&w.b_cmask[4 * b2 + (color >> 5)], bit);
+                w.p_color[s] = color;
+                w.p_colorb[s] = (d1 && d2) ? make_int2(b1, b2) : make_int2(d1 ? b1 : b2, -1);
+            }
+            w.todo_tmp[t] = 2; // coloured this round: still has to reset its bids
+        }
+        __threadfence();
+        __syncthreads();
+        // phase C: reset the bids
+        for (int t = threadIdx.x; t < T; t += blockDim.x) {
+            int st = w.todo_tmp[t];
+            if (!st) continue;
+            int s = w.todo_slot[t];
+            int b1 = w.c_parent[w.p_c1[s]], b2 = w.c_parent[w.p_c2[s]];
+            if (body_dynamic(w, b1)) __hip_atomic_store(&w.b_min[b1], RP_EMPTY_KEY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (body_dynamic(w, b2)) __hip_atomic_store(&w.b_min[b2], RP_EMPTY_KEY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (st == 2) w.todo_tmp[t] = 0;
+        }
+        __threadfence();
+        __syncthreads();
+        int rem = remaining;
+        __syncthreads();
+        if (rem == 0) break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Solver contact graph buckets (maintain_solver_contact_graph, solver_graph.rs:129-361) and the
+// stage order of init.rs:163-254: colours with >= 32 four-lane chunks ascending, then the smaller
+// colours ascending; the overflow colour is always swept last (serially).
+__global__ void k_bucket_count(DevWorld w) {
+    if (!w.flags[FL_LAYOUT_DIRTY]) return;
+    int top = w.flags[FL_POOL_TOP];
+    if (top > w.pool_cap) top = w.pool_cap;
+    int stride = gridDim.x * blockDim.x;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < top; s += stride) {
+        if (w.p_c1[s] < 0 || w.p_nsc[s] == 0) { if (s < w.pool_cap) w.p_conspos[s] = -1; continue; }
+        int color = w.p_color[s];
+        if (color > RP_COLOR_OVERFLOW) continue;
+        atomicAdd(&w.color_count[color], 1);
+        atomicAdd(&w.flags[FL_N_SC], w.p_nsc[s]);
+    }
+}
+__global__ void k_bucket_clear(DevWorld w) {
+    if (!w.flags[FL_LAYOUT_DIRTY]) return;
+    if (threadIdx.x < RP_NUM_COLORS) w.color_count[threadIdx.x] = 0;
+    if (threadIdx.x == 0) w.flags[FL_N_SC] = 0;
+}
+__global__ void k_bucket_layout(DevWorld w) {
+    if (!w.flags[FL_LAYOUT_DIRTY]) return;
+    if (threadIdx.x != 0) return;
+    // constraint positions are laid out stage by stage so that each stage is a contiguous column range
+    int nst = 0, npar = 0, pos = 0, maxs = 0, ncol = 0;
+    for (int pass = 0; pass < 2; ++pass)
+        for (int c = 0; c < RP_NUM_COLORS - 1; ++c) {
+            int n = w.color_count[c];
+            if (n == 0) continue;
+            bool par = n >= RP_PARALLEL_MIN_MANIFOLDS;
+            if ((pass == 0) != par) continue;
+            w.stage_color[nst] = c; w.stage_begin[nst] = pos; w.stage_count[nst] = n;
+            w.color_begin[c] = pos; w.color_cursor[c] = pos;
+            pos += n; nst++; ncol++;
+            if (par) npar++;
+            if (n > maxs) maxs = n;
+        }
+    int nov = w.color_count[RP_COLOR_OVERFLOW];
+    w.stage_color[nst] = RP_COLOR_OVERFLOW; w.stage_begin[nst] = pos; w.stage_count[nst] = nov;
+    w.color_begin[RP_COLOR_OVERFLOW] = pos; w.color_cursor[RP_COLOR_OVERFLOW] = pos;
+    pos += nov;
+    if (nov) ncol++;
+    w.flags[FL_N_STAGES] = nst; w.flags[FL_N_PARALLEL] = npar; w.flags[FL_MAX_STAGE] = maxs;
+    w.flags[FL_HAS_OVERFLOW_COLOR] = nov > 0; w.flags[FL_N_COLORS] = ncol;
+    w.flags[FL_N_CONS] = pos;
+    if (pos > w.cons_cap) atomicOr(&w.flags[FL_OVERFLOW], RP_OVF_CONS);
+}
+__global__ void k_bucket_scatter(DevWorld w) {
+    if (!w.flags[FL_LAYOUT_DIRTY]) return;
+    int top = w.flags[FL_POOL_TOP];
+    if (top > w.pool_cap) top = w.pool_cap;
+    int stride = gridDim.x * blockDim.x;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < top; s += stride) {
+        if (w.p_c1[s] < 0 || w.p_nsc[s] == 0) continue;
+        int color = w.p_color[s];
+        if (color > RP_COLOR_OVERFLOW) continue;
+        int pos = atomicAdd(&w.color_cursor[color], 1);
+        if (pos < w.cons_cap) { w.cons_pair[pos] = s; w.p_conspos[s] = pos; }
+    }
+}
+__global__ void k_bucket_finish(DevWorld w) { w.flags[FL_LAYOUT_DIRTY] = 0; }
+
+void rp_launch_narrowphase(const DevWorld &w, hipStream_t st) {
+    if (w.n_colliders == 0) return;
+    int blocks = (w.pool_cap + 255) / 256; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_np_begin, dim3(1), dim3(1), 0, st, w);
+    hipLaunchKernelGGL(k_np_pairs, dim3(blocks), dim3(256), 0, st, w);
+    hipLaunchKernelGGL(k_color_pairs, dim3(1), dim3(1024), 0, st, w);
+    hipLaunchKernelGGL(k_bucket_clear, dim3(1), dim3(256), 0, st, w);
+    hipLaunchKernelGGL(k_bucket_count, dim3(blocks), dim3(256), 0, st, w);
+    hipLaunchKernelGGL(k_bucket_layout, dim3(1), dim3(64), 0, st, w);
+    hipLaunchKernelGGL(k_bucket_scatter, dim3(blocks), dim3(256), 0, st, w);
+    hipLaunchKernelGGL(k_bucket_finish, dim3(1), dim3(1), 0, st, w);
+}

@@ -1,0 +1,181 @@
+// rp_world.h — HBM data layout of one physics world (Structure-of-Arrays) shared by every kernel.
+//
+// Everything a step touches lives in device memory; kernels receive a `DevWorld` by value (plain
+// pointers + sizes).  Layout choices:
+//   * bodies / colliders: one float4 array per attribute, indexed by arena index (coalesced per-item kernels);
+//   * contact pairs: pool slot s owns column s of every pair array; manifold points are
+//     [point k][slot] planes so a wavefront reading point k of 64 consecutive slots is coalesced;
+//   * solver constraints: float4 planes C[plane][position], position = rank of the manifold in the
+//     colour-major (stage-major) order, so one colour stage reads contiguous columns.
+#pragma once
+#include "rp_math.h"
+#include "../../include/rapier_hip.h"
+
+#define RP_NUM_COLORS 129
+#define RP_COLOR_OVERFLOW 128
+#define RP_COLOR_UNCOLORED 255
+#define RP_DYNAMIC_COLOR_COUNT 120   // contact_pair.rs:167
+#define RP_MAX_PTS 8                 // manifold points kept per pair (face/face clip max)
+#define RP_PARALLEL_MIN_MANIFOLDS 125 // ceil(n/4) >= 32 chunks  (init.rs:169, mod.rs:41-57)
+#define RP_EMPTY_KEY 0xffffffffffffffffull
+#define RP_FID_UNKNOWN 0xffffu
+
+// body flag bits
+#define RP_BF_TYPE_MASK 0x3
+#define RP_BF_GYRO 0x4
+#define RP_BF_FASTROT 0x8
+#define RP_BF_DOM_SHIFT 8
+
+// pair flag bits
+#define RP_PF_RECYCLE 0x1
+
+// overflow / error flag bits (dev flags[FL_OVERFLOW])
+#define RP_OVF_POOL 0x1
+#define RP_OVF_HASH 0x2
+#define RP_OVF_CELLS 0x4
+#define RP_OVF_LARGE 0x8
+#define RP_OVF_CONS 0x10
+
+// device scalar slots (int32) in DevWorld::flags
+enum {
+    FL_BP_DIRTY = 0,    // some fat AABB changed -> pair set must be rebuilt this step
+    FL_BP_EPOCH,        // rebuild counter; parity selects the live hash table
+    FL_N_LARGE,         // colliders spanning > 3 grid cells on an axis
+    FL_N_ENTRIES,       // grid cell entries
+    FL_POOL_TOP,        // bump allocator of pair slots
+    FL_FREE_TOP,        // free-slot stack height
+    FL_TODO_COUNT,      // begin-touch pairs waiting for a colour
+    FL_LAYOUT_DIRTY,    // the active-manifold set changed -> rebuild buckets
+    FL_N_CONS,          // M: active solver manifolds
+    FL_N_STAGES,        // colour stages (non-empty colours, overflow excluded)
+    FL_N_PARALLEL,      // stages with >= RP_PARALLEL_MIN_MANIFOLDS
+    FL_MAX_STAGE,       // largest stage size
+    FL_OVERFLOW,        // RP_OVF_* bits
+    FL_FULL_UPDATES,    // narrow-phase full updates this step
+    FL_N_SC,            // solver contacts
+    FL_QUARANTINE,      // non-finite poses detected
+    FL_ANY_BOUNCY,      // some constraint holds a restitution seed
+    FL_HAS_OVERFLOW_COLOR, // overflow bucket non-empty
+    FL_N_COLORS,
+    FL_BP_REBUILDS,
+    FL_STEP,            // step counter
+    FL_COUNT = 32
+};
+
+// constraint float4 planes (per solver manifold) — restates ContactWithTwistFriction +
+// ContactWithTwistFrictionBuilder (contact_with_twist_friction.rs:18-55,600-630)
+enum {
+    CP_H0 = 0,  // dir1.xyz, limit (friction coefficient)
+    CP_H1,      // im1.xyz, twist r
+    CP_H2,      // im2.xyz, tangent r[2]
+    CP_H3,      // ii1: m11 m12 m13 m22
+    CP_H4,      // ii1: m23 m33 ; ii2: m11 m12
+    CP_H5,      // ii2: m13 m22 m23 m33
+    CP_H6,      // tangent1.xyz, tangent rhs_wo_bias[0]
+    CP_H7,      // tangent rhs_wo_bias[1], tangent r[0], r[1], -
+    CP_H8,      // twist_dists[0..3]
+    CP_HM0,     // mutable: twist impulse, twist accumulator, tangent impulse[0], [1]
+    CP_HM1,     // mutable: tangent accumulator[0],[1], tangent rhs[0],[1]
+    CP_T0,      // tangent torque_dir1[0].xyz
+    CP_T1,      // tangent torque_dir1[1]
+    CP_T2,      // tangent torque_dir2[0]
+    CP_T3,      // tangent torque_dir2[1]
+    CP_T4,      // tangent ii_torque_dir1[0]
+    CP_T5,      // tangent ii_torque_dir1[1]
+    CP_T6,      // tangent ii_torque_dir2[0]
+    CP_T7,      // tangent ii_torque_dir2[1]
+    CP_B0,      // builder: local_friction_center1.xyz
+    CP_B1,      // builder: local_friction_center2.xyz
+    CP_B2,      // builder: tangent_vel.xyz
+    CP_N0,      // first per-point plane; point k uses CP_N0 + 7*k + {NM..NF}
+    CP_COUNT = CP_N0 + 7 * 4
+};
+enum {
+    NP_M = 0,   // mutable: rhs, cfm_factor, impulse, impulse_accumulator
+    NP_A,       // torque_dir1.xyz, r
+    NP_B,       // torque_dir2.xyz, restitution_seed
+    NP_C,       // ii_torque_dir1.xyz, builder dist
+    NP_D,       // ii_torque_dir2.xyz, -
+    NP_E,       // builder local_p1.xyz
+    NP_F        // builder local_p2.xyz
+};
+
+struct SimParams {
+    rp_integration_params p;
+    float gravity[3];
+    // derived per substep (host-computed in f32 exactly as SpringCoefficients does)
+    float dt_sub, inv_dt_sub;
+    float dyn_cfm, static_cfm, dyn_erp_inv_dt, static_erp_inv_dt;
+    float prediction, recycle_distance, max_corrective_velocity, max_lin, max_ang;
+    float bp_skin;
+    float cell_size, inv_cell_size;
+    int num_substeps;
+};
+
+struct DevWorld {
+    int n_bodies, n_colliders;
+    int pool_cap;      // pair slots
+    int hash_cap;      // power of two
+    int grid_cap;      // power of two (cell hash buckets)
+    int entries_cap;   // grid entries
+    int large_cap;
+    int cons_cap;      // solver manifolds
+    SimParams prm;
+    int *flags;        // FL_* scalars
+
+    // ---- bodies (index = arena index) ----
+    float4 *b_pos, *b_rot, *b_linvel, *b_angvel;
+    float4 *b_lcom_invm;   // local_com.xyz, inv_mass
+    float4 *b_invpi;       // inv principal inertia xyz
+    float4 *b_pframe;      // principal inertia local frame (quat)
+    float4 *b_wcom;        // world centre of mass
+    float4 *b_eim;         // effective inverse mass (per axis)
+    float4 *b_eii0, *b_eii1; // effective world inverse inertia: (m11 m12 m13 m22), (m23 m33 - -)
+    float4 *b_damp;        // linear damping, angular damping, gravity scale, -
+    float4 *b_uforce, *b_utorque;
+    int *b_flags;
+    // ---- solver bodies (index = arena index; non-dynamic = world-attached) ----
+    float4 *s_lin, *s_ang, *s_rot, *s_trans, *s_incl, *s_inca;
+    unsigned int *b_cmask; // 4 x u32 colour mask per body (body_solver_color_masks)
+    unsigned long long *b_min; // colouring scratch: min pending key per body
+
+    // ---- colliders ----
+    int *c_parent, *c_shape;
+    float4 *c_lpos, *c_lrot, *c_pos, *c_rot, *c_he;
+    float4 *c_mat;         // friction, restitution, density, -
+    int2 *c_rules;
+    uint2 *c_groups;
+    float4 *c_fatmin, *c_fatmax;
+
+    // ---- broad phase ----
+    int *cell_count, *cell_start, *cell_fill, *scan_block;
+    unsigned long long *e_key; int *e_col;
+    int *large_list;
+    unsigned long long *h_key[2]; int *h_slot[2];
+    int *free_stack;
+
+    // ---- pair pool ----
+    int *p_c1, *p_c2, *p_stamp, *p_color, *p_nsc, *p_npts, *p_pflags, *p_reldom;
+    int2 *p_colorb;
+    float4 *p_ln1, *p_ln2;      // manifold local normals
+    float4 *p_normal;           // world normal xyz, friction
+    float4 *p_misc;             // restitution, recycle max_extent, recycle max_drift, -
+    float4 *r_t, *r_r, *r_rot1, *r_rot2; // recycle state
+    float4 *pt_lp1d;            // [RP_MAX_PTS][pool]: local_p1.xyz, dist
+    float4 *pt_lp2f;            // local_p2.xyz, (fid1 | fid2<<16) bits
+    float4 *pt_imp;             // impulse, warmstart_impulse, warmstart_twist, -
+    float4 *pt_wst;             // warmstart_tangent_world.xyz
+    float4 *pt_dp1, *pt_dp2;    // frozen solver lever arms
+    float4 *sc_a1;              // [4][pool]: anchor1.xyz, dist
+    float4 *sc_a2;              // anchor2.xyz, contact id bits
+
+    // ---- colouring / buckets ----
+    int *todo_slot; unsigned long long *todo_key; int *todo_tmp;
+    int *color_count, *color_begin, *color_cursor, *stage_color, *stage_begin, *stage_count;
+    int *cons_pair;             // [cons_cap] position -> pair slot
+    int *p_conspos;             // pair slot -> position (or -1)
+
+    // ---- constraints ----
+    float4 *C;                  // [CP_COUNT][cons_cap]
+    int *k_b1, *k_b2, *k_n, *k_cid;
+};

@@ -1,0 +1,264 @@
+"""Host-side mirror of the reference's public API for the step path, over the C ABI.
+
+Names follow the reference: `PhysicsWorld` (physics_world.rs:61-157) owns
+`RigidBodySet` / `ColliderSet` / `ImpulseJointSet` / `PhysicsPipeline` /
+`IntegrationParameters`; `insert`, `insert_body`, `insert_collider`, `insert_impulse_joint`,
+`step` keep the reference's argument meaning.  All state lives on the MI355X; reading a body
+downloads it.  Errors from the device library raise `RapierHipError` (the reference panics).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi, scenes as S
+
+
+class RapierHipError(RuntimeError):
+    pass
+
+
+def _check(world_ptr, status: int, what: str):
+    if status != 0:
+        msg = _ffi.lib().rp_last_error(world_ptr)
+        raise RapierHipError(f"{what} failed (status {status}): {msg.decode() if msg else ''}")
+
+
+class IntegrationParameters:
+    """IntegrationParameters (integration_parameters.rs:181-304): attribute access on the packed struct."""
+
+    def __init__(self, values: np.ndarray | None = None):
+        object.__setattr__(self, "_v", S.default_params() if values is None else np.array(values, dtype=S.PARAMS_DTYPE))
+
+    def __getattr__(self, name):
+        v = object.__getattribute__(self, "_v")
+        if name in v.dtype.names:
+            return v[name].item()
+        raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        if name in self._v.dtype.names:
+            self._v[name] = value
+        else:
+            raise AttributeError(name)
+
+    def inv_dt(self) -> float:
+        return 0.0 if self.dt == 0.0 else 1.0 / self.dt
+
+    def prediction_distance(self) -> float:
+        return self.normalized_prediction_distance * self.length_unit
+
+    def as_array(self) -> np.ndarray:
+        return np.ascontiguousarray(self._v)
+
+
+class RigidBodyHandle(int):
+    """Index{index, generation} packed as generation<<32 | index (arena.rs:58-90)."""
+
+    def into_raw_parts(self):
+        return int(self) & 0xFFFFFFFF, int(self) >> 32
+
+
+class ColliderHandle(RigidBodyHandle):
+    pass
+
+
+class RigidBodySet:
+    def __init__(self, world: "PhysicsWorld"):
+        self._w = world
+        self._n = 0
+
+    def insert(self, body: np.ndarray) -> RigidBodyHandle:
+        return self._w.insert_body(body)
+
+    def __len__(self):
+        return self._n
+
+    def translation(self, handle) -> np.ndarray:
+        pos, _ = self._w.read_bodies([handle])
+        return pos[0, :3]
+
+
+class ColliderSet:
+    def __init__(self, world: "PhysicsWorld"):
+        self._w = world
+        self._n = 0
+
+    def insert_with_parent(self, collider: np.ndarray, parent) -> ColliderHandle:
+        return self._w.insert_collider(collider, parent)
+
+    def insert(self, collider: np.ndarray) -> ColliderHandle:
+        return self._w.insert_collider(collider, None)
+
+    def __len__(self):
+        return self._n
+
+
+class ImpulseJointSet:
+    def __init__(self, world: "PhysicsWorld"):
+        self._w = world
+        self._n = 0
+
+    def insert(self, body1, body2, joint: np.ndarray):
+        return self._w.insert_impulse_joint(body1, body2, joint)
+
+    def __len__(self):
+        return self._n
+
+
+class PhysicsPipeline:
+    """PhysicsPipeline (physics_pipeline/mod.rs:45): `step` + `counters`."""
+
+    def __init__(self, world: "PhysicsWorld"):
+        self._w = world
+
+    def step(self, nsteps: int = 1):
+        self._w.step(nsteps)
+
+    @property
+    def counters(self) -> dict:
+        return self._w.counters()
+
+
+class PhysicsWorld:
+    """PhysicsWorld::new() on device `device` (physics_world.rs:61-157)."""
+
+    def __init__(self, gravity=(0.0, -9.81, 0.0), integration_parameters: IntegrationParameters | None = None, device: int = 0):
+        self._lib = _ffi.lib()
+        self.integration_parameters = integration_parameters or IntegrationParameters()
+        self.gravity = tuple(float(g) for g in gravity)
+        self._ptr = C.c_void_p()
+        prm = self.integration_parameters.as_array()
+        grav = np.asarray(self.gravity, dtype=np.float32)
+        st = self._lib.rp_world_create(prm.ctypes.data, grav.ctypes.data, device, C.byref(self._ptr))
+        if st != 0 or not self._ptr:
+            raise RapierHipError(f"rp_world_create failed (status {st}): no usable HIP device; there is no CPU fallback")
+        self.bodies = RigidBodySet(self)
+        self.colliders = ColliderSet(self)
+        self.impulse_joints = ImpulseJointSet(self)
+        self.physics_pipeline = PhysicsPipeline(self)
+
+    @classmethod
+    def from_scene(cls, scene: S.Scene, device: int = 0) -> "PhysicsWorld":
+        w = cls(gravity=scene.gravity, integration_parameters=IntegrationParameters(scene.params), device=device)
+        bodies = scene.body_array()
+        if len(bodies):
+            w.insert_bodies(bodies)
+        cols = scene.collider_array()
+        if len(cols):
+            parents = scene.parent_array().astype(np.int64)
+            ph = np.where(parents < 0, np.uint64(_ffi.RP_INVALID_HANDLE), parents.astype(np.uint64)).astype(np.uint64)
+            w.insert_colliders(cols, ph)
+        joints = scene.joint_array()
+        if len(joints):
+            w.insert_impulse_joints(joints)
+        return w
+
+    # ---- insertion (RigidBodySet::insert, ColliderSet::insert_with_parent, ...) ----
+    def insert_bodies(self, descs: np.ndarray) -> np.ndarray:
+        descs = np.ascontiguousarray(descs, dtype=S.BODY_DTYPE)
+        out = np.zeros(len(descs), np.uint64)
+        _check(self._ptr, self._lib.rp_bodies_insert(self._ptr, len(descs), descs.ctypes.data, out.ctypes.data), "rp_bodies_insert")
+        self.bodies._n += len(descs)
+        return out
+
+    def insert_body(self, body: np.ndarray) -> RigidBodyHandle:
+        return RigidBodyHandle(int(self.insert_bodies(np.array([body], dtype=S.BODY_DTYPE))[0]))
+
+    def insert_colliders(self, descs: np.ndarray, parents: np.ndarray) -> np.ndarray:
+        descs = np.ascontiguousarray(descs, dtype=S.COLLIDER_DTYPE)
+        parents = np.ascontiguousarray(parents, dtype=np.uint64)
+        out = np.zeros(len(descs), np.uint64)
+        _check(self._ptr, self._lib.rp_colliders_insert(self._ptr, len(descs), descs.ctypes.data, parents.ctypes.data, out.ctypes.data), "rp_colliders_insert")
+        self.colliders._n += len(descs)
+        return out
+
+    def insert_collider(self, collider: np.ndarray, parent=None) -> ColliderHandle:
+        p = np.array([_ffi.RP_INVALID_HANDLE if parent is None else int(parent)], dtype=np.uint64)
+        return ColliderHandle(int(self.insert_colliders(np.array([collider], dtype=S.COLLIDER_DTYPE), p)[0]))
+
+    def insert(self, body: np.ndarray, collider: np.ndarray):
+        """PhysicsWorld::insert(body, collider) -> (body handle, collider handle)."""
+        b = self.insert_body(body)
+        return b, self.insert_collider(collider, b)
+
+    def insert_impulse_joints(self, descs: np.ndarray) -> np.ndarray:
+        descs = np.ascontiguousarray(descs, dtype=S.JOINT_DTYPE)
+        out = np.zeros(len(descs), np.uint64)
+        _check(self._ptr, self._lib.rp_impulse_joints_insert(self._ptr, len(descs), descs.ctypes.data, out.ctypes.data), "rp_impulse_joints_insert")
+        self.impulse_joints._n += len(descs)
+        return out
+
+    def insert_impulse_joint(self, body1, body2, joint: np.ndarray):
+        j = np.array([joint], dtype=S.JOINT_DTYPE)
+        j["body1"], j["body2"] = int(body1) & 0xFFFFFFFF, int(body2) & 0xFFFFFFFF
+        return int(self.insert_impulse_joints(j)[0])
+
+    # ---- stepping ----
+    def step(self, nsteps: int = 1):
+        """PhysicsWorld::step() x nsteps (asynchronous; see `sync`)."""
+        _check(self._ptr, self._lib.rp_step(self._ptr, int(nsteps)), "rp_step")
+
+    def sync(self):
+        _check(self._ptr, self._lib.rp_sync(self._ptr), "rp_sync")
+
+    # ---- readback ----
+    def read_bodies(self, handles=None):
+        if handles is None:
+            n = self._lib.rp_num_bodies(self._ptr)
+            hp = None
+        else:
+            h = np.ascontiguousarray(np.asarray(handles, dtype=np.uint64))
+            n, hp = len(h), h.ctypes.data
+        pos = np.zeros((n, 7), np.float32)
+        vel = np.zeros((n, 6), np.float32)
+        _check(self._ptr, self._lib.rp_bodies_read(self._ptr, n, hp, pos.ctypes.data, vel.ctypes.data), "rp_bodies_read")
+        return pos, vel
+
+    def write_bodies(self, handles, pos7=None, vel6=None):
+        h = np.ascontiguousarray(np.asarray(handles, dtype=np.uint64))
+        p = None if pos7 is None else np.ascontiguousarray(pos7, dtype=np.float32)
+        v = None if vel6 is None else np.ascontiguousarray(vel6, dtype=np.float32)
+        _check(self._ptr, self._lib.rp_bodies_write(self._ptr, len(h), h.ctypes.data, None if p is None else p.ctypes.data,
+                                                  None if v is None else v.ctypes.data), "rp_bodies_write")
+
+    def contacts(self):
+        m = self._lib.rp_contacts_read(self._ptr, 0, None, None, None)
+        if m < 0:
+            _check(self._ptr, m, "rp_contacts_read")
+        meta = np.zeros((m, 4), np.int32)
+        nrm = np.zeros((m, 3), np.float32)
+        imp = np.zeros((m, 4), np.float32)
+        if m:
+            self._lib.rp_contacts_read(self._ptr, m, meta.ctypes.data, nrm.ctypes.data, imp.ctypes.data)
+        return meta, nrm, imp
+
+    def total_contact_impulse(self) -> float:
+        _, _, imp = self.contacts()
+        return float(imp.sum())
+
+    def enable_timers(self, enable: bool = True):
+        _check(self._ptr, self._lib.rp_counters_enable(self._ptr, 1 if enable else 0), "rp_counters_enable")
+
+    def counters(self) -> dict:
+        c = _ffi.Counters()
+        _check(self._ptr, self._lib.rp_counters_read(self._ptr, C.byref(c)), "rp_counters_read")
+        return {n: getattr(c, n) for n, _ in _ffi.Counters._fields_}
+
+    def solver_loop_time_ms(self):
+        avg = C.c_float()
+        n = C.c_int32()
+        self._lib.rp_solver_loop_time_ms(self._ptr, C.byref(avg), C.byref(n))
+        return float(avg.value), int(n.value)
+
+    def close(self):
+        if getattr(self, "_ptr", None):
+            self._lib.rp_world_destroy(self._ptr)
+            self._ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
