@@ -244,3 +244,41 @@ def box_stack(height: int = 3, gap: float = 0.0) -> Scene:
         b = s.add_body(translation=(0.0, 0.5 + i * (1.0 + gap), 0.0))
         s.add_collider(b, half_extents=(0.5, 0.5, 0.5))
     return s
+
+
+def tumble(n: int = 64, seed: int = 7, balls: bool = True) -> Scene:
+    """Seeded dynamic test scene (not a reference scene): rotated cuboids (and balls) with initial
+    velocities dropped on a slab inside a shallow box of walls — exercises full narrow-phase updates,
+    edge/edge SAT axes, 5-8 point manifold reduction, ball cases, pair creation/deletion and
+    begin/end-touch recolouring."""
+    rng = np.random.default_rng(seed)
+    s = Scene(name=f"tumble_{n}_{seed}", gravity=(0.0, -9.81, 0.0))
+    g = s.add_body(body_type=BODY_FIXED, translation=(0.0, -0.5, 0.0))
+    s.add_collider(g, half_extents=(12.0, 0.5, 12.0))
+    for sx, sz, hx, hz in ((6.0, 0.0, 0.25, 6.0), (-6.0, 0.0, 0.25, 6.0), (0.0, 6.0, 6.0, 0.25), (0.0, -6.0, 6.0, 0.25)):
+        wb = s.add_body(body_type=BODY_FIXED, translation=(sx, 1.0, sz))
+        s.add_collider(wb, half_extents=(hx, 1.0, hz))
+    side = int(np.ceil(n ** (1.0 / 3.0)))
+    k = 0
+    for iy in range(side * 2):
+        for ix in range(side):
+            for iz in range(side):
+                if k >= n:
+                    break
+                q = rng.normal(size=4).astype(np.float32)
+                q /= np.linalg.norm(q)
+                pos = (np.float32(1.3 * (ix - side / 2) + 0.1 * rng.random()), np.float32(1.0 + 1.4 * iy),
+                       np.float32(1.3 * (iz - side / 2) + 0.1 * rng.random()))
+                lv = (rng.normal(size=3) * 1.5).astype(np.float32)
+                av = (rng.normal(size=3) * 2.0).astype(np.float32)
+                b = s.add_body(translation=pos, rotation=tuple(q), linvel=tuple(lv), angvel=tuple(av),
+                               linear_damping=0.05 if k % 5 == 0 else 0.0, angular_damping=0.1 if k % 7 == 0 else 0.0)
+                if balls and k % 3 == 2:
+                    s.add_collider(b, shape=SHAPE_BALL, half_extents=(np.float32(0.3 + 0.2 * rng.random()), 0, 0),
+                                   restitution=0.6 if k % 2 == 0 else 0.0, friction=0.4)
+                else:
+                    he = (0.25 + 0.35 * rng.random(size=3)).astype(np.float32)
+                    s.add_collider(b, half_extents=tuple(he), friction=np.float32(0.2 + 0.6 * rng.random()),
+                                   restitution=0.3 if k % 4 == 0 else 0.0, density=np.float32(0.5 + 2.0 * rng.random()))
+                k += 1
+    return s

@@ -1,0 +1,99 @@
+"""Multi-GPU sharding of independent contact islands.
+
+The solve does not shard inside an island, but islands that only touch fixed geometry never couple
+(fixed bodies are not island members, island_manager/persistent.rs:1).  Each rank owns a subset of
+the dynamic bodies (whole islands), replicates every fixed body, and runs the full step on its own
+MI355X with NO data-path collective; one all-gather of packed body state (13 f32 per body) over
+RCCL/xGMI assembles the world state at readback.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import scenes as S
+
+
+def bin_pack(sizes, world_size: int) -> np.ndarray:
+    """Greedy longest-first bin packing of islands (by body count) onto ranks; returns rank per island."""
+    sizes = np.asarray(sizes)
+    order = np.argsort(-sizes, kind="stable")
+    load = np.zeros(world_size, np.int64)
+    out = np.zeros(len(sizes), np.int32)
+    for i in order:
+        r = int(np.argmin(load))
+        out[i] = r
+        load[r] += sizes[i]
+    return out
+
+
+def partition_scene(scene: S.Scene, body_rank: np.ndarray, rank: int):
+    """Sub-scene of `rank`: its dynamic bodies + every fixed body (replicated), with colliders.
+    Returns (sub_scene, global_index_of_local_body)."""
+    sub = S.Scene(name=f"{scene.name}@{rank}", gravity=scene.gravity, params=scene.params.copy())
+    local_of = {}
+    global_ids = []
+    for gi, b in enumerate(scene.bodies):
+        if int(b["body_type"]) != S.BODY_DYNAMIC or int(body_rank[gi]) == rank:
+            local_of[gi] = len(sub.bodies)
+            sub.bodies.append(b)
+            global_ids.append(gi)
+    for c, p in zip(scene.colliders, scene.collider_parents):
+        if p < 0:
+            sub.colliders.append(c)
+            sub.collider_parents.append(-1)
+        elif p in local_of:
+            sub.colliders.append(c)
+            sub.collider_parents.append(local_of[p])
+    for j in scene.joints:
+        b1, b2 = int(j["body1"]), int(j["body2"])
+        if b1 in local_of and b2 in local_of:
+            jj = j.copy()
+            jj["body1"], jj["body2"] = local_of[b1], local_of[b2]
+            sub.joints.append(jj)
+    return sub, np.asarray(global_ids, np.int64)
+
+
+def many_pyramids_body_ranks(rows: int, cols: int, base_count: int, world_size: int) -> np.ndarray:
+    """Island (= pyramid) -> rank for the many_pyramids generator; body 0 is the ground."""
+    per = base_count * (base_count + 1) // 2
+    ranks = bin_pack([per] * (rows * cols), world_size)
+    body_rank = np.zeros(1 + rows * cols * per, np.int32)
+    body_rank[1:] = np.repeat(ranks, per)
+    return body_rank
+
+
+def all_gather_bodies(local_pos: np.ndarray, local_vel: np.ndarray, global_ids: np.ndarray, n_global: int,
+                      dynamic_mask_local: np.ndarray, device=None):
+    """All-gather packed body state (pos7 + vel6 = 13 f32 per body) from every rank and scatter it into
+    arena order.  Uses torch.distributed (backend nccl = RCCL over xGMI on GPU, gloo on CPU)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size()
+    packed = np.concatenate([local_pos, local_vel], axis=1).astype(np.float32)
+    own = dynamic_mask_local.astype(bool)
+    counts = torch.tensor([int(own.sum())], dtype=torch.int64, device=device)
+    all_counts = [torch.zeros_like(counts) for _ in range(world)]
+    dist.all_gather(all_counts, counts)
+    maxn = int(max(int(c.item()) for c in all_counts))
+    buf = torch.zeros((maxn, 14), dtype=torch.float32, device=device)
+    if own.any():
+        payload = np.concatenate([packed[own], global_ids[own, None].astype(np.float32)], axis=1)
+        buf[: payload.shape[0]] = torch.from_numpy(payload).to(buf.device)
+    gathered = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(gathered, buf)
+    pos = np.zeros((n_global, 7), np.float32)
+    vel = np.zeros((n_global, 6), np.float32)
+    # fixed bodies are replicated: take them from the local copy
+    fixed = ~own
+    pos[global_ids[fixed]] = local_pos[fixed]
+    vel[global_ids[fixed]] = local_vel[fixed]
+    for r in range(world):
+        n = int(all_counts[r].item())
+        if n == 0:
+            continue
+        g = gathered[r][:n].cpu().numpy()
+        ids = g[:, 13].astype(np.int64)
+        pos[ids] = g[:, :7]
+        vel[ids] = g[:, 7:13]
+    return pos, vel

@@ -1,0 +1,33 @@
+"""Generates tests/golden/*.npz: body poses/velocities after N steps of small fixed scenes.
+
+The reference itself (Rust, v0.35.2) cannot be built or run in this environment and is not a
+Python package, so these vectors come from the CPU oracle after it passed the reference's
+known-answer tests (tests/test_oracle_kat.py).  Run: python -m tests.golden.make_golden
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, os.path.dirname(HERE))
+
+from rapier_amd import scenes as S  # noqa: E402
+
+CASES = {
+    "box_stack3_s60": lambda: (S.box_stack(3), 60),
+    "pyramid10_s120": lambda: (S.pyramid10(), 120),
+    "tumble40_s90": lambda: (S.tumble(40, seed=11), 90),
+    "many_pyramids_2x2_s30": lambda: (S.many_pyramids(rows=2, cols=2), 30),
+}
+
+if __name__ == "__main__":
+    from oracle_ffi import OracleWorld
+    for name, mk in CASES.items():
+        scene, steps = mk()
+        w = OracleWorld(scene)
+        w.step(steps)
+        pos, vel = w.read()
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), pos=pos, vel=vel)
+        print(name, pos.shape, float(np.abs(pos).max()))

@@ -1,0 +1,73 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every declared symbol, the
+descriptor layouts match the header, there is no CPU fallback, sharding logic."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from rapier_amd import _ffi, scenes as S, sharding
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "rapier_hip.h")).read()
+    declared = set(re.findall(r"\b(rp_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(_ffi.SYMBOLS), declared ^ set(_ffi.SYMBOLS)
+    L = _ffi.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_descriptor_layouts_match_header():
+    # sizes implied by include/rapier_hip.h (all 4-byte fields, no padding)
+    assert S.PARAMS_DTYPE.itemsize == 14 * 4 + 7 * 4
+    assert S.BODY_DTYPE.itemsize == 4 + 12 + 16 + 12 + 12 + 4 * 4 + 3 * 4
+    assert S.COLLIDER_DTYPE.itemsize == 4 + 12 + 12 + 16 + 12 + 8 + 8
+    assert S.JOINT_DTYPE.itemsize == 8 + 24 + 32 + 8
+    assert C.sizeof(_ffi.Counters) == 9 * 4 + 10 * 4
+    p = S.default_params()
+    q = np.zeros((), S.PARAMS_DTYPE)
+    _ffi.lib().rp_default_params(q.ctypes.data)
+    assert p.tobytes() == q.tobytes()  # IntegrationParameters::default() agrees on both sides
+
+
+def test_no_cpu_fallback_without_device():
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import rapier_amd\n"
+            "try:\n    rapier_amd.PhysicsWorld(); print('CREATED')\n"
+            "except rapier_amd.RapierHipError as e:\n    print('REFUSED')\n") % ROOT
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert "REFUSED" in out.stdout, out.stdout + out.stderr
+
+
+def test_product_does_not_import_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "rapier_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "rapier_oracle" not in txt and "oracle_ffi" not in txt, f
+
+
+def test_bin_pack_balances_islands():
+    ranks = sharding.bin_pack([55] * 196, 8)
+    counts = np.bincount(ranks, minlength=8)
+    assert counts.max() - counts.min() <= 1
+
+
+def test_partition_scene_keeps_islands_and_replicates_fixed():
+    sc = S.many_pyramids(rows=2, cols=4)
+    br = sharding.many_pyramids_body_ranks(2, 4, 10, 2)
+    total_dyn = 0
+    for r in range(2):
+        sub, gids = sharding.partition_scene(sc, br, r)
+        assert int(sub.bodies[0]["body_type"]) == S.BODY_FIXED and gids[0] == 0
+        total_dyn += sub.num_dynamic
+        assert sub.num_dynamic % 55 == 0
+        for li, gi in enumerate(gids):
+            assert np.array_equal(sub.bodies[li]["translation"], sc.bodies[gi]["translation"])
+    assert total_dyn == sc.num_dynamic
