@@ -532,7 +532,7 @@ void rp_launch_init_bodies(const DevWorld &w, hipStream_t st) {
 }
 
 void rp_launch_solver_assembly(const DevWorld &w, hipStream_t st) {
-    int nb = (w.n_bodies + 255) / 256;
+    int nb = (w.n_bodies + 255) / 256; if (nb < 1) nb = 1;
     int cb = (w.cons_cap + 255) / 256; if (cb > 2048) cb = 2048; if (cb < 1) cb = 1;
     hipLaunchKernelGGL(k_solver_begin, dim3(nb), dim3(256), 0, st, w);
     hipLaunchKernelGGL(k_generate, dim3(cb), dim3(256), 0, st, w);
@@ -541,7 +541,7 @@ void rp_launch_solver_assembly(const DevWorld &w, hipStream_t st) {
 // The TGS loop proper: S2..S7 for every substep (+ S8 restitution) — worker.rs:207-734.
 void rp_launch_solver_loop(const DevWorld &w, hipStream_t st, int parallel_stages, int stage_blocks, int has_restitution) {
     SolverLaunchPlan plan = {parallel_stages, stage_blocks < 1 ? 1 : stage_blocks, has_restitution};
-    int nb = (w.n_bodies + 255) / 256;
+    int nb = (w.n_bodies + 255) / 256; if (nb < 1) nb = 1;
     const rp_integration_params &p = w.prm.p;
     int fib = (p.friction_in_bias_pass || p.num_internal_stabilization_iterations == 0) ? 1 : 0;
     for (int s = 0; s < w.prm.num_substeps; ++s) {
@@ -556,7 +556,7 @@ void rp_launch_solver_loop(const DevWorld &w, hipStream_t st, int parallel_stage
 }
 
 void rp_launch_solver_writeback(const DevWorld &w, hipStream_t st) {
-    int nb = (w.n_bodies + 255) / 256;
+    int nb = (w.n_bodies + 255) / 256; if (nb < 1) nb = 1;
     int cb = (w.cons_cap + 255) / 256; if (cb > 2048) cb = 2048; if (cb < 1) cb = 1;
     hipLaunchKernelGGL(k_writeback_impulses, dim3(cb), dim3(256), 0, st, w);
     hipLaunchKernelGGL(k_writeback_bodies, dim3(nb), dim3(256), 0, st, w);
