@@ -1,0 +1,155 @@
+#!/usr/bin/env python
+"""bench.py — physics steps/sec on b3d_many_pyramids (BASELINE.json metric), MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+A "step" is one PhysicsPipeline::step() of the resident world (inputs already in HBM).  N = 1: the
+workload is BASELINE config C3 = b3d_many_pyramids (14x14 pyramids, 10,780 cuboids, M = 28,420
+solver manifolds).  N > 1: weak scaling over independent contact islands: the node
+holds a 14 x 14N pyramid world, rank r owns pyramid columns [14r, 14r+14) (ground replicated) and
+steps them with NO data-path collective; `value` = N * K / t_max = many_pyramids-sized world-steps
+per second across the node.  One all-gather of packed body state (RCCL) after the timed region
+assembles the world on every rank (readback, not timed).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes_per_step(M: int, N: int, substeps: int = 4) -> float:
+    """B_solve(step) = S * [ M * (1100 + 476 + 1008) + N * 224 ] bytes."""
+    return substeps * (M * (1100.0 + 476.0 + 1008.0) + N * 224.0)
+
+
+def cpu_baseline(steps: int = 120, warmup: int = 60):
+    """The C oracle (a scalar port of the reference algorithm) timed on ONE host core on a bounded
+    sample of the same workload."""
+    from rapier_amd import scenes as S
+    from oracle_ffi import OracleWorld
+    w = OracleWorld(S.many_pyramids())
+    w.step(warmup)
+    t = time.perf_counter()
+    w.step(steps)
+    dt = time.perf_counter() - t
+    return {"value": steps / dt, "unit": "steps/s", "cores": 1, "kind": "port",
+            "sample": f"{steps} steps of b3d_many_pyramids (10,780 cuboids) after {warmup} warm-up steps, oracle/librapier_oracle.so, 1 thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=60)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roofline-steps", type=int, default=200)
+    args = ap.parse_args()
+
+    import torch  # first: the HIP runtime that torch loads is the one the library binds to
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+
+    import numpy as np
+    from rapier_amd import PhysicsWorld, scenes as S, sharding
+
+    if world > 1:
+        scene = S.many_pyramids(rows=14, cols=14 * world, col_range=(14 * rank, 14 * rank + 14))
+        workload = f"b3d_many_pyramids weak-scaled: 14x{14 * world} pyramids, rank owns 14x14 (10,780 cuboids/GPU)"
+    else:
+        scene = S.many_pyramids()
+        workload = "b3d_many_pyramids (14x14 pyramids, 10,780 cuboids, f32, dt=1/60, 4 substeps)"
+    w = PhysicsWorld.from_scene(scene, device=local_rank)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    w.step(args.warmup)
+    w.sync()
+    barrier()
+    t0 = time.perf_counter()
+    w.step(args.steps)
+    w.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    counters = w.counters()
+    M, Nd = counters["num_manifolds"], counters["num_dynamic_bodies"]
+
+    # roofline leg: hipEvent-timed TGS velocity-solve loop on the world's own stream
+    w.enable_timers(True)
+    w.step(args.roofline_steps)
+    w.sync()
+    loop_ms, nmeas = w.solver_loop_time_ms()
+    tc = w.counters()
+    w.enable_timers(False)
+    bytes_step = algorithmic_bytes_per_step(M, Nd, int(scene.params["num_solver_iterations"]))
+    achieved = bytes_step / (loop_ms * 1e-3) / 1e9 if loop_ms > 0 else 0.0
+
+    # readback (not timed): assemble the world state with one all-gather over RCCL/xGMI
+    pos, vel = w.read_bodies()
+    finite = bool(np.isfinite(pos).all())
+    if dist is not None:
+        dyn = np.array([int(b["body_type"]) == S.BODY_DYNAMIC for b in scene.bodies])
+        per = 55
+        gids = np.concatenate([[0], 1 + (np.arange(14 * 14 * per) // (14 * per)) * (14 * world * per) + rank * 14 * per + (np.arange(14 * 14 * per) % (14 * per))])
+        gpos, _ = sharding.all_gather_bodies(pos, vel, gids, 1 + 14 * 14 * world * per, dyn, device="cuda")
+        finite = finite and bool(np.isfinite(gpos).all())
+
+    if rank == 0:
+        out = {
+            "metric": "physics steps/sec (whole node), b3d_many_pyramids 3D f32",
+            "value": world * args.steps / dt,
+            "unit": "steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (closed-form scene generator, no RNG)",
+            "config": {"workload": workload, "bodies_per_gpu": Nd, "solver_manifolds_per_gpu": M,
+                       "colors": counters["num_colors"], "value_definition": "n_gpus * steps / max-over-ranks time"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "TGS velocity-solve loop (k_increment/k_stage<ws|bias|relax>/k_tail/k_integrate x 4 substeps)",
+                         "algorithmic_bytes_per_step": bytes_step, "loop_ms_per_step": loop_ms, "measured_steps": nmeas,
+                         "stage_ms": {k: tc[k] for k in ("collision_detection_ms", "velocity_assembly_ms", "velocity_resolution_ms", "velocity_update_ms")}},
+            "finite": finite,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
