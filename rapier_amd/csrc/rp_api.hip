@@ -24,6 +24,8 @@ void rp_launch_init_bodies(const DevWorld &w, hipStream_t st);
 void rp_launch_solver_assembly(const DevWorld &w, hipStream_t st);
 void rp_launch_solver_loop(const DevWorld &w, hipStream_t st, int parallel_stages, int stage_blocks, int has_restitution);
 void rp_launch_solver_writeback(const DevWorld &w, hipStream_t st);
+void rp_launch_global_single(const DevWorld &w, hipStream_t st, int has_restitution);
+void rp_launch_island_solve(const DevWorld &w, hipStream_t st, int grid, int has_restitution);
 
 struct HostBody { rp_body_desc d; float inv_mass; float inv_pi[3]; float lcom[3]; int ncolliders; };
 
@@ -42,12 +44,12 @@ struct rp_world {
     DevWorld dw;
     int *pinned_flags = nullptr; // FL_COUNT ints, written by an async D2H copy at the end of each step
     // launch plan + graph
-    int plan_stages = 0, plan_blocks = 1;
+    int plan_stages = 0, plan_blocks = 1, plan_single = 1, plan_island_grid = 1;
     bool has_restitution = false;
     hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;
     hipGraph_t g_col = nullptr, g_asm = nullptr, g_loop = nullptr, g_fin = nullptr;
     hipGraphExec_t ge_col = nullptr, ge_asm = nullptr, ge_loop = nullptr, ge_fin = nullptr;
-    int graph_stages = -1, graph_blocks = -1;
+    int graph_stages = -1, graph_blocks = -1, graph_single = -1, graph_island_grid = -1;
     bool use_graph = true;
     // timers
     bool timers = false;
@@ -160,7 +162,7 @@ static void destroy_graphs(rp_world *w) {
     hipGraph_t *gr[] = {&w->graph, &w->g_col, &w->g_asm, &w->g_loop, &w->g_fin};
     for (auto e : ex) if (*e) { hipGraphExecDestroy(*e); *e = nullptr; }
     for (auto g : gr) if (*g) { hipGraphDestroy(*g); *g = nullptr; }
-    w->graph_stages = -1; w->graph_blocks = -1;
+    w->graph_stages = -1; w->graph_blocks = -1; w->graph_single = -1; w->graph_island_grid = -1;
 }
 static void free_device(rp_world *w) {
     destroy_graphs(w);
@@ -342,6 +344,11 @@ static int finalize(rp_world *w) {
     DA(d.color_count, RP_NUM_COLORS + 1); DA(d.color_begin, RP_NUM_COLORS + 1); DA(d.color_cursor, RP_NUM_COLORS + 1);
     DA(d.stage_color, RP_NUM_COLORS + 1); DA(d.stage_begin, RP_NUM_COLORS + 1); DA(d.stage_count, RP_NUM_COLORS + 1);
     DA(d.cons_pair, d.cons_cap); DAF(d.p_conspos, P, 0xff);
+    DA(d.color_count_glob, RP_NUM_COLORS + 1); DA(d.color_rank, RP_NUM_COLORS + 1);
+    DA(d.b_label, nb); DAF(d.b_island, nb, 0xff); DAF(d.b_local, nb, 0xff); DA(d.r_nb, nb); DA(d.r_nc, nb); DAF(d.r_island, nb, 0xff);
+    DAF(d.p_island, P, 0xff);
+    DA(d.isl_body_begin, nb); DA(d.isl_nb, nb); DA(d.isl_cons_begin, nb); DA(d.isl_nc, nb); DA(d.isl_fill_b, nb); DA(d.isl_fill_c, nb);
+    DA(d.isl_bodies, nb); DA(d.isl_cons, P);
     DA(d.C, (size_t)CP_COUNT * d.cons_cap);
     DA(d.k_b1, d.cons_cap); DA(d.k_b2, d.cons_cap); DA(d.k_n, d.cons_cap); DA(d.k_cid, d.cons_cap);
 
@@ -404,22 +411,32 @@ static void enqueue_collision(rp_world *w) {
     rp_launch_broadphase(w->dw, w->stream);
     rp_launch_narrowphase(w->dw, w->stream);
 }
-static void enqueue_assembly(rp_world *w) { rp_launch_solver_assembly(w->dw, w->stream); }
-static void enqueue_loop(rp_world *w) { rp_launch_solver_loop(w->dw, w->stream, w->plan_stages, w->plan_blocks, w->has_restitution ? 1 : 0); }
+// build_islands_and_solve_velocity_constraints: LDS island megakernel + the global path
+static void enqueue_solver(rp_world *w) {
+    int hr = w->has_restitution ? 1 : 0;
+    rp_launch_island_solve(w->dw, w->stream, w->plan_island_grid, hr);
+    if (w->plan_single) rp_launch_global_single(w->dw, w->stream, hr);
+    else {
+        rp_launch_solver_assembly(w->dw, w->stream);
+        rp_launch_solver_loop(w->dw, w->stream, w->plan_stages, w->plan_blocks, hr);
+        rp_launch_solver_writeback(w->dw, w->stream);
+    }
+}
 static void enqueue_finish(rp_world *w) {
-    rp_launch_solver_writeback(w->dw, w->stream);
     rp_launch_collider_update(w->dw, w->stream);
     hipMemcpyAsync(w->pinned_flags, w->dw.flags, FL_COUNT * sizeof(int), hipMemcpyDeviceToHost, w->stream);
 }
 
+static int pow2_ceil(int x) { int b = 1; while (b < x) b <<= 1; return b; }
 static void plan_from_hints(rp_world *w, const int *fl) {
-    int npar = fl[FL_N_PARALLEL];
-    int maxs = fl[FL_MAX_STAGE];
-    w->plan_stages = npar;
-    int blocks = (maxs + 255) / 256;
+    // global path: one workgroup is enough while it holds little work, else one launch per colour stage
+    w->plan_single = (fl[FL_N_CONS] <= 1024 && fl[FL_N_GLOB_BODIES] <= 4096) ? 1 : 0;
+    const char *force = getenv("RP_FORCE_MULTI");
+    if (force && force[0] == '1') w->plan_single = 0;
+    w->plan_stages = fl[FL_N_PARALLEL];
     // round up to a power of two so small changes of the stage size do not force a re-capture
-    int b = 1; while (b < blocks) b <<= 1;
-    w->plan_blocks = std::min(std::max(b, 1), 4096);
+    w->plan_blocks = std::min(std::max(pow2_ceil((fl[FL_MAX_STAGE] + 255) / 256), 1), 4096);
+    w->plan_island_grid = std::min(std::max(pow2_ceil(fl[FL_N_ISLANDS]), 1), 8192);
 }
 
 static int capture(rp_world *w, hipGraph_t *g, hipGraphExec_t *ge, void (*fn)(rp_world *)) {
@@ -429,7 +446,7 @@ static int capture(rp_world *w, hipGraph_t *g, hipGraphExec_t *ge, void (*fn)(rp
     HIPCHK(w, hipGraphInstantiate(ge, *g, nullptr, nullptr, 0));
     return RP_OK;
 }
-static void enqueue_whole(rp_world *w) { enqueue_collision(w); enqueue_assembly(w); enqueue_loop(w); enqueue_finish(w); }
+static void enqueue_whole(rp_world *w) { enqueue_collision(w); enqueue_solver(w); enqueue_finish(w); }
 
 static int check_overflow(rp_world *w, const int *fl) {
     if (fl[FL_OVERFLOW]) {
@@ -454,7 +471,7 @@ static int step_once(rp_world *w) {
         if (r != RP_OK) return r;
         plan_from_hints(w, fl);
         memcpy(w->pinned_flags, fl, sizeof(fl));
-        enqueue_assembly(w); enqueue_loop(w); enqueue_finish(w);
+        enqueue_solver(w); enqueue_finish(w);
         w->hints_valid = true;
         HIPCHK(w, hipGetLastError());
         return RP_OK;
@@ -463,45 +480,48 @@ static int step_once(rp_world *w) {
     {
         int fl[FL_COUNT];
         memcpy(fl, w->pinned_flags, sizeof(fl));
-        int old_s = w->plan_stages, old_b = w->plan_blocks;
+        int old_b = w->plan_blocks, old_g = w->plan_island_grid;
         plan_from_hints(w, fl);
         if (w->plan_blocks < old_b && w->plan_blocks * 2 >= old_b) w->plan_blocks = old_b; // hysteresis
-        (void)old_s;
+        if (w->plan_island_grid < old_g && w->plan_island_grid * 2 >= old_g) w->plan_island_grid = old_g;
     }
+    auto plan_changed = [&]() {
+        return w->graph_stages != w->plan_stages || w->graph_blocks != w->plan_blocks || w->graph_single != w->plan_single ||
+               w->graph_island_grid != w->plan_island_grid;
+    };
+    auto plan_commit = [&]() {
+        w->graph_stages = w->plan_stages; w->graph_blocks = w->plan_blocks; w->graph_single = w->plan_single; w->graph_island_grid = w->plan_island_grid;
+    };
     if (w->timers) {
-        // four sub-graphs with events in between (Counters from hipEvents)
-        if (!w->ge_col || w->graph_stages != w->plan_stages || w->graph_blocks != w->plan_blocks) {
+        // three sub-graphs with events in between (Counters from hipEvents)
+        if (!w->ge_col || plan_changed()) {
             destroy_graphs(w);
             int r;
             if ((r = capture(w, &w->g_col, &w->ge_col, enqueue_collision)) != RP_OK) return r;
-            if ((r = capture(w, &w->g_asm, &w->ge_asm, enqueue_assembly)) != RP_OK) return r;
-            if ((r = capture(w, &w->g_loop, &w->ge_loop, enqueue_loop)) != RP_OK) return r;
+            if ((r = capture(w, &w->g_loop, &w->ge_loop, enqueue_solver)) != RP_OK) return r;
             if ((r = capture(w, &w->g_fin, &w->ge_fin, enqueue_finish)) != RP_OK) return r;
-            w->graph_stages = w->plan_stages; w->graph_blocks = w->plan_blocks;
+            plan_commit();
         }
         HIPCHK(w, hipEventRecord(w->ev[0], w->stream));
         HIPCHK(w, hipGraphLaunch(w->ge_col, w->stream));
         HIPCHK(w, hipEventRecord(w->ev[1], w->stream));
-        HIPCHK(w, hipGraphLaunch(w->ge_asm, w->stream));
-        HIPCHK(w, hipEventRecord(w->ev[2], w->stream));
         HIPCHK(w, hipGraphLaunch(w->ge_loop, w->stream));
-        HIPCHK(w, hipEventRecord(w->ev[3], w->stream));
+        HIPCHK(w, hipEventRecord(w->ev[2], w->stream));
         HIPCHK(w, hipGraphLaunch(w->ge_fin, w->stream));
-        HIPCHK(w, hipEventRecord(w->ev[4], w->stream));
-        HIPCHK(w, hipEventSynchronize(w->ev[4]));
-        float a = 0, b = 0, c = 0, d = 0;
-        hipEventElapsedTime(&a, w->ev[0], w->ev[1]); hipEventElapsedTime(&b, w->ev[1], w->ev[2]);
-        hipEventElapsedTime(&c, w->ev[2], w->ev[3]); hipEventElapsedTime(&d, w->ev[3], w->ev[4]);
-        w->acc_col_ms += a; w->acc_asm_ms += b; w->acc_loop_ms += c; w->acc_fin_ms += d; w->acc_step_ms += a + b + c + d; w->acc_steps++;
+        HIPCHK(w, hipEventRecord(w->ev[3], w->stream));
+        HIPCHK(w, hipEventSynchronize(w->ev[3]));
+        float a = 0, c = 0, d = 0;
+        hipEventElapsedTime(&a, w->ev[0], w->ev[1]); hipEventElapsedTime(&c, w->ev[1], w->ev[2]); hipEventElapsedTime(&d, w->ev[2], w->ev[3]);
+        w->acc_col_ms += a; w->acc_loop_ms += c; w->acc_fin_ms += d; w->acc_step_ms += a + c + d; w->acc_steps++;
         w->loop_ms_since_read += c; w->loop_steps_since_read++;
         return RP_OK;
     }
     if (!w->use_graph) { enqueue_whole(w); HIPCHK(w, hipGetLastError()); return RP_OK; }
-    if (!w->graph_exec || w->graph_stages != w->plan_stages || w->graph_blocks != w->plan_blocks) {
+    if (!w->graph_exec || plan_changed()) {
         destroy_graphs(w);
         int r = capture(w, &w->graph, &w->graph_exec, enqueue_whole);
         if (r != RP_OK) return r;
-        w->graph_stages = w->plan_stages; w->graph_blocks = w->plan_blocks;
+        plan_commit();
     }
     HIPCHK(w, hipGraphLaunch(w->graph_exec, w->stream));
     return RP_OK;
@@ -638,7 +658,7 @@ extern "C" int32_t rp_counters_read(rp_world *w, rp_counters *out) {
         live = top - fl[FL_FREE_TOP];
     }
     out->num_pairs = live;
-    out->num_manifolds = fl[FL_N_CONS];
+    out->num_manifolds = fl[FL_N_CONS_ALL];
     out->num_solver_contacts = fl[FL_N_SC];
     out->num_colors = fl[FL_N_COLORS];
     out->num_parallel_stages = fl[FL_N_PARALLEL];

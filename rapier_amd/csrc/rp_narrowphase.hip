@@ -561,50 +561,55 @@ __global__ void __launch_bounds__(1024) k_color_pairs(DevWorld w) {
 // ------------------------------------------------------------------------------------------
 // Solver contact graph buckets (maintain_solver_contact_graph, solver_graph.rs:129-361) and the
 // stage order of init.rs:163-254: colours with >= 32 four-lane chunks ascending, then the smaller
-// colours ascending; the overflow colour is always swept last (serially).
+// colours ascending; the overflow colour is always swept last (serially).  The order is decided
+// from ALL active manifolds per colour (the reference's bucket sizes); positions in the global
+// constraint planes are only handed to manifolds that are not solved by the island kernel.
+void rp_launch_islands_build(const DevWorld &w, hipStream_t st);
+
+__global__ void k_bucket_clear(DevWorld w) {
+    if (!w.flags[FL_LAYOUT_DIRTY]) return;
+    if (threadIdx.x < RP_NUM_COLORS) { w.color_count[threadIdx.x] = 0; w.color_count_glob[threadIdx.x] = 0; }
+    if (threadIdx.x == 0) w.flags[FL_N_SC] = 0;
+}
 __global__ void k_bucket_count(DevWorld w) {
     if (!w.flags[FL_LAYOUT_DIRTY]) return;
     int top = w.flags[FL_POOL_TOP];
     if (top > w.pool_cap) top = w.pool_cap;
     int stride = gridDim.x * blockDim.x;
     for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < top; s += stride) {
-        if (w.p_c1[s] < 0 || w.p_nsc[s] == 0) { if (s < w.pool_cap) w.p_conspos[s] = -1; continue; }
+        w.p_conspos[s] = -1;
+        if (w.p_c1[s] < 0 || w.p_nsc[s] == 0) continue;
         int color = w.p_color[s];
         if (color > RP_COLOR_OVERFLOW) continue;
         atomicAdd(&w.color_count[color], 1);
         atomicAdd(&w.flags[FL_N_SC], w.p_nsc[s]);
     }
 }
-__global__ void k_bucket_clear(DevWorld w) {
-    if (!w.flags[FL_LAYOUT_DIRTY]) return;
-    if (threadIdx.x < RP_NUM_COLORS) w.color_count[threadIdx.x] = 0;
-    if (threadIdx.x == 0) w.flags[FL_N_SC] = 0;
-}
 __global__ void k_bucket_layout(DevWorld w) {
     if (!w.flags[FL_LAYOUT_DIRTY]) return;
     if (threadIdx.x != 0) return;
-    // constraint positions are laid out stage by stage so that each stage is a contiguous column range
-    int nst = 0, npar = 0, pos = 0, maxs = 0, ncol = 0;
+    int nst = 0, npar = 0, pos = 0, maxs = 0, ncol = 0, mall = 0;
     for (int pass = 0; pass < 2; ++pass)
         for (int c = 0; c < RP_NUM_COLORS - 1; ++c) {
             int n = w.color_count[c];
             if (n == 0) continue;
             bool par = n >= RP_PARALLEL_MIN_MANIFOLDS;
             if ((pass == 0) != par) continue;
-            w.stage_color[nst] = c; w.stage_begin[nst] = pos; w.stage_count[nst] = n;
-            w.color_begin[c] = pos; w.color_cursor[c] = pos;
-            pos += n; nst++; ncol++;
+            int ng = w.color_count_glob[c];
+            w.stage_color[nst] = c; w.stage_begin[nst] = pos; w.stage_count[nst] = ng;
+            w.color_begin[c] = pos; w.color_cursor[c] = pos; w.color_rank[c] = nst;
+            pos += ng; nst++; ncol++; mall += n;
             if (par) npar++;
-            if (n > maxs) maxs = n;
+            if (ng > maxs) maxs = ng;
         }
-    int nov = w.color_count[RP_COLOR_OVERFLOW];
-    w.stage_color[nst] = RP_COLOR_OVERFLOW; w.stage_begin[nst] = pos; w.stage_count[nst] = nov;
-    w.color_begin[RP_COLOR_OVERFLOW] = pos; w.color_cursor[RP_COLOR_OVERFLOW] = pos;
-    pos += nov;
+    int nov = w.color_count[RP_COLOR_OVERFLOW], novg = w.color_count_glob[RP_COLOR_OVERFLOW];
+    w.stage_color[nst] = RP_COLOR_OVERFLOW; w.stage_begin[nst] = pos; w.stage_count[nst] = novg;
+    w.color_begin[RP_COLOR_OVERFLOW] = pos; w.color_cursor[RP_COLOR_OVERFLOW] = pos; w.color_rank[RP_COLOR_OVERFLOW] = nst;
+    pos += novg; mall += nov;
     if (nov) ncol++;
     w.flags[FL_N_STAGES] = nst; w.flags[FL_N_PARALLEL] = npar; w.flags[FL_MAX_STAGE] = maxs;
-    w.flags[FL_HAS_OVERFLOW_COLOR] = nov > 0; w.flags[FL_N_COLORS] = ncol;
-    w.flags[FL_N_CONS] = pos;
+    w.flags[FL_HAS_OVERFLOW_COLOR] = novg > 0; w.flags[FL_N_COLORS] = ncol;
+    w.flags[FL_N_CONS] = pos; w.flags[FL_N_CONS_ALL] = mall;
     if (pos > w.cons_cap) atomicOr(&w.flags[FL_OVERFLOW], RP_OVF_CONS);
 }
 __global__ void k_bucket_scatter(DevWorld w) {
@@ -613,7 +618,7 @@ __global__ void k_bucket_scatter(DevWorld w) {
     if (top > w.pool_cap) top = w.pool_cap;
     int stride = gridDim.x * blockDim.x;
     for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < top; s += stride) {
-        if (w.p_c1[s] < 0 || w.p_nsc[s] == 0) continue;
+        if (w.p_c1[s] < 0 || w.p_nsc[s] == 0 || w.p_island[s] >= 0) continue;
         int color = w.p_color[s];
         if (color > RP_COLOR_OVERFLOW) continue;
         int pos = atomicAdd(&w.color_cursor[color], 1);
@@ -630,6 +635,7 @@ void rp_launch_narrowphase(const DevWorld &w, hipStream_t st) {
     hipLaunchKernelGGL(k_color_pairs, dim3(1), dim3(1024), 0, st, w);
     hipLaunchKernelGGL(k_bucket_clear, dim3(1), dim3(256), 0, st, w);
     hipLaunchKernelGGL(k_bucket_count, dim3(blocks), dim3(256), 0, st, w);
+    rp_launch_islands_build(w, st);
     hipLaunchKernelGGL(k_bucket_layout, dim3(1), dim3(64), 0, st, w);
     hipLaunchKernelGGL(k_bucket_scatter, dim3(blocks), dim3(256), 0, st, w);
     hipLaunchKernelGGL(k_bucket_finish, dim3(1), dim3(1), 0, st, w);

@@ -18,6 +18,8 @@
 #define RP_MAX_PTS 8                 // manifold points kept per pair (face/face clip max)
 #define RP_PARALLEL_MIN_MANIFOLDS 125 // ceil(n/4) >= 32 chunks  (init.rs:169, mod.rs:41-57)
 #define RP_EMPTY_KEY 0xffffffffffffffffull
+#define RP_ISL_NB_MAX 64             // bodies per LDS-resident island
+#define RP_ISL_NC_MAX 160            // solver manifolds per LDS-resident island
 #define RP_FID_UNKNOWN 0xffffu
 
 // body flag bits
@@ -59,6 +61,10 @@ enum {
     FL_N_COLORS,
     FL_BP_REBUILDS,
     FL_STEP,            // step counter
+    FL_N_ISLANDS,       // small islands solved by the LDS island kernel
+    FL_N_GLOB_BODIES,   // dynamic bodies outside small islands (global path)
+    FL_N_CONS_ALL,      // M: all active solver manifolds (island + global)
+    FL_ISL_BODY_CURSOR, FL_ISL_CONS_CURSOR,
     FL_COUNT = 32
 };
 
@@ -174,6 +180,16 @@ struct DevWorld {
     int *color_count, *color_begin, *color_cursor, *stage_color, *stage_begin, *stage_count;
     int *cons_pair;             // [cons_cap] position -> pair slot
     int *p_conspos;             // pair slot -> position (or -1)
+    int *color_count_glob;      // per colour: manifolds on the global (non-island) path
+    int *color_rank;            // colour -> stage index in the sweep order
+
+    // ---- contact islands (connected components of dynamic bodies over active manifolds) ----
+    int *b_label;               // union-find labels
+    int *b_island, *b_local;    // island id (>= 0: LDS island path, -1: global path), index inside the island
+    int *r_nb, *r_nc, *r_island; // per-root scratch: body count, manifold count, island id
+    int *p_island;              // pair slot -> island id or -1
+    int *isl_body_begin, *isl_nb, *isl_cons_begin, *isl_nc, *isl_fill_b, *isl_fill_c;
+    int *isl_bodies, *isl_cons;
 
     // ---- constraints ----
     float4 *C;                  // [CP_COUNT][cons_cap]
