@@ -348,7 +348,7 @@ static int finalize(rp_world *w) {
     DA(d.b_label, nb); DAF(d.b_island, nb, 0xff); DAF(d.b_local, nb, 0xff); DA(d.r_nb, nb); DA(d.r_nc, nb); DAF(d.r_island, nb, 0xff);
     DAF(d.p_island, P, 0xff);
     DA(d.isl_body_begin, nb); DA(d.isl_nb, nb); DA(d.isl_cons_begin, nb); DA(d.isl_nc, nb); DA(d.isl_fill_b, nb); DA(d.isl_fill_c, nb);
-    DA(d.isl_bodies, nb); DA(d.isl_cons, P);
+    DA(d.isl_bodies, nb); DA(d.isl_cons, P); DA(d.isl_cstage, P); DA(d.isl_sorted, nb); DA(d.isl_nstages, nb);
     DA(d.C, (size_t)CP_COUNT * d.cons_cap);
     DA(d.k_b1, d.cons_cap); DA(d.k_b2, d.cons_cap); DA(d.k_n, d.cons_cap); DA(d.k_cid, d.cons_cap);
 

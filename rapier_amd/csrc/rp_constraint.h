@@ -70,11 +70,13 @@ RP_DEV bool cons_generate(const DevWorld &w, const Acc &A, int s, int gid1, int 
 
     V3 friction_center = v3(0, 0, 0), friction_center2 = v3(0, 0, 0), tangent_vel = v3(0, 0, 0);
     float twist_warmstart = 0.0f, tw0 = 0.0f, tw1 = 0.0f;
-    V3 points[4];
+    V3 points0 = v3(0, 0, 0), points1 = points0, points2 = points0, points3 = points0;
     int cids = 0;
     bool bouncy_seed = false;
     V3 imsum = im1 + im2;
-    for (int k = 0; k < count; ++k) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k >= count) break;
         float weight = inv_num_points;
         float4 a1 = PT(w.sc_a1, k, s), a2 = PT(w.sc_a2, k, s);
         int cid = __float_as_int(a2.w);
@@ -91,7 +93,7 @@ RP_DEV bool cons_generate(const DevWorld &w, const Acc &A, int s, int gid1, int 
         float dist = dot(p1 - p2, force_dir1);
         V3 dp1 = v3(PT(w.pt_dp1, cid, s)), dp2 = v3(PT(w.pt_dp2, cid, s));
         V3 point = world_com1 + dp1;
-        points[k] = point;
+        if (k == 0) points0 = point; else if (k == 1) points1 = point; else if (k == 2) points2 = point; else points3 = point;
         friction_center = friction_center + point * weight;
         friction_center2 = friction_center2 + (world_com2 + dp2) * weight;
         V3 vel1 = vels1.lin + cross(vels1.ang, dp1);
@@ -121,9 +123,10 @@ RP_DEV bool cons_generate(const DevWorld &w, const Acc &A, int s, int gid1, int 
     float twist_r = 0.0f;
     float4 tdists = make_float4(0, 0, 0, 0);
     if (count > 1) {
-        float td[4] = {0, 0, 0, 0};
-        for (int k = 0; k < count; ++k) td[k] = len(friction_center - points[k]);
-        tdists = make_float4(td[0], td[1], td[2], td[3]);
+        tdists.x = len(friction_center - points0);
+        tdists.y = len(friction_center - points1);
+        if (count > 2) tdists.z = len(friction_center - points2);
+        if (count > 3) tdists.w = len(friction_center - points3);
         V3 ii_twist_dir1 = sym_mul(ii1, force_dir1);
         V3 ii_twist_dir2 = sym_mul(ii2, -force_dir1);
         twist_r = rp_inv(dot(ii_twist_dir1, force_dir1) + dot(ii_twist_dir2, -force_dir1));
@@ -179,7 +182,9 @@ RP_DEV void cons_update_warmstart(const DevWorld &w, const Acc &A, float solved_
     V3 im1 = v3(A.ld(CP_H1)), im2 = v3(A.ld(CP_H2));
     Vel v1 = A.vel(id1), v2 = A.vel(id2);
     bool ws = wc != 0.0f;
-    for (int k = 0; k < n; ++k) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k >= n) break;
         float4 m = A.ld(NPL(k, NP_M));
         float4 c = A.ld(NPL(k, NP_C)), d = A.ld(NPL(k, NP_D));
         V3 p1 = xf_tp(x1, v3(A.ld(NPL(k, NP_E)))) + tangent_delta;
@@ -313,11 +318,14 @@ template <class Acc>
 RP_DEV void cons_restitution(const DevWorld &w, const Acc &A) {
     int id1 = A.id1(), id2 = A.id2(), n = A.n();
     bool any = false;
-    for (int k = 0; k < n; ++k) any |= A.ld(NPL(k, NP_B)).w < 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { if (k >= n) break; any |= A.ld(NPL(k, NP_B)).w < 0.0f; }
     if (!any) return;
     V3 dir1 = v3(A.ld(CP_H0)), im1 = v3(A.ld(CP_H1)), im2 = v3(A.ld(CP_H2));
     Vel v1 = A.vel(id1), v2 = A.vel(id2);
-    for (int k = 0; k < n; ++k) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k >= n) break;
         float4 m = A.ld(NPL(k, NP_M));
         float4 a = A.ld(NPL(k, NP_A)), b = A.ld(NPL(k, NP_B)), c = A.ld(NPL(k, NP_C)), d = A.ld(NPL(k, NP_D));
         float seed = b.w;
@@ -342,7 +350,9 @@ RP_DEV void cons_writeback(const DevWorld &w, const Acc &A, int s) {
     float4 h0 = A.ld(CP_H0), h6 = A.ld(CP_H6), hm0 = A.ld(CP_HM0);
     V3 dir1 = v3(h0), t0 = v3(h6), t1 = cross(dir1, t0);
     V3 wtw = t0 * hm0.z + t1 * hm0.w;
-    for (int k = 0; k < n; ++k) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k >= n) break;
         int cid = (cids >> (8 * k)) & 0xff;
         float4 m = A.ld(NPL(k, NP_M));
         PT(w.pt_imp, cid, s) = make_float4(m.w + m.z, m.z, hm0.x, 0.0f);

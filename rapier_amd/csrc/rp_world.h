@@ -190,6 +190,8 @@ struct DevWorld {
     int *p_island;              // pair slot -> island id or -1
     int *isl_body_begin, *isl_nb, *isl_cons_begin, *isl_nc, *isl_fill_b, *isl_fill_c;
     int *isl_bodies, *isl_cons;
+    int *isl_cstage;            // [pool] local stage index of isl_cons[i] once the island list is sorted
+    int *isl_sorted, *isl_nstages; // per island: list sorted by sweep stage?, number of local stages
 
     // ---- constraints ----
     float4 *C;                  // [CP_COUNT][cons_cap]

@@ -1,4 +1,4 @@
-"""Step a scene N times on the GPU (profiling driver for rocprofv3)."""
+"""Step a scene N times on the GPU (profiling driver for rocprofv3); prints steps/s and per-stage ms."""
 import os
 import sys
 import time
@@ -9,8 +9,13 @@ from rapier_amd import PhysicsWorld, scenes as S  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "many_pyramids"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-scene = {"many_pyramids": S.many_pyramids, "large_pyramid": S.large_pyramid, "pyramid10": S.pyramid10}[name]()
+scene = {"many_pyramids": S.many_pyramids, "large_pyramid": S.large_pyramid, "pyramid10": S.pyramid10,
+         "joint_grid": getattr(S, "joint_grid", None)}[name]()
 w = PhysicsWorld.from_scene(scene)
 w.step(60); w.sync()
 t = time.time(); w.step(steps); w.sync(); dt = time.time() - t
 print(f"{name}: {steps / dt:.1f} steps/s  {dt / steps * 1e3:.3f} ms/step", w.counters())
+if os.environ.get("RP_PROF_TIMERS", "1") == "1":
+    w.enable_timers(True); w.step(50); w.sync()
+    c = w.counters()
+    print(f"{name} stage ms: collision {c['collision_detection_ms']:.4f} solver-loop {c['velocity_resolution_ms']:.4f} finish {c['velocity_update_ms']:.4f}")
