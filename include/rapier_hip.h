@@ -117,6 +117,9 @@ typedef struct rp_counters {
     int32_t full_updates;          /* narrow-phase full updates in the last step */
     int32_t overflow_flags;        /* nonzero = a device buffer overflowed (see rp_last_error) */
     int32_t quarantined;           /* bodies with non-finite state detected (Quarantine) */
+    int32_t fast_steps;            /* step graphs enqueued on the steady-state fast path */
+    int32_t full_steps;            /* step graphs enqueued on the full path */
+    int32_t replayed_steps;        /* fast steps that gave up on the device and were replayed on the full path */
 } rp_counters;
 
 #define RP_INVALID_HANDLE 0xffffffffffffffffull

@@ -30,7 +30,8 @@ class Counters(C.Structure):
         "island_construction_ms", "solver_ms", "velocity_assembly_ms", "velocity_resolution_ms",
         "velocity_update_ms")] + [(n, C.c_int32) for n in (
         "num_pairs", "num_manifolds", "num_solver_contacts", "num_colors", "num_parallel_stages",
-        "num_dynamic_bodies", "bp_rebuilds", "full_updates", "overflow_flags", "quarantined")]
+        "num_dynamic_bodies", "bp_rebuilds", "full_updates", "overflow_flags", "quarantined",
+        "fast_steps", "full_steps", "replayed_steps")]
 
 
 _LIB = None

@@ -8,6 +8,17 @@
 // The host never needs device-side counts to be correct: kernels size themselves from device
 // scalars and the solver's single-workgroup tail absorbs any colour stage the host did not launch.
 // Layout hints (parallel colour count, largest stage) are read lazily from pinned memory.
+//
+// Two graphs exist per world:
+//   * the FULL graph: collider poses/AABBs -> broad phase -> narrow phase -> colouring/buckets/islands
+//     -> solver.  Always correct; ~25 (mostly early-exiting) kernels.
+//   * the FAST graph (steady state): k_fast_front -> k_island_solve -> k_global_single.  k_fast_front
+//     proves on the device that the broad phase and the narrow phase would be no-ops this step (no fat
+//     AABB left, every pair passes its recycle test); if not, it raises FL_FAST_ABORT and the other two
+//     kernels exit without touching the world.  The device counts executed steps (FL_STEP); every host
+//     entry point that observes the world first replays the missing steps through the FULL graph
+//     (settle()).  The physics is identical either way: the fast graph only skips work that the full
+//     graph would have found to be empty.
 #include "rp_world.h"
 #include <algorithm>
 #include <cmath>
@@ -24,8 +35,9 @@ void rp_launch_init_bodies(const DevWorld &w, hipStream_t st);
 void rp_launch_solver_assembly(const DevWorld &w, hipStream_t st);
 void rp_launch_solver_loop(const DevWorld &w, hipStream_t st, int parallel_stages, int stage_blocks, int has_restitution);
 void rp_launch_solver_writeback(const DevWorld &w, hipStream_t st);
-void rp_launch_global_single(const DevWorld &w, hipStream_t st, int has_restitution);
-void rp_launch_island_solve(const DevWorld &w, hipStream_t st, int grid, int has_restitution);
+void rp_launch_global_single(const DevWorld &w, hipStream_t st, int has_restitution, int fast);
+void rp_launch_island_solve(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast);
+void rp_launch_fast_front(const DevWorld &w, hipStream_t st);
 
 struct HostBody { rp_body_desc d; float inv_mass; float inv_pi[3]; float lcom[3]; int ncolliders; };
 
@@ -46,11 +58,16 @@ struct rp_world {
     // launch plan + graph
     int plan_stages = 0, plan_blocks = 1, plan_single = 1, plan_island_grid = 1;
     bool has_restitution = false;
-    hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;
-    hipGraph_t g_col = nullptr, g_asm = nullptr, g_loop = nullptr, g_fin = nullptr;
-    hipGraphExec_t ge_col = nullptr, ge_asm = nullptr, ge_loop = nullptr, ge_fin = nullptr;
+    // [0] = full path, [1] = fast path; "whole" = one graph per step, col/loop/fin = timed thirds
+    hipGraph_t g_whole[2] = {nullptr, nullptr}, g_col[2] = {nullptr, nullptr}, g_loop[2] = {nullptr, nullptr}, g_fin[2] = {nullptr, nullptr};
+    hipGraphExec_t ge_whole[2] = {nullptr, nullptr}, ge_col[2] = {nullptr, nullptr}, ge_loop[2] = {nullptr, nullptr}, ge_fin[2] = {nullptr, nullptr};
     int graph_stages = -1, graph_blocks = -1, graph_single = -1, graph_island_grid = -1;
-    bool use_graph = true;
+    bool use_graph = true, use_fast = true;
+    int cur_fast = 0;              // mode the enqueue_* callbacks capture
+    long long steps_requested = 0; // steps asked for since finalize (device FL_STEP counts the executed ones)
+    long long seq_enqueued = 0;    // step graphs enqueued since finalize (device FL_SEQ counts the retired ones)
+    long long full_until = 0;      // stay on the full graph until this many steps were requested
+    long long fast_steps = 0, full_steps = 0, replayed_steps = 0;
     // timers
     bool timers = false;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -68,6 +85,8 @@ struct rp_world {
             return RP_ERR_DEVICE;                                                                         \
         }                                                                                                 \
     } while (0)
+
+static int settle(rp_world *w);
 
 extern "C" void rp_default_params(rp_integration_params *p) {
     // IntegrationParameters::default() — integration_parameters.rs:379-408
@@ -152,16 +171,20 @@ extern "C" int32_t rp_world_create(const rp_integration_params *params, const fl
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) { delete w; return RP_ERR_DEVICE; }
     const char *g = getenv("RP_NO_GRAPH");
     if (g && g[0] == '1') w->use_graph = false;
+    g = getenv("RP_NO_FAST");
+    if (g && g[0] == '1') w->use_fast = false;
     memset(&w->dw, 0, sizeof(w->dw));
     *out = w;
     return RP_OK;
 }
 
 static void destroy_graphs(rp_world *w) {
-    hipGraphExec_t *ex[] = {&w->graph_exec, &w->ge_col, &w->ge_asm, &w->ge_loop, &w->ge_fin};
-    hipGraph_t *gr[] = {&w->graph, &w->g_col, &w->g_asm, &w->g_loop, &w->g_fin};
-    for (auto e : ex) if (*e) { hipGraphExecDestroy(*e); *e = nullptr; }
-    for (auto g : gr) if (*g) { hipGraphDestroy(*g); *g = nullptr; }
+    for (int m = 0; m < 2; ++m) {
+        hipGraphExec_t *ex[] = {&w->ge_whole[m], &w->ge_col[m], &w->ge_loop[m], &w->ge_fin[m]};
+        hipGraph_t *gr[] = {&w->g_whole[m], &w->g_col[m], &w->g_loop[m], &w->g_fin[m]};
+        for (auto e : ex) if (*e) { hipGraphExecDestroy(*e); *e = nullptr; }
+        for (auto g : gr) if (*g) { hipGraphDestroy(*g); *g = nullptr; }
+    }
     w->graph_stages = -1; w->graph_blocks = -1; w->graph_single = -1; w->graph_island_grid = -1;
 }
 static void free_device(rp_world *w) {
@@ -186,6 +209,7 @@ extern "C" const char *rp_last_error(const rp_world *w) { return w ? w->err.c_st
 extern "C" int32_t rp_params_get(const rp_world *w, rp_integration_params *out) { if (!w || !out) return RP_ERR_INVALID; *out = w->params; return RP_OK; }
 extern "C" int32_t rp_params_set(rp_world *w, const rp_integration_params *in) {
     if (!w || !in) return RP_ERR_INVALID;
+    if (w->finalized) { int r = settle(w); if (r != RP_OK) return r; }
     w->params = *in;
     if (w->finalized) { fill_sim_params(w, w->dw.prm, w->dw.prm.cell_size); destroy_graphs(w); }
     return RP_OK;
@@ -397,8 +421,10 @@ static int finalize(rp_world *w) {
     std::vector<int> fl(FL_COUNT, 0);
     fl[FL_BP_DIRTY] = 1; fl[FL_LAYOUT_DIRTY] = 1;
     UP(d.flags, fl);
-    HIPCHK(w, hipHostMalloc((void **)&w->pinned_flags, FL_COUNT * sizeof(int), hipHostMallocDefault));
+    HIPCHK(w, hipHostMalloc((void **)&w->pinned_flags, FL_COUNT * sizeof(int), hipHostMallocMapped));
     memset(w->pinned_flags, 0, FL_COUNT * sizeof(int));
+    HIPCHK(w, hipHostGetDevicePointer((void **)&d.host_flags, w->pinned_flags, 0));
+    w->steps_requested = 0; w->seq_enqueued = 0; w->full_until = 0;
     rp_launch_init_bodies(d, w->stream);
     rp_launch_collider_update(d, w->stream);
     HIPCHK(w, hipStreamSynchronize(w->stream));
@@ -408,14 +434,16 @@ static int finalize(rp_world *w) {
 }
 
 static void enqueue_collision(rp_world *w) {
+    if (w->cur_fast) { rp_launch_fast_front(w->dw, w->stream); return; }
+    rp_launch_collider_update(w->dw, w->stream);
     rp_launch_broadphase(w->dw, w->stream);
     rp_launch_narrowphase(w->dw, w->stream);
 }
 // build_islands_and_solve_velocity_constraints: LDS island megakernel + the global path
 static void enqueue_solver(rp_world *w) {
     int hr = w->has_restitution ? 1 : 0;
-    rp_launch_island_solve(w->dw, w->stream, w->plan_island_grid, hr);
-    if (w->plan_single) rp_launch_global_single(w->dw, w->stream, hr);
+    rp_launch_island_solve(w->dw, w->stream, w->plan_island_grid, hr, w->cur_fast);
+    if (w->plan_single) rp_launch_global_single(w->dw, w->stream, hr, w->cur_fast);
     else {
         rp_launch_solver_assembly(w->dw, w->stream);
         rp_launch_solver_loop(w->dw, w->stream, w->plan_stages, w->plan_blocks, hr);
@@ -423,8 +451,8 @@ static void enqueue_solver(rp_world *w) {
     }
 }
 static void enqueue_finish(rp_world *w) {
-    rp_launch_collider_update(w->dw, w->stream);
-    hipMemcpyAsync(w->pinned_flags, w->dw.flags, FL_COUNT * sizeof(int), hipMemcpyDeviceToHost, w->stream);
+    // SINGLE mode: k_global_single already published the scalars to the mapped hint buffer
+    if (!w->plan_single) hipMemcpyAsync(w->pinned_flags, w->dw.flags, FL_COUNT * sizeof(int), hipMemcpyDeviceToHost, w->stream);
 }
 
 static int pow2_ceil(int x) { int b = 1; while (b < x) b <<= 1; return b; }
@@ -459,10 +487,49 @@ static int check_overflow(rp_world *w, const int *fl) {
     return RP_OK;
 }
 
-static int step_once(rp_world *w) {
+// Enqueue one step graph.  `fast` selects the steady-state graph (see the file header).
+static int launch_step(rp_world *w, int fast) {
+    w->cur_fast = fast;
+    w->seq_enqueued++;
+    if (fast) w->fast_steps++; else w->full_steps++;
+    if (w->timers) {
+        // three sub-graphs with events in between (Counters from hipEvents)
+        if (!w->ge_col[fast]) {
+            int r;
+            if ((r = capture(w, &w->g_col[fast], &w->ge_col[fast], enqueue_collision)) != RP_OK) return r;
+            if ((r = capture(w, &w->g_loop[fast], &w->ge_loop[fast], enqueue_solver)) != RP_OK) return r;
+            if (!w->plan_single && (r = capture(w, &w->g_fin[fast], &w->ge_fin[fast], enqueue_finish)) != RP_OK) return r;
+        }
+        HIPCHK(w, hipEventRecord(w->ev[0], w->stream));
+        HIPCHK(w, hipGraphLaunch(w->ge_col[fast], w->stream));
+        HIPCHK(w, hipEventRecord(w->ev[1], w->stream));
+        HIPCHK(w, hipGraphLaunch(w->ge_loop[fast], w->stream));
+        HIPCHK(w, hipEventRecord(w->ev[2], w->stream));
+        if (w->ge_fin[fast]) HIPCHK(w, hipGraphLaunch(w->ge_fin[fast], w->stream));
+        HIPCHK(w, hipEventRecord(w->ev[3], w->stream));
+        HIPCHK(w, hipEventSynchronize(w->ev[3]));
+        float a = 0, c = 0, d = 0;
+        hipEventElapsedTime(&a, w->ev[0], w->ev[1]); hipEventElapsedTime(&c, w->ev[1], w->ev[2]); hipEventElapsedTime(&d, w->ev[2], w->ev[3]);
+        if (!fast || !w->pinned_flags[FL_FAST_ABORT]) { // aborted fast steps did no work: keep them out of the averages
+            w->acc_col_ms += a; w->acc_loop_ms += c; w->acc_fin_ms += d; w->acc_step_ms += a + c + d; w->acc_steps++;
+            w->loop_ms_since_read += c; w->loop_steps_since_read++;
+        }
+        return RP_OK;
+    }
+    if (!w->use_graph) { enqueue_whole(w); HIPCHK(w, hipGetLastError()); return RP_OK; }
+    if (!w->ge_whole[fast]) {
+        int r = capture(w, &w->g_whole[fast], &w->ge_whole[fast], enqueue_whole);
+        if (r != RP_OK) return r;
+    }
+    HIPCHK(w, hipGraphLaunch(w->ge_whole[fast], w->stream));
+    return RP_OK;
+}
+
+static int step_once(rp_world *w, bool allow_fast) {
     if (!w->hints_valid) {
         // First step after (re)building the world: run collision detection eagerly and read the
         // colour layout once so the solver launch plan is right from the start.
+        w->cur_fast = 0;
         enqueue_collision(w);
         int fl[FL_COUNT];
         HIPCHK(w, hipMemcpyAsync(fl, w->dw.flags, sizeof(fl), hipMemcpyDeviceToHost, w->stream));
@@ -472,73 +539,82 @@ static int step_once(rp_world *w) {
         plan_from_hints(w, fl);
         memcpy(w->pinned_flags, fl, sizeof(fl));
         enqueue_solver(w); enqueue_finish(w);
+        w->seq_enqueued++; w->full_steps++;
         w->hints_valid = true;
+        w->full_until = w->steps_requested + 2;
         HIPCHK(w, hipGetLastError());
         return RP_OK;
     }
     // lazy hint refresh (values from some already finished step; correctness never depends on them)
+    volatile int *pf = w->pinned_flags;
     {
         int fl[FL_COUNT];
-        memcpy(fl, w->pinned_flags, sizeof(fl));
+        for (int k = 0; k < FL_COUNT; ++k) fl[k] = pf[k];
         int old_b = w->plan_blocks, old_g = w->plan_island_grid;
         plan_from_hints(w, fl);
         if (w->plan_blocks < old_b && w->plan_blocks * 2 >= old_b) w->plan_blocks = old_b; // hysteresis
         if (w->plan_island_grid < old_g && w->plan_island_grid * 2 >= old_g) w->plan_island_grid = old_g;
     }
-    auto plan_changed = [&]() {
-        return w->graph_stages != w->plan_stages || w->graph_blocks != w->plan_blocks || w->graph_single != w->plan_single ||
-               w->graph_island_grid != w->plan_island_grid;
-    };
-    auto plan_commit = [&]() {
-        w->graph_stages = w->plan_stages; w->graph_blocks = w->plan_blocks; w->graph_single = w->plan_single; w->graph_island_grid = w->plan_island_grid;
-    };
-    if (w->timers) {
-        // three sub-graphs with events in between (Counters from hipEvents)
-        if (!w->ge_col || plan_changed()) {
-            destroy_graphs(w);
-            int r;
-            if ((r = capture(w, &w->g_col, &w->ge_col, enqueue_collision)) != RP_OK) return r;
-            if ((r = capture(w, &w->g_loop, &w->ge_loop, enqueue_solver)) != RP_OK) return r;
-            if ((r = capture(w, &w->g_fin, &w->ge_fin, enqueue_finish)) != RP_OK) return r;
-            plan_commit();
-        }
-        HIPCHK(w, hipEventRecord(w->ev[0], w->stream));
-        HIPCHK(w, hipGraphLaunch(w->ge_col, w->stream));
-        HIPCHK(w, hipEventRecord(w->ev[1], w->stream));
-        HIPCHK(w, hipGraphLaunch(w->ge_loop, w->stream));
-        HIPCHK(w, hipEventRecord(w->ev[2], w->stream));
-        HIPCHK(w, hipGraphLaunch(w->ge_fin, w->stream));
-        HIPCHK(w, hipEventRecord(w->ev[3], w->stream));
-        HIPCHK(w, hipEventSynchronize(w->ev[3]));
-        float a = 0, c = 0, d = 0;
-        hipEventElapsedTime(&a, w->ev[0], w->ev[1]); hipEventElapsedTime(&c, w->ev[1], w->ev[2]); hipEventElapsedTime(&d, w->ev[2], w->ev[3]);
-        w->acc_col_ms += a; w->acc_loop_ms += c; w->acc_fin_ms += d; w->acc_step_ms += a + c + d; w->acc_steps++;
-        w->loop_ms_since_read += c; w->loop_steps_since_read++;
-        return RP_OK;
-    }
-    if (!w->use_graph) { enqueue_whole(w); HIPCHK(w, hipGetLastError()); return RP_OK; }
-    if (!w->graph_exec || plan_changed()) {
+    if (w->graph_stages != w->plan_stages || w->graph_blocks != w->plan_blocks || w->graph_single != w->plan_single ||
+        w->graph_island_grid != w->plan_island_grid) {
         destroy_graphs(w);
-        int r = capture(w, &w->graph, &w->graph_exec, enqueue_whole);
-        if (r != RP_OK) return r;
-        plan_commit();
+        w->graph_stages = w->plan_stages; w->graph_blocks = w->plan_blocks; w->graph_single = w->plan_single; w->graph_island_grid = w->plan_island_grid;
     }
-    HIPCHK(w, hipGraphLaunch(w->graph_exec, w->stream));
-    return RP_OK;
+    // keep the host at most a few steps ahead of the device so the hints stay fresh (the device
+    // never idles: several step graphs are always queued)
+    const long long max_ahead = 4;
+    if (w->plan_single && w->use_graph && !w->timers) {
+        long long spins = 0;
+        while (w->seq_enqueued - (long long)pf[FL_SEQ] > max_ahead) {
+            if (++spins > (1 << 14)) { if (hipStreamQuery(w->stream) != hipErrorNotReady) break; spins = 0; }
+            __builtin_ia32_pause();
+        }
+    }
+    // mode: fast graph only while the last observed steps were clean
+    bool fast = allow_fast && w->use_fast && w->plan_single && w->dw.n_colliders > 0 && w->steps_requested >= w->full_until;
+    if (fast && (pf[FL_FAST_ABORT] || pf[FL_FULL_UPDATES] || pf[FL_LAYOUT_DIRTY] || pf[FL_TODO_COUNT])) {
+        fast = false;
+        w->full_until = w->steps_requested + 3;
+    }
+    return launch_step(w, fast ? 1 : 0);
+}
+
+// Make the device catch up with every requested step: fast steps that aborted are replayed through
+// the full graph.  Synchronises the stream.
+static int settle(rp_world *w) {
+    if (!w->finalized) return RP_OK;
+    for (int guard = 0; guard < 64; ++guard) {
+        HIPCHK(w, hipStreamSynchronize(w->stream));
+        int fl[FL_COUNT];
+        HIPCHK(w, hipMemcpy(fl, w->dw.flags, sizeof(fl), hipMemcpyDeviceToHost));
+        memcpy(w->pinned_flags, fl, sizeof(fl));
+        long long missing = w->steps_requested - (long long)fl[FL_STEP];
+        if (missing <= 0) return check_overflow(w, fl);
+        w->full_until = w->steps_requested + 3;
+        w->replayed_steps += missing;
+        for (long long i = 0; i < missing; ++i) { int r = step_once(w, false); if (r != RP_OK) return r; }
+    }
+    w->err = "settle: the device did not catch up with the requested steps";
+    return RP_ERR_DEVICE;
 }
 
 extern "C" int32_t rp_step(rp_world *w, uint32_t nsteps) {
     if (!w) return RP_ERR_INVALID;
     HIPCHK(w, hipSetDevice(w->device));
     if (!w->finalized) { int r = finalize(w); if (r != RP_OK) return r; }
-    for (uint32_t i = 0; i < nsteps; ++i) { int r = step_once(w); if (r != RP_OK) return r; }
+    for (uint32_t i = 0; i < nsteps; ++i) {
+        w->steps_requested++;
+        int r = step_once(w, true);
+        if (r != RP_OK) return r;
+        if (w->timers) { r = settle(w); if (r != RP_OK) return r; } // timed steps are observed one by one
+    }
     return RP_OK;
 }
 extern "C" int32_t rp_sync(rp_world *w) {
     if (!w) return RP_ERR_INVALID;
     HIPCHK(w, hipSetDevice(w->device));
+    if (w->finalized) return settle(w);
     HIPCHK(w, hipStreamSynchronize(w->stream));
-    if (w->finalized) return check_overflow(w, w->pinned_flags);
     return RP_OK;
 }
 
@@ -546,6 +622,7 @@ extern "C" int32_t rp_bodies_read(rp_world *w, int32_t n, const uint64_t *handle
     if (!w) return RP_ERR_INVALID;
     HIPCHK(w, hipSetDevice(w->device));
     if (!w->finalized) { int r = finalize(w); if (r != RP_OK) return r; }
+    { int r = settle(w); if (r != RP_OK) return r; }
     int nb = w->dw.n_bodies;
     std::vector<float4> pos(nb), rot(nb), lv(nb), av(nb);
     HIPCHK(w, hipMemcpyAsync(pos.data(), w->dw.b_pos, nb * sizeof(float4), hipMemcpyDeviceToHost, w->stream));
@@ -560,14 +637,14 @@ extern "C" int32_t rp_bodies_read(rp_world *w, int32_t n, const uint64_t *handle
         if (pos7_out) { float *p = pos7_out + 7 * i; p[0] = pos[b].x; p[1] = pos[b].y; p[2] = pos[b].z; p[3] = rot[b].x; p[4] = rot[b].y; p[5] = rot[b].z; p[6] = rot[b].w; }
         if (vel6_out) { float *v = vel6_out + 6 * i; v[0] = lv[b].x; v[1] = lv[b].y; v[2] = lv[b].z; v[3] = av[b].x; v[4] = av[b].y; v[5] = av[b].z; }
     }
-    return check_overflow(w, w->pinned_flags);
+    return RP_OK;
 }
 
 extern "C" int32_t rp_bodies_write(rp_world *w, int32_t n, const uint64_t *handles, const float *pos7, const float *vel6) {
     if (!w || n < 0 || !handles) return RP_ERR_INVALID;
     HIPCHK(w, hipSetDevice(w->device));
     if (!w->finalized) { int r = finalize(w); if (r != RP_OK) return r; }
-    HIPCHK(w, hipStreamSynchronize(w->stream));
+    { int r = settle(w); if (r != RP_OK) return r; }
     for (int i = 0; i < n; ++i) {
         int b = (int)(handles[i] & 0xffffffffull);
         if (b < 0 || b >= w->dw.n_bodies) { w->err = "rp_bodies_write: invalid handle"; return RP_ERR_INVALID; }
@@ -593,7 +670,7 @@ extern "C" int32_t rp_contacts_read(rp_world *w, int32_t cap, int32_t *meta, flo
     if (!w) return RP_ERR_INVALID;
     HIPCHK(w, hipSetDevice(w->device));
     if (!w->finalized) return 0;
-    HIPCHK(w, hipStreamSynchronize(w->stream));
+    { int r = settle(w); if (r != RP_OK) return r; }
     int fl[FL_COUNT];
     HIPCHK(w, hipMemcpy(fl, w->dw.flags, sizeof(fl), hipMemcpyDeviceToHost));
     int top = std::min(fl[FL_POOL_TOP], w->dw.pool_cap);
@@ -630,7 +707,7 @@ extern "C" int32_t rp_counters_enable(rp_world *w, int32_t enable) {
     if (!w) return RP_ERR_INVALID;
     HIPCHK(w, hipSetDevice(w->device));
     if (enable && !w->ev[0]) for (auto &e : w->ev) HIPCHK(w, hipEventCreate(&e));
-    if ((enable != 0) != w->timers) { if (w->stream) hipStreamSynchronize(w->stream); destroy_graphs(w); }
+    if ((enable != 0) != w->timers) { int r = settle(w); if (r != RP_OK) return r; destroy_graphs(w); }
     w->timers = enable != 0;
     w->acc_loop_ms = w->acc_col_ms = w->acc_asm_ms = w->acc_fin_ms = w->acc_step_ms = 0.0; w->acc_steps = 0;
     w->loop_ms_since_read = 0.0; w->loop_steps_since_read = 0;
@@ -642,7 +719,7 @@ extern "C" int32_t rp_counters_read(rp_world *w, rp_counters *out) {
     memset(out, 0, sizeof(*out));
     HIPCHK(w, hipSetDevice(w->device));
     if (!w->finalized) return RP_OK;
-    HIPCHK(w, hipStreamSynchronize(w->stream));
+    { int r = settle(w); if (r != RP_OK) return r; }
     int fl[FL_COUNT];
     HIPCHK(w, hipMemcpy(fl, w->dw.flags, sizeof(fl), hipMemcpyDeviceToHost));
     double n = w->acc_steps > 0 ? (double)w->acc_steps : 1.0;
@@ -668,6 +745,7 @@ extern "C" int32_t rp_counters_read(rp_world *w, rp_counters *out) {
     out->full_updates = fl[FL_FULL_UPDATES];
     out->overflow_flags = fl[FL_OVERFLOW];
     out->quarantined = fl[FL_QUARANTINE];
+    out->fast_steps = (int32_t)w->fast_steps; out->full_steps = (int32_t)w->full_steps; out->replayed_steps = (int32_t)w->replayed_steps;
     return RP_OK;
 }
 

@@ -11,7 +11,7 @@
 // work, one thread per collider, wave-coalesced SoA loads) plus a brute-force list for colliders
 // spanning more than 3 cells.  Like the reference's change detection the whole rebuild is skipped
 // (every kernel early-exits on FL_BP_DIRTY == 0) while no fat AABB changed.
-#include "rp_world.h"
+#include "rp_pairs.h"
 
 __device__ __forceinline__ unsigned long long rp_hash64(unsigned long long x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
@@ -35,41 +35,39 @@ __device__ __forceinline__ CellRange cell_range(const DevWorld &w, int i) {
     return r;
 }
 
-// Collider world pose + fat AABB maintenance (BroadPhaseBvh::set_aabb; advance_to_final_positions
-// substep.rs:103-119).  One thread per collider.
 __global__ void k_collider_update(DevWorld w) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) w.flags[FL_FAST_ABORT] = 0; // a full step is starting: the fast path may be tried again later
     if (i >= w.n_colliders) return;
-    int parent = w.c_parent[i];
-    Pose lp; lp.r = q4(w.c_lrot[i]); lp.t = v3(w.c_lpos[i]);
-    Pose pos = lp;
-    if (parent >= 0) { Pose bp; bp.r = q4(w.b_rot[parent]); bp.t = v3(w.b_pos[parent]); pos = pose_mul(bp, lp); }
-    bool finite = isfinite(pos.t.x) && isfinite(pos.t.y) && isfinite(pos.t.z) && isfinite(pos.r.x) && isfinite(pos.r.y) &&
-                  isfinite(pos.r.z) && isfinite(pos.r.w);
-    if (!finite) { atomicAdd(&w.flags[FL_QUARANTINE], 1); return; }
-    w.c_pos[i] = f4(pos.t, 0.0f);
-    w.c_rot[i] = f4(pos.r);
-    float4 he = w.c_he[i];
-    V3 h;
-    if (w.c_shape[i] == RP_SHAPE_CUBOID) {
-        float m[3][3]; quat_to_mat(pos.r, m);
-        h = v3(fabsf(m[0][0]) * he.x + fabsf(m[0][1]) * he.y + fabsf(m[0][2]) * he.z,
-               fabsf(m[1][0]) * he.x + fabsf(m[1][1]) * he.y + fabsf(m[1][2]) * he.z,
-               fabsf(m[2][0]) * he.x + fabsf(m[2][1]) * he.y + fabsf(m[2][2]) * he.z);
-    } else {
-        h = v3(he.x, he.x, he.x);
+    collider_update_one(w, i);
+}
+
+// Steady-state fast path, first kernel (see rp_api.hip "fast graph"): collider poses + fat-AABB checks
+// for every collider AND the contact-recycling test of every pair (pair_update.rs:111-171) computed
+// straight from the body poses.  If any fat AABB changed (broad phase must run) or any pair fails its
+// recycle test (narrow phase must run) the step cannot be done by the fast graph: FL_FAST_ABORT is
+// raised, nothing else has been modified that the full path would not recompute identically, and the
+// remaining fast kernels exit; the host replays the step through the full graph.
+__global__ void k_fast_front(DevWorld w) {
+    if (w.flags[FL_FAST_ABORT]) return;
+    int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid == 0) { w.flags[FL_FULL_UPDATES] = 0; if (w.flags[FL_BP_DIRTY]) w.flags[FL_FAST_ABORT] = 1; }
+    bool abort = false;
+    if (gid < w.n_colliders) {
+        abort |= collider_update_one(w, gid); // rewritten fat AABB => FL_BP_DIRTY
     }
-    float loosen = w.prm.prediction / 2.0f;
-    V3 mn = pos.t - h - v3(loosen, loosen, loosen);
-    V3 mx = pos.t + h + v3(loosen, loosen, loosen);
-    float4 fmn = w.c_fatmin[i], fmx = w.c_fatmax[i];
-    bool inside = fmn.x <= mn.x && fmn.y <= mn.y && fmn.z <= mn.z && fmx.x >= mx.x && fmx.y >= mx.y && fmx.z >= mx.z;
-    if (!inside) {
-        float s = w.prm.bp_skin;
-        w.c_fatmin[i] = f4(mn - v3(s, s, s), 0.0f);
-        w.c_fatmax[i] = f4(mx + v3(s, s, s), 0.0f);
-        w.flags[FL_BP_DIRTY] = 1;
+    int top = w.flags[FL_POOL_TOP];
+    if (top > w.pool_cap) top = w.pool_cap;
+    int stride = gridDim.x * blockDim.x;
+    for (int s = gid; s < top; s += stride) {
+        int c1 = w.p_c1[s];
+        if (c1 < 0) continue;
+        int c2 = w.p_c2[s];
+        Pose pc1 = collider_world_pose(w, c1), pc2 = collider_world_pose(w, c2);
+        Pose pos12 = pose_inv_mul(pc1, pc2);
+        if (!pair_recycle_ok(w, s, pc1, pc2, pos12)) abort = true;
     }
+    if (abort) w.flags[FL_FAST_ABORT] = 1;
 }
 
 __global__ void k_bp_clear(DevWorld w) {
@@ -294,6 +292,14 @@ __global__ void k_bp_finish(DevWorld w) {
 void rp_launch_collider_update(const DevWorld &w, hipStream_t st) {
     if (w.n_colliders == 0) return;
     hipLaunchKernelGGL(k_collider_update, dim3((w.n_colliders + 255) / 256), dim3(256), 0, st, w);
+}
+
+void rp_launch_fast_front(const DevWorld &w, hipStream_t st) {
+    int n = w.n_colliders > w.pool_cap ? w.n_colliders : w.pool_cap;
+    int blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
+    int need = (w.n_colliders + 255) / 256; if (blocks < need) blocks = need;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_fast_front, dim3(blocks), dim3(256), 0, st, w);
 }
 
 void rp_launch_broadphase(const DevWorld &w, hipStream_t st) {

@@ -396,7 +396,8 @@ RP_DEV void island_sort(const DevWorld &w, int isl, int nc, int cb, int nst_glob
 }
 
 // One workgroup = one island.
-__global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int has_restitution) {
+__global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int has_restitution, int fast) {
+    if (fast && w.flags[FL_FAST_ABORT]) return; // fast graph gave up on this step (rp_api.hip)
     __shared__ float4 B_lin[RP_ISL_NB_MAX], B_ang[RP_ISL_NB_MAX], B_rot[RP_ISL_NB_MAX], B_trans[RP_ISL_NB_MAX];
     __shared__ float4 L_E[4 * RP_ISL_NC_MAX], L_F[4 * RP_ISL_NC_MAX], L_B0[RP_ISL_NC_MAX], L_B1[RP_ISL_NC_MAX];
     __shared__ int S_a[RP_ISL_NC_MAX], S_b[RP_ISL_NC_MAX], S_c[RP_ISL_NC_MAX], S_d[RP_ISL_NC_MAX];
@@ -477,7 +478,7 @@ __global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int ha
 void rp_launch_islands_build(const DevWorld &w, hipStream_t st) {
     hipLaunchKernelGGL(k_islands_build, dim3(1), dim3(1024), 0, st, w);
 }
-void rp_launch_island_solve(const DevWorld &w, hipStream_t st, int grid, int has_restitution) {
+void rp_launch_island_solve(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast) {
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(k_island_solve, dim3(grid), dim3(ISL_THREADS), 0, st, w, has_restitution);
+    hipLaunchKernelGGL(k_island_solve, dim3(grid), dim3(ISL_THREADS), 0, st, w, has_restitution, fast);
 }

@@ -13,7 +13,7 @@
 // reproduced exactly by a dependency-round scheme inside ONE workgroup (k_color_pairs): a pair is
 // coloured in the round where it is the smallest uncoloured key at both of its dynamic bodies, so
 // it sees precisely the masks the serial order would have produced.
-#include "rp_world.h"
+#include "rp_pairs.h"
 #include <float.h>
 
 #define PT(plane, k, s) plane[(size_t)(k) * w.pool_cap + (s)]
@@ -467,17 +467,7 @@ __global__ void k_np_pairs(DevWorld w) {
         pc1.r = q4(w.c_rot[c1]); pc1.t = v3(w.c_pos[c1]);
         pc2.r = q4(w.c_rot[c2]); pc2.t = v3(w.c_pos[c2]);
         Pose pos12 = pose_inv_mul(pc1, pc2);
-        // contact recycling — pair_update.rs:111-171, contact_pair.rs:284-325
-        if (w.prm.recycle_distance > 0.0f && (w.p_pflags[s] & RP_PF_RECYCLE)) {
-            Pose base; base.t = v3(w.r_t[s]); base.r = q4(w.r_r[s]);
-            float4 misc = w.p_misc[s];
-            float trans = len(pos12.t - base.t);
-            Q4 d = qmul(pos12.r, qconj(base.r));
-            float drift = trans + 2.0f * len(v3(d.x, d.y, d.z)) * misc.y;
-            float ca = qdot(q4(w.r_rot1[s]), pc1.r), cb = qdot(q4(w.r_rot2[s]), pc2.r);
-            float rot_cos = rp_min(2.0f * ca * ca - 1.0f, 2.0f * cb * cb - 1.0f);
-            if (drift <= misc.z && rot_cos > 0.98f) continue;
-        }
+        if (pair_recycle_ok(w, s, pc1, pc2, pos12)) continue;
         pair_full_update(w, s, c1, c2, pc1, pc2, pos12);
     }
 }

@@ -1,0 +1,60 @@
+// rp_pairs.h — per-collider / per-pair device helpers shared by the broad-phase, narrow-phase and
+// fast-path kernels.
+#pragma once
+#include "rp_world.h"
+
+RP_DEV Pose collider_world_pose(const DevWorld &w, int i) {
+    int parent = w.c_parent[i];
+    Pose lp; lp.r = q4(w.c_lrot[i]); lp.t = v3(w.c_lpos[i]);
+    if (parent < 0) return lp;
+    Pose bp; bp.r = q4(w.b_rot[parent]); bp.t = v3(w.b_pos[parent]);
+    return pose_mul(bp, lp);
+}
+
+// Collider world pose + fat AABB maintenance (BroadPhaseBvh::set_aabb; advance_to_final_positions
+// substep.rs:103-119).  One thread per collider.  Runs at the START of a step (the reference runs it
+// at the end of the previous one; nothing reads collider poses in between).
+RP_DEV bool collider_update_one(const DevWorld &w, int i) { // true = the fat AABB was rewritten
+    Pose pos = collider_world_pose(w, i);
+    bool finite = isfinite(pos.t.x) && isfinite(pos.t.y) && isfinite(pos.t.z) && isfinite(pos.r.x) && isfinite(pos.r.y) &&
+                  isfinite(pos.r.z) && isfinite(pos.r.w);
+    if (!finite) { atomicAdd(&w.flags[FL_QUARANTINE], 1); return false; }
+    w.c_pos[i] = f4(pos.t, 0.0f);
+    w.c_rot[i] = f4(pos.r);
+    float4 he = w.c_he[i];
+    V3 h;
+    if (w.c_shape[i] == RP_SHAPE_CUBOID) {
+        float m[3][3]; quat_to_mat(pos.r, m);
+        h = v3(fabsf(m[0][0]) * he.x + fabsf(m[0][1]) * he.y + fabsf(m[0][2]) * he.z,
+               fabsf(m[1][0]) * he.x + fabsf(m[1][1]) * he.y + fabsf(m[1][2]) * he.z,
+               fabsf(m[2][0]) * he.x + fabsf(m[2][1]) * he.y + fabsf(m[2][2]) * he.z);
+    } else {
+        h = v3(he.x, he.x, he.x);
+    }
+    float loosen = w.prm.prediction / 2.0f;
+    V3 mn = pos.t - h - v3(loosen, loosen, loosen);
+    V3 mx = pos.t + h + v3(loosen, loosen, loosen);
+    float4 fmn = w.c_fatmin[i], fmx = w.c_fatmax[i];
+    bool inside = fmn.x <= mn.x && fmn.y <= mn.y && fmn.z <= mn.z && fmx.x >= mx.x && fmx.y >= mx.y && fmx.z >= mx.z;
+    if (!inside) {
+        float s = w.prm.bp_skin;
+        w.c_fatmin[i] = f4(mn - v3(s, s, s), 0.0f);
+        w.c_fatmax[i] = f4(mx + v3(s, s, s), 0.0f);
+        w.flags[FL_BP_DIRTY] = 1;
+    }
+    return !inside;
+}
+
+// Contact recycling test — pair_update.rs:111-171, contact_pair.rs:284-325.  true = the pair keeps
+// last step's manifold (no narrow-phase work).
+RP_DEV bool pair_recycle_ok(const DevWorld &w, int s, const Pose &pc1, const Pose &pc2, const Pose &pos12) {
+    if (!(w.prm.recycle_distance > 0.0f) || !(w.p_pflags[s] & RP_PF_RECYCLE)) return false;
+    Pose base; base.t = v3(w.r_t[s]); base.r = q4(w.r_r[s]);
+    float4 misc = w.p_misc[s];
+    float trans = len(pos12.t - base.t);
+    Q4 d = qmul(pos12.r, qconj(base.r));
+    float drift = trans + 2.0f * len(v3(d.x, d.y, d.z)) * misc.y;
+    float ca = qdot(q4(w.r_rot1[s]), pc1.r), cb = qdot(q4(w.r_rot2[s]), pc2.r);
+    float rot_cos = rp_min(2.0f * ca * ca - 1.0f, 2.0f * cb * cb - 1.0f);
+    return drift <= misc.z && rot_cos > 0.98f;
+}

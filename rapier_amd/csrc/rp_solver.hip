@@ -123,20 +123,33 @@ __global__ void k_writeback_impulses(DevWorld w) {
 }
 __global__ void k_writeback_bodies(DevWorld w) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) w.flags[FL_STEP] += 1;
+    if (i == 0) { w.flags[FL_STEP] += 1; w.flags[FL_SEQ] += 1; }
     if (i >= w.n_bodies || !global_body(w, i)) return;
     g_body_writeback(w, i);
 }
 
 // ---- SINGLE mode: the whole global path in one workgroup -----------------------------------------
-__global__ void __launch_bounds__(1024) k_global_single(DevWorld w, int has_restitution) {
+// Last kernel of a step in SINGLE mode: also publishes the device scalars to the host-mapped hint
+// buffer (posted PCIe writes; the host only ever uses them as hints or after a stream sync).
+RP_DEV void publish_flags(const DevWorld &w) {
+    if (threadIdx.x < FL_COUNT) {
+        int v = __hip_atomic_load(&w.flags[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&w.host_flags[threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+__global__ void __launch_bounds__(1024) k_global_single(DevWorld w, int has_restitution, int fast) {
     const int t = threadIdx.x, nt = blockDim.x;
     __shared__ int bouncy;
-    if (t == 0) { w.flags[FL_STEP] += 1; bouncy = 0; }
+    const bool skip = fast && w.flags[FL_FAST_ABORT]; // fast graph gave up: the step is replayed by the full graph
+    if (t == 0) { w.flags[FL_SEQ] += 1; if (!skip) w.flags[FL_STEP] += 1; bouncy = 0; }
     int M = w.flags[FL_N_CONS];
     if (M > w.cons_cap) M = w.cons_cap;
     int ngb = w.flags[FL_N_GLOB_BODIES];
-    if (M == 0 && ngb == 0) return; // everything lives in LDS islands
+    if (skip || (M == 0 && ngb == 0)) { // nothing to do here (aborted, or everything lives in LDS islands)
+        __threadfence(); __syncthreads();
+        publish_flags(w);
+        return;
+    }
     const rp_integration_params &prm = w.prm.p;
     const bool fib = prm.friction_in_bias_pass || prm.num_internal_stabilization_iterations == 0;
     const int nb = w.n_bodies;
@@ -158,6 +171,8 @@ __global__ void __launch_bounds__(1024) k_global_single(DevWorld w, int has_rest
     if (has_restitution && bouncy) tail_sweep<MODE_RESTITUTION>(w, 0, fib, 0.0f);
     for (int pos = t; pos < M; pos += nt) cons_writeback(w, GlobalAcc(w, pos), w.cons_pair[pos]);
     for (int i = t; i < nb; i += nt) if (global_body(w, i)) g_body_writeback(w, i);
+    __threadfence(); __syncthreads();
+    publish_flags(w);
 }
 
 // World mass properties at insertion time (RigidBodyMassProps::update_world_mass_properties).
@@ -195,8 +210,8 @@ void rp_launch_init_bodies(const DevWorld &w, hipStream_t st) {
     if (w.n_bodies == 0) return;
     hipLaunchKernelGGL(k_init_bodies, dim3(body_blocks(w)), dim3(256), 0, st, w);
 }
-void rp_launch_global_single(const DevWorld &w, hipStream_t st, int has_restitution) {
-    hipLaunchKernelGGL(k_global_single, dim3(1), dim3(1024), 0, st, w, has_restitution);
+void rp_launch_global_single(const DevWorld &w, hipStream_t st, int has_restitution, int fast) {
+    hipLaunchKernelGGL(k_global_single, dim3(1), dim3(1024), 0, st, w, has_restitution, fast);
 }
 void rp_launch_solver_assembly(const DevWorld &w, hipStream_t st) {
     hipLaunchKernelGGL(k_solver_begin, dim3(body_blocks(w)), dim3(256), 0, st, w);

@@ -65,6 +65,8 @@ enum {
     FL_N_GLOB_BODIES,   // dynamic bodies outside small islands (global path)
     FL_N_CONS_ALL,      // M: all active solver manifolds (island + global)
     FL_ISL_BODY_CURSOR, FL_ISL_CONS_CURSOR,
+    FL_SEQ,             // step graphs retired (executed or aborted)
+    FL_FAST_ABORT,      // steady-state fast path found work it cannot do (see rp_api.hip); sticky until a full step
     FL_COUNT = 32
 };
 
@@ -128,6 +130,7 @@ struct DevWorld {
     int cons_cap;      // solver manifolds
     SimParams prm;
     int *flags;        // FL_* scalars
+    int *host_flags;   // host-mapped (pinned) copy of the scalars, published by the last kernel of a step
 
     // ---- bodies (index = arena index) ----
     float4 *b_pos, *b_rot, *b_linvel, *b_angvel;
