@@ -345,7 +345,7 @@ static int finalize(rp_world *w) {
     if (!(cell > 1.0e-6f)) cell = 1.0f;
     fill_sim_params(w, d.prm, cell);
 
-    DA(d.flags, FL_COUNT);
+    DA(d.flags, FL_COUNT); DA(d.dbg, 64);
     DA(d.b_pos, nb); DA(d.b_rot, nb); DA(d.b_linvel, nb); DA(d.b_angvel, nb); DA(d.b_lcom_invm, nb); DA(d.b_invpi, nb);
     DA(d.b_pframe, nb); DA(d.b_wcom, nb); DA(d.b_eim, nb); DA(d.b_eii0, nb); DA(d.b_eii1, nb); DA(d.b_damp, nb);
     DA(d.b_uforce, nb); DA(d.b_utorque, nb); DA(d.b_flags, nb);
@@ -746,6 +746,16 @@ extern "C" int32_t rp_counters_read(rp_world *w, rp_counters *out) {
     out->overflow_flags = fl[FL_OVERFLOW];
     out->quarantined = fl[FL_QUARANTINE];
     out->fast_steps = (int32_t)w->fast_steps; out->full_steps = (int32_t)w->full_steps; out->replayed_steps = (int32_t)w->replayed_steps;
+    return RP_OK;
+}
+
+// Debug aid (not part of include/rapier_hip.h): cycle stamps written by k_island_solve for island 0
+// when the library is built with -DRP_ISL_PROFILE.
+extern "C" int32_t rp_debug_cycles(rp_world *w, long long *out64) {
+    if (!w || !w->finalized || !out64) return RP_ERR_INVALID;
+    HIPCHK(w, hipSetDevice(w->device));
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    HIPCHK(w, hipMemcpy(out64, w->dw.dbg, 64 * sizeof(long long), hipMemcpyDeviceToHost));
     return RP_OK;
 }
 

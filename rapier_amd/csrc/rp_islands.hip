@@ -112,45 +112,10 @@ __global__ void __launch_bounds__(1024) k_islands_build(DevWorld w) {
 // s+1 (same expression on the same poses; tangent_velocity is identically zero without contact
 // modification hooks, which are outside this ABI).  Every f32 expression is evaluated exactly as in
 // rp_constraint.h, so the result stays bit-identical to the per-colour launch path and the oracle.
-struct IslPoint {
-    V3 a, b, c, d;             // torque_dir1, torque_dir2, ii_torque_dir1, ii_torque_dir2
-    float r, seed, d0;         // projected mass, restitution seed, builder dist
-    float lam, acc, rhs, cfm;  // impulse, impulse accumulator, active rhs / cfm factor
-    float rhsR, rhsB, cfmB;    // rhs of the relax sweep; rhs / cfm of the next biased sweeps
-};
-struct IslCons {
-    int id1, id2, n, cids;
-    V3 dir, dim1, dim2, im1, im2, t0, t1, twa, twb;
-    float mu, twist_r, k11, k22, k12, inv_det, rhs_wo0, rhs_wo1;
-    float td[4];
-    float tw_imp, tw_acc, t_imp0, t_imp1, t_acc0, t_acc1, t_rhs0, t_rhs1, tb0, tb1;
-    V3 T[8];
-    IslPoint P[4];
-    float cfm_factor, erp_inv_dt;
-};
 struct IslLds {
     float4 *lin, *ang, *rot, *trans;   // [RP_ISL_NB_MAX] solver bodies
     float4 *E, *F;                     // [4][RP_ISL_NC_MAX] builder local_p1 / local_p2
     float4 *B0, *B1;                   // [RP_ISL_NC_MAX] builder local friction centres
-};
-// scratch accessor cons_generate writes into (all plane indices are compile-time constants)
-struct GenAcc {
-    float4 (&R)[CP_COUNT];
-    int &m1, &m2, &mn, &mcid;
-    const IslLds &L;
-    RP_DEV GenAcc(float4 (&R_)[CP_COUNT], int &a, int &b, int &c, int &d, const IslLds &L_) : R(R_), m1(a), m2(b), mn(c), mcid(d), L(L_) {}
-    RP_DEV void st(int plane, float4 v) const { R[plane] = v; }
-    RP_DEV void set_meta(int a, int b, int cnt, int cid) const { m1 = a; m2 = b; mn = cnt; mcid = cid; }
-    RP_DEV Vel vel(int id) const {
-        Vel v;
-        if (id < 0) { v.lin = v3(0, 0, 0); v.ang = v3(0, 0, 0); } else { v.lin = v3(L.lin[id]); v.ang = v3(L.ang[id]); }
-        return v;
-    }
-    RP_DEV Xf xf(int id) const {
-        Xf x;
-        if (id < 0) { x.r = q4(0, 0, 0, 1); x.t = v3(0, 0, 0); } else { x.r = q4(L.rot[id]); x.t = v3(L.trans[id]); }
-        return x;
-    }
 };
 RP_DEV Vel isl_vel(const IslLds &L, int id) {
     Vel v;
@@ -164,200 +129,319 @@ RP_DEV Xf isl_xf(const IslLds &L, int id) {
     return x;
 }
 
-// generate (S1) + unpack into registers / LDS
-RP_DEV bool isl_generate(const DevWorld &w, IslCons &c, const IslLds &L, int t, int slot, int g1, int g2, int l1, int l2) {
-    float4 R[CP_COUNT];
-    GenAcc G(R, c.id1, c.id2, c.n, c.cids, L);
-    bool bouncy = cons_generate(w, G, slot, g1, g2, l1, l2);
-    c.dir = v3(R[CP_H0]); c.mu = R[CP_H0].w;
-    c.im1 = v3(R[CP_H1]); c.twist_r = R[CP_H1].w;
-    c.im2 = v3(R[CP_H2]);
-    Sym3 ii1 = {R[CP_H3].x, R[CP_H3].y, R[CP_H3].z, R[CP_H3].w, R[CP_H4].x, R[CP_H4].y};
-    Sym3 ii2 = {R[CP_H4].z, R[CP_H4].w, R[CP_H5].x, R[CP_H5].y, R[CP_H5].z, R[CP_H5].w};
-    c.t0 = v3(R[CP_H6]); c.rhs_wo0 = R[CP_H6].w; c.rhs_wo1 = R[CP_H7].x;
-    c.k11 = R[CP_H7].y; c.k22 = R[CP_H7].z;
-    c.td[0] = R[CP_H8].x; c.td[1] = R[CP_H8].y; c.td[2] = R[CP_H8].z; c.td[3] = R[CP_H8].w;
-    c.tw_imp = R[CP_HM0].x; c.tw_acc = R[CP_HM0].y; c.t_imp0 = R[CP_HM0].z; c.t_imp1 = R[CP_HM0].w;
-    c.t_acc0 = R[CP_HM1].x; c.t_acc1 = R[CP_HM1].y; c.t_rhs0 = R[CP_HM1].z; c.t_rhs1 = R[CP_HM1].w;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) c.T[q] = v3(R[CP_T0 + q]);
-    L.B0[t] = R[CP_B0]; L.B1[t] = R[CP_B1];
+// ---- two lanes per manifold -----------------------------------------------------------------------
+// The sweeps are latency-bound (one wave walks a dependent instruction stream per colour stage), so
+// each manifold is solved by a PAIR of adjacent lanes: the even lane owns body 1's half of every row
+// (direction, torque arms, velocity), the odd lane body 2's half.  The two halves of each relative
+// velocity meet through DPP quad permutes (no LDS, no extra wave), the even lane evaluates the impulse
+// and broadcasts it back.  The operations and their order are exactly those of rp_constraint.h:
+//   dvel = (((n.v1 + t1.w1) - n.v2) + t2.w2) + rhs           a * (-b) == (-a) * b,  x - y == x + (-y)
+// so the results stay bit-identical to the single-lane form and to the oracle.
+#define DPP_FROM_ODD 0xF5   // quad_perm [1,1,3,3]: both lanes of a pair read the odd lane
+#define DPP_FROM_EVEN 0xA0  // quad_perm [0,0,2,2]: both lanes of a pair read the even lane
+template <int CTRL> RP_DEV float dppf(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL> RP_DEV int dppi(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true); }
+template <int CTRL> RP_DEV V3 dppv(V3 v) { return v3(dppf<CTRL>(v.x), dppf<CTRL>(v.y), dppf<CTRL>(v.z)); }
+RP_DEV float sel(bool odd, float o, float e) { return odd ? o : e; }
+RP_DEV V3 sel(bool odd, V3 o, V3 e) { return v3(odd ? o.x : e.x, odd ? o.y : e.y, odd ? o.z : e.z); }
+
+struct SidePoint {
+    V3 pa, pc;                 // own torque_dir, ii_torque_dir (a,c on the even lane; b,d on the odd lane)
+    float r, seed, d0;         // even lane
+    float lam, acc, rhs, cfm;  // even lane
+    float rhsR, rhsB, cfmB;    // even lane
+};
+struct IslSide {
+    int id, n, cids;           // own body (LDS index or -1); point count (both lanes); contact ids (even)
+    bool odd;
+    V3 dir, t0, t1;            // both lanes
+    V3 sdim, im, stw;          // even: dim1, im1, twa ; odd: -dim2, im2, -twb
+    V3 td0, td1, itd0, itd1;   // own tangent torque dirs: T[0],T[1],T[4],T[5] | T[2],T[3],T[6],T[7]
+    float mu, twist_r, k11, k22, k12, inv_det, rhs_wo0, rhs_wo1;   // even lane
+    float td[4];
+    float tw_imp, tw_acc, t_imp0, t_imp1, t_acc0, t_acc1, t_rhs0, t_rhs1, tb0, tb1;
+    float cfm_factor, erp_inv_dt;
+    SidePoint P[4];
+};
+
+// generate (S1, ContactWithTwistFrictionBuilder::generate :58-424) by the lane pair: every lane builds
+// its own body's half (world points, torque arms, inertia products), the halves of each effective mass
+// meet through DPP, the even lane keeps the scalars.  `gid` / `lid` = the lane's own body as arena
+// index / island-local index (-1 = world-attached side).  Returns true on the even lane when a
+// restitution seed is armed.
+RP_DEV bool isl_generate(const DevWorld &w, IslSide &h, const IslLds &L, int m, int s, int gid, int lid, bool odd) {
+    h.odd = odd; h.id = lid;
+    Vel vels = isl_vel(L, lid);
+    Xf pose = isl_xf(L, lid);
+    V3 im = gid >= 0 ? v3(w.b_eim[gid]) : v3(0, 0, 0);
+    Sym3 ii = load_ii(w, gid);
+    V3 world_com = pose.t;
+    float4 nf = w.p_normal[s];
+    V3 dir = -v3(nf);
+    V3 sdir = odd ? -dir : dir;
+    float friction = nf.w;
+    float restitution = w.p_misc[s].x;
+    int count = w.p_nsc[s]; if (count > 4) count = 4;
+    V3 t0 = orthonormal_vector(dir); // contact_constraint/mod.rs:27-46
+    V3 t1 = cross(dir, t0);
+    float inv_num_points = 1.0f / (float)count;
+    V3 friction_center = v3(0, 0, 0), tangent_vel = v3(0, 0, 0);
+    float twist_warmstart = 0.0f, tw0 = 0.0f, tw1 = 0.0f;
+    V3 points0 = v3(0, 0, 0), points1 = points0, points2 = points0, points3 = points0;
+    int cids = 0;
+    bool bouncy_seed = false;
+    V3 im2 = dppv<DPP_FROM_ODD>(im);
+    V3 imsum = im + im2;                   // even lane: im1 + im2
+    h.n = count; h.dir = dir; h.t0 = t0; h.t1 = t1; h.im = im;
+    const float4 *anchors = odd ? w.sc_a2 : w.sc_a1;
+    const float4 *levers = odd ? w.pt_dp2 : w.pt_dp1;
+    float4 *LP = odd ? L.F : L.E;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if (k >= c.n) break;
-        IslPoint &p = c.P[k];
-        p.rhs = R[NPL(k, NP_M)].x; p.cfm = R[NPL(k, NP_M)].y; p.lam = R[NPL(k, NP_M)].z; p.acc = R[NPL(k, NP_M)].w;
-        p.a = v3(R[NPL(k, NP_A)]); p.r = R[NPL(k, NP_A)].w;
-        p.b = v3(R[NPL(k, NP_B)]); p.seed = R[NPL(k, NP_B)].w;
-        p.c = v3(R[NPL(k, NP_C)]); p.d0 = R[NPL(k, NP_C)].w;
-        p.d = v3(R[NPL(k, NP_D)]);
-        L.E[k * RP_ISL_NC_MAX + t] = R[NPL(k, NP_E)];
-        L.F[k * RP_ISL_NC_MAX + t] = R[NPL(k, NP_F)];
+        if (k >= count) break;
+        SidePoint &q = h.P[k];
+        float weight = inv_num_points;
+        float4 an = PT(anchors, k, s);
+        int cid = __float_as_int(PT(w.sc_a2, k, s).w);
+        cids |= (cid & 0xff) << (8 * k);
+        float4 pimp = PT(w.pt_imp, cid, s);
+        V3 wt = v3(PT(w.pt_wst, cid, s));
+        float warmstart_impulse = pimp.y;
+        float wti0 = dot(wt, t0), wti1 = dot(wt, t1);
+        float warmstart_twist_impulse = pimp.z;
+        bool is_new = pimp.x == 0.0f;
+        float is_bouncy = is_new ? (restitution > 0.0f ? 1.0f : 0.0f) : (restitution >= 1.0f ? 1.0f : 0.0f);
+        V3 pw = xf_tp(pose, v3(an));
+        float dist = dot(pw - dppv<DPP_FROM_ODD>(pw), dir);
+        V3 dp = v3(PT(levers, cid, s));
+        V3 point = world_com + dp;
+        if (k == 0) points0 = point; else if (k == 1) points1 = point; else if (k == 2) points2 = point; else points3 = point;
+        friction_center = friction_center + point * weight;
+        V3 vel = vels.lin + cross(vels.ang, dp);
+        twist_warmstart += warmstart_twist_impulse * weight;
+        tw0 += wti0 * weight; tw1 += wti1 * weight;
+        // tangent_velocity is always zero in this scope (no contact-modification hooks)
+        V3 torque_dir = cross(dp, sdir);
+        V3 ii_torque_dir = sym_mul(ii, torque_dir);
+        float G = dot(ii_torque_dir, torque_dir);
+        float projected_mass = rp_inv(dot(dir, cmul(imsum, dir)) + G + dppf<DPP_FROM_ODD>(G));
+        float projected_velocity = dot(vel - dppv<DPP_FROM_ODD>(vel), dir);
+        float restitution_seed = is_bouncy * restitution * projected_velocity;
+        bouncy_seed |= restitution_seed < 0.0f;
+        float info_dist = dist - dot(point - dppv<DPP_FROM_ODD>(point), dir);
+        q.rhs = 0.0f; q.cfm = 1.0f; q.lam = warmstart_impulse; q.acc = -warmstart_impulse;
+        q.pa = torque_dir; q.r = projected_mass; q.seed = restitution_seed;
+        q.pc = ii_torque_dir; q.d0 = info_dist;
+        q.rhsR = 0.0f; q.rhsB = 0.0f; q.cfmB = 1.0f;
+        LP[k * RP_ISL_NC_MAX + m] = f4(xf_itp(pose, point), 0.0f);
     }
+    h.cids = cids;
+    float twist_imp = count > 1 ? twist_warmstart : 0.0f;
+    V3 dpf = friction_center - world_com;
+    float twist_r = 0.0f;
+    h.td[0] = 0.0f; h.td[1] = 0.0f; h.td[2] = 0.0f; h.td[3] = 0.0f;
+    V3 tw = sym_mul(ii, dir);
+    h.stw = odd ? -tw : tw;
+    if (count > 1) {
+        h.td[0] = len(friction_center - points0);
+        h.td[1] = len(friction_center - points1);
+        if (count > 2) h.td[2] = len(friction_center - points2);
+        if (count > 3) h.td[3] = len(friction_center - points3);
+        V3 ii_twist_dir = sym_mul(ii, sdir);
+        float Hh = dot(ii_twist_dir, sdir);
+        twist_r = rp_inv(Hh + dppf<DPP_FROM_ODD>(Hh));
+    }
+    float r[3], rhs_wo[2];
+    V3 td[2], itd[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        V3 tj = j == 0 ? t0 : t1;
+        td[j] = cross(dpf, odd ? -tj : tj);
+        itd[j] = sym_mul(ii, td[j]);
+        float G = dot(itd[j], td[j]);
+        r[j] = dot(tj, cmul(imsum, tj)) + G + dppf<DPP_FROM_ODD>(G);
+        rhs_wo[j] = dot(tangent_vel, tj);
+    }
+    {
+        float K = dot(itd[0], td[1]);
+        r[2] = 2.0f * (K + dppf<DPP_FROM_ODD>(K));
+    }
+    h.td0 = td[0]; h.td1 = td[1]; h.itd0 = itd[0]; h.itd1 = itd[1];
+    h.mu = friction; h.twist_r = twist_r;
+    h.rhs_wo0 = rhs_wo[0]; h.rhs_wo1 = rhs_wo[1];
+    h.k11 = r[0]; h.k22 = r[1];
+    h.tw_imp = twist_imp; h.tw_acc = -twist_imp; h.t_imp0 = tw0; h.t_imp1 = tw1;
+    h.t_acc0 = -tw0; h.t_acc1 = -tw1; h.t_rhs0 = rhs_wo[0]; h.t_rhs1 = rhs_wo[1]; h.tb0 = 0.0f; h.tb1 = 0.0f;
+    (odd ? L.B1 : L.B0)[m] = f4(xf_itp(pose, friction_center), 0.0f);
     // loop invariants of the sweeps (same expressions the per-colour path re-evaluates every sweep)
-    c.t1 = cross(c.dir, c.t0);
-    c.dim1 = cmul(c.dir, c.im1); c.dim2 = cmul(c.dir, c.im2);
-    c.twa = sym_mul(ii1, c.dir); c.twb = sym_mul(ii2, c.dir);
-    c.k12 = R[CP_H2].w * 0.5f;
-    c.inv_det = rp_inv(c.k11 * c.k22 - c.k12 * c.k12);
-    bool is_static = c.id1 < 0 || c.id2 < 0;
+    V3 dim = cmul(dir, im);
+    h.sdim = odd ? -dim : dim;
+    h.k12 = r[2] * 0.5f;
+    h.inv_det = rp_inv(h.k11 * h.k22 - h.k12 * h.k12);
+    bool is_static = lid < 0 || dppi<DPP_FROM_ODD>(lid) < 0 || dppi<DPP_FROM_EVEN>(lid) < 0;
     float fstatic = is_static ? 1.0f : 0.0f;
-    c.cfm_factor = w.prm.dyn_cfm + fstatic * (w.prm.static_cfm - w.prm.dyn_cfm);
-    c.erp_inv_dt = w.prm.dyn_erp_inv_dt + fstatic * (w.prm.static_erp_inv_dt - w.prm.dyn_erp_inv_dt);
-    return bouncy;
+    h.cfm_factor = w.prm.dyn_cfm + fstatic * (w.prm.static_cfm - w.prm.dyn_cfm);
+    h.erp_inv_dt = w.prm.dyn_erp_inv_dt + fstatic * (w.prm.static_erp_inv_dt - w.prm.dyn_erp_inv_dt);
+    return bouncy_seed;
 }
 
 // Pose-dependent half of update / refresh_rhs_wo_bias (contact_with_twist_friction.rs:426-554), for the
-// poses currently in LDS.  `solved_dt` only scales the (zero) tangent velocity.
-RP_DEV void isl_pose_stage(const DevWorld &w, IslCons &c, const IslLds &L, int t, float solved_dt) {
-    Xf x1 = isl_xf(L, c.id1), x2 = isl_xf(L, c.id2);
+// poses currently in LDS.  `solved_dt` only scales the (zero) tangent velocity.  m = manifold index.
+RP_DEV void isl_pose_stage(const DevWorld &w, IslSide &h, const IslLds &L, int m, float solved_dt) {
+    Xf x = isl_xf(L, h.id);
     V3 tangent_delta = v3(0.0f, 0.0f, 0.0f) * solved_dt;
     float inv_dt = w.prm.inv_dt_sub, maxcv = w.prm.max_corrective_velocity;
+    const float4 *LP = h.odd ? L.F : L.E;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if (k >= c.n) break;
-        IslPoint &p = c.P[k];
-        V3 p1 = xf_tp(x1, v3(L.E[k * RP_ISL_NC_MAX + t])) + tangent_delta;
-        V3 p2 = xf_tp(x2, v3(L.F[k * RP_ISL_NC_MAX + t]));
-        float dist = p.d0 + dot(p1 - p2, c.dir);
+        if (k >= h.n) break;
+        SidePoint &p = h.P[k];
+        V3 pw = xf_tp(x, v3(LP[k * RP_ISL_NC_MAX + m]));
+        pw = sel(h.odd, pw, pw + tangent_delta);          // p1 = T1 lp1 + delta ; p2 = T2 lp2
+        V3 p2 = dppv<DPP_FROM_ODD>(pw);
+        float dist = p.d0 + dot(pw - p2, h.dir);
         float rhs_wo_bias = rp_max(dist, 0.0f) * inv_dt;
-        float rhs_bias = rp_clamp(dist * c.erp_inv_dt, -maxcv, 0.0f);
+        float rhs_bias = rp_clamp(dist * h.erp_inv_dt, -maxcv, 0.0f);
         p.rhsR = rhs_wo_bias;
         p.rhsB = rhs_wo_bias + rhs_bias;
-        p.cfmB = dist <= 0.0f ? c.cfm_factor : 1.0f;
+        p.cfmB = dist <= 0.0f ? h.cfm_factor : 1.0f;
     }
-    V3 p1 = xf_tp(x1, v3(L.B0[t])) + tangent_delta;
-    V3 p2 = xf_tp(x2, v3(L.B1[t]));
-    c.tb0 = dot(p1 - p2, c.t0) * inv_dt; c.tb1 = dot(p1 - p2, c.t1) * inv_dt;
+    V3 pf = xf_tp(x, v3((h.odd ? L.B1 : L.B0)[m]));
+    pf = sel(h.odd, pf, pf + tangent_delta);
+    V3 pf2 = dppv<DPP_FROM_ODD>(pf);
+    h.tb0 = dot(pf - pf2, h.t0) * inv_dt; h.tb1 = dot(pf - pf2, h.t1) * inv_dt;
 }
 
 // Velocity-dependent half of update + warmstart (:426-522, :633-678), colour-ordered.
-RP_DEV void isl_warmstart(const DevWorld &w, IslCons &c, const IslLds &L) {
+RP_DEV void isl_warmstart(const DevWorld &w, IslSide &h, const IslLds &L) {
     float wc = w.prm.p.warmstart_coefficient;
     bool ws = wc != 0.0f;
-    Vel v1 = isl_vel(L, c.id1), v2 = isl_vel(L, c.id2);
+    Vel v = isl_vel(L, h.id);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if (k >= c.n) break;
-        IslPoint &p = c.P[k];
+        if (k >= h.n) break;
+        SidePoint &p = h.P[k];
         p.rhs = p.rhsB; p.cfm = p.cfmB;
         p.acc += p.lam;
         p.lam *= wc;
         if (ws) {
-            v1.lin = v1.lin + c.dim1 * p.lam;
-            v1.ang = v1.ang + p.c * p.lam;
-            v2.lin = v2.lin + c.dim2 * (-p.lam);
-            v2.ang = v2.ang + p.d * p.lam;
+            float lam = dppf<DPP_FROM_EVEN>(p.lam);
+            v.lin = v.lin + h.sdim * lam;
+            v.ang = v.ang + p.pc * lam;
         }
     }
-    c.t_rhs0 = c.rhs_wo0 + c.tb0; c.t_rhs1 = c.rhs_wo1 + c.tb1;
-    c.t_acc0 += c.t_imp0; c.t_acc1 += c.t_imp1;
-    c.t_imp0 *= wc; c.t_imp1 *= wc;
-    c.tw_acc += c.tw_imp;
-    c.tw_imp *= wc;
+    h.t_rhs0 = h.rhs_wo0 + h.tb0; h.t_rhs1 = h.rhs_wo1 + h.tb1;
+    h.t_acc0 += h.t_imp0; h.t_acc1 += h.t_imp1;
+    h.t_imp0 *= wc; h.t_imp1 *= wc;
+    h.tw_acc += h.tw_imp;
+    h.tw_imp *= wc;
     if (ws) {
-        float i0 = c.t_imp0, i1 = c.t_imp1;
-        v1.lin = v1.lin + cmul(c.t0 * i0 + c.t1 * i1, c.im1);
-        v1.ang = v1.ang + (c.T[4] * i0 + c.T[5] * i1);
-        v2.lin = v2.lin + cmul(c.t0 * (-i0) + c.t1 * (-i1), c.im2);
-        v2.ang = v2.ang + (c.T[6] * i0 + c.T[7] * i1);
-        if (c.n > 1) {
-            v1.ang = v1.ang + c.twa * c.tw_imp;
-            v2.ang = v2.ang - c.twb * c.tw_imp;
-        }
-        isl_set_vel(L, c.id1, v1); isl_set_vel(L, c.id2, v2);
+        float i0 = dppf<DPP_FROM_EVEN>(h.t_imp0), i1 = dppf<DPP_FROM_EVEN>(h.t_imp1);
+        float s0 = h.odd ? -i0 : i0, s1 = h.odd ? -i1 : i1;
+        v.lin = v.lin + cmul(h.t0 * s0 + h.t1 * s1, h.im);
+        v.ang = v.ang + (h.itd0 * i0 + h.itd1 * i1);
+        if (h.n > 1) v.ang = v.ang + h.stw * dppf<DPP_FROM_EVEN>(h.tw_imp);
+        isl_set_vel(L, h.id, v);
     }
 }
 
 // solve (:680-781); `relax` first switches to the bias-free right-hand sides of isl_pose_stage.
-RP_DEV void isl_solve(IslCons &c, const IslLds &L, bool relax, bool friction) {
-    Vel v1 = isl_vel(L, c.id1), v2 = isl_vel(L, c.id2);
+RP_DEV void isl_solve(IslSide &h, const IslLds &L, bool relax, bool friction) {
+    Vel v = isl_vel(L, h.id);
     float imp[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if (k >= c.n) break;
-        IslPoint &p = c.P[k];
+        if (k >= h.n) break;
+        SidePoint &p = h.P[k];
         if (relax) { p.rhs = p.rhsR; p.cfm = 1.0f; }
-        float dvel = dot(c.dir, v1.lin) + dot(p.a, v1.ang) - dot(c.dir, v2.lin) + dot(p.b, v2.ang) + p.rhs;
+        float X = dot(h.dir, v.lin), Y = dot(p.pa, v.ang);
+        float S = X + Y;
+        float dvel = S - dppf<DPP_FROM_ODD>(X) + dppf<DPP_FROM_ODD>(Y) + p.rhs;
         float new_impulse = p.cfm * rp_max(p.lam - p.r * dvel, 0.0f);
-        float dl = new_impulse - p.lam;
+        float dl = dppf<DPP_FROM_EVEN>(new_impulse - p.lam);
         p.lam = new_impulse;
         imp[k] = new_impulse;
-        v1.lin = v1.lin + c.dim1 * dl;
-        v1.ang = v1.ang + p.c * dl;
-        v2.lin = v2.lin + c.dim2 * (-dl);
-        v2.ang = v2.ang + p.d * dl;
+        v.lin = v.lin + h.sdim * dl;
+        v.ang = v.ang + p.pc * dl;
     }
     if (friction) {
-        if (relax) { c.t_rhs0 = c.rhs_wo0; c.t_rhs1 = c.rhs_wo1; }
+        if (relax) { h.t_rhs0 = h.rhs_wo0; h.t_rhs1 = h.rhs_wo1; }
         float tangent_limit = 0.0f, twist_limit = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { if (k >= c.n) break; tangent_limit += imp[k]; twist_limit += imp[k] * c.td[k]; }
-        tangent_limit *= c.mu; twist_limit *= c.mu;
-        if (c.n > 1) {
-            float dvel = dot(c.dir, v1.ang - v2.ang) + 0.0f;
-            float new_impulse = rp_clamp(c.tw_imp - c.twist_r * dvel, -twist_limit, twist_limit);
-            float dl = new_impulse - c.tw_imp;
-            c.tw_imp = new_impulse;
-            v1.ang = v1.ang + c.twa * dl;
-            v2.ang = v2.ang - c.twb * dl;
+        for (int k = 0; k < 4; ++k) { if (k >= h.n) break; tangent_limit += imp[k]; twist_limit += imp[k] * h.td[k]; }
+        tangent_limit *= h.mu; twist_limit *= h.mu;
+        if (h.n > 1) {
+            V3 w2 = dppv<DPP_FROM_ODD>(v.ang);
+            float dvel = dot(h.dir, v.ang - w2) + 0.0f;
+            float new_impulse = rp_clamp(h.tw_imp - h.twist_r * dvel, -twist_limit, twist_limit);
+            float dl = dppf<DPP_FROM_EVEN>(new_impulse - h.tw_imp);
+            h.tw_imp = new_impulse;
+            v.ang = v.ang + h.stw * dl;
         }
         {
-            float dvel_0 = dot(c.t0, v1.lin) + dot(c.T[0], v1.ang) - dot(c.t0, v2.lin) + dot(c.T[2], v2.ang) + c.t_rhs0;
-            float dvel_1 = dot(c.t1, v1.lin) + dot(c.T[1], v1.ang) - dot(c.t1, v2.lin) + dot(c.T[3], v2.ang) + c.t_rhs1;
-            float d0 = (c.k22 * dvel_0 - c.k12 * dvel_1) * c.inv_det;
-            float d1 = (c.k11 * dvel_1 - c.k12 * dvel_0) * c.inv_det;
-            float n0 = c.t_imp0 - d0, n1 = c.t_imp1 - d1;
+            float X0 = dot(h.t0, v.lin), Y0 = dot(h.td0, v.ang), X1 = dot(h.t1, v.lin), Y1 = dot(h.td1, v.ang);
+            float S0 = X0 + Y0, S1 = X1 + Y1;
+            float dvel_0 = S0 - dppf<DPP_FROM_ODD>(X0) + dppf<DPP_FROM_ODD>(Y0) + h.t_rhs0;
+            float dvel_1 = S1 - dppf<DPP_FROM_ODD>(X1) + dppf<DPP_FROM_ODD>(Y1) + h.t_rhs1;
+            float d0 = (h.k22 * dvel_0 - h.k12 * dvel_1) * h.inv_det;
+            float d1 = (h.k11 * dvel_1 - h.k12 * dvel_0) * h.inv_det;
+            float n0 = h.t_imp0 - d0, n1 = h.t_imp1 - d1;
             float l = sqrtf(n0 * n0 + n1 * n1);
             if (l > tangent_limit) { float sc = tangent_limit / l; n0 *= sc; n1 *= sc; }
-            float dl0 = n0 - c.t_imp0, dl1 = n1 - c.t_imp1;
-            c.t_imp0 = n0; c.t_imp1 = n1;
-            v1.lin = v1.lin + cmul(c.t0 * dl0 + c.t1 * dl1, c.im1);
-            v1.ang = v1.ang + (c.T[4] * dl0 + c.T[5] * dl1);
-            v2.lin = v2.lin + cmul(c.t0 * (-dl0) + c.t1 * (-dl1), c.im2);
-            v2.ang = v2.ang + (c.T[6] * dl0 + c.T[7] * dl1);
+            float dl0 = dppf<DPP_FROM_EVEN>(n0 - h.t_imp0), dl1 = dppf<DPP_FROM_EVEN>(n1 - h.t_imp1);
+            h.t_imp0 = n0; h.t_imp1 = n1;
+            float s0 = h.odd ? -dl0 : dl0, s1 = h.odd ? -dl1 : dl1;
+            v.lin = v.lin + cmul(h.t0 * s0 + h.t1 * s1, h.im);
+            v.ang = v.ang + (h.itd0 * dl0 + h.itd1 * dl1);
         }
     }
-    isl_set_vel(L, c.id1, v1); isl_set_vel(L, c.id2, v2);
+    isl_set_vel(L, h.id, v);
 }
 
 // apply_restitution (:568-597)
-RP_DEV void isl_restitution(IslCons &c, const IslLds &L) {
+RP_DEV void isl_restitution(IslSide &h, const IslLds &L) {
     bool any = false;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { if (k >= c.n) break; any |= c.P[k].seed < 0.0f; }
+    for (int k = 0; k < 4; ++k) { if (k >= h.n) break; any |= dppf<DPP_FROM_EVEN>(h.P[k].seed) < 0.0f; }
     if (!any) return;
-    Vel v1 = isl_vel(L, c.id1), v2 = isl_vel(L, c.id2);
+    Vel v = isl_vel(L, h.id);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if (k >= c.n) break;
-        IslPoint &p = c.P[k];
-        float dvel = dot(c.dir, v1.lin) + dot(p.a, v1.ang) - dot(c.dir, v2.lin) + dot(p.b, v2.ang) + p.seed;
+        if (k >= h.n) break;
+        SidePoint &p = h.P[k];
+        float X = dot(h.dir, v.lin), Y = dot(p.pa, v.ang);
+        float S = X + Y;
+        float dvel = S - dppf<DPP_FROM_ODD>(X) + dppf<DPP_FROM_ODD>(Y) + p.seed;
         bool gate = p.seed < 0.0f && (p.acc + p.lam) > 0.0f;
         float new_impulse = gate ? rp_max(p.lam - p.r * dvel, 0.0f) : p.lam;
-        float dl = new_impulse - p.lam;
+        float dl = dppf<DPP_FROM_EVEN>(new_impulse - p.lam);
         p.lam = new_impulse;
-        v1.lin = v1.lin + c.dim1 * dl;
-        v1.ang = v1.ang + p.c * dl;
-        v2.lin = v2.lin + c.dim2 * (-dl);
-        v2.ang = v2.ang + p.d * dl;
+        v.lin = v.lin + h.sdim * dl;
+        v.ang = v.ang + p.pc * dl;
     }
-    isl_set_vel(L, c.id1, v1); isl_set_vel(L, c.id2, v2);
+    isl_set_vel(L, h.id, v);
 }
 
-// writeback_impulses (:783-829)
-RP_DEV void isl_writeback(const DevWorld &w, const IslCons &c, int s) {
-    V3 wtw = c.t0 * c.t_imp0 + c.t1 * c.t_imp1;
+// writeback_impulses (:783-829) — even lane
+RP_DEV void isl_writeback(const DevWorld &w, const IslSide &h, int s) {
+    V3 wtw = h.t0 * h.t_imp0 + h.t1 * h.t_imp1;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if (k >= c.n) break;
-        int cid = (c.cids >> (8 * k)) & 0xff;
-        PT(w.pt_imp, cid, s) = make_float4(c.P[k].acc + c.P[k].lam, c.P[k].lam, c.tw_imp, 0.0f);
+        if (k >= h.n) break;
+        int cid = (h.cids >> (8 * k)) & 0xff;
+        PT(w.pt_imp, cid, s) = make_float4(h.P[k].acc + h.P[k].lam, h.P[k].lam, h.tw_imp, 0.0f);
         PT(w.pt_wst, cid, s) = f4(wtw, 0.0f);
     }
 }
 
-#define ISL_THREADS 192
+#define ISL_THREADS (2 * RP_ISL_NC_MAX)
+#ifdef RP_ISL_PROFILE
+#define ISL_STAMP(slot) do { if (blockIdx.x == 0 && threadIdx.x == 0) w.dbg[slot] += (long long)__builtin_readcyclecounter() - t_prev, t_prev = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define ISL_STAMP(slot) do { } while (0)
+#endif
 
 // Sort an island's manifold list by sweep stage (rank of the pair's colour) and hand every manifold
 // its local stage index; overflow-colour manifolds (serial in the reference, worker 0) each get a
@@ -395,7 +479,7 @@ RP_DEV void island_sort(const DevWorld &w, int isl, int nc, int cb, int nst_glob
     __syncthreads();
 }
 
-// One workgroup = one island.
+// One workgroup = one island; lanes 2m, 2m+1 = manifold m (sorted by sweep stage), threads < nb also own a body.
 __global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int has_restitution, int fast) {
     if (fast && w.flags[FL_FAST_ABORT]) return; // fast graph gave up on this step (rp_api.hip)
     __shared__ float4 B_lin[RP_ISL_NB_MAX], B_ang[RP_ISL_NB_MAX], B_rot[RP_ISL_NB_MAX], B_trans[RP_ISL_NB_MAX];
@@ -403,7 +487,8 @@ __global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int ha
     __shared__ int S_a[RP_ISL_NC_MAX], S_b[RP_ISL_NC_MAX], S_c[RP_ISL_NC_MAX], S_d[RP_ISL_NC_MAX];
     __shared__ int any_bouncy;
 
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, m = t >> 1;
+    const bool odd = (t & 1) != 0;
     const int n_islands = w.flags[FL_N_ISLANDS];
     const int nst_global = w.flags[FL_N_STAGES];
     const rp_integration_params &prm = w.prm.p;
@@ -415,6 +500,9 @@ __global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int ha
         const int nb = w.isl_nb[isl], nc = w.isl_nc[isl];
         const int bb = w.isl_body_begin[isl], cb = w.isl_cons_begin[isl];
         __syncthreads(); // previous island of this workgroup fully written back
+#ifdef RP_ISL_PROFILE
+        long long t_prev = (long long)__builtin_readcyclecounter();
+#endif
         if (!w.isl_sorted[isl]) island_sort(w, isl, nc, cb, nst_global, S_a, S_b, S_c, S_d);
         // ---- bodies -> LDS (+ per-body constants in the owning thread's registers) (S0) ----
         int b_gid = -1, b_fl = 0;
@@ -429,21 +517,25 @@ __global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int ha
         }
         if (t == 0) any_bouncy = 0;
         const int nls = w.isl_nstages[isl];
+        const bool live = m < nc;
         int slot = -1, myq = -1;
-        if (t < nc) { slot = w.isl_cons[cb + t]; myq = w.isl_cstage[cb + t]; }
+        if (live) { slot = w.isl_cons[cb + m]; myq = w.isl_cstage[cb + m]; }
         __syncthreads();
-        IslCons c;
-        c.n = 0; c.id1 = -1; c.id2 = -1; c.cids = 0;
-        // ---- generate (S1) + pose stage for the initial poses ----
-        if (t < nc) {
-            int rb1 = w.c_parent[w.p_c1[slot]], rb2 = w.c_parent[w.p_c2[slot]];
+        ISL_STAMP(0); // body load + list
+        IslSide h;
+        h.n = 0; h.id = -1; h.odd = odd; h.cids = 0;
+        // ---- generate (S1) by the lane pair, pose stage for the initial poses ----
+        if (live) {
+            int c1 = w.p_c1[slot], c2 = w.p_c2[slot];
+            int rb = w.c_parent[odd ? c2 : c1];
             int rel_dom = w.p_reldom[slot];
-            int g1 = (is_dyn(w, rb1) && rel_dom <= 0) ? rb1 : -1;
-            int g2 = (is_dyn(w, rb2) && rel_dom >= 0) ? rb2 : -1;
-            int l1 = g1 >= 0 ? w.b_local[g1] : -1, l2 = g2 >= 0 ? w.b_local[g2] : -1;
-            if (isl_generate(w, c, L, t, slot, g1, g2, l1, l2)) any_bouncy = 1;
-            isl_pose_stage(w, c, L, t, 0.0f);
+            bool attached = is_dyn(w, rb) && (odd ? rel_dom >= 0 : rel_dom <= 0);
+            int g = attached ? rb : -1;
+            int l = g >= 0 ? w.b_local[g] : -1;
+            if (isl_generate(w, h, L, m, slot, g, l, odd) && !odd) any_bouncy = 1;
         }
+        if (live) isl_pose_stage(w, h, L, m, 0.0f); // each lane reads back only what it stored itself
+        ISL_STAMP(1); // generate + first pose stage
 
         for (int sub = 0; sub < w.prm.num_substeps; ++sub) {
             float solved_dt = (float)sub * w.prm.dt_sub;
@@ -454,24 +546,34 @@ __global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int ha
                 B_lin[t] = f4(lin, 0.0f); B_ang[t] = f4(ang, 0.0f);
             }
             __syncthreads();
-            for (int q = 0; q < nls; ++q) { if (myq == q) isl_warmstart(w, c, L); __syncthreads(); }
+            ISL_STAMP(2); // increment
+            for (int q = 0; q < nls; ++q) { if (myq == q) isl_warmstart(w, h, L); __syncthreads(); }
+            ISL_STAMP(3); // warmstart sweep
             for (int it = 0; it < prm.num_internal_pgs_iterations; ++it)
-                for (int q = 0; q < nls; ++q) { if (myq == q) isl_solve(c, L, false, fib); __syncthreads(); }
+                for (int q = 0; q < nls; ++q) { if (myq == q) isl_solve(h, L, false, fib); __syncthreads(); }
+            ISL_STAMP(4); // biased sweep
             if (t < nb) { // S6
                 V3 lin = v3(B_lin[t]), ang = v3(B_ang[t]), trans = v3(B_trans[t]); Q4 rot = q4(B_rot[t]);
                 body_integrate(w, b_fl, lin, ang, rot, trans);
                 B_lin[t] = f4(lin, 0.0f); B_ang[t] = f4(ang, 0.0f); B_rot[t] = f4(rot); B_trans[t] = f4(trans, 0.0f);
             }
             __syncthreads();
-            if (t < nc) isl_pose_stage(w, c, L, t, solved_dt + w.prm.dt_sub);
+            ISL_STAMP(5); // integrate
+            if (live) isl_pose_stage(w, h, L, m, solved_dt + w.prm.dt_sub);
+            ISL_STAMP(6); // pose stage
             for (int it = 0; it < prm.num_internal_stabilization_iterations; ++it)
-                for (int q = 0; q < nls; ++q) { if (myq == q) isl_solve(c, L, true, true); __syncthreads(); }
+                for (int q = 0; q < nls; ++q) { if (myq == q) isl_solve(h, L, true, true); __syncthreads(); }
+            ISL_STAMP(7); // relax sweep
         }
         if (has_restitution && any_bouncy)
-            for (int q = 0; q < nls; ++q) { if (myq == q) isl_restitution(c, L); __syncthreads(); }
+            for (int q = 0; q < nls; ++q) { if (myq == q) isl_restitution(h, L); __syncthreads(); }
         // ---- write-back (S9, S10, advance_to_final_positions) ----
-        if (t < nc) isl_writeback(w, c, slot);
+        if (live && !odd) isl_writeback(w, h, slot);
         if (t < nb) body_writeback(w, b_gid, v3(B_lin[t]), v3(B_ang[t]), q4(B_rot[t]), v3(B_trans[t]));
+        ISL_STAMP(8); // write-back
+#ifdef RP_ISL_PROFILE
+        if (blockIdx.x == 0 && threadIdx.x == 0) w.dbg[63] += 1;
+#endif
     }
 }
 

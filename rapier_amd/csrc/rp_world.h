@@ -130,6 +130,7 @@ struct DevWorld {
     int cons_cap;      // solver manifolds
     SimParams prm;
     int *flags;        // FL_* scalars
+    long long *dbg;    // [64] cycle stamps of island 0 (only written when built with -DRP_ISL_PROFILE)
     int *host_flags;   // host-mapped (pinned) copy of the scalars, published by the last kernel of a step
 
     // ---- bodies (index = arena index) ----

@@ -1,0 +1,23 @@
+"""Cycle breakdown of k_island_solve (island 0); needs the library built with -DRP_ISL_PROFILE."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from rapier_amd import PhysicsWorld, scenes as S, _ffi  # noqa: E402
+
+w = PhysicsWorld.from_scene(S.many_pyramids())
+w.step(200); w.sync()
+buf = np.zeros(64, np.int64)
+L = _ffi.lib()
+L.rp_debug_cycles.argtypes = [C.c_void_p, C.c_void_p]
+L.rp_debug_cycles(w._ptr, buf.ctypes.data)
+n = max(int(buf[63]), 1)
+names = ["load", "generate+pose0", "increment", "warmstart sweep", "biased sweep", "integrate", "pose stage", "relax sweep", "writeback"]
+tot = buf[:9].sum() / n
+for k, nm in enumerate(names):
+    print(f"{nm:18s} {buf[k] / n:10.0f} cycles/step  {100.0 * buf[k] / n / tot:5.1f}%")
+print(f"total {tot:.0f} cycles/step over {n} steps")
