@@ -30,7 +30,7 @@ def algorithmic_bytes_per_step(M: int, N: int, substeps: int = 4) -> float:
     return substeps * (M * (1100.0 + 476.0 + 1008.0) + N * 224.0)
 
 
-def cpu_baseline(steps: int = 120, warmup: int = 60):
+def cpu_baseline(steps: int = 300, warmup: int = 60):
     """The C oracle (a scalar port of the reference algorithm) timed on ONE host core on a bounded
     sample of the same workload."""
     from rapier_amd import scenes as S
@@ -98,7 +98,8 @@ def main():
     counters = w.counters()
     M, Nd = counters["num_manifolds"], counters["num_dynamic_bodies"]
 
-    # roofline leg: hipEvent-timed TGS velocity-solve loop on the world's own stream
+    # roofline leg: k_island_solve (one launch per step = the whole TGS velocity-solve loop of every
+    # island) timed with hipEvents on the world's own stream, right after the timed region
     w.enable_timers(True)
     w.step(args.roofline_steps)
     w.sync()
@@ -107,6 +108,11 @@ def main():
     w.enable_timers(False)
     bytes_step = algorithmic_bytes_per_step(M, Nd, int(scene.params["num_solver_iterations"]))
     achieved = bytes_step / (loop_ms * 1e-3) / 1e9 if loop_ms > 0 else 0.0
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "r01_many_pyramids_hbm_traffic.json")
+    if world == 1 and os.path.exists(tfile):  # PMC passes are separate rocprofv3 runs (tools/gpu_profile.sh)
+        with open(tfile) as f:
+            traffic = json.load(f).get("k_island_solve_hbm_bytes_per_launch")
 
     # readback (not timed): assemble the world state with one all-gather over RCCL/xGMI
     pos, vel = w.read_bodies()
@@ -135,10 +141,12 @@ def main():
             "config": {"workload": workload, "bodies_per_gpu": Nd, "solver_manifolds_per_gpu": M,
                        "colors": counters["num_colors"], "value_definition": "n_gpus * steps / max-over-ranks time"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "TGS velocity-solve loop (k_increment/k_stage<ws|bias|relax>/k_tail/k_integrate x 4 substeps)",
-                         "algorithmic_bytes_per_step": bytes_step, "loop_ms_per_step": loop_ms, "measured_steps": nmeas,
-                         "stage_ms": {k: tc[k] for k in ("collision_detection_ms", "velocity_assembly_ms", "velocity_resolution_ms", "velocity_update_ms")}},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_island_solve (TGS velocity-solve loop: 4 substeps x [warmstart, biased, relaxed sweeps] of all 196 islands, 1 launch/step)",
+                         "algorithmic_bytes_per_launch": bytes_step, "kernel_ms_per_launch": loop_ms, "measured_launches": nmeas,
+                         "traffic_note": "HBM bytes/launch from rocprofv3 PMC passes (profiles/); constraints live in VGPRs/LDS, so traffic << algorithmic bytes",
+                         "stage_ms": {k: tc[k] for k in ("collision_detection_ms", "velocity_resolution_ms", "velocity_update_ms")},
+                         "path": {k: tc[k] for k in ("fast_steps", "full_steps", "replayed_steps")}},
             "finite": finite,
         }
         if not args.no_cpu_baseline and world == 1:

@@ -104,9 +104,9 @@ typedef struct rp_counters {
     float narrow_phase_ms;         /* CollisionDetectionCounters::narrow_phase_time */
     float island_construction_ms;  /* StagesCounters::island_construction_time (colouring + buckets) */
     float solver_ms;               /* StagesCounters::solver_time */
-    float velocity_assembly_ms;    /* SolverCounters::velocity_assembly_time */
-    float velocity_resolution_ms;  /* SolverCounters::velocity_resolution_time (the TGS loop) */
-    float velocity_update_ms;      /* SolverCounters::velocity_update_time (writeback + advance) */
+    float velocity_assembly_ms;    /* SolverCounters::velocity_assembly_time (0: fused into the solve kernels) */
+    float velocity_resolution_ms;  /* SolverCounters::velocity_resolution_time: k_island_solve, the TGS loop of all LDS-resident islands */
+    float velocity_update_ms;      /* SolverCounters::velocity_update_time: the global solve path (large islands, free bodies) + writeback */
     int32_t num_pairs;             /* CollisionDetectionCounters::ncontact_pairs */
     int32_t num_manifolds;         /* SolverCounters::nconstraints (solver manifolds M) */
     int32_t num_solver_contacts;   /* SolverCounters::ncontacts */
@@ -162,8 +162,9 @@ int32_t rp_contacts_read(rp_world *w, int32_t cap, int32_t *c1_c2_color_count, f
 int32_t rp_counters_enable(rp_world *w, int32_t enable_timers);
 int32_t rp_counters_read(rp_world *w, rp_counters *out);
 
-/* Average device time (ms) of the TGS velocity-solve loop kernels over the steps since the last
- * call, measured with hipEvents on the world's stream (bench.py roofline leg). */
+/* Average device time (ms) of k_island_solve (the TGS velocity-solve loop of every LDS-resident island)
+ * per step since the last call, measured with hipEvents on the world's stream while timers are
+ * enabled (bench.py roofline leg). */
 int32_t rp_solver_loop_time_ms(rp_world *w, float *avg_ms_per_step, int32_t *steps_measured);
 
 #ifdef __cplusplus

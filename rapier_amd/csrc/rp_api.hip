@@ -71,7 +71,7 @@ struct rp_world {
     // timers
     bool timers = false;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    double acc_loop_ms = 0.0, acc_col_ms = 0.0, acc_asm_ms = 0.0, acc_fin_ms = 0.0, acc_step_ms = 0.0;
+    double acc_isl_ms = 0.0, acc_glob_ms = 0.0, acc_col_ms = 0.0, acc_step_ms = 0.0;
     int acc_steps = 0;
     double loop_ms_since_read = 0.0; int loop_steps_since_read = 0;
     std::string err;
@@ -440,9 +440,11 @@ static void enqueue_collision(rp_world *w) {
     rp_launch_narrowphase(w->dw, w->stream);
 }
 // build_islands_and_solve_velocity_constraints: LDS island megakernel + the global path
-static void enqueue_solver(rp_world *w) {
+static void enqueue_island_solver(rp_world *w) {
+    rp_launch_island_solve(w->dw, w->stream, w->plan_island_grid, w->has_restitution ? 1 : 0, w->cur_fast);
+}
+static void enqueue_global_solver(rp_world *w) {
     int hr = w->has_restitution ? 1 : 0;
-    rp_launch_island_solve(w->dw, w->stream, w->plan_island_grid, hr, w->cur_fast);
     if (w->plan_single) rp_launch_global_single(w->dw, w->stream, hr, w->cur_fast);
     else {
         rp_launch_solver_assembly(w->dw, w->stream);
@@ -450,6 +452,7 @@ static void enqueue_solver(rp_world *w) {
         rp_launch_solver_writeback(w->dw, w->stream);
     }
 }
+static void enqueue_solver(rp_world *w) { enqueue_island_solver(w); enqueue_global_solver(w); }
 static void enqueue_finish(rp_world *w) {
     // SINGLE mode: k_global_single already published the scalars to the mapped hint buffer
     if (!w->plan_single) hipMemcpyAsync(w->pinned_flags, w->dw.flags, FL_COUNT * sizeof(int), hipMemcpyDeviceToHost, w->stream);
@@ -474,6 +477,7 @@ static int capture(rp_world *w, hipGraph_t *g, hipGraphExec_t *ge, void (*fn)(rp
     HIPCHK(w, hipGraphInstantiate(ge, *g, nullptr, nullptr, 0));
     return RP_OK;
 }
+static void enqueue_global_and_finish(rp_world *w) { enqueue_global_solver(w); enqueue_finish(w); }
 static void enqueue_whole(rp_world *w) { enqueue_collision(w); enqueue_solver(w); enqueue_finish(w); }
 
 static int check_overflow(rp_world *w, const int *fl) {
@@ -497,8 +501,8 @@ static int launch_step(rp_world *w, int fast) {
         if (!w->ge_col[fast]) {
             int r;
             if ((r = capture(w, &w->g_col[fast], &w->ge_col[fast], enqueue_collision)) != RP_OK) return r;
-            if ((r = capture(w, &w->g_loop[fast], &w->ge_loop[fast], enqueue_solver)) != RP_OK) return r;
-            if (!w->plan_single && (r = capture(w, &w->g_fin[fast], &w->ge_fin[fast], enqueue_finish)) != RP_OK) return r;
+            if ((r = capture(w, &w->g_loop[fast], &w->ge_loop[fast], enqueue_island_solver)) != RP_OK) return r;
+            if ((r = capture(w, &w->g_fin[fast], &w->ge_fin[fast], enqueue_global_and_finish)) != RP_OK) return r;
         }
         HIPCHK(w, hipEventRecord(w->ev[0], w->stream));
         HIPCHK(w, hipGraphLaunch(w->ge_col[fast], w->stream));
@@ -511,7 +515,9 @@ static int launch_step(rp_world *w, int fast) {
         float a = 0, c = 0, d = 0;
         hipEventElapsedTime(&a, w->ev[0], w->ev[1]); hipEventElapsedTime(&c, w->ev[1], w->ev[2]); hipEventElapsedTime(&d, w->ev[2], w->ev[3]);
         if (!fast || !w->pinned_flags[FL_FAST_ABORT]) { // aborted fast steps did no work: keep them out of the averages
-            w->acc_col_ms += a; w->acc_loop_ms += c; w->acc_fin_ms += d; w->acc_step_ms += a + c + d; w->acc_steps++;
+            // SINGLE mode: c = k_island_solve alone (the TGS loop of every LDS-resident island), d = the
+            // global single-workgroup solve; MULTI mode: the per-colour launch sequence is in d.
+            w->acc_col_ms += a; w->acc_isl_ms += c; w->acc_glob_ms += d; w->acc_step_ms += a + c + d; w->acc_steps++;
             w->loop_ms_since_read += c; w->loop_steps_since_read++;
         }
         return RP_OK;
@@ -709,7 +715,7 @@ extern "C" int32_t rp_counters_enable(rp_world *w, int32_t enable) {
     if (enable && !w->ev[0]) for (auto &e : w->ev) HIPCHK(w, hipEventCreate(&e));
     if ((enable != 0) != w->timers) { int r = settle(w); if (r != RP_OK) return r; destroy_graphs(w); }
     w->timers = enable != 0;
-    w->acc_loop_ms = w->acc_col_ms = w->acc_asm_ms = w->acc_fin_ms = w->acc_step_ms = 0.0; w->acc_steps = 0;
+    w->acc_isl_ms = w->acc_glob_ms = w->acc_col_ms = w->acc_step_ms = 0.0; w->acc_steps = 0;
     w->loop_ms_since_read = 0.0; w->loop_steps_since_read = 0;
     return RP_OK;
 }
@@ -725,10 +731,10 @@ extern "C" int32_t rp_counters_read(rp_world *w, rp_counters *out) {
     double n = w->acc_steps > 0 ? (double)w->acc_steps : 1.0;
     out->step_time_ms = (float)(w->acc_step_ms / n);
     out->collision_detection_ms = (float)(w->acc_col_ms / n);
-    out->solver_ms = (float)((w->acc_asm_ms + w->acc_loop_ms + w->acc_fin_ms) / n);
-    out->velocity_assembly_ms = (float)(w->acc_asm_ms / n);
-    out->velocity_resolution_ms = (float)(w->acc_loop_ms / n);
-    out->velocity_update_ms = (float)(w->acc_fin_ms / n);
+    out->solver_ms = (float)((w->acc_isl_ms + w->acc_glob_ms) / n);
+    out->velocity_assembly_ms = 0.0f; // assembly is fused into the solve kernels
+    out->velocity_resolution_ms = (float)(w->acc_isl_ms / n);  // k_island_solve (LDS-resident islands)
+    out->velocity_update_ms = (float)(w->acc_glob_ms / n);     // global path (islands too large for LDS, free bodies)
     int live = 0;
     {
         int top = std::min(fl[FL_POOL_TOP], w->dw.pool_cap);

@@ -315,13 +315,14 @@ RP_DEV void isl_pose_stage(const DevWorld &w, IslSide &h, const IslLds &L, int m
 }
 
 // Velocity-dependent half of update + warmstart (:426-522, :633-678), colour-ordered.
-RP_DEV void isl_warmstart(const DevWorld &w, IslSide &h, const IslLds &L) {
+template <bool F4> RP_DEV void isl_warmstart_t(const DevWorld &w, IslSide &h, const IslLds &L) {
+    const int hn = F4 ? 4 : h.n;
     float wc = w.prm.p.warmstart_coefficient;
     bool ws = wc != 0.0f;
     Vel v = isl_vel(L, h.id);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if (k >= h.n) break;
+        if (k >= hn) break;
         SidePoint &p = h.P[k];
         p.rhs = p.rhsB; p.cfm = p.cfmB;
         p.acc += p.lam;
@@ -342,18 +343,20 @@ RP_DEV void isl_warmstart(const DevWorld &w, IslSide &h, const IslLds &L) {
         float s0 = h.odd ? -i0 : i0, s1 = h.odd ? -i1 : i1;
         v.lin = v.lin + cmul(h.t0 * s0 + h.t1 * s1, h.im);
         v.ang = v.ang + (h.itd0 * i0 + h.itd1 * i1);
-        if (h.n > 1) v.ang = v.ang + h.stw * dppf<DPP_FROM_EVEN>(h.tw_imp);
+        if (hn > 1) v.ang = v.ang + h.stw * dppf<DPP_FROM_EVEN>(h.tw_imp);
         isl_set_vel(L, h.id, v);
     }
 }
 
 // solve (:680-781); `relax` first switches to the bias-free right-hand sides of isl_pose_stage.
-RP_DEV void isl_solve(IslSide &h, const IslLds &L, bool relax, bool friction) {
+template <bool F4> RP_DEV void isl_solve_t(IslSide &h, const IslLds &L, bool relax, bool friction) {
+    const int hn = F4 ? 4 : h.n;
     Vel v = isl_vel(L, h.id);
+
     float imp[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if (k >= h.n) break;
+        if (k >= hn) break;
         SidePoint &p = h.P[k];
         if (relax) { p.rhs = p.rhsR; p.cfm = 1.0f; }
         float X = dot(h.dir, v.lin), Y = dot(p.pa, v.ang);
@@ -370,9 +373,9 @@ RP_DEV void isl_solve(IslSide &h, const IslLds &L, bool relax, bool friction) {
         if (relax) { h.t_rhs0 = h.rhs_wo0; h.t_rhs1 = h.rhs_wo1; }
         float tangent_limit = 0.0f, twist_limit = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { if (k >= h.n) break; tangent_limit += imp[k]; twist_limit += imp[k] * h.td[k]; }
+        for (int k = 0; k < 4; ++k) { if (k >= hn) break; tangent_limit += imp[k]; twist_limit += imp[k] * h.td[k]; }
         tangent_limit *= h.mu; twist_limit *= h.mu;
-        if (h.n > 1) {
+        if (hn > 1) {
             V3 w2 = dppv<DPP_FROM_ODD>(v.ang);
             float dvel = dot(h.dir, v.ang - w2) + 0.0f;
             float new_impulse = rp_clamp(h.tw_imp - h.twist_r * dvel, -twist_limit, twist_limit);
@@ -398,6 +401,15 @@ RP_DEV void isl_solve(IslSide &h, const IslLds &L, bool relax, bool friction) {
         }
     }
     isl_set_vel(L, h.id, v);
+}
+
+// Wave-uniform dispatch: when every active manifold of this wave has 4 points (face/face contacts, the
+// common case) the per-point exec-mask branches disappear.
+RP_DEV void isl_warmstart(const DevWorld &w, IslSide &h, const IslLds &L) {
+    if (__all(h.n == 4)) isl_warmstart_t<true>(w, h, L); else isl_warmstart_t<false>(w, h, L);
+}
+RP_DEV void isl_solve(IslSide &h, const IslLds &L, bool relax, bool friction) {
+    if (__all(h.n == 4)) isl_solve_t<true>(h, L, relax, friction); else isl_solve_t<false>(h, L, relax, friction);
 }
 
 // apply_restitution (:568-597)
@@ -549,6 +561,10 @@ __global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int ha
             ISL_STAMP(2); // increment
             for (int q = 0; q < nls; ++q) { if (myq == q) isl_warmstart(w, h, L); __syncthreads(); }
             ISL_STAMP(3); // warmstart sweep
+#ifdef RP_ISL_EXTRA_EMPTY
+            for (int q = 0; q < nls; ++q) { if (myq == q) { Vel v = isl_vel(L, h.id); isl_set_vel(L, h.id, v); } __syncthreads(); }
+            ISL_STAMP(9); // extra sweep of empty stages (overhead measurement only)
+#endif
             for (int it = 0; it < prm.num_internal_pgs_iterations; ++it)
                 for (int q = 0; q < nls; ++q) { if (myq == q) isl_solve(h, L, false, fib); __syncthreads(); }
             ISL_STAMP(4); // biased sweep

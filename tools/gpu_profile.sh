@@ -1,0 +1,19 @@
+#!/bin/bash
+# rocprofv3 evidence for one scene: kernel-trace stats + FETCH_SIZE / WRITE_SIZE PMC passes (separate runs).
+# Usage: tools/gpu_profile.sh <scene> <tag>     outputs: gpurun_out/<tag>_*
+set -u
+export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $OUT
+SC=${1:-many_pyramids}; TAG=${2:-prof}
+cd /tmp
+rm -rf /tmp/pr_kt /tmp/pr_f /tmp/pr_w
+RP_PROF_TIMERS=0 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/pr_kt -o kt -- python $GRAFT_REPO_ROOT/tools/prof_run.py $SC 300 > $OUT/${TAG}_kt.log 2>&1
+d=$(find /tmp/pr_kt -name '*.db' | head -1)
+[[ -n "$d" ]] && python $GRAFT_REPO_ROOT/tools/rocpd_stats.py $d > $OUT/${TAG}_kernel_stats.txt 2>&1
+find /tmp/pr_kt -name '*kernel_stats.csv' -exec cp {} $OUT/${TAG}_kernel_stats.csv \;
+RP_PROF_TIMERS=0 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pr_f -o f --output-format csv -- python $GRAFT_REPO_ROOT/tools/prof_run.py $SC 100 > $OUT/${TAG}_pmc_fetch.log 2>&1
+RP_PROF_TIMERS=0 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pr_w -o w --output-format csv -- python $GRAFT_REPO_ROOT/tools/prof_run.py $SC 100 > $OUT/${TAG}_pmc_write.log 2>&1
+python $GRAFT_REPO_ROOT/tools/pmc_summary.py /tmp/pr_f /tmp/pr_w > $OUT/${TAG}_hbm_traffic.json 2> $OUT/${TAG}_pmc_summary.err
+cat $OUT/${TAG}_hbm_traffic.json
+head -12 $OUT/${TAG}_kernel_stats.txt
+tail -2 $OUT/${TAG}_kt.log

@@ -1,0 +1,35 @@
+"""Summarise the FETCH_SIZE / WRITE_SIZE rocprofv3 PMC passes into HBM bytes per launch per kernel.
+
+gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE (KiB) reports half of the bytes of wide
+coalesced reads -> doubled; WRITE_SIZE (KiB) taken as is.  hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def load(dirname, counter):
+    acc = defaultdict(lambda: [0.0, 0])
+    for f in glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if row.get("Counter_Name") != counter:
+                    continue
+                a = acc[row["Kernel_Name"].split("(")[0]]
+                a[0] += float(row["Counter_Value"]); a[1] += 1
+    return acc
+
+
+fetch = load(sys.argv[1], "FETCH_SIZE")
+write = load(sys.argv[2], "WRITE_SIZE")
+out = {"unit": "bytes per launch", "correction": "hbm = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE under-count)", "kernels": {}}
+for k in sorted(set(fetch) | set(write)):
+    f = fetch[k][0] / max(fetch[k][1], 1) if k in fetch else 0.0
+    w = write[k][0] / max(write[k][1], 1) if k in write else 0.0
+    out["kernels"][k] = {"launches_fetch_pass": fetch[k][1] if k in fetch else 0, "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "hbm_bytes": (2.0 * f + w) * 1024.0}
+isl = out["kernels"].get("k_island_solve")
+out["k_island_solve_hbm_bytes_per_launch"] = isl["hbm_bytes"] if isl else None
+print(json.dumps(out, indent=1))
