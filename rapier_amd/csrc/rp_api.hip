@@ -35,8 +35,8 @@ void rp_launch_init_bodies(const DevWorld &w, hipStream_t st);
 void rp_launch_solver_assembly(const DevWorld &w, hipStream_t st);
 void rp_launch_solver_loop(const DevWorld &w, hipStream_t st, int parallel_stages, int stage_blocks, int has_restitution);
 void rp_launch_solver_writeback(const DevWorld &w, hipStream_t st);
+void rp_launch_island_solve(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast, int retire);
 void rp_launch_global_single(const DevWorld &w, hipStream_t st, int has_restitution, int fast);
-void rp_launch_island_solve(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast);
 void rp_launch_fast_front(const DevWorld &w, hipStream_t st);
 
 struct HostBody { rp_body_desc d; float inv_mass; float inv_pi[3]; float lcom[3]; int ncolliders; };
@@ -441,7 +441,8 @@ static void enqueue_collision(rp_world *w) {
 }
 // build_islands_and_solve_velocity_constraints: LDS island megakernel + the global path
 static void enqueue_island_solver(rp_world *w) {
-    rp_launch_island_solve(w->dw, w->stream, w->plan_island_grid, w->has_restitution ? 1 : 0, w->cur_fast);
+    // SINGLE mode: workgroup 0 of this launch retires the step (FL_SEQ / FL_STEP, hint publication)
+    rp_launch_island_solve(w->dw, w->stream, w->plan_island_grid, w->has_restitution ? 1 : 0, w->cur_fast, w->plan_single);
 }
 static void enqueue_global_solver(rp_world *w) {
     int hr = w->has_restitution ? 1 : 0;
@@ -454,7 +455,7 @@ static void enqueue_global_solver(rp_world *w) {
 }
 static void enqueue_solver(rp_world *w) { enqueue_island_solver(w); enqueue_global_solver(w); }
 static void enqueue_finish(rp_world *w) {
-    // SINGLE mode: k_global_single already published the scalars to the mapped hint buffer
+    // SINGLE mode: k_island_solve already published the scalars to the mapped hint buffer
     if (!w->plan_single) hipMemcpyAsync(w->pinned_flags, w->dw.flags, FL_COUNT * sizeof(int), hipMemcpyDeviceToHost, w->stream);
 }
 

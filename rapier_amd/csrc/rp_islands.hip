@@ -16,7 +16,7 @@
 // Island discovery (only when the active-manifold set changed): union-find hooking with atomicMin
 // over the active dynamic-dynamic pairs inside one workgroup, then island numbering and list filling.
 // persistent.rs keeps comparable connected components for sleeping; here they drive scheduling only.
-#include "rp_constraint.h"
+#include "rp_global.h"
 
 RP_DEV int ld_i32(int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 RP_DEV int uf_find(int *label, int x) {
@@ -492,8 +492,16 @@ RP_DEV void island_sort(const DevWorld &w, int isl, int nc, int cb, int nst_glob
 }
 
 // One workgroup = one island; lanes 2m, 2m+1 = manifold m (sorted by sweep stage), threads < nb also own a body.
-__global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int has_restitution, int fast) {
-    if (fast && w.flags[FL_FAST_ABORT]) return; // fast graph gave up on this step (rp_api.hip)
+__global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int has_restitution, int fast, int retire) {
+    const bool aborted = fast && w.flags[FL_FAST_ABORT]; // fast graph gave up on this step (rp_api.hip)
+    if (retire && blockIdx.x == 0) {
+        // SINGLE mode: workgroup 0 retires the step and publishes the scalars to the host hint buffer
+        // up front, so the PCIe writes overlap the solve instead of ending the step
+        if (threadIdx.x == 0) { w.flags[FL_SEQ] += 1; if (!aborted) w.flags[FL_STEP] += 1; }
+        __threadfence(); __syncthreads();
+        publish_flags(w);
+    }
+    if (aborted) return;
     __shared__ float4 B_lin[RP_ISL_NB_MAX], B_ang[RP_ISL_NB_MAX], B_rot[RP_ISL_NB_MAX], B_trans[RP_ISL_NB_MAX];
     __shared__ float4 L_E[4 * RP_ISL_NC_MAX], L_F[4 * RP_ISL_NC_MAX], L_B0[RP_ISL_NC_MAX], L_B1[RP_ISL_NC_MAX];
     __shared__ int S_a[RP_ISL_NC_MAX], S_b[RP_ISL_NC_MAX], S_c[RP_ISL_NC_MAX], S_d[RP_ISL_NC_MAX];
@@ -596,7 +604,7 @@ __global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int ha
 void rp_launch_islands_build(const DevWorld &w, hipStream_t st) {
     hipLaunchKernelGGL(k_islands_build, dim3(1), dim3(1024), 0, st, w);
 }
-void rp_launch_island_solve(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast) {
+void rp_launch_island_solve(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast, int retire) {
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(k_island_solve, dim3(grid), dim3(ISL_THREADS), 0, st, w, has_restitution, fast);
+    hipLaunchKernelGGL(k_island_solve, dim3(grid), dim3(ISL_THREADS), 0, st, w, has_restitution, fast, retire);
 }

@@ -17,43 +17,7 @@
 //     fits in LDS) ONE single-workgroup launch runs the whole assembly/loop/write-back sequence.
 // Both modes are correct for any amount of work; the host picks by lazily read hints.
 // No FMA contraction (-ffp-contract=off), IEEE divide/sqrt: same arithmetic as the reference's lanes.
-#include "rp_constraint.h"
-
-RP_DEV bool global_body(const DevWorld &w, int i) {
-    return (w.b_flags[i] & RP_BF_TYPE_MASK) == RP_BODY_DYNAMIC && w.b_island[i] < 0;
-}
-
-// ---- per-body device steps over the HBM solver-body arrays --------------------------------------
-RP_DEV void g_body_begin(const DevWorld &w, int i) {
-    V3 lin, ang, trans, incl, inca; Q4 rot;
-    body_begin(w, i, lin, ang, rot, trans, incl, inca);
-    w.s_inca[i] = f4(inca, 0.0f); w.s_incl[i] = f4(incl, 0.0f);
-    w.s_lin[i] = f4(lin, 0.0f); w.s_ang[i] = f4(ang, 0.0f);
-    w.s_rot[i] = f4(rot); w.s_trans[i] = f4(trans, 0.0f);
-}
-RP_DEV void g_body_increment(const DevWorld &w, int i) {
-    V3 lin = v3(w.s_lin[i]), ang = v3(w.s_ang[i]);
-    body_increment(w, w.b_flags[i], lin, ang, q4(w.s_rot[i]), v3(w.s_incl[i]), v3(w.s_inca[i]), v3(w.b_invpi[i]), q4(w.b_pframe[i]));
-    w.s_lin[i] = f4(lin, 0.0f); w.s_ang[i] = f4(ang, 0.0f);
-}
-RP_DEV void g_body_integrate(const DevWorld &w, int i) {
-    V3 lin = v3(w.s_lin[i]), ang = v3(w.s_ang[i]), trans = v3(w.s_trans[i]); Q4 rot = q4(w.s_rot[i]);
-    body_integrate(w, w.b_flags[i], lin, ang, rot, trans);
-    w.s_lin[i] = f4(lin, 0.0f); w.s_ang[i] = f4(ang, 0.0f); w.s_rot[i] = f4(rot); w.s_trans[i] = f4(trans, 0.0f);
-}
-RP_DEV void g_body_writeback(const DevWorld &w, int i) {
-    body_writeback(w, i, v3(w.s_lin[i]), v3(w.s_ang[i]), q4(w.s_rot[i]), v3(w.s_trans[i]));
-}
-RP_DEV bool g_generate(const DevWorld &w, int pos) {
-    int s = w.cons_pair[pos];
-    int rb1 = w.c_parent[w.p_c1[s]], rb2 = w.c_parent[w.p_c2[s]];
-    int rel_dom = w.p_reldom[s];
-    bool dyn1 = rb1 >= 0 && (w.b_flags[rb1] & RP_BF_TYPE_MASK) == RP_BODY_DYNAMIC;
-    bool dyn2 = rb2 >= 0 && (w.b_flags[rb2] & RP_BF_TYPE_MASK) == RP_BODY_DYNAMIC;
-    int id1 = (dyn1 && rel_dom <= 0) ? rb1 : -1;
-    int id2 = (dyn2 && rel_dom >= 0) ? rb2 : -1;
-    return cons_generate(w, GlobalAcc(w, pos), s, id1, id2, id1, id2);
-}
+#include "rp_global.h"
 
 // ---- MULTI mode kernels ---------------------------------------------------------------------------
 __global__ void k_solver_begin(DevWorld w) {
@@ -89,26 +53,6 @@ __global__ void __launch_bounds__(256) k_stage(DevWorld w, int stage, int fricti
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride)
         cons_apply(w, GlobalAcc(w, beg + i), MODE, friction_in_bias != 0, solved_dt);
 }
-// Serial tail of one sweep (worker 0 of the reference): stages [first, n_stages) one after the other
-// inside one workgroup, then the overflow colour on lane 0.
-template <int MODE>
-RP_DEV void tail_sweep(const DevWorld &w, int first, bool fib, float solved_dt) {
-    int nst = w.flags[FL_N_STAGES];
-    for (int st = first; st < nst; ++st) {
-        int beg = w.stage_begin[st], cnt = w.stage_count[st];
-        for (int i = threadIdx.x; i < cnt; i += blockDim.x) cons_apply(w, GlobalAcc(w, beg + i), MODE, fib, solved_dt);
-        __threadfence();
-        __syncthreads();
-    }
-    if (w.flags[FL_HAS_OVERFLOW_COLOR]) {
-        if (threadIdx.x == 0) {
-            int beg = w.stage_begin[nst], cnt = w.stage_count[nst];
-            for (int i = 0; i < cnt; ++i) { cons_apply(w, GlobalAcc(w, beg + i), MODE, fib, solved_dt); __threadfence(); }
-        }
-        __threadfence();
-        __syncthreads();
-    }
-}
 template <int MODE>
 __global__ void __launch_bounds__(1024) k_tail(DevWorld w, int first, int friction_in_bias, float solved_dt) {
     if (MODE == MODE_RESTITUTION && !w.flags[FL_ANY_BOUNCY]) return;
@@ -128,52 +72,7 @@ __global__ void k_writeback_bodies(DevWorld w) {
     g_body_writeback(w, i);
 }
 
-// ---- SINGLE mode: the whole global path in one workgroup -----------------------------------------
-// Last kernel of a step in SINGLE mode: also publishes the device scalars to the host-mapped hint
-// buffer (posted PCIe writes; the host only ever uses them as hints or after a stream sync).
-RP_DEV void publish_flags(const DevWorld &w) {
-    if (threadIdx.x < FL_COUNT) {
-        int v = __hip_atomic_load(&w.flags[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&w.host_flags[threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-__global__ void __launch_bounds__(1024) k_global_single(DevWorld w, int has_restitution, int fast) {
-    const int t = threadIdx.x, nt = blockDim.x;
-    __shared__ int bouncy;
-    const bool skip = fast && w.flags[FL_FAST_ABORT]; // fast graph gave up: the step is replayed by the full graph
-    if (t == 0) { w.flags[FL_SEQ] += 1; if (!skip) w.flags[FL_STEP] += 1; bouncy = 0; }
-    int M = w.flags[FL_N_CONS];
-    if (M > w.cons_cap) M = w.cons_cap;
-    int ngb = w.flags[FL_N_GLOB_BODIES];
-    if (skip || (M == 0 && ngb == 0)) { // nothing to do here (aborted, or everything lives in LDS islands)
-        __threadfence(); __syncthreads();
-        publish_flags(w);
-        return;
-    }
-    const rp_integration_params &prm = w.prm.p;
-    const bool fib = prm.friction_in_bias_pass || prm.num_internal_stabilization_iterations == 0;
-    const int nb = w.n_bodies;
-    __syncthreads();
-    for (int i = t; i < nb; i += nt) if (global_body(w, i)) g_body_begin(w, i);
-    __threadfence(); __syncthreads();
-    for (int pos = t; pos < M; pos += nt) if (g_generate(w, pos)) bouncy = 1;
-    __threadfence(); __syncthreads();
-    for (int sub = 0; sub < w.prm.num_substeps; ++sub) {
-        float solved_dt = (float)sub * w.prm.dt_sub;
-        for (int i = t; i < nb; i += nt) if (global_body(w, i)) g_body_increment(w, i);
-        __threadfence(); __syncthreads();
-        tail_sweep<MODE_WARMSTART>(w, 0, fib, solved_dt);
-        for (int it = 0; it < prm.num_internal_pgs_iterations; ++it) tail_sweep<MODE_BIAS>(w, 0, fib, solved_dt);
-        for (int i = t; i < nb; i += nt) if (global_body(w, i)) g_body_integrate(w, i);
-        __threadfence(); __syncthreads();
-        for (int it = 0; it < prm.num_internal_stabilization_iterations; ++it) tail_sweep<MODE_RELAX>(w, 0, fib, solved_dt + w.prm.dt_sub);
-    }
-    if (has_restitution && bouncy) tail_sweep<MODE_RESTITUTION>(w, 0, fib, 0.0f);
-    for (int pos = t; pos < M; pos += nt) cons_writeback(w, GlobalAcc(w, pos), w.cons_pair[pos]);
-    for (int i = t; i < nb; i += nt) if (global_body(w, i)) g_body_writeback(w, i);
-    __threadfence(); __syncthreads();
-    publish_flags(w);
-}
+__global__ void __launch_bounds__(1024) k_global_single(DevWorld w, int has_restitution, int fast) { global_single_block(w, has_restitution, fast); }
 
 // World mass properties at insertion time (RigidBodyMassProps::update_world_mass_properties).
 __global__ void k_init_bodies(DevWorld w) {
