@@ -138,8 +138,13 @@ int32_t rp_params_set(rp_world *w, const rp_integration_params *in);
 int32_t rp_bodies_insert(rp_world *w, int32_t n, const rp_body_desc *descs, uint64_t *handles_out);
 /* ColliderSet::insert_with_parent ×n (parent RP_INVALID_HANDLE = ColliderSet::insert). */
 int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider_desc *descs, const uint64_t *parents, uint64_t *handles_out);
-/* ImpulseJointSet::insert ×n. */
+/* ImpulseJointSet::insert ×n (impulse_joint_set.rs).  Device path scope: locked linear axes (spherical
+ * joints, JointAxesMask::LIN_AXES) with contacts between the two bodies enabled; anything else is
+ * refused with RP_ERR_INVALID. */
 int32_t rp_impulse_joints_insert(rp_world *w, int32_t n, const rp_joint_desc *descs, uint64_t *handles_out);
+/* ImpulseJoint::impulses (per locked linear dof, as written back by the last step) and the persistent
+ * solver colour of n joints (NULL handles = all, insertion order). */
+int32_t rp_impulse_joints_read(rp_world *w, int32_t n, const uint64_t *handles, int32_t *color_out, float *impulse3_out);
 
 /* PhysicsWorld::step() × nsteps with hooks = &(), events = &() (physics_world.rs:120-157). */
 int32_t rp_step(rp_world *w, uint32_t nsteps);

@@ -92,6 +92,29 @@ typedef struct {
 
 typedef struct { v3 linear, angular; } SolverVel;
 typedef struct { quat rotation; v3 translation; sym3 ii; v3 im; } SolverPose;
+
+/* ImpulseJoint (joint/impulse_joint/impulse_joint.rs) + JointConstraintBuilder
+ * (solver/joint_constraint/joint_constraint_builder.rs:19-60), restricted to locked linear axes
+ * (spherical joints: JointAxesMask::LIN_AXES). */
+typedef struct {
+    int body1, body2;
+    pose local_frame1, local_frame2;      /* GenericJoint::local_frame1/2 (body space) */
+    uint32_t locked_axes; int contacts_enabled;
+    uint8_t solver_color;                 /* persistent colour, impulse_joint.rs:38 */
+    uint32_t solver_body_ids[2];          /* stamped by select_active_interactions */
+    float impulses[6];                    /* per-dof impulses written back last step */
+    pose sb_frame1, sb_frame2;            /* frames in solver-body (CoM) space */
+    int first_row;
+} Joint;
+/* JointConstraint<Real, 1> — joint_velocity_constraint.rs:71-95 */
+typedef struct {
+    uint32_t solver_vel1, solver_vel2;
+    float impulse, impulse_bounds[2];
+    v3 lin_jac, ang_jac1, ang_jac2, ii_ang_jac1, ii_ang_jac2;
+    float inv_lhs, rhs, rhs_wo_bias, cfm_gain, cfm_coeff;
+    v3 im1, im2;
+    int dof;                              /* WritebackId::Dof(i) */
+} JointRow;
 typedef struct { int enabled; v3 principal_inertia, inv_principal_inertia; quat principal_frame; } Gyro;
 
 struct ro_world {
@@ -108,6 +131,11 @@ struct ro_world {
     Constraint *cons; int ncons, cap_cons;
     int bucket_begin[RO_NUM_COLORS + 1];
     int stage_color[RO_NUM_COLORS]; int nstages;
+    /* joints */
+    Joint *joints; int njoints, cap_joints;
+    int *active_joints; int nactive_joints;       /* select_active_interactions output (edge order) */
+    int *joint_order; int njoint_parallel;         /* solve order: parallel colours ascending, then the serial overflow */
+    JointRow *joint_rows; u128 *joint_body_colors;
     ro_stats stats;
 };
 
@@ -149,6 +177,13 @@ static float spring_cfm_factor(float freq, float damping, float dt) {
     return 1.0f / (1.0f + cfm_coeff);
 }
 
+static float spring_cfm_coeff(float freq, float damping, float dt) {
+    float erp = dt * spring_erp_inv_dt(freq, damping, dt);
+    if (erp == 0.0f) return 0.0f;
+    float inv_erp_minus_one = 1.0f / erp - 1.0f;
+    return inv_erp_minus_one * inv_erp_minus_one / ((1.0f + inv_erp_minus_one) * 4.0f * damping * damping);
+}
+
 float ro_combine_coefficient(float a, float b, int32_t ra, int32_t rb) {
     /* coefficient_combine_rule.rs:58-86 */
     int rule = ra > rb ? ra : rb;
@@ -177,7 +212,8 @@ void ro_world_free(ro_world *w) {
     if (!w) return;
     free(w->bodies); free(w->colliders); free(w->pairs); free(w->map_keys); free(w->map_vals);
     free(w->color_masks); free(w->vels); free(w->incr); free(w->poses); free(w->gyro); free(w->flags);
-    free(w->dyn_bodies); free(w->cons); free(w);
+    free(w->dyn_bodies); free(w->cons); free(w->joints); free(w->active_joints); free(w->joint_order);
+    free(w->joint_rows); free(w->joint_body_colors); free(w);
 }
 
 /* parry MassProperties::world_inv_inertia */
@@ -1012,6 +1048,192 @@ static v3 gyroscopic_corrected_angvel(v3 angvel, quat principal_axes, v3 pi, v3 
 }
 
 /* StagedIslandSolver::init_and_solve + run_worker — staged_island_solver/init.rs:30-545, worker.rs:32-898 */
+/* ------------------------------------------------------------------------------------ */
+/* Impulse joints */
+
+/* ImpulseJointSet::select_active_interactions — impulse_joint_set.rs:504-572 (no sleeping in scope):
+ * enabled joints with at least one dynamic body, in edge (insertion) order; stamps solver-body ids. */
+static void joints_select_active(ro_world *w) {
+    w->nactive_joints = 0;
+    for (int i = 0; i < w->njoints; ++i) {
+        Joint *j = &w->joints[i];
+        const Body *rb1 = &w->bodies[j->body1], *rb2 = &w->bodies[j->body2];
+        int d1 = rb1->body_type == RO_BODY_DYNAMIC, d2 = rb2->body_type == RO_BODY_DYNAMIC;
+        if (!d1 && !d2) continue;
+        j->solver_body_ids[0] = d1 ? rb1->solver_id : RO_NO_BODY;
+        j->solver_body_ids[1] = d2 ? rb2->solver_id : RO_NO_BODY;
+        w->active_joints[w->nactive_joints++] = i;
+    }
+}
+static u128 u128_or(u128 a, u128 b) { u128 r = {a.lo | b.lo, a.hi | b.hi}; return r; }
+/* ParallelInteractionGroups::group_interactions — interaction_groups.rs:59-197: greedy colouring of
+ * the joints in the contacts' colour space (external masks = persistent contact colours per body). */
+static void joints_color(ro_world *w) {
+    memset(w->joint_body_colors, 0, sizeof(u128) * (size_t)(w->ndyn + 1));
+    for (int a = 0; a < w->nactive_joints; ++a) {
+        Joint *j = &w->joints[w->active_joints[a]];
+        uint32_t id1 = j->solver_body_ids[0], id2 = j->solver_body_ids[1];
+        u128 ext = {0, 0};
+        if (j->body1 < w->cap_masks) ext = u128_or(ext, w->color_masks[j->body1]);
+        if (j->body2 < w->cap_masks) ext = u128_or(ext, w->color_masks[j->body2]);
+        int color;
+        if (id1 != RO_NO_BODY && id2 != RO_NO_BODY) {
+            u128 m = u128_or(u128_or(w->joint_body_colors[id1], w->joint_body_colors[id2]), ext);
+            if (j->solver_color < 128 && !u128_test(m, j->solver_color)) color = j->solver_color;
+            else { color = 128; for (int c = 0; c < RO_DYNAMIC_COLOR_COUNT; ++c) if (!u128_test(m, c)) { color = c; break; } }
+            if (color < 128) { u128_set(&w->joint_body_colors[id1], color); u128_set(&w->joint_body_colors[id2], color); }
+        } else {
+            uint32_t id = id1 != RO_NO_BODY ? id1 : id2;
+            u128 m = u128_or(w->joint_body_colors[id], ext);
+            if (j->solver_color < 128 && !u128_test(m, j->solver_color)) color = j->solver_color;
+            else { color = 128; for (int c = 127; c >= 0; --c) if (!u128_test(m, c)) { color = c; break; } }
+            if (color < 128) u128_set(&w->joint_body_colors[id], color);
+        }
+        j->solver_color = (uint8_t)color;
+    }
+    /* single_group_joint_layout — staged_island_solver/joints.rs:331-395: colours with at least
+     * JOINT_BATCH * LAYOUT_REF_WORKERS / 2 = 64 joints are parallel stages (ascending colour), every
+     * other colour (and the overflow colour 128) is solved serially afterwards, colour-major. */
+    int counts[RO_NUM_COLORS]; memset(counts, 0, sizeof(counts));
+    for (int a = 0; a < w->nactive_joints; ++a) counts[w->joints[w->active_joints[a]].solver_color]++;
+    int n = 0;
+    for (int pass = 0; pass < 2; ++pass)
+        for (int c = 0; c < RO_NUM_COLORS; ++c) {
+            int parallel = c < 128 && counts[c] >= 64;
+            if (counts[c] == 0 || (pass == 0) != parallel) continue;
+            for (int a = 0; a < w->nactive_joints; ++a)
+                if (w->joints[w->active_joints[a]].solver_color == c) w->joint_order[n++] = w->active_joints[a];
+            if (pass == 0) w->njoint_parallel = n;
+        }
+    if (n == 0) w->njoint_parallel = 0;
+}
+/* JointConstraintBuilder::generate — joint_constraint_builder.rs:34-60 +
+ * GenericJoint::transform_to_solver_body_space — generic_joint.rs:624-636 */
+static void joint_builder_generate(ro_world *w, Joint *j, int *num_rows) {
+    const Body *rb1 = &w->bodies[j->body1], *rb2 = &w->bodies[j->body2];
+    j->sb_frame1 = j->local_frame1; j->sb_frame2 = j->local_frame2;
+    if (rb1->body_type == RO_BODY_FIXED) j->sb_frame1 = pose_mul(rb1->position, j->local_frame1);
+    else j->sb_frame1.t = vsub(j->sb_frame1.t, rb1->local_com);
+    if (rb2->body_type == RO_BODY_FIXED) j->sb_frame2 = pose_mul(rb2->position, j->local_frame2);
+    else j->sb_frame2.t = vsub(j->sb_frame2.t, rb2->local_com);
+    j->first_row = *num_rows;
+    for (int i = 0; i < 3; ++i) if (j->locked_axes & (1u << i)) (*num_rows)++;
+}
+/* JointConstraint::<Real,1>::update (joint_velocity_constraint.rs:144-353) for locked linear axes:
+ * JointConstraintHelper::new (joint_constraint_helper.rs:95-164), lock_linear (:411-458),
+ * finalize_constraints (:676-720). */
+static int joint_update_rows(const ro_world *w, const Joint *j, float dt, JointRow *out) {
+    SolverPose rb1, rb2;
+    gather_pose(w, j->solver_body_ids[0], &rb1); gather_pose(w, j->solver_body_ids[1], &rb2);
+    pose p1, p2; p1.r = rb1.rotation; p1.t = rb1.translation; p2.r = rb2.rotation; p2.t = rb2.translation;
+    pose frame1 = pose_mul(p1, j->sb_frame1), frame2 = pose_mul(p2, j->sb_frame2);
+    v3 world_com1 = rb1.translation, world_com2 = rb2.translation;
+    float erp_inv_dt = spring_erp_inv_dt(w->params.joint_natural_frequency, w->params.joint_damping_ratio, dt);
+    float cfm_coeff = spring_cfm_coeff(w->params.joint_natural_frequency, w->params.joint_damping_ratio, dt);
+    float m[3][3]; quat_to_mat(frame1.r, m); /* basis: column i = (m[0][i], m[1][i], m[2][i]) */
+    v3 col[3]; for (int i = 0; i < 3; ++i) col[i] = V3(m[0][i], m[1][i], m[2][i]);
+    v3 lin_err = vsub(frame2.t, frame1.t);
+    v3 new_center1 = frame2.t;
+    for (int i = 0; i < 3; ++i) if (j->locked_axes & (1u << i)) new_center1 = vsub(new_center1, vmul(col[i], vdot(lin_err, col[i])));
+    frame1.t = new_center1;
+    v3 r1 = vsub(frame1.t, world_com1), r2 = vsub(frame2.t, world_com2);
+    /* cmat * basis: column i = gcross_matrix(r) * col[i] with glam Mat3 * Vec3 = x_axis*v.x + y_axis*v.y + z_axis*v.z */
+    v3 c1x = V3(0.0f, r1.z, -r1.y), c1y = V3(-r1.z, 0.0f, r1.x), c1z = V3(r1.y, -r1.x, 0.0f);
+    v3 c2x = V3(0.0f, r2.z, -r2.y), c2y = V3(-r2.z, 0.0f, r2.x), c2z = V3(r2.y, -r2.x, 0.0f);
+    int len = 0;
+    for (int i = 0; i < 3; ++i) {
+        if (!(j->locked_axes & (1u << i))) continue;
+        JointRow *c = &out[len++];
+        c->solver_vel1 = j->solver_body_ids[0]; c->solver_vel2 = j->solver_body_ids[1];
+        c->im1 = rb1.im; c->im2 = rb2.im;
+        c->impulse = 0.0f; c->impulse_bounds[0] = -FLT_MAX; c->impulse_bounds[1] = FLT_MAX;
+        c->lin_jac = col[i];
+        c->ang_jac1 = vadd(vadd(vmul(c1x, col[i].x), vmul(c1y, col[i].y)), vmul(c1z, col[i].z));
+        c->ang_jac2 = vadd(vadd(vmul(c2x, col[i].x), vmul(c2y, col[i].y)), vmul(c2z, col[i].z));
+        float rhs_wo_bias = 0.0f;
+        float rhs_bias = vdot(c->lin_jac, lin_err) * erp_inv_dt;
+        c->ii_ang_jac1 = sym3_mul(rb1.ii, c->ang_jac1);
+        c->ii_ang_jac2 = sym3_mul(rb2.ii, c->ang_jac2);
+        c->inv_lhs = 0.0f; c->cfm_coeff = cfm_coeff; c->cfm_gain = 0.0f;
+        c->rhs = rhs_wo_bias + rhs_bias; c->rhs_wo_bias = rhs_wo_bias; c->dof = i;
+    }
+    if (len == 0) return 0;
+    /* finalize_constraints: modified Gram-Schmidt */
+    v3 imsum = vadd(out[0].im1, out[0].im2);
+    for (int a = 0; a < len; ++a) {
+        JointRow *cj = &out[a];
+        float dot_jj = vdot(cj->lin_jac, vcmul(imsum, cj->lin_jac)) + vdot(cj->ii_ang_jac1, cj->ang_jac1) + vdot(cj->ii_ang_jac2, cj->ang_jac2);
+        float cfm_gain = dot_jj * cj->cfm_coeff + cj->cfm_gain;
+        float inv_dot_jj = ro_inv(dot_jj);
+        cj->inv_lhs = ro_inv(dot_jj + cfm_gain);
+        cj->cfm_gain = cfm_gain;
+        if (cj->impulse_bounds[0] != -FLT_MAX || cj->impulse_bounds[1] != FLT_MAX) continue;
+        for (int b = a + 1; b < len; ++b) {
+            JointRow *ci = &out[b];
+            float dot_ij = vdot(ci->lin_jac, vcmul(imsum, cj->lin_jac)) + vdot(ci->ii_ang_jac1, cj->ang_jac1) + vdot(ci->ii_ang_jac2, cj->ang_jac2);
+            float coeff = dot_ij * inv_dot_jj;
+            ci->lin_jac = vsub(ci->lin_jac, vmul(cj->lin_jac, coeff));
+            ci->ang_jac1 = vsub(ci->ang_jac1, vmul(cj->ang_jac1, coeff));
+            ci->ang_jac2 = vsub(ci->ang_jac2, vmul(cj->ang_jac2, coeff));
+            ci->ii_ang_jac1 = vsub(ci->ii_ang_jac1, vmul(cj->ii_ang_jac1, coeff));
+            ci->ii_ang_jac2 = vsub(ci->ii_ang_jac2, vmul(cj->ii_ang_jac2, coeff));
+            ci->rhs_wo_bias = ci->rhs_wo_bias - cj->rhs_wo_bias * coeff;
+            ci->rhs = ci->rhs - cj->rhs * coeff;
+        }
+    }
+    return len;
+}
+/* JointConstraintBuilder::update — joint_constraint_builder.rs:76-150 (row rebuild + warm-start carry) */
+static void joint_builder_update(ro_world *w, const Joint *j, float dt, int substep_id) {
+    JointRow *rows = &w->joint_rows[j->first_row];
+    float prev[3] = {0, 0, 0};
+    int ws = w->params.warmstart_joints;
+    int count = 0; for (int i = 0; i < 3; ++i) if (j->locked_axes & (1u << i)) count++;
+    if (ws && substep_id > 0) for (int k = 0; k < count; ++k) prev[k] = rows[k].impulse;
+    int len = joint_update_rows(w, j, dt, rows);
+    if (ws) {
+        float coeff = w->params.warmstart_coefficient;
+        for (int k = 0; k < len; ++k) rows[k].impulse = (substep_id == 0 ? j->impulses[rows[k].dof] : prev[k]) * coeff;
+    }
+}
+/* JointConstraint::solve_generic / warmstart_generic — joint_velocity_constraint.rs:97-142 */
+static void joint_row_warmstart(ro_world *w, JointRow *c) {
+    SolverVel v1, v2; gather_vel(w, c->solver_vel1, &v1); gather_vel(w, c->solver_vel2, &v2);
+    v3 lin_impulse = vmul(c->lin_jac, c->impulse);
+    v3 ii1 = vmul(c->ii_ang_jac1, c->impulse), ii2 = vmul(c->ii_ang_jac2, c->impulse);
+    v1.linear = vadd(v1.linear, vcmul(lin_impulse, c->im1)); v1.angular = vadd(v1.angular, ii1);
+    v2.linear = vsub(v2.linear, vcmul(lin_impulse, c->im2)); v2.angular = vsub(v2.angular, ii2);
+    scatter_vel(w, c->solver_vel1, &v1); scatter_vel(w, c->solver_vel2, &v2);
+}
+static void joint_row_solve(ro_world *w, JointRow *c) {
+    SolverVel v1, v2; gather_vel(w, c->solver_vel1, &v1); gather_vel(w, c->solver_vel2, &v2);
+    float dlinvel = vdot(c->lin_jac, vsub(v2.linear, v1.linear));
+    float dangvel = vdot(c->ang_jac2, v2.angular) - vdot(c->ang_jac1, v1.angular);
+    float rhs = dlinvel + dangvel + c->rhs;
+    float total = ro_clampf(c->impulse + c->inv_lhs * (rhs - c->cfm_gain * c->impulse), c->impulse_bounds[0], c->impulse_bounds[1]);
+    float delta = total - c->impulse;
+    c->impulse = total;
+    v3 lin_impulse = vmul(c->lin_jac, delta);
+    v3 ii1 = vmul(c->ii_ang_jac1, delta), ii2 = vmul(c->ii_ang_jac2, delta);
+    v1.linear = vadd(v1.linear, vcmul(lin_impulse, c->im1)); v1.angular = vadd(v1.angular, ii1);
+    v2.linear = vsub(v2.linear, vcmul(lin_impulse, c->im2)); v2.angular = vsub(v2.angular, ii2);
+    scatter_vel(w, c->solver_vel1, &v1); scatter_vel(w, c->solver_vel2, &v2);
+}
+/* The joint part of solve_pass — staged_island_solver/solve.rs:31-150: every joint (parallel colours
+ * ascending, then the serial overflow) solves BEFORE any contact in every pass. */
+static void joints_solve_pass(ro_world *w, int wo_bias, int warmstart_joints) {
+    for (int a = 0; a < w->nactive_joints; ++a) {
+        const Joint *j = &w->joints[w->joint_order[a]];
+        int count = 0; for (int i = 0; i < 3; ++i) if (j->locked_axes & (1u << i)) count++;
+        for (int k = 0; k < count; ++k) {
+            JointRow *c = &w->joint_rows[j->first_row + k];
+            if (wo_bias) c->rhs = c->rhs_wo_bias;
+            if (warmstart_joints) joint_row_warmstart(w, c);
+            joint_row_solve(w, c);
+        }
+    }
+}
+
 static void solve_velocity_constraints(ro_world *w) {
     const ro_params *prm = &w->params;
     int num_substeps = prm->num_solver_iterations;
@@ -1085,6 +1307,16 @@ static void solve_velocity_constraints(ro_world *w) {
         for (int k = 0; k < w->cons[i].num_contacts; ++k) any_bouncy |= w->cons[i].infos[k].restitution_seed < 0.0f;
     }
     free(order);
+    /* joints: selection, colouring in the contacts' colour space, builders — init_joints, joints.rs:25-329 */
+    int num_joint_rows = 0;
+    if (w->njoints > 0) {
+        w->joint_body_colors = (u128 *)realloc(w->joint_body_colors, sizeof(u128) * (size_t)(nd + 1));
+        masks_reserve(w, w->nbodies + 1);
+        joints_select_active(w);
+        joints_color(w);
+        for (int a = 0; a < w->nactive_joints; ++a) joint_builder_generate(w, &w->joints[w->active_joints[a]], &num_joint_rows);
+        w->joint_rows = (JointRow *)realloc(w->joint_rows, sizeof(JointRow) * (size_t)(num_joint_rows + 1));
+    } else w->nactive_joints = 0;
 
     int solve_friction_in_bias = prm->friction_in_bias_pass || prm->num_internal_stabilization_iterations == 0;
     float max_lin = prm->normalized_max_linear_velocity * prm->length_unit;
@@ -1101,6 +1333,8 @@ static void solve_velocity_constraints(ro_world *w) {
                                                                  w->gyro[i].inv_principal_inertia, dt_s);
             }
         }
+        /* S3 joint rows rebuilt from the current poses — worker.rs:287-357 */
+        for (int a = 0; a < w->nactive_joints; ++a) joint_builder_update(w, &w->joints[w->active_joints[a]], dt_s, s);
         /* S4 fused update + warmstart per colour — worker.rs:438-538 (non-fused when coefficient == 0) */
         for (int st = 0; st < w->nstages; ++st) {
             int c = w->stage_color[st];
@@ -1110,11 +1344,13 @@ static void solve_velocity_constraints(ro_world *w) {
             }
         }
         /* S5 biased pass — worker.rs:544-561, staged_island_solver/solve.rs:12-209 */
-        for (int it = 0; it < prm->num_internal_pgs_iterations; ++it)
+        for (int it = 0; it < prm->num_internal_pgs_iterations; ++it) {
+            joints_solve_pass(w, 0, prm->warmstart_joints && it == 0);
             for (int st = 0; st < w->nstages; ++st) {
                 int c = w->stage_color[st];
                 for (int i = w->bucket_begin[c]; i < w->bucket_begin[c + 1]; ++i) constraint_solve(w, &w->cons[i], solve_friction_in_bias);
             }
+        }
         /* S6 integrate — worker.rs:568-631, rigid_body_components.rs:884-898 */
         for (int i = 0; i < nd; ++i) {
             SolverVel *v = &w->vels[i];
@@ -1126,7 +1362,8 @@ static void solve_velocity_constraints(ro_world *w) {
             w->poses[i].translation = vadd(w->poses[i].translation, vmul(v->linear, dt_s));
         }
         /* S7 unbiased pass with refreshed rhs — worker.rs:636-649 */
-        for (int it = 0; it < prm->num_internal_stabilization_iterations; ++it)
+        for (int it = 0; it < prm->num_internal_stabilization_iterations; ++it) {
+            joints_solve_pass(w, 1, 0);
             for (int st = 0; st < w->nstages; ++st) {
                 int c = w->stage_color[st];
                 for (int i = w->bucket_begin[c]; i < w->bucket_begin[c + 1]; ++i) {
@@ -1134,6 +1371,7 @@ static void solve_velocity_constraints(ro_world *w) {
                     constraint_solve(w, &w->cons[i], 1);
                 }
             }
+        }
     }
     /* S8 restitution — worker.rs:657-734 */
     if (any_bouncy)
@@ -1143,6 +1381,12 @@ static void solve_velocity_constraints(ro_world *w) {
         }
     /* S9 impulse writeback — worker.rs:742-802 */
     for (int i = 0; i < M; ++i) constraint_writeback(w, &w->cons[i]);
+    /* JointConstraintsSet::writeback_impulses — joint_velocity_constraint.rs:346-353 */
+    for (int a = 0; a < w->nactive_joints; ++a) {
+        Joint *j = &w->joints[w->active_joints[a]];
+        int k = 0;
+        for (int i = 0; i < 3; ++i) if (j->locked_axes & (1u << i)) { j->impulses[i] = w->joint_rows[j->first_row + k].impulse; k++; }
+    }
     /* S10 body writeback — worker.rs:809-897 */
     for (int i = 0; i < nd; ++i) {
         Body *rb = &w->bodies[w->dyn_bodies[i]];
@@ -1211,4 +1455,33 @@ int32_t ro_dump_manifolds(const ro_world *w, int32_t cap, int32_t *meta, float *
     }
     return n;
 }
-int32_t ro_add_joint(ro_world *w, const ro_joint_desc *d) { (void)w; (void)d; return -1; }
+/* ImpulseJointSet::insert — impulse_joint_set.rs.  Scope: locked linear axes only (spherical joints),
+ * contacts between the two bodies enabled. */
+int32_t ro_add_joint(ro_world *w, const ro_joint_desc *d) {
+    if (d->body1 < 0 || d->body2 < 0 || d->body1 >= w->nbodies || d->body2 >= w->nbodies) return -1;
+    if ((d->locked_axes & ~7u) != 0 || !d->contacts_enabled) return -1;
+    if (w->njoints == w->cap_joints) {
+        w->cap_joints = w->cap_joints ? w->cap_joints * 2 : 1024;
+        w->joints = (Joint *)realloc(w->joints, sizeof(Joint) * w->cap_joints);
+        w->active_joints = (int *)realloc(w->active_joints, sizeof(int) * w->cap_joints);
+        w->joint_order = (int *)realloc(w->joint_order, sizeof(int) * w->cap_joints);
+    }
+    Joint *j = &w->joints[w->njoints];
+    memset(j, 0, sizeof(*j));
+    j->body1 = d->body1; j->body2 = d->body2;
+    j->local_frame1.t = V3(d->local_anchor1[0], d->local_anchor1[1], d->local_anchor1[2]);
+    j->local_frame2.t = V3(d->local_anchor2[0], d->local_anchor2[1], d->local_anchor2[2]);
+    j->local_frame1.r = qnormalize(Q(d->local_basis1[0], d->local_basis1[1], d->local_basis1[2], d->local_basis1[3]));
+    j->local_frame2.r = qnormalize(Q(d->local_basis2[0], d->local_basis2[1], d->local_basis2[2], d->local_basis2[3]));
+    j->locked_axes = d->locked_axes; j->contacts_enabled = d->contacts_enabled;
+    j->solver_color = 255; /* default_solver_color: uncoloured */
+    return w->njoints++;
+}
+int32_t ro_num_joints(const ro_world *w) { return w->njoints; }
+/* per joint: (colour, impulse x, y, z) */
+void ro_read_joints(const ro_world *w, int32_t *color, float *impulses3) {
+    for (int i = 0; i < w->njoints; ++i) {
+        if (color) color[i] = w->joints[i].solver_color;
+        if (impulses3) for (int k = 0; k < 3; ++k) impulses3[3 * i + k] = w->joints[i].impulses[k];
+    }
+}

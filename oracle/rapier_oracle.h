@@ -93,6 +93,8 @@ void ro_world_free(ro_world *w);
 int32_t ro_add_body(ro_world *w, const ro_body_desc *d);
 int32_t ro_add_collider(ro_world *w, const ro_collider_desc *d, int32_t parent_body);
 int32_t ro_add_joint(ro_world *w, const ro_joint_desc *d);
+int32_t ro_num_joints(const ro_world *w);
+void ro_read_joints(const ro_world *w, int32_t *color, float *impulses3);
 void ro_step(ro_world *w, int32_t nsteps);
 int32_t ro_num_bodies(const ro_world *w);
 /* pos7 = (tx,ty,tz, qx,qy,qz,qw) per body, vel6 = (lin, ang) per body, arena order. */

@@ -17,7 +17,8 @@ RP_INVALID_HANDLE = 0xFFFFFFFFFFFFFFFF
 # every symbol include/rapier_hip.h declares
 SYMBOLS = [
     "rp_world_create", "rp_world_destroy", "rp_last_error", "rp_default_params", "rp_params_get",
-    "rp_params_set", "rp_bodies_insert", "rp_colliders_insert", "rp_impulse_joints_insert", "rp_step",
+    "rp_params_set", "rp_bodies_insert", "rp_colliders_insert", "rp_impulse_joints_insert",
+    "rp_impulse_joints_read", "rp_step",
     "rp_sync", "rp_bodies_read", "rp_bodies_write", "rp_num_bodies", "rp_contacts_read",
     "rp_counters_enable", "rp_counters_read", "rp_solver_loop_time_ms",
 ]
@@ -60,6 +61,7 @@ def lib():
     L.rp_bodies_insert.argtypes = [vp, i32, vp, vp]
     L.rp_colliders_insert.argtypes = [vp, i32, vp, vp, vp]
     L.rp_impulse_joints_insert.argtypes = [vp, i32, vp, vp]
+    L.rp_impulse_joints_read.argtypes = [vp, i32, vp, vp, vp]
     L.rp_step.argtypes = [vp, u32]
     L.rp_sync.argtypes = [vp]
     L.rp_bodies_read.argtypes = [vp, i32, vp, vp, vp]

@@ -33,7 +33,7 @@ void rp_launch_broadphase(const DevWorld &w, hipStream_t st);
 void rp_launch_narrowphase(const DevWorld &w, hipStream_t st);
 void rp_launch_init_bodies(const DevWorld &w, hipStream_t st);
 void rp_launch_solver_assembly(const DevWorld &w, hipStream_t st);
-void rp_launch_solver_loop(const DevWorld &w, hipStream_t st, int parallel_stages, int stage_blocks, int has_restitution);
+void rp_launch_solver_loop(const DevWorld &w, hipStream_t st, int parallel_stages, int stage_blocks, int has_restitution, int joint_stages);
 void rp_launch_solver_writeback(const DevWorld &w, hipStream_t st);
 void rp_launch_island_solve(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast, int retire);
 void rp_launch_global_single(const DevWorld &w, hipStream_t st, int has_restitution, int fast);
@@ -50,18 +50,19 @@ struct rp_world {
     std::vector<rp_collider_desc> colliders;
     std::vector<int> collider_parent;
     std::vector<rp_joint_desc> joints;
+    std::vector<int> active_joint_ids; // device joint index -> index into `joints`
     bool finalized = false;
     bool hints_valid = false;
     std::vector<void *> allocs;
     DevWorld dw;
     int *pinned_flags = nullptr; // FL_COUNT ints, written by an async D2H copy at the end of each step
     // launch plan + graph
-    int plan_stages = 0, plan_blocks = 1, plan_single = 1, plan_island_grid = 1;
+    int plan_stages = 0, plan_blocks = 1, plan_single = 1, plan_island_grid = 1, plan_joint_stages = 0;
     bool has_restitution = false;
     // [0] = full path, [1] = fast path; "whole" = one graph per step, col/loop/fin = timed thirds
     hipGraph_t g_whole[2] = {nullptr, nullptr}, g_col[2] = {nullptr, nullptr}, g_loop[2] = {nullptr, nullptr}, g_fin[2] = {nullptr, nullptr};
     hipGraphExec_t ge_whole[2] = {nullptr, nullptr}, ge_col[2] = {nullptr, nullptr}, ge_loop[2] = {nullptr, nullptr}, ge_fin[2] = {nullptr, nullptr};
-    int graph_stages = -1, graph_blocks = -1, graph_single = -1, graph_island_grid = -1;
+    int graph_stages = -1, graph_blocks = -1, graph_single = -1, graph_island_grid = -1, graph_joint_stages = -1;
     bool use_graph = true, use_fast = true;
     int cur_fast = 0;              // mode the enqueue_* callbacks capture
     long long steps_requested = 0; // steps asked for since finalize (device FL_STEP counts the executed ones)
@@ -135,6 +136,19 @@ static float spring_cfm_factor(float freq, float damping, float dt) {
     return 1.0f / den;
 }
 
+static float spring_cfm_coeff(float freq, float damping, float dt) {
+    volatile float erp = dt * spring_erp_inv_dt(freq, damping, dt);
+    if (erp == 0.0f) return 0.0f;
+    volatile float q = 1.0f / erp;
+    volatile float iem1 = q - 1.0f;
+    volatile float num = iem1 * iem1;
+    volatile float d0 = 1.0f + iem1;
+    volatile float d1 = d0 * 4.0f;
+    volatile float d2 = d1 * damping;
+    volatile float d3 = d2 * damping;
+    return num / d3;
+}
+
 static void fill_sim_params(rp_world *w, SimParams &sp, float cell) {
     const rp_integration_params &p = w->params;
     sp.p = p;
@@ -147,6 +161,8 @@ static void fill_sim_params(rp_world *w, SimParams &sp, float cell) {
     sp.static_cfm = spring_cfm_factor(p.static_contact_natural_frequency, p.static_contact_damping_ratio, dts);
     sp.dyn_erp_inv_dt = spring_erp_inv_dt(p.contact_natural_frequency, p.contact_damping_ratio, dts);
     sp.static_erp_inv_dt = spring_erp_inv_dt(p.static_contact_natural_frequency, p.static_contact_damping_ratio, dts);
+    sp.joint_erp_inv_dt = spring_erp_inv_dt(p.joint_natural_frequency, p.joint_damping_ratio, dts);
+    sp.joint_cfm_coeff = spring_cfm_coeff(p.joint_natural_frequency, p.joint_damping_ratio, dts);
     sp.prediction = p.normalized_prediction_distance * p.length_unit;
     sp.recycle_distance = p.contact_recycling ? p.normalized_contact_recycle_distance * p.length_unit : 0.0f;
     sp.max_corrective_velocity = p.normalized_max_corrective_velocity * p.length_unit;
@@ -185,7 +201,7 @@ static void destroy_graphs(rp_world *w) {
         for (auto e : ex) if (*e) { hipGraphExecDestroy(*e); *e = nullptr; }
         for (auto g : gr) if (*g) { hipGraphDestroy(*g); *g = nullptr; }
     }
-    w->graph_stages = -1; w->graph_blocks = -1; w->graph_single = -1; w->graph_island_grid = -1;
+    w->graph_stages = -1; w->graph_blocks = -1; w->graph_single = -1; w->graph_island_grid = -1; w->graph_joint_stages = -1;
 }
 static void free_device(rp_world *w) {
     destroy_graphs(w);
@@ -287,8 +303,17 @@ extern "C" int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider
 }
 extern "C" int32_t rp_impulse_joints_insert(rp_world *w, int32_t n, const rp_joint_desc *descs, uint64_t *handles_out) {
     if (!w || n < 0 || (n > 0 && !descs)) return RP_ERR_INVALID;
-    if (n > 0) { w->err = "rp_impulse_joints_insert: impulse joints are not implemented on the device path yet"; return RP_ERR_INVALID; }
-    (void)handles_out;
+    for (int i = 0; i < n; ++i) {
+        const rp_joint_desc &j = descs[i];
+        if (j.body1 < 0 || j.body2 < 0 || j.body1 >= (int)w->bodies.size() || j.body2 >= (int)w->bodies.size()) { w->err = "rp_impulse_joints_insert: invalid body index"; return RP_ERR_INVALID; }
+        if ((j.locked_axes & ~7u) != 0) { w->err = "rp_impulse_joints_insert: only locked linear axes (spherical joints) are implemented on the device path"; return RP_ERR_INVALID; }
+        if (!j.contacts_enabled) { w->err = "rp_impulse_joints_insert: contacts_enabled = false is not implemented on the device path"; return RP_ERR_INVALID; }
+    }
+    if (w->finalized && n > 0) { hipSetDevice(w->device); hipStreamSynchronize(w->stream); free_device(w); }
+    for (int i = 0; i < n; ++i) {
+        w->joints.push_back(descs[i]);
+        if (handles_out) handles_out[i] = (uint64_t)(w->joints.size() - 1);
+    }
     return RP_OK;
 }
 
@@ -373,6 +398,48 @@ static int finalize(rp_world *w) {
     DAF(d.p_island, P, 0xff);
     DA(d.isl_body_begin, nb); DA(d.isl_nb, nb); DA(d.isl_cons_begin, nb); DA(d.isl_nc, nb); DA(d.isl_fill_b, nb); DA(d.isl_fill_c, nb);
     DA(d.isl_bodies, nb); DA(d.isl_cons, P); DA(d.isl_cstage, P); DA(d.isl_sorted, nb); DA(d.isl_nstages, nb);
+    // impulse joints: only joints with a dynamic side are active (select_active_interactions,
+    // impulse_joint_set.rs:504-572), kept in edge order; frames go to solver-body space once
+    // (GenericJoint::transform_to_solver_body_space, generic_joint.rs:624-636)
+    std::vector<int> jb1, jb2, jlocked, jcolor, bnj(nb, 0);
+    std::vector<float4> jf1t, jf1r, jf2t, jf2r;
+    w->active_joint_ids.clear();
+    for (size_t ji = 0; ji < w->joints.size(); ++ji) {
+        const rp_joint_desc &j = w->joints[ji];
+        const HostBody &rb1 = w->bodies[j.body1], &rb2 = w->bodies[j.body2];
+        bool d1 = rb1.d.body_type == RP_BODY_DYNAMIC, d2 = rb2.d.body_type == RP_BODY_DYNAMIC;
+        if (!d1 && !d2) continue;
+        auto body_pose = [](const HostBody &b) {
+            Pose p; const float *r = b.d.rotation;
+            float qn = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
+            float qi = qn > 0.0f ? 1.0f / qn : 1.0f;
+            p.r = q4(r[0] * qi, r[1] * qi, r[2] * qi, qn > 0.0f ? r[3] * qi : 1.0f);
+            p.t = v3(b.d.translation[0], b.d.translation[1], b.d.translation[2]);
+            return p;
+        };
+        auto local_frame = [](const float *anchor, const float *basis) {
+            Pose p; p.r = qnormalize(q4(basis[0], basis[1], basis[2], basis[3])); p.t = v3(anchor[0], anchor[1], anchor[2]); return p;
+        };
+        Pose f1 = local_frame(j.local_anchor1, j.local_basis1), f2 = local_frame(j.local_anchor2, j.local_basis2);
+        if (!d1) f1 = pose_mul(body_pose(rb1), f1); else f1.t = f1.t - v3(rb1.lcom[0], rb1.lcom[1], rb1.lcom[2]);
+        if (!d2) f2 = pose_mul(body_pose(rb2), f2); else f2.t = f2.t - v3(rb2.lcom[0], rb2.lcom[1], rb2.lcom[2]);
+        jb1.push_back(d1 ? j.body1 : -1); jb2.push_back(d2 ? j.body2 : -1);
+        jf1t.push_back(mk4(f1.t.x, f1.t.y, f1.t.z, 0)); jf1r.push_back(mk4(f1.r.x, f1.r.y, f1.r.z, f1.r.w));
+        jf2t.push_back(mk4(f2.t.x, f2.t.y, f2.t.z, 0)); jf2r.push_back(mk4(f2.r.x, f2.r.y, f2.r.z, f2.r.w));
+        jlocked.push_back((int)j.locked_axes); jcolor.push_back(RP_COLOR_UNCOLORED);
+        if (d1) bnj[j.body1]++;
+        if (d2) bnj[j.body2]++;
+        w->active_joint_ids.push_back((int)ji);
+    }
+    int nj = (int)jb1.size();
+    d.n_joints = nj;
+    DA(d.j_b1, nj); DA(d.j_b2, nj); DA(d.j_f1t, nj); DA(d.j_f1r, nj); DA(d.j_f2t, nj); DA(d.j_f2r, nj);
+    DA(d.j_locked, nj); DA(d.j_color, nj); DA(d.j_tmp, nj); DA(d.j_order, nj); DA(d.j_imp, nj);
+    DA(d.j_stage_begin, RP_NUM_COLORS + 1); DA(d.j_stage_count, RP_NUM_COLORS + 1);
+    DA(d.bj_cmask, 4 * (size_t)nb); DAF(d.bj_min, nb, 0xff); DA(d.b_njoints, nb);
+    DA(d.JR, (size_t)17 * std::max(nj, 1));
+    UP(d.j_b1, jb1); UP(d.j_b2, jb2); UP(d.j_f1t, jf1t); UP(d.j_f1r, jf1r); UP(d.j_f2t, jf2t); UP(d.j_f2r, jf2r);
+    UP(d.j_locked, jlocked); UP(d.j_color, jcolor); UP(d.b_njoints, bnj);
     DA(d.C, (size_t)CP_COUNT * d.cons_cap);
     DA(d.k_b1, d.cons_cap); DA(d.k_b2, d.cons_cap); DA(d.k_n, d.cons_cap); DA(d.k_cid, d.cons_cap);
 
@@ -419,7 +486,7 @@ static int finalize(rp_world *w) {
     UP(d.c_parent, cpar); UP(d.c_shape, csh); UP(d.c_lpos, clp); UP(d.c_lrot, clr); UP(d.c_he, che); UP(d.c_mat, cmat);
     UP(d.c_rules, crul); UP(d.c_groups, cgrp); UP(d.c_fatmin, fmn); UP(d.c_fatmax, fmx);
     std::vector<int> fl(FL_COUNT, 0);
-    fl[FL_BP_DIRTY] = 1; fl[FL_LAYOUT_DIRTY] = 1;
+    fl[FL_BP_DIRTY] = 1; fl[FL_LAYOUT_DIRTY] = 1; fl[FL_JOINT_DIRTY] = 1;
     UP(d.flags, fl);
     HIPCHK(w, hipHostMalloc((void **)&w->pinned_flags, FL_COUNT * sizeof(int), hipHostMallocMapped));
     memset(w->pinned_flags, 0, FL_COUNT * sizeof(int));
@@ -449,7 +516,7 @@ static void enqueue_global_solver(rp_world *w) {
     if (w->plan_single) rp_launch_global_single(w->dw, w->stream, hr, w->cur_fast);
     else {
         rp_launch_solver_assembly(w->dw, w->stream);
-        rp_launch_solver_loop(w->dw, w->stream, w->plan_stages, w->plan_blocks, hr);
+        rp_launch_solver_loop(w->dw, w->stream, w->plan_stages, w->plan_blocks, hr, w->plan_joint_stages);
         rp_launch_solver_writeback(w->dw, w->stream);
     }
 }
@@ -462,10 +529,11 @@ static void enqueue_finish(rp_world *w) {
 static int pow2_ceil(int x) { int b = 1; while (b < x) b <<= 1; return b; }
 static void plan_from_hints(rp_world *w, const int *fl) {
     // global path: one workgroup is enough while it holds little work, else one launch per colour stage
-    w->plan_single = (fl[FL_N_CONS] <= 1024 && fl[FL_N_GLOB_BODIES] <= 4096) ? 1 : 0;
+    w->plan_single = (fl[FL_N_CONS] <= 1024 && fl[FL_N_GLOB_BODIES] <= 4096 && w->dw.n_joints <= 1024) ? 1 : 0;
     const char *force = getenv("RP_FORCE_MULTI");
     if (force && force[0] == '1') w->plan_single = 0;
     w->plan_stages = fl[FL_N_PARALLEL];
+    w->plan_joint_stages = fl[FL_NJ_STAGES];
     // round up to a power of two so small changes of the stage size do not force a re-capture
     w->plan_blocks = std::min(std::max(pow2_ceil((fl[FL_MAX_STAGE] + 255) / 256), 1), 4096);
     w->plan_island_grid = std::min(std::max(pow2_ceil(fl[FL_N_ISLANDS]), 1), 8192);
@@ -563,9 +631,10 @@ static int step_once(rp_world *w, bool allow_fast) {
         if (w->plan_island_grid < old_g && w->plan_island_grid * 2 >= old_g) w->plan_island_grid = old_g;
     }
     if (w->graph_stages != w->plan_stages || w->graph_blocks != w->plan_blocks || w->graph_single != w->plan_single ||
-        w->graph_island_grid != w->plan_island_grid) {
+        w->graph_island_grid != w->plan_island_grid || w->graph_joint_stages != w->plan_joint_stages) {
         destroy_graphs(w);
         w->graph_stages = w->plan_stages; w->graph_blocks = w->plan_blocks; w->graph_single = w->plan_single; w->graph_island_grid = w->plan_island_grid;
+        w->graph_joint_stages = w->plan_joint_stages;
     }
     // keep the host at most a few steps ahead of the device so the hints stay fresh (the device
     // never idles: several step graphs are always queued)
@@ -708,6 +777,32 @@ extern "C" int32_t rp_contacts_read(rp_world *w, int32_t cap, int32_t *meta, flo
         m++;
     }
     return m;
+}
+
+// ImpulseJoint::impulses + the persistent solver colour, for n joint handles (NULL = all joints in
+// insertion order).  Joints between two non-dynamic bodies are never solved: colour 255, zero impulse.
+extern "C" int32_t rp_impulse_joints_read(rp_world *w, int32_t n, const uint64_t *handles, int32_t *color_out, float *impulse3_out) {
+    if (!w) return RP_ERR_INVALID;
+    HIPCHK(w, hipSetDevice(w->device));
+    if (!w->finalized) { int r = finalize(w); if (r != RP_OK) return r; }
+    { int r = settle(w); if (r != RP_OK) return r; }
+    int nj = w->dw.n_joints, total = (int)w->joints.size();
+    std::vector<int> col(std::max(nj, 1)); std::vector<float4> imp(std::max(nj, 1));
+    if (nj > 0) {
+        HIPCHK(w, hipMemcpy(col.data(), w->dw.j_color, nj * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(w, hipMemcpy(imp.data(), w->dw.j_imp, nj * sizeof(float4), hipMemcpyDeviceToHost));
+    }
+    std::vector<int> dev_of(total, -1);
+    for (int k = 0; k < nj; ++k) dev_of[w->active_joint_ids[k]] = k;
+    int count = handles ? n : total;
+    for (int i = 0; i < count; ++i) {
+        int j = handles ? (int)(handles[i] & 0xffffffffull) : i;
+        if (j < 0 || j >= total) { w->err = "rp_impulse_joints_read: invalid handle"; return RP_ERR_INVALID; }
+        int k = dev_of[j];
+        if (color_out) color_out[i] = k >= 0 ? col[k] : 255;
+        if (impulse3_out) { impulse3_out[3 * i] = k >= 0 ? imp[k].x : 0.0f; impulse3_out[3 * i + 1] = k >= 0 ? imp[k].y : 0.0f; impulse3_out[3 * i + 2] = k >= 0 ? imp[k].z : 0.0f; }
+    }
+    return RP_OK;
 }
 
 extern "C" int32_t rp_counters_enable(rp_world *w, int32_t enable) {

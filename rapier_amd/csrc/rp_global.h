@@ -2,6 +2,7 @@
 // per colour stage) and rp_islands.hip (SINGLE mode: one extra workgroup of the island launch).
 #pragma once
 #include "rp_constraint.h"
+#include "rp_joints.h"
 
 RP_DEV bool global_body(const DevWorld &w, int i) {
     return (w.b_flags[i] & RP_BF_TYPE_MASK) == RP_BODY_DYNAMIC && w.b_island[i] < 0;
@@ -77,7 +78,8 @@ RP_DEV void global_single_block(const DevWorld &w, int has_restitution, int fast
     int M = w.flags[FL_N_CONS];
     if (M > w.cons_cap) M = w.cons_cap;
     int ngb = w.flags[FL_N_GLOB_BODIES];
-    if (M == 0 && ngb == 0) return; // everything lives in LDS islands
+    const int nj = w.n_joints;
+    if (M == 0 && ngb == 0 && nj == 0) return; // everything lives in LDS islands
     const rp_integration_params &prm = w.prm.p;
     const bool fib = prm.friction_in_bias_pass || prm.num_internal_stabilization_iterations == 0;
     const int nb = w.n_bodies;
@@ -89,15 +91,23 @@ RP_DEV void global_single_block(const DevWorld &w, int has_restitution, int fast
     for (int sub = 0; sub < w.prm.num_substeps; ++sub) {
         float solved_dt = (float)sub * w.prm.dt_sub;
         for (int i = t; i < nb; i += nt) if (global_body(w, i)) g_body_increment(w, i);
+        for (int j = t; j < nj; j += nt) joint_update_one(w, j, sub); // reads poses only
         __threadfence(); __syncthreads();
         tail_sweep<MODE_WARMSTART>(w, 0, fib, solved_dt);
-        for (int it = 0; it < prm.num_internal_pgs_iterations; ++it) tail_sweep<MODE_BIAS>(w, 0, fib, solved_dt);
+        for (int it = 0; it < prm.num_internal_pgs_iterations; ++it) {
+            joint_tail_sweep(w, 0, false, prm.warmstart_joints && it == 0); // every joint before any contact
+            tail_sweep<MODE_BIAS>(w, 0, fib, solved_dt);
+        }
         for (int i = t; i < nb; i += nt) if (global_body(w, i)) g_body_integrate(w, i);
         __threadfence(); __syncthreads();
-        for (int it = 0; it < prm.num_internal_stabilization_iterations; ++it) tail_sweep<MODE_RELAX>(w, 0, fib, solved_dt + w.prm.dt_sub);
+        for (int it = 0; it < prm.num_internal_stabilization_iterations; ++it) {
+            joint_tail_sweep(w, 0, true, false);
+            tail_sweep<MODE_RELAX>(w, 0, fib, solved_dt + w.prm.dt_sub);
+        }
     }
     if (has_restitution && bouncy) tail_sweep<MODE_RESTITUTION>(w, 0, fib, 0.0f);
     for (int pos = t; pos < M; pos += nt) cons_writeback(w, GlobalAcc(w, pos), w.cons_pair[pos]);
+    for (int j = t; j < nj; j += nt) joint_writeback_one(w, j);
     for (int i = t; i < nb; i += nt) if (global_body(w, i)) g_body_writeback(w, i);
 }
 

@@ -55,7 +55,12 @@ __global__ void __launch_bounds__(1024) k_islands_build(DevWorld w) {
         if (!c) break;
     }
     // (c) per-root sizes
-    for (int b = tid; b < nb; b += nt) if (is_dyn(w, b)) atomicAdd(&w.r_nb[ld_i32(&w.b_label[b])], 1);
+    // a body that carries a joint is solved on the global path (joints live there): poison its component
+    for (int b = tid; b < nb; b += nt) if (is_dyn(w, b)) {
+        int root = ld_i32(&w.b_label[b]);
+        atomicAdd(&w.r_nb[root], 1);
+        if (w.b_njoints[b] > 0) atomicAdd(&w.r_nc[root], RP_ISL_NC_MAX + 1); // poison: never LDS-eligible
+    }
     for (int s = tid; s < top; s += nt) {
         if (w.p_c1[s] < 0 || w.p_nsc[s] == 0) continue;
         int b1 = w.c_parent[w.p_c1[s]], b2 = w.c_parent[w.p_c2[s]];

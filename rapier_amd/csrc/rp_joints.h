@@ -1,0 +1,179 @@
+// rp_joints.h — impulse joints on the global solver path: locked linear axes
+// (spherical joints), rows rebuilt from the current poses every substep, solved before the contacts in
+// every pass, coloured in the contacts' colour space.
+//
+// Restates (one joint per thread instead of one 4-lane chunk):
+//   JointConstraintBuilder::update            solver/joint_constraint/joint_constraint_builder.rs:76-150
+//   JointConstraint::<Real,1>::update         solver/joint_constraint/joint_velocity_constraint.rs:144-353
+//   JointConstraintHelper::{new, lock_linear, finalize_constraints}
+//                                             solver/joint_constraint/joint_constraint_helper.rs:95-164, 411-458, 676-720
+//   JointConstraint::{solve_generic, warmstart_generic, remove_bias_from_rhs}   joint_velocity_constraint.rs:97-142
+// The reference's wide (SIMD) path uses nalgebra's quaternion->matrix / rotate formulas and its scalar
+// path glam's; like the oracle this file uses the scalar path's forms for every joint.
+#pragma once
+#include "rp_world.h"
+
+// row planes: JR[plane][joint]; row r uses planes 5*r .. 5*r+4
+enum { JR_LIN = 0, JR_A1, JR_A2, JR_I1, JR_I2, JR_ROW_PLANES = 5, JR_IM1 = 15, JR_IM2 = 16, JR_COUNT = 17 };
+#define JRP(plane, j) w.JR[(size_t)(plane) * w.n_joints + (j)]
+
+struct JointRow { V3 lin_jac, ang_jac1, ang_jac2, ii1, ii2; float impulse, inv_lhs, rhs, rhs_wo_bias, cfm_gain; };
+
+RP_DEV void jrow_load(const DevWorld &w, int j, int r, JointRow &c) {
+    float4 a = JRP(5 * r + JR_LIN, j), b = JRP(5 * r + JR_A1, j), d = JRP(5 * r + JR_A2, j), e = JRP(5 * r + JR_I1, j), f = JRP(5 * r + JR_I2, j);
+    c.lin_jac = v3(a); c.impulse = a.w; c.ang_jac1 = v3(b); c.inv_lhs = b.w; c.ang_jac2 = v3(d); c.rhs = d.w;
+    c.ii1 = v3(e); c.rhs_wo_bias = e.w; c.ii2 = v3(f); c.cfm_gain = f.w;
+}
+RP_DEV void jrow_store(const DevWorld &w, int j, int r, const JointRow &c) {
+    JRP(5 * r + JR_LIN, j) = f4(c.lin_jac, c.impulse); JRP(5 * r + JR_A1, j) = f4(c.ang_jac1, c.inv_lhs);
+    JRP(5 * r + JR_A2, j) = f4(c.ang_jac2, c.rhs); JRP(5 * r + JR_I1, j) = f4(c.ii1, c.rhs_wo_bias); JRP(5 * r + JR_I2, j) = f4(c.ii2, c.cfm_gain);
+}
+RP_DEV int joint_row_count(int locked) { return (locked & 1) + ((locked >> 1) & 1) + ((locked >> 2) & 1); }
+
+// JointConstraintBuilder::update for joint j (rows rebuilt from the solver poses s_rot / s_trans).
+RP_DEV void joint_update_one(const DevWorld &w, int j, int substep_id) {
+    int b1 = w.j_b1[j], b2 = w.j_b2[j], locked = w.j_locked[j];
+    Pose p1, p2; p1.r = q4(0, 0, 0, 1); p1.t = v3(0, 0, 0); p2 = p1;
+    V3 im1 = v3(0, 0, 0), im2 = im1; Sym3 ii1 = {0, 0, 0, 0, 0, 0}, ii2 = ii1;
+    if (b1 >= 0) { p1.r = q4(w.s_rot[b1]); p1.t = v3(w.s_trans[b1]); im1 = v3(w.b_eim[b1]); float4 a = w.b_eii0[b1], b = w.b_eii1[b1]; ii1.m11 = a.x; ii1.m12 = a.y; ii1.m13 = a.z; ii1.m22 = a.w; ii1.m23 = b.x; ii1.m33 = b.y; }
+    if (b2 >= 0) { p2.r = q4(w.s_rot[b2]); p2.t = v3(w.s_trans[b2]); im2 = v3(w.b_eim[b2]); float4 a = w.b_eii0[b2], b = w.b_eii1[b2]; ii2.m11 = a.x; ii2.m12 = a.y; ii2.m13 = a.z; ii2.m22 = a.w; ii2.m23 = b.x; ii2.m33 = b.y; }
+    Pose lf1, lf2; lf1.r = q4(w.j_f1r[j]); lf1.t = v3(w.j_f1t[j]); lf2.r = q4(w.j_f2r[j]); lf2.t = v3(w.j_f2t[j]);
+    Pose frame1 = pose_mul(p1, lf1), frame2 = pose_mul(p2, lf2);
+    V3 world_com1 = p1.t, world_com2 = p2.t;
+    float m[3][3]; quat_to_mat(frame1.r, m);
+    V3 col[3] = {v3(m[0][0], m[1][0], m[2][0]), v3(m[0][1], m[1][1], m[2][1]), v3(m[0][2], m[1][2], m[2][2])};
+    V3 lin_err = frame2.t - frame1.t;
+    V3 new_center1 = frame2.t;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) if (locked & (1 << i)) new_center1 = new_center1 - col[i] * dot(lin_err, col[i]);
+    frame1.t = new_center1;
+    V3 r1 = frame1.t - world_com1, r2 = frame2.t - world_com2;
+    V3 c1x = v3(0.0f, r1.z, -r1.y), c1y = v3(-r1.z, 0.0f, r1.x), c1z = v3(r1.y, -r1.x, 0.0f);
+    V3 c2x = v3(0.0f, r2.z, -r2.y), c2y = v3(-r2.z, 0.0f, r2.x), c2z = v3(r2.y, -r2.x, 0.0f);
+    const bool ws = w.prm.p.warmstart_joints != 0;
+    float prev[3] = {0, 0, 0}, seed[3] = {0, 0, 0};
+    int nrows = joint_row_count(locked);
+    if (ws) {
+        if (substep_id > 0) { for (int k = 0; k < nrows; ++k) prev[k] = JRP(5 * k + JR_LIN, j).w; }
+        else { float4 s = w.j_imp[j]; seed[0] = s.x; seed[1] = s.y; seed[2] = s.z; }
+    }
+    JointRow rows[3];
+    int dof[3] = {0, 0, 0};
+    int len = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (!(locked & (1 << i))) continue;
+        JointRow &c = rows[len];
+        c.impulse = 0.0f;
+        c.lin_jac = col[i];
+        c.ang_jac1 = c1x * col[i].x + c1y * col[i].y + c1z * col[i].z;
+        c.ang_jac2 = c2x * col[i].x + c2y * col[i].y + c2z * col[i].z;
+        float rhs_wo_bias = 0.0f;
+        float rhs_bias = dot(c.lin_jac, lin_err) * w.prm.joint_erp_inv_dt;
+        c.ii1 = sym_mul(ii1, c.ang_jac1);
+        c.ii2 = sym_mul(ii2, c.ang_jac2);
+        c.inv_lhs = 0.0f; c.cfm_gain = 0.0f;
+        c.rhs = rhs_wo_bias + rhs_bias; c.rhs_wo_bias = rhs_wo_bias;
+        dof[len] = i;
+        len++;
+    }
+    // finalize_constraints: modified Gram-Schmidt (every lock row has unbounded impulses)
+    V3 imsum = im1 + im2;
+    for (int a = 0; a < len; ++a) {
+        JointRow &cj = rows[a];
+        float dot_jj = dot(cj.lin_jac, cmul(imsum, cj.lin_jac)) + dot(cj.ii1, cj.ang_jac1) + dot(cj.ii2, cj.ang_jac2);
+        float cfm_gain = dot_jj * w.prm.joint_cfm_coeff + cj.cfm_gain;
+        float inv_dot_jj = rp_inv(dot_jj);
+        cj.inv_lhs = rp_inv(dot_jj + cfm_gain);
+        cj.cfm_gain = cfm_gain;
+        for (int b = a + 1; b < len; ++b) {
+            JointRow &ci = rows[b];
+            float dot_ij = dot(ci.lin_jac, cmul(imsum, cj.lin_jac)) + dot(ci.ii1, cj.ang_jac1) + dot(ci.ii2, cj.ang_jac2);
+            float coeff = dot_ij * inv_dot_jj;
+            ci.lin_jac = ci.lin_jac - cj.lin_jac * coeff;
+            ci.ang_jac1 = ci.ang_jac1 - cj.ang_jac1 * coeff;
+            ci.ang_jac2 = ci.ang_jac2 - cj.ang_jac2 * coeff;
+            ci.ii1 = ci.ii1 - cj.ii1 * coeff;
+            ci.ii2 = ci.ii2 - cj.ii2 * coeff;
+            ci.rhs_wo_bias = ci.rhs_wo_bias - cj.rhs_wo_bias * coeff;
+            ci.rhs = ci.rhs - cj.rhs * coeff;
+        }
+    }
+    if (ws) {
+        float coeff = w.prm.p.warmstart_coefficient;
+        for (int k = 0; k < len; ++k) rows[k].impulse = (substep_id == 0 ? seed[dof[k]] : prev[k]) * coeff;
+    }
+    for (int k = 0; k < len; ++k) jrow_store(w, j, k, rows[k]);
+    JRP(JR_IM1, j) = f4(im1, 0.0f); JRP(JR_IM2, j) = f4(im2, 0.0f);
+}
+
+// All rows of joint j: [remove bias] [warm start] solve — solve_joint, staged_island_solver/solve.rs:31-47
+RP_DEV void joint_solve_one(const DevWorld &w, int j, bool wo_bias, bool warmstart) {
+    int b1 = w.j_b1[j], b2 = w.j_b2[j];
+    int nrows = joint_row_count(w.j_locked[j]);
+    V3 im1 = v3(JRP(JR_IM1, j)), im2 = v3(JRP(JR_IM2, j));
+    V3 l1 = v3(0, 0, 0), a1 = l1, l2 = l1, a2 = l1;
+    if (b1 >= 0) { l1 = v3(w.s_lin[b1]); a1 = v3(w.s_ang[b1]); }
+    if (b2 >= 0) { l2 = v3(w.s_lin[b2]); a2 = v3(w.s_ang[b2]); }
+    for (int r = 0; r < nrows; ++r) {
+        JointRow c; jrow_load(w, j, r, c);
+        if (wo_bias) c.rhs = c.rhs_wo_bias;
+        if (warmstart) {
+            V3 lin_impulse = c.lin_jac * c.impulse;
+            V3 i1 = c.ii1 * c.impulse, i2 = c.ii2 * c.impulse;
+            l1 = l1 + cmul(lin_impulse, im1); a1 = a1 + i1;
+            l2 = l2 - cmul(lin_impulse, im2); a2 = a2 - i2;
+            // a world-attached side reloads zeros for every row (gather of solver id u32::MAX)
+            if (b1 < 0) { l1 = v3(0, 0, 0); a1 = l1; }
+            if (b2 < 0) { l2 = v3(0, 0, 0); a2 = l2; }
+        }
+        float dlinvel = dot(c.lin_jac, l2 - l1);
+        float dangvel = dot(c.ang_jac2, a2) - dot(c.ang_jac1, a1);
+        float rhs = dlinvel + dangvel + c.rhs;
+        float total = c.impulse + c.inv_lhs * (rhs - c.cfm_gain * c.impulse); // lock rows: unbounded impulses (clamp to +-f32::MAX is the identity on finite values)
+        total = rp_clamp(total, -3.402823466e+38f, 3.402823466e+38f);
+        float delta = total - c.impulse;
+        c.impulse = total;
+        V3 lin_impulse = c.lin_jac * delta;
+        V3 i1 = c.ii1 * delta, i2 = c.ii2 * delta;
+        l1 = l1 + cmul(lin_impulse, im1); a1 = a1 + i1;
+        l2 = l2 - cmul(lin_impulse, im2); a2 = a2 - i2;
+        if (b1 < 0) { l1 = v3(0, 0, 0); a1 = l1; }
+        if (b2 < 0) { l2 = v3(0, 0, 0); a2 = l2; }
+        // only the mutable words of the row go back
+        JRP(5 * r + JR_LIN, j).w = c.impulse;
+        if (wo_bias) JRP(5 * r + JR_A2, j).w = c.rhs;
+    }
+    if (b1 >= 0) { w.s_lin[b1] = f4(l1, 0.0f); w.s_ang[b1] = f4(a1, 0.0f); }
+    if (b2 >= 0) { w.s_lin[b2] = f4(l2, 0.0f); w.s_ang[b2] = f4(a2, 0.0f); }
+}
+
+// JointConstraint::writeback_impulses — joint_velocity_constraint.rs:346-353
+RP_DEV void joint_writeback_one(const DevWorld &w, int j) {
+    int locked = w.j_locked[j];
+    float imp[3] = {0, 0, 0};
+    float4 old = w.j_imp[j];
+    imp[0] = old.x; imp[1] = old.y; imp[2] = old.z;
+    int k = 0;
+    for (int i = 0; i < 3; ++i) if (locked & (1 << i)) { imp[i] = JRP(5 * k + JR_LIN, j).w; k++; }
+    w.j_imp[j] = make_float4(imp[0], imp[1], imp[2], 0.0f);
+}
+
+// One sweep over the joints inside a single workgroup (SINGLE mode and the serial tail): parallel joint
+// colours from `first` one after the other, then the overflow list on lane 0.
+RP_DEV void joint_tail_sweep(const DevWorld &w, int first, bool wo_bias, bool warmstart) {
+    if (w.n_joints == 0) return;
+    int nst = w.flags[FL_NJ_STAGES];
+    for (int st = first; st < nst; ++st) {
+        int beg = w.j_stage_begin[st], cnt = w.j_stage_count[st];
+        for (int i = threadIdx.x; i < cnt; i += blockDim.x) joint_solve_one(w, w.j_order[beg + i], wo_bias, warmstart);
+        __threadfence();
+        __syncthreads();
+    }
+    int ob = w.flags[FL_NJ_OVF_BEGIN], oc = w.flags[FL_NJ_OVF_COUNT];
+    if (oc > 0) {
+        if (threadIdx.x == 0) for (int i = 0; i < oc; ++i) { joint_solve_one(w, w.j_order[ob + i], wo_bias, warmstart); __threadfence(); }
+        __threadfence();
+        __syncthreads();
+    }
+}

@@ -1,0 +1,173 @@
+// rp_joints.hip — joint colouring / layout kernels and the MULTI-mode joint launches.
+//
+//   * colouring: ParallelInteractionGroups::group_interactions (solver/interaction_groups.rs:59-197) is
+//     a serial greedy pass over the joints in edge order that keeps a joint's stored colour while it
+//     is free of the bodies' contact colours and of the colours taken by earlier joints.  While every
+//     stored colour is still free the pass is the identity (staged_joint_colors_still_free,
+//     staged_island_solver/joints.rs:462-480), which a parallel check establishes each step; otherwise
+//     the greedy order is reproduced exactly by dependency rounds inside one workgroup (a joint
+//     decides in the round where it holds the smallest undecided index at both of its bodies).
+//   * layout: colours with >= 64 joints (JOINT_BATCH * LAYOUT_REF_WORKERS / 2, joints.rs:352) are
+//     parallel stages in ascending colour order, everything else is the serial overflow, colour-major
+//     in edge order (single_group_joint_layout, joints.rs:331-460).
+#include "rp_joints.h"
+
+#define RP_JOINT_PARALLEL_MIN 64
+
+RP_DEV unsigned long long jld_u64(unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+RP_DEV unsigned jld_u32(unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Does any joint's stored colour collide with its bodies' contact colours (or is it uncoloured)?
+__global__ void k_joint_color_check(DevWorld w) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= w.n_joints) return;
+    int color = w.j_color[j];
+    bool bad = color >= 128;
+    if (!bad) {
+        int b1 = w.j_b1[j], b2 = w.j_b2[j];
+        unsigned bit = 1u << (color & 31);
+        if (b1 >= 0 && (w.b_cmask[4 * b1 + (color >> 5)] & bit)) bad = true;
+        if (b2 >= 0 && (w.b_cmask[4 * b2 + (color >> 5)] & bit)) bad = true;
+    }
+    if (bad) w.flags[FL_JOINT_DIRTY] = 1;
+}
+
+__global__ void __launch_bounds__(1024) k_joint_color(DevWorld w) {
+    if (!w.flags[FL_JOINT_DIRTY]) return;
+    const int nj = w.n_joints, nb = w.n_bodies;
+    __shared__ int remaining;
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) { for (int q = 0; q < 4; ++q) w.bj_cmask[4 * b + q] = 0; w.bj_min[b] = RP_EMPTY_KEY; }
+    for (int j = threadIdx.x; j < nj; j += blockDim.x) w.j_tmp[j] = 1; // 1 = undecided
+    __threadfence(); __syncthreads();
+    for (int round = 0; round < (1 << 24); ++round) {
+        if (threadIdx.x == 0) remaining = 0;
+        __syncthreads();
+        for (int j = threadIdx.x; j < nj; j += blockDim.x) {
+            if (!w.j_tmp[j]) continue;
+            int b1 = w.j_b1[j], b2 = w.j_b2[j];
+            if (b1 >= 0) atomicMin(&w.bj_min[b1], (unsigned long long)j);
+            if (b2 >= 0) atomicMin(&w.bj_min[b2], (unsigned long long)j);
+        }
+        __threadfence(); __syncthreads();
+        for (int j = threadIdx.x; j < nj; j += blockDim.x) {
+            if (!w.j_tmp[j]) continue;
+            int b1 = w.j_b1[j], b2 = w.j_b2[j];
+            bool win = (b1 < 0 || jld_u64(&w.bj_min[b1]) == (unsigned long long)j) && (b2 < 0 || jld_u64(&w.bj_min[b2]) == (unsigned long long)j);
+            if (!win) { atomicAdd(&remaining, 1); continue; }
+            unsigned m[4] = {0, 0, 0, 0};
+            if (b1 >= 0) for (int q = 0; q < 4; ++q) m[q] |= jld_u32(&w.bj_cmask[4 * b1 + q]) | jld_u32(&w.b_cmask[4 * b1 + q]);
+            if (b2 >= 0) for (int q = 0; q < 4; ++q) m[q] |= jld_u32(&w.bj_cmask[4 * b2 + q]) | jld_u32(&w.b_cmask[4 * b2 + q]);
+            int stored = w.j_color[j], color = 128;
+            if (stored < 128 && !((m[stored >> 5] >> (stored & 31)) & 1u)) color = stored;          // keep_or_pick
+            else if (b1 >= 0 && b2 >= 0) { for (int c = 0; c < RP_DYNAMIC_COLOR_COUNT; ++c) if (!((m[c >> 5] >> (c & 31)) & 1u)) { color = c; break; } }
+            else { for (int c = 127; c >= 0; --c) if (!((m[c >> 5] >> (c & 31)) & 1u)) { color = c; break; } }
+            if (color < 128) {
+                unsigned bit = 1u << (color & 31);
+                if (b1 >= 0) atomicOr(&w.bj_cmask[4 * b1 + (color >> 5)], bit);
+                if (b2 >= 0) atomicOr(&w.bj_cmask[4 * b2 + (color >> 5)], bit);
+            }
+            w.j_color[j] = color;
+            w.j_tmp[j] = 2; // decided this round: still has to reset its bids
+        }
+        __threadfence(); __syncthreads();
+        for (int j = threadIdx.x; j < nj; j += blockDim.x) {
+            int st = w.j_tmp[j];
+            if (!st) continue;
+            int b1 = w.j_b1[j], b2 = w.j_b2[j];
+            if (b1 >= 0) __hip_atomic_store(&w.bj_min[b1], RP_EMPTY_KEY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (b2 >= 0) __hip_atomic_store(&w.bj_min[b2], RP_EMPTY_KEY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (st == 2) w.j_tmp[j] = 0;
+        }
+        __threadfence(); __syncthreads();
+        int rem = remaining;
+        __syncthreads();
+        if (rem == 0) break;
+    }
+}
+
+// Stage layout of the coloured joints (one workgroup).
+__global__ void __launch_bounds__(1024) k_joint_layout(DevWorld w) {
+    if (!w.flags[FL_JOINT_DIRTY]) return;
+    const int nj = w.n_joints;
+    __shared__ int count[RP_NUM_COLORS], begin[RP_NUM_COLORS], cursor[RP_NUM_COLORS], stage_of[RP_NUM_COLORS];
+    __shared__ int n_ovf, ovf_begin;
+    for (int c = threadIdx.x; c < RP_NUM_COLORS; c += blockDim.x) count[c] = 0;
+    __syncthreads();
+    for (int j = threadIdx.x; j < nj; j += blockDim.x) atomicAdd(&count[w.j_color[j]], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int pos = 0, nst = 0;
+        for (int c = 0; c < RP_NUM_COLORS; ++c) {
+            stage_of[c] = -1;
+            if (c < 128 && count[c] >= RP_JOINT_PARALLEL_MIN) {
+                w.j_stage_begin[nst] = pos; w.j_stage_count[nst] = count[c];
+                begin[c] = pos; cursor[c] = pos; stage_of[c] = nst; pos += count[c]; nst++;
+            }
+        }
+        ovf_begin = pos; n_ovf = 0;
+        w.flags[FL_NJ_STAGES] = nst; w.flags[FL_NJ_OVF_BEGIN] = pos; w.flags[FL_NJ_OVF_COUNT] = nj - pos;
+    }
+    __syncthreads();
+    // parallel colours: order inside a colour is free (body-disjoint); overflow: collected, then ranked
+    for (int j = threadIdx.x; j < nj; j += blockDim.x) {
+        int c = w.j_color[j];
+        if (stage_of[c] >= 0) w.j_order[atomicAdd(&cursor[c], 1)] = j;
+        else w.j_tmp[atomicAdd(&n_ovf, 1)] = j;
+    }
+    __threadfence(); __syncthreads();
+    const int no = n_ovf, ob = ovf_begin;
+    for (int i = threadIdx.x; i < no; i += blockDim.x) { // colour-major, edge order within a colour
+        int j = w.j_tmp[i];
+        long long key = ((long long)w.j_color[j] << 32) | j;
+        int rank = 0;
+        for (int q = 0; q < no; ++q) { int jq = w.j_tmp[q]; long long kq = ((long long)w.j_color[jq] << 32) | jq; rank += kq < key; }
+        w.j_order[ob + rank] = j;
+    }
+    __threadfence(); __syncthreads();
+    if (threadIdx.x == 0) w.flags[FL_JOINT_DIRTY] = 0;
+}
+
+// ---- MULTI mode launches -----------------------------------------------------------------------
+__global__ void k_joint_update(DevWorld w, int substep_id) {
+    int stride = gridDim.x * blockDim.x;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < w.n_joints; j += stride) joint_update_one(w, j, substep_id);
+}
+__global__ void __launch_bounds__(256) k_joint_stage(DevWorld w, int stage, int wo_bias, int warmstart) {
+    if (stage >= w.flags[FL_NJ_STAGES]) return;
+    int beg = w.j_stage_begin[stage], cnt = w.j_stage_count[stage];
+    int stride = gridDim.x * blockDim.x;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) joint_solve_one(w, w.j_order[beg + i], wo_bias != 0, warmstart != 0);
+}
+// joint stages the host did not launch + the serial overflow, in one workgroup
+__global__ void __launch_bounds__(1024) k_joint_tail(DevWorld w, int first, int wo_bias, int warmstart) {
+    int nst = w.flags[FL_NJ_STAGES];
+    joint_tail_sweep(w, first < nst ? first : nst, wo_bias != 0, warmstart != 0);
+}
+__global__ void k_joint_writeback(DevWorld w) {
+    int stride = gridDim.x * blockDim.x;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < w.n_joints; j += stride) joint_writeback_one(w, j);
+}
+
+static int joint_blocks(const DevWorld &w) { int b = (w.n_joints + 255) / 256; if (b > 2048) b = 2048; return b < 1 ? 1 : b; }
+
+// after the contact colouring of the narrow phase (the contact masks are final for this step)
+void rp_launch_joint_coloring(const DevWorld &w, hipStream_t st) {
+    if (w.n_joints == 0) return;
+    hipLaunchKernelGGL(k_joint_color_check, dim3((w.n_joints + 255) / 256), dim3(256), 0, st, w);
+    hipLaunchKernelGGL(k_joint_color, dim3(1), dim3(1024), 0, st, w);
+    hipLaunchKernelGGL(k_joint_layout, dim3(1), dim3(1024), 0, st, w);
+}
+void rp_launch_joint_update(const DevWorld &w, hipStream_t st, int substep_id) {
+    if (w.n_joints == 0) return;
+    hipLaunchKernelGGL(k_joint_update, dim3(joint_blocks(w)), dim3(256), 0, st, w, substep_id);
+}
+void rp_launch_joint_sweep(const DevWorld &w, hipStream_t st, int parallel_stages, int wo_bias, int warmstart) {
+    if (w.n_joints == 0) return;
+    int blocks = joint_blocks(w);
+    for (int s = 0; s < parallel_stages; ++s) hipLaunchKernelGGL(k_joint_stage, dim3(blocks), dim3(256), 0, st, w, s, wo_bias, warmstart);
+    hipLaunchKernelGGL(k_joint_tail, dim3(1), dim3(1024), 0, st, w, parallel_stages, wo_bias, warmstart);
+}
+void rp_launch_joint_writeback(const DevWorld &w, hipStream_t st) {
+    if (w.n_joints == 0) return;
+    hipLaunchKernelGGL(k_joint_writeback, dim3(joint_blocks(w)), dim3(256), 0, st, w);
+}

@@ -555,6 +555,7 @@ __global__ void __launch_bounds__(1024) k_color_pairs(DevWorld w) {
 // from ALL active manifolds per colour (the reference's bucket sizes); positions in the global
 // constraint planes are only handed to manifolds that are not solved by the island kernel.
 void rp_launch_islands_build(const DevWorld &w, hipStream_t st);
+void rp_launch_joint_coloring(const DevWorld &w, hipStream_t st);
 
 __global__ void k_bucket_clear(DevWorld w) {
     if (!w.flags[FL_LAYOUT_DIRTY]) return;
@@ -623,6 +624,7 @@ void rp_launch_narrowphase(const DevWorld &w, hipStream_t st) {
     hipLaunchKernelGGL(k_np_begin, dim3(1), dim3(1), 0, st, w);
     hipLaunchKernelGGL(k_np_pairs, dim3(blocks), dim3(256), 0, st, w);
     hipLaunchKernelGGL(k_color_pairs, dim3(1), dim3(1024), 0, st, w);
+    rp_launch_joint_coloring(w, st); // joints avoid this step's contact colours (init_joints, joints.rs:25-329)
     hipLaunchKernelGGL(k_bucket_clear, dim3(1), dim3(256), 0, st, w);
     hipLaunchKernelGGL(k_bucket_count, dim3(blocks), dim3(256), 0, st, w);
     rp_launch_islands_build(w, st);

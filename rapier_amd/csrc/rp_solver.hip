@@ -93,6 +93,10 @@ __global__ void k_init_bodies(DevWorld w) {
     }
 }
 
+void rp_launch_joint_update(const DevWorld &w, hipStream_t st, int substep_id);
+void rp_launch_joint_sweep(const DevWorld &w, hipStream_t st, int parallel_stages, int wo_bias, int warmstart);
+void rp_launch_joint_writeback(const DevWorld &w, hipStream_t st);
+
 // ---- host-side launch sequences -------------------------------------------------------------------
 struct SolverLaunchPlan { int parallel_stages; int stage_blocks; };
 
@@ -117,7 +121,7 @@ void rp_launch_solver_assembly(const DevWorld &w, hipStream_t st) {
     hipLaunchKernelGGL(k_generate, dim3(cons_blocks(w)), dim3(256), 0, st, w);
 }
 // The TGS loop proper: S2..S7 for every substep (+ S8 restitution) — worker.rs:207-734.
-void rp_launch_solver_loop(const DevWorld &w, hipStream_t st, int parallel_stages, int stage_blocks, int has_restitution) {
+void rp_launch_solver_loop(const DevWorld &w, hipStream_t st, int parallel_stages, int stage_blocks, int has_restitution, int joint_stages) {
     SolverLaunchPlan plan = {parallel_stages, stage_blocks < 1 ? 1 : stage_blocks};
     int nb = body_blocks(w);
     const rp_integration_params &p = w.prm.p;
@@ -125,14 +129,22 @@ void rp_launch_solver_loop(const DevWorld &w, hipStream_t st, int parallel_stage
     for (int s = 0; s < w.prm.num_substeps; ++s) {
         float solved_dt = (float)s * w.prm.dt_sub;
         hipLaunchKernelGGL(k_increment, dim3(nb), dim3(256), 0, st, w);
+        rp_launch_joint_update(w, st, s); // rows rebuilt from the current poses (worker.rs:287-357)
         launch_sweep<MODE_WARMSTART>(w, st, plan, fib, solved_dt);
-        for (int it = 0; it < p.num_internal_pgs_iterations; ++it) launch_sweep<MODE_BIAS>(w, st, plan, fib, solved_dt);
+        for (int it = 0; it < p.num_internal_pgs_iterations; ++it) {
+            rp_launch_joint_sweep(w, st, joint_stages, 0, (p.warmstart_joints && it == 0) ? 1 : 0); // all joints before any contact
+            launch_sweep<MODE_BIAS>(w, st, plan, fib, solved_dt);
+        }
         hipLaunchKernelGGL(k_integrate, dim3(nb), dim3(256), 0, st, w);
-        for (int it = 0; it < p.num_internal_stabilization_iterations; ++it) launch_sweep<MODE_RELAX>(w, st, plan, fib, solved_dt + w.prm.dt_sub);
+        for (int it = 0; it < p.num_internal_stabilization_iterations; ++it) {
+            rp_launch_joint_sweep(w, st, joint_stages, 1, 0);
+            launch_sweep<MODE_RELAX>(w, st, plan, fib, solved_dt + w.prm.dt_sub);
+        }
     }
     if (has_restitution) launch_sweep<MODE_RESTITUTION>(w, st, plan, fib, 0.0f);
 }
 void rp_launch_solver_writeback(const DevWorld &w, hipStream_t st) {
     hipLaunchKernelGGL(k_writeback_impulses, dim3(cons_blocks(w)), dim3(256), 0, st, w);
+    rp_launch_joint_writeback(w, st);
     hipLaunchKernelGGL(k_writeback_bodies, dim3(body_blocks(w)), dim3(256), 0, st, w);
 }

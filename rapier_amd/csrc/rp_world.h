@@ -66,8 +66,10 @@ enum {
     FL_N_CONS_ALL,      // M: all active solver manifolds (island + global)
     FL_ISL_BODY_CURSOR, FL_ISL_CONS_CURSOR,
     FL_SEQ,             // step graphs retired (executed or aborted)
+    FL_JOINT_DIRTY,     // joint colours / stage layout must be rebuilt
+    FL_NJ_STAGES, FL_NJ_OVF_BEGIN, FL_NJ_OVF_COUNT, // joint stage layout: parallel colours, serial overflow range in j_order
     FL_FAST_ABORT,      // steady-state fast path found work it cannot do (see rp_api.hip); sticky until a full step
-    FL_COUNT = 32
+    FL_COUNT = 48
 };
 
 // constraint float4 planes (per solver manifold) — restates ContactWithTwistFriction +
@@ -117,11 +119,12 @@ struct SimParams {
     float prediction, recycle_distance, max_corrective_velocity, max_lin, max_ang;
     float bp_skin;
     float cell_size, inv_cell_size;
+    float joint_erp_inv_dt, joint_cfm_coeff; // SpringCoefficients::{erp_inv_dt, cfm_coeff}(dt_sub) of the joint softness
     int num_substeps;
 };
 
 struct DevWorld {
-    int n_bodies, n_colliders;
+    int n_bodies, n_colliders, n_joints;
     int pool_cap;      // pair slots
     int hash_cap;      // power of two
     int grid_cap;      // power of two (cell hash buckets)
@@ -196,6 +199,17 @@ struct DevWorld {
     int *isl_bodies, *isl_cons;
     int *isl_cstage;            // [pool] local stage index of isl_cons[i] once the island list is sorted
     int *isl_sorted, *isl_nstages; // per island: list sorted by sweep stage?, number of local stages
+
+    // ---- impulse joints (active joints only, edge order) ----
+    int *j_b1, *j_b2;           // arena index of the dynamic body on each side, -1 = world-attached side
+    float4 *j_f1t, *j_f1r, *j_f2t, *j_f2r; // local frames in solver-body (CoM) space: translation, rotation
+    int *j_locked, *j_color, *j_tmp, *j_order;
+    int *j_stage_begin, *j_stage_count;    // parallel joint colour stages inside j_order
+    float4 *j_imp;              // per-dof impulses written back at the end of the step
+    unsigned int *bj_cmask;     // [4 * n_bodies] colours taken by joints (bodies_color workspace)
+    unsigned long long *bj_min; // joint colouring scratch
+    int *b_njoints;             // joints attached to a body (bodies with joints stay on the global path)
+    float4 *JR;                 // [JR_COUNT][n_joints] constraint rows (rp_joints.h)
 
     // ---- constraints ----
     float4 *C;                  // [CP_COUNT][cons_cap]

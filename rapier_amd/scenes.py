@@ -235,6 +235,48 @@ def joint_grid(n: int = 100) -> Scene:
     return s
 
 
+def joint_net(n: int = 32) -> Scene:
+    """The pinned net of spherical joints of crates/rapier3d/tests/joint_stability.rs:105-175
+    (`joint_net_remains_stable`): n x n balls (r 0.4, spacing 1), row 0 pinned every 4th ball and at
+    the last one, default gravity (0, -9.81, 0)."""
+    s = Scene(name=f"joint_net_{n}", gravity=(0.0, -9.81, 0.0))
+    h = [-1] * (n * n)
+    for i in range(n):
+        for j in range(n):
+            fixed = i == 0 and (j % 4 == 0 or j == n - 1)
+            b = s.add_body(body_type=BODY_FIXED if fixed else BODY_DYNAMIC, translation=(_f(j), -_f(i), 0.0))
+            s.add_collider(b, shape=SHAPE_BALL, half_extents=(0.4, 0.0, 0.0), density=1.0)
+            h[i * n + j] = b
+    for i in range(n):
+        for j in range(n):
+            if i > 0:
+                s.add_joint(h[(i - 1) * n + j], h[i * n + j], (0.0, -0.5, 0.0), (0.0, 0.5, 0.0))
+            if j > 0:
+                s.add_joint(h[i * n + j - 1], h[i * n + j], (0.5, 0.0, 0.0), (-0.5, 0.0, 0.0))
+    return s
+
+
+def joint_chain(n: int = 8, with_boxes: bool = False) -> Scene:
+    """A pendulum chain of n bodies hanging from a fixed one by spherical joints, released
+    horizontally (not a reference scene): exercises joints with large motion and, with boxes next to a
+    wall slab, joints + contacts on the same bodies."""
+    s = Scene(name=f"joint_chain_{n}{'_boxes' if with_boxes else ''}", gravity=(0.0, -9.81, 0.0))
+    prev = s.add_body(body_type=BODY_FIXED, translation=(0.0, 5.0, 0.0))
+    s.add_collider(prev, shape=SHAPE_BALL, half_extents=(0.2, 0.0, 0.0))
+    if with_boxes:
+        g = s.add_body(body_type=BODY_FIXED, translation=(0.0, -0.5, 0.0))
+        s.add_collider(g, half_extents=(20.0, 0.5, 20.0))
+    for i in range(n):
+        b = s.add_body(translation=(_f(i + 1), 5.0, 0.0))
+        if with_boxes:
+            s.add_collider(b, half_extents=(0.3, 0.3, 0.3), density=2.0)
+        else:
+            s.add_collider(b, shape=SHAPE_BALL, half_extents=(0.3, 0.0, 0.0), density=2.0)
+        s.add_joint(prev, b, (0.5, 0.0, 0.0), (-0.5, 0.0, 0.0))
+        prev = b
+    return s
+
+
 def box_stack(height: int = 3, gap: float = 0.0) -> Scene:
     """Small cube stack on a slab (the 3-cube stack of test_staged.rs:86-148)."""
     s = Scene(name=f"box_stack_{height}", gravity=(0.0, -9.81, 0.0))

@@ -234,6 +234,15 @@ class PhysicsWorld:
             self._lib.rp_contacts_read(self._ptr, m, meta.ctypes.data, nrm.ctypes.data, imp.ctypes.data)
         return meta, nrm, imp
 
+    def read_joints(self):
+        """(colour, impulse xyz) of every impulse joint, insertion order."""
+        n = self.impulse_joints._n
+        col = np.zeros(n, np.int32)
+        imp = np.zeros((n, 3), np.float32)
+        if n:
+            _check(self._ptr, self._lib.rp_impulse_joints_read(self._ptr, n, None, col.ctypes.data, imp.ctypes.data), "rp_impulse_joints_read")
+        return col, imp
+
     def total_contact_impulse(self) -> float:
         _, _, imp = self.contacts()
         return float(imp.sum())

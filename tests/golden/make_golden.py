@@ -20,11 +20,16 @@ CASES = {
     "pyramid10_s120": lambda: (S.pyramid10(), 120),
     "tumble40_s90": lambda: (S.tumble(40, seed=11), 90),
     "many_pyramids_2x2_s30": lambda: (S.many_pyramids(rows=2, cols=2), 30),
+    "joint_chain8_s200": lambda: (S.joint_chain(8), 200),
+    "joint_grid12_s100": lambda: (S.joint_grid(12), 100),
 }
 
 if __name__ == "__main__":
     from oracle_ffi import OracleWorld
+    only = set(sys.argv[1:])
     for name, mk in CASES.items():
+        if only and name not in only:
+            continue
         scene, steps = mk()
         w = OracleWorld(scene)
         w.step(steps)

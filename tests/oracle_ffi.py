@@ -49,6 +49,8 @@ def lib():
         L.ro_combine_coefficient.argtypes = [C.c_float, C.c_float, C.c_int32, C.c_int32]
         L.ro_combine_coefficient.restype = C.c_float
         L.ro_set_body_vel.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        L.ro_num_joints.argtypes = [C.c_void_p]
+        L.ro_read_joints.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -70,7 +72,8 @@ class OracleWorld:
             L.ro_add_collider(self._w, cols[i:i + 1].ctypes.data, int(parents[i]))
         joints = scene.joint_array()
         for i in range(len(joints)):
-            L.ro_add_joint(self._w, joints[i:i + 1].ctypes.data)
+            if L.ro_add_joint(self._w, joints[i:i + 1].ctypes.data) < 0:
+                raise ValueError("oracle: unsupported joint")
         self.n = len(bodies)
 
     def step(self, n: int = 1):
@@ -98,6 +101,13 @@ class OracleWorld:
         imp = np.zeros((m, 4), np.float32)
         L.ro_dump_manifolds(self._w, m, meta.ctypes.data, nrm.ctypes.data, imp.ctypes.data)
         return meta, nrm, imp
+
+    def read_joints(self):
+        n = lib().ro_num_joints(self._w)
+        col = np.zeros(n, np.int32)
+        imp = np.zeros((n, 3), np.float32)
+        lib().ro_read_joints(self._w, col.ctypes.data, imp.ctypes.data)
+        return col, imp
 
     def set_vel(self, body, linvel, angvel=(0, 0, 0)):
         lv = np.asarray(linvel, np.float32)

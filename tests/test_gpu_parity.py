@@ -105,6 +105,53 @@ def test_ball_rests_on_floor_on_gpu():
     assert abs(w.read_bodies()[0][b, 1] - 1.0) < 0.02
 
 
+def _compare_joints(g, o):
+    gc, gi = g.read_joints()
+    oc, oi = o.read_joints()
+    np.testing.assert_array_equal(gc, oc, err_msg="joint colours")
+    np.testing.assert_array_equal(gi, oi, err_msg="joint impulses")
+
+
+def test_joint_chain_bit_exact():
+    """Spherical joints with large motion: rows rebuilt every substep, joints before contacts."""
+    g, o = _compare(S.joint_chain(8), [1, 10, 100, 300])
+    _compare_joints(g, o)
+
+
+def test_joint_chain_with_contacts_bit_exact():
+    """Jointed boxes falling on a slab: joints and contacts on the same bodies, joint colours avoid the
+    contact colours (recolouring when contacts appear)."""
+    g, o = _compare(S.joint_chain(6, with_boxes=True), [1, 30, 120, 240])
+    _compare_joints(g, o)
+
+
+def test_joint_grid_bit_exact():
+    """BASELINE config C5 (b3d_joint_grid) at 24 x 24 for oracle speed: parallel joint colours + serial overflow."""
+    g, o = _compare(S.joint_grid(24), [1, 10, 60, 150])
+    _compare_joints(g, o)
+
+
+def test_joint_net_stays_bounded_on_gpu():
+    """joint_stability.rs:105-175 through the C ABI (reduced horizon): positions bounded, no runaway velocity."""
+    sc = S.joint_net(32)
+    w = PhysicsWorld.from_scene(sc)
+    w.step(1000)
+    pos, vel = w.read_bodies()
+    assert np.isfinite(pos).all()
+    assert np.linalg.norm(pos[:, :3], axis=1).max() < 500.0
+    assert np.linalg.norm(vel[:, :3], axis=1).max() < 100.0
+
+
+def test_joint_grid_full_size():
+    """b3d_joint_grid at full size (100 x 100, 19,800 joints): 5 steps bit-exact, then properties."""
+    sc = S.joint_grid(100)
+    g, o = _compare(sc, [1, 5])
+    _compare_joints(g, o)
+    g.step(200)
+    pos, vel = g.read_bodies()
+    assert np.isfinite(pos).all() and np.abs(vel).max() < 100.0
+
+
 def test_golden_fixtures_on_gpu():
     import glob
     import os

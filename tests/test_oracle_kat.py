@@ -144,6 +144,40 @@ def test_linear_speed_cap():
     assert abs(np.linalg.norm(w.read()[1][b, :3]) - 400.0) < 1e-2
 
 
+# /root/reference/crates/rapier3d/tests/joint_stability.rs:105-175 (joint_net_remains_stable)
+def test_spherical_joint_net_remains_stable():
+    w = OracleWorld(S.joint_net(32))
+    for _ in range(4):
+        w.step(1000)
+        pos, vel = w.read()
+        assert np.linalg.norm(pos[:, :3], axis=1).max() < 500.0
+        assert np.linalg.norm(vel[:, :3], axis=1).max() < 100.0
+
+
+def test_spherical_joint_holds_its_anchors():
+    """A swinging chain keeps every pair of joint anchors together (bilateral lock rows)."""
+    sc = S.joint_chain(8)
+    w = OracleWorld(sc)
+
+    def rot(q, x):
+        b, ww = q[:3], q[3]
+        return x * (ww * ww - b @ b) + b * (x @ b) * 2 + np.cross(b, x) * ww * 2
+
+    for _ in range(6):
+        w.step(50)
+        pos, _ = w.read()
+        for j in sc.joints:
+            b1, b2 = int(j["body1"]), int(j["body2"])
+            a1 = pos[b1, :3] + rot(pos[b1, 3:], np.array(j["local_anchor1"]))
+            a2 = pos[b2, :3] + rot(pos[b2, 3:], np.array(j["local_anchor2"]))
+            assert np.linalg.norm(a1 - a2) < 0.05
+
+
+def test_joint_grid_scene_matches_reference_formula():
+    sc = S.joint_grid(100)
+    assert len(sc.bodies) == 10000 and len(sc.joints) == 19800 and sc.num_dynamic == 9900
+
+
 def test_golden_fixtures_match_oracle():
     """tests/golden/*.npz were produced by tests/golden/make_golden.py from this oracle; they pin it
     (and, in the GPU tests, the HIP path) against silent drift."""
