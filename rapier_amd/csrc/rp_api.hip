@@ -398,6 +398,7 @@ static int finalize(rp_world *w) {
     DAF(d.p_island, P, 0xff);
     DA(d.isl_body_begin, nb); DA(d.isl_nb, nb); DA(d.isl_cons_begin, nb); DA(d.isl_nc, nb); DA(d.isl_fill_b, nb); DA(d.isl_fill_c, nb);
     DA(d.isl_bodies, nb); DA(d.isl_cons, P); DA(d.isl_cstage, P); DA(d.isl_sorted, nb); DA(d.isl_nstages, nb);
+    DA(d.isl_cg1, P); DA(d.isl_cg2, P); DA(d.isl_cl1, P); DA(d.isl_cl2, P); DA(d.isl_inc_pos, 2 * P); DA(d.isl_inc_begin, nb); DA(d.isl_inc_cnt, nb);
     // impulse joints: only joints with a dynamic side are active (select_active_interactions,
     // impulse_joint_set.rs:504-572), kept in edge order; frames go to solver-body space once
     // (GenericJoint::transform_to_solver_body_space, generic_joint.rs:624-636)

@@ -142,6 +142,7 @@ RP_DEV Xf isl_xf(const IslLds &L, int id) {
 // and broadcasts it back.  The operations and their order are exactly those of rp_constraint.h:
 //   dvel = (((n.v1 + t1.w1) - n.v2) + t2.w2) + rhs           a * (-b) == (-a) * b,  x - y == x + (-y)
 // so the results stay bit-identical to the single-lane form and to the oracle.
+#define ISL_THREADS (2 * RP_ISL_NC_MAX)
 #define DPP_FROM_ODD 0xF5   // quad_perm [1,1,3,3]: both lanes of a pair read the odd lane
 #define DPP_FROM_EVEN 0xA0  // quad_perm [0,0,2,2]: both lanes of a pair read the even lane
 template <int CTRL> RP_DEV float dppf(float x) {
@@ -353,6 +354,61 @@ template <bool F4> RP_DEV void isl_warmstart_t(const DevWorld &w, IslSide &h, co
     }
 }
 
+// Body-centric warm start.  The impulses a warm start applies do not depend on velocities, only the
+// order in which they are ADDED to a body does (colour order, and inside a manifold: the points, the
+// tangent part, the twist part).  Every lane therefore writes its terms to LDS in one parallel stage
+// (isl_ws_terms) and the thread that owns a body adds them in exactly that order (isl_ws_accumulate):
+// 2 stages per substep instead of one per colour, same additions, same order, same bits.
+#define WS_SLOTS 11   // per lane: 4 x (lin, ang) point terms, tangent lin, tangent ang, twist ang
+#define WS_STRIDE (ISL_THREADS + 2) // rows of one slot: every lane's row + two scratch rows for world-attached sides
+RP_DEV void isl_ws_terms(const DevWorld &w, IslSide &h, float4 *W, int t) { // t = this lane's row in W (its rank in its body's list)
+    float wc = w.prm.p.warmstart_coefficient;
+    bool ws = wc != 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k >= h.n) break;
+        SidePoint &p = h.P[k];
+        p.rhs = p.rhsB; p.cfm = p.cfmB;
+        p.acc += p.lam;
+        p.lam *= wc;
+        if (ws) {
+            float lam = dppf<DPP_FROM_EVEN>(p.lam);
+            W[(2 * k) * WS_STRIDE + t] = f4(h.sdim * lam, 0.0f);
+            W[(2 * k + 1) * WS_STRIDE + t] = f4(p.pc * lam, 0.0f);
+        }
+    }
+    h.t_rhs0 = h.rhs_wo0 + h.tb0; h.t_rhs1 = h.rhs_wo1 + h.tb1;
+    h.t_acc0 += h.t_imp0; h.t_acc1 += h.t_imp1;
+    h.t_imp0 *= wc; h.t_imp1 *= wc;
+    h.tw_acc += h.tw_imp;
+    h.tw_imp *= wc;
+    if (ws) {
+        float i0 = dppf<DPP_FROM_EVEN>(h.t_imp0), i1 = dppf<DPP_FROM_EVEN>(h.t_imp1);
+        float s0 = h.odd ? -i0 : i0, s1 = h.odd ? -i1 : i1;
+        W[8 * WS_STRIDE + t] = f4(cmul(h.t0 * s0 + h.t1 * s1, h.im), __int_as_float(h.n));
+        W[9 * WS_STRIDE + t] = f4(h.itd0 * i0 + h.itd1 * i1, 0.0f);
+        float tw = dppf<DPP_FROM_EVEN>(h.tw_imp);
+        if (h.n > 1) W[10 * WS_STRIDE + t] = f4(h.stw * tw, 0.0f);
+    }
+}
+RP_DEV void isl_ws_accumulate(const float4 *W, int begin, int count, V3 &lin, V3 &ang) {
+#pragma unroll 2
+    for (int e = 0; e < count; ++e) {
+        const int row = begin + e;
+        float4 tl = W[8 * WS_STRIDE + row], ta = W[9 * WS_STRIDE + row], tw = W[10 * WS_STRIDE + row];
+        float4 l0 = W[0 * WS_STRIDE + row], a0 = W[1 * WS_STRIDE + row], l1 = W[2 * WS_STRIDE + row], a1 = W[3 * WS_STRIDE + row];
+        float4 l2 = W[4 * WS_STRIDE + row], a2 = W[5 * WS_STRIDE + row], l3 = W[6 * WS_STRIDE + row], a3 = W[7 * WS_STRIDE + row];
+        const int n = __float_as_int(tl.w);
+        lin = lin + v3(l0); ang = ang + v3(a0);
+        if (n > 1) { lin = lin + v3(l1); ang = ang + v3(a1); }
+        if (n > 2) { lin = lin + v3(l2); ang = ang + v3(a2); }
+        if (n > 3) { lin = lin + v3(l3); ang = ang + v3(a3); }
+        lin = lin + v3(tl);
+        ang = ang + v3(ta);
+        if (n > 1) ang = ang + v3(tw);
+    }
+}
+
 // solve (:680-781); `relax` first switches to the bias-free right-hand sides of isl_pose_stage.
 template <bool F4> RP_DEV void isl_solve_t(IslSide &h, const IslLds &L, bool relax, bool friction) {
     const int hn = F4 ? 4 : h.n;
@@ -453,7 +509,6 @@ RP_DEV void isl_writeback(const DevWorld &w, const IslSide &h, int s) {
     }
 }
 
-#define ISL_THREADS (2 * RP_ISL_NC_MAX)
 #ifdef RP_ISL_PROFILE
 #define ISL_STAMP(slot) do { if (blockIdx.x == 0 && threadIdx.x == 0) w.dbg[slot] += (long long)__builtin_readcyclecounter() - t_prev, t_prev = (long long)__builtin_readcyclecounter(); } while (0)
 #else
@@ -488,11 +543,44 @@ RP_DEV void island_sort(const DevWorld &w, int isl, int nc, int cb, int nst_glob
             prev = r;
             w.isl_cons[cb + i] = K_slot[i];
             w.isl_cstage[cb + i] = q;
+            T_rank[i] = q;
         }
         w.isl_nstages[isl] = q + 1;
-        __threadfence();
-        w.isl_sorted[isl] = 1;
     }
+    __syncthreads();
+    // Per sorted manifold: the solver-attached body of each side (arena and island-local index);
+    // per body: the lanes (2m + side) that touch it, in sweep order — the body-centric warm start
+    // walks this list.  I_body / I_cnt reuse the scratch arrays.
+    int *I_body0 = T_slot, *I_body1 = K_rank, *I_cnt = K_slot; // T_rank keeps the stage of manifold m
+    if (t < RP_ISL_NB_MAX) I_cnt[t] = 0;
+    __syncthreads();
+    if (t < nc) {
+        int slot = w.isl_cons[cb + t];
+        int rb1 = w.c_parent[w.p_c1[slot]], rb2 = w.c_parent[w.p_c2[slot]];
+        int rel_dom = w.p_reldom[slot];
+        int g1 = (is_dyn(w, rb1) && rel_dom <= 0) ? rb1 : -1;
+        int g2 = (is_dyn(w, rb2) && rel_dom >= 0) ? rb2 : -1;
+        int l1 = g1 >= 0 ? w.b_local[g1] : -1, l2 = g2 >= 0 ? w.b_local[g2] : -1;
+        w.isl_cg1[cb + t] = g1; w.isl_cg2[cb + t] = g2; w.isl_cl1[cb + t] = l1; w.isl_cl2[cb + t] = l2;
+        I_body0[t] = l1; I_body1[t] = l2;
+        if (l1 >= 0) atomicAdd(&I_cnt[l1], 1);
+        if (l2 >= 0) atomicAdd(&I_cnt[l2], 1);
+    }
+    __syncthreads();
+    const int bb = w.isl_body_begin[isl], nb = w.isl_nb[isl];
+    if (t == 0) { int pos = 0; for (int b = 0; b < nb; ++b) { w.isl_inc_begin[bb + b] = pos; w.isl_inc_cnt[bb + b] = I_cnt[b]; pos += I_cnt[b]; } }
+    __threadfence(); __syncthreads();
+    if (t < 2 * nc) {
+        int m = t >> 1, side = t & 1;
+        int b = side ? I_body1[m] : I_body0[m];
+        if (b >= 0) {
+            int q = T_rank[m], rank = 0;
+            for (int m2 = 0; m2 < nc; ++m2) { int q2 = T_rank[m2]; rank += (q2 < q) && (I_body0[m2] == b || I_body1[m2] == b); }
+            w.isl_inc_pos[2 * cb + t] = w.isl_inc_begin[bb + b] + rank;
+        } else w.isl_inc_pos[2 * cb + t] = ISL_THREADS + (t & 1); // world-attached side: scratch rows nobody reads
+    }
+    __threadfence(); __syncthreads();
+    if (t == 0) w.isl_sorted[isl] = 1;
     __syncthreads();
 }
 
@@ -510,6 +598,7 @@ __global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int ha
     __shared__ float4 B_lin[RP_ISL_NB_MAX], B_ang[RP_ISL_NB_MAX], B_rot[RP_ISL_NB_MAX], B_trans[RP_ISL_NB_MAX];
     __shared__ float4 L_E[4 * RP_ISL_NC_MAX], L_F[4 * RP_ISL_NC_MAX], L_B0[RP_ISL_NC_MAX], L_B1[RP_ISL_NC_MAX];
     __shared__ int S_a[RP_ISL_NC_MAX], S_b[RP_ISL_NC_MAX], S_c[RP_ISL_NC_MAX], S_d[RP_ISL_NC_MAX];
+    __shared__ float4 W[WS_SLOTS * WS_STRIDE];
     __shared__ int any_bouncy;
 
     const int t = threadIdx.x, m = t >> 1;
@@ -543,37 +632,38 @@ __global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int ha
         if (t == 0) any_bouncy = 0;
         const int nls = w.isl_nstages[isl];
         const bool live = m < nc;
-        int slot = -1, myq = -1;
-        if (live) { slot = w.isl_cons[cb + m]; myq = w.isl_cstage[cb + m]; }
+        int slot = -1, myq = -1, own_g = -1, own_l = -1, ws_row = 0;
+        if (live) {
+            slot = w.isl_cons[cb + m]; myq = w.isl_cstage[cb + m];
+            own_g = (odd ? w.isl_cg2 : w.isl_cg1)[cb + m]; own_l = (odd ? w.isl_cl2 : w.isl_cl1)[cb + m];
+            ws_row = w.isl_inc_pos[2 * cb + t];
+        }
+        int inc_begin = 0, inc_cnt = 0;
+        if (t < nb) { inc_begin = w.isl_inc_begin[bb + t]; inc_cnt = w.isl_inc_cnt[bb + t]; }
         __syncthreads();
         ISL_STAMP(0); // body load + list
         IslSide h;
         h.n = 0; h.id = -1; h.odd = odd; h.cids = 0;
         // ---- generate (S1) by the lane pair, pose stage for the initial poses ----
         if (live) {
-            int c1 = w.p_c1[slot], c2 = w.p_c2[slot];
-            int rb = w.c_parent[odd ? c2 : c1];
-            int rel_dom = w.p_reldom[slot];
-            bool attached = is_dyn(w, rb) && (odd ? rel_dom >= 0 : rel_dom <= 0);
-            int g = attached ? rb : -1;
-            int l = g >= 0 ? w.b_local[g] : -1;
-            if (isl_generate(w, h, L, m, slot, g, l, odd) && !odd) any_bouncy = 1;
+            if (isl_generate(w, h, L, m, slot, own_g, own_l, odd) && !odd) any_bouncy = 1;
         }
         if (live) isl_pose_stage(w, h, L, m, 0.0f); // each lane reads back only what it stored itself
         ISL_STAMP(1); // generate + first pose stage
 
         for (int sub = 0; sub < w.prm.num_substeps; ++sub) {
             float solved_dt = (float)sub * w.prm.dt_sub;
-            __syncthreads(); // pose stage read rot/trans; relax sweep of the previous substep done
-            if (t < nb) { // S2
+            if (live) isl_ws_terms(w, h, W, ws_row); // warm-start terms of every manifold, in parallel
+            __syncthreads(); // + pose stage read rot/trans; relax sweep of the previous substep done
+            ISL_STAMP(2); // warm-start terms
+            if (t < nb) { // S2 increment, then the warm start of this body in sweep order
                 V3 lin = v3(B_lin[t]), ang = v3(B_ang[t]);
                 body_increment(w, b_fl, lin, ang, q4(B_rot[t]), b_incl, b_inca, b_invpi, b_pframe);
+                if (prm.warmstart_coefficient != 0.0f) isl_ws_accumulate(W, inc_begin, inc_cnt, lin, ang);
                 B_lin[t] = f4(lin, 0.0f); B_ang[t] = f4(ang, 0.0f);
             }
             __syncthreads();
-            ISL_STAMP(2); // increment
-            for (int q = 0; q < nls; ++q) { if (myq == q) isl_warmstart(w, h, L); __syncthreads(); }
-            ISL_STAMP(3); // warmstart sweep
+            ISL_STAMP(3); // increment + body-centric warm start
 #ifdef RP_ISL_EXTRA_EMPTY
             for (int q = 0; q < nls; ++q) { if (myq == q) { Vel v = isl_vel(L, h.id); isl_set_vel(L, h.id, v); } __syncthreads(); }
             ISL_STAMP(9); // extra sweep of empty stages (overhead measurement only)

@@ -198,6 +198,8 @@ struct DevWorld {
     int *isl_body_begin, *isl_nb, *isl_cons_begin, *isl_nc, *isl_fill_b, *isl_fill_c;
     int *isl_bodies, *isl_cons;
     int *isl_cstage;            // [pool] local stage index of isl_cons[i] once the island list is sorted
+    int *isl_cg1, *isl_cg2, *isl_cl1, *isl_cl2; // [pool] per sorted manifold: attached body of each side (arena / island-local index, -1 = world)
+    int *isl_inc_pos, *isl_inc_begin, *isl_inc_cnt; // warm-start rows: per lane (2m + side) its row = rank in its body's sweep-ordered list ([2*pool]); per island body the row range ([n_bodies] x2)
     int *isl_sorted, *isl_nstages; // per island: list sorted by sweep stage?, number of local stages
 
     // ---- impulse joints (active joints only, edge order) ----

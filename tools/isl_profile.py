@@ -16,7 +16,7 @@ L = _ffi.lib()
 L.rp_debug_cycles.argtypes = [C.c_void_p, C.c_void_p]
 L.rp_debug_cycles(w._ptr, buf.ctypes.data)
 n = max(int(buf[63]), 1)
-names = ["load", "generate+pose0", "increment", "warmstart sweep", "biased sweep", "integrate", "pose stage", "relax sweep", "writeback", "extra empty sweep"]
+names = ["load", "generate+pose0", "ws terms", "incr+ws accumulate", "biased sweep", "integrate", "pose stage", "relax sweep", "writeback", "extra empty sweep"]
 tot = buf[:10].sum() / n
 for k, nm in enumerate(names):
     print(f"{nm:18s} {buf[k] / n:10.0f} cycles/step  {100.0 * buf[k] / n / tot:5.1f}%")
