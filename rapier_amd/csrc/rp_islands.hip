@@ -13,8 +13,8 @@
 // Islands that do not fit (more than RP_ISL_NB_MAX bodies or RP_ISL_NC_MAX manifolds) and bodies
 // without contacts stay on the global per-colour path (rp_solver.hip).
 //
-// Island discovery (only when the active-manifold set changed): union-find hooking with atomicMin
-// over the active dynamic-dynamic pairs inside one workgroup, then island numbering and list filling.
+// Island discovery (only when the active-manifold set changed): lock-free union-find over the active
+// dynamic-dynamic pairs, then island numbering and list filling — five grid-wide kernels.
 // persistent.rs keeps comparable connected components for sleeping; here they drive scheduling only.
 #include "rp_global.h"
 
@@ -26,82 +26,103 @@ RP_DEV int uf_find(int *label, int x) {
 }
 RP_DEV bool is_dyn(const DevWorld &w, int b) { return b >= 0 && (w.b_flags[b] & RP_BF_TYPE_MASK) == RP_BODY_DYNAMIC; }
 
-__global__ void __launch_bounds__(1024) k_islands_build(DevWorld w) {
+// Lock-free union (hook the larger root under the smaller one, retry on races).
+RP_DEV void uf_union(int *label, int a, int b) {
+    for (;;) {
+        a = uf_find(label, a); b = uf_find(label, b);
+        if (a == b) return;
+        if (a < b) { int t = a; a = b; b = t; }
+        if (atomicCAS(&label[a], a, b) == a) return;
+    }
+}
+RP_DEV bool pair_active(const DevWorld &w, int s) { return w.p_c1[s] >= 0 && w.p_nsc[s] != 0; }
+
+// Island discovery runs only when the set of active manifolds changed (FL_LAYOUT_DIRTY): five
+// grid-wide kernels, every pass one thread per body or per pair slot.
+__global__ void k_isl_init(DevWorld w) {
     if (!w.flags[FL_LAYOUT_DIRTY]) return;
-    __shared__ int changed;
-    int tid = threadIdx.x, nt = blockDim.x;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { w.flags[FL_N_ISLANDS] = 0; w.flags[FL_N_GLOB_BODIES] = 0; w.flags[FL_ISL_BODY_CURSOR] = 0; w.flags[FL_ISL_CONS_CURSOR] = 0; }
+    if (i < w.n_bodies) { w.b_label[i] = i; w.r_nb[i] = 0; w.r_nc[i] = 0; w.r_island[i] = -1; w.b_island[i] = -1; w.b_local[i] = -1; }
+}
+// connected components over active pairs whose two sides are dynamic
+__global__ void k_isl_union(DevWorld w) {
+    if (!w.flags[FL_LAYOUT_DIRTY]) return;
     int top = w.flags[FL_POOL_TOP];
     if (top > w.pool_cap) top = w.pool_cap;
-    int nb = w.n_bodies;
-    for (int b = tid; b < nb; b += nt) { w.b_label[b] = b; w.r_nb[b] = 0; w.r_nc[b] = 0; w.r_island[b] = -1; w.b_island[b] = -1; w.b_local[b] = -1; }
-    if (tid == 0) { w.flags[FL_N_ISLANDS] = 0; w.flags[FL_N_GLOB_BODIES] = 0; w.flags[FL_ISL_BODY_CURSOR] = 0; w.flags[FL_ISL_CONS_CURSOR] = 0; }
-    __threadfence(); __syncthreads();
-    // (b) connected components over active pairs whose two sides are dynamic
-    for (int iter = 0; iter < 4096; ++iter) {
-        if (tid == 0) changed = 0;
-        __syncthreads();
-        for (int s = tid; s < top; s += nt) {
-            if (w.p_c1[s] < 0 || w.p_nsc[s] == 0) continue;
-            int b1 = w.c_parent[w.p_c1[s]], b2 = w.c_parent[w.p_c2[s]];
-            if (!is_dyn(w, b1) || !is_dyn(w, b2)) continue;
-            int r1 = uf_find(w.b_label, b1), r2 = uf_find(w.b_label, b2);
-            if (r1 != r2) { int hi = r1 > r2 ? r1 : r2, lo = r1 > r2 ? r2 : r1; atomicMin(&w.b_label[hi], lo); changed = 1; }
-        }
-        __threadfence(); __syncthreads();
-        for (int b = tid; b < nb; b += nt) { int r = uf_find(w.b_label, b); __hip_atomic_store(&w.b_label[b], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-        __threadfence(); __syncthreads();
-        int c = changed;
-        __syncthreads();
-        if (!c) break;
+    int stride = gridDim.x * blockDim.x;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < top; s += stride) {
+        if (!pair_active(w, s)) continue;
+        int b1 = w.c_parent[w.p_c1[s]], b2 = w.c_parent[w.p_c2[s]];
+        if (is_dyn(w, b1) && is_dyn(w, b2)) uf_union(w.b_label, b1, b2);
     }
-    // (c) per-root sizes
-    // a body that carries a joint is solved on the global path (joints live there): poison its component
-    for (int b = tid; b < nb; b += nt) if (is_dyn(w, b)) {
-        int root = ld_i32(&w.b_label[b]);
+}
+// flatten the labels; per-root body and manifold counts
+__global__ void k_isl_count(DevWorld w) {
+    if (!w.flags[FL_LAYOUT_DIRTY]) return;
+    int top = w.flags[FL_POOL_TOP];
+    if (top > w.pool_cap) top = w.pool_cap;
+    int stride = gridDim.x * blockDim.x, gid = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int b = gid; b < w.n_bodies; b += stride) {
+        if (!is_dyn(w, b)) continue;
+        int root = uf_find(w.b_label, b);
+        __hip_atomic_store(&w.b_label[b], root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         atomicAdd(&w.r_nb[root], 1);
-        if (w.b_njoints[b] > 0) atomicAdd(&w.r_nc[root], RP_ISL_NC_MAX + 1); // poison: never LDS-eligible
+        // a body that carries a joint is solved on the global path (joints live there): poison its component
+        if (w.b_njoints[b] > 0) atomicAdd(&w.r_nc[root], RP_ISL_NC_MAX + 1);
     }
-    for (int s = tid; s < top; s += nt) {
-        if (w.p_c1[s] < 0 || w.p_nsc[s] == 0) continue;
+    for (int s = gid; s < top; s += stride) {
+        if (!pair_active(w, s)) continue;
         int b1 = w.c_parent[w.p_c1[s]], b2 = w.c_parent[w.p_c2[s]];
         int b = is_dyn(w, b1) ? b1 : b2;
-        if (is_dyn(w, b)) atomicAdd(&w.r_nc[ld_i32(&w.b_label[b])], 1);
+        if (is_dyn(w, b)) atomicAdd(&w.r_nc[uf_find(w.b_label, b)], 1);
     }
-    __threadfence(); __syncthreads();
-    // (d) number the islands that fit in LDS
-    for (int b = tid; b < nb; b += nt) {
-        if (!is_dyn(w, b) || ld_i32(&w.b_label[b]) != b) continue;
-        int cnb = ld_i32(&w.r_nb[b]), cnc = ld_i32(&w.r_nc[b]);
-        if (cnc > 0 && cnb <= RP_ISL_NB_MAX && cnc <= RP_ISL_NC_MAX) {
-            int id = atomicAdd(&w.flags[FL_N_ISLANDS], 1);
-            w.isl_body_begin[id] = atomicAdd(&w.flags[FL_ISL_BODY_CURSOR], cnb);
-            w.isl_cons_begin[id] = atomicAdd(&w.flags[FL_ISL_CONS_CURSOR], cnc);
-            w.isl_nb[id] = cnb; w.isl_nc[id] = cnc; w.isl_fill_b[id] = 0; w.isl_fill_c[id] = 0; w.isl_sorted[id] = 0; w.isl_nstages[id] = 0;
-            w.r_island[b] = id;
-        } else {
-            atomicAdd(&w.flags[FL_N_GLOB_BODIES], cnb);
-        }
+}
+// number the islands that fit one workgroup (registers + LDS)
+__global__ void k_isl_number(DevWorld w) {
+    if (!w.flags[FL_LAYOUT_DIRTY]) return;
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= w.n_bodies || !is_dyn(w, b) || w.b_label[b] != b) return;
+    int cnb = w.r_nb[b], cnc = w.r_nc[b];
+    if (cnc > 0 && cnb <= RP_ISL_NB_MAX && cnc <= RP_ISL_NC_MAX) {
+        int id = atomicAdd(&w.flags[FL_N_ISLANDS], 1);
+        w.isl_body_begin[id] = atomicAdd(&w.flags[FL_ISL_BODY_CURSOR], cnb);
+        w.isl_cons_begin[id] = atomicAdd(&w.flags[FL_ISL_CONS_CURSOR], cnc);
+        w.isl_nb[id] = cnb; w.isl_nc[id] = cnc; w.isl_fill_b[id] = 0; w.isl_fill_c[id] = 0; w.isl_sorted[id] = 0; w.isl_nstages[id] = 0;
+        w.r_island[b] = id;
+    } else {
+        atomicAdd(&w.flags[FL_N_GLOB_BODIES], cnb);
     }
-    __threadfence(); __syncthreads();
-    // (e) fill the island lists
-    for (int b = tid; b < nb; b += nt) {
+}
+// fill the island lists; count the global-path manifolds per colour
+__global__ void k_isl_fill(DevWorld w) {
+    if (!w.flags[FL_LAYOUT_DIRTY]) return;
+    __shared__ int hist[RP_NUM_COLORS];
+    for (int c = threadIdx.x; c < RP_NUM_COLORS; c += blockDim.x) hist[c] = 0;
+    __syncthreads();
+    int top = w.flags[FL_POOL_TOP];
+    if (top > w.pool_cap) top = w.pool_cap;
+    int stride = gridDim.x * blockDim.x, gid = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int b = gid; b < w.n_bodies; b += stride) {
         if (!is_dyn(w, b)) continue;
-        int id = ld_i32(&w.r_island[ld_i32(&w.b_label[b])]);
+        int id = w.r_island[w.b_label[b]];
         if (id >= 0) {
             int k = atomicAdd(&w.isl_fill_b[id], 1);
             w.isl_bodies[w.isl_body_begin[id] + k] = b;
             w.b_island[b] = id; w.b_local[b] = k;
         }
     }
-    for (int s = tid; s < top; s += nt) {
-        if (w.p_c1[s] < 0 || w.p_nsc[s] == 0) { w.p_island[s] = -1; continue; }
+    for (int s = gid; s < top; s += stride) {
+        if (!pair_active(w, s)) { w.p_island[s] = -1; continue; }
         int b1 = w.c_parent[w.p_c1[s]], b2 = w.c_parent[w.p_c2[s]];
         int b = is_dyn(w, b1) ? b1 : b2;
-        int id = is_dyn(w, b) ? ld_i32(&w.r_island[ld_i32(&w.b_label[b])]) : -1;
+        int id = is_dyn(w, b) ? w.r_island[w.b_label[b]] : -1;
         w.p_island[s] = id;
         if (id >= 0) { int k = atomicAdd(&w.isl_fill_c[id], 1); w.isl_cons[w.isl_cons_begin[id] + k] = s; }
-        else { int color = w.p_color[s]; if (color <= RP_COLOR_OVERFLOW) atomicAdd(&w.color_count_glob[color], 1); }
+        else { int color = w.p_color[s]; if (color <= RP_COLOR_OVERFLOW) atomicAdd(&hist[color], 1); }
     }
+    __syncthreads();
+    for (int c = threadIdx.x; c < RP_NUM_COLORS; c += blockDim.x) if (hist[c]) atomicAdd(&w.color_count_glob[c], hist[c]);
 }
 
 // ---- register-resident constraint of one island thread ------------------------------------------
@@ -697,7 +718,14 @@ __global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int ha
 }
 
 void rp_launch_islands_build(const DevWorld &w, hipStream_t st) {
-    hipLaunchKernelGGL(k_islands_build, dim3(1), dim3(1024), 0, st, w);
+    int nbb = (w.n_bodies + 255) / 256; if (nbb < 1) nbb = 1;
+    int n = w.n_bodies > w.pool_cap ? w.n_bodies : w.pool_cap;
+    int blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_isl_init, dim3(nbb), dim3(256), 0, st, w);
+    hipLaunchKernelGGL(k_isl_union, dim3(blocks), dim3(256), 0, st, w);
+    hipLaunchKernelGGL(k_isl_count, dim3(blocks), dim3(256), 0, st, w);
+    hipLaunchKernelGGL(k_isl_number, dim3(nbb), dim3(256), 0, st, w);
+    hipLaunchKernelGGL(k_isl_fill, dim3(blocks), dim3(256), 0, st, w);
 }
 void rp_launch_island_solve(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast, int retire) {
     if (grid < 1) grid = 1;

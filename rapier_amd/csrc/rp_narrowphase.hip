@@ -564,6 +564,10 @@ __global__ void k_bucket_clear(DevWorld w) {
 }
 __global__ void k_bucket_count(DevWorld w) {
     if (!w.flags[FL_LAYOUT_DIRTY]) return;
+    __shared__ int hist[RP_NUM_COLORS], nsc_sum;
+    for (int c = threadIdx.x; c < RP_NUM_COLORS; c += blockDim.x) hist[c] = 0;
+    if (threadIdx.x == 0) nsc_sum = 0;
+    __syncthreads();
     int top = w.flags[FL_POOL_TOP];
     if (top > w.pool_cap) top = w.pool_cap;
     int stride = gridDim.x * blockDim.x;
@@ -572,9 +576,12 @@ __global__ void k_bucket_count(DevWorld w) {
         if (w.p_c1[s] < 0 || w.p_nsc[s] == 0) continue;
         int color = w.p_color[s];
         if (color > RP_COLOR_OVERFLOW) continue;
-        atomicAdd(&w.color_count[color], 1);
-        atomicAdd(&w.flags[FL_N_SC], w.p_nsc[s]);
+        atomicAdd(&hist[color], 1);
+        atomicAdd(&nsc_sum, w.p_nsc[s]);
     }
+    __syncthreads();
+    for (int c = threadIdx.x; c < RP_NUM_COLORS; c += blockDim.x) if (hist[c]) atomicAdd(&w.color_count[c], hist[c]);
+    if (threadIdx.x == 0 && nsc_sum) atomicAdd(&w.flags[FL_N_SC], nsc_sum);
 }
 __global__ void k_bucket_layout(DevWorld w) {
     if (!w.flags[FL_LAYOUT_DIRTY]) return;
@@ -605,6 +612,10 @@ __global__ void k_bucket_layout(DevWorld w) {
 }
 __global__ void k_bucket_scatter(DevWorld w) {
     if (!w.flags[FL_LAYOUT_DIRTY]) return;
+    // two passes per block: count its manifolds per colour, reserve one range per colour, then place
+    __shared__ int cnt[RP_NUM_COLORS], base[RP_NUM_COLORS];
+    for (int c = threadIdx.x; c < RP_NUM_COLORS; c += blockDim.x) cnt[c] = 0;
+    __syncthreads();
     int top = w.flags[FL_POOL_TOP];
     if (top > w.pool_cap) top = w.pool_cap;
     int stride = gridDim.x * blockDim.x;
@@ -612,7 +623,16 @@ __global__ void k_bucket_scatter(DevWorld w) {
         if (w.p_c1[s] < 0 || w.p_nsc[s] == 0 || w.p_island[s] >= 0) continue;
         int color = w.p_color[s];
         if (color > RP_COLOR_OVERFLOW) continue;
-        int pos = atomicAdd(&w.color_cursor[color], 1);
+        atomicAdd(&cnt[color], 1);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < RP_NUM_COLORS; c += blockDim.x) { base[c] = cnt[c] ? atomicAdd(&w.color_cursor[c], cnt[c]) : 0; cnt[c] = 0; }
+    __syncthreads();
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < top; s += stride) {
+        if (w.p_c1[s] < 0 || w.p_nsc[s] == 0 || w.p_island[s] >= 0) continue;
+        int color = w.p_color[s];
+        if (color > RP_COLOR_OVERFLOW) continue;
+        int pos = base[color] + atomicAdd(&cnt[color], 1);
         if (pos < w.cons_cap) { w.cons_pair[pos] = s; w.p_conspos[s] = pos; }
     }
 }
