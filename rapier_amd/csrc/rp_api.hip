@@ -523,8 +523,8 @@ static void enqueue_global_solver(rp_world *w) {
 }
 static void enqueue_solver(rp_world *w) { enqueue_island_solver(w); enqueue_global_solver(w); }
 static void enqueue_finish(rp_world *w) {
-    // SINGLE mode: k_island_solve already published the scalars to the mapped hint buffer
-    if (!w->plan_single) hipMemcpyAsync(w->pinned_flags, w->dw.flags, FL_COUNT * sizeof(int), hipMemcpyDeviceToHost, w->stream);
+    // the scalars reach the mapped hint buffer from the device: k_island_solve (SINGLE) / k_publish (MULTI)
+    (void)w;
 }
 
 static int pow2_ceil(int x) { int b = 1; while (b < x) b <<= 1; return b; }
@@ -593,10 +593,14 @@ static int launch_step(rp_world *w, int fast) {
         return RP_OK;
     }
     if (!w->use_graph) { enqueue_whole(w); HIPCHK(w, hipGetLastError()); return RP_OK; }
+    static const bool dbg = getenv("RP_DEBUG") != nullptr;
     if (!w->ge_whole[fast]) {
+        if (dbg) fprintf(stderr, "RPDBG capture fast=%d seq=%lld stages=%d blocks=%d single=%d grid=%d jst=%d\n", fast, w->seq_enqueued, w->plan_stages, w->plan_blocks, w->plan_single, w->plan_island_grid, w->plan_joint_stages);
         int r = capture(w, &w->g_whole[fast], &w->ge_whole[fast], enqueue_whole);
         if (r != RP_OK) return r;
+        if (dbg) fprintf(stderr, "RPDBG captured\n");
     }
+    if (dbg) fprintf(stderr, "RPDBG launch seq=%lld\n", w->seq_enqueued);
     HIPCHK(w, hipGraphLaunch(w->ge_whole[fast], w->stream));
     return RP_OK;
 }
@@ -633,6 +637,7 @@ static int step_once(rp_world *w, bool allow_fast) {
     }
     if (w->graph_stages != w->plan_stages || w->graph_blocks != w->plan_blocks || w->graph_single != w->plan_single ||
         w->graph_island_grid != w->plan_island_grid || w->graph_joint_stages != w->plan_joint_stages) {
+        if (w->ge_whole[0] || w->ge_whole[1] || w->ge_col[0] || w->ge_col[1]) HIPCHK(w, hipStreamSynchronize(w->stream)); // replays of the old graphs may still be in flight
         destroy_graphs(w);
         w->graph_stages = w->plan_stages; w->graph_blocks = w->plan_blocks; w->graph_single = w->plan_single; w->graph_island_grid = w->plan_island_grid;
         w->graph_joint_stages = w->plan_joint_stages;
@@ -640,7 +645,7 @@ static int step_once(rp_world *w, bool allow_fast) {
     // keep the host at most a few steps ahead of the device so the hints stay fresh (the device
     // never idles: several step graphs are always queued)
     const long long max_ahead = 4;
-    if (w->plan_single && w->use_graph && !w->timers) {
+    if (w->use_graph && !w->timers) {
         long long spins = 0;
         while (w->seq_enqueued - (long long)pf[FL_SEQ] > max_ahead) {
             if (++spins > (1 << 14)) { if (hipStreamQuery(w->stream) != hipErrorNotReady) break; spins = 0; }

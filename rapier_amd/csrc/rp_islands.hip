@@ -67,7 +67,9 @@ __global__ void k_isl_count(DevWorld w) {
         if (!is_dyn(w, b)) continue;
         int root = uf_find(w.b_label, b);
         __hip_atomic_store(&w.b_label[b], root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        atomicAdd(&w.r_nb[root], 1);
+        // saturating counts: a component that already exceeds the island limits stays on the global path
+        // whatever its exact size, so further increments (all on ONE address for a giant island) are skipped
+        if (ld_i32(&w.r_nb[root]) <= RP_ISL_NB_MAX) atomicAdd(&w.r_nb[root], 1);
         // a body that carries a joint is solved on the global path (joints live there): poison its component
         if (w.b_njoints[b] > 0) atomicAdd(&w.r_nc[root], RP_ISL_NC_MAX + 1);
     }
@@ -75,7 +77,7 @@ __global__ void k_isl_count(DevWorld w) {
         if (!pair_active(w, s)) continue;
         int b1 = w.c_parent[w.p_c1[s]], b2 = w.c_parent[w.p_c2[s]];
         int b = is_dyn(w, b1) ? b1 : b2;
-        if (is_dyn(w, b)) atomicAdd(&w.r_nc[uf_find(w.b_label, b)], 1);
+        if (is_dyn(w, b)) { int root = uf_find(w.b_label, b); if (ld_i32(&w.r_nc[root]) <= RP_ISL_NC_MAX) atomicAdd(&w.r_nc[root], 1); }
     }
 }
 // number the islands that fit one workgroup (registers + LDS)
@@ -90,15 +92,14 @@ __global__ void k_isl_number(DevWorld w) {
         w.isl_cons_begin[id] = atomicAdd(&w.flags[FL_ISL_CONS_CURSOR], cnc);
         w.isl_nb[id] = cnb; w.isl_nc[id] = cnc; w.isl_fill_b[id] = 0; w.isl_fill_c[id] = 0; w.isl_sorted[id] = 0; w.isl_nstages[id] = 0;
         w.r_island[b] = id;
-    } else {
-        atomicAdd(&w.flags[FL_N_GLOB_BODIES], cnb);
     }
 }
 // fill the island lists; count the global-path manifolds per colour
 __global__ void k_isl_fill(DevWorld w) {
     if (!w.flags[FL_LAYOUT_DIRTY]) return;
-    __shared__ int hist[RP_NUM_COLORS];
+    __shared__ int hist[RP_NUM_COLORS], n_glob;
     for (int c = threadIdx.x; c < RP_NUM_COLORS; c += blockDim.x) hist[c] = 0;
+    if (threadIdx.x == 0) n_glob = 0;
     __syncthreads();
     int top = w.flags[FL_POOL_TOP];
     if (top > w.pool_cap) top = w.pool_cap;
@@ -110,7 +111,7 @@ __global__ void k_isl_fill(DevWorld w) {
             int k = atomicAdd(&w.isl_fill_b[id], 1);
             w.isl_bodies[w.isl_body_begin[id] + k] = b;
             w.b_island[b] = id; w.b_local[b] = k;
-        }
+        } else atomicAdd(&n_glob, 1); // dynamic bodies left to the global path (launch-plan hint)
     }
     for (int s = gid; s < top; s += stride) {
         if (!pair_active(w, s)) { w.p_island[s] = -1; continue; }
@@ -123,6 +124,7 @@ __global__ void k_isl_fill(DevWorld w) {
     }
     __syncthreads();
     for (int c = threadIdx.x; c < RP_NUM_COLORS; c += blockDim.x) if (hist[c]) atomicAdd(&w.color_count_glob[c], hist[c]);
+    if (threadIdx.x == 0 && n_glob) atomicAdd(&w.flags[FL_N_GLOB_BODIES], n_glob);
 }
 
 // ---- register-resident constraint of one island thread ------------------------------------------

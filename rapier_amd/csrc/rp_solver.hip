@@ -72,6 +72,7 @@ __global__ void k_writeback_bodies(DevWorld w) {
     g_body_writeback(w, i);
 }
 
+__global__ void k_publish(DevWorld w) { publish_flags(w); }
 __global__ void __launch_bounds__(1024) k_global_single(DevWorld w, int has_restitution, int fast) { global_single_block(w, has_restitution, fast); }
 
 // World mass properties at insertion time (RigidBodyMassProps::update_world_mass_properties).
@@ -147,4 +148,5 @@ void rp_launch_solver_writeback(const DevWorld &w, hipStream_t st) {
     hipLaunchKernelGGL(k_writeback_impulses, dim3(cons_blocks(w)), dim3(256), 0, st, w);
     rp_launch_joint_writeback(w, st);
     hipLaunchKernelGGL(k_writeback_bodies, dim3(body_blocks(w)), dim3(256), 0, st, w);
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, w); // hint buffer (MULTI mode: after the step)
 }
