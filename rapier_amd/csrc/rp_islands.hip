@@ -414,19 +414,32 @@ RP_DEV void isl_ws_terms(const DevWorld &w, IslSide &h, float4 *W, int t) { // t
         if (h.n > 1) W[10 * WS_STRIDE + t] = f4(h.stw * tw, 0.0f);
     }
 }
-RP_DEV void isl_ws_accumulate(const float4 *W, int begin, int count, V3 &lin, V3 &ang) {
+// one thread adds the linear terms of a body, another one (64 lanes further) its angular terms
+RP_DEV void isl_ws_accumulate_lin(const float4 *W, int begin, int count, V3 &lin) {
+#pragma unroll 2
+    for (int e = 0; e < count; ++e) {
+        const int row = begin + e;
+        float4 tl = W[8 * WS_STRIDE + row];
+        float4 l0 = W[0 * WS_STRIDE + row], l1 = W[2 * WS_STRIDE + row], l2 = W[4 * WS_STRIDE + row], l3 = W[6 * WS_STRIDE + row];
+        const int n = __float_as_int(tl.w);
+        lin = lin + v3(l0);
+        if (n > 1) lin = lin + v3(l1);
+        if (n > 2) lin = lin + v3(l2);
+        if (n > 3) lin = lin + v3(l3);
+        lin = lin + v3(tl);
+    }
+}
+RP_DEV void isl_ws_accumulate_ang(const float4 *W, int begin, int count, V3 &ang) {
 #pragma unroll 2
     for (int e = 0; e < count; ++e) {
         const int row = begin + e;
         float4 tl = W[8 * WS_STRIDE + row], ta = W[9 * WS_STRIDE + row], tw = W[10 * WS_STRIDE + row];
-        float4 l0 = W[0 * WS_STRIDE + row], a0 = W[1 * WS_STRIDE + row], l1 = W[2 * WS_STRIDE + row], a1 = W[3 * WS_STRIDE + row];
-        float4 l2 = W[4 * WS_STRIDE + row], a2 = W[5 * WS_STRIDE + row], l3 = W[6 * WS_STRIDE + row], a3 = W[7 * WS_STRIDE + row];
+        float4 a0 = W[1 * WS_STRIDE + row], a1 = W[3 * WS_STRIDE + row], a2 = W[5 * WS_STRIDE + row], a3 = W[7 * WS_STRIDE + row];
         const int n = __float_as_int(tl.w);
-        lin = lin + v3(l0); ang = ang + v3(a0);
-        if (n > 1) { lin = lin + v3(l1); ang = ang + v3(a1); }
-        if (n > 2) { lin = lin + v3(l2); ang = ang + v3(a2); }
-        if (n > 3) { lin = lin + v3(l3); ang = ang + v3(a3); }
-        lin = lin + v3(tl);
+        ang = ang + v3(a0);
+        if (n > 1) ang = ang + v3(a1);
+        if (n > 2) ang = ang + v3(a2);
+        if (n > 3) ang = ang + v3(a3);
         ang = ang + v3(ta);
         if (n > 1) ang = ang + v3(tw);
     }
@@ -642,14 +655,20 @@ __global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int ha
 #endif
         if (!w.isl_sorted[isl]) island_sort(w, isl, nc, cb, nst_global, S_a, S_b, S_c, S_d);
         // ---- bodies -> LDS (+ per-body constants in the owning thread's registers) (S0) ----
+        // threads [0, nb) own the linear half of body t (and integrate / write it back), threads
+        // [64, 64 + nb) the angular half of body t - 64: the two halves of the increment and of the
+        // body-centric warm start are independent chains
+        const int bt = t & (RP_ISL_NB_MAX - 1);
+        const bool role_lin = t < nb, role_ang = t >= RP_ISL_NB_MAX && t < RP_ISL_NB_MAX + nb;
         int b_gid = -1, b_fl = 0;
         V3 b_incl = v3(0, 0, 0), b_inca = b_incl, b_invpi = b_incl; Q4 b_pframe = q4(0, 0, 0, 1);
-        if (t < nb) {
-            int g = w.isl_bodies[bb + t];
+        if (role_lin || role_ang) {
+            int g = w.isl_bodies[bb + bt];
             V3 lin, ang, trans; Q4 rot;
             body_begin(w, g, lin, ang, rot, trans, b_incl, b_inca);
             b_gid = g; b_fl = w.b_flags[g];
-            B_lin[t] = f4(lin, 0.0f); B_ang[t] = f4(ang, 0.0f); B_rot[t] = f4(rot); B_trans[t] = f4(trans, 0.0f);
+            if (role_lin) { B_lin[bt] = f4(lin, 0.0f); B_rot[bt] = f4(rot); B_trans[bt] = f4(trans, 0.0f); }
+            else B_ang[bt] = f4(ang, 0.0f);
             b_invpi = v3(w.b_invpi[g]); b_pframe = q4(w.b_pframe[g]);
         }
         if (t == 0) any_bouncy = 0;
@@ -662,7 +681,7 @@ __global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int ha
             ws_row = w.isl_inc_pos[2 * cb + t];
         }
         int inc_begin = 0, inc_cnt = 0;
-        if (t < nb) { inc_begin = w.isl_inc_begin[bb + t]; inc_cnt = w.isl_inc_cnt[bb + t]; }
+        if (role_lin || role_ang) { inc_begin = w.isl_inc_begin[bb + bt]; inc_cnt = w.isl_inc_cnt[bb + bt]; }
         __syncthreads();
         ISL_STAMP(0); // body load + list
         IslSide h;
@@ -679,11 +698,16 @@ __global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int ha
             if (live) isl_ws_terms(w, h, W, ws_row); // warm-start terms of every manifold, in parallel
             __syncthreads(); // + pose stage read rot/trans; relax sweep of the previous substep done
             ISL_STAMP(2); // warm-start terms
-            if (t < nb) { // S2 increment, then the warm start of this body in sweep order
-                V3 lin = v3(B_lin[t]), ang = v3(B_ang[t]);
-                body_increment(w, b_fl, lin, ang, q4(B_rot[t]), b_incl, b_inca, b_invpi, b_pframe);
-                if (prm.warmstart_coefficient != 0.0f) isl_ws_accumulate(W, inc_begin, inc_cnt, lin, ang);
-                B_lin[t] = f4(lin, 0.0f); B_ang[t] = f4(ang, 0.0f);
+            // S2 increment (worker.rs:235-284), then the warm start of this body in sweep order
+            if (role_lin) {
+                V3 lin = v3(B_lin[bt]) + b_incl;
+                if (prm.warmstart_coefficient != 0.0f) isl_ws_accumulate_lin(W, inc_begin, inc_cnt, lin);
+                B_lin[bt] = f4(lin, 0.0f);
+            } else if (role_ang) {
+                V3 lin_unused = v3(0, 0, 0), ang = v3(B_ang[bt]);
+                body_increment(w, b_fl, lin_unused, ang, q4(B_rot[bt]), v3(0, 0, 0), b_inca, b_invpi, b_pframe);
+                if (prm.warmstart_coefficient != 0.0f) isl_ws_accumulate_ang(W, inc_begin, inc_cnt, ang);
+                B_ang[bt] = f4(ang, 0.0f);
             }
             __syncthreads();
             ISL_STAMP(3); // increment + body-centric warm start

@@ -104,7 +104,7 @@ struct SolverLaunchPlan { int parallel_stages; int stage_blocks; };
 template <int MODE>
 static void launch_sweep(const DevWorld &w, hipStream_t st, const SolverLaunchPlan &plan, int fib, float solved_dt) {
     for (int s = 0; s < plan.parallel_stages; ++s)
-        hipLaunchKernelGGL(k_stage<MODE>, dim3(plan.stage_blocks), dim3(256), 0, st, w, s, fib, solved_dt);
+        hipLaunchKernelGGL(k_stage<MODE>, dim3(plan.stage_blocks * 4), dim3(64), 0, st, w, s, fib, solved_dt); // one wave per workgroup: a colour stage of ~10k manifolds then spreads over ~150 CUs instead of ~40
     hipLaunchKernelGGL(k_tail<MODE>, dim3(1), dim3(1024), 0, st, w, plan.parallel_stages, fib, solved_dt);
 }
 static int body_blocks(const DevWorld &w) { int nb = (w.n_bodies + 255) / 256; return nb < 1 ? 1 : nb; }
