@@ -37,7 +37,7 @@ void rp_launch_solver_loop(const DevWorld &w, hipStream_t st, int parallel_stage
 void rp_launch_solver_writeback(const DevWorld &w, hipStream_t st);
 void rp_launch_island_solve(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast, int retire);
 void rp_launch_global_single(const DevWorld &w, hipStream_t st, int has_restitution, int fast);
-void rp_launch_fast_front(const DevWorld &w, hipStream_t st);
+void rp_launch_fast_front(const DevWorld &w, hipStream_t st, int no_global_kernel);
 
 struct HostBody { rp_body_desc d; float inv_mass; float inv_pi[3]; float lcom[3]; int ncolliders; };
 
@@ -57,12 +57,12 @@ struct rp_world {
     DevWorld dw;
     int *pinned_flags = nullptr; // FL_COUNT ints, written by an async D2H copy at the end of each step
     // launch plan + graph
-    int plan_stages = 0, plan_blocks = 1, plan_single = 1, plan_island_grid = 1, plan_joint_stages = 0;
+    int plan_stages = 0, plan_blocks = 1, plan_single = 1, plan_island_grid = 1, plan_joint_stages = 0, plan_no_global = 0;
     bool has_restitution = false;
     // [0] = full path, [1] = fast path; "whole" = one graph per step, col/loop/fin = timed thirds
     hipGraph_t g_whole[2] = {nullptr, nullptr}, g_col[2] = {nullptr, nullptr}, g_loop[2] = {nullptr, nullptr}, g_fin[2] = {nullptr, nullptr};
     hipGraphExec_t ge_whole[2] = {nullptr, nullptr}, ge_col[2] = {nullptr, nullptr}, ge_loop[2] = {nullptr, nullptr}, ge_fin[2] = {nullptr, nullptr};
-    int graph_stages = -1, graph_blocks = -1, graph_single = -1, graph_island_grid = -1, graph_joint_stages = -1;
+    int graph_stages = -1, graph_blocks = -1, graph_single = -1, graph_island_grid = -1, graph_joint_stages = -1, graph_no_global = -1;
     bool use_graph = true, use_fast = true;
     int cur_fast = 0;              // mode the enqueue_* callbacks capture
     long long steps_requested = 0; // steps asked for since finalize (device FL_STEP counts the executed ones)
@@ -201,7 +201,7 @@ static void destroy_graphs(rp_world *w) {
         for (auto e : ex) if (*e) { hipGraphExecDestroy(*e); *e = nullptr; }
         for (auto g : gr) if (*g) { hipGraphDestroy(*g); *g = nullptr; }
     }
-    w->graph_stages = -1; w->graph_blocks = -1; w->graph_single = -1; w->graph_island_grid = -1; w->graph_joint_stages = -1;
+    w->graph_stages = -1; w->graph_blocks = -1; w->graph_single = -1; w->graph_island_grid = -1; w->graph_joint_stages = -1; w->graph_no_global = -1;
 }
 static void free_device(rp_world *w) {
     destroy_graphs(w);
@@ -502,7 +502,7 @@ static int finalize(rp_world *w) {
 }
 
 static void enqueue_collision(rp_world *w) {
-    if (w->cur_fast) { rp_launch_fast_front(w->dw, w->stream); return; }
+    if (w->cur_fast) { rp_launch_fast_front(w->dw, w->stream, w->plan_no_global); return; }
     rp_launch_collider_update(w->dw, w->stream);
     rp_launch_broadphase(w->dw, w->stream);
     rp_launch_narrowphase(w->dw, w->stream);
@@ -514,6 +514,7 @@ static void enqueue_island_solver(rp_world *w) {
 }
 static void enqueue_global_solver(rp_world *w) {
     int hr = w->has_restitution ? 1 : 0;
+    if (w->cur_fast && w->plan_no_global) return; // k_fast_front verified on the device that the global path is empty
     if (w->plan_single) rp_launch_global_single(w->dw, w->stream, hr, w->cur_fast);
     else {
         rp_launch_solver_assembly(w->dw, w->stream);
@@ -535,6 +536,7 @@ static void plan_from_hints(rp_world *w, const int *fl) {
     if (force && force[0] == '1') w->plan_single = 0;
     w->plan_stages = fl[FL_N_PARALLEL];
     w->plan_joint_stages = fl[FL_NJ_STAGES];
+    w->plan_no_global = (fl[FL_N_CONS] == 0 && fl[FL_N_GLOB_BODIES] == 0 && w->dw.n_joints == 0) ? 1 : 0;
     // round up to a power of two so small changes of the stage size do not force a re-capture
     w->plan_blocks = std::min(std::max(pow2_ceil((fl[FL_MAX_STAGE] + 255) / 256), 1), 4096);
     w->plan_island_grid = std::min(std::max(pow2_ceil(fl[FL_N_ISLANDS]), 1), 8192);
@@ -572,7 +574,7 @@ static int launch_step(rp_world *w, int fast) {
             int r;
             if ((r = capture(w, &w->g_col[fast], &w->ge_col[fast], enqueue_collision)) != RP_OK) return r;
             if ((r = capture(w, &w->g_loop[fast], &w->ge_loop[fast], enqueue_island_solver)) != RP_OK) return r;
-            if ((r = capture(w, &w->g_fin[fast], &w->ge_fin[fast], enqueue_global_and_finish)) != RP_OK) return r;
+            if (!(fast && w->plan_no_global) && (r = capture(w, &w->g_fin[fast], &w->ge_fin[fast], enqueue_global_and_finish)) != RP_OK) return r;
         }
         HIPCHK(w, hipEventRecord(w->ev[0], w->stream));
         HIPCHK(w, hipGraphLaunch(w->ge_col[fast], w->stream));
@@ -636,11 +638,11 @@ static int step_once(rp_world *w, bool allow_fast) {
         if (w->plan_island_grid < old_g && w->plan_island_grid * 2 >= old_g) w->plan_island_grid = old_g;
     }
     if (w->graph_stages != w->plan_stages || w->graph_blocks != w->plan_blocks || w->graph_single != w->plan_single ||
-        w->graph_island_grid != w->plan_island_grid || w->graph_joint_stages != w->plan_joint_stages) {
+        w->graph_island_grid != w->plan_island_grid || w->graph_joint_stages != w->plan_joint_stages || w->graph_no_global != w->plan_no_global) {
         if (w->ge_whole[0] || w->ge_whole[1] || w->ge_col[0] || w->ge_col[1]) HIPCHK(w, hipStreamSynchronize(w->stream)); // replays of the old graphs may still be in flight
         destroy_graphs(w);
         w->graph_stages = w->plan_stages; w->graph_blocks = w->plan_blocks; w->graph_single = w->plan_single; w->graph_island_grid = w->plan_island_grid;
-        w->graph_joint_stages = w->plan_joint_stages;
+        w->graph_joint_stages = w->plan_joint_stages; w->graph_no_global = w->plan_no_global;
     }
     // keep the host at most a few steps ahead of the device so the hints stay fresh (the device
     // never idles: several step graphs are always queued)

@@ -48,10 +48,15 @@ __global__ void k_collider_update(DevWorld w) {
 // recycle test (narrow phase must run) the step cannot be done by the fast graph: FL_FAST_ABORT is
 // raised, nothing else has been modified that the full path would not recompute identically, and the
 // remaining fast kernels exit; the host replays the step through the full graph.
-__global__ void k_fast_front(DevWorld w) {
+__global__ void k_fast_front(DevWorld w, int no_global_kernel) {
     if (w.flags[FL_FAST_ABORT]) return;
     int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid == 0) { w.flags[FL_FULL_UPDATES] = 0; if (w.flags[FL_BP_DIRTY]) w.flags[FL_FAST_ABORT] = 1; }
+    if (gid == 0) {
+        w.flags[FL_FULL_UPDATES] = 0;
+        if (w.flags[FL_BP_DIRTY]) w.flags[FL_FAST_ABORT] = 1;
+        // this graph variant carries no global-path kernel: it is only valid while everything lives in LDS islands
+        if (no_global_kernel && (w.flags[FL_N_CONS] > 0 || w.flags[FL_N_GLOB_BODIES] > 0 || w.n_joints > 0)) w.flags[FL_FAST_ABORT] = 1;
+    }
     bool abort = false;
     if (gid < w.n_colliders) {
         abort |= collider_update_one(w, gid); // rewritten fat AABB => FL_BP_DIRTY
@@ -294,12 +299,12 @@ void rp_launch_collider_update(const DevWorld &w, hipStream_t st) {
     hipLaunchKernelGGL(k_collider_update, dim3((w.n_colliders + 255) / 256), dim3(256), 0, st, w);
 }
 
-void rp_launch_fast_front(const DevWorld &w, hipStream_t st) {
+void rp_launch_fast_front(const DevWorld &w, hipStream_t st, int no_global_kernel) {
     int n = w.n_colliders > w.pool_cap ? w.n_colliders : w.pool_cap;
     int blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
     int need = (w.n_colliders + 255) / 256; if (blocks < need) blocks = need;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_fast_front, dim3(blocks), dim3(256), 0, st, w);
+    hipLaunchKernelGGL(k_fast_front, dim3(blocks), dim3(256), 0, st, w, no_global_kernel);
 }
 
 void rp_launch_broadphase(const DevWorld &w, hipStream_t st) {
