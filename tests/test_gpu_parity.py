@@ -152,6 +152,62 @@ def test_joint_grid_full_size():
     assert np.isfinite(pos).all() and np.abs(vel).max() < 100.0
 
 
+def test_fast_path_abort_and_replay_bit_exact():
+    """A settled stack runs on the steady-state fast graph; a velocity kick makes k_fast_front give up
+    (recycle tests fail, fat AABBs are left) and the host replays those steps on the full graph.  The
+    result must not depend on which graph ran."""
+    sc = S.many_pyramids(rows=1, cols=2)
+    g = PhysicsWorld.from_scene(sc)
+    o = OracleWorld(sc)
+    g.step(150); o.step(150)
+    c0 = g.counters()
+    assert c0["fast_steps"] > 50, c0
+    top = len(sc.bodies) - 1
+    kick = np.array([[3.0, 2.0, 0.5, 0.0, 1.0, 0.0]], np.float32)
+    g.write_bodies([top], vel6=kick)
+    o.set_vel(top, kick[0, :3], kick[0, 3:])
+    for cp in (1, 20, 150):
+        g.step(cp); o.step(cp)
+        gp, gv = g.read_bodies()
+        op, ov = o.read()
+        np.testing.assert_array_equal(gp, op)
+        np.testing.assert_array_equal(gv, ov)
+    c1 = g.counters()
+    assert c1["full_steps"] > c0["full_steps"]
+
+
+def test_fast_and_full_graphs_agree(monkeypatch):
+    sc = S.many_pyramids(rows=2, cols=2)
+    a = PhysicsWorld.from_scene(sc)
+    a.step(200)
+    pa, va = a.read_bodies()
+    assert a.counters()["fast_steps"] > 100
+    monkeypatch.setenv("RP_NO_FAST", "1")
+    b = PhysicsWorld.from_scene(sc)
+    b.step(200)
+    pb, vb = b.read_bodies()
+    assert b.counters()["fast_steps"] == 0
+    np.testing.assert_array_equal(pa, pb)
+    np.testing.assert_array_equal(va, vb)
+
+
+@pytest.mark.parametrize("override", [
+    {"warmstart_joints": 1},
+    {"friction_in_bias_pass": 1},
+    {"num_internal_pgs_iterations": 2, "num_internal_stabilization_iterations": 2},
+    {"num_solver_iterations": 2, "warmstart_coefficient": 0.5},
+    {"num_internal_stabilization_iterations": 0},
+])
+def test_integration_parameter_variants_bit_exact(override):
+    """Non-default IntegrationParameters (integration_parameters.rs:181-304) through both solver paths:
+    LDS islands (pyramid) and the global path with joints (jointed boxes on a slab)."""
+    for mk in (lambda: S.pyramid10(), lambda: S.joint_chain(5, with_boxes=True)):
+        sc = mk()
+        for k, v in override.items():
+            sc.params[k] = v
+        _compare(sc, [1, 20, 90])
+
+
 def test_golden_fixtures_on_gpu():
     import glob
     import os
