@@ -30,18 +30,26 @@ def algorithmic_bytes_per_step(M: int, N: int, substeps: int = 4) -> float:
     return substeps * (M * (1100.0 + 476.0 + 1008.0) + N * 224.0)
 
 
-def cpu_baseline(steps: int = 300, warmup: int = 60):
-    """The C oracle (a scalar port of the reference algorithm) timed on ONE host core on a bounded
-    sample of the same workload."""
+def cpu_baseline(steps: int = 400, warmup: int = 60):
+    """The C oracle (a scalar port of the reference algorithm, OpenMP over the same body-disjoint colour
+    stages the reference hands to its rayon pool) timed on the host cores on a bounded sample of the
+    same workload.  `value` = the multi-threaded rate; the single-thread rate is reported beside it."""
+    import oracle_ffi
     from rapier_amd import scenes as S
-    from oracle_ffi import OracleWorld
-    w = OracleWorld(S.many_pyramids())
-    w.step(warmup)
-    t = time.perf_counter()
-    w.step(steps)
-    dt = time.perf_counter() - t
-    return {"value": steps / dt, "unit": "steps/s", "cores": 1, "kind": "port",
-            "sample": f"{steps} steps of b3d_many_pyramids (10,780 cuboids) after {warmup} warm-up steps, oracle/librapier_oracle.so, 1 thread"}
+    cores = max(1, min(os.cpu_count() or 1, 32))
+    out = {}
+    for threads in (1, cores):
+        oracle_ffi.set_threads(threads)
+        w = oracle_ffi.OracleWorld(S.many_pyramids())
+        w.step(warmup)
+        n = steps if threads > 1 else steps // 4
+        t = time.perf_counter()
+        w.step(n)
+        out[threads] = n / (time.perf_counter() - t)
+    oracle_ffi.set_threads(1)
+    return {"value": out[cores], "unit": "steps/s", "cores": cores, "kind": "port", "single_thread_value": out[1],
+            "sample": f"{steps} steps of b3d_many_pyramids (10,780 cuboids) after {warmup} warm-up steps, oracle/librapier_oracle.so "
+                      f"(C restatement, OpenMP, {cores} threads; {steps // 4} steps on 1 thread)"}
 
 
 def main():

@@ -20,6 +20,24 @@
  */
 #include "rapier_oracle.h"
 #include "ro_shapes.h"
+/* Optional OpenMP (bench.py's cpu_baseline leg): loops over items that touch pairwise-disjoint state
+ * — the pairs of the narrow phase, the bodies, the constraints of one colour (the reference runs
+ * exactly these loops on its rayon pool, staged_island_solver/worker.rs) — are parallel; the colour
+ * order and every f32 expression are unchanged, so results do not depend on the thread count. */
+#ifdef _OPENMP
+#include <omp.h>
+#define RO_PRAGMA(x) _Pragma(#x)
+#define RO_PARALLEL_FOR RO_PRAGMA(omp parallel for schedule(static) if (ro_threads > 1) num_threads(ro_threads))
+#define RO_PARALLEL_FOR_RED(a, b) RO_PRAGMA(omp parallel for schedule(static) reduction(+ : a, b) if (ro_threads > 1) num_threads(ro_threads))
+#define RO_PRAGMA_IF_PAR(serial) RO_PRAGMA(omp parallel for schedule(static) if (ro_threads > 1 && !(serial)) num_threads(ro_threads))
+#else
+#define RO_PARALLEL_FOR
+#define RO_PARALLEL_FOR_RED(a, b)
+#define RO_PRAGMA_IF_PAR(serial)
+#endif
+static int ro_threads = 1;
+void ro_set_threads(int32_t n) { ro_threads = n < 1 ? 1 : n; }
+int32_t ro_get_threads(void) { return ro_threads; }
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -581,24 +599,25 @@ static int effective_dominance_group(const ro_world *w, int body) {
     return 128;
 }
 
-static void process_pair(ro_world *w, int pair_idx, Transition *transitions, int *ntransitions) {
+/* outcome: 0 = recycled, 1 = full update; *tr_out->pair = -1 when the pair has no transition */
+static int process_pair(ro_world *w, int pair_idx, Transition *tr_out) {
+    tr_out->pair = -1;
     Pair *p = &w->pairs[pair_idx];
     const Collider *co1 = &w->colliders[p->c1], *co2 = &w->colliders[p->c2];
     const ro_params *prm = &w->params;
     float prediction = prm->normalized_prediction_distance * prm->length_unit;
     float recycle_dist = prm->contact_recycling ? prm->normalized_contact_recycle_distance * prm->length_unit : 0.0f;
     /* :98-106 — neither body awake (non-dynamic): skipped */
-    if (!body_is_dynamic(w, co1->parent) && !body_is_dynamic(w, co2->parent)) return;
+    if (!body_is_dynamic(w, co1->parent) && !body_is_dynamic(w, co2->parent)) return 2;
 
     /* :111-171 contact recycling */
     if (recycle_dist > 0.0f && p->has_recycle) {
         pose pos12 = pose_inv_mul(co1->pos, co2->pos);
         float drift = relative_pose_drift(p->rec_pos12, pos12, p->rec_max_extent);
         float rot_cos = ro_minf(relative_rot_cos(p->rec_rot1, co1->pos.r), relative_rot_cos(p->rec_rot2, co2->pos.r));
-        if (drift <= p->rec_max_drift && rot_cos > 0.98f) { w->stats.num_recycled++; return; }
+        if (drift <= p->rec_max_drift && rot_cos > 0.98f) return 0;
     }
     int had = p->nsc > 0;
-    w->stats.num_full_updates++;
     int rb1 = co1->parent, rb2 = co2->parent;
     /* filters (:179-252) were applied when the pair was created (static in this scope) */
     pose pos12 = pose_inv_mul(co1->pos, co2->pos);
@@ -688,9 +707,10 @@ static void process_pair(ro_world *w, int pair_idx, Transition *transitions, int
     /* :622-629 begin/end-touch transition */
     int has = p->nsc > 0;
     if (has != had) {
-        Transition *t = &transitions[(*ntransitions)++];
+        Transition *t = tr_out;
         t->pair = pair_idx; t->body1 = rb1; t->body2 = rb2; t->touching = has;
     }
+    return 1;
 }
 
 typedef struct { uint64_t key; int pair; int b1, b2; } ColorTodo;
@@ -703,7 +723,13 @@ static void narrow_phase_compute_contacts(ro_world *w) {
     Transition *tr = (Transition *)malloc(sizeof(Transition) * (w->npairs + 1));
     int ntr = 0;
     w->stats.num_full_updates = 0; w->stats.num_recycled = 0;
-    for (int i = 0; i < w->npairs; ++i) process_pair(w, i, tr, &ntr);
+    /* pairs are independent (contacts.rs:22-251 hands them to a rayon broadcast); transitions are
+     * collected per pair and compacted in edge order afterwards */
+    int nfull = 0, nrec = 0;
+    RO_PARALLEL_FOR_RED(nfull, nrec)
+    for (int i = 0; i < w->npairs; ++i) { int o = process_pair(w, i, &tr[i]); nfull += o == 1; nrec += o == 0; }
+    w->stats.num_full_updates = nfull; w->stats.num_recycled = nrec;
+    for (int i = 0; i < w->npairs; ++i) if (tr[i].pair >= 0) tr[ntr++] = tr[i];
     /* transitions are visited in edge order (already ascending); end-touch frees its colour first */
     ColorTodo *todo = (ColorTodo *)malloc(sizeof(ColorTodo) * (ntr + 1));
     int ntodo = 0;
@@ -1221,17 +1247,25 @@ static void joint_row_solve(ro_world *w, JointRow *c) {
 }
 /* The joint part of solve_pass — staged_island_solver/solve.rs:31-150: every joint (parallel colours
  * ascending, then the serial overflow) solves BEFORE any contact in every pass. */
-static void joints_solve_pass(ro_world *w, int wo_bias, int warmstart_joints) {
-    for (int a = 0; a < w->nactive_joints; ++a) {
-        const Joint *j = &w->joints[w->joint_order[a]];
-        int count = 0; for (int i = 0; i < 3; ++i) if (j->locked_axes & (1u << i)) count++;
-        for (int k = 0; k < count; ++k) {
-            JointRow *c = &w->joint_rows[j->first_row + k];
-            if (wo_bias) c->rhs = c->rhs_wo_bias;
-            if (warmstart_joints) joint_row_warmstart(w, c);
-            joint_row_solve(w, c);
-        }
+static void joint_solve_all_rows(ro_world *w, const Joint *j, int wo_bias, int warmstart_joints) {
+    int count = 0; for (int i = 0; i < 3; ++i) if (j->locked_axes & (1u << i)) count++;
+    for (int k = 0; k < count; ++k) {
+        JointRow *c = &w->joint_rows[j->first_row + k];
+        if (wo_bias) c->rhs = c->rhs_wo_bias;
+        if (warmstart_joints) joint_row_warmstart(w, c);
+        joint_row_solve(w, c);
     }
+}
+static void joints_solve_pass(ro_world *w, int wo_bias, int warmstart_joints) {
+    int a = 0;
+    while (a < w->njoint_parallel) { /* one parallel colour = one body-disjoint stage */
+        int c = w->joints[w->joint_order[a]].solver_color, e = a;
+        while (e < w->njoint_parallel && w->joints[w->joint_order[e]].solver_color == c) ++e;
+        RO_PARALLEL_FOR
+        for (int i = a; i < e; ++i) joint_solve_all_rows(w, &w->joints[w->joint_order[i]], wo_bias, warmstart_joints);
+        a = e;
+    }
+    for (; a < w->nactive_joints; ++a) joint_solve_all_rows(w, &w->joints[w->joint_order[a]], wo_bias, warmstart_joints);
 }
 
 static void solve_velocity_constraints(ro_world *w) {
@@ -1283,6 +1317,7 @@ static void solve_velocity_constraints(ro_world *w) {
     w->ncons = M;
 
     /* S0: solver bodies + increments — worker.rs:46-104, solver_body.rs:82-121 */
+    RO_PARALLEL_FOR
     for (int i = 0; i < nd; ++i) {
         Body *rb = &w->bodies[w->dyn_bodies[i]];
         w->flags[i] = rb->allow_fast_rotation ? 1 : 0;
@@ -1302,10 +1337,10 @@ static void solve_velocity_constraints(ro_world *w) {
     }
     /* S1: generate — worker.rs:109-190.  Constraint i lives at bucket position i. */
     int any_bouncy = 0;
-    for (int i = 0; i < M; ++i) {
-        constraint_generate(w, order[i], &w->cons[i]);
+    RO_PARALLEL_FOR
+    for (int i = 0; i < M; ++i) constraint_generate(w, order[i], &w->cons[i]);
+    for (int i = 0; i < M; ++i)
         for (int k = 0; k < w->cons[i].num_contacts; ++k) any_bouncy |= w->cons[i].infos[k].restitution_seed < 0.0f;
-    }
     free(order);
     /* joints: selection, colouring in the contacts' colour space, builders — init_joints, joints.rs:25-329 */
     int num_joint_rows = 0;
@@ -1324,6 +1359,7 @@ static void solve_velocity_constraints(ro_world *w) {
     for (int s = 0; s < num_substeps; ++s) {
         float solved_dt = (float)s * dt_s;
         /* S2 increments + gyroscopic — worker.rs:235-284 */
+        RO_PARALLEL_FOR
         for (int i = 0; i < nd; ++i) {
             w->vels[i].linear = vadd(w->vels[i].linear, w->incr[i].linear);
             w->vels[i].angular = vadd(w->vels[i].angular, w->incr[i].angular);
@@ -1334,10 +1370,13 @@ static void solve_velocity_constraints(ro_world *w) {
             }
         }
         /* S3 joint rows rebuilt from the current poses — worker.rs:287-357 */
+        RO_PARALLEL_FOR
         for (int a = 0; a < w->nactive_joints; ++a) joint_builder_update(w, &w->joints[w->active_joints[a]], dt_s, s);
         /* S4 fused update + warmstart per colour — worker.rs:438-538 (non-fused when coefficient == 0) */
         for (int st = 0; st < w->nstages; ++st) {
             int c = w->stage_color[st];
+            int serial = c == RO_COLOR_OVERFLOW; /* the overflow colour is not body-disjoint */
+            RO_PRAGMA_IF_PAR(serial)
             for (int i = w->bucket_begin[c]; i < w->bucket_begin[c + 1]; ++i) {
                 constraint_update(w, &w->cons[i], dt_s, solved_dt);
                 if (prm->warmstart_coefficient != 0.0f) constraint_warmstart(w, &w->cons[i]);
@@ -1348,10 +1387,13 @@ static void solve_velocity_constraints(ro_world *w) {
             joints_solve_pass(w, 0, prm->warmstart_joints && it == 0);
             for (int st = 0; st < w->nstages; ++st) {
                 int c = w->stage_color[st];
+                int serial = c == RO_COLOR_OVERFLOW;
+                RO_PRAGMA_IF_PAR(serial)
                 for (int i = w->bucket_begin[c]; i < w->bucket_begin[c + 1]; ++i) constraint_solve(w, &w->cons[i], solve_friction_in_bias);
             }
         }
         /* S6 integrate — worker.rs:568-631, rigid_body_components.rs:884-898 */
+        RO_PARALLEL_FOR
         for (int i = 0; i < nd; ++i) {
             SolverVel *v = &w->vels[i];
             if (max_lin != FLT_MAX) { float n = vlen(v->linear); if (n > max_lin) v->linear = vmul(v->linear, max_lin / n); }
@@ -1366,6 +1408,8 @@ static void solve_velocity_constraints(ro_world *w) {
             joints_solve_pass(w, 1, 0);
             for (int st = 0; st < w->nstages; ++st) {
                 int c = w->stage_color[st];
+                int serial = c == RO_COLOR_OVERFLOW;
+                RO_PRAGMA_IF_PAR(serial)
                 for (int i = w->bucket_begin[c]; i < w->bucket_begin[c + 1]; ++i) {
                     constraint_refresh_rhs_wo_bias(w, &w->cons[i], dt_s, solved_dt + dt_s);
                     constraint_solve(w, &w->cons[i], 1);
@@ -1380,6 +1424,7 @@ static void solve_velocity_constraints(ro_world *w) {
             for (int i = w->bucket_begin[c]; i < w->bucket_begin[c + 1]; ++i) constraint_apply_restitution(w, &w->cons[i]);
         }
     /* S9 impulse writeback — worker.rs:742-802 */
+    RO_PARALLEL_FOR
     for (int i = 0; i < M; ++i) constraint_writeback(w, &w->cons[i]);
     /* JointConstraintsSet::writeback_impulses — joint_velocity_constraint.rs:346-353 */
     for (int a = 0; a < w->nactive_joints; ++a) {

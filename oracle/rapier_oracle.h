@@ -96,6 +96,9 @@ int32_t ro_add_joint(ro_world *w, const ro_joint_desc *d);
 int32_t ro_num_joints(const ro_world *w);
 void ro_read_joints(const ro_world *w, int32_t *color, float *impulses3);
 void ro_step(ro_world *w, int32_t nsteps);
+/* OpenMP threads used by the data-parallel loops (default 1; results do not depend on it). */
+void ro_set_threads(int32_t n);
+int32_t ro_get_threads(void);
 int32_t ro_num_bodies(const ro_world *w);
 /* pos7 = (tx,ty,tz, qx,qy,qz,qw) per body, vel6 = (lin, ang) per body, arena order. */
 void ro_read_bodies(const ro_world *w, float *pos7, float *vel6);

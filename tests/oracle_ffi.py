@@ -49,10 +49,16 @@ def lib():
         L.ro_combine_coefficient.argtypes = [C.c_float, C.c_float, C.c_int32, C.c_int32]
         L.ro_combine_coefficient.restype = C.c_float
         L.ro_set_body_vel.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        L.ro_set_threads.argtypes = [C.c_int32]
         L.ro_num_joints.argtypes = [C.c_void_p]
         L.ro_read_joints.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
+
+
+def set_threads(n: int):
+    """OpenMP threads of the oracle's data-parallel loops (results do not depend on it)."""
+    lib().ro_set_threads(int(n))
 
 
 class OracleWorld:

@@ -178,6 +178,26 @@ def test_joint_grid_scene_matches_reference_formula():
     assert len(sc.bodies) == 10000 and len(sc.joints) == 19800 and sc.num_dynamic == 9900
 
 
+def test_oracle_threads_do_not_change_results():
+    """The OpenMP loops only cover body-disjoint work, so any thread count gives the same bits."""
+    import oracle_ffi
+    res = []
+    for threads in (1, 4):
+        oracle_ffi.set_threads(threads)
+        try:
+            out = []
+            for sc in (S.tumble(40, seed=3), S.joint_grid(12), S.many_pyramids(rows=2, cols=2)):
+                w = OracleWorld(sc)
+                w.step(60)
+                out.append(w.read())
+            res.append(out)
+        finally:
+            oracle_ffi.set_threads(1)
+    for (p1, v1), (p4, v4) in zip(*res):
+        np.testing.assert_array_equal(p1, p4)
+        np.testing.assert_array_equal(v1, v4)
+
+
 def test_golden_fixtures_match_oracle():
     """tests/golden/*.npz were produced by tests/golden/make_golden.py from this oracle; they pin it
     (and, in the GPU tests, the HIP path) against silent drift."""
