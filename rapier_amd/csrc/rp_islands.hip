@@ -5,11 +5,12 @@
 // pays a barrier per colour per sweep.  Constraints of different connected components never share a
 // body, so sweeping each component through the same colour sequence independently is bit-identical
 // to the global sweep (SURVEY Appendix B.3 applied across components).  On MI355X that turns ~100
-// dependent kernel launches per step into ONE launch: each workgroup owns one island, stages its
-// bodies (13 floats each) and all of its constraint planes (800 B per manifold) in the CU's 160 KiB
-// LDS, and runs generate -> 4 x (increment, update+warmstart, biased solve, integrate, relaxed
-// solve) -> restitution -> write-back with workgroup barriers between colours.  HBM is touched once
-// per step per manifold (pair data in, impulses out) instead of 12 sweeps.
+// dependent kernel launches per step into ONE launch: each workgroup owns one island, keeps every
+// manifold's constraint in the VGPRs of a lane pair and the solver bodies (64 B each) in LDS, and runs
+// generate -> 4 x (increment + body-centric warm start, biased sweep, integrate, pose stage, relaxed
+// sweep) -> restitution -> write-back with workgroup barriers between colour stages.  HBM is touched
+// once per step per manifold (pair data in, impulses out) instead of 12 sweeps.  The kernel is bound
+// by the latency of its ~60 dependent stages, not by bandwidth.
 // Islands that do not fit (more than RP_ISL_NB_MAX bodies or RP_ISL_NC_MAX manifolds) and bodies
 // without contacts stay on the global per-colour path (rp_solver.hip).
 //
@@ -343,41 +344,7 @@ RP_DEV void isl_pose_stage(const DevWorld &w, IslSide &h, const IslLds &L, int m
     h.tb0 = dot(pf - pf2, h.t0) * inv_dt; h.tb1 = dot(pf - pf2, h.t1) * inv_dt;
 }
 
-// Velocity-dependent half of update + warmstart (:426-522, :633-678), colour-ordered.
-template <bool F4> RP_DEV void isl_warmstart_t(const DevWorld &w, IslSide &h, const IslLds &L) {
-    const int hn = F4 ? 4 : h.n;
-    float wc = w.prm.p.warmstart_coefficient;
-    bool ws = wc != 0.0f;
-    Vel v = isl_vel(L, h.id);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (k >= hn) break;
-        SidePoint &p = h.P[k];
-        p.rhs = p.rhsB; p.cfm = p.cfmB;
-        p.acc += p.lam;
-        p.lam *= wc;
-        if (ws) {
-            float lam = dppf<DPP_FROM_EVEN>(p.lam);
-            v.lin = v.lin + h.sdim * lam;
-            v.ang = v.ang + p.pc * lam;
-        }
-    }
-    h.t_rhs0 = h.rhs_wo0 + h.tb0; h.t_rhs1 = h.rhs_wo1 + h.tb1;
-    h.t_acc0 += h.t_imp0; h.t_acc1 += h.t_imp1;
-    h.t_imp0 *= wc; h.t_imp1 *= wc;
-    h.tw_acc += h.tw_imp;
-    h.tw_imp *= wc;
-    if (ws) {
-        float i0 = dppf<DPP_FROM_EVEN>(h.t_imp0), i1 = dppf<DPP_FROM_EVEN>(h.t_imp1);
-        float s0 = h.odd ? -i0 : i0, s1 = h.odd ? -i1 : i1;
-        v.lin = v.lin + cmul(h.t0 * s0 + h.t1 * s1, h.im);
-        v.ang = v.ang + (h.itd0 * i0 + h.itd1 * i1);
-        if (hn > 1) v.ang = v.ang + h.stw * dppf<DPP_FROM_EVEN>(h.tw_imp);
-        isl_set_vel(L, h.id, v);
-    }
-}
-
-// Body-centric warm start.  The impulses a warm start applies do not depend on velocities, only the
+// Body-centric warm start (update + warmstart, :426-522 and :633-678).  The impulses a warm start applies do not depend on velocities, only the
 // order in which they are ADDED to a body does (colour order, and inside a manifold: the points, the
 // tangent part, the twist part).  Every lane therefore writes its terms to LDS in one parallel stage
 // (isl_ws_terms) and the thread that owns a body adds them in exactly that order (isl_ws_accumulate):
@@ -502,9 +469,6 @@ template <bool F4> RP_DEV void isl_solve_t(IslSide &h, const IslLds &L, bool rel
 
 // Wave-uniform dispatch: when every active manifold of this wave has 4 points (face/face contacts, the
 // common case) the per-point exec-mask branches disappear.
-RP_DEV void isl_warmstart(const DevWorld &w, IslSide &h, const IslLds &L) {
-    if (__all(h.n == 4)) isl_warmstart_t<true>(w, h, L); else isl_warmstart_t<false>(w, h, L);
-}
 RP_DEV void isl_solve(IslSide &h, const IslLds &L, bool relax, bool friction) {
     if (__all(h.n == 4)) isl_solve_t<true>(h, L, relax, friction); else isl_solve_t<false>(h, L, relax, friction);
 }
@@ -711,9 +675,9 @@ __global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int ha
             }
             __syncthreads();
             ISL_STAMP(3); // increment + body-centric warm start
-#ifdef RP_ISL_EXTRA_EMPTY
+#ifdef RP_ISL_EXTRA_EMPTY // overhead measurement only: one extra sweep of empty stages (velocity read/write + barrier)
             for (int q = 0; q < nls; ++q) { if (myq == q) { Vel v = isl_vel(L, h.id); isl_set_vel(L, h.id, v); } __syncthreads(); }
-            ISL_STAMP(9); // extra sweep of empty stages (overhead measurement only)
+            ISL_STAMP(9);
 #endif
             for (int it = 0; it < prm.num_internal_pgs_iterations; ++it)
                 for (int q = 0; q < nls; ++q) { if (myq == q) isl_solve(h, L, false, fib); __syncthreads(); }
