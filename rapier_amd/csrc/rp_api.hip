@@ -292,6 +292,13 @@ extern "C" int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider
         if (parents && parents[i] != RP_INVALID_HANDLE) {
             parent = (int)(parents[i] & 0xffffffffull);
             if (parent < 0 || parent >= (int)w->bodies.size()) { w->err = "rp_colliders_insert: invalid parent handle"; return RP_ERR_INVALID; }
+            // mass properties scope (recompute_mass below): ONE collider per dynamic body, attached at the body origin
+            const float *t = descs[i].translation, *r = descs[i].rotation;
+            bool at_origin = t[0] == 0.0f && t[1] == 0.0f && t[2] == 0.0f && r[0] == 0.0f && r[1] == 0.0f && r[2] == 0.0f;
+            if (w->bodies[parent].d.body_type == RP_BODY_DYNAMIC && (w->bodies[parent].ncolliders > 0 || !at_origin)) {
+                w->err = "rp_colliders_insert: compound bodies (several colliders per body, or a collider offset from its body) are not implemented on the device path";
+                return RP_ERR_INVALID;
+            }
         }
         w->colliders.push_back(descs[i]);
         w->collider_parent.push_back(parent);

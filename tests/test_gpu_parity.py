@@ -208,6 +208,29 @@ def test_integration_parameter_variants_bit_exact(override):
         _compare(sc, [1, 20, 90])
 
 
+def test_out_of_scope_inputs_are_refused():
+    """Angular joint locks, contact-disabled joints and compound bodies are refused loudly, not mis-simulated."""
+    from rapier_amd import RapierHipError
+    w = PhysicsWorld()
+    b = w.insert_body(S.body_desc(translation=(0.0, 1.0, 0.0)))
+    w.insert_collider(S.collider_desc(), b)
+    with pytest.raises(RapierHipError):
+        w.insert_collider(S.collider_desc(), b)  # second collider on the same body
+    b2 = w.insert_body(S.body_desc(translation=(2.0, 1.0, 0.0)))
+    with pytest.raises(RapierHipError):
+        w.insert_collider(S.collider_desc(translation=(0.1, 0.0, 0.0)), b2)  # offset collider
+    sc = S.Scene(name="tmp")
+    sc.add_body(); sc.add_body()
+    j = sc.joint_array() if sc.joints else None
+    sc.add_joint(0, 1, (0, 0, 0), (0, 0, 0), locked_axes=0x3F)
+    with pytest.raises(RapierHipError):
+        w.insert_impulse_joints(sc.joint_array())  # fixed joint: angular locks
+    sc.joints.clear()
+    sc.add_joint(0, 1, (0, 0, 0), (0, 0, 0), contacts_enabled=0)
+    with pytest.raises(RapierHipError):
+        w.insert_impulse_joints(sc.joint_array())
+
+
 def test_golden_fixtures_on_gpu():
     import glob
     import os

@@ -71,3 +71,8 @@ def test_partition_scene_keeps_islands_and_replicates_fixed():
         for li, gi in enumerate(gids):
             assert np.array_equal(sub.bodies[li]["translation"], sc.bodies[gi]["translation"])
     assert total_dyn == sc.num_dynamic
+
+
+def test_header_documents_scope_limits():
+    hdr = open(os.path.join(ROOT, "include", "rapier_hip.h")).read()
+    assert "compound bodies" in hdr and "locked linear axes" in hdr
