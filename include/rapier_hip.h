@@ -148,6 +148,14 @@ int32_t rp_impulse_joints_insert(rp_world *w, int32_t n, const rp_joint_desc *de
  * solver colour of n joints (NULL handles = all, insertion order). */
 int32_t rp_impulse_joints_read(rp_world *w, int32_t n, const uint64_t *handles, int32_t *color_out, float *impulse3_out);
 
+/* RigidBodySet::remove (with its attached colliders and joints, rigid_body_set.rs:121-170),
+ * ColliderSet::remove (collider_set.rs), ImpulseJointSet::remove (impulse_joint_set.rs).  Arena slots are
+ * kept as tombstones: indices stay stable, removed handles become invalid, the pairs of a removed
+ * collider are deleted by the next broad-phase pass while every other pair keeps its warm-start data. */
+int32_t rp_bodies_remove(rp_world *w, int32_t n, const uint64_t *handles);
+int32_t rp_colliders_remove(rp_world *w, int32_t n, const uint64_t *handles);
+int32_t rp_impulse_joints_remove(rp_world *w, int32_t n, const uint64_t *handles);
+
 /* PhysicsWorld::step() × nsteps with hooks = &(), events = &() (physics_world.rs:120-157). */
 int32_t rp_step(rp_world *w, uint32_t nsteps);
 /* Block until every enqueued step has finished (hipStreamSynchronize). */
@@ -164,6 +172,10 @@ int32_t rp_num_bodies(const rp_world *w);
  * colour, num solver contacts), world normal, total normal impulse per solver contact.
  * Returns the number of active manifolds (may exceed cap; only cap are written). */
 int32_t rp_contacts_read(rp_world *w, int32_t cap, int32_t *c1_c2_color_count, float *normal3, float *impulse4);
+
+/* Quarantine (pipeline/physics_pipeline/quarantine.rs:68-131): handles of the bodies whose state went
+ * non-finite (rolled back to the last valid pose and stopped).  Returns the count (may exceed cap). */
+int32_t rp_quarantine_read(rp_world *w, int32_t cap, uint64_t *handles_out);
 
 /* PhysicsPipeline::counters; `enable_timers` != 0 turns on hipEvent stage timing (off = no events). */
 int32_t rp_counters_enable(rp_world *w, int32_t enable_timers);

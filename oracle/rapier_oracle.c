@@ -123,6 +123,7 @@ typedef struct {
     float impulses[6];                    /* per-dof impulses written back last step */
     pose sb_frame1, sb_frame2;            /* frames in solver-body (CoM) space */
     int first_row;
+    int removed;                          /* ImpulseJointSet::remove */
 } Joint;
 /* JointConstraint<Real, 1> — joint_velocity_constraint.rs:71-95 */
 typedef struct {
@@ -281,7 +282,7 @@ static void recompute_mass_properties(ro_world *w, Body *b) {
     float mass = 0.0f; v3 pi = V3(0, 0, 0);
     const Collider *c0 = NULL;
     for (int i = 0; i < w->ncolliders; ++i)
-        if (w->colliders[i].parent == (int)(b - w->bodies)) { c0 = &w->colliders[i]; break; }
+        if (w->colliders[i].parent == (int)(b - w->bodies) && !(w->colliders[i].memberships == 0 && w->colliders[i].filter == 0)) { c0 = &w->colliders[i]; break; }
     if (c0) shape_mass_props(c0, c0->density, &mass, &pi);
     if (b->additional_mass != 0.0f) {
         if (mass > 0.0f) {
@@ -1083,6 +1084,7 @@ static void joints_select_active(ro_world *w) {
     w->nactive_joints = 0;
     for (int i = 0; i < w->njoints; ++i) {
         Joint *j = &w->joints[i];
+        if (j->removed) continue;
         const Body *rb1 = &w->bodies[j->body1], *rb2 = &w->bodies[j->body2];
         int d1 = rb1->body_type == RO_BODY_DYNAMIC, d2 = rb2->body_type == RO_BODY_DYNAMIC;
         if (!d1 && !d2) continue;
@@ -1521,6 +1523,38 @@ int32_t ro_add_joint(ro_world *w, const ro_joint_desc *d) {
     j->locked_axes = d->locked_axes; j->contacts_enabled = d->contacts_enabled;
     j->solver_color = 255; /* default_solver_color: uncoloured */
     return w->njoints++;
+}
+/* ImpulseJointSet::remove (impulse_joint_set.rs:574-...): the joint stops being selected. */
+int32_t ro_remove_joint(ro_world *w, int32_t joint) {
+    if (joint < 0 || joint >= w->njoints || w->joints[joint].removed) return -1;
+    w->joints[joint].removed = 1;
+    memset(w->joints[joint].impulses, 0, sizeof(w->joints[joint].impulses));
+    return 0;
+}
+/* ColliderSet::remove (collider_set.rs) + NarrowPhase::handle_user_changes removing its pairs
+ * (pair_management.rs:24-203): the collider keeps its arena slot but can no longer form pairs, and the
+ * next broad-phase pass deletes its pairs (DeletePair frees their colours) before any contact is computed. */
+int32_t ro_remove_collider(ro_world *w, int32_t collider) {
+    if (collider < 0 || collider >= w->ncolliders) return -1;
+    Collider *c = &w->colliders[collider];
+    if (c->memberships == 0 && c->filter == 0) return -1;
+    c->memberships = 0; c->filter = 0;
+    w->bp_dirty = 1;
+    if (c->parent >= 0) recompute_mass_properties(w, &w->bodies[c->parent]);
+    return 0;
+}
+/* RigidBodySet::remove with remove_attached_colliders = true (rigid_body_set.rs:121-170): attached
+ * colliders and joints go too; the arena slot is kept as an inert (fixed, collider-less) body. */
+int32_t ro_remove_body(ro_world *w, int32_t body) {
+    if (body < 0 || body >= w->nbodies) return -1;
+    Body *b = &w->bodies[body];
+    for (int i = 0; i < w->ncolliders; ++i) if (w->colliders[i].parent == body) ro_remove_collider(w, i);
+    for (int i = 0; i < w->njoints; ++i) if (!w->joints[i].removed && (w->joints[i].body1 == body || w->joints[i].body2 == body)) ro_remove_joint(w, i);
+    b->body_type = RO_BODY_FIXED;
+    b->linvel = V3(0, 0, 0); b->angvel = V3(0, 0, 0);
+    b->solver_id = RO_NO_BODY;
+    update_world_mass_properties(b);
+    return 0;
 }
 int32_t ro_num_joints(const ro_world *w) { return w->njoints; }
 /* per joint: (colour, impulse x, y, z) */

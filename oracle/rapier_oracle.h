@@ -93,6 +93,9 @@ void ro_world_free(ro_world *w);
 int32_t ro_add_body(ro_world *w, const ro_body_desc *d);
 int32_t ro_add_collider(ro_world *w, const ro_collider_desc *d, int32_t parent_body);
 int32_t ro_add_joint(ro_world *w, const ro_joint_desc *d);
+int32_t ro_remove_body(ro_world *w, int32_t body);
+int32_t ro_remove_collider(ro_world *w, int32_t collider);
+int32_t ro_remove_joint(ro_world *w, int32_t joint);
 int32_t ro_num_joints(const ro_world *w);
 void ro_read_joints(const ro_world *w, int32_t *color, float *impulses3);
 void ro_step(ro_world *w, int32_t nsteps);

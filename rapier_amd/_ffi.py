@@ -18,7 +18,8 @@ RP_INVALID_HANDLE = 0xFFFFFFFFFFFFFFFF
 SYMBOLS = [
     "rp_world_create", "rp_world_destroy", "rp_last_error", "rp_default_params", "rp_params_get",
     "rp_params_set", "rp_bodies_insert", "rp_colliders_insert", "rp_impulse_joints_insert",
-    "rp_impulse_joints_read", "rp_step",
+    "rp_impulse_joints_read", "rp_bodies_remove", "rp_colliders_remove", "rp_impulse_joints_remove",
+    "rp_quarantine_read", "rp_step",
     "rp_sync", "rp_bodies_read", "rp_bodies_write", "rp_num_bodies", "rp_contacts_read",
     "rp_counters_enable", "rp_counters_read", "rp_solver_loop_time_ms",
 ]
@@ -62,6 +63,10 @@ def lib():
     L.rp_colliders_insert.argtypes = [vp, i32, vp, vp, vp]
     L.rp_impulse_joints_insert.argtypes = [vp, i32, vp, vp]
     L.rp_impulse_joints_read.argtypes = [vp, i32, vp, vp, vp]
+    L.rp_bodies_remove.argtypes = [vp, i32, vp]
+    L.rp_colliders_remove.argtypes = [vp, i32, vp]
+    L.rp_impulse_joints_remove.argtypes = [vp, i32, vp]
+    L.rp_quarantine_read.argtypes = [vp, i32, vp]
     L.rp_step.argtypes = [vp, u32]
     L.rp_sync.argtypes = [vp]
     L.rp_bodies_read.argtypes = [vp, i32, vp, vp, vp]

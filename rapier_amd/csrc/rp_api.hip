@@ -39,7 +39,7 @@ void rp_launch_island_solve(const DevWorld &w, hipStream_t st, int grid, int has
 void rp_launch_global_single(const DevWorld &w, hipStream_t st, int has_restitution, int fast);
 void rp_launch_fast_front(const DevWorld &w, hipStream_t st, int no_global_kernel);
 
-struct HostBody { rp_body_desc d; float inv_mass; float inv_pi[3]; float lcom[3]; int ncolliders; };
+struct HostBody { rp_body_desc d; float inv_mass; float inv_pi[3]; float lcom[3]; int ncolliders; bool removed; };
 
 struct rp_world {
     int device = 0;
@@ -49,6 +49,7 @@ struct rp_world {
     std::vector<HostBody> bodies;
     std::vector<rp_collider_desc> colliders;
     std::vector<int> collider_parent;
+    std::vector<char> collider_removed, joint_removed;
     std::vector<rp_joint_desc> joints;
     std::vector<int> active_joint_ids; // device joint index -> index into `joints`
     bool finalized = false;
@@ -258,7 +259,7 @@ static void recompute_mass(rp_world *w, int body) {
     HostBody &b = w->bodies[body];
     float mass = 0.0f, pi[3] = {0, 0, 0};
     const rp_collider_desc *c0 = nullptr;
-    for (size_t i = 0; i < w->colliders.size(); ++i) if (w->collider_parent[i] == body) { c0 = &w->colliders[i]; break; }
+    for (size_t i = 0; i < w->colliders.size(); ++i) if (w->collider_parent[i] == body && !w->collider_removed[i]) { c0 = &w->colliders[i]; break; }
     if (c0) shape_mass_props(*c0, c0->density, mass, pi);
     float add = b.d.additional_mass;
     if (add != 0.0f) {
@@ -273,11 +274,41 @@ static void recompute_mass(rp_world *w, int body) {
     for (int q = 0; q < 3; ++q) { b.inv_pi[q] = h_inv(pi[q]); b.lcom[q] = 0.0f; }
 }
 
+// Bring the host mirrors up to date with the device (poses, velocities) before the device world is
+// rebuilt from them: inserting into a world that has been stepped continues from the current state
+// (contact warm-start data is not carried over a rebuild).
+static int download_state(rp_world *w) {
+    if (!w->finalized) return RP_OK;
+    { int r = settle(w); if (r != RP_OK) return r; }
+    int nb = w->dw.n_bodies;
+    std::vector<float4> pos(nb), rot(nb), lv(nb), av(nb);
+    HIPCHK(w, hipMemcpy(pos.data(), w->dw.b_pos, nb * sizeof(float4), hipMemcpyDeviceToHost));
+    HIPCHK(w, hipMemcpy(rot.data(), w->dw.b_rot, nb * sizeof(float4), hipMemcpyDeviceToHost));
+    HIPCHK(w, hipMemcpy(lv.data(), w->dw.b_linvel, nb * sizeof(float4), hipMemcpyDeviceToHost));
+    HIPCHK(w, hipMemcpy(av.data(), w->dw.b_angvel, nb * sizeof(float4), hipMemcpyDeviceToHost));
+    for (int i = 0; i < nb; ++i) {
+        rp_body_desc &d = w->bodies[i].d;
+        d.translation[0] = pos[i].x; d.translation[1] = pos[i].y; d.translation[2] = pos[i].z;
+        d.rotation[0] = rot[i].x; d.rotation[1] = rot[i].y; d.rotation[2] = rot[i].z; d.rotation[3] = rot[i].w;
+        d.linvel[0] = lv[i].x; d.linvel[1] = lv[i].y; d.linvel[2] = lv[i].z;
+        d.angvel[0] = av[i].x; d.angvel[1] = av[i].y; d.angvel[2] = av[i].z;
+    }
+    return RP_OK;
+}
+static int rebuild_begin(rp_world *w) { // called before the host mirrors grow
+    if (!w->finalized) return RP_OK;
+    HIPCHK(w, hipSetDevice(w->device));
+    int r = download_state(w);
+    if (r != RP_OK) return r;
+    free_device(w);
+    return RP_OK;
+}
+
 extern "C" int32_t rp_bodies_insert(rp_world *w, int32_t n, const rp_body_desc *descs, uint64_t *handles_out) {
     if (!w || n < 0 || (n > 0 && !descs)) return RP_ERR_INVALID;
-    if (w->finalized) { hipSetDevice(w->device); hipStreamSynchronize(w->stream); free_device(w); }
+    if (n > 0) { int r = rebuild_begin(w); if (r != RP_OK) return r; }
     for (int i = 0; i < n; ++i) {
-        HostBody b; b.d = descs[i]; b.ncolliders = 0; b.inv_mass = 0; b.inv_pi[0] = b.inv_pi[1] = b.inv_pi[2] = 0; b.lcom[0] = b.lcom[1] = b.lcom[2] = 0;
+        HostBody b; b.d = descs[i]; b.ncolliders = 0; b.removed = false; b.inv_mass = 0; b.inv_pi[0] = b.inv_pi[1] = b.inv_pi[2] = 0; b.lcom[0] = b.lcom[1] = b.lcom[2] = 0;
         w->bodies.push_back(b);
         recompute_mass(w, (int)w->bodies.size() - 1);
         if (handles_out) handles_out[i] = (uint64_t)(w->bodies.size() - 1);
@@ -286,7 +317,7 @@ extern "C" int32_t rp_bodies_insert(rp_world *w, int32_t n, const rp_body_desc *
 }
 extern "C" int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider_desc *descs, const uint64_t *parents, uint64_t *handles_out) {
     if (!w || n < 0 || (n > 0 && !descs)) return RP_ERR_INVALID;
-    if (w->finalized) { hipSetDevice(w->device); hipStreamSynchronize(w->stream); free_device(w); }
+    if (n > 0) { int r = rebuild_begin(w); if (r != RP_OK) return r; }
     for (int i = 0; i < n; ++i) {
         int parent = -1;
         if (parents && parents[i] != RP_INVALID_HANDLE) {
@@ -302,6 +333,7 @@ extern "C" int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider
         }
         w->colliders.push_back(descs[i]);
         w->collider_parent.push_back(parent);
+        w->collider_removed.push_back(0);
         if (parent >= 0) { w->bodies[parent].ncolliders++; recompute_mass(w, parent); }
         if (descs[i].restitution > 0.0f) w->has_restitution = true;
         if (handles_out) handles_out[i] = (uint64_t)(w->colliders.size() - 1);
@@ -316,9 +348,10 @@ extern "C" int32_t rp_impulse_joints_insert(rp_world *w, int32_t n, const rp_joi
         if ((j.locked_axes & ~7u) != 0) { w->err = "rp_impulse_joints_insert: only locked linear axes (spherical joints) are implemented on the device path"; return RP_ERR_INVALID; }
         if (!j.contacts_enabled) { w->err = "rp_impulse_joints_insert: contacts_enabled = false is not implemented on the device path"; return RP_ERR_INVALID; }
     }
-    if (w->finalized && n > 0) { hipSetDevice(w->device); hipStreamSynchronize(w->stream); free_device(w); }
+    if (n > 0) { int r = rebuild_begin(w); if (r != RP_OK) return r; }
     for (int i = 0; i < n; ++i) {
         w->joints.push_back(descs[i]);
+        w->joint_removed.push_back(0);
         if (handles_out) handles_out[i] = (uint64_t)(w->joints.size() - 1);
     }
     return RP_OK;
@@ -380,7 +413,7 @@ static int finalize(rp_world *w) {
     DA(d.flags, FL_COUNT); DA(d.dbg, 64);
     DA(d.b_pos, nb); DA(d.b_rot, nb); DA(d.b_linvel, nb); DA(d.b_angvel, nb); DA(d.b_lcom_invm, nb); DA(d.b_invpi, nb);
     DA(d.b_pframe, nb); DA(d.b_wcom, nb); DA(d.b_eim, nb); DA(d.b_eii0, nb); DA(d.b_eii1, nb); DA(d.b_damp, nb);
-    DA(d.b_uforce, nb); DA(d.b_utorque, nb); DA(d.b_flags, nb);
+    DA(d.b_uforce, nb); DA(d.b_utorque, nb); DA(d.b_flags, nb); DA(d.b_quar, nb);
     DA(d.s_lin, nb); DA(d.s_ang, nb); DA(d.s_rot, nb); DA(d.s_trans, nb); DA(d.s_incl, nb); DA(d.s_inca, nb);
     DA(d.b_cmask, 4 * (size_t)nb); DAF(d.b_min, nb, 0xff);
     DA(d.c_parent, nc); DA(d.c_shape, nc); DA(d.c_lpos, nc); DA(d.c_lrot, nc); DA(d.c_pos, nc); DA(d.c_rot, nc); DA(d.c_he, nc);
@@ -413,6 +446,7 @@ static int finalize(rp_world *w) {
     std::vector<float4> jf1t, jf1r, jf2t, jf2r;
     w->active_joint_ids.clear();
     for (size_t ji = 0; ji < w->joints.size(); ++ji) {
+        if (w->joint_removed[ji]) continue;
         const rp_joint_desc &j = w->joints[ji];
         const HostBody &rb1 = w->bodies[j.body1], &rb2 = w->bodies[j.body2];
         bool d1 = rb1.d.body_type == RP_BODY_DYNAMIC, d2 = rb2.d.body_type == RP_BODY_DYNAMIC;
@@ -466,7 +500,7 @@ static int finalize(rp_world *w) {
         ipi[i] = mk4(b.inv_pi[0], b.inv_pi[1], b.inv_pi[2], 0);
         pfr[i] = mk4(0, 0, 0, 1);
         damp[i] = mk4(bd.linear_damping, bd.angular_damping, bd.gravity_scale, 0);
-        int fl = (bd.body_type & RP_BF_TYPE_MASK);
+        int fl = ((b.removed ? RP_BODY_FIXED : bd.body_type) & RP_BF_TYPE_MASK);
         if (bd.gyroscopic) fl |= RP_BF_GYRO;
         if (bd.allow_fast_rotation) fl |= RP_BF_FASTROT;
         fl |= ((int)(bd.dominance & 0xff)) << RP_BF_DOM_SHIFT;
@@ -487,7 +521,7 @@ static int finalize(rp_world *w) {
         che[i] = mk4(c.half_extents[0], c.half_extents[1], c.half_extents[2], 0);
         cmat[i] = mk4(c.friction, c.restitution, c.density, 0);
         crul[i].x = c.friction_rule; crul[i].y = c.restitution_rule;
-        cgrp[i].x = c.collision_memberships; cgrp[i].y = c.collision_filter;
+        cgrp[i].x = w->collider_removed[i] ? 0u : c.collision_memberships; cgrp[i].y = w->collider_removed[i] ? 0u : c.collision_filter;
         // an "inverted" AABB: the first k_collider_update always rewrites it
         fmn[i] = mk4(1.0f, 1.0f, 1.0f, 0); fmx[i] = mk4(-1.0f, -1.0f, -1.0f, 0);
     }
@@ -738,7 +772,7 @@ extern "C" int32_t rp_bodies_write(rp_world *w, int32_t n, const uint64_t *handl
     { int r = settle(w); if (r != RP_OK) return r; }
     for (int i = 0; i < n; ++i) {
         int b = (int)(handles[i] & 0xffffffffull);
-        if (b < 0 || b >= w->dw.n_bodies) { w->err = "rp_bodies_write: invalid handle"; return RP_ERR_INVALID; }
+        if (b < 0 || b >= w->dw.n_bodies || w->bodies[b].removed) { w->err = "rp_bodies_write: invalid handle"; return RP_ERR_INVALID; }
         if (vel6) {
             float4 l = mk4(vel6[6 * i], vel6[6 * i + 1], vel6[6 * i + 2], 0), a = mk4(vel6[6 * i + 3], vel6[6 * i + 4], vel6[6 * i + 5], 0);
             HIPCHK(w, hipMemcpy(w->dw.b_linvel + b, &l, sizeof(l), hipMemcpyHostToDevice));
@@ -755,6 +789,125 @@ extern "C" int32_t rp_bodies_write(rp_world *w, int32_t n, const uint64_t *handl
         rp_launch_collider_update(w->dw, w->stream);
     }
     return RP_OK;
+}
+
+// ---- removal (RigidBodySet::remove / ColliderSet::remove / ImpulseJointSet::remove) ---------------
+// Arena slots are kept as tombstones (indices stay stable, handles of removed items become invalid).
+// A removed collider loses its interaction groups, so the next broad-phase pass deletes its pairs
+// (DeletePair frees their colours; the other pairs keep their warm-start data, like
+// NarrowPhase::handle_user_changes, pair_management.rs:24-203); a removed body becomes an inert fixed
+// body without colliders or joints; a removed joint loses its rows.
+template <typename T> static int poke(rp_world *w, T *dst, const T &v) {
+    HIPCHK(w, hipMemcpy(dst, &v, sizeof(T), hipMemcpyHostToDevice));
+    return RP_OK;
+}
+static int set_flag(rp_world *w, int slot, int v) { return poke(w, w->dw.flags + slot, v); }
+static int after_topology_edit(rp_world *w) {
+    if (!w->finalized) return RP_OK;
+    int r;
+    if ((r = set_flag(w, FL_BP_DIRTY, 1)) != RP_OK || (r = set_flag(w, FL_LAYOUT_DIRTY, 1)) != RP_OK || (r = set_flag(w, FL_JOINT_DIRTY, 1)) != RP_OK) return r;
+    w->pinned_flags[FL_LAYOUT_DIRTY] = 1; // keeps the next steps on the full graph until the device reports a clean state
+    w->full_until = w->steps_requested + 3;
+    rp_launch_init_bodies(w->dw, w->stream);
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    return RP_OK;
+}
+static int remove_joint_at(rp_world *w, int j) {
+    if (w->joint_removed[j]) return RP_OK;
+    w->joint_removed[j] = 1;
+    if (!w->finalized) return RP_OK;
+    for (int k = 0; k < (int)w->active_joint_ids.size(); ++k) {
+        if (w->active_joint_ids[k] != j) continue;
+        const rp_joint_desc &jd = w->joints[j];
+        int r;
+        if ((r = poke(w, w->dw.j_b1 + k, -1)) != RP_OK || (r = poke(w, w->dw.j_b2 + k, -1)) != RP_OK || (r = poke(w, w->dw.j_locked + k, 0)) != RP_OK ||
+            (r = poke(w, w->dw.j_imp + k, mk4(0, 0, 0, 0))) != RP_OK) return r;
+        for (int b : {jd.body1, jd.body2}) {
+            if (w->bodies[b].d.body_type != RP_BODY_DYNAMIC || w->bodies[b].removed) continue;
+            int cnt = 0;
+            for (size_t q = 0; q < w->joints.size(); ++q) if (!w->joint_removed[q] && (w->joints[q].body1 == b || w->joints[q].body2 == b)) cnt++;
+            if ((r = poke(w, w->dw.b_njoints + b, cnt)) != RP_OK) return r;
+        }
+    }
+    return RP_OK;
+}
+static int remove_collider_at(rp_world *w, int c) {
+    if (w->collider_removed[c]) return RP_OK;
+    w->collider_removed[c] = 1;
+    int parent = w->collider_parent[c];
+    if (parent >= 0) { w->bodies[parent].ncolliders--; recompute_mass(w, parent); }
+    if (!w->finalized) return RP_OK;
+    uint2 none; none.x = 0; none.y = 0;
+    int r = poke(w, w->dw.c_groups + c, none);
+    if (r != RP_OK) return r;
+    if (parent >= 0) {
+        const HostBody &b = w->bodies[parent];
+        if ((r = poke(w, w->dw.b_lcom_invm + parent, mk4(b.lcom[0], b.lcom[1], b.lcom[2], b.inv_mass))) != RP_OK) return r;
+        if ((r = poke(w, w->dw.b_invpi + parent, mk4(b.inv_pi[0], b.inv_pi[1], b.inv_pi[2], 0))) != RP_OK) return r;
+    }
+    return RP_OK;
+}
+static int handle_index(uint64_t h) { return (h >> 32) == 0 ? (int)(h & 0xffffffffull) : -1; }
+
+extern "C" int32_t rp_impulse_joints_remove(rp_world *w, int32_t n, const uint64_t *handles) {
+    if (!w || n < 0 || (n > 0 && !handles)) return RP_ERR_INVALID;
+    HIPCHK(w, hipSetDevice(w->device));
+    if (w->finalized) { int r = settle(w); if (r != RP_OK) return r; }
+    for (int i = 0; i < n; ++i) {
+        int j = handle_index(handles[i]);
+        if (j < 0 || j >= (int)w->joints.size() || w->joint_removed[j]) { w->err = "rp_impulse_joints_remove: invalid handle"; return RP_ERR_INVALID; }
+        int r = remove_joint_at(w, j);
+        if (r != RP_OK) return r;
+    }
+    return after_topology_edit(w);
+}
+extern "C" int32_t rp_colliders_remove(rp_world *w, int32_t n, const uint64_t *handles) {
+    if (!w || n < 0 || (n > 0 && !handles)) return RP_ERR_INVALID;
+    HIPCHK(w, hipSetDevice(w->device));
+    if (w->finalized) { int r = settle(w); if (r != RP_OK) return r; }
+    for (int i = 0; i < n; ++i) {
+        int c = handle_index(handles[i]);
+        if (c < 0 || c >= (int)w->colliders.size() || w->collider_removed[c]) { w->err = "rp_colliders_remove: invalid handle"; return RP_ERR_INVALID; }
+        int r = remove_collider_at(w, c);
+        if (r != RP_OK) return r;
+    }
+    return after_topology_edit(w);
+}
+extern "C" int32_t rp_bodies_remove(rp_world *w, int32_t n, const uint64_t *handles) {
+    if (!w || n < 0 || (n > 0 && !handles)) return RP_ERR_INVALID;
+    HIPCHK(w, hipSetDevice(w->device));
+    if (w->finalized) { int r = settle(w); if (r != RP_OK) return r; }
+    for (int i = 0; i < n; ++i) {
+        int b = handle_index(handles[i]);
+        if (b < 0 || b >= (int)w->bodies.size() || w->bodies[b].removed) { w->err = "rp_bodies_remove: invalid handle"; return RP_ERR_INVALID; }
+        int r;
+        for (size_t c = 0; c < w->colliders.size(); ++c) if (w->collider_parent[c] == b && (r = remove_collider_at(w, (int)c)) != RP_OK) return r;
+        for (size_t j = 0; j < w->joints.size(); ++j) if ((w->joints[j].body1 == b || w->joints[j].body2 == b) && (r = remove_joint_at(w, (int)j)) != RP_OK) return r;
+        HostBody &hb = w->bodies[b];
+        hb.removed = true; hb.d.body_type = RP_BODY_FIXED;
+        for (int k = 0; k < 3; ++k) { hb.d.linvel[k] = 0.0f; hb.d.angvel[k] = 0.0f; }
+        if (w->finalized) {
+            int fl = RP_BODY_FIXED | (hb.d.gyroscopic ? RP_BF_GYRO : 0) | (hb.d.allow_fast_rotation ? RP_BF_FASTROT : 0) | (((int)(hb.d.dominance & 0xff)) << RP_BF_DOM_SHIFT);
+            if ((r = poke(w, w->dw.b_flags + b, fl)) != RP_OK || (r = poke(w, w->dw.b_linvel + b, mk4(0, 0, 0, 0))) != RP_OK ||
+                (r = poke(w, w->dw.b_angvel + b, mk4(0, 0, 0, 0))) != RP_OK || (r = poke(w, w->dw.b_njoints + b, 0)) != RP_OK) return r;
+        }
+    }
+    return after_topology_edit(w);
+}
+
+// Quarantine (quarantine.rs:68-131): bodies whose state went non-finite.  The device rolls such a body
+// back to its last valid pose, stops it and keeps it in the simulation (the reference disables it);
+// this returns the handles that were ever flagged.  Returns the count (may exceed cap).
+extern "C" int32_t rp_quarantine_read(rp_world *w, int32_t cap, uint64_t *handles_out) {
+    if (!w) return RP_ERR_INVALID;
+    HIPCHK(w, hipSetDevice(w->device));
+    if (!w->finalized) return 0;
+    { int r = settle(w); if (r != RP_OK) return r; }
+    int nb = w->dw.n_bodies, m = 0;
+    std::vector<int> q(std::max(nb, 1));
+    if (nb > 0) HIPCHK(w, hipMemcpy(q.data(), w->dw.b_quar, nb * sizeof(int), hipMemcpyDeviceToHost));
+    for (int i = 0; i < nb; ++i) if (q[i]) { if (handles_out && m < cap) handles_out[m] = (uint64_t)i; m++; }
+    return m;
 }
 
 extern "C" int32_t rp_contacts_read(rp_world *w, int32_t cap, int32_t *meta, float *normal3, float *impulse4) {

@@ -427,6 +427,7 @@ RP_DEV void body_writeback(const DevWorld &w, int i, V3 slin, V3 sang, Q4 rot, V
                   isfinite(lin.x) && isfinite(lin.y) && isfinite(lin.z) && isfinite(ang.x) && isfinite(ang.y) && isfinite(ang.z);
     if (!finite) { // roll back to the last valid pose, stop the body
         atomicAdd(&w.flags[FL_QUARANTINE], 1);
+        w.b_quar[i] = 1;
         w.b_linvel[i] = make_float4(0, 0, 0, 0); w.b_angvel[i] = make_float4(0, 0, 0, 0);
         return;
     }

@@ -22,9 +22,10 @@ __global__ void k_joint_color_check(DevWorld w) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= w.n_joints) return;
     int color = w.j_color[j];
+    int b1 = w.j_b1[j], b2 = w.j_b2[j];
+    if (b1 < 0 && b2 < 0) return; // removed joint: no rows, no colour
     bool bad = color >= 128;
     if (!bad) {
-        int b1 = w.j_b1[j], b2 = w.j_b2[j];
         unsigned bit = 1u << (color & 31);
         if (b1 >= 0 && (w.b_cmask[4 * b1 + (color >> 5)] & bit)) bad = true;
         if (b2 >= 0 && (w.b_cmask[4 * b2 + (color >> 5)] & bit)) bad = true;
@@ -58,7 +59,8 @@ __global__ void __launch_bounds__(1024) k_joint_color(DevWorld w) {
             if (b1 >= 0) for (int q = 0; q < 4; ++q) m[q] |= jld_u32(&w.bj_cmask[4 * b1 + q]) | jld_u32(&w.b_cmask[4 * b1 + q]);
             if (b2 >= 0) for (int q = 0; q < 4; ++q) m[q] |= jld_u32(&w.bj_cmask[4 * b2 + q]) | jld_u32(&w.b_cmask[4 * b2 + q]);
             int stored = w.j_color[j], color = 128;
-            if (stored < 128 && !((m[stored >> 5] >> (stored & 31)) & 1u)) color = stored;          // keep_or_pick
+            if (b1 < 0 && b2 < 0) color = 128;                                                          // removed joint (no rows)
+            else if (stored < 128 && !((m[stored >> 5] >> (stored & 31)) & 1u)) color = stored;      // keep_or_pick
             else if (b1 >= 0 && b2 >= 0) { for (int c = 0; c < RP_DYNAMIC_COLOR_COUNT; ++c) if (!((m[c >> 5] >> (c & 31)) & 1u)) { color = c; break; } }
             else { for (int c = 127; c >= 0; --c) if (!((m[c >> 5] >> (c & 31)) & 1u)) { color = c; break; } }
             if (color < 128) {

@@ -147,6 +147,7 @@ struct DevWorld {
     float4 *b_damp;        // linear damping, angular damping, gravity scale, -
     float4 *b_uforce, *b_utorque;
     int *b_flags;
+    int *b_quar;           // sticky: non-finite state was detected (and rolled back) for this body
     // ---- solver bodies (index = arena index; non-dynamic = world-attached) ----
     float4 *s_lin, *s_ang, *s_rot, *s_trans, *s_incl, *s_inca;
     unsigned int *b_cmask; // 4 x u32 colour mask per body (body_solver_color_masks)

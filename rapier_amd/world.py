@@ -72,6 +72,9 @@ class RigidBodySet:
     def insert(self, body: np.ndarray) -> RigidBodyHandle:
         return self._w.insert_body(body)
 
+    def remove(self, handle):
+        self._w.remove_body(handle)
+
     def __len__(self):
         return self._n
 
@@ -91,6 +94,9 @@ class ColliderSet:
     def insert(self, collider: np.ndarray) -> ColliderHandle:
         return self._w.insert_collider(collider, None)
 
+    def remove(self, handle):
+        self._w.remove_collider(handle)
+
     def __len__(self):
         return self._n
 
@@ -102,6 +108,9 @@ class ImpulseJointSet:
 
     def insert(self, body1, body2, joint: np.ndarray):
         return self._w.insert_impulse_joint(body1, body2, joint)
+
+    def remove(self, handle):
+        self._w.remove_impulse_joint(handle)
 
     def __len__(self):
         return self._n
@@ -194,6 +203,30 @@ class PhysicsWorld:
         j = np.array([joint], dtype=S.JOINT_DTYPE)
         j["body1"], j["body2"] = int(body1) & 0xFFFFFFFF, int(body2) & 0xFFFFFFFF
         return int(self.insert_impulse_joints(j)[0])
+
+    # ---- removal (RigidBodySet::remove, ColliderSet::remove, ImpulseJointSet::remove) ----
+    def _remove(self, fn, handles, what):
+        h = np.ascontiguousarray(np.atleast_1d(np.asarray(handles, dtype=np.uint64)))
+        _check(self._ptr, fn(self._ptr, len(h), h.ctypes.data), what)
+
+    def remove_body(self, handles):
+        """RigidBodySet::remove(handle, ..., remove_attached_colliders = true)."""
+        self._remove(self._lib.rp_bodies_remove, handles, "rp_bodies_remove")
+
+    def remove_collider(self, handles):
+        self._remove(self._lib.rp_colliders_remove, handles, "rp_colliders_remove")
+
+    def remove_impulse_joint(self, handles):
+        self._remove(self._lib.rp_impulse_joints_remove, handles, "rp_impulse_joints_remove")
+
+    def quarantined(self) -> np.ndarray:
+        n = self._lib.rp_quarantine_read(self._ptr, 0, None)
+        if n < 0:
+            _check(self._ptr, n, "rp_quarantine_read")
+        out = np.zeros(n, np.uint64)
+        if n:
+            self._lib.rp_quarantine_read(self._ptr, n, out.ctypes.data)
+        return out
 
     # ---- stepping ----
     def step(self, nsteps: int = 1):

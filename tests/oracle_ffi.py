@@ -50,6 +50,9 @@ def lib():
         L.ro_combine_coefficient.restype = C.c_float
         L.ro_set_body_vel.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.ro_set_threads.argtypes = [C.c_int32]
+        L.ro_remove_body.argtypes = [C.c_void_p, C.c_int32]
+        L.ro_remove_collider.argtypes = [C.c_void_p, C.c_int32]
+        L.ro_remove_joint.argtypes = [C.c_void_p, C.c_int32]
         L.ro_num_joints.argtypes = [C.c_void_p]
         L.ro_read_joints.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _LIB = L
@@ -107,6 +110,15 @@ class OracleWorld:
         imp = np.zeros((m, 4), np.float32)
         L.ro_dump_manifolds(self._w, m, meta.ctypes.data, nrm.ctypes.data, imp.ctypes.data)
         return meta, nrm, imp
+
+    def remove_body(self, body):
+        assert lib().ro_remove_body(self._w, int(body)) == 0
+
+    def remove_collider(self, collider):
+        assert lib().ro_remove_collider(self._w, int(collider)) == 0
+
+    def remove_joint(self, joint):
+        assert lib().ro_remove_joint(self._w, int(joint)) == 0
 
     def read_joints(self):
         n = lib().ro_num_joints(self._w)

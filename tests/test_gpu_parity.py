@@ -208,6 +208,66 @@ def test_integration_parameter_variants_bit_exact(override):
         _compare(sc, [1, 20, 90])
 
 
+def _same_state(g, o, msg):
+    gp, gv = g.read_bodies()
+    op, ov = o.read()
+    np.testing.assert_array_equal(gp, op, err_msg=msg)
+    np.testing.assert_array_equal(gv, ov, err_msg=msg)
+
+
+def test_remove_body_mid_simulation_bit_exact():
+    """RigidBodySet::remove in a settled stack: its pairs are deleted by the next broad-phase pass, every
+    other pair keeps its warm-start data, the boxes above fall."""
+    sc = S.box_stack(5)
+    g, o = PhysicsWorld.from_scene(sc), OracleWorld(sc)
+    g.step(80); o.step(80)
+    victim = 3  # body 0 = slab, 1..5 = boxes
+    g.remove_body(victim); o.remove_body(victim)
+    for n in (1, 30, 120):
+        g.step(n); o.step(n)
+        _same_state(g, o, f"after removing body {victim}, +{n}")
+    with pytest.raises(Exception):
+        g.remove_body(victim)  # stale handle
+    pos, _ = g.read_bodies()
+    assert pos[4, 1] < 3.0  # the box that sat on the victim came down
+
+
+def test_remove_joint_and_collider_bit_exact():
+    sc = S.joint_chain(8)
+    g, o = PhysicsWorld.from_scene(sc), OracleWorld(sc)
+    g.step(40); o.step(40)
+    g.remove_impulse_joint(3); o.remove_joint(3)  # the chain splits
+    g.step(60); o.step(60)
+    _same_state(g, o, "after removing joint 3")
+    gc, gi = g.read_joints()
+    oc, oi = o.read_joints()
+    keep = np.arange(len(gc)) != 3
+    np.testing.assert_array_equal(gi[keep], oi[keep])
+    sc2 = S.pyramid10()
+    g2, o2 = PhysicsWorld.from_scene(sc2), OracleWorld(sc2)
+    g2.step(50); o2.step(50)
+    g2.remove_collider(30); o2.remove_collider(30)  # a cube in the pyramid loses its shape: neighbours fall through it
+    for n in (1, 60):
+        g2.step(n); o2.step(n)
+        _same_state(g2, o2, f"after removing collider 30, +{n}")
+
+
+def test_insert_after_stepping_continues_from_current_state():
+    """Inserting into a stepped world rebuilds the device world from the CURRENT body states."""
+    sc = S.box_stack(2)
+    g = PhysicsWorld.from_scene(sc)
+    g.step(60)
+    before, _ = g.read_bodies()
+    b = g.insert_body(S.body_desc(translation=(5.0, 3.0, 0.0)))
+    g.insert_collider(S.collider_desc(), b)
+    after, _ = g.read_bodies()
+    np.testing.assert_array_equal(after[:3], before[:3])
+    g.step(120)
+    pos, _ = g.read_bodies()
+    assert np.isfinite(pos).all() and abs(pos[int(b) & 0xFFFFFFFF, 1] - 0.5) < 0.05  # the new box landed on the slab
+    assert g.quarantined().size == 0
+
+
 def test_out_of_scope_inputs_are_refused():
     """Angular joint locks, contact-disabled joints and compound bodies are refused loudly, not mis-simulated."""
     from rapier_amd import RapierHipError
