@@ -614,13 +614,12 @@ static int launch_step(rp_world *w, int fast) {
         if (!w->ge_col[fast]) {
             int r;
             if ((r = capture(w, &w->g_col[fast], &w->ge_col[fast], enqueue_collision)) != RP_OK) return r;
-            if ((r = capture(w, &w->g_loop[fast], &w->ge_loop[fast], enqueue_island_solver)) != RP_OK) return r;
             if (!(fast && w->plan_no_global) && (r = capture(w, &w->g_fin[fast], &w->ge_fin[fast], enqueue_global_and_finish)) != RP_OK) return r;
         }
         HIPCHK(w, hipEventRecord(w->ev[0], w->stream));
         HIPCHK(w, hipGraphLaunch(w->ge_col[fast], w->stream));
         HIPCHK(w, hipEventRecord(w->ev[1], w->stream));
-        HIPCHK(w, hipGraphLaunch(w->ge_loop[fast], w->stream));
+        enqueue_island_solver(w); // launched directly so the two events bracket the kernel alone (no graph-launch gap)
         HIPCHK(w, hipEventRecord(w->ev[2], w->stream));
         if (w->ge_fin[fast]) HIPCHK(w, hipGraphLaunch(w->ge_fin[fast], w->stream));
         HIPCHK(w, hipEventRecord(w->ev[3], w->stream));

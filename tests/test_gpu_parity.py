@@ -62,6 +62,21 @@ def test_many_pyramids_bit_exact():
     assert c["num_manifolds"] == 28420 and c["num_dynamic_bodies"] == 10780
 
 
+def test_many_pyramids_1000_steps_bit_exact():
+    """The north-star accuracy check (positions after 1000 steps vs the CPU path; BASELINE.json allows
+    1e-4 relative): full-size b3d_many_pyramids, checkpoints at 100 and 1000 steps, equality of every bit.
+    The oracle runs its body-disjoint loops on the host cores (results do not depend on the thread count)."""
+    import os
+    import oracle_ffi
+    oracle_ffi.set_threads(max(1, min(os.cpu_count() or 1, 16)))
+    try:
+        g, o = _compare(S.many_pyramids(), [100, 1000])
+    finally:
+        oracle_ffi.set_threads(1)
+    c = g.counters()
+    assert c["fast_steps"] > 800 and c["replayed_steps"] == 0, c
+
+
 def test_large_pyramid_bit_exact():
     """BASELINE config C2 (single island) at base 60 for oracle speed (1,830 cubes)."""
     _compare(S.large_pyramid(60), [1, 10, 30])
