@@ -53,6 +53,7 @@ struct rp_world {
     std::vector<rp_joint_desc> joints;
     std::vector<int> active_joint_ids; // device joint index -> index into `joints`
     bool finalized = false;
+    int cap_bodies = 0, cap_colliders = 0; // device array capacities (rows beyond n_bodies / n_colliders are spare)
     bool hints_valid = false;
     std::vector<void *> allocs;
     DevWorld dw;
@@ -89,6 +90,10 @@ struct rp_world {
     } while (0)
 
 static int settle(rp_world *w);
+static int upload_body_row(rp_world *w, int i);
+static int upload_body_row_mass(rp_world *w, int i);
+static int upload_collider_row(rp_world *w, int i);
+static int after_topology_edit(rp_world *w);
 
 extern "C" void rp_default_params(rp_integration_params *p) {
     // IntegrationParameters::default() — integration_parameters.rs:379-408
@@ -306,18 +311,38 @@ static int rebuild_begin(rp_world *w) { // called before the host mirrors grow
 
 extern "C" int32_t rp_bodies_insert(rp_world *w, int32_t n, const rp_body_desc *descs, uint64_t *handles_out) {
     if (!w || n < 0 || (n > 0 && !descs)) return RP_ERR_INVALID;
-    if (n > 0) { int r = rebuild_begin(w); if (r != RP_OK) return r; }
+    // RigidBodySet::insert into a live world: rows are appended in place while the device arrays have
+    // room (every pair keeps its warm-start data); otherwise the device world is rebuilt from the
+    // current body states
+    const bool in_place = w->finalized && (int)w->bodies.size() + n <= w->cap_bodies;
+    if (n > 0 && w->finalized) {
+        HIPCHK(w, hipSetDevice(w->device));
+        int r = in_place ? settle(w) : rebuild_begin(w);
+        if (r != RP_OK) return r;
+    }
     for (int i = 0; i < n; ++i) {
         HostBody b; b.d = descs[i]; b.ncolliders = 0; b.removed = false; b.inv_mass = 0; b.inv_pi[0] = b.inv_pi[1] = b.inv_pi[2] = 0; b.lcom[0] = b.lcom[1] = b.lcom[2] = 0;
         w->bodies.push_back(b);
         recompute_mass(w, (int)w->bodies.size() - 1);
         if (handles_out) handles_out[i] = (uint64_t)(w->bodies.size() - 1);
+        if (in_place) { int r = upload_body_row(w, (int)w->bodies.size() - 1); if (r != RP_OK) return r; }
+    }
+    if (in_place && n > 0) {
+        w->dw.n_bodies = (int)w->bodies.size();
+        HIPCHK(w, hipStreamSynchronize(w->stream));
+        destroy_graphs(w); // kernel arguments (DevWorld by value) hold the body count
+        return after_topology_edit(w);
     }
     return RP_OK;
 }
 extern "C" int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider_desc *descs, const uint64_t *parents, uint64_t *handles_out) {
     if (!w || n < 0 || (n > 0 && !descs)) return RP_ERR_INVALID;
-    if (n > 0) { int r = rebuild_begin(w); if (r != RP_OK) return r; }
+    const bool in_place = w->finalized && (int)w->colliders.size() + n <= w->cap_colliders; // see rp_bodies_insert
+    if (n > 0 && w->finalized) {
+        HIPCHK(w, hipSetDevice(w->device));
+        int r = in_place ? settle(w) : rebuild_begin(w);
+        if (r != RP_OK) return r;
+    }
     for (int i = 0; i < n; ++i) {
         int parent = -1;
         if (parents && parents[i] != RP_INVALID_HANDLE) {
@@ -337,6 +362,17 @@ extern "C" int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider
         if (parent >= 0) { w->bodies[parent].ncolliders++; recompute_mass(w, parent); }
         if (descs[i].restitution > 0.0f) w->has_restitution = true;
         if (handles_out) handles_out[i] = (uint64_t)(w->colliders.size() - 1);
+        if (in_place) {
+            int r = upload_collider_row(w, (int)w->colliders.size() - 1);
+            if (r == RP_OK && parent >= 0) r = upload_body_row_mass(w, parent);
+            if (r != RP_OK) return r;
+        }
+    }
+    if (in_place && n > 0) {
+        w->dw.n_colliders = (int)w->colliders.size();
+        HIPCHK(w, hipStreamSynchronize(w->stream));
+        destroy_graphs(w);
+        return after_topology_edit(w);
     }
     return RP_OK;
 }
@@ -381,6 +417,67 @@ static int upload(rp_world *w, T *dst, const std::vector<T> &src) {
 static int next_pow2(long long x) { long long p = 1; while (p < x) p <<= 1; return (int)p; }
 static float4 mk4(float x, float y, float z, float w_) { float4 r; r.x = x; r.y = y; r.z = z; r.w = w_; return r; }
 
+// One body / collider row of the SoA device world from the host mirrors (finalize and incremental inserts).
+struct BodyRow { float4 pos, rot, lv, av, lci, ipi, pfr, damp; int fl; };
+static BodyRow pack_body(const HostBody &b) {
+    const rp_body_desc &bd = b.d;
+    BodyRow o;
+    float qn = std::sqrt(bd.rotation[0] * bd.rotation[0] + bd.rotation[1] * bd.rotation[1] + bd.rotation[2] * bd.rotation[2] + bd.rotation[3] * bd.rotation[3]);
+    float qi = qn > 0.0f ? 1.0f / qn : 1.0f;
+    o.pos = mk4(bd.translation[0], bd.translation[1], bd.translation[2], 0);
+    o.rot = mk4(bd.rotation[0] * qi, bd.rotation[1] * qi, bd.rotation[2] * qi, qn > 0.0f ? bd.rotation[3] * qi : 1.0f);
+    o.lv = mk4(bd.linvel[0], bd.linvel[1], bd.linvel[2], 0); o.av = mk4(bd.angvel[0], bd.angvel[1], bd.angvel[2], 0);
+    o.lci = mk4(b.lcom[0], b.lcom[1], b.lcom[2], b.inv_mass);
+    o.ipi = mk4(b.inv_pi[0], b.inv_pi[1], b.inv_pi[2], 0);
+    o.pfr = mk4(0, 0, 0, 1);
+    o.damp = mk4(bd.linear_damping, bd.angular_damping, bd.gravity_scale, 0);
+    int fl = ((b.removed ? RP_BODY_FIXED : bd.body_type) & RP_BF_TYPE_MASK);
+    if (bd.gyroscopic) fl |= RP_BF_GYRO;
+    if (bd.allow_fast_rotation) fl |= RP_BF_FASTROT;
+    fl |= ((int)(bd.dominance & 0xff)) << RP_BF_DOM_SHIFT;
+    o.fl = fl;
+    return o;
+}
+#define PUT(arr, idx, val) HIPCHK(w, hipMemcpyAsync((arr) + (idx), &(val), sizeof(val), hipMemcpyHostToDevice, w->stream))
+static int upload_body_row(rp_world *w, int i) {
+    // hipMemcpyAsync from pageable stack memory is staged by the runtime before it returns
+    const DevWorld &d = w->dw;
+    BodyRow r = pack_body(w->bodies[i]);
+    PUT(d.b_pos, i, r.pos); PUT(d.b_rot, i, r.rot); PUT(d.b_linvel, i, r.lv); PUT(d.b_angvel, i, r.av); PUT(d.b_lcom_invm, i, r.lci);
+    PUT(d.b_invpi, i, r.ipi); PUT(d.b_pframe, i, r.pfr); PUT(d.b_damp, i, r.damp); PUT(d.b_flags, i, r.fl);
+    return RP_OK;
+}
+struct ColliderRow { int parent, shape; float4 lp, lr, he, mat, fmn, fmx; int2 rules; uint2 groups; };
+static ColliderRow pack_collider(const rp_world *w, int i) {
+    const rp_collider_desc &c = w->colliders[i];
+    ColliderRow o;
+    o.parent = w->collider_parent[i]; o.shape = c.shape;
+    float qn = std::sqrt(c.rotation[0] * c.rotation[0] + c.rotation[1] * c.rotation[1] + c.rotation[2] * c.rotation[2] + c.rotation[3] * c.rotation[3]);
+    float qi = qn > 0.0f ? 1.0f / qn : 1.0f;
+    o.lp = mk4(c.translation[0], c.translation[1], c.translation[2], 0);
+    o.lr = mk4(c.rotation[0] * qi, c.rotation[1] * qi, c.rotation[2] * qi, qn > 0.0f ? c.rotation[3] * qi : 1.0f);
+    o.he = mk4(c.half_extents[0], c.half_extents[1], c.half_extents[2], 0);
+    o.mat = mk4(c.friction, c.restitution, c.density, 0);
+    o.rules.x = c.friction_rule; o.rules.y = c.restitution_rule;
+    o.groups.x = w->collider_removed[i] ? 0u : c.collision_memberships; o.groups.y = w->collider_removed[i] ? 0u : c.collision_filter;
+    // an "inverted" AABB: the first k_collider_update always rewrites it (and flags the broad phase)
+    o.fmn = mk4(1.0f, 1.0f, 1.0f, 0); o.fmx = mk4(-1.0f, -1.0f, -1.0f, 0);
+    return o;
+}
+static int upload_body_row_mass(rp_world *w, int i) { // mass properties only (a collider was attached / removed)
+    const DevWorld &d = w->dw;
+    BodyRow r = pack_body(w->bodies[i]);
+    PUT(d.b_lcom_invm, i, r.lci); PUT(d.b_invpi, i, r.ipi);
+    return RP_OK;
+}
+static int upload_collider_row(rp_world *w, int i) {
+    const DevWorld &d = w->dw;
+    ColliderRow r = pack_collider(w, i);
+    PUT(d.c_parent, i, r.parent); PUT(d.c_shape, i, r.shape); PUT(d.c_lpos, i, r.lp); PUT(d.c_lrot, i, r.lr); PUT(d.c_he, i, r.he); PUT(d.c_mat, i, r.mat);
+    PUT(d.c_rules, i, r.rules); PUT(d.c_groups, i, r.groups); PUT(d.c_fatmin, i, r.fmn); PUT(d.c_fatmax, i, r.fmx);
+    return RP_OK;
+}
+
 // Upload the host mirrors into the SoA device world (the "upload = resume" path of SURVEY §5).
 static int finalize(rp_world *w) {
     HIPCHK(w, hipSetDevice(w->device));
@@ -388,14 +485,17 @@ static int finalize(rp_world *w) {
     memset(&d, 0, sizeof(d));
     int nb = (int)w->bodies.size(), nc = (int)w->colliders.size();
     d.n_bodies = nb; d.n_colliders = nc;
+    // capacities leave room for bodies / colliders inserted later without rebuilding the device world
+    const int capb = nb + nb / 4 + 256, capc = nc + nc / 4 + 256;
+    w->cap_bodies = capb; w->cap_colliders = capc;
     const char *env_pool = getenv("RP_PAIRS_PER_COLLIDER");
     int ppc = env_pool ? atoi(env_pool) : 8;
-    d.pool_cap = ppc * nc + 1024;
+    d.pool_cap = ppc * capc + 1024;
     d.hash_cap = next_pow2(4LL * d.pool_cap);
-    d.grid_cap = std::min(next_pow2(8LL * std::max(nc, 1)), 1 << 20);
+    d.grid_cap = std::min(next_pow2(8LL * std::max(capc, 1)), 1 << 20);
     d.grid_cap = std::max(d.grid_cap, 1024);
-    d.entries_cap = 27 * nc + 64;
-    d.large_cap = std::min(std::max(nc, 1), 4096);
+    d.entries_cap = 27 * capc + 64;
+    d.large_cap = std::min(std::max(capc, 1), 4096);
     d.cons_cap = d.pool_cap;
     // grid cell size: 90th percentile of the collider bounding extents (+ fat margins)
     float pred = w->params.normalized_prediction_distance * w->params.length_unit;
@@ -411,13 +511,13 @@ static int finalize(rp_world *w) {
     fill_sim_params(w, d.prm, cell);
 
     DA(d.flags, FL_COUNT); DA(d.dbg, 64);
-    DA(d.b_pos, nb); DA(d.b_rot, nb); DA(d.b_linvel, nb); DA(d.b_angvel, nb); DA(d.b_lcom_invm, nb); DA(d.b_invpi, nb);
-    DA(d.b_pframe, nb); DA(d.b_wcom, nb); DA(d.b_eim, nb); DA(d.b_eii0, nb); DA(d.b_eii1, nb); DA(d.b_damp, nb);
-    DA(d.b_uforce, nb); DA(d.b_utorque, nb); DA(d.b_flags, nb); DA(d.b_quar, nb);
-    DA(d.s_lin, nb); DA(d.s_ang, nb); DA(d.s_rot, nb); DA(d.s_trans, nb); DA(d.s_incl, nb); DA(d.s_inca, nb);
-    DA(d.b_cmask, 4 * (size_t)nb); DAF(d.b_min, nb, 0xff);
-    DA(d.c_parent, nc); DA(d.c_shape, nc); DA(d.c_lpos, nc); DA(d.c_lrot, nc); DA(d.c_pos, nc); DA(d.c_rot, nc); DA(d.c_he, nc);
-    DA(d.c_mat, nc); DA(d.c_rules, nc); DA(d.c_groups, nc); DA(d.c_fatmin, nc); DA(d.c_fatmax, nc);
+    DA(d.b_pos, capb); DA(d.b_rot, capb); DA(d.b_linvel, capb); DA(d.b_angvel, capb); DA(d.b_lcom_invm, capb); DA(d.b_invpi, capb);
+    DA(d.b_pframe, capb); DA(d.b_wcom, capb); DA(d.b_eim, capb); DA(d.b_eii0, capb); DA(d.b_eii1, capb); DA(d.b_damp, capb);
+    DA(d.b_uforce, capb); DA(d.b_utorque, capb); DA(d.b_flags, capb); DA(d.b_quar, capb);
+    DA(d.s_lin, capb); DA(d.s_ang, capb); DA(d.s_rot, capb); DA(d.s_trans, capb); DA(d.s_incl, capb); DA(d.s_inca, capb);
+    DA(d.b_cmask, 4 * (size_t)capb); DAF(d.b_min, capb, 0xff);
+    DA(d.c_parent, capc); DA(d.c_shape, capc); DA(d.c_lpos, capc); DA(d.c_lrot, capc); DA(d.c_pos, capc); DA(d.c_rot, capc); DA(d.c_he, capc);
+    DA(d.c_mat, capc); DA(d.c_rules, capc); DA(d.c_groups, capc); DA(d.c_fatmin, capc); DA(d.c_fatmax, capc);
     DA(d.cell_count, d.grid_cap); DA(d.cell_start, d.grid_cap + 1); DA(d.cell_fill, d.grid_cap); DA(d.scan_block, 1024);
     DA(d.e_key, d.entries_cap); DA(d.e_col, d.entries_cap); DA(d.large_list, d.large_cap);
     DAF(d.h_key[0], d.hash_cap, 0xff); DAF(d.h_key[1], d.hash_cap, 0xff); DA(d.h_slot[0], d.hash_cap); DA(d.h_slot[1], d.hash_cap);
@@ -434,11 +534,11 @@ static int finalize(rp_world *w) {
     DA(d.stage_color, RP_NUM_COLORS + 1); DA(d.stage_begin, RP_NUM_COLORS + 1); DA(d.stage_count, RP_NUM_COLORS + 1);
     DA(d.cons_pair, d.cons_cap); DAF(d.p_conspos, P, 0xff);
     DA(d.color_count_glob, RP_NUM_COLORS + 1); DA(d.color_rank, RP_NUM_COLORS + 1);
-    DA(d.b_label, nb); DAF(d.b_island, nb, 0xff); DAF(d.b_local, nb, 0xff); DA(d.r_nb, nb); DA(d.r_nc, nb); DAF(d.r_island, nb, 0xff);
+    DA(d.b_label, capb); DAF(d.b_island, capb, 0xff); DAF(d.b_local, capb, 0xff); DA(d.r_nb, capb); DA(d.r_nc, capb); DAF(d.r_island, capb, 0xff);
     DAF(d.p_island, P, 0xff);
-    DA(d.isl_body_begin, nb); DA(d.isl_nb, nb); DA(d.isl_cons_begin, nb); DA(d.isl_nc, nb); DA(d.isl_fill_b, nb); DA(d.isl_fill_c, nb);
-    DA(d.isl_bodies, nb); DA(d.isl_cons, P); DA(d.isl_cstage, P); DA(d.isl_sorted, nb); DA(d.isl_nstages, nb);
-    DA(d.isl_cg1, P); DA(d.isl_cg2, P); DA(d.isl_cl1, P); DA(d.isl_cl2, P); DA(d.isl_inc_pos, 2 * P); DA(d.isl_inc_begin, nb); DA(d.isl_inc_cnt, nb);
+    DA(d.isl_body_begin, capb); DA(d.isl_nb, capb); DA(d.isl_cons_begin, capb); DA(d.isl_nc, capb); DA(d.isl_fill_b, capb); DA(d.isl_fill_c, capb);
+    DA(d.isl_bodies, capb); DA(d.isl_cons, P); DA(d.isl_cstage, P); DA(d.isl_sorted, capb); DA(d.isl_nstages, capb);
+    DA(d.isl_cg1, P); DA(d.isl_cg2, P); DA(d.isl_cl1, P); DA(d.isl_cl2, P); DA(d.isl_inc_pos, 2 * P); DA(d.isl_inc_begin, capb); DA(d.isl_inc_cnt, capb);
     // impulse joints: only joints with a dynamic side are active (select_active_interactions,
     // impulse_joint_set.rs:504-572), kept in edge order; frames go to solver-body space once
     // (GenericJoint::transform_to_solver_body_space, generic_joint.rs:624-636)
@@ -478,55 +578,34 @@ static int finalize(rp_world *w) {
     DA(d.j_b1, nj); DA(d.j_b2, nj); DA(d.j_f1t, nj); DA(d.j_f1r, nj); DA(d.j_f2t, nj); DA(d.j_f2r, nj);
     DA(d.j_locked, nj); DA(d.j_color, nj); DA(d.j_tmp, nj); DA(d.j_order, nj); DA(d.j_imp, nj);
     DA(d.j_stage_begin, RP_NUM_COLORS + 1); DA(d.j_stage_count, RP_NUM_COLORS + 1);
-    DA(d.bj_cmask, 4 * (size_t)nb); DAF(d.bj_min, nb, 0xff); DA(d.b_njoints, nb);
+    DA(d.bj_cmask, 4 * (size_t)capb); DAF(d.bj_min, capb, 0xff); DA(d.b_njoints, capb);
     DA(d.JR, (size_t)17 * std::max(nj, 1));
     UP(d.j_b1, jb1); UP(d.j_b2, jb2); UP(d.j_f1t, jf1t); UP(d.j_f1r, jf1r); UP(d.j_f2t, jf2t); UP(d.j_f2r, jf2r);
     UP(d.j_locked, jlocked); UP(d.j_color, jcolor); UP(d.b_njoints, bnj);
     DA(d.C, (size_t)CP_COUNT * d.cons_cap);
     DA(d.k_b1, d.cons_cap); DA(d.k_b2, d.cons_cap); DA(d.k_n, d.cons_cap); DA(d.k_cid, d.cons_cap);
 
-    // host SoA staging
-    std::vector<float4> pos(nb), rot(nb), lv(nb), av(nb), lci(nb), ipi(nb), pfr(nb), damp(nb);
-    std::vector<int> bfl(nb);
-    for (int i = 0; i < nb; ++i) {
-        const HostBody &b = w->bodies[i];
-        const rp_body_desc &bd = b.d;
-        float qn = std::sqrt(bd.rotation[0] * bd.rotation[0] + bd.rotation[1] * bd.rotation[1] + bd.rotation[2] * bd.rotation[2] + bd.rotation[3] * bd.rotation[3]);
-        float qi = qn > 0.0f ? 1.0f / qn : 1.0f;
-        pos[i] = mk4(bd.translation[0], bd.translation[1], bd.translation[2], 0);
-        rot[i] = mk4(bd.rotation[0] * qi, bd.rotation[1] * qi, bd.rotation[2] * qi, qn > 0.0f ? bd.rotation[3] * qi : 1.0f);
-        lv[i] = mk4(bd.linvel[0], bd.linvel[1], bd.linvel[2], 0); av[i] = mk4(bd.angvel[0], bd.angvel[1], bd.angvel[2], 0);
-        lci[i] = mk4(b.lcom[0], b.lcom[1], b.lcom[2], b.inv_mass);
-        ipi[i] = mk4(b.inv_pi[0], b.inv_pi[1], b.inv_pi[2], 0);
-        pfr[i] = mk4(0, 0, 0, 1);
-        damp[i] = mk4(bd.linear_damping, bd.angular_damping, bd.gravity_scale, 0);
-        int fl = ((b.removed ? RP_BODY_FIXED : bd.body_type) & RP_BF_TYPE_MASK);
-        if (bd.gyroscopic) fl |= RP_BF_GYRO;
-        if (bd.allow_fast_rotation) fl |= RP_BF_FASTROT;
-        fl |= ((int)(bd.dominance & 0xff)) << RP_BF_DOM_SHIFT;
-        bfl[i] = fl;
+    // host SoA staging (one batched copy per attribute)
+    {
+        std::vector<float4> pos(nb), rot(nb), lv(nb), av(nb), lci(nb), ipi(nb), pfr(nb), damp(nb);
+        std::vector<int> bfl(nb);
+        for (int i = 0; i < nb; ++i) {
+            BodyRow r = pack_body(w->bodies[i]);
+            pos[i] = r.pos; rot[i] = r.rot; lv[i] = r.lv; av[i] = r.av; lci[i] = r.lci; ipi[i] = r.ipi; pfr[i] = r.pfr; damp[i] = r.damp; bfl[i] = r.fl;
+        }
+        UP(d.b_pos, pos); UP(d.b_rot, rot); UP(d.b_linvel, lv); UP(d.b_angvel, av); UP(d.b_lcom_invm, lci); UP(d.b_invpi, ipi);
+        UP(d.b_pframe, pfr); UP(d.b_damp, damp); UP(d.b_flags, bfl);
+        std::vector<int> cpar(nc), csh(nc);
+        std::vector<float4> clp(nc), clr(nc), che(nc), cmat(nc), fmn(nc), fmx(nc);
+        std::vector<int2> crul(nc); std::vector<uint2> cgrp(nc);
+        for (int i = 0; i < nc; ++i) {
+            ColliderRow r = pack_collider(w, i);
+            cpar[i] = r.parent; csh[i] = r.shape; clp[i] = r.lp; clr[i] = r.lr; che[i] = r.he; cmat[i] = r.mat; crul[i] = r.rules; cgrp[i] = r.groups; fmn[i] = r.fmn; fmx[i] = r.fmx;
+        }
+        UP(d.c_parent, cpar); UP(d.c_shape, csh); UP(d.c_lpos, clp); UP(d.c_lrot, clr); UP(d.c_he, che); UP(d.c_mat, cmat);
+        UP(d.c_rules, crul); UP(d.c_groups, cgrp); UP(d.c_fatmin, fmn); UP(d.c_fatmax, fmx);
+        HIPCHK(w, hipStreamSynchronize(w->stream)); // the staging vectors die here
     }
-    UP(d.b_pos, pos); UP(d.b_rot, rot); UP(d.b_linvel, lv); UP(d.b_angvel, av); UP(d.b_lcom_invm, lci); UP(d.b_invpi, ipi);
-    UP(d.b_pframe, pfr); UP(d.b_damp, damp); UP(d.b_flags, bfl);
-    std::vector<int> cpar(nc), csh(nc);
-    std::vector<float4> clp(nc), clr(nc), che(nc), cmat(nc), fmn(nc), fmx(nc);
-    std::vector<int2> crul(nc); std::vector<uint2> cgrp(nc);
-    for (int i = 0; i < nc; ++i) {
-        const rp_collider_desc &c = w->colliders[i];
-        cpar[i] = w->collider_parent[i]; csh[i] = c.shape;
-        float qn = std::sqrt(c.rotation[0] * c.rotation[0] + c.rotation[1] * c.rotation[1] + c.rotation[2] * c.rotation[2] + c.rotation[3] * c.rotation[3]);
-        float qi = qn > 0.0f ? 1.0f / qn : 1.0f;
-        clp[i] = mk4(c.translation[0], c.translation[1], c.translation[2], 0);
-        clr[i] = mk4(c.rotation[0] * qi, c.rotation[1] * qi, c.rotation[2] * qi, qn > 0.0f ? c.rotation[3] * qi : 1.0f);
-        che[i] = mk4(c.half_extents[0], c.half_extents[1], c.half_extents[2], 0);
-        cmat[i] = mk4(c.friction, c.restitution, c.density, 0);
-        crul[i].x = c.friction_rule; crul[i].y = c.restitution_rule;
-        cgrp[i].x = w->collider_removed[i] ? 0u : c.collision_memberships; cgrp[i].y = w->collider_removed[i] ? 0u : c.collision_filter;
-        // an "inverted" AABB: the first k_collider_update always rewrites it
-        fmn[i] = mk4(1.0f, 1.0f, 1.0f, 0); fmx[i] = mk4(-1.0f, -1.0f, -1.0f, 0);
-    }
-    UP(d.c_parent, cpar); UP(d.c_shape, csh); UP(d.c_lpos, clp); UP(d.c_lrot, clr); UP(d.c_he, che); UP(d.c_mat, cmat);
-    UP(d.c_rules, crul); UP(d.c_groups, cgrp); UP(d.c_fatmin, fmn); UP(d.c_fatmax, fmx);
     std::vector<int> fl(FL_COUNT, 0);
     fl[FL_BP_DIRTY] = 1; fl[FL_LAYOUT_DIRTY] = 1; fl[FL_JOINT_DIRTY] = 1;
     UP(d.flags, fl);

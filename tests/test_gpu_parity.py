@@ -267,20 +267,44 @@ def test_remove_joint_and_collider_bit_exact():
         _same_state(g2, o2, f"after removing collider 30, +{n}")
 
 
-def test_insert_after_stepping_continues_from_current_state():
-    """Inserting into a stepped world rebuilds the device world from the CURRENT body states."""
+def test_insert_into_live_world_bit_exact():
+    """RigidBodySet::insert / ColliderSet::insert_with_parent into a stepped world: the rows are appended
+    in place, every existing pair keeps its warm-start data, so the result matches the oracle bit for bit."""
+    sc = S.box_stack(3)
+    g, o = PhysicsWorld.from_scene(sc), OracleWorld(sc)
+    g.step(60); o.step(60)
+    body = S.body_desc(translation=(0.1, 6.0, 0.05), linvel=(0.0, -1.0, 0.0))
+    col = S.collider_desc(half_extents=(0.4, 0.4, 0.4), density=2.0)
+    hb = g.insert_body(body)
+    g.insert_collider(col, hb)
+    from oracle_ffi import lib
+    ob = lib().ro_add_body(o._w, np.array([body], S.BODY_DTYPE).ctypes.data)
+    lib().ro_add_collider(o._w, np.array([col], S.COLLIDER_DTYPE).ctypes.data, ob)
+    o.n += 1
+    assert int(hb) & 0xFFFFFFFF == ob
+    for n in (1, 40, 200):
+        g.step(n); o.step(n)
+        _same_state(g, o, f"after inserting a box, +{n}")
+    pos, _ = g.read_bodies()
+    assert pos[ob, 1] < 5.0 and g.quarantined().size == 0
+
+
+def test_insert_beyond_capacity_rebuilds_from_current_state():
+    """More inserts than the spare device rows: the device world is rebuilt from the CURRENT body states."""
     sc = S.box_stack(2)
     g = PhysicsWorld.from_scene(sc)
     g.step(60)
     before, _ = g.read_bodies()
-    b = g.insert_body(S.body_desc(translation=(5.0, 3.0, 0.0)))
-    g.insert_collider(S.collider_desc(), b)
+    n_new = 400
+    descs = np.array([S.body_desc(translation=(-8.0 + 1.6 * (i % 10) + (2.0 if i % 10 >= 5 else 0.0), 0.6 + 1.2 * (i // 100), -8.0 + 1.6 * ((i // 10) % 10)))
+                      for i in range(n_new)], S.BODY_DTYPE)  # 4 layers of 10 x 10 boxes on the slab, clear of the stack at the origin
+    handles = g.insert_bodies(descs)
+    g.insert_colliders(np.array([S.collider_desc() for _ in range(n_new)], S.COLLIDER_DTYPE), handles)
     after, _ = g.read_bodies()
     np.testing.assert_array_equal(after[:3], before[:3])
-    g.step(120)
-    pos, _ = g.read_bodies()
-    assert np.isfinite(pos).all() and abs(pos[int(b) & 0xFFFFFFFF, 1] - 0.5) < 0.05  # the new box landed on the slab
-    assert g.quarantined().size == 0
+    g.step(240)
+    pos, vel = g.read_bodies()
+    assert np.isfinite(pos).all() and np.abs(vel).max() < 1.0 and pos[:, 1].min() > -1.0
 
 
 def test_out_of_scope_inputs_are_refused():
