@@ -35,7 +35,7 @@ void rp_launch_init_bodies(const DevWorld &w, hipStream_t st);
 void rp_launch_solver_assembly(const DevWorld &w, hipStream_t st);
 void rp_launch_solver_loop(const DevWorld &w, hipStream_t st, int parallel_stages, int stage_blocks, int has_restitution, int joint_stages);
 void rp_launch_solver_writeback(const DevWorld &w, hipStream_t st);
-void rp_launch_island_solve(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast, int retire);
+void rp_launch_island_solve(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast, int retire, int fused);
 void rp_launch_global_single(const DevWorld &w, hipStream_t st, int has_restitution, int fast);
 void rp_launch_fast_front(const DevWorld &w, hipStream_t st, int no_global_kernel);
 
@@ -59,13 +59,14 @@ struct rp_world {
     DevWorld dw;
     int *pinned_flags = nullptr; // FL_COUNT ints, written by an async D2H copy at the end of each step
     // launch plan + graph
-    int plan_stages = 0, plan_blocks = 1, plan_single = 1, plan_island_grid = 1, plan_joint_stages = 0, plan_no_global = 0;
+    int plan_stages = 0, plan_blocks = 1, plan_single = 1, plan_island_grid = 1, plan_joint_stages = 0, plan_no_global = 0, plan_fused = 0;
     bool has_restitution = false;
     // [0] = full path, [1] = fast path; "whole" = one graph per step, col/loop/fin = timed thirds
     hipGraph_t g_whole[2] = {nullptr, nullptr}, g_col[2] = {nullptr, nullptr}, g_loop[2] = {nullptr, nullptr}, g_fin[2] = {nullptr, nullptr};
     hipGraphExec_t ge_whole[2] = {nullptr, nullptr}, ge_col[2] = {nullptr, nullptr}, ge_loop[2] = {nullptr, nullptr}, ge_fin[2] = {nullptr, nullptr};
-    int graph_stages = -1, graph_blocks = -1, graph_single = -1, graph_island_grid = -1, graph_joint_stages = -1, graph_no_global = -1;
-    bool use_graph = true, use_fast = true;
+    int graph_stages = -1, graph_blocks = -1, graph_single = -1, graph_island_grid = -1, graph_joint_stages = -1, graph_no_global = -1, graph_fused = -1;
+    bool use_graph = true, use_fast = true, use_fused = true;
+    bool timed_ready[2] = {false, false};
     int cur_fast = 0;              // mode the enqueue_* callbacks capture
     long long steps_requested = 0; // steps asked for since finalize (device FL_STEP counts the executed ones)
     long long seq_enqueued = 0;    // step graphs enqueued since finalize (device FL_SEQ counts the retired ones)
@@ -195,6 +196,8 @@ extern "C" int32_t rp_world_create(const rp_integration_params *params, const fl
     if (g && g[0] == '1') w->use_graph = false;
     g = getenv("RP_NO_FAST");
     if (g && g[0] == '1') w->use_fast = false;
+    g = getenv("RP_NO_FUSED");
+    if (g && g[0] == '1') w->use_fused = false;
     memset(&w->dw, 0, sizeof(w->dw));
     *out = w;
     return RP_OK;
@@ -207,7 +210,8 @@ static void destroy_graphs(rp_world *w) {
         for (auto e : ex) if (*e) { hipGraphExecDestroy(*e); *e = nullptr; }
         for (auto g : gr) if (*g) { hipGraphDestroy(*g); *g = nullptr; }
     }
-    w->graph_stages = -1; w->graph_blocks = -1; w->graph_single = -1; w->graph_island_grid = -1; w->graph_joint_stages = -1; w->graph_no_global = -1;
+    w->graph_stages = -1; w->graph_blocks = -1; w->graph_single = -1; w->graph_island_grid = -1; w->graph_joint_stages = -1; w->graph_no_global = -1; w->graph_fused = -1;
+    w->timed_ready[0] = w->timed_ready[1] = false;
 }
 static void free_device(rp_world *w) {
     destroy_graphs(w);
@@ -365,6 +369,7 @@ extern "C" int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider
         if (in_place) {
             int r = upload_collider_row(w, (int)w->colliders.size() - 1);
             if (r == RP_OK && parent >= 0) r = upload_body_row_mass(w, parent);
+            if (r == RP_OK && parent >= 0 && w->bodies[parent].d.body_type == RP_BODY_DYNAMIC) { int ci = (int)w->colliders.size() - 1; HIPCHK(w, hipMemcpy(w->dw.b_collider + parent, &ci, sizeof(int), hipMemcpyHostToDevice)); }
             if (r != RP_OK) return r;
         }
     }
@@ -513,7 +518,7 @@ static int finalize(rp_world *w) {
     DA(d.flags, FL_COUNT); DA(d.dbg, 64);
     DA(d.b_pos, capb); DA(d.b_rot, capb); DA(d.b_linvel, capb); DA(d.b_angvel, capb); DA(d.b_lcom_invm, capb); DA(d.b_invpi, capb);
     DA(d.b_pframe, capb); DA(d.b_wcom, capb); DA(d.b_eim, capb); DA(d.b_eii0, capb); DA(d.b_eii1, capb); DA(d.b_damp, capb);
-    DA(d.b_uforce, capb); DA(d.b_utorque, capb); DA(d.b_flags, capb); DA(d.b_quar, capb);
+    DA(d.b_uforce, capb); DA(d.b_utorque, capb); DA(d.b_flags, capb); DA(d.b_quar, capb); DAF(d.b_collider, capb, 0xff);
     DA(d.s_lin, capb); DA(d.s_ang, capb); DA(d.s_rot, capb); DA(d.s_trans, capb); DA(d.s_incl, capb); DA(d.s_inca, capb);
     DA(d.b_cmask, 4 * (size_t)capb); DAF(d.b_min, capb, 0xff);
     DA(d.c_parent, capc); DA(d.c_shape, capc); DA(d.c_lpos, capc); DA(d.c_lrot, capc); DA(d.c_pos, capc); DA(d.c_rot, capc); DA(d.c_he, capc);
@@ -524,7 +529,7 @@ static int finalize(rp_world *w) {
     DA(d.free_stack, d.pool_cap);
     size_t P = (size_t)d.pool_cap;
     DAF(d.p_c1, P, 0xff); DA(d.p_c2, P); DA(d.p_stamp, P); DA(d.p_color, P); DA(d.p_nsc, P); DA(d.p_npts, P); DA(d.p_pflags, P); DA(d.p_reldom, P);
-    DA(d.p_colorb, P); DA(d.p_ln1, P); DA(d.p_ln2, P); DA(d.p_normal, P); DA(d.p_misc, P);
+    DA(d.p_colorb, P); DA(d.p_rb, P); DA(d.p_ln1, P); DA(d.p_ln2, P); DA(d.p_normal, P); DA(d.p_misc, P);
     DA(d.r_t, P); DA(d.r_r, P); DA(d.r_rot1, P); DA(d.r_rot2, P);
     DA(d.pt_lp1d, RP_MAX_PTS * P); DA(d.pt_lp2f, RP_MAX_PTS * P); DA(d.pt_imp, RP_MAX_PTS * P); DA(d.pt_wst, RP_MAX_PTS * P);
     DA(d.pt_dp1, RP_MAX_PTS * P); DA(d.pt_dp2, RP_MAX_PTS * P);
@@ -538,7 +543,7 @@ static int finalize(rp_world *w) {
     DAF(d.p_island, P, 0xff);
     DA(d.isl_body_begin, capb); DA(d.isl_nb, capb); DA(d.isl_cons_begin, capb); DA(d.isl_nc, capb); DA(d.isl_fill_b, capb); DA(d.isl_fill_c, capb);
     DA(d.isl_bodies, capb); DA(d.isl_cons, P); DA(d.isl_cstage, P); DA(d.isl_sorted, capb); DA(d.isl_nstages, capb);
-    DA(d.isl_cg1, P); DA(d.isl_cg2, P); DA(d.isl_cl1, P); DA(d.isl_cl2, P); DA(d.isl_inc_pos, 2 * P); DA(d.isl_inc_begin, capb); DA(d.isl_inc_cnt, capb);
+    DA(d.isl_cg1, P); DA(d.isl_cg2, P); DA(d.isl_cl1, P); DA(d.isl_cl2, P); DA(d.isl_inc_pos, 2 * P); DA(d.r_ni, capb); DA(d.isl_ni, capb); DA(d.isl_icons_begin, capb); DA(d.isl_fill_i, capb); DA(d.isl_icons, P); DA(d.isl_inc_begin, capb); DA(d.isl_inc_cnt, capb);
     // impulse joints: only joints with a dynamic side are active (select_active_interactions,
     // impulse_joint_set.rs:504-572), kept in edge order; frames go to solver-body space once
     // (GenericJoint::transform_to_solver_body_space, generic_joint.rs:624-636)
@@ -582,6 +587,12 @@ static int finalize(rp_world *w) {
     DA(d.JR, (size_t)17 * std::max(nj, 1));
     UP(d.j_b1, jb1); UP(d.j_b2, jb2); UP(d.j_f1t, jf1t); UP(d.j_f1r, jf1r); UP(d.j_f2t, jf2t); UP(d.j_f2r, jf2r);
     UP(d.j_locked, jlocked); UP(d.j_color, jcolor); UP(d.b_njoints, bnj);
+    {
+        std::vector<int> bcol(nb, -1);
+        for (int c = 0; c < nc; ++c) { int pb = w->collider_parent[c]; if (pb >= 0 && !w->collider_removed[c] && w->bodies[pb].d.body_type == RP_BODY_DYNAMIC && !w->bodies[pb].removed) bcol[pb] = c; }
+        UP(d.b_collider, bcol);
+        HIPCHK(w, hipStreamSynchronize(w->stream));
+    }
     DA(d.C, (size_t)CP_COUNT * d.cons_cap);
     DA(d.k_b1, d.cons_cap); DA(d.k_b2, d.cons_cap); DA(d.k_n, d.cons_cap); DA(d.k_cid, d.cons_cap);
 
@@ -622,6 +633,7 @@ static int finalize(rp_world *w) {
 }
 
 static void enqueue_collision(rp_world *w) {
+    if (w->cur_fast && w->plan_fused) return; // the fused k_island_solve validates the step itself
     if (w->cur_fast) { rp_launch_fast_front(w->dw, w->stream, w->plan_no_global); return; }
     rp_launch_collider_update(w->dw, w->stream);
     rp_launch_broadphase(w->dw, w->stream);
@@ -630,7 +642,10 @@ static void enqueue_collision(rp_world *w) {
 // build_islands_and_solve_velocity_constraints: LDS island megakernel + the global path
 static void enqueue_island_solver(rp_world *w) {
     // SINGLE mode: workgroup 0 of this launch retires the step (FL_SEQ / FL_STEP, hint publication)
-    rp_launch_island_solve(w->dw, w->stream, w->plan_island_grid, w->has_restitution ? 1 : 0, w->cur_fast, w->plan_single);
+    const int fused = (w->cur_fast && w->plan_fused) ? 1 : 0;
+    const int RP_FUSED_MAX_GRID = 240; // < 256 CUs: every workgroup of the fused step must be resident at once
+    rp_launch_island_solve(w->dw, w->stream, fused ? std::min(w->plan_island_grid, RP_FUSED_MAX_GRID) : w->plan_island_grid,
+                           w->has_restitution ? 1 : 0, w->cur_fast, w->plan_single, fused);
 }
 static void enqueue_global_solver(rp_world *w) {
     int hr = w->has_restitution ? 1 : 0;
@@ -660,6 +675,9 @@ static void plan_from_hints(rp_world *w, const int *fl) {
     // round up to a power of two so small changes of the stage size do not force a re-capture
     w->plan_blocks = std::min(std::max(pow2_ceil((fl[FL_MAX_STAGE] + 255) / 256), 1), 4096);
     w->plan_island_grid = std::min(std::max(pow2_ceil(fl[FL_N_ISLANDS]), 1), 8192);
+    // fused single-kernel fast step: every workgroup must be resident at once (in-launch arrival barrier)
+    // (a grid of at most RP_FUSED_MAX_GRID workgroups, one per CU; workgroups loop over islands beyond that)
+    w->plan_fused = (w->use_fused && w->plan_no_global && w->plan_single && fl[FL_N_ISLANDS] > 0) ? 1 : 0;
 }
 
 static int capture(rp_world *w, hipGraph_t *g, hipGraphExec_t *ge, void (*fn)(rp_world *)) {
@@ -690,13 +708,14 @@ static int launch_step(rp_world *w, int fast) {
     if (fast) w->fast_steps++; else w->full_steps++;
     if (w->timers) {
         // three sub-graphs with events in between (Counters from hipEvents)
-        if (!w->ge_col[fast]) {
+        if (!w->timed_ready[fast]) {
             int r;
-            if ((r = capture(w, &w->g_col[fast], &w->ge_col[fast], enqueue_collision)) != RP_OK) return r;
+            if (!(fast && w->plan_fused) && (r = capture(w, &w->g_col[fast], &w->ge_col[fast], enqueue_collision)) != RP_OK) return r;
+            w->timed_ready[fast] = true;
             if (!(fast && w->plan_no_global) && (r = capture(w, &w->g_fin[fast], &w->ge_fin[fast], enqueue_global_and_finish)) != RP_OK) return r;
         }
         HIPCHK(w, hipEventRecord(w->ev[0], w->stream));
-        HIPCHK(w, hipGraphLaunch(w->ge_col[fast], w->stream));
+        if (w->ge_col[fast]) HIPCHK(w, hipGraphLaunch(w->ge_col[fast], w->stream));
         HIPCHK(w, hipEventRecord(w->ev[1], w->stream));
         enqueue_island_solver(w); // launched directly so the two events bracket the kernel alone (no graph-launch gap)
         HIPCHK(w, hipEventRecord(w->ev[2], w->stream));
@@ -757,11 +776,11 @@ static int step_once(rp_world *w, bool allow_fast) {
         if (w->plan_island_grid < old_g && w->plan_island_grid * 2 >= old_g) w->plan_island_grid = old_g;
     }
     if (w->graph_stages != w->plan_stages || w->graph_blocks != w->plan_blocks || w->graph_single != w->plan_single ||
-        w->graph_island_grid != w->plan_island_grid || w->graph_joint_stages != w->plan_joint_stages || w->graph_no_global != w->plan_no_global) {
-        if (w->ge_whole[0] || w->ge_whole[1] || w->ge_col[0] || w->ge_col[1]) HIPCHK(w, hipStreamSynchronize(w->stream)); // replays of the old graphs may still be in flight
+        w->graph_island_grid != w->plan_island_grid || w->graph_joint_stages != w->plan_joint_stages || w->graph_no_global != w->plan_no_global || w->graph_fused != w->plan_fused) {
+        if (w->ge_whole[0] || w->ge_whole[1] || w->timed_ready[0] || w->timed_ready[1]) HIPCHK(w, hipStreamSynchronize(w->stream)); // replays of the old graphs may still be in flight
         destroy_graphs(w);
         w->graph_stages = w->plan_stages; w->graph_blocks = w->plan_blocks; w->graph_single = w->plan_single; w->graph_island_grid = w->plan_island_grid;
-        w->graph_joint_stages = w->plan_joint_stages; w->graph_no_global = w->plan_no_global;
+        w->graph_joint_stages = w->plan_joint_stages; w->graph_no_global = w->plan_no_global; w->graph_fused = w->plan_fused;
     }
     // keep the host at most a few steps ahead of the device so the hints stay fresh (the device
     // never idles: several step graphs are always queued)
@@ -920,6 +939,7 @@ static int remove_collider_at(rp_world *w, int c) {
     if (r != RP_OK) return r;
     if (parent >= 0) {
         const HostBody &b = w->bodies[parent];
+        if ((r = poke(w, w->dw.b_collider + parent, -1)) != RP_OK) return r;
         if ((r = poke(w, w->dw.b_lcom_invm + parent, mk4(b.lcom[0], b.lcom[1], b.lcom[2], b.inv_mass))) != RP_OK) return r;
         if ((r = poke(w, w->dw.b_invpi + parent, mk4(b.inv_pi[0], b.inv_pi[1], b.inv_pi[2], 0))) != RP_OK) return r;
     }

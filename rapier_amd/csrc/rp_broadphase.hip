@@ -65,12 +65,7 @@ __global__ void k_fast_front(DevWorld w, int no_global_kernel) {
     if (top > w.pool_cap) top = w.pool_cap;
     int stride = gridDim.x * blockDim.x;
     for (int s = gid; s < top; s += stride) {
-        int c1 = w.p_c1[s];
-        if (c1 < 0) continue;
-        int c2 = w.p_c2[s];
-        Pose pc1 = collider_world_pose(w, c1), pc2 = collider_world_pose(w, c2);
-        Pose pos12 = pose_inv_mul(pc1, pc2);
-        if (!pair_recycle_ok(w, s, pc1, pc2, pos12)) abort = true;
+        if (pair_needs_narrow_phase(w, s)) abort = true;
     }
     if (abort) w.flags[FL_FAST_ABORT] = 1;
 }
@@ -200,9 +195,10 @@ __device__ void bp_insert_pair(DevWorld &w, int c1, int c2) {
         if (t > 0) slot = w.free_stack[t - 1];
         else { atomicAdd(&w.flags[FL_FREE_TOP], 1); slot = atomicAdd(&w.flags[FL_POOL_TOP], 1); }
         if (slot >= w.pool_cap) { atomicOr(&w.flags[FL_OVERFLOW], RP_OVF_POOL); return; }
-        w.p_c1[slot] = c1; w.p_c2[slot] = c2;
+        w.p_c1[slot] = c1; w.p_c2[slot] = c2; w.p_rb[slot] = make_int2(w.c_parent[c1], w.c_parent[c2]);
         w.p_color[slot] = RP_COLOR_UNCOLORED; w.p_nsc[slot] = 0; w.p_npts[slot] = 0; w.p_pflags[slot] = 0;
         w.p_reldom[slot] = 0; w.p_colorb[slot] = make_int2(-1, -1); w.p_conspos[slot] = -1;
+        w.flags[FL_LAYOUT_DIRTY] = 1; // the island lists also hold the pairs without solver contacts
     }
     w.p_stamp[slot] = epoch + 1;
     int h = (int)(rp_hash64(key) & (unsigned long long)(w.hash_cap - 1));
@@ -281,7 +277,7 @@ __global__ void k_bp_finish_pairs(DevWorld w) {
             if (cb.x >= 0) atomicAnd(&w.b_cmask[4 * cb.x + (color >> 5)], ~bit);
             if (cb.y >= 0) atomicAnd(&w.b_cmask[4 * cb.y + (color >> 5)], ~bit);
         }
-        if (w.p_nsc[s] > 0) w.flags[FL_LAYOUT_DIRTY] = 1;
+        w.flags[FL_LAYOUT_DIRTY] = 1;
         w.p_c1[s] = -1; w.p_nsc[s] = 0; w.p_npts[s] = 0; w.p_color[s] = RP_COLOR_UNCOLORED;
         int t = atomicAdd(&w.flags[FL_FREE_TOP], 1);
         w.free_stack[t] = s;

@@ -18,6 +18,7 @@
 // dynamic-dynamic pairs, then island numbering and list filling — five grid-wide kernels.
 // persistent.rs keeps comparable connected components for sleeping; here they drive scheduling only.
 #include "rp_global.h"
+#include "rp_pairs.h"
 
 RP_DEV int ld_i32(int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 RP_DEV int uf_find(int *label, int x) {
@@ -43,8 +44,8 @@ RP_DEV bool pair_active(const DevWorld &w, int s) { return w.p_c1[s] >= 0 && w.p
 __global__ void k_isl_init(DevWorld w) {
     if (!w.flags[FL_LAYOUT_DIRTY]) return;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) { w.flags[FL_N_ISLANDS] = 0; w.flags[FL_N_GLOB_BODIES] = 0; w.flags[FL_ISL_BODY_CURSOR] = 0; w.flags[FL_ISL_CONS_CURSOR] = 0; }
-    if (i < w.n_bodies) { w.b_label[i] = i; w.r_nb[i] = 0; w.r_nc[i] = 0; w.r_island[i] = -1; w.b_island[i] = -1; w.b_local[i] = -1; }
+    if (i == 0) { w.flags[FL_N_ISLANDS] = 0; w.flags[FL_N_GLOB_BODIES] = 0; w.flags[FL_ISL_BODY_CURSOR] = 0; w.flags[FL_ISL_CONS_CURSOR] = 0; w.flags[FL_ISL_ICONS_CURSOR] = 0; }
+    if (i < w.n_bodies) { w.b_label[i] = i; w.r_nb[i] = 0; w.r_nc[i] = 0; w.r_ni[i] = 0; w.r_island[i] = -1; w.b_island[i] = -1; w.b_local[i] = -1; }
 }
 // connected components over active pairs whose two sides are dynamic
 __global__ void k_isl_union(DevWorld w) {
@@ -75,9 +76,10 @@ __global__ void k_isl_count(DevWorld w) {
         if (w.b_njoints[b] > 0) atomicAdd(&w.r_nc[root], RP_ISL_NC_MAX + 1);
     }
     for (int s = gid; s < top; s += stride) {
-        if (!pair_active(w, s)) continue;
+        if (w.p_c1[s] < 0) continue;
         int b1 = w.c_parent[w.p_c1[s]], b2 = w.c_parent[w.p_c2[s]];
         int b = is_dyn(w, b1) ? b1 : b2;
+        if (!pair_active(w, s)) { if (is_dyn(w, b)) atomicAdd(&w.r_ni[uf_find(w.b_label, b)], 1); continue; } // pair without solver contacts
         if (is_dyn(w, b)) { int root = uf_find(w.b_label, b); if (ld_i32(&w.r_nc[root]) <= RP_ISL_NC_MAX) atomicAdd(&w.r_nc[root], 1); }
     }
 }
@@ -92,6 +94,8 @@ __global__ void k_isl_number(DevWorld w) {
         w.isl_body_begin[id] = atomicAdd(&w.flags[FL_ISL_BODY_CURSOR], cnb);
         w.isl_cons_begin[id] = atomicAdd(&w.flags[FL_ISL_CONS_CURSOR], cnc);
         w.isl_nb[id] = cnb; w.isl_nc[id] = cnc; w.isl_fill_b[id] = 0; w.isl_fill_c[id] = 0; w.isl_sorted[id] = 0; w.isl_nstages[id] = 0;
+        int cni = w.r_ni[b];
+        w.isl_ni[id] = cni; w.isl_fill_i[id] = 0; w.isl_icons_begin[id] = atomicAdd(&w.flags[FL_ISL_ICONS_CURSOR], cni);
         w.r_island[b] = id;
     }
 }
@@ -115,10 +119,15 @@ __global__ void k_isl_fill(DevWorld w) {
         } else atomicAdd(&n_glob, 1); // dynamic bodies left to the global path (launch-plan hint)
     }
     for (int s = gid; s < top; s += stride) {
-        if (!pair_active(w, s)) { w.p_island[s] = -1; continue; }
+        if (w.p_c1[s] < 0) { w.p_island[s] = -1; continue; }
         int b1 = w.c_parent[w.p_c1[s]], b2 = w.c_parent[w.p_c2[s]];
         int b = is_dyn(w, b1) ? b1 : b2;
         int id = is_dyn(w, b) ? w.r_island[w.b_label[b]] : -1;
+        if (!pair_active(w, s)) { // owned by the island of its first dynamic body (recycle-tested there)
+            w.p_island[s] = -1;
+            if (id >= 0) { int k = atomicAdd(&w.isl_fill_i[id], 1); w.isl_icons[w.isl_icons_begin[id] + k] = s; }
+            continue;
+        }
         w.p_island[s] = id;
         if (id >= 0) { int k = atomicAdd(&w.isl_fill_c[id], 1); w.isl_cons[w.isl_cons_begin[id] + k] = s; }
         else { int color = w.p_color[s]; if (color <= RP_COLOR_OVERFLOW) atomicAdd(&hist[color], 1); }
@@ -166,7 +175,8 @@ RP_DEV Xf isl_xf(const IslLds &L, int id) {
 // and broadcasts it back.  The operations and their order are exactly those of rp_constraint.h:
 //   dvel = (((n.v1 + t1.w1) - n.v2) + t2.w2) + rhs           a * (-b) == (-a) * b,  x - y == x + (-y)
 // so the results stay bit-identical to the single-lane form and to the oracle.
-#define ISL_THREADS (2 * RP_ISL_NC_MAX)
+#define ISL_LANES (2 * RP_ISL_NC_MAX)   // lanes 2m, 2m+1 = manifold m
+#define ISL_THREADS 512                  // the lanes beyond an island's 2 * nc only validate the step (fused fast path)
 #define DPP_FROM_ODD 0xF5   // quad_perm [1,1,3,3]: both lanes of a pair read the odd lane
 #define DPP_FROM_EVEN 0xA0  // quad_perm [0,0,2,2]: both lanes of a pair read the even lane
 template <int CTRL> RP_DEV float dppf(float x) {
@@ -350,7 +360,7 @@ RP_DEV void isl_pose_stage(const DevWorld &w, IslSide &h, const IslLds &L, int m
 // (isl_ws_terms) and the thread that owns a body adds them in exactly that order (isl_ws_accumulate):
 // 2 stages per substep instead of one per colour, same additions, same order, same bits.
 #define WS_SLOTS 11   // per lane: 4 x (lin, ang) point terms, tangent lin, tangent ang, twist ang
-#define WS_STRIDE (ISL_THREADS + 2) // rows of one slot: every lane's row + two scratch rows for world-attached sides
+#define WS_STRIDE (ISL_LANES + 2) // rows of one slot: every lane's row + two scratch rows for world-attached sides
 RP_DEV void isl_ws_terms(const DevWorld &w, IslSide &h, float4 *W, int t) { // t = this lane's row in W (its rank in its body's list)
     float wc = w.prm.p.warmstart_coefficient;
     bool ws = wc != 0.0f;
@@ -577,7 +587,7 @@ RP_DEV void island_sort(const DevWorld &w, int isl, int nc, int cb, int nst_glob
             int q = T_rank[m], rank = 0;
             for (int m2 = 0; m2 < nc; ++m2) { int q2 = T_rank[m2]; rank += (q2 < q) && (I_body0[m2] == b || I_body1[m2] == b); }
             w.isl_inc_pos[2 * cb + t] = w.isl_inc_begin[bb + b] + rank;
-        } else w.isl_inc_pos[2 * cb + t] = ISL_THREADS + (t & 1); // world-attached side: scratch rows nobody reads
+        } else w.isl_inc_pos[2 * cb + t] = ISL_LANES + (t & 1); // world-attached side: scratch rows nobody reads
     }
     __threadfence(); __syncthreads();
     if (t == 0) w.isl_sorted[isl] = 1;
@@ -585,16 +595,58 @@ RP_DEV void island_sort(const DevWorld &w, int isl, int nc, int cb, int nst_glob
 }
 
 // One workgroup = one island; lanes 2m, 2m+1 = manifold m (sorted by sweep stage), threads < nb also own a body.
-__global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int has_restitution, int fast, int retire) {
+//
+// `fused` (steady-state fast graph whose ONLY kernel this is): the launch first proves that this step
+// needs neither the broad phase nor the narrow phase — every workgroup checks the fat AABBs of its
+// islands' bodies and the recycle tests of its islands' pairs (pair_update.rs:111-171) against the
+// start-of-step poses, raises FL_FAST_ABORT on a failure and then arrives on FL_ARRIVE.  The solve
+// runs meanwhile; nothing is written back until every workgroup has arrived (~70 us later: the wait is
+// free) and no abort was raised.  An aborted launch leaves the world untouched and the host replays the
+// step on the full graph.  Needs every workgroup resident at once: the grid is capped below the CU count.
+__global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int has_restitution, int fast, int retire, int fused) {
     const bool aborted = fast && w.flags[FL_FAST_ABORT]; // fast graph gave up on this step (rp_api.hip)
     if (retire && blockIdx.x == 0) {
         // SINGLE mode: workgroup 0 retires the step and publishes the scalars to the host hint buffer
         // up front, so the PCIe writes overlap the solve instead of ending the step
-        if (threadIdx.x == 0) { w.flags[FL_SEQ] += 1; if (!aborted) w.flags[FL_STEP] += 1; }
+        if (threadIdx.x == 0) { w.flags[FL_SEQ] += 1; if (!aborted && !fused) w.flags[FL_STEP] += 1; if (fused) w.flags[FL_FULL_UPDATES] = 0; }
         __threadfence(); __syncthreads();
         publish_flags(w);
     }
     if (aborted) return;
+    __shared__ int s_abort, s_go;
+#ifdef RP_ISL_PROFILE
+    long long t_fused0 = (long long)__builtin_readcyclecounter();
+#endif
+    if (fused) {
+        // validation of this workgroup's islands BEYOND its first one (the first is validated under its own
+        // load phase below, where the latency of these loads hides behind the island's loads); FL_ARRIVE
+        // counts arrivals in its low 16 bits and aborting workgroups above: one atomic, no fence needed
+        const int t = threadIdx.x;
+        const int n_islands = w.flags[FL_N_ISLANDS];
+        if (t == 0) {
+            s_abort = 0;
+            // block 0: the conditions k_fast_front checks for the whole world
+            if (blockIdx.x == 0 && (w.flags[FL_BP_DIRTY] || w.flags[FL_N_CONS] > 0 || w.flags[FL_N_GLOB_BODIES] > 0 || w.n_joints > 0)) s_abort = 1;
+        }
+        __syncthreads();
+        bool bad = false;
+        for (int isl = blockIdx.x + gridDim.x; isl < n_islands; isl += gridDim.x) {
+            const int nb = w.isl_nb[isl], nc = w.isl_nc[isl], ni = w.isl_ni[isl];
+            const int bb = w.isl_body_begin[isl], cb = w.isl_cons_begin[isl], ib = w.isl_icons_begin[isl];
+            for (int i = t; i < nb; i += blockDim.x) { int c = w.b_collider[w.isl_bodies[bb + i]]; if (c >= 0 && collider_left_fat_aabb(w, c)) bad = true; }
+            for (int i = t; i < nc; i += blockDim.x) if (pair_needs_narrow_phase(w, w.isl_cons[cb + i])) bad = true;
+            for (int i = t; i < ni; i += blockDim.x) if (pair_needs_narrow_phase(w, w.isl_icons[ib + i])) bad = true;
+        }
+        if (bad) s_abort = 1;
+        if ((int)blockIdx.x >= n_islands) { // no island at all: arrive now
+            __syncthreads();
+            if (t == 0) atomicAdd(&w.flags[FL_ARRIVE], 1 + (s_abort ? (1 << 16) : 0));
+        }
+#ifdef RP_ISL_PROFILE
+        if (blockIdx.x == 0 && threadIdx.x == 0) w.dbg[10] += (long long)__builtin_readcyclecounter() - t_fused0;
+#endif
+    }
+    bool decided = !fused, go = true;
     __shared__ float4 B_lin[RP_ISL_NB_MAX], B_ang[RP_ISL_NB_MAX], B_rot[RP_ISL_NB_MAX], B_trans[RP_ISL_NB_MAX];
     __shared__ float4 L_E[4 * RP_ISL_NC_MAX], L_F[4 * RP_ISL_NC_MAX], L_B0[RP_ISL_NC_MAX], L_B1[RP_ISL_NC_MAX];
     __shared__ int S_a[RP_ISL_NC_MAX], S_b[RP_ISL_NC_MAX], S_c[RP_ISL_NC_MAX], S_d[RP_ISL_NC_MAX];
@@ -654,6 +706,21 @@ __global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int ha
         if (live) {
             if (isl_generate(w, h, L, m, slot, own_g, own_l, odd) && !odd) any_bouncy = 1;
         }
+        const int v_first = (2 * nc + 63) & ~63; // first wavefront without any manifold lane
+        if (fused && isl == (int)blockIdx.x && t >= v_first) {
+            // the wavefronts without a manifold prove, under cover of generate (the longest interval of the
+            // kernel), that this island needs neither broad nor narrow phase this step: one item (a body's
+            // collider, an active pair, a pair without solver contacts) per lane and round
+            const int vt = t - v_first, vn = ISL_THREADS - v_first;
+            const int ni = w.isl_ni[isl], ib = w.isl_icons_begin[isl];
+            bool bad = false;
+            for (int i = vt; i < nb + nc + ni; i += vn) {
+                if (i < nb) { int c = w.b_collider[w.isl_bodies[bb + i]]; if (c >= 0 && collider_left_fat_aabb(w, c)) bad = true; }
+                else if (i < nb + nc) { if (pair_needs_narrow_phase(w, w.isl_cons[cb + i - nb])) bad = true; }
+                else if (pair_needs_narrow_phase(w, w.isl_icons[ib + i - nb - nc])) bad = true;
+            }
+            if (bad) s_abort = 1;
+        }
         if (live) isl_pose_stage(w, h, L, m, 0.0f); // each lane reads back only what it stored itself
         ISL_STAMP(1); // generate + first pose stage
 
@@ -661,6 +728,7 @@ __global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int ha
             float solved_dt = (float)sub * w.prm.dt_sub;
             if (live) isl_ws_terms(w, h, W, ws_row); // warm-start terms of every manifold, in parallel
             __syncthreads(); // + pose stage read rot/trans; relax sweep of the previous substep done
+            if (fused && sub == 0 && isl == (int)blockIdx.x && t == 0) atomicAdd(&w.flags[FL_ARRIVE], 1 + (s_abort ? (1 << 16) : 0)); // this workgroup validated all of its islands
             ISL_STAMP(2); // warm-start terms
             // S2 increment (worker.rs:235-284), then the warm start of this body in sweep order
             if (role_lin) {
@@ -698,12 +766,44 @@ __global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int ha
         if (has_restitution && any_bouncy)
             for (int q = 0; q < nls; ++q) { if (myq == q) isl_restitution(h, L); __syncthreads(); }
         // ---- write-back (S9, S10, advance_to_final_positions) ----
+        if (!decided) { // fused: nothing leaves the workgroup before every workgroup validated its islands
+#ifdef RP_ISL_PROFILE
+            long long t_w0 = (long long)__builtin_readcyclecounter();
+#endif
+            if (t == 0) {
+                int spins = 0, v;
+                while (((v = __hip_atomic_load(&w.flags[FL_ARRIVE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffff) < (int)gridDim.x) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > (1 << 24)) { atomicOr(&w.flags[FL_OVERFLOW], RP_OVF_GRID); break; } // a workgroup never became resident
+                }
+                s_go = spins <= (1 << 24) && (v >> 16) == 0;
+            }
+            __syncthreads();
+            go = s_go != 0; decided = true;
+#ifdef RP_ISL_PROFILE
+            if (blockIdx.x == 0 && threadIdx.x == 0) w.dbg[11] += (long long)__builtin_readcyclecounter() - t_w0;
+#endif
+        }
+        if (!go) break;
         if (live && !odd) isl_writeback(w, h, slot);
         if (t < nb) body_writeback(w, b_gid, v3(B_lin[t]), v3(B_ang[t]), q4(B_rot[t]), v3(B_trans[t]));
         ISL_STAMP(8); // write-back
 #ifdef RP_ISL_PROFILE
         if (blockIdx.x == 0 && threadIdx.x == 0) w.dbg[63] += 1;
 #endif
+    }
+    if (fused) { // the last workgroup to leave retires the step (or not, when aborted) and re-arms the counters
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (atomicAdd(&w.flags[FL_DEPART], 1) == (int)gridDim.x - 1) {
+                // every workgroup has arrived by now (each one arrives before it can reach this point)
+                int v = __hip_atomic_load(&w.flags[FL_ARRIVE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((v >> 16) == 0 && !(w.flags[FL_OVERFLOW] & RP_OVF_GRID)) w.flags[FL_STEP] += 1;
+                else w.flags[FL_FAST_ABORT] = 1; // sticky: later fast launches exit until a full step ran
+                __hip_atomic_store(&w.flags[FL_ARRIVE], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&w.flags[FL_DEPART], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
 }
 
@@ -717,7 +817,7 @@ void rp_launch_islands_build(const DevWorld &w, hipStream_t st) {
     hipLaunchKernelGGL(k_isl_number, dim3(nbb), dim3(256), 0, st, w);
     hipLaunchKernelGGL(k_isl_fill, dim3(blocks), dim3(256), 0, st, w);
 }
-void rp_launch_island_solve(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast, int retire) {
+void rp_launch_island_solve(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast, int retire, int fused) {
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(k_island_solve, dim3(grid), dim3(ISL_THREADS), 0, st, w, has_restitution, fast, retire);
+    hipLaunchKernelGGL(k_island_solve, dim3(grid), dim3(ISL_THREADS), 0, st, w, has_restitution, fast, retire, fused);
 }

@@ -45,6 +45,29 @@ RP_DEV bool collider_update_one(const DevWorld &w, int i) { // true = the fat AA
     return !inside;
 }
 
+// Would collider_update_one rewrite this collider's fat AABB (i.e. must the broad phase run)?  Read-only.
+RP_DEV bool collider_left_fat_aabb(const DevWorld &w, int i) {
+    Pose pos = collider_world_pose(w, i);
+    bool finite = isfinite(pos.t.x) && isfinite(pos.t.y) && isfinite(pos.t.z) && isfinite(pos.r.x) && isfinite(pos.r.y) &&
+                  isfinite(pos.r.z) && isfinite(pos.r.w);
+    if (!finite) return true;
+    float4 he = w.c_he[i];
+    V3 h;
+    if (w.c_shape[i] == RP_SHAPE_CUBOID) {
+        float m[3][3]; quat_to_mat(pos.r, m);
+        h = v3(fabsf(m[0][0]) * he.x + fabsf(m[0][1]) * he.y + fabsf(m[0][2]) * he.z,
+               fabsf(m[1][0]) * he.x + fabsf(m[1][1]) * he.y + fabsf(m[1][2]) * he.z,
+               fabsf(m[2][0]) * he.x + fabsf(m[2][1]) * he.y + fabsf(m[2][2]) * he.z);
+    } else {
+        h = v3(he.x, he.x, he.x);
+    }
+    float loosen = w.prm.prediction / 2.0f;
+    V3 mn = pos.t - h - v3(loosen, loosen, loosen);
+    V3 mx = pos.t + h + v3(loosen, loosen, loosen);
+    float4 fmn = w.c_fatmin[i], fmx = w.c_fatmax[i];
+    bool inside = fmn.x <= mn.x && fmn.y <= mn.y && fmn.z <= mn.z && fmx.x >= mx.x && fmx.y >= mx.y && fmx.z >= mx.z;
+    return !inside;
+}
 // Contact recycling test — pair_update.rs:111-171, contact_pair.rs:284-325.  true = the pair keeps
 // last step's manifold (no narrow-phase work).
 RP_DEV bool pair_recycle_ok(const DevWorld &w, int s, const Pose &pc1, const Pose &pc2, const Pose &pos12) {
@@ -57,4 +80,19 @@ RP_DEV bool pair_recycle_ok(const DevWorld &w, int s, const Pose &pc1, const Pos
     float ca = qdot(q4(w.r_rot1[s]), pc1.r), cb = qdot(q4(w.r_rot2[s]), pc2.r);
     float rot_cos = rp_min(2.0f * ca * ca - 1.0f, 2.0f * cb * cb - 1.0f);
     return drift <= misc.z && rot_cos > 0.98f;
+}
+RP_DEV Pose collider_world_pose_of(const DevWorld &w, int i, int parent) { // parent = c_parent[i], already known
+    Pose lp; lp.r = q4(w.c_lrot[i]); lp.t = v3(w.c_lpos[i]);
+    if (parent < 0) return lp;
+    Pose bp; bp.r = q4(w.b_rot[parent]); bp.t = v3(w.b_pos[parent]);
+    return pose_mul(bp, lp);
+}
+RP_DEV bool pair_needs_narrow_phase(const DevWorld &w, int s) {
+    int c1 = w.p_c1[s];
+    if (c1 < 0) return false;
+    int c2 = w.p_c2[s];
+    int2 rb = w.p_rb[s];
+    Pose pc1 = collider_world_pose_of(w, c1, rb.x), pc2 = collider_world_pose_of(w, c2, rb.y);
+    Pose pos12 = pose_inv_mul(pc1, pc2);
+    return !pair_recycle_ok(w, s, pc1, pc2, pos12);
 }

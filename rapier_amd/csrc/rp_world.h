@@ -37,6 +37,7 @@
 #define RP_OVF_CELLS 0x4
 #define RP_OVF_LARGE 0x8
 #define RP_OVF_CONS 0x10
+#define RP_OVF_GRID 0x20   // a fused-step workgroup never became resident (grid barrier timed out)
 
 // device scalar slots (int32) in DevWorld::flags
 enum {
@@ -68,6 +69,8 @@ enum {
     FL_SEQ,             // step graphs retired (executed or aborted)
     FL_JOINT_DIRTY,     // joint colours / stage layout must be rebuilt
     FL_NJ_STAGES, FL_NJ_OVF_BEGIN, FL_NJ_OVF_COUNT, // joint stage layout: parallel colours, serial overflow range in j_order
+    FL_ARRIVE, FL_DEPART, // fused fast step: workgroups that validated their islands / that finished (reset by the last one)
+    FL_ISL_ICONS_CURSOR,
     FL_FAST_ABORT,      // steady-state fast path found work it cannot do (see rp_api.hip); sticky until a full step
     FL_COUNT = 48
 };
@@ -147,6 +150,7 @@ struct DevWorld {
     float4 *b_damp;        // linear damping, angular damping, gravity scale, -
     float4 *b_uforce, *b_utorque;
     int *b_flags;
+    int *b_collider;       // the collider of a dynamic body (one per dynamic body, -1 = none)
     int *b_quar;           // sticky: non-finite state was detected (and rolled back) for this body
     // ---- solver bodies (index = arena index; non-dynamic = world-attached) ----
     float4 *s_lin, *s_ang, *s_rot, *s_trans, *s_incl, *s_inca;
@@ -171,6 +175,7 @@ struct DevWorld {
     // ---- pair pool ----
     int *p_c1, *p_c2, *p_stamp, *p_color, *p_nsc, *p_npts, *p_pflags, *p_reldom;
     int2 *p_colorb;
+    int2 *p_rb;                 // parent bodies of the two colliders (c_parent is static), saves a dependent load
     float4 *p_ln1, *p_ln2;      // manifold local normals
     float4 *p_normal;           // world normal xyz, friction
     float4 *p_misc;             // restitution, recycle max_extent, recycle max_drift, -
@@ -201,6 +206,7 @@ struct DevWorld {
     int *isl_cstage;            // [pool] local stage index of isl_cons[i] once the island list is sorted
     int *isl_cg1, *isl_cg2, *isl_cl1, *isl_cl2; // [pool] per sorted manifold: attached body of each side (arena / island-local index, -1 = world)
     int *isl_inc_pos, *isl_inc_begin, *isl_inc_cnt; // warm-start rows: per lane (2m + side) its row = rank in its body's sweep-ordered list ([2*pool]); per island body the row range ([n_bodies] x2)
+    int *r_ni, *isl_ni, *isl_icons_begin, *isl_fill_i, *isl_icons; // inactive pairs (no solver contact) owned by an island: recycle-tested by the fused fast step
     int *isl_sorted, *isl_nstages; // per island: list sorted by sweep stage?, number of local stages
 
     // ---- impulse joints (active joints only, edge order) ----
