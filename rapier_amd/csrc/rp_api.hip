@@ -732,7 +732,9 @@ static int launch_step(rp_world *w, int fast) {
         }
         return RP_OK;
     }
-    if (!w->use_graph) { enqueue_whole(w); HIPCHK(w, hipGetLastError()); return RP_OK; }
+    // a fused fast step is ONE kernel: launched directly (a one-node graph replay costs more than the launch)
+    static const bool fused_eager = getenv("RP_FUSED_GRAPH") == nullptr;
+    if (!w->use_graph || (fast && w->plan_fused && fused_eager)) { enqueue_whole(w); HIPCHK(w, hipGetLastError()); return RP_OK; }
     static const bool dbg = getenv("RP_DEBUG") != nullptr;
     if (!w->ge_whole[fast]) {
         if (dbg) fprintf(stderr, "RPDBG capture fast=%d seq=%lld stages=%d blocks=%d single=%d grid=%d jst=%d\n", fast, w->seq_enqueued, w->plan_stages, w->plan_blocks, w->plan_single, w->plan_island_grid, w->plan_joint_stages);
