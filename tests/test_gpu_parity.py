@@ -191,6 +191,35 @@ def test_fast_path_abort_and_replay_bit_exact():
     assert c1["full_steps"] > c0["full_steps"]
 
 
+def test_fused_step_with_more_islands_than_workgroups():
+    """16 x 16 pyramids = 256 islands > the 240 co-resident workgroups of the fused fast step: some
+    workgroups own two islands (the second one is validated in the prologue, before the arrival)."""
+    import os
+    import oracle_ffi
+    sc = S.many_pyramids(rows=16, cols=16)
+    oracle_ffi.set_threads(max(1, min(os.cpu_count() or 1, 16)))
+    try:
+        g, _ = _compare(sc, [30, 160])
+    finally:
+        oracle_ffi.set_threads(1)
+    c = g.counters()
+    assert c["fast_steps"] > 60 and c["replayed_steps"] == 0, c
+
+
+def test_fused_and_unfused_fast_paths_agree(monkeypatch):
+    sc = S.many_pyramids(rows=2, cols=3)
+    a = PhysicsWorld.from_scene(sc)
+    a.step(150)
+    pa, va = a.read_bodies()
+    monkeypatch.setenv("RP_NO_FUSED", "1")
+    b = PhysicsWorld.from_scene(sc)
+    b.step(150)
+    pb, vb = b.read_bodies()
+    assert a.counters()["fast_steps"] > 50 and b.counters()["fast_steps"] > 50
+    np.testing.assert_array_equal(pa, pb)
+    np.testing.assert_array_equal(va, vb)
+
+
 def test_fast_and_full_graphs_agree(monkeypatch):
     sc = S.many_pyramids(rows=2, cols=2)
     a = PhysicsWorld.from_scene(sc)
