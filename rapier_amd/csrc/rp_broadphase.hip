@@ -37,7 +37,9 @@ __device__ __forceinline__ CellRange cell_range(const DevWorld &w, int i) {
 
 __global__ void k_collider_update(DevWorld w) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) w.flags[FL_FAST_ABORT] = 0; // a full step is starting: the fast path may be tried again later
+    if (i == 0) { // a full step is starting: the fast path may be tried again later; per-step narrow-phase counters (k_np_begin)
+        w.flags[FL_FAST_ABORT] = 0; w.flags[FL_FULL_UPDATES] = 0; w.flags[FL_TODO_COUNT] = 0;
+    }
     if (i >= w.n_colliders) return;
     collider_update_one(w, i);
 }
@@ -210,11 +212,27 @@ __device__ void bp_insert_pair(DevWorld &w, int c1, int c2) {
     atomicOr(&w.flags[FL_OVERFLOW], RP_OVF_HASH);
 }
 
+// Colliders spanning > 3 cells (ground slabs, walls) against everything: looping over the (short) large list.
+__device__ void bp_pairs_vs_large(DevWorld &w, int i, bool i_large) {
+    int nl = w.flags[FL_N_LARGE];
+    if (nl > w.large_cap) nl = w.large_cap;
+    for (int k = 0; k < nl; ++k) {
+        int L = w.large_list[k];
+        if (L == i) continue;
+        if (i_large && i > L) continue; // large-large pairs reported from the lower index
+        V3 imin;
+        if (!fat_overlap(w, i, L, imin)) continue;
+        if (!pair_allowed(w, i, L)) continue;
+        bp_insert_pair(w, i < L ? i : L, i < L ? L : i);
+    }
+}
+
 __global__ void k_bp_pairs(DevWorld w) {
     if (!w.flags[FL_BP_DIRTY]) return;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= w.n_colliders) return;
     CellRange r = cell_range(w, i);
+    bp_pairs_vs_large(w, i, r.large);
     if (r.large) return;
     float ic = w.prm.inv_cell_size;
     for (int z = r.lo[2]; z <= r.hi[2]; ++z)
@@ -236,27 +254,6 @@ __global__ void k_bp_pairs(DevWorld w) {
                     bp_insert_pair(w, i, j);
                 }
             }
-}
-
-// Colliders spanning > 3 cells (ground slabs, walls) against everything: one thread per collider,
-// looping over the (short) large list.
-__global__ void k_bp_pairs_large(DevWorld w) {
-    if (!w.flags[FL_BP_DIRTY]) return;
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= w.n_colliders) return;
-    int nl = w.flags[FL_N_LARGE];
-    if (nl > w.large_cap) nl = w.large_cap;
-    if (nl == 0) return;
-    bool i_large = cell_range(w, i).large;
-    for (int k = 0; k < nl; ++k) {
-        int L = w.large_list[k];
-        if (L == i) continue;
-        if (i_large && i > L) continue; // large-large pairs reported from the lower index
-        V3 imin;
-        if (!fat_overlap(w, i, L, imin)) continue;
-        if (!pair_allowed(w, i, L)) continue;
-        bp_insert_pair(w, i < L ? i : L, i < L ? L : i);
-    }
 }
 
 // DeletePair: slots not re-stamped by this rebuild are dead (NarrowPhase::remove_pair,
@@ -282,12 +279,17 @@ __global__ void k_bp_finish_pairs(DevWorld w) {
         int t = atomicAdd(&w.flags[FL_FREE_TOP], 1);
         w.free_stack[t] = s;
     }
-}
-__global__ void k_bp_finish(DevWorld w) {
-    if (!w.flags[FL_BP_DIRTY]) return;
-    w.flags[FL_BP_EPOCH] += 1;
-    w.flags[FL_BP_DIRTY] = 0;
-    w.flags[FL_BP_REBUILDS] += 1;
+    // the last workgroup to finish closes the rebuild (epoch flip, dirty flag)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&w.flags[FL_TICKET], 1) == (int)gridDim.x - 1) {
+            w.flags[FL_TICKET] = 0;
+            w.flags[FL_BP_EPOCH] = epoch + 1;
+            w.flags[FL_BP_REBUILDS] += 1;
+            __hip_atomic_store(&w.flags[FL_BP_DIRTY], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 void rp_launch_collider_update(const DevWorld &w, hipStream_t st) {
@@ -316,8 +318,6 @@ void rp_launch_broadphase(const DevWorld &w, hipStream_t st) {
     hipLaunchKernelGGL(k_scan_add, dim3(scan_blocks), dim3(1024), 0, st, w);
     hipLaunchKernelGGL(k_bp_fill, dim3(nb), dim3(256), 0, st, w);
     hipLaunchKernelGGL(k_bp_pairs, dim3(nb), dim3(256), 0, st, w);
-    hipLaunchKernelGGL(k_bp_pairs_large, dim3(nb), dim3(256), 0, st, w);
     int fin_blocks = (w.pool_cap + 255) / 256; if (fin_blocks > 1024) fin_blocks = 1024;
     hipLaunchKernelGGL(k_bp_finish_pairs, dim3(fin_blocks), dim3(256), 0, st, w);
-    hipLaunchKernelGGL(k_bp_finish, dim3(1), dim3(1), 0, st, w);
 }

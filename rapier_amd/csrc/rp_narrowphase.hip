@@ -635,13 +635,18 @@ __global__ void k_bucket_scatter(DevWorld w) {
         int pos = base[color] + atomicAdd(&cnt[color], 1);
         if (pos < w.cons_cap) { w.cons_pair[pos] = s; w.p_conspos[s] = pos; }
     }
+    // the last workgroup to finish closes the layout rebuild (k_bucket_finish)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&w.flags[FL_TICKET], 1) == (int)gridDim.x - 1) { w.flags[FL_TICKET] = 0; __hip_atomic_store(&w.flags[FL_LAYOUT_DIRTY], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    }
 }
 __global__ void k_bucket_finish(DevWorld w) { w.flags[FL_LAYOUT_DIRTY] = 0; }
 
 void rp_launch_narrowphase(const DevWorld &w, hipStream_t st) {
     if (w.n_colliders == 0) return;
     int blocks = (w.pool_cap + 255) / 256; if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_np_begin, dim3(1), dim3(1), 0, st, w);
     hipLaunchKernelGGL(k_np_pairs, dim3(blocks), dim3(256), 0, st, w);
     hipLaunchKernelGGL(k_color_pairs, dim3(1), dim3(1024), 0, st, w);
     rp_launch_joint_coloring(w, st); // joints avoid this step's contact colours (init_joints, joints.rs:25-329)
@@ -650,5 +655,4 @@ void rp_launch_narrowphase(const DevWorld &w, hipStream_t st) {
     rp_launch_islands_build(w, st);
     hipLaunchKernelGGL(k_bucket_layout, dim3(1), dim3(64), 0, st, w);
     hipLaunchKernelGGL(k_bucket_scatter, dim3(blocks), dim3(256), 0, st, w);
-    hipLaunchKernelGGL(k_bucket_finish, dim3(1), dim3(1), 0, st, w);
 }

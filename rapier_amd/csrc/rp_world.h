@@ -71,6 +71,7 @@ enum {
     FL_NJ_STAGES, FL_NJ_OVF_BEGIN, FL_NJ_OVF_COUNT, // joint stage layout: parallel colours, serial overflow range in j_order
     FL_ARRIVE, FL_DEPART, // fused fast step: workgroups that validated their islands / that finished (reset by the last one)
     FL_ISL_ICONS_CURSOR,
+    FL_TICKET,          // last-workgroup-done ticket (one user at a time: kernels of a step are serialised)
     FL_FAST_ABORT,      // steady-state fast path found work it cannot do (see rp_api.hip); sticky until a full step
     FL_COUNT = 48
 };
