@@ -73,6 +73,7 @@ typedef struct rp_body_desc {
     int32_t dominance;
     int32_t gyroscopic;
     int32_t allow_fast_rotation;
+    int32_t can_sleep; /* RigidBodyBuilder::can_sleep (rigid_body.rs:1845): 1 = RigidBodyActivation::active(), 0 = cannot_sleep() */
 } rp_body_desc;
 
 /* ColliderBuilder — /root/reference/src/geometry/collider.rs:600-1130 */
@@ -120,6 +121,7 @@ typedef struct rp_counters {
     int32_t fast_steps;            /* step graphs enqueued on the steady-state fast path */
     int32_t full_steps;            /* step graphs enqueued on the full path */
     int32_t replayed_steps;        /* fast steps that gave up on the device and were replayed on the full path */
+    int32_t num_sleeping_bodies;   /* dynamic bodies asleep (IslandManager: bodies outside the active set) */
 } rp_counters;
 
 #define RP_INVALID_HANDLE 0xffffffffffffffffull
@@ -164,8 +166,19 @@ int32_t rp_sync(rp_world *w);
 /* RigidBody::position()/linvel()/angvel() for n handles (NULL handles = all bodies in arena order):
  * pos7 = tx,ty,tz,qx,qy,qz,qw ; vel6 = linvel, angvel.  Synchronises. */
 int32_t rp_bodies_read(rp_world *w, int32_t n, const uint64_t *handles, float *pos7_out, float *vel6_out);
-/* RigidBody::set_linvel/set_angvel/set_position (user changes).  NULL arrays are left untouched. */
+/* RigidBody::set_linvel/set_angvel/set_position(.., wake_up = true) (user changes).  NULL arrays are left
+ * untouched.  The written bodies are woken (strong); a moved body also wakes every body it has a contact
+ * pair with (pair_management.rs:236-258). */
 int32_t rp_bodies_write(rp_world *w, int32_t n, const uint64_t *handles, const float *pos7, const float *vel6);
+/* Sleeping — RigidBodyActivation (rigid_body_components.rs:1300-1480), whole-island sleep
+ * (island_manager/manager.rs:335-388, sleep.rs).  Bodies built with can_sleep = 1 fall asleep with their whole
+ * contact island once EVERY member stayed below the motion thresholds for time_until_sleep (0.5 s), and wake
+ * island-wide on a begin-touch, a deleted touching pair, a removed collider or a user change.
+ * rp_bodies_wake_up = IslandManager::wake_up(handle, strong) (sleep.rs:31), effective at the next step;
+ * rp_bodies_is_sleeping = RigidBody::is_sleeping (NULL handles are not accepted).  Scope: impulse joints in a
+ * world with can_sleep bodies are refused with RP_ERR_INVALID. */
+int32_t rp_bodies_wake_up(rp_world *w, int32_t n, const uint64_t *handles, int32_t strong);
+int32_t rp_bodies_is_sleeping(rp_world *w, int32_t n, const uint64_t *handles, int32_t *sleeping_out);
 int32_t rp_num_bodies(const rp_world *w);
 
 /* NarrowPhase::contact_pairs() analogue: for each active solver manifold: (collider1, collider2,

@@ -61,7 +61,14 @@ typedef struct {
     float linear_damping, angular_damping, gravity_scale, additional_mass;
     int dominance, gyroscopic, allow_fast_rotation;
     int ncolliders, first_collider;
-    uint32_t solver_id; /* active_set_id, RO_NO_BODY for non-dynamic */
+    uint32_t solver_id; /* active_set_id, RO_NO_BODY for bodies outside the active set */
+    /* RigidBodyActivation — rigid_body_components.rs:1300-1480 */
+    float normalized_linear_threshold, angular_threshold, time_until_sleep, time_since_can_sleep;
+    int sleeping; pose sleep_prev_pose;
+    float max_extent;   /* RigidBodyMassProps::max_extent — rigid_body_components.rs:491-515 */
+    int slept_at;       /* step at which the body last fell asleep (pair hints cleared then) */
+    int sleep_label;    /* island label: smallest body index of the connected component */
+    int wake_req;       /* pending IslandManager::wake_up */
 } Body;
 
 typedef struct { v3 mins, maxs; } Aabb;
@@ -88,6 +95,7 @@ typedef struct {
     /* recycle state — contact_pair.rs:262-278 */
     int has_recycle; pose rec_pos12; quat rec_rot1, rec_rot2; float rec_max_extent, rec_max_drift;
     uint8_t color; uint32_t color_bodies[2];
+    int hint_seq;       /* step at which pair_solver_hints[edge] was last computed (pair_update.rs:141-161,636-650) */
 } Pair;
 
 /* ContactWithTwistFriction + builder, one lane — contact_with_twist_friction.rs:18-55,600-630 */
@@ -156,6 +164,8 @@ struct ro_world {
     int *joint_order; int njoint_parallel;         /* solve order: parallel colours ascending, then the serial overflow */
     JointRow *joint_rows; u128 *joint_body_colors;
     ro_stats stats;
+    int step_seq;       /* 1-based number of the step in progress */
+    int *uf;            /* union-find scratch of the sleep islands */
 };
 
 /* ------------------------------------------------------------------------------------ */
@@ -232,7 +242,7 @@ void ro_world_free(ro_world *w) {
     free(w->bodies); free(w->colliders); free(w->pairs); free(w->map_keys); free(w->map_vals);
     free(w->color_masks); free(w->vels); free(w->incr); free(w->poses); free(w->gyro); free(w->flags);
     free(w->dyn_bodies); free(w->cons); free(w->joints); free(w->active_joints); free(w->joint_order);
-    free(w->joint_rows); free(w->joint_body_colors); free(w);
+    free(w->joint_rows); free(w->joint_body_colors); free(w->uf); free(w);
 }
 
 /* parry MassProperties::world_inv_inertia */
@@ -298,6 +308,8 @@ static void recompute_mass_properties(ro_world *w, Body *b) {
         }
     }
     b->local_com = V3(0, 0, 0);
+    /* recompute_max_extent: bounding sphere of the attached shape about the local CoM (collider at the body origin) */
+    b->max_extent = c0 ? (c0->shape == RO_SHAPE_CUBOID ? vlen(c0->he) : c0->radius) : 0.0f;
     b->inv_mass = ro_inv(mass);
     b->inv_principal_inertia = V3(ro_inv(pi.x), ro_inv(pi.y), ro_inv(pi.z));
     b->principal_frame = qident();
@@ -322,6 +334,11 @@ int32_t ro_add_body(ro_world *w, const ro_body_desc *d) {
     b->dominance = d->dominance; b->gyroscopic = d->gyroscopic; b->allow_fast_rotation = d->allow_fast_rotation;
     b->principal_frame = qident();
     b->solver_id = RO_NO_BODY;
+    /* RigidBodyActivation::active() / cannot_sleep() — rigid_body_components.rs:1354-1385 */
+    b->normalized_linear_threshold = d->can_sleep ? 0.05f : -1.0f;
+    b->angular_threshold = d->can_sleep ? 0.5f : -1.0f;
+    b->time_until_sleep = 0.5f; b->time_since_can_sleep = 0.0f; b->sleeping = 0;
+    b->sleep_prev_pose = pose_ident(); b->sleep_label = w->nbodies; b->slept_at = 0;
     recompute_mass_properties(w, b);
     return w->nbodies++;
 }
@@ -366,9 +383,40 @@ void ro_read_bodies(const ro_world *w, float *pos7, float *vel6) {
         }
     }
 }
+static void wake_request(ro_world *w, int body, int strong);
 void ro_set_body_vel(ro_world *w, int32_t body, const float lv[3], const float av[3]) {
     w->bodies[body].linvel = V3(lv[0], lv[1], lv[2]);
     w->bodies[body].angvel = V3(av[0], av[1], av[2]);
+    wake_request(w, body, 1); /* set_linvel(.., wake_up = true) -> RigidBody::wake_up(true) */
+}
+static void bp_set_aabb(ro_world *w, Collider *c);
+static void update_world_mass_properties(Body *b);
+/* RigidBody::set_position(.., wake_up = true) + user_changes.rs: world mass properties, collider poses and AABBs follow;
+ * the body is woken and so is every body it has a contact pair with (pair_management.rs:236-258). */
+void ro_set_body_pose(ro_world *w, int32_t body, const float pos7[7]) {
+    Body *b = &w->bodies[body];
+    b->position.t = V3(pos7[0], pos7[1], pos7[2]);
+    b->position.r = Q(pos7[3], pos7[4], pos7[5], pos7[6]);
+    b->next_position = b->position;
+    update_world_mass_properties(b);
+    for (int i = 0; i < w->ncolliders; ++i) {
+        Collider *c = &w->colliders[i];
+        if (c->parent != body) continue;
+        c->pos = pose_mul(b->position, c->pos_wrt_parent);
+        bp_set_aabb(w, c);
+    }
+    wake_request(w, body, 1);
+    for (int i = 0; i < w->npairs; ++i) {
+        const Pair *p = &w->pairs[i];
+        if (!p->alive) continue;
+        int b1 = w->colliders[p->c1].parent, b2 = w->colliders[p->c2].parent;
+        if (b1 == body) wake_request(w, b2, 1);
+        if (b2 == body) wake_request(w, b1, 1);
+    }
+}
+void ro_wake_up(ro_world *w, int32_t body, int32_t strong) { if (body >= 0 && body < w->nbodies) wake_request(w, body, strong); }
+void ro_read_sleeping(const ro_world *w, int32_t *sleeping) {
+    for (int i = 0; i < w->nbodies; ++i) sleeping[i] = w->bodies[i].body_type == RO_BODY_DYNAMIC && w->bodies[i].sleeping;
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -439,6 +487,22 @@ static void map_rebuild(ro_world *w) {
 }
 
 static int body_is_dynamic(const ro_world *w, int parent) { return parent >= 0 && w->bodies[parent].body_type == RO_BODY_DYNAMIC; }
+/* member of the active set: an awake dynamic body (IslandManager::active_bodies) */
+static int body_is_active(const ro_world *w, int body) { return body >= 0 && w->bodies[body].body_type == RO_BODY_DYNAMIC && !w->bodies[body].sleeping; }
+static int body_is_sleeping_dyn(const ro_world *w, int body) { return body >= 0 && w->bodies[body].body_type == RO_BODY_DYNAMIC && w->bodies[body].sleeping; }
+/* pair_solver_hints count cleared by clear_asleep_pair_solver_hint_counts_of (solver_graph.rs:21-49): one of the
+ * pair's bodies fell asleep after the hint was last computed */
+static int pair_hint_cleared(const ro_world *w, const Pair *p) {
+    int b1 = w->colliders[p->c1].parent, b2 = w->colliders[p->c2].parent;
+    int s1 = b1 >= 0 ? w->bodies[b1].slept_at : 0, s2 = b2 >= 0 ? w->bodies[b2].slept_at : 0;
+    return (s1 > s2 ? s1 : s2) >= p->hint_seq;
+}
+/* for_each_desired_manifold (solver_graph.rs:517-571) + qualify_manifold_bqi (:101-124) */
+static int pair_selected(const ro_world *w, const Pair *p) {
+    if (!p->alive || p->nsc == 0 || p->color == RO_COLOR_UNCOLORED) return 0;
+    if (pair_hint_cleared(w, p)) return 0;
+    return body_is_active(w, w->colliders[p->c1].parent) || body_is_active(w, w->colliders[p->c2].parent);
+}
 
 /* update.rs:334-396 pair filter (same parent, collision types, groups) */
 static int bp_pair_allowed(const ro_world *w, const Collider *a, const Collider *b) {
@@ -454,6 +518,35 @@ static int sweep_cmp(const void *a, const void *b) {
     if (x->minx < y->minx) return -1; if (x->minx > y->minx) return 1; return x->idx - y->idx;
 }
 static void clear_pair_solver_color(ro_world *w, Pair *p);
+
+/* ---- sleeping: IslandManager::wake_up (island_manager/sleep.rs:31-79) --------------------------------
+ * Requests are collected per body (1 = weak, 2 = strong) and applied island-wide by apply_wakes: waking
+ * any body of a sleeping island wakes the whole island with a strong timer reset for every member; a
+ * strong wake of an awake body only resets its own timer. */
+static void wake_request(ro_world *w, int body, int strong) {
+    if (body < 0 || w->bodies[body].body_type != RO_BODY_DYNAMIC) return;
+    int lvl = strong ? 2 : 1;
+    if (w->bodies[body].wake_req < lvl) w->bodies[body].wake_req = lvl;
+}
+static void apply_wakes(ro_world *w) {
+    int any = 0;
+    for (int i = 0; i < w->nbodies; ++i) if (w->bodies[i].wake_req) { any = 1; break; }
+    if (!any) return;
+    w->uf = (int *)realloc(w->uf, sizeof(int) * (size_t)(w->nbodies + 1));
+    int *woken = w->uf; /* scratch: label -> woken this pass */
+    for (int i = 0; i < w->nbodies; ++i) woken[i] = 0;
+    for (int i = 0; i < w->nbodies; ++i) {
+        Body *b = &w->bodies[i];
+        if (!b->wake_req) continue;
+        if (b->sleeping) woken[b->sleep_label] = 1;
+        else if (b->wake_req == 2) b->time_since_can_sleep = 0.0f; /* RigidBodyActivation::wake_up(strong) */
+        b->wake_req = 0;
+    }
+    for (int i = 0; i < w->nbodies; ++i) {
+        Body *b = &w->bodies[i];
+        if (b->body_type == RO_BODY_DYNAMIC && b->sleeping && woken[b->sleep_label]) { b->sleeping = 0; b->time_since_can_sleep = 0.0f; }
+    }
+}
 
 static void broad_phase_update(ro_world *w) {
     for (int i = 0; i < w->ncolliders; ++i) if (!w->colliders[i].has_fat) bp_set_aabb(w, &w->colliders[i]);
@@ -494,7 +587,15 @@ static void broad_phase_update(ro_world *w) {
     /* DeletePair: NarrowPhase::remove_pair (pair_management.rs:382) frees the colour and drops the edge. */
     int out = 0, removed = 0;
     for (int i = 0; i < w->npairs; ++i) {
-        if (!w->pairs[i].alive) { clear_pair_solver_color(w, &w->pairs[i]); removed = 1; continue; }
+        if (!w->pairs[i].alive) {
+            Pair *p = &w->pairs[i];
+            const Collider *a = &w->colliders[p->c1], *b = &w->colliders[p->c2];
+            /* remove_pair wakes the bodies of a touching pair (pair_management.rs:541-552); remove_collider wakes
+             * every body that had a pair with the removed collider (:88-99) */
+            int gone = (a->memberships == 0 && a->filter == 0) || (b->memberships == 0 && b->filter == 0);
+            if (p->nsc > 0 || gone) { wake_request(w, a->parent, 1); wake_request(w, b->parent, 1); }
+            clear_pair_solver_color(w, p); removed = 1; continue;
+        }
         if (out != i) w->pairs[out] = w->pairs[i];
         out++;
     }
@@ -608,15 +709,19 @@ static int process_pair(ro_world *w, int pair_idx, Transition *tr_out) {
     const ro_params *prm = &w->params;
     float prediction = prm->normalized_prediction_distance * prm->length_unit;
     float recycle_dist = prm->contact_recycling ? prm->normalized_contact_recycle_distance * prm->length_unit : 0.0f;
-    /* :98-106 — neither body awake (non-dynamic): skipped */
-    if (!body_is_dynamic(w, co1->parent) && !body_is_dynamic(w, co2->parent)) return 2;
+    /* :98-106 — neither body awake (fixed or asleep): skipped */
+    if (!body_is_active(w, co1->parent) && !body_is_active(w, co2->parent)) return 2;
 
     /* :111-171 contact recycling */
     if (recycle_dist > 0.0f && p->has_recycle) {
         pose pos12 = pose_inv_mul(co1->pos, co2->pos);
         float drift = relative_pose_drift(p->rec_pos12, pos12, p->rec_max_extent);
         float rot_cos = ro_minf(relative_rot_cos(p->rec_rot1, co1->pos.r), relative_rot_cos(p->rec_rot2, co2->pos.r));
-        if (drift <= p->rec_max_drift && rot_cos > 0.98f) return 0;
+        if (drift <= p->rec_max_drift && rot_cos > 0.98f) {
+            /* :141-161 a count-cleared hint (the pair slept) is recomputed: the pair re-enters the selection */
+            if (pair_hint_cleared(w, p)) p->hint_seq = w->step_seq;
+            return 0;
+        }
     }
     int had = p->nsc > 0;
     int rb1 = co1->parent, rb2 = co2->parent;
@@ -705,6 +810,7 @@ static int process_pair(ro_world *w, int pair_idx, Transition *tr_out) {
         p->rec_pos12 = pos12; p->rec_rot1 = co1->pos.r; p->rec_rot2 = co2->pos.r; p->rec_max_extent = max_extent;
         p->has_recycle = 1;
     }
+    p->hint_seq = w->step_seq; /* :636-650 hint refreshed from the final state */
     /* :622-629 begin/end-touch transition */
     int has = p->nsc > 0;
     if (has != had) {
@@ -737,6 +843,9 @@ static void narrow_phase_compute_contacts(ro_world *w) {
     for (int i = 0; i < ntr; ++i) {
         Pair *p = &w->pairs[tr[i].pair];
         if (!tr[i].touching) { clear_pair_solver_color(w, p); continue; }
+        /* wake rule (contacts.rs:333-351): starts wake the sleeping side strongly (whole island), stops never wake */
+        if (body_is_sleeping_dyn(w, tr[i].body1)) wake_request(w, tr[i].body1, 1);
+        if (body_is_sleeping_dyn(w, tr[i].body2)) wake_request(w, tr[i].body2, 1);
         uint32_t a = tr[i].body1 >= 0 ? (uint32_t)tr[i].body1 : RO_NO_BODY;
         uint32_t b = tr[i].body2 >= 0 ? (uint32_t)tr[i].body2 : RO_NO_BODY;
         uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
@@ -1078,7 +1187,7 @@ static v3 gyroscopic_corrected_angvel(v3 angvel, quat principal_axes, v3 pi, v3 
 /* ------------------------------------------------------------------------------------ */
 /* Impulse joints */
 
-/* ImpulseJointSet::select_active_interactions — impulse_joint_set.rs:504-572 (no sleeping in scope):
+/* ImpulseJointSet::select_active_interactions — impulse_joint_set.rs:504-572:
  * enabled joints with at least one dynamic body, in edge (insertion) order; stamps solver-body ids. */
 static void joints_select_active(ro_world *w) {
     w->nactive_joints = 0;
@@ -1088,6 +1197,7 @@ static void joints_select_active(ro_world *w) {
         const Body *rb1 = &w->bodies[j->body1], *rb2 = &w->bodies[j->body2];
         int d1 = rb1->body_type == RO_BODY_DYNAMIC, d2 = rb2->body_type == RO_BODY_DYNAMIC;
         if (!d1 && !d2) continue;
+        if ((d1 && rb1->sleeping) || (d2 && rb2->sleeping)) continue; /* :553-556 */
         j->solver_body_ids[0] = d1 ? rb1->solver_id : RO_NO_BODY;
         j->solver_body_ids[1] = d2 ? rb2->solver_id : RO_NO_BODY;
         w->active_joints[w->nactive_joints++] = i;
@@ -1275,23 +1385,23 @@ static void solve_velocity_constraints(ro_world *w) {
     int num_substeps = prm->num_solver_iterations;
     float dt_s = prm->dt / (float)num_substeps;
 
-    /* active set = dynamic bodies in arena order (never-sleeping scope), manager.rs:20-39 */
+    /* active set = awake dynamic bodies in arena order, manager.rs:20-39 */
     int nd = 0;
-    for (int i = 0; i < w->nbodies; ++i) if (w->bodies[i].body_type == RO_BODY_DYNAMIC) nd++;
+    for (int i = 0; i < w->nbodies; ++i) if (body_is_active(w, i)) nd++;
     /* maintain_solver_contact_graph — solver_graph.rs:129-361: buckets of active manifolds per colour,
      * full-rebuild order = ascending (edge, manifold) */
     int counts[RO_NUM_COLORS]; memset(counts, 0, sizeof(counts));
     int M = 0, nsc = 0;
     for (int i = 0; i < w->npairs; ++i) {
         Pair *p = &w->pairs[i];
-        if (p->nsc == 0 || p->color == RO_COLOR_UNCOLORED) continue;
+        if (!pair_selected(w, p)) continue;
         counts[p->color]++; M++; nsc += p->nsc;
     }
     solver_reserve(w, nd, M);
     nd = 0;
     for (int i = 0; i < w->nbodies; ++i) {
         Body *b = &w->bodies[i];
-        if (b->body_type == RO_BODY_DYNAMIC) { b->solver_id = (uint32_t)nd; w->dyn_bodies[nd++] = i; } else b->solver_id = RO_NO_BODY;
+        if (body_is_active(w, i)) { b->solver_id = (uint32_t)nd; w->dyn_bodies[nd++] = i; } else b->solver_id = RO_NO_BODY;
     }
     w->ndyn = nd;
     w->bucket_begin[0] = 0;
@@ -1300,7 +1410,7 @@ static void solve_velocity_constraints(ro_world *w) {
     int *order = (int *)malloc(sizeof(int) * (M + 1));
     for (int i = 0; i < w->npairs; ++i) {
         Pair *p = &w->pairs[i];
-        if (p->nsc == 0 || p->color == RO_COLOR_UNCOLORED) continue;
+        if (!pair_selected(w, p)) continue;
         /* qualify_manifold_bqi — solver_contact_graph.rs:101-124 */
         int b1 = w->colliders[p->c1].parent, b2 = w->colliders[p->c2].parent;
         p->solver_body_ids[0] = b1 >= 0 ? w->bodies[b1].solver_id : RO_NO_BODY;
@@ -1446,15 +1556,78 @@ static void solve_velocity_constraints(ro_world *w) {
     }
 }
 
+/* Whole-island sleep (manager.rs:335-388, solve.rs:196-300).  The reference maintains persistent islands
+ * incrementally (merge on begin-touch / joint link, deferred split on end-touch); the sleep decision only
+ * needs the partition, so it is recomputed here exactly — connected components of the awake dynamic bodies
+ * over touching pairs and joints — which is the partition the reference converges to once its pending splits
+ * are resolved (the split cooldown of persistent.rs:31 only delays a sleep by <= 16 steps).  Label = the
+ * smallest body index of the component. */
+static int uf_find(int *uf, int x) { while (uf[x] != x) { uf[x] = uf[uf[x]]; x = uf[x]; } return x; }
+static void uf_union(int *uf, int a, int b) { a = uf_find(uf, a); b = uf_find(uf, b); if (a == b) return; if (a < b) uf[b] = a; else uf[a] = b; }
+static void update_sleep(ro_world *w) {
+    const float dt = w->params.dt, length_unit = w->params.length_unit;
+    int n = w->nbodies, any_can_sleep = 0;
+    /* update_body_energy (manager.rs:320-333) -> RigidBodyActivation::update_energy (rigid_body_components.rs:1412-1478) */
+    for (int i = 0; i < n; ++i) {
+        Body *b = &w->bodies[i];
+        if (!body_is_active(w, i)) continue;
+        float linear_threshold = b->normalized_linear_threshold * length_unit;
+        pose prev = b->sleep_prev_pose; b->sleep_prev_pose = b->position;
+        float sq_angvel = vdot(b->angvel, b->angvel);
+        int angular_ok;
+        if (b->max_extent > 0.0f) angular_ok = b->angular_threshold >= 0.0f && sq_angvel < 1.5707964f * 1.5707964f;
+        else angular_ok = sq_angvel < b->angular_threshold * fabsf(b->angular_threshold);
+        float drift = relative_pose_drift(prev, b->position, b->max_extent);
+        int can_sleep = angular_ok && drift * 0.5f < linear_threshold * dt;
+        if (can_sleep) b->time_since_can_sleep += dt; else b->time_since_can_sleep = 0.0f;
+        any_can_sleep |= b->normalized_linear_threshold >= 0.0f;
+    }
+    if (!any_can_sleep) return;
+    w->uf = (int *)realloc(w->uf, sizeof(int) * (size_t)(2 * n + 2));
+    int *uf = w->uf, *awake = w->uf + n + 1;
+    for (int i = 0; i < n; ++i) { uf[i] = i; awake[i] = 0; }
+    for (int i = 0; i < w->npairs; ++i) {
+        const Pair *p = &w->pairs[i];
+        if (!p->alive || p->nsc == 0) continue;
+        int b1 = w->colliders[p->c1].parent, b2 = w->colliders[p->c2].parent;
+        if (body_is_active(w, b1) && body_is_active(w, b2)) uf_union(uf, b1, b2);
+    }
+    for (int i = 0; i < w->njoints; ++i) {
+        const Joint *j = &w->joints[i];
+        if (!j->removed && body_is_active(w, j->body1) && body_is_active(w, j->body2)) uf_union(uf, j->body1, j->body2);
+    }
+    /* observe_body_for_sleep: an island sleeps once EVERY body is eligible (time_since_can_sleep >= time_until_sleep) */
+    for (int i = 0; i < n; ++i) {
+        const Body *b = &w->bodies[i];
+        if (body_is_active(w, i) && !(b->time_since_can_sleep >= b->time_until_sleep)) awake[uf_find(uf, i)] = 1;
+    }
+    /* commit_sleeping_chunks -> RigidBody::sleep (rigid_body.rs:804-807) + clear_asleep_pair_solver_hint_counts_of */
+    for (int i = 0; i < n; ++i) {
+        Body *b = &w->bodies[i];
+        if (!body_is_active(w, i)) continue;
+        int root = uf_find(uf, i);
+        if (awake[root]) continue;
+        b->sleeping = 1; b->time_since_can_sleep = b->time_until_sleep;
+        b->linvel = V3(0, 0, 0); b->angvel = V3(0, 0, 0);
+        b->sleep_label = root; b->slept_at = w->step_seq;
+    }
+}
+
 /* PhysicsPipeline::step_inner — pipeline/physics_pipeline/substep.rs:267-581 */
 static void step_once(ro_world *w) {
-    /* detect_collisions — solve.rs:45-157 */
+    w->step_seq++;
+    /* detect_collisions — solve.rs:45-157 (user-requested wake-ups and pair deletions take effect before the
+     * narrow phase reads the awake mask) */
     broad_phase_update(w);
+    apply_wakes(w);
     narrow_phase_compute_contacts(w);
-    /* fused body pass — solve.rs:234-291; compute_effective_force_and_torque rigid_body_components.rs:1030-1033 */
+    apply_wakes(w);
+    /* fused body pass — solve.rs:234-291: sleep timers, then the island sleep decision (update_islands) */
+    update_sleep(w);
+    /* compute_effective_force_and_torque rigid_body_components.rs:1030-1033 */
     for (int i = 0; i < w->nbodies; ++i) {
         Body *b = &w->bodies[i];
-        if (b->body_type != RO_BODY_DYNAMIC) continue;
+        if (!body_is_active(w, i)) continue;
         v3 mass = V3(ro_inv(b->effective_inv_mass.x), ro_inv(b->effective_inv_mass.y), ro_inv(b->effective_inv_mass.z));
         b->force = vadd(b->user_force, vmul(vcmul(w->gravity, mass), b->gravity_scale));
         b->torque = b->user_torque;
@@ -1463,13 +1636,13 @@ static void step_once(ro_world *w) {
     /* advance_to_final_positions — substep.rs:84-224; refresh_moved_collider_aabbs :229-240 */
     for (int i = 0; i < w->nbodies; ++i) {
         Body *b = &w->bodies[i];
-        if (b->body_type != RO_BODY_DYNAMIC) continue;
+        if (!body_is_active(w, i)) continue;
         b->position = b->next_position;
         update_world_mass_properties(b);
     }
     for (int i = 0; i < w->ncolliders; ++i) {
         Collider *c = &w->colliders[i];
-        if (c->parent < 0 || w->bodies[c->parent].body_type != RO_BODY_DYNAMIC) continue;
+        if (!body_is_active(w, c->parent)) continue;
         c->pos = pose_mul(w->bodies[c->parent].position, c->pos_wrt_parent);
         bp_set_aabb(w, c);
     }
@@ -1522,12 +1695,14 @@ int32_t ro_add_joint(ro_world *w, const ro_joint_desc *d) {
     j->local_frame2.r = qnormalize(Q(d->local_basis2[0], d->local_basis2[1], d->local_basis2[2], d->local_basis2[3]));
     j->locked_axes = d->locked_axes; j->contacts_enabled = d->contacts_enabled;
     j->solver_color = 255; /* default_solver_color: uncoloured */
+    wake_request(w, d->body1, 1); wake_request(w, d->body2, 1); /* insert(.., wake_up = true), substep.rs:289-300 */
     return w->njoints++;
 }
 /* ImpulseJointSet::remove (impulse_joint_set.rs:574-...): the joint stops being selected. */
 int32_t ro_remove_joint(ro_world *w, int32_t joint) {
     if (joint < 0 || joint >= w->njoints || w->joints[joint].removed) return -1;
     w->joints[joint].removed = 1;
+    wake_request(w, w->joints[joint].body1, 1); wake_request(w, w->joints[joint].body2, 1); /* remove(.., wake_up = true) */
     memset(w->joints[joint].impulses, 0, sizeof(w->joints[joint].impulses));
     return 0;
 }

@@ -64,6 +64,7 @@ typedef struct ro_body_desc {
     int32_t dominance;      /* i8 group */
     int32_t gyroscopic;     /* default 1 — rigid_body.rs:1579 */
     int32_t allow_fast_rotation;
+    int32_t can_sleep;      /* RigidBodyBuilder::can_sleep — RigidBodyActivation::active() vs cannot_sleep() */
 } ro_body_desc;
 
 typedef struct ro_collider_desc {
@@ -105,7 +106,14 @@ int32_t ro_get_threads(void);
 int32_t ro_num_bodies(const ro_world *w);
 /* pos7 = (tx,ty,tz, qx,qy,qz,qw) per body, vel6 = (lin, ang) per body, arena order. */
 void ro_read_bodies(const ro_world *w, float *pos7, float *vel6);
+/* RigidBody::set_linvel/set_angvel(.., wake_up = true) */
 void ro_set_body_vel(ro_world *w, int32_t body, const float linvel[3], const float angvel[3]);
+/* RigidBody::set_position(.., wake_up = true) */
+void ro_set_body_pose(ro_world *w, int32_t body, const float pos7[7]);
+/* IslandManager::wake_up (island_manager/sleep.rs:31): wakes the body's whole island. */
+void ro_wake_up(ro_world *w, int32_t body, int32_t strong);
+/* RigidBody::is_sleeping per body (arena order). */
+void ro_read_sleeping(const ro_world *w, int32_t *sleeping);
 
 /* Statistics of the last step (for DESIGN/bench: M and colour histogram). */
 typedef struct ro_stats {

@@ -20,7 +20,7 @@ SYMBOLS = [
     "rp_params_set", "rp_bodies_insert", "rp_colliders_insert", "rp_impulse_joints_insert",
     "rp_impulse_joints_read", "rp_bodies_remove", "rp_colliders_remove", "rp_impulse_joints_remove",
     "rp_quarantine_read", "rp_step",
-    "rp_sync", "rp_bodies_read", "rp_bodies_write", "rp_num_bodies", "rp_contacts_read",
+    "rp_sync", "rp_bodies_read", "rp_bodies_write", "rp_bodies_wake_up", "rp_bodies_is_sleeping", "rp_num_bodies", "rp_contacts_read",
     "rp_counters_enable", "rp_counters_read", "rp_solver_loop_time_ms",
 ]
 
@@ -33,7 +33,7 @@ class Counters(C.Structure):
         "velocity_update_ms")] + [(n, C.c_int32) for n in (
         "num_pairs", "num_manifolds", "num_solver_contacts", "num_colors", "num_parallel_stages",
         "num_dynamic_bodies", "bp_rebuilds", "full_updates", "overflow_flags", "quarantined",
-        "fast_steps", "full_steps", "replayed_steps")]
+        "fast_steps", "full_steps", "replayed_steps", "num_sleeping_bodies")]
 
 
 _LIB = None
@@ -71,6 +71,8 @@ def lib():
     L.rp_sync.argtypes = [vp]
     L.rp_bodies_read.argtypes = [vp, i32, vp, vp, vp]
     L.rp_bodies_write.argtypes = [vp, i32, vp, vp, vp]
+    L.rp_bodies_wake_up.argtypes = [vp, i32, vp, i32]
+    L.rp_bodies_is_sleeping.argtypes = [vp, i32, vp, vp]
     L.rp_num_bodies.argtypes = [vp]
     L.rp_contacts_read.argtypes = [vp, i32, vp, vp, vp]
     L.rp_counters_enable.argtypes = [vp, i32]

@@ -38,8 +38,15 @@ void rp_launch_solver_writeback(const DevWorld &w, hipStream_t st);
 void rp_launch_island_solve(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast, int retire, int fused);
 void rp_launch_global_single(const DevWorld &w, hipStream_t st, int has_restitution, int fast);
 void rp_launch_fast_front(const DevWorld &w, hipStream_t st, int no_global_kernel);
+void rp_launch_wake(const DevWorld &w, hipStream_t st, int phase);
+void rp_launch_wake_partners(const DevWorld &w, hipStream_t st);
 
-struct HostBody { rp_body_desc d; float inv_mass; float inv_pi[3]; float lcom[3]; int ncolliders; bool removed; };
+struct HostBody {
+    rp_body_desc d; float inv_mass; float inv_pi[3]; float lcom[3]; int ncolliders; bool removed;
+    // RigidBodyActivation state carried across device rebuilds (rp_sleep.hip)
+    float max_extent = 0.0f, sleep_timer = 0.0f, sprev[7] = {0, 0, 0, 0, 0, 0, 1};
+    int sleeping = 0, slabel = 0;
+};
 
 struct rp_world {
     int device = 0;
@@ -95,6 +102,8 @@ static int upload_body_row(rp_world *w, int i);
 static int upload_body_row_mass(rp_world *w, int i);
 static int upload_collider_row(rp_world *w, int i);
 static int after_topology_edit(rp_world *w);
+static bool world_sleep_enabled(const rp_world *w);
+static int check_sleep_scope(rp_world *w);
 
 extern "C" void rp_default_params(rp_integration_params *p) {
     // IntegrationParameters::default() — integration_parameters.rs:379-408
@@ -281,6 +290,13 @@ static void recompute_mass(rp_world *w, int body) {
     }
     b.inv_mass = h_inv(mass);
     for (int q = 0; q < 3; ++q) { b.inv_pi[q] = h_inv(pi[q]); b.lcom[q] = 0.0f; }
+    // recompute_max_extent (rigid_body_components.rs:491-515): bounding sphere of the shape about the local CoM
+    b.max_extent = 0.0f;
+    if (c0) {
+        volatile float x2 = c0->half_extents[0] * c0->half_extents[0], y2 = c0->half_extents[1] * c0->half_extents[1], z2 = c0->half_extents[2] * c0->half_extents[2];
+        volatile float sxy = x2 + y2; volatile float sxyz = sxy + z2;
+        b.max_extent = c0->shape == RP_SHAPE_CUBOID ? std::sqrt(sxyz) : c0->half_extents[0];
+    }
 }
 
 // Bring the host mirrors up to date with the device (poses, velocities) before the device world is
@@ -295,6 +311,18 @@ static int download_state(rp_world *w) {
     HIPCHK(w, hipMemcpy(rot.data(), w->dw.b_rot, nb * sizeof(float4), hipMemcpyDeviceToHost));
     HIPCHK(w, hipMemcpy(lv.data(), w->dw.b_linvel, nb * sizeof(float4), hipMemcpyDeviceToHost));
     HIPCHK(w, hipMemcpy(av.data(), w->dw.b_angvel, nb * sizeof(float4), hipMemcpyDeviceToHost));
+    std::vector<float4> slp(nb), spt(nb), spr(nb); std::vector<int> bfl(nb), slab(nb);
+    HIPCHK(w, hipMemcpy(slp.data(), w->dw.b_sleep, nb * sizeof(float4), hipMemcpyDeviceToHost));
+    HIPCHK(w, hipMemcpy(spt.data(), w->dw.b_sprev_t, nb * sizeof(float4), hipMemcpyDeviceToHost));
+    HIPCHK(w, hipMemcpy(spr.data(), w->dw.b_sprev_r, nb * sizeof(float4), hipMemcpyDeviceToHost));
+    HIPCHK(w, hipMemcpy(bfl.data(), w->dw.b_flags, nb * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(w, hipMemcpy(slab.data(), w->dw.b_slabel, nb * sizeof(int), hipMemcpyDeviceToHost));
+    for (int i = 0; i < nb; ++i) {
+        HostBody &hb = w->bodies[i];
+        hb.sleep_timer = slp[i].x; hb.sleeping = (bfl[i] & RP_BF_SLEEPING) ? 1 : 0; hb.slabel = slab[i];
+        hb.sprev[0] = spt[i].x; hb.sprev[1] = spt[i].y; hb.sprev[2] = spt[i].z;
+        hb.sprev[3] = spr[i].x; hb.sprev[4] = spr[i].y; hb.sprev[5] = spr[i].z; hb.sprev[6] = spr[i].w;
+    }
     for (int i = 0; i < nb; ++i) {
         rp_body_desc &d = w->bodies[i].d;
         d.translation[0] = pos[i].x; d.translation[1] = pos[i].y; d.translation[2] = pos[i].z;
@@ -326,6 +354,7 @@ extern "C" int32_t rp_bodies_insert(rp_world *w, int32_t n, const rp_body_desc *
     }
     for (int i = 0; i < n; ++i) {
         HostBody b; b.d = descs[i]; b.ncolliders = 0; b.removed = false; b.inv_mass = 0; b.inv_pi[0] = b.inv_pi[1] = b.inv_pi[2] = 0; b.lcom[0] = b.lcom[1] = b.lcom[2] = 0;
+        b.slabel = (int)w->bodies.size();
         w->bodies.push_back(b);
         recompute_mass(w, (int)w->bodies.size() - 1);
         if (handles_out) handles_out[i] = (uint64_t)(w->bodies.size() - 1);
@@ -333,6 +362,8 @@ extern "C" int32_t rp_bodies_insert(rp_world *w, int32_t n, const rp_body_desc *
     }
     if (in_place && n > 0) {
         w->dw.n_bodies = (int)w->bodies.size();
+        { int r = check_sleep_scope(w); if (r != RP_OK) return r; }
+        w->dw.sleep_enabled = world_sleep_enabled(w) ? 1 : 0;
         HIPCHK(w, hipStreamSynchronize(w->stream));
         destroy_graphs(w); // kernel arguments (DevWorld by value) hold the body count
         return after_topology_edit(w);
@@ -423,7 +454,7 @@ static int next_pow2(long long x) { long long p = 1; while (p < x) p <<= 1; retu
 static float4 mk4(float x, float y, float z, float w_) { float4 r; r.x = x; r.y = y; r.z = z; r.w = w_; return r; }
 
 // One body / collider row of the SoA device world from the host mirrors (finalize and incremental inserts).
-struct BodyRow { float4 pos, rot, lv, av, lci, ipi, pfr, damp; int fl; };
+struct BodyRow { float4 pos, rot, lv, av, lci, ipi, pfr, damp, slp, spt, spr; int fl, slabel; };
 static BodyRow pack_body(const HostBody &b) {
     const rp_body_desc &bd = b.d;
     BodyRow o;
@@ -440,7 +471,13 @@ static BodyRow pack_body(const HostBody &b) {
     if (bd.gyroscopic) fl |= RP_BF_GYRO;
     if (bd.allow_fast_rotation) fl |= RP_BF_FASTROT;
     fl |= ((int)(bd.dominance & 0xff)) << RP_BF_DOM_SHIFT;
+    if (b.sleeping && !b.removed && bd.body_type == RP_BODY_DYNAMIC) fl |= RP_BF_SLEEPING;
     o.fl = fl;
+    // RigidBodyActivation::active() / cannot_sleep() — rigid_body_components.rs:1354-1385
+    o.slp = mk4(b.sleep_timer, bd.can_sleep ? 0.05f : -1.0f, bd.can_sleep ? 0.5f : -1.0f, 0.5f);
+    o.spt = mk4(b.sprev[0], b.sprev[1], b.sprev[2], b.max_extent);
+    o.spr = mk4(b.sprev[3], b.sprev[4], b.sprev[5], b.sprev[6]);
+    o.slabel = b.slabel;
     return o;
 }
 #define PUT(arr, idx, val) HIPCHK(w, hipMemcpyAsync((arr) + (idx), &(val), sizeof(val), hipMemcpyHostToDevice, w->stream))
@@ -450,6 +487,7 @@ static int upload_body_row(rp_world *w, int i) {
     BodyRow r = pack_body(w->bodies[i]);
     PUT(d.b_pos, i, r.pos); PUT(d.b_rot, i, r.rot); PUT(d.b_linvel, i, r.lv); PUT(d.b_angvel, i, r.av); PUT(d.b_lcom_invm, i, r.lci);
     PUT(d.b_invpi, i, r.ipi); PUT(d.b_pframe, i, r.pfr); PUT(d.b_damp, i, r.damp); PUT(d.b_flags, i, r.fl);
+    PUT(d.b_sleep, i, r.slp); PUT(d.b_sprev_t, i, r.spt); PUT(d.b_sprev_r, i, r.spr); PUT(d.b_slabel, i, r.slabel);
     return RP_OK;
 }
 struct ColliderRow { int parent, shape; float4 lp, lr, he, mat, fmn, fmx; int2 rules; uint2 groups; };
@@ -473,6 +511,7 @@ static int upload_body_row_mass(rp_world *w, int i) { // mass properties only (a
     const DevWorld &d = w->dw;
     BodyRow r = pack_body(w->bodies[i]);
     PUT(d.b_lcom_invm, i, r.lci); PUT(d.b_invpi, i, r.ipi);
+    PUT((float *)(d.b_sprev_t + i) + 3, 0, r.spt.w); // max_extent follows the attached shape
     return RP_OK;
 }
 static int upload_collider_row(rp_world *w, int i) {
@@ -483,11 +522,24 @@ static int upload_collider_row(rp_world *w, int i) {
     return RP_OK;
 }
 
+static bool world_sleep_enabled(const rp_world *w) {
+    for (const HostBody &b : w->bodies) if (!b.removed && b.d.body_type == RP_BODY_DYNAMIC && b.d.can_sleep) return true;
+    return false;
+}
+static int check_sleep_scope(rp_world *w) {
+    if (!world_sleep_enabled(w)) return RP_OK;
+    for (size_t j = 0; j < w->joints.size(); ++j)
+        if (!w->joint_removed[j]) { w->err = "impulse joints in a world with can_sleep bodies are not implemented on the device path (build the bodies with can_sleep = 0)"; return RP_ERR_INVALID; }
+    return RP_OK;
+}
+
 // Upload the host mirrors into the SoA device world (the "upload = resume" path of SURVEY §5).
 static int finalize(rp_world *w) {
     HIPCHK(w, hipSetDevice(w->device));
+    { int r = check_sleep_scope(w); if (r != RP_OK) return r; }
     DevWorld &d = w->dw;
     memset(&d, 0, sizeof(d));
+    d.sleep_enabled = world_sleep_enabled(w) ? 1 : 0;
     int nb = (int)w->bodies.size(), nc = (int)w->colliders.size();
     d.n_bodies = nb; d.n_colliders = nc;
     // capacities leave room for bodies / colliders inserted later without rebuilding the device world
@@ -519,6 +571,8 @@ static int finalize(rp_world *w) {
     DA(d.b_pos, capb); DA(d.b_rot, capb); DA(d.b_linvel, capb); DA(d.b_angvel, capb); DA(d.b_lcom_invm, capb); DA(d.b_invpi, capb);
     DA(d.b_pframe, capb); DA(d.b_wcom, capb); DA(d.b_eim, capb); DA(d.b_eii0, capb); DA(d.b_eii1, capb); DA(d.b_damp, capb);
     DA(d.b_uforce, capb); DA(d.b_utorque, capb); DA(d.b_flags, capb); DA(d.b_quar, capb); DAF(d.b_collider, capb, 0xff);
+    DA(d.b_sleep, capb); DA(d.b_sprev_t, capb); DA(d.b_sprev_r, capb); DA(d.b_slabel, capb); DA(d.b_slept_at, capb); DA(d.b_wake_req, capb);
+    DA(d.lab_wake, capb); DA(d.lab_awake, capb);
     DA(d.s_lin, capb); DA(d.s_ang, capb); DA(d.s_rot, capb); DA(d.s_trans, capb); DA(d.s_incl, capb); DA(d.s_inca, capb);
     DA(d.b_cmask, 4 * (size_t)capb); DAF(d.b_min, capb, 0xff);
     DA(d.c_parent, capc); DA(d.c_shape, capc); DA(d.c_lpos, capc); DA(d.c_lrot, capc); DA(d.c_pos, capc); DA(d.c_rot, capc); DA(d.c_he, capc);
@@ -529,7 +583,7 @@ static int finalize(rp_world *w) {
     DA(d.free_stack, d.pool_cap);
     size_t P = (size_t)d.pool_cap;
     DAF(d.p_c1, P, 0xff); DA(d.p_c2, P); DA(d.p_stamp, P); DA(d.p_color, P); DA(d.p_nsc, P); DA(d.p_npts, P); DA(d.p_pflags, P); DA(d.p_reldom, P);
-    DA(d.p_colorb, P); DA(d.p_rb, P); DA(d.p_ln1, P); DA(d.p_ln2, P); DA(d.p_normal, P); DA(d.p_misc, P);
+    DA(d.p_hint_seq, P); DA(d.p_colorb, P); DA(d.p_rb, P); DA(d.p_ln1, P); DA(d.p_ln2, P); DA(d.p_normal, P); DA(d.p_misc, P);
     DA(d.r_t, P); DA(d.r_r, P); DA(d.r_rot1, P); DA(d.r_rot2, P);
     DA(d.pt_lp1d, RP_MAX_PTS * P); DA(d.pt_lp2f, RP_MAX_PTS * P); DA(d.pt_imp, RP_MAX_PTS * P); DA(d.pt_wst, RP_MAX_PTS * P);
     DA(d.pt_dp1, RP_MAX_PTS * P); DA(d.pt_dp2, RP_MAX_PTS * P);
@@ -599,11 +653,14 @@ static int finalize(rp_world *w) {
     // host SoA staging (one batched copy per attribute)
     {
         std::vector<float4> pos(nb), rot(nb), lv(nb), av(nb), lci(nb), ipi(nb), pfr(nb), damp(nb);
-        std::vector<int> bfl(nb);
+        std::vector<float4> slp(nb), spt(nb), spr(nb);
+        std::vector<int> bfl(nb), slab(nb);
         for (int i = 0; i < nb; ++i) {
             BodyRow r = pack_body(w->bodies[i]);
             pos[i] = r.pos; rot[i] = r.rot; lv[i] = r.lv; av[i] = r.av; lci[i] = r.lci; ipi[i] = r.ipi; pfr[i] = r.pfr; damp[i] = r.damp; bfl[i] = r.fl;
+            slp[i] = r.slp; spt[i] = r.spt; spr[i] = r.spr; slab[i] = r.slabel;
         }
+        UP(d.b_sleep, slp); UP(d.b_sprev_t, spt); UP(d.b_sprev_r, spr); UP(d.b_slabel, slab);
         UP(d.b_pos, pos); UP(d.b_rot, rot); UP(d.b_linvel, lv); UP(d.b_angvel, av); UP(d.b_lcom_invm, lci); UP(d.b_invpi, ipi);
         UP(d.b_pframe, pfr); UP(d.b_damp, damp); UP(d.b_flags, bfl);
         std::vector<int> cpar(nc), csh(nc);
@@ -637,6 +694,7 @@ static void enqueue_collision(rp_world *w) {
     if (w->cur_fast) { rp_launch_fast_front(w->dw, w->stream, w->plan_no_global); return; }
     rp_launch_collider_update(w->dw, w->stream);
     rp_launch_broadphase(w->dw, w->stream);
+    rp_launch_wake(w->dw, w->stream, 0); // user wake-ups and pair deletions take effect before the narrow phase reads the awake set
     rp_launch_narrowphase(w->dw, w->stream);
 }
 // build_islands_and_solve_velocity_constraints: LDS island megakernel + the global path
@@ -795,7 +853,8 @@ static int step_once(rp_world *w, bool allow_fast) {
         }
     }
     // mode: fast graph only while the last observed steps were clean
-    bool fast = allow_fast && w->use_fast && w->plan_single && w->dw.n_colliders > 0 && w->steps_requested >= w->full_until;
+    // sleep-enabled worlds always take the full path (the sleep timers and the island decision run every step)
+    bool fast = allow_fast && w->use_fast && !w->dw.sleep_enabled && w->plan_single && w->dw.n_colliders > 0 && w->steps_requested >= w->full_until;
     if (fast && (pf[FL_FAST_ABORT] || pf[FL_FULL_UPDATES] || pf[FL_LAYOUT_DIRTY] || pf[FL_TODO_COUNT])) {
         fast = false;
         w->full_until = w->steps_requested + 3;
@@ -883,9 +942,49 @@ extern "C" int32_t rp_bodies_write(rp_world *w, int32_t n, const uint64_t *handl
             HIPCHK(w, hipMemcpy(w->dw.b_rot + b, &q, sizeof(q), hipMemcpyHostToDevice));
         }
     }
+    if (w->dw.sleep_enabled) {
+        // set_linvel / set_position(.., wake_up = true): strong wake of the body (its whole island when asleep); a moved
+        // body also wakes every body it has a pair with (pair_management.rs:236-258)
+        for (int i = 0; i < n; ++i) {
+            int b = (int)(handles[i] & 0xffffffffull), lvl = pos7 ? 3 : 2;
+            HIPCHK(w, hipMemcpy(w->dw.b_wake_req + b, &lvl, sizeof(int), hipMemcpyHostToDevice));
+        }
+        if (pos7) rp_launch_wake_partners(w->dw, w->stream);
+    }
     if (pos7) { // user_changes.rs: moved bodies refresh world mass properties, collider poses and AABBs
         rp_launch_init_bodies(w->dw, w->stream);
         rp_launch_collider_update(w->dw, w->stream);
+    }
+    return RP_OK;
+}
+
+// IslandManager::wake_up (island_manager/sleep.rs:31): takes effect at the start of the next step and wakes the
+// body's whole island.
+extern "C" int32_t rp_bodies_wake_up(rp_world *w, int32_t n, const uint64_t *handles, int32_t strong) {
+    if (!w || n < 0 || (n > 0 && !handles)) return RP_ERR_INVALID;
+    HIPCHK(w, hipSetDevice(w->device));
+    if (!w->finalized) { int r = finalize(w); if (r != RP_OK) return r; }
+    { int r = settle(w); if (r != RP_OK) return r; }
+    for (int i = 0; i < n; ++i) {
+        int b = (int)(handles[i] & 0xffffffffull);
+        if ((handles[i] >> 32) != 0 || b >= w->dw.n_bodies || w->bodies[b].removed) { w->err = "rp_bodies_wake_up: invalid handle"; return RP_ERR_INVALID; }
+        int lvl = strong ? 2 : 1;
+        HIPCHK(w, hipMemcpy(w->dw.b_wake_req + b, &lvl, sizeof(int), hipMemcpyHostToDevice));
+    }
+    return RP_OK;
+}
+// RigidBody::is_sleeping per handle (1 = asleep).
+extern "C" int32_t rp_bodies_is_sleeping(rp_world *w, int32_t n, const uint64_t *handles, int32_t *out) {
+    if (!w || n < 0 || (n > 0 && (!handles || !out))) return RP_ERR_INVALID;
+    HIPCHK(w, hipSetDevice(w->device));
+    if (!w->finalized) { int r = finalize(w); if (r != RP_OK) return r; }
+    { int r = settle(w); if (r != RP_OK) return r; }
+    std::vector<int> fl(w->dw.n_bodies);
+    if (!fl.empty()) HIPCHK(w, hipMemcpy(fl.data(), w->dw.b_flags, fl.size() * sizeof(int), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) {
+        int b = (int)(handles[i] & 0xffffffffull);
+        if ((handles[i] >> 32) != 0 || b >= w->dw.n_bodies) { w->err = "rp_bodies_is_sleeping: invalid handle"; return RP_ERR_INVALID; }
+        out[i] = ((fl[b] & RP_BF_TYPE_MASK) == RP_BODY_DYNAMIC && (fl[b] & RP_BF_SLEEPING)) ? 1 : 0;
     }
     return RP_OK;
 }
@@ -1116,6 +1215,12 @@ extern "C" int32_t rp_counters_read(rp_world *w, rp_counters *out) {
     out->overflow_flags = fl[FL_OVERFLOW];
     out->quarantined = fl[FL_QUARANTINE];
     out->fast_steps = (int32_t)w->fast_steps; out->full_steps = (int32_t)w->full_steps; out->replayed_steps = (int32_t)w->replayed_steps;
+    if (w->dw.sleep_enabled && w->dw.n_bodies > 0) {
+        std::vector<int> bfl(w->dw.n_bodies);
+        HIPCHK(w, hipMemcpy(bfl.data(), w->dw.b_flags, bfl.size() * sizeof(int), hipMemcpyDeviceToHost));
+        int ns = 0; for (int f : bfl) ns += (f & (RP_BF_TYPE_MASK | RP_BF_SLEEPING)) == (RP_BODY_DYNAMIC | RP_BF_SLEEPING);
+        out->num_sleeping_bodies = ns;
+    }
     return RP_OK;
 }
 

@@ -199,7 +199,7 @@ __device__ void bp_insert_pair(DevWorld &w, int c1, int c2) {
         if (slot >= w.pool_cap) { atomicOr(&w.flags[FL_OVERFLOW], RP_OVF_POOL); return; }
         w.p_c1[slot] = c1; w.p_c2[slot] = c2; w.p_rb[slot] = make_int2(w.c_parent[c1], w.c_parent[c2]);
         w.p_color[slot] = RP_COLOR_UNCOLORED; w.p_nsc[slot] = 0; w.p_npts[slot] = 0; w.p_pflags[slot] = 0;
-        w.p_reldom[slot] = 0; w.p_colorb[slot] = make_int2(-1, -1); w.p_conspos[slot] = -1;
+        w.p_reldom[slot] = 0; w.p_colorb[slot] = make_int2(-1, -1); w.p_conspos[slot] = -1; w.p_hint_seq[slot] = 0;
         w.flags[FL_LAYOUT_DIRTY] = 1; // the island lists also hold the pairs without solver contacts
     }
     w.p_stamp[slot] = epoch + 1;
@@ -275,6 +275,18 @@ __global__ void k_bp_finish_pairs(DevWorld w) {
             if (cb.y >= 0) atomicAnd(&w.b_cmask[4 * cb.y + (color >> 5)], ~bit);
         }
         w.flags[FL_LAYOUT_DIRTY] = 1;
+        if (w.sleep_enabled) {
+            // remove_pair wakes the bodies of a touching pair (pair_management.rs:541-552); remove_collider wakes every
+            // body that had a pair with the removed collider (:88-99)
+            int c1 = w.p_c1[s], c2 = w.p_c2[s];
+            uint2 g1 = w.c_groups[c1], g2 = w.c_groups[c2];
+            bool gone = (g1.x == 0 && g1.y == 0) || (g2.x == 0 && g2.y == 0);
+            if (w.p_nsc[s] > 0 || gone) {
+                int2 rb = w.p_rb[s];
+                if (rb.x >= 0) atomicMax(&w.b_wake_req[rb.x], 2);
+                if (rb.y >= 0) atomicMax(&w.b_wake_req[rb.y], 2);
+            }
+        }
         w.p_c1[s] = -1; w.p_nsc[s] = 0; w.p_npts[s] = 0; w.p_color[s] = RP_COLOR_UNCOLORED;
         int t = atomicAdd(&w.flags[FL_FREE_TOP], 1);
         w.free_stack[t] = s;

@@ -2,10 +2,11 @@
 // per colour stage) and rp_islands.hip (SINGLE mode: one extra workgroup of the island launch).
 #pragma once
 #include "rp_constraint.h"
+#include "rp_pairs.h"
 #include "rp_joints.h"
 
 RP_DEV bool global_body(const DevWorld &w, int i) {
-    return (w.b_flags[i] & RP_BF_TYPE_MASK) == RP_BODY_DYNAMIC && w.b_island[i] < 0;
+    return flags_active(w.b_flags[i]) && w.b_island[i] < 0;
 }
 
 // ---- per-body device steps over the HBM solver-body arrays --------------------------------------
@@ -33,8 +34,7 @@ RP_DEV bool g_generate(const DevWorld &w, int pos) {
     int s = w.cons_pair[pos];
     int rb1 = w.c_parent[w.p_c1[s]], rb2 = w.c_parent[w.p_c2[s]];
     int rel_dom = w.p_reldom[s];
-    bool dyn1 = rb1 >= 0 && (w.b_flags[rb1] & RP_BF_TYPE_MASK) == RP_BODY_DYNAMIC;
-    bool dyn2 = rb2 >= 0 && (w.b_flags[rb2] & RP_BF_TYPE_MASK) == RP_BODY_DYNAMIC;
+    bool dyn1 = body_active(w, rb1), dyn2 = body_active(w, rb2); // solver bodies = the active set (solver_body.rs:114)
     int id1 = (dyn1 && rel_dom <= 0) ? rb1 : -1;
     int id2 = (dyn2 && rel_dom >= 0) ? rb2 : -1;
     return cons_generate(w, GlobalAcc(w, pos), s, id1, id2, id1, id2);

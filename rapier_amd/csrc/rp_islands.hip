@@ -26,7 +26,7 @@ RP_DEV int uf_find(int *label, int x) {
     while (p != x) { x = p; p = ld_i32(&label[x]); }
     return x;
 }
-RP_DEV bool is_dyn(const DevWorld &w, int b) { return b >= 0 && (w.b_flags[b] & RP_BF_TYPE_MASK) == RP_BODY_DYNAMIC; }
+RP_DEV bool is_dyn(const DevWorld &w, int b) { return body_active(w, b); } // awake dynamic bodies: the active set
 
 // Lock-free union (hook the larger root under the smaller one, retry on races).
 RP_DEV void uf_union(int *label, int a, int b) {
@@ -37,7 +37,7 @@ RP_DEV void uf_union(int *label, int a, int b) {
         if (atomicCAS(&label[a], a, b) == a) return;
     }
 }
-RP_DEV bool pair_active(const DevWorld &w, int s) { return w.p_c1[s] >= 0 && w.p_nsc[s] != 0; }
+RP_DEV bool pair_active(const DevWorld &w, int s) { return pair_selected(w, s); }
 
 // Island discovery runs only when the set of active manifolds changed (FL_LAYOUT_DIRTY): five
 // grid-wide kernels, every pass one thread per body or per pair slot.

@@ -429,6 +429,16 @@ __device__ __noinline__ void pair_full_update(DevWorld &w, int s, int c1, int c2
     atomicAdd(&w.flags[FL_FULL_UPDATES], 1);
     // begin/end-touch transition — pair_update.rs:622-629, contacts.rs:300-364
     int has = nsc > 0;
+    if (w.sleep_enabled) {
+        // :636-650 hint refreshed from the final state; a pair that re-enters the selection dirties the layout
+        if (has && pair_hint_cleared(w, s, make_int2(rb1, rb2))) w.flags[FL_LAYOUT_DIRTY] = 1;
+        w.p_hint_seq[s] = cur_step(w);
+        // wake rule (contacts.rs:333-351): a begin-touch wakes the sleeping side (its whole island, rp_sleep.hip)
+        if (has && !had) {
+            if (body_sleeping(w, rb1)) atomicMax(&w.b_wake_req[rb1], 1);
+            if (body_sleeping(w, rb2)) atomicMax(&w.b_wake_req[rb2], 1);
+        }
+    }
     if (has != had) {
         w.flags[FL_LAYOUT_DIRTY] = 1;
         if (!has) { // end touch: free the colour now (clear_pair_solver_color, mod.rs:157-172)
@@ -467,7 +477,16 @@ __global__ void k_np_pairs(DevWorld w) {
         pc1.r = q4(w.c_rot[c1]); pc1.t = v3(w.c_pos[c1]);
         pc2.r = q4(w.c_rot[c2]); pc2.t = v3(w.c_pos[c2]);
         Pose pos12 = pose_inv_mul(pc1, pc2);
-        if (pair_recycle_ok(w, s, pc1, pc2, pos12)) continue;
+        if (w.sleep_enabled) {
+            int2 rb = w.p_rb[s];
+            // pair_update.rs:98-106: neither body awake (fixed or asleep) -> skipped
+            if (!body_active(w, rb.x) && !body_active(w, rb.y)) continue;
+            if (pair_recycle_ok(w, s, pc1, pc2, pos12)) {
+                // :141-161 a count-cleared hint (the pair slept) is recomputed: the pair re-enters the selection
+                if (pair_hint_cleared(w, s, rb)) { w.p_hint_seq[s] = cur_step(w); if (w.p_nsc[s] != 0) w.flags[FL_LAYOUT_DIRTY] = 1; }
+                continue;
+            }
+        } else if (pair_recycle_ok(w, s, pc1, pc2, pos12)) continue;
         pair_full_update(w, s, c1, c2, pc1, pc2, pos12);
     }
 }
@@ -556,6 +575,8 @@ __global__ void __launch_bounds__(1024) k_color_pairs(DevWorld w) {
 // constraint planes are only handed to manifolds that are not solved by the island kernel.
 void rp_launch_islands_build(const DevWorld &w, hipStream_t st);
 void rp_launch_joint_coloring(const DevWorld &w, hipStream_t st);
+void rp_launch_wake(const DevWorld &w, hipStream_t st, int phase);
+void rp_launch_sleep(const DevWorld &w, hipStream_t st);
 
 __global__ void k_bucket_clear(DevWorld w) {
     if (!w.flags[FL_LAYOUT_DIRTY]) return;
@@ -573,7 +594,7 @@ __global__ void k_bucket_count(DevWorld w) {
     int stride = gridDim.x * blockDim.x;
     for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < top; s += stride) {
         w.p_conspos[s] = -1;
-        if (w.p_c1[s] < 0 || w.p_nsc[s] == 0) continue;
+        if (!pair_selected(w, s)) continue;
         int color = w.p_color[s];
         if (color > RP_COLOR_OVERFLOW) continue;
         atomicAdd(&hist[color], 1);
@@ -620,7 +641,7 @@ __global__ void k_bucket_scatter(DevWorld w) {
     if (top > w.pool_cap) top = w.pool_cap;
     int stride = gridDim.x * blockDim.x;
     for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < top; s += stride) {
-        if (w.p_c1[s] < 0 || w.p_nsc[s] == 0 || w.p_island[s] >= 0) continue;
+        if (!pair_selected(w, s) || w.p_island[s] >= 0) continue;
         int color = w.p_color[s];
         if (color > RP_COLOR_OVERFLOW) continue;
         atomicAdd(&cnt[color], 1);
@@ -629,7 +650,7 @@ __global__ void k_bucket_scatter(DevWorld w) {
     for (int c = threadIdx.x; c < RP_NUM_COLORS; c += blockDim.x) { base[c] = cnt[c] ? atomicAdd(&w.color_cursor[c], cnt[c]) : 0; cnt[c] = 0; }
     __syncthreads();
     for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < top; s += stride) {
-        if (w.p_c1[s] < 0 || w.p_nsc[s] == 0 || w.p_island[s] >= 0) continue;
+        if (!pair_selected(w, s) || w.p_island[s] >= 0) continue;
         int color = w.p_color[s];
         if (color > RP_COLOR_OVERFLOW) continue;
         int pos = base[color] + atomicAdd(&cnt[color], 1);
@@ -645,10 +666,12 @@ __global__ void k_bucket_scatter(DevWorld w) {
 __global__ void k_bucket_finish(DevWorld w) { w.flags[FL_LAYOUT_DIRTY] = 0; }
 
 void rp_launch_narrowphase(const DevWorld &w, hipStream_t st) {
-    if (w.n_colliders == 0) return;
+    if (w.n_colliders == 0) { rp_launch_wake(w, st, 1); rp_launch_sleep(w, st); return; } // collider-less bodies still keep sleep timers
     int blocks = (w.pool_cap + 255) / 256; if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_np_pairs, dim3(blocks), dim3(256), 0, st, w);
     hipLaunchKernelGGL(k_color_pairs, dim3(1), dim3(1024), 0, st, w);
+    rp_launch_wake(w, st, 1); // begin-touch wake-ups (contacts.rs:333-351)
+    rp_launch_sleep(w, st);   // sleep timers + the whole-island sleep decision (solve.rs:196-300, manager.rs:335-388)
     rp_launch_joint_coloring(w, st); // joints avoid this step's contact colours (init_joints, joints.rs:25-329)
     hipLaunchKernelGGL(k_bucket_clear, dim3(1), dim3(256), 0, st, w);
     hipLaunchKernelGGL(k_bucket_count, dim3(blocks), dim3(256), 0, st, w);

@@ -3,6 +3,26 @@
 #pragma once
 #include "rp_world.h"
 
+// member of the active set: an awake dynamic body (IslandManager::active_bodies)
+RP_DEV bool flags_active(int fl) { return (fl & (RP_BF_TYPE_MASK | RP_BF_SLEEPING)) == RP_BODY_DYNAMIC; }
+RP_DEV bool body_active(const DevWorld &w, int b) { return b >= 0 && flags_active(w.b_flags[b]); }
+RP_DEV bool body_sleeping(const DevWorld &w, int b) { return b >= 0 && (w.b_flags[b] & (RP_BF_TYPE_MASK | RP_BF_SLEEPING)) == (RP_BODY_DYNAMIC | RP_BF_SLEEPING); }
+RP_DEV int cur_step(const DevWorld &w) { return w.flags[FL_STEP] + 1; } // 1-based number of the step in progress
+// pair_solver_hints count cleared by clear_asleep_pair_solver_hint_counts_of (solver_graph.rs:21-49): one of the
+// pair's bodies fell asleep after the hint was last computed (only meaningful when w.sleep_enabled)
+RP_DEV bool pair_hint_cleared(const DevWorld &w, int s, int2 rb) {
+    int s1 = rb.x >= 0 ? w.b_slept_at[rb.x] : 0, s2 = rb.y >= 0 ? w.b_slept_at[rb.y] : 0;
+    return (s1 > s2 ? s1 : s2) >= w.p_hint_seq[s];
+}
+// a manifold the solver takes: for_each_desired_manifold (solver_graph.rs:517-571) + qualify_manifold_bqi (:101-124)
+RP_DEV bool pair_selected(const DevWorld &w, int s) {
+    if (w.p_c1[s] < 0 || w.p_nsc[s] == 0) return false;
+    if (!w.sleep_enabled) return true;
+    int2 rb = w.p_rb[s];
+    if (pair_hint_cleared(w, s, rb)) return false;
+    return body_active(w, rb.x) || body_active(w, rb.y);
+}
+
 RP_DEV Pose collider_world_pose(const DevWorld &w, int i) {
     int parent = w.c_parent[i];
     Pose lp; lp.r = q4(w.c_lrot[i]); lp.t = v3(w.c_lpos[i]);

@@ -1,0 +1,165 @@
+// rp_sleep.hip — sleeping on device: sleep timers, whole-island sleep decision, island-wide wake-up.
+//
+// Reference: RigidBodyActivation::update_energy (/root/reference/src/dynamics/rigid_body_components.rs:1412-1478),
+// the fused active-body pass and its sleep observations (pipeline/physics_pipeline/solve.rs:196-300),
+// IslandManager::update_islands / commit_sleeping_chunks (island_manager/manager.rs:335-388, sleep.rs:81-131) and
+// IslandManager::wake_up (sleep.rs:31-79).
+//
+// The reference maintains its persistent islands incrementally on the host (merge on begin-touch / joint link,
+// deferred cooldown-throttled splits).  The sleep decision only needs the PARTITION, and on MI355X recomputing it
+// is cheaper than maintaining it: a lock-free union-find over the touching pairs of the awake bodies, re-run only
+// when the touching set or the awake set changed (FL_LAYOUT_DIRTY).  This is the partition the reference
+// converges to once its pending splits are resolved (its split cooldown only DELAYS a sleep by <= 16 steps).
+// Label of an island = smallest body index of the component; a sleeping island keeps its label in b_slabel, so
+// waking any member wakes every body carrying that label.
+//
+// Per step (sleep-enabled worlds only; every kernel is one thread per body or per pair slot):
+//   after the broad phase : k_wake_spread(0) + k_wake_commit(0)   user wake-ups, pair deletions
+//   after the narrow phase: k_wake_spread(1) + k_wake_commit(1)   begin-touch wake-ups
+//   then                  : k_slp_init/union/flatten (labels, only when dirty), k_sleep_observe, k_sleep_commit
+// and the bucket / island rebuild that follows sees the new awake set.
+#include "rp_pairs.h"
+
+RP_DEV int slp_ld(int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+RP_DEV int slp_find(int *label, int x) {
+    int p = slp_ld(&label[x]);
+    while (p != x) { x = p; p = slp_ld(&label[x]); }
+    return x;
+}
+RP_DEV void slp_union(int *label, int a, int b) { // the smaller index becomes the root
+    for (;;) {
+        a = slp_find(label, a); b = slp_find(label, b);
+        if (a == b) return;
+        if (a < b) { int t = a; a = b; b = t; }
+        if (atomicCAS(&label[a], a, b) == a) return;
+    }
+}
+
+// Wake requests -> per-island wake marks.  A strong request on an awake body only resets its own timer
+// (RigidBodyActivation::wake_up(strong)).
+__global__ void k_wake_spread(DevWorld w, int phase) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= w.n_bodies) return;
+    int r = w.b_wake_req[i];
+    if (!r) return;
+    w.b_wake_req[i] = 0;
+    int fl = w.b_flags[i];
+    if ((fl & RP_BF_TYPE_MASK) != RP_BODY_DYNAMIC) return;
+    if (fl & RP_BF_SLEEPING) {
+        w.lab_wake[w.b_slabel[i]] = cur_step(w);
+        w.flags[FL_WAKE_STAMP] = 2 * cur_step(w) + phase;
+    } else if (r >= 2) {
+        float4 sl = w.b_sleep[i]; sl.x = 0.0f; w.b_sleep[i] = sl;
+    }
+}
+// Whole-island wake: every sleeping body of a marked island wakes with a strong timer reset (sleep.rs:44-70).
+__global__ void k_wake_commit(DevWorld w, int phase) {
+    if (w.flags[FL_WAKE_STAMP] != 2 * cur_step(w) + phase) return;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= w.n_bodies) return;
+    int fl = w.b_flags[i];
+    if ((fl & (RP_BF_TYPE_MASK | RP_BF_SLEEPING)) != (RP_BODY_DYNAMIC | RP_BF_SLEEPING)) return;
+    if (w.lab_wake[w.b_slabel[i]] != cur_step(w)) return;
+    w.b_flags[i] = fl & ~RP_BF_SLEEPING;
+    float4 sl = w.b_sleep[i]; sl.x = 0.0f; w.b_sleep[i] = sl;
+    w.flags[FL_LAYOUT_DIRTY] = 1; // the awake set changed: buckets, islands and labels are rebuilt
+}
+// The user moved a body (rp_bodies_write with a pose): every body that has a pair with it is woken
+// (handle_user_changes_on_colliders, pair_management.rs:236-258).
+__global__ void k_wake_partners(DevWorld w) {
+    int top = w.flags[FL_POOL_TOP];
+    if (top > w.pool_cap) top = w.pool_cap;
+    int stride = gridDim.x * blockDim.x;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < top; s += stride) {
+        if (w.p_c1[s] < 0) continue;
+        int2 rb = w.p_rb[s];
+        bool m1 = rb.x >= 0 && slp_ld(&w.b_wake_req[rb.x]) == 3, m2 = rb.y >= 0 && slp_ld(&w.b_wake_req[rb.y]) == 3;
+        if (m1 && rb.y >= 0) atomicMax(&w.b_wake_req[rb.y], 2);
+        if (m2 && rb.x >= 0) atomicMax(&w.b_wake_req[rb.x], 2);
+    }
+}
+
+// ---- sleep-island labels (only when the touching set or the awake set changed) --------------------
+__global__ void k_slp_init(DevWorld w) {
+    if (!w.flags[FL_LAYOUT_DIRTY]) return;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < w.n_bodies && flags_active(w.b_flags[i])) w.b_slabel[i] = i;
+}
+__global__ void k_slp_union(DevWorld w) {
+    if (!w.flags[FL_LAYOUT_DIRTY]) return;
+    int top = w.flags[FL_POOL_TOP];
+    if (top > w.pool_cap) top = w.pool_cap;
+    int stride = gridDim.x * blockDim.x;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < top; s += stride) {
+        if (w.p_c1[s] < 0 || w.p_nsc[s] == 0) continue; // touching pairs link (contacts.rs:352-359), whatever their solver hint
+        int2 rb = w.p_rb[s];
+        if (body_active(w, rb.x) && body_active(w, rb.y)) slp_union(w.b_slabel, rb.x, rb.y);
+    }
+}
+__global__ void k_slp_flatten(DevWorld w) {
+    if (!w.flags[FL_LAYOUT_DIRTY]) return;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= w.n_bodies || !flags_active(w.b_flags[i])) return;
+    int root = slp_find(w.b_slabel, i);
+    __hip_atomic_store(&w.b_slabel[i], root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// update_body_energy for every awake body + the island observation (an island sleeps once EVERY member is eligible).
+__global__ void k_sleep_observe(DevWorld w) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= w.n_bodies || !flags_active(w.b_flags[i])) return;
+    float4 sl = w.b_sleep[i];
+    float4 pt = w.b_sprev_t[i];
+    Q4 prev_r = q4(w.b_sprev_r[i]);
+    V3 pos = v3(w.b_pos[i]); Q4 rot = q4(w.b_rot[i]);
+    float max_extent = pt.w;
+    w.b_sprev_t[i] = f4(pos, max_extent); w.b_sprev_r[i] = f4(rot);
+    float linear_threshold = sl.y * w.prm.p.length_unit;
+    V3 av = v3(w.b_angvel[i]);
+    float sq_angvel = dot(av, av);
+    bool angular_ok;
+    if (max_extent > 0.0f) angular_ok = sl.z >= 0.0f && sq_angvel < 1.5707964f * 1.5707964f;
+    else angular_ok = sq_angvel < sl.z * fabsf(sl.z);
+    float trans = len(pos - v3(pt));
+    Q4 d = qmul(rot, qconj(prev_r));
+    float drift = trans + 2.0f * len(v3(d.x, d.y, d.z)) * max_extent; // relative_pose_drift, contact_pair.rs:300-323
+    bool can_sleep = angular_ok && drift * 0.5f < linear_threshold * w.prm.p.dt;
+    sl.x = can_sleep ? sl.x + w.prm.p.dt : 0.0f;
+    w.b_sleep[i] = sl;
+    if (!(sl.x >= sl.w)) w.lab_awake[w.b_slabel[i]] = cur_step(w);
+}
+// commit_sleeping_chunks -> RigidBody::sleep (rigid_body.rs:804-807) + clear_asleep_pair_solver_hint_counts_of
+__global__ void k_sleep_commit(DevWorld w) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= w.n_bodies) return;
+    int fl = w.b_flags[i];
+    if (!flags_active(fl)) return;
+    if (w.lab_awake[w.b_slabel[i]] == cur_step(w)) return;
+    w.b_flags[i] = fl | RP_BF_SLEEPING;
+    float4 sl = w.b_sleep[i]; sl.x = sl.w; w.b_sleep[i] = sl;
+    w.b_linvel[i] = make_float4(0, 0, 0, 0); w.b_angvel[i] = make_float4(0, 0, 0, 0);
+    w.b_slept_at[i] = cur_step(w);
+    w.flags[FL_LAYOUT_DIRTY] = 1;
+}
+
+static int slp_body_blocks(const DevWorld &w) { int nb = (w.n_bodies + 255) / 256; return nb < 1 ? 1 : nb; }
+static int slp_pair_blocks(const DevWorld &w) { int b = (w.pool_cap + 255) / 256; if (b > 2048) b = 2048; return b < 1 ? 1 : b; }
+
+void rp_launch_wake(const DevWorld &w, hipStream_t st, int phase) {
+    if (!w.sleep_enabled || w.n_bodies == 0) return;
+    hipLaunchKernelGGL(k_wake_spread, dim3(slp_body_blocks(w)), dim3(256), 0, st, w, phase);
+    hipLaunchKernelGGL(k_wake_commit, dim3(slp_body_blocks(w)), dim3(256), 0, st, w, phase);
+}
+void rp_launch_wake_partners(const DevWorld &w, hipStream_t st) {
+    if (!w.sleep_enabled || w.n_colliders == 0) return;
+    hipLaunchKernelGGL(k_wake_partners, dim3(slp_pair_blocks(w)), dim3(256), 0, st, w);
+}
+void rp_launch_sleep(const DevWorld &w, hipStream_t st) {
+    if (!w.sleep_enabled || w.n_bodies == 0) return;
+    int nb = slp_body_blocks(w);
+    hipLaunchKernelGGL(k_slp_init, dim3(nb), dim3(256), 0, st, w);
+    if (w.n_colliders > 0) hipLaunchKernelGGL(k_slp_union, dim3(slp_pair_blocks(w)), dim3(256), 0, st, w);
+    hipLaunchKernelGGL(k_slp_flatten, dim3(nb), dim3(256), 0, st, w);
+    hipLaunchKernelGGL(k_sleep_observe, dim3(nb), dim3(256), 0, st, w);
+    hipLaunchKernelGGL(k_sleep_commit, dim3(nb), dim3(256), 0, st, w);
+}

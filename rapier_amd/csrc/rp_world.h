@@ -26,6 +26,7 @@
 #define RP_BF_TYPE_MASK 0x3
 #define RP_BF_GYRO 0x4
 #define RP_BF_FASTROT 0x8
+#define RP_BF_SLEEPING 0x10          // RigidBodyActivation::sleeping (dynamic bodies only)
 #define RP_BF_DOM_SHIFT 8
 
 // pair flag bits
@@ -73,6 +74,7 @@ enum {
     FL_ISL_ICONS_CURSOR,
     FL_TICKET,          // last-workgroup-done ticket (one user at a time: kernels of a step are serialised)
     FL_FAST_ABORT,      // steady-state fast path found work it cannot do (see rp_api.hip); sticky until a full step
+    FL_WAKE_STAMP,      // 2 * step + phase of the last wake pass that found a sleeping island to wake (rp_sleep.hip)
     FL_COUNT = 48
 };
 
@@ -135,6 +137,7 @@ struct DevWorld {
     int entries_cap;   // grid entries
     int large_cap;
     int cons_cap;      // solver manifolds
+    int sleep_enabled; // some dynamic body may fall asleep: the sleep kernels run and pairs carry solver hints
     SimParams prm;
     int *flags;        // FL_* scalars
     long long *dbg;    // [64] cycle stamps of island 0 (only written when built with -DRP_ISL_PROFILE)
@@ -153,6 +156,15 @@ struct DevWorld {
     int *b_flags;
     int *b_collider;       // the collider of a dynamic body (one per dynamic body, -1 = none)
     int *b_quar;           // sticky: non-finite state was detected (and rolled back) for this body
+    // ---- sleeping (RigidBodyActivation + whole-island sleep, rp_sleep.hip) ----
+    float4 *b_sleep;       // time_since_can_sleep, normalized_linear_threshold, angular_threshold, time_until_sleep
+    float4 *b_sprev_t;     // sleep_prev_pose translation xyz, max_extent
+    float4 *b_sprev_r;     // sleep_prev_pose rotation
+    int *b_slabel;         // sleep-island label = smallest body index of the component (union-find parent while awake)
+    int *b_slept_at;       // step at which the body last fell asleep (clears the solver hints of its pairs)
+    int *b_wake_req;       // pending wake-up: 1 weak, 2 strong, 3 strong + the user moved the body
+    int *lab_wake;         // [n_bodies] per label: step of the last wake-up of that sleeping island
+    int *lab_awake;        // [n_bodies] per label: step at which some member was found not eligible for sleep
     // ---- solver bodies (index = arena index; non-dynamic = world-attached) ----
     float4 *s_lin, *s_ang, *s_rot, *s_trans, *s_incl, *s_inca;
     unsigned int *b_cmask; // 4 x u32 colour mask per body (body_solver_color_masks)
@@ -176,6 +188,7 @@ struct DevWorld {
     // ---- pair pool ----
     int *p_c1, *p_c2, *p_stamp, *p_color, *p_nsc, *p_npts, *p_pflags, *p_reldom;
     int2 *p_colorb;
+    int *p_hint_seq;            // step at which the pair's solver hint was last computed (pair_update.rs:141-161,636-650)
     int2 *p_rb;                 // parent bodies of the two colliders (c_parent is static), saves a dependent load
     float4 *p_ln1, *p_ln2;      // manifold local normals
     float4 *p_normal;           // world normal xyz, friction

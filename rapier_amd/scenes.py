@@ -24,7 +24,7 @@ BODY_DTYPE = np.dtype([
     ("linvel", "<f4", 3), ("angvel", "<f4", 3),
     ("linear_damping", "<f4"), ("angular_damping", "<f4"), ("gravity_scale", "<f4"),
     ("additional_mass", "<f4"), ("dominance", "<i4"), ("gyroscopic", "<i4"),
-    ("allow_fast_rotation", "<i4"),
+    ("allow_fast_rotation", "<i4"), ("can_sleep", "<i4"),
 ], align=False)
 COLLIDER_DTYPE = np.dtype([
     ("shape", "<i4"), ("half_extents", "<f4", 3), ("translation", "<f4", 3), ("rotation", "<f4", 4),
@@ -81,8 +81,10 @@ def default_params() -> np.ndarray:
 
 def body_desc(body_type=BODY_DYNAMIC, translation=(0, 0, 0), rotation=(0, 0, 0, 1), linvel=(0, 0, 0),
               angvel=(0, 0, 0), linear_damping=0.0, angular_damping=0.0, gravity_scale=1.0,
-              additional_mass=0.0, dominance=0, gyroscopic=1, allow_fast_rotation=0) -> np.ndarray:
-    """RigidBodyBuilder defaults — /root/reference/src/dynamics/rigid_body.rs:1560-1600."""
+              additional_mass=0.0, dominance=0, gyroscopic=1, allow_fast_rotation=0, can_sleep=0) -> np.ndarray:
+    """RigidBodyBuilder defaults — /root/reference/src/dynamics/rigid_body.rs:1560-1600 — except
+    ``can_sleep``: the builder's default is true, every b3d benchmark scene calls ``.can_sleep(false)``
+    (b3d_many_pyramids.rs:52) and so do the generators here unless a scene asks for sleeping."""
     b = np.zeros((), dtype=BODY_DTYPE)
     b["body_type"] = body_type
     b["translation"] = translation
@@ -91,6 +93,7 @@ def body_desc(body_type=BODY_DYNAMIC, translation=(0, 0, 0), rotation=(0, 0, 0, 
     b["linear_damping"], b["angular_damping"] = linear_damping, angular_damping
     b["gravity_scale"], b["additional_mass"] = gravity_scale, additional_mass
     b["dominance"], b["gyroscopic"], b["allow_fast_rotation"] = dominance, gyroscopic, allow_fast_rotation
+    b["can_sleep"] = can_sleep
     return b
 
 
@@ -125,6 +128,13 @@ class Scene:
     def add_body(self, **kw) -> int:
         self.bodies.append(body_desc(**kw))
         return len(self.bodies) - 1
+
+    def enable_sleep(self, on: bool = True) -> "Scene":
+        """RigidBodyBuilder::can_sleep(on) for every dynamic body of the scene."""
+        for b in self.bodies:
+            if int(b["body_type"]) == BODY_DYNAMIC:
+                b["can_sleep"] = 1 if on else 0
+        return self
 
     def add_collider(self, parent: int, **kw) -> int:
         self.colliders.append(collider_desc(**kw))
@@ -323,4 +333,20 @@ def tumble(n: int = 64, seed: int = 7, balls: bool = True) -> Scene:
                     s.add_collider(b, half_extents=tuple(he), friction=np.float32(0.2 + 0.6 * rng.random()),
                                    restitution=0.3 if k % 4 == 0 else 0.0, density=np.float32(0.5 + 2.0 * rng.random()))
                 k += 1
+    return s
+
+
+def sleep_impact(height: float = 12.0, stack: int = 3) -> Scene:
+    """Sleeping test scene (not a reference scene): a cube stack that falls asleep long before a small cube dropped
+    from ``height`` reaches it; the impact wakes the whole island (contacts.rs:333-351), then everything
+    falls asleep again.  A second, untouched stack nearby must stay asleep throughout."""
+    s = Scene(name=f"sleep_impact_{int(height)}_{stack}", gravity=(0.0, -9.81, 0.0))
+    g = s.add_body(body_type=BODY_FIXED, translation=(0.0, -0.5, 0.0))
+    s.add_collider(g, half_extents=(10.0, 0.5, 10.0))
+    for x in (0.0, 4.0):
+        for i in range(stack):
+            b = s.add_body(translation=(x, 0.5 + i * 1.0, 0.0), can_sleep=1)
+            s.add_collider(b, half_extents=(0.5, 0.5, 0.5))
+    drop = s.add_body(translation=(0.15, height, 0.1), rotation=(0.0, 0.19866933, 0.0, 0.98006658), can_sleep=1)
+    s.add_collider(drop, half_extents=(0.3, 0.3, 0.3), density=2.0)
     return s

@@ -256,6 +256,20 @@ class PhysicsWorld:
         _check(self._ptr, self._lib.rp_bodies_write(self._ptr, len(h), h.ctypes.data, None if p is None else p.ctypes.data,
                                                   None if v is None else v.ctypes.data), "rp_bodies_write")
 
+    def wake_up(self, handles, strong: bool = True):
+        """IslandManager::wake_up (island_manager/sleep.rs:31) — effective at the next step, island-wide."""
+        h = np.ascontiguousarray(np.atleast_1d(np.asarray(handles, dtype=np.uint64)))
+        _check(self._ptr, self._lib.rp_bodies_wake_up(self._ptr, len(h), h.ctypes.data, 1 if strong else 0), "rp_bodies_wake_up")
+
+    def sleeping(self, handles=None) -> np.ndarray:
+        """RigidBody::is_sleeping for the given handles (default: every body, arena order)."""
+        if handles is None:
+            handles = np.arange(self._lib.rp_num_bodies(self._ptr), dtype=np.uint64)
+        h = np.ascontiguousarray(np.atleast_1d(np.asarray(handles, dtype=np.uint64)))
+        out = np.zeros(len(h), np.int32)
+        _check(self._ptr, self._lib.rp_bodies_is_sleeping(self._ptr, len(h), h.ctypes.data, out.ctypes.data), "rp_bodies_is_sleeping")
+        return out.astype(bool)
+
     def contacts(self):
         m = self._lib.rp_contacts_read(self._ptr, 0, None, None, None)
         if m < 0:

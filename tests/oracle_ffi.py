@@ -50,6 +50,9 @@ def lib():
         L.ro_combine_coefficient.restype = C.c_float
         L.ro_set_body_vel.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.ro_set_threads.argtypes = [C.c_int32]
+        L.ro_set_body_pose.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        L.ro_wake_up.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        L.ro_read_sleeping.argtypes = [C.c_void_p, C.c_void_p]
         L.ro_remove_body.argtypes = [C.c_void_p, C.c_int32]
         L.ro_remove_collider.argtypes = [C.c_void_p, C.c_int32]
         L.ro_remove_joint.argtypes = [C.c_void_p, C.c_int32]
@@ -126,6 +129,18 @@ class OracleWorld:
         imp = np.zeros((n, 3), np.float32)
         lib().ro_read_joints(self._w, col.ctypes.data, imp.ctypes.data)
         return col, imp
+
+    def set_pose(self, body, pos7):
+        p = np.ascontiguousarray(pos7, np.float32)
+        lib().ro_set_body_pose(self._w, int(body), p.ctypes.data)
+
+    def wake_up(self, body, strong=True):
+        lib().ro_wake_up(self._w, int(body), 1 if strong else 0)
+
+    def sleeping(self):
+        out = np.zeros(self.n, np.int32)
+        lib().ro_read_sleeping(self._w, out.ctypes.data)
+        return out.astype(bool)
 
     def set_vel(self, body, linvel, angvel=(0, 0, 0)):
         lv = np.asarray(linvel, np.float32)

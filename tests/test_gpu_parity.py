@@ -336,8 +336,98 @@ def test_insert_beyond_capacity_rebuilds_from_current_state():
     assert np.isfinite(pos).all() and np.abs(vel).max() < 1.0 and pos[:, 1].min() > -1.0
 
 
+# ---- sleeping: timers, whole-island sleep, island-wide wake-up — rp_sleep.hip vs the oracle ----
+def _same_sleep_state(g, o, msg):
+    _same_state(g, o, msg)
+    np.testing.assert_array_equal(g.sleeping(), o.sleeping(), err_msg=msg + " (sleeping flags)")
+
+
+def test_sleeping_stack_kick_and_wake_up_bit_exact():
+    sc = S.box_stack(3).enable_sleep()
+    g, o = PhysicsWorld.from_scene(sc), OracleWorld(sc)
+    done = 0
+    for cp in (20, 33, 36, 40, 60, 110):
+        g.step(cp - done); o.step(cp - done); done = cp
+        _same_sleep_state(g, o, f"box_stack sleep @ {cp}")
+    assert g.sleeping()[1:].all() and g.counters()["num_manifolds"] == 0 and g.counters()["num_sleeping_bodies"] == 3
+    kick = np.array([[1.0, 0.0, 0.0, 0.0, 0.0, 0.0]], np.float32)
+    g.write_bodies([3], vel6=kick); o.set_vel(3, kick[0, :3], kick[0, 3:])   # set_linvel(.., wake_up = true)
+    for n in (1, 1, 30, 150):
+        g.step(n); o.step(n)
+        _same_sleep_state(g, o, f"box_stack after the kick, +{n}")
+    assert g.sleeping()[1:].all()
+    g.wake_up([2]); o.wake_up(2)            # IslandManager::wake_up on the middle box wakes the island
+    g.step(1); o.step(1)
+    _same_sleep_state(g, o, "box_stack after wake_up")
+    assert not g.sleeping().any()
+    g.step(60); o.step(60)
+    _same_sleep_state(g, o, "box_stack asleep again")
+    assert g.sleeping()[1:].all()
+
+
+def test_sleep_impact_wakes_one_island_bit_exact():
+    """A cube dropped on a sleeping stack: begin-touch wakes the struck island only (contacts.rs:333-351); the woken
+    island's other pairs re-enter the solver one step later (their hints were count-cleared, solver_graph.rs:21-49)."""
+    sc = S.sleep_impact()
+    g, o = PhysicsWorld.from_scene(sc), OracleWorld(sc)
+    seen_partial = False
+    for cp in range(5, 261, 5):
+        g.step(5); o.step(5)
+        _same_sleep_state(g, o, f"sleep_impact @ {cp}")
+        sl = g.sleeping()
+        seen_partial |= (not sl[1:4].any()) and sl[4:7].all()
+    assert seen_partial and g.sleeping()[1:].all()
+
+
+def test_sleep_many_islands_bit_exact():
+    sc = S.many_pyramids(rows=2, cols=2).enable_sleep()
+    g, o = _compare(sc, [10, 30, 35, 40, 60])
+    np.testing.assert_array_equal(g.sleeping(), o.sleeping())
+    assert g.sleeping()[1:].all() and g.counters()["num_sleeping_bodies"] == 220
+    sc2 = S.tumble(40, seed=11).enable_sleep()
+    g2, o2 = PhysicsWorld.from_scene(sc2), OracleWorld(sc2)
+    for cp in range(50, 601, 50):
+        g2.step(50); o2.step(50)
+        _same_sleep_state(g2, o2, f"tumble sleep @ {cp}")
+
+
+def test_sleep_user_changes_wake_partners_bit_exact():
+    """Collider removal wakes every body that had a pair with it (pair_management.rs:88-99); a teleported body wakes
+    its contact partners (:236-258)."""
+    sc = S.box_stack(4).enable_sleep()
+    g, o = PhysicsWorld.from_scene(sc), OracleWorld(sc)
+    g.step(70); o.step(70)
+    assert g.sleeping()[1:].all()
+    g.remove_body(1); o.remove_body(1)
+    for n in (1, 40, 120):
+        g.step(n); o.step(n)
+        _same_sleep_state(g, o, f"sleeping stack, bottom box removed, +{n}")
+    assert g.sleeping()[2:].all()
+    pose = np.array([[3.0, 0.5, 0.0, 0.0, 0.0, 0.0, 1.0]], np.float32)
+    g.write_bodies([2], pos7=pose); o.set_pose(2, pose[0])   # the (new) bottom box is teleported away
+    for n in (1, 40, 120):
+        g.step(n); o.step(n)
+        _same_sleep_state(g, o, f"sleeping stack, bottom box teleported, +{n}")
+    pos, _ = g.read_bodies()
+    assert pos[3, 1] < 0.6 and g.sleeping()[2:].all()
+
+
+def test_sleep_full_size_many_pyramids():
+    """b3d_many_pyramids with the builder's default can_sleep(true): all 196 islands fall asleep on their own."""
+    sc = S.many_pyramids().enable_sleep()
+    g, o = _compare(sc, [35, 60])
+    np.testing.assert_array_equal(g.sleeping(), o.sleeping())
+    g.step(60)
+    c = g.counters()
+    assert c["num_sleeping_bodies"] == 10780 and c["num_manifolds"] == 0
+
+
 def test_out_of_scope_inputs_are_refused():
-    """Angular joint locks, contact-disabled joints and compound bodies are refused loudly, not mis-simulated."""
+    """Angular joint locks, contact-disabled joints, compound bodies and joints on can_sleep bodies are refused
+    loudly, not mis-simulated."""
+    sj = S.joint_chain(4).enable_sleep()
+    with pytest.raises(Exception):
+        PhysicsWorld.from_scene(sj).step(1)
     from rapier_amd import RapierHipError
     w = PhysicsWorld()
     b = w.insert_body(S.body_desc(translation=(0.0, 1.0, 0.0)))

@@ -198,6 +198,73 @@ def test_oracle_threads_do_not_change_results():
         np.testing.assert_array_equal(v1, v4)
 
 
+# Sleeping: RigidBodyActivation::update_energy (rigid_body_components.rs:1412-1478), whole-island sleep
+# (island_manager/manager.rs:335-388), wake rules (contacts.rs:333-351, sleep.rs:31-79).  The reference's own
+# sleep tests (src/pipeline/physics_pipeline/test.rs:340-372: a resting body falls asleep, a woken one is awake)
+# are restated as outcomes.
+def test_resting_stack_falls_asleep_as_one_island_and_wakes_as_one():
+    sc = S.box_stack(3).enable_sleep()
+    w = OracleWorld(sc)
+    w.step(20)
+    assert not w.sleeping().any()             # time_until_sleep = 0.5 s = 30 steps
+    w.step(40)
+    assert w.sleeping()[1:].all() and not w.sleeping()[0]   # fixed bodies never report asleep
+    p0, v0 = w.read()
+    assert np.all(v0 == 0.0)                  # RigidBody::sleep zeroes the velocities
+    assert w.stats()["num_active_manifolds"] == 0
+    w.step(50)
+    p1, _ = w.read()
+    np.testing.assert_array_equal(p0, p1)     # nothing moves while asleep
+    w.set_vel(3, (1.0, 0.0, 0.0))             # set_linvel(.., wake_up = true) on the top box
+    w.step(1)
+    assert not w.sleeping().any()             # the whole island woke up
+    assert w.stats()["num_active_manifolds"] == 3
+    w.step(120)
+    assert w.sleeping()[1:].all()
+
+
+def test_islands_sleep_independently_and_impact_wakes_only_the_touched_island():
+    sc = S.sleep_impact()
+    w = OracleWorld(sc)
+    w.step(60)
+    sl = w.sleeping()
+    assert sl[1:7].all() and not sl[7]        # both stacks asleep, the dropped cube still falling
+    woke = None
+    for k in range(200):
+        w.step(1)
+        sl = w.sleeping()
+        if not sl[1]:
+            woke = k
+            break
+    assert woke is not None
+    assert not sl[1:4].any() and sl[4:7].all()  # the struck stack woke as one island, the other stack sleeps on
+    w.step(400)
+    assert w.sleeping()[1:].all()
+    pos, _ = w.read()
+    assert np.isfinite(pos).all() and pos[7, 1] < 4.0
+
+
+def test_can_sleep_false_never_sleeps_and_blocks_its_island():
+    sc = S.box_stack(3).enable_sleep()
+    sc.bodies[2]["can_sleep"] = 0             # the middle box cannot sleep => the island never does
+    w = OracleWorld(sc)
+    w.step(200)
+    assert not w.sleeping().any()
+
+
+def test_removing_a_collider_wakes_its_contact_partners():
+    sc = S.box_stack(3).enable_sleep()
+    w = OracleWorld(sc)
+    w.step(60)
+    assert w.sleeping()[1:].all()
+    w.remove_body(1)                          # the bottom box disappears
+    w.step(1)
+    assert not w.sleeping()[2:].any()
+    w.step(30)
+    pos, _ = w.read()
+    assert pos[2, 1] < 1.4                    # the boxes above came down
+
+
 def test_golden_fixtures_match_oracle():
     """tests/golden/*.npz were produced by tests/golden/make_golden.py from this oracle; they pin it
     (and, in the GPU tests, the HIP path) against silent drift."""

@@ -1,0 +1,60 @@
+"""Step-by-step divergence report for the sleeping scenarios (GPU vs oracle).  Debug aid: prints the first
+step at which poses / velocities / sleeping flags differ and which bodies are involved."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from rapier_amd import PhysicsWorld, scenes as S  # noqa: E402
+from oracle_ffi import OracleWorld  # noqa: E402
+
+
+def run(name, scene, steps, actions=None):
+    g, o = PhysicsWorld.from_scene(scene), OracleWorld(scene)
+    actions = actions or {}
+    for k in range(1, steps + 1):
+        if k in actions:
+            actions[k](g, o)
+        g.step(1); o.step(1)
+        gp, gv = g.read_bodies(); op, ov = o.read()
+        gs, os_ = g.sleeping(), o.sleeping()
+        bad = np.where((gp != op).any(1) | (gv != ov).any(1) | (gs != os_))[0]
+        if len(bad):
+            print(f"[{name}] FIRST DIVERGENCE at step {k}: bodies {bad[:12].tolist()} (of {len(bad)})")
+            for b in bad[:4]:
+                print(f"   body {b}: sleep gpu={int(gs[b])} oracle={int(os_[b])}\n     gpu pos {gp[b]} vel {gv[b]}\n     ora pos {op[b]} vel {ov[b]}")
+            print(f"   gpu counters {g.counters()}\n   oracle stats {o.stats()}")
+            print(f"   sleeping gpu {gs.astype(int).tolist()[:40]}\n   sleeping ora {os_.astype(int).tolist()[:40]}")
+            return False
+    print(f"[{name}] ok: {steps} steps bit-exact, asleep at the end: {int(g.sleeping().sum())}")
+    return True
+
+
+def kick(g, o):
+    v = np.array([[1.0, 0, 0, 0, 0, 0]], np.float32)
+    g.write_bodies([3], vel6=v); o.set_vel(3, v[0, :3], v[0, 3:])
+
+
+def wake(g, o):
+    g.wake_up([2]); o.wake_up(2)
+
+
+def rm(g, o):
+    g.remove_body(1); o.remove_body(1)
+
+
+def tele(g, o):
+    p = np.array([[3.0, 0.5, 0.0, 0, 0, 0, 1.0]], np.float32)
+    g.write_bodies([2], pos7=p); o.set_pose(2, p[0])
+
+
+if __name__ == "__main__":
+    run("box_stack3 no-sleep", S.box_stack(3), 50)
+    run("box_stack3 sleep", S.box_stack(3).enable_sleep(), 320, {111: kick, 230: wake})
+    run("sleep_impact", S.sleep_impact(), 260)
+    run("pyramids2x2 sleep", S.many_pyramids(rows=2, cols=2).enable_sleep(), 70)
+    run("box_stack4 remove/teleport", S.box_stack(4).enable_sleep(), 400, {71: rm, 232: tele})
+    run("tumble40 sleep", S.tumble(40, seed=11).enable_sleep(), 600)
