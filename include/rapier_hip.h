@@ -55,7 +55,10 @@ typedef struct rp_integration_params {
     int32_t friction_in_bias_pass;
     int32_t warmstart_joints;
     int32_t max_ccd_substeps;
+    int32_t friction_model; /* FrictionModel (integration_parameters.rs:13-32): RP_FRICTION_SIMPLIFIED (default) | RP_FRICTION_COULOMB */
 } rp_integration_params;
+
+enum { RP_FRICTION_SIMPLIFIED = 0, RP_FRICTION_COULOMB = 1 };
 
 enum { RP_BODY_DYNAMIC = 0, RP_BODY_FIXED = 1 };
 enum { RP_SHAPE_BALL = 0, RP_SHAPE_CUBOID = 1 };

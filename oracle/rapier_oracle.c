@@ -110,6 +110,9 @@ typedef struct {
              float rhs[2], rhs_wo_bias[2], impulse[2], impulse_accumulator[2], r[3]; } tangent_part;
     struct { float rhs, impulse, impulse_accumulator, r; } twist_part;
     float twist_dists[4];
+    /* ContactWithCoulombFriction: one ContactConstraintTangentPart per point (contact_constraint_element.rs:17-36) */
+    struct { v3 torque_dir1[2], torque_dir2[2], ii_torque_dir1[2], ii_torque_dir2[2];
+             float rhs[2], rhs_wo_bias[2], impulse[2], impulse_accumulator[2], r[3]; } ctangent[4];
     uint32_t solver_vel1, solver_vel2; int pair; int num_contacts; int contact_id[4];
     /* builder */
     struct { float restitution_seed; v3 local_p1, local_p2; float dist; } infos[4];
@@ -189,6 +192,7 @@ void ro_default_params(ro_params *p) {
     p->friction_in_bias_pass = 0;
     p->warmstart_joints = 0;
     p->max_ccd_substeps = 1;
+    p->friction_model = RO_FRICTION_SIMPLIFIED;
 }
 
 /* SpringCoefficients — integration_parameters.rs:86-149 */
@@ -1169,6 +1173,203 @@ static void constraint_writeback(ro_world *w, const Constraint *c) {
     }
 }
 
+
+/* ---- FrictionModel::Coulomb: ContactWithCoulombFriction(+Builder) — contact_with_coulomb_friction.rs:52-760 --------
+ * One Coulomb friction constraint per contact point (exact coupled 2x2 solve, limit mu * lambda_k) instead of the
+ * friction-centre tangent + twist pair.  The normal parts are the twist model's. */
+static void coulomb_generate(ro_world *w, int pair_idx, Constraint *c) {
+    const Pair *p = &w->pairs[pair_idx];
+    memset(c, 0, sizeof(*c));
+    uint32_t ids1 = p->relative_dominance <= 0 ? p->solver_body_ids[0] : RO_NO_BODY;
+    uint32_t ids2 = p->relative_dominance >= 0 ? p->solver_body_ids[1] : RO_NO_BODY;
+    SolverVel vels1, vels2; SolverPose poses1, poses2;
+    gather_vel(w, ids1, &vels1); gather_vel(w, ids2, &vels2);
+    gather_pose(w, ids1, &poses1); gather_pose(w, ids2, &poses2);
+    v3 world_com1 = poses1.translation, world_com2 = poses2.translation;
+    v3 force_dir1 = vneg(p->normal);
+    int count = p->nsc < 4 ? p->nsc : 4;
+    v3 tangents1[2];
+    tangents1[0] = orthonormal_vector(force_dir1);           /* compute_tangent_contact_directions, mod.rs:27-46 */
+    tangents1[1] = vcross(force_dir1, tangents1[0]);
+    c->dir1 = force_dir1; c->im1 = poses1.im; c->im2 = poses2.im; c->ii1 = poses1.ii; c->ii2 = poses2.ii;
+    c->local_n1 = qrot_inv(poses1.rotation, force_dir1);
+    c->restitution = p->restitution;
+    c->solver_vel1 = ids1; c->solver_vel2 = ids2; c->pair = pair_idx; c->num_contacts = count;
+    c->tangent1 = tangents1[0];
+    c->limit = p->friction;
+    v3 imsum = vadd(poses1.im, poses2.im);
+    for (int k = 0; k < count; ++k) {
+        const SolverContact *sc = &p->sc[k];
+        const ContactData *pd = &p->m.points[sc->cid].data;
+        float warmstart_impulse = pd->warmstart_impulse;
+        v3 wt = pd->warmstart_tangent_world;
+        float wti[2] = {vdot(wt, tangents1[0]), vdot(wt, tangents1[1])};
+        int is_new = pd->impulse == 0.0f;
+        float is_bouncy = is_new ? (p->restitution > 0.0f ? 1.0f : 0.0f) : (p->restitution >= 1.0f ? 1.0f : 0.0f);
+        v3 p1 = spose_tp(&poses1, sc->anchor1);
+        v3 p2 = spose_tp(&poses2, sc->anchor2);
+        float dist = vdot(vsub(p1, p2), force_dir1);
+        v3 dp1 = pd->solver_dp1, dp2 = pd->solver_dp2;
+        v3 vel1 = vadd(vels1.linear, vcross(vels1.angular, dp1));
+        v3 vel2 = vadd(vels2.linear, vcross(vels2.angular, dp2));
+        c->contact_id[k] = sc->cid;
+        {
+            v3 torque_dir1 = vcross(dp1, force_dir1);
+            v3 torque_dir2 = vcross(dp2, vneg(force_dir1));
+            v3 ii_torque_dir1 = sym3_mul(poses1.ii, torque_dir1);
+            v3 ii_torque_dir2 = sym3_mul(poses2.ii, torque_dir2);
+            float projected_mass = ro_inv(vdot(force_dir1, vcmul(imsum, force_dir1)) + vdot(ii_torque_dir1, torque_dir1) +
+                                          vdot(ii_torque_dir2, torque_dir2));
+            float projected_velocity = vdot(vsub(vel1, vel2), force_dir1);
+            NormalPart *n = &c->normal_part[k];
+            n->torque_dir1 = torque_dir1; n->torque_dir2 = torque_dir2;
+            n->ii_torque_dir1 = ii_torque_dir1; n->ii_torque_dir2 = ii_torque_dir2;
+            n->impulse = warmstart_impulse; n->impulse_accumulator = -warmstart_impulse; n->r = projected_mass;
+            c->infos[k].restitution_seed = is_bouncy * p->restitution * projected_velocity;
+        }
+        c->ctangent[k].impulse[0] = wti[0]; c->ctangent[k].impulse[1] = wti[1];
+        c->ctangent[k].impulse_accumulator[0] = -wti[0]; c->ctangent[k].impulse_accumulator[1] = -wti[1];
+        for (int j = 0; j < 2; ++j) {
+            v3 torque_dir1 = vcross(dp1, tangents1[j]);
+            v3 torque_dir2 = vcross(dp2, vneg(tangents1[j]));
+            v3 ii_torque_dir1 = sym3_mul(poses1.ii, torque_dir1);
+            v3 ii_torque_dir2 = sym3_mul(poses2.ii, torque_dir2);
+            float r = vdot(tangents1[j], vcmul(imsum, tangents1[j])) + vdot(ii_torque_dir1, torque_dir1) + vdot(ii_torque_dir2, torque_dir2);
+            float rhs_wo_bias = vdot(sc->tangent_velocity, tangents1[j]);
+            c->ctangent[k].torque_dir1[j] = torque_dir1; c->ctangent[k].torque_dir2[j] = torque_dir2;
+            c->ctangent[k].ii_torque_dir1[j] = ii_torque_dir1; c->ctangent[k].ii_torque_dir2[j] = ii_torque_dir2;
+            c->ctangent[k].rhs_wo_bias[j] = rhs_wo_bias; c->ctangent[k].rhs[j] = rhs_wo_bias; c->ctangent[k].r[j] = r;
+        }
+        c->ctangent[k].r[2] = 2.0f * (vdot(c->ctangent[k].ii_torque_dir1[0], c->ctangent[k].torque_dir1[1]) +
+                                      vdot(c->ctangent[k].ii_torque_dir2[0], c->ctangent[k].torque_dir2[1]));
+        c->infos[k].local_p1 = spose_itp(&poses1, vadd(world_com1, dp1));
+        c->infos[k].local_p2 = spose_itp(&poses2, vadd(world_com2, dp2));
+        c->infos[k].dist = dist - vdot(vsub(vadd(world_com1, dp1), vadd(world_com2, dp2)), force_dir1);
+    }
+}
+/* update :362-455 (tangent_velocity is zero without contact-modification hooks, so the p1 shift vanishes) */
+static void coulomb_update(const ro_world *w, Constraint *c, float dt, float solved_dt) {
+    const ro_params *prm = &w->params;
+    (void)solved_dt;
+    int is_static = c->solver_vel1 == RO_NO_BODY || c->solver_vel2 == RO_NO_BODY;
+    float dyn_cfm = spring_cfm_factor(prm->contact_natural_frequency, prm->contact_damping_ratio, dt);
+    float static_cfm = spring_cfm_factor(prm->static_contact_natural_frequency, prm->static_contact_damping_ratio, dt);
+    float dyn_erp = spring_erp_inv_dt(prm->contact_natural_frequency, prm->contact_damping_ratio, dt);
+    float static_erp = spring_erp_inv_dt(prm->static_contact_natural_frequency, prm->static_contact_damping_ratio, dt);
+    float fstatic = is_static ? 1.0f : 0.0f;
+    float cfm_factor = dyn_cfm + fstatic * (static_cfm - dyn_cfm);
+    float inv_dt = dt == 0.0f ? 0.0f : 1.0f / dt;
+    float erp_inv_dt = dyn_erp + fstatic * (static_erp - dyn_erp);
+    float max_corrective_velocity = prm->normalized_max_corrective_velocity * prm->length_unit;
+    float warmstart_coeff = prm->warmstart_coefficient;
+    Xform poses1, poses2; gather_xform(w, c->solver_vel1, &poses1); gather_xform(w, c->solver_vel2, &poses2);
+    v3 tangents1[2] = {c->tangent1, vcross(c->dir1, c->tangent1)};
+    for (int k = 0; k < c->num_contacts; ++k) {
+        NormalPart *n = &c->normal_part[k];
+        v3 p1 = xform_tp(&poses1, c->infos[k].local_p1);
+        v3 p2 = xform_tp(&poses2, c->infos[k].local_p2);
+        float dist = c->infos[k].dist + vdot(vsub(p1, p2), c->dir1);
+        float rhs_wo_bias = ro_maxf(dist, 0.0f) * inv_dt;
+        float rhs_bias = ro_clampf(dist * erp_inv_dt, -max_corrective_velocity, 0.0f);
+        n->rhs_wo_bias = rhs_wo_bias; n->rhs = rhs_wo_bias + rhs_bias;
+        n->cfm_factor = dist <= 0.0f ? cfm_factor : 1.0f;
+        n->impulse_accumulator += n->impulse;
+        n->impulse *= warmstart_coeff;
+        for (int j = 0; j < 2; ++j) { c->ctangent[k].impulse_accumulator[j] += c->ctangent[k].impulse[j]; c->ctangent[k].impulse[j] *= warmstart_coeff; }
+        for (int j = 0; j < 2; ++j) {
+            float bias = vdot(vsub(p1, p2), tangents1[j]) * inv_dt;
+            c->ctangent[k].rhs[j] = c->ctangent[k].rhs_wo_bias[j] + bias;
+        }
+    }
+    c->cfm_factor = cfm_factor;
+}
+/* refresh_rhs_wo_bias :460-489 */
+static void coulomb_refresh_rhs_wo_bias(const ro_world *w, Constraint *c, float dt, float solved_dt) {
+    (void)solved_dt;
+    float inv_dt = dt == 0.0f ? 0.0f : 1.0f / dt;
+    Xform poses1, poses2; gather_xform(w, c->solver_vel1, &poses1); gather_xform(w, c->solver_vel2, &poses2);
+    for (int k = 0; k < c->num_contacts; ++k) {
+        v3 p1 = xform_tp(&poses1, c->infos[k].local_p1);
+        v3 p2 = xform_tp(&poses2, c->infos[k].local_p2);
+        float dist = c->infos[k].dist + vdot(vsub(p1, p2), c->dir1);
+        c->normal_part[k].rhs = ro_maxf(dist, 0.0f) * inv_dt;
+        c->normal_part[k].cfm_factor = 1.0f;
+        c->ctangent[k].rhs[0] = c->ctangent[k].rhs_wo_bias[0]; c->ctangent[k].rhs[1] = c->ctangent[k].rhs_wo_bias[1];
+    }
+    c->cfm_factor = 1.0f;
+}
+/* warmstart :561-603; elements contact_constraint_element.rs:64-97,226-240 */
+static void coulomb_warmstart(ro_world *w, Constraint *c) {
+    SolverVel v1, v2; gather_vel(w, c->solver_vel1, &v1); gather_vel(w, c->solver_vel2, &v2);
+    for (int k = 0; k < c->num_contacts; ++k) {
+        NormalPart *n = &c->normal_part[k];
+        v1.linear = vadd(v1.linear, vmul(vcmul(c->dir1, c->im1), n->impulse));
+        v1.angular = vadd(v1.angular, vmul(n->ii_torque_dir1, n->impulse));
+        v2.linear = vadd(v2.linear, vmul(vcmul(c->dir1, c->im2), -n->impulse));
+        v2.angular = vadd(v2.angular, vmul(n->ii_torque_dir2, n->impulse));
+    }
+    v3 t0 = c->tangent1, t1 = vcross(c->dir1, c->tangent1);
+    for (int k = 0; k < c->num_contacts; ++k) {
+        float i0 = c->ctangent[k].impulse[0], i1 = c->ctangent[k].impulse[1];
+        v1.linear = vadd(v1.linear, vcmul(vadd(vmul(t0, i0), vmul(t1, i1)), c->im1));
+        v1.angular = vadd(v1.angular, vadd(vmul(c->ctangent[k].ii_torque_dir1[0], i0), vmul(c->ctangent[k].ii_torque_dir1[1], i1)));
+        v2.linear = vadd(v2.linear, vcmul(vadd(vmul(t0, -i0), vmul(t1, -i1)), c->im2));
+        v2.angular = vadd(v2.angular, vadd(vmul(c->ctangent[k].ii_torque_dir2[0], i0), vmul(c->ctangent[k].ii_torque_dir2[1], i1)));
+    }
+    scatter_vel(w, c->solver_vel1, &v1); scatter_vel(w, c->solver_vel2, &v2);
+}
+/* solve :605-690; elements contact_constraint_element.rs:100-176,242-270 */
+static void coulomb_solve(ro_world *w, Constraint *c, int solve_friction) {
+    SolverVel v1, v2; gather_vel(w, c->solver_vel1, &v1); gather_vel(w, c->solver_vel2, &v2);
+    for (int k = 0; k < c->num_contacts; ++k) {
+        NormalPart *n = &c->normal_part[k];
+        float dvel = vdot(c->dir1, v1.linear) + vdot(n->torque_dir1, v1.angular) - vdot(c->dir1, v2.linear) +
+                     vdot(n->torque_dir2, v2.angular) + n->rhs;
+        float new_impulse = n->cfm_factor * ro_maxf(n->impulse - n->r * dvel, 0.0f);
+        float dlambda = new_impulse - n->impulse;
+        n->impulse = new_impulse;
+        v1.linear = vadd(v1.linear, vmul(vcmul(c->dir1, c->im1), dlambda));
+        v1.angular = vadd(v1.angular, vmul(n->ii_torque_dir1, dlambda));
+        v2.linear = vadd(v2.linear, vmul(vcmul(c->dir1, c->im2), -dlambda));
+        v2.angular = vadd(v2.angular, vmul(n->ii_torque_dir2, dlambda));
+    }
+    if (solve_friction) {
+        v3 t0 = c->tangent1, t1 = vcross(c->dir1, c->tangent1);
+        for (int k = 0; k < c->num_contacts; ++k) {
+            float limit = c->limit * c->normal_part[k].impulse;
+            float dvel_0 = vdot(t0, v1.linear) + vdot(c->ctangent[k].torque_dir1[0], v1.angular) - vdot(t0, v2.linear) +
+                           vdot(c->ctangent[k].torque_dir2[0], v2.angular) + c->ctangent[k].rhs[0];
+            float dvel_1 = vdot(t1, v1.linear) + vdot(c->ctangent[k].torque_dir1[1], v1.angular) - vdot(t1, v2.linear) +
+                           vdot(c->ctangent[k].torque_dir2[1], v2.angular) + c->ctangent[k].rhs[1];
+            float k11 = c->ctangent[k].r[0], k22 = c->ctangent[k].r[1], k12 = c->ctangent[k].r[2] * 0.5f;
+            float inv_det = ro_inv(k11 * k22 - k12 * k12);
+            float d0 = (k22 * dvel_0 - k12 * dvel_1) * inv_det;
+            float d1 = (k11 * dvel_1 - k12 * dvel_0) * inv_det;
+            float n0 = c->ctangent[k].impulse[0] - d0, n1 = c->ctangent[k].impulse[1] - d1;
+            float len = sqrtf(n0 * n0 + n1 * n1);            /* nalgebra simd_cap_magnitude(limit) */
+            if (len > limit) { float s = limit / len; n0 *= s; n1 *= s; }
+            float dl0 = n0 - c->ctangent[k].impulse[0], dl1 = n1 - c->ctangent[k].impulse[1];
+            c->ctangent[k].impulse[0] = n0; c->ctangent[k].impulse[1] = n1;
+            v1.linear = vadd(v1.linear, vcmul(vadd(vmul(t0, dl0), vmul(t1, dl1)), c->im1));
+            v1.angular = vadd(v1.angular, vadd(vmul(c->ctangent[k].ii_torque_dir1[0], dl0), vmul(c->ctangent[k].ii_torque_dir1[1], dl1)));
+            v2.linear = vadd(v2.linear, vcmul(vadd(vmul(t0, -dl0), vmul(t1, -dl1)), c->im2));
+            v2.angular = vadd(v2.angular, vadd(vmul(c->ctangent[k].ii_torque_dir2[0], dl0), vmul(c->ctangent[k].ii_torque_dir2[1], dl1)));
+        }
+    }
+    scatter_vel(w, c->solver_vel1, &v1); scatter_vel(w, c->solver_vel2, &v2);
+}
+/* writeback_impulses :692-760: per-point world-space friction impulse; the twist warm start is left untouched */
+static void coulomb_writeback(ro_world *w, const Constraint *c) {
+    Pair *p = &w->pairs[c->pair];
+    v3 tangent2 = vcross(c->dir1, c->tangent1);
+    for (int k = 0; k < c->num_contacts; ++k) {
+        ContactData *pd = &p->m.points[c->contact_id[k]].data;
+        pd->warmstart_impulse = c->normal_part[k].impulse;
+        pd->impulse = c->normal_part[k].impulse_accumulator + c->normal_part[k].impulse;
+        pd->warmstart_tangent_world = vadd(vmul(c->tangent1, c->ctangent[k].impulse[0]), vmul(tangent2, c->ctangent[k].impulse[1]));
+    }
+}
+
 /* gyroscopic_corrected_angvel — dynamics/rigid_body.rs:2023-2046 */
 static v3 gyroscopic_corrected_angvel(v3 angvel, quat principal_axes, v3 pi, v3 inv_pi, float dt) {
     v3 wl = qrot_inv(principal_axes, angvel);
@@ -1449,8 +1650,9 @@ static void solve_velocity_constraints(ro_world *w) {
     }
     /* S1: generate — worker.rs:109-190.  Constraint i lives at bucket position i. */
     int any_bouncy = 0;
+    const int coulomb = prm->friction_model == RO_FRICTION_COULOMB; /* init.rs:419 */
     RO_PARALLEL_FOR
-    for (int i = 0; i < M; ++i) constraint_generate(w, order[i], &w->cons[i]);
+    for (int i = 0; i < M; ++i) { if (coulomb) coulomb_generate(w, order[i], &w->cons[i]); else constraint_generate(w, order[i], &w->cons[i]); }
     for (int i = 0; i < M; ++i)
         for (int k = 0; k < w->cons[i].num_contacts; ++k) any_bouncy |= w->cons[i].infos[k].restitution_seed < 0.0f;
     free(order);
@@ -1490,6 +1692,7 @@ static void solve_velocity_constraints(ro_world *w) {
             int serial = c == RO_COLOR_OVERFLOW; /* the overflow colour is not body-disjoint */
             RO_PRAGMA_IF_PAR(serial)
             for (int i = w->bucket_begin[c]; i < w->bucket_begin[c + 1]; ++i) {
+                if (coulomb) { coulomb_update(w, &w->cons[i], dt_s, solved_dt); if (prm->warmstart_coefficient != 0.0f) coulomb_warmstart(w, &w->cons[i]); continue; }
                 constraint_update(w, &w->cons[i], dt_s, solved_dt);
                 if (prm->warmstart_coefficient != 0.0f) constraint_warmstart(w, &w->cons[i]);
             }
@@ -1501,7 +1704,7 @@ static void solve_velocity_constraints(ro_world *w) {
                 int c = w->stage_color[st];
                 int serial = c == RO_COLOR_OVERFLOW;
                 RO_PRAGMA_IF_PAR(serial)
-                for (int i = w->bucket_begin[c]; i < w->bucket_begin[c + 1]; ++i) constraint_solve(w, &w->cons[i], solve_friction_in_bias);
+                for (int i = w->bucket_begin[c]; i < w->bucket_begin[c + 1]; ++i) { if (coulomb) coulomb_solve(w, &w->cons[i], solve_friction_in_bias); else constraint_solve(w, &w->cons[i], solve_friction_in_bias); }
             }
         }
         /* S6 integrate — worker.rs:568-631, rigid_body_components.rs:884-898 */
@@ -1523,6 +1726,7 @@ static void solve_velocity_constraints(ro_world *w) {
                 int serial = c == RO_COLOR_OVERFLOW;
                 RO_PRAGMA_IF_PAR(serial)
                 for (int i = w->bucket_begin[c]; i < w->bucket_begin[c + 1]; ++i) {
+                    if (coulomb) { coulomb_refresh_rhs_wo_bias(w, &w->cons[i], dt_s, solved_dt + dt_s); coulomb_solve(w, &w->cons[i], 1); continue; }
                     constraint_refresh_rhs_wo_bias(w, &w->cons[i], dt_s, solved_dt + dt_s);
                     constraint_solve(w, &w->cons[i], 1);
                 }
@@ -1537,7 +1741,7 @@ static void solve_velocity_constraints(ro_world *w) {
         }
     /* S9 impulse writeback — worker.rs:742-802 */
     RO_PARALLEL_FOR
-    for (int i = 0; i < M; ++i) constraint_writeback(w, &w->cons[i]);
+    for (int i = 0; i < M; ++i) { if (coulomb) coulomb_writeback(w, &w->cons[i]); else constraint_writeback(w, &w->cons[i]); }
     /* JointConstraintsSet::writeback_impulses — joint_velocity_constraint.rs:346-353 */
     for (int a = 0; a < w->nactive_joints; ++a) {
         Joint *j = &w->joints[w->active_joints[a]];

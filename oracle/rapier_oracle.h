@@ -45,9 +45,11 @@ typedef struct ro_params {
     int32_t friction_in_bias_pass;                                        /* 0 */
     int32_t warmstart_joints;                                             /* 0 */
     int32_t max_ccd_substeps;                                             /* 1 (flag only) */
+    int32_t friction_model;                                               /* FrictionModel: 0 Simplified (twist), 1 Coulomb */
 } ro_params;
 
 enum { RO_BODY_DYNAMIC = 0, RO_BODY_FIXED = 1 };
+enum { RO_FRICTION_SIMPLIFIED = 0, RO_FRICTION_COULOMB = 1 }; /* integration_parameters.rs:13-32 */
 enum { RO_SHAPE_BALL = 0, RO_SHAPE_CUBOID = 1 };
 /* CoefficientCombineRule — coefficient_combine_rule.rs:37-57 */
 enum { RO_RULE_AVERAGE = 0, RO_RULE_MIN = 1, RO_RULE_MULTIPLY = 2, RO_RULE_MAX = 3,

@@ -104,6 +104,7 @@ static int upload_collider_row(rp_world *w, int i);
 static int after_topology_edit(rp_world *w);
 static bool world_sleep_enabled(const rp_world *w);
 static int check_sleep_scope(rp_world *w);
+static int rebuild_begin(rp_world *w);
 
 extern "C" void rp_default_params(rp_integration_params *p) {
     // IntegrationParameters::default() — integration_parameters.rs:379-408
@@ -123,6 +124,7 @@ extern "C" void rp_default_params(rp_integration_params *p) {
     p->num_internal_stabilization_iterations = 1;
     p->contact_recycling = 1;
     p->friction_in_bias_pass = 0;
+    p->friction_model = RP_FRICTION_SIMPLIFIED;
     p->warmstart_joints = 0;
     p->max_ccd_substeps = 1;
 }
@@ -245,6 +247,12 @@ extern "C" int32_t rp_params_get(const rp_world *w, rp_integration_params *out) 
 extern "C" int32_t rp_params_set(rp_world *w, const rp_integration_params *in) {
     if (!w || !in) return RP_ERR_INVALID;
     if (w->finalized) { int r = settle(w); if (r != RP_OK) return r; }
+    if (in->friction_model != RP_FRICTION_SIMPLIFIED && in->friction_model != RP_FRICTION_COULOMB) { w->err = "rp_params_set: unknown friction_model"; return RP_ERR_INVALID; }
+    if (w->finalized && in->friction_model != w->params.friction_model) {
+        // the constraint planes are sized per friction model: rebuild the device world from the current state
+        int r = rebuild_begin(w);
+        if (r != RP_OK) return r;
+    }
     w->params = *in;
     if (w->finalized) { fill_sim_params(w, w->dw.prm, w->dw.prm.cell_size); destroy_graphs(w); }
     return RP_OK;
@@ -647,7 +655,7 @@ static int finalize(rp_world *w) {
         UP(d.b_collider, bcol);
         HIPCHK(w, hipStreamSynchronize(w->stream));
     }
-    DA(d.C, (size_t)CP_COUNT * d.cons_cap);
+    DA(d.C, (size_t)(w->params.friction_model == RP_FRICTION_COULOMB ? CQ_COUNT : CP_COUNT) * d.cons_cap); // Coulomb: + 9 tangent planes per point (rp_coulomb.h)
     DA(d.k_b1, d.cons_cap); DA(d.k_b2, d.cons_cap); DA(d.k_n, d.cons_cap); DA(d.k_cid, d.cons_cap);
 
     // host SoA staging (one batched copy per attribute)

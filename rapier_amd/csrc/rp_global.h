@@ -1,7 +1,7 @@
 // rp_global.h — the HBM-resident (global) solver path shared by rp_solver.hip (MULTI mode: one launch
 // per colour stage) and rp_islands.hip (SINGLE mode: one extra workgroup of the island launch).
 #pragma once
-#include "rp_constraint.h"
+#include "rp_coulomb.h"
 #include "rp_pairs.h"
 #include "rp_joints.h"
 
@@ -37,6 +37,7 @@ RP_DEV bool g_generate(const DevWorld &w, int pos) {
     bool dyn1 = body_active(w, rb1), dyn2 = body_active(w, rb2); // solver bodies = the active set (solver_body.rs:114)
     int id1 = (dyn1 && rel_dom <= 0) ? rb1 : -1;
     int id2 = (dyn2 && rel_dom >= 0) ? rb2 : -1;
+    if (coulomb_model(w)) return coul_generate(w, GlobalAcc(w, pos), s, id1, id2, id1, id2);
     return cons_generate(w, GlobalAcc(w, pos), s, id1, id2, id1, id2);
 }
 
@@ -47,14 +48,14 @@ RP_DEV void tail_sweep(const DevWorld &w, int first, bool fib, float solved_dt) 
     int nst = w.flags[FL_N_STAGES];
     for (int st = first; st < nst; ++st) {
         int beg = w.stage_begin[st], cnt = w.stage_count[st];
-        for (int i = threadIdx.x; i < cnt; i += blockDim.x) cons_apply(w, GlobalAcc(w, beg + i), MODE, fib, solved_dt);
+        for (int i = threadIdx.x; i < cnt; i += blockDim.x) cons_apply_model(w, GlobalAcc(w, beg + i), MODE, fib, solved_dt);
         __threadfence();
         __syncthreads();
     }
     if (w.flags[FL_HAS_OVERFLOW_COLOR]) {
         if (threadIdx.x == 0) {
             int beg = w.stage_begin[nst], cnt = w.stage_count[nst];
-            for (int i = 0; i < cnt; ++i) { cons_apply(w, GlobalAcc(w, beg + i), MODE, fib, solved_dt); __threadfence(); }
+            for (int i = 0; i < cnt; ++i) { cons_apply_model(w, GlobalAcc(w, beg + i), MODE, fib, solved_dt); __threadfence(); }
         }
         __threadfence();
         __syncthreads();
@@ -106,7 +107,7 @@ RP_DEV void global_single_block(const DevWorld &w, int has_restitution, int fast
         }
     }
     if (has_restitution && bouncy) tail_sweep<MODE_RESTITUTION>(w, 0, fib, 0.0f);
-    for (int pos = t; pos < M; pos += nt) cons_writeback(w, GlobalAcc(w, pos), w.cons_pair[pos]);
+    for (int pos = t; pos < M; pos += nt) { if (coulomb_model(w)) coul_writeback(w, GlobalAcc(w, pos), w.cons_pair[pos]); else cons_writeback(w, GlobalAcc(w, pos), w.cons_pair[pos]); }
     for (int j = t; j < nj; j += nt) joint_writeback_one(w, j);
     for (int i = t; i < nb; i += nt) if (global_body(w, i)) g_body_writeback(w, i);
 }

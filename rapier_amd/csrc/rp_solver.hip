@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(256) k_stage(DevWorld w, int stage, int fricti
     int beg = w.stage_begin[stage], cnt = w.stage_count[stage];
     int stride = gridDim.x * blockDim.x;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride)
-        cons_apply(w, GlobalAcc(w, beg + i), MODE, friction_in_bias != 0, solved_dt);
+        cons_apply_model(w, GlobalAcc(w, beg + i), MODE, friction_in_bias != 0, solved_dt);
 }
 template <int MODE>
 __global__ void __launch_bounds__(1024) k_tail(DevWorld w, int first, int friction_in_bias, float solved_dt) {
@@ -63,7 +63,7 @@ __global__ void k_writeback_impulses(DevWorld w) {
     int M = w.flags[FL_N_CONS];
     if (M > w.cons_cap) M = w.cons_cap;
     int stride = gridDim.x * blockDim.x;
-    for (int pos = blockIdx.x * blockDim.x + threadIdx.x; pos < M; pos += stride) cons_writeback(w, GlobalAcc(w, pos), w.cons_pair[pos]);
+    for (int pos = blockIdx.x * blockDim.x + threadIdx.x; pos < M; pos += stride) { if (coulomb_model(w)) coul_writeback(w, GlobalAcc(w, pos), w.cons_pair[pos]); else cons_writeback(w, GlobalAcc(w, pos), w.cons_pair[pos]); }
 }
 __global__ void k_writeback_bodies(DevWorld w) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -106,6 +106,9 @@ enum {
     CP_N0,      // first per-point plane; point k uses CP_N0 + 7*k + {NM..NF}
     CP_COUNT = CP_N0 + 7 * 4
 };
+// FrictionModel::Coulomb adds 9 tangent planes per point behind CP_COUNT (rp_coulomb.h)
+#define CQ_PER_POINT 9
+#define CQ_COUNT (CP_COUNT + CQ_PER_POINT * 4)
 enum {
     NP_M = 0,   // mutable: rhs, cfm_factor, impulse, impulse_accumulator
     NP_A,       // torque_dir1.xyz, r

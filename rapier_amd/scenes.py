@@ -49,7 +49,10 @@ PARAMS_DTYPE = np.dtype([
     ("num_solver_iterations", "<i4"), ("num_internal_pgs_iterations", "<i4"),
     ("num_internal_stabilization_iterations", "<i4"), ("contact_recycling", "<i4"),
     ("friction_in_bias_pass", "<i4"), ("warmstart_joints", "<i4"), ("max_ccd_substeps", "<i4"),
+    ("friction_model", "<i4"),
 ], align=False)
+
+FRICTION_SIMPLIFIED, FRICTION_COULOMB = 0, 1  # FrictionModel, integration_parameters.rs:13-32
 
 LOCK_LIN = 0b000111
 LOCK_ALL = 0b111111
@@ -76,6 +79,7 @@ def default_params() -> np.ndarray:
     p["friction_in_bias_pass"] = 0
     p["warmstart_joints"] = 0
     p["max_ccd_substeps"] = 1
+    p["friction_model"] = FRICTION_SIMPLIFIED
     return p
 
 

@@ -164,6 +164,13 @@ class PhysicsWorld:
             w.insert_impulse_joints(joints)
         return w
 
+    def set_integration_parameters(self, params):
+        """Replace the world's IntegrationParameters (rp_params_set); switching `friction_model` on a stepped
+        world rebuilds the device world from the current body states."""
+        ip = params if isinstance(params, IntegrationParameters) else IntegrationParameters(params)
+        _check(self._ptr, self._lib.rp_params_set(self._ptr, ip.as_array().ctypes.data), "rp_params_set")
+        self.integration_parameters = ip
+
     # ---- insertion (RigidBodySet::insert, ColliderSet::insert_with_parent, ...) ----
     def insert_bodies(self, descs: np.ndarray) -> np.ndarray:
         descs = np.ascontiguousarray(descs, dtype=S.BODY_DTYPE)

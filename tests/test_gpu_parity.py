@@ -422,6 +422,41 @@ def test_sleep_full_size_many_pyramids():
     assert c["num_sleeping_bodies"] == 10780 and c["num_manifolds"] == 0
 
 
+# ---- FrictionModel::Coulomb (SURVEY §8a SV1 twin): rp_coulomb.h on the global path vs the oracle ----
+def _coulomb(scene):
+    scene.params["friction_model"] = S.FRICTION_COULOMB
+    return scene
+
+
+def test_coulomb_friction_bit_exact():
+    _compare(_coulomb(S.box_stack(3)), [1, 2, 10, 60])
+    sl = _coulomb(S.box_stack(1)); sl.bodies[1]["linvel"] = (3.0, 0.0, 0.5)
+    _compare(sl, [1, 5, 20, 80])
+    g, o = _compare(_coulomb(S.pyramid10()), [1, 10, 100, 300])
+    gm, gn, gi = g.contacts()
+    om, on, oi = o.manifolds()
+    gk = {(a, b): (c, n, tuple(i)) for (a, b, c, n), i in zip(gm.tolist(), gi.tolist())}
+    ok = {(a, b): (c, n, tuple(i)) for (a, b, c, n), i in zip(om.tolist(), oi.tolist())}
+    assert gk == ok
+    _compare(_coulomb(S.tumble(40, seed=11)), [1, 30, 90, 250])   # restitution, balls, pair churn
+
+
+def test_coulomb_multi_mode_and_model_switch():
+    """Full-size b3d_many_pyramids under Coulomb friction: every manifold on the per-colour launch path."""
+    g, o = _compare(_coulomb(S.many_pyramids()), [1, 5, 30])
+    assert g.counters()["num_manifolds"] == 28420
+    # switching the model on a live world rebuilds the device world from the current state and keeps simulating
+    sc = S.pyramid10()
+    w = PhysicsWorld.from_scene(sc)
+    w.step(30)
+    p = w.integration_parameters.as_array().copy()
+    p["friction_model"] = S.FRICTION_COULOMB
+    w.set_integration_parameters(p)
+    w.step(120)
+    pos, vel = w.read_bodies()
+    assert np.isfinite(pos).all() and np.abs(vel).max() < 0.05 and pos[1:, 1].max() == pytest.approx(9.5, abs=0.05)
+
+
 def test_out_of_scope_inputs_are_refused():
     """Angular joint locks, contact-disabled joints, compound bodies and joints on can_sleep bodies are refused
     loudly, not mis-simulated."""

@@ -198,6 +198,36 @@ def test_oracle_threads_do_not_change_results():
         np.testing.assert_array_equal(v1, v4)
 
 
+# FrictionModel::Coulomb (contact_with_coulomb_friction.rs): a sliding box decelerates at mu * g under either
+# friction model, and a resting pyramid carries its weight (total_contact_impulse.rs restated for the twin).
+@pytest.mark.parametrize("model", [S.FRICTION_SIMPLIFIED, S.FRICTION_COULOMB])
+def test_sliding_box_decelerates_at_mu_g(model):
+    sc = S.box_stack(1)
+    sc.params["friction_model"] = model
+    sc.bodies[1]["linvel"] = (3.0, 0.0, 0.0)
+    w = OracleWorld(sc)
+    w.step(20)
+    _, v = w.read()
+    mu, g, t = 0.5, 9.81, 20.0 / 60.0
+    assert v[1, 0] == pytest.approx(3.0 - mu * g * t, abs=0.15)
+    w.step(60)
+    _, v = w.read()
+    assert abs(v[1, 0]) < 1e-3                # came to rest: static friction holds
+
+
+def test_coulomb_pyramid_rests_and_carries_its_weight():
+    sc = S.pyramid10()
+    sc.params["friction_model"] = S.FRICTION_COULOMB
+    w = OracleWorld(sc)
+    w.step(300)
+    pos, vel = w.read()
+    assert np.abs(vel).max() < 1e-3 and pos[1:, 1].max() == pytest.approx(9.5, abs=0.02)
+    meta, nrm, imp = w.manifolds()
+    ground = meta[:, 0] == 0
+    weight = 55 * 100.0 * 10.0 / 60.0         # 55 unit cubes of density 100, g = 10, dt = 1/60
+    assert imp[ground].sum() == pytest.approx(weight, rel=0.01)
+
+
 # Sleeping: RigidBodyActivation::update_energy (rigid_body_components.rs:1412-1478), whole-island sleep
 # (island_manager/manager.rs:335-388), wake rules (contacts.rs:333-351, sleep.rs:31-79).  The reference's own
 # sleep tests (src/pipeline/physics_pipeline/test.rs:340-372: a resting body falls asleep, a woken one is awake)
