@@ -60,7 +60,8 @@ typedef struct rp_integration_params {
 
 enum { RP_FRICTION_SIMPLIFIED = 0, RP_FRICTION_COULOMB = 1 };
 
-enum { RP_BODY_DYNAMIC = 0, RP_BODY_FIXED = 1 };
+/* RigidBodyType — rigid_body_components.rs */
+enum { RP_BODY_DYNAMIC = 0, RP_BODY_FIXED = 1, RP_BODY_KINEMATIC_POSITION = 2, RP_BODY_KINEMATIC_VELOCITY = 3 };
 enum { RP_SHAPE_BALL = 0, RP_SHAPE_CUBOID = 1 };
 enum { RP_RULE_AVERAGE = 0, RP_RULE_MIN, RP_RULE_MULTIPLY, RP_RULE_MAX, RP_RULE_CLAMPED_SUM, RP_RULE_GEOMETRIC_MEAN };
 
@@ -181,6 +182,12 @@ int32_t rp_bodies_write(rp_world *w, int32_t n, const uint64_t *handles, const f
  * rp_bodies_is_sleeping = RigidBody::is_sleeping (NULL handles are not accepted).  Scope: impulse joints in a
  * world with can_sleep bodies are refused with RP_ERR_INVALID. */
 int32_t rp_bodies_wake_up(rp_world *w, int32_t n, const uint64_t *handles, int32_t strong);
+/* RigidBody::set_next_kinematic_position (rigid_body.rs:1085-1093) for n kinematic bodies: the pose to reach by the
+ * end of the next step.  Position-based kinematic bodies get their velocity from it (interpolate_kinematic_velocities,
+ * substep.rs:242-264) and land on it exactly; the body is woken when the pose differs from its current one.
+ * Kinematic bodies are solver bodies with zero inverse mass: they push dynamic bodies and are never pushed.
+ * Scope: worlds holding kinematic bodies take the full step path and refuse impulse joints. */
+int32_t rp_bodies_set_next_kinematic_position(rp_world *w, int32_t n, const uint64_t *handles, const float *pos7);
 int32_t rp_bodies_is_sleeping(rp_world *w, int32_t n, const uint64_t *handles, int32_t *sleeping_out);
 int32_t rp_num_bodies(const rp_world *w);
 

@@ -418,9 +418,18 @@ void ro_set_body_pose(ro_world *w, int32_t body, const float pos7[7]) {
         if (b2 == body) wake_request(w, b1, 1);
     }
 }
+void ro_set_next_kinematic_position(ro_world *w, int32_t body, const float pos7[7]) {
+    Body *b = &w->bodies[body];
+    if (b->body_type != RO_BODY_KINEMATIC_POSITION && b->body_type != RO_BODY_KINEMATIC_VELOCITY) return;
+    pose np; np.t = V3(pos7[0], pos7[1], pos7[2]); np.r = Q(pos7[3], pos7[4], pos7[5], pos7[6]);
+    b->next_position = np;
+    const pose *p = &b->position;
+    if (p->t.x != np.t.x || p->t.y != np.t.y || p->t.z != np.t.z || p->r.x != np.r.x || p->r.y != np.r.y || p->r.z != np.r.z || p->r.w != np.r.w)
+        wake_request(w, body, 1);
+}
 void ro_wake_up(ro_world *w, int32_t body, int32_t strong) { if (body >= 0 && body < w->nbodies) wake_request(w, body, strong); }
 void ro_read_sleeping(const ro_world *w, int32_t *sleeping) {
-    for (int i = 0; i < w->nbodies; ++i) sleeping[i] = w->bodies[i].body_type == RO_BODY_DYNAMIC && w->bodies[i].sleeping;
+    for (int i = 0; i < w->nbodies; ++i) sleeping[i] = w->bodies[i].body_type != RO_BODY_FIXED && w->bodies[i].sleeping;
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -492,8 +501,9 @@ static void map_rebuild(ro_world *w) {
 
 static int body_is_dynamic(const ro_world *w, int parent) { return parent >= 0 && w->bodies[parent].body_type == RO_BODY_DYNAMIC; }
 /* member of the active set: an awake dynamic body (IslandManager::active_bodies) */
-static int body_is_active(const ro_world *w, int body) { return body >= 0 && w->bodies[body].body_type == RO_BODY_DYNAMIC && !w->bodies[body].sleeping; }
-static int body_is_sleeping_dyn(const ro_world *w, int body) { return body >= 0 && w->bodies[body].body_type == RO_BODY_DYNAMIC && w->bodies[body].sleeping; }
+static int body_is_active(const ro_world *w, int body) { return body >= 0 && w->bodies[body].body_type != RO_BODY_FIXED && !w->bodies[body].sleeping; } /* dynamic or kinematic, awake */
+static int body_is_dyn_awake(const ro_world *w, int body) { return body >= 0 && w->bodies[body].body_type == RO_BODY_DYNAMIC && !w->bodies[body].sleeping; }
+static int body_is_sleeping_nonfixed(const ro_world *w, int body) { return body >= 0 && w->bodies[body].body_type != RO_BODY_FIXED && w->bodies[body].sleeping; }
 /* pair_solver_hints count cleared by clear_asleep_pair_solver_hint_counts_of (solver_graph.rs:21-49): one of the
  * pair's bodies fell asleep after the hint was last computed */
 static int pair_hint_cleared(const ro_world *w, const Pair *p) {
@@ -505,7 +515,8 @@ static int pair_hint_cleared(const ro_world *w, const Pair *p) {
 static int pair_selected(const ro_world *w, const Pair *p) {
     if (!p->alive || p->nsc == 0 || p->color == RO_COLOR_UNCOLORED) return 0;
     if (pair_hint_cleared(w, p)) return 0;
-    return body_is_active(w, w->colliders[p->c1].parent) || body_is_active(w, w->colliders[p->c2].parent);
+    /* PAIR_HINT_DYN_BIT + qualify_manifold_bqi: at least one awake DYNAMIC body */
+    return body_is_dyn_awake(w, w->colliders[p->c1].parent) || body_is_dyn_awake(w, w->colliders[p->c2].parent);
 }
 
 /* update.rs:334-396 pair filter (same parent, collision types, groups) */
@@ -528,7 +539,7 @@ static void clear_pair_solver_color(ro_world *w, Pair *p);
  * any body of a sleeping island wakes the whole island with a strong timer reset for every member; a
  * strong wake of an awake body only resets its own timer. */
 static void wake_request(ro_world *w, int body, int strong) {
-    if (body < 0 || w->bodies[body].body_type != RO_BODY_DYNAMIC) return;
+    if (body < 0 || w->bodies[body].body_type == RO_BODY_FIXED) return;
     int lvl = strong ? 2 : 1;
     if (w->bodies[body].wake_req < lvl) w->bodies[body].wake_req = lvl;
 }
@@ -548,7 +559,7 @@ static void apply_wakes(ro_world *w) {
     }
     for (int i = 0; i < w->nbodies; ++i) {
         Body *b = &w->bodies[i];
-        if (b->body_type == RO_BODY_DYNAMIC && b->sleeping && woken[b->sleep_label]) { b->sleeping = 0; b->time_since_can_sleep = 0.0f; }
+        if (b->body_type != RO_BODY_FIXED && b->sleeping && woken[b->sleep_label]) { b->sleeping = 0; b->time_since_can_sleep = 0.0f; }
     }
 }
 
@@ -701,7 +712,7 @@ typedef struct { int pair; int body1, body2; int touching; } Transition;
 
 static int effective_dominance_group(const ro_world *w, int body) {
     /* RigidBodyDominance::effective_group — rigid_body_components.rs:1269-1275 */
-    if (body >= 0 && w->bodies[body].body_type == RO_BODY_DYNAMIC) return w->bodies[body].dominance;
+    if (body >= 0 && w->bodies[body].body_type != RO_BODY_FIXED) return w->bodies[body].dominance; /* is_dynamic_or_kinematic, rigid_body_components.rs:1269 */
     return 128;
 }
 
@@ -848,8 +859,8 @@ static void narrow_phase_compute_contacts(ro_world *w) {
         Pair *p = &w->pairs[tr[i].pair];
         if (!tr[i].touching) { clear_pair_solver_color(w, p); continue; }
         /* wake rule (contacts.rs:333-351): starts wake the sleeping side strongly (whole island), stops never wake */
-        if (body_is_sleeping_dyn(w, tr[i].body1)) wake_request(w, tr[i].body1, 1);
-        if (body_is_sleeping_dyn(w, tr[i].body2)) wake_request(w, tr[i].body2, 1);
+        if (body_is_sleeping_nonfixed(w, tr[i].body1)) wake_request(w, tr[i].body1, 1);
+        if (body_is_sleeping_nonfixed(w, tr[i].body2)) wake_request(w, tr[i].body2, 1);
         uint32_t a = tr[i].body1 >= 0 ? (uint32_t)tr[i].body1 : RO_NO_BODY;
         uint32_t b = tr[i].body2 >= 0 ? (uint32_t)tr[i].body2 : RO_NO_BODY;
         uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
@@ -1396,7 +1407,7 @@ static void joints_select_active(ro_world *w) {
         Joint *j = &w->joints[i];
         if (j->removed) continue;
         const Body *rb1 = &w->bodies[j->body1], *rb2 = &w->bodies[j->body2];
-        int d1 = rb1->body_type == RO_BODY_DYNAMIC, d2 = rb2->body_type == RO_BODY_DYNAMIC;
+        int d1 = rb1->body_type != RO_BODY_FIXED, d2 = rb2->body_type != RO_BODY_FIXED; /* is_dynamic_or_kinematic */
         if (!d1 && !d2) continue;
         if ((d1 && rb1->sleeping) || (d2 && rb2->sleeping)) continue; /* :553-556 */
         j->solver_body_ids[0] = d1 ? rb1->solver_id : RO_NO_BODY;
@@ -1642,7 +1653,7 @@ static void solve_velocity_constraints(ro_world *w) {
         w->incr[i].angular = vmul(sym3_mul(rb->effective_world_inv_inertia, rb->torque), dt_s);
         w->incr[i].linear = vmul(vcmul(rb->force, rb->effective_inv_mass), dt_s);
         Gyro *g = &w->gyro[i];
-        if (rb->gyroscopic) {
+        if (rb->gyroscopic && rb->body_type == RO_BODY_DYNAMIC) { /* worker.rs:86 */
             g->inv_principal_inertia = rb->inv_principal_inertia;
             g->principal_inertia = V3(ro_inv(rb->inv_principal_inertia.x), ro_inv(rb->inv_principal_inertia.y), ro_inv(rb->inv_principal_inertia.z));
             g->principal_frame = rb->principal_frame; g->enabled = 1;
@@ -1754,6 +1765,7 @@ static void solve_velocity_constraints(ro_world *w) {
         rb->linvel = vmul(w->vels[i].linear, 1.0f / (1.0f + prm->dt * rb->linear_damping));
         rb->angvel = vmul(w->vels[i].angular, 1.0f / (1.0f + prm->dt * rb->angular_damping));
         pose sp; sp.r = w->poses[i].rotation; sp.t = w->poses[i].translation;
+        if (rb->body_type == RO_BODY_KINEMATIC_POSITION) continue; /* :836-842 keep exactly the pose the user asked for */
         /* pose.prepend_translation(-local_com) */
         rb->next_position.r = sp.r;
         rb->next_position.t = vadd(sp.t, qrot(sp.r, vneg(rb->local_com)));
@@ -1775,6 +1787,12 @@ static void update_sleep(ro_world *w) {
     for (int i = 0; i < n; ++i) {
         Body *b = &w->bodies[i];
         if (!body_is_active(w, i)) continue;
+        if (b->body_type != RO_BODY_DYNAMIC) { /* platforms only sleep when both velocities are exactly zero (:1464-1468) */
+            int still = vdot(b->linvel, b->linvel) == 0.0f && vdot(b->angvel, b->angvel) == 0.0f;
+            if (still) b->time_since_can_sleep += dt; else b->time_since_can_sleep = 0.0f;
+            any_can_sleep |= 1;
+            continue;
+        }
         float linear_threshold = b->normalized_linear_threshold * length_unit;
         pose prev = b->sleep_prev_pose; b->sleep_prev_pose = b->position;
         float sq_angvel = vdot(b->angvel, b->angvel);
@@ -1826,6 +1844,18 @@ static void step_once(ro_world *w) {
     apply_wakes(w);
     narrow_phase_compute_contacts(w);
     apply_wakes(w);
+    /* interpolate_kinematic_velocities — substep.rs:242-264, RigidBodyPosition::interpolate_velocity
+     * (rigid_body_components.rs:147-194) */
+    for (int i = 0; i < w->nbodies; ++i) {
+        Body *b = &w->bodies[i];
+        if (b->body_type != RO_BODY_KINEMATIC_POSITION || b->sleeping) continue;
+        float inv_dt = w->params.dt == 0.0f ? 0.0f : 1.0f / w->params.dt;
+        v3 com = pose_tp(b->position, b->local_com);
+        pose shift = pose_ident(); shift.t = com;
+        pose dpos = pose_mul(pose_mul(pose_mul(pose_inv(shift), b->next_position), pose_inv(b->position)), shift);
+        b->linvel = vmul(dpos.t, inv_dt);
+        b->angvel = vmul(quat_to_scaled_axis(dpos.r), inv_dt);
+    }
     /* fused body pass — solve.rs:234-291: sleep timers, then the island sleep decision (update_islands) */
     update_sleep(w);
     /* compute_effective_force_and_torque rigid_body_components.rs:1030-1033 */

@@ -48,7 +48,8 @@ typedef struct ro_params {
     int32_t friction_model;                                               /* FrictionModel: 0 Simplified (twist), 1 Coulomb */
 } ro_params;
 
-enum { RO_BODY_DYNAMIC = 0, RO_BODY_FIXED = 1 };
+/* RigidBodyType — rigid_body_components.rs */
+enum { RO_BODY_DYNAMIC = 0, RO_BODY_FIXED = 1, RO_BODY_KINEMATIC_POSITION = 2, RO_BODY_KINEMATIC_VELOCITY = 3 };
 enum { RO_FRICTION_SIMPLIFIED = 0, RO_FRICTION_COULOMB = 1 }; /* integration_parameters.rs:13-32 */
 enum { RO_SHAPE_BALL = 0, RO_SHAPE_CUBOID = 1 };
 /* CoefficientCombineRule — coefficient_combine_rule.rs:37-57 */
@@ -110,6 +111,8 @@ int32_t ro_num_bodies(const ro_world *w);
 void ro_read_bodies(const ro_world *w, float *pos7, float *vel6);
 /* RigidBody::set_linvel/set_angvel(.., wake_up = true) */
 void ro_set_body_vel(ro_world *w, int32_t body, const float linvel[3], const float angvel[3]);
+/* RigidBody::set_next_kinematic_position (rigid_body.rs:1085-1093): kinematic bodies only; wakes when the pose differs */
+void ro_set_next_kinematic_position(ro_world *w, int32_t body, const float pos7[7]);
 /* RigidBody::set_position(.., wake_up = true) */
 void ro_set_body_pose(ro_world *w, int32_t body, const float pos7[7]);
 /* IslandManager::wake_up (island_manager/sleep.rs:31): wakes the body's whole island. */

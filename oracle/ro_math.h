@@ -86,6 +86,33 @@ static inline v3 pose_tp(pose a, v3 p) { return vadd(qrot(a.r, p), a.t); }
 static inline v3 pose_itp(pose a, v3 p) { return qrot_inv(a.r, vsub(p, a.t)); }
 static inline pose pose_ident(void) { pose p; p.r = qident(); p.t = V3(0, 0, 0); return p; }
 
+/* Portable single-precision atan (Cephes atanf scheme: two range reductions + a degree-9 odd polynomial, only
+ * + - * /), so that the oracle and the HIP kernels (rp_math.h: rp_atan_portable) agree bit for bit; libm's and
+ * ocml's atan2f are each within 1 ulp of it but not of each other. */
+static inline float ro_atan_portable(float x) {
+    float sign = 1.0f; if (x < 0.0f) { sign = -1.0f; x = -x; }
+    float y;
+    if (x > 2.414213562373095f) { y = 1.5707963267948966f; x = -(1.0f / x); }
+    else if (x > 0.4142135623730950f) { y = 0.7853981633974483f; x = (x - 1.0f) / (x + 1.0f); }
+    else y = 0.0f;
+    float z = x * x;
+    y = y + ((((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * x + x);
+    return sign * y;
+}
+/* atan2(y, x) for y >= 0 */
+static inline float ro_atan2_pos(float y, float x) {
+    if (x > 0.0f) return ro_atan_portable(y / x);
+    if (x < 0.0f) return 3.14159265358979323846f + ro_atan_portable(y / x);
+    return y > 0.0f ? 1.5707963267948966f : 0.0f;
+}
+/* Quat::to_scaled_axis: axis * angle, angle = 2 atan2(|v|, w) */
+static inline v3 quat_to_scaled_axis(quat q) {
+    v3 v = V3(q.x, q.y, q.z);
+    float length = vlen(v);
+    if (length >= 1.0e-8f) { float angle = 2.0f * ro_atan2_pos(length, q.w); return vmul(vmul(v, 1.0f / length), angle); }
+    return V3(0, 0, 0);
+}
+
 static inline v3 sym3_mul(sym3 m, v3 v) {
     return V3(m.m11 * v.x + m.m12 * v.y + m.m13 * v.z,
               m.m12 * v.x + m.m22 * v.y + m.m23 * v.z,

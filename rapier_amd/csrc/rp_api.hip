@@ -46,6 +46,7 @@ struct HostBody {
     // RigidBodyActivation state carried across device rebuilds (rp_sleep.hip)
     float max_extent = 0.0f, sleep_timer = 0.0f, sprev[7] = {0, 0, 0, 0, 0, 0, 1};
     int sleeping = 0, slabel = 0;
+    bool has_next = false; float next[7] = {0, 0, 0, 0, 0, 0, 1}; // RigidBodyPosition::next_position of a kinematic body
 };
 
 struct rp_world {
@@ -103,8 +104,10 @@ static int upload_body_row_mass(rp_world *w, int i);
 static int upload_collider_row(rp_world *w, int i);
 static int after_topology_edit(rp_world *w);
 static bool world_sleep_enabled(const rp_world *w);
+static bool world_has_kinematic_pos(const rp_world *w);
 static int check_sleep_scope(rp_world *w);
 static int rebuild_begin(rp_world *w);
+static int finalize(rp_world *w);
 
 extern "C" void rp_default_params(rp_integration_params *p) {
     // IntegrationParameters::default() — integration_parameters.rs:379-408
@@ -325,8 +328,13 @@ static int download_state(rp_world *w) {
     HIPCHK(w, hipMemcpy(spr.data(), w->dw.b_sprev_r, nb * sizeof(float4), hipMemcpyDeviceToHost));
     HIPCHK(w, hipMemcpy(bfl.data(), w->dw.b_flags, nb * sizeof(int), hipMemcpyDeviceToHost));
     HIPCHK(w, hipMemcpy(slab.data(), w->dw.b_slabel, nb * sizeof(int), hipMemcpyDeviceToHost));
+    std::vector<float4> npos(nb), nrot(nb);
+    HIPCHK(w, hipMemcpy(npos.data(), w->dw.b_next_pos, nb * sizeof(float4), hipMemcpyDeviceToHost));
+    HIPCHK(w, hipMemcpy(nrot.data(), w->dw.b_next_rot, nb * sizeof(float4), hipMemcpyDeviceToHost));
     for (int i = 0; i < nb; ++i) {
         HostBody &hb = w->bodies[i];
+        hb.has_next = true; hb.next[0] = npos[i].x; hb.next[1] = npos[i].y; hb.next[2] = npos[i].z;
+        hb.next[3] = nrot[i].x; hb.next[4] = nrot[i].y; hb.next[5] = nrot[i].z; hb.next[6] = nrot[i].w;
         hb.sleep_timer = slp[i].x; hb.sleeping = (bfl[i] & RP_BF_SLEEPING) ? 1 : 0; hb.slabel = slab[i];
         hb.sprev[0] = spt[i].x; hb.sprev[1] = spt[i].y; hb.sprev[2] = spt[i].z;
         hb.sprev[3] = spr[i].x; hb.sprev[4] = spr[i].y; hb.sprev[5] = spr[i].z; hb.sprev[6] = spr[i].w;
@@ -360,6 +368,7 @@ extern "C" int32_t rp_bodies_insert(rp_world *w, int32_t n, const rp_body_desc *
         int r = in_place ? settle(w) : rebuild_begin(w);
         if (r != RP_OK) return r;
     }
+    for (int i = 0; i < n; ++i) if (descs[i].body_type < RP_BODY_DYNAMIC || descs[i].body_type > RP_BODY_KINEMATIC_VELOCITY) { w->err = "rp_bodies_insert: unknown body_type"; return RP_ERR_INVALID; }
     for (int i = 0; i < n; ++i) {
         HostBody b; b.d = descs[i]; b.ncolliders = 0; b.removed = false; b.inv_mass = 0; b.inv_pi[0] = b.inv_pi[1] = b.inv_pi[2] = 0; b.lcom[0] = b.lcom[1] = b.lcom[2] = 0;
         b.slabel = (int)w->bodies.size();
@@ -372,6 +381,7 @@ extern "C" int32_t rp_bodies_insert(rp_world *w, int32_t n, const rp_body_desc *
         w->dw.n_bodies = (int)w->bodies.size();
         { int r = check_sleep_scope(w); if (r != RP_OK) return r; }
         w->dw.sleep_enabled = world_sleep_enabled(w) ? 1 : 0;
+        w->dw.has_kinematic_pos = world_has_kinematic_pos(w) ? 1 : 0;
         HIPCHK(w, hipStreamSynchronize(w->stream));
         destroy_graphs(w); // kernel arguments (DevWorld by value) hold the body count
         return after_topology_edit(w);
@@ -462,7 +472,7 @@ static int next_pow2(long long x) { long long p = 1; while (p < x) p <<= 1; retu
 static float4 mk4(float x, float y, float z, float w_) { float4 r; r.x = x; r.y = y; r.z = z; r.w = w_; return r; }
 
 // One body / collider row of the SoA device world from the host mirrors (finalize and incremental inserts).
-struct BodyRow { float4 pos, rot, lv, av, lci, ipi, pfr, damp, slp, spt, spr; int fl, slabel; };
+struct BodyRow { float4 pos, rot, lv, av, lci, ipi, pfr, damp, slp, spt, spr, npos, nrot; int fl, slabel; };
 static BodyRow pack_body(const HostBody &b) {
     const rp_body_desc &bd = b.d;
     BodyRow o;
@@ -476,16 +486,18 @@ static BodyRow pack_body(const HostBody &b) {
     o.pfr = mk4(0, 0, 0, 1);
     o.damp = mk4(bd.linear_damping, bd.angular_damping, bd.gravity_scale, 0);
     int fl = ((b.removed ? RP_BODY_FIXED : bd.body_type) & RP_BF_TYPE_MASK);
-    if (bd.gyroscopic) fl |= RP_BF_GYRO;
+    if (bd.gyroscopic && bd.body_type == RP_BODY_DYNAMIC) fl |= RP_BF_GYRO; // gyroscopic forces: dynamic bodies only (worker.rs:86)
     if (bd.allow_fast_rotation) fl |= RP_BF_FASTROT;
     fl |= ((int)(bd.dominance & 0xff)) << RP_BF_DOM_SHIFT;
-    if (b.sleeping && !b.removed && bd.body_type == RP_BODY_DYNAMIC) fl |= RP_BF_SLEEPING;
+    if (b.sleeping && !b.removed && bd.body_type != RP_BODY_FIXED) fl |= RP_BF_SLEEPING;
     o.fl = fl;
     // RigidBodyActivation::active() / cannot_sleep() — rigid_body_components.rs:1354-1385
     o.slp = mk4(b.sleep_timer, bd.can_sleep ? 0.05f : -1.0f, bd.can_sleep ? 0.5f : -1.0f, 0.5f);
     o.spt = mk4(b.sprev[0], b.sprev[1], b.sprev[2], b.max_extent);
     o.spr = mk4(b.sprev[3], b.sprev[4], b.sprev[5], b.sprev[6]);
     o.slabel = b.slabel;
+    o.npos = b.has_next ? mk4(b.next[0], b.next[1], b.next[2], 0) : o.pos;
+    o.nrot = b.has_next ? mk4(b.next[3], b.next[4], b.next[5], b.next[6]) : o.rot;
     return o;
 }
 #define PUT(arr, idx, val) HIPCHK(w, hipMemcpyAsync((arr) + (idx), &(val), sizeof(val), hipMemcpyHostToDevice, w->stream))
@@ -496,6 +508,7 @@ static int upload_body_row(rp_world *w, int i) {
     PUT(d.b_pos, i, r.pos); PUT(d.b_rot, i, r.rot); PUT(d.b_linvel, i, r.lv); PUT(d.b_angvel, i, r.av); PUT(d.b_lcom_invm, i, r.lci);
     PUT(d.b_invpi, i, r.ipi); PUT(d.b_pframe, i, r.pfr); PUT(d.b_damp, i, r.damp); PUT(d.b_flags, i, r.fl);
     PUT(d.b_sleep, i, r.slp); PUT(d.b_sprev_t, i, r.spt); PUT(d.b_sprev_r, i, r.spr); PUT(d.b_slabel, i, r.slabel);
+    PUT(d.b_next_pos, i, r.npos); PUT(d.b_next_rot, i, r.nrot);
     return RP_OK;
 }
 struct ColliderRow { int parent, shape; float4 lp, lr, he, mat, fmn, fmx; int2 rules; uint2 groups; };
@@ -531,13 +544,22 @@ static int upload_collider_row(rp_world *w, int i) {
 }
 
 static bool world_sleep_enabled(const rp_world *w) {
-    for (const HostBody &b : w->bodies) if (!b.removed && b.d.body_type == RP_BODY_DYNAMIC && b.d.can_sleep) return true;
+    for (const HostBody &b : w->bodies) {
+        if (b.removed) continue;
+        if (b.d.body_type == RP_BODY_DYNAMIC && b.d.can_sleep) return true;
+        // a kinematic body is sleep-eligible whenever its velocity is exactly zero, whatever can_sleep says
+        if (b.d.body_type == RP_BODY_KINEMATIC_POSITION || b.d.body_type == RP_BODY_KINEMATIC_VELOCITY) return true;
+    }
+    return false;
+}
+static bool world_has_kinematic_pos(const rp_world *w) {
+    for (const HostBody &b : w->bodies) if (!b.removed && b.d.body_type == RP_BODY_KINEMATIC_POSITION) return true;
     return false;
 }
 static int check_sleep_scope(rp_world *w) {
     if (!world_sleep_enabled(w)) return RP_OK;
     for (size_t j = 0; j < w->joints.size(); ++j)
-        if (!w->joint_removed[j]) { w->err = "impulse joints in a world with can_sleep bodies are not implemented on the device path (build the bodies with can_sleep = 0)"; return RP_ERR_INVALID; }
+        if (!w->joint_removed[j]) { w->err = "impulse joints in a world with can_sleep or kinematic bodies are not implemented on the device path"; return RP_ERR_INVALID; }
     return RP_OK;
 }
 
@@ -548,6 +570,7 @@ static int finalize(rp_world *w) {
     DevWorld &d = w->dw;
     memset(&d, 0, sizeof(d));
     d.sleep_enabled = world_sleep_enabled(w) ? 1 : 0;
+    d.has_kinematic_pos = world_has_kinematic_pos(w) ? 1 : 0;
     int nb = (int)w->bodies.size(), nc = (int)w->colliders.size();
     d.n_bodies = nb; d.n_colliders = nc;
     // capacities leave room for bodies / colliders inserted later without rebuilding the device world
@@ -580,7 +603,7 @@ static int finalize(rp_world *w) {
     DA(d.b_pframe, capb); DA(d.b_wcom, capb); DA(d.b_eim, capb); DA(d.b_eii0, capb); DA(d.b_eii1, capb); DA(d.b_damp, capb);
     DA(d.b_uforce, capb); DA(d.b_utorque, capb); DA(d.b_flags, capb); DA(d.b_quar, capb); DAF(d.b_collider, capb, 0xff);
     DA(d.b_sleep, capb); DA(d.b_sprev_t, capb); DA(d.b_sprev_r, capb); DA(d.b_slabel, capb); DA(d.b_slept_at, capb); DA(d.b_wake_req, capb);
-    DA(d.lab_wake, capb); DA(d.lab_awake, capb);
+    DA(d.lab_wake, capb); DA(d.lab_awake, capb); DA(d.b_next_pos, capb); DA(d.b_next_rot, capb);
     DA(d.s_lin, capb); DA(d.s_ang, capb); DA(d.s_rot, capb); DA(d.s_trans, capb); DA(d.s_incl, capb); DA(d.s_inca, capb);
     DA(d.b_cmask, 4 * (size_t)capb); DAF(d.b_min, capb, 0xff);
     DA(d.c_parent, capc); DA(d.c_shape, capc); DA(d.c_lpos, capc); DA(d.c_lrot, capc); DA(d.c_pos, capc); DA(d.c_rot, capc); DA(d.c_he, capc);
@@ -661,13 +684,14 @@ static int finalize(rp_world *w) {
     // host SoA staging (one batched copy per attribute)
     {
         std::vector<float4> pos(nb), rot(nb), lv(nb), av(nb), lci(nb), ipi(nb), pfr(nb), damp(nb);
-        std::vector<float4> slp(nb), spt(nb), spr(nb);
+        std::vector<float4> slp(nb), spt(nb), spr(nb), npos(nb), nrot(nb);
         std::vector<int> bfl(nb), slab(nb);
         for (int i = 0; i < nb; ++i) {
             BodyRow r = pack_body(w->bodies[i]);
             pos[i] = r.pos; rot[i] = r.rot; lv[i] = r.lv; av[i] = r.av; lci[i] = r.lci; ipi[i] = r.ipi; pfr[i] = r.pfr; damp[i] = r.damp; bfl[i] = r.fl;
-            slp[i] = r.slp; spt[i] = r.spt; spr[i] = r.spr; slab[i] = r.slabel;
+            slp[i] = r.slp; spt[i] = r.spt; spr[i] = r.spr; slab[i] = r.slabel; npos[i] = r.npos; nrot[i] = r.nrot;
         }
+        UP(d.b_next_pos, npos); UP(d.b_next_rot, nrot);
         UP(d.b_sleep, slp); UP(d.b_sprev_t, spt); UP(d.b_sprev_r, spr); UP(d.b_slabel, slab);
         UP(d.b_pos, pos); UP(d.b_rot, rot); UP(d.b_linvel, lv); UP(d.b_angvel, av); UP(d.b_lcom_invm, lci); UP(d.b_invpi, ipi);
         UP(d.b_pframe, pfr); UP(d.b_damp, damp); UP(d.b_flags, bfl);
@@ -948,6 +972,8 @@ extern "C" int32_t rp_bodies_write(rp_world *w, int32_t n, const uint64_t *handl
             float4 t = mk4(pos7[7 * i], pos7[7 * i + 1], pos7[7 * i + 2], 0), q = mk4(pos7[7 * i + 3], pos7[7 * i + 4], pos7[7 * i + 5], pos7[7 * i + 6]);
             HIPCHK(w, hipMemcpy(w->dw.b_pos + b, &t, sizeof(t), hipMemcpyHostToDevice));
             HIPCHK(w, hipMemcpy(w->dw.b_rot + b, &q, sizeof(q), hipMemcpyHostToDevice));
+            HIPCHK(w, hipMemcpy(w->dw.b_next_pos + b, &t, sizeof(t), hipMemcpyHostToDevice)); // set_position sets position AND next_position
+            HIPCHK(w, hipMemcpy(w->dw.b_next_rot + b, &q, sizeof(q), hipMemcpyHostToDevice));
         }
     }
     if (w->dw.sleep_enabled) {
@@ -981,6 +1007,28 @@ extern "C" int32_t rp_bodies_wake_up(rp_world *w, int32_t n, const uint64_t *han
     }
     return RP_OK;
 }
+// RigidBody::set_next_kinematic_position (rigid_body.rs:1085-1093)
+extern "C" int32_t rp_bodies_set_next_kinematic_position(rp_world *w, int32_t n, const uint64_t *handles, const float *pos7) {
+    if (!w || n < 0 || (n > 0 && (!handles || !pos7))) return RP_ERR_INVALID;
+    HIPCHK(w, hipSetDevice(w->device));
+    if (!w->finalized) { int r = finalize(w); if (r != RP_OK) return r; }
+    { int r = settle(w); if (r != RP_OK) return r; }
+    for (int i = 0; i < n; ++i) {
+        int b = (int)(handles[i] & 0xffffffffull);
+        if ((handles[i] >> 32) != 0 || b >= w->dw.n_bodies || w->bodies[b].removed) { w->err = "rp_bodies_set_next_kinematic_position: invalid handle"; return RP_ERR_INVALID; }
+        int type = w->bodies[b].d.body_type;
+        if (type != RP_BODY_KINEMATIC_POSITION && type != RP_BODY_KINEMATIC_VELOCITY) continue; // "if self.is_kinematic()"
+        float4 t = mk4(pos7[7 * i], pos7[7 * i + 1], pos7[7 * i + 2], 0), q = mk4(pos7[7 * i + 3], pos7[7 * i + 4], pos7[7 * i + 5], pos7[7 * i + 6]);
+        float4 ct, cq;
+        HIPCHK(w, hipMemcpy(&ct, w->dw.b_pos + b, sizeof(ct), hipMemcpyDeviceToHost));
+        HIPCHK(w, hipMemcpy(&cq, w->dw.b_rot + b, sizeof(cq), hipMemcpyDeviceToHost));
+        HIPCHK(w, hipMemcpy(w->dw.b_next_pos + b, &t, sizeof(t), hipMemcpyHostToDevice));
+        HIPCHK(w, hipMemcpy(w->dw.b_next_rot + b, &q, sizeof(q), hipMemcpyHostToDevice));
+        bool differs = ct.x != t.x || ct.y != t.y || ct.z != t.z || cq.x != q.x || cq.y != q.y || cq.z != q.z || cq.w != q.w;
+        if (differs) { int lvl = 2; HIPCHK(w, hipMemcpy(w->dw.b_wake_req + b, &lvl, sizeof(int), hipMemcpyHostToDevice)); } // wake_up(true)
+    }
+    return RP_OK;
+}
 // RigidBody::is_sleeping per handle (1 = asleep).
 extern "C" int32_t rp_bodies_is_sleeping(rp_world *w, int32_t n, const uint64_t *handles, int32_t *out) {
     if (!w || n < 0 || (n > 0 && (!handles || !out))) return RP_ERR_INVALID;
@@ -992,7 +1040,7 @@ extern "C" int32_t rp_bodies_is_sleeping(rp_world *w, int32_t n, const uint64_t 
     for (int i = 0; i < n; ++i) {
         int b = (int)(handles[i] & 0xffffffffull);
         if ((handles[i] >> 32) != 0 || b >= w->dw.n_bodies) { w->err = "rp_bodies_is_sleeping: invalid handle"; return RP_ERR_INVALID; }
-        out[i] = ((fl[b] & RP_BF_TYPE_MASK) == RP_BODY_DYNAMIC && (fl[b] & RP_BF_SLEEPING)) ? 1 : 0;
+        out[i] = ((fl[b] & RP_BF_TYPE_MASK) != RP_BODY_FIXED && (fl[b] & RP_BF_SLEEPING)) ? 1 : 0;
     }
     return RP_OK;
 }
@@ -1226,7 +1274,7 @@ extern "C" int32_t rp_counters_read(rp_world *w, rp_counters *out) {
     if (w->dw.sleep_enabled && w->dw.n_bodies > 0) {
         std::vector<int> bfl(w->dw.n_bodies);
         HIPCHK(w, hipMemcpy(bfl.data(), w->dw.b_flags, bfl.size() * sizeof(int), hipMemcpyDeviceToHost));
-        int ns = 0; for (int f : bfl) ns += (f & (RP_BF_TYPE_MASK | RP_BF_SLEEPING)) == (RP_BODY_DYNAMIC | RP_BF_SLEEPING);
+        int ns = 0; for (int f : bfl) ns += (f & RP_BF_TYPE_MASK) != RP_BODY_FIXED && (f & RP_BF_SLEEPING);
         out->num_sleeping_bodies = ns;
     }
     return RP_OK;

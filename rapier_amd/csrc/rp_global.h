@@ -28,7 +28,25 @@ RP_DEV void g_body_integrate(const DevWorld &w, int i) {
     w.s_lin[i] = f4(lin, 0.0f); w.s_ang[i] = f4(ang, 0.0f); w.s_rot[i] = f4(rot); w.s_trans[i] = f4(trans, 0.0f);
 }
 RP_DEV void g_body_writeback(const DevWorld &w, int i) {
-    body_writeback(w, i, v3(w.s_lin[i]), v3(w.s_ang[i]), q4(w.s_rot[i]), v3(w.s_trans[i]));
+    int type = w.b_flags[i] & RP_BF_TYPE_MASK;
+    if (type == RP_BODY_DYNAMIC) { body_writeback(w, i, v3(w.s_lin[i]), v3(w.s_ang[i]), q4(w.s_rot[i]), v3(w.s_trans[i])); return; }
+    // kinematic bodies (worker.rs:826-842): damped velocity; a velocity-based body takes the integrated solver pose, a
+    // position-based one lands exactly on the pose the user asked for; their inverse mass / inertia stay zero
+    float4 damp = w.b_damp[i];
+    float dt = w.prm.p.dt;
+    V3 lin = v3(w.s_lin[i]) * (1.0f / (1.0f + dt * damp.x));
+    V3 ang = v3(w.s_ang[i]) * (1.0f / (1.0f + dt * damp.y));
+    V3 lcom = v3(w.b_lcom_invm[i]);
+    Q4 rot = q4(w.s_rot[i]);
+    V3 t = v3(w.s_trans[i]) + qrot(rot, -lcom);
+    if (type == RP_BODY_KINEMATIC_POSITION) { rot = q4(w.b_next_rot[i]); t = v3(w.b_next_pos[i]); }
+    bool finite = isfinite(t.x) && isfinite(t.y) && isfinite(t.z) && isfinite(rot.x) && isfinite(rot.y) && isfinite(rot.z) && isfinite(rot.w) &&
+                  isfinite(lin.x) && isfinite(lin.y) && isfinite(lin.z) && isfinite(ang.x) && isfinite(ang.y) && isfinite(ang.z);
+    if (!finite) { atomicAdd(&w.flags[FL_QUARANTINE], 1); w.b_quar[i] = 1; w.b_linvel[i] = make_float4(0, 0, 0, 0); w.b_angvel[i] = make_float4(0, 0, 0, 0); return; }
+    w.b_linvel[i] = f4(lin, 0.0f); w.b_angvel[i] = f4(ang, 0.0f);
+    w.b_pos[i] = f4(t, 0.0f); w.b_rot[i] = f4(rot);
+    w.b_next_pos[i] = f4(t, 0.0f); w.b_next_rot[i] = f4(rot); // position = next_position (advance_to_final_positions)
+    w.b_wcom[i] = f4(qrot(rot, lcom) + t, 0.0f);
 }
 RP_DEV bool g_generate(const DevWorld &w, int pos) {
     int s = w.cons_pair[pos];

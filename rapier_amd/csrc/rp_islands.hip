@@ -74,7 +74,8 @@ __global__ void k_isl_count(DevWorld w) {
         if (ld_i32(&w.r_nb[root]) <= RP_ISL_NB_MAX) atomicAdd(&w.r_nb[root], 1);
         // a body that carries a joint is solved on the global path (joints live there): poison its component
         // ... and so is every body under FrictionModel::Coulomb (the island kernel holds the twist constraint only)
-        if (w.b_njoints[b] > 0 || coulomb_model(w)) atomicAdd(&w.r_nc[root], RP_ISL_NC_MAX + 1);
+        // ... and so are kinematic bodies (solver bodies with zero inverse mass and their own write-back rule)
+        if (w.b_njoints[b] > 0 || coulomb_model(w) || (w.b_flags[b] & RP_BF_TYPE_MASK) != RP_BODY_DYNAMIC) atomicAdd(&w.r_nc[root], RP_ISL_NC_MAX + 1);
     }
     for (int s = gid; s < top; s += stride) {
         if (w.p_c1[s] < 0) continue;

@@ -73,6 +73,31 @@ RP_HD Pose pose_inv_mul(Pose a, Pose b) { Pose r; Q4 ai = qconj(a.r); r.r = qmul
 RP_HD V3 pose_tp(Pose a, V3 p) { return qrot(a.r, p) + a.t; }
 RP_HD V3 pose_itp(Pose a, V3 p) { return qrot_inv(a.r, p - a.t); }
 
+// Portable single-precision atan (Cephes atanf scheme, only + - * /): identical to oracle/ro_math.h so both sides
+// agree bit for bit (libm's and ocml's atan2f do not).
+RP_HD float rp_atan_portable(float x) {
+    float sign = 1.0f; if (x < 0.0f) { sign = -1.0f; x = -x; }
+    float y;
+    if (x > 2.414213562373095f) { y = 1.5707963267948966f; x = -(1.0f / x); }
+    else if (x > 0.4142135623730950f) { y = 0.7853981633974483f; x = (x - 1.0f) / (x + 1.0f); }
+    else y = 0.0f;
+    float z = x * x;
+    y = y + ((((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * x + x);
+    return sign * y;
+}
+RP_HD float rp_atan2_pos(float y, float x) { // y >= 0
+    if (x > 0.0f) return rp_atan_portable(y / x);
+    if (x < 0.0f) return 3.14159265358979323846f + rp_atan_portable(y / x);
+    return y > 0.0f ? 1.5707963267948966f : 0.0f;
+}
+// Quat::to_scaled_axis: axis * angle, angle = 2 atan2(|v|, w)
+RP_HD V3 quat_to_scaled_axis(Q4 q) {
+    V3 v = v3(q.x, q.y, q.z);
+    float length = len(v);
+    if (length >= 1.0e-8f) { float angle = 2.0f * rp_atan2_pos(length, q.w); return (v * (1.0f / length)) * angle; }
+    return v3(0, 0, 0);
+}
+
 RP_HD V3 sym_mul(Sym3 m, V3 v) {
     return v3(m.m11 * v.x + m.m12 * v.y + m.m13 * v.z, m.m12 * v.x + m.m22 * v.y + m.m23 * v.z,
               m.m13 * v.x + m.m23 * v.y + m.m33 * v.z);

@@ -307,10 +307,11 @@ RP_DEV float combine_coeff(float a, float b, int ra, int rb) {
     }
 }
 RP_DEV int effective_dominance(const DevWorld &w, int body) {
-    if (body >= 0) { int f = w.b_flags[body]; if ((f & RP_BF_TYPE_MASK) == RP_BODY_DYNAMIC) return (int)(signed char)((f >> RP_BF_DOM_SHIFT) & 0xff); }
+    if (body >= 0) { int f = w.b_flags[body]; if ((f & RP_BF_TYPE_MASK) != RP_BODY_FIXED) return (int)(signed char)((f >> RP_BF_DOM_SHIFT) & 0xff); }
     return 128;
 }
-RP_DEV bool body_dynamic(const DevWorld &w, int body) { return body >= 0 && (w.b_flags[body] & RP_BF_TYPE_MASK) == RP_BODY_DYNAMIC; }
+// a side that takes part in the colouring: any non-fixed body (assign_pair_solver_color, mod.rs:104-105)
+RP_DEV bool body_dynamic(const DevWorld &w, int body) { return body >= 0 && (w.b_flags[body] & RP_BF_TYPE_MASK) != RP_BODY_FIXED; }
 
 // The full narrow-phase update of one pair (pair_update.rs:173-613).
 __device__ __noinline__ void pair_full_update(DevWorld &w, int s, int c1, int c2, Pose pc1, Pose pc2, Pose pos12) {
@@ -527,7 +528,6 @@ __global__ void __launch_bounds__(1024) k_color_pairs(DevWorld w) {
             bool d1 = body_dynamic(w, b1), d2 = body_dynamic(w, b2);
             bool win = (!d1 || ld_u64(&w.b_min[b1]) == key) && (!d2 || ld_u64(&w.b_min[b2]) == key);
             if (!win) { atomicAdd(&remaining, 1); continue; }
-            // a non-fixed side conflicts (mod.rs:104-105); only dynamic bodies exist besides fixed here
             int color = 128;
             unsigned m[4] = {0, 0, 0, 0};
             if (d1) for (int q = 0; q < 4; ++q) m[q] |= ld_u32(&w.b_cmask[4 * b1 + q]);

@@ -3,10 +3,12 @@
 #pragma once
 #include "rp_world.h"
 
-// member of the active set: an awake dynamic body (IslandManager::active_bodies)
-RP_DEV bool flags_active(int fl) { return (fl & (RP_BF_TYPE_MASK | RP_BF_SLEEPING)) == RP_BODY_DYNAMIC; }
+// member of the active set: an awake dynamic or kinematic body (IslandManager::active_bodies)
+RP_DEV bool flags_active(int fl) { return (fl & RP_BF_TYPE_MASK) != RP_BODY_FIXED && !(fl & RP_BF_SLEEPING); }
+RP_DEV bool flags_dyn_awake(int fl) { return (fl & (RP_BF_TYPE_MASK | RP_BF_SLEEPING)) == RP_BODY_DYNAMIC; }
 RP_DEV bool body_active(const DevWorld &w, int b) { return b >= 0 && flags_active(w.b_flags[b]); }
-RP_DEV bool body_sleeping(const DevWorld &w, int b) { return b >= 0 && (w.b_flags[b] & (RP_BF_TYPE_MASK | RP_BF_SLEEPING)) == (RP_BODY_DYNAMIC | RP_BF_SLEEPING); }
+RP_DEV bool body_dyn_awake(const DevWorld &w, int b) { return b >= 0 && flags_dyn_awake(w.b_flags[b]); }
+RP_DEV bool body_sleeping(const DevWorld &w, int b) { if (b < 0) return false; int fl = w.b_flags[b]; return (fl & RP_BF_TYPE_MASK) != RP_BODY_FIXED && (fl & RP_BF_SLEEPING); }
 RP_DEV int cur_step(const DevWorld &w) { return w.flags[FL_STEP] + 1; } // 1-based number of the step in progress
 // pair_solver_hints count cleared by clear_asleep_pair_solver_hint_counts_of (solver_graph.rs:21-49): one of the
 // pair's bodies fell asleep after the hint was last computed (only meaningful when w.sleep_enabled)
@@ -20,7 +22,7 @@ RP_DEV bool pair_selected(const DevWorld &w, int s) {
     if (!w.sleep_enabled) return true;
     int2 rb = w.p_rb[s];
     if (pair_hint_cleared(w, s, rb)) return false;
-    return body_active(w, rb.x) || body_active(w, rb.y);
+    return body_dyn_awake(w, rb.x) || body_dyn_awake(w, rb.y); // PAIR_HINT_DYN_BIT: at least one awake DYNAMIC body
 }
 
 RP_DEV Pose collider_world_pose(const DevWorld &w, int i) {

@@ -44,7 +44,7 @@ __global__ void k_wake_spread(DevWorld w, int phase) {
     if (!r) return;
     w.b_wake_req[i] = 0;
     int fl = w.b_flags[i];
-    if ((fl & RP_BF_TYPE_MASK) != RP_BODY_DYNAMIC) return;
+    if ((fl & RP_BF_TYPE_MASK) == RP_BODY_FIXED) return;
     if (fl & RP_BF_SLEEPING) {
         w.lab_wake[w.b_slabel[i]] = cur_step(w);
         w.flags[FL_WAKE_STAMP] = 2 * cur_step(w) + phase;
@@ -58,7 +58,7 @@ __global__ void k_wake_commit(DevWorld w, int phase) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= w.n_bodies) return;
     int fl = w.b_flags[i];
-    if ((fl & (RP_BF_TYPE_MASK | RP_BF_SLEEPING)) != (RP_BODY_DYNAMIC | RP_BF_SLEEPING)) return;
+    if ((fl & RP_BF_TYPE_MASK) == RP_BODY_FIXED || !(fl & RP_BF_SLEEPING)) return;
     if (w.lab_wake[w.b_slabel[i]] != cur_step(w)) return;
     w.b_flags[i] = fl & ~RP_BF_SLEEPING;
     float4 sl = w.b_sleep[i]; sl.x = 0.0f; w.b_sleep[i] = sl;
@@ -109,6 +109,14 @@ __global__ void k_sleep_observe(DevWorld w) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= w.n_bodies || !flags_active(w.b_flags[i])) return;
     float4 sl = w.b_sleep[i];
+    if ((w.b_flags[i] & RP_BF_TYPE_MASK) != RP_BODY_DYNAMIC) { // platforms only sleep when both velocities are exactly zero (:1464-1468)
+        V3 lv = v3(w.b_linvel[i]), kav = v3(w.b_angvel[i]);
+        bool still = dot(lv, lv) == 0.0f && dot(kav, kav) == 0.0f;
+        sl.x = still ? sl.x + w.prm.p.dt : 0.0f;
+        w.b_sleep[i] = sl;
+        if (!(sl.x >= sl.w)) w.lab_awake[w.b_slabel[i]] = cur_step(w);
+        return;
+    }
     float4 pt = w.b_sprev_t[i];
     Q4 prev_r = q4(w.b_sprev_r[i]);
     V3 pos = v3(w.b_pos[i]); Q4 rot = q4(w.b_rot[i]);
@@ -142,6 +150,22 @@ __global__ void k_sleep_commit(DevWorld w) {
     w.flags[FL_LAYOUT_DIRTY] = 1;
 }
 
+// interpolate_kinematic_velocities (substep.rs:242-264): a position-based kinematic body gets the velocity that
+// reaches its next_position in one step (RigidBodyPosition::interpolate_velocity, rigid_body_components.rs:147-194).
+__global__ void k_kinematic_velocities(DevWorld w) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= w.n_bodies) return;
+    int fl = w.b_flags[i];
+    if ((fl & RP_BF_TYPE_MASK) != RP_BODY_KINEMATIC_POSITION || (fl & RP_BF_SLEEPING)) return;
+    float inv_dt = w.prm.p.dt == 0.0f ? 0.0f : 1.0f / w.prm.p.dt;
+    Pose pos; pos.r = q4(w.b_rot[i]); pos.t = v3(w.b_pos[i]);
+    Pose next; next.r = q4(w.b_next_rot[i]); next.t = v3(w.b_next_pos[i]);
+    Pose shift; shift.r = q4(0, 0, 0, 1); shift.t = pose_tp(pos, v3(w.b_lcom_invm[i]));
+    Pose dpos = pose_mul(pose_mul(pose_mul(pose_inv(shift), next), pose_inv(pos)), shift);
+    w.b_linvel[i] = f4(dpos.t * inv_dt, 0.0f);
+    w.b_angvel[i] = f4(quat_to_scaled_axis(dpos.r) * inv_dt, 0.0f);
+}
+
 static int slp_body_blocks(const DevWorld &w) { int nb = (w.n_bodies + 255) / 256; return nb < 1 ? 1 : nb; }
 static int slp_pair_blocks(const DevWorld &w) { int b = (w.pool_cap + 255) / 256; if (b > 2048) b = 2048; return b < 1 ? 1 : b; }
 
@@ -157,6 +181,7 @@ void rp_launch_wake_partners(const DevWorld &w, hipStream_t st) {
 void rp_launch_sleep(const DevWorld &w, hipStream_t st) {
     if (!w.sleep_enabled || w.n_bodies == 0) return;
     int nb = slp_body_blocks(w);
+    if (w.has_kinematic_pos) hipLaunchKernelGGL(k_kinematic_velocities, dim3(nb), dim3(256), 0, st, w); // after the narrow phase, before the sleep timers
     hipLaunchKernelGGL(k_slp_init, dim3(nb), dim3(256), 0, st, w);
     if (w.n_colliders > 0) hipLaunchKernelGGL(k_slp_union, dim3(slp_pair_blocks(w)), dim3(256), 0, st, w);
     hipLaunchKernelGGL(k_slp_flatten, dim3(nb), dim3(256), 0, st, w);

@@ -140,7 +140,8 @@ struct DevWorld {
     int entries_cap;   // grid entries
     int large_cap;
     int cons_cap;      // solver manifolds
-    int sleep_enabled; // some dynamic body may fall asleep: the sleep kernels run and pairs carry solver hints
+    int sleep_enabled; // some body may fall asleep (can_sleep dynamic bodies, any kinematic body): the sleep kernels run and pairs carry solver hints
+    int has_kinematic_pos; // some body is KinematicPositionBased: k_kinematic_velocities runs
     SimParams prm;
     int *flags;        // FL_* scalars
     long long *dbg;    // [64] cycle stamps of island 0 (only written when built with -DRP_ISL_PROFILE)
@@ -168,6 +169,7 @@ struct DevWorld {
     int *b_wake_req;       // pending wake-up: 1 weak, 2 strong, 3 strong + the user moved the body
     int *lab_wake;         // [n_bodies] per label: step of the last wake-up of that sleeping island
     int *lab_awake;        // [n_bodies] per label: step at which some member was found not eligible for sleep
+    float4 *b_next_pos, *b_next_rot; // RigidBodyPosition::next_position of kinematic bodies (set_next_kinematic_position)
     // ---- solver bodies (index = arena index; non-dynamic = world-attached) ----
     float4 *s_lin, *s_ang, *s_rot, *s_trans, *s_incl, *s_inca;
     unsigned int *b_cmask; // 4 x u32 colour mask per body (body_solver_color_masks)

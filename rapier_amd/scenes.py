@@ -14,7 +14,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-BODY_DYNAMIC, BODY_FIXED = 0, 1
+BODY_DYNAMIC, BODY_FIXED, BODY_KINEMATIC_POSITION, BODY_KINEMATIC_VELOCITY = 0, 1, 2, 3  # RigidBodyType
 SHAPE_BALL, SHAPE_CUBOID = 0, 1
 RULE_AVERAGE, RULE_MIN, RULE_MULTIPLY, RULE_MAX, RULE_CLAMPED_SUM, RULE_GEOMETRIC_MEAN = range(6)
 
@@ -353,4 +353,22 @@ def sleep_impact(height: float = 12.0, stack: int = 3) -> Scene:
             s.add_collider(b, half_extents=(0.5, 0.5, 0.5))
     drop = s.add_body(translation=(0.15, height, 0.1), rotation=(0.0, 0.19866933, 0.0, 0.98006658), can_sleep=1)
     s.add_collider(drop, half_extents=(0.3, 0.3, 0.3), density=2.0)
+    return s
+
+
+def kinematic_platform(position_based: bool = False, boxes: int = 3) -> Scene:
+    """Kinematic test scene (not a reference scene): a slab-sized kinematic platform carrying a small cube stack
+    over a fixed floor, plus a free dynamic cube on the floor next to it.  Velocity-based: the platform is given
+    a velocity; position-based: the test feeds ``set_next_kinematic_position`` every step."""
+    s = Scene(name=f"kinematic_platform_{'pos' if position_based else 'vel'}_{boxes}", gravity=(0.0, -9.81, 0.0))
+    g = s.add_body(body_type=BODY_FIXED, translation=(0.0, -0.5, 0.0))
+    s.add_collider(g, half_extents=(20.0, 0.5, 20.0))
+    p = s.add_body(body_type=BODY_KINEMATIC_POSITION if position_based else BODY_KINEMATIC_VELOCITY, translation=(0.0, 1.0, 0.0),
+                   linvel=(0.0, 0.0, 0.0) if position_based else (0.6, 0.15, 0.0), angvel=(0.0, 0.0, 0.0) if position_based else (0.0, 0.2, 0.0))
+    s.add_collider(p, half_extents=(3.0, 0.25, 3.0))
+    for i in range(boxes):
+        b = s.add_body(translation=(0.2 * i, 1.25 + 0.5 + i * 1.0, 0.1 * i))
+        s.add_collider(b, half_extents=(0.5, 0.5, 0.5))
+    f = s.add_body(translation=(5.0, 0.5, 0.0))
+    s.add_collider(f, half_extents=(0.5, 0.5, 0.5))
     return s

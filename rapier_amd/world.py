@@ -263,6 +263,12 @@ class PhysicsWorld:
         _check(self._ptr, self._lib.rp_bodies_write(self._ptr, len(h), h.ctypes.data, None if p is None else p.ctypes.data,
                                                   None if v is None else v.ctypes.data), "rp_bodies_write")
 
+    def set_next_kinematic_position(self, handles, pos7):
+        """RigidBody::set_next_kinematic_position (rigid_body.rs:1085-1093) for kinematic bodies."""
+        h = np.ascontiguousarray(np.atleast_1d(np.asarray(handles, dtype=np.uint64)))
+        p = np.ascontiguousarray(np.asarray(pos7, dtype=np.float32).reshape(len(h), 7))
+        _check(self._ptr, self._lib.rp_bodies_set_next_kinematic_position(self._ptr, len(h), h.ctypes.data, p.ctypes.data), "rp_bodies_set_next_kinematic_position")
+
     def wake_up(self, handles, strong: bool = True):
         """IslandManager::wake_up (island_manager/sleep.rs:31) — effective at the next step, island-wide."""
         h = np.ascontiguousarray(np.atleast_1d(np.asarray(handles, dtype=np.uint64)))

@@ -51,6 +51,7 @@ def lib():
         L.ro_set_body_vel.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.ro_set_threads.argtypes = [C.c_int32]
         L.ro_set_body_pose.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        L.ro_set_next_kinematic_position.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         L.ro_wake_up.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         L.ro_read_sleeping.argtypes = [C.c_void_p, C.c_void_p]
         L.ro_remove_body.argtypes = [C.c_void_p, C.c_int32]
@@ -133,6 +134,10 @@ class OracleWorld:
     def set_pose(self, body, pos7):
         p = np.ascontiguousarray(pos7, np.float32)
         lib().ro_set_body_pose(self._w, int(body), p.ctypes.data)
+
+    def set_next_kinematic_position(self, body, pos7):
+        p = np.ascontiguousarray(pos7, np.float32)
+        lib().ro_set_next_kinematic_position(self._w, int(body), p.ctypes.data)
 
     def wake_up(self, body, strong=True):
         lib().ro_wake_up(self._w, int(body), 1 if strong else 0)

@@ -457,6 +457,61 @@ def test_coulomb_multi_mode_and_model_switch():
     assert np.isfinite(pos).all() and np.abs(vel).max() < 0.05 and pos[1:, 1].max() == pytest.approx(9.5, abs=0.05)
 
 
+# ---- kinematic bodies (SURVEY §8a MISC: interpolate_kinematic_velocities) ----
+def test_kinematic_velocity_platform_bit_exact():
+    g, o = _compare(S.kinematic_platform(False), [1, 2, 10, 60, 150])
+    np.testing.assert_array_equal(g.sleeping(), o.sleeping())
+    gm, _, gi = g.contacts()
+    om, _, oi = o.manifolds()
+    assert {(a, b): (c, n, tuple(i)) for (a, b, c, n), i in zip(gm.tolist(), gi.tolist())} == \
+           {(a, b): (c, n, tuple(i)) for (a, b, c, n), i in zip(om.tolist(), oi.tolist())}   # same colours and impulses
+    pos, vel = g.read_bodies()
+    assert pos[1, 0] == pytest.approx(1.5, abs=1e-3) and vel[2, 0] == pytest.approx(0.6, abs=0.1)  # the box rides the platform
+
+
+def test_kinematic_position_platform_sleep_and_wake_bit_exact():
+    sc = S.kinematic_platform(True).enable_sleep()
+    g, o = PhysicsWorld.from_scene(sc), OracleWorld(sc)
+
+    def target(k):
+        t = k / 60.0
+        return np.array([0.6 * t, 1.0 + 0.15 * t, 0.0, 0.0, np.sin(0.1 * t), 0.0, np.cos(0.1 * t)], np.float32)
+
+    for k in range(1, 91):
+        g.set_next_kinematic_position([1], target(k)); o.set_next_kinematic_position(1, target(k))
+        g.step(1); o.step(1)
+        if k % 10 == 0:
+            _same_sleep_state(g, o, f"kinematic position platform @ {k}")
+    pos, vel = g.read_bodies()
+    np.testing.assert_array_equal(pos[1], target(90))        # lands exactly on the pose the user asked for
+    assert vel[1, 0] == pytest.approx(0.6, abs=1e-3) and vel[1, 4] == pytest.approx(0.2, abs=1e-3)
+    for n in (1, 30, 60):                                    # no new target: the platform stops where it is
+        g.step(n); o.step(n)
+        _same_sleep_state(g, o, f"kinematic platform at rest, +{n}")
+    # (an idle position-based platform keeps a rounding-sized interpolated velocity, so only "exactly zero" velocity-based
+    # platforms ever satisfy the kinematic sleep rule, rigid_body_components.rs:1464-1468)
+
+
+def test_kinematic_velocity_platform_sleep_and_wake_bit_exact():
+    sc = S.kinematic_platform(False).enable_sleep()
+    g, o = PhysicsWorld.from_scene(sc), OracleWorld(sc)
+    g.step(40); o.step(40)
+    _same_sleep_state(g, o, "moving platform")
+    assert not g.sleeping()[1:5].any()                       # a moving platform keeps its island awake
+    stop = np.zeros((1, 6), np.float32)
+    g.write_bodies([1], vel6=stop); o.set_vel(1, stop[0, :3], stop[0, 3:])
+    for n in (1, 40, 60, 100):
+        g.step(n); o.step(n)
+        _same_sleep_state(g, o, f"platform stopped, +{n}")
+    assert g.sleeping()[1:].all()                            # platform (exactly zero velocity) and boxes sleep as one island
+    go = np.array([[0.0, 0.0, 0.5, 0.0, 0.0, 0.0]], np.float32)
+    g.write_bodies([1], vel6=go); o.set_vel(1, go[0, :3], go[0, 3:])   # set_linvel(.., wake_up = true) wakes the island
+    for n in (1, 1, 30):
+        g.step(n); o.step(n)
+        _same_sleep_state(g, o, f"platform moving again, +{n}")
+    assert not g.sleeping()[1:5].any() and g.sleeping()[5]   # the free cube on the floor sleeps on
+
+
 def test_out_of_scope_inputs_are_refused():
     """Angular joint locks, contact-disabled joints, compound bodies and joints on can_sleep bodies are refused
     loudly, not mis-simulated."""

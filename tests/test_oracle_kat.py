@@ -228,6 +228,25 @@ def test_coulomb_pyramid_rests_and_carries_its_weight():
     assert imp[ground].sum() == pytest.approx(weight, rel=0.01)
 
 
+# Kinematic bodies (solver bodies with zero inverse mass; interpolate_kinematic_velocities, substep.rs:242-264):
+# a platform carries the boxes standing on it and is never pushed back.
+@pytest.mark.parametrize("position_based", [False, True])
+def test_kinematic_platform_carries_boxes(position_based):
+    sc = S.kinematic_platform(position_based)
+    w = OracleWorld(sc)
+    for k in range(120):
+        if position_based:
+            t = (k + 1) / 60.0
+            w.set_next_kinematic_position(1, [0.6 * t, 1.0 + 0.15 * t, 0.0, 0.0, np.sin(0.1 * t), 0.0, np.cos(0.1 * t)])
+        w.step(1)
+    pos, vel = w.read()
+    assert pos[1, 0] == pytest.approx(1.2, abs=1e-3) and pos[1, 1] == pytest.approx(1.3, abs=1e-3)   # the platform follows its program exactly
+    assert vel[1, 0] == pytest.approx(0.6, abs=1e-3) and vel[1, 4] == pytest.approx(0.2, abs=1e-3)  # interpolated / prescribed velocity
+    assert pos[2, 1] == pytest.approx(pos[1, 1] + 0.75, abs=0.01)     # the bottom box still stands on it
+    assert abs(pos[2, 0] - pos[1, 0]) < 0.3 and vel[2, 0] == pytest.approx(0.6, abs=0.1)   # and rides along
+    assert pos[5, 0] == pytest.approx(5.0, abs=1e-3)                  # the free cube on the floor is untouched
+
+
 # Sleeping: RigidBodyActivation::update_energy (rigid_body_components.rs:1412-1478), whole-island sleep
 # (island_manager/manager.rs:335-388), wake rules (contacts.rs:333-351, sleep.rs:31-79).  The reference's own
 # sleep tests (src/pipeline/physics_pipeline/test.rs:340-372: a resting body falls asleep, a woken one is awake)

@@ -51,7 +51,18 @@ def tele(g, o):
     g.write_bodies([2], pos7=p); o.set_pose(2, p[0])
 
 
+def kin_targets(g, o, k):
+    t = k / 60.0
+    p = np.array([0.6 * t, 1.0 + 0.15 * t, 0.0, 0.0, np.sin(0.1 * t), 0.0, np.cos(0.1 * t)], np.float32)
+    g.set_next_kinematic_position([1], p); o.set_next_kinematic_position(1, p)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "kin":
+        run("kinematic velocity platform", S.kinematic_platform(False), 150)
+        acts = {k: (lambda g, o, k=k: kin_targets(g, o, k)) for k in list(range(1, 91)) + [212]}
+        run("kinematic position platform", S.kinematic_platform(True).enable_sleep(), 240, acts)
+        sys.exit(0)
     run("box_stack3 no-sleep", S.box_stack(3), 50)
     run("box_stack3 sleep", S.box_stack(3).enable_sleep(), 320, {111: kick, 230: wake})
     run("sleep_impact", S.sleep_impact(), 260)
