@@ -89,7 +89,30 @@ typedef struct rp_collider_desc {
     float density, friction, restitution;
     int32_t friction_rule, restitution_rule;
     uint32_t collision_memberships, collision_filter;
+    uint32_t active_events;              /* ActiveEvents (pipeline/event_handler.rs:11-24): RP_EVENTS_COLLISION | RP_EVENTS_CONTACT_FORCE */
+    float contact_force_event_threshold; /* ColliderBuilder::contact_force_event_threshold (collider.rs:1040) */
 } rp_collider_desc;
+
+enum { RP_EVENTS_COLLISION = 1, RP_EVENTS_CONTACT_FORCE = 2 };
+enum { RP_COLLISION_EVENT_REMOVED = 2 }; /* CollisionEventFlags::REMOVED (geometry/mod.rs:95-102) */
+
+/* CollisionEvent::{Started, Stopped}(collider1, collider2, flags) — geometry/mod.rs:105-140 */
+typedef struct rp_collision_event {
+    int32_t collider1, collider2;
+    int32_t started;   /* 1 = Started, 0 = Stopped */
+    int32_t flags;     /* CollisionEventFlags */
+    int32_t step;      /* 1-based step (since the device world was built) that raised the event */
+} rp_collision_event;
+/* ContactForceEvent — geometry/mod.rs:180-258 */
+typedef struct rp_contact_force_event {
+    int32_t collider1, collider2;
+    int32_t step;
+    int32_t started;   /* the pair was not above its threshold in the previous step */
+    float total_force[3];
+    float total_force_magnitude;
+    float max_force_direction[3];
+    float max_force_magnitude;
+} rp_contact_force_event;
 
 /* GenericJoint restricted to locked axes — /root/reference/src/dynamics/joint/generic_joint.rs:341-355 */
 typedef struct rp_joint_desc {
@@ -199,6 +222,16 @@ int32_t rp_contacts_read(rp_world *w, int32_t cap, int32_t *c1_c2_color_count, f
 /* Quarantine (pipeline/physics_pipeline/quarantine.rs:68-131): handles of the bodies whose state went
  * non-finite (rolled back to the last valid pose and stopped).  Returns the count (may exceed cap). */
 int32_t rp_quarantine_read(rp_world *w, int32_t cap, uint64_t *handles_out);
+
+/* EventHandler::{handle_collision_event, handle_contact_force_event} (pipeline/event_handler.rs:94-160) as queues
+ * instead of callbacks: the device appends an event whenever a pair with ActiveEvents::COLLISION_EVENTS starts / stops
+ * touching (contacts.rs:316-323; a deleted touching pair or a removed collider raises Stopped, the latter with
+ * RP_COLLISION_EVENT_REMOVED) and, after every step, for every solver-active pair with ActiveEvents::CONTACT_FORCE_EVENTS
+ * whose total contact force exceeds the smaller of the two colliders' thresholds (solver_graph.rs:462-498).  These calls
+ * drain the queue (oldest first, sorted by step, collider1, collider2) and return the number of pending events (only
+ * `cap` are written; a queue that overflowed its 65,536 slots drops the newest events and says so in rp_last_error). */
+int32_t rp_collision_events_read(rp_world *w, int32_t cap, rp_collision_event *out);
+int32_t rp_contact_force_events_read(rp_world *w, int32_t cap, rp_contact_force_event *out);
 
 /* PhysicsPipeline::counters; `enable_timers` != 0 turns on hipEvent stage timing (off = no events). */
 int32_t rp_counters_enable(rp_world *w, int32_t enable_timers);

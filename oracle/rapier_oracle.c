@@ -78,6 +78,7 @@ typedef struct {
     int shape; v3 he; float radius;
     float density, friction, restitution; int friction_rule, restitution_rule;
     uint32_t memberships, filter;
+    uint32_t active_events; float force_threshold;
     Aabb fat; int has_fat;
 } Collider;
 
@@ -95,6 +96,7 @@ typedef struct {
     /* recycle state — contact_pair.rs:262-278 */
     int has_recycle; pose rec_pos12; quat rec_rot1, rec_rot2; float rec_max_extent, rec_max_drift;
     uint8_t color; uint32_t color_bodies[2];
+    int force_emitted;  /* PairEventStatus::INITIAL_FORCE_THRESHOLD_EVENT_EMITTED */
     int hint_seq;       /* step at which pair_solver_hints[edge] was last computed (pair_update.rs:141-161,636-650) */
 } Pair;
 
@@ -169,6 +171,8 @@ struct ro_world {
     ro_stats stats;
     int step_seq;       /* 1-based number of the step in progress */
     int *uf;            /* union-find scratch of the sleep islands */
+    int32_t *col_events; int ncol_events, cap_col_events;       /* 5 ints per event */
+    int32_t *force_meta; float *force_vals; int nforce_events, cap_force_events;
 };
 
 /* ------------------------------------------------------------------------------------ */
@@ -246,7 +250,7 @@ void ro_world_free(ro_world *w) {
     free(w->bodies); free(w->colliders); free(w->pairs); free(w->map_keys); free(w->map_vals);
     free(w->color_masks); free(w->vels); free(w->incr); free(w->poses); free(w->gyro); free(w->flags);
     free(w->dyn_bodies); free(w->cons); free(w->joints); free(w->active_joints); free(w->joint_order);
-    free(w->joint_rows); free(w->joint_body_colors); free(w->uf); free(w);
+    free(w->joint_rows); free(w->joint_body_colors); free(w->uf); free(w->col_events); free(w->force_meta); free(w->force_vals); free(w);
 }
 
 /* parry MassProperties::world_inv_inertia */
@@ -363,6 +367,7 @@ int32_t ro_add_collider(ro_world *w, const ro_collider_desc *d, int32_t parent) 
     c->density = d->density; c->friction = d->friction; c->restitution = d->restitution;
     c->friction_rule = d->friction_rule; c->restitution_rule = d->restitution_rule;
     c->memberships = d->collision_memberships; c->filter = d->collision_filter;
+    c->active_events = d->active_events; c->force_threshold = d->contact_force_event_threshold;
     if (parent >= 0) c->pos = pose_mul(w->bodies[parent].position, c->pos_wrt_parent);
     else c->pos = c->pos_wrt_parent;
     int idx = w->ncolliders++;
@@ -426,6 +431,18 @@ void ro_set_next_kinematic_position(ro_world *w, int32_t body, const float pos7[
     const pose *p = &b->position;
     if (p->t.x != np.t.x || p->t.y != np.t.y || p->t.z != np.t.z || p->r.x != np.r.x || p->r.y != np.r.y || p->r.z != np.r.z || p->r.w != np.r.w)
         wake_request(w, body, 1);
+}
+int32_t ro_collision_events_drain(ro_world *w, int32_t cap, int32_t *out5) {
+    int n = w->ncol_events;
+    for (int i = 0; i < n && i < cap; ++i) memcpy(out5 + 5 * i, w->col_events + 5 * i, sizeof(int32_t) * 5);
+    if (out5 || cap == 0) { if (out5) w->ncol_events = 0; }
+    return n;
+}
+int32_t ro_force_events_drain(ro_world *w, int32_t cap, int32_t *meta4, float *vals8) {
+    int n = w->nforce_events;
+    for (int i = 0; i < n && i < cap; ++i) { memcpy(meta4 + 4 * i, w->force_meta + 4 * i, sizeof(int32_t) * 4); memcpy(vals8 + 8 * i, w->force_vals + 8 * i, sizeof(float) * 8); }
+    if (meta4) w->nforce_events = 0;
+    return n;
 }
 void ro_wake_up(ro_world *w, int32_t body, int32_t strong) { if (body >= 0 && body < w->nbodies) wake_request(w, body, strong); }
 void ro_read_sleeping(const ro_world *w, int32_t *sleeping) {
@@ -534,6 +551,16 @@ static int sweep_cmp(const void *a, const void *b) {
 }
 static void clear_pair_solver_color(ro_world *w, Pair *p);
 
+/* EventHandler::handle_collision_event — event_handler.rs:94-130 (collected, not called back) */
+static void push_collision_event(ro_world *w, int c1, int c2, int started, int flags) {
+    if (w->ncol_events == w->cap_col_events) {
+        w->cap_col_events = w->cap_col_events ? 2 * w->cap_col_events : 256;
+        w->col_events = (int32_t *)realloc(w->col_events, sizeof(int32_t) * 5 * (size_t)w->cap_col_events);
+    }
+    int32_t *e = w->col_events + 5 * w->ncol_events++;
+    e[0] = c1; e[1] = c2; e[2] = started; e[3] = flags; e[4] = w->step_seq;
+}
+
 /* ---- sleeping: IslandManager::wake_up (island_manager/sleep.rs:31-79) --------------------------------
  * Requests are collected per body (1 = weak, 2 = strong) and applied island-wide by apply_wakes: waking
  * any body of a sleeping island wakes the whole island with a strong timer reset for every member; a
@@ -609,6 +636,8 @@ static void broad_phase_update(ro_world *w) {
              * every body that had a pair with the removed collider (:88-99) */
             int gone = (a->memberships == 0 && a->filter == 0) || (b->memberships == 0 && b->filter == 0);
             if (p->nsc > 0 || gone) { wake_request(w, a->parent, 1); wake_request(w, b->parent, 1); }
+            /* Stopped event of a touching pair: remove_pair (pair_management.rs:554-558), remove_collider (:101-110, REMOVED flag) */
+            if (p->nsc > 0 && ((a->active_events | b->active_events) & 1u)) push_collision_event(w, p->c1, p->c2, 0, gone ? 2 : 0);
             clear_pair_solver_color(w, p); removed = 1; continue;
         }
         if (out != i) w->pairs[out] = w->pairs[i];
@@ -857,6 +886,8 @@ static void narrow_phase_compute_contacts(ro_world *w) {
     int ntodo = 0;
     for (int i = 0; i < ntr; ++i) {
         Pair *p = &w->pairs[tr[i].pair];
+        /* contacts.rs:316-323: Started / Stopped for pairs with ActiveEvents::COLLISION_EVENTS */
+        if ((w->colliders[p->c1].active_events | w->colliders[p->c2].active_events) & 1u) push_collision_event(w, p->c1, p->c2, tr[i].touching, 0);
         if (!tr[i].touching) { clear_pair_solver_color(w, p); continue; }
         /* wake rule (contacts.rs:333-351): starts wake the sleeping side strongly (whole island), stops never wake */
         if (body_is_sleeping_nonfixed(w, tr[i].body1)) wake_request(w, tr[i].body1, 1);
@@ -1835,6 +1866,40 @@ static void update_sleep(ro_world *w) {
     }
 }
 
+/* NarrowPhase::emit_contact_force_events — solver_graph.rs:462-498; ContactForceEvent::from_contact_pair — geometry/mod.rs:223-258 */
+static void emit_contact_force_events(ro_world *w) {
+    float dt = w->params.dt, inv_dt = dt == 0.0f ? 0.0f : 1.0f / dt;
+    for (int i = 0; i < w->npairs; ++i) {
+        Pair *p = &w->pairs[i];
+        const Collider *a = &w->colliders[p->c1], *b = &w->colliders[p->c2];
+        float ta = (a->active_events & 2u) ? a->force_threshold : FLT_MAX, tb = (b->active_events & 2u) ? b->force_threshold : FLT_MAX;
+        float threshold = ta < tb ? ta : tb;
+        if (!(threshold < FLT_MAX) || !pair_selected(w, p)) continue; /* force_event_pairs: solver-active pairs with force events enabled */
+        float total = 0.0f;
+        for (int k = 0; k < p->m.npoints; ++k) total += p->m.points[k].data.impulse;
+        float total_magnitude = (0.0f + total) * inv_dt;
+        if (total_magnitude > threshold) {
+            if (w->nforce_events == w->cap_force_events) {
+                w->cap_force_events = w->cap_force_events ? 2 * w->cap_force_events : 256;
+                w->force_meta = (int32_t *)realloc(w->force_meta, sizeof(int32_t) * 4 * (size_t)w->cap_force_events);
+                w->force_vals = (float *)realloc(w->force_vals, sizeof(float) * 8 * (size_t)w->cap_force_events);
+            }
+            int32_t *m = w->force_meta + 4 * w->nforce_events; float *v = w->force_vals + 8 * w->nforce_events; w->nforce_events++;
+            m[0] = p->c1; m[1] = p->c2; m[2] = w->step_seq; m[3] = !p->force_emitted;
+            float max_mag = 0.0f; v3 max_dir = V3(0, 0, 0); float tmi = 0.0f;
+            for (int k = 0; k < p->m.npoints; ++k) {
+                float imp = p->m.points[k].data.impulse;
+                tmi += imp;
+                if (imp > max_mag) { max_mag = imp; max_dir = p->normal; }
+            }
+            v3 total_force = vmul(vadd(V3(0, 0, 0), vmul(p->normal, tmi)), inv_dt);
+            v[0] = total_force.x; v[1] = total_force.y; v[2] = total_force.z; v[3] = total_magnitude;
+            v[4] = max_dir.x; v[5] = max_dir.y; v[6] = max_dir.z; v[7] = max_mag * inv_dt;
+            p->force_emitted = 1;
+        } else p->force_emitted = 0;
+    }
+}
+
 /* PhysicsPipeline::step_inner — pipeline/physics_pipeline/substep.rs:267-581 */
 static void step_once(ro_world *w) {
     w->step_seq++;
@@ -1867,6 +1932,7 @@ static void step_once(ro_world *w) {
         b->torque = b->user_torque;
     }
     solve_velocity_constraints(w);
+    emit_contact_force_events(w);
     /* advance_to_final_positions — substep.rs:84-224; refresh_moved_collider_aabbs :229-240 */
     for (int i = 0; i < w->nbodies; ++i) {
         Body *b = &w->bodies[i];

@@ -78,6 +78,8 @@ typedef struct ro_collider_desc {
     float density, friction, restitution;
     int32_t friction_rule, restitution_rule;
     uint32_t collision_memberships, collision_filter; /* InteractionGroups */
+    uint32_t active_events;                /* ActiveEvents: bit0 COLLISION_EVENTS, bit1 CONTACT_FORCE_EVENTS */
+    float contact_force_event_threshold;   /* ColliderBuilder::contact_force_event_threshold */
 } ro_collider_desc;
 
 /* GenericJoint restricted to lock rows (spherical = LIN_X|LIN_Y|LIN_Z, fixed = all six). */
@@ -111,6 +113,12 @@ int32_t ro_num_bodies(const ro_world *w);
 void ro_read_bodies(const ro_world *w, float *pos7, float *vel6);
 /* RigidBody::set_linvel/set_angvel(.., wake_up = true) */
 void ro_set_body_vel(ro_world *w, int32_t body, const float linvel[3], const float angvel[3]);
+/* CollisionEvent (geometry/mod.rs:105-140) and ContactForceEvent (:180-258) raised since the last drain, in emission
+ * order.  Collision: 5 ints (collider1, collider2, started, CollisionEventFlags, step).  Force: 4 ints (collider1,
+ * collider2, step, started) + 8 floats (total_force xyz, total_force_magnitude, max_force_direction xyz,
+ * max_force_magnitude).  Return the number of pending events (only `cap` are written); the lists are cleared. */
+int32_t ro_collision_events_drain(ro_world *w, int32_t cap, int32_t *out5);
+int32_t ro_force_events_drain(ro_world *w, int32_t cap, int32_t *meta4, float *vals8);
 /* RigidBody::set_next_kinematic_position (rigid_body.rs:1085-1093): kinematic bodies only; wakes when the pose differs */
 void ro_set_next_kinematic_position(ro_world *w, int32_t body, const float pos7[7]);
 /* RigidBody::set_position(.., wake_up = true) */

@@ -40,6 +40,7 @@ void rp_launch_global_single(const DevWorld &w, hipStream_t st, int has_restitut
 void rp_launch_fast_front(const DevWorld &w, hipStream_t st, int no_global_kernel);
 void rp_launch_wake(const DevWorld &w, hipStream_t st, int phase);
 void rp_launch_wake_partners(const DevWorld &w, hipStream_t st);
+void rp_launch_force_events(const DevWorld &w, hipStream_t st);
 
 struct HostBody {
     rp_body_desc d; float inv_mass; float inv_pi[3]; float lcom[3]; int ncolliders; bool removed;
@@ -105,6 +106,7 @@ static int upload_collider_row(rp_world *w, int i);
 static int after_topology_edit(rp_world *w);
 static bool world_sleep_enabled(const rp_world *w);
 static bool world_has_kinematic_pos(const rp_world *w);
+static bool world_has_force_events(const rp_world *w);
 static int check_sleep_scope(rp_world *w);
 static int rebuild_begin(rp_world *w);
 static int finalize(rp_world *w);
@@ -424,6 +426,7 @@ extern "C" int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider
     }
     if (in_place && n > 0) {
         w->dw.n_colliders = (int)w->colliders.size();
+        w->dw.has_force_events = world_has_force_events(w) ? 1 : 0;
         HIPCHK(w, hipStreamSynchronize(w->stream));
         destroy_graphs(w);
         return after_topology_edit(w);
@@ -511,7 +514,7 @@ static int upload_body_row(rp_world *w, int i) {
     PUT(d.b_next_pos, i, r.npos); PUT(d.b_next_rot, i, r.nrot);
     return RP_OK;
 }
-struct ColliderRow { int parent, shape; float4 lp, lr, he, mat, fmn, fmx; int2 rules; uint2 groups; };
+struct ColliderRow { int parent, shape; float4 lp, lr, he, mat, fmn, fmx; int2 rules; uint2 groups; float2 events; };
 static ColliderRow pack_collider(const rp_world *w, int i) {
     const rp_collider_desc &c = w->colliders[i];
     ColliderRow o;
@@ -526,6 +529,7 @@ static ColliderRow pack_collider(const rp_world *w, int i) {
     o.groups.x = w->collider_removed[i] ? 0u : c.collision_memberships; o.groups.y = w->collider_removed[i] ? 0u : c.collision_filter;
     // an "inverted" AABB: the first k_collider_update always rewrites it (and flags the broad phase)
     o.fmn = mk4(1.0f, 1.0f, 1.0f, 0); o.fmx = mk4(-1.0f, -1.0f, -1.0f, 0);
+    int ev = (int)(c.active_events & 3u); memcpy(&o.events.x, &ev, sizeof(int)); o.events.y = c.contact_force_event_threshold;
     return o;
 }
 static int upload_body_row_mass(rp_world *w, int i) { // mass properties only (a collider was attached / removed)
@@ -539,7 +543,7 @@ static int upload_collider_row(rp_world *w, int i) {
     const DevWorld &d = w->dw;
     ColliderRow r = pack_collider(w, i);
     PUT(d.c_parent, i, r.parent); PUT(d.c_shape, i, r.shape); PUT(d.c_lpos, i, r.lp); PUT(d.c_lrot, i, r.lr); PUT(d.c_he, i, r.he); PUT(d.c_mat, i, r.mat);
-    PUT(d.c_rules, i, r.rules); PUT(d.c_groups, i, r.groups); PUT(d.c_fatmin, i, r.fmn); PUT(d.c_fatmax, i, r.fmx);
+    PUT(d.c_rules, i, r.rules); PUT(d.c_groups, i, r.groups); PUT(d.c_fatmin, i, r.fmn); PUT(d.c_fatmax, i, r.fmx); PUT(d.c_events, i, r.events);
     return RP_OK;
 }
 
@@ -550,6 +554,10 @@ static bool world_sleep_enabled(const rp_world *w) {
         // a kinematic body is sleep-eligible whenever its velocity is exactly zero, whatever can_sleep says
         if (b.d.body_type == RP_BODY_KINEMATIC_POSITION || b.d.body_type == RP_BODY_KINEMATIC_VELOCITY) return true;
     }
+    return false;
+}
+static bool world_has_force_events(const rp_world *w) {
+    for (size_t i = 0; i < w->colliders.size(); ++i) if (!w->collider_removed[i] && (w->colliders[i].active_events & RP_EVENTS_CONTACT_FORCE)) return true;
     return false;
 }
 static bool world_has_kinematic_pos(const rp_world *w) {
@@ -571,6 +579,7 @@ static int finalize(rp_world *w) {
     memset(&d, 0, sizeof(d));
     d.sleep_enabled = world_sleep_enabled(w) ? 1 : 0;
     d.has_kinematic_pos = world_has_kinematic_pos(w) ? 1 : 0;
+    d.has_force_events = world_has_force_events(w) ? 1 : 0;
     int nb = (int)w->bodies.size(), nc = (int)w->colliders.size();
     d.n_bodies = nb; d.n_colliders = nc;
     // capacities leave room for bodies / colliders inserted later without rebuilding the device world
@@ -607,7 +616,9 @@ static int finalize(rp_world *w) {
     DA(d.s_lin, capb); DA(d.s_ang, capb); DA(d.s_rot, capb); DA(d.s_trans, capb); DA(d.s_incl, capb); DA(d.s_inca, capb);
     DA(d.b_cmask, 4 * (size_t)capb); DAF(d.b_min, capb, 0xff);
     DA(d.c_parent, capc); DA(d.c_shape, capc); DA(d.c_lpos, capc); DA(d.c_lrot, capc); DA(d.c_pos, capc); DA(d.c_rot, capc); DA(d.c_he, capc);
-    DA(d.c_mat, capc); DA(d.c_rules, capc); DA(d.c_groups, capc); DA(d.c_fatmin, capc); DA(d.c_fatmax, capc);
+    DA(d.c_mat, capc); DA(d.c_rules, capc); DA(d.c_groups, capc); DA(d.c_fatmin, capc); DA(d.c_fatmax, capc); DA(d.c_events, capc);
+    d.ev_cap = 65536;
+    DA(d.ev_col, d.ev_cap); DA(d.ev_force_meta, d.ev_cap); DA(d.ev_force_a, d.ev_cap); DA(d.ev_force_b, d.ev_cap);
     DA(d.cell_count, d.grid_cap); DA(d.cell_start, d.grid_cap + 1); DA(d.cell_fill, d.grid_cap); DA(d.scan_block, 1024);
     DA(d.e_key, d.entries_cap); DA(d.e_col, d.entries_cap); DA(d.large_list, d.large_cap);
     DAF(d.h_key[0], d.hash_cap, 0xff); DAF(d.h_key[1], d.hash_cap, 0xff); DA(d.h_slot[0], d.hash_cap); DA(d.h_slot[1], d.hash_cap);
@@ -697,13 +708,13 @@ static int finalize(rp_world *w) {
         UP(d.b_pframe, pfr); UP(d.b_damp, damp); UP(d.b_flags, bfl);
         std::vector<int> cpar(nc), csh(nc);
         std::vector<float4> clp(nc), clr(nc), che(nc), cmat(nc), fmn(nc), fmx(nc);
-        std::vector<int2> crul(nc); std::vector<uint2> cgrp(nc);
+        std::vector<int2> crul(nc); std::vector<uint2> cgrp(nc); std::vector<float2> cev(nc);
         for (int i = 0; i < nc; ++i) {
             ColliderRow r = pack_collider(w, i);
-            cpar[i] = r.parent; csh[i] = r.shape; clp[i] = r.lp; clr[i] = r.lr; che[i] = r.he; cmat[i] = r.mat; crul[i] = r.rules; cgrp[i] = r.groups; fmn[i] = r.fmn; fmx[i] = r.fmx;
+            cpar[i] = r.parent; csh[i] = r.shape; clp[i] = r.lp; clr[i] = r.lr; che[i] = r.he; cmat[i] = r.mat; crul[i] = r.rules; cgrp[i] = r.groups; fmn[i] = r.fmn; fmx[i] = r.fmx; cev[i] = r.events;
         }
         UP(d.c_parent, cpar); UP(d.c_shape, csh); UP(d.c_lpos, clp); UP(d.c_lrot, clr); UP(d.c_he, che); UP(d.c_mat, cmat);
-        UP(d.c_rules, crul); UP(d.c_groups, cgrp); UP(d.c_fatmin, fmn); UP(d.c_fatmax, fmx);
+        UP(d.c_rules, crul); UP(d.c_groups, cgrp); UP(d.c_fatmin, fmn); UP(d.c_fatmax, fmx); UP(d.c_events, cev);
         HIPCHK(w, hipStreamSynchronize(w->stream)); // the staging vectors die here
     }
     std::vector<int> fl(FL_COUNT, 0);
@@ -750,7 +761,7 @@ static void enqueue_global_solver(rp_world *w) {
 static void enqueue_solver(rp_world *w) { enqueue_island_solver(w); enqueue_global_solver(w); }
 static void enqueue_finish(rp_world *w) {
     // the scalars reach the mapped hint buffer from the device: k_island_solve (SINGLE) / k_publish (MULTI)
-    (void)w;
+    rp_launch_force_events(w->dw, w->stream); // contact force events of the step that just retired
 }
 
 static int pow2_ceil(int x) { int b = 1; while (b < x) b <<= 1; return b; }
@@ -886,7 +897,8 @@ static int step_once(rp_world *w, bool allow_fast) {
     }
     // mode: fast graph only while the last observed steps were clean
     // sleep-enabled worlds always take the full path (the sleep timers and the island decision run every step)
-    bool fast = allow_fast && w->use_fast && !w->dw.sleep_enabled && w->plan_single && w->dw.n_colliders > 0 && w->steps_requested >= w->full_until;
+    // ... and so do worlds with contact-force events (evaluated after every step)
+    bool fast = allow_fast && w->use_fast && !w->dw.sleep_enabled && !w->dw.has_force_events && w->plan_single && w->dw.n_colliders > 0 && w->steps_requested >= w->full_until;
     if (fast && (pf[FL_FAST_ABORT] || pf[FL_FULL_UPDATES] || pf[FL_LAYOUT_DIRTY] || pf[FL_TODO_COUNT])) {
         fast = false;
         w->full_until = w->steps_requested + 3;
@@ -1148,6 +1160,53 @@ extern "C" int32_t rp_bodies_remove(rp_world *w, int32_t n, const uint64_t *hand
         }
     }
     return after_topology_edit(w);
+}
+
+// Event queues (EventHandler, pipeline/event_handler.rs:94-160): drained oldest first.
+static int drain_count(rp_world *w, int slot, int *count) {
+    int r = settle(w); if (r != RP_OK) return r;
+    HIPCHK(w, hipMemcpy(count, w->dw.flags + slot, sizeof(int), hipMemcpyDeviceToHost));
+    return RP_OK;
+}
+extern "C" int32_t rp_collision_events_read(rp_world *w, int32_t cap, rp_collision_event *out) {
+    if (!w || cap < 0 || (cap > 0 && !out)) return RP_ERR_INVALID;
+    HIPCHK(w, hipSetDevice(w->device));
+    if (!w->finalized) return 0;
+    int n = 0; { int r = drain_count(w, FL_EV_COL, &n); if (r != RP_OK) return r; }
+    if (!out) return n;
+    int stored = std::min(n, w->dw.ev_cap);
+    if (n > stored) w->err = "rp_collision_events_read: the collision event queue overflowed; the newest events were dropped";
+    std::vector<int4> ev(stored);
+    if (stored) HIPCHK(w, hipMemcpy(ev.data(), w->dw.ev_col, stored * sizeof(int4), hipMemcpyDeviceToHost));
+    std::sort(ev.begin(), ev.end(), [](const int4 &a, const int4 &b) { if (a.w != b.w) return a.w < b.w; if (a.x != b.x) return a.x < b.x; if (a.y != b.y) return a.y < b.y; return a.z < b.z; });
+    for (int i = 0; i < stored && i < cap; ++i) { out[i].collider1 = ev[i].x; out[i].collider2 = ev[i].y; out[i].started = ev[i].z & 0xff; out[i].flags = ev[i].z >> 8; out[i].step = ev[i].w; }
+    int zero = 0; HIPCHK(w, hipMemcpy(w->dw.flags + FL_EV_COL, &zero, sizeof(int), hipMemcpyHostToDevice));
+    return stored;
+}
+extern "C" int32_t rp_contact_force_events_read(rp_world *w, int32_t cap, rp_contact_force_event *out) {
+    if (!w || cap < 0 || (cap > 0 && !out)) return RP_ERR_INVALID;
+    HIPCHK(w, hipSetDevice(w->device));
+    if (!w->finalized) return 0;
+    int n = 0; { int r = drain_count(w, FL_EV_FORCE, &n); if (r != RP_OK) return r; }
+    if (!out) return n;
+    int stored = std::min(n, w->dw.ev_cap);
+    if (n > stored) w->err = "rp_contact_force_events_read: the contact force event queue overflowed; the newest events were dropped";
+    std::vector<int4> meta(stored); std::vector<float4> a(stored), b(stored); std::vector<int> order(stored);
+    if (stored) {
+        HIPCHK(w, hipMemcpy(meta.data(), w->dw.ev_force_meta, stored * sizeof(int4), hipMemcpyDeviceToHost));
+        HIPCHK(w, hipMemcpy(a.data(), w->dw.ev_force_a, stored * sizeof(float4), hipMemcpyDeviceToHost));
+        HIPCHK(w, hipMemcpy(b.data(), w->dw.ev_force_b, stored * sizeof(float4), hipMemcpyDeviceToHost));
+    }
+    for (int i = 0; i < stored; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int p, int q) { const int4 &x = meta[p], &y = meta[q]; if (x.z != y.z) return x.z < y.z; if (x.x != y.x) return x.x < y.x; return x.y < y.y; });
+    for (int i = 0; i < stored && i < cap; ++i) {
+        int k = order[i];
+        out[i].collider1 = meta[k].x; out[i].collider2 = meta[k].y; out[i].step = meta[k].z; out[i].started = meta[k].w;
+        out[i].total_force[0] = a[k].x; out[i].total_force[1] = a[k].y; out[i].total_force[2] = a[k].z; out[i].total_force_magnitude = a[k].w;
+        out[i].max_force_direction[0] = b[k].x; out[i].max_force_direction[1] = b[k].y; out[i].max_force_direction[2] = b[k].z; out[i].max_force_magnitude = b[k].w;
+    }
+    int zero = 0; HIPCHK(w, hipMemcpy(w->dw.flags + FL_EV_FORCE, &zero, sizeof(int), hipMemcpyHostToDevice));
+    return stored;
 }
 
 // Quarantine (quarantine.rs:68-131): bodies whose state went non-finite.  The device rolls such a body

@@ -442,6 +442,7 @@ __device__ __noinline__ void pair_full_update(DevWorld &w, int s, int c1, int c2
     }
     if (has != had) {
         w.flags[FL_LAYOUT_DIRTY] = 1;
+        if (pair_wants_collision_events(w, c1, c2)) push_collision_event(w, c1, c2, has, 0, cur_step(w)); // contacts.rs:316-323
         if (!has) { // end touch: free the colour now (clear_pair_solver_color, mod.rs:157-172)
             int color = w.p_color[s];
             if (color < RP_COLOR_OVERFLOW) {

@@ -25,6 +25,15 @@ RP_DEV bool pair_selected(const DevWorld &w, int s) {
     return body_dyn_awake(w, rb.x) || body_dyn_awake(w, rb.y); // PAIR_HINT_DYN_BIT: at least one awake DYNAMIC body
 }
 
+// CollisionEvent queue (EventHandler::handle_collision_event, event_handler.rs:94-130)
+RP_DEV bool pair_wants_collision_events(const DevWorld &w, int c1, int c2) {
+    return ((__float_as_int(w.c_events[c1].x) | __float_as_int(w.c_events[c2].x)) & RP_EVENTS_COLLISION) != 0;
+}
+RP_DEV void push_collision_event(const DevWorld &w, int c1, int c2, int started, int flags, int step) {
+    int k = atomicAdd(&w.flags[FL_EV_COL], 1);
+    if (k < w.ev_cap) w.ev_col[k] = make_int4(c1, c2, started | (flags << 8), step);
+}
+
 RP_DEV Pose collider_world_pose(const DevWorld &w, int i) {
     int parent = w.c_parent[i];
     Pose lp; lp.r = q4(w.c_lrot[i]); lp.t = v3(w.c_lpos[i]);

@@ -72,6 +72,53 @@ __global__ void k_writeback_bodies(DevWorld w) {
     g_body_writeback(w, i);
 }
 
+// NarrowPhase::emit_contact_force_events (solver_graph.rs:462-498) + ContactForceEvent::from_contact_pair
+// (geometry/mod.rs:223-258): one thread per pair slot, after the impulses of the step were written back.
+__global__ void k_force_events(DevWorld w) {
+    int top = w.flags[FL_POOL_TOP];
+    if (top > w.pool_cap) top = w.pool_cap;
+    const float dt = w.prm.p.dt, inv_dt = dt == 0.0f ? 0.0f : 1.0f / dt;
+    const int step = w.flags[FL_STEP]; // the step that just retired
+    int stride = gridDim.x * blockDim.x;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < top; s += stride) {
+        int c1 = w.p_c1[s];
+        if (c1 < 0) continue;
+        int c2 = w.p_c2[s];
+        float2 e1 = w.c_events[c1], e2 = w.c_events[c2];
+        float ta = (__float_as_int(e1.x) & RP_EVENTS_CONTACT_FORCE) ? e1.y : 3.402823466e+38f;
+        float tb = (__float_as_int(e2.x) & RP_EVENTS_CONTACT_FORCE) ? e2.y : 3.402823466e+38f;
+        float threshold = ta < tb ? ta : tb;
+        if (!(threshold < 3.402823466e+38f) || !pair_selected(w, s)) continue;
+        int npts = w.p_npts[s];
+        float total = 0.0f;
+        for (int k = 0; k < npts; ++k) total += PT(w.pt_imp, k, s).x; // every tracked point, like ContactManifoldExt::total_impulse
+        float total_magnitude = (0.0f + total) * inv_dt;
+        int pf = w.p_pflags[s];
+        if (total_magnitude > threshold) {
+            V3 normal = v3(w.p_normal[s]);
+            float max_mag = 0.0f, tmi = 0.0f; V3 max_dir = v3(0, 0, 0);
+            for (int k = 0; k < npts; ++k) {
+                float imp = PT(w.pt_imp, k, s).x;
+                tmi += imp;
+                if (imp > max_mag) { max_mag = imp; max_dir = normal; }
+            }
+            V3 total_force = (v3(0, 0, 0) + normal * tmi) * inv_dt;
+            int k = atomicAdd(&w.flags[FL_EV_FORCE], 1);
+            if (k < w.ev_cap) {
+                w.ev_force_meta[k] = make_int4(c1, c2, step, (pf & RP_PF_FORCE_EMITTED) ? 0 : 1);
+                w.ev_force_a[k] = f4(total_force, total_magnitude);
+                w.ev_force_b[k] = f4(max_dir, max_mag * inv_dt);
+            }
+            w.p_pflags[s] = pf | RP_PF_FORCE_EMITTED;
+        } else if (pf & RP_PF_FORCE_EMITTED) w.p_pflags[s] = pf & ~RP_PF_FORCE_EMITTED;
+    }
+}
+void rp_launch_force_events(const DevWorld &w, hipStream_t st) {
+    if (!w.has_force_events || w.n_colliders == 0) return;
+    int blocks = (w.pool_cap + 255) / 256; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_force_events, dim3(blocks), dim3(256), 0, st, w);
+}
+
 __global__ void k_publish(DevWorld w) { publish_flags(w); }
 __global__ void __launch_bounds__(1024) k_global_single(DevWorld w, int has_restitution, int fast) { global_single_block(w, has_restitution, fast); }
 

@@ -31,6 +31,7 @@
 
 // pair flag bits
 #define RP_PF_RECYCLE 0x1
+#define RP_PF_FORCE_EMITTED 0x2       // PairEventStatus::INITIAL_FORCE_THRESHOLD_EVENT_EMITTED
 
 // overflow / error flag bits (dev flags[FL_OVERFLOW])
 #define RP_OVF_POOL 0x1
@@ -74,6 +75,7 @@ enum {
     FL_ISL_ICONS_CURSOR,
     FL_TICKET,          // last-workgroup-done ticket (one user at a time: kernels of a step are serialised)
     FL_FAST_ABORT,      // steady-state fast path found work it cannot do (see rp_api.hip); sticky until a full step
+    FL_EV_COL, FL_EV_FORCE, // events appended to the collision / contact-force queues (may exceed the queue capacity)
     FL_WAKE_STAMP,      // 2 * step + phase of the last wake pass that found a sleeping island to wake (rp_sleep.hip)
     FL_COUNT = 48
 };
@@ -141,6 +143,8 @@ struct DevWorld {
     int large_cap;
     int cons_cap;      // solver manifolds
     int sleep_enabled; // some body may fall asleep (can_sleep dynamic bodies, any kinematic body): the sleep kernels run and pairs carry solver hints
+    int has_force_events;  // some collider has ActiveEvents::CONTACT_FORCE_EVENTS: k_force_events runs after every step
+    int ev_cap;            // slots per event queue
     int has_kinematic_pos; // some body is KinematicPositionBased: k_kinematic_velocities runs
     SimParams prm;
     int *flags;        // FL_* scalars
@@ -182,6 +186,11 @@ struct DevWorld {
     int2 *c_rules;
     uint2 *c_groups;
     float4 *c_fatmin, *c_fatmax;
+    float2 *c_events;      // ActiveEvents bits (as int bits), contact_force_event_threshold
+    // ---- event queues (rp_collision_event / rp_contact_force_event) ----
+    int4 *ev_col;          // collider1, collider2, started | flags << 8, step
+    int4 *ev_force_meta;   // collider1, collider2, step, started
+    float4 *ev_force_a, *ev_force_b; // total_force xyz + magnitude ; max_force_direction xyz + max magnitude
 
     // ---- broad phase ----
     int *cell_count, *cell_start, *cell_fill, *scan_block;

@@ -269,6 +269,30 @@ class PhysicsWorld:
         p = np.ascontiguousarray(np.asarray(pos7, dtype=np.float32).reshape(len(h), 7))
         _check(self._ptr, self._lib.rp_bodies_set_next_kinematic_position(self._ptr, len(h), h.ctypes.data, p.ctypes.data), "rp_bodies_set_next_kinematic_position")
 
+    def collision_events(self) -> np.ndarray:
+        """Drain the CollisionEvent queue: rows (collider1, collider2, started, flags, step)."""
+        n = self._lib.rp_collision_events_read(self._ptr, 0, None)
+        if n < 0:
+            _check(self._ptr, n, "rp_collision_events_read")
+        out = np.zeros((max(n, 1), 5), np.int32)
+        m = self._lib.rp_collision_events_read(self._ptr, n, out.ctypes.data)
+        if m < 0:
+            _check(self._ptr, m, "rp_collision_events_read")
+        return out[:m]
+
+    def contact_force_events(self):
+        """Drain the ContactForceEvent queue: (meta rows (collider1, collider2, step, started), 8 floats per event:
+        total_force xyz, total_force_magnitude, max_force_direction xyz, max_force_magnitude)."""
+        n = self._lib.rp_contact_force_events_read(self._ptr, 0, None)
+        if n < 0:
+            _check(self._ptr, n, "rp_contact_force_events_read")
+        raw = np.zeros((max(n, 1), 12), np.float32)
+        m = self._lib.rp_contact_force_events_read(self._ptr, n, raw.ctypes.data)
+        if m < 0:
+            _check(self._ptr, m, "rp_contact_force_events_read")
+        raw = raw[:m]
+        return raw[:, :4].copy().view(np.int32), raw[:, 4:].copy()
+
     def wake_up(self, handles, strong: bool = True):
         """IslandManager::wake_up (island_manager/sleep.rs:31) — effective at the next step, island-wide."""
         h = np.ascontiguousarray(np.atleast_1d(np.asarray(handles, dtype=np.uint64)))

@@ -52,6 +52,8 @@ def lib():
         L.ro_set_threads.argtypes = [C.c_int32]
         L.ro_set_body_pose.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         L.ro_set_next_kinematic_position.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        L.ro_collision_events_drain.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        L.ro_force_events_drain.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.ro_wake_up.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         L.ro_read_sleeping.argtypes = [C.c_void_p, C.c_void_p]
         L.ro_remove_body.argtypes = [C.c_void_p, C.c_int32]
@@ -138,6 +140,21 @@ class OracleWorld:
     def set_next_kinematic_position(self, body, pos7):
         p = np.ascontiguousarray(pos7, np.float32)
         lib().ro_set_next_kinematic_position(self._w, int(body), p.ctypes.data)
+
+    def collision_events(self):
+        """Drain: rows (collider1, collider2, started, flags, step)."""
+        n = lib().ro_collision_events_drain(self._w, 0, None)
+        out = np.zeros((n, 5), np.int32)
+        lib().ro_collision_events_drain(self._w, n, out.ctypes.data)
+        return out
+
+    def force_events(self):
+        """Drain: (meta rows (collider1, collider2, step, started), value rows of 8 floats)."""
+        n = lib().ro_force_events_drain(self._w, 0, None, None)
+        meta = np.zeros((n, 4), np.int32)
+        vals = np.zeros((n, 8), np.float32)
+        lib().ro_force_events_drain(self._w, n, meta.ctypes.data, vals.ctypes.data)
+        return meta, vals
 
     def wake_up(self, body, strong=True):
         lib().ro_wake_up(self._w, int(body), 1 if strong else 0)

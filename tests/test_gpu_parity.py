@@ -512,6 +512,45 @@ def test_kinematic_velocity_platform_sleep_and_wake_bit_exact():
     assert not g.sleeping()[1:5].any() and g.sleeping()[5]   # the free cube on the floor sleeps on
 
 
+# ---- events (SURVEY §8a MISC emit_contact_force_events, §8f.3 collision events) ----
+def _sorted_events(ev):
+    return sorted(tuple(int(x) for x in e) for e in ev)
+
+
+def _same_events(g, o, msg):
+    assert _sorted_events(g.collision_events()) == _sorted_events(o.collision_events()), msg
+    gm, gv = g.contact_force_events()
+    om, ov = o.force_events()
+    go = np.lexsort((gm[:, 1], gm[:, 0], gm[:, 2])) if len(gm) else np.zeros(0, int)
+    oo = np.lexsort((om[:, 1], om[:, 0], om[:, 2])) if len(om) else np.zeros(0, int)
+    np.testing.assert_array_equal(gm[go], om[oo], err_msg=msg + " (force event pairs / steps / started)")
+    np.testing.assert_array_equal(gv[go], ov[oo], err_msg=msg + " (force event values)")
+
+
+def test_collision_and_contact_force_events_bit_exact():
+    sc = S.box_stack(2, gap=0.5).enable_events(S.ACTIVE_EVENTS_COLLISION | S.ACTIVE_EVENTS_CONTACT_FORCE, 15.0)
+    g, o = PhysicsWorld.from_scene(sc), OracleWorld(sc)
+    g.step(80); o.step(80)
+    _same_state(g, o, "events scene")
+    _same_events(g, o, "box stack events")
+    g.remove_body(1); o.remove_body(1)
+    g.step(40); o.step(40)
+    _same_events(g, o, "events after removing the lower box")
+    assert len(g.collision_events()) == 0                       # drained
+    sc2 = S.tumble(40, seed=11).enable_events(S.ACTIVE_EVENTS_COLLISION | S.ACTIVE_EVENTS_CONTACT_FORCE, 2.0)
+    g2, o2 = PhysicsWorld.from_scene(sc2), OracleWorld(sc2)
+    for cp in (30, 120, 250):
+        g2.step(cp); o2.step(cp)
+        _same_state(g2, o2, f"tumble with events +{cp}")
+        _same_events(g2, o2, f"tumble events +{cp}")
+    sc3 = S.many_pyramids(rows=2, cols=2).enable_events(S.ACTIVE_EVENTS_COLLISION, 0.0)   # collision events ride the fast path
+    g3, o3 = PhysicsWorld.from_scene(sc3), OracleWorld(sc3)
+    g3.step(100); o3.step(100)
+    _same_state(g3, o3, "pyramids with collision events")
+    _same_events(g3, o3, "pyramid collision events")
+    assert g3.counters()["fast_steps"] > 0
+
+
 def test_out_of_scope_inputs_are_refused():
     """Angular joint locks, contact-disabled joints, compound bodies and joints on can_sleep bodies are refused
     loudly, not mis-simulated."""

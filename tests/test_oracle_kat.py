@@ -228,6 +228,28 @@ def test_coulomb_pyramid_rests_and_carries_its_weight():
     assert imp[ground].sum() == pytest.approx(weight, rel=0.01)
 
 
+# Events (pipeline/event_handler.rs:94-160): Started / Stopped on touching transitions, contact force events above the
+# threshold with `started` on the first step above it (geometry/mod.rs:223-258).
+def test_collision_and_contact_force_events():
+    sc = S.box_stack(2, gap=0.5).enable_events(S.ACTIVE_EVENTS_COLLISION | S.ACTIVE_EVENTS_CONTACT_FORCE, 15.0)
+    w = OracleWorld(sc)
+    w.step(80)
+    ev = w.collision_events()
+    assert [tuple(e[:4]) for e in ev] == [(0, 1, 1, 0), (1, 2, 1, 0)]          # Started(ground, box1), Started(box1, box2)
+    assert ev[0, 4] == 1 and ev[1, 4] > 10                                      # the upper box lands later
+    meta, vals = w.force_events()
+    ground = meta[(meta[:, 0] == 0) & (meta[:, 1] == 1)]
+    assert ground[0, 3] == 1 and (ground[-20:, 3] == 0).all()                   # `started` only on the first step above the threshold
+    last = vals[(meta[:, 0] == 0) & (meta[:, 1] == 1)][-1]
+    assert last[3] == pytest.approx(2 * 9.81, rel=0.02) and last[1] == pytest.approx(last[3])   # carries both boxes, along +y
+    assert not ((meta[:, 0] == 1) & (meta[:, 1] == 2) & (meta[:, 2] > 60)).any()   # 9.81 N between the boxes stays below 15 N
+    w.remove_body(1)
+    w.step(40)
+    ev = w.collision_events()
+    assert (0, 1, 0, 2) in [tuple(e[:4]) for e in ev] and (1, 2, 0, 2) in [tuple(e[:4]) for e in ev]   # Stopped(.., REMOVED)
+    assert (0, 2, 1, 0) in [tuple(e[:4]) for e in ev]                           # the upper box lands on the ground
+
+
 # Kinematic bodies (solver bodies with zero inverse mass; interpolate_kinematic_velocities, substep.rs:242-264):
 # a platform carries the boxes standing on it and is never pushed back.
 @pytest.mark.parametrize("position_based", [False, True])
