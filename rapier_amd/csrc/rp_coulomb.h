@@ -247,11 +247,12 @@ RP_DEV void coul_writeback(const DevWorld &w, const Acc &A, int s) {
     }
 }
 
-// ---- model dispatch used by the global path (uniform branch on IntegrationParameters::friction_model) ----
+// ---- model dispatch used by the global path: a compile-time switch, so the default (twist) kernels carry no Coulomb
+// code (their register / scratch budget is unchanged); the host launches the variant of IntegrationParameters::friction_model
 RP_DEV bool coulomb_model(const DevWorld &w) { return w.prm.p.friction_model == RP_FRICTION_COULOMB; }
-template <class Acc>
+template <bool COUL, class Acc>
 RP_DEV void cons_apply_model(const DevWorld &w, const Acc &A, int mode, bool friction_in_bias, float solved_dt) {
-    if (!coulomb_model(w)) { cons_apply(w, A, mode, friction_in_bias, solved_dt); return; }
+    if (!COUL) { cons_apply(w, A, mode, friction_in_bias, solved_dt); return; }
     if (mode == MODE_WARMSTART) coul_update_warmstart(w, A);
     else if (mode == MODE_BIAS) coul_solve(w, A, false, friction_in_bias);
     else if (mode == MODE_RELAX) coul_solve(w, A, true, true);

@@ -27,27 +27,35 @@ RP_DEV void g_body_integrate(const DevWorld &w, int i) {
     body_integrate(w, w.b_flags[i], lin, ang, rot, trans);
     w.s_lin[i] = f4(lin, 0.0f); w.s_ang[i] = f4(ang, 0.0f); w.s_rot[i] = f4(rot); w.s_trans[i] = f4(trans, 0.0f);
 }
-RP_DEV void g_body_writeback(const DevWorld &w, int i) {
-    int type = w.b_flags[i] & RP_BF_TYPE_MASK;
-    if (type == RP_BODY_DYNAMIC) { body_writeback(w, i, v3(w.s_lin[i]), v3(w.s_ang[i]), q4(w.s_rot[i]), v3(w.s_trans[i])); return; }
-    // kinematic bodies (worker.rs:826-842): damped velocity; a velocity-based body takes the integrated solver pose, a
-    // position-based one lands exactly on the pose the user asked for; their inverse mass / inertia stay zero
-    float4 damp = w.b_damp[i];
-    float dt = w.prm.p.dt;
-    V3 lin = v3(w.s_lin[i]) * (1.0f / (1.0f + dt * damp.x));
-    V3 ang = v3(w.s_ang[i]) * (1.0f / (1.0f + dt * damp.y));
-    V3 lcom = v3(w.b_lcom_invm[i]);
-    Q4 rot = q4(w.s_rot[i]);
-    V3 t = v3(w.s_trans[i]) + qrot(rot, -lcom);
-    if (type == RP_BODY_KINEMATIC_POSITION) { rot = q4(w.b_next_rot[i]); t = v3(w.b_next_pos[i]); }
+// kinematic bodies (worker.rs:826-842): damped velocity; a velocity-based body takes the integrated solver pose, a
+// position-based one lands exactly on the pose the user asked for; their inverse mass / inertia stay zero.
+// Kept out of line: kinematic bodies are rare and the call keeps the dynamic path's register / scratch budget unchanged.
+// (the arrays are handed over as plain pointers: a DevWorld reference in this out-of-line path makes the compiler keep a
+// 1.4 KB stack copy of the kernel argument, and that much scratch costs ~40 us of launch latency on every step)
+struct KinWb { float4 *b_damp, *s_lin, *s_ang, *s_rot, *s_trans, *b_lcom_invm, *b_next_rot, *b_next_pos, *b_linvel, *b_angvel, *b_pos, *b_rot, *b_wcom; int *flags, *b_quar; float dt; };
+__device__ __noinline__ void g_kinematic_writeback(KinWb k, int i, int type) {
+    float4 damp = k.b_damp[i];
+    float dt = k.dt;
+    V3 lin = v3(k.s_lin[i]) * (1.0f / (1.0f + dt * damp.x));
+    V3 ang = v3(k.s_ang[i]) * (1.0f / (1.0f + dt * damp.y));
+    V3 lcom = v3(k.b_lcom_invm[i]);
+    Q4 rot = q4(k.s_rot[i]);
+    V3 t = v3(k.s_trans[i]) + qrot(rot, -lcom);
+    if (type == RP_BODY_KINEMATIC_POSITION) { rot = q4(k.b_next_rot[i]); t = v3(k.b_next_pos[i]); }
     bool finite = isfinite(t.x) && isfinite(t.y) && isfinite(t.z) && isfinite(rot.x) && isfinite(rot.y) && isfinite(rot.z) && isfinite(rot.w) &&
                   isfinite(lin.x) && isfinite(lin.y) && isfinite(lin.z) && isfinite(ang.x) && isfinite(ang.y) && isfinite(ang.z);
-    if (!finite) { atomicAdd(&w.flags[FL_QUARANTINE], 1); w.b_quar[i] = 1; w.b_linvel[i] = make_float4(0, 0, 0, 0); w.b_angvel[i] = make_float4(0, 0, 0, 0); return; }
-    w.b_linvel[i] = f4(lin, 0.0f); w.b_angvel[i] = f4(ang, 0.0f);
-    w.b_pos[i] = f4(t, 0.0f); w.b_rot[i] = f4(rot);
-    w.b_next_pos[i] = f4(t, 0.0f); w.b_next_rot[i] = f4(rot); // position = next_position (advance_to_final_positions)
-    w.b_wcom[i] = f4(qrot(rot, lcom) + t, 0.0f);
+    if (!finite) { atomicAdd(&k.flags[FL_QUARANTINE], 1); k.b_quar[i] = 1; k.b_linvel[i] = make_float4(0, 0, 0, 0); k.b_angvel[i] = make_float4(0, 0, 0, 0); return; }
+    k.b_linvel[i] = f4(lin, 0.0f); k.b_angvel[i] = f4(ang, 0.0f);
+    k.b_pos[i] = f4(t, 0.0f); k.b_rot[i] = f4(rot);
+    k.b_next_pos[i] = f4(t, 0.0f); k.b_next_rot[i] = f4(rot);
+    k.b_wcom[i] = f4(qrot(rot, lcom) + t, 0.0f);
 }
+RP_DEV void g_body_writeback(const DevWorld &w, int i) {
+    int type = w.b_flags[i] & RP_BF_TYPE_MASK;
+    if (type == RP_BODY_DYNAMIC) body_writeback(w, i, v3(w.s_lin[i]), v3(w.s_ang[i]), q4(w.s_rot[i]), v3(w.s_trans[i]));
+    else { KinWb k = {w.b_damp, w.s_lin, w.s_ang, w.s_rot, w.s_trans, w.b_lcom_invm, w.b_next_rot, w.b_next_pos, w.b_linvel, w.b_angvel, w.b_pos, w.b_rot, w.b_wcom, w.flags, w.b_quar, w.prm.p.dt}; g_kinematic_writeback(k, i, type); }
+}
+template <bool COUL>
 RP_DEV bool g_generate(const DevWorld &w, int pos) {
     int s = w.cons_pair[pos];
     int rb1 = w.c_parent[w.p_c1[s]], rb2 = w.c_parent[w.p_c2[s]];
@@ -55,25 +63,25 @@ RP_DEV bool g_generate(const DevWorld &w, int pos) {
     bool dyn1 = body_active(w, rb1), dyn2 = body_active(w, rb2); // solver bodies = the active set (solver_body.rs:114)
     int id1 = (dyn1 && rel_dom <= 0) ? rb1 : -1;
     int id2 = (dyn2 && rel_dom >= 0) ? rb2 : -1;
-    if (coulomb_model(w)) return coul_generate(w, GlobalAcc(w, pos), s, id1, id2, id1, id2);
+    if (COUL) return coul_generate(w, GlobalAcc(w, pos), s, id1, id2, id1, id2);
     return cons_generate(w, GlobalAcc(w, pos), s, id1, id2, id1, id2);
 }
 
 // Serial tail of one sweep (worker 0 of the reference): stages [first, n_stages) one after the other
 // inside one workgroup, then the overflow colour on lane 0.
-template <int MODE>
+template <int MODE, bool COUL>
 RP_DEV void tail_sweep(const DevWorld &w, int first, bool fib, float solved_dt) {
     int nst = w.flags[FL_N_STAGES];
     for (int st = first; st < nst; ++st) {
         int beg = w.stage_begin[st], cnt = w.stage_count[st];
-        for (int i = threadIdx.x; i < cnt; i += blockDim.x) cons_apply_model(w, GlobalAcc(w, beg + i), MODE, fib, solved_dt);
+        for (int i = threadIdx.x; i < cnt; i += blockDim.x) cons_apply_model<COUL>(w, GlobalAcc(w, beg + i), MODE, fib, solved_dt);
         __threadfence();
         __syncthreads();
     }
     if (w.flags[FL_HAS_OVERFLOW_COLOR]) {
         if (threadIdx.x == 0) {
             int beg = w.stage_begin[nst], cnt = w.stage_count[nst];
-            for (int i = 0; i < cnt; ++i) { cons_apply_model(w, GlobalAcc(w, beg + i), MODE, fib, solved_dt); __threadfence(); }
+            for (int i = 0; i < cnt; ++i) { cons_apply_model<COUL>(w, GlobalAcc(w, beg + i), MODE, fib, solved_dt); __threadfence(); }
         }
         __threadfence();
         __syncthreads();
@@ -89,6 +97,7 @@ RP_DEV void publish_flags(const DevWorld &w) {
         __hip_atomic_store(&w.host_flags[threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
+template <bool COUL>
 RP_DEV void global_single_block(const DevWorld &w, int has_restitution, int fast) {
     const int t = threadIdx.x, nt = blockDim.x;
     __shared__ int bouncy;
@@ -105,27 +114,27 @@ RP_DEV void global_single_block(const DevWorld &w, int has_restitution, int fast
     __syncthreads();
     for (int i = t; i < nb; i += nt) if (global_body(w, i)) g_body_begin(w, i);
     __threadfence(); __syncthreads();
-    for (int pos = t; pos < M; pos += nt) if (g_generate(w, pos)) bouncy = 1;
+    for (int pos = t; pos < M; pos += nt) if (g_generate<COUL>(w, pos)) bouncy = 1;
     __threadfence(); __syncthreads();
     for (int sub = 0; sub < w.prm.num_substeps; ++sub) {
         float solved_dt = (float)sub * w.prm.dt_sub;
         for (int i = t; i < nb; i += nt) if (global_body(w, i)) g_body_increment(w, i);
         for (int j = t; j < nj; j += nt) joint_update_one(w, j, sub); // reads poses only
         __threadfence(); __syncthreads();
-        tail_sweep<MODE_WARMSTART>(w, 0, fib, solved_dt);
+        tail_sweep<MODE_WARMSTART, COUL>(w, 0, fib, solved_dt);
         for (int it = 0; it < prm.num_internal_pgs_iterations; ++it) {
             joint_tail_sweep(w, 0, false, prm.warmstart_joints && it == 0); // every joint before any contact
-            tail_sweep<MODE_BIAS>(w, 0, fib, solved_dt);
+            tail_sweep<MODE_BIAS, COUL>(w, 0, fib, solved_dt);
         }
         for (int i = t; i < nb; i += nt) if (global_body(w, i)) g_body_integrate(w, i);
         __threadfence(); __syncthreads();
         for (int it = 0; it < prm.num_internal_stabilization_iterations; ++it) {
             joint_tail_sweep(w, 0, true, false);
-            tail_sweep<MODE_RELAX>(w, 0, fib, solved_dt + w.prm.dt_sub);
+            tail_sweep<MODE_RELAX, COUL>(w, 0, fib, solved_dt + w.prm.dt_sub);
         }
     }
-    if (has_restitution && bouncy) tail_sweep<MODE_RESTITUTION>(w, 0, fib, 0.0f);
-    for (int pos = t; pos < M; pos += nt) { if (coulomb_model(w)) coul_writeback(w, GlobalAcc(w, pos), w.cons_pair[pos]); else cons_writeback(w, GlobalAcc(w, pos), w.cons_pair[pos]); }
+    if (has_restitution && bouncy) tail_sweep<MODE_RESTITUTION, COUL>(w, 0, fib, 0.0f);
+    for (int pos = t; pos < M; pos += nt) { if (COUL) coul_writeback(w, GlobalAcc(w, pos), w.cons_pair[pos]); else cons_writeback(w, GlobalAcc(w, pos), w.cons_pair[pos]); }
     for (int j = t; j < nj; j += nt) joint_writeback_one(w, j);
     for (int i = t; i < nb; i += nt) if (global_body(w, i)) g_body_writeback(w, i);
 }

@@ -26,12 +26,13 @@ __global__ void k_solver_begin(DevWorld w) {
     if (i >= w.n_bodies || !global_body(w, i)) return;
     g_body_begin(w, i);
 }
+template <bool COUL>
 __global__ void k_generate(DevWorld w) {
     int M = w.flags[FL_N_CONS];
     if (M > w.cons_cap) M = w.cons_cap;
     int stride = gridDim.x * blockDim.x;
     for (int pos = blockIdx.x * blockDim.x + threadIdx.x; pos < M; pos += stride)
-        if (g_generate(w, pos)) w.flags[FL_ANY_BOUNCY] = 1;
+        if (g_generate<COUL>(w, pos)) w.flags[FL_ANY_BOUNCY] = 1;
 }
 __global__ void k_increment(DevWorld w) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -44,26 +45,27 @@ __global__ void k_integrate(DevWorld w) {
     g_body_integrate(w, i);
 }
 // One parallel colour stage: the reference's claim/steal chunk loop becomes a grid-stride loop.
-template <int MODE>
+template <int MODE, bool COUL>
 __global__ void __launch_bounds__(256) k_stage(DevWorld w, int stage, int friction_in_bias, float solved_dt) {
     if (stage >= w.flags[FL_N_PARALLEL]) return;
     if (MODE == MODE_RESTITUTION && !w.flags[FL_ANY_BOUNCY]) return;
     int beg = w.stage_begin[stage], cnt = w.stage_count[stage];
     int stride = gridDim.x * blockDim.x;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride)
-        cons_apply_model(w, GlobalAcc(w, beg + i), MODE, friction_in_bias != 0, solved_dt);
+        cons_apply_model<COUL>(w, GlobalAcc(w, beg + i), MODE, friction_in_bias != 0, solved_dt);
 }
-template <int MODE>
+template <int MODE, bool COUL>
 __global__ void __launch_bounds__(1024) k_tail(DevWorld w, int first, int friction_in_bias, float solved_dt) {
     if (MODE == MODE_RESTITUTION && !w.flags[FL_ANY_BOUNCY]) return;
     int npar = w.flags[FL_N_PARALLEL];
-    tail_sweep<MODE>(w, first < npar ? first : npar, friction_in_bias != 0, solved_dt);
+    tail_sweep<MODE, COUL>(w, first < npar ? first : npar, friction_in_bias != 0, solved_dt);
 }
+template <bool COUL>
 __global__ void k_writeback_impulses(DevWorld w) {
     int M = w.flags[FL_N_CONS];
     if (M > w.cons_cap) M = w.cons_cap;
     int stride = gridDim.x * blockDim.x;
-    for (int pos = blockIdx.x * blockDim.x + threadIdx.x; pos < M; pos += stride) { if (coulomb_model(w)) coul_writeback(w, GlobalAcc(w, pos), w.cons_pair[pos]); else cons_writeback(w, GlobalAcc(w, pos), w.cons_pair[pos]); }
+    for (int pos = blockIdx.x * blockDim.x + threadIdx.x; pos < M; pos += stride) { if (COUL) coul_writeback(w, GlobalAcc(w, pos), w.cons_pair[pos]); else cons_writeback(w, GlobalAcc(w, pos), w.cons_pair[pos]); }
 }
 __global__ void k_writeback_bodies(DevWorld w) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -120,7 +122,8 @@ void rp_launch_force_events(const DevWorld &w, hipStream_t st) {
 }
 
 __global__ void k_publish(DevWorld w) { publish_flags(w); }
-__global__ void __launch_bounds__(1024) k_global_single(DevWorld w, int has_restitution, int fast) { global_single_block(w, has_restitution, fast); }
+template <bool COUL>
+__global__ void __launch_bounds__(512) k_global_single(DevWorld w, int has_restitution, int fast) { global_single_block<COUL>(w, has_restitution, fast); }
 
 // World mass properties at insertion time (RigidBodyMassProps::update_world_mass_properties).
 __global__ void k_init_bodies(DevWorld w) {
@@ -148,11 +151,16 @@ void rp_launch_joint_writeback(const DevWorld &w, hipStream_t st);
 // ---- host-side launch sequences -------------------------------------------------------------------
 struct SolverLaunchPlan { int parallel_stages; int stage_blocks; };
 
+static bool host_coulomb(const DevWorld &w) { return w.prm.p.friction_model == RP_FRICTION_COULOMB; }
+template <int MODE, bool COUL>
+static void launch_sweep_model(const DevWorld &w, hipStream_t st, const SolverLaunchPlan &plan, int fib, float solved_dt) {
+    for (int s = 0; s < plan.parallel_stages; ++s)
+        hipLaunchKernelGGL((k_stage<MODE, COUL>), dim3(plan.stage_blocks * 4), dim3(64), 0, st, w, s, fib, solved_dt); // one wave per workgroup: a colour stage of ~10k manifolds then spreads over ~150 CUs instead of ~40
+    hipLaunchKernelGGL((k_tail<MODE, COUL>), dim3(1), dim3(1024), 0, st, w, plan.parallel_stages, fib, solved_dt);
+}
 template <int MODE>
 static void launch_sweep(const DevWorld &w, hipStream_t st, const SolverLaunchPlan &plan, int fib, float solved_dt) {
-    for (int s = 0; s < plan.parallel_stages; ++s)
-        hipLaunchKernelGGL(k_stage<MODE>, dim3(plan.stage_blocks * 4), dim3(64), 0, st, w, s, fib, solved_dt); // one wave per workgroup: a colour stage of ~10k manifolds then spreads over ~150 CUs instead of ~40
-    hipLaunchKernelGGL(k_tail<MODE>, dim3(1), dim3(1024), 0, st, w, plan.parallel_stages, fib, solved_dt);
+    if (host_coulomb(w)) launch_sweep_model<MODE, true>(w, st, plan, fib, solved_dt); else launch_sweep_model<MODE, false>(w, st, plan, fib, solved_dt);
 }
 static int body_blocks(const DevWorld &w) { int nb = (w.n_bodies + 255) / 256; return nb < 1 ? 1 : nb; }
 static int cons_blocks(const DevWorld &w) { int cb = (w.cons_cap + 255) / 256; if (cb > 2048) cb = 2048; return cb < 1 ? 1 : cb; }
@@ -162,11 +170,13 @@ void rp_launch_init_bodies(const DevWorld &w, hipStream_t st) {
     hipLaunchKernelGGL(k_init_bodies, dim3(body_blocks(w)), dim3(256), 0, st, w);
 }
 void rp_launch_global_single(const DevWorld &w, hipStream_t st, int has_restitution, int fast) {
-    hipLaunchKernelGGL(k_global_single, dim3(1), dim3(1024), 0, st, w, has_restitution, fast);
+    if (host_coulomb(w)) hipLaunchKernelGGL(k_global_single<true>, dim3(1), dim3(512), 0, st, w, has_restitution, fast);
+    else hipLaunchKernelGGL(k_global_single<false>, dim3(1), dim3(512), 0, st, w, has_restitution, fast);
 }
 void rp_launch_solver_assembly(const DevWorld &w, hipStream_t st) {
     hipLaunchKernelGGL(k_solver_begin, dim3(body_blocks(w)), dim3(256), 0, st, w);
-    hipLaunchKernelGGL(k_generate, dim3(cons_blocks(w)), dim3(256), 0, st, w);
+    if (host_coulomb(w)) hipLaunchKernelGGL(k_generate<true>, dim3(cons_blocks(w)), dim3(256), 0, st, w);
+    else hipLaunchKernelGGL(k_generate<false>, dim3(cons_blocks(w)), dim3(256), 0, st, w);
 }
 // The TGS loop proper: S2..S7 for every substep (+ S8 restitution) — worker.rs:207-734.
 void rp_launch_solver_loop(const DevWorld &w, hipStream_t st, int parallel_stages, int stage_blocks, int has_restitution, int joint_stages) {
@@ -192,7 +202,8 @@ void rp_launch_solver_loop(const DevWorld &w, hipStream_t st, int parallel_stage
     if (has_restitution) launch_sweep<MODE_RESTITUTION>(w, st, plan, fib, 0.0f);
 }
 void rp_launch_solver_writeback(const DevWorld &w, hipStream_t st) {
-    hipLaunchKernelGGL(k_writeback_impulses, dim3(cons_blocks(w)), dim3(256), 0, st, w);
+    if (host_coulomb(w)) hipLaunchKernelGGL(k_writeback_impulses<true>, dim3(cons_blocks(w)), dim3(256), 0, st, w);
+    else hipLaunchKernelGGL(k_writeback_impulses<false>, dim3(cons_blocks(w)), dim3(256), 0, st, w);
     rp_launch_joint_writeback(w, st);
     hipLaunchKernelGGL(k_writeback_bodies, dim3(body_blocks(w)), dim3(256), 0, st, w);
     hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, w); // hint buffer (MULTI mode: after the step)

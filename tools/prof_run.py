@@ -9,8 +9,21 @@ from rapier_amd import PhysicsWorld, scenes as S  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "many_pyramids"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-scene = {"many_pyramids": S.many_pyramids, "large_pyramid": S.large_pyramid, "pyramid10": S.pyramid10,
-         "joint_grid": getattr(S, "joint_grid", None)}[name]()
+variants = {
+    "many_pyramids": S.many_pyramids, "large_pyramid": S.large_pyramid, "pyramid10": S.pyramid10, "joint_grid": S.joint_grid,
+    # feature variants of the headline scene (full step path): sleeping allowed, Coulomb friction, all events on
+    "many_pyramids_sleep": lambda: S.many_pyramids().enable_sleep(),
+    "many_pyramids_coulomb": lambda: _with(S.many_pyramids(), "friction_model", S.FRICTION_COULOMB),
+    "many_pyramids_events": lambda: S.many_pyramids().enable_events(3, 100.0),
+}
+
+
+def _with(scene, key, value):
+    scene.params[key] = value
+    return scene
+
+
+scene = variants[name]()
 w = PhysicsWorld.from_scene(scene)
 w.step(60); w.sync()
 t = time.time(); w.step(steps); w.sync(); dt = time.time() - t
