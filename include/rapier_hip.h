@@ -114,7 +114,8 @@ typedef struct rp_contact_force_event {
     float max_force_magnitude;
 } rp_contact_force_event;
 
-/* GenericJoint restricted to locked axes — /root/reference/src/dynamics/joint/generic_joint.rs:341-355 */
+/* GenericJoint restricted to locked axes — /root/reference/src/dynamics/joint/generic_joint.rs:341-355; the local frames
+ * are (local_anchor, local_basis) like GenericJoint::local_frame1/2 */
 typedef struct rp_joint_desc {
     int32_t body1, body2; /* dense body indices (handle low 32 bits) */
     float local_anchor1[3], local_anchor2[3];
@@ -169,9 +170,10 @@ int32_t rp_bodies_insert(rp_world *w, int32_t n, const rp_body_desc *descs, uint
  * cuboid / ball shapes, one collider per body attached at the body origin (compound bodies are
  * refused with RP_ERR_INVALID). */
 int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider_desc *descs, const uint64_t *parents, uint64_t *handles_out);
-/* ImpulseJointSet::insert ×n (impulse_joint_set.rs).  Device path scope: locked linear axes (spherical
- * joints, JointAxesMask::LIN_AXES) with contacts between the two bodies enabled; anything else is
- * refused with RP_ERR_INVALID. */
+/* ImpulseJointSet::insert ×n (impulse_joint_set.rs).  Device path scope: locked axes only — any JointAxesMask of locked
+ * linear / angular axes (spherical 0x07, revolute 0x37, prismatic without limits 0x3e, fixed 0x3f; the free axis is the
+ * local frame's X axis as in RevoluteJointBuilder / PrismaticJointBuilder), contacts between the two bodies enabled;
+ * limits, motors, coupled axes and contacts_enabled = 0 are refused with RP_ERR_INVALID. */
 int32_t rp_impulse_joints_insert(rp_world *w, int32_t n, const rp_joint_desc *descs, uint64_t *handles_out);
 /* ImpulseJoint::impulses (per locked linear dof, as written back by the last step) and the persistent
  * solver colour of n joints (NULL handles = all, insertion order). */

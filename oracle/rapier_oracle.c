@@ -1498,7 +1498,7 @@ static void joint_builder_generate(ro_world *w, Joint *j, int *num_rows) {
     if (rb2->body_type == RO_BODY_FIXED) j->sb_frame2 = pose_mul(rb2->position, j->local_frame2);
     else j->sb_frame2.t = vsub(j->sb_frame2.t, rb2->local_com);
     j->first_row = *num_rows;
-    for (int i = 0; i < 3; ++i) if (j->locked_axes & (1u << i)) (*num_rows)++;
+    for (int i = 0; i < 6; ++i) if (j->locked_axes & (1u << i)) (*num_rows)++;
 }
 /* JointConstraint::<Real,1>::update (joint_velocity_constraint.rs:144-353) for locked linear axes:
  * JointConstraintHelper::new (joint_constraint_helper.rs:95-164), lock_linear (:411-458),
@@ -1522,6 +1522,48 @@ static int joint_update_rows(const ro_world *w, const Joint *j, float dt, JointR
     v3 c1x = V3(0.0f, r1.z, -r1.y), c1y = V3(-r1.z, 0.0f, r1.x), c1z = V3(r1.y, -r1.x, 0.0f);
     v3 c2x = V3(0.0f, r2.z, -r2.y), c2y = V3(-r2.z, 0.0f, r2.x), c2z = V3(r2.y, -r2.x, 0.0f);
     int len = 0;
+    if (j->locked_axes & 0x38u) {
+        /* locked angular axes — JointConstraintHelper::new (:129-139): ang_basis = diff_conj1_2_tr(q1, q2) * sgn,
+         * ang_err = (q1^-1 q2) * sgn, sgn = copysign(1, q1 . q2); lock_angular (:628-673).  The scalar update emits the
+         * angular lock rows BEFORE the linear ones (joint_velocity_constraint.rs:253-283). */
+        quat q1 = frame1.r, q2 = frame2.r;
+        v3 v1 = V3(q1.x, q1.y, q1.z), v2 = V3(q2.x, q2.y, q2.z);
+        float w1 = q1.w, w2 = q2.w;
+        /* RotationOps::diff_conj1_2 (utils/rotation_ops.rs:121-135), matrices as columns */
+        v3 u = vadd(vmul(v1, w2), vmul(v2, w1));
+        v3 cu[3] = {V3(0.0f, u.z, -u.y), V3(-u.z, 0.0f, u.x), V3(u.y, -u.x, 0.0f)};
+        v3 ca[3] = {V3(0.0f, v1.z, -v1.y), V3(-v1.z, 0.0f, v1.x), V3(v1.y, -v1.x, 0.0f)};
+        v3 cb[3] = {V3(0.0f, v2.z, -v2.y), V3(-v2.z, 0.0f, v2.x), V3(v2.y, -v2.x, 0.0f)};
+        float d = w1 * w2;
+        v3 dg[3] = {V3(d, 0.0f, 0.0f), V3(0.0f, d, 0.0f), V3(0.0f, 0.0f, d)};
+        float v2c[3] = {v2.x, v2.y, v2.z};
+        v3 M[3];
+        for (int c = 0; c < 3; ++c) {
+            v3 kron = vmul(v1, v2c[c]);
+            v3 prod = vadd(vadd(vmul(ca[0], cb[c].x), vmul(ca[1], cb[c].y)), vmul(ca[2], cb[c].z));
+            M[c] = vmul(vadd(vsub(vadd(kron, dg[c]), cu[c]), prod), 0.5f);
+        }
+        float sgn = copysignf(1.0f, qdot(q1, q2));
+        quat ang_err = qmul(qconj(q1), q2);
+        float ang_err_imag[3] = {ang_err.x * sgn, ang_err.y * sgn, ang_err.z * sgn};
+        for (int a = 0; a < 3; ++a) {
+            if (!(j->locked_axes & (8u << a))) continue;
+            /* column a of the transpose = row a of M */
+            v3 ang_jac = a == 0 ? V3(M[0].x, M[1].x, M[2].x) : a == 1 ? V3(M[0].y, M[1].y, M[2].y) : V3(M[0].z, M[1].z, M[2].z);
+            ang_jac = vmul(ang_jac, sgn);
+            JointRow *c = &out[len++];
+            c->solver_vel1 = j->solver_body_ids[0]; c->solver_vel2 = j->solver_body_ids[1];
+            c->im1 = rb1.im; c->im2 = rb2.im;
+            c->impulse = 0.0f; c->impulse_bounds[0] = -FLT_MAX; c->impulse_bounds[1] = FLT_MAX;
+            c->lin_jac = V3(0, 0, 0); c->ang_jac1 = ang_jac; c->ang_jac2 = ang_jac;
+            float rhs_wo_bias = 0.0f;
+            float rhs_bias = ang_err_imag[a] * erp_inv_dt;
+            c->ii_ang_jac1 = sym3_mul(rb1.ii, ang_jac);
+            c->ii_ang_jac2 = sym3_mul(rb2.ii, ang_jac);
+            c->inv_lhs = 0.0f; c->cfm_coeff = cfm_coeff; c->cfm_gain = 0.0f;
+            c->rhs = rhs_wo_bias + rhs_bias; c->rhs_wo_bias = rhs_wo_bias; c->dof = 3 + a;
+        }
+    }
     for (int i = 0; i < 3; ++i) {
         if (!(j->locked_axes & (1u << i))) continue;
         JointRow *c = &out[len++];
@@ -1567,9 +1609,9 @@ static int joint_update_rows(const ro_world *w, const Joint *j, float dt, JointR
 /* JointConstraintBuilder::update — joint_constraint_builder.rs:76-150 (row rebuild + warm-start carry) */
 static void joint_builder_update(ro_world *w, const Joint *j, float dt, int substep_id) {
     JointRow *rows = &w->joint_rows[j->first_row];
-    float prev[3] = {0, 0, 0};
+    float prev[6] = {0, 0, 0, 0, 0, 0};
     int ws = w->params.warmstart_joints;
-    int count = 0; for (int i = 0; i < 3; ++i) if (j->locked_axes & (1u << i)) count++;
+    int count = 0; for (int i = 0; i < 6; ++i) if (j->locked_axes & (1u << i)) count++;
     if (ws && substep_id > 0) for (int k = 0; k < count; ++k) prev[k] = rows[k].impulse;
     int len = joint_update_rows(w, j, dt, rows);
     if (ws) {
@@ -1603,7 +1645,7 @@ static void joint_row_solve(ro_world *w, JointRow *c) {
 /* The joint part of solve_pass — staged_island_solver/solve.rs:31-150: every joint (parallel colours
  * ascending, then the serial overflow) solves BEFORE any contact in every pass. */
 static void joint_solve_all_rows(ro_world *w, const Joint *j, int wo_bias, int warmstart_joints) {
-    int count = 0; for (int i = 0; i < 3; ++i) if (j->locked_axes & (1u << i)) count++;
+    int count = 0; for (int i = 0; i < 6; ++i) if (j->locked_axes & (1u << i)) count++;
     for (int k = 0; k < count; ++k) {
         JointRow *c = &w->joint_rows[j->first_row + k];
         if (wo_bias) c->rhs = c->rhs_wo_bias;
@@ -1787,8 +1829,8 @@ static void solve_velocity_constraints(ro_world *w) {
     /* JointConstraintsSet::writeback_impulses — joint_velocity_constraint.rs:346-353 */
     for (int a = 0; a < w->nactive_joints; ++a) {
         Joint *j = &w->joints[w->active_joints[a]];
-        int k = 0;
-        for (int i = 0; i < 3; ++i) if (j->locked_axes & (1u << i)) { j->impulses[i] = w->joint_rows[j->first_row + k].impulse; k++; }
+        int nrows = 0; for (int i = 0; i < 6; ++i) if (j->locked_axes & (1u << i)) nrows++;
+        for (int k = 0; k < nrows; ++k) { const JointRow *r = &w->joint_rows[j->first_row + k]; j->impulses[r->dof] = r->impulse; } /* WritebackId::Dof(i) */
     }
     /* S10 body writeback — worker.rs:809-897 */
     for (int i = 0; i < nd; ++i) {
@@ -1979,7 +2021,7 @@ int32_t ro_dump_manifolds(const ro_world *w, int32_t cap, int32_t *meta, float *
  * contacts between the two bodies enabled. */
 int32_t ro_add_joint(ro_world *w, const ro_joint_desc *d) {
     if (d->body1 < 0 || d->body2 < 0 || d->body1 >= w->nbodies || d->body2 >= w->nbodies) return -1;
-    if ((d->locked_axes & ~7u) != 0 || !d->contacts_enabled) return -1;
+    if ((d->locked_axes & ~0x3fu) != 0 || !d->contacts_enabled) return -1;
     if (w->njoints == w->cap_joints) {
         w->cap_joints = w->cap_joints ? w->cap_joints * 2 : 1024;
         w->joints = (Joint *)realloc(w->joints, sizeof(Joint) * w->cap_joints);

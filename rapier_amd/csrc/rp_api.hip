@@ -438,7 +438,7 @@ extern "C" int32_t rp_impulse_joints_insert(rp_world *w, int32_t n, const rp_joi
     for (int i = 0; i < n; ++i) {
         const rp_joint_desc &j = descs[i];
         if (j.body1 < 0 || j.body2 < 0 || j.body1 >= (int)w->bodies.size() || j.body2 >= (int)w->bodies.size()) { w->err = "rp_impulse_joints_insert: invalid body index"; return RP_ERR_INVALID; }
-        if ((j.locked_axes & ~7u) != 0) { w->err = "rp_impulse_joints_insert: only locked linear axes (spherical joints) are implemented on the device path"; return RP_ERR_INVALID; }
+        if ((j.locked_axes & ~0x3fu) != 0 || j.locked_axes == 0) { w->err = "rp_impulse_joints_insert: locked_axes must be a non-empty JointAxesMask (limits, motors and coupled axes are not implemented on the device path)"; return RP_ERR_INVALID; }
         if (!j.contacts_enabled) { w->err = "rp_impulse_joints_insert: contacts_enabled = false is not implemented on the device path"; return RP_ERR_INVALID; }
     }
     if (n > 0) { int r = rebuild_begin(w); if (r != RP_OK) return r; }
@@ -677,10 +677,10 @@ static int finalize(rp_world *w) {
     int nj = (int)jb1.size();
     d.n_joints = nj;
     DA(d.j_b1, nj); DA(d.j_b2, nj); DA(d.j_f1t, nj); DA(d.j_f1r, nj); DA(d.j_f2t, nj); DA(d.j_f2r, nj);
-    DA(d.j_locked, nj); DA(d.j_color, nj); DA(d.j_tmp, nj); DA(d.j_order, nj); DA(d.j_imp, nj);
+    DA(d.j_locked, nj); DA(d.j_color, nj); DA(d.j_tmp, nj); DA(d.j_order, nj); DA(d.j_imp, nj); DA(d.j_imp_ang, nj);
     DA(d.j_stage_begin, RP_NUM_COLORS + 1); DA(d.j_stage_count, RP_NUM_COLORS + 1);
     DA(d.bj_cmask, 4 * (size_t)capb); DAF(d.bj_min, capb, 0xff); DA(d.b_njoints, capb);
-    DA(d.JR, (size_t)17 * std::max(nj, 1));
+    DA(d.JR, (size_t)32 * std::max(nj, 1)); // JR_COUNT planes: 6 rows x 5 + im1 + im2 (rp_joints.h)
     UP(d.j_b1, jb1); UP(d.j_b2, jb2); UP(d.j_f1t, jf1t); UP(d.j_f1r, jf1r); UP(d.j_f2t, jf2t); UP(d.j_f2r, jf2r);
     UP(d.j_locked, jlocked); UP(d.j_color, jcolor); UP(d.b_njoints, bnj);
     {
@@ -1087,7 +1087,7 @@ static int remove_joint_at(rp_world *w, int j) {
         const rp_joint_desc &jd = w->joints[j];
         int r;
         if ((r = poke(w, w->dw.j_b1 + k, -1)) != RP_OK || (r = poke(w, w->dw.j_b2 + k, -1)) != RP_OK || (r = poke(w, w->dw.j_locked + k, 0)) != RP_OK ||
-            (r = poke(w, w->dw.j_imp + k, mk4(0, 0, 0, 0))) != RP_OK) return r;
+            (r = poke(w, w->dw.j_imp + k, mk4(0, 0, 0, 0))) != RP_OK || (r = poke(w, w->dw.j_imp_ang + k, mk4(0, 0, 0, 0))) != RP_OK) return r;
         for (int b : {jd.body1, jd.body2}) {
             if (w->bodies[b].d.body_type != RP_BODY_DYNAMIC || w->bodies[b].removed) continue;
             int cnt = 0;

@@ -1,20 +1,22 @@
-// rp_joints.h — impulse joints on the global solver path: locked linear axes
-// (spherical joints), rows rebuilt from the current poses every substep, solved before the contacts in
+// rp_joints.h — impulse joints on the global solver path: locked linear and angular axes
+// (spherical, revolute, prismatic-without-limits and fixed joints), rows rebuilt from the current poses every substep, solved before the contacts in
 // every pass, coloured in the contacts' colour space.
 //
 // Restates (one joint per thread instead of one 4-lane chunk):
 //   JointConstraintBuilder::update            solver/joint_constraint/joint_constraint_builder.rs:76-150
 //   JointConstraint::<Real,1>::update         solver/joint_constraint/joint_velocity_constraint.rs:144-353
-//   JointConstraintHelper::{new, lock_linear, finalize_constraints}
-//                                             solver/joint_constraint/joint_constraint_helper.rs:95-164, 411-458, 676-720
+//   JointConstraintHelper::{new, lock_linear, lock_angular, finalize_constraints}
+//                                             solver/joint_constraint/joint_constraint_helper.rs:95-164, 411-458, 628-673, 676-720
 //   JointConstraint::{solve_generic, warmstart_generic, remove_bias_from_rhs}   joint_velocity_constraint.rs:97-142
 // The reference's wide (SIMD) path uses nalgebra's quaternion->matrix / rotate formulas and its scalar
-// path glam's; like the oracle this file uses the scalar path's forms for every joint.
+// path glam's, and the two emit the lock rows in different orders (wide: linear then angular; scalar: angular then
+// linear, joint_velocity_constraint.rs:253-283 vs :438-468); like the oracle this file uses the scalar path's forms
+// and row order for every joint.
 #pragma once
 #include "rp_world.h"
 
 // row planes: JR[plane][joint]; row r uses planes 5*r .. 5*r+4
-enum { JR_LIN = 0, JR_A1, JR_A2, JR_I1, JR_I2, JR_ROW_PLANES = 5, JR_IM1 = 15, JR_IM2 = 16, JR_COUNT = 17 };
+enum { JR_LIN = 0, JR_A1, JR_A2, JR_I1, JR_I2, JR_ROW_PLANES = 5, JR_MAX_ROWS = 6, JR_IM1 = 30, JR_IM2 = 31, JR_COUNT = 32 };
 #define JRP(plane, j) w.JR[(size_t)(plane) * w.n_joints + (j)]
 
 struct JointRow { V3 lin_jac, ang_jac1, ang_jac2, ii1, ii2; float impulse, inv_lhs, rhs, rhs_wo_bias, cfm_gain; };
@@ -28,7 +30,13 @@ RP_DEV void jrow_store(const DevWorld &w, int j, int r, const JointRow &c) {
     JRP(5 * r + JR_LIN, j) = f4(c.lin_jac, c.impulse); JRP(5 * r + JR_A1, j) = f4(c.ang_jac1, c.inv_lhs);
     JRP(5 * r + JR_A2, j) = f4(c.ang_jac2, c.rhs); JRP(5 * r + JR_I1, j) = f4(c.ii1, c.rhs_wo_bias); JRP(5 * r + JR_I2, j) = f4(c.ii2, c.cfm_gain);
 }
-RP_DEV int joint_row_count(int locked) { return (locked & 1) + ((locked >> 1) & 1) + ((locked >> 2) & 1); }
+RP_DEV int joint_row_count(int locked) { return __popc((unsigned)locked & 0x3fu); }
+// WritebackId::Dof of row k: locked angular axes first (dof 3 + a), then locked linear axes (dof i)
+RP_DEV int joint_row_dof(int locked, int k) {
+    for (int a = 0; a < 3; ++a) if (locked & (8 << a)) { if (k == 0) return 3 + a; --k; }
+    for (int i = 0; i < 3; ++i) if (locked & (1 << i)) { if (k == 0) return i; --k; }
+    return 0;
+}
 
 // JointConstraintBuilder::update for joint j (rows rebuilt from the solver poses s_rot / s_trans).
 RP_DEV void joint_update_one(const DevWorld &w, int j, int substep_id) {
@@ -51,15 +59,56 @@ RP_DEV void joint_update_one(const DevWorld &w, int j, int substep_id) {
     V3 c1x = v3(0.0f, r1.z, -r1.y), c1y = v3(-r1.z, 0.0f, r1.x), c1z = v3(r1.y, -r1.x, 0.0f);
     V3 c2x = v3(0.0f, r2.z, -r2.y), c2y = v3(-r2.z, 0.0f, r2.x), c2z = v3(r2.y, -r2.x, 0.0f);
     const bool ws = w.prm.p.warmstart_joints != 0;
-    float prev[3] = {0, 0, 0}, seed[3] = {0, 0, 0};
+    float prev[6] = {0, 0, 0, 0, 0, 0}, seed[6] = {0, 0, 0, 0, 0, 0};
     int nrows = joint_row_count(locked);
     if (ws) {
         if (substep_id > 0) { for (int k = 0; k < nrows; ++k) prev[k] = JRP(5 * k + JR_LIN, j).w; }
-        else { float4 s = w.j_imp[j]; seed[0] = s.x; seed[1] = s.y; seed[2] = s.z; }
+        else { float4 s = w.j_imp[j], sa = w.j_imp_ang[j]; seed[0] = s.x; seed[1] = s.y; seed[2] = s.z; seed[3] = sa.x; seed[4] = sa.y; seed[5] = sa.z; }
     }
-    JointRow rows[3];
-    int dof[3] = {0, 0, 0};
+    JointRow rows[6];
+    int dof[6] = {0, 0, 0, 0, 0, 0};
     int len = 0;
+    if (locked & 0x38) {
+        // locked angular axes — JointConstraintHelper::new (:129-139): ang_basis = diff_conj1_2_tr(q1, q2) * sgn, ang_err =
+        // (q1^-1 q2) * sgn, sgn = copysign(1, q1 . q2); lock_angular (:628-673); RotationOps::diff_conj1_2 (utils/rotation_ops.rs:121-135)
+        Q4 q1 = frame1.r, q2 = frame2.r;
+        V3 v1 = v3(q1.x, q1.y, q1.z), v2 = v3(q2.x, q2.y, q2.z);
+        float w1 = q1.w, w2 = q2.w;
+        V3 u = v1 * w2 + v2 * w1;
+        V3 cu[3] = {v3(0.0f, u.z, -u.y), v3(-u.z, 0.0f, u.x), v3(u.y, -u.x, 0.0f)};
+        V3 ca[3] = {v3(0.0f, v1.z, -v1.y), v3(-v1.z, 0.0f, v1.x), v3(v1.y, -v1.x, 0.0f)};
+        V3 cb[3] = {v3(0.0f, v2.z, -v2.y), v3(-v2.z, 0.0f, v2.x), v3(v2.y, -v2.x, 0.0f)};
+        float d = w1 * w2;
+        V3 dg[3] = {v3(d, 0.0f, 0.0f), v3(0.0f, d, 0.0f), v3(0.0f, 0.0f, d)};
+        float v2c[3] = {v2.x, v2.y, v2.z};
+        V3 M[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            V3 kron = v1 * v2c[c];
+            V3 prod = ca[0] * cb[c].x + ca[1] * cb[c].y + ca[2] * cb[c].z;
+            M[c] = (((kron + dg[c]) - cu[c]) + prod) * 0.5f;
+        }
+        float sgn = copysignf(1.0f, qdot(q1, q2));
+        Q4 ang_err = qmul(qconj(q1), q2);
+        float ang_err_imag[3] = {ang_err.x * sgn, ang_err.y * sgn, ang_err.z * sgn};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            if (!(locked & (8 << a))) continue;
+            V3 ang_jac = a == 0 ? v3(M[0].x, M[1].x, M[2].x) : a == 1 ? v3(M[0].y, M[1].y, M[2].y) : v3(M[0].z, M[1].z, M[2].z);
+            ang_jac = ang_jac * sgn;
+            JointRow &c = rows[len];
+            c.impulse = 0.0f;
+            c.lin_jac = v3(0, 0, 0); c.ang_jac1 = ang_jac; c.ang_jac2 = ang_jac;
+            float rhs_wo_bias = 0.0f;
+            float rhs_bias = ang_err_imag[a] * w.prm.joint_erp_inv_dt;
+            c.ii1 = sym_mul(ii1, ang_jac);
+            c.ii2 = sym_mul(ii2, ang_jac);
+            c.inv_lhs = 0.0f; c.cfm_gain = 0.0f;
+            c.rhs = rhs_wo_bias + rhs_bias; c.rhs_wo_bias = rhs_wo_bias;
+            dof[len] = 3 + a;
+            len++;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         if (!(locked & (1 << i))) continue;
@@ -151,12 +200,13 @@ RP_DEV void joint_solve_one(const DevWorld &w, int j, bool wo_bias, bool warmsta
 // JointConstraint::writeback_impulses — joint_velocity_constraint.rs:346-353
 RP_DEV void joint_writeback_one(const DevWorld &w, int j) {
     int locked = w.j_locked[j];
-    float imp[3] = {0, 0, 0};
-    float4 old = w.j_imp[j];
-    imp[0] = old.x; imp[1] = old.y; imp[2] = old.z;
-    int k = 0;
-    for (int i = 0; i < 3; ++i) if (locked & (1 << i)) { imp[i] = JRP(5 * k + JR_LIN, j).w; k++; }
+    float imp[6] = {0, 0, 0, 0, 0, 0};
+    float4 old = w.j_imp[j], olda = w.j_imp_ang[j];
+    imp[0] = old.x; imp[1] = old.y; imp[2] = old.z; imp[3] = olda.x; imp[4] = olda.y; imp[5] = olda.z;
+    int nrows = joint_row_count(locked);
+    for (int k = 0; k < nrows; ++k) imp[joint_row_dof(locked, k)] = JRP(5 * k + JR_LIN, j).w;
     w.j_imp[j] = make_float4(imp[0], imp[1], imp[2], 0.0f);
+    w.j_imp_ang[j] = make_float4(imp[3], imp[4], imp[5], 0.0f);
 }
 
 // One sweep over the joints inside a single workgroup (SINGLE mode and the serial tail): parallel joint

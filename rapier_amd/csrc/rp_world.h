@@ -242,11 +242,11 @@ struct DevWorld {
     float4 *j_f1t, *j_f1r, *j_f2t, *j_f2r; // local frames in solver-body (CoM) space: translation, rotation
     int *j_locked, *j_color, *j_tmp, *j_order;
     int *j_stage_begin, *j_stage_count;    // parallel joint colour stages inside j_order
-    float4 *j_imp;              // per-dof impulses written back at the end of the step
+    float4 *j_imp, *j_imp_ang;  // per-dof impulses written back at the end of the step (linear dofs, angular dofs)
     unsigned int *bj_cmask;     // [4 * n_bodies] colours taken by joints (bodies_color workspace)
     unsigned long long *bj_min; // joint colouring scratch
     int *b_njoints;             // joints attached to a body (bodies with joints stay on the global path)
-    float4 *JR;                 // [JR_COUNT][n_joints] constraint rows (rp_joints.h)
+    float4 *JR;                 // [JR_COUNT][n_joints] constraint rows, up to 6 per joint (rp_joints.h)
 
     // ---- constraints ----
     float4 *C;                  // [CP_COUNT][cons_cap]

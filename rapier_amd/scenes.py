@@ -57,8 +57,10 @@ PARAMS_DTYPE = np.dtype([
 
 FRICTION_SIMPLIFIED, FRICTION_COULOMB = 0, 1  # FrictionModel, integration_parameters.rs:13-32
 
-LOCK_LIN = 0b000111
-LOCK_ALL = 0b111111
+LOCK_LIN = 0b000111       # JointAxesMask::LIN_AXES (spherical joint)
+LOCK_ALL = 0b111111       # LOCKED_FIXED_AXES (fixed joint)
+LOCK_REVOLUTE = 0b110111  # LOCKED_REVOLUTE_AXES: everything but the rotation about the frame's X axis
+LOCK_PRISMATIC = 0b111110  # LOCKED_PRISMATIC_AXES: everything but the translation along the frame's X axis
 
 
 def default_params() -> np.ndarray:
@@ -155,12 +157,13 @@ class Scene:
         self.collider_parents.append(parent)
         return len(self.colliders) - 1
 
-    def add_joint(self, body1, body2, anchor1, anchor2, locked_axes=LOCK_LIN, contacts_enabled=1) -> int:
+    def add_joint(self, body1, body2, anchor1, anchor2, locked_axes=LOCK_LIN, contacts_enabled=1,
+                  basis1=(0, 0, 0, 1), basis2=(0, 0, 0, 1)) -> int:
         j = np.zeros((), dtype=JOINT_DTYPE)
         j["body1"], j["body2"] = body1, body2
         j["local_anchor1"], j["local_anchor2"] = anchor1, anchor2
-        j["local_basis1"] = (0, 0, 0, 1)
-        j["local_basis2"] = (0, 0, 0, 1)
+        j["local_basis1"] = basis1
+        j["local_basis2"] = basis2
         j["locked_axes"], j["contacts_enabled"] = locked_axes, contacts_enabled
         self.joints.append(j)
         return len(self.joints) - 1
@@ -381,4 +384,38 @@ def kinematic_platform(position_based: bool = False, boxes: int = 3) -> Scene:
         s.add_collider(b, half_extents=(0.5, 0.5, 0.5))
     f = s.add_body(translation=(5.0, 0.5, 0.0))
     s.add_collider(f, half_extents=(0.5, 0.5, 0.5))
+    return s
+
+
+# local joint frame whose X axis is the body's Z axis (RevoluteJointBuilder::new(Vector::Z)): rotation by -90 deg about Y
+AXIS_Z_BASIS = (0.0, -0.70710678, 0.0, 0.70710678)
+
+
+def jointed_pairs(n: int = 1) -> Scene:
+    """The jointed pair of test_staged.rs:86-148 (a revolute joint about Z between two elevated cubes, next to the
+    3-cube stack), ``n`` times; plus a door on a revolute hinge about Y on a fixed post and a cube welded to another
+    by a fixed joint (all six axes locked).  Exercises locked angular axes (JointConstraintHelper::lock_angular)."""
+    s = Scene(name=f"jointed_pairs_{n}", gravity=(0.0, -9.81, 0.0))
+    g = s.add_body(body_type=BODY_FIXED, translation=(0.0, -0.5, 0.0))
+    s.add_collider(g, half_extents=(30.0, 0.5, 30.0))
+    for i in range(3):
+        b = s.add_body(translation=(0.0, 0.5 + i * 1.0, 0.0))
+        s.add_collider(b, half_extents=(0.5, 0.5, 0.5))
+    for k in range(n):
+        a = s.add_body(translation=(5.0 + 4.0 * k, 3.0, 0.0))
+        s.add_collider(a, half_extents=(0.5, 0.5, 0.5))
+        b = s.add_body(translation=(6.5 + 4.0 * k, 3.0, 0.0), linvel=(0.0, 0.0, 0.3 * (k % 3)))
+        s.add_collider(b, half_extents=(0.5, 0.5, 0.5))
+        s.add_joint(a, b, (0.75, 0.0, 0.0), (-0.75, 0.0, 0.0), locked_axes=LOCK_REVOLUTE, basis1=AXIS_Z_BASIS, basis2=AXIS_Z_BASIS)
+    post = s.add_body(body_type=BODY_FIXED, translation=(-5.0, 1.5, 0.0))
+    s.add_collider(post, half_extents=(0.1, 1.5, 0.1))
+    door = s.add_body(translation=(-4.0, 1.5, 0.0), angvel=(0.0, 1.5, 0.0), linvel=(0.0, 0.0, -1.5))
+    s.add_collider(door, half_extents=(0.8, 1.0, 0.05), density=2.0)
+    axis_y = (0.0, 0.0, 0.70710678, 0.70710678)   # frame X axis = body Y axis
+    s.add_joint(post, door, (0.0, 0.0, 0.0), (-1.0, 0.0, 0.0), locked_axes=LOCK_REVOLUTE, basis1=axis_y, basis2=axis_y)
+    w1 = s.add_body(translation=(-10.0, 4.0, 0.0), angvel=(0.5, 0.2, 0.0))
+    s.add_collider(w1, half_extents=(0.5, 0.5, 0.5))
+    w2 = s.add_body(translation=(-8.8, 4.0, 0.0))
+    s.add_collider(w2, half_extents=(0.5, 0.5, 0.5), density=3.0)
+    s.add_joint(w1, w2, (0.6, 0.0, 0.0), (-0.6, 0.0, 0.0), locked_axes=LOCK_ALL)
     return s

@@ -422,6 +422,22 @@ def test_sleep_full_size_many_pyramids():
     assert c["num_sleeping_bodies"] == 10780 and c["num_manifolds"] == 0
 
 
+def test_revolute_and_fixed_joints_bit_exact():
+    """Locked angular axes (JointConstraintHelper::lock_angular): the jointed pair of test_staged.rs:86-148, a door on a
+    hinge, two welded cubes; then 80 pairs so the joints fill a parallel colour (>= 64 joints)."""
+    for n in (1, 80):
+        g, o = _compare(S.jointed_pairs(n), [1, 2, 10, 60, 200])
+        gc, gi = g.read_joints()
+        oc, oi = o.read_joints()
+        np.testing.assert_array_equal(gc, oc)
+        np.testing.assert_array_equal(gi, oi)
+    pos, vel = g.read_bodies()
+    nb = len(pos)
+    door, w1, w2 = nb - 3, nb - 2, nb - 1
+    assert pos[door, 1] == pytest.approx(1.5, abs=1e-3) and abs(vel[door, 3]) < 1e-3 and abs(vel[door, 5]) < 1e-3   # the hinge only lets it turn about Y
+    assert np.linalg.norm(pos[w2, :3] - pos[w1, :3]) == pytest.approx(1.2, abs=2e-3)                       # the weld holds
+
+
 # ---- FrictionModel::Coulomb (SURVEY §8a SV1 twin): rp_coulomb.h on the global path vs the oracle ----
 def _coulomb(scene):
     scene.params["friction_model"] = S.FRICTION_COULOMB
@@ -552,8 +568,7 @@ def test_collision_and_contact_force_events_bit_exact():
 
 
 def test_out_of_scope_inputs_are_refused():
-    """Angular joint locks, contact-disabled joints, compound bodies and joints on can_sleep bodies are refused
-    loudly, not mis-simulated."""
+    """Contact-disabled joints, compound bodies and joints on can_sleep bodies are refused loudly, not mis-simulated."""
     sj = S.joint_chain(4).enable_sleep()
     with pytest.raises(Exception):
         PhysicsWorld.from_scene(sj).step(1)
@@ -568,10 +583,9 @@ def test_out_of_scope_inputs_are_refused():
         w.insert_collider(S.collider_desc(translation=(0.1, 0.0, 0.0)), b2)  # offset collider
     sc = S.Scene(name="tmp")
     sc.add_body(); sc.add_body()
-    j = sc.joint_array() if sc.joints else None
-    sc.add_joint(0, 1, (0, 0, 0), (0, 0, 0), locked_axes=0x3F)
+    sc.add_joint(0, 1, (0, 0, 0), (0, 0, 0), locked_axes=0x7F)
     with pytest.raises(RapierHipError):
-        w.insert_impulse_joints(sc.joint_array())  # fixed joint: angular locks
+        w.insert_impulse_joints(sc.joint_array())  # not a JointAxesMask of locked axes
     sc.joints.clear()
     sc.add_joint(0, 1, (0, 0, 0), (0, 0, 0), contacts_enabled=0)
     with pytest.raises(RapierHipError):

@@ -228,6 +228,26 @@ def test_coulomb_pyramid_rests_and_carries_its_weight():
     assert imp[ground].sum() == pytest.approx(weight, rel=0.01)
 
 
+# test_staged.rs:86-148 scene: the 3-cube stack AND the elevated pair joined by a revolute joint about Z rest after 60
+# steps; a hinge keeps its axis, a fixed joint keeps the relative pose (lock_angular, joint_constraint_helper.rs:628-673).
+def test_staged_scene_with_revolute_pair_and_locked_angular_axes():
+    sc = S.jointed_pairs(1)
+    w = OracleWorld(sc)
+    w.step(60)
+    pos, vel = w.read()
+    np.testing.assert_allclose(pos[1:4, 1], [0.5, 1.5, 2.5], atol=0.05)        # the stack rests (same bar as the reference test)
+    a, b = 4, 5
+    assert np.linalg.norm(pos[b, :3] - pos[a, :3]) == pytest.approx(1.5, abs=2e-3)   # revolute anchors coincide
+    assert abs(pos[a, 2]) < 0.01 and abs(pos[b, 2]) < 0.01                     # the pair stays in its plane
+    w.step(140)
+    pos, vel = w.read()
+    door, w1, w2 = 7, 8, 9
+    assert pos[door, 1] == pytest.approx(1.5, abs=1e-3) and abs(vel[door, 3]) < 1e-3 and abs(vel[door, 5]) < 1e-3
+    assert np.linalg.norm(pos[door, :3] - np.array([-5.0, 1.5, 0.0])) == pytest.approx(1.0, abs=2e-3)
+    assert np.linalg.norm(pos[w2, :3] - pos[w1, :3]) == pytest.approx(1.2, abs=2e-3)
+    np.testing.assert_allclose(pos[w1, 3:], pos[w2, 3:], atol=2e-3)            # welded: same orientation
+
+
 # Events (pipeline/event_handler.rs:94-160): Started / Stopped on touching transitions, contact force events above the
 # threshold with `started` on the first step above it (geometry/mod.rs:223-258).
 def test_collision_and_contact_force_events():
