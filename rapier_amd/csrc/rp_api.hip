@@ -41,6 +41,7 @@ void rp_launch_fast_front(const DevWorld &w, hipStream_t st, int no_global_kerne
 void rp_launch_wake(const DevWorld &w, hipStream_t st, int phase);
 void rp_launch_wake_partners(const DevWorld &w, hipStream_t st);
 void rp_launch_force_events(const DevWorld &w, hipStream_t st);
+void rp_launch_idle_step(const DevWorld &w, hipStream_t st);
 
 struct HostBody {
     rp_body_desc d; float inv_mass; float inv_pi[3]; float lcom[3]; int ncolliders; bool removed;
@@ -109,6 +110,7 @@ static bool world_has_kinematic_pos(const rp_world *w);
 static bool world_has_force_events(const rp_world *w);
 static int check_sleep_scope(rp_world *w);
 static int rebuild_begin(rp_world *w);
+static int queue_wake(rp_world *w, int b, int lvl);
 static int finalize(rp_world *w);
 
 extern "C" void rp_default_params(rp_integration_params *p) {
@@ -903,6 +905,16 @@ static int step_once(rp_world *w, bool allow_fast) {
         fast = false;
         w->full_until = w->steps_requested + 3;
     }
+    // idle steps: the whole world sleeps (FL_N_AWAKE == 0 as of the last retired step) and nothing is pending; the
+    // device re-checks and aborts otherwise (k_idle_step), the host then replays through the full graph
+    if (!fast && allow_fast && w->use_fast && w->dw.sleep_enabled && !w->timers && w->steps_requested >= w->full_until) {
+        if (pf[FL_N_AWAKE] == 0 && !pf[FL_FAST_ABORT] && !pf[FL_WAKE_PENDING] && !pf[FL_LAYOUT_DIRTY] && !pf[FL_BP_DIRTY]) {
+            w->cur_fast = 1; w->seq_enqueued++; w->fast_steps++;
+            rp_launch_idle_step(w->dw, w->stream);
+            HIPCHK(w, hipGetLastError());
+            return RP_OK;
+        } else if (pf[FL_FAST_ABORT]) w->full_until = w->steps_requested + 3;
+    }
     return launch_step(w, fast ? 1 : 0);
 }
 
@@ -993,7 +1005,7 @@ extern "C" int32_t rp_bodies_write(rp_world *w, int32_t n, const uint64_t *handl
         // body also wakes every body it has a pair with (pair_management.rs:236-258)
         for (int i = 0; i < n; ++i) {
             int b = (int)(handles[i] & 0xffffffffull), lvl = pos7 ? 3 : 2;
-            HIPCHK(w, hipMemcpy(w->dw.b_wake_req + b, &lvl, sizeof(int), hipMemcpyHostToDevice));
+            { int r = queue_wake(w, b, lvl); if (r != RP_OK) return r; }
         }
         if (pos7) rp_launch_wake_partners(w->dw, w->stream);
     }
@@ -1004,6 +1016,14 @@ extern "C" int32_t rp_bodies_write(rp_world *w, int32_t n, const uint64_t *handl
     return RP_OK;
 }
 
+// Queue a wake-up request for body b (consumed by the next full step, rp_sleep.hip) and stop enqueuing idle steps.
+static int queue_wake(rp_world *w, int b, int lvl) {
+    HIPCHK(w, hipMemcpy(w->dw.b_wake_req + b, &lvl, sizeof(int), hipMemcpyHostToDevice));
+    int one = 1;
+    HIPCHK(w, hipMemcpy(w->dw.flags + FL_WAKE_PENDING, &one, sizeof(int), hipMemcpyHostToDevice));
+    w->pinned_flags[FL_WAKE_PENDING] = 1;
+    return RP_OK;
+}
 // IslandManager::wake_up (island_manager/sleep.rs:31): takes effect at the start of the next step and wakes the
 // body's whole island.
 extern "C" int32_t rp_bodies_wake_up(rp_world *w, int32_t n, const uint64_t *handles, int32_t strong) {
@@ -1014,8 +1034,7 @@ extern "C" int32_t rp_bodies_wake_up(rp_world *w, int32_t n, const uint64_t *han
     for (int i = 0; i < n; ++i) {
         int b = (int)(handles[i] & 0xffffffffull);
         if ((handles[i] >> 32) != 0 || b >= w->dw.n_bodies || w->bodies[b].removed) { w->err = "rp_bodies_wake_up: invalid handle"; return RP_ERR_INVALID; }
-        int lvl = strong ? 2 : 1;
-        HIPCHK(w, hipMemcpy(w->dw.b_wake_req + b, &lvl, sizeof(int), hipMemcpyHostToDevice));
+        { int r = queue_wake(w, b, strong ? 2 : 1); if (r != RP_OK) return r; }
     }
     return RP_OK;
 }
@@ -1037,7 +1056,7 @@ extern "C" int32_t rp_bodies_set_next_kinematic_position(rp_world *w, int32_t n,
         HIPCHK(w, hipMemcpy(w->dw.b_next_pos + b, &t, sizeof(t), hipMemcpyHostToDevice));
         HIPCHK(w, hipMemcpy(w->dw.b_next_rot + b, &q, sizeof(q), hipMemcpyHostToDevice));
         bool differs = ct.x != t.x || ct.y != t.y || ct.z != t.z || cq.x != q.x || cq.y != q.y || cq.z != q.z || cq.w != q.w;
-        if (differs) { int lvl = 2; HIPCHK(w, hipMemcpy(w->dw.b_wake_req + b, &lvl, sizeof(int), hipMemcpyHostToDevice)); } // wake_up(true)
+        if (differs) { int r = queue_wake(w, b, 2); if (r != RP_OK) return r; } // wake_up(true)
     }
     return RP_OK;
 }

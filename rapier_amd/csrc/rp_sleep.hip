@@ -39,6 +39,7 @@ RP_DEV void slp_union(int *label, int a, int b) { // the smaller index becomes t
 // (RigidBodyActivation::wake_up(strong)).
 __global__ void k_wake_spread(DevWorld w, int phase) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && phase == 0) { w.flags[FL_N_AWAKE] = 0; w.flags[FL_WAKE_PENDING] = 0; } // recounted by k_sleep_commit; requests consumed below
     if (i >= w.n_bodies) return;
     int r = w.b_wake_req[i];
     if (!r) return;
@@ -139,10 +140,13 @@ __global__ void k_sleep_observe(DevWorld w) {
 // commit_sleeping_chunks -> RigidBody::sleep (rigid_body.rs:804-807) + clear_asleep_pair_solver_hint_counts_of
 __global__ void k_sleep_commit(DevWorld w) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= w.n_bodies) return;
-    int fl = w.b_flags[i];
-    if (!flags_active(fl)) return;
-    if (w.lab_awake[w.b_slabel[i]] == cur_step(w)) return;
+    int fl = i < w.n_bodies ? w.b_flags[i] : RP_BODY_FIXED;
+    bool active = flags_active(fl);
+    bool stays_awake = active && w.lab_awake[w.b_slabel[i]] == cur_step(w);
+    // awake bodies left after this pass, one atomic per wavefront (0 = the whole world sleeps: the host may enqueue idle steps)
+    unsigned long long awake_mask = __ballot(stays_awake);
+    if ((threadIdx.x & 63) == 0 && awake_mask) atomicAdd(&w.flags[FL_N_AWAKE], __popcll(awake_mask));
+    if (!active || stays_awake) return;
     w.b_flags[i] = fl | RP_BF_SLEEPING;
     float4 sl = w.b_sleep[i]; sl.x = sl.w; w.b_sleep[i] = sl;
     w.b_linvel[i] = make_float4(0, 0, 0, 0); w.b_angvel[i] = make_float4(0, 0, 0, 0);
@@ -165,6 +169,27 @@ __global__ void k_kinematic_velocities(DevWorld w) {
     w.b_linvel[i] = f4(dpos.t * inv_dt, 0.0f);
     w.b_angvel[i] = f4(quat_to_scaled_axis(dpos.r) * inv_dt, 0.0f);
 }
+
+// Idle step: while every non-fixed body sleeps and nothing is pending, PhysicsPipeline::step changes nothing but the
+// step count (no awake body => no pair is processed, no timer runs, no island can wake).  One tiny kernel verifies
+// that on the device and retires the step; otherwise it raises FL_FAST_ABORT and the host replays the step through
+// the full graph (same protocol as the steady-state fast path, rp_api.hip).
+__global__ void k_idle_step(DevWorld w) {
+    if (threadIdx.x == 0) {
+        bool idle = !w.flags[FL_FAST_ABORT] && w.flags[FL_N_AWAKE] == 0 && !w.flags[FL_WAKE_PENDING] && !w.flags[FL_BP_DIRTY] &&
+                    !w.flags[FL_LAYOUT_DIRTY];
+        if (idle) w.flags[FL_STEP] += 1; else w.flags[FL_FAST_ABORT] = 1;
+        w.flags[FL_SEQ] += 1;
+        w.flags[FL_FULL_UPDATES] = 0;
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x < FL_COUNT) {
+        int v = __hip_atomic_load(&w.flags[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&w.host_flags[threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+void rp_launch_idle_step(const DevWorld &w, hipStream_t st) { hipLaunchKernelGGL(k_idle_step, dim3(1), dim3(64), 0, st, w); }
 
 static int slp_body_blocks(const DevWorld &w) { int nb = (w.n_bodies + 255) / 256; return nb < 1 ? 1 : nb; }
 static int slp_pair_blocks(const DevWorld &w) { int b = (w.pool_cap + 255) / 256; if (b > 2048) b = 2048; return b < 1 ? 1 : b; }

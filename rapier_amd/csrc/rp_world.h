@@ -76,6 +76,8 @@ enum {
     FL_TICKET,          // last-workgroup-done ticket (one user at a time: kernels of a step are serialised)
     FL_FAST_ABORT,      // steady-state fast path found work it cannot do (see rp_api.hip); sticky until a full step
     FL_EV_COL, FL_EV_FORCE, // events appended to the collision / contact-force queues (may exceed the queue capacity)
+    FL_N_AWAKE,         // awake non-fixed bodies after the last sleep pass (0 = the whole world sleeps: idle steps, rp_sleep.hip)
+    FL_WAKE_PENDING,    // the host queued wake-up requests (b_wake_req) that no step has consumed yet
     FL_WAKE_STAMP,      // 2 * step + phase of the last wake pass that found a sleeping island to wake (rp_sleep.hip)
     FL_COUNT = 48
 };

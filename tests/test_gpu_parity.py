@@ -384,6 +384,14 @@ def test_sleep_many_islands_bit_exact():
     g, o = _compare(sc, [10, 30, 35, 40, 60])
     np.testing.assert_array_equal(g.sleeping(), o.sleeping())
     assert g.sleeping()[1:].all() and g.counters()["num_sleeping_bodies"] == 220
+    before = g.counters()["fast_steps"]
+    g.step(200); o.step(200)                                  # a fully sleeping world retires idle steps (one tiny kernel each)
+    _same_sleep_state(g, o, "sleeping world, 200 idle steps")
+    assert g.counters()["fast_steps"] - before >= 150
+    g.wake_up([7]); o.wake_up(7)                              # ... until something wakes up
+    g.step(3); o.step(3)
+    _same_sleep_state(g, o, "sleeping world woken")
+    assert g.sleeping().sum() == 220 - 55
     sc2 = S.tumble(40, seed=11).enable_sleep()
     g2, o2 = PhysicsWorld.from_scene(sc2), OracleWorld(sc2)
     for cp in range(50, 601, 50):
