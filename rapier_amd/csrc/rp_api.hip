@@ -632,7 +632,7 @@ static int finalize(rp_world *w) {
     DA(d.pt_lp1d, RP_MAX_PTS * P); DA(d.pt_lp2f, RP_MAX_PTS * P); DA(d.pt_imp, RP_MAX_PTS * P); DA(d.pt_wst, RP_MAX_PTS * P);
     DA(d.pt_dp1, RP_MAX_PTS * P); DA(d.pt_dp2, RP_MAX_PTS * P);
     DA(d.sc_a1, 4 * P); DA(d.sc_a2, 4 * P);
-    DA(d.todo_slot, P); DA(d.todo_key, P); DA(d.todo_tmp, P);
+    DA(d.todo_slot, P); DA(d.todo_key, P); DA(d.todo_tmp, P); DA(d.np_list, P);
     DA(d.color_count, RP_NUM_COLORS + 1); DA(d.color_begin, RP_NUM_COLORS + 1); DA(d.color_cursor, RP_NUM_COLORS + 1);
     DA(d.stage_color, RP_NUM_COLORS + 1); DA(d.stage_begin, RP_NUM_COLORS + 1); DA(d.stage_count, RP_NUM_COLORS + 1);
     DA(d.cons_pair, d.cons_cap); DAF(d.p_conspos, P, 0xff);

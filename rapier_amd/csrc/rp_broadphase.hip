@@ -37,8 +37,8 @@ __device__ __forceinline__ CellRange cell_range(const DevWorld &w, int i) {
 
 __global__ void k_collider_update(DevWorld w) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) { // a full step is starting: the fast path may be tried again later; per-step narrow-phase counters (k_np_begin)
-        w.flags[FL_FAST_ABORT] = 0; w.flags[FL_FULL_UPDATES] = 0; w.flags[FL_TODO_COUNT] = 0;
+    if (i == 0) { // a full step is starting: the fast path may be tried again later; per-step narrow-phase counters
+        w.flags[FL_FAST_ABORT] = 0; w.flags[FL_FULL_UPDATES] = 0; w.flags[FL_TODO_COUNT] = 0; w.flags[FL_NP_COUNT] = 0;
     }
     if (i >= w.n_colliders) return;
     collider_update_one(w, i);

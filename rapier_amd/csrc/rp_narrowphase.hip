@@ -462,12 +462,12 @@ __device__ __noinline__ void pair_full_update(DevWorld &w, int s, int c1, int c2
     }
 }
 
-__global__ void k_np_begin(DevWorld w) {
-    w.flags[FL_FULL_UPDATES] = 0;
-    w.flags[FL_TODO_COUNT] = 0;
-}
-
-__global__ void k_np_pairs(DevWorld w) {
+// The narrow phase runs as two kernels: k_np_test (one thread per pair slot, a few dozen flops: who is awake, the
+// contact-recycling test of pair_update.rs:111-171) queues the pairs that need contact determination, k_np_update runs
+// the full update (parry manifolds, reduction, solver contacts: ~2.7 KB of scratch per lane) over that queue only.  On a
+// settled scene the queue is empty and the heavy kernel exits at once instead of taxing every pair with its launch
+// footprint (29 us -> a few us per step on b3d_many_pyramids).
+__global__ void k_np_test(DevWorld w) {
     int top = w.flags[FL_POOL_TOP];
     if (top > w.pool_cap) top = w.pool_cap;
     int stride = gridDim.x * blockDim.x;
@@ -489,6 +489,20 @@ __global__ void k_np_pairs(DevWorld w) {
                 continue;
             }
         } else if (pair_recycle_ok(w, s, pc1, pc2, pos12)) continue;
+        w.np_list[atomicAdd(&w.flags[FL_NP_COUNT], 1)] = s;
+    }
+}
+__global__ void k_np_update(DevWorld w) {
+    int count = w.flags[FL_NP_COUNT];
+    if (count > w.pool_cap) count = w.pool_cap;
+    int stride = gridDim.x * blockDim.x;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        int s = w.np_list[i];
+        int c1 = w.p_c1[s], c2 = w.p_c2[s];
+        Pose pc1, pc2;
+        pc1.r = q4(w.c_rot[c1]); pc1.t = v3(w.c_pos[c1]);
+        pc2.r = q4(w.c_rot[c2]); pc2.t = v3(w.c_pos[c2]);
+        Pose pos12 = pose_inv_mul(pc1, pc2);
         pair_full_update(w, s, c1, c2, pc1, pc2, pos12);
     }
 }
@@ -669,7 +683,10 @@ __global__ void k_bucket_finish(DevWorld w) { w.flags[FL_LAYOUT_DIRTY] = 0; }
 void rp_launch_narrowphase(const DevWorld &w, hipStream_t st) {
     if (w.n_colliders == 0) { rp_launch_wake(w, st, 1); rp_launch_sleep(w, st); return; } // collider-less bodies still keep sleep timers
     int blocks = (w.pool_cap + 255) / 256; if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_np_pairs, dim3(blocks), dim3(256), 0, st, w);
+    hipLaunchKernelGGL(k_np_test, dim3(blocks), dim3(256), 0, st, w);
+    // at most one workgroup per CU: with 128 VGPRs and 2.7 KB of scratch per lane a second round of workgroups costs ~10 us
+    // even when the queue is empty (measured: 341 -> 256 workgroups = 140 -> 130 us per full step on b3d_many_pyramids)
+    hipLaunchKernelGGL(k_np_update, dim3(blocks < 256 ? blocks : 256), dim3(256), 0, st, w);
     hipLaunchKernelGGL(k_color_pairs, dim3(1), dim3(1024), 0, st, w);
     rp_launch_wake(w, st, 1); // begin-touch wake-ups (contacts.rs:333-351)
     rp_launch_sleep(w, st);   // sleep timers + the whole-island sleep decision (solve.rs:196-300, manager.rs:335-388)

@@ -78,6 +78,7 @@ enum {
     FL_EV_COL, FL_EV_FORCE, // events appended to the collision / contact-force queues (may exceed the queue capacity)
     FL_N_AWAKE,         // awake non-fixed bodies after the last sleep pass (0 = the whole world sleeps: idle steps, rp_sleep.hip)
     FL_WAKE_PENDING,    // the host queued wake-up requests (b_wake_req) that no step has consumed yet
+    FL_NP_COUNT,        // pairs queued for a full narrow-phase update this step (np_list)
     FL_WAKE_STAMP,      // 2 * step + phase of the last wake pass that found a sleeping island to wake (rp_sleep.hip)
     FL_COUNT = 48
 };
@@ -220,6 +221,7 @@ struct DevWorld {
 
     // ---- colouring / buckets ----
     int *todo_slot; unsigned long long *todo_key; int *todo_tmp;
+    int *np_list;               // [pool] pair slots that failed the recycle test this step (k_np_test -> k_np_update)
     int *color_count, *color_begin, *color_cursor, *stage_color, *stage_begin, *stage_count;
     int *cons_pair;             // [cons_cap] position -> pair slot
     int *p_conspos;             // pair slot -> position (or -1)
