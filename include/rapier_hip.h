@@ -166,9 +166,9 @@ int32_t rp_params_set(rp_world *w, const rp_integration_params *in);
 
 /* RigidBodySet::insert ×n; handles = generation<<32 | index (arena.rs:58-90). */
 int32_t rp_bodies_insert(rp_world *w, int32_t n, const rp_body_desc *descs, uint64_t *handles_out);
-/* ColliderSet::insert_with_parent ×n (parent RP_INVALID_HANDLE = ColliderSet::insert).  Device path scope:
- * cuboid / ball shapes, one collider per body attached at the body origin (compound bodies are
- * refused with RP_ERR_INVALID). */
+/* ColliderSet::insert_with_parent ×n (parent RP_INVALID_HANDLE = ColliderSet::insert).  Device path scope: cuboid / ball
+ * shapes.  A body may carry any number of colliders at any pos_wrt_parent (compound bodies): its mass, centre of mass and
+ * principal inertia are the sum of the colliders' MassProperties (rigid_body_components.rs:421-489). */
 int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider_desc *descs, const uint64_t *parents, uint64_t *handles_out);
 /* ImpulseJointSet::insert ×n (impulse_joint_set.rs).  Device path scope: locked axes only — any JointAxesMask of locked
  * linear / angular axes (spherical 0x07, revolute 0x37, prismatic without limits 0x3e, fixed 0x3f; the free axis is the

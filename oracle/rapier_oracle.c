@@ -79,6 +79,7 @@ typedef struct {
     float density, friction, restitution; int friction_rule, restitution_rule;
     uint32_t memberships, filter;
     uint32_t active_events; float force_threshold;
+    int ord;            /* ordinal among the colliders attached to the same parent (attachment order) */
     Aabb fat; int has_fat;
 } Collider;
 
@@ -171,6 +172,7 @@ struct ro_world {
     ro_stats stats;
     int step_seq;       /* 1-based number of the step in progress */
     int *uf;            /* union-find scratch of the sleep islands */
+    int nfree_colliders; /* colliders inserted without a parent */
     int32_t *col_events; int ncol_events, cap_col_events;       /* 5 ints per event */
     int32_t *force_meta; float *force_vals; int nforce_events, cap_force_events;
 };
@@ -294,33 +296,166 @@ static void shape_mass_props(const Collider *c, float density, float *mass, v3 *
     }
 }
 
-/* RigidBodyMassProps::recompute_mass_properties_from_colliders — rigid_body_components.rs:421-489.
- * Scope: one collider per body attached at the body origin (all benchmark scenes). */
+/* ---- parry MassProperties algebra (not in /root/reference; restated from its public definition) ----------------
+ * A MassProperties value = (mass, local_com, principal inertia, principal frame).  `transform_by(pos)` moves the
+ * centre and rotates the frame; `a + b` = total mass, mass-weighted centre, sum of the two inertia tensors shifted
+ * to the common centre (parallel-axis theorem), re-diagonalised.  parry diagonalises with nalgebra's
+ * symmetric_eigen (Householder + QR); a cyclic Jacobi iteration is used here instead — same eigen-system, rounding
+ * differs (unpinned like every other parry quantity).  Arithmetic is plain f32, no contraction. */
+typedef struct { float mass; float com[3]; float pi[3]; float frame[4]; } ro_mp;   /* frame: quaternion x,y,z,w */
+
+static void ro_quat_to_rot(const float q[4], float r[3][3]) {
+    float x2 = q[0] + q[0], y2 = q[1] + q[1], z2 = q[2] + q[2];
+    float xx = q[0] * x2, xy = q[0] * y2, xz = q[0] * z2;
+    float yy = q[1] * y2, yz = q[1] * z2, zz = q[2] * z2;
+    float wx = q[3] * x2, wy = q[3] * y2, wz = q[3] * z2;
+    r[0][0] = 1.0f - (yy + zz); r[0][1] = xy - wz; r[0][2] = xz + wy;
+    r[1][0] = xy + wz; r[1][1] = 1.0f - (xx + zz); r[1][2] = yz - wx;
+    r[2][0] = xz - wy; r[2][1] = yz + wx; r[2][2] = 1.0f - (xx + yy);
+}
+/* reconstruct_inertia_matrix: R diag(pi) R^T */
+static void ro_inertia_matrix(const ro_mp *m, float out[3][3]) {
+    float r[3][3]; ro_quat_to_rot(m->frame, r);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            out[i][j] = r[i][0] * m->pi[0] * r[j][0] + r[i][1] * m->pi[1] * r[j][1] + r[i][2] * m->pi[2] * r[j][2];
+}
+/* construct_shifted_inertia_matrix: I + (|s|^2 Id - s s^T) * mass */
+static void ro_shifted_inertia(const ro_mp *m, const float s[3], float out[3][3]) {
+    ro_inertia_matrix(m, out);
+    float d = s[0] * s[0] + s[1] * s[1] + s[2] * s[2];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            out[i][j] = out[i][j] + ((i == j ? d : 0.0f) - s[i] * s[j]) * m->mass;
+}
+/* rotation matrix (columns = axes) -> unit quaternion (Shepperd's method) */
+static void ro_rot_to_quat(float v[3][3], float q[4]) {
+    float tr = v[0][0] + v[1][1] + v[2][2];
+    if (tr > 0.0f) {
+        float s = sqrtf(tr + 1.0f) * 2.0f;
+        q[3] = 0.25f * s; q[0] = (v[2][1] - v[1][2]) / s; q[1] = (v[0][2] - v[2][0]) / s; q[2] = (v[1][0] - v[0][1]) / s;
+    } else if (v[0][0] > v[1][1] && v[0][0] > v[2][2]) {
+        float s = sqrtf(1.0f + v[0][0] - v[1][1] - v[2][2]) * 2.0f;
+        q[3] = (v[2][1] - v[1][2]) / s; q[0] = 0.25f * s; q[1] = (v[0][1] + v[1][0]) / s; q[2] = (v[0][2] + v[2][0]) / s;
+    } else if (v[1][1] > v[2][2]) {
+        float s = sqrtf(1.0f + v[1][1] - v[0][0] - v[2][2]) * 2.0f;
+        q[3] = (v[0][2] - v[2][0]) / s; q[0] = (v[0][1] + v[1][0]) / s; q[1] = 0.25f * s; q[2] = (v[1][2] + v[2][1]) / s;
+    } else {
+        float s = sqrtf(1.0f + v[2][2] - v[0][0] - v[1][1]) * 2.0f;
+        q[3] = (v[1][0] - v[0][1]) / s; q[0] = (v[0][2] + v[2][0]) / s; q[1] = (v[1][2] + v[2][1]) / s; q[2] = 0.25f * s;
+    }
+    float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    float inv = 1.0f / n;
+    q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
+}
+/* with_inertia_matrix: principal inertia + frame of a symmetric 3x3 tensor (cyclic Jacobi, 12 sweeps) */
+static void ro_diagonalise(float a[3][3], float pi[3], float frame[4]) {
+    float v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        float off = fabsf(a[0][1]) + fabsf(a[0][2]) + fabsf(a[1][2]);
+        if (off == 0.0f) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (a[p][q] == 0.0f) continue;
+                float theta = (a[q][q] - a[p][p]) / (2.0f * a[p][q]);
+                float t = (theta >= 0.0f ? 1.0f : -1.0f) / (fabsf(theta) + sqrtf(theta * theta + 1.0f));
+                float c = 1.0f / sqrtf(t * t + 1.0f), s = t * c;
+                for (int k = 0; k < 3; ++k) { float akp = a[k][p], akq = a[k][q]; a[k][p] = c * akp - s * akq; a[k][q] = s * akp + c * akq; }
+                for (int k = 0; k < 3; ++k) { float apk = a[p][k], aqk = a[q][k]; a[p][k] = c * apk - s * aqk; a[q][k] = s * apk + c * aqk; }
+                for (int k = 0; k < 3; ++k) { float vkp = v[k][p], vkq = v[k][q]; v[k][p] = c * vkp - s * vkq; v[k][q] = s * vkp + c * vkq; }
+            }
+    }
+    /* a proper rotation: flip the last axis when the determinant is negative */
+    float det = v[0][0] * (v[1][1] * v[2][2] - v[1][2] * v[2][1]) - v[0][1] * (v[1][0] * v[2][2] - v[1][2] * v[2][0]) +
+                v[0][2] * (v[1][0] * v[2][1] - v[1][1] * v[2][0]);
+    if (det < 0.0f) { v[0][2] = -v[0][2]; v[1][2] = -v[1][2]; v[2][2] = -v[2][2]; }
+    for (int i = 0; i < 3; ++i) pi[i] = a[i][i] > 0.0f ? a[i][i] : 0.0f;
+    ro_rot_to_quat(v, frame);
+}
+/* MassProperties::transform_by(pose): centre moved, frame rotated */
+static void ro_mp_transform(ro_mp *m, const float t[3], const float q[4]) {
+    /* rotate com by q (glam Quat::mul_vec3), then translate */
+    float bx = q[0], by = q[1], bz = q[2], w = q[3];
+    float b2 = bx * bx + by * by + bz * bz, vb = m->com[0] * bx + m->com[1] * by + m->com[2] * bz;
+    float cx = by * m->com[2] - bz * m->com[1], cy = bz * m->com[0] - bx * m->com[2], cz = bx * m->com[1] - by * m->com[0];
+    float k0 = w * w - b2, k1 = vb * 2.0f, k2 = w * 2.0f;
+    float rx = m->com[0] * k0 + bx * k1 + cx * k2, ry = m->com[1] * k0 + by * k1 + cy * k2, rz = m->com[2] * k0 + bz * k1 + cz * k2;
+    m->com[0] = rx + t[0]; m->com[1] = ry + t[1]; m->com[2] = rz + t[2];
+    /* frame = q * frame */
+    float a[4] = {q[0], q[1], q[2], q[3]}, f[4] = {m->frame[0], m->frame[1], m->frame[2], m->frame[3]};
+    m->frame[0] = a[3] * f[0] + a[0] * f[3] + a[1] * f[2] - a[2] * f[1];
+    m->frame[1] = a[3] * f[1] - a[0] * f[2] + a[1] * f[3] + a[2] * f[0];
+    m->frame[2] = a[3] * f[2] + a[0] * f[1] - a[1] * f[0] + a[2] * f[3];
+    m->frame[3] = a[3] * f[3] - a[0] * f[0] - a[1] * f[1] - a[2] * f[2];
+}
+/* MassProperties + MassProperties */
+static void ro_mp_add(ro_mp *acc, const ro_mp *o) {
+    if (acc->mass == 0.0f) { *acc = *o; return; }
+    if (o->mass == 0.0f) return;
+    float m1 = acc->mass, m2 = o->mass, total = m1 + m2, inv = 1.0f / total;
+    float com[3], s1[3], s2[3];
+    for (int k = 0; k < 3; ++k) com[k] = (acc->com[k] * m1 + o->com[k] * m2) * inv;
+    for (int k = 0; k < 3; ++k) { s1[k] = com[k] - acc->com[k]; s2[k] = com[k] - o->com[k]; }
+    float i1[3][3], i2[3][3], sum[3][3];
+    ro_shifted_inertia(acc, s1, i1); ro_shifted_inertia(o, s2, i2);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) sum[i][j] = i1[i][j] + i2[i][j];
+    /* symmetrise exactly (the shifted tensors are symmetric up to rounding) */
+    sum[1][0] = sum[0][1]; sum[2][0] = sum[0][2]; sum[2][1] = sum[1][2];
+    acc->mass = total; acc->com[0] = com[0]; acc->com[1] = com[1]; acc->com[2] = com[2];
+    ro_diagonalise(sum, acc->pi, acc->frame);
+}
+
+static int collider_enabled(const Collider *c) { return !(c->memberships == 0 && c->filter == 0); }
+/* sum of the attached colliders' mass properties at `density_override` (< 0: each collider's own density) */
+static void sum_collider_mass_props(const ro_world *w, int body, float density_override, ro_mp *acc) {
+    memset(acc, 0, sizeof(*acc)); acc->frame[3] = 1.0f;
+    for (int i = 0; i < w->ncolliders; ++i) {
+        const Collider *c = &w->colliders[i];
+        if (c->parent != body || !collider_enabled(c)) continue;
+        ro_mp m; memset(&m, 0, sizeof(m)); m.frame[3] = 1.0f;
+        v3 pi; shape_mass_props(c, density_override < 0.0f ? c->density : density_override, &m.mass, &pi);
+        m.pi[0] = pi.x; m.pi[1] = pi.y; m.pi[2] = pi.z;
+        float t[3] = {c->pos_wrt_parent.t.x, c->pos_wrt_parent.t.y, c->pos_wrt_parent.t.z};
+        float q[4] = {c->pos_wrt_parent.r.x, c->pos_wrt_parent.r.y, c->pos_wrt_parent.r.z, c->pos_wrt_parent.r.w};
+        ro_mp_transform(&m, t, q);
+        ro_mp_add(acc, &m);
+    }
+}
+/* RigidBodyMassProps::recompute_mass_properties_from_colliders — rigid_body_components.rs:421-489: the attached
+ * colliders' MassProperties (transformed by pos_wrt_parent) are summed in attachment order, then the additional mass. */
 static void recompute_mass_properties(ro_world *w, Body *b) {
-    float mass = 0.0f; v3 pi = V3(0, 0, 0);
-    const Collider *c0 = NULL;
-    for (int i = 0; i < w->ncolliders; ++i)
-        if (w->colliders[i].parent == (int)(b - w->bodies) && !(w->colliders[i].memberships == 0 && w->colliders[i].filter == 0)) { c0 = &w->colliders[i]; break; }
-    if (c0) shape_mass_props(c0, c0->density, &mass, &pi);
+    int body = (int)(b - w->bodies);
+    ro_mp acc; sum_collider_mass_props(w, body, -1.0f, &acc);
     if (b->additional_mass != 0.0f) {
-        if (mass > 0.0f) {
+        if (acc.mass > 0.0f) {
             /* MassProperties::set_mass(prev + add, adjust_angular_inertia = true) */
-            float nm = mass + b->additional_mass;
-            float k = nm / mass; pi = vmul(pi, k); mass = nm;
-        } else if (c0) {
-            float um; v3 upi; shape_mass_props(c0, 1.0f, &um, &upi);
-            if (um > 0.0f) { float k = b->additional_mass / um; pi = vmul(upi, k); }
-            mass = b->additional_mass;
+            float nm = acc.mass + b->additional_mass;
+            float k = nm / acc.mass;
+            acc.pi[0] = acc.pi[0] * k; acc.pi[1] = acc.pi[1] * k; acc.pi[2] = acc.pi[2] * k; acc.mass = nm;
         } else {
-            mass = b->additional_mass;
+            ro_mp unit; sum_collider_mass_props(w, body, 1.0f, &unit);
+            if (unit.mass > 0.0f) {
+                float k = b->additional_mass / unit.mass;
+                unit.pi[0] = unit.pi[0] * k; unit.pi[1] = unit.pi[1] * k; unit.pi[2] = unit.pi[2] * k; unit.mass = b->additional_mass;
+                acc = unit; /* local_mprops (zero) += unit_mprops */
+            } else {
+                acc.mass = b->additional_mass;
+            }
         }
     }
-    b->local_com = V3(0, 0, 0);
-    /* recompute_max_extent: bounding sphere of the attached shape about the local CoM (collider at the body origin) */
-    b->max_extent = c0 ? (c0->shape == RO_SHAPE_CUBOID ? vlen(c0->he) : c0->radius) : 0.0f;
-    b->inv_mass = ro_inv(mass);
-    b->inv_principal_inertia = V3(ro_inv(pi.x), ro_inv(pi.y), ro_inv(pi.z));
-    b->principal_frame = qident();
+    b->local_com = V3(acc.com[0], acc.com[1], acc.com[2]);
+    /* recompute_max_extent (:491-515): bounding spheres of the attached shapes about the local CoM */
+    b->max_extent = 0.0f;
+    for (int i = 0; i < w->ncolliders; ++i) {
+        const Collider *c = &w->colliders[i];
+        if (c->parent != body || !collider_enabled(c)) continue;
+        float radius = c->shape == RO_SHAPE_CUBOID ? vlen(c->he) : c->radius;
+        float extent = vlen(vsub(c->pos_wrt_parent.t, b->local_com)) + radius;
+        b->max_extent = ro_maxf(b->max_extent, extent);
+    }
+    b->inv_mass = ro_inv(acc.mass);
+    b->inv_principal_inertia = V3(ro_inv(acc.pi[0]), ro_inv(acc.pi[1]), ro_inv(acc.pi[2]));
+    b->principal_frame = Q(acc.frame[0], acc.frame[1], acc.frame[2], acc.frame[3]);
     update_world_mass_properties(b);
 }
 
@@ -368,6 +503,7 @@ int32_t ro_add_collider(ro_world *w, const ro_collider_desc *d, int32_t parent) 
     c->friction_rule = d->friction_rule; c->restitution_rule = d->restitution_rule;
     c->memberships = d->collision_memberships; c->filter = d->collision_filter;
     c->active_events = d->active_events; c->force_threshold = d->contact_force_event_threshold;
+    c->ord = parent >= 0 ? w->bodies[parent].ncolliders++ : w->nfree_colliders++;
     if (parent >= 0) c->pos = pose_mul(w->bodies[parent].position, c->pos_wrt_parent);
     else c->pos = c->pos_wrt_parent;
     int idx = w->ncolliders++;
@@ -443,6 +579,13 @@ int32_t ro_force_events_drain(ro_world *w, int32_t cap, int32_t *meta4, float *v
     for (int i = 0; i < n && i < cap; ++i) { memcpy(meta4 + 4 * i, w->force_meta + 4 * i, sizeof(int32_t) * 4); memcpy(vals8 + 8 * i, w->force_vals + 8 * i, sizeof(float) * 8); }
     if (meta4) w->nforce_events = 0;
     return n;
+}
+/* RigidBodyMassProps::local_mprops: inv_mass, local_com xyz, inv_principal_inertia xyz, principal frame xyzw */
+void ro_body_mass_props(const ro_world *w, int32_t body, float out11[11]) {
+    const Body *b = &w->bodies[body];
+    out11[0] = b->inv_mass; out11[1] = b->local_com.x; out11[2] = b->local_com.y; out11[3] = b->local_com.z;
+    out11[4] = b->inv_principal_inertia.x; out11[5] = b->inv_principal_inertia.y; out11[6] = b->inv_principal_inertia.z;
+    out11[7] = b->principal_frame.x; out11[8] = b->principal_frame.y; out11[9] = b->principal_frame.z; out11[10] = b->principal_frame.w;
 }
 void ro_wake_up(ro_world *w, int32_t body, int32_t strong) { if (body >= 0 && body < w->nbodies) wake_request(w, body, strong); }
 void ro_read_sleeping(const ro_world *w, int32_t *sleeping) {
@@ -864,10 +1007,15 @@ static int process_pair(ro_world *w, int pair_idx, Transition *tr_out) {
     return 1;
 }
 
-typedef struct { uint64_t key; int pair; int b1, b2; } ColorTodo;
+/* Canonical order of the deferred colouring: (min body, max body) like contacts.rs:369-385; the reference breaks ties
+ * (several collider pairs between the same two bodies: compound bodies) by contact-graph edge id, i.e. by the creation
+ * order of its BVH traversal, which no other broad phase reproduces — ties are broken here by the colliders' attachment
+ * ordinals on the (min body, max body) sides, a total order that does not depend on pair creation order. */
+typedef struct { uint64_t key; uint32_t tie; int pair; int b1, b2; } ColorTodo;
 static int todo_cmp(const void *a, const void *b) {
     const ColorTodo *x = (const ColorTodo *)a, *y = (const ColorTodo *)b;
-    if (x->key < y->key) return -1; if (x->key > y->key) return 1; return x->pair - y->pair;
+    if (x->key < y->key) return -1; if (x->key > y->key) return 1;
+    if (x->tie < y->tie) return -1; if (x->tie > y->tie) return 1; return 0;
 }
 /* NarrowPhase::compute_contacts + apply_pair_transitions — contacts.rs:22-385 */
 static void narrow_phase_compute_contacts(ro_world *w) {
@@ -896,6 +1044,7 @@ static void narrow_phase_compute_contacts(ro_world *w) {
         uint32_t b = tr[i].body2 >= 0 ? (uint32_t)tr[i].body2 : RO_NO_BODY;
         uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
         todo[ntodo].key = ((uint64_t)lo << 32) | hi; todo[ntodo].pair = tr[i].pair;
+        { uint32_t o1 = (uint32_t)w->colliders[p->c1].ord, o2 = (uint32_t)w->colliders[p->c2].ord; todo[ntodo].tie = a < b ? (o1 << 12) | o2 : (o2 << 12) | o1; }
         todo[ntodo].b1 = tr[i].body1; todo[ntodo].b2 = tr[i].body2; ntodo++;
     }
     /* apply_deferred_solver_coloring — contacts.rs:369-385 */

@@ -123,6 +123,8 @@ int32_t ro_force_events_drain(ro_world *w, int32_t cap, int32_t *meta4, float *v
 void ro_set_next_kinematic_position(ro_world *w, int32_t body, const float pos7[7]);
 /* RigidBody::set_position(.., wake_up = true) */
 void ro_set_body_pose(ro_world *w, int32_t body, const float pos7[7]);
+/* RigidBodyMassProps::local_mprops of a body: inv_mass, local_com, inv_principal_inertia, principal frame (x,y,z,w) */
+void ro_body_mass_props(const ro_world *w, int32_t body, float out11[11]);
 /* IslandManager::wake_up (island_manager/sleep.rs:31): wakes the body's whole island. */
 void ro_wake_up(ro_world *w, int32_t body, int32_t strong);
 /* RigidBody::is_sleeping per body (arena order). */

@@ -46,8 +46,9 @@ void rp_launch_idle_step(const DevWorld &w, hipStream_t st);
 struct HostBody {
     rp_body_desc d; float inv_mass; float inv_pi[3]; float lcom[3]; int ncolliders; bool removed;
     // RigidBodyActivation state carried across device rebuilds (rp_sleep.hip)
+    float pframe[4] = {0, 0, 0, 1};   // principal inertia frame (MassProperties::principal_inertia_local_frame)
     float max_extent = 0.0f, sleep_timer = 0.0f, sprev[7] = {0, 0, 0, 0, 0, 0, 1};
-    int sleeping = 0, slabel = 0;
+    int sleeping = 0, slabel = 0, next_ord = 0;
     bool has_next = false; float next[7] = {0, 0, 0, 0, 0, 0, 1}; // RigidBodyPosition::next_position of a kinematic body
 };
 
@@ -58,7 +59,8 @@ struct rp_world {
     float gravity[3];
     std::vector<HostBody> bodies;
     std::vector<rp_collider_desc> colliders;
-    std::vector<int> collider_parent;
+    std::vector<int> collider_parent, collider_ord; // ord: ordinal among the colliders of the same parent (attachment order)
+    int next_free_ord = 0;
     std::vector<char> collider_removed, joint_removed;
     std::vector<rp_joint_desc> joints;
     std::vector<int> active_joint_ids; // device joint index -> index into `joints`
@@ -76,6 +78,7 @@ struct rp_world {
     hipGraphExec_t ge_whole[2] = {nullptr, nullptr}, ge_col[2] = {nullptr, nullptr}, ge_loop[2] = {nullptr, nullptr}, ge_fin[2] = {nullptr, nullptr};
     int graph_stages = -1, graph_blocks = -1, graph_single = -1, graph_island_grid = -1, graph_joint_stages = -1, graph_no_global = -1, graph_fused = -1;
     bool use_graph = true, use_fast = true, use_fused = true;
+    bool compound = false;         // some dynamic body carries several colliders or an offset collider (no fused fast step)
     bool timed_ready[2] = {false, false};
     int cur_fast = 0;              // mode the enqueue_* callbacks capture
     long long steps_requested = 0; // steps asked for since finalize (device FL_STEP counts the executed ones)
@@ -108,6 +111,7 @@ static int after_topology_edit(rp_world *w);
 static bool world_sleep_enabled(const rp_world *w);
 static bool world_has_kinematic_pos(const rp_world *w);
 static bool world_has_force_events(const rp_world *w);
+static bool world_has_compound_bodies(const rp_world *w);
 static int check_sleep_scope(rp_world *w);
 static int rebuild_begin(rp_world *w);
 static int queue_wake(rp_world *w, int b, int lvl);
@@ -286,32 +290,175 @@ static void shape_mass_props(const rp_collider_desc &c, float density, float &ma
 }
 static float h_inv(float x) { return (x > -1.0e-20f && x < 1.0e-20f) ? 0.0f : 1.0f / x; }
 
-// RigidBodyMassProps::recompute_mass_properties_from_colliders — rigid_body_components.rs:421-489.
-// Scope: one collider per body attached at the body origin (all the hot-path scenes).
+/* ---- parry MassProperties algebra (not in /root/reference; restated from its public definition) ----------------
+ * A MassProperties value = (mass, local_com, principal inertia, principal frame).  `transform_by(pos)` moves the
+ * centre and rotates the frame; `a + b` = total mass, mass-weighted centre, sum of the two inertia tensors shifted
+ * to the common centre (parallel-axis theorem), re-diagonalised.  parry diagonalises with nalgebra's
+ * symmetric_eigen (Householder + QR); a cyclic Jacobi iteration is used here instead — same eigen-system, rounding
+ * differs (unpinned like every other parry quantity).  Arithmetic is plain f32, no contraction. */
+typedef struct { float mass; float com[3]; float pi[3]; float frame[4]; } hmp_mp;   /* frame: quaternion x,y,z,w */
+
+static void hmp_quat_to_rot(const float q[4], float r[3][3]) {
+    float x2 = q[0] + q[0], y2 = q[1] + q[1], z2 = q[2] + q[2];
+    float xx = q[0] * x2, xy = q[0] * y2, xz = q[0] * z2;
+    float yy = q[1] * y2, yz = q[1] * z2, zz = q[2] * z2;
+    float wx = q[3] * x2, wy = q[3] * y2, wz = q[3] * z2;
+    r[0][0] = 1.0f - (yy + zz); r[0][1] = xy - wz; r[0][2] = xz + wy;
+    r[1][0] = xy + wz; r[1][1] = 1.0f - (xx + zz); r[1][2] = yz - wx;
+    r[2][0] = xz - wy; r[2][1] = yz + wx; r[2][2] = 1.0f - (xx + yy);
+}
+/* reconstruct_inertia_matrix: R diag(pi) R^T */
+static void hmp_inertia_matrix(const hmp_mp *m, float out[3][3]) {
+    float r[3][3]; hmp_quat_to_rot(m->frame, r);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            out[i][j] = r[i][0] * m->pi[0] * r[j][0] + r[i][1] * m->pi[1] * r[j][1] + r[i][2] * m->pi[2] * r[j][2];
+}
+/* construct_shifted_inertia_matrix: I + (|s|^2 Id - s s^T) * mass */
+static void hmp_shifted_inertia(const hmp_mp *m, const float s[3], float out[3][3]) {
+    hmp_inertia_matrix(m, out);
+    float d = s[0] * s[0] + s[1] * s[1] + s[2] * s[2];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            out[i][j] = out[i][j] + ((i == j ? d : 0.0f) - s[i] * s[j]) * m->mass;
+}
+/* rotation matrix (columns = axes) -> unit quaternion (Shepperd's method) */
+static void hmp_rot_to_quat(float v[3][3], float q[4]) {
+    float tr = v[0][0] + v[1][1] + v[2][2];
+    if (tr > 0.0f) {
+        float s = sqrtf(tr + 1.0f) * 2.0f;
+        q[3] = 0.25f * s; q[0] = (v[2][1] - v[1][2]) / s; q[1] = (v[0][2] - v[2][0]) / s; q[2] = (v[1][0] - v[0][1]) / s;
+    } else if (v[0][0] > v[1][1] && v[0][0] > v[2][2]) {
+        float s = sqrtf(1.0f + v[0][0] - v[1][1] - v[2][2]) * 2.0f;
+        q[3] = (v[2][1] - v[1][2]) / s; q[0] = 0.25f * s; q[1] = (v[0][1] + v[1][0]) / s; q[2] = (v[0][2] + v[2][0]) / s;
+    } else if (v[1][1] > v[2][2]) {
+        float s = sqrtf(1.0f + v[1][1] - v[0][0] - v[2][2]) * 2.0f;
+        q[3] = (v[0][2] - v[2][0]) / s; q[0] = (v[0][1] + v[1][0]) / s; q[1] = 0.25f * s; q[2] = (v[1][2] + v[2][1]) / s;
+    } else {
+        float s = sqrtf(1.0f + v[2][2] - v[0][0] - v[1][1]) * 2.0f;
+        q[3] = (v[1][0] - v[0][1]) / s; q[0] = (v[0][2] + v[2][0]) / s; q[1] = (v[1][2] + v[2][1]) / s; q[2] = 0.25f * s;
+    }
+    float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    float inv = 1.0f / n;
+    q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
+}
+/* with_inertia_matrix: principal inertia + frame of a symmetric 3x3 tensor (cyclic Jacobi, 12 sweeps) */
+static void hmp_diagonalise(float a[3][3], float pi[3], float frame[4]) {
+    float v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        float off = fabsf(a[0][1]) + fabsf(a[0][2]) + fabsf(a[1][2]);
+        if (off == 0.0f) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (a[p][q] == 0.0f) continue;
+                float theta = (a[q][q] - a[p][p]) / (2.0f * a[p][q]);
+                float t = (theta >= 0.0f ? 1.0f : -1.0f) / (fabsf(theta) + sqrtf(theta * theta + 1.0f));
+                float c = 1.0f / sqrtf(t * t + 1.0f), s = t * c;
+                for (int k = 0; k < 3; ++k) { float akp = a[k][p], akq = a[k][q]; a[k][p] = c * akp - s * akq; a[k][q] = s * akp + c * akq; }
+                for (int k = 0; k < 3; ++k) { float apk = a[p][k], aqk = a[q][k]; a[p][k] = c * apk - s * aqk; a[q][k] = s * apk + c * aqk; }
+                for (int k = 0; k < 3; ++k) { float vkp = v[k][p], vkq = v[k][q]; v[k][p] = c * vkp - s * vkq; v[k][q] = s * vkp + c * vkq; }
+            }
+    }
+    /* a proper rotation: flip the last axis when the determinant is negative */
+    float det = v[0][0] * (v[1][1] * v[2][2] - v[1][2] * v[2][1]) - v[0][1] * (v[1][0] * v[2][2] - v[1][2] * v[2][0]) +
+                v[0][2] * (v[1][0] * v[2][1] - v[1][1] * v[2][0]);
+    if (det < 0.0f) { v[0][2] = -v[0][2]; v[1][2] = -v[1][2]; v[2][2] = -v[2][2]; }
+    for (int i = 0; i < 3; ++i) pi[i] = a[i][i] > 0.0f ? a[i][i] : 0.0f;
+    hmp_rot_to_quat(v, frame);
+}
+/* MassProperties::transform_by(pose): centre moved, frame rotated */
+static void hmp_mp_transform(hmp_mp *m, const float t[3], const float q[4]) {
+    /* rotate com by q (glam Quat::mul_vec3), then translate */
+    float bx = q[0], by = q[1], bz = q[2], w = q[3];
+    float b2 = bx * bx + by * by + bz * bz, vb = m->com[0] * bx + m->com[1] * by + m->com[2] * bz;
+    float cx = by * m->com[2] - bz * m->com[1], cy = bz * m->com[0] - bx * m->com[2], cz = bx * m->com[1] - by * m->com[0];
+    float k0 = w * w - b2, k1 = vb * 2.0f, k2 = w * 2.0f;
+    float rx = m->com[0] * k0 + bx * k1 + cx * k2, ry = m->com[1] * k0 + by * k1 + cy * k2, rz = m->com[2] * k0 + bz * k1 + cz * k2;
+    m->com[0] = rx + t[0]; m->com[1] = ry + t[1]; m->com[2] = rz + t[2];
+    /* frame = q * frame */
+    float a[4] = {q[0], q[1], q[2], q[3]}, f[4] = {m->frame[0], m->frame[1], m->frame[2], m->frame[3]};
+    m->frame[0] = a[3] * f[0] + a[0] * f[3] + a[1] * f[2] - a[2] * f[1];
+    m->frame[1] = a[3] * f[1] - a[0] * f[2] + a[1] * f[3] + a[2] * f[0];
+    m->frame[2] = a[3] * f[2] + a[0] * f[1] - a[1] * f[0] + a[2] * f[3];
+    m->frame[3] = a[3] * f[3] - a[0] * f[0] - a[1] * f[1] - a[2] * f[2];
+}
+/* MassProperties + MassProperties */
+static void hmp_mp_add(hmp_mp *acc, const hmp_mp *o) {
+    if (acc->mass == 0.0f) { *acc = *o; return; }
+    if (o->mass == 0.0f) return;
+    float m1 = acc->mass, m2 = o->mass, total = m1 + m2, inv = 1.0f / total;
+    float com[3], s1[3], s2[3];
+    for (int k = 0; k < 3; ++k) com[k] = (acc->com[k] * m1 + o->com[k] * m2) * inv;
+    for (int k = 0; k < 3; ++k) { s1[k] = com[k] - acc->com[k]; s2[k] = com[k] - o->com[k]; }
+    float i1[3][3], i2[3][3], sum[3][3];
+    hmp_shifted_inertia(acc, s1, i1); hmp_shifted_inertia(o, s2, i2);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) sum[i][j] = i1[i][j] + i2[i][j];
+    /* symmetrise exactly (the shifted tensors are symmetric up to rounding) */
+    sum[1][0] = sum[0][1]; sum[2][0] = sum[0][2]; sum[2][1] = sum[1][2];
+    acc->mass = total; acc->com[0] = com[0]; acc->com[1] = com[1]; acc->com[2] = com[2];
+    hmp_diagonalise(sum, acc->pi, acc->frame);
+}
+
+// sum of the attached colliders' mass properties at `density_override` (< 0: each collider's own density)
+static void sum_collider_mass_props(const rp_world *w, int body, float density_override, hmp_mp *acc) {
+    memset(acc, 0, sizeof(*acc)); acc->frame[3] = 1.0f;
+    for (size_t i = 0; i < w->colliders.size(); ++i) {
+        if (w->collider_parent[i] != body || w->collider_removed[i]) continue;
+        const rp_collider_desc &c = w->colliders[i];
+        hmp_mp m; memset(&m, 0, sizeof(m)); m.frame[3] = 1.0f;
+        shape_mass_props(c, density_override < 0.0f ? c.density : density_override, m.mass, m.pi);
+        float qn = std::sqrt(c.rotation[0] * c.rotation[0] + c.rotation[1] * c.rotation[1] + c.rotation[2] * c.rotation[2] + c.rotation[3] * c.rotation[3]);
+        float qi = qn > 0.0f ? 1.0f / qn : 1.0f;
+        float q[4] = {c.rotation[0] * qi, c.rotation[1] * qi, c.rotation[2] * qi, qn > 0.0f ? c.rotation[3] * qi : 1.0f};
+        hmp_mp_transform(&m, c.translation, q);
+        hmp_mp_add(acc, &m);
+    }
+}
+// RigidBodyMassProps::recompute_mass_properties_from_colliders — rigid_body_components.rs:421-489: the attached colliders'
+// MassProperties (transformed by pos_wrt_parent) are summed in attachment order, then the additional mass.
 static void recompute_mass(rp_world *w, int body) {
     HostBody &b = w->bodies[body];
-    float mass = 0.0f, pi[3] = {0, 0, 0};
-    const rp_collider_desc *c0 = nullptr;
-    for (size_t i = 0; i < w->colliders.size(); ++i) if (w->collider_parent[i] == body && !w->collider_removed[i]) { c0 = &w->colliders[i]; break; }
-    if (c0) shape_mass_props(*c0, c0->density, mass, pi);
+    hmp_mp acc; sum_collider_mass_props(w, body, -1.0f, &acc);
     float add = b.d.additional_mass;
     if (add != 0.0f) {
-        if (mass > 0.0f) { volatile float nm = mass + add; volatile float k = nm / mass; for (int q = 0; q < 3; ++q) pi[q] = pi[q] * k; mass = nm; }
-        else if (c0) {
-            float um, upi[3]; shape_mass_props(*c0, 1.0f, um, upi);
-            if (um > 0.0f) { volatile float k = add / um; for (int q = 0; q < 3; ++q) pi[q] = upi[q] * k; }
-            mass = add;
-        } else mass = add;
+        if (acc.mass > 0.0f) { // MassProperties::set_mass(prev + add, adjust_angular_inertia = true)
+            float nm = acc.mass + add;
+            float k = nm / acc.mass;
+            acc.pi[0] = acc.pi[0] * k; acc.pi[1] = acc.pi[1] * k; acc.pi[2] = acc.pi[2] * k; acc.mass = nm;
+        } else {
+            hmp_mp unit; sum_collider_mass_props(w, body, 1.0f, &unit);
+            if (unit.mass > 0.0f) {
+                float k = add / unit.mass;
+                unit.pi[0] = unit.pi[0] * k; unit.pi[1] = unit.pi[1] * k; unit.pi[2] = unit.pi[2] * k; unit.mass = add;
+                acc = unit;
+            } else acc.mass = add;
+        }
     }
-    b.inv_mass = h_inv(mass);
-    for (int q = 0; q < 3; ++q) { b.inv_pi[q] = h_inv(pi[q]); b.lcom[q] = 0.0f; }
-    // recompute_max_extent (rigid_body_components.rs:491-515): bounding sphere of the shape about the local CoM
+    b.inv_mass = h_inv(acc.mass);
+    for (int q = 0; q < 3; ++q) { b.inv_pi[q] = h_inv(acc.pi[q]); b.lcom[q] = acc.com[q]; }
+    for (int q = 0; q < 4; ++q) b.pframe[q] = acc.frame[q];
+    // recompute_max_extent (rigid_body_components.rs:491-515): bounding spheres of the attached shapes about the local CoM
     b.max_extent = 0.0f;
-    if (c0) {
-        volatile float x2 = c0->half_extents[0] * c0->half_extents[0], y2 = c0->half_extents[1] * c0->half_extents[1], z2 = c0->half_extents[2] * c0->half_extents[2];
-        volatile float sxy = x2 + y2; volatile float sxyz = sxy + z2;
-        b.max_extent = c0->shape == RP_SHAPE_CUBOID ? std::sqrt(sxyz) : c0->half_extents[0];
+    for (size_t i = 0; i < w->colliders.size(); ++i) {
+        if (w->collider_parent[i] != body || w->collider_removed[i]) continue;
+        const rp_collider_desc &c = w->colliders[i];
+        float radius = c.shape == RP_SHAPE_CUBOID ? std::sqrt(c.half_extents[0] * c.half_extents[0] + c.half_extents[1] * c.half_extents[1] + c.half_extents[2] * c.half_extents[2]) : c.half_extents[0];
+        float dx = c.translation[0] - b.lcom[0], dy = c.translation[1] - b.lcom[1], dz = c.translation[2] - b.lcom[2];
+        float extent = std::sqrt(dx * dx + dy * dy + dz * dz) + radius;
+        if (extent > b.max_extent) b.max_extent = extent;
     }
+}
+// dynamic bodies with several colliders, or with a collider away from the body origin: the fused fast step validates ONE
+// collider per body (b_collider), so such worlds keep to the fast graph / full graph
+static bool world_has_compound_bodies(const rp_world *w) {
+    for (size_t i = 0; i < w->colliders.size(); ++i) {
+        int p = w->collider_parent[i];
+        if (p < 0 || w->collider_removed[i] || w->bodies[p].d.body_type != RP_BODY_DYNAMIC) continue;
+        const float *t = w->colliders[i].translation, *r = w->colliders[i].rotation;
+        bool at_origin = t[0] == 0.0f && t[1] == 0.0f && t[2] == 0.0f && r[0] == 0.0f && r[1] == 0.0f && r[2] == 0.0f;
+        if (!at_origin || w->bodies[p].ncolliders > 1) return true;
+    }
+    return false;
 }
 
 // Bring the host mirrors up to date with the device (poses, velocities) before the device world is
@@ -372,6 +519,7 @@ extern "C" int32_t rp_bodies_insert(rp_world *w, int32_t n, const rp_body_desc *
         int r = in_place ? settle(w) : rebuild_begin(w);
         if (r != RP_OK) return r;
     }
+    if ((long long)w->bodies.size() + n >= 0xfffff) { w->err = "rp_bodies_insert: more than 2^20 - 1 bodies"; return RP_ERR_CAPACITY; }
     for (int i = 0; i < n; ++i) if (descs[i].body_type < RP_BODY_DYNAMIC || descs[i].body_type > RP_BODY_KINEMATIC_VELOCITY) { w->err = "rp_bodies_insert: unknown body_type"; return RP_ERR_INVALID; }
     for (int i = 0; i < n; ++i) {
         HostBody b; b.d = descs[i]; b.ncolliders = 0; b.removed = false; b.inv_mass = 0; b.inv_pi[0] = b.inv_pi[1] = b.inv_pi[2] = 0; b.lcom[0] = b.lcom[1] = b.lcom[2] = 0;
@@ -405,14 +553,10 @@ extern "C" int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider
         if (parents && parents[i] != RP_INVALID_HANDLE) {
             parent = (int)(parents[i] & 0xffffffffull);
             if (parent < 0 || parent >= (int)w->bodies.size()) { w->err = "rp_colliders_insert: invalid parent handle"; return RP_ERR_INVALID; }
-            // mass properties scope (recompute_mass below): ONE collider per dynamic body, attached at the body origin
-            const float *t = descs[i].translation, *r = descs[i].rotation;
-            bool at_origin = t[0] == 0.0f && t[1] == 0.0f && t[2] == 0.0f && r[0] == 0.0f && r[1] == 0.0f && r[2] == 0.0f;
-            if (w->bodies[parent].d.body_type == RP_BODY_DYNAMIC && (w->bodies[parent].ncolliders > 0 || !at_origin)) {
-                w->err = "rp_colliders_insert: compound bodies (several colliders per body, or a collider offset from its body) are not implemented on the device path";
-                return RP_ERR_INVALID;
-            }
         }
+        int &ord_counter = parent >= 0 ? w->bodies[parent].next_ord : w->next_free_ord;
+        if (ord_counter >= 4096) { w->err = "rp_colliders_insert: more than 4096 colliders on one body (or without a parent)"; return RP_ERR_CAPACITY; }
+        w->collider_ord.push_back(ord_counter++);
         w->colliders.push_back(descs[i]);
         w->collider_parent.push_back(parent);
         w->collider_removed.push_back(0);
@@ -429,6 +573,7 @@ extern "C" int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider
     if (in_place && n > 0) {
         w->dw.n_colliders = (int)w->colliders.size();
         w->dw.has_force_events = world_has_force_events(w) ? 1 : 0;
+        w->compound = world_has_compound_bodies(w);
         HIPCHK(w, hipStreamSynchronize(w->stream));
         destroy_graphs(w);
         return after_topology_edit(w);
@@ -488,7 +633,7 @@ static BodyRow pack_body(const HostBody &b) {
     o.lv = mk4(bd.linvel[0], bd.linvel[1], bd.linvel[2], 0); o.av = mk4(bd.angvel[0], bd.angvel[1], bd.angvel[2], 0);
     o.lci = mk4(b.lcom[0], b.lcom[1], b.lcom[2], b.inv_mass);
     o.ipi = mk4(b.inv_pi[0], b.inv_pi[1], b.inv_pi[2], 0);
-    o.pfr = mk4(0, 0, 0, 1);
+    o.pfr = mk4(b.pframe[0], b.pframe[1], b.pframe[2], b.pframe[3]);
     o.damp = mk4(bd.linear_damping, bd.angular_damping, bd.gravity_scale, 0);
     int fl = ((b.removed ? RP_BODY_FIXED : bd.body_type) & RP_BF_TYPE_MASK);
     if (bd.gyroscopic && bd.body_type == RP_BODY_DYNAMIC) fl |= RP_BF_GYRO; // gyroscopic forces: dynamic bodies only (worker.rs:86)
@@ -516,11 +661,11 @@ static int upload_body_row(rp_world *w, int i) {
     PUT(d.b_next_pos, i, r.npos); PUT(d.b_next_rot, i, r.nrot);
     return RP_OK;
 }
-struct ColliderRow { int parent, shape; float4 lp, lr, he, mat, fmn, fmx; int2 rules; uint2 groups; float2 events; };
+struct ColliderRow { int ord; int parent, shape; float4 lp, lr, he, mat, fmn, fmx; int2 rules; uint2 groups; float2 events; };
 static ColliderRow pack_collider(const rp_world *w, int i) {
     const rp_collider_desc &c = w->colliders[i];
     ColliderRow o;
-    o.parent = w->collider_parent[i]; o.shape = c.shape;
+    o.parent = w->collider_parent[i]; o.shape = c.shape; o.ord = w->collider_ord[i];
     float qn = std::sqrt(c.rotation[0] * c.rotation[0] + c.rotation[1] * c.rotation[1] + c.rotation[2] * c.rotation[2] + c.rotation[3] * c.rotation[3]);
     float qi = qn > 0.0f ? 1.0f / qn : 1.0f;
     o.lp = mk4(c.translation[0], c.translation[1], c.translation[2], 0);
@@ -537,14 +682,14 @@ static ColliderRow pack_collider(const rp_world *w, int i) {
 static int upload_body_row_mass(rp_world *w, int i) { // mass properties only (a collider was attached / removed)
     const DevWorld &d = w->dw;
     BodyRow r = pack_body(w->bodies[i]);
-    PUT(d.b_lcom_invm, i, r.lci); PUT(d.b_invpi, i, r.ipi);
-    PUT((float *)(d.b_sprev_t + i) + 3, 0, r.spt.w); // max_extent follows the attached shape
+    PUT(d.b_lcom_invm, i, r.lci); PUT(d.b_invpi, i, r.ipi); PUT(d.b_pframe, i, r.pfr);
+    PUT((float *)(d.b_sprev_t + i) + 3, 0, r.spt.w); // max_extent follows the attached shapes
     return RP_OK;
 }
 static int upload_collider_row(rp_world *w, int i) {
     const DevWorld &d = w->dw;
     ColliderRow r = pack_collider(w, i);
-    PUT(d.c_parent, i, r.parent); PUT(d.c_shape, i, r.shape); PUT(d.c_lpos, i, r.lp); PUT(d.c_lrot, i, r.lr); PUT(d.c_he, i, r.he); PUT(d.c_mat, i, r.mat);
+    PUT(d.c_parent, i, r.parent); PUT(d.c_ord, i, r.ord); PUT(d.c_shape, i, r.shape); PUT(d.c_lpos, i, r.lp); PUT(d.c_lrot, i, r.lr); PUT(d.c_he, i, r.he); PUT(d.c_mat, i, r.mat);
     PUT(d.c_rules, i, r.rules); PUT(d.c_groups, i, r.groups); PUT(d.c_fatmin, i, r.fmn); PUT(d.c_fatmax, i, r.fmx); PUT(d.c_events, i, r.events);
     return RP_OK;
 }
@@ -582,6 +727,7 @@ static int finalize(rp_world *w) {
     d.sleep_enabled = world_sleep_enabled(w) ? 1 : 0;
     d.has_kinematic_pos = world_has_kinematic_pos(w) ? 1 : 0;
     d.has_force_events = world_has_force_events(w) ? 1 : 0;
+    w->compound = world_has_compound_bodies(w);
     int nb = (int)w->bodies.size(), nc = (int)w->colliders.size();
     d.n_bodies = nb; d.n_colliders = nc;
     // capacities leave room for bodies / colliders inserted later without rebuilding the device world
@@ -617,7 +763,7 @@ static int finalize(rp_world *w) {
     DA(d.lab_wake, capb); DA(d.lab_awake, capb); DA(d.b_next_pos, capb); DA(d.b_next_rot, capb);
     DA(d.s_lin, capb); DA(d.s_ang, capb); DA(d.s_rot, capb); DA(d.s_trans, capb); DA(d.s_incl, capb); DA(d.s_inca, capb);
     DA(d.b_cmask, 4 * (size_t)capb); DAF(d.b_min, capb, 0xff);
-    DA(d.c_parent, capc); DA(d.c_shape, capc); DA(d.c_lpos, capc); DA(d.c_lrot, capc); DA(d.c_pos, capc); DA(d.c_rot, capc); DA(d.c_he, capc);
+    DA(d.c_parent, capc); DA(d.c_ord, capc); DA(d.c_shape, capc); DA(d.c_lpos, capc); DA(d.c_lrot, capc); DA(d.c_pos, capc); DA(d.c_rot, capc); DA(d.c_he, capc);
     DA(d.c_mat, capc); DA(d.c_rules, capc); DA(d.c_groups, capc); DA(d.c_fatmin, capc); DA(d.c_fatmax, capc); DA(d.c_events, capc);
     d.ev_cap = 65536;
     DA(d.ev_col, d.ev_cap); DA(d.ev_force_meta, d.ev_cap); DA(d.ev_force_a, d.ev_cap); DA(d.ev_force_b, d.ev_cap);
@@ -708,14 +854,14 @@ static int finalize(rp_world *w) {
         UP(d.b_sleep, slp); UP(d.b_sprev_t, spt); UP(d.b_sprev_r, spr); UP(d.b_slabel, slab);
         UP(d.b_pos, pos); UP(d.b_rot, rot); UP(d.b_linvel, lv); UP(d.b_angvel, av); UP(d.b_lcom_invm, lci); UP(d.b_invpi, ipi);
         UP(d.b_pframe, pfr); UP(d.b_damp, damp); UP(d.b_flags, bfl);
-        std::vector<int> cpar(nc), csh(nc);
+        std::vector<int> cpar(nc), csh(nc), cord(nc);
         std::vector<float4> clp(nc), clr(nc), che(nc), cmat(nc), fmn(nc), fmx(nc);
         std::vector<int2> crul(nc); std::vector<uint2> cgrp(nc); std::vector<float2> cev(nc);
         for (int i = 0; i < nc; ++i) {
             ColliderRow r = pack_collider(w, i);
-            cpar[i] = r.parent; csh[i] = r.shape; clp[i] = r.lp; clr[i] = r.lr; che[i] = r.he; cmat[i] = r.mat; crul[i] = r.rules; cgrp[i] = r.groups; fmn[i] = r.fmn; fmx[i] = r.fmx; cev[i] = r.events;
+            cpar[i] = r.parent; cord[i] = r.ord; csh[i] = r.shape; clp[i] = r.lp; clr[i] = r.lr; che[i] = r.he; cmat[i] = r.mat; crul[i] = r.rules; cgrp[i] = r.groups; fmn[i] = r.fmn; fmx[i] = r.fmx; cev[i] = r.events;
         }
-        UP(d.c_parent, cpar); UP(d.c_shape, csh); UP(d.c_lpos, clp); UP(d.c_lrot, clr); UP(d.c_he, che); UP(d.c_mat, cmat);
+        UP(d.c_parent, cpar); UP(d.c_ord, cord); UP(d.c_shape, csh); UP(d.c_lpos, clp); UP(d.c_lrot, clr); UP(d.c_he, che); UP(d.c_mat, cmat);
         UP(d.c_rules, crul); UP(d.c_groups, cgrp); UP(d.c_fatmin, fmn); UP(d.c_fatmax, fmx); UP(d.c_events, cev);
         HIPCHK(w, hipStreamSynchronize(w->stream)); // the staging vectors die here
     }
@@ -780,7 +926,7 @@ static void plan_from_hints(rp_world *w, const int *fl) {
     w->plan_island_grid = std::min(std::max(pow2_ceil(fl[FL_N_ISLANDS]), 1), 8192);
     // fused single-kernel fast step: every workgroup must be resident at once (in-launch arrival barrier)
     // (a grid of at most RP_FUSED_MAX_GRID workgroups, one per CU; workgroups loop over islands beyond that)
-    w->plan_fused = (w->use_fused && w->plan_no_global && w->plan_single && fl[FL_N_ISLANDS] > 0) ? 1 : 0;
+    w->plan_fused = (w->use_fused && !w->compound && w->plan_no_global && w->plan_single && fl[FL_N_ISLANDS] > 0) ? 1 : 0;
 }
 
 static int capture(rp_world *w, hipGraph_t *g, hipGraphExec_t *ge, void (*fn)(rp_world *)) {

@@ -454,10 +454,14 @@ __device__ __noinline__ void pair_full_update(DevWorld &w, int s, int c1, int c2
             w.p_color[s] = RP_COLOR_UNCOLORED; w.p_colorb[s] = make_int2(-1, -1);
         } else { // begin touch: queue for the sorted greedy colouring
             int t = atomicAdd(&w.flags[FL_TODO_COUNT], 1);
-            unsigned a = rb1 >= 0 ? (unsigned)rb1 : 0x1fffffu, b = rb2 >= 0 ? (unsigned)rb2 : 0x1fffffu;
+            // canonical greedy order: (min body, max body) as in contacts.rs:369-385; ties (several collider pairs between the
+            // same two bodies) by the colliders' attachment ordinals — the reference uses its edge creation order there
+            unsigned a = rb1 >= 0 ? (unsigned)rb1 : 0xfffffu, b = rb2 >= 0 ? (unsigned)rb2 : 0xfffffu;
             unsigned lo = a < b ? a : b, hi = a < b ? b : a;
+            unsigned o1 = (unsigned)w.c_ord[c1] & 0xfffu, o2 = (unsigned)w.c_ord[c2] & 0xfffu;
+            unsigned tie = a < b ? (o1 << 12) | o2 : (o2 << 12) | o1;
             w.todo_slot[t] = s;
-            w.todo_key[t] = ((unsigned long long)lo << 43) | ((unsigned long long)hi << 22) | (unsigned long long)(s & 0x3fffff);
+            w.todo_key[t] = ((unsigned long long)lo << 44) | ((unsigned long long)hi << 24) | (unsigned long long)tie;
         }
     }
 }

@@ -184,6 +184,7 @@ struct DevWorld {
 
     // ---- colliders ----
     int *c_parent, *c_shape;
+    int *c_ord;            // ordinal of the collider among the colliders of its parent (attachment order, < 4096)
     float4 *c_lpos, *c_lrot, *c_pos, *c_rot, *c_he;
     float4 *c_mat;         // friction, restitution, density, -
     int2 *c_rules;

@@ -419,3 +419,24 @@ def jointed_pairs(n: int = 1) -> Scene:
     s.add_collider(w2, half_extents=(0.5, 0.5, 0.5), density=3.0)
     s.add_joint(w1, w2, (0.6, 0.0, 0.0), (-0.6, 0.0, 0.0), locked_axes=LOCK_ALL)
     return s
+
+
+def compound_bodies(n: int = 12) -> Scene:
+    """Compound-body test scene (not a reference scene): hammers (a handle cuboid + an offset, rotated head cuboid +
+    a ball at the other end) and L-shapes dropped with spin onto a slab.  Exercises summed MassProperties (offset centre
+    of mass, non-trivial principal frame), several colliders per body and pairs that share a body."""
+    s = Scene(name=f"compound_bodies_{n}", gravity=(0.0, -9.81, 0.0))
+    g = s.add_body(body_type=BODY_FIXED, translation=(0.0, -0.5, 0.0))
+    s.add_collider(g, half_extents=(15.0, 0.5, 15.0))
+    for i in range(n):
+        x, z = _f(2.5 * (i % 4) - 3.75), _f(2.5 * (i // 4) - 2.5)
+        b = s.add_body(translation=(x, _f(1.5 + 0.8 * (i % 3)), z), angvel=(_f(0.5 * (i % 3)), _f(0.3 * i), _f(-0.4 * (i % 2))),
+                       linvel=(_f(0.2 * (i % 2)), 0.0, 0.0))
+        if i % 2 == 0:   # hammer
+            s.add_collider(b, half_extents=(0.6, 0.1, 0.1), density=1.0)
+            s.add_collider(b, half_extents=(0.15, 0.3, 0.2), translation=(0.7, 0.0, 0.0), rotation=(0.0, 0.0, 0.38268343, 0.92387953), density=4.0)
+            s.add_collider(b, shape=SHAPE_BALL, half_extents=(0.15, 0.0, 0.0), translation=(-0.7, 0.0, 0.0), density=0.5)
+        else:            # L-shape
+            s.add_collider(b, half_extents=(0.5, 0.15, 0.15), translation=(0.5, 0.0, 0.0), density=2.0)
+            s.add_collider(b, half_extents=(0.15, 0.5, 0.15), translation=(0.0, 0.5, 0.0), density=2.0)
+    return s

@@ -54,6 +54,7 @@ def lib():
         L.ro_set_next_kinematic_position.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         L.ro_collision_events_drain.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         L.ro_force_events_drain.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        L.ro_body_mass_props.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         L.ro_wake_up.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         L.ro_read_sleeping.argtypes = [C.c_void_p, C.c_void_p]
         L.ro_remove_body.argtypes = [C.c_void_p, C.c_int32]
@@ -155,6 +156,11 @@ class OracleWorld:
         vals = np.zeros((n, 8), np.float32)
         lib().ro_force_events_drain(self._w, n, meta.ctypes.data, vals.ctypes.data)
         return meta, vals
+
+    def mass_props(self, body):
+        out = np.zeros(11, np.float32)
+        lib().ro_body_mass_props(self._w, int(body), out.ctypes.data)
+        return out
 
     def wake_up(self, body, strong=True):
         lib().ro_wake_up(self._w, int(body), 1 if strong else 0)

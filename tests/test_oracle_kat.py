@@ -228,6 +228,41 @@ def test_coulomb_pyramid_rests_and_carries_its_weight():
     assert imp[ground].sum() == pytest.approx(weight, rel=0.01)
 
 
+# Compound bodies: the summed MassProperties of several colliders (parallel-axis theorem + diagonalisation) against a
+# float64 reference, and a hammer that comes to rest head-down-ish without gaining energy.
+def test_compound_mass_properties_and_rest():
+    sc = S.Scene(name="cmp")
+    b = sc.add_body(translation=(0, 5, 0))
+    q = np.array([0.1, 0.2, 0.3, 0.9]); q /= np.linalg.norm(q)
+    sc.add_collider(b, half_extents=(0.5, 0.25, 0.75), translation=(1.0, 0.2, -0.3), rotation=tuple(q), density=2.0)
+    sc.add_collider(b, shape=S.SHAPE_BALL, half_extents=(0.4, 0, 0), translation=(-0.7, 0.0, 0.5), density=3.0)
+    sc.add_collider(b, half_extents=(0.2, 0.9, 0.1), translation=(0.0, -0.8, 0.0), density=1.0)
+    mp = OracleWorld(sc).mass_props(b).astype(np.float64)
+
+    def rot(q):
+        x, y, z, w = q
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                         [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+    def box(he, rho):
+        he = np.array(he); m = 8 * he.prod() * rho
+        return m, np.diag([m / 3 * (he[1] ** 2 + he[2] ** 2), m / 3 * (he[0] ** 2 + he[2] ** 2), m / 3 * (he[0] ** 2 + he[1] ** 2)])
+    m1, i1 = box((0.5, 0.25, 0.75), 2.0); r1 = rot(q)
+    m2 = 4 / 3 * np.pi * 0.4 ** 3 * 3.0; i2 = np.eye(3) * 0.4 * m2 * 0.16
+    m3, i3 = box((0.2, 0.9, 0.1), 1.0)
+    parts = [(m1, np.array([1.0, 0.2, -0.3]), r1 @ i1 @ r1.T), (m2, np.array([-0.7, 0, 0.5]), i2), (m3, np.array([0, -0.8, 0.0]), i3)]
+    M = sum(p[0] for p in parts); com = sum(p[0] * p[1] for p in parts) / M
+    tensor = sum(I + m * ((com - c) @ (com - c) * np.eye(3) - np.outer(com - c, com - c)) for m, c, I in parts)
+    assert mp[0] == pytest.approx(1 / M, rel=1e-6)
+    np.testing.assert_allclose(mp[1:4], com, atol=1e-6)
+    R = rot(mp[7:11])
+    np.testing.assert_allclose(R @ np.diag(1 / mp[4:7]) @ R.T, tensor, atol=5e-6)
+    w = OracleWorld(S.compound_bodies(4))
+    w.step(400)
+    pos, vel = w.read()
+    assert np.isfinite(pos).all() and np.abs(vel).max() < 0.05 and pos[1:, 1].min() > 0.05
+
+
 # test_staged.rs:86-148 scene: the 3-cube stack AND the elevated pair joined by a revolute joint about Z rest after 60
 # steps; a hinge keeps its axis, a fixed joint keeps the relative pose (lock_angular, joint_constraint_helper.rs:628-673).
 def test_staged_scene_with_revolute_pair_and_locked_angular_axes():

@@ -27,6 +27,12 @@ def run(name, scene, steps, actions=None):
             for b in bad[:4]:
                 print(f"   body {b}: sleep gpu={int(gs[b])} oracle={int(os_[b])}\n     gpu pos {gp[b]} vel {gv[b]}\n     ora pos {op[b]} vel {ov[b]}")
             print(f"   gpu counters {g.counters()}\n   oracle stats {o.stats()}")
+            gm, gn, gi = g.contacts(); om, on, oi = o.manifolds()
+            gk = {(a, b): (c, n, tuple(i)) for (a, b, c, n), i in zip(gm.tolist(), gi.tolist())}
+            ok = {(a, b): (c, n, tuple(i)) for (a, b, c, n), i in zip(om.tolist(), oi.tolist())}
+            for key in sorted(set(gk) | set(ok)):
+                if gk.get(key) != ok.get(key):
+                    print(f"   manifold {key}: gpu {gk.get(key)}\n                     ora {ok.get(key)}")
             print(f"   sleeping gpu {gs.astype(int).tolist()[:40]}\n   sleeping ora {os_.astype(int).tolist()[:40]}")
             return False
     print(f"[{name}] ok: {steps} steps bit-exact, asleep at the end: {int(g.sleeping().sum())}")
@@ -58,6 +64,11 @@ def kin_targets(g, o, k):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "compound":
+        run("compound 12", S.compound_bodies(12), 80)
+        run("compound 2", S.compound_bodies(2), 200)
+        run("compound 1 (hammer)", S.compound_bodies(1), 200)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "kin":
         run("kinematic velocity platform", S.kinematic_platform(False), 150)
         acts = {k: (lambda g, o, k=k: kin_targets(g, o, k)) for k in list(range(1, 91)) + [212]}
