@@ -78,6 +78,7 @@ typedef struct rp_body_desc {
     int32_t gyroscopic;
     int32_t allow_fast_rotation;
     int32_t can_sleep; /* RigidBodyBuilder::can_sleep (rigid_body.rs:1845): 1 = RigidBodyActivation::active(), 0 = cannot_sleep() */
+    uint32_t locked_axes; /* LockedAxes (rigid_body_components.rs:271-288): bit0..2 TRANSLATION_LOCKED_X/Y/Z, bit3..5 ROTATION_LOCKED_X/Y/Z */
 } rp_body_desc;
 
 /* ColliderBuilder — /root/reference/src/geometry/collider.rs:600-1130 */

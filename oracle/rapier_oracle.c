@@ -60,6 +60,7 @@ typedef struct {
     v3 force, torque, user_force, user_torque;
     float linear_damping, angular_damping, gravity_scale, additional_mass;
     int dominance, gyroscopic, allow_fast_rotation;
+    uint32_t locked_axes; /* LockedAxes — rigid_body_components.rs:271-288 */
     int ncolliders, first_collider;
     uint32_t solver_id; /* active_set_id, RO_NO_BODY for bodies outside the active set */
     /* RigidBodyActivation — rigid_body_components.rs:1300-1480 */
@@ -272,6 +273,15 @@ static void update_world_mass_properties(Body *b) {
     if (b->body_type == RO_BODY_DYNAMIC) {
         b->effective_inv_mass = V3(b->inv_mass, b->inv_mass, b->inv_mass);
         b->effective_world_inv_inertia = world_inv_inertia(b->inv_principal_inertia, b->principal_frame, b->position.r);
+        /* translation / rotation locking (:533-571) */
+        uint32_t la = b->locked_axes;
+        if (la & 1u) b->effective_inv_mass.x = 0.0f;
+        if (la & 2u) b->effective_inv_mass.y = 0.0f;
+        if (la & 4u) b->effective_inv_mass.z = 0.0f;
+        sym3 *ii = &b->effective_world_inv_inertia;
+        if (la & 8u) { ii->m11 = 0.0f; ii->m12 = 0.0f; ii->m13 = 0.0f; }
+        if (la & 16u) { ii->m22 = 0.0f; ii->m12 = 0.0f; ii->m23 = 0.0f; }
+        if (la & 32u) { ii->m33 = 0.0f; ii->m13 = 0.0f; ii->m23 = 0.0f; }
     } else {
         b->effective_inv_mass = V3(0, 0, 0);
         sym3 z = {0, 0, 0, 0, 0, 0}; b->effective_world_inv_inertia = z;
@@ -475,6 +485,7 @@ int32_t ro_add_body(ro_world *w, const ro_body_desc *d) {
     b->linear_damping = d->linear_damping; b->angular_damping = d->angular_damping;
     b->gravity_scale = d->gravity_scale; b->additional_mass = d->additional_mass;
     b->dominance = d->dominance; b->gyroscopic = d->gyroscopic; b->allow_fast_rotation = d->allow_fast_rotation;
+    b->locked_axes = d->locked_axes & 0x3fu;
     b->principal_frame = qident();
     b->solver_id = RO_NO_BODY;
     /* RigidBodyActivation::active() / cannot_sleep() — rigid_body_components.rs:1354-1385 */

@@ -68,6 +68,7 @@ typedef struct ro_body_desc {
     int32_t gyroscopic;     /* default 1 — rigid_body.rs:1579 */
     int32_t allow_fast_rotation;
     int32_t can_sleep;      /* RigidBodyBuilder::can_sleep — RigidBodyActivation::active() vs cannot_sleep() */
+    uint32_t locked_axes;   /* LockedAxes: bit0..2 TRANSLATION_LOCKED_X/Y/Z, bit3..5 ROTATION_LOCKED_X/Y/Z */
 } ro_body_desc;
 
 typedef struct ro_collider_desc {

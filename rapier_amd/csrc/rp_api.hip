@@ -639,6 +639,7 @@ static BodyRow pack_body(const HostBody &b) {
     if (bd.gyroscopic && bd.body_type == RP_BODY_DYNAMIC) fl |= RP_BF_GYRO; // gyroscopic forces: dynamic bodies only (worker.rs:86)
     if (bd.allow_fast_rotation) fl |= RP_BF_FASTROT;
     fl |= ((int)(bd.dominance & 0xff)) << RP_BF_DOM_SHIFT;
+    fl |= ((int)(bd.locked_axes & 0x3fu)) << RP_BF_LOCK_SHIFT;
     if (b.sleeping && !b.removed && bd.body_type != RP_BODY_FIXED) fl |= RP_BF_SLEEPING;
     o.fl = fl;
     // RigidBodyActivation::active() / cannot_sleep() — rigid_body_components.rs:1354-1385

@@ -435,6 +435,7 @@ RP_DEV void body_writeback(const DevWorld &w, int i, V3 slin, V3 sang, Q4 rot, V
     w.b_pos[i] = f4(t, 0.0f); w.b_rot[i] = f4(rot);
     w.b_wcom[i] = f4(qrot(rot, lcom) + t, 0.0f);
     Sym3 ii = world_inv_inertia(v3(w.b_invpi[i]), q4(w.b_pframe[i]), rot);
+    apply_locked_rotations((w.b_flags[i] >> RP_BF_LOCK_SHIFT) & 0x3f, ii);
     w.b_eii0[i] = make_float4(ii.m11, ii.m12, ii.m13, ii.m22);
     w.b_eii1[i] = make_float4(ii.m23, ii.m33, 0.0f, 0.0f);
 }

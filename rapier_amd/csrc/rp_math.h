@@ -73,6 +73,13 @@ RP_HD Pose pose_inv_mul(Pose a, Pose b) { Pose r; Q4 ai = qconj(a.r); r.r = qmul
 RP_HD V3 pose_tp(Pose a, V3 p) { return qrot(a.r, p) + a.t; }
 RP_HD V3 pose_itp(Pose a, V3 p) { return qrot_inv(a.r, p - a.t); }
 
+// translation / rotation locking of update_world_mass_properties (rigid_body_components.rs:533-571); `la` = LockedAxes bits
+RP_HD void apply_locked_rotations(int la, Sym3 &ii) {
+    if (la & 8) { ii.m11 = 0.0f; ii.m12 = 0.0f; ii.m13 = 0.0f; }
+    if (la & 16) { ii.m22 = 0.0f; ii.m12 = 0.0f; ii.m23 = 0.0f; }
+    if (la & 32) { ii.m33 = 0.0f; ii.m13 = 0.0f; ii.m23 = 0.0f; }
+}
+
 // Portable single-precision atan (Cephes atanf scheme, only + - * /): identical to oracle/ro_math.h so both sides
 // agree bit for bit (libm's and ocml's atan2f do not).
 RP_HD float rp_atan_portable(float x) {

@@ -135,8 +135,10 @@ __global__ void k_init_bodies(DevWorld w) {
     float4 li = w.b_lcom_invm[i];
     w.b_wcom[i] = f4(qrot(rot, v3(li)) + t, 0.0f);
     if ((fl & RP_BF_TYPE_MASK) == RP_BODY_DYNAMIC) {
-        w.b_eim[i] = make_float4(li.w, li.w, li.w, 0.0f);
+        int la = (fl >> RP_BF_LOCK_SHIFT) & 0x3f;
+        w.b_eim[i] = make_float4((la & 1) ? 0.0f : li.w, (la & 2) ? 0.0f : li.w, (la & 4) ? 0.0f : li.w, 0.0f);
         Sym3 ii = world_inv_inertia(v3(w.b_invpi[i]), q4(w.b_pframe[i]), rot);
+        apply_locked_rotations(la, ii);
         w.b_eii0[i] = make_float4(ii.m11, ii.m12, ii.m13, ii.m22);
         w.b_eii1[i] = make_float4(ii.m23, ii.m33, 0.0f, 0.0f);
     } else {

@@ -28,6 +28,7 @@
 #define RP_BF_FASTROT 0x8
 #define RP_BF_SLEEPING 0x10          // RigidBodyActivation::sleeping (dynamic bodies only)
 #define RP_BF_DOM_SHIFT 8
+#define RP_BF_LOCK_SHIFT 16           // LockedAxes (6 bits): translation x,y,z then rotation x,y,z
 
 // pair flag bits
 #define RP_PF_RECYCLE 0x1

@@ -24,7 +24,7 @@ BODY_DTYPE = np.dtype([
     ("linvel", "<f4", 3), ("angvel", "<f4", 3),
     ("linear_damping", "<f4"), ("angular_damping", "<f4"), ("gravity_scale", "<f4"),
     ("additional_mass", "<f4"), ("dominance", "<i4"), ("gyroscopic", "<i4"),
-    ("allow_fast_rotation", "<i4"), ("can_sleep", "<i4"),
+    ("allow_fast_rotation", "<i4"), ("can_sleep", "<i4"), ("locked_axes", "<u4"),
 ], align=False)
 COLLIDER_DTYPE = np.dtype([
     ("shape", "<i4"), ("half_extents", "<f4", 3), ("translation", "<f4", 3), ("rotation", "<f4", 4),
@@ -90,7 +90,7 @@ def default_params() -> np.ndarray:
 
 def body_desc(body_type=BODY_DYNAMIC, translation=(0, 0, 0), rotation=(0, 0, 0, 1), linvel=(0, 0, 0),
               angvel=(0, 0, 0), linear_damping=0.0, angular_damping=0.0, gravity_scale=1.0,
-              additional_mass=0.0, dominance=0, gyroscopic=1, allow_fast_rotation=0, can_sleep=0) -> np.ndarray:
+              additional_mass=0.0, dominance=0, gyroscopic=1, allow_fast_rotation=0, can_sleep=0, locked_axes=0) -> np.ndarray:
     """RigidBodyBuilder defaults — /root/reference/src/dynamics/rigid_body.rs:1560-1600 — except
     ``can_sleep``: the builder's default is true, every b3d benchmark scene calls ``.can_sleep(false)``
     (b3d_many_pyramids.rs:52) and so do the generators here unless a scene asks for sleeping."""
@@ -103,6 +103,7 @@ def body_desc(body_type=BODY_DYNAMIC, translation=(0, 0, 0), rotation=(0, 0, 0, 
     b["gravity_scale"], b["additional_mass"] = gravity_scale, additional_mass
     b["dominance"], b["gyroscopic"], b["allow_fast_rotation"] = dominance, gyroscopic, allow_fast_rotation
     b["can_sleep"] = can_sleep
+    b["locked_axes"] = locked_axes  # LockedAxes bits: 1,2,4 = translation x,y,z; 8,16,32 = rotation x,y,z
     return b
 
 
@@ -439,4 +440,23 @@ def compound_bodies(n: int = 12) -> Scene:
         else:            # L-shape
             s.add_collider(b, half_extents=(0.5, 0.15, 0.15), translation=(0.5, 0.0, 0.0), density=2.0)
             s.add_collider(b, half_extents=(0.15, 0.5, 0.15), translation=(0.0, 0.5, 0.0), density=2.0)
+    return s
+
+
+def locked_axes_scene() -> Scene:
+    """LockedAxes test scene (not a reference scene): spinning cubes dropped on a slab and on each other with different
+    translation / rotation locks (RigidBodyBuilder::locked_axes)."""
+    s = Scene(name="locked_axes", gravity=(0.0, -9.81, 0.0))
+    g = s.add_body(body_type=BODY_FIXED, translation=(0.0, -0.5, 0.0))
+    s.add_collider(g, half_extents=(10.0, 0.5, 10.0))
+    locks = [0x00, 0x38, 0x04 | 0x08 | 0x10, 0x3F, 0x07, 0x10, 0x01, 0x22]
+    for i, la in enumerate(locks):
+        # a locked degree of freedom keeps whatever velocity it starts with (only its inverse mass is zeroed): start those at rest
+        lv = (0.0 if la & 1 else 0.5, 0.0, 0.0 if la & 4 else _f(0.3 * (i % 3)))
+        av = (0.0 if la & 8 else 1.0, 0.0 if la & 16 else 0.5, 0.0 if la & 32 else -0.7)
+        b = s.add_body(translation=(_f(1.2 * (i % 4) - 1.8), _f(1.0 + 1.3 * (i // 4)), _f(0.2 * (i % 2))), rotation=(0.1, 0.05, 0.0, 0.9937304),
+                       linvel=lv, angvel=av, locked_axes=la)
+        s.add_collider(b, half_extents=(0.4, 0.5, 0.3), density=1.5)
+    top = s.add_body(translation=(-1.6, 4.0, 0.1), angvel=(0.0, 0.0, 2.0))   # falls onto the locked ones
+    s.add_collider(top, half_extents=(1.5, 0.2, 0.5))
     return s

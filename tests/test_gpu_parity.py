@@ -430,6 +430,12 @@ def test_sleep_full_size_many_pyramids():
     assert c["num_sleeping_bodies"] == 10780 and c["num_manifolds"] == 0
 
 
+def test_locked_axes_bit_exact():
+    g, o = _compare(S.locked_axes_scene(), [1, 2, 10, 60, 240])
+    pos, _ = g.read_bodies()
+    np.testing.assert_array_equal(pos[4, :3], np.array(S.locked_axes_scene().bodies[4]["translation"]))   # fully locked body
+
+
 def test_compound_bodies_bit_exact():
     """Several colliders per body at arbitrary pos_wrt_parent: summed MassProperties (offset centre of mass, principal
     frame from the diagonalised tensor), pairs sharing a body, gyroscopic term in a non-trivial principal frame."""

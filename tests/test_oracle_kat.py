@@ -228,6 +228,21 @@ def test_coulomb_pyramid_rests_and_carries_its_weight():
     assert imp[ground].sum() == pytest.approx(weight, rel=0.01)
 
 
+# LockedAxes (rigid_body_components.rs:533-571): a fully locked body never moves, rotation locks keep the orientation,
+# a translation lock keeps that coordinate.
+def test_locked_axes():
+    sc = S.locked_axes_scene()
+    w = OracleWorld(sc)
+    p0, _ = w.read()
+    w.step(240)
+    p, v = w.read()
+    np.testing.assert_array_equal(p[4], p0[4])                                  # 0x3F: fully locked, even when hit
+    np.testing.assert_array_equal(p[2, 3:], p0[2, 3:])                          # 0x38: rotations locked
+    assert p[3, 2] == p0[3, 2]                                                  # 0x1c: z translation locked
+    np.testing.assert_array_equal(p[5, :3], p0[5, :3])                          # 0x07: no translation
+    assert p[1, 1] < p0[1, 1] and np.isfinite(p).all()                          # the free one fell
+
+
 # Compound bodies: the summed MassProperties of several colliders (parallel-axis theorem + diagonalisation) against a
 # float64 reference, and a hammer that comes to rest head-down-ish without gaining energy.
 def test_compound_mass_properties_and_rest():
