@@ -200,6 +200,13 @@ int32_t rp_bodies_read(rp_world *w, int32_t n, const uint64_t *handles, float *p
  * untouched.  The written bodies are woken (strong); a moved body also wakes every body it has a contact
  * pair with (pair_management.rs:236-258). */
 int32_t rp_bodies_write(rp_world *w, int32_t n, const uint64_t *handles, const float *pos7, const float *vel6);
+/* RigidBody::{reset_forces, reset_torques} (when `reset` != 0) followed by add_force / add_torque (.., wake_up = true)
+ * (rigid_body.rs:1145-1252) for n dynamic bodies: force3 / torque3 are n x 3 (NULL = skip).  The user force persists across
+ * steps until reset, exactly like RigidBodyForces::user_force. */
+int32_t rp_bodies_add_force(rp_world *w, int32_t n, const uint64_t *handles, const float *force3, const float *torque3, int32_t reset);
+/* RigidBody::{apply_impulse, apply_torque_impulse} (.., wake_up = true) (rigid_body.rs:1304-1343): linvel += impulse *
+ * effective_inv_mass, angvel += effective_world_inv_inertia * torque_impulse. */
+int32_t rp_bodies_apply_impulse(rp_world *w, int32_t n, const uint64_t *handles, const float *impulse3, const float *torque_impulse3);
 /* Sleeping — RigidBodyActivation (rigid_body_components.rs:1300-1480), whole-island sleep
  * (island_manager/manager.rs:335-388, sleep.rs).  Bodies built with can_sleep = 1 fall asleep with their whole
  * contact island once EVERY member stayed below the motion thresholds for time_until_sleep (0.5 s), and wake

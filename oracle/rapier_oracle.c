@@ -598,6 +598,28 @@ void ro_body_mass_props(const ro_world *w, int32_t body, float out11[11]) {
     out11[4] = b->inv_principal_inertia.x; out11[5] = b->inv_principal_inertia.y; out11[6] = b->inv_principal_inertia.z;
     out11[7] = b->principal_frame.x; out11[8] = b->principal_frame.y; out11[9] = b->principal_frame.z; out11[10] = b->principal_frame.w;
 }
+void ro_add_force(ro_world *w, int32_t body, const float force[3], const float torque[3], int32_t reset) {
+    Body *b = &w->bodies[body];
+    if (reset) {
+        if (b->user_force.x != 0.0f || b->user_force.y != 0.0f || b->user_force.z != 0.0f) { b->user_force = V3(0, 0, 0); wake_request(w, body, 1); }
+        if (b->user_torque.x != 0.0f || b->user_torque.y != 0.0f || b->user_torque.z != 0.0f) { b->user_torque = V3(0, 0, 0); wake_request(w, body, 1); }
+    }
+    if (b->body_type != RO_BODY_DYNAMIC) return;
+    if (force && (force[0] != 0.0f || force[1] != 0.0f || force[2] != 0.0f)) { b->user_force = vadd(b->user_force, V3(force[0], force[1], force[2])); wake_request(w, body, 1); }
+    if (torque && (torque[0] != 0.0f || torque[1] != 0.0f || torque[2] != 0.0f)) { b->user_torque = vadd(b->user_torque, V3(torque[0], torque[1], torque[2])); wake_request(w, body, 1); }
+}
+void ro_apply_impulse(ro_world *w, int32_t body, const float impulse[3], const float torque_impulse[3]) {
+    Body *b = &w->bodies[body];
+    if (b->body_type != RO_BODY_DYNAMIC) return;
+    if (impulse && (impulse[0] != 0.0f || impulse[1] != 0.0f || impulse[2] != 0.0f)) {
+        b->linvel = vadd(b->linvel, vcmul(V3(impulse[0], impulse[1], impulse[2]), b->effective_inv_mass));
+        wake_request(w, body, 1);
+    }
+    if (torque_impulse && (torque_impulse[0] != 0.0f || torque_impulse[1] != 0.0f || torque_impulse[2] != 0.0f)) {
+        b->angvel = vadd(b->angvel, sym3_mul(b->effective_world_inv_inertia, V3(torque_impulse[0], torque_impulse[1], torque_impulse[2])));
+        wake_request(w, body, 1);
+    }
+}
 void ro_wake_up(ro_world *w, int32_t body, int32_t strong) { if (body >= 0 && body < w->nbodies) wake_request(w, body, strong); }
 void ro_read_sleeping(const ro_world *w, int32_t *sleeping) {
     for (int i = 0; i < w->nbodies; ++i) sleeping[i] = w->bodies[i].body_type != RO_BODY_FIXED && w->bodies[i].sleeping;

@@ -120,6 +120,11 @@ void ro_set_body_vel(ro_world *w, int32_t body, const float linvel[3], const flo
  * max_force_magnitude).  Return the number of pending events (only `cap` are written); the lists are cleared. */
 int32_t ro_collision_events_drain(ro_world *w, int32_t cap, int32_t *out5);
 int32_t ro_force_events_drain(ro_world *w, int32_t cap, int32_t *meta4, float *vals8);
+/* RigidBody::{reset_forces, reset_torques} (when `reset`), then add_force / add_torque (.., wake_up = true), rigid_body.rs:1145-1252:
+ * the user force persists across steps until reset.  NULL vectors are skipped; dynamic bodies only. */
+void ro_add_force(ro_world *w, int32_t body, const float force[3], const float torque[3], int32_t reset);
+/* RigidBody::{apply_impulse, apply_torque_impulse} (.., wake_up = true), rigid_body.rs:1304-1343 */
+void ro_apply_impulse(ro_world *w, int32_t body, const float impulse[3], const float torque_impulse[3]);
 /* RigidBody::set_next_kinematic_position (rigid_body.rs:1085-1093): kinematic bodies only; wakes when the pose differs */
 void ro_set_next_kinematic_position(ro_world *w, int32_t body, const float pos7[7]);
 /* RigidBody::set_position(.., wake_up = true) */

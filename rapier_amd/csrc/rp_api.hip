@@ -1185,6 +1185,68 @@ extern "C" int32_t rp_bodies_wake_up(rp_world *w, int32_t n, const uint64_t *han
     }
     return RP_OK;
 }
+// RigidBody::{reset_forces, reset_torques, add_force, add_torque} — rigid_body.rs:1145-1252
+extern "C" int32_t rp_bodies_add_force(rp_world *w, int32_t n, const uint64_t *handles, const float *force3, const float *torque3, int32_t reset) {
+    if (!w || n < 0 || (n > 0 && !handles)) return RP_ERR_INVALID;
+    HIPCHK(w, hipSetDevice(w->device));
+    if (!w->finalized) { int r = finalize(w); if (r != RP_OK) return r; }
+    { int r = settle(w); if (r != RP_OK) return r; }
+    for (int i = 0; i < n; ++i) {
+        int b = (int)(handles[i] & 0xffffffffull);
+        if ((handles[i] >> 32) != 0 || b >= w->dw.n_bodies || w->bodies[b].removed) { w->err = "rp_bodies_add_force: invalid handle"; return RP_ERR_INVALID; }
+        float4 f, t; bool wake = false;
+        HIPCHK(w, hipMemcpy(&f, w->dw.b_uforce + b, sizeof(f), hipMemcpyDeviceToHost));
+        HIPCHK(w, hipMemcpy(&t, w->dw.b_utorque + b, sizeof(t), hipMemcpyDeviceToHost));
+        if (reset) {
+            if (f.x != 0.0f || f.y != 0.0f || f.z != 0.0f) { f = mk4(0, 0, 0, 0); wake = true; }
+            if (t.x != 0.0f || t.y != 0.0f || t.z != 0.0f) { t = mk4(0, 0, 0, 0); wake = true; }
+        }
+        if (w->bodies[b].d.body_type == RP_BODY_DYNAMIC) {
+            const float *ff = force3 ? force3 + 3 * i : nullptr, *tt = torque3 ? torque3 + 3 * i : nullptr;
+            if (ff && (ff[0] != 0.0f || ff[1] != 0.0f || ff[2] != 0.0f)) { f.x = f.x + ff[0]; f.y = f.y + ff[1]; f.z = f.z + ff[2]; wake = true; }
+            if (tt && (tt[0] != 0.0f || tt[1] != 0.0f || tt[2] != 0.0f)) { t.x = t.x + tt[0]; t.y = t.y + tt[1]; t.z = t.z + tt[2]; wake = true; }
+        }
+        HIPCHK(w, hipMemcpy(w->dw.b_uforce + b, &f, sizeof(f), hipMemcpyHostToDevice));
+        HIPCHK(w, hipMemcpy(w->dw.b_utorque + b, &t, sizeof(t), hipMemcpyHostToDevice));
+        if (wake && w->dw.sleep_enabled) { int r = queue_wake(w, b, 2); if (r != RP_OK) return r; }
+    }
+    return RP_OK;
+}
+// RigidBody::{apply_impulse, apply_torque_impulse} — rigid_body.rs:1304-1343
+extern "C" int32_t rp_bodies_apply_impulse(rp_world *w, int32_t n, const uint64_t *handles, const float *impulse3, const float *torque_impulse3) {
+    if (!w || n < 0 || (n > 0 && !handles)) return RP_ERR_INVALID;
+    HIPCHK(w, hipSetDevice(w->device));
+    if (!w->finalized) { int r = finalize(w); if (r != RP_OK) return r; }
+    { int r = settle(w); if (r != RP_OK) return r; }
+    for (int i = 0; i < n; ++i) {
+        int b = (int)(handles[i] & 0xffffffffull);
+        if ((handles[i] >> 32) != 0 || b >= w->dw.n_bodies || w->bodies[b].removed) { w->err = "rp_bodies_apply_impulse: invalid handle"; return RP_ERR_INVALID; }
+        if (w->bodies[b].d.body_type != RP_BODY_DYNAMIC) continue;
+        const float *p = impulse3 ? impulse3 + 3 * i : nullptr, *q = torque_impulse3 ? torque_impulse3 + 3 * i : nullptr;
+        bool wake = false;
+        if (p && (p[0] != 0.0f || p[1] != 0.0f || p[2] != 0.0f)) {
+            float4 lv, im;
+            HIPCHK(w, hipMemcpy(&lv, w->dw.b_linvel + b, sizeof(lv), hipMemcpyDeviceToHost));
+            HIPCHK(w, hipMemcpy(&im, w->dw.b_eim + b, sizeof(im), hipMemcpyDeviceToHost));
+            lv.x = lv.x + p[0] * im.x; lv.y = lv.y + p[1] * im.y; lv.z = lv.z + p[2] * im.z;
+            HIPCHK(w, hipMemcpy(w->dw.b_linvel + b, &lv, sizeof(lv), hipMemcpyHostToDevice));
+            wake = true;
+        }
+        if (q && (q[0] != 0.0f || q[1] != 0.0f || q[2] != 0.0f)) {
+            float4 av, a, c;
+            HIPCHK(w, hipMemcpy(&av, w->dw.b_angvel + b, sizeof(av), hipMemcpyDeviceToHost));
+            HIPCHK(w, hipMemcpy(&a, w->dw.b_eii0 + b, sizeof(a), hipMemcpyDeviceToHost));
+            HIPCHK(w, hipMemcpy(&c, w->dw.b_eii1 + b, sizeof(c), hipMemcpyDeviceToHost));
+            // SdpMatrix3 * v with (m11 m12 m13 m22 | m23 m33)
+            float rx = a.x * q[0] + a.y * q[1] + a.z * q[2], ry = a.y * q[0] + a.w * q[1] + c.x * q[2], rz = a.z * q[0] + c.x * q[1] + c.y * q[2];
+            av.x = av.x + rx; av.y = av.y + ry; av.z = av.z + rz;
+            HIPCHK(w, hipMemcpy(w->dw.b_angvel + b, &av, sizeof(av), hipMemcpyHostToDevice));
+            wake = true;
+        }
+        if (wake && w->dw.sleep_enabled) { int r = queue_wake(w, b, 2); if (r != RP_OK) return r; }
+    }
+    return RP_OK;
+}
 // RigidBody::set_next_kinematic_position (rigid_body.rs:1085-1093)
 extern "C" int32_t rp_bodies_set_next_kinematic_position(rp_world *w, int32_t n, const uint64_t *handles, const float *pos7) {
     if (!w || n < 0 || (n > 0 && (!handles || !pos7))) return RP_ERR_INVALID;

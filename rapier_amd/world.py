@@ -263,6 +263,22 @@ class PhysicsWorld:
         _check(self._ptr, self._lib.rp_bodies_write(self._ptr, len(h), h.ctypes.data, None if p is None else p.ctypes.data,
                                                   None if v is None else v.ctypes.data), "rp_bodies_write")
 
+    def add_force(self, handles, force=None, torque=None, reset: bool = False):
+        """RigidBody::{reset_forces, reset_torques} (when ``reset``) then add_force / add_torque(.., wake_up=true)."""
+        h = np.ascontiguousarray(np.atleast_1d(np.asarray(handles, dtype=np.uint64)))
+        f = None if force is None else np.ascontiguousarray(np.asarray(force, np.float32).reshape(len(h), 3))
+        t = None if torque is None else np.ascontiguousarray(np.asarray(torque, np.float32).reshape(len(h), 3))
+        _check(self._ptr, self._lib.rp_bodies_add_force(self._ptr, len(h), h.ctypes.data, None if f is None else f.ctypes.data,
+                                                      None if t is None else t.ctypes.data, 1 if reset else 0), "rp_bodies_add_force")
+
+    def apply_impulse(self, handles, impulse=None, torque_impulse=None):
+        """RigidBody::{apply_impulse, apply_torque_impulse}(.., wake_up=true)."""
+        h = np.ascontiguousarray(np.atleast_1d(np.asarray(handles, dtype=np.uint64)))
+        f = None if impulse is None else np.ascontiguousarray(np.asarray(impulse, np.float32).reshape(len(h), 3))
+        t = None if torque_impulse is None else np.ascontiguousarray(np.asarray(torque_impulse, np.float32).reshape(len(h), 3))
+        _check(self._ptr, self._lib.rp_bodies_apply_impulse(self._ptr, len(h), h.ctypes.data, None if f is None else f.ctypes.data,
+                                                          None if t is None else t.ctypes.data), "rp_bodies_apply_impulse")
+
     def set_next_kinematic_position(self, handles, pos7):
         """RigidBody::set_next_kinematic_position (rigid_body.rs:1085-1093) for kinematic bodies."""
         h = np.ascontiguousarray(np.atleast_1d(np.asarray(handles, dtype=np.uint64)))

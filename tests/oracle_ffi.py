@@ -55,6 +55,8 @@ def lib():
         L.ro_collision_events_drain.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         L.ro_force_events_drain.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.ro_body_mass_props.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        L.ro_add_force.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
+        L.ro_apply_impulse.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.ro_wake_up.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         L.ro_read_sleeping.argtypes = [C.c_void_p, C.c_void_p]
         L.ro_remove_body.argtypes = [C.c_void_p, C.c_int32]
@@ -161,6 +163,16 @@ class OracleWorld:
         out = np.zeros(11, np.float32)
         lib().ro_body_mass_props(self._w, int(body), out.ctypes.data)
         return out
+
+    def add_force(self, body, force=None, torque=None, reset=False):
+        f = None if force is None else np.ascontiguousarray(force, np.float32)
+        t = None if torque is None else np.ascontiguousarray(torque, np.float32)
+        lib().ro_add_force(self._w, int(body), None if f is None else f.ctypes.data, None if t is None else t.ctypes.data, 1 if reset else 0)
+
+    def apply_impulse(self, body, impulse=None, torque_impulse=None):
+        f = None if impulse is None else np.ascontiguousarray(impulse, np.float32)
+        t = None if torque_impulse is None else np.ascontiguousarray(torque_impulse, np.float32)
+        lib().ro_apply_impulse(self._w, int(body), None if f is None else f.ctypes.data, None if t is None else t.ctypes.data)
 
     def wake_up(self, body, strong=True):
         lib().ro_wake_up(self._w, int(body), 1 if strong else 0)

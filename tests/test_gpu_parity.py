@@ -430,6 +430,29 @@ def test_sleep_full_size_many_pyramids():
     assert c["num_sleeping_bodies"] == 10780 and c["num_manifolds"] == 0
 
 
+def test_user_forces_and_impulses_bit_exact():
+    """RigidBody::{add_force, add_torque, reset_forces, apply_impulse, apply_torque_impulse} (rigid_body.rs:1145-1343)."""
+    sc = S.box_stack(3).enable_sleep()
+    g, o = PhysicsWorld.from_scene(sc), OracleWorld(sc)
+    g.step(60); o.step(60)
+    assert g.sleeping()[1:].all()
+    g.apply_impulse([3], impulse=(0.4, 2.5, 0.1), torque_impulse=(0.0, 0.3, 0.1)); o.apply_impulse(3, (0.4, 2.5, 0.1), (0.0, 0.3, 0.1))   # wakes the stack
+    for n in (1, 10, 40):
+        g.step(n); o.step(n)
+        _same_sleep_state(g, o, f"after the impulse, +{n}")
+    g.add_force([2], force=(0.0, 25.0, 3.0), torque=(0.0, 0.0, 1.0)); o.add_force(2, (0.0, 25.0, 3.0), (0.0, 0.0, 1.0))   # persistent thrust > weight
+    for n in (1, 20):
+        g.step(n); o.step(n)
+        _same_sleep_state(g, o, f"under thrust, +{n}")
+    pos, vel = g.read_bodies()
+    assert vel[2, 1] > 1.0                                      # the middle box lifts the top one
+    g.add_force([2], reset=True); o.add_force(2, reset=True)    # reset_forces + reset_torques
+    for n in (1, 60, 120):
+        g.step(n); o.step(n)
+        _same_sleep_state(g, o, f"thrust removed, +{n}")
+    assert g.sleeping()[1:].all()
+
+
 def test_locked_axes_bit_exact():
     g, o = _compare(S.locked_axes_scene(), [1, 2, 10, 60, 240])
     pos, _ = g.read_bodies()
