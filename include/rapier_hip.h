@@ -173,8 +173,8 @@ int32_t rp_bodies_insert(rp_world *w, int32_t n, const rp_body_desc *descs, uint
 int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider_desc *descs, const uint64_t *parents, uint64_t *handles_out);
 /* ImpulseJointSet::insert ×n (impulse_joint_set.rs).  Device path scope: locked axes only — any JointAxesMask of locked
  * linear / angular axes (spherical 0x07, revolute 0x37, prismatic without limits 0x3e, fixed 0x3f; the free axis is the
- * local frame's X axis as in RevoluteJointBuilder / PrismaticJointBuilder), contacts between the two bodies enabled;
- * limits, motors, coupled axes and contacts_enabled = 0 are refused with RP_ERR_INVALID. */
+ * local frame's X axis as in RevoluteJointBuilder / PrismaticJointBuilder); contacts_enabled = 0 filters the contact pairs between
+ * the two bodies (pair_update.rs:191-201); limits, motors, coupled axes are refused with RP_ERR_INVALID. */
 int32_t rp_impulse_joints_insert(rp_world *w, int32_t n, const rp_joint_desc *descs, uint64_t *handles_out);
 /* ImpulseJoint::impulses (per locked linear dof, as written back by the last step) and the persistent
  * solver colour of n joints (NULL handles = all, insertion order). */

@@ -174,6 +174,7 @@ struct ro_world {
     int step_seq;       /* 1-based number of the step in progress */
     int *uf;            /* union-find scratch of the sleep islands */
     int nfree_colliders; /* colliders inserted without a parent */
+    uint64_t *nc_keys; int n_nc, nc_dirty; /* sorted (min body, max body) keys of the joints with contacts_enabled = false */
     int32_t *col_events; int ncol_events, cap_col_events;       /* 5 ints per event */
     int32_t *force_meta; float *force_vals; int nforce_events, cap_force_events;
 };
@@ -253,7 +254,7 @@ void ro_world_free(ro_world *w) {
     free(w->bodies); free(w->colliders); free(w->pairs); free(w->map_keys); free(w->map_vals);
     free(w->color_masks); free(w->vels); free(w->incr); free(w->poses); free(w->gyro); free(w->flags);
     free(w->dyn_bodies); free(w->cons); free(w->joints); free(w->active_joints); free(w->joint_order);
-    free(w->joint_rows); free(w->joint_body_colors); free(w->uf); free(w->col_events); free(w->force_meta); free(w->force_vals); free(w);
+    free(w->joint_rows); free(w->joint_body_colors); free(w->uf); free(w->col_events); free(w->force_meta); free(w->force_vals); free(w->nc_keys); free(w);
 }
 
 /* parry MassProperties::world_inv_inertia */
@@ -921,6 +922,28 @@ static int effective_dominance_group(const ro_world *w, int body) {
     return 128;
 }
 
+static int u64_cmp(const void *a, const void *b) { uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b; return x < y ? -1 : x > y; }
+/* ImpulseJointSet::joints_between(b1, b2).any(|j| !j.data.contacts_enabled) — pair_update.rs:191-201 */
+static void joints_disable_contacts_prepare(ro_world *w) { /* before the (parallel) pair loop */
+    if (w->nc_dirty) {
+        w->n_nc = 0;
+        w->nc_keys = (uint64_t *)realloc(w->nc_keys, sizeof(uint64_t) * (size_t)(w->njoints + 1));
+        for (int i = 0; i < w->njoints; ++i) {
+            const Joint *j = &w->joints[i];
+            if (j->removed || j->contacts_enabled) continue;
+            uint32_t lo = (uint32_t)(j->body1 < j->body2 ? j->body1 : j->body2), hi = (uint32_t)(j->body1 < j->body2 ? j->body2 : j->body1);
+            w->nc_keys[w->n_nc++] = ((uint64_t)lo << 32) | hi;
+        }
+        qsort(w->nc_keys, w->n_nc, sizeof(uint64_t), u64_cmp);
+        w->nc_dirty = 0;
+    }
+}
+static int joints_disable_contacts(const ro_world *w, int b1, int b2) {
+    if (w->n_nc == 0) return 0;
+    uint32_t lo = (uint32_t)(b1 < b2 ? b1 : b2), hi = (uint32_t)(b1 < b2 ? b2 : b1);
+    uint64_t key = ((uint64_t)lo << 32) | hi;
+    return bsearch(&key, w->nc_keys, w->n_nc, sizeof(uint64_t), u64_cmp) != NULL;
+}
 /* outcome: 0 = recycled, 1 = full update; *tr_out->pair = -1 when the pair has no transition */
 static int process_pair(ro_world *w, int pair_idx, Transition *tr_out) {
     tr_out->pair = -1;
@@ -945,7 +968,14 @@ static int process_pair(ro_world *w, int pair_idx, Transition *tr_out) {
     }
     int had = p->nsc > 0;
     int rb1 = co1->parent, rb2 = co2->parent;
-    /* filters (:179-252) were applied when the pair was created (static in this scope) */
+    /* :191-201 contacts disabled between two bodies attached by a joint: clear_filtered_pair */
+    if (rb1 >= 0 && rb2 >= 0 && joints_disable_contacts(w, rb1, rb2)) {
+        p->m.npoints = 0; p->nsc = 0; p->has_recycle = 0; /* ContactPair::clear */
+        p->hint_seq = w->step_seq;
+        if (had) { tr_out->pair = pair_idx; tr_out->body1 = rb1; tr_out->body2 = rb2; tr_out->touching = 0; }
+        return 1;
+    }
+    /* the other filters (:203-252) were applied when the pair was created (static in this scope) */
     pose pos12 = pose_inv_mul(co1->pos, co2->pos);
     float eff_prediction = prediction; /* contact_skin = 0, no soft-ccd */
 
@@ -1058,6 +1088,7 @@ static void narrow_phase_compute_contacts(ro_world *w) {
     /* pairs are independent (contacts.rs:22-251 hands them to a rayon broadcast); transitions are
      * collected per pair and compacted in edge order afterwards */
     int nfull = 0, nrec = 0;
+    joints_disable_contacts_prepare(w);
     RO_PARALLEL_FOR_RED(nfull, nrec)
     for (int i = 0; i < w->npairs; ++i) { int o = process_pair(w, i, &tr[i]); nfull += o == 1; nrec += o == 0; }
     w->stats.num_full_updates = nfull; w->stats.num_recycled = nrec;
@@ -2203,7 +2234,7 @@ int32_t ro_dump_manifolds(const ro_world *w, int32_t cap, int32_t *meta, float *
  * contacts between the two bodies enabled. */
 int32_t ro_add_joint(ro_world *w, const ro_joint_desc *d) {
     if (d->body1 < 0 || d->body2 < 0 || d->body1 >= w->nbodies || d->body2 >= w->nbodies) return -1;
-    if ((d->locked_axes & ~0x3fu) != 0 || !d->contacts_enabled) return -1;
+    if ((d->locked_axes & ~0x3fu) != 0) return -1;
     if (w->njoints == w->cap_joints) {
         w->cap_joints = w->cap_joints ? w->cap_joints * 2 : 1024;
         w->joints = (Joint *)realloc(w->joints, sizeof(Joint) * w->cap_joints);
@@ -2219,6 +2250,7 @@ int32_t ro_add_joint(ro_world *w, const ro_joint_desc *d) {
     j->local_frame2.r = qnormalize(Q(d->local_basis2[0], d->local_basis2[1], d->local_basis2[2], d->local_basis2[3]));
     j->locked_axes = d->locked_axes; j->contacts_enabled = d->contacts_enabled;
     j->solver_color = 255; /* default_solver_color: uncoloured */
+    w->nc_dirty = 1;
     wake_request(w, d->body1, 1); wake_request(w, d->body2, 1); /* insert(.., wake_up = true), substep.rs:289-300 */
     return w->njoints++;
 }
@@ -2226,6 +2258,7 @@ int32_t ro_add_joint(ro_world *w, const ro_joint_desc *d) {
 int32_t ro_remove_joint(ro_world *w, int32_t joint) {
     if (joint < 0 || joint >= w->njoints || w->joints[joint].removed) return -1;
     w->joints[joint].removed = 1;
+    w->nc_dirty = 1;
     wake_request(w, w->joints[joint].body1, 1); wake_request(w, w->joints[joint].body2, 1); /* remove(.., wake_up = true) */
     memset(w->joints[joint].impulses, 0, sizeof(w->joints[joint].impulses));
     return 0;

@@ -42,6 +42,7 @@ void rp_launch_wake(const DevWorld &w, hipStream_t st, int phase);
 void rp_launch_wake_partners(const DevWorld &w, hipStream_t st);
 void rp_launch_force_events(const DevWorld &w, hipStream_t st);
 void rp_launch_idle_step(const DevWorld &w, hipStream_t st);
+void rp_launch_clear_no_contact(const DevWorld &w, hipStream_t st);
 
 struct HostBody {
     rp_body_desc d; float inv_mass; float inv_pi[3]; float lcom[3]; int ncolliders; bool removed;
@@ -112,6 +113,7 @@ static bool world_sleep_enabled(const rp_world *w);
 static bool world_has_kinematic_pos(const rp_world *w);
 static bool world_has_force_events(const rp_world *w);
 static bool world_has_compound_bodies(const rp_world *w);
+static std::vector<unsigned long long> no_contact_keys(const rp_world *w);
 static int check_sleep_scope(rp_world *w);
 static int rebuild_begin(rp_world *w);
 static int queue_wake(rp_world *w, int b, int lvl);
@@ -586,7 +588,6 @@ extern "C" int32_t rp_impulse_joints_insert(rp_world *w, int32_t n, const rp_joi
         const rp_joint_desc &j = descs[i];
         if (j.body1 < 0 || j.body2 < 0 || j.body1 >= (int)w->bodies.size() || j.body2 >= (int)w->bodies.size()) { w->err = "rp_impulse_joints_insert: invalid body index"; return RP_ERR_INVALID; }
         if ((j.locked_axes & ~0x3fu) != 0 || j.locked_axes == 0) { w->err = "rp_impulse_joints_insert: locked_axes must be a non-empty JointAxesMask (limits, motors and coupled axes are not implemented on the device path)"; return RP_ERR_INVALID; }
-        if (!j.contacts_enabled) { w->err = "rp_impulse_joints_insert: contacts_enabled = false is not implemented on the device path"; return RP_ERR_INVALID; }
     }
     if (n > 0) { int r = rebuild_begin(w); if (r != RP_OK) return r; }
     for (int i = 0; i < n; ++i) {
@@ -708,6 +709,16 @@ static bool world_has_force_events(const rp_world *w) {
     for (size_t i = 0; i < w->colliders.size(); ++i) if (!w->collider_removed[i] && (w->colliders[i].active_events & RP_EVENTS_CONTACT_FORCE)) return true;
     return false;
 }
+static std::vector<unsigned long long> no_contact_keys(const rp_world *w) {
+    std::vector<unsigned long long> k;
+    for (size_t j = 0; j < w->joints.size(); ++j) {
+        if (w->joint_removed[j] || w->joints[j].contacts_enabled) continue;
+        unsigned lo = (unsigned)std::min(w->joints[j].body1, w->joints[j].body2), hi = (unsigned)std::max(w->joints[j].body1, w->joints[j].body2);
+        k.push_back(((unsigned long long)lo << 32) | hi);
+    }
+    std::sort(k.begin(), k.end());
+    return k;
+}
 static bool world_has_kinematic_pos(const rp_world *w) {
     for (const HostBody &b : w->bodies) if (!b.removed && b.d.body_type == RP_BODY_KINEMATIC_POSITION) return true;
     return false;
@@ -825,6 +836,13 @@ static int finalize(rp_world *w) {
     }
     int nj = (int)jb1.size();
     d.n_joints = nj;
+    { // joints that disable the contacts between their two bodies (GenericJoint::contacts_enabled = false)
+        std::vector<unsigned long long> nck = no_contact_keys(w);
+        d.n_nc = (int)nck.size();
+        DA(d.nc_keys, w->joints.size() + 1);
+        UP(d.nc_keys, nck);
+        HIPCHK(w, hipStreamSynchronize(w->stream));
+    }
     DA(d.j_b1, nj); DA(d.j_b2, nj); DA(d.j_f1t, nj); DA(d.j_f1r, nj); DA(d.j_f2t, nj); DA(d.j_f2r, nj);
     DA(d.j_locked, nj); DA(d.j_color, nj); DA(d.j_tmp, nj); DA(d.j_order, nj); DA(d.j_imp, nj); DA(d.j_imp_ang, nj);
     DA(d.j_stage_begin, RP_NUM_COLORS + 1); DA(d.j_stage_count, RP_NUM_COLORS + 1);
@@ -1310,6 +1328,14 @@ static int remove_joint_at(rp_world *w, int j) {
     if (w->joint_removed[j]) return RP_OK;
     w->joint_removed[j] = 1;
     if (!w->finalized) return RP_OK;
+    if (!w->joints[j].contacts_enabled) { // the pairs it filtered are evaluated again
+        std::vector<unsigned long long> nck = no_contact_keys(w);
+        if (!nck.empty()) HIPCHK(w, hipMemcpy(w->dw.nc_keys, nck.data(), nck.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+        w->dw.n_nc = (int)nck.size();
+        HIPCHK(w, hipStreamSynchronize(w->stream));
+        destroy_graphs(w); // kernel arguments (DevWorld by value) hold n_nc
+        w->dw.n_nc = std::max(w->dw.n_nc, 1); rp_launch_clear_no_contact(w->dw, w->stream); w->dw.n_nc = (int)nck.size();
+    }
     for (int k = 0; k < (int)w->active_joint_ids.size(); ++k) {
         if (w->active_joint_ids[k] != j) continue;
         const rp_joint_desc &jd = w->joints[j];

@@ -320,6 +320,7 @@ __device__ __noinline__ void pair_full_update(DevWorld &w, int s, int c1, int c2
     int sh1 = w.c_shape[c1], sh2 = w.c_shape[c2];
     float4 he1 = w.c_he[c1], he2 = w.c_he[c2];
     int had = w.p_nsc[s] > 0;
+    const bool no_contact = joints_disable_contacts(w, rb1, rb2); // pair_update.rs:191-201: clear_filtered_pair
 
     LocalManifold m;
     m.n = w.p_npts[s];
@@ -362,6 +363,7 @@ __device__ __noinline__ void pair_full_update(DevWorld &w, int s, int c1, int c2
     w.p_reldom[s] = rel_dom;
 
     int nsc = 0;
+    if (no_contact) { m.n = 0; w.p_npts[s] = 0; }
     if (m.n > 0) {
         int sel[4] = {0, 1, 2, 3};
         int nsel = m.n < 4 ? m.n : 4;
@@ -412,7 +414,10 @@ __device__ __noinline__ void pair_full_update(DevWorld &w, int s, int c1, int c2
     w.p_nsc[s] = nsc;
     // recycle state — pair_update.rs:582-613
     float recycle = w.prm.recycle_distance;
-    if (recycle > 0.0f) {
+    if (no_contact) { // ContactPair::clear: no manifold, no recycle state; skipped from now on (k_np_test) until the joint set changes
+        w.p_pflags[s] = (w.p_pflags[s] & ~RP_PF_RECYCLE) | RP_PF_NO_CONTACT;
+        w.p_misc[s] = make_float4(restitution, 0.0f, 0.0f, 0.0f);
+    } else if (recycle > 0.0f) {
         float max_extent;
         if (w.p_pflags[s] & RP_PF_RECYCLE) max_extent = w.p_misc[s].y;
         else {
@@ -479,6 +484,7 @@ __global__ void k_np_test(DevWorld w) {
         int c1 = w.p_c1[s];
         if (c1 < 0) continue;
         int c2 = w.p_c2[s];
+        if (w.n_nc && (w.p_pflags[s] & RP_PF_NO_CONTACT)) continue; // filtered by a contact-disabling joint (cleared below)
         Pose pc1, pc2;
         pc1.r = q4(w.c_rot[c1]); pc1.t = v3(w.c_pos[c1]);
         pc2.r = q4(w.c_rot[c2]); pc2.t = v3(w.c_pos[c2]);
@@ -509,6 +515,18 @@ __global__ void k_np_update(DevWorld w) {
         Pose pos12 = pose_inv_mul(pc1, pc2);
         pair_full_update(w, s, c1, c2, pc1, pc2, pos12);
     }
+}
+
+// the set of contact-disabling joints changed: every filtered pair is evaluated again by the next narrow phase
+__global__ void k_clear_no_contact(DevWorld w) {
+    int top = w.flags[FL_POOL_TOP];
+    if (top > w.pool_cap) top = w.pool_cap;
+    int stride = gridDim.x * blockDim.x;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < top; s += stride) if (w.p_c1[s] >= 0) w.p_pflags[s] &= ~RP_PF_NO_CONTACT;
+}
+void rp_launch_clear_no_contact(const DevWorld &w, hipStream_t st) {
+    int blocks = (w.pool_cap + 255) / 256; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_clear_no_contact, dim3(blocks), dim3(256), 0, st, w);
 }
 
 // ------------------------------------------------------------------------------------------

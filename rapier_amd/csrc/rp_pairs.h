@@ -112,6 +112,15 @@ RP_DEV bool pair_recycle_ok(const DevWorld &w, int s, const Pose &pc1, const Pos
     float rot_cos = rp_min(2.0f * ca * ca - 1.0f, 2.0f * cb * cb - 1.0f);
     return drift <= misc.z && rot_cos > 0.98f;
 }
+// ImpulseJointSet::joints_between(b1, b2).any(|j| !j.data.contacts_enabled) — pair_update.rs:191-201
+RP_DEV bool joints_disable_contacts(const DevWorld &w, int b1, int b2) {
+    if (w.n_nc == 0 || b1 < 0 || b2 < 0) return false;
+    unsigned lo = (unsigned)(b1 < b2 ? b1 : b2), hi = (unsigned)(b1 < b2 ? b2 : b1);
+    unsigned long long key = ((unsigned long long)lo << 32) | hi;
+    int a = 0, b = w.n_nc - 1;
+    while (a <= b) { int m = (a + b) >> 1; unsigned long long k = w.nc_keys[m]; if (k == key) return true; if (k < key) a = m + 1; else b = m - 1; }
+    return false;
+}
 RP_DEV Pose collider_world_pose_of(const DevWorld &w, int i, int parent) { // parent = c_parent[i], already known
     Pose lp; lp.r = q4(w.c_lrot[i]); lp.t = v3(w.c_lpos[i]);
     if (parent < 0) return lp;
@@ -121,6 +130,7 @@ RP_DEV Pose collider_world_pose_of(const DevWorld &w, int i, int parent) { // pa
 RP_DEV bool pair_needs_narrow_phase(const DevWorld &w, int s) {
     int c1 = w.p_c1[s];
     if (c1 < 0) return false;
+    if (w.n_nc && (w.p_pflags[s] & RP_PF_NO_CONTACT)) return false; // filtered by a contact-disabling joint: nothing to compute
     int c2 = w.p_c2[s];
     int2 rb = w.p_rb[s];
     Pose pc1 = collider_world_pose_of(w, c1, rb.x), pc2 = collider_world_pose_of(w, c2, rb.y);

@@ -32,7 +32,8 @@
 
 // pair flag bits
 #define RP_PF_RECYCLE 0x1
-#define RP_PF_FORCE_EMITTED 0x2       // PairEventStatus::INITIAL_FORCE_THRESHOLD_EVENT_EMITTED
+#define RP_PF_FORCE_EMITTED 0x2
+#define RP_PF_NO_CONTACT 0x4          // cleared by a joint with contacts_enabled = false (pair_update.rs:191-201); skipped until the joint set changes       // PairEventStatus::INITIAL_FORCE_THRESHOLD_EVENT_EMITTED
 
 // overflow / error flag bits (dev flags[FL_OVERFLOW])
 #define RP_OVF_POOL 0x1
@@ -140,6 +141,7 @@ struct SimParams {
 
 struct DevWorld {
     int n_bodies, n_colliders, n_joints;
+    int n_nc;          // joints that disable the contacts between their two bodies
     int pool_cap;      // pair slots
     int hash_cap;      // power of two
     int grid_cap;      // power of two (cell hash buckets)
@@ -251,6 +253,7 @@ struct DevWorld {
     float4 *j_imp, *j_imp_ang;  // per-dof impulses written back at the end of the step (linear dofs, angular dofs)
     unsigned int *bj_cmask;     // [4 * n_bodies] colours taken by joints (bodies_color workspace)
     unsigned long long *bj_min; // joint colouring scratch
+    unsigned long long *nc_keys; // [n_nc] sorted (min body << 32 | max body) keys of the joints with contacts_enabled = false
     int *b_njoints;             // joints attached to a body (bodies with joints stay on the global path)
     float4 *JR;                 // [JR_COUNT][n_joints] constraint rows, up to 6 per joint (rp_joints.h)
 

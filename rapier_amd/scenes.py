@@ -460,3 +460,19 @@ def locked_axes_scene() -> Scene:
     top = s.add_body(translation=(-1.6, 4.0, 0.1), angvel=(0.0, 0.0, 2.0))   # falls onto the locked ones
     s.add_collider(top, half_extents=(1.5, 0.2, 0.5))
     return s
+
+
+def overlapping_chain(n: int = 6, contacts_enabled: int = 0) -> Scene:
+    """A chain of cuboid links whose neighbours OVERLAP at the joints (like the limbs of a ragdoll), joined by spherical
+    joints with ``contacts_enabled = false`` (GenericJoint::contacts_enabled, pair_update.rs:191-201), dropped on a slab."""
+    s = Scene(name=f"overlapping_chain_{n}_{contacts_enabled}", gravity=(0.0, -9.81, 0.0))
+    g = s.add_body(body_type=BODY_FIXED, translation=(0.0, -0.5, 0.0))
+    s.add_collider(g, half_extents=(20.0, 0.5, 20.0))
+    prev = None
+    for i in range(n):
+        b = s.add_body(translation=(_f(i) * 1.0, 2.0, 0.0), angvel=(0.0, 0.0, _f(0.2 * (i % 2))))
+        s.add_collider(b, half_extents=(0.6, 0.15, 0.15), density=2.0)
+        if prev is not None:
+            s.add_joint(prev, b, (0.5, 0.0, 0.0), (-0.5, 0.0, 0.0), contacts_enabled=contacts_enabled)
+        prev = b
+    return s
