@@ -212,14 +212,14 @@ int32_t rp_bodies_apply_impulse(rp_world *w, int32_t n, const uint64_t *handles,
  * contact island once EVERY member stayed below the motion thresholds for time_until_sleep (0.5 s), and wake
  * island-wide on a begin-touch, a deleted touching pair, a removed collider or a user change.
  * rp_bodies_wake_up = IslandManager::wake_up(handle, strong) (sleep.rs:31), effective at the next step;
- * rp_bodies_is_sleeping = RigidBody::is_sleeping (NULL handles are not accepted).  Scope: impulse joints in a
- * world with can_sleep bodies are refused with RP_ERR_INVALID. */
+ * rp_bodies_is_sleeping = RigidBody::is_sleeping (NULL handles are not accepted).  Impulse joints link the islands of their
+ * bodies; a joint whose bodies sleep leaves the solver selection (impulse_joint_set.rs:504-572). */
 int32_t rp_bodies_wake_up(rp_world *w, int32_t n, const uint64_t *handles, int32_t strong);
 /* RigidBody::set_next_kinematic_position (rigid_body.rs:1085-1093) for n kinematic bodies: the pose to reach by the
  * end of the next step.  Position-based kinematic bodies get their velocity from it (interpolate_kinematic_velocities,
  * substep.rs:242-264) and land on it exactly; the body is woken when the pose differs from its current one.
  * Kinematic bodies are solver bodies with zero inverse mass: they push dynamic bodies and are never pushed.
- * Scope: worlds holding kinematic bodies take the full step path and refuse impulse joints. */
+ * Worlds holding kinematic bodies take the full step path. */
 int32_t rp_bodies_set_next_kinematic_position(rp_world *w, int32_t n, const uint64_t *handles, const float *pos7);
 int32_t rp_bodies_is_sleeping(rp_world *w, int32_t n, const uint64_t *handles, int32_t *sleeping_out);
 int32_t rp_num_bodies(const rp_world *w);

@@ -65,6 +65,7 @@ struct rp_world {
     std::vector<char> collider_removed, joint_removed;
     std::vector<rp_joint_desc> joints;
     std::vector<int> active_joint_ids; // device joint index -> index into `joints`
+    std::vector<int> pending_wake;     // bodies to wake once the device world exists again (joints inserted: insert(.., wake_up = true))
     bool finalized = false;
     int cap_bodies = 0, cap_colliders = 0; // device array capacities (rows beyond n_bodies / n_colliders are spare)
     bool hints_valid = false;
@@ -592,6 +593,7 @@ extern "C" int32_t rp_impulse_joints_insert(rp_world *w, int32_t n, const rp_joi
     if (n > 0) { int r = rebuild_begin(w); if (r != RP_OK) return r; }
     for (int i = 0; i < n; ++i) {
         w->joints.push_back(descs[i]);
+        w->pending_wake.push_back(descs[i].body1); w->pending_wake.push_back(descs[i].body2);
         w->joint_removed.push_back(0);
         if (handles_out) handles_out[i] = (uint64_t)(w->joints.size() - 1);
     }
@@ -723,12 +725,7 @@ static bool world_has_kinematic_pos(const rp_world *w) {
     for (const HostBody &b : w->bodies) if (!b.removed && b.d.body_type == RP_BODY_KINEMATIC_POSITION) return true;
     return false;
 }
-static int check_sleep_scope(rp_world *w) {
-    if (!world_sleep_enabled(w)) return RP_OK;
-    for (size_t j = 0; j < w->joints.size(); ++j)
-        if (!w->joint_removed[j]) { w->err = "impulse joints in a world with can_sleep or kinematic bodies are not implemented on the device path"; return RP_ERR_INVALID; }
-    return RP_OK;
-}
+static int check_sleep_scope(rp_world *w) { (void)w; return RP_OK; } // impulse joints, sleeping and kinematic bodies mix freely
 
 // Upload the host mirrors into the SoA device world (the "upload = resume" path of SURVEY §5).
 static int finalize(rp_world *w) {
@@ -810,7 +807,7 @@ static int finalize(rp_world *w) {
         if (w->joint_removed[ji]) continue;
         const rp_joint_desc &j = w->joints[ji];
         const HostBody &rb1 = w->bodies[j.body1], &rb2 = w->bodies[j.body2];
-        bool d1 = rb1.d.body_type == RP_BODY_DYNAMIC, d2 = rb2.d.body_type == RP_BODY_DYNAMIC;
+        bool d1 = rb1.d.body_type != RP_BODY_FIXED && !rb1.removed, d2 = rb2.d.body_type != RP_BODY_FIXED && !rb2.removed; // is_dynamic_or_kinematic
         if (!d1 && !d2) continue;
         auto body_pose = [](const HostBody &b) {
             Pose p; const float *r = b.d.rotation;
@@ -896,6 +893,8 @@ static int finalize(rp_world *w) {
     HIPCHK(w, hipStreamSynchronize(w->stream));
     HIPCHK(w, hipGetLastError());
     w->finalized = true; w->hints_valid = false;
+    if (d.sleep_enabled) for (int b : w->pending_wake) if (b >= 0 && b < nb) { int r = queue_wake(w, b, 2); if (r != RP_OK) return r; }
+    w->pending_wake.clear();
     return RP_OK;
 }
 
@@ -1343,7 +1342,8 @@ static int remove_joint_at(rp_world *w, int j) {
         if ((r = poke(w, w->dw.j_b1 + k, -1)) != RP_OK || (r = poke(w, w->dw.j_b2 + k, -1)) != RP_OK || (r = poke(w, w->dw.j_locked + k, 0)) != RP_OK ||
             (r = poke(w, w->dw.j_imp + k, mk4(0, 0, 0, 0))) != RP_OK || (r = poke(w, w->dw.j_imp_ang + k, mk4(0, 0, 0, 0))) != RP_OK) return r;
         for (int b : {jd.body1, jd.body2}) {
-            if (w->bodies[b].d.body_type != RP_BODY_DYNAMIC || w->bodies[b].removed) continue;
+            if (w->bodies[b].d.body_type == RP_BODY_FIXED || w->bodies[b].removed) continue;
+            if (w->dw.sleep_enabled && (r = queue_wake(w, b, 2)) != RP_OK) return r; // ImpulseJointSet::remove(.., wake_up = true)
             int cnt = 0;
             for (size_t q = 0; q < w->joints.size(); ++q) if (!w->joint_removed[q] && (w->joints[q].body1 == b || w->joints[q].body2 == b)) cnt++;
             if ((r = poke(w, w->dw.b_njoints + b, cnt)) != RP_OK) return r;

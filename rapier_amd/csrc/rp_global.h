@@ -119,7 +119,7 @@ RP_DEV void global_single_block(const DevWorld &w, int has_restitution, int fast
     for (int sub = 0; sub < w.prm.num_substeps; ++sub) {
         float solved_dt = (float)sub * w.prm.dt_sub;
         for (int i = t; i < nb; i += nt) if (global_body(w, i)) g_body_increment(w, i);
-        for (int j = t; j < nj; j += nt) joint_update_one(w, j, sub); // reads poses only
+        for (int j = t; j < nj; j += nt) if (joint_live(w, j)) joint_update_one(w, j, sub); // reads poses only
         __threadfence(); __syncthreads();
         tail_sweep<MODE_WARMSTART, COUL>(w, 0, fib, solved_dt);
         for (int it = 0; it < prm.num_internal_pgs_iterations; ++it) {
@@ -135,7 +135,7 @@ RP_DEV void global_single_block(const DevWorld &w, int has_restitution, int fast
     }
     if (has_restitution && bouncy) tail_sweep<MODE_RESTITUTION, COUL>(w, 0, fib, 0.0f);
     for (int pos = t; pos < M; pos += nt) { if (COUL) coul_writeback(w, GlobalAcc(w, pos), w.cons_pair[pos]); else cons_writeback(w, GlobalAcc(w, pos), w.cons_pair[pos]); }
-    for (int j = t; j < nj; j += nt) joint_writeback_one(w, j);
+    for (int j = t; j < nj; j += nt) if (joint_live(w, j)) joint_writeback_one(w, j);
     for (int i = t; i < nb; i += nt) if (global_body(w, i)) g_body_writeback(w, i);
 }
 

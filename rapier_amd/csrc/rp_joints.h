@@ -19,6 +19,15 @@
 enum { JR_LIN = 0, JR_A1, JR_A2, JR_I1, JR_I2, JR_ROW_PLANES = 5, JR_MAX_ROWS = 6, JR_IM1 = 30, JR_IM2 = 31, JR_COUNT = 32 };
 #define JRP(plane, j) w.JR[(size_t)(plane) * w.n_joints + (j)]
 
+// select_active_interactions (impulse_joint_set.rs:504-572): a joint takes part in the step when it has a non-fixed side and
+// none of its dynamic / kinematic bodies sleeps (removed joints have no side left)
+RP_DEV bool joint_live(const DevWorld &w, int j) {
+    int b1 = w.j_b1[j], b2 = w.j_b2[j];
+    if (b1 < 0 && b2 < 0) return false;
+    if (!w.sleep_enabled) return true;
+    return !(b1 >= 0 && (w.b_flags[b1] & RP_BF_SLEEPING)) && !(b2 >= 0 && (w.b_flags[b2] & RP_BF_SLEEPING));
+}
+
 struct JointRow { V3 lin_jac, ang_jac1, ang_jac2, ii1, ii2; float impulse, inv_lhs, rhs, rhs_wo_bias, cfm_gain; };
 
 RP_DEV void jrow_load(const DevWorld &w, int j, int r, JointRow &c) {

@@ -21,9 +21,9 @@ RP_DEV unsigned jld_u32(unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELA
 __global__ void k_joint_color_check(DevWorld w) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= w.n_joints) return;
+    if (!joint_live(w, j)) return; // removed or sleeping joint: not in this step's selection
     int color = w.j_color[j];
     int b1 = w.j_b1[j], b2 = w.j_b2[j];
-    if (b1 < 0 && b2 < 0) return; // removed joint: no rows, no colour
     bool bad = color >= 128;
     if (!bad) {
         unsigned bit = 1u << (color & 31);
@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(1024) k_joint_color(DevWorld w) {
     const int nj = w.n_joints, nb = w.n_bodies;
     __shared__ int remaining;
     for (int b = threadIdx.x; b < nb; b += blockDim.x) { for (int q = 0; q < 4; ++q) w.bj_cmask[4 * b + q] = 0; w.bj_min[b] = RP_EMPTY_KEY; }
-    for (int j = threadIdx.x; j < nj; j += blockDim.x) w.j_tmp[j] = 1; // 1 = undecided
+    for (int j = threadIdx.x; j < nj; j += blockDim.x) w.j_tmp[j] = joint_live(w, j) ? 1 : 0; // 1 = undecided; joints outside the selection keep their stored colour
     __threadfence(); __syncthreads();
     for (int round = 0; round < (1 << 24); ++round) {
         if (threadIdx.x == 0) remaining = 0;
@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(1024) k_joint_layout(DevWorld w) {
     __shared__ int n_ovf, ovf_begin;
     for (int c = threadIdx.x; c < RP_NUM_COLORS; c += blockDim.x) count[c] = 0;
     __syncthreads();
-    for (int j = threadIdx.x; j < nj; j += blockDim.x) atomicAdd(&count[w.j_color[j]], 1);
+    for (int j = threadIdx.x; j < nj; j += blockDim.x) if (joint_live(w, j)) atomicAdd(&count[w.j_color[j]], 1);
     __syncthreads();
     if (threadIdx.x == 0) {
         int pos = 0, nst = 0;
@@ -107,11 +107,13 @@ __global__ void __launch_bounds__(1024) k_joint_layout(DevWorld w) {
             }
         }
         ovf_begin = pos; n_ovf = 0;
-        w.flags[FL_NJ_STAGES] = nst; w.flags[FL_NJ_OVF_BEGIN] = pos; w.flags[FL_NJ_OVF_COUNT] = nj - pos;
+        int live = 0; for (int c = 0; c < RP_NUM_COLORS; ++c) live += count[c];
+        w.flags[FL_NJ_STAGES] = nst; w.flags[FL_NJ_OVF_BEGIN] = pos; w.flags[FL_NJ_OVF_COUNT] = live - pos;
     }
     __syncthreads();
     // parallel colours: order inside a colour is free (body-disjoint); overflow: collected, then ranked
     for (int j = threadIdx.x; j < nj; j += blockDim.x) {
+        if (!joint_live(w, j)) continue;
         int c = w.j_color[j];
         if (stage_of[c] >= 0) w.j_order[atomicAdd(&cursor[c], 1)] = j;
         else w.j_tmp[atomicAdd(&n_ovf, 1)] = j;
@@ -132,7 +134,7 @@ __global__ void __launch_bounds__(1024) k_joint_layout(DevWorld w) {
 // ---- MULTI mode launches -----------------------------------------------------------------------
 __global__ void k_joint_update(DevWorld w, int substep_id) {
     int stride = gridDim.x * blockDim.x;
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < w.n_joints; j += stride) joint_update_one(w, j, substep_id);
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < w.n_joints; j += stride) if (joint_live(w, j)) joint_update_one(w, j, substep_id);
 }
 __global__ void __launch_bounds__(256) k_joint_stage(DevWorld w, int stage, int wo_bias, int warmstart) {
     if (stage >= w.flags[FL_NJ_STAGES]) return;
@@ -147,7 +149,7 @@ __global__ void __launch_bounds__(1024) k_joint_tail(DevWorld w, int first, int 
 }
 __global__ void k_joint_writeback(DevWorld w) {
     int stride = gridDim.x * blockDim.x;
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < w.n_joints; j += stride) joint_writeback_one(w, j);
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < w.n_joints; j += stride) if (joint_live(w, j)) joint_writeback_one(w, j);
 }
 
 static int joint_blocks(const DevWorld &w) { int b = (w.n_joints + 255) / 256; if (b > 2048) b = 2048; return b < 1 ? 1 : b; }

@@ -64,6 +64,7 @@ __global__ void k_wake_commit(DevWorld w, int phase) {
     w.b_flags[i] = fl & ~RP_BF_SLEEPING;
     float4 sl = w.b_sleep[i]; sl.x = 0.0f; w.b_sleep[i] = sl;
     w.flags[FL_LAYOUT_DIRTY] = 1; // the awake set changed: buckets, islands and labels are rebuilt
+    if (w.n_joints) w.flags[FL_JOINT_DIRTY] = 1; // ... and so is the joint selection (select_active_interactions)
 }
 // The user moved a body (rp_bodies_write with a pose): every body that has a pair with it is woken
 // (handle_user_changes_on_colliders, pair_management.rs:236-258).
@@ -95,6 +96,15 @@ __global__ void k_slp_union(DevWorld w) {
         if (w.p_c1[s] < 0 || w.p_nsc[s] == 0) continue; // touching pairs link (contacts.rs:352-359), whatever their solver hint
         int2 rb = w.p_rb[s];
         if (body_active(w, rb.x) && body_active(w, rb.y)) slp_union(w.b_slabel, rb.x, rb.y);
+    }
+}
+// impulse joints link the islands of their two bodies (ImpulseJointIslandEvent::Link, persistent.rs:13-24)
+__global__ void k_slp_union_joints(DevWorld w) {
+    if (!w.flags[FL_LAYOUT_DIRTY]) return;
+    int stride = gridDim.x * blockDim.x;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < w.n_joints; j += stride) {
+        int b1 = w.j_b1[j], b2 = w.j_b2[j];
+        if (body_active(w, b1) && body_active(w, b2)) slp_union(w.b_slabel, b1, b2);
     }
 }
 __global__ void k_slp_flatten(DevWorld w) {
@@ -152,6 +162,7 @@ __global__ void k_sleep_commit(DevWorld w) {
     w.b_linvel[i] = make_float4(0, 0, 0, 0); w.b_angvel[i] = make_float4(0, 0, 0, 0);
     w.b_slept_at[i] = cur_step(w);
     w.flags[FL_LAYOUT_DIRTY] = 1;
+    if (w.n_joints) w.flags[FL_JOINT_DIRTY] = 1;
 }
 
 // interpolate_kinematic_velocities (substep.rs:242-264): a position-based kinematic body gets the velocity that
@@ -209,6 +220,7 @@ void rp_launch_sleep(const DevWorld &w, hipStream_t st) {
     if (w.has_kinematic_pos) hipLaunchKernelGGL(k_kinematic_velocities, dim3(nb), dim3(256), 0, st, w); // after the narrow phase, before the sleep timers
     hipLaunchKernelGGL(k_slp_init, dim3(nb), dim3(256), 0, st, w);
     if (w.n_colliders > 0) hipLaunchKernelGGL(k_slp_union, dim3(slp_pair_blocks(w)), dim3(256), 0, st, w);
+    if (w.n_joints > 0) { int jb = (w.n_joints + 255) / 256; if (jb > 2048) jb = 2048; hipLaunchKernelGGL(k_slp_union_joints, dim3(jb), dim3(256), 0, st, w); }
     hipLaunchKernelGGL(k_slp_flatten, dim3(nb), dim3(256), 0, st, w);
     hipLaunchKernelGGL(k_sleep_observe, dim3(nb), dim3(256), 0, st, w);
     hipLaunchKernelGGL(k_sleep_commit, dim3(nb), dim3(256), 0, st, w);

@@ -476,3 +476,23 @@ def overlapping_chain(n: int = 6, contacts_enabled: int = 0) -> Scene:
             s.add_joint(prev, b, (0.5, 0.0, 0.0), (-0.5, 0.0, 0.0), contacts_enabled=contacts_enabled)
         prev = b
     return s
+
+
+def kinematic_crane(n: int = 5) -> Scene:
+    """A chain of balls hanging by spherical joints from a velocity-based kinematic trolley (a joint with a kinematic side:
+    a solver body with zero inverse mass), above a slab with a few cubes the chain sweeps through."""
+    s = Scene(name=f"kinematic_crane_{n}", gravity=(0.0, -9.81, 0.0))
+    g = s.add_body(body_type=BODY_FIXED, translation=(0.0, -0.5, 0.0))
+    s.add_collider(g, half_extents=(20.0, 0.5, 20.0))
+    trolley = s.add_body(body_type=BODY_KINEMATIC_VELOCITY, translation=(-3.0, 4.0, 0.0), linvel=(1.0, 0.0, 0.0))
+    s.add_collider(trolley, half_extents=(0.3, 0.1, 0.3))
+    prev = trolley
+    for i in range(n):
+        b = s.add_body(translation=(-3.0, _f(4.0 - 0.7 * (i + 1)), 0.0), can_sleep=1)
+        s.add_collider(b, shape=SHAPE_BALL, half_extents=(0.25, 0.0, 0.0), density=3.0)
+        s.add_joint(prev, b, (0.0, -0.35, 0.0), (0.0, 0.35, 0.0))
+        prev = b
+    for k in range(3):
+        c = s.add_body(translation=(_f(0.5 + 1.2 * k), 0.5, 0.0), can_sleep=1)
+        s.add_collider(c, half_extents=(0.3, 0.5, 0.3))
+    return s

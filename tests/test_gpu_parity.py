@@ -478,6 +478,31 @@ def test_compound_bodies_bit_exact():
         _same_state(g2, o2, f"collider attached to a live body, +{n}")
 
 
+def test_joints_with_sleeping_and_kinematic_bodies_bit_exact():
+    """Joints link sleep islands, a sleeping joint leaves the solver selection, a kick on one body wakes its jointed partner;
+    a joint may hang from a kinematic body (impulse_joint_set.rs:504-572)."""
+    sc = S.jointed_pairs(3).enable_sleep()
+    g, o = PhysicsWorld.from_scene(sc), OracleWorld(sc)
+    done = 0
+    for cp in (30, 60, 90, 120, 200):
+        g.step(cp - done); o.step(cp - done); done = cp
+        _same_sleep_state(g, o, f"jointed pairs with sleep @ {cp}")
+    sl = g.sleeping()
+    assert sl[1:10].all()                                       # the stack and the three revolute pairs sleep (pairs as joint-linked islands)
+    kick = np.array([[0.0, 2.0, 0.5, 0.0, 0.0, 0.0]], np.float32)
+    g.write_bodies([5], vel6=kick); o.set_vel(5, kick[0, :3], kick[0, 3:])   # body 5 = second cube of the first pair
+    for n in (1, 1, 20, 150):
+        g.step(n); o.step(n)
+        _same_sleep_state(g, o, f"jointed pair kicked, +{n}")
+    gc, gi = g.read_joints(); oc, oi = o.read_joints()
+    np.testing.assert_array_equal(gc, oc); np.testing.assert_array_equal(gi, oi)
+    g2, o2 = _compare(S.kinematic_crane(5), [1, 10, 60, 200, 400])
+    np.testing.assert_array_equal(g2.sleeping(), o2.sleeping())
+    pos, _ = g2.read_bodies()
+    assert pos[1, 0] == pytest.approx(-3.0 + 400 / 60.0, abs=1e-3)                          # the trolley follows its velocity
+    assert np.linalg.norm(pos[2, :3] - pos[1, :3]) == pytest.approx(0.7, abs=2e-2)           # and drags the chain along
+
+
 def test_contact_disabling_joints_bit_exact():
     """GenericJoint::contacts_enabled = false: the pairs between the two jointed bodies are cleared (pair_update.rs:191-201)."""
     g, o = _compare(S.overlapping_chain(6, 0), [1, 2, 10, 60, 200])
@@ -637,10 +662,7 @@ def test_collision_and_contact_force_events_bit_exact():
 
 
 def test_out_of_scope_inputs_are_refused():
-    """Contact-disabled joints, unknown axis masks and joints on can_sleep bodies are refused loudly, not mis-simulated."""
-    sj = S.joint_chain(4).enable_sleep()
-    with pytest.raises(Exception):
-        PhysicsWorld.from_scene(sj).step(1)
+    """Unknown joint axis masks and body types are refused loudly, not mis-simulated."""
     from rapier_amd import RapierHipError
     w = PhysicsWorld()
     b = w.insert_body(S.body_desc(translation=(0.0, 1.0, 0.0)))
@@ -650,6 +672,11 @@ def test_out_of_scope_inputs_are_refused():
     sc.add_joint(0, 1, (0, 0, 0), (0, 0, 0), locked_axes=0x7F)
     with pytest.raises(RapierHipError):
         w.insert_impulse_joints(sc.joint_array())  # not a JointAxesMask of locked axes
+    with pytest.raises(RapierHipError):
+        w.insert_body(S.body_desc(body_type=7))    # not a RigidBodyType
+    p = S.default_params(); p["friction_model"] = 5
+    with pytest.raises(RapierHipError):
+        w.set_integration_parameters(p)            # not a FrictionModel
 
 
 def test_golden_fixtures_on_gpu():

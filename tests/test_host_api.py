@@ -76,4 +76,4 @@ def test_partition_scene_keeps_islands_and_replicates_fixed():
 def test_header_documents_scope_limits():
     hdr = open(os.path.join(ROOT, "include", "rapier_hip.h")).read()
     # what the device path refuses is stated where the entry points are declared
-    assert "compound bodies" in hdr and "limits, motors, coupled axes" in hdr and "impulse joints in a" in hdr
+    assert "compound bodies" in hdr and "limits, motors, coupled axes" in hdr
