@@ -22,7 +22,21 @@ CASES = {
     "many_pyramids_2x2_s30": lambda: (S.many_pyramids(rows=2, cols=2), 30),
     "joint_chain8_s200": lambda: (S.joint_chain(8), 200),
     "joint_grid12_s100": lambda: (S.joint_grid(12), 100),
+    # feature scenes (sleeping, Coulomb friction, kinematic platform, locked angular joint axes, compound bodies, locked axes)
+    "sleep_impact_s200": lambda: (S.sleep_impact(), 200),
+    "pyramid10_coulomb_s120": lambda: (_coulomb(S.pyramid10()), 120),
+    "kinematic_platform_vel_s120": lambda: (S.kinematic_platform(False), 120),
+    "jointed_pairs2_s150": lambda: (S.jointed_pairs(2), 150),
+    "compound_bodies6_s150": lambda: (S.compound_bodies(6), 150),
+    "locked_axes_s150": lambda: (S.locked_axes_scene(), 150),
+    "overlapping_chain6_s100": lambda: (S.overlapping_chain(6, 0), 100),
 }
+
+
+def _coulomb(scene):
+    scene.params["friction_model"] = S.FRICTION_COULOMB
+    return scene
+
 
 if __name__ == "__main__":
     from oracle_ffi import OracleWorld
