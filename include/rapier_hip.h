@@ -130,9 +130,9 @@ typedef struct rp_joint_desc {
 typedef struct rp_counters {
     float step_time_ms;            /* Counters::step_time (last rp_step call, per step) */
     float collision_detection_ms;  /* StagesCounters::collision_detection_time */
-    float broad_phase_ms;          /* CollisionDetectionCounters::broad_phase_time */
-    float narrow_phase_ms;         /* CollisionDetectionCounters::narrow_phase_time */
-    float island_construction_ms;  /* StagesCounters::island_construction_time (colouring + buckets) */
+    float broad_phase_ms;          /* CollisionDetectionCounters::broad_phase_time (collider poses + pair-set maintenance); timed full steps only */
+    float narrow_phase_ms;         /* CollisionDetectionCounters::narrow_phase_time (recycle test, contact determination, colouring); full steps only */
+    float island_construction_ms;  /* StagesCounters::island_construction_time (sleep decision, solver-graph buckets, contact islands); full steps only */
     float solver_ms;               /* StagesCounters::solver_time */
     float velocity_assembly_ms;    /* SolverCounters::velocity_assembly_time (0: fused into the solve kernels) */
     float velocity_resolution_ms;  /* SolverCounters::velocity_resolution_time: k_island_solve, the TGS loop of all LDS-resident islands */

@@ -31,6 +31,7 @@
 void rp_launch_collider_update(const DevWorld &w, hipStream_t st);
 void rp_launch_broadphase(const DevWorld &w, hipStream_t st);
 void rp_launch_narrowphase(const DevWorld &w, hipStream_t st);
+void rp_launch_narrowphase_part(const DevWorld &w, hipStream_t st, int part);
 void rp_launch_init_bodies(const DevWorld &w, hipStream_t st);
 void rp_launch_solver_assembly(const DevWorld &w, hipStream_t st);
 void rp_launch_solver_loop(const DevWorld &w, hipStream_t st, int parallel_stages, int stage_blocks, int has_restitution, int joint_stages);
@@ -91,6 +92,7 @@ struct rp_world {
     bool timers = false;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     double acc_isl_ms = 0.0, acc_glob_ms = 0.0, acc_col_ms = 0.0, acc_step_ms = 0.0;
+    double acc_bp_ms = 0.0, acc_np_ms = 0.0, acc_islc_ms = 0.0; int acc_full_steps = 0; // full steps only: broad phase, narrow phase, island construction
     int acc_steps = 0;
     double loop_ms_since_read = 0.0; int loop_steps_since_read = 0;
     std::string err;
@@ -977,12 +979,20 @@ static int launch_step(rp_world *w, int fast) {
         // three sub-graphs with events in between (Counters from hipEvents)
         if (!w->timed_ready[fast]) {
             int r;
-            if (!(fast && w->plan_fused) && (r = capture(w, &w->g_col[fast], &w->ge_col[fast], enqueue_collision)) != RP_OK) return r;
+            if (fast && !w->plan_fused && (r = capture(w, &w->g_col[fast], &w->ge_col[fast], enqueue_collision)) != RP_OK) return r;
             w->timed_ready[fast] = true;
             if (!(fast && w->plan_no_global) && (r = capture(w, &w->g_fin[fast], &w->ge_fin[fast], enqueue_global_and_finish)) != RP_OK) return r;
         }
         HIPCHK(w, hipEventRecord(w->ev[0], w->stream));
-        if (w->ge_col[fast]) HIPCHK(w, hipGraphLaunch(w->ge_col[fast], w->stream));
+        if (!fast) { // full step: the collision stage is launched piecewise so CollisionDetectionCounters / island_construction_time get their own events
+            rp_launch_collider_update(w->dw, w->stream);
+            rp_launch_broadphase(w->dw, w->stream);
+            rp_launch_wake(w->dw, w->stream, 0);
+            HIPCHK(w, hipEventRecord(w->ev[4], w->stream));
+            rp_launch_narrowphase_part(w->dw, w->stream, 0);
+            HIPCHK(w, hipEventRecord(w->ev[5], w->stream));
+            rp_launch_narrowphase_part(w->dw, w->stream, 1);
+        } else if (w->ge_col[fast]) HIPCHK(w, hipGraphLaunch(w->ge_col[fast], w->stream));
         HIPCHK(w, hipEventRecord(w->ev[1], w->stream));
         enqueue_island_solver(w); // launched directly so the two events bracket the kernel alone (no graph-launch gap)
         HIPCHK(w, hipEventRecord(w->ev[2], w->stream));
@@ -995,6 +1005,11 @@ static int launch_step(rp_world *w, int fast) {
             // SINGLE mode: c = k_island_solve alone (the TGS loop of every LDS-resident island), d = the
             // global single-workgroup solve; MULTI mode: the per-colour launch sequence is in d.
             w->acc_col_ms += a; w->acc_isl_ms += c; w->acc_glob_ms += d; w->acc_step_ms += a + c + d; w->acc_steps++;
+            if (!fast) {
+                float bp = 0, np = 0, ic = 0;
+                hipEventElapsedTime(&bp, w->ev[0], w->ev[4]); hipEventElapsedTime(&np, w->ev[4], w->ev[5]); hipEventElapsedTime(&ic, w->ev[5], w->ev[1]);
+                w->acc_bp_ms += bp; w->acc_np_ms += np; w->acc_islc_ms += ic; w->acc_full_steps++;
+            }
             w->loop_ms_since_read += c; w->loop_steps_since_read++;
         }
         return RP_OK;
@@ -1548,6 +1563,7 @@ extern "C" int32_t rp_counters_enable(rp_world *w, int32_t enable) {
     if ((enable != 0) != w->timers) { int r = settle(w); if (r != RP_OK) return r; destroy_graphs(w); }
     w->timers = enable != 0;
     w->acc_isl_ms = w->acc_glob_ms = w->acc_col_ms = w->acc_step_ms = 0.0; w->acc_steps = 0;
+    w->acc_bp_ms = w->acc_np_ms = w->acc_islc_ms = 0.0; w->acc_full_steps = 0;
     w->loop_ms_since_read = 0.0; w->loop_steps_since_read = 0;
     return RP_OK;
 }
@@ -1563,6 +1579,10 @@ extern "C" int32_t rp_counters_read(rp_world *w, rp_counters *out) {
     double n = w->acc_steps > 0 ? (double)w->acc_steps : 1.0;
     out->step_time_ms = (float)(w->acc_step_ms / n);
     out->collision_detection_ms = (float)(w->acc_col_ms / n);
+    if (w->acc_full_steps > 0) { // averages over the timed FULL steps (the fast paths have no separate broad / narrow phase)
+        double nf = (double)w->acc_full_steps;
+        out->broad_phase_ms = (float)(w->acc_bp_ms / nf); out->narrow_phase_ms = (float)(w->acc_np_ms / nf); out->island_construction_ms = (float)(w->acc_islc_ms / nf);
+    }
     out->solver_ms = (float)((w->acc_isl_ms + w->acc_glob_ms) / n);
     out->velocity_assembly_ms = 0.0f; // assembly is fused into the solve kernels
     out->velocity_resolution_ms = (float)(w->acc_isl_ms / n);  // k_island_solve (LDS-resident islands)

@@ -702,20 +702,30 @@ __global__ void k_bucket_scatter(DevWorld w) {
 }
 __global__ void k_bucket_finish(DevWorld w) { w.flags[FL_LAYOUT_DIRTY] = 0; }
 
-void rp_launch_narrowphase(const DevWorld &w, hipStream_t st) {
-    if (w.n_colliders == 0) { rp_launch_wake(w, st, 1); rp_launch_sleep(w, st); return; } // collider-less bodies still keep sleep timers
+// `part`: 0 = contact determination (NarrowPhase::compute_contacts: test, update, deferred colouring, begin-touch wake-ups),
+// 1 = island construction in the reference's stage accounting (sleep decision, joint colouring, solver contact graph
+// buckets, contact islands), -1 = both (the step graphs).
+void rp_launch_narrowphase_part(const DevWorld &w, hipStream_t st, int part) {
     int blocks = (w.pool_cap + 255) / 256; if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_np_test, dim3(blocks), dim3(256), 0, st, w);
-    // at most one workgroup per CU: with 128 VGPRs and 2.7 KB of scratch per lane a second round of workgroups costs ~10 us
-    // even when the queue is empty (measured: 341 -> 256 workgroups = 140 -> 130 us per full step on b3d_many_pyramids)
-    hipLaunchKernelGGL(k_np_update, dim3(blocks < 256 ? blocks : 256), dim3(256), 0, st, w);
-    hipLaunchKernelGGL(k_color_pairs, dim3(1), dim3(1024), 0, st, w);
-    rp_launch_wake(w, st, 1); // begin-touch wake-ups (contacts.rs:333-351)
-    rp_launch_sleep(w, st);   // sleep timers + the whole-island sleep decision (solve.rs:196-300, manager.rs:335-388)
-    rp_launch_joint_coloring(w, st); // joints avoid this step's contact colours (init_joints, joints.rs:25-329)
-    hipLaunchKernelGGL(k_bucket_clear, dim3(1), dim3(256), 0, st, w);
-    hipLaunchKernelGGL(k_bucket_count, dim3(blocks), dim3(256), 0, st, w);
-    rp_launch_islands_build(w, st);
-    hipLaunchKernelGGL(k_bucket_layout, dim3(1), dim3(64), 0, st, w);
-    hipLaunchKernelGGL(k_bucket_scatter, dim3(blocks), dim3(256), 0, st, w);
+    if (part != 1) {
+        if (w.n_colliders > 0) {
+            hipLaunchKernelGGL(k_np_test, dim3(blocks), dim3(256), 0, st, w);
+            // at most one workgroup per CU: with 128 VGPRs and 2.7 KB of scratch per lane a second round of workgroups costs ~10 us
+            // even when the queue is empty (measured: 341 -> 256 workgroups = 140 -> 130 us per full step on b3d_many_pyramids)
+            hipLaunchKernelGGL(k_np_update, dim3(blocks < 256 ? blocks : 256), dim3(256), 0, st, w);
+            hipLaunchKernelGGL(k_color_pairs, dim3(1), dim3(1024), 0, st, w);
+        }
+        rp_launch_wake(w, st, 1); // begin-touch wake-ups (contacts.rs:333-351)
+    }
+    if (part != 0) {
+        rp_launch_sleep(w, st);   // sleep timers + the whole-island sleep decision (solve.rs:196-300, manager.rs:335-388); collider-less bodies too
+        if (w.n_colliders == 0) return;
+        rp_launch_joint_coloring(w, st); // joints avoid this step's contact colours (init_joints, joints.rs:25-329)
+        hipLaunchKernelGGL(k_bucket_clear, dim3(1), dim3(256), 0, st, w);
+        hipLaunchKernelGGL(k_bucket_count, dim3(blocks), dim3(256), 0, st, w);
+        rp_launch_islands_build(w, st);
+        hipLaunchKernelGGL(k_bucket_layout, dim3(1), dim3(64), 0, st, w);
+        hipLaunchKernelGGL(k_bucket_scatter, dim3(blocks), dim3(256), 0, st, w);
+    }
 }
+void rp_launch_narrowphase(const DevWorld &w, hipStream_t st) { rp_launch_narrowphase_part(w, st, -1); }

@@ -718,6 +718,27 @@ def test_graph_and_eager_paths_agree(monkeypatch):
     np.testing.assert_array_equal(va, vb)
 
 
+def test_stage_counters_from_hip_events(monkeypatch):
+    """Counters / StagesCounters / CollisionDetectionCounters mirror: timed steps report every stage, and timing does not
+    change the simulation."""
+    sc = S.many_pyramids(rows=2, cols=2)
+    ref = PhysicsWorld.from_scene(sc)
+    ref.step(50)
+    monkeypatch.setenv("RP_NO_FAST", "1")
+    w = PhysicsWorld.from_scene(sc)
+    w.step(10)
+    w.enable_timers(True)
+    w.step(40)
+    c = w.counters()
+    assert c["full_steps"] >= 50 and c["fast_steps"] == 0
+    for k in ("step_time_ms", "collision_detection_ms", "broad_phase_ms", "narrow_phase_ms", "island_construction_ms", "solver_ms", "velocity_resolution_ms"):
+        assert 0.0 < c[k] < 50.0, (k, c[k])
+    assert c["collision_detection_ms"] == pytest.approx(c["broad_phase_ms"] + c["narrow_phase_ms"] + c["island_construction_ms"], rel=0.05)
+    w.enable_timers(False)
+    pa, va = ref.read_bodies(); pb, vb = w.read_bodies()
+    np.testing.assert_array_equal(pa, pb); np.testing.assert_array_equal(va, vb)
+
+
 def test_full_size_properties_many_pyramids():
     """Size-independent properties at the full BASELINE size: finite, settled, weight carried by the
     ground contacts (sum of ground impulses = N m g dt), every colour body-disjoint."""
