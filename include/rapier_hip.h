@@ -123,6 +123,8 @@ typedef struct rp_joint_desc {
     float local_basis1[4], local_basis2[4];
     uint32_t locked_axes; /* JointAxesMask: bit0..2 LIN_X,Y,Z ; bit3..5 ANG_X,Y,Z */
     int32_t contacts_enabled;
+    uint32_t limit_axes;  /* GenericJoint::limit_axes: JointAxesMask of the limited (free) axes */
+    float limits[6][2];   /* JointLimits::{min, max} per axis (GenericJoint::limits, generic_joint.rs:230-245): metres / radians */
 } rp_joint_desc;
 
 /* Counters mirror (ms, from hipEvents) — /root/reference/src/counters/{mod,stages_counters,
@@ -174,7 +176,8 @@ int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider_desc *desc
 /* ImpulseJointSet::insert ×n (impulse_joint_set.rs).  Device path scope: locked axes only — any JointAxesMask of locked
  * linear / angular axes (spherical 0x07, revolute 0x37, prismatic without limits 0x3e, fixed 0x3f; the free axis is the
  * local frame's X axis as in RevoluteJointBuilder / PrismaticJointBuilder); contacts_enabled = 0 filters the contact pairs between
- * the two bodies (pair_update.rs:191-201); limits, motors, coupled axes are refused with RP_ERR_INVALID. */
+ * the two bodies (pair_update.rs:191-201); limit_axes / limits bound the free axes (limit_linear, limit_angular:
+ * joint_constraint_helper.rs:166-208, 468-564); motors and coupled axes are not part of this descriptor. */
 int32_t rp_impulse_joints_insert(rp_world *w, int32_t n, const rp_joint_desc *descs, uint64_t *handles_out);
 /* ImpulseJoint::impulses (per locked linear dof, as written back by the last step) and the persistent
  * solver colour of n joints (NULL handles = all, insertion order). */

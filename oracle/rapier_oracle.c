@@ -133,6 +133,9 @@ typedef struct {
     int body1, body2;
     pose local_frame1, local_frame2;      /* GenericJoint::local_frame1/2 (body space) */
     uint32_t locked_axes; int contacts_enabled;
+    uint32_t limit_axes; float limits[6][2];   /* GenericJoint::{limit_axes, limits} */
+    float ang_limit_center[3][2], ang_limit_half_range[3]; /* AngularLimitParams (joint_constraint_helper.rs:34-72) */
+    float limit_impulses[6];                    /* JointLimits::impulse */
     uint8_t solver_color;                 /* persistent colour, impulse_joint.rs:38 */
     uint32_t solver_body_ids[2];          /* stamped by select_active_interactions */
     float impulses[6];                    /* per-dof impulses written back last step */
@@ -1703,6 +1706,7 @@ static void joints_color(ro_world *w) {
 }
 /* JointConstraintBuilder::generate — joint_constraint_builder.rs:34-60 +
  * GenericJoint::transform_to_solver_body_space — generic_joint.rs:624-636 */
+static int joint_num_rows(const Joint *j) { int n = 0; for (int i = 0; i < 6; ++i) if ((j->locked_axes | (j->limit_axes & ~j->locked_axes)) & (1u << i)) n++; return n; }
 static void joint_builder_generate(ro_world *w, Joint *j, int *num_rows) {
     const Body *rb1 = &w->bodies[j->body1], *rb2 = &w->bodies[j->body2];
     j->sb_frame1 = j->local_frame1; j->sb_frame2 = j->local_frame2;
@@ -1711,7 +1715,7 @@ static void joint_builder_generate(ro_world *w, Joint *j, int *num_rows) {
     if (rb2->body_type == RO_BODY_FIXED) j->sb_frame2 = pose_mul(rb2->position, j->local_frame2);
     else j->sb_frame2.t = vsub(j->sb_frame2.t, rb2->local_com);
     j->first_row = *num_rows;
-    for (int i = 0; i < 6; ++i) if (j->locked_axes & (1u << i)) (*num_rows)++;
+    for (int i = 0; i < 6; ++i) if ((j->locked_axes | (j->limit_axes & ~j->locked_axes)) & (1u << i)) (*num_rows)++;
 }
 /* JointConstraint::<Real,1>::update (joint_velocity_constraint.rs:144-353) for locked linear axes:
  * JointConstraintHelper::new (joint_constraint_helper.rs:95-164), lock_linear (:411-458),
@@ -1793,6 +1797,61 @@ static int joint_update_rows(const ro_world *w, const Joint *j, float dt, JointR
         c->inv_lhs = 0.0f; c->cfm_coeff = cfm_coeff; c->cfm_gain = 0.0f;
         c->rhs = rhs_wo_bias + rhs_bias; c->rhs_wo_bias = rhs_wo_bias; c->dof = i;
     }
+    /* limited (free) axes — scalar update order: limit_angular rows, then limit_linear rows (joint_velocity_constraint.rs:285-314) */
+    uint32_t limit_axes = j->limit_axes & ~j->locked_axes;
+    float max_bias = w->params.normalized_max_corrective_velocity * w->params.length_unit;
+    if (limit_axes & 0x38u) {
+        /* limit_angular (joint_constraint_helper.rs:503-564) with recentered_angle (:468-501) */
+        quat q1 = frame1.r, q2 = frame2.r;
+        float sgn = copysignf(1.0f, qdot(q1, q2));
+        quat ang_err = qmul(qconj(q1), q2);
+        float imag[3] = {ang_err.x * sgn, ang_err.y * sgn, ang_err.z * sgn}, real = ang_err.w * sgn;
+        for (int a = 0; a < 3; ++a) {
+            if (!(limit_axes & (8u << a))) continue;
+            float c_cos = j->ang_limit_center[a][0], c_sin = j->ang_limit_center[a][1], half_range = j->ang_limit_half_range[a];
+            float x = imag[a];
+            float sin_half = c_cos * x - c_sin * real;
+            float cos_half = c_cos * real + c_sin * x;
+            float half = ro_atan2_portable(sin_half, cos_half);
+            float shift = copysignf(3.14159265358979323846f, half);
+            float wrapped_half = fabsf(half) > 1.5707963267948966f ? half - shift : half;
+            float ang = wrapped_half * 2.0f;
+            int min_enabled = ang <= -half_range, max_enabled = half_range <= ang;
+            v3 ang_jac = col[a];
+            JointRow *c = &out[len++];
+            c->solver_vel1 = j->solver_body_ids[0]; c->solver_vel2 = j->solver_body_ids[1];
+            c->im1 = rb1.im; c->im2 = rb2.im;
+            c->impulse = 0.0f; c->impulse_bounds[0] = min_enabled ? -INFINITY : 0.0f; c->impulse_bounds[1] = max_enabled ? INFINITY : 0.0f;
+            c->lin_jac = V3(0, 0, 0); c->ang_jac1 = ang_jac; c->ang_jac2 = ang_jac;
+            float rhs_wo_bias = 0.0f;
+            float rhs_bias = ro_clampf((ro_maxf(ang - half_range, 0.0f) - ro_maxf(-half_range - ang, 0.0f)) * erp_inv_dt, -max_bias, max_bias);
+            c->ii_ang_jac1 = sym3_mul(rb1.ii, ang_jac);
+            c->ii_ang_jac2 = sym3_mul(rb2.ii, ang_jac);
+            c->inv_lhs = 0.0f; c->cfm_coeff = cfm_coeff; c->cfm_gain = 0.0f;
+            c->rhs = rhs_wo_bias + rhs_bias; c->rhs_wo_bias = rhs_wo_bias; c->dof = 6 + 3 + a;
+        }
+    }
+    for (int i = 0; i < 3; ++i) {
+        if (!(limit_axes & (1u << i))) continue;
+        /* limit_linear (:166-208) = lock_linear row with one-sided impulse bounds */
+        JointRow *c = &out[len++];
+        c->solver_vel1 = j->solver_body_ids[0]; c->solver_vel2 = j->solver_body_ids[1];
+        c->im1 = rb1.im; c->im2 = rb2.im;
+        c->impulse = 0.0f;
+        c->lin_jac = col[i];
+        c->ang_jac1 = vadd(vadd(vmul(c1x, col[i].x), vmul(c1y, col[i].y)), vmul(c1z, col[i].z));
+        c->ang_jac2 = vadd(vadd(vmul(c2x, col[i].x), vmul(c2y, col[i].y)), vmul(c2z, col[i].z));
+        c->ii_ang_jac1 = sym3_mul(rb1.ii, c->ang_jac1);
+        c->ii_ang_jac2 = sym3_mul(rb2.ii, c->ang_jac2);
+        float dist = vdot(lin_err, c->lin_jac);
+        float lmin = j->limits[i][0], lmax = j->limits[i][1];
+        int min_enabled = dist <= lmin, max_enabled = lmax <= dist;
+        float rhs_wo_bias = 0.0f;
+        float rhs_bias = ro_clampf((ro_maxf(dist - lmax, 0.0f) - ro_maxf(lmin - dist, 0.0f)) * erp_inv_dt, -max_bias, max_bias);
+        c->inv_lhs = 0.0f; c->cfm_coeff = cfm_coeff; c->cfm_gain = 0.0f;
+        c->rhs = rhs_wo_bias + rhs_bias; c->rhs_wo_bias = rhs_wo_bias; c->dof = 6 + i;
+        c->impulse_bounds[0] = min_enabled ? -INFINITY : 0.0f; c->impulse_bounds[1] = max_enabled ? INFINITY : 0.0f;
+    }
     if (len == 0) return 0;
     /* finalize_constraints: modified Gram-Schmidt */
     v3 imsum = vadd(out[0].im1, out[0].im2);
@@ -1824,12 +1883,12 @@ static void joint_builder_update(ro_world *w, const Joint *j, float dt, int subs
     JointRow *rows = &w->joint_rows[j->first_row];
     float prev[6] = {0, 0, 0, 0, 0, 0};
     int ws = w->params.warmstart_joints;
-    int count = 0; for (int i = 0; i < 6; ++i) if (j->locked_axes & (1u << i)) count++;
+    int count = joint_num_rows(j);
     if (ws && substep_id > 0) for (int k = 0; k < count; ++k) prev[k] = rows[k].impulse;
     int len = joint_update_rows(w, j, dt, rows);
     if (ws) {
         float coeff = w->params.warmstart_coefficient;
-        for (int k = 0; k < len; ++k) rows[k].impulse = (substep_id == 0 ? j->impulses[rows[k].dof] : prev[k]) * coeff;
+        for (int k = 0; k < len; ++k) rows[k].impulse = (substep_id == 0 ? (rows[k].dof >= 6 ? j->limit_impulses[rows[k].dof - 6] : j->impulses[rows[k].dof]) : prev[k]) * coeff;
     }
 }
 /* JointConstraint::solve_generic / warmstart_generic — joint_velocity_constraint.rs:97-142 */
@@ -1858,7 +1917,7 @@ static void joint_row_solve(ro_world *w, JointRow *c) {
 /* The joint part of solve_pass — staged_island_solver/solve.rs:31-150: every joint (parallel colours
  * ascending, then the serial overflow) solves BEFORE any contact in every pass. */
 static void joint_solve_all_rows(ro_world *w, const Joint *j, int wo_bias, int warmstart_joints) {
-    int count = 0; for (int i = 0; i < 6; ++i) if (j->locked_axes & (1u << i)) count++;
+    int count = joint_num_rows(j);
     for (int k = 0; k < count; ++k) {
         JointRow *c = &w->joint_rows[j->first_row + k];
         if (wo_bias) c->rhs = c->rhs_wo_bias;
@@ -2042,8 +2101,11 @@ static void solve_velocity_constraints(ro_world *w) {
     /* JointConstraintsSet::writeback_impulses — joint_velocity_constraint.rs:346-353 */
     for (int a = 0; a < w->nactive_joints; ++a) {
         Joint *j = &w->joints[w->active_joints[a]];
-        int nrows = 0; for (int i = 0; i < 6; ++i) if (j->locked_axes & (1u << i)) nrows++;
-        for (int k = 0; k < nrows; ++k) { const JointRow *r = &w->joint_rows[j->first_row + k]; j->impulses[r->dof] = r->impulse; } /* WritebackId::Dof(i) */
+        int nrows = joint_num_rows(j);
+        for (int k = 0; k < nrows; ++k) { /* WritebackId::Dof(i) / WritebackId::Limit(i) */
+            const JointRow *r = &w->joint_rows[j->first_row + k];
+            if (r->dof >= 6) j->limit_impulses[r->dof - 6] = r->impulse; else j->impulses[r->dof] = r->impulse;
+        }
     }
     /* S10 body writeback — worker.rs:809-897 */
     for (int i = 0; i < nd; ++i) {
@@ -2234,7 +2296,7 @@ int32_t ro_dump_manifolds(const ro_world *w, int32_t cap, int32_t *meta, float *
  * contacts between the two bodies enabled. */
 int32_t ro_add_joint(ro_world *w, const ro_joint_desc *d) {
     if (d->body1 < 0 || d->body2 < 0 || d->body1 >= w->nbodies || d->body2 >= w->nbodies) return -1;
-    if ((d->locked_axes & ~0x3fu) != 0) return -1;
+    if ((d->locked_axes & ~0x3fu) != 0 || (d->limit_axes & ~0x3fu) != 0) return -1;
     if (w->njoints == w->cap_joints) {
         w->cap_joints = w->cap_joints ? w->cap_joints * 2 : 1024;
         w->joints = (Joint *)realloc(w->joints, sizeof(Joint) * w->cap_joints);
@@ -2249,6 +2311,14 @@ int32_t ro_add_joint(ro_world *w, const ro_joint_desc *d) {
     j->local_frame1.r = qnormalize(Q(d->local_basis1[0], d->local_basis1[1], d->local_basis1[2], d->local_basis1[3]));
     j->local_frame2.r = qnormalize(Q(d->local_basis2[0], d->local_basis2[1], d->local_basis2[2], d->local_basis2[3]));
     j->locked_axes = d->locked_axes; j->contacts_enabled = d->contacts_enabled;
+    j->limit_axes = d->limit_axes & 0x3fu;
+    for (int i = 0; i < 6; ++i) { j->limits[i][0] = d->limits[i][0]; j->limits[i][1] = d->limits[i][1]; }
+    for (int a = 0; a < 3; ++a) { /* AngularLimitParams::new(min, max) */
+        float mn = j->limits[3 + a][0], mx = j->limits[3 + a][1];
+        float half_range = (mx - mn) * 0.5f;
+        if (half_range >= 3.14159265358979323846f || half_range != half_range) { j->ang_limit_center[a][0] = 1.0f; j->ang_limit_center[a][1] = 0.0f; j->ang_limit_half_range[a] = 10.0f; }
+        else { float center = (mn + mx) * 0.5f; j->ang_limit_center[a][0] = cosf(center * 0.5f); j->ang_limit_center[a][1] = sinf(center * 0.5f); j->ang_limit_half_range[a] = half_range; }
+    }
     j->solver_color = 255; /* default_solver_color: uncoloured */
     w->nc_dirty = 1;
     wake_request(w, d->body1, 1); wake_request(w, d->body2, 1); /* insert(.., wake_up = true), substep.rs:289-300 */

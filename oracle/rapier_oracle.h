@@ -90,6 +90,8 @@ typedef struct ro_joint_desc {
     float local_basis1[4], local_basis2[4];
     uint32_t locked_axes; /* bit0..2 lin x,y,z ; bit3..5 ang x,y,z */
     int32_t contacts_enabled;
+    uint32_t limit_axes;  /* JointAxesMask of the limited (free) axes — GenericJoint::limit_axes */
+    float limits[6][2];   /* JointLimits::{min, max} per axis (metres for the linear axes, radians for the angular ones) */
 } ro_joint_desc;
 
 typedef struct ro_world ro_world;

@@ -105,6 +105,12 @@ static inline float ro_atan2_pos(float y, float x) {
     if (x < 0.0f) return 3.14159265358979323846f + ro_atan_portable(y / x);
     return y > 0.0f ? 1.5707963267948966f : 0.0f;
 }
+/* atan2(y, x), full range, from the portable atan */
+static inline float ro_atan2_portable(float y, float x) {
+    if (x > 0.0f) return ro_atan_portable(y / x);
+    if (x < 0.0f) return y >= 0.0f ? ro_atan_portable(y / x) + 3.14159265358979323846f : ro_atan_portable(y / x) - 3.14159265358979323846f;
+    return y > 0.0f ? 1.5707963267948966f : (y < 0.0f ? -1.5707963267948966f : 0.0f);
+}
 /* Quat::to_scaled_axis: axis * angle, angle = 2 atan2(|v|, w) */
 static inline v3 quat_to_scaled_axis(quat q) {
     v3 v = V3(q.x, q.y, q.z);

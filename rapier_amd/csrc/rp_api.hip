@@ -590,7 +590,7 @@ extern "C" int32_t rp_impulse_joints_insert(rp_world *w, int32_t n, const rp_joi
     for (int i = 0; i < n; ++i) {
         const rp_joint_desc &j = descs[i];
         if (j.body1 < 0 || j.body2 < 0 || j.body1 >= (int)w->bodies.size() || j.body2 >= (int)w->bodies.size()) { w->err = "rp_impulse_joints_insert: invalid body index"; return RP_ERR_INVALID; }
-        if ((j.locked_axes & ~0x3fu) != 0 || j.locked_axes == 0) { w->err = "rp_impulse_joints_insert: locked_axes must be a non-empty JointAxesMask (limits, motors and coupled axes are not implemented on the device path)"; return RP_ERR_INVALID; }
+        if ((j.locked_axes & ~0x3fu) != 0 || (j.limit_axes & ~0x3fu) != 0 || (j.locked_axes | j.limit_axes) == 0) { w->err = "rp_impulse_joints_insert: locked_axes / limit_axes must be JointAxesMasks with at least one axis (motors and coupled axes are not implemented on the device path)"; return RP_ERR_INVALID; }
     }
     if (n > 0) { int r = rebuild_begin(w); if (r != RP_OK) return r; }
     for (int i = 0; i < n; ++i) {
@@ -802,7 +802,8 @@ static int finalize(rp_world *w) {
     // impulse joints: only joints with a dynamic side are active (select_active_interactions,
     // impulse_joint_set.rs:504-572), kept in edge order; frames go to solver-body space once
     // (GenericJoint::transform_to_solver_body_space, generic_joint.rs:624-636)
-    std::vector<int> jb1, jb2, jlocked, jcolor, bnj(nb, 0);
+    std::vector<int> jb1, jb2, jlocked, jlimited, jcolor, bnj(nb, 0);
+    std::vector<float4> jlim[6];
     std::vector<float4> jf1t, jf1r, jf2t, jf2r;
     w->active_joint_ids.clear();
     for (size_t ji = 0; ji < w->joints.size(); ++ji) {
@@ -828,7 +829,14 @@ static int finalize(rp_world *w) {
         jb1.push_back(d1 ? j.body1 : -1); jb2.push_back(d2 ? j.body2 : -1);
         jf1t.push_back(mk4(f1.t.x, f1.t.y, f1.t.z, 0)); jf1r.push_back(mk4(f1.r.x, f1.r.y, f1.r.z, f1.r.w));
         jf2t.push_back(mk4(f2.t.x, f2.t.y, f2.t.z, 0)); jf2r.push_back(mk4(f2.r.x, f2.r.y, f2.r.z, f2.r.w));
-        jlocked.push_back((int)j.locked_axes); jcolor.push_back(RP_COLOR_UNCOLORED);
+        jlocked.push_back((int)j.locked_axes); jlimited.push_back((int)(j.limit_axes & 0x3fu)); jcolor.push_back(RP_COLOR_UNCOLORED);
+        for (int a = 0; a < 3; ++a) jlim[a].push_back(mk4(j.limits[a][0], j.limits[a][1], 0, 0));
+        for (int a = 0; a < 3; ++a) { // AngularLimitParams::new(min, max) — joint_constraint_helper.rs:44-72
+            float mn = j.limits[3 + a][0], mx = j.limits[3 + a][1];
+            float half_range = (mx - mn) * 0.5f;
+            if (half_range >= 3.14159265358979323846f || half_range != half_range) jlim[3 + a].push_back(mk4(1.0f, 0.0f, 10.0f, 0));
+            else { float center = (mn + mx) * 0.5f; jlim[3 + a].push_back(mk4(cosf(center * 0.5f), sinf(center * 0.5f), half_range, 0)); }
+        }
         if (d1) bnj[j.body1]++;
         if (d2) bnj[j.body2]++;
         w->active_joint_ids.push_back((int)ji);
@@ -843,12 +851,14 @@ static int finalize(rp_world *w) {
         HIPCHK(w, hipStreamSynchronize(w->stream));
     }
     DA(d.j_b1, nj); DA(d.j_b2, nj); DA(d.j_f1t, nj); DA(d.j_f1r, nj); DA(d.j_f2t, nj); DA(d.j_f2r, nj);
-    DA(d.j_locked, nj); DA(d.j_color, nj); DA(d.j_tmp, nj); DA(d.j_order, nj); DA(d.j_imp, nj); DA(d.j_imp_ang, nj);
+    DA(d.j_locked, nj); DA(d.j_limited, nj); DA(d.j_color, nj); DA(d.j_tmp, nj); DA(d.j_order, nj); DA(d.j_imp, nj); DA(d.j_imp_ang, nj);
+    DA(d.j_lim, (size_t)6 * std::max(nj, 1)); DA(d.j_imp_lim, nj); DA(d.j_imp_lim_ang, nj);
     DA(d.j_stage_begin, RP_NUM_COLORS + 1); DA(d.j_stage_count, RP_NUM_COLORS + 1);
     DA(d.bj_cmask, 4 * (size_t)capb); DAF(d.bj_min, capb, 0xff); DA(d.b_njoints, capb);
-    DA(d.JR, (size_t)32 * std::max(nj, 1)); // JR_COUNT planes: 6 rows x 5 + im1 + im2 (rp_joints.h)
+    DA(d.JR, (size_t)38 * std::max(nj, 1)); // JR_COUNT planes: 6 rows x 6 + im1 + im2 (rp_joints.h)
     UP(d.j_b1, jb1); UP(d.j_b2, jb2); UP(d.j_f1t, jf1t); UP(d.j_f1r, jf1r); UP(d.j_f2t, jf2t); UP(d.j_f2r, jf2r);
-    UP(d.j_locked, jlocked); UP(d.j_color, jcolor); UP(d.b_njoints, bnj);
+    UP(d.j_locked, jlocked); UP(d.j_limited, jlimited); UP(d.j_color, jcolor); UP(d.b_njoints, bnj);
+    for (int a = 0; a < 6; ++a) if (nj > 0 && hipMemcpyAsync(d.j_lim + (size_t)a * nj, jlim[a].data(), (size_t)nj * sizeof(float4), hipMemcpyHostToDevice, w->stream) != hipSuccess) { w->err = "upload failed"; return RP_ERR_DEVICE; }
     {
         std::vector<int> bcol(nb, -1);
         for (int c = 0; c < nc; ++c) { int pb = w->collider_parent[c]; if (pb >= 0 && !w->collider_removed[c] && w->bodies[pb].d.body_type == RP_BODY_DYNAMIC && !w->bodies[pb].removed) bcol[pb] = c; }
@@ -1354,7 +1364,7 @@ static int remove_joint_at(rp_world *w, int j) {
         if (w->active_joint_ids[k] != j) continue;
         const rp_joint_desc &jd = w->joints[j];
         int r;
-        if ((r = poke(w, w->dw.j_b1 + k, -1)) != RP_OK || (r = poke(w, w->dw.j_b2 + k, -1)) != RP_OK || (r = poke(w, w->dw.j_locked + k, 0)) != RP_OK ||
+        if ((r = poke(w, w->dw.j_b1 + k, -1)) != RP_OK || (r = poke(w, w->dw.j_b2 + k, -1)) != RP_OK || (r = poke(w, w->dw.j_locked + k, 0)) != RP_OK || (r = poke(w, w->dw.j_limited + k, 0)) != RP_OK ||
             (r = poke(w, w->dw.j_imp + k, mk4(0, 0, 0, 0))) != RP_OK || (r = poke(w, w->dw.j_imp_ang + k, mk4(0, 0, 0, 0))) != RP_OK) return r;
         for (int b : {jd.body1, jd.body2}) {
             if (w->bodies[b].d.body_type == RP_BODY_FIXED || w->bodies[b].removed) continue;

@@ -15,8 +15,8 @@
 #pragma once
 #include "rp_world.h"
 
-// row planes: JR[plane][joint]; row r uses planes 5*r .. 5*r+4
-enum { JR_LIN = 0, JR_A1, JR_A2, JR_I1, JR_I2, JR_ROW_PLANES = 5, JR_MAX_ROWS = 6, JR_IM1 = 30, JR_IM2 = 31, JR_COUNT = 32 };
+// row planes: JR[plane][joint]; row r uses planes 6*r .. 6*r+5
+enum { JR_LIN = 0, JR_A1, JR_A2, JR_I1, JR_I2, JR_BND, JR_ROW_PLANES = 6, JR_MAX_ROWS = 6, JR_IM1 = 36, JR_IM2 = 37, JR_COUNT = 38 };
 #define JRP(plane, j) w.JR[(size_t)(plane) * w.n_joints + (j)]
 
 // select_active_interactions (impulse_joint_set.rs:504-572): a joint takes part in the step when it has a non-fixed side and
@@ -28,28 +28,36 @@ RP_DEV bool joint_live(const DevWorld &w, int j) {
     return !(b1 >= 0 && (w.b_flags[b1] & RP_BF_SLEEPING)) && !(b2 >= 0 && (w.b_flags[b2] & RP_BF_SLEEPING));
 }
 
-struct JointRow { V3 lin_jac, ang_jac1, ang_jac2, ii1, ii2; float impulse, inv_lhs, rhs, rhs_wo_bias, cfm_gain; };
+struct JointRow { V3 lin_jac, ang_jac1, ang_jac2, ii1, ii2; float impulse, inv_lhs, rhs, rhs_wo_bias, cfm_gain, bmin, bmax; };
+#define JR_UNBOUNDED 3.402823466e+38f // impulse_bounds of a lock row: [-f32::MAX, f32::MAX]
 
 RP_DEV void jrow_load(const DevWorld &w, int j, int r, JointRow &c) {
-    float4 a = JRP(5 * r + JR_LIN, j), b = JRP(5 * r + JR_A1, j), d = JRP(5 * r + JR_A2, j), e = JRP(5 * r + JR_I1, j), f = JRP(5 * r + JR_I2, j);
+    float4 a = JRP(JR_ROW_PLANES * r + JR_LIN, j), b = JRP(JR_ROW_PLANES * r + JR_A1, j), d = JRP(JR_ROW_PLANES * r + JR_A2, j), e = JRP(JR_ROW_PLANES * r + JR_I1, j), f = JRP(JR_ROW_PLANES * r + JR_I2, j);
     c.lin_jac = v3(a); c.impulse = a.w; c.ang_jac1 = v3(b); c.inv_lhs = b.w; c.ang_jac2 = v3(d); c.rhs = d.w;
     c.ii1 = v3(e); c.rhs_wo_bias = e.w; c.ii2 = v3(f); c.cfm_gain = f.w;
+    float4 g = JRP(JR_ROW_PLANES * r + JR_BND, j); c.bmin = g.x; c.bmax = g.y;
 }
 RP_DEV void jrow_store(const DevWorld &w, int j, int r, const JointRow &c) {
-    JRP(5 * r + JR_LIN, j) = f4(c.lin_jac, c.impulse); JRP(5 * r + JR_A1, j) = f4(c.ang_jac1, c.inv_lhs);
-    JRP(5 * r + JR_A2, j) = f4(c.ang_jac2, c.rhs); JRP(5 * r + JR_I1, j) = f4(c.ii1, c.rhs_wo_bias); JRP(5 * r + JR_I2, j) = f4(c.ii2, c.cfm_gain);
+    JRP(JR_ROW_PLANES * r + JR_LIN, j) = f4(c.lin_jac, c.impulse); JRP(JR_ROW_PLANES * r + JR_A1, j) = f4(c.ang_jac1, c.inv_lhs);
+    JRP(JR_ROW_PLANES * r + JR_A2, j) = f4(c.ang_jac2, c.rhs); JRP(JR_ROW_PLANES * r + JR_I1, j) = f4(c.ii1, c.rhs_wo_bias); JRP(JR_ROW_PLANES * r + JR_I2, j) = f4(c.ii2, c.cfm_gain);
+    JRP(JR_ROW_PLANES * r + JR_BND, j) = make_float4(c.bmin, c.bmax, 0.0f, 0.0f);
 }
-RP_DEV int joint_row_count(int locked) { return __popc((unsigned)locked & 0x3fu); }
-// WritebackId::Dof of row k: locked angular axes first (dof 3 + a), then locked linear axes (dof i)
-RP_DEV int joint_row_dof(int locked, int k) {
+// rows of a joint: its locked axes, then the limits of its free axes (GenericJoint::limit_axes & !locked_axes)
+RP_DEV int joint_row_count(int locked, int limited) { return __popc(((unsigned)locked | ((unsigned)limited & ~(unsigned)locked)) & 0x3fu); }
+// WritebackId of row k (scalar update order, joint_velocity_constraint.rs:253-314): Dof(3 + a) for the locked angular axes,
+// Dof(i) for the locked linear ones, then Limit(3 + a) and Limit(i), encoded as 6 + axis
+RP_DEV int joint_row_dof(int locked, int limited, int k) {
+    limited &= ~locked;
     for (int a = 0; a < 3; ++a) if (locked & (8 << a)) { if (k == 0) return 3 + a; --k; }
     for (int i = 0; i < 3; ++i) if (locked & (1 << i)) { if (k == 0) return i; --k; }
+    for (int a = 0; a < 3; ++a) if (limited & (8 << a)) { if (k == 0) return 6 + 3 + a; --k; }
+    for (int i = 0; i < 3; ++i) if (limited & (1 << i)) { if (k == 0) return 6 + i; --k; }
     return 0;
 }
 
 // JointConstraintBuilder::update for joint j (rows rebuilt from the solver poses s_rot / s_trans).
 RP_DEV void joint_update_one(const DevWorld &w, int j, int substep_id) {
-    int b1 = w.j_b1[j], b2 = w.j_b2[j], locked = w.j_locked[j];
+    int b1 = w.j_b1[j], b2 = w.j_b2[j], locked = w.j_locked[j], limited = w.j_limited[j] & ~locked;
     Pose p1, p2; p1.r = q4(0, 0, 0, 1); p1.t = v3(0, 0, 0); p2 = p1;
     V3 im1 = v3(0, 0, 0), im2 = im1; Sym3 ii1 = {0, 0, 0, 0, 0, 0}, ii2 = ii1;
     if (b1 >= 0) { p1.r = q4(w.s_rot[b1]); p1.t = v3(w.s_trans[b1]); im1 = v3(w.b_eim[b1]); float4 a = w.b_eii0[b1], b = w.b_eii1[b1]; ii1.m11 = a.x; ii1.m12 = a.y; ii1.m13 = a.z; ii1.m22 = a.w; ii1.m23 = b.x; ii1.m33 = b.y; }
@@ -68,11 +76,14 @@ RP_DEV void joint_update_one(const DevWorld &w, int j, int substep_id) {
     V3 c1x = v3(0.0f, r1.z, -r1.y), c1y = v3(-r1.z, 0.0f, r1.x), c1z = v3(r1.y, -r1.x, 0.0f);
     V3 c2x = v3(0.0f, r2.z, -r2.y), c2y = v3(-r2.z, 0.0f, r2.x), c2z = v3(r2.y, -r2.x, 0.0f);
     const bool ws = w.prm.p.warmstart_joints != 0;
-    float prev[6] = {0, 0, 0, 0, 0, 0}, seed[6] = {0, 0, 0, 0, 0, 0};
-    int nrows = joint_row_count(locked);
+    float prev[6] = {0, 0, 0, 0, 0, 0}, seed[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int nrows = joint_row_count(locked, limited);
     if (ws) {
-        if (substep_id > 0) { for (int k = 0; k < nrows; ++k) prev[k] = JRP(5 * k + JR_LIN, j).w; }
-        else { float4 s = w.j_imp[j], sa = w.j_imp_ang[j]; seed[0] = s.x; seed[1] = s.y; seed[2] = s.z; seed[3] = sa.x; seed[4] = sa.y; seed[5] = sa.z; }
+        if (substep_id > 0) { for (int k = 0; k < nrows; ++k) prev[k] = JRP(JR_ROW_PLANES * k + JR_LIN, j).w; }
+        else {
+            float4 s = w.j_imp[j], sa = w.j_imp_ang[j]; seed[0] = s.x; seed[1] = s.y; seed[2] = s.z; seed[3] = sa.x; seed[4] = sa.y; seed[5] = sa.z;
+            if (limited) { float4 l = w.j_imp_lim[j], la = w.j_imp_lim_ang[j]; seed[6] = l.x; seed[7] = l.y; seed[8] = l.z; seed[9] = la.x; seed[10] = la.y; seed[11] = la.z; }
+        }
     }
     JointRow rows[6];
     int dof[6] = {0, 0, 0, 0, 0, 0};
@@ -112,7 +123,7 @@ RP_DEV void joint_update_one(const DevWorld &w, int j, int substep_id) {
             float rhs_bias = ang_err_imag[a] * w.prm.joint_erp_inv_dt;
             c.ii1 = sym_mul(ii1, ang_jac);
             c.ii2 = sym_mul(ii2, ang_jac);
-            c.inv_lhs = 0.0f; c.cfm_gain = 0.0f;
+            c.inv_lhs = 0.0f; c.cfm_gain = 0.0f; c.bmin = -JR_UNBOUNDED; c.bmax = JR_UNBOUNDED;
             c.rhs = rhs_wo_bias + rhs_bias; c.rhs_wo_bias = rhs_wo_bias;
             dof[len] = 3 + a;
             len++;
@@ -130,12 +141,69 @@ RP_DEV void joint_update_one(const DevWorld &w, int j, int substep_id) {
         float rhs_bias = dot(c.lin_jac, lin_err) * w.prm.joint_erp_inv_dt;
         c.ii1 = sym_mul(ii1, c.ang_jac1);
         c.ii2 = sym_mul(ii2, c.ang_jac2);
-        c.inv_lhs = 0.0f; c.cfm_gain = 0.0f;
+        c.inv_lhs = 0.0f; c.cfm_gain = 0.0f; c.bmin = -JR_UNBOUNDED; c.bmax = JR_UNBOUNDED;
         c.rhs = rhs_wo_bias + rhs_bias; c.rhs_wo_bias = rhs_wo_bias;
         dof[len] = i;
         len++;
     }
-    // finalize_constraints: modified Gram-Schmidt (every lock row has unbounded impulses)
+    if (limited) {
+        // limited (free) axes: limit_angular rows, then limit_linear rows (joint_constraint_helper.rs:166-208, 468-564)
+        const float maxcv = w.prm.max_corrective_velocity, erp = w.prm.joint_erp_inv_dt;
+        const float inf = __int_as_float(0x7f800000);
+        if (limited & 0x38) {
+            Q4 q1 = frame1.r, q2 = frame2.r;
+            float sgn = copysignf(1.0f, qdot(q1, q2));
+            Q4 ang_err = qmul(qconj(q1), q2);
+            float imag[3] = {ang_err.x * sgn, ang_err.y * sgn, ang_err.z * sgn}, real = ang_err.w * sgn;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                if (!(limited & (8 << a))) continue;
+                float4 lp = w.j_lim[(size_t)(3 + a) * w.n_joints + j]; // c_cos, c_sin, half_range
+                float x = imag[a];
+                float sin_half = lp.x * x - lp.y * real;
+                float cos_half = lp.x * real + lp.y * x;
+                float half = rp_atan2_portable(sin_half, cos_half);
+                float shift = copysignf(3.14159265358979323846f, half);
+                float wrapped_half = fabsf(half) > 1.5707963267948966f ? half - shift : half;
+                float ang = wrapped_half * 2.0f;
+                bool min_enabled = ang <= -lp.z, max_enabled = lp.z <= ang;
+                V3 ang_jac = col[a];
+                JointRow &c = rows[len];
+                c.impulse = 0.0f; c.bmin = min_enabled ? -inf : 0.0f; c.bmax = max_enabled ? inf : 0.0f;
+                c.lin_jac = v3(0, 0, 0); c.ang_jac1 = ang_jac; c.ang_jac2 = ang_jac;
+                float rhs_wo_bias = 0.0f;
+                float rhs_bias = rp_clamp((rp_max(ang - lp.z, 0.0f) - rp_max(-lp.z - ang, 0.0f)) * erp, -maxcv, maxcv);
+                c.ii1 = sym_mul(ii1, ang_jac);
+                c.ii2 = sym_mul(ii2, ang_jac);
+                c.inv_lhs = 0.0f; c.cfm_gain = 0.0f;
+                c.rhs = rhs_wo_bias + rhs_bias; c.rhs_wo_bias = rhs_wo_bias;
+                dof[len] = 6 + 3 + a;
+                len++;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (!(limited & (1 << i))) continue;
+            float4 lp = w.j_lim[(size_t)i * w.n_joints + j]; // min, max
+            JointRow &c = rows[len];
+            c.impulse = 0.0f;
+            c.lin_jac = col[i];
+            c.ang_jac1 = c1x * col[i].x + c1y * col[i].y + c1z * col[i].z;
+            c.ang_jac2 = c2x * col[i].x + c2y * col[i].y + c2z * col[i].z;
+            c.ii1 = sym_mul(ii1, c.ang_jac1);
+            c.ii2 = sym_mul(ii2, c.ang_jac2);
+            float dist = dot(lin_err, c.lin_jac);
+            bool min_enabled = dist <= lp.x, max_enabled = lp.y <= dist;
+            float rhs_wo_bias = 0.0f;
+            float rhs_bias = rp_clamp((rp_max(dist - lp.y, 0.0f) - rp_max(lp.x - dist, 0.0f)) * erp, -maxcv, maxcv);
+            c.inv_lhs = 0.0f; c.cfm_gain = 0.0f;
+            c.rhs = rhs_wo_bias + rhs_bias; c.rhs_wo_bias = rhs_wo_bias;
+            c.bmin = min_enabled ? -inf : 0.0f; c.bmax = max_enabled ? inf : 0.0f;
+            dof[len] = 6 + i;
+            len++;
+        }
+    }
+    // finalize_constraints: modified Gram-Schmidt; rows with bounded impulses (limits) are not removed from the others
     V3 imsum = im1 + im2;
     for (int a = 0; a < len; ++a) {
         JointRow &cj = rows[a];
@@ -144,6 +212,7 @@ RP_DEV void joint_update_one(const DevWorld &w, int j, int substep_id) {
         float inv_dot_jj = rp_inv(dot_jj);
         cj.inv_lhs = rp_inv(dot_jj + cfm_gain);
         cj.cfm_gain = cfm_gain;
+        if (cj.bmin != -JR_UNBOUNDED || cj.bmax != JR_UNBOUNDED) continue;
         for (int b = a + 1; b < len; ++b) {
             JointRow &ci = rows[b];
             float dot_ij = dot(ci.lin_jac, cmul(imsum, cj.lin_jac)) + dot(ci.ii1, cj.ang_jac1) + dot(ci.ii2, cj.ang_jac2);
@@ -168,7 +237,7 @@ RP_DEV void joint_update_one(const DevWorld &w, int j, int substep_id) {
 // All rows of joint j: [remove bias] [warm start] solve — solve_joint, staged_island_solver/solve.rs:31-47
 RP_DEV void joint_solve_one(const DevWorld &w, int j, bool wo_bias, bool warmstart) {
     int b1 = w.j_b1[j], b2 = w.j_b2[j];
-    int nrows = joint_row_count(w.j_locked[j]);
+    int nrows = joint_row_count(w.j_locked[j], w.j_limited[j]);
     V3 im1 = v3(JRP(JR_IM1, j)), im2 = v3(JRP(JR_IM2, j));
     V3 l1 = v3(0, 0, 0), a1 = l1, l2 = l1, a2 = l1;
     if (b1 >= 0) { l1 = v3(w.s_lin[b1]); a1 = v3(w.s_ang[b1]); }
@@ -188,8 +257,8 @@ RP_DEV void joint_solve_one(const DevWorld &w, int j, bool wo_bias, bool warmsta
         float dlinvel = dot(c.lin_jac, l2 - l1);
         float dangvel = dot(c.ang_jac2, a2) - dot(c.ang_jac1, a1);
         float rhs = dlinvel + dangvel + c.rhs;
-        float total = c.impulse + c.inv_lhs * (rhs - c.cfm_gain * c.impulse); // lock rows: unbounded impulses (clamp to +-f32::MAX is the identity on finite values)
-        total = rp_clamp(total, -3.402823466e+38f, 3.402823466e+38f);
+        float total = c.impulse + c.inv_lhs * (rhs - c.cfm_gain * c.impulse);
+        total = rp_clamp(total, c.bmin, c.bmax); // lock rows: +-f32::MAX; limit rows: one-sided or zero
         float delta = total - c.impulse;
         c.impulse = total;
         V3 lin_impulse = c.lin_jac * delta;
@@ -199,8 +268,8 @@ RP_DEV void joint_solve_one(const DevWorld &w, int j, bool wo_bias, bool warmsta
         if (b1 < 0) { l1 = v3(0, 0, 0); a1 = l1; }
         if (b2 < 0) { l2 = v3(0, 0, 0); a2 = l2; }
         // only the mutable words of the row go back
-        JRP(5 * r + JR_LIN, j).w = c.impulse;
-        if (wo_bias) JRP(5 * r + JR_A2, j).w = c.rhs;
+        JRP(JR_ROW_PLANES * r + JR_LIN, j).w = c.impulse;
+        if (wo_bias) JRP(JR_ROW_PLANES * r + JR_A2, j).w = c.rhs;
     }
     if (b1 >= 0) { w.s_lin[b1] = f4(l1, 0.0f); w.s_ang[b1] = f4(a1, 0.0f); }
     if (b2 >= 0) { w.s_lin[b2] = f4(l2, 0.0f); w.s_ang[b2] = f4(a2, 0.0f); }
@@ -208,14 +277,16 @@ RP_DEV void joint_solve_one(const DevWorld &w, int j, bool wo_bias, bool warmsta
 
 // JointConstraint::writeback_impulses — joint_velocity_constraint.rs:346-353
 RP_DEV void joint_writeback_one(const DevWorld &w, int j) {
-    int locked = w.j_locked[j];
-    float imp[6] = {0, 0, 0, 0, 0, 0};
+    int locked = w.j_locked[j], limited = w.j_limited[j] & ~locked;
+    float imp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     float4 old = w.j_imp[j], olda = w.j_imp_ang[j];
     imp[0] = old.x; imp[1] = old.y; imp[2] = old.z; imp[3] = olda.x; imp[4] = olda.y; imp[5] = olda.z;
-    int nrows = joint_row_count(locked);
-    for (int k = 0; k < nrows; ++k) imp[joint_row_dof(locked, k)] = JRP(5 * k + JR_LIN, j).w;
+    if (limited) { float4 l = w.j_imp_lim[j], la = w.j_imp_lim_ang[j]; imp[6] = l.x; imp[7] = l.y; imp[8] = l.z; imp[9] = la.x; imp[10] = la.y; imp[11] = la.z; }
+    int nrows = joint_row_count(locked, limited);
+    for (int k = 0; k < nrows; ++k) imp[joint_row_dof(locked, limited, k)] = JRP(JR_ROW_PLANES * k + JR_LIN, j).w;
     w.j_imp[j] = make_float4(imp[0], imp[1], imp[2], 0.0f);
     w.j_imp_ang[j] = make_float4(imp[3], imp[4], imp[5], 0.0f);
+    if (limited) { w.j_imp_lim[j] = make_float4(imp[6], imp[7], imp[8], 0.0f); w.j_imp_lim_ang[j] = make_float4(imp[9], imp[10], imp[11], 0.0f); } // JointLimits::impulse
 }
 
 // One sweep over the joints inside a single workgroup (SINGLE mode and the serial tail): parallel joint

@@ -97,6 +97,11 @@ RP_HD float rp_atan2_pos(float y, float x) { // y >= 0
     if (x < 0.0f) return 3.14159265358979323846f + rp_atan_portable(y / x);
     return y > 0.0f ? 1.5707963267948966f : 0.0f;
 }
+RP_HD float rp_atan2_portable(float y, float x) { // full range
+    if (x > 0.0f) return rp_atan_portable(y / x);
+    if (x < 0.0f) return y >= 0.0f ? rp_atan_portable(y / x) + 3.14159265358979323846f : rp_atan_portable(y / x) - 3.14159265358979323846f;
+    return y > 0.0f ? 1.5707963267948966f : (y < 0.0f ? -1.5707963267948966f : 0.0f);
+}
 // Quat::to_scaled_axis: axis * angle, angle = 2 atan2(|v|, w)
 RP_HD V3 quat_to_scaled_axis(Q4 q) {
     V3 v = v3(q.x, q.y, q.z);

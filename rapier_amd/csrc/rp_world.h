@@ -248,7 +248,9 @@ struct DevWorld {
     // ---- impulse joints (active joints only, edge order) ----
     int *j_b1, *j_b2;           // arena index of the dynamic body on each side, -1 = world-attached side
     float4 *j_f1t, *j_f1r, *j_f2t, *j_f2r; // local frames in solver-body (CoM) space: translation, rotation
-    int *j_locked, *j_color, *j_tmp, *j_order;
+    int *j_locked, *j_limited, *j_color, *j_tmp, *j_order; // JointAxesMask of the locked / limited axes
+    float4 *j_lim;              // [6][n_joints] limit of axis a: linear (min, max, -, -), angular AngularLimitParams (cos, sin, half_range, -)
+    float4 *j_imp_lim, *j_imp_lim_ang; // JointLimits::impulse of the linear / angular axes
     int *j_stage_begin, *j_stage_count;    // parallel joint colour stages inside j_order
     float4 *j_imp, *j_imp_ang;  // per-dof impulses written back at the end of the step (linear dofs, angular dofs)
     unsigned int *bj_cmask;     // [4 * n_bodies] colours taken by joints (bodies_color workspace)

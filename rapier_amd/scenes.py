@@ -38,7 +38,7 @@ ACTIVE_EVENTS_COLLISION, ACTIVE_EVENTS_CONTACT_FORCE = 1, 2  # ActiveEvents bits
 JOINT_DTYPE = np.dtype([
     ("body1", "<i4"), ("body2", "<i4"), ("local_anchor1", "<f4", 3), ("local_anchor2", "<f4", 3),
     ("local_basis1", "<f4", 4), ("local_basis2", "<f4", 4), ("locked_axes", "<u4"),
-    ("contacts_enabled", "<i4"),
+    ("contacts_enabled", "<i4"), ("limit_axes", "<u4"), ("limits", "<f4", (6, 2)),
 ], align=False)
 PARAMS_DTYPE = np.dtype([
     ("dt", "<f4"),
@@ -159,13 +159,18 @@ class Scene:
         return len(self.colliders) - 1
 
     def add_joint(self, body1, body2, anchor1, anchor2, locked_axes=LOCK_LIN, contacts_enabled=1,
-                  basis1=(0, 0, 0, 1), basis2=(0, 0, 0, 1)) -> int:
+                  basis1=(0, 0, 0, 1), basis2=(0, 0, 0, 1), limits=None) -> int:
+        """``limits`` = {axis: (min, max)} with axis 0..2 = translation along the frame's X/Y/Z (metres), 3..5 = rotation about
+        them (radians): GenericJoint::set_limits."""
         j = np.zeros((), dtype=JOINT_DTYPE)
         j["body1"], j["body2"] = body1, body2
         j["local_anchor1"], j["local_anchor2"] = anchor1, anchor2
         j["local_basis1"] = basis1
         j["local_basis2"] = basis2
         j["locked_axes"], j["contacts_enabled"] = locked_axes, contacts_enabled
+        for axis, (lo, hi) in (limits or {}).items():
+            j["limit_axes"] |= np.uint32(1 << axis)
+            j["limits"][axis] = (lo, hi)
         self.joints.append(j)
         return len(self.joints) - 1
 
@@ -495,4 +500,33 @@ def kinematic_crane(n: int = 5) -> Scene:
     for k in range(3):
         c = s.add_body(translation=(_f(0.5 + 1.2 * k), 0.5, 0.0), can_sleep=1)
         s.add_collider(c, half_extents=(0.3, 0.5, 0.3))
+    return s
+
+
+def limited_joints() -> Scene:
+    """Joint-limit test scene (not a reference scene): a weight on a vertical prismatic slider with limits (it drops to
+    the lower stop), a door on a revolute hinge with limits +-0.6 rad pushed into its stop, and a free-swinging limited
+    pendulum; next to a small stack."""
+    s = Scene(name="limited_joints", gravity=(0.0, -9.81, 0.0))
+    g = s.add_body(body_type=BODY_FIXED, translation=(0.0, -0.5, 0.0))
+    s.add_collider(g, half_extents=(20.0, 0.5, 20.0))
+    axis_y = (0.0, 0.0, 0.70710678, 0.70710678)   # frame X axis = body Y axis
+    rail = s.add_body(body_type=BODY_FIXED, translation=(0.0, 5.0, 0.0))
+    s.add_collider(rail, half_extents=(0.1, 0.1, 0.1))
+    w = s.add_body(translation=(0.0, 5.0, 0.0))
+    s.add_collider(w, half_extents=(0.3, 0.3, 0.3), density=2.0)
+    s.add_joint(rail, w, (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), locked_axes=LOCK_PRISMATIC, basis1=axis_y, basis2=axis_y, limits={0: (-1.5, 0.5)})
+    post = s.add_body(body_type=BODY_FIXED, translation=(-5.0, 1.5, 0.0))
+    s.add_collider(post, half_extents=(0.1, 1.5, 0.1))
+    door = s.add_body(translation=(-4.0, 1.5, 0.0), angvel=(0.0, 2.5, 0.0), linvel=(0.0, 0.0, -2.5))
+    s.add_collider(door, half_extents=(0.8, 1.0, 0.05), density=2.0)
+    s.add_joint(post, door, (0.0, 0.0, 0.0), (-1.0, 0.0, 0.0), locked_axes=LOCK_REVOLUTE, basis1=axis_y, basis2=axis_y, limits={3: (-0.6, 0.6)})
+    pivot = s.add_body(body_type=BODY_FIXED, translation=(5.0, 4.0, 0.0))
+    s.add_collider(pivot, shape=SHAPE_BALL, half_extents=(0.1, 0.0, 0.0))
+    bob = s.add_body(translation=(6.5, 4.0, 0.0))
+    s.add_collider(bob, shape=SHAPE_BALL, half_extents=(0.3, 0.0, 0.0), density=3.0)
+    s.add_joint(pivot, bob, (0.0, 0.0, 0.0), (-1.5, 0.0, 0.0), locked_axes=LOCK_REVOLUTE, basis1=AXIS_Z_BASIS, basis2=AXIS_Z_BASIS, limits={3: (-0.8, 0.3)})
+    for i in range(2):
+        b = s.add_body(translation=(2.0, 0.5 + i, 0.0))
+        s.add_collider(b, half_extents=(0.5, 0.5, 0.5))
     return s

@@ -30,6 +30,7 @@ CASES = {
     "compound_bodies6_s150": lambda: (S.compound_bodies(6), 150),
     "locked_axes_s150": lambda: (S.locked_axes_scene(), 150),
     "overlapping_chain6_s100": lambda: (S.overlapping_chain(6, 0), 100),
+    "limited_joints_s150": lambda: (S.limited_joints(), 150),
 }
 
 

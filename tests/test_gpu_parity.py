@@ -503,6 +503,14 @@ def test_joints_with_sleeping_and_kinematic_bodies_bit_exact():
     assert np.linalg.norm(pos[2, :3] - pos[1, :3]) == pytest.approx(0.7, abs=2e-2)           # and drags the chain along
 
 
+def test_joint_limits_bit_exact():
+    g, o = _compare(S.limited_joints(), [1, 2, 10, 40, 120, 300])
+    gc, gi = g.read_joints(); oc, oi = o.read_joints()
+    np.testing.assert_array_equal(gc, oc); np.testing.assert_array_equal(gi, oi)
+    pos, _ = g.read_bodies()
+    assert pos[2, 1] == pytest.approx(3.5, abs=5e-3)           # the slider rests on its lower stop
+
+
 def test_contact_disabling_joints_bit_exact():
     """GenericJoint::contacts_enabled = false: the pairs between the two jointed bodies are cleared (pair_update.rs:191-201)."""
     g, o = _compare(S.overlapping_chain(6, 0), [1, 2, 10, 60, 200])

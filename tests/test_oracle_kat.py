@@ -298,6 +298,20 @@ def test_staged_scene_with_revolute_pair_and_locked_angular_axes():
     np.testing.assert_allclose(pos[w1, 3:], pos[w2, 3:], atol=2e-3)            # welded: same orientation
 
 
+# Joint limits (limit_linear / limit_angular, joint_constraint_helper.rs:166-208, 468-564): a slider drops to its lower stop,
+# a door pushed into its stop stays at the limit angle, a pendulum cannot swing past its range.
+def test_joint_limits_stop_at_their_bounds():
+    w = OracleWorld(S.limited_joints())
+    w.step(200)
+    pos, vel = w.read()
+    assert pos[2, 1] == pytest.approx(5.0 - 1.5, abs=5e-3)                       # prismatic lower limit -1.5 along the rail
+    assert abs(pos[2, 0]) < 1e-3 and abs(pos[2, 2]) < 1e-3
+    yaw = 2.0 * np.arctan2(pos[4, 4], pos[4, 6])
+    assert yaw == pytest.approx(0.6, abs=5e-3) and abs(vel[4, 4]) < 1e-2          # revolute upper limit +0.6 rad
+    roll = 2.0 * np.arctan2(pos[6, 5], pos[6, 6])
+    assert roll == pytest.approx(-0.8, abs=5e-3)                                  # pendulum lower limit -0.8 rad
+
+
 # Events (pipeline/event_handler.rs:94-160): Started / Stopped on touching transitions, contact force events above the
 # threshold with `started` on the first step above it (geometry/mod.rs:223-258).
 def test_collision_and_contact_force_events():
