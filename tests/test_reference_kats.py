@@ -1,0 +1,356 @@
+"""More of the reference's own outcome-level tests, restated against the CPU oracle (CPU only).
+
+Each test names the reference test it restates (/root/reference/crates/rapier3d/tests/*.rs) and keeps its scene, step
+counts and acceptance thresholds.  Together with tests/test_oracle_kat.py these pin the oracle — and, through the bit-exact
+GPU parity tests, the HIP path — to the behaviour the reference's maintainers assert.
+"""
+import numpy as np
+import pytest
+
+from rapier_amd import scenes as S
+from oracle_ffi import OracleWorld
+
+
+def quat_from_scaled_axis(v):
+    v = np.asarray(v, np.float64)
+    ang = np.linalg.norm(v)
+    if ang == 0.0:
+        return (0.0, 0.0, 0.0, 1.0)
+    ax = v / ang
+    s = np.sin(ang / 2)
+    return (float(ax[0] * s), float(ax[1] * s), float(ax[2] * s), float(np.cos(ang / 2)))
+
+
+def rot_matrix(q):
+    x, y, z, w = [float(c) for c in q]
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def world(gravity=(0.0, -9.81, 0.0), dt=None):
+    sc = S.Scene(name="kat", gravity=gravity)
+    if dt is not None:
+        sc.params["dt"] = dt
+    return sc
+
+
+def ground(sc, he=(100.0, 0.5, 100.0), y=-0.5):
+    g = sc.add_body(body_type=S.BODY_FIXED, translation=(0.0, y, 0.0))
+    sc.add_collider(g, half_extents=he)
+    return g
+
+
+def stack(sc, x, num, can_sleep=1):
+    out = []
+    for i in range(num):
+        b = sc.add_body(translation=(x, 0.5 + i * 1.0, 0.0), can_sleep=can_sleep)
+        sc.add_collider(b, half_extents=(0.5, 0.5, 0.5))
+        out.append(b)
+    return out
+
+
+# ---- whole_island_sleep.rs ------------------------------------------------------------------------------------
+def test_whole_island_blocks_partial_sleep():
+    """whole_island_sleep.rs:39-77 (and :79-103): no body of an island holding a can_sleep(false) body may sleep; once that
+    body is removed the whole stack sleeps; waking one body wakes the island as a unit."""
+    sc = world()
+    ground(sc)
+    st = stack(sc, 0.0, 6)
+    restless = sc.add_body(translation=(0.0, 6.5, 0.0), can_sleep=0)
+    sc.add_collider(restless, half_extents=(0.5, 0.5, 0.5))
+    w = OracleWorld(sc)
+    w.step(240)
+    assert w.sleeping().sum() == 0
+    w.remove_body(restless)
+    w.step(240)
+    assert w.sleeping()[st].all()
+    w.wake_up(st[0], True)
+    w.step(1)                                   # a wake-up request takes effect at the next step here
+    assert w.sleeping().sum() == 0
+
+
+def test_whole_island_sleeps_after_mover_departs():
+    """whole_island_sleep.rs:105-140: a sliding kinematic body in contact keeps the island awake; the stack sleeps once the
+    mover slid out of contact; the mover itself (non-zero velocity) never sleeps."""
+    sc = world()
+    ground(sc)
+    st = stack(sc, 0.0, 4)
+    mover = sc.add_body(body_type=S.BODY_KINEMATIC_VELOCITY, translation=(0.999, 0.5, -0.9), linvel=(0.0, 0.0, 0.8))
+    sc.add_collider(mover, half_extents=(0.5, 0.5, 0.5))
+    w = OracleWorld(sc)
+    w.step(90)
+    assert w.sleeping().sum() == 0
+    w.step(240)
+    assert w.sleeping()[st].all() and not w.sleeping()[mover]
+
+
+# ---- gyroscopic.rs ----------------------------------------------------------------------------------------------
+def _spinning_box(gyroscopic):
+    sc = world(gravity=(0.0, 0.0, 0.0))
+    b = sc.add_body(angvel=(6.0, 6.0, 0.0), gyroscopic=1 if gyroscopic else 0)
+    sc.add_collider(b, half_extents=(1.0, 2.0, 3.0), density=1.0)
+    return OracleWorld(sc), b
+
+
+def test_angular_velocity_precesses_with_gyroscopic():
+    """gyroscopic.rs:39-55"""
+    w, b = _spinning_box(True)
+    w0 = np.array([6.0, 6.0, 0.0])
+    min_cos = np.inf
+    for _ in range(300):
+        w.step(1)
+        av = w.read()[1][b, 3:].astype(np.float64)
+        min_cos = min(min_cos, av @ w0 / (np.linalg.norm(av) * np.linalg.norm(w0)))
+    assert min_cos < 0.9
+
+
+def test_angular_velocity_fixed_without_gyroscopic():
+    """gyroscopic.rs:57-82"""
+    w, b = _spinning_box(False)
+    w0 = np.array([6.0, 6.0, 0.0])
+    min_cos, max_err = np.inf, 0.0
+    for _ in range(300):
+        w.step(1)
+        av = w.read()[1][b, 3:].astype(np.float64)
+        min_cos = min(min_cos, av @ w0 / (np.linalg.norm(av) * np.linalg.norm(w0)))
+        max_err = max(max_err, abs(np.linalg.norm(av) - np.linalg.norm(w0)))
+    assert min_cos > 0.9999 and max_err < 1.0e-3
+
+
+def test_angular_momentum_conserved_with_tilted_principal_frame():
+    """gyroscopic.rs:84-140: a cuboid collider attached with a rotation gives a tilted principal frame; the world angular
+    momentum keeps its magnitude (2 %) and direction (cos > 0.999) over 600 steps."""
+    sc = world(gravity=(0.0, 0.0, 0.0))
+    b = sc.add_body(angvel=(3.0, 7.0, 2.0), gyroscopic=1)
+    tilt = quat_from_scaled_axis(np.array([1.0, 1.0, 1.0]) / np.sqrt(3.0) * 0.7)
+    sc.add_collider(b, half_extents=(1.0, 2.0, 3.0), density=1.0, rotation=tilt)
+    w = OracleWorld(sc)
+    mp = w.mass_props(b).astype(np.float64)
+    frame = mp[7:11]
+    assert 2.0 * np.arccos(min(1.0, abs(frame[3]))) > 0.1       # tilted principal frame
+    inertia_local = rot_matrix(frame) @ np.diag(1.0 / mp[4:7]) @ rot_matrix(frame).T
+
+    def momentum():
+        pos, vel = w.read()
+        r = rot_matrix(pos[b, 3:])
+        return r @ (inertia_local @ (r.T @ vel[b, 3:].astype(np.float64)))
+    l0 = momentum(); n0 = np.linalg.norm(l0)
+    max_mag_err, min_cos = 0.0, np.inf
+    for _ in range(600):
+        w.step(1)
+        l = momentum()
+        max_mag_err = max(max_mag_err, abs(np.linalg.norm(l) - n0) / n0)
+        min_cos = min(min_cos, l @ l0 / (np.linalg.norm(l) * n0))
+    assert max_mag_err < 0.02 and min_cos > 0.999
+
+
+# ---- issue_287_kinematic_wakes_jointed_dynamic.rs -------------------------------------------------------------------
+def test_moving_kinematic_wakes_jointed_dynamic():
+    sc = world()
+    kin = sc.add_body(body_type=S.BODY_KINEMATIC_POSITION, can_sleep=1)
+    dyn = sc.add_body(translation=(0.0, -2.0, 0.0), can_sleep=1)
+    sc.add_collider(dyn, shape=S.SHAPE_BALL, half_extents=(0.5, 0.0, 0.0))
+    sc.add_joint(kin, dyn, (0.0, 0.0, 0.0), (0.0, 2.0, 0.0), locked_axes=S.LOCK_REVOLUTE)   # RevoluteJointBuilder::new(Vector::X)
+    w = OracleWorld(sc)
+    steps = 0
+    while not w.sleeping()[dyn]:
+        w.step(1); steps += 1
+        assert steps < 2000, "dynamic body never fell asleep"
+    woke, x = False, 0.0
+    for _ in range(200):
+        x += 0.05
+        w.set_next_kinematic_position(kin, [x, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0])
+        w.step(1)
+        woke = woke or not w.sleeping()[dyn]
+    assert woke
+    assert abs(w.read()[0][dyn, 0] - x) < 2.0
+
+
+# ---- issue_309_locked_rotations_offset_com.rs --------------------------------------------------------------------------
+def _offset_com_body():
+    sc = world(gravity=(0.0, 0.0, 0.0))
+    b = sc.add_body(locked_axes=0x38)           # lock_rotations()
+    sc.add_collider(b, half_extents=(0.5, 0.5, 0.5), translation=(1.0, 0.0, 0.0))
+    return OracleWorld(sc), b
+
+
+def test_angvel_rotation_pivots_about_center_of_mass():
+    w, b = _offset_com_body()
+    w.step(1)
+
+    def com():
+        pos, _ = w.read()
+        return pos[b, :3].astype(np.float64) + rot_matrix(pos[b, 3:]) @ np.array([1.0, 0.0, 0.0])
+    c0 = com()
+    for i in range(100):
+        w.set_vel(b, (0.0, 0.0, 0.0), (0.0, 0.0, 3.0))
+        w.step(1)
+        assert np.linalg.norm(com() - c0) < 1.0e-3, i
+
+
+def test_set_rotation_does_not_inject_motion():
+    w, b = _offset_com_body()
+    for i in range(100):
+        a = 0.05 * i
+        w.set_pose(b, [0.0, 0.0, 0.0, 0.0, 0.0, np.sin(a / 2), np.cos(a / 2)])
+        w.step(1)
+        pos, vel = w.read()
+        assert np.linalg.norm(pos[b, :3]) < 1.0e-4 and np.linalg.norm(vel[b, :3]) < 1.0e-4, i
+
+
+# ---- issue_746_prismatic_axis_frames.rs -----------------------------------------------------------------------------------
+def test_prismatic_joint_stays_bounded_for_all_axis_rotations():
+    for i in range(8):
+        angle = np.pi / 2.0 * i
+        sc = world(dt=0.016)
+        b1 = sc.add_body(gravity_scale=0.0)
+        b2 = sc.add_body(translation=(1.0, 0.0, 0.0), rotation=quat_from_scaled_axis((0.0, angle, 0.0)), gravity_scale=0.0)
+        sc.add_collider(b1, half_extents=(1.0, 1.0, 1.0))
+        sc.add_collider(b2, half_extents=(1.0, 1.0, 1.0))
+        # local_axis2 = R^-1 X: the frame of body 2 is rotated back so that both frames' X axes agree in world space
+        sc.add_joint(b1, b2, (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), locked_axes=S.LOCK_PRISMATIC, contacts_enabled=0,
+                     basis2=quat_from_scaled_axis((0.0, -angle, 0.0)))
+        w = OracleWorld(sc)
+        w.step(60)
+        pos, _ = w.read()
+        assert np.linalg.norm(pos[b1, :3]) < 5.0 and np.linalg.norm(pos[b2, :3]) < 5.0, i
+
+
+# ---- issue_666_additional_mass_inertia.rs / issue_78_additional_mass_rest.rs ------------------------------------------------
+def _topple_world(use_additional_mass):
+    sc = world()
+    g = sc.add_body(body_type=S.BODY_FIXED, translation=(0.0, -0.1, 0.0))
+    sc.add_collider(g, half_extents=(100.1, 0.1, 100.1), friction=0.5)
+    vol = 8 * 0.2 * 5.0 * 1.5
+    b = sc.add_body(translation=(-10.0, 6.0, 0.0), linvel=(20.0, 0.0, 0.0), additional_mass=0.5 if use_additional_mass else 0.0)
+    sc.add_collider(b, half_extents=(0.2, 5.0, 1.5), friction=0.5, density=0.0 if use_additional_mass else 0.5 / vol)
+    return OracleWorld(sc), b
+
+
+def test_additional_mass_body_topples_like_density_twin():
+    """issue_666: a tall plate sliding at 20 m/s topples (angle > 0.5 rad) whether its mass comes from the density or from
+    additional_mass with a massless collider (the inertia is then derived from the shape at unit density)."""
+    for use_add in (False, True):
+        w, b = _topple_world(use_add)
+        if use_add:
+            w.step(1)
+            assert (w.mass_props(b)[4:7] > 0).all()         # non-zero angular inertia
+        max_angle = 0.0
+        for _ in range(200):
+            w.step(1)
+            q = w.read()[0][b, 3:]
+            max_angle = max(max_angle, 2.0 * np.arccos(min(1.0, abs(float(q[3])))))
+        assert max_angle > 0.5, use_add
+
+
+def test_additional_mass_body_rests_like_density_twin():
+    """issue_78: a tilted 100 kg cube comes to rest (falls asleep) at the same height either way, in comparable time."""
+    res = []
+    for use_add in (False, True):
+        sc = world()
+        g = sc.add_body(body_type=S.BODY_FIXED, translation=(0.0, -0.5, 0.0))
+        sc.add_collider(g, half_extents=(5.0, 0.5, 5.0), friction=0.5)
+        b = sc.add_body(translation=(0.0, 1.0, 0.0), rotation=quat_from_scaled_axis((0.0, 0.0, np.pi / 4 * 0.9)),
+                        additional_mass=100.0 if use_add else 0.0, can_sleep=1)
+        sc.add_collider(b, half_extents=(0.5, 0.5, 0.5), friction=0.5, restitution=0.0, density=0.0 if use_add else 100.0)
+        w = OracleWorld(sc)
+        for step in range(1000):
+            w.step(1)
+            assert w.read()[0][b, 1] > -0.5
+            if w.sleeping()[b]:
+                break
+        else:
+            pytest.fail("body never came to rest")
+        res.append((step, float(w.read()[0][b, 1])))
+    assert abs(res[0][1] - res[1][1]) < 0.1
+    assert res[1][0] < max(res[0][0], 1) * 4
+
+
+# ---- sleep_wide_bodies.rs ----------------------------------------------------------------------------------------------
+def test_wide_bodies_at_rest_fall_asleep():
+    """sleep_wide_bodies.rs:46-62: 64 wide U-shaped compound bodies resting on the ground all sleep within 300 steps (the
+    pose-drift sleep metric scales the rotation chord with the body's extent)."""
+    sc = world()
+    g = sc.add_body(body_type=S.BODY_FIXED, translation=(0.0, -0.1, 0.0))
+    sc.add_collider(g, half_extents=(50.0, 0.1, 50.0))
+    rad = 0.2
+    handles = []
+    for i in range(8):
+        for k in range(8):
+            b = sc.add_body(translation=(i * 6.0, rad + 0.01, k * 6.0), rotation=quat_from_scaled_axis((0.0, i * 0.11 + k * 0.037, 0.0)), can_sleep=1)
+            sc.add_collider(b, half_extents=(rad * 10.0, rad, rad))
+            sc.add_collider(b, half_extents=(rad, rad * 10.0, rad), translation=(rad * 10.0, rad * 10.0, 0.0))
+            sc.add_collider(b, half_extents=(rad, rad * 10.0, rad), translation=(-rad * 10.0, rad * 10.0, 0.0))
+            handles.append(b)
+    w = OracleWorld(sc)
+    w.step(300)
+    assert w.sleeping()[handles].all()
+
+
+def test_still_wide_body_reports_no_drift():
+    """sleep_wide_bodies.rs:64-90: a force-free body does not move at all and sleeps despite its far-reaching shape."""
+    sc = world(gravity=(0.0, 0.0, 0.0))
+    b = sc.add_body(rotation=quat_from_scaled_axis((0.3, -0.7, 0.15)), can_sleep=1)
+    sc.add_collider(b, half_extents=(0.2, 8.0, 0.2))
+    w = OracleWorld(sc)
+    p0 = w.read()[0].copy()
+    w.step(200)
+    np.testing.assert_array_equal(w.read()[0], p0)
+    assert w.sleeping()[b]
+
+
+# ---- issue_499_angular_limits.rs (the impulse-joint + torque drive) ---------------------------------------------------------
+def _settled_angle_deg(limits_deg, direction):
+    sc = world(gravity=(0.0, 0.0, 0.0), dt=1.0 / 60.0)
+    b1 = sc.add_body(body_type=S.BODY_FIXED)
+    b2 = sc.add_body(translation=(1.0, 0.0, 0.0), angular_damping=3.0)
+    sc.add_collider(b2, half_extents=(0.5, 0.1, 0.1))
+    sc.add_joint(b1, b2, (0.0, 0.0, 0.0), (-1.0, 0.0, 0.0), locked_axes=S.LOCK_REVOLUTE, basis1=S.AXIS_Z_BASIS, basis2=S.AXIS_Z_BASIS,
+                 limits={3: (np.radians(limits_deg[0]), np.radians(limits_deg[1]))})
+    w = OracleWorld(sc)
+    unwrapped, prev = 0.0, 0.0
+    for _ in range(600):
+        w.add_force(b2, torque=(0.0, 0.0, direction * 0.1))      # add_torque accumulates (it is never reset in the reference test)
+        w.step(1)
+        q = w.read()[0][b2, 3:].astype(np.float64)
+        ang = 2.0 * np.arctan2(q[2], q[3])
+        delta = ang - prev
+        if delta > np.pi:
+            delta -= 2 * np.pi
+        elif delta < -np.pi:
+            delta += 2 * np.pi
+        unwrapped += delta
+        prev = ang
+    return np.degrees(unwrapped)
+
+
+@pytest.mark.parametrize("limits", [(-45.0, 45.0), (-135.0, 135.0), (0.0, 90.0), (-170.0, -10.0),        # within half a turn
+                                    (0.0, 270.0), (-270.0, 0.0), (-90.0, 200.0), (-350.0, 0.0),          # past half a turn
+                                    (45.0, 315.0), (-315.0, -45.0), (135.0, 225.0)])                     # straddling half a turn
+def test_angular_limits_are_reached(limits):
+    """issue_499_angular_limits.rs:93-121 (Drive::Torque on the impulse joint): driving + / - settles within 2 degrees of
+    the upper / lower limit."""
+    assert abs(_settled_angle_deg(limits, 1.0) - limits[1]) < 2.0
+    assert abs(_settled_angle_deg(limits, -1.0) - limits[0]) < 2.0
+
+
+@pytest.mark.parametrize("limits", [(-180.0, 180.0), (-200.0, 200.0), (-350.0, 350.0)])
+def test_angular_limits_wider_than_a_turn_leave_the_joint_free(limits):
+    """issue_499_angular_limits.rs:123-133 (driven by the torque instead of the motor)."""
+    assert _settled_angle_deg(limits, 1.0) > 360.0
+
+
+def test_a_joint_shoved_past_its_limit_comes_back():
+    """issue_499_angular_limits.rs:135-170"""
+    sc = world(gravity=(0.0, 0.0, 0.0), dt=1.0 / 60.0)
+    b1 = sc.add_body(body_type=S.BODY_FIXED)
+    b2 = sc.add_body(translation=(-0.996, -0.087, 0.0), rotation=quat_from_scaled_axis((0.0, 0.0, np.radians(185.0))))
+    sc.add_collider(b2, half_extents=(0.5, 0.1, 0.1))
+    sc.add_joint(b1, b2, (0.0, 0.0, 0.0), (-1.0, 0.0, 0.0), locked_axes=S.LOCK_REVOLUTE, basis1=S.AXIS_Z_BASIS, basis2=S.AXIS_Z_BASIS,
+                 limits={3: (0.0, np.radians(170.0))})
+    w = OracleWorld(sc)
+    w.step(300)
+    q = w.read()[0][b2, 3:].astype(np.float64)
+    angle = np.degrees(2.0 * np.arctan2(q[2], q[3]))
+    assert -2.0 <= angle < 172.0
