@@ -115,7 +115,16 @@ typedef struct rp_contact_force_event {
     float max_force_magnitude;
 } rp_contact_force_event;
 
-/* GenericJoint restricted to locked axes — /root/reference/src/dynamics/joint/generic_joint.rs:341-355; the local frames
+/* JointMotor — /root/reference/src/dynamics/joint/generic_joint.rs:200-232 (the accumulated impulse is read back with
+ * rp_impulse_joints_read_motor_impulses); JointMotor::default(): all zero, max_force = FLT_MAX, AccelerationBased */
+#define RP_MOTOR_ACCELERATION_BASED 0 /* MotorModel::AccelerationBased — motor_model.rs:24-31 */
+#define RP_MOTOR_FORCE_BASED 1        /* MotorModel::ForceBased */
+typedef struct rp_joint_motor {
+    float target_vel, target_pos, stiffness, damping, max_force;
+    int32_t model;
+} rp_joint_motor;
+
+/* GenericJoint without coupled axes — /root/reference/src/dynamics/joint/generic_joint.rs:341-355; the local frames
  * are (local_anchor, local_basis) like GenericJoint::local_frame1/2 */
 typedef struct rp_joint_desc {
     int32_t body1, body2; /* dense body indices (handle low 32 bits) */
@@ -125,6 +134,8 @@ typedef struct rp_joint_desc {
     int32_t contacts_enabled;
     uint32_t limit_axes;  /* GenericJoint::limit_axes: JointAxesMask of the limited (free) axes */
     float limits[6][2];   /* JointLimits::{min, max} per axis (GenericJoint::limits, generic_joint.rs:230-245): metres / radians */
+    uint32_t motor_axes;  /* GenericJoint::motor_axes: JointAxesMask of the motorised (free) axes */
+    rp_joint_motor motors[6]; /* GenericJoint::motors */
 } rp_joint_desc;
 
 /* Counters mirror (ms, from hipEvents) — /root/reference/src/counters/{mod,stages_counters,
@@ -177,8 +188,17 @@ int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider_desc *desc
  * linear / angular axes (spherical 0x07, revolute 0x37, prismatic without limits 0x3e, fixed 0x3f; the free axis is the
  * local frame's X axis as in RevoluteJointBuilder / PrismaticJointBuilder); contacts_enabled = 0 filters the contact pairs between
  * the two bodies (pair_update.rs:191-201); limit_axes / limits bound the free axes (limit_linear, limit_angular:
- * joint_constraint_helper.rs:166-208, 468-564); motors and coupled axes are not part of this descriptor. */
+ * joint_constraint_helper.rs:166-208, 468-564); motor_axes / motors drive them (motor_linear, motor_angular: :285-331, 566-625;
+ * motor rows are solved before the lock and limit rows, joint_velocity_constraint.rs:186-246); coupled axes are not part of
+ * this descriptor. */
 int32_t rp_impulse_joints_insert(rp_world *w, int32_t n, const rp_joint_desc *descs, uint64_t *handles_out);
+/* GenericJoint::set_motor / set_motor_velocity / set_motor_position / set_motor_max_force / set_motor_model
+ * (generic_joint.rs:538-603) through ImpulseJointSet::get_mut(handle, wake_up_connected_bodies = true)
+ * (impulse_joint_set.rs:235-250): axes[i] (0..5 = LinX..AngZ) of joint handles[i] gets motors[i], its motor is enabled,
+ * and both bodies of the joint are woken. */
+int32_t rp_impulse_joints_set_motor(rp_world *w, int32_t n, const uint64_t *handles, const int32_t *axes, const rp_joint_motor *motors);
+/* JointMotor::impulse of the six axes of n joints (NULL handles = all, insertion order), as written back by the last step. */
+int32_t rp_impulse_joints_read_motor_impulses(rp_world *w, int32_t n, const uint64_t *handles, float *impulse6_out);
 /* ImpulseJoint::impulses (per locked linear dof, as written back by the last step) and the persistent
  * solver colour of n joints (NULL handles = all, insertion order). */
 int32_t rp_impulse_joints_read(rp_world *w, int32_t n, const uint64_t *handles, int32_t *color_out, float *impulse3_out);

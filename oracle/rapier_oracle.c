@@ -136,6 +136,8 @@ typedef struct {
     uint32_t limit_axes; float limits[6][2];   /* GenericJoint::{limit_axes, limits} */
     float ang_limit_center[3][2], ang_limit_half_range[3]; /* AngularLimitParams (joint_constraint_helper.rs:34-72) */
     float limit_impulses[6];                    /* JointLimits::impulse */
+    uint32_t motor_axes; ro_joint_motor motors[6]; /* GenericJoint::{motor_axes, motors} */
+    float motor_impulses[6];                    /* JointMotor::impulse */
     uint8_t solver_color;                 /* persistent colour, impulse_joint.rs:38 */
     uint32_t solver_body_ids[2];          /* stamped by select_active_interactions */
     float impulses[6];                    /* per-dof impulses written back last step */
@@ -150,7 +152,7 @@ typedef struct {
     v3 lin_jac, ang_jac1, ang_jac2, ii_ang_jac1, ii_ang_jac2;
     float inv_lhs, rhs, rhs_wo_bias, cfm_gain, cfm_coeff;
     v3 im1, im2;
-    int dof;                              /* WritebackId::Dof(i) */
+    int dof;                              /* WritebackId: Dof(i) = i, Limit(i) = 6 + i, Motor(i) = 12 + i */
 } JointRow;
 typedef struct { int enabled; v3 principal_inertia, inv_principal_inertia; quat principal_frame; } Gyro;
 
@@ -1706,7 +1708,11 @@ static void joints_color(ro_world *w) {
 }
 /* JointConstraintBuilder::generate — joint_constraint_builder.rs:34-60 +
  * GenericJoint::transform_to_solver_body_space — generic_joint.rs:624-636 */
-static int joint_num_rows(const Joint *j) { int n = 0; for (int i = 0; i < 6; ++i) if ((j->locked_axes | (j->limit_axes & ~j->locked_axes)) & (1u << i)) n++; return n; }
+static int joint_num_rows(const Joint *j) {
+    int n = 0;
+    for (int i = 0; i < 6; ++i) { if ((j->locked_axes | j->limit_axes) & (1u << i)) n++; if ((j->motor_axes & ~j->locked_axes) & (1u << i)) n++; }
+    return n;
+}
 static void joint_builder_generate(ro_world *w, Joint *j, int *num_rows) {
     const Body *rb1 = &w->bodies[j->body1], *rb2 = &w->bodies[j->body2];
     j->sb_frame1 = j->local_frame1; j->sb_frame2 = j->local_frame2;
@@ -1715,7 +1721,52 @@ static void joint_builder_generate(ro_world *w, Joint *j, int *num_rows) {
     if (rb2->body_type == RO_BODY_FIXED) j->sb_frame2 = pose_mul(rb2->position, j->local_frame2);
     else j->sb_frame2.t = vsub(j->sb_frame2.t, rb2->local_com);
     j->first_row = *num_rows;
-    for (int i = 0; i < 6; ++i) if ((j->locked_axes | (j->limit_axes & ~j->locked_axes)) & (1u << i)) (*num_rows)++;
+    *num_rows += joint_num_rows(j);
+}
+/* JointConstraintHelper::finalize_constraints (joint_constraint_helper.rs:676-720): modified Gram-Schmidt over one block of
+ * rows; rows with bounded impulses (limits, motors) are not removed from the others */
+static void joint_finalize_rows(JointRow *out, int len) {
+    if (len == 0) return;
+    v3 imsum = vadd(out[0].im1, out[0].im2);
+    for (int a = 0; a < len; ++a) {
+        JointRow *cj = &out[a];
+        float dot_jj = vdot(cj->lin_jac, vcmul(imsum, cj->lin_jac)) + vdot(cj->ii_ang_jac1, cj->ang_jac1) + vdot(cj->ii_ang_jac2, cj->ang_jac2);
+        float cfm_gain = dot_jj * cj->cfm_coeff + cj->cfm_gain;
+        float inv_dot_jj = ro_inv(dot_jj);
+        cj->inv_lhs = ro_inv(dot_jj + cfm_gain);
+        cj->cfm_gain = cfm_gain;
+        if (cj->impulse_bounds[0] != -FLT_MAX || cj->impulse_bounds[1] != FLT_MAX) continue;
+        for (int b = a + 1; b < len; ++b) {
+            JointRow *ci = &out[b];
+            float dot_ij = vdot(ci->lin_jac, vcmul(imsum, cj->lin_jac)) + vdot(ci->ii_ang_jac1, cj->ang_jac1) + vdot(ci->ii_ang_jac2, cj->ang_jac2);
+            float coeff = dot_ij * inv_dot_jj;
+            ci->lin_jac = vsub(ci->lin_jac, vmul(cj->lin_jac, coeff));
+            ci->ang_jac1 = vsub(ci->ang_jac1, vmul(cj->ang_jac1, coeff));
+            ci->ang_jac2 = vsub(ci->ang_jac2, vmul(cj->ang_jac2, coeff));
+            ci->ii_ang_jac1 = vsub(ci->ii_ang_jac1, vmul(cj->ii_ang_jac1, coeff));
+            ci->ii_ang_jac2 = vsub(ci->ii_ang_jac2, vmul(cj->ii_ang_jac2, coeff));
+            ci->rhs_wo_bias = ci->rhs_wo_bias - cj->rhs_wo_bias * coeff;
+            ci->rhs = ci->rhs - cj->rhs * coeff;
+        }
+    }
+}
+/* JointMotor::motor_params (generic_joint.rs:236-250) + MotorModel::combine_coefficients (motor_model.rs:39-58) */
+typedef struct { float erp_inv_dt, cfm_coeff, cfm_gain, target_pos, target_vel, max_impulse; } MotorParams;
+static MotorParams motor_params(const ro_joint_motor *m, float dt) {
+    MotorParams p;
+    p.erp_inv_dt = m->stiffness * ro_inv(dt * m->stiffness + m->damping);
+    float c = ro_inv(dt * dt * m->stiffness + dt * m->damping);
+    p.cfm_coeff = m->model == 0 ? c : 0.0f;
+    p.cfm_gain = m->model == 0 ? 0.0f : c;
+    p.target_pos = m->target_pos; p.target_vel = m->target_vel; p.max_impulse = m->max_force * dt;
+    return p;
+}
+/* utils::smallest_abs_diff_between_angles (utils/mod.rs:217-224); simd_signum = copysign(1, x) */
+static float smallest_abs_diff_between_angles(float a, float b) {
+    float s_err = a - b;
+    float sgn = copysignf(1.0f, s_err);
+    float s_err_complement = s_err - sgn * 6.28318530717958647692f;
+    return fabsf(s_err) < fabsf(s_err_complement) ? s_err : s_err_complement;
 }
 /* JointConstraint::<Real,1>::update (joint_velocity_constraint.rs:144-353) for locked linear axes:
  * JointConstraintHelper::new (joint_constraint_helper.rs:95-164), lock_linear (:411-458),
@@ -1738,7 +1789,59 @@ static int joint_update_rows(const ro_world *w, const Joint *j, float dt, JointR
     /* cmat * basis: column i = gcross_matrix(r) * col[i] with glam Mat3 * Vec3 = x_axis*v.x + y_axis*v.y + z_axis*v.z */
     v3 c1x = V3(0.0f, r1.z, -r1.y), c1y = V3(-r1.z, 0.0f, r1.x), c1z = V3(r1.y, -r1.x, 0.0f);
     v3 c2x = V3(0.0f, r2.z, -r2.y), c2y = V3(-r2.z, 0.0f, r2.x), c2z = V3(r2.y, -r2.x, 0.0f);
-    int len = 0;
+    int len = 0, start = 0;
+    /* motor rows first, finalised as a block of their own (joint_velocity_constraint.rs:186-246): motor_angular
+     * (joint_constraint_helper.rs:566-625) for the angular axes, then motor_linear (:285-331) */
+    uint32_t motor_axes = j->motor_axes & ~j->locked_axes;
+    if (motor_axes) {
+        quat q1m = frame1.r, q2m = frame2.r;
+        float sgnm = copysignf(1.0f, qdot(q1m, q2m));
+        quat ang_errm = qmul(qconj(q1m), q2m);
+        float imagm[3] = {ang_errm.x * sgnm, ang_errm.y * sgnm, ang_errm.z * sgnm};
+        for (int a = 0; a < 3; ++a) {
+            if (!(motor_axes & (8u << a))) continue;
+            MotorParams mp = motor_params(&j->motors[3 + a], dt);
+            v3 ang_jac = col[a];
+            float rhs_wo_bias = 0.0f;
+            if (mp.erp_inv_dt != 0.0f) {
+                float ang_dist = ro_asin_portable(ro_clampf(imagm[a], -1.0f, 1.0f)) * 2.0f;
+                rhs_wo_bias += smallest_abs_diff_between_angles(ang_dist, mp.target_pos) * mp.erp_inv_dt;
+            }
+            rhs_wo_bias += -mp.target_vel;
+            JointRow *c = &out[len++];
+            c->solver_vel1 = j->solver_body_ids[0]; c->solver_vel2 = j->solver_body_ids[1];
+            c->im1 = rb1.im; c->im2 = rb2.im;
+            c->impulse = 0.0f; c->impulse_bounds[0] = -mp.max_impulse; c->impulse_bounds[1] = mp.max_impulse;
+            c->lin_jac = V3(0, 0, 0); c->ang_jac1 = ang_jac; c->ang_jac2 = ang_jac;
+            c->ii_ang_jac1 = sym3_mul(rb1.ii, ang_jac);
+            c->ii_ang_jac2 = sym3_mul(rb2.ii, ang_jac);
+            c->inv_lhs = 0.0f; c->cfm_coeff = mp.cfm_coeff; c->cfm_gain = mp.cfm_gain;
+            c->rhs = rhs_wo_bias; c->rhs_wo_bias = rhs_wo_bias; c->dof = 12 + 3 + a;
+        }
+        for (int i = 0; i < 3; ++i) {
+            if (!(motor_axes & (1u << i))) continue;
+            MotorParams mp = motor_params(&j->motors[i], dt);
+            JointRow *c = &out[len++];
+            c->solver_vel1 = j->solver_body_ids[0]; c->solver_vel2 = j->solver_body_ids[1];
+            c->im1 = rb1.im; c->im2 = rb2.im;
+            c->impulse = 0.0f; c->impulse_bounds[0] = -mp.max_impulse; c->impulse_bounds[1] = mp.max_impulse;
+            c->lin_jac = col[i];
+            c->ang_jac1 = vadd(vadd(vmul(c1x, col[i].x), vmul(c1y, col[i].y)), vmul(c1z, col[i].z));
+            c->ang_jac2 = vadd(vadd(vmul(c2x, col[i].x), vmul(c2y, col[i].y)), vmul(c2z, col[i].z));
+            c->ii_ang_jac1 = sym3_mul(rb1.ii, c->ang_jac1);
+            c->ii_ang_jac2 = sym3_mul(rb2.ii, c->ang_jac2);
+            float rhs_wo_bias = 0.0f;
+            float dist = vdot(lin_err, c->lin_jac);
+            if (mp.erp_inv_dt != 0.0f) rhs_wo_bias += (dist - mp.target_pos) * mp.erp_inv_dt;
+            float target_vel = mp.target_vel;
+            if ((j->limit_axes & ~j->locked_axes) & (1u << i)) { float inv_dt = ro_inv(dt); target_vel = ro_clampf(target_vel, (j->limits[i][0] - dist) * inv_dt, (j->limits[i][1] - dist) * inv_dt); }
+            rhs_wo_bias += -target_vel;
+            c->inv_lhs = 0.0f; c->cfm_coeff = mp.cfm_coeff; c->cfm_gain = mp.cfm_gain;
+            c->rhs = rhs_wo_bias; c->rhs_wo_bias = rhs_wo_bias; c->dof = 12 + i;
+        }
+        joint_finalize_rows(out, len);
+        start = len;
+    }
     if (j->locked_axes & 0x38u) {
         /* locked angular axes — JointConstraintHelper::new (:129-139): ang_basis = diff_conj1_2_tr(q1, q2) * sgn,
          * ang_err = (q1^-1 q2) * sgn, sgn = copysign(1, q1 . q2); lock_angular (:628-673).  The scalar update emits the
@@ -1852,43 +1955,20 @@ static int joint_update_rows(const ro_world *w, const Joint *j, float dt, JointR
         c->rhs = rhs_wo_bias + rhs_bias; c->rhs_wo_bias = rhs_wo_bias; c->dof = 6 + i;
         c->impulse_bounds[0] = min_enabled ? -INFINITY : 0.0f; c->impulse_bounds[1] = max_enabled ? INFINITY : 0.0f;
     }
-    if (len == 0) return 0;
-    /* finalize_constraints: modified Gram-Schmidt */
-    v3 imsum = vadd(out[0].im1, out[0].im2);
-    for (int a = 0; a < len; ++a) {
-        JointRow *cj = &out[a];
-        float dot_jj = vdot(cj->lin_jac, vcmul(imsum, cj->lin_jac)) + vdot(cj->ii_ang_jac1, cj->ang_jac1) + vdot(cj->ii_ang_jac2, cj->ang_jac2);
-        float cfm_gain = dot_jj * cj->cfm_coeff + cj->cfm_gain;
-        float inv_dot_jj = ro_inv(dot_jj);
-        cj->inv_lhs = ro_inv(dot_jj + cfm_gain);
-        cj->cfm_gain = cfm_gain;
-        if (cj->impulse_bounds[0] != -FLT_MAX || cj->impulse_bounds[1] != FLT_MAX) continue;
-        for (int b = a + 1; b < len; ++b) {
-            JointRow *ci = &out[b];
-            float dot_ij = vdot(ci->lin_jac, vcmul(imsum, cj->lin_jac)) + vdot(ci->ii_ang_jac1, cj->ang_jac1) + vdot(ci->ii_ang_jac2, cj->ang_jac2);
-            float coeff = dot_ij * inv_dot_jj;
-            ci->lin_jac = vsub(ci->lin_jac, vmul(cj->lin_jac, coeff));
-            ci->ang_jac1 = vsub(ci->ang_jac1, vmul(cj->ang_jac1, coeff));
-            ci->ang_jac2 = vsub(ci->ang_jac2, vmul(cj->ang_jac2, coeff));
-            ci->ii_ang_jac1 = vsub(ci->ii_ang_jac1, vmul(cj->ii_ang_jac1, coeff));
-            ci->ii_ang_jac2 = vsub(ci->ii_ang_jac2, vmul(cj->ii_ang_jac2, coeff));
-            ci->rhs_wo_bias = ci->rhs_wo_bias - cj->rhs_wo_bias * coeff;
-            ci->rhs = ci->rhs - cj->rhs * coeff;
-        }
-    }
+    joint_finalize_rows(out + start, len - start);
     return len;
 }
 /* JointConstraintBuilder::update — joint_constraint_builder.rs:76-150 (row rebuild + warm-start carry) */
 static void joint_builder_update(ro_world *w, const Joint *j, float dt, int substep_id) {
     JointRow *rows = &w->joint_rows[j->first_row];
-    float prev[6] = {0, 0, 0, 0, 0, 0};
+    float prev[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int ws = w->params.warmstart_joints;
     int count = joint_num_rows(j);
     if (ws && substep_id > 0) for (int k = 0; k < count; ++k) prev[k] = rows[k].impulse;
     int len = joint_update_rows(w, j, dt, rows);
     if (ws) {
         float coeff = w->params.warmstart_coefficient;
-        for (int k = 0; k < len; ++k) rows[k].impulse = (substep_id == 0 ? (rows[k].dof >= 6 ? j->limit_impulses[rows[k].dof - 6] : j->impulses[rows[k].dof]) : prev[k]) * coeff;
+        for (int k = 0; k < len; ++k) rows[k].impulse = (substep_id == 0 ? (rows[k].dof >= 12 ? j->motor_impulses[rows[k].dof - 12] : rows[k].dof >= 6 ? j->limit_impulses[rows[k].dof - 6] : j->impulses[rows[k].dof]) : prev[k]) * coeff;
     }
 }
 /* JointConstraint::solve_generic / warmstart_generic — joint_velocity_constraint.rs:97-142 */
@@ -2104,7 +2184,7 @@ static void solve_velocity_constraints(ro_world *w) {
         int nrows = joint_num_rows(j);
         for (int k = 0; k < nrows; ++k) { /* WritebackId::Dof(i) / WritebackId::Limit(i) */
             const JointRow *r = &w->joint_rows[j->first_row + k];
-            if (r->dof >= 6) j->limit_impulses[r->dof - 6] = r->impulse; else j->impulses[r->dof] = r->impulse;
+            if (r->dof >= 12) j->motor_impulses[r->dof - 12] = r->impulse; else if (r->dof >= 6) j->limit_impulses[r->dof - 6] = r->impulse; else j->impulses[r->dof] = r->impulse;
         }
     }
     /* S10 body writeback — worker.rs:809-897 */
@@ -2296,7 +2376,7 @@ int32_t ro_dump_manifolds(const ro_world *w, int32_t cap, int32_t *meta, float *
  * contacts between the two bodies enabled. */
 int32_t ro_add_joint(ro_world *w, const ro_joint_desc *d) {
     if (d->body1 < 0 || d->body2 < 0 || d->body1 >= w->nbodies || d->body2 >= w->nbodies) return -1;
-    if ((d->locked_axes & ~0x3fu) != 0 || (d->limit_axes & ~0x3fu) != 0) return -1;
+    if ((d->locked_axes & ~0x3fu) != 0 || (d->limit_axes & ~0x3fu) != 0 || (d->motor_axes & ~0x3fu) != 0) return -1;
     if (w->njoints == w->cap_joints) {
         w->cap_joints = w->cap_joints ? w->cap_joints * 2 : 1024;
         w->joints = (Joint *)realloc(w->joints, sizeof(Joint) * w->cap_joints);
@@ -2319,10 +2399,25 @@ int32_t ro_add_joint(ro_world *w, const ro_joint_desc *d) {
         if (half_range >= 3.14159265358979323846f || half_range != half_range) { j->ang_limit_center[a][0] = 1.0f; j->ang_limit_center[a][1] = 0.0f; j->ang_limit_half_range[a] = 10.0f; }
         else { float center = (mn + mx) * 0.5f; j->ang_limit_center[a][0] = cosf(center * 0.5f); j->ang_limit_center[a][1] = sinf(center * 0.5f); j->ang_limit_half_range[a] = half_range; }
     }
+    j->motor_axes = d->motor_axes & 0x3fu;
+    for (int i = 0; i < 6; ++i) j->motors[i] = d->motors[i];
     j->solver_color = 255; /* default_solver_color: uncoloured */
     w->nc_dirty = 1;
     wake_request(w, d->body1, 1); wake_request(w, d->body2, 1); /* insert(.., wake_up = true), substep.rs:289-300 */
     return w->njoints++;
+}
+/* GenericJoint::set_motor (generic_joint.rs) on ImpulseJointSet::get_mut(handle, wake_up = true) (impulse_joint_set.rs):
+ * the axis' motor is enabled, its accumulated impulse kept, both bodies woken */
+int32_t ro_set_joint_motor(ro_world *w, int32_t joint, int32_t axis, const ro_joint_motor *m) {
+    if (joint < 0 || joint >= w->njoints || w->joints[joint].removed || axis < 0 || axis >= 6) return -1;
+    Joint *j = &w->joints[joint];
+    j->motor_axes |= 1u << axis;
+    j->motors[axis] = *m;
+    wake_request(w, j->body1, 1); wake_request(w, j->body2, 1);
+    return 0;
+}
+void ro_read_joint_motor_impulses(const ro_world *w, float *impulses6) {
+    for (int i = 0; i < w->njoints; ++i) for (int a = 0; a < 6; ++a) impulses6[6 * i + a] = w->joints[i].motor_impulses[a];
 }
 /* ImpulseJointSet::remove (impulse_joint_set.rs:574-...): the joint stops being selected. */
 int32_t ro_remove_joint(ro_world *w, int32_t joint) {

@@ -83,7 +83,10 @@ typedef struct ro_collider_desc {
     float contact_force_event_threshold;   /* ColliderBuilder::contact_force_event_threshold */
 } ro_collider_desc;
 
-/* GenericJoint restricted to lock rows (spherical = LIN_X|LIN_Y|LIN_Z, fixed = all six). */
+/* JointMotor (dynamics/joint/generic_joint.rs:200-232); model: 0 = MotorModel::AccelerationBased, 1 = ForceBased */
+typedef struct ro_joint_motor { float target_vel, target_pos, stiffness, damping, max_force; int32_t model; } ro_joint_motor;
+
+/* GenericJoint: locked axes, limits and motors of the free axes (no coupled axes). */
 typedef struct ro_joint_desc {
     int32_t body1, body2;
     float local_anchor1[3], local_anchor2[3];
@@ -92,6 +95,8 @@ typedef struct ro_joint_desc {
     int32_t contacts_enabled;
     uint32_t limit_axes;  /* JointAxesMask of the limited (free) axes — GenericJoint::limit_axes */
     float limits[6][2];   /* JointLimits::{min, max} per axis (metres for the linear axes, radians for the angular ones) */
+    uint32_t motor_axes;  /* JointAxesMask of the motorised (free) axes — GenericJoint::motor_axes */
+    ro_joint_motor motors[6];
 } ro_joint_desc;
 
 typedef struct ro_world ro_world;
@@ -105,6 +110,10 @@ int32_t ro_add_joint(ro_world *w, const ro_joint_desc *d);
 int32_t ro_remove_body(ro_world *w, int32_t body);
 int32_t ro_remove_collider(ro_world *w, int32_t collider);
 int32_t ro_remove_joint(ro_world *w, int32_t joint);
+/* GenericJoint::set_motor through ImpulseJointSet::get_mut(handle, wake_up = true): enables the axis' motor */
+int32_t ro_set_joint_motor(ro_world *w, int32_t joint, int32_t axis, const ro_joint_motor *m);
+/* JointMotor::impulse of the six axes of every joint */
+void ro_read_joint_motor_impulses(const ro_world *w, float *impulses6);
 int32_t ro_num_joints(const ro_world *w);
 void ro_read_joints(const ro_world *w, int32_t *color, float *impulses3);
 void ro_step(ro_world *w, int32_t nsteps);

@@ -111,6 +111,8 @@ static inline float ro_atan2_portable(float y, float x) {
     if (x < 0.0f) return y >= 0.0f ? ro_atan_portable(y / x) + 3.14159265358979323846f : ro_atan_portable(y / x) - 3.14159265358979323846f;
     return y > 0.0f ? 1.5707963267948966f : (y < 0.0f ? -1.5707963267948966f : 0.0f);
 }
+/* asin(x) for |x| <= 1 from the portable atan: atan2(x, sqrt((1 - x)(1 + x))) */
+static inline float ro_asin_portable(float x) { return ro_atan2_portable(x, sqrtf((1.0f - x) * (1.0f + x))); }
 /* Quat::to_scaled_axis: axis * angle, angle = 2 atan2(|v|, w) */
 static inline v3 quat_to_scaled_axis(quat q) {
     v3 v = V3(q.x, q.y, q.z);

@@ -590,7 +590,8 @@ extern "C" int32_t rp_impulse_joints_insert(rp_world *w, int32_t n, const rp_joi
     for (int i = 0; i < n; ++i) {
         const rp_joint_desc &j = descs[i];
         if (j.body1 < 0 || j.body2 < 0 || j.body1 >= (int)w->bodies.size() || j.body2 >= (int)w->bodies.size()) { w->err = "rp_impulse_joints_insert: invalid body index"; return RP_ERR_INVALID; }
-        if ((j.locked_axes & ~0x3fu) != 0 || (j.limit_axes & ~0x3fu) != 0 || (j.locked_axes | j.limit_axes) == 0) { w->err = "rp_impulse_joints_insert: locked_axes / limit_axes must be JointAxesMasks with at least one axis (motors and coupled axes are not implemented on the device path)"; return RP_ERR_INVALID; }
+        if ((j.locked_axes & ~0x3fu) != 0 || (j.limit_axes & ~0x3fu) != 0 || (j.motor_axes & ~0x3fu) != 0) { w->err = "rp_impulse_joints_insert: locked_axes / limit_axes / motor_axes must be JointAxesMasks (coupled axes are not implemented on the device path)"; return RP_ERR_INVALID; }
+        for (int a = 0; a < 6; ++a) if (j.motors[a].model != RP_MOTOR_ACCELERATION_BASED && j.motors[a].model != RP_MOTOR_FORCE_BASED) { w->err = "rp_impulse_joints_insert: unknown motor model"; return RP_ERR_INVALID; }
     }
     if (n > 0) { int r = rebuild_begin(w); if (r != RP_OK) return r; }
     for (int i = 0; i < n; ++i) {
@@ -802,8 +803,8 @@ static int finalize(rp_world *w) {
     // impulse joints: only joints with a dynamic side are active (select_active_interactions,
     // impulse_joint_set.rs:504-572), kept in edge order; frames go to solver-body space once
     // (GenericJoint::transform_to_solver_body_space, generic_joint.rs:624-636)
-    std::vector<int> jb1, jb2, jlocked, jlimited, jcolor, bnj(nb, 0);
-    std::vector<float4> jlim[6];
+    std::vector<int> jb1, jb2, jlocked, jlimited, jmotor, jcolor, bnj(nb, 0);
+    std::vector<float4> jlim[6], jmot[12];
     std::vector<float4> jf1t, jf1r, jf2t, jf2r;
     w->active_joint_ids.clear();
     for (size_t ji = 0; ji < w->joints.size(); ++ji) {
@@ -829,7 +830,8 @@ static int finalize(rp_world *w) {
         jb1.push_back(d1 ? j.body1 : -1); jb2.push_back(d2 ? j.body2 : -1);
         jf1t.push_back(mk4(f1.t.x, f1.t.y, f1.t.z, 0)); jf1r.push_back(mk4(f1.r.x, f1.r.y, f1.r.z, f1.r.w));
         jf2t.push_back(mk4(f2.t.x, f2.t.y, f2.t.z, 0)); jf2r.push_back(mk4(f2.r.x, f2.r.y, f2.r.z, f2.r.w));
-        jlocked.push_back((int)j.locked_axes); jlimited.push_back((int)(j.limit_axes & 0x3fu)); jcolor.push_back(RP_COLOR_UNCOLORED);
+        jlocked.push_back((int)j.locked_axes); jlimited.push_back((int)(j.limit_axes & 0x3fu)); jmotor.push_back((int)(j.motor_axes & 0x3fu)); jcolor.push_back(RP_COLOR_UNCOLORED);
+        for (int a = 0; a < 6; ++a) { const rp_joint_motor &m = j.motors[a]; jmot[2 * a].push_back(mk4(m.target_vel, m.target_pos, m.stiffness, m.damping)); jmot[2 * a + 1].push_back(mk4(m.max_force, (float)m.model, 0, 0)); }
         for (int a = 0; a < 3; ++a) jlim[a].push_back(mk4(j.limits[a][0], j.limits[a][1], 0, 0));
         for (int a = 0; a < 3; ++a) { // AngularLimitParams::new(min, max) — joint_constraint_helper.rs:44-72
             float mn = j.limits[3 + a][0], mx = j.limits[3 + a][1];
@@ -853,11 +855,13 @@ static int finalize(rp_world *w) {
     DA(d.j_b1, nj); DA(d.j_b2, nj); DA(d.j_f1t, nj); DA(d.j_f1r, nj); DA(d.j_f2t, nj); DA(d.j_f2r, nj);
     DA(d.j_locked, nj); DA(d.j_limited, nj); DA(d.j_color, nj); DA(d.j_tmp, nj); DA(d.j_order, nj); DA(d.j_imp, nj); DA(d.j_imp_ang, nj);
     DA(d.j_lim, (size_t)6 * std::max(nj, 1)); DA(d.j_imp_lim, nj); DA(d.j_imp_lim_ang, nj);
+    DA(d.j_motor, nj); DA(d.j_mot, (size_t)12 * std::max(nj, 1)); DA(d.j_imp_mot, nj); DA(d.j_imp_mot_ang, nj);
     DA(d.j_stage_begin, RP_NUM_COLORS + 1); DA(d.j_stage_count, RP_NUM_COLORS + 1);
     DA(d.bj_cmask, 4 * (size_t)capb); DAF(d.bj_min, capb, 0xff); DA(d.b_njoints, capb);
-    DA(d.JR, (size_t)38 * std::max(nj, 1)); // JR_COUNT planes: 6 rows x 6 + im1 + im2 (rp_joints.h)
+    DA(d.JR, (size_t)RP_JR_COUNT * std::max(nj, 1)); // im1, im2 + 12 rows x 6 planes (rp_joints.h); planes of unused rows are never touched
     UP(d.j_b1, jb1); UP(d.j_b2, jb2); UP(d.j_f1t, jf1t); UP(d.j_f1r, jf1r); UP(d.j_f2t, jf2t); UP(d.j_f2r, jf2r);
-    UP(d.j_locked, jlocked); UP(d.j_limited, jlimited); UP(d.j_color, jcolor); UP(d.b_njoints, bnj);
+    UP(d.j_locked, jlocked); UP(d.j_limited, jlimited); UP(d.j_motor, jmotor); UP(d.j_color, jcolor); UP(d.b_njoints, bnj);
+    for (int a = 0; a < 12; ++a) if (nj > 0 && hipMemcpyAsync(d.j_mot + (size_t)a * nj, jmot[a].data(), (size_t)nj * sizeof(float4), hipMemcpyHostToDevice, w->stream) != hipSuccess) { w->err = "upload failed"; return RP_ERR_DEVICE; }
     for (int a = 0; a < 6; ++a) if (nj > 0 && hipMemcpyAsync(d.j_lim + (size_t)a * nj, jlim[a].data(), (size_t)nj * sizeof(float4), hipMemcpyHostToDevice, w->stream) != hipSuccess) { w->err = "upload failed"; return RP_ERR_DEVICE; }
     {
         std::vector<int> bcol(nb, -1);
@@ -1364,7 +1368,7 @@ static int remove_joint_at(rp_world *w, int j) {
         if (w->active_joint_ids[k] != j) continue;
         const rp_joint_desc &jd = w->joints[j];
         int r;
-        if ((r = poke(w, w->dw.j_b1 + k, -1)) != RP_OK || (r = poke(w, w->dw.j_b2 + k, -1)) != RP_OK || (r = poke(w, w->dw.j_locked + k, 0)) != RP_OK || (r = poke(w, w->dw.j_limited + k, 0)) != RP_OK ||
+        if ((r = poke(w, w->dw.j_b1 + k, -1)) != RP_OK || (r = poke(w, w->dw.j_b2 + k, -1)) != RP_OK || (r = poke(w, w->dw.j_locked + k, 0)) != RP_OK || (r = poke(w, w->dw.j_limited + k, 0)) != RP_OK || (r = poke(w, w->dw.j_motor + k, 0)) != RP_OK ||
             (r = poke(w, w->dw.j_imp + k, mk4(0, 0, 0, 0))) != RP_OK || (r = poke(w, w->dw.j_imp_ang + k, mk4(0, 0, 0, 0))) != RP_OK) return r;
         for (int b : {jd.body1, jd.body2}) {
             if (w->bodies[b].d.body_type == RP_BODY_FIXED || w->bodies[b].removed) continue;
@@ -1562,6 +1566,64 @@ extern "C" int32_t rp_impulse_joints_read(rp_world *w, int32_t n, const uint64_t
         int k = dev_of[j];
         if (color_out) color_out[i] = k >= 0 ? col[k] : 255;
         if (impulse3_out) { impulse3_out[3 * i] = k >= 0 ? imp[k].x : 0.0f; impulse3_out[3 * i + 1] = k >= 0 ? imp[k].y : 0.0f; impulse3_out[3 * i + 2] = k >= 0 ? imp[k].z : 0.0f; }
+    }
+    return RP_OK;
+}
+
+// GenericJoint::set_motor* on ImpulseJointSet::get_mut(handle, true): the host descriptor and (once the world is resident) the
+// device planes of the axis change, the motor axis is enabled, both bodies are woken.
+extern "C" int32_t rp_impulse_joints_set_motor(rp_world *w, int32_t n, const uint64_t *handles, const int32_t *axes, const rp_joint_motor *motors) {
+    if (!w || n < 0 || (n > 0 && (!handles || !axes || !motors))) return RP_ERR_INVALID;
+    HIPCHK(w, hipSetDevice(w->device));
+    for (int i = 0; i < n; ++i) {
+        int j = handle_index(handles[i]);
+        if (j < 0 || j >= (int)w->joints.size() || w->joint_removed[j]) { w->err = "rp_impulse_joints_set_motor: invalid handle"; return RP_ERR_INVALID; }
+        if (axes[i] < 0 || axes[i] >= 6) { w->err = "rp_impulse_joints_set_motor: axis must be 0..5 (LinX..AngZ)"; return RP_ERR_INVALID; }
+        if (motors[i].model != RP_MOTOR_ACCELERATION_BASED && motors[i].model != RP_MOTOR_FORCE_BASED) { w->err = "rp_impulse_joints_set_motor: unknown motor model"; return RP_ERR_INVALID; }
+    }
+    if (w->finalized && n > 0) { int r = settle(w); if (r != RP_OK) return r; }
+    for (int i = 0; i < n; ++i) {
+        int j = handle_index(handles[i]), a = axes[i];
+        rp_joint_desc &jd = w->joints[j];
+        jd.motor_axes |= 1u << a;
+        jd.motors[a] = motors[i];
+        if (!w->finalized) { w->pending_wake.push_back(jd.body1); w->pending_wake.push_back(jd.body2); continue; }
+        int nj = w->dw.n_joints, r;
+        for (int k = 0; k < nj; ++k) {
+            if (w->active_joint_ids[k] != j) continue;
+            const rp_joint_motor &m = motors[i];
+            if ((r = poke(w, w->dw.j_motor + k, (int)(jd.motor_axes & 0x3fu))) != RP_OK ||
+                (r = poke(w, w->dw.j_mot + (size_t)(2 * a) * nj + k, mk4(m.target_vel, m.target_pos, m.stiffness, m.damping))) != RP_OK ||
+                (r = poke(w, w->dw.j_mot + (size_t)(2 * a + 1) * nj + k, mk4(m.max_force, (float)m.model, 0, 0))) != RP_OK) return r;
+        }
+        for (int b : {jd.body1, jd.body2}) {
+            if (w->bodies[b].d.body_type == RP_BODY_FIXED || w->bodies[b].removed) continue;
+            if (w->dw.sleep_enabled && (r = queue_wake(w, b, 2)) != RP_OK) return r;
+        }
+    }
+    return RP_OK;
+}
+extern "C" int32_t rp_impulse_joints_read_motor_impulses(rp_world *w, int32_t n, const uint64_t *handles, float *impulse6_out) {
+    if (!w || !impulse6_out) return RP_ERR_INVALID;
+    HIPCHK(w, hipSetDevice(w->device));
+    if (!w->finalized) { int r = finalize(w); if (r != RP_OK) return r; }
+    { int r = settle(w); if (r != RP_OK) return r; }
+    int nj = w->dw.n_joints, total = (int)w->joints.size();
+    std::vector<float4> lin(std::max(nj, 1)), ang(std::max(nj, 1));
+    if (nj > 0) {
+        HIPCHK(w, hipMemcpy(lin.data(), w->dw.j_imp_mot, nj * sizeof(float4), hipMemcpyDeviceToHost));
+        HIPCHK(w, hipMemcpy(ang.data(), w->dw.j_imp_mot_ang, nj * sizeof(float4), hipMemcpyDeviceToHost));
+    }
+    std::vector<int> dev_of(total, -1);
+    for (int k = 0; k < nj; ++k) dev_of[w->active_joint_ids[k]] = k;
+    int count = handles ? n : total;
+    for (int i = 0; i < count; ++i) {
+        int j = handles ? (int)(handles[i] & 0xffffffffull) : i;
+        if (j < 0 || j >= total) { w->err = "rp_impulse_joints_read_motor_impulses: invalid handle"; return RP_ERR_INVALID; }
+        int k = dev_of[j];
+        float *o = impulse6_out + 6 * i;
+        o[0] = k >= 0 ? lin[k].x : 0.0f; o[1] = k >= 0 ? lin[k].y : 0.0f; o[2] = k >= 0 ? lin[k].z : 0.0f;
+        o[3] = k >= 0 ? ang[k].x : 0.0f; o[4] = k >= 0 ? ang[k].y : 0.0f; o[5] = k >= 0 ? ang[k].z : 0.0f;
     }
     return RP_OK;
 }

@@ -1,12 +1,14 @@
 // rp_joints.h — impulse joints on the global solver path: locked linear and angular axes
-// (spherical, revolute, prismatic-without-limits and fixed joints), rows rebuilt from the current poses every substep, solved before the contacts in
-// every pass, coloured in the contacts' colour space.
+// (spherical, revolute, prismatic and fixed joints), limits and motors of the free axes, rows rebuilt from the current poses
+// every substep, solved before the contacts in every pass, coloured in the contacts' colour space.
 //
 // Restates (one joint per thread instead of one 4-lane chunk):
 //   JointConstraintBuilder::update            solver/joint_constraint/joint_constraint_builder.rs:76-150
 //   JointConstraint::<Real,1>::update         solver/joint_constraint/joint_velocity_constraint.rs:144-353
 //   JointConstraintHelper::{new, lock_linear, lock_angular, finalize_constraints}
 //                                             solver/joint_constraint/joint_constraint_helper.rs:95-164, 411-458, 628-673, 676-720
+//   JointConstraintHelper::{limit_linear, limit_angular, motor_linear, motor_angular}   :166-208, 468-564, 285-331, 566-625
+//   JointMotor::motor_params, MotorModel::combine_coefficients   joint/generic_joint.rs:236-250, joint/motor_model.rs:39-58
 //   JointConstraint::{solve_generic, warmstart_generic, remove_bias_from_rhs}   joint_velocity_constraint.rs:97-142
 // The reference's wide (SIMD) path uses nalgebra's quaternion->matrix / rotate formulas and its scalar
 // path glam's, and the two emit the lock rows in different orders (wide: linear then angular; scalar: angular then
@@ -15,9 +17,12 @@
 #pragma once
 #include "rp_world.h"
 
-// row planes: JR[plane][joint]; row r uses planes 6*r .. 6*r+5
-enum { JR_LIN = 0, JR_A1, JR_A2, JR_I1, JR_I2, JR_BND, JR_ROW_PLANES = 6, JR_MAX_ROWS = 6, JR_IM1 = 36, JR_IM2 = 37, JR_COUNT = 38 };
+// row planes: JR[plane][joint]; planes 0, 1 = the two inverse masses, row r uses planes 2 + 6*r .. 2 + 6*r + 5.  A joint has at
+// most 12 rows: one per motorised free axis, then one per locked or limited axis.
+enum { JR_IM1 = 0, JR_IM2 = 1, JR_ROW0 = 2, JR_LIN = 0, JR_A1, JR_A2, JR_I1, JR_I2, JR_BND, JR_ROW_PLANES = 6, JR_MAX_ROWS = 12, JR_COUNT = JR_ROW0 + JR_ROW_PLANES * JR_MAX_ROWS };
+static_assert(JR_COUNT == RP_JR_COUNT, "DevWorld::JR plane count");
 #define JRP(plane, j) w.JR[(size_t)(plane) * w.n_joints + (j)]
+#define JRR(r, plane, j) JRP(JR_ROW0 + JR_ROW_PLANES * (r) + (plane), j)
 
 // select_active_interactions (impulse_joint_set.rs:504-572): a joint takes part in the step when it has a non-fixed side and
 // none of its dynamic / kinematic bodies sleeps (removed joints have no side left)
@@ -28,36 +33,90 @@ RP_DEV bool joint_live(const DevWorld &w, int j) {
     return !(b1 >= 0 && (w.b_flags[b1] & RP_BF_SLEEPING)) && !(b2 >= 0 && (w.b_flags[b2] & RP_BF_SLEEPING));
 }
 
-struct JointRow { V3 lin_jac, ang_jac1, ang_jac2, ii1, ii2; float impulse, inv_lhs, rhs, rhs_wo_bias, cfm_gain, bmin, bmax; };
+struct JointRow { V3 lin_jac, ang_jac1, ang_jac2, ii1, ii2; float impulse, inv_lhs, rhs, rhs_wo_bias, cfm_gain, cfm_coeff, bmin, bmax; };
 #define JR_UNBOUNDED 3.402823466e+38f // impulse_bounds of a lock row: [-f32::MAX, f32::MAX]
 
 RP_DEV void jrow_load(const DevWorld &w, int j, int r, JointRow &c) {
-    float4 a = JRP(JR_ROW_PLANES * r + JR_LIN, j), b = JRP(JR_ROW_PLANES * r + JR_A1, j), d = JRP(JR_ROW_PLANES * r + JR_A2, j), e = JRP(JR_ROW_PLANES * r + JR_I1, j), f = JRP(JR_ROW_PLANES * r + JR_I2, j);
+    float4 a = JRR(r, JR_LIN, j), b = JRR(r, JR_A1, j), d = JRR(r, JR_A2, j), e = JRR(r, JR_I1, j), f = JRR(r, JR_I2, j);
     c.lin_jac = v3(a); c.impulse = a.w; c.ang_jac1 = v3(b); c.inv_lhs = b.w; c.ang_jac2 = v3(d); c.rhs = d.w;
     c.ii1 = v3(e); c.rhs_wo_bias = e.w; c.ii2 = v3(f); c.cfm_gain = f.w;
-    float4 g = JRP(JR_ROW_PLANES * r + JR_BND, j); c.bmin = g.x; c.bmax = g.y;
+    float4 g = JRR(r, JR_BND, j); c.bmin = g.x; c.bmax = g.y;
 }
 RP_DEV void jrow_store(const DevWorld &w, int j, int r, const JointRow &c) {
-    JRP(JR_ROW_PLANES * r + JR_LIN, j) = f4(c.lin_jac, c.impulse); JRP(JR_ROW_PLANES * r + JR_A1, j) = f4(c.ang_jac1, c.inv_lhs);
-    JRP(JR_ROW_PLANES * r + JR_A2, j) = f4(c.ang_jac2, c.rhs); JRP(JR_ROW_PLANES * r + JR_I1, j) = f4(c.ii1, c.rhs_wo_bias); JRP(JR_ROW_PLANES * r + JR_I2, j) = f4(c.ii2, c.cfm_gain);
-    JRP(JR_ROW_PLANES * r + JR_BND, j) = make_float4(c.bmin, c.bmax, 0.0f, 0.0f);
+    JRR(r, JR_LIN, j) = f4(c.lin_jac, c.impulse); JRR(r, JR_A1, j) = f4(c.ang_jac1, c.inv_lhs);
+    JRR(r, JR_A2, j) = f4(c.ang_jac2, c.rhs); JRR(r, JR_I1, j) = f4(c.ii1, c.rhs_wo_bias); JRR(r, JR_I2, j) = f4(c.ii2, c.cfm_gain);
+    JRR(r, JR_BND, j) = make_float4(c.bmin, c.bmax, 0.0f, 0.0f);
 }
-// rows of a joint: its locked axes, then the limits of its free axes (GenericJoint::limit_axes & !locked_axes)
-RP_DEV int joint_row_count(int locked, int limited) { return __popc(((unsigned)locked | ((unsigned)limited & ~(unsigned)locked)) & 0x3fu); }
-// WritebackId of row k (scalar update order, joint_velocity_constraint.rs:253-314): Dof(3 + a) for the locked angular axes,
-// Dof(i) for the locked linear ones, then Limit(3 + a) and Limit(i), encoded as 6 + axis
-RP_DEV int joint_row_dof(int locked, int limited, int k) {
-    limited &= ~locked;
+// rows of a joint: the motors of its free axes (GenericJoint::motor_axes & !locked_axes), its locked axes, then the limits of
+// its free axes (limit_axes & !locked_axes)
+RP_DEV int joint_row_count(int locked, int limited, int motor) {
+    return __popc(((unsigned)locked | (unsigned)limited) & 0x3fu) + __popc((unsigned)motor & ~(unsigned)locked & 0x3fu);
+}
+// WritebackId of row k (scalar update order, joint_velocity_constraint.rs:186-314): Motor(3 + a), Motor(i), Dof(3 + a) for the locked
+// angular axes, Dof(i) for the locked linear ones, then Limit(3 + a) and Limit(i); Dof = axis, Limit = 6 + axis, Motor = 12 + axis
+RP_DEV int joint_row_dof(int locked, int limited, int motor, int k) {
+    limited &= ~locked; motor &= ~locked;
+    for (int a = 0; a < 3; ++a) if (motor & (8 << a)) { if (k == 0) return 12 + 3 + a; --k; }
+    for (int i = 0; i < 3; ++i) if (motor & (1 << i)) { if (k == 0) return 12 + i; --k; }
     for (int a = 0; a < 3; ++a) if (locked & (8 << a)) { if (k == 0) return 3 + a; --k; }
     for (int i = 0; i < 3; ++i) if (locked & (1 << i)) { if (k == 0) return i; --k; }
     for (int a = 0; a < 3; ++a) if (limited & (8 << a)) { if (k == 0) return 6 + 3 + a; --k; }
     for (int i = 0; i < 3; ++i) if (limited & (1 << i)) { if (k == 0) return 6 + i; --k; }
     return 0;
 }
+// impulse written back by the last step for a WritebackId (warm start of substep 0)
+RP_DEV float joint_seed_impulse(const DevWorld &w, int j, int dof) {
+    int g = dof / 3, c = dof - 3 * g;
+    float4 v = g == 0 ? w.j_imp[j] : g == 1 ? w.j_imp_ang[j] : g == 2 ? w.j_imp_lim[j] : g == 3 ? w.j_imp_lim_ang[j] : g == 4 ? w.j_imp_mot[j] : w.j_imp_mot_ang[j];
+    return c == 0 ? v.x : c == 1 ? v.y : v.z;
+}
+// JointMotor::motor_params(dt) of axis `axis`
+struct MotorParams { float erp_inv_dt, cfm_coeff, cfm_gain, target_pos, target_vel, max_impulse; };
+RP_DEV MotorParams joint_motor_params(const DevWorld &w, int j, int axis, float dt) {
+    float4 a = w.j_mot[(size_t)(2 * axis) * w.n_joints + j], b = w.j_mot[(size_t)(2 * axis + 1) * w.n_joints + j]; // (target_vel, target_pos, stiffness, damping), (max_force, model)
+    MotorParams p;
+    p.erp_inv_dt = a.z * rp_inv(dt * a.z + a.w);
+    float c = rp_inv(dt * dt * a.z + dt * a.w);
+    bool acc = b.y == 0.0f; // MotorModel::AccelerationBased
+    p.cfm_coeff = acc ? c : 0.0f; p.cfm_gain = acc ? 0.0f : c;
+    p.target_pos = a.y; p.target_vel = a.x; p.max_impulse = b.x * dt;
+    return p;
+}
+// JointConstraintHelper::finalize_constraints over one block of rows (modified Gram-Schmidt; rows with bounded impulses — limits,
+// motors — are not removed from the others), the warm-start carry of JointConstraintBuilder::update, and the store
+RP_DEV void joint_finalize_store(const DevWorld &w, int j, JointRow *rows, const int *dof, int len, int base, V3 imsum, int substep_id) {
+    for (int a = 0; a < len; ++a) {
+        JointRow &cj = rows[a];
+        float dot_jj = dot(cj.lin_jac, cmul(imsum, cj.lin_jac)) + dot(cj.ii1, cj.ang_jac1) + dot(cj.ii2, cj.ang_jac2);
+        float cfm_gain = dot_jj * cj.cfm_coeff + cj.cfm_gain;
+        float inv_dot_jj = rp_inv(dot_jj);
+        cj.inv_lhs = rp_inv(dot_jj + cfm_gain);
+        cj.cfm_gain = cfm_gain;
+        if (cj.bmin != -JR_UNBOUNDED || cj.bmax != JR_UNBOUNDED) continue;
+        for (int b = a + 1; b < len; ++b) {
+            JointRow &ci = rows[b];
+            float dot_ij = dot(ci.lin_jac, cmul(imsum, cj.lin_jac)) + dot(ci.ii1, cj.ang_jac1) + dot(ci.ii2, cj.ang_jac2);
+            float coeff = dot_ij * inv_dot_jj;
+            ci.lin_jac = ci.lin_jac - cj.lin_jac * coeff;
+            ci.ang_jac1 = ci.ang_jac1 - cj.ang_jac1 * coeff;
+            ci.ang_jac2 = ci.ang_jac2 - cj.ang_jac2 * coeff;
+            ci.ii1 = ci.ii1 - cj.ii1 * coeff;
+            ci.ii2 = ci.ii2 - cj.ii2 * coeff;
+            ci.rhs_wo_bias = ci.rhs_wo_bias - cj.rhs_wo_bias * coeff;
+            ci.rhs = ci.rhs - cj.rhs * coeff;
+        }
+    }
+    const bool ws = w.prm.p.warmstart_joints != 0;
+    for (int k = 0; k < len; ++k) {
+        // the previous substep's impulse of the same row is still in its plane (the row count of a joint is constant within a step)
+        if (ws) rows[k].impulse = (substep_id == 0 ? joint_seed_impulse(w, j, dof[k]) : JRR(base + k, JR_LIN, j).w) * w.prm.p.warmstart_coefficient;
+        jrow_store(w, j, base + k, rows[k]);
+    }
+}
 
 // JointConstraintBuilder::update for joint j (rows rebuilt from the solver poses s_rot / s_trans).
 RP_DEV void joint_update_one(const DevWorld &w, int j, int substep_id) {
-    int b1 = w.j_b1[j], b2 = w.j_b2[j], locked = w.j_locked[j], limited = w.j_limited[j] & ~locked;
+    int b1 = w.j_b1[j], b2 = w.j_b2[j], locked = w.j_locked[j], limited = w.j_limited[j] & ~locked, motor = w.j_motor[j] & ~locked;
     Pose p1, p2; p1.r = q4(0, 0, 0, 1); p1.t = v3(0, 0, 0); p2 = p1;
     V3 im1 = v3(0, 0, 0), im2 = im1; Sym3 ii1 = {0, 0, 0, 0, 0, 0}, ii2 = ii1;
     if (b1 >= 0) { p1.r = q4(w.s_rot[b1]); p1.t = v3(w.s_trans[b1]); im1 = v3(w.b_eim[b1]); float4 a = w.b_eii0[b1], b = w.b_eii1[b1]; ii1.m11 = a.x; ii1.m12 = a.y; ii1.m13 = a.z; ii1.m22 = a.w; ii1.m23 = b.x; ii1.m33 = b.y; }
@@ -75,19 +134,67 @@ RP_DEV void joint_update_one(const DevWorld &w, int j, int substep_id) {
     V3 r1 = frame1.t - world_com1, r2 = frame2.t - world_com2;
     V3 c1x = v3(0.0f, r1.z, -r1.y), c1y = v3(-r1.z, 0.0f, r1.x), c1z = v3(r1.y, -r1.x, 0.0f);
     V3 c2x = v3(0.0f, r2.z, -r2.y), c2y = v3(-r2.z, 0.0f, r2.x), c2z = v3(r2.y, -r2.x, 0.0f);
-    const bool ws = w.prm.p.warmstart_joints != 0;
-    float prev[6] = {0, 0, 0, 0, 0, 0}, seed[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    int nrows = joint_row_count(locked, limited);
-    if (ws) {
-        if (substep_id > 0) { for (int k = 0; k < nrows; ++k) prev[k] = JRP(JR_ROW_PLANES * k + JR_LIN, j).w; }
-        else {
-            float4 s = w.j_imp[j], sa = w.j_imp_ang[j]; seed[0] = s.x; seed[1] = s.y; seed[2] = s.z; seed[3] = sa.x; seed[4] = sa.y; seed[5] = sa.z;
-            if (limited) { float4 l = w.j_imp_lim[j], la = w.j_imp_lim_ang[j]; seed[6] = l.x; seed[7] = l.y; seed[8] = l.z; seed[9] = la.x; seed[10] = la.y; seed[11] = la.z; }
-        }
-    }
+    V3 imsum = im1 + im2;
     JointRow rows[6];
     int dof[6] = {0, 0, 0, 0, 0, 0};
-    int len = 0;
+    int len = 0, base = 0;
+    if (motor) {
+        // motor rows come first and are finalised as a block of their own (joint_velocity_constraint.rs:186-246): motor_angular for
+        // the angular axes (joint_constraint_helper.rs:566-625), then motor_linear (:285-331)
+        const float dt = w.prm.dt_sub;
+        Q4 q1 = frame1.r, q2 = frame2.r;
+        float sgn = copysignf(1.0f, qdot(q1, q2));
+        Q4 ang_err = qmul(qconj(q1), q2);
+        float imag[3] = {ang_err.x * sgn, ang_err.y * sgn, ang_err.z * sgn};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            if (!(motor & (8 << a))) continue;
+            MotorParams mp = joint_motor_params(w, j, 3 + a, dt);
+            V3 ang_jac = col[a];
+            float rhs_wo_bias = 0.0f;
+            if (mp.erp_inv_dt != 0.0f) {
+                float ang_dist = rp_asin_portable(rp_clamp(imag[a], -1.0f, 1.0f)) * 2.0f;
+                // utils::smallest_abs_diff_between_angles (utils/mod.rs:217-224)
+                float s_err = ang_dist - mp.target_pos;
+                float s_err_complement = s_err - copysignf(1.0f, s_err) * 6.28318530717958647692f;
+                rhs_wo_bias += (fabsf(s_err) < fabsf(s_err_complement) ? s_err : s_err_complement) * mp.erp_inv_dt;
+            }
+            rhs_wo_bias += -mp.target_vel;
+            JointRow &c = rows[len];
+            c.impulse = 0.0f; c.bmin = -mp.max_impulse; c.bmax = mp.max_impulse;
+            c.lin_jac = v3(0, 0, 0); c.ang_jac1 = ang_jac; c.ang_jac2 = ang_jac;
+            c.ii1 = sym_mul(ii1, ang_jac);
+            c.ii2 = sym_mul(ii2, ang_jac);
+            c.inv_lhs = 0.0f; c.cfm_coeff = mp.cfm_coeff; c.cfm_gain = mp.cfm_gain;
+            c.rhs = rhs_wo_bias; c.rhs_wo_bias = rhs_wo_bias;
+            dof[len] = 12 + 3 + a;
+            len++;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (!(motor & (1 << i))) continue;
+            MotorParams mp = joint_motor_params(w, j, i, dt);
+            JointRow &c = rows[len];
+            c.impulse = 0.0f; c.bmin = -mp.max_impulse; c.bmax = mp.max_impulse;
+            c.lin_jac = col[i];
+            c.ang_jac1 = c1x * col[i].x + c1y * col[i].y + c1z * col[i].z;
+            c.ang_jac2 = c2x * col[i].x + c2y * col[i].y + c2z * col[i].z;
+            c.ii1 = sym_mul(ii1, c.ang_jac1);
+            c.ii2 = sym_mul(ii2, c.ang_jac2);
+            float rhs_wo_bias = 0.0f;
+            float dist = dot(lin_err, c.lin_jac);
+            if (mp.erp_inv_dt != 0.0f) rhs_wo_bias += (dist - mp.target_pos) * mp.erp_inv_dt;
+            float target_vel = mp.target_vel;
+            if (limited & (1 << i)) { float4 lp = w.j_lim[(size_t)i * w.n_joints + j]; float inv_dt = rp_inv(dt); target_vel = rp_clamp(target_vel, (lp.x - dist) * inv_dt, (lp.y - dist) * inv_dt); }
+            rhs_wo_bias += -target_vel;
+            c.inv_lhs = 0.0f; c.cfm_coeff = mp.cfm_coeff; c.cfm_gain = mp.cfm_gain;
+            c.rhs = rhs_wo_bias; c.rhs_wo_bias = rhs_wo_bias;
+            dof[len] = 12 + i;
+            len++;
+        }
+        joint_finalize_store(w, j, rows, dof, len, 0, imsum, substep_id);
+        base = len; len = 0;
+    }
     if (locked & 0x38) {
         // locked angular axes — JointConstraintHelper::new (:129-139): ang_basis = diff_conj1_2_tr(q1, q2) * sgn, ang_err =
         // (q1^-1 q2) * sgn, sgn = copysign(1, q1 . q2); lock_angular (:628-673); RotationOps::diff_conj1_2 (utils/rotation_ops.rs:121-135)
@@ -123,7 +230,7 @@ RP_DEV void joint_update_one(const DevWorld &w, int j, int substep_id) {
             float rhs_bias = ang_err_imag[a] * w.prm.joint_erp_inv_dt;
             c.ii1 = sym_mul(ii1, ang_jac);
             c.ii2 = sym_mul(ii2, ang_jac);
-            c.inv_lhs = 0.0f; c.cfm_gain = 0.0f; c.bmin = -JR_UNBOUNDED; c.bmax = JR_UNBOUNDED;
+            c.inv_lhs = 0.0f; c.cfm_coeff = w.prm.joint_cfm_coeff; c.cfm_gain = 0.0f; c.bmin = -JR_UNBOUNDED; c.bmax = JR_UNBOUNDED;
             c.rhs = rhs_wo_bias + rhs_bias; c.rhs_wo_bias = rhs_wo_bias;
             dof[len] = 3 + a;
             len++;
@@ -141,7 +248,7 @@ RP_DEV void joint_update_one(const DevWorld &w, int j, int substep_id) {
         float rhs_bias = dot(c.lin_jac, lin_err) * w.prm.joint_erp_inv_dt;
         c.ii1 = sym_mul(ii1, c.ang_jac1);
         c.ii2 = sym_mul(ii2, c.ang_jac2);
-        c.inv_lhs = 0.0f; c.cfm_gain = 0.0f; c.bmin = -JR_UNBOUNDED; c.bmax = JR_UNBOUNDED;
+        c.inv_lhs = 0.0f; c.cfm_coeff = w.prm.joint_cfm_coeff; c.cfm_gain = 0.0f; c.bmin = -JR_UNBOUNDED; c.bmax = JR_UNBOUNDED;
         c.rhs = rhs_wo_bias + rhs_bias; c.rhs_wo_bias = rhs_wo_bias;
         dof[len] = i;
         len++;
@@ -175,7 +282,7 @@ RP_DEV void joint_update_one(const DevWorld &w, int j, int substep_id) {
                 float rhs_bias = rp_clamp((rp_max(ang - lp.z, 0.0f) - rp_max(-lp.z - ang, 0.0f)) * erp, -maxcv, maxcv);
                 c.ii1 = sym_mul(ii1, ang_jac);
                 c.ii2 = sym_mul(ii2, ang_jac);
-                c.inv_lhs = 0.0f; c.cfm_gain = 0.0f;
+                c.inv_lhs = 0.0f; c.cfm_coeff = w.prm.joint_cfm_coeff; c.cfm_gain = 0.0f;
                 c.rhs = rhs_wo_bias + rhs_bias; c.rhs_wo_bias = rhs_wo_bias;
                 dof[len] = 6 + 3 + a;
                 len++;
@@ -196,48 +303,21 @@ RP_DEV void joint_update_one(const DevWorld &w, int j, int substep_id) {
             bool min_enabled = dist <= lp.x, max_enabled = lp.y <= dist;
             float rhs_wo_bias = 0.0f;
             float rhs_bias = rp_clamp((rp_max(dist - lp.y, 0.0f) - rp_max(lp.x - dist, 0.0f)) * erp, -maxcv, maxcv);
-            c.inv_lhs = 0.0f; c.cfm_gain = 0.0f;
+            c.inv_lhs = 0.0f; c.cfm_coeff = w.prm.joint_cfm_coeff; c.cfm_gain = 0.0f;
             c.rhs = rhs_wo_bias + rhs_bias; c.rhs_wo_bias = rhs_wo_bias;
             c.bmin = min_enabled ? -inf : 0.0f; c.bmax = max_enabled ? inf : 0.0f;
             dof[len] = 6 + i;
             len++;
         }
     }
-    // finalize_constraints: modified Gram-Schmidt; rows with bounded impulses (limits) are not removed from the others
-    V3 imsum = im1 + im2;
-    for (int a = 0; a < len; ++a) {
-        JointRow &cj = rows[a];
-        float dot_jj = dot(cj.lin_jac, cmul(imsum, cj.lin_jac)) + dot(cj.ii1, cj.ang_jac1) + dot(cj.ii2, cj.ang_jac2);
-        float cfm_gain = dot_jj * w.prm.joint_cfm_coeff + cj.cfm_gain;
-        float inv_dot_jj = rp_inv(dot_jj);
-        cj.inv_lhs = rp_inv(dot_jj + cfm_gain);
-        cj.cfm_gain = cfm_gain;
-        if (cj.bmin != -JR_UNBOUNDED || cj.bmax != JR_UNBOUNDED) continue;
-        for (int b = a + 1; b < len; ++b) {
-            JointRow &ci = rows[b];
-            float dot_ij = dot(ci.lin_jac, cmul(imsum, cj.lin_jac)) + dot(ci.ii1, cj.ang_jac1) + dot(ci.ii2, cj.ang_jac2);
-            float coeff = dot_ij * inv_dot_jj;
-            ci.lin_jac = ci.lin_jac - cj.lin_jac * coeff;
-            ci.ang_jac1 = ci.ang_jac1 - cj.ang_jac1 * coeff;
-            ci.ang_jac2 = ci.ang_jac2 - cj.ang_jac2 * coeff;
-            ci.ii1 = ci.ii1 - cj.ii1 * coeff;
-            ci.ii2 = ci.ii2 - cj.ii2 * coeff;
-            ci.rhs_wo_bias = ci.rhs_wo_bias - cj.rhs_wo_bias * coeff;
-            ci.rhs = ci.rhs - cj.rhs * coeff;
-        }
-    }
-    if (ws) {
-        float coeff = w.prm.p.warmstart_coefficient;
-        for (int k = 0; k < len; ++k) rows[k].impulse = (substep_id == 0 ? seed[dof[k]] : prev[k]) * coeff;
-    }
-    for (int k = 0; k < len; ++k) jrow_store(w, j, k, rows[k]);
+    joint_finalize_store(w, j, rows, dof, len, base, imsum, substep_id);
     JRP(JR_IM1, j) = f4(im1, 0.0f); JRP(JR_IM2, j) = f4(im2, 0.0f);
 }
 
 // All rows of joint j: [remove bias] [warm start] solve — solve_joint, staged_island_solver/solve.rs:31-47
 RP_DEV void joint_solve_one(const DevWorld &w, int j, bool wo_bias, bool warmstart) {
     int b1 = w.j_b1[j], b2 = w.j_b2[j];
-    int nrows = joint_row_count(w.j_locked[j], w.j_limited[j]);
+    int nrows = joint_row_count(w.j_locked[j], w.j_limited[j], w.j_motor[j]);
     V3 im1 = v3(JRP(JR_IM1, j)), im2 = v3(JRP(JR_IM2, j));
     V3 l1 = v3(0, 0, 0), a1 = l1, l2 = l1, a2 = l1;
     if (b1 >= 0) { l1 = v3(w.s_lin[b1]); a1 = v3(w.s_ang[b1]); }
@@ -268,8 +348,8 @@ RP_DEV void joint_solve_one(const DevWorld &w, int j, bool wo_bias, bool warmsta
         if (b1 < 0) { l1 = v3(0, 0, 0); a1 = l1; }
         if (b2 < 0) { l2 = v3(0, 0, 0); a2 = l2; }
         // only the mutable words of the row go back
-        JRP(JR_ROW_PLANES * r + JR_LIN, j).w = c.impulse;
-        if (wo_bias) JRP(JR_ROW_PLANES * r + JR_A2, j).w = c.rhs;
+        JRR(r, JR_LIN, j).w = c.impulse;
+        if (wo_bias) JRR(r, JR_A2, j).w = c.rhs;
     }
     if (b1 >= 0) { w.s_lin[b1] = f4(l1, 0.0f); w.s_ang[b1] = f4(a1, 0.0f); }
     if (b2 >= 0) { w.s_lin[b2] = f4(l2, 0.0f); w.s_ang[b2] = f4(a2, 0.0f); }
@@ -277,16 +357,18 @@ RP_DEV void joint_solve_one(const DevWorld &w, int j, bool wo_bias, bool warmsta
 
 // JointConstraint::writeback_impulses — joint_velocity_constraint.rs:346-353
 RP_DEV void joint_writeback_one(const DevWorld &w, int j) {
-    int locked = w.j_locked[j], limited = w.j_limited[j] & ~locked;
-    float imp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int locked = w.j_locked[j], limited = w.j_limited[j] & ~locked, motor = w.j_motor[j] & ~locked;
+    float imp[18];
     float4 old = w.j_imp[j], olda = w.j_imp_ang[j];
     imp[0] = old.x; imp[1] = old.y; imp[2] = old.z; imp[3] = olda.x; imp[4] = olda.y; imp[5] = olda.z;
-    if (limited) { float4 l = w.j_imp_lim[j], la = w.j_imp_lim_ang[j]; imp[6] = l.x; imp[7] = l.y; imp[8] = l.z; imp[9] = la.x; imp[10] = la.y; imp[11] = la.z; }
-    int nrows = joint_row_count(locked, limited);
-    for (int k = 0; k < nrows; ++k) imp[joint_row_dof(locked, limited, k)] = JRP(JR_ROW_PLANES * k + JR_LIN, j).w;
+    { float4 l = w.j_imp_lim[j], la = w.j_imp_lim_ang[j]; imp[6] = l.x; imp[7] = l.y; imp[8] = l.z; imp[9] = la.x; imp[10] = la.y; imp[11] = la.z; }
+    { float4 m = w.j_imp_mot[j], ma = w.j_imp_mot_ang[j]; imp[12] = m.x; imp[13] = m.y; imp[14] = m.z; imp[15] = ma.x; imp[16] = ma.y; imp[17] = ma.z; }
+    int nrows = joint_row_count(locked, limited, motor);
+    for (int k = 0; k < nrows; ++k) imp[joint_row_dof(locked, limited, motor, k)] = JRR(k, JR_LIN, j).w;
     w.j_imp[j] = make_float4(imp[0], imp[1], imp[2], 0.0f);
     w.j_imp_ang[j] = make_float4(imp[3], imp[4], imp[5], 0.0f);
     if (limited) { w.j_imp_lim[j] = make_float4(imp[6], imp[7], imp[8], 0.0f); w.j_imp_lim_ang[j] = make_float4(imp[9], imp[10], imp[11], 0.0f); } // JointLimits::impulse
+    if (motor) { w.j_imp_mot[j] = make_float4(imp[12], imp[13], imp[14], 0.0f); w.j_imp_mot_ang[j] = make_float4(imp[15], imp[16], imp[17], 0.0f); } // JointMotor::impulse
 }
 
 // One sweep over the joints inside a single workgroup (SINGLE mode and the serial tail): parallel joint

@@ -102,6 +102,8 @@ RP_HD float rp_atan2_portable(float y, float x) { // full range
     if (x < 0.0f) return y >= 0.0f ? rp_atan_portable(y / x) + 3.14159265358979323846f : rp_atan_portable(y / x) - 3.14159265358979323846f;
     return y > 0.0f ? 1.5707963267948966f : (y < 0.0f ? -1.5707963267948966f : 0.0f);
 }
+// asin(x) for |x| <= 1 from the portable atan: atan2(x, sqrt((1 - x)(1 + x)))
+RP_HD float rp_asin_portable(float x) { return rp_atan2_portable(x, sqrtf((1.0f - x) * (1.0f + x))); }
 // Quat::to_scaled_axis: axis * angle, angle = 2 atan2(|v|, w)
 RP_HD V3 quat_to_scaled_axis(Q4 q) {
     V3 v = v3(q.x, q.y, q.z);

@@ -126,6 +126,8 @@ enum {
     NP_F        // builder local_p2.xyz
 };
 
+#define RP_JR_COUNT 74 // planes of DevWorld::JR: im1, im2 + 12 rows x 6 (rp_joints.h)
+
 struct SimParams {
     rp_integration_params p;
     float gravity[3];
@@ -251,13 +253,16 @@ struct DevWorld {
     int *j_locked, *j_limited, *j_color, *j_tmp, *j_order; // JointAxesMask of the locked / limited axes
     float4 *j_lim;              // [6][n_joints] limit of axis a: linear (min, max, -, -), angular AngularLimitParams (cos, sin, half_range, -)
     float4 *j_imp_lim, *j_imp_lim_ang; // JointLimits::impulse of the linear / angular axes
+    int *j_motor;               // JointAxesMask of the motorised axes (GenericJoint::motor_axes)
+    float4 *j_mot;              // [12][n_joints] JointMotor of axis a: plane 2a = (target_vel, target_pos, stiffness, damping), 2a + 1 = (max_force, model, -, -)
+    float4 *j_imp_mot, *j_imp_mot_ang; // JointMotor::impulse of the linear / angular axes
     int *j_stage_begin, *j_stage_count;    // parallel joint colour stages inside j_order
     float4 *j_imp, *j_imp_ang;  // per-dof impulses written back at the end of the step (linear dofs, angular dofs)
     unsigned int *bj_cmask;     // [4 * n_bodies] colours taken by joints (bodies_color workspace)
     unsigned long long *bj_min; // joint colouring scratch
     unsigned long long *nc_keys; // [n_nc] sorted (min body << 32 | max body) keys of the joints with contacts_enabled = false
     int *b_njoints;             // joints attached to a body (bodies with joints stay on the global path)
-    float4 *JR;                 // [JR_COUNT][n_joints] constraint rows, up to 6 per joint (rp_joints.h)
+    float4 *JR;                 // [JR_COUNT][n_joints] constraint rows, up to 12 per joint (rp_joints.h)
 
     // ---- constraints ----
     float4 *C;                  // [CP_COUNT][cons_cap]

@@ -35,11 +35,25 @@ COLLIDER_DTYPE = np.dtype([
 ], align=False)
 
 ACTIVE_EVENTS_COLLISION, ACTIVE_EVENTS_CONTACT_FORCE = 1, 2  # ActiveEvents bits
+MOTOR_DTYPE = np.dtype([  # rp_joint_motor = JointMotor (generic_joint.rs:200-232)
+    ("target_vel", "<f4"), ("target_pos", "<f4"), ("stiffness", "<f4"), ("damping", "<f4"), ("max_force", "<f4"), ("model", "<i4"),
+], align=False)
+MOTOR_ACCELERATION_BASED, MOTOR_FORCE_BASED = 0, 1  # MotorModel
+F32_MAX = float(np.finfo(np.float32).max)
 JOINT_DTYPE = np.dtype([
     ("body1", "<i4"), ("body2", "<i4"), ("local_anchor1", "<f4", 3), ("local_anchor2", "<f4", 3),
     ("local_basis1", "<f4", 4), ("local_basis2", "<f4", 4), ("locked_axes", "<u4"),
     ("contacts_enabled", "<i4"), ("limit_axes", "<u4"), ("limits", "<f4", (6, 2)),
+    ("motor_axes", "<u4"), ("motors", MOTOR_DTYPE, 6),
 ], align=False)
+
+
+def motor_desc(target_vel=0.0, target_pos=0.0, stiffness=0.0, damping=0.0, max_force=F32_MAX, model=MOTOR_ACCELERATION_BASED) -> np.ndarray:
+    """JointMotor::default() (generic_joint.rs:216-228) with the fields GenericJoint::set_motor* write."""
+    m = np.zeros((), dtype=MOTOR_DTYPE)
+    m["target_vel"], m["target_pos"], m["stiffness"], m["damping"] = target_vel, target_pos, stiffness, damping
+    m["max_force"], m["model"] = max_force, model
+    return m
 PARAMS_DTYPE = np.dtype([
     ("dt", "<f4"),
     ("contact_natural_frequency", "<f4"), ("contact_damping_ratio", "<f4"),
@@ -159,9 +173,10 @@ class Scene:
         return len(self.colliders) - 1
 
     def add_joint(self, body1, body2, anchor1, anchor2, locked_axes=LOCK_LIN, contacts_enabled=1,
-                  basis1=(0, 0, 0, 1), basis2=(0, 0, 0, 1), limits=None) -> int:
+                  basis1=(0, 0, 0, 1), basis2=(0, 0, 0, 1), limits=None, motors=None) -> int:
         """``limits`` = {axis: (min, max)} with axis 0..2 = translation along the frame's X/Y/Z (metres), 3..5 = rotation about
-        them (radians): GenericJoint::set_limits."""
+        them (radians): GenericJoint::set_limits.  ``motors`` = {axis: motor_desc(...) or its keyword dict}:
+        GenericJoint::set_motor / set_motor_velocity / set_motor_position / set_motor_max_force / set_motor_model."""
         j = np.zeros((), dtype=JOINT_DTYPE)
         j["body1"], j["body2"] = body1, body2
         j["local_anchor1"], j["local_anchor2"] = anchor1, anchor2
@@ -171,6 +186,11 @@ class Scene:
         for axis, (lo, hi) in (limits or {}).items():
             j["limit_axes"] |= np.uint32(1 << axis)
             j["limits"][axis] = (lo, hi)
+        for a in range(6):
+            j["motors"][a] = motor_desc()
+        for axis, m in (motors or {}).items():
+            j["motor_axes"] |= np.uint32(1 << axis)
+            j["motors"][axis] = motor_desc(**m) if isinstance(m, dict) else m
         self.joints.append(j)
         return len(self.joints) - 1
 
@@ -528,5 +548,42 @@ def limited_joints() -> Scene:
     s.add_joint(pivot, bob, (0.0, 0.0, 0.0), (-1.5, 0.0, 0.0), locked_axes=LOCK_REVOLUTE, basis1=AXIS_Z_BASIS, basis2=AXIS_Z_BASIS, limits={3: (-0.8, 0.3)})
     for i in range(2):
         b = s.add_body(translation=(2.0, 0.5 + i, 0.0))
+        s.add_collider(b, half_extents=(0.5, 0.5, 0.5))
+    return s
+
+
+def motorised_joints() -> Scene:
+    """Joint-motor test scene (not a reference scene): a wheel spun by a velocity motor on a fixed axle, a lift on a limited
+    prismatic rail driven by a force-based position motor with a force cap, an arm on a spherical joint held by three angular
+    position motors, and a two-wheeled cart whose wheels (revolute joints between dynamic bodies) are driven along the ground."""
+    s = Scene(name="motorised_joints", gravity=(0.0, -9.81, 0.0))
+    g = s.add_body(body_type=BODY_FIXED, translation=(0.0, -0.5, 0.0))
+    s.add_collider(g, half_extents=(30.0, 0.5, 30.0))
+    axis_y = (0.0, 0.0, 0.70710678, 0.70710678)   # frame X axis = body Y axis
+    axle = s.add_body(body_type=BODY_FIXED, translation=(-6.0, 3.0, 0.0))
+    wheel = s.add_body(translation=(-6.0, 3.0, 0.0))
+    s.add_collider(wheel, half_extents=(0.8, 0.8, 0.1), density=2.0)
+    s.add_joint(axle, wheel, (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), locked_axes=LOCK_REVOLUTE, basis1=AXIS_Z_BASIS, basis2=AXIS_Z_BASIS,
+                motors={3: dict(target_vel=3.0, damping=5.0)})
+    rail = s.add_body(body_type=BODY_FIXED, translation=(0.0, 4.0, 0.0))
+    lift = s.add_body(translation=(0.0, 4.0, 0.0))
+    s.add_collider(lift, half_extents=(0.4, 0.2, 0.4), density=3.0)
+    s.add_joint(rail, lift, (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), locked_axes=LOCK_PRISMATIC, basis1=axis_y, basis2=axis_y, limits={0: (-2.0, 0.4)},
+                motors={0: dict(target_pos=-0.5, stiffness=400.0, damping=40.0, max_force=60.0, model=MOTOR_FORCE_BASED)})
+    pivot = s.add_body(body_type=BODY_FIXED, translation=(6.0, 4.0, 0.0))
+    arm = s.add_body(translation=(7.0, 4.0, 0.0), angvel=(0.5, 1.0, -0.5))
+    s.add_collider(arm, half_extents=(0.8, 0.1, 0.15), density=1.5)
+    s.add_joint(pivot, arm, (0.0, 0.0, 0.0), (-1.0, 0.0, 0.0), locked_axes=LOCK_LIN,
+                motors={3: dict(target_pos=0.3, stiffness=80.0, damping=8.0), 4: dict(target_pos=-0.2, stiffness=80.0, damping=8.0),
+                        5: dict(target_pos=0.5, stiffness=80.0, damping=8.0)})
+    cart = s.add_body(translation=(0.0, 0.7, 6.0))
+    s.add_collider(cart, half_extents=(1.0, 0.15, 0.4), density=1.0)
+    for sx in (-0.8, 0.8):
+        wh = s.add_body(translation=(sx, 0.4, 6.0))
+        s.add_collider(wh, shape=SHAPE_BALL, half_extents=(0.4, 0.0, 0.0), density=1.0, friction=1.0)
+        s.add_joint(cart, wh, (sx, -0.3, 0.0), (0.0, 0.0, 0.0), locked_axes=LOCK_REVOLUTE, basis1=AXIS_Z_BASIS, basis2=AXIS_Z_BASIS, contacts_enabled=0,
+                    motors={3: dict(target_vel=-4.0, damping=30.0, max_force=5.0)})
+    for i in range(2):
+        b = s.add_body(translation=(3.0, 0.5 + i, 0.0))
         s.add_collider(b, half_extents=(0.5, 0.5, 0.5))
     return s

@@ -343,6 +343,22 @@ class PhysicsWorld:
             _check(self._ptr, self._lib.rp_impulse_joints_read(self._ptr, n, None, col.ctypes.data, imp.ctypes.data), "rp_impulse_joints_read")
         return col, imp
 
+    def set_joint_motor(self, handles, axes, **motor):
+        """GenericJoint::set_motor* through ImpulseJointSet::get_mut(handle, true): joint ``handles[i]`` gets the motor described by
+        the keywords (scenes.motor_desc) on axis ``axes[i]`` (0..5 = LinX..AngZ); the motor is enabled and both bodies are woken."""
+        h = np.ascontiguousarray(np.atleast_1d(np.asarray(handles, dtype=np.uint64)))
+        a = np.ascontiguousarray(np.broadcast_to(np.atleast_1d(np.asarray(axes, dtype=np.int32)), h.shape))
+        m = np.ascontiguousarray(np.broadcast_to(S.motor_desc(**motor), h.shape))
+        _check(self._ptr, self._lib.rp_impulse_joints_set_motor(self._ptr, len(h), h.ctypes.data, a.ctypes.data, m.ctypes.data), "rp_impulse_joints_set_motor")
+
+    def joint_motor_impulses(self) -> np.ndarray:
+        """JointMotor::impulse of the six axes of every impulse joint, insertion order."""
+        n = self.impulse_joints._n
+        out = np.zeros((n, 6), np.float32)
+        if n:
+            _check(self._ptr, self._lib.rp_impulse_joints_read_motor_impulses(self._ptr, n, None, out.ctypes.data), "rp_impulse_joints_read_motor_impulses")
+        return out
+
     def total_contact_impulse(self) -> float:
         _, _, imp = self.contacts()
         return float(imp.sum())

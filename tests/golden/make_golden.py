@@ -31,6 +31,7 @@ CASES = {
     "locked_axes_s150": lambda: (S.locked_axes_scene(), 150),
     "overlapping_chain6_s100": lambda: (S.overlapping_chain(6, 0), 100),
     "limited_joints_s150": lambda: (S.limited_joints(), 150),
+    "motorised_joints_s150": lambda: (S.motorised_joints(), 150),
 }
 
 

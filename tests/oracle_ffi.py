@@ -64,6 +64,8 @@ def lib():
         L.ro_remove_joint.argtypes = [C.c_void_p, C.c_int32]
         L.ro_num_joints.argtypes = [C.c_void_p]
         L.ro_read_joints.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ro_set_joint_motor.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        L.ro_read_joint_motor_impulses.argtypes = [C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -128,6 +130,16 @@ class OracleWorld:
 
     def remove_joint(self, joint):
         assert lib().ro_remove_joint(self._w, int(joint)) == 0
+
+    def set_joint_motor(self, joint, axis, **motor):
+        m = np.ascontiguousarray(S.motor_desc(**motor))
+        assert lib().ro_set_joint_motor(self._w, int(joint), int(axis), m.ctypes.data) == 0
+
+    def joint_motor_impulses(self):
+        n = lib().ro_num_joints(self._w)
+        out = np.zeros((n, 6), np.float32)
+        lib().ro_read_joint_motor_impulses(self._w, out.ctypes.data)
+        return out
 
     def read_joints(self):
         n = lib().ro_num_joints(self._w)

@@ -511,6 +511,44 @@ def test_joint_limits_bit_exact():
     assert pos[2, 1] == pytest.approx(3.5, abs=5e-3)           # the slider rests on its lower stop
 
 
+def test_joint_motors_bit_exact():
+    """Motor rows (motor_angular / motor_linear, both motor models, force caps, a motorised axis that is also limited, three
+    motors on one joint, motors between dynamic bodies) built and solved before the lock rows; then a motor changed at run time
+    through rp_impulse_joints_set_motor, and the same scene with warm-started joints (JointMotor::impulse seeds)."""
+    g, o = _compare(S.motorised_joints(), [1, 2, 10, 40, 120, 300])
+    np.testing.assert_array_equal(g.joint_motor_impulses(), o.joint_motor_impulses())
+    _, vel = g.read_bodies()
+    assert vel[2, 5] == pytest.approx(3.0, abs=1e-3)            # the wheel reached its target speed
+    g.set_joint_motor(0, 3, target_vel=-2.0, damping=5.0); o.set_joint_motor(0, 3, target_vel=-2.0, damping=5.0)
+    g.set_joint_motor(1, 0, target_pos=0.2, stiffness=400.0, damping=40.0, max_force=60.0, model=S.MOTOR_FORCE_BASED)
+    o.set_joint_motor(1, 0, target_pos=0.2, stiffness=400.0, damping=40.0, max_force=60.0, model=S.MOTOR_FORCE_BASED)
+    for n in (1, 9, 90):
+        g.step(n); o.step(n)
+        _same_state(g, o, f"motors retargeted, +{n}")
+    np.testing.assert_array_equal(g.joint_motor_impulses(), o.joint_motor_impulses())
+    sc = S.motorised_joints()
+    sc.params["warmstart_joints"] = 1
+    g, o = _compare(sc, [1, 2, 10, 60, 150])
+    np.testing.assert_array_equal(g.joint_motor_impulses(), o.joint_motor_impulses())
+
+
+def test_joint_motor_wakes_sleeping_bodies_bit_exact():
+    """issue_692 on the device: a motor set on a sleeping jointed pair wakes it and drives it."""
+    sc = S.Scene(name="motor_wake", gravity=(0.0, -9.81, 0.0))
+    kin = sc.add_body(body_type=S.BODY_KINEMATIC_POSITION, can_sleep=1)
+    dyn = sc.add_body(translation=(0.0, -2.0, 0.0), can_sleep=1)
+    sc.add_collider(dyn, shape=S.SHAPE_BALL, half_extents=(0.5, 0.0, 0.0))
+    sc.add_joint(kin, dyn, (0.0, 0.0, 0.0), (0.0, 2.0, 0.0), locked_axes=S.LOCK_REVOLUTE)
+    g, o = _compare(sc, [1, 10, 150])
+    assert g.sleeping()[dyn] and o.sleeping()[dyn]
+    g.set_joint_motor(0, 3, target_vel=2.0, damping=100.0); o.set_joint_motor(0, 3, target_vel=2.0, damping=100.0)
+    for n in (1, 5, 50):
+        g.step(n); o.step(n)
+        _same_state(g, o, f"motor set on a sleeping pair, +{n}")
+        np.testing.assert_array_equal(g.sleeping(), o.sleeping())
+    assert not g.sleeping()[dyn] and np.linalg.norm(g.read_bodies()[1][dyn, 3:]) > 0.1
+
+
 def test_contact_disabling_joints_bit_exact():
     """GenericJoint::contacts_enabled = false: the pairs between the two jointed bodies are cleared (pair_update.rs:191-201)."""
     g, o = _compare(S.overlapping_chain(6, 0), [1, 2, 10, 60, 200])

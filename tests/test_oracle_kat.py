@@ -312,6 +312,28 @@ def test_joint_limits_stop_at_their_bounds():
     assert roll == pytest.approx(-0.8, abs=5e-3)                                  # pendulum lower limit -0.8 rad
 
 
+# Joint motors (motor_linear / motor_angular, joint_constraint_helper.rs:285-331, 566-625; MotorModel::combine_coefficients,
+# motor_model.rs:39-58): a velocity motor reaches its target speed, a force-based position motor holds its target within what
+# its force cap allows, a capped wheel motor drives a cart at a steady speed, motor impulses stay inside +-max_force * dt.
+def test_joint_motors_reach_their_targets():
+    sc = S.motorised_joints()
+    w = OracleWorld(sc)
+    w.step(300)
+    pos, vel = w.read()
+    assert vel[2, 5] == pytest.approx(3.0, abs=1e-3) and np.abs(vel[2, :5]).max() < 1e-4   # wheel: 3 rad/s about its axle
+    # lift: spring 400 N/m towards -0.5 against its weight m g (m = 0.768 kg): rests at -0.5 - m g / k
+    m = 8 * 0.4 * 0.2 * 0.4 * 3.0
+    assert pos[4, 1] - 4.0 == pytest.approx(-0.5 - m * 9.81 / 400.0, abs=2e-3) and abs(vel[4, 1]) < 1e-3
+    assert 1.0 < vel[7, 0] < 2.0 and abs(vel[7, 2]) < 1e-3                               # the cart rolls along +x
+    imp = w.joint_motor_impulses()
+    dt_sub = float(sc.params["dt"]) / int(sc.params["num_solver_iterations"])
+    assert abs(imp[1, 0]) <= 60.0 * dt_sub * 1.0001 and np.abs(imp[3:5, 3]).max() <= 5.0 * dt_sub * 1.0001
+    # a motor with a tiny force cap cannot hold the lift: it sags onto its lower stop
+    w.set_joint_motor(1, 0, target_pos=-0.5, stiffness=400.0, damping=40.0, max_force=1.0, model=S.MOTOR_FORCE_BASED)
+    w.step(200)
+    assert w.read()[0][4, 1] - 4.0 == pytest.approx(-2.0, abs=5e-3)
+
+
 # Events (pipeline/event_handler.rs:94-160): Started / Stopped on touching transitions, contact force events above the
 # threshold with `started` on the first step above it (geometry/mod.rs:223-258).
 def test_collision_and_contact_force_events():

@@ -301,17 +301,19 @@ def test_still_wide_body_reports_no_drift():
 
 
 # ---- issue_499_angular_limits.rs (the impulse-joint + torque drive) ---------------------------------------------------------
-def _settled_angle_deg(limits_deg, direction):
+def _settled_angle_deg(limits_deg, direction, motor=False):
     sc = world(gravity=(0.0, 0.0, 0.0), dt=1.0 / 60.0)
     b1 = sc.add_body(body_type=S.BODY_FIXED)
     b2 = sc.add_body(translation=(1.0, 0.0, 0.0), angular_damping=3.0)
     sc.add_collider(b2, half_extents=(0.5, 0.1, 0.1))
     sc.add_joint(b1, b2, (0.0, 0.0, 0.0), (-1.0, 0.0, 0.0), locked_axes=S.LOCK_REVOLUTE, basis1=S.AXIS_Z_BASIS, basis2=S.AXIS_Z_BASIS,
-                 limits={3: (np.radians(limits_deg[0]), np.radians(limits_deg[1]))})
+                 limits={3: (np.radians(limits_deg[0]), np.radians(limits_deg[1]))},
+                 motors={3: dict(target_vel=direction * 5.0, damping=20.0)} if motor else None)   # motor_velocity(dir * 5, 20)
     w = OracleWorld(sc)
     unwrapped, prev = 0.0, 0.0
     for _ in range(600):
-        w.add_force(b2, torque=(0.0, 0.0, direction * 0.1))      # add_torque accumulates (it is never reset in the reference test)
+        if not motor:
+            w.add_force(b2, torque=(0.0, 0.0, direction * 0.1))  # add_torque accumulates (it is never reset in the reference test)
         w.step(1)
         q = w.read()[0][b2, 3:].astype(np.float64)
         ang = 2.0 * np.arctan2(q[2], q[3])
@@ -328,17 +330,19 @@ def _settled_angle_deg(limits_deg, direction):
 @pytest.mark.parametrize("limits", [(-45.0, 45.0), (-135.0, 135.0), (0.0, 90.0), (-170.0, -10.0),        # within half a turn
                                     (0.0, 270.0), (-270.0, 0.0), (-90.0, 200.0), (-350.0, 0.0),          # past half a turn
                                     (45.0, 315.0), (-315.0, -45.0), (135.0, 225.0)])                     # straddling half a turn
-def test_angular_limits_are_reached(limits):
-    """issue_499_angular_limits.rs:93-121 (Drive::Torque on the impulse joint): driving + / - settles within 2 degrees of
-    the upper / lower limit."""
-    assert abs(_settled_angle_deg(limits, 1.0) - limits[1]) < 2.0
-    assert abs(_settled_angle_deg(limits, -1.0) - limits[0]) < 2.0
+@pytest.mark.parametrize("motor", [False, True])
+def test_angular_limits_are_reached(limits, motor):
+    """issue_499_angular_limits.rs:93-121 (Drive::Torque and Drive::Motor on the impulse joint): driving + / - settles within
+    2 degrees of the upper / lower limit."""
+    assert abs(_settled_angle_deg(limits, 1.0, motor) - limits[1]) < 2.0
+    assert abs(_settled_angle_deg(limits, -1.0, motor) - limits[0]) < 2.0
 
 
 @pytest.mark.parametrize("limits", [(-180.0, 180.0), (-200.0, 200.0), (-350.0, 350.0)])
-def test_angular_limits_wider_than_a_turn_leave_the_joint_free(limits):
-    """issue_499_angular_limits.rs:123-133 (driven by the torque instead of the motor)."""
-    assert _settled_angle_deg(limits, 1.0) > 360.0
+@pytest.mark.parametrize("motor", [False, True])
+def test_angular_limits_wider_than_a_turn_leave_the_joint_free(limits, motor):
+    """issue_499_angular_limits.rs:123-133 (the reference drives this one with the velocity motor)."""
+    assert _settled_angle_deg(limits, 1.0, motor) > 360.0
 
 
 def test_a_joint_shoved_past_its_limit_comes_back():
@@ -354,3 +358,46 @@ def test_a_joint_shoved_past_its_limit_comes_back():
     q = w.read()[0][b2, 3:].astype(np.float64)
     angle = np.degrees(2.0 * np.arctan2(q[2], q[3]))
     assert -2.0 <= angle < 172.0
+
+
+# ---- issue_692_joint_get_mut_wakes_bodies.rs / issue_856_motor_position_rotating_base.rs -------------------------------------
+def test_joint_get_mut_wakes_sleeping_bodies():
+    """issue_692: changing a joint's motor through ImpulseJointSet::get_mut(handle, true) wakes both bodies and the motor acts."""
+    sc = world()
+    kin = sc.add_body(body_type=S.BODY_KINEMATIC_POSITION, can_sleep=1)
+    dyn = sc.add_body(translation=(0.0, -2.0, 0.0), can_sleep=1)
+    sc.add_collider(dyn, shape=S.SHAPE_BALL, half_extents=(0.5, 0.0, 0.0))
+    j = sc.add_joint(kin, dyn, (0.0, 0.0, 0.0), (0.0, 2.0, 0.0), locked_axes=S.LOCK_REVOLUTE)
+    w = OracleWorld(sc)
+    steps = 0
+    while not w.sleeping()[dyn]:
+        w.step(1); steps += 1
+        assert steps < 2000, "dynamic body never fell asleep"
+    w.set_joint_motor(j, 3, target_vel=2.0, damping=100.0)      # set_motor_velocity(JointAxis::AngX, 2.0, 100.0)
+    w.step(1)
+    assert not w.sleeping()[dyn]
+    moved = False
+    for _ in range(50):
+        w.step(1)
+        moved = moved or np.linalg.norm(w.read()[1][dyn, 3:]) > 0.1
+    assert moved
+
+
+def test_motor_position_with_rotating_base_stays_finite():
+    """issue_856 (the base is a cuboid here instead of a cylinder): a stiff position motor whose base body is re-oriented by
+    the user every frame keeps every body finite."""
+    sc = world()
+    base = sc.add_body(translation=(0.0, 3.0, 0.0))
+    sc.add_collider(base, half_extents=(1.0, 0.2, 1.0))
+    hammer = sc.add_body(translation=(2.0, 3.0, 0.0))
+    sc.add_collider(hammer, half_extents=(0.5, 0.1, 0.1))
+    sc.add_joint(base, hammer, (1.0, 0.0, 0.0), (-1.0, 0.0, 0.0), locked_axes=S.LOCK_REVOLUTE, basis1=S.AXIS_Z_BASIS, basis2=S.AXIS_Z_BASIS,
+                 motors={3: dict(target_pos=np.pi, stiffness=1.0e4, damping=100.0)})     # motor_position(PI, 1e4, 100)
+    w = OracleWorld(sc)
+    for i in range(300):
+        a = i * 0.05
+        t = w.read()[0][base, :3]
+        w.set_pose(base, [t[0], t[1], t[2], 0.0, np.sin(a / 2), 0.0, np.cos(a / 2)])
+        w.step(1)
+        pos, vel = w.read()
+        assert np.isfinite(pos).all() and np.isfinite(vel).all(), i
