@@ -575,6 +575,14 @@ void ro_set_body_pose(ro_world *w, int32_t body, const float pos7[7]) {
         if (b1 == body) wake_request(w, b2, 1);
         if (b2 == body) wake_request(w, b1, 1);
     }
+    /* a moved FIXED body wakes its joint partners (user_changes.rs:228-246): it is no island member, so its own wake is a no-op */
+    if (b->body_type == RO_BODY_FIXED)
+        for (int i = 0; i < w->njoints; ++i) {
+            const Joint *j = &w->joints[i];
+            if (j->removed) continue;
+            if (j->body1 == body) wake_request(w, j->body2, 1);
+            if (j->body2 == body) wake_request(w, j->body1, 1);
+        }
 }
 void ro_set_next_kinematic_position(ro_world *w, int32_t body, const float pos7[7]) {
     Body *b = &w->bodies[body];

@@ -121,6 +121,7 @@ static int check_sleep_scope(rp_world *w);
 static int rebuild_begin(rp_world *w);
 static int queue_wake(rp_world *w, int b, int lvl);
 static int finalize(rp_world *w);
+template <typename T> static int poke(rp_world *w, T *dst, const T &v);
 
 extern "C" void rp_default_params(rp_integration_params *p) {
     // IntegrationParameters::default() — integration_parameters.rs:379-408
@@ -504,6 +505,18 @@ static int download_state(rp_world *w) {
     }
     return RP_OK;
 }
+// pose of a body descriptor / local frame of a joint descriptor (GenericJoint::local_frame1/2)
+static Pose host_body_pose(const HostBody &b) {
+    Pose p; const float *r = b.d.rotation;
+    float qn = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
+    float qi = qn > 0.0f ? 1.0f / qn : 1.0f;
+    p.r = q4(r[0] * qi, r[1] * qi, r[2] * qi, qn > 0.0f ? r[3] * qi : 1.0f);
+    p.t = v3(b.d.translation[0], b.d.translation[1], b.d.translation[2]);
+    return p;
+}
+static Pose joint_local_frame(const float *anchor, const float *basis) {
+    Pose p; p.r = qnormalize(q4(basis[0], basis[1], basis[2], basis[3])); p.t = v3(anchor[0], anchor[1], anchor[2]); return p;
+}
 static int rebuild_begin(rp_world *w) { // called before the host mirrors grow
     if (!w->finalized) return RP_OK;
     HIPCHK(w, hipSetDevice(w->device));
@@ -813,20 +826,9 @@ static int finalize(rp_world *w) {
         const HostBody &rb1 = w->bodies[j.body1], &rb2 = w->bodies[j.body2];
         bool d1 = rb1.d.body_type != RP_BODY_FIXED && !rb1.removed, d2 = rb2.d.body_type != RP_BODY_FIXED && !rb2.removed; // is_dynamic_or_kinematic
         if (!d1 && !d2) continue;
-        auto body_pose = [](const HostBody &b) {
-            Pose p; const float *r = b.d.rotation;
-            float qn = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
-            float qi = qn > 0.0f ? 1.0f / qn : 1.0f;
-            p.r = q4(r[0] * qi, r[1] * qi, r[2] * qi, qn > 0.0f ? r[3] * qi : 1.0f);
-            p.t = v3(b.d.translation[0], b.d.translation[1], b.d.translation[2]);
-            return p;
-        };
-        auto local_frame = [](const float *anchor, const float *basis) {
-            Pose p; p.r = qnormalize(q4(basis[0], basis[1], basis[2], basis[3])); p.t = v3(anchor[0], anchor[1], anchor[2]); return p;
-        };
-        Pose f1 = local_frame(j.local_anchor1, j.local_basis1), f2 = local_frame(j.local_anchor2, j.local_basis2);
-        if (!d1) f1 = pose_mul(body_pose(rb1), f1); else f1.t = f1.t - v3(rb1.lcom[0], rb1.lcom[1], rb1.lcom[2]);
-        if (!d2) f2 = pose_mul(body_pose(rb2), f2); else f2.t = f2.t - v3(rb2.lcom[0], rb2.lcom[1], rb2.lcom[2]);
+        Pose f1 = joint_local_frame(j.local_anchor1, j.local_basis1), f2 = joint_local_frame(j.local_anchor2, j.local_basis2);
+        if (!d1) f1 = pose_mul(host_body_pose(rb1), f1); else f1.t = f1.t - v3(rb1.lcom[0], rb1.lcom[1], rb1.lcom[2]);
+        if (!d2) f2 = pose_mul(host_body_pose(rb2), f2); else f2.t = f2.t - v3(rb2.lcom[0], rb2.lcom[1], rb2.lcom[2]);
         jb1.push_back(d1 ? j.body1 : -1); jb2.push_back(d2 ? j.body2 : -1);
         jf1t.push_back(mk4(f1.t.x, f1.t.y, f1.t.z, 0)); jf1r.push_back(mk4(f1.r.x, f1.r.y, f1.r.z, f1.r.w));
         jf2t.push_back(mk4(f2.t.x, f2.t.y, f2.t.z, 0)); jf2r.push_back(mk4(f2.r.x, f2.r.y, f2.r.z, f2.r.w));
@@ -1191,6 +1193,28 @@ extern "C" int32_t rp_bodies_write(rp_world *w, int32_t n, const uint64_t *handl
             HIPCHK(w, hipMemcpy(w->dw.b_rot + b, &q, sizeof(q), hipMemcpyHostToDevice));
             HIPCHK(w, hipMemcpy(w->dw.b_next_pos + b, &t, sizeof(t), hipMemcpyHostToDevice)); // set_position sets position AND next_position
             HIPCHK(w, hipMemcpy(w->dw.b_next_rot + b, &q, sizeof(q), hipMemcpyHostToDevice));
+            if (w->bodies[b].d.body_type == RP_BODY_FIXED) {
+                // the frame of a world-attached joint side is kept in world space (transform_to_solver_body_space): a moved fixed body
+                // takes the frames of its joints along and wakes its joint partners (user_changes.rs:228-246)
+                rp_body_desc &bd = w->bodies[b].d;
+                for (int k = 0; k < 3; ++k) bd.translation[k] = pos7[7 * i + k];
+                for (int k = 0; k < 4; ++k) bd.rotation[k] = pos7[7 * i + 3 + k];
+                for (int k = 0; k < (int)w->active_joint_ids.size(); ++k) {
+                    const rp_joint_desc &jd = w->joints[w->active_joint_ids[k]];
+                    if (w->joint_removed[w->active_joint_ids[k]] || (jd.body1 != b && jd.body2 != b)) continue;
+                    int r;
+                    if (jd.body1 == b) {
+                        Pose f = pose_mul(host_body_pose(w->bodies[b]), joint_local_frame(jd.local_anchor1, jd.local_basis1));
+                        if ((r = poke(w, w->dw.j_f1t + k, mk4(f.t.x, f.t.y, f.t.z, 0))) != RP_OK || (r = poke(w, w->dw.j_f1r + k, mk4(f.r.x, f.r.y, f.r.z, f.r.w))) != RP_OK) return r;
+                    }
+                    if (jd.body2 == b) {
+                        Pose f = pose_mul(host_body_pose(w->bodies[b]), joint_local_frame(jd.local_anchor2, jd.local_basis2));
+                        if ((r = poke(w, w->dw.j_f2t + k, mk4(f.t.x, f.t.y, f.t.z, 0))) != RP_OK || (r = poke(w, w->dw.j_f2r + k, mk4(f.r.x, f.r.y, f.r.z, f.r.w))) != RP_OK) return r;
+                    }
+                    int partner = jd.body1 == b ? jd.body2 : jd.body1;
+                    if (w->dw.sleep_enabled && partner != b && w->bodies[partner].d.body_type != RP_BODY_FIXED && !w->bodies[partner].removed && (r = queue_wake(w, partner, 2)) != RP_OK) return r;
+                }
+            }
         }
     }
     if (w->dw.sleep_enabled) {

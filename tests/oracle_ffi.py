@@ -99,6 +99,17 @@ class OracleWorld:
     def step(self, n: int = 1):
         lib().ro_step(self._w, n)
 
+    def add_body(self, **kw) -> int:
+        """RigidBodySet::insert into the (possibly already stepped) world."""
+        b = np.ascontiguousarray(S.body_desc(**kw))
+        h = lib().ro_add_body(self._w, b.ctypes.data)
+        self.n += 1
+        return h
+
+    def add_collider(self, parent: int, **kw) -> int:
+        c = np.ascontiguousarray(S.collider_desc(**kw))
+        return lib().ro_add_collider(self._w, c.ctypes.data, int(parent))
+
     def read(self):
         pos = np.zeros((self.n, 7), np.float32)
         vel = np.zeros((self.n, 6), np.float32)

@@ -549,6 +549,64 @@ def test_joint_motor_wakes_sleeping_bodies_bit_exact():
     assert not g.sleeping()[dyn] and np.linalg.norm(g.read_bodies()[1][dyn, 3:]) > 0.1
 
 
+def test_reference_sleep_wake_scenes_bit_exact():
+    """Scenes of the reference's sleep_wake.rs / joint_assembly_persistence.rs / joint_stability.rs (restated against the oracle
+    in tests/test_reference_kats.py) through the device path: a toppling domino wave running through sleeping dominoes, a
+    sub-gate impact by a body inserted into the stepped world, a fixed joint anchor moved while its bob sleeps, hanging
+    chains on limited prismatic joints."""
+    import test_reference_kats as K
+    sc = K._sw_world()
+    for i in range(10):
+        b = sc.add_body(translation=(i * 0.4, 2.0, 0.0), rotation=K.quat_from_scaled_axis((0.0, 0.0, -0.2)) if i == 0 else (0, 0, 0, 1), can_sleep=1)
+        sc.add_collider(b, half_extents=(0.1, 2.0, 1.0))
+    g, o = _compare(sc, [1, 30, 120, 400, 900, 1500])
+    np.testing.assert_array_equal(g.sleeping(), o.sleeping())
+    assert g.sleeping()[1:].all()
+
+    sc = K._sw_world()
+    g0 = sc.add_body(body_type=S.BODY_FIXED, translation=(0.0, -0.5, 70.0))
+    sc.add_collider(g0, half_extents=(20.0, 0.5, 10.0), friction=0.0)
+    target = sc.add_body(translation=(0.0, 0.5, 70.0), can_sleep=1)
+    sc.add_collider(target, half_extents=(0.5, 0.5, 0.5), friction=0.0)
+    g, o = _compare(sc, [1, 120])
+    assert g.sleeping()[target]
+    body = S.body_desc(translation=(-3.0, 0.5, 70.0), linvel=(0.6, 0.0, 0.0), can_sleep=1)
+    col = S.collider_desc(half_extents=(0.5, 0.5, 0.5), friction=0.0)
+    hb = g.insert_body(body); g.insert_collider(col, hb)
+    ob = o.add_body(translation=(-3.0, 0.5, 70.0), linvel=(0.6, 0.0, 0.0), can_sleep=1); o.add_collider(ob, half_extents=(0.5, 0.5, 0.5), friction=0.0)
+    for n in (1, 199, 40):
+        g.step(n); o.step(n)
+        _same_state(g, o, f"sub-gate impact, +{n}")
+        np.testing.assert_array_equal(g.sleeping(), o.sleeping())
+    assert not g.sleeping()[target] and g.read_bodies()[1][target, 0] > 0.25
+
+    sc = S.Scene(name="moved_anchor", gravity=(0.0, -9.81, 0.0))
+    anchor = sc.add_body(body_type=S.BODY_FIXED)
+    bob = sc.add_body(translation=(0.0, -2.0, 0.0), can_sleep=1)
+    sc.add_collider(bob, shape=S.SHAPE_BALL, half_extents=(0.2, 0.0, 0.0))
+    sc.add_joint(anchor, bob, (0.0, 0.0, 0.0), (0.0, 2.0, 0.0), locked_axes=S.LOCK_LIN)
+    g, o = _compare(sc, [1, 40])
+    assert g.sleeping()[bob]
+    new_pose = [5.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0]
+    g.write_bodies([anchor], pos7=[new_pose]); o.set_pose(anchor, new_pose)
+    for n in (1, 9, 290):
+        g.step(n); o.step(n)
+        _same_state(g, o, f"fixed anchor moved, +{n}")
+    assert abs(np.linalg.norm(g.read_bodies()[0][bob, :3] - np.array([5.0, 0.0, 0.0])) - 2.0) < 0.3
+
+    sc = S.Scene(name="prismatic_chains", gravity=(0.0, -9.81, 0.0))
+    for chain in range(10):
+        parent = sc.add_body(body_type=S.BODY_FIXED, translation=(chain * 4.0, 0.0, 0.0))
+        sc.add_collider(parent, half_extents=(0.4, 0.4, 0.4))
+        for i in range(10):
+            child = sc.add_body(translation=(chain * 4.0, -(i + 1) * 1.0, 0.0))
+            sc.add_collider(child, half_extents=(0.4, 0.4, 0.4))
+            basis = K._axis_basis_z(np.pi / 4 if i % 2 == 0 else 3 * np.pi / 4)
+            sc.add_joint(parent, child, (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), locked_axes=S.LOCK_PRISMATIC, basis1=basis, basis2=basis, limits={0: (-1.5, 1.5)})
+            parent = child
+    _compare(sc, [1, 10, 100, 1000])
+
+
 def test_contact_disabling_joints_bit_exact():
     """GenericJoint::contacts_enabled = false: the pairs between the two jointed bodies are cleared (pair_update.rs:191-201)."""
     g, o = _compare(S.overlapping_chain(6, 0), [1, 2, 10, 60, 200])

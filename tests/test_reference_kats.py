@@ -401,3 +401,376 @@ def test_motor_position_with_rotating_base_stays_finite():
         w.step(1)
         pos, vel = w.read()
         assert np.isfinite(pos).all() and np.isfinite(vel).all(), i
+
+
+# ---- sleep_wake.rs -------------------------------------------------------------------------------------------------------
+def _sw_world():
+    sc = world()
+    ground(sc, he=(50.0, 0.5, 50.0))
+    return sc
+
+
+def _cube(sc, t, **kw):
+    kw.setdefault("can_sleep", 1)
+    b = sc.add_body(translation=t, **kw)
+    sc.add_collider(b, half_extents=(0.5, 0.5, 0.5))
+    return b
+
+
+def test_woken_body_is_supported_by_recycled_contacts():
+    """sleep_wake.rs:3-97: a cube woken by an impulse (colliders unmoved -> contact recycling path) is still supported."""
+    sc = world()
+    ground(sc, he=(10.0, 0.5, 10.0))
+    cube = _cube(sc, (0.0, 0.6, 0.0))
+    w = OracleWorld(sc)
+    for _ in range(400):
+        w.step(1)
+        if w.sleeping()[cube]:
+            break
+    assert w.sleeping()[cube]
+    w.apply_impulse(cube, impulse=(0.5, 0.0, 0.0))
+    for _ in range(120):
+        w.step(1)
+        assert w.read()[0][cube, 1] > 0.4
+
+
+def test_non_sleeping_neighbor_keeps_touching_row_awake():
+    """sleep_wake.rs:171-210"""
+    sc = _sw_world()
+    row = [_cube(sc, (float(i), 0.5, 0.0), can_sleep=0 if i == 0 else 1) for i in range(8)]
+    lone = _cube(sc, (30.0, 0.5, 0.0))
+    w = OracleWorld(sc)
+    w.step(400)
+    slp = w.sleeping()
+    assert not slp[row].any() and slp[lone]
+    pos = w.read()[0]
+    for i, h in enumerate(row):
+        assert abs(pos[h, 1] - 0.5) < 0.1 and abs(pos[h, 0] - i) < 0.1
+
+
+def test_impact_wakes_sleeping_region():
+    """sleep_wake.rs:212-255: a fast cube thrown at a sleeping row wakes the cube it hits, which responds physically."""
+    sc = _sw_world()
+    row = [_cube(sc, (float(i), 0.5, 0.0)) for i in range(6)]
+    w = OracleWorld(sc)
+    w.step(400)
+    assert w.sleeping()[row].all()
+    bullet = w.add_body(translation=(-3.0, 0.5, 0.0), linvel=(20.0, 0.0, 0.0), can_sleep=1)
+    w.add_collider(bullet, half_extents=(0.5, 0.5, 0.5))
+    w.step(30)
+    pos, vel = w.read()
+    assert not w.sleeping()[row[0]]
+    assert np.linalg.norm(vel[row[0], :3]) > 0.05 or pos[row[0], 0] > 0.05
+
+
+def test_joint_keeps_both_sides_awake():
+    """sleep_wake.rs:257-310"""
+    sc = _sw_world()
+    mover = _cube(sc, (0.0, 0.5, 0.0), can_sleep=0)
+    b = _cube(sc, (1.0, 0.5, 0.0))
+    a = _cube(sc, (2.5, 0.5, 0.0))
+    control = _cube(sc, (10.0, 0.5, 0.0))
+    sc.add_joint(b, a, (1.5, 0.0, 0.0), (0.0, 0.0, 0.0), locked_axes=S.LOCK_ALL)
+    w = OracleWorld(sc)
+    w.step(400)
+    slp = w.sleeping()
+    assert not slp[mover] and not slp[b] and not slp[a] and slp[control]
+    pos = w.read()[0]
+    assert abs(pos[a, 0] - 2.5) < 0.1 and abs(pos[b, 0] - 1.0) < 0.1
+
+
+def test_corner_velocity_sleep_metric():
+    """sleep_wake.rs:312-356: a long beam pivoting at 0.3 rad/s (tips at 3 m/s) stays awake; a 5 cm pebble spinning at
+    0.55 rad/s (surface at < 0.05 m/s) sleeps."""
+    sc = _sw_world()
+    beam = sc.add_body(translation=(0.0, 30.0, 0.0), angvel=(0.0, 0.0, 0.3), gravity_scale=0.0, can_sleep=1)
+    sc.add_collider(beam, half_extents=(10.0, 0.1, 0.1))
+    pebble = sc.add_body(translation=(0.0, 30.0, 20.0), angvel=(0.0, 0.0, 0.55), gravity_scale=0.0, can_sleep=1)
+    sc.add_collider(pebble, half_extents=(0.05, 0.05, 0.05))
+    w = OracleWorld(sc)
+    w.step(200)
+    assert not w.sleeping()[beam] and w.sleeping()[pebble]
+
+
+def test_sliding_support_wakes_sleeping_rider():
+    """sleep_wake.rs:358-418"""
+    sc = _sw_world()
+    pusher = sc.add_body(body_type=S.BODY_KINEMATIC_VELOCITY, translation=(-1.55, 0.5, 0.0), linvel=(0.15, 0.0, 0.0), can_sleep=1)
+    sc.add_collider(pusher, half_extents=(0.5, 0.5, 0.5))
+    support = _cube(sc, (0.0, 0.5, 0.0))
+    rider = _cube(sc, (0.0, 1.5, 0.0))
+    w = OracleWorld(sc)
+    slept = woke = False
+    for _ in range(400):
+        w.step(1)
+        if w.sleeping()[rider]:
+            slept = True
+        elif slept:
+            woke = True
+    assert slept and woke
+    pos = w.read()[0]
+    assert pos[rider, 0] > 0.3
+    assert abs(pos[rider, 1] - 1.5) < 0.2 and abs(pos[rider, 0] - pos[support, 0]) < 0.75
+
+
+def test_slow_kinematic_wakes_sleeping_body_on_contact():
+    """sleep_wake.rs:420-462"""
+    sc = _sw_world()
+    cube = _cube(sc, (0.0, 0.5, 0.0))
+    wall = sc.add_body(body_type=S.BODY_KINEMATIC_VELOCITY, translation=(-2.5, 0.5, 0.0), linvel=(0.3, 0.0, 0.0), can_sleep=1)
+    sc.add_collider(wall, half_extents=(0.5, 0.5, 0.5))
+    w = OracleWorld(sc)
+    w.step(120)
+    assert w.sleeping()[cube]
+    w.step(320)
+    assert not w.sleeping()[cube] and w.read()[0][cube, 0] > 0.2
+
+
+def test_huge_slow_platform_wakes_small_sleeping_body():
+    """sleep_wake.rs:464-508"""
+    sc = _sw_world()
+    cube = _cube(sc, (0.0, 0.5, 0.0))
+    plat = sc.add_body(body_type=S.BODY_KINEMATIC_VELOCITY, translation=(-11.0, 0.5, 0.0), linvel=(0.3, 0.0, 0.0), can_sleep=1)
+    sc.add_collider(plat, half_extents=(10.0, 0.4, 10.0))
+    w = OracleWorld(sc)
+    w.step(90)
+    assert w.sleeping()[cube]
+    w.step(60)
+    assert not w.sleeping()[cube] and w.read()[0][cube, 0] > 0.02
+
+
+def _tilt(q):
+    return float(np.arccos(np.clip((rot_matrix(q) @ np.array([0.0, 1.0, 0.0]))[1], -1.0, 1.0)))
+
+
+def test_slow_dynamic_intruder_wakes_sleeping_body():
+    """sleep_wake.rs:510-556: a slowly toppling domino chain falls completely (the wave does not stall against sleeping
+    dominoes) and the fallen chain goes back to sleep."""
+    sc = _sw_world()
+    dom = []
+    for i in range(10):
+        b = sc.add_body(translation=(i * 0.4, 2.0, 0.0), rotation=quat_from_scaled_axis((0.0, 0.0, -0.2)) if i == 0 else (0, 0, 0, 1), can_sleep=1)
+        sc.add_collider(b, half_extents=(0.1, 2.0, 1.0))
+        dom.append(b)
+    w = OracleWorld(sc)
+    w.step(900)
+    pos = w.read()[0]
+    for i, h in enumerate(dom):
+        assert _tilt(pos[h, 3:]) > 0.5, i
+    w.step(600)
+    assert w.sleeping()[dom].all()
+
+
+def test_grazing_wedge_wakes_sleeping_chain():
+    """sleep_wake.rs:558-618: dominoes 150..186 of the domino-spiral demo, the pre-tilted one leaning backward onto the segment."""
+    sc = _sw_world()
+    f32 = np.float32
+    two_pi = f32(2.0) * f32(np.pi)
+    curr_angle, curr_rad = f32(0.0), f32(10.0)
+    dom = []
+    for i in range(187):
+        perimeter = two_pi * curr_rad
+        prev_angle = curr_angle
+        curr_angle = f32(curr_angle + two_pi * f32(0.4) / perimeter)
+        x, z = np.sin(curr_angle), np.cos(curr_angle)
+        nudged = np.fmod(curr_angle, two_pi) < np.fmod(prev_angle, two_pi)
+        tilt = 0.2 if nudged else 0.0
+        if i >= 150:
+            rot = quat_from_scaled_axis((0.0, float(curr_angle), 0.0))
+            tilt_axis = rot_matrix(rot) @ np.array([0.0, 0.0, 1.0])
+            tq = quat_from_scaled_axis(tilt_axis * tilt)
+            # tilt_rot * rot
+            ax, ay, az, aw = tq; bx, by, bz, bw = rot
+            q = (aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                 aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz)
+            b = sc.add_body(translation=(float(x * curr_rad), 2.1, float(z * curr_rad)), rotation=q, can_sleep=1)
+            sc.add_collider(b, half_extents=(0.1, 2.0, 1.0))
+            dom.append(b)
+        curr_rad = f32(curr_rad + f32(1.5) / perimeter)
+    w = OracleWorld(sc)
+    w.step(1800)
+    pos = w.read()[0]
+    for i, h in enumerate(dom):
+        assert _tilt(pos[h, 3:]) > 0.5, i
+
+
+def test_sub_gate_impact_wakes_and_transfers_momentum():
+    """sleep_wake.rs:620-676: a 0.6 m/s frictionless impact on a sleeping cube wakes it in the contact step and hands over
+    its momentum (target vx ~ 0.3, > 0.25)."""
+    sc = _sw_world()
+    g0 = sc.add_body(body_type=S.BODY_FIXED, translation=(0.0, -0.5, 70.0))
+    sc.add_collider(g0, half_extents=(20.0, 0.5, 10.0), friction=0.0)
+    target = sc.add_body(translation=(0.0, 0.5, 70.0), can_sleep=1)
+    sc.add_collider(target, half_extents=(0.5, 0.5, 0.5), friction=0.0)
+    w = OracleWorld(sc)
+    w.step(120)
+    assert w.sleeping()[target]
+    mover = w.add_body(translation=(-3.0, 0.5, 70.0), linvel=(0.6, 0.0, 0.0), can_sleep=1)
+    w.add_collider(mover, half_extents=(0.5, 0.5, 0.5), friction=0.0)
+    w.step(240)
+    assert not w.sleeping()[target]
+    assert w.read()[1][target, 0] > 0.25
+
+
+def test_floating_region_does_not_sleep_partially():
+    """sleep_wake.rs:678-740"""
+    sc = _sw_world()
+    mover = _cube(sc, (0.0, 0.5, 0.0), can_sleep=0)
+    col = [_cube(sc, (0.0, 1.5 + i, 0.0)) for i in range(3)]
+    control = [_cube(sc, (10.0, 0.5 + i, 0.0)) for i in range(3)]
+    w = OracleWorld(sc)
+    w.step(600)
+    slp = w.sleeping()
+    assert not slp[mover] and not slp[col].any() and slp[control].all()
+    pos = w.read()[0]
+    for i, h in enumerate([mover] + col):
+        assert abs(pos[h, 1] - (0.5 + i)) < 0.1 and abs(pos[h, 0]) < 0.1
+
+
+def test_whole_floating_island_sleeps():
+    """sleep_wake.rs:742-772"""
+    sc = _sw_world()
+    a = sc.add_body(translation=(0.0, 30.0, 0.0), gravity_scale=0.0, can_sleep=1)
+    sc.add_collider(a, half_extents=(0.5, 0.5, 0.5))
+    b = sc.add_body(translation=(0.999, 30.0, 0.0), gravity_scale=0.0, can_sleep=1)
+    sc.add_collider(b, half_extents=(0.5, 0.5, 0.5))
+    w = OracleWorld(sc)
+    w.step(400)
+    assert w.sleeping()[a] and w.sleeping()[b]
+
+
+def test_slow_drift_does_not_sleep_mid_motion():
+    """sleep_wake.rs:774-810"""
+    sc = _sw_world()
+    drifter = sc.add_body(translation=(0.0, 30.0, 0.0), linvel=(0.3, 0.0, 0.0), gravity_scale=0.0, can_sleep=1)
+    sc.add_collider(drifter, half_extents=(0.5, 0.5, 0.5))
+    creeper = sc.add_body(translation=(0.0, 30.0, 20.0), linvel=(0.03, 0.0, 0.0), gravity_scale=0.0, can_sleep=1)
+    sc.add_collider(creeper, half_extents=(0.5, 0.5, 0.5))
+    w = OracleWorld(sc)
+    w.step(400)
+    assert not w.sleeping()[drifter] and w.sleeping()[creeper]
+
+
+# ---- joint_stability.rs / joint_assembly_persistence.rs / issue_952_simd_joint_offset_com.rs -------------------------------
+def _axis_basis_z(angle):
+    """local basis whose X axis is X rotated by `angle` about Z (PrismaticJointBuilder::new(axis) completes the frame with
+    the minimal rotation taking +X to the axis)"""
+    return (0.0, 0.0, float(np.sin(angle / 2)), float(np.cos(angle / 2)))
+
+
+def test_prismatic_limit_chains_remain_stable():
+    """joint_stability.rs:38-102: ten chains of ten boxes hanging from limited prismatic joints on alternating diagonal rails
+    stay bounded (|pos| < 200, |v| < 100) over 10,000 steps."""
+    sc = world()
+    rad, shift = 0.4, 1.0
+    for chain in range(10):
+        x = chain * 4.0
+        parent = sc.add_body(body_type=S.BODY_FIXED, translation=(x, 0.0, 0.0))
+        sc.add_collider(parent, half_extents=(rad, rad, rad))
+        for i in range(10):
+            child = sc.add_body(translation=(x, -(i + 1) * shift, 0.0))
+            sc.add_collider(child, half_extents=(rad, rad, rad))
+            basis = _axis_basis_z(np.pi / 4 if i % 2 == 0 else 3 * np.pi / 4)          # (+-1, 1, 0) / sqrt(2)
+            sc.add_joint(parent, child, (0.0, 0.0, 0.0), (0.0, shift, 0.0), locked_axes=S.LOCK_PRISMATIC, basis1=basis, basis2=basis,
+                         limits={0: (-1.5, 1.5)})
+            parent = child
+    w = OracleWorld(sc)
+    for _ in range(10):
+        w.step(1000)
+        pos, vel = w.read()
+        assert np.linalg.norm(pos[:, :3], axis=1).max() < 200.0
+        assert np.linalg.norm(vel[:, :3], axis=1).max() < 100.0
+
+
+def _pendulum(anchor_pos=(0.0, 0.0, 0.0)):
+    sc = world()
+    anchor = sc.add_body(body_type=S.BODY_FIXED, translation=anchor_pos)
+    bob = sc.add_body(translation=(anchor_pos[0], anchor_pos[1] - 2.0, anchor_pos[2]), can_sleep=1)
+    sc.add_collider(bob, shape=S.SHAPE_BALL, half_extents=(0.2, 0.0, 0.0))
+    j = sc.add_joint(anchor, bob, (0.0, 0.0, 0.0), (0.0, 2.0, 0.0), locked_axes=S.LOCK_LIN)
+    return OracleWorld(sc), anchor, bob, j
+
+
+def test_removed_joint_stops_constraining():
+    """joint_assembly_persistence.rs:32-54"""
+    w, _, bob, j = _pendulum()
+    w.step(30)
+    assert w.read()[0][bob, 1] > -2.5
+    w.remove_joint(j)
+    w.step(60)
+    assert w.read()[0][bob, 1] < -4.0
+
+
+def test_moved_fixed_anchor_takes_its_joint_along():
+    """joint_assembly_persistence.rs:84-107: after the fixed anchor is moved the bob is pinned 2.0 from the NEW anchor."""
+    w, anchor, bob, _ = _pendulum()
+    w.step(30)
+    w.set_pose(anchor, [5.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0])
+    w.step(300)
+    dist = np.linalg.norm(w.read()[0][bob, :3] - np.array([5.0, 0.0, 0.0]))
+    assert abs(dist - 2.0) < 0.3
+
+
+@pytest.mark.parametrize("n", [8, 128])
+def test_joints_respect_offset_center_of_mass(n):
+    """issue_952 (cuboid instead of capsule_x): pendulums whose collider — hence centre of mass — sits 1.0 off the body
+    origin the revolute joint is anchored at; 128 of them fill a parallel joint colour (>= 64 joints).  The anchor never
+    strays more than 1e-2 from its base."""
+    sc = world()
+    bodies = []
+    for i in range(n):
+        base = sc.add_body(body_type=S.BODY_FIXED, translation=(i * 20.0, 0.0, 0.0))
+        b = sc.add_body(translation=(i * 20.0, 0.0, 0.0))
+        sc.add_collider(b, half_extents=(1.2, 0.2, 0.2), translation=(1.0, 0.0, 0.0))
+        sc.add_joint(base, b, (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), locked_axes=S.LOCK_REVOLUTE, basis1=S.AXIS_Z_BASIS, basis2=S.AXIS_Z_BASIS, contacts_enabled=0)
+        bodies.append(b)
+    w = OracleWorld(sc)
+    max_err = 0.0
+    for _ in range(120):
+        w.step(1)
+        pos = w.read()[0]
+        err = np.abs(pos[bodies, :3] - np.array([[i * 20.0, 0.0, 0.0] for i in range(n)])).max()
+        max_err = max(max_err, float(err))
+    assert max_err < 1.0e-2
+
+
+# ---- contact_force_event_first_tick.rs -----------------------------------------------------------------------------------
+def test_force_event_started_marks_threshold_crossings_not_contact_newness():
+    sc = world()
+    g = sc.add_body(body_type=S.BODY_FIXED)
+    sc.add_collider(g, half_extents=(10.0, 0.5, 10.0), translation=(0.0, -0.5, 0.0))
+    ball = sc.add_body(translation=(0.0, 0.5, 0.0), additional_mass=1.0)
+    sc.add_collider(ball, shape=S.SHAPE_BALL, half_extents=(0.5, 0.0, 0.0), density=0.0,
+                    active_events=S.ACTIVE_EVENTS_COLLISION | S.ACTIVE_EVENTS_CONTACT_FORCE, contact_force_event_threshold=30.0)
+    w = OracleWorld(sc)
+    started_steps, force_events = [], []
+
+    def step_range(lo, hi, press):
+        for i in range(lo, hi):
+            if press:
+                w.add_force(ball, force=(0.0, -100.0, 0.0))
+            w.step(1)
+            w.add_force(ball, reset=True)
+            started_steps.extend(i for e in w.collision_events() if e[2])
+            meta, _ = w.force_events()
+            force_events.extend((i, bool(m[3])) for m in meta)
+
+    step_range(0, 100, False)                                   # A: settle; contact starts, no force events
+    assert len(started_steps) == 1 and not force_events
+    step_range(100, 160, True)                                  # B: press; the crossing comes long after Started
+    assert force_events and force_events[0][1]
+    assert force_events[0][0] >= 100 and force_events[0][0] > started_steps[0] + 50
+    assert not any(first for _, first in force_events[1:]) and len(force_events) > 10
+    step_range(160, 165, False)                                 # C: release; relaxation events are continuations
+    assert not any(first for _, first in force_events[1:])
+    after_press = len(force_events)
+    step_range(165, 220, False)
+    assert len(force_events) == after_press
+    step_range(220, 280, True)                                  # D: press again: a fresh episode
+    ep2 = force_events[after_press:]
+    assert ep2 and ep2[0][1] and not any(first for _, first in ep2[1:])
+    before = len(force_events)                                  # E: separate entirely, land hard
+    w.set_vel(ball, (0.0, 8.0, 0.0))
+    step_range(280, 500, False)
+    ep3 = force_events[before:]
+    assert ep3 and ep3[0][1]
