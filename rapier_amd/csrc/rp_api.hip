@@ -30,6 +30,7 @@
 
 void rp_launch_collider_update(const DevWorld &w, hipStream_t st);
 void rp_launch_broadphase(const DevWorld &w, hipStream_t st);
+void rp_launch_bp_rehash(const DevWorld &w, hipStream_t st);
 void rp_launch_narrowphase(const DevWorld &w, hipStream_t st);
 void rp_launch_narrowphase_part(const DevWorld &w, hipStream_t st, int part);
 void rp_launch_init_bodies(const DevWorld &w, hipStream_t st);
@@ -54,6 +55,12 @@ struct HostBody {
     bool has_next = false; float next[7] = {0, 0, 0, 0, 0, 0, 1}; // RigidBodyPosition::next_position of a kinematic body
 };
 
+// Device allocations of finalize(): which DevWorld member they back and how they are indexed, so that a world that outgrows its
+// capacities (or receives a joint) can move to larger arrays and keep every persistent row: `per` contiguous elements per item,
+// `planes` planes of `stride` items each, items indexed by body / collider / pair slot / device joint.
+enum { DOM_NONE = 0, DOM_BODY, DOM_COLL, DOM_PAIR, DOM_JOINT, DOM_FIXED /* fixed-size array, carried whole */ };
+struct AllocRec { void *ptr; size_t off, elem, per, stride; int planes, dom; };
+
 struct rp_world {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -70,9 +77,15 @@ struct rp_world {
     bool finalized = false;
     int cap_bodies = 0, cap_colliders = 0; // device array capacities (rows beyond n_bodies / n_colliders are spare)
     bool hints_valid = false;
-    std::vector<void *> allocs;
+    std::vector<AllocRec> allocs;
     DevWorld dw;
     int *pinned_flags = nullptr; // FL_COUNT ints, written by an async D2H copy at the end of each step
+    // growth with state carry-over (grow_begin -> finalize -> carry_over): the previous device world, kept until its rows were copied
+    bool carry = false;
+    std::vector<AllocRec> old_allocs;
+    DevWorld old_dw;
+    int *old_pinned = nullptr;
+    std::vector<int> old_active_joint_ids;
     // launch plan + graph
     int plan_stages = 0, plan_blocks = 1, plan_single = 1, plan_island_grid = 1, plan_joint_stages = 0, plan_no_global = 0, plan_fused = 0;
     bool has_restitution = false;
@@ -119,6 +132,8 @@ static bool world_has_compound_bodies(const rp_world *w);
 static std::vector<unsigned long long> no_contact_keys(const rp_world *w);
 static int check_sleep_scope(rp_world *w);
 static int rebuild_begin(rp_world *w);
+static int grow_begin(rp_world *w);
+static int carry_over(rp_world *w);
 static int queue_wake(rp_world *w, int b, int lvl);
 static int finalize(rp_world *w);
 template <typename T> static int poke(rp_world *w, T *dst, const T &v);
@@ -243,9 +258,12 @@ static void destroy_graphs(rp_world *w) {
 }
 static void free_device(rp_world *w) {
     destroy_graphs(w);
-    for (void *p : w->allocs) hipFree(p);
+    for (const AllocRec &a : w->allocs) hipFree(a.ptr);
     w->allocs.clear();
+    for (const AllocRec &a : w->old_allocs) hipFree(a.ptr);
+    w->old_allocs.clear(); w->carry = false;
     if (w->pinned_flags) { hipHostFree(w->pinned_flags); w->pinned_flags = nullptr; }
+    if (w->old_pinned) { hipHostFree(w->old_pinned); w->old_pinned = nullptr; }
     w->finalized = false;
 }
 
@@ -534,7 +552,7 @@ extern "C" int32_t rp_bodies_insert(rp_world *w, int32_t n, const rp_body_desc *
     const bool in_place = w->finalized && (int)w->bodies.size() + n <= w->cap_bodies;
     if (n > 0 && w->finalized) {
         HIPCHK(w, hipSetDevice(w->device));
-        int r = in_place ? settle(w) : rebuild_begin(w);
+        int r = in_place ? settle(w) : grow_begin(w);
         if (r != RP_OK) return r;
     }
     if ((long long)w->bodies.size() + n >= 0xfffff) { w->err = "rp_bodies_insert: more than 2^20 - 1 bodies"; return RP_ERR_CAPACITY; }
@@ -556,6 +574,7 @@ extern "C" int32_t rp_bodies_insert(rp_world *w, int32_t n, const rp_body_desc *
         destroy_graphs(w); // kernel arguments (DevWorld by value) hold the body count
         return after_topology_edit(w);
     }
+    if (w->carry) return finalize(w); // the larger device world takes over the rows of the one it replaces
     return RP_OK;
 }
 extern "C" int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider_desc *descs, const uint64_t *parents, uint64_t *handles_out) {
@@ -563,7 +582,7 @@ extern "C" int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider
     const bool in_place = w->finalized && (int)w->colliders.size() + n <= w->cap_colliders; // see rp_bodies_insert
     if (n > 0 && w->finalized) {
         HIPCHK(w, hipSetDevice(w->device));
-        int r = in_place ? settle(w) : rebuild_begin(w);
+        int r = in_place ? settle(w) : grow_begin(w);
         if (r != RP_OK) return r;
     }
     for (int i = 0; i < n; ++i) {
@@ -596,6 +615,7 @@ extern "C" int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider
         destroy_graphs(w);
         return after_topology_edit(w);
     }
+    if (w->carry) return finalize(w);
     return RP_OK;
 }
 extern "C" int32_t rp_impulse_joints_insert(rp_world *w, int32_t n, const rp_joint_desc *descs, uint64_t *handles_out) {
@@ -606,28 +626,34 @@ extern "C" int32_t rp_impulse_joints_insert(rp_world *w, int32_t n, const rp_joi
         if ((j.locked_axes & ~0x3fu) != 0 || (j.limit_axes & ~0x3fu) != 0 || (j.motor_axes & ~0x3fu) != 0) { w->err = "rp_impulse_joints_insert: locked_axes / limit_axes / motor_axes must be JointAxesMasks (coupled axes are not implemented on the device path)"; return RP_ERR_INVALID; }
         for (int a = 0; a < 6; ++a) if (j.motors[a].model != RP_MOTOR_ACCELERATION_BASED && j.motors[a].model != RP_MOTOR_FORCE_BASED) { w->err = "rp_impulse_joints_insert: unknown motor model"; return RP_ERR_INVALID; }
     }
-    if (n > 0) { int r = rebuild_begin(w); if (r != RP_OK) return r; }
+    if (n > 0) { int r = grow_begin(w); if (r != RP_OK) return r; } // the joint arrays have no spare rows: the world moves to larger ones
     for (int i = 0; i < n; ++i) {
         w->joints.push_back(descs[i]);
         w->pending_wake.push_back(descs[i].body1); w->pending_wake.push_back(descs[i].body2);
         w->joint_removed.push_back(0);
         if (handles_out) handles_out[i] = (uint64_t)(w->joints.size() - 1);
     }
+    if (w->carry) return finalize(w);
     return RP_OK;
 }
 
 template <typename T>
-static int dalloc(rp_world *w, T *&p, size_t count, int fill_byte = 0) {
+static int dalloc(rp_world *w, T *&p, size_t count, int fill_byte = 0, int dom = DOM_NONE, int planes = 1, int per = 1) {
     void *q = nullptr;
     size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
     if (hipMalloc(&q, bytes) != hipSuccess) { w->err = "hipMalloc failed"; return RP_ERR_DEVICE; }
     if (hipMemsetAsync(q, fill_byte, bytes, w->stream) != hipSuccess) { w->err = "hipMemset failed"; return RP_ERR_DEVICE; }
-    w->allocs.push_back(q);
+    AllocRec a; a.ptr = q; a.off = (size_t)((char *)&p - (char *)&w->dw); a.elem = sizeof(T); a.per = (size_t)per; a.planes = planes; a.dom = dom;
+    a.stride = count / ((size_t)planes * (size_t)per);
+    w->allocs.push_back(a);
     p = (T *)q;
     return RP_OK;
 }
+// DA / DAF: scratch or host-authoritative arrays; DAC / DAFC: persistent rows carried over when the world grows (domain, planes[, per])
 #define DA(ptr, count) do { int r_ = dalloc(w, ptr, (size_t)(count)); if (r_ != RP_OK) return r_; } while (0)
 #define DAF(ptr, count, fill) do { int r_ = dalloc(w, ptr, (size_t)(count), fill); if (r_ != RP_OK) return r_; } while (0)
+#define DAC(ptr, count, ...) do { int r_ = dalloc(w, ptr, (size_t)(count), 0, __VA_ARGS__); if (r_ != RP_OK) return r_; } while (0)
+#define DAFC(ptr, count, fill, ...) do { int r_ = dalloc(w, ptr, (size_t)(count), fill, __VA_ARGS__); if (r_ != RP_OK) return r_; } while (0)
 
 template <typename T>
 static int upload(rp_world *w, T *dst, const std::vector<T> &src) {
@@ -743,6 +769,59 @@ static bool world_has_kinematic_pos(const rp_world *w) {
 }
 static int check_sleep_scope(rp_world *w) { (void)w; return RP_OK; } // impulse joints, sleeping and kinematic bodies mix freely
 
+// Growth with state carry-over.  A live world that outgrows its row capacities — or receives a joint, whose arrays have no spare
+// rows — moves to larger device arrays: grow_begin() parks the current device world, finalize() builds the larger one from the host
+// mirrors (new rows included), and carry_over() copies every persistent row of the old world into it (bodies, colliders, pair
+// slots with their manifolds / warm-start impulses / colours / recycle state, joints by device index, the step flags), rebuilds
+// the pair hash for the new table size and marks the pair set / solver layout / joint layout dirty — exactly the state an
+// in-place insertion leaves behind, so the next step matches the oracle bit for bit.  Host-authoritative arrays (mass
+// properties, body -> collider / joint counts, joint limits and motors) come from the fresh upload.
+static int grow_begin(rp_world *w) {
+    if (!w->finalized) return RP_OK;
+    HIPCHK(w, hipSetDevice(w->device));
+    int r = download_state(w); // settles; the host mirrors of the body states are refreshed too
+    if (r != RP_OK) return r;
+    destroy_graphs(w);
+    w->old_allocs.swap(w->allocs); w->allocs.clear();
+    w->old_dw = w->dw;
+    w->old_pinned = w->pinned_flags; w->pinned_flags = nullptr;
+    w->old_active_joint_ids = w->active_joint_ids;
+    w->carry = true;
+    w->finalized = false;
+    return RP_OK;
+}
+static int carry_over(rp_world *w) {
+    const DevWorld &o = w->old_dw, &d = w->dw;
+    for (const AllocRec &a : w->allocs) {
+        if (a.dom == DOM_NONE) continue;
+        const AllocRec *b = nullptr;
+        for (const AllocRec &q : w->old_allocs) if (q.off == a.off) { b = &q; break; }
+        if (!b || b->planes != a.planes || b->per != a.per || b->elem != a.elem) { w->err = "carry_over: allocation layout changed"; return RP_ERR_DEVICE; }
+        size_t n = a.dom == DOM_BODY ? (size_t)o.n_bodies : a.dom == DOM_COLL ? (size_t)o.n_colliders : a.dom == DOM_PAIR ? (size_t)o.pool_cap : a.dom == DOM_JOINT ? (size_t)o.n_joints : a.stride;
+        n = std::min(n, std::min(a.stride, b->stride));
+        if (n == 0) continue;
+        for (int p = 0; p < a.planes; ++p)
+            HIPCHK(w, hipMemcpyAsync((char *)a.ptr + (size_t)p * a.stride * a.per * a.elem, (const char *)b->ptr + (size_t)p * b->stride * b->per * b->elem,
+                                     n * a.per * a.elem, hipMemcpyDeviceToDevice, w->stream));
+    }
+    // b_sprev_t: xyz = the sleep reference translation (device state), w = max_extent of the attached shapes (host-authoritative)
+    if (o.n_bodies > 0) HIPCHK(w, hipMemcpy2DAsync(d.b_sprev_t, sizeof(float4), o.b_sprev_t, sizeof(float4), 3 * sizeof(float), (size_t)o.n_bodies, hipMemcpyDeviceToDevice, w->stream));
+    HIPCHK(w, hipMemcpyAsync(d.flags, o.flags, FL_COUNT * sizeof(int), hipMemcpyDeviceToDevice, w->stream));
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    memcpy(w->pinned_flags, w->old_pinned, FL_COUNT * sizeof(int));
+    rp_launch_bp_rehash(d, w->stream); // the live pairs enter the (larger) current-epoch table
+    int one = 1;
+    for (int f : {FL_BP_DIRTY, FL_LAYOUT_DIRTY, FL_JOINT_DIRTY}) HIPCHK(w, hipMemcpyAsync(d.flags + f, &one, sizeof(int), hipMemcpyHostToDevice, w->stream));
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    w->pinned_flags[FL_LAYOUT_DIRTY] = 1; // next steps stay on the full graph until the device reports a clean state
+    w->full_until = w->steps_requested + 3;
+    for (const AllocRec &a : w->old_allocs) hipFree(a.ptr);
+    w->old_allocs.clear();
+    hipHostFree(w->old_pinned); w->old_pinned = nullptr;
+    w->carry = false;
+    return RP_OK;
+}
+
 // Upload the host mirrors into the SoA device world (the "upload = resume" path of SURVEY §5).
 static int finalize(rp_world *w) {
     HIPCHK(w, hipSetDevice(w->device));
@@ -781,38 +860,38 @@ static int finalize(rp_world *w) {
     fill_sim_params(w, d.prm, cell);
 
     DA(d.flags, FL_COUNT); DA(d.dbg, 64);
-    DA(d.b_pos, capb); DA(d.b_rot, capb); DA(d.b_linvel, capb); DA(d.b_angvel, capb); DA(d.b_lcom_invm, capb); DA(d.b_invpi, capb);
-    DA(d.b_pframe, capb); DA(d.b_wcom, capb); DA(d.b_eim, capb); DA(d.b_eii0, capb); DA(d.b_eii1, capb); DA(d.b_damp, capb);
-    DA(d.b_uforce, capb); DA(d.b_utorque, capb); DA(d.b_flags, capb); DA(d.b_quar, capb); DAF(d.b_collider, capb, 0xff);
-    DA(d.b_sleep, capb); DA(d.b_sprev_t, capb); DA(d.b_sprev_r, capb); DA(d.b_slabel, capb); DA(d.b_slept_at, capb); DA(d.b_wake_req, capb);
-    DA(d.lab_wake, capb); DA(d.lab_awake, capb); DA(d.b_next_pos, capb); DA(d.b_next_rot, capb);
-    DA(d.s_lin, capb); DA(d.s_ang, capb); DA(d.s_rot, capb); DA(d.s_trans, capb); DA(d.s_incl, capb); DA(d.s_inca, capb);
-    DA(d.b_cmask, 4 * (size_t)capb); DAF(d.b_min, capb, 0xff);
-    DA(d.c_parent, capc); DA(d.c_ord, capc); DA(d.c_shape, capc); DA(d.c_lpos, capc); DA(d.c_lrot, capc); DA(d.c_pos, capc); DA(d.c_rot, capc); DA(d.c_he, capc);
-    DA(d.c_mat, capc); DA(d.c_rules, capc); DA(d.c_groups, capc); DA(d.c_fatmin, capc); DA(d.c_fatmax, capc); DA(d.c_events, capc);
+    DAC(d.b_pos, capb, DOM_BODY, 1, 1); DAC(d.b_rot, capb, DOM_BODY, 1, 1); DAC(d.b_linvel, capb, DOM_BODY, 1, 1); DAC(d.b_angvel, capb, DOM_BODY, 1, 1); DA(d.b_lcom_invm, capb); DA(d.b_invpi, capb);
+    DA(d.b_pframe, capb); DAC(d.b_wcom, capb, DOM_BODY, 1, 1); DAC(d.b_eim, capb, DOM_BODY, 1, 1); DAC(d.b_eii0, capb, DOM_BODY, 1, 1); DAC(d.b_eii1, capb, DOM_BODY, 1, 1); DAC(d.b_damp, capb, DOM_BODY, 1, 1);
+    DAC(d.b_uforce, capb, DOM_BODY, 1, 1); DAC(d.b_utorque, capb, DOM_BODY, 1, 1); DAC(d.b_flags, capb, DOM_BODY, 1, 1); DAC(d.b_quar, capb, DOM_BODY, 1, 1); DAF(d.b_collider, capb, 0xff);
+    DAC(d.b_sleep, capb, DOM_BODY, 1, 1); DA(d.b_sprev_t, capb); DAC(d.b_sprev_r, capb, DOM_BODY, 1, 1); DAC(d.b_slabel, capb, DOM_BODY, 1, 1); DAC(d.b_slept_at, capb, DOM_BODY, 1, 1); DAC(d.b_wake_req, capb, DOM_BODY, 1, 1);
+    DAC(d.lab_wake, capb, DOM_BODY, 1, 1); DAC(d.lab_awake, capb, DOM_BODY, 1, 1); DAC(d.b_next_pos, capb, DOM_BODY, 1, 1); DAC(d.b_next_rot, capb, DOM_BODY, 1, 1);
+    DAC(d.s_lin, capb, DOM_BODY, 1, 1); DAC(d.s_ang, capb, DOM_BODY, 1, 1); DAC(d.s_rot, capb, DOM_BODY, 1, 1); DAC(d.s_trans, capb, DOM_BODY, 1, 1); DAC(d.s_incl, capb, DOM_BODY, 1, 1); DAC(d.s_inca, capb, DOM_BODY, 1, 1);
+    DAC(d.b_cmask, 4 * (size_t)capb, DOM_BODY, 1, 4); DAFC(d.b_min, capb, 0xff, DOM_BODY, 1, 1);
+    DAC(d.c_parent, capc, DOM_COLL, 1, 1); DAC(d.c_ord, capc, DOM_COLL, 1, 1); DAC(d.c_shape, capc, DOM_COLL, 1, 1); DAC(d.c_lpos, capc, DOM_COLL, 1, 1); DAC(d.c_lrot, capc, DOM_COLL, 1, 1); DAC(d.c_pos, capc, DOM_COLL, 1, 1); DAC(d.c_rot, capc, DOM_COLL, 1, 1); DAC(d.c_he, capc, DOM_COLL, 1, 1);
+    DAC(d.c_mat, capc, DOM_COLL, 1, 1); DAC(d.c_rules, capc, DOM_COLL, 1, 1); DAC(d.c_groups, capc, DOM_COLL, 1, 1); DAC(d.c_fatmin, capc, DOM_COLL, 1, 1); DAC(d.c_fatmax, capc, DOM_COLL, 1, 1); DAC(d.c_events, capc, DOM_COLL, 1, 1);
     d.ev_cap = 65536;
-    DA(d.ev_col, d.ev_cap); DA(d.ev_force_meta, d.ev_cap); DA(d.ev_force_a, d.ev_cap); DA(d.ev_force_b, d.ev_cap);
+    DAC(d.ev_col, d.ev_cap, DOM_FIXED, 1, 1); DAC(d.ev_force_meta, d.ev_cap, DOM_FIXED, 1, 1); DAC(d.ev_force_a, d.ev_cap, DOM_FIXED, 1, 1); DAC(d.ev_force_b, d.ev_cap, DOM_FIXED, 1, 1);
     DA(d.cell_count, d.grid_cap); DA(d.cell_start, d.grid_cap + 1); DA(d.cell_fill, d.grid_cap); DA(d.scan_block, 1024);
     DA(d.e_key, d.entries_cap); DA(d.e_col, d.entries_cap); DA(d.large_list, d.large_cap);
     DAF(d.h_key[0], d.hash_cap, 0xff); DAF(d.h_key[1], d.hash_cap, 0xff); DA(d.h_slot[0], d.hash_cap); DA(d.h_slot[1], d.hash_cap);
-    DA(d.free_stack, d.pool_cap);
+    DAC(d.free_stack, d.pool_cap, DOM_PAIR, 1, 1);
     size_t P = (size_t)d.pool_cap;
-    DAF(d.p_c1, P, 0xff); DA(d.p_c2, P); DA(d.p_stamp, P); DA(d.p_color, P); DA(d.p_nsc, P); DA(d.p_npts, P); DA(d.p_pflags, P); DA(d.p_reldom, P);
-    DA(d.p_hint_seq, P); DA(d.p_colorb, P); DA(d.p_rb, P); DA(d.p_ln1, P); DA(d.p_ln2, P); DA(d.p_normal, P); DA(d.p_misc, P);
-    DA(d.r_t, P); DA(d.r_r, P); DA(d.r_rot1, P); DA(d.r_rot2, P);
-    DA(d.pt_lp1d, RP_MAX_PTS * P); DA(d.pt_lp2f, RP_MAX_PTS * P); DA(d.pt_imp, RP_MAX_PTS * P); DA(d.pt_wst, RP_MAX_PTS * P);
-    DA(d.pt_dp1, RP_MAX_PTS * P); DA(d.pt_dp2, RP_MAX_PTS * P);
-    DA(d.sc_a1, 4 * P); DA(d.sc_a2, 4 * P);
-    DA(d.todo_slot, P); DA(d.todo_key, P); DA(d.todo_tmp, P); DA(d.np_list, P);
+    DAFC(d.p_c1, P, 0xff, DOM_PAIR, 1, 1); DAC(d.p_c2, P, DOM_PAIR, 1, 1); DAC(d.p_stamp, P, DOM_PAIR, 1, 1); DAC(d.p_color, P, DOM_PAIR, 1, 1); DAC(d.p_nsc, P, DOM_PAIR, 1, 1); DAC(d.p_npts, P, DOM_PAIR, 1, 1); DAC(d.p_pflags, P, DOM_PAIR, 1, 1); DAC(d.p_reldom, P, DOM_PAIR, 1, 1);
+    DAC(d.p_hint_seq, P, DOM_PAIR, 1, 1); DAC(d.p_colorb, P, DOM_PAIR, 1, 1); DAC(d.p_rb, P, DOM_PAIR, 1, 1); DAC(d.p_ln1, P, DOM_PAIR, 1, 1); DAC(d.p_ln2, P, DOM_PAIR, 1, 1); DAC(d.p_normal, P, DOM_PAIR, 1, 1); DAC(d.p_misc, P, DOM_PAIR, 1, 1);
+    DAC(d.r_t, P, DOM_PAIR, 1, 1); DAC(d.r_r, P, DOM_PAIR, 1, 1); DAC(d.r_rot1, P, DOM_PAIR, 1, 1); DAC(d.r_rot2, P, DOM_PAIR, 1, 1);
+    DAC(d.pt_lp1d, RP_MAX_PTS * P, DOM_PAIR, RP_MAX_PTS, 1); DAC(d.pt_lp2f, RP_MAX_PTS * P, DOM_PAIR, RP_MAX_PTS, 1); DAC(d.pt_imp, RP_MAX_PTS * P, DOM_PAIR, RP_MAX_PTS, 1); DAC(d.pt_wst, RP_MAX_PTS * P, DOM_PAIR, RP_MAX_PTS, 1);
+    DAC(d.pt_dp1, RP_MAX_PTS * P, DOM_PAIR, RP_MAX_PTS, 1); DAC(d.pt_dp2, RP_MAX_PTS * P, DOM_PAIR, RP_MAX_PTS, 1);
+    DAC(d.sc_a1, 4 * P, DOM_PAIR, 4, 1); DAC(d.sc_a2, 4 * P, DOM_PAIR, 4, 1);
+    DAC(d.todo_slot, P, DOM_PAIR, 1, 1); DAC(d.todo_key, P, DOM_PAIR, 1, 1); DAC(d.todo_tmp, P, DOM_PAIR, 1, 1); DAC(d.np_list, P, DOM_PAIR, 1, 1);
     DA(d.color_count, RP_NUM_COLORS + 1); DA(d.color_begin, RP_NUM_COLORS + 1); DA(d.color_cursor, RP_NUM_COLORS + 1);
     DA(d.stage_color, RP_NUM_COLORS + 1); DA(d.stage_begin, RP_NUM_COLORS + 1); DA(d.stage_count, RP_NUM_COLORS + 1);
-    DA(d.cons_pair, d.cons_cap); DAF(d.p_conspos, P, 0xff);
+    DA(d.cons_pair, d.cons_cap); DAFC(d.p_conspos, P, 0xff, DOM_PAIR, 1, 1);
     DA(d.color_count_glob, RP_NUM_COLORS + 1); DA(d.color_rank, RP_NUM_COLORS + 1);
-    DA(d.b_label, capb); DAF(d.b_island, capb, 0xff); DAF(d.b_local, capb, 0xff); DA(d.r_nb, capb); DA(d.r_nc, capb); DAF(d.r_island, capb, 0xff);
-    DAF(d.p_island, P, 0xff);
-    DA(d.isl_body_begin, capb); DA(d.isl_nb, capb); DA(d.isl_cons_begin, capb); DA(d.isl_nc, capb); DA(d.isl_fill_b, capb); DA(d.isl_fill_c, capb);
-    DA(d.isl_bodies, capb); DA(d.isl_cons, P); DA(d.isl_cstage, P); DA(d.isl_sorted, capb); DA(d.isl_nstages, capb);
-    DA(d.isl_cg1, P); DA(d.isl_cg2, P); DA(d.isl_cl1, P); DA(d.isl_cl2, P); DA(d.isl_inc_pos, 2 * P); DA(d.r_ni, capb); DA(d.isl_ni, capb); DA(d.isl_icons_begin, capb); DA(d.isl_fill_i, capb); DA(d.isl_icons, P); DA(d.isl_inc_begin, capb); DA(d.isl_inc_cnt, capb);
+    DAC(d.b_label, capb, DOM_BODY, 1, 1); DAFC(d.b_island, capb, 0xff, DOM_BODY, 1, 1); DAFC(d.b_local, capb, 0xff, DOM_BODY, 1, 1); DAC(d.r_nb, capb, DOM_BODY, 1, 1); DAC(d.r_nc, capb, DOM_BODY, 1, 1); DAFC(d.r_island, capb, 0xff, DOM_BODY, 1, 1);
+    DAFC(d.p_island, P, 0xff, DOM_PAIR, 1, 1);
+    DAC(d.isl_body_begin, capb, DOM_BODY, 1, 1); DAC(d.isl_nb, capb, DOM_BODY, 1, 1); DAC(d.isl_cons_begin, capb, DOM_BODY, 1, 1); DAC(d.isl_nc, capb, DOM_BODY, 1, 1); DAC(d.isl_fill_b, capb, DOM_BODY, 1, 1); DAC(d.isl_fill_c, capb, DOM_BODY, 1, 1);
+    DAC(d.isl_bodies, capb, DOM_BODY, 1, 1); DAC(d.isl_cons, P, DOM_PAIR, 1, 1); DAC(d.isl_cstage, P, DOM_PAIR, 1, 1); DAC(d.isl_sorted, capb, DOM_BODY, 1, 1); DAC(d.isl_nstages, capb, DOM_BODY, 1, 1);
+    DAC(d.isl_cg1, P, DOM_PAIR, 1, 1); DAC(d.isl_cg2, P, DOM_PAIR, 1, 1); DAC(d.isl_cl1, P, DOM_PAIR, 1, 1); DAC(d.isl_cl2, P, DOM_PAIR, 1, 1); DA(d.isl_inc_pos, 2 * P); DAC(d.r_ni, capb, DOM_BODY, 1, 1); DAC(d.isl_ni, capb, DOM_BODY, 1, 1); DAC(d.isl_icons_begin, capb, DOM_BODY, 1, 1); DAC(d.isl_fill_i, capb, DOM_BODY, 1, 1); DAC(d.isl_icons, P, DOM_PAIR, 1, 1); DAC(d.isl_inc_begin, capb, DOM_BODY, 1, 1); DAC(d.isl_inc_cnt, capb, DOM_BODY, 1, 1);
     // impulse joints: only joints with a dynamic side are active (select_active_interactions,
     // impulse_joint_set.rs:504-572), kept in edge order; frames go to solver-body space once
     // (GenericJoint::transform_to_solver_body_space, generic_joint.rs:624-636)
@@ -821,11 +900,20 @@ static int finalize(rp_world *w) {
     std::vector<float4> jf1t, jf1r, jf2t, jf2r;
     w->active_joint_ids.clear();
     for (size_t ji = 0; ji < w->joints.size(); ++ji) {
-        if (w->joint_removed[ji]) continue;
+        // a world that is growing keeps the device index of every joint it already held: removed ones stay as tombstones
+        const bool held = w->carry && std::binary_search(w->old_active_joint_ids.begin(), w->old_active_joint_ids.end(), (int)ji);
         const rp_joint_desc &j = w->joints[ji];
         const HostBody &rb1 = w->bodies[j.body1], &rb2 = w->bodies[j.body2];
         bool d1 = rb1.d.body_type != RP_BODY_FIXED && !rb1.removed, d2 = rb2.d.body_type != RP_BODY_FIXED && !rb2.removed; // is_dynamic_or_kinematic
-        if (!d1 && !d2) continue;
+        if (w->joint_removed[ji] || (!d1 && !d2)) {
+            if (!held) continue;
+            jb1.push_back(-1); jb2.push_back(-1); jf1t.push_back(mk4(0, 0, 0, 0)); jf1r.push_back(mk4(0, 0, 0, 1)); jf2t.push_back(mk4(0, 0, 0, 0)); jf2r.push_back(mk4(0, 0, 0, 1));
+            jlocked.push_back(0); jlimited.push_back(0); jmotor.push_back(0); jcolor.push_back(RP_COLOR_UNCOLORED);
+            for (int a = 0; a < 12; ++a) jmot[a].push_back(mk4(0, 0, 0, 0));
+            for (int a = 0; a < 6; ++a) jlim[a].push_back(mk4(0, 0, 0, 0));
+            w->active_joint_ids.push_back((int)ji);
+            continue;
+        }
         Pose f1 = joint_local_frame(j.local_anchor1, j.local_basis1), f2 = joint_local_frame(j.local_anchor2, j.local_basis2);
         if (!d1) f1 = pose_mul(host_body_pose(rb1), f1); else f1.t = f1.t - v3(rb1.lcom[0], rb1.lcom[1], rb1.lcom[2]);
         if (!d2) f2 = pose_mul(host_body_pose(rb2), f2); else f2.t = f2.t - v3(rb2.lcom[0], rb2.lcom[1], rb2.lcom[2]);
@@ -854,12 +942,12 @@ static int finalize(rp_world *w) {
         UP(d.nc_keys, nck);
         HIPCHK(w, hipStreamSynchronize(w->stream));
     }
-    DA(d.j_b1, nj); DA(d.j_b2, nj); DA(d.j_f1t, nj); DA(d.j_f1r, nj); DA(d.j_f2t, nj); DA(d.j_f2r, nj);
-    DA(d.j_locked, nj); DA(d.j_limited, nj); DA(d.j_color, nj); DA(d.j_tmp, nj); DA(d.j_order, nj); DA(d.j_imp, nj); DA(d.j_imp_ang, nj);
-    DA(d.j_lim, (size_t)6 * std::max(nj, 1)); DA(d.j_imp_lim, nj); DA(d.j_imp_lim_ang, nj);
-    DA(d.j_motor, nj); DA(d.j_mot, (size_t)12 * std::max(nj, 1)); DA(d.j_imp_mot, nj); DA(d.j_imp_mot_ang, nj);
+    DAC(d.j_b1, nj, DOM_JOINT, 1, 1); DAC(d.j_b2, nj, DOM_JOINT, 1, 1); DAC(d.j_f1t, nj, DOM_JOINT, 1, 1); DAC(d.j_f1r, nj, DOM_JOINT, 1, 1); DAC(d.j_f2t, nj, DOM_JOINT, 1, 1); DAC(d.j_f2r, nj, DOM_JOINT, 1, 1);
+    DAC(d.j_locked, nj, DOM_JOINT, 1, 1); DAC(d.j_limited, nj, DOM_JOINT, 1, 1); DAC(d.j_color, nj, DOM_JOINT, 1, 1); DAC(d.j_tmp, nj, DOM_JOINT, 1, 1); DAC(d.j_order, nj, DOM_JOINT, 1, 1); DAC(d.j_imp, nj, DOM_JOINT, 1, 1); DAC(d.j_imp_ang, nj, DOM_JOINT, 1, 1);
+    DA(d.j_lim, (size_t)6 * std::max(nj, 1)); DAC(d.j_imp_lim, nj, DOM_JOINT, 1, 1); DAC(d.j_imp_lim_ang, nj, DOM_JOINT, 1, 1);
+    DAC(d.j_motor, nj, DOM_JOINT, 1, 1); DA(d.j_mot, (size_t)12 * std::max(nj, 1)); DAC(d.j_imp_mot, nj, DOM_JOINT, 1, 1); DAC(d.j_imp_mot_ang, nj, DOM_JOINT, 1, 1);
     DA(d.j_stage_begin, RP_NUM_COLORS + 1); DA(d.j_stage_count, RP_NUM_COLORS + 1);
-    DA(d.bj_cmask, 4 * (size_t)capb); DAF(d.bj_min, capb, 0xff); DA(d.b_njoints, capb);
+    DAC(d.bj_cmask, 4 * (size_t)capb, DOM_BODY, 1, 4); DAFC(d.bj_min, capb, 0xff, DOM_BODY, 1, 1); DA(d.b_njoints, capb);
     DA(d.JR, (size_t)RP_JR_COUNT * std::max(nj, 1)); // im1, im2 + 12 rows x 6 planes (rp_joints.h); planes of unused rows are never touched
     UP(d.j_b1, jb1); UP(d.j_b2, jb2); UP(d.j_f1t, jf1t); UP(d.j_f1r, jf1r); UP(d.j_f2t, jf2t); UP(d.j_f2r, jf2r);
     UP(d.j_locked, jlocked); UP(d.j_limited, jlimited); UP(d.j_motor, jmotor); UP(d.j_color, jcolor); UP(d.b_njoints, bnj);
@@ -905,7 +993,8 @@ static int finalize(rp_world *w) {
     HIPCHK(w, hipHostMalloc((void **)&w->pinned_flags, FL_COUNT * sizeof(int), hipHostMallocMapped));
     memset(w->pinned_flags, 0, FL_COUNT * sizeof(int));
     HIPCHK(w, hipHostGetDevicePointer((void **)&d.host_flags, w->pinned_flags, 0));
-    w->steps_requested = 0; w->seq_enqueued = 0; w->full_until = 0;
+    if (w->carry) { int r = carry_over(w); if (r != RP_OK) return r; } // the rows of the previous device world move in; step counters keep running
+    else { w->steps_requested = 0; w->seq_enqueued = 0; w->full_until = 0; }
     rp_launch_init_bodies(d, w->stream);
     rp_launch_collider_update(d, w->stream);
     HIPCHK(w, hipStreamSynchronize(w->stream));

@@ -323,6 +323,31 @@ void rp_launch_fast_front(const DevWorld &w, hipStream_t st, int no_global_kerne
     hipLaunchKernelGGL(k_fast_front, dim3(blocks), dim3(256), 0, st, w, no_global_kernel);
 }
 
+// A world that moved to larger arrays (rp_api.hip: carry_over): its live pairs enter the current-epoch hash table, whose size changed.
+__global__ void k_bp_rehash(DevWorld w) {
+    int cur = w.flags[FL_BP_EPOCH] & 1;
+    int top = w.flags[FL_POOL_TOP];
+    if (top > w.pool_cap) top = w.pool_cap;
+    int stride = gridDim.x * blockDim.x;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < top; s += stride) {
+        int c1 = w.p_c1[s];
+        if (c1 < 0) continue;
+        unsigned long long key = ((unsigned long long)(unsigned)c1 << 32) | (unsigned)w.p_c2[s];
+        int h = (int)(rp_hash64(key) & (unsigned long long)(w.hash_cap - 1));
+        bool placed = false;
+        for (int probe = 0; probe < w.hash_cap && !placed; ++probe) {
+            unsigned long long prev = atomicCAS(&w.h_key[cur][h], RP_EMPTY_KEY, key);
+            if (prev == RP_EMPTY_KEY) { w.h_slot[cur][h] = s; placed = true; }
+            h = (h + 1) & (w.hash_cap - 1);
+        }
+        if (!placed) atomicOr(&w.flags[FL_OVERFLOW], RP_OVF_HASH);
+    }
+}
+void rp_launch_bp_rehash(const DevWorld &w, hipStream_t st) {
+    int blocks = (w.pool_cap + 255) / 256; if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_bp_rehash, dim3(blocks), dim3(256), 0, st, w);
+}
+
 void rp_launch_broadphase(const DevWorld &w, hipStream_t st) {
     if (w.n_colliders == 0) return;
     int nb = (w.n_colliders + 255) / 256;

@@ -607,6 +607,76 @@ def test_reference_sleep_wake_scenes_bit_exact():
     _compare(sc, [1, 10, 100, 1000])
 
 
+def test_insert_joint_into_live_world_bit_exact():
+    """ImpulseJointSet::insert into a stepped world (the joint arrays have no spare rows: the device world moves to larger ones
+    and carries every row over): contacts keep their warm-start data and colours, the existing joints their colours and
+    impulses, so the result matches the oracle bit for bit; also after a removal (tombstoned device index) and with
+    warm-started joints."""
+    for ws in (0, 1):
+        sc = S.joint_chain(6, with_boxes=True)
+        sc.params["warmstart_joints"] = ws
+        g, o = _compare(sc, [1, 30, 150])
+        n = len(sc.bodies)
+        a, b = n - 1, n - 2
+        jd = np.zeros((), S.JOINT_DTYPE)
+        jd["body1"], jd["body2"] = a, b
+        jd["local_anchor1"], jd["local_anchor2"] = (0.0, 0.6, 0.0), (0.0, -0.6, 0.0)
+        jd["local_basis1"] = jd["local_basis2"] = (0, 0, 0, 1)
+        jd["locked_axes"], jd["contacts_enabled"] = S.LOCK_LIN, 1
+        for k in range(6):
+            jd["motors"][k] = S.motor_desc()
+        from oracle_ffi import lib
+        hj = g.insert_impulse_joint(a, b, jd)
+        oj = lib().ro_add_joint(o._w, np.array([jd], S.JOINT_DTYPE).ctypes.data)
+        assert hj == oj
+        for k in (1, 9, 90):
+            g.step(k); o.step(k)
+            _same_state(g, o, f"joint inserted (warmstart_joints={ws}), +{k}")
+        _compare_joints(g, o)
+        g.remove_impulse_joint(1); o.remove_joint(1)
+        g.step(20); o.step(20)
+        jd["body1"], jd["body2"] = 2, 4
+        hj = g.insert_impulse_joint(2, 4, jd); oj = lib().ro_add_joint(o._w, np.array([jd], S.JOINT_DTYPE).ctypes.data)
+        assert hj == oj
+        for k in (1, 9, 120):
+            g.step(k); o.step(k)
+            _same_state(g, o, f"joint removed, another inserted (warmstart_joints={ws}), +{k}")
+        _compare_joints(g, o)
+
+
+def test_body_churn_bit_exact():
+    """The fountain churn of solver_graph_stale_refs.rs:24-79 (cuboids / balls): one body inserted every step, the outermost
+    ones removed beyond 60 live bodies — collider removal, pair deletion, in-place appends and capacity rebuilds, sleep / wake
+    transitions — bit-exact against the oracle all along."""
+    sc = S.Scene(name="churn", gravity=(0.0, -9.81, 0.0))
+    gb = sc.add_body(body_type=S.BODY_FIXED, translation=(0.0, -2.1, 0.0))
+    sc.add_collider(gb, half_extents=(40.0, 2.1, 40.0))
+    g, o = PhysicsWorld.from_scene(sc), OracleWorld(sc)
+    alive = []
+    for step_id in range(1, 260):
+        g.step(1); o.step(1)
+        body = S.body_desc(translation=(0.0, 10.0, 0.0), can_sleep=1)
+        col = S.collider_desc(shape=S.SHAPE_BALL, half_extents=(0.5, 0.0, 0.0)) if step_id % 3 == 0 else \
+            S.collider_desc(half_extents=(0.5, 0.5, 0.5) if step_id % 3 == 2 else (0.5, 0.25, 0.5))
+        hb = g.insert_body(body); g.insert_collider(col, hb)
+        ob = o.add_body(translation=(0.0, 10.0, 0.0), can_sleep=1)
+        from oracle_ffi import lib
+        lib().ro_add_collider(o._w, np.array([col], S.COLLIDER_DTYPE).ctypes.data, ob)
+        assert int(hb) & 0xFFFFFFFF == ob
+        alive.append(ob)
+        if len(alive) > 60:
+            pos = o.read()[0]
+            order = sorted(alive, key=lambda h: -(abs(pos[h, 0]) + abs(pos[h, 2])))
+            for h in order[:len(alive) - 60]:
+                g.remove_body(h); o.remove_body(h); alive.remove(h)
+        if step_id % 20 == 0 or step_id > 250:
+            gp, gv = g.read_bodies(); op, ov = o.read()
+            np.testing.assert_array_equal(gp[alive], op[alive], err_msg=f"churn poses @ {step_id}")
+            np.testing.assert_array_equal(gv[alive], ov[alive], err_msg=f"churn velocities @ {step_id}")
+            np.testing.assert_array_equal(g.sleeping()[alive], o.sleeping()[alive])
+    assert g.counters()["overflow_flags"] == 0 and g.counters()["quarantined"] == 0
+
+
 def test_contact_disabling_joints_bit_exact():
     """GenericJoint::contacts_enabled = false: the pairs between the two jointed bodies are cleared (pair_update.rs:191-201)."""
     g, o = _compare(S.overlapping_chain(6, 0), [1, 2, 10, 60, 200])

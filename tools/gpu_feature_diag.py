@@ -63,7 +63,50 @@ def kin_targets(g, o, k):
     g.set_next_kinematic_position([1], p); o.set_next_kinematic_position(1, p)
 
 
+def churn(steps=300, cap=60, env_sleep=1):
+    """fountain churn (tests/test_gpu_parity.py::test_body_churn_bit_exact) with a per-step comparison"""
+    from oracle_ffi import lib
+    sc = S.Scene(name="churn", gravity=(0.0, -9.81, 0.0))
+    gb = sc.add_body(body_type=S.BODY_FIXED, translation=(0.0, -2.1, 0.0))
+    sc.add_collider(gb, half_extents=(40.0, 2.1, 40.0))
+    g, o = PhysicsWorld.from_scene(sc), OracleWorld(sc)
+    alive = []
+    for k in range(1, steps):
+        g.step(1); o.step(1)
+        gp, gv = g.read_bodies(); op, ov = o.read()
+        bad = [b for b in alive if (gp[b] != op[b]).any() or (gv[b] != ov[b]).any()]
+        if bad:
+            print(f"[churn] FIRST DIVERGENCE at step {k}: bodies {bad[:12]} (of {len(bad)}), alive {len(alive)}")
+            for b in bad[:4]:
+                print(f"   body {b}:\n     gpu pos {gp[b]} vel {gv[b]}\n     ora pos {op[b]} vel {ov[b]}")
+            print(f"   gpu counters {g.counters()}\n   oracle stats {o.stats()}")
+            gm, gn, gi = g.contacts(); om, on, oi = o.manifolds()
+            gk = {(a, b): (c, n, tuple(i)) for (a, b, c, n), i in zip(gm.tolist(), gi.tolist())}
+            ok = {(a, b): (c, n, tuple(i)) for (a, b, c, n), i in zip(om.tolist(), oi.tolist())}
+            for key in sorted(set(gk) | set(ok)):
+                if gk.get(key) != ok.get(key):
+                    print(f"   manifold {key}: gpu {gk.get(key)}\n                     ora {ok.get(key)}")
+            return False
+        body = S.body_desc(translation=(0.0, 10.0, 0.0), can_sleep=env_sleep)
+        col = S.collider_desc(shape=S.SHAPE_BALL, half_extents=(0.5, 0.0, 0.0)) if k % 3 == 0 else \
+            S.collider_desc(half_extents=(0.5, 0.5, 0.5) if k % 3 == 2 else (0.5, 0.25, 0.5))
+        hb = g.insert_body(body); g.insert_collider(col, hb)
+        ob = o.add_body(translation=(0.0, 10.0, 0.0), can_sleep=env_sleep)
+        lib().ro_add_collider(o._w, np.array([col], S.COLLIDER_DTYPE).ctypes.data, ob)
+        alive.append(ob)
+        if len(alive) > cap:
+            op = o.read()[0]
+            order = sorted(alive, key=lambda h: -(abs(op[h, 0]) + abs(op[h, 2])))
+            for h in order[:len(alive) - cap]:
+                g.remove_body(h); o.remove_body(h); alive.remove(h)
+    print(f"[churn] ok: {steps} steps bit-exact")
+    return True
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "churn":
+        churn(int(sys.argv[2]) if len(sys.argv) > 2 else 300, int(sys.argv[3]) if len(sys.argv) > 3 else 60, int(sys.argv[4]) if len(sys.argv) > 4 else 1)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "compound":
         run("compound 12", S.compound_bodies(12), 80)
         run("compound 2", S.compound_bodies(2), 200)
