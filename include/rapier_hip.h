@@ -62,7 +62,8 @@ enum { RP_FRICTION_SIMPLIFIED = 0, RP_FRICTION_COULOMB = 1 };
 
 /* RigidBodyType — rigid_body_components.rs */
 enum { RP_BODY_DYNAMIC = 0, RP_BODY_FIXED = 1, RP_BODY_KINEMATIC_POSITION = 2, RP_BODY_KINEMATIC_VELOCITY = 3 };
-enum { RP_SHAPE_BALL = 0, RP_SHAPE_CUBOID = 1 };
+enum { RP_SHAPE_BALL = 0, RP_SHAPE_CUBOID = 1,
+       RP_SHAPE_CAPSULE = 2 /* ColliderBuilder::capsule_x/y/z (collider.rs): half_extents = (half_height, radius, axis 0|1|2) */ };
 enum { RP_RULE_AVERAGE = 0, RP_RULE_MIN, RP_RULE_MULTIPLY, RP_RULE_MAX, RP_RULE_CLAMPED_SUM, RP_RULE_GEOMETRIC_MEAN };
 
 /* RigidBodyBuilder — /root/reference/src/dynamics/rigid_body.rs:1560-1900 */
@@ -84,7 +85,7 @@ typedef struct rp_body_desc {
 /* ColliderBuilder — /root/reference/src/geometry/collider.rs:600-1130 */
 typedef struct rp_collider_desc {
     int32_t shape;
-    float half_extents[3]; /* cuboid half extents; ball radius in [0] */
+    float half_extents[3]; /* cuboid half extents; ball radius in [0]; capsule (half_height, radius, axis) */
     float translation[3];  /* pos_wrt_parent (world pose when parent handle is RP_INVALID_HANDLE) */
     float rotation[4];
     float density, friction, restitution;

@@ -76,7 +76,7 @@ typedef struct { v3 mins, maxs; } Aabb;
 
 typedef struct {
     int parent; pose pos_wrt_parent, pos;
-    int shape; v3 he; float radius;
+    int shape; v3 he; float radius; int axis; /* capsule: he.x = half height, radius, axis */
     float density, friction, restitution; int friction_rule, restitution_rule;
     uint32_t memberships, filter;
     uint32_t active_events; float force_threshold;
@@ -294,8 +294,10 @@ static void update_world_mass_properties(Body *b) {
     }
 }
 
-/* parry Shape::mass_properties (cuboid / ball), SURVEY Appendix C */
-static void shape_mass_props(const Collider *c, float density, float *mass, v3 *principal_inertia) {
+/* parry Shape::mass_properties (cuboid / ball / capsule), SURVEY Appendix C.  `frame` = principal inertia local frame of the
+ * shape (identity except for capsules along X / Z: MassProperties::from_capsule rotates Y onto the segment direction). */
+static void shape_mass_props(const Collider *c, float density, float *mass, v3 *principal_inertia, float frame[4]) {
+    frame[0] = 0.0f; frame[1] = 0.0f; frame[2] = 0.0f; frame[3] = 1.0f;
     if (c->shape == RO_SHAPE_CUBOID) {
         float vol = c->he.x * c->he.y * c->he.z * 8.0f;
         float m = vol * density;
@@ -303,6 +305,23 @@ static void shape_mass_props(const Collider *c, float density, float *mass, v3 *
         float iy = (c->he.x * c->he.x + c->he.z * c->he.z) / 3.0f;
         float iz = (c->he.x * c->he.x + c->he.y * c->he.y) / 3.0f;
         *mass = m; *principal_inertia = V3(ix * m, iy * m, iz * m);
+    } else if (c->shape == RO_SHAPE_CAPSULE) {
+        /* MassProperties::from_capsule: a Y cylinder (cylinder_y_volume_unit_inertia) + a ball split in two caps */
+        float hh = c->he.x, r = c->radius;
+        float cyl_vol = hh * r * r * 3.14159265358979323846f * 2.0f;
+        float sq_radius = r * r, sq_height = hh * hh * 4.0f;
+        float off_principal = (sq_radius * 3.0f + sq_height) / 12.0f;
+        float ball_vol = 3.14159265358979323846f * r * r * r * 4.0f / 3.0f;
+        float ball_i = r * r * 0.4f;
+        float cap_mass = (cyl_vol + ball_vol) * density;
+        float ix = (off_principal * cyl_vol + ball_i * ball_vol) * density;
+        float iy = (sq_radius / 2.0f * cyl_vol + ball_i * ball_vol) * density;
+        float h = hh * 2.0f;
+        float extra = (h * h * 0.25f + h * r * 3.0f / 8.0f) * ball_vol * density;
+        *mass = cap_mass; *principal_inertia = V3(ix + extra, iy, ix + extra);
+        /* rotation_between(Y, segment direction): -90 deg about Z for the X axis, +90 deg about X for the Z axis */
+        if (c->axis == 0) { frame[2] = -0.70710678118654752f; frame[3] = 0.70710678118654752f; }
+        else if (c->axis == 2) { frame[0] = 0.70710678118654752f; frame[3] = 0.70710678118654752f; }
     } else {
         float r = c->radius;
         float vol = 3.14159265358979323846f * r * r * r * 4.0f / 3.0f;
@@ -310,6 +329,12 @@ static void shape_mass_props(const Collider *c, float density, float *mass, v3 *
         float i = r * r * 0.4f;
         *mass = m; *principal_inertia = V3(i * m, i * m, i * m);
     }
+}
+/* radius of the shape's local bounding sphere (centred on the collider origin) — Shape::compute_local_bounding_sphere */
+static float shape_bounding_radius(const Collider *c) {
+    if (c->shape == RO_SHAPE_CUBOID) return vlen(c->he);
+    if (c->shape == RO_SHAPE_CAPSULE) return c->he.x + c->radius;
+    return c->radius;
 }
 
 /* ---- parry MassProperties algebra (not in /root/reference; restated from its public definition) ----------------
@@ -429,7 +454,7 @@ static void sum_collider_mass_props(const ro_world *w, int body, float density_o
         const Collider *c = &w->colliders[i];
         if (c->parent != body || !collider_enabled(c)) continue;
         ro_mp m; memset(&m, 0, sizeof(m)); m.frame[3] = 1.0f;
-        v3 pi; shape_mass_props(c, density_override < 0.0f ? c->density : density_override, &m.mass, &pi);
+        v3 pi; shape_mass_props(c, density_override < 0.0f ? c->density : density_override, &m.mass, &pi, m.frame);
         m.pi[0] = pi.x; m.pi[1] = pi.y; m.pi[2] = pi.z;
         float t[3] = {c->pos_wrt_parent.t.x, c->pos_wrt_parent.t.y, c->pos_wrt_parent.t.z};
         float q[4] = {c->pos_wrt_parent.r.x, c->pos_wrt_parent.r.y, c->pos_wrt_parent.r.z, c->pos_wrt_parent.r.w};
@@ -465,7 +490,7 @@ static void recompute_mass_properties(ro_world *w, Body *b) {
     for (int i = 0; i < w->ncolliders; ++i) {
         const Collider *c = &w->colliders[i];
         if (c->parent != body || !collider_enabled(c)) continue;
-        float radius = c->shape == RO_SHAPE_CUBOID ? vlen(c->he) : c->radius;
+        float radius = shape_bounding_radius(c);
         float extent = vlen(vsub(c->pos_wrt_parent.t, b->local_com)) + radius;
         b->max_extent = ro_maxf(b->max_extent, extent);
     }
@@ -514,6 +539,7 @@ int32_t ro_add_collider(ro_world *w, const ro_collider_desc *d, int32_t parent) 
     c->shape = d->shape;
     c->he = V3(d->half_extents[0], d->half_extents[1], d->half_extents[2]);
     c->radius = d->half_extents[0];
+    if (c->shape == RO_SHAPE_CAPSULE) { c->radius = d->half_extents[1]; c->axis = (int)d->half_extents[2]; if (c->axis < 0 || c->axis > 2) c->axis = 1; }
     c->pos_wrt_parent.t = V3(d->translation[0], d->translation[1], d->translation[2]);
     c->pos_wrt_parent.r = qnormalize(Q(d->rotation[0], d->rotation[1], d->rotation[2], d->rotation[3]));
     c->density = d->density; c->friction = d->friction; c->restitution = d->restitution;
@@ -655,6 +681,13 @@ static Aabb collider_collision_aabb(const Collider *c, float loosen) {
                   fabsf(m[1][0]) * c->he.x + fabsf(m[1][1]) * c->he.y + fabsf(m[1][2]) * c->he.z,
                   fabsf(m[2][0]) * c->he.x + fabsf(m[2][1]) * c->he.y + fabsf(m[2][2]) * c->he.z);
         a.mins = vsub(c->pos.t, h); a.maxs = vadd(c->pos.t, h);
+    } else if (c->shape == RO_SHAPE_CAPSULE) {
+        /* Capsule::aabb: the transformed segment's box loosened by the radius */
+        v3 e = capsule_axis_dir(c->axis);
+        v3 pa = pose_tp(c->pos, vmul(e, -c->he.x)), pb = pose_tp(c->pos, vmul(e, c->he.x));
+        v3 r = V3(c->radius, c->radius, c->radius);
+        a.mins = vsub(V3(ro_minf(pa.x, pb.x), ro_minf(pa.y, pb.y), ro_minf(pa.z, pb.z)), r);
+        a.maxs = vadd(V3(ro_maxf(pa.x, pb.x), ro_maxf(pa.y, pb.y), ro_maxf(pa.z, pb.z)), r);
     } else {
         v3 h = V3(c->radius, c->radius, c->radius);
         a.mins = vsub(c->pos.t, h); a.maxs = vadd(c->pos.t, h);
@@ -895,6 +928,7 @@ static float relative_pose_drift(pose base, pose cur, float max_extent) {
 }
 static float collider_origin_radius(const Collider *c) {
     if (c->shape == RO_SHAPE_CUBOID) return vlen(c->he); /* max(|mins|,|maxs|) of the local AABB */
+    if (c->shape == RO_SHAPE_CAPSULE) { v3 h = V3(c->radius, c->radius, c->radius); vset(&h, c->axis, c->he.x + c->radius); return vlen(h); }
     return vlen(V3(c->radius, c->radius, c->radius));
 }
 
@@ -993,9 +1027,15 @@ static int process_pair(ro_world *w, int pair_idx, Transition *tr_out) {
     float eff_prediction = prediction; /* contact_skin = 0, no soft-ccd */
 
     /* :323-330 parry DefaultQueryDispatcher::contact_manifolds */
-    if (co1->shape == RO_SHAPE_CUBOID && co2->shape == RO_SHAPE_CUBOID) manifold_cuboid_cuboid(pos12, co1->he, co2->he, eff_prediction, &p->m);
-    else if (co1->shape == RO_SHAPE_BALL && co2->shape == RO_SHAPE_BALL) manifold_ball_ball(pos12, co1->radius, co2->radius, eff_prediction, &p->m);
-    else if (co1->shape == RO_SHAPE_CUBOID) manifold_cuboid_ball(pos12, co1->he, co2->radius, eff_prediction, &p->m, 0);
+    int s1 = co1->shape, s2 = co2->shape;
+    if (s1 == RO_SHAPE_CUBOID && s2 == RO_SHAPE_CUBOID) manifold_cuboid_cuboid(pos12, co1->he, co2->he, eff_prediction, &p->m);
+    else if (s1 == RO_SHAPE_BALL && s2 == RO_SHAPE_BALL) manifold_ball_ball(pos12, co1->radius, co2->radius, eff_prediction, &p->m);
+    else if (s1 == RO_SHAPE_CAPSULE && s2 == RO_SHAPE_CAPSULE) manifold_capsule_capsule(pos12, co1->he.x, co1->radius, co1->axis, co2->he.x, co2->radius, co2->axis, eff_prediction, &p->m);
+    else if (s1 == RO_SHAPE_CUBOID && s2 == RO_SHAPE_CAPSULE) manifold_cuboid_capsule(pos12, pos12, co1->he, co2->he.x, co2->radius, co2->axis, eff_prediction, &p->m, 0);
+    else if (s1 == RO_SHAPE_CAPSULE && s2 == RO_SHAPE_CUBOID) manifold_cuboid_capsule(pose_inv(pos12), pos12, co2->he, co1->he.x, co1->radius, co1->axis, eff_prediction, &p->m, 1);
+    else if (s1 == RO_SHAPE_CAPSULE && s2 == RO_SHAPE_BALL) manifold_capsule_ball(pos12, co1->he.x, co1->radius, co1->axis, co2->radius, eff_prediction, &p->m, 0);
+    else if (s1 == RO_SHAPE_BALL && s2 == RO_SHAPE_CAPSULE) manifold_capsule_ball(pose_inv(pos12), co2->he.x, co2->radius, co2->axis, co1->radius, eff_prediction, &p->m, 1);
+    else if (s1 == RO_SHAPE_CUBOID) manifold_cuboid_ball(pos12, co1->he, co2->radius, eff_prediction, &p->m, 0);
     else manifold_cuboid_ball(pose_inv(pos12), co2->he, co1->radius, eff_prediction, &p->m, 1);
 
     p->friction = ro_combine_coefficient(co1->friction, co2->friction, co1->friction_rule, co2->friction_rule);

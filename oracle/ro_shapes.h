@@ -8,7 +8,11 @@
  *   - SAT for cuboid-cuboid (3+3 face axes one-way, 9 edge-edge axes two-way),
  *   - support faces + projected 2-D face/face clipping (PolygonalFeature::contacts),
  *   - ContactManifold::try_update_contacts (1 degree / 1e-6 thresholds), match_contacts,
- *   - ball-ball and convex(cuboid)-ball single-point manifolds.
+ *   - ball-ball and convex(cuboid)-ball single-point manifolds,
+ *   - capsules: segment-segment closest points (capsule-capsule), convex(capsule)-ball, and cuboid-capsule (SAT of the
+ *     cuboid against the capsule's segment: 6 face axes one-way + 3 edge axes two-way, then the support face clipped against
+ *     the segment and pushed out by the radius).  One deliberate simplification, marked below: the segment is treated as ONE
+ *     edge in the edge/edge pass of the clipping (a 2-vertex PolygonalFeature walked generically would meet it twice).
  * The algorithm is restated from parry's published source as recalled; it cannot be
  * diffed against the crate here ("manifold-level parity unpinned", see rapier_oracle.h).
  */
@@ -354,5 +358,196 @@ static inline void manifold_cuboid_ball(pose pos12, v3 he1, float r2, float pred
     } else {
         m->npoints = 0;
     }
+}
+/* ---- capsules (parry shape::Capsule = segment [a, b] + radius; ColliderBuilder::capsule_x/y/z: a = -hh e_axis, b = +hh e_axis) ---- */
+static inline v3 capsule_axis_dir(int axis) { return axis == 0 ? V3(1, 0, 0) : axis == 2 ? V3(0, 0, 1) : V3(0, 1, 0); }
+/* Segment::project_local_point */
+static inline v3 segment_project_point(v3 a, v3 b, v3 pt) {
+    v3 ab = vsub(b, a), ap = vsub(pt, a);
+    float ab_ap = vdot(ab, ap), sqnab = vdot(ab, ab);
+    if (ab_ap <= 0.0f) return a;
+    if (ab_ap >= sqnab) return b;
+    float u = ab_ap / sqnab;
+    return vadd(a, vmul(ab, u));
+}
+/* query::details::closest_points_segment_segment_with_locations_nD (Ericson, Real-Time Collision Detection 5.1.9) */
+static inline void closest_points_segment_segment(v3 a1, v3 b1, v3 a2, v3 b2, float *s_out, float *t_out) {
+    v3 d1 = vsub(b1, a1), d2 = vsub(b2, a2), r = vsub(a1, a2);
+    float a = vdot(d1, d1), e = vdot(d2, d2), f = vdot(d2, r);
+    const float eps = FLT_EPSILON;
+    float s, t;
+    if (a <= eps && e <= eps) { s = 0.0f; t = 0.0f; }
+    else if (a <= eps) { s = 0.0f; t = ro_clampf(f / e, 0.0f, 1.0f); }
+    else {
+        float c = vdot(d1, r);
+        if (e <= eps) { t = 0.0f; s = ro_clampf(-c / a, 0.0f, 1.0f); }
+        else {
+            float b = vdot(d1, d2);
+            float ae = a * e, bb = b * b, denom = ae - bb;
+            if (denom > eps && !ro_ulps_eq(ae, bb)) s = ro_clampf((b * f - c * e) / denom, 0.0f, 1.0f); else s = 0.0f;
+            t = (b * s + f) / e;
+            if (t < 0.0f) { t = 0.0f; s = ro_clampf(-c / a, 0.0f, 1.0f); }
+            else if (t > 1.0f) { t = 1.0f; s = ro_clampf((b - c) / a, 0.0f, 1.0f); }
+        }
+    }
+    *s_out = s; *t_out = t;
+}
+/* contact_manifold_capsule_capsule (3-D): one contact between the closest points of the two segments */
+static inline void manifold_capsule_capsule(pose pos12, float hh1, float r1, int axis1, float hh2, float r2, int axis2, float prediction, Manifold *m) {
+    v3 e1 = capsule_axis_dir(axis1), e2 = capsule_axis_dir(axis2);
+    v3 a1 = vmul(e1, -hh1), b1 = vmul(e1, hh1);
+    v3 a2 = pose_tp(pos12, vmul(e2, -hh2)), b2 = pose_tp(pos12, vmul(e2, hh2));
+    float s, t; closest_points_segment_segment(a1, b1, a2, b2, &s, &t);
+    v3 p1 = vadd(vmul(a1, 1.0f - s), vmul(b1, s)), p2_1 = vadd(vmul(a2, 1.0f - t), vmul(b2, t));
+    v3 d = vsub(p2_1, p1);
+    float l = vlen(d);
+    v3 n1 = l > FLT_EPSILON ? vmul(d, 1.0f / l) : V3(0, 1, 0);
+    float dist = vdot(d, n1) - r1 - r2;
+    if (dist <= prediction) {
+        v3 n2 = qrot_inv(pos12.r, vneg(n1));
+        v3 lp1 = vadd(p1, vmul(n1, r1)), lp2 = vadd(pose_itp(pos12, p2_1), vmul(n2, r2));
+        if (m->npoints != 0) {
+            m->points[0].local_p1 = lp1; m->points[0].local_p2 = lp2; m->points[0].dist = dist;
+            m->points[0].fid1 = 0; m->points[0].fid2 = 0; m->npoints = 1;
+        } else manifold_push(m, lp1, lp2, 0, 0, dist);
+        m->local_n1 = n1; m->local_n2 = n2;
+    } else m->npoints = 0;
+}
+/* contact_manifold_convex_ball with shape1 = capsule (Capsule::project_local_point, solid); `flipped` = the ball is collider 1 */
+static inline void manifold_capsule_ball(pose pos12, float hh1, float r1, int axis1, float r2, float prediction, Manifold *m, int flipped) {
+    v3 e1 = capsule_axis_dir(axis1);
+    v3 pt = pos12.t;
+    v3 sp = segment_project_point(vmul(e1, -hh1), vmul(e1, hh1), pt);
+    v3 dproj = vsub(pt, sp);
+    float dseg = vlen(dproj);
+    if (!(dseg > FLT_EPSILON) || dseg <= r1) return; /* centre inside the solid capsule: manifold left untouched */
+    v3 dir = vmul(dproj, 1.0f / dseg);
+    v3 proj = vadd(sp, vmul(dir, r1));
+    v3 dpos = vsub(pt, proj);
+    float dist = vlen(dpos);
+    if (!(dist > 0.0f)) return;
+    v3 n1 = vmul(dpos, 1.0f / dist);
+    if (dist <= r2 + prediction) {
+        v3 n2 = qrot_inv(pos12.r, vneg(n1));
+        v3 p2 = vmul(n2, r2);
+        float d = dist - r2;
+        v3 a = flipped ? p2 : proj, b = flipped ? proj : p2;
+        if (m->npoints != 1) { m->npoints = 0; manifold_push(m, a, b, RO_FID_UNKNOWN, RO_FID_UNKNOWN, d); }
+        else { m->points[0].local_p1 = a; m->points[0].local_p2 = b; m->points[0].dist = d; }
+        if (flipped) { m->local_n1 = n2; m->local_n2 = n1; } else { m->local_n1 = n1; m->local_n2 = n2; }
+    } else m->npoints = 0;
+}
+/* sat::cuboid_support_map_find_local_separating_normal_oneway with shape2 = segment [a2, b2] (already in the cuboid's frame) */
+static inline float sat_cuboid_segment_normal_oneway(v3 he1, v3 a2, v3 b2, v3 *out_dir) {
+    float best = -FLT_MAX; v3 best_dir = V3(0, 0, 0);
+    for (int i = 0; i < 3; ++i)
+        for (int sg = 0; sg < 2; ++sg) {
+            float sign = sg == 0 ? -1.0f : 1.0f;
+            v3 axis1 = V3(0, 0, 0); vset(&axis1, i, sign);
+            /* support point of the segment toward -axis1 */
+            v3 dir = vneg(axis1);
+            v3 pt2 = vdot(a2, dir) > vdot(b2, dir) ? a2 : b2;
+            float sep = vget(pt2, i) * sign - vget(he1, i);
+            if (sep > best) { best = sep; best_dir = axis1; }
+        }
+    *out_dir = best_dir;
+    return best;
+}
+/* sat::cuboid_support_map_compute_separation_wrt_local_line (two-way) + cuboid_segment_find_local_separating_edge_twoway */
+static inline float sat_cuboid_segment_edge_twoway(v3 he1, v3 a2, v3 b2, v3 *out_dir) {
+    float best = -FLT_MAX; v3 best_dir = V3(0, 0, 0);
+    v3 x2 = vsub(b2, a2);
+    v3 axes[3] = {V3(0, -x2.z, x2.y), V3(x2.z, 0, -x2.x), V3(-x2.y, x2.x, 0)};
+    for (int k = 0; k < 3; ++k) {
+        float n = vlen(axes[k]);
+        if (!(n > FLT_EPSILON)) continue;
+        v3 axis1 = vmul(axes[k], 1.0f / n);
+        v3 lp1 = cuboid_support_point(he1, axis1);
+        v3 q = vdot(a2, vneg(axis1)) > vdot(b2, vneg(axis1)) ? a2 : b2;
+        float sep1 = vdot(vsub(q, lp1), axis1);
+        v3 naxis = vneg(axis1);
+        v3 lp1b = cuboid_support_point(he1, naxis);
+        v3 qb = vdot(a2, axis1) > vdot(b2, axis1) ? a2 : b2;
+        float sep2 = vdot(vsub(qb, lp1b), naxis);
+        float sep = sep1 > sep2 ? sep1 : sep2;
+        v3 ax = sep1 > sep2 ? axis1 : naxis;
+        if (sep > best) { best = sep; best_dir = ax; }
+    }
+    *out_dir = best_dir;
+    return best;
+}
+/* contact_manifold_cuboid_capsule: `pos12` = pose of the capsule in the cuboid's frame, `upd` = pose of collider 2 in collider
+ * 1's frame (== pos12 unless flipped), `flipped` = the capsule is collider 1 (points, feature ids and normals swap on output) */
+static inline void manifold_cuboid_capsule(pose pos12, pose upd, v3 he1, float hh2, float r2, int axis2, float prediction, Manifold *m, int flipped) {
+    if (manifold_try_update_contacts(m, upd)) return;
+    pose pos21 = pose_inv(pos12);
+    v3 e2 = capsule_axis_dir(axis2);
+    v3 a2 = pose_tp(pos12, vmul(e2, -hh2)), b2 = pose_tp(pos12, vmul(e2, hh2));
+    v3 d1, d3;
+    float s1 = sat_cuboid_segment_normal_oneway(he1, a2, b2, &d1);
+    if (s1 > r2 + prediction) { m->npoints = 0; return; }
+    float s3 = sat_cuboid_segment_edge_twoway(he1, a2, b2, &d3);
+    if (s3 > r2 + prediction) { m->npoints = 0; return; }
+    v3 best_dir = s3 > s1 ? d3 : d1;
+    v3 n2 = qrot(pos21.r, vneg(best_dir));
+    PolyFace f1 = cuboid_support_face(he1, best_dir);
+    v3 sv[2] = {a2, b2};
+    const uint32_t seg_vid[2] = {0u, 2u}, seg_eid = 1u;
+
+    Manifold t; t.npoints = 0;
+    v3 basis[2]; orthonormal_basis(best_dir, basis);
+    float pf1[4][2], ps[2][2];
+    for (int i = 0; i < 4; ++i) { pf1[i][0] = vdot(f1.vertices[i], basis[0]); pf1[i][1] = vdot(f1.vertices[i], basis[1]); }
+    for (int i = 0; i < 2; ++i) { ps[i][0] = vdot(sv[i], basis[0]); ps[i][1] = vdot(sv[i], basis[1]); }
+#define PERP(ax, ay, bx, by) ((ax) * (by) - (ay) * (bx))
+    {   /* segment vertices inside the face */
+        v3 normal1 = vcross(vsub(f1.vertices[2], f1.vertices[1]), vsub(f1.vertices[0], f1.vertices[1]));
+        float denom = -vdot(normal1, best_dir);
+        if (!ro_relative_eq0(denom)) {
+            for (int i = 0; i < 2; ++i) {
+                float px = ps[i][0], py = ps[i][1];
+                float sign = PERP(pf1[0][0] - pf1[3][0], pf1[0][1] - pf1[3][1], px - pf1[3][0], py - pf1[3][1]);
+                int outside = 0;
+                for (int j = 0; j < 3; ++j) {
+                    float ns = PERP(pf1[j + 1][0] - pf1[j][0], pf1[j + 1][1] - pf1[j][1], px - pf1[j][0], py - pf1[j][1]);
+                    if (sign == 0.0f) sign = ns;
+                    else if (sign * ns < 0.0f) { outside = 1; break; }
+                }
+                if (outside) continue;
+                float dist = vdot(vsub(f1.vertices[0], sv[i]), normal1) / denom;
+                v3 local_p1 = vsub(sv[i], vmul(best_dir, dist));
+                manifold_push(&t, local_p1, pose_itp(pos12, sv[i]), f1.fid, seg_vid[i], dist);
+            }
+        }
+    }
+#undef PERP
+    {   /* the segment against the face's edges (ONE pass over the segment, see the header) */
+        float e2p[2][2] = {{ps[0][0], ps[0][1]}, {ps[1][0], ps[1][1]}};
+        for (int i = 0; i < 4; ++i) {
+            float e1p[2][2] = {{pf1[i][0], pf1[i][1]}, {pf1[(i + 1) & 3][0], pf1[(i + 1) & 3][1]}};
+            float s, tt;
+            if (closest_points_line2d(e1p, e2p, &s, &tt) && s > 0.0f && s < 1.0f && tt > 0.0f && tt < 1.0f) {
+                v3 local_p1 = vadd(vmul(f1.vertices[i], 1.0f - s), vmul(f1.vertices[(i + 1) & 3], s));
+                v3 local_p2_1 = vadd(vmul(sv[0], 1.0f - tt), vmul(sv[1], tt));
+                float dist = vdot(vsub(local_p2_1, local_p1), best_dir);
+                manifold_push(&t, local_p1, pose_itp(pos12, local_p2_1), f1.eids[i], seg_eid, dist);
+            }
+        }
+    }
+    TrackedContact old[RO_MAX_MANIFOLD_PTS]; int nold = m->npoints;
+    memcpy(old, m->points, sizeof(old));
+    m->npoints = 0;
+    for (int i = 0; i < t.npoints; ++i) {
+        TrackedContact c = t.points[i];
+        c.local_p2 = vadd(c.local_p2, vmul(n2, r2)); /* push the segment point out to the capsule's surface */
+        c.dist = c.dist - r2;
+        if (flipped) { v3 tp = c.local_p1; c.local_p1 = c.local_p2; c.local_p2 = tp; uint32_t tf = c.fid1; c.fid1 = c.fid2; c.fid2 = tf; }
+        m->points[m->npoints++] = c;
+    }
+    if (flipped) { m->local_n1 = n2; m->local_n2 = best_dir; } else { m->local_n1 = best_dir; m->local_n2 = n2; }
+    for (int i = 0; i < m->npoints; ++i)
+        for (int j = 0; j < nold; ++j)
+            if (m->points[i].fid1 == old[j].fid1 && m->points[i].fid2 == old[j].fid2)
+                m->points[i].data = old[j].data;
 }
 #endif

@@ -294,8 +294,15 @@ extern "C" int32_t rp_params_set(rp_world *w, const rp_integration_params *in) {
 }
 extern "C" int32_t rp_num_bodies(const rp_world *w) { return w ? (int32_t)w->bodies.size() : 0; }
 
-// parry Shape::mass_properties for cuboid / ball
-static void shape_mass_props(const rp_collider_desc &c, float density, float &mass, float pi[3]) {
+// parry Shape::mass_properties for cuboid / ball / capsule; frame = the shape's principal inertia local frame
+// (identity except for capsules along X / Z: MassProperties::from_capsule rotates Y onto the segment direction)
+static float shape_bounding_radius(const rp_collider_desc &c) { // Shape::compute_local_bounding_sphere
+    if (c.shape == RP_SHAPE_CUBOID) return std::sqrt(c.half_extents[0] * c.half_extents[0] + c.half_extents[1] * c.half_extents[1] + c.half_extents[2] * c.half_extents[2]);
+    if (c.shape == RP_SHAPE_CAPSULE) return c.half_extents[0] + c.half_extents[1];
+    return c.half_extents[0];
+}
+static void shape_mass_props(const rp_collider_desc &c, float density, float &mass, float pi[3], float frame[4]) {
+    frame[0] = 0.0f; frame[1] = 0.0f; frame[2] = 0.0f; frame[3] = 1.0f;
     if (c.shape == RP_SHAPE_CUBOID) {
         const float *he = c.half_extents;
         volatile float vol = he[0] * he[1] * he[2] * 8.0f;
@@ -304,6 +311,22 @@ static void shape_mass_props(const rp_collider_desc &c, float density, float &ma
         volatile float iy = (he[0] * he[0] + he[2] * he[2]) / 3.0f;
         volatile float iz = (he[0] * he[0] + he[1] * he[1]) / 3.0f;
         mass = m; pi[0] = ix * m; pi[1] = iy * m; pi[2] = iz * m;
+    } else if (c.shape == RP_SHAPE_CAPSULE) { // MassProperties::from_capsule: a Y cylinder + a ball split in two caps
+        float hh = c.half_extents[0], r = c.half_extents[1];
+        volatile float cyl_vol = hh * r * r * 3.14159265358979323846f * 2.0f;
+        volatile float sq_radius = r * r, sq_height = hh * hh * 4.0f;
+        volatile float off_principal = (sq_radius * 3.0f + sq_height) / 12.0f;
+        volatile float ball_vol = 3.14159265358979323846f * r * r * r * 4.0f / 3.0f;
+        volatile float ball_i = r * r * 0.4f;
+        volatile float cap_mass = (cyl_vol + ball_vol) * density;
+        volatile float ix = (off_principal * cyl_vol + ball_i * ball_vol) * density;
+        volatile float iy = (sq_radius / 2.0f * cyl_vol + ball_i * ball_vol) * density;
+        volatile float h = hh * 2.0f;
+        volatile float extra = (h * h * 0.25f + h * r * 3.0f / 8.0f) * ball_vol * density;
+        mass = cap_mass; pi[0] = ix + extra; pi[1] = iy; pi[2] = ix + extra;
+        int axis = (int)c.half_extents[2];
+        if (axis == 0) { frame[2] = -0.70710678118654752f; frame[3] = 0.70710678118654752f; }
+        else if (axis == 2) { frame[0] = 0.70710678118654752f; frame[3] = 0.70710678118654752f; }
     } else {
         float r = c.half_extents[0];
         volatile float vol = 3.14159265358979323846f * r * r * r * 4.0f / 3.0f;
@@ -430,7 +453,7 @@ static void sum_collider_mass_props(const rp_world *w, int body, float density_o
         if (w->collider_parent[i] != body || w->collider_removed[i]) continue;
         const rp_collider_desc &c = w->colliders[i];
         hmp_mp m; memset(&m, 0, sizeof(m)); m.frame[3] = 1.0f;
-        shape_mass_props(c, density_override < 0.0f ? c.density : density_override, m.mass, m.pi);
+        shape_mass_props(c, density_override < 0.0f ? c.density : density_override, m.mass, m.pi, m.frame);
         float qn = std::sqrt(c.rotation[0] * c.rotation[0] + c.rotation[1] * c.rotation[1] + c.rotation[2] * c.rotation[2] + c.rotation[3] * c.rotation[3]);
         float qi = qn > 0.0f ? 1.0f / qn : 1.0f;
         float q[4] = {c.rotation[0] * qi, c.rotation[1] * qi, c.rotation[2] * qi, qn > 0.0f ? c.rotation[3] * qi : 1.0f};
@@ -466,7 +489,7 @@ static void recompute_mass(rp_world *w, int body) {
     for (size_t i = 0; i < w->colliders.size(); ++i) {
         if (w->collider_parent[i] != body || w->collider_removed[i]) continue;
         const rp_collider_desc &c = w->colliders[i];
-        float radius = c.shape == RP_SHAPE_CUBOID ? std::sqrt(c.half_extents[0] * c.half_extents[0] + c.half_extents[1] * c.half_extents[1] + c.half_extents[2] * c.half_extents[2]) : c.half_extents[0];
+        float radius = shape_bounding_radius(c);
         float dx = c.translation[0] - b.lcom[0], dy = c.translation[1] - b.lcom[1], dz = c.translation[2] - b.lcom[2];
         float extent = std::sqrt(dx * dx + dy * dy + dz * dz) + radius;
         if (extent > b.max_extent) b.max_extent = extent;
@@ -579,6 +602,11 @@ extern "C" int32_t rp_bodies_insert(rp_world *w, int32_t n, const rp_body_desc *
 }
 extern "C" int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider_desc *descs, const uint64_t *parents, uint64_t *handles_out) {
     if (!w || n < 0 || (n > 0 && !descs)) return RP_ERR_INVALID;
+    for (int i = 0; i < n; ++i) {
+        const rp_collider_desc &cd = descs[i];
+        if (cd.shape != RP_SHAPE_BALL && cd.shape != RP_SHAPE_CUBOID && cd.shape != RP_SHAPE_CAPSULE) { w->err = "rp_colliders_insert: unknown shape (ball, cuboid and capsule are implemented)"; return RP_ERR_INVALID; }
+        if (cd.shape == RP_SHAPE_CAPSULE && (cd.half_extents[2] != 0.0f && cd.half_extents[2] != 1.0f && cd.half_extents[2] != 2.0f)) { w->err = "rp_colliders_insert: capsule half_extents = (half_height, radius, axis) with axis 0, 1 or 2"; return RP_ERR_INVALID; }
+    }
     const bool in_place = w->finalized && (int)w->colliders.size() + n <= w->cap_colliders; // see rp_bodies_insert
     if (n > 0 && w->finalized) {
         HIPCHK(w, hipSetDevice(w->device));
@@ -851,7 +879,7 @@ static int finalize(rp_world *w) {
     float margin = 2.0f * (pred * 0.5f + 4.0e-2f * w->params.length_unit);
     std::vector<float> ext;
     for (auto &c : w->colliders) {
-        float r = c.shape == RP_SHAPE_CUBOID ? std::sqrt(c.half_extents[0] * c.half_extents[0] + c.half_extents[1] * c.half_extents[1] + c.half_extents[2] * c.half_extents[2]) : c.half_extents[0];
+        float r = shape_bounding_radius(c);
         ext.push_back(2.0f * r + margin);
     }
     float cell = 1.0f;

@@ -102,6 +102,8 @@ RP_HD float rp_atan2_portable(float y, float x) { // full range
     if (x < 0.0f) return y >= 0.0f ? rp_atan_portable(y / x) + 3.14159265358979323846f : rp_atan_portable(y / x) - 3.14159265358979323846f;
     return y > 0.0f ? 1.5707963267948966f : (y < 0.0f ? -1.5707963267948966f : 0.0f);
 }
+// direction of a capsule's segment (ColliderBuilder::capsule_x / capsule_y / capsule_z)
+RP_HD V3 capsule_axis_dir(int axis) { return axis == 0 ? v3(1, 0, 0) : axis == 2 ? v3(0, 0, 1) : v3(0, 1, 0); }
 // asin(x) for |x| <= 1 from the portable atan: atan2(x, sqrt((1 - x)(1 + x)))
 RP_HD float rp_asin_portable(float x) { return rp_atan2_portable(x, sqrtf((1.0f - x) * (1.0f + x))); }
 // Quat::to_scaled_axis: axis * angle, angle = 2 atan2(|v|, w)

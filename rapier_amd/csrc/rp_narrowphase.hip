@@ -268,6 +268,184 @@ __device__ void manifold_cuboid_ball(Pose pos12, V3 he1, float r2, float predict
     } else m.n = 0;
 }
 
+// ---- capsules (parry shape::Capsule = segment [a, b] + radius; c_he = (half_height, radius, axis)) — restated like oracle/ro_shapes.h ----
+RP_DEV V3 segment_project_point(V3 a, V3 b, V3 pt) { // Segment::project_local_point
+    V3 ab = b - a, ap = pt - a;
+    float ab_ap = dot(ab, ap), sqnab = dot(ab, ab);
+    if (ab_ap <= 0.0f) return a;
+    if (ab_ap >= sqnab) return b;
+    float u = ab_ap / sqnab;
+    return a + ab * u;
+}
+// closest_points_segment_segment_with_locations_nD (Ericson 5.1.9)
+__device__ void closest_points_segment_segment(V3 a1, V3 b1, V3 a2, V3 b2, float &s_out, float &t_out) {
+    V3 d1 = b1 - a1, d2 = b2 - a2, r = a1 - a2;
+    float a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r);
+    const float eps = FLT_EPSILON;
+    float s, t;
+    if (a <= eps && e <= eps) { s = 0.0f; t = 0.0f; }
+    else if (a <= eps) { s = 0.0f; t = rp_clamp(f / e, 0.0f, 1.0f); }
+    else {
+        float c = dot(d1, r);
+        if (e <= eps) { t = 0.0f; s = rp_clamp(-c / a, 0.0f, 1.0f); }
+        else {
+            float b = dot(d1, d2);
+            float ae = a * e, bb = b * b, denom = ae - bb;
+            if (denom > eps && !ulps_eq(ae, bb)) s = rp_clamp((b * f - c * e) / denom, 0.0f, 1.0f); else s = 0.0f;
+            t = (b * s + f) / e;
+            if (t < 0.0f) { t = 0.0f; s = rp_clamp(-c / a, 0.0f, 1.0f); }
+            else if (t > 1.0f) { t = 1.0f; s = rp_clamp((b - c) / a, 0.0f, 1.0f); }
+        }
+    }
+    s_out = s; t_out = t;
+}
+// contact_manifold_capsule_capsule (3-D): one contact between the closest points of the two segments
+__device__ void manifold_capsule_capsule(Pose pos12, float4 c1, float4 c2, float prediction, LocalManifold &m) {
+    V3 e1 = capsule_axis_dir((int)c1.z), e2 = capsule_axis_dir((int)c2.z);
+    V3 a1 = e1 * -c1.x, b1 = e1 * c1.x;
+    V3 a2 = pose_tp(pos12, e2 * -c2.x), b2 = pose_tp(pos12, e2 * c2.x);
+    float s, t; closest_points_segment_segment(a1, b1, a2, b2, s, t);
+    V3 p1 = a1 * (1.0f - s) + b1 * s, p2_1 = a2 * (1.0f - t) + b2 * t;
+    V3 d = p2_1 - p1;
+    float l = len(d);
+    V3 n1 = l > FLT_EPSILON ? d * (1.0f / l) : v3(0, 1, 0);
+    float dist = dot(d, n1) - c1.y - c2.y;
+    if (dist <= prediction) {
+        V3 n2 = qrot_inv(pos12.r, -n1);
+        int keep = m.n != 0 ? 0 : -1;
+        m.n = 1; m.lp1[0] = p1 + n1 * c1.y; m.lp2[0] = pose_itp(pos12, p2_1) + n2 * c2.y; m.dist[0] = dist; m.fid[0] = 0; m.src[0] = keep;
+        m.ln1 = n1; m.ln2 = n2;
+    } else m.n = 0;
+}
+// contact_manifold_convex_ball with shape1 = capsule (Capsule::project_local_point, solid); flipped = the ball is collider 1
+__device__ void manifold_capsule_ball(Pose pos12, float4 c1, float r2, float prediction, LocalManifold &m, bool flipped) {
+    V3 e1 = capsule_axis_dir((int)c1.z);
+    V3 pt = pos12.t;
+    V3 sp = segment_project_point(e1 * -c1.x, e1 * c1.x, pt);
+    V3 dproj = pt - sp;
+    float dseg = len(dproj);
+    if (!(dseg > FLT_EPSILON) || dseg <= c1.y) return;
+    V3 dir = dproj * (1.0f / dseg);
+    V3 proj = sp + dir * c1.y;
+    V3 dpos = pt - proj;
+    float dist = len(dpos);
+    if (!(dist > 0.0f)) return;
+    V3 n1 = dpos * (1.0f / dist);
+    if (dist <= r2 + prediction) {
+        V3 n2 = qrot_inv(pos12.r, -n1);
+        V3 p2 = n2 * r2;
+        int keep = m.n == 1 ? 0 : -1;
+        m.n = 1;
+        m.lp1[0] = flipped ? p2 : proj; m.lp2[0] = flipped ? proj : p2; m.dist[0] = dist - r2;
+        if (keep < 0) m.fid[0] = RP_FID_UNKNOWN | (RP_FID_UNKNOWN << 16);
+        m.src[0] = keep;
+        if (flipped) { m.ln1 = n2; m.ln2 = n1; } else { m.ln1 = n1; m.ln2 = n2; }
+    } else m.n = 0;
+}
+// sat::cuboid_support_map_find_local_separating_normal_oneway with shape2 = the segment [a2, b2] (cuboid frame)
+__device__ float sat_cuboid_segment_normal_oneway(V3 he1, V3 a2, V3 b2, V3 &out_dir) {
+    float best = -FLT_MAX; V3 best_dir = v3(0, 0, 0);
+    for (int i = 0; i < 3; ++i)
+        for (int sg = 0; sg < 2; ++sg) {
+            float sign = sg == 0 ? -1.0f : 1.0f;
+            V3 axis1 = v3(i == 0 ? sign : 0.0f, i == 1 ? sign : 0.0f, i == 2 ? sign : 0.0f);
+            V3 dir = -axis1;
+            V3 pt2 = dot(a2, dir) > dot(b2, dir) ? a2 : b2;
+            float sep = comp(pt2, i) * sign - comp(he1, i);
+            if (sep > best) { best = sep; best_dir = axis1; }
+        }
+    out_dir = best_dir;
+    return best;
+}
+// cuboid_segment_find_local_separating_edge_twoway (cuboid_support_map_compute_separation_wrt_local_line, both directions)
+__device__ float sat_cuboid_segment_edge_twoway(V3 he1, V3 a2, V3 b2, V3 &out_dir) {
+    float best = -FLT_MAX; V3 best_dir = v3(0, 0, 0);
+    V3 x2 = b2 - a2;
+    V3 axes[3] = {v3(0, -x2.z, x2.y), v3(x2.z, 0, -x2.x), v3(-x2.y, x2.x, 0)};
+    for (int k = 0; k < 3; ++k) {
+        float n = len(axes[k]);
+        if (!(n > FLT_EPSILON)) continue;
+        V3 axis1 = axes[k] * (1.0f / n);
+        V3 lp1 = cuboid_support_point(he1, axis1);
+        V3 q = dot(a2, -axis1) > dot(b2, -axis1) ? a2 : b2;
+        float sep1 = dot(q - lp1, axis1);
+        V3 naxis = -axis1;
+        V3 lp1b = cuboid_support_point(he1, naxis);
+        V3 qb = dot(a2, axis1) > dot(b2, axis1) ? a2 : b2;
+        float sep2 = dot(qb - lp1b, naxis);
+        float sep = sep1 > sep2 ? sep1 : sep2;
+        V3 ax = sep1 > sep2 ? axis1 : naxis;
+        if (sep > best) { best = sep; best_dir = ax; }
+    }
+    out_dir = best_dir;
+    return best;
+}
+// contact_manifold_cuboid_capsule: pos12 = pose of the capsule in the cuboid's frame, upd = pose of collider 2 in collider 1's
+// frame (== pos12 unless flipped), flipped = the capsule is collider 1 (points, feature ids and normals swap on output)
+#define PERP(ax, ay, bx, by) ((ax) * (by) - (ay) * (bx))
+__device__ void manifold_cuboid_capsule(Pose pos12, Pose upd, V3 he1, float4 c2, float prediction, LocalManifold &m, bool flipped) {
+    if (try_update_contacts(m, upd)) return;
+    Pose pos21 = pose_inv(pos12);
+    const float hh2 = c2.x, r2 = c2.y;
+    V3 e2 = capsule_axis_dir((int)c2.z);
+    V3 a2 = pose_tp(pos12, e2 * -hh2), b2 = pose_tp(pos12, e2 * hh2);
+    V3 d1, d3;
+    float s1 = sat_cuboid_segment_normal_oneway(he1, a2, b2, d1);
+    if (s1 > r2 + prediction) { m.n = 0; return; }
+    float s3 = sat_cuboid_segment_edge_twoway(he1, a2, b2, d3);
+    if (s3 > r2 + prediction) { m.n = 0; return; }
+    V3 best = s3 > s1 ? d3 : d1;
+    V3 n2 = qrot(pos21.r, -best);
+    Face f1 = cuboid_support_face(he1, best);
+    unsigned oldfid[RP_MAX_PTS]; int nold = m.n;
+    for (int i = 0; i < nold; ++i) oldfid[i] = m.fid[i];
+    m.n = 0;
+    V3 bx, by; orthonormal_basis(best, bx, by);
+    float p1x[4], p1y[4];
+    for (int i = 0; i < 4; ++i) { p1x[i] = dot(f1.v[i], bx); p1y[i] = dot(f1.v[i], by); }
+    const float s0x = dot(a2, bx), s0y = dot(a2, by), s1x = dot(b2, bx), s1y = dot(b2, by);
+    { // segment vertices inside the face
+        V3 normal1 = cross(f1.v[2] - f1.v[1], f1.v[0] - f1.v[1]);
+        float denom = -dot(normal1, best);
+        if (!(fabsf(denom) <= FLT_EPSILON)) {
+            for (int i = 0; i < 2; ++i) {
+                float px = i == 0 ? s0x : s1x, py = i == 0 ? s0y : s1y;
+                V3 sv = i == 0 ? a2 : b2;
+                float sign = PERP(p1x[0] - p1x[3], p1y[0] - p1y[3], px - p1x[3], py - p1y[3]);
+                bool outside = false;
+                for (int j = 0; j < 3; ++j) {
+                    float ns = PERP(p1x[j + 1] - p1x[j], p1y[j + 1] - p1y[j], px - p1x[j], py - p1y[j]);
+                    if (sign == 0.0f) sign = ns; else if (sign * ns < 0.0f) { outside = true; break; }
+                }
+                if (outside) continue;
+                float dist = dot(f1.v[0] - sv, normal1) / denom;
+                V3 lp1 = sv - best * dist;
+                lm_push(m, lp1, pose_itp(pos12, sv), f1.fid, i == 0 ? 0u : 2u, dist);
+            }
+        }
+    }
+    for (int i = 0; i < 4; ++i) { // the segment against the face's edges (one pass over the segment)
+        int i1 = (i + 1) & 3;
+        float s, t;
+        if (closest_points_line2d(p1x[i], p1y[i], p1x[i1], p1y[i1], s0x, s0y, s1x, s1y, s, t) && s > 0.0f && s < 1.0f && t > 0.0f && t < 1.0f) {
+            V3 lp1 = f1.v[i] * (1.0f - s) + f1.v[i1] * s;
+            V3 lp2_1 = a2 * (1.0f - t) + b2 * t;
+            float dist = dot(lp2_1 - lp1, best);
+            lm_push(m, lp1, pose_itp(pos12, lp2_1), f1.eid[i], 1u, dist);
+        }
+    }
+    for (int i = 0; i < m.n; ++i) {
+        m.lp2[i] = m.lp2[i] + n2 * r2; // push the segment point out to the capsule's surface
+        m.dist[i] = m.dist[i] - r2;
+        if (flipped) { V3 tp = m.lp1[i]; m.lp1[i] = m.lp2[i]; m.lp2[i] = tp; m.fid[i] = (m.fid[i] >> 16) | (m.fid[i] << 16); }
+    }
+    if (flipped) { m.ln1 = n2; m.ln2 = best; } else { m.ln1 = best; m.ln2 = n2; }
+    for (int i = 0; i < m.n; ++i)
+        for (int j = 0; j < nold; ++j)
+            if (m.fid[i] == oldfid[j]) m.src[i] = j;
+}
+#undef PERP
+
 // manifold_reduction::reduce_manifold_naive — geometry/manifold_reduction.rs:4-84
 __device__ void reduce_manifold(const LocalManifold &m, int sel[4], int &nsel, float prediction) {
     if (m.n <= 4) return;
@@ -295,6 +473,12 @@ __device__ void reduce_manifold(const LocalManifold &m, int sel[4], int &nsel, f
     if (sel[2] < 0) nsel = 2; else if (sel[2] == sel[3]) nsel = 3; else nsel = 4;
 }
 
+// max(|mins|, |maxs|) of the shape's local AABB (the recycle extent of pair_update.rs:582-613)
+RP_DEV float shape_origin_radius(int sh, float4 he) {
+    if (sh == RP_SHAPE_CUBOID) return len(v3(he));
+    if (sh == RP_SHAPE_CAPSULE) { int ax = (int)he.z; return len(v3(ax == 0 ? he.x + he.y : he.y, ax == 1 ? he.x + he.y : he.y, ax == 2 ? he.x + he.y : he.y)); }
+    return len(v3(he.x, he.x, he.x));
+}
 RP_DEV float combine_coeff(float a, float b, int ra, int rb) {
     int rule = ra > rb ? ra : rb; // coefficient_combine_rule.rs:58-86
     switch (rule) {
@@ -333,6 +517,11 @@ __device__ __noinline__ void pair_full_update(DevWorld &w, int s, int c1, int c2
     // pair_update.rs:323-330 -> parry DefaultQueryDispatcher::contact_manifolds
     if (sh1 == RP_SHAPE_CUBOID && sh2 == RP_SHAPE_CUBOID) manifold_cuboid_cuboid(pos12, v3(he1), v3(he2), prediction, m);
     else if (sh1 == RP_SHAPE_BALL && sh2 == RP_SHAPE_BALL) manifold_ball_ball(pos12, he1.x, he2.x, prediction, m);
+    else if (sh1 == RP_SHAPE_CAPSULE && sh2 == RP_SHAPE_CAPSULE) manifold_capsule_capsule(pos12, he1, he2, prediction, m);
+    else if (sh1 == RP_SHAPE_CUBOID && sh2 == RP_SHAPE_CAPSULE) manifold_cuboid_capsule(pos12, pos12, v3(he1), he2, prediction, m, false);
+    else if (sh1 == RP_SHAPE_CAPSULE && sh2 == RP_SHAPE_CUBOID) manifold_cuboid_capsule(pose_inv(pos12), pos12, v3(he2), he1, prediction, m, true);
+    else if (sh1 == RP_SHAPE_CAPSULE && sh2 == RP_SHAPE_BALL) manifold_capsule_ball(pos12, he1, he2.x, prediction, m, false);
+    else if (sh1 == RP_SHAPE_BALL && sh2 == RP_SHAPE_CAPSULE) manifold_capsule_ball(pose_inv(pos12), he2, he1.x, prediction, m, true);
     else if (sh1 == RP_SHAPE_CUBOID) manifold_cuboid_ball(pos12, v3(he1), he2.x, prediction, m, false);
     else manifold_cuboid_ball(pose_inv(pos12), v3(he2), he1.x, prediction, m, true);
 
@@ -421,8 +610,7 @@ __device__ __noinline__ void pair_full_update(DevWorld &w, int s, int c1, int c2
         float max_extent;
         if (w.p_pflags[s] & RP_PF_RECYCLE) max_extent = w.p_misc[s].y;
         else {
-            float e1 = sh1 == RP_SHAPE_CUBOID ? len(v3(he1)) : len(v3(he1.x, he1.x, he1.x));
-            float e2 = sh2 == RP_SHAPE_CUBOID ? len(v3(he2)) : len(v3(he2.x, he2.x, he2.x));
+            float e1 = shape_origin_radius(sh1, he1), e2 = shape_origin_radius(sh2, he2);
             max_extent = rp_max(e1, e2);
         }
         float max_drift = nsc > 0 ? recycle : rp_min(recycle, prediction);

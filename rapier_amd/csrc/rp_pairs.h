@@ -65,6 +65,13 @@ RP_DEV bool collider_update_one(const DevWorld &w, int i) { // true = the fat AA
     float loosen = w.prm.prediction / 2.0f;
     V3 mn = pos.t - h - v3(loosen, loosen, loosen);
     V3 mx = pos.t + h + v3(loosen, loosen, loosen);
+    if (w.c_shape[i] == RP_SHAPE_CAPSULE) { // Capsule::aabb: the transformed segment's box loosened by the radius
+        V3 e = capsule_axis_dir((int)he.z);
+        V3 pa = pose_tp(pos, e * -he.x), pb = pose_tp(pos, e * he.x);
+        V3 r = v3(he.y, he.y, he.y);
+        mn = (v3(rp_min(pa.x, pb.x), rp_min(pa.y, pb.y), rp_min(pa.z, pb.z)) - r) - v3(loosen, loosen, loosen);
+        mx = (v3(rp_max(pa.x, pb.x), rp_max(pa.y, pb.y), rp_max(pa.z, pb.z)) + r) + v3(loosen, loosen, loosen);
+    }
     float4 fmn = w.c_fatmin[i], fmx = w.c_fatmax[i];
     bool inside = fmn.x <= mn.x && fmn.y <= mn.y && fmn.z <= mn.z && fmx.x >= mx.x && fmx.y >= mx.y && fmx.z >= mx.z;
     if (!inside) {
@@ -95,6 +102,13 @@ RP_DEV bool collider_left_fat_aabb(const DevWorld &w, int i) {
     float loosen = w.prm.prediction / 2.0f;
     V3 mn = pos.t - h - v3(loosen, loosen, loosen);
     V3 mx = pos.t + h + v3(loosen, loosen, loosen);
+    if (w.c_shape[i] == RP_SHAPE_CAPSULE) { // Capsule::aabb: the transformed segment's box loosened by the radius
+        V3 e = capsule_axis_dir((int)he.z);
+        V3 pa = pose_tp(pos, e * -he.x), pb = pose_tp(pos, e * he.x);
+        V3 r = v3(he.y, he.y, he.y);
+        mn = (v3(rp_min(pa.x, pb.x), rp_min(pa.y, pb.y), rp_min(pa.z, pb.z)) - r) - v3(loosen, loosen, loosen);
+        mx = (v3(rp_max(pa.x, pb.x), rp_max(pa.y, pb.y), rp_max(pa.z, pb.z)) + r) + v3(loosen, loosen, loosen);
+    }
     float4 fmn = w.c_fatmin[i], fmx = w.c_fatmax[i];
     bool inside = fmn.x <= mn.x && fmn.y <= mn.y && fmn.z <= mn.z && fmx.x >= mx.x && fmx.y >= mx.y && fmx.z >= mx.z;
     return !inside;

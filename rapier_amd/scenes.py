@@ -15,7 +15,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 BODY_DYNAMIC, BODY_FIXED, BODY_KINEMATIC_POSITION, BODY_KINEMATIC_VELOCITY = 0, 1, 2, 3  # RigidBodyType
-SHAPE_BALL, SHAPE_CUBOID = 0, 1
+SHAPE_BALL, SHAPE_CUBOID, SHAPE_CAPSULE = 0, 1, 2  # capsule: half_extents = (half_height, radius, axis 0|1|2) = ColliderBuilder::capsule_x/y/z
 RULE_AVERAGE, RULE_MIN, RULE_MULTIPLY, RULE_MAX, RULE_CLAMPED_SUM, RULE_GEOMETRIC_MEAN = range(6)
 
 # Field-for-field mirrors of rp_body_desc / rp_collider_desc / rp_joint_desc / rp_integration_params.
@@ -586,4 +586,37 @@ def motorised_joints() -> Scene:
     for i in range(2):
         b = s.add_body(translation=(3.0, 0.5 + i, 0.0))
         s.add_collider(b, half_extents=(0.5, 0.5, 0.5))
+    return s
+
+
+def capsules(n: int = 6) -> Scene:
+    """Capsule test scene (not a reference scene): capsules lying along X and Z dropped in a criss-cross pile (capsule-capsule),
+    tilted capsules falling on the slab and on a box (cuboid-capsule, both collider orders), balls dropped on capsules
+    (capsule-ball), a compound dumbbell of a capsule and two balls."""
+    s = Scene(name=f"capsules_{n}", gravity=(0.0, -9.81, 0.0))
+    g = s.add_body(body_type=BODY_FIXED, translation=(0.0, -0.5, 0.0))
+    s.add_collider(g, half_extents=(30.0, 0.5, 30.0))
+    for i in range(n):                       # criss-cross pile
+        b = s.add_body(translation=(0.05 * i, 0.4 + 0.85 * i, -0.03 * i))
+        s.add_collider(b, shape=SHAPE_CAPSULE, half_extents=(0.9, 0.35, 0.0 if i % 2 == 0 else 2.0))
+    box = s.add_body(translation=(6.0, 0.5, 0.0))
+    s.add_collider(box, half_extents=(1.0, 0.5, 1.0))
+    for i in range(3):                       # tilted capsules: on the box (box first in the pair), on the slab, on each other
+        b = s.add_body(translation=(6.0 + 0.3 * i, 2.0 + 1.4 * i, 0.1 * i), rotation=(0.0, 0.0, 0.25881905, 0.96592583), angvel=(0.0, 0.5, 0.0))
+        s.add_collider(b, shape=SHAPE_CAPSULE, half_extents=(0.6, 0.3, 1.0))
+    cap0 = s.add_body(translation=(-6.0, 0.4, 0.0))    # a capsule inserted BEFORE a box: capsule is collider 1 of that pair
+    s.add_collider(cap0, shape=SHAPE_CAPSULE, half_extents=(1.2, 0.4, 0.0))
+    b = s.add_body(translation=(-6.0, 1.5, 0.0), rotation=(0.0, 0.38268343, 0.0, 0.92387953))
+    s.add_collider(b, half_extents=(0.5, 0.4, 0.5))
+    for i in range(2):                       # balls on capsules, both collider orders
+        b = s.add_body(translation=(-6.2 + 0.5 * i, 3.0 + i, 0.1))
+        s.add_collider(b, shape=SHAPE_BALL, half_extents=(0.3, 0.0, 0.0))
+    ball0 = s.add_body(translation=(0.0, 0.5, 6.0))
+    s.add_collider(ball0, shape=SHAPE_BALL, half_extents=(0.5, 0.0, 0.0))
+    b = s.add_body(translation=(0.1, 2.0, 6.0))
+    s.add_collider(b, shape=SHAPE_CAPSULE, half_extents=(0.7, 0.25, 2.0))
+    d = s.add_body(translation=(3.0, 3.0, 6.0), angvel=(1.0, 0.0, 2.0))     # dumbbell
+    s.add_collider(d, shape=SHAPE_CAPSULE, half_extents=(0.8, 0.15, 0.0))
+    s.add_collider(d, shape=SHAPE_BALL, half_extents=(0.35, 0.0, 0.0), translation=(0.95, 0.0, 0.0))
+    s.add_collider(d, shape=SHAPE_BALL, half_extents=(0.35, 0.0, 0.0), translation=(-0.95, 0.0, 0.0))
     return s

@@ -32,6 +32,7 @@ CASES = {
     "overlapping_chain6_s100": lambda: (S.overlapping_chain(6, 0), 100),
     "limited_joints_s150": lambda: (S.limited_joints(), 150),
     "motorised_joints_s150": lambda: (S.motorised_joints(), 150),
+    "capsules6_s150": lambda: (S.capsules(6), 150),
 }
 
 

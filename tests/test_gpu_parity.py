@@ -607,6 +607,16 @@ def test_reference_sleep_wake_scenes_bit_exact():
     _compare(sc, [1, 10, 100, 1000])
 
 
+def test_capsules_bit_exact():
+    """Capsule colliders (ColliderBuilder::capsule_x/y/z): capsule-capsule (segment-segment closest points), cuboid-capsule in
+    both collider orders (SAT against the segment, support face clipped against it), capsule-ball in both orders, capsule mass
+    properties with their principal frame, a compound dumbbell; with sleeping too."""
+    g, o = _compare(S.capsules(6), [1, 2, 10, 40, 120, 300, 600])
+    gm, _, gi = g.contacts(); om, _, oi = o.manifolds()
+    assert len(gm) == len(om)
+    _compare(S.capsules(4).enable_sleep(), [1, 30, 200, 500])
+
+
 def test_insert_joint_into_live_world_bit_exact():
     """ImpulseJointSet::insert into a stepped world (the joint arrays have no spare rows: the device world moves to larger ones
     and carries every row over): contacts keep their warm-start data and colours, the existing joints their colours and

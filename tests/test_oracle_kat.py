@@ -334,6 +334,39 @@ def test_joint_motors_reach_their_targets():
     assert w.read()[0][4, 1] - 4.0 == pytest.approx(-2.0, abs=5e-3)
 
 
+# Capsules (ColliderBuilder::capsule_x/y/z; parry MassProperties::from_capsule, Capsule::aabb, contact_manifold_capsule_capsule /
+# cuboid_capsule / convex_ball): analytic mass properties, rest heights, and the weight carried by the contacts.
+def test_capsule_mass_properties_and_rest_poses():
+    sc = S.Scene(name="caps", gravity=(0.0, -9.81, 0.0))
+    g = sc.add_body(body_type=S.BODY_FIXED, translation=(0.0, -0.5, 0.0))
+    sc.add_collider(g, half_extents=(20.0, 0.5, 20.0))
+    hh, r = 0.9, 0.35
+    lying = sc.add_body(translation=(0.0, 1.0, 0.0)); sc.add_collider(lying, shape=S.SHAPE_CAPSULE, half_extents=(hh, r, 0.0))
+    standing = sc.add_body(translation=(4.0, 2.0, 0.0)); sc.add_collider(standing, shape=S.SHAPE_CAPSULE, half_extents=(hh, r, 1.0))
+    cross = sc.add_body(translation=(0.0, 2.0, 0.0)); sc.add_collider(cross, shape=S.SHAPE_CAPSULE, half_extents=(hh, r, 2.0))  # lands across `lying`
+    ball = sc.add_body(translation=(8.0, 0.3, 0.0)); sc.add_collider(ball, shape=S.SHAPE_BALL, half_extents=(0.3, 0.0, 0.0))
+    over = sc.add_body(translation=(8.0, 1.5, 0.0)); sc.add_collider(over, shape=S.SHAPE_CAPSULE, half_extents=(0.5, 0.2, 2.0))  # balances on the ball
+    w = OracleWorld(sc)
+    cyl, sph = np.pi * r * r * 2 * hh, 4.0 / 3.0 * np.pi * r ** 3
+    i_axis = cyl * r * r / 2 + sph * 0.4 * r * r
+    i_off = cyl * (3 * r * r + 4 * hh * hh) / 12 + sph * 0.4 * r * r + sph * (hh * hh + 0.75 * hh * r)
+    for b, frame in ((lying, (0, 0, -np.sqrt(0.5), np.sqrt(0.5))), (standing, (0, 0, 0, 1)), (cross, (np.sqrt(0.5), 0, 0, np.sqrt(0.5)))):
+        mp = w.mass_props(b)
+        assert 1.0 / mp[0] == pytest.approx(cyl + sph, rel=1e-5)
+        np.testing.assert_allclose(1.0 / mp[4:7], (i_off, i_axis, i_off), rtol=1e-5)
+        np.testing.assert_allclose(mp[7:], frame, atol=1e-6)
+    w.step(300)
+    pos, vel = w.read()
+    assert pos[lying, 1] == pytest.approx(r, abs=5e-3) and pos[standing, 1] == pytest.approx(hh + r, abs=5e-3)
+    assert pos[cross, 1] == pytest.approx(3 * r, abs=1e-2)                       # resting across the lying capsule
+    assert pos[over, 1] == pytest.approx(0.6 + 0.2, abs=1e-2)                    # on top of the ball (radius 0.3)
+    assert np.abs(vel[[lying, standing]]).max() < 1e-2 and np.abs(vel[cross]).max() < 0.1   # the crossed pair balances on one contact point
+    total = w.total_contact_impulse()                                            # every body's weight reaches the ground (+ stacked ones twice)
+    m_big, m_small, m_ball = cyl + sph, np.pi * 0.04 * 1.0 + 4.0 / 3.0 * np.pi * 0.008, 4.0 / 3.0 * np.pi * 0.027
+    expected = (m_big * 2 + m_big * 2 + (m_ball + m_small) + m_small) * 9.81 / 60.0
+    assert total == pytest.approx(expected, rel=0.03)
+
+
 # Events (pipeline/event_handler.rs:94-160): Started / Stopped on touching transitions, contact force events above the
 # threshold with `started` on the first step above it (geometry/mod.rs:223-258).
 def test_collision_and_contact_force_events():

@@ -713,7 +713,7 @@ def test_moved_fixed_anchor_takes_its_joint_along():
 
 @pytest.mark.parametrize("n", [8, 128])
 def test_joints_respect_offset_center_of_mass(n):
-    """issue_952 (cuboid instead of capsule_x): pendulums whose collider — hence centre of mass — sits 1.0 off the body
+    """issue_952: pendulums whose capsule_x(1.0, 0.2) collider — hence centre of mass — sits 1.0 off the body
     origin the revolute joint is anchored at; 128 of them fill a parallel joint colour (>= 64 joints).  The anchor never
     strays more than 1e-2 from its base."""
     sc = world()
@@ -721,7 +721,7 @@ def test_joints_respect_offset_center_of_mass(n):
     for i in range(n):
         base = sc.add_body(body_type=S.BODY_FIXED, translation=(i * 20.0, 0.0, 0.0))
         b = sc.add_body(translation=(i * 20.0, 0.0, 0.0))
-        sc.add_collider(b, half_extents=(1.2, 0.2, 0.2), translation=(1.0, 0.0, 0.0))
+        sc.add_collider(b, shape=S.SHAPE_CAPSULE, half_extents=(1.0, 0.2, 0.0), translation=(1.0, 0.0, 0.0))
         sc.add_joint(base, b, (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), locked_axes=S.LOCK_REVOLUTE, basis1=S.AXIS_Z_BASIS, basis2=S.AXIS_Z_BASIS, contacts_enabled=0)
         bodies.append(b)
     w = OracleWorld(sc)
