@@ -322,7 +322,11 @@ RP_DEV bool isl_generate(const DevWorld &w, IslSide &h, const IslLds &L, int m, 
     h.sdim = odd ? -dim : dim;
     h.k12 = r[2] * 0.5f;
     h.inv_det = rp_inv(h.k11 * h.k22 - h.k12 * h.k12);
-    bool is_static = lid < 0 || dppi<DPP_FROM_ODD>(lid) < 0 || dppi<DPP_FROM_EVEN>(lid) < 0;
+    // both cross-lane reads run on every lane BEFORE they are combined: inside a short-circuit `||` the lane whose own side is
+    // world-attached would leave the expression early and its neighbour's DPP read of an inactive lane returns garbage (seen
+    // with a dominated body on the odd side; a fixed body always sits on the even side, which keeps the scalars)
+    const int lid_odd = dppi<DPP_FROM_ODD>(lid), lid_even = dppi<DPP_FROM_EVEN>(lid);
+    bool is_static = (lid < 0) | (lid_odd < 0) | (lid_even < 0);
     float fstatic = is_static ? 1.0f : 0.0f;
     h.cfm_factor = w.prm.dyn_cfm + fstatic * (w.prm.static_cfm - w.prm.dyn_cfm);
     h.erp_inv_dt = w.prm.dyn_erp_inv_dt + fstatic * (w.prm.static_erp_inv_dt - w.prm.dyn_erp_inv_dt);

@@ -1,0 +1,183 @@
+"""Randomised differential test (GPU, through the C ABI, vs the oracle): seeded scenes mixing every implemented feature — the three
+shapes, compound bodies, kinematic bodies, locked axes, sleeping, restitution / friction rules, collision groups, all joint kinds
+with limits and motors, events, both friction models, joint warm start — driven by random user actions (impulses, velocity and
+pose writes, wake-ups, body / collider / joint removal, body and joint insertion, motor changes).  State, sleeping flags and drained
+events must match bit for bit all along."""
+import numpy as np
+import pytest
+
+from rapier_amd import PhysicsWorld, scenes as S
+from oracle_ffi import OracleWorld, lib
+
+import os
+
+pytestmark = pytest.mark.gpu
+SEEDS = list(range(int(os.environ.get("RP_FUZZ_FIRST", "0")), int(os.environ.get("RP_FUZZ_LAST", "16"))))
+
+
+def _rand_quat(rng):
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    return tuple(float(x) for x in q)
+
+
+def _rand_collider(rng, scale=1.0):
+    kind = rng.integers(0, 3)
+    kw = dict(density=float(rng.uniform(0.5, 3.0)), friction=float(rng.choice([0.0, 0.3, 0.5, 1.0])),
+              restitution=float(rng.choice([0.0, 0.0, 0.3, 0.8])), friction_rule=int(rng.integers(0, 6)), restitution_rule=int(rng.integers(0, 6)))
+    if kind == 0:
+        return dict(shape=S.SHAPE_BALL, half_extents=(float(rng.uniform(0.2, 0.5)) * scale, 0.0, 0.0), **kw)
+    if kind == 1:
+        return dict(shape=S.SHAPE_CUBOID, half_extents=tuple(float(x) * scale for x in rng.uniform(0.15, 0.6, size=3)), **kw)
+    return dict(shape=S.SHAPE_CAPSULE, half_extents=(float(rng.uniform(0.2, 0.6)) * scale, float(rng.uniform(0.15, 0.35)) * scale, float(rng.integers(0, 3))), **kw)
+
+
+def _rand_joint(rng, sc, b1, b2, p1, p2):
+    """a joint whose two anchors coincide in world space at the midpoint of the two bodies (unrotated bodies only)"""
+    mid = (np.asarray(p1) + np.asarray(p2)) / 2
+    a1, a2 = tuple(float(x) for x in mid - p1), tuple(float(x) for x in mid - p2)
+    kind = rng.integers(0, 5)
+    limits, motors = None, None
+    if kind == 0:
+        locked = S.LOCK_LIN
+        if rng.random() < 0.5:
+            motors = {3 + int(rng.integers(0, 3)): dict(target_pos=float(rng.uniform(-0.5, 0.5)), stiffness=40.0, damping=4.0)}
+    elif kind == 1:
+        locked = S.LOCK_REVOLUTE
+        if rng.random() < 0.6:
+            limits = {3: (-float(rng.uniform(0.2, 1.5)), float(rng.uniform(0.2, 1.5)))}
+        if rng.random() < 0.6:
+            motors = {3: dict(target_vel=float(rng.uniform(-3, 3)), damping=float(rng.uniform(1, 20)), max_force=float(rng.choice([S.F32_MAX, 5.0, 50.0])))}
+    elif kind == 2:
+        locked = S.LOCK_PRISMATIC
+        limits = {0: (-float(rng.uniform(0.1, 1.0)), float(rng.uniform(0.1, 1.0)))}
+        if rng.random() < 0.5:
+            motors = {0: dict(target_pos=float(rng.uniform(-0.5, 0.5)), stiffness=200.0, damping=20.0, max_force=float(rng.choice([S.F32_MAX, 30.0])),
+                              model=int(rng.integers(0, 2)))}
+    elif kind == 3:
+        locked = S.LOCK_ALL
+    else:
+        locked = int(rng.integers(1, 64))                        # any mask of locked axes
+        free = [a for a in range(6) if not locked & (1 << a)]
+        if free and rng.random() < 0.5:
+            a = int(rng.choice(free))
+            limits = {a: (-0.4, 0.6)}
+    basis = _rand_quat(rng) if rng.random() < 0.5 else (0.0, 0.0, 0.0, 1.0)
+    return sc.add_joint(b1, b2, a1, a2, locked_axes=locked, contacts_enabled=int(rng.random() < 0.7), basis1=basis, basis2=basis, limits=limits, motors=motors)
+
+
+def _scene(seed):
+    rng = np.random.default_rng(seed)
+    sc = S.Scene(name=f"fuzz{seed}", gravity=(0.0, -9.81, 0.0))
+    sc.params["friction_model"] = S.FRICTION_COULOMB if seed % 4 == 3 else S.FRICTION_SIMPLIFIED
+    sc.params["warmstart_joints"] = int(seed % 3 == 1)
+    g = sc.add_body(body_type=S.BODY_FIXED, translation=(0.0, -0.5, 0.0))
+    sc.add_collider(g, half_extents=(12.0, 0.5, 12.0), friction=0.6, active_events=3 if seed % 2 else 0, contact_force_event_threshold=40.0)
+    for k in range(3):                                            # fixed obstacles
+        f = sc.add_body(body_type=S.BODY_FIXED, translation=(float(rng.uniform(-4, 4)), 0.4, float(rng.uniform(-4, 4))), rotation=_rand_quat(rng))
+        sc.add_collider(f, **_rand_collider(rng, 1.5))
+    plat = sc.add_body(body_type=S.BODY_KINEMATIC_VELOCITY, translation=(-3.0, 0.2, 3.0), linvel=(0.3, 0.0, -0.2), angvel=(0.0, 0.4, 0.0), can_sleep=1)
+    sc.add_collider(plat, half_extents=(1.5, 0.2, 1.5), friction=1.0)
+    n = 40
+    pos = []
+    for i in range(n):
+        p = (float(rng.uniform(-3.5, 3.5)), float(1.0 + 0.9 * (i // 4) + rng.uniform(0, 0.3)), float(rng.uniform(-3.5, 3.5)))
+        unrot = i % 3 == 0
+        b = sc.add_body(translation=p, rotation=(0.0, 0.0, 0.0, 1.0) if unrot else _rand_quat(rng),
+                        linvel=tuple(float(x) for x in rng.uniform(-1, 1, size=3)), angvel=tuple(float(x) for x in rng.uniform(-2, 2, size=3)),
+                        can_sleep=int(rng.random() < 0.8), linear_damping=float(rng.choice([0.0, 0.0, 0.2])), angular_damping=float(rng.choice([0.0, 0.1, 1.0])),
+                        gravity_scale=float(rng.choice([1.0, 1.0, 0.5])), additional_mass=float(rng.choice([0.0, 0.0, 2.0])),
+                        dominance=int(rng.choice([0, 0, 0, 1])), gyroscopic=int(rng.random() < 0.8),
+                        locked_axes=int(rng.choice([0, 0, 0, 0x38, 0x02, 0x15])))
+        c = _rand_collider(rng)
+        sc.add_collider(b, active_events=int(rng.choice([0, 0, 1, 3])), contact_force_event_threshold=float(rng.choice([0.0, 20.0])),
+                        memberships=int(rng.choice([0xFFFFFFFF, 0xFFFFFFFF, 0x1])), filter=int(rng.choice([0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFE])), **c)
+        if rng.random() < 0.25:                                   # compound body
+            sc.add_collider(b, translation=tuple(float(x) for x in rng.uniform(-0.5, 0.5, size=3)), rotation=_rand_quat(rng), **_rand_collider(rng, 0.7))
+        pos.append((b, p, unrot))
+    unrot = [(b, p) for b, p, u in pos if u]
+    for k in range(0, len(unrot) - 1, 2):                         # joints between unrotated neighbours
+        (b1, p1), (b2, p2) = unrot[k], unrot[k + 1]
+        _rand_joint(rng, sc, b1, b2, np.array(p1), np.array(p2))
+    (b1, p1) = unrot[-1]
+    sc.add_joint(g, b1, tuple(float(x) for x in (np.array(p1) + (0, 0.5, 0) - (0.0, -0.5, 0.0))), (0.0, 0.5, 0.0), locked_axes=S.LOCK_LIN)   # a pendulum on the ground body
+    return sc, rng
+
+
+def _check(g, o, alive, msg):
+    gp, gv = g.read_bodies(); op, ov = o.read()
+    np.testing.assert_array_equal(gp[alive], op[alive], err_msg=msg + " poses")
+    np.testing.assert_array_equal(gv[alive], ov[alive], err_msg=msg + " velocities")
+    np.testing.assert_array_equal(g.sleeping()[alive], o.sleeping()[alive], err_msg=msg + " sleeping")
+    gc = g.collision_events(); oc = o.collision_events()
+    key = lambda e: (int(e[4]), int(e[0]), int(e[1]), int(e[2]))
+    assert sorted(map(key, gc)) == sorted(map(key, oc)), msg + " collision events"
+    gm, gvv = g.contact_force_events(); om, ovv = o.force_events()
+    assert len(gm) == len(om), msg + " force event count"
+    if len(gm):
+        gi = np.lexsort((gm[:, 1], gm[:, 0], gm[:, 2])); oi = np.lexsort((om[:, 1], om[:, 0], om[:, 2]))
+        np.testing.assert_array_equal(gm[gi], om[oi], err_msg=msg + " force event meta")
+        np.testing.assert_array_equal(gvv[gi], ovv[oi], err_msg=msg + " force event values")
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_fuzz_bit_exact(seed):
+    sc, rng = _scene(seed)
+    g, o = PhysicsWorld.from_scene(sc), OracleWorld(sc)
+    nb0 = len(sc.bodies)
+    dyn = [i for i, b in enumerate(sc.bodies) if int(b["body_type"]) == S.BODY_DYNAMIC]
+    alive = list(range(nb0))
+    jb = {j: (int(sc.joints[j]["body1"]), int(sc.joints[j]["body2"])) for j in range(len(sc.joints))}   # live joints -> their bodies
+    for step in range(1, 241):
+        if step % 7 == 0:                                         # a random user action
+            act = int(rng.integers(0, 9))
+            live_dyn = [b for b in dyn if b in alive]
+            b = int(rng.choice(live_dyn))
+            if act == 0:
+                imp = rng.uniform(-3, 3, size=3).astype(np.float32)
+                g.apply_impulse([b], impulse=[imp]); o.apply_impulse(b, impulse=imp)
+            elif act == 1:
+                v = rng.uniform(-2, 2, size=6).astype(np.float32)
+                g.write_bodies([b], vel6=[v]); o.set_vel(b, v[:3], v[3:])
+            elif act == 2:
+                p = np.array([rng.uniform(-3, 3), rng.uniform(2, 6), rng.uniform(-3, 3), 0, 0, 0, 1], np.float32)
+                g.write_bodies([b], pos7=[p]); o.set_pose(b, p)
+            elif act == 3:
+                g.wake_up([b]); o.wake_up(b)
+            elif act == 4 and len(live_dyn) > 10:
+                g.remove_body(b); o.remove_body(b); alive.remove(b)
+                jb = {j: bb for j, bb in jb.items() if b not in bb}       # RigidBodySet::remove takes the attached joints along
+            elif act == 5:
+                body = S.body_desc(translation=(float(rng.uniform(-2, 2)), float(rng.uniform(4, 7)), float(rng.uniform(-2, 2))), rotation=_rand_quat(rng), can_sleep=1)
+                col = S.collider_desc(**_rand_collider(rng))
+                hb = g.insert_body(body); g.insert_collider(col, hb)
+                ob = lib().ro_add_body(o._w, np.array([body], S.BODY_DTYPE).ctypes.data); o.n += 1
+                lib().ro_add_collider(o._w, np.array([col], S.COLLIDER_DTYPE).ctypes.data, ob)
+                assert int(hb) & 0xFFFFFFFF == ob
+                alive.append(ob); dyn.append(ob)
+            elif act == 6 and jb:
+                j = int(rng.choice(sorted(jb)))
+                g.remove_impulse_joint(j); o.remove_joint(j); del jb[j]
+            elif act == 7 and len(live_dyn) > 2:
+                b2 = int(rng.choice([x for x in live_dyn if x != b]))
+                jd = np.zeros((), S.JOINT_DTYPE)
+                jd["body1"], jd["body2"] = b, b2
+                jd["local_anchor1"], jd["local_anchor2"] = (0.0, 0.5, 0.0), (0.0, -0.5, 0.0)
+                jd["local_basis1"] = jd["local_basis2"] = (0, 0, 0, 1)
+                jd["locked_axes"], jd["contacts_enabled"] = S.LOCK_LIN, int(rng.random() < 0.5)
+                for k in range(6):
+                    jd["motors"][k] = S.motor_desc()
+                hj = g.insert_impulse_joint(b, b2, jd)
+                oj = lib().ro_add_joint(o._w, np.array([jd], S.JOINT_DTYPE).ctypes.data)
+                assert hj == oj
+                jb[hj] = (b, b2)
+            elif act == 8 and jb:
+                j = int(rng.choice(sorted(jb)))
+                kw = dict(target_vel=float(rng.uniform(-2, 2)), damping=float(rng.uniform(1, 10)))
+                axis = int(rng.integers(0, 6))
+                g.set_joint_motor(j, axis, **kw); o.set_joint_motor(j, axis, **kw)
+        g.step(1); o.step(1)
+        if step % 10 == 0 or step < 4:
+            _check(g, o, alive, f"seed {seed} step {step}")
+    c = g.counters()
+    assert c["overflow_flags"] == 0
