@@ -66,7 +66,7 @@ def _rand_joint(rng, sc, b1, b2, p1, p2):
     return sc.add_joint(b1, b2, a1, a2, locked_axes=locked, contacts_enabled=int(rng.random() < 0.7), basis1=basis, basis2=basis, limits=limits, motors=motors)
 
 
-def _scene(seed):
+def _scene(seed, n=40, spread=3.5, per_layer=4, calm=False):
     rng = np.random.default_rng(seed)
     sc = S.Scene(name=f"fuzz{seed}", gravity=(0.0, -9.81, 0.0))
     sc.params["friction_model"] = S.FRICTION_COULOMB if seed % 4 == 3 else S.FRICTION_SIMPLIFIED
@@ -78,10 +78,14 @@ def _scene(seed):
         sc.add_collider(f, **_rand_collider(rng, 1.5))
     plat = sc.add_body(body_type=S.BODY_KINEMATIC_VELOCITY, translation=(-3.0, 0.2, 3.0), linvel=(0.3, 0.0, -0.2), angvel=(0.0, 0.4, 0.0), can_sleep=1)
     sc.add_collider(plat, half_extents=(1.5, 0.2, 1.5), friction=1.0)
-    n = 40
     pos = []
     for i in range(n):
-        p = (float(rng.uniform(-3.5, 3.5)), float(1.0 + 0.9 * (i // 4) + rng.uniform(0, 0.3)), float(rng.uniform(-3.5, 3.5)))
+        p = (float(rng.uniform(-spread, spread)), float(1.0 + 0.9 * (i // per_layer) + rng.uniform(0, 0.3)), float(rng.uniform(-spread, spread)))
+        if calm:                                                   # a jittered, non-overlapping grid: the bodies rain into a pile
+            side = int(np.ceil(np.sqrt(per_layer)))
+            k = i % per_layer
+            cell = 2.0 * spread / side
+            p = (float(-spread + (k % side + 0.5) * cell + rng.uniform(-0.05, 0.05)), float(0.8 + 0.75 * (i // per_layer)), float(-spread + (k // side + 0.5) * cell + rng.uniform(-0.05, 0.05)))
         unrot = i % 3 == 0
         b = sc.add_body(translation=p, rotation=(0.0, 0.0, 0.0, 1.0) if unrot else _rand_quat(rng),
                         linvel=tuple(float(x) for x in rng.uniform(-1, 1, size=3)), angvel=tuple(float(x) for x in rng.uniform(-2, 2, size=3)),
@@ -89,14 +93,14 @@ def _scene(seed):
                         gravity_scale=float(rng.choice([1.0, 1.0, 0.5])), additional_mass=float(rng.choice([0.0, 0.0, 2.0])),
                         dominance=int(rng.choice([0, 0, 0, 1])), gyroscopic=int(rng.random() < 0.8),
                         locked_axes=int(rng.choice([0, 0, 0, 0x38, 0x02, 0x15])))
-        c = _rand_collider(rng)
+        c = _rand_collider(rng, 0.55 if calm else 1.0)
         sc.add_collider(b, active_events=int(rng.choice([0, 0, 1, 3])), contact_force_event_threshold=float(rng.choice([0.0, 20.0])),
                         memberships=int(rng.choice([0xFFFFFFFF, 0xFFFFFFFF, 0x1])), filter=int(rng.choice([0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFE])), **c)
-        if rng.random() < 0.25:                                   # compound body
+        if rng.random() < 0.25 and not calm:                      # compound body
             sc.add_collider(b, translation=tuple(float(x) for x in rng.uniform(-0.5, 0.5, size=3)), rotation=_rand_quat(rng), **_rand_collider(rng, 0.7))
         pos.append((b, p, unrot))
     unrot = [(b, p) for b, p, u in pos if u]
-    for k in range(0, len(unrot) - 1, 2):                         # joints between unrotated neighbours
+    for k in range(0, (0 if calm else len(unrot) - 1), 2):                         # joints between unrotated neighbours
         (b1, p1), (b2, p2) = unrot[k], unrot[k + 1]
         _rand_joint(rng, sc, b1, b2, np.array(p1), np.array(p2))
     (b1, p1) = unrot[-1]
@@ -120,15 +124,29 @@ def _check(g, o, alive, msg):
         np.testing.assert_array_equal(gvv[gi], ovv[oi], err_msg=msg + " force event values")
 
 
+@pytest.mark.parametrize("seed", [1000, 1001, 1002])
+def test_fuzz_pile_bit_exact(seed):
+    """the same generator at 600 bodies dropped into a walled pit: one giant island on the global multi-kernel path (> 1024
+    manifolds, parallel colour stages + serial tail), islands around it on the LDS path"""
+    _run(seed, steps=260, n=700, spread=2.2, per_layer=49, walls=True, calm=True)
+
+
 @pytest.mark.parametrize("seed", SEEDS)
 def test_fuzz_bit_exact(seed):
-    sc, rng = _scene(seed)
+    _run(seed)
+
+
+def _run(seed, steps=240, walls=False, **kw):
+    sc, rng = _scene(seed, **kw)
+    if walls:
+        for k, (x, z, hx, hz) in enumerate(((3.2, 0, 0.3, 3.5), (-3.2, 0, 0.3, 3.5), (0, 3.2, 3.5, 0.3), (0, -3.2, 3.5, 0.3))):
+            sc.add_collider(0, half_extents=(hx, 6.0, hz), translation=(x, 6.5, z))
     g, o = PhysicsWorld.from_scene(sc), OracleWorld(sc)
     nb0 = len(sc.bodies)
     dyn = [i for i, b in enumerate(sc.bodies) if int(b["body_type"]) == S.BODY_DYNAMIC]
     alive = list(range(nb0))
     jb = {j: (int(sc.joints[j]["body1"]), int(sc.joints[j]["body2"])) for j in range(len(sc.joints))}   # live joints -> their bodies
-    for step in range(1, 241):
+    for step in range(1, steps + 1):
         if step % 7 == 0:                                         # a random user action
             act = int(rng.integers(0, 9))
             live_dyn = [b for b in dyn if b in alive]
