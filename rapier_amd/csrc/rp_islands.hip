@@ -213,7 +213,7 @@ struct IslSide {
 // meet through DPP, the even lane keeps the scalars.  `gid` / `lid` = the lane's own body as arena
 // index / island-local index (-1 = world-attached side).  Returns true on the even lane when a
 // restitution seed is armed.
-RP_DEV bool isl_generate(const DevWorld &w, IslSide &h, const IslLds &L, int m, int s, int gid, int lid, bool odd) {
+RP_DEV bool isl_generate(const DevWorld &w, IslSide &h, const IslLds &L, int m, int s, int gid, int lid, bool odd, bool is_static) {
     h.odd = odd; h.id = lid;
     Vel vels = isl_vel(L, lid);
     Xf pose = isl_xf(L, lid);
@@ -322,11 +322,8 @@ RP_DEV bool isl_generate(const DevWorld &w, IslSide &h, const IslLds &L, int m, 
     h.sdim = odd ? -dim : dim;
     h.k12 = r[2] * 0.5f;
     h.inv_det = rp_inv(h.k11 * h.k22 - h.k12 * h.k12);
-    // both cross-lane reads run on every lane BEFORE they are combined: inside a short-circuit `||` the lane whose own side is
-    // world-attached would leave the expression early and its neighbour's DPP read of an inactive lane returns garbage (seen
-    // with a dominated body on the odd side; a fixed body always sits on the even side, which keeps the scalars)
-    const int lid_odd = dppi<DPP_FROM_ODD>(lid), lid_even = dppi<DPP_FROM_EVEN>(lid);
-    bool is_static = (lid < 0) | (lid_odd < 0) | (lid_even < 0);
+    // is_static (a world-attached side on either lane) comes from the island's side tables: no cross-lane read, hence no hazard
+    // when the two lanes of the pair disagree on it (a dominated body may sit on the odd side, a fixed body is always even)
     float fstatic = is_static ? 1.0f : 0.0f;
     h.cfm_factor = w.prm.dyn_cfm + fstatic * (w.prm.static_cfm - w.prm.dyn_cfm);
     h.erp_inv_dt = w.prm.dyn_erp_inv_dt + fstatic * (w.prm.static_erp_inv_dt - w.prm.dyn_erp_inv_dt);
@@ -697,9 +694,12 @@ __global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int ha
         const int nls = w.isl_nstages[isl];
         const bool live = m < nc;
         int slot = -1, myq = -1, own_g = -1, own_l = -1, ws_row = 0;
+        bool pair_static = false;
         if (live) {
             slot = w.isl_cons[cb + m]; myq = w.isl_cstage[cb + m];
-            own_g = (odd ? w.isl_cg2 : w.isl_cg1)[cb + m]; own_l = (odd ? w.isl_cl2 : w.isl_cl1)[cb + m];
+            const int l1 = w.isl_cl1[cb + m], l2 = w.isl_cl2[cb + m];
+            own_g = (odd ? w.isl_cg2 : w.isl_cg1)[cb + m]; own_l = odd ? l2 : l1;
+            pair_static = l1 < 0 || l2 < 0;
             ws_row = w.isl_inc_pos[2 * cb + t];
         }
         int inc_begin = 0, inc_cnt = 0;
@@ -710,7 +710,7 @@ __global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int ha
         h.n = 0; h.id = -1; h.odd = odd; h.cids = 0;
         // ---- generate (S1) by the lane pair, pose stage for the initial poses ----
         if (live) {
-            if (isl_generate(w, h, L, m, slot, own_g, own_l, odd) && !odd) any_bouncy = 1;
+            if (isl_generate(w, h, L, m, slot, own_g, own_l, odd, pair_static) && !odd) any_bouncy = 1;
         }
         const int v_first = (2 * nc + 63) & ~63; // first wavefront without any manifold lane
         if (fused && isl == (int)blockIdx.x && t >= v_first) {

@@ -45,6 +45,15 @@ RP_DEV Pose collider_world_pose(const DevWorld &w, int i) {
 // Collider world pose + fat AABB maintenance (BroadPhaseBvh::set_aabb; advance_to_final_positions
 // substep.rs:103-119).  One thread per collider.  Runs at the START of a step (the reference runs it
 // at the end of the previous one; nothing reads collider poses in between).
+// Capsule::aabb: the transformed segment's box loosened by the radius (then by the collision margin).  Kept out of line: the
+// cuboid / ball worlds of the hot kernels (k_island_solve validates fat AABBs in its idle lanes) must not pay for it.
+__device__ __noinline__ void capsule_collision_aabb(Pose pos, float4 he, float loosen, V3 &mn, V3 &mx) {
+    V3 e = capsule_axis_dir((int)he.z);
+    V3 pa = pose_tp(pos, e * -he.x), pb = pose_tp(pos, e * he.x);
+    V3 r = v3(he.y, he.y, he.y);
+    mn = (v3(rp_min(pa.x, pb.x), rp_min(pa.y, pb.y), rp_min(pa.z, pb.z)) - r) - v3(loosen, loosen, loosen);
+    mx = (v3(rp_max(pa.x, pb.x), rp_max(pa.y, pb.y), rp_max(pa.z, pb.z)) + r) + v3(loosen, loosen, loosen);
+}
 RP_DEV bool collider_update_one(const DevWorld &w, int i) { // true = the fat AABB was rewritten
     Pose pos = collider_world_pose(w, i);
     bool finite = isfinite(pos.t.x) && isfinite(pos.t.y) && isfinite(pos.t.z) && isfinite(pos.r.x) && isfinite(pos.r.y) &&
@@ -65,13 +74,7 @@ RP_DEV bool collider_update_one(const DevWorld &w, int i) { // true = the fat AA
     float loosen = w.prm.prediction / 2.0f;
     V3 mn = pos.t - h - v3(loosen, loosen, loosen);
     V3 mx = pos.t + h + v3(loosen, loosen, loosen);
-    if (w.c_shape[i] == RP_SHAPE_CAPSULE) { // Capsule::aabb: the transformed segment's box loosened by the radius
-        V3 e = capsule_axis_dir((int)he.z);
-        V3 pa = pose_tp(pos, e * -he.x), pb = pose_tp(pos, e * he.x);
-        V3 r = v3(he.y, he.y, he.y);
-        mn = (v3(rp_min(pa.x, pb.x), rp_min(pa.y, pb.y), rp_min(pa.z, pb.z)) - r) - v3(loosen, loosen, loosen);
-        mx = (v3(rp_max(pa.x, pb.x), rp_max(pa.y, pb.y), rp_max(pa.z, pb.z)) + r) + v3(loosen, loosen, loosen);
-    }
+    if (w.c_shape[i] == RP_SHAPE_CAPSULE) capsule_collision_aabb(pos, he, loosen, mn, mx);
     float4 fmn = w.c_fatmin[i], fmx = w.c_fatmax[i];
     bool inside = fmn.x <= mn.x && fmn.y <= mn.y && fmn.z <= mn.z && fmx.x >= mx.x && fmx.y >= mx.y && fmx.z >= mx.z;
     if (!inside) {
@@ -102,13 +105,7 @@ RP_DEV bool collider_left_fat_aabb(const DevWorld &w, int i) {
     float loosen = w.prm.prediction / 2.0f;
     V3 mn = pos.t - h - v3(loosen, loosen, loosen);
     V3 mx = pos.t + h + v3(loosen, loosen, loosen);
-    if (w.c_shape[i] == RP_SHAPE_CAPSULE) { // Capsule::aabb: the transformed segment's box loosened by the radius
-        V3 e = capsule_axis_dir((int)he.z);
-        V3 pa = pose_tp(pos, e * -he.x), pb = pose_tp(pos, e * he.x);
-        V3 r = v3(he.y, he.y, he.y);
-        mn = (v3(rp_min(pa.x, pb.x), rp_min(pa.y, pb.y), rp_min(pa.z, pb.z)) - r) - v3(loosen, loosen, loosen);
-        mx = (v3(rp_max(pa.x, pb.x), rp_max(pa.y, pb.y), rp_max(pa.z, pb.z)) + r) + v3(loosen, loosen, loosen);
-    }
+    if (w.c_shape[i] == RP_SHAPE_CAPSULE) capsule_collision_aabb(pos, he, loosen, mn, mx);
     float4 fmn = w.c_fatmin[i], fmx = w.c_fatmax[i];
     bool inside = fmn.x <= mn.x && fmn.y <= mn.y && fmn.z <= mn.z && fmx.x >= mx.x && fmx.y >= mx.y && fmx.z >= mx.z;
     return !inside;
