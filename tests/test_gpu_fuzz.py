@@ -136,8 +136,40 @@ def test_fuzz_bit_exact(seed):
     _run(seed)
 
 
-def _run(seed, steps=240, walls=False, **kw):
+def _random_params(sc, rng):
+    """IntegrationParameters away from their defaults: substep count, inner PGS / stabilisation sweeps, warm-start coefficient,
+    contact recycling, friction in the bias pass, time step, softness, correction limits, length unit"""
+    p = sc.params
+    p["num_solver_iterations"] = int(rng.choice([1, 2, 3, 4, 6]))
+    p["num_internal_pgs_iterations"] = int(rng.choice([1, 1, 2, 3]))
+    p["num_internal_stabilization_iterations"] = int(rng.choice([0, 1, 1, 2]))
+    p["warmstart_coefficient"] = float(rng.choice([1.0, 1.0, 0.5, 0.0]))
+    p["contact_recycling"] = int(rng.random() < 0.7)
+    p["friction_in_bias_pass"] = int(rng.random() < 0.3)
+    p["dt"] = float(rng.choice([1.0 / 60.0, 1.0 / 120.0, 0.016, 1.0 / 30.0]))
+    p["contact_natural_frequency"] = float(rng.choice([30.0, 20.0, 60.0]))
+    p["static_contact_natural_frequency"] = float(rng.choice([60.0, 30.0, 90.0]))
+    p["contact_damping_ratio"] = float(rng.choice([10.0, 5.0, 1.0]))
+    p["joint_natural_frequency"] = float(rng.choice([1.0e6, 50.0]))
+    p["joint_damping_ratio"] = float(rng.choice([1.0, 0.5]))
+    p["normalized_max_corrective_velocity"] = float(rng.choice([3.0, 1.0, 10.0]))
+    p["normalized_prediction_distance"] = float(rng.choice([0.02, 0.05, 0.002]))
+    p["normalized_allowed_linear_error"] = float(rng.choice([0.005, 0.001]))
+    p["normalized_max_linear_velocity"] = float(rng.choice([400.0, 20.0]))
+    p["normalized_contact_recycle_distance"] = float(rng.choice([0.05, 0.01]))
+    p["length_unit"] = float(rng.choice([1.0, 1.0, 2.0]))
+
+
+@pytest.mark.parametrize("seed", list(range(2000, 2016)))
+def test_fuzz_params_bit_exact(seed):
+    """the same scenes and actions under randomised IntegrationParameters"""
+    _run(seed, steps=160, params=True)
+
+
+def _run(seed, steps=240, walls=False, params=False, **kw):
     sc, rng = _scene(seed, **kw)
+    if params:
+        _random_params(sc, rng)
     if walls:
         for k, (x, z, hx, hz) in enumerate(((3.2, 0, 0.3, 3.5), (-3.2, 0, 0.3, 3.5), (0, 3.2, 3.5, 0.3), (0, -3.2, 3.5, 0.3))):
             sc.add_collider(0, half_extents=(hx, 6.0, hz), translation=(x, 6.5, z))
