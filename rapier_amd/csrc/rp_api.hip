@@ -133,6 +133,7 @@ static std::vector<unsigned long long> no_contact_keys(const rp_world *w);
 static int check_sleep_scope(rp_world *w);
 static int rebuild_begin(rp_world *w);
 static int grow_begin(rp_world *w);
+static int refresh_joint_frames(rp_world *w, int b);
 static int carry_over(rp_world *w);
 static int queue_wake(rp_world *w, int b, int lvl);
 static int finalize(rp_world *w);
@@ -631,6 +632,7 @@ extern "C" int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider
         if (in_place) {
             int r = upload_collider_row(w, (int)w->colliders.size() - 1);
             if (r == RP_OK && parent >= 0) r = upload_body_row_mass(w, parent);
+            if (r == RP_OK && parent >= 0) r = refresh_joint_frames(w, parent); // the local centre of mass moved
             if (r == RP_OK && parent >= 0 && w->bodies[parent].d.body_type == RP_BODY_DYNAMIC) { int ci = (int)w->colliders.size() - 1; HIPCHK(w, hipMemcpy(w->dw.b_collider + parent, &ci, sizeof(int), hipMemcpyHostToDevice)); }
             if (r != RP_OK) return r;
         }
@@ -753,6 +755,27 @@ static ColliderRow pack_collider(const rp_world *w, int i) {
     int ev = (int)(c.active_events & 3u); memcpy(&o.events.x, &ev, sizeof(int)); o.events.y = c.contact_force_event_threshold;
     return o;
 }
+// GenericJoint::transform_to_solver_body_space for the joints of body b after its local centre of mass changed (a collider was
+// attached or removed): the frame of a non-fixed side lives in CoM space, local_frame.t - local_com
+static int refresh_joint_frames(rp_world *w, int b) {
+    if (!w->finalized || w->bodies[b].d.body_type == RP_BODY_FIXED) return RP_OK;
+    const HostBody &hb = w->bodies[b];
+    for (int k = 0; k < (int)w->active_joint_ids.size(); ++k) {
+        int ji = w->active_joint_ids[k];
+        const rp_joint_desc &jd = w->joints[ji];
+        if (w->joint_removed[ji] || (jd.body1 != b && jd.body2 != b)) continue;
+        int r;
+        if (jd.body1 == b) {
+            Pose f = joint_local_frame(jd.local_anchor1, jd.local_basis1); f.t = f.t - v3(hb.lcom[0], hb.lcom[1], hb.lcom[2]);
+            if ((r = poke(w, w->dw.j_f1t + k, mk4(f.t.x, f.t.y, f.t.z, 0))) != RP_OK) return r;
+        }
+        if (jd.body2 == b) {
+            Pose f = joint_local_frame(jd.local_anchor2, jd.local_basis2); f.t = f.t - v3(hb.lcom[0], hb.lcom[1], hb.lcom[2]);
+            if ((r = poke(w, w->dw.j_f2t + k, mk4(f.t.x, f.t.y, f.t.z, 0))) != RP_OK) return r;
+        }
+    }
+    return RP_OK;
+}
 static int upload_body_row_mass(rp_world *w, int i) { // mass properties only (a collider was attached / removed)
     const DevWorld &d = w->dw;
     BodyRow r = pack_body(w->bodies[i]);
@@ -863,7 +886,10 @@ static int finalize(rp_world *w) {
     int nb = (int)w->bodies.size(), nc = (int)w->colliders.size();
     d.n_bodies = nb; d.n_colliders = nc;
     // capacities leave room for bodies / colliders inserted later without rebuilding the device world
-    const int capb = nb + nb / 4 + 256, capc = nc + nc / 4 + 256;
+    // (RP_SPARE_ROWS: test hook — a tiny spare makes live worlds outgrow their arrays, i.e. exercises the carry-over path)
+    const char *env_spare = getenv("RP_SPARE_ROWS");
+    const int spare = env_spare ? std::max(0, atoi(env_spare)) : 256, quarter = env_spare ? 0 : 1;
+    const int capb = nb + quarter * (nb / 4) + spare, capc = nc + quarter * (nc / 4) + spare;
     w->cap_bodies = capb; w->cap_colliders = capc;
     const char *env_pool = getenv("RP_PAIRS_PER_COLLIDER");
     int ppc = env_pool ? atoi(env_pool) : 8;
@@ -970,10 +996,12 @@ static int finalize(rp_world *w) {
         UP(d.nc_keys, nck);
         HIPCHK(w, hipStreamSynchronize(w->stream));
     }
-    DAC(d.j_b1, nj, DOM_JOINT, 1, 1); DAC(d.j_b2, nj, DOM_JOINT, 1, 1); DAC(d.j_f1t, nj, DOM_JOINT, 1, 1); DAC(d.j_f1r, nj, DOM_JOINT, 1, 1); DAC(d.j_f2t, nj, DOM_JOINT, 1, 1); DAC(d.j_f2r, nj, DOM_JOINT, 1, 1);
-    DAC(d.j_locked, nj, DOM_JOINT, 1, 1); DAC(d.j_limited, nj, DOM_JOINT, 1, 1); DAC(d.j_color, nj, DOM_JOINT, 1, 1); DAC(d.j_tmp, nj, DOM_JOINT, 1, 1); DAC(d.j_order, nj, DOM_JOINT, 1, 1); DAC(d.j_imp, nj, DOM_JOINT, 1, 1); DAC(d.j_imp_ang, nj, DOM_JOINT, 1, 1);
+    // the joint descriptors (bodies, CoM-space frames, axis masks, limits, motors) are host-authoritative: the fresh upload holds the
+    // current local centres of mass and fixed-body poses; only the solver's own state (colours, impulses) is carried over
+    DA(d.j_b1, nj); DA(d.j_b2, nj); DA(d.j_f1t, nj); DA(d.j_f1r, nj); DA(d.j_f2t, nj); DA(d.j_f2r, nj);
+    DA(d.j_locked, nj); DA(d.j_limited, nj); DAC(d.j_color, nj, DOM_JOINT, 1, 1); DAC(d.j_tmp, nj, DOM_JOINT, 1, 1); DAC(d.j_order, nj, DOM_JOINT, 1, 1); DAC(d.j_imp, nj, DOM_JOINT, 1, 1); DAC(d.j_imp_ang, nj, DOM_JOINT, 1, 1);
     DA(d.j_lim, (size_t)6 * std::max(nj, 1)); DAC(d.j_imp_lim, nj, DOM_JOINT, 1, 1); DAC(d.j_imp_lim_ang, nj, DOM_JOINT, 1, 1);
-    DAC(d.j_motor, nj, DOM_JOINT, 1, 1); DA(d.j_mot, (size_t)12 * std::max(nj, 1)); DAC(d.j_imp_mot, nj, DOM_JOINT, 1, 1); DAC(d.j_imp_mot_ang, nj, DOM_JOINT, 1, 1);
+    DA(d.j_motor, nj); DA(d.j_mot, (size_t)12 * std::max(nj, 1)); DAC(d.j_imp_mot, nj, DOM_JOINT, 1, 1); DAC(d.j_imp_mot_ang, nj, DOM_JOINT, 1, 1);
     DA(d.j_stage_begin, RP_NUM_COLORS + 1); DA(d.j_stage_count, RP_NUM_COLORS + 1);
     DAC(d.bj_cmask, 4 * (size_t)capb, DOM_BODY, 1, 4); DAFC(d.bj_min, capb, 0xff, DOM_BODY, 1, 1); DA(d.b_njoints, capb);
     DA(d.JR, (size_t)RP_JR_COUNT * std::max(nj, 1)); // im1, im2 + 12 rows x 6 planes (rp_joints.h); planes of unused rows are never touched
@@ -1531,10 +1559,13 @@ static int remove_collider_at(rp_world *w, int c) {
     int r = poke(w, w->dw.c_groups + c, none);
     if (r != RP_OK) return r;
     if (parent >= 0) {
-        const HostBody &b = w->bodies[parent];
-        if ((r = poke(w, w->dw.b_collider + parent, -1)) != RP_OK) return r;
-        if ((r = poke(w, w->dw.b_lcom_invm + parent, mk4(b.lcom[0], b.lcom[1], b.lcom[2], b.inv_mass))) != RP_OK) return r;
-        if ((r = poke(w, w->dw.b_invpi + parent, mk4(b.inv_pi[0], b.inv_pi[1], b.inv_pi[2], 0))) != RP_OK) return r;
+        // the body's mass properties follow its remaining colliders (local centre of mass, principal inertia AND frame, the
+        // sleep metric's max_extent), and so do the CoM-space frames of its joints
+        int last = -1;
+        if (w->bodies[parent].d.body_type == RP_BODY_DYNAMIC) for (int q = 0; q < (int)w->colliders.size(); ++q) if (w->collider_parent[q] == parent && !w->collider_removed[q]) last = q;
+        if ((r = poke(w, w->dw.b_collider + parent, last)) != RP_OK) return r;
+        if ((r = upload_body_row_mass(w, parent)) != RP_OK) return r;
+        if ((r = refresh_joint_frames(w, parent)) != RP_OK) return r;
     }
     return RP_OK;
 }

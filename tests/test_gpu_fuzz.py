@@ -12,6 +12,7 @@ from oracle_ffi import OracleWorld, lib
 import os
 
 pytestmark = pytest.mark.gpu
+TRACE = os.environ.get("RP_FUZZ_TRACE") is not None
 SEEDS = list(range(int(os.environ.get("RP_FUZZ_FIRST", "0")), int(os.environ.get("RP_FUZZ_LAST", "16"))))
 
 
@@ -78,6 +79,8 @@ def _scene(seed, n=40, spread=3.5, per_layer=4, calm=False):
         sc.add_collider(f, **_rand_collider(rng, 1.5))
     plat = sc.add_body(body_type=S.BODY_KINEMATIC_VELOCITY, translation=(-3.0, 0.2, 3.0), linvel=(0.3, 0.0, -0.2), angvel=(0.0, 0.4, 0.0), can_sleep=1)
     sc.add_collider(plat, half_extents=(1.5, 0.2, 1.5), friction=1.0)
+    kpos = sc.add_body(body_type=S.BODY_KINEMATIC_POSITION, translation=(3.0, 0.3, -3.0), can_sleep=1)
+    sc.add_collider(kpos, half_extents=(1.2, 0.3, 1.2), friction=0.8)
     pos = []
     for i in range(n):
         p = (float(rng.uniform(-spread, spread)), float(1.0 + 0.9 * (i // per_layer) + rng.uniform(0, 0.3)), float(rng.uniform(-spread, spread)))
@@ -136,6 +139,14 @@ def test_fuzz_bit_exact(seed):
     _run(seed)
 
 
+@pytest.mark.parametrize("seed", [3000, 3001, 3002, 3003])
+def test_fuzz_growth_bit_exact(seed, monkeypatch):
+    """RP_SPARE_ROWS=1: every inserted body / collider makes the device world outgrow its arrays, so each insertion goes through
+    the state carry-over (and every joint insertion does anyway)"""
+    monkeypatch.setenv("RP_SPARE_ROWS", "1")
+    _run(seed)
+
+
 def _random_params(sc, rng):
     """IntegrationParameters away from their defaults: substep count, inner PGS / stabilisation sweeps, warm-start coefficient,
     contact recycling, friction in the bias pass, time step, softness, correction limits, length unit"""
@@ -178,9 +189,16 @@ def _run(seed, steps=240, walls=False, params=False, **kw):
     dyn = [i for i, b in enumerate(sc.bodies) if int(b["body_type"]) == S.BODY_DYNAMIC]
     alive = list(range(nb0))
     jb = {j: (int(sc.joints[j]["body1"]), int(sc.joints[j]["body2"])) for j in range(len(sc.joints))}   # live joints -> their bodies
+    col_parent = list(sc.collider_parents); ncol = len(col_parent); removed_cols = set()
+    log = []
     for step in range(1, steps + 1):
+        if step % 3 == 0:                                         # the position-based platform follows a script
+            t = step / 60.0
+            kp = np.array([3.0 - 0.5 * t, 0.3 + 0.1 * np.sin(t), -3.0 + 0.4 * t, 0.0, np.sin(0.15 * t), 0.0, np.cos(0.15 * t)], np.float32)
+            g.set_next_kinematic_position([5], kp); o.set_next_kinematic_position(5, kp)
         if step % 7 == 0:                                         # a random user action
-            act = int(rng.integers(0, 9))
+            act = int(rng.integers(0, 13))
+            log.append((step, act))
             live_dyn = [b for b in dyn if b in alive]
             b = int(rng.choice(live_dyn))
             if act == 0:
@@ -205,6 +223,7 @@ def _run(seed, steps=240, walls=False, params=False, **kw):
                 lib().ro_add_collider(o._w, np.array([col], S.COLLIDER_DTYPE).ctypes.data, ob)
                 assert int(hb) & 0xFFFFFFFF == ob
                 alive.append(ob); dyn.append(ob)
+                col_parent.append(ob); ncol += 1
             elif act == 6 and jb:
                 j = int(rng.choice(sorted(jb)))
                 g.remove_impulse_joint(j); o.remove_joint(j); del jb[j]
@@ -221,13 +240,38 @@ def _run(seed, steps=240, walls=False, params=False, **kw):
                 oj = lib().ro_add_joint(o._w, np.array([jd], S.JOINT_DTYPE).ctypes.data)
                 assert hj == oj
                 jb[hj] = (b, b2)
+            elif act == 9:
+                f = rng.uniform(-5, 5, size=3).astype(np.float32); tq = rng.uniform(-1, 1, size=3).astype(np.float32)
+                reset = bool(rng.random() < 0.5)
+                g.add_force([b], force=[f], torque=[tq], reset=reset); o.add_force(b, force=f, torque=tq, reset=reset)
+            elif act == 10:
+                cols = [c for c in range(ncol) if col_parent[c] == b and c not in removed_cols]
+                if len(cols) > 1:                                 # drop one collider of a compound body
+                    c = int(rng.choice(cols))
+                    g.remove_collider(c); o.remove_collider(c); removed_cols.add(c)
+            elif act == 11:                                       # attach another collider to a live body
+                col = S.collider_desc(translation=tuple(float(x) for x in rng.uniform(-0.4, 0.4, size=3)), **_rand_collider(rng, 0.6))
+                hc = g.insert_collider(col, b)
+                oc = lib().ro_add_collider(o._w, np.array([col], S.COLLIDER_DTYPE).ctypes.data, b)
+                assert int(hc) & 0xFFFFFFFF == oc
+                col_parent.append(b); ncol += 1
+            elif act == 12:
+                tqi = rng.uniform(-0.5, 0.5, size=3).astype(np.float32)
+                g.apply_impulse([b], torque_impulse=[tqi]); o.apply_impulse(b, torque_impulse=tqi)
             elif act == 8 and jb:
                 j = int(rng.choice(sorted(jb)))
                 kw = dict(target_vel=float(rng.uniform(-2, 2)), damping=float(rng.uniform(1, 10)))
                 axis = int(rng.integers(0, 6))
                 g.set_joint_motor(j, axis, **kw); o.set_joint_motor(j, axis, **kw)
         g.step(1); o.step(1)
-        if step % 10 == 0 or step < 4:
-            _check(g, o, alive, f"seed {seed} step {step}")
+        if step % 10 == 0 or step < 4 or TRACE:
+            try:
+                _check(g, o, alive, f"seed {seed} step {step}")
+            except AssertionError:
+                if TRACE:
+                    gp, gv = g.read_bodies(); op, ov = o.read()
+                    bad = [b for b in alive if (gp[b] != op[b]).any() or (gv[b] != ov[b]).any()]
+                    print(f"TRACE seed {seed}: first divergence at step {step}, bodies {bad[:10]}, types {[int(sc.bodies[b]['body_type']) if b < len(sc.bodies) else 0 for b in bad[:10]]}; last actions {log[-6:]}")
+                raise
     c = g.counters()
     assert c["overflow_flags"] == 0
