@@ -620,3 +620,43 @@ def capsules(n: int = 6) -> Scene:
     s.add_collider(d, shape=SHAPE_BALL, half_extents=(0.35, 0.0, 0.0), translation=(0.95, 0.0, 0.0))
     s.add_collider(d, shape=SHAPE_BALL, half_extents=(0.35, 0.0, 0.0), translation=(-0.95, 0.0, 0.0))
     return s
+
+
+def reference_pile(nx: int = 12, ny: int = 3, nz: int = 12, chain: bool = True, sleep: bool = True) -> Scene:
+    """The stress scene of the reference's simd_backend_determinism.rs:61-139 (nx, ny, nz = 12, 3, 12 + a 4-ball spherical-joint
+    chain) and, with (14, 2, 14) and no chain, the pile of parallel_path_parity.rs:113-134: a jittered grid of unit cubes that
+    settles asymmetrically; bodies keep the builder's can_sleep default (true)."""
+    s = Scene(name=f"reference_pile_{nx}x{ny}x{nz}", gravity=(0.0, -9.81, 0.0))
+    g = s.add_body(body_type=BODY_FIXED, translation=(0.0, -0.5, 0.0))
+    s.add_collider(g, half_extents=(30.0 if not chain else 20.0, 0.5, 30.0 if not chain else 20.0))
+    f32 = np.float32
+    off = f32(nx) * f32(0.5)
+    for i in range(nx):
+        for j in range(ny):
+            for k in range(nz):
+                jitter = np.fmod(f32(i) * f32(0.013) + f32(k) * f32(0.017), f32(0.05))
+                b = s.add_body(translation=(float(f32(i) * f32(1.05) - off + jitter), float(f32(j) * f32(1.05) + f32(0.55)),
+                                            float(f32(k) * f32(1.05) - off - jitter)), can_sleep=1 if sleep else 0)
+                s.add_collider(b, half_extents=(0.5, 0.5, 0.5))
+    if chain:
+        prev = s.add_body(body_type=BODY_FIXED, translation=(0.0, 8.0, 0.0))
+        for i in range(4):
+            b = s.add_body(translation=(0.6 * (i + 1), 8.0, 0.0), can_sleep=1 if sleep else 0)
+            s.add_collider(b, shape=SHAPE_BALL, half_extents=(0.25, 0.0, 0.0))
+            s.add_joint(prev, b, (0.3, 0.0, 0.0), (-0.3, 0.0, 0.0), locked_axes=LOCK_LIN)
+            prev = b
+    return s
+
+
+def reference_cluster(seed: int, height: float = 6.0):
+    """spawn_cluster of parallel_path_parity.rs:80-100: 12 kicked unit cubes as (body_desc, collider_desc) pairs"""
+    f32 = np.float32
+    out = []
+    for i in range(12):
+        a = f32(seed * 7 + i * 13) * f32(0.011)
+        b = f32(seed * 11 + i * 5) * f32(0.017)
+        body = body_desc(translation=(float(np.fmod(f32(i), f32(4.0)) * f32(1.1) - f32(2.2) + a), float(f32(height) + f32(i // 4) * f32(1.1)),
+                                      float(np.fmod(b, f32(3.0)) - f32(1.5))),
+                         linvel=(float(np.fmod(a, f32(1.5)) - f32(0.75)), 0.0, float(np.fmod(b, f32(1.5)) - f32(0.75))), can_sleep=1)
+        out.append((body, collider_desc(half_extents=(0.5, 0.5, 0.5))))
+    return out

@@ -654,6 +654,31 @@ def test_insert_joint_into_live_world_bit_exact():
         _compare_joints(g, o)
 
 
+def test_reference_stress_scenes_bit_exact():
+    """The two stress scenes behind the reference's bitwise goldens (which need the Rust build): simd_backend_determinism.rs
+    (12x3x12 jittered pile + spherical chain, 200 steps) and parallel_path_parity.rs (14x2x14 pile that falls asleep, then ten
+    rounds of twelve kicked cubes dropped onto it, 40 steps each) — against the oracle, bit for bit, sleeping flags included."""
+    g, o = _compare(S.reference_pile(12, 3, 12, chain=True), [1, 10, 60, 200])
+    np.testing.assert_array_equal(g.sleeping(), o.sleeping())
+    _compare_joints(g, o)
+    sc = S.reference_pile(14, 2, 14, chain=False)
+    g, o = _compare(sc, [1, 60, 220])
+    np.testing.assert_array_equal(g.sleeping(), o.sleeping())
+    assert g.sleeping()[1:].mean() > 0.9                                   # the pile is (mostly) asleep before the drops
+    from oracle_ffi import lib
+    for rnd in range(10):
+        for body, col in S.reference_cluster(rnd):
+            hb = g.insert_body(body); g.insert_collider(col, hb)
+            ob = lib().ro_add_body(o._w, np.array([body], S.BODY_DTYPE).ctypes.data); o.n += 1
+            lib().ro_add_collider(o._w, np.array([col], S.COLLIDER_DTYPE).ctypes.data, ob)
+            assert int(hb) & 0xFFFFFFFF == ob
+        for n in (1, 19, 20):
+            g.step(n); o.step(n)
+            _same_state(g, o, f"drop round {rnd}, +{n}")
+            np.testing.assert_array_equal(g.sleeping(), o.sleeping())
+    assert g.counters()["overflow_flags"] == 0 and g.counters()["quarantined"] == 0
+
+
 def test_body_churn_bit_exact():
     """The fountain churn of solver_graph_stale_refs.rs:24-79 (cuboids / balls): one body inserted every step, the outermost
     ones removed beyond 60 live bodies — collider removal, pair deletion, in-place appends and capacity rebuilds, sleep / wake

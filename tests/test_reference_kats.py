@@ -892,3 +892,29 @@ def test_body_churn_keeps_the_world_sane():
             assert pos[alive, 1].min() > -0.5
             meta, _, _ = w.manifolds()
             assert len(meta) > 0
+
+
+# ---- parallel_path_parity.rs / simd_backend_determinism.rs (scene definitions; their bitwise goldens need the Rust build) ------
+def test_reference_stress_scenes_settle_sanely():
+    """The piles settle into resting cubes (two / three layers at their rest heights), fall asleep, and the kicked clusters dropped
+    onto the sleeping pile wake it and come to rest on top."""
+    w = OracleWorld(S.reference_pile(12, 3, 12, chain=True))
+    w.step(200)
+    pos, vel = w.read()
+    cubes = pos[1:433]
+    assert np.abs(vel[1:433]).max() < 0.5 and cubes[:, 1].min() > 0.45 and cubes[:, 1].max() < 3.0
+    assert abs(np.linalg.norm(pos[434, :3] - np.array([0.3, 8.0, 0.0])) - 0.3) < 0.02    # the first link stays pinned to the anchor's joint point
+    sc = S.reference_pile(14, 2, 14, chain=False)
+    w = OracleWorld(sc)
+    w.step(220)
+    assert w.sleeping()[1:].mean() > 0.9
+    for rnd in range(10):
+        for body, col in S.reference_cluster(rnd):
+            b = w.add_body(**{k: (tuple(body[k]) if body[k].shape else body[k].item()) for k in ("translation", "linvel", "can_sleep")})
+            w.add_collider(b, half_extents=(0.5, 0.5, 0.5))
+        w.step(40)
+        pos, vel = w.read()
+        assert np.isfinite(pos).all() and pos[1:, 1].min() > 0.4
+    w.step(300)
+    pos, vel = w.read()
+    assert np.abs(vel[1:, :3]).max() < 0.5 and pos[1:, 1].max() < 8.0               # the drops came to rest on the pile
