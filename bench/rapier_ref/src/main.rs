@@ -1,0 +1,122 @@
+//! Headless steps/s of rapier3d's own CPU `parallel` path on the BASELINE.json scenes — written against the API of the
+//! reference tree (`PhysicsWorld`, /root/reference/src/pipeline/physics_world.rs:61-157; scene formulas from
+//! /root/reference/examples3d/{b3d_many_pyramids,b3d_large_pyramid,b3d_joint_grid}.rs).  Not compiled in this repository's image
+//! (no Rust toolchain); kept as source so a maintainer can produce the true reference number on the GPU box's host CPU.
+//!
+//!   cargo run --release -- <many_pyramids|large_pyramid|joint_grid|pyramid10> [warmup_steps] [timed_steps]
+
+use rapier3d::prelude::*;
+use std::time::Instant;
+
+fn small_pyramid(world: &mut PhysicsWorld, base_count: i32, extent: f32, center_x: f32, base_z: f32) {
+    for i in 0..base_count {
+        let y = (2.0 * i as f32 + 1.0) * extent;
+        for j in i..base_count {
+            let x = (i as f32 + 1.0) * extent + 2.0 * (j - i) as f32 * extent + center_x - 0.5;
+            world.insert(
+                RigidBodyBuilder::dynamic().translation(Vector::new(x, y, base_z)).can_sleep(false),
+                ColliderBuilder::cuboid(extent, extent, extent).density(100.0),
+            );
+        }
+    }
+}
+
+/// b3d_many_pyramids.rs:36-64 (rows = cols = 14) and the one-pyramid plumbing case (rows = cols = 1)
+fn many_pyramids(rows: i32, cols: i32) -> PhysicsWorld {
+    let mut world = PhysicsWorld::new();
+    world.gravity = Vector::new(0.0, -10.0, 0.0);
+    let (base_count, extent) = (10i32, 0.5f32);
+    let ground_extent = extent * cols as f32 * (base_count as f32 + 1.0);
+    world.insert(
+        RigidBodyBuilder::fixed().translation(Vector::new(0.0, -1.0, 0.0)),
+        ColliderBuilder::cuboid(ground_extent, 1.0, ground_extent),
+    );
+    let base_width = 2.0 * extent * base_count as f32;
+    let mut base_z = -ground_extent + 2.0 * extent;
+    let delta_z = if rows > 1 { 2.0 * (ground_extent - 2.0 * extent) / (rows as f32 - 1.0) } else { 0.0 };
+    for _ in 0..rows {
+        for j in 0..cols {
+            let center_x = -ground_extent + j as f32 * (base_width + 2.0 * extent) + 2.0 * extent;
+            small_pyramid(&mut world, base_count, extent, center_x, base_z);
+        }
+        base_z += delta_z;
+    }
+    world
+}
+
+/// b3d_large_pyramid.rs:15-36
+fn large_pyramid(base_count: i32) -> PhysicsWorld {
+    let mut world = PhysicsWorld::new();
+    world.gravity = Vector::new(0.0, -10.0, 0.0);
+    let extent = 0.5f32;
+    world.insert(
+        RigidBodyBuilder::fixed().translation(Vector::new(0.0, -1.0, 0.0)),
+        ColliderBuilder::cuboid(400.0, 1.0, 400.0),
+    );
+    for i in 0..base_count {
+        let y = (2.0 * i as f32 + 1.0) * extent;
+        for j in i..base_count {
+            let x = (i as f32 + 1.0) * extent + 2.0 * (j - i) as f32 * extent - 100.0;
+            world.insert(
+                RigidBodyBuilder::dynamic().translation(Vector::new(x, y, 0.0)).can_sleep(false),
+                ColliderBuilder::cuboid(extent, extent, extent).density(100.0),
+            );
+        }
+    }
+    world
+}
+
+/// b3d_joint_grid.rs:17-53
+fn joint_grid(n: usize) -> PhysicsWorld {
+    let mut world = PhysicsWorld::new();
+    world.gravity = Vector::new(0.0, -10.0, 0.0);
+    let mut handles = vec![RigidBodyHandle::invalid(); n * n];
+    for k in 0..n {
+        for i in 0..n {
+            let builder = if i == 0 { RigidBodyBuilder::fixed() } else { RigidBodyBuilder::dynamic().can_sleep(false) };
+            let (h, _) = world.insert(
+                builder.translation(Vector::new(k as f32, -(i as f32), 0.0)),
+                ColliderBuilder::ball(0.4).density(1.0),
+            );
+            handles[k * n + i] = h;
+            if i > 0 {
+                let j = SphericalJointBuilder::new().local_anchor1(Vector::new(0.0, -0.5, 0.0)).local_anchor2(Vector::new(0.0, 0.5, 0.0));
+                world.insert_impulse_joint(handles[k * n + i - 1], h, j);
+            }
+            if k > 0 {
+                let j = SphericalJointBuilder::new().local_anchor1(Vector::new(0.5, 0.0, 0.0)).local_anchor2(Vector::new(-0.5, 0.0, 0.0));
+                world.insert_impulse_joint(handles[(k - 1) * n + i], h, j);
+            }
+        }
+    }
+    world
+}
+
+fn main() {
+    let args: Vec<String> = std::env::args().collect();
+    let scene = args.get(1).map(String::as_str).unwrap_or("many_pyramids");
+    let warmup: usize = args.get(2).and_then(|s| s.parse().ok()).unwrap_or(60);
+    let steps: usize = args.get(3).and_then(|s| s.parse().ok()).unwrap_or(1000);
+    let mut world = match scene {
+        "many_pyramids" => many_pyramids(14, 14),
+        "pyramid10" => many_pyramids(1, 1),
+        "large_pyramid" => large_pyramid(200),
+        "joint_grid" => joint_grid(100),
+        other => panic!("unknown scene {other}"),
+    };
+    for _ in 0..warmup {
+        world.step();
+    }
+    let t0 = Instant::now();
+    for _ in 0..steps {
+        world.step();
+    }
+    let dt = t0.elapsed().as_secs_f64();
+    println!(
+        "{{\"scene\": \"{scene}\", \"threads\": {}, \"steps\": {steps}, \"steps_per_s\": {:.2}, \"ms_per_step\": {:.4}}}",
+        rayon::current_num_threads(),
+        steps as f64 / dt,
+        dt / steps as f64 * 1e3
+    );
+    println!("{}", world.physics_pipeline.counters);
+}
