@@ -8,17 +8,13 @@
 use rapier3d::prelude::*;
 use std::time::Instant;
 
-fn small_pyramid(world: &mut PhysicsWorld, base_count: i32, extent: f32, center_x: f32, base_z: f32) {
-    for i in 0..base_count {
-        let y = (2.0 * i as f32 + 1.0) * extent;
-        for j in i..base_count {
-            let x = (i as f32 + 1.0) * extent + 2.0 * (j - i) as f32 * extent + center_x - 0.5;
-            world.insert(
-                RigidBodyBuilder::dynamic().translation(Vector::new(x, y, base_z)).can_sleep(false),
-                ColliderBuilder::cuboid(extent, extent, extent).density(100.0),
-            );
-        }
-    }
+/// Cube centres of one 2-D pyramid of `base` cubes (half extent `e`) relative to its left end: row r holds base - r cubes.
+fn pyramid_cells(base: i32, e: f32) -> impl Iterator<Item = (f32, f32)> {
+    (0..base).flat_map(move |row| (row..base).map(move |col| ((row as f32 + 1.0) * e + 2.0 * (col - row) as f32 * e, (2.0 * row as f32 + 1.0) * e)))
+}
+
+fn add_cube(world: &mut PhysicsWorld, at: Vector, e: f32) {
+    world.insert(RigidBodyBuilder::dynamic().translation(at).can_sleep(false), ColliderBuilder::cuboid(e, e, e).density(100.0));
 }
 
 /// b3d_many_pyramids.rs:36-64 (rows = cols = 14) and the one-pyramid plumbing case (rows = cols = 1)
@@ -37,7 +33,9 @@ fn many_pyramids(rows: i32, cols: i32) -> PhysicsWorld {
     for _ in 0..rows {
         for j in 0..cols {
             let center_x = -ground_extent + j as f32 * (base_width + 2.0 * extent) + 2.0 * extent;
-            small_pyramid(&mut world, base_count, extent, center_x, base_z);
+            for (dx, y) in pyramid_cells(base_count, extent) {
+                add_cube(&mut world, Vector::new(dx + center_x - 0.5, y, base_z), extent);
+            }
         }
         base_z += delta_z;
     }
@@ -53,15 +51,8 @@ fn large_pyramid(base_count: i32) -> PhysicsWorld {
         RigidBodyBuilder::fixed().translation(Vector::new(0.0, -1.0, 0.0)),
         ColliderBuilder::cuboid(400.0, 1.0, 400.0),
     );
-    for i in 0..base_count {
-        let y = (2.0 * i as f32 + 1.0) * extent;
-        for j in i..base_count {
-            let x = (i as f32 + 1.0) * extent + 2.0 * (j - i) as f32 * extent - 100.0;
-            world.insert(
-                RigidBodyBuilder::dynamic().translation(Vector::new(x, y, 0.0)).can_sleep(false),
-                ColliderBuilder::cuboid(extent, extent, extent).density(100.0),
-            );
-        }
+    for (dx, y) in pyramid_cells(base_count, extent) {
+        add_cube(&mut world, Vector::new(dx - 100.0, y, 0.0), extent);
     }
     world
 }
