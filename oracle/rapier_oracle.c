@@ -2102,6 +2102,25 @@ static void solve_velocity_constraints(ro_world *w) {
         p->solver_body_ids[1] = b2 >= 0 ? w->bodies[b2].solver_id : RO_NO_BODY;
         order[cursor[p->color]++] = i;
     }
+    /* The overflow colour is swept serially and is not body-disjoint, so its order is part of the result.  The reference orders it
+     * by its body-mask regrouping of contact-graph edge ids (interaction_groups.rs:240-355), which depend on the BVH's pair creation
+     * order; here — and on the device — it is swept in ascending (collider1, collider2) order, a total order that no creation order
+     * can change (deliberate deviations). */
+    if (counts[RO_COLOR_OVERFLOW] > 1) {
+        int ob = w->bucket_begin[RO_COLOR_OVERFLOW], on = counts[RO_COLOR_OVERFLOW];
+        for (int a = 1; a < on; ++a) { /* insertion sort: the bucket is nearly sorted (pairs are created in sweep order) */
+            int v = order[ob + a]; const Pair *pv = &w->pairs[v];
+            uint64_t kv = ((uint64_t)(uint32_t)pv->c1 << 32) | (uint32_t)pv->c2;
+            int b = a - 1;
+            while (b >= 0) {
+                const Pair *pb = &w->pairs[order[ob + b]];
+                uint64_t kb = ((uint64_t)(uint32_t)pb->c1 << 32) | (uint32_t)pb->c2;
+                if (kb <= kv) break;
+                order[ob + b + 1] = order[ob + b]; --b;
+            }
+            order[ob + b + 1] = v;
+        }
+    }
     /* chunk layout — init.rs:163-254: colours with >= 32 four-lane chunks first (ascending),
      * then the smaller colours (ascending), then the overflow colour. */
     w->nstages = 0; int nparallel = 0, nused = 0;

@@ -856,6 +856,7 @@ __global__ void k_bucket_layout(DevWorld w) {
     w.flags[FL_N_CONS] = pos; w.flags[FL_N_CONS_ALL] = mall;
     if (pos > w.cons_cap) atomicOr(&w.flags[FL_OVERFLOW], RP_OVF_CONS);
 }
+RP_DEV int ld_i32(int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __global__ void k_bucket_scatter(DevWorld w) {
     if (!w.flags[FL_LAYOUT_DIRTY]) return;
     // two passes per block: count its manifolds per colour, reserve one range per colour, then place
@@ -882,11 +883,32 @@ __global__ void k_bucket_scatter(DevWorld w) {
         if (pos < w.cons_cap) { w.cons_pair[pos] = s; w.p_conspos[s] = pos; }
     }
     // the last workgroup to finish closes the layout rebuild (k_bucket_finish)
+    __shared__ int last;
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
-        if (atomicAdd(&w.flags[FL_TICKET], 1) == (int)gridDim.x - 1) { w.flags[FL_TICKET] = 0; __hip_atomic_store(&w.flags[FL_LAYOUT_DIRTY], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        last = atomicAdd(&w.flags[FL_TICKET], 1) == (int)gridDim.x - 1;
     }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    // The overflow colour is swept serially and is not body-disjoint: its order is part of the result, and the scatter above is
+    // ordered by atomics.  The closing workgroup ranks it by (collider1, collider2) — the order the oracle uses.
+    const int nst = ld_i32(&w.flags[FL_N_STAGES]);
+    const int ob = ld_i32(&w.stage_begin[nst]), on = ld_i32(&w.flags[FL_HAS_OVERFLOW_COLOR]) ? ld_i32(&w.stage_count[nst]) : 0;
+    if (on > 1 && ob + on <= w.cons_cap) {
+        for (int i = threadIdx.x; i < on; i += blockDim.x) w.todo_tmp[i] = ld_i32(&w.cons_pair[ob + i]);
+        __threadfence(); __syncthreads();
+        for (int i = threadIdx.x; i < on; i += blockDim.x) {
+            int si = ld_i32(&w.todo_tmp[i]);
+            unsigned long long ki = ((unsigned long long)(unsigned)w.p_c1[si] << 32) | (unsigned)w.p_c2[si];
+            int rank = 0;
+            for (int j = 0; j < on; ++j) { int sj = ld_i32(&w.todo_tmp[j]); unsigned long long kj = ((unsigned long long)(unsigned)w.p_c1[sj] << 32) | (unsigned)w.p_c2[sj]; rank += kj < ki; }
+            w.cons_pair[ob + rank] = si; w.p_conspos[si] = ob + rank;
+        }
+        __threadfence(); __syncthreads();
+    }
+    if (threadIdx.x == 0) { w.flags[FL_TICKET] = 0; __hip_atomic_store(&w.flags[FL_LAYOUT_DIRTY], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 }
 __global__ void k_bucket_finish(DevWorld w) { w.flags[FL_LAYOUT_DIRTY] = 0; }
 

@@ -679,6 +679,20 @@ def test_reference_stress_scenes_bit_exact():
     assert g.counters()["overflow_flags"] == 0 and g.counters()["quarantined"] == 0
 
 
+def test_many_colliders_per_body_bit_exact():
+    """issue_970 / issue_730 scenes (tests/test_reference_kats.py): a dynamic body made of 2,000 boxes — 2,000 manifolds between the
+    same two bodies, i.e. ~1,870 of them on the serial overflow colour — and 500 balls raining on 400 sibling colliders of one
+    fixed body (cuboids and capsules)."""
+    import test_reference_kats as K
+    sc, body = K.multi_collider_slab()
+    g, o = _compare(sc, [1, 5, 40, 80])
+    np.testing.assert_array_equal(g.sleeping(), o.sleeping())
+    assert g.sleeping()[body] and g.counters()["num_pairs"] == 2000
+    sc, balls = K.separate_colliders_scene()
+    g, o = _compare(sc, [1, 30, 100])
+    np.testing.assert_array_equal(g.sleeping(), o.sleeping())
+
+
 def test_body_churn_bit_exact():
     """The fountain churn of solver_graph_stale_refs.rs:24-79 (cuboids / balls): one body inserted every step, the outermost
     ones removed beyond 60 live bodies — collider removal, pair deletion, in-place appends and capacity rebuilds, sleep / wake

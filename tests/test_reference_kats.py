@@ -918,3 +918,59 @@ def test_reference_stress_scenes_settle_sanely():
     w.step(300)
     pos, vel = w.read()
     assert np.abs(vel[1:, :3]).max() < 0.5 and pos[1:, 1].max() < 8.0               # the drops came to rest on the pile
+
+
+# ---- issue_970_multi_collider_body_perf.rs / issue_730_many_separate_colliders_perf.rs (their behavioural halves) -------------
+def multi_collider_slab(nx=50, nz=40):
+    sc = world()
+    g = sc.add_body(body_type=S.BODY_FIXED)
+    sc.add_collider(g, half_extents=(100.0, 0.5, 100.0))
+    body = sc.add_body(translation=(0.0, 1.05, 0.0), can_sleep=1)
+    for i in range(nx):
+        for j in range(nz):
+            sc.add_collider(body, half_extents=(0.5, 0.5, 0.5), translation=(i - nx / 2.0, 0.0, j - nz / 2.0))
+    return sc, body
+
+
+def test_multi_collider_body_rests_and_sleeps():
+    """issue_970: ONE dynamic body carrying a 50 x 40 slab of 2,000 unit boxes (same-parent colliders never pair; every collider
+    pairs with the ground, far more manifolds between the same two bodies than there are colours) comes to rest and falls asleep."""
+    sc, body = multi_collider_slab()
+    w = OracleWorld(sc)
+    w.step(400)
+    assert w.sleeping()[body]
+    assert w.read()[0][body, 1] == pytest.approx(1.0, abs=0.02)
+    assert w.stats()["num_pairs"] == 2000                       # one pair per collider, none between siblings
+
+
+def separate_colliders_scene():
+    sc = world()
+    g = sc.add_body(body_type=S.BODY_FIXED)
+    n = 0
+    for i in range(20):
+        for j in range(20):
+            pos = (i - 10.0, 0.0, j - 10.0)
+            if n % 3 == 2:
+                sc.add_collider(g, shape=S.SHAPE_CAPSULE, half_extents=(0.3, 0.4, 1.0), translation=pos)
+            else:                                               # the reference alternates cuboids and cylinders here
+                sc.add_collider(g, half_extents=(0.5, 0.5, 0.5) if n % 3 == 0 else (0.4, 0.5, 0.4), translation=pos)
+            n += 1
+    balls = []
+    for k in range(500):
+        b = sc.add_body(translation=((k % 10) - 5.0, 3.0 + (k // 100) * 1.5, ((k // 10) % 10) - 5.0), can_sleep=1)
+        sc.add_collider(b, shape=S.SHAPE_BALL, half_extents=(0.4, 0.0, 0.0))
+        balls.append(b)
+    return sc, balls
+
+
+def test_balls_rain_on_many_separate_fixed_colliders():
+    """issue_730: 400 primitives attached to one fixed body, 500 balls raining on them: nothing tunnels, the fixed siblings never
+    pair with each other."""
+    sc, balls = separate_colliders_scene()
+    w = OracleWorld(sc)
+    w.step(100)
+    pos, vel = w.read()
+    assert np.isfinite(pos).all() and pos[balls, 1].min() > 0.0
+    meta, _, _ = w.manifolds()
+    parents = np.array(sc.collider_parents)
+    assert (parents[meta[:, 0]] != parents[meta[:, 1]]).all()
