@@ -186,16 +186,19 @@ def test_oracle_threads_do_not_change_results():
         oracle_ffi.set_threads(threads)
         try:
             out = []
-            for sc in (S.tumble(40, seed=3), S.joint_grid(12), S.many_pyramids(rows=2, cols=2)):
+            import test_gpu_fuzz as F       # the randomised feature-mix scenes (sleeping, joints, events, both friction models, piles)
+            fuzz = [F._scene(seed)[0] for seed in (1, 3, 6)] + [F._scene(1000, n=300, spread=2.2, per_layer=49, calm=True)[0]]
+            for sc in [S.tumble(40, seed=3), S.joint_grid(12), S.many_pyramids(rows=2, cols=2), S.capsules(6), S.motorised_joints()] + fuzz:
                 w = OracleWorld(sc)
                 w.step(60)
-                out.append(w.read())
+                out.append(w.read() + (w.sleeping(),))
             res.append(out)
         finally:
             oracle_ffi.set_threads(1)
-    for (p1, v1), (p4, v4) in zip(*res):
+    for (p1, v1, s1), (p4, v4, s4) in zip(*res):
         np.testing.assert_array_equal(p1, p4)
         np.testing.assert_array_equal(v1, v4)
+        np.testing.assert_array_equal(s1, s4)
 
 
 # FrictionModel::Coulomb (contact_with_coulomb_friction.rs): a sliding box decelerates at mu * g under either
