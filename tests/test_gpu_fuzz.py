@@ -11,7 +11,6 @@ from oracle_ffi import OracleWorld, lib
 
 import os
 
-pytestmark = pytest.mark.gpu
 TRACE = os.environ.get("RP_FUZZ_TRACE") is not None
 SEEDS = list(range(int(os.environ.get("RP_FUZZ_FIRST", "0")), int(os.environ.get("RP_FUZZ_LAST", "16"))))
 
@@ -127,6 +126,7 @@ def _check(g, o, alive, msg):
         np.testing.assert_array_equal(gvv[gi], ovv[oi], err_msg=msg + " force event values")
 
 
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", [1000, 1001, 1002])
 def test_fuzz_pile_bit_exact(seed):
     """the same generator at 600 bodies dropped into a walled pit: one giant island on the global multi-kernel path (> 1024
@@ -134,11 +134,13 @@ def test_fuzz_pile_bit_exact(seed):
     _run(seed, steps=260, n=700, spread=2.2, per_layer=49, walls=True, calm=True)
 
 
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", SEEDS)
 def test_fuzz_bit_exact(seed):
     _run(seed)
 
 
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", [3000, 3001, 3002, 3003])
 def test_fuzz_growth_bit_exact(seed, monkeypatch):
     """RP_SPARE_ROWS=1: every inserted body / collider makes the device world outgrow its arrays, so each insertion goes through
@@ -171,20 +173,69 @@ def _random_params(sc, rng):
     p["length_unit"] = float(rng.choice([1.0, 1.0, 2.0]))
 
 
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", list(range(2000, 2016)))
 def test_fuzz_params_bit_exact(seed):
     """the same scenes and actions under randomised IntegrationParameters"""
     _run(seed, steps=160, params=True)
 
 
-def _run(seed, steps=240, walls=False, params=False, **kw):
+class OracleTwin:
+    """A second oracle behind the PhysicsWorld method names the driver uses: the CPU twin of the differential test (the same random
+    scenes and user actions, the multi-threaded oracle against the single-threaded one) keeps the driver itself and the oracle's
+    determinism under user actions covered by the `-m "not gpu"` suite."""
+
+    def __init__(self, scene):
+        self.o = OracleWorld(scene)
+
+    def step(self, n=1):
+        import oracle_ffi
+        oracle_ffi.set_threads(4)
+        try:
+            self.o.step(n)
+        finally:
+            oracle_ffi.set_threads(1)
+
+    def read_bodies(self): return self.o.read()
+    def sleeping(self): return self.o.sleeping()
+    def collision_events(self): return self.o.collision_events()
+    def contact_force_events(self): return self.o.force_events()
+    def counters(self): return {"overflow_flags": 0}
+    def apply_impulse(self, h, impulse=None, torque_impulse=None): self.o.apply_impulse(int(h[0]), None if impulse is None else impulse[0], None if torque_impulse is None else torque_impulse[0])
+    def add_force(self, h, force=None, torque=None, reset=False): self.o.add_force(int(h[0]), force[0], torque[0], reset)
+    def wake_up(self, h): self.o.wake_up(int(h[0]))
+    def remove_body(self, b): self.o.remove_body(b)
+    def remove_collider(self, c): self.o.remove_collider(c)
+    def remove_impulse_joint(self, j): self.o.remove_joint(j)
+    def set_joint_motor(self, j, axis, **kw): self.o.set_joint_motor(j, axis, **kw)
+    def set_next_kinematic_position(self, h, p): self.o.set_next_kinematic_position(int(h[0]), p)
+
+    def write_bodies(self, h, pos7=None, vel6=None):
+        if pos7 is not None: self.o.set_pose(int(h[0]), pos7[0])
+        if vel6 is not None: self.o.set_vel(int(h[0]), vel6[0][:3], vel6[0][3:])
+
+    def insert_body(self, body):
+        h = lib().ro_add_body(self.o._w, np.array([body], S.BODY_DTYPE).ctypes.data); self.o.n += 1
+        return h
+
+    def insert_collider(self, col, parent): return lib().ro_add_collider(self.o._w, np.array([col], S.COLLIDER_DTYPE).ctypes.data, int(parent))
+    def insert_impulse_joint(self, b1, b2, jd): return lib().ro_add_joint(self.o._w, np.array([jd], S.JOINT_DTYPE).ctypes.data)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 2001, 2004])
+def test_fuzz_driver_on_the_oracle_twin(seed):
+    """CPU: the fuzz driver with the 4-thread oracle in the device's place (same scenes, same actions, bit-exact expectations)"""
+    _run(seed, steps=120, params=seed >= 2000, world=OracleTwin)
+
+
+def _run(seed, steps=240, walls=False, params=False, world=None, **kw):
     sc, rng = _scene(seed, **kw)
     if params:
         _random_params(sc, rng)
     if walls:
         for k, (x, z, hx, hz) in enumerate(((3.2, 0, 0.3, 3.5), (-3.2, 0, 0.3, 3.5), (0, 3.2, 3.5, 0.3), (0, -3.2, 3.5, 0.3))):
             sc.add_collider(0, half_extents=(hx, 6.0, hz), translation=(x, 6.5, z))
-    g, o = PhysicsWorld.from_scene(sc), OracleWorld(sc)
+    g, o = (world(sc) if world else PhysicsWorld.from_scene(sc)), OracleWorld(sc)
     nb0 = len(sc.bodies)
     dyn = [i for i, b in enumerate(sc.bodies) if int(b["body_type"]) == S.BODY_DYNAMIC]
     alive = list(range(nb0))
