@@ -128,7 +128,7 @@ def main():
     if dist is not None:
         dyn = np.array([int(b["body_type"]) == S.BODY_DYNAMIC for b in scene.bodies])
         per = 55
-        gids = np.concatenate([[0], 1 + (np.arange(14 * 14 * per) // (14 * per)) * (14 * world * per) + rank * 14 * per + (np.arange(14 * 14 * per) % (14 * per))])
+        gids = sharding.column_shard_global_ids(14, 14, 10, world, rank)
         gpos, _ = sharding.all_gather_bodies(pos, vel, gids, 1 + 14 * 14 * world * per, dyn, device="cuda")
         finite = finite and bool(np.isfinite(gpos).all())
 

@@ -97,3 +97,13 @@ def all_gather_bodies(local_pos: np.ndarray, local_vel: np.ndarray, global_ids: 
         pos[ids] = g[:, :7]
         vel[ids] = g[:, 7:13]
     return pos, vel
+
+
+def column_shard_global_ids(rows: int, cols_per_rank: int, base_count: int, world_size: int, rank: int) -> np.ndarray:
+    """Global body ids of rank `rank`'s bodies when a rows x (cols_per_rank * world_size) many_pyramids world is sharded by
+    pyramid columns (bench.py --gpus N): local body 0 is the replicated ground (global 0); the generator emits pyramids row by
+    row, so row r of the rank's local scene maps into row r of the global one at column offset rank * cols_per_rank."""
+    per = base_count * (base_count + 1) // 2
+    local = np.arange(rows * cols_per_rank * per)
+    row, in_row = local // (cols_per_rank * per), local % (cols_per_rank * per)
+    return np.concatenate([[0], 1 + row * (cols_per_rank * world_size * per) + rank * cols_per_rank * per + in_row]).astype(np.int64)

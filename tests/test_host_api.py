@@ -77,3 +77,22 @@ def test_header_documents_scope_limits():
     hdr = open(os.path.join(ROOT, "include", "rapier_hip.h")).read()
     # what the device path refuses is stated where the entry points are declared
     assert "compound bodies" in hdr and "coupled axes are not part" in hdr
+
+
+def test_column_shard_global_ids_partition_the_world():
+    """bench.py --gpus N: the per-rank global body ids are disjoint, cover every dynamic body once, and agree with the generator
+    (rank r's local scene = columns [14 r, 14 r + 14) of the 14 x 14N world)."""
+    import numpy as np
+    from rapier_amd import scenes as S, sharding
+    for world in (2, 4, 8):
+        ids = [sharding.column_shard_global_ids(14, 14, 10, world, r) for r in range(world)]
+        cat = np.concatenate([g[1:] for g in ids])
+        assert len(np.unique(cat)) == len(cat) == 14 * 14 * world * 55 and cat.min() == 1 and cat.max() == len(cat)
+        assert all(g[0] == 0 for g in ids)
+    full = S.many_pyramids(rows=2, cols=4)
+    for r in range(2):
+        local = S.many_pyramids(rows=2, cols=4, col_range=(2 * r, 2 * r + 2))
+        gids = sharding.column_shard_global_ids(2, 2, 10, 2, r)
+        assert len(gids) == len(local.bodies)
+        for li, gi in enumerate(gids):
+            np.testing.assert_array_equal(local.bodies[li]["translation"], full.bodies[gi]["translation"])
