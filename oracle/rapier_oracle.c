@@ -2364,6 +2364,31 @@ static void emit_contact_force_events(ro_world *w) {
     }
 }
 
+/* IslandManager::persistent_island_of (test accessor): the island of every body = its connected component over touching pairs
+ * and joints among awake non-fixed bodies (label = smallest member), the label it fell asleep with for a sleeping body, -1 for
+ * fixed bodies.  The reference maintains these incrementally (eager merge, local / deferred split); the partition it converges to
+ * is this one. */
+void ro_read_island_labels(ro_world *w, int32_t *out) {
+    int n = w->nbodies;
+    int *uf = (int *)malloc(sizeof(int) * (size_t)(n + 1));
+    for (int i = 0; i < n; ++i) uf[i] = i;
+    for (int i = 0; i < w->npairs; ++i) {
+        const Pair *p = &w->pairs[i];
+        if (!p->alive || p->nsc == 0) continue;
+        int b1 = w->colliders[p->c1].parent, b2 = w->colliders[p->c2].parent;
+        if (body_is_active(w, b1) && body_is_active(w, b2)) uf_union(uf, b1, b2);
+    }
+    for (int i = 0; i < w->njoints; ++i) {
+        const Joint *j = &w->joints[i];
+        if (!j->removed && body_is_active(w, j->body1) && body_is_active(w, j->body2)) uf_union(uf, j->body1, j->body2);
+    }
+    for (int i = 0; i < n; ++i) {
+        const Body *b = &w->bodies[i];
+        out[i] = b->body_type == RO_BODY_FIXED ? -1 : b->sleeping ? b->sleep_label : uf_find(uf, i);
+    }
+    free(uf);
+}
+
 /* PhysicsPipeline::step_inner — pipeline/physics_pipeline/substep.rs:267-581 */
 static void step_once(ro_world *w) {
     w->step_seq++;

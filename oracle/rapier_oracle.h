@@ -114,6 +114,8 @@ int32_t ro_remove_joint(ro_world *w, int32_t joint);
 int32_t ro_set_joint_motor(ro_world *w, int32_t joint, int32_t axis, const ro_joint_motor *m);
 /* JointMotor::impulse of the six axes of every joint */
 void ro_read_joint_motor_impulses(const ro_world *w, float *impulses6);
+/* island label of every body (IslandManager::persistent_island_of): -1 for fixed bodies */
+void ro_read_island_labels(ro_world *w, int32_t *out);
 int32_t ro_num_joints(const ro_world *w);
 void ro_read_joints(const ro_world *w, int32_t *color, float *impulses3);
 void ro_step(ro_world *w, int32_t nsteps);

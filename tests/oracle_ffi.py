@@ -66,6 +66,7 @@ def lib():
         L.ro_read_joints.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.ro_set_joint_motor.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         L.ro_read_joint_motor_impulses.argtypes = [C.c_void_p, C.c_void_p]
+        L.ro_read_island_labels.argtypes = [C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -199,6 +200,11 @@ class OracleWorld:
 
     def wake_up(self, body, strong=True):
         lib().ro_wake_up(self._w, int(body), 1 if strong else 0)
+
+    def island_labels(self):
+        out = np.zeros(self.n, np.int32)
+        lib().ro_read_island_labels(self._w, out.ctypes.data)
+        return out
 
     def sleeping(self):
         out = np.zeros(self.n, np.int32)

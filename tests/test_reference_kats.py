@@ -974,3 +974,69 @@ def test_balls_rain_on_many_separate_fixed_colliders():
     meta, _, _ = w.manifolds()
     parents = np.array(sc.collider_parents)
     assert (parents[meta[:, 0]] != parents[meta[:, 1]]).all()
+
+
+# ---- persistent_islands.rs (island equality through the oracle's label accessor) ---------------------------------------------
+def _islands_world(xs):
+    sc = world()
+    ground(sc)
+    hs = [_cube(sc, (float(x), float(y), 0.0)) for x, y in xs]
+    return OracleWorld(sc), hs
+
+
+def _same(w, a, b):
+    lab = w.island_labels()
+    return lab[a] >= 0 and lab[a] == lab[b]
+
+
+def test_islands_merge_on_touch_and_split_on_separation():
+    """persistent_islands.rs:45-76, :136-157: stacked boxes share an island, distant ones do not; once the top box is teleported
+    away the two are in distinct islands — in the very step the contact stops touching."""
+    w, (bottom, top, lone) = _islands_world([(0.0, 0.5), (0.0, 1.5), (20.0, 0.5)])
+    w.step(240)
+    assert _same(w, bottom, top) and not _same(w, bottom, lone)
+    w.set_pose(top, [40.0, 0.5, 0.0, 0.0, 0.0, 0.0, 1.0])
+    w.step(1)
+    assert not _same(w, bottom, top)
+    w.step(240)
+    assert not _same(w, bottom, top)
+
+
+def test_islands_follow_joints():
+    """persistent_islands.rs:78-109 (a spherical joint satisfied at rest instead of the rope joint): a joint between two distant
+    resting boxes merges their islands; removing it separates them again."""
+    w, (a, b) = _islands_world([(0.0, 0.5), (20.0, 0.5)])
+    w.step(240)
+    assert not _same(w, a, b)
+    jd = np.zeros((), S.JOINT_DTYPE)
+    jd["body1"], jd["body2"] = a, b
+    jd["local_anchor1"], jd["local_anchor2"] = (10.0, 0.0, 0.0), (-10.0, 0.0, 0.0)
+    jd["local_basis1"] = jd["local_basis2"] = (0, 0, 0, 1)
+    jd["locked_axes"], jd["contacts_enabled"] = S.LOCK_LIN, 1
+    for k in range(6):
+        jd["motors"][k] = S.motor_desc()
+    from oracle_ffi import lib
+    j = lib().ro_add_joint(w._w, np.array([jd], S.JOINT_DTYPE).ctypes.data)
+    w.step(1)
+    assert _same(w, a, b)
+    w.remove_joint(j)
+    w.step(240)
+    assert not _same(w, a, b)
+
+
+def test_islands_split_when_the_bridge_goes():
+    """persistent_islands.rs:111-134, :159-198: removing the middle box of a touching row splits the sides; lifting half of a
+    six-box row away as a block leaves two multi-body islands."""
+    w, (left, middle, right) = _islands_world([(0.0, 0.5), (1.0, 0.5), (2.0, 0.5)])
+    w.step(240)
+    assert _same(w, left, right)
+    w.remove_body(middle)
+    w.step(240)
+    assert not _same(w, left, right)
+    w, row = _islands_world([(float(i), 0.5) for i in range(6)])
+    w.step(240)
+    assert _same(w, row[0], row[5])
+    for i in range(3, 6):
+        w.set_pose(row[i], [30.0 + (i - 3), 0.5, 0.0, 0.0, 0.0, 0.0, 1.0])
+    w.step(240)
+    assert not _same(w, row[0], row[3]) and _same(w, row[0], row[2]) and _same(w, row[3], row[5])
