@@ -693,6 +693,18 @@ def test_many_colliders_per_body_bit_exact():
     np.testing.assert_array_equal(g.sleeping(), o.sleeping())
 
 
+def test_runs_are_bitwise_identical_and_match_the_oracle():
+    """issue_868 (8 deeply overlapping bouncy balls, a parentless ground collider): two device runs from identical initial
+    conditions give identical bits — and the oracle's."""
+    import test_reference_kats as K
+    res = []
+    for _ in range(2):
+        sc, hs = K.eight_ball_drop()
+        g, o = _compare(sc, [1, 20, 200])
+        res.append(g.read_bodies()[0][hs].copy())
+    np.testing.assert_array_equal(res[0], res[1])
+
+
 def test_body_churn_bit_exact():
     """The fountain churn of solver_graph_stale_refs.rs:24-79 (cuboids / balls): one body inserted every step, the outermost
     ones removed beyond 60 live bodies — collider removal, pair deletion, in-place appends and capacity rebuilds, sleep / wake

@@ -1040,3 +1040,35 @@ def test_islands_split_when_the_bridge_goes():
         w.set_pose(row[i], [30.0 + (i - 3), 0.5, 0.0, 0.0, 0.0, 0.0, 1.0])
     w.step(240)
     assert not _same(w, row[0], row[3]) and _same(w, row[0], row[2]) and _same(w, row[3], row[5])
+
+
+# ---- issue_868_same_machine_determinism.rs -----------------------------------------------------------------------------------
+def eight_ball_drop():
+    sc = world()
+    sc.add_collider(-1, half_extents=(100.0, 0.1, 100.0))
+    hs = []
+    for x in range(2):
+        for y in range(2):
+            for z in range(2):
+                b = sc.add_body(translation=(x * 0.51 + 3.0, y * 0.5 + 3.5, z * 0.5 + 3.0), can_sleep=1)
+                sc.add_collider(b, shape=S.SHAPE_BALL, half_extents=(0.5, 0.0, 0.0), restitution=0.7)
+                hs.append(b)
+    return sc, hs
+
+
+def test_same_machine_runs_are_bitwise_identical():
+    """issue_868: the 8-ball drop (deeply overlapping bouncy balls) run twice — and on 1 and 4 threads — gives identical bits."""
+    import oracle_ffi
+    runs = []
+    for threads in (1, 1, 4):
+        oracle_ffi.set_threads(threads)
+        try:
+            sc, hs = eight_ball_drop()
+            w = OracleWorld(sc)
+            w.step(200)
+            runs.append(w.read()[0][hs, :3].copy())
+        finally:
+            oracle_ffi.set_threads(1)
+    np.testing.assert_array_equal(runs[0], runs[1])
+    np.testing.assert_array_equal(runs[0], runs[2])
+    assert np.isfinite(runs[0]).all()
