@@ -1072,3 +1072,22 @@ def test_same_machine_runs_are_bitwise_identical():
     np.testing.assert_array_equal(runs[0], runs[1])
     np.testing.assert_array_equal(runs[0], runs[2])
     assert np.isfinite(runs[0]).all()
+
+
+# ---- broad_phase_pair_filter.rs ----------------------------------------------------------------------------------------------
+def test_no_fixed_fixed_pairs():
+    """broad_phase_pair_filter.rs:23-30: the broad phase creates no pair between colliders of two fixed bodies (the default
+    ActiveCollisionTypes would drop it every frame), nor between a fixed body's collider and a parentless one."""
+    sc = world()
+    a = sc.add_body(body_type=S.BODY_FIXED)
+    sc.add_collider(a, half_extents=(1.0, 1.0, 1.0))
+    b = sc.add_body(body_type=S.BODY_FIXED, translation=(0.5, 0.0, 0.0))
+    sc.add_collider(b, half_extents=(1.0, 1.0, 1.0))
+    sc.add_collider(-1, half_extents=(1.0, 1.0, 1.0), translation=(0.0, 0.5, 0.0))
+    w = OracleWorld(sc)
+    w.step(3)
+    assert w.stats()["num_pairs"] == 0
+    d = w.add_body(translation=(0.2, 1.3, 0.0))                 # a dynamic body does pair with all three
+    w.add_collider(d, half_extents=(0.5, 0.5, 0.5))
+    w.step(1)
+    assert w.stats()["num_pairs"] == 3
