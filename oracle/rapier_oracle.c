@@ -70,6 +70,8 @@ typedef struct {
     int slept_at;       /* step at which the body last fell asleep (pair hints cleared then) */
     int sleep_label;    /* island label: smallest body index of the connected component */
     int wake_req;       /* pending IslandManager::wake_up */
+    int additional_solver_iterations; /* RigidBody::additional_solver_iterations — extra substeps for the body's whole component */
+    int last_group_extra;             /* extra substeps of the solve group the body was in during the last step (-1: not in the active set) */
 } Body;
 
 typedef struct { v3 mins, maxs; } Aabb;
@@ -2053,22 +2055,84 @@ static void joint_solve_all_rows(ro_world *w, const Joint *j, int wo_bias, int w
         joint_row_solve(w, c);
     }
 }
-static void joints_solve_pass(ro_world *w, int wo_bias, int warmstart_joints) {
+/* `order` / `nparallel` / `ntotal`: the group's own layout (single_group_joint_layout applied to the joints of one solve group) */
+static void joints_solve_pass(ro_world *w, const int *order, int nparallel, int ntotal, int wo_bias, int warmstart_joints) {
     int a = 0;
-    while (a < w->njoint_parallel) { /* one parallel colour = one body-disjoint stage */
-        int c = w->joints[w->joint_order[a]].solver_color, e = a;
-        while (e < w->njoint_parallel && w->joints[w->joint_order[e]].solver_color == c) ++e;
+    while (a < nparallel) { /* one parallel colour = one body-disjoint stage */
+        int c = w->joints[order[a]].solver_color, e = a;
+        while (e < nparallel && w->joints[order[e]].solver_color == c) ++e;
         RO_PARALLEL_FOR
-        for (int i = a; i < e; ++i) joint_solve_all_rows(w, &w->joints[w->joint_order[i]], wo_bias, warmstart_joints);
+        for (int i = a; i < e; ++i) joint_solve_all_rows(w, &w->joints[order[i]], wo_bias, warmstart_joints);
         a = e;
     }
-    for (; a < w->nactive_joints; ++a) joint_solve_all_rows(w, &w->joints[w->joint_order[a]], wo_bias, warmstart_joints);
+    for (; a < ntotal; ++a) joint_solve_all_rows(w, &w->joints[order[a]], wo_bias, warmstart_joints);
+}
+
+/* Substep solve-groups — island_manager/substep_groups.rs:44-229: the awake set is partitioned by the effective
+ * RigidBody::additional_solver_iterations: connected components of awake DYNAMIC bodies over pairs with an active contact and over
+ * joints take the maximum extra count of their members; a kinematic body is lifted to the largest count among the dynamic bodies it
+ * touches; one group per distinct count, in descending order.  Returns the number of groups; key_of_body[solver id] = group index. */
+#define RO_MAX_GROUPS 16
+/* union-find over small index sets; the root of a set is its smallest member */
+static int uf_find(int *uf, int x) { while (uf[x] != x) { uf[x] = uf[uf[x]]; x = uf[x]; } return x; }
+static void uf_union(int *uf, int a, int b) { a = uf_find(uf, a); b = uf_find(uf, b); if (a == b) return; if (a < b) uf[b] = a; else uf[a] = b; }
+static int compute_solve_groups(ro_world *w, int nd, int *group_of_body, int *group_extra) {
+    int any_extra = 0;
+    for (int i = 0; i < nd; ++i) any_extra |= w->bodies[w->dyn_bodies[i]].additional_solver_iterations > 0;
+    if (!any_extra) { for (int i = 0; i < nd; ++i) group_of_body[i] = 0; group_extra[0] = 0; return 1; }
+    int *uf = (int *)malloc(sizeof(int) * (size_t)(nd + 1)), *key = (int *)calloc((size_t)nd + 1, sizeof(int));
+    for (int i = 0; i < nd; ++i) uf[i] = i;
+#define RO_DYN_SLOT(b) ((b) >= 0 && w->bodies[b].body_type == RO_BODY_DYNAMIC && w->bodies[b].solver_id != RO_NO_BODY ? (int)w->bodies[b].solver_id : -1)
+#define RO_KIN_SLOT(b) ((b) >= 0 && w->bodies[b].body_type != RO_BODY_DYNAMIC && w->bodies[b].body_type != RO_BODY_FIXED && w->bodies[b].solver_id != RO_NO_BODY ? (int)w->bodies[b].solver_id : -1)
+    for (int i = 0; i < w->npairs; ++i) {
+        const Pair *p = &w->pairs[i];
+        if (!p->alive || p->nsc == 0) continue;
+        int s1 = RO_DYN_SLOT(w->colliders[p->c1].parent), s2 = RO_DYN_SLOT(w->colliders[p->c2].parent);
+        if (s1 >= 0 && s2 >= 0) uf_union(uf, s1, s2);
+    }
+    for (int i = 0; i < w->njoints; ++i) {
+        const Joint *j = &w->joints[i];
+        if (j->removed) continue;
+        int s1 = RO_DYN_SLOT(j->body1), s2 = RO_DYN_SLOT(j->body2);
+        if (s1 >= 0 && s2 >= 0) uf_union(uf, s1, s2);
+    }
+    for (int i = 0; i < nd; ++i) {
+        int extra = w->bodies[w->dyn_bodies[i]].additional_solver_iterations;
+        if (extra > 0) { int r = uf_find(uf, i); if (key[r] < extra) key[r] = extra; }
+    }
+    for (int i = 0; i < nd; ++i) if (uf_find(uf, i) != i) key[i] = key[uf_find(uf, i)];
+    for (int i = 0; i < w->npairs; ++i) { /* lift the kinematic bodies */
+        const Pair *p = &w->pairs[i];
+        if (!p->alive || p->nsc == 0) continue;
+        int b1 = w->colliders[p->c1].parent, b2 = w->colliders[p->c2].parent;
+        int k1 = RO_KIN_SLOT(b1), d2 = RO_DYN_SLOT(b2), k2 = RO_KIN_SLOT(b2), d1 = RO_DYN_SLOT(b1);
+        if (k1 >= 0 && d2 >= 0 && key[k1] < key[d2]) key[k1] = key[d2];
+        if (k2 >= 0 && d1 >= 0 && key[k2] < key[d1]) key[k2] = key[d1];
+    }
+    for (int i = 0; i < w->njoints; ++i) {
+        const Joint *j = &w->joints[i];
+        if (j->removed) continue;
+        int k1 = RO_KIN_SLOT(j->body1), d2 = RO_DYN_SLOT(j->body2), k2 = RO_KIN_SLOT(j->body2), d1 = RO_DYN_SLOT(j->body1);
+        if (k1 >= 0 && d2 >= 0 && key[k1] < key[d2]) key[k1] = key[d2];
+        if (k2 >= 0 && d1 >= 0 && key[k2] < key[d1]) key[k2] = key[d1];
+    }
+#undef RO_DYN_SLOT
+#undef RO_KIN_SLOT
+    int ng = 0;
+    for (int i = 0; i < nd; ++i) { /* distinct keys, descending */
+        int seen = 0;
+        for (int g = 0; g < ng; ++g) seen |= group_extra[g] == key[i];
+        if (!seen && ng < RO_MAX_GROUPS) group_extra[ng++] = key[i];
+    }
+    for (int a = 1; a < ng; ++a) { int v = group_extra[a], b = a - 1; while (b >= 0 && group_extra[b] < v) { group_extra[b + 1] = group_extra[b]; --b; } group_extra[b + 1] = v; }
+    for (int i = 0; i < nd; ++i) { group_of_body[i] = ng - 1; for (int g = 0; g < ng; ++g) if (group_extra[g] == key[i]) { group_of_body[i] = g; break; } }
+    free(uf); free(key);
+    return ng;
 }
 
 static void solve_velocity_constraints(ro_world *w) {
     const ro_params *prm = &w->params;
-    int num_substeps = prm->num_solver_iterations;
-    float dt_s = prm->dt / (float)num_substeps;
+    const int base_substeps = prm->num_solver_iterations;
 
     /* active set = awake dynamic bodies in arena order, manager.rs:20-39 */
     int nd = 0;
@@ -2132,6 +2196,34 @@ static void solve_velocity_constraints(ro_world *w) {
     w->stats.num_colors_used = nused; w->stats.num_parallel_colors = nparallel; w->stats.num_pairs = w->npairs;
     w->ncons = M;
 
+    /* substep solve-groups (substep_groups.rs; init.rs:52-100, 163-420): group g runs base + extra[g] substeps at its own dt, over
+     * its own bodies, joints and constraints; a constraint belongs to the highest group index (= lowest cadence) among its solver
+     * bodies, i.e. to its dynamic side.  Without any elevated body there is one group and everything below is the plain loop. */
+    int *grp_body = (int *)malloc(sizeof(int) * (size_t)(nd + 1)), *grp_cons = (int *)malloc(sizeof(int) * (size_t)(M + 1));
+    int g_extra[RO_MAX_GROUPS];
+    const int ngroups = compute_solve_groups(w, nd, grp_body, g_extra);
+    for (int i = 0; i < w->nbodies; ++i) w->bodies[i].last_group_extra = -1;
+    for (int i = 0; i < nd; ++i) w->bodies[w->dyn_bodies[i]].last_group_extra = g_extra[grp_body[i]];
+    for (int i = 0; i < M; ++i) {
+        const Pair *p = &w->pairs[order[i]];
+        int g = 0;
+        for (int k = 0; k < 2; ++k) if (p->solver_body_ids[k] != RO_NO_BODY && grp_body[p->solver_body_ids[k]] > g) g = grp_body[p->solver_body_ids[k]];
+        grp_cons[i] = g;
+    }
+    /* per-group chunk layout — init.rs:163-254 applied to the group's share of every colour bucket */
+    int (*g_stage_color)[RO_NUM_COLORS + 1] = (int (*)[RO_NUM_COLORS + 1])malloc(sizeof(int[RO_NUM_COLORS + 1]) * (size_t)ngroups);
+    int g_nstages[RO_MAX_GROUPS];
+    for (int g = 0; g < ngroups; ++g) {
+        int cg[RO_NUM_COLORS]; memset(cg, 0, sizeof(cg));
+        if (ngroups == 1) memcpy(cg, counts, sizeof(cg));
+        else for (int c = 0; c < RO_NUM_COLORS; ++c) for (int i = w->bucket_begin[c]; i < w->bucket_begin[c + 1]; ++i) cg[c] += grp_cons[i] == g;
+        int ns = 0;
+        for (int c = 0; c < RO_NUM_COLORS - 1; ++c) if ((cg[c] + 3) / 4 >= 32) g_stage_color[g][ns++] = c;
+        for (int c = 0; c < RO_NUM_COLORS - 1; ++c) if (cg[c] > 0 && (cg[c] + 3) / 4 < 32) g_stage_color[g][ns++] = c;
+        if (cg[RO_COLOR_OVERFLOW] > 0) g_stage_color[g][ns++] = RO_COLOR_OVERFLOW;
+        g_nstages[g] = ns;
+    }
+
     /* S0: solver bodies + increments — worker.rs:46-104, solver_body.rs:82-121 */
     RO_PARALLEL_FOR
     for (int i = 0; i < nd; ++i) {
@@ -2142,8 +2234,9 @@ static void solve_velocity_constraints(ro_world *w) {
         w->poses[i].translation = pose_tp(rb->position, rb->local_com);
         w->poses[i].ii = rb->effective_world_inv_inertia;
         w->poses[i].im = rb->effective_inv_mass;
-        w->incr[i].angular = vmul(sym3_mul(rb->effective_world_inv_inertia, rb->torque), dt_s);
-        w->incr[i].linear = vmul(vcmul(rb->force, rb->effective_inv_mass), dt_s);
+        const float dt_b = prm->dt / (float)(base_substeps + g_extra[grp_body[i]]); /* the substep length of the body's group */
+        w->incr[i].angular = vmul(sym3_mul(rb->effective_world_inv_inertia, rb->torque), dt_b);
+        w->incr[i].linear = vmul(vcmul(rb->force, rb->effective_inv_mass), dt_b);
         Gyro *g = &w->gyro[i];
         if (rb->gyroscopic && rb->body_type == RO_BODY_DYNAMIC) { /* worker.rs:86 */
             g->inv_principal_inertia = rb->inv_principal_inertia;
@@ -2170,14 +2263,56 @@ static void solve_velocity_constraints(ro_world *w) {
         w->joint_rows = (JointRow *)realloc(w->joint_rows, sizeof(JointRow) * (size_t)(num_joint_rows + 1));
     } else w->nactive_joints = 0;
 
+    /* joints per group (a joint follows its dynamic side like a contact does) and the group's own single_group_joint_layout */
+    int *grp_joint = (int *)malloc(sizeof(int) * (size_t)(w->nactive_joints + 1));
+    int *g_joint_order = (int *)malloc(sizeof(int) * (size_t)(w->nactive_joints + 1));
+    int g_joint_begin[RO_MAX_GROUPS + 1], g_joint_parallel[RO_MAX_GROUPS];
+    for (int a = 0; a < w->nactive_joints; ++a) {
+        const Joint *j = &w->joints[w->active_joints[a]];
+        int g = 0;
+        for (int k = 0; k < 2; ++k) if (j->solver_body_ids[k] != RO_NO_BODY && grp_body[j->solver_body_ids[k]] > g) g = grp_body[j->solver_body_ids[k]];
+        grp_joint[a] = g;
+    }
+    {
+        int n = 0;
+        for (int g = 0; g < ngroups; ++g) {
+            g_joint_begin[g] = n; g_joint_parallel[g] = 0;
+            if (ngroups == 1) { /* the layout joints_color() already built */
+                for (int a = 0; a < w->nactive_joints; ++a) g_joint_order[n++] = w->joint_order[a];
+                g_joint_parallel[g] = w->njoint_parallel;
+                continue;
+            }
+            int cj[RO_NUM_COLORS]; memset(cj, 0, sizeof(cj));
+            for (int a = 0; a < w->nactive_joints; ++a) if (grp_joint[a] == g) cj[w->joints[w->active_joints[a]].solver_color]++;
+            for (int pass = 0; pass < 2; ++pass)
+                for (int c = 0; c < RO_NUM_COLORS; ++c) {
+                    int parallel = c < 128 && cj[c] >= 64;
+                    if (cj[c] == 0 || (pass == 0) != parallel) continue;
+                    for (int a = 0; a < w->nactive_joints; ++a)
+                        if (grp_joint[a] == g && w->joints[w->active_joints[a]].solver_color == c) g_joint_order[n++] = w->active_joints[a];
+                    if (pass == 0) g_joint_parallel[g] = n - g_joint_begin[g];
+                }
+        }
+        g_joint_begin[ngroups] = n;
+    }
+
     int solve_friction_in_bias = prm->friction_in_bias_pass || prm->num_internal_stabilization_iterations == 0;
     float max_lin = prm->normalized_max_linear_velocity * prm->length_unit;
     float max_ang = 0.78539816339744830962f * (prm->dt == 0.0f ? 0.0f : 1.0f / prm->dt);
+    /* groups in descending cadence, each with its whole substep loop (a kinematic body is integrated with the highest-cadence group
+     * it touches, before any lower-cadence group solves against it) */
+    for (int grp = 0; grp < ngroups; ++grp) {
+    const int num_substeps = base_substeps + g_extra[grp];
+    const float dt_s = prm->dt / (float)num_substeps;
+    const int *jorder = g_joint_order + g_joint_begin[grp];
+    const int jpar = g_joint_parallel[grp], jtot = g_joint_begin[grp + 1] - g_joint_begin[grp];
+    const int one_group = ngroups == 1;
     for (int s = 0; s < num_substeps; ++s) {
         float solved_dt = (float)s * dt_s;
         /* S2 increments + gyroscopic — worker.rs:235-284 */
         RO_PARALLEL_FOR
         for (int i = 0; i < nd; ++i) {
+            if (!one_group && grp_body[i] != grp) continue;
             w->vels[i].linear = vadd(w->vels[i].linear, w->incr[i].linear);
             w->vels[i].angular = vadd(w->vels[i].angular, w->incr[i].angular);
             if (w->gyro[i].enabled) {
@@ -2188,13 +2323,14 @@ static void solve_velocity_constraints(ro_world *w) {
         }
         /* S3 joint rows rebuilt from the current poses — worker.rs:287-357 */
         RO_PARALLEL_FOR
-        for (int a = 0; a < w->nactive_joints; ++a) joint_builder_update(w, &w->joints[w->active_joints[a]], dt_s, s);
+        for (int a = 0; a < w->nactive_joints; ++a) { if (one_group || grp_joint[a] == grp) joint_builder_update(w, &w->joints[w->active_joints[a]], dt_s, s); }
         /* S4 fused update + warmstart per colour — worker.rs:438-538 (non-fused when coefficient == 0) */
-        for (int st = 0; st < w->nstages; ++st) {
-            int c = w->stage_color[st];
+        for (int st = 0; st < g_nstages[grp]; ++st) {
+            int c = g_stage_color[grp][st];
             int serial = c == RO_COLOR_OVERFLOW; /* the overflow colour is not body-disjoint */
             RO_PRAGMA_IF_PAR(serial)
             for (int i = w->bucket_begin[c]; i < w->bucket_begin[c + 1]; ++i) {
+                if (!one_group && grp_cons[i] != grp) continue;
                 if (coulomb) { coulomb_update(w, &w->cons[i], dt_s, solved_dt); if (prm->warmstart_coefficient != 0.0f) coulomb_warmstart(w, &w->cons[i]); continue; }
                 constraint_update(w, &w->cons[i], dt_s, solved_dt);
                 if (prm->warmstart_coefficient != 0.0f) constraint_warmstart(w, &w->cons[i]);
@@ -2202,17 +2338,21 @@ static void solve_velocity_constraints(ro_world *w) {
         }
         /* S5 biased pass — worker.rs:544-561, staged_island_solver/solve.rs:12-209 */
         for (int it = 0; it < prm->num_internal_pgs_iterations; ++it) {
-            joints_solve_pass(w, 0, prm->warmstart_joints && it == 0);
-            for (int st = 0; st < w->nstages; ++st) {
-                int c = w->stage_color[st];
+            joints_solve_pass(w, jorder, jpar, jtot, 0, prm->warmstart_joints && it == 0);
+            for (int st = 0; st < g_nstages[grp]; ++st) {
+                int c = g_stage_color[grp][st];
                 int serial = c == RO_COLOR_OVERFLOW;
                 RO_PRAGMA_IF_PAR(serial)
-                for (int i = w->bucket_begin[c]; i < w->bucket_begin[c + 1]; ++i) { if (coulomb) coulomb_solve(w, &w->cons[i], solve_friction_in_bias); else constraint_solve(w, &w->cons[i], solve_friction_in_bias); }
+                for (int i = w->bucket_begin[c]; i < w->bucket_begin[c + 1]; ++i) {
+                    if (!one_group && grp_cons[i] != grp) continue;
+                    if (coulomb) coulomb_solve(w, &w->cons[i], solve_friction_in_bias); else constraint_solve(w, &w->cons[i], solve_friction_in_bias);
+                }
             }
         }
         /* S6 integrate — worker.rs:568-631, rigid_body_components.rs:884-898 */
         RO_PARALLEL_FOR
         for (int i = 0; i < nd; ++i) {
+            if (!one_group && grp_body[i] != grp) continue;
             SolverVel *v = &w->vels[i];
             if (max_lin != FLT_MAX) { float n = vlen(v->linear); if (n > max_lin) v->linear = vmul(v->linear, max_lin / n); }
             if (!(w->flags[i] & 1)) { float n = vlen(v->angular); if (n > max_ang) v->angular = vmul(v->angular, max_ang / n); }
@@ -2223,12 +2363,13 @@ static void solve_velocity_constraints(ro_world *w) {
         }
         /* S7 unbiased pass with refreshed rhs — worker.rs:636-649 */
         for (int it = 0; it < prm->num_internal_stabilization_iterations; ++it) {
-            joints_solve_pass(w, 1, 0);
-            for (int st = 0; st < w->nstages; ++st) {
-                int c = w->stage_color[st];
+            joints_solve_pass(w, jorder, jpar, jtot, 1, 0);
+            for (int st = 0; st < g_nstages[grp]; ++st) {
+                int c = g_stage_color[grp][st];
                 int serial = c == RO_COLOR_OVERFLOW;
                 RO_PRAGMA_IF_PAR(serial)
                 for (int i = w->bucket_begin[c]; i < w->bucket_begin[c + 1]; ++i) {
+                    if (!one_group && grp_cons[i] != grp) continue;
                     if (coulomb) { coulomb_refresh_rhs_wo_bias(w, &w->cons[i], dt_s, solved_dt + dt_s); coulomb_solve(w, &w->cons[i], 1); continue; }
                     constraint_refresh_rhs_wo_bias(w, &w->cons[i], dt_s, solved_dt + dt_s);
                     constraint_solve(w, &w->cons[i], 1);
@@ -2236,6 +2377,8 @@ static void solve_velocity_constraints(ro_world *w) {
             }
         }
     }
+    }
+    free(grp_body); free(grp_cons); free(grp_joint); free(g_joint_order); free(g_stage_color);
     /* S8 restitution — worker.rs:657-734 */
     if (any_bouncy)
         for (int st = 0; st < w->nstages; ++st) {
@@ -2273,8 +2416,6 @@ static void solve_velocity_constraints(ro_world *w) {
  * over touching pairs and joints — which is the partition the reference converges to once its pending splits
  * are resolved (the split cooldown of persistent.rs:31 only delays a sleep by <= 16 steps).  Label = the
  * smallest body index of the component. */
-static int uf_find(int *uf, int x) { while (uf[x] != x) { uf[x] = uf[uf[x]]; x = uf[x]; } return x; }
-static void uf_union(int *uf, int a, int b) { a = uf_find(uf, a); b = uf_find(uf, b); if (a == b) return; if (a < b) uf[b] = a; else uf[a] = b; }
 static void update_sleep(ro_world *w) {
     const float dt = w->params.dt, length_unit = w->params.length_unit;
     int n = w->nbodies, any_can_sleep = 0;
@@ -2508,6 +2649,12 @@ int32_t ro_set_joint_motor(ro_world *w, int32_t joint, int32_t axis, const ro_jo
     wake_request(w, j->body1, 1); wake_request(w, j->body2, 1);
     return 0;
 }
+/* RigidBody::set_additional_solver_iterations (rigid_body.rs): extra substeps for the body's connected component */
+void ro_set_additional_solver_iterations(ro_world *w, int32_t body, int32_t n) {
+    if (body >= 0 && body < w->nbodies) w->bodies[body].additional_solver_iterations = n < 0 ? 0 : n;
+}
+/* IslandManager::solve_groups as seen from the bodies: the extra substep count of each body's group in the last step */
+void ro_read_solve_group_extras(const ro_world *w, int32_t *out) { for (int i = 0; i < w->nbodies; ++i) out[i] = w->bodies[i].last_group_extra; }
 void ro_read_joint_motor_impulses(const ro_world *w, float *impulses6) {
     for (int i = 0; i < w->njoints; ++i) for (int a = 0; a < 6; ++a) impulses6[6 * i + a] = w->joints[i].motor_impulses[a];
 }

@@ -114,6 +114,10 @@ int32_t ro_remove_joint(ro_world *w, int32_t joint);
 int32_t ro_set_joint_motor(ro_world *w, int32_t joint, int32_t axis, const ro_joint_motor *m);
 /* JointMotor::impulse of the six axes of every joint */
 void ro_read_joint_motor_impulses(const ro_world *w, float *impulses6);
+/* RigidBody::additional_solver_iterations: the body's whole connected component runs that many extra substeps (substep solve-groups,
+ * island_manager/substep_groups.rs).  Oracle only so far: the device ABI does not expose it yet. */
+void ro_set_additional_solver_iterations(ro_world *w, int32_t body, int32_t n);
+void ro_read_solve_group_extras(const ro_world *w, int32_t *out); /* per body: extra substeps of its solve group in the last step, -1 outside the active set */
 /* island label of every body (IslandManager::persistent_island_of): -1 for fixed bodies */
 void ro_read_island_labels(ro_world *w, int32_t *out);
 int32_t ro_num_joints(const ro_world *w);

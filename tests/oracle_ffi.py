@@ -67,6 +67,8 @@ def lib():
         L.ro_set_joint_motor.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         L.ro_read_joint_motor_impulses.argtypes = [C.c_void_p, C.c_void_p]
         L.ro_read_island_labels.argtypes = [C.c_void_p, C.c_void_p]
+        L.ro_set_additional_solver_iterations.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        L.ro_read_solve_group_extras.argtypes = [C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -200,6 +202,14 @@ class OracleWorld:
 
     def wake_up(self, body, strong=True):
         lib().ro_wake_up(self._w, int(body), 1 if strong else 0)
+
+    def set_additional_solver_iterations(self, body, n):
+        lib().ro_set_additional_solver_iterations(self._w, int(body), int(n))
+
+    def solve_group_extras(self):
+        out = np.zeros(self.n, np.int32)
+        lib().ro_read_solve_group_extras(self._w, out.ctypes.data)
+        return out
 
     def island_labels(self):
         out = np.zeros(self.n, np.int32)

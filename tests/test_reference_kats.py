@@ -1091,3 +1091,143 @@ def test_no_fixed_fixed_pairs():
     w.add_collider(d, half_extents=(0.5, 0.5, 0.5))
     w.step(1)
     assert w.stats()["num_pairs"] == 3
+
+
+# ---- additional_solver_iterations.rs / substep_chain_high_mass_ratio.rs / test_staged.rs:214-330 (ORACLE ONLY: the device ABI does
+# ---- not expose additional_solver_iterations yet — DESIGN.md section 9) --------------------------------------------------------
+def _heavy_stack(extra):
+    sc = world()
+    g = sc.add_body(body_type=S.BODY_FIXED)
+    sc.add_collider(g, half_extents=(10.0, 0.5, 10.0), translation=(0.0, -0.5, 0.0))
+    light = sc.add_body(translation=(0.0, 0.5, 0.0), can_sleep=1)
+    sc.add_collider(light, half_extents=(0.5, 0.5, 0.5), density=1.0)
+    heavy = sc.add_body(translation=(0.0, 1.5, 0.0), can_sleep=1)
+    sc.add_collider(heavy, half_extents=(0.5, 0.5, 0.5), density=200.0)
+    w = OracleWorld(sc)
+    w.set_additional_solver_iterations(heavy, extra)
+    return w, light, heavy
+
+
+def test_heavy_stack_stays_stable_with_extra_iterations():
+    """additional_solver_iterations.rs:115-141"""
+    w, light, heavy = _heavy_stack(16)
+    w.step(300)
+    pos, vel = w.read()
+    assert 0.3 < pos[light, 1] < 0.7 and 1.2 < pos[heavy, 1] < 1.8 and np.linalg.norm(vel[heavy, :3]) < 0.1
+
+
+def test_heavy_chain_stays_stable_with_extra_iterations():
+    """additional_solver_iterations.rs:143-164: a six-link rope with a 100x heavier end ball, extra iterations on the weight"""
+    sc = world()
+    prev = sc.add_body(body_type=S.BODY_FIXED)
+    for i in range(6):
+        link = sc.add_body(translation=(0.0, -(i + 1.0), 0.0), can_sleep=1)
+        sc.add_collider(link, shape=S.SHAPE_BALL, half_extents=(0.4, 0.0, 0.0), density=100.0 if i == 5 else 1.0)
+        sc.add_joint(prev, link, (0.0, -0.5, 0.0), (0.0, 0.5, 0.0), locked_axes=S.LOCK_LIN)
+        prev = link
+    w = OracleWorld(sc)
+    w.set_additional_solver_iterations(prev, 16)
+    w.step(300)
+    end = w.read()[0][prev, :3]
+    assert np.isfinite(end).all() and np.linalg.norm(end) < 20.0 and -7.5 < end[1] < -4.5
+
+
+def test_extra_iterations_take_effect_and_are_deterministic():
+    """additional_solver_iterations.rs:166-194"""
+    def run(extra):
+        w, light, heavy = _heavy_stack(extra)
+        w.set_pose(heavy, [0.1, 3.0, 0.0, 0.0, 0.0, 0.0, 1.0])
+        w.step(60)
+        pos = w.read()[0]
+        return pos[[light, heavy], :3].copy()
+    plain, extra1, extra2 = run(0), run(8), run(8)
+    np.testing.assert_array_equal(extra1, extra2)
+    assert (plain != extra1).any()
+
+
+def test_substep_chain_high_mass_ratio_stretch():
+    """substep_chain_high_mass_ratio.rs:145-161: a 16-link chain with a 1000:1 end ball holds together at least 4x more tightly
+    with 16 extra substeps on every body than without."""
+    def peak_stretch(extra):
+        sc = world()
+        rad, num = 0.2, 17
+        prev, joints = None, []
+        for i in range(num):
+            ball_rad = rad * 10.0 if i == num - 1 else rad
+            shift1, shift2 = rad * 1.1, ball_rad + rad * 0.1
+            z = 0.0 if i == 0 else (i - 1.0) * 2.0 * shift1 + shift1 + shift2
+            b = sc.add_body(body_type=S.BODY_FIXED if i == 0 else S.BODY_DYNAMIC, translation=(0.0, 0.0, z))
+            sc.add_collider(b, shape=S.SHAPE_BALL, half_extents=(ball_rad, 0.0, 0.0))
+            if prev is not None:
+                a1, a2 = ((0.0, 0.0, 0.0), (0.0, 0.0, -shift1 * 2.0)) if i == 1 else ((0.0, 0.0, shift1), (0.0, 0.0, -shift2))
+                sc.add_joint(prev, b, a1, a2, locked_axes=S.LOCK_LIN)
+                joints.append((prev, b, np.array(a1), np.array(a2)))
+            prev = b
+        w = OracleWorld(sc)
+        for b in range(1, num):
+            w.set_additional_solver_iterations(b, extra)
+        peak = 0.0
+        for _ in range(300):
+            w.step(1)
+            pos = w.read()[0]
+            for b1, b2, a1, a2 in joints:
+                p1 = pos[b1, :3] + rot_matrix(pos[b1, 3:]) @ a1
+                p2 = pos[b2, :3] + rot_matrix(pos[b2, 3:]) @ a2
+                peak = max(peak, float(np.linalg.norm(p1 - p2)))
+        return peak
+    baseline, elevated = peak_stretch(0), peak_stretch(16)
+    assert elevated < baseline / 4.0, (baseline, elevated)
+
+
+def test_substep_groups_partition():
+    """test_staged.rs:214-330: three groups in descending cadence — {lone} = 8, {chain_a, chain_b} = 4 (the joint lifts the
+    non-elevated partner), {plain} = 0; un-elevating every body leaves the single implicit group."""
+    sc = world()
+    g = sc.add_body(body_type=S.BODY_FIXED)
+    sc.add_collider(g, half_extents=(0.5, 0.5, 0.5))
+    plain = _cube(sc, (0.0, 1.001, 0.0), can_sleep=0)
+    chain_a = _cube(sc, (10.0, 5.0, 0.0), can_sleep=0)
+    chain_b = _cube(sc, (10.0, 3.0, 0.0), can_sleep=0)
+    sc.add_joint(chain_a, chain_b, (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), locked_axes=S.LOCK_REVOLUTE, basis1=S.AXIS_Z_BASIS, basis2=S.AXIS_Z_BASIS)
+    lone = _cube(sc, (-10.0, 5.0, 0.0), can_sleep=0)
+    w = OracleWorld(sc)
+    w.set_additional_solver_iterations(chain_b, 4)
+    w.set_additional_solver_iterations(lone, 8)
+    w.step(3)
+    ex = w.solve_group_extras()
+    assert ex[g] == -1 and ex[lone] == 8 and ex[chain_a] == 4 and ex[chain_b] == 4 and ex[plain] == 0
+    w.set_additional_solver_iterations(chain_b, 0)
+    w.set_additional_solver_iterations(lone, 0)
+    w.step(1)
+    assert (w.solve_group_extras()[[plain, chain_a, chain_b, lone]] == 0).all()
+
+
+def test_solve_groups_do_not_disturb_each_other():
+    """Solve groups are constraint-closed: a default-cadence stack next to an elevated chain evolves bit for bit like the same stack
+    alone, and the elevated chain like the same chain alone (every body of it elevated)."""
+    def build(with_stack, with_chain):
+        sc = world()
+        ground(sc)
+        stack_h = stack(sc, 0.0, 4, can_sleep=0) if with_stack else []
+        chain_h = []
+        if with_chain:
+            prev = sc.add_body(body_type=S.BODY_FIXED, translation=(30.0, 10.0, 0.0))
+            for i in range(5):
+                b = sc.add_body(translation=(30.0 + (i + 1.0), 10.0, 0.0))
+                sc.add_collider(b, shape=S.SHAPE_BALL, half_extents=(0.3, 0.0, 0.0), density=50.0 if i == 4 else 1.0)
+                sc.add_joint(prev, b, (0.5, 0.0, 0.0), (-0.5, 0.0, 0.0), locked_axes=S.LOCK_LIN)
+                chain_h.append(b); prev = b
+        w = OracleWorld(sc)
+        if chain_h:
+            w.set_additional_solver_iterations(chain_h[-1], 6)
+        return w, stack_h, chain_h
+    both, s_both, c_both = build(True, True)
+    only_stack, s_only, _ = build(True, False)
+    only_chain, _, c_only = build(False, True)
+    for w in (both, only_stack, only_chain):
+        w.step(150)
+    ex = both.solve_group_extras()
+    assert (ex[s_both] == 0).all() and (ex[c_both] == 6).all()
+    np.testing.assert_array_equal(both.read()[0][s_both], only_stack.read()[0][s_only])
+    np.testing.assert_array_equal(both.read()[1][s_both], only_stack.read()[1][s_only])
+    np.testing.assert_array_equal(both.read()[0][c_both], only_chain.read()[0][c_only])
