@@ -2378,13 +2378,14 @@ static void solve_velocity_constraints(ro_world *w) {
         }
     }
     }
-    free(grp_body); free(grp_cons); free(grp_joint); free(g_joint_order); free(g_stage_color);
-    /* S8 restitution — worker.rs:657-734 */
+    /* S8 restitution — worker.rs:657-734 (group by group, in the group's own stage order) */
     if (any_bouncy)
-        for (int st = 0; st < w->nstages; ++st) {
-            int c = w->stage_color[st];
-            for (int i = w->bucket_begin[c]; i < w->bucket_begin[c + 1]; ++i) constraint_apply_restitution(w, &w->cons[i]);
-        }
+        for (int grp = 0; grp < ngroups; ++grp)
+            for (int st = 0; st < g_nstages[grp]; ++st) {
+                int c = g_stage_color[grp][st];
+                for (int i = w->bucket_begin[c]; i < w->bucket_begin[c + 1]; ++i) if (ngroups == 1 || grp_cons[i] == grp) constraint_apply_restitution(w, &w->cons[i]);
+            }
+    free(grp_body); free(grp_cons); free(grp_joint); free(g_joint_order); free(g_stage_color);
     /* S9 impulse writeback — worker.rs:742-802 */
     RO_PARALLEL_FOR
     for (int i = 0; i < M; ++i) { if (coulomb) coulomb_writeback(w, &w->cons[i]); else constraint_writeback(w, &w->cons[i]); }

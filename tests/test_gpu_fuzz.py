@@ -228,7 +228,14 @@ def test_fuzz_driver_on_the_oracle_twin(seed):
     _run(seed, steps=120, params=seed >= 2000, world=OracleTwin)
 
 
-def _run(seed, steps=240, walls=False, params=False, world=None, **kw):
+@pytest.mark.parametrize("seed", [10, 11, 12, 2002, 2009])
+def test_fuzz_solve_groups_on_the_oracle_twin(seed):
+    """CPU, oracle only (the device ABI has no additional_solver_iterations yet): random extra substep counts on a third of the
+    bodies — several solve groups with their own cadence — must not depend on the thread count either"""
+    _run(seed, steps=120, params=seed >= 2000, world=OracleTwin, extras=True)
+
+
+def _run(seed, steps=240, walls=False, params=False, world=None, extras=False, **kw):
     sc, rng = _scene(seed, **kw)
     if params:
         _random_params(sc, rng)
@@ -242,6 +249,11 @@ def _run(seed, steps=240, walls=False, params=False, world=None, **kw):
     jb = {j: (int(sc.joints[j]["body1"]), int(sc.joints[j]["body2"])) for j in range(len(sc.joints))}   # live joints -> their bodies
     col_parent = list(sc.collider_parents); ncol = len(col_parent); removed_cols = set()
     log = []
+    if extras:
+        for b in dyn:
+            if rng.random() < 0.33:
+                n_extra = int(rng.choice([1, 2, 4, 7]))
+                g.o.set_additional_solver_iterations(b, n_extra); o.set_additional_solver_iterations(b, n_extra)
     for step in range(1, steps + 1):
         if step % 3 == 0:                                         # the position-based platform follows a script
             t = step / 60.0
