@@ -1,6 +1,8 @@
 """Bisect a fuzz divergence: keep the ground + a chosen set of bodies of a seed scene, neutralise attributes one at a time."""
 import sys
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import copy
 import numpy as np
 import test_gpu_fuzz as F

@@ -1,5 +1,6 @@
 import sys, time
-sys.path.insert(0, '/root/repo')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rapier_amd import PhysicsWorld, scenes as S
 w = PhysicsWorld.from_scene(S.large_pyramid())
 for warm in (60, 500, 1500):
