@@ -79,6 +79,7 @@ typedef struct { v3 mins, maxs; } Aabb;
 typedef struct {
     int parent; pose pos_wrt_parent, pos;
     int shape; v3 he; float radius; int axis; /* capsule: he.x = half height, radius, axis */
+    int sensor;         /* ColliderBuilder::sensor(true): intersection events only, no contacts (oracle only so far) */
     float density, friction, restitution; int friction_rule, restitution_rule;
     uint32_t memberships, filter;
     uint32_t active_events; float force_threshold;
@@ -94,6 +95,7 @@ typedef struct {
     int alive;
     Manifold m;
     /* ContactManifoldData */
+    int intersecting;   /* IntersectionPair::intersecting (sensor pairs) */
     v3 normal; float friction, restitution; int relative_dominance;
     SolverContact sc[4]; int nsc;
     uint32_t solver_body_ids[2];
@@ -863,6 +865,8 @@ static void broad_phase_update(ro_world *w) {
             if (p->nsc > 0 || gone) { wake_request(w, a->parent, 1); wake_request(w, b->parent, 1); }
             /* Stopped event of a touching pair: remove_pair (pair_management.rs:554-558), remove_collider (:101-110, REMOVED flag) */
             if (p->nsc > 0 && ((a->active_events | b->active_events) & 1u)) push_collision_event(w, p->c1, p->c2, 0, gone ? 2 : 0);
+            if (p->intersecting && ((a->active_events | b->active_events) & 1u)) push_collision_event(w, p->c1, p->c2, 0, (gone ? 2 : 0) | 1); /* remove_pair / remove_collider on the intersection graph */
+            p->intersecting = 0;
             clear_pair_solver_color(w, p); removed = 1; continue;
         }
         if (out != i) w->pairs[out] = w->pairs[i];
@@ -963,7 +967,7 @@ static void reduce_manifold_naive(const Manifold *m, int selected[4], int *num_s
     else *num_selected = 4;
 }
 
-typedef struct { int pair; int body1, body2; int touching; } Transition;
+typedef struct { int pair; int body1, body2; int touching; int sensor; } Transition;
 
 static int effective_dominance_group(const ro_world *w, int body) {
     /* RigidBodyDominance::effective_group — rigid_body_components.rs:1269-1275 */
@@ -994,6 +998,56 @@ static int joints_disable_contacts(const ro_world *w, int b1, int b2) {
     return bsearch(&key, w->nc_keys, w->n_nc, sizeof(uint64_t), u64_cmp) != NULL;
 }
 /* outcome: 0 = recycled, 1 = full update; *tr_out->pair = -1 when the pair has no transition */
+/* parry intersection_test for the three shapes: ball-ball (centre distance), cuboid-cuboid (the SAT of the manifold generator: no
+ * separating axis among 3 + 3 face normals and 9 edge cross products), a ball against a convex shape (solid point projection),
+ * capsule-capsule (segment distance).  Cuboid-capsule goes through GJK in parry; here the distance from the capsule's segment to
+ * the box is minimised over the segment parameter (a convex function: ternary search, 48 fixed iterations). */
+static float point_box_dist2(v3 p, v3 he) {
+    float dx = ro_maxf(fabsf(p.x) - he.x, 0.0f), dy = ro_maxf(fabsf(p.y) - he.y, 0.0f), dz = ro_maxf(fabsf(p.z) - he.z, 0.0f);
+    return dx * dx + dy * dy + dz * dz;
+}
+static int shapes_intersect(const Collider *c1, const Collider *c2) {
+    pose pos12 = pose_inv_mul(c1->pos, c2->pos);
+    int s1 = c1->shape, s2 = c2->shape;
+    if (s1 > s2) { /* order the pair: ball < cuboid < capsule */
+        const Collider *t = c1; c1 = c2; c2 = t; pos12 = pose_inv(pos12); s1 = c1->shape; s2 = c2->shape;
+    }
+    if (s1 == RO_SHAPE_BALL && s2 == RO_SHAPE_BALL) { float r = c1->radius + c2->radius; return vdot(pos12.t, pos12.t) <= r * r; }
+    if (s1 == RO_SHAPE_BALL && s2 == RO_SHAPE_CUBOID) { v3 c = pose_itp(pos12, V3(0, 0, 0)); return point_box_dist2(c, c2->he) <= c1->radius * c1->radius; }
+    if (s1 == RO_SHAPE_BALL && s2 == RO_SHAPE_CAPSULE) {
+        v3 c = pose_itp(pos12, V3(0, 0, 0)), e = capsule_axis_dir(c2->axis);
+        v3 q = segment_project_point(vmul(e, -c2->he.x), vmul(e, c2->he.x), c);
+        float r = c1->radius + c2->radius; v3 d = vsub(c, q);
+        return vdot(d, d) <= r * r;
+    }
+    if (s1 == RO_SHAPE_CUBOID && s2 == RO_SHAPE_CUBOID) {
+        v3 d;
+        if (sat_normal_oneway(c1->he, c2->he, pos12, &d) > 0.0f) return 0;
+        if (sat_normal_oneway(c2->he, c1->he, pose_inv(pos12), &d) > 0.0f) return 0;
+        if (sat_edge_twoway(c1->he, c2->he, pos12, &d) > 0.0f) return 0;
+        return 1;
+    }
+    if (s1 == RO_SHAPE_CUBOID && s2 == RO_SHAPE_CAPSULE) {
+        v3 e = capsule_axis_dir(c2->axis);
+        v3 a = pose_tp(pos12, vmul(e, -c2->he.x)), b = pose_tp(pos12, vmul(e, c2->he.x));
+        float lo = 0.0f, hi = 1.0f;
+        for (int it = 0; it < 48; ++it) {
+            float m1 = lo + (hi - lo) / 3.0f, m2 = hi - (hi - lo) / 3.0f;
+            float d1 = point_box_dist2(vadd(vmul(a, 1.0f - m1), vmul(b, m1)), c1->he), d2 = point_box_dist2(vadd(vmul(a, 1.0f - m2), vmul(b, m2)), c1->he);
+            if (d1 <= d2) hi = m2; else lo = m1;
+        }
+        float t = 0.5f * (lo + hi);
+        return point_box_dist2(vadd(vmul(a, 1.0f - t), vmul(b, t)), c1->he) <= c2->radius * c2->radius;
+    }
+    { /* capsule - capsule */
+        v3 e1 = capsule_axis_dir(c1->axis), e2 = capsule_axis_dir(c2->axis);
+        v3 a1 = vmul(e1, -c1->he.x), b1 = vmul(e1, c1->he.x), a2 = pose_tp(pos12, vmul(e2, -c2->he.x)), b2 = pose_tp(pos12, vmul(e2, c2->he.x));
+        float s, t; closest_points_segment_segment(a1, b1, a2, b2, &s, &t);
+        v3 d = vsub(vadd(vmul(a2, 1.0f - t), vmul(b2, t)), vadd(vmul(a1, 1.0f - s), vmul(b1, s)));
+        float r = c1->radius + c2->radius;
+        return vdot(d, d) <= r * r;
+    }
+}
 static int process_pair(ro_world *w, int pair_idx, Transition *tr_out) {
     tr_out->pair = -1;
     Pair *p = &w->pairs[pair_idx];
@@ -1004,6 +1058,16 @@ static int process_pair(ro_world *w, int pair_idx, Transition *tr_out) {
     /* :98-106 — neither body awake (fixed or asleep): skipped */
     if (!body_is_active(w, co1->parent) && !body_is_active(w, co2->parent)) return 2;
 
+    tr_out->sensor = 0;
+    /* sensor pairs live in the intersection graph (narrow_phase/intersections.rs:17-175): no manifold, no solver, no wake-up; the
+     * pair is re-tested while one of its bodies may have moved, Started / Stopped (CollisionEventFlags::SENSOR) on a change */
+    if (co1->sensor || co2->sensor) {
+        int had_i = p->intersecting;
+        p->m.npoints = 0; p->nsc = 0; p->has_recycle = 0;
+        p->intersecting = co1->parent == co2->parent && co1->parent >= 0 ? 0 : shapes_intersect(co1, co2);
+        if (had_i != p->intersecting) { tr_out->pair = pair_idx; tr_out->body1 = co1->parent; tr_out->body2 = co2->parent; tr_out->touching = p->intersecting; tr_out->sensor = 1; }
+        return 2;
+    }
     /* :111-171 contact recycling */
     if (recycle_dist > 0.0f && p->has_recycle) {
         pose pos12 = pose_inv_mul(co1->pos, co2->pos);
@@ -1154,7 +1218,8 @@ static void narrow_phase_compute_contacts(ro_world *w) {
     for (int i = 0; i < ntr; ++i) {
         Pair *p = &w->pairs[tr[i].pair];
         /* contacts.rs:316-323: Started / Stopped for pairs with ActiveEvents::COLLISION_EVENTS */
-        if ((w->colliders[p->c1].active_events | w->colliders[p->c2].active_events) & 1u) push_collision_event(w, p->c1, p->c2, tr[i].touching, 0);
+        if ((w->colliders[p->c1].active_events | w->colliders[p->c2].active_events) & 1u) push_collision_event(w, p->c1, p->c2, tr[i].touching, tr[i].sensor ? 1 : 0);
+        if (tr[i].sensor) continue; /* intersections neither colour nor wake anything */
         if (!tr[i].touching) { clear_pair_solver_color(w, p); continue; }
         /* wake rule (contacts.rs:333-351): starts wake the sleeping side strongly (whole island), stops never wake */
         if (body_is_sleeping_nonfixed(w, tr[i].body1)) wake_request(w, tr[i].body1, 1);
@@ -2649,6 +2714,13 @@ int32_t ro_set_joint_motor(ro_world *w, int32_t joint, int32_t axis, const ro_jo
     j->motors[axis] = *m;
     wake_request(w, j->body1, 1); wake_request(w, j->body2, 1);
     return 0;
+}
+/* Collider::set_sensor (collider.rs) and NarrowPhase::intersection_pair (narrow_phase/queries.rs:167): -1 = no such pair */
+void ro_set_collider_sensor(ro_world *w, int32_t collider, int32_t on) { if (collider >= 0 && collider < w->ncolliders) w->colliders[collider].sensor = on != 0; }
+int32_t ro_intersection_pair(const ro_world *w, int32_t c1, int32_t c2) {
+    int lo = c1 < c2 ? c1 : c2, hi = c1 < c2 ? c2 : c1;
+    for (int i = 0; i < w->npairs; ++i) if (w->pairs[i].alive && w->pairs[i].c1 == lo && w->pairs[i].c2 == hi) return (w->colliders[lo].sensor || w->colliders[hi].sensor) ? w->pairs[i].intersecting : -1;
+    return -1;
 }
 /* RigidBody::set_additional_solver_iterations (rigid_body.rs): extra substeps for the body's connected component */
 void ro_set_additional_solver_iterations(ro_world *w, int32_t body, int32_t n) {

@@ -114,6 +114,10 @@ int32_t ro_remove_joint(ro_world *w, int32_t joint);
 int32_t ro_set_joint_motor(ro_world *w, int32_t joint, int32_t axis, const ro_joint_motor *m);
 /* JointMotor::impulse of the six axes of every joint */
 void ro_read_joint_motor_impulses(const ro_world *w, float *impulses6);
+/* ColliderBuilder::sensor / NarrowPhase::intersection_pair — oracle only so far: sensor pairs generate no
+ * contacts, only Started / Stopped collision events flagged CollisionEventFlags::SENSOR (= 1) */
+void ro_set_collider_sensor(ro_world *w, int32_t collider, int32_t on);
+int32_t ro_intersection_pair(const ro_world *w, int32_t c1, int32_t c2); /* 1 / 0 = intersecting or not, -1 = no such sensor pair */
 /* RigidBody::additional_solver_iterations: the body's whole connected component runs that many extra substeps (substep solve-groups,
  * island_manager/substep_groups.rs).  Oracle only so far: the device ABI does not expose it yet. */
 void ro_set_additional_solver_iterations(ro_world *w, int32_t body, int32_t n);

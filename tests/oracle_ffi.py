@@ -69,6 +69,8 @@ def lib():
         L.ro_read_island_labels.argtypes = [C.c_void_p, C.c_void_p]
         L.ro_set_additional_solver_iterations.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         L.ro_read_solve_group_extras.argtypes = [C.c_void_p, C.c_void_p]
+        L.ro_set_collider_sensor.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        L.ro_intersection_pair.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         _LIB = L
     return _LIB
 
@@ -205,6 +207,13 @@ class OracleWorld:
 
     def set_additional_solver_iterations(self, body, n):
         lib().ro_set_additional_solver_iterations(self._w, int(body), int(n))
+
+    def set_sensor(self, collider, on=True):
+        lib().ro_set_collider_sensor(self._w, int(collider), 1 if on else 0)
+
+    def intersection_pair(self, c1, c2):
+        r = lib().ro_intersection_pair(self._w, int(c1), int(c2))
+        return None if r < 0 else bool(r)
 
     def solve_group_extras(self):
         out = np.zeros(self.n, np.int32)

@@ -1231,3 +1231,55 @@ def test_solve_groups_do_not_disturb_each_other():
     np.testing.assert_array_equal(both.read()[0][s_both], only_stack.read()[0][s_only])
     np.testing.assert_array_equal(both.read()[1][s_both], only_stack.read()[1][s_only])
     np.testing.assert_array_equal(both.read()[0][c_both], only_chain.read()[0][c_only])
+
+
+# ---- sensors (ORACLE ONLY so far): miri_scenes.rs:196-229, narrow_phase/intersections.rs ------------------------------------------
+def test_sensor_overlap():
+    """miri_scenes.rs sensor_overlap: a fixed ball sensor detects the overlapping dynamic ball after one step; the ball falls away
+    (no floor, no contact with the sensor) and the intersection ends.  Started / Stopped carry CollisionEventFlags::SENSOR."""
+    sc = world()
+    sb = sc.add_body(body_type=S.BODY_FIXED)
+    sensor = sc.add_collider(sb, shape=S.SHAPE_BALL, half_extents=(0.5, 0.0, 0.0), active_events=S.ACTIVE_EVENTS_COLLISION)
+    ball = sc.add_body(translation=(0.0, 0.4, 0.0))
+    ball_co = sc.add_collider(ball, shape=S.SHAPE_BALL, half_extents=(0.5, 0.0, 0.0))
+    w = OracleWorld(sc)
+    w.set_sensor(sensor)
+    w.step(1)
+    assert w.intersection_pair(sensor, ball_co) is True
+    ev = w.collision_events()
+    assert len(ev) == 1 and ev[0][2] == 1 and ev[0][3] & 1                      # Started, SENSOR
+    w.step(120)
+    assert w.intersection_pair(sensor, ball_co) is not True
+    assert w.read()[0][ball, 1] < -5.0                                          # it fell straight through: sensors exert no force
+    ev = w.collision_events()
+    assert len(ev) == 1 and ev[0][2] == 0 and ev[0][3] & 1                      # Stopped, SENSOR
+    assert w.stats()["num_active_manifolds"] == 0
+
+
+def test_sensor_shapes_and_trigger_volume():
+    """A cuboid trigger volume on the floor: a capsule, a box and a ball dropped through it raise Started when they enter and
+    Stopped when they have come to rest below / left it; the sensor never deflects them (intersection tests of all shape pairs)."""
+    sc = world()
+    g = ground(sc)
+    trig = sc.add_body(body_type=S.BODY_FIXED, translation=(0.0, 3.0, 0.0))
+    tc = sc.add_collider(trig, half_extents=(4.0, 0.5, 4.0), active_events=S.ACTIVE_EVENTS_COLLISION)
+    cap = sc.add_body(translation=(-2.0, 6.0, 0.0), rotation=quat_from_scaled_axis((0.0, 0.0, 0.7)))
+    sc.add_collider(cap, shape=S.SHAPE_CAPSULE, half_extents=(0.5, 0.25, 1.0))
+    box = sc.add_body(translation=(0.0, 6.5, 0.0), rotation=quat_from_scaled_axis((0.3, 0.2, 0.1)))
+    sc.add_collider(box, half_extents=(0.3, 0.3, 0.3))
+    ball = sc.add_body(translation=(2.0, 7.0, 0.0))
+    sc.add_collider(ball, shape=S.SHAPE_BALL, half_extents=(0.3, 0.0, 0.0))
+    free = OracleWorld(sc)                                                     # the same world without the trigger being a sensor...
+    w = OracleWorld(sc)
+    w.set_sensor(tc)
+    started, stopped = set(), set()
+    for _ in range(240):
+        w.step(1)
+        for c1, c2, st, fl, _ in w.collision_events():
+            assert fl & 1 and tc in (c1, c2)
+            (started if st else stopped).add(c1 + c2 - tc)
+    assert started == stopped == {tc + 1, tc + 2, tc + 3}
+    pos = w.read()[0]
+    assert pos[[cap, box, ball], 1].max() < 1.0                                 # all three rest on the ground, below the trigger
+    free.step(240)
+    assert free.read()[0][[cap, box, ball], 1].min() > 3.0                      # ... where the solid slab catches them
