@@ -96,3 +96,25 @@ def test_column_shard_global_ids_partition_the_world():
         assert len(gids) == len(local.bodies)
         for li, gi in enumerate(gids):
             np.testing.assert_array_equal(local.bodies[li]["translation"], full.bodies[gi]["translation"])
+
+
+def test_header_is_plain_c_and_the_c_example_links(tmp_path):
+    """include/rapier_hip.h is a C header (C99, -pedantic clean) and examples/pyramid.c — a plain-C caller of the ABI — compiles and
+    links against librapier_hip.so (running it needs the GPU)."""
+    import subprocess
+    out = tmp_path / "pyramid"
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "examples", "pyramid.c"), "-L", os.path.join(ROOT, "rapier_amd"), "-lrapier_hip",
+           "-Wl,-rpath," + os.path.join(ROOT, "rapier_amd"), "-o", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert out.exists()
+
+
+def test_roofline_bookkeeping_of_bench():
+    """bench.py's algorithmic bytes: S * [M * 2584 + N * 224] = 303.4 MB for b3d_many_pyramids"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    assert mod.algorithmic_bytes_per_step(28420, 10780) == 4 * (28420 * 2584 + 10780 * 224) == 303408000
+    assert mod.HBM_PEAK_GBS == 8000.0
