@@ -33,6 +33,7 @@ CASES = {
     "limited_joints_s150": lambda: (S.limited_joints(), 150),
     "motorised_joints_s150": lambda: (S.motorised_joints(), 150),
     "capsules6_s150": lambda: (S.capsules(6), 150),
+    "reference_pile_12x3x12_s100": lambda: (S.reference_pile(12, 3, 12, chain=True), 100),
 }
 
 
