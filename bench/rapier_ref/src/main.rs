@@ -3,7 +3,14 @@
 //! /root/reference/examples3d/{b3d_many_pyramids,b3d_large_pyramid,b3d_joint_grid}.rs).  Not compiled in this repository's image
 //! (no Rust toolchain); kept as source so a maintainer can produce the true reference number on the GPU box's host CPU.
 //!
-//!   cargo run --release -- <many_pyramids|large_pyramid|joint_grid|pyramid10> [warmup_steps] [timed_steps]
+//!   cargo run --release -- <many_pyramids|large_pyramid|joint_grid|pyramid10|many_pyramids_c4|reference_pile> [warmup_steps] [timed_steps]
+//!   cargo run --release -- <scene> --dump <dir>     # body states after 1, 10, 100, 1000 steps -> <dir>/<scene>_s<steps>.rpdump
+//!
+//! `--dump` closes SURVEY §8(c) on any machine with cargo: copy the .rpdump files to tests/golden/reference/ and
+//! tests/test_reference_dump.py compares the oracle with them (1e-4 relative on positions, the BASELINE.json tolerance).
+//! File format (little endian): 8 bytes "RPDUMP1\0", u32 body count, u32 steps, then per body in handle-index order 13 f32:
+//! translation xyz, rotation xyzw, linvel xyz, angvel xyz; the last 8 bytes are the FNV-1a state hash of
+//! crates/rapier3d/tests/simd_backend_determinism.rs:36-57 over the same floats.
 
 use rapier3d::prelude::*;
 use std::time::Instant;
@@ -83,18 +90,83 @@ fn joint_grid(n: usize) -> PhysicsWorld {
     world
 }
 
+/// simd_backend_determinism.rs:61-139: jittered 12 x 3 x 12 pile + a 4-ball spherical-joint chain (default sleeping, g = 9.81)
+fn reference_pile() -> PhysicsWorld {
+    let mut world = PhysicsWorld::new();
+    world.gravity = Vector::Y * -9.81;
+    world.insert(RigidBodyBuilder::fixed().translation(Vector::new(0.0, -0.5, 0.0)), ColliderBuilder::cuboid(20.0, 0.5, 20.0));
+    for i in 0..12 {
+        for j in 0..3 {
+            for k in 0..12 {
+                let jitter = (i as f32 * 0.013 + k as f32 * 0.017) % 0.05;
+                world.insert(
+                    RigidBodyBuilder::dynamic().translation(Vector::new(i as f32 * 1.05 - 6.0 + jitter, j as f32 * 1.05 + 0.55, k as f32 * 1.05 - 6.0 - jitter)),
+                    ColliderBuilder::cuboid(0.5, 0.5, 0.5),
+                );
+            }
+        }
+    }
+    let anchor = world.insert_body(RigidBodyBuilder::fixed().translation(Vector::new(0.0, 8.0, 0.0))); // no collider, as in the test
+    let mut prev = anchor;
+    for i in 0..4 {
+        let (rb, _) = world.insert(RigidBodyBuilder::dynamic().translation(Vector::new(0.6 * (i + 1) as f32, 8.0, 0.0)), ColliderBuilder::ball(0.25));
+        world.insert_impulse_joint(prev, rb, SphericalJointBuilder::new().local_anchor1(Vector::X * 0.3).local_anchor2(Vector::X * -0.3));
+        prev = rb;
+    }
+    world
+}
+
+/// Body states in handle-index order + the reference's FNV-1a state hash (see the file header for the format).
+fn dump(world: &PhysicsWorld, path: &std::path::Path, steps: u32) {
+    let mut handles: Vec<_> = world.bodies.iter().map(|(h, _)| h).collect();
+    handles.sort_by_key(|h| h.into_raw_parts().0);
+    let mut out: Vec<u8> = b"RPDUMP1\0".to_vec();
+    out.extend_from_slice(&(handles.len() as u32).to_le_bytes());
+    out.extend_from_slice(&steps.to_le_bytes());
+    let mut hash: u64 = 0xcbf29ce484222325;
+    for h in handles {
+        let rb = &world.bodies[h];
+        let vals = rb.translation().to_array().into_iter().chain(rb.rotation().to_array()).chain(rb.linvel().to_array()).chain(rb.angvel().to_array());
+        for v in vals {
+            for b in v.to_bits().to_le_bytes() {
+                hash ^= b as u64;
+                hash = hash.wrapping_mul(0x100000001b3);
+                out.push(b);
+            }
+        }
+    }
+    out.extend_from_slice(&hash.to_le_bytes());
+    std::fs::write(path, out).expect("write dump");
+    println!("{{\"dump\": \"{}\", \"steps\": {steps}, \"state_hash\": \"{hash:#018x}\"}}", path.display());
+}
+
 fn main() {
     let args: Vec<String> = std::env::args().collect();
     let scene = args.get(1).map(String::as_str).unwrap_or("many_pyramids");
-    let warmup: usize = args.get(2).and_then(|s| s.parse().ok()).unwrap_or(60);
-    let steps: usize = args.get(3).and_then(|s| s.parse().ok()).unwrap_or(1000);
     let mut world = match scene {
         "many_pyramids" => many_pyramids(14, 14),
+        "many_pyramids_c4" => many_pyramids(54, 54), // BASELINE config 4: 160,380 cuboids
         "pyramid10" => many_pyramids(1, 1),
         "large_pyramid" => large_pyramid(200),
         "joint_grid" => joint_grid(100),
+        "reference_pile" => reference_pile(),
         other => panic!("unknown scene {other}"),
     };
+    if args.get(2).map(String::as_str) == Some("--dump") {
+        let dir = std::path::PathBuf::from(args.get(3).expect("--dump <dir>"));
+        std::fs::create_dir_all(&dir).expect("create dump dir");
+        let mut done = 0u32;
+        for target in [1u32, 10, 100, 120, 1000] {
+            while done < target {
+                world.step();
+                done += 1;
+            }
+            dump(&world, &dir.join(format!("{scene}_s{target}.rpdump")), target);
+        }
+        return;
+    }
+    let warmup: usize = args.get(2).and_then(|s| s.parse().ok()).unwrap_or(60);
+    let steps: usize = args.get(3).and_then(|s| s.parse().ok()).unwrap_or(1000);
     for _ in 0..warmup {
         world.step();
     }

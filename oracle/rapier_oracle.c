@@ -1538,13 +1538,15 @@ static void constraint_apply_restitution(ro_world *w, Constraint *c) {
 static void constraint_writeback(ro_world *w, const Constraint *c) {
     Pair *p = &w->pairs[c->pair];
     v3 tangent2 = vcross(c->dir1, c->tangent1);
-    v3 wtw = vadd(vmul(c->tangent1, c->tangent_part.impulse[0]), vmul(tangent2, c->tangent_part.impulse[1]));
+    /* the stored impulses go through utils::canonicalize_zero (x + 0.0: -0.0 becomes +0.0; utils/mod.rs:80-102, enabled by the
+     * reference's enhanced-determinism feature, a bit-level no-op for every other value) */
+    v3 wtw = vcanon(vadd(vmul(c->tangent1, canon0(c->tangent_part.impulse[0])), vmul(tangent2, canon0(c->tangent_part.impulse[1]))));
     for (int k = 0; k < c->num_contacts; ++k) {
         ContactData *pd = &p->m.points[c->contact_id[k]].data;
-        pd->warmstart_impulse = c->normal_part[k].impulse;
-        pd->impulse = c->normal_part[k].impulse_accumulator + c->normal_part[k].impulse;
+        pd->warmstart_impulse = canon0(c->normal_part[k].impulse);
+        pd->impulse = canon0(c->normal_part[k].impulse_accumulator + c->normal_part[k].impulse);
         pd->warmstart_tangent_world = wtw;
-        pd->warmstart_twist_impulse = c->twist_part.impulse;
+        pd->warmstart_twist_impulse = canon0(c->twist_part.impulse);
     }
 }
 
@@ -1739,9 +1741,9 @@ static void coulomb_writeback(ro_world *w, const Constraint *c) {
     v3 tangent2 = vcross(c->dir1, c->tangent1);
     for (int k = 0; k < c->num_contacts; ++k) {
         ContactData *pd = &p->m.points[c->contact_id[k]].data;
-        pd->warmstart_impulse = c->normal_part[k].impulse;
-        pd->impulse = c->normal_part[k].impulse_accumulator + c->normal_part[k].impulse;
-        pd->warmstart_tangent_world = vadd(vmul(c->tangent1, c->ctangent[k].impulse[0]), vmul(tangent2, c->ctangent[k].impulse[1]));
+        pd->warmstart_impulse = canon0(c->normal_part[k].impulse);
+        pd->impulse = canon0(c->normal_part[k].impulse_accumulator + c->normal_part[k].impulse);
+        pd->warmstart_tangent_world = vcanon(vadd(vmul(c->tangent1, canon0(c->ctangent[k].impulse[0])), vmul(tangent2, canon0(c->ctangent[k].impulse[1]))));
     }
 }
 

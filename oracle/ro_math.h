@@ -21,6 +21,9 @@ typedef struct { float m11, m12, m13, m22, m23, m33; } sym3; /* parry SdpMatrix3
 
 static inline v3 V3(float x, float y, float z) { v3 r = {x, y, z}; return r; }
 static inline v3 vadd(v3 a, v3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+/* utils::canonicalize_zero (utils/mod.rs:80-102): x + 0.0 turns -0.0 into +0.0 and leaves every other value untouched */
+static inline float canon0(float x) { volatile float z = 0.0f; return x + z; }
+static inline v3 vcanon(v3 a) { return V3(canon0(a.x), canon0(a.y), canon0(a.z)); }
 static inline v3 vsub(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
 static inline v3 vmul(v3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
 static inline v3 vcmul(v3 a, v3 b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }

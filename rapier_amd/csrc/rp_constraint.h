@@ -349,13 +349,15 @@ RP_DEV void cons_writeback(const DevWorld &w, const Acc &A, int s) {
     int n = A.n(), cids = A.cids();
     float4 h0 = A.ld(CP_H0), h6 = A.ld(CP_H6), hm0 = A.ld(CP_HM0);
     V3 dir1 = v3(h0), t0 = v3(h6), t1 = cross(dir1, t0);
-    V3 wtw = t0 * hm0.z + t1 * hm0.w;
+    // stored impulses are canonicalised (signed zeros -> +0.0, writeback_impulses :783-805)
+    V3 wtw = t0 * rp_canon0(hm0.z) + t1 * rp_canon0(hm0.w);
+    wtw = v3(rp_canon0(wtw.x), rp_canon0(wtw.y), rp_canon0(wtw.z));
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (k >= n) break;
         int cid = (cids >> (8 * k)) & 0xff;
         float4 m = A.ld(NPL(k, NP_M));
-        PT(w.pt_imp, cid, s) = make_float4(m.w + m.z, m.z, hm0.x, 0.0f);
+        PT(w.pt_imp, cid, s) = make_float4(rp_canon0(m.w + m.z), rp_canon0(m.z), rp_canon0(hm0.x), 0.0f);
         PT(w.pt_wst, cid, s) = f4(wtw, 0.0f);
     }
 }

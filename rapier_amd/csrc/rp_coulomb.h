@@ -242,8 +242,9 @@ RP_DEV void coul_writeback(const DevWorld &w, const Acc &A, int s) {
         int cid = (cids >> (8 * k)) & 0xff;
         float4 m = A.ld(NPL(k, NP_M)), tm = A.ld(CQL(k, CQ_M));
         float4 old = PT(w.pt_imp, cid, s);
-        PT(w.pt_imp, cid, s) = make_float4(m.w + m.z, m.z, old.z, 0.0f);
-        PT(w.pt_wst, cid, s) = f4(t0 * tm.x + t1 * tm.y, 0.0f);
+        V3 wtw = t0 * rp_canon0(tm.x) + t1 * rp_canon0(tm.y); // canonicalised like every stored impulse (:690-711)
+        PT(w.pt_imp, cid, s) = make_float4(rp_canon0(m.w + m.z), rp_canon0(m.z), old.z, 0.0f);
+        PT(w.pt_wst, cid, s) = f4(v3(rp_canon0(wtw.x), rp_canon0(wtw.y), rp_canon0(wtw.z)), 0.0f);
     }
 }
 

@@ -512,12 +512,13 @@ RP_DEV void isl_restitution(IslSide &h, const IslLds &L) {
 
 // writeback_impulses (:783-829) — even lane
 RP_DEV void isl_writeback(const DevWorld &w, const IslSide &h, int s) {
-    V3 wtw = h.t0 * h.t_imp0 + h.t1 * h.t_imp1;
+    V3 wtw = h.t0 * rp_canon0(h.t_imp0) + h.t1 * rp_canon0(h.t_imp1); // canonicalised zeros, as in cons_writeback
+    wtw = v3(rp_canon0(wtw.x), rp_canon0(wtw.y), rp_canon0(wtw.z));
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (k >= h.n) break;
         int cid = (h.cids >> (8 * k)) & 0xff;
-        PT(w.pt_imp, cid, s) = make_float4(h.P[k].acc + h.P[k].lam, h.P[k].lam, h.tw_imp, 0.0f);
+        PT(w.pt_imp, cid, s) = make_float4(rp_canon0(h.P[k].acc + h.P[k].lam), rp_canon0(h.P[k].lam), rp_canon0(h.tw_imp), 0.0f);
         PT(w.pt_wst, cid, s) = f4(wtw, 0.0f);
     }
 }

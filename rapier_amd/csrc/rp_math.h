@@ -28,6 +28,8 @@ RP_HD float comp(V3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 RP_HD float4 f4(V3 a, float w) { return make_float4(a.x, a.y, a.z, w); }
 RP_HD float rp_inv(float x) { return (x > -1.0e-20f && x < 1.0e-20f) ? 0.0f : 1.0f / x; }
 RP_HD float rp_max(float a, float b) { return a > b ? a : b; }
+// utils::canonicalize_zero (utils/mod.rs:80-102): x + 0.0 turns -0.0 into +0.0, every other value is untouched (IEEE: not foldable)
+RP_HD float rp_canon0(float x) { return x + 0.0f; }
 RP_HD float rp_min(float a, float b) { return a < b ? a : b; }
 RP_HD float rp_clamp(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
