@@ -1,18 +1,25 @@
 #!/usr/bin/env python
 """bench.py — physics steps/sec on b3d_many_pyramids (BASELINE.json metric), MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload auto|c3|c4|large_pyramid|joint_grid]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-A "step" is one PhysicsPipeline::step() of the resident world (inputs already in HBM).  N = 1: the
-workload is BASELINE config C3 = b3d_many_pyramids (14x14 pyramids, 10,780 cuboids, M = 28,420
-solver manifolds).  N > 1: weak scaling over independent contact islands: the node
-holds a 14 x 14N pyramid world, rank r owns pyramid columns [14r, 14r+14) (ground replicated) and
-steps them with NO data-path collective; `value` = N * K / t_max = many_pyramids-sized world-steps
-per second across the node.  One all-gather of packed body state (RCCL) after the timed region
-assembles the world on every rank (readback, not timed).
+A "step" is one PhysicsPipeline::step() of the resident world (inputs already in HBM).
+
+N = 1 (default workload): BASELINE config C3 = b3d_many_pyramids (14x14 pyramids, 10,780 cuboids, M = 28,420 solver
+manifolds); `value` = steps/s.
+
+N > 1: independent contact islands sharded over the ranks, NO data-path collective.  The world is the
+many_pyramids generator at BASELINE config C4's density: N = 8 is exactly C4 (54x54 = 2,916 pyramids = 160,380 cuboids,
+364-365 islands per rank by `sharding.bin_pack`), N = 2 / 4 are 27x27 / 27x54 (the same ~364.5 islands per rank), so the
+per-GPU work is fixed as N grows ("weak").  `value` keeps the metric's unit and workload: C3-equivalent steps/s =
+(cuboids stepped by all ranks / 10,780) * K / t_max, i.e. whole-job cuboid-steps/s normalised to the b3d_many_pyramids
+world of N = 1; the absolute rate of the sharded world (C4 steps/s at N = 8) is reported beside it as
+`config.sharded_world_steps_per_s`.  `--workload c4 --gpus 1` steps all of C4 on one GPU (the strong-scaling reference
+for the N = 8 line).  One all-gather of packed body state (RCCL) after the timed region assembles the world (readback, not timed).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -23,11 +30,35 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+C3_CUBOIDS = 10780
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "many_pyramids_hbm_traffic.json")
+# sources whose change invalidates a recorded HBM-traffic measurement of the dominant kernel
+KERNEL_SOURCES = ["rapier_amd/csrc/rp_islands.hip", "rapier_amd/csrc/rp_constraint.h", "rapier_amd/csrc/rp_pairs.h", "rapier_amd/csrc/rp_world.h"]
 
 
 def algorithmic_bytes_per_step(M: int, N: int, substeps: int = 4) -> float:
     """B_solve(step) = S * [ M * (1100 + 476 + 1008) + N * 224 ] bytes."""
     return substeps * (M * (1100.0 + 476.0 + 1008.0) + N * 224.0)
+
+
+def kernel_code_sha() -> str:
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def recorded_traffic():
+    """HBM bytes per launch of the dominant kernel from the separate rocprofv3 --pmc passes (tools/gpu_profile.sh writes the file
+    with the hash of the kernel sources it measured).  A record taken on different kernel code is refused: traffic = null."""
+    if not os.path.exists(TRAFFIC_FILE):
+        return None, "no PMC record (profiles/many_pyramids_hbm_traffic.json)"
+    with open(TRAFFIC_FILE) as f:
+        rec = json.load(f)
+    if rec.get("kernel_code_sha") != kernel_code_sha():
+        return None, f"stale PMC record refused (kernel sources changed since {rec.get('kernel_code_sha')})"
+    return rec.get("k_island_solve_hbm_bytes_per_launch"), "rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE per the guide), same kernel sources"
 
 
 def cpu_baseline(steps: int = 400, warmup: int = 60):
@@ -52,44 +83,73 @@ def cpu_baseline(steps: int = 400, warmup: int = 60):
                       f"(C restatement, OpenMP, {cores} threads; {steps // 4} steps on 1 thread)"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=60)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--roofline-steps", type=int, default=200)
-    args = ap.parse_args()
+def build_workload(name: str, world: int, rank: int):
+    """(scene of this rank, description, global ids of its bodies or None, global body count, pyramid grid or None)"""
+    from rapier_amd import scenes as S, sharding
+    if name == "auto":
+        name = "c3" if world == 1 else "c4"
+    if name == "c3":
+        if world != 1:
+            raise SystemExit("--workload c3 is the single-GPU metric configuration")
+        return S.many_pyramids(), "b3d_many_pyramids (14x14 pyramids, 10,780 cuboids, f32, dt=1/60, 4 substeps)", None, None, (14, 14)
+    if name == "c4":
+        rows, cols = sharding.C4_GRIDS.get(world, (54, 54))
+        mask, gids, n_global = sharding.island_shard(rows, cols, 10, world, rank)
+        scene = S.many_pyramids(rows, cols, pyramids=mask)
+        desc = (f"b3d_many_pyramids at BASELINE config C4 density: {rows}x{cols} pyramids = {rows * cols * 55:,} cuboids"
+                f"{' (= C4)' if (rows, cols) == (54, 54) else ''}, islands bin-packed over {world} rank(s): {int(mask.sum())} islands on rank {rank}")
+        return scene, desc, gids, n_global, (rows, cols)
+    if name.startswith("grid:"):  # grid:RxC — small sharded worlds for the CPU control-flow test
+        rows, cols = (int(v) for v in name[5:].split("x"))
+        mask, gids, n_global = sharding.island_shard(rows, cols, 10, world, rank)
+        return S.many_pyramids(rows, cols, pyramids=mask), f"many_pyramids {rows}x{cols} sharded over {world}", gids, n_global, (rows, cols)
+    if world != 1:
+        raise SystemExit(f"--workload {name} is a single-island / single-GPU scene: replicas only (DESIGN.md §7)")
+    if name == "large_pyramid":
+        return S.large_pyramid(200), "b3d_large_pyramid (20,100 cuboids, one island)", None, None, None
+    if name == "joint_grid":
+        return S.joint_grid(100), "b3d_joint_grid (100x100 balls, 19,800 spherical joints)", None, None, None
+    raise SystemExit(f"unknown workload {name}")
 
-    import torch  # first: the HIP runtime that torch loads is the one the library binds to
+
+def run(args, make_world=None, backend: str = "nccl", use_cuda: bool = True):
+    """The bench control flow.  `make_world(scene, device)` defaults to the HIP product (`PhysicsWorld.from_scene`); the CPU test of
+    the N > 1 leg passes the oracle in its place with backend="gloo", so the only lines it cannot reach are the nccl / cuda ones."""
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch = None
+    if use_cuda:
+        import torch  # first: the HIP runtime that torch loads is the one the library binds to
     dist = None
     if world > 1:
+        import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    elif torch.cuda.is_available():
+        if use_cuda:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    elif use_cuda and torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
 
     import numpy as np
-    from rapier_amd import PhysicsWorld, scenes as S, sharding
+    from rapier_amd import scenes as S, sharding
+    if make_world is None:
+        from rapier_amd import PhysicsWorld
+        make_world = PhysicsWorld.from_scene
 
-    if world > 1:
-        scene = S.many_pyramids(rows=14, cols=14 * world, col_range=(14 * rank, 14 * rank + 14))
-        workload = f"b3d_many_pyramids weak-scaled: 14x{14 * world} pyramids, rank owns 14x14 (10,780 cuboids/GPU)"
-    else:
-        scene = S.many_pyramids()
-        workload = "b3d_many_pyramids (14x14 pyramids, 10,780 cuboids, f32, dt=1/60, 4 substeps)"
-    w = PhysicsWorld.from_scene(scene, device=local_rank)
+    scene, workload, gids, n_global, grid = build_workload(args.workload, world, rank)
+    w = make_world(scene, local_rank)
+    dev = "cuda" if use_cuda else None
 
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if use_cuda:
+            torch.cuda.synchronize()
 
     w.step(args.warmup)
     w.sync()
@@ -100,42 +160,52 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     counters = w.counters()
     M, Nd = counters["num_manifolds"], counters["num_dynamic_bodies"]
+    total_cuboids = Nd
+    if dist is not None:
+        tn = torch.tensor([Nd], dtype=torch.int64, device=dev)
+        dist.all_reduce(tn, op=dist.ReduceOp.SUM)
+        total_cuboids = int(tn.item())
 
-    # roofline leg: k_island_solve (one launch per step = the whole TGS velocity-solve loop of every
-    # island) timed with hipEvents on the world's own stream, right after the timed region
-    w.enable_timers(True)
-    w.step(args.roofline_steps)
-    w.sync()
-    loop_ms, nmeas = w.solver_loop_time_ms()
-    tc = w.counters()
-    w.enable_timers(False)
-    bytes_step = algorithmic_bytes_per_step(M, Nd, int(scene.params["num_solver_iterations"]))
-    achieved = bytes_step / (loop_ms * 1e-3) / 1e9 if loop_ms > 0 else 0.0
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "r01_many_pyramids_hbm_traffic.json")
-    if world == 1 and os.path.exists(tfile):  # PMC passes are separate rocprofv3 runs (tools/gpu_profile.sh)
-        with open(tfile) as f:
-            traffic = json.load(f).get("k_island_solve_hbm_bytes_per_launch")
+    # roofline leg: the dominant kernel timed with hipEvents on the world's own stream, right after the timed region
+    roof = None
+    if hasattr(w, "enable_timers"):
+        w.enable_timers(True)
+        w.step(args.roofline_steps)
+        w.sync()
+        loop_ms, nmeas = w.solver_loop_time_ms()
+        tc = w.counters()
+        w.enable_timers(False)
+        bytes_step = algorithmic_bytes_per_step(M, Nd, int(scene.params["num_solver_iterations"]))
+        achieved = bytes_step / (loop_ms * 1e-3) / 1e9 if loop_ms > 0 else 0.0
+        traffic, traffic_note = recorded_traffic() if (world == 1 and args.workload in ("auto", "c3")) else (None, "PMC record exists for the N = 1 metric workload only")
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": "k_island_solve (TGS velocity-solve loop: 4 substeps x [warmstart, biased, relaxed sweeps] of every LDS-resident island, 1 launch/step)",
+                "algorithmic_bytes_per_launch": bytes_step, "kernel_ms_per_launch": loop_ms, "measured_launches": nmeas,
+                "traffic_note": traffic_note, "kernel_code_sha": kernel_code_sha(),
+                "stage_ms": {k: tc[k] for k in ("collision_detection_ms", "velocity_resolution_ms", "velocity_update_ms")},
+                "path": {k: tc[k] for k in ("fast_steps", "full_steps", "replayed_steps")}}
 
     # readback (not timed): assemble the world state with one all-gather over RCCL/xGMI
     pos, vel = w.read_bodies()
     finite = bool(np.isfinite(pos).all())
+    gathered = None
     if dist is not None:
         dyn = np.array([int(b["body_type"]) == S.BODY_DYNAMIC for b in scene.bodies])
-        per = 55
-        gids = sharding.column_shard_global_ids(14, 14, 10, world, rank)
-        gpos, _ = sharding.all_gather_bodies(pos, vel, gids, 1 + 14 * 14 * world * per, dyn, device="cuda")
-        finite = finite and bool(np.isfinite(gpos).all())
+        gathered = sharding.all_gather_bodies(pos, vel, gids, n_global, dyn, device=dev)
+        finite = finite and bool(np.isfinite(gathered[0]).all())
 
+    out = None
     if rank == 0:
+        is_metric_workload = world == 1 and args.workload in ("auto", "c3")
+        value = (total_cuboids / C3_CUBOIDS) * args.steps / dt
         out = {
             "metric": "physics steps/sec (whole node), b3d_many_pyramids 3D f32",
-            "value": world * args.steps / dt,
+            "value": args.steps / dt if is_metric_workload else value,
             "unit": "steps/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -146,26 +216,35 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic (closed-form scene generator, no RNG)",
-            "config": {"workload": workload, "bodies_per_gpu": Nd, "solver_manifolds_per_gpu": M,
-                       "colors": counters["num_colors"], "value_definition": "n_gpus * steps / max-over-ranks time"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_island_solve (TGS velocity-solve loop: 4 substeps x [warmstart, biased, relaxed sweeps] of all 196 islands, 1 launch/step)",
-                         "algorithmic_bytes_per_launch": bytes_step, "kernel_ms_per_launch": loop_ms, "measured_launches": nmeas,
-                         "traffic_note": "HBM bytes/launch from rocprofv3 PMC passes (profiles/); constraints live in VGPRs/LDS, so traffic << algorithmic bytes",
-                         "stage_ms": {k: tc[k] for k in ("collision_detection_ms", "velocity_resolution_ms", "velocity_update_ms")},
-                         "path": {k: tc[k] for k in ("fast_steps", "full_steps", "replayed_steps")}},
+            "config": {"workload": workload, "bodies_per_gpu": Nd, "solver_manifolds_per_gpu": M, "total_cuboids": total_cuboids,
+                       "colors": counters["num_colors"], "pyramid_grid": list(grid) if grid else None,
+                       "sharded_world_steps_per_s": args.steps / dt,
+                       "value_definition": "steps / max-over-ranks time" if is_metric_workload else
+                       "C3-equivalent steps/s = (cuboids stepped by all ranks / 10,780) * steps / max-over-ranks time; sharded_world_steps_per_s = steps/s of the whole sharded world"},
+            "roofline": roof,
             "finite": finite,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and is_metric_workload:
             out["cpu_baseline"] = cpu_baseline()
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return out, gathered
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=60)
+    ap.add_argument("--workload", default="auto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roofline-steps", type=int, default=200)
+    return ap.parse_args(argv)
 
 
 if __name__ == "__main__":
-    main()
+    run(parse_args())

@@ -227,9 +227,9 @@ def _small_pyramid(scene: Scene, base_count: int, extent, center_x, base_z):
             scene.add_collider(b, half_extents=(extent, extent, extent), density=100.0)
 
 
-def many_pyramids(rows: int = 14, cols: int = 14, base_count: int = 10, col_range=None) -> Scene:
-    """b3d_many_pyramids.rs:36-64.  ``col_range=(lo, hi)`` keeps only pyramid columns lo..hi-1 (the
-    multi-GPU island shard; the ground is replicated)."""
+def many_pyramids(rows: int = 14, cols: int = 14, base_count: int = 10, col_range=None, pyramids=None) -> Scene:
+    """b3d_many_pyramids.rs:36-64.  ``col_range=(lo, hi)`` keeps only pyramid columns lo..hi-1, ``pyramids`` (a boolean mask over
+    the row-major pyramid index r * cols + c) only the selected islands: the multi-GPU island shards (the ground is replicated)."""
     s = Scene(name=f"b3d_many_pyramids_{rows}x{cols}")
     extent = _f(0.5)
     ground_extent = extent * _f(cols) * (_f(base_count) + _f(1.0))
@@ -239,10 +239,10 @@ def many_pyramids(rows: int = 14, cols: int = 14, base_count: int = 10, col_rang
     base_z = -ground_extent + _f(2.0) * extent
     delta_z = _f(2.0) * (ground_extent - _f(2.0) * extent) / (_f(rows) - _f(1.0)) if rows > 1 else _f(0.0)
     lo, hi = col_range if col_range is not None else (0, cols)
-    for _ in range(rows):
+    for _r in range(rows):
         for j in range(cols):
             center_x = -ground_extent + _f(j) * (base_width + _f(2.0) * extent) + _f(2.0) * extent
-            if lo <= j < hi:
+            if lo <= j < hi and (pyramids is None or pyramids[_r * cols + j]):
                 _small_pyramid(s, base_count, extent, center_x, base_z)
         base_z = base_z + delta_z
     return s

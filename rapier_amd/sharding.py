@@ -76,12 +76,17 @@ def all_gather_bodies(local_pos: np.ndarray, local_vel: np.ndarray, global_ids: 
     all_counts = [torch.zeros_like(counts) for _ in range(world)]
     dist.all_gather(all_counts, counts)
     maxn = int(max(int(c.item()) for c in all_counts))
-    buf = torch.zeros((maxn, 14), dtype=torch.float32, device=device)
+    # body state travels as f32, the global ids as int64 in a gather of their own (an f32 is exact only below 2^24 bodies)
+    buf = torch.zeros((maxn, 13), dtype=torch.float32, device=device)
+    ids_buf = torch.full((maxn,), -1, dtype=torch.int64, device=device)
     if own.any():
-        payload = np.concatenate([packed[own], global_ids[own, None].astype(np.float32)], axis=1)
-        buf[: payload.shape[0]] = torch.from_numpy(payload).to(buf.device)
+        n_own = int(own.sum())
+        buf[:n_own] = torch.from_numpy(packed[own]).to(buf.device)
+        ids_buf[:n_own] = torch.from_numpy(np.ascontiguousarray(global_ids[own], np.int64)).to(buf.device)
     gathered = [torch.zeros_like(buf) for _ in range(world)]
+    gathered_ids = [torch.zeros_like(ids_buf) for _ in range(world)]
     dist.all_gather(gathered, buf)
+    dist.all_gather(gathered_ids, ids_buf)
     pos = np.zeros((n_global, 7), np.float32)
     vel = np.zeros((n_global, 6), np.float32)
     # fixed bodies are replicated: take them from the local copy
@@ -93,7 +98,7 @@ def all_gather_bodies(local_pos: np.ndarray, local_vel: np.ndarray, global_ids: 
         if n == 0:
             continue
         g = gathered[r][:n].cpu().numpy()
-        ids = g[:, 13].astype(np.int64)
+        ids = gathered_ids[r][:n].cpu().numpy()
         pos[ids] = g[:, :7]
         vel[ids] = g[:, 7:13]
     return pos, vel
@@ -107,3 +112,20 @@ def column_shard_global_ids(rows: int, cols_per_rank: int, base_count: int, worl
     local = np.arange(rows * cols_per_rank * per)
     row, in_row = local // (cols_per_rank * per), local % (cols_per_rank * per)
     return np.concatenate([[0], 1 + row * (cols_per_rank * world_size * per) + rank * cols_per_rank * per + in_row]).astype(np.int64)
+
+
+def island_shard(rows: int, cols: int, base_count: int, world_size: int, rank: int):
+    """Shard of a rows x cols many_pyramids world for `rank`: the pyramids (= independent contact islands) are bin-packed by body
+    count onto the ranks (`bin_pack`: 2,916 islands over 8 ranks = 364 or 365 each for BASELINE config C4), the ground is
+    replicated.  Returns (pyramid mask for scenes.many_pyramids(pyramids=...), global body ids of the shard's bodies in the
+    shard's own insertion order, global body count)."""
+    per = base_count * (base_count + 1) // 2
+    ranks = bin_pack([per] * (rows * cols), world_size)
+    mask = ranks == rank
+    owned = np.flatnonzero(mask)
+    gids = np.concatenate([[0], (1 + owned[:, None] * per + np.arange(per)[None, :]).ravel()]).astype(np.int64)
+    return mask, gids, 1 + rows * cols * per
+
+
+# bench.py --gpus N: the pyramid grid each N steps (C4-shaped: ~364.5 islands per GPU; N = 8 is exactly BASELINE config C4)
+C4_GRIDS = {1: (54, 54), 2: (27, 27), 4: (27, 54), 8: (54, 54)}

@@ -82,6 +82,47 @@ def test_large_pyramid_bit_exact():
     _compare(S.large_pyramid(60), [1, 10, 30])
 
 
+def _oracle_threads():
+    import os
+    import oracle_ffi
+    oracle_ffi.set_threads(max(1, min(os.cpu_count() or 1, 16)))
+    return oracle_ffi
+
+
+def test_large_pyramid_full_size_bit_exact():
+    """BASELINE config C2 at its stated size: b3d_large_pyramid base 200 = 20,100 cuboids in ONE island (~59,900 manifolds, the
+    global path with every colour a parallel stage), 1 / 3 / 10 steps, every bit."""
+    ffi = _oracle_threads()
+    try:
+        g, _ = _compare(S.large_pyramid(200), [1, 3, 10])
+    finally:
+        ffi.set_threads(1)
+    c = g.counters()
+    assert c["num_dynamic_bodies"] == 20100 and c["num_manifolds"] > 59000, c
+
+
+def test_many_pyramids_c4_single_gpu_bit_exact():
+    """BASELINE config C4 (b3d_many_pyramids scaled to 54 x 54 = 2,916 pyramids = 160,380 cuboids) on ONE GPU: 1 and 5 steps."""
+    ffi = _oracle_threads()
+    try:
+        g, _ = _compare(S.many_pyramids(54, 54), [1, 5])
+    finally:
+        ffi.set_threads(1)
+    c = g.counters()
+    assert c["num_dynamic_bodies"] == 160380 and c["num_manifolds"] == 2916 * 145, c
+
+
+def test_joint_grid_full_size_60_steps_bit_exact():
+    """BASELINE config C5 at its stated size (100 x 100 balls, 19,800 spherical joints) for 60 steps, joint colours and impulses
+    included."""
+    ffi = _oracle_threads()
+    try:
+        g, o = _compare(S.joint_grid(100), [1, 20, 60])
+    finally:
+        ffi.set_threads(1)
+    _compare_joints(g, o)
+
+
 def test_tumble_dynamic_scene_bit_exact():
     """Rotated cuboids + balls with velocities: full updates, edge/edge SAT, reduction, pair
     deletion, recolouring, restitution, damping."""

@@ -32,4 +32,8 @@ for k in sorted(set(fetch) | set(write)):
     out["kernels"][k] = {"launches_fetch_pass": fetch[k][1] if k in fetch else 0, "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "hbm_bytes": (2.0 * f + w) * 1024.0}
 isl = out["kernels"].get("k_island_solve")
 out["k_island_solve_hbm_bytes_per_launch"] = isl["hbm_bytes"] if isl else None
+# stamp: bench.py refuses this record once the kernel sources change (a stale traffic figure is worse than none)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+out["kernel_code_sha"] = bench.kernel_code_sha()
 print(json.dumps(out, indent=1))
