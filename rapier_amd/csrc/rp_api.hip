@@ -45,6 +45,8 @@ void rp_launch_wake_partners(const DevWorld &w, hipStream_t st);
 void rp_launch_force_events(const DevWorld &w, hipStream_t st);
 void rp_launch_idle_step(const DevWorld &w, hipStream_t st);
 void rp_launch_clear_no_contact(const DevWorld &w, hipStream_t st);
+void rp_launch_global_flow(const DevWorld &w, hipStream_t st, int grid, int has_restitution);
+int rp_flow_grid(int device);
 
 struct HostBody {
     rp_body_desc d; float inv_mass; float inv_pi[3]; float lcom[3]; int ncolliders; bool removed;
@@ -94,6 +96,8 @@ struct rp_world {
     hipGraphExec_t ge_whole[2] = {nullptr, nullptr}, ge_col[2] = {nullptr, nullptr}, ge_loop[2] = {nullptr, nullptr}, ge_fin[2] = {nullptr, nullptr};
     int graph_stages = -1, graph_blocks = -1, graph_single = -1, graph_island_grid = -1, graph_joint_stages = -1, graph_no_global = -1, graph_fused = -1;
     bool use_graph = true, use_fast = true, use_fused = true;
+    bool use_flow = true;          // MULTI mode of the global path = the dataflow launch (rp_flow.hip); RP_NO_FLOW=1: one launch per colour stage
+    int flow_grid = 0;             // workgroups of the dataflow launch (all resident at once), 0 = unavailable
     bool compound = false;         // some dynamic body carries several colliders or an offset collider (no fused fast step)
     bool timed_ready[2] = {false, false};
     int cur_fast = 0;              // mode the enqueue_* callbacks capture
@@ -242,6 +246,9 @@ extern "C" int32_t rp_world_create(const rp_integration_params *params, const fl
     if (g && g[0] == '1') w->use_fast = false;
     g = getenv("RP_NO_FUSED");
     if (g && g[0] == '1') w->use_fused = false;
+    g = getenv("RP_NO_FLOW");
+    if (g && g[0] == '1') w->use_flow = false;
+    if (w->use_flow) { w->flow_grid = rp_flow_grid(device); if (w->flow_grid <= 0) w->use_flow = false; }
     memset(&w->dw, 0, sizeof(w->dw));
     *out = w;
     return RP_OK;
@@ -862,7 +869,7 @@ static int carry_over(rp_world *w) {
     memcpy(w->pinned_flags, w->old_pinned, FL_COUNT * sizeof(int));
     rp_launch_bp_rehash(d, w->stream); // the live pairs enter the (larger) current-epoch table
     int one = 1;
-    for (int f : {FL_BP_DIRTY, FL_LAYOUT_DIRTY, FL_JOINT_DIRTY}) HIPCHK(w, hipMemcpyAsync(d.flags + f, &one, sizeof(int), hipMemcpyHostToDevice, w->stream));
+    for (int f : {FL_BP_DIRTY, FL_LAYOUT_DIRTY, FL_JOINT_DIRTY, FL_FLOW_DIRTY}) HIPCHK(w, hipMemcpyAsync(d.flags + f, &one, sizeof(int), hipMemcpyHostToDevice, w->stream));
     HIPCHK(w, hipStreamSynchronize(w->stream));
     w->pinned_flags[FL_LAYOUT_DIRTY] = 1; // next steps stay on the full graph until the device reports a clean state
     w->full_until = w->steps_requested + 3;
@@ -1017,6 +1024,9 @@ static int finalize(rp_world *w) {
     }
     DA(d.C, (size_t)(w->params.friction_model == RP_FRICTION_COULOMB ? CQ_COUNT : CP_COUNT) * d.cons_cap); // Coulomb: + 9 tangent planes per point (rp_coulomb.h)
     DA(d.k_b1, d.cons_cap); DA(d.k_b2, d.cons_cap); DA(d.k_n, d.cons_cap); DA(d.k_cid, d.cons_cap);
+    // dataflow solver: toucher lists, rebuilt on the device whenever the layout changes (no carry-over needed)
+    DA(d.fk_rank, d.cons_cap); DA(d.fj_rank, std::max(nj, 1)); DA(d.fb_deg, capb); DA(d.fb_begin, capb); DA(d.fb_fill, capb);
+    DA(d.f_adj, 2 * (size_t)d.cons_cap); DA(d.f_jadj, 2 * (size_t)std::max(nj, 1));
 
     // host SoA staging (one batched copy per attribute)
     {
@@ -1044,7 +1054,7 @@ static int finalize(rp_world *w) {
         HIPCHK(w, hipStreamSynchronize(w->stream)); // the staging vectors die here
     }
     std::vector<int> fl(FL_COUNT, 0);
-    fl[FL_BP_DIRTY] = 1; fl[FL_LAYOUT_DIRTY] = 1; fl[FL_JOINT_DIRTY] = 1;
+    fl[FL_BP_DIRTY] = 1; fl[FL_LAYOUT_DIRTY] = 1; fl[FL_JOINT_DIRTY] = 1; fl[FL_FLOW_DIRTY] = 1;
     UP(d.flags, fl);
     HIPCHK(w, hipHostMalloc((void **)&w->pinned_flags, FL_COUNT * sizeof(int), hipHostMallocMapped));
     memset(w->pinned_flags, 0, FL_COUNT * sizeof(int));
@@ -1081,6 +1091,7 @@ static void enqueue_global_solver(rp_world *w) {
     int hr = w->has_restitution ? 1 : 0;
     if (w->cur_fast && w->plan_no_global) return; // k_fast_front verified on the device that the global path is empty
     if (w->plan_single) rp_launch_global_single(w->dw, w->stream, hr, w->cur_fast);
+    else if (w->use_flow) rp_launch_global_flow(w->dw, w->stream, w->flow_grid, hr); // one dataflow launch (rp_flow.hip)
     else {
         rp_launch_solver_assembly(w->dw, w->stream);
         rp_launch_solver_loop(w->dw, w->stream, w->plan_stages, w->plan_blocks, hr, w->plan_joint_stages);
@@ -1101,9 +1112,10 @@ static void plan_from_hints(rp_world *w, const int *fl) {
     if (force && force[0] == '1') w->plan_single = 0;
     w->plan_stages = fl[FL_N_PARALLEL];
     w->plan_joint_stages = fl[FL_NJ_STAGES];
+    if (w->use_flow) { w->plan_stages = 0; w->plan_joint_stages = 0; } // the dataflow launch does not depend on the stage layout
     w->plan_no_global = (fl[FL_N_CONS] == 0 && fl[FL_N_GLOB_BODIES] == 0 && w->dw.n_joints == 0) ? 1 : 0;
     // round up to a power of two so small changes of the stage size do not force a re-capture
-    w->plan_blocks = std::min(std::max(pow2_ceil((fl[FL_MAX_STAGE] + 255) / 256), 1), 4096);
+    w->plan_blocks = w->use_flow ? 1 : std::min(std::max(pow2_ceil((fl[FL_MAX_STAGE] + 255) / 256), 1), 4096);
     w->plan_island_grid = std::min(std::max(pow2_ceil(fl[FL_N_ISLANDS]), 1), 8192);
     // fused single-kernel fast step: every workgroup must be resident at once (in-launch arrival barrier)
     // (a grid of at most RP_FUSED_MAX_GRID workgroups, one per CU; workgroups loop over islands beyond that)
@@ -1123,8 +1135,8 @@ static void enqueue_whole(rp_world *w) { enqueue_collision(w); enqueue_solver(w)
 static int check_overflow(rp_world *w, const int *fl) {
     if (fl[FL_OVERFLOW]) {
         char buf[256];
-        snprintf(buf, sizeof(buf), "device buffer overflow (flags 0x%x: 1=pair pool 2=pair hash 4=grid cells 8=large list 16=constraints); "
-                 "raise RP_PAIRS_PER_COLLIDER", fl[FL_OVERFLOW]);
+        snprintf(buf, sizeof(buf), "device error (flags 0x%x: 1=pair pool 2=pair hash 4=grid cells 8=large list 16=constraints: raise RP_PAIRS_PER_COLLIDER; "
+                 "32=fused step: a workgroup was not resident 64=dataflow solver stalled: the GPU is shared, set RP_NO_FLOW=1)", fl[FL_OVERFLOW]);
         w->err = buf;
         return RP_ERR_CAPACITY;
     }
@@ -1514,7 +1526,7 @@ static int set_flag(rp_world *w, int slot, int v) { return poke(w, w->dw.flags +
 static int after_topology_edit(rp_world *w) {
     if (!w->finalized) return RP_OK;
     int r;
-    if ((r = set_flag(w, FL_BP_DIRTY, 1)) != RP_OK || (r = set_flag(w, FL_LAYOUT_DIRTY, 1)) != RP_OK || (r = set_flag(w, FL_JOINT_DIRTY, 1)) != RP_OK) return r;
+    if ((r = set_flag(w, FL_BP_DIRTY, 1)) != RP_OK || (r = set_flag(w, FL_LAYOUT_DIRTY, 1)) != RP_OK || (r = set_flag(w, FL_JOINT_DIRTY, 1)) != RP_OK || (r = set_flag(w, FL_FLOW_DIRTY, 1)) != RP_OK) return r;
     w->pinned_flags[FL_LAYOUT_DIRTY] = 1; // keeps the next steps on the full graph until the device reports a clean state
     w->full_until = w->steps_requested + 3;
     rp_launch_init_bodies(w->dw, w->stream);

@@ -114,13 +114,23 @@ RP_DEV void joint_finalize_store(const DevWorld &w, int j, JointRow *rows, const
     }
 }
 
+// How a joint reaches the solver bodies: plain HBM arrays on the per-stage launch path (PlainBodyIO), tagged write-through
+// records on the dataflow path (rp_flow.hip).  `side` = 0 / 1 for body1 / body2.
+struct PlainBodyIO {
+    const DevWorld &w;
+    RP_DEV void pose(int side, int b, Pose &p) const { p.r = q4(w.s_rot[b]); p.t = v3(w.s_trans[b]); }
+    RP_DEV void load_vel(int side, int b, V3 &l, V3 &a) const { l = v3(w.s_lin[b]); a = v3(w.s_ang[b]); }
+    RP_DEV void store_vel(int side, int b, V3 l, V3 a) const { w.s_lin[b] = f4(l, 0.0f); w.s_ang[b] = f4(a, 0.0f); }
+};
+
 // JointConstraintBuilder::update for joint j (rows rebuilt from the solver poses s_rot / s_trans).
-RP_DEV void joint_update_one(const DevWorld &w, int j, int substep_id) {
+template <class IO>
+RP_DEV void joint_update_one_t(const DevWorld &w, const IO &io, int j, int substep_id) {
     int b1 = w.j_b1[j], b2 = w.j_b2[j], locked = w.j_locked[j], limited = w.j_limited[j] & ~locked, motor = w.j_motor[j] & ~locked;
     Pose p1, p2; p1.r = q4(0, 0, 0, 1); p1.t = v3(0, 0, 0); p2 = p1;
     V3 im1 = v3(0, 0, 0), im2 = im1; Sym3 ii1 = {0, 0, 0, 0, 0, 0}, ii2 = ii1;
-    if (b1 >= 0) { p1.r = q4(w.s_rot[b1]); p1.t = v3(w.s_trans[b1]); im1 = v3(w.b_eim[b1]); float4 a = w.b_eii0[b1], b = w.b_eii1[b1]; ii1.m11 = a.x; ii1.m12 = a.y; ii1.m13 = a.z; ii1.m22 = a.w; ii1.m23 = b.x; ii1.m33 = b.y; }
-    if (b2 >= 0) { p2.r = q4(w.s_rot[b2]); p2.t = v3(w.s_trans[b2]); im2 = v3(w.b_eim[b2]); float4 a = w.b_eii0[b2], b = w.b_eii1[b2]; ii2.m11 = a.x; ii2.m12 = a.y; ii2.m13 = a.z; ii2.m22 = a.w; ii2.m23 = b.x; ii2.m33 = b.y; }
+    if (b1 >= 0) { io.pose(0, b1, p1); im1 = v3(w.b_eim[b1]); float4 a = w.b_eii0[b1], b = w.b_eii1[b1]; ii1.m11 = a.x; ii1.m12 = a.y; ii1.m13 = a.z; ii1.m22 = a.w; ii1.m23 = b.x; ii1.m33 = b.y; }
+    if (b2 >= 0) { io.pose(1, b2, p2); im2 = v3(w.b_eim[b2]); float4 a = w.b_eii0[b2], b = w.b_eii1[b2]; ii2.m11 = a.x; ii2.m12 = a.y; ii2.m13 = a.z; ii2.m22 = a.w; ii2.m23 = b.x; ii2.m33 = b.y; }
     Pose lf1, lf2; lf1.r = q4(w.j_f1r[j]); lf1.t = v3(w.j_f1t[j]); lf2.r = q4(w.j_f2r[j]); lf2.t = v3(w.j_f2t[j]);
     Pose frame1 = pose_mul(p1, lf1), frame2 = pose_mul(p2, lf2);
     V3 world_com1 = p1.t, world_com2 = p2.t;
@@ -313,15 +323,17 @@ RP_DEV void joint_update_one(const DevWorld &w, int j, int substep_id) {
     joint_finalize_store(w, j, rows, dof, len, base, imsum, substep_id);
     JRP(JR_IM1, j) = f4(im1, 0.0f); JRP(JR_IM2, j) = f4(im2, 0.0f);
 }
+RP_DEV void joint_update_one(const DevWorld &w, int j, int substep_id) { PlainBodyIO io = {w}; joint_update_one_t(w, io, j, substep_id); }
 
 // All rows of joint j: [remove bias] [warm start] solve — solve_joint, staged_island_solver/solve.rs:31-47
-RP_DEV void joint_solve_one(const DevWorld &w, int j, bool wo_bias, bool warmstart) {
+template <class IO>
+RP_DEV void joint_solve_one_t(const DevWorld &w, const IO &io, int j, bool wo_bias, bool warmstart) {
     int b1 = w.j_b1[j], b2 = w.j_b2[j];
     int nrows = joint_row_count(w.j_locked[j], w.j_limited[j], w.j_motor[j]);
     V3 im1 = v3(JRP(JR_IM1, j)), im2 = v3(JRP(JR_IM2, j));
     V3 l1 = v3(0, 0, 0), a1 = l1, l2 = l1, a2 = l1;
-    if (b1 >= 0) { l1 = v3(w.s_lin[b1]); a1 = v3(w.s_ang[b1]); }
-    if (b2 >= 0) { l2 = v3(w.s_lin[b2]); a2 = v3(w.s_ang[b2]); }
+    if (b1 >= 0) io.load_vel(0, b1, l1, a1);
+    if (b2 >= 0) io.load_vel(1, b2, l2, a2);
     for (int r = 0; r < nrows; ++r) {
         JointRow c; jrow_load(w, j, r, c);
         if (wo_bias) c.rhs = c.rhs_wo_bias;
@@ -351,9 +363,10 @@ RP_DEV void joint_solve_one(const DevWorld &w, int j, bool wo_bias, bool warmsta
         JRR(r, JR_LIN, j).w = c.impulse;
         if (wo_bias) JRR(r, JR_A2, j).w = c.rhs;
     }
-    if (b1 >= 0) { w.s_lin[b1] = f4(l1, 0.0f); w.s_ang[b1] = f4(a1, 0.0f); }
-    if (b2 >= 0) { w.s_lin[b2] = f4(l2, 0.0f); w.s_ang[b2] = f4(a2, 0.0f); }
+    if (b1 >= 0) io.store_vel(0, b1, l1, a1);
+    if (b2 >= 0) io.store_vel(1, b2, l2, a2);
 }
+RP_DEV void joint_solve_one(const DevWorld &w, int j, bool wo_bias, bool warmstart) { PlainBodyIO io = {w}; joint_solve_one_t(w, io, j, wo_bias, warmstart); }
 
 // JointConstraint::writeback_impulses — joint_velocity_constraint.rs:346-353
 RP_DEV void joint_writeback_one(const DevWorld &w, int j) {

@@ -42,6 +42,7 @@
 #define RP_OVF_LARGE 0x8
 #define RP_OVF_CONS 0x10
 #define RP_OVF_GRID 0x20   // a fused-step workgroup never became resident (grid barrier timed out)
+#define RP_OVF_FLOW 0x40   // the dataflow solver (rp_flow.hip) gave up waiting for a body record (its grid was not fully resident)
 
 // device scalar slots (int32) in DevWorld::flags
 enum {
@@ -82,6 +83,9 @@ enum {
     FL_WAKE_PENDING,    // the host queued wake-up requests (b_wake_req) that no step has consumed yet
     FL_NP_COUNT,        // pairs queued for a full narrow-phase update this step (np_list)
     FL_WAKE_STAMP,      // 2 * step + phase of the last wake pass that found a sleeping island to wake (rp_sleep.hip)
+    FL_FLOW_DIRTY,      // the constraint / joint layout changed: the per-body toucher ranks of the dataflow solver must be rebuilt
+    FL_FLOW_ABORT,      // a dataflow-solver wave timed out: every wave leaves its wait loops (rp_flow.hip)
+    FL_FLOW_CURSOR, FL_FLOW_JCURSOR, // bump allocators of the per-body toucher lists (contacts, joints)
     FL_COUNT = 48
 };
 
@@ -267,4 +271,11 @@ struct DevWorld {
     // ---- constraints ----
     float4 *C;                  // [CP_COUNT][cons_cap]
     int *k_b1, *k_b2, *k_n, *k_cid;
+
+    // ---- dataflow solver (rp_flow.hip): per-body toucher lists in sweep order ----
+    int2 *fk_rank;              // [cons_cap] position -> rank among the contact touchers of its body 1 / body 2 (-1 = world-attached side)
+    int2 *fj_rank;              // [n_joints] joint -> rank among the joints of its body 1 / body 2 (in joint sweep order)
+    int2 *fb_deg;               // [n_bodies] contact touchers, joint touchers of a solver body
+    int2 *fb_begin, *fb_fill;   // [n_bodies] list begin / fill cursor inside f_adj, f_jadj
+    int *f_adj, *f_jadj;        // [2 * cons_cap] positions, [2 * n_joints] joint sweep indices
 };

@@ -123,6 +123,44 @@ def test_joint_grid_full_size_60_steps_bit_exact():
     _compare_joints(g, o)
 
 
+def _world_with_env(scene, **env):
+    """PhysicsWorld built while the given environment switches are set (the library reads them in rp_world_create)."""
+    import os
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return PhysicsWorld.from_scene(scene)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("scene", ["large_pyramid60", "joint_grid40", "tumble_coulomb", "joint_chain_boxes"])
+def test_dataflow_launch_equals_per_stage_launches(scene):
+    """The global path as ONE dataflow launch (rp_flow.hip: per-body ticket hand-offs) against the same path as one launch per
+    colour stage (RP_NO_FLOW=1): identical bits, whatever ran ahead of what."""
+    make = {"large_pyramid60": lambda: S.large_pyramid(60), "joint_grid40": lambda: S.joint_grid(40),
+            "tumble_coulomb": lambda: _with_param(S.tumble(64, seed=7), "friction_model", S.FRICTION_COULOMB),
+            "joint_chain_boxes": lambda: S.joint_chain(6, with_boxes=True)}[scene]
+    a = _world_with_env(make(), RP_FORCE_MULTI=1)
+    b = _world_with_env(make(), RP_FORCE_MULTI=1, RP_NO_FLOW=1)
+    done = 0
+    for cp in (1, 7, 40, 120):
+        a.step(cp - done); b.step(cp - done); done = cp
+        (ap, av), (bp, bv) = a.read_bodies(), b.read_bodies()
+        np.testing.assert_array_equal(ap, bp, err_msg=f"{scene} poses @ {cp}")
+        np.testing.assert_array_equal(av, bv, err_msg=f"{scene} velocities @ {cp}")
+    assert a.counters()["overflow_flags"] == 0
+
+
+def _with_param(scene, key, value):
+    scene.params[key] = value
+    return scene
+
+
 def test_tumble_dynamic_scene_bit_exact():
     """Rotated cuboids + balls with velocities: full updates, edge/edge SAT, reduction, pair
     deletion, recolouring, restitution, damping."""
