@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librapier_hip.so")
+LIB_PATH = os.environ.get("RP_HIP_LIB") or os.path.join(_HERE, "librapier_hip.so")  # RP_HIP_LIB: an instrumented build of the same library (tools/)
 
 RP_OK = 0
 RP_INVALID_HANDLE = 0xFFFFFFFFFFFFFFFF

@@ -920,7 +920,7 @@ static int finalize(rp_world *w) {
     if (!(cell > 1.0e-6f)) cell = 1.0f;
     fill_sim_params(w, d.prm, cell);
 
-    DA(d.flags, FL_COUNT); DA(d.dbg, 64);
+    DA(d.flags, FL_COUNT); DA(d.dbg, 1024);
     DAC(d.b_pos, capb, DOM_BODY, 1, 1); DAC(d.b_rot, capb, DOM_BODY, 1, 1); DAC(d.b_linvel, capb, DOM_BODY, 1, 1); DAC(d.b_angvel, capb, DOM_BODY, 1, 1); DA(d.b_lcom_invm, capb); DA(d.b_invpi, capb);
     DA(d.b_pframe, capb); DAC(d.b_wcom, capb, DOM_BODY, 1, 1); DAC(d.b_eim, capb, DOM_BODY, 1, 1); DAC(d.b_eii0, capb, DOM_BODY, 1, 1); DAC(d.b_eii1, capb, DOM_BODY, 1, 1); DAC(d.b_damp, capb, DOM_BODY, 1, 1);
     DAC(d.b_uforce, capb, DOM_BODY, 1, 1); DAC(d.b_utorque, capb, DOM_BODY, 1, 1); DAC(d.b_flags, capb, DOM_BODY, 1, 1); DAC(d.b_quar, capb, DOM_BODY, 1, 1); DAF(d.b_collider, capb, 0xff);
@@ -948,6 +948,8 @@ static int finalize(rp_world *w) {
     DA(d.stage_color, RP_NUM_COLORS + 1); DA(d.stage_begin, RP_NUM_COLORS + 1); DA(d.stage_count, RP_NUM_COLORS + 1);
     DA(d.cons_pair, d.cons_cap); DAFC(d.p_conspos, P, 0xff, DOM_PAIR, 1, 1);
     DA(d.color_count_glob, RP_NUM_COLORS + 1); DA(d.color_rank, RP_NUM_COLORS + 1);
+    d.cb_words = (capb + 31) / 32;
+    DA(d.cb_bits, (size_t)128 * d.cb_words); DA(d.cb_prefix, (size_t)128 * d.cb_words);
     DAC(d.b_label, capb, DOM_BODY, 1, 1); DAFC(d.b_island, capb, 0xff, DOM_BODY, 1, 1); DAFC(d.b_local, capb, 0xff, DOM_BODY, 1, 1); DAC(d.r_nb, capb, DOM_BODY, 1, 1); DAC(d.r_nc, capb, DOM_BODY, 1, 1); DAFC(d.r_island, capb, 0xff, DOM_BODY, 1, 1);
     DAFC(d.p_island, P, 0xff, DOM_PAIR, 1, 1);
     DAC(d.isl_body_begin, capb, DOM_BODY, 1, 1); DAC(d.isl_nb, capb, DOM_BODY, 1, 1); DAC(d.isl_cons_begin, capb, DOM_BODY, 1, 1); DAC(d.isl_nc, capb, DOM_BODY, 1, 1); DAC(d.isl_fill_b, capb, DOM_BODY, 1, 1); DAC(d.isl_fill_c, capb, DOM_BODY, 1, 1);
@@ -1025,7 +1027,7 @@ static int finalize(rp_world *w) {
     DA(d.C, (size_t)(w->params.friction_model == RP_FRICTION_COULOMB ? CQ_COUNT : CP_COUNT) * d.cons_cap); // Coulomb: + 9 tangent planes per point (rp_coulomb.h)
     DA(d.k_b1, d.cons_cap); DA(d.k_b2, d.cons_cap); DA(d.k_n, d.cons_cap); DA(d.k_cid, d.cons_cap);
     // dataflow solver: toucher lists, rebuilt on the device whenever the layout changes (no carry-over needed)
-    DA(d.fk_rank, d.cons_cap); DA(d.fj_rank, std::max(nj, 1)); DA(d.fb_deg, capb); DA(d.fb_begin, capb); DA(d.fb_fill, capb);
+    DA(d.f_rec, 2 * (size_t)capb); DA(d.fk_rank, d.cons_cap); DA(d.fj_rank, std::max(nj, 1)); DA(d.fb_deg, capb); DA(d.fb_begin, capb); DA(d.fb_fill, capb);
     DA(d.f_adj, 2 * (size_t)d.cons_cap); DA(d.f_jadj, 2 * (size_t)std::max(nj, 1));
 
     // host SoA staging (one batched copy per attribute)
@@ -1876,6 +1878,15 @@ extern "C" int32_t rp_debug_cycles(rp_world *w, long long *out64) {
     HIPCHK(w, hipSetDevice(w->device));
     HIPCHK(w, hipStreamSynchronize(w->stream));
     HIPCHK(w, hipMemcpy(out64, w->dw.dbg, 64 * sizeof(long long), hipMemcpyDeviceToHost));
+    return RP_OK;
+}
+
+// debug aid: raw slice of the device debug counters (slots 64.. hold the event timeline of one traced body, rp_flow.hip)
+extern "C" int32_t rp_debug_read(rp_world *w, int32_t offset, int32_t n, long long *out) {
+    if (!w || !w->finalized || !out || offset < 0 || n < 0 || offset + n > 1024) return RP_ERR_INVALID;
+    HIPCHK(w, hipSetDevice(w->device));
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    HIPCHK(w, hipMemcpy(out, w->dw.dbg + offset, (size_t)n * sizeof(long long), hipMemcpyDeviceToHost));
     return RP_OK;
 }
 

@@ -8,7 +8,7 @@
 // algorithm: a Gauss-Seidel sweep in colour order only demands that the constraints touching ONE body are applied in sweep
 // order.  So on MI355X the stage barrier becomes a per-body hand-off:
 //
-//   * every solver body's velocity record carries a ticket: s_lin[b].w = s_ang[b].w = (epoch << 21) | events completed on b;
+//   * every solver body's velocity record carries a ticket: f_rec[2b].w = f_rec[2b + 1].w = (epoch << 21) | events completed on b;
 //   * every event on a body — increment, each contact's warm start / biased / relaxed / restitution application, each joint
 //     solve, integrate, write-back — knows its ticket from the body's toucher lists (ranks in sweep order, built once per
 //     layout change by the k_flow_* kernels below): it polls the body records of its (at most two) bodies until they show
@@ -35,7 +35,7 @@ typedef unsigned int flow_u4 __attribute__((ext_vector_type(4)));
 #define FLOW_TICKET_MASK ((1u << FLOW_TICKET_BITS) - 1u)
 #define FLOW_TIMEOUT_TICKS 300000000ll // wall_clock64 runs at 100 MHz: 3 s
 
-struct FlowBufs { __amdgpu_buffer_rsrc_t lin, ang, rot, trans; };
+struct FlowBufs { __amdgpu_buffer_rsrc_t rec, rot, trans; }; // rec: [2 * body] = (lin, tag), (ang, tag): both halves of a record share a 32-byte slot
 RP_DEV __amdgpu_buffer_rsrc_t flow_rsrc(void *p, int n_items) { return __builtin_amdgcn_make_buffer_rsrc(p, 0, n_items * 16, 0x00020000); }
 RP_DEV flow_u4 flow_ld(__amdgpu_buffer_rsrc_t r, int i) { return __builtin_amdgcn_raw_buffer_load_b128(r, i * 16, 0, FLOW_SC1); }
 RP_DEV void flow_st(__amdgpu_buffer_rsrc_t r, int i, V3 v, unsigned tag) {
@@ -46,6 +46,13 @@ RP_DEV void flow_st4(__amdgpu_buffer_rsrc_t r, int i, float4 v) {
     flow_u4 x; x.x = (unsigned)__float_as_int(v.x); x.y = (unsigned)__float_as_int(v.y); x.z = (unsigned)__float_as_int(v.z); x.w = (unsigned)__float_as_int(v.w);
     __builtin_amdgcn_raw_buffer_store_b128(x, r, i * 16, 0, FLOW_SC1);
 }
+#ifdef RP_FLOW_TRACE
+__device__ long long *g_flow_trace; __device__ int g_flow_trace_body;
+#define FLOW_TRACE(i, tag) do { if ((i) == g_flow_trace_body) g_flow_trace[64 + ((tag) & 1023u)] = (long long)wall_clock64(); } while (0)
+#else
+#define FLOW_TRACE(i, tag) do { } while (0)
+#endif
+RP_DEV void flow_st_vel(const FlowBufs &B, int i, V3 lin, V3 ang, unsigned tag) { FLOW_TRACE(i, tag); flow_st(B.rec, 2 * i, lin, tag); flow_st(B.rec, 2 * i + 1, ang, tag); }
 RP_DEV V3 flow_v3(flow_u4 x) { return v3(__int_as_float((int)x.x), __int_as_float((int)x.y), __int_as_float((int)x.z)); }
 RP_DEV Q4 flow_q4(flow_u4 x) { return q4(__int_as_float((int)x.x), __int_as_float((int)x.y), __int_as_float((int)x.z), __int_as_float((int)x.w)); }
 
@@ -56,6 +63,8 @@ struct FlowCtx {
     int *ovf_flag;        // flags[FL_OVERFLOW]
     long long t0;
     bool dead;            // this wave saw the abort flag: skip every remaining wait
+    unsigned n_items, n_polls, n_applies; // per wave: wait loops entered, poll rounds, APPLY executions (flushed to dbg[20..22])
+    long long t_apply, t_wait;            // wall-clock ticks (10 ns) spent inside APPLY / inside the wait loops (dbg[24], dbg[25])
 };
 
 // The event schedule of one body inside a step (see the file header): tickets are event indices.
@@ -71,18 +80,29 @@ RP_DEV int fs_crelax(const FlowSched &s, int dc, int dj, int sub, int it, int r)
 RP_DEV int fs_rest(const FlowSched &s, int dc, int dj, int r) { return s.nsub * fs_events(s, dc, dj) + r; }
 RP_DEV int fs_final(const FlowSched &s, int dc, int dj) { return s.nsub * fs_events(s, dc, dj) + (s.hr ? dc : 0); }
 
-// One poll of the records of up to two bodies: true when both show their expected tags (then v1 / v2 hold the velocities).
-RP_DEV bool flow_poll(const FlowCtx &cx, int i1, unsigned e1, int i2, unsigned e2, Vel &v1, Vel &v2) {
-    flow_u4 l1 = {0, 0, 0, e1}, a1 = {0, 0, 0, e1}, l2 = {0, 0, 0, e2}, a2 = {0, 0, 0, e2};
-    if (i1 >= 0) { l1 = flow_ld(cx.B.lin, i1); a1 = flow_ld(cx.B.ang, i1); }
-    if (i2 >= 0) { l2 = flow_ld(cx.B.lin, i2); a2 = flow_ld(cx.B.ang, i2); }
-    v1.lin = flow_v3(l1); v1.ang = flow_v3(a1); v2.lin = flow_v3(l2); v2.ang = flow_v3(a2);
-    return l1.w == e1 && a1.w == e1 && l2.w == e2 && a2.w == e2;
+// One poll of the records of up to two bodies: 0 when both show their expected tags (then v1 / v2 hold the velocities), else how
+// many events the slower body still is away from this one (the polling cadence adapts to it).
+RP_DEV unsigned flow_gap(unsigned lw, unsigned aw, unsigned e) {
+    if (lw == e && aw == e) return 0u;
+    const unsigned c = lw < aw ? lw : aw;
+    return ((c ^ e) & ~FLOW_TICKET_MASK) ? 1024u : (e - c > 0u ? e - c : 1u); // another step's record: its owner has not begun yet
 }
+RP_DEV unsigned flow_poll(const FlowCtx &cx, int i1, unsigned e1, int i2, unsigned e2, Vel &v1, Vel &v2) {
+    flow_u4 l1 = {0, 0, 0, e1}, a1 = {0, 0, 0, e1}, l2 = {0, 0, 0, e2}, a2 = {0, 0, 0, e2};
+    if (i1 >= 0) { l1 = flow_ld(cx.B.rec, 2 * i1); a1 = flow_ld(cx.B.rec, 2 * i1 + 1); }
+    if (i2 >= 0) { l2 = flow_ld(cx.B.rec, 2 * i2); a2 = flow_ld(cx.B.rec, 2 * i2 + 1); }
+    v1.lin = flow_v3(l1); v1.ang = flow_v3(a1); v2.lin = flow_v3(l2); v2.ang = flow_v3(a2);
+    const unsigned g1 = flow_gap(l1.w, a1.w, e1), g2 = flow_gap(l2.w, a2.w, e2);
+    return g1 > g2 ? g1 : g2;
+}
+// rounds a lane sits out after a poll that found it `gap` events away from its ticket (an event takes a microsecond or more)
+// (the chip-wide request rate bounds a poll round: ~1 us with a thousand fully polling wavefronts, ~0.2 us when a quarter of the
+// lanes poll — tools/ubench/pollcost.hip; so lanes that cannot be next stay quiet, and wake up together when a neighbour fires)
+RP_DEV unsigned flow_skip(unsigned gap) { return gap <= 1u ? 0u : (gap >= 9u ? 32u : 4u * (gap - 1u)); }
 // Wave-uniform back-off after an iteration in which no lane of the wavefront made progress; returns false when the launch is
 // being aborted (timeout here or in another wave).
 RP_DEV bool flow_backoff(FlowCtx &cx, unsigned &spins) {
-    __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_s_sleep(6); // ~0.15 us: the cadence of a round in which no (or few) lanes poll
     if ((++spins & 255u) != 0u) return true;
     int ab = __hip_atomic_load(cx.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!ab && (long long)wall_clock64() - cx.t0 > FLOW_TIMEOUT_TICKS) {
@@ -96,7 +116,7 @@ RP_DEV bool flow_backoff(FlowCtx &cx, unsigned &spins) {
 // pose readers outside the ticket chain (joint rows): wait until the body's record shows this step's epoch and at least `need`
 RP_DEV bool flow_reached(const FlowCtx &cx, int i, int need) {
     if (i < 0) return true;
-    flow_u4 l = flow_ld(cx.B.lin, i);
+    flow_u4 l = flow_ld(cx.B.rec, 2 * i);
     return (l.w & ~FLOW_TICKET_MASK) == cx.epoch && (int)(l.w & FLOW_TICKET_MASK) >= need;
 }
 
@@ -121,17 +141,21 @@ struct FlowGenAcc {
     }
 };
 // sweeps: constraint planes are private to the owning thread (plain accesses); bodies come from the poll and leave as tagged
-// write-through records
+// write-through records; the poses are fetched by the wait loop as soon as they are final for the sweep (FLOW_RUN_CONTACT).
+// (Preloading the planes into registers ahead of the wait was measured and dropped: the hand-off latency, not the plane loads,
+// bounds a hop — DESIGN.md §4.6.)
 struct FlowAcc {
-    const DevWorld &w; const FlowCtx &cx; int pos, i1, i2; Vel v1, v2; unsigned t1, t2; // t = tag to publish (expected + 1)
+    const DevWorld &w; const FlowCtx &cx; int pos, i1, i2, nn; unsigned t1, t2; // t = tag to publish (expected + 1)
+    mutable Vel v1, v2;
+    mutable Xf x1, x2;     // solver poses of the two bodies, loaded by the wait loop as soon as they are final for this sweep
     mutable bool wrote1, wrote2;
-    RP_DEV FlowAcc(const DevWorld &w_, const FlowCtx &cx_, int pos_, int i1_, int i2_, const Vel &a, const Vel &b, unsigned t1_, unsigned t2_)
-        : w(w_), cx(cx_), pos(pos_), i1(i1_), i2(i2_), v1(a), v2(b), t1(t1_), t2(t2_), wrote1(false), wrote2(false) {}
+    RP_DEV FlowAcc(const DevWorld &w_, const FlowCtx &cx_, int pos_, int i1_, int i2_, int n_, unsigned t1_, unsigned t2_)
+        : w(w_), cx(cx_), pos(pos_), i1(i1_), i2(i2_), nn(n_), t1(t1_), t2(t2_), wrote1(false), wrote2(false) {}
     RP_DEV float4 ld(int plane) const { return w.C[(size_t)plane * w.cons_cap + pos]; }
     RP_DEV void st(int plane, float4 v) const { w.C[(size_t)plane * w.cons_cap + pos] = v; }
     RP_DEV int id1() const { return i1; }
     RP_DEV int id2() const { return i2; }
-    RP_DEV int n() const { return w.k_n[pos]; }
+    RP_DEV int n() const { return nn; }
     RP_DEV int cids() const { return w.k_cid[pos]; }
     RP_DEV Vel vel(int id) const {
         Vel z; z.lin = v3(0, 0, 0); z.ang = v3(0, 0, 0);
@@ -141,25 +165,26 @@ struct FlowAcc {
         if (id < 0) return;
         const bool first = id == i1;
         const unsigned t = first ? t1 : t2;
-        flow_st(cx.B.lin, id, v.lin, t); flow_st(cx.B.ang, id, v.ang, t);
+        flow_st_vel(cx.B, id, v.lin, v.ang, t);
         if (first) wrote1 = true; else wrote2 = true;
     }
-    RP_DEV Xf xf(int id) const {
-        Xf x;
-        if (id < 0) { x.r = q4(0, 0, 0, 1); x.t = v3(0, 0, 0); } else { x.r = flow_q4(flow_ld(cx.B.rot, id)); x.t = flow_v3(flow_ld(cx.B.trans, id)); }
-        return x;
+    RP_DEV void load_poses() const {
+        x1.r = q4(0, 0, 0, 1); x1.t = v3(0, 0, 0); x2 = x1;
+        if (i1 >= 0) { x1.r = flow_q4(flow_ld(cx.B.rot, i1)); x1.t = flow_v3(flow_ld(cx.B.trans, i1)); }
+        if (i2 >= 0) { x2.r = flow_q4(flow_ld(cx.B.rot, i2)); x2.t = flow_v3(flow_ld(cx.B.trans, i2)); }
     }
+    RP_DEV Xf xf(int id) const { Xf z; z.r = q4(0, 0, 0, 1); z.t = v3(0, 0, 0); return id < 0 ? z : (id == i1 ? x1 : x2); }
     // an application that left a body's velocity alone still completes its event on that body
     RP_DEV void finish() const {
-        if (i1 >= 0 && !wrote1) { flow_st(cx.B.lin, i1, v1.lin, t1); flow_st(cx.B.ang, i1, v1.ang, t1); }
-        if (i2 >= 0 && !wrote2) { flow_st(cx.B.lin, i2, v2.lin, t2); flow_st(cx.B.ang, i2, v2.ang, t2); }
+        if (i1 >= 0 && !wrote1) { flow_st_vel(cx.B, i1, v1.lin, v1.ang, t1); }
+        if (i2 >= 0 && !wrote2) { flow_st_vel(cx.B, i2, v2.lin, v2.ang, t2); }
     }
 };
 struct FlowJointIO {
     const FlowCtx &cx; Vel v[2]; unsigned t[2];
     RP_DEV void pose(int side, int b, Pose &p) const { p.r = flow_q4(flow_ld(cx.B.rot, b)); p.t = flow_v3(flow_ld(cx.B.trans, b)); }
     RP_DEV void load_vel(int side, int b, V3 &l, V3 &a) const { l = v[side].lin; a = v[side].ang; }
-    RP_DEV void store_vel(int side, int b, V3 l, V3 a) const { flow_st(cx.B.lin, b, l, t[side]); flow_st(cx.B.ang, b, a, t[side]); }
+    RP_DEV void store_vel(int side, int b, V3 l, V3 a) const { flow_st_vel(cx.B, b, l, a, t[side]); }
 };
 
 // ---- toucher lists: ranks of every constraint / joint among the events of its bodies (rebuilt when the layout changed) ---
@@ -256,7 +281,7 @@ __global__ void k_flow_begin(DevWorld w) {
     body_begin(w, i, lin, ang, rot, trans, incl, inca);
     const float tag = __int_as_float((int)flow_epoch(w));
     w.s_inca[i] = f4(inca, 0.0f); w.s_incl[i] = f4(incl, 0.0f);
-    w.s_lin[i] = f4(lin, tag); w.s_ang[i] = f4(ang, tag);
+    w.f_rec[2 * i] = f4(lin, tag); w.f_rec[2 * i + 1] = f4(ang, tag);
     w.s_rot[i] = f4(rot); w.s_trans[i] = f4(trans, 0.0f);
 }
 
@@ -284,35 +309,92 @@ __device__ __noinline__ void flow_kinematic_writeback(KinWb k, int i, int type, 
     do {                                                                                         \
         bool pending_ = (has) && !cx.dead;                                                       \
         unsigned spins_ = 0;                                                                     \
+        cx.n_items += __any(pending_) ? 1u : 0u;                                                 \
+        const long long tw0_ = (long long)wall_clock64();                                        \
+        unsigned skip_ = 0;                                                                      \
         while (__any(pending_)) {                                                                \
-            bool ready_ = false;                                                                 \
+            unsigned gap_ = 4096u;                                                               \
             Vel v1, v2;                                                                          \
-            if (pending_) ready_ = flow_poll(cx, (i1), (e1), (i2), (e2), v1, v2);                \
-            if (ready_) { __VA_ARGS__; pending_ = false; }                                          \
-            if (!__any(ready_) && !flow_backoff(cx, spins_)) break;                              \
+            const bool poll_ = pending_ && skip_ == 0u; /* a lane far from its ticket sits rounds out: its loads would only add to the request stream */ \
+            cx.n_polls += __any(poll_) ? 1u : 0u;                                                \
+            if (poll_) { gap_ = flow_poll(cx, (i1), (e1), (i2), (e2), v1, v2); skip_ = flow_skip(gap_); } else if (skip_) skip_--; \
+            const bool ready_ = gap_ == 0u;                                                      \
+            if (__any(ready_) && skip_ > 2u) skip_ = 2u; /* neighbours become ready together */  \
+            cx.n_applies += __any(ready_) ? 1u : 0u;                                             \
+            if (ready_) { __VA_ARGS__; pending_ = false; }                                       \
+            if (!__any(ready_) && !flow_backoff(cx, spins_)) break; \
         }                                                                                        \
+        cx.t_wait += (long long)wall_clock64() - tw0_;                                           \
+    } while (0)
+
+// The wait loop of a contact application.  POSE_MODE 0: the sweep reads no pose.  2: the poses it reads become final when both
+// records have passed an integrate ticket (p1 / p2: this substep's integrate for the relaxed sweep, last substep's for update +
+// warm start) — they are fetched at that moment, normally several events before this application's own ticket (for the warm
+// start: in the first poll round), so their latency is off the hand-off chain.
+#define FLOW_RUN_CONTACT(A, has, e1, e2, POSE_MODE, p1, p2, ...)                                 \
+    do {                                                                                         \
+        bool pending_ = (has) && !cx.dead, posed_ = (POSE_MODE) != 2;                               \
+        unsigned spins_ = 0;                                                                     \
+        cx.n_items += __any(pending_) ? 1u : 0u;                                                 \
+        const long long tw0_ = (long long)wall_clock64();                                        \
+        if (pending_ && (POSE_MODE) == 1) (A).load_poses();                                        \
+        unsigned skip_ = 0;                                                                      \
+        while (__any(pending_)) {                                                                \
+            unsigned gap_ = 4096u;                                                               \
+            Vel v1, v2;                                                                          \
+            const bool poll_ = pending_ && skip_ == 0u;                                          \
+            cx.n_polls += __any(poll_) ? 1u : 0u;                                                \
+            if (!poll_ && skip_) skip_--;                                                        \
+            if (poll_) {                                                                         \
+                gap_ = flow_poll(cx, (A).i1, (e1), (A).i2, (e2), v1, v2);                        \
+                skip_ = flow_skip(gap_);                                                         \
+                if (!posed_) {                                                                   \
+                    const unsigned g1_ = (A).i1 >= 0 ? (e1) - (p1) : 0xffffffffu, g2_ = (A).i2 >= 0 ? (e2) - (p2) : 0xffffffffu; /* events between integrate and this one */ \
+                    if (gap_ <= (g1_ < g2_ ? g1_ : g2_)) { (A).load_poses(); posed_ = true; }    \
+                }                                                                                \
+            }                                                                                    \
+            const bool ready_ = gap_ == 0u && posed_;                                            \
+            if (__any(ready_) && skip_ > 2u) skip_ = 2u;                                         \
+            cx.n_applies += __any(ready_) ? 1u : 0u;                                             \
+            if (ready_) { (A).v1 = v1; (A).v2 = v2; __VA_ARGS__; (A).finish(); pending_ = false; } \
+            if (!__any(ready_) && !flow_backoff(cx, spins_)) break; \
+        }                                                                                        \
+        cx.t_wait += (long long)wall_clock64() - tw0_;                                           \
     } while (0)
 
 // JOINTS = false: the instantiation for worlds without impulse joints carries none of the joint code (its row arrays live in
 // scratch memory, which a launch pays for whether or not a joint exists)
 template <bool COUL, bool JOINTS>
 __global__ void __launch_bounds__(256) k_global_flow(DevWorld w, int has_restitution) {
-    const int T = gridDim.x * blockDim.x, tid = blockIdx.x * blockDim.x + threadIdx.x;
+    // Workgroups are dedicated to ONE kind of event — body events (increment, integrate, write-back), joints, or contacts: a
+    // wavefront walks its phases in order, so a wavefront that served both bodies and contacts would hold its contacts' warm start
+    // back until the slowest of its (unrelated) bodies could be incremented, and chain such artificial waits across the scene.
+    const int G = gridDim.x;
+    const int GB = max(1, min(G / 4, (w.n_bodies + 255) / 256));
+    const int GJ = (JOINTS && w.n_joints > 0) ? max(1, min(G / 4, (w.n_joints + 255) / 256)) : 0;
+    const int bid = blockIdx.x;
+    const int role = bid < GB ? 0 : (bid < GB + GJ ? 1 : 2); // 0 bodies, 1 joints, 2 contacts
+    const int rb0 = role == 0 ? 0 : (role == 1 ? GB : GB + GJ), rbn = role == 0 ? GB : (role == 1 ? GJ : G - GB - GJ);
+    const int T = rbn * blockDim.x, tid = (bid - rb0) * blockDim.x + threadIdx.x;
     int M = w.flags[FL_N_CONS]; if (M > w.cons_cap) M = w.cons_cap;
     const int nb = w.n_bodies, njl = JOINTS ? flow_live_joints(w) : 0;
     const rp_integration_params &prm = w.prm.p;
     const bool fib = prm.friction_in_bias_pass || prm.num_internal_stabilization_iterations == 0;
     FlowSched sc = {prm.num_internal_pgs_iterations, prm.num_internal_stabilization_iterations, w.prm.num_substeps, has_restitution};
     FlowCtx cx;
-    cx.B.lin = flow_rsrc(w.s_lin, nb); cx.B.ang = flow_rsrc(w.s_ang, nb); cx.B.rot = flow_rsrc(w.s_rot, nb); cx.B.trans = flow_rsrc(w.s_trans, nb);
+    cx.B.rec = flow_rsrc(w.f_rec, 2 * nb); cx.B.rot = flow_rsrc(w.s_rot, nb); cx.B.trans = flow_rsrc(w.s_trans, nb);
     cx.epoch = flow_epoch(w);
+#ifdef RP_FLOW_TRACE
+    if (blockIdx.x == 0 && threadIdx.x == 0) { g_flow_trace = w.dbg; g_flow_trace_body = w.n_bodies / 2; }
+#endif
     cx.abort_flag = &w.flags[FL_FLOW_ABORT]; cx.ovf_flag = &w.flags[FL_OVERFLOW];
     cx.t0 = (long long)wall_clock64();
+    cx.n_items = 0; cx.n_polls = 0; cx.n_applies = 0; cx.t_apply = 0; cx.t_wait = 0;
     cx.dead = (w.flags[FL_OVERFLOW] & RP_OVF_FLOW) != 0; // an earlier failure (or a ticket range overflow): no waiting at all
     const unsigned ep = cx.epoch;
 
     // ---- S1 generate: this thread's constraints (start-of-step state only) ----
-    for (int pos = tid; pos < M; pos += T) {
+    if (role == 2) for (int pos = tid; pos < M; pos += T) {
         int s = w.cons_pair[pos], id1, id2;
         flow_ids(w, pos, id1, id2);
         int2 rk = w.fk_rank[pos];
@@ -325,7 +407,7 @@ __global__ void __launch_bounds__(256) k_global_flow(DevWorld w, int has_restitu
     for (int sub = 0; sub < sc.nsub; ++sub) {
         const float solved_dt = (float)sub * w.prm.dt_sub;
         // ---- S2 increment (+ gyroscopic term): the owner of each body ----
-        for (int base = 0; base < nb; base += T) {
+        if (role == 0) for (int base = 0; base < nb; base += T) {
             const int i = base + tid;
             const bool has = i < nb && global_body(w, i);
             int2 dg = has ? w.fb_deg[i] : make_int2(0, 0);
@@ -333,11 +415,11 @@ __global__ void __launch_bounds__(256) k_global_flow(DevWorld w, int has_restitu
             FLOW_RUN(has, i, e, -1, 0u, {
                 V3 lin = v1.lin, ang = v1.ang;
                 body_increment(w, w.b_flags[i], lin, ang, flow_q4(flow_ld(cx.B.rot, i)), v3(w.s_incl[i]), v3(w.s_inca[i]), v3(w.b_invpi[i]), q4(w.b_pframe[i]));
-                flow_st(cx.B.lin, i, lin, e + 1u); flow_st(cx.B.ang, i, ang, e + 1u);
+                flow_st_vel(cx.B, i, lin, ang, e + 1u);
             });
         }
         // ---- joint rows from the current poses (off the ticket chain: only needs last substep's integrate) ----
-        if (JOINTS) for (int base = 0; base < njl; base += T) {
+        if (JOINTS && role == 1) for (int base = 0; base < njl; base += T) {
             const int idx = base + tid;
             const bool has = idx < njl;
             int j = 0, b1 = -1, b2 = -1, need1 = 0, need2 = 0;
@@ -358,25 +440,23 @@ __global__ void __launch_bounds__(256) k_global_flow(DevWorld w, int has_restitu
             }
         }
         // ---- update + warm start of every contact, in sweep order per body ----
-        for (int base = 0; base < M; base += T) {
+        if (role == 2) for (int base = 0; base < M; base += T) {
             const int pos = base + tid;
             const bool has = pos < M;
-            int i1 = -1, i2 = -1; unsigned e1 = 0, e2 = 0;
+            int i1 = -1, i2 = -1, nn = 0; unsigned e1 = 0, e2 = 0, pt1 = 0, pt2 = 0;
             if (has) {
-                i1 = w.k_b1[pos]; i2 = w.k_b2[pos];
+                i1 = w.k_b1[pos]; i2 = w.k_b2[pos]; nn = w.k_n[pos];
                 int2 rk = w.fk_rank[pos];
-                if (i1 >= 0) { int2 d = w.fb_deg[i1]; e1 = ep | (unsigned)fs_ws(sc, d.x, d.y, sub, rk.x); }
-                if (i2 >= 0) { int2 d = w.fb_deg[i2]; e2 = ep | (unsigned)fs_ws(sc, d.x, d.y, sub, rk.y); }
+                // the poses this sweep reads are last substep's: final once the record has passed that integrate (at once in substep 0)
+                if (i1 >= 0) { int2 d = w.fb_deg[i1]; e1 = ep | (unsigned)fs_ws(sc, d.x, d.y, sub, rk.x); pt1 = ep | (unsigned)(sub > 0 ? fs_integ(sc, d.x, d.y, sub - 1) + 1 : 0); }
+                if (i2 >= 0) { int2 d = w.fb_deg[i2]; e2 = ep | (unsigned)fs_ws(sc, d.x, d.y, sub, rk.y); pt2 = ep | (unsigned)(sub > 0 ? fs_integ(sc, d.x, d.y, sub - 1) + 1 : 0); }
             }
-            FLOW_RUN(has, i1, e1, i2, e2, {
-                FlowAcc A(w, cx, pos, i1, i2, v1, v2, e1 + 1u, e2 + 1u);
-                cons_apply_model<COUL>(w, A, MODE_WARMSTART, fib, solved_dt);
-                A.finish();
-            });
+            FlowAcc A(w, cx, pos, i1, i2, nn, e1 + 1u, e2 + 1u);
+            FLOW_RUN_CONTACT(A, has, e1, e2, 2, pt1, pt2, cons_apply_model<COUL>(w, A, MODE_WARMSTART, fib, solved_dt));
         }
         // ---- biased sweeps: every joint before any contact ----
         for (int it = 0; it < sc.npgs; ++it) {
-            if (JOINTS) for (int base = 0; base < njl; base += T) {
+            if (JOINTS && role == 1) for (int base = 0; base < njl; base += T) {
                 const int idx = base + tid;
                 const bool has = idx < njl;
                 int j = 0, i1 = -1, i2 = -1; unsigned e1 = 0, e2 = 0;
@@ -391,25 +471,22 @@ __global__ void __launch_bounds__(256) k_global_flow(DevWorld w, int has_restitu
                     joint_solve_one_t(w, io, j, false, prm.warmstart_joints && it == 0);
                 });
             }
-            for (int base = 0; base < M; base += T) {
+            if (role == 2) for (int base = 0; base < M; base += T) {
                 const int pos = base + tid;
                 const bool has = pos < M;
-                int i1 = -1, i2 = -1; unsigned e1 = 0, e2 = 0;
+                int i1 = -1, i2 = -1, nn = 0; unsigned e1 = 0, e2 = 0;
                 if (has) {
-                    i1 = w.k_b1[pos]; i2 = w.k_b2[pos];
+                    i1 = w.k_b1[pos]; i2 = w.k_b2[pos]; nn = w.k_n[pos];
                     int2 rk = w.fk_rank[pos];
                     if (i1 >= 0) { int2 d = w.fb_deg[i1]; e1 = ep | (unsigned)fs_cbias(sc, d.x, d.y, sub, it, rk.x); }
                     if (i2 >= 0) { int2 d = w.fb_deg[i2]; e2 = ep | (unsigned)fs_cbias(sc, d.x, d.y, sub, it, rk.y); }
                 }
-                FLOW_RUN(has, i1, e1, i2, e2, {
-                    FlowAcc A(w, cx, pos, i1, i2, v1, v2, e1 + 1u, e2 + 1u);
-                    cons_apply_model<COUL>(w, A, MODE_BIAS, fib, solved_dt);
-                    A.finish();
-                });
+                FlowAcc A(w, cx, pos, i1, i2, nn, e1 + 1u, e2 + 1u);
+                FLOW_RUN_CONTACT(A, has, e1, e2, 0, 0u, 0u, cons_apply_model<COUL>(w, A, MODE_BIAS, fib, solved_dt));
             }
         }
         // ---- S6 integrate: poses first (write-through), then the record that announces them ----
-        for (int base = 0; base < nb; base += T) {
+        if (role == 0) for (int base = 0; base < nb; base += T) {
             const int i = base + tid;
             const bool has = i < nb && global_body(w, i);
             int2 dg = has ? w.fb_deg[i] : make_int2(0, 0);
@@ -419,12 +496,12 @@ __global__ void __launch_bounds__(256) k_global_flow(DevWorld w, int has_restitu
                 body_integrate(w, w.b_flags[i], lin, ang, rot, trans);
                 flow_st4(cx.B.rot, i, f4(rot)); flow_st4(cx.B.trans, i, f4(trans, 0.0f));
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                flow_st(cx.B.lin, i, lin, e + 1u); flow_st(cx.B.ang, i, ang, e + 1u);
+                flow_st_vel(cx.B, i, lin, ang, e + 1u);
             });
         }
         // ---- relaxed sweeps (refresh_rhs_wo_bias + solve with friction) ----
         for (int it = 0; it < sc.nstab; ++it) {
-            if (JOINTS) for (int base = 0; base < njl; base += T) {
+            if (JOINTS && role == 1) for (int base = 0; base < njl; base += T) {
                 const int idx = base + tid;
                 const bool has = idx < njl;
                 int j = 0, i1 = -1, i2 = -1; unsigned e1 = 0, e2 = 0;
@@ -439,49 +516,43 @@ __global__ void __launch_bounds__(256) k_global_flow(DevWorld w, int has_restitu
                     joint_solve_one_t(w, io, j, true, false);
                 });
             }
-            for (int base = 0; base < M; base += T) {
+            if (role == 2) for (int base = 0; base < M; base += T) {
                 const int pos = base + tid;
                 const bool has = pos < M;
-                int i1 = -1, i2 = -1; unsigned e1 = 0, e2 = 0;
+                int i1 = -1, i2 = -1, nn = 0; unsigned e1 = 0, e2 = 0, pt1 = 0, pt2 = 0;
                 if (has) {
-                    i1 = w.k_b1[pos]; i2 = w.k_b2[pos];
+                    i1 = w.k_b1[pos]; i2 = w.k_b2[pos]; nn = w.k_n[pos];
                     int2 rk = w.fk_rank[pos];
-                    if (i1 >= 0) { int2 d = w.fb_deg[i1]; e1 = ep | (unsigned)fs_crelax(sc, d.x, d.y, sub, it, rk.x); }
-                    if (i2 >= 0) { int2 d = w.fb_deg[i2]; e2 = ep | (unsigned)fs_crelax(sc, d.x, d.y, sub, it, rk.y); }
+                    if (i1 >= 0) { int2 d = w.fb_deg[i1]; e1 = ep | (unsigned)fs_crelax(sc, d.x, d.y, sub, it, rk.x); pt1 = ep | (unsigned)(fs_integ(sc, d.x, d.y, sub) + 1); }
+                    if (i2 >= 0) { int2 d = w.fb_deg[i2]; e2 = ep | (unsigned)fs_crelax(sc, d.x, d.y, sub, it, rk.y); pt2 = ep | (unsigned)(fs_integ(sc, d.x, d.y, sub) + 1); }
                 }
-                FLOW_RUN(has, i1, e1, i2, e2, {
-                    FlowAcc A(w, cx, pos, i1, i2, v1, v2, e1 + 1u, e2 + 1u);
-                    cons_apply_model<COUL>(w, A, MODE_RELAX, fib, solved_dt + w.prm.dt_sub);
-                    A.finish();
-                });
+                FlowAcc A(w, cx, pos, i1, i2, nn, e1 + 1u, e2 + 1u);
+                FLOW_RUN_CONTACT(A, has, e1, e2, 2, pt1, pt2, cons_apply_model<COUL>(w, A, MODE_RELAX, fib, solved_dt + w.prm.dt_sub));
             }
         }
     }
     // ---- S8 restitution (a no-op for constraints without a seed) ----
-    if (has_restitution) {
+    if (has_restitution && role == 2) {
         for (int base = 0; base < M; base += T) {
             const int pos = base + tid;
             const bool has = pos < M;
-            int i1 = -1, i2 = -1; unsigned e1 = 0, e2 = 0;
+            int i1 = -1, i2 = -1, nn = 0; unsigned e1 = 0, e2 = 0;
             if (has) {
-                i1 = w.k_b1[pos]; i2 = w.k_b2[pos];
+                i1 = w.k_b1[pos]; i2 = w.k_b2[pos]; nn = w.k_n[pos];
                 int2 rk = w.fk_rank[pos];
                 if (i1 >= 0) { int2 d = w.fb_deg[i1]; e1 = ep | (unsigned)fs_rest(sc, d.x, d.y, rk.x); }
                 if (i2 >= 0) { int2 d = w.fb_deg[i2]; e2 = ep | (unsigned)fs_rest(sc, d.x, d.y, rk.y); }
             }
-            FLOW_RUN(has, i1, e1, i2, e2, {
-                FlowAcc A(w, cx, pos, i1, i2, v1, v2, e1 + 1u, e2 + 1u);
-                cons_apply_model<COUL>(w, A, MODE_RESTITUTION, fib, 0.0f);
-                A.finish();
-            });
+            FlowAcc A(w, cx, pos, i1, i2, nn, e1 + 1u, e2 + 1u);
+            FLOW_RUN_CONTACT(A, has, e1, e2, 0, 0u, 0u, cons_apply_model<COUL>(w, A, MODE_RESTITUTION, fib, 0.0f));
         }
     }
     // ---- S9 impulse write-back (this thread's own constraints and joints), S10 body write-back ----
-    if (!cx.dead) {
+    if (!cx.dead && role == 2) {
         for (int pos = tid; pos < M; pos += T) { if (COUL) coul_writeback(w, GlobalAcc(w, pos), w.cons_pair[pos]); else cons_writeback(w, GlobalAcc(w, pos), w.cons_pair[pos]); }
-        if (JOINTS) for (int idx = tid; idx < njl; idx += T) joint_writeback_one(w, w.j_order[idx]);
     }
-    for (int base = 0; base < nb; base += T) {
+    if (JOINTS && !cx.dead && role == 1) for (int idx = tid; idx < njl; idx += T) joint_writeback_one(w, w.j_order[idx]);
+    if (role == 0) for (int base = 0; base < nb; base += T) {
         const int i = base + tid;
         const bool has = i < nb && global_body(w, i);
         int2 dg = has ? w.fb_deg[i] : make_int2(0, 0);
@@ -495,6 +566,15 @@ __global__ void __launch_bounds__(256) k_global_flow(DevWorld w, int has_restitu
                 flow_kinematic_writeback(k, i, type, v1.lin, v1.ang, rot, trans);
             }
         });
+    }
+    if ((threadIdx.x & 63) == 0 && cx.n_items) { // hand-off statistics of this wavefront (rp_debug_cycles slots 20..23)
+        atomicAdd((unsigned long long *)&w.dbg[20], (unsigned long long)cx.n_items);
+        atomicAdd((unsigned long long *)&w.dbg[21], (unsigned long long)cx.n_polls);
+        atomicAdd((unsigned long long *)&w.dbg[22], (unsigned long long)cx.n_applies);
+        atomicAdd((unsigned long long *)&w.dbg[23], 1ull);
+        atomicAdd((unsigned long long *)&w.dbg[24], (unsigned long long)cx.t_apply);
+        atomicAdd((unsigned long long *)&w.dbg[25], (unsigned long long)cx.t_wait);
+        atomicAdd((unsigned long long *)&w.dbg[26], (unsigned long long)((long long)wall_clock64() - cx.t0));
     }
 }
 
@@ -521,7 +601,7 @@ int rp_flow_grid(int device) {
     int want = 1; // workgroups per CU (RP_FLOW_WG_PER_CU); stays well below the occupancy answer: the hardware may admit one fewer
     const char *e = getenv("RP_FLOW_WG_PER_CU");
     if (e && atoi(e) > 0) want = atoi(e);
-    if (want > per_cu - 1 && per_cu > 1) want = per_cu - 1;
+    if (want > per_cu - 1 && per_cu > 4) want = per_cu - 1; // near the hardware's own limit the occupancy answer can be one too many
     if (per_cu < 1 || cus < 1) return 0;
     if (want > per_cu) want = per_cu;
     int g = cus * want;
@@ -538,9 +618,9 @@ void rp_launch_global_flow(const DevWorld &w, hipStream_t st, int grid, int has_
     hipLaunchKernelGGL(k_flow_rank, dim3(blocks), dim3(256), 0, st, w);
     hipLaunchKernelGGL(k_flow_begin, dim3(nbb), dim3(256), 0, st, w);
     const bool coul = w.prm.p.friction_model == RP_FRICTION_COULOMB, joints = w.n_joints > 0;
-    if (coul && joints) hipLaunchKernelGGL((k_global_flow<true, true>), dim3(grid), dim3(256), 0, st, w, has_restitution);
-    else if (coul) hipLaunchKernelGGL((k_global_flow<true, false>), dim3(grid), dim3(256), 0, st, w, has_restitution);
-    else if (joints) hipLaunchKernelGGL((k_global_flow<false, true>), dim3(grid), dim3(256), 0, st, w, has_restitution);
-    else hipLaunchKernelGGL((k_global_flow<false, false>), dim3(grid), dim3(256), 0, st, w, has_restitution);
+#define FLOW_LAUNCH(C, J) hipLaunchKernelGGL((k_global_flow<C, J>), dim3(grid), dim3(256), 0, st, w, has_restitution)
+    if (coul) { if (joints) FLOW_LAUNCH(true, true); else FLOW_LAUNCH(true, false); }
+    else { if (joints) FLOW_LAUNCH(false, true); else FLOW_LAUNCH(false, false); }
+#undef FLOW_LAUNCH
     hipLaunchKernelGGL(k_flow_retire, dim3(1), dim3(64), 0, st, w);
 }

@@ -45,6 +45,7 @@ __global__ void k_isl_init(DevWorld w) {
     if (!w.flags[FL_LAYOUT_DIRTY]) return;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) { w.flags[FL_N_ISLANDS] = 0; w.flags[FL_N_GLOB_BODIES] = 0; w.flags[FL_ISL_BODY_CURSOR] = 0; w.flags[FL_ISL_CONS_CURSOR] = 0; w.flags[FL_ISL_ICONS_CURSOR] = 0; }
+    for (size_t k = i, n = (size_t)128 * w.cb_words, st = (size_t)gridDim.x * blockDim.x; k < n; k += st) w.cb_bits[k] = 0u; // owner bitmaps of the colour stages
     if (i < w.n_bodies) { w.b_label[i] = i; w.r_nb[i] = 0; w.r_nc[i] = 0; w.r_ni[i] = 0; w.r_island[i] = -1; w.b_island[i] = -1; w.b_local[i] = -1; }
 }
 // connected components over active pairs whose two sides are dynamic
@@ -132,7 +133,14 @@ __global__ void k_isl_fill(DevWorld w) {
         }
         w.p_island[s] = id;
         if (id >= 0) { int k = atomicAdd(&w.isl_fill_c[id], 1); w.isl_cons[w.isl_cons_begin[id] + k] = s; }
-        else { int color = w.p_color[s]; if (color <= RP_COLOR_OVERFLOW) atomicAdd(&hist[color], 1); }
+        else {
+            int color = w.p_color[s];
+            if (color <= RP_COLOR_OVERFLOW) atomicAdd(&hist[color], 1);
+            if (color < RP_COLOR_OVERFLOW) { // owner = the first awake dynamic body: at most one manifold per colour names it
+                int owner = body_dyn_awake(w, b1) ? b1 : b2;
+                atomicOr(&w.cb_bits[(size_t)color * w.cb_words + (owner >> 5)], 1u << (owner & 31));
+            }
+        }
     }
     __syncthreads();
     for (int c = threadIdx.x; c < RP_NUM_COLORS; c += blockDim.x) if (hist[c]) atomicAdd(&w.color_count_glob[c], hist[c]);

@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(1024) k_joint_layout(DevWorld w) {
         w.j_order[ob + rank] = j;
     }
     __threadfence(); __syncthreads();
-    if (threadIdx.x == 0) w.flags[FL_JOINT_DIRTY] = 0;
+    if (threadIdx.x == 0) { w.flags[FL_JOINT_DIRTY] = 0; w.flags[FL_FLOW_DIRTY] = 1; } // the joint sweep order changed: re-rank (rp_flow.hip)
 }
 
 // ---- MULTI mode launches -----------------------------------------------------------------------

@@ -829,8 +829,31 @@ __global__ void k_bucket_count(DevWorld w) {
     for (int c = threadIdx.x; c < RP_NUM_COLORS; c += blockDim.x) if (hist[c]) atomicAdd(&w.color_count[c], hist[c]);
     if (threadIdx.x == 0 && nsc_sum) atomicAdd(&w.flags[FL_N_SC], nsc_sum);
 }
-__global__ void k_bucket_layout(DevWorld w) {
+__global__ void __launch_bounds__(1024) k_bucket_layout(DevWorld w) {
     if (!w.flags[FL_LAYOUT_DIRTY]) return;
+    // all threads: per colour, the exclusive prefix popcount of the owner bitmap along its words (rank of a body among the owners)
+    {
+        __shared__ int part[1024];
+        const int words = w.cb_words, per = (words + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < words ? lo + per : words;
+        for (int c = 0; c < RP_COLOR_OVERFLOW; ++c) {
+            if (w.color_count_glob[c] == 0) continue; // uniform
+            const unsigned *bits = w.cb_bits + (size_t)c * words;
+            int *pre = w.cb_prefix + (size_t)c * words;
+            int sum = 0;
+            for (int i = lo; i < hi; ++i) sum += __popc(bits[i]);
+            part[threadIdx.x] = sum;
+            __syncthreads();
+            for (int off = 1; off < 1024; off <<= 1) { // Hillis-Steele inclusive scan of the 1024 partial sums
+                int v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+                __syncthreads();
+                part[threadIdx.x] += v;
+                __syncthreads();
+            }
+            int run = part[threadIdx.x] - sum;
+            for (int i = lo; i < hi; ++i) { pre[i] = run; run += __popc(bits[i]); }
+            __syncthreads();
+        }
+    }
     if (threadIdx.x != 0) return;
     int nst = 0, npar = 0, pos = 0, maxs = 0, ncol = 0, mall = 0;
     for (int pass = 0; pass < 2; ++pass)
@@ -854,6 +877,7 @@ __global__ void k_bucket_layout(DevWorld w) {
     w.flags[FL_N_STAGES] = nst; w.flags[FL_N_PARALLEL] = npar; w.flags[FL_MAX_STAGE] = maxs;
     w.flags[FL_HAS_OVERFLOW_COLOR] = novg > 0; w.flags[FL_N_COLORS] = ncol;
     w.flags[FL_N_CONS] = pos; w.flags[FL_N_CONS_ALL] = mall;
+    w.flags[FL_FLOW_DIRTY] = 1; // constraint positions are about to move: the dataflow solver's toucher ranks follow (rp_flow.hip)
     if (pos > w.cons_cap) atomicOr(&w.flags[FL_OVERFLOW], RP_OVF_CONS);
 }
 RP_DEV int ld_i32(int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -866,20 +890,28 @@ __global__ void k_bucket_scatter(DevWorld w) {
     int top = w.flags[FL_POOL_TOP];
     if (top > w.pool_cap) top = w.pool_cap;
     int stride = gridDim.x * blockDim.x;
+    // colour stages: position = rank of the owner body among the colour's owners (no atomics, ascending with the body index);
+    // the overflow colour (not body-disjoint) keeps its reserve-and-place scheme and is ranked by the closing workgroup below
     for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < top; s += stride) {
         if (!pair_selected(w, s) || w.p_island[s] >= 0) continue;
         int color = w.p_color[s];
-        if (color > RP_COLOR_OVERFLOW) continue;
-        atomicAdd(&cnt[color], 1);
+        if (color == RP_COLOR_OVERFLOW) atomicAdd(&cnt[color], 1);
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < RP_NUM_COLORS; c += blockDim.x) { base[c] = cnt[c] ? atomicAdd(&w.color_cursor[c], cnt[c]) : 0; cnt[c] = 0; }
+    if (threadIdx.x == 0) { base[RP_COLOR_OVERFLOW] = cnt[RP_COLOR_OVERFLOW] ? atomicAdd(&w.color_cursor[RP_COLOR_OVERFLOW], cnt[RP_COLOR_OVERFLOW]) : 0; cnt[RP_COLOR_OVERFLOW] = 0; }
     __syncthreads();
     for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < top; s += stride) {
         if (!pair_selected(w, s) || w.p_island[s] >= 0) continue;
         int color = w.p_color[s];
         if (color > RP_COLOR_OVERFLOW) continue;
-        int pos = base[color] + atomicAdd(&cnt[color], 1);
+        int pos;
+        if (color == RP_COLOR_OVERFLOW) pos = base[color] + atomicAdd(&cnt[color], 1);
+        else {
+            int2 rb = w.p_rb[s];
+            int owner = body_dyn_awake(w, rb.x) ? rb.x : rb.y;
+            size_t wi = (size_t)color * w.cb_words + (owner >> 5);
+            pos = w.color_begin[color] + w.cb_prefix[wi] + __popc(w.cb_bits[wi] & ((1u << (owner & 31)) - 1u));
+        }
         if (pos < w.cons_cap) { w.cons_pair[pos] = s; w.p_conspos[s] = pos; }
     }
     // the last workgroup to finish closes the layout rebuild (k_bucket_finish)
@@ -934,7 +966,7 @@ void rp_launch_narrowphase_part(const DevWorld &w, hipStream_t st, int part) {
         hipLaunchKernelGGL(k_bucket_clear, dim3(1), dim3(256), 0, st, w);
         hipLaunchKernelGGL(k_bucket_count, dim3(blocks), dim3(256), 0, st, w);
         rp_launch_islands_build(w, st);
-        hipLaunchKernelGGL(k_bucket_layout, dim3(1), dim3(64), 0, st, w);
+        hipLaunchKernelGGL(k_bucket_layout, dim3(1), dim3(1024), 0, st, w);
         hipLaunchKernelGGL(k_bucket_scatter, dim3(blocks), dim3(256), 0, st, w);
     }
 }

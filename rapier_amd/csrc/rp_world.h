@@ -237,6 +237,12 @@ struct DevWorld {
     int *p_conspos;             // pair slot -> position (or -1)
     int *color_count_glob;      // per colour: manifolds on the global (non-island) path
     int *color_rank;            // colour -> stage index in the sweep order
+    // positions inside a colour stage ascend with the manifold's owner body (its first awake dynamic body; unique inside a colour,
+    // whose manifolds are body-disjoint): neighbouring lanes of the solver kernels then hold neighbouring bodies — coalesced body
+    // records, and lanes that become ready together on the dataflow path
+    int cb_words;               // ceil(body capacity / 32)
+    unsigned *cb_bits;          // [128][cb_words] bit b of colour c: body b owns a global-path manifold of colour c
+    int *cb_prefix;             // [128][cb_words] exclusive prefix popcount of cb_bits along the words of a colour
 
     // ---- contact islands (connected components of dynamic bodies over active manifolds) ----
     int *b_label;               // union-find labels
@@ -273,6 +279,7 @@ struct DevWorld {
     int *k_b1, *k_b2, *k_n, *k_cid;
 
     // ---- dataflow solver (rp_flow.hip): per-body toucher lists in sweep order ----
+    float4 *f_rec;              // [2 * n_bodies] velocity records: (lin.xyz, tag), (ang.xyz, tag) side by side
     int2 *fk_rank;              // [cons_cap] position -> rank among the contact touchers of its body 1 / body 2 (-1 = world-attached side)
     int2 *fj_rank;              // [n_joints] joint -> rank among the joints of its body 1 / body 2 (in joint sweep order)
     int2 *fb_deg;               // [n_bodies] contact touchers, joint touchers of a solver body

@@ -28,6 +28,19 @@ w = PhysicsWorld.from_scene(scene)
 w.step(60); w.sync()
 t = time.time(); w.step(steps); w.sync(); dt = time.time() - t
 print(f"{name}: {steps / dt:.1f} steps/s  {dt / steps * 1e3:.3f} ms/step", w.counters())
+try:  # hand-off statistics of the dataflow launch (rp_flow.hip), accumulated since world creation
+    import ctypes as C
+    import numpy as np
+    from rapier_amd import _ffi
+    buf = np.zeros(64, np.int64)
+    L = _ffi.lib()
+    L.rp_debug_cycles.argtypes = [C.c_void_p, C.c_void_p]
+    if L.rp_debug_cycles(w._ptr, buf.ctypes.data) == 0 and buf[20]:
+        print(f"{name} flow: wave-items {buf[20]}  polls/item {buf[21] / buf[20]:.2f}  applies/item {buf[22] / buf[20]:.2f}  waves*launches {buf[23]}"
+              f"  per wave-launch: kernel {buf[26] / buf[23] / 100:.1f} us, in wait loops {buf[25] / buf[23] / 100:.1f} us"
+              )
+except Exception as e:  # noqa: BLE001
+    print("no flow statistics:", e)
 if os.environ.get("RP_PROF_TIMERS", "1") == "1":
     w.enable_timers(True); w.step(50); w.sync()
     c = w.counters()
