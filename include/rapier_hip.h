@@ -261,9 +261,11 @@ int32_t rp_quarantine_read(rp_world *w, int32_t cap, uint64_t *handles_out);
  * instead of callbacks: the device appends an event whenever a pair with ActiveEvents::COLLISION_EVENTS starts / stops
  * touching (contacts.rs:316-323; a deleted touching pair or a removed collider raises Stopped, the latter with
  * RP_COLLISION_EVENT_REMOVED) and, after every step, for every solver-active pair with ActiveEvents::CONTACT_FORCE_EVENTS
- * whose total contact force exceeds the smaller of the two colliders' thresholds (solver_graph.rs:462-498).  These calls
- * drain the queue (oldest first, sorted by step, collider1, collider2) and return the number of pending events (only
- * `cap` are written; a queue that overflowed its 65,536 slots drops the newest events and says so in rp_last_error). */
+ * whose total contact force exceeds the smaller of the two colliders' thresholds (solver_graph.rs:462-498).  With
+ * out == NULL a call returns the number of queued events and consumes nothing.  Otherwise it writes the oldest
+ * min(queued, cap) events (sorted by step, collider1, collider2), removes exactly those from the queue and returns how many
+ * it wrote; the rest stays queued for the next call.  (A queue that overflowed its 65,536 slots between two reads has
+ * dropped the newest events and says so in rp_last_error.) */
 int32_t rp_collision_events_read(rp_world *w, int32_t cap, rp_collision_event *out);
 int32_t rp_contact_force_events_read(rp_world *w, int32_t cap, rp_contact_force_event *out);
 

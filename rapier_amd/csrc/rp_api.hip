@@ -47,6 +47,7 @@ void rp_launch_idle_step(const DevWorld &w, hipStream_t st);
 void rp_launch_clear_no_contact(const DevWorld &w, hipStream_t st);
 void rp_launch_global_flow(const DevWorld &w, hipStream_t st, int grid, int has_restitution);
 int rp_flow_grid(int device);
+int rp_fused_grid(int device);
 
 struct HostBody {
     rp_body_desc d; float inv_mass; float inv_pi[3]; float lcom[3]; int ncolliders; bool removed;
@@ -55,6 +56,7 @@ struct HostBody {
     float max_extent = 0.0f, sleep_timer = 0.0f, sprev[7] = {0, 0, 0, 0, 0, 0, 1};
     int sleeping = 0, slabel = 0, next_ord = 0;
     bool has_next = false; float next[7] = {0, 0, 0, 0, 0, 0, 1}; // RigidBodyPosition::next_position of a kinematic body
+    bool quarantined = false;         // disabled by the quarantine (quarantine.rs): inert like a removed body, handle still readable
 };
 
 // Device allocations of finalize(): which DevWorld member they back and how they are indexed, so that a world that outgrows its
@@ -75,6 +77,8 @@ struct rp_world {
     std::vector<char> collider_removed, joint_removed;
     std::vector<rp_joint_desc> joints;
     std::vector<int> active_joint_ids; // device joint index -> index into `joints`
+    std::vector<int> quarantine_log;   // bodies disabled by the quarantine, in detection order
+    int quar_seen = 0;                 // value of FL_QUARANTINE the host has already acted on
     std::vector<int> pending_wake;     // bodies to wake once the device world exists again (joints inserted: insert(.., wake_up = true))
     bool finalized = false;
     int cap_bodies = 0, cap_colliders = 0; // device array capacities (rows beyond n_bodies / n_colliders are spare)
@@ -98,6 +102,7 @@ struct rp_world {
     bool use_graph = true, use_fast = true, use_fused = true;
     bool use_flow = true;          // MULTI mode of the global path = the dataflow launch (rp_flow.hip); RP_NO_FLOW=1: one launch per colour stage
     int flow_grid = 0;             // workgroups of the dataflow launch (all resident at once), 0 = unavailable
+    int fused_grid = 0;            // most workgroups a fused fast step may use (all resident at once), 0 = no fused step on this device
     bool compound = false;         // some dynamic body carries several colliders or an offset collider (no fused fast step)
     bool timed_ready[2] = {false, false};
     int cur_fast = 0;              // mode the enqueue_* callbacks capture
@@ -141,6 +146,8 @@ static int refresh_joint_frames(rp_world *w, int b);
 static int carry_over(rp_world *w);
 static int queue_wake(rp_world *w, int b, int lvl);
 static int finalize(rp_world *w);
+static int quarantine_body_at(rp_world *w, int b);
+static bool all_finite(const float *v, int n);
 template <typename T> static int poke(rp_world *w, T *dst, const T &v);
 
 extern "C" void rp_default_params(rp_integration_params *p) {
@@ -229,9 +236,31 @@ static void fill_sim_params(rp_world *w, SimParams &sp, float cell) {
     sp.inv_cell_size = 1.0f / cell;
 }
 
+// IntegrationParameters as the reference types them (integration_parameters.rs:181-304): num_solver_iterations is a NonZeroUsize,
+// the other counts are usize, the lengths and frequencies are positive reals.  One check shared by create and set, so that a
+// zero-iteration substep loop (dt_sub = inf, a fused step whose arrival never happens) cannot reach the device.
+static const char *params_problem(const rp_integration_params &p) {
+    auto real = [](float x) { return std::isfinite(x); };
+    if (!real(p.dt) || p.dt < 0.0f) return "dt must be finite and >= 0";
+    if (p.num_solver_iterations < 1) return "num_solver_iterations must be >= 1";
+    if (p.num_internal_pgs_iterations < 0 || p.num_internal_stabilization_iterations < 0) return "the internal iteration counts must be >= 0";
+    if (p.num_solver_iterations > 4096 || p.num_internal_pgs_iterations > 4096 || p.num_internal_stabilization_iterations > 4096) return "iteration counts above 4096";
+    if (!real(p.length_unit) || !(p.length_unit > 0.0f)) return "length_unit must be finite and > 0";
+    if (p.friction_model != RP_FRICTION_SIMPLIFIED && p.friction_model != RP_FRICTION_COULOMB) return "unknown friction_model";
+    if (!real(p.contact_natural_frequency) || !real(p.contact_damping_ratio) || !real(p.static_contact_natural_frequency) || !real(p.static_contact_damping_ratio) ||
+        !real(p.joint_natural_frequency) || !real(p.joint_damping_ratio) || p.contact_natural_frequency < 0.0f || p.static_contact_natural_frequency < 0.0f || p.joint_natural_frequency < 0.0f)
+        return "spring frequencies / damping ratios must be finite (frequencies >= 0)";
+    if (!real(p.warmstart_coefficient) || !real(p.normalized_allowed_linear_error) || !real(p.normalized_max_corrective_velocity) || !real(p.normalized_prediction_distance) ||
+        !real(p.normalized_max_linear_velocity) || !real(p.normalized_contact_recycle_distance))
+        return "non-finite parameter";
+    if (p.normalized_prediction_distance < 0.0f || p.normalized_allowed_linear_error < 0.0f) return "negative distance parameter";
+    return nullptr;
+}
 extern "C" int32_t rp_world_create(const rp_integration_params *params, const float gravity[3], int32_t device, rp_world **out) {
     if (!out) return RP_ERR_INVALID;
     *out = nullptr;
+    if (params && params_problem(*params)) return RP_ERR_INVALID;
+    if (gravity && !(std::isfinite(gravity[0]) && std::isfinite(gravity[1]) && std::isfinite(gravity[2]))) return RP_ERR_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RP_ERR_DEVICE; // no CPU fallback
     if (device < 0 || device >= ndev) return RP_ERR_DEVICE;
@@ -249,6 +278,7 @@ extern "C" int32_t rp_world_create(const rp_integration_params *params, const fl
     g = getenv("RP_NO_FLOW");
     if (g && g[0] == '1') w->use_flow = false;
     if (w->use_flow) { w->flow_grid = rp_flow_grid(device); if (w->flow_grid <= 0) w->use_flow = false; }
+    if (w->use_fused) { w->fused_grid = rp_fused_grid(device); if (w->fused_grid <= 0) w->use_fused = false; }
     memset(&w->dw, 0, sizeof(w->dw));
     *out = w;
     return RP_OK;
@@ -290,7 +320,7 @@ extern "C" int32_t rp_params_get(const rp_world *w, rp_integration_params *out) 
 extern "C" int32_t rp_params_set(rp_world *w, const rp_integration_params *in) {
     if (!w || !in) return RP_ERR_INVALID;
     if (w->finalized) { int r = settle(w); if (r != RP_OK) return r; }
-    if (in->friction_model != RP_FRICTION_SIMPLIFIED && in->friction_model != RP_FRICTION_COULOMB) { w->err = "rp_params_set: unknown friction_model"; return RP_ERR_INVALID; }
+    if (const char *why = params_problem(*in)) { w->err = std::string("rp_params_set: ") + why; return RP_ERR_INVALID; }
     if (w->finalized && in->friction_model != w->params.friction_model) {
         // the constraint planes are sized per friction model: rebuild the device world from the current state
         int r = rebuild_begin(w);
@@ -944,6 +974,8 @@ static int finalize(rp_world *w) {
     DAC(d.pt_dp1, RP_MAX_PTS * P, DOM_PAIR, RP_MAX_PTS, 1); DAC(d.pt_dp2, RP_MAX_PTS * P, DOM_PAIR, RP_MAX_PTS, 1);
     DAC(d.sc_a1, 4 * P, DOM_PAIR, 4, 1); DAC(d.sc_a2, 4 * P, DOM_PAIR, 4, 1);
     DAC(d.todo_slot, P, DOM_PAIR, 1, 1); DAC(d.todo_key, P, DOM_PAIR, 1, 1); DAC(d.todo_tmp, P, DOM_PAIR, 1, 1); DAC(d.np_list, P, DOM_PAIR, 1, 1);
+    DA(d.col_cnt, capb); DA(d.col_fill, capb); DA(d.col_begin, capb); DA(d.col_list, 2 * P); DA(d.col_sorted, 2 * P);
+    DA(d.col_rec, P); DA(d.col_rank, P); DA(d.col_succ, P); DA(d.col_deps, P); DA(d.col_q, 2 * P);
     DA(d.color_count, RP_NUM_COLORS + 1); DA(d.color_begin, RP_NUM_COLORS + 1); DA(d.color_cursor, RP_NUM_COLORS + 1);
     DA(d.stage_color, RP_NUM_COLORS + 1); DA(d.stage_begin, RP_NUM_COLORS + 1); DA(d.stage_count, RP_NUM_COLORS + 1);
     DA(d.cons_pair, d.cons_cap); DAFC(d.p_conspos, P, 0xff, DOM_PAIR, 1, 1);
@@ -1085,8 +1117,8 @@ static void enqueue_collision(rp_world *w) {
 static void enqueue_island_solver(rp_world *w) {
     // SINGLE mode: workgroup 0 of this launch retires the step (FL_SEQ / FL_STEP, hint publication)
     const int fused = (w->cur_fast && w->plan_fused) ? 1 : 0;
-    const int RP_FUSED_MAX_GRID = 240; // < 256 CUs: every workgroup of the fused step must be resident at once
-    rp_launch_island_solve(w->dw, w->stream, fused ? std::min(w->plan_island_grid, RP_FUSED_MAX_GRID) : w->plan_island_grid,
+    // every workgroup of the fused step must be resident at once: the grid is capped by what the device can hold (rp_fused_grid)
+    rp_launch_island_solve(w->dw, w->stream, fused ? std::min(w->plan_island_grid, w->fused_grid) : w->plan_island_grid,
                            w->has_restitution ? 1 : 0, w->cur_fast, w->plan_single, fused);
 }
 static void enqueue_global_solver(rp_world *w) {
@@ -1120,8 +1152,8 @@ static void plan_from_hints(rp_world *w, const int *fl) {
     w->plan_blocks = w->use_flow ? 1 : std::min(std::max(pow2_ceil((fl[FL_MAX_STAGE] + 255) / 256), 1), 4096);
     w->plan_island_grid = std::min(std::max(pow2_ceil(fl[FL_N_ISLANDS]), 1), 8192);
     // fused single-kernel fast step: every workgroup must be resident at once (in-launch arrival barrier)
-    // (a grid of at most RP_FUSED_MAX_GRID workgroups, one per CU; workgroups loop over islands beyond that)
-    w->plan_fused = (w->use_fused && !w->compound && w->plan_no_global && w->plan_single && fl[FL_N_ISLANDS] > 0) ? 1 : 0;
+    // (a grid of at most fused_grid workgroups; workgroups loop over islands beyond that)
+    w->plan_fused = (w->use_fused && w->fused_grid > 0 && !w->compound && w->plan_no_global && w->plan_single && fl[FL_N_ISLANDS] > 0) ? 1 : 0;
 }
 
 static int capture(rp_world *w, hipGraph_t *g, hipGraphExec_t *ge, void (*fn)(rp_world *)) {
@@ -1138,7 +1170,7 @@ static int check_overflow(rp_world *w, const int *fl) {
     if (fl[FL_OVERFLOW]) {
         char buf[256];
         snprintf(buf, sizeof(buf), "device error (flags 0x%x: 1=pair pool 2=pair hash 4=grid cells 8=large list 16=constraints: raise RP_PAIRS_PER_COLLIDER; "
-                 "32=fused step: a workgroup was not resident 64=dataflow solver stalled: the GPU is shared, set RP_NO_FLOW=1)", fl[FL_OVERFLOW]);
+                 "64=dataflow solver stalled: the GPU is shared, set RP_NO_FLOW=1)", fl[FL_OVERFLOW]);
         w->err = buf;
         return RP_ERR_CAPACITY;
     }
@@ -1246,7 +1278,7 @@ static int step_once(rp_world *w, bool allow_fast) {
     const long long max_ahead = 4;
     if (w->use_graph && !w->timers) {
         long long spins = 0;
-        while (w->seq_enqueued - (long long)pf[FL_SEQ] > max_ahead) {
+        while ((long long)(int32_t)((uint32_t)w->seq_enqueued - (uint32_t)pf[FL_SEQ]) > max_ahead) {
             if (++spins > (1 << 14)) { if (hipStreamQuery(w->stream) != hipErrorNotReady) break; spins = 0; }
             __builtin_ia32_pause();
         }
@@ -1281,8 +1313,30 @@ static int settle(rp_world *w) {
         int fl[FL_COUNT];
         HIPCHK(w, hipMemcpy(fl, w->dw.flags, sizeof(fl), hipMemcpyDeviceToHost));
         memcpy(w->pinned_flags, fl, sizeof(fl));
-        long long missing = w->steps_requested - (long long)fl[FL_STEP];
-        if (missing <= 0) return check_overflow(w, fl);
+        if (fl[FL_GRID_TIMEOUT]) {
+            // a fused fast step waited ~1 s for a workgroup that was not resident (another process or stream holds CUs): that step
+            // aborted without writing anything and is replayed below; this world stops using the single-kernel fused step
+            w->use_fused = false;
+            int zero = 0;
+            HIPCHK(w, hipMemcpy(w->dw.flags + FL_GRID_TIMEOUT, &zero, sizeof(int), hipMemcpyHostToDevice));
+            w->pinned_flags[FL_GRID_TIMEOUT] = 0;
+        }
+        // the device counters are 32-bit and wrap: compare modulo 2^32 (the host is never more than a few steps ahead)
+        long long missing = (long long)(int32_t)((uint32_t)w->steps_requested - (uint32_t)fl[FL_STEP]);
+        if (missing <= 0) {
+            if (fl[FL_QUARANTINE] != w->quar_seen) {
+                // the end-of-step chokepoint (body_writeback) rolled bodies back and stopped them: disable them now, as the reference
+                // does at the start of the next step (quarantine.rs:131-195)
+                w->quar_seen = fl[FL_QUARANTINE];
+                int nb = w->dw.n_bodies;
+                std::vector<int> q(std::max(nb, 1));
+                if (nb > 0) HIPCHK(w, hipMemcpy(q.data(), w->dw.b_quar, nb * sizeof(int), hipMemcpyDeviceToHost));
+                bool any = false;
+                for (int b = 0; b < nb; ++b) if (q[b] && !w->bodies[b].quarantined && !w->bodies[b].removed) { int r = quarantine_body_at(w, b); if (r != RP_OK) return r; any = true; }
+                if (any) { int r = after_topology_edit(w); if (r != RP_OK) return r; }
+            }
+            return check_overflow(w, fl);
+        }
         w->full_until = w->steps_requested + 3;
         w->replayed_steps += missing;
         for (long long i = 0; i < missing; ++i) { int r = step_once(w, false); if (r != RP_OK) return r; }
@@ -1338,9 +1392,19 @@ extern "C" int32_t rp_bodies_write(rp_world *w, int32_t n, const uint64_t *handl
     HIPCHK(w, hipSetDevice(w->device));
     if (!w->finalized) { int r = finalize(w); if (r != RP_OK) return r; }
     { int r = settle(w); if (r != RP_OK) return r; }
+    bool quarantined_any = false;
     for (int i = 0; i < n; ++i) {
         int b = (int)(handles[i] & 0xffffffffull);
         if (b < 0 || b >= w->dw.n_bodies || w->bodies[b].removed) { w->err = "rp_bodies_write: invalid handle"; return RP_ERR_INVALID; }
+        if ((vel6 && !all_finite(vel6 + 6 * i, 6)) || (pos7 && !all_finite(pos7 + 7 * i, 7))) {
+            // Quarantine::detect_user_changes (quarantine.rs:68-129): a non-finite user write never reaches the broad phase; the body
+            // keeps its last valid pose, loses its velocities and forces and is disabled
+            int r = quarantine_body_at(w, b);
+            if (r != RP_OK) return r;
+            quarantined_any = true;
+            continue;
+        }
+        if (w->bodies[b].quarantined) continue; // disabled: writes are ignored
         if (vel6) {
             float4 l = mk4(vel6[6 * i], vel6[6 * i + 1], vel6[6 * i + 2], 0), a = mk4(vel6[6 * i + 3], vel6[6 * i + 4], vel6[6 * i + 5], 0);
             HIPCHK(w, hipMemcpy(w->dw.b_linvel + b, &l, sizeof(l), hipMemcpyHostToDevice));
@@ -1389,6 +1453,7 @@ extern "C" int32_t rp_bodies_write(rp_world *w, int32_t n, const uint64_t *handl
         rp_launch_init_bodies(w->dw, w->stream);
         rp_launch_collider_update(w->dw, w->stream);
     }
+    if (quarantined_any) return after_topology_edit(w);
     return RP_OK;
 }
 
@@ -1482,11 +1547,18 @@ extern "C" int32_t rp_bodies_set_next_kinematic_position(rp_world *w, int32_t n,
     HIPCHK(w, hipSetDevice(w->device));
     if (!w->finalized) { int r = finalize(w); if (r != RP_OK) return r; }
     { int r = settle(w); if (r != RP_OK) return r; }
+    bool quarantined_any = false;
     for (int i = 0; i < n; ++i) {
         int b = (int)(handles[i] & 0xffffffffull);
         if ((handles[i] >> 32) != 0 || b >= w->dw.n_bodies || w->bodies[b].removed) { w->err = "rp_bodies_set_next_kinematic_position: invalid handle"; return RP_ERR_INVALID; }
         int type = w->bodies[b].d.body_type;
         if (type != RP_BODY_KINEMATIC_POSITION && type != RP_BODY_KINEMATIC_VELOCITY) continue; // "if self.is_kinematic()"
+        if (!all_finite(pos7 + 7 * i, 7)) { // only the kinematic target is invalid: the pose keeps its valid half (quarantine.rs:93-99)
+            int r = quarantine_body_at(w, b);
+            if (r != RP_OK) return r;
+            quarantined_any = true;
+            continue;
+        }
         float4 t = mk4(pos7[7 * i], pos7[7 * i + 1], pos7[7 * i + 2], 0), q = mk4(pos7[7 * i + 3], pos7[7 * i + 4], pos7[7 * i + 5], pos7[7 * i + 6]);
         float4 ct, cq;
         HIPCHK(w, hipMemcpy(&ct, w->dw.b_pos + b, sizeof(ct), hipMemcpyDeviceToHost));
@@ -1496,6 +1568,7 @@ extern "C" int32_t rp_bodies_set_next_kinematic_position(rp_world *w, int32_t n,
         bool differs = ct.x != t.x || ct.y != t.y || ct.z != t.z || cq.x != q.x || cq.y != q.y || cq.z != q.z || cq.w != q.w;
         if (differs) { int r = queue_wake(w, b, 2); if (r != RP_OK) return r; } // wake_up(true)
     }
+    if (quarantined_any) return after_topology_edit(w);
     return RP_OK;
 }
 // RigidBody::is_sleeping per handle (1 = asleep).
@@ -1609,6 +1682,23 @@ extern "C" int32_t rp_colliders_remove(rp_world *w, int32_t n, const uint64_t *h
     }
     return after_topology_edit(w);
 }
+// A body leaves the simulation: its colliders and joints go, the device row becomes an inert fixed body.  Shared by
+// rp_bodies_remove (the handle dies) and the quarantine (RigidBody::set_enabled(false): the handle stays readable).
+static int detach_body_at(rp_world *w, int b) {
+    int r;
+    for (size_t c = 0; c < w->colliders.size(); ++c) if (w->collider_parent[c] == b && (r = remove_collider_at(w, (int)c)) != RP_OK) return r;
+    for (size_t j = 0; j < w->joints.size(); ++j) if ((w->joints[j].body1 == b || w->joints[j].body2 == b) && (r = remove_joint_at(w, (int)j)) != RP_OK) return r;
+    HostBody &hb = w->bodies[b];
+    hb.d.body_type = RP_BODY_FIXED;
+    for (int k = 0; k < 3; ++k) { hb.d.linvel[k] = 0.0f; hb.d.angvel[k] = 0.0f; }
+    if (w->finalized) {
+        int fl = RP_BODY_FIXED | (hb.d.gyroscopic ? RP_BF_GYRO : 0) | (hb.d.allow_fast_rotation ? RP_BF_FASTROT : 0) | (((int)(hb.d.dominance & 0xff)) << RP_BF_DOM_SHIFT);
+        if ((r = poke(w, w->dw.b_flags + b, fl)) != RP_OK || (r = poke(w, w->dw.b_linvel + b, mk4(0, 0, 0, 0))) != RP_OK ||
+            (r = poke(w, w->dw.b_angvel + b, mk4(0, 0, 0, 0))) != RP_OK || (r = poke(w, w->dw.b_njoints + b, 0)) != RP_OK ||
+            (r = poke(w, w->dw.b_uforce + b, mk4(0, 0, 0, 0))) != RP_OK || (r = poke(w, w->dw.b_utorque + b, mk4(0, 0, 0, 0))) != RP_OK) return r;
+    }
+    return RP_OK;
+}
 extern "C" int32_t rp_bodies_remove(rp_world *w, int32_t n, const uint64_t *handles) {
     if (!w || n < 0 || (n > 0 && !handles)) return RP_ERR_INVALID;
     HIPCHK(w, hipSetDevice(w->device));
@@ -1616,20 +1706,26 @@ extern "C" int32_t rp_bodies_remove(rp_world *w, int32_t n, const uint64_t *hand
     for (int i = 0; i < n; ++i) {
         int b = handle_index(handles[i]);
         if (b < 0 || b >= (int)w->bodies.size() || w->bodies[b].removed) { w->err = "rp_bodies_remove: invalid handle"; return RP_ERR_INVALID; }
-        int r;
-        for (size_t c = 0; c < w->colliders.size(); ++c) if (w->collider_parent[c] == b && (r = remove_collider_at(w, (int)c)) != RP_OK) return r;
-        for (size_t j = 0; j < w->joints.size(); ++j) if ((w->joints[j].body1 == b || w->joints[j].body2 == b) && (r = remove_joint_at(w, (int)j)) != RP_OK) return r;
-        HostBody &hb = w->bodies[b];
-        hb.removed = true; hb.d.body_type = RP_BODY_FIXED;
-        for (int k = 0; k < 3; ++k) { hb.d.linvel[k] = 0.0f; hb.d.angvel[k] = 0.0f; }
-        if (w->finalized) {
-            int fl = RP_BODY_FIXED | (hb.d.gyroscopic ? RP_BF_GYRO : 0) | (hb.d.allow_fast_rotation ? RP_BF_FASTROT : 0) | (((int)(hb.d.dominance & 0xff)) << RP_BF_DOM_SHIFT);
-            if ((r = poke(w, w->dw.b_flags + b, fl)) != RP_OK || (r = poke(w, w->dw.b_linvel + b, mk4(0, 0, 0, 0))) != RP_OK ||
-                (r = poke(w, w->dw.b_angvel + b, mk4(0, 0, 0, 0))) != RP_OK || (r = poke(w, w->dw.b_njoints + b, 0)) != RP_OK) return r;
-        }
+        int r = detach_body_at(w, b);
+        if (r != RP_OK) return r;
+        w->bodies[b].removed = true;
     }
     return after_topology_edit(w);
 }
+// Quarantine::detect_user_changes / apply_end_step (quarantine.rs:68-195): the body keeps its last valid pose, its velocities and
+// user forces are zeroed and it is disabled (RigidBody::set_enabled(false): no colliders in the broad phase, no joints, not in
+// the active set).  Re-enabling is not offered by this ABI.
+static int quarantine_body_at(rp_world *w, int b) {
+    HostBody &hb = w->bodies[b];
+    if (hb.quarantined || hb.removed) return RP_OK;
+    int r = detach_body_at(w, b);
+    if (r != RP_OK) return r;
+    hb.quarantined = true;
+    if (w->finalized && (r = poke(w, w->dw.b_quar + b, 1)) != RP_OK) return r;
+    w->quarantine_log.push_back(b);
+    return RP_OK;
+}
+static bool all_finite(const float *v, int n) { for (int k = 0; k < n; ++k) if (!std::isfinite(v[k])) return false; return true; }
 
 // Event queues (EventHandler, pipeline/event_handler.rs:94-160): drained oldest first.
 static int drain_count(rp_world *w, int slot, int *count) {
@@ -1642,23 +1738,27 @@ extern "C" int32_t rp_collision_events_read(rp_world *w, int32_t cap, rp_collisi
     HIPCHK(w, hipSetDevice(w->device));
     if (!w->finalized) return 0;
     int n = 0; { int r = drain_count(w, FL_EV_COL, &n); if (r != RP_OK) return r; }
-    if (!out) return n;
     int stored = std::min(n, w->dw.ev_cap);
+    if (!out) return stored;
     if (n > stored) w->err = "rp_collision_events_read: the collision event queue overflowed; the newest events were dropped";
     std::vector<int4> ev(stored);
     if (stored) HIPCHK(w, hipMemcpy(ev.data(), w->dw.ev_col, stored * sizeof(int4), hipMemcpyDeviceToHost));
     std::sort(ev.begin(), ev.end(), [](const int4 &a, const int4 &b) { if (a.w != b.w) return a.w < b.w; if (a.x != b.x) return a.x < b.x; if (a.y != b.y) return a.y < b.y; return a.z < b.z; });
-    for (int i = 0; i < stored && i < cap; ++i) { out[i].collider1 = ev[i].x; out[i].collider2 = ev[i].y; out[i].started = ev[i].z & 0xff; out[i].flags = ev[i].z >> 8; out[i].step = ev[i].w; }
-    int zero = 0; HIPCHK(w, hipMemcpy(w->dw.flags + FL_EV_COL, &zero, sizeof(int), hipMemcpyHostToDevice));
-    return stored;
+    const int written = std::min(stored, cap);
+    for (int i = 0; i < written; ++i) { out[i].collider1 = ev[i].x; out[i].collider2 = ev[i].y; out[i].started = ev[i].z & 0xff; out[i].flags = ev[i].z >> 8; out[i].step = ev[i].w; }
+    // only the events handed out leave the queue: the rest moves to its front (Started / Stopped are edge-triggered, a dropped one is lost for good)
+    const int rest = stored - written;
+    if (rest > 0) HIPCHK(w, hipMemcpy(w->dw.ev_col, ev.data() + written, rest * sizeof(int4), hipMemcpyHostToDevice));
+    HIPCHK(w, hipMemcpy(w->dw.flags + FL_EV_COL, &rest, sizeof(int), hipMemcpyHostToDevice));
+    return written;
 }
 extern "C" int32_t rp_contact_force_events_read(rp_world *w, int32_t cap, rp_contact_force_event *out) {
     if (!w || cap < 0 || (cap > 0 && !out)) return RP_ERR_INVALID;
     HIPCHK(w, hipSetDevice(w->device));
     if (!w->finalized) return 0;
     int n = 0; { int r = drain_count(w, FL_EV_FORCE, &n); if (r != RP_OK) return r; }
-    if (!out) return n;
     int stored = std::min(n, w->dw.ev_cap);
+    if (!out) return stored;
     if (n > stored) w->err = "rp_contact_force_events_read: the contact force event queue overflowed; the newest events were dropped";
     std::vector<int4> meta(stored); std::vector<float4> a(stored), b(stored); std::vector<int> order(stored);
     if (stored) {
@@ -1668,14 +1768,23 @@ extern "C" int32_t rp_contact_force_events_read(rp_world *w, int32_t cap, rp_con
     }
     for (int i = 0; i < stored; ++i) order[i] = i;
     std::sort(order.begin(), order.end(), [&](int p, int q) { const int4 &x = meta[p], &y = meta[q]; if (x.z != y.z) return x.z < y.z; if (x.x != y.x) return x.x < y.x; return x.y < y.y; });
-    for (int i = 0; i < stored && i < cap; ++i) {
+    const int written = std::min(stored, cap);
+    for (int i = 0; i < written; ++i) {
         int k = order[i];
         out[i].collider1 = meta[k].x; out[i].collider2 = meta[k].y; out[i].step = meta[k].z; out[i].started = meta[k].w;
         out[i].total_force[0] = a[k].x; out[i].total_force[1] = a[k].y; out[i].total_force[2] = a[k].z; out[i].total_force_magnitude = a[k].w;
         out[i].max_force_direction[0] = b[k].x; out[i].max_force_direction[1] = b[k].y; out[i].max_force_direction[2] = b[k].z; out[i].max_force_magnitude = b[k].w;
     }
-    int zero = 0; HIPCHK(w, hipMemcpy(w->dw.flags + FL_EV_FORCE, &zero, sizeof(int), hipMemcpyHostToDevice));
-    return stored;
+    const int rest = stored - written; // the events not handed out stay queued, oldest first
+    if (rest > 0) {
+        std::vector<int4> m2(rest); std::vector<float4> a2(rest), b2(rest);
+        for (int i = 0; i < rest; ++i) { int k = order[written + i]; m2[i] = meta[k]; a2[i] = a[k]; b2[i] = b[k]; }
+        HIPCHK(w, hipMemcpy(w->dw.ev_force_meta, m2.data(), rest * sizeof(int4), hipMemcpyHostToDevice));
+        HIPCHK(w, hipMemcpy(w->dw.ev_force_a, a2.data(), rest * sizeof(float4), hipMemcpyHostToDevice));
+        HIPCHK(w, hipMemcpy(w->dw.ev_force_b, b2.data(), rest * sizeof(float4), hipMemcpyHostToDevice));
+    }
+    HIPCHK(w, hipMemcpy(w->dw.flags + FL_EV_FORCE, &rest, sizeof(int), hipMemcpyHostToDevice));
+    return written;
 }
 
 // Quarantine (quarantine.rs:68-131): bodies whose state went non-finite.  The device rolls such a body

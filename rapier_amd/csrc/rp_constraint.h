@@ -431,6 +431,7 @@ RP_DEV void body_writeback(const DevWorld &w, int i, V3 slin, V3 sang, Q4 rot, V
         atomicAdd(&w.flags[FL_QUARANTINE], 1);
         w.b_quar[i] = 1;
         w.b_linvel[i] = make_float4(0, 0, 0, 0); w.b_angvel[i] = make_float4(0, 0, 0, 0);
+        w.b_uforce[i] = make_float4(0, 0, 0, 0); w.b_utorque[i] = make_float4(0, 0, 0, 0); // sanitize_body_dynamics (quarantine.rs:56-63)
         return;
     }
     w.b_linvel[i] = f4(lin, 0.0f); w.b_angvel[i] = f4(ang, 0.0f);

@@ -795,9 +795,18 @@ __global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int ha
                 int spins = 0, v;
                 while (((v = __hip_atomic_load(&w.flags[FL_ARRIVE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffff) < (int)gridDim.x) {
                     __builtin_amdgcn_s_sleep(8);
-                    if (++spins > (1 << 24)) { atomicOr(&w.flags[FL_OVERFLOW], RP_OVF_GRID); break; } // a workgroup never became resident
+                    if (++spins > (1 << 22)) {
+                        // ~1 s: a workgroup never became resident (the GPU is shared).  Turn the wait into an abort of the whole launch:
+                        // the abort count is added only while the arrival count is still short (CAS), so a workgroup that later
+                        // finds the count complete also finds the abort — either every workgroup writes back or none does.
+                        int seen = v;
+                        while ((seen & 0xffff) < (int)gridDim.x &&
+                               !__hip_atomic_compare_exchange_strong(&w.flags[FL_ARRIVE], &seen, seen + (1 << 16), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { }
+                        if ((seen & 0xffff) < (int)gridDim.x) { v = seen + (1 << 16); __hip_atomic_store(&w.flags[FL_GRID_TIMEOUT], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                        v = seen; break; // the last arrival came in meanwhile: decide from the complete count
+                    }
                 }
-                s_go = spins <= (1 << 24) && (v >> 16) == 0;
+                s_go = (v & 0xffff) >= (int)gridDim.x && (v >> 16) == 0;
             }
             __syncthreads();
             go = s_go != 0; decided = true;
@@ -819,7 +828,7 @@ __global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int ha
             if (atomicAdd(&w.flags[FL_DEPART], 1) == (int)gridDim.x - 1) {
                 // every workgroup has arrived by now (each one arrives before it can reach this point)
                 int v = __hip_atomic_load(&w.flags[FL_ARRIVE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((v >> 16) == 0 && !(w.flags[FL_OVERFLOW] & RP_OVF_GRID)) w.flags[FL_STEP] += 1;
+                if ((v >> 16) == 0) w.flags[FL_STEP] += 1;
                 else w.flags[FL_FAST_ABORT] = 1; // sticky: later fast launches exit until a full step ran
                 __hip_atomic_store(&w.flags[FL_ARRIVE], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&w.flags[FL_DEPART], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -837,6 +846,24 @@ void rp_launch_islands_build(const DevWorld &w, hipStream_t st) {
     hipLaunchKernelGGL(k_isl_count, dim3(blocks), dim3(256), 0, st, w);
     hipLaunchKernelGGL(k_isl_number, dim3(nbb), dim3(256), 0, st, w);
     hipLaunchKernelGGL(k_isl_fill, dim3(blocks), dim3(256), 0, st, w);
+}
+// Most workgroups a fused fast step may launch: its arrival barrier needs every workgroup resident at once, so the cap comes from
+// the device (CU count x the occupancy of k_island_solve) with 1/16 of the CUs left free for whatever else the GPU is running
+// (256 CUs, one 512-thread workgroup with ~90 KB of LDS per CU -> 240).  A launch that still meets a non-resident workgroup
+// aborts the step after ~1 s (FL_GRID_TIMEOUT) and the world falls back to the two-kernel fast graph.
+int rp_fused_grid(int device) {
+    static int cached[64] = {0};
+    if (device >= 0 && device < 64 && cached[device]) return cached[device];
+    hipDeviceProp_t prop;
+    int per_cu = 0, cus = 0;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_island_solve, ISL_THREADS, 0) != hipSuccess) per_cu = 0;
+    if (per_cu < 1 || cus < 1) return 0;
+    if (per_cu > 2) per_cu = 2; // more co-resident islands per CU than this only slow each other down
+    int g = cus * per_cu - (cus + 15) / 16;
+    if (g < 1) g = 1;
+    if (device >= 0 && device < 64) cached[device] = g;
+    return g;
 }
 void rp_launch_island_solve(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast, int retire, int fused) {
     if (grid < 1) grid = 1;

@@ -719,76 +719,132 @@ void rp_launch_clear_no_contact(const DevWorld &w, hipStream_t st) {
 
 // ------------------------------------------------------------------------------------------
 // Deferred greedy colouring (apply_deferred_solver_coloring, contacts.rs:369-385 +
-// assign_pair_solver_color, narrow_phase/mod.rs:90-154) — ONE workgroup, dependency rounds.
-RP_DEV unsigned long long ld_u64(unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// assign_pair_solver_color, narrow_phase/mod.rs:90-154).
+//
+// The reference colours this step's begin-touch pairs one after the other in key order; a pair's colour depends only on the
+// masks of its (at most two) dynamic bodies at that moment, i.e. on the pairs with SMALLER keys at those bodies.  That is a
+// dependency DAG with at most two predecessors per pair (the previous pair, by key, at each body), and any schedule that
+// respects it yields the serial result.  ONE workgroup runs it as a wavefront over that DAG:
+//   passes 1-4  per-body lists of the queued pairs (count -> reserve -> fill -> rank by key: the same count/rank scheme as the
+//               toucher lists of rp_flow.hip), each pair learns its successor at either body and its number of predecessors;
+//   rounds      the frontier (pairs without an uncoloured predecessor — never two at one body) is coloured in parallel; each
+//               coloured pair releases its successors, which form the next frontier.
+// Work is O(pairs + sum of degree^2), a round costs a few dependent L2 round trips, and the number of rounds is the depth of the
+// DAG — the first step of b3d_large_pyramid (59,900 pairs) takes a few ms where the bidding scheme of round 1, which rescanned
+// every pending pair in every round, took 525 ms.
 RP_DEV unsigned ld_u32(unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+RP_DEV int ld_i32a(int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __global__ void __launch_bounds__(1024) k_color_pairs(DevWorld w) {
-    int T = w.flags[FL_TODO_COUNT];
+    const int T = w.flags[FL_TODO_COUNT];
     if (T == 0) return;
-    __shared__ int remaining;
-    // todo_tmp[t] = 1 while uncoloured
-    for (int t = threadIdx.x; t < T; t += blockDim.x) w.todo_tmp[t] = 1;
+    __shared__ int cursor, n_cur, n_next;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (tid == 0) { cursor = 0; n_cur = 0; n_next = 0; }
     __syncthreads();
-    for (int round = 0; round < (1 << 24); ++round) {
-        if (threadIdx.x == 0) remaining = 0;
-        __syncthreads();
-        // phase A: each uncoloured pair bids its key at its dynamic bodies
-        for (int t = threadIdx.x; t < T; t += blockDim.x) {
-            if (!w.todo_tmp[t]) continue;
-            int s = w.todo_slot[t];
-            unsigned long long key = w.todo_key[t];
-            int b1 = w.c_parent[w.p_c1[s]], b2 = w.c_parent[w.p_c2[s]];
-            if (body_dynamic(w, b1)) atomicMin(&w.b_min[b1], key);
-            if (body_dynamic(w, b2)) atomicMin(&w.b_min[b2], key);
+    // pass 1: dynamic sides, per-body counts; the first pair to touch a body reserves its list in pass 2
+    for (int t = tid; t < T; t += nt) {
+        int s = w.todo_slot[t];
+        int b1 = w.c_parent[w.p_c1[s]], b2 = w.c_parent[w.p_c2[s]];
+        if (!body_dynamic(w, b1)) b1 = -1;
+        if (!body_dynamic(w, b2)) b2 = -1;
+        int first = 0;
+        if (b1 >= 0 && atomicAdd(&w.col_cnt[b1], 1) == 0) first |= 1;
+        if (b2 >= 0 && atomicAdd(&w.col_cnt[b2], 1) == 0) first |= 2;
+        w.col_rec[t] = make_int4(b1, b2, first, s);
+    }
+    __threadfence(); __syncthreads();
+    // pass 2: reserve
+    for (int t = tid; t < T; t += nt) {
+        int4 r = w.col_rec[t];
+        if (r.z & 1) w.col_begin[r.x] = atomicAdd(&cursor, ld_i32a(&w.col_cnt[r.x]));
+        if (r.z & 2) w.col_begin[r.y] = atomicAdd(&cursor, ld_i32a(&w.col_cnt[r.y]));
+    }
+    __threadfence(); __syncthreads();
+    // pass 3: fill (any order)
+    for (int t = tid; t < T; t += nt) {
+        int4 r = w.col_rec[t];
+        if (r.x >= 0) w.col_list[ld_i32a(&w.col_begin[r.x]) + atomicAdd(&w.col_fill[r.x], 1)] = t;
+        if (r.y >= 0) w.col_list[ld_i32a(&w.col_begin[r.y]) + atomicAdd(&w.col_fill[r.y], 1)] = t;
+    }
+    __threadfence(); __syncthreads();
+    // pass 4: rank by key inside each body's list -> sorted lists
+    for (int t = tid; t < T; t += nt) {
+        int4 r = w.col_rec[t];
+        const unsigned long long key = w.todo_key[t];
+        int2 rk = make_int2(-1, -1);
+        for (int side = 0; side < 2; ++side) {
+            int b = side ? r.y : r.x;
+            if (b < 0) continue;
+            int beg = ld_i32a(&w.col_begin[b]), n = ld_i32a(&w.col_cnt[b]), q = 0;
+            for (int k = 0; k < n; ++k) q += w.todo_key[ld_i32a(&w.col_list[beg + k])] < key;
+            w.col_sorted[beg + q] = t;
+            if (side) rk.y = q; else rk.x = q;
         }
-        __threadfence();
+        w.col_rank[t] = rk;
+        w.col_deps[t] = (rk.x > 0) + (rk.y > 0);
+    }
+    __threadfence(); __syncthreads();
+    // pass 5: successors, first frontier; the per-body counters go back to rest
+    for (int t = tid; t < T; t += nt) {
+        int4 r = w.col_rec[t];
+        int2 rk = w.col_rank[t];
+        int s1 = -1, s2 = -1;
+        if (r.x >= 0 && rk.x + 1 < ld_i32a(&w.col_cnt[r.x])) s1 = ld_i32a(&w.col_sorted[ld_i32a(&w.col_begin[r.x]) + rk.x + 1]);
+        if (r.y >= 0 && rk.y + 1 < ld_i32a(&w.col_cnt[r.y])) s2 = ld_i32a(&w.col_sorted[ld_i32a(&w.col_begin[r.y]) + rk.y + 1]);
+        w.col_succ[t] = make_int2(s1, s2);
+        if (rk.x <= 0 && rk.y <= 0) w.col_q[atomicAdd(&n_cur, 1)] = t;
+    }
+    __threadfence(); __syncthreads();
+    for (int t = tid; t < T; t += nt) {
+        int4 r = w.col_rec[t];
+        if (r.x >= 0) { w.col_cnt[r.x] = 0; w.col_fill[r.x] = 0; }
+        if (r.y >= 0) { w.col_cnt[r.y] = 0; w.col_fill[r.y] = 0; }
+    }
+    // rounds
+    int *qc = w.col_q, *qn = w.col_q + w.pool_cap;
+    for (;;) {
+        const int n = n_cur;
         __syncthreads();
-        // phase B: winners at both bodies take the first free colour
-        for (int t = threadIdx.x; t < T; t += blockDim.x) {
-            if (!w.todo_tmp[t]) continue;
-            int s = w.todo_slot[t];
-            unsigned long long key = w.todo_key[t];
-            int b1 = w.c_parent[w.p_c1[s]], b2 = w.c_parent[w.p_c2[s]];
-            bool d1 = body_dynamic(w, b1), d2 = body_dynamic(w, b2);
-            bool win = (!d1 || ld_u64(&w.b_min[b1]) == key) && (!d2 || ld_u64(&w.b_min[b2]) == key);
-            if (!win) { atomicAdd(&remaining, 1); continue; }
-            int color = 128;
-            unsigned m[4] = {0, 0, 0, 0};
-            if (d1) for (int q = 0; q < 4; ++q) m[q] |= ld_u32(&w.b_cmask[4 * b1 + q]);
-            if (d2) for (int q = 0; q < 4; ++q) m[q] |= ld_u32(&w.b_cmask[4 * b2 + q]);
-            if (d1 && d2) {
-                for (int c = 0; c < RP_DYNAMIC_COLOR_COUNT; ++c) if (!((m[c >> 5] >> (c & 31)) & 1u)) { color = c; break; }
-            } else if (d1 || d2) {
-                for (int c = 127; c >= 0; --c) if (!((m[c >> 5] >> (c & 31)) & 1u)) { color = c; break; }
+        if (n == 0) break;
+        for (int f = tid; f < n; f += nt) {
+            // a thread follows its pair's chain: the first successor it releases is coloured by the same thread at once (most of the
+            // DAG is chains — body k's pairs one after the other), only further released successors wait in the queue for the next round
+            int t = ld_i32a(&qc[f]);
+            while (t >= 0) {
+                const int4 r = w.col_rec[t];
+                const int2 su = w.col_succ[t];
+                const int b1 = r.x, b2 = r.y, s = r.w;
+                const bool d1 = b1 >= 0, d2 = b2 >= 0;
+                int color = 128;
+                unsigned m[4] = {0, 0, 0, 0};
+                if (d1) for (int q = 0; q < 4; ++q) m[q] |= ld_u32(&w.b_cmask[4 * b1 + q]);
+                if (d2) for (int q = 0; q < 4; ++q) m[q] |= ld_u32(&w.b_cmask[4 * b2 + q]);
+                if (d1 && d2) {
+                    for (int c = 0; c < RP_DYNAMIC_COLOR_COUNT; ++c) if (!((m[c >> 5] >> (c & 31)) & 1u)) { color = c; break; }
+                } else if (d1 || d2) {
+                    for (int c = 127; c >= 0; --c) if (!((m[c >> 5] >> (c & 31)) & 1u)) { color = c; break; }
+                }
+                if (color >= 128) { w.p_color[s] = RP_COLOR_OVERFLOW; w.p_colorb[s] = make_int2(-1, -1); }
+                else {
+                    unsigned bit = 1u << (color & 31);
+                    if (d1) atomicOr(&w.b_cmask[4 * b1 + (color >> 5)], bit);
+                    if (d2) atomicOr(&w.b_cmask[4 * b2 + (color >> 5)], bit);
+                    w.p_color[s] = color;
+                    w.p_colorb[s] = (d1 && d2) ? make_int2(b1, b2) : make_int2(d1 ? b1 : b2, -1);
+                }
+                __threadfence(); // the mask bits are in L2 before a successor can be released (its colourer reads them with L2 loads)
+                // (when the same pair follows at both bodies it holds two predecessors' worth of this pair: the second decrement releases it)
+                int next = -1;
+                if (su.x >= 0 && atomicSub(&w.col_deps[su.x], 1) == 1) next = su.x;
+                if (su.y >= 0 && atomicSub(&w.col_deps[su.y], 1) == 1) { if (next < 0) next = su.y; else qn[atomicAdd(&n_next, 1)] = su.y; }
+                t = next;
             }
-            if (color >= 128) { w.p_color[s] = RP_COLOR_OVERFLOW; w.p_colorb[s] = make_int2(-1, -1); }
-            else {
-                unsigned bit = 1u << (color & 31);
-                if (d1) atomicOr(&w.b_cmask[4 * b1 + (color >> 5)], bit);
-                if (d2) atomicOr(&w.b_cmask[4 * b2 + (color >> 5)], bit);
-                w.p_color[s] = color;
-                w.p_colorb[s] = (d1 && d2) ? make_int2(b1, b2) : make_int2(d1 ? b1 : b2, -1);
-            }
-            w.todo_tmp[t] = 2; // coloured this round: still has to reset its bids
         }
-        __threadfence();
+        __threadfence(); __syncthreads();
+        if (tid == 0) { n_cur = n_next; n_next = 0; }
+        int *tmp = qc; qc = qn; qn = tmp;
         __syncthreads();
-        // phase C: reset the bids
-        for (int t = threadIdx.x; t < T; t += blockDim.x) {
-            int st = w.todo_tmp[t];
-            if (!st) continue;
-            int s = w.todo_slot[t];
-            int b1 = w.c_parent[w.p_c1[s]], b2 = w.c_parent[w.p_c2[s]];
-            if (body_dynamic(w, b1)) __hip_atomic_store(&w.b_min[b1], RP_EMPTY_KEY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (body_dynamic(w, b2)) __hip_atomic_store(&w.b_min[b2], RP_EMPTY_KEY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (st == 2) w.todo_tmp[t] = 0;
-        }
-        __threadfence();
-        __syncthreads();
-        int rem = remaining;
-        __syncthreads();
-        if (rem == 0) break;
     }
 }
 

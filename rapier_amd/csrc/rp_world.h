@@ -41,7 +41,7 @@
 #define RP_OVF_CELLS 0x4
 #define RP_OVF_LARGE 0x8
 #define RP_OVF_CONS 0x10
-#define RP_OVF_GRID 0x20   // a fused-step workgroup never became resident (grid barrier timed out)
+#define RP_OVF_GRID 0x20   // (retired: a fused-step barrier time-out is now the recoverable FL_GRID_TIMEOUT)
 #define RP_OVF_FLOW 0x40   // the dataflow solver (rp_flow.hip) gave up waiting for a body record (its grid was not fully resident)
 
 // device scalar slots (int32) in DevWorld::flags
@@ -86,7 +86,9 @@ enum {
     FL_FLOW_DIRTY,      // the constraint / joint layout changed: the per-body toucher ranks of the dataflow solver must be rebuilt
     FL_FLOW_ABORT,      // a dataflow-solver wave timed out: every wave leaves its wait loops (rp_flow.hip)
     FL_FLOW_CURSOR, FL_FLOW_JCURSOR, // bump allocators of the per-body toucher lists (contacts, joints)
-    FL_COUNT = 48
+    FL_GRID_TIMEOUT,    // a fused fast step gave up waiting for a workgroup that was not resident: the step was aborted (nothing written),
+                        // the host replays it on the full graph and stops using the fused launch (rp_api.hip settle())
+    FL_COUNT = 64       // <= 64: publish_flags copies one slot per lane of a wavefront
 };
 
 // constraint float4 planes (per solver manifold) — restates ContactWithTwistFriction +
@@ -231,6 +233,13 @@ struct DevWorld {
 
     // ---- colouring / buckets ----
     int *todo_slot; unsigned long long *todo_key; int *todo_tmp;
+    // k_color_pairs scratch (rp_narrowphase.hip): per-body lists of the queued pairs and the dependency DAG over them
+    int *col_cnt, *col_fill, *col_begin; // [bodies] (cnt / fill rest at zero between launches)
+    int *col_list, *col_sorted;          // [2 * pool] per-body lists: fill order, key order
+    int4 *col_rec;                       // [pool] per queued pair: dynamic body 1, dynamic body 2 (-1 = none), first-toucher bits, pair slot
+    int2 *col_rank, *col_succ;           // [pool] rank in either body's list; the next pair (queue index) at either body
+    int *col_deps;                       // [pool] uncoloured predecessors
+    int *col_q;                          // [2 * pool] frontier queues (double buffer)
     int *np_list;               // [pool] pair slots that failed the recycle test this step (k_np_test -> k_np_update)
     int *color_count, *color_begin, *color_cursor, *stage_color, *stage_begin, *stage_count;
     int *cons_pair;             // [cons_cap] position -> pair slot

@@ -285,11 +285,14 @@ class PhysicsWorld:
         p = np.ascontiguousarray(np.asarray(pos7, dtype=np.float32).reshape(len(h), 7))
         _check(self._ptr, self._lib.rp_bodies_set_next_kinematic_position(self._ptr, len(h), h.ctypes.data, p.ctypes.data), "rp_bodies_set_next_kinematic_position")
 
-    def collision_events(self) -> np.ndarray:
-        """Drain the CollisionEvent queue: rows (collider1, collider2, started, flags, step)."""
+    def collision_events(self, cap: int | None = None) -> np.ndarray:
+        """Drain the CollisionEvent queue: rows (collider1, collider2, started, flags, step).  ``cap`` bounds how many events this
+        call takes; the rest stays queued."""
         n = self._lib.rp_collision_events_read(self._ptr, 0, None)
         if n < 0:
             _check(self._ptr, n, "rp_collision_events_read")
+        if cap is not None:
+            n = min(n, int(cap))
         out = np.zeros((max(n, 1), 5), np.int32)
         m = self._lib.rp_collision_events_read(self._ptr, n, out.ctypes.data)
         if m < 0:
