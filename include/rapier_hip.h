@@ -93,10 +93,13 @@ typedef struct rp_collider_desc {
     uint32_t collision_memberships, collision_filter;
     uint32_t active_events;              /* ActiveEvents (pipeline/event_handler.rs:11-24): RP_EVENTS_COLLISION | RP_EVENTS_CONTACT_FORCE */
     float contact_force_event_threshold; /* ColliderBuilder::contact_force_event_threshold (collider.rs:1040) */
+    int32_t sensor;                      /* ColliderBuilder::sensor(true) (collider.rs): the collider's pairs live in the intersection graph
+                                          * (narrow_phase/intersections.rs:17-175): no contacts, no forces, no wake-ups, only Started / Stopped
+                                          * collision events flagged RP_COLLISION_EVENT_SENSOR and rp_intersection_pairs_read */
 } rp_collider_desc;
 
 enum { RP_EVENTS_COLLISION = 1, RP_EVENTS_CONTACT_FORCE = 2 };
-enum { RP_COLLISION_EVENT_REMOVED = 2 }; /* CollisionEventFlags::REMOVED (geometry/mod.rs:95-102) */
+enum { RP_COLLISION_EVENT_SENSOR = 1, RP_COLLISION_EVENT_REMOVED = 2 }; /* CollisionEventFlags::{SENSOR, REMOVED} (geometry/mod.rs:95-102) */
 
 /* CollisionEvent::{Started, Stopped}(collider1, collider2, flags) — geometry/mod.rs:105-140 */
 typedef struct rp_collision_event {
@@ -267,6 +270,9 @@ int32_t rp_quarantine_read(rp_world *w, int32_t cap, uint64_t *handles_out);
  * it wrote; the rest stays queued for the next call.  (A queue that overflowed its 65,536 slots between two reads has
  * dropped the newest events and says so in rp_last_error.) */
 int32_t rp_collision_events_read(rp_world *w, int32_t cap, rp_collision_event *out);
+/* NarrowPhase::intersection_pairs (narrow_phase/queries.rs:150-190): every pair that involves a sensor collider, as triples
+ * (collider1, collider2, intersecting 0|1) in triples3[3 * i ..]; returns the number of such pairs (may exceed cap). */
+int32_t rp_intersection_pairs_read(rp_world *w, int32_t cap, int32_t *triples3);
 int32_t rp_contact_force_events_read(rp_world *w, int32_t cap, rp_contact_force_event *out);
 
 /* PhysicsPipeline::counters; `enable_timers` != 0 turns on hipEvent stage timing (off = no events). */

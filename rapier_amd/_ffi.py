@@ -21,7 +21,7 @@ SYMBOLS = [
     "rp_impulse_joints_read", "rp_impulse_joints_set_motor", "rp_impulse_joints_read_motor_impulses", "rp_bodies_remove", "rp_colliders_remove", "rp_impulse_joints_remove",
     "rp_quarantine_read", "rp_step",
     "rp_sync", "rp_bodies_read", "rp_bodies_write", "rp_bodies_add_force", "rp_bodies_apply_impulse", "rp_bodies_wake_up", "rp_bodies_is_sleeping", "rp_bodies_set_next_kinematic_position", "rp_num_bodies", "rp_contacts_read",
-    "rp_collision_events_read", "rp_contact_force_events_read", "rp_counters_enable", "rp_counters_read", "rp_solver_loop_time_ms",
+    "rp_collision_events_read", "rp_intersection_pairs_read", "rp_contact_force_events_read", "rp_counters_enable", "rp_counters_read", "rp_solver_loop_time_ms",
 ]
 
 
@@ -82,6 +82,7 @@ def lib():
     L.rp_contacts_read.argtypes = [vp, i32, vp, vp, vp]
     L.rp_collision_events_read.argtypes = [vp, i32, vp]
     L.rp_contact_force_events_read.argtypes = [vp, i32, vp]
+    L.rp_intersection_pairs_read.argtypes = [vp, i32, vp]
     L.rp_counters_enable.argtypes = [vp, i32]
     L.rp_counters_read.argtypes = [vp, vp]
     L.rp_solver_loop_time_ms.argtypes = [vp, C.POINTER(f32), C.POINTER(i32)]

@@ -137,6 +137,7 @@ static int after_topology_edit(rp_world *w);
 static bool world_sleep_enabled(const rp_world *w);
 static bool world_has_kinematic_pos(const rp_world *w);
 static bool world_has_force_events(const rp_world *w);
+static bool world_has_sensors(const rp_world *w);
 static bool world_has_compound_bodies(const rp_world *w);
 static std::vector<unsigned long long> no_contact_keys(const rp_world *w);
 static int check_sleep_scope(rp_world *w);
@@ -677,6 +678,7 @@ extern "C" int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider
     if (in_place && n > 0) {
         w->dw.n_colliders = (int)w->colliders.size();
         w->dw.has_force_events = world_has_force_events(w) ? 1 : 0;
+        w->dw.has_sensors = world_has_sensors(w) ? 1 : 0;
         w->compound = world_has_compound_bodies(w);
         HIPCHK(w, hipStreamSynchronize(w->stream));
         destroy_graphs(w);
@@ -789,7 +791,7 @@ static ColliderRow pack_collider(const rp_world *w, int i) {
     o.groups.x = w->collider_removed[i] ? 0u : c.collision_memberships; o.groups.y = w->collider_removed[i] ? 0u : c.collision_filter;
     // an "inverted" AABB: the first k_collider_update always rewrites it (and flags the broad phase)
     o.fmn = mk4(1.0f, 1.0f, 1.0f, 0); o.fmx = mk4(-1.0f, -1.0f, -1.0f, 0);
-    int ev = (int)(c.active_events & 3u); memcpy(&o.events.x, &ev, sizeof(int)); o.events.y = c.contact_force_event_threshold;
+    int ev = (int)(c.active_events & 3u) | (c.sensor ? RP_EVENTS_SENSOR_BIT : 0); memcpy(&o.events.x, &ev, sizeof(int)); o.events.y = c.contact_force_event_threshold;
     return o;
 }
 // GenericJoint::transform_to_solver_body_space for the joints of body b after its local centre of mass changed (a collider was
@@ -835,6 +837,10 @@ static bool world_sleep_enabled(const rp_world *w) {
         // a kinematic body is sleep-eligible whenever its velocity is exactly zero, whatever can_sleep says
         if (b.d.body_type == RP_BODY_KINEMATIC_POSITION || b.d.body_type == RP_BODY_KINEMATIC_VELOCITY) return true;
     }
+    return false;
+}
+static bool world_has_sensors(const rp_world *w) {
+    for (size_t i = 0; i < w->colliders.size(); ++i) if (!w->collider_removed[i] && w->colliders[i].sensor) return true;
     return false;
 }
 static bool world_has_force_events(const rp_world *w) {
@@ -919,6 +925,7 @@ static int finalize(rp_world *w) {
     d.sleep_enabled = world_sleep_enabled(w) ? 1 : 0;
     d.has_kinematic_pos = world_has_kinematic_pos(w) ? 1 : 0;
     d.has_force_events = world_has_force_events(w) ? 1 : 0;
+    d.has_sensors = world_has_sensors(w) ? 1 : 0;
     w->compound = world_has_compound_bodies(w);
     int nb = (int)w->bodies.size(), nc = (int)w->colliders.size();
     d.n_bodies = nb; d.n_colliders = nc;
@@ -1286,7 +1293,7 @@ static int step_once(rp_world *w, bool allow_fast) {
     // mode: fast graph only while the last observed steps were clean
     // sleep-enabled worlds always take the full path (the sleep timers and the island decision run every step)
     // ... and so do worlds with contact-force events (evaluated after every step)
-    bool fast = allow_fast && w->use_fast && !w->dw.sleep_enabled && !w->dw.has_force_events && w->plan_single && w->dw.n_colliders > 0 && w->steps_requested >= w->full_until;
+    bool fast = allow_fast && w->use_fast && !w->dw.sleep_enabled && !w->dw.has_force_events && !w->dw.has_sensors && w->plan_single && w->dw.n_colliders > 0 && w->steps_requested >= w->full_until;
     if (fast && (pf[FL_FAST_ABORT] || pf[FL_FULL_UPDATES] || pf[FL_LAYOUT_DIRTY] || pf[FL_TODO_COUNT])) {
         fast = false;
         w->full_until = w->steps_requested + 3;
@@ -1751,6 +1758,28 @@ extern "C" int32_t rp_collision_events_read(rp_world *w, int32_t cap, rp_collisi
     if (rest > 0) HIPCHK(w, hipMemcpy(w->dw.ev_col, ev.data() + written, rest * sizeof(int4), hipMemcpyHostToDevice));
     HIPCHK(w, hipMemcpy(w->dw.flags + FL_EV_COL, &rest, sizeof(int), hipMemcpyHostToDevice));
     return written;
+}
+extern "C" int32_t rp_intersection_pairs_read(rp_world *w, int32_t cap, int32_t *triples3) {
+    if (!w || cap < 0 || (cap > 0 && !triples3)) return RP_ERR_INVALID;
+    HIPCHK(w, hipSetDevice(w->device));
+    if (!w->finalized) return 0;
+    { int r = settle(w); if (r != RP_OK) return r; }
+    int top = 0;
+    HIPCHK(w, hipMemcpy(&top, w->dw.flags + FL_POOL_TOP, sizeof(int), hipMemcpyDeviceToHost));
+    top = std::min(top, w->dw.pool_cap);
+    std::vector<int> c1(std::max(top, 1)), c2(std::max(top, 1)), pf(std::max(top, 1));
+    if (top > 0) {
+        HIPCHK(w, hipMemcpy(c1.data(), w->dw.p_c1, top * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(w, hipMemcpy(c2.data(), w->dw.p_c2, top * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(w, hipMemcpy(pf.data(), w->dw.p_pflags, top * sizeof(int), hipMemcpyDeviceToHost));
+    }
+    int m = 0;
+    for (int s = 0; s < top; ++s) {
+        if (c1[s] < 0 || !(w->colliders[c1[s]].sensor || w->colliders[c2[s]].sensor)) continue;
+        if (m < cap) { triples3[3 * m] = c1[s]; triples3[3 * m + 1] = c2[s]; triples3[3 * m + 2] = (pf[s] & RP_PF_INTERSECTING) ? 1 : 0; }
+        m++;
+    }
+    return m;
 }
 extern "C" int32_t rp_contact_force_events_read(rp_world *w, int32_t cap, rp_contact_force_event *out) {
     if (!w || cap < 0 || (cap > 0 && !out)) return RP_ERR_INVALID;

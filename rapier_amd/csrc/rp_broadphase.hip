@@ -281,6 +281,12 @@ __global__ void k_bp_finish_pairs(DevWorld w) {
             bool removed = (e1.x == 0 && e1.y == 0) || (e2.x == 0 && e2.y == 0);
             push_collision_event(w, w.p_c1[s], w.p_c2[s], 0, removed ? RP_COLLISION_EVENT_REMOVED : 0, cur_step(w));
         }
+        if ((w.p_pflags[s] & RP_PF_INTERSECTING) && pair_wants_collision_events(w, w.p_c1[s], w.p_c2[s])) {
+            // remove_pair / remove_collider on the intersection graph (pair_management.rs:382-460): Stopped | SENSOR
+            uint2 e1 = w.c_groups[w.p_c1[s]], e2 = w.c_groups[w.p_c2[s]];
+            bool removed = (e1.x == 0 && e1.y == 0) || (e2.x == 0 && e2.y == 0);
+            push_collision_event(w, w.p_c1[s], w.p_c2[s], 0, (removed ? RP_COLLISION_EVENT_REMOVED : 0) | RP_COLLISION_EVENT_SENSOR, cur_step(w));
+        }
         if (w.sleep_enabled) {
             // remove_pair wakes the bodies of a touching pair (pair_management.rs:541-552); remove_collider wakes every
             // body that had a pair with the removed collider (:88-99)

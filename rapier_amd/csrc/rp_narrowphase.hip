@@ -497,12 +497,72 @@ RP_DEV int effective_dominance(const DevWorld &w, int body) {
 // a side that takes part in the colouring: any non-fixed body (assign_pair_solver_color, mod.rs:104-105)
 RP_DEV bool body_dynamic(const DevWorld &w, int body) { return body >= 0 && (w.b_flags[body] & RP_BF_TYPE_MASK) != RP_BODY_FIXED; }
 
+// parry intersection_test for the three shapes (sensor pairs, narrow_phase/intersections.rs:120-160): ball-ball (centre distance),
+// cuboid-cuboid (no separating axis among the 3 + 3 face normals and the 9 edge cross products), a ball against a convex shape (solid
+// point projection), capsule-capsule (segment distance); cuboid-capsule (GJK in parry) minimises the distance from the capsule's
+// segment to the box over the segment parameter (a convex function: ternary search, 48 fixed iterations).  Same arithmetic as
+// the oracle's shapes_intersect.
+RP_DEV float point_box_dist2(V3 p, V3 he) {
+    float dx = rp_max(fabsf(p.x) - he.x, 0.0f), dy = rp_max(fabsf(p.y) - he.y, 0.0f), dz = rp_max(fabsf(p.z) - he.z, 0.0f);
+    return dx * dx + dy * dy + dz * dz;
+}
+__device__ __noinline__ bool shapes_intersect(int s1, float4 h1, int s2, float4 h2, Pose pos12) {
+    if (s1 > s2) { int ts = s1; s1 = s2; s2 = ts; float4 th = h1; h1 = h2; h2 = th; pos12 = pose_inv(pos12); } // ball < cuboid < capsule
+    if (s1 == RP_SHAPE_BALL && s2 == RP_SHAPE_BALL) { float r = h1.x + h2.x; return dot(pos12.t, pos12.t) <= r * r; }
+    if (s1 == RP_SHAPE_BALL && s2 == RP_SHAPE_CUBOID) { V3 c = pose_itp(pos12, v3(0, 0, 0)); return point_box_dist2(c, v3(h2)) <= h1.x * h1.x; }
+    if (s1 == RP_SHAPE_BALL && s2 == RP_SHAPE_CAPSULE) {
+        V3 c = pose_itp(pos12, v3(0, 0, 0)), e = capsule_axis_dir((int)h2.z);
+        V3 q = segment_project_point(e * -h2.x, e * h2.x, c);
+        float r = h1.x + h2.y; V3 d = c - q;
+        return dot(d, d) <= r * r;
+    }
+    if (s1 == RP_SHAPE_CUBOID && s2 == RP_SHAPE_CUBOID) {
+        V3 d;
+        if (sat_normal_oneway(v3(h1), v3(h2), pos12, d) > 0.0f) return false;
+        if (sat_normal_oneway(v3(h2), v3(h1), pose_inv(pos12), d) > 0.0f) return false;
+        if (sat_edge_twoway(v3(h1), v3(h2), pos12, d) > 0.0f) return false;
+        return true;
+    }
+    if (s1 == RP_SHAPE_CUBOID && s2 == RP_SHAPE_CAPSULE) {
+        V3 e = capsule_axis_dir((int)h2.z);
+        V3 a = pose_tp(pos12, e * -h2.x), b = pose_tp(pos12, e * h2.x);
+        float lo = 0.0f, hi = 1.0f;
+        for (int it = 0; it < 48; ++it) {
+            float m1 = lo + (hi - lo) / 3.0f, m2 = hi - (hi - lo) / 3.0f;
+            float d1 = point_box_dist2(a * (1.0f - m1) + b * m1, v3(h1)), d2 = point_box_dist2(a * (1.0f - m2) + b * m2, v3(h1));
+            if (d1 <= d2) hi = m2; else lo = m1;
+        }
+        float t = 0.5f * (lo + hi);
+        return point_box_dist2(a * (1.0f - t) + b * t, v3(h1)) <= h2.y * h2.y;
+    }
+    V3 e1 = capsule_axis_dir((int)h1.z), e2 = capsule_axis_dir((int)h2.z);
+    V3 a1 = e1 * -h1.x, b1 = e1 * h1.x, a2 = pose_tp(pos12, e2 * -h2.x), b2 = pose_tp(pos12, e2 * h2.x);
+    float sp, tp; closest_points_segment_segment(a1, b1, a2, b2, sp, tp);
+    V3 d = (a2 * (1.0f - tp) + b2 * tp) - (a1 * (1.0f - sp) + b1 * sp);
+    float r = h1.y + h2.y;
+    return dot(d, d) <= r * r;
+}
+
 // The full narrow-phase update of one pair (pair_update.rs:173-613).
 __device__ __noinline__ void pair_full_update(DevWorld &w, int s, int c1, int c2, Pose pc1, Pose pc2, Pose pos12) {
     const float prediction = w.prm.prediction;
     int rb1 = w.c_parent[c1], rb2 = w.c_parent[c2];
     int sh1 = w.c_shape[c1], sh2 = w.c_shape[c2];
     float4 he1 = w.c_he[c1], he2 = w.c_he[c2];
+    if (w.has_sensors && ((__float_as_int(w.c_events[c1].x) | __float_as_int(w.c_events[c2].x)) & RP_EVENTS_SENSOR_BIT)) {
+        // a sensor pair lives in the intersection graph (narrow_phase/intersections.rs:17-175): no manifold, no solver contact, no
+        // colour, no wake-up; it is re-tested while one of its bodies may have moved and raises Started / Stopped | SENSOR on a change
+        int pf = w.p_pflags[s] & ~RP_PF_RECYCLE;
+        const bool had_i = (pf & RP_PF_INTERSECTING) != 0;
+        const bool now_i = (rb1 == rb2 && rb1 >= 0) ? false : shapes_intersect(sh1, he1, sh2, he2, pos12);
+        w.p_npts[s] = 0; w.p_nsc[s] = 0;
+        if (now_i != had_i) {
+            pf ^= RP_PF_INTERSECTING;
+            if (pair_wants_collision_events(w, c1, c2)) push_collision_event(w, c1, c2, now_i ? 1 : 0, RP_COLLISION_EVENT_SENSOR, cur_step(w));
+        }
+        w.p_pflags[s] = pf;
+        return;
+    }
     int had = w.p_nsc[s] > 0;
     const bool no_contact = joints_disable_contacts(w, rb1, rb2); // pair_update.rs:191-201: clear_filtered_pair
 

@@ -33,6 +33,8 @@
 // pair flag bits
 #define RP_PF_RECYCLE 0x1
 #define RP_PF_FORCE_EMITTED 0x2
+#define RP_PF_INTERSECTING 0x8       // IntersectionPair::intersecting of a sensor pair (narrow_phase/intersections.rs)
+#define RP_EVENTS_SENSOR_BIT 0x100    // internal: the collider is a sensor (kept next to the ActiveEvents bits in c_events.x)
 #define RP_PF_NO_CONTACT 0x4          // cleared by a joint with contacts_enabled = false (pair_update.rs:191-201); skipped until the joint set changes       // PairEventStatus::INITIAL_FORCE_THRESHOLD_EVENT_EMITTED
 
 // overflow / error flag bits (dev flags[FL_OVERFLOW])
@@ -160,6 +162,7 @@ struct DevWorld {
     int has_force_events;  // some collider has ActiveEvents::CONTACT_FORCE_EVENTS: k_force_events runs after every step
     int ev_cap;            // slots per event queue
     int has_kinematic_pos; // some body is KinematicPositionBased: k_kinematic_velocities runs
+    int has_sensors;       // some collider is a sensor: its pairs are intersection-tested every step (full step path)
     SimParams prm;
     int *flags;        // FL_* scalars
     long long *dbg;    // [64] cycle stamps of island 0 (only written when built with -DRP_ISL_PROFILE)

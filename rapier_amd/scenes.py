@@ -31,7 +31,7 @@ COLLIDER_DTYPE = np.dtype([
     ("density", "<f4"), ("friction", "<f4"), ("restitution", "<f4"),
     ("friction_rule", "<i4"), ("restitution_rule", "<i4"),
     ("collision_memberships", "<u4"), ("collision_filter", "<u4"),
-    ("active_events", "<u4"), ("contact_force_event_threshold", "<f4"),
+    ("active_events", "<u4"), ("contact_force_event_threshold", "<f4"), ("sensor", "<i4"),
 ], align=False)
 
 ACTIVE_EVENTS_COLLISION, ACTIVE_EVENTS_CONTACT_FORCE = 1, 2  # ActiveEvents bits
@@ -124,7 +124,7 @@ def body_desc(body_type=BODY_DYNAMIC, translation=(0, 0, 0), rotation=(0, 0, 0, 
 def collider_desc(shape=SHAPE_CUBOID, half_extents=(0.5, 0.5, 0.5), translation=(0, 0, 0),
                   rotation=(0, 0, 0, 1), density=1.0, friction=0.5, restitution=0.0,
                   friction_rule=RULE_AVERAGE, restitution_rule=RULE_AVERAGE,
-                  memberships=0xFFFFFFFF, filter=0xFFFFFFFF, active_events=0, contact_force_event_threshold=0.0) -> np.ndarray:
+                  memberships=0xFFFFFFFF, filter=0xFFFFFFFF, active_events=0, contact_force_event_threshold=0.0, sensor=0) -> np.ndarray:
     """ColliderBuilder defaults — /root/reference/src/geometry/collider.rs:1125-1127 (friction 0.5,
     restitution 0, density 1, rule Average)."""
     c = np.zeros((), dtype=COLLIDER_DTYPE)
@@ -137,6 +137,7 @@ def collider_desc(shape=SHAPE_CUBOID, half_extents=(0.5, 0.5, 0.5), translation=
     c["friction_rule"], c["restitution_rule"] = friction_rule, restitution_rule
     c["collision_memberships"], c["collision_filter"] = memberships, filter
     c["active_events"], c["contact_force_event_threshold"] = active_events, contact_force_event_threshold
+    c["sensor"] = sensor  # ColliderBuilder::sensor(true): intersection events only
     return c
 
 

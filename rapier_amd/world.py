@@ -299,6 +299,25 @@ class PhysicsWorld:
             _check(self._ptr, m, "rp_collision_events_read")
         return out[:m]
 
+    def intersection_pairs(self) -> np.ndarray:
+        """NarrowPhase::intersection_pairs: rows (collider1, collider2, intersecting) of every pair that involves a sensor."""
+        n = self._lib.rp_intersection_pairs_read(self._ptr, 0, None)
+        if n < 0:
+            _check(self._ptr, n, "rp_intersection_pairs_read")
+        out = np.zeros((max(n, 1), 3), np.int32)
+        m = self._lib.rp_intersection_pairs_read(self._ptr, n, out.ctypes.data)
+        if m < 0:
+            _check(self._ptr, m, "rp_intersection_pairs_read")
+        return out[:min(n, m)]
+
+    def intersection_pair(self, c1, c2):
+        """NarrowPhase::intersection_pair(c1, c2): True / False, or None when the two colliders form no sensor pair."""
+        lo, hi = (int(c1), int(c2)) if int(c1) < int(c2) else (int(c2), int(c1))
+        for a, b, i in self.intersection_pairs():
+            if (min(a, b), max(a, b)) == (lo, hi):
+                return bool(i)
+        return None
+
     def contact_force_events(self):
         """Drain the ContactForceEvent queue: (meta rows (collider1, collider2, step, started), 8 floats per event:
         total_force xyz, total_force_magnitude, max_force_direction xyz, max_force_magnitude)."""

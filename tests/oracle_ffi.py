@@ -94,7 +94,9 @@ class OracleWorld:
         cols = scene.collider_array()
         parents = scene.parent_array()
         for i in range(len(cols)):
-            L.ro_add_collider(self._w, cols[i:i + 1].ctypes.data, int(parents[i]))
+            ci = L.ro_add_collider(self._w, cols[i:i + 1].ctypes.data, int(parents[i]))
+            if int(cols["sensor"][i]):  # the descriptor's trailing `sensor` field (the oracle's struct ends before it)
+                L.ro_set_collider_sensor(self._w, ci, 1)
         joints = scene.joint_array()
         for i in range(len(joints)):
             if L.ro_add_joint(self._w, joints[i:i + 1].ctypes.data) < 0:
@@ -113,7 +115,10 @@ class OracleWorld:
 
     def add_collider(self, parent: int, **kw) -> int:
         c = np.ascontiguousarray(S.collider_desc(**kw))
-        return lib().ro_add_collider(self._w, c.ctypes.data, int(parent))
+        ci = lib().ro_add_collider(self._w, c.ctypes.data, int(parent))
+        if int(np.asarray(c["sensor"]).reshape(-1)[0]):
+            lib().ro_set_collider_sensor(self._w, ci, 1)
+        return ci
 
     def read(self):
         pos = np.zeros((self.n, 7), np.float32)

@@ -25,7 +25,7 @@ def test_descriptor_layouts_match_header():
     # sizes implied by include/rapier_hip.h (all 4-byte fields, no padding)
     assert S.PARAMS_DTYPE.itemsize == 14 * 4 + 8 * 4
     assert S.BODY_DTYPE.itemsize == 4 + 12 + 16 + 12 + 12 + 4 * 4 + 5 * 4
-    assert S.COLLIDER_DTYPE.itemsize == 4 + 12 + 12 + 16 + 12 + 8 + 8 + 8
+    assert S.COLLIDER_DTYPE.itemsize == 4 + 12 + 12 + 16 + 12 + 8 + 8 + 8 + 4
     assert S.JOINT_DTYPE.itemsize == 8 + 24 + 32 + 8 + 4 + 48 + 4 + 6 * 24
     assert C.sizeof(_ffi.Counters) == 9 * 4 + 14 * 4
     p = S.default_params()
@@ -118,3 +118,29 @@ def test_roofline_bookkeeping_of_bench():
     mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
     assert mod.algorithmic_bytes_per_step(28420, 10780) == 4 * (28420 * 2584 + 10780 * 224) == 303408000
     assert mod.HBM_PEAK_GBS == 8000.0
+
+
+def test_world_create_validates_integration_parameters():
+    """IntegrationParameters are checked before any device work (NonZeroUsize num_solver_iterations, finite dt >= 0, length_unit > 0,
+    a known friction model — integration_parameters.rs:181-304): a bad set is RP_ERR_INVALID (-1) even on a box without a GPU,
+    where a good one gets as far as RP_ERR_DEVICE (-2)."""
+    L = _ffi.lib()
+    g = np.array([0.0, -9.81, 0.0], np.float32)
+
+    def create(**kw):
+        p = S.default_params()
+        for k, v in kw.items():
+            p[k] = v
+        out = C.c_void_p()
+        rc = L.rp_world_create(p.ctypes.data, g.ctypes.data, 0, C.byref(out))
+        if rc == 0:
+            L.rp_world_destroy(out)
+        return rc
+    assert create() in (0, -2)
+    for bad in (dict(num_solver_iterations=0), dict(num_solver_iterations=-3), dict(dt=np.nan), dict(dt=-1.0), dict(dt=np.inf),
+                dict(length_unit=0.0), dict(length_unit=-1.0), dict(friction_model=7), dict(num_internal_pgs_iterations=-1),
+                dict(contact_natural_frequency=np.nan), dict(normalized_prediction_distance=-0.1)):
+        assert create(**bad) == -1, bad
+    out = C.c_void_p()
+    bad_g = np.array([0.0, np.nan, 0.0], np.float32)
+    assert L.rp_world_create(S.default_params().ctypes.data, bad_g.ctypes.data, 0, C.byref(out)) == -1
