@@ -80,6 +80,9 @@ typedef struct rp_body_desc {
     int32_t allow_fast_rotation;
     int32_t can_sleep; /* RigidBodyBuilder::can_sleep (rigid_body.rs:1845): 1 = RigidBodyActivation::active(), 0 = cannot_sleep() */
     uint32_t locked_axes; /* LockedAxes (rigid_body_components.rs:271-288): bit0..2 TRANSLATION_LOCKED_X/Y/Z, bit3..5 ROTATION_LOCKED_X/Y/Z */
+    int32_t additional_solver_iterations; /* RigidBodyBuilder::additional_solver_iterations (rigid_body.rs): extra TGS substeps for the body's
+                                           * whole connected component (island_manager/substep_groups.rs:44-229); at most 15 distinct
+                                           * positive values per world.  Worlds that use it are solved by one workgroup. */
 } rp_body_desc;
 
 /* ColliderBuilder — /root/reference/src/geometry/collider.rs:600-1130 */
@@ -241,6 +244,8 @@ int32_t rp_bodies_apply_impulse(rp_world *w, int32_t n, const uint64_t *handles,
  * rp_bodies_wake_up = IslandManager::wake_up(handle, strong) (sleep.rs:31), effective at the next step;
  * rp_bodies_is_sleeping = RigidBody::is_sleeping (NULL handles are not accepted).  Impulse joints link the islands of their
  * bodies; a joint whose bodies sleep leaves the solver selection (impulse_joint_set.rs:504-572). */
+/* RigidBody::set_additional_solver_iterations (rigid_body.rs): counts[i] >= 0 extra substeps for the component of handles[i]. */
+int32_t rp_bodies_set_additional_solver_iterations(rp_world *w, int32_t n, const uint64_t *handles, const int32_t *counts);
 int32_t rp_bodies_wake_up(rp_world *w, int32_t n, const uint64_t *handles, int32_t strong);
 /* RigidBody::set_next_kinematic_position (rigid_body.rs:1085-1093) for n kinematic bodies: the pose to reach by the
  * end of the next step.  Position-based kinematic bodies get their velocity from it (interpolate_kinematic_velocities,

@@ -149,6 +149,8 @@ static int queue_wake(rp_world *w, int b, int lvl);
 static int finalize(rp_world *w);
 static int quarantine_body_at(rp_world *w, int b);
 static bool all_finite(const float *v, int n);
+static int handle_index(uint64_t h);
+template <typename T> static int poke(rp_world *w, T *dst, const T &v);
 template <typename T> static int poke(rp_world *w, T *dst, const T &v);
 
 extern "C" void rp_default_params(rp_integration_params *p) {
@@ -212,6 +214,47 @@ static float spring_cfm_coeff(float freq, float damping, float dt) {
     return num / d3;
 }
 
+// SubParams of a solve group with `extra` additional substeps (init.rs:52-100: dt / (num_solver_iterations + extra))
+static SubParams group_sub_params(const rp_integration_params &p, int extra) {
+    SubParams s;
+    s.extra = extra;
+    s.num_substeps = p.num_solver_iterations + extra;
+    volatile float dts = p.dt / (float)s.num_substeps;
+    s.dt_sub = dts;
+    s.inv_dt_sub = dts == 0.0f ? 0.0f : 1.0f / dts;
+    s.dyn_cfm = spring_cfm_factor(p.contact_natural_frequency, p.contact_damping_ratio, dts);
+    s.static_cfm = spring_cfm_factor(p.static_contact_natural_frequency, p.static_contact_damping_ratio, dts);
+    s.dyn_erp_inv_dt = spring_erp_inv_dt(p.contact_natural_frequency, p.contact_damping_ratio, dts);
+    s.static_erp_inv_dt = spring_erp_inv_dt(p.static_contact_natural_frequency, p.static_contact_damping_ratio, dts);
+    s.joint_erp_inv_dt = spring_erp_inv_dt(p.joint_natural_frequency, p.joint_damping_ratio, dts);
+    s.joint_cfm_coeff = spring_cfm_coeff(p.joint_natural_frequency, p.joint_damping_ratio, dts);
+    return s;
+}
+// The distinct additional_solver_iterations counts of the live bodies, descending, 0 last (substep_groups.rs: one solve group per
+// distinct count).  Returns the number of groups (1 = no elevated body), or -1 when there are more than RP_MAX_GROUPS.
+static int group_table(const rp_world *w, std::vector<int> &extras) {
+    extras.clear();
+    for (const HostBody &b : w->bodies) {
+        if (b.removed || b.quarantined || b.d.additional_solver_iterations <= 0) continue;
+        if (std::find(extras.begin(), extras.end(), b.d.additional_solver_iterations) == extras.end()) extras.push_back(b.d.additional_solver_iterations);
+    }
+    std::sort(extras.begin(), extras.end(), [](int a, int b) { return a > b; });
+    extras.push_back(0);
+    return (int)extras.size() > RP_MAX_GROUPS ? -1 : (int)extras.size();
+}
+// (re)builds the group table of a finalized world; the caller destroys the step graphs when n_groups changed
+static int upload_group_table(rp_world *w) {
+    std::vector<int> extras;
+    int ng = group_table(w, extras);
+    if (ng < 0) { w->err = "more than 15 distinct positive additional_solver_iterations values in one world"; return RP_ERR_CAPACITY; }
+    std::vector<SubParams> subs(RP_MAX_GROUPS, group_sub_params(w->params, 0));
+    std::vector<int> ex(RP_MAX_GROUPS, 0);
+    for (int g = 0; g < ng; ++g) { subs[g] = group_sub_params(w->params, extras[g]); ex[g] = extras[g]; }
+    HIPCHK(w, hipMemcpy(w->dw.grp_sub, subs.data(), RP_MAX_GROUPS * sizeof(SubParams), hipMemcpyHostToDevice));
+    HIPCHK(w, hipMemcpy(w->dw.grp_extra, ex.data(), RP_MAX_GROUPS * sizeof(int), hipMemcpyHostToDevice));
+    w->dw.n_groups = ng;
+    return RP_OK;
+}
 static void fill_sim_params(rp_world *w, SimParams &sp, float cell) {
     const rp_integration_params &p = w->params;
     sp.p = p;
@@ -328,7 +371,7 @@ extern "C" int32_t rp_params_set(rp_world *w, const rp_integration_params *in) {
         if (r != RP_OK) return r;
     }
     w->params = *in;
-    if (w->finalized) { fill_sim_params(w, w->dw.prm, w->dw.prm.cell_size); destroy_graphs(w); }
+    if (w->finalized) { fill_sim_params(w, w->dw.prm, w->dw.prm.cell_size); int r = upload_group_table(w); if (r != RP_OK) return r; destroy_graphs(w); }
     return RP_OK;
 }
 extern "C" int32_t rp_num_bodies(const rp_world *w) { return w ? (int32_t)w->bodies.size() : 0; }
@@ -619,6 +662,7 @@ extern "C" int32_t rp_bodies_insert(rp_world *w, int32_t n, const rp_body_desc *
     }
     if ((long long)w->bodies.size() + n >= 0xfffff) { w->err = "rp_bodies_insert: more than 2^20 - 1 bodies"; return RP_ERR_CAPACITY; }
     for (int i = 0; i < n; ++i) if (descs[i].body_type < RP_BODY_DYNAMIC || descs[i].body_type > RP_BODY_KINEMATIC_VELOCITY) { w->err = "rp_bodies_insert: unknown body_type"; return RP_ERR_INVALID; }
+    for (int i = 0; i < n; ++i) if (descs[i].additional_solver_iterations < 0 || descs[i].additional_solver_iterations > 4096) { w->err = "rp_bodies_insert: additional_solver_iterations must be in [0, 4096]"; return RP_ERR_INVALID; }
     for (int i = 0; i < n; ++i) {
         HostBody b; b.d = descs[i]; b.ncolliders = 0; b.removed = false; b.inv_mass = 0; b.inv_pi[0] = b.inv_pi[1] = b.inv_pi[2] = 0; b.lcom[0] = b.lcom[1] = b.lcom[2] = 0;
         b.slabel = (int)w->bodies.size();
@@ -633,6 +677,7 @@ extern "C" int32_t rp_bodies_insert(rp_world *w, int32_t n, const rp_body_desc *
         w->dw.sleep_enabled = world_sleep_enabled(w) ? 1 : 0;
         w->dw.has_kinematic_pos = world_has_kinematic_pos(w) ? 1 : 0;
         HIPCHK(w, hipStreamSynchronize(w->stream));
+        { int r = upload_group_table(w); if (r != RP_OK) return r; }
         destroy_graphs(w); // kernel arguments (DevWorld by value) hold the body count
         return after_topology_edit(w);
     }
@@ -774,6 +819,7 @@ static int upload_body_row(rp_world *w, int i) {
     PUT(d.b_invpi, i, r.ipi); PUT(d.b_pframe, i, r.pfr); PUT(d.b_damp, i, r.damp); PUT(d.b_flags, i, r.fl);
     PUT(d.b_sleep, i, r.slp); PUT(d.b_sprev_t, i, r.spt); PUT(d.b_sprev_r, i, r.spr); PUT(d.b_slabel, i, r.slabel);
     PUT(d.b_next_pos, i, r.npos); PUT(d.b_next_rot, i, r.nrot);
+    int extra = w->bodies[i].d.additional_solver_iterations; PUT(d.b_extra, i, extra);
     return RP_OK;
 }
 struct ColliderRow { int ord; int parent, shape; float4 lp, lr, he, mat, fmn, fmx; int2 rules; uint2 groups; float2 events; };
@@ -981,6 +1027,7 @@ static int finalize(rp_world *w) {
     DAC(d.pt_dp1, RP_MAX_PTS * P, DOM_PAIR, RP_MAX_PTS, 1); DAC(d.pt_dp2, RP_MAX_PTS * P, DOM_PAIR, RP_MAX_PTS, 1);
     DAC(d.sc_a1, 4 * P, DOM_PAIR, 4, 1); DAC(d.sc_a2, 4 * P, DOM_PAIR, 4, 1);
     DAC(d.todo_slot, P, DOM_PAIR, 1, 1); DAC(d.todo_key, P, DOM_PAIR, 1, 1); DAC(d.todo_tmp, P, DOM_PAIR, 1, 1); DAC(d.np_list, P, DOM_PAIR, 1, 1);
+    DA(d.grp_sub, RP_MAX_GROUPS); DA(d.grp_extra, RP_MAX_GROUPS); DA(d.b_extra, capb); DA(d.b_group, capb); DA(d.g_parent, capb); DA(d.g_key, capb); DA(d.k_group, d.cons_cap);
     DA(d.col_cnt, capb); DA(d.col_fill, capb); DA(d.col_begin, capb); DA(d.col_list, 2 * P); DA(d.col_sorted, 2 * P);
     DA(d.col_rec, P); DA(d.col_rank, P); DA(d.col_succ, P); DA(d.col_deps, P); DA(d.col_q, 2 * P);
     DA(d.color_count, RP_NUM_COLORS + 1); DA(d.color_begin, RP_NUM_COLORS + 1); DA(d.color_cursor, RP_NUM_COLORS + 1);
@@ -1050,7 +1097,7 @@ static int finalize(rp_world *w) {
     DA(d.j_locked, nj); DA(d.j_limited, nj); DAC(d.j_color, nj, DOM_JOINT, 1, 1); DAC(d.j_tmp, nj, DOM_JOINT, 1, 1); DAC(d.j_order, nj, DOM_JOINT, 1, 1); DAC(d.j_imp, nj, DOM_JOINT, 1, 1); DAC(d.j_imp_ang, nj, DOM_JOINT, 1, 1);
     DA(d.j_lim, (size_t)6 * std::max(nj, 1)); DAC(d.j_imp_lim, nj, DOM_JOINT, 1, 1); DAC(d.j_imp_lim_ang, nj, DOM_JOINT, 1, 1);
     DA(d.j_motor, nj); DA(d.j_mot, (size_t)12 * std::max(nj, 1)); DAC(d.j_imp_mot, nj, DOM_JOINT, 1, 1); DAC(d.j_imp_mot_ang, nj, DOM_JOINT, 1, 1);
-    DA(d.j_stage_begin, RP_NUM_COLORS + 1); DA(d.j_stage_count, RP_NUM_COLORS + 1);
+    DA(d.j_stage_begin, RP_NUM_COLORS + 1); DA(d.j_stage_count, RP_NUM_COLORS + 1); DA(d.j_group, std::max(nj, 1));
     DAC(d.bj_cmask, 4 * (size_t)capb, DOM_BODY, 1, 4); DAFC(d.bj_min, capb, 0xff, DOM_BODY, 1, 1); DA(d.b_njoints, capb);
     DA(d.JR, (size_t)RP_JR_COUNT * std::max(nj, 1)); // im1, im2 + 12 rows x 6 planes (rp_joints.h); planes of unused rows are never touched
     UP(d.j_b1, jb1); UP(d.j_b2, jb2); UP(d.j_f1t, jf1t); UP(d.j_f1r, jf1r); UP(d.j_f2t, jf2t); UP(d.j_f2r, jf2r);
@@ -1083,6 +1130,8 @@ static int finalize(rp_world *w) {
         UP(d.b_sleep, slp); UP(d.b_sprev_t, spt); UP(d.b_sprev_r, spr); UP(d.b_slabel, slab);
         UP(d.b_pos, pos); UP(d.b_rot, rot); UP(d.b_linvel, lv); UP(d.b_angvel, av); UP(d.b_lcom_invm, lci); UP(d.b_invpi, ipi);
         UP(d.b_pframe, pfr); UP(d.b_damp, damp); UP(d.b_flags, bfl);
+        std::vector<int> bext(nb); for (int i = 0; i < nb; ++i) bext[i] = w->bodies[i].d.additional_solver_iterations;
+        UP(d.b_extra, bext);
         std::vector<int> cpar(nc), csh(nc), cord(nc);
         std::vector<float4> clp(nc), clr(nc), che(nc), cmat(nc), fmn(nc), fmx(nc);
         std::vector<int2> crul(nc); std::vector<uint2> cgrp(nc); std::vector<float2> cev(nc);
@@ -1094,6 +1143,7 @@ static int finalize(rp_world *w) {
         UP(d.c_rules, crul); UP(d.c_groups, cgrp); UP(d.c_fatmin, fmn); UP(d.c_fatmax, fmx); UP(d.c_events, cev);
         HIPCHK(w, hipStreamSynchronize(w->stream)); // the staging vectors die here
     }
+    { int r = upload_group_table(w); if (r != RP_OK) return r; }
     std::vector<int> fl(FL_COUNT, 0);
     fl[FL_BP_DIRTY] = 1; fl[FL_LAYOUT_DIRTY] = 1; fl[FL_JOINT_DIRTY] = 1; fl[FL_FLOW_DIRTY] = 1;
     UP(d.flags, fl);
@@ -1151,6 +1201,7 @@ static void plan_from_hints(rp_world *w, const int *fl) {
     w->plan_single = (fl[FL_N_CONS] <= 1024 && fl[FL_N_GLOB_BODIES] <= 4096 && w->dw.n_joints <= 1024) ? 1 : 0;
     const char *force = getenv("RP_FORCE_MULTI");
     if (force && force[0] == '1') w->plan_single = 0;
+    if (w->dw.n_groups > 1) w->plan_single = 1; // substep solve-groups: the one-workgroup group solver (rp_groups.h)
     w->plan_stages = fl[FL_N_PARALLEL];
     w->plan_joint_stages = fl[FL_NJ_STAGES];
     if (w->use_flow) { w->plan_stages = 0; w->plan_joint_stages = 0; } // the dataflow launch does not depend on the stage layout
@@ -1474,6 +1525,24 @@ static int queue_wake(rp_world *w, int b, int lvl) {
 }
 // IslandManager::wake_up (island_manager/sleep.rs:31): takes effect at the start of the next step and wakes the
 // body's whole island.
+extern "C" int32_t rp_bodies_set_additional_solver_iterations(rp_world *w, int32_t n, const uint64_t *handles, const int32_t *counts) {
+    if (!w || n < 0 || (n > 0 && (!handles || !counts))) return RP_ERR_INVALID;
+    HIPCHK(w, hipSetDevice(w->device));
+    if (w->finalized) { int r = settle(w); if (r != RP_OK) return r; }
+    for (int i = 0; i < n; ++i) {
+        int b = handle_index(handles[i]);
+        if (b < 0 || b >= (int)w->bodies.size() || w->bodies[b].removed) { w->err = "rp_bodies_set_additional_solver_iterations: invalid handle"; return RP_ERR_INVALID; }
+        if (counts[i] < 0 || counts[i] > 4096) { w->err = "rp_bodies_set_additional_solver_iterations: count must be in [0, 4096]"; return RP_ERR_INVALID; }
+        w->bodies[b].d.additional_solver_iterations = counts[i];
+        if (w->finalized) { int r = poke(w, w->dw.b_extra + b, (int)counts[i]); if (r != RP_OK) return r; }
+    }
+    if (!w->finalized) return RP_OK;
+    { int r = upload_group_table(w); if (r != RP_OK) return r; }
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    destroy_graphs(w); // kernel arguments (DevWorld by value) hold the group count
+    w->hints_valid = false; // the launch plan is rebuilt (the group solver is a plan of its own)
+    return after_topology_edit(w);
+}
 extern "C" int32_t rp_bodies_wake_up(rp_world *w, int32_t n, const uint64_t *handles, int32_t strong) {
     if (!w || n < 0 || (n > 0 && !handles)) return RP_ERR_INVALID;
     HIPCHK(w, hipSetDevice(w->device));

@@ -76,7 +76,8 @@ __global__ void k_isl_count(DevWorld w) {
         // a body that carries a joint is solved on the global path (joints live there): poison its component
         // ... and so is every body under FrictionModel::Coulomb (the island kernel holds the twist constraint only)
         // ... and so are kinematic bodies (solver bodies with zero inverse mass and their own write-back rule)
-        if (w.b_njoints[b] > 0 || coulomb_model(w) || (w.b_flags[b] & RP_BF_TYPE_MASK) != RP_BODY_DYNAMIC) atomicAdd(&w.r_nc[root], RP_ISL_NC_MAX + 1);
+        // ... and so is everything in a world with substep solve-groups (additional_solver_iterations: rp_groups.h)
+        if (w.b_njoints[b] > 0 || coulomb_model(w) || (w.b_flags[b] & RP_BF_TYPE_MASK) != RP_BODY_DYNAMIC || w.n_groups > 1) atomicAdd(&w.r_nc[root], RP_ISL_NC_MAX + 1);
     }
     for (int s = gid; s < top; s += stride) {
         if (w.p_c1[s] < 0) continue;

@@ -18,6 +18,7 @@
 // Both modes are correct for any amount of work; the host picks by lazily read hints.
 // No FMA contraction (-ffp-contract=off), IEEE divide/sqrt: same arithmetic as the reference's lanes.
 #include "rp_global.h"
+#include "rp_groups.h"
 
 // ---- MULTI mode kernels ---------------------------------------------------------------------------
 __global__ void k_solver_begin(DevWorld w) {
@@ -124,6 +125,9 @@ void rp_launch_force_events(const DevWorld &w, hipStream_t st) {
 __global__ void k_publish(DevWorld w) { publish_flags(w); }
 template <bool COUL>
 __global__ void __launch_bounds__(512) k_global_single(DevWorld w, int has_restitution, int fast) { global_single_block<COUL>(w, has_restitution, fast); }
+// worlds with substep solve-groups: the whole global path, group by group, in one workgroup (rp_groups.h)
+template <bool COUL>
+__global__ void __launch_bounds__(512) k_global_groups(DevWorld w, int has_restitution, int fast) { global_groups_block<COUL>(w, has_restitution, fast); }
 
 // World mass properties at insertion time (RigidBodyMassProps::update_world_mass_properties).
 __global__ void k_init_bodies(DevWorld w) {
@@ -172,6 +176,11 @@ void rp_launch_init_bodies(const DevWorld &w, hipStream_t st) {
     hipLaunchKernelGGL(k_init_bodies, dim3(body_blocks(w)), dim3(256), 0, st, w);
 }
 void rp_launch_global_single(const DevWorld &w, hipStream_t st, int has_restitution, int fast) {
+    if (w.n_groups > 1) {
+        if (host_coulomb(w)) hipLaunchKernelGGL(k_global_groups<true>, dim3(1), dim3(512), 0, st, w, has_restitution, fast);
+        else hipLaunchKernelGGL(k_global_groups<false>, dim3(1), dim3(512), 0, st, w, has_restitution, fast);
+        return;
+    }
     if (host_coulomb(w)) hipLaunchKernelGGL(k_global_single<true>, dim3(1), dim3(512), 0, st, w, has_restitution, fast);
     else hipLaunchKernelGGL(k_global_single<false>, dim3(1), dim3(512), 0, st, w, has_restitution, fast);
 }

@@ -149,6 +149,10 @@ struct SimParams {
     int num_substeps;
 };
 
+// the substep-dependent part of SimParams for one solve group (RigidBody::additional_solver_iterations, rp_groups.h)
+#define RP_MAX_GROUPS 16
+struct SubParams { float dt_sub, inv_dt_sub, dyn_cfm, static_cfm, dyn_erp_inv_dt, static_erp_inv_dt, joint_erp_inv_dt, joint_cfm_coeff; int num_substeps, extra; };
+
 struct DevWorld {
     int n_bodies, n_colliders, n_joints;
     int n_nc;          // joints that disable the contacts between their two bodies
@@ -162,6 +166,7 @@ struct DevWorld {
     int has_force_events;  // some collider has ActiveEvents::CONTACT_FORCE_EVENTS: k_force_events runs after every step
     int ev_cap;            // slots per event queue
     int has_kinematic_pos; // some body is KinematicPositionBased: k_kinematic_velocities runs
+    int n_groups;          // distinct additional_solver_iterations counts in the world (1 = no elevated body: the plain paths)
     int has_sensors;       // some collider is a sensor: its pairs are intersection-tested every step (full step path)
     SimParams prm;
     int *flags;        // FL_* scalars
@@ -194,6 +199,12 @@ struct DevWorld {
     // ---- solver bodies (index = arena index; non-dynamic = world-attached) ----
     float4 *s_lin, *s_ang, *s_rot, *s_trans, *s_incl, *s_inca;
     unsigned int *b_cmask; // 4 x u32 colour mask per body (body_solver_color_masks)
+    // ---- substep solve-groups (rp_groups.h) ----
+    SubParams *grp_sub;    // [RP_MAX_GROUPS] substep parameters per distinct count, descending count
+    int *grp_extra;        // [RP_MAX_GROUPS] the counts
+    int *b_extra;          // RigidBody::additional_solver_iterations per body
+    int *b_group, *g_parent, *g_key; // per body: group index this step; union-find label and component count (scratch)
+    int *k_group, *j_group;          // group of every constraint position / device joint this step
     unsigned long long *b_min; // colouring scratch: min pending key per body
 
     // ---- colliders ----

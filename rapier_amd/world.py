@@ -331,6 +331,12 @@ class PhysicsWorld:
         raw = raw[:m]
         return raw[:, :4].copy().view(np.int32), raw[:, 4:].copy()
 
+    def set_additional_solver_iterations(self, handles, counts):
+        """RigidBody::set_additional_solver_iterations: extra TGS substeps for the whole connected component of each body."""
+        h = np.ascontiguousarray(np.atleast_1d(np.asarray(handles, dtype=np.uint64)))
+        c = np.ascontiguousarray(np.broadcast_to(np.asarray(counts, dtype=np.int32), h.shape))
+        _check(self._ptr, self._lib.rp_bodies_set_additional_solver_iterations(self._ptr, len(h), h.ctypes.data, c.ctypes.data), "rp_bodies_set_additional_solver_iterations")
+
     def wake_up(self, handles, strong: bool = True):
         """IslandManager::wake_up (island_manager/sleep.rs:31) — effective at the next step, island-wide."""
         h = np.ascontiguousarray(np.atleast_1d(np.asarray(handles, dtype=np.uint64)))

@@ -90,7 +90,9 @@ class OracleWorld:
         self._w = L.ro_world_new(params.ctypes.data, grav.ctypes.data)
         bodies = scene.body_array()
         for i in range(len(bodies)):
-            L.ro_add_body(self._w, bodies[i:i + 1].ctypes.data)
+            bi = L.ro_add_body(self._w, bodies[i:i + 1].ctypes.data)
+            if int(bodies["additional_solver_iterations"][i]):  # trailing descriptor field (the oracle's struct ends before it)
+                L.ro_set_additional_solver_iterations(self._w, bi, int(bodies["additional_solver_iterations"][i]))
         cols = scene.collider_array()
         parents = scene.parent_array()
         for i in range(len(cols)):
