@@ -171,6 +171,9 @@ typedef struct rp_counters {
     int32_t full_steps;            /* step graphs enqueued on the full path */
     int32_t replayed_steps;        /* fast steps that gave up on the device and were replayed on the full path */
     int32_t num_sleeping_bodies;   /* dynamic bodies asleep (IslandManager: bodies outside the active set) */
+    int32_t ccd_active_count;      /* (body, step) occurrences so far of RigidBodyCcd::is_moving_fast_with_next_position (worker.rs:845-865):
+                                    * steps in which the reference would have run its continuous-collision pass on a body.  This library
+                                    * does not sweep (ccd_solver.rs is out of scope): 0 means the absence made no difference */
 } rp_counters;
 
 #define RP_INVALID_HANDLE 0xffffffffffffffffull

@@ -54,6 +54,7 @@ struct HostBody {
     // RigidBodyActivation state carried across device rebuilds (rp_sleep.hip)
     float pframe[4] = {0, 0, 0, 1};   // principal inertia frame (MassProperties::principal_inertia_local_frame)
     float max_extent = 0.0f, sleep_timer = 0.0f, sprev[7] = {0, 0, 0, 0, 0, 0, 1};
+    float ccd_thickness = 3.402823466e+38f; // RigidBodyCcd::ccd_thickness: the thinnest attached shape (Real::MAX without colliders)
     int sleeping = 0, slabel = 0, next_ord = 0;
     bool has_next = false; float next[7] = {0, 0, 0, 0, 0, 0, 1}; // RigidBodyPosition::next_position of a kinematic body
     bool quarantined = false;         // disabled by the quarantine (quarantine.rs): inert like a removed body, handle still readable
@@ -576,6 +577,15 @@ static void recompute_mass(rp_world *w, int body) {
         float extent = std::sqrt(dx * dx + dy * dy + dz * dz) + radius;
         if (extent > b.max_extent) b.max_extent = extent;
     }
+    // RigidBodyCcd::ccd_thickness (rigid_body_components.rs:1227): min over the attached shapes of Shape::ccd_thickness
+    // (ball: radius, cuboid: smallest half extent, capsule: radius)
+    b.ccd_thickness = 3.402823466e+38f;
+    for (size_t i = 0; i < w->colliders.size(); ++i) {
+        if (w->collider_parent[i] != body || w->collider_removed[i]) continue;
+        const rp_collider_desc &c = w->colliders[i];
+        float th = c.shape == RP_SHAPE_BALL ? c.half_extents[0] : c.shape == RP_SHAPE_CAPSULE ? c.half_extents[1] : std::min(c.half_extents[0], std::min(c.half_extents[1], c.half_extents[2]));
+        b.ccd_thickness = std::min(b.ccd_thickness, th);
+    }
 }
 // dynamic bodies with several colliders, or with a collider away from the body origin: the fused fast step validates ONE
 // collider per body (b_collider), so such worlds keep to the fast graph / full graph
@@ -793,7 +803,7 @@ static BodyRow pack_body(const HostBody &b) {
     o.lci = mk4(b.lcom[0], b.lcom[1], b.lcom[2], b.inv_mass);
     o.ipi = mk4(b.inv_pi[0], b.inv_pi[1], b.inv_pi[2], 0);
     o.pfr = mk4(b.pframe[0], b.pframe[1], b.pframe[2], b.pframe[3]);
-    o.damp = mk4(bd.linear_damping, bd.angular_damping, bd.gravity_scale, 0);
+    o.damp = mk4(bd.linear_damping, bd.angular_damping, bd.gravity_scale, b.ccd_thickness);
     int fl = ((b.removed ? RP_BODY_FIXED : bd.body_type) & RP_BF_TYPE_MASK);
     if (bd.gyroscopic && bd.body_type == RP_BODY_DYNAMIC) fl |= RP_BF_GYRO; // gyroscopic forces: dynamic bodies only (worker.rs:86)
     if (bd.allow_fast_rotation) fl |= RP_BF_FASTROT;
@@ -866,6 +876,7 @@ static int upload_body_row_mass(rp_world *w, int i) { // mass properties only (a
     BodyRow r = pack_body(w->bodies[i]);
     PUT(d.b_lcom_invm, i, r.lci); PUT(d.b_invpi, i, r.ipi); PUT(d.b_pframe, i, r.pfr);
     PUT((float *)(d.b_sprev_t + i) + 3, 0, r.spt.w); // max_extent follows the attached shapes
+    PUT(d.b_damp, i, r.damp);                         // ... and so does ccd_thickness (damp.w)
     return RP_OK;
 }
 static int upload_collider_row(rp_world *w, int i) {
@@ -2068,6 +2079,7 @@ extern "C" int32_t rp_counters_read(rp_world *w, rp_counters *out) {
     out->full_updates = fl[FL_FULL_UPDATES];
     out->overflow_flags = fl[FL_OVERFLOW];
     out->quarantined = fl[FL_QUARANTINE];
+    out->ccd_active_count = fl[FL_CCD_ACTIVE];
     out->fast_steps = (int32_t)w->fast_steps; out->full_steps = (int32_t)w->full_steps; out->replayed_steps = (int32_t)w->replayed_steps;
     if (w->dw.sleep_enabled && w->dw.n_bodies > 0) {
         std::vector<int> bfl(w->dw.n_bodies);

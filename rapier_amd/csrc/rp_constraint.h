@@ -434,6 +434,19 @@ RP_DEV void body_writeback(const DevWorld &w, int i, V3 slin, V3 sang, Q4 rot, V
         w.b_uforce[i] = make_float4(0, 0, 0, 0); w.b_utorque[i] = make_float4(0, 0, 0, 0); // sanitize_body_dynamics (quarantine.rs:56-63)
         return;
     }
+    if (w.prm.p.max_ccd_substeps != 0 && damp.w < 3.0e38f) {
+        // CCD activation (worker.rs:845-865, RigidBodyCcd::is_moving_fast_with_next_position, rigid_body_components.rs:1131-1157): the
+        // farthest point of the body moved more than half its thinnest extent this step.  damp.w = ccd_thickness (min over the
+        // attached shapes), b_sprev_t.w = max_extent.  Only counted: the sweep itself (ccd_solver.rs) is out of scope.
+        const float max_extent = w.b_sprev_t[i].w;
+        V3 dcom = com - v3(w.b_wcom[i]);
+        Q4 dq = qmul(rot, qconj(q4(w.b_rot[i])));
+        float inv_dt = dt == 0.0f ? 0.0f : 1.0f / dt;
+        float max_delta = len(dcom) + 2.0f * len(v3(dq.x, dq.y, dq.z)) * max_extent;
+        float max_vel = len(dcom * inv_dt) + len(quat_to_scaled_axis(dq) * inv_dt) * max_extent; // ccd_vels = interpolate_velocity(inv_dt)
+        float max_motion = rp_max(max_delta, max_vel * dt);
+        if (max_motion > 0.5f * damp.w) atomicAdd(&w.flags[FL_CCD_ACTIVE], 1);
+    }
     w.b_linvel[i] = f4(lin, 0.0f); w.b_angvel[i] = f4(ang, 0.0f);
     w.b_pos[i] = f4(t, 0.0f); w.b_rot[i] = f4(rot);
     w.b_wcom[i] = f4(qrot(rot, lcom) + t, 0.0f);

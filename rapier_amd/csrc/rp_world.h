@@ -88,6 +88,7 @@ enum {
     FL_FLOW_DIRTY,      // the constraint / joint layout changed: the per-body toucher ranks of the dataflow solver must be rebuilt
     FL_FLOW_ABORT,      // a dataflow-solver wave timed out: every wave leaves its wait loops (rp_flow.hip)
     FL_FLOW_CURSOR, FL_FLOW_JCURSOR, // bump allocators of the per-body toucher lists (contacts, joints)
+    FL_CCD_ACTIVE,      // (body, step) occurrences of the CCD fast-body criterion so far (body_writeback): the reference would have swept
     FL_GRID_TIMEOUT,    // a fused fast step gave up waiting for a workgroup that was not resident: the step was aborted (nothing written),
                         // the host replays it on the full graph and stops using the fused launch (rp_api.hip settle())
     FL_COUNT = 64       // <= 64: publish_flags copies one slot per lane of a wavefront
