@@ -42,7 +42,7 @@ void rp_launch_global_single(const DevWorld &w, hipStream_t st, int has_restitut
 void rp_launch_fast_front(const DevWorld &w, hipStream_t st, int no_global_kernel);
 void rp_launch_wake(const DevWorld &w, hipStream_t st, int phase);
 void rp_launch_wake_partners(const DevWorld &w, hipStream_t st);
-void rp_launch_force_events(const DevWorld &w, hipStream_t st);
+void rp_launch_force_events(const DevWorld &w, hipStream_t st, int fast);
 void rp_launch_idle_step(const DevWorld &w, hipStream_t st);
 void rp_launch_clear_no_contact(const DevWorld &w, hipStream_t st);
 void rp_launch_global_flow(const DevWorld &w, hipStream_t st, int grid, int has_restitution);
@@ -801,7 +801,7 @@ static BodyRow pack_body(const HostBody &b) {
     o.rot = mk4(bd.rotation[0] * qi, bd.rotation[1] * qi, bd.rotation[2] * qi, qn > 0.0f ? bd.rotation[3] * qi : 1.0f);
     o.lv = mk4(bd.linvel[0], bd.linvel[1], bd.linvel[2], 0); o.av = mk4(bd.angvel[0], bd.angvel[1], bd.angvel[2], 0);
     o.lci = mk4(b.lcom[0], b.lcom[1], b.lcom[2], b.inv_mass);
-    o.ipi = mk4(b.inv_pi[0], b.inv_pi[1], b.inv_pi[2], 0);
+    o.ipi = mk4(b.inv_pi[0], b.inv_pi[1], b.inv_pi[2], b.max_extent); // w: max_extent again (next to what body_writeback loads anyway)
     o.pfr = mk4(b.pframe[0], b.pframe[1], b.pframe[2], b.pframe[3]);
     o.damp = mk4(bd.linear_damping, bd.angular_damping, bd.gravity_scale, b.ccd_thickness);
     int fl = ((b.removed ? RP_BODY_FIXED : bd.body_type) & RP_BF_TYPE_MASK);
@@ -1109,6 +1109,7 @@ static int finalize(rp_world *w) {
     DA(d.j_lim, (size_t)6 * std::max(nj, 1)); DAC(d.j_imp_lim, nj, DOM_JOINT, 1, 1); DAC(d.j_imp_lim_ang, nj, DOM_JOINT, 1, 1);
     DA(d.j_motor, nj); DA(d.j_mot, (size_t)12 * std::max(nj, 1)); DAC(d.j_imp_mot, nj, DOM_JOINT, 1, 1); DAC(d.j_imp_mot_ang, nj, DOM_JOINT, 1, 1);
     DA(d.j_stage_begin, RP_NUM_COLORS + 1); DA(d.j_stage_count, RP_NUM_COLORS + 1); DA(d.j_group, std::max(nj, 1));
+    DA(d.jc_first, std::max(nj, 1)); DA(d.jc_list, 2 * (size_t)std::max(nj, 1)); DA(d.jc_sorted, 2 * (size_t)std::max(nj, 1)); DA(d.jc_deps, std::max(nj, 1)); DA(d.jc_q, 2 * (size_t)std::max(nj, 1)); DA(d.jc_rank, std::max(nj, 1)); DA(d.jc_succ, std::max(nj, 1));
     DAC(d.bj_cmask, 4 * (size_t)capb, DOM_BODY, 1, 4); DAFC(d.bj_min, capb, 0xff, DOM_BODY, 1, 1); DA(d.b_njoints, capb);
     DA(d.JR, (size_t)RP_JR_COUNT * std::max(nj, 1)); // im1, im2 + 12 rows x 6 planes (rp_joints.h); planes of unused rows are never touched
     UP(d.j_b1, jb1); UP(d.j_b2, jb2); UP(d.j_f1t, jf1t); UP(d.j_f1r, jf1r); UP(d.j_f2t, jf2t); UP(d.j_f2r, jf2r);
@@ -1203,7 +1204,7 @@ static void enqueue_global_solver(rp_world *w) {
 static void enqueue_solver(rp_world *w) { enqueue_island_solver(w); enqueue_global_solver(w); }
 static void enqueue_finish(rp_world *w) {
     // the scalars reach the mapped hint buffer from the device: k_island_solve (SINGLE) / k_publish (MULTI)
-    rp_launch_force_events(w->dw, w->stream); // contact force events of the step that just retired
+    rp_launch_force_events(w->dw, w->stream, w->cur_fast); // contact force events of the step that just retired
 }
 
 static int pow2_ceil(int x) { int b = 1; while (b < x) b <<= 1; return b; }
@@ -1222,7 +1223,8 @@ static void plan_from_hints(rp_world *w, const int *fl) {
     w->plan_island_grid = std::min(std::max(pow2_ceil(fl[FL_N_ISLANDS]), 1), 8192);
     // fused single-kernel fast step: every workgroup must be resident at once (in-launch arrival barrier)
     // (a grid of at most fused_grid workgroups; workgroups loop over islands beyond that)
-    w->plan_fused = (w->use_fused && w->fused_grid > 0 && !w->compound && w->plan_no_global && w->plan_single && fl[FL_N_ISLANDS] > 0) ? 1 : 0;
+    // (contact-force events are evaluated by a kernel of their own after every step: such worlds take the two-kernel fast graph)
+    w->plan_fused = (w->use_fused && w->fused_grid > 0 && !w->compound && !w->dw.has_force_events && w->plan_no_global && w->plan_single && fl[FL_N_ISLANDS] > 0) ? 1 : 0;
 }
 
 static int capture(rp_world *w, hipGraph_t *g, hipGraphExec_t *ge, void (*fn)(rp_world *)) {
@@ -1257,7 +1259,7 @@ static int launch_step(rp_world *w, int fast) {
             int r;
             if (fast && !w->plan_fused && (r = capture(w, &w->g_col[fast], &w->ge_col[fast], enqueue_collision)) != RP_OK) return r;
             w->timed_ready[fast] = true;
-            if (!(fast && w->plan_no_global) && (r = capture(w, &w->g_fin[fast], &w->ge_fin[fast], enqueue_global_and_finish)) != RP_OK) return r;
+            if (!(fast && w->plan_no_global && !w->dw.has_force_events) && (r = capture(w, &w->g_fin[fast], &w->ge_fin[fast], enqueue_global_and_finish)) != RP_OK) return r;
         }
         HIPCHK(w, hipEventRecord(w->ev[0], w->stream));
         if (!fast) { // full step: the collision stage is launched piecewise so CollisionDetectionCounters / island_construction_time get their own events
@@ -1354,8 +1356,8 @@ static int step_once(rp_world *w, bool allow_fast) {
     }
     // mode: fast graph only while the last observed steps were clean
     // sleep-enabled worlds always take the full path (the sleep timers and the island decision run every step)
-    // ... and so do worlds with contact-force events (evaluated after every step)
-    bool fast = allow_fast && w->use_fast && !w->dw.sleep_enabled && !w->dw.has_force_events && !w->dw.has_sensors && w->plan_single && w->dw.n_colliders > 0 && w->steps_requested >= w->full_until;
+    // ... and so do worlds with sensors (their pairs are intersection-tested every step)
+    bool fast = allow_fast && w->use_fast && !w->dw.sleep_enabled && !w->dw.has_sensors && w->plan_single && w->dw.n_colliders > 0 && w->steps_requested >= w->full_until;
     if (fast && (pf[FL_FAST_ABORT] || pf[FL_FULL_UPDATES] || pf[FL_LAYOUT_DIRTY] || pf[FL_TODO_COUNT])) {
         fast = false;
         w->full_until = w->steps_requested + 3;

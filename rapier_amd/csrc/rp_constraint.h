@@ -434,23 +434,29 @@ RP_DEV void body_writeback(const DevWorld &w, int i, V3 slin, V3 sang, Q4 rot, V
         w.b_uforce[i] = make_float4(0, 0, 0, 0); w.b_utorque[i] = make_float4(0, 0, 0, 0); // sanitize_body_dynamics (quarantine.rs:56-63)
         return;
     }
+    const float4 invpi_ext = w.b_invpi[i]; // xyz: inverse principal inertia, w: max_extent of the attached shapes
     if (w.prm.p.max_ccd_substeps != 0 && damp.w < 3.0e38f) {
         // CCD activation (worker.rs:845-865, RigidBodyCcd::is_moving_fast_with_next_position, rigid_body_components.rs:1131-1157): the
         // farthest point of the body moved more than half its thinnest extent this step.  damp.w = ccd_thickness (min over the
-        // attached shapes), b_sprev_t.w = max_extent.  Only counted: the sweep itself (ccd_solver.rs) is out of scope.
-        const float max_extent = w.b_sprev_t[i].w;
+        // attached shapes).  Only counted: the sweep itself (ccd_solver.rs) is out of scope.
+        const float max_extent = invpi_ext.w;
         V3 dcom = com - v3(w.b_wcom[i]);
         Q4 dq = qmul(rot, qconj(q4(w.b_rot[i])));
-        float inv_dt = dt == 0.0f ? 0.0f : 1.0f / dt;
-        float max_delta = len(dcom) + 2.0f * len(v3(dq.x, dq.y, dq.z)) * max_extent;
-        float max_vel = len(dcom * inv_dt) + len(quat_to_scaled_axis(dq) * inv_dt) * max_extent; // ccd_vels = interpolate_velocity(inv_dt)
-        float max_motion = rp_max(max_delta, max_vel * dt);
-        if (max_motion > 0.5f * damp.w) atomicAdd(&w.flags[FL_CCD_ACTIVE], 1);
+        V3 dv = v3(dq.x, dq.y, dq.z);
+        // cheap bound first (no square root, no atan): motion <= |dcom| + pi |dq.v| max_extent; a body at rest stops here
+        const float quarter = 0.25f * damp.w, q2 = quarter * quarter;
+        if (dot(dcom, dcom) > q2 || dot(dv, dv) * (9.8696044f * max_extent * max_extent) > q2) {
+            float inv_dt = dt == 0.0f ? 0.0f : 1.0f / dt;
+            float max_delta = len(dcom) + 2.0f * len(dv) * max_extent;
+            float max_vel = len(dcom * inv_dt) + len(quat_to_scaled_axis(dq) * inv_dt) * max_extent; // ccd_vels = interpolate_velocity(inv_dt)
+            float max_motion = rp_max(max_delta, max_vel * dt);
+            if (max_motion > 0.5f * damp.w) atomicAdd(&w.flags[FL_CCD_ACTIVE], 1);
+        }
     }
     w.b_linvel[i] = f4(lin, 0.0f); w.b_angvel[i] = f4(ang, 0.0f);
     w.b_pos[i] = f4(t, 0.0f); w.b_rot[i] = f4(rot);
     w.b_wcom[i] = f4(qrot(rot, lcom) + t, 0.0f);
-    Sym3 ii = world_inv_inertia(v3(w.b_invpi[i]), q4(w.b_pframe[i]), rot);
+    Sym3 ii = world_inv_inertia(v3(invpi_ext), q4(w.b_pframe[i]), rot);
     apply_locked_rotations((w.b_flags[i] >> RP_BF_LOCK_SHIFT) & 0x3f, ii);
     w.b_eii0[i] = make_float4(ii.m11, ii.m12, ii.m13, ii.m22);
     w.b_eii1[i] = make_float4(ii.m23, ii.m33, 0.0f, 0.0f);

@@ -793,6 +793,7 @@ void rp_launch_clear_no_contact(const DevWorld &w, hipStream_t st) {
 // DAG — the first step of b3d_large_pyramid (59,900 pairs) takes a few ms where the bidding scheme of round 1, which rescanned
 // every pending pair in every round, took 525 ms.
 RP_DEV unsigned ld_u32(unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#define RP_COLOR_CHAIN_HOPS 8
 RP_DEV int ld_i32a(int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __global__ void __launch_bounds__(1024) k_color_pairs(DevWorld w) {
@@ -871,7 +872,9 @@ __global__ void __launch_bounds__(1024) k_color_pairs(DevWorld w) {
             // a thread follows its pair's chain: the first successor it releases is coloured by the same thread at once (most of the
             // DAG is chains — body k's pairs one after the other), only further released successors wait in the queue for the next round
             int t = ld_i32a(&qc[f]);
-            while (t >= 0) {
+            for (int hops = 0; t >= 0; ++hops) {
+                // (bounded: a thread that walked a long chain to its end would hold the round open while every other ready pair waits)
+                if (hops == RP_COLOR_CHAIN_HOPS) { qn[atomicAdd(&n_next, 1)] = t; break; }
                 const int4 r = w.col_rec[t];
                 const int2 su = w.col_succ[t];
                 const int b1 = r.x, b2 = r.y, s = r.w;

@@ -77,7 +77,8 @@ __global__ void k_writeback_bodies(DevWorld w) {
 
 // NarrowPhase::emit_contact_force_events (solver_graph.rs:462-498) + ContactForceEvent::from_contact_pair
 // (geometry/mod.rs:223-258): one thread per pair slot, after the impulses of the step were written back.
-__global__ void k_force_events(DevWorld w) {
+__global__ void k_force_events(DevWorld w, int fast) {
+    if (fast && w.flags[FL_FAST_ABORT]) return; // the fast graph gave up on this step: it is replayed (events included) on the full graph
     int top = w.flags[FL_POOL_TOP];
     if (top > w.pool_cap) top = w.pool_cap;
     const float dt = w.prm.p.dt, inv_dt = dt == 0.0f ? 0.0f : 1.0f / dt;
@@ -116,10 +117,10 @@ __global__ void k_force_events(DevWorld w) {
         } else if (pf & RP_PF_FORCE_EMITTED) w.p_pflags[s] = pf & ~RP_PF_FORCE_EMITTED;
     }
 }
-void rp_launch_force_events(const DevWorld &w, hipStream_t st) {
+void rp_launch_force_events(const DevWorld &w, hipStream_t st, int fast) {
     if (!w.has_force_events || w.n_colliders == 0) return;
     int blocks = (w.pool_cap + 255) / 256; if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_force_events, dim3(blocks), dim3(256), 0, st, w);
+    hipLaunchKernelGGL(k_force_events, dim3(blocks), dim3(256), 0, st, w, fast);
 }
 
 __global__ void k_publish(DevWorld w) { publish_flags(w); }

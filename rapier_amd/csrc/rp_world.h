@@ -291,6 +291,7 @@ struct DevWorld {
     float4 *j_mot;              // [12][n_joints] JointMotor of axis a: plane 2a = (target_vel, target_pos, stiffness, damping), 2a + 1 = (max_force, model, -, -)
     float4 *j_imp_mot, *j_imp_mot_ang; // JointMotor::impulse of the linear / angular axes
     int *j_stage_begin, *j_stage_count;    // parallel joint colour stages inside j_order
+    int *jc_first, *jc_list, *jc_sorted, *jc_deps, *jc_q; int2 *jc_rank, *jc_succ; // k_joint_color scratch: per-body joint lists and the dependency DAG (lists / queues: 2 x joints)
     float4 *j_imp, *j_imp_ang;  // per-dof impulses written back at the end of the step (linear dofs, angular dofs)
     unsigned int *bj_cmask;     // [4 * n_bodies] colours taken by joints (bodies_color workspace)
     unsigned long long *bj_min; // joint colouring scratch

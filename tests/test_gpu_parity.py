@@ -975,6 +975,23 @@ def test_collision_and_contact_force_events_bit_exact():
     assert g3.counters()["fast_steps"] > 0
 
 
+def test_contact_force_events_ride_the_fast_graph():
+    """Worlds with ActiveEvents::CONTACT_FORCE_EVENTS take the two-kernel fast graph + k_force_events once they have settled; a kick
+    in the middle aborts fast steps on the device (replayed on the full graph) without losing or duplicating a force event."""
+    sc = S.many_pyramids(rows=2, cols=2).enable_events(S.ACTIVE_EVENTS_COLLISION | S.ACTIVE_EVENTS_CONTACT_FORCE, 20.0)
+    g, o = PhysicsWorld.from_scene(sc), OracleWorld(sc)
+    for k in range(6):
+        g.step(40); o.step(40)
+        _same_state(g, o, f"force events on the fast graph +{40 * (k + 1)}")
+        _same_events(g, o, f"force events on the fast graph +{40 * (k + 1)}")
+        if k == 3:  # knock the top cube of a pyramid off: new pairs, full updates, then settling again
+            top = 55
+            v = np.array([[3.0, 1.0, 0.5, 0.0, 0.0, 0.0]], np.float32)
+            g.write_bodies([top], vel6=v); o.set_vel(top, v[0, :3], v[0, 3:])
+    c = g.counters()
+    assert c["fast_steps"] > 60 and c["overflow_flags"] == 0
+
+
 def test_out_of_scope_inputs_are_refused():
     """Unknown joint axis masks and body types are refused loudly, not mis-simulated."""
     from rapier_amd import RapierHipError
