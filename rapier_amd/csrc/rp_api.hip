@@ -1014,7 +1014,7 @@ static int finalize(rp_world *w) {
     if (!(cell > 1.0e-6f)) cell = 1.0f;
     fill_sim_params(w, d.prm, cell);
 
-    DA(d.flags, FL_COUNT); DA(d.dbg, 1024);
+    DA(d.flags, FL_COUNT); DA(d.dbg, 1024); DA(d.bar, 8);
     DAC(d.b_pos, capb, DOM_BODY, 1, 1); DAC(d.b_rot, capb, DOM_BODY, 1, 1); DAC(d.b_linvel, capb, DOM_BODY, 1, 1); DAC(d.b_angvel, capb, DOM_BODY, 1, 1); DA(d.b_lcom_invm, capb); DA(d.b_invpi, capb);
     DA(d.b_pframe, capb); DAC(d.b_wcom, capb, DOM_BODY, 1, 1); DAC(d.b_eim, capb, DOM_BODY, 1, 1); DAC(d.b_eii0, capb, DOM_BODY, 1, 1); DAC(d.b_eii1, capb, DOM_BODY, 1, 1); DAC(d.b_damp, capb, DOM_BODY, 1, 1);
     DAC(d.b_uforce, capb, DOM_BODY, 1, 1); DAC(d.b_utorque, capb, DOM_BODY, 1, 1); DAC(d.b_flags, capb, DOM_BODY, 1, 1); DAC(d.b_quar, capb, DOM_BODY, 1, 1); DAF(d.b_collider, capb, 0xff);
@@ -1241,7 +1241,7 @@ static int check_overflow(rp_world *w, const int *fl) {
     if (fl[FL_OVERFLOW]) {
         char buf[256];
         snprintf(buf, sizeof(buf), "device error (flags 0x%x: 1=pair pool 2=pair hash 4=grid cells 8=large list 16=constraints: raise RP_PAIRS_PER_COLLIDER; "
-                 "64=dataflow solver stalled: the GPU is shared, set RP_NO_FLOW=1)", fl[FL_OVERFLOW]);
+                 "32=a rebuild kernel's grid barrier timed out: the GPU is shared 64=dataflow solver stalled: the GPU is shared, set RP_NO_FLOW=1)", fl[FL_OVERFLOW]);
         w->err = buf;
         return RP_ERR_CAPACITY;
     }

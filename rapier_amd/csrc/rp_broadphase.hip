@@ -12,6 +12,7 @@
 // spanning more than 3 cells.  Like the reference's change detection the whole rebuild is skipped
 // (every kernel early-exits on FL_BP_DIRTY == 0) while no fat AABB changed.
 #include "rp_pairs.h"
+#include "rp_gridbar.h"
 
 __device__ __forceinline__ unsigned long long rp_hash64(unsigned long long x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
@@ -72,54 +73,51 @@ __global__ void k_fast_front(DevWorld w, int no_global_kernel) {
     if (abort) w.flags[FL_FAST_ABORT] = 1;
 }
 
-__global__ void k_bp_clear(DevWorld w) {
-    if (!w.flags[FL_BP_DIRTY]) return;
+// ---- the rebuild, pass by pass (k_bp_rebuild below runs them behind grid barriers; gid / gstride span the whole launch) ----
+RP_DEV void bp_clear(DevWorld &w, int gid, int gstride) {
     int nxt = (w.flags[FL_BP_EPOCH] & 1) ^ 1;
-    int stride = gridDim.x * blockDim.x;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < w.grid_cap; i += stride) { w.cell_count[i] = 0; w.cell_fill[i] = 0; }
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < w.hash_cap; i += stride) w.h_key[nxt][i] = RP_EMPTY_KEY;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { w.flags[FL_N_LARGE] = 0; w.flags[FL_N_ENTRIES] = 0; }
+    for (int i = gid; i < w.grid_cap; i += gstride) { w.cell_count[i] = 0; w.cell_fill[i] = 0; }
+    for (int i = gid; i < w.hash_cap; i += gstride) w.h_key[nxt][i] = RP_EMPTY_KEY;
+    if (gid == 0) { w.flags[FL_N_LARGE] = 0; w.flags[FL_N_ENTRIES] = 0; }
 }
-
-__global__ void k_bp_count(DevWorld w) {
-    if (!w.flags[FL_BP_DIRTY]) return;
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= w.n_colliders) return;
-    CellRange r = cell_range(w, i);
-    if (r.large) {
-        int k = atomicAdd(&w.flags[FL_N_LARGE], 1);
-        if (k < w.large_cap) w.large_list[k] = i; else atomicOr(&w.flags[FL_OVERFLOW], RP_OVF_LARGE);
-        return;
+RP_DEV void bp_count(DevWorld &w, int gid, int gstride) {
+    for (int i = gid; i < w.n_colliders; i += gstride) {
+        CellRange r = cell_range(w, i);
+        if (r.large) {
+            int k = atomicAdd(&w.flags[FL_N_LARGE], 1);
+            if (k < w.large_cap) w.large_list[k] = i; else atomicOr(&w.flags[FL_OVERFLOW], RP_OVF_LARGE);
+            continue;
+        }
+        for (int z = r.lo[2]; z <= r.hi[2]; ++z)
+            for (int y = r.lo[1]; y <= r.hi[1]; ++y)
+                for (int x = r.lo[0]; x <= r.hi[0]; ++x) {
+                    unsigned long long key = cell_key(x, y, z);
+                    int h = (int)(rp_hash64(key) & (unsigned long long)(w.grid_cap - 1));
+                    atomicAdd(&w.cell_count[h], 1);
+                }
     }
-    for (int z = r.lo[2]; z <= r.hi[2]; ++z)
-        for (int y = r.lo[1]; y <= r.hi[1]; ++y)
-            for (int x = r.lo[0]; x <= r.hi[0]; ++x) {
-                unsigned long long key = cell_key(x, y, z);
-                int h = (int)(rp_hash64(key) & (unsigned long long)(w.grid_cap - 1));
-                atomicAdd(&w.cell_count[h], 1);
-            }
 }
-
-// ---- exclusive scan of cell_count -> cell_start (three small launches, 1024 items per block) ----
-__global__ void k_scan_blocks(DevWorld w) {
-    if (!w.flags[FL_BP_DIRTY]) return;
-    __shared__ int s[1024];
-    int gid = blockIdx.x * 1024 + threadIdx.x;
-    int v = gid < w.grid_cap ? w.cell_count[gid] : 0;
-    s[threadIdx.x] = v;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        int t = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+// exclusive scan of cell_count -> cell_start: 1024-item chunks scanned in LDS, the chunk sums by workgroup 0, then added back
+RP_DEV void bp_scan_chunks(DevWorld &w, int *s) {
+    const int chunks = (w.grid_cap + 1023) / 1024;
+    for (int c = blockIdx.x; c < chunks; c += gridDim.x) {
+        int gid = c * 1024 + threadIdx.x;
+        int v = gid < w.grid_cap ? w.cell_count[gid] : 0;
+        s[threadIdx.x] = v;
         __syncthreads();
-        s[threadIdx.x] += t;
+        for (int off = 1; off < 1024; off <<= 1) {
+            int t = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (gid < w.grid_cap) w.cell_start[gid] = s[threadIdx.x] - v;
+        if (threadIdx.x == 1023) w.scan_block[c] = s[1023];
         __syncthreads();
     }
-    if (gid < w.grid_cap) w.cell_start[gid] = s[threadIdx.x] - v;
-    if (threadIdx.x == 1023) w.scan_block[blockIdx.x] = s[1023];
 }
-__global__ void k_scan_sums(DevWorld w, int nblocks) {
-    if (!w.flags[FL_BP_DIRTY]) return;
-    __shared__ int s[1024];
+RP_DEV void bp_scan_sums(DevWorld &w, int *s) { // workgroup 0 only; at most 1024 chunks (grid_cap <= 2^20)
+    const int nblocks = (w.grid_cap + 1023) / 1024;
     int v = threadIdx.x < nblocks ? w.scan_block[threadIdx.x] : 0;
     s[threadIdx.x] = v;
     __syncthreads();
@@ -135,26 +133,22 @@ __global__ void k_scan_sums(DevWorld w, int nblocks) {
         if (s[1023] > w.entries_cap) atomicOr(&w.flags[FL_OVERFLOW], RP_OVF_CELLS);
     }
 }
-__global__ void k_scan_add(DevWorld w) {
-    if (!w.flags[FL_BP_DIRTY]) return;
-    int gid = blockIdx.x * 1024 + threadIdx.x;
-    if (gid < w.grid_cap) w.cell_start[gid] += w.scan_block[blockIdx.x];
+RP_DEV void bp_scan_add(DevWorld &w, int gid, int gstride) {
+    for (int i = gid; i < w.grid_cap; i += gstride) w.cell_start[i] += w.scan_block[i >> 10];
 }
-
-__global__ void k_bp_fill(DevWorld w) {
-    if (!w.flags[FL_BP_DIRTY]) return;
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= w.n_colliders) return;
-    CellRange r = cell_range(w, i);
-    if (r.large) return;
-    for (int z = r.lo[2]; z <= r.hi[2]; ++z)
-        for (int y = r.lo[1]; y <= r.hi[1]; ++y)
-            for (int x = r.lo[0]; x <= r.hi[0]; ++x) {
-                unsigned long long key = cell_key(x, y, z);
-                int h = (int)(rp_hash64(key) & (unsigned long long)(w.grid_cap - 1));
-                int pos = w.cell_start[h] + atomicAdd(&w.cell_fill[h], 1);
-                if (pos < w.entries_cap) { w.e_key[pos] = key; w.e_col[pos] = i; }
-            }
+RP_DEV void bp_fill(DevWorld &w, int gid, int gstride) {
+    for (int i = gid; i < w.n_colliders; i += gstride) {
+        CellRange r = cell_range(w, i);
+        if (r.large) continue;
+        for (int z = r.lo[2]; z <= r.hi[2]; ++z)
+            for (int y = r.lo[1]; y <= r.hi[1]; ++y)
+                for (int x = r.lo[0]; x <= r.hi[0]; ++x) {
+                    unsigned long long key = cell_key(x, y, z);
+                    int h = (int)(rp_hash64(key) & (unsigned long long)(w.grid_cap - 1));
+                    int pos = w.cell_start[h] + atomicAdd(&w.cell_fill[h], 1);
+                    if (pos < w.entries_cap) { w.e_key[pos] = key; w.e_col[pos] = i; }
+                }
+    }
 }
 
 __device__ __forceinline__ bool fat_overlap(const DevWorld &w, int a, int b, V3 &imin) {
@@ -227,44 +221,41 @@ __device__ void bp_pairs_vs_large(DevWorld &w, int i, bool i_large) {
     }
 }
 
-__global__ void k_bp_pairs(DevWorld w) {
-    if (!w.flags[FL_BP_DIRTY]) return;
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= w.n_colliders) return;
-    CellRange r = cell_range(w, i);
-    bp_pairs_vs_large(w, i, r.large);
-    if (r.large) return;
+RP_DEV void bp_pairs(DevWorld &w, int gid, int gstride) {
     float ic = w.prm.inv_cell_size;
-    for (int z = r.lo[2]; z <= r.hi[2]; ++z)
-        for (int y = r.lo[1]; y <= r.hi[1]; ++y)
-            for (int x = r.lo[0]; x <= r.hi[0]; ++x) {
-                unsigned long long key = cell_key(x, y, z);
-                int h = (int)(rp_hash64(key) & (unsigned long long)(w.grid_cap - 1));
-                int beg = w.cell_start[h], end = beg + w.cell_count[h];
-                if (end > w.entries_cap) end = w.entries_cap;
-                for (int e = beg; e < end; ++e) {
-                    if (w.e_key[e] != key) continue;
-                    int j = w.e_col[e];
-                    if (j <= i) continue;
-                    V3 imin;
-                    if (!fat_overlap(w, i, j, imin)) continue;
-                    // report only in the cell that holds the min corner of the intersection
-                    if (cell_coord(imin.x, ic) != x || cell_coord(imin.y, ic) != y || cell_coord(imin.z, ic) != z) continue;
-                    if (!pair_allowed(w, i, j)) continue;
-                    bp_insert_pair(w, i, j);
+    for (int i = gid; i < w.n_colliders; i += gstride) {
+        CellRange r = cell_range(w, i);
+        bp_pairs_vs_large(w, i, r.large);
+        if (r.large) continue;
+        for (int z = r.lo[2]; z <= r.hi[2]; ++z)
+            for (int y = r.lo[1]; y <= r.hi[1]; ++y)
+                for (int x = r.lo[0]; x <= r.hi[0]; ++x) {
+                    unsigned long long key = cell_key(x, y, z);
+                    int h = (int)(rp_hash64(key) & (unsigned long long)(w.grid_cap - 1));
+                    int beg = w.cell_start[h], end = beg + w.cell_count[h];
+                    if (end > w.entries_cap) end = w.entries_cap;
+                    for (int e = beg; e < end; ++e) {
+                        if (w.e_key[e] != key) continue;
+                        int j = w.e_col[e];
+                        if (j <= i) continue;
+                        V3 imin;
+                        if (!fat_overlap(w, i, j, imin)) continue;
+                        // report only in the cell that holds the min corner of the intersection
+                        if (cell_coord(imin.x, ic) != x || cell_coord(imin.y, ic) != y || cell_coord(imin.z, ic) != z) continue;
+                        if (!pair_allowed(w, i, j)) continue;
+                        bp_insert_pair(w, i, j);
+                    }
                 }
-            }
+    }
 }
 
 // DeletePair: slots not re-stamped by this rebuild are dead (NarrowPhase::remove_pair,
 // pair_management.rs:382): free the colour, drop from the solver graph, recycle the slot.
-__global__ void k_bp_finish_pairs(DevWorld w) {
-    if (!w.flags[FL_BP_DIRTY]) return;
+RP_DEV void bp_finish_pairs(DevWorld &w, int gid, int gstride) {
     int epoch = w.flags[FL_BP_EPOCH];
     int top = w.flags[FL_POOL_TOP];
     if (top > w.pool_cap) top = w.pool_cap;
-    int stride = gridDim.x * blockDim.x;
-    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < top; s += stride) {
+    for (int s = gid; s < top; s += gstride) {
         if (w.p_c1[s] < 0) continue;
         if (w.p_stamp[s] == epoch + 1) continue;
         int color = w.p_color[s];
@@ -303,16 +294,36 @@ __global__ void k_bp_finish_pairs(DevWorld w) {
         int t = atomicAdd(&w.flags[FL_FREE_TOP], 1);
         w.free_stack[t] = s;
     }
-    // the last workgroup to finish closes the rebuild (epoch flip, dirty flag)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(&w.flags[FL_TICKET], 1) == (int)gridDim.x - 1) {
-            w.flags[FL_TICKET] = 0;
-            w.flags[FL_BP_EPOCH] = epoch + 1;
-            w.flags[FL_BP_REBUILDS] += 1;
-            __hip_atomic_store(&w.flags[FL_BP_DIRTY], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+}
+
+// The whole rebuild in ONE launch (see rp_gridbar.h): a clean step (no fat AABB changed) costs a single early exit.
+__global__ void __launch_bounds__(1024) k_bp_rebuild(DevWorld w) {
+    if (!w.flags[FL_BP_DIRTY]) return; // (cleared only after the last barrier: every workgroup reads the same value)
+    __shared__ int scan_lds[1024];
+    const int gid = gbar_item(), gstride = gridDim.x * blockDim.x;
+    GridBar bar = gbar_begin(w, 0);
+    const int epoch = w.flags[FL_BP_EPOCH];
+    bp_clear(w, gid, gstride);
+    gbar_sync(bar);
+    bp_count(w, gid, gstride);
+    gbar_sync(bar);
+    bp_scan_chunks(w, scan_lds);
+    gbar_sync(bar);
+    if (blockIdx.x == 0) bp_scan_sums(w, scan_lds);
+    gbar_sync(bar);
+    bp_scan_add(w, gid, gstride);
+    gbar_sync(bar);
+    bp_fill(w, gid, gstride);
+    gbar_sync(bar);
+    bp_pairs(w, gid, gstride);
+    gbar_sync(bar);
+    bp_finish_pairs(w, gid, gstride);
+    gbar_sync(bar);
+    gbar_end(bar);
+    if (gid == 0) { // the rebuild is closed: epoch flip, dirty flag
+        w.flags[FL_BP_EPOCH] = epoch + 1;
+        w.flags[FL_BP_REBUILDS] += 1;
+        __hip_atomic_store(&w.flags[FL_BP_DIRTY], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -356,17 +367,9 @@ void rp_launch_bp_rehash(const DevWorld &w, hipStream_t st) {
 
 void rp_launch_broadphase(const DevWorld &w, hipStream_t st) {
     if (w.n_colliders == 0) return;
-    int nb = (w.n_colliders + 255) / 256;
-    int clear_n = w.grid_cap > w.hash_cap ? w.grid_cap : w.hash_cap;
-    int clear_blocks = (clear_n + 255) / 256; if (clear_blocks > 2048) clear_blocks = 2048;
-    int scan_blocks = (w.grid_cap + 1023) / 1024;
-    hipLaunchKernelGGL(k_bp_clear, dim3(clear_blocks), dim3(256), 0, st, w);
-    hipLaunchKernelGGL(k_bp_count, dim3(nb), dim3(256), 0, st, w);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(scan_blocks), dim3(1024), 0, st, w);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, w, scan_blocks);
-    hipLaunchKernelGGL(k_scan_add, dim3(scan_blocks), dim3(1024), 0, st, w);
-    hipLaunchKernelGGL(k_bp_fill, dim3(nb), dim3(256), 0, st, w);
-    hipLaunchKernelGGL(k_bp_pairs, dim3(nb), dim3(256), 0, st, w);
-    int fin_blocks = (w.pool_cap + 255) / 256; if (fin_blocks > 1024) fin_blocks = 1024;
-    hipLaunchKernelGGL(k_bp_finish_pairs, dim3(fin_blocks), dim3(256), 0, st, w);
+    // every workgroup must be resident (grid barriers): at most 192 workgroups of 1024 threads (one per CU, 256 CUs)
+    int blocks = (w.n_colliders + 255) / 256; // ~4 wavefronts of colliders per workgroup: the cell walks are latency-bound, spread them
+    if (blocks < 8) blocks = 8;    // the clears and the pair-slot sweep are sized by capacities, not by the collider count
+    if (blocks > 192) blocks = 192;
+    hipLaunchKernelGGL(k_bp_rebuild, dim3(blocks), dim3(1024), 0, st, w);
 }

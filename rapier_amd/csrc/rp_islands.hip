@@ -19,6 +19,7 @@
 // persistent.rs keeps comparable connected components for sleeping; here they drive scheduling only.
 #include "rp_global.h"
 #include "rp_pairs.h"
+#include "rp_gridbar.h"
 
 RP_DEV int ld_i32(int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 RP_DEV int uf_find(int *label, int x) {
@@ -39,33 +40,28 @@ RP_DEV void uf_union(int *label, int a, int b) {
 }
 RP_DEV bool pair_active(const DevWorld &w, int s) { return pair_selected(w, s); }
 
-// Island discovery runs only when the set of active manifolds changed (FL_LAYOUT_DIRTY): five
-// grid-wide kernels, every pass one thread per body or per pair slot.
-__global__ void k_isl_init(DevWorld w) {
-    if (!w.flags[FL_LAYOUT_DIRTY]) return;
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+// Island discovery runs only when the set of active manifolds changed (FL_LAYOUT_DIRTY): passes of k_layout_rebuild below,
+// every pass one thread per body or per pair slot (gid / gstride span the whole launch).
+RP_DEV void lay_isl_init(DevWorld &w, int gid, int gstride) {
+    const int i = gid;
     if (i == 0) { w.flags[FL_N_ISLANDS] = 0; w.flags[FL_N_GLOB_BODIES] = 0; w.flags[FL_ISL_BODY_CURSOR] = 0; w.flags[FL_ISL_CONS_CURSOR] = 0; w.flags[FL_ISL_ICONS_CURSOR] = 0; }
-    for (size_t k = i, n = (size_t)128 * w.cb_words, st = (size_t)gridDim.x * blockDim.x; k < n; k += st) w.cb_bits[k] = 0u; // owner bitmaps of the colour stages
-    if (i < w.n_bodies) { w.b_label[i] = i; w.r_nb[i] = 0; w.r_nc[i] = 0; w.r_ni[i] = 0; w.r_island[i] = -1; w.b_island[i] = -1; w.b_local[i] = -1; }
+    for (size_t k = i, n = (size_t)128 * w.cb_words; k < n; k += (size_t)gstride) w.cb_bits[k] = 0u; // owner bitmaps of the colour stages
+    for (int b = gid; b < w.n_bodies; b += gstride) { w.b_label[b] = b; w.r_nb[b] = 0; w.r_nc[b] = 0; w.r_ni[b] = 0; w.r_island[b] = -1; w.b_island[b] = -1; w.b_local[b] = -1; }
 }
 // connected components over active pairs whose two sides are dynamic
-__global__ void k_isl_union(DevWorld w) {
-    if (!w.flags[FL_LAYOUT_DIRTY]) return;
+RP_DEV void lay_isl_union(DevWorld &w, int gid, int gstride) {
     int top = w.flags[FL_POOL_TOP];
     if (top > w.pool_cap) top = w.pool_cap;
-    int stride = gridDim.x * blockDim.x;
-    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < top; s += stride) {
+    for (int s = gid; s < top; s += gstride) {
         if (!pair_active(w, s)) continue;
         int b1 = w.c_parent[w.p_c1[s]], b2 = w.c_parent[w.p_c2[s]];
         if (is_dyn(w, b1) && is_dyn(w, b2)) uf_union(w.b_label, b1, b2);
     }
 }
 // flatten the labels; per-root body and manifold counts
-__global__ void k_isl_count(DevWorld w) {
-    if (!w.flags[FL_LAYOUT_DIRTY]) return;
+RP_DEV void lay_isl_count(DevWorld &w, int gid, int stride) {
     int top = w.flags[FL_POOL_TOP];
     if (top > w.pool_cap) top = w.pool_cap;
-    int stride = gridDim.x * blockDim.x, gid = blockIdx.x * blockDim.x + threadIdx.x;
     for (int b = gid; b < w.n_bodies; b += stride) {
         if (!is_dyn(w, b)) continue;
         int root = uf_find(w.b_label, b);
@@ -88,10 +84,9 @@ __global__ void k_isl_count(DevWorld w) {
     }
 }
 // number the islands that fit one workgroup (registers + LDS)
-__global__ void k_isl_number(DevWorld w) {
-    if (!w.flags[FL_LAYOUT_DIRTY]) return;
-    int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= w.n_bodies || !is_dyn(w, b) || w.b_label[b] != b) return;
+RP_DEV void lay_isl_number(DevWorld &w, int gid, int gstride) {
+  for (int b = gid; b < w.n_bodies; b += gstride) {
+    if (!is_dyn(w, b) || w.b_label[b] != b) continue;
     int cnb = w.r_nb[b], cnc = w.r_nc[b];
     if (cnc > 0 && cnb <= RP_ISL_NB_MAX && cnc <= RP_ISL_NC_MAX) {
         int id = atomicAdd(&w.flags[FL_N_ISLANDS], 1);
@@ -102,17 +97,15 @@ __global__ void k_isl_number(DevWorld w) {
         w.isl_ni[id] = cni; w.isl_fill_i[id] = 0; w.isl_icons_begin[id] = atomicAdd(&w.flags[FL_ISL_ICONS_CURSOR], cni);
         w.r_island[b] = id;
     }
+  }
 }
 // fill the island lists; count the global-path manifolds per colour
-__global__ void k_isl_fill(DevWorld w) {
-    if (!w.flags[FL_LAYOUT_DIRTY]) return;
-    __shared__ int hist[RP_NUM_COLORS], n_glob;
+RP_DEV void lay_isl_fill(DevWorld &w, int gid, int stride, int *hist, int &n_glob) {
     for (int c = threadIdx.x; c < RP_NUM_COLORS; c += blockDim.x) hist[c] = 0;
     if (threadIdx.x == 0) n_glob = 0;
     __syncthreads();
     int top = w.flags[FL_POOL_TOP];
     if (top > w.pool_cap) top = w.pool_cap;
-    int stride = gridDim.x * blockDim.x, gid = blockIdx.x * blockDim.x + threadIdx.x;
     for (int b = gid; b < w.n_bodies; b += stride) {
         if (!is_dyn(w, b)) continue;
         int id = w.r_island[w.b_label[b]];
@@ -146,6 +139,160 @@ __global__ void k_isl_fill(DevWorld w) {
     __syncthreads();
     for (int c = threadIdx.x; c < RP_NUM_COLORS; c += blockDim.x) if (hist[c]) atomicAdd(&w.color_count_glob[c], hist[c]);
     if (threadIdx.x == 0 && n_glob) atomicAdd(&w.flags[FL_N_GLOB_BODIES], n_glob);
+}
+
+
+// ---- solver contact graph buckets + stage layout (were rp_narrowphase.hip kernels) ----
+RP_DEV void lay_bucket_clear(DevWorld &w) { // workgroup 0
+    if (threadIdx.x < RP_NUM_COLORS) { w.color_count[threadIdx.x] = 0; w.color_count_glob[threadIdx.x] = 0; }
+    if (threadIdx.x == 0) w.flags[FL_N_SC] = 0;
+}
+RP_DEV void lay_bucket_count(DevWorld &w, int gid, int stride, int *hist, int &nsc_sum) {
+    for (int c = threadIdx.x; c < RP_NUM_COLORS; c += blockDim.x) hist[c] = 0;
+    if (threadIdx.x == 0) nsc_sum = 0;
+    __syncthreads();
+    int top = w.flags[FL_POOL_TOP];
+    if (top > w.pool_cap) top = w.pool_cap;
+    for (int s = gid; s < top; s += stride) {
+        w.p_conspos[s] = -1;
+        if (!pair_selected(w, s)) continue;
+        int color = w.p_color[s];
+        if (color > RP_COLOR_OVERFLOW) continue;
+        atomicAdd(&hist[color], 1);
+        atomicAdd(&nsc_sum, w.p_nsc[s]);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < RP_NUM_COLORS; c += blockDim.x) if (hist[c]) atomicAdd(&w.color_count[c], hist[c]);
+    if (threadIdx.x == 0 && nsc_sum) atomicAdd(&w.flags[FL_N_SC], nsc_sum);
+}
+RP_DEV void lay_bucket_layout(DevWorld &w, int *part) { // workgroup 0, 1024 threads
+    // all threads: per colour, the exclusive prefix popcount of the owner bitmap along its words (rank of a body among the owners)
+    {
+        const int words = w.cb_words, per = (words + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < words ? lo + per : words;
+        for (int c = 0; c < RP_COLOR_OVERFLOW; ++c) {
+            if (w.color_count_glob[c] == 0) continue; // uniform
+            const unsigned *bits = w.cb_bits + (size_t)c * words;
+            int *pre = w.cb_prefix + (size_t)c * words;
+            int sum = 0;
+            for (int i = lo; i < hi; ++i) sum += __popc(bits[i]);
+            part[threadIdx.x] = sum;
+            __syncthreads();
+            for (int off = 1; off < 1024; off <<= 1) { // Hillis-Steele inclusive scan of the 1024 partial sums
+                int v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+                __syncthreads();
+                part[threadIdx.x] += v;
+                __syncthreads();
+            }
+            int run = part[threadIdx.x] - sum;
+            for (int i = lo; i < hi; ++i) { pre[i] = run; run += __popc(bits[i]); }
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x != 0) return;
+    int nst = 0, npar = 0, pos = 0, maxs = 0, ncol = 0, mall = 0;
+    for (int pass = 0; pass < 2; ++pass)
+        for (int c = 0; c < RP_NUM_COLORS - 1; ++c) {
+            int n = w.color_count[c];
+            if (n == 0) continue;
+            bool par = n >= RP_PARALLEL_MIN_MANIFOLDS;
+            if ((pass == 0) != par) continue;
+            int ng = w.color_count_glob[c];
+            w.stage_color[nst] = c; w.stage_begin[nst] = pos; w.stage_count[nst] = ng;
+            w.color_begin[c] = pos; w.color_cursor[c] = pos; w.color_rank[c] = nst;
+            pos += ng; nst++; ncol++; mall += n;
+            if (par) npar++;
+            if (ng > maxs) maxs = ng;
+        }
+    int nov = w.color_count[RP_COLOR_OVERFLOW], novg = w.color_count_glob[RP_COLOR_OVERFLOW];
+    w.stage_color[nst] = RP_COLOR_OVERFLOW; w.stage_begin[nst] = pos; w.stage_count[nst] = novg;
+    w.color_begin[RP_COLOR_OVERFLOW] = pos; w.color_cursor[RP_COLOR_OVERFLOW] = pos; w.color_rank[RP_COLOR_OVERFLOW] = nst;
+    pos += novg; mall += nov;
+    if (nov) ncol++;
+    w.flags[FL_N_STAGES] = nst; w.flags[FL_N_PARALLEL] = npar; w.flags[FL_MAX_STAGE] = maxs;
+    w.flags[FL_HAS_OVERFLOW_COLOR] = novg > 0; w.flags[FL_N_COLORS] = ncol;
+    w.flags[FL_N_CONS] = pos; w.flags[FL_N_CONS_ALL] = mall;
+    w.flags[FL_FLOW_DIRTY] = 1; // constraint positions are about to move: the dataflow solver's toucher ranks follow (rp_flow.hip)
+    if (pos > w.cons_cap) atomicOr(&w.flags[FL_OVERFLOW], RP_OVF_CONS);
+}
+RP_DEV void lay_bucket_scatter(DevWorld &w, int gid, int stride, int *cnt, int *base) {
+    // two passes per block: count its manifolds per colour, reserve one range per colour, then place
+    for (int c = threadIdx.x; c < RP_NUM_COLORS; c += blockDim.x) cnt[c] = 0;
+    __syncthreads();
+    int top = w.flags[FL_POOL_TOP];
+    if (top > w.pool_cap) top = w.pool_cap;
+    // colour stages: position = rank of the owner body among the colour's owners (no atomics, ascending with the body index);
+    // the overflow colour (not body-disjoint) keeps its reserve-and-place scheme and is ranked by the closing workgroup below
+    for (int s = gid; s < top; s += stride) {
+        if (!pair_selected(w, s) || w.p_island[s] >= 0) continue;
+        int color = w.p_color[s];
+        if (color == RP_COLOR_OVERFLOW) atomicAdd(&cnt[color], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { base[RP_COLOR_OVERFLOW] = cnt[RP_COLOR_OVERFLOW] ? atomicAdd(&w.color_cursor[RP_COLOR_OVERFLOW], cnt[RP_COLOR_OVERFLOW]) : 0; cnt[RP_COLOR_OVERFLOW] = 0; }
+    __syncthreads();
+    for (int s = gid; s < top; s += stride) {
+        if (!pair_selected(w, s) || w.p_island[s] >= 0) continue;
+        int color = w.p_color[s];
+        if (color > RP_COLOR_OVERFLOW) continue;
+        int pos;
+        if (color == RP_COLOR_OVERFLOW) pos = base[color] + atomicAdd(&cnt[color], 1);
+        else {
+            int2 rb = w.p_rb[s];
+            int owner = body_dyn_awake(w, rb.x) ? rb.x : rb.y;
+            size_t wi = (size_t)color * w.cb_words + (owner >> 5);
+            pos = w.color_begin[color] + w.cb_prefix[wi] + __popc(w.cb_bits[wi] & ((1u << (owner & 31)) - 1u));
+        }
+        if (pos < w.cons_cap) { w.cons_pair[pos] = s; w.p_conspos[s] = pos; }
+    }
+}
+RP_DEV void lay_rank_overflow(DevWorld &w) { // workgroup 0, after a grid barrier
+    // The overflow colour is swept serially and is not body-disjoint: its order is part of the result, and the scatter above is
+    // ordered by atomics.  The closing workgroup ranks it by (collider1, collider2) — the order the oracle uses.
+    const int nst = ld_i32(&w.flags[FL_N_STAGES]);
+    const int ob = ld_i32(&w.stage_begin[nst]), on = ld_i32(&w.flags[FL_HAS_OVERFLOW_COLOR]) ? ld_i32(&w.stage_count[nst]) : 0;
+    if (on > 1 && ob + on <= w.cons_cap) {
+        for (int i = threadIdx.x; i < on; i += blockDim.x) w.todo_tmp[i] = ld_i32(&w.cons_pair[ob + i]);
+        __threadfence(); __syncthreads();
+        for (int i = threadIdx.x; i < on; i += blockDim.x) {
+            int si = ld_i32(&w.todo_tmp[i]);
+            unsigned long long ki = ((unsigned long long)(unsigned)w.p_c1[si] << 32) | (unsigned)w.p_c2[si];
+            int rank = 0;
+            for (int j = 0; j < on; ++j) { int sj = ld_i32(&w.todo_tmp[j]); unsigned long long kj = ((unsigned long long)(unsigned)w.p_c1[sj] << 32) | (unsigned)w.p_c2[sj]; rank += kj < ki; }
+            w.cons_pair[ob + rank] = si; w.p_conspos[si] = ob + rank;
+        }
+        __threadfence(); __syncthreads();
+    }
+}
+
+// The whole layout rebuild in ONE launch (rp_gridbar.h): colour buckets (maintain_solver_contact_graph, solver_graph.rs:129-361),
+// contact islands, the stage order of init.rs:163-254 and the constraint positions.  A step whose active-manifold set did not
+// change pays a single early exit instead of nine.
+__global__ void __launch_bounds__(1024) k_layout_rebuild(DevWorld w) {
+    if (!w.flags[FL_LAYOUT_DIRTY]) return; // (cleared only after the last barrier: every workgroup reads the same value)
+    __shared__ int lds_a[1024], lds_b[RP_NUM_COLORS], lds_scalar;
+    const int gid = gbar_item(), gstride = gridDim.x * blockDim.x;
+    GridBar bar = gbar_begin(w, 1);
+    if (blockIdx.x == 0) lay_bucket_clear(w);
+    lay_isl_init(w, gid, gstride);
+    gbar_sync(bar);
+    lay_bucket_count(w, gid, gstride, lds_a, lds_scalar);
+    lay_isl_union(w, gid, gstride);
+    gbar_sync(bar);
+    lay_isl_count(w, gid, gstride);
+    gbar_sync(bar);
+    lay_isl_number(w, gid, gstride);
+    gbar_sync(bar);
+    __syncthreads();
+    lay_isl_fill(w, gid, gstride, lds_a, lds_scalar);
+    gbar_sync(bar);
+    if (blockIdx.x == 0) lay_bucket_layout(w, lds_a);
+    gbar_sync(bar);
+    lay_bucket_scatter(w, gid, gstride, lds_a, lds_b);
+    gbar_sync(bar);
+    if (blockIdx.x == 0) lay_rank_overflow(w);
+    gbar_sync(bar);
+    gbar_end(bar);
+    if (gid == 0) __hip_atomic_store(&w.flags[FL_LAYOUT_DIRTY], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- register-resident constraint of one island thread ------------------------------------------
@@ -839,14 +986,10 @@ __global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int ha
 }
 
 void rp_launch_islands_build(const DevWorld &w, hipStream_t st) {
-    int nbb = (w.n_bodies + 255) / 256; if (nbb < 1) nbb = 1;
+    // every workgroup must be resident (grid barriers): at most 192 workgroups of 1024 threads (one per CU, 256 CUs)
     int n = w.n_bodies > w.pool_cap ? w.n_bodies : w.pool_cap;
-    int blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_isl_init, dim3(nbb), dim3(256), 0, st, w);
-    hipLaunchKernelGGL(k_isl_union, dim3(blocks), dim3(256), 0, st, w);
-    hipLaunchKernelGGL(k_isl_count, dim3(blocks), dim3(256), 0, st, w);
-    hipLaunchKernelGGL(k_isl_number, dim3(nbb), dim3(256), 0, st, w);
-    hipLaunchKernelGGL(k_isl_fill, dim3(blocks), dim3(256), 0, st, w);
+    int blocks = (n + 255) / 256; if (blocks > 192) blocks = 192; if (blocks < 1) blocks = 1; // ~4 wavefronts of items per workgroup
+    hipLaunchKernelGGL(k_layout_rebuild, dim3(blocks), dim3(1024), 0, st, w);
 }
 // Most workgroups a fused fast step may launch: its arrival barrier needs every workgroup resident at once, so the cap comes from
 // the device (CU count x the occupancy of k_island_solve) with 1/16 of the CUs left free for whatever else the GPU is running

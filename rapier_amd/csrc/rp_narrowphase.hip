@@ -922,147 +922,6 @@ void rp_launch_joint_coloring(const DevWorld &w, hipStream_t st);
 void rp_launch_wake(const DevWorld &w, hipStream_t st, int phase);
 void rp_launch_sleep(const DevWorld &w, hipStream_t st);
 
-__global__ void k_bucket_clear(DevWorld w) {
-    if (!w.flags[FL_LAYOUT_DIRTY]) return;
-    if (threadIdx.x < RP_NUM_COLORS) { w.color_count[threadIdx.x] = 0; w.color_count_glob[threadIdx.x] = 0; }
-    if (threadIdx.x == 0) w.flags[FL_N_SC] = 0;
-}
-__global__ void k_bucket_count(DevWorld w) {
-    if (!w.flags[FL_LAYOUT_DIRTY]) return;
-    __shared__ int hist[RP_NUM_COLORS], nsc_sum;
-    for (int c = threadIdx.x; c < RP_NUM_COLORS; c += blockDim.x) hist[c] = 0;
-    if (threadIdx.x == 0) nsc_sum = 0;
-    __syncthreads();
-    int top = w.flags[FL_POOL_TOP];
-    if (top > w.pool_cap) top = w.pool_cap;
-    int stride = gridDim.x * blockDim.x;
-    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < top; s += stride) {
-        w.p_conspos[s] = -1;
-        if (!pair_selected(w, s)) continue;
-        int color = w.p_color[s];
-        if (color > RP_COLOR_OVERFLOW) continue;
-        atomicAdd(&hist[color], 1);
-        atomicAdd(&nsc_sum, w.p_nsc[s]);
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < RP_NUM_COLORS; c += blockDim.x) if (hist[c]) atomicAdd(&w.color_count[c], hist[c]);
-    if (threadIdx.x == 0 && nsc_sum) atomicAdd(&w.flags[FL_N_SC], nsc_sum);
-}
-__global__ void __launch_bounds__(1024) k_bucket_layout(DevWorld w) {
-    if (!w.flags[FL_LAYOUT_DIRTY]) return;
-    // all threads: per colour, the exclusive prefix popcount of the owner bitmap along its words (rank of a body among the owners)
-    {
-        __shared__ int part[1024];
-        const int words = w.cb_words, per = (words + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < words ? lo + per : words;
-        for (int c = 0; c < RP_COLOR_OVERFLOW; ++c) {
-            if (w.color_count_glob[c] == 0) continue; // uniform
-            const unsigned *bits = w.cb_bits + (size_t)c * words;
-            int *pre = w.cb_prefix + (size_t)c * words;
-            int sum = 0;
-            for (int i = lo; i < hi; ++i) sum += __popc(bits[i]);
-            part[threadIdx.x] = sum;
-            __syncthreads();
-            for (int off = 1; off < 1024; off <<= 1) { // Hillis-Steele inclusive scan of the 1024 partial sums
-                int v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
-                __syncthreads();
-                part[threadIdx.x] += v;
-                __syncthreads();
-            }
-            int run = part[threadIdx.x] - sum;
-            for (int i = lo; i < hi; ++i) { pre[i] = run; run += __popc(bits[i]); }
-            __syncthreads();
-        }
-    }
-    if (threadIdx.x != 0) return;
-    int nst = 0, npar = 0, pos = 0, maxs = 0, ncol = 0, mall = 0;
-    for (int pass = 0; pass < 2; ++pass)
-        for (int c = 0; c < RP_NUM_COLORS - 1; ++c) {
-            int n = w.color_count[c];
-            if (n == 0) continue;
-            bool par = n >= RP_PARALLEL_MIN_MANIFOLDS;
-            if ((pass == 0) != par) continue;
-            int ng = w.color_count_glob[c];
-            w.stage_color[nst] = c; w.stage_begin[nst] = pos; w.stage_count[nst] = ng;
-            w.color_begin[c] = pos; w.color_cursor[c] = pos; w.color_rank[c] = nst;
-            pos += ng; nst++; ncol++; mall += n;
-            if (par) npar++;
-            if (ng > maxs) maxs = ng;
-        }
-    int nov = w.color_count[RP_COLOR_OVERFLOW], novg = w.color_count_glob[RP_COLOR_OVERFLOW];
-    w.stage_color[nst] = RP_COLOR_OVERFLOW; w.stage_begin[nst] = pos; w.stage_count[nst] = novg;
-    w.color_begin[RP_COLOR_OVERFLOW] = pos; w.color_cursor[RP_COLOR_OVERFLOW] = pos; w.color_rank[RP_COLOR_OVERFLOW] = nst;
-    pos += novg; mall += nov;
-    if (nov) ncol++;
-    w.flags[FL_N_STAGES] = nst; w.flags[FL_N_PARALLEL] = npar; w.flags[FL_MAX_STAGE] = maxs;
-    w.flags[FL_HAS_OVERFLOW_COLOR] = novg > 0; w.flags[FL_N_COLORS] = ncol;
-    w.flags[FL_N_CONS] = pos; w.flags[FL_N_CONS_ALL] = mall;
-    w.flags[FL_FLOW_DIRTY] = 1; // constraint positions are about to move: the dataflow solver's toucher ranks follow (rp_flow.hip)
-    if (pos > w.cons_cap) atomicOr(&w.flags[FL_OVERFLOW], RP_OVF_CONS);
-}
-RP_DEV int ld_i32(int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__global__ void k_bucket_scatter(DevWorld w) {
-    if (!w.flags[FL_LAYOUT_DIRTY]) return;
-    // two passes per block: count its manifolds per colour, reserve one range per colour, then place
-    __shared__ int cnt[RP_NUM_COLORS], base[RP_NUM_COLORS];
-    for (int c = threadIdx.x; c < RP_NUM_COLORS; c += blockDim.x) cnt[c] = 0;
-    __syncthreads();
-    int top = w.flags[FL_POOL_TOP];
-    if (top > w.pool_cap) top = w.pool_cap;
-    int stride = gridDim.x * blockDim.x;
-    // colour stages: position = rank of the owner body among the colour's owners (no atomics, ascending with the body index);
-    // the overflow colour (not body-disjoint) keeps its reserve-and-place scheme and is ranked by the closing workgroup below
-    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < top; s += stride) {
-        if (!pair_selected(w, s) || w.p_island[s] >= 0) continue;
-        int color = w.p_color[s];
-        if (color == RP_COLOR_OVERFLOW) atomicAdd(&cnt[color], 1);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) { base[RP_COLOR_OVERFLOW] = cnt[RP_COLOR_OVERFLOW] ? atomicAdd(&w.color_cursor[RP_COLOR_OVERFLOW], cnt[RP_COLOR_OVERFLOW]) : 0; cnt[RP_COLOR_OVERFLOW] = 0; }
-    __syncthreads();
-    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < top; s += stride) {
-        if (!pair_selected(w, s) || w.p_island[s] >= 0) continue;
-        int color = w.p_color[s];
-        if (color > RP_COLOR_OVERFLOW) continue;
-        int pos;
-        if (color == RP_COLOR_OVERFLOW) pos = base[color] + atomicAdd(&cnt[color], 1);
-        else {
-            int2 rb = w.p_rb[s];
-            int owner = body_dyn_awake(w, rb.x) ? rb.x : rb.y;
-            size_t wi = (size_t)color * w.cb_words + (owner >> 5);
-            pos = w.color_begin[color] + w.cb_prefix[wi] + __popc(w.cb_bits[wi] & ((1u << (owner & 31)) - 1u));
-        }
-        if (pos < w.cons_cap) { w.cons_pair[pos] = s; w.p_conspos[s] = pos; }
-    }
-    // the last workgroup to finish closes the layout rebuild (k_bucket_finish)
-    __shared__ int last;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        last = atomicAdd(&w.flags[FL_TICKET], 1) == (int)gridDim.x - 1;
-    }
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
-    // The overflow colour is swept serially and is not body-disjoint: its order is part of the result, and the scatter above is
-    // ordered by atomics.  The closing workgroup ranks it by (collider1, collider2) — the order the oracle uses.
-    const int nst = ld_i32(&w.flags[FL_N_STAGES]);
-    const int ob = ld_i32(&w.stage_begin[nst]), on = ld_i32(&w.flags[FL_HAS_OVERFLOW_COLOR]) ? ld_i32(&w.stage_count[nst]) : 0;
-    if (on > 1 && ob + on <= w.cons_cap) {
-        for (int i = threadIdx.x; i < on; i += blockDim.x) w.todo_tmp[i] = ld_i32(&w.cons_pair[ob + i]);
-        __threadfence(); __syncthreads();
-        for (int i = threadIdx.x; i < on; i += blockDim.x) {
-            int si = ld_i32(&w.todo_tmp[i]);
-            unsigned long long ki = ((unsigned long long)(unsigned)w.p_c1[si] << 32) | (unsigned)w.p_c2[si];
-            int rank = 0;
-            for (int j = 0; j < on; ++j) { int sj = ld_i32(&w.todo_tmp[j]); unsigned long long kj = ((unsigned long long)(unsigned)w.p_c1[sj] << 32) | (unsigned)w.p_c2[sj]; rank += kj < ki; }
-            w.cons_pair[ob + rank] = si; w.p_conspos[si] = ob + rank;
-        }
-        __threadfence(); __syncthreads();
-    }
-    if (threadIdx.x == 0) { w.flags[FL_TICKET] = 0; __hip_atomic_store(&w.flags[FL_LAYOUT_DIRTY], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-}
-__global__ void k_bucket_finish(DevWorld w) { w.flags[FL_LAYOUT_DIRTY] = 0; }
-
 // `part`: 0 = contact determination (NarrowPhase::compute_contacts: test, update, deferred colouring, begin-touch wake-ups),
 // 1 = island construction in the reference's stage accounting (sleep decision, joint colouring, solver contact graph
 // buckets, contact islands), -1 = both (the step graphs).
@@ -1082,11 +941,7 @@ void rp_launch_narrowphase_part(const DevWorld &w, hipStream_t st, int part) {
         rp_launch_sleep(w, st);   // sleep timers + the whole-island sleep decision (solve.rs:196-300, manager.rs:335-388); collider-less bodies too
         if (w.n_colliders == 0) return;
         rp_launch_joint_coloring(w, st); // joints avoid this step's contact colours (init_joints, joints.rs:25-329)
-        hipLaunchKernelGGL(k_bucket_clear, dim3(1), dim3(256), 0, st, w);
-        hipLaunchKernelGGL(k_bucket_count, dim3(blocks), dim3(256), 0, st, w);
-        rp_launch_islands_build(w, st);
-        hipLaunchKernelGGL(k_bucket_layout, dim3(1), dim3(1024), 0, st, w);
-        hipLaunchKernelGGL(k_bucket_scatter, dim3(blocks), dim3(256), 0, st, w);
+        rp_launch_islands_build(w, st); // colour buckets, contact islands, stage layout, constraint positions: one launch (rp_islands.hip)
     }
 }
 void rp_launch_narrowphase(const DevWorld &w, hipStream_t st) { rp_launch_narrowphase_part(w, st, -1); }

@@ -16,9 +16,10 @@
 // Per step (sleep-enabled worlds only; every kernel is one thread per body or per pair slot):
 //   after the broad phase : k_wake_spread(0) + k_wake_commit(0)   user wake-ups, pair deletions
 //   after the narrow phase: k_wake_spread(1) + k_wake_commit(1)   begin-touch wake-ups
-//   then                  : k_slp_init/union/flatten (labels, only when dirty), k_sleep_observe, k_sleep_commit
+//   then                  : k_sleep_pass = labels (init / union / flatten, only when dirty) + observe, then k_sleep_commit
 // and the bucket / island rebuild that follows sees the new awake set.
 #include "rp_pairs.h"
+#include "rp_gridbar.h"
 
 RP_DEV int slp_ld(int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 RP_DEV int slp_find(int *label, int x) {
@@ -82,43 +83,34 @@ __global__ void k_wake_partners(DevWorld w) {
 }
 
 // ---- sleep-island labels (only when the touching set or the awake set changed) --------------------
-__global__ void k_slp_init(DevWorld w) {
-    if (!w.flags[FL_LAYOUT_DIRTY]) return;
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < w.n_bodies && flags_active(w.b_flags[i])) w.b_slabel[i] = i;
+RP_DEV void slp_init(DevWorld &w, int gid, int gstride) {
+    for (int i = gid; i < w.n_bodies; i += gstride) if (flags_active(w.b_flags[i])) w.b_slabel[i] = i;
 }
-__global__ void k_slp_union(DevWorld w) {
-    if (!w.flags[FL_LAYOUT_DIRTY]) return;
+RP_DEV void slp_union_pairs(DevWorld &w, int gid, int gstride) {
     int top = w.flags[FL_POOL_TOP];
     if (top > w.pool_cap) top = w.pool_cap;
-    int stride = gridDim.x * blockDim.x;
-    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < top; s += stride) {
+    for (int s = gid; s < top; s += gstride) {
         if (w.p_c1[s] < 0 || w.p_nsc[s] == 0) continue; // touching pairs link (contacts.rs:352-359), whatever their solver hint
         int2 rb = w.p_rb[s];
         if (body_active(w, rb.x) && body_active(w, rb.y)) slp_union(w.b_slabel, rb.x, rb.y);
     }
-}
-// impulse joints link the islands of their two bodies (ImpulseJointIslandEvent::Link, persistent.rs:13-24)
-__global__ void k_slp_union_joints(DevWorld w) {
-    if (!w.flags[FL_LAYOUT_DIRTY]) return;
-    int stride = gridDim.x * blockDim.x;
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < w.n_joints; j += stride) {
+    // impulse joints link the islands of their two bodies (ImpulseJointIslandEvent::Link, persistent.rs:13-24)
+    for (int j = gid; j < w.n_joints; j += gstride) {
         int b1 = w.j_b1[j], b2 = w.j_b2[j];
         if (body_active(w, b1) && body_active(w, b2)) slp_union(w.b_slabel, b1, b2);
     }
 }
-__global__ void k_slp_flatten(DevWorld w) {
-    if (!w.flags[FL_LAYOUT_DIRTY]) return;
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= w.n_bodies || !flags_active(w.b_flags[i])) return;
-    int root = slp_find(w.b_slabel, i);
-    __hip_atomic_store(&w.b_slabel[i], root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+RP_DEV void slp_flatten(DevWorld &w, int gid, int gstride) {
+    for (int i = gid; i < w.n_bodies; i += gstride) {
+        if (!flags_active(w.b_flags[i])) continue;
+        int root = slp_find(w.b_slabel, i);
+        __hip_atomic_store(&w.b_slabel[i], root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // update_body_energy for every awake body + the island observation (an island sleeps once EVERY member is eligible).
-__global__ void k_sleep_observe(DevWorld w) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= w.n_bodies || !flags_active(w.b_flags[i])) return;
+RP_DEV void sleep_observe_one(DevWorld &w, int i) {
+    if (!flags_active(w.b_flags[i])) return;
     float4 sl = w.b_sleep[i];
     if ((w.b_flags[i] & RP_BF_TYPE_MASK) != RP_BODY_DYNAMIC) { // platforms only sleep when both velocities are exactly zero (:1464-1468)
         V3 lv = v3(w.b_linvel[i]), kav = v3(w.b_angvel[i]);
@@ -148,22 +140,43 @@ __global__ void k_sleep_observe(DevWorld w) {
     if (!(sl.x >= sl.w)) w.lab_awake[w.b_slabel[i]] = cur_step(w);
 }
 // commit_sleeping_chunks -> RigidBody::sleep (rigid_body.rs:804-807) + clear_asleep_pair_solver_hint_counts_of
-__global__ void k_sleep_commit(DevWorld w) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int fl = i < w.n_bodies ? w.b_flags[i] : RP_BODY_FIXED;
-    bool active = flags_active(fl);
-    bool stays_awake = active && w.lab_awake[w.b_slabel[i]] == cur_step(w);
-    // awake bodies left after this pass, one atomic per wavefront (0 = the whole world sleeps: the host may enqueue idle steps)
-    unsigned long long awake_mask = __ballot(stays_awake);
-    if ((threadIdx.x & 63) == 0 && awake_mask) atomicAdd(&w.flags[FL_N_AWAKE], __popcll(awake_mask));
-    if (!active || stays_awake) return;
-    w.b_flags[i] = fl | RP_BF_SLEEPING;
-    float4 sl = w.b_sleep[i]; sl.x = sl.w; w.b_sleep[i] = sl;
-    w.b_linvel[i] = make_float4(0, 0, 0, 0); w.b_angvel[i] = make_float4(0, 0, 0, 0);
-    w.b_slept_at[i] = cur_step(w);
-    w.flags[FL_LAYOUT_DIRTY] = 1;
-    if (w.n_joints) w.flags[FL_JOINT_DIRTY] = 1;
+RP_DEV void sleep_commit(DevWorld &w, int gid, int gstride) {
+    for (int base = 0; base < w.n_bodies; base += gstride) { // wave-uniform trip count: the ballot below needs whole wavefronts
+        const int i = base + gid;
+        int fl = i < w.n_bodies ? w.b_flags[i] : RP_BODY_FIXED;
+        bool active = flags_active(fl);
+        bool stays_awake = active && w.lab_awake[w.b_slabel[i]] == cur_step(w);
+        // awake bodies left after this pass, one atomic per wavefront (0 = the whole world sleeps: the host may enqueue idle steps)
+        unsigned long long awake_mask = __ballot(stays_awake);
+        if ((threadIdx.x & 63) == 0 && awake_mask) atomicAdd(&w.flags[FL_N_AWAKE], __popcll(awake_mask));
+        if (!active || stays_awake) continue;
+        w.b_flags[i] = fl | RP_BF_SLEEPING;
+        float4 sl = w.b_sleep[i]; sl.x = sl.w; w.b_sleep[i] = sl;
+        w.b_linvel[i] = make_float4(0, 0, 0, 0); w.b_angvel[i] = make_float4(0, 0, 0, 0);
+        w.b_slept_at[i] = cur_step(w);
+        w.flags[FL_LAYOUT_DIRTY] = 1;
+        if (w.n_joints) w.flags[FL_JOINT_DIRTY] = 1;
+    }
 }
+// The sleep pass of a step in TWO launches: (1) the island labels when the touching set or the awake set changed (three passes
+// behind grid barriers, rp_gridbar.h — skipped on a clean step) and the per-body observation; (2) the commit, which may only
+// run once EVERY member of an island was observed: that dependency is a kernel boundary, cheaper on MI355X than a fenced grid
+// barrier that would have to run every step (~4 us against ~7 us).
+__global__ void __launch_bounds__(1024) k_sleep_pass(DevWorld w) {
+    const int gid = gbar_item(), gstride = gridDim.x * blockDim.x;
+    if (w.flags[FL_LAYOUT_DIRTY]) { // (nothing in this launch writes the flag)
+        GridBar bar = gbar_begin(w, 2);
+        slp_init(w, gid, gstride);
+        gbar_sync(bar);
+        slp_union_pairs(w, gid, gstride);
+        gbar_sync(bar);
+        slp_flatten(w, gid, gstride);
+        gbar_sync(bar);
+        gbar_end(bar);
+    }
+    for (int i = gid; i < w.n_bodies; i += gstride) sleep_observe_one(w, i);
+}
+__global__ void k_sleep_commit(DevWorld w) { sleep_commit(w, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x); }
 
 // interpolate_kinematic_velocities (substep.rs:242-264): a position-based kinematic body gets the velocity that
 // reaches its next_position in one step (RigidBodyPosition::interpolate_velocity, rigid_body_components.rs:147-194).
@@ -218,10 +231,8 @@ void rp_launch_sleep(const DevWorld &w, hipStream_t st) {
     if (!w.sleep_enabled || w.n_bodies == 0) return;
     int nb = slp_body_blocks(w);
     if (w.has_kinematic_pos) hipLaunchKernelGGL(k_kinematic_velocities, dim3(nb), dim3(256), 0, st, w); // after the narrow phase, before the sleep timers
-    hipLaunchKernelGGL(k_slp_init, dim3(nb), dim3(256), 0, st, w);
-    if (w.n_colliders > 0) hipLaunchKernelGGL(k_slp_union, dim3(slp_pair_blocks(w)), dim3(256), 0, st, w);
-    if (w.n_joints > 0) { int jb = (w.n_joints + 255) / 256; if (jb > 2048) jb = 2048; hipLaunchKernelGGL(k_slp_union_joints, dim3(jb), dim3(256), 0, st, w); }
-    hipLaunchKernelGGL(k_slp_flatten, dim3(nb), dim3(256), 0, st, w);
-    hipLaunchKernelGGL(k_sleep_observe, dim3(nb), dim3(256), 0, st, w);
+    // every workgroup must be resident (grid barriers): at most 192 workgroups of 1024 threads
+    int blocks = (w.n_bodies + 255) / 256; if (blocks > 192) blocks = 192; if (blocks < 1) blocks = 1; // sized by the bodies (the every-step observation); the pair pass of a relabel is grid-stride
+    hipLaunchKernelGGL(k_sleep_pass, dim3(blocks), dim3(1024), 0, st, w);
     hipLaunchKernelGGL(k_sleep_commit, dim3(nb), dim3(256), 0, st, w);
 }

@@ -43,7 +43,7 @@
 #define RP_OVF_CELLS 0x4
 #define RP_OVF_LARGE 0x8
 #define RP_OVF_CONS 0x10
-#define RP_OVF_GRID 0x20   // (retired: a fused-step barrier time-out is now the recoverable FL_GRID_TIMEOUT)
+#define RP_OVF_GRID 0x20   // a workgroup of a fused rebuild kernel was not resident (rp_gridbar.h: its grid barrier timed out)
 #define RP_OVF_FLOW 0x40   // the dataflow solver (rp_flow.hip) gave up waiting for a body record (its grid was not fully resident)
 
 // device scalar slots (int32) in DevWorld::flags
@@ -171,6 +171,7 @@ struct DevWorld {
     int has_sensors;       // some collider is a sensor: its pairs are intersection-tested every step (full step path)
     SimParams prm;
     int *flags;        // FL_* scalars
+    unsigned *bar;     // [8] grid-barrier words of the fused rebuild kernels (rp_gridbar.h): {arrivals, base} per kernel
     long long *dbg;    // [64] cycle stamps of island 0 (only written when built with -DRP_ISL_PROFILE)
     int *host_flags;   // host-mapped (pinned) copy of the scalars, published by the last kernel of a step
 

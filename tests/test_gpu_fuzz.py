@@ -209,6 +209,7 @@ class OracleTwin:
     def remove_impulse_joint(self, j): self.o.remove_joint(j)
     def set_joint_motor(self, j, axis, **kw): self.o.set_joint_motor(j, axis, **kw)
     def set_next_kinematic_position(self, h, p): self.o.set_next_kinematic_position(int(h[0]), p)
+    def set_additional_solver_iterations(self, h, n): self.o.set_additional_solver_iterations(int(h[0]), int(n))
 
     def write_bodies(self, h, pos7=None, vel6=None):
         if pos7 is not None: self.o.set_pose(int(h[0]), pos7[0])
@@ -230,13 +231,38 @@ def test_fuzz_driver_on_the_oracle_twin(seed):
 
 @pytest.mark.parametrize("seed", [10, 11, 12, 2002, 2009])
 def test_fuzz_solve_groups_on_the_oracle_twin(seed):
-    """CPU, oracle only (the device ABI has no additional_solver_iterations yet): random extra substep counts on a third of the
-    bodies — several solve groups with their own cadence — must not depend on the thread count either"""
+    """CPU: random extra substep counts on a third of the bodies — several solve groups with their own cadence — must not depend on
+    the oracle's thread count either"""
     _run(seed, steps=120, params=seed >= 2000, world=OracleTwin, extras=True)
 
 
-def _run(seed, steps=240, walls=False, params=False, world=None, extras=False, **kw):
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [10, 11, 12, 13, 2002, 2009])
+def test_fuzz_solve_groups_bit_exact(seed):
+    """the same scenes and actions with random additional_solver_iterations on a third of the bodies: up to five solve groups with
+    their own substep counts (rp_groups.h), bodies / joints / colliders coming and going under them"""
+    _run(seed, steps=160, params=seed >= 2000, extras=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [20, 21, 22, 23, 2005])
+def test_fuzz_sensors_bit_exact(seed):
+    """the same scenes and actions with sensor colliders: a trigger volume in the middle of the pile, sensor obstacles, sensor
+    parts of compound bodies (intersection graph, Started / Stopped | SENSOR events, removal of intersecting colliders)"""
+    _run(seed, steps=200, params=seed >= 2000, sensors=True)
+
+
+def _run(seed, steps=240, walls=False, params=False, world=None, extras=False, sensors=False, **kw):
     sc, rng = _scene(seed, **kw)
+    if sensors:
+        trig = sc.add_body(body_type=S.BODY_FIXED, translation=(0.0, 1.2, 0.0))
+        sc.add_collider(trig, half_extents=(2.5, 0.8, 2.5), sensor=1, active_events=S.ACTIVE_EVENTS_COLLISION)
+        for c in range(len(sc.colliders) - 1):
+            parent = sc.collider_parents[c]
+            first = c == 0 or sc.collider_parents[c - 1] != parent
+            if c in (1, 2) or (not first and rng.random() < 0.5):   # two of the fixed obstacles, half of the extra colliders of compound bodies
+                sc.colliders[c]["sensor"] = 1
+                sc.colliders[c]["active_events"] = S.ACTIVE_EVENTS_COLLISION
     if params:
         _random_params(sc, rng)
     if walls:
@@ -253,7 +279,7 @@ def _run(seed, steps=240, walls=False, params=False, world=None, extras=False, *
         for b in dyn:
             if rng.random() < 0.33:
                 n_extra = int(rng.choice([1, 2, 4, 7]))
-                g.o.set_additional_solver_iterations(b, n_extra); o.set_additional_solver_iterations(b, n_extra)
+                g.set_additional_solver_iterations([b], n_extra); o.set_additional_solver_iterations(b, n_extra)
     for step in range(1, steps + 1):
         if step % 3 == 0:                                         # the position-based platform follows a script
             t = step / 60.0
