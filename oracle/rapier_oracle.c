@@ -5,6 +5,12 @@
  * (reference v0.35.2).  Every function cites the reference lines it follows; paths are
  * relative to /root/reference/src.  See rapier_oracle.h for the parity-pinning statement.
  *
+ * PARITY UNPINNED: the reference is Rust with un-vendored crates (parry3d, nalgebra, glam) and cannot be built in this image, so
+ * there is no oracle/_ref; the one bitwise golden of the reference reachable without cargo (the FNV-1a state hash of
+ * crates/rapier3d/tests/simd_backend_determinism.rs:144) does NOT match this restatement (tests/test_reference_golden.py, strict
+ * xfail).  What pins the oracle are the reference's outcome-level tests restated in tests/test_oracle_kat.py
+ * and tests/test_reference_kats.py.
+ *
  * Ordering rules that are part of the numerical contract and are
  * reproduced here exactly:
  *   1. pair colour = greedy first-fit over per-body u128 masks on begin-touch pairs sorted by
