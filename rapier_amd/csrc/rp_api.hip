@@ -101,7 +101,8 @@ struct rp_world {
     hipGraphExec_t ge_whole[2] = {nullptr, nullptr}, ge_col[2] = {nullptr, nullptr}, ge_loop[2] = {nullptr, nullptr}, ge_fin[2] = {nullptr, nullptr};
     int graph_stages = -1, graph_blocks = -1, graph_single = -1, graph_island_grid = -1, graph_joint_stages = -1, graph_no_global = -1, graph_fused = -1;
     bool use_graph = true, use_fast = true, use_fused = true;
-    bool use_flow = true;          // MULTI mode of the global path = the dataflow launch (rp_flow.hip); RP_NO_FLOW=1: one launch per colour stage
+    bool use_flow = true;          // the dataflow launch (rp_flow.hip) is available; RP_NO_FLOW=1: never, RP_FLOW=1: for every large world
+    bool force_flow = false;
     int flow_grid = 0;             // workgroups of the dataflow launch (all resident at once), 0 = unavailable
     int fused_grid = 0;            // most workgroups a fused fast step may use (all resident at once), 0 = no fused step on this device
     bool compound = false;         // some dynamic body carries several colliders or an offset collider (no fused fast step)
@@ -322,6 +323,8 @@ extern "C" int32_t rp_world_create(const rp_integration_params *params, const fl
     if (g && g[0] == '1') w->use_fused = false;
     g = getenv("RP_NO_FLOW");
     if (g && g[0] == '1') w->use_flow = false;
+    g = getenv("RP_FLOW");
+    if (g && g[0] == '1') w->force_flow = true;
     if (w->use_flow) { w->flow_grid = rp_flow_grid(device); if (w->flow_grid <= 0) w->use_flow = false; }
     if (w->use_fused) { w->fused_grid = rp_fused_grid(device); if (w->fused_grid <= 0) w->use_fused = false; }
     memset(&w->dw, 0, sizeof(w->dw));
@@ -1126,7 +1129,8 @@ static int finalize(rp_world *w) {
     DA(d.k_b1, d.cons_cap); DA(d.k_b2, d.cons_cap); DA(d.k_n, d.cons_cap); DA(d.k_cid, d.cons_cap);
     // dataflow solver: toucher lists, rebuilt on the device whenever the layout changes (no carry-over needed)
     DA(d.f_rec, 2 * (size_t)capb); DA(d.fk_rank, d.cons_cap); DA(d.fj_rank, std::max(nj, 1)); DA(d.fb_deg, capb); DA(d.fb_begin, capb); DA(d.fb_fill, capb);
-    DA(d.f_adj, 2 * (size_t)d.cons_cap); DA(d.f_jadj, 2 * (size_t)std::max(nj, 1));
+    DA(d.f_adj, 2 * (size_t)d.cons_cap); DA(d.f_jadj, 2 * (size_t)std::max(nj, 1)); DA(d.f_sorted, 2 * (size_t)d.cons_cap);
+    if (w->params.friction_model != RP_FRICTION_COULOMB) DA(d.ws_terms, (size_t)11 * 2 * d.cons_cap);
 
     // host SoA staging (one batched copy per attribute)
     {
@@ -1190,11 +1194,18 @@ static void enqueue_island_solver(rp_world *w) {
     rp_launch_island_solve(w->dw, w->stream, fused ? std::min(w->plan_island_grid, w->fused_grid) : w->plan_island_grid,
                            w->has_restitution ? 1 : 0, w->cur_fast, w->plan_single, fused);
 }
+// MULTI mode of the global path, measured on MI355X: contact-only worlds under the twist model are fastest
+// with one launch per colour stage + the body-centric warm start (b3d_large_pyramid 0.81 ms against 0.94 ms); worlds with impulse
+// joints (b3d_joint_grid 0.37 against 0.45 ms) and the Coulomb model (no body-centric warm start) with the dataflow launch.
+static bool flow_now(const rp_world *w) {
+    if (!w->use_flow) return false;
+    return w->force_flow || w->dw.n_joints > 0 || w->params.friction_model == RP_FRICTION_COULOMB;
+}
 static void enqueue_global_solver(rp_world *w) {
     int hr = w->has_restitution ? 1 : 0;
     if (w->cur_fast && w->plan_no_global) return; // k_fast_front verified on the device that the global path is empty
     if (w->plan_single) rp_launch_global_single(w->dw, w->stream, hr, w->cur_fast);
-    else if (w->use_flow) rp_launch_global_flow(w->dw, w->stream, w->flow_grid, hr); // one dataflow launch (rp_flow.hip)
+    else if (flow_now(w)) rp_launch_global_flow(w->dw, w->stream, w->flow_grid, hr); // one dataflow launch (rp_flow.hip)
     else {
         rp_launch_solver_assembly(w->dw, w->stream);
         rp_launch_solver_loop(w->dw, w->stream, w->plan_stages, w->plan_blocks, hr, w->plan_joint_stages);
@@ -1216,10 +1227,10 @@ static void plan_from_hints(rp_world *w, const int *fl) {
     if (w->dw.n_groups > 1) w->plan_single = 1; // substep solve-groups: the one-workgroup group solver (rp_groups.h)
     w->plan_stages = fl[FL_N_PARALLEL];
     w->plan_joint_stages = fl[FL_NJ_STAGES];
-    if (w->use_flow) { w->plan_stages = 0; w->plan_joint_stages = 0; } // the dataflow launch does not depend on the stage layout
+    if (flow_now(w)) { w->plan_stages = 0; w->plan_joint_stages = 0; } // the dataflow launch does not depend on the stage layout
     w->plan_no_global = (fl[FL_N_CONS] == 0 && fl[FL_N_GLOB_BODIES] == 0 && w->dw.n_joints == 0) ? 1 : 0;
     // round up to a power of two so small changes of the stage size do not force a re-capture
-    w->plan_blocks = w->use_flow ? 1 : std::min(std::max(pow2_ceil((fl[FL_MAX_STAGE] + 255) / 256), 1), 4096);
+    w->plan_blocks = flow_now(w) ? 1 : std::min(std::max(pow2_ceil((fl[FL_MAX_STAGE] + 255) / 256), 1), 4096);
     w->plan_island_grid = std::min(std::max(pow2_ceil(fl[FL_N_ISLANDS]), 1), 8192);
     // fused single-kernel fast step: every workgroup must be resident at once (in-launch arrival barrier)
     // (a grid of at most fused_grid workgroups; workgroups loop over islands beyond that)

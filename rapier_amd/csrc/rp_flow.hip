@@ -28,6 +28,7 @@
 // workgroup resident: the grid is sized from the occupancy query (rp_api.hip) and every wait is bounded — a timeout raises
 // FL_FLOW_ABORT / RP_OVF_FLOW, all waves leave their loops and the host reports the step as failed.
 #include "rp_global.h"
+#include "rp_gridbar.h"
 
 typedef unsigned int flow_u4 __attribute__((ext_vector_type(4)));
 #define FLOW_SC1 16                  // cache policy bits of the raw buffer builtins on gfx950: sc1 = agent scope (write-through / L1 bypass)
@@ -197,11 +198,9 @@ RP_DEV void flow_ids(const DevWorld &w, int pos, int &id1, int &id2) { // the so
 }
 RP_DEV int flow_live_joints(const DevWorld &w) { return w.n_joints > 0 ? w.flags[FL_NJ_OVF_BEGIN] + w.flags[FL_NJ_OVF_COUNT] : 0; }
 // pass 0: count (into the fill cursors, which rest at zero between rebuilds)
-__global__ void k_flow_count(DevWorld w) {
-    if (!w.flags[FL_FLOW_DIRTY]) return;
+RP_DEV void flow_count(DevWorld &w, int gid, int stride) {
     int M = w.flags[FL_N_CONS]; if (M > w.cons_cap) M = w.cons_cap;
     const int njl = flow_live_joints(w);
-    int stride = gridDim.x * blockDim.x, gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid == 0) { w.flags[FL_FLOW_CURSOR] = 0; w.flags[FL_FLOW_JCURSOR] = 0; }
     for (int pos = gid; pos < M; pos += stride) {
         int a, b; flow_ids(w, pos, a, b);
@@ -215,10 +214,8 @@ __global__ void k_flow_count(DevWorld w) {
     }
 }
 // pass 1: every body reserves its two list ranges
-__global__ void k_flow_alloc(DevWorld w) {
-    if (!w.flags[FL_FLOW_DIRTY]) return;
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= w.n_bodies) return;
+RP_DEV void flow_alloc(DevWorld &w, int gid, int stride) {
+  for (int i = gid; i < w.n_bodies; i += stride) {
     int2 d = w.fb_fill[i];
     w.fb_deg[i] = d;
     { // every ticket of a step must fit FLOW_TICKET_BITS
@@ -228,13 +225,12 @@ __global__ void k_flow_alloc(DevWorld w) {
     }
     w.fb_begin[i] = make_int2(d.x ? atomicAdd(&w.flags[FL_FLOW_CURSOR], d.x) : 0, d.y ? atomicAdd(&w.flags[FL_FLOW_JCURSOR], d.y) : 0);
     w.fb_fill[i] = make_int2(0, 0);
+  }
 }
 // pass 2: fill
-__global__ void k_flow_fill(DevWorld w) {
-    if (!w.flags[FL_FLOW_DIRTY]) return;
+RP_DEV void flow_fill(DevWorld &w, int gid, int stride) {
     int M = w.flags[FL_N_CONS]; if (M > w.cons_cap) M = w.cons_cap;
     const int njl = flow_live_joints(w);
-    int stride = gridDim.x * blockDim.x, gid = blockIdx.x * blockDim.x + threadIdx.x;
     for (int pos = gid; pos < M; pos += stride) {
         int a, b; flow_ids(w, pos, a, b);
         if (a >= 0) w.f_adj[w.fb_begin[a].x + atomicAdd(&w.fb_fill[a].x, 1)] = pos;
@@ -248,16 +244,14 @@ __global__ void k_flow_fill(DevWorld w) {
 }
 // pass 3: rank = how many touchers of the same body come earlier in the sweep (constraint position / joint sweep index)
 RP_DEV int flow_rank_in(const int *list, int begin, int n, int key) { int r = 0; for (int k = 0; k < n; ++k) r += list[begin + k] < key; return r; }
-__global__ void k_flow_rank(DevWorld w) {
-    if (!w.flags[FL_FLOW_DIRTY]) return;
+RP_DEV void flow_rank(DevWorld &w, int gid, int stride) {
     int M = w.flags[FL_N_CONS]; if (M > w.cons_cap) M = w.cons_cap;
     const int njl = flow_live_joints(w);
-    int stride = gridDim.x * blockDim.x, gid = blockIdx.x * blockDim.x + threadIdx.x;
     for (int pos = gid; pos < M; pos += stride) {
         int a, b; flow_ids(w, pos, a, b);
         int2 r = make_int2(-1, -1);
-        if (a >= 0) r.x = flow_rank_in(w.f_adj, w.fb_begin[a].x, w.fb_deg[a].x, pos);
-        if (b >= 0) r.y = flow_rank_in(w.f_adj, w.fb_begin[b].x, w.fb_deg[b].x, pos);
+        if (a >= 0) { r.x = flow_rank_in(w.f_adj, w.fb_begin[a].x, w.fb_deg[a].x, pos); w.f_sorted[w.fb_begin[a].x + r.x] = pos; }
+        if (b >= 0) { r.y = flow_rank_in(w.f_adj, w.fb_begin[b].x, w.fb_deg[b].x, pos); w.f_sorted[w.fb_begin[b].x + r.y] = pos; }
         w.fk_rank[pos] = r;
     }
     for (int idx = gid; idx < njl; idx += stride) {
@@ -268,6 +262,22 @@ __global__ void k_flow_rank(DevWorld w) {
         w.fj_rank[j] = r;
     }
     for (int i = gid; i < w.n_bodies; i += stride) w.fb_fill[i] = make_int2(0, 0); // cursors rest at zero for the next rebuild
+}
+
+// the four passes as ONE launch behind grid barriers (rp_gridbar.h): a step whose layout did not change pays a single early exit
+__global__ void __launch_bounds__(1024) k_flow_ranks(DevWorld w) {
+    if (!w.flags[FL_FLOW_DIRTY]) return; // (cleared by the kernel that starts the solve: k_flow_begin / k_solver_begin)
+    const int gid = gbar_item(), gstride = gridDim.x * blockDim.x;
+    GridBar bar = gbar_begin(w, 3);
+    flow_count(w, gid, gstride);
+    gbar_sync(bar);
+    flow_alloc(w, gid, gstride);
+    gbar_sync(bar);
+    flow_fill(w, gid, gstride);
+    gbar_sync(bar);
+    flow_rank(w, gid, gstride);
+    gbar_sync(bar);
+    gbar_end(bar);
 }
 
 // ---- the step ---------------------------------------------------------------------------------------
@@ -608,14 +618,15 @@ int rp_flow_grid(int device) {
     if (device >= 0 && device < 64) cached[device] = g;
     return g;
 }
+// per-body toucher lists in sweep order (rebuilt only when FL_FLOW_DIRTY; the flag is cleared by the kernel that starts the solve)
+void rp_launch_flow_ranks(const DevWorld &w, hipStream_t st) {
+    int n = w.cons_cap > w.n_joints ? w.cons_cap : w.n_joints; if (n < w.n_bodies) n = w.n_bodies;
+    int blocks = (n + 255) / 256; if (blocks > 192) blocks = 192; if (blocks < 1) blocks = 1; // all resident (grid barriers)
+    hipLaunchKernelGGL(k_flow_ranks, dim3(blocks), dim3(1024), 0, st, w);
+}
 void rp_launch_global_flow(const DevWorld &w, hipStream_t st, int grid, int has_restitution) {
     int nbb = (w.n_bodies + 255) / 256; if (nbb < 1) nbb = 1;
-    int n = w.cons_cap > w.n_joints ? w.cons_cap : w.n_joints; if (n < w.n_bodies) n = w.n_bodies;
-    int blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_flow_count, dim3(blocks), dim3(256), 0, st, w);
-    hipLaunchKernelGGL(k_flow_alloc, dim3(nbb), dim3(256), 0, st, w);
-    hipLaunchKernelGGL(k_flow_fill, dim3(blocks), dim3(256), 0, st, w);
-    hipLaunchKernelGGL(k_flow_rank, dim3(blocks), dim3(256), 0, st, w);
+    rp_launch_flow_ranks(w, st);
     hipLaunchKernelGGL(k_flow_begin, dim3(nbb), dim3(256), 0, st, w);
     const bool coul = w.prm.p.friction_model == RP_FRICTION_COULOMB, joints = w.n_joints > 0;
 #define FLOW_LAUNCH(C, J) hipLaunchKernelGGL((k_global_flow<C, J>), dim3(grid), dim3(256), 0, st, w, has_restitution)

@@ -23,7 +23,7 @@
 // ---- MULTI mode kernels ---------------------------------------------------------------------------
 __global__ void k_solver_begin(DevWorld w) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) w.flags[FL_ANY_BOUNCY] = 0;
+    if (i == 0) { w.flags[FL_ANY_BOUNCY] = 0; w.flags[FL_FLOW_DIRTY] = 0; } // (the toucher ranks were rebuilt by the launches before this one)
     if (i >= w.n_bodies || !global_body(w, i)) return;
     g_body_begin(w, i);
 }
@@ -45,6 +45,108 @@ __global__ void k_integrate(DevWorld w) {
     if (i >= w.n_bodies || !global_body(w, i)) return;
     g_body_integrate(w, i);
 }
+// ---- body-centric warm start (twist model) -------------------------------------------------------------------------------
+// The reference fuses `update` + `warmstart` into its colour sweep (contact_with_twist_friction.rs:426-522, :633-678; stage
+// worker.rs:438-488) and pays one stage per colour for it.  Neither half needs that: `update` reads poses only, and the warm start
+// adds velocity terms that do not depend on the velocities — per body, a fixed sequence of float adds in sweep order.  So the
+// per-stage path runs them as TWO launches per substep instead of one per colour (9 on b3d_large_pyramid):
+//   k_ws_prepare    every manifold in parallel: update (rhs, cfm, banked impulses) and the 11 velocity terms of either side
+//                   (5 linear: the <= 4 normal terms + the tangent term; 6 angular: + the twist term) into ws_terms;
+//   k_increment_ws  every body: increment (+ gyroscopic term), then its touchers' terms in sweep order (f_sorted, built with the
+//                   dataflow solver's toucher ranks), each added exactly as the colour sweep would have added it.
+// Same operands, same order per accumulator (-ffp-contract=off): bit-identical to the per-colour sweep and to the oracle.
+#define WS_TERMS 11
+#define WS_TERMS 11
+// ws_terms = [11][2 * cons_cap] planes indexed by 2 * position + side: the writes of k_ws_prepare are coalesced plane by plane (a
+// per-body layout, one contiguous run of terms per body, was measured: the scattered 176-byte writes doubled k_ws_prepare and
+// bought the accumulation nothing).  `row` = 2 * pos + side, -1 for a world-attached side.
+RP_DEV void ws_put(const DevWorld &w, int slot, int row, V3 v) { if (row >= 0) w.ws_terms[(size_t)slot * (2 * (size_t)w.cons_cap) + row] = f4(v, 0.0f); }
+RP_DEV V3 ws_get(const DevWorld &w, int slot, int row) { return v3(w.ws_terms[(size_t)slot * (2 * (size_t)w.cons_cap) + row]); }
+__global__ void __launch_bounds__(256) k_ws_prepare(DevWorld w, float solved_dt) {
+    int M = w.flags[FL_N_CONS];
+    if (M > w.cons_cap) M = w.cons_cap;
+    const int stride = gridDim.x * blockDim.x;
+    for (int pos = blockIdx.x * blockDim.x + threadIdx.x; pos < M; pos += stride) {
+        const GlobalAcc A(w, pos);
+        const int id1 = A.id1(), id2 = A.id2(), n = A.n();
+        const bool is_static = id1 < 0 || id2 < 0;
+        const float fstatic = is_static ? 1.0f : 0.0f;
+        const float cfm_factor = w.prm.dyn_cfm + fstatic * (w.prm.static_cfm - w.prm.dyn_cfm);
+        const float erp_inv_dt = w.prm.dyn_erp_inv_dt + fstatic * (w.prm.static_erp_inv_dt - w.prm.dyn_erp_inv_dt);
+        const float inv_dt = w.prm.inv_dt_sub, maxcv = w.prm.max_corrective_velocity, wc = w.prm.p.warmstart_coefficient;
+        const Xf x1 = A.xf(id1), x2 = A.xf(id2);
+        const float4 h0 = A.ld(CP_H0), h6 = A.ld(CP_H6);
+        const V3 dir1 = v3(h0), t0 = v3(h6), t1 = cross(dir1, t0);
+        const V3 tangent_delta = v3(A.ld(CP_B2)) * solved_dt;
+        const V3 im1 = v3(A.ld(CP_H1)), im2 = v3(A.ld(CP_H2));
+        const bool ws = wc != 0.0f;
+        const int s1 = id1 >= 0 ? 2 * pos : -1, s2 = id2 >= 0 ? 2 * pos + 1 : -1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k >= n) break;
+            float4 m = A.ld(NPL(k, NP_M));
+            float4 c = A.ld(NPL(k, NP_C)), d = A.ld(NPL(k, NP_D));
+            V3 p1 = xf_tp(x1, v3(A.ld(NPL(k, NP_E)))) + tangent_delta;
+            V3 p2 = xf_tp(x2, v3(A.ld(NPL(k, NP_F))));
+            float dist = c.w + dot(p1 - p2, dir1);
+            float rhs_wo_bias = rp_max(dist, 0.0f) * inv_dt;
+            float rhs_bias = rp_clamp(dist * erp_inv_dt, -maxcv, 0.0f);
+            m.x = rhs_wo_bias + rhs_bias;
+            m.y = dist <= 0.0f ? cfm_factor : 1.0f;
+            m.w += m.z;
+            m.z *= wc;
+            A.st(NPL(k, NP_M), m);
+            if (ws) { // ContactConstraintNormalPartSlim::warmstart, contact_constraint_element.rs:465-478
+                ws_put(w, k, s1, cmul(dir1, im1) * m.z); ws_put(w, 5 + k, s1, v3(c) * m.z);
+                ws_put(w, k, s2, cmul(dir1, im2) * (-m.z)); ws_put(w, 5 + k, s2, v3(d) * m.z);
+            }
+        }
+        float4 hm0 = A.ld(CP_HM0), hm1 = A.ld(CP_HM1), h7 = A.ld(CP_H7);
+        {
+            V3 p1 = xf_tp(x1, v3(A.ld(CP_B0))) + tangent_delta;
+            V3 p2 = xf_tp(x2, v3(A.ld(CP_B1)));
+            float bias0 = dot(p1 - p2, t0) * inv_dt, bias1 = dot(p1 - p2, t1) * inv_dt;
+            hm1.z = h6.w + bias0; hm1.w = h7.x + bias1;
+            hm1.x += hm0.z; hm1.y += hm0.w;
+            hm0.z *= wc; hm0.w *= wc;
+            hm0.y += hm0.x;
+            hm0.x *= wc;
+        }
+        A.st(CP_HM0, hm0); A.st(CP_HM1, hm1);
+        if (ws) {
+            const float i0 = hm0.z, i1 = hm0.w;
+            ws_put(w, 4, s1, cmul(t0 * i0 + t1 * i1, im1)); ws_put(w, 9, s1, v3(A.ld(CP_T4)) * i0 + v3(A.ld(CP_T5)) * i1);
+            ws_put(w, 4, s2, cmul(t0 * (-i0) + t1 * (-i1), im2)); ws_put(w, 9, s2, v3(A.ld(CP_T6)) * i0 + v3(A.ld(CP_T7)) * i1);
+            if (n > 1) {
+                float4 h3 = A.ld(CP_H3), h4 = A.ld(CP_H4), h5 = A.ld(CP_H5);
+                Sym3 ii1 = {h3.x, h3.y, h3.z, h3.w, h4.x, h4.y}, ii2 = {h4.z, h4.w, h5.x, h5.y, h5.z, h5.w};
+                ws_put(w, 10, s1, sym_mul(ii1, dir1) * hm0.x);
+                ws_put(w, 10, s2, -(sym_mul(ii2, dir1) * hm0.x)); // v2.ang - y == v2.ang + (-y), exactly
+            }
+        }
+    }
+}
+__global__ void __launch_bounds__(256) k_increment_ws(DevWorld w) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= w.n_bodies || !global_body(w, i)) return;
+    V3 lin = v3(w.s_lin[i]), ang = v3(w.s_ang[i]);
+    body_increment(w, w.b_flags[i], lin, ang, q4(w.s_rot[i]), v3(w.s_incl[i]), v3(w.s_inca[i]), v3(w.b_invpi[i]), q4(w.b_pframe[i]));
+    if (w.prm.p.warmstart_coefficient != 0.0f) {
+        const int beg = w.fb_begin[i].x, deg = w.fb_deg[i].x;
+        for (int r = 0; r < deg; ++r) { // this body's constraints in sweep order
+            const int pos = w.f_sorted[beg + r];
+            const int row = w.k_b1[pos] == i ? 2 * pos : 2 * pos + 1;
+            const int n = w.k_n[pos];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { if (k >= n) break; lin = lin + ws_get(w, k, row); ang = ang + ws_get(w, 5 + k, row); }
+            lin = lin + ws_get(w, 4, row);
+            ang = ang + ws_get(w, 9, row);
+            if (n > 1) ang = ang + ws_get(w, 10, row);
+        }
+    }
+    w.s_lin[i] = f4(lin, 0.0f); w.s_ang[i] = f4(ang, 0.0f);
+}
+
 // One parallel colour stage: the reference's claim/steal chunk loop becomes a grid-stride loop.
 template <int MODE, bool COUL>
 __global__ void __launch_bounds__(256) k_stage(DevWorld w, int stage, int friction_in_bias, float solved_dt) {
@@ -185,7 +287,9 @@ void rp_launch_global_single(const DevWorld &w, hipStream_t st, int has_restitut
     if (host_coulomb(w)) hipLaunchKernelGGL(k_global_single<true>, dim3(1), dim3(512), 0, st, w, has_restitution, fast);
     else hipLaunchKernelGGL(k_global_single<false>, dim3(1), dim3(512), 0, st, w, has_restitution, fast);
 }
+void rp_launch_flow_ranks(const DevWorld &w, hipStream_t st);
 void rp_launch_solver_assembly(const DevWorld &w, hipStream_t st) {
+    rp_launch_flow_ranks(w, st); // the per-body toucher lists of the body-centric warm start (only rebuilt when the layout changed)
     hipLaunchKernelGGL(k_solver_begin, dim3(body_blocks(w)), dim3(256), 0, st, w);
     if (host_coulomb(w)) hipLaunchKernelGGL(k_generate<true>, dim3(cons_blocks(w)), dim3(256), 0, st, w);
     else hipLaunchKernelGGL(k_generate<false>, dim3(cons_blocks(w)), dim3(256), 0, st, w);
@@ -198,9 +302,15 @@ void rp_launch_solver_loop(const DevWorld &w, hipStream_t st, int parallel_stage
     int fib = (p.friction_in_bias_pass || p.num_internal_stabilization_iterations == 0) ? 1 : 0;
     for (int s = 0; s < w.prm.num_substeps; ++s) {
         float solved_dt = (float)s * w.prm.dt_sub;
-        hipLaunchKernelGGL(k_increment, dim3(nb), dim3(256), 0, st, w);
-        rp_launch_joint_update(w, st, s); // rows rebuilt from the current poses (worker.rs:287-357)
-        launch_sweep<MODE_WARMSTART>(w, st, plan, fib, solved_dt);
+        if (!host_coulomb(w) && w.ws_terms) { // body-centric warm start: two launches instead of one per colour
+            hipLaunchKernelGGL(k_ws_prepare, dim3(cons_blocks(w)), dim3(256), 0, st, w, solved_dt);
+            hipLaunchKernelGGL(k_increment_ws, dim3(nb), dim3(256), 0, st, w);
+            rp_launch_joint_update(w, st, s);
+        } else {
+            hipLaunchKernelGGL(k_increment, dim3(nb), dim3(256), 0, st, w);
+            rp_launch_joint_update(w, st, s); // rows rebuilt from the current poses (worker.rs:287-357)
+            launch_sweep<MODE_WARMSTART>(w, st, plan, fib, solved_dt);
+        }
         for (int it = 0; it < p.num_internal_pgs_iterations; ++it) {
             rp_launch_joint_sweep(w, st, joint_stages, 0, (p.warmstart_joints && it == 0) ? 1 : 0); // all joints before any contact
             launch_sweep<MODE_BIAS>(w, st, plan, fib, solved_dt);

@@ -311,4 +311,6 @@ struct DevWorld {
     int2 *fb_deg;               // [n_bodies] contact touchers, joint touchers of a solver body
     int2 *fb_begin, *fb_fill;   // [n_bodies] list begin / fill cursor inside f_adj, f_jadj
     int *f_adj, *f_jadj;        // [2 * cons_cap] positions, [2 * n_joints] joint sweep indices
+    int *f_sorted;              // [2 * cons_cap] the contact touchers of every body in sweep order (f_adj ranked): the body-centric warm start
+    float4 *ws_terms;           // [11][2 * cons_cap] warm-start velocity terms per constraint side (rp_solver.hip: k_ws_prepare / k_increment_ws)
 };

@@ -145,8 +145,8 @@ def test_dataflow_launch_equals_per_stage_launches(scene):
     make = {"large_pyramid60": lambda: S.large_pyramid(60), "joint_grid40": lambda: S.joint_grid(40),
             "tumble_coulomb": lambda: _with_param(S.tumble(64, seed=7), "friction_model", S.FRICTION_COULOMB),
             "joint_chain_boxes": lambda: S.joint_chain(6, with_boxes=True)}[scene]
-    a = _world_with_env(make(), RP_FORCE_MULTI=1)
-    b = _world_with_env(make(), RP_FORCE_MULTI=1, RP_NO_FLOW=1)
+    a = _world_with_env(make(), RP_FORCE_MULTI=1, RP_FLOW=1)     # RP_FLOW=1: the dataflow launch whatever the world holds
+    b = _world_with_env(make(), RP_FORCE_MULTI=1, RP_NO_FLOW=1)  # per-stage launches (+ the body-centric warm start under the twist model)
     done = 0
     for cp in (1, 7, 40, 120):
         a.step(cp - done); b.step(cp - done); done = cp
