@@ -713,8 +713,8 @@ extern "C" int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider
     for (int i = 0; i < n; ++i) {
         int parent = -1;
         if (parents && parents[i] != RP_INVALID_HANDLE) {
-            parent = (int)(parents[i] & 0xffffffffull);
-            if (parent < 0 || parent >= (int)w->bodies.size()) { w->err = "rp_colliders_insert: invalid parent handle"; return RP_ERR_INVALID; }
+            parent = handle_index(parents[i]);
+            if (parent < 0 || parent >= (int)w->bodies.size() || w->bodies[parent].removed || w->bodies[parent].quarantined) { w->err = "rp_colliders_insert: invalid parent handle (unknown, removed or quarantined body)"; return RP_ERR_INVALID; }
         }
         int &ord_counter = parent >= 0 ? w->bodies[parent].next_ord : w->next_free_ord;
         if (ord_counter >= 4096) { w->err = "rp_colliders_insert: more than 4096 colliders on one body (or without a parent)"; return RP_ERR_CAPACITY; }
@@ -1461,7 +1461,7 @@ extern "C" int32_t rp_bodies_read(rp_world *w, int32_t n, const uint64_t *handle
     HIPCHK(w, hipStreamSynchronize(w->stream));
     int count = handles ? n : nb;
     for (int i = 0; i < count; ++i) {
-        int b = handles ? (int)(handles[i] & 0xffffffffull) : i;
+        int b = handles ? handle_index(handles[i]) : i;
         if (b < 0 || b >= nb) { w->err = "rp_bodies_read: invalid handle"; return RP_ERR_INVALID; }
         if (pos7_out) { float *p = pos7_out + 7 * i; p[0] = pos[b].x; p[1] = pos[b].y; p[2] = pos[b].z; p[3] = rot[b].x; p[4] = rot[b].y; p[5] = rot[b].z; p[6] = rot[b].w; }
         if (vel6_out) { float *v = vel6_out + 6 * i; v[0] = lv[b].x; v[1] = lv[b].y; v[2] = lv[b].z; v[3] = av[b].x; v[4] = av[b].y; v[5] = av[b].z; }
@@ -1476,7 +1476,7 @@ extern "C" int32_t rp_bodies_write(rp_world *w, int32_t n, const uint64_t *handl
     { int r = settle(w); if (r != RP_OK) return r; }
     bool quarantined_any = false;
     for (int i = 0; i < n; ++i) {
-        int b = (int)(handles[i] & 0xffffffffull);
+        int b = handle_index(handles[i]);
         if (b < 0 || b >= w->dw.n_bodies || w->bodies[b].removed) { w->err = "rp_bodies_write: invalid handle"; return RP_ERR_INVALID; }
         if ((vel6 && !all_finite(vel6 + 6 * i, 6)) || (pos7 && !all_finite(pos7 + 7 * i, 7))) {
             // Quarantine::detect_user_changes (quarantine.rs:68-129): a non-finite user write never reaches the broad phase; the body
@@ -1526,7 +1526,7 @@ extern "C" int32_t rp_bodies_write(rp_world *w, int32_t n, const uint64_t *handl
         // set_linvel / set_position(.., wake_up = true): strong wake of the body (its whole island when asleep); a moved
         // body also wakes every body it has a pair with (pair_management.rs:236-258)
         for (int i = 0; i < n; ++i) {
-            int b = (int)(handles[i] & 0xffffffffull), lvl = pos7 ? 3 : 2;
+            int b = handle_index(handles[i]), lvl = pos7 ? 3 : 2;
             { int r = queue_wake(w, b, lvl); if (r != RP_OK) return r; }
         }
         if (pos7) rp_launch_wake_partners(w->dw, w->stream);
@@ -1978,7 +1978,7 @@ extern "C" int32_t rp_impulse_joints_read(rp_world *w, int32_t n, const uint64_t
     for (int k = 0; k < nj; ++k) dev_of[w->active_joint_ids[k]] = k;
     int count = handles ? n : total;
     for (int i = 0; i < count; ++i) {
-        int j = handles ? (int)(handles[i] & 0xffffffffull) : i;
+        int j = handles ? handle_index(handles[i]) : i;
         if (j < 0 || j >= total) { w->err = "rp_impulse_joints_read: invalid handle"; return RP_ERR_INVALID; }
         int k = dev_of[j];
         if (color_out) color_out[i] = k >= 0 ? col[k] : 255;
@@ -2035,7 +2035,7 @@ extern "C" int32_t rp_impulse_joints_read_motor_impulses(rp_world *w, int32_t n,
     for (int k = 0; k < nj; ++k) dev_of[w->active_joint_ids[k]] = k;
     int count = handles ? n : total;
     for (int i = 0; i < count; ++i) {
-        int j = handles ? (int)(handles[i] & 0xffffffffull) : i;
+        int j = handles ? handle_index(handles[i]) : i;
         if (j < 0 || j >= total) { w->err = "rp_impulse_joints_read_motor_impulses: invalid handle"; return RP_ERR_INVALID; }
         int k = dev_of[j];
         float *o = impulse6_out + 6 * i;
