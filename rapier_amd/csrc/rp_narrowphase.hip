@@ -932,6 +932,8 @@ void rp_launch_narrowphase_part(const DevWorld &w, hipStream_t st, int part) {
             hipLaunchKernelGGL(k_np_test, dim3(blocks), dim3(256), 0, st, w);
             // at most one workgroup per CU: with 128 VGPRs and 2.7 KB of scratch per lane a second round of workgroups costs ~10 us
             // even when the queue is empty (measured: 341 -> 256 workgroups = 140 -> 130 us per full step on b3d_many_pyramids)
+            // (sizing this grid from the recent queue lengths was measured: 5-10 us per full step, paid for with a ~10 ms re-capture of
+            // the step graphs whenever the size changed — not kept)
             hipLaunchKernelGGL(k_np_update, dim3(blocks < 256 ? blocks : 256), dim3(256), 0, st, w);
             hipLaunchKernelGGL(k_color_pairs, dim3(1), dim3(1024), 0, st, w);
         }
