@@ -802,6 +802,13 @@ __global__ void __launch_bounds__(1024) k_color_pairs(DevWorld w) {
     __shared__ int cursor, n_cur, n_next;
     const int tid = threadIdx.x, nt = blockDim.x;
     if (tid == 0) { cursor = 0; n_cur = 0; n_next = 0; }
+#ifdef RP_COLOR_PROFILE // tools/color_profile.py: time stamps (10 ns ticks) after every pass, rounds and frontier sizes of the largest launch
+#define COL_STAMP(k) do { if (tid == 0 && T > 1000) w.dbg[40 + (k)] = (long long)wall_clock64(); } while (0)
+    int prof_rounds = 0; long long prof_items = 0;
+#else
+#define COL_STAMP(k) do { } while (0)
+#endif
+    COL_STAMP(0);
     __syncthreads();
     // pass 1: dynamic sides, per-body counts; the first pair to touch a body reserves its list in pass 2
     for (int t = tid; t < T; t += nt) {
@@ -815,6 +822,7 @@ __global__ void __launch_bounds__(1024) k_color_pairs(DevWorld w) {
         w.col_rec[t] = make_int4(b1, b2, first, s);
     }
     __threadfence(); __syncthreads();
+    COL_STAMP(1);
     // pass 2: reserve
     for (int t = tid; t < T; t += nt) {
         int4 r = w.col_rec[t];
@@ -822,6 +830,7 @@ __global__ void __launch_bounds__(1024) k_color_pairs(DevWorld w) {
         if (r.z & 2) w.col_begin[r.y] = atomicAdd(&cursor, ld_i32a(&w.col_cnt[r.y]));
     }
     __threadfence(); __syncthreads();
+    COL_STAMP(2);
     // pass 3: fill (any order)
     for (int t = tid; t < T; t += nt) {
         int4 r = w.col_rec[t];
@@ -829,6 +838,7 @@ __global__ void __launch_bounds__(1024) k_color_pairs(DevWorld w) {
         if (r.y >= 0) w.col_list[ld_i32a(&w.col_begin[r.y]) + atomicAdd(&w.col_fill[r.y], 1)] = t;
     }
     __threadfence(); __syncthreads();
+    COL_STAMP(3);
     // pass 4: rank by key inside each body's list -> sorted lists
     for (int t = tid; t < T; t += nt) {
         int4 r = w.col_rec[t];
@@ -846,6 +856,7 @@ __global__ void __launch_bounds__(1024) k_color_pairs(DevWorld w) {
         w.col_deps[t] = (rk.x > 0) + (rk.y > 0);
     }
     __threadfence(); __syncthreads();
+    COL_STAMP(4);
     // pass 5: successors, first frontier; the per-body counters go back to rest
     for (int t = tid; t < T; t += nt) {
         int4 r = w.col_rec[t];
@@ -863,11 +874,15 @@ __global__ void __launch_bounds__(1024) k_color_pairs(DevWorld w) {
         if (r.y >= 0) { w.col_cnt[r.y] = 0; w.col_fill[r.y] = 0; }
     }
     // rounds
+    COL_STAMP(5);
     int *qc = w.col_q, *qn = w.col_q + w.pool_cap;
     for (;;) {
         const int n = n_cur;
         __syncthreads();
         if (n == 0) break;
+#ifdef RP_COLOR_PROFILE
+        prof_rounds++; prof_items += n;
+#endif
         for (int f = tid; f < n; f += nt) {
             // a thread follows its pair's chain: the first successor it releases is coloured by the same thread at once (most of the
             // DAG is chains — body k's pairs one after the other), only further released successors wait in the queue for the next round
@@ -909,6 +924,10 @@ __global__ void __launch_bounds__(1024) k_color_pairs(DevWorld w) {
         int *tmp = qc; qc = qn; qn = tmp;
         __syncthreads();
     }
+    COL_STAMP(6);
+#ifdef RP_COLOR_PROFILE
+    if (tid == 0 && T > 1000) { w.dbg[48] = prof_rounds; w.dbg[49] = prof_items; w.dbg[50] = T; }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
