@@ -44,6 +44,7 @@ void rp_launch_wake(const DevWorld &w, hipStream_t st, int phase);
 void rp_launch_wake_partners(const DevWorld &w, hipStream_t st);
 void rp_launch_force_events(const DevWorld &w, hipStream_t st, int fast);
 void rp_launch_idle_step(const DevWorld &w, hipStream_t st);
+void rp_launch_sleep_fast(const DevWorld &w, hipStream_t st);
 void rp_launch_clear_no_contact(const DevWorld &w, hipStream_t st);
 void rp_launch_global_flow(const DevWorld &w, hipStream_t st, int grid, int has_restitution);
 int rp_flow_grid(int device);
@@ -1021,7 +1022,7 @@ static int finalize(rp_world *w) {
     DAC(d.b_pos, capb, DOM_BODY, 1, 1); DAC(d.b_rot, capb, DOM_BODY, 1, 1); DAC(d.b_linvel, capb, DOM_BODY, 1, 1); DAC(d.b_angvel, capb, DOM_BODY, 1, 1); DA(d.b_lcom_invm, capb); DA(d.b_invpi, capb);
     DA(d.b_pframe, capb); DAC(d.b_wcom, capb, DOM_BODY, 1, 1); DAC(d.b_eim, capb, DOM_BODY, 1, 1); DAC(d.b_eii0, capb, DOM_BODY, 1, 1); DAC(d.b_eii1, capb, DOM_BODY, 1, 1); DAC(d.b_damp, capb, DOM_BODY, 1, 1);
     DAC(d.b_uforce, capb, DOM_BODY, 1, 1); DAC(d.b_utorque, capb, DOM_BODY, 1, 1); DAC(d.b_flags, capb, DOM_BODY, 1, 1); DAC(d.b_quar, capb, DOM_BODY, 1, 1); DAF(d.b_collider, capb, 0xff);
-    DAC(d.b_sleep, capb, DOM_BODY, 1, 1); DA(d.b_sprev_t, capb); DAC(d.b_sprev_r, capb, DOM_BODY, 1, 1); DAC(d.b_slabel, capb, DOM_BODY, 1, 1); DAC(d.b_slept_at, capb, DOM_BODY, 1, 1); DAC(d.b_wake_req, capb, DOM_BODY, 1, 1);
+    DAC(d.b_sleep, capb, DOM_BODY, 1, 1); DA(d.b_sprev_t, capb); DAC(d.b_sprev_r, capb, DOM_BODY, 1, 1); DAC(d.b_slabel, capb, DOM_BODY, 1, 1); DAC(d.b_slept_at, capb, DOM_BODY, 1, 1); DA(d.b_sleep_stamp, capb); DAC(d.b_wake_req, capb, DOM_BODY, 1, 1);
     DAC(d.lab_wake, capb, DOM_BODY, 1, 1); DAC(d.lab_awake, capb, DOM_BODY, 1, 1); DAC(d.b_next_pos, capb, DOM_BODY, 1, 1); DAC(d.b_next_rot, capb, DOM_BODY, 1, 1);
     DAC(d.s_lin, capb, DOM_BODY, 1, 1); DAC(d.s_ang, capb, DOM_BODY, 1, 1); DAC(d.s_rot, capb, DOM_BODY, 1, 1); DAC(d.s_trans, capb, DOM_BODY, 1, 1); DAC(d.s_incl, capb, DOM_BODY, 1, 1); DAC(d.s_inca, capb, DOM_BODY, 1, 1);
     DAC(d.b_cmask, 4 * (size_t)capb, DOM_BODY, 1, 4); DAFC(d.b_min, capb, 0xff, DOM_BODY, 1, 1);
@@ -1180,7 +1181,11 @@ static int finalize(rp_world *w) {
 
 static void enqueue_collision(rp_world *w) {
     if (w->cur_fast && w->plan_fused) return; // the fused k_island_solve validates the step itself
-    if (w->cur_fast) { rp_launch_fast_front(w->dw, w->stream, w->plan_no_global); return; }
+    if (w->cur_fast) {
+        rp_launch_fast_front(w->dw, w->stream, w->plan_no_global);
+        rp_launch_sleep_fast(w->dw, w->stream); // sleep-enabled worlds: the per-step observation + "would an island fall asleep?" (then: abort)
+        return;
+    }
     rp_launch_collider_update(w->dw, w->stream);
     rp_launch_broadphase(w->dw, w->stream);
     rp_launch_wake(w->dw, w->stream, 0); // user wake-ups and pair deletions take effect before the narrow phase reads the awake set
@@ -1235,7 +1240,8 @@ static void plan_from_hints(rp_world *w, const int *fl) {
     // fused single-kernel fast step: every workgroup must be resident at once (in-launch arrival barrier)
     // (a grid of at most fused_grid workgroups; workgroups loop over islands beyond that)
     // (contact-force events are evaluated by a kernel of their own after every step: such worlds take the two-kernel fast graph)
-    w->plan_fused = (w->use_fused && w->fused_grid > 0 && !w->compound && !w->dw.has_force_events && w->plan_no_global && w->plan_single && fl[FL_N_ISLANDS] > 0) ? 1 : 0;
+    // (... and so do sleep-enabled worlds: their sleep observation is a pass of its own)
+    w->plan_fused = (w->use_fused && w->fused_grid > 0 && !w->compound && !w->dw.has_force_events && !w->dw.sleep_enabled && w->plan_no_global && w->plan_single && fl[FL_N_ISLANDS] > 0) ? 1 : 0;
 }
 
 static int capture(rp_world *w, hipGraph_t *g, hipGraphExec_t *ge, void (*fn)(rp_world *)) {
@@ -1366,9 +1372,11 @@ static int step_once(rp_world *w, bool allow_fast) {
         }
     }
     // mode: fast graph only while the last observed steps were clean
-    // sleep-enabled worlds always take the full path (the sleep timers and the island decision run every step)
     // ... and so do worlds with sensors (their pairs are intersection-tested every step)
-    bool fast = allow_fast && w->use_fast && !w->dw.sleep_enabled && !w->dw.has_sensors && w->plan_single && w->dw.n_colliders > 0 && w->steps_requested >= w->full_until;
+    // sleep-enabled worlds take the fast graph while bodies are awake, nothing is about to fall asleep and no wake-up is pending (all
+    // three verified on the device: k_fast_front, k_sleep_check); position-based kinematic bodies need the per-step velocity pass
+    const bool sleep_fast_ok = !w->dw.sleep_enabled || (!w->dw.has_kinematic_pos && pf[FL_N_AWAKE] > 0 && !pf[FL_WAKE_PENDING]);
+    bool fast = allow_fast && w->use_fast && sleep_fast_ok && !w->dw.has_sensors && w->plan_single && w->dw.n_colliders > 0 && w->steps_requested >= w->full_until;
     if (fast && (pf[FL_FAST_ABORT] || pf[FL_FULL_UPDATES] || pf[FL_LAYOUT_DIRTY] || pf[FL_TODO_COUNT])) {
         fast = false;
         w->full_until = w->steps_requested + 3;

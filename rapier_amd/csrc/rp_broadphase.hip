@@ -57,6 +57,8 @@ __global__ void k_fast_front(DevWorld w, int no_global_kernel) {
     if (gid == 0) {
         w.flags[FL_FULL_UPDATES] = 0;
         if (w.flags[FL_BP_DIRTY]) w.flags[FL_FAST_ABORT] = 1;
+        // sleep-enabled worlds: the awake set must be settled — no layout change or wake-up request waiting for a full step
+        if (w.sleep_enabled && (w.flags[FL_LAYOUT_DIRTY] || w.flags[FL_WAKE_PENDING] || w.flags[FL_N_AWAKE] == 0)) w.flags[FL_FAST_ABORT] = 1;
         // this graph variant carries no global-path kernel: it is only valid while everything lives in LDS islands
         if (no_global_kernel && (w.flags[FL_N_CONS] > 0 || w.flags[FL_N_GLOB_BODIES] > 0 || w.n_joints > 0)) w.flags[FL_FAST_ABORT] = 1;
     }
@@ -68,6 +70,12 @@ __global__ void k_fast_front(DevWorld w, int no_global_kernel) {
     if (top > w.pool_cap) top = w.pool_cap;
     int stride = gridDim.x * blockDim.x;
     for (int s = gid; s < top; s += stride) {
+        if (w.sleep_enabled) {
+            if (w.p_c1[s] < 0) continue;
+            int2 rb = w.p_rb[s];
+            if (!body_active(w, rb.x) && !body_active(w, rb.y)) continue;   // pair_update.rs:98-106: neither body awake -> skipped
+            if (pair_hint_cleared(w, s, rb)) abort = true;                  // a count-cleared hint is recomputed by the narrow phase
+        }
         if (pair_needs_narrow_phase(w, s)) abort = true;
     }
     if (abort) w.flags[FL_FAST_ABORT] = 1;

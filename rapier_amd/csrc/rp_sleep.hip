@@ -109,9 +109,14 @@ RP_DEV void slp_flatten(DevWorld &w, int gid, int gstride) {
 }
 
 // update_body_energy for every awake body + the island observation (an island sleeps once EVERY member is eligible).
+// The timer update runs at most once per step NUMBER (b_sleep_stamp): a fast step that observes, then aborts (an island is about to
+// fall asleep, k_sleep_check) is replayed on the full graph with the same step number, finds every timer already advanced and only
+// repeats the (idempotent) island marks.
 RP_DEV void sleep_observe_one(DevWorld &w, int i) {
     if (!flags_active(w.b_flags[i])) return;
     float4 sl = w.b_sleep[i];
+    if (w.b_sleep_stamp[i] == cur_step(w)) { if (!(sl.x >= sl.w)) w.lab_awake[w.b_slabel[i]] = cur_step(w); return; }
+    w.b_sleep_stamp[i] = cur_step(w);
     if ((w.b_flags[i] & RP_BF_TYPE_MASK) != RP_BODY_DYNAMIC) { // platforms only sleep when both velocities are exactly zero (:1464-1468)
         V3 lv = v3(w.b_linvel[i]), kav = v3(w.b_angvel[i]);
         bool still = dot(lv, lv) == 0.0f && dot(kav, kav) == 0.0f;
@@ -162,7 +167,8 @@ RP_DEV void sleep_commit(DevWorld &w, int gid, int gstride) {
 // behind grid barriers, rp_gridbar.h — skipped on a clean step) and the per-body observation; (2) the commit, which may only
 // run once EVERY member of an island was observed: that dependency is a kernel boundary, cheaper on MI355X than a fenced grid
 // barrier that would have to run every step (~4 us against ~7 us).
-__global__ void __launch_bounds__(1024) k_sleep_pass(DevWorld w) {
+__global__ void __launch_bounds__(1024) k_sleep_pass(DevWorld w, int fast) {
+    if (fast && w.flags[FL_FAST_ABORT]) return; // the fast graph gave up on this step: nothing may change
     const int gid = gbar_item(), gstride = gridDim.x * blockDim.x;
     if (w.flags[FL_LAYOUT_DIRTY]) { // (nothing in this launch writes the flag)
         GridBar bar = gbar_begin(w, 2);
@@ -177,6 +183,14 @@ __global__ void __launch_bounds__(1024) k_sleep_pass(DevWorld w) {
     for (int i = gid; i < w.n_bodies; i += gstride) sleep_observe_one(w, i);
 }
 __global__ void k_sleep_commit(DevWorld w) { sleep_commit(w, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x); }
+// fast graph: would the commit put an island to sleep (no member marked it awake this step)?  Then the step needs the full graph
+// (the layout changes): abort before anything but the — once-per-step — observation has happened.
+__global__ void k_sleep_check(DevWorld w) {
+    if (w.flags[FL_FAST_ABORT]) return;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= w.n_bodies || !flags_active(w.b_flags[i])) return;
+    if (w.lab_awake[w.b_slabel[i]] != cur_step(w)) w.flags[FL_FAST_ABORT] = 1;
+}
 
 // interpolate_kinematic_velocities (substep.rs:242-264): a position-based kinematic body gets the velocity that
 // reaches its next_position in one step (RigidBodyPosition::interpolate_velocity, rigid_body_components.rs:147-194).
@@ -233,6 +247,14 @@ void rp_launch_sleep(const DevWorld &w, hipStream_t st) {
     if (w.has_kinematic_pos) hipLaunchKernelGGL(k_kinematic_velocities, dim3(nb), dim3(256), 0, st, w); // after the narrow phase, before the sleep timers
     // every workgroup must be resident (grid barriers): at most 192 workgroups of 1024 threads
     int blocks = (w.n_bodies + 255) / 256; if (blocks > 192) blocks = 192; if (blocks < 1) blocks = 1; // sized by the bodies (the every-step observation); the pair pass of a relabel is grid-stride
-    hipLaunchKernelGGL(k_sleep_pass, dim3(blocks), dim3(1024), 0, st, w);
+    hipLaunchKernelGGL(k_sleep_pass, dim3(blocks), dim3(1024), 0, st, w, 0);
     hipLaunchKernelGGL(k_sleep_commit, dim3(nb), dim3(256), 0, st, w);
+}
+// the sleep pass of a FAST step (after k_fast_front): observation + the check that nothing is about to fall asleep
+void rp_launch_sleep_fast(const DevWorld &w, hipStream_t st) {
+    if (!w.sleep_enabled || w.n_bodies == 0) return;
+    int nb = slp_body_blocks(w);
+    int blocks = nb > 192 ? 192 : nb;
+    hipLaunchKernelGGL(k_sleep_pass, dim3(blocks), dim3(1024), 0, st, w, 1);
+    hipLaunchKernelGGL(k_sleep_check, dim3(nb), dim3(256), 0, st, w);
 }

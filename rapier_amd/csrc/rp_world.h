@@ -193,6 +193,8 @@ struct DevWorld {
     float4 *b_sprev_t;     // sleep_prev_pose translation xyz, max_extent
     float4 *b_sprev_r;     // sleep_prev_pose rotation
     int *b_slabel;         // sleep-island label = smallest body index of the component (union-find parent while awake)
+    int *b_sleep_stamp;    // step whose sleep observation this body's timer already holds (the observation runs at most once per step number:
+                           // a fast step that aborts after observing is replayed on the full graph without counting the step twice)
     int *b_slept_at;       // step at which the body last fell asleep (clears the solver hints of its pairs)
     int *b_wake_req;       // pending wake-up: 1 weak, 2 strong, 3 strong + the user moved the body
     int *lab_wake;         // [n_bodies] per label: step of the last wake-up of that sleeping island
