@@ -10,9 +10,11 @@
 // Layout hints (parallel colour count, largest stage) are read lazily from pinned memory.
 //
 // Two graphs exist per world:
-//   * the FULL graph: collider poses/AABBs -> broad phase -> narrow phase -> colouring/buckets/islands
-//     -> solver.  Always correct; ~25 (mostly early-exiting) kernels.
-//   * the FAST graph (steady state): k_fast_front -> k_island_solve -> k_global_single.  k_fast_front
+//   * the FULL graph: collider poses/AABBs -> broad phase (one launch, rp_gridbar.h) -> narrow phase -> colouring -> sleep pass ->
+//     solver-graph / island layout (one launch) -> solver.  Always correct; ~13 launches.
+//   * the FAST graph (steady state): k_fast_front [-> k_sleep_pass -> k_sleep_check in sleep-enabled worlds] -> k_island_solve ->
+//     k_global_single [-> k_force_events]; when every body lives in an LDS island and nothing else is asked for, the single fused
+//     launch of k_island_solve instead.  k_fast_front
 //     proves on the device that the broad phase and the narrow phase would be no-ops this step (no fat
 //     AABB left, every pair passes its recycle test); if not, it raises FL_FAST_ABORT and the other two
 //     kernels exit without touching the world.  The device counts executed steps (FL_STEP); every host

@@ -5,8 +5,8 @@
 //     is free of the bodies' contact colours and of the colours taken by earlier joints.  While every
 //     stored colour is still free the pass is the identity (staged_joint_colors_still_free,
 //     staged_island_solver/joints.rs:462-480), which a parallel check establishes each step; otherwise
-//     the greedy order is reproduced exactly by dependency rounds inside one workgroup (a joint
-//     decides in the round where it holds the smallest undecided index at both of its bodies).
+//     the greedy order is reproduced exactly as a wavefront over the joints' dependency DAG inside one
+//     workgroup (a joint decides once the previous joint, by edge index, at either of its bodies has).
 //   * layout: colours with >= 64 joints (JOINT_BATCH * LAYOUT_REF_WORKERS / 2, joints.rs:352) are
 //     parallel stages in ascending colour order, everything else is the serial overflow, colour-major
 //     in edge order (single_group_joint_layout, joints.rs:331-460).

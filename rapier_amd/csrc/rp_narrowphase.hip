@@ -10,9 +10,10 @@
 //
 // Then (contacts.rs:300-385, narrow_phase/mod.rs:90-172) begin-touch pairs get a persistent colour by
 // first-fit over per-body 128-bit masks in (min body, max body) order.  The serial greedy loop is
-// reproduced exactly by a dependency-round scheme inside ONE workgroup (k_color_pairs): a pair is
-// coloured in the round where it is the smallest uncoloured key at both of its dynamic bodies, so
-// it sees precisely the masks the serial order would have produced.
+// reproduced exactly as a wavefront over the pairs' dependency DAG inside ONE workgroup (k_color_pairs):
+// a pair is coloured once its predecessor (by key) at either of its dynamic bodies is, so it sees
+// precisely the masks the serial order would have produced.  Sensor pairs (intersections.rs) are
+// intersection-tested here too.
 #include "rp_pairs.h"
 #include <float.h>
 
