@@ -379,9 +379,19 @@ __global__ void __launch_bounds__(256) k_global_flow(DevWorld w, int has_restitu
     // Workgroups are dedicated to ONE kind of event — body events (increment, integrate, write-back), joints, or contacts: a
     // wavefront walks its phases in order, so a wavefront that served both bodies and contacts would hold its contacts' warm start
     // back until the slowest of its (unrelated) bodies could be incremented, and chain such artificial waits across the scene.
+    // The grid is split in proportion to the three item counts (one item per thread and phase where the grid allows: a thread that
+    // holds two items of a phase chains the second behind the first for nothing — b3d_joint_grid's 19,800 joints on a quarter of
+    // the grid did).
     const int G = gridDim.x;
-    const int GB = max(1, min(G / 4, (w.n_bodies + 255) / 256));
-    const int GJ = (JOINTS && w.n_joints > 0) ? max(1, min(G / 4, (w.n_joints + 255) / 256)) : 0;
+    int GB, GJ;
+    {
+        int Mq = w.flags[FL_N_CONS]; if (Mq > w.cons_cap) Mq = w.cons_cap;
+        const int needB = max(1, (w.n_bodies + 255) / 256), needJ = (JOINTS && w.n_joints > 0) ? max(1, (flow_live_joints(w) + 255) / 256) : 0;
+        const int needC = max(1, (Mq + 255) / 256), total = needB + needJ + needC;
+        if (total <= G) { GB = needB; GJ = needJ; }
+        else { GB = max(1, (int)((long long)needB * G / total)); GJ = needJ ? max(1, (int)((long long)needJ * G / total)) : 0; }
+        if (GB + GJ > G - 1) { GB = max(1, (G - 1) / 2); GJ = needJ ? max(1, G - 1 - GB) : 0; } // a tiny grid still keeps one contact workgroup
+    }
     const int bid = blockIdx.x;
     const int role = bid < GB ? 0 : (bid < GB + GJ ? 1 : 2); // 0 bodies, 1 joints, 2 contacts
     const int rb0 = role == 0 ? 0 : (role == 1 ? GB : GB + GJ), rbn = role == 0 ? GB : (role == 1 ? GJ : G - GB - GJ);
