@@ -33,7 +33,7 @@ RP_DEV void gbar_sync(GridBar &b) {
         unsigned spins = 0;
         while ((int)(__hip_atomic_load(b.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - b.target) < 0) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 24)) { atomicOr(b.ovf, RP_OVF_GRID); break; } // a workgroup of this launch is not resident
+            if (++spins > (1u << 21)) { atomicOr(b.ovf, RP_OVF_GRID); break; } // ~2 s: a workgroup of this launch is not resident
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
