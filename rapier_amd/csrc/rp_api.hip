@@ -47,6 +47,7 @@ void rp_launch_wake_partners(const DevWorld &w, hipStream_t st);
 void rp_launch_force_events(const DevWorld &w, hipStream_t st, int fast);
 void rp_launch_idle_step(const DevWorld &w, hipStream_t st);
 void rp_launch_sleep_fast(const DevWorld &w, hipStream_t st);
+void rp_launch_sensor_fast(const DevWorld &w, hipStream_t st);
 void rp_launch_clear_no_contact(const DevWorld &w, hipStream_t st);
 void rp_launch_global_flow(const DevWorld &w, hipStream_t st, int grid, int has_restitution);
 int rp_flow_grid(int device);
@@ -1186,6 +1187,7 @@ static void enqueue_collision(rp_world *w) {
     if (w->cur_fast) {
         rp_launch_fast_front(w->dw, w->stream, w->plan_no_global);
         rp_launch_sleep_fast(w->dw, w->stream); // sleep-enabled worlds: the per-step observation + "would an island fall asleep?" (then: abort)
+        rp_launch_sensor_fast(w->dw, w->stream); // worlds with sensors: their pairs' intersection tests (after the last kernel that can abort)
         return;
     }
     rp_launch_collider_update(w->dw, w->stream);
@@ -1243,7 +1245,7 @@ static void plan_from_hints(rp_world *w, const int *fl) {
     // (a grid of at most fused_grid workgroups; workgroups loop over islands beyond that)
     // (contact-force events are evaluated by a kernel of their own after every step: such worlds take the two-kernel fast graph)
     // (... and so do sleep-enabled worlds: their sleep observation is a pass of its own)
-    w->plan_fused = (w->use_fused && w->fused_grid > 0 && !w->compound && !w->dw.has_force_events && !w->dw.sleep_enabled && w->plan_no_global && w->plan_single && fl[FL_N_ISLANDS] > 0) ? 1 : 0;
+    w->plan_fused = (w->use_fused && w->fused_grid > 0 && !w->compound && !w->dw.has_force_events && !w->dw.sleep_enabled && !w->dw.has_sensors && w->plan_no_global && w->plan_single && fl[FL_N_ISLANDS] > 0) ? 1 : 0;
 }
 
 static int capture(rp_world *w, hipGraph_t *g, hipGraphExec_t *ge, void (*fn)(rp_world *)) {
@@ -1374,11 +1376,10 @@ static int step_once(rp_world *w, bool allow_fast) {
         }
     }
     // mode: fast graph only while the last observed steps were clean
-    // ... and so do worlds with sensors (their pairs are intersection-tested every step)
     // sleep-enabled worlds take the fast graph while bodies are awake, nothing is about to fall asleep and no wake-up is pending (all
     // three verified on the device: k_fast_front, k_sleep_check); position-based kinematic bodies need the per-step velocity pass
     const bool sleep_fast_ok = !w->dw.sleep_enabled || (!w->dw.has_kinematic_pos && pf[FL_N_AWAKE] > 0 && !pf[FL_WAKE_PENDING]);
-    bool fast = allow_fast && w->use_fast && sleep_fast_ok && !w->dw.has_sensors && w->plan_single && w->dw.n_colliders > 0 && w->steps_requested >= w->full_until;
+    bool fast = allow_fast && w->use_fast && sleep_fast_ok && w->plan_single && w->dw.n_colliders > 0 && w->steps_requested >= w->full_until;
     if (fast && (pf[FL_FAST_ABORT] || pf[FL_FULL_UPDATES] || pf[FL_LAYOUT_DIRTY] || pf[FL_TODO_COUNT])) {
         fast = false;
         w->full_until = w->steps_requested + 3;

@@ -544,26 +544,28 @@ __device__ __noinline__ bool shapes_intersect(int s1, float4 h1, int s2, float4 
     return dot(d, d) <= r * r;
 }
 
+// A sensor pair lives in the intersection graph (narrow_phase/intersections.rs:17-175): no manifold, no solver contact, no colour, no
+// wake-up; it is re-tested while one of its bodies may have moved and raises Started / Stopped | SENSOR on a change.
+__device__ __noinline__ void sensor_pair_update(DevWorld &w, int s, int c1, int c2, Pose pos12) {
+    const int rb1 = w.c_parent[c1], rb2 = w.c_parent[c2];
+    int pf = w.p_pflags[s] & ~RP_PF_RECYCLE;
+    const bool had_i = (pf & RP_PF_INTERSECTING) != 0;
+    const bool now_i = (rb1 == rb2 && rb1 >= 0) ? false : shapes_intersect(w.c_shape[c1], w.c_he[c1], w.c_shape[c2], w.c_he[c2], pos12);
+    w.p_npts[s] = 0; w.p_nsc[s] = 0;
+    if (now_i != had_i) {
+        pf ^= RP_PF_INTERSECTING;
+        if (pair_wants_collision_events(w, c1, c2)) push_collision_event(w, c1, c2, now_i ? 1 : 0, RP_COLLISION_EVENT_SENSOR, cur_step(w));
+    }
+    w.p_pflags[s] = pf;
+}
+
 // The full narrow-phase update of one pair (pair_update.rs:173-613).
 __device__ __noinline__ void pair_full_update(DevWorld &w, int s, int c1, int c2, Pose pc1, Pose pc2, Pose pos12) {
     const float prediction = w.prm.prediction;
     int rb1 = w.c_parent[c1], rb2 = w.c_parent[c2];
     int sh1 = w.c_shape[c1], sh2 = w.c_shape[c2];
     float4 he1 = w.c_he[c1], he2 = w.c_he[c2];
-    if (w.has_sensors && ((__float_as_int(w.c_events[c1].x) | __float_as_int(w.c_events[c2].x)) & RP_EVENTS_SENSOR_BIT)) {
-        // a sensor pair lives in the intersection graph (narrow_phase/intersections.rs:17-175): no manifold, no solver contact, no
-        // colour, no wake-up; it is re-tested while one of its bodies may have moved and raises Started / Stopped | SENSOR on a change
-        int pf = w.p_pflags[s] & ~RP_PF_RECYCLE;
-        const bool had_i = (pf & RP_PF_INTERSECTING) != 0;
-        const bool now_i = (rb1 == rb2 && rb1 >= 0) ? false : shapes_intersect(sh1, he1, sh2, he2, pos12);
-        w.p_npts[s] = 0; w.p_nsc[s] = 0;
-        if (now_i != had_i) {
-            pf ^= RP_PF_INTERSECTING;
-            if (pair_wants_collision_events(w, c1, c2)) push_collision_event(w, c1, c2, now_i ? 1 : 0, RP_COLLISION_EVENT_SENSOR, cur_step(w));
-        }
-        w.p_pflags[s] = pf;
-        return;
-    }
+    if (w.has_sensors && pair_is_sensor(w, c1, c2)) { sensor_pair_update(w, s, c1, c2, pos12); return; }
     int had = w.p_nsc[s] > 0;
     const bool no_contact = joints_disable_contacts(w, rb1, rb2); // pair_update.rs:191-201: clear_filtered_pair
 
@@ -764,6 +766,32 @@ __global__ void k_np_update(DevWorld w) {
         Pose pos12 = pose_inv_mul(pc1, pc2);
         pair_full_update(w, s, c1, c2, pc1, pc2, pos12);
     }
+}
+
+// Fast graph, worlds with sensors: k_fast_front leaves the sensor pairs alone (they hold no recycle state), this pass re-tests them
+// from the collider poses k_fast_front just refreshed — what the narrow phase of a full step would have done for them.  Runs only
+// once no later kernel of the graph can still abort the step.
+__global__ void k_sensor_pass(DevWorld w) {
+    if (w.flags[FL_FAST_ABORT]) return;
+    int top = w.flags[FL_POOL_TOP];
+    if (top > w.pool_cap) top = w.pool_cap;
+    int stride = gridDim.x * blockDim.x;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < top; s += stride) {
+        int c1 = w.p_c1[s];
+        if (c1 < 0) continue;
+        int c2 = w.p_c2[s];
+        if (!pair_is_sensor(w, c1, c2)) continue;
+        if (w.sleep_enabled) { int2 rb = w.p_rb[s]; if (!body_active(w, rb.x) && !body_active(w, rb.y)) continue; } // pair_update.rs:98-106
+        Pose pc1, pc2;
+        pc1.r = q4(w.c_rot[c1]); pc1.t = v3(w.c_pos[c1]);
+        pc2.r = q4(w.c_rot[c2]); pc2.t = v3(w.c_pos[c2]);
+        sensor_pair_update(w, s, c1, c2, pose_inv_mul(pc1, pc2));
+    }
+}
+void rp_launch_sensor_fast(const DevWorld &w, hipStream_t st) {
+    if (!w.has_sensors || w.n_colliders == 0) return;
+    int blocks = (w.pool_cap + 255) / 256; if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_sensor_pass, dim3(blocks), dim3(256), 0, st, w);
 }
 
 // the set of contact-disabling joints changed: every filtered pair is evaluated again by the next narrow phase

@@ -29,6 +29,7 @@ RP_DEV bool pair_selected(const DevWorld &w, int s) {
 RP_DEV bool pair_wants_collision_events(const DevWorld &w, int c1, int c2) {
     return ((__float_as_int(w.c_events[c1].x) | __float_as_int(w.c_events[c2].x)) & RP_EVENTS_COLLISION) != 0;
 }
+RP_DEV bool pair_is_sensor(const DevWorld &w, int c1, int c2) { return ((__float_as_int(w.c_events[c1].x) | __float_as_int(w.c_events[c2].x)) & RP_EVENTS_SENSOR_BIT) != 0; }
 RP_DEV void push_collision_event(const DevWorld &w, int c1, int c2, int started, int flags, int step) {
     int k = atomicAdd(&w.flags[FL_EV_COL], 1);
     if (k < w.ev_cap) w.ev_col[k] = make_int4(c1, c2, started | (flags << 8), step);
@@ -143,6 +144,7 @@ RP_DEV bool pair_needs_narrow_phase(const DevWorld &w, int s) {
     if (c1 < 0) return false;
     if (w.n_nc && (w.p_pflags[s] & RP_PF_NO_CONTACT)) return false; // filtered by a contact-disabling joint: nothing to compute
     int c2 = w.p_c2[s];
+    if (w.has_sensors && pair_is_sensor(w, c1, c2)) return false; // intersection-tested by k_sensor_pass on the fast graph
     int2 rb = w.p_rb[s];
     Pose pc1 = collider_world_pose_of(w, c1, rb.x), pc2 = collider_world_pose_of(w, c2, rb.y);
     Pose pos12 = pose_inv_mul(pc1, pc2);
