@@ -1249,7 +1249,9 @@ static void plan_from_hints(rp_world *w, const int *fl) {
 }
 
 static int capture(rp_world *w, hipGraph_t *g, hipGraphExec_t *ge, void (*fn)(rp_world *)) {
-    HIPCHK(w, hipStreamBeginCapture(w->stream, hipStreamCaptureModeThreadLocal));
+    // Relaxed: another host thread stepping another world on this device may issue synchronous HIP calls (hipMemcpy in settle())
+    // while this thread captures; only kernel launches on this world's own stream happen between Begin and End
+    HIPCHK(w, hipStreamBeginCapture(w->stream, hipStreamCaptureModeRelaxed));
     fn(w);
     HIPCHK(w, hipStreamEndCapture(w->stream, g));
     HIPCHK(w, hipGraphInstantiate(ge, *g, nullptr, nullptr, 0));
