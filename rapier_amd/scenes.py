@@ -663,3 +663,49 @@ def reference_cluster(seed: int, height: float = 6.0):
                          linvel=(float(np.fmod(a, f32(1.5)) - f32(0.75)), 0.0, float(np.fmod(b, f32(1.5)) - f32(0.75))), can_sleep=1)
         out.append((body, collider_desc(half_extents=(0.5, 0.5, 0.5))))
     return out
+
+
+def solve_groups_scene() -> Scene:
+    """Substep solve-groups (RigidBody::additional_solver_iterations; not a reference scene): a default-cadence stack, a jointed chain
+    whose heavy end ball carries 6 extra substeps (the joint lifts the whole chain), a 150:1 stack with 12 extra substeps on the heavy
+    cube riding a velocity-based kinematic platform (lifted to that group) — three groups with 4, 10 and 16 substeps."""
+    s = Scene(name="solve_groups", gravity=(0.0, -9.81, 0.0))
+    g = s.add_body(body_type=BODY_FIXED, translation=(0.0, -0.5, 0.0))
+    s.add_collider(g, half_extents=(100.0, 0.5, 100.0))
+    for i in range(4):
+        b = s.add_body(translation=(0.0, 0.5 + i * 1.0, 0.0))
+        s.add_collider(b, half_extents=(0.5, 0.5, 0.5))
+    prev = s.add_body(body_type=BODY_FIXED, translation=(30.0, 10.0, 0.0))
+    for i in range(5):
+        b = s.add_body(translation=(30.0 + (i + 1.0), 10.0, 0.0), additional_solver_iterations=6 if i == 4 else 0)
+        s.add_collider(b, shape=SHAPE_BALL, half_extents=(0.3, 0.0, 0.0), density=50.0 if i == 4 else 1.0)
+        s.add_joint(prev, b, (0.5, 0.0, 0.0), (-0.5, 0.0, 0.0), locked_axes=LOCK_LIN)
+        prev = b
+    plat = s.add_body(body_type=BODY_KINEMATIC_VELOCITY, translation=(-20.0, 2.0, 0.0), linvel=(0.3, 0.0, 0.0))
+    s.add_collider(plat, half_extents=(2.0, 0.25, 2.0))
+    lo = s.add_body(translation=(-20.0, 2.75, 0.0))
+    s.add_collider(lo, half_extents=(0.5, 0.5, 0.5), density=1.0)
+    hi = s.add_body(translation=(-20.0, 3.75, 0.0), additional_solver_iterations=12)
+    s.add_collider(hi, half_extents=(0.5, 0.5, 0.5), density=150.0, restitution=0.3)
+    return s
+
+
+def sensor_scene() -> Scene:
+    """Sensors (ColliderBuilder::sensor; not a reference scene): a cuboid trigger volume over the floor that a capsule, a box and a
+    ball fall through, a ball sensor riding a falling body, and a sensor part on a compound body."""
+    s = Scene(name="sensors", gravity=(0.0, -9.81, 0.0))
+    g = s.add_body(body_type=BODY_FIXED, translation=(0.0, -0.5, 0.0))
+    s.add_collider(g, half_extents=(100.0, 0.5, 100.0))
+    trig = s.add_body(body_type=BODY_FIXED, translation=(0.0, 3.0, 0.0))
+    s.add_collider(trig, half_extents=(4.0, 0.5, 4.0), active_events=ACTIVE_EVENTS_COLLISION, sensor=1)
+    cap = s.add_body(translation=(-2.0, 6.0, 0.0), rotation=(0.0, 0.0, 0.3428978, 0.9393727))
+    s.add_collider(cap, shape=SHAPE_CAPSULE, half_extents=(0.5, 0.25, 1.0))
+    box = s.add_body(translation=(0.0, 6.5, 0.0), rotation=(0.1435722, 0.1060205, 0.0342708, 0.9833474))
+    s.add_collider(box, half_extents=(0.3, 0.3, 0.3))
+    ball = s.add_body(translation=(2.0, 7.0, 0.0))
+    s.add_collider(ball, shape=SHAPE_BALL, half_extents=(0.3, 0.0, 0.0))
+    rider = s.add_body(translation=(0.5, 9.0, 0.5), gravity_scale=0.5)
+    s.add_collider(rider, half_extents=(0.25, 0.25, 0.25))
+    s.add_collider(rider, shape=SHAPE_BALL, half_extents=(0.9, 0.0, 0.0), density=0.0, sensor=1, active_events=ACTIVE_EVENTS_COLLISION)
+    return s
+

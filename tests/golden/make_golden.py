@@ -34,6 +34,9 @@ CASES = {
     "motorised_joints_s150": lambda: (S.motorised_joints(), 150),
     "capsules6_s150": lambda: (S.capsules(6), 150),
     "reference_pile_12x3x12_s100": lambda: (S.reference_pile(12, 3, 12, chain=True), 100),
+    # round 2: substep solve-groups (additional_solver_iterations) and sensors
+    "solve_groups_s150": lambda: (S.solve_groups_scene(), 150),
+    "sensors_s200": lambda: (S.sensor_scene(), 200),
 }
 
 
