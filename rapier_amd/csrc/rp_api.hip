@@ -29,6 +29,22 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <mutex>
+
+// HIP stream capture is process-wide in effect: while ANY thread captures, a synchronising runtime call from another thread
+// (hipMemcpy, hipMalloc, hipFree, hipHostMalloc ...) fails and poisons the capture, whatever the capture mode (measured on ROCm
+// 7.2: worlds stepped from several host threads broke each other's graph captures).  So the capture sections and those calls take
+// one process-wide lock; kernels, async copies on a world's own stream and stream / event waits stay outside it, so worlds still
+// overlap on the device.
+static std::mutex g_hip_unsafe_api;
+static inline hipError_t locked_hipMemcpy(void *dst, const void *src, size_t n, hipMemcpyKind k) { std::lock_guard<std::mutex> g(g_hip_unsafe_api); return hipMemcpy(dst, src, n, k); }
+static inline hipError_t locked_hipMallocBytes(void **p, size_t n) { std::lock_guard<std::mutex> g(g_hip_unsafe_api); return hipMalloc(p, n); }
+static inline hipError_t locked_hipFree(void *p) { std::lock_guard<std::mutex> g(g_hip_unsafe_api); return hipFree(p); }
+static inline hipError_t locked_hipHostMalloc(void **p, size_t n, unsigned flags) { std::lock_guard<std::mutex> g(g_hip_unsafe_api); return hipHostMalloc(p, n, flags); }
+static inline hipError_t locked_hipHostFree(void *p) { std::lock_guard<std::mutex> g(g_hip_unsafe_api); return hipHostFree(p); }
+#define hipMemcpy(dst, src, n, k) locked_hipMemcpy((void *)(dst), (const void *)(src), (n), (k))
+#define hipFree(p) locked_hipFree((void *)(p))
+#define hipHostFree(p) locked_hipHostFree((void *)(p))
 
 void rp_launch_collider_update(const DevWorld &w, hipStream_t st);
 void rp_launch_broadphase(const DevWorld &w, hipStream_t st);
@@ -314,6 +330,7 @@ extern "C" int32_t rp_world_create(const rp_integration_params *params, const fl
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RP_ERR_DEVICE; // no CPU fallback
     if (device < 0 || device >= ndev) return RP_ERR_DEVICE;
+    std::lock_guard<std::mutex> guard(g_hip_unsafe_api); // device queries and stream creation next to another world's graph capture
     rp_world *w = new rp_world();
     w->device = device;
     if (params) w->params = *params; else rp_default_params(&w->params);
@@ -772,7 +789,7 @@ template <typename T>
 static int dalloc(rp_world *w, T *&p, size_t count, int fill_byte = 0, int dom = DOM_NONE, int planes = 1, int per = 1) {
     void *q = nullptr;
     size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
-    if (hipMalloc(&q, bytes) != hipSuccess) { w->err = "hipMalloc failed"; return RP_ERR_DEVICE; }
+    if (locked_hipMallocBytes((void **)&q, bytes) != hipSuccess) { w->err = "hipMalloc failed"; return RP_ERR_DEVICE; }
     if (hipMemsetAsync(q, fill_byte, bytes, w->stream) != hipSuccess) { w->err = "hipMemset failed"; return RP_ERR_DEVICE; }
     AllocRec a; a.ptr = q; a.off = (size_t)((char *)&p - (char *)&w->dw); a.elem = sizeof(T); a.per = (size_t)per; a.planes = planes; a.dom = dom;
     a.stride = count / ((size_t)planes * (size_t)per);
@@ -1167,7 +1184,7 @@ static int finalize(rp_world *w) {
     std::vector<int> fl(FL_COUNT, 0);
     fl[FL_BP_DIRTY] = 1; fl[FL_LAYOUT_DIRTY] = 1; fl[FL_JOINT_DIRTY] = 1; fl[FL_FLOW_DIRTY] = 1;
     UP(d.flags, fl);
-    HIPCHK(w, hipHostMalloc((void **)&w->pinned_flags, FL_COUNT * sizeof(int), hipHostMallocMapped));
+    HIPCHK(w, locked_hipHostMalloc((void **)&w->pinned_flags, FL_COUNT * sizeof(int), hipHostMallocMapped));
     memset(w->pinned_flags, 0, FL_COUNT * sizeof(int));
     HIPCHK(w, hipHostGetDevicePointer((void **)&d.host_flags, w->pinned_flags, 0));
     if (w->carry) { int r = carry_over(w); if (r != RP_OK) return r; } // the rows of the previous device world move in; step counters keep running
@@ -1251,6 +1268,7 @@ static void plan_from_hints(rp_world *w, const int *fl) {
 static int capture(rp_world *w, hipGraph_t *g, hipGraphExec_t *ge, void (*fn)(rp_world *)) {
     // Relaxed: another host thread stepping another world on this device may issue synchronous HIP calls (hipMemcpy in settle())
     // while this thread captures; only kernel launches on this world's own stream happen between Begin and End
+    std::lock_guard<std::mutex> guard(g_hip_unsafe_api); // (fn only launches kernels on this world's stream)
     HIPCHK(w, hipStreamBeginCapture(w->stream, hipStreamCaptureModeRelaxed));
     fn(w);
     HIPCHK(w, hipStreamEndCapture(w->stream, g));

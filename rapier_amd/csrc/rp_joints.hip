@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(1024) k_joint_color(DevWorld w) {
                     if (b2 >= 0) atomicOr(&w.bj_cmask[4 * b2 + (color >> 5)], bit);
                 }
                 w.j_color[j] = color;
-                __threadfence(); // the mask bits are in L2 before a successor can be released
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the mask bits have reached L2 before a successor can be released (one workgroup, L2 atomics only: see k_color_pairs)
                 int next = -1;
                 if (su.x >= 0 && atomicSub(&w.jc_deps[su.x], 1) == 1) next = su.x;
                 if (su.y >= 0 && atomicSub(&w.jc_deps[su.y], 1) == 1) { if (next < 0) next = su.y; else qn[atomicAdd(&n_next, 1)] = su.y; }

@@ -916,11 +916,16 @@ __global__ void __launch_bounds__(1024) k_color_pairs(DevWorld w) {
             // a thread follows its pair's chain: the first successor it releases is coloured by the same thread at once (most of the
             // DAG is chains — body k's pairs one after the other), only further released successors wait in the queue for the next round
             int t = ld_i32a(&qc[f]);
+            int4 r = w.col_rec[t];
+            int2 su = w.col_succ[t];
             for (int hops = 0; t >= 0; ++hops) {
                 // (bounded: a thread that walked a long chain to its end would hold the round open while every other ready pair waits)
                 if (hops == RP_COLOR_CHAIN_HOPS) { qn[atomicAdd(&n_next, 1)] = t; break; }
-                const int4 r = w.col_rec[t];
-                const int2 su = w.col_succ[t];
+                // the records of both successors are fetched now, behind the mask / atomic round trips of this pair: a hop is three
+                // dependent L2 round trips instead of four
+                int4 rx = r, ry = r; int2 sx = su, sy = su;
+                if (su.x >= 0) { rx = w.col_rec[su.x]; sx = w.col_succ[su.x]; }
+                if (su.y >= 0) { ry = w.col_rec[su.y]; sy = w.col_succ[su.y]; }
                 const int b1 = r.x, b2 = r.y, s = r.w;
                 const bool d1 = b1 >= 0, d2 = b2 >= 0;
                 int color = 128;
@@ -940,11 +945,16 @@ __global__ void __launch_bounds__(1024) k_color_pairs(DevWorld w) {
                     w.p_color[s] = color;
                     w.p_colorb[s] = (d1 && d2) ? make_int2(b1, b2) : make_int2(d1 ? b1 : b2, -1);
                 }
-                __threadfence(); // the mask bits are in L2 before a successor can be released (its colourer reads them with L2 loads)
+                // the mask bits have reached L2 before a successor can be released: this kernel is ONE workgroup (one XCD's L2) and the
+                // masks are only ever touched by L2 atomics / L1-bypassing loads, so draining this wave's memory operations orders them —
+                // no agent-scope release (L2 write-back) per hop
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 // (when the same pair follows at both bodies it holds two predecessors' worth of this pair: the second decrement releases it)
-                int next = -1;
+                int next = -1; bool from_y = false;
                 if (su.x >= 0 && atomicSub(&w.col_deps[su.x], 1) == 1) next = su.x;
-                if (su.y >= 0 && atomicSub(&w.col_deps[su.y], 1) == 1) { if (next < 0) next = su.y; else qn[atomicAdd(&n_next, 1)] = su.y; }
+                if (su.y >= 0 && atomicSub(&w.col_deps[su.y], 1) == 1) { if (next < 0) { next = su.y; from_y = true; } else qn[atomicAdd(&n_next, 1)] = su.y; }
+                t = next;
+                if (from_y) { r = ry; su = sy; } else { r = rx; su = sx; }
                 t = next;
             }
         }
