@@ -187,6 +187,7 @@ __device__ __forceinline__ int hash_find(const unsigned long long *keys, const i
     return -1;
 }
 
+RP_DEV bool pair_touches_island(const DevWorld &w, int rb1, int rb2) { return (rb1 >= 0 && w.b_island[rb1] >= 0) || (rb2 >= 0 && w.b_island[rb2] >= 0); }
 // AddPair (NarrowPhase::add_pair, pair_management.rs:572): find-or-create the pair slot and
 // register it in the next-epoch table.  Each unordered pair reaches this exactly once per rebuild.
 __device__ void bp_insert_pair(DevWorld &w, int c1, int c2) {
@@ -202,7 +203,10 @@ __device__ void bp_insert_pair(DevWorld &w, int c1, int c2) {
         w.p_c1[slot] = c1; w.p_c2[slot] = c2; w.p_rb[slot] = make_int2(w.c_parent[c1], w.c_parent[c2]);
         w.p_color[slot] = RP_COLOR_UNCOLORED; w.p_nsc[slot] = 0; w.p_npts[slot] = 0; w.p_pflags[slot] = 0;
         w.p_reldom[slot] = 0; w.p_colorb[slot] = make_int2(-1, -1); w.p_conspos[slot] = -1; w.p_hint_seq[slot] = 0;
-        w.flags[FL_LAYOUT_DIRTY] = 1; // the island lists also hold the pairs without solver contacts
+        // the lists of an LDS island also hold its pairs WITHOUT solver contacts (the fused step recycle-tests them): a new pair
+        // changes the layout only when one of its bodies lives in such an island — not when both sit on the global path (the
+        // creeping 20,100-body island of b3d_large_pyramid gains and loses near-miss pairs every step)
+        if (pair_touches_island(w, w.c_parent[c1], w.c_parent[c2])) w.flags[FL_LAYOUT_DIRTY] = 1;
     }
     w.p_stamp[slot] = epoch + 1;
     int h = (int)(rp_hash64(key) & (unsigned long long)(w.hash_cap - 1));
@@ -273,7 +277,10 @@ RP_DEV void bp_finish_pairs(DevWorld &w, int gid, int gstride) {
             if (cb.x >= 0) atomicAnd(&w.b_cmask[4 * cb.x + (color >> 5)], ~bit);
             if (cb.y >= 0) atomicAnd(&w.b_cmask[4 * cb.y + (color >> 5)], ~bit);
         }
-        w.flags[FL_LAYOUT_DIRTY] = 1;
+        { // a dead pair changes the layout when it was a solver manifold or when an LDS island lists it (see bp_insert_pair)
+            int2 drb = w.p_rb[s];
+            if (w.p_nsc[s] > 0 || pair_touches_island(w, drb.x, drb.y)) w.flags[FL_LAYOUT_DIRTY] = 1;
+        }
         if (w.p_nsc[s] > 0 && pair_wants_collision_events(w, w.p_c1[s], w.p_c2[s])) {
             // Stopped event of a touching pair: remove_pair (pair_management.rs:554-558), remove_collider (:101-110, REMOVED)
             uint2 e1 = w.c_groups[w.p_c1[s]], e2 = w.c_groups[w.p_c2[s]];
