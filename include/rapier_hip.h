@@ -63,7 +63,10 @@ enum { RP_FRICTION_SIMPLIFIED = 0, RP_FRICTION_COULOMB = 1 };
 /* RigidBodyType — rigid_body_components.rs */
 enum { RP_BODY_DYNAMIC = 0, RP_BODY_FIXED = 1, RP_BODY_KINEMATIC_POSITION = 2, RP_BODY_KINEMATIC_VELOCITY = 3 };
 enum { RP_SHAPE_BALL = 0, RP_SHAPE_CUBOID = 1,
-       RP_SHAPE_CAPSULE = 2 /* ColliderBuilder::capsule_x/y/z (collider.rs): half_extents = (half_height, radius, axis 0|1|2) */ };
+       RP_SHAPE_CAPSULE = 2 /* ColliderBuilder::capsule_x/y/z (collider.rs): half_extents = (half_height, radius, axis 0|1|2) */,
+       RP_SHAPE_HALFSPACE = 3 /* ColliderBuilder::halfspace(outward_normal): half_extents = the unit normal in the collider's frame; the
+                                 solid side is dot(normal, p) <= 0.  Parent: none, a fixed or a kinematic body (an unbounded shape
+                                 on a dynamic body is refused); weighs nothing (MassProperties::zero) */ };
 enum { RP_RULE_AVERAGE = 0, RP_RULE_MIN, RP_RULE_MULTIPLY, RP_RULE_MAX, RP_RULE_CLAMPED_SUM, RP_RULE_GEOMETRIC_MEAN };
 
 /* RigidBodyBuilder — /root/reference/src/dynamics/rigid_body.rs:1560-1900 */

@@ -332,6 +332,8 @@ static void shape_mass_props(const Collider *c, float density, float *mass, v3 *
         /* rotation_between(Y, segment direction): -90 deg about Z for the X axis, +90 deg about X for the Z axis */
         if (c->axis == 0) { frame[2] = -0.70710678118654752f; frame[3] = 0.70710678118654752f; }
         else if (c->axis == 2) { frame[0] = 0.70710678118654752f; frame[3] = 0.70710678118654752f; }
+    } else if (c->shape == RO_SHAPE_HALFSPACE) {
+        *mass = 0.0f; *principal_inertia = V3(0, 0, 0); /* MassProperties::zero(): an unbounded shape weighs nothing */
     } else {
         float r = c->radius;
         float vol = 3.14159265358979323846f * r * r * r * 4.0f / 3.0f;
@@ -344,6 +346,7 @@ static void shape_mass_props(const Collider *c, float density, float *mass, v3 *
 static float shape_bounding_radius(const Collider *c) {
     if (c->shape == RO_SHAPE_CUBOID) return vlen(c->he);
     if (c->shape == RO_SHAPE_CAPSULE) return c->he.x + c->radius;
+    if (c->shape == RO_SHAPE_HALFSPACE) return FLT_MAX;
     return c->radius;
 }
 
@@ -698,6 +701,10 @@ static Aabb collider_collision_aabb(const Collider *c, float loosen) {
         v3 r = V3(c->radius, c->radius, c->radius);
         a.mins = vsub(V3(ro_minf(pa.x, pb.x), ro_minf(pa.y, pb.y), ro_minf(pa.z, pb.z)), r);
         a.maxs = vadd(V3(ro_maxf(pa.x, pb.x), ro_maxf(pa.y, pb.y), ro_maxf(pa.z, pb.z)), r);
+    } else if (c->shape == RO_SHAPE_HALFSPACE) {
+        /* HalfSpace::aabb: half of the float range in every direction, wherever the plane is ("so that we can still loosen it") */
+        v3 h = V3(FLT_MAX / 2.0f, FLT_MAX / 2.0f, FLT_MAX / 2.0f);
+        a.mins = vneg(h); a.maxs = h;
     } else {
         v3 h = V3(c->radius, c->radius, c->radius);
         a.mins = vsub(c->pos.t, h); a.maxs = vadd(c->pos.t, h);
@@ -941,6 +948,7 @@ static float relative_pose_drift(pose base, pose cur, float max_extent) {
 static float collider_origin_radius(const Collider *c) {
     if (c->shape == RO_SHAPE_CUBOID) return vlen(c->he); /* max(|mins|,|maxs|) of the local AABB */
     if (c->shape == RO_SHAPE_CAPSULE) { v3 h = V3(c->radius, c->radius, c->radius); vset(&h, c->axis, c->he.x + c->radius); return vlen(h); }
+    if (c->shape == RO_SHAPE_HALFSPACE) return INFINITY; /* |(MAX/2, MAX/2, MAX/2)| overflows: a pair with a half-space never recycles */
     return vlen(V3(c->radius, c->radius, c->radius));
 }
 
@@ -1015,8 +1023,22 @@ static float point_box_dist2(v3 p, v3 he) {
 static int shapes_intersect(const Collider *c1, const Collider *c2) {
     pose pos12 = pose_inv_mul(c1->pos, c2->pos);
     int s1 = c1->shape, s2 = c2->shape;
-    if (s1 > s2) { /* order the pair: ball < cuboid < capsule */
+    if (s1 > s2) { /* order the pair: ball < cuboid < capsule < half-space */
         const Collider *t = c1; c1 = c2; c2 = t; pos12 = pose_inv(pos12); s1 = c1->shape; s2 = c2->shape;
+    }
+    if (s2 == RO_SHAPE_HALFSPACE) {
+        /* intersection_test_support_map_halfspace: the shape's support point toward -normal lies in the solid side.
+         * pos12 = the half-space in shape 1's frame here: work in the half-space's frame */
+        pose pos21 = pose_inv(pos12);
+        v3 n = c2->he, dir = qrot_inv(pos21.r, vneg(n)), sp;
+        if (s1 == RO_SHAPE_HALFSPACE) return 0; /* unsupported pair in parry: never intersecting */
+        if (s1 == RO_SHAPE_BALL) sp = vmul(dir, c1->radius);
+        else if (s1 == RO_SHAPE_CUBOID) sp = cuboid_support_point(c1->he, dir);
+        else {
+            v3 e = capsule_axis_dir(c1->axis), a = vmul(e, -c1->he.x), b = vmul(e, c1->he.x);
+            sp = vadd(vdot(dir, a) > vdot(dir, b) ? a : b, vmul(dir, c1->radius));
+        }
+        return vdot(n, pose_tp(pos21, sp)) <= 0.0f;
     }
     if (s1 == RO_SHAPE_BALL && s2 == RO_SHAPE_BALL) { float r = c1->radius + c2->radius; return vdot(pos12.t, pos12.t) <= r * r; }
     if (s1 == RO_SHAPE_BALL && s2 == RO_SHAPE_CUBOID) { v3 c = pose_itp(pos12, V3(0, 0, 0)); return point_box_dist2(c, c2->he) <= c1->radius * c1->radius; }
@@ -1100,7 +1122,15 @@ static int process_pair(ro_world *w, int pair_idx, Transition *tr_out) {
 
     /* :323-330 parry DefaultQueryDispatcher::contact_manifolds */
     int s1 = co1->shape, s2 = co2->shape;
-    if (s1 == RO_SHAPE_CUBOID && s2 == RO_SHAPE_CUBOID) manifold_cuboid_cuboid(pos12, co1->he, co2->he, eff_prediction, &p->m);
+    if (s1 == RO_SHAPE_HALFSPACE || s2 == RO_SHAPE_HALFSPACE) {
+        /* (_, Ball) | (Ball, _) -> convex_ball comes before (HalfSpace, pfm) | (pfm, HalfSpace) in the dispatcher */
+        if (s1 == RO_SHAPE_HALFSPACE && s2 == RO_SHAPE_HALFSPACE) p->m.npoints = 0; /* Unsupported */
+        else if (s1 == RO_SHAPE_HALFSPACE && s2 == RO_SHAPE_BALL) manifold_halfspace_ball(pos12, co1->he, co2->radius, eff_prediction, &p->m, 0);
+        else if (s2 == RO_SHAPE_HALFSPACE && s1 == RO_SHAPE_BALL) manifold_halfspace_ball(pose_inv(pos12), co2->he, co1->radius, eff_prediction, &p->m, 1);
+        else if (s1 == RO_SHAPE_HALFSPACE) manifold_halfspace_pfm(pos12, co1->he, s2 == RO_SHAPE_CAPSULE, co2->he, co2->he.x, co2->radius, co2->axis, eff_prediction, &p->m, 0);
+        else manifold_halfspace_pfm(pose_inv(pos12), co2->he, s1 == RO_SHAPE_CAPSULE, co1->he, co1->he.x, co1->radius, co1->axis, eff_prediction, &p->m, 1);
+    }
+    else if (s1 == RO_SHAPE_CUBOID && s2 == RO_SHAPE_CUBOID) manifold_cuboid_cuboid(pos12, co1->he, co2->he, eff_prediction, &p->m);
     else if (s1 == RO_SHAPE_BALL && s2 == RO_SHAPE_BALL) manifold_ball_ball(pos12, co1->radius, co2->radius, eff_prediction, &p->m);
     else if (s1 == RO_SHAPE_CAPSULE && s2 == RO_SHAPE_CAPSULE) manifold_capsule_capsule(pos12, co1->he.x, co1->radius, co1->axis, co2->he.x, co2->radius, co2->axis, eff_prediction, &p->m);
     else if (s1 == RO_SHAPE_CUBOID && s2 == RO_SHAPE_CAPSULE) manifold_cuboid_capsule(pos12, pos12, co1->he, co2->he.x, co2->radius, co2->axis, eff_prediction, &p->m, 0);

@@ -329,19 +329,31 @@ static inline void manifold_ball_ball(pose pos12, float r1, float r2, float pred
     }
 }
 
-/* contact_manifold_convex_ball with shape1 = cuboid; `flipped` = the ball is collider 1. */
+/* contact_manifold_convex_ball with shape1 = cuboid; `flipped` = the ball is collider 1.  The projection is the NON-solid one
+ * (project_local_point(.., false)): a centre inside the cuboid projects onto the nearest face and the normal / distance are negated
+ * (`proj.is_inside`), so a deeply penetrating ball is pushed back out through that face. */
 static inline void manifold_cuboid_ball(pose pos12, v3 he1, float r2, float prediction, Manifold *m, int flipped) {
     v3 pt = pos12.t;
-    /* Aabb::project_local_point(solid = true) */
+    /* Aabb::project_local_point */
     v3 mins_pt = vsub(vneg(he1), pt), pt_maxs = vsub(pt, he1);
     v3 shift = V3(ro_maxf(mins_pt.x, 0) - ro_maxf(pt_maxs.x, 0), ro_maxf(mins_pt.y, 0) - ro_maxf(pt_maxs.y, 0),
                   ro_maxf(mins_pt.z, 0) - ro_maxf(pt_maxs.z, 0));
     int inside = (shift.x == 0.0f && shift.y == 0.0f && shift.z == 0.0f);
-    v3 proj = inside ? pt : vadd(pt, shift);
+    if (inside) { /* nearest face: the largest (closest to zero) of the six negative slacks */
+        float best = -FLT_MAX; int best_id = 0, is_mins = 0;
+        for (int i = 0; i < 3; ++i) {
+            float mp = vget(mins_pt, i), pm = vget(pt_maxs, i);
+            if (mp < pm) { if (pm > best) { best_id = i; is_mins = 0; best = pm; } }
+            else if (mp > best) { best_id = i; is_mins = 1; best = mp; }
+        }
+        shift = V3(0, 0, 0); vset(&shift, best_id, is_mins ? best : -best);
+    }
+    v3 proj = vadd(pt, shift);
     v3 dpos = vsub(pt, proj);
     float dist = vlen(dpos);
-    if (!(dist > 0.0f)) return; /* centre inside the solid cuboid: manifold left untouched */
+    if (!(dist > 0.0f)) return; /* Unit::try_new_and_get(dpos, 0.0) fails: manifold left untouched */
     v3 n1 = vmul(dpos, 1.0f / dist);
+    if (inside) { n1 = vneg(n1); dist = -dist; }
     if (dist <= r2 + prediction) {
         v3 n2 = qrot_inv(pos12.r, vneg(n1));
         v3 p2 = vmul(n2, r2);
@@ -413,20 +425,22 @@ static inline void manifold_capsule_capsule(pose pos12, float hh1, float r1, int
         m->local_n1 = n1; m->local_n2 = n2;
     } else m->npoints = 0;
 }
-/* contact_manifold_convex_ball with shape1 = capsule (Capsule::project_local_point, solid); `flipped` = the ball is collider 1 */
+/* contact_manifold_convex_ball with shape1 = capsule (Capsule::project_local_point, non-solid: a centre inside the capsule projects
+ * onto its surface along the direction from the segment, normal and distance negated); `flipped` = the ball is collider 1 */
 static inline void manifold_capsule_ball(pose pos12, float hh1, float r1, int axis1, float r2, float prediction, Manifold *m, int flipped) {
     v3 e1 = capsule_axis_dir(axis1);
     v3 pt = pos12.t;
     v3 sp = segment_project_point(vmul(e1, -hh1), vmul(e1, hh1), pt);
     v3 dproj = vsub(pt, sp);
     float dseg = vlen(dproj);
-    if (!(dseg > FLT_EPSILON) || dseg <= r1) return; /* centre inside the solid capsule: manifold left untouched */
-    v3 dir = vmul(dproj, 1.0f / dseg);
-    v3 proj = vadd(sp, vmul(dir, r1));
+    int inside; v3 proj;
+    if (dseg > FLT_EPSILON) { inside = dseg <= r1; proj = vadd(sp, vmul(vmul(dproj, 1.0f / dseg), r1)); }
+    else { inside = 1; proj = vadd(sp, V3(0, r1, 0)); } /* centre on the segment: pushed along +Y */
     v3 dpos = vsub(pt, proj);
     float dist = vlen(dpos);
     if (!(dist > 0.0f)) return;
     v3 n1 = vmul(dpos, 1.0f / dist);
+    if (inside) { n1 = vneg(n1); dist = -dist; }
     if (dist <= r2 + prediction) {
         v3 n2 = qrot_inv(pos12.r, vneg(n1));
         v3 p2 = vmul(n2, r2);
@@ -545,6 +559,64 @@ static inline void manifold_cuboid_capsule(pose pos12, pose upd, v3 he1, float h
         m->points[m->npoints++] = c;
     }
     if (flipped) { m->local_n1 = n2; m->local_n2 = best_dir; } else { m->local_n1 = best_dir; m->local_n2 = n2; }
+    for (int i = 0; i < m->npoints; ++i)
+        for (int j = 0; j < nold; ++j)
+            if (m->points[i].fid1 == old[j].fid1 && m->points[i].fid2 == old[j].fid2)
+                m->points[i].data = old[j].data;
+}
+/* ---- half-spaces (parry shape::HalfSpace{normal}: the solid region dot(normal, p) <= 0 of the collider's frame;
+ * ColliderBuilder::halfspace(outward_normal), collider.rs) ---- */
+/* contact_manifold_convex_ball with shape1 = half-space: HalfSpace::project_local_point(pt, false) = pt - normal * dot(normal, pt),
+ * is_inside = dot <= 0; the contact normal is always the plane's, the distance is signed.  `flipped` = the ball is collider 1 */
+static inline void manifold_halfspace_ball(pose pos12, v3 normal1, float r2, float prediction, Manifold *m, int flipped) {
+    v3 pt = pos12.t;
+    float dd = vdot(normal1, pt);
+    v3 proj = vadd(pt, vmul(vneg(normal1), dd));
+    v3 dpos = vsub(pt, proj);
+    float dist = vlen(dpos);
+    if (!(dist > 0.0f)) return;
+    v3 n1 = vmul(dpos, 1.0f / dist);
+    if (dd <= 0.0f) { n1 = vneg(n1); dist = -dist; }
+    if (dist <= r2 + prediction) {
+        v3 n2 = qrot_inv(pos12.r, vneg(n1));
+        v3 p2 = vmul(n2, r2);
+        float d = dist - r2;
+        v3 a = flipped ? p2 : proj, b = flipped ? proj : p2;
+        if (m->npoints != 1) { m->npoints = 0; manifold_push(m, a, b, RO_FID_UNKNOWN, RO_FID_UNKNOWN, d); }
+        else { m->points[0].local_p1 = a; m->points[0].local_p2 = b; m->points[0].dist = d; }
+        if (flipped) { m->local_n1 = n2; m->local_n2 = n1; } else { m->local_n1 = n1; m->local_n2 = n2; }
+    } else m->npoints = 0;
+}
+/* contact_manifold_halfspace_pfm: shape2 = a cuboid (support face toward the plane, border radius 0) or a capsule (its segment, both
+ * end points, border radius = the capsule's); every feature vertex within `prediction` of the plane is a contact.  No
+ * try_update_contacts in this generator: the points are recomputed on every full update and matched by feature id.
+ * `pos12` = pose of shape 2 in the half-space's frame; `flipped` = the half-space is collider 2 */
+static inline void manifold_halfspace_pfm(pose pos12, v3 normal1, int shape2_is_capsule, v3 he2, float hh2, float r2, int axis2, float prediction, Manifold *m, int flipped) {
+    v3 normal1_2 = qrot_inv(pos12.r, normal1);
+    v3 vtx[4]; uint32_t vid[4]; int nv; float border = 0.0f;
+    if (shape2_is_capsule) {
+        v3 e2 = capsule_axis_dir(axis2);
+        vtx[0] = vmul(e2, -hh2); vtx[1] = vmul(e2, hh2); vid[0] = 0u; vid[1] = 2u; nv = 2; border = r2;
+    } else {
+        PolyFace f = cuboid_support_face(he2, vneg(normal1_2));
+        for (int i = 0; i < 4; ++i) { vtx[i] = f.vertices[i]; vid[i] = f.vids[i]; }
+        nv = 4;
+    }
+    TrackedContact old[RO_MAX_MANIFOLD_PTS]; int nold = m->npoints;
+    memcpy(old, m->points, sizeof(old));
+    m->npoints = 0;
+    for (int i = 0; i < nv; ++i) {
+        v3 vtx2_1 = pose_tp(pos12, vtx[i]);
+        float dist_to_plane = vdot(vtx2_1, normal1);
+        if (dist_to_plane - border <= prediction) {
+            v3 p1 = vsub(vtx2_1, vmul(normal1, dist_to_plane));
+            v3 p2 = vsub(vtx[i], vmul(normal1_2, border));
+            if (flipped) manifold_push(m, p2, p1, vid[i], 0u, dist_to_plane - border);
+            else manifold_push(m, p1, p2, 0u, vid[i], dist_to_plane - border);
+        }
+    }
+    if (flipped) { m->local_n1 = vneg(normal1_2); m->local_n2 = normal1; }
+    else { m->local_n1 = normal1; m->local_n2 = vneg(normal1_2); }
     for (int i = 0; i < m->npoints; ++i)
         for (int j = 0; j < nold; ++j)
             if (m->points[i].fid1 == old[j].fid1 && m->points[i].fid2 == old[j].fid2)

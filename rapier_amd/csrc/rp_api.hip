@@ -406,6 +406,7 @@ extern "C" int32_t rp_num_bodies(const rp_world *w) { return w ? (int32_t)w->bod
 static float shape_bounding_radius(const rp_collider_desc &c) { // Shape::compute_local_bounding_sphere
     if (c.shape == RP_SHAPE_CUBOID) return std::sqrt(c.half_extents[0] * c.half_extents[0] + c.half_extents[1] * c.half_extents[1] + c.half_extents[2] * c.half_extents[2]);
     if (c.shape == RP_SHAPE_CAPSULE) return c.half_extents[0] + c.half_extents[1];
+    if (c.shape == RP_SHAPE_HALFSPACE) return 3.402823466e+38f;
     return c.half_extents[0];
 }
 static void shape_mass_props(const rp_collider_desc &c, float density, float &mass, float pi[3], float frame[4]) {
@@ -434,6 +435,8 @@ static void shape_mass_props(const rp_collider_desc &c, float density, float &ma
         int axis = (int)c.half_extents[2];
         if (axis == 0) { frame[2] = -0.70710678118654752f; frame[3] = 0.70710678118654752f; }
         else if (axis == 2) { frame[0] = 0.70710678118654752f; frame[3] = 0.70710678118654752f; }
+    } else if (c.shape == RP_SHAPE_HALFSPACE) { // MassProperties::zero(): an unbounded shape weighs nothing
+        mass = 0.0f; pi[0] = pi[1] = pi[2] = 0.0f;
     } else {
         float r = c.half_extents[0];
         volatile float vol = 3.14159265358979323846f * r * r * r * 4.0f / 3.0f;
@@ -607,6 +610,7 @@ static void recompute_mass(rp_world *w, int body) {
     for (size_t i = 0; i < w->colliders.size(); ++i) {
         if (w->collider_parent[i] != body || w->collider_removed[i]) continue;
         const rp_collider_desc &c = w->colliders[i];
+        if (c.shape == RP_SHAPE_HALFSPACE) continue; // Shape::ccd_thickness of a half-space is f32::MAX
         float th = c.shape == RP_SHAPE_BALL ? c.half_extents[0] : c.shape == RP_SHAPE_CAPSULE ? c.half_extents[1] : std::min(c.half_extents[0], std::min(c.half_extents[1], c.half_extents[2]));
         b.ccd_thickness = std::min(b.ccd_thickness, th);
     }
@@ -722,7 +726,15 @@ extern "C" int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider
     if (!w || n < 0 || (n > 0 && !descs)) return RP_ERR_INVALID;
     for (int i = 0; i < n; ++i) {
         const rp_collider_desc &cd = descs[i];
-        if (cd.shape != RP_SHAPE_BALL && cd.shape != RP_SHAPE_CUBOID && cd.shape != RP_SHAPE_CAPSULE) { w->err = "rp_colliders_insert: unknown shape (ball, cuboid and capsule are implemented)"; return RP_ERR_INVALID; }
+        if (cd.shape != RP_SHAPE_BALL && cd.shape != RP_SHAPE_CUBOID && cd.shape != RP_SHAPE_CAPSULE && cd.shape != RP_SHAPE_HALFSPACE) { w->err = "rp_colliders_insert: unknown shape (ball, cuboid, capsule and half-space are implemented)"; return RP_ERR_INVALID; }
+        if (cd.shape == RP_SHAPE_HALFSPACE) {
+            const float *nn = cd.half_extents; const float l2 = nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2];
+            if (!(std::fabs(l2 - 1.0f) <= 1.0e-3f)) { w->err = "rp_colliders_insert: a half-space's half_extents hold its unit outward normal"; return RP_ERR_INVALID; }
+            if (parents && parents[i] != RP_INVALID_HANDLE) {
+                const int pb = handle_index(parents[i]);
+                if (pb >= 0 && pb < (int)w->bodies.size() && w->bodies[pb].d.body_type == RP_BODY_DYNAMIC) { w->err = "rp_colliders_insert: a half-space needs a fixed or kinematic parent (or none)"; return RP_ERR_INVALID; }
+            }
+        }
         if (cd.shape == RP_SHAPE_CAPSULE && (cd.half_extents[2] != 0.0f && cd.half_extents[2] != 1.0f && cd.half_extents[2] != 2.0f)) { w->err = "rp_colliders_insert: capsule half_extents = (half_height, radius, axis) with axis 0, 1 or 2"; return RP_ERR_INVALID; }
     }
     const bool in_place = w->finalized && (int)w->colliders.size() + n <= w->cap_colliders; // see rp_bodies_insert
@@ -1030,6 +1042,7 @@ static int finalize(rp_world *w) {
     float margin = 2.0f * (pred * 0.5f + 4.0e-2f * w->params.length_unit);
     std::vector<float> ext;
     for (auto &c : w->colliders) {
+        if (c.shape == RP_SHAPE_HALFSPACE) continue; // unbounded: always on the broad phase's large list
         float r = shape_bounding_radius(c);
         ext.push_back(2.0f * r + margin);
     }

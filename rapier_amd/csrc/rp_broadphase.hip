@@ -32,7 +32,9 @@ __device__ __forceinline__ CellRange cell_range(const DevWorld &w, int i) {
     float ic = w.prm.inv_cell_size;
     r.lo[0] = cell_coord(mn.x, ic); r.lo[1] = cell_coord(mn.y, ic); r.lo[2] = cell_coord(mn.z, ic);
     r.hi[0] = cell_coord(mx.x, ic); r.hi[1] = cell_coord(mx.y, ic); r.hi[2] = cell_coord(mx.z, ic);
-    r.large = (r.hi[0] - r.lo[0] > 2) || (r.hi[1] - r.lo[1] > 2) || (r.hi[2] - r.lo[2] > 2);
+    // (an unbounded AABB — a half-space — saturates the cell coordinates: sized from the floats, not from their difference)
+    const bool unbounded = (mx.x - mn.x) * ic > 1.0e6f || (mx.y - mn.y) * ic > 1.0e6f || (mx.z - mn.z) * ic > 1.0e6f;
+    r.large = unbounded || (r.hi[0] - r.lo[0] > 2) || (r.hi[1] - r.lo[1] > 2) || (r.hi[2] - r.lo[2] > 2);
     return r;
 }
 

@@ -246,17 +246,14 @@ __device__ void manifold_ball_ball(Pose pos12, float r1, float r2, float predict
         m.ln1 = n1; m.ln2 = n2;
     } else m.n = 0;
 }
-// contact_manifold_convex_ball with shape1 = cuboid (solid projection); flipped = ball is collider 1
-__device__ void manifold_cuboid_ball(Pose pos12, V3 he1, float r2, float prediction, LocalManifold &m, bool flipped) {
-    V3 pt = pos12.t;
-    V3 shift = v3(rp_max(-he1.x - pt.x, 0.0f) - rp_max(pt.x - he1.x, 0.0f), rp_max(-he1.y - pt.y, 0.0f) - rp_max(pt.y - he1.y, 0.0f),
-                  rp_max(-he1.z - pt.z, 0.0f) - rp_max(pt.z - he1.z, 0.0f));
-    bool inside = shift.x == 0.0f && shift.y == 0.0f && shift.z == 0.0f;
-    V3 proj = inside ? pt : pt + shift;
+// the tail every convex-vs-ball generator shares (contact_manifold_convex_ball): proj = the ball centre projected on shape 1
+// (non-solid), inside = the centre lies in shape 1 (normal and distance negated)
+RP_DEV void convex_ball_finish(Pose pos12, V3 pt, V3 proj, bool inside, float r2, float prediction, LocalManifold &m, bool flipped) {
     V3 dpos = pt - proj;
     float dist = len(dpos);
-    if (!(dist > 0.0f)) return;
+    if (!(dist > 0.0f)) return; // Unit::try_new_and_get(dpos, 0.0) fails: manifold left untouched
     V3 n1 = dpos * (1.0f / dist);
+    if (inside) { n1 = -n1; dist = -dist; }
     if (dist <= r2 + prediction) {
         V3 n2 = qrot_inv(pos12.r, -n1);
         V3 p2 = n2 * r2;
@@ -268,7 +265,26 @@ __device__ void manifold_cuboid_ball(Pose pos12, V3 he1, float r2, float predict
         if (flipped) { m.ln1 = n2; m.ln2 = n1; } else { m.ln1 = n1; m.ln2 = n2; }
     } else m.n = 0;
 }
-
+// contact_manifold_convex_ball with shape1 = cuboid (Aabb::project_local_point, non-solid: a centre inside the cuboid projects onto the
+// nearest face); flipped = ball is collider 1
+__device__ void manifold_cuboid_ball(Pose pos12, V3 he1, float r2, float prediction, LocalManifold &m, bool flipped) {
+    V3 pt = pos12.t;
+    V3 mins_pt = -he1 - pt, pt_maxs = pt - he1;
+    V3 shift = v3(rp_max(mins_pt.x, 0.0f) - rp_max(pt_maxs.x, 0.0f), rp_max(mins_pt.y, 0.0f) - rp_max(pt_maxs.y, 0.0f),
+                  rp_max(mins_pt.z, 0.0f) - rp_max(pt_maxs.z, 0.0f));
+    bool inside = shift.x == 0.0f && shift.y == 0.0f && shift.z == 0.0f;
+    if (inside) { // nearest face: the largest (closest to zero) of the six negative slacks
+        float best = -FLT_MAX; int best_id = 0; bool is_mins = false;
+        for (int i = 0; i < 3; ++i) {
+            float mp = comp(mins_pt, i), pm = comp(pt_maxs, i);
+            if (mp < pm) { if (pm > best) { best_id = i; is_mins = false; best = pm; } }
+            else if (mp > best) { best_id = i; is_mins = true; best = mp; }
+        }
+        const float sv = is_mins ? best : -best;
+        shift = v3(best_id == 0 ? sv : 0.0f, best_id == 1 ? sv : 0.0f, best_id == 2 ? sv : 0.0f);
+    }
+    convex_ball_finish(pos12, pt, pt + shift, inside, r2, prediction, m, flipped);
+}
 // ---- capsules (parry shape::Capsule = segment [a, b] + radius; c_he = (half_height, radius, axis)) — restated like oracle/ro_shapes.h ----
 RP_DEV V3 segment_project_point(V3 a, V3 b, V3 pt) { // Segment::project_local_point
     V3 ab = b - a, ap = pt - a;
@@ -318,30 +334,58 @@ __device__ void manifold_capsule_capsule(Pose pos12, float4 c1, float4 c2, float
         m.ln1 = n1; m.ln2 = n2;
     } else m.n = 0;
 }
-// contact_manifold_convex_ball with shape1 = capsule (Capsule::project_local_point, solid); flipped = the ball is collider 1
+// contact_manifold_convex_ball with shape1 = capsule (Capsule::project_local_point, non-solid: a centre inside the capsule projects
+// onto its surface along the direction from the segment); flipped = the ball is collider 1
 __device__ void manifold_capsule_ball(Pose pos12, float4 c1, float r2, float prediction, LocalManifold &m, bool flipped) {
     V3 e1 = capsule_axis_dir((int)c1.z);
     V3 pt = pos12.t;
     V3 sp = segment_project_point(e1 * -c1.x, e1 * c1.x, pt);
     V3 dproj = pt - sp;
     float dseg = len(dproj);
-    if (!(dseg > FLT_EPSILON) || dseg <= c1.y) return;
-    V3 dir = dproj * (1.0f / dseg);
-    V3 proj = sp + dir * c1.y;
-    V3 dpos = pt - proj;
-    float dist = len(dpos);
-    if (!(dist > 0.0f)) return;
-    V3 n1 = dpos * (1.0f / dist);
-    if (dist <= r2 + prediction) {
-        V3 n2 = qrot_inv(pos12.r, -n1);
-        V3 p2 = n2 * r2;
-        int keep = m.n == 1 ? 0 : -1;
-        m.n = 1;
-        m.lp1[0] = flipped ? p2 : proj; m.lp2[0] = flipped ? proj : p2; m.dist[0] = dist - r2;
-        if (keep < 0) m.fid[0] = RP_FID_UNKNOWN | (RP_FID_UNKNOWN << 16);
-        m.src[0] = keep;
-        if (flipped) { m.ln1 = n2; m.ln2 = n1; } else { m.ln1 = n1; m.ln2 = n2; }
-    } else m.n = 0;
+    bool inside; V3 proj;
+    if (dseg > FLT_EPSILON) { inside = dseg <= c1.y; proj = sp + (dproj * (1.0f / dseg)) * c1.y; }
+    else { inside = true; proj = sp + v3(0, c1.y, 0); } // centre on the segment: pushed along +Y
+    convex_ball_finish(pos12, pt, proj, inside, r2, prediction, m, flipped);
+}
+// ---- half-spaces (parry shape::HalfSpace{normal}; c_he = the unit outward normal) — restated like oracle/ro_shapes.h ----
+// contact_manifold_convex_ball with shape1 = half-space (HalfSpace::project_local_point); flipped = the ball is collider 1
+__device__ void manifold_halfspace_ball(Pose pos12, V3 normal1, float r2, float prediction, LocalManifold &m, bool flipped) {
+    V3 pt = pos12.t;
+    float dd = dot(normal1, pt);
+    V3 proj = pt + (-normal1) * dd;
+    convex_ball_finish(pos12, pt, proj, dd <= 0.0f, r2, prediction, m, flipped);
+}
+// contact_manifold_halfspace_pfm: shape 2 = a cuboid (its support face toward the plane) or a capsule (its segment, border radius =
+// the capsule's); every feature vertex within `prediction` of the plane is a contact.  pos12 = pose of shape 2 in the half-space's
+// frame; flipped = the half-space is collider 2
+__device__ void manifold_halfspace_pfm(Pose pos12, V3 normal1, int sh2, float4 c2, float prediction, LocalManifold &m, bool flipped) {
+    V3 normal1_2 = qrot_inv(pos12.r, normal1);
+    V3 vtx[4]; unsigned vid[4]; int nv; float border = 0.0f;
+    if (sh2 == RP_SHAPE_CAPSULE) {
+        V3 e2 = capsule_axis_dir((int)c2.z);
+        vtx[0] = e2 * -c2.x; vtx[1] = e2 * c2.x; vid[0] = 0u; vid[1] = 2u; vtx[2] = vtx[1]; vtx[3] = vtx[1]; vid[2] = vid[3] = 2u; nv = 2; border = c2.y;
+    } else {
+        Face f = cuboid_support_face(v3(c2), -normal1_2);
+        for (int i = 0; i < 4; ++i) { vtx[i] = f.v[i]; vid[i] = f.vid[i]; }
+        nv = 4;
+    }
+    unsigned oldfid[RP_MAX_PTS]; int nold = m.n;
+    for (int i = 0; i < nold; ++i) oldfid[i] = m.fid[i];
+    m.n = 0;
+    for (int i = 0; i < nv; ++i) {
+        V3 vtx2_1 = pose_tp(pos12, vtx[i]);
+        float dist_to_plane = dot(vtx2_1, normal1);
+        if (dist_to_plane - border <= prediction) {
+            V3 p1 = vtx2_1 - normal1 * dist_to_plane;
+            V3 p2 = vtx[i] - normal1_2 * border;
+            if (flipped) lm_push(m, p2, p1, vid[i], 0u, dist_to_plane - border);
+            else lm_push(m, p1, p2, 0u, vid[i], dist_to_plane - border);
+        }
+    }
+    if (flipped) { m.ln1 = -normal1_2; m.ln2 = normal1; } else { m.ln1 = normal1; m.ln2 = -normal1_2; }
+    for (int i = 0; i < m.n; ++i)
+        for (int j = 0; j < nold; ++j)
+            if (m.fid[i] == oldfid[j]) m.src[i] = j;
 }
 // sat::cuboid_support_map_find_local_separating_normal_oneway with shape2 = the segment [a2, b2] (cuboid frame)
 __device__ float sat_cuboid_segment_normal_oneway(V3 he1, V3 a2, V3 b2, V3 &out_dir) {
@@ -478,6 +522,7 @@ __device__ void reduce_manifold(const LocalManifold &m, int sel[4], int &nsel, f
 RP_DEV float shape_origin_radius(int sh, float4 he) {
     if (sh == RP_SHAPE_CUBOID) return len(v3(he));
     if (sh == RP_SHAPE_CAPSULE) { int ax = (int)he.z; return len(v3(ax == 0 ? he.x + he.y : he.y, ax == 1 ? he.x + he.y : he.y, ax == 2 ? he.x + he.y : he.y)); }
+    if (sh == RP_SHAPE_HALFSPACE) return INFINITY; // |(MAX/2, MAX/2, MAX/2)| overflows: a pair with a half-space never recycles
     return len(v3(he.x, he.x, he.x));
 }
 RP_DEV float combine_coeff(float a, float b, int ra, int rb) {
@@ -508,7 +553,19 @@ RP_DEV float point_box_dist2(V3 p, V3 he) {
     return dx * dx + dy * dy + dz * dz;
 }
 __device__ __noinline__ bool shapes_intersect(int s1, float4 h1, int s2, float4 h2, Pose pos12) {
-    if (s1 > s2) { int ts = s1; s1 = s2; s2 = ts; float4 th = h1; h1 = h2; h2 = th; pos12 = pose_inv(pos12); } // ball < cuboid < capsule
+    if (s1 > s2) { int ts = s1; s1 = s2; s2 = ts; float4 th = h1; h1 = h2; h2 = th; pos12 = pose_inv(pos12); } // ball < cuboid < capsule < half-space
+    if (s2 == RP_SHAPE_HALFSPACE) { // intersection_test_support_map_halfspace: the support point toward -normal lies in the solid side
+        if (s1 == RP_SHAPE_HALFSPACE) return false;
+        Pose pos21 = pose_inv(pos12);
+        V3 n = v3(h2), dir = qrot_inv(pos21.r, -n), sp;
+        if (s1 == RP_SHAPE_BALL) sp = dir * h1.x;
+        else if (s1 == RP_SHAPE_CUBOID) sp = cuboid_support_point(v3(h1), dir);
+        else {
+            V3 e = capsule_axis_dir((int)h1.z), a = e * -h1.x, b = e * h1.x;
+            sp = (dot(dir, a) > dot(dir, b) ? a : b) + dir * h1.y;
+        }
+        return dot(n, pose_tp(pos21, sp)) <= 0.0f;
+    }
     if (s1 == RP_SHAPE_BALL && s2 == RP_SHAPE_BALL) { float r = h1.x + h2.x; return dot(pos12.t, pos12.t) <= r * r; }
     if (s1 == RP_SHAPE_BALL && s2 == RP_SHAPE_CUBOID) { V3 c = pose_itp(pos12, v3(0, 0, 0)); return point_box_dist2(c, v3(h2)) <= h1.x * h1.x; }
     if (s1 == RP_SHAPE_BALL && s2 == RP_SHAPE_CAPSULE) {
@@ -578,7 +635,14 @@ __device__ __noinline__ void pair_full_update(DevWorld &w, int s, int c1, int c2
     }
     int nold = m.n;
     // pair_update.rs:323-330 -> parry DefaultQueryDispatcher::contact_manifolds
-    if (sh1 == RP_SHAPE_CUBOID && sh2 == RP_SHAPE_CUBOID) manifold_cuboid_cuboid(pos12, v3(he1), v3(he2), prediction, m);
+    if (sh1 == RP_SHAPE_HALFSPACE || sh2 == RP_SHAPE_HALFSPACE) { // the ball arms come before (HalfSpace, pfm) | (pfm, HalfSpace) in the dispatcher
+        if (sh1 == sh2) m.n = 0; // unsupported pair
+        else if (sh1 == RP_SHAPE_HALFSPACE && sh2 == RP_SHAPE_BALL) manifold_halfspace_ball(pos12, v3(he1), he2.x, prediction, m, false);
+        else if (sh2 == RP_SHAPE_HALFSPACE && sh1 == RP_SHAPE_BALL) manifold_halfspace_ball(pose_inv(pos12), v3(he2), he1.x, prediction, m, true);
+        else if (sh1 == RP_SHAPE_HALFSPACE) manifold_halfspace_pfm(pos12, v3(he1), sh2, he2, prediction, m, false);
+        else manifold_halfspace_pfm(pose_inv(pos12), v3(he2), sh1, he1, prediction, m, true);
+    }
+    else if (sh1 == RP_SHAPE_CUBOID && sh2 == RP_SHAPE_CUBOID) manifold_cuboid_cuboid(pos12, v3(he1), v3(he2), prediction, m);
     else if (sh1 == RP_SHAPE_BALL && sh2 == RP_SHAPE_BALL) manifold_ball_ball(pos12, he1.x, he2.x, prediction, m);
     else if (sh1 == RP_SHAPE_CAPSULE && sh2 == RP_SHAPE_CAPSULE) manifold_capsule_capsule(pos12, he1, he2, prediction, m);
     else if (sh1 == RP_SHAPE_CUBOID && sh2 == RP_SHAPE_CAPSULE) manifold_cuboid_capsule(pos12, pos12, v3(he1), he2, prediction, m, false);

@@ -55,6 +55,12 @@ __device__ __noinline__ void capsule_collision_aabb(Pose pos, float4 he, float l
     mn = (v3(rp_min(pa.x, pb.x), rp_min(pa.y, pb.y), rp_min(pa.z, pb.z)) - r) - v3(loosen, loosen, loosen);
     mx = (v3(rp_max(pa.x, pb.x), rp_max(pa.y, pb.y), rp_max(pa.z, pb.z)) + r) + v3(loosen, loosen, loosen);
 }
+// HalfSpace::aabb: half of the float range in every direction, wherever the plane is
+__device__ __noinline__ void halfspace_collision_aabb(float loosen, V3 &mn, V3 &mx) {
+    const float h = 3.402823466e+38f / 2.0f;
+    mn = v3(-h, -h, -h) - v3(loosen, loosen, loosen);
+    mx = v3(h, h, h) + v3(loosen, loosen, loosen);
+}
 RP_DEV bool collider_update_one(const DevWorld &w, int i) { // true = the fat AABB was rewritten
     Pose pos = collider_world_pose(w, i);
     bool finite = isfinite(pos.t.x) && isfinite(pos.t.y) && isfinite(pos.t.z) && isfinite(pos.r.x) && isfinite(pos.r.y) &&
@@ -76,6 +82,7 @@ RP_DEV bool collider_update_one(const DevWorld &w, int i) { // true = the fat AA
     V3 mn = pos.t - h - v3(loosen, loosen, loosen);
     V3 mx = pos.t + h + v3(loosen, loosen, loosen);
     if (w.c_shape[i] == RP_SHAPE_CAPSULE) capsule_collision_aabb(pos, he, loosen, mn, mx);
+    if (w.c_shape[i] == RP_SHAPE_HALFSPACE) halfspace_collision_aabb(loosen, mn, mx);
     float4 fmn = w.c_fatmin[i], fmx = w.c_fatmax[i];
     bool inside = fmn.x <= mn.x && fmn.y <= mn.y && fmn.z <= mn.z && fmx.x >= mx.x && fmx.y >= mx.y && fmx.z >= mx.z;
     if (!inside) {
@@ -107,6 +114,7 @@ RP_DEV bool collider_left_fat_aabb(const DevWorld &w, int i) {
     V3 mn = pos.t - h - v3(loosen, loosen, loosen);
     V3 mx = pos.t + h + v3(loosen, loosen, loosen);
     if (w.c_shape[i] == RP_SHAPE_CAPSULE) capsule_collision_aabb(pos, he, loosen, mn, mx);
+    if (w.c_shape[i] == RP_SHAPE_HALFSPACE) halfspace_collision_aabb(loosen, mn, mx);
     float4 fmn = w.c_fatmin[i], fmx = w.c_fatmax[i];
     bool inside = fmn.x <= mn.x && fmn.y <= mn.y && fmn.z <= mn.z && fmx.x >= mx.x && fmx.y >= mx.y && fmx.z >= mx.z;
     return !inside;

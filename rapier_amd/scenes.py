@@ -16,6 +16,7 @@ import numpy as np
 
 BODY_DYNAMIC, BODY_FIXED, BODY_KINEMATIC_POSITION, BODY_KINEMATIC_VELOCITY = 0, 1, 2, 3  # RigidBodyType
 SHAPE_BALL, SHAPE_CUBOID, SHAPE_CAPSULE = 0, 1, 2  # capsule: half_extents = (half_height, radius, axis 0|1|2) = ColliderBuilder::capsule_x/y/z
+SHAPE_HALFSPACE = 3  # half_extents = the unit outward normal in the collider frame = ColliderBuilder::halfspace (fixed or kinematic parents only)
 RULE_AVERAGE, RULE_MIN, RULE_MULTIPLY, RULE_MAX, RULE_CLAMPED_SUM, RULE_GEOMETRIC_MEAN = range(6)
 
 # Field-for-field mirrors of rp_body_desc / rp_collider_desc / rp_joint_desc / rp_integration_params.
@@ -709,3 +710,33 @@ def sensor_scene() -> Scene:
     s.add_collider(rider, shape=SHAPE_BALL, half_extents=(0.9, 0.0, 0.0), density=0.0, sensor=1, active_events=ACTIVE_EVENTS_COLLISION)
     return s
 
+
+
+def halfspace_scene(n_side: int = 4) -> Scene:
+    """Half-spaces (ColliderBuilder::halfspace; not a reference scene): a ground plane without a parent body, a slanted plane on
+    a fixed body inserted AFTER the dynamic bodies (so it is the second collider of its pairs), a slowly rising plane on a
+    velocity-based kinematic body, and a grid of tumbling cuboids, balls and capsules (all three axes) dropped between them."""
+    s = Scene(name="halfspaces", gravity=(0.0, -9.81, 0.0))
+    s.add_collider(-1, shape=SHAPE_HALFSPACE, half_extents=(0.0, 1.0, 0.0), friction=0.7, active_events=ACTIVE_EVENTS_COLLISION)
+    lift = s.add_body(body_type=BODY_KINEMATIC_VELOCITY, translation=(0.0, -0.6, 0.0), linvel=(0.0, 0.15, 0.0))
+    s.add_collider(lift, shape=SHAPE_HALFSPACE, half_extents=(0.0, 1.0, 0.0), translation=(0.0, 0.0, 0.0), friction=0.4,
+                   memberships=0x4, filter=0x4)                   # only the colliders with bit 2 ride it
+    rng = np.random.default_rng(7)
+    k = 0
+    for i in range(n_side):
+        for j in range(n_side):
+            q = rng.normal(size=4); q /= np.linalg.norm(q)
+            b = s.add_body(translation=(1.4 * i - 2.0, 1.0 + 0.5 * ((i + j) % 3), 1.4 * j - 2.0), rotation=tuple(float(x) for x in q),
+                           angvel=tuple(float(x) for x in rng.uniform(-2, 2, size=3)))
+            kind = k % 4
+            grp = dict(memberships=0x3, filter=0x3) if k % 5 else dict(memberships=0x7, filter=0x7)
+            if kind == 0:
+                s.add_collider(b, half_extents=(0.3, 0.2, 0.4), **grp)
+            elif kind == 1:
+                s.add_collider(b, shape=SHAPE_BALL, half_extents=(0.3, 0.0, 0.0), restitution=0.4, **grp)
+            else:
+                s.add_collider(b, shape=SHAPE_CAPSULE, half_extents=(0.35, 0.2, float(k % 3)), **grp)
+            k += 1
+    ramp = s.add_body(body_type=BODY_FIXED, translation=(3.0, 0.0, 0.0))
+    s.add_collider(ramp, shape=SHAPE_HALFSPACE, half_extents=(-0.6, 0.8, 0.0), friction=0.2)
+    return s

@@ -37,6 +37,8 @@ CASES = {
     # round 2: substep solve-groups (additional_solver_iterations) and sensors
     "solve_groups_s150": lambda: (S.solve_groups_scene(), 150),
     "sensors_s200": lambda: (S.sensor_scene(), 200),
+    # half-spaces (ground plane, slanted plane, rising kinematic plane) under cuboids, balls and capsules
+    "halfspaces_s240": lambda: (S.halfspace_scene(), 240),
 }
 
 

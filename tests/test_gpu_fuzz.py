@@ -252,8 +252,20 @@ def test_fuzz_sensors_bit_exact(seed):
     _run(seed, steps=200, params=seed >= 2000, sensors=True)
 
 
-def _run(seed, steps=240, walls=False, params=False, world=None, extras=False, sensors=False, **kw):
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [30, 31, 32, 2007])
+def test_fuzz_halfspace_ground_bit_exact(seed):
+    """the same scenes and actions on a ground PLANE (RP_SHAPE_HALFSPACE on the fixed ground body) with a slanted plane beside the
+    pile: pairs that never recycle (full narrow-phase update every step), the plane against every shape and compound body"""
+    _run(seed, steps=200, params=seed >= 2000, halfspace=True)
+
+
+def _run(seed, steps=240, walls=False, params=False, world=None, extras=False, sensors=False, halfspace=False, **kw):
     sc, rng = _scene(seed, **kw)
+    if halfspace:
+        c0 = sc.colliders[0]                                       # the ground slab (top face at y = 0) becomes the plane y = 0
+        c0["shape"] = S.SHAPE_HALFSPACE; c0["half_extents"] = (0.0, 1.0, 0.0); c0["translation"] = (0.0, 0.5, 0.0)
+        sc.add_collider(0, shape=S.SHAPE_HALFSPACE, half_extents=(-0.6, 0.0, 0.8), translation=(5.0, 0.5, -5.0), friction=0.3)
     if sensors:
         trig = sc.add_body(body_type=S.BODY_FIXED, translation=(0.0, 1.2, 0.0))
         sc.add_collider(trig, half_extents=(2.5, 0.8, 2.5), sensor=1, active_events=S.ACTIVE_EVENTS_COLLISION)
