@@ -1019,6 +1019,7 @@ static int finalize(rp_world *w) {
     d.has_kinematic_pos = world_has_kinematic_pos(w) ? 1 : 0;
     d.has_force_events = world_has_force_events(w) ? 1 : 0;
     d.has_sensors = world_has_sensors(w) ? 1 : 0;
+    { const char *ig = getenv("RP_ISL_GENERIC"); d.isl_generic = (ig && ig[0] == '1') ? 1 : 0; }
     w->compound = world_has_compound_bodies(w);
     int nb = (int)w->bodies.size(), nc = (int)w->colliders.size();
     d.n_bodies = nb; d.n_colliders = nc;
@@ -1275,7 +1276,8 @@ static void plan_from_hints(rp_world *w, const int *fl) {
     // (a grid of at most fused_grid workgroups; workgroups loop over islands beyond that)
     // (contact-force events are evaluated by a kernel of their own after every step: such worlds take the two-kernel fast graph)
     // (... and so do sleep-enabled worlds: their sleep observation is a pass of its own)
-    w->plan_fused = (w->use_fused && w->fused_grid > 0 && !w->compound && !w->dw.has_force_events && !w->dw.sleep_enabled && !w->dw.has_sensors && w->plan_no_global && w->plan_single && fl[FL_N_ISLANDS] > 0) ? 1 : 0;
+    // (... and so do the worlds whose islands run on k_island_generic: FrictionModel::Coulomb)
+    w->plan_fused = (w->use_fused && w->fused_grid > 0 && !w->compound && w->params.friction_model != RP_FRICTION_COULOMB && !w->dw.isl_generic && !w->dw.has_force_events && !w->dw.sleep_enabled && !w->dw.has_sensors && w->plan_no_global && w->plan_single && fl[FL_N_ISLANDS] > 0) ? 1 : 0;
 }
 
 static int capture(rp_world *w, hipGraph_t *g, hipGraphExec_t *ge, void (*fn)(rp_world *)) {

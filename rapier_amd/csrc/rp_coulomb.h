@@ -6,8 +6,9 @@
 // element solves of contact_constraint_element.rs:64-176 (ContactConstraintTangentPart: exact coupled 2x2
 // tangent solve, capped at mu * lambda_k of ITS point) and :226-310 (ContactConstraintNormalPart).
 // Selected by IntegrationParameters::friction_model (staged_island_solver/init.rs:419); the default
-// Simplified model is rp_constraint.h.  Runs on the global (HBM-resident) path only: the LDS island kernel keeps
-// the twist constraint in registers, so Coulomb worlds route every manifold through rp_solver.hip.
+// Simplified model is rp_constraint.h.  Its 87 planes per manifold do not fit the registers of k_island_solve (which holds the twist
+// constraint only): Coulomb islands run on k_island_generic (rp_islands.hip: one workgroup per island, these functions over thread-private
+// HBM rows, bodies in LDS), everything else on the global path of rp_solver.hip / rp_flow.hip.
 // The normal parts share the twist model's planes (NP_*); each point adds 9 tangent planes behind CP_COUNT.
 #pragma once
 #include "rp_constraint.h"

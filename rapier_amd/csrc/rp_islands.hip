@@ -70,10 +70,10 @@ RP_DEV void lay_isl_count(DevWorld &w, int gid, int stride) {
         // whatever its exact size, so further increments (all on ONE address for a giant island) are skipped
         if (ld_i32(&w.r_nb[root]) <= RP_ISL_NB_MAX) atomicAdd(&w.r_nb[root], 1);
         // a body that carries a joint is solved on the global path (joints live there): poison its component
-        // ... and so is every body under FrictionModel::Coulomb (the island kernel holds the twist constraint only)
+        // (FrictionModel::Coulomb: the islands are solved by k_island_generic, the twist-only k_island_solve is not launched)
         // ... and so are kinematic bodies (solver bodies with zero inverse mass and their own write-back rule)
         // ... and so is everything in a world with substep solve-groups (additional_solver_iterations: rp_groups.h)
-        if (w.b_njoints[b] > 0 || coulomb_model(w) || (w.b_flags[b] & RP_BF_TYPE_MASK) != RP_BODY_DYNAMIC || w.n_groups > 1) atomicAdd(&w.r_nc[root], RP_ISL_NC_MAX + 1);
+        if (w.b_njoints[b] > 0 || (w.b_flags[b] & RP_BF_TYPE_MASK) != RP_BODY_DYNAMIC || w.n_groups > 1) atomicAdd(&w.r_nc[root], RP_ISL_NC_MAX + 1);
     }
     for (int s = gid; s < top; s += stride) {
         if (w.p_c1[s] < 0) continue;
@@ -985,6 +985,107 @@ __global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int ha
     }
 }
 
+// ---- the generic island kernel ----------------------------------------------------------------------------------------------------
+// One workgroup = one island, like k_island_solve, but the constraint is the HBM-resident one of the global path (rp_constraint.h /
+// rp_coulomb.h through an accessor): thread m owns manifold m for the whole step, so its constraint planes are private to the
+// thread (no fence, L2-resident: 87 planes x 16 B under FrictionModel::Coulomb do not fit registers or LDS), and only the solver
+// bodies — the one thing manifolds share — live in LDS, ordered by the workgroup barrier between colour stages.  Serves the worlds
+// whose constraint model k_island_solve does not hold in registers (FrictionModel::Coulomb): their islands used to be poisoned
+// onto the global path, where every colour stage costs a cross-CU hand-off (~8 us) instead of a barrier.
+// Same stage order as global_single_block (rp_global.h), so the result is bit-identical to the global path and the oracle.
+struct IslGenAcc {
+    const DevWorld &w; int pos; const IslLds &L;
+    RP_DEV IslGenAcc(const DevWorld &w_, int pos_, const IslLds &L_) : w(w_), pos(pos_), L(L_) {}
+    RP_DEV float4 ld(int plane) const { return w.C[(size_t)plane * w.cons_cap + pos]; }
+    RP_DEV void st(int plane, float4 v) const { w.C[(size_t)plane * w.cons_cap + pos] = v; }
+    RP_DEV int id1() const { return w.k_b1[pos]; }
+    RP_DEV int id2() const { return w.k_b2[pos]; }
+    RP_DEV int n() const { return w.k_n[pos]; }
+    RP_DEV int cids() const { return w.k_cid[pos]; }
+    RP_DEV void set_meta(int a, int b, int cnt, int cid) const { w.k_b1[pos] = a; w.k_b2[pos] = b; w.k_n[pos] = cnt; w.k_cid[pos] = cid; }
+    RP_DEV Vel vel(int id) const { return isl_vel(L, id); }
+    RP_DEV void set_vel(int id, const Vel &v) const { isl_set_vel(L, id, v); }
+    RP_DEV Xf xf(int id) const { return isl_xf(L, id); }
+};
+template <bool COUL>
+__global__ void __launch_bounds__(ISL_THREADS) k_island_generic(DevWorld w, int has_restitution, int fast, int retire) {
+    const bool aborted = fast && w.flags[FL_FAST_ABORT];
+    if (retire && blockIdx.x == 0) { // SINGLE mode: workgroup 0 retires the step and publishes the scalars (as k_island_solve does)
+        if (threadIdx.x == 0) { w.flags[FL_SEQ] += 1; if (!aborted) w.flags[FL_STEP] += 1; }
+        __threadfence(); __syncthreads();
+        publish_flags(w);
+    }
+    if (aborted) return;
+    __shared__ float4 B_lin[RP_ISL_NB_MAX], B_ang[RP_ISL_NB_MAX], B_rot[RP_ISL_NB_MAX], B_trans[RP_ISL_NB_MAX];
+    __shared__ int S_a[RP_ISL_NC_MAX], S_b[RP_ISL_NC_MAX], S_c[RP_ISL_NC_MAX], S_d[RP_ISL_NC_MAX];
+    __shared__ int any_bouncy;
+    const int t = threadIdx.x;
+    const int n_islands = w.flags[FL_N_ISLANDS];
+    const int nst_global = w.flags[FL_N_STAGES];
+    const rp_integration_params &prm = w.prm.p;
+    const bool fib = prm.friction_in_bias_pass || prm.num_internal_stabilization_iterations == 0;
+    IslLds L;
+    L.lin = B_lin; L.ang = B_ang; L.rot = B_rot; L.trans = B_trans; L.E = nullptr; L.F = nullptr; L.B0 = nullptr; L.B1 = nullptr;
+    for (int isl = blockIdx.x; isl < n_islands; isl += gridDim.x) {
+        const int nb = w.isl_nb[isl], nc = w.isl_nc[isl];
+        const int bb = w.isl_body_begin[isl], cb = w.isl_cons_begin[isl];
+        __syncthreads(); // previous island of this workgroup fully written back
+        if (!w.isl_sorted[isl]) island_sort(w, isl, nc, cb, nst_global, S_a, S_b, S_c, S_d);
+        int b_gid = -1, b_fl = 0;
+        V3 b_incl = v3(0, 0, 0), b_inca = b_incl, b_invpi = b_incl; Q4 b_pframe = q4(0, 0, 0, 1);
+        if (t < nb) { // S0: thread t owns solver body t
+            int g = w.isl_bodies[bb + t];
+            V3 lin, ang, trans; Q4 rot;
+            body_begin(w, g, lin, ang, rot, trans, b_incl, b_inca);
+            b_gid = g; b_fl = w.b_flags[g];
+            B_lin[t] = f4(lin, 0.0f); B_ang[t] = f4(ang, 0.0f); B_rot[t] = f4(rot); B_trans[t] = f4(trans, 0.0f);
+            b_invpi = v3(w.b_invpi[g]); b_pframe = q4(w.b_pframe[g]);
+        }
+        if (t == 0) any_bouncy = 0;
+        const int nls = w.isl_nstages[isl];
+        const bool live = t < nc;
+        int slot = -1, myq = -1;
+        // the island's manifolds take the constraint rows from the top of the planes down; the global path's own rows grow from 0
+        // (together they are at most the live pairs, and cons_cap = pool_cap)
+        const IslGenAcc A(w, w.cons_cap - 1 - (cb + (live ? t : 0)), L);
+        if (live) { slot = w.isl_cons[cb + t]; myq = w.isl_cstage[cb + t]; }
+        __syncthreads();
+        if (live) { // S1
+            const int g1 = w.isl_cg1[cb + t], g2 = w.isl_cg2[cb + t], l1 = w.isl_cl1[cb + t], l2 = w.isl_cl2[cb + t];
+            const bool bouncy = COUL ? coul_generate(w, A, slot, g1, g2, l1, l2) : cons_generate(w, A, slot, g1, g2, l1, l2);
+            if (bouncy) any_bouncy = 1;
+        }
+        __syncthreads();
+        // (the barrier orders the LDS velocities only: a thread's constraint rows are its own, so its global stores may stay in flight —
+        // __syncthreads() would drain them, ~0.7 us per stage)
+#define ISLGEN_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define ISLGEN_SWEEP(MODE, SDT) for (int q = 0; q < nls; ++q) { if (myq == q) cons_apply_model<COUL>(w, A, MODE, fib, SDT); ISLGEN_BARRIER(); }
+        for (int sub = 0; sub < w.prm.num_substeps; ++sub) {
+            const float solved_dt = (float)sub * w.prm.dt_sub;
+            if (t < nb) { // S2
+                V3 lin = v3(B_lin[t]), ang = v3(B_ang[t]);
+                body_increment(w, b_fl, lin, ang, q4(B_rot[t]), b_incl, b_inca, b_invpi, b_pframe);
+                B_lin[t] = f4(lin, 0.0f); B_ang[t] = f4(ang, 0.0f);
+            }
+            __syncthreads();
+            ISLGEN_SWEEP(MODE_WARMSTART, solved_dt)
+            for (int it = 0; it < prm.num_internal_pgs_iterations; ++it) ISLGEN_SWEEP(MODE_BIAS, solved_dt)
+            if (t < nb) { // S6
+                V3 lin = v3(B_lin[t]), ang = v3(B_ang[t]), trans = v3(B_trans[t]); Q4 rot = q4(B_rot[t]);
+                body_integrate(w, b_fl, lin, ang, rot, trans);
+                B_lin[t] = f4(lin, 0.0f); B_ang[t] = f4(ang, 0.0f); B_rot[t] = f4(rot); B_trans[t] = f4(trans, 0.0f);
+            }
+            __syncthreads();
+            for (int it = 0; it < prm.num_internal_stabilization_iterations; ++it) ISLGEN_SWEEP(MODE_RELAX, solved_dt + w.prm.dt_sub)
+        }
+        if (has_restitution && any_bouncy) ISLGEN_SWEEP(MODE_RESTITUTION, 0.0f)
+#undef ISLGEN_SWEEP
+#undef ISLGEN_BARRIER
+        if (live) { if (COUL) coul_writeback(w, A, slot); else cons_writeback(w, A, slot); }
+        if (t < nb) body_writeback(w, b_gid, v3(B_lin[t]), v3(B_ang[t]), q4(B_rot[t]), v3(B_trans[t]));
+    }
+}
+
 void rp_launch_islands_build(const DevWorld &w, hipStream_t st) {
     // every workgroup must be resident (grid barriers): at most 192 workgroups of 1024 threads (one per CU, 256 CUs)
     int n = w.n_bodies > w.pool_cap ? w.n_bodies : w.pool_cap;
@@ -1011,5 +1112,7 @@ int rp_fused_grid(int device) {
 }
 void rp_launch_island_solve(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast, int retire, int fused) {
     if (grid < 1) grid = 1;
+    if (w.prm.p.friction_model == RP_FRICTION_COULOMB) { hipLaunchKernelGGL(k_island_generic<true>, dim3(grid), dim3(ISL_THREADS), 0, st, w, has_restitution, fast, retire); return; }
+    if (w.isl_generic) { hipLaunchKernelGGL(k_island_generic<false>, dim3(grid), dim3(ISL_THREADS), 0, st, w, has_restitution, fast, retire); return; } // RP_ISL_GENERIC=1: the twist model through the generic kernel (tests)
     hipLaunchKernelGGL(k_island_solve, dim3(grid), dim3(ISL_THREADS), 0, st, w, has_restitution, fast, retire, fused);
 }

@@ -167,6 +167,7 @@ struct DevWorld {
     int has_force_events;  // some collider has ActiveEvents::CONTACT_FORCE_EVENTS: k_force_events runs after every step
     int ev_cap;            // slots per event queue
     int has_kinematic_pos; // some body is KinematicPositionBased: k_kinematic_velocities runs
+    int isl_generic;       // RP_ISL_GENERIC=1: islands through k_island_generic even under the twist model (tests of that kernel)
     int n_groups;          // distinct additional_solver_iterations counts in the world (1 = no elevated body: the plain paths)
     int has_sensors;       // some collider is a sensor: its pairs are intersection-tested every step (full step path)
     SimParams prm;
