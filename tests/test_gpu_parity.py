@@ -866,7 +866,7 @@ def test_coulomb_friction_bit_exact():
 
 
 def test_coulomb_multi_mode_and_model_switch():
-    """Full-size b3d_many_pyramids under Coulomb friction: every manifold on the per-colour launch path."""
+    """Full-size b3d_many_pyramids under Coulomb friction: 196 islands on k_island_generic (one workgroup per island)."""
     g, o = _compare(_coulomb(S.many_pyramids()), [1, 5, 30])
     assert g.counters()["num_manifolds"] == 28420
     # switching the model on a live world rebuilds the device world from the current state and keeps simulating
@@ -879,6 +879,28 @@ def test_coulomb_multi_mode_and_model_switch():
     w.step(120)
     pos, vel = w.read_bodies()
     assert np.isfinite(pos).all() and np.abs(vel).max() < 0.05 and pos[1:, 1].max() == pytest.approx(9.5, abs=0.05)
+
+
+def test_coulomb_islands_next_to_a_global_component():
+    """Coulomb world with both kinds of components: pyramids (islands on k_island_generic) and a 20 x 20 pile too large for an
+    island (global path, dataflow launch) — the two share the constraint planes from opposite ends."""
+    sc = _coulomb(S.many_pyramids(rows=2, cols=2))
+    for i in range(20):
+        for j in range(20):
+            b = sc.add_body(translation=(40.0 + 1.01 * i, 0.5 + 1.0 * ((i + j) % 2), 1.01 * j))
+            sc.add_collider(b, half_extents=(0.5, 0.5, 0.5))
+    g, o = _compare(sc, [1, 10, 60, 150])
+    assert g.counters()["num_manifolds"] > 580 + 400
+
+
+def test_twist_model_through_the_generic_island_kernel(monkeypatch):
+    """RP_ISL_GENERIC=1 sends the islands of a twist-model world through k_island_generic<false> instead of k_island_solve: the
+    same scenes must come out bit for bit (the kernel's stage order is the global path's)."""
+    monkeypatch.setenv("RP_ISL_GENERIC", "1")
+    _compare(S.pyramid10(), [1, 10, 100, 300])
+    _compare(S.many_pyramids(rows=2, cols=2), [1, 5, 40])
+    _compare(S.tumble(40, seed=11), [1, 30, 90, 250])
+    sc = S.sleep_impact(); _compare(sc, [60, 200])
 
 
 # ---- kinematic bodies (SURVEY §8a MISC: interpolate_kinematic_velocities) ----
