@@ -28,7 +28,7 @@ CONFIGS = [
     ("C3 b3d_many_pyramids (10,780 cuboids, 196 islands) — the bench.py workload", S.many_pyramids, 60, 2000, 300),
     ("C5 b3d_joint_grid (9,900 balls, 19,800 spherical joints)", S.joint_grid, 60, 500, 100),
     ("C3 + sleeping allowed (awake while settling, then idle steps)", lambda: S.many_pyramids().enable_sleep(), 60, 2000, 300),
-    ("C3 + FrictionModel::Coulomb (global per-colour path)", lambda: _with(S.many_pyramids(), "friction_model", S.FRICTION_COULOMB), 60, 300, 100),
+    ("C3 + FrictionModel::Coulomb (islands on k_island_generic)", lambda: _with(S.many_pyramids(), "friction_model", S.FRICTION_COULOMB), 60, 300, 100),
     ("C3 + collision and contact-force events on every collider", lambda: S.many_pyramids().enable_events(3, 100.0), 60, 1000, 100),
     ("capsules(6) feature scene (full updates every step)", lambda: S.capsules(6), 30, 1000, 1000),
 ]
