@@ -25,9 +25,17 @@ RP_DEV Sym3 load_ii(const DevWorld &w, int gid) {
 }
 
 // ---- accessor over HBM ------------------------------------------------------------------------
-struct GlobalAcc {
+// PRELOAD (a trait of every accessor): the constraint functions fetch every row they read before storing their first one.  The compiler
+// cannot tell the rows apart, so a load placed after a store is ISSUED after the arithmetic that feeds the store — one exposed memory
+// round trip per contact point on the Gauss-Seidel critical path of a colour stage (k_stage<BIAS> 5.9 -> 4.x us on b3d_large_pyramid).
+// It costs ~100 live VGPRs: the standalone kernels (k_generate, k_stage, k_tail) take it, the fused ones (one workgroup running the
+// whole solver, the dataflow launch, the generic island kernel) would pay it in scratch spills — measured 3x slower — and do not.
+// Same operands, same order either way: only the issue order of the loads changes.
+template <bool PRE>
+struct GlobalAccT {
+    static constexpr bool PRELOAD = PRE;
     const DevWorld &w; int pos;
-    RP_DEV GlobalAcc(const DevWorld &w_, int pos_) : w(w_), pos(pos_) {}
+    RP_DEV GlobalAccT(const DevWorld &w_, int pos_) : w(w_), pos(pos_) {}
     RP_DEV float4 ld(int plane) const { return w.C[(size_t)plane * w.cons_cap + pos]; }
     RP_DEV void st(int plane, float4 v) const { w.C[(size_t)plane * w.cons_cap + pos] = v; }
     RP_DEV int id1() const { return w.k_b1[pos]; }
@@ -47,6 +55,11 @@ struct GlobalAcc {
         return x;
     }
 };
+typedef GlobalAccT<false> GlobalAcc;
+typedef GlobalAccT<true> GlobalAccP;
+// row `plane` of point k: from the preloaded copy, or straight from the accessor
+#define ROWK(arr, k, plane) (Acc::PRELOAD ? arr[k] : A.ld(plane))
+#define ROW1(var, plane) (Acc::PRELOAD ? var : A.ld(plane))
 
 #define NPL(k, sub) (CP_N0 + 7 * (k) + (sub))
 
@@ -74,15 +87,28 @@ RP_DEV bool cons_generate(const DevWorld &w, const Acc &A, int s, int gid1, int 
     int cids = 0;
     bool bouncy_seed = false;
     V3 imsum = im1 + im2;
+    // every input of every point is fetched before the first constraint row is stored: the rows may alias the inputs as far as the
+    // compiler can tell, so loads issued after a store wait for it — four points x two dependent round trips, ~45 us of a 59 us
+    // k_generate on b3d_large_pyramid before this
+    float4 in_a1[4], in_a2[4], in_imp[4], in_wst[4], in_dp1[4], in_dp2[4];
+    if (Acc::PRELOAD) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (k < count) { in_a1[k] = PT(w.sc_a1, k, s); in_a2[k] = PT(w.sc_a2, k, s); }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (k < count) {
+            const int cid = __float_as_int(in_a2[k].w);
+            in_imp[k] = PT(w.pt_imp, cid, s); in_wst[k] = PT(w.pt_wst, cid, s); in_dp1[k] = PT(w.pt_dp1, cid, s); in_dp2[k] = PT(w.pt_dp2, cid, s);
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (k >= count) break;
         float weight = inv_num_points;
-        float4 a1 = PT(w.sc_a1, k, s), a2 = PT(w.sc_a2, k, s);
+        float4 a1 = Acc::PRELOAD ? in_a1[k] : PT(w.sc_a1, k, s), a2 = Acc::PRELOAD ? in_a2[k] : PT(w.sc_a2, k, s);
         int cid = __float_as_int(a2.w);
         cids |= (cid & 0xff) << (8 * k);
-        float4 pimp = PT(w.pt_imp, cid, s);
-        V3 wt = v3(PT(w.pt_wst, cid, s));
+        float4 pimp = Acc::PRELOAD ? in_imp[k] : PT(w.pt_imp, cid, s);
+        V3 wt = v3(Acc::PRELOAD ? in_wst[k] : PT(w.pt_wst, cid, s));
         float warmstart_impulse = pimp.y;
         float wti0 = dot(wt, t0), wti1 = dot(wt, t1);
         float warmstart_twist_impulse = pimp.z;
@@ -91,7 +117,7 @@ RP_DEV bool cons_generate(const DevWorld &w, const Acc &A, int s, int gid1, int 
         V3 p1 = xf_tp(poses1, v3(a1));
         V3 p2 = xf_tp(poses2, v3(a2));
         float dist = dot(p1 - p2, force_dir1);
-        V3 dp1 = v3(PT(w.pt_dp1, cid, s)), dp2 = v3(PT(w.pt_dp2, cid, s));
+        V3 dp1 = v3(Acc::PRELOAD ? in_dp1[k] : PT(w.pt_dp1, cid, s)), dp2 = v3(Acc::PRELOAD ? in_dp2[k] : PT(w.pt_dp2, cid, s));
         V3 point = world_com1 + dp1;
         if (k == 0) points0 = point; else if (k == 1) points1 = point; else if (k == 2) points2 = point; else points3 = point;
         friction_center = friction_center + point * weight;
@@ -182,13 +208,22 @@ RP_DEV void cons_update_warmstart(const DevWorld &w, const Acc &A, float solved_
     V3 im1 = v3(A.ld(CP_H1)), im2 = v3(A.ld(CP_H2));
     Vel v1 = A.vel(id1), v2 = A.vel(id2);
     bool ws = wc != 0.0f;
+    // (Acc::PRELOAD: every row in before the first one goes out, see GlobalAccT)
+    float4 pm[4], pc[4], pd[4], pe[4], pf[4];
+    float4 phm0 = make_float4(0, 0, 0, 0), phm1 = phm0, ph7 = phm0, pb0 = phm0, pb1 = phm0, t4 = phm0, t5 = phm0, t6 = phm0, t7 = phm0, ph3 = phm0, ph4 = phm0, ph5 = phm0;
+    if (Acc::PRELOAD) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (k < n) { pm[k] = A.ld(NPL(k, NP_M)); pc[k] = A.ld(NPL(k, NP_C)); pd[k] = A.ld(NPL(k, NP_D)); pe[k] = A.ld(NPL(k, NP_E)); pf[k] = A.ld(NPL(k, NP_F)); }
+        phm0 = A.ld(CP_HM0); phm1 = A.ld(CP_HM1); ph7 = A.ld(CP_H7); pb0 = A.ld(CP_B0); pb1 = A.ld(CP_B1);
+        if (ws) { t4 = A.ld(CP_T4); t5 = A.ld(CP_T5); t6 = A.ld(CP_T6); t7 = A.ld(CP_T7); if (n > 1) { ph3 = A.ld(CP_H3); ph4 = A.ld(CP_H4); ph5 = A.ld(CP_H5); } }
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (k >= n) break;
-        float4 m = A.ld(NPL(k, NP_M));
-        float4 c = A.ld(NPL(k, NP_C)), d = A.ld(NPL(k, NP_D));
-        V3 p1 = xf_tp(x1, v3(A.ld(NPL(k, NP_E)))) + tangent_delta;
-        V3 p2 = xf_tp(x2, v3(A.ld(NPL(k, NP_F))));
+        float4 m = ROWK(pm, k, NPL(k, NP_M));
+        float4 c = ROWK(pc, k, NPL(k, NP_C)), d = ROWK(pd, k, NPL(k, NP_D));
+        V3 p1 = xf_tp(x1, v3(ROWK(pe, k, NPL(k, NP_E)))) + tangent_delta;
+        V3 p2 = xf_tp(x2, v3(ROWK(pf, k, NPL(k, NP_F))));
         float dist = c.w + dot(p1 - p2, dir1);
         float rhs_wo_bias = rp_max(dist, 0.0f) * inv_dt;
         float rhs_bias = rp_clamp(dist * erp_inv_dt, -maxcv, 0.0f);
@@ -204,10 +239,10 @@ RP_DEV void cons_update_warmstart(const DevWorld &w, const Acc &A, float solved_
             v2.ang = v2.ang + v3(d) * m.z;
         }
     }
-    float4 hm0 = A.ld(CP_HM0), hm1 = A.ld(CP_HM1), h7 = A.ld(CP_H7);
+    float4 hm0 = ROW1(phm0, CP_HM0), hm1 = ROW1(phm1, CP_HM1), h7 = ROW1(ph7, CP_H7);
     {
-        V3 p1 = xf_tp(x1, v3(A.ld(CP_B0))) + tangent_delta;
-        V3 p2 = xf_tp(x2, v3(A.ld(CP_B1)));
+        V3 p1 = xf_tp(x1, v3(ROW1(pb0, CP_B0))) + tangent_delta;
+        V3 p2 = xf_tp(x2, v3(ROW1(pb1, CP_B1)));
         float bias0 = dot(p1 - p2, t0) * inv_dt, bias1 = dot(p1 - p2, t1) * inv_dt;
         hm1.z = h6.w + bias0; hm1.w = h7.x + bias1;
         hm1.x += hm0.z; hm1.y += hm0.w;
@@ -219,11 +254,11 @@ RP_DEV void cons_update_warmstart(const DevWorld &w, const Acc &A, float solved_
     if (ws) {
         float i0 = hm0.z, i1 = hm0.w;
         v1.lin = v1.lin + cmul(t0 * i0 + t1 * i1, im1);
-        v1.ang = v1.ang + (v3(A.ld(CP_T4)) * i0 + v3(A.ld(CP_T5)) * i1);
+        v1.ang = v1.ang + (v3(ROW1(t4, CP_T4)) * i0 + v3(ROW1(t5, CP_T5)) * i1);
         v2.lin = v2.lin + cmul(t0 * (-i0) + t1 * (-i1), im2);
-        v2.ang = v2.ang + (v3(A.ld(CP_T6)) * i0 + v3(A.ld(CP_T7)) * i1);
+        v2.ang = v2.ang + (v3(ROW1(t6, CP_T6)) * i0 + v3(ROW1(t7, CP_T7)) * i1);
         if (n > 1) {
-            float4 h3 = A.ld(CP_H3), h4 = A.ld(CP_H4), h5 = A.ld(CP_H5);
+            float4 h3 = ROW1(ph3, CP_H3), h4 = ROW1(ph4, CP_H4), h5 = ROW1(ph5, CP_H5);
             Sym3 ii1 = {h3.x, h3.y, h3.z, h3.w, h4.x, h4.y}, ii2 = {h4.z, h4.w, h5.x, h5.y, h5.z, h5.w};
             v1.ang = v1.ang + sym_mul(ii1, dir1) * hm0.x;
             v2.ang = v2.ang - sym_mul(ii2, dir1) * hm0.x;
@@ -245,14 +280,30 @@ RP_DEV void cons_solve(const DevWorld &w, const Acc &A, bool refresh, bool frict
     x1.r = q4(0, 0, 0, 1); x1.t = v3(0, 0, 0); x2 = x1;
     if (refresh) { x1 = A.xf(id1); x2 = A.xf(id2); tangent_delta = v3(A.ld(CP_B2)) * solved_dt; }
     float imp[4] = {0, 0, 0, 0};
+    // (Acc::PRELOAD: all rows in before the first one goes out — the four point solves and the friction solve then run back to back
+    // instead of each waiting for its own loads)
+    float4 pm[4], pa[4], pb[4], pc[4], pd[4], pe[4], pf[4];
+    float4 ph6 = make_float4(0, 0, 0, 0), ph7 = ph6, ph8 = ph6, phm0 = ph6, phm1 = ph6, ph3 = ph6, ph4 = ph6, ph5 = ph6, q0 = ph6, q1 = ph6, q2 = ph6, q3 = ph6, q4_ = ph6, q5 = ph6, q6 = ph6, q7 = ph6;
+    if (Acc::PRELOAD) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (k < n) {
+            pm[k] = A.ld(NPL(k, NP_M)); pa[k] = A.ld(NPL(k, NP_A)); pb[k] = A.ld(NPL(k, NP_B)); pc[k] = A.ld(NPL(k, NP_C)); pd[k] = A.ld(NPL(k, NP_D));
+            if (refresh) { pe[k] = A.ld(NPL(k, NP_E)); pf[k] = A.ld(NPL(k, NP_F)); }
+        }
+        if (friction) {
+            ph6 = A.ld(CP_H6); ph7 = A.ld(CP_H7); ph8 = A.ld(CP_H8); phm0 = A.ld(CP_HM0); phm1 = A.ld(CP_HM1);
+            if (n > 1) { ph3 = A.ld(CP_H3); ph4 = A.ld(CP_H4); ph5 = A.ld(CP_H5); }
+            q0 = A.ld(CP_T0); q1 = A.ld(CP_T1); q2 = A.ld(CP_T2); q3 = A.ld(CP_T3); q4_ = A.ld(CP_T4); q5 = A.ld(CP_T5); q6 = A.ld(CP_T6); q7 = A.ld(CP_T7);
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (k >= n) break;
-        float4 m = A.ld(NPL(k, NP_M));
-        float4 a = A.ld(NPL(k, NP_A)), b = A.ld(NPL(k, NP_B)), c = A.ld(NPL(k, NP_C)), d = A.ld(NPL(k, NP_D));
+        float4 m = ROWK(pm, k, NPL(k, NP_M));
+        float4 a = ROWK(pa, k, NPL(k, NP_A)), b = ROWK(pb, k, NPL(k, NP_B)), c = ROWK(pc, k, NPL(k, NP_C)), d = ROWK(pd, k, NPL(k, NP_D));
         if (refresh) {
-            V3 p1 = xf_tp(x1, v3(A.ld(NPL(k, NP_E)))) + tangent_delta;
-            V3 p2 = xf_tp(x2, v3(A.ld(NPL(k, NP_F))));
+            V3 p1 = xf_tp(x1, v3(ROWK(pe, k, NPL(k, NP_E)))) + tangent_delta;
+            V3 p2 = xf_tp(x2, v3(ROWK(pf, k, NPL(k, NP_F))));
             float dist = c.w + dot(p1 - p2, dir1);
             m.x = rp_max(dist, 0.0f) * w.prm.inv_dt_sub;
             m.y = 1.0f;
@@ -269,8 +320,8 @@ RP_DEV void cons_solve(const DevWorld &w, const Acc &A, bool refresh, bool frict
         v2.ang = v2.ang + v3(d) * dl;
     }
     if (friction) {
-        float4 h6 = A.ld(CP_H6), h7 = A.ld(CP_H7), h8 = A.ld(CP_H8);
-        float4 hm0 = A.ld(CP_HM0), hm1 = A.ld(CP_HM1);
+        float4 h6 = ROW1(ph6, CP_H6), h7 = ROW1(ph7, CP_H7), h8 = ROW1(ph8, CP_H8);
+        float4 hm0 = ROW1(phm0, CP_HM0), hm1 = ROW1(phm1, CP_HM1);
         if (refresh) { hm1.z = h6.w; hm1.w = h7.x; }
         V3 t0 = v3(h6), t1 = cross(dir1, t0);
         float tdist[4] = {h8.x, h8.y, h8.z, h8.w};
@@ -279,7 +330,7 @@ RP_DEV void cons_solve(const DevWorld &w, const Acc &A, bool refresh, bool frict
         for (int k = 0; k < 4; ++k) { if (k >= n) break; tangent_limit += imp[k]; twist_limit += imp[k] * tdist[k]; }
         tangent_limit *= h0.w; twist_limit *= h0.w;
         if (n > 1) { // ContactConstraintTwistPartSlim::solve, contact_constraint_element.rs:735-755
-            float4 h3 = A.ld(CP_H3), h4 = A.ld(CP_H4), h5 = A.ld(CP_H5);
+            float4 h3 = ROW1(ph3, CP_H3), h4 = ROW1(ph4, CP_H4), h5 = ROW1(ph5, CP_H5);
             Sym3 ii1 = {h3.x, h3.y, h3.z, h3.w, h4.x, h4.y}, ii2 = {h4.z, h4.w, h5.x, h5.y, h5.z, h5.w};
             V3 a = sym_mul(ii1, dir1), b = sym_mul(ii2, dir1);
             float dvel = dot(dir1, v1.ang - v2.ang) + 0.0f; // twist rhs is always zero
@@ -290,7 +341,7 @@ RP_DEV void cons_solve(const DevWorld &w, const Acc &A, bool refresh, bool frict
             v2.ang = v2.ang - b * dl;
         }
         { // ContactConstraintTangentPartSlim::solve, contact_constraint_element.rs:650-705
-            V3 td10 = v3(A.ld(CP_T0)), td11 = v3(A.ld(CP_T1)), td20 = v3(A.ld(CP_T2)), td21 = v3(A.ld(CP_T3));
+            V3 td10 = v3(ROW1(q0, CP_T0)), td11 = v3(ROW1(q1, CP_T1)), td20 = v3(ROW1(q2, CP_T2)), td21 = v3(ROW1(q3, CP_T3));
             float dvel_0 = dot(t0, v1.lin) + dot(td10, v1.ang) - dot(t0, v2.lin) + dot(td20, v2.ang) + hm1.z;
             float dvel_1 = dot(t1, v1.lin) + dot(td11, v1.ang) - dot(t1, v2.lin) + dot(td21, v2.ang) + hm1.w;
             float k11 = h7.y, k22 = h7.z, k12 = h2.w * 0.5f;
@@ -303,9 +354,9 @@ RP_DEV void cons_solve(const DevWorld &w, const Acc &A, bool refresh, bool frict
             float dl0 = n0 - hm0.z, dl1 = n1 - hm0.w;
             hm0.z = n0; hm0.w = n1;
             v1.lin = v1.lin + cmul(t0 * dl0 + t1 * dl1, im1);
-            v1.ang = v1.ang + (v3(A.ld(CP_T4)) * dl0 + v3(A.ld(CP_T5)) * dl1);
+            v1.ang = v1.ang + (v3(ROW1(q4_, CP_T4)) * dl0 + v3(ROW1(q5, CP_T5)) * dl1);
             v2.lin = v2.lin + cmul(t0 * (-dl0) + t1 * (-dl1), im2);
-            v2.ang = v2.ang + (v3(A.ld(CP_T6)) * dl0 + v3(A.ld(CP_T7)) * dl1);
+            v2.ang = v2.ang + (v3(ROW1(q6, CP_T6)) * dl0 + v3(ROW1(q7, CP_T7)) * dl1);
         }
         A.st(CP_HM0, hm0);
         if (refresh) A.st(CP_HM1, hm1);

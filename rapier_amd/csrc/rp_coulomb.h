@@ -30,6 +30,7 @@ static_assert(CQ_M + 1 == CQ_PER_POINT, "tangent planes per point (rp_world.h)")
 // generate — contact_with_coulomb_friction.rs:52-300
 template <class Acc>
 RP_DEV bool coul_generate(const DevWorld &w, const Acc &A, int s, int gid1, int gid2, int id1, int id2) {
+    constexpr int RP_UNR = Acc::PRELOAD ? 4 : 1; // the point loops are unrolled only where the preloaded rows need static indices
     Vel vels1 = A.vel(id1), vels2 = A.vel(id2);
     Xf poses1 = A.xf(id1), poses2 = A.xf(id2);
     V3 im1 = gid1 >= 0 ? v3(w.b_eim[gid1]) : v3(0, 0, 0), im2 = gid2 >= 0 ? v3(w.b_eim[gid2]) : v3(0, 0, 0);
@@ -45,13 +46,25 @@ RP_DEV bool coul_generate(const DevWorld &w, const Acc &A, int s, int gid1, int 
     int cids = 0;
     bool bouncy_seed = false;
     V3 imsum = im1 + im2;
+    // inputs of every point first, rows after (see cons_generate)
+    float4 in_a1[4], in_a2[4], in_imp[4], in_wst[4], in_dp1[4], in_dp2[4];
+    if (Acc::PRELOAD) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (k < count) { in_a1[k] = PT(w.sc_a1, k, s); in_a2[k] = PT(w.sc_a2, k, s); }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (k < count) {
+            const int cid = __float_as_int(in_a2[k].w);
+            in_imp[k] = PT(w.pt_imp, cid, s); in_wst[k] = PT(w.pt_wst, cid, s); in_dp1[k] = PT(w.pt_dp1, cid, s); in_dp2[k] = PT(w.pt_dp2, cid, s);
+        }
+    }
+#pragma unroll RP_UNR
     for (int k = 0; k < 4; ++k) {
         if (k >= count) break;
-        float4 a1 = PT(w.sc_a1, k, s), a2 = PT(w.sc_a2, k, s);
+        float4 a1 = Acc::PRELOAD ? in_a1[k] : PT(w.sc_a1, k, s), a2 = Acc::PRELOAD ? in_a2[k] : PT(w.sc_a2, k, s);
         int cid = __float_as_int(a2.w);
         cids |= (cid & 0xff) << (8 * k);
-        float4 pimp = PT(w.pt_imp, cid, s);
-        V3 wt = v3(PT(w.pt_wst, cid, s));
+        float4 pimp = Acc::PRELOAD ? in_imp[k] : PT(w.pt_imp, cid, s);
+        V3 wt = v3(Acc::PRELOAD ? in_wst[k] : PT(w.pt_wst, cid, s));
         float warmstart_impulse = pimp.y;
         float wti0 = dot(wt, t0), wti1 = dot(wt, t1);
         bool is_new = pimp.x == 0.0f;
@@ -59,7 +72,7 @@ RP_DEV bool coul_generate(const DevWorld &w, const Acc &A, int s, int gid1, int 
         V3 p1 = xf_tp(poses1, v3(a1));
         V3 p2 = xf_tp(poses2, v3(a2));
         float dist = dot(p1 - p2, force_dir1);
-        V3 dp1 = v3(PT(w.pt_dp1, cid, s)), dp2 = v3(PT(w.pt_dp2, cid, s));
+        V3 dp1 = v3(Acc::PRELOAD ? in_dp1[k] : PT(w.pt_dp1, cid, s)), dp2 = v3(Acc::PRELOAD ? in_dp2[k] : PT(w.pt_dp2, cid, s));
         V3 vel1 = vels1.lin + cross(vels1.ang, dp1);
         V3 vel2 = vels2.lin + cross(vels2.ang, dp2);
         {
@@ -112,6 +125,7 @@ RP_DEV bool coul_generate(const DevWorld &w, const Acc &A, int s, int gid1, int 
 // update (:362-455) + warmstart (:561-603)
 template <class Acc>
 RP_DEV void coul_update_warmstart(const DevWorld &w, const Acc &A) {
+    constexpr int RP_UNR = Acc::PRELOAD ? 4 : 1; // the point loops are unrolled only where the preloaded rows need static indices
     int id1 = A.id1(), id2 = A.id2(), n = A.n();
     bool is_static = id1 < 0 || id2 < 0;
     float fstatic = is_static ? 1.0f : 0.0f;
@@ -126,12 +140,23 @@ RP_DEV void coul_update_warmstart(const DevWorld &w, const Acc &A) {
     Vel v1 = A.vel(id1), v2 = A.vel(id2);
     bool ws = wc != 0.0f;
     float ti0[4] = {0, 0, 0, 0}, ti1[4] = {0, 0, 0, 0};
+    // (Acc::PRELOAD: every row in before the first one goes out, see GlobalAccT in rp_constraint.h)
+    float4 pm[4], pc[4], pd[4], pe[4], pf[4], qm[4], qa[4], qb[4], qc[4], qd[4], qi10[4], qi11[4], qi20[4], qi21[4];
+    if (Acc::PRELOAD) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (k < n) {
+            pm[k] = A.ld(NPL(k, NP_M)); pc[k] = A.ld(NPL(k, NP_C)); pd[k] = A.ld(NPL(k, NP_D)); pe[k] = A.ld(NPL(k, NP_E)); pf[k] = A.ld(NPL(k, NP_F));
+            qm[k] = A.ld(CQL(k, CQ_M)); qa[k] = A.ld(CQL(k, CQ_TD10)); qb[k] = A.ld(CQL(k, CQ_TD11)); qc[k] = A.ld(CQL(k, CQ_TD20)); qd[k] = A.ld(CQL(k, CQ_TD21));
+            if (ws) { qi10[k] = A.ld(CQL(k, CQ_I10)); qi11[k] = A.ld(CQL(k, CQ_I11)); qi20[k] = A.ld(CQL(k, CQ_I20)); qi21[k] = A.ld(CQL(k, CQ_I21)); }
+        }
+    }
+#pragma unroll RP_UNR
     for (int k = 0; k < 4; ++k) {
         if (k >= n) break;
-        float4 m = A.ld(NPL(k, NP_M));
-        float4 c = A.ld(NPL(k, NP_C)), d = A.ld(NPL(k, NP_D));
-        V3 p1 = xf_tp(x1, v3(A.ld(NPL(k, NP_E))));
-        V3 p2 = xf_tp(x2, v3(A.ld(NPL(k, NP_F))));
+        float4 m = ROWK(pm, k, NPL(k, NP_M));
+        float4 c = ROWK(pc, k, NPL(k, NP_C)), d = ROWK(pd, k, NPL(k, NP_D));
+        V3 p1 = xf_tp(x1, v3(ROWK(pe, k, NPL(k, NP_E))));
+        V3 p2 = xf_tp(x2, v3(ROWK(pf, k, NPL(k, NP_F))));
         float dist = c.w + dot(p1 - p2, dir1);
         float rhs_wo_bias = rp_max(dist, 0.0f) * inv_dt;
         float rhs_bias = rp_clamp(dist * erp_inv_dt, -maxcv, 0.0f);
@@ -140,14 +165,14 @@ RP_DEV void coul_update_warmstart(const DevWorld &w, const Acc &A) {
         m.w += m.z;
         m.z *= wc;
         A.st(NPL(k, NP_M), m);
-        float4 tm = A.ld(CQL(k, CQ_M));
+        float4 tm = ROWK(qm, k, CQL(k, CQ_M));
         tm.z += tm.x; tm.w += tm.y;
         tm.x *= wc; tm.y *= wc;
         A.st(CQL(k, CQ_M), tm);
         ti0[k] = tm.x; ti1[k] = tm.y;
-        float4 a = A.ld(CQL(k, CQ_TD10)), b = A.ld(CQL(k, CQ_TD11));
-        a.w = A.ld(CQL(k, CQ_TD20)).w + dot(p1 - p2, t0) * inv_dt;
-        b.w = A.ld(CQL(k, CQ_TD21)).w + dot(p1 - p2, t1) * inv_dt;
+        float4 a = ROWK(qa, k, CQL(k, CQ_TD10)), b = ROWK(qb, k, CQL(k, CQ_TD11));
+        a.w = ROWK(qc, k, CQL(k, CQ_TD20)).w + dot(p1 - p2, t0) * inv_dt;
+        b.w = ROWK(qd, k, CQL(k, CQ_TD21)).w + dot(p1 - p2, t1) * inv_dt;
         A.st(CQL(k, CQ_TD10), a); A.st(CQL(k, CQ_TD11), b);
         if (ws) { // ContactConstraintNormalPart::warmstart, contact_constraint_element.rs:226-240
             v1.lin = v1.lin + cmul(dir1, im1) * m.z;
@@ -157,13 +182,14 @@ RP_DEV void coul_update_warmstart(const DevWorld &w, const Acc &A) {
         }
     }
     if (ws) {
+#pragma unroll RP_UNR
         for (int k = 0; k < 4; ++k) { // ContactConstraintTangentPart::warmstart, :64-97
             if (k >= n) break;
             float i0 = ti0[k], i1 = ti1[k];
             v1.lin = v1.lin + cmul(t0 * i0 + t1 * i1, im1);
-            v1.ang = v1.ang + (v3(A.ld(CQL(k, CQ_I10))) * i0 + v3(A.ld(CQL(k, CQ_I11))) * i1);
+            v1.ang = v1.ang + (v3(ROWK(qi10, k, CQL(k, CQ_I10))) * i0 + v3(ROWK(qi11, k, CQL(k, CQ_I11))) * i1);
             v2.lin = v2.lin + cmul(t0 * (-i0) + t1 * (-i1), im2);
-            v2.ang = v2.ang + (v3(A.ld(CQL(k, CQ_I20))) * i0 + v3(A.ld(CQL(k, CQ_I21))) * i1);
+            v2.ang = v2.ang + (v3(ROWK(qi20, k, CQL(k, CQ_I20))) * i0 + v3(ROWK(qi21, k, CQL(k, CQ_I21))) * i1);
         }
         A.set_vel(id1, v1); A.set_vel(id2, v2);
     }
@@ -172,6 +198,7 @@ RP_DEV void coul_update_warmstart(const DevWorld &w, const Acc &A) {
 // solve (:605-690) (+ refresh_rhs_wo_bias :460-489 when `refresh`)
 template <class Acc>
 RP_DEV void coul_solve(const DevWorld &w, const Acc &A, bool refresh, bool friction) {
+    constexpr int RP_UNR = Acc::PRELOAD ? 4 : 1; // the point loops are unrolled only where the preloaded rows need static indices
     int id1 = A.id1(), id2 = A.id2(), n = A.n();
     float4 h0 = A.ld(CP_H0);
     V3 dir1 = v3(h0);
@@ -181,13 +208,31 @@ RP_DEV void coul_solve(const DevWorld &w, const Acc &A, bool refresh, bool frict
     x1.r = q4(0, 0, 0, 1); x1.t = v3(0, 0, 0); x2 = x1;
     if (refresh) { x1 = A.xf(id1); x2 = A.xf(id2); }
     float imp[4] = {0, 0, 0, 0};
+    // (Acc::PRELOAD: every row in before the first one goes out, see GlobalAccT in rp_constraint.h)
+    float4 pm[4], pa[4], pb[4], pc[4], pd[4], pe[4], pf[4];
+    float4 r10[4], r11[4], r20[4], r21[4], s10[4], s11[4], s20[4], s21[4], rm[4];
+    float4 ph6 = make_float4(0, 0, 0, 0);
+    if (Acc::PRELOAD) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (k < n) {
+            pm[k] = A.ld(NPL(k, NP_M)); pa[k] = A.ld(NPL(k, NP_A)); pb[k] = A.ld(NPL(k, NP_B)); pc[k] = A.ld(NPL(k, NP_C)); pd[k] = A.ld(NPL(k, NP_D));
+            if (refresh) { pe[k] = A.ld(NPL(k, NP_E)); pf[k] = A.ld(NPL(k, NP_F)); }
+            if (friction) {
+                r10[k] = A.ld(CQL(k, CQ_TD10)); r11[k] = A.ld(CQL(k, CQ_TD11)); r20[k] = A.ld(CQL(k, CQ_TD20)); r21[k] = A.ld(CQL(k, CQ_TD21));
+                s10[k] = A.ld(CQL(k, CQ_I10)); s11[k] = A.ld(CQL(k, CQ_I11)); s20[k] = A.ld(CQL(k, CQ_I20)); s21[k] = A.ld(CQL(k, CQ_I21));
+                rm[k] = A.ld(CQL(k, CQ_M));
+            }
+        }
+        if (friction) ph6 = A.ld(CP_H6);
+    }
+#pragma unroll RP_UNR
     for (int k = 0; k < 4; ++k) {
         if (k >= n) break;
-        float4 m = A.ld(NPL(k, NP_M));
-        float4 a = A.ld(NPL(k, NP_A)), b = A.ld(NPL(k, NP_B)), c = A.ld(NPL(k, NP_C)), d = A.ld(NPL(k, NP_D));
+        float4 m = ROWK(pm, k, NPL(k, NP_M));
+        float4 a = ROWK(pa, k, NPL(k, NP_A)), b = ROWK(pb, k, NPL(k, NP_B)), c = ROWK(pc, k, NPL(k, NP_C)), d = ROWK(pd, k, NPL(k, NP_D));
         if (refresh) {
-            V3 p1 = xf_tp(x1, v3(A.ld(NPL(k, NP_E))));
-            V3 p2 = xf_tp(x2, v3(A.ld(NPL(k, NP_F))));
+            V3 p1 = xf_tp(x1, v3(ROWK(pe, k, NPL(k, NP_E))));
+            V3 p2 = xf_tp(x2, v3(ROWK(pf, k, NPL(k, NP_F))));
             float dist = c.w + dot(p1 - p2, dir1);
             m.x = rp_max(dist, 0.0f) * w.prm.inv_dt_sub;
             m.y = 1.0f;
@@ -204,13 +249,14 @@ RP_DEV void coul_solve(const DevWorld &w, const Acc &A, bool refresh, bool frict
         v2.ang = v2.ang + v3(d) * dl;
     }
     if (friction) {
-        V3 t0 = v3(A.ld(CP_H6)), t1 = cross(dir1, t0);
+        V3 t0 = v3(ROW1(ph6, CP_H6)), t1 = cross(dir1, t0);
+#pragma unroll RP_UNR
         for (int k = 0; k < 4; ++k) { // ContactConstraintTangentPart::solve, contact_constraint_element.rs:100-176
             if (k >= n) break;
             float limit = h0.w * imp[k];
-            float4 td10 = A.ld(CQL(k, CQ_TD10)), td11 = A.ld(CQL(k, CQ_TD11)), td20 = A.ld(CQL(k, CQ_TD20)), td21 = A.ld(CQL(k, CQ_TD21));
-            float4 i10 = A.ld(CQL(k, CQ_I10)), i11 = A.ld(CQL(k, CQ_I11)), i20 = A.ld(CQL(k, CQ_I20)), i21 = A.ld(CQL(k, CQ_I21));
-            float4 tm = A.ld(CQL(k, CQ_M));
+            float4 td10 = ROWK(r10, k, CQL(k, CQ_TD10)), td11 = ROWK(r11, k, CQL(k, CQ_TD11)), td20 = ROWK(r20, k, CQL(k, CQ_TD20)), td21 = ROWK(r21, k, CQL(k, CQ_TD21));
+            float4 i10 = ROWK(s10, k, CQL(k, CQ_I10)), i11 = ROWK(s11, k, CQL(k, CQ_I11)), i20 = ROWK(s20, k, CQL(k, CQ_I20)), i21 = ROWK(s21, k, CQL(k, CQ_I21));
+            float4 tm = ROWK(rm, k, CQL(k, CQ_M));
             if (refresh) { td10.w = td20.w; td11.w = td21.w; A.st(CQL(k, CQ_TD10), td10); A.st(CQL(k, CQ_TD11), td11); }
             float dvel_0 = dot(t0, v1.lin) + dot(v3(td10), v1.ang) - dot(t0, v2.lin) + dot(v3(td20), v2.ang) + td10.w;
             float dvel_1 = dot(t1, v1.lin) + dot(v3(td11), v1.ang) - dot(t1, v2.lin) + dot(v3(td21), v2.ang) + td11.w;

@@ -125,6 +125,7 @@ RP_DEV bool flow_reached(const FlowCtx &cx, int i, int need) {
 // generate reads the start-of-step body state, which nothing modifies before the final write-back: no hand-off needed.
 // (same expressions as body_begin: lin / ang = the body velocities, solver pose = (rotation, world centre of mass))
 struct FlowGenAcc {
+    static constexpr bool PRELOAD = false; // persistent kernel at 256 VGPRs already: see GlobalAccT
     const DevWorld &w; int pos;
     RP_DEV FlowGenAcc(const DevWorld &w_, int pos_) : w(w_), pos(pos_) {}
     RP_DEV void st(int plane, float4 v) const { w.C[(size_t)plane * w.cons_cap + pos] = v; }
@@ -146,6 +147,7 @@ struct FlowGenAcc {
 // (Preloading the planes into registers ahead of the wait was measured and dropped: the hand-off latency, not the plane loads,
 // bounds a hop — DESIGN.md §4.6.)
 struct FlowAcc {
+    static constexpr bool PRELOAD = false; // persistent kernel at 256 VGPRs already: see GlobalAccT
     const DevWorld &w; const FlowCtx &cx; int pos, i1, i2, nn; unsigned t1, t2; // t = tag to publish (expected + 1)
     mutable Vel v1, v2;
     mutable Xf x1, x2;     // solver poses of the two bodies, loaded by the wait loop as soon as they are final for this sweep

@@ -55,7 +55,7 @@ RP_DEV void g_body_writeback(const DevWorld &w, int i) {
     if (type == RP_BODY_DYNAMIC) body_writeback(w, i, v3(w.s_lin[i]), v3(w.s_ang[i]), q4(w.s_rot[i]), v3(w.s_trans[i]));
     else { KinWb k = {w.b_damp, w.s_lin, w.s_ang, w.s_rot, w.s_trans, w.b_lcom_invm, w.b_next_rot, w.b_next_pos, w.b_linvel, w.b_angvel, w.b_pos, w.b_rot, w.b_wcom, w.flags, w.b_quar, w.prm.p.dt}; g_kinematic_writeback(k, i, type); }
 }
-template <bool COUL>
+template <bool COUL, bool PRE = false>
 RP_DEV bool g_generate(const DevWorld &w, int pos) {
     int s = w.cons_pair[pos];
     int rb1 = w.c_parent[w.p_c1[s]], rb2 = w.c_parent[w.p_c2[s]];
@@ -63,25 +63,25 @@ RP_DEV bool g_generate(const DevWorld &w, int pos) {
     bool dyn1 = body_active(w, rb1), dyn2 = body_active(w, rb2); // solver bodies = the active set (solver_body.rs:114)
     int id1 = (dyn1 && rel_dom <= 0) ? rb1 : -1;
     int id2 = (dyn2 && rel_dom >= 0) ? rb2 : -1;
-    if (COUL) return coul_generate(w, GlobalAcc(w, pos), s, id1, id2, id1, id2);
-    return cons_generate(w, GlobalAcc(w, pos), s, id1, id2, id1, id2);
+    if (COUL) return coul_generate(w, GlobalAccT<PRE>(w, pos), s, id1, id2, id1, id2);
+    return cons_generate(w, GlobalAccT<PRE>(w, pos), s, id1, id2, id1, id2);
 }
 
 // Serial tail of one sweep (worker 0 of the reference): stages [first, n_stages) one after the other
 // inside one workgroup, then the overflow colour on lane 0.
-template <int MODE, bool COUL>
+template <int MODE, bool COUL, bool PRE = false>
 RP_DEV void tail_sweep(const DevWorld &w, int first, bool fib, float solved_dt) {
     int nst = w.flags[FL_N_STAGES];
     for (int st = first; st < nst; ++st) {
         int beg = w.stage_begin[st], cnt = w.stage_count[st];
-        for (int i = threadIdx.x; i < cnt; i += blockDim.x) cons_apply_model<COUL>(w, GlobalAcc(w, beg + i), MODE, fib, solved_dt);
+        for (int i = threadIdx.x; i < cnt; i += blockDim.x) cons_apply_model<COUL>(w, GlobalAccT<PRE>(w, beg + i), MODE, fib, solved_dt);
         __threadfence();
         __syncthreads();
     }
     if (w.flags[FL_HAS_OVERFLOW_COLOR]) {
         if (threadIdx.x == 0) {
             int beg = w.stage_begin[nst], cnt = w.stage_count[nst];
-            for (int i = 0; i < cnt; ++i) { cons_apply_model<COUL>(w, GlobalAcc(w, beg + i), MODE, fib, solved_dt); __threadfence(); }
+            for (int i = 0; i < cnt; ++i) { cons_apply_model<COUL>(w, GlobalAccT<PRE>(w, beg + i), MODE, fib, solved_dt); __threadfence(); }
         }
         __threadfence();
         __syncthreads();

@@ -994,6 +994,7 @@ __global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int ha
 // onto the global path, where every colour stage costs a cross-CU hand-off (~8 us) instead of a barrier.
 // Same stage order as global_single_block (rp_global.h), so the result is bit-identical to the global path and the oracle.
 struct IslGenAcc {
+    static constexpr bool PRELOAD = false; // a fused kernel: the preloaded rows would live in scratch (measured: 0.57 -> 1.67 ms)
     const DevWorld &w; int pos; const IslLds &L;
     RP_DEV IslGenAcc(const DevWorld &w_, int pos_, const IslLds &L_) : w(w_), pos(pos_), L(L_) {}
     RP_DEV float4 ld(int plane) const { return w.C[(size_t)plane * w.cons_cap + pos]; }

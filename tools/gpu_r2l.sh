@@ -1,15 +1,17 @@
 #!/bin/bash
-# Round-2 GPU session L: CCD counter tests, bench.py (headline), PMC traffic record for the stamped roofline, C4 on one GPU, configs table.
+# rows preloaded before the first store in the global path's constraint functions: parity of every global-path form + timings
 set -u
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-TAG=${1:-r2l}
-timeout 300 python -m pytest tests/test_gpu_ccd_flag.py -m gpu -q -s > $OUT/pytest_ccd_$TAG.log 2>&1; echo "rc=$?" >> $OUT/pytest_ccd_$TAG.log
-tail -12 $OUT/pytest_ccd_$TAG.log | cut -c1-200
-bash tools/gpu_profile.sh many_pyramids ${TAG}_mp > $OUT/profile_mp_$TAG.log 2>&1
-cp $OUT/${TAG}_mp_hbm_traffic.json profiles/many_pyramids_hbm_traffic.json 2>/dev/null
-head -14 $OUT/${TAG}_mp_kernel_stats.txt | cut -c1-150
-timeout 400 python bench.py > $OUT/bench_$TAG.log 2>&1; tail -1 $OUT/bench_$TAG.log
-timeout 400 python bench.py --workload c4 --gpus 1 --steps 300 --no-cpu-baseline > $OUT/bench_c4_$TAG.log 2>&1; tail -1 $OUT/bench_c4_$TAG.log
-timeout 900 python tools/bench_configs.py $OUT/configs_$TAG.json > $OUT/configs_$TAG.log 2>&1; cat $OUT/configs_$TAG.log | cut -c1-200
+timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_groups.py -x -q -m gpu -k "not full_size" 2>&1 | tail -6 | cut -c1-250
+timeout 900 python -m pytest tests/test_gpu_fuzz.py -x -q -m gpu 2>&1 | tail -4 | cut -c1-250
+timeout 200 python tools/lp_steady.py 2>&1 | cut -c1-300
+python tools/coulomb_rate.py 2>&1 | head -1
+python - <<'P'
+import time
+from rapier_amd import PhysicsWorld, scenes as S
+w = PhysicsWorld.from_scene(S.joint_grid(100)); w.step(200); w.sync()
+t=time.perf_counter(); w.step(500); w.sync(); dt=time.perf_counter()-t
+print("C5 joint_grid: %.1f steps/s (%.3f ms)" % (500/dt, dt*2))
+P
