@@ -124,6 +124,7 @@ RP_DEV bool flow_reached(const FlowCtx &cx, int i, int need) {
 // ---- accessors ------------------------------------------------------------------------------------
 // generate reads the start-of-step body state, which nothing modifies before the final write-back: no hand-off needed.
 // (same expressions as body_begin: lin / ang = the body velocities, solver pose = (rotation, world centre of mass))
+#define FLOW_JROWS 3 // joint rows fetched ahead of the ticket wait (a spherical joint has 3)
 struct FlowGenAcc {
     static constexpr bool PRELOAD = false; // persistent kernel at 256 VGPRs already: see GlobalAccT
     const DevWorld &w; int pos;
@@ -146,13 +147,14 @@ struct FlowGenAcc {
 // write-through records; the poses are fetched by the wait loop as soon as they are final for the sweep (FLOW_RUN_CONTACT).
 // (Preloading the planes into registers ahead of the wait was measured and dropped: the hand-off latency, not the plane loads,
 // bounds a hop — DESIGN.md §4.6.)
-struct FlowAcc {
-    static constexpr bool PRELOAD = false; // persistent kernel at 256 VGPRs already: see GlobalAccT
+template <bool PRE>
+struct FlowAccT {
+    static constexpr bool PRELOAD = PRE; // the twist model has the registers for it (no spill), the Coulomb model does not: see GlobalAccT
     const DevWorld &w; const FlowCtx &cx; int pos, i1, i2, nn; unsigned t1, t2; // t = tag to publish (expected + 1)
     mutable Vel v1, v2;
     mutable Xf x1, x2;     // solver poses of the two bodies, loaded by the wait loop as soon as they are final for this sweep
     mutable bool wrote1, wrote2;
-    RP_DEV FlowAcc(const DevWorld &w_, const FlowCtx &cx_, int pos_, int i1_, int i2_, int n_, unsigned t1_, unsigned t2_)
+    RP_DEV FlowAccT(const DevWorld &w_, const FlowCtx &cx_, int pos_, int i1_, int i2_, int n_, unsigned t1_, unsigned t2_)
         : w(w_), cx(cx_), pos(pos_), i1(i1_), i2(i2_), nn(n_), t1(t1_), t2(t2_), wrote1(false), wrote2(false) {}
     RP_DEV float4 ld(int plane) const { return w.C[(size_t)plane * w.cons_cap + pos]; }
     RP_DEV void st(int plane, float4 v) const { w.C[(size_t)plane * w.cons_cap + pos] = v; }
@@ -473,7 +475,7 @@ __global__ void __launch_bounds__(256) k_global_flow(DevWorld w, int has_restitu
                 if (i1 >= 0) { int2 d = w.fb_deg[i1]; e1 = ep | (unsigned)fs_ws(sc, d.x, d.y, sub, rk.x); pt1 = ep | (unsigned)(sub > 0 ? fs_integ(sc, d.x, d.y, sub - 1) + 1 : 0); }
                 if (i2 >= 0) { int2 d = w.fb_deg[i2]; e2 = ep | (unsigned)fs_ws(sc, d.x, d.y, sub, rk.y); pt2 = ep | (unsigned)(sub > 0 ? fs_integ(sc, d.x, d.y, sub - 1) + 1 : 0); }
             }
-            FlowAcc A(w, cx, pos, i1, i2, nn, e1 + 1u, e2 + 1u);
+            FlowAccT<!COUL && !JOINTS> A(w, cx, pos, i1, i2, nn, e1 + 1u, e2 + 1u);
             FLOW_RUN_CONTACT(A, has, e1, e2, 2, pt1, pt2, cons_apply_model<COUL>(w, A, MODE_WARMSTART, fib, solved_dt));
         }
         // ---- biased sweeps: every joint before any contact ----
@@ -488,9 +490,12 @@ __global__ void __launch_bounds__(256) k_global_flow(DevWorld w, int has_restitu
                     if (i1 >= 0) { int2 d = w.fb_deg[i1]; e1 = ep | (unsigned)fs_jbias(sc, d.x, d.y, sub, it, rk.x); }
                     if (i2 >= 0) { int2 d = w.fb_deg[i2]; e2 = ep | (unsigned)fs_jbias(sc, d.x, d.y, sub, it, rk.y); }
                 }
+                // the joint's rows are this thread's own: fetched now, before the wait for its bodies' tickets, they are off the hand-off chain
+                int nrows = 0; V3 jim1 = v3(0, 0, 0), jim2 = jim1; JointRowsT<FLOW_JROWS> R0;
+                if (has) { nrows = joint_row_count(w.j_locked[j], w.j_limited[j], w.j_motor[j]); jim1 = v3(JRP(JR_IM1, j)); jim2 = v3(JRP(JR_IM2, j)); jrows_load<FLOW_JROWS>(w, j, 0, nrows, R0); }
                 FLOW_RUN(has, i1, e1, i2, e2, {
                     FlowJointIO io = {cx, {v1, v2}, {e1 + 1u, e2 + 1u}};
-                    joint_solve_one_t(w, io, j, false, prm.warmstart_joints && it == 0);
+                    joint_solve_fetched<FlowJointIO, FLOW_JROWS>(w, io, j, nrows, jim1, jim2, R0, false, prm.warmstart_joints && it == 0);
                 });
             }
             if (role == 2) for (int base = 0; base < M; base += T) {
@@ -503,7 +508,7 @@ __global__ void __launch_bounds__(256) k_global_flow(DevWorld w, int has_restitu
                     if (i1 >= 0) { int2 d = w.fb_deg[i1]; e1 = ep | (unsigned)fs_cbias(sc, d.x, d.y, sub, it, rk.x); }
                     if (i2 >= 0) { int2 d = w.fb_deg[i2]; e2 = ep | (unsigned)fs_cbias(sc, d.x, d.y, sub, it, rk.y); }
                 }
-                FlowAcc A(w, cx, pos, i1, i2, nn, e1 + 1u, e2 + 1u);
+                FlowAccT<!COUL && !JOINTS> A(w, cx, pos, i1, i2, nn, e1 + 1u, e2 + 1u);
                 FLOW_RUN_CONTACT(A, has, e1, e2, 0, 0u, 0u, cons_apply_model<COUL>(w, A, MODE_BIAS, fib, solved_dt));
             }
         }
@@ -533,9 +538,11 @@ __global__ void __launch_bounds__(256) k_global_flow(DevWorld w, int has_restitu
                     if (i1 >= 0) { int2 d = w.fb_deg[i1]; e1 = ep | (unsigned)fs_jrelax(sc, d.x, d.y, sub, it, rk.x); }
                     if (i2 >= 0) { int2 d = w.fb_deg[i2]; e2 = ep | (unsigned)fs_jrelax(sc, d.x, d.y, sub, it, rk.y); }
                 }
+                int nrows = 0; V3 jim1 = v3(0, 0, 0), jim2 = jim1; JointRowsT<FLOW_JROWS> R0;
+                if (has) { nrows = joint_row_count(w.j_locked[j], w.j_limited[j], w.j_motor[j]); jim1 = v3(JRP(JR_IM1, j)); jim2 = v3(JRP(JR_IM2, j)); jrows_load<FLOW_JROWS>(w, j, 0, nrows, R0); }
                 FLOW_RUN(has, i1, e1, i2, e2, {
                     FlowJointIO io = {cx, {v1, v2}, {e1 + 1u, e2 + 1u}};
-                    joint_solve_one_t(w, io, j, true, false);
+                    joint_solve_fetched<FlowJointIO, FLOW_JROWS>(w, io, j, nrows, jim1, jim2, R0, true, false);
                 });
             }
             if (role == 2) for (int base = 0; base < M; base += T) {
@@ -548,7 +555,7 @@ __global__ void __launch_bounds__(256) k_global_flow(DevWorld w, int has_restitu
                     if (i1 >= 0) { int2 d = w.fb_deg[i1]; e1 = ep | (unsigned)fs_crelax(sc, d.x, d.y, sub, it, rk.x); pt1 = ep | (unsigned)(fs_integ(sc, d.x, d.y, sub) + 1); }
                     if (i2 >= 0) { int2 d = w.fb_deg[i2]; e2 = ep | (unsigned)fs_crelax(sc, d.x, d.y, sub, it, rk.y); pt2 = ep | (unsigned)(fs_integ(sc, d.x, d.y, sub) + 1); }
                 }
-                FlowAcc A(w, cx, pos, i1, i2, nn, e1 + 1u, e2 + 1u);
+                FlowAccT<!COUL && !JOINTS> A(w, cx, pos, i1, i2, nn, e1 + 1u, e2 + 1u);
                 FLOW_RUN_CONTACT(A, has, e1, e2, 2, pt1, pt2, cons_apply_model<COUL>(w, A, MODE_RELAX, fib, solved_dt + w.prm.dt_sub));
             }
         }
@@ -565,7 +572,7 @@ __global__ void __launch_bounds__(256) k_global_flow(DevWorld w, int has_restitu
                 if (i1 >= 0) { int2 d = w.fb_deg[i1]; e1 = ep | (unsigned)fs_rest(sc, d.x, d.y, rk.x); }
                 if (i2 >= 0) { int2 d = w.fb_deg[i2]; e2 = ep | (unsigned)fs_rest(sc, d.x, d.y, rk.y); }
             }
-            FlowAcc A(w, cx, pos, i1, i2, nn, e1 + 1u, e2 + 1u);
+            FlowAccT<!COUL && !JOINTS> A(w, cx, pos, i1, i2, nn, e1 + 1u, e2 + 1u);
             FLOW_RUN_CONTACT(A, has, e1, e2, 0, 0u, 0u, cons_apply_model<COUL>(w, A, MODE_RESTITUTION, fib, 0.0f));
         }
     }

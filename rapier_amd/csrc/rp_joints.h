@@ -325,17 +325,23 @@ RP_DEV void joint_update_one_t(const DevWorld &w, const IO &io, int j, int subst
 }
 RP_DEV void joint_update_one(const DevWorld &w, int j, int substep_id) { PlainBodyIO io = {w}; joint_update_one_t(w, io, j, substep_id); }
 
-// All rows of joint j: [remove bias] [warm start] solve — solve_joint, staged_island_solver/solve.rs:31-47
-template <class IO>
-RP_DEV void joint_solve_one_t(const DevWorld &w, const IO &io, int j, bool wo_bias, bool warmstart) {
-    int b1 = w.j_b1[j], b2 = w.j_b2[j];
-    int nrows = joint_row_count(w.j_locked[j], w.j_limited[j], w.j_motor[j]);
-    V3 im1 = v3(JRP(JR_IM1, j)), im2 = v3(JRP(JR_IM2, j));
-    V3 l1 = v3(0, 0, 0), a1 = l1, l2 = l1, a2 = l1;
-    if (b1 >= 0) io.load_vel(0, b1, l1, a1);
-    if (b2 >= 0) io.load_vel(1, b2, l2, a2);
-    for (int r = 0; r < nrows; ++r) {
-        JointRow c; jrow_load(w, j, r, c);
+// All rows of joint j: [remove bias] [warm start] solve — solve_joint, staged_island_solver/solve.rs:31-47.
+// The rows are walked CH at a time: the CH rows of a chunk are fetched together before the first of them is solved (a row's store
+// would otherwise hold back the next row's loads: one exposed round trip per row), and a caller that knows its joint early
+// (the dataflow launch: while it waits for its bodies' tickets) fetches the first chunk itself — jrows_load + joint_solve_fetched.
+template <int CH> struct JointRowsT { JointRow c[CH]; };
+template <int CH>
+RP_DEV void jrows_load(const DevWorld &w, int j, int r0, int nrows, JointRowsT<CH> &R) {
+#pragma unroll
+    for (int q = 0; q < CH; ++q) if (r0 + q < nrows) jrow_load(w, j, r0 + q, R.c[q]);
+}
+template <int CH>
+RP_DEV void jrows_solve(const DevWorld &w, int j, int r0, int nrows, JointRowsT<CH> &R, V3 im1, V3 im2, int b1, int b2, V3 &l1, V3 &a1, V3 &l2, V3 &a2, bool wo_bias, bool warmstart) {
+#pragma unroll
+    for (int q = 0; q < CH; ++q) {
+        if (r0 + q >= nrows) break;
+        const int r = r0 + q;
+        JointRow &c = R.c[q];
         if (wo_bias) c.rhs = c.rhs_wo_bias;
         if (warmstart) {
             V3 lin_impulse = c.lin_jac * c.impulse;
@@ -363,8 +369,25 @@ RP_DEV void joint_solve_one_t(const DevWorld &w, const IO &io, int j, bool wo_bi
         JRR(r, JR_LIN, j).w = c.impulse;
         if (wo_bias) JRR(r, JR_A2, j).w = c.rhs;
     }
+}
+// rows [0, CH) already fetched into R0 (with nrows, im1, im2) by the caller
+template <class IO, int CH>
+RP_DEV void joint_solve_fetched(const DevWorld &w, const IO &io, int j, int nrows, V3 im1, V3 im2, JointRowsT<CH> &R0, bool wo_bias, bool warmstart) {
+    int b1 = w.j_b1[j], b2 = w.j_b2[j];
+    V3 l1 = v3(0, 0, 0), a1 = l1, l2 = l1, a2 = l1;
+    if (b1 >= 0) io.load_vel(0, b1, l1, a1);
+    if (b2 >= 0) io.load_vel(1, b2, l2, a2);
+    jrows_solve<CH>(w, j, 0, nrows, R0, im1, im2, b1, b2, l1, a1, l2, a2, wo_bias, warmstart);
+    for (int r0 = CH; r0 < nrows; r0 += CH) { JointRowsT<CH> R; jrows_load<CH>(w, j, r0, nrows, R); jrows_solve<CH>(w, j, r0, nrows, R, im1, im2, b1, b2, l1, a1, l2, a2, wo_bias, warmstart); }
     if (b1 >= 0) io.store_vel(0, b1, l1, a1);
     if (b2 >= 0) io.store_vel(1, b2, l2, a2);
+}
+template <class IO, int CH = 1>
+RP_DEV void joint_solve_one_t(const DevWorld &w, const IO &io, int j, bool wo_bias, bool warmstart) {
+    int nrows = joint_row_count(w.j_locked[j], w.j_limited[j], w.j_motor[j]);
+    V3 im1 = v3(JRP(JR_IM1, j)), im2 = v3(JRP(JR_IM2, j));
+    JointRowsT<CH> R0; jrows_load<CH>(w, j, 0, nrows, R0);
+    joint_solve_fetched<IO, CH>(w, io, j, nrows, im1, im2, R0, wo_bias, warmstart);
 }
 RP_DEV void joint_solve_one(const DevWorld &w, int j, bool wo_bias, bool warmstart) { PlainBodyIO io = {w}; joint_solve_one_t(w, io, j, wo_bias, warmstart); }
 
