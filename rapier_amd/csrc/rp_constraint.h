@@ -25,11 +25,13 @@ RP_DEV Sym3 load_ii(const DevWorld &w, int gid) {
 }
 
 // ---- accessor over HBM ------------------------------------------------------------------------
-// PRELOAD (a trait of every accessor): the constraint functions fetch every row they read before storing their first one.  The compiler
-// cannot tell the rows apart, so a load placed after a store is ISSUED after the arithmetic that feeds the store — one exposed memory
-// round trip per contact point on the Gauss-Seidel critical path of a colour stage (k_stage<BIAS> 5.9 -> 4.x us on b3d_large_pyramid).
-// It costs ~100 live VGPRs: the standalone kernels (k_generate, k_stage, k_tail) take it, the fused ones (one workgroup running the
-// whole solver, the dataflow launch, the generic island kernel) would pay it in scratch spills — measured 3x slower — and do not.
+// PRELOAD (a trait of every accessor): the constraint functions fetch every input they read before storing their first row, instead
+// of point by point.  Measured on b3d_large_pyramid: it pays in k_generate (whose inputs — solver contacts, tracked impulses, lever
+// arms — come from other arrays than the rows it stores, so the compiler must keep every load behind the preceding stores: with all
+// of them issued up front, and the whole register file instead of the 128 VGPRs + scratch a 1024-thread bound left it, 59 -> 36 us)
+// and for the twist contacts of the dataflow launch; it does NOT pay in the colour-stage kernels (the rows of one constraint are
+// distinct offsets from one base: the compiler already hoists those loads; k_stage stayed at 5.9 / 8.6 us) and costs the fused
+// kernels their registers (k_island_generic 0.57 -> 1.67 ms in scratch spills) — those keep the plain form.
 // Same operands, same order either way: only the issue order of the loads changes.
 template <bool PRE>
 struct GlobalAccT {

@@ -81,21 +81,13 @@ __global__ void __launch_bounds__(256) k_ws_prepare(DevWorld w, float solved_dt)
         const V3 im1 = v3(A.ld(CP_H1)), im2 = v3(A.ld(CP_H2));
         const bool ws = wc != 0.0f;
         const int s1 = id1 >= 0 ? 2 * pos : -1, s2 = id2 >= 0 ? 2 * pos + 1 : -1;
-        // rows in before the first row / term goes out (see cons_update_warmstart)
-        float4 pm[4], pc[4], pd[4], pe[4], pf[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) if (k < n) { pm[k] = A.ld(NPL(k, NP_M)); pc[k] = A.ld(NPL(k, NP_C)); pd[k] = A.ld(NPL(k, NP_D)); pe[k] = A.ld(NPL(k, NP_E)); pf[k] = A.ld(NPL(k, NP_F)); }
-        float4 hm0 = A.ld(CP_HM0), hm1 = A.ld(CP_HM1), h7 = A.ld(CP_H7);
-        const float4 b0 = A.ld(CP_B0), b1 = A.ld(CP_B1);
-        float4 t4 = make_float4(0, 0, 0, 0), t5 = t4, t6 = t4, t7 = t4, h3 = t4, h4 = t4, h5 = t4;
-        if (ws) { t4 = A.ld(CP_T4); t5 = A.ld(CP_T5); t6 = A.ld(CP_T6); t7 = A.ld(CP_T7); if (n > 1) { h3 = A.ld(CP_H3); h4 = A.ld(CP_H4); h5 = A.ld(CP_H5); } }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (k >= n) break;
-            float4 m = pm[k];
-            float4 c = pc[k], d = pd[k];
-            V3 p1 = xf_tp(x1, v3(pe[k])) + tangent_delta;
-            V3 p2 = xf_tp(x2, v3(pf[k]));
+            float4 m = A.ld(NPL(k, NP_M));
+            float4 c = A.ld(NPL(k, NP_C)), d = A.ld(NPL(k, NP_D));
+            V3 p1 = xf_tp(x1, v3(A.ld(NPL(k, NP_E)))) + tangent_delta;
+            V3 p2 = xf_tp(x2, v3(A.ld(NPL(k, NP_F))));
             float dist = c.w + dot(p1 - p2, dir1);
             float rhs_wo_bias = rp_max(dist, 0.0f) * inv_dt;
             float rhs_bias = rp_clamp(dist * erp_inv_dt, -maxcv, 0.0f);
@@ -109,9 +101,10 @@ __global__ void __launch_bounds__(256) k_ws_prepare(DevWorld w, float solved_dt)
                 ws_put(w, k, s2, cmul(dir1, im2) * (-m.z)); ws_put(w, 5 + k, s2, v3(d) * m.z);
             }
         }
+        float4 hm0 = A.ld(CP_HM0), hm1 = A.ld(CP_HM1), h7 = A.ld(CP_H7);
         {
-            V3 p1 = xf_tp(x1, v3(b0)) + tangent_delta;
-            V3 p2 = xf_tp(x2, v3(b1));
+            V3 p1 = xf_tp(x1, v3(A.ld(CP_B0))) + tangent_delta;
+            V3 p2 = xf_tp(x2, v3(A.ld(CP_B1)));
             float bias0 = dot(p1 - p2, t0) * inv_dt, bias1 = dot(p1 - p2, t1) * inv_dt;
             hm1.z = h6.w + bias0; hm1.w = h7.x + bias1;
             hm1.x += hm0.z; hm1.y += hm0.w;
@@ -122,9 +115,10 @@ __global__ void __launch_bounds__(256) k_ws_prepare(DevWorld w, float solved_dt)
         A.st(CP_HM0, hm0); A.st(CP_HM1, hm1);
         if (ws) {
             const float i0 = hm0.z, i1 = hm0.w;
-            ws_put(w, 4, s1, cmul(t0 * i0 + t1 * i1, im1)); ws_put(w, 9, s1, v3(t4) * i0 + v3(t5) * i1);
-            ws_put(w, 4, s2, cmul(t0 * (-i0) + t1 * (-i1), im2)); ws_put(w, 9, s2, v3(t6) * i0 + v3(t7) * i1);
+            ws_put(w, 4, s1, cmul(t0 * i0 + t1 * i1, im1)); ws_put(w, 9, s1, v3(A.ld(CP_T4)) * i0 + v3(A.ld(CP_T5)) * i1);
+            ws_put(w, 4, s2, cmul(t0 * (-i0) + t1 * (-i1), im2)); ws_put(w, 9, s2, v3(A.ld(CP_T6)) * i0 + v3(A.ld(CP_T7)) * i1);
             if (n > 1) {
+                float4 h3 = A.ld(CP_H3), h4 = A.ld(CP_H4), h5 = A.ld(CP_H5);
                 Sym3 ii1 = {h3.x, h3.y, h3.z, h3.w, h4.x, h4.y}, ii2 = {h4.z, h4.w, h5.x, h5.y, h5.z, h5.w};
                 ws_put(w, 10, s1, sym_mul(ii1, dir1) * hm0.x);
                 ws_put(w, 10, s2, -(sym_mul(ii2, dir1) * hm0.x)); // v2.ang - y == v2.ang + (-y), exactly
@@ -139,31 +133,15 @@ __global__ void __launch_bounds__(256) k_increment_ws(DevWorld w) {
     body_increment(w, w.b_flags[i], lin, ang, q4(w.s_rot[i]), v3(w.s_incl[i]), v3(w.s_inca[i]), v3(w.b_invpi[i]), q4(w.b_pframe[i]));
     if (w.prm.p.warmstart_coefficient != 0.0f) {
         const int beg = w.fb_begin[i].x, deg = w.fb_deg[i].x;
-        // this body's constraints in sweep order, four at a time: positions, then rows, then all their terms are fetched as three
-        // batches of independent loads (a loop over one toucher at a time walks three dependent round trips per toucher); the sums
-        // are still taken in sweep order
-        for (int r0 = 0; r0 < deg; r0 += 4) {
-            int pos[4], row[4], n[4];
+        for (int r = 0; r < deg; ++r) { // this body's constraints in sweep order
+            const int pos = w.f_sorted[beg + r];
+            const int row = w.k_b1[pos] == i ? 2 * pos : 2 * pos + 1;
+            const int n = w.k_n[pos];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) pos[q] = r0 + q < deg ? w.f_sorted[beg + r0 + q] : -1;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { row[q] = 0; n[q] = 0; if (pos[q] >= 0) { row[q] = w.k_b1[pos[q]] == i ? 2 * pos[q] : 2 * pos[q] + 1; n[q] = w.k_n[pos[q]]; } }
-            V3 tl[4][5], ta[4][6];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) if (pos[q] >= 0) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) if (k < n[q]) { tl[q][k] = ws_get(w, k, row[q]); ta[q][k] = ws_get(w, 5 + k, row[q]); }
-                tl[q][4] = ws_get(w, 4, row[q]); ta[q][4] = ws_get(w, 9, row[q]);
-                if (n[q] > 1) ta[q][5] = ws_get(w, 10, row[q]);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) if (pos[q] >= 0) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { if (k >= n[q]) break; lin = lin + tl[q][k]; ang = ang + ta[q][k]; }
-                lin = lin + tl[q][4];
-                ang = ang + ta[q][4];
-                if (n[q] > 1) ang = ang + ta[q][5];
-            }
+            for (int k = 0; k < 4; ++k) { if (k >= n) break; lin = lin + ws_get(w, k, row); ang = ang + ws_get(w, 5 + k, row); }
+            lin = lin + ws_get(w, 4, row);
+            ang = ang + ws_get(w, 9, row);
+            if (n > 1) ang = ang + ws_get(w, 10, row);
         }
     }
     w.s_lin[i] = f4(lin, 0.0f); w.s_ang[i] = f4(ang, 0.0f);
@@ -177,13 +155,13 @@ __global__ void __launch_bounds__(256) k_stage(DevWorld w, int stage, int fricti
     int beg = w.stage_begin[stage], cnt = w.stage_count[stage];
     int stride = gridDim.x * blockDim.x;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride)
-        cons_apply_model<COUL>(w, GlobalAccP(w, beg + i), MODE, friction_in_bias != 0, solved_dt);
+        cons_apply_model<COUL>(w, GlobalAcc(w, beg + i), MODE, friction_in_bias != 0, solved_dt);
 }
 template <int MODE, bool COUL>
-__global__ void __launch_bounds__(512) k_tail(DevWorld w, int first, int friction_in_bias, float solved_dt) { // 512 threads: 256 VGPRs hold the preloaded rows
+__global__ void __launch_bounds__(1024) k_tail(DevWorld w, int first, int friction_in_bias, float solved_dt) {
     if (MODE == MODE_RESTITUTION && !w.flags[FL_ANY_BOUNCY]) return;
     int npar = w.flags[FL_N_PARALLEL];
-    tail_sweep<MODE, COUL, true>(w, first < npar ? first : npar, friction_in_bias != 0, solved_dt);
+    tail_sweep<MODE, COUL>(w, first < npar ? first : npar, friction_in_bias != 0, solved_dt);
 }
 template <bool COUL>
 __global__ void k_writeback_impulses(DevWorld w) {
@@ -287,7 +265,7 @@ template <int MODE, bool COUL>
 static void launch_sweep_model(const DevWorld &w, hipStream_t st, const SolverLaunchPlan &plan, int fib, float solved_dt) {
     for (int s = 0; s < plan.parallel_stages; ++s)
         hipLaunchKernelGGL((k_stage<MODE, COUL>), dim3(plan.stage_blocks * 4), dim3(64), 0, st, w, s, fib, solved_dt); // one wave per workgroup: a colour stage of ~10k manifolds then spreads over ~150 CUs instead of ~40
-    hipLaunchKernelGGL((k_tail<MODE, COUL>), dim3(1), dim3(512), 0, st, w, plan.parallel_stages, fib, solved_dt);
+    hipLaunchKernelGGL((k_tail<MODE, COUL>), dim3(1), dim3(1024), 0, st, w, plan.parallel_stages, fib, solved_dt);
 }
 template <int MODE>
 static void launch_sweep(const DevWorld &w, hipStream_t st, const SolverLaunchPlan &plan, int fib, float solved_dt) {
