@@ -1283,3 +1283,35 @@ def test_sensor_shapes_and_trigger_volume():
     assert pos[[cap, box, ball], 1].max() < 1.0                                 # all three rest on the ground, below the trigger
     free.step(240)
     assert free.read()[0][[cap, box, ball], 1].min() > 3.0                      # ... where the solid slab catches them
+
+
+# ---- joint_contact_solve_order.rs: joints are solved BEFORE contacts in every pass ----
+def test_joint_contact_solve_order_heavy_cubes_rest_on_sprung_balls():
+    """crates/rapier3d/tests/joint_contact_solve_order.rs:29-82 (`Spring Joints` demo): 31 light balls hang from springs, a cube 200
+    times heavier is dropped on each; with joints solved after the contacts every cube tunnels through its ball.  The reference
+    uses SpringJoint (coupled axes, outside this ABI); the same physics is restated with a prismatic joint along Y whose position
+    motor is the spring (stiffness 1e3, damping from 0 to twice critical across the row)."""
+    sc = world()
+    g = sc.add_body(body_type=S.BODY_FIXED)
+    num, radius = 30, 0.5
+    mass = 4.0 / 3.0 * np.pi * radius ** 3
+    stiffness = 1.0e3
+    critical = 2.0 * np.sqrt(stiffness * mass)
+    along_y = (0.0, 0.0, 0.70710678, 0.70710678)       # the joint frame's X axis (the free one) turned onto world Y
+    pairs = []
+    for i in range(num + 1):
+        x = -6.0 + 1.5 * i
+        ball = sc.add_body(translation=(x, 4.5, 0.0))
+        sc.add_collider(ball, shape=S.SHAPE_BALL, half_extents=(radius, 0.0, 0.0))
+        damping = (i / (num / 2.0)) * critical
+        sc.add_joint(g, ball, (x, 1.5, 0.0), (0.0, 0.0, 0.0), locked_axes=S.LOCK_PRISMATIC, basis1=along_y, basis2=along_y,
+                     motors={0: dict(target_pos=0.0, stiffness=stiffness, damping=float(damping), model=S.MOTOR_FORCE_BASED)})
+        cube = sc.add_body(translation=(x, 9.5, 0.0), can_sleep=1)
+        sc.add_collider(cube, half_extents=(radius, radius, radius), density=100.0)
+        pairs.append((ball, cube))
+    w = OracleWorld(sc)
+    w.step(300)
+    pos, _ = w.read()
+    assert np.isfinite(pos).all()
+    for i, (ball, cube) in enumerate(pairs):
+        assert pos[cube, 1] > pos[ball, 1], f"cube {i} tunnelled through its sprung ball (cube y = {pos[cube, 1]:.3f}, ball y = {pos[ball, 1]:.3f})"
