@@ -34,6 +34,19 @@ def test_descriptor_layouts_match_header():
     assert p.tobytes() == q.tobytes()  # IntegrationParameters::default() agrees on both sides
 
 
+def test_shape_and_body_enums_agree_across_header_python_and_oracle():
+    """the numeric shape / body-type codes are spelled three times (C header, scenes.py, the oracle's header): they must agree"""
+    def enum_values(path, prefix):
+        txt = re.sub(r"/\*.*?\*/", "", open(path).read(), flags=re.S)
+        return {m.group(1): int(m.group(2)) for m in re.finditer(prefix + r"_([A-Z_]+)\s*=\s*(\d+)", txt)}
+    hdr = enum_values(os.path.join(ROOT, "include", "rapier_hip.h"), "RP_SHAPE")
+    ora = enum_values(os.path.join(ROOT, "oracle", "rapier_oracle.h"), "RO_SHAPE")
+    assert hdr == ora == {"BALL": S.SHAPE_BALL, "CUBOID": S.SHAPE_CUBOID, "CAPSULE": S.SHAPE_CAPSULE, "HALFSPACE": S.SHAPE_HALFSPACE}
+    hb = enum_values(os.path.join(ROOT, "include", "rapier_hip.h"), "RP_BODY")
+    ob = enum_values(os.path.join(ROOT, "oracle", "rapier_oracle.h"), "RO_BODY")
+    assert hb == ob and hb["DYNAMIC"] == S.BODY_DYNAMIC and hb["FIXED"] == S.BODY_FIXED and hb["KINEMATIC_POSITION"] == S.BODY_KINEMATIC_POSITION
+
+
 def test_no_cpu_fallback_without_device():
     import subprocess
     import sys
