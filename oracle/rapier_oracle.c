@@ -74,7 +74,7 @@ typedef struct {
     int sleeping; pose sleep_prev_pose;
     float max_extent;   /* RigidBodyMassProps::max_extent — rigid_body_components.rs:491-515 */
     int slept_at;       /* step at which the body last fell asleep (pair hints cleared then) */
-    int sleep_label;    /* island label: smallest body index of the connected component */
+    int island_id;      /* RigidBodyIds::island_id: persistent island of a non-fixed body, -1 = INVALID_ISLAND */
     int wake_req;       /* pending IslandManager::wake_up */
     int additional_solver_iterations; /* RigidBody::additional_solver_iterations — extra substeps for the body's whole component */
     int last_group_extra;             /* extra substeps of the solve group the body was in during the last step (-1: not in the active set) */
@@ -154,6 +154,7 @@ typedef struct {
     pose sb_frame1, sb_frame2;            /* frames in solver-body (CoM) space */
     int first_row;
     int removed;                          /* ImpulseJointSet::remove */
+    int linked;                           /* ImpulseJointIslandEvent::Link applied (persistent.rs:13-24) */
 } Joint;
 /* JointConstraint<Real, 1> — joint_velocity_constraint.rs:71-95 */
 typedef struct {
@@ -165,6 +166,20 @@ typedef struct {
     int dof;                              /* WritebackId: Dof(i) = i, Limit(i) = 6 + i, Motor(i) = 12 + i */
 } JointRow;
 typedef struct { int enabled; v3 principal_inertia, inv_principal_inertia; quat principal_frame; } Gyro;
+
+/* PersistentIsland — island_manager/persistent.rs:74-93.  The body / link vectors of the reference are replaced by a per-body
+ * island id + counts: every decision below needs the PARTITION, the body count, and these four scalars. */
+typedef struct PIsland {
+    int used, nbodies;
+    int dirty;      /* constraint_remove_count > 0 (only ever tested against zero: persistent.rs:184, :508) */
+    int denied;     /* split_denied_until */
+    int sleeping;
+} PIsland;
+/* Removal (persistent.rs:98-103) + the canonical position of the unlink in the step: phase 0 = joint edits drained at the top of
+ * the step, 1 = pairs deleted by the broad phase, 2 = end-touch transitions of the narrow phase; key orders a phase. */
+typedef struct Removal { int body1, body2; int phase; uint64_t key; } Removal;
+#define RO_SPLIT_RETRY_COOLDOWN 16   /* persistent.rs:31 */
+#define RO_SEARCH_BUDGET 1024        /* local_split.rs:21 */
 
 struct ro_world {
     ro_params params; v3 gravity;
@@ -188,6 +203,12 @@ struct ro_world {
     ro_stats stats;
     int step_seq;       /* 1-based number of the step in progress */
     int *uf;            /* union-find scratch of the sleep islands */
+    /* PersistentIslands — island_manager/persistent.rs:128-171 */
+    struct PIsland *isl; int isl_cap, isl_next; int *isl_free; int n_isl_free, cap_isl_free;
+    int scan_stamp;     /* sleep_scan_stamp */
+    int pending_split;  /* split_island: the candidate chosen last step, -1 = None */
+    struct Removal *journal; int njournal, cap_journal; /* removal_journal */
+    int32_t pi_stats[RO_ISLAND_STATS];
     int nfree_colliders; /* colliders inserted without a parent */
     uint64_t *nc_keys; int n_nc, nc_dirty; /* sorted (min body, max body) keys of the joints with contacts_enabled = false */
     int32_t *col_events; int ncol_events, cap_col_events;       /* 5 ints per event */
@@ -262,6 +283,7 @@ ro_world *ro_world_new(const ro_params *params, const float gravity[3]) {
     w->map_vals = (int *)malloc(sizeof(int) * w->map_cap);
     for (int i = 0; i < w->map_cap; ++i) w->map_keys[i] = -1;
     w->bp_dirty = 1;
+    w->pending_split = -1;
     return w;
 }
 void ro_world_free(ro_world *w) {
@@ -269,7 +291,53 @@ void ro_world_free(ro_world *w) {
     free(w->bodies); free(w->colliders); free(w->pairs); free(w->map_keys); free(w->map_vals);
     free(w->color_masks); free(w->vels); free(w->incr); free(w->poses); free(w->gyro); free(w->flags);
     free(w->dyn_bodies); free(w->cons); free(w->joints); free(w->active_joints); free(w->joint_order);
-    free(w->joint_rows); free(w->joint_body_colors); free(w->uf); free(w->col_events); free(w->force_meta); free(w->force_vals); free(w->nc_keys); free(w);
+    free(w->joint_rows); free(w->joint_body_colors); free(w->uf); free(w->col_events); free(w->force_meta); free(w->force_vals); free(w->nc_keys); free(w->isl); free(w->isl_free); free(w->journal); free(w);
+}
+
+/* ---- Persistent islands: allocation and membership — island_manager/persistent.rs:196-288 ------------------------------------
+ * Island ids are handed out exactly like PersistentIslands::alloc_island: the most recently freed id first, otherwise the next
+ * unused one.  Fixed bodies are never members; a removed body becomes an inert fixed row here, so "member" = non-fixed. */
+static int pi_alloc(ro_world *w) {
+    int id = w->n_isl_free ? w->isl_free[--w->n_isl_free] : w->isl_next++;
+    if (id >= w->isl_cap) {
+        int nc = w->isl_cap ? w->isl_cap : 1024; while (nc <= id) nc *= 2;
+        w->isl = (PIsland *)realloc(w->isl, sizeof(PIsland) * (size_t)nc);
+        memset(w->isl + w->isl_cap, 0, sizeof(PIsland) * (size_t)(nc - w->isl_cap));
+        w->isl_cap = nc;
+    }
+    PIsland z = {1, 0, 0, 0, 0};
+    w->isl[id] = z;
+    return id;
+}
+static void pi_free(ro_world *w, int id) { /* free_island: a pending split of the freed island is dropped (:211-213) */
+    w->isl[id].used = 0;
+    if (w->pending_split == id) w->pending_split = -1;
+    if (w->n_isl_free == w->cap_isl_free) { w->cap_isl_free = w->cap_isl_free ? 2 * w->cap_isl_free : 1024; w->isl_free = (int *)realloc(w->isl_free, sizeof(int) * (size_t)w->cap_isl_free); }
+    w->isl_free[w->n_isl_free++] = id;
+}
+/* ensure_body (:217-232): a first-seen non-fixed body gets a singleton island */
+static void pi_ensure_body(ro_world *w, int body) {
+    Body *b = &w->bodies[body];
+    if (b->body_type == RO_BODY_FIXED || b->island_id >= 0) return;
+    int id = pi_alloc(w);
+    b->island_id = id; w->isl[id].nbodies = 1; w->isl[id].sleeping = b->sleeping;
+}
+/* remove_body_raw (:254-288): losing a body can split the island exactly like losing a constraint (a body can be a cut vertex),
+ * so the island is dirtied eagerly; the last body frees it */
+static void pi_remove_body(ro_world *w, int body) {
+    Body *b = &w->bodies[body];
+    int id = b->island_id;
+    b->island_id = -1;
+    if (id < 0 || !w->isl[id].used) return;
+    w->isl[id].nbodies--; w->isl[id].dirty = 1;
+    if (w->isl[id].nbodies == 0) pi_free(w, id);
+}
+/* unlink_contact / unlink_joint -> journal_removal (:331-343, :395-418): only the endpoints are recorded, self-loops are not */
+static void pi_journal(ro_world *w, int body1, int body2, int phase, uint64_t key) {
+    if (body1 == body2 || body1 < 0 || body2 < 0) return; /* a side without a body carries no connectivity (local_split.rs:188-196) */
+    if (w->njournal == w->cap_journal) { w->cap_journal = w->cap_journal ? 2 * w->cap_journal : 256; w->journal = (Removal *)realloc(w->journal, sizeof(Removal) * (size_t)w->cap_journal); }
+    Removal r = {body1, body2, phase, key};
+    w->journal[w->njournal++] = r;
 }
 
 /* parry MassProperties::world_inv_inertia */
@@ -536,8 +604,9 @@ int32_t ro_add_body(ro_world *w, const ro_body_desc *d) {
     b->normalized_linear_threshold = d->can_sleep ? 0.05f : -1.0f;
     b->angular_threshold = d->can_sleep ? 0.5f : -1.0f;
     b->time_until_sleep = 0.5f; b->time_since_can_sleep = 0.0f; b->sleeping = 0;
-    b->sleep_prev_pose = pose_ident(); b->sleep_label = w->nbodies; b->slept_at = 0;
+    b->sleep_prev_pose = pose_ident(); b->island_id = -1; b->slept_at = 0;
     recompute_mass_properties(w, b);
+    pi_ensure_body(w, w->nbodies); /* IslandManager::rigid_body_updated -> PersistentIslands::ensure_body (manager.rs:303) */
     return w->nbodies++;
 }
 
@@ -814,20 +883,18 @@ static void apply_wakes(ro_world *w) {
     int any = 0;
     for (int i = 0; i < w->nbodies; ++i) if (w->bodies[i].wake_req) { any = 1; break; }
     if (!any) return;
-    w->uf = (int *)realloc(w->uf, sizeof(int) * (size_t)(w->nbodies + 1));
-    int *woken = w->uf; /* scratch: label -> woken this pass */
-    for (int i = 0; i < w->nbodies; ++i) woken[i] = 0;
     for (int i = 0; i < w->nbodies; ++i) {
         Body *b = &w->bodies[i];
         if (!b->wake_req) continue;
-        if (b->sleeping) woken[b->sleep_label] = 1;
+        if (b->sleeping && b->island_id >= 0) w->isl[b->island_id].sleeping = 2; /* marked: the whole persistent island wakes (sleep.rs:44-70) */
         else if (b->wake_req == 2) b->time_since_can_sleep = 0.0f; /* RigidBodyActivation::wake_up(strong) */
         b->wake_req = 0;
     }
     for (int i = 0; i < w->nbodies; ++i) {
         Body *b = &w->bodies[i];
-        if (b->body_type != RO_BODY_FIXED && b->sleeping && woken[b->sleep_label]) { b->sleeping = 0; b->time_since_can_sleep = 0.0f; }
+        if (b->body_type != RO_BODY_FIXED && b->sleeping && b->island_id >= 0 && w->isl[b->island_id].sleeping == 2) { b->sleeping = 0; b->time_since_can_sleep = 0.0f; }
     }
+    for (int i = 0; i < w->isl_next; ++i) if (w->isl[i].used && w->isl[i].sleeping == 2) w->isl[i].sleeping = 0;
 }
 
 static void broad_phase_update(ro_world *w) {
@@ -876,6 +943,7 @@ static void broad_phase_update(ro_world *w) {
              * every body that had a pair with the removed collider (:88-99) */
             int gone = (a->memberships == 0 && a->filter == 0) || (b->memberships == 0 && b->filter == 0);
             if (p->nsc > 0 || gone) { wake_request(w, a->parent, 1); wake_request(w, b->parent, 1); }
+            if (p->nsc > 0) pi_journal(w, a->parent, b->parent, 1, ((uint64_t)(uint32_t)p->c1 << 32) | (uint32_t)p->c2); /* unlink_contact (pair_management.rs:531) */
             /* Stopped event of a touching pair: remove_pair (pair_management.rs:554-558), remove_collider (:101-110, REMOVED flag) */
             if (p->nsc > 0 && ((a->active_events | b->active_events) & 1u)) push_collision_event(w, p->c1, p->c2, 0, gone ? 2 : 0);
             if (p->intersecting && ((a->active_events | b->active_events) & 1u)) push_collision_event(w, p->c1, p->c2, 0, (gone ? 2 : 0) | 1); /* remove_pair / remove_collider on the intersection graph */
@@ -1256,7 +1324,11 @@ static void narrow_phase_compute_contacts(ro_world *w) {
         /* contacts.rs:316-323: Started / Stopped for pairs with ActiveEvents::COLLISION_EVENTS */
         if ((w->colliders[p->c1].active_events | w->colliders[p->c2].active_events) & 1u) push_collision_event(w, p->c1, p->c2, tr[i].touching, tr[i].sensor ? 1 : 0);
         if (tr[i].sensor) continue; /* intersections neither colour nor wake anything */
-        if (!tr[i].touching) { clear_pair_solver_color(w, p); continue; }
+        if (!tr[i].touching) { /* end touch: the colour is freed, the contact link unlinked (contacts.rs:328-330, :359) */
+            clear_pair_solver_color(w, p);
+            pi_journal(w, tr[i].body1, tr[i].body2, 2, ((uint64_t)(uint32_t)p->c1 << 32) | (uint32_t)p->c2);
+            continue;
+        }
         /* wake rule (contacts.rs:333-351): starts wake the sleeping side strongly (whole island), stops never wake */
         if (body_is_sleeping_nonfixed(w, tr[i].body1)) wake_request(w, tr[i].body1, 1);
         if (body_is_sleeping_nonfixed(w, tr[i].body2)) wake_request(w, tr[i].body2, 1);
@@ -2514,15 +2586,224 @@ static void solve_velocity_constraints(ro_world *w) {
     }
 }
 
-/* Whole-island sleep (manager.rs:335-388, solve.rs:196-300).  The reference maintains persistent islands
- * incrementally (merge on begin-touch / joint link, deferred split on end-touch); the sleep decision only
- * needs the partition, so it is recomputed here exactly — connected components of the awake dynamic bodies
- * over touching pairs and joints — which is the partition the reference converges to once its pending splits
- * are resolved (the split cooldown of persistent.rs:31 only delays a sleep by <= 16 steps).  Label = the
- * smallest body index of the component. */
+/* ---- Persistent islands: connectivity maintenance — island_manager/{persistent,local_split,global_split}.rs ------------------
+ *
+ * The reference keeps one PersistentIsland per connected component of the touching-contact / joint graph over the non-fixed
+ * bodies, merged EAGERLY (link_contact / link_joint, union by size) and split LAZILY: an unlinked edge is journaled and resolved
+ * at the top of the next solve by a bounded local search (still connected: nothing happens; detached: the smaller piece moves out
+ * at once; both endpoints moving fast, budget exceeded, sleeping island or a removed body: constraint_remove_count > 0), and an
+ * island with constraint_remove_count > 0 may NOT sleep (finish_sleep_scan, persistent.rs:498-516) until the deferred global
+ * union-find split — one island per step, chosen by the sleepiest eligible body's bid, then SPLIT_RETRY_COOLDOWN steps of rest —
+ * has cleared it.  All of that is restated here; what the decisions READ is the same: the partition, the body counts, the flag,
+ * the cooldown stamp.
+ *
+ * What cannot be taken from /root/reference is the ORDER in which the reference visits links: its link vectors and its
+ * transition sort are keyed by contact-graph edge ids, which are handed out in the pair-creation order of parry's BVH traversal
+ * (not in the tree).  Wherever that order can change an outcome the rule below is canonical (independent of any creation order,
+ * the same on the device), and ro_read_island_stats counts how often a scene exercised it:
+ *   - a merge group of more than two islands in one step keeps the identity (id, cooldown stamp, pending-split status) of its
+ *     LARGEST member, the smaller id on equal size (reference: a tournament of pairwise union-by-size merges in edge order; the
+ *     island of collider1's parent wins equal sizes) — RO_IS_MULTIWAY_GROUPS;
+ *   - absorbed ids are freed in ascending order (reference: in merge order);
+ *   - journal order: joint unlinks (joint index), broad-phase deletions, end-touch transitions (collider pair key) — it matters
+ *     only when two detaching removals hit one island in one step — RO_IS_ORDER_DEPENDENT;
+ *   - a detached component of equal size: body1 = the parent of the pair's smaller collider handle (reference: of collider1, whose
+ *     order is the BVH's) — RO_IS_DETACH_SIZE_TIES;
+ *   - a still-connected verdict is never over budget (the reference's expansion count up to the meeting point depends on its
+ *     adjacency order; a detached verdict costs exactly 2·min(|C0|, |C1|) (+1) expansions and IS budgeted like the reference) —
+ *     differs only inside components of >= 1024 bodies;
+ *   - the global split keeps the largest component in the base island, the one with the smallest body on ties (reference: the first
+ *     root in island-vector order), and creates the others in ascending order of their smallest body (reference: island-vector
+ *     order) — RO_IS_SPLIT_KEEP_TIES;
+ *   - a bid tie goes to the larger island id like the reference (solve.rs:206-211); the ids themselves are canonical as above —
+ *     RO_IS_BID_TIES. */
+static int pi_member(const ro_world *w, int body) { return body >= 0 && w->bodies[body].body_type != RO_BODY_FIXED && w->bodies[body].island_id >= 0; }
+
+/* connected components of the CURRENT touching / joint graph over the awake non-fixed bodies (IslandGraph::for_each_neighbor,
+ * local_split.rs:80-118): uf[i] = smallest body of i's component */
+static void pi_components(ro_world *w, int *uf) {
+    for (int i = 0; i < w->nbodies; ++i) uf[i] = i;
+    for (int i = 0; i < w->npairs; ++i) {
+        const Pair *p = &w->pairs[i];
+        if (!p->alive || p->nsc == 0) continue; /* has_any_active_contact (queries.rs:230) */
+        int b1 = w->colliders[p->c1].parent, b2 = w->colliders[p->c2].parent;
+        if (body_is_active(w, b1) && body_is_active(w, b2)) uf_union(uf, b1, b2);
+    }
+    for (int i = 0; i < w->njoints; ++i) {
+        const Joint *j = &w->joints[i];
+        if (!j->removed && body_is_active(w, j->body1) && body_is_active(w, j->body2)) uf_union(uf, j->body1, j->body2);
+    }
+    for (int i = 0; i < w->nbodies; ++i) uf[i] = uf_find(uf, i);
+}
+
+/* ImpulseJointIslandEvent::Link events, drained in insertion order at the top of the step (substep.rs:357-362) -> link_joint ->
+ * merge_islands (persistent.rs:361-393, :420-461): pairwise union by size, the island of body1 survives equal sizes, the absorbed
+ * id is freed at once.  Joint events are ordered by in-tree code, so this is the reference's own sequence. */
+static void pi_link_joints(ro_world *w) {
+    for (int k = 0; k < w->njoints; ++k) {
+        Joint *j = &w->joints[k];
+        if (j->linked || j->removed) continue;
+        j->linked = 1;
+        if (!pi_member(w, j->body1) || !pi_member(w, j->body2)) continue; /* a fixed side does not connect */
+        int a = w->bodies[j->body1].island_id, b = w->bodies[j->body2].island_id;
+        if (a == b) continue;
+        int big = w->isl[a].nbodies >= w->isl[b].nbodies ? a : b, small = big == a ? b : a;
+        for (int i = 0; i < w->nbodies; ++i) if (w->bodies[i].island_id == small) w->bodies[i].island_id = big;
+        w->isl[big].nbodies += w->isl[small].nbodies; w->isl[big].dirty |= w->isl[small].dirty; w->isl[big].sleeping &= w->isl[small].sleeping;
+        w->isl[small].nbodies = 0; pi_free(w, small);
+        w->pi_stats[RO_IS_MERGED]++;
+    }
+}
+
+/* link_contact -> merge_islands (persistent.rs:293-329, :420-461), for every touching pair whose endpoints sit in different
+ * islands after this step's transitions and wake-ups.  Already-linked edges join nothing, so walking all touching pairs equals
+ * walking the step's begin-touch transitions. */
+static void pi_merge_links(ro_world *w) {
+    int any = 0;
+    for (int i = 0; i < w->npairs && !any; ++i) {
+        const Pair *p = &w->pairs[i];
+        if (!p->alive || p->nsc == 0) continue;
+        int b1 = w->colliders[p->c1].parent, b2 = w->colliders[p->c2].parent;
+        any = pi_member(w, b1) && pi_member(w, b2) && w->bodies[b1].island_id != w->bodies[b2].island_id;
+    }
+    if (!any) return;
+    int n = w->isl_next;
+    int *uf = (int *)malloc(sizeof(int) * (size_t)(4 * n + 4)), *win = uf + n + 1, *cnt = uf + 2 * n + 2, *start_size = uf + 3 * n + 3;
+    for (int i = 0; i < n; ++i) { uf[i] = i; win[i] = -1; cnt[i] = 0; start_size[i] = w->isl[i].used ? w->isl[i].nbodies : 0; }
+    for (int i = 0; i < w->npairs; ++i) {
+        const Pair *p = &w->pairs[i];
+        if (!p->alive || p->nsc == 0) continue;
+        int b1 = w->colliders[p->c1].parent, b2 = w->colliders[p->c2].parent;
+        if (pi_member(w, b1) && pi_member(w, b2)) uf_union(uf, w->bodies[b1].island_id, w->bodies[b2].island_id);
+    }
+    /* the identity that survives a group: its largest island at the start of the step, the smaller id on equal size */
+    for (int i = 0; i < n; ++i) {
+        if (!w->isl[i].used) continue;
+        int r = uf_find(uf, i); cnt[r]++;
+        if (win[r] < 0 || start_size[i] > start_size[win[r]]) win[r] = i; /* ascending i: ties keep the smaller id */
+    }
+    for (int i = 0; i < n; ++i) {
+        if (!w->isl[i].used) continue;
+        int r = uf_find(uf, i), k = win[r];
+        if (cnt[r] > 2 && k == i) w->pi_stats[RO_IS_MULTIWAY_GROUPS]++;
+        if (k == i) continue;
+        /* merge_islands: counts add (the flag ORs), sleeping ANDs, the absorbed island is freed (dropping a pending split of it) */
+        w->isl[k].nbodies += w->isl[i].nbodies; w->isl[k].dirty |= w->isl[i].dirty; w->isl[k].sleeping &= w->isl[i].sleeping;
+        w->pi_stats[RO_IS_MERGED]++;
+    }
+    for (int i = 0; i < w->nbodies; ++i) { Body *b = &w->bodies[i]; if (b->island_id >= 0) b->island_id = win[uf_find(uf, b->island_id)]; }
+    for (int i = 0; i < n; ++i) if (w->isl[i].used && win[uf_find(uf, i)] != i) { w->isl[i].nbodies = 0; pi_free(w, i); } /* ascending id order */
+    free(uf);
+}
+
+static int removal_cmp(const void *a, const void *b) {
+    const Removal *x = (const Removal *)a, *y = (const Removal *)b;
+    if (x->phase != y->phase) return x->phase - y->phase;
+    return x->key < y->key ? -1 : x->key > y->key;
+}
+/* resolve_removals — local_split.rs:164-255 */
+static void pi_resolve_removals(ro_world *w) {
+    if (w->njournal == 0) return;
+    qsort(w->journal, (size_t)w->njournal, sizeof(Removal), removal_cmp);
+    int n = w->nbodies;
+    int *comp = (int *)malloc(sizeof(int) * (size_t)(4 * n + 4)), *size = comp + n + 1, *comp_isl = comp + 2 * n + 2, *detaches = comp + 3 * n + 3;
+    pi_components(w, comp);
+    for (int i = 0; i < n; ++i) { size[i] = 0; comp_isl[i] = -1; }
+    for (int i = 0; i < w->isl_next; ++i) if (i < n) detaches[i] = 0;
+    int ndet_isl = w->isl_next < n ? w->isl_next : n;
+    for (int i = 0; i < n; ++i) if (body_is_active(w, i) && w->bodies[i].island_id >= 0) { size[comp[i]]++; comp_isl[comp[i]] = w->bodies[i].island_id; }
+    const float length_unit = w->params.length_unit;
+    for (int k = 0; k < w->njournal; ++k) {
+        const Removal *r = &w->journal[k];
+        w->pi_stats[RO_IS_REMOVALS]++;
+        /* :186-196 an endpoint that is fixed or gone carried no connectivity */
+        if (!pi_member(w, r->body1) || !pi_member(w, r->body2)) continue;
+        const Body *ba = &w->bodies[r->body1], *bb = &w->bodies[r->body2];
+        /* the island of an endpoint: awake bodies follow their component (an earlier removal of this batch may have moved it out) */
+        int i1 = ba->sleeping ? ba->island_id : comp_isl[comp[r->body1]], i2 = bb->sleeping ? bb->island_id : comp_isl[comp[r->body2]];
+        if (i1 != i2) continue;                                   /* :198-202 */
+        PIsland *isl = &w->isl[i1];
+        if (isl->sleeping) { isl->dirty = 1; w->pi_stats[RO_IS_SLEEPING_DEFERRED]++; continue; } /* :207-210 */
+        /* :212-231 both endpoints above the sleep speed (the farthest-point metric of the sleep energy): defer to the global split */
+        int hot = 1;
+        for (int e = 0; e < 2; ++e) {
+            const Body *b = e ? bb : ba;
+            float lin_threshold = b->normalized_linear_threshold * length_unit;
+            if (lin_threshold < 0.0f) continue; /* never sleeps: always hot */
+            float max_point_vel = sqrtf(vdot(b->linvel, b->linvel)) + sqrtf(vdot(b->angvel, b->angvel)) * b->max_extent;
+            if (!(max_point_vel > lin_threshold)) hot = 0;
+        }
+        if (hot) { isl->dirty = 1; w->pi_stats[RO_IS_HOT]++; continue; }
+        /* search (:371-413): a lockstep dual flood from both endpoints.  Meeting = still connected; otherwise side 0 runs dry
+         * after |C0| expansions of either side if |C0| <= |C1|, side 1 after |C1| + 1 and |C1| expansions if |C1| < |C0| */
+        int c1 = comp[r->body1], c2 = comp[r->body2];
+        if (c1 == c2) { w->pi_stats[RO_IS_CONNECTED]++; continue; }
+        int side = size[c1] <= size[c2] ? 0 : 1;
+        int expansions = side == 0 ? 2 * size[c1] : 2 * size[c2] + 1;
+        if (expansions >= RO_SEARCH_BUDGET) { isl->dirty = 1; w->pi_stats[RO_IS_OVER_BUDGET]++; continue; }
+        if (size[c1] == size[c2]) w->pi_stats[RO_IS_DETACH_SIZE_TIES]++;
+        /* move_component_out (:260-345): a fresh island takes the detached component and its links */
+        int c = side == 0 ? c1 : c2;
+        int id = pi_alloc(w);
+        isl = &w->isl[i1]; /* pi_alloc may have moved the table */
+        w->isl[id].nbodies = size[c]; w->isl[id].sleeping = isl->sleeping;
+        isl->nbodies -= size[c];
+        comp_isl[c] = id;
+        w->pi_stats[RO_IS_DETACHED]++;
+        if (i1 < ndet_isl && ++detaches[i1] == 2) w->pi_stats[RO_IS_ORDER_DEPENDENT]++;
+    }
+    for (int i = 0; i < n; ++i) if (body_is_active(w, i) && w->bodies[i].island_id >= 0) w->bodies[i].island_id = comp_isl[comp[i]];
+    w->njournal = 0;
+    free(comp);
+}
+
+/* run_pending_split -> split_island_now — global_split.rs:44-308 */
+static void pi_run_pending_split(ro_world *w) {
+    int id = w->pending_split;
+    w->pending_split = -1;                                        /* take() */
+    if (id < 0 || !w->isl[id].used || w->isl[id].sleeping) return; /* :46-53 splits only run on awake islands */
+    PIsland *isl = &w->isl[id];
+    w->pi_stats[RO_IS_GLOBAL_SPLITS]++;
+    int n = w->nbodies, ncomp = 0, keep = -1, nkeep = 0;
+    int *comp = NULL, *size = NULL;
+    if (isl->nbodies > 1) {
+        comp = (int *)malloc(sizeof(int) * (size_t)(2 * n + 2)); size = comp + n + 1;
+        pi_components(w, comp);
+        for (int i = 0; i < n; ++i) size[i] = 0;
+        for (int i = 0; i < n; ++i) if (w->bodies[i].island_id == id) size[body_is_active(w, i) ? comp[i] : i]++;
+        for (int i = 0; i < n; ++i) { /* ascending smallest body: the largest component keeps the base island */
+            if (!size[i]) continue;
+            ncomp++;
+            if (keep < 0 || size[i] > size[keep]) { keep = i; nkeep = 1; } else if (size[i] == size[keep]) nkeep++;
+        }
+    }
+    if (ncomp > 1) {
+        if (nkeep > 1) w->pi_stats[RO_IS_SPLIT_KEEP_TIES]++;
+        int base_sleeping = isl->sleeping;
+        for (int c = 0; c < n; ++c) {
+            if (!size[c] || c == keep) continue;
+            int nid = pi_alloc(w);
+            w->isl[nid].nbodies = size[c]; w->isl[nid].sleeping = base_sleeping;
+            for (int i = 0; i < n; ++i) if (w->bodies[i].island_id == id && (body_is_active(w, i) ? comp[i] : i) == c) w->bodies[i].island_id = nid;
+            w->pi_stats[RO_IS_GLOBAL_SPLIT_PIECES]++;
+        }
+        isl = &w->isl[id];
+        isl->nbodies = size[keep];
+    }
+    /* every outcome re-arms the cooldown and clears the count (:69-74, :156-162, :302-305) */
+    isl->dirty = 0; isl->denied = w->scan_stamp + RO_SPLIT_RETRY_COOLDOWN;
+    free(comp);
+}
+
+/* The island part of build_islands_and_solve_velocity_constraints (solve.rs:159-300) and IslandManager::update_islands
+ * (manager.rs:335-388): removals resolved, the pending split run, then the fused pass over the awake bodies — sleep timers
+ * (update_body_energy), the split bid of the sleepiest eligible body of an island that may bid (split_allowed), the per-island
+ * observation — and the whole-island sleep decision behind the constraint_remove_count gate. */
 static void update_sleep(ro_world *w) {
     const float dt = w->params.dt, length_unit = w->params.length_unit;
     int n = w->nbodies, any_can_sleep = 0;
+    pi_resolve_removals(w);
+    pi_run_pending_split(w);
     /* update_body_energy (manager.rs:320-333) -> RigidBodyActivation::update_energy (rigid_body_components.rs:1412-1478) */
     for (int i = 0; i < n; ++i) {
         Body *b = &w->bodies[i];
@@ -2544,35 +2825,48 @@ static void update_sleep(ro_world *w) {
         if (can_sleep) b->time_since_can_sleep += dt; else b->time_since_can_sleep = 0.0f;
         any_can_sleep |= b->normalized_linear_threshold >= 0.0f;
     }
-    if (!any_can_sleep) return;
-    w->uf = (int *)realloc(w->uf, sizeof(int) * (size_t)(2 * n + 2));
-    int *uf = w->uf, *awake = w->uf + n + 1;
-    for (int i = 0; i < n; ++i) { uf[i] = i; awake[i] = 0; }
-    for (int i = 0; i < w->npairs; ++i) {
-        const Pair *p = &w->pairs[i];
-        if (!p->alive || p->nsc == 0) continue;
-        int b1 = w->colliders[p->c1].parent, b2 = w->colliders[p->c2].parent;
-        if (body_is_active(w, b1) && body_is_active(w, b2)) uf_union(uf, b1, b2);
-    }
-    for (int i = 0; i < w->njoints; ++i) {
-        const Joint *j = &w->joints[i];
-        if (!j->removed && body_is_active(w, j->body1) && body_is_active(w, j->body2)) uf_union(uf, j->body1, j->body2);
-    }
-    /* observe_body_for_sleep: an island sleeps once EVERY body is eligible (time_since_can_sleep >= time_until_sleep) */
+    /* split bid (solve.rs:200-237): max (time_since_can_sleep, island id) over the eligible awake bodies whose island has pending
+     * removals and is out of its cooldown; the winner is next step's (single) pending split (:293-295) */
+    int bid_island = -1, bid_tie = 0; float bid_score = 0.0f;
+    int observed = 0;
     for (int i = 0; i < n; ++i) {
         const Body *b = &w->bodies[i];
-        if (body_is_active(w, i) && !(b->time_since_can_sleep >= b->time_until_sleep)) awake[uf_find(uf, i)] = 1;
+        if (!body_is_active(w, i) || b->island_id < 0) continue;
+        observed = 1;
+        if (!(b->time_since_can_sleep >= b->time_until_sleep)) continue;
+        const PIsland *isl = &w->isl[b->island_id];
+        if (!(isl->dirty && w->scan_stamp >= isl->denied)) continue; /* split_allowed (persistent.rs:181-186) */
+        if (bid_island < 0 || b->time_since_can_sleep > bid_score) { bid_score = b->time_since_can_sleep; bid_island = b->island_id; bid_tie = 0; }
+        else if (b->time_since_can_sleep == bid_score && b->island_id != bid_island) { bid_tie = 1; if (b->island_id > bid_island) bid_island = b->island_id; }
     }
-    /* commit_sleeping_chunks -> RigidBody::sleep (rigid_body.rs:804-807) + clear_asleep_pair_solver_hint_counts_of */
+    if (bid_island >= 0) { w->pending_split = bid_island; w->pi_stats[RO_IS_BIDS]++; if (bid_tie) w->pi_stats[RO_IS_BID_TIES]++; }
+    if (!observed) return;
+    /* begin_sleep_scan / observe_body_for_sleep / finish_sleep_scan (persistent.rs:463-516): an island sleeps once EVERY awake
+     * body of it is eligible — unless it lost constraints and holds more than one body: it must split first */
+    w->scan_stamp++;
+    if (!any_can_sleep) return;
+    int *awake = (int *)malloc(sizeof(int) * (size_t)(w->isl_next + 1));
+    for (int i = 0; i < w->isl_next; ++i) awake[i] = 0;
+    for (int i = 0; i < n; ++i) {
+        const Body *b = &w->bodies[i];
+        if (body_is_active(w, i) && b->island_id >= 0 && !(b->time_since_can_sleep >= b->time_until_sleep)) awake[b->island_id] = 1;
+    }
+    for (int i = 0; i < w->isl_next; ++i) {
+        PIsland *isl = &w->isl[i];
+        if (!isl->used || isl->sleeping || awake[i]) { awake[i] = 1; continue; }
+        if (isl->dirty && isl->nbodies > 1) { awake[i] = 1; w->pi_stats[RO_IS_SLEEP_BLOCKED]++; }
+    }
+    /* mark_island_sleeping + commit_sleeping_chunks -> RigidBody::sleep (rigid_body.rs:804-807) + clear_asleep_pair_solver_hint_counts_of */
     for (int i = 0; i < n; ++i) {
         Body *b = &w->bodies[i];
-        if (!body_is_active(w, i)) continue;
-        int root = uf_find(uf, i);
-        if (awake[root]) continue;
+        if (!body_is_active(w, i) || b->island_id < 0 || awake[b->island_id]) continue;
         b->sleeping = 1; b->time_since_can_sleep = b->time_until_sleep;
         b->linvel = V3(0, 0, 0); b->angvel = V3(0, 0, 0);
-        b->sleep_label = root; b->slept_at = w->step_seq;
+        b->slept_at = w->step_seq;
+        w->isl[b->island_id].sleeping = 1;
+        if (w->pending_split == b->island_id) w->pending_split = -1; /* clear_pending_split_of */
     }
+    free(awake);
 }
 
 /* NarrowPhase::emit_contact_force_events — solver_graph.rs:462-498; ContactForceEvent::from_contact_pair — geometry/mod.rs:223-258 */
@@ -2609,40 +2903,31 @@ static void emit_contact_force_events(ro_world *w) {
     }
 }
 
-/* IslandManager::persistent_island_of (test accessor): the island of every body = its connected component over touching pairs
- * and joints among awake non-fixed bodies (label = smallest member), the label it fell asleep with for a sleeping body, -1 for
- * fixed bodies.  The reference maintains these incrementally (eager merge, local / deferred split); the partition it converges to
- * is this one. */
+/* IslandManager::persistent_island_of (manager.rs:214-220) */
 void ro_read_island_labels(ro_world *w, int32_t *out) {
-    int n = w->nbodies;
-    int *uf = (int *)malloc(sizeof(int) * (size_t)(n + 1));
-    for (int i = 0; i < n; ++i) uf[i] = i;
-    for (int i = 0; i < w->npairs; ++i) {
-        const Pair *p = &w->pairs[i];
-        if (!p->alive || p->nsc == 0) continue;
-        int b1 = w->colliders[p->c1].parent, b2 = w->colliders[p->c2].parent;
-        if (body_is_active(w, b1) && body_is_active(w, b2)) uf_union(uf, b1, b2);
-    }
-    for (int i = 0; i < w->njoints; ++i) {
-        const Joint *j = &w->joints[i];
-        if (!j->removed && body_is_active(w, j->body1) && body_is_active(w, j->body2)) uf_union(uf, j->body1, j->body2);
-    }
-    for (int i = 0; i < n; ++i) {
-        const Body *b = &w->bodies[i];
-        out[i] = b->body_type == RO_BODY_FIXED ? -1 : b->sleeping ? b->sleep_label : uf_find(uf, i);
-    }
-    free(uf);
+    for (int i = 0; i < w->nbodies; ++i) out[i] = w->bodies[i].body_type == RO_BODY_FIXED ? -1 : w->bodies[i].island_id;
 }
+void ro_read_island_state(const ro_world *w, int32_t island, int32_t out5[5]) {
+    PIsland z = {0, 0, 0, 0, 0};
+    const PIsland *i = island >= 0 && island < w->isl_next ? &w->isl[island] : &z;
+    out5[0] = i->used; out5[1] = i->nbodies; out5[2] = i->dirty; out5[3] = i->denied; out5[4] = i->sleeping;
+}
+void ro_read_island_globals(const ro_world *w, int32_t out2[2]) { out2[0] = w->scan_stamp; out2[1] = w->pending_split; }
+void ro_read_island_stats(const ro_world *w, int32_t *out) { memcpy(out, w->pi_stats, sizeof(w->pi_stats)); }
+void ro_read_slept_at(const ro_world *w, int32_t *out) { for (int i = 0; i < w->nbodies; ++i) out[i] = w->bodies[i].slept_at; }
 
 /* PhysicsPipeline::step_inner — pipeline/physics_pipeline/substep.rs:267-581 */
 static void step_once(ro_world *w) {
     w->step_seq++;
+    apply_wakes(w);     /* user wake-ups precede the joint edits (substep.rs:288-300) */
+    pi_link_joints(w);
     /* detect_collisions — solve.rs:45-157 (user-requested wake-ups and pair deletions take effect before the
      * narrow phase reads the awake mask) */
     broad_phase_update(w);
     apply_wakes(w);
     narrow_phase_compute_contacts(w);
     apply_wakes(w);
+    pi_merge_links(w); /* link_contact of this step's begin-touch transitions */
     /* interpolate_kinematic_velocities — substep.rs:242-264, RigidBodyPosition::interpolate_velocity
      * (rigid_body_components.rs:147-194) */
     for (int i = 0; i < w->nbodies; ++i) {
@@ -2774,6 +3059,7 @@ int32_t ro_remove_joint(ro_world *w, int32_t joint) {
     if (joint < 0 || joint >= w->njoints || w->joints[joint].removed) return -1;
     w->joints[joint].removed = 1;
     w->nc_dirty = 1;
+    pi_journal(w, w->joints[joint].body1, w->joints[joint].body2, 0, (uint64_t)(uint32_t)joint); /* ImpulseJointIslandEvent::Unlink -> unlink_joint */
     wake_request(w, w->joints[joint].body1, 1); wake_request(w, w->joints[joint].body2, 1); /* remove(.., wake_up = true) */
     memset(w->joints[joint].impulses, 0, sizeof(w->joints[joint].impulses));
     return 0;
@@ -2797,6 +3083,7 @@ int32_t ro_remove_body(ro_world *w, int32_t body) {
     Body *b = &w->bodies[body];
     for (int i = 0; i < w->ncolliders; ++i) if (w->colliders[i].parent == body) ro_remove_collider(w, i);
     for (int i = 0; i < w->njoints; ++i) if (!w->joints[i].removed && (w->joints[i].body1 == body || w->joints[i].body2 == body)) ro_remove_joint(w, i);
+    pi_remove_body(w, body); /* IslandManager::rigid_body_removed_or_disabled (manager.rs:62-78) */
     b->body_type = RO_BODY_FIXED;
     b->linvel = V3(0, 0, 0); b->angvel = V3(0, 0, 0);
     b->solver_id = RO_NO_BODY;

@@ -100,6 +100,7 @@ typedef struct ro_joint_desc {
     ro_joint_motor motors[6];
 } ro_joint_desc;
 
+#define RO_ISLAND_STATS_MAX 16
 typedef struct ro_world ro_world;
 
 void ro_default_params(ro_params *out);
@@ -123,8 +124,40 @@ int32_t ro_intersection_pair(const ro_world *w, int32_t c1, int32_t c2); /* 1 / 
  * island_manager/substep_groups.rs).  Oracle only so far: the device ABI does not expose it yet. */
 void ro_set_additional_solver_iterations(ro_world *w, int32_t body, int32_t n);
 void ro_read_solve_group_extras(const ro_world *w, int32_t *out); /* per body: extra substeps of its solve group in the last step, -1 outside the active set */
-/* island label of every body (IslandManager::persistent_island_of): -1 for fixed bodies */
+/* persistent island id of every body (IslandManager::persistent_island_of, manager.rs:214-220): -1 for fixed / removed bodies.
+ * Only equality between two bodies' ids is meaningful in the reference; here the ids are also canonical (see the island section
+ * of rapier_oracle.c), so the device's ids can be compared one to one. */
 void ro_read_island_labels(ro_world *w, int32_t *out);
+/* Counters of the persistent-island machinery since world creation (diagnostics for the parity argument in DESIGN.md section 5):
+ * which of the decisions that the reference takes in contact-graph edge order — an order owned by parry's BVH traversal — were
+ * actually exercised by a scene. */
+enum {
+    RO_IS_MERGED = 0,            /* islands absorbed by merge_islands */
+    RO_IS_MULTIWAY_GROUPS,       /* merge groups of > 2 islands in one step (the surviving identity may depend on the merge order) */
+    RO_IS_REMOVALS,              /* journal entries resolved */
+    RO_IS_CONNECTED,             /* local search verdict: still connected */
+    RO_IS_DETACHED,              /* local search verdict: detached, component moved out */
+    RO_IS_HOT,                   /* both endpoints above the sleep speed: deferred to the global split */
+    RO_IS_OVER_BUDGET,           /* SEARCH_BUDGET exceeded */
+    RO_IS_SLEEPING_DEFERRED,     /* removal inside a sleeping island */
+    RO_IS_GLOBAL_SPLITS,         /* split_island_now runs */
+    RO_IS_GLOBAL_SPLIT_PIECES,   /* islands created by them */
+    RO_IS_BIDS,                  /* steps with a split bid */
+    RO_IS_BID_TIES,              /* ... whose winning score was shared by two or more islands (island-id tie-break) */
+    RO_IS_SLEEP_BLOCKED,         /* (island, step): every body eligible, sleep refused by the constraint_remove_count gate */
+    RO_IS_ORDER_DEPENDENT,       /* steps in which two detaching removals hit one island (journal order can matter) */
+    RO_IS_DETACH_SIZE_TIES,      /* detach between components of equal size (side 0 = body1's side wins) */
+    RO_IS_SPLIT_KEEP_TIES,       /* global split whose largest component was not unique */
+    RO_ISLAND_STATS
+};
+void ro_read_island_stats(const ro_world *w, int32_t *out /* RO_ISLAND_STATS */);
+/* PersistentIsland of an id: (in use, bodies.len(), constraint_remove_count > 0, split_denied_until, sleeping); PersistentIslands:
+ * (sleep_scan_stamp, split_island or -1) */
+void ro_read_island_state(const ro_world *w, int32_t island, int32_t out5[5]);
+void ro_read_island_globals(const ro_world *w, int32_t out2[2]);
+/* the step each body last fell asleep at (0 = never) and the step of each pair's last full narrow-phase update: per-step trace
+ * material for bisecting against bench/rapier_ref --dump */
+void ro_read_slept_at(const ro_world *w, int32_t *out);
 int32_t ro_num_joints(const ro_world *w);
 void ro_read_joints(const ro_world *w, int32_t *color, float *impulses3);
 void ro_step(ro_world *w, int32_t nsteps);

@@ -630,7 +630,8 @@ def reference_pile(nx: int = 12, ny: int = 3, nz: int = 12, chain: bool = True, 
     """The stress scene of the reference's simd_backend_determinism.rs:61-139 (nx, ny, nz = 12, 3, 12 + a 4-ball spherical-joint
     chain) and, with (14, 2, 14) and no chain, the pile of parallel_path_parity.rs:113-134: a jittered grid of unit cubes that
     settles asymmetrically; bodies keep the builder's can_sleep default (true)."""
-    s = Scene(name=f"reference_pile_{nx}x{ny}x{nz}", gravity=(0.0, -9.81, 0.0))
+    # `Vector::Y * -9.81` = (-0.0, -9.81, -0.0): the zeros keep their sign (they vanish in `user_force + gravity * mass`)
+    s = Scene(name=f"reference_pile_{nx}x{ny}x{nz}", gravity=(-0.0, -9.81, -0.0))
     g = s.add_body(body_type=BODY_FIXED, translation=(0.0, -0.5, 0.0))
     s.add_collider(g, half_extents=(30.0 if not chain else 20.0, 0.5, 30.0 if not chain else 20.0))
     f32 = np.float32
@@ -645,9 +646,12 @@ def reference_pile(nx: int = 12, ny: int = 3, nz: int = 12, chain: bool = True, 
     if chain:
         prev = s.add_body(body_type=BODY_FIXED, translation=(0.0, 8.0, 0.0))
         for i in range(4):
-            b = s.add_body(translation=(0.6 * (i + 1), 8.0, 0.0), can_sleep=1 if sleep else 0)
+            # `0.6 * (i + 1) as Real` is an f32 product (simd_backend_determinism.rs:108-112): 0x3fe66667 for i = 2, not the
+            # narrowed f64 product 0x3fe66666
+            b = s.add_body(translation=(float(f32(0.6) * f32(i + 1)), 8.0, 0.0), can_sleep=1 if sleep else 0)
             s.add_collider(b, shape=SHAPE_BALL, half_extents=(0.25, 0.0, 0.0))
-            s.add_joint(prev, b, (0.3, 0.0, 0.0), (-0.3, 0.0, 0.0), locked_axes=LOCK_LIN)
+            # `Vector::X * -0.3` = (-0.3, -0.0, -0.0): the zeros keep their sign
+            s.add_joint(prev, b, (0.3, 0.0, 0.0), (-0.3, -0.0, -0.0), locked_axes=LOCK_LIN)
             prev = b
     return s
 

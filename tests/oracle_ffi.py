@@ -67,6 +67,10 @@ def lib():
         L.ro_set_joint_motor.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         L.ro_read_joint_motor_impulses.argtypes = [C.c_void_p, C.c_void_p]
         L.ro_read_island_labels.argtypes = [C.c_void_p, C.c_void_p]
+        L.ro_read_island_stats.argtypes = [C.c_void_p, C.c_void_p]
+        L.ro_read_slept_at.argtypes = [C.c_void_p, C.c_void_p]
+        L.ro_read_island_state.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        L.ro_read_island_globals.argtypes = [C.c_void_p, C.c_void_p]
         L.ro_set_additional_solver_iterations.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         L.ro_read_solve_group_extras.argtypes = [C.c_void_p, C.c_void_p]
         L.ro_set_collider_sensor.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
@@ -230,6 +234,33 @@ class OracleWorld:
     def island_labels(self):
         out = np.zeros(self.n, np.int32)
         lib().ro_read_island_labels(self._w, out.ctypes.data)
+        return out
+
+    ISLAND_STATS = ("merged", "multiway_groups", "removals", "connected", "detached", "hot", "over_budget", "sleeping_deferred",
+                    "global_splits", "global_split_pieces", "bids", "bid_ties", "sleep_blocked", "order_dependent", "detach_size_ties",
+                    "split_keep_ties")
+
+    def island_stats(self):
+        """counters of the persistent-island machinery since world creation (ro_read_island_stats)"""
+        out = np.zeros(len(self.ISLAND_STATS), np.int32)
+        lib().ro_read_island_stats(self._w, out.ctypes.data)
+        return dict(zip(self.ISLAND_STATS, (int(v) for v in out)))
+
+    def island_state(self, island):
+        """PersistentIsland: dict(used, nbodies, dirty = constraint_remove_count > 0, denied = split_denied_until, sleeping)"""
+        out = np.zeros(5, np.int32)
+        lib().ro_read_island_state(self._w, int(island), out.ctypes.data)
+        return dict(zip(("used", "nbodies", "dirty", "denied", "sleeping"), (int(v) for v in out)))
+
+    def island_globals(self):
+        """(sleep_scan_stamp, pending split island or -1)"""
+        out = np.zeros(2, np.int32)
+        lib().ro_read_island_globals(self._w, out.ctypes.data)
+        return int(out[0]), int(out[1])
+
+    def slept_at(self):
+        out = np.zeros(self.n, np.int32)
+        lib().ro_read_slept_at(self._w, out.ctypes.data)
         return out
 
     def sleeping(self):
