@@ -260,6 +260,12 @@ int32_t rp_bodies_wake_up(rp_world *w, int32_t n, const uint64_t *handles, int32
  * Worlds holding kinematic bodies take the full step path. */
 int32_t rp_bodies_set_next_kinematic_position(rp_world *w, int32_t n, const uint64_t *handles, const float *pos7);
 int32_t rp_bodies_is_sleeping(rp_world *w, int32_t n, const uint64_t *handles, int32_t *sleeping_out);
+/* IslandManager::persistent_island_of (island_manager/manager.rs:214-220): the persistent island of each body — one connected
+ * component of the touching-contact / joint graph, merged eagerly, split lazily (persistent.rs, local_split.rs, global_split.rs:
+ * an island that lost constraints may not sleep before its deferred, cooldown-throttled split).  -1 for fixed and removed bodies,
+ * and for every body of a world that holds no sleepable body (such a world keeps no islands; the first sleepable body bootstraps
+ * them, persistent.rs:600-625).  As in the reference only EQUALITY of two ids is meaningful. */
+int32_t rp_bodies_persistent_island(rp_world *w, int32_t n, const uint64_t *handles, int32_t *island_out);
 int32_t rp_num_bodies(const rp_world *w);
 
 /* NarrowPhase::contact_pairs() analogue: for each active solver manifold: (collider1, collider2,

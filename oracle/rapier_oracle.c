@@ -3059,7 +3059,7 @@ int32_t ro_remove_joint(ro_world *w, int32_t joint) {
     if (joint < 0 || joint >= w->njoints || w->joints[joint].removed) return -1;
     w->joints[joint].removed = 1;
     w->nc_dirty = 1;
-    pi_journal(w, w->joints[joint].body1, w->joints[joint].body2, 0, (uint64_t)(uint32_t)joint); /* ImpulseJointIslandEvent::Unlink -> unlink_joint */
+    if (w->joints[joint].linked) pi_journal(w, w->joints[joint].body1, w->joints[joint].body2, 0, (uint64_t)(uint32_t)joint); /* ImpulseJointIslandEvent::Unlink -> unlink_joint: a no-op for a joint that was never linked (persistent.rs:396-399) */
     wake_request(w, w->joints[joint].body1, 1); wake_request(w, w->joints[joint].body2, 1); /* remove(.., wake_up = true) */
     memset(w->joints[joint].impulses, 0, sizeof(w->joints[joint].impulses));
     return 0;

@@ -66,6 +66,9 @@ void rp_launch_sleep_fast(const DevWorld &w, hipStream_t st);
 void rp_launch_sensor_fast(const DevWorld &w, hipStream_t st);
 void rp_launch_clear_no_contact(const DevWorld &w, hipStream_t st);
 void rp_launch_global_flow(const DevWorld &w, hipStream_t st, int grid, int has_restitution);
+void rp_launch_pi_ensure(const DevWorld &w, hipStream_t st, int first, int count, int reset);
+void rp_launch_pi_remove_body(const DevWorld &w, hipStream_t st, int b);
+void rp_launch_pj_append_joint(const DevWorld &w, hipStream_t st, int dev_joint, int b1, int b2, int key);
 int rp_flow_grid(int device);
 int rp_fused_grid(int device);
 
@@ -76,6 +79,7 @@ struct HostBody {
     float max_extent = 0.0f, sleep_timer = 0.0f, sprev[7] = {0, 0, 0, 0, 0, 0, 1};
     float ccd_thickness = 3.402823466e+38f; // RigidBodyCcd::ccd_thickness: the thinnest attached shape (Real::MAX without colliders)
     int sleeping = 0, slabel = 0, next_ord = 0;
+    int isl = -1;                     // RigidBodyIds::island_id (persistent islands, rp_sleep.hip), mirrored across device rebuilds
     bool has_next = false; float next[7] = {0, 0, 0, 0, 0, 0, 1}; // RigidBodyPosition::next_position of a kinematic body
     bool quarantined = false;         // disabled by the quarantine (quarantine.rs): inert like a removed body, handle still readable
 };
@@ -100,6 +104,8 @@ struct rp_world {
     std::vector<int> active_joint_ids; // device joint index -> index into `joints`
     std::vector<int> quarantine_log;   // bodies disabled by the quarantine, in detection order
     int quar_seen = 0;                 // value of FL_QUARANTINE the host has already acted on
+    // persistent-island tables saved by download_state() for a rebuild without carry-over (friction-model change)
+    struct { bool valid = false; std::vector<int> used, nb, dirty, denied, sleeping, freel, stats; unsigned long long w64[4] = {0, 0, 0, 0}; int next = 0, nfree = 0, pending = 0; } pi_saved;
     std::vector<int> pending_wake;     // bodies to wake once the device world exists again (joints inserted: insert(.., wake_up = true))
     bool finalized = false;
     int cap_bodies = 0, cap_colliders = 0; // device array capacities (rows beyond n_bodies / n_colliders are spare)
@@ -649,6 +655,26 @@ static int download_state(rp_world *w) {
     std::vector<float4> npos(nb), nrot(nb);
     HIPCHK(w, hipMemcpy(npos.data(), w->dw.b_next_pos, nb * sizeof(float4), hipMemcpyDeviceToHost));
     HIPCHK(w, hipMemcpy(nrot.data(), w->dw.b_next_rot, nb * sizeof(float4), hipMemcpyDeviceToHost));
+    if (w->dw.sleep_enabled) { // persistent islands: ids per body + the island table
+        std::vector<int> isl(nb);
+        HIPCHK(w, hipMemcpy(isl.data(), w->dw.b_isl, nb * sizeof(int), hipMemcpyDeviceToHost));
+        for (int i = 0; i < nb; ++i) w->bodies[i].isl = isl[i];
+        auto &ps = w->pi_saved;
+        int fl[FL_COUNT];
+        HIPCHK(w, hipMemcpy(fl, w->dw.flags, sizeof(fl), hipMemcpyDeviceToHost));
+        ps.next = fl[FL_PI_NEXT]; ps.nfree = fl[FL_PI_NFREE]; ps.pending = fl[FL_PI_PENDING];
+        const int n = std::max(ps.next, 1);
+        ps.used.resize(n); ps.nb.resize(n); ps.dirty.resize(n); ps.denied.resize(n); ps.sleeping.resize(n); ps.freel.resize(std::max(ps.nfree, 1)); ps.stats.resize(16);
+        HIPCHK(w, hipMemcpy(ps.used.data(), w->dw.pi_used, n * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(w, hipMemcpy(ps.nb.data(), w->dw.pi_nb, n * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(w, hipMemcpy(ps.dirty.data(), w->dw.pi_dirty, n * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(w, hipMemcpy(ps.denied.data(), w->dw.pi_denied, n * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(w, hipMemcpy(ps.sleeping.data(), w->dw.pi_sleeping, n * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(w, hipMemcpy(ps.freel.data(), w->dw.pi_free, ps.freel.size() * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(w, hipMemcpy(ps.stats.data(), w->dw.pi_stats, 16 * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(w, hipMemcpy(ps.w64, w->dw.pi_w64, sizeof(ps.w64), hipMemcpyDeviceToHost));
+        ps.valid = true;
+    } else w->pi_saved.valid = false;
     for (int i = 0; i < nb; ++i) {
         HostBody &hb = w->bodies[i];
         hb.has_next = true; hb.next[0] = npos[i].x; hb.next[1] = npos[i].y; hb.next[2] = npos[i].z;
@@ -710,9 +736,12 @@ extern "C" int32_t rp_bodies_insert(rp_world *w, int32_t n, const rp_body_desc *
         if (in_place) { int r = upload_body_row(w, (int)w->bodies.size() - 1); if (r != RP_OK) return r; }
     }
     if (in_place && n > 0) {
+        const int first_new = w->dw.n_bodies, was_sleep_enabled = w->dw.sleep_enabled;
         w->dw.n_bodies = (int)w->bodies.size();
         { int r = check_sleep_scope(w); if (r != RP_OK) return r; }
         w->dw.sleep_enabled = world_sleep_enabled(w) ? 1 : 0;
+        // persistent islands: ensure_body for the new rows; a world that becomes sleep-enabled now bootstraps its islands
+        if (w->dw.sleep_enabled) rp_launch_pi_ensure(w->dw, w->stream, was_sleep_enabled ? first_new : 0, was_sleep_enabled ? n : w->dw.n_bodies, was_sleep_enabled ? 0 : 1);
         w->dw.has_kinematic_pos = world_has_kinematic_pos(w) ? 1 : 0;
         HIPCHK(w, hipStreamSynchronize(w->stream));
         { int r = upload_group_table(w); if (r != RP_OK) return r; }
@@ -1058,6 +1087,10 @@ static int finalize(rp_world *w) {
     DAC(d.b_uforce, capb, DOM_BODY, 1, 1); DAC(d.b_utorque, capb, DOM_BODY, 1, 1); DAC(d.b_flags, capb, DOM_BODY, 1, 1); DAC(d.b_quar, capb, DOM_BODY, 1, 1); DAF(d.b_collider, capb, 0xff);
     DAC(d.b_sleep, capb, DOM_BODY, 1, 1); DA(d.b_sprev_t, capb); DAC(d.b_sprev_r, capb, DOM_BODY, 1, 1); DAC(d.b_slabel, capb, DOM_BODY, 1, 1); DAC(d.b_slept_at, capb, DOM_BODY, 1, 1); DA(d.b_sleep_stamp, capb); DAC(d.b_wake_req, capb, DOM_BODY, 1, 1);
     DAC(d.lab_wake, capb, DOM_BODY, 1, 1); DAC(d.lab_awake, capb, DOM_BODY, 1, 1); DAC(d.b_next_pos, capb, DOM_BODY, 1, 1); DAC(d.b_next_rot, capb, DOM_BODY, 1, 1);
+    // persistent islands (rp_sleep.hip): ids per body, the island table (index = island id < bodies), scratch of a maintenance pass
+    DAFC(d.b_isl, capb, 0xff, DOM_BODY, 1, 1); DAC(d.pi_used, capb, DOM_BODY, 1, 1); DAC(d.pi_nb, capb, DOM_BODY, 1, 1); DAC(d.pi_dirty, capb, DOM_BODY, 1, 1); DAC(d.pi_denied, capb, DOM_BODY, 1, 1);
+    DAC(d.pi_sleeping, capb, DOM_BODY, 1, 1); DAC(d.pi_free, capb, DOM_BODY, 1, 1); DA(d.pi_uf, capb); DA(d.pi_new, capb); DA(d.pi_best, capb); DA(d.pi_csize, capb); DA(d.pi_cisl, capb); DA(d.pi_list, capb);
+    DAC(d.pi_w64, 4, DOM_FIXED, 1, 1); DAC(d.pi_stats, 16, DOM_FIXED, 1, 1);
     DAC(d.s_lin, capb, DOM_BODY, 1, 1); DAC(d.s_ang, capb, DOM_BODY, 1, 1); DAC(d.s_rot, capb, DOM_BODY, 1, 1); DAC(d.s_trans, capb, DOM_BODY, 1, 1); DAC(d.s_incl, capb, DOM_BODY, 1, 1); DAC(d.s_inca, capb, DOM_BODY, 1, 1);
     DAC(d.b_cmask, 4 * (size_t)capb, DOM_BODY, 1, 4); DAFC(d.b_min, capb, 0xff, DOM_BODY, 1, 1);
     DAC(d.c_parent, capc, DOM_COLL, 1, 1); DAC(d.c_ord, capc, DOM_COLL, 1, 1); DAC(d.c_shape, capc, DOM_COLL, 1, 1); DAC(d.c_lpos, capc, DOM_COLL, 1, 1); DAC(d.c_lrot, capc, DOM_COLL, 1, 1); DAC(d.c_pos, capc, DOM_COLL, 1, 1); DAC(d.c_rot, capc, DOM_COLL, 1, 1); DAC(d.c_he, capc, DOM_COLL, 1, 1);
@@ -1146,6 +1179,8 @@ static int finalize(rp_world *w) {
     DA(d.j_locked, nj); DA(d.j_limited, nj); DAC(d.j_color, nj, DOM_JOINT, 1, 1); DAC(d.j_tmp, nj, DOM_JOINT, 1, 1); DAC(d.j_order, nj, DOM_JOINT, 1, 1); DAC(d.j_imp, nj, DOM_JOINT, 1, 1); DAC(d.j_imp_ang, nj, DOM_JOINT, 1, 1);
     DA(d.j_lim, (size_t)6 * std::max(nj, 1)); DAC(d.j_imp_lim, nj, DOM_JOINT, 1, 1); DAC(d.j_imp_lim_ang, nj, DOM_JOINT, 1, 1);
     DA(d.j_motor, nj); DA(d.j_mot, (size_t)12 * std::max(nj, 1)); DAC(d.j_imp_mot, nj, DOM_JOINT, 1, 1); DAC(d.j_imp_mot_ang, nj, DOM_JOINT, 1, 1);
+    d.pj_cap = next_pow2((long long)d.pool_cap + (long long)w->joints.size() + 16); // removal journal: every pair and joint at most once between two sleep passes
+    DAC(d.pj_key, d.pj_cap, DOM_FIXED, 1, 1); DAC(d.pj_b, d.pj_cap, DOM_FIXED, 1, 1);
     DA(d.j_stage_begin, RP_NUM_COLORS + 1); DA(d.j_stage_count, RP_NUM_COLORS + 1); DA(d.j_group, std::max(nj, 1));
     DA(d.jc_first, std::max(nj, 1)); DA(d.jc_list, 2 * (size_t)std::max(nj, 1)); DA(d.jc_sorted, 2 * (size_t)std::max(nj, 1)); DA(d.jc_deps, std::max(nj, 1)); DA(d.jc_q, 2 * (size_t)std::max(nj, 1)); DA(d.jc_rank, std::max(nj, 1)); DA(d.jc_succ, std::max(nj, 1));
     DAC(d.bj_cmask, 4 * (size_t)capb, DOM_BODY, 1, 4); DAFC(d.bj_min, capb, 0xff, DOM_BODY, 1, 1); DA(d.b_njoints, capb);
@@ -1201,8 +1236,29 @@ static int finalize(rp_world *w) {
     HIPCHK(w, locked_hipHostMalloc((void **)&w->pinned_flags, FL_COUNT * sizeof(int), hipHostMallocMapped));
     memset(w->pinned_flags, 0, FL_COUNT * sizeof(int));
     HIPCHK(w, hipHostGetDevicePointer((void **)&d.host_flags, w->pinned_flags, 0));
+    const bool had_islands = w->carry && w->old_dw.sleep_enabled;
+    const int old_nb = w->carry ? w->old_dw.n_bodies : 0, old_nj = w->carry ? w->old_dw.n_joints : 0;
     if (w->carry) { int r = carry_over(w); if (r != RP_OK) return r; } // the rows of the previous device world move in; step counters keep running
     else { w->steps_requested = 0; w->seq_enqueued = 0; w->full_until = 0; }
+    if (d.sleep_enabled) {
+        // persistent islands: a world that grew keeps its table (carried rows) and gives the new bodies singleton islands, its new
+        // joints are linked by the next sleep pass; a rebuilt world takes the saved table; everything else starts from singletons
+        if (had_islands) {
+            rp_launch_pi_ensure(d, w->stream, old_nb, nb - old_nb, 0);
+            if (nj > old_nj) { int cur = 0; HIPCHK(w, hipMemcpy(&cur, d.flags + FL_PI_JLINK, sizeof(int), hipMemcpyDeviceToHost)); if (cur == 0) { cur = old_nj + 1; HIPCHK(w, hipMemcpy(d.flags + FL_PI_JLINK, &cur, sizeof(int), hipMemcpyHostToDevice)); } }
+        } else if (!w->carry && w->pi_saved.valid) {
+            auto &ps = w->pi_saved;
+            std::vector<int> isl(nb); for (int i = 0; i < nb; ++i) isl[i] = w->bodies[i].isl;
+            UP(d.b_isl, isl); UP(d.pi_used, ps.used); UP(d.pi_nb, ps.nb); UP(d.pi_dirty, ps.dirty); UP(d.pi_denied, ps.denied); UP(d.pi_sleeping, ps.sleeping); UP(d.pi_free, ps.freel); UP(d.pi_stats, ps.stats);
+            HIPCHK(w, hipMemcpyAsync(d.pi_w64, ps.w64, sizeof(ps.w64), hipMemcpyHostToDevice, w->stream));
+            int v[3] = {ps.next, ps.nfree, ps.pending};
+            HIPCHK(w, hipMemcpyAsync(d.flags + FL_PI_NEXT, &v[0], sizeof(int), hipMemcpyHostToDevice, w->stream));
+            HIPCHK(w, hipMemcpyAsync(d.flags + FL_PI_NFREE, &v[1], sizeof(int), hipMemcpyHostToDevice, w->stream));
+            HIPCHK(w, hipMemcpyAsync(d.flags + FL_PI_PENDING, &v[2], sizeof(int), hipMemcpyHostToDevice, w->stream));
+            HIPCHK(w, hipStreamSynchronize(w->stream));
+        } else rp_launch_pi_ensure(d, w->stream, 0, nb, 1); // bootstrap (persistent.rs:600-625): singletons; joints and touching pairs link in the first sleep pass
+    }
+    w->pi_saved.valid = false;
     rp_launch_init_bodies(d, w->stream);
     rp_launch_collider_update(d, w->stream);
     HIPCHK(w, hipStreamSynchronize(w->stream));
@@ -1415,7 +1471,7 @@ static int step_once(rp_world *w, bool allow_fast) {
     // three verified on the device: k_fast_front, k_sleep_check); position-based kinematic bodies need the per-step velocity pass
     const bool sleep_fast_ok = !w->dw.sleep_enabled || (!w->dw.has_kinematic_pos && pf[FL_N_AWAKE] > 0 && !pf[FL_WAKE_PENDING]);
     bool fast = allow_fast && w->use_fast && sleep_fast_ok && w->plan_single && w->dw.n_colliders > 0 && w->steps_requested >= w->full_until;
-    if (fast && (pf[FL_FAST_ABORT] || pf[FL_FULL_UPDATES] || pf[FL_LAYOUT_DIRTY] || pf[FL_TODO_COUNT])) {
+    if (fast && (pf[FL_FAST_ABORT] || pf[FL_FULL_UPDATES] || pf[FL_LAYOUT_DIRTY] || pf[FL_TODO_COUNT] || pf[FL_PI_PENDING] || pf[FL_PJ_COUNT] || pf[FL_PI_JLINK])) {
         fast = false;
         w->full_until = w->steps_requested + 3;
     }
@@ -1733,6 +1789,42 @@ extern "C" int32_t rp_bodies_is_sleeping(rp_world *w, int32_t n, const uint64_t 
     return RP_OK;
 }
 
+// IslandManager::persistent_island_of (manager.rs:214-220) per handle: -1 for fixed / removed bodies and in worlds that hold no
+// sleepable body (such worlds keep no islands).  Only equality is meaningful in the reference; here the ids are the oracle's.
+extern "C" int32_t rp_bodies_persistent_island(rp_world *w, int32_t n, const uint64_t *handles, int32_t *out) {
+    if (!w || n < 0 || (n > 0 && (!handles || !out))) return RP_ERR_INVALID;
+    HIPCHK(w, hipSetDevice(w->device));
+    if (!w->finalized) { int r = finalize(w); if (r != RP_OK) return r; }
+    { int r = settle(w); if (r != RP_OK) return r; }
+    std::vector<int> isl(std::max(w->dw.n_bodies, 1), -1);
+    if (w->dw.sleep_enabled && w->dw.n_bodies > 0) HIPCHK(w, hipMemcpy(isl.data(), w->dw.b_isl, (size_t)w->dw.n_bodies * sizeof(int), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) {
+        int b = handle_index(handles[i]);
+        if (b < 0 || b >= w->dw.n_bodies) { w->err = "rp_bodies_persistent_island: invalid handle"; return RP_ERR_INVALID; }
+        out[i] = w->bodies[b].removed ? -1 : isl[b];
+    }
+    return RP_OK;
+}
+// Debug aid (not part of include/rapier_hip.h): the island machinery's counters (slots of the oracle's RO_IS_*), the scan stamp, the
+// pending split (-1 = none) and, for `island` >= 0, its table row (in use, bodies, dirty, denied-until, sleeping).
+extern "C" int32_t rp_debug_islands(rp_world *w, int32_t *stats16, int32_t *stamp_pending2, int32_t island, int32_t *row5) {
+    if (!w || !w->finalized) return RP_ERR_INVALID;
+    HIPCHK(w, hipSetDevice(w->device));
+    { int r = settle(w); if (r != RP_OK) return r; }
+    if (stats16) HIPCHK(w, hipMemcpy(stats16, w->dw.pi_stats, 16 * sizeof(int), hipMemcpyDeviceToHost));
+    if (stamp_pending2) {
+        unsigned long long w64 = 0; int pend = 0;
+        HIPCHK(w, hipMemcpy(&w64, w->dw.pi_w64, sizeof(w64), hipMemcpyDeviceToHost));
+        HIPCHK(w, hipMemcpy(&pend, w->dw.flags + FL_PI_PENDING, sizeof(int), hipMemcpyDeviceToHost));
+        stamp_pending2[0] = (int)(unsigned)(w64 & 0xffffffffull); stamp_pending2[1] = pend - 1;
+    }
+    if (row5 && island >= 0 && island < w->dw.n_bodies) {
+        int *src[5] = {w->dw.pi_used, w->dw.pi_nb, w->dw.pi_dirty, w->dw.pi_denied, w->dw.pi_sleeping};
+        for (int k = 0; k < 5; ++k) HIPCHK(w, hipMemcpy(row5 + k, src[k] + island, sizeof(int), hipMemcpyDeviceToHost));
+    }
+    return RP_OK;
+}
+
 // ---- removal (RigidBodySet::remove / ColliderSet::remove / ImpulseJointSet::remove) ---------------
 // Arena slots are kept as tombstones (indices stay stable, handles of removed items become invalid).
 // A removed collider loses its interaction groups, so the next broad-phase pass deletes its pairs
@@ -1772,6 +1864,7 @@ static int remove_joint_at(rp_world *w, int j) {
         int r;
         if ((r = poke(w, w->dw.j_b1 + k, -1)) != RP_OK || (r = poke(w, w->dw.j_b2 + k, -1)) != RP_OK || (r = poke(w, w->dw.j_locked + k, 0)) != RP_OK || (r = poke(w, w->dw.j_limited + k, 0)) != RP_OK || (r = poke(w, w->dw.j_motor + k, 0)) != RP_OK ||
             (r = poke(w, w->dw.j_imp + k, mk4(0, 0, 0, 0))) != RP_OK || (r = poke(w, w->dw.j_imp_ang + k, mk4(0, 0, 0, 0))) != RP_OK) return r;
+        if (w->dw.sleep_enabled) rp_launch_pj_append_joint(w->dw, w->stream, k, jd.body1, jd.body2, j); // ImpulseJointIslandEvent::Unlink (journaled for resolve_removals)
         for (int b : {jd.body1, jd.body2}) {
             if (w->bodies[b].d.body_type == RP_BODY_FIXED || w->bodies[b].removed) continue;
             if (w->dw.sleep_enabled && (r = queue_wake(w, b, 2)) != RP_OK) return r; // ImpulseJointSet::remove(.., wake_up = true)
@@ -1835,7 +1928,8 @@ static int detach_body_at(rp_world *w, int b) {
     for (size_t c = 0; c < w->colliders.size(); ++c) if (w->collider_parent[c] == b && (r = remove_collider_at(w, (int)c)) != RP_OK) return r;
     for (size_t j = 0; j < w->joints.size(); ++j) if ((w->joints[j].body1 == b || w->joints[j].body2 == b) && (r = remove_joint_at(w, (int)j)) != RP_OK) return r;
     HostBody &hb = w->bodies[b];
-    hb.d.body_type = RP_BODY_FIXED;
+    if (w->finalized && w->dw.sleep_enabled && hb.d.body_type != RP_BODY_FIXED) rp_launch_pi_remove_body(w->dw, w->stream, b); // rigid_body_removed_or_disabled (manager.rs:62-78)
+    hb.d.body_type = RP_BODY_FIXED; hb.isl = -1;
     for (int k = 0; k < 3; ++k) { hb.d.linvel[k] = 0.0f; hb.d.angvel[k] = 0.0f; }
     if (w->finalized) {
         int fl = RP_BODY_FIXED | (hb.d.gyroscopic ? RP_BF_GYRO : 0) | (hb.d.allow_fast_rotation ? RP_BF_FASTROT : 0) | (((int)(hb.d.dominance & 0xff)) << RP_BF_DOM_SHIFT);

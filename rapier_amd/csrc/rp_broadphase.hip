@@ -60,7 +60,7 @@ __global__ void k_fast_front(DevWorld w, int no_global_kernel) {
         w.flags[FL_FULL_UPDATES] = 0;
         if (w.flags[FL_BP_DIRTY]) w.flags[FL_FAST_ABORT] = 1;
         // sleep-enabled worlds: the awake set must be settled — no layout change or wake-up request waiting for a full step
-        if (w.sleep_enabled && (w.flags[FL_LAYOUT_DIRTY] || w.flags[FL_WAKE_PENDING] || w.flags[FL_N_AWAKE] == 0)) w.flags[FL_FAST_ABORT] = 1;
+        if (w.sleep_enabled && (w.flags[FL_LAYOUT_DIRTY] || w.flags[FL_WAKE_PENDING] || w.flags[FL_N_AWAKE] == 0 || w.flags[FL_PI_PENDING] || w.flags[FL_PJ_COUNT] || w.flags[FL_PI_JLINK])) w.flags[FL_FAST_ABORT] = 1; // (a pending island split, journaled removals, joint links: the full graph's sleep pass)
         // this graph variant carries no global-path kernel: it is only valid while everything lives in LDS islands
         if (no_global_kernel && (w.flags[FL_N_CONS] > 0 || w.flags[FL_N_GLOB_BODIES] > 0 || w.n_joints > 0)) w.flags[FL_FAST_ABORT] = 1;
     }
@@ -303,11 +303,12 @@ RP_DEV void bp_finish_pairs(DevWorld &w, int gid, int gstride) {
             int c1 = w.p_c1[s], c2 = w.p_c2[s];
             uint2 g1 = w.c_groups[c1], g2 = w.c_groups[c2];
             bool gone = (g1.x == 0 && g1.y == 0) || (g2.x == 0 && g2.y == 0);
+            int2 rb = w.p_rb[s];
             if (w.p_nsc[s] > 0 || gone) {
-                int2 rb = w.p_rb[s];
                 if (rb.x >= 0) atomicMax(&w.b_wake_req[rb.x], 2);
                 if (rb.y >= 0) atomicMax(&w.b_wake_req[rb.y], 2);
             }
+            if (w.p_nsc[s] > 0) pi_journal(w, rb.x, rb.y, 1, c1, c2); // unlink_contact of a removed touching pair (pair_management.rs:531)
         }
         w.p_c1[s] = -1; w.p_nsc[s] = 0; w.p_npts[s] = 0; w.p_color[s] = RP_COLOR_UNCOLORED;
         int t = atomicAdd(&w.flags[FL_FREE_TOP], 1);

@@ -763,7 +763,8 @@ __device__ __noinline__ void pair_full_update(DevWorld &w, int s, int c1, int c2
     if (has != had) {
         w.flags[FL_LAYOUT_DIRTY] = 1;
         if (pair_wants_collision_events(w, c1, c2)) push_collision_event(w, c1, c2, has, 0, cur_step(w)); // contacts.rs:316-323
-        if (!has) { // end touch: free the colour now (clear_pair_solver_color, mod.rs:157-172)
+        if (!has) { // end touch: free the colour now (clear_pair_solver_color, mod.rs:157-172); the contact link is unlinked (contacts.rs:359)
+            if (w.sleep_enabled) pi_journal(w, rb1, rb2, 2, c1, c2);
             int color = w.p_color[s];
             if (color < RP_COLOR_OVERFLOW) {
                 int2 cb = w.p_colorb[s];

@@ -25,6 +25,15 @@ RP_DEV bool pair_selected(const DevWorld &w, int s) {
     return body_dyn_awake(w, rb.x) || body_dyn_awake(w, rb.y); // PAIR_HINT_DYN_BIT: at least one awake DYNAMIC body
 }
 
+// unlink_contact -> journal_removal (persistent.rs:331-343, :395-418): the endpoints of a touching pair that stopped touching or was
+// deleted wait for resolve_removals (rp_sleep.hip).  phase 1 = broad-phase deletion, 2 = end-touch transition (0 = joint edits, appended
+// by the host); the key orders a phase like the oracle does (ascending collider pair).  Self-loops and parentless sides are not recorded.
+RP_DEV void pi_journal(const DevWorld &w, int b1, int b2, int phase, int c1, int c2) {
+    if (b1 == b2 || b1 < 0 || b2 < 0) return;
+    int k = atomicAdd(&w.flags[FL_PJ_COUNT], 1);
+    if (k < w.pj_cap) { w.pj_key[k] = ((unsigned long long)phase << 62) | ((unsigned long long)(unsigned)c1 << 31) | (unsigned long long)(unsigned)c2; w.pj_b[k] = make_int2(b1, b2); }
+}
+
 // CollisionEvent queue (EventHandler::handle_collision_event, event_handler.rs:94-130)
 RP_DEV bool pair_wants_collision_events(const DevWorld &w, int c1, int c2) {
     return ((__float_as_int(w.c_events[c1].x) | __float_as_int(w.c_events[c2].x)) & RP_EVENTS_COLLISION) != 0;

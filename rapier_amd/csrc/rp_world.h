@@ -91,6 +91,13 @@ enum {
     FL_CCD_ACTIVE,      // (body, step) occurrences of the CCD fast-body criterion so far (body_writeback): the reference would have swept
     FL_GRID_TIMEOUT,    // a fused fast step gave up waiting for a workgroup that was not resident: the step was aborted (nothing written),
                         // the host replays it on the full graph and stops using the fused launch (rp_api.hip settle())
+    // persistent islands (rp_sleep.hip; PersistentIslands, island_manager/persistent.rs:128-171)
+    FL_PI_NEXT,         // island ids handed out so far without reuse (alloc_island: `islands.len()` once the free list is empty)
+    FL_PI_NFREE,        // height of the free-id stack (free_islands)
+    FL_PI_PENDING,      // split_island + 1: the island chosen last step for this step's global split, 0 = None
+    FL_PJ_COUNT,        // removal_journal entries waiting for resolve_removals
+    FL_PI_MERGED,       // scratch of one sleep pass: some touching pair joins two islands
+    FL_PI_JLINK,        // first device joint whose ImpulseJointIslandEvent::Link is not applied yet, + 1 (0 = none)
     FL_COUNT = 64       // <= 64: publish_flags copies one slot per lane of a wavefront
 };
 
@@ -198,8 +205,18 @@ struct DevWorld {
                            // a fast step that aborts after observing is replayed on the full graph without counting the step twice)
     int *b_slept_at;       // step at which the body last fell asleep (clears the solver hints of its pairs)
     int *b_wake_req;       // pending wake-up: 1 weak, 2 strong, 3 strong + the user moved the body
-    int *lab_wake;         // [n_bodies] per label: step of the last wake-up of that sleeping island
-    int *lab_awake;        // [n_bodies] per label: step at which some member was found not eligible for sleep
+    int *lab_wake;         // [n_bodies] per island id: step of the last wake-up of that sleeping island
+    int *lab_awake;        // [n_bodies] per island id: step at which some member was found not eligible for sleep
+    // ---- persistent islands (PersistentIslands, island_manager/persistent.rs; maintained while sleep_enabled) ----
+    int *b_isl;            // RigidBodyIds::island_id per body, -1 = INVALID_ISLAND (fixed / removed bodies)
+    int *pi_used, *pi_nb, *pi_dirty, *pi_denied, *pi_sleeping; // [n_bodies] per island id: in use, bodies.len(), constraint_remove_count > 0, split_denied_until, sleeping
+    int *pi_free;          // [n_bodies] free_islands (stack)
+    int *pi_uf, *pi_new;   // [n_bodies] scratch of a merge pass: union-find over island ids, surviving id of every island (-1 = not in use)
+    unsigned long long *pi_best; // [n_bodies] scratch: per merge-group root, max of (bodies << 32 | ~id) = the identity that survives
+    int *pi_csize, *pi_cisl, *pi_list; // [n_bodies] scratch: bodies per connected component (index = its smallest body), island of a component, compaction output
+    unsigned long long *pi_w64;  // [4]: [0] = step << 32 | sleep_scan_stamp (the step whose scan bumped it), [1] = best split bid of the step (score bits << 32 | island id)
+    int *pi_stats;         // [16] counters, same slots as the oracle's RO_IS_* (tests)
+    unsigned long long *pj_key; int2 *pj_b; int pj_cap; // removal journal: phase << 62 | key, the two endpoints; capacity (a power of two)
     float4 *b_next_pos, *b_next_rot; // RigidBodyPosition::next_position of kinematic bodies (set_next_kinematic_position)
     // ---- solver bodies (index = arena index; non-dynamic = world-attached) ----
     float4 *s_lin, *s_ang, *s_rot, *s_trans, *s_incl, *s_inca;

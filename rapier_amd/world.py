@@ -351,6 +351,34 @@ class PhysicsWorld:
         _check(self._ptr, self._lib.rp_bodies_is_sleeping(self._ptr, len(h), h.ctypes.data, out.ctypes.data), "rp_bodies_is_sleeping")
         return out.astype(bool)
 
+    def island_labels(self, handles=None) -> np.ndarray:
+        """IslandManager::persistent_island_of per body (-1: fixed / removed, or a world without sleepable bodies)."""
+        if handles is None:
+            handles = np.arange(self._lib.rp_num_bodies(self._ptr), dtype=np.uint64)
+        h = np.ascontiguousarray(np.atleast_1d(np.asarray(handles, dtype=np.uint64)))
+        out = np.zeros(len(h), np.int32)
+        _check(self._ptr, self._lib.rp_bodies_persistent_island(self._ptr, len(h), h.ctypes.data, out.ctypes.data), "rp_bodies_persistent_island")
+        return out
+
+    ISLAND_STATS = ("merged", "multiway_groups", "removals", "connected", "detached", "hot", "over_budget", "sleeping_deferred", "global_splits",
+                    "global_split_pieces", "bids", "bid_ties", "sleep_blocked", "order_dependent", "detach_size_ties", "split_keep_ties")
+
+    def island_stats(self) -> dict:
+        """debug aid: counters of the persistent-island machinery (the slots the device maintains; same names as the oracle's)"""
+        out = np.zeros(16, np.int32)
+        _check(self._ptr, self._lib.rp_debug_islands(self._ptr, out.ctypes.data, None, -1, None), "rp_debug_islands")
+        return dict(zip(self.ISLAND_STATS, (int(v) for v in out)))
+
+    def island_state(self, island: int) -> dict:
+        row = np.zeros(5, np.int32)
+        _check(self._ptr, self._lib.rp_debug_islands(self._ptr, None, None, int(island), row.ctypes.data), "rp_debug_islands")
+        return dict(zip(("used", "nbodies", "dirty", "denied", "sleeping"), (int(v) for v in row)))
+
+    def island_globals(self):
+        sp = np.zeros(2, np.int32)
+        _check(self._ptr, self._lib.rp_debug_islands(self._ptr, None, sp.ctypes.data, -1, None), "rp_debug_islands")
+        return int(sp[0]), int(sp[1])
+
     def contacts(self):
         m = self._lib.rp_contacts_read(self._ptr, 0, None, None, None)
         if m < 0:

@@ -76,6 +76,26 @@ def test_bench_control_flow_two_ranks(tmp_path):
     assert abs(line["config"]["sharded_world_steps_per_s"] - 1e3 / line["ms_per_step"]) <= 1e-6 * line["config"]["sharded_world_steps_per_s"]
 
 
+def _worker_forced(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import bench
+    args = bench.parse_args(["--gpus", "1", "--steps", "4", "--warmup", "2", "--workload", "grid:2x2", "--no-cpu-baseline", "--force-dist"])
+    out, gathered = bench.run(args, make_world=OracleAdapter, backend="gloo", use_cuda=False)
+    with open(os.path.join(out_dir, "forced.json"), "w") as f:
+        json.dump({"line": out, "n": int(gathered[0].shape[0])}, f)
+
+
+def test_force_dist_runs_the_collective_leg_on_one_rank(tmp_path):
+    """`bench.py --gpus 1 --force-dist` = the N > 1 code path (process group, barrier, all-reduce, all-gather of body state) with a
+    single rank: what `gpurun` runs on one MI355X with the nccl backend (the log is kept under profiles/)"""
+    mp.spawn(_worker_forced, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    rec = json.load(open(os.path.join(str(tmp_path), "forced.json")))
+    assert rec["line"]["dist"] == {"backend": "gloo", "world_size": 1, "forced": True, "gathered_bodies": 1 + 4 * 55}
+    assert rec["line"]["n_gpus"] == 1 and rec["n"] == 221 and rec["line"]["finite"]
+
+
 def test_c4_shards_cover_the_world():
     """BASELINE config C4 over 8 ranks: 2,916 islands -> 364 or 365 per rank, disjoint and complete, ids as int64."""
     sys.path.insert(0, ROOT)
