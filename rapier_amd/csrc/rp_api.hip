@@ -70,6 +70,25 @@ void rp_launch_pi_ensure(const DevWorld &w, hipStream_t st, int first, int count
 void rp_launch_pi_remove_body(const DevWorld &w, hipStream_t st, int b);
 void rp_launch_pj_append_joint(const DevWorld &w, hipStream_t st, int dev_joint, int b1, int b2, int key);
 int rp_flow_grid(int device);
+int rp_occ_bp_rebuild(void); int rp_occ_layout_rebuild(void); int rp_occ_sleep_pass(void); int rp_occ_flow_ranks(void);
+// Grid of the kernels that synchronise through device-side grid barriers (rp_gridbar.h): every workgroup must be resident at once, so
+// the cap is what THIS device holds of the hungriest of them — CUs x the smallest occupancy answer — with a quarter left free for
+// whatever else runs on the device (other worlds' rebuilds, other streams); never more than 192 (more workgroups only lengthen the
+// barriers), at least 1 (a single workgroup needs no co-residency at all: the passes are grid-stride).
+static int gbar_grid_for_device(int device) {
+    static int cached[64] = {0};
+    if (device >= 0 && device < 64 && cached[device]) return cached[device];
+    hipDeviceProp_t prop;
+    int cus = 0;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
+    int occ = std::min(std::min(rp_occ_bp_rebuild(), rp_occ_layout_rebuild()), std::min(rp_occ_sleep_pass(), rp_occ_flow_ranks()));
+    int g = (cus * occ * 3) / 4;
+    const char *e = getenv("RP_GBAR_BLOCKS"); // test hook: a small part / a busy device
+    if (e && atoi(e) > 0) g = std::min(g > 0 ? g : atoi(e), atoi(e));
+    g = std::max(1, std::min(g, 192));
+    if (device >= 0 && device < 64) cached[device] = g;
+    return g;
+}
 int rp_fused_grid(int device);
 
 struct HostBody {
@@ -402,7 +421,13 @@ extern "C" int32_t rp_params_set(rp_world *w, const rp_integration_params *in) {
         if (r != RP_OK) return r;
     }
     w->params = *in;
-    if (w->finalized) { fill_sim_params(w, w->dw.prm, w->dw.prm.cell_size); int r = upload_group_table(w); if (r != RP_OK) return r; destroy_graphs(w); }
+    if (w->finalized) {
+        fill_sim_params(w, w->dw.prm, w->dw.prm.cell_size);
+        int r = upload_group_table(w); if (r != RP_OK) return r;
+        // the dataflow solver's tickets are laid out per (substep, iteration): rebuilt, and re-checked against FLOW_TICKET_BITS, by the next step
+        int one = 1; HIPCHK(w, hipMemcpy(w->dw.flags + FL_FLOW_DIRTY, &one, sizeof(int), hipMemcpyHostToDevice));
+        destroy_graphs(w);
+    }
     return RP_OK;
 }
 extern "C" int32_t rp_num_bodies(const rp_world *w) { return w ? (int32_t)w->bodies.size() : 0; }
@@ -727,6 +752,11 @@ extern "C" int32_t rp_bodies_insert(rp_world *w, int32_t n, const rp_body_desc *
     if ((long long)w->bodies.size() + n >= 0xfffff) { w->err = "rp_bodies_insert: more than 2^20 - 1 bodies"; return RP_ERR_CAPACITY; }
     for (int i = 0; i < n; ++i) if (descs[i].body_type < RP_BODY_DYNAMIC || descs[i].body_type > RP_BODY_KINEMATIC_VELOCITY) { w->err = "rp_bodies_insert: unknown body_type"; return RP_ERR_INVALID; }
     for (int i = 0; i < n; ++i) if (descs[i].additional_solver_iterations < 0 || descs[i].additional_solver_iterations > 4096) { w->err = "rp_bodies_insert: additional_solver_iterations must be in [0, 4096]"; return RP_ERR_INVALID; }
+    { // the distinct-count limit of the solve groups is checked on the prospective values, before host or device state changes
+        std::vector<int> extras; group_table(w, extras);
+        for (int i = 0; i < n; ++i) if (descs[i].additional_solver_iterations > 0 && std::find(extras.begin(), extras.end(), descs[i].additional_solver_iterations) == extras.end()) extras.push_back(descs[i].additional_solver_iterations);
+        if ((int)extras.size() > RP_MAX_GROUPS) { w->err = "more than 15 distinct positive additional_solver_iterations values in one world"; return RP_ERR_CAPACITY; }
+    }
     for (int i = 0; i < n; ++i) {
         HostBody b; b.d = descs[i]; b.ncolliders = 0; b.removed = false; b.inv_mass = 0; b.inv_pi[0] = b.inv_pi[1] = b.inv_pi[2] = 0; b.lcom[0] = b.lcom[1] = b.lcom[2] = 0;
         b.slabel = (int)w->bodies.size();
@@ -1048,6 +1078,7 @@ static int finalize(rp_world *w) {
     d.has_kinematic_pos = world_has_kinematic_pos(w) ? 1 : 0;
     d.has_force_events = world_has_force_events(w) ? 1 : 0;
     d.has_sensors = world_has_sensors(w) ? 1 : 0;
+    d.gbar_blocks = gbar_grid_for_device(w->device);
     { const char *ig = getenv("RP_ISL_GENERIC"); d.isl_generic = (ig && ig[0] == '1') ? 1 : 0; }
     w->compound = world_has_compound_bodies(w);
     int nb = (int)w->bodies.size(), nc = (int)w->colliders.size();
@@ -1295,6 +1326,9 @@ static void enqueue_island_solver(rp_world *w) {
 // joints (b3d_joint_grid 0.37 against 0.45 ms) and the Coulomb model (no body-centric warm start) with the dataflow launch.
 static bool flow_now(const rp_world *w) {
     if (!w->use_flow) return false;
+    // with no internal PGS iteration nothing on a body's hand-off chain separates the joint-row update of a substep from that substep's
+    // integrate, so the dataflow launch could rebuild joint rows from poses one substep ahead: such worlds take the per-stage launches
+    if (w->dw.n_joints > 0 && w->params.num_internal_pgs_iterations == 0) return false;
     return w->force_flow || w->dw.n_joints > 0 || w->params.friction_model == RP_FRICTION_COULOMB;
 }
 static void enqueue_global_solver(rp_world *w) {
@@ -1339,10 +1373,13 @@ static void plan_from_hints(rp_world *w, const int *fl) {
 static int capture(rp_world *w, hipGraph_t *g, hipGraphExec_t *ge, void (*fn)(rp_world *)) {
     // Relaxed: another host thread stepping another world on this device may issue synchronous HIP calls (hipMemcpy in settle())
     // while this thread captures; only kernel launches on this world's own stream happen between Begin and End
-    std::lock_guard<std::mutex> guard(g_hip_unsafe_api); // (fn only launches kernels on this world's stream)
-    HIPCHK(w, hipStreamBeginCapture(w->stream, hipStreamCaptureModeRelaxed));
-    fn(w);
-    HIPCHK(w, hipStreamEndCapture(w->stream, g));
+    {   // the lock covers the capture only (fn launches kernels on this world's stream); instantiation (~10 ms) runs outside it, so a
+        // re-capture in one world no longer stalls every other host thread's copies
+        std::lock_guard<std::mutex> guard(g_hip_unsafe_api);
+        HIPCHK(w, hipStreamBeginCapture(w->stream, hipStreamCaptureModeRelaxed));
+        fn(w);
+        HIPCHK(w, hipStreamEndCapture(w->stream, g));
+    }
     HIPCHK(w, hipGraphInstantiate(ge, *g, nullptr, nullptr, 0));
     return RP_OK;
 }
@@ -1659,6 +1696,20 @@ extern "C" int32_t rp_bodies_set_additional_solver_iterations(rp_world *w, int32
         int b = handle_index(handles[i]);
         if (b < 0 || b >= (int)w->bodies.size() || w->bodies[b].removed) { w->err = "rp_bodies_set_additional_solver_iterations: invalid handle"; return RP_ERR_INVALID; }
         if (counts[i] < 0 || counts[i] > 4096) { w->err = "rp_bodies_set_additional_solver_iterations: count must be in [0, 4096]"; return RP_ERR_INVALID; }
+    }
+    { // validate the distinct-count limit on the prospective values before touching host or device state
+        std::vector<int> prospective;
+        for (size_t q = 0; q < w->bodies.size(); ++q) {
+            const HostBody &hb = w->bodies[q];
+            if (hb.removed || hb.quarantined) continue;
+            int v = hb.d.additional_solver_iterations;
+            for (int i = 0; i < n; ++i) if (handle_index(handles[i]) == (int)q) v = counts[i];
+            if (v > 0 && std::find(prospective.begin(), prospective.end(), v) == prospective.end()) prospective.push_back(v);
+        }
+        if ((int)prospective.size() + 1 > RP_MAX_GROUPS) { w->err = "more than 15 distinct positive additional_solver_iterations values in one world"; return RP_ERR_CAPACITY; }
+    }
+    for (int i = 0; i < n; ++i) {
+        int b = handle_index(handles[i]);
         w->bodies[b].d.additional_solver_iterations = counts[i];
         if (w->finalized) { int r = poke(w, w->dw.b_extra + b, (int)counts[i]); if (r != RP_OK) return r; }
     }

@@ -324,21 +324,21 @@ __global__ void __launch_bounds__(1024) k_bp_rebuild(DevWorld w) {
     GridBar bar = gbar_begin(w, 0);
     const int epoch = w.flags[FL_BP_EPOCH];
     bp_clear(w, gid, gstride);
-    gbar_sync(bar);
+    GBAR_SYNC(bar);
     bp_count(w, gid, gstride);
-    gbar_sync(bar);
+    GBAR_SYNC(bar);
     bp_scan_chunks(w, scan_lds);
-    gbar_sync(bar);
+    GBAR_SYNC(bar);
     if (blockIdx.x == 0) bp_scan_sums(w, scan_lds);
-    gbar_sync(bar);
+    GBAR_SYNC(bar);
     bp_scan_add(w, gid, gstride);
-    gbar_sync(bar);
+    GBAR_SYNC(bar);
     bp_fill(w, gid, gstride);
-    gbar_sync(bar);
+    GBAR_SYNC(bar);
     bp_pairs(w, gid, gstride);
-    gbar_sync(bar);
+    GBAR_SYNC(bar);
     bp_finish_pairs(w, gid, gstride);
-    gbar_sync(bar);
+    GBAR_SYNC(bar);
     gbar_end(bar);
     if (gid == 0) { // the rebuild is closed: epoch flip, dirty flag
         w.flags[FL_BP_EPOCH] = epoch + 1;
@@ -387,9 +387,12 @@ void rp_launch_bp_rehash(const DevWorld &w, hipStream_t st) {
 
 void rp_launch_broadphase(const DevWorld &w, hipStream_t st) {
     if (w.n_colliders == 0) return;
-    // every workgroup must be resident (grid barriers): at most 192 workgroups of 1024 threads (one per CU, 256 CUs)
+    // every workgroup must be resident (grid barriers): at most DevWorld::gbar_blocks workgroups of 1024 threads (rp_gridbar.h)
     int blocks = (w.n_colliders + 255) / 256; // ~4 wavefronts of colliders per workgroup: the cell walks are latency-bound, spread them
     if (blocks < 8) blocks = 8;    // the clears and the pair-slot sweep are sized by capacities, not by the collider count
-    if (blocks > 192) blocks = 192;
+    if (blocks > w.gbar_blocks) blocks = w.gbar_blocks;
     hipLaunchKernelGGL(k_bp_rebuild, dim3(blocks), dim3(1024), 0, st, w);
 }
+
+// workgroups of k_bp_rebuild (1024 threads) one CU holds at once (0 = the query failed): input of DevWorld::gbar_blocks (rp_api.hip)
+int rp_occ_bp_rebuild(void) { int n = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bp_rebuild, 1024, 0) != hipSuccess) n = 0; return n; }

@@ -274,13 +274,13 @@ __global__ void __launch_bounds__(1024) k_flow_ranks(DevWorld w) {
     const int gid = gbar_item(), gstride = gridDim.x * blockDim.x;
     GridBar bar = gbar_begin(w, 3);
     flow_count(w, gid, gstride);
-    gbar_sync(bar);
+    GBAR_SYNC(bar);
     flow_alloc(w, gid, gstride);
-    gbar_sync(bar);
+    GBAR_SYNC(bar);
     flow_fill(w, gid, gstride);
-    gbar_sync(bar);
+    GBAR_SYNC(bar);
     flow_rank(w, gid, gstride);
-    gbar_sync(bar);
+    GBAR_SYNC(bar);
     gbar_end(bar);
 }
 
@@ -640,7 +640,7 @@ int rp_flow_grid(int device) {
 // per-body toucher lists in sweep order (rebuilt only when FL_FLOW_DIRTY; the flag is cleared by the kernel that starts the solve)
 void rp_launch_flow_ranks(const DevWorld &w, hipStream_t st) {
     int n = w.cons_cap > w.n_joints ? w.cons_cap : w.n_joints; if (n < w.n_bodies) n = w.n_bodies;
-    int blocks = (n + 255) / 256; if (blocks > 192) blocks = 192; if (blocks < 1) blocks = 1; // all resident (grid barriers)
+    int blocks = (n + 255) / 256; if (blocks > w.gbar_blocks) blocks = w.gbar_blocks; if (blocks < 1) blocks = 1; // all resident (grid barriers)
     hipLaunchKernelGGL(k_flow_ranks, dim3(blocks), dim3(1024), 0, st, w);
 }
 void rp_launch_global_flow(const DevWorld &w, hipStream_t st, int grid, int has_restitution) {
@@ -654,3 +654,6 @@ void rp_launch_global_flow(const DevWorld &w, hipStream_t st, int grid, int has_
 #undef FLOW_LAUNCH
     hipLaunchKernelGGL(k_flow_retire, dim3(1), dim3(64), 0, st, w);
 }
+
+// workgroups of k_flow_ranks (1024 threads) one CU holds at once (0 = the query failed): input of DevWorld::gbar_blocks (rp_api.hip)
+int rp_occ_flow_ranks(void) { int n = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_flow_ranks, 1024, 0) != hipSuccess) n = 0; return n; }

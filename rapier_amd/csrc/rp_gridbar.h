@@ -10,7 +10,11 @@
 // (stale L1 / L2 lines dropped) and the workgroup meets again: plain loads and stores on either side are then safe on any
 // XCD placement.  The counter never resets: a launch starts from `base` (published by the previous launch after its last
 // barrier) and barrier k completes at base + k * gridDim.x; comparisons are wrap-safe.  Every workgroup of the launch must be
-// resident (the grids are far below the CU count); a bounded spin turns a violation into RP_OVF_GRID instead of a hang.
+// resident: the grids are capped by DevWorld::gbar_blocks, which the host derives from the occupancy of these very kernels on the
+// device it runs on (rp_api.hip: CUs x the smallest occupancy answer, a quarter left free), not from a CU count.  A bounded spin
+// turns a violation into RP_OVF_GRID instead of a hang, and the launch then ENDS there: the waiter that gave up raises the bit, every
+// workgroup looks at it behind every barrier and returns — no later pass ever runs on half-built scans (a late arrival cannot
+// slip through either: it finds the bit the early leavers raised).  The error is sticky (rp_last_error); the world must be rebuilt.
 #pragma once
 #include "rp_world.h"
 
@@ -22,10 +26,12 @@ RP_DEV GridBar gbar_begin(const DevWorld &w, int which) {
     b.ovf = &w.flags[FL_OVERFLOW];
     return b;
 }
-RP_DEV void gbar_sync(GridBar &b) {
+// true = the launch is dead (some barrier of it timed out): the caller returns
+RP_DEV bool gbar_sync(GridBar &b) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every wave: its stores have left the CU
     __syncthreads();
     b.target += gridDim.x;
+    int dead = 0;
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the write-back has completed before the arrival is visible
@@ -36,9 +42,11 @@ RP_DEV void gbar_sync(GridBar &b) {
             if (++spins > (1u << 21)) { atomicOr(b.ovf, RP_OVF_GRID); break; } // ~2 s: a workgroup of this launch is not resident
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        dead = (__hip_atomic_load(b.ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & RP_OVF_GRID) != 0;
     }
-    __syncthreads();
+    return __syncthreads_or(dead) != 0;
 }
+#define GBAR_SYNC(bar) do { if (gbar_sync(bar)) return; } while (0)
 // Item index of this thread for the grid-stride passes: consecutive 64-item groups go to DIFFERENT workgroups (wave w of workgroup b
 // takes group w * gridDim + b), so a pass over a few thousand items still spreads over every CU of the launch instead of filling
 // the first few 1024-thread workgroups; a wavefront keeps 64 consecutive items (coalesced).  Stride = gridDim.x * blockDim.x.

@@ -274,23 +274,23 @@ __global__ void __launch_bounds__(1024) k_layout_rebuild(DevWorld w) {
     GridBar bar = gbar_begin(w, 1);
     if (blockIdx.x == 0) lay_bucket_clear(w);
     lay_isl_init(w, gid, gstride);
-    gbar_sync(bar);
+    GBAR_SYNC(bar);
     lay_bucket_count(w, gid, gstride, lds_a, lds_scalar);
     lay_isl_union(w, gid, gstride);
-    gbar_sync(bar);
+    GBAR_SYNC(bar);
     lay_isl_count(w, gid, gstride);
-    gbar_sync(bar);
+    GBAR_SYNC(bar);
     lay_isl_number(w, gid, gstride);
-    gbar_sync(bar);
+    GBAR_SYNC(bar);
     __syncthreads();
     lay_isl_fill(w, gid, gstride, lds_a, lds_scalar);
-    gbar_sync(bar);
+    GBAR_SYNC(bar);
     if (blockIdx.x == 0) lay_bucket_layout(w, lds_a);
-    gbar_sync(bar);
+    GBAR_SYNC(bar);
     lay_bucket_scatter(w, gid, gstride, lds_a, lds_b);
-    gbar_sync(bar);
+    GBAR_SYNC(bar);
     if (blockIdx.x == 0) lay_rank_overflow(w);
-    gbar_sync(bar);
+    GBAR_SYNC(bar);
     gbar_end(bar);
     if (gid == 0) __hip_atomic_store(&w.flags[FL_LAYOUT_DIRTY], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -1089,9 +1089,9 @@ __global__ void __launch_bounds__(ISL_THREADS) k_island_generic(DevWorld w, int 
 }
 
 void rp_launch_islands_build(const DevWorld &w, hipStream_t st) {
-    // every workgroup must be resident (grid barriers): at most 192 workgroups of 1024 threads (one per CU, 256 CUs)
+    // every workgroup must be resident (grid barriers): at most DevWorld::gbar_blocks workgroups of 1024 threads (rp_gridbar.h)
     int n = w.n_bodies > w.pool_cap ? w.n_bodies : w.pool_cap;
-    int blocks = (n + 255) / 256; if (blocks > 192) blocks = 192; if (blocks < 1) blocks = 1; // ~4 wavefronts of items per workgroup
+    int blocks = (n + 255) / 256; if (blocks > w.gbar_blocks) blocks = w.gbar_blocks; if (blocks < 1) blocks = 1; // ~4 wavefronts of items per workgroup
     hipLaunchKernelGGL(k_layout_rebuild, dim3(blocks), dim3(1024), 0, st, w);
 }
 // Most workgroups a fused fast step may launch: its arrival barrier needs every workgroup resident at once, so the cap comes from
@@ -1118,3 +1118,6 @@ void rp_launch_island_solve(const DevWorld &w, hipStream_t st, int grid, int has
     if (w.isl_generic) { hipLaunchKernelGGL(k_island_generic<false>, dim3(grid), dim3(ISL_THREADS), 0, st, w, has_restitution, fast, retire); return; } // RP_ISL_GENERIC=1: the twist model through the generic kernel (tests)
     hipLaunchKernelGGL(k_island_solve, dim3(grid), dim3(ISL_THREADS), 0, st, w, has_restitution, fast, retire, fused);
 }
+
+// workgroups of k_layout_rebuild (1024 threads) one CU holds at once (0 = the query failed): input of DevWorld::gbar_blocks (rp_api.hip)
+int rp_occ_layout_rebuild(void) { int n = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_layout_rebuild, 1024, 0) != hipSuccess) n = 0; return n; }

@@ -433,7 +433,7 @@ __global__ void __launch_bounds__(1024) k_sleep_pass(DevWorld w, int fast) {
         for (int s = gid; s < n_isl; s += gstride) { w.pi_uf[s] = s; w.pi_best[s] = 0ull; w.pi_new[s] = w.pi_used[s] ? s : -1; }
         for (int i = gid; i < w.n_bodies; i += gstride) w.pi_csize[i] = 0;
         if (gid == 0) w.flags[FL_PI_MERGED] = 0;
-        gbar_sync(bar);
+        GBAR_SYNC(bar);
         // P1: components of the awake bodies over touching pairs and joints; link_contact (persistent.rs:293-329): a touching pair
         // whose endpoints sit in different islands joins them (already-linked pairs join nothing)
         slp_union_pairs(w, gid, gstride);
@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(1024) k_sleep_pass(DevWorld w, int fast) {
                 if (i1 != i2) { slp_union(w.pi_uf, i1, i2); w.flags[FL_PI_MERGED] = 1; }
             }
         }
-        gbar_sync(bar);
+        GBAR_SYNC(bar);
         const bool merged = w.flags[FL_PI_MERGED] != 0;
         // P2: final component labels; merge_islands (:420-461): the identity that survives a group is its largest island as of
         // the start of the step, the smaller id on equal size
@@ -456,7 +456,7 @@ __global__ void __launch_bounds__(1024) k_sleep_pass(DevWorld w, int fast) {
         if (merged)
             for (int s = gid; s < n_isl; s += gstride)
                 if (w.pi_used[s]) atomicMax(&w.pi_best[slp_find(w.pi_uf, s)], ((unsigned long long)(unsigned)w.pi_nb[s] << 32) | (unsigned)~(unsigned)s);
-        gbar_sync(bar);
+        GBAR_SYNC(bar);
         // P3: absorbed islands hand their bodies, flag and sleep state to the survivor
         if (merged)
             for (int s = gid; s < n_isl; s += gstride) {
@@ -470,7 +470,7 @@ __global__ void __launch_bounds__(1024) k_sleep_pass(DevWorld w, int fast) {
                 if (w.flags[FL_PI_PENDING] == s + 1) w.flags[FL_PI_PENDING] = 0; // free_island drops a pending split of the absorbed island
                 atomicAdd(&w.pi_stats[PIS_MERGED], 1);
             }
-        gbar_sync(bar);
+        GBAR_SYNC(bar);
         // P4: bodies follow; component sizes and the island of every component; absorbed ids are freed in ascending order
         for (int i = gid; i < w.n_bodies; i += gstride) {
             int isl = w.b_isl[i];
@@ -484,7 +484,7 @@ __global__ void __launch_bounds__(1024) k_sleep_pass(DevWorld w, int fast) {
             for (int k = threadIdx.x; k < freed; k += blockDim.x) { int s = w.pi_free[nf + k]; w.pi_used[s] = 0; w.pi_nb[s] = 0; }
             if (threadIdx.x == 0) w.flags[FL_PI_NFREE] = nf + freed;
         }
-        gbar_sync(bar);
+        GBAR_SYNC(bar);
         // P5 (workgroup 0): resolve_removals over the sorted journal, then the pending global split
         if (blockIdx.x == 0) {
             if (n_journal > 0) {
@@ -494,7 +494,7 @@ __global__ void __launch_bounds__(1024) k_sleep_pass(DevWorld w, int fast) {
             }
             pi_split_pending(w, lds, lds64);
         }
-        gbar_sync(bar);
+        GBAR_SYNC(bar);
         // P6: awake bodies follow their component's island
         for (int i = gid; i < w.n_bodies; i += gstride) if (flags_active(w.b_flags[i]) && w.b_isl[i] >= 0) w.b_isl[i] = w.pi_cisl[w.b_slabel[i]];
         gbar_end(bar);
@@ -580,8 +580,8 @@ void rp_launch_sleep(const DevWorld &w, hipStream_t st) {
     if (!w.sleep_enabled || w.n_bodies == 0) return;
     int nb = slp_body_blocks(w);
     if (w.has_kinematic_pos) hipLaunchKernelGGL(k_kinematic_velocities, dim3(nb), dim3(256), 0, st, w); // after the narrow phase, before the sleep timers
-    // every workgroup must be resident (grid barriers): at most 192 workgroups of 1024 threads
-    int blocks = (w.n_bodies + 255) / 256; if (blocks > 192) blocks = 192; if (blocks < 1) blocks = 1; // sized by the bodies (the every-step observation); the pair pass of a relabel is grid-stride
+    // every workgroup must be resident (grid barriers): at most DevWorld::gbar_blocks workgroups of 1024 threads
+    int blocks = (w.n_bodies + 255) / 256; if (blocks > w.gbar_blocks) blocks = w.gbar_blocks; if (blocks < 1) blocks = 1; // sized by the bodies (the every-step observation); the pair pass of a relabel is grid-stride
     if (w.n_joints > 0) hipLaunchKernelGGL(k_pi_link_joints, dim3(1), dim3(1024), 0, st, w); // joint Link events queued by the host (early exit otherwise)
     hipLaunchKernelGGL(k_sleep_pass, dim3(blocks), dim3(1024), 0, st, w, 0);
     hipLaunchKernelGGL(k_sleep_commit, dim3(nb), dim3(256), 0, st, w);
@@ -590,7 +590,7 @@ void rp_launch_sleep(const DevWorld &w, hipStream_t st) {
 void rp_launch_sleep_fast(const DevWorld &w, hipStream_t st) {
     if (!w.sleep_enabled || w.n_bodies == 0) return;
     int nb = slp_body_blocks(w);
-    int blocks = nb > 192 ? 192 : nb;
+    int blocks = nb > w.gbar_blocks ? w.gbar_blocks : nb;
     hipLaunchKernelGGL(k_sleep_pass, dim3(blocks), dim3(1024), 0, st, w, 1);
     hipLaunchKernelGGL(k_sleep_check, dim3(nb), dim3(256), 0, st, w);
 }
@@ -599,3 +599,6 @@ void rp_launch_sleep_fast(const DevWorld &w, hipStream_t st) {
 void rp_launch_pi_ensure(const DevWorld &w, hipStream_t st, int first, int count, int reset) { if (count > 0 || reset) hipLaunchKernelGGL(k_pi_ensure, dim3(1), dim3(1024), 0, st, w, first, count, reset); }
 void rp_launch_pj_append_joint(const DevWorld &w, hipStream_t st, int dev_joint, int b1, int b2, int key) { hipLaunchKernelGGL(k_pj_append_joint, dim3(1), dim3(64), 0, st, w, dev_joint, b1, b2, key); }
 void rp_launch_pi_remove_body(const DevWorld &w, hipStream_t st, int b) { hipLaunchKernelGGL(k_pi_remove_body, dim3(1), dim3(64), 0, st, w, b); }
+
+// workgroups of k_sleep_pass (1024 threads) one CU holds at once (0 = the query failed): input of DevWorld::gbar_blocks (rp_api.hip)
+int rp_occ_sleep_pass(void) { int n = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_sleep_pass, 1024, 0) != hipSuccess) n = 0; return n; }

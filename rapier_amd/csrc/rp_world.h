@@ -176,6 +176,7 @@ struct DevWorld {
     int has_kinematic_pos; // some body is KinematicPositionBased: k_kinematic_velocities runs
     int isl_generic;       // RP_ISL_GENERIC=1: islands through k_island_generic even under the twist model (tests of that kernel)
     int n_groups;          // distinct additional_solver_iterations counts in the world (1 = no elevated body: the plain paths)
+    int gbar_blocks;       // most workgroups (of 1024 threads) a grid-barrier kernel may use on this device: all of them resident at once (rp_gridbar.h)
     int has_sensors;       // some collider is a sensor: its pairs are intersection-tested every step (full step path)
     SimParams prm;
     int *flags;        // FL_* scalars

@@ -161,6 +161,28 @@ def _with_param(scene, key, value):
     return scene
 
 
+@pytest.mark.parametrize("npgs,nstab", [(0, 1), (1, 0), (0, 0), (2, 2)])
+def test_jointed_world_with_unusual_inner_iteration_counts(npgs, nstab):
+    """num_internal_pgs_iterations = 0 leaves no joint event between a substep's joint-row update and its integrate on a body's hand-off
+    chain, so such jointed worlds keep to the per-stage launches (rp_api.hip: flow_now); every combination matches the oracle, on the
+    default launch and with the global path forced onto several launches"""
+    def make():
+        sc = S.joint_chain(6, with_boxes=True)
+        sc.params["num_internal_pgs_iterations"] = npgs
+        sc.params["num_internal_stabilization_iterations"] = nstab
+        return sc
+    _compare(make(), [1, 7, 60])
+    a = _world_with_env(make(), RP_FORCE_MULTI=1)
+    o = OracleWorld(make())
+    a.step(60); o.step(60)
+    (ap, av), (op, ov) = a.read_bodies(), o.read()
+    np.testing.assert_array_equal(ap, op); np.testing.assert_array_equal(av, ov)
+    sc2 = S.joint_grid(24)
+    sc2.params["num_internal_pgs_iterations"] = npgs
+    sc2.params["num_internal_stabilization_iterations"] = nstab
+    _compare(sc2, [1, 20])
+
+
 def test_tumble_dynamic_scene_bit_exact():
     """Rotated cuboids + balls with velocities: full updates, edge/edge SAT, reduction, pair
     deletion, recolouring, restitution, damping."""
