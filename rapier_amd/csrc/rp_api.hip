@@ -1058,6 +1058,7 @@ static int carry_over(rp_world *w) {
     rp_launch_bp_rehash(d, w->stream); // the live pairs enter the (larger) current-epoch table
     int one = 1;
     for (int f : {FL_BP_DIRTY, FL_LAYOUT_DIRTY, FL_JOINT_DIRTY, FL_FLOW_DIRTY}) HIPCHK(w, hipMemcpyAsync(d.flags + f, &one, sizeof(int), hipMemcpyHostToDevice, w->stream));
+    { int zero = 0; for (int f : {FL_BP_GRID_OK, FL_BP_NCHG, FL_BP_NMOVED, FL_BP_TOMBS, FL_BP_FORCE_FULL}) HIPCHK(w, hipMemcpyAsync(d.flags + f, &zero, sizeof(int), hipMemcpyHostToDevice, w->stream)); } // the grid and the change lists are scratch of the old world
     HIPCHK(w, hipStreamSynchronize(w->stream));
     w->pinned_flags[FL_LAYOUT_DIRTY] = 1; // next steps stay on the full graph until the device reports a clean state
     w->full_until = w->steps_requested + 3;
@@ -1079,6 +1080,7 @@ static int finalize(rp_world *w) {
     d.has_force_events = world_has_force_events(w) ? 1 : 0;
     d.has_sensors = world_has_sensors(w) ? 1 : 0;
     d.gbar_blocks = gbar_grid_for_device(w->device);
+    { const char *ni = getenv("RP_NO_BP_INCR"); d.bp_incremental = (ni && ni[0] == '1') ? 0 : 1; }
     { const char *ig = getenv("RP_ISL_GENERIC"); d.isl_generic = (ig && ig[0] == '1') ? 1 : 0; }
     w->compound = world_has_compound_bodies(w);
     int nb = (int)w->bodies.size(), nc = (int)w->colliders.size();
@@ -1130,6 +1132,7 @@ static int finalize(rp_world *w) {
     DAC(d.ev_col, d.ev_cap, DOM_FIXED, 1, 1); DAC(d.ev_force_meta, d.ev_cap, DOM_FIXED, 1, 1); DAC(d.ev_force_a, d.ev_cap, DOM_FIXED, 1, 1); DAC(d.ev_force_b, d.ev_cap, DOM_FIXED, 1, 1);
     DA(d.cell_count, d.grid_cap); DA(d.cell_start, d.grid_cap + 1); DA(d.cell_fill, d.grid_cap); DA(d.scan_block, 1024);
     DA(d.e_key, d.entries_cap); DA(d.e_col, d.entries_cap); DA(d.large_list, d.large_cap);
+    DA(d.c_chgstamp, capc); DA(d.c_stale, capc); DA(d.c_inlarge, capc); DA(d.bp_chg_list, capc); DA(d.bp_moved_list, RP_BP_MOVED_CAP); // incremental broad phase (scratch: rebuilt by the next full pass)
     DAF(d.h_key[0], d.hash_cap, 0xff); DAF(d.h_key[1], d.hash_cap, 0xff); DA(d.h_slot[0], d.hash_cap); DA(d.h_slot[1], d.hash_cap);
     DAC(d.free_stack, d.pool_cap, DOM_PAIR, 1, 1);
     size_t P = (size_t)d.pool_cap;
@@ -1890,6 +1893,7 @@ static int set_flag(rp_world *w, int slot, int v) { return poke(w, w->dw.flags +
 static int after_topology_edit(rp_world *w) {
     if (!w->finalized) return RP_OK;
     int r;
+    if ((r = set_flag(w, FL_BP_GRID_OK, 0)) != RP_OK) return r; // colliders came, went or changed their filters: the next broad-phase pass is a full rebuild
     if ((r = set_flag(w, FL_BP_DIRTY, 1)) != RP_OK || (r = set_flag(w, FL_LAYOUT_DIRTY, 1)) != RP_OK || (r = set_flag(w, FL_JOINT_DIRTY, 1)) != RP_OK || (r = set_flag(w, FL_FLOW_DIRTY, 1)) != RP_OK) return r;
     w->pinned_flags[FL_LAYOUT_DIRTY] = 1; // keeps the next steps on the full graph until the device reports a clean state
     w->full_until = w->steps_requested + 3;

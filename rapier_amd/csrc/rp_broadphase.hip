@@ -9,8 +9,15 @@
 //   * AddPair creates an empty ContactPair, DeletePair frees its solver colour (pair_management.rs:382).
 // The tree is free to differ: here a hashed uniform grid built by counting sort (HBM-bound integer
 // work, one thread per collider, wave-coalesced SoA loads) plus a brute-force list for colliders
-// spanning more than 3 cells.  Like the reference's change detection the whole rebuild is skipped
-// (every kernel early-exits on FL_BP_DIRTY == 0) while no fat AABB changed.
+// spanning more than 3 cells.  Like the reference's change detection the whole pass is skipped
+// (every kernel early-exits on FL_BP_DIRTY == 0) while no fat AABB changed, and — like its refit of the changed
+// leaves only (update.rs:139-331, :448-601) — a pass in which FEW fat AABBs changed touches only those colliders:
+// the grid of the last full rebuild still describes every collider that has not moved since, so a changed collider
+// finds its new partners by walking the cells under its new AABB (unmoved partners), the short list of colliders
+// that moved since the rebuild (their cells are stale) and the large list, and the pairs it lost by one sweep over
+// the pair slots; deleted pairs leave a tombstone in the live hash table.  The pair SET equals the full rebuild's;
+// a full rebuild runs when many colliders moved, the stale list or the tombstones grew, a large collider moved or
+// the topology changed (FL_BP_GRID_OK).
 #include "rp_pairs.h"
 #include "rp_gridbar.h"
 
@@ -93,6 +100,7 @@ RP_DEV void bp_clear(DevWorld &w, int gid, int gstride) {
 RP_DEV void bp_count(DevWorld &w, int gid, int gstride) {
     for (int i = gid; i < w.n_colliders; i += gstride) {
         CellRange r = cell_range(w, i);
+        w.c_inlarge[i] = r.large ? 1 : 0; w.c_stale[i] = 0; // the grid is being rebuilt: nobody is stale
         if (r.large) {
             int k = atomicAdd(&w.flags[FL_N_LARGE], 1);
             if (k < w.large_cap) w.large_list[k] = i; else atomicOr(&w.flags[FL_OVERFLOW], RP_OVF_LARGE);
@@ -192,11 +200,12 @@ __device__ __forceinline__ int hash_find(const unsigned long long *keys, const i
 RP_DEV bool pair_touches_island(const DevWorld &w, int rb1, int rb2) { return (rb1 >= 0 && w.b_island[rb1] >= 0) || (rb2 >= 0 && w.b_island[rb2] >= 0); }
 // AddPair (NarrowPhase::add_pair, pair_management.rs:572): find-or-create the pair slot and
 // register it in the next-epoch table.  Each unordered pair reaches this exactly once per rebuild.
-__device__ void bp_insert_pair(DevWorld &w, int c1, int c2) {
+__device__ void bp_insert_pair(DevWorld &w, int c1, int c2, bool incremental = false) {
     int epoch = w.flags[FL_BP_EPOCH];
     int cur = epoch & 1, nxt = cur ^ 1;
     unsigned long long key = ((unsigned long long)(unsigned)c1 << 32) | (unsigned)c2;
     int slot = hash_find(w.h_key[cur], w.h_slot[cur], w.hash_cap, key);
+    if (incremental && slot >= 0) return; // the pair lives on
     if (slot < 0) {
         int t = atomicSub(&w.flags[FL_FREE_TOP], 1);
         if (t > 0) slot = w.free_stack[t - 1];
@@ -210,11 +219,12 @@ __device__ void bp_insert_pair(DevWorld &w, int c1, int c2) {
         // creeping 20,100-body island of b3d_large_pyramid gains and loses near-miss pairs every step)
         if (pair_touches_island(w, w.c_parent[c1], w.c_parent[c2])) w.flags[FL_LAYOUT_DIRTY] = 1;
     }
-    w.p_stamp[slot] = epoch + 1;
+    w.p_stamp[slot] = incremental ? epoch : epoch + 1;
+    const int tab = incremental ? cur : nxt; // an incremental pass keeps the live table; a rebuild fills the next one
     int h = (int)(rp_hash64(key) & (unsigned long long)(w.hash_cap - 1));
     for (int probe = 0; probe < w.hash_cap; ++probe) {
-        unsigned long long prev = atomicCAS(&w.h_key[nxt][h], RP_EMPTY_KEY, key);
-        if (prev == RP_EMPTY_KEY) { w.h_slot[nxt][h] = slot; return; }
+        unsigned long long prev = atomicCAS(&w.h_key[tab][h], RP_EMPTY_KEY, key);
+        if (prev == RP_EMPTY_KEY) { w.h_slot[tab][h] = slot; return; }
         h = (h + 1) & (w.hash_cap - 1);
     }
     atomicOr(&w.flags[FL_OVERFLOW], RP_OVF_HASH);
@@ -265,8 +275,51 @@ RP_DEV void bp_pairs(DevWorld &w, int gid, int gstride) {
     }
 }
 
-// DeletePair: slots not re-stamped by this rebuild are dead (NarrowPhase::remove_pair,
-// pair_management.rs:382): free the colour, drop from the solver graph, recycle the slot.
+// DeletePair (NarrowPhase::remove_pair, pair_management.rs:382) of pair slot s: free the colour, raise the events and wake-ups,
+// journal the unlink, recycle the slot.
+RP_DEV void bp_delete_pair(DevWorld &w, int s) {
+    int color = w.p_color[s];
+    if (color < RP_COLOR_OVERFLOW) {
+        int2 cb = w.p_colorb[s];
+        unsigned bit = 1u << (color & 31);
+        if (cb.x >= 0) atomicAnd(&w.b_cmask[4 * cb.x + (color >> 5)], ~bit);
+        if (cb.y >= 0) atomicAnd(&w.b_cmask[4 * cb.y + (color >> 5)], ~bit);
+    }
+    { // a dead pair changes the layout when it was a solver manifold or when an LDS island lists it (see bp_insert_pair)
+        int2 drb = w.p_rb[s];
+        if (w.p_nsc[s] > 0 || pair_touches_island(w, drb.x, drb.y)) w.flags[FL_LAYOUT_DIRTY] = 1;
+    }
+    if (w.p_nsc[s] > 0 && pair_wants_collision_events(w, w.p_c1[s], w.p_c2[s])) {
+        // Stopped event of a touching pair: remove_pair (pair_management.rs:554-558), remove_collider (:101-110, REMOVED)
+        uint2 e1 = w.c_groups[w.p_c1[s]], e2 = w.c_groups[w.p_c2[s]];
+        bool removed = (e1.x == 0 && e1.y == 0) || (e2.x == 0 && e2.y == 0);
+        push_collision_event(w, w.p_c1[s], w.p_c2[s], 0, removed ? RP_COLLISION_EVENT_REMOVED : 0, cur_step(w));
+    }
+    if ((w.p_pflags[s] & RP_PF_INTERSECTING) && pair_wants_collision_events(w, w.p_c1[s], w.p_c2[s])) {
+        // remove_pair / remove_collider on the intersection graph (pair_management.rs:382-460): Stopped | SENSOR
+        uint2 e1 = w.c_groups[w.p_c1[s]], e2 = w.c_groups[w.p_c2[s]];
+        bool removed = (e1.x == 0 && e1.y == 0) || (e2.x == 0 && e2.y == 0);
+        push_collision_event(w, w.p_c1[s], w.p_c2[s], 0, (removed ? RP_COLLISION_EVENT_REMOVED : 0) | RP_COLLISION_EVENT_SENSOR, cur_step(w));
+    }
+    if (w.sleep_enabled) {
+        // remove_pair wakes the bodies of a touching pair (pair_management.rs:541-552); remove_collider wakes every
+        // body that had a pair with the removed collider (:88-99)
+        int c1 = w.p_c1[s], c2 = w.p_c2[s];
+        uint2 g1 = w.c_groups[c1], g2 = w.c_groups[c2];
+        bool gone = (g1.x == 0 && g1.y == 0) || (g2.x == 0 && g2.y == 0);
+        int2 rb = w.p_rb[s];
+        if (w.p_nsc[s] > 0 || gone) {
+            if (rb.x >= 0) atomicMax(&w.b_wake_req[rb.x], 2);
+            if (rb.y >= 0) atomicMax(&w.b_wake_req[rb.y], 2);
+        }
+        if (w.p_nsc[s] > 0) pi_journal(w, rb.x, rb.y, 1, c1, c2); // unlink_contact of a removed touching pair (pair_management.rs:531)
+    }
+    w.p_c1[s] = -1; w.p_nsc[s] = 0; w.p_npts[s] = 0; w.p_color[s] = RP_COLOR_UNCOLORED;
+    int t = atomicAdd(&w.flags[FL_FREE_TOP], 1);
+    w.free_stack[t] = s;
+}
+
+// DeletePair of a rebuild: slots not re-stamped by it are dead.
 RP_DEV void bp_finish_pairs(DevWorld &w, int gid, int gstride) {
     int epoch = w.flags[FL_BP_EPOCH];
     int top = w.flags[FL_POOL_TOP];
@@ -274,54 +327,111 @@ RP_DEV void bp_finish_pairs(DevWorld &w, int gid, int gstride) {
     for (int s = gid; s < top; s += gstride) {
         if (w.p_c1[s] < 0) continue;
         if (w.p_stamp[s] == epoch + 1) continue;
-        int color = w.p_color[s];
-        if (color < RP_COLOR_OVERFLOW) {
-            int2 cb = w.p_colorb[s];
-            unsigned bit = 1u << (color & 31);
-            if (cb.x >= 0) atomicAnd(&w.b_cmask[4 * cb.x + (color >> 5)], ~bit);
-            if (cb.y >= 0) atomicAnd(&w.b_cmask[4 * cb.y + (color >> 5)], ~bit);
-        }
-        { // a dead pair changes the layout when it was a solver manifold or when an LDS island lists it (see bp_insert_pair)
-            int2 drb = w.p_rb[s];
-            if (w.p_nsc[s] > 0 || pair_touches_island(w, drb.x, drb.y)) w.flags[FL_LAYOUT_DIRTY] = 1;
-        }
-        if (w.p_nsc[s] > 0 && pair_wants_collision_events(w, w.p_c1[s], w.p_c2[s])) {
-            // Stopped event of a touching pair: remove_pair (pair_management.rs:554-558), remove_collider (:101-110, REMOVED)
-            uint2 e1 = w.c_groups[w.p_c1[s]], e2 = w.c_groups[w.p_c2[s]];
-            bool removed = (e1.x == 0 && e1.y == 0) || (e2.x == 0 && e2.y == 0);
-            push_collision_event(w, w.p_c1[s], w.p_c2[s], 0, removed ? RP_COLLISION_EVENT_REMOVED : 0, cur_step(w));
-        }
-        if ((w.p_pflags[s] & RP_PF_INTERSECTING) && pair_wants_collision_events(w, w.p_c1[s], w.p_c2[s])) {
-            // remove_pair / remove_collider on the intersection graph (pair_management.rs:382-460): Stopped | SENSOR
-            uint2 e1 = w.c_groups[w.p_c1[s]], e2 = w.c_groups[w.p_c2[s]];
-            bool removed = (e1.x == 0 && e1.y == 0) || (e2.x == 0 && e2.y == 0);
-            push_collision_event(w, w.p_c1[s], w.p_c2[s], 0, (removed ? RP_COLLISION_EVENT_REMOVED : 0) | RP_COLLISION_EVENT_SENSOR, cur_step(w));
-        }
-        if (w.sleep_enabled) {
-            // remove_pair wakes the bodies of a touching pair (pair_management.rs:541-552); remove_collider wakes every
-            // body that had a pair with the removed collider (:88-99)
-            int c1 = w.p_c1[s], c2 = w.p_c2[s];
-            uint2 g1 = w.c_groups[c1], g2 = w.c_groups[c2];
-            bool gone = (g1.x == 0 && g1.y == 0) || (g2.x == 0 && g2.y == 0);
-            int2 rb = w.p_rb[s];
-            if (w.p_nsc[s] > 0 || gone) {
-                if (rb.x >= 0) atomicMax(&w.b_wake_req[rb.x], 2);
-                if (rb.y >= 0) atomicMax(&w.b_wake_req[rb.y], 2);
-            }
-            if (w.p_nsc[s] > 0) pi_journal(w, rb.x, rb.y, 1, c1, c2); // unlink_contact of a removed touching pair (pair_management.rs:531)
-        }
-        w.p_c1[s] = -1; w.p_nsc[s] = 0; w.p_npts[s] = 0; w.p_color[s] = RP_COLOR_UNCOLORED;
-        int t = atomicAdd(&w.flags[FL_FREE_TOP], 1);
-        w.free_stack[t] = s;
+        bp_delete_pair(w, s);
     }
 }
 
-// The whole rebuild in ONE launch (see rp_gridbar.h): a clean step (no fat AABB changed) costs a single early exit.
+// ---- incremental pass ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void hash_erase(unsigned long long *keys, int cap, unsigned long long key) {
+    int h = (int)(rp_hash64(key) & (unsigned long long)(cap - 1));
+    for (int probe = 0; probe < cap; ++probe) {
+        unsigned long long k = keys[h];
+        if (k == key) { keys[h] = RP_TOMB_KEY; return; }
+        if (k == RP_EMPTY_KEY) return;
+        h = (h + 1) & (cap - 1);
+    }
+}
+__device__ __forceinline__ void bp_try_pair(DevWorld &w, int i, int j) {
+    V3 imin;
+    if (!fat_overlap(w, i, j, imin) || !pair_allowed(w, i, j)) return;
+    bp_insert_pair(w, i < j ? i : j, i < j ? j : i, true);
+}
+// new partners of the colliders on bp_chg_list: one wavefront per changed collider
+RP_DEV void bp_incr_insert(DevWorld &w, int nchg, int nmoved) {
+    const int lane = threadIdx.x & 63, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int stamp = w.flags[FL_BP_SEQ] + 1;
+    const float ic = w.prm.inv_cell_size;
+    int nl = w.flags[FL_N_LARGE]; if (nl > w.large_cap) nl = w.large_cap;
+    for (int k = wave; k < nchg; k += nwaves) {
+        const int i = w.bp_chg_list[k];
+        CellRange r = cell_range(w, i);
+        if (r.large || w.c_inlarge[i]) { if (lane == 0) w.flags[FL_BP_FORCE_FULL] = 1; continue; } // the large list is only rebuilt by a full pass
+        // (a) the large colliders (ground slabs, walls: never stale)
+        for (int q = lane; q < nl; q += 64) bp_try_pair(w, i, w.large_list[q]);
+        // (b) colliders that moved since the last full rebuild but not in this pass: their cells are stale, the list is short
+        for (int q = lane; q < nmoved; q += 64) { int j = w.bp_moved_list[q]; if (j != i && w.c_chgstamp[j] != stamp) bp_try_pair(w, i, j); }
+        // (c) colliders that changed in this pass too: reported from the smaller index
+        for (int q = lane; q < nchg; q += 64) { int j = w.bp_chg_list[q]; if (j > i) bp_try_pair(w, i, j); }
+        // (d) everybody else through the grid: one lane per cell of the new AABB (at most 27); a pair is reported from the cell that
+        // holds the min corner of the intersection, which lies in both cell ranges
+        const int nx = r.hi[0] - r.lo[0] + 1, ny = r.hi[1] - r.lo[1] + 1, nz = r.hi[2] - r.lo[2] + 1;
+        if (lane < nx * ny * nz) {
+            const int x = r.lo[0] + lane % nx, y = r.lo[1] + (lane / nx) % ny, z = r.lo[2] + lane / (nx * ny);
+            unsigned long long key = cell_key(x, y, z);
+            int h = (int)(rp_hash64(key) & (unsigned long long)(w.grid_cap - 1));
+            int beg = w.cell_start[h], end = beg + w.cell_count[h];
+            if (end > w.entries_cap) end = w.entries_cap;
+            for (int e = beg; e < end; ++e) {
+                if (w.e_key[e] != key) continue;
+                int j = w.e_col[e];
+                if (j == i || w.c_stale[j] || w.c_chgstamp[j] == stamp) continue; // stale cells: covered by (b) / (c)
+                V3 imin;
+                if (!fat_overlap(w, i, j, imin)) continue;
+                if (cell_coord(imin.x, ic) != x || cell_coord(imin.y, ic) != y || cell_coord(imin.z, ic) != z) continue;
+                if (!pair_allowed(w, i, j)) continue;
+                bp_insert_pair(w, i < j ? i : j, i < j ? j : i, true);
+            }
+        }
+    }
+}
+// lost partners: every pair with a changed collider whose fat AABBs no longer intersect; the changed colliders join the stale list
+RP_DEV void bp_incr_delete(DevWorld &w, int gid, int gstride, int nchg) {
+    const int stamp = w.flags[FL_BP_SEQ] + 1, cur = w.flags[FL_BP_EPOCH] & 1;
+    int top = w.flags[FL_POOL_TOP];
+    if (top > w.pool_cap) top = w.pool_cap;
+    for (int s = gid; s < top; s += gstride) {
+        const int c1 = w.p_c1[s];
+        if (c1 < 0) continue;
+        const int c2 = w.p_c2[s];
+        if (w.c_chgstamp[c1] != stamp && w.c_chgstamp[c2] != stamp) continue;
+        V3 imin;
+        if (fat_overlap(w, c1, c2, imin)) continue;
+        hash_erase(w.h_key[cur], w.hash_cap, ((unsigned long long)(unsigned)c1 << 32) | (unsigned)c2);
+        atomicAdd(&w.flags[FL_BP_TOMBS], 1);
+        bp_delete_pair(w, s);
+    }
+    for (int k = gid; k < nchg; k += gstride) {
+        const int i = w.bp_chg_list[k];
+        if (!w.c_stale[i]) { w.c_stale[i] = 1; int q = atomicAdd(&w.flags[FL_BP_NMOVED], 1); if (q < RP_BP_MOVED_CAP) w.bp_moved_list[q] = i; }
+    }
+}
+
+// The whole pass in ONE launch (see rp_gridbar.h): a clean step (no fat AABB changed) costs a single early exit, a step in which few
+// colliders left their fat AABBs two passes over those colliders and the pair slots, anything else the full rebuild.
 __global__ void __launch_bounds__(1024) k_bp_rebuild(DevWorld w) {
     if (!w.flags[FL_BP_DIRTY]) return; // (cleared only after the last barrier: every workgroup reads the same value)
     __shared__ int scan_lds[1024];
     const int gid = gbar_item(), gstride = gridDim.x * blockDim.x;
+    // the mode is decided from scalars that only change behind a barrier of this launch (or at its very end)
+    const int nchg = w.flags[FL_BP_NCHG] < w.n_colliders ? w.flags[FL_BP_NCHG] : w.n_colliders, nmoved = w.flags[FL_BP_NMOVED];
+    const bool incremental = w.bp_incremental && w.flags[FL_BP_GRID_OK] && nchg > 0 && nchg <= w.n_colliders / 4 + 16 && nmoved + nchg <= RP_BP_MOVED_CAP &&
+                             w.flags[FL_BP_TOMBS] < w.hash_cap / 8;
     GridBar bar = gbar_begin(w, 0);
+    if (incremental) {
+        bp_incr_insert(w, nchg, nmoved);
+        GBAR_SYNC(bar);
+        if (!w.flags[FL_BP_FORCE_FULL]) {
+            bp_incr_delete(w, gid, gstride, nchg);
+            GBAR_SYNC(bar);
+            gbar_end(bar);
+            if (gid == 0) {
+                w.flags[FL_BP_NCHG] = 0; w.flags[FL_BP_SEQ] += 1; w.flags[FL_BP_REBUILDS] += 1;
+                __hip_atomic_store(&w.flags[FL_BP_DIRTY], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+        // a large collider moved: the pairs inserted so far are found again (and re-stamped) by the rebuild below
+    }
     const int epoch = w.flags[FL_BP_EPOCH];
     bp_clear(w, gid, gstride);
     GBAR_SYNC(bar);
@@ -340,9 +450,11 @@ __global__ void __launch_bounds__(1024) k_bp_rebuild(DevWorld w) {
     bp_finish_pairs(w, gid, gstride);
     GBAR_SYNC(bar);
     gbar_end(bar);
-    if (gid == 0) { // the rebuild is closed: epoch flip, dirty flag
+    if (gid == 0) { // the rebuild is closed: epoch flip, dirty flag; the grid is valid and nobody is stale
         w.flags[FL_BP_EPOCH] = epoch + 1;
         w.flags[FL_BP_REBUILDS] += 1;
+        w.flags[FL_BP_NCHG] = 0; w.flags[FL_BP_NMOVED] = 0; w.flags[FL_BP_TOMBS] = 0; w.flags[FL_BP_FORCE_FULL] = 0; w.flags[FL_BP_SEQ] += 1;
+        w.flags[FL_BP_GRID_OK] = (w.flags[FL_OVERFLOW] & (RP_OVF_CELLS | RP_OVF_LARGE)) ? 0 : 1;
         __hip_atomic_store(&w.flags[FL_BP_DIRTY], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }

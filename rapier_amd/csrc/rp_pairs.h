@@ -99,6 +99,9 @@ RP_DEV bool collider_update_one(const DevWorld &w, int i) { // true = the fat AA
         w.c_fatmin[i] = f4(mn - v3(s, s, s), 0.0f);
         w.c_fatmax[i] = f4(mx + v3(s, s, s), 0.0f);
         w.flags[FL_BP_DIRTY] = 1;
+        // queued once per broad-phase pass for the incremental update (rp_broadphase.hip)
+        const int stamp = w.flags[FL_BP_SEQ] + 1;
+        if (w.c_chgstamp[i] != stamp) { w.c_chgstamp[i] = stamp; int k = atomicAdd(&w.flags[FL_BP_NCHG], 1); if (k < w.n_colliders) w.bp_chg_list[k] = i; }
     }
     return !inside;
 }

@@ -18,6 +18,8 @@
 #define RP_MAX_PTS 8                 // manifold points kept per pair (face/face clip max)
 #define RP_PARALLEL_MIN_MANIFOLDS 125 // ceil(n/4) >= 32 chunks  (init.rs:169, mod.rs:41-57)
 #define RP_EMPTY_KEY 0xffffffffffffffffull
+#define RP_TOMB_KEY 0xfffffffffffffffeull   // a pair deleted by an incremental broad-phase pass (probing continues past it)
+#define RP_BP_MOVED_CAP 2048                // stale colliders an incremental pass may leave behind before a full rebuild is due
 #define RP_ISL_NB_MAX 64             // bodies per LDS-resident island
 #define RP_ISL_NC_MAX 160            // solver manifolds per LDS-resident island
 #define RP_FID_UNKNOWN 0xffffu
@@ -98,6 +100,13 @@ enum {
     FL_PJ_COUNT,        // removal_journal entries waiting for resolve_removals
     FL_PI_MERGED,       // scratch of one sleep pass: some touching pair joins two islands
     FL_PI_JLINK,        // first device joint whose ImpulseJointIslandEvent::Link is not applied yet, + 1 (0 = none)
+    // incremental broad phase (rp_broadphase.hip)
+    FL_BP_NCHG,         // colliders whose fat AABB was rewritten since the last broad-phase pass (bp_chg_list)
+    FL_BP_NMOVED,       // colliders whose grid cells are stale since the last FULL rebuild (bp_moved_list)
+    FL_BP_GRID_OK,      // the grid describes every collider that is not on bp_moved_list (cleared by topology edits)
+    FL_BP_SEQ,          // broad-phase passes run so far (stamps c_chgstamp)
+    FL_BP_FORCE_FULL,   // scratch of one pass: the incremental update met a case it leaves to the full rebuild
+    FL_BP_TOMBS,        // tombstones in the live pair hash table since the last full rebuild
     FL_COUNT = 64       // <= 64: publish_flags copies one slot per lane of a wavefront
 };
 
@@ -176,6 +185,7 @@ struct DevWorld {
     int has_kinematic_pos; // some body is KinematicPositionBased: k_kinematic_velocities runs
     int isl_generic;       // RP_ISL_GENERIC=1: islands through k_island_generic even under the twist model (tests of that kernel)
     int n_groups;          // distinct additional_solver_iterations counts in the world (1 = no elevated body: the plain paths)
+    int bp_incremental;    // the broad phase may update incrementally (0: RP_NO_BP_INCR=1, every pass is a full rebuild)
     int gbar_blocks;       // most workgroups (of 1024 threads) a grid-barrier kernel may use on this device: all of them resident at once (rp_gridbar.h)
     int has_sensors;       // some collider is a sensor: its pairs are intersection-tested every step (full step path)
     SimParams prm;
@@ -248,6 +258,8 @@ struct DevWorld {
     int *cell_count, *cell_start, *cell_fill, *scan_block;
     unsigned long long *e_key; int *e_col;
     int *large_list;
+    int *c_chgstamp, *c_stale, *c_inlarge; // per collider: pass (FL_BP_SEQ + 1) that already queued it on bp_chg_list; grid cells stale; on large_list
+    int *bp_chg_list, *bp_moved_list;      // [colliders] fat AABBs rewritten since the last pass; [RP_BP_MOVED_CAP] stale colliders
     unsigned long long *h_key[2]; int *h_slot[2];
     int *free_stack;
 
