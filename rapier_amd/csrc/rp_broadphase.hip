@@ -198,6 +198,22 @@ __device__ __forceinline__ int hash_find(const unsigned long long *keys, const i
 }
 
 RP_DEV bool pair_touches_island(const DevWorld &w, int rb1, int rb2) { return (rb1 >= 0 && w.b_island[rb1] >= 0) || (rb2 >= 0 && w.b_island[rb2] >= 0); }
+// A pair slot for every lane that is active here: the free stack first, then the bump allocator — ONE atomic per wavefront and
+// counter instead of one per lane (the first step of b3d_many_pyramids creates 28,420 pairs: their 85 k same-address atomics were
+// the whole cost of the pair pass once it ran wide)
+__device__ int pair_slot_alloc(DevWorld &w) {
+    const unsigned long long m = __ballot(1);
+    const int lane = threadIdx.x & 63, n = __popcll(m), leader = __ffsll((long long)m) - 1, rank = __popcll(m & ((1ull << lane) - 1ull));
+    int t = 0, p = 0;
+    if (lane == leader) {
+        t = atomicSub(&w.flags[FL_FREE_TOP], n);
+        const int from_free = t > 0 ? (t < n ? t : n) : 0, from_pool = n - from_free;
+        if (from_pool) { atomicAdd(&w.flags[FL_FREE_TOP], from_pool); p = atomicAdd(&w.flags[FL_POOL_TOP], from_pool); }
+    }
+    t = __shfl(t, leader, 64); p = __shfl(p, leader, 64);
+    const int from_free = t > 0 ? (t < n ? t : n) : 0;
+    return rank < from_free ? w.free_stack[t - 1 - rank] : p + (rank - from_free);
+}
 // AddPair (NarrowPhase::add_pair, pair_management.rs:572): find-or-create the pair slot and
 // register it in the next-epoch table.  Each unordered pair reaches this exactly once per rebuild.
 __device__ void bp_insert_pair(DevWorld &w, int c1, int c2, bool incremental = false) {
@@ -207,9 +223,7 @@ __device__ void bp_insert_pair(DevWorld &w, int c1, int c2, bool incremental = f
     int slot = hash_find(w.h_key[cur], w.h_slot[cur], w.hash_cap, key);
     if (incremental && slot >= 0) return; // the pair lives on
     if (slot < 0) {
-        int t = atomicSub(&w.flags[FL_FREE_TOP], 1);
-        if (t > 0) slot = w.free_stack[t - 1];
-        else { atomicAdd(&w.flags[FL_FREE_TOP], 1); slot = atomicAdd(&w.flags[FL_POOL_TOP], 1); }
+        slot = pair_slot_alloc(w);
         if (slot >= w.pool_cap) { atomicOr(&w.flags[FL_OVERFLOW], RP_OVF_POOL); return; }
         w.p_c1[slot] = c1; w.p_c2[slot] = c2; w.p_rb[slot] = make_int2(w.c_parent[c1], w.c_parent[c2]);
         w.p_color[slot] = RP_COLOR_UNCOLORED; w.p_nsc[slot] = 0; w.p_npts[slot] = 0; w.p_pflags[slot] = 0;
@@ -230,48 +244,45 @@ __device__ void bp_insert_pair(DevWorld &w, int c1, int c2, bool incremental = f
     atomicOr(&w.flags[FL_OVERFLOW], RP_OVF_HASH);
 }
 
-// Colliders spanning > 3 cells (ground slabs, walls) against everything: looping over the (short) large list.
-__device__ void bp_pairs_vs_large(DevWorld &w, int i, bool i_large) {
+// The pair pass of a full rebuild: EIGHT lanes per collider, each walking every eighth cell of the collider's range (at most 27; a
+// pair is reported from the cell that holds the min corner of the two fat AABBs' intersection, so once) and every eighth entry of
+// the (short) list of large colliders — ground slabs, walls.  One thread per collider walked its 27 cells one after the other: a
+// chain of ~100 dependent L2 round trips, 150 us of the 213 us rebuild on b3d_large_pyramid (tools/pass_profile.py); a whole
+// wavefront per collider does not fit the resident grid of a barrier kernel (16 rounds: slower).
+#define BP_GROUP 8
+RP_DEV void bp_pairs(DevWorld &w) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, sub = tid & (BP_GROUP - 1), ngroups = (gridDim.x * blockDim.x) / BP_GROUP;
+    const float ic = w.prm.inv_cell_size;
     int nl = w.flags[FL_N_LARGE];
     if (nl > w.large_cap) nl = w.large_cap;
-    for (int k = 0; k < nl; ++k) {
-        int L = w.large_list[k];
-        if (L == i) continue;
-        if (i_large && i > L) continue; // large-large pairs reported from the lower index
-        V3 imin;
-        if (!fat_overlap(w, i, L, imin)) continue;
-        if (!pair_allowed(w, i, L)) continue;
-        bp_insert_pair(w, i < L ? i : L, i < L ? L : i);
-    }
-}
-
-// (one lane per (collider, cell) instead of per collider was measured on b3d_large_pyramid: 27x the range computations for a shorter
-// walk — the pass got 20 % slower; not kept)
-RP_DEV void bp_pairs(DevWorld &w, int gid, int gstride) {
-    float ic = w.prm.inv_cell_size;
-    for (int i = gid; i < w.n_colliders; i += gstride) {
+    for (int i = tid / BP_GROUP; i < w.n_colliders; i += ngroups) {
         CellRange r = cell_range(w, i);
-        bp_pairs_vs_large(w, i, r.large);
+        for (int q = sub; q < nl; q += BP_GROUP) {
+            int L = w.large_list[q];
+            if (L == i || (r.large && i > L)) continue; // large-large pairs reported from the lower index
+            V3 imin;
+            if (!fat_overlap(w, i, L, imin) || !pair_allowed(w, i, L)) continue;
+            bp_insert_pair(w, i < L ? i : L, i < L ? L : i);
+        }
         if (r.large) continue;
-        for (int z = r.lo[2]; z <= r.hi[2]; ++z)
-            for (int y = r.lo[1]; y <= r.hi[1]; ++y)
-                for (int x = r.lo[0]; x <= r.hi[0]; ++x) {
-                    unsigned long long key = cell_key(x, y, z);
-                    int h = (int)(rp_hash64(key) & (unsigned long long)(w.grid_cap - 1));
-                    int beg = w.cell_start[h], end = beg + w.cell_count[h];
-                    if (end > w.entries_cap) end = w.entries_cap;
-                    for (int e = beg; e < end; ++e) {
-                        if (w.e_key[e] != key) continue;
-                        int j = w.e_col[e];
-                        if (j <= i) continue;
-                        V3 imin;
-                        if (!fat_overlap(w, i, j, imin)) continue;
-                        // report only in the cell that holds the min corner of the intersection
-                        if (cell_coord(imin.x, ic) != x || cell_coord(imin.y, ic) != y || cell_coord(imin.z, ic) != z) continue;
-                        if (!pair_allowed(w, i, j)) continue;
-                        bp_insert_pair(w, i, j);
-                    }
-                }
+        const int nx = r.hi[0] - r.lo[0] + 1, ny = r.hi[1] - r.lo[1] + 1, nz = r.hi[2] - r.lo[2] + 1;
+        for (int c = sub; c < nx * ny * nz; c += BP_GROUP) {
+            const int x = r.lo[0] + c % nx, y = r.lo[1] + (c / nx) % ny, z = r.lo[2] + c / (nx * ny);
+            unsigned long long key = cell_key(x, y, z);
+            int h = (int)(rp_hash64(key) & (unsigned long long)(w.grid_cap - 1));
+            int beg = w.cell_start[h], end = beg + w.cell_count[h];
+            if (end > w.entries_cap) end = w.entries_cap;
+            for (int e = beg; e < end; ++e) {
+                if (w.e_key[e] != key) continue;
+                int j = w.e_col[e];
+                if (j <= i) continue;
+                V3 imin;
+                if (!fat_overlap(w, i, j, imin)) continue;
+                if (cell_coord(imin.x, ic) != x || cell_coord(imin.y, ic) != y || cell_coord(imin.z, ic) != z) continue;
+                if (!pair_allowed(w, i, j)) continue;
+                bp_insert_pair(w, i, j);
+            }
+        }
     }
 }
 
@@ -433,22 +444,23 @@ __global__ void __launch_bounds__(1024) k_bp_rebuild(DevWorld w) {
         // a large collider moved: the pairs inserted so far are found again (and re-stamped) by the rebuild below
     }
     const int epoch = w.flags[FL_BP_EPOCH];
+    RP_PASS_BEGIN();
     bp_clear(w, gid, gstride);
-    GBAR_SYNC(bar);
+    GBAR_SYNC(bar); RP_PASS_STAMP(w, 220);
     bp_count(w, gid, gstride);
-    GBAR_SYNC(bar);
+    GBAR_SYNC(bar); RP_PASS_STAMP(w, 220);
     bp_scan_chunks(w, scan_lds);
-    GBAR_SYNC(bar);
+    GBAR_SYNC(bar); RP_PASS_STAMP(w, 220);
     if (blockIdx.x == 0) bp_scan_sums(w, scan_lds);
-    GBAR_SYNC(bar);
+    GBAR_SYNC(bar); RP_PASS_STAMP(w, 220);
     bp_scan_add(w, gid, gstride);
-    GBAR_SYNC(bar);
+    GBAR_SYNC(bar); RP_PASS_STAMP(w, 220);
     bp_fill(w, gid, gstride);
-    GBAR_SYNC(bar);
-    bp_pairs(w, gid, gstride);
-    GBAR_SYNC(bar);
+    GBAR_SYNC(bar); RP_PASS_STAMP(w, 220);
+    bp_pairs(w);
+    GBAR_SYNC(bar); RP_PASS_STAMP(w, 220);
     bp_finish_pairs(w, gid, gstride);
-    GBAR_SYNC(bar);
+    GBAR_SYNC(bar); RP_PASS_STAMP(w, 220);
     gbar_end(bar);
     if (gid == 0) { // the rebuild is closed: epoch flip, dirty flag; the grid is valid and nobody is stale
         w.flags[FL_BP_EPOCH] = epoch + 1;
@@ -500,7 +512,7 @@ void rp_launch_bp_rehash(const DevWorld &w, hipStream_t st) {
 void rp_launch_broadphase(const DevWorld &w, hipStream_t st) {
     if (w.n_colliders == 0) return;
     // every workgroup must be resident (grid barriers): at most DevWorld::gbar_blocks workgroups of 1024 threads (rp_gridbar.h)
-    int blocks = (w.n_colliders + 255) / 256; // ~4 wavefronts of colliders per workgroup: the cell walks are latency-bound, spread them
+    int blocks = (w.n_colliders + 127) / 128; // the pair pass gives every collider 8 lanes (BP_GROUP): one round when the grid allows
     if (blocks < 8) blocks = 8;    // the clears and the pair-slot sweep are sized by capacities, not by the collider count
     if (blocks > w.gbar_blocks) blocks = w.gbar_blocks;
     hipLaunchKernelGGL(k_bp_rebuild, dim3(blocks), dim3(1024), 0, st, w);

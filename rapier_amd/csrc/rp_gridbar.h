@@ -55,3 +55,14 @@ RP_DEV int gbar_item(void) { return (int)((((threadIdx.x >> 6) * gridDim.x + blo
 RP_DEV void gbar_end(const GridBar &b) {
     if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(b.word + 1, b.target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+
+// -DRP_PASS_PROFILE (tools/pass_profile.py): thread 0 of the launch accumulates the time between stamps (10 ns ticks) into
+// DevWorld::dbg[base + k], so the passes of a fused rebuild kernel can be told apart.  Stamps sit BEHIND barriers: what is measured is
+// the slowest workgroup of each pass plus its barrier.
+#ifdef RP_PASS_PROFILE
+#define RP_PASS_BEGIN() long long rp_pp_t = wall_clock64(); int rp_pp_k = 0
+#define RP_PASS_STAMP(w, base) do { if (blockIdx.x == 0 && threadIdx.x == 0) { long long n_ = wall_clock64(); (w).dbg[(base) + rp_pp_k] += n_ - rp_pp_t; rp_pp_t = n_; (w).dbg[(base) + 15] += (rp_pp_k == 0); } rp_pp_k++; } while (0)
+#else
+#define RP_PASS_BEGIN() do { } while (0)
+#define RP_PASS_STAMP(w, base) do { } while (0)
+#endif

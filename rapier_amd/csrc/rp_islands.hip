@@ -22,19 +22,32 @@
 #include "rp_gridbar.h"
 
 RP_DEV int ld_i32(int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// find with path halving: a non-root node is re-pointed at its grandparent (an ancestor stays an ancestor under concurrent
+// hooks, which only ever write roots), so the chains of a giant component — b3d_large_pyramid hooks 20,100 bodies into one —
+// stay short however the unions interleave
 RP_DEV int uf_find(int *label, int x) {
     int p = ld_i32(&label[x]);
-    while (p != x) { x = p; p = ld_i32(&label[x]); }
+    while (p != x) {
+        int gp = ld_i32(&label[p]);
+        if (gp != p) atomicCAS(&label[x], p, gp);
+        x = p; p = gp;
+    }
     return x;
 }
 RP_DEV bool is_dyn(const DevWorld &w, int b) { return body_active(w, b); } // awake dynamic bodies: the active set
 
-// Lock-free union (hook the larger root under the smaller one, retry on races).
+// Lock-free union: a root is hooked under the root of HIGHER priority, retry on races.  The priority is a bijective scramble of the
+// body index, not the index itself: bodies are numbered along the rows of a stack, and "hook the larger index under the smaller"
+// turned every row of b3d_large_pyramid into one 200-link chain (all its hooks succeed at once), which the finds of the same pass
+// then walked at one L2 round trip per link — 330 us of a 510 us layout rebuild.  Random linking keeps the trees O(log n) deep.
+// (Which member ends up as the root is irrelevant here: the labels only name components.)
+RP_DEV unsigned uf_priority(int x) { return (unsigned)x * 2654435761u; }
 RP_DEV void uf_union(int *label, int a, int b) {
+    if (ld_i32(&label[a]) == ld_i32(&label[b])) return; // siblings (after compression: most pairs of a big component) — the root's line is not touched
     for (;;) {
         a = uf_find(label, a); b = uf_find(label, b);
         if (a == b) return;
-        if (a < b) { int t = a; a = b; b = t; }
+        if (uf_priority(a) < uf_priority(b)) { int t = a; a = b; b = t; }
         if (atomicCAS(&label[a], a, b) == a) return;
     }
 }
@@ -58,29 +71,59 @@ RP_DEV void lay_isl_union(DevWorld &w, int gid, int gstride) {
         if (is_dyn(w, b1) && is_dyn(w, b2)) uf_union(w.b_label, b1, b2);
     }
 }
-// flatten the labels; per-root body and manifold counts
+// flatten the labels; per-root body and manifold counts.  Lanes of a wavefront that name the same root (a giant component: all of them)
+// add through ONE lane: the counts saturate just above the island limits, so what the others would do is a load of one hot line each.
+RP_DEV void wave_add_saturating(int *counts, int root, int amount, int limit, bool active) {
+    unsigned long long todo = __ballot(active);
+    const int lane = threadIdx.x & 63;
+    // components are mostly runs of neighbouring indices: when no lane shares its root with its neighbour the wavefront holds (about)
+    // as many roots as lanes — b3d_joint_grid: 9,900 singletons — and grouping would only cost a round per lane
+    if (!__ballot(active && lane > 0 && root == __shfl_up(root, 1, 64) && ((todo >> (lane - 1)) & 1ull))) {
+        if (active && ld_i32(&counts[root]) <= limit) atomicAdd(&counts[root], amount);
+        return;
+    }
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int r = __shfl(root, leader, 64);
+        const unsigned long long same = __ballot(active && root == r) & todo;
+        // sum the amounts of the matching lanes (a 64-lane ballot walk is cheaper than a segmented reduction here: one or two groups per wave)
+        int total = 0;
+        for (unsigned long long m = same; m; m &= m - 1) total += __shfl(amount, __ffsll((long long)m) - 1, 64);
+        if (lane == leader && ld_i32(&counts[r]) <= limit) atomicAdd(&counts[r], total > limit + 1 ? limit + 1 : total);
+        todo &= ~same;
+    }
+}
 RP_DEV void lay_isl_count(DevWorld &w, int gid, int stride) {
     int top = w.flags[FL_POOL_TOP];
     if (top > w.pool_cap) top = w.pool_cap;
-    for (int b = gid; b < w.n_bodies; b += stride) {
-        if (!is_dyn(w, b)) continue;
-        int root = uf_find(w.b_label, b);
-        __hip_atomic_store(&w.b_label[b], root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // saturating counts: a component that already exceeds the island limits stays on the global path
-        // whatever its exact size, so further increments (all on ONE address for a giant island) are skipped
-        if (ld_i32(&w.r_nb[root]) <= RP_ISL_NB_MAX) atomicAdd(&w.r_nb[root], 1);
-        // a body that carries a joint is solved on the global path (joints live there): poison its component
-        // (FrictionModel::Coulomb: the islands are solved by k_island_generic, the twist-only k_island_solve is not launched)
-        // ... and so are kinematic bodies (solver bodies with zero inverse mass and their own write-back rule)
-        // ... and so is everything in a world with substep solve-groups (additional_solver_iterations: rp_groups.h)
-        if (w.b_njoints[b] > 0 || (w.b_flags[b] & RP_BF_TYPE_MASK) != RP_BODY_DYNAMIC || w.n_groups > 1) atomicAdd(&w.r_nc[root], RP_ISL_NC_MAX + 1);
+    for (int base = 0; base < w.n_bodies; base += stride) { // wave-uniform trip count (ballots / shuffles inside)
+        const int b = base + gid;
+        const bool act = b < w.n_bodies && is_dyn(w, b);
+        int root = 0, poison = 0;
+        if (act) {
+            root = uf_find(w.b_label, b);
+            __hip_atomic_store(&w.b_label[b], root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // a body that carries a joint is solved on the global path (joints live there): poison its component
+            // (FrictionModel::Coulomb: the islands are solved by k_island_generic, the twist-only k_island_solve is not launched)
+            // ... and so are kinematic bodies (solver bodies with zero inverse mass and their own write-back rule)
+            // ... and so is everything in a world with substep solve-groups (additional_solver_iterations: rp_groups.h)
+            if (w.b_njoints[b] > 0 || (w.b_flags[b] & RP_BF_TYPE_MASK) != RP_BODY_DYNAMIC || w.n_groups > 1) poison = RP_ISL_NC_MAX + 1;
+        }
+        // saturating counts: a component that already exceeds the island limits stays on the global path whatever its exact size
+        wave_add_saturating(w.r_nb, root, 1, RP_ISL_NB_MAX, act);
+        wave_add_saturating(w.r_nc, root, poison, RP_ISL_NC_MAX, act && poison > 0);
     }
-    for (int s = gid; s < top; s += stride) {
-        if (w.p_c1[s] < 0) continue;
-        int b1 = w.c_parent[w.p_c1[s]], b2 = w.c_parent[w.p_c2[s]];
-        int b = is_dyn(w, b1) ? b1 : b2;
-        if (!pair_active(w, s)) { if (is_dyn(w, b)) atomicAdd(&w.r_ni[uf_find(w.b_label, b)], 1); continue; } // pair without solver contacts
-        if (is_dyn(w, b)) { int root = uf_find(w.b_label, b); if (ld_i32(&w.r_nc[root]) <= RP_ISL_NC_MAX) atomicAdd(&w.r_nc[root], 1); }
+    for (int base = 0; base < top; base += stride) {
+        const int s = base + gid;
+        bool inactive_pair = false, active_pair = false;
+        int root = 0;
+        if (s < top && w.p_c1[s] >= 0) {
+            int b1 = w.c_parent[w.p_c1[s]], b2 = w.c_parent[w.p_c2[s]];
+            int b = is_dyn(w, b1) ? b1 : b2;
+            if (is_dyn(w, b)) { root = uf_find(w.b_label, b); if (pair_active(w, s)) active_pair = true; else inactive_pair = true; } // inactive: a pair without solver contacts
+        }
+        wave_add_saturating(w.r_nc, root, 1, RP_ISL_NC_MAX, active_pair);
+        if (inactive_pair) atomicAdd(&w.r_ni[root], 1);
     }
 }
 // number the islands that fit one workgroup (registers + LDS)
@@ -165,29 +208,25 @@ RP_DEV void lay_bucket_count(DevWorld &w, int gid, int stride, int *hist, int &n
     for (int c = threadIdx.x; c < RP_NUM_COLORS; c += blockDim.x) if (hist[c]) atomicAdd(&w.color_count[c], hist[c]);
     if (threadIdx.x == 0 && nsc_sum) atomicAdd(&w.flags[FL_N_SC], nsc_sum);
 }
-RP_DEV void lay_bucket_layout(DevWorld &w, int *part) { // workgroup 0, 1024 threads
-    // all threads: per colour, the exclusive prefix popcount of the owner bitmap along its words (rank of a body among the owners)
-    {
-        const int words = w.cb_words, per = (words + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < words ? lo + per : words;
-        for (int c = 0; c < RP_COLOR_OVERFLOW; ++c) {
-            if (w.color_count_glob[c] == 0) continue; // uniform
-            const unsigned *bits = w.cb_bits + (size_t)c * words;
-            int *pre = w.cb_prefix + (size_t)c * words;
-            int sum = 0;
-            for (int i = lo; i < hi; ++i) sum += __popc(bits[i]);
-            part[threadIdx.x] = sum;
-            __syncthreads();
-            for (int off = 1; off < 1024; off <<= 1) { // Hillis-Steele inclusive scan of the 1024 partial sums
-                int v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
-                __syncthreads();
-                part[threadIdx.x] += v;
-                __syncthreads();
-            }
-            int run = part[threadIdx.x] - sum;
-            for (int i = lo; i < hi; ++i) { pre[i] = run; run += __popc(bits[i]); }
-            __syncthreads();
-        }
+// per colour, the exclusive prefix popcount of the owner bitmap along its words (rank of a body among the colour's owners): one
+// WAVEFRONT per colour over the whole launch (shuffles, no workgroup barrier) — the 128 colours used to be scanned one after the
+// other by workgroup 0 with 20 workgroup barriers each (~15 us per colour in use while every other workgroup waited)
+RP_DEV void lay_owner_prefix(DevWorld &w) {
+    const int lane = threadIdx.x & 63, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int words = w.cb_words, per = (words + 63) / 64, lo = lane * per, hi = lo + per < words ? lo + per : words;
+    for (int c = wave; c < RP_COLOR_OVERFLOW; c += nwaves) {
+        if (w.color_count_glob[c] == 0) continue; // wave-uniform
+        const unsigned *bits = w.cb_bits + (size_t)c * words;
+        int *pre = w.cb_prefix + (size_t)c * words;
+        int sum = 0;
+        for (int i = lo; i < hi; ++i) sum += __popc(bits[i]);
+        int incl = sum;
+        for (int off = 1; off < 64; off <<= 1) { int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
+        int run = incl - sum;
+        for (int i = lo; i < hi; ++i) { pre[i] = run; run += __popc(bits[i]); }
     }
+}
+RP_DEV void lay_bucket_layout(DevWorld &w) { // workgroup 0: the stage order (serial, a few hundred scalar operations)
     if (threadIdx.x != 0) return;
     int nst = 0, npar = 0, pos = 0, maxs = 0, ncol = 0, mall = 0;
     for (int pass = 0; pass < 2; ++pass)
@@ -272,25 +311,30 @@ __global__ void __launch_bounds__(1024) k_layout_rebuild(DevWorld w) {
     __shared__ int lds_a[1024], lds_b[RP_NUM_COLORS], lds_scalar;
     const int gid = gbar_item(), gstride = gridDim.x * blockDim.x;
     GridBar bar = gbar_begin(w, 1);
+    RP_PASS_BEGIN();
     if (blockIdx.x == 0) lay_bucket_clear(w);
     lay_isl_init(w, gid, gstride);
-    GBAR_SYNC(bar);
+    GBAR_SYNC(bar); RP_PASS_STAMP(w, 200);
     lay_bucket_count(w, gid, gstride, lds_a, lds_scalar);
+#ifdef RP_PASS_PROFILE
+    GBAR_SYNC(bar); RP_PASS_STAMP(w, 200); // (profiling only: the bucket count apart from the union)
+#endif
     lay_isl_union(w, gid, gstride);
-    GBAR_SYNC(bar);
+    GBAR_SYNC(bar); RP_PASS_STAMP(w, 200);
     lay_isl_count(w, gid, gstride);
-    GBAR_SYNC(bar);
+    GBAR_SYNC(bar); RP_PASS_STAMP(w, 200);
     lay_isl_number(w, gid, gstride);
-    GBAR_SYNC(bar);
+    GBAR_SYNC(bar); RP_PASS_STAMP(w, 200);
     __syncthreads();
     lay_isl_fill(w, gid, gstride, lds_a, lds_scalar);
-    GBAR_SYNC(bar);
-    if (blockIdx.x == 0) lay_bucket_layout(w, lds_a);
-    GBAR_SYNC(bar);
+    GBAR_SYNC(bar); RP_PASS_STAMP(w, 200);
+    lay_owner_prefix(w);
+    if (blockIdx.x == 0) lay_bucket_layout(w);
+    GBAR_SYNC(bar); RP_PASS_STAMP(w, 200);
     lay_bucket_scatter(w, gid, gstride, lds_a, lds_b);
-    GBAR_SYNC(bar);
+    GBAR_SYNC(bar); RP_PASS_STAMP(w, 200);
     if (blockIdx.x == 0) lay_rank_overflow(w);
-    GBAR_SYNC(bar);
+    GBAR_SYNC(bar); RP_PASS_STAMP(w, 200);
     gbar_end(bar);
     if (gid == 0) __hip_atomic_store(&w.flags[FL_LAYOUT_DIRTY], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -35,9 +35,13 @@
 #include "rp_gridbar.h"
 
 RP_DEV int slp_ld(int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-RP_DEV int slp_find(int *label, int x) {
+RP_DEV int slp_find(int *label, int x) { // with path halving (a non-root node is re-pointed at its grandparent: still an ancestor)
     int p = slp_ld(&label[x]);
-    while (p != x) { x = p; p = slp_ld(&label[x]); }
+    while (p != x) {
+        int gp = slp_ld(&label[p]);
+        if (gp != p) atomicCAS(&label[x], p, gp);
+        x = p; p = gp;
+    }
     return x;
 }
 RP_DEV void slp_union(int *label, int a, int b) { // the smaller index becomes the root
