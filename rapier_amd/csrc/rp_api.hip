@@ -1153,7 +1153,7 @@ static int finalize(rp_world *w) {
     d.cb_words = (capb + 31) / 32;
     DA(d.cb_bits, (size_t)128 * d.cb_words); DA(d.cb_prefix, (size_t)128 * d.cb_words);
     DAC(d.b_label, capb, DOM_BODY, 1, 1); DAFC(d.b_island, capb, 0xff, DOM_BODY, 1, 1); DAFC(d.b_local, capb, 0xff, DOM_BODY, 1, 1); DAC(d.r_nb, capb, DOM_BODY, 1, 1); DAC(d.r_nc, capb, DOM_BODY, 1, 1); DAFC(d.r_island, capb, 0xff, DOM_BODY, 1, 1);
-    DAFC(d.p_island, P, 0xff, DOM_PAIR, 1, 1);
+    DAFC(d.p_island, P, 0xff, DOM_PAIR, 1, 1); DA(d.uf_pairs, P);
     DAC(d.isl_body_begin, capb, DOM_BODY, 1, 1); DAC(d.isl_nb, capb, DOM_BODY, 1, 1); DAC(d.isl_cons_begin, capb, DOM_BODY, 1, 1); DAC(d.isl_nc, capb, DOM_BODY, 1, 1); DAC(d.isl_fill_b, capb, DOM_BODY, 1, 1); DAC(d.isl_fill_c, capb, DOM_BODY, 1, 1);
     DAC(d.isl_bodies, capb, DOM_BODY, 1, 1); DAC(d.isl_cons, P, DOM_PAIR, 1, 1); DAC(d.isl_cstage, P, DOM_PAIR, 1, 1); DAC(d.isl_sorted, capb, DOM_BODY, 1, 1); DAC(d.isl_nstages, capb, DOM_BODY, 1, 1);
     DAC(d.isl_cg1, P, DOM_PAIR, 1, 1); DAC(d.isl_cg2, P, DOM_PAIR, 1, 1); DAC(d.isl_cl1, P, DOM_PAIR, 1, 1); DAC(d.isl_cl2, P, DOM_PAIR, 1, 1); DA(d.isl_inc_pos, 2 * P); DAC(d.r_ni, capb, DOM_BODY, 1, 1); DAC(d.isl_ni, capb, DOM_BODY, 1, 1); DAC(d.isl_icons_begin, capb, DOM_BODY, 1, 1); DAC(d.isl_fill_i, capb, DOM_BODY, 1, 1); DAC(d.isl_icons, P, DOM_PAIR, 1, 1); DAC(d.isl_inc_begin, capb, DOM_BODY, 1, 1); DAC(d.isl_inc_cnt, capb, DOM_BODY, 1, 1);

@@ -34,6 +34,7 @@ RP_DEV int uf_find(int *label, int x) {
     }
     return x;
 }
+RP_DEV unsigned uf_priority(int x) { return (unsigned)x * 2654435761u; } // hooking priority: a bijective scramble of the body index (see uf_union)
 RP_DEV bool is_dyn(const DevWorld &w, int b) { return body_active(w, b); } // awake dynamic bodies: the active set
 
 // Lock-free union: a root is hooked under the root of HIGHER priority, retry on races.  The priority is a bijective scramble of the
@@ -41,7 +42,6 @@ RP_DEV bool is_dyn(const DevWorld &w, int b) { return body_active(w, b); } // aw
 // turned every row of b3d_large_pyramid into one 200-link chain (all its hooks succeed at once), which the finds of the same pass
 // then walked at one L2 round trip per link — 330 us of a 510 us layout rebuild.  Random linking keeps the trees O(log n) deep.
 // (Which member ends up as the root is irrelevant here: the labels only name components.)
-RP_DEV unsigned uf_priority(int x) { return (unsigned)x * 2654435761u; }
 RP_DEV void uf_union(int *label, int a, int b) {
     if (ld_i32(&label[a]) == ld_i32(&label[b])) return; // siblings (after compression: most pairs of a big component) — the root's line is not touched
     for (;;) {
@@ -61,15 +61,56 @@ RP_DEV void lay_isl_init(DevWorld &w, int gid, int gstride) {
     for (size_t k = i, n = (size_t)128 * w.cb_words; k < n; k += (size_t)gstride) w.cb_bits[k] = 0u; // owner bitmaps of the colour stages
     for (int b = gid; b < w.n_bodies; b += gstride) { w.b_label[b] = b; w.r_nb[b] = 0; w.r_nc[b] = 0; w.r_ni[b] = 0; w.r_island[b] = -1; w.b_island[b] = -1; w.b_local[b] = -1; }
 }
-// connected components over active pairs whose two sides are dynamic
-RP_DEV void lay_isl_union(DevWorld &w, int gid, int gstride) {
+// the edges of the island graph, compacted (one atomic per wavefront): active pairs whose two sides are awake non-fixed bodies
+RP_DEV void lay_isl_edges(DevWorld &w, int gid, int gstride) {
     int top = w.flags[FL_POOL_TOP];
     if (top > w.pool_cap) top = w.pool_cap;
-    for (int s = gid; s < top; s += gstride) {
-        if (!pair_active(w, s)) continue;
-        int b1 = w.c_parent[w.p_c1[s]], b2 = w.c_parent[w.p_c2[s]];
-        if (is_dyn(w, b1) && is_dyn(w, b2)) uf_union(w.b_label, b1, b2);
+    const int lane = threadIdx.x & 63;
+    for (int base = 0; base < top; base += gstride) { // wave-uniform trip count
+        const int s = base + gid;
+        int2 rb = make_int2(-1, -1);
+        bool edge = false;
+        if (s < top && pair_active(w, s)) { rb = w.p_rb[s]; edge = is_dyn(w, rb.x) && is_dyn(w, rb.y); }
+        const unsigned long long m = __ballot(edge);
+        if (!m) continue;
+        int at = 0;
+        const int leader = __ffsll((long long)m) - 1;
+        if (lane == leader) at = atomicAdd(&w.flags[FL_UF_NPAIRS], __popcll(m));
+        at = __shfl(at, leader, 64);
+        if (edge) w.uf_pairs[at + __popcll(m & ((1ull << lane) - 1ull))] = rb;
     }
+}
+// The components themselves.  Worlds of up to LAY_LDS_BODIES bodies: ONE workgroup runs the whole union-find in LDS (a hop costs ~100
+// cycles there, an L2 round trip ~1,500: the 60 k edges of b3d_large_pyramid's single component took 143 us across the chip) and
+// writes flat labels; larger worlds: every workgroup, in global memory.
+#define LAY_LDS_BODIES 36864
+RP_DEV int lds_find(int *label, int x) {
+    int p = label[x];
+    while (p != x) { int gp = label[p]; if (gp != p) atomicCAS(&label[x], p, gp); x = p; p = gp; }
+    return x;
+}
+RP_DEV void lay_isl_union_lds(DevWorld &w, int *label) { // workgroup 0
+    for (int b = threadIdx.x; b < w.n_bodies; b += blockDim.x) label[b] = b;
+    __syncthreads();
+    const int n = w.flags[FL_UF_NPAIRS];
+    for (int k = threadIdx.x; k < n; k += blockDim.x) {
+        int2 e = w.uf_pairs[k];
+        int a = e.x, b = e.y;
+        if (label[a] == label[b]) continue;
+        for (;;) {
+            a = lds_find(label, a); b = lds_find(label, b);
+            if (a == b) break;
+            if (uf_priority(a) < uf_priority(b)) { int t = a; a = b; b = t; }
+            if (atomicCAS(&label[a], a, b) == a) break;
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < w.n_bodies; b += blockDim.x) w.b_label[b] = lds_find(label, b);
+}
+// connected components over the listed edges (worlds too large for the LDS form)
+RP_DEV void lay_isl_union(DevWorld &w, int gid, int gstride) {
+    const int n = w.flags[FL_UF_NPAIRS];
+    for (int k = gid; k < n; k += gstride) { int2 e = w.uf_pairs[k]; uf_union(w.b_label, e.x, e.y); }
 }
 // flatten the labels; per-root body and manifold counts.  Lanes of a wavefront that name the same root (a giant component: all of them)
 // add through ONE lane: the counts saturate just above the island limits, so what the others would do is a load of one hot line each.
@@ -308,18 +349,20 @@ RP_DEV void lay_rank_overflow(DevWorld &w) { // workgroup 0, after a grid barrie
 // change pays a single early exit instead of nine.
 __global__ void __launch_bounds__(1024) k_layout_rebuild(DevWorld w) {
     if (!w.flags[FL_LAYOUT_DIRTY]) return; // (cleared only after the last barrier: every workgroup reads the same value)
-    __shared__ int lds_a[1024], lds_b[RP_NUM_COLORS], lds_scalar;
+    __shared__ int lds_a[1024], lds_b[RP_NUM_COLORS], lds_scalar, lds_uf[LAY_LDS_BODIES];
     const int gid = gbar_item(), gstride = gridDim.x * blockDim.x;
     GridBar bar = gbar_begin(w, 1);
     RP_PASS_BEGIN();
     if (blockIdx.x == 0) lay_bucket_clear(w);
     lay_isl_init(w, gid, gstride);
+    lay_isl_edges(w, gid, gstride);
     GBAR_SYNC(bar); RP_PASS_STAMP(w, 200);
     lay_bucket_count(w, gid, gstride, lds_a, lds_scalar);
 #ifdef RP_PASS_PROFILE
     GBAR_SYNC(bar); RP_PASS_STAMP(w, 200); // (profiling only: the bucket count apart from the union)
 #endif
-    lay_isl_union(w, gid, gstride);
+    if (w.n_bodies <= LAY_LDS_BODIES) { if (blockIdx.x == 0) lay_isl_union_lds(w, lds_uf); }
+    else lay_isl_union(w, gid, gstride);
     GBAR_SYNC(bar); RP_PASS_STAMP(w, 200);
     lay_isl_count(w, gid, gstride);
     GBAR_SYNC(bar); RP_PASS_STAMP(w, 200);
@@ -336,7 +379,7 @@ __global__ void __launch_bounds__(1024) k_layout_rebuild(DevWorld w) {
     if (blockIdx.x == 0) lay_rank_overflow(w);
     GBAR_SYNC(bar); RP_PASS_STAMP(w, 200);
     gbar_end(bar);
-    if (gid == 0) __hip_atomic_store(&w.flags[FL_LAYOUT_DIRTY], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (gid == 0) { w.flags[FL_UF_NPAIRS] = 0; __hip_atomic_store(&w.flags[FL_LAYOUT_DIRTY], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 }
 
 // ---- register-resident constraint of one island thread ------------------------------------------

@@ -107,6 +107,7 @@ enum {
     FL_BP_SEQ,          // broad-phase passes run so far (stamps c_chgstamp)
     FL_BP_FORCE_FULL,   // scratch of one pass: the incremental update met a case it leaves to the full rebuild
     FL_BP_TOMBS,        // tombstones in the live pair hash table since the last full rebuild
+    FL_UF_NPAIRS,       // scratch of a layout rebuild: active dynamic-dynamic pairs listed for the island union-find (uf_pairs)
     FL_COUNT = 64       // <= 64: publish_flags copies one slot per lane of a wavefront
 };
 
@@ -304,6 +305,7 @@ struct DevWorld {
 
     // ---- contact islands (connected components of dynamic bodies over active manifolds) ----
     int *b_label;               // union-find labels
+    int2 *uf_pairs;             // [pool] scratch: the two bodies of every active pair that links two awake non-fixed bodies
     int *b_island, *b_local;    // island id (>= 0: LDS island path, -1: global path), index inside the island
     int *r_nb, *r_nc, *r_island; // per-root scratch: body count, manifold count, island id
     int *p_island;              // pair slot -> island id or -1
