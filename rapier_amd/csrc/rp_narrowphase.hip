@@ -19,13 +19,38 @@
 
 #define PT(plane, k, s) plane[(size_t)(k) * w.pool_cap + (s)]
 
+// The working manifold of one lane.  Its point arrays are indexed at run time (points are pushed, matched, reduced), which the
+// compiler can only serve from scratch memory: 3.6 KB per lane in round 2, every access a memory round trip — one full update took
+// ~70 us however few pairs a step queued, and the launch wrote ~130 MB of scratch back to HBM.  The arrays now live in LDS:
+// NP_THREADS lanes per workgroup, element k of lane t at [k * NP_THREADS + t] (conflict-free for 4-byte items, 12-byte V3 items
+// step 3 banks per lane).  NP_LDS_DWORDS dwords per lane: region A = the manifold (72), region B = the old ContactData while it is
+// permuted (64), aliased before that by the scratch of try_update_contacts / match_contacts (40).
+#define NP_THREADS 128
+#define NP_LDS_DWORDS 136
+template <typename T> struct LdsCol { T *p; RP_DEV T &operator[](int k) const { return p[k * NP_THREADS]; } };
 struct LocalManifold {
-    V3 lp1[RP_MAX_PTS], lp2[RP_MAX_PTS];
-    float dist[RP_MAX_PTS];
-    unsigned fid[RP_MAX_PTS]; // fid1 | fid2 << 16
-    int src[RP_MAX_PTS];      // old point index whose ContactData this point inherits (-1 = fresh)
+    LdsCol<V3> lp1, lp2;
+    LdsCol<float> dist;
+    LdsCol<unsigned> fid;     // fid1 | fid2 << 16
+    LdsCol<int> src;          // old point index whose ContactData this point inherits (-1 = fresh)
+    // region B: 64 floats per lane, always accessed AS floats (one element type: the two uses below alias in time, and accesses of
+    // different types to one address may be reordered by type-based alias analysis).  Generators: entries 3i..3i+2 = a point, 24 + i = a
+    // distance, 32 + i = an old feature-id word; permutation of the old ContactData: 4k..4k+3 = impulses, 32 + 4k.. = warm-start vector.
+    LdsCol<float> b;
+    RP_DEV void b_set3(int i, V3 v) const { b[3 * i] = v.x; b[3 * i + 1] = v.y; b[3 * i + 2] = v.z; }
+    RP_DEV V3 b_get3(int i) const { return v3(b[3 * i], b[3 * i + 1], b[3 * i + 2]); }
+    RP_DEV void b_set4(int e, float4 v) const { b[e] = v.x; b[e + 1] = v.y; b[e + 2] = v.z; b[e + 3] = v.w; }
+    RP_DEV float4 b_get4(int e) const { return make_float4(b[e], b[e + 1], b[e + 2], b[e + 3]); }
+    RP_DEV void old_fid_set(int i, unsigned f) const { b[32 + i] = __uint_as_float(f); }
+    RP_DEV unsigned old_fid(int i) const { return __float_as_uint(b[32 + i]); }
     int n;
     V3 ln1, ln2;
+    RP_DEV void bind(float *lds) { // lds = this workgroup's NP_THREADS * NP_LDS_DWORDS floats
+        float *a = lds, *b = lds + NP_THREADS * 72; // (local `b` = region B's base)
+        lp1.p = (V3 *)a + threadIdx.x; lp2.p = (V3 *)(a + NP_THREADS * 24) + threadIdx.x;
+        dist.p = a + NP_THREADS * 48 + threadIdx.x; fid.p = (unsigned *)(a + NP_THREADS * 56) + threadIdx.x; src.p = (int *)(a + NP_THREADS * 64) + threadIdx.x;
+        this->b.p = b + threadIdx.x;
+    }
 };
 
 struct Face { V3 v[4]; unsigned vid[4], eid[4], fid; };
@@ -194,16 +219,15 @@ __device__ bool try_update_contacts(LocalManifold &m, Pose pos12) {
     if (m.n == 0) return false;
     V3 ln2 = qrot(pos12.r, m.ln2);
     if (-dot(m.ln1, ln2) < 0.99984769515f) return false;
-    V3 nlp1[RP_MAX_PTS]; float nd[RP_MAX_PTS];
     for (int i = 0; i < m.n; ++i) {
         V3 lp2 = pose_tp(pos12, m.lp2[i]);
         float dist = dot(lp2 - m.lp1[i], m.ln1);
         if (dist * m.dist[i] < 0.0f) return false;
         V3 np1 = lp2 - m.ln1 * dist;
         if (len2(m.lp1[i] - np1) > 1.0e-6f) return false;
-        nlp1[i] = np1; nd[i] = dist;
+        m.b_set3(i, np1); m.b[24 + i] = dist;
     }
-    for (int i = 0; i < m.n; ++i) { m.lp1[i] = nlp1[i]; m.dist[i] = nd[i]; }
+    for (int i = 0; i < m.n; ++i) { m.lp1[i] = m.b_get3(i); m.dist[i] = m.b[24 + i]; }
     return true;
 }
 
@@ -224,15 +248,15 @@ __device__ void manifold_cuboid_cuboid(Pose pos12, V3 he1, V3 he2, float predict
     Face f1 = cuboid_support_face(he1, best);
     Face f2 = cuboid_support_face(he2, ln2);
     for (int i = 0; i < 4; ++i) f2.v[i] = pose_tp(pos12, f2.v[i]);
-    unsigned oldfid[RP_MAX_PTS]; int nold = m.n;
-    for (int i = 0; i < nold; ++i) oldfid[i] = m.fid[i];
+    int nold = m.n;
+    for (int i = 0; i < nold; ++i) m.old_fid_set(i, m.fid[i]);
     m.n = 0;
     contacts_face_face(pos12, f1, best, f2, m);
     m.ln1 = best; m.ln2 = ln2;
     // match_contacts: inherit tracked data by (fid1, fid2); the LAST matching old point wins
     for (int i = 0; i < m.n; ++i)
         for (int j = 0; j < nold; ++j)
-            if (m.fid[i] == oldfid[j]) m.src[i] = j;
+            if (m.fid[i] == m.old_fid(j)) m.src[i] = j;
 }
 
 __device__ void manifold_ball_ball(Pose pos12, float r1, float r2, float prediction, LocalManifold &m) {
@@ -369,8 +393,8 @@ __device__ void manifold_halfspace_pfm(Pose pos12, V3 normal1, int sh2, float4 c
         for (int i = 0; i < 4; ++i) { vtx[i] = f.v[i]; vid[i] = f.vid[i]; }
         nv = 4;
     }
-    unsigned oldfid[RP_MAX_PTS]; int nold = m.n;
-    for (int i = 0; i < nold; ++i) oldfid[i] = m.fid[i];
+    int nold = m.n;
+    for (int i = 0; i < nold; ++i) m.old_fid_set(i, m.fid[i]);
     m.n = 0;
     for (int i = 0; i < nv; ++i) {
         V3 vtx2_1 = pose_tp(pos12, vtx[i]);
@@ -385,7 +409,7 @@ __device__ void manifold_halfspace_pfm(Pose pos12, V3 normal1, int sh2, float4 c
     if (flipped) { m.ln1 = -normal1_2; m.ln2 = normal1; } else { m.ln1 = normal1; m.ln2 = -normal1_2; }
     for (int i = 0; i < m.n; ++i)
         for (int j = 0; j < nold; ++j)
-            if (m.fid[i] == oldfid[j]) m.src[i] = j;
+            if (m.fid[i] == m.old_fid(j)) m.src[i] = j;
 }
 // sat::cuboid_support_map_find_local_separating_normal_oneway with shape2 = the segment [a2, b2] (cuboid frame)
 __device__ float sat_cuboid_segment_normal_oneway(V3 he1, V3 a2, V3 b2, V3 &out_dir) {
@@ -442,8 +466,8 @@ __device__ void manifold_cuboid_capsule(Pose pos12, Pose upd, V3 he1, float4 c2,
     V3 best = s3 > s1 ? d3 : d1;
     V3 n2 = qrot(pos21.r, -best);
     Face f1 = cuboid_support_face(he1, best);
-    unsigned oldfid[RP_MAX_PTS]; int nold = m.n;
-    for (int i = 0; i < nold; ++i) oldfid[i] = m.fid[i];
+    int nold = m.n;
+    for (int i = 0; i < nold; ++i) m.old_fid_set(i, m.fid[i]);
     m.n = 0;
     V3 bx, by; orthonormal_basis(best, bx, by);
     float p1x[4], p1y[4];
@@ -487,7 +511,7 @@ __device__ void manifold_cuboid_capsule(Pose pos12, Pose upd, V3 he1, float4 c2,
     if (flipped) { m.ln1 = n2; m.ln2 = best; } else { m.ln1 = best; m.ln2 = n2; }
     for (int i = 0; i < m.n; ++i)
         for (int j = 0; j < nold; ++j)
-            if (m.fid[i] == oldfid[j]) m.src[i] = j;
+            if (m.fid[i] == m.old_fid(j)) m.src[i] = j;
 }
 #undef PERP
 
@@ -603,7 +627,7 @@ __device__ __noinline__ bool shapes_intersect(int s1, float4 h1, int s2, float4 
 
 // A sensor pair lives in the intersection graph (narrow_phase/intersections.rs:17-175): no manifold, no solver contact, no colour, no
 // wake-up; it is re-tested while one of its bodies may have moved and raises Started / Stopped | SENSOR on a change.
-__device__ __noinline__ void sensor_pair_update(DevWorld &w, int s, int c1, int c2, Pose pos12) {
+__device__ __forceinline__ void sensor_pair_update(DevWorld &w, int s, int c1, int c2, Pose pos12) {
     const int rb1 = w.c_parent[c1], rb2 = w.c_parent[c2];
     int pf = w.p_pflags[s] & ~RP_PF_RECYCLE;
     const bool had_i = (pf & RP_PF_INTERSECTING) != 0;
@@ -617,7 +641,7 @@ __device__ __noinline__ void sensor_pair_update(DevWorld &w, int s, int c1, int 
 }
 
 // The full narrow-phase update of one pair (pair_update.rs:173-613).
-__device__ __noinline__ void pair_full_update(DevWorld &w, int s, int c1, int c2, Pose pc1, Pose pc2, Pose pos12) {
+__device__ __forceinline__ void pair_full_update(DevWorld &w, int s, int c1, int c2, Pose pc1, Pose pc2, Pose pos12, float *np_lds) {
     const float prediction = w.prm.prediction;
     int rb1 = w.c_parent[c1], rb2 = w.c_parent[c2];
     int sh1 = w.c_shape[c1], sh2 = w.c_shape[c2];
@@ -627,6 +651,7 @@ __device__ __noinline__ void pair_full_update(DevWorld &w, int s, int c1, int c2
     const bool no_contact = joints_disable_contacts(w, rb1, rb2); // pair_update.rs:191-201: clear_filtered_pair
 
     LocalManifold m;
+    m.bind(np_lds);
     m.n = w.p_npts[s];
     m.ln1 = v3(w.p_ln1[s]); m.ln2 = v3(w.p_ln2[s]);
     for (int k = 0; k < m.n; ++k) {
@@ -653,19 +678,15 @@ __device__ __noinline__ void pair_full_update(DevWorld &w, int s, int c1, int c2
     else manifold_cuboid_ball(pose_inv(pos12), v3(he2), he1.x, prediction, m, true);
 
     // carry ContactData (impulse, warm starts) to the new point order
-    float4 oimp[RP_MAX_PTS], owst[RP_MAX_PTS];
-    for (int k = 0; k < nold; ++k) { oimp[k] = PT(w.pt_imp, k, s); owst[k] = PT(w.pt_wst, k, s); }
-    float impulse_of[RP_MAX_PTS];
+    for (int k = 0; k < nold; ++k) { m.b_set4(4 * k, PT(w.pt_imp, k, s)); m.b_set4(32 + 4 * k, PT(w.pt_wst, k, s)); }
     for (int k = 0; k < m.n; ++k) {
         int j = m.src[k];
-        float4 im = j >= 0 ? oimp[j] : make_float4(0, 0, 0, 0);
-        float4 ws = j >= 0 ? owst[j] : make_float4(0, 0, 0, 0);
+        float4 im = j >= 0 ? m.b_get4(4 * j) : make_float4(0, 0, 0, 0);
+        float4 ws = j >= 0 ? m.b_get4(32 + 4 * j) : make_float4(0, 0, 0, 0);
         PT(w.pt_imp, k, s) = im; PT(w.pt_wst, k, s) = ws;
         PT(w.pt_lp1d, k, s) = f4(m.lp1[k], m.dist[k]);
         PT(w.pt_lp2f, k, s) = f4(m.lp2[k], __uint_as_float(m.fid[k]));
-        impulse_of[k] = im.x;
     }
-    (void)impulse_of;
     w.p_npts[s] = m.n;
     w.p_ln1[s] = f4(m.ln1, 0.0f); w.p_ln2[s] = f4(m.ln2, 0.0f);
 
@@ -818,7 +839,8 @@ __global__ void k_np_test(DevWorld w) {
         w.np_list[atomicAdd(&w.flags[FL_NP_COUNT], 1)] = s;
     }
 }
-__global__ void k_np_update(DevWorld w) {
+__global__ void __launch_bounds__(NP_THREADS) k_np_update(DevWorld w) {
+    __shared__ __align__(16) float np_lds[NP_THREADS * NP_LDS_DWORDS];
     int count = w.flags[FL_NP_COUNT];
     if (count > w.pool_cap) count = w.pool_cap;
     int stride = gridDim.x * blockDim.x;
@@ -829,7 +851,7 @@ __global__ void k_np_update(DevWorld w) {
         pc1.r = q4(w.c_rot[c1]); pc1.t = v3(w.c_pos[c1]);
         pc2.r = q4(w.c_rot[c2]); pc2.t = v3(w.c_pos[c2]);
         Pose pos12 = pose_inv_mul(pc1, pc2);
-        pair_full_update(w, s, c1, c2, pc1, pc2, pos12);
+        pair_full_update(w, s, c1, c2, pc1, pc2, pos12, np_lds);
     }
 }
 
@@ -1057,7 +1079,7 @@ void rp_launch_narrowphase_part(const DevWorld &w, hipStream_t st, int part) {
             // even when the queue is empty (measured: 341 -> 256 workgroups = 140 -> 130 us per full step on b3d_many_pyramids)
             // (sizing this grid from the recent queue lengths was measured: 5-10 us per full step, paid for with a ~10 ms re-capture of
             // the step graphs whenever the size changed — not kept)
-            hipLaunchKernelGGL(k_np_update, dim3(blocks < 256 ? blocks : 256), dim3(256), 0, st, w);
+            { int nb = (w.pool_cap + NP_THREADS - 1) / NP_THREADS; hipLaunchKernelGGL(k_np_update, dim3(nb < 512 ? nb : 512), dim3(NP_THREADS), 0, st, w); } // 2 workgroups per CU (70 KB of LDS each)
             hipLaunchKernelGGL(k_color_pairs, dim3(1), dim3(1024), 0, st, w);
         }
         rp_launch_wake(w, st, 1); // begin-touch wake-ups (contacts.rs:333-351)
