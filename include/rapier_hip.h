@@ -86,6 +86,9 @@ typedef struct rp_body_desc {
     int32_t additional_solver_iterations; /* RigidBodyBuilder::additional_solver_iterations (rigid_body.rs): extra TGS substeps for the body's
                                            * whole connected component (island_manager/substep_groups.rs:44-229); at most 15 distinct
                                            * positive values per world.  Worlds that use it are solved by one workgroup. */
+    int32_t ccd_enabled; /* RigidBodyBuilder::ccd_enabled (rigid_body.rs): 1 = a "bullet" whose continuous-collision sweep also meets kinematic
+                          * and dynamic bodies (dynamics/ccd/sweeps.rs:22-41).  Every fast dynamic body sweeps the FIXED colliders
+                          * whatever this flag says, unless IntegrationParameters::max_ccd_substeps = 0 (ccd_solver.rs:17-25). */
 } rp_body_desc;
 
 /* ColliderBuilder — /root/reference/src/geometry/collider.rs:600-1130 */
@@ -175,8 +178,8 @@ typedef struct rp_counters {
     int32_t replayed_steps;        /* fast steps that gave up on the device and were replayed on the full path */
     int32_t num_sleeping_bodies;   /* dynamic bodies asleep (IslandManager: bodies outside the active set) */
     int32_t ccd_active_count;      /* (body, step) occurrences so far of RigidBodyCcd::is_moving_fast_with_next_position (worker.rs:845-865):
-                                    * steps in which the reference would have run its continuous-collision pass on a body.  This library
-                                    * does not sweep (ccd_solver.rs is out of scope): 0 means the absence made no difference */
+                                    * the bodies the continuous-collision pass looked at (full steps) */
+    int32_t ccd_clamp_count;       /* (body, step) cases in which CCDSolver::solve_continuous clamped next_position to a time of impact */
 } rp_counters;
 
 #define RP_INVALID_HANDLE 0xffffffffffffffffull

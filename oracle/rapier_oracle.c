@@ -26,6 +26,7 @@
  */
 #include "rapier_oracle.h"
 #include "ro_shapes.h"
+#include "ro_ccd.h"
 /* Optional OpenMP (bench.py's cpu_baseline leg): loops over items that touch pairwise-disjoint state
  * — the pairs of the narrow phase, the bodies, the constraints of one colour (the reference runs
  * exactly these loops on its rayon pool, staged_island_solver/worker.rs) — are parallel; the colour
@@ -76,6 +77,8 @@ typedef struct {
     int slept_at;       /* step at which the body last fell asleep (pair hints cleared then) */
     int island_id;      /* RigidBodyIds::island_id: persistent island of a non-fixed body, -1 = INVALID_ISLAND */
     int wake_req;       /* pending IslandManager::wake_up */
+    /* RigidBodyCcd — rigid_body_components.rs:1170-1230 */
+    int ccd_enabled, ccd_active; float ccd_thickness;
     int additional_solver_iterations; /* RigidBody::additional_solver_iterations — extra substeps for the body's whole component */
     int last_group_extra;             /* extra substeps of the solve group the body was in during the last step (-1: not in the active set) */
 } Body;
@@ -209,6 +212,7 @@ struct ro_world {
     int pending_split;  /* split_island: the candidate chosen last step, -1 = None */
     struct Removal *journal; int njournal, cap_journal; /* removal_journal */
     int32_t pi_stats[RO_ISLAND_STATS];
+    int32_t ccd_active_count, ccd_clamp_count; /* (body, step) cases of the fast-body criterion / of a clamped next_position */
     int nfree_colliders; /* colliders inserted without a parent */
     uint64_t *nc_keys; int n_nc, nc_dirty; /* sorted (min body, max body) keys of the joints with contacts_enabled = false */
     int32_t *col_events; int ncol_events, cap_col_events;       /* 5 ints per event */
@@ -574,6 +578,15 @@ static void recompute_mass_properties(ro_world *w, Body *b) {
         float radius = shape_bounding_radius(c);
         float extent = vlen(vsub(c->pos_wrt_parent.t, b->local_com)) + radius;
         b->max_extent = ro_maxf(b->max_extent, extent);
+    }
+    /* RigidBodyCcd::ccd_thickness (rigid_body_components.rs:1227): the thinnest attached shape (Shape::ccd_thickness: ball radius,
+     * smallest cuboid half extent, capsule radius; a half-space has none), Real::MAX without colliders */
+    b->ccd_thickness = FLT_MAX;
+    for (int i = 0; i < w->ncolliders; ++i) {
+        const Collider *c = &w->colliders[i];
+        if (c->parent != body || !collider_enabled(c) || c->shape == RO_SHAPE_HALFSPACE) continue;
+        float th = c->shape == RO_SHAPE_BALL ? c->radius : c->shape == RO_SHAPE_CAPSULE ? c->radius : ro_minf(c->he.x, ro_minf(c->he.y, c->he.z));
+        b->ccd_thickness = ro_minf(b->ccd_thickness, th);
     }
     b->inv_mass = ro_inv(acc.mass);
     b->inv_principal_inertia = V3(ro_inv(acc.pi[0]), ro_inv(acc.pi[1]), ro_inv(acc.pi[2]));
@@ -2583,7 +2596,65 @@ static void solve_velocity_constraints(ro_world *w) {
         /* pose.prepend_translation(-local_com) */
         rb->next_position.r = sp.r;
         rb->next_position.t = vadd(sp.t, qrot(sp.r, vneg(rb->local_com)));
+        /* CCD activation (worker.rs:845-865): RigidBodyCcd::is_moving_fast_with_next_position (rigid_body_components.rs:1131-1157) with
+         * ccd_vels = interpolate_velocity(inv_dt) of the solved motion; dynamic bodies only (ccd_solver.rs:66) */
+        rb->ccd_active = 0;
+        if (prm->max_ccd_substeps != 0 && rb->body_type == RO_BODY_DYNAMIC && rb->ccd_thickness < 3.0e38f) {
+            v3 dcom = vsub(sp.t, rb->world_com);
+            quat dq = qmul(sp.r, qconj(rb->position.r));
+            v3 dv = V3(dq.x, dq.y, dq.z);
+            float inv_dt = prm->dt == 0.0f ? 0.0f : 1.0f / prm->dt;
+            float max_delta = vlen(dcom) + 2.0f * vlen(dv) * rb->max_extent;
+            float max_vel = vlen(vmul(dcom, inv_dt)) + vlen(vmul(quat_to_scaled_axis(dq), inv_dt)) * rb->max_extent;
+            float max_motion = ro_maxf(max_delta, max_vel * prm->dt);
+            if (max_motion > 0.5f * rb->ccd_thickness) { rb->ccd_active = 1; w->ccd_active_count++; }
+        }
     }
+}
+
+/* ---- CCDSolver::solve_continuous — dynamics/ccd/ccd_solver.rs:158-340, sweeps.rs:470-640 (the time-of-impact query itself: ro_ccd.h) ----
+ * Fast non-bullet bodies sweep the FIXED colliders (parentless or on a fixed body), then bullets (ccd_enabled) sweep every collider
+ * that is not on a bullet, targets standing at their — possibly just clamped — next_position; the earliest solid impact clamps the
+ * body's next_position (apply_clamps :325-339), velocities are untouched.  Sensors and colliders whose groups do not match never
+ * stop a body (the paired intersection events of sensor crossings, :265-320, are not raised). */
+static CcdShape ccd_shape_of(const Collider *c) { CcdShape s; s.shape = c->shape; s.he = c->he; s.radius = c->radius; s.axis = c->axis; return s; }
+static int ccd_is_bullet(const Body *b) { return b->body_type == RO_BODY_DYNAMIC && b->ccd_enabled; } /* sweeps.rs:29-31 */
+static void ccd_sweep_tier(ro_world *w, int bullets) {
+    const float slop = w->params.normalized_allowed_linear_error * w->params.length_unit; /* IntegrationParameters::allowed_linear_error */
+    for (int bi = 0; bi < w->nbodies; ++bi) {
+        Body *rb1 = &w->bodies[bi];
+        if (!rb1->ccd_active || rb1->sleeping || ccd_is_bullet(rb1) != bullets) continue;
+        CcdSweep sw = ccd_sweep_from_poses(rb1->position, rb1->next_position, rb1->local_com);
+        float fraction = 1.0f;
+        for (int f = 0; f < w->ncolliders; ++f) {
+            const Collider *co1 = &w->colliders[f];
+            if (co1->parent != bi || !collider_enabled(co1) || co1->sensor) continue;
+            CcdShape s2 = ccd_shape_of(co1);
+            const float rot_radius = ccd_rot_radius(&s2, co1->pos_wrt_parent, rb1->local_com);
+            for (int t = 0; t < w->ncolliders; ++t) {
+                const Collider *co2 = &w->colliders[t];
+                if (t == f || co2->parent == bi || !collider_enabled(co2) || co2->sensor) continue;
+                const Body *rb2 = co2->parent >= 0 ? &w->bodies[co2->parent] : NULL;
+                /* tier_allows (sweeps.rs:35-41): a non-bullet only meets fixed targets, a bullet everything but bullets */
+                if (bullets) { if (rb2 && ccd_is_bullet(rb2)) continue; } else if (rb2 && rb2->body_type != RO_BODY_FIXED) continue;
+                if (!((co1->memberships & co2->filter) != 0 && (co2->memberships & co1->filter) != 0)) continue; /* collision_groups.test */
+                /* target_collider_pose (:97-102): stationary at its end-of-step pose */
+                pose tp = (rb2 && rb2->body_type != RO_BODY_FIXED) ? pose_mul(rb2->next_position, co2->pos_wrt_parent) : co2->pos;
+                if (co2->shape != RO_SHAPE_HALFSPACE && !ccd_may_reach(sw.c0, sw.c1, rb1->max_extent, tp.t, shape_bounding_radius(co2), 2.0f * slop)) continue;
+                CcdShape s1 = ccd_shape_of(co2);
+                float hit = ccd_cast_pair(&s1, tp, &s2, co1->pos_wrt_parent, &sw, rot_radius, fraction, slop);
+                if (hit > 0.0f && hit < fraction) fraction = hit;
+            }
+        }
+        if (fraction < 1.0f) { rb1->next_position = ccd_sweep_transform_at(&sw, fraction); w->ccd_clamp_count++; }
+    }
+}
+static void ccd_solve_continuous(ro_world *w) {
+    int any = 0;
+    for (int i = 0; i < w->nbodies && !any; ++i) any = w->bodies[i].ccd_active;
+    if (!any) return;
+    ccd_sweep_tier(w, 0);
+    ccd_sweep_tier(w, 1);
 }
 
 /* ---- Persistent islands: connectivity maintenance — island_manager/{persistent,local_split,global_split}.rs ------------------
@@ -2913,6 +2984,9 @@ void ro_read_island_state(const ro_world *w, int32_t island, int32_t out5[5]) {
     out5[0] = i->used; out5[1] = i->nbodies; out5[2] = i->dirty; out5[3] = i->denied; out5[4] = i->sleeping;
 }
 void ro_read_island_globals(const ro_world *w, int32_t out2[2]) { out2[0] = w->scan_stamp; out2[1] = w->pending_split; }
+/* RigidBodyBuilder::ccd_enabled / RigidBody::enable_ccd: the body becomes a bullet (sweeps.rs:29-31) */
+void ro_set_ccd_enabled(ro_world *w, int32_t body, int32_t on) { if (body >= 0 && body < w->nbodies) w->bodies[body].ccd_enabled = on != 0; }
+void ro_read_ccd_counts(const ro_world *w, int32_t out2[2]) { out2[0] = w->ccd_active_count; out2[1] = w->ccd_clamp_count; }
 void ro_read_island_stats(const ro_world *w, int32_t *out) { memcpy(out, w->pi_stats, sizeof(w->pi_stats)); }
 void ro_read_slept_at(const ro_world *w, int32_t *out) { for (int i = 0; i < w->nbodies; ++i) out[i] = w->bodies[i].slept_at; }
 
@@ -2952,6 +3026,8 @@ static void step_once(ro_world *w) {
     }
     solve_velocity_constraints(w);
     emit_contact_force_events(w);
+    /* run_ccd_motion_clamping (substep.rs:54-82, :496-519): only when some body moved fast */
+    if (w->params.max_ccd_substeps != 0) ccd_solve_continuous(w);
     /* advance_to_final_positions — substep.rs:84-224; refresh_moved_collider_aabbs :229-240 */
     for (int i = 0; i < w->nbodies; ++i) {
         Body *b = &w->bodies[i];

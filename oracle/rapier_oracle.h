@@ -158,6 +158,10 @@ void ro_read_island_globals(const ro_world *w, int32_t out2[2]);
 /* the step each body last fell asleep at (0 = never) and the step of each pair's last full narrow-phase update: per-step trace
  * material for bisecting against bench/rapier_ref --dump */
 void ro_read_slept_at(const ro_world *w, int32_t *out);
+/* RigidBodyBuilder::ccd_enabled (the body sweeps kinematic / dynamic targets too: a "bullet", dynamics/ccd/sweeps.rs:29-41) and the
+ * counters of the continuous pass: (body, step) cases of the fast-body criterion, clamped next_positions */
+void ro_set_ccd_enabled(ro_world *w, int32_t body, int32_t on);
+void ro_read_ccd_counts(const ro_world *w, int32_t out2[2]);
 int32_t ro_num_joints(const ro_world *w);
 void ro_read_joints(const ro_world *w, int32_t *color, float *impulses3);
 void ro_step(ro_world *w, int32_t nsteps);

@@ -66,6 +66,7 @@ void rp_launch_sleep_fast(const DevWorld &w, hipStream_t st);
 void rp_launch_sensor_fast(const DevWorld &w, hipStream_t st);
 void rp_launch_clear_no_contact(const DevWorld &w, hipStream_t st);
 void rp_launch_global_flow(const DevWorld &w, hipStream_t st, int grid, int has_restitution);
+void rp_launch_ccd(const DevWorld &w, hipStream_t st, int has_bullets);
 void rp_launch_pi_ensure(const DevWorld &w, hipStream_t st, int first, int count, int reset);
 void rp_launch_pi_remove_body(const DevWorld &w, hipStream_t st, int b);
 void rp_launch_pj_append_joint(const DevWorld &w, hipStream_t st, int dev_joint, int b1, int b2, int key);
@@ -150,6 +151,8 @@ struct rp_world {
     bool force_flow = false;
     int flow_grid = 0;             // workgroups of the dataflow launch (all resident at once), 0 = unavailable
     int fused_grid = 0;            // most workgroups a fused fast step may use (all resident at once), 0 = no fused step on this device
+    bool has_bullets = false;      // some dynamic body has ccd_enabled: the continuous-collision pass runs its second tier
+    float min_ccd_thickness = 3.402823466e+38f; // thinnest dynamic body (the fused single-kernel step needs it above the fat-AABB margin)
     bool compound = false;         // some dynamic body carries several colliders or an offset collider (no fused fast step)
     bool timed_ready[2] = {false, false};
     int cur_fast = 0;              // mode the enqueue_* callbacks capture
@@ -185,6 +188,7 @@ static bool world_sleep_enabled(const rp_world *w);
 static bool world_has_kinematic_pos(const rp_world *w);
 static bool world_has_force_events(const rp_world *w);
 static bool world_has_sensors(const rp_world *w);
+static void refresh_ccd_facts(rp_world *w);
 static bool world_has_compound_bodies(const rp_world *w);
 static std::vector<unsigned long long> no_contact_keys(const rp_world *w);
 static int check_sleep_scope(rp_world *w);
@@ -772,7 +776,7 @@ extern "C" int32_t rp_bodies_insert(rp_world *w, int32_t n, const rp_body_desc *
         w->dw.sleep_enabled = world_sleep_enabled(w) ? 1 : 0;
         // persistent islands: ensure_body for the new rows; a world that becomes sleep-enabled now bootstraps its islands
         if (w->dw.sleep_enabled) rp_launch_pi_ensure(w->dw, w->stream, was_sleep_enabled ? first_new : 0, was_sleep_enabled ? n : w->dw.n_bodies, was_sleep_enabled ? 0 : 1);
-        w->dw.has_kinematic_pos = world_has_kinematic_pos(w) ? 1 : 0;
+        w->dw.has_kinematic_pos = world_has_kinematic_pos(w) ? 1 : 0; refresh_ccd_facts(w);
         HIPCHK(w, hipStreamSynchronize(w->stream));
         { int r = upload_group_table(w); if (r != RP_OK) return r; }
         destroy_graphs(w); // kernel arguments (DevWorld by value) hold the body count
@@ -829,7 +833,7 @@ extern "C" int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider
         w->dw.n_colliders = (int)w->colliders.size();
         w->dw.has_force_events = world_has_force_events(w) ? 1 : 0;
         w->dw.has_sensors = world_has_sensors(w) ? 1 : 0;
-        w->compound = world_has_compound_bodies(w);
+        w->compound = world_has_compound_bodies(w); refresh_ccd_facts(w);
         HIPCHK(w, hipStreamSynchronize(w->stream));
         destroy_graphs(w);
         return after_topology_edit(w);
@@ -905,6 +909,7 @@ static BodyRow pack_body(const HostBody &b) {
     fl |= ((int)(bd.dominance & 0xff)) << RP_BF_DOM_SHIFT;
     fl |= ((int)(bd.locked_axes & 0x3fu)) << RP_BF_LOCK_SHIFT;
     if (b.sleeping && !b.removed && bd.body_type != RP_BODY_FIXED) fl |= RP_BF_SLEEPING;
+    if (bd.ccd_enabled && bd.body_type == RP_BODY_DYNAMIC && !b.removed) fl |= RP_BF_CCD_ENABLED; // a bullet (sweeps.rs:29-31)
     o.fl = fl;
     // RigidBodyActivation::active() / cannot_sleep() — rigid_body_components.rs:1354-1385
     o.slp = mk4(b.sleep_timer, bd.can_sleep ? 0.05f : -1.0f, bd.can_sleep ? 0.5f : -1.0f, 0.5f);
@@ -990,6 +995,15 @@ static bool world_sleep_enabled(const rp_world *w) {
         if (b.d.body_type == RP_BODY_KINEMATIC_POSITION || b.d.body_type == RP_BODY_KINEMATIC_VELOCITY) return true;
     }
     return false;
+}
+// continuous-collision facts of the world: any bullet (a dynamic body with ccd_enabled), the thinnest dynamic body
+static void refresh_ccd_facts(rp_world *w) {
+    w->has_bullets = false; w->min_ccd_thickness = 3.402823466e+38f;
+    for (const HostBody &b : w->bodies) {
+        if (b.removed || b.quarantined || b.d.body_type != RP_BODY_DYNAMIC) continue;
+        if (b.d.ccd_enabled) w->has_bullets = true;
+        w->min_ccd_thickness = std::min(w->min_ccd_thickness, b.ccd_thickness);
+    }
 }
 static bool world_has_sensors(const rp_world *w) {
     for (size_t i = 0; i < w->colliders.size(); ++i) if (!w->collider_removed[i] && w->colliders[i].sensor) return true;
@@ -1082,7 +1096,7 @@ static int finalize(rp_world *w) {
     d.gbar_blocks = gbar_grid_for_device(w->device);
     { const char *ni = getenv("RP_NO_BP_INCR"); d.bp_incremental = (ni && ni[0] == '1') ? 0 : 1; }
     { const char *ig = getenv("RP_ISL_GENERIC"); d.isl_generic = (ig && ig[0] == '1') ? 1 : 0; }
-    w->compound = world_has_compound_bodies(w);
+    w->compound = world_has_compound_bodies(w); refresh_ccd_facts(w);
     int nb = (int)w->bodies.size(), nc = (int)w->colliders.size();
     d.n_bodies = nb; d.n_colliders = nc;
     // capacities leave room for bodies / colliders inserted later without rebuilding the device world
@@ -1118,6 +1132,7 @@ static int finalize(rp_world *w) {
     DAC(d.b_pos, capb, DOM_BODY, 1, 1); DAC(d.b_rot, capb, DOM_BODY, 1, 1); DAC(d.b_linvel, capb, DOM_BODY, 1, 1); DAC(d.b_angvel, capb, DOM_BODY, 1, 1); DA(d.b_lcom_invm, capb); DA(d.b_invpi, capb);
     DA(d.b_pframe, capb); DAC(d.b_wcom, capb, DOM_BODY, 1, 1); DAC(d.b_eim, capb, DOM_BODY, 1, 1); DAC(d.b_eii0, capb, DOM_BODY, 1, 1); DAC(d.b_eii1, capb, DOM_BODY, 1, 1); DAC(d.b_damp, capb, DOM_BODY, 1, 1);
     DAC(d.b_uforce, capb, DOM_BODY, 1, 1); DAC(d.b_utorque, capb, DOM_BODY, 1, 1); DAC(d.b_flags, capb, DOM_BODY, 1, 1); DAC(d.b_quar, capb, DOM_BODY, 1, 1); DAF(d.b_collider, capb, 0xff);
+    DA(d.b_ccd0_pos, capb); DA(d.b_ccd0_rot, capb); DA(d.ccd_list, capb); // continuous-collision pass: scratch of one step
     DAC(d.b_sleep, capb, DOM_BODY, 1, 1); DA(d.b_sprev_t, capb); DAC(d.b_sprev_r, capb, DOM_BODY, 1, 1); DAC(d.b_slabel, capb, DOM_BODY, 1, 1); DAC(d.b_slept_at, capb, DOM_BODY, 1, 1); DA(d.b_sleep_stamp, capb); DAC(d.b_wake_req, capb, DOM_BODY, 1, 1);
     DAC(d.lab_wake, capb, DOM_BODY, 1, 1); DAC(d.lab_awake, capb, DOM_BODY, 1, 1); DAC(d.b_next_pos, capb, DOM_BODY, 1, 1); DAC(d.b_next_rot, capb, DOM_BODY, 1, 1);
     // persistent islands (rp_sleep.hip): ids per body, the island table (index = island id < bodies), scratch of a maintenance pass
@@ -1348,6 +1363,7 @@ static void enqueue_global_solver(rp_world *w) {
 static void enqueue_solver(rp_world *w) { enqueue_island_solver(w); enqueue_global_solver(w); }
 static void enqueue_finish(rp_world *w) {
     // the scalars reach the mapped hint buffer from the device: k_island_solve (SINGLE) / k_publish (MULTI)
+    if (!w->cur_fast) rp_launch_ccd(w->dw, w->stream, w->has_bullets ? 1 : 0); // run_ccd_motion_clamping (substep.rs:496-519): fast bodies are swept on full steps
     rp_launch_force_events(w->dw, w->stream, w->cur_fast); // contact force events of the step that just retired
 }
 
@@ -1370,7 +1386,10 @@ static void plan_from_hints(rp_world *w, const int *fl) {
     // (contact-force events are evaluated by a kernel of their own after every step: such worlds take the two-kernel fast graph)
     // (... and so do sleep-enabled worlds: their sleep observation is a pass of its own)
     // (... and so do the worlds whose islands run on k_island_generic: FrictionModel::Coulomb)
-    w->plan_fused = (w->use_fused && w->fused_grid > 0 && !w->compound && w->params.friction_model != RP_FRICTION_COULOMB && !w->dw.isl_generic && !w->dw.has_force_events && !w->dw.sleep_enabled && !w->dw.has_sensors && w->plan_no_global && w->plan_single && fl[FL_N_ISLANDS] > 0) ? 1 : 0;
+    // (a body thinner than ~3.5 x the fat-AABB margin could move half its thickness — the CCD criterion — without leaving its fat AABB,
+    // i.e. without the fused step noticing: such worlds take the fast graph, whose front kernel predicts the criterion)
+    const bool ccd_safe = w->params.max_ccd_substeps == 0 || w->min_ccd_thickness >= 0.14f * w->params.length_unit;
+    w->plan_fused = (ccd_safe && w->use_fused && w->fused_grid > 0 && !w->compound && w->params.friction_model != RP_FRICTION_COULOMB && !w->dw.isl_generic && !w->dw.has_force_events && !w->dw.sleep_enabled && !w->dw.has_sensors && w->plan_no_global && w->plan_single && fl[FL_N_ISLANDS] > 0) ? 1 : 0;
 }
 
 static int capture(rp_world *w, hipGraph_t *g, hipGraphExec_t *ge, void (*fn)(rp_world *)) {
@@ -2287,7 +2306,7 @@ extern "C" int32_t rp_counters_read(rp_world *w, rp_counters *out) {
     out->full_updates = fl[FL_FULL_UPDATES];
     out->overflow_flags = fl[FL_OVERFLOW];
     out->quarantined = fl[FL_QUARANTINE];
-    out->ccd_active_count = fl[FL_CCD_ACTIVE];
+    out->ccd_active_count = fl[FL_CCD_ACTIVE]; out->ccd_clamp_count = fl[FL_CCD_CLAMPS];
     out->fast_steps = (int32_t)w->fast_steps; out->full_steps = (int32_t)w->full_steps; out->replayed_steps = (int32_t)w->replayed_steps;
     if (w->dw.sleep_enabled && w->dw.n_bodies > 0) {
         std::vector<int> bfl(w->dw.n_bodies);

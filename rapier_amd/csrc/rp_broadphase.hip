@@ -48,7 +48,7 @@ __device__ __forceinline__ CellRange cell_range(const DevWorld &w, int i) {
 __global__ void k_collider_update(DevWorld w) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) { // a full step is starting: the fast path may be tried again later; per-step narrow-phase counters
-        w.flags[FL_FAST_ABORT] = 0; w.flags[FL_FULL_UPDATES] = 0; w.flags[FL_TODO_COUNT] = 0; w.flags[FL_NP_COUNT] = 0;
+        w.flags[FL_FAST_ABORT] = 0; w.flags[FL_FULL_UPDATES] = 0; w.flags[FL_TODO_COUNT] = 0; w.flags[FL_NP_COUNT] = 0; w.flags[FL_CCD_N] = 0;
     }
     if (i >= w.n_colliders) return;
     collider_update_one(w, i);
@@ -64,7 +64,7 @@ __global__ void k_fast_front(DevWorld w, int no_global_kernel) {
     if (w.flags[FL_FAST_ABORT]) return;
     int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid == 0) {
-        w.flags[FL_FULL_UPDATES] = 0;
+        w.flags[FL_FULL_UPDATES] = 0; w.flags[FL_CCD_N] = 0;
         if (w.flags[FL_BP_DIRTY]) w.flags[FL_FAST_ABORT] = 1;
         // sleep-enabled worlds: the awake set must be settled — no layout change or wake-up request waiting for a full step
         if (w.sleep_enabled && (w.flags[FL_LAYOUT_DIRTY] || w.flags[FL_WAKE_PENDING] || w.flags[FL_N_AWAKE] == 0 || w.flags[FL_PI_PENDING] || w.flags[FL_PJ_COUNT] || w.flags[FL_PI_JLINK])) w.flags[FL_FAST_ABORT] = 1; // (a pending island split, journaled removals, joint links: the full graph's sleep pass)
@@ -72,6 +72,19 @@ __global__ void k_fast_front(DevWorld w, int no_global_kernel) {
         if (no_global_kernel && (w.flags[FL_N_CONS] > 0 || w.flags[FL_N_GLOB_BODIES] > 0 || w.n_joints > 0)) w.flags[FL_FAST_ABORT] = 1;
     }
     bool abort = false;
+    // the continuous-collision pass only exists on the full graph: a dynamic body that may move more than a quarter of its thinnest
+    // extent this step (velocity + one step of gravity, rotation about the farthest point: twice the margin of the activation
+    // criterion, rigid_body_components.rs:1131-1157) sends the step there
+    if (w.prm.p.max_ccd_substeps != 0)
+        for (int b = gid; b < w.n_bodies; b += gridDim.x * blockDim.x) {
+            if (!flags_dyn_awake(w.b_flags[b])) continue;
+            const float thickness = w.b_damp[b].w;
+            if (!(thickness < 3.0e38f)) continue;
+            const float dt = w.prm.p.dt;
+            const V3 lv = v3(w.b_linvel[b]), av = v3(w.b_angvel[b]), g = v3(w.prm.gravity[0], w.prm.gravity[1], w.prm.gravity[2]);
+            const float motion = (len(lv) + len(g) * dt + len(av) * w.b_invpi[b].w) * dt;
+            if (motion > 0.25f * thickness) abort = true;
+        }
     if (gid < w.n_colliders) {
         abort |= collider_update_one(w, gid); // rewritten fat AABB => FL_BP_DIRTY
     }

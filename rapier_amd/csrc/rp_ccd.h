@@ -1,0 +1,253 @@
+// rp_ccd.h — the continuous-collision pass on the device (included at the end of rp_narrowphase.hip: it reuses the SAT and
+// closest-point helpers of the manifold generators).
+//
+// DRIVER: CCDSolver::solve_continuous + apply_clamps (/root/reference/src/dynamics/ccd/ccd_solver.rs:158-340) and sweep_fast_body
+// (sweeps.rs:470-640) with the tiers of sweeps.rs:22-41: a fast dynamic body (RigidBodyCcd::is_moving_fast_with_next_position,
+// evaluated in body_writeback) sweeps the FIXED colliders; a `ccd_enabled` body — a bullet — sweeps every collider that is not on a
+// bullet, targets standing at their (possibly just clamped) end-of-step pose.  The earliest solid impact fraction in (0, 1) clamps
+// the body's pose (velocities untouched); sensors never stop a body (the paired intersection events of sensor crossings,
+// ccd_solver.rs:265-320, are not raised).
+//
+// TIME OF IMPACT: the reference calls parry3d's query::sweep_toi (not under /root/reference).  In its place: conservative
+// advancement over a lower bound of the distance — the largest separation over the SAT axes of the manifold generators, exact
+// point projections for balls, segment / segment closest points for capsules, the support point for half-spaces — with Box2D's
+// impact distance (core shapes within max(slop, total radius - slop), tolerance slop / 4, slop = allowed_linear_error):
+//     t += (separation - target) / (approach speed along the separating direction + 4 tan(angle / 4) * rotation radius)
+// until separation < target + tolerance (hit) or t >= the best fraction so far (miss); the iteration cap ends in a miss (a body that
+// hovers within a few slops of a surface is the speculative contacts' job).  One workgroup per fast body: its lanes take
+// (collider of the body, target collider) candidates, the earliest fraction is an atomicMin over positive float bits, so the result
+// does not depend on the visiting order.  Every function mirrors the checker's restatement operation for operation.
+#pragma once
+
+#define RP_CCD_MAX_ITERS 48
+
+struct CcdSweep { V3 c0, c1; Q4 q0, q1; V3 local_com; };
+RP_DEV CcdSweep ccd_sweep_from_poses(Pose start, Pose end, V3 local_com) {
+    CcdSweep s;
+    s.c0 = pose_tp(start, local_com); s.c1 = pose_tp(end, local_com);
+    s.q0 = start.r; s.q1 = end.r;
+    if (qdot(s.q0, s.q1) < 0.0f) s.q1 = q4(-s.q1.x, -s.q1.y, -s.q1.z, -s.q1.w);
+    s.local_com = local_com;
+    return s;
+}
+RP_DEV Pose ccd_sweep_transform_at(const CcdSweep &s, float t) {
+    V3 c = s.c0 + (s.c1 - s.c0) * t;
+    Q4 q = qnormalize(q4(s.q0.x + (s.q1.x - s.q0.x) * t, s.q0.y + (s.q1.y - s.q0.y) * t, s.q0.z + (s.q1.z - s.q0.z) * t, s.q0.w + (s.q1.w - s.q0.w) * t));
+    Pose p; p.r = q; p.t = c - qrot(q, s.local_com);
+    return p;
+}
+// a collider's shape as the query sees it (c_shape / c_he of rp_world.h): he = cuboid half extents | half-space normal; capsule:
+// he.x = half height, radius, axis; ball: radius
+struct CcdShape { int shape; V3 he; float radius; int axis; };
+RP_DEV CcdShape ccd_shape_of(int sh, float4 he) {
+    CcdShape s; s.shape = sh; s.he = v3(he); s.axis = 1;
+    s.radius = sh == RP_SHAPE_CAPSULE ? he.y : he.x;
+    if (sh == RP_SHAPE_CAPSULE) s.axis = (int)he.z;
+    return s;
+}
+RP_DEV V3 ccd_clamp_box(V3 p, V3 he) { return v3(rp_clamp(p.x, -he.x, he.x), rp_clamp(p.y, -he.y, he.y), rp_clamp(p.z, -he.z, he.z)); }
+RP_DEV float ccd_point_dir(V3 dv, V3 &dir) {
+    float dist = len(dv);
+    if (!(dist > 0.0f)) { dir = v3(0, 1, 0); return -1.0f; }
+    dir = dv * (1.0f / dist);
+    return dist;
+}
+RP_DEV float ccd_point_box(V3 p, V3 he, V3 &dir) { return ccd_point_dir(p - ccd_clamp_box(p, he), dir); }
+
+__device__ float ccd_separation(const CcdShape &s1, const CcdShape &s2, Pose pos12, V3 &n1) {
+    const Pose pos21 = pose_inv(pos12);
+    if (s1.shape == RP_SHAPE_HALFSPACE) {
+        const V3 n = s1.he;
+        n1 = n;
+        if (s2.shape == RP_SHAPE_BALL) return dot(n, pos12.t) - s2.radius;
+        if (s2.shape == RP_SHAPE_CUBOID) {
+            V3 n2 = qrot_inv(pos12.r, n);
+            float ext = (fabsf(n2.x) * s2.he.x + fabsf(n2.y) * s2.he.y) + fabsf(n2.z) * s2.he.z;
+            return dot(n, pos12.t) - ext;
+        }
+        V3 e = capsule_axis_dir(s2.axis) * s2.he.x;
+        float da = dot(n, pose_tp(pos12, -e)), db = dot(n, pose_tp(pos12, e));
+        return rp_min(da, db) - s2.radius;
+    }
+    if (s1.shape == RP_SHAPE_BALL) {
+        if (s2.shape == RP_SHAPE_BALL) { float d = ccd_point_dir(pos12.t, n1); return d < 0.0f ? d : d - s1.radius - s2.radius; }
+        if (s2.shape == RP_SHAPE_CUBOID) {
+            V3 dir2; float d = ccd_point_box(pos21.t, s2.he, dir2);
+            n1 = qrot(pos12.r, -dir2);
+            return d < 0.0f ? d : d - s1.radius;
+        }
+        V3 e = capsule_axis_dir(s2.axis) * s2.he.x;
+        V3 p = segment_project_point(pose_tp(pos12, -e), pose_tp(pos12, e), v3(0, 0, 0));
+        float d = ccd_point_dir(p, n1);
+        return d < 0.0f ? d : d - s1.radius - s2.radius;
+    }
+    if (s1.shape == RP_SHAPE_CUBOID) {
+        if (s2.shape == RP_SHAPE_BALL) { float d = ccd_point_box(pos12.t, s1.he, n1); return d < 0.0f ? d : d - s2.radius; }
+        if (s2.shape == RP_SHAPE_CUBOID) {
+            V3 d1, d2, d3;
+            float sa = sat_normal_oneway(s1.he, s2.he, pos12, d1);
+            float sb = sat_normal_oneway(s2.he, s1.he, pos21, d2);
+            float sc = sat_edge_twoway(s1.he, s2.he, pos12, d3);
+            float sep = sa; n1 = d1;
+            if (sb > sep) { sep = sb; n1 = qrot(pos12.r, -d2); }
+            if (sc > sep) { sep = sc; n1 = d3; }
+            return sep;
+        }
+        V3 e = capsule_axis_dir(s2.axis) * s2.he.x;
+        V3 a2 = pose_tp(pos12, -e), b2 = pose_tp(pos12, e), d1, d3;
+        float sa = sat_cuboid_segment_normal_oneway(s1.he, a2, b2, d1);
+        float sc = sat_cuboid_segment_edge_twoway(s1.he, a2, b2, d3);
+        float sep = sa; n1 = d1;
+        if (sc > sep) { sep = sc; n1 = d3; }
+        return sep - s2.radius;
+    }
+    {   // target capsule
+        V3 e1 = capsule_axis_dir(s1.axis) * s1.he.x, a1 = -e1, b1 = e1;
+        if (s2.shape == RP_SHAPE_BALL) {
+            V3 p = segment_project_point(a1, b1, pos12.t);
+            float d = ccd_point_dir(pos12.t - p, n1);
+            return d < 0.0f ? d : d - s1.radius - s2.radius;
+        }
+        if (s2.shape == RP_SHAPE_CUBOID) {
+            V3 a = pose_tp(pos21, a1), b = pose_tp(pos21, b1), d1, d3;
+            float sa = sat_cuboid_segment_normal_oneway(s2.he, a, b, d1);
+            float sc = sat_cuboid_segment_edge_twoway(s2.he, a, b, d3);
+            float sep = sa; V3 dir2 = d1;
+            if (sc > sep) { sep = sc; dir2 = d3; }
+            n1 = qrot(pos12.r, -dir2);
+            return sep - s1.radius;
+        }
+        V3 e2 = capsule_axis_dir(s2.axis) * s2.he.x;
+        V3 a2 = pose_tp(pos12, -e2), b2 = pose_tp(pos12, e2);
+        float s, t;
+        closest_points_segment_segment(a1, b1, a2, b2, s, t);
+        V3 p1 = a1 + (b1 - a1) * s, p2 = a2 + (b2 - a2) * t;
+        float d = ccd_point_dir(p2 - p1, n1);
+        return d < 0.0f ? d : d - s1.radius - s2.radius;
+    }
+}
+RP_DEV float ccd_rot_radius(const CcdShape &s2, Pose pos_wrt_parent, V3 local_com) {
+    V3 c = pos_wrt_parent.t - local_com;
+    if (s2.shape == RP_SHAPE_BALL) return len(c);
+    if (s2.shape == RP_SHAPE_CAPSULE) {
+        V3 e = qrot(pos_wrt_parent.r, capsule_axis_dir(s2.axis) * s2.he.x);
+        return rp_max(len(c - e), len(c + e));
+    }
+    return len(c) + len(s2.he);
+}
+__device__ float ccd_cast_pair(const CcdShape &s1, Pose target_pose, const CcdShape &s2, Pose pos_wrt_parent, const CcdSweep &sw, float rot_radius,
+                               float max_fraction, float slop) {
+    const float total_radius = ((s1.shape == RP_SHAPE_BALL || s1.shape == RP_SHAPE_CAPSULE) ? s1.radius : 0.0f) + ((s2.shape == RP_SHAPE_BALL || s2.shape == RP_SHAPE_CAPSULE) ? s2.radius : 0.0f);
+    const float target = rp_max(slop, total_radius - slop) - total_radius, tol = 0.25f * slop;
+    const V3 D = sw.c1 - sw.c0;
+    const Q4 dq = qmul(sw.q1, qconj(sw.q0));
+    const float sv = sqrtf((dq.x * dq.x + dq.y * dq.y) + dq.z * dq.z);
+    const float rot_bound = (4.0f * sv / (1.0f + fabsf(dq.w))) * rot_radius;
+    float t = 0.0f;
+    for (int iter = 0; iter < RP_CCD_MAX_ITERS; ++iter) {
+        Pose cp = pose_mul(ccd_sweep_transform_at(sw, t), pos_wrt_parent);
+        Pose pos12 = pose_inv_mul(target_pose, cp);
+        V3 n1;
+        float sep = ccd_separation(s1, s2, pos12, n1);
+        if (sep < target + tol) return iter == 0 ? -1.0f : t;
+        V3 nw = qrot(target_pose.r, n1);
+        float approach = -dot(D, nw);
+        if (approach < 0.0f) approach = 0.0f;
+        float bound = approach + rot_bound;
+        if (!(bound > 0.0f)) return -1.0f;
+        t = t + (sep - target) / bound;
+        if (!(t < max_fraction)) return -1.0f;
+    }
+    return -1.0f;
+}
+RP_DEV bool ccd_may_reach(V3 c0, V3 c1, float max_extent, V3 target_centre, float target_radius, float margin) {
+    V3 p = segment_project_point(c0, c1, target_centre);
+    float reach = (max_extent + target_radius) + margin;
+    return len2(target_centre - p) <= reach * reach;
+}
+RP_DEV float ccd_bounding_radius(int sh, float4 he) { // Shape::compute_local_bounding_sphere
+    if (sh == RP_SHAPE_CUBOID) return len(v3(he));
+    if (sh == RP_SHAPE_CAPSULE) return he.x + he.y;
+    return he.x;
+}
+
+#define CCD_MAX_FAST_COLLIDERS 64
+// One workgroup per fast body of the list body_writeback filled this step (w.ccd_list, FL_CCD_N).  tier 0: non-bullets against fixed
+// targets; tier 1: bullets against everything that is not on a bullet.
+__global__ void __launch_bounds__(256) k_ccd(DevWorld w, int tier) {
+    int n = w.flags[FL_CCD_N];
+    if (n <= 0) return;
+    if (n > w.n_bodies) n = w.n_bodies;
+    __shared__ unsigned best;
+    __shared__ int nfast, fast[CCD_MAX_FAST_COLLIDERS];
+    const float slop = w.prm.p.normalized_allowed_linear_error * w.prm.p.length_unit; // IntegrationParameters::allowed_linear_error
+    for (int k = blockIdx.x; k < n; k += gridDim.x) {
+        const int bi = w.ccd_list[k];
+        const int fl1 = w.b_flags[bi];
+        const bool bullet = (fl1 & RP_BF_TYPE_MASK) == RP_BODY_DYNAMIC && (fl1 & RP_BF_CCD_ENABLED);
+        __syncthreads();
+        if ((bullet ? 1 : 0) != tier || (fl1 & RP_BF_SLEEPING)) continue; // (uniform over the workgroup)
+        if (threadIdx.x == 0) { best = __float_as_uint(1.0f); nfast = 0; }
+        __syncthreads();
+        for (int c = threadIdx.x; c < w.n_colliders; c += blockDim.x) { // the body's own colliders (enabled, not sensors)
+            if (w.c_parent[c] != bi) continue;
+            uint2 g = w.c_groups[c];
+            if ((g.x == 0 && g.y == 0) || (__float_as_int(w.c_events[c].x) & RP_EVENTS_SENSOR_BIT)) continue;
+            int q = atomicAdd(&nfast, 1);
+            if (q < CCD_MAX_FAST_COLLIDERS) fast[q] = c;
+        }
+        __syncthreads();
+        const int nf = nfast < CCD_MAX_FAST_COLLIDERS ? nfast : CCD_MAX_FAST_COLLIDERS;
+        Pose start, end;
+        start.t = v3(w.b_ccd0_pos[bi]); start.r = q4(w.b_ccd0_rot[bi]);
+        end.t = v3(w.b_pos[bi]); end.r = q4(w.b_rot[bi]);
+        const V3 lcom = v3(w.b_lcom_invm[bi]);
+        const float max_extent = w.b_invpi[bi].w;
+        const CcdSweep sw = ccd_sweep_from_poses(start, end, lcom);
+        for (int f = 0; f < nf; ++f) {
+            const int c1 = fast[f];
+            const CcdShape s2 = ccd_shape_of(w.c_shape[c1], w.c_he[c1]);
+            Pose pwp; pwp.t = v3(w.c_lpos[c1]); pwp.r = q4(w.c_lrot[c1]);
+            const float rot_radius = ccd_rot_radius(s2, pwp, lcom);
+            const uint2 g1 = w.c_groups[c1];
+            for (int c2 = threadIdx.x; c2 < w.n_colliders; c2 += blockDim.x) {
+                const int p2 = w.c_parent[c2];
+                if (c2 == c1 || p2 == bi) continue;
+                const uint2 g2 = w.c_groups[c2];
+                if ((g2.x == 0 && g2.y == 0) || (__float_as_int(w.c_events[c2].x) & RP_EVENTS_SENSOR_BIT)) continue;
+                const int fl2 = p2 >= 0 ? w.b_flags[p2] : RP_BODY_FIXED;
+                const bool fixed2 = (fl2 & RP_BF_TYPE_MASK) == RP_BODY_FIXED;
+                // tier_allows (sweeps.rs:35-41)
+                if (tier) { if ((fl2 & RP_BF_TYPE_MASK) == RP_BODY_DYNAMIC && (fl2 & RP_BF_CCD_ENABLED)) continue; } else if (!fixed2) continue;
+                if (!((g1.x & g2.y) != 0 && (g2.x & g1.y) != 0)) continue; // collision_groups.test
+                Pose tp = collider_world_pose(w, c2); // target_collider_pose (:97-102): bodies already stand at their end-of-step pose
+                const int sh2 = w.c_shape[c2];
+                const float4 he2 = w.c_he[c2];
+                if (sh2 != RP_SHAPE_HALFSPACE && !ccd_may_reach(sw.c0, sw.c1, max_extent, tp.t, ccd_bounding_radius(sh2, he2), 2.0f * slop)) continue;
+                const CcdShape s1 = ccd_shape_of(sh2, he2);
+                const float cur = __uint_as_float(__hip_atomic_load(&best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                const float hit = ccd_cast_pair(s1, tp, s2, pwp, sw, rot_radius, cur, slop);
+                if (hit > 0.0f && hit < cur) atomicMin(&best, __float_as_uint(hit));
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float fraction = __uint_as_float(best);
+            if (fraction < 1.0f) { // apply_clamps (ccd_solver.rs:325-339) + what advance_to_final_positions derives from the pose
+                const Pose p = ccd_sweep_transform_at(sw, fraction);
+                w.b_pos[bi] = f4(p.t, 0.0f); w.b_rot[bi] = f4(p.r);
+                w.b_wcom[bi] = f4(qrot(p.r, lcom) + p.t, 0.0f);
+                Sym3 ii = world_inv_inertia(v3(w.b_invpi[bi]), q4(w.b_pframe[bi]), p.r);
+                apply_locked_rotations((fl1 >> RP_BF_LOCK_SHIFT) & 0x3f, ii);
+                w.b_eii0[bi] = make_float4(ii.m11, ii.m12, ii.m13, ii.m22);
+                w.b_eii1[bi] = make_float4(ii.m23, ii.m33, 0.0f, 0.0f);
+                atomicAdd(&w.flags[FL_CCD_CLAMPS], 1);
+            }
+        }
+    }
+}
+void rp_launch_ccd(const DevWorld &w, hipStream_t st, int has_bullets) {
+    if (w.prm.p.max_ccd_substeps == 0 || w.n_bodies == 0 || w.n_colliders == 0) return;
+    hipLaunchKernelGGL(k_ccd, dim3(64), dim3(256), 0, st, w, 0);
+    if (has_bullets) hipLaunchKernelGGL(k_ccd, dim3(64), dim3(256), 0, st, w, 1);
+}

@@ -491,7 +491,7 @@ RP_DEV void body_writeback(const DevWorld &w, int i, V3 slin, V3 sang, Q4 rot, V
     if (w.prm.p.max_ccd_substeps != 0 && damp.w < 3.0e38f) {
         // CCD activation (worker.rs:845-865, RigidBodyCcd::is_moving_fast_with_next_position, rigid_body_components.rs:1131-1157): the
         // farthest point of the body moved more than half its thinnest extent this step.  damp.w = ccd_thickness (min over the
-        // attached shapes).  Only counted: the sweep itself (ccd_solver.rs) is out of scope.
+        // attached shapes).
         const float max_extent = invpi_ext.w;
         V3 dcom = com - v3(w.b_wcom[i]);
         Q4 dq = qmul(rot, qconj(q4(w.b_rot[i])));
@@ -503,7 +503,12 @@ RP_DEV void body_writeback(const DevWorld &w, int i, V3 slin, V3 sang, Q4 rot, V
             float max_delta = len(dcom) + 2.0f * len(dv) * max_extent;
             float max_vel = len(dcom * inv_dt) + len(quat_to_scaled_axis(dq) * inv_dt) * max_extent; // ccd_vels = interpolate_velocity(inv_dt)
             float max_motion = rp_max(max_delta, max_vel * dt);
-            if (max_motion > 0.5f * damp.w) atomicAdd(&w.flags[FL_CCD_ACTIVE], 1);
+            if (max_motion > 0.5f * damp.w) { // the continuous-collision pass (k_ccd, full steps) sweeps this body from its start-of-step pose
+                atomicAdd(&w.flags[FL_CCD_ACTIVE], 1);
+                w.b_ccd0_pos[i] = w.b_pos[i]; w.b_ccd0_rot[i] = w.b_rot[i];
+                const int k = atomicAdd(&w.flags[FL_CCD_N], 1);
+                if (k < w.n_bodies) w.ccd_list[k] = i;
+            }
         }
     }
     w.b_linvel[i] = f4(lin, 0.0f); w.b_angvel[i] = f4(ang, 0.0f);

@@ -1092,3 +1092,6 @@ void rp_launch_narrowphase_part(const DevWorld &w, hipStream_t st, int part) {
     }
 }
 void rp_launch_narrowphase(const DevWorld &w, hipStream_t st) { rp_launch_narrowphase_part(w, st, -1); }
+
+// ---- continuous collision detection (dynamics/ccd): kernel and launcher ----
+#include "rp_ccd.h"

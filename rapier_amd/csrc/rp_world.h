@@ -29,6 +29,7 @@
 #define RP_BF_GYRO 0x4
 #define RP_BF_FASTROT 0x8
 #define RP_BF_SLEEPING 0x10          // RigidBodyActivation::sleeping (dynamic bodies only)
+#define RP_BF_CCD_ENABLED 0x20       // RigidBodyCcd::ccd_enabled: a bullet (dynamics/ccd/sweeps.rs:29-31)
 #define RP_BF_DOM_SHIFT 8
 #define RP_BF_LOCK_SHIFT 16           // LockedAxes (6 bits): translation x,y,z then rotation x,y,z
 
@@ -107,6 +108,8 @@ enum {
     FL_BP_SEQ,          // broad-phase passes run so far (stamps c_chgstamp)
     FL_BP_FORCE_FULL,   // scratch of one pass: the incremental update met a case it leaves to the full rebuild
     FL_BP_TOMBS,        // tombstones in the live pair hash table since the last full rebuild
+    FL_CCD_N,           // bodies body_writeback found moving fast this step (ccd_list): the input of k_ccd
+    FL_CCD_CLAMPS,      // (body, step) cases in which k_ccd clamped a pose to a time of impact
     FL_UF_NPAIRS,       // scratch of a layout rebuild: active dynamic-dynamic pairs listed for the island union-find (uf_pairs)
     FL_COUNT = 64       // <= 64: publish_flags copies one slot per lane of a wavefront
 };
@@ -208,6 +211,7 @@ struct DevWorld {
     int *b_flags;
     int *b_collider;       // the collider of a dynamic body (one per dynamic body, -1 = none)
     int *b_quar;           // sticky: non-finite state was detected (and rolled back) for this body
+    float4 *b_ccd0_pos, *b_ccd0_rot; int *ccd_list; // continuous-collision pass (rp_ccd.h): start-of-step pose of the bodies on ccd_list
     // ---- sleeping (RigidBodyActivation + whole-island sleep, rp_sleep.hip) ----
     float4 *b_sleep;       // time_since_can_sleep, normalized_linear_threshold, angular_threshold, time_until_sleep
     float4 *b_sprev_t;     // sleep_prev_pose translation xyz, max_extent

@@ -25,7 +25,7 @@ BODY_DTYPE = np.dtype([
     ("linvel", "<f4", 3), ("angvel", "<f4", 3),
     ("linear_damping", "<f4"), ("angular_damping", "<f4"), ("gravity_scale", "<f4"),
     ("additional_mass", "<f4"), ("dominance", "<i4"), ("gyroscopic", "<i4"),
-    ("allow_fast_rotation", "<i4"), ("can_sleep", "<i4"), ("locked_axes", "<u4"), ("additional_solver_iterations", "<i4"),
+    ("allow_fast_rotation", "<i4"), ("can_sleep", "<i4"), ("locked_axes", "<u4"), ("additional_solver_iterations", "<i4"), ("ccd_enabled", "<i4"),
 ], align=False)
 COLLIDER_DTYPE = np.dtype([
     ("shape", "<i4"), ("half_extents", "<f4", 3), ("translation", "<f4", 3), ("rotation", "<f4", 4),
@@ -106,7 +106,7 @@ def default_params() -> np.ndarray:
 def body_desc(body_type=BODY_DYNAMIC, translation=(0, 0, 0), rotation=(0, 0, 0, 1), linvel=(0, 0, 0),
               angvel=(0, 0, 0), linear_damping=0.0, angular_damping=0.0, gravity_scale=1.0,
               additional_mass=0.0, dominance=0, gyroscopic=1, allow_fast_rotation=0, can_sleep=0, locked_axes=0,
-              additional_solver_iterations=0) -> np.ndarray:
+              additional_solver_iterations=0, ccd_enabled=0) -> np.ndarray:
     """RigidBodyBuilder defaults — /root/reference/src/dynamics/rigid_body.rs:1560-1600 — except
     ``can_sleep``: the builder's default is true, every b3d benchmark scene calls ``.can_sleep(false)``
     (b3d_many_pyramids.rs:52) and so do the generators here unless a scene asks for sleeping."""
@@ -121,6 +121,7 @@ def body_desc(body_type=BODY_DYNAMIC, translation=(0, 0, 0), rotation=(0, 0, 0, 
     b["can_sleep"] = can_sleep
     b["locked_axes"] = locked_axes  # LockedAxes bits: 1,2,4 = translation x,y,z; 8,16,32 = rotation x,y,z
     b["additional_solver_iterations"] = additional_solver_iterations  # extra TGS substeps for the body's whole component
+    b["ccd_enabled"] = ccd_enabled  # RigidBodyBuilder::ccd_enabled: a "bullet" also sweeps kinematic / dynamic targets (dynamics/ccd/sweeps.rs:29-41)
     return b
 
 

@@ -72,6 +72,8 @@ def lib():
         L.ro_read_island_state.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         L.ro_read_island_globals.argtypes = [C.c_void_p, C.c_void_p]
         L.ro_set_additional_solver_iterations.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        L.ro_set_ccd_enabled.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        L.ro_read_ccd_counts.argtypes = [C.c_void_p, C.c_void_p]
         L.ro_read_solve_group_extras.argtypes = [C.c_void_p, C.c_void_p]
         L.ro_set_collider_sensor.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         L.ro_intersection_pair.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
@@ -97,6 +99,8 @@ class OracleWorld:
             bi = L.ro_add_body(self._w, bodies[i:i + 1].ctypes.data)
             if int(bodies["additional_solver_iterations"][i]):  # trailing descriptor field (the oracle's struct ends before it)
                 L.ro_set_additional_solver_iterations(self._w, bi, int(bodies["additional_solver_iterations"][i]))
+            if int(bodies["ccd_enabled"][i]):
+                L.ro_set_ccd_enabled(self._w, bi, 1)
         cols = scene.collider_array()
         parents = scene.parent_array()
         for i in range(len(cols)):
@@ -116,6 +120,8 @@ class OracleWorld:
         """RigidBodySet::insert into the (possibly already stepped) world."""
         b = np.ascontiguousarray(S.body_desc(**kw))
         h = lib().ro_add_body(self._w, b.ctypes.data)
+        if int(np.asarray(b["ccd_enabled"]).reshape(-1)[0]):
+            lib().ro_set_ccd_enabled(self._w, h, 1)
         self.n += 1
         return h
 
@@ -256,6 +262,12 @@ class OracleWorld:
         """(sleep_scan_stamp, pending split island or -1)"""
         out = np.zeros(2, np.int32)
         lib().ro_read_island_globals(self._w, out.ctypes.data)
+        return int(out[0]), int(out[1])
+
+    def ccd_counts(self):
+        """((body, step) cases of the CCD fast-body criterion, clamped next_positions) since world creation"""
+        out = np.zeros(2, np.int32)
+        lib().ro_read_ccd_counts(self._w, out.ctypes.data)
         return int(out[0]), int(out[1])
 
     def slept_at(self):

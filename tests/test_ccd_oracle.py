@@ -1,0 +1,195 @@
+"""The continuous-collision pass (dynamics/ccd/ccd_solver.rs, sweeps.rs) as restated by the oracle: the reference's own CCD tests
+restated scene for scene, plus properties of the stand-in time-of-impact query (oracle/ro_ccd.h: conservative advancement over a lower
+bound of the distance — parry3d's sweep_time_of_impact is not under /root/reference).  GPU twins: tests/test_gpu_ccd.py."""
+import numpy as np
+import pytest
+
+from rapier_amd import scenes as S
+from oracle_ffi import OracleWorld
+
+
+def harness(dt=None, gravity=(0.0, 0.0, 0.0), max_ccd_substeps=1):
+    sc = S.Scene(name="ccd", gravity=gravity)
+    if dt is not None:
+        sc.params["dt"] = dt
+    sc.params["max_ccd_substeps"] = max_ccd_substeps
+    return sc
+
+
+def thin_fixed_wall(sc, x=0.0):
+    wall = sc.add_body(body_type=S.BODY_FIXED)
+    sc.add_collider(wall, half_extents=(0.05, 5.0, 5.0), translation=(x, 0.0, 0.0))
+    return wall
+
+
+def fast_dynamic(sc, ccd_enabled, shape=S.SHAPE_CUBOID, he=(0.1, 0.1, 0.1), x=-3.0, vx=200.0):
+    b = sc.add_body(translation=(x, 0.0, 0.0), linvel=(vx, 0.0, 0.0), ccd_enabled=1 if ccd_enabled else 0)
+    sc.add_collider(b, shape=shape, half_extents=he)
+    return b
+
+
+# ---- ccd_default_vs_fixed.rs ----------------------------------------------------------------------------------------------------
+def default_ccd_vs_fixed_scene():
+    sc = harness()
+    thin_fixed_wall(sc)
+    return sc, fast_dynamic(sc, False)
+
+
+def test_default_ccd_vs_fixed_no_tunnel():
+    """ccd_default_vs_fixed.rs:93-108: a fast dynamic body (3.3 m per step against a 0.1 m wall) is stopped on the near side even without
+    ccd_enabled"""
+    sc, body = default_ccd_vs_fixed_scene()
+    w = OracleWorld(sc)
+    w.step(120)
+    pos, _ = w.read()
+    assert pos[body, 0] < 0.0, pos[body]
+    active, clamps = w.ccd_counts()
+    assert active >= 1 and clamps >= 1
+
+
+def test_default_tier_ignores_dynamic():
+    """:110-141: two default-tier fast bodies on a head-on course pass through each other (fixed targets only)"""
+    sc = harness()
+    a = fast_dynamic(sc, False, x=-3.0, vx=200.0)
+    b = fast_dynamic(sc, False, x=3.0, vx=-200.0)
+    w = OracleWorld(sc)
+    w.step(5)
+    pos, _ = w.read()
+    assert pos[a, 0] > 0.0 and pos[b, 0] < 0.0
+    assert w.ccd_counts()[1] == 0
+
+
+def bullet_vs_dynamic_scene():
+    sc = harness()
+    bullet = fast_dynamic(sc, True)
+    target = sc.add_body(translation=(0.0, 0.0, 0.0))
+    sc.add_collider(target, half_extents=(0.2, 0.2, 0.2))
+    return sc, bullet, target
+
+
+def test_bullet_still_hits_dynamic():
+    """:143-177: a ccd_enabled body sweeps dynamic targets: it pushes the target along and stays behind it"""
+    sc, bullet, target = bullet_vs_dynamic_scene()
+    w = OracleWorld(sc)
+    w.step(60)
+    pos, _ = w.read()
+    assert pos[target, 0] > 0.05 and pos[bullet, 0] < pos[target, 0]
+
+
+def test_global_ccd_off_tunnels():
+    """:179-196: max_ccd_substeps = 0 disables CCD for the whole world"""
+    sc = harness(max_ccd_substeps=0)
+    thin_fixed_wall(sc)
+    body = fast_dynamic(sc, False)
+    w = OracleWorld(sc)
+    w.step(60)
+    pos, _ = w.read()
+    assert pos[body, 0] > 1.0 and w.ccd_counts() == (0, 0)
+
+
+def test_compound_fast_body_no_tunnel():
+    """:236-270: a fast compound body sweeps each convex child (two cuboids as two colliders of one body)"""
+    sc = harness()
+    thin_fixed_wall(sc)
+    b = sc.add_body(translation=(-3.0, 0.0, 0.0), linvel=(200.0, 0.0, 0.0))
+    sc.add_collider(b, half_extents=(0.1, 0.1, 0.1), translation=(0.0, 0.15, 0.0))
+    sc.add_collider(b, half_extents=(0.1, 0.1, 0.1), translation=(0.0, -0.15, 0.0))
+    w = OracleWorld(sc)
+    w.step(120)
+    pos, _ = w.read()
+    assert pos[b, 0] < 0.0
+
+
+# ---- issue_217_ccd_large_dt_hitch.rs ----------------------------------------------------------------------------------------------
+def large_dt_scene():
+    sc = harness(dt=0.25)
+    wall = sc.add_body(body_type=S.BODY_FIXED)
+    sc.add_collider(wall, half_extents=(0.05, 5.0, 5.0), translation=(12.25, 0.0, 0.0))
+    ball = sc.add_body(linvel=(20.0, 0.0, 0.0), ccd_enabled=1)
+    sc.add_collider(ball, shape=S.SHAPE_BALL, half_extents=(0.5, 0.0, 0.0))
+    return sc, ball
+
+
+def test_ccd_large_dt_no_mid_air_hitch():
+    """issue_217:60-118: dt = 0.25, 5 m per step: full-speed advance until the impact step, then resting against the wall (x ~ 11.7),
+    never frozen mid-air, never through"""
+    sc, ball = large_dt_scene()
+    w = OracleWorld(sc)
+    contact_x, step_travel, prev_x = 12.2 - 0.5, 20.0 * 0.25, 0.0
+    for i in range(10):
+        w.step(1)
+        pos, vel = w.read()
+        x, vx = float(pos[ball, 0]), float(vel[ball, 0])
+        if prev_x + step_travel < contact_x - 0.5:
+            assert abs(x - (prev_x + step_travel)) < 1.0e-3, (i, x)
+        else:
+            assert contact_x - 0.35 < x < contact_x + 0.01, (i, x)
+            if i >= 4:
+                assert abs(vx) < 0.1, (i, vx)
+        prev_x = x
+
+
+# ---- issue_932_low_ccd_substeps_stutter.rs ----------------------------------------------------------------------------------------
+def tiled_floor_scene():
+    """a fast ccd-enabled ball skimming a floor made of separate cuboid tiles (issue_932:59-110)"""
+    sc = harness(gravity=(0.0, -9.81, 0.0))
+    floor = sc.add_body(body_type=S.BODY_FIXED)
+    for i in range(40):
+        sc.add_collider(floor, half_extents=(0.5, 0.1, 2.0), translation=(i * 1.0, -0.1, 0.0))
+    ball = sc.add_body(translation=(0.0, 0.26, 0.0), linvel=(30.0, 0.0, 0.0), ccd_enabled=1)
+    sc.add_collider(ball, shape=S.SHAPE_BALL, half_extents=(0.25, 0.0, 0.0), friction=0.0)
+    return sc, ball
+
+
+def test_low_ccd_substeps_do_not_stutter():
+    """issue_932: with max_ccd_substeps = 1 every step of a fast body rolling over tile seams must make a good part of its free-flight
+    progress (the old substep splitter pinned it at each seam); an initial touch is not an impact (sweeps.rs:409-411)"""
+    sc, ball = tiled_floor_scene()
+    w = OracleWorld(sc)
+    prev = 0.0
+    for i in range(40):
+        w.step(1)
+        pos, vel = w.read()
+        x = float(pos[ball, 0])
+        assert x - prev > 0.2 * 30.0 / 60.0, (i, x, prev)
+        assert pos[ball, 1] > 0.2, (i, pos[ball])
+        prev = x
+
+
+# ---- the stand-in time-of-impact query ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape,he", [(S.SHAPE_CUBOID, (0.1, 0.2, 0.15)), (S.SHAPE_BALL, (0.15, 0.0, 0.0)), (S.SHAPE_CAPSULE, (0.2, 0.08, 0.0))])
+@pytest.mark.parametrize("target", ["wall", "halfspace", "ball", "capsule"])
+def test_clamped_pose_touches_the_target_without_crossing(shape, he, target):
+    """conservative advancement: after the impact step the fast shape stands within a few slops IN FRONT of the target — never behind
+    its surface — whatever the shape pair; tumbling bodies included"""
+    sc = harness()
+    t = sc.add_body(body_type=S.BODY_FIXED)
+    if target == "wall":
+        sc.add_collider(t, half_extents=(0.05, 5.0, 5.0)); surface = -0.05
+    elif target == "halfspace":
+        sc.add_collider(t, shape=S.SHAPE_HALFSPACE, half_extents=(-1.0, 0.0, 0.0)); surface = 0.0
+    elif target == "ball":
+        sc.add_collider(t, shape=S.SHAPE_BALL, half_extents=(1.0, 0.0, 0.0)); surface = -1.0
+    else:
+        sc.add_collider(t, shape=S.SHAPE_CAPSULE, half_extents=(2.0, 0.5, 1.0)); surface = -0.5
+    b = sc.add_body(translation=(-3.0, 0.0, 0.0), linvel=(200.0, 0.0, 0.0), angvel=(3.0, -7.0, 5.0))
+    sc.add_collider(b, shape=shape, half_extents=he)
+    w = OracleWorld(sc)
+    w.step(1)
+    pos, _ = w.read()
+    reach = max(he) + (he[1] if shape == S.SHAPE_CAPSULE else 0.0) if shape != S.SHAPE_CUBOID else float(np.linalg.norm(he))
+    inner = min(he) if shape == S.SHAPE_CUBOID else (he[0] if shape == S.SHAPE_BALL else he[1])
+    assert w.ccd_counts() == (1, 1)
+    slop = 0.005  # allowed_linear_error: round shapes count as touching once they overlap by a slop (Box2D's target distance)
+    assert surface - reach - 0.02 <= pos[b, 0] <= surface - inner + slop + 1.0e-3, (pos[b], surface)
+    w.step(60)
+    pos, _ = w.read()
+    if target in ("wall", "halfspace"):  # (a round target may deflect the body around itself)
+        assert pos[b, 0] < surface + 0.01
+
+
+def test_slow_bodies_never_enter_the_pass():
+    """the criterion (rigid_body_components.rs:1131-1157): a settling stack never moves half its thinnest extent in a step"""
+    w = OracleWorld(S.pyramid10())
+    w.step(120)
+    assert w.ccd_counts() == (0, 0)
