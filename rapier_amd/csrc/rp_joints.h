@@ -114,6 +114,41 @@ RP_DEV void joint_finalize_store(const DevWorld &w, int j, JointRow *rows, const
     }
 }
 
+// The same block with a compile-time row count and dofs 0..LEN-1 (joints that lock the three linear axes and nothing else — every
+// joint of b3d_joint_grid): every loop unrolls, the rows stay in registers.  The run-time-indexed form above keeps its rows in scratch
+// memory (720 B per lane of the dataflow kernel), a memory round trip per access on a path that is rebuilt every substep.
+template <int LEN>
+RP_DEV void joint_finalize_store_static(const DevWorld &w, int j, JointRow (&rows)[LEN], V3 imsum, int substep_id) {
+#pragma unroll
+    for (int a = 0; a < LEN; ++a) {
+        JointRow &cj = rows[a];
+        float dot_jj = dot(cj.lin_jac, cmul(imsum, cj.lin_jac)) + dot(cj.ii1, cj.ang_jac1) + dot(cj.ii2, cj.ang_jac2);
+        float cfm_gain = dot_jj * cj.cfm_coeff + cj.cfm_gain;
+        float inv_dot_jj = rp_inv(dot_jj);
+        cj.inv_lhs = rp_inv(dot_jj + cfm_gain);
+        cj.cfm_gain = cfm_gain;
+#pragma unroll
+        for (int b = a + 1; b < LEN; ++b) { // (lock rows are unbounded: none is skipped)
+            JointRow &ci = rows[b];
+            float dot_ij = dot(ci.lin_jac, cmul(imsum, cj.lin_jac)) + dot(ci.ii1, cj.ang_jac1) + dot(ci.ii2, cj.ang_jac2);
+            float coeff = dot_ij * inv_dot_jj;
+            ci.lin_jac = ci.lin_jac - cj.lin_jac * coeff;
+            ci.ang_jac1 = ci.ang_jac1 - cj.ang_jac1 * coeff;
+            ci.ang_jac2 = ci.ang_jac2 - cj.ang_jac2 * coeff;
+            ci.ii1 = ci.ii1 - cj.ii1 * coeff;
+            ci.ii2 = ci.ii2 - cj.ii2 * coeff;
+            ci.rhs_wo_bias = ci.rhs_wo_bias - cj.rhs_wo_bias * coeff;
+            ci.rhs = ci.rhs - cj.rhs * coeff;
+        }
+    }
+    const bool ws = w.prm.p.warmstart_joints != 0;
+#pragma unroll
+    for (int k = 0; k < LEN; ++k) {
+        if (ws) rows[k].impulse = (substep_id == 0 ? joint_seed_impulse(w, j, k) : JRR(k, JR_LIN, j).w) * w.prm.p.warmstart_coefficient;
+        jrow_store(w, j, k, rows[k]);
+    }
+}
+
 // How a joint reaches the solver bodies: plain HBM arrays on the per-stage launch path (PlainBodyIO), tagged write-through
 // records on the dataflow path (rp_flow.hip).  `side` = 0 / 1 for body1 / body2.
 struct PlainBodyIO {
@@ -145,6 +180,26 @@ RP_DEV void joint_update_one_t(const DevWorld &w, const IO &io, int j, int subst
     V3 c1x = v3(0.0f, r1.z, -r1.y), c1y = v3(-r1.z, 0.0f, r1.x), c1z = v3(r1.y, -r1.x, 0.0f);
     V3 c2x = v3(0.0f, r2.z, -r2.y), c2y = v3(-r2.z, 0.0f, r2.x), c2z = v3(r2.y, -r2.x, 0.0f);
     V3 imsum = im1 + im2;
+    if (locked == 0x7 && !motor && !limited) { // three locked linear axes, nothing else (a spherical joint): rows in registers
+        JointRow r3[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            JointRow &c = r3[i];
+            c.impulse = 0.0f;
+            c.lin_jac = col[i];
+            c.ang_jac1 = c1x * col[i].x + c1y * col[i].y + c1z * col[i].z;
+            c.ang_jac2 = c2x * col[i].x + c2y * col[i].y + c2z * col[i].z;
+            float rhs_wo_bias = 0.0f;
+            float rhs_bias = dot(c.lin_jac, lin_err) * w.prm.joint_erp_inv_dt;
+            c.ii1 = sym_mul(ii1, c.ang_jac1);
+            c.ii2 = sym_mul(ii2, c.ang_jac2);
+            c.inv_lhs = 0.0f; c.cfm_coeff = w.prm.joint_cfm_coeff; c.cfm_gain = 0.0f; c.bmin = -JR_UNBOUNDED; c.bmax = JR_UNBOUNDED;
+            c.rhs = rhs_wo_bias + rhs_bias; c.rhs_wo_bias = rhs_wo_bias;
+        }
+        joint_finalize_store_static<3>(w, j, r3, imsum, substep_id);
+        JRP(JR_IM1, j) = f4(im1, 0.0f); JRP(JR_IM2, j) = f4(im2, 0.0f);
+        return;
+    }
     JointRow rows[6];
     int dof[6] = {0, 0, 0, 0, 0, 0};
     int len = 0, base = 0;
