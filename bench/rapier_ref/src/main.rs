@@ -8,7 +8,14 @@
 //!
 //! `--dump` closes SURVEY §8(c) on any machine with cargo: copy the .rpdump files to tests/golden/reference/ and
 //! tests/test_reference_dump.py compares the oracle with them (1e-4 relative on positions, the BASELINE.json tolerance).
-//! File format (little endian): 8 bytes "RPDUMP1\0", u32 body count, u32 steps, then per body in handle-index order 13 f32:
+//!   cargo run --release -- <scene> --trace <file> [steps]   # per-step trace -> tests/reference_trace.py diff <file> <oracle trace>
+//!
+//! `--trace` writes what is needed to bisect a divergence between this crate and the oracle in ONE run: for every step the state
+//! hash, the number of sleeping bodies, of contact pairs holding a solver contact and of solver contacts, followed by that step's
+//! transitions — `S body` / `W body` (fell asleep / woke up) and `B c1 c2` / `E c1 c2` (the pair gained its first / lost its last
+//! solver contact), all by arena index.  tests/reference_trace.py writes the same file from the oracle
+//! (tests/golden/reference_pile_s120.rptrace is committed) and reports the first step at which the two differ, and how.
+//! Dump file format (little endian): 8 bytes "RPDUMP1\0", u32 body count, u32 steps, then per body in handle-index order 13 f32:
 //! translation xyz, rotation xyzw, linvel xyz, angvel xyz; the last 8 bytes are the FNV-1a state hash of
 //! crates/rapier3d/tests/simd_backend_determinism.rs:36-57 over the same floats.
 
@@ -116,6 +123,62 @@ fn reference_pile() -> PhysicsWorld {
     world
 }
 
+/// Per-step trace (see the file header); `steps` steps of `world`.
+fn trace(world: &mut PhysicsWorld, scene: &str, path: &std::path::Path, steps: u32) {
+    use std::collections::BTreeSet;
+    use std::fmt::Write as _;
+    let mut handles: Vec<_> = world.bodies.iter().map(|(h, _)| h).collect();
+    handles.sort_by_key(|h| h.into_raw_parts().0);
+    let mut out = format!("RPTRACE1 {scene} {} {steps}\n", handles.len());
+    let mut asleep: BTreeSet<u32> = BTreeSet::new();
+    let mut touching: BTreeSet<(u32, u32)> = BTreeSet::new();
+    for step in 1..=steps {
+        world.step();
+        let mut hash: u64 = 0xcbf29ce484222325;
+        let mut now_asleep = BTreeSet::new();
+        for h in &handles {
+            let rb = &world.bodies[*h];
+            if rb.is_sleeping() {
+                now_asleep.insert(h.into_raw_parts().0);
+            }
+            let vals = rb.translation().to_array().into_iter().chain(rb.rotation().to_array()).chain(rb.linvel().to_array()).chain(rb.angvel().to_array());
+            for v in vals {
+                for b in v.to_bits().to_le_bytes() {
+                    hash ^= b as u64;
+                    hash = hash.wrapping_mul(0x100000001b3);
+                }
+            }
+        }
+        let mut now_touching = BTreeSet::new();
+        let mut contacts = 0usize;
+        for pair in world.contact_pairs() {
+            let n: usize = pair.solver_manifolds().iter().map(|m| m.data.solver_contacts.len()).sum();
+            if n > 0 {
+                let (a, b) = (pair.collider1.into_raw_parts().0, pair.collider2.into_raw_parts().0);
+                now_touching.insert((a.min(b), a.max(b)));
+                contacts += n;
+            }
+        }
+        writeln!(out, "step {step} hash {hash:016x} asleep {} touching {} contacts {contacts}", now_asleep.len(), now_touching.len()).unwrap();
+        for b in now_asleep.difference(&asleep) {
+            writeln!(out, "S {b}").unwrap();
+        }
+        for b in asleep.difference(&now_asleep) {
+            writeln!(out, "W {b}").unwrap();
+        }
+        for (a, b) in now_touching.difference(&touching) {
+            writeln!(out, "B {a} {b}").unwrap();
+        }
+        for (a, b) in touching.difference(&now_touching) {
+            writeln!(out, "E {a} {b}").unwrap();
+        }
+        asleep = now_asleep;
+        touching = now_touching;
+    }
+    std::fs::write(path, out).expect("write trace");
+    println!("{{\"trace\": \"{}\", \"steps\": {steps}}}", path.display());
+}
+
 /// Body states in handle-index order + the reference's FNV-1a state hash (see the file header for the format).
 fn dump(world: &PhysicsWorld, path: &std::path::Path, steps: u32) {
     let mut handles: Vec<_> = world.bodies.iter().map(|(h, _)| h).collect();
@@ -163,6 +226,12 @@ fn main() {
             }
             dump(&world, &dir.join(format!("{scene}_s{target}.rpdump")), target);
         }
+        return;
+    }
+    if args.get(2).map(String::as_str) == Some("--trace") {
+        let path = std::path::PathBuf::from(args.get(3).expect("--trace <file> [steps]"));
+        let steps: u32 = args.get(4).and_then(|s| s.parse().ok()).unwrap_or(120);
+        trace(&mut world, scene, &path, steps);
         return;
     }
     let warmup: usize = args.get(2).and_then(|s| s.parse().ok()).unwrap_or(60);
