@@ -31,7 +31,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 C3_CUBOIDS = 10780
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "many_pyramids_hbm_traffic.json")
+import glob
+_TRAFFIC = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_many_pyramids_hbm_traffic.json")))
+TRAFFIC_FILE = _TRAFFIC[-1] if _TRAFFIC else os.path.join(ROOT, "profiles", "r00_many_pyramids_hbm_traffic.json")  # the latest round's PMC record
 # sources whose change invalidates a recorded HBM-traffic measurement of the dominant kernel
 KERNEL_SOURCES = ["rapier_amd/csrc/rp_islands.hip", "rapier_amd/csrc/rp_constraint.h", "rapier_amd/csrc/rp_pairs.h", "rapier_amd/csrc/rp_world.h"]
 
@@ -53,7 +55,7 @@ def recorded_traffic():
     """HBM bytes per launch of the dominant kernel from the separate rocprofv3 --pmc passes (tools/gpu_profile.sh writes the file
     with the hash of the kernel sources it measured).  A record taken on different kernel code is refused: traffic = null."""
     if not os.path.exists(TRAFFIC_FILE):
-        return None, "no PMC record (profiles/many_pyramids_hbm_traffic.json)"
+        return None, "no PMC record (profiles/rNN_many_pyramids_hbm_traffic.json)"
     with open(TRAFFIC_FILE) as f:
         rec = json.load(f)
     if rec.get("kernel_code_sha") != kernel_code_sha():
