@@ -180,6 +180,8 @@ typedef struct rp_counters {
     int32_t ccd_active_count;      /* (body, step) occurrences so far of RigidBodyCcd::is_moving_fast_with_next_position (worker.rs:845-865):
                                     * the bodies the continuous-collision pass looked at (full steps) */
     int32_t ccd_clamp_count;       /* (body, step) cases in which CCDSolver::solve_continuous clamped next_position to a time of impact */
+    int32_t num_tiles;             /* LDS tiles the global solver path's big component is cut into (0 = colour stages run as launches) */
+    int32_t tile_sweeps;           /* 1 = the last enqueued step ran its biased / relaxed sweeps as one launch over the tiles */
 } rp_counters;
 
 #define RP_INVALID_HANDLE 0xffffffffffffffffull

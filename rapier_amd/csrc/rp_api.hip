@@ -53,8 +53,8 @@ void rp_launch_narrowphase(const DevWorld &w, hipStream_t st);
 void rp_launch_narrowphase_part(const DevWorld &w, hipStream_t st, int part);
 void rp_launch_init_bodies(const DevWorld &w, hipStream_t st);
 void rp_launch_solver_assembly(const DevWorld &w, hipStream_t st);
-void rp_launch_solver_loop(const DevWorld &w, hipStream_t st, int parallel_stages, int stage_blocks, int has_restitution, int joint_stages);
-void rp_launch_solver_writeback(const DevWorld &w, hipStream_t st);
+int rp_launch_solver_loop(const DevWorld &w, hipStream_t st, int parallel_stages, int stage_blocks, int has_restitution, int joint_stages, int tile_grid);
+void rp_launch_solver_writeback(const DevWorld &w, hipStream_t st, int parity);
 void rp_launch_island_solve(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast, int retire, int fused);
 void rp_launch_global_single(const DevWorld &w, hipStream_t st, int has_restitution, int fast);
 void rp_launch_fast_front(const DevWorld &w, hipStream_t st, int no_global_kernel);
@@ -71,7 +71,7 @@ void rp_launch_pi_ensure(const DevWorld &w, hipStream_t st, int first, int count
 void rp_launch_pi_remove_body(const DevWorld &w, hipStream_t st, int b);
 void rp_launch_pj_append_joint(const DevWorld &w, hipStream_t st, int dev_joint, int b1, int b2, int key);
 int rp_flow_grid(int device);
-int rp_occ_bp_rebuild(void); int rp_occ_layout_rebuild(void); int rp_occ_sleep_pass(void); int rp_occ_flow_ranks(void);
+int rp_occ_bp_rebuild(void); int rp_occ_layout_rebuild(void); int rp_occ_sleep_pass(void); int rp_occ_flow_ranks(void); int rp_occ_tiles_build(void);
 // Grid of the kernels that synchronise through device-side grid barriers (rp_gridbar.h): every workgroup must be resident at once, so
 // the cap is what THIS device holds of the hungriest of them — CUs x the smallest occupancy answer — with a quarter left free for
 // whatever else runs on the device (other worlds' rebuilds, other streams); never more than 192 (more workgroups only lengthen the
@@ -82,7 +82,7 @@ static int gbar_grid_for_device(int device) {
     hipDeviceProp_t prop;
     int cus = 0;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
-    int occ = std::min(std::min(rp_occ_bp_rebuild(), rp_occ_layout_rebuild()), std::min(rp_occ_sleep_pass(), rp_occ_flow_ranks()));
+    int occ = std::min(std::min(rp_occ_bp_rebuild(), rp_occ_layout_rebuild()), std::min(std::min(rp_occ_sleep_pass(), rp_occ_flow_ranks()), rp_occ_tiles_build()));
     int g = (cus * occ * 3) / 4;
     const char *e = getenv("RP_GBAR_BLOCKS"); // test hook: a small part / a busy device
     if (e && atoi(e) > 0) g = std::min(g > 0 ? g : atoi(e), atoi(e));
@@ -140,12 +140,12 @@ struct rp_world {
     int *old_pinned = nullptr;
     std::vector<int> old_active_joint_ids;
     // launch plan + graph
-    int plan_stages = 0, plan_blocks = 1, plan_single = 1, plan_island_grid = 1, plan_joint_stages = 0, plan_no_global = 0, plan_fused = 0;
+    int plan_stages = 0, plan_blocks = 1, plan_single = 1, plan_island_grid = 1, plan_joint_stages = 0, plan_no_global = 0, plan_fused = 0, plan_tile_grid = 0;
     bool has_restitution = false;
     // [0] = full path, [1] = fast path; "whole" = one graph per step, col/loop/fin = timed thirds
     hipGraph_t g_whole[2] = {nullptr, nullptr}, g_col[2] = {nullptr, nullptr}, g_loop[2] = {nullptr, nullptr}, g_fin[2] = {nullptr, nullptr};
     hipGraphExec_t ge_whole[2] = {nullptr, nullptr}, ge_col[2] = {nullptr, nullptr}, ge_loop[2] = {nullptr, nullptr}, ge_fin[2] = {nullptr, nullptr};
-    int graph_stages = -1, graph_blocks = -1, graph_single = -1, graph_island_grid = -1, graph_joint_stages = -1, graph_no_global = -1, graph_fused = -1;
+    int graph_stages = -1, graph_blocks = -1, graph_single = -1, graph_island_grid = -1, graph_joint_stages = -1, graph_no_global = -1, graph_fused = -1, graph_tile_grid = -1;
     bool use_graph = true, use_fast = true, use_fused = true;
     bool use_flow = true;          // the dataflow launch (rp_flow.hip) is available; RP_NO_FLOW=1: never, RP_FLOW=1: for every large world
     bool force_flow = false;
@@ -389,7 +389,7 @@ static void destroy_graphs(rp_world *w) {
         for (auto e : ex) if (*e) { hipGraphExecDestroy(*e); *e = nullptr; }
         for (auto g : gr) if (*g) { hipGraphDestroy(*g); *g = nullptr; }
     }
-    w->graph_stages = -1; w->graph_blocks = -1; w->graph_single = -1; w->graph_island_grid = -1; w->graph_joint_stages = -1; w->graph_no_global = -1; w->graph_fused = -1;
+    w->graph_stages = -1; w->graph_blocks = -1; w->graph_single = -1; w->graph_island_grid = -1; w->graph_joint_stages = -1; w->graph_no_global = -1; w->graph_fused = -1; w->graph_tile_grid = -1;
     w->timed_ready[0] = w->timed_ready[1] = false;
 }
 static void free_device(rp_world *w) {
@@ -1128,7 +1128,7 @@ static int finalize(rp_world *w) {
     if (!(cell > 1.0e-6f)) cell = 1.0f;
     fill_sim_params(w, d.prm, cell);
 
-    DA(d.flags, FL_COUNT); DA(d.dbg, 1024); DA(d.bar, 8);
+    DA(d.flags, FL_COUNT); DA(d.dbg, 1024); DA(d.bar, 16);
     DAC(d.b_pos, capb, DOM_BODY, 1, 1); DAC(d.b_rot, capb, DOM_BODY, 1, 1); DAC(d.b_linvel, capb, DOM_BODY, 1, 1); DAC(d.b_angvel, capb, DOM_BODY, 1, 1); DA(d.b_lcom_invm, capb); DA(d.b_invpi, capb);
     DA(d.b_pframe, capb); DAC(d.b_wcom, capb, DOM_BODY, 1, 1); DAC(d.b_eim, capb, DOM_BODY, 1, 1); DAC(d.b_eii0, capb, DOM_BODY, 1, 1); DAC(d.b_eii1, capb, DOM_BODY, 1, 1); DAC(d.b_damp, capb, DOM_BODY, 1, 1);
     DAC(d.b_uforce, capb, DOM_BODY, 1, 1); DAC(d.b_utorque, capb, DOM_BODY, 1, 1); DAC(d.b_flags, capb, DOM_BODY, 1, 1); DAC(d.b_quar, capb, DOM_BODY, 1, 1); DAF(d.b_collider, capb, 0xff);
@@ -1244,12 +1244,31 @@ static int finalize(rp_world *w) {
         UP(d.b_collider, bcol);
         HIPCHK(w, hipStreamSynchronize(w->stream));
     }
-    DA(d.C, (size_t)(w->params.friction_model == RP_FRICTION_COULOMB ? CQ_COUNT : CP_COUNT) * d.cons_cap); // Coulomb: + 9 tangent planes per point (rp_coulomb.h)
     DA(d.k_b1, d.cons_cap); DA(d.k_b2, d.cons_cap); DA(d.k_n, d.cons_cap); DA(d.k_cid, d.cons_cap);
     // dataflow solver: toucher lists, rebuilt on the device whenever the layout changes (no carry-over needed)
     DA(d.f_rec, 2 * (size_t)capb); DA(d.fk_rank, d.cons_cap); DA(d.fj_rank, std::max(nj, 1)); DA(d.fb_deg, capb); DA(d.fb_begin, capb); DA(d.fb_fill, capb);
-    DA(d.f_adj, 2 * (size_t)d.cons_cap); DA(d.f_jadj, 2 * (size_t)std::max(nj, 1)); DA(d.f_sorted, 2 * (size_t)d.cons_cap);
+    DA(d.f_adj, 2 * (size_t)d.cons_cap); DA(d.f_jadj, 2 * (size_t)std::max(nj, 1)); DA(d.f_sorted, 2 * (size_t)d.cons_cap); DA(d.f_other, 2 * (size_t)d.cons_cap);
     if (w->params.friction_model != RP_FRICTION_COULOMB) DA(d.ws_terms, (size_t)11 * 2 * d.cons_cap);
+    // LDS tiles of the global path (rp_tiles.hip): contact-only worlds under the twist model that are large enough to leave the single
+    // workgroup; RP_NO_TILES=1 keeps the per-stage launches, RP_TILE_TARGET=<n> sets the number of tiles aimed at (default: one per CU)
+    {
+        const char *nt = getenv("RP_NO_TILES"), *tt = getenv("RP_TILE_TARGET"), *tm = getenv("RP_TILE_MIN");
+        d.tile_min = tm && atoi(tm) > 0 ? atoi(tm) : RP_TILE_MIN_BODIES;
+        const bool eligible = !(nt && nt[0] == '1') && nj == 0 && w->params.friction_model != RP_FRICTION_COULOMB && capb >= d.tile_min;
+        d.tile_cap = eligible ? capb / 64 + 2 : 0;
+        d.tile_target = tt && atoi(tt) > 0 ? atoi(tt) : 240;
+        // constraint planes: Coulomb: + 9 tangent planes per point (rp_coulomb.h); worlds that may tile: + the shadow copy of the mutable planes
+        DA(d.C, (size_t)(w->params.friction_model == RP_FRICTION_COULOMB ? CQ_COUNT : CP_COUNT + (d.tile_cap ? CP_SHADOW_COUNT : 0)) * d.cons_cap);
+        if (d.tile_cap) {
+            DA(d.t_lin, capb); DA(d.t_ang, capb); DA(d.t_rot, capb); DA(d.t_trans, capb); DA(d.fk_ids, d.cons_cap); DA(d.tl_body_tile, capb); DA(d.tl_owned, capb);
+            DA(d.tl_hist, 2 * RP_TILE_CELLS); DA(d.tl_cellofs, 2 * RP_TILE_CELLS); DA(d.tl_bbox, 16); DA(d.tl_hdr, d.tile_cap);
+            DA(d.tl_cell, capb); DA(d.tl_sorted, capb); DA(d.b_order, capb);
+            { std::vector<int> iota(capb); for (int i = 0; i < capb; ++i) iota[i] = i; HIPCHK(w, hipMemcpy(d.b_order, iota.data(), (size_t)capb * sizeof(int), hipMemcpyHostToDevice)); }
+            DA(d.tl_soff, (size_t)d.tile_cap * (RP_TILE_STAGES + 1)); DA(d.tl_bodies, (size_t)d.tile_cap * RP_TILE_BCAP); DA(d.tl_cons, (size_t)d.tile_cap * RP_TILE_CCAP);
+            const unsigned rest[16] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+            HIPCHK(w, hipMemcpy(d.tl_bbox, rest, sizeof(rest), hipMemcpyHostToDevice));
+        }
+    }
 
     // host SoA staging (one batched copy per attribute)
     {
@@ -1356,8 +1375,8 @@ static void enqueue_global_solver(rp_world *w) {
     else if (flow_now(w)) rp_launch_global_flow(w->dw, w->stream, w->flow_grid, hr); // one dataflow launch (rp_flow.hip)
     else {
         rp_launch_solver_assembly(w->dw, w->stream);
-        rp_launch_solver_loop(w->dw, w->stream, w->plan_stages, w->plan_blocks, hr, w->plan_joint_stages);
-        rp_launch_solver_writeback(w->dw, w->stream);
+        const int parity = rp_launch_solver_loop(w->dw, w->stream, w->plan_stages, w->plan_blocks, hr, w->plan_joint_stages, w->plan_tile_grid);
+        rp_launch_solver_writeback(w->dw, w->stream, parity);
     }
 }
 static void enqueue_solver(rp_world *w) { enqueue_island_solver(w); enqueue_global_solver(w); }
@@ -1381,6 +1400,9 @@ static void plan_from_hints(rp_world *w, const int *fl) {
     // round up to a power of two so small changes of the stage size do not force a re-capture
     w->plan_blocks = flow_now(w) ? 1 : std::min(std::max(pow2_ceil((fl[FL_MAX_STAGE] + 255) / 256), 1), 4096);
     w->plan_island_grid = std::min(std::max(pow2_ceil(fl[FL_N_ISLANDS]), 1), 8192);
+    // LDS tiles (rp_tiles.hip): once the device has published a valid tiling of the global component, a sweep is one launch over the
+    // tiles (grid rounded up to 16 so small changes of the tile count do not force a re-capture; the kernel loops over tiles beyond it)
+    w->plan_tile_grid = (w->dw.tile_cap > 0 && !w->plan_single && !flow_now(w) && fl[FL_N_TILES] > 0) ? ((fl[FL_N_TILES] + 15) / 16) * 16 : 0;
     // fused single-kernel fast step: every workgroup must be resident at once (in-launch arrival barrier)
     // (a grid of at most fused_grid workgroups; workgroups loop over islands beyond that)
     // (contact-force events are evaluated by a kernel of their own after every step: such worlds take the two-kernel fast graph)
@@ -1509,11 +1531,11 @@ static int step_once(rp_world *w, bool allow_fast) {
         if (w->plan_island_grid < old_g && w->plan_island_grid * 2 >= old_g) w->plan_island_grid = old_g;
     }
     if (w->graph_stages != w->plan_stages || w->graph_blocks != w->plan_blocks || w->graph_single != w->plan_single ||
-        w->graph_island_grid != w->plan_island_grid || w->graph_joint_stages != w->plan_joint_stages || w->graph_no_global != w->plan_no_global || w->graph_fused != w->plan_fused) {
+        w->graph_island_grid != w->plan_island_grid || w->graph_joint_stages != w->plan_joint_stages || w->graph_no_global != w->plan_no_global || w->graph_fused != w->plan_fused || w->graph_tile_grid != w->plan_tile_grid) {
         if (w->ge_whole[0] || w->ge_whole[1] || w->timed_ready[0] || w->timed_ready[1]) HIPCHK(w, hipStreamSynchronize(w->stream)); // replays of the old graphs may still be in flight
         destroy_graphs(w);
         w->graph_stages = w->plan_stages; w->graph_blocks = w->plan_blocks; w->graph_single = w->plan_single; w->graph_island_grid = w->plan_island_grid;
-        w->graph_joint_stages = w->plan_joint_stages; w->graph_no_global = w->plan_no_global; w->graph_fused = w->plan_fused;
+        w->graph_joint_stages = w->plan_joint_stages; w->graph_no_global = w->plan_no_global; w->graph_fused = w->plan_fused; w->graph_tile_grid = w->plan_tile_grid;
     }
     // keep the host at most a few steps ahead of the device so the hints stay fresh (the device
     // never idles: several step graphs are always queued)
@@ -2307,6 +2329,7 @@ extern "C" int32_t rp_counters_read(rp_world *w, rp_counters *out) {
     out->overflow_flags = fl[FL_OVERFLOW];
     out->quarantined = fl[FL_QUARANTINE];
     out->ccd_active_count = fl[FL_CCD_ACTIVE]; out->ccd_clamp_count = fl[FL_CCD_CLAMPS];
+    out->num_tiles = fl[FL_N_TILES]; out->tile_sweeps = (w->graph_tile_grid > 0 && !w->plan_single) ? 1 : 0;
     out->fast_steps = (int32_t)w->fast_steps; out->full_steps = (int32_t)w->full_steps; out->replayed_steps = (int32_t)w->replayed_steps;
     if (w->dw.sleep_enabled && w->dw.n_bodies > 0) {
         std::vector<int> bfl(w->dw.n_bodies);

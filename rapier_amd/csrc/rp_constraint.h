@@ -24,6 +24,10 @@ RP_DEV Sym3 load_ii(const DevWorld &w, int gid) {
     return m;
 }
 
+// the plane that currently holds `plane`: the six mutable planes live in place (par = 0) or in the shadow planes behind CP_COUNT (par = 1)
+RP_DEV int cplane_mut_index(int plane) { return plane == CP_HM0 ? 4 : (plane == CP_HM1 ? 5 : ((plane >= CP_N0 && (plane - CP_N0) % 7 == NP_M) ? (plane - CP_N0) / 7 : -1)); }
+RP_DEV int cplane(int plane, int par) { const int m = cplane_mut_index(plane); return (m >= 0 && par) ? CP_COUNT + m : plane; }
+
 // ---- accessor over HBM ------------------------------------------------------------------------
 // PRELOAD (a trait of every accessor): the constraint functions fetch every input they read before storing their first row, instead
 // of point by point.  Measured on b3d_large_pyramid: it pays in k_generate (whose inputs — solver contacts, tracked impulses, lever
@@ -38,8 +42,8 @@ struct GlobalAccT {
     static constexpr bool PRELOAD = PRE;
     const DevWorld &w; int pos;
     RP_DEV GlobalAccT(const DevWorld &w_, int pos_) : w(w_), pos(pos_) {}
-    RP_DEV float4 ld(int plane) const { return w.C[(size_t)plane * w.cons_cap + pos]; }
-    RP_DEV void st(int plane, float4 v) const { w.C[(size_t)plane * w.cons_cap + pos] = v; }
+    RP_DEV float4 ld(int plane) const { return w.C[(size_t)cplane(plane, w.c_par) * w.cons_cap + pos]; }
+    RP_DEV void st(int plane, float4 v) const { w.C[(size_t)cplane(plane, w.c_par) * w.cons_cap + pos] = v; }
     RP_DEV int id1() const { return w.k_b1[pos]; }
     RP_DEV int id2() const { return w.k_b2[pos]; }
     RP_DEV int n() const { return w.k_n[pos]; }

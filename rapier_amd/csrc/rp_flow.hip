@@ -193,13 +193,7 @@ struct FlowJointIO {
 };
 
 // ---- toucher lists: ranks of every constraint / joint among the events of its bodies (rebuilt when the layout changed) ---
-RP_DEV void flow_ids(const DevWorld &w, int pos, int &id1, int &id2) { // the solver bodies g_generate will attach
-    int s = w.cons_pair[pos];
-    int rb1 = w.c_parent[w.p_c1[s]], rb2 = w.c_parent[w.p_c2[s]];
-    int rel_dom = w.p_reldom[s];
-    id1 = (body_active(w, rb1) && rel_dom <= 0) ? rb1 : -1;
-    id2 = (body_active(w, rb2) && rel_dom >= 0) ? rb2 : -1;
-}
+// (flow_ids: rp_global.h)
 RP_DEV int flow_live_joints(const DevWorld &w) { return w.n_joints > 0 ? w.flags[FL_NJ_OVF_BEGIN] + w.flags[FL_NJ_OVF_COUNT] : 0; }
 // pass 0: count (into the fill cursors, which rest at zero between rebuilds)
 RP_DEV void flow_count(DevWorld &w, int gid, int stride) {
@@ -254,8 +248,8 @@ RP_DEV void flow_rank(DevWorld &w, int gid, int stride) {
     for (int pos = gid; pos < M; pos += stride) {
         int a, b; flow_ids(w, pos, a, b);
         int2 r = make_int2(-1, -1);
-        if (a >= 0) { r.x = flow_rank_in(w.f_adj, w.fb_begin[a].x, w.fb_deg[a].x, pos); w.f_sorted[w.fb_begin[a].x + r.x] = pos; }
-        if (b >= 0) { r.y = flow_rank_in(w.f_adj, w.fb_begin[b].x, w.fb_deg[b].x, pos); w.f_sorted[w.fb_begin[b].x + r.y] = pos; }
+        if (a >= 0) { r.x = flow_rank_in(w.f_adj, w.fb_begin[a].x, w.fb_deg[a].x, pos); w.f_sorted[w.fb_begin[a].x + r.x] = 2 * pos; w.f_other[w.fb_begin[a].x + r.x] = b; }
+        if (b >= 0) { r.y = flow_rank_in(w.f_adj, w.fb_begin[b].x, w.fb_deg[b].x, pos); w.f_sorted[w.fb_begin[b].x + r.y] = 2 * pos + 1; w.f_other[w.fb_begin[b].x + r.y] = a; }
         w.fk_rank[pos] = r;
     }
     for (int idx = gid; idx < njl; idx += stride) {

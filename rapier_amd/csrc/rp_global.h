@@ -67,6 +67,62 @@ RP_DEV bool g_generate(const DevWorld &w, int pos) {
     return cons_generate(w, GlobalAccT<PRE>(w, pos), s, id1, id2, id1, id2);
 }
 
+// the solver bodies g_generate will attach to the manifold at `pos` (toucher lists of rp_flow.hip, tiling of rp_tiles.hip)
+RP_DEV void flow_ids(const DevWorld &w, int pos, int &id1, int &id2) {
+    int s = w.cons_pair[pos];
+    int rb1 = w.c_parent[w.p_c1[s]], rb2 = w.c_parent[w.p_c2[s]];
+    int rel_dom = w.p_reldom[s];
+    id1 = (body_active(w, rb1) && rel_dom <= 0) ? rb1 : -1;
+    id2 = (body_active(w, rb2) && rel_dom >= 0) ? rb2 : -1;
+}
+
+// ---- body-centric warm start (rp_solver.hip: k_ws_prepare writes the terms, k_increment_ws / the tile sweeps add them) ----
+#define WS_TERMS 11
+// ws_terms = [11][2 * cons_cap] planes indexed by 2 * position + side: the writes of k_ws_prepare are coalesced plane by plane (a
+// per-body layout, one contiguous run of terms per body, was measured: the scattered 176-byte writes doubled k_ws_prepare and
+// bought the accumulation nothing).  `row` = 2 * pos + side, -1 for a world-attached side.
+RP_DEV void ws_put(const DevWorld &w, int slot, int row, V3 v) { if (row >= 0) w.ws_terms[(size_t)slot * (2 * (size_t)w.cons_cap) + row] = f4(v, 0.0f); }
+RP_DEV V3 ws_get(const DevWorld &w, int slot, int row) { return v3(w.ws_terms[(size_t)slot * (2 * (size_t)w.cons_cap) + row]); }
+// S2 + the warm start of one global-path body: increment (+ gyroscopic term), then its touchers' terms in sweep order (f_sorted holds the
+// term row 2 * position + side of every toucher), each added exactly as the colour sweep would have added it (same operands, same order
+// per accumulator).  The loads are batched — every row index of up to eight touchers, then their point counts and the terms two
+// touchers at a time (all eleven terms of a side: the slots of unused points hold stale values that are fetched and ignored) — so the
+// chain is ~5 round trips instead of three per toucher (measured as the prologue of the tile sweeps: 24 us before).
+RP_DEV void ws_fetch(const DevWorld &w, int row, float4 (&tm)[WS_TERMS]) {
+#pragma unroll
+    for (int s = 0; s < WS_TERMS; ++s) tm[s] = w.ws_terms[(size_t)s * (2 * (size_t)w.cons_cap) + row];
+}
+RP_DEV void ws_accumulate(V3 &lin, V3 &ang, const float4 (&tm)[WS_TERMS], int n) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { if (k >= n) break; lin = lin + v3(tm[k]); ang = ang + v3(tm[5 + k]); }
+    lin = lin + v3(tm[4]);
+    ang = ang + v3(tm[9]);
+    if (n > 1) ang = ang + v3(tm[10]);
+}
+RP_DEV void body_increment_ws(const DevWorld &w, int i, V3 &lin, V3 &ang) {
+    lin = v3(w.s_lin[i]); ang = v3(w.s_ang[i]);
+    const int2 beg2 = w.fb_begin[i], deg2 = w.fb_deg[i];
+    body_increment(w, w.b_flags[i], lin, ang, q4(w.s_rot[i]), v3(w.s_incl[i]), v3(w.s_inca[i]), v3(w.b_invpi[i]), q4(w.b_pframe[i]));
+    if (w.prm.p.warmstart_coefficient == 0.0f) return;
+    const int beg = beg2.x, deg = deg2.x;
+    for (int r0 = 0; r0 < deg; r0 += 8) { // this body's constraints in sweep order, eight at a time
+        int rows[8], ns[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rows[j] = r0 + j < deg ? w.f_sorted[beg + r0 + j] : -1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ns[j] = rows[j] >= 0 ? w.k_n[rows[j] >> 1] : 0;
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+            if (rows[j] < 0) break;
+            float4 ta[WS_TERMS], tb[WS_TERMS];
+            ws_fetch(w, rows[j], ta);
+            if (rows[j + 1] >= 0) ws_fetch(w, rows[j + 1], tb);
+            ws_accumulate(lin, ang, ta, ns[j]);
+            if (rows[j + 1] >= 0) ws_accumulate(lin, ang, tb, ns[j + 1]);
+        }
+    }
+}
+
 // Serial tail of one sweep (worker 0 of the reference): stages [first, n_stages) one after the other
 // inside one workgroup, then the overflow colour on lane 0.
 template <int MODE, bool COUL, bool PRE = false>

@@ -216,6 +216,7 @@ RP_DEV void lay_isl_fill(DevWorld &w, int gid, int stride, int *hist, int &n_glo
             if (color <= RP_COLOR_OVERFLOW) atomicAdd(&hist[color], 1);
             if (color < RP_COLOR_OVERFLOW) { // owner = the first awake dynamic body: at most one manifold per colour names it
                 int owner = body_dyn_awake(w, b1) ? b1 : b2;
+                if (w.b_order) owner = w.b_order[owner]; // worlds that tile: the owners' Morton order (rp_tiles.hip), any injective order will do
                 atomicOr(&w.cb_bits[(size_t)color * w.cb_words + (owner >> 5)], 1u << (owner & 31));
             }
         }
@@ -319,6 +320,7 @@ RP_DEV void lay_bucket_scatter(DevWorld &w, int gid, int stride, int *cnt, int *
         else {
             int2 rb = w.p_rb[s];
             int owner = body_dyn_awake(w, rb.x) ? rb.x : rb.y;
+            if (w.b_order) owner = w.b_order[owner];
             size_t wi = (size_t)color * w.cb_words + (owner >> 5);
             pos = w.color_begin[color] + w.cb_prefix[wi] + __popc(w.cb_bits[wi] & ((1u << (owner & 31)) - 1u));
         }

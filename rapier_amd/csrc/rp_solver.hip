@@ -19,6 +19,8 @@
 // No FMA contraction (-ffp-contract=off), IEEE divide/sqrt: same arithmetic as the reference's lanes.
 #include "rp_global.h"
 #include "rp_groups.h"
+#include <utility>
+#include <cstdlib>
 
 // ---- MULTI mode kernels ---------------------------------------------------------------------------
 __global__ void k_solver_begin(DevWorld w) {
@@ -55,13 +57,7 @@ __global__ void k_integrate(DevWorld w) {
 //   k_increment_ws  every body: increment (+ gyroscopic term), then its touchers' terms in sweep order (f_sorted, built with the
 //                   dataflow solver's toucher ranks), each added exactly as the colour sweep would have added it.
 // Same operands, same order per accumulator (-ffp-contract=off): bit-identical to the per-colour sweep and to the oracle.
-#define WS_TERMS 11
-#define WS_TERMS 11
-// ws_terms = [11][2 * cons_cap] planes indexed by 2 * position + side: the writes of k_ws_prepare are coalesced plane by plane (a
-// per-body layout, one contiguous run of terms per body, was measured: the scattered 176-byte writes doubled k_ws_prepare and
-// bought the accumulation nothing).  `row` = 2 * pos + side, -1 for a world-attached side.
-RP_DEV void ws_put(const DevWorld &w, int slot, int row, V3 v) { if (row >= 0) w.ws_terms[(size_t)slot * (2 * (size_t)w.cons_cap) + row] = f4(v, 0.0f); }
-RP_DEV V3 ws_get(const DevWorld &w, int slot, int row) { return v3(w.ws_terms[(size_t)slot * (2 * (size_t)w.cons_cap) + row]); }
+// (WS_TERMS, ws_put / ws_get, body_increment_ws: rp_global.h — shared with the tile sweeps of rp_tiles.hip)
 __global__ void __launch_bounds__(256) k_ws_prepare(DevWorld w, float solved_dt) {
     int M = w.flags[FL_N_CONS];
     if (M > w.cons_cap) M = w.cons_cap;
@@ -129,21 +125,8 @@ __global__ void __launch_bounds__(256) k_ws_prepare(DevWorld w, float solved_dt)
 __global__ void __launch_bounds__(256) k_increment_ws(DevWorld w) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= w.n_bodies || !global_body(w, i)) return;
-    V3 lin = v3(w.s_lin[i]), ang = v3(w.s_ang[i]);
-    body_increment(w, w.b_flags[i], lin, ang, q4(w.s_rot[i]), v3(w.s_incl[i]), v3(w.s_inca[i]), v3(w.b_invpi[i]), q4(w.b_pframe[i]));
-    if (w.prm.p.warmstart_coefficient != 0.0f) {
-        const int beg = w.fb_begin[i].x, deg = w.fb_deg[i].x;
-        for (int r = 0; r < deg; ++r) { // this body's constraints in sweep order
-            const int pos = w.f_sorted[beg + r];
-            const int row = w.k_b1[pos] == i ? 2 * pos : 2 * pos + 1;
-            const int n = w.k_n[pos];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { if (k >= n) break; lin = lin + ws_get(w, k, row); ang = ang + ws_get(w, 5 + k, row); }
-            lin = lin + ws_get(w, 4, row);
-            ang = ang + ws_get(w, 9, row);
-            if (n > 1) ang = ang + ws_get(w, 10, row);
-        }
-    }
+    V3 lin, ang;
+    body_increment_ws(w, i, lin, ang);
     w.s_lin[i] = f4(lin, 0.0f); w.s_ang[i] = f4(ang, 0.0f);
 }
 
@@ -288,23 +271,39 @@ void rp_launch_global_single(const DevWorld &w, hipStream_t st, int has_restitut
     else hipLaunchKernelGGL(k_global_single<false>, dim3(1), dim3(512), 0, st, w, has_restitution, fast);
 }
 void rp_launch_flow_ranks(const DevWorld &w, hipStream_t st);
+void rp_launch_tiles_build(const DevWorld &w, hipStream_t st);
+void rp_launch_tile_sweep(const DevWorld &w, hipStream_t st, int mode, int grid, int friction_in_bias, float solved_dt, int fuse);
 void rp_launch_solver_assembly(const DevWorld &w, hipStream_t st) {
     rp_launch_flow_ranks(w, st); // the per-body toucher lists of the body-centric warm start (only rebuilt when the layout changed)
+    rp_launch_tiles_build(w, st); // ... and the LDS tiling of the big component (rp_tiles.hip; same gate)
     hipLaunchKernelGGL(k_solver_begin, dim3(body_blocks(w)), dim3(256), 0, st, w);
     if (host_coulomb(w)) hipLaunchKernelGGL(k_generate<true>, dim3(cons_blocks(w)), dim3(256), 0, st, w);
     else hipLaunchKernelGGL(k_generate<false>, dim3(cons_blocks(w)), dim3(256), 0, st, w);
 }
 // The TGS loop proper: S2..S7 for every substep (+ S8 restitution) — worker.rs:207-734.
-void rp_launch_solver_loop(const DevWorld &w, hipStream_t st, int parallel_stages, int stage_blocks, int has_restitution, int joint_stages) {
+// tile_grid > 0: every biased / relaxed sweep is ONE launch over the LDS tiles (rp_tiles.hip) instead of one per colour stage.  A tile
+// sweep reads the solver velocities from one buffer and writes the other, so the kernels that follow get a DevWorld with the two
+// pointer pairs swapped; returns the parity (1 = the velocities ended in t_lin / t_ang) for rp_launch_solver_writeback.
+int rp_launch_solver_loop(const DevWorld &w0, hipStream_t st, int parallel_stages, int stage_blocks, int has_restitution, int joint_stages, int tile_grid) {
     SolverLaunchPlan plan = {parallel_stages, stage_blocks < 1 ? 1 : stage_blocks};
+    DevWorld w = w0;
+    int parity = 0; // bit 0: velocities + mutable constraint planes in the other copy, bit 1: poses in the other copy
+    const bool tiles = tile_grid > 0 && w.tile_cap > 0 && w.n_joints == 0 && !host_coulomb(w) && w.ws_terms;
     int nb = body_blocks(w);
     const rp_integration_params &p = w.prm.p;
     int fib = (p.friction_in_bias_pass || p.num_internal_stabilization_iterations == 0) ? 1 : 0;
+    // with tiles the first biased sweep of a substep also increments + warm-starts the bodies, the last one also integrates them
+    static const int fuse_mask = getenv("RP_TILE_FUSE") ? atoi(getenv("RP_TILE_FUSE")) : 2; // (experiments: 0 = k_increment_ws / k_integrate stay launches)
+    const bool can_fuse = tiles && p.num_internal_pgs_iterations >= 1;
+    const bool fuse_inc = can_fuse && (fuse_mask & 1), fuse_int = can_fuse && (fuse_mask & 2);
+#define TILE_SWEEP(MODE, SDT, FUSE) do { const int fuse_ = (FUSE); rp_launch_tile_sweep(w, st, MODE, tile_grid, fib, SDT, fuse_); \
+        std::swap(w.s_lin, w.t_lin); std::swap(w.s_ang, w.t_ang); w.c_par ^= 1; parity ^= 1; \
+        if (fuse_ & 2) { std::swap(w.s_rot, w.t_rot); std::swap(w.s_trans, w.t_trans); parity ^= 2; } } while (0)
     for (int s = 0; s < w.prm.num_substeps; ++s) {
         float solved_dt = (float)s * w.prm.dt_sub;
         if (!host_coulomb(w) && w.ws_terms) { // body-centric warm start: two launches instead of one per colour
             hipLaunchKernelGGL(k_ws_prepare, dim3(cons_blocks(w)), dim3(256), 0, st, w, solved_dt);
-            hipLaunchKernelGGL(k_increment_ws, dim3(nb), dim3(256), 0, st, w);
+            if (!fuse_inc) hipLaunchKernelGGL(k_increment_ws, dim3(nb), dim3(256), 0, st, w);
             rp_launch_joint_update(w, st, s);
         } else {
             hipLaunchKernelGGL(k_increment, dim3(nb), dim3(256), 0, st, w);
@@ -313,17 +312,23 @@ void rp_launch_solver_loop(const DevWorld &w, hipStream_t st, int parallel_stage
         }
         for (int it = 0; it < p.num_internal_pgs_iterations; ++it) {
             rp_launch_joint_sweep(w, st, joint_stages, 0, (p.warmstart_joints && it == 0) ? 1 : 0); // all joints before any contact
-            launch_sweep<MODE_BIAS>(w, st, plan, fib, solved_dt);
+            if (tiles) TILE_SWEEP(MODE_BIAS, solved_dt, ((fuse_inc && it == 0) ? 1 : 0) | ((fuse_int && it == p.num_internal_pgs_iterations - 1) ? 2 : 0));
+            else launch_sweep<MODE_BIAS>(w, st, plan, fib, solved_dt);
         }
-        hipLaunchKernelGGL(k_integrate, dim3(nb), dim3(256), 0, st, w);
+        if (!fuse_int) hipLaunchKernelGGL(k_integrate, dim3(nb), dim3(256), 0, st, w);
         for (int it = 0; it < p.num_internal_stabilization_iterations; ++it) {
             rp_launch_joint_sweep(w, st, joint_stages, 1, 0);
-            launch_sweep<MODE_RELAX>(w, st, plan, fib, solved_dt + w.prm.dt_sub);
+            if (tiles) TILE_SWEEP(MODE_RELAX, solved_dt + w.prm.dt_sub, 0); else launch_sweep<MODE_RELAX>(w, st, plan, fib, solved_dt + w.prm.dt_sub);
         }
     }
+#undef TILE_SWEEP
     if (has_restitution) launch_sweep<MODE_RESTITUTION>(w, st, plan, fib, 0.0f);
+    return parity;
 }
-void rp_launch_solver_writeback(const DevWorld &w, hipStream_t st) {
+void rp_launch_solver_writeback(const DevWorld &w0, hipStream_t st, int parity) {
+    DevWorld w = w0;
+    if (parity & 1) { std::swap(w.s_lin, w.t_lin); std::swap(w.s_ang, w.t_ang); w.c_par = 1; } // the tile sweeps left the velocities (and the mutable constraint planes) in the other copy
+    if (parity & 2) { std::swap(w.s_rot, w.t_rot); std::swap(w.s_trans, w.t_trans); } // ... and the poses
     if (host_coulomb(w)) hipLaunchKernelGGL(k_writeback_impulses<true>, dim3(cons_blocks(w)), dim3(256), 0, st, w);
     else hipLaunchKernelGGL(k_writeback_impulses<false>, dim3(cons_blocks(w)), dim3(256), 0, st, w);
     rp_launch_joint_writeback(w, st);

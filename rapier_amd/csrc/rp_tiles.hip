@@ -1,0 +1,486 @@
+// rp_tiles.hip — a whole colour sweep of a giant island inside one CU per tile.
+//
+// What it replaces: on the global path (rp_solver.hip) every colour stage of every sweep is a kernel launch — StagedIslandSolver's
+// stage machine (/root/reference/src/dynamics/solver/staged_island_solver/{worker.rs:438-734, solve.rs:12-92, sync.rs:39-186}) pays a
+// worker barrier at the same places.  On MI355X any dependent cross-CU exchange (launch boundary, grid barrier, per-body hand-off:
+// all three measured) costs 5-9 us, so a step of b3d_large_pyramid (one island of 20,100 bodies, 4 substeps x 2
+// sweeps x 7 colours) spent ~0.5 ms on 64 stage launches.  A workgroup barrier costs ~0.2 us.  So the island is cut into TILES:
+//
+//   * the global-path bodies are ordered along a Morton curve of their centres of mass (counting sort by cell) and cut into runs of T
+//     bodies: tile = the bodies one workgroup OWNS;
+//   * a tile's CONE is everything the state of its owned bodies after a whole sweep depends on: walking the sweep's stages backwards,
+//     every constraint of stage s that touches a body already needed is taken in and its bodies become needed for the stages before s.
+//     Dependencies only run along paths of strictly decreasing stage, so the cone is a thin halo, not the H-ring neighbourhood;
+//   * one workgroup loads the velocities of its cone bodies into LDS, runs ALL stages of the sweep over its cone constraints with a
+//     workgroup barrier between stages, and writes back the bodies it owns.  Halo constraints are solved redundantly by every tile
+//     whose cone holds them — on identical inputs, in the reference's order per body, hence with identical bits (-ffp-contract=off);
+//     only the tile that owns a constraint's first body stores its rows;
+//   * the velocities are double-buffered (s_lin / s_ang <-> t_lin / t_ang): a tile reads its halo from the buffer the previous kernel
+//     left and writes its owned bodies to the other one, so no tile ever sees another tile's result of the same sweep.
+//
+// A sweep is then ONE launch (8 per step instead of 64) whose critical path is stages x (row fetch + ~100 dependent flops + barrier).
+// The arithmetic is cons_solve / cons_restitution of rp_constraint.h through an accessor: same operands, same order per accumulator as
+// the per-stage launches, the dataflow launch and the oracle.  Tilings are rebuilt on the device when the constraint layout changes
+// (FL_FLOW_DIRTY) and verified there: a world the tiling cannot hold (overflow colour in use, cone larger than the LDS budget, fewer
+// than RP_TILE_MIN_BODIES bodies) publishes FL_N_TILES = 0 and keeps the per-stage launches; a sweep kernel that finds no tiling runs
+// the sweep in one workgroup (correct, slow) until the host has read the hint.
+#include "rp_global.h"
+#include "rp_gridbar.h"
+
+#define RP_TILE_THREADS 256
+#define RP_TILE_HASH 4096 // slots of the body -> local id table of one tile (> 2 x RP_TILE_BCAP)
+
+// floats as order-preserving unsigned keys (atomicMin / atomicMax over the centres of mass)
+RP_DEV unsigned tile_ord(float f) { unsigned u = (unsigned)__float_as_int(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+RP_DEV float tile_unord(unsigned u) { u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u; return __int_as_float((int)u); }
+RP_DEV unsigned tile_hash(int g) { return ((unsigned)g * 2654435761u) >> 20; } // 12 bits
+
+// ---- tiling (one launch behind grid barriers, only when the layout changed) --------------------------------------------------------
+// k_tiles_sort orders the bodies along a Morton curve and produces two things:
+//   * tl_owned / tl_body_tile: the global-path bodies in curve order, cut into tiles of T;
+//   * b_order: the curve rank of EVERY body (a permutation of the body indices).  The NEXT layout rebuild ranks the manifolds of a colour
+//     stage by the order value of their owner body (k_layout_rebuild, rp_islands.hip) instead of its arena index, so the rows a tile
+//     fetches in one stage are runs of consecutive positions — with index order a tile's 16-byte rows each sat in a cache line of their
+//     own and the sweeps were bound by the CU's L2 bandwidth (128 B fetched per 16 B used; measured: 4 us per relaxed stage).
+//     Positions inside a stage never matter for the result (a colour is body-disjoint), and any injective order is valid: bodies
+//     inserted after a sort keep b_order[i] = i, which lies above every rank handed out before.
+__global__ void __launch_bounds__(1024) k_tiles_sort(DevWorld w) {
+    if (!w.flags[FL_FLOW_DIRTY]) return; // (cleared by k_solver_begin, which runs after this kernel)
+    const int gid = gbar_item(), gstride = gridDim.x * blockDim.x, t = threadIdx.x;
+    int M = w.flags[FL_N_CONS]; if (M > w.cons_cap) M = w.cons_cap;
+    const int nst = w.flags[FL_N_STAGES], nb = w.n_bodies;
+    if (w.flags[FL_N_GLOB_BODIES] < w.tile_min || M < w.tile_min || w.flags[FL_HAS_OVERFLOW_COLOR] || nst > RP_TILE_STAGES || nst < 1) {
+        if (gid == 0) { w.flags[FL_N_TILES] = 0; w.tl_bbox[8] = 0u; w.dbg[900] += 1; w.dbg[901] = 1; } // nothing worth tiling / a serial overflow colour: colour stages stay launches
+        return;
+    }
+    GridBar bar = gbar_begin(w, 4);
+    // pass 0: the solver bodies of every position; bounding box of the centres of mass (tl_bbox rests at min = ~0, max = 0)
+    for (int pos = gid; pos < M; pos += gstride) { int a, b; flow_ids(w, pos, a, b); w.fk_ids[pos] = make_int2(a, b); }
+    for (int i0 = gid - (t & 63); i0 < nb; i0 += gstride) { // (wave-uniform trip count: one atomic per wavefront and bound, not per body)
+        const int i = i0 + (t & 63);
+        unsigned lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
+        if (i < nb) {
+            const float4 c = w.b_wcom[i];
+            if (isfinite(c.x) && isfinite(c.y) && isfinite(c.z)) { lo[0] = hi[0] = tile_ord(c.x); lo[1] = hi[1] = tile_ord(c.y); lo[2] = hi[2] = tile_ord(c.z); }
+        }
+        for (int off = 32; off > 0; off >>= 1)
+            for (int a = 0; a < 3; ++a) {
+                const unsigned l2 = (unsigned)__shfl_xor((int)lo[a], off, 64), h2 = (unsigned)__shfl_xor((int)hi[a], off, 64);
+                lo[a] = l2 < lo[a] ? l2 : lo[a]; hi[a] = h2 > hi[a] ? h2 : hi[a];
+            }
+        if ((t & 63) == 0 && hi[0] != 0u)
+            for (int a = 0; a < 3; ++a) { atomicMin(&w.tl_bbox[a], lo[a]); atomicMax(&w.tl_bbox[3 + a], hi[a]); }
+    }
+    GBAR_SYNC(bar);
+    // pass 1: Morton cell of every body.  The 12 cell bits go to the axes greedily (always to the axis whose cells are the longest), so
+    // a flat scene spends none on its thin axis; the interleaving follows the same order, most significant bit first.
+    {
+        float mn[3], ex[3], cs[3];
+        for (int a = 0; a < 3; ++a) { mn[a] = tile_unord(w.tl_bbox[a]); ex[a] = tile_unord(w.tl_bbox[3 + a]) - mn[a]; if (!(ex[a] > 0.0f)) ex[a] = 0.0f; cs[a] = ex[a]; }
+        int bits[3] = {0, 0, 0};
+        unsigned ordw = 0;
+        for (int k = 0; k < 12; ++k) {
+            int a = (cs[1] > cs[0]) ? 1 : 0; if (cs[2] > cs[a]) a = 2;
+            ordw |= (unsigned)a << (2 * k); bits[a]++; cs[a] *= 0.5f;
+        }
+        for (int i = gid; i < nb; i += gstride) {
+            const float4 c = w.b_wcom[i];
+            const float p[3] = {c.x, c.y, c.z};
+            int q[3], rem[3];
+            for (int a = 0; a < 3; ++a) {
+                const int n = 1 << bits[a];
+                int v = (ex[a] > 0.0f && isfinite(p[a])) ? (int)((p[a] - mn[a]) / ex[a] * (float)n) : 0;
+                q[a] = v < 0 ? 0 : (v > n - 1 ? n - 1 : v); rem[a] = bits[a];
+            }
+            int cell = 0;
+            for (int k = 0; k < 12; ++k) { const int a = (ordw >> (2 * k)) & 3; rem[a]--; cell = (cell << 1) | ((q[a] >> rem[a]) & 1); }
+            const bool glob = global_body(w, i);
+            atomicAdd(&w.tl_hist[cell], 1);
+            if (glob) atomicAdd(&w.tl_hist[RP_TILE_CELLS + cell], 1);
+            w.tl_cell[i] = glob ? cell : -1 - cell; // (the sign carries "on the global path")
+        }
+    }
+    GBAR_SYNC(bar);
+    // pass 2: exclusive scans of the two cell histograms (workgroup 0; 4 cells per thread): every body / global-path bodies; the
+    // histograms go back to zero and serve as fill cursors in pass 3
+    if (blockIdx.x == 0) {
+        __shared__ int sc[1024];
+        for (int which = 0; which < 2; ++which) {
+            int *hist = w.tl_hist + which * RP_TILE_CELLS, *ofs = w.tl_cellofs + which * RP_TILE_CELLS;
+            const int base = t * (RP_TILE_CELLS / 1024);
+            int sum = 0;
+            for (int k = 0; k < RP_TILE_CELLS / 1024; ++k) sum += hist[base + k];
+            __syncthreads();
+            sc[t] = sum;
+            __syncthreads();
+            for (int off = 1; off < 1024; off <<= 1) { int v = t >= off ? sc[t - off] : 0; __syncthreads(); sc[t] += v; __syncthreads(); }
+            int run = sc[t] - sum;
+            for (int k = 0; k < RP_TILE_CELLS / 1024; ++k) { int h = hist[base + k]; ofs[base + k] = run; run += h; hist[base + k] = 0; }
+            if (which == 1 && t == 1023) w.tl_bbox[6] = (unsigned)sc[1023]; // global-path bodies
+        }
+    }
+    GBAR_SYNC(bar);
+    // pass 3: every body takes a slot of its cell's segment (tl_sorted: the input of the order pass in k_tiles_cones); a global-path body
+    // also takes its rank among the global-path bodies -> owner tile (the order inside a cell is whatever the atomics make it: a tiling
+    // only schedules the work, any partition gives the same bits)
+    const int NG = (int)w.tl_bbox[6];
+    int T = (NG + w.tile_target - 1) / w.tile_target; T = T < 64 ? 64 : (T > 256 ? 256 : T);
+    const int NT = (NG + T - 1) / T;
+    const bool fits = NT >= 1 && NT <= w.tile_cap;
+    for (int i = gid; i < nb; i += gstride) {
+        const int cc = w.tl_cell[i], cell = cc >= 0 ? cc : -1 - cc;
+        w.tl_sorted[w.tl_cellofs[cell] + atomicAdd(&w.tl_hist[cell], 1)] = i;
+        int tile = -1;
+        if (cc >= 0 && fits) { const int r = w.tl_cellofs[RP_TILE_CELLS + cell] + atomicAdd(&w.tl_hist[RP_TILE_CELLS + cell], 1); w.tl_owned[r] = i; tile = r / T; }
+        w.tl_body_tile[i] = tile;
+    }
+    if (gid == 0) { // (dbg[900..]: statistics of the last tiling, tools/tile_diag.py)
+        w.flags[FL_N_TILES] = fits ? NT : 0;
+        w.tl_bbox[7] = (unsigned)T; w.tl_bbox[8] = 1u; w.tl_bbox[9] = (unsigned)nb; // [8]: the sort ran — k_tiles_cones derives b_order from it
+        w.dbg[900] += 1; w.dbg[901] = fits ? 0 : 2; w.dbg[902] = NG; w.dbg[903] = NT; w.dbg[904] = T; w.dbg[905] = 0; w.dbg[906] = 0; w.dbg[907] = 0; w.dbg[908] = 0;
+    }
+    // the scratch of the sort goes back to its rest state once the ranks are out: by the cone kernel (next launch: a kernel boundary)
+    gbar_end(bar);
+}
+
+// The cone of every tile (see the file header): one workgroup per tile, launched behind k_tiles_sort.
+// The needed-bodies table of a tile lives in LDS: arena index -> begin of the body's sweep-ordered toucher list, and one packed word
+// (tile-local id | list entries still ahead | the stage at which the body joined the cone: it takes part in the stages BEFORE that one,
+// owned bodies in all of them).
+#define TW_LID(wd) ((wd) & 0x7ff)
+#define TW_CUR(wd) (((wd) >> 11) & 0x1fff)
+#define TW_SINCE(wd) ((wd) >> 24)
+#define TW_PACK(since, cur, lid) (((since) << 24) | ((cur) << 11) | (lid))
+struct TileTab { int *hk, *hw, *hbeg, *live, *nloc, *bad; }; // live[tile-local id] = slot: the walkers go over the bodies, not over the (sparse) table
+RP_DEV void tile_insert(const TileTab &T, int g, int since, int cursor, int begin) {
+    unsigned h = tile_hash(g) & (RP_TILE_HASH - 1);
+    for (int probes = 0; probes < RP_TILE_HASH; ++probes) {
+        int old = atomicCAS(&T.hk[h], -1, g);
+        if (old == -1) {
+            const int lid = atomicAdd(T.nloc, 1);
+            if (lid >= RP_TILE_BCAP || cursor > 0x1fff) { *T.bad = 1; return; } // (the word keeps its rest value: since = -1, never walked)
+            T.hbeg[h] = begin; T.hw[h] = TW_PACK(since, cursor, lid); T.live[lid] = (int)h;
+            return;
+        }
+        if (old == g) return;
+        if (*T.bad) return; // over budget: the tiling is being abandoned, do not fill the table
+        h = (h + 1) & (RP_TILE_HASH - 1);
+    }
+    *T.bad = 1;
+}
+RP_DEV int tile_find(const TileTab &T, int g) { // slot of body g or -1
+    unsigned h = tile_hash(g) & (RP_TILE_HASH - 1);
+    for (int probes = 0; probes < RP_TILE_HASH; ++probes) {
+        int k = T.hk[h];
+        if (k == g) return (int)h;
+        if (k == -1) return -1;
+        h = (h + 1) & (RP_TILE_HASH - 1);
+    }
+    return -1;
+}
+#define RP_CONE_THREADS 512
+__global__ void __launch_bounds__(RP_CONE_THREADS) k_tiles_cones(DevWorld w) {
+    if (!w.flags[FL_FLOW_DIRTY]) return;
+    const int t = threadIdx.x, nt = blockDim.x, gid = blockIdx.x * nt + t, gstride = gridDim.x * nt;
+    for (int idx = gid; idx < 2 * RP_TILE_CELLS; idx += gstride) w.tl_hist[idx] = 0; // rest state of the sort scratch
+    if (gid == 0) { w.tl_bbox[0] = w.tl_bbox[1] = w.tl_bbox[2] = 0xffffffffu; w.tl_bbox[3] = w.tl_bbox[4] = w.tl_bbox[5] = 0u; }
+    if (w.tl_bbox[8]) {
+        // the curve rank of every body, deterministic: begin of its cell's segment + the bodies of that cell with a smaller index (the
+        // slots inside a segment were handed out by atomics; a cell holds a handful of bodies)
+        const int nb = (int)w.tl_bbox[9]; // bodies the sort covered
+        for (int i = gid; i < nb; i += gstride) {
+            const int cc = w.tl_cell[i], cell = cc >= 0 ? cc : -1 - cc;
+            const int beg = w.tl_cellofs[cell], end = cell + 1 < RP_TILE_CELLS ? w.tl_cellofs[cell + 1] : nb;
+            int r = 0;
+            for (int k = beg; k < end; ++k) r += w.tl_sorted[k] < i;
+            w.b_order[i] = beg + r;
+        }
+        // the first sort of a world: its layout was still built in arena-index order — have the next step rebuild it along the curve
+        if (gid == 0) { if (w.tl_bbox[10] == 0u) w.flags[FL_LAYOUT_DIRTY] = 1; w.tl_bbox[10] += 1u; }
+    }
+    const int NT = w.flags[FL_N_TILES];
+    if (NT <= 0) return;
+    const int nst = w.flags[FL_N_STAGES], NG = (int)w.tl_bbox[6], T = (int)w.tl_bbox[7];
+    __shared__ int hk[RP_TILE_HASH], hw[RP_TILE_HASH], hbeg[RP_TILE_HASH];
+    __shared__ int live[RP_TILE_BCAP], cpos[RP_TILE_CCAP / 2], ssoff[RP_TILE_STAGES + 2];
+    __shared__ int nloc, ncons, bad, nsnap;
+    const TileTab Tb = {hk, hw, hbeg, live, &nloc, &bad};
+    for (int tile = blockIdx.x; tile < NT; tile += gridDim.x) {
+        __syncthreads();
+        for (int h = t; h < RP_TILE_HASH; h += nt) { hk[h] = -1; hw[h] = (int)0xff000000; } // (a slot claimed during a stage shows since = -1 until its owner has filled it in: skipped)
+        if (t == 0) { nloc = 0; ncons = 0; bad = 0; }
+        __syncthreads();
+        const int ob = tile * T, oc = (NG - ob) < T ? (NG - ob) : T;
+        for (int k = t; k < oc; k += nt) { const int g = w.tl_owned[ob + k]; tile_insert(Tb, g, nst, w.fb_deg[g].x, w.fb_begin[g].x); }
+        int4 *cons = w.tl_cons + (size_t)tile * RP_TILE_CCAP;
+        int *soff = w.tl_soff + (size_t)tile * (RP_TILE_STAGES + 1);
+        __syncthreads();
+        if (t == 0) { soff[nst] = RP_TILE_CCAP; nsnap = nloc; }
+        __syncthreads();
+        // Backwards over the sweep.  Every needed body walks its own toucher list (k_flow_ranks: the positions of the manifolds that
+        // touch it, ascending = sweep order, and the body on the other side of each) from the end: the positions of a stage are one
+        // contiguous range and a body has at most one manifold per stage (a colour is body-disjoint), so "my manifold of stage s" is the
+        // list entry under the cursor or nothing.  The manifold joins the cone; its other body, if it was not needed yet, becomes needed
+        // for the stages before s — nothing else of stage s can touch that body, so lookups and insertions of one stage may interleave
+        // freely.  When both bodies were needed already, both find the manifold: the one with the smaller index reports it.
+        for (int s = nst - 1; s >= 0; --s) {
+            const int beg = w.stage_begin[s];
+            const int n0 = nsnap < RP_TILE_BCAP ? nsnap : RP_TILE_BCAP; // the bodies needed before this stage began
+            for (int lid = t; lid < n0; lid += nt) {
+                const int h = live[lid];
+                const int a = hk[h], wd = hw[h];
+                if (TW_SINCE(wd) <= s) continue;
+                const int c = TW_CUR(wd);
+                if (c <= 0) continue;
+                const int at = hbeg[h] + c - 1;
+                const int pos = w.f_sorted[at] >> 1, b = w.f_other[at];
+                if (pos < beg) continue; // this body has no manifold of stage s
+                hw[h] = wd - (1 << 11);
+                if (b >= 0) {
+                    const int hb = tile_find(Tb, b);
+                    if (hb >= 0 && TW_SINCE(hw[hb]) > s) { if (b < a) continue; } // needed on both sides: b's walker reports it
+                    else { // b joins the cone for the stages before s: its cursor skips the entries of stage s and later
+                        const int lb = w.fb_begin[b].x; int cb = w.fb_deg[b].x;
+                        int e8[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) e8[k] = k < cb ? (w.f_sorted[lb + cb - 1 - k] >> 1) : -1; // the last eight entries in one round trip
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) if (e8[k] >= beg) --cb; // (entries descend from the end: the ones >= beg are a prefix of e8)
+                        if (cb > 0 && e8[7] >= beg) while (cb > 0 && (w.f_sorted[lb + cb - 1] >> 1) >= beg) --cb;
+                        tile_insert(Tb, b, s, cb, lb);
+                    }
+                }
+                const int k = atomicAdd(&ncons, 1);
+                if (k < RP_TILE_CCAP) cons[RP_TILE_CCAP - 1 - k] = make_int4(pos, 0, 0, 0); else bad = 1;
+            }
+            __syncthreads();
+            if (t == 0) { soff[s] = RP_TILE_CCAP - (ncons < RP_TILE_CCAP ? ncons : RP_TILE_CCAP); nsnap = nloc; } // the list is filled from its end: ascending stages once read forwards
+            __syncthreads();
+        }
+        if (t == 0) { // statistics of the tiling (tools/tile_diag.py)
+            atomicMax((unsigned long long *)&w.dbg[905], (unsigned long long)nloc); atomicMax((unsigned long long *)&w.dbg[906], (unsigned long long)ncons);
+            atomicAdd((unsigned long long *)&w.dbg[907], (unsigned long long)nloc); atomicAdd((unsigned long long *)&w.dbg[908], (unsigned long long)ncons);
+        }
+        if (bad || nloc > RP_TILE_BCAP || ncons > RP_TILE_CCAP) { if (t == 0) { atomicExch(&w.flags[FL_N_TILES], 0); w.dbg[901] = 3; } continue; } // cone over the LDS budget
+        for (int h = t; h < RP_TILE_HASH; h += nt) if (hk[h] >= 0) w.tl_bodies[(size_t)tile * RP_TILE_BCAP + TW_LID(hw[h])] = hk[h];
+        const int nc = ncons;
+        // arena indices -> tile-local ids; which tile stores the rows.  A cone of at most half the list's capacity is also packed to the
+        // front of the list with every stage sorted by position: neighbouring lanes of a sweep then fetch neighbouring rows (the
+        // positions of a stage follow the owners' curve order: runs of consecutive positions, one per tile that owns part of the cone)
+        const bool pack = nc <= RP_TILE_CCAP / 2;
+        const int tail0 = RP_TILE_CCAP - nc;
+        if (pack) for (int k = t; k < nc; k += nt) cpos[k] = cons[tail0 + k].x;
+        for (int s2 = t; s2 <= nst; s2 += nt) ssoff[s2] = soff[s2] - tail0; // stage begins relative to the cone's first entry
+        __syncthreads();
+        for (int k = t; k < nc; k += nt) {
+            const int pos = pack ? cpos[k] : cons[tail0 + k].x;
+            int dst = tail0 + k;
+            if (pack) {
+                int sg = 0; while (sg + 1 < nst && ssoff[sg + 1] <= k) ++sg;
+                int r = 0;
+                for (int j = ssoff[sg]; j < ssoff[sg + 1]; ++j) r += cpos[j] < pos;
+                dst = ssoff[sg] + r;
+            }
+            const int2 ab = w.fk_ids[pos];
+            const int first = ab.x >= 0 ? ab.x : ab.y;
+            const int own = w.tl_body_tile[first] == tile ? 1 : 0;
+            const int l1 = ab.x >= 0 ? TW_LID(hw[tile_find(Tb, ab.x)]) : -1, l2 = ab.y >= 0 ? TW_LID(hw[tile_find(Tb, ab.y)]) : -1;
+            cons[dst] = make_int4(pos, l1, l2, own);
+        }
+        if (pack) for (int s2 = t; s2 <= nst; s2 += nt) soff[s2] = ssoff[s2];
+        if (t == 0) w.tl_hdr[tile] = make_int4(nloc, nc, oc, 0);
+    }
+}
+
+// ---- the sweep -------------------------------------------------------------------------------------------------------------------------
+// Constraint rows in registers (fetched in one go, before the first dependent instruction), solver velocities in LDS, poses (read-only
+// during a sweep) fetched with the rows.
+struct TileAcc {
+    static constexpr bool PRELOAD = false; // the rows already sit in registers
+    const DevWorld &w; const float4 *v; int pos, l1, l2, nn; bool own; float4 *Ll, *La; Xf X1, X2;
+    RP_DEV float4 ld(int plane) const { return v[plane]; }
+    RP_DEV void st(int plane, float4 x) const { if (own) w.C[(size_t)cplane(plane, w.c_par ^ 1) * w.cons_cap + pos] = x; } // (only mutable planes are ever stored: the other copy)
+    RP_DEV int id1() const { return l1; }
+    RP_DEV int id2() const { return l2; }
+    RP_DEV int n() const { return nn; }
+    RP_DEV Vel vel(int id) const {
+        Vel r;
+        if (id < 0) { r.lin = v3(0, 0, 0); r.ang = v3(0, 0, 0); } else { r.lin = v3(Ll[id]); r.ang = v3(La[id]); }
+        return r;
+    }
+    RP_DEV void set_vel(int id, const Vel &x) const { if (id >= 0) { Ll[id] = f4(x.lin, 0.0f); La[id] = f4(x.ang, 0.0f); } }
+    RP_DEV Xf xf(int id) const {
+        if (id < 0) { Xf x; x.r = q4(0, 0, 0, 1); x.t = v3(0, 0, 0); return x; }
+        return id == l1 ? X1 : X2;
+    }
+};
+
+// one cone constraint of one stage: its rows come in with a single round trip, then cons_solve / cons_restitution over LDS velocities.
+// Left to itself the compiler sinks every row load into the branch that consumes it (if (k < n) ..., if (friction) ...) and keeps only
+// ~10 in flight: 5-6 exposed round trips per stage (measured: 4.0 us per relaxed stage).  The empty asm statements "use" every fetched
+// component right after the loads, so nothing can sink, and the scheduling barrier asks for the loads as one group.
+template <int MODE>
+RP_DEV void tile_apply(const DevWorld &w, const int4 e, const int n, const int *Lg, float4 *Ll, float4 *La, bool fib, bool friction, float solved_dt) {
+    const int pos = e.x;
+    float4 v[CP_COUNT];
+#define TL_LD(p) v[p] = w.C[(size_t)cplane(p, w.c_par) * w.cons_cap + pos]
+    TL_LD(CP_H0); TL_LD(CP_H1); TL_LD(CP_H2);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { // (all four points: no load waits for the point count; the planes of unused points are never read)
+        TL_LD(NPL(k, NP_M)); TL_LD(NPL(k, NP_A)); TL_LD(NPL(k, NP_B)); TL_LD(NPL(k, NP_C)); TL_LD(NPL(k, NP_D));
+        if (MODE == MODE_RELAX) { TL_LD(NPL(k, NP_E)); TL_LD(NPL(k, NP_F)); }
+    }
+    TL_LD(CP_HM0); TL_LD(CP_HM1); // (always: an owner instance carries them over to the other copy even when the sweep leaves them alone)
+    if (friction) {
+        TL_LD(CP_H3); TL_LD(CP_H4); TL_LD(CP_H5); TL_LD(CP_H6); TL_LD(CP_H7); TL_LD(CP_H8);
+        TL_LD(CP_T0); TL_LD(CP_T1); TL_LD(CP_T2); TL_LD(CP_T3); TL_LD(CP_T4); TL_LD(CP_T5); TL_LD(CP_T6); TL_LD(CP_T7);
+    }
+    Xf X1, X2; X1.r = q4(0, 0, 0, 1); X1.t = v3(0, 0, 0); X2 = X1;
+    if (MODE == MODE_RELAX) { // (poses fetched unconditionally — of cone body 0 for a world-attached side, whose pose is never looked at: TileAcc::xf)
+        TL_LD(CP_B2);
+        const int g1 = Lg[e.y >= 0 ? e.y : 0], g2 = Lg[e.z >= 0 ? e.z : 0];
+        X1.r = q4(w.s_rot[g1]); X1.t = v3(w.s_trans[g1]); X2.r = q4(w.s_rot[g2]); X2.t = v3(w.s_trans[g2]);
+    }
+#undef TL_LD
+    __builtin_amdgcn_sched_group_barrier(0x020, 64, 0); // every VMEM read above as one group, ahead of whatever follows
+#define TL_PIN4(p) asm volatile("" : "+v"(v[p].x), "+v"(v[p].y), "+v"(v[p].z), "+v"(v[p].w))
+#define TL_PIN3(p) asm volatile("" : "+v"(v[p].x), "+v"(v[p].y), "+v"(v[p].z))
+    TL_PIN4(CP_H0); TL_PIN4(CP_H1); TL_PIN4(CP_H2); TL_PIN4(CP_HM0); TL_PIN4(CP_HM1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        TL_PIN4(NPL(k, NP_M)); TL_PIN4(NPL(k, NP_A)); TL_PIN4(NPL(k, NP_C)); TL_PIN3(NPL(k, NP_D));
+        if (MODE == MODE_RESTITUTION) TL_PIN4(NPL(k, NP_B)); else TL_PIN3(NPL(k, NP_B));
+        if (MODE == MODE_RELAX) { TL_PIN3(NPL(k, NP_E)); TL_PIN3(NPL(k, NP_F)); }
+    }
+    if (friction) {
+        TL_PIN4(CP_H3); TL_PIN4(CP_H4); TL_PIN4(CP_H5); TL_PIN4(CP_H6); TL_PIN3(CP_H7); TL_PIN4(CP_H8);
+        TL_PIN3(CP_T0); TL_PIN3(CP_T1); TL_PIN3(CP_T2); TL_PIN3(CP_T3); TL_PIN3(CP_T4); TL_PIN3(CP_T5); TL_PIN3(CP_T6); TL_PIN3(CP_T7);
+    }
+    if (MODE == MODE_RELAX) {
+        TL_PIN3(CP_B2);
+        asm volatile("" : "+v"(X1.r.x), "+v"(X1.r.y), "+v"(X1.r.z), "+v"(X1.r.w), "+v"(X1.t.x), "+v"(X1.t.y), "+v"(X1.t.z));
+        asm volatile("" : "+v"(X2.r.x), "+v"(X2.r.y), "+v"(X2.r.z), "+v"(X2.r.w), "+v"(X2.t.x), "+v"(X2.t.y), "+v"(X2.t.z));
+    }
+#undef TL_PIN4
+#undef TL_PIN3
+    const TileAcc A = {w, v, pos, e.y, e.z, n, e.w != 0, Ll, La, X1, X2};
+    if (MODE == MODE_BIAS) cons_solve(w, A, false, fib, solved_dt);
+    else if (MODE == MODE_RELAX) cons_solve(w, A, true, true, solved_dt);
+    else cons_restitution(w, A);
+    // the other copy of the mutable planes must be complete after every sweep: what this sweep did not store is carried over
+    // (cons_solve stores NP_M of every live point; CP_HM0 only with friction, CP_HM1 only when it refreshes the rhs)
+    if (!friction) A.st(CP_HM0, v[CP_HM0]);
+    if (MODE != MODE_RELAX) A.st(CP_HM1, v[CP_HM1]);
+}
+
+// fuse bit 0: the sweep starts the substep — every cone body is incremented and warm-started on its way into LDS (k_increment_ws folded
+//             in; halo bodies redundantly);  bit 1: the sweep ends the biased phase — owned bodies are integrated on their way out
+//             (k_integrate folded in): velocities AND poses then go to the other buffers (t_lin / t_ang / t_rot / t_trans).
+template <int MODE>
+__global__ void __launch_bounds__(RP_TILE_THREADS) k_tile_sweep(DevWorld w, int friction_in_bias, float solved_dt, int fuse) {
+    const int NT = w.flags[FL_N_TILES];
+    const int t = threadIdx.x, nt = blockDim.x;
+    const bool fib = friction_in_bias != 0;
+    if (NT <= 0) {
+        // no valid tiling (the host planned on a stale hint): the whole sweep in workgroup 0, then the result moves to the other buffers
+        if (blockIdx.x != 0) return;
+        if (fuse & 1) {
+            for (int i = t; i < w.n_bodies; i += nt) if (global_body(w, i)) { V3 lin, ang; body_increment_ws(w, i, lin, ang); w.s_lin[i] = f4(lin, 0.0f); w.s_ang[i] = f4(ang, 0.0f); }
+            __threadfence(); __syncthreads();
+        }
+        tail_sweep<MODE, false>(w, 0, fib, solved_dt);
+        if (fuse & 2) {
+            for (int i = t; i < w.n_bodies; i += nt) if (global_body(w, i)) g_body_integrate(w, i);
+            __threadfence(); __syncthreads();
+        }
+        for (int i = t; i < w.n_bodies; i += nt) if (global_body(w, i)) {
+            w.t_lin[i] = w.s_lin[i]; w.t_ang[i] = w.s_ang[i];
+            if (fuse & 2) { w.t_rot[i] = w.s_rot[i]; w.t_trans[i] = w.s_trans[i]; }
+        }
+        int M = w.flags[FL_N_CONS]; if (M > w.cons_cap) M = w.cons_cap;
+        for (int pos = t; pos < M; pos += nt)
+            for (int m = 0; m < CP_SHADOW_COUNT; ++m) {
+                const int plane = m < 4 ? NPL(m, NP_M) : (m == 4 ? CP_HM0 : CP_HM1);
+                w.C[(size_t)cplane(plane, w.c_par ^ 1) * w.cons_cap + pos] = w.C[(size_t)cplane(plane, w.c_par) * w.cons_cap + pos];
+            }
+        return;
+    }
+    __shared__ float4 Ll[RP_TILE_BCAP], La[RP_TILE_BCAP];
+    __shared__ int Lg[RP_TILE_BCAP];
+    __shared__ int Soff[RP_TILE_STAGES + 2];
+    const int nst = w.flags[FL_N_STAGES];
+    const bool friction = MODE == MODE_RELAX || (MODE == MODE_BIAS && fib);
+#ifdef RP_TILE_PROFILE // thread 0 of tile 0 accumulates wall-clock ticks (10 ns) per phase into dbg[920 + 24 * MODE ..] (tools/tile_diag.py)
+#define TP_STAMP(k) do { if (blockIdx.x == 0 && t == 0) { const long long n_ = (long long)wall_clock64(); w.dbg[920 + 24 * MODE + (k)] += n_ - tp_; tp_ = n_; } } while (0)
+    long long tp_ = (long long)wall_clock64();
+#else
+#define TP_STAMP(k) do { } while (0)
+#endif
+    for (int tile = blockIdx.x; tile < NT; tile += gridDim.x) {
+        __syncthreads();
+        const int nb = w.tl_hdr[tile].x;
+        for (int l = t; l < nb; l += nt) {
+            const int g = w.tl_bodies[(size_t)tile * RP_TILE_BCAP + l];
+            Lg[l] = g;
+            if (fuse & 1) { V3 lin, ang; body_increment_ws(w, g, lin, ang); Ll[l] = f4(lin, 0.0f); La[l] = f4(ang, 0.0f); }
+            else { Ll[l] = w.s_lin[g]; La[l] = w.s_ang[g]; }
+        }
+        for (int s = t; s <= nst + 1; s += nt) Soff[s] = w.tl_soff[(size_t)tile * (RP_TILE_STAGES + 1) + (s < nst ? s : nst)];
+        __syncthreads();
+        const int4 *cons = w.tl_cons + (size_t)tile * RP_TILE_CCAP;
+        // the list entry (and point count) of a thread's next stage is fetched while it works on the current one: a stage then costs one
+        // round trip (the rows) instead of two
+        // (branch-free: a load inside a conditional block is waited for at the end of the block)
+        int4 e_next; int n_next; bool have_next;
+        { const int i0 = Soff[0] + t; have_next = i0 < Soff[1]; e_next = cons[have_next ? i0 : 0]; n_next = w.k_n[e_next.x]; }
+        TP_STAMP(0);
+        for (int s = 0; s < nst; ++s) {
+            const int end = Soff[s + 1];
+            int i = Soff[s] + t;
+            int4 e = e_next; int n = n_next;
+            bool have = have_next;
+            { const int i1 = end + t; have_next = i1 < Soff[s + 2]; e_next = cons[have_next ? i1 : 0]; } // (Soff[nst + 1] = Soff[nst]: nothing behind the last stage)
+            while (have) {
+                tile_apply<MODE>(w, e, n, Lg, Ll, La, fib, friction, solved_dt);
+                i += nt; have = i < end;
+                if (have) { e = cons[i]; n = w.k_n[e.x]; }
+            }
+            n_next = w.k_n[e_next.x];
+            // the barrier orders the LDS velocities only: a thread's row stores may stay in flight (nothing reads them before the next kernel)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            TP_STAMP(4 + (s < 16 ? s : 16));
+        }
+        for (int l = t; l < nb; l += nt) {
+            const int g = Lg[l];
+            if (w.tl_body_tile[g] != tile) continue;
+            if (fuse & 2) {
+                V3 lin = v3(Ll[l]), ang = v3(La[l]), trans = v3(w.s_trans[g]); Q4 rot = q4(w.s_rot[g]);
+                body_integrate(w, w.b_flags[g], lin, ang, rot, trans);
+                w.t_lin[g] = f4(lin, 0.0f); w.t_ang[g] = f4(ang, 0.0f); w.t_rot[g] = f4(rot); w.t_trans[g] = f4(trans, 0.0f);
+            } else { w.t_lin[g] = Ll[l]; w.t_ang[g] = La[l]; }
+        }
+#ifdef RP_TILE_PROFILE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TP_STAMP(1);
+        if (blockIdx.x == 0 && t == 0) w.dbg[920 + 24 * MODE + 2] += 1;
+#endif
+    }
+#undef TP_STAMP
+}
+
+void rp_launch_tiles_build(const DevWorld &w, hipStream_t st) {
+    if (!w.tile_cap) return;
+    int n = w.cons_cap > w.n_bodies ? w.cons_cap : w.n_bodies;
+    int blocks = (n + 1023) / 1024; if (blocks > w.gbar_blocks) blocks = w.gbar_blocks; if (blocks < 1) blocks = 1; // all resident (grid barriers)
+    hipLaunchKernelGGL(k_tiles_sort, dim3(blocks), dim3(1024), 0, st, w);
+    hipLaunchKernelGGL(k_tiles_cones, dim3(w.tile_target < w.tile_cap ? w.tile_target : w.tile_cap), dim3(RP_CONE_THREADS), 0, st, w); // (no grid barrier: any grid will do, workgroups loop over tiles)
+}
+// one sweep over every tile: reads w.s_lin / w.s_ang, leaves the result in w.t_lin / w.t_ang (the caller swaps the pointers)
+void rp_launch_tile_sweep(const DevWorld &w, hipStream_t st, int mode, int grid, int friction_in_bias, float solved_dt, int fuse) {
+    if (grid < 1) grid = 1;
+    if (mode == MODE_BIAS) hipLaunchKernelGGL(k_tile_sweep<MODE_BIAS>, dim3(grid), dim3(RP_TILE_THREADS), 0, st, w, friction_in_bias, solved_dt, fuse);
+    else hipLaunchKernelGGL(k_tile_sweep<MODE_RELAX>, dim3(grid), dim3(RP_TILE_THREADS), 0, st, w, friction_in_bias, solved_dt, fuse);
+    // (the restitution sweep, rare, stays on the per-stage launches: rp_solver.hip)
+}
+// workgroups of k_tiles_sort (1024 threads) one CU holds at once (0 = the query failed): input of DevWorld::gbar_blocks (rp_api.hip)
+int rp_occ_tiles_build(void) { int n = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_tiles_sort, 1024, 0) != hipSuccess) n = 0; return n; }

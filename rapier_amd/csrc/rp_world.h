@@ -23,6 +23,11 @@
 #define RP_ISL_NB_MAX 64             // bodies per LDS-resident island
 #define RP_ISL_NC_MAX 160            // solver manifolds per LDS-resident island
 #define RP_FID_UNKNOWN 0xffffu
+#define RP_TILE_BCAP 1536            // cone bodies (owned + halo) of one LDS tile (rp_tiles.hip)
+#define RP_TILE_CCAP 3072            // cone constraints of one tile
+#define RP_TILE_STAGES 127           // sweep stages a tiling handles (every colour but the overflow one)
+#define RP_TILE_CELLS 4096           // cells of the Morton counting sort that orders bodies into tiles (12 bits)
+#define RP_TILE_MIN_BODIES 1024      // global-path bodies below which the colour stages stay launches
 
 // body flag bits
 #define RP_BF_TYPE_MASK 0x3
@@ -111,6 +116,7 @@ enum {
     FL_CCD_N,           // bodies body_writeback found moving fast this step (ccd_list): the input of k_ccd
     FL_CCD_CLAMPS,      // (body, step) cases in which k_ccd clamped a pose to a time of impact
     FL_UF_NPAIRS,       // scratch of a layout rebuild: active dynamic-dynamic pairs listed for the island union-find (uf_pairs)
+    FL_N_TILES,         // LDS tiles the global path's big component is cut into (rp_tiles.hip); 0 = no valid tiling: colour stages as launches
     FL_COUNT = 64       // <= 64: publish_flags copies one slot per lane of a wavefront
 };
 
@@ -143,6 +149,7 @@ enum {
     CP_COUNT = CP_N0 + 7 * 4
 };
 // FrictionModel::Coulomb adds 9 tangent planes per point behind CP_COUNT (rp_coulomb.h)
+#define CP_SHADOW_COUNT 6 // shadow copies of the mutable planes (worlds that may tile: DevWorld::c_par)
 #define CQ_PER_POINT 9
 #define CQ_COUNT (CP_COUNT + CQ_PER_POINT * 4)
 enum {
@@ -350,6 +357,30 @@ struct DevWorld {
     int2 *fb_deg;               // [n_bodies] contact touchers, joint touchers of a solver body
     int2 *fb_begin, *fb_fill;   // [n_bodies] list begin / fill cursor inside f_adj, f_jadj
     int *f_adj, *f_jadj;        // [2 * cons_cap] positions, [2 * n_joints] joint sweep indices
-    int *f_sorted;              // [2 * cons_cap] the contact touchers of every body in sweep order (f_adj ranked): the body-centric warm start
+    int *f_sorted;              // [2 * cons_cap] the contact touchers of every body in sweep order (f_adj ranked), as term rows 2 * position + side (side 0 = the manifold's body 1): the body-centric warm start, the cone walk of the tiles
+    int *f_other;               // [2 * cons_cap] the solver body on the other side of f_sorted[i] (-1 = world-attached): the cone walk of rp_tiles.hip
     float4 *ws_terms;           // [11][2 * cons_cap] warm-start velocity terms per constraint side (rp_solver.hip: k_ws_prepare / k_increment_ws)
+
+    // ---- LDS tiles of the global path (rp_tiles.hip): a whole colour sweep inside one CU per tile, halo constraints solved redundantly ----
+    int c_par;                  // which copy of the MUTABLE constraint planes (impulses, accumulators, rhs: NP_M x 4, CP_HM0, CP_HM1) is current:
+                                // 0 = in place, 1 = the shadow planes behind CP_COUNT.  A tile sweep reads one copy and its owner instances write
+                                // the other (a halo instance must not see the owner's result of the same sweep); every other kernel works in
+                                // place on the current copy (cplane(), rp_constraint.h).  Always 0 outside a tiled solver loop.
+    int tile_cap;               // tiles the arrays below hold (0 = the world never tiles: joints, Coulomb, solve groups, RP_NO_TILES=1)
+    int tile_target;            // tiles wanted for the global component (~ one per CU)
+    int tile_min;               // global-path bodies / manifolds below which no tiling is attempted (RP_TILE_MIN_BODIES; a test hook: RP_TILE_MIN=<n>)
+    float4 *t_lin, *t_ang;      // [n_bodies] the other half of the solver-velocity double buffer: a tile sweep reads s_lin / s_ang and writes here
+    float4 *t_rot, *t_trans;    // [n_bodies] ... and of the solver poses: written by the sweep that also integrates (another tile may still read s_rot / s_trans)
+    int2 *fk_ids;               // [cons_cap] the two solver bodies of every position (flow_ids), refreshed with the tiling
+    int *tl_body_tile;          // [n_bodies] owner tile of a global-path body, -1 otherwise
+    int *tl_owned;              // [n_bodies] global-path bodies in tile order (Morton cell order of the centres of mass)
+    int *tl_hist, *tl_cellofs;  // [2][RP_TILE_CELLS] counting sort by cell: every body / global-path bodies (hist rests at zero between rebuilds)
+    int *tl_cell, *tl_sorted;   // [n_bodies] Morton cell of a body (-1 - cell off the global path); the bodies cell by cell
+    int *b_order;               // [n_bodies] curve rank of every body (a permutation of the indices the last sort covered, i beyond them): the order
+                                // of the owner bodies inside a colour stage (k_layout_rebuild); null = arena-index order
+    unsigned *tl_bbox;          // [16] ordered-uint min xyz, max xyz of the centres of mass (rest state: min = ~0, max = 0), [6] global-path bodies, [7] T, [8] sorted?, [9] bodies sorted
+    int4 *tl_hdr;               // [tile_cap] cone bodies, cone constraints, owned bodies, -
+    int *tl_soff;               // [tile_cap][RP_TILE_STAGES + 1] begin of every sweep stage inside the tile's constraint list
+    int *tl_bodies;             // [tile_cap][RP_TILE_BCAP] arena index of every cone body (owned + halo), index = tile-local id
+    int4 *tl_cons;              // [tile_cap][RP_TILE_CCAP] cone constraints in stage order: position, local body 1, local body 2, owner?
 };

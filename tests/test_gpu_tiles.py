@@ -1,0 +1,112 @@
+"""LDS tiles of the global solver path (rapier_amd/csrc/rp_tiles.hip): a whole colour sweep of a giant island as ONE launch, every
+tile's halo constraints solved redundantly.  The tiling only schedules work — whichever partition the device picks, poses and
+velocities must equal the oracle's (and the per-stage launches') bit for bit.  Restates no reference test: the reference's stage
+order is staged_island_solver/solve.rs:12-92, and equality with the oracle is the check that the tiles keep it."""
+import numpy as np
+import pytest
+
+from rapier_amd import PhysicsWorld, scenes as S
+from oracle_ffi import OracleWorld
+
+pytestmark = pytest.mark.gpu
+
+
+def _world(scene, monkeypatch, **env):
+    for k in ("RP_NO_TILES", "RP_TILE_TARGET", "RP_TILE_MIN", "RP_FORCE_MULTI"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, str(v))
+    w = PhysicsWorld.from_scene(scene)
+    w.step(0)                                   # the switches are read when the device world is built: by the first rp_step
+    return w
+
+
+def _equal(g, o, msg):
+    gp, gv = g.read_bodies()
+    op, ov = o.read() if isinstance(o, OracleWorld) else o.read_bodies()
+    assert np.isfinite(gp).all() and np.isfinite(gv).all()
+    np.testing.assert_array_equal(gp, op, err_msg=msg + " poses")
+    np.testing.assert_array_equal(gv, ov, err_msg=msg + " velocities")
+
+
+def _run(scene, checkpoints, monkeypatch, want_tiles=True, **env):
+    import os
+    import oracle_ffi
+    oracle_ffi.set_threads(max(1, min(os.cpu_count() or 1, 16)))   # (the oracle's results do not depend on the thread count)
+    try:
+        g, o = _world(scene, monkeypatch, **env), OracleWorld(scene)
+        done, tiled = 0, 0
+        for cp in checkpoints:
+            g.step(cp - done); o.step(cp - done); done = cp
+            _equal(g, o, f"{scene.name} @ step {cp}")
+            c = g.counters()
+            tiled += 1 if (c["num_tiles"] > 0 and c["tile_sweeps"] == 1) else 0
+    finally:
+        oracle_ffi.set_threads(1)
+    assert c["overflow_flags"] == 0 and c["quarantined"] == 0, c
+    if want_tiles:
+        assert tiled > 0, c   # some checkpoint saw the sweeps on tiles
+    return g, o, c
+
+
+def test_large_pyramid_on_tiles_bit_exact(monkeypatch):
+    """b3d_large_pyramid at base 60 (1,830 cuboids, one island, ~5,400 manifolds): ~29 tiles of 64 bodies."""
+    _, _, c = _run(S.large_pyramid(60), [1, 3, 10, 40, 80], monkeypatch)
+    assert c["num_tiles"] >= 16, c
+
+
+def test_tiles_equal_the_per_stage_launches(monkeypatch):
+    a = _world(S.large_pyramid(60), monkeypatch)
+    a.step(5)                                  # (the device world — and with it the switches — is built by the first step)
+    b = _world(S.large_pyramid(60), monkeypatch, RP_NO_TILES=1)
+    b.step(5)
+    _equal(a, b, "tiles vs launches after 5 steps")
+    for n in (25, 30):
+        a.step(n); b.step(n)
+        _equal(a, b, f"tiles vs launches after another {n} steps")
+    assert a.counters()["tile_sweeps"] == 1 and b.counters()["tile_sweeps"] == 0 and b.counters()["num_tiles"] == 0
+
+
+@pytest.mark.parametrize("target", [3, 40, 4000])
+def test_any_tile_size_gives_the_same_bits(monkeypatch, target):
+    """3 tiles of 256 bodies (large cones), 40 tiles, and the smallest tiles (64 bodies) the builder makes."""
+    _run(S.large_pyramid(60), [2, 20], monkeypatch, RP_TILE_TARGET=target)
+
+
+def test_tumbling_pile_on_tiles_bit_exact(monkeypatch):
+    """1,300 rotated cuboids and balls with initial velocities, restitution and damping falling into a walled pit: a 3-D contact graph
+    whose layout changes every step (tiling rebuilt every step), the restitution sweep on the per-stage launches between tile sweeps."""
+    _, _, c = _run(S.tumble(1300, seed=11), [1, 10, 40, 90, 150], monkeypatch, RP_TILE_MIN=256)
+    assert c["num_manifolds"] > 1024, c
+
+
+def test_tumbling_cuboids_second_seed_on_tiles_bit_exact(monkeypatch):
+    """cuboids only, another seed, larger tiles (12 aimed at)"""
+    _run(S.tumble(1100, seed=5, balls=False), [2, 30, 100], monkeypatch, RP_TILE_MIN=256, RP_TILE_TARGET=12)
+
+
+def test_body_removal_and_impulses_retile(monkeypatch):
+    """user changes between steps: bodies removed from the middle of the pyramid (the layout changes, the tiling is rebuilt), impulses
+    on others (nothing changes but the velocities)"""
+    sc = S.large_pyramid(60)
+    g, o = _world(sc, monkeypatch), OracleWorld(sc)
+    g.step(10); o.step(10)
+    _equal(g, o, "before the edits")
+    assert g.counters()["tile_sweeps"] == 1
+    dyn = [i for i, b in enumerate(sc.bodies) if int(b["body_type"]) == S.BODY_DYNAMIC]
+    for b in dyn[500:540:3]:
+        g.remove_body([b]); o.remove_body(b)
+    for b in dyn[100:1500:97]:
+        g.apply_impulse([b], impulse=(30.0, 80.0, -20.0)); o.apply_impulse(b, impulse=(30.0, 80.0, -20.0))
+    alive = np.ones(len(sc.bodies), bool); alive[dyn[500:540:3]] = False
+    for cp in (1, 5, 30):
+        g.step(cp); o.step(cp)
+        gp, gv = g.read_bodies(); op, ov = o.read()
+        np.testing.assert_array_equal(gp[alive], op[alive]); np.testing.assert_array_equal(gv[alive], ov[alive])
+    c = g.counters()
+    assert c["overflow_flags"] == 0 and c["num_tiles"] > 0, c
+
+
+def test_world_below_the_threshold_keeps_the_launches(monkeypatch):
+    g, _, c = _run(S.large_pyramid(30), [5], monkeypatch, want_tiles=False, RP_FORCE_MULTI=1)
+    assert c["num_tiles"] == 0 and c["tile_sweeps"] == 0, c

@@ -1,0 +1,26 @@
+"""Counters of a scene step by step (which path the global solver took; tiles built?)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rapier_amd import PhysicsWorld, scenes as S
+sc = S.large_pyramid(200) if len(sys.argv) > 1 and sys.argv[1] == "lp" else S.reference_pile(14, 5, 14, chain=False, sleep=False)
+w = PhysicsWorld.from_scene(sc)
+done = 0
+for cp in (1, 5, 20, 40, 60, 80, 120):
+    w.step(cp - done); done = cp
+    c = w.counters()
+    print(cp, {k: c[k] for k in ("num_manifolds", "num_colors", "num_parallel_stages", "num_tiles", "tile_sweeps", "overflow_flags", "num_pairs", "full_updates")})
+import ctypes as C, numpy as np
+from rapier_amd import _ffi
+L = _ffi.lib()
+L.rp_debug_read.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+buf = np.zeros(16, np.int64)
+print("rp_debug_read", L.rp_debug_read(w._ptr, 900, 16, buf.ctypes.data))
+print("tilings", buf[0], "reason", buf[1], "NG", buf[2], "NT", buf[3], "T", buf[4], "max cone bodies", buf[5], "max cone cons", buf[6], "sum cone bodies", buf[7], "sum cone cons", buf[8])
+
+prof = np.zeros(48, np.int64)
+L.rp_debug_read(w._ptr, 920 + 24, 48, prof.ctypes.data)
+for mode, name in ((0, "biased"), (1, "relaxed")):
+    r = prof[24 * mode: 24 * mode + 24]
+    if r[2]:
+        n = float(r[2])
+        print(f"tile 0 {name} sweep ({int(n)} launches): load {r[0] / n / 100:.2f} us, store {r[1] / n / 100:.2f} us, stages " + " ".join(f"{r[4 + k] / n / 100:.2f}" for k in range(17) if r[4 + k]))
