@@ -1145,7 +1145,7 @@ static int finalize(rp_world *w) {
     DAC(d.c_mat, capc, DOM_COLL, 1, 1); DAC(d.c_rules, capc, DOM_COLL, 1, 1); DAC(d.c_groups, capc, DOM_COLL, 1, 1); DAC(d.c_fatmin, capc, DOM_COLL, 1, 1); DAC(d.c_fatmax, capc, DOM_COLL, 1, 1); DAC(d.c_events, capc, DOM_COLL, 1, 1);
     d.ev_cap = 65536;
     DAC(d.ev_col, d.ev_cap, DOM_FIXED, 1, 1); DAC(d.ev_force_meta, d.ev_cap, DOM_FIXED, 1, 1); DAC(d.ev_force_a, d.ev_cap, DOM_FIXED, 1, 1); DAC(d.ev_force_b, d.ev_cap, DOM_FIXED, 1, 1);
-    DA(d.cell_count, d.grid_cap); DA(d.cell_start, d.grid_cap + 1); DA(d.cell_fill, d.grid_cap); DA(d.scan_block, 1024);
+    DA(d.cell_count, d.grid_cap); DA(d.cell_start, d.grid_cap + 1); DA(d.cell_fill, d.grid_cap); DA(d.scan_block, 1024 + 8); // + the scratch counters of a running broad-phase rebuild
     DA(d.e_key, d.entries_cap); DA(d.e_col, d.entries_cap); DA(d.large_list, d.large_cap);
     DA(d.c_chgstamp, capc); DA(d.c_stale, capc); DA(d.c_inlarge, capc); DA(d.bp_chg_list, capc); DA(d.bp_moved_list, RP_BP_MOVED_CAP); // incremental broad phase (scratch: rebuilt by the next full pass)
     DAF(d.h_key[0], d.hash_cap, 0xff); DAF(d.h_key[1], d.hash_cap, 0xff); DA(d.h_slot[0], d.hash_cap); DA(d.h_slot[1], d.hash_cap);

@@ -104,18 +104,15 @@ __global__ void k_fast_front(DevWorld w, int no_global_kernel) {
 }
 
 // ---- the rebuild, pass by pass (k_bp_rebuild below runs them behind grid barriers; gid / gstride span the whole launch) ----
-RP_DEV void bp_clear(DevWorld &w, int gid, int gstride) {
-    int nxt = (w.flags[FL_BP_EPOCH] & 1) ^ 1;
-    for (int i = gid; i < w.grid_cap; i += gstride) { w.cell_count[i] = 0; w.cell_fill[i] = 0; }
-    for (int i = gid; i < w.hash_cap; i += gstride) w.h_key[nxt][i] = RP_EMPTY_KEY;
-    if (gid == 0) { w.flags[FL_N_LARGE] = 0; w.flags[FL_N_ENTRIES] = 0; }
-}
+// (no clearing pass: a full rebuild leaves its scratch at rest — bp_finish_pairs empties the cell counters, the hash table that goes
+// out of service and the large-collider counter for the next rebuild; allocation provides the first rest state)
+#define BP_LARGE_SCRATCH 1024 // scan_block[1024]: large colliders counted by the running rebuild (FL_N_LARGE keeps serving incremental passes until then)
 RP_DEV void bp_count(DevWorld &w, int gid, int gstride) {
     for (int i = gid; i < w.n_colliders; i += gstride) {
         CellRange r = cell_range(w, i);
         w.c_inlarge[i] = r.large ? 1 : 0; w.c_stale[i] = 0; // the grid is being rebuilt: nobody is stale
         if (r.large) {
-            int k = atomicAdd(&w.flags[FL_N_LARGE], 1);
+            int k = atomicAdd(&w.scan_block[BP_LARGE_SCRATCH], 1);
             if (k < w.large_cap) w.large_list[k] = i; else atomicOr(&w.flags[FL_OVERFLOW], RP_OVF_LARGE);
             continue;
         }
@@ -128,7 +125,27 @@ RP_DEV void bp_count(DevWorld &w, int gid, int gstride) {
                 }
     }
 }
-// exclusive scan of cell_count -> cell_start: 1024-item chunks scanned in LDS, the chunk sums by workgroup 0, then added back
+// exclusive scan of cell_count -> cell_start: 1024-item chunks scanned in LDS; the workgroup that finishes last (a ticket) scans the
+// chunk sums, and the pass that fills the cells adds them back (bp_add_fill) — two barriers instead of four
+RP_DEV void bp_scan_sums(DevWorld &w, int *s) { // one workgroup; at most 1024 chunks (grid_cap <= 2^20)
+    const int nblocks = (w.grid_cap + 1023) / 1024;
+    int v = threadIdx.x < nblocks ? __hip_atomic_load(&w.scan_block[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0; // (written by other CUs in this launch)
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int t = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+        __syncthreads();
+        s[threadIdx.x] += t;
+        __syncthreads();
+    }
+    if (threadIdx.x < nblocks) w.scan_block[threadIdx.x] = s[threadIdx.x] - v;
+    if (threadIdx.x == 1023) {
+        w.flags[FL_N_ENTRIES] = s[1023];
+        if (s[1023] > w.entries_cap) atomicOr(&w.flags[FL_OVERFLOW], RP_OVF_CELLS);
+        const int nl = __hip_atomic_load(&w.scan_block[BP_LARGE_SCRATCH], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        w.flags[FL_N_LARGE] = nl < w.large_cap ? nl : w.large_cap; // the count pass is complete: the new large list goes into service
+    }
+}
 RP_DEV void bp_scan_chunks(DevWorld &w, int *s) {
     const int chunks = (w.grid_cap + 1023) / 1024;
     for (int c = blockIdx.x; c < chunks; c += gridDim.x) {
@@ -142,30 +159,30 @@ RP_DEV void bp_scan_chunks(DevWorld &w, int *s) {
             s[threadIdx.x] += t;
             __syncthreads();
         }
-        if (gid < w.grid_cap) w.cell_start[gid] = s[threadIdx.x] - v;
+        if (gid < w.grid_cap) { w.cell_start[gid] = s[threadIdx.x] - v; w.cell_fill[gid] = s[threadIdx.x] - v; } // (cell_fill: the fill cursor starts at the chunk-local begin)
         if (threadIdx.x == 1023) w.scan_block[c] = s[1023];
         __syncthreads();
     }
-}
-RP_DEV void bp_scan_sums(DevWorld &w, int *s) { // workgroup 0 only; at most 1024 chunks (grid_cap <= 2^20)
-    const int nblocks = (w.grid_cap + 1023) / 1024;
-    int v = threadIdx.x < nblocks ? w.scan_block[threadIdx.x] : 0;
-    s[threadIdx.x] = v;
+    // (the hand-over of rp_gridbar.h: every wave drains its stores, the workgroup meets, ONE lane releases at agent scope and takes the
+    // ticket — a __threadfence() per thread made this pass 32 us)
+    __shared__ int last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        int t = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
-        __syncthreads();
-        s[threadIdx.x] += t;
-        __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        last = __hip_atomic_fetch_add(&w.flags[FL_TICKET], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+        if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
-    if (threadIdx.x < nblocks) w.scan_block[threadIdx.x] = s[threadIdx.x] - v;
-    if (threadIdx.x == 1023) {
-        w.flags[FL_N_ENTRIES] = s[1023];
-        if (s[1023] > w.entries_cap) atomicOr(&w.flags[FL_OVERFLOW], RP_OVF_CELLS);
+    __syncthreads();
+    if (last) {
+        bp_scan_sums(w, s);
+        if (threadIdx.x == 0) w.flags[FL_TICKET] = 0;
     }
 }
 RP_DEV void bp_scan_add(DevWorld &w, int gid, int gstride) {
     for (int i = gid; i < w.grid_cap; i += gstride) w.cell_start[i] += w.scan_block[i >> 10];
+    if (gid == 0) w.cell_start[w.grid_cap] = w.flags[FL_N_ENTRIES]; // the end of the last cell
 }
 RP_DEV void bp_fill(DevWorld &w, int gid, int gstride) {
     for (int i = gid; i < w.n_colliders; i += gstride) {
@@ -176,7 +193,7 @@ RP_DEV void bp_fill(DevWorld &w, int gid, int gstride) {
                 for (int x = r.lo[0]; x <= r.hi[0]; ++x) {
                     unsigned long long key = cell_key(x, y, z);
                     int h = (int)(rp_hash64(key) & (unsigned long long)(w.grid_cap - 1));
-                    int pos = w.cell_start[h] + atomicAdd(&w.cell_fill[h], 1);
+                    int pos = w.scan_block[h >> 10] + atomicAdd(&w.cell_fill[h], 1); // (cell_start is being finalised by bp_scan_add in this very pass: the cursor carries the chunk-local begin)
                     if (pos < w.entries_cap) { w.e_key[pos] = key; w.e_col[pos] = i; }
                 }
     }
@@ -283,7 +300,7 @@ RP_DEV void bp_pairs(DevWorld &w) {
             const int x = r.lo[0] + c % nx, y = r.lo[1] + (c / nx) % ny, z = r.lo[2] + c / (nx * ny);
             unsigned long long key = cell_key(x, y, z);
             int h = (int)(rp_hash64(key) & (unsigned long long)(w.grid_cap - 1));
-            int beg = w.cell_start[h], end = beg + w.cell_count[h];
+            int beg = w.cell_start[h], end = w.cell_start[h + 1]; // (cells are consecutive ranges of the entry array; cell_count is scratch of a rebuild)
             if (end > w.entries_cap) end = w.entries_cap;
             for (int e = beg; e < end; ++e) {
                 if (w.e_key[e] != key) continue;
@@ -353,6 +370,10 @@ RP_DEV void bp_finish_pairs(DevWorld &w, int gid, int gstride) {
         if (w.p_stamp[s] == epoch + 1) continue;
         bp_delete_pair(w, s);
     }
+    // rest state for the next rebuild: empty cell counters, the table that goes out of service (it becomes the next rebuild's target)
+    for (int i = gid; i < w.grid_cap; i += gstride) w.cell_count[i] = 0;
+    { unsigned long long *old = w.h_key[epoch & 1]; for (int i = gid; i < w.hash_cap; i += gstride) old[i] = RP_EMPTY_KEY; }
+    if (gid == 0) w.scan_block[BP_LARGE_SCRATCH] = 0;
 }
 
 // ---- incremental pass ------------------------------------------------------------------------------------------------------
@@ -393,7 +414,7 @@ RP_DEV void bp_incr_insert(DevWorld &w, int nchg, int nmoved) {
             const int x = r.lo[0] + lane % nx, y = r.lo[1] + (lane / nx) % ny, z = r.lo[2] + lane / (nx * ny);
             unsigned long long key = cell_key(x, y, z);
             int h = (int)(rp_hash64(key) & (unsigned long long)(w.grid_cap - 1));
-            int beg = w.cell_start[h], end = beg + w.cell_count[h];
+            int beg = w.cell_start[h], end = w.cell_start[h + 1]; // (cells are consecutive ranges of the entry array; cell_count is scratch of a rebuild)
             if (end > w.entries_cap) end = w.entries_cap;
             for (int e = beg; e < end; ++e) {
                 if (w.e_key[e] != key) continue;
@@ -458,16 +479,11 @@ __global__ void __launch_bounds__(1024) k_bp_rebuild(DevWorld w) {
     }
     const int epoch = w.flags[FL_BP_EPOCH];
     RP_PASS_BEGIN();
-    bp_clear(w, gid, gstride);
-    GBAR_SYNC(bar); RP_PASS_STAMP(w, 220);
     bp_count(w, gid, gstride);
     GBAR_SYNC(bar); RP_PASS_STAMP(w, 220);
     bp_scan_chunks(w, scan_lds);
     GBAR_SYNC(bar); RP_PASS_STAMP(w, 220);
-    if (blockIdx.x == 0) bp_scan_sums(w, scan_lds);
-    GBAR_SYNC(bar); RP_PASS_STAMP(w, 220);
     bp_scan_add(w, gid, gstride);
-    GBAR_SYNC(bar); RP_PASS_STAMP(w, 220);
     bp_fill(w, gid, gstride);
     GBAR_SYNC(bar); RP_PASS_STAMP(w, 220);
     bp_pairs(w);

@@ -13,7 +13,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "build":
     subprocess.run(["make", "-s", "-C", src], check=True)
     flags = "-O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -DRP_PASS_PROFILE".split()
     objs = []
-    for f in ("rp_api", "rp_broadphase", "rp_narrowphase", "rp_solver", "rp_islands", "rp_joints", "rp_sleep", "rp_flow"):
+    for f in ("rp_api", "rp_broadphase", "rp_narrowphase", "rp_solver", "rp_islands", "rp_joints", "rp_sleep", "rp_flow", "rp_tiles"):
         if f in ("rp_islands", "rp_broadphase"):
             o = f"/tmp/{f}_pp.o"
             subprocess.run(["/opt/rocm/bin/hipcc", *flags, "-c", os.path.join(src, f + ".hip"), "-o", o], check=True)
@@ -38,7 +38,7 @@ L.rp_debug_read.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
 buf = np.zeros(64, np.int64)
 assert L.rp_debug_read(w._ptr, 200, 64, buf.ctypes.data) == 0
 lay = ["init+clear", "bucket count", "union", "isl_count", "isl_number", "isl_fill", "owner prefix + stage order", "scatter", "rank overflow"]
-bp = ["clear", "count", "scan chunks", "scan sums", "scan add", "fill", "pairs", "finish"]
+bp = ["count", "scan (chunks + last-block sums)", "add + fill", "pairs", "finish + rest state"]
 for title, base, names in (("k_layout_rebuild", 0, lay), ("k_bp_rebuild (full pass)", 20, bp)):
     n = max(int(buf[base + 15]), 1)
     tot = sum(int(buf[base + k]) for k in range(len(names)))
