@@ -148,7 +148,34 @@ def run(args, make_world=None, backend: str = "nccl", use_cuda: bool = True):
     if args.force_dist and world == 1 and wl in ("auto", "c3"):
         wl = "grid:14x14"  # the C3 world through the sharded code path (one rank owns every island): global ids, all-gather at readback
     scene, workload, gids, n_global, grid = build_workload(wl, world, rank)
+    guard, shard_source = None, None
+    if gids is not None:
+        shard_source = "generator (sharding.island_shard: the pyramids of the closed-form scene)"
+        if args.shard_by == "device" and grid is not None:
+            # the shards come from the device's own proximity groups of the WHOLE scene (built once per rank, stepped once, dropped):
+            # whole groups are bin-packed over the ranks, and every rank's world is guarded against the boxes of the other ranks' groups
+            try:
+                full = S.many_pyramids(grid[0], grid[1])
+                wf = make_world(full, local_rank)
+                wf.step(1)
+                groups = wf.proximity_groups() if hasattr(wf, "proximity_groups") else sharding.proximity_groups_from_scene(full)
+                if hasattr(wf, "close"):
+                    wf.close()
+                del wf
+                body_rank, n_groups = sharding.shards_from_groups(groups, world)
+                scene, gids = sharding.partition_scene(full, body_rank, rank)
+                n_global = len(full.bodies)
+                guard = sharding.guard_boxes(full, groups, body_rank, rank)
+                shard_source = f"device proximity groups ({n_groups} groups of the whole scene, bin-packed; {len(guard[0])} foreign boxes guarded on rank {rank})"
+                workload += f"; shards from the device's proximity groups ({int((body_rank == rank).sum()) // 55} islands on rank {rank})"
+                del full
+            except Exception as e:  # noqa: BLE001 — the generator's shards are the fallback
+                shard_source = f"generator (device discovery failed: {type(e).__name__}: {e})"
+                scene, workload, gids, n_global, grid = build_workload(wl, world, rank)
+                guard = None
     w = make_world(scene, local_rank)
+    if guard is not None and len(guard[0]) and hasattr(w, "set_shard_guard"):
+        w.set_shard_guard(*guard)
     dev = "cuda" if use_cuda else None
 
     def barrier():
@@ -240,7 +267,7 @@ def run(args, make_world=None, backend: str = "nccl", use_cuda: bool = True):
                        "C3-equivalent steps/s = (cuboids stepped by all ranks / 10,780) * steps / max-over-ranks time; sharded_world_steps_per_s = steps/s of the whole sharded world"},
             "roofline": roof,
             "finite": finite,
-            "dist": None if dist is None else {"backend": backend, "world_size": world, "forced": bool(args.force_dist),
+            "dist": None if dist is None else {"backend": backend, "world_size": world, "forced": bool(args.force_dist), "shard_source": shard_source,
                                                "gathered_bodies": None if gathered is None else int(gathered[0].shape[0])},
         }
         if not args.no_cpu_baseline and is_metric_workload:
@@ -262,6 +289,8 @@ def parse_args(argv=None):
     ap.add_argument("--workload", default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-steps", type=int, default=200)
+    ap.add_argument("--shard-by", choices=("device", "generator"), default="device",
+                    help="N > 1: shards from the device's proximity groups of the whole scene (default) or from the scene generator's pyramid list")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N > 1 code path (init_process_group('nccl'), barrier, all-reduce, all-gather of body state) even with one rank")
     return ap.parse_args(argv)

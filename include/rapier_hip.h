@@ -271,6 +271,18 @@ int32_t rp_bodies_is_sleeping(rp_world *w, int32_t n, const uint64_t *handles, i
  * and for every body of a world that holds no sleepable body (such a world keeps no islands; the first sleepable body bootstraps
  * them, persistent.rs:600-625).  As in the reference only EQUALITY of two ids is meaningful. */
 int32_t rp_bodies_persistent_island(rp_world *w, int32_t n, const uint64_t *handles, int32_t *island_out);
+/* Proximity groups: connected components of the non-fixed bodies over everything that can couple them within a step — every live
+ * broad-phase pair (fat AABBs overlap: ColliderPair events of broad_phase_bvh/mod.rs:171-263) and every impulse joint.  Two bodies in
+ * different groups cannot interact before one of them moves out of its fat AABB: the unit of island sharding over GPUs (SURVEY §8e;
+ * the reference's islands, island_manager/persistent.rs, are the touching subset).  -1 for fixed / removed bodies; only EQUALITY of
+ * two ids is meaningful.  Needs at least one step (the pair set is built by the first broad-phase pass). */
+int32_t rp_bodies_proximity_group(rp_world *w, int32_t n, const uint64_t *handles, int32_t *group_out);
+/* Shard guard of a world that holds ONE shard of a larger scene: n axis-aligned boxes (min xyz / max xyz, e.g. one per proximity
+ * group of the other shards, already inflated by whatever clearance the caller wants) that hold the bodies of OTHER shards.  When
+ * the fat AABB of a non-fixed body of this world is rewritten so that it overlaps one of them, the shards are no longer independent
+ * (the reference would have created the ColliderPair; a sharded run cannot): the next rp_sync / read returns RP_ERR_INVALID.
+ * n = 0 removes the guard. */
+int32_t rp_world_set_shard_guard(rp_world *w, int32_t n, const float *box_min3, const float *box_max3);
 int32_t rp_num_bodies(const rp_world *w);
 
 /* NarrowPhase::contact_pairs() analogue: for each active solver manifold: (collider1, collider2,

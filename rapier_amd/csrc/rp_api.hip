@@ -139,6 +139,8 @@ struct rp_world {
     DevWorld old_dw;
     int *old_pinned = nullptr;
     std::vector<int> old_active_joint_ids;
+    // shard guard (rp_world_set_shard_guard): host copy, re-uploaded whenever the device world is rebuilt
+    std::vector<float4> guard_min, guard_max; std::vector<int> guard_start, guard_items; float guard_origin[3] = {0, 0, 0}, guard_cell = 0.0f; int guard_dims[3] = {0, 0, 0};
     // launch plan + graph
     int plan_stages = 0, plan_blocks = 1, plan_single = 1, plan_island_grid = 1, plan_joint_stages = 0, plan_no_global = 0, plan_fused = 0, plan_tile_grid = 0;
     bool has_restitution = false;
@@ -1083,6 +1085,19 @@ static int carry_over(rp_world *w) {
     return RP_OK;
 }
 
+// the shard guard (rp_world_set_shard_guard) of the current device world: boxes + the coarse grid over them
+static int upload_shard_guard(rp_world *w) {
+    DevWorld &d = w->dw;
+    d.sg_bmin = nullptr; d.sg_bmax = nullptr; d.sg_cell_start = nullptr; d.sg_cell_items = nullptr;
+    if (w->guard_min.empty()) return RP_OK;
+    DA(d.sg_bmin, w->guard_min.size()); DA(d.sg_bmax, w->guard_max.size()); DA(d.sg_cell_start, w->guard_start.size()); DA(d.sg_cell_items, std::max<size_t>(w->guard_items.size(), 1));
+    UP(d.sg_bmin, w->guard_min); UP(d.sg_bmax, w->guard_max); UP(d.sg_cell_start, w->guard_start); UP(d.sg_cell_items, w->guard_items);
+    for (int k = 0; k < 3; ++k) { d.sg_origin[k] = w->guard_origin[k]; d.sg_dims[k] = w->guard_dims[k]; }
+    d.sg_inv_cell = 1.0f / w->guard_cell;
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    return RP_OK;
+}
+
 // Upload the host mirrors into the SoA device world (the "upload = resume" path of SURVEY §5).
 static int finalize(rp_world *w) {
     HIPCHK(w, hipSetDevice(w->device));
@@ -1270,6 +1285,7 @@ static int finalize(rp_world *w) {
         }
     }
 
+    { int r = upload_shard_guard(w); if (r != RP_OK) return r; } // the shard guard follows the device world
     // host SoA staging (one batched copy per attribute)
     {
         std::vector<float4> pos(nb), rot(nb), lv(nb), av(nb), lci(nb), ipi(nb), pfr(nb), damp(nb);
@@ -1431,6 +1447,10 @@ static void enqueue_global_and_finish(rp_world *w) { enqueue_global_solver(w); e
 static void enqueue_whole(rp_world *w) { enqueue_collision(w); enqueue_solver(w); enqueue_finish(w); }
 
 static int check_overflow(rp_world *w, const int *fl) {
+    if (fl[FL_OVERFLOW] & RP_OVF_SHARD) {
+        w->err = "shard guard: a body of this shard moved into a cell that holds another shard's bodies (the shards are no longer independent)";
+        return RP_ERR_INVALID;
+    }
     if (fl[FL_OVERFLOW]) {
         char buf[256];
         snprintf(buf, sizeof(buf), "device error (flags 0x%x: 1=pair pool 2=pair hash 4=grid cells 8=large list 16=constraints: raise RP_PAIRS_PER_COLLIDER; "
@@ -1898,6 +1918,79 @@ extern "C" int32_t rp_bodies_persistent_island(rp_world *w, int32_t n, const uin
         if (b < 0 || b >= w->dw.n_bodies) { w->err = "rp_bodies_persistent_island: invalid handle"; return RP_ERR_INVALID; }
         out[i] = w->bodies[b].removed ? -1 : isl[b];
     }
+    return RP_OK;
+}
+// Proximity groups (include/rapier_hip.h): union-find on the host over the live pair slots (read back once) and the joints.
+extern "C" int32_t rp_bodies_proximity_group(rp_world *w, int32_t n, const uint64_t *handles, int32_t *out) {
+    if (!w || n < 0 || (n > 0 && (!handles || !out))) return RP_ERR_INVALID;
+    HIPCHK(w, hipSetDevice(w->device));
+    if (!w->finalized) { int r = finalize(w); if (r != RP_OK) return r; }
+    { int r = settle(w); if (r != RP_OK) return r; }
+    const int nb = w->dw.n_bodies;
+    std::vector<int> parent(std::max(nb, 1));
+    for (int i = 0; i < nb; ++i) parent[i] = i;
+    auto find = [&](int x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+    auto unite = [&](int a, int b) { a = find(a); b = find(b); if (a != b) { if (a < b) parent[b] = a; else parent[a] = b; } };
+    auto links = [&](int b) { return b >= 0 && b < nb && !w->bodies[b].removed && w->bodies[b].d.body_type != RP_BODY_FIXED; };
+    int top = 0;
+    HIPCHK(w, hipMemcpy(&top, w->dw.flags + FL_POOL_TOP, sizeof(int), hipMemcpyDeviceToHost));
+    top = std::min(top, w->dw.pool_cap);
+    if (top > 0) {
+        std::vector<int> c1(top); std::vector<int2> rb(top);
+        HIPCHK(w, hipMemcpy(c1.data(), w->dw.p_c1, (size_t)top * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(w, hipMemcpy(rb.data(), w->dw.p_rb, (size_t)top * sizeof(int2), hipMemcpyDeviceToHost));
+        for (int s = 0; s < top; ++s) if (c1[s] >= 0 && links(rb[s].x) && links(rb[s].y)) unite(rb[s].x, rb[s].y);
+    }
+    for (size_t j = 0; j < w->joints.size(); ++j) if (!w->joint_removed[j] && links((int)w->joints[j].body1) && links((int)w->joints[j].body2)) unite((int)w->joints[j].body1, (int)w->joints[j].body2);
+    for (int i = 0; i < n; ++i) {
+        int b = handle_index(handles[i]);
+        if (b < 0 || b >= nb) { w->err = "rp_bodies_proximity_group: invalid handle"; return RP_ERR_INVALID; }
+        out[i] = links(b) ? find(b) : -1;
+    }
+    return RP_OK;
+}
+extern "C" int32_t rp_world_set_shard_guard(rp_world *w, int32_t n, const float *bmin, const float *bmax) {
+    if (!w || n < 0 || (n > 0 && (!bmin || !bmax))) return RP_ERR_INVALID;
+    HIPCHK(w, hipSetDevice(w->device));
+    w->guard_min.clear(); w->guard_max.clear(); w->guard_start.clear(); w->guard_items.clear();
+    if (n > 0) {
+        // coarse uniform grid over the boxes: cell = the largest box edge (a box then touches at most 2 x 2 x 2 cells), CSR lists
+        float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f}, edge = 0.0f;
+        for (int i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) {
+            const float a = bmin[3 * i + k], b = bmax[3 * i + k];
+            if (!(a <= b) || !std::isfinite(a) || !std::isfinite(b)) { w->err = "rp_world_set_shard_guard: bad box"; return RP_ERR_INVALID; }
+            lo[k] = std::min(lo[k], a); hi[k] = std::max(hi[k], b); edge = std::max(edge, b - a);
+        }
+        float cell = std::max(edge, 1.0e-3f);
+        for (;;) { // at most 2^22 cells
+            double cells = 1.0; for (int k = 0; k < 3; ++k) cells *= std::floor((hi[k] - lo[k]) / cell) + 1.0;
+            if (cells <= (double)(1 << 22)) break;
+            cell *= 2.0f;
+        }
+        for (int k = 0; k < 3; ++k) { w->guard_origin[k] = lo[k]; w->guard_dims[k] = (int)std::floor((hi[k] - lo[k]) / cell) + 1; }
+        w->guard_cell = cell;
+        const int nc = w->guard_dims[0] * w->guard_dims[1] * w->guard_dims[2];
+        auto range = [&](int i, int k, int &a, int &b) {
+            a = std::min(std::max((int)std::floor((bmin[3 * i + k] - lo[k]) / cell), 0), w->guard_dims[k] - 1);
+            b = std::min(std::max((int)std::floor((bmax[3 * i + k] - lo[k]) / cell), 0), w->guard_dims[k] - 1);
+        };
+        std::vector<int> count(nc + 1, 0);
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int i = 0; i < n; ++i) {
+                int x0, x1, y0, y1, z0, z1; range(i, 0, x0, x1); range(i, 1, y0, y1); range(i, 2, z0, z1);
+                for (int z = z0; z <= z1; ++z) for (int y = y0; y <= y1; ++y) for (int x = x0; x <= x1; ++x) {
+                    const int c = (z * w->guard_dims[1] + y) * w->guard_dims[0] + x;
+                    if (pass == 0) count[c + 1]++; else w->guard_items[count[c]++] = i;
+                }
+            }
+            if (pass == 0) { for (int c = 0; c < nc; ++c) count[c + 1] += count[c]; w->guard_start = count; w->guard_items.assign((size_t)count[nc], 0); }
+        }
+        for (int i = 0; i < n; ++i) { w->guard_min.push_back(mk4(bmin[3 * i], bmin[3 * i + 1], bmin[3 * i + 2], 0)); w->guard_max.push_back(mk4(bmax[3 * i], bmax[3 * i + 1], bmax[3 * i + 2], 0)); }
+    }
+    if (!w->finalized) return RP_OK; // uploaded when the device world is built
+    { int r = settle(w); if (r != RP_OK) return r; }
+    { int r = upload_shard_guard(w); if (r != RP_OK) return r; }
+    destroy_graphs(w); // the captured launches hold the old DevWorld
     return RP_OK;
 }
 // Debug aid (not part of include/rapier_hip.h): the island machinery's counters (slots of the oracle's RO_IS_*), the scan stamp, the

@@ -99,9 +99,29 @@ RP_DEV bool collider_update_one(const DevWorld &w, int i) { // true = the fat AA
         w.c_fatmin[i] = f4(mn - v3(s, s, s), 0.0f);
         w.c_fatmax[i] = f4(mx + v3(s, s, s), 0.0f);
         w.flags[FL_BP_DIRTY] = 1;
-        // queued once per broad-phase pass for the incremental update (rp_broadphase.hip)
-        const int stamp = w.flags[FL_BP_SEQ] + 1;
-        if (w.c_chgstamp[i] != stamp) { w.c_chgstamp[i] = stamp; int k = atomicAdd(&w.flags[FL_BP_NCHG], 1); if (k < w.n_colliders) w.bp_chg_list[k] = i; }
+        // shard guard: islands are sharded over GPUs without any exchange, which is only sound while no body of this shard comes near
+        // a body of another one — a rewritten fat AABB that overlaps a box another shard occupies ends the run with an error
+        if (w.sg_bmin && w.c_parent[i] >= 0 && (w.b_flags[w.c_parent[i]] & RP_BF_TYPE_MASK) != RP_BODY_FIXED && w.c_shape[i] != RP_SHAPE_HALFSPACE) {
+            int lo[3], hi[3];
+            const float a[3] = {mn.x - s, mn.y - s, mn.z - s}, b[3] = {mx.x + s, mx.y + s, mx.z + s};
+            bool outside = false;
+            for (int k = 0; k < 3; ++k) {
+                lo[k] = (int)floorf((a[k] - w.sg_origin[k]) * w.sg_inv_cell); hi[k] = (int)floorf((b[k] - w.sg_origin[k]) * w.sg_inv_cell);
+                outside |= hi[k] < 0 || lo[k] > w.sg_dims[k] - 1;
+                lo[k] = lo[k] < 0 ? 0 : lo[k]; hi[k] = hi[k] > w.sg_dims[k] - 1 ? w.sg_dims[k] - 1 : hi[k];
+            }
+            bool foreign = false;
+            if (!outside)
+                for (int z = lo[2]; z <= hi[2]; ++z) for (int y = lo[1]; y <= hi[1]; ++y) for (int x = lo[0]; x <= hi[0]; ++x) {
+                    const int c = (z * w.sg_dims[1] + y) * w.sg_dims[0] + x;
+                    for (int k = w.sg_cell_start[c]; k < w.sg_cell_start[c + 1]; ++k) {
+                        const int bx = w.sg_cell_items[k];
+                        const float4 bmn = w.sg_bmin[bx], bmx = w.sg_bmax[bx];
+                        foreign |= a[0] <= bmx.x && bmn.x <= b[0] && a[1] <= bmx.y && bmn.y <= b[1] && a[2] <= bmx.z && bmn.z <= b[2];
+                    }
+                }
+            if (foreign) atomicOr(&w.flags[FL_OVERFLOW], RP_OVF_SHARD);
+        }
     }
     return !inside;
 }

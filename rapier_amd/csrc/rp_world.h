@@ -53,6 +53,7 @@
 #define RP_OVF_CONS 0x10
 #define RP_OVF_GRID 0x20   // a workgroup of a fused rebuild kernel was not resident (rp_gridbar.h: its grid barrier timed out)
 #define RP_OVF_FLOW 0x40   // the dataflow solver (rp_flow.hip) gave up waiting for a body record (its grid was not fully resident)
+#define RP_OVF_SHARD 0x80  // a collider of this shard moved into a cell that holds another shard's bodies (rp_world_set_shard_guard)
 
 // device scalar slots (int32) in DevWorld::flags
 enum {
@@ -362,6 +363,10 @@ struct DevWorld {
     float4 *ws_terms;           // [11][2 * cons_cap] warm-start velocity terms per constraint side (rp_solver.hip: k_ws_prepare / k_increment_ws)
 
     // ---- LDS tiles of the global path (rp_tiles.hip): a whole colour sweep inside one CU per tile, halo constraints solved redundantly ----
+    // ---- shard guard (multi-GPU island sharding: this world holds one shard, the cells below belong to the others) ----
+    float4 *sg_bmin, *sg_bmax;  // [boxes] AABBs that hold the bodies of OTHER shards (one per foreign proximity group); null = no guard
+    int *sg_cell_start, *sg_cell_items; // coarse uniform grid over the boxes: CSR lists of the boxes touching each cell (x fastest)
+    float sg_origin[3], sg_inv_cell; int sg_dims[3];
     int c_par;                  // which copy of the MUTABLE constraint planes (impulses, accumulators, rhs: NP_M x 4, CP_HM0, CP_HM1) is current:
                                 // 0 = in place, 1 = the shadow planes behind CP_COUNT.  A tile sweep reads one copy and its owner instances write
                                 // the other (a halo instance must not see the owner's result of the same sweep); every other kernel works in

@@ -129,3 +129,79 @@ def island_shard(rows: int, cols: int, base_count: int, world_size: int, rank: i
 
 # bench.py --gpus N: the pyramid grid each N steps (C4-shaped: ~364.5 islands per GPU; N = 8 is exactly BASELINE config C4)
 C4_GRIDS = {1: (54, 54), 2: (27, 27), 4: (27, 54), 8: (54, 54)}
+
+
+# ---- shards from the device's own proximity groups (no generator knowledge) -------------------------------------------------------------
+def shards_from_groups(groups: np.ndarray, world_size: int):
+    """groups[i] = proximity group of body i (PhysicsWorld.proximity_groups: -1 for fixed bodies) -> (rank of every body, -1 for fixed
+    ones; number of groups): whole groups are bin-packed by body count (`bin_pack`), so no pair or joint ever spans two ranks."""
+    groups = np.asarray(groups)
+    ids, inv, counts = np.unique(groups[groups >= 0], return_inverse=True, return_counts=True)
+    rank_of_group = bin_pack(counts, world_size)
+    body_rank = np.full(len(groups), -1, np.int32)
+    body_rank[groups >= 0] = rank_of_group[inv]
+    return body_rank, len(ids)
+
+
+def body_boxes(scene: S.Scene):
+    """Conservative world AABB of every body (centre of every collider +- its bounding radius): (min[n, 3], max[n, 3])."""
+    nb = len(scene.bodies)
+    lo = np.full((nb, 3), np.inf, np.float64); hi = np.full((nb, 3), -np.inf, np.float64)
+    pos = np.array([b["translation"] for b in scene.bodies], np.float64).reshape(nb, 3)
+    for c, p in zip(scene.colliders, scene.collider_parents):
+        if p < 0:
+            continue
+        he = np.asarray(c["half_extents"], np.float64)
+        shape = int(c["shape"])
+        if shape == S.SHAPE_BALL:
+            r = he[0]
+        elif shape == S.SHAPE_CAPSULE:
+            r = he[0] + he[1]
+        elif shape == S.SHAPE_CUBOID:
+            r = float(np.linalg.norm(he))
+        else:
+            continue  # (half-spaces sit on fixed bodies: never boxed)
+        r += float(np.linalg.norm(np.asarray(c["translation"], np.float64)))  # the collider's offset from the body, whatever the rotation
+        lo[p] = np.minimum(lo[p], pos[p] - r); hi[p] = np.maximum(hi[p], pos[p] + r)
+    return lo, hi
+
+
+def guard_boxes(scene: S.Scene, groups: np.ndarray, body_rank: np.ndarray, rank: int, clearance: float = 0.25):
+    """One box per proximity group that lives on ANOTHER rank (the union of its bodies' boxes, inflated by `clearance`): the input of
+    PhysicsWorld.set_shard_guard for the shard of `rank`."""
+    lo, hi = body_boxes(scene)
+    groups = np.asarray(groups); body_rank = np.asarray(body_rank)
+    foreign = (groups >= 0) & (body_rank != rank) & np.isfinite(lo[:, 0])
+    ids, inv = np.unique(groups[foreign], return_inverse=True)
+    bmin = np.full((len(ids), 3), np.inf); bmax = np.full((len(ids), 3), -np.inf)
+    np.minimum.at(bmin, inv, lo[foreign]); np.maximum.at(bmax, inv, hi[foreign])
+    return (bmin - clearance).astype(np.float32), (bmax + clearance).astype(np.float32)
+
+
+def proximity_groups_from_scene(scene: S.Scene, margin: float = 0.1) -> np.ndarray:
+    """CPU stand-in for PhysicsWorld.proximity_groups on small scenes (tests, the oracle adapter of the gloo bench test): components of
+    the non-fixed bodies whose conservative boxes (inflated by `margin`) overlap, plus joints.  O(n^2): small worlds only."""
+    lo, hi = body_boxes(scene)
+    nb = len(scene.bodies)
+    dyn = np.array([int(b["body_type"]) != S.BODY_FIXED for b in scene.bodies]) & np.isfinite(lo[:, 0])
+    parent = np.arange(nb)
+
+    def find(x):
+        while parent[x] != x:
+            parent[x] = parent[parent[x]]; x = parent[x]
+        return x
+    idx = np.nonzero(dyn)[0]
+    for k, i in enumerate(idx):
+        rest = idx[k + 1:]
+        ov = np.all((lo[i] - margin <= hi[rest] + margin) & (lo[rest] - margin <= hi[i] + margin), axis=1)
+        for j in rest[ov]:
+            a, b = find(i), find(j)
+            if a != b:
+                parent[max(a, b)] = min(a, b)
+    for j in scene.joints:
+        b1, b2 = int(j["body1"]), int(j["body2"])
+        if dyn[b1] and dyn[b2]:
+            a, b = find(b1), find(b2)
+            if a != b:
+                parent[max(a, b)] = min(a, b)
+    return np.array([find(i) if dyn[i] else -1 for i in range(nb)], np.int32)

@@ -360,6 +360,24 @@ class PhysicsWorld:
         _check(self._ptr, self._lib.rp_bodies_persistent_island(self._ptr, len(h), h.ctypes.data, out.ctypes.data), "rp_bodies_persistent_island")
         return out
 
+    def proximity_groups(self, handles=None) -> np.ndarray:
+        """Connected components of the non-fixed bodies over the live broad-phase pairs and the joints (rp_bodies_proximity_group): the
+        unit of island sharding over GPUs.  -1: fixed / removed bodies.  Needs one step."""
+        if handles is None:
+            handles = np.arange(self._lib.rp_num_bodies(self._ptr), dtype=np.uint64)
+        h = np.ascontiguousarray(np.atleast_1d(np.asarray(handles, dtype=np.uint64)))
+        out = np.zeros(len(h), np.int32)
+        _check(self._ptr, self._lib.rp_bodies_proximity_group(self._ptr, len(h), h.ctypes.data, out.ctypes.data), "rp_bodies_proximity_group")
+        return out
+
+    def set_shard_guard(self, box_min=None, box_max=None):
+        """Boxes that hold the bodies of OTHER shards (rp_world_set_shard_guard); None removes the guard."""
+        if box_min is None or len(box_min) == 0:
+            _check(self._ptr, self._lib.rp_world_set_shard_guard(self._ptr, 0, None, None), "rp_world_set_shard_guard")
+            return
+        a = np.ascontiguousarray(np.asarray(box_min, np.float32).reshape(-1, 3)); b = np.ascontiguousarray(np.asarray(box_max, np.float32).reshape(-1, 3))
+        _check(self._ptr, self._lib.rp_world_set_shard_guard(self._ptr, len(a), a.ctypes.data, b.ctypes.data), "rp_world_set_shard_guard")
+
     ISLAND_STATS = ("merged", "multiway_groups", "removals", "connected", "detached", "hot", "over_budget", "sleeping_deferred", "global_splits",
                     "global_split_pieces", "bids", "bid_ties", "sleep_blocked", "order_dependent", "detach_size_ties", "split_keep_ties")
 

@@ -92,7 +92,9 @@ def test_force_dist_runs_the_collective_leg_on_one_rank(tmp_path):
     single rank: what `gpurun` runs on one MI355X with the nccl backend (the log is kept under profiles/)"""
     mp.spawn(_worker_forced, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
     rec = json.load(open(os.path.join(str(tmp_path), "forced.json")))
-    assert rec["line"]["dist"] == {"backend": "gloo", "world_size": 1, "forced": True, "gathered_bodies": 1 + 4 * 55}
+    d = rec["line"]["dist"]
+    assert d["shard_source"].startswith("device proximity groups (4 groups")   # shards derived from the (stand-in) device's groups
+    assert {k: d[k] for k in ("backend", "world_size", "forced", "gathered_bodies")} == {"backend": "gloo", "world_size": 1, "forced": True, "gathered_bodies": 1 + 4 * 55}
     assert rec["line"]["n_gpus"] == 1 and rec["n"] == 221 and rec["line"]["finite"]
 
 
@@ -113,3 +115,29 @@ def test_c4_shards_cover_the_world():
     for n_ranks, grid in sharding.C4_GRIDS.items():
         if n_ranks > 1:
             assert abs(grid[0] * grid[1] / n_ranks - 364.5) < 1e-9
+
+
+def test_shards_from_proximity_groups_and_guard_boxes():
+    """the N > 1 leg no longer needs generator knowledge: groups (here from the CPU stand-in; on the GPU from
+    rp_bodies_proximity_group) -> whole groups bin-packed over ranks -> per-rank sub-scenes + the boxes of the OTHER ranks' groups"""
+    sys.path.insert(0, ROOT)
+    from rapier_amd import scenes as S, sharding
+    sc = S.many_pyramids(3, 4)
+    groups = sharding.proximity_groups_from_scene(sc)
+    assert groups[0] == -1 and len(set(groups[groups >= 0].tolist())) == 12 and (np.bincount(groups[groups >= 0])[np.unique(groups[groups >= 0])] == 55).all()
+    body_rank, ng = sharding.shards_from_groups(groups, 3)
+    assert ng == 12 and body_rank[0] == -1 and sorted(np.bincount(body_rank[body_rank >= 0]).tolist()) == [220, 220, 220]
+    for g in np.unique(groups[groups >= 0]):
+        assert len(set(body_rank[groups == g].tolist())) == 1           # a group never spans two ranks
+    seen = np.zeros(len(sc.bodies), np.int32)
+    lo, hi = sharding.body_boxes(sc)
+    for r in range(3):
+        sub, gids = sharding.partition_scene(sc, body_rank, r)
+        seen[gids[1:]] += 1
+        bmin, bmax = sharding.guard_boxes(sc, groups, body_rank, r)
+        assert bmin.shape == (8, 3) and (bmin < bmax).all()
+        own = np.nonzero(body_rank == r)[0]
+        # no body of this rank starts inside a foreign box (the guard would otherwise fire on the first rewritten fat AABB)
+        for i in own:
+            assert not np.any(np.all((lo[i] <= bmax) & (bmin <= hi[i]), axis=1))
+    assert (seen[1:] == 1).all()
