@@ -53,7 +53,7 @@ void rp_launch_narrowphase(const DevWorld &w, hipStream_t st);
 void rp_launch_narrowphase_part(const DevWorld &w, hipStream_t st, int part);
 void rp_launch_init_bodies(const DevWorld &w, hipStream_t st);
 void rp_launch_solver_assembly(const DevWorld &w, hipStream_t st);
-int rp_launch_solver_loop(const DevWorld &w, hipStream_t st, int parallel_stages, int stage_blocks, int has_restitution, int joint_stages, int tile_grid);
+int rp_launch_solver_loop(const DevWorld &w, hipStream_t st, int parallel_stages, int stage_blocks, int has_restitution, int joint_stages, int tile_grid, int no_contacts_hint);
 void rp_launch_solver_writeback(const DevWorld &w, hipStream_t st, int parity);
 void rp_launch_island_solve(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast, int retire, int fused);
 void rp_launch_global_single(const DevWorld &w, hipStream_t st, int has_restitution, int fast);
@@ -142,12 +142,12 @@ struct rp_world {
     // shard guard (rp_world_set_shard_guard): host copy, re-uploaded whenever the device world is rebuilt
     std::vector<float4> guard_min, guard_max; std::vector<int> guard_start, guard_items; float guard_origin[3] = {0, 0, 0}, guard_cell = 0.0f; int guard_dims[3] = {0, 0, 0};
     // launch plan + graph
-    int plan_stages = 0, plan_blocks = 1, plan_single = 1, plan_island_grid = 1, plan_joint_stages = 0, plan_no_global = 0, plan_fused = 0, plan_tile_grid = 0;
+    int plan_stages = 0, plan_blocks = 1, plan_single = 1, plan_island_grid = 1, plan_joint_stages = 0, plan_no_global = 0, plan_fused = 0, plan_tile_grid = 0, plan_no_contacts = 0;
     bool has_restitution = false;
     // [0] = full path, [1] = fast path; "whole" = one graph per step, col/loop/fin = timed thirds
     hipGraph_t g_whole[2] = {nullptr, nullptr}, g_col[2] = {nullptr, nullptr}, g_loop[2] = {nullptr, nullptr}, g_fin[2] = {nullptr, nullptr};
     hipGraphExec_t ge_whole[2] = {nullptr, nullptr}, ge_col[2] = {nullptr, nullptr}, ge_loop[2] = {nullptr, nullptr}, ge_fin[2] = {nullptr, nullptr};
-    int graph_stages = -1, graph_blocks = -1, graph_single = -1, graph_island_grid = -1, graph_joint_stages = -1, graph_no_global = -1, graph_fused = -1, graph_tile_grid = -1;
+    int graph_stages = -1, graph_blocks = -1, graph_single = -1, graph_island_grid = -1, graph_joint_stages = -1, graph_no_global = -1, graph_fused = -1, graph_tile_grid = -1, graph_no_contacts = -1;
     bool use_graph = true, use_fast = true, use_fused = true;
     bool use_flow = true;          // the dataflow launch (rp_flow.hip) is available; RP_NO_FLOW=1: never, RP_FLOW=1: for every large world
     bool force_flow = false;
@@ -391,7 +391,7 @@ static void destroy_graphs(rp_world *w) {
         for (auto e : ex) if (*e) { hipGraphExecDestroy(*e); *e = nullptr; }
         for (auto g : gr) if (*g) { hipGraphDestroy(*g); *g = nullptr; }
     }
-    w->graph_stages = -1; w->graph_blocks = -1; w->graph_single = -1; w->graph_island_grid = -1; w->graph_joint_stages = -1; w->graph_no_global = -1; w->graph_fused = -1; w->graph_tile_grid = -1;
+    w->graph_stages = -1; w->graph_blocks = -1; w->graph_single = -1; w->graph_island_grid = -1; w->graph_joint_stages = -1; w->graph_no_global = -1; w->graph_fused = -1; w->graph_tile_grid = -1; w->graph_no_contacts = -1;
     w->timed_ready[0] = w->timed_ready[1] = false;
 }
 static void free_device(rp_world *w) {
@@ -1269,7 +1269,7 @@ static int finalize(rp_world *w) {
     {
         const char *nt = getenv("RP_NO_TILES"), *tt = getenv("RP_TILE_TARGET"), *tm = getenv("RP_TILE_MIN");
         d.tile_min = tm && atoi(tm) > 0 ? atoi(tm) : RP_TILE_MIN_BODIES;
-        const bool eligible = !(nt && nt[0] == '1') && nj == 0 && w->params.friction_model != RP_FRICTION_COULOMB && capb >= d.tile_min;
+        const bool eligible = !(nt && nt[0] == '1') && w->params.friction_model != RP_FRICTION_COULOMB && capb >= d.tile_min;
         d.tile_cap = eligible ? capb / 64 + 2 : 0;
         d.tile_target = tt && atoi(tt) > 0 ? atoi(tt) : 240;
         // constraint planes: Coulomb: + 9 tangent planes per point (rp_coulomb.h); worlds that may tile: + the shadow copy of the mutable planes
@@ -1278,6 +1278,7 @@ static int finalize(rp_world *w) {
             DA(d.t_lin, capb); DA(d.t_ang, capb); DA(d.t_rot, capb); DA(d.t_trans, capb); DA(d.fk_ids, d.cons_cap); DA(d.tl_body_tile, capb); DA(d.tl_owned, capb);
             DA(d.tl_hist, 2 * RP_TILE_CELLS); DA(d.tl_cellofs, 2 * RP_TILE_CELLS); DA(d.tl_bbox, 16); DA(d.tl_hdr, d.tile_cap);
             DA(d.tl_cell, capb); DA(d.tl_sorted, capb); DA(d.b_order, capb);
+            if (nj > 0) { DA(d.jm, (size_t)2 * 12 * nj); DA(d.f_jsorted, 2 * (size_t)nj); DA(d.f_jother, 2 * (size_t)nj); } // joint stages on tiles: the sweeps' mutable row words (two copies), sorted joint toucher lists
             { std::vector<int> iota(capb); for (int i = 0; i < capb; ++i) iota[i] = i; HIPCHK(w, hipMemcpy(d.b_order, iota.data(), (size_t)capb * sizeof(int), hipMemcpyHostToDevice)); }
             DA(d.tl_soff, (size_t)d.tile_cap * (RP_TILE_STAGES + 1)); DA(d.tl_bodies, (size_t)d.tile_cap * RP_TILE_BCAP); DA(d.tl_cons, (size_t)d.tile_cap * RP_TILE_CCAP);
             const unsigned rest[16] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
@@ -1388,10 +1389,10 @@ static void enqueue_global_solver(rp_world *w) {
     int hr = w->has_restitution ? 1 : 0;
     if (w->cur_fast && w->plan_no_global) return; // k_fast_front verified on the device that the global path is empty
     if (w->plan_single) rp_launch_global_single(w->dw, w->stream, hr, w->cur_fast);
-    else if (flow_now(w)) rp_launch_global_flow(w->dw, w->stream, w->flow_grid, hr); // one dataflow launch (rp_flow.hip)
+    else if (w->plan_tile_grid == 0 && flow_now(w)) rp_launch_global_flow(w->dw, w->stream, w->flow_grid, hr); // one dataflow launch (rp_flow.hip)
     else {
         rp_launch_solver_assembly(w->dw, w->stream);
-        const int parity = rp_launch_solver_loop(w->dw, w->stream, w->plan_stages, w->plan_blocks, hr, w->plan_joint_stages, w->plan_tile_grid);
+        const int parity = rp_launch_solver_loop(w->dw, w->stream, w->plan_stages, w->plan_blocks, hr, w->plan_joint_stages, w->plan_tile_grid, w->plan_no_contacts);
         rp_launch_solver_writeback(w->dw, w->stream, parity);
     }
 }
@@ -1418,7 +1419,10 @@ static void plan_from_hints(rp_world *w, const int *fl) {
     w->plan_island_grid = std::min(std::max(pow2_ceil(fl[FL_N_ISLANDS]), 1), 8192);
     // LDS tiles (rp_tiles.hip): once the device has published a valid tiling of the global component, a sweep is one launch over the
     // tiles (grid rounded up to 16 so small changes of the tile count do not force a re-capture; the kernel loops over tiles beyond it)
-    w->plan_tile_grid = (w->dw.tile_cap > 0 && !w->plan_single && !flow_now(w) && fl[FL_N_TILES] > 0) ? ((fl[FL_N_TILES] + 15) / 16) * 16 : 0;
+    w->plan_no_contacts = (fl[FL_N_CONS] == 0 && w->dw.tile_cap > 0) ? 1 : 0; // (tile sweeps: the increment folds into the sweep while no manifold exists)
+    // (a valid tiling also replaces the dataflow launch of jointed worlds; forced flow — RP_FLOW=1 — keeps it)
+    w->plan_tile_grid = (w->dw.tile_cap > 0 && !w->plan_single && !w->force_flow && fl[FL_N_TILES] > 0) ? ((fl[FL_N_TILES] + 15) / 16) * 16 : 0;
+    if (w->plan_tile_grid > 0) { w->plan_stages = fl[FL_N_PARALLEL]; w->plan_joint_stages = fl[FL_NJ_STAGES]; w->plan_blocks = std::min(std::max(pow2_ceil((fl[FL_MAX_STAGE] + 255) / 256), 1), 4096); } // (the per-stage launches of the restitution sweep)
     // fused single-kernel fast step: every workgroup must be resident at once (in-launch arrival barrier)
     // (a grid of at most fused_grid workgroups; workgroups loop over islands beyond that)
     // (contact-force events are evaluated by a kernel of their own after every step: such worlds take the two-kernel fast graph)
@@ -1551,11 +1555,11 @@ static int step_once(rp_world *w, bool allow_fast) {
         if (w->plan_island_grid < old_g && w->plan_island_grid * 2 >= old_g) w->plan_island_grid = old_g;
     }
     if (w->graph_stages != w->plan_stages || w->graph_blocks != w->plan_blocks || w->graph_single != w->plan_single ||
-        w->graph_island_grid != w->plan_island_grid || w->graph_joint_stages != w->plan_joint_stages || w->graph_no_global != w->plan_no_global || w->graph_fused != w->plan_fused || w->graph_tile_grid != w->plan_tile_grid) {
+        w->graph_island_grid != w->plan_island_grid || w->graph_joint_stages != w->plan_joint_stages || w->graph_no_global != w->plan_no_global || w->graph_fused != w->plan_fused || w->graph_tile_grid != w->plan_tile_grid || w->graph_no_contacts != w->plan_no_contacts) {
         if (w->ge_whole[0] || w->ge_whole[1] || w->timed_ready[0] || w->timed_ready[1]) HIPCHK(w, hipStreamSynchronize(w->stream)); // replays of the old graphs may still be in flight
         destroy_graphs(w);
         w->graph_stages = w->plan_stages; w->graph_blocks = w->plan_blocks; w->graph_single = w->plan_single; w->graph_island_grid = w->plan_island_grid;
-        w->graph_joint_stages = w->plan_joint_stages; w->graph_no_global = w->plan_no_global; w->graph_fused = w->plan_fused; w->graph_tile_grid = w->plan_tile_grid;
+        w->graph_joint_stages = w->plan_joint_stages; w->graph_no_global = w->plan_no_global; w->graph_fused = w->plan_fused; w->graph_tile_grid = w->plan_tile_grid; w->graph_no_contacts = w->plan_no_contacts;
     }
     // keep the host at most a few steps ahead of the device so the hints stay fresh (the device
     // never idles: several step graphs are always queued)

@@ -462,6 +462,12 @@ __global__ void __launch_bounds__(1024) k_bp_rebuild(DevWorld w) {
     const bool incremental = w.bp_incremental && w.flags[FL_BP_GRID_OK] && nchg > 0 && nchg <= w.n_colliders / 4 + 16 && nmoved + nchg <= RP_BP_MOVED_CAP &&
                              w.flags[FL_BP_TOMBS] < w.hash_cap / 8;
     GridBar bar = gbar_begin(w, 0);
+#ifdef RP_PASS_PROFILE // why a pass was (not) incremental: dbg[240..] (tools/pass_profile.py)
+    if (gid == 0) {
+        w.dbg[240] += 1; w.dbg[241] += incremental ? 1 : 0; w.dbg[242] += w.flags[FL_BP_GRID_OK] ? 0 : 1; w.dbg[243] += (nchg > w.n_colliders / 4 + 16) ? 1 : 0;
+        w.dbg[244] += (nmoved + nchg > RP_BP_MOVED_CAP) ? 1 : 0; w.dbg[245] += (w.flags[FL_BP_TOMBS] >= w.hash_cap / 8) ? 1 : 0; w.dbg[246] += nchg; w.dbg[247] += nmoved;
+    }
+#endif
     if (incremental) {
         bp_incr_insert(w, nchg, nmoved);
         GBAR_SYNC(bar);

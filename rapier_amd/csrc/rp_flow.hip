@@ -190,6 +190,8 @@ struct FlowJointIO {
     RP_DEV void pose(int side, int b, Pose &p) const { p.r = flow_q4(flow_ld(cx.B.rot, b)); p.t = flow_v3(flow_ld(cx.B.trans, b)); }
     RP_DEV void load_vel(int side, int b, V3 &l, V3 &a) const { l = v[side].lin; a = v[side].ang; }
     RP_DEV void store_vel(int side, int b, V3 l, V3 a) const { flow_st_vel(cx.B, b, l, a, t[side]); }
+    RP_DEV int jm_out(const DevWorld &w_) const { return w_.c_par; }
+    RP_DEV bool jm_store() const { return true; }
 };
 
 // ---- toucher lists: ranks of every constraint / joint among the events of its bodies (rebuilt when the layout changed) ---
@@ -255,8 +257,8 @@ RP_DEV void flow_rank(DevWorld &w, int gid, int stride) {
     for (int idx = gid; idx < njl; idx += stride) {
         int j = w.j_order[idx], a = w.j_b1[j], b = w.j_b2[j];
         int2 r = make_int2(-1, -1);
-        if (a >= 0) r.x = flow_rank_in(w.f_jadj, w.fb_begin[a].y, w.fb_deg[a].y, idx);
-        if (b >= 0) r.y = flow_rank_in(w.f_jadj, w.fb_begin[b].y, w.fb_deg[b].y, idx);
+        if (a >= 0) { r.x = flow_rank_in(w.f_jadj, w.fb_begin[a].y, w.fb_deg[a].y, idx); if (w.f_jsorted) { w.f_jsorted[w.fb_begin[a].y + r.x] = idx; w.f_jother[w.fb_begin[a].y + r.x] = b; } }
+        if (b >= 0) { r.y = flow_rank_in(w.f_jadj, w.fb_begin[b].y, w.fb_deg[b].y, idx); if (w.f_jsorted) { w.f_jsorted[w.fb_begin[b].y + r.y] = idx; w.f_jother[w.fb_begin[b].y + r.y] = a; } }
         w.fj_rank[j] = r;
     }
     for (int i = gid; i < w.n_bodies; i += stride) w.fb_fill[i] = make_int2(0, 0); // cursors rest at zero for the next rebuild
@@ -637,9 +639,11 @@ void rp_launch_flow_ranks(const DevWorld &w, hipStream_t st) {
     int blocks = (n + 255) / 256; if (blocks > w.gbar_blocks) blocks = w.gbar_blocks; if (blocks < 1) blocks = 1; // all resident (grid barriers)
     hipLaunchKernelGGL(k_flow_ranks, dim3(blocks), dim3(1024), 0, st, w);
 }
+void rp_launch_tiles_build(const DevWorld &w, hipStream_t st);
 void rp_launch_global_flow(const DevWorld &w, hipStream_t st, int grid, int has_restitution) {
     int nbb = (w.n_bodies + 255) / 256; if (nbb < 1) nbb = 1;
     rp_launch_flow_ranks(w, st);
+    rp_launch_tiles_build(w, st); // worlds that may tile (rp_tiles.hip): the tiling follows the ranks, same gate; once it is valid the host moves the sweeps onto tiles
     hipLaunchKernelGGL(k_flow_begin, dim3(nbb), dim3(256), 0, st, w);
     const bool coul = w.prm.p.friction_model == RP_FRICTION_COULOMB, joints = w.n_joints > 0;
 #define FLOW_LAUNCH(C, J) hipLaunchKernelGGL((k_global_flow<C, J>), dim3(grid), dim3(256), 0, st, w, has_restitution)

@@ -36,16 +36,26 @@ RP_DEV bool joint_live(const DevWorld &w, int j) {
 struct JointRow { V3 lin_jac, ang_jac1, ang_jac2, ii1, ii2; float impulse, inv_lhs, rhs, rhs_wo_bias, cfm_gain, cfm_coeff, bmin, bmax; };
 #define JR_UNBOUNDED 3.402823466e+38f // impulse_bounds of a lock row: [-f32::MAX, f32::MAX]
 
+// The two words of a row that a SWEEP changes — the accumulated impulse (JR_LIN.w) and, when the bias is removed, the right-hand side
+// (JR_A2.w).  Worlds that may run their sweeps on LDS tiles (rp_tiles.hip) keep them in DevWorld::jm instead, two copies: a tile sweep
+// reads copy c_par and its owner instances write the other one (a halo instance must not see the owner's result of the same sweep);
+// every other kernel works in place on the current copy.  jm == null: the words live in the row planes, as ever.
+RP_DEV float2 jm_get(const DevWorld &w, int j, int r, int par) { return w.jm[((size_t)par * JR_MAX_ROWS + r) * w.n_joints + j]; }
+RP_DEV void jm_put(const DevWorld &w, int j, int r, int par, float impulse, float rhs) { w.jm[((size_t)par * JR_MAX_ROWS + r) * w.n_joints + j] = make_float2(impulse, rhs); }
+RP_DEV float jrow_impulse(const DevWorld &w, int j, int r) { return w.jm ? jm_get(w, j, r, w.c_par).x : JRR(r, JR_LIN, j).w; }
+
 RP_DEV void jrow_load(const DevWorld &w, int j, int r, JointRow &c) {
     float4 a = JRR(r, JR_LIN, j), b = JRR(r, JR_A1, j), d = JRR(r, JR_A2, j), e = JRR(r, JR_I1, j), f = JRR(r, JR_I2, j);
     c.lin_jac = v3(a); c.impulse = a.w; c.ang_jac1 = v3(b); c.inv_lhs = b.w; c.ang_jac2 = v3(d); c.rhs = d.w;
     c.ii1 = v3(e); c.rhs_wo_bias = e.w; c.ii2 = v3(f); c.cfm_gain = f.w;
     float4 g = JRR(r, JR_BND, j); c.bmin = g.x; c.bmax = g.y;
+    if (w.jm) { const float2 m = jm_get(w, j, r, w.c_par); c.impulse = m.x; c.rhs = m.y; }
 }
 RP_DEV void jrow_store(const DevWorld &w, int j, int r, const JointRow &c) {
     JRR(r, JR_LIN, j) = f4(c.lin_jac, c.impulse); JRR(r, JR_A1, j) = f4(c.ang_jac1, c.inv_lhs);
     JRR(r, JR_A2, j) = f4(c.ang_jac2, c.rhs); JRR(r, JR_I1, j) = f4(c.ii1, c.rhs_wo_bias); JRR(r, JR_I2, j) = f4(c.ii2, c.cfm_gain);
     JRR(r, JR_BND, j) = make_float4(c.bmin, c.bmax, 0.0f, 0.0f);
+    if (w.jm) jm_put(w, j, r, w.c_par, c.impulse, c.rhs);
 }
 // rows of a joint: the motors of its free axes (GenericJoint::motor_axes & !locked_axes), its locked axes, then the limits of
 // its free axes (limit_axes & !locked_axes)
@@ -109,7 +119,7 @@ RP_DEV void joint_finalize_store(const DevWorld &w, int j, JointRow *rows, const
     const bool ws = w.prm.p.warmstart_joints != 0;
     for (int k = 0; k < len; ++k) {
         // the previous substep's impulse of the same row is still in its plane (the row count of a joint is constant within a step)
-        if (ws) rows[k].impulse = (substep_id == 0 ? joint_seed_impulse(w, j, dof[k]) : JRR(base + k, JR_LIN, j).w) * w.prm.p.warmstart_coefficient;
+        if (ws) rows[k].impulse = (substep_id == 0 ? joint_seed_impulse(w, j, dof[k]) : jrow_impulse(w, j, base + k)) * w.prm.p.warmstart_coefficient;
         jrow_store(w, j, base + k, rows[k]);
     }
 }
@@ -144,7 +154,7 @@ RP_DEV void joint_finalize_store_static(const DevWorld &w, int j, JointRow (&row
     const bool ws = w.prm.p.warmstart_joints != 0;
 #pragma unroll
     for (int k = 0; k < LEN; ++k) {
-        if (ws) rows[k].impulse = (substep_id == 0 ? joint_seed_impulse(w, j, k) : JRR(k, JR_LIN, j).w) * w.prm.p.warmstart_coefficient;
+        if (ws) rows[k].impulse = (substep_id == 0 ? joint_seed_impulse(w, j, k) : jrow_impulse(w, j, k)) * w.prm.p.warmstart_coefficient;
         jrow_store(w, j, k, rows[k]);
     }
 }
@@ -156,6 +166,8 @@ struct PlainBodyIO {
     RP_DEV void pose(int side, int b, Pose &p) const { p.r = q4(w.s_rot[b]); p.t = v3(w.s_trans[b]); }
     RP_DEV void load_vel(int side, int b, V3 &l, V3 &a) const { l = v3(w.s_lin[b]); a = v3(w.s_ang[b]); }
     RP_DEV void store_vel(int side, int b, V3 l, V3 a) const { w.s_lin[b] = f4(l, 0.0f); w.s_ang[b] = f4(a, 0.0f); }
+    RP_DEV int jm_out(const DevWorld &w_) const { return w_.c_par; } // the sweep's mutable row words go back in place
+    RP_DEV bool jm_store() const { return true; }
 };
 
 // JointConstraintBuilder::update for joint j (rows rebuilt from the solver poses s_rot / s_trans).
@@ -391,7 +403,7 @@ RP_DEV void jrows_load(const DevWorld &w, int j, int r0, int nrows, JointRowsT<C
     for (int q = 0; q < CH; ++q) if (r0 + q < nrows) jrow_load(w, j, r0 + q, R.c[q]);
 }
 template <int CH>
-RP_DEV void jrows_solve(const DevWorld &w, int j, int r0, int nrows, JointRowsT<CH> &R, V3 im1, V3 im2, int b1, int b2, V3 &l1, V3 &a1, V3 &l2, V3 &a2, bool wo_bias, bool warmstart) {
+RP_DEV void jrows_solve(const DevWorld &w, int j, int r0, int nrows, JointRowsT<CH> &R, V3 im1, V3 im2, int b1, int b2, V3 &l1, V3 &a1, V3 &l2, V3 &a2, bool wo_bias, bool warmstart, int jm_out, bool jm_store) {
 #pragma unroll
     for (int q = 0; q < CH; ++q) {
         if (r0 + q >= nrows) break;
@@ -421,8 +433,8 @@ RP_DEV void jrows_solve(const DevWorld &w, int j, int r0, int nrows, JointRowsT<
         if (b1 < 0) { l1 = v3(0, 0, 0); a1 = l1; }
         if (b2 < 0) { l2 = v3(0, 0, 0); a2 = l2; }
         // only the mutable words of the row go back
-        JRR(r, JR_LIN, j).w = c.impulse;
-        if (wo_bias) JRR(r, JR_A2, j).w = c.rhs;
+        if (w.jm) { if (jm_store) jm_put(w, j, r, jm_out, c.impulse, c.rhs); }
+        else { JRR(r, JR_LIN, j).w = c.impulse; if (wo_bias) JRR(r, JR_A2, j).w = c.rhs; }
     }
 }
 // rows [0, CH) already fetched into R0 (with nrows, im1, im2) by the caller
@@ -432,8 +444,9 @@ RP_DEV void joint_solve_fetched(const DevWorld &w, const IO &io, int j, int nrow
     V3 l1 = v3(0, 0, 0), a1 = l1, l2 = l1, a2 = l1;
     if (b1 >= 0) io.load_vel(0, b1, l1, a1);
     if (b2 >= 0) io.load_vel(1, b2, l2, a2);
-    jrows_solve<CH>(w, j, 0, nrows, R0, im1, im2, b1, b2, l1, a1, l2, a2, wo_bias, warmstart);
-    for (int r0 = CH; r0 < nrows; r0 += CH) { JointRowsT<CH> R; jrows_load<CH>(w, j, r0, nrows, R); jrows_solve<CH>(w, j, r0, nrows, R, im1, im2, b1, b2, l1, a1, l2, a2, wo_bias, warmstart); }
+    const int jo = io.jm_out(w); const bool js = io.jm_store();
+    jrows_solve<CH>(w, j, 0, nrows, R0, im1, im2, b1, b2, l1, a1, l2, a2, wo_bias, warmstart, jo, js);
+    for (int r0 = CH; r0 < nrows; r0 += CH) { JointRowsT<CH> R; jrows_load<CH>(w, j, r0, nrows, R); jrows_solve<CH>(w, j, r0, nrows, R, im1, im2, b1, b2, l1, a1, l2, a2, wo_bias, warmstart, jo, js); }
     if (b1 >= 0) io.store_vel(0, b1, l1, a1);
     if (b2 >= 0) io.store_vel(1, b2, l2, a2);
 }
@@ -455,7 +468,7 @@ RP_DEV void joint_writeback_one(const DevWorld &w, int j) {
     { float4 l = w.j_imp_lim[j], la = w.j_imp_lim_ang[j]; imp[6] = l.x; imp[7] = l.y; imp[8] = l.z; imp[9] = la.x; imp[10] = la.y; imp[11] = la.z; }
     { float4 m = w.j_imp_mot[j], ma = w.j_imp_mot_ang[j]; imp[12] = m.x; imp[13] = m.y; imp[14] = m.z; imp[15] = ma.x; imp[16] = ma.y; imp[17] = ma.z; }
     int nrows = joint_row_count(locked, limited, motor);
-    for (int k = 0; k < nrows; ++k) imp[joint_row_dof(locked, limited, motor, k)] = JRR(k, JR_LIN, j).w;
+    for (int k = 0; k < nrows; ++k) imp[joint_row_dof(locked, limited, motor, k)] = jrow_impulse(w, j, k);
     w.j_imp[j] = make_float4(imp[0], imp[1], imp[2], 0.0f);
     w.j_imp_ang[j] = make_float4(imp[3], imp[4], imp[5], 0.0f);
     if (limited) { w.j_imp_lim[j] = make_float4(imp[6], imp[7], imp[8], 0.0f); w.j_imp_lim_ang[j] = make_float4(imp[9], imp[10], imp[11], 0.0f); } // JointLimits::impulse

@@ -166,6 +166,12 @@ __global__ void __launch_bounds__(1024) k_joint_layout(DevWorld w) {
         ovf_begin = pos; n_ovf = 0;
         int live = 0; for (int c = 0; c < RP_NUM_COLORS; ++c) live += count[c];
         w.flags[FL_NJ_STAGES] = nst; w.flags[FL_NJ_OVF_BEGIN] = pos; w.flags[FL_NJ_OVF_COUNT] = live - pos;
+        // the serial tail is colour-major too, and a colour below 128 is body-disjoint whatever its size: the tile sweeps (rp_tiles.hip)
+        // take the small colours as further stages behind the parallel ones.  [RP_NUM_COLORS] of the two arrays: how many stages that
+        // makes in all, and how many joints sit in the one colour that is NOT disjoint (128: such a world does not tile)
+        int nall = nst, p2 = pos;
+        for (int c = 0; c < 128; ++c) if (count[c] > 0 && count[c] < RP_JOINT_PARALLEL_MIN) { w.j_stage_begin[nall] = p2; w.j_stage_count[nall] = count[c]; p2 += count[c]; nall++; }
+        w.j_stage_count[RP_NUM_COLORS] = nall; w.j_stage_begin[RP_NUM_COLORS] = count[128];
     }
     __syncthreads();
     // parallel colours: order inside a colour is free (body-disjoint); overflow: collected, then ranked

@@ -99,6 +99,9 @@ RP_DEV bool collider_update_one(const DevWorld &w, int i) { // true = the fat AA
         w.c_fatmin[i] = f4(mn - v3(s, s, s), 0.0f);
         w.c_fatmax[i] = f4(mx + v3(s, s, s), 0.0f);
         w.flags[FL_BP_DIRTY] = 1;
+        // queued once per broad-phase pass for the incremental update (rp_broadphase.hip)
+        const int stamp = w.flags[FL_BP_SEQ] + 1;
+        if (w.c_chgstamp[i] != stamp) { w.c_chgstamp[i] = stamp; int k = atomicAdd(&w.flags[FL_BP_NCHG], 1); if (k < w.n_colliders) w.bp_chg_list[k] = i; }
         // shard guard: islands are sharded over GPUs without any exchange, which is only sound while no body of this shard comes near
         // a body of another one — a rewritten fat AABB that overlaps a box another shard occupies ends the run with an error
         if (w.sg_bmin && w.c_parent[i] >= 0 && (w.b_flags[w.c_parent[i]] & RP_BF_TYPE_MASK) != RP_BODY_FIXED && w.c_shape[i] != RP_SHAPE_HALFSPACE) {

@@ -58,7 +58,13 @@ __global__ void k_integrate(DevWorld w) {
 //                   dataflow solver's toucher ranks), each added exactly as the colour sweep would have added it.
 // Same operands, same order per accumulator (-ffp-contract=off): bit-identical to the per-colour sweep and to the oracle.
 // (WS_TERMS, ws_put / ws_get, body_increment_ws: rp_global.h — shared with the tile sweeps of rp_tiles.hip)
-__global__ void __launch_bounds__(256) k_ws_prepare(DevWorld w, float solved_dt) {
+// joint_substep >= 0: the launch also rebuilds the rows of every impulse joint from the current poses (k_joint_update folded in: both
+// are the pose-dependent, fully parallel preparation of a substep; jointed worlds on tiles save a launch per substep)
+__global__ void __launch_bounds__(256) k_ws_prepare(DevWorld w, float solved_dt, int joint_substep) {
+    if (joint_substep >= 0) {
+        const int jstride = gridDim.x * blockDim.x;
+        for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < w.n_joints; j += jstride) if (joint_live(w, j)) joint_update_one(w, j, joint_substep);
+    }
     int M = w.flags[FL_N_CONS];
     if (M > w.cons_cap) M = w.cons_cap;
     const int stride = gridDim.x * blockDim.x;
@@ -272,7 +278,7 @@ void rp_launch_global_single(const DevWorld &w, hipStream_t st, int has_restitut
 }
 void rp_launch_flow_ranks(const DevWorld &w, hipStream_t st);
 void rp_launch_tiles_build(const DevWorld &w, hipStream_t st);
-void rp_launch_tile_sweep(const DevWorld &w, hipStream_t st, int mode, int grid, int friction_in_bias, float solved_dt, int fuse);
+void rp_launch_tile_sweep(const DevWorld &w, hipStream_t st, int mode, int grid, int friction_in_bias, float solved_dt, int fuse, int joint_warmstart);
 void rp_launch_solver_assembly(const DevWorld &w, hipStream_t st) {
     rp_launch_flow_ranks(w, st); // the per-body toucher lists of the body-centric warm start (only rebuilt when the layout changed)
     rp_launch_tiles_build(w, st); // ... and the LDS tiling of the big component (rp_tiles.hip; same gate)
@@ -284,41 +290,43 @@ void rp_launch_solver_assembly(const DevWorld &w, hipStream_t st) {
 // tile_grid > 0: every biased / relaxed sweep is ONE launch over the LDS tiles (rp_tiles.hip) instead of one per colour stage.  A tile
 // sweep reads the solver velocities from one buffer and writes the other, so the kernels that follow get a DevWorld with the two
 // pointer pairs swapped; returns the parity (1 = the velocities ended in t_lin / t_ang) for rp_launch_solver_writeback.
-int rp_launch_solver_loop(const DevWorld &w0, hipStream_t st, int parallel_stages, int stage_blocks, int has_restitution, int joint_stages, int tile_grid) {
+int rp_launch_solver_loop(const DevWorld &w0, hipStream_t st, int parallel_stages, int stage_blocks, int has_restitution, int joint_stages, int tile_grid, int no_contacts_hint) {
     SolverLaunchPlan plan = {parallel_stages, stage_blocks < 1 ? 1 : stage_blocks};
     DevWorld w = w0;
     int parity = 0; // bit 0: velocities + mutable constraint planes in the other copy, bit 1: poses in the other copy
-    const bool tiles = tile_grid > 0 && w.tile_cap > 0 && w.n_joints == 0 && !host_coulomb(w) && w.ws_terms;
+    const bool tiles = tile_grid > 0 && w.tile_cap > 0 && !host_coulomb(w) && w.ws_terms; // (a tile sweep = the joint stages, then the contact stages)
     int nb = body_blocks(w);
     const rp_integration_params &p = w.prm.p;
     int fib = (p.friction_in_bias_pass || p.num_internal_stabilization_iterations == 0) ? 1 : 0;
     // with tiles the first biased sweep of a substep also increments + warm-starts the bodies, the last one also integrates them
     static const int fuse_mask = getenv("RP_TILE_FUSE") ? atoi(getenv("RP_TILE_FUSE")) : 2; // (experiments: 0 = k_increment_ws / k_integrate stay launches)
     const bool can_fuse = tiles && p.num_internal_pgs_iterations >= 1;
-    const bool fuse_inc = can_fuse && (fuse_mask & 1), fuse_int = can_fuse && (fuse_mask & 2);
-#define TILE_SWEEP(MODE, SDT, FUSE) do { const int fuse_ = (FUSE); rp_launch_tile_sweep(w, st, MODE, tile_grid, fib, SDT, fuse_); \
+    // (a world without contact manifolds — a hint: the folded form is correct either way — has no warm-start terms to gather: the
+    // increment rides the sweep's prologue for free; with contacts the gather of every halo body costs more than the launch, measured)
+    const bool fuse_inc = can_fuse && ((fuse_mask & 1) || ((fuse_mask & 4) == 0 && no_contacts_hint)), fuse_int = can_fuse && (fuse_mask & 2);
+#define TILE_SWEEP(MODE, SDT, FUSE, JWS) do { const int fuse_ = (FUSE); rp_launch_tile_sweep(w, st, MODE, tile_grid, fib, SDT, fuse_, JWS); \
         std::swap(w.s_lin, w.t_lin); std::swap(w.s_ang, w.t_ang); w.c_par ^= 1; parity ^= 1; \
         if (fuse_ & 2) { std::swap(w.s_rot, w.t_rot); std::swap(w.s_trans, w.t_trans); parity ^= 2; } } while (0)
     for (int s = 0; s < w.prm.num_substeps; ++s) {
         float solved_dt = (float)s * w.prm.dt_sub;
         if (!host_coulomb(w) && w.ws_terms) { // body-centric warm start: two launches instead of one per colour
-            hipLaunchKernelGGL(k_ws_prepare, dim3(cons_blocks(w)), dim3(256), 0, st, w, solved_dt);
+            hipLaunchKernelGGL(k_ws_prepare, dim3(cons_blocks(w)), dim3(256), 0, st, w, solved_dt, (tiles && w.n_joints > 0) ? s : -1);
             if (!fuse_inc) hipLaunchKernelGGL(k_increment_ws, dim3(nb), dim3(256), 0, st, w);
-            rp_launch_joint_update(w, st, s);
+            if (!tiles) rp_launch_joint_update(w, st, s);
         } else {
             hipLaunchKernelGGL(k_increment, dim3(nb), dim3(256), 0, st, w);
             rp_launch_joint_update(w, st, s); // rows rebuilt from the current poses (worker.rs:287-357)
             launch_sweep<MODE_WARMSTART>(w, st, plan, fib, solved_dt);
         }
         for (int it = 0; it < p.num_internal_pgs_iterations; ++it) {
-            rp_launch_joint_sweep(w, st, joint_stages, 0, (p.warmstart_joints && it == 0) ? 1 : 0); // all joints before any contact
-            if (tiles) TILE_SWEEP(MODE_BIAS, solved_dt, ((fuse_inc && it == 0) ? 1 : 0) | ((fuse_int && it == p.num_internal_pgs_iterations - 1) ? 2 : 0));
-            else launch_sweep<MODE_BIAS>(w, st, plan, fib, solved_dt);
+            const int jws = (p.warmstart_joints && it == 0) ? 1 : 0;
+            if (tiles) TILE_SWEEP(MODE_BIAS, solved_dt, ((fuse_inc && it == 0) ? 1 : 0) | ((fuse_int && it == p.num_internal_pgs_iterations - 1) ? 2 : 0), jws);
+            else { rp_launch_joint_sweep(w, st, joint_stages, 0, jws); launch_sweep<MODE_BIAS>(w, st, plan, fib, solved_dt); } // all joints before any contact
         }
         if (!fuse_int) hipLaunchKernelGGL(k_integrate, dim3(nb), dim3(256), 0, st, w);
         for (int it = 0; it < p.num_internal_stabilization_iterations; ++it) {
-            rp_launch_joint_sweep(w, st, joint_stages, 1, 0);
-            if (tiles) TILE_SWEEP(MODE_RELAX, solved_dt + w.prm.dt_sub, 0); else launch_sweep<MODE_RELAX>(w, st, plan, fib, solved_dt + w.prm.dt_sub);
+            if (tiles) TILE_SWEEP(MODE_RELAX, solved_dt + w.prm.dt_sub, 0, 0);
+            else { rp_launch_joint_sweep(w, st, joint_stages, 1, 0); launch_sweep<MODE_RELAX>(w, st, plan, fib, solved_dt + w.prm.dt_sub); }
         }
     }
 #undef TILE_SWEEP

@@ -28,12 +28,14 @@
 #include "rp_gridbar.h"
 
 #define RP_TILE_THREADS 256
-#define RP_TILE_HASH 4096 // slots of the body -> local id table of one tile (> 2 x RP_TILE_BCAP)
+#define RP_TILE_HASH 2048 // slots of the body -> local id table of one tile (2 x RP_TILE_BCAP)
 
 // floats as order-preserving unsigned keys (atomicMin / atomicMax over the centres of mass)
 RP_DEV unsigned tile_ord(float f) { unsigned u = (unsigned)__float_as_int(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 RP_DEV float tile_unord(unsigned u) { u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u; return __int_as_float((int)u); }
-RP_DEV unsigned tile_hash(int g) { return ((unsigned)g * 2654435761u) >> 20; } // 12 bits
+// joint colour stages of a sweep as the tiles see them: the parallel colours, then the small ones (k_joint_layout)
+RP_DEV int tile_joint_stages(const DevWorld &w) { return w.n_joints > 0 ? w.j_stage_count[RP_NUM_COLORS] : 0; }
+RP_DEV unsigned tile_hash(int g) { return ((unsigned)g * 2654435761u) >> 21; } // 11 bits
 
 // ---- tiling (one launch behind grid barriers, only when the layout changed) --------------------------------------------------------
 // k_tiles_sort orders the bodies along a Morton curve and produces two things:
@@ -49,7 +51,9 @@ __global__ void __launch_bounds__(1024) k_tiles_sort(DevWorld w) {
     const int gid = gbar_item(), gstride = gridDim.x * blockDim.x, t = threadIdx.x;
     int M = w.flags[FL_N_CONS]; if (M > w.cons_cap) M = w.cons_cap;
     const int nst = w.flags[FL_N_STAGES], nb = w.n_bodies;
-    if (w.flags[FL_N_GLOB_BODIES] < w.tile_min || M < w.tile_min || w.flags[FL_HAS_OVERFLOW_COLOR] || nst > RP_TILE_STAGES || nst < 1) {
+    const int njl = w.n_joints > 0 ? w.flags[FL_NJ_OVF_BEGIN] + w.flags[FL_NJ_OVF_COUNT] : 0, njs = tile_joint_stages(w); // live joints, their colour stages (small colours included)
+    const bool joint_overflow = w.n_joints > 0 && w.j_stage_begin[RP_NUM_COLORS] > 0; // joints in the one colour that is not body-disjoint: not tiled
+    if (w.flags[FL_N_GLOB_BODIES] < w.tile_min || M + njl < w.tile_min || w.flags[FL_HAS_OVERFLOW_COLOR] || joint_overflow || nst + njs > RP_TILE_STAGES || nst + njs < 1) {
         if (gid == 0) { w.flags[FL_N_TILES] = 0; w.tl_bbox[8] = 0u; w.dbg[900] += 1; w.dbg[901] = 1; } // nothing worth tiling / a serial overflow colour: colour stages stay launches
         return;
     }
@@ -151,15 +155,18 @@ __global__ void __launch_bounds__(1024) k_tiles_sort(DevWorld w) {
 #define TW_CUR(wd) (((wd) >> 11) & 0x1fff)
 #define TW_SINCE(wd) ((wd) >> 24)
 #define TW_PACK(since, cur, lid) (((since) << 24) | ((cur) << 11) | (lid))
-struct TileTab { int *hk, *hw, *hbeg, *live, *nloc, *bad; }; // live[tile-local id] = slot: the walkers go over the bodies, not over the (sparse) table
-RP_DEV void tile_insert(const TileTab &T, int g, int since, int cursor, int begin) {
+// hk: arena index; hw: TW_PACK(stage at which the body joined, contact-list entries still ahead, tile-local id); hbeg / hjbeg: begin of
+// the body's contact / joint toucher list; hj: joint-list entries still ahead; live[tile-local id] = slot (the walkers go over the
+// bodies, not over the sparse table)
+struct TileTab { int *hk, *hw, *hbeg, *hj, *hjbeg, *live, *nloc, *bad; };
+RP_DEV void tile_insert(const TileTab &T, int g, int since, int cursor, int begin, int jcursor, int jbegin) {
     unsigned h = tile_hash(g) & (RP_TILE_HASH - 1);
     for (int probes = 0; probes < RP_TILE_HASH; ++probes) {
         int old = atomicCAS(&T.hk[h], -1, g);
         if (old == -1) {
             const int lid = atomicAdd(T.nloc, 1);
             if (lid >= RP_TILE_BCAP || cursor > 0x1fff) { *T.bad = 1; return; } // (the word keeps its rest value: since = -1, never walked)
-            T.hbeg[h] = begin; T.hw[h] = TW_PACK(since, cursor, lid); T.live[lid] = (int)h;
+            T.hbeg[h] = begin; T.hj[h] = jcursor; T.hjbeg[h] = jbegin; T.hw[h] = TW_PACK(since, cursor, lid); T.live[lid] = (int)h;
             return;
         }
         if (old == g) return;
@@ -177,6 +184,20 @@ RP_DEV int tile_find(const TileTab &T, int g) { // slot of body g or -1
         h = (h + 1) & (RP_TILE_HASH - 1);
     }
     return -1;
+}
+// entries of `list` (ascending keys, `key(v)` = v >> shift) that lie below `limit`, of the first `n`: the cursor of a body that joins
+// the cone for the stages before the one that begins at `limit`
+RP_DEV int tile_cursor_below(const int *list, int begin, int n, int shift, int limit) {
+    int c = n;
+    int e8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) e8[k] = k < c ? (list[begin + c - 1 - k] >> shift) : -1; // the last eight entries in one round trip
+    int drop = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (e8[k] >= limit) ++drop; // (entries descend from the end: the ones >= limit are a prefix of e8)
+    c -= drop;
+    if (drop == 8) while (c > 0 && (list[begin + c - 1] >> shift) >= limit) --c;
+    return c;
 }
 #define RP_CONE_THREADS 512
 __global__ void __launch_bounds__(RP_CONE_THREADS) k_tiles_cones(DevWorld w) {
@@ -201,60 +222,59 @@ __global__ void __launch_bounds__(RP_CONE_THREADS) k_tiles_cones(DevWorld w) {
     const int NT = w.flags[FL_N_TILES];
     if (NT <= 0) return;
     const int nst = w.flags[FL_N_STAGES], NG = (int)w.tl_bbox[6], T = (int)w.tl_bbox[7];
-    __shared__ int hk[RP_TILE_HASH], hw[RP_TILE_HASH], hbeg[RP_TILE_HASH];
+    const int njs = tile_joint_stages(w), nall = njs + nst; // a sweep = every joint stage, then every contact stage (solve.rs:89-92)
+    __shared__ int hk[RP_TILE_HASH], hw[RP_TILE_HASH], hbeg[RP_TILE_HASH], hj[RP_TILE_HASH], hjbeg[RP_TILE_HASH];
     __shared__ int live[RP_TILE_BCAP], cpos[RP_TILE_CCAP / 2], ssoff[RP_TILE_STAGES + 2];
     __shared__ int nloc, ncons, bad, nsnap;
-    const TileTab Tb = {hk, hw, hbeg, live, &nloc, &bad};
+    const TileTab Tb = {hk, hw, hbeg, hj, hjbeg, live, &nloc, &bad};
     for (int tile = blockIdx.x; tile < NT; tile += gridDim.x) {
         __syncthreads();
         for (int h = t; h < RP_TILE_HASH; h += nt) { hk[h] = -1; hw[h] = (int)0xff000000; } // (a slot claimed during a stage shows since = -1 until its owner has filled it in: skipped)
         if (t == 0) { nloc = 0; ncons = 0; bad = 0; }
         __syncthreads();
         const int ob = tile * T, oc = (NG - ob) < T ? (NG - ob) : T;
-        for (int k = t; k < oc; k += nt) { const int g = w.tl_owned[ob + k]; tile_insert(Tb, g, nst, w.fb_deg[g].x, w.fb_begin[g].x); }
+        for (int k = t; k < oc; k += nt) { const int g = w.tl_owned[ob + k]; const int2 d = w.fb_deg[g], bg = w.fb_begin[g]; tile_insert(Tb, g, nall, d.x, bg.x, njs ? d.y : 0, bg.y); }
         int4 *cons = w.tl_cons + (size_t)tile * RP_TILE_CCAP;
         int *soff = w.tl_soff + (size_t)tile * (RP_TILE_STAGES + 1);
         __syncthreads();
-        if (t == 0) { soff[nst] = RP_TILE_CCAP; nsnap = nloc; }
+        if (t == 0) { soff[nall] = RP_TILE_CCAP; nsnap = nloc; }
         __syncthreads();
-        // Backwards over the sweep.  Every needed body walks its own toucher list (k_flow_ranks: the positions of the manifolds that
-        // touch it, ascending = sweep order, and the body on the other side of each) from the end: the positions of a stage are one
-        // contiguous range and a body has at most one manifold per stage (a colour is body-disjoint), so "my manifold of stage s" is the
-        // list entry under the cursor or nothing.  The manifold joins the cone; its other body, if it was not needed yet, becomes needed
-        // for the stages before s — nothing else of stage s can touch that body, so lookups and insertions of one stage may interleave
-        // freely.  When both bodies were needed already, both find the manifold: the one with the smaller index reports it.
-        for (int s = nst - 1; s >= 0; --s) {
-            const int beg = w.stage_begin[s];
+        // Backwards over the sweep.  Every needed body walks its own toucher lists (k_flow_ranks: the manifolds / joints that touch it in
+        // sweep order, and the body on the other side of each) from the end: the items of a stage are one contiguous range of positions
+        // (joint sweep indices) and a body has at most one item per stage (a colour is body-disjoint), so "my item of stage S" is the
+        // list entry under the cursor or nothing.  The item joins the cone; its other body, if it was not needed yet, becomes needed for
+        // the stages before S — nothing else of stage S can touch that body, so lookups and insertions of one stage may interleave
+        // freely.  When both bodies were needed already, both find the item: the one with the smaller index reports it.
+        for (int S = nall - 1; S >= 0; --S) {
+            const bool jst = S < njs;
+            const int beg = jst ? w.j_stage_begin[S] : w.stage_begin[S - njs];
             const int n0 = nsnap < RP_TILE_BCAP ? nsnap : RP_TILE_BCAP; // the bodies needed before this stage began
             for (int lid = t; lid < n0; lid += nt) {
                 const int h = live[lid];
                 const int a = hk[h], wd = hw[h];
-                if (TW_SINCE(wd) <= s) continue;
-                const int c = TW_CUR(wd);
+                if (TW_SINCE(wd) <= S) continue;
+                const int c = jst ? hj[h] : TW_CUR(wd);
                 if (c <= 0) continue;
-                const int at = hbeg[h] + c - 1;
-                const int pos = w.f_sorted[at] >> 1, b = w.f_other[at];
-                if (pos < beg) continue; // this body has no manifold of stage s
-                hw[h] = wd - (1 << 11);
+                const int at = (jst ? hjbeg[h] : hbeg[h]) + c - 1;
+                const int item = jst ? w.f_jsorted[at] : (w.f_sorted[at] >> 1), b = jst ? w.f_jother[at] : w.f_other[at];
+                if (item < beg) continue; // this body has no item of stage S
+                if (jst) hj[h] = c - 1; else hw[h] = wd - (1 << 11);
                 if (b >= 0) {
                     const int hb = tile_find(Tb, b);
-                    if (hb >= 0 && TW_SINCE(hw[hb]) > s) { if (b < a) continue; } // needed on both sides: b's walker reports it
-                    else { // b joins the cone for the stages before s: its cursor skips the entries of stage s and later
-                        const int lb = w.fb_begin[b].x; int cb = w.fb_deg[b].x;
-                        int e8[8];
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) e8[k] = k < cb ? (w.f_sorted[lb + cb - 1 - k] >> 1) : -1; // the last eight entries in one round trip
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) if (e8[k] >= beg) --cb; // (entries descend from the end: the ones >= beg are a prefix of e8)
-                        if (cb > 0 && e8[7] >= beg) while (cb > 0 && (w.f_sorted[lb + cb - 1] >> 1) >= beg) --cb;
-                        tile_insert(Tb, b, s, cb, lb);
+                    if (hb >= 0 && TW_SINCE(hw[hb]) > S) { if (b < a) continue; } // needed on both sides: b's walker reports it
+                    else { // b joins the cone for the stages before S: its cursors skip the entries of stage S and later
+                        const int2 db = w.fb_deg[b], bb = w.fb_begin[b];
+                        // (joining at a joint stage: only joint stages lie before it; at a contact stage: every joint stage does)
+                        const int cc = jst ? 0 : tile_cursor_below(w.f_sorted, bb.x, db.x, 1, beg);
+                        const int cj = !njs ? 0 : (jst ? tile_cursor_below(w.f_jsorted, bb.y, db.y, 0, beg) : db.y);
+                        tile_insert(Tb, b, S, cc, bb.x, cj, bb.y);
                     }
                 }
                 const int k = atomicAdd(&ncons, 1);
-                if (k < RP_TILE_CCAP) cons[RP_TILE_CCAP - 1 - k] = make_int4(pos, 0, 0, 0); else bad = 1;
+                if (k < RP_TILE_CCAP) cons[RP_TILE_CCAP - 1 - k] = make_int4(jst ? -1 - item : item, 0, 0, 0); else bad = 1;
             }
             __syncthreads();
-            if (t == 0) { soff[s] = RP_TILE_CCAP - (ncons < RP_TILE_CCAP ? ncons : RP_TILE_CCAP); nsnap = nloc; } // the list is filled from its end: ascending stages once read forwards
+            if (t == 0) { soff[S] = RP_TILE_CCAP - (ncons < RP_TILE_CCAP ? ncons : RP_TILE_CCAP); nsnap = nloc; } // the list is filled from its end: ascending stages once read forwards
             __syncthreads();
         }
         if (t == 0) { // statistics of the tiling (tools/tile_diag.py)
@@ -270,24 +290,27 @@ __global__ void __launch_bounds__(RP_CONE_THREADS) k_tiles_cones(DevWorld w) {
         const bool pack = nc <= RP_TILE_CCAP / 2;
         const int tail0 = RP_TILE_CCAP - nc;
         if (pack) for (int k = t; k < nc; k += nt) cpos[k] = cons[tail0 + k].x;
-        for (int s2 = t; s2 <= nst; s2 += nt) ssoff[s2] = soff[s2] - tail0; // stage begins relative to the cone's first entry
+        for (int s2 = t; s2 <= nall; s2 += nt) ssoff[s2] = soff[s2] - tail0; // stage begins relative to the cone's first entry
         __syncthreads();
         for (int k = t; k < nc; k += nt) {
-            const int pos = pack ? cpos[k] : cons[tail0 + k].x;
+            const int item = pack ? cpos[k] : cons[tail0 + k].x; // a manifold position, or -1 - (joint sweep index)
             int dst = tail0 + k;
             if (pack) {
-                int sg = 0; while (sg + 1 < nst && ssoff[sg + 1] <= k) ++sg;
+                int sg = 0; while (sg + 1 < nall && ssoff[sg + 1] <= k) ++sg;
                 int r = 0;
-                for (int j = ssoff[sg]; j < ssoff[sg + 1]; ++j) r += cpos[j] < pos;
+                if (item >= 0) { for (int q = ssoff[sg]; q < ssoff[sg + 1]; ++q) r += cpos[q] < item; }
+                else { for (int q = ssoff[sg]; q < ssoff[sg + 1]; ++q) r += cpos[q] > item; } // (-1 - index: ascending index = descending code)
                 dst = ssoff[sg] + r;
             }
-            const int2 ab = w.fk_ids[pos];
+            int2 ab; int code;
+            if (item >= 0) { ab = w.fk_ids[item]; code = item; }
+            else { const int j = w.j_order[-1 - item]; ab = make_int2(w.j_b1[j], w.j_b2[j]); code = -1 - j; } // (the sweep wants the joint itself)
             const int first = ab.x >= 0 ? ab.x : ab.y;
             const int own = w.tl_body_tile[first] == tile ? 1 : 0;
             const int l1 = ab.x >= 0 ? TW_LID(hw[tile_find(Tb, ab.x)]) : -1, l2 = ab.y >= 0 ? TW_LID(hw[tile_find(Tb, ab.y)]) : -1;
-            cons[dst] = make_int4(pos, l1, l2, own);
+            cons[dst] = make_int4(code, l1, l2, own);
         }
-        if (pack) for (int s2 = t; s2 <= nst; s2 += nt) soff[s2] = ssoff[s2];
+        if (pack) for (int s2 = t; s2 <= nall; s2 += nt) soff[s2] = ssoff[s2];
         if (t == 0) w.tl_hdr[tile] = make_int4(nloc, nc, oc, 0);
     }
 }
@@ -373,11 +396,36 @@ RP_DEV void tile_apply(const DevWorld &w, const int4 e, const int n, const int *
     if (MODE != MODE_RELAX) A.st(CP_HM1, v[CP_HM1]);
 }
 
+// one cone JOINT of one joint stage: joint_solve_one_t of rp_joints.h (the rows of k_joint_update, [remove bias] [warm start] solve)
+// over LDS velocities; the two words a sweep changes per row live in DevWorld::jm (read copy c_par, owner instances write the other)
+struct TileJointIO {
+    float4 *Ll, *La; int l1, l2, out; bool own;
+    RP_DEV void load_vel(int side, int b, V3 &l, V3 &a) const { const int lid = side ? l2 : l1; l = v3(Ll[lid]); a = v3(La[lid]); }
+    RP_DEV void store_vel(int side, int b, V3 l, V3 a) const { const int lid = side ? l2 : l1; Ll[lid] = f4(l, 0.0f); La[lid] = f4(a, 0.0f); }
+    RP_DEV int jm_out(const DevWorld &) const { return out; }
+    RP_DEV bool jm_store() const { return own; }
+};
+// Everything a joint solve reads that is not a velocity: the axis masks (-> row count), the inverse masses and the first three rows,
+// fetched in ONE round trip whatever the count turns out to be (every joint owns twelve row slots; a spherical joint — b3d_joint_grid —
+// has exactly three).  None of it changes during a sweep (the rows are rebuilt between sweeps, the sweep's own words go to the other
+// copy of DevWorld::jm), so the fetch of a thread's NEXT joint stage is issued a whole stage ahead.
+struct TileJointPre { int locked, limited, motor; V3 im1, im2; JointRowsT<3> R; };
+RP_DEV void tile_joint_fetch(const DevWorld &w, int j, TileJointPre &P) {
+    P.locked = w.j_locked[j]; P.limited = w.j_limited[j]; P.motor = w.j_motor[j];
+    P.im1 = v3(JRP(JR_IM1, j)); P.im2 = v3(JRP(JR_IM2, j));
+#pragma unroll
+    for (int q = 0; q < 3; ++q) jrow_load(w, j, q, P.R.c[q]);
+}
+RP_DEV void tile_apply_joint(const DevWorld &w, const int4 e, TileJointPre &P, float4 *Ll, float4 *La, bool wo_bias, bool warmstart) {
+    const TileJointIO io = {Ll, La, e.y, e.z, w.c_par ^ 1, e.w != 0};
+    joint_solve_fetched<TileJointIO, 3>(w, io, -1 - e.x, joint_row_count(P.locked, P.limited, P.motor), P.im1, P.im2, P.R, wo_bias, warmstart);
+}
+
 // fuse bit 0: the sweep starts the substep — every cone body is incremented and warm-started on its way into LDS (k_increment_ws folded
 //             in; halo bodies redundantly);  bit 1: the sweep ends the biased phase — owned bodies are integrated on their way out
 //             (k_integrate folded in): velocities AND poses then go to the other buffers (t_lin / t_ang / t_rot / t_trans).
 template <int MODE>
-__global__ void __launch_bounds__(RP_TILE_THREADS) k_tile_sweep(DevWorld w, int friction_in_bias, float solved_dt, int fuse) {
+__global__ void __launch_bounds__(RP_TILE_THREADS) k_tile_sweep(DevWorld w, int friction_in_bias, float solved_dt, int fuse, int joint_warmstart) {
     const int NT = w.flags[FL_N_TILES];
     const int t = threadIdx.x, nt = blockDim.x;
     const bool fib = friction_in_bias != 0;
@@ -388,6 +436,7 @@ __global__ void __launch_bounds__(RP_TILE_THREADS) k_tile_sweep(DevWorld w, int 
             for (int i = t; i < w.n_bodies; i += nt) if (global_body(w, i)) { V3 lin, ang; body_increment_ws(w, i, lin, ang); w.s_lin[i] = f4(lin, 0.0f); w.s_ang[i] = f4(ang, 0.0f); }
             __threadfence(); __syncthreads();
         }
+        if (MODE != MODE_RESTITUTION) joint_tail_sweep(w, 0, MODE == MODE_RELAX, joint_warmstart != 0); // every joint before any contact
         tail_sweep<MODE, false>(w, 0, fib, solved_dt);
         if (fuse & 2) {
             for (int i = t; i < w.n_bodies; i += nt) if (global_body(w, i)) g_body_integrate(w, i);
@@ -403,12 +452,14 @@ __global__ void __launch_bounds__(RP_TILE_THREADS) k_tile_sweep(DevWorld w, int 
                 const int plane = m < 4 ? NPL(m, NP_M) : (m == 4 ? CP_HM0 : CP_HM1);
                 w.C[(size_t)cplane(plane, w.c_par ^ 1) * w.cons_cap + pos] = w.C[(size_t)cplane(plane, w.c_par) * w.cons_cap + pos];
             }
+        if (w.jm) for (size_t k = t; k < (size_t)JR_MAX_ROWS * w.n_joints; k += nt) w.jm[(size_t)(w.c_par ^ 1) * JR_MAX_ROWS * w.n_joints + k] = w.jm[(size_t)w.c_par * JR_MAX_ROWS * w.n_joints + k];
         return;
     }
     __shared__ float4 Ll[RP_TILE_BCAP], La[RP_TILE_BCAP];
     __shared__ int Lg[RP_TILE_BCAP];
-    __shared__ int Soff[RP_TILE_STAGES + 2];
-    const int nst = w.flags[FL_N_STAGES];
+    __shared__ int Soff[RP_TILE_STAGES + 4];
+    const int njs = tile_joint_stages(w); // joint stages come first in a sweep
+    const int nst = njs + w.flags[FL_N_STAGES];
     const bool friction = MODE == MODE_RELAX || (MODE == MODE_BIAS && fib);
 #ifdef RP_TILE_PROFILE // thread 0 of tile 0 accumulates wall-clock ticks (10 ns) per phase into dbg[920 + 24 * MODE ..] (tools/tile_diag.py)
 #define TP_STAMP(k) do { if (blockIdx.x == 0 && t == 0) { const long long n_ = (long long)wall_clock64(); w.dbg[920 + 24 * MODE + (k)] += n_ - tp_; tp_ = n_; } } while (0)
@@ -425,14 +476,15 @@ __global__ void __launch_bounds__(RP_TILE_THREADS) k_tile_sweep(DevWorld w, int 
             if (fuse & 1) { V3 lin, ang; body_increment_ws(w, g, lin, ang); Ll[l] = f4(lin, 0.0f); La[l] = f4(ang, 0.0f); }
             else { Ll[l] = w.s_lin[g]; La[l] = w.s_ang[g]; }
         }
-        for (int s = t; s <= nst + 1; s += nt) Soff[s] = w.tl_soff[(size_t)tile * (RP_TILE_STAGES + 1) + (s < nst ? s : nst)];
+        for (int s = t; s <= nst + 3; s += nt) Soff[s] = w.tl_soff[(size_t)tile * (RP_TILE_STAGES + 1) + (s < nst ? s : nst)];
         __syncthreads();
         const int4 *cons = w.tl_cons + (size_t)tile * RP_TILE_CCAP;
         // the list entry (and point count) of a thread's next stage is fetched while it works on the current one: a stage then costs one
-        // round trip (the rows) instead of two
-        // (branch-free: a load inside a conditional block is waited for at the end of the block)
+        // round trip (the rows) instead of two (branch-free: a load inside a conditional block is waited for at the end of the block).
+        // (A deeper pipeline — entries two stages ahead, the rows of the next JOINT stage one ahead — was built and measured: the
+        // registers it holds across the contact stages cost b3d_large_pyramid 0.544 -> 0.623 ms and the joint stages gained nothing.)
         int4 e_next; int n_next; bool have_next;
-        { const int i0 = Soff[0] + t; have_next = i0 < Soff[1]; e_next = cons[have_next ? i0 : 0]; n_next = w.k_n[e_next.x]; }
+        { const int i0 = Soff[0] + t; have_next = i0 < Soff[1]; e_next = cons[have_next ? i0 : 0]; n_next = w.k_n[e_next.x > 0 ? e_next.x : 0]; }
         TP_STAMP(0);
         for (int s = 0; s < nst; ++s) {
             const int end = Soff[s + 1];
@@ -440,12 +492,22 @@ __global__ void __launch_bounds__(RP_TILE_THREADS) k_tile_sweep(DevWorld w, int 
             int4 e = e_next; int n = n_next;
             bool have = have_next;
             { const int i1 = end + t; have_next = i1 < Soff[s + 2]; e_next = cons[have_next ? i1 : 0]; } // (Soff[nst + 1] = Soff[nst]: nothing behind the last stage)
-            while (have) {
-                tile_apply<MODE>(w, e, n, Lg, Ll, La, fib, friction, solved_dt);
-                i += nt; have = i < end;
-                if (have) { e = cons[i]; n = w.k_n[e.x]; }
+            if (s < njs) { // a joint stage (wave-uniform)
+                while (have) {
+                    TileJointPre P;
+                    tile_joint_fetch(w, -1 - e.x, P);
+                    tile_apply_joint(w, e, P, Ll, La, MODE == MODE_RELAX, joint_warmstart != 0);
+                    i += nt; have = i < end;
+                    if (have) e = cons[i];
+                }
+            } else {
+                while (have) {
+                    tile_apply<MODE>(w, e, n, Lg, Ll, La, fib, friction, solved_dt);
+                    i += nt; have = i < end;
+                    if (have) { e = cons[i]; n = w.k_n[e.x]; }
+                }
             }
-            n_next = w.k_n[e_next.x];
+            n_next = w.k_n[e_next.x > 0 ? e_next.x : 0]; // (a joint entry carries a negative code: no point count)
             // the barrier orders the LDS velocities only: a thread's row stores may stay in flight (nothing reads them before the next kernel)
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             TP_STAMP(4 + (s < 16 ? s : 16));
@@ -476,10 +538,10 @@ void rp_launch_tiles_build(const DevWorld &w, hipStream_t st) {
     hipLaunchKernelGGL(k_tiles_cones, dim3(w.tile_target < w.tile_cap ? w.tile_target : w.tile_cap), dim3(RP_CONE_THREADS), 0, st, w); // (no grid barrier: any grid will do, workgroups loop over tiles)
 }
 // one sweep over every tile: reads w.s_lin / w.s_ang, leaves the result in w.t_lin / w.t_ang (the caller swaps the pointers)
-void rp_launch_tile_sweep(const DevWorld &w, hipStream_t st, int mode, int grid, int friction_in_bias, float solved_dt, int fuse) {
+void rp_launch_tile_sweep(const DevWorld &w, hipStream_t st, int mode, int grid, int friction_in_bias, float solved_dt, int fuse, int joint_warmstart) {
     if (grid < 1) grid = 1;
-    if (mode == MODE_BIAS) hipLaunchKernelGGL(k_tile_sweep<MODE_BIAS>, dim3(grid), dim3(RP_TILE_THREADS), 0, st, w, friction_in_bias, solved_dt, fuse);
-    else hipLaunchKernelGGL(k_tile_sweep<MODE_RELAX>, dim3(grid), dim3(RP_TILE_THREADS), 0, st, w, friction_in_bias, solved_dt, fuse);
+    if (mode == MODE_BIAS) hipLaunchKernelGGL(k_tile_sweep<MODE_BIAS>, dim3(grid), dim3(RP_TILE_THREADS), 0, st, w, friction_in_bias, solved_dt, fuse, joint_warmstart);
+    else hipLaunchKernelGGL(k_tile_sweep<MODE_RELAX>, dim3(grid), dim3(RP_TILE_THREADS), 0, st, w, friction_in_bias, solved_dt, fuse, joint_warmstart);
     // (the restitution sweep, rare, stays on the per-stage launches: rp_solver.hip)
 }
 // workgroups of k_tiles_sort (1024 threads) one CU holds at once (0 = the query failed): input of DevWorld::gbar_blocks (rp_api.hip)

@@ -23,7 +23,7 @@
 #define RP_ISL_NB_MAX 64             // bodies per LDS-resident island
 #define RP_ISL_NC_MAX 160            // solver manifolds per LDS-resident island
 #define RP_FID_UNKNOWN 0xffffu
-#define RP_TILE_BCAP 1536            // cone bodies (owned + halo) of one LDS tile (rp_tiles.hip)
+#define RP_TILE_BCAP 1024            // cone bodies (owned + halo) of one LDS tile (rp_tiles.hip)
 #define RP_TILE_CCAP 3072            // cone constraints of one tile
 #define RP_TILE_STAGES 127           // sweep stages a tiling handles (every colour but the overflow one)
 #define RP_TILE_CELLS 4096           // cells of the Morton counting sort that orders bodies into tiles (12 bits)
@@ -346,6 +346,7 @@ struct DevWorld {
     unsigned long long *nc_keys; // [n_nc] sorted (min body << 32 | max body) keys of the joints with contacts_enabled = false
     int *b_njoints;             // joints attached to a body (bodies with joints stay on the global path)
     float4 *JR;                 // [JR_COUNT][n_joints] constraint rows, up to 12 per joint (rp_joints.h)
+    float2 *jm;                 // [2][12][n_joints] (impulse, rhs) of every row, two copies (worlds that may tile: rp_joints.h jm_get; null otherwise)
 
     // ---- constraints ----
     float4 *C;                  // [CP_COUNT][cons_cap]
@@ -359,6 +360,7 @@ struct DevWorld {
     int2 *fb_begin, *fb_fill;   // [n_bodies] list begin / fill cursor inside f_adj, f_jadj
     int *f_adj, *f_jadj;        // [2 * cons_cap] positions, [2 * n_joints] joint sweep indices
     int *f_sorted;              // [2 * cons_cap] the contact touchers of every body in sweep order (f_adj ranked), as term rows 2 * position + side (side 0 = the manifold's body 1): the body-centric warm start, the cone walk of the tiles
+    int *f_jsorted, *f_jother;  // [2 * n_joints] the joint touchers of every body in joint sweep order (indices into j_order) and the body on the other side (worlds that may tile)
     int *f_other;               // [2 * cons_cap] the solver body on the other side of f_sorted[i] (-1 = world-attached): the cone walk of rp_tiles.hip
     float4 *ws_terms;           // [11][2 * cons_cap] warm-start velocity terms per constraint side (rp_solver.hip: k_ws_prepare / k_increment_ws)
 

@@ -110,3 +110,38 @@ def test_body_removal_and_impulses_retile(monkeypatch):
 def test_world_below_the_threshold_keeps_the_launches(monkeypatch):
     g, _, c = _run(S.large_pyramid(30), [5], monkeypatch, want_tiles=False, RP_FORCE_MULTI=1)
     assert c["num_tiles"] == 0 and c["tile_sweeps"] == 0, c
+
+
+# ---- impulse joints on tiles: the joint stages of a sweep run ahead of its contact stages inside the same launch --------------------
+def test_joint_grid_on_tiles_bit_exact(monkeypatch):
+    """b3d_joint_grid at 40 x 40 (1,560 balls, 3,120 spherical joints, no contacts): the dataflow launch until the tiling is valid,
+    then joint stages on tiles; joint impulses included"""
+    g, o, c = _run(S.joint_grid(40), [1, 4, 20, 60, 120], monkeypatch)
+    gc, gi = g.read_joints(); oc, oi = o.read_joints()
+    np.testing.assert_array_equal(gc, oc, err_msg="joint colours"); np.testing.assert_array_equal(gi, oi, err_msg="joint impulses")
+
+
+def test_joint_net_with_warm_start_on_tiles_bit_exact(monkeypatch):
+    sc = S.joint_net(36)
+    sc.params["warmstart_joints"] = 1
+    _run(sc, [2, 30, 90], monkeypatch, RP_TILE_MIN=256)
+
+
+@pytest.mark.parametrize("seed", [1000, 1001, 1002])
+def test_fuzz_pile_on_tiles_bit_exact(monkeypatch, seed):
+    """the randomised differential test's 700-body pile (three shapes, compound and kinematic bodies, sleeping, events, a pendulum
+    joint, random user actions) with the tiling threshold lowered so that its giant island runs on tiles"""
+    import test_gpu_fuzz as F
+    for k in ("RP_NO_TILES", "RP_TILE_TARGET", "RP_FORCE_MULTI"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("RP_TILE_MIN", "128")
+    F._run(seed, steps=260, n=700, spread=2.2, per_layer=49, walls=True, calm=True)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_fuzz_jointed_clutter_on_tiles_bit_exact(monkeypatch, seed):
+    """400 bodies with every joint kind (limits, motors, up to 12 rows per joint), joint warm start on seed 1"""
+    import test_gpu_fuzz as F
+    monkeypatch.setenv("RP_TILE_MIN", "64")
+    monkeypatch.setenv("RP_FORCE_MULTI", "1")
+    F._run(seed, steps=200, n=400, spread=4.0, per_layer=36, walls=True)

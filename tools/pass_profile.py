@@ -44,3 +44,9 @@ for title, base, names in (("k_layout_rebuild", 0, lay), ("k_bp_rebuild (full pa
     tot = sum(int(buf[base + k]) for k in range(len(names)))
     print(f"{name} {title}: {n} dirty launches, {tot / n / 100:.1f} us each:", " | ".join(f"{nm} {int(buf[base + k]) / n / 100:.1f}" for k, nm in enumerate(names)))
 print(w.counters())
+
+why = np.zeros(8, np.int64)
+assert L.rp_debug_read(w._ptr, 240, 8, why.ctypes.data) == 0
+if why[0]:
+    print(f"{name} broad-phase passes {why[0]}: incremental {why[1]}, not incremental because: grid not ok {why[2]}, too many changed {why[3]}, stale list full {why[4]}, tombstones {why[5]}; "
+          f"changed colliders per pass {why[6] / why[0]:.0f}, stale colliders {why[7] / why[0]:.0f}")

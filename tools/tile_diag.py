@@ -2,7 +2,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rapier_amd import PhysicsWorld, scenes as S
-sc = S.large_pyramid(200) if len(sys.argv) > 1 and sys.argv[1] == "lp" else S.reference_pile(14, 5, 14, chain=False, sleep=False)
+sc = {"lp": lambda: S.large_pyramid(200), "jg": lambda: S.joint_grid(100)}.get(sys.argv[1] if len(sys.argv) > 1 else "", lambda: S.reference_pile(14, 5, 14, chain=False, sleep=False))()
 w = PhysicsWorld.from_scene(sc)
 done = 0
 for cp in (1, 5, 20, 40, 60, 80, 120):
