@@ -68,65 +68,7 @@ __global__ void __launch_bounds__(256) k_ws_prepare(DevWorld w, float solved_dt,
     int M = w.flags[FL_N_CONS];
     if (M > w.cons_cap) M = w.cons_cap;
     const int stride = gridDim.x * blockDim.x;
-    for (int pos = blockIdx.x * blockDim.x + threadIdx.x; pos < M; pos += stride) {
-        const GlobalAcc A(w, pos);
-        const int id1 = A.id1(), id2 = A.id2(), n = A.n();
-        const bool is_static = id1 < 0 || id2 < 0;
-        const float fstatic = is_static ? 1.0f : 0.0f;
-        const float cfm_factor = w.prm.dyn_cfm + fstatic * (w.prm.static_cfm - w.prm.dyn_cfm);
-        const float erp_inv_dt = w.prm.dyn_erp_inv_dt + fstatic * (w.prm.static_erp_inv_dt - w.prm.dyn_erp_inv_dt);
-        const float inv_dt = w.prm.inv_dt_sub, maxcv = w.prm.max_corrective_velocity, wc = w.prm.p.warmstart_coefficient;
-        const Xf x1 = A.xf(id1), x2 = A.xf(id2);
-        const float4 h0 = A.ld(CP_H0), h6 = A.ld(CP_H6);
-        const V3 dir1 = v3(h0), t0 = v3(h6), t1 = cross(dir1, t0);
-        const V3 tangent_delta = v3(A.ld(CP_B2)) * solved_dt;
-        const V3 im1 = v3(A.ld(CP_H1)), im2 = v3(A.ld(CP_H2));
-        const bool ws = wc != 0.0f;
-        const int s1 = id1 >= 0 ? 2 * pos : -1, s2 = id2 >= 0 ? 2 * pos + 1 : -1;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (k >= n) break;
-            float4 m = A.ld(NPL(k, NP_M));
-            float4 c = A.ld(NPL(k, NP_C)), d = A.ld(NPL(k, NP_D));
-            V3 p1 = xf_tp(x1, v3(A.ld(NPL(k, NP_E)))) + tangent_delta;
-            V3 p2 = xf_tp(x2, v3(A.ld(NPL(k, NP_F))));
-            float dist = c.w + dot(p1 - p2, dir1);
-            float rhs_wo_bias = rp_max(dist, 0.0f) * inv_dt;
-            float rhs_bias = rp_clamp(dist * erp_inv_dt, -maxcv, 0.0f);
-            m.x = rhs_wo_bias + rhs_bias;
-            m.y = dist <= 0.0f ? cfm_factor : 1.0f;
-            m.w += m.z;
-            m.z *= wc;
-            A.st(NPL(k, NP_M), m);
-            if (ws) { // ContactConstraintNormalPartSlim::warmstart, contact_constraint_element.rs:465-478
-                ws_put(w, k, s1, cmul(dir1, im1) * m.z); ws_put(w, 5 + k, s1, v3(c) * m.z);
-                ws_put(w, k, s2, cmul(dir1, im2) * (-m.z)); ws_put(w, 5 + k, s2, v3(d) * m.z);
-            }
-        }
-        float4 hm0 = A.ld(CP_HM0), hm1 = A.ld(CP_HM1), h7 = A.ld(CP_H7);
-        {
-            V3 p1 = xf_tp(x1, v3(A.ld(CP_B0))) + tangent_delta;
-            V3 p2 = xf_tp(x2, v3(A.ld(CP_B1)));
-            float bias0 = dot(p1 - p2, t0) * inv_dt, bias1 = dot(p1 - p2, t1) * inv_dt;
-            hm1.z = h6.w + bias0; hm1.w = h7.x + bias1;
-            hm1.x += hm0.z; hm1.y += hm0.w;
-            hm0.z *= wc; hm0.w *= wc;
-            hm0.y += hm0.x;
-            hm0.x *= wc;
-        }
-        A.st(CP_HM0, hm0); A.st(CP_HM1, hm1);
-        if (ws) {
-            const float i0 = hm0.z, i1 = hm0.w;
-            ws_put(w, 4, s1, cmul(t0 * i0 + t1 * i1, im1)); ws_put(w, 9, s1, v3(A.ld(CP_T4)) * i0 + v3(A.ld(CP_T5)) * i1);
-            ws_put(w, 4, s2, cmul(t0 * (-i0) + t1 * (-i1), im2)); ws_put(w, 9, s2, v3(A.ld(CP_T6)) * i0 + v3(A.ld(CP_T7)) * i1);
-            if (n > 1) {
-                float4 h3 = A.ld(CP_H3), h4 = A.ld(CP_H4), h5 = A.ld(CP_H5);
-                Sym3 ii1 = {h3.x, h3.y, h3.z, h3.w, h4.x, h4.y}, ii2 = {h4.z, h4.w, h5.x, h5.y, h5.z, h5.w};
-                ws_put(w, 10, s1, sym_mul(ii1, dir1) * hm0.x);
-                ws_put(w, 10, s2, -(sym_mul(ii2, dir1) * hm0.x)); // v2.ang - y == v2.ang + (-y), exactly
-            }
-        }
-    }
+    for (int pos = blockIdx.x * blockDim.x + threadIdx.x; pos < M; pos += stride) ws_prepare_one(w, GlobalAcc(w, pos), pos, solved_dt);
 }
 __global__ void __launch_bounds__(256) k_increment_ws(DevWorld w) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -307,6 +249,9 @@ int rp_launch_solver_loop(const DevWorld &w0, hipStream_t st, int parallel_stage
 #define TILE_SWEEP(MODE, SDT, FUSE, JWS) do { const int fuse_ = (FUSE); rp_launch_tile_sweep(w, st, MODE, tile_grid, fib, SDT, fuse_, JWS); \
         std::swap(w.s_lin, w.t_lin); std::swap(w.s_ang, w.t_ang); w.c_par ^= 1; parity ^= 1; \
         if (fuse_ & 2) { std::swap(w.s_rot, w.t_rot); std::swap(w.s_trans, w.t_trans); parity ^= 2; } } while (0)
+    // (Folding k_ws_prepare into the owner instances of the relaxed sweep — the rows are in registers there — was built and measured:
+    // the extra arithmetic and 22 term stores per manifold inside the issue-bound stage loop cost more than the three launches it
+    // removes: b3d_large_pyramid solver 0.472 -> 0.497 ms.  It stays a launch.)
     for (int s = 0; s < w.prm.num_substeps; ++s) {
         float solved_dt = (float)s * w.prm.dt_sub;
         if (!host_coulomb(w) && w.ws_terms) { // body-centric warm start: two launches instead of one per colour
