@@ -25,7 +25,9 @@
 // than RP_TILE_MIN_BODIES bodies) publishes FL_N_TILES = 0 and keeps the per-stage launches; a sweep kernel that finds no tiling runs
 // the sweep in one workgroup (correct, slow) until the host has read the hint.
 #include "rp_global.h"
+#include "rp_lanepair.h"
 #include "rp_gridbar.h"
+#include <cstdlib>
 
 #define RP_TILE_THREADS 256
 #define RP_TILE_HASH 2048 // slots of the body -> local id table of one tile (2 x RP_TILE_BCAP)
@@ -396,6 +398,84 @@ RP_DEV void tile_apply(const DevWorld &w, const int4 e, const int n, const int *
     if (MODE != MODE_RELAX) A.st(CP_HM1, v[CP_HM1]);
 }
 
+// The same constraint by a PAIR of adjacent lanes (rp_lanepair.h: the island kernel's form): the even lane fetches and holds body 1's
+// half of every row, the odd lane body 2's, the halves of each relative velocity meet through DPP quad permutes.  A tile stage is
+// bound by the instruction issue of its one wavefront per SIMD (~2,000 instructions for a relaxed 4-point solve in the one-lane form):
+// the pair halves the stream and the row loads per lane.  Same operations on the same operands as cons_solve (the island kernel is
+// compared with the oracle bit for bit over the same rows): identical results.
+template <int MODE>
+RP_DEV void tile_apply2(const DevWorld &w, const int4 e, const int n, const bool odd, const int *Lg, float4 *Ll, float4 *La, bool friction, float solved_dt) {
+    const int pos = e.x;
+    const size_t cap = w.cons_cap;
+#define TL2(pe, po) w.C[(size_t)(odd ? (po) : (pe)) * cap + pos]   // an immutable plane per lane parity
+#define TLM(p) w.C[(size_t)cplane(p, w.c_par) * cap + pos]          // a mutable plane (even lane's business; both lanes fetch it)
+    float4 h0 = TL2(CP_H0, CP_H0), h6 = TL2(CP_H6, CP_H6), imr = TL2(CP_H1, CP_H2), h2 = TL2(CP_H2, CP_H2), hm0 = TLM(CP_HM0), hm1 = TLM(CP_HM1);
+    float4 pa[4], pc[4], pm[4], lp[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { // (all four points: no load waits for the point count)
+        pa[k] = TL2(NPL(k, NP_A), NPL(k, NP_B)); pc[k] = TL2(NPL(k, NP_C), NPL(k, NP_D)); pm[k] = TLM(NPL(k, NP_M));
+        if (MODE == MODE_RELAX) lp[k] = TL2(NPL(k, NP_E), NPL(k, NP_F));
+    }
+    float4 iiA = h0, iiB = h0, td0 = h0, td1 = h0, itd0 = h0, itd1 = h0, h7 = h0, h8 = h0, b2 = h0, xr = h0, xt = h0;
+    if (friction) {
+        iiA = TL2(CP_H3, CP_H5); iiB = TL2(CP_H4, CP_H4); td0 = TL2(CP_T0, CP_T2); td1 = TL2(CP_T1, CP_T3); itd0 = TL2(CP_T4, CP_T6); itd1 = TL2(CP_T5, CP_T7);
+        h7 = TL2(CP_H7, CP_H7); h8 = TL2(CP_H8, CP_H8);
+    }
+    const int lid = odd ? e.z : e.y;
+    if (MODE == MODE_RELAX) { b2 = TL2(CP_B2, CP_B2); const int g = Lg[lid >= 0 ? lid : 0]; xr = w.s_rot[g]; xt = w.s_trans[g]; }
+#undef TL2
+#undef TLM
+    __builtin_amdgcn_sched_group_barrier(0x020, 48, 0); // every VMEM read above as one group
+#define P4(r_) asm volatile("" : "+v"((r_).x), "+v"((r_).y), "+v"((r_).z), "+v"((r_).w))
+    P4(h0); P4(h6); P4(imr); P4(h2); P4(hm0); P4(hm1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { P4(pa[k]); P4(pc[k]); P4(pm[k]); if (MODE == MODE_RELAX) P4(lp[k]); }
+    if (friction) { P4(iiA); P4(iiB); P4(td0); P4(td1); P4(itd0); P4(itd1); P4(h7); P4(h8); }
+    if (MODE == MODE_RELAX) { P4(b2); P4(xr); P4(xt); }
+#undef P4
+    IslSide h;
+    h.odd = odd; h.id = lid; h.n = n; h.cids = 0;
+    h.dir = v3(h0); h.t0 = v3(h6); h.t1 = cross(h.dir, h.t0);
+    h.im = v3(imr);
+    { const V3 dim = cmul(h.dir, h.im); h.sdim = odd ? -dim : dim; }
+    {
+        const Sym3 ii = odd ? Sym3{iiB.z, iiB.w, iiA.x, iiA.y, iiA.z, iiA.w} : Sym3{iiA.x, iiA.y, iiA.z, iiA.w, iiB.x, iiB.y};
+        const V3 tw = sym_mul(ii, h.dir);
+        h.stw = odd ? -tw : tw;
+    }
+    h.td0 = v3(td0); h.td1 = v3(td1); h.itd0 = v3(itd0); h.itd1 = v3(itd1);
+    h.mu = h0.w; h.twist_r = imr.w; h.rhs_wo0 = h6.w; h.rhs_wo1 = h7.x; h.k11 = h7.y; h.k22 = h7.z; h.k12 = h2.w * 0.5f;
+    h.inv_det = rp_inv(h.k11 * h.k22 - h.k12 * h.k12);
+    h.td[0] = h8.x; h.td[1] = h8.y; h.td[2] = h8.z; h.td[3] = h8.w;
+    h.tw_imp = hm0.x; h.tw_acc = hm0.y; h.t_imp0 = hm0.z; h.t_imp1 = hm0.w; h.t_acc0 = hm1.x; h.t_acc1 = hm1.y; h.t_rhs0 = hm1.z; h.t_rhs1 = hm1.w;
+    h.tb0 = 0.0f; h.tb1 = 0.0f; h.cfm_factor = 0.0f; h.erp_inv_dt = 0.0f;
+    Xf x; x.r = q4(xr); x.t = v3(xt);
+    if (lid < 0) { x.r = q4(0, 0, 0, 1); x.t = v3(0, 0, 0); }
+    const V3 tangent_delta = v3(b2) * solved_dt;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        SidePoint &q = h.P[k];
+        q.pa = v3(pa[k]); q.r = pa[k].w; q.pc = v3(pc[k]); q.d0 = pc[k].w; q.seed = 0.0f;
+        q.rhs = pm[k].x; q.cfm = pm[k].y; q.lam = pm[k].z; q.acc = pm[k].w; q.rhsR = 0.0f; q.rhsB = 0.0f; q.cfmB = 1.0f;
+        if (MODE == MODE_RELAX) { // refresh_rhs_wo_bias (:529-554): p1 = T1 lp1 + delta on the even lane, p2 = T2 lp2 on the odd one
+            V3 pw = xf_tp(x, v3(lp[k]));
+            pw = sel(odd, pw, pw + tangent_delta);
+            const V3 p2 = dppv<DPP_FROM_ODD>(pw);
+            const float dist = q.d0 + dot(pw - p2, h.dir);
+            q.rhsR = rp_max(dist, 0.0f) * w.prm.inv_dt_sub;
+        }
+    }
+    IslLds L; L.lin = Ll; L.ang = La; L.rot = nullptr; L.trans = nullptr; L.E = nullptr; L.F = nullptr; L.B0 = nullptr; L.B1 = nullptr;
+    isl_solve(h, L, MODE == MODE_RELAX, friction);
+    if (!odd && e.w != 0) { // the owner's even lane stores the manifold's mutable planes into the other copy (all of them: see tile_apply)
+        const int par = w.c_par ^ 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { if (k >= n) break; const SidePoint &q = h.P[k]; w.C[(size_t)cplane(NPL(k, NP_M), par) * cap + pos] = make_float4(q.rhs, q.cfm, q.lam, q.acc); }
+        w.C[(size_t)cplane(CP_HM0, par) * cap + pos] = make_float4(h.tw_imp, h.tw_acc, h.t_imp0, h.t_imp1);
+        w.C[(size_t)cplane(CP_HM1, par) * cap + pos] = make_float4(h.t_acc0, h.t_acc1, h.t_rhs0, h.t_rhs1);
+    }
+}
+
 // one cone JOINT of one joint stage: joint_solve_one_t of rp_joints.h (the rows of k_joint_update, [remove bias] [warm start] solve)
 // over LDS velocities; the two words a sweep changes per row live in DevWorld::jm (read copy c_par, owner instances write the other)
 struct TileJointIO {
@@ -424,7 +504,8 @@ RP_DEV void tile_apply_joint(const DevWorld &w, const int4 e, TileJointPre &P, f
 // fuse bit 0: the sweep starts the substep — every cone body is incremented and warm-started on its way into LDS (k_increment_ws folded
 //             in; halo bodies redundantly);  bit 1: the sweep ends the biased phase — owned bodies are integrated on their way out
 //             (k_integrate folded in): velocities AND poses then go to the other buffers (t_lin / t_ang / t_rot / t_trans).
-template <int MODE>
+// LP: two lanes per manifold (tile_apply2) instead of one (tile_apply); RP_TILE_LANES=1 keeps the one-lane form
+template <int MODE, bool LP>
 __global__ void __launch_bounds__(RP_TILE_THREADS) k_tile_sweep(DevWorld w, int friction_in_bias, float solved_dt, int fuse, int joint_warmstart) {
     const int NT = w.flags[FL_N_TILES];
     const int t = threadIdx.x, nt = blockDim.x;
@@ -483,27 +564,35 @@ __global__ void __launch_bounds__(RP_TILE_THREADS) k_tile_sweep(DevWorld w, int 
         // round trip (the rows) instead of two (branch-free: a load inside a conditional block is waited for at the end of the block).
         // (A deeper pipeline — entries two stages ahead, the rows of the next JOINT stage one ahead — was built and measured: the
         // registers it holds across the contact stages cost b3d_large_pyramid 0.544 -> 0.623 ms and the joint stages gained nothing.)
+        const int my = LP ? (t >> 1) : t, per = LP ? (nt >> 1) : nt; // a stage's entries go to lanes (one-lane form) or lane pairs
+        const bool odd = LP && (t & 1);
+        // (Asking for the rows of stage s + 1 a stage ahead — one dword per row through global_load_lds into a junk LDS slot — was built
+        // and measured: every stage got ~50 % SLOWER.  The sweeps already pull 2.3-4.6 TB/s from HBM (PMC FETCH_SIZE: 100 MB per relaxed
+        // launch in 43 us): what bounds a stage is the traffic the tiling demands — rows x 1.95 instances — not the latency of one miss.)
         int4 e_next; int n_next; bool have_next;
-        { const int i0 = Soff[0] + t; have_next = i0 < Soff[1]; e_next = cons[have_next ? i0 : 0]; n_next = w.k_n[e_next.x > 0 ? e_next.x : 0]; }
+        { const int i0 = Soff[0] + my; have_next = i0 < Soff[1]; e_next = cons[have_next ? i0 : 0]; n_next = w.k_n[e_next.x > 0 ? e_next.x : 0]; }
         TP_STAMP(0);
         for (int s = 0; s < nst; ++s) {
             const int end = Soff[s + 1];
-            int i = Soff[s] + t;
+            int i = Soff[s] + my;
             int4 e = e_next; int n = n_next;
             bool have = have_next;
-            { const int i1 = end + t; have_next = i1 < Soff[s + 2]; e_next = cons[have_next ? i1 : 0]; } // (Soff[nst + 1] = Soff[nst]: nothing behind the last stage)
-            if (s < njs) { // a joint stage (wave-uniform)
+            { const int i1 = end + my; have_next = i1 < Soff[s + 2]; e_next = cons[have_next ? i1 : 0]; } // (Soff[nst + 1] = Soff[nst]: nothing behind the last stage)
+            if (s < njs) { // a joint stage (wave-uniform); one lane per joint (the even lane of a pair)
                 while (have) {
-                    TileJointPre P;
-                    tile_joint_fetch(w, -1 - e.x, P);
-                    tile_apply_joint(w, e, P, Ll, La, MODE == MODE_RELAX, joint_warmstart != 0);
-                    i += nt; have = i < end;
+                    if (!odd) {
+                        TileJointPre P;
+                        tile_joint_fetch(w, -1 - e.x, P);
+                        tile_apply_joint(w, e, P, Ll, La, MODE == MODE_RELAX, joint_warmstart != 0);
+                    }
+                    i += per; have = i < end;
                     if (have) e = cons[i];
                 }
             } else {
                 while (have) {
-                    tile_apply<MODE>(w, e, n, Lg, Ll, La, fib, friction, solved_dt);
-                    i += nt; have = i < end;
+                    if (LP) tile_apply2<MODE>(w, e, n, odd, Lg, Ll, La, friction, solved_dt);
+                    else tile_apply<MODE>(w, e, n, Lg, Ll, La, fib, friction, solved_dt);
+                    i += per; have = i < end;
                     if (have) { e = cons[i]; n = w.k_n[e.x]; }
                 }
             }
@@ -540,8 +629,14 @@ void rp_launch_tiles_build(const DevWorld &w, hipStream_t st) {
 // one sweep over every tile: reads w.s_lin / w.s_ang, leaves the result in w.t_lin / w.t_ang (the caller swaps the pointers)
 void rp_launch_tile_sweep(const DevWorld &w, hipStream_t st, int mode, int grid, int friction_in_bias, float solved_dt, int fuse, int joint_warmstart) {
     if (grid < 1) grid = 1;
-    if (mode == MODE_BIAS) hipLaunchKernelGGL(k_tile_sweep<MODE_BIAS>, dim3(grid), dim3(RP_TILE_THREADS), 0, st, w, friction_in_bias, solved_dt, fuse, joint_warmstart);
-    else hipLaunchKernelGGL(k_tile_sweep<MODE_RELAX>, dim3(grid), dim3(RP_TILE_THREADS), 0, st, w, friction_in_bias, solved_dt, fuse, joint_warmstart);
+    static const bool pairs = !(getenv("RP_TILE_LANES") && atoi(getenv("RP_TILE_LANES")) == 1);
+    if (pairs) {
+        if (mode == MODE_BIAS) hipLaunchKernelGGL((k_tile_sweep<MODE_BIAS, true>), dim3(grid), dim3(RP_TILE_THREADS), 0, st, w, friction_in_bias, solved_dt, fuse, joint_warmstart);
+        else hipLaunchKernelGGL((k_tile_sweep<MODE_RELAX, true>), dim3(grid), dim3(RP_TILE_THREADS), 0, st, w, friction_in_bias, solved_dt, fuse, joint_warmstart);
+    } else {
+        if (mode == MODE_BIAS) hipLaunchKernelGGL((k_tile_sweep<MODE_BIAS, false>), dim3(grid), dim3(RP_TILE_THREADS), 0, st, w, friction_in_bias, solved_dt, fuse, joint_warmstart);
+        else hipLaunchKernelGGL((k_tile_sweep<MODE_RELAX, false>), dim3(grid), dim3(RP_TILE_THREADS), 0, st, w, friction_in_bias, solved_dt, fuse, joint_warmstart);
+    }
     // (the restitution sweep, rare, stays on the per-stage launches: rp_solver.hip)
 }
 // workgroups of k_tiles_sort (1024 threads) one CU holds at once (0 = the query failed): input of DevWorld::gbar_blocks (rp_api.hip)
