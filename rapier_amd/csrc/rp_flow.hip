@@ -266,6 +266,7 @@ RP_DEV void flow_rank(DevWorld &w, int gid, int stride) {
 
 // the four passes as ONE launch behind grid barriers (rp_gridbar.h): a step whose layout did not change pays a single early exit
 __global__ void __launch_bounds__(1024) k_flow_ranks(DevWorld w) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) w.flags[FL_ANY_BOUNCY] = 0; // (the first launch of every solver assembly: k_begin_generate / k_flow_begin raise it)
     if (!w.flags[FL_FLOW_DIRTY]) return; // (cleared by the kernel that starts the solve: k_flow_begin / k_solver_begin)
     const int gid = gbar_item(), gstride = gridDim.x * blockDim.x;
     GridBar bar = gbar_begin(w, 3);

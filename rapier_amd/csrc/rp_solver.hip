@@ -21,6 +21,7 @@
 #include "rp_groups.h"
 #include <utility>
 #include <cstdlib>
+#include <algorithm>
 
 // ---- MULTI mode kernels ---------------------------------------------------------------------------
 __global__ void k_solver_begin(DevWorld w) {
@@ -28,6 +29,41 @@ __global__ void k_solver_begin(DevWorld w) {
     if (i == 0) { w.flags[FL_ANY_BOUNCY] = 0; w.flags[FL_FLOW_DIRTY] = 0; } // (the toucher ranks were rebuilt by the launches before this one)
     if (i >= w.n_bodies || !global_body(w, i)) return;
     g_body_begin(w, i);
+}
+// generate straight from the body arrays: the solver bodies k_solver_begin derives (lin / ang = the body velocities, solver pose =
+// (rotation, world centre of mass): the very expressions of body_begin) are recomputed per manifold side, so S0 and S1 need no kernel
+// boundary between them — one launch (k_begin_generate) instead of two
+template <bool PRE>
+struct GenAccT : GlobalAccT<PRE> {
+    RP_DEV GenAccT(const DevWorld &w_, int pos_) : GlobalAccT<PRE>(w_, pos_) {}
+    RP_DEV Vel vel(int id) const {
+        const DevWorld &w = this->w;
+        Vel v;
+        if (id < 0) { v.lin = v3(0, 0, 0); v.ang = v3(0, 0, 0); } else { v.lin = v3(w.b_linvel[id]); v.ang = v3(w.b_angvel[id]); }
+        return v;
+    }
+    RP_DEV Xf xf(int id) const {
+        const DevWorld &w = this->w;
+        Xf x;
+        if (id < 0) { x.r = q4(0, 0, 0, 1); x.t = v3(0, 0, 0); }
+        else { x.r = q4(w.b_rot[id]); x.t = qrot(x.r, v3(w.b_lcom_invm[id])) + v3(w.b_pos[id]); }
+        return x;
+    }
+};
+template <bool COUL>
+__global__ void __launch_bounds__(256) k_begin_generate(DevWorld w) { // (FL_ANY_BOUNCY was reset by k_flow_ranks, the launch before)
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    if (gid == 0) w.flags[FL_FLOW_DIRTY] = 0; // (the toucher ranks and the tiling were rebuilt by the launches before this one)
+    for (int i = gid; i < w.n_bodies; i += stride) if (global_body(w, i)) g_body_begin(w, i);
+    int M = w.flags[FL_N_CONS];
+    if (M > w.cons_cap) M = w.cons_cap;
+    for (int pos = gid; pos < M; pos += stride) {
+        const int s = w.cons_pair[pos];
+        const int rb1 = w.c_parent[w.p_c1[s]], rb2 = w.c_parent[w.p_c2[s]], rel_dom = w.p_reldom[s];
+        const int id1 = (body_active(w, rb1) && rel_dom <= 0) ? rb1 : -1, id2 = (body_active(w, rb2) && rel_dom >= 0) ? rb2 : -1; // (g_generate)
+        const bool bouncy = COUL ? coul_generate(w, GenAccT<true>(w, pos), s, id1, id2, id1, id2) : cons_generate(w, GenAccT<true>(w, pos), s, id1, id2, id1, id2);
+        if (bouncy) w.flags[FL_ANY_BOUNCY] = 1;
+    }
 }
 template <bool COUL>
 __global__ void __launch_bounds__(256) k_generate(DevWorld w) { // (256 threads: the whole register file, no spills)
@@ -100,6 +136,8 @@ __global__ void k_writeback_impulses(DevWorld w) {
     if (M > w.cons_cap) M = w.cons_cap;
     int stride = gridDim.x * blockDim.x;
     for (int pos = blockIdx.x * blockDim.x + threadIdx.x; pos < M; pos += stride) { if (COUL) coul_writeback(w, GlobalAcc(w, pos), w.cons_pair[pos]); else cons_writeback(w, GlobalAcc(w, pos), w.cons_pair[pos]); }
+    // (the joints' impulses ride the same launch: an independent item-parallel loop — one launch less per step in jointed worlds)
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < w.n_joints; j += stride) if (joint_live(w, j)) joint_writeback_one(w, j);
 }
 __global__ void k_writeback_bodies(DevWorld w) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -224,9 +262,9 @@ void rp_launch_tile_sweep(const DevWorld &w, hipStream_t st, int mode, int grid,
 void rp_launch_solver_assembly(const DevWorld &w, hipStream_t st) {
     rp_launch_flow_ranks(w, st); // the per-body toucher lists of the body-centric warm start (only rebuilt when the layout changed)
     rp_launch_tiles_build(w, st); // ... and the LDS tiling of the big component (rp_tiles.hip; same gate)
-    hipLaunchKernelGGL(k_solver_begin, dim3(body_blocks(w)), dim3(256), 0, st, w);
-    if (host_coulomb(w)) hipLaunchKernelGGL(k_generate<true>, dim3(cons_blocks(w)), dim3(256), 0, st, w);
-    else hipLaunchKernelGGL(k_generate<false>, dim3(cons_blocks(w)), dim3(256), 0, st, w);
+    const int blocks = std::max(body_blocks(w), cons_blocks(w)) > 2048 ? 2048 : std::max(body_blocks(w), cons_blocks(w));
+    if (host_coulomb(w)) hipLaunchKernelGGL(k_begin_generate<true>, dim3(blocks), dim3(256), 0, st, w);
+    else hipLaunchKernelGGL(k_begin_generate<false>, dim3(blocks), dim3(256), 0, st, w);
 }
 // The TGS loop proper: S2..S7 for every substep (+ S8 restitution) — worker.rs:207-734.
 // tile_grid > 0: every biased / relaxed sweep is ONE launch over the LDS tiles (rp_tiles.hip) instead of one per colour stage.  A tile
@@ -284,7 +322,6 @@ void rp_launch_solver_writeback(const DevWorld &w0, hipStream_t st, int parity) 
     if (parity & 2) { std::swap(w.s_rot, w.t_rot); std::swap(w.s_trans, w.t_trans); } // ... and the poses
     if (host_coulomb(w)) hipLaunchKernelGGL(k_writeback_impulses<true>, dim3(cons_blocks(w)), dim3(256), 0, st, w);
     else hipLaunchKernelGGL(k_writeback_impulses<false>, dim3(cons_blocks(w)), dim3(256), 0, st, w);
-    rp_launch_joint_writeback(w, st);
     hipLaunchKernelGGL(k_writeback_bodies, dim3(body_blocks(w)), dim3(256), 0, st, w);
     hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, w); // hint buffer (MULTI mode: after the step)
 }
