@@ -54,7 +54,8 @@ void rp_launch_narrowphase_part(const DevWorld &w, hipStream_t st, int part);
 void rp_launch_init_bodies(const DevWorld &w, hipStream_t st);
 void rp_launch_solver_assembly(const DevWorld &w, hipStream_t st);
 int rp_launch_solver_loop(const DevWorld &w, hipStream_t st, int parallel_stages, int stage_blocks, int has_restitution, int joint_stages, int tile_grid, int no_contacts_hint);
-void rp_launch_solver_writeback(const DevWorld &w, hipStream_t st, int parity);
+void rp_launch_solver_writeback(const DevWorld &w, hipStream_t st, int parity, int publish);
+bool rp_ccd_launches(const DevWorld &w);
 void rp_launch_island_solve(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast, int retire, int fused);
 void rp_launch_global_single(const DevWorld &w, hipStream_t st, int has_restitution, int fast);
 void rp_launch_fast_front(const DevWorld &w, hipStream_t st, int no_global_kernel);
@@ -66,7 +67,7 @@ void rp_launch_sleep_fast(const DevWorld &w, hipStream_t st);
 void rp_launch_sensor_fast(const DevWorld &w, hipStream_t st);
 void rp_launch_clear_no_contact(const DevWorld &w, hipStream_t st);
 void rp_launch_global_flow(const DevWorld &w, hipStream_t st, int grid, int has_restitution);
-void rp_launch_ccd(const DevWorld &w, hipStream_t st, int has_bullets);
+void rp_launch_ccd(const DevWorld &w, hipStream_t st, int has_bullets, int publish);
 void rp_launch_pi_ensure(const DevWorld &w, hipStream_t st, int first, int count, int reset);
 void rp_launch_pi_remove_body(const DevWorld &w, hipStream_t st, int b);
 void rp_launch_pj_append_joint(const DevWorld &w, hipStream_t st, int dev_joint, int b1, int b2, int key);
@@ -1393,13 +1394,13 @@ static void enqueue_global_solver(rp_world *w) {
     else {
         rp_launch_solver_assembly(w->dw, w->stream);
         const int parity = rp_launch_solver_loop(w->dw, w->stream, w->plan_stages, w->plan_blocks, hr, w->plan_joint_stages, w->plan_tile_grid, w->plan_no_contacts);
-        rp_launch_solver_writeback(w->dw, w->stream, parity);
+        rp_launch_solver_writeback(w->dw, w->stream, parity, (!w->cur_fast && rp_ccd_launches(w->dw)) ? 0 : 1); // (a full step's k_ccd publishes the hints)
     }
 }
 static void enqueue_solver(rp_world *w) { enqueue_island_solver(w); enqueue_global_solver(w); }
 static void enqueue_finish(rp_world *w) {
     // the scalars reach the mapped hint buffer from the device: k_island_solve (SINGLE) / k_publish (MULTI)
-    if (!w->cur_fast) rp_launch_ccd(w->dw, w->stream, w->has_bullets ? 1 : 0); // run_ccd_motion_clamping (substep.rs:496-519): fast bodies are swept on full steps
+    if (!w->cur_fast) rp_launch_ccd(w->dw, w->stream, w->has_bullets ? 1 : 0, (!w->plan_single && !(w->plan_tile_grid == 0 && flow_now(w))) ? 1 : 0); // (publishes for the per-stage / tile path) // run_ccd_motion_clamping (substep.rs:496-519): fast bodies are swept on full steps
     rp_launch_force_events(w->dw, w->stream, w->cur_fast); // contact force events of the step that just retired
 }
 

@@ -174,7 +174,10 @@ RP_DEV float ccd_bounding_radius(int sh, float4 he) { // Shape::compute_local_bo
 #define CCD_MAX_FAST_COLLIDERS 64
 // One workgroup per fast body of the list body_writeback filled this step (w.ccd_list, FL_CCD_N).  tier 0: non-bullets against fixed
 // targets; tier 1: bullets against everything that is not on a bullet.
-__global__ void __launch_bounds__(256) k_ccd(DevWorld w, int tier) {
+__global__ void __launch_bounds__(256) k_ccd(DevWorld w, int tier, int publish) {
+    // (MULTI-mode steps: the hint buffer is published here, by the launch that follows the body write-back anyway — one launch less; the
+    // two CCD counters reach the host's hints a step late, rp_counters_read reads the device)
+    if (publish && blockIdx.x == 0) { if (threadIdx.x < FL_COUNT) { int v = __hip_atomic_load(&w.flags[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&w.host_flags[threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } }
     int n = w.flags[FL_CCD_N];
     if (n <= 0) return;
     if (n > w.n_bodies) n = w.n_bodies;
@@ -246,8 +249,10 @@ __global__ void __launch_bounds__(256) k_ccd(DevWorld w, int tier) {
         }
     }
 }
-void rp_launch_ccd(const DevWorld &w, hipStream_t st, int has_bullets) {
-    if (w.prm.p.max_ccd_substeps == 0 || w.n_bodies == 0 || w.n_colliders == 0) return;
-    hipLaunchKernelGGL(k_ccd, dim3(64), dim3(256), 0, st, w, 0);
-    if (has_bullets) hipLaunchKernelGGL(k_ccd, dim3(64), dim3(256), 0, st, w, 1);
+// true = rp_launch_ccd will run for this world (then it can carry the hint publication: rp_ccd_launches / `publish`)
+bool rp_ccd_launches(const DevWorld &w) { return !(w.prm.p.max_ccd_substeps == 0 || w.n_bodies == 0 || w.n_colliders == 0); }
+void rp_launch_ccd(const DevWorld &w, hipStream_t st, int has_bullets, int publish) {
+    if (!rp_ccd_launches(w)) return;
+    hipLaunchKernelGGL(k_ccd, dim3(64), dim3(256), 0, st, w, 0, publish);
+    if (has_bullets) hipLaunchKernelGGL(k_ccd, dim3(64), dim3(256), 0, st, w, 1, 0);
 }

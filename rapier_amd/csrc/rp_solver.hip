@@ -316,12 +316,12 @@ int rp_launch_solver_loop(const DevWorld &w0, hipStream_t st, int parallel_stage
     if (has_restitution) launch_sweep<MODE_RESTITUTION>(w, st, plan, fib, 0.0f);
     return parity;
 }
-void rp_launch_solver_writeback(const DevWorld &w0, hipStream_t st, int parity) {
+void rp_launch_solver_writeback(const DevWorld &w0, hipStream_t st, int parity, int publish) {
     DevWorld w = w0;
     if (parity & 1) { std::swap(w.s_lin, w.t_lin); std::swap(w.s_ang, w.t_ang); w.c_par = 1; } // the tile sweeps left the velocities (and the mutable constraint planes) in the other copy
     if (parity & 2) { std::swap(w.s_rot, w.t_rot); std::swap(w.s_trans, w.t_trans); } // ... and the poses
     if (host_coulomb(w)) hipLaunchKernelGGL(k_writeback_impulses<true>, dim3(cons_blocks(w)), dim3(256), 0, st, w);
     else hipLaunchKernelGGL(k_writeback_impulses<false>, dim3(cons_blocks(w)), dim3(256), 0, st, w);
     hipLaunchKernelGGL(k_writeback_bodies, dim3(body_blocks(w)), dim3(256), 0, st, w);
-    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, w); // hint buffer (MULTI mode: after the step)
+    if (publish) hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, w); // hint buffer (MULTI mode: after the step; else k_ccd carries it)
 }
