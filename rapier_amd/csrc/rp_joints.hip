@@ -39,7 +39,7 @@ __global__ void k_joint_color_check(DevWorld w) {
 // to the successor it releases.  (The bidding rounds this replaces rescanned every joint per round: 21 ms for the first step of
 // b3d_joint_grid.)
 RP_DEV int jld_i32(int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__global__ void __launch_bounds__(1024) k_joint_color(DevWorld w) {
+RP_DEV void joint_color_body(DevWorld &w) { // one workgroup
     if (!w.flags[FL_JOINT_DIRTY]) return;
     const int nj = w.n_joints, nb = w.n_bodies;
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(1024) k_joint_color(DevWorld w) {
 }
 
 // Stage layout of the coloured joints (one workgroup).
-__global__ void __launch_bounds__(1024) k_joint_layout(DevWorld w) {
+RP_DEV void joint_layout_body(DevWorld &w) { // one workgroup
     if (!w.flags[FL_JOINT_DIRTY]) return;
     const int nj = w.n_joints;
     __shared__ int count[RP_NUM_COLORS], begin[RP_NUM_COLORS], cursor[RP_NUM_COLORS], stage_of[RP_NUM_COLORS];
@@ -194,6 +194,15 @@ __global__ void __launch_bounds__(1024) k_joint_layout(DevWorld w) {
     if (threadIdx.x == 0) { w.flags[FL_JOINT_DIRTY] = 0; w.flags[FL_FLOW_DIRTY] = 1; } // the joint sweep order changed: re-rank (rp_flow.hip)
 }
 
+// colouring + stage layout of the joints in ONE single-workgroup launch (both are gated by FL_JOINT_DIRTY: a clean step pays one
+// early exit instead of two)
+__global__ void __launch_bounds__(1024) k_joint_color_layout(DevWorld w) {
+    if (!w.flags[FL_JOINT_DIRTY]) return; // (uniform: raised by k_joint_color_check or the host before this launch)
+    joint_color_body(w);
+    __threadfence(); __syncthreads();
+    joint_layout_body(w);
+}
+
 // ---- MULTI mode launches -----------------------------------------------------------------------
 __global__ void k_joint_update(DevWorld w, int substep_id) {
     int stride = gridDim.x * blockDim.x;
@@ -221,8 +230,7 @@ static int joint_blocks(const DevWorld &w) { int b = (w.n_joints + 255) / 256; i
 void rp_launch_joint_coloring(const DevWorld &w, hipStream_t st) {
     if (w.n_joints == 0) return;
     hipLaunchKernelGGL(k_joint_color_check, dim3((w.n_joints + 255) / 256), dim3(256), 0, st, w);
-    hipLaunchKernelGGL(k_joint_color, dim3(1), dim3(1024), 0, st, w);
-    hipLaunchKernelGGL(k_joint_layout, dim3(1), dim3(1024), 0, st, w);
+    hipLaunchKernelGGL(k_joint_color_layout, dim3(1), dim3(1024), 0, st, w);
 }
 void rp_launch_joint_update(const DevWorld &w, hipStream_t st, int substep_id) {
     if (w.n_joints == 0) return;
