@@ -145,3 +145,48 @@ def test_fuzz_jointed_clutter_on_tiles_bit_exact(monkeypatch, seed):
     monkeypatch.setenv("RP_TILE_MIN", "64")
     monkeypatch.setenv("RP_FORCE_MULTI", "1")
     F._run(seed, steps=200, n=400, spread=4.0, per_layer=36, walls=True)
+
+
+def _drop_boxes(g, o, positions):
+    from oracle_ffi import lib
+    for p in positions:
+        body = S.body_desc(translation=p, linvel=(0.0, -2.0, 0.0))
+        col = S.collider_desc(half_extents=(0.5, 0.5, 0.5), density=100.0)
+        hb = g.insert_body(body)
+        g.insert_collider(col, hb)
+        ob = lib().ro_add_body(o._w, np.array([body], S.BODY_DTYPE).ctypes.data)
+        lib().ro_add_collider(o._w, np.array([col], S.COLLIDER_DTYPE).ctypes.data, ob)
+        o.n += 1
+        assert int(hb) & 0xFFFFFFFF == ob
+
+
+@pytest.mark.parametrize("spare", [None, 1])
+def test_insertion_into_a_tiled_world_bit_exact(monkeypatch, spare):
+    """boxes dropped onto the pyramid of a world that runs on tiles: appended in place (spare rows) or through the growth carry-over
+    (RP_SPARE_ROWS=1: every insertion moves the world to larger device arrays — tile arrays, the second copies of the velocities /
+    poses / mutable planes and the body order start afresh, the persistent rows are carried)"""
+    env = {} if spare is None else {"RP_SPARE_ROWS": spare}
+    sc = S.large_pyramid(60)
+    g, o = _world(sc, monkeypatch, **env), OracleWorld(sc)
+    g.step(12); o.step(12)
+    _equal(g, o, "before the insertions")
+    assert g.counters()["tile_sweeps"] == 1
+    _drop_boxes(g, o, [(-10.0 + 4.0 * k, 40.0 + k, 0.0) for k in range(6)])
+    for n in (1, 10, 60, 150):
+        g.step(n); o.step(n)
+        _equal(g, o, f"after the insertions, +{n}")
+    c = g.counters()
+    assert c["overflow_flags"] == 0 and c["num_tiles"] > 0 and c["tile_sweeps"] == 1, c
+
+
+@pytest.mark.parametrize("override", [{"num_internal_pgs_iterations": 2}, {"num_internal_stabilization_iterations": 0},
+                                      {"num_internal_pgs_iterations": 3, "num_internal_stabilization_iterations": 2}, {"num_internal_pgs_iterations": 0},
+                                      {"num_solver_iterations": 2, "warmstart_coefficient": 0.0}])
+def test_sweep_counts_on_a_tiled_world_bit_exact(monkeypatch, override):
+    """IntegrationParameters that change the launch sequence of a substep: several biased sweeps (the first increments when folded, the
+    last integrates), no stabilisation sweep (friction moves into the biased pass), no biased sweep at all (the increment and the
+    integrate stay launches), no warm start"""
+    sc = S.large_pyramid(60)
+    for k, v in override.items():
+        sc.params[k] = v
+    _run(sc, [2, 12, 40], monkeypatch)
