@@ -52,7 +52,7 @@ void rp_launch_bp_rehash(const DevWorld &w, hipStream_t st);
 void rp_launch_narrowphase(const DevWorld &w, hipStream_t st);
 void rp_launch_narrowphase_part(const DevWorld &w, hipStream_t st, int part);
 void rp_launch_init_bodies(const DevWorld &w, hipStream_t st);
-void rp_launch_solver_assembly(const DevWorld &w, hipStream_t st);
+void rp_launch_solver_assembly(const DevWorld &w, hipStream_t st, int lean);
 int rp_launch_solver_loop(const DevWorld &w, hipStream_t st, int parallel_stages, int stage_blocks, int has_restitution, int joint_stages, int tile_grid, int no_contacts_hint);
 void rp_launch_solver_writeback(const DevWorld &w, hipStream_t st, int parity, int publish);
 bool rp_ccd_launches(const DevWorld &w);
@@ -145,11 +145,17 @@ struct rp_world {
     // launch plan + graph
     int plan_stages = 0, plan_blocks = 1, plan_single = 1, plan_island_grid = 1, plan_joint_stages = 0, plan_no_global = 0, plan_fused = 0, plan_tile_grid = 0, plan_no_contacts = 0;
     bool has_restitution = false;
-    // [0] = full path, [1] = fast path; "whole" = one graph per step, col/loop/fin = timed thirds
-    hipGraph_t g_whole[2] = {nullptr, nullptr}, g_col[2] = {nullptr, nullptr}, g_loop[2] = {nullptr, nullptr}, g_fin[2] = {nullptr, nullptr};
-    hipGraphExec_t ge_whole[2] = {nullptr, nullptr}, ge_col[2] = {nullptr, nullptr}, ge_loop[2] = {nullptr, nullptr}, ge_fin[2] = {nullptr, nullptr};
+    // [0] = full path, [1] = fast path, [2] = lean path; "whole" = one graph per step, col/loop/fin = timed thirds (full / fast only)
+    hipGraph_t g_whole[3] = {nullptr, nullptr, nullptr}, g_col[3] = {nullptr, nullptr, nullptr}, g_loop[3] = {nullptr, nullptr, nullptr}, g_fin[3] = {nullptr, nullptr, nullptr};
+    hipGraphExec_t ge_whole[3] = {nullptr, nullptr, nullptr}, ge_col[3] = {nullptr, nullptr, nullptr}, ge_loop[3] = {nullptr, nullptr, nullptr}, ge_fin[3] = {nullptr, nullptr, nullptr};
     int graph_stages = -1, graph_blocks = -1, graph_single = -1, graph_island_grid = -1, graph_joint_stages = -1, graph_no_global = -1, graph_fused = -1, graph_tile_grid = -1, graph_no_contacts = -1;
     bool use_graph = true, use_fast = true, use_fused = true;
+    bool use_lean = true;          // the lean step graph of MULTI-mode worlds (below: "lean graph"); RP_NO_LEAN=1: never
+    int cur_lean = 0;              // the enqueue_* callbacks capture / launch the lean graph (with dw_lean)
+    DevWorld dw_lean;              // dw with lean = 1: the kernel argument of a lean graph's launches
+    long long lean_steps = 0;      // lean graphs enqueued
+    long long lean_backoff = 3;    // full steps after a lean step died (doubles per death up to 256, back to 3 after 64 clean lean steps)
+    int lean_streak = 0; bool lean_death_seen = false;
     bool use_flow = true;          // the dataflow launch (rp_flow.hip) is available; RP_NO_FLOW=1: never, RP_FLOW=1: for every large world
     bool force_flow = false;
     int flow_grid = 0;             // workgroups of the dataflow launch (all resident at once), 0 = unavailable
@@ -374,6 +380,8 @@ extern "C" int32_t rp_world_create(const rp_integration_params *params, const fl
     if (g && g[0] == '1') w->use_fast = false;
     g = getenv("RP_NO_FUSED");
     if (g && g[0] == '1') w->use_fused = false;
+    g = getenv("RP_NO_LEAN");
+    if (g && g[0] == '1') w->use_lean = false;
     g = getenv("RP_NO_FLOW");
     if (g && g[0] == '1') w->use_flow = false;
     g = getenv("RP_FLOW");
@@ -386,7 +394,7 @@ extern "C" int32_t rp_world_create(const rp_integration_params *params, const fl
 }
 
 static void destroy_graphs(rp_world *w) {
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < 3; ++m) {
         hipGraphExec_t *ex[] = {&w->ge_whole[m], &w->ge_col[m], &w->ge_loop[m], &w->ge_fin[m]};
         hipGraph_t *gr[] = {&w->g_whole[m], &w->g_col[m], &w->g_loop[m], &w->g_fin[m]};
         for (auto e : ex) if (*e) { hipGraphExecDestroy(*e); *e = nullptr; }
@@ -1251,6 +1259,8 @@ static int finalize(rp_world *w) {
     DAC(d.bj_cmask, 4 * (size_t)capb, DOM_BODY, 1, 4); DAFC(d.bj_min, capb, 0xff, DOM_BODY, 1, 1); DA(d.b_njoints, capb);
     DA(d.JR, (size_t)RP_JR_COUNT * std::max(nj, 1)); // im1, im2 + 12 rows x 6 planes (rp_joints.h); planes of unused rows are never touched
     UP(d.j_b1, jb1); UP(d.j_b2, jb2); UP(d.j_f1t, jf1t); UP(d.j_f1r, jf1r); UP(d.j_f2t, jf2t); UP(d.j_f2r, jf2r);
+    d.joints_spherical = nj > 0 ? 1 : 0;
+    for (int k = 0; k < nj; ++k) if (!(jlocked[k] == 0x7 && (jlimited[k] & ~jlocked[k]) == 0 && (jmotor[k] & ~jlocked[k]) == 0)) d.joints_spherical = 0; // (joint_update_one_t's test)
     UP(d.j_locked, jlocked); UP(d.j_limited, jlimited); UP(d.j_motor, jmotor); UP(d.j_color, jcolor); UP(d.b_njoints, bnj);
     for (int a = 0; a < 12; ++a) if (nj > 0 && hipMemcpyAsync(d.j_mot + (size_t)a * nj, jmot[a].data(), (size_t)nj * sizeof(float4), hipMemcpyHostToDevice, w->stream) != hipSuccess) { w->err = "upload failed"; return RP_ERR_DEVICE; }
     for (int a = 0; a < 6; ++a) if (nj > 0 && hipMemcpyAsync(d.j_lim + (size_t)a * nj, jlim[a].data(), (size_t)nj * sizeof(float4), hipMemcpyHostToDevice, w->stream) != hipSuccess) { w->err = "upload failed"; return RP_ERR_DEVICE; }
@@ -1363,6 +1373,12 @@ static void enqueue_collision(rp_world *w) {
         rp_launch_sensor_fast(w->dw, w->stream); // worlds with sensors: their pairs' intersection tests (after the last kernel that can abort)
         return;
     }
+    if (w->cur_lean) { // lean graph: collision detection only (the world has no sleeping, no sensors: lean_world_ok)
+        rp_launch_collider_update(w->dw_lean, w->stream);
+        rp_launch_broadphase(w->dw_lean, w->stream);
+        rp_launch_narrowphase_part(w->dw_lean, w->stream, 2);
+        return;
+    }
     rp_launch_collider_update(w->dw, w->stream);
     rp_launch_broadphase(w->dw, w->stream);
     rp_launch_wake(w->dw, w->stream, 0); // user wake-ups and pair deletions take effect before the narrow phase reads the awake set
@@ -1373,7 +1389,7 @@ static void enqueue_island_solver(rp_world *w) {
     // SINGLE mode: workgroup 0 of this launch retires the step (FL_SEQ / FL_STEP, hint publication)
     const int fused = (w->cur_fast && w->plan_fused) ? 1 : 0;
     // every workgroup of the fused step must be resident at once: the grid is capped by what the device can hold (rp_fused_grid)
-    rp_launch_island_solve(w->dw, w->stream, fused ? std::min(w->plan_island_grid, w->fused_grid) : w->plan_island_grid,
+    rp_launch_island_solve(w->cur_lean ? w->dw_lean : w->dw, w->stream, fused ? std::min(w->plan_island_grid, w->fused_grid) : w->plan_island_grid,
                            w->has_restitution ? 1 : 0, w->cur_fast, w->plan_single, fused);
 }
 // MULTI mode of the global path, measured on MI355X: contact-only worlds under the twist model are fastest
@@ -1392,15 +1408,16 @@ static void enqueue_global_solver(rp_world *w) {
     if (w->plan_single) rp_launch_global_single(w->dw, w->stream, hr, w->cur_fast);
     else if (w->plan_tile_grid == 0 && flow_now(w)) rp_launch_global_flow(w->dw, w->stream, w->flow_grid, hr); // one dataflow launch (rp_flow.hip)
     else {
-        rp_launch_solver_assembly(w->dw, w->stream);
-        const int parity = rp_launch_solver_loop(w->dw, w->stream, w->plan_stages, w->plan_blocks, hr, w->plan_joint_stages, w->plan_tile_grid, w->plan_no_contacts);
-        rp_launch_solver_writeback(w->dw, w->stream, parity, (!w->cur_fast && rp_ccd_launches(w->dw)) ? 0 : 1); // (a full step's k_ccd publishes the hints)
+        const DevWorld &dw = w->cur_lean ? w->dw_lean : w->dw;
+        rp_launch_solver_assembly(dw, w->stream, w->cur_lean);
+        const int parity = rp_launch_solver_loop(dw, w->stream, w->plan_stages, w->plan_blocks, hr, w->plan_joint_stages, w->plan_tile_grid, w->plan_no_contacts);
+        rp_launch_solver_writeback(dw, w->stream, parity, (!w->cur_fast && rp_ccd_launches(w->dw)) ? 0 : 1); // (a full step's k_ccd publishes the hints)
     }
 }
 static void enqueue_solver(rp_world *w) { enqueue_island_solver(w); enqueue_global_solver(w); }
 static void enqueue_finish(rp_world *w) {
     // the scalars reach the mapped hint buffer from the device: k_island_solve (SINGLE) / k_publish (MULTI)
-    if (!w->cur_fast) rp_launch_ccd(w->dw, w->stream, w->has_bullets ? 1 : 0, (!w->plan_single && !(w->plan_tile_grid == 0 && flow_now(w))) ? 1 : 0); // (publishes for the per-stage / tile path) // run_ccd_motion_clamping (substep.rs:496-519): fast bodies are swept on full steps
+    if (!w->cur_fast) rp_launch_ccd(w->cur_lean ? w->dw_lean : w->dw, w->stream, w->has_bullets ? 1 : 0, (!w->plan_single && !(w->plan_tile_grid == 0 && flow_now(w))) ? 1 : 0); // (publishes for the per-stage / tile path) // run_ccd_motion_clamping (substep.rs:496-519): fast bodies are swept on full steps
     rp_launch_force_events(w->dw, w->stream, w->cur_fast); // contact force events of the step that just retired
 }
 
@@ -1466,11 +1483,14 @@ static int check_overflow(rp_world *w, const int *fl) {
     return RP_OK;
 }
 
-// Enqueue one step graph.  `fast` selects the steady-state graph (see the file header).
+// Enqueue one step graph.  `fast`: 1 selects the steady-state graph (see the file header), 2 the lean graph (rp_world.h "lean step
+// graphs": a full step without the launches that rebuild colouring / layout / toucher ranks / tiling, self-validating on the device).
 static int launch_step(rp_world *w, int fast) {
-    w->cur_fast = fast;
+    w->cur_lean = fast == 2 ? 1 : 0;
+    if (w->cur_lean) { w->dw_lean = w->dw; w->dw_lean.lean = 1; }
+    w->cur_fast = fast == 1 ? 1 : 0;
     w->seq_enqueued++;
-    if (fast) w->fast_steps++; else w->full_steps++;
+    if (fast == 1) w->fast_steps++; else if (fast == 2) w->lean_steps++; else w->full_steps++;
     if (w->timers) {
         // three sub-graphs with events in between (Counters from hipEvents)
         if (!w->timed_ready[fast]) {
@@ -1512,7 +1532,7 @@ static int launch_step(rp_world *w, int fast) {
     }
     // a fused fast step is ONE kernel: launched directly (a one-node graph replay costs more than the launch)
     static const bool fused_eager = getenv("RP_FUSED_GRAPH") == nullptr;
-    if (!w->use_graph || (fast && w->plan_fused && fused_eager)) { enqueue_whole(w); HIPCHK(w, hipGetLastError()); return RP_OK; }
+    if (!w->use_graph || (fast == 1 && w->plan_fused && fused_eager)) { enqueue_whole(w); HIPCHK(w, hipGetLastError()); return RP_OK; }
     static const bool dbg = getenv("RP_DEBUG") != nullptr;
     if (!w->ge_whole[fast]) {
         if (dbg) fprintf(stderr, "RPDBG capture fast=%d seq=%lld stages=%d blocks=%d single=%d grid=%d jst=%d\n", fast, w->seq_enqueued, w->plan_stages, w->plan_blocks, w->plan_single, w->plan_island_grid, w->plan_joint_stages);
@@ -1529,7 +1549,7 @@ static int step_once(rp_world *w, bool allow_fast) {
     if (!w->hints_valid) {
         // First step after (re)building the world: run collision detection eagerly and read the
         // colour layout once so the solver launch plan is right from the start.
-        w->cur_fast = 0;
+        w->cur_fast = 0; w->cur_lean = 0;
         enqueue_collision(w);
         int fl[FL_COUNT];
         HIPCHK(w, hipMemcpyAsync(fl, w->dw.flags, sizeof(fl), hipMemcpyDeviceToHost, w->stream));
@@ -1585,13 +1605,30 @@ static int step_once(rp_world *w, bool allow_fast) {
     // device re-checks and aborts otherwise (k_idle_step), the host then replays through the full graph
     if (!fast && allow_fast && w->use_fast && w->dw.sleep_enabled && !w->timers && w->steps_requested >= w->full_until) {
         if (pf[FL_N_AWAKE] == 0 && !pf[FL_FAST_ABORT] && !pf[FL_WAKE_PENDING] && !pf[FL_LAYOUT_DIRTY] && !pf[FL_BP_DIRTY]) {
-            w->cur_fast = 1; w->seq_enqueued++; w->fast_steps++;
+            w->cur_fast = 1; w->cur_lean = 0; w->seq_enqueued++; w->fast_steps++;
             rp_launch_idle_step(w->dw, w->stream);
             HIPCHK(w, hipGetLastError());
             return RP_OK;
         } else if (pf[FL_FAST_ABORT]) w->full_until = w->steps_requested + 3;
     }
-    return launch_step(w, fast ? 1 : 0);
+    // lean graph (rp_world.h "lean step graphs"): a MULTI-mode world on tiles whose last observed steps brought no new pair and no
+    // layout change skips the nine rebuild launches; the device validates (lean_dead) and the full graph resumes a step that died
+    int lean = 0;
+    if (!fast && allow_fast && w->use_lean && w->use_graph && !w->timers && !w->plan_single && w->plan_tile_grid > 0 && !w->has_restitution && !w->dw.sleep_enabled &&
+        !w->dw.has_force_events && !w->dw.has_sensors && !w->dw.has_kinematic_pos && w->dw.n_groups <= 1 && rp_ccd_launches(w->dw) && w->dw.n_colliders > 0) {
+        if (pf[FL_FAST_ABORT]) {
+            if (!w->lean_death_seen) { // once per death: stay on the full graph for a while, longer when deaths repeat
+                w->lean_death_seen = true; w->lean_streak = 0;
+                w->full_until = std::max(w->full_until, w->steps_requested + w->lean_backoff);
+                w->lean_backoff = std::min<long long>(w->lean_backoff * 2, 256);
+            }
+        } else {
+            w->lean_death_seen = false;
+            if (pf[FL_TODO_COUNT] || pf[FL_LAYOUT_DIRTY] || pf[FL_FLOW_DIRTY] || (w->dw.n_joints > 0 && pf[FL_JOINT_DIRTY])) w->full_until = std::max(w->full_until, w->steps_requested + 3);
+            else if (w->steps_requested >= w->full_until) { lean = 2; if (++w->lean_streak >= 64) { w->lean_streak = 0; w->lean_backoff = 3; } }
+        }
+    }
+    return launch_step(w, fast ? 1 : lean);
 }
 
 // Make the device catch up with every requested step: fast steps that aborted are replayed through
@@ -2427,7 +2464,7 @@ extern "C" int32_t rp_counters_read(rp_world *w, rp_counters *out) {
     out->overflow_flags = fl[FL_OVERFLOW];
     out->quarantined = fl[FL_QUARANTINE];
     out->ccd_active_count = fl[FL_CCD_ACTIVE]; out->ccd_clamp_count = fl[FL_CCD_CLAMPS];
-    out->num_tiles = fl[FL_N_TILES]; out->tile_sweeps = (w->graph_tile_grid > 0 && !w->plan_single) ? 1 : 0;
+    out->num_tiles = fl[FL_N_TILES]; out->tile_sweeps = (w->graph_tile_grid > 0 && !w->plan_single) ? 1 : 0; out->lean_steps = (int32_t)w->lean_steps;
     out->fast_steps = (int32_t)w->fast_steps; out->full_steps = (int32_t)w->full_steps; out->replayed_steps = (int32_t)w->replayed_steps;
     if (w->dw.sleep_enabled && w->dw.n_bodies > 0) {
         std::vector<int> bfl(w->dw.n_bodies);

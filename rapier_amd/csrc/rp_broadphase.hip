@@ -47,8 +47,12 @@ __device__ __forceinline__ CellRange cell_range(const DevWorld &w, int i) {
 
 __global__ void k_collider_update(DevWorld w) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // (FL_FAST_ABORT == 2: a lean step died behind its collision stage — rp_world.h "lean step graphs" — and this is either its resume
+    // on the full graph or a lean graph enqueued before the host noticed: the stage already ran for this step, nothing is reset)
+    if (collision_done(w)) return;
     if (i == 0) { // a full step is starting: the fast path may be tried again later; per-step narrow-phase counters
-        w.flags[FL_FAST_ABORT] = 0; w.flags[FL_FULL_UPDATES] = 0; w.flags[FL_TODO_COUNT] = 0; w.flags[FL_NP_COUNT] = 0; w.flags[FL_CCD_N] = 0;
+        if (!w.lean) w.flags[FL_FAST_ABORT] = 0;
+        w.flags[FL_FULL_UPDATES] = 0; w.flags[FL_TODO_COUNT] = 0; w.flags[FL_NP_COUNT] = 0; w.flags[FL_CCD_N] = 0;
     }
     if (i >= w.n_colliders) return;
     collider_update_one(w, i);
@@ -455,6 +459,7 @@ RP_DEV void bp_incr_delete(DevWorld &w, int gid, int gstride, int nchg) {
 // colliders left their fat AABBs two passes over those colliders and the pair slots, anything else the full rebuild.
 __global__ void __launch_bounds__(1024) k_bp_rebuild(DevWorld w) {
     if (!w.flags[FL_BP_DIRTY]) return; // (cleared only after the last barrier: every workgroup reads the same value)
+    if (collision_done(w)) return;     // (a dead lean step's collision stage is not repeated: rp_world.h "lean step graphs")
     __shared__ int scan_lds[1024];
     const int gid = gbar_item(), gstride = gridDim.x * blockDim.x;
     // the mode is decided from scalars that only change behind a barrier of this launch (or at its very end)

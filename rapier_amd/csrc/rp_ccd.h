@@ -177,7 +177,15 @@ RP_DEV float ccd_bounding_radius(int sh, float4 he) { // Shape::compute_local_bo
 __global__ void __launch_bounds__(256) k_ccd(DevWorld w, int tier, int publish) {
     // (MULTI-mode steps: the hint buffer is published here, by the launch that follows the body write-back anyway — one launch less; the
     // two CCD counters reach the host's hints a step late, rp_counters_read reads the device)
+    // (last kernel of a lean graph — rp_world.h "lean step graphs": a step that died is marked here for the graphs that follow and for
+    // the host; the graph still counts in FL_SEQ.  The flags of lean_dead only ever stay or become non-zero here: every workgroup decides alike)
+    const bool dead = lean_dead(w);
+    if (dead && publish && blockIdx.x == 0) {
+        if (threadIdx.x == 0) { w.flags[FL_FAST_ABORT] = 2; w.flags[FL_SEQ] += 1; }
+        __threadfence(); __syncthreads();
+    }
     if (publish && blockIdx.x == 0) { if (threadIdx.x < FL_COUNT) { int v = __hip_atomic_load(&w.flags[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&w.host_flags[threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } }
+    if (dead) return;
     int n = w.flags[FL_CCD_N];
     if (n <= 0) return;
     if (n > w.n_bodies) n = w.n_bodies;

@@ -743,7 +743,7 @@ RP_DEV void island_sort(const DevWorld &w, int isl, int nc, int cb, int nst_glob
 // free) and no abort was raised.  An aborted launch leaves the world untouched and the host replays the
 // step on the full graph.  Needs every workgroup resident at once: the grid is capped below the CU count.
 __global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int has_restitution, int fast, int retire, int fused) {
-    const bool aborted = fast && w.flags[FL_FAST_ABORT]; // fast graph gave up on this step (rp_api.hip)
+    const bool aborted = (fast && w.flags[FL_FAST_ABORT]) || lean_dead(w); // fast graph gave up on this step (rp_api.hip) / dead lean step (rp_world.h)
     if (retire && blockIdx.x == 0) {
         // SINGLE mode: workgroup 0 retires the step and publishes the scalars to the host hint buffer
         // up front, so the PCIe writes overlap the solve instead of ending the step

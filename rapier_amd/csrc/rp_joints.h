@@ -57,6 +57,12 @@ RP_DEV void jrow_store(const DevWorld &w, int j, int r, const JointRow &c) {
     JRR(r, JR_BND, j) = make_float4(c.bmin, c.bmax, 0.0f, 0.0f);
     if (w.jm) jm_put(w, j, r, w.c_par, c.impulse, c.rhs);
 }
+// the planes of a row without its two sweep words (tile sweeps that rebuild rows themselves: the words go to the other copy of jm)
+RP_DEV void jrow_store_planes(const DevWorld &w, int j, int r, const JointRow &c) {
+    JRR(r, JR_LIN, j) = f4(c.lin_jac, c.impulse); JRR(r, JR_A1, j) = f4(c.ang_jac1, c.inv_lhs);
+    JRR(r, JR_A2, j) = f4(c.ang_jac2, c.rhs); JRR(r, JR_I1, j) = f4(c.ii1, c.rhs_wo_bias); JRR(r, JR_I2, j) = f4(c.ii2, c.cfm_gain);
+    JRR(r, JR_BND, j) = make_float4(c.bmin, c.bmax, 0.0f, 0.0f);
+}
 // rows of a joint: the motors of its free axes (GenericJoint::motor_axes & !locked_axes), its locked axes, then the limits of
 // its free axes (limit_axes & !locked_axes)
 RP_DEV int joint_row_count(int locked, int limited, int motor) {
@@ -128,7 +134,7 @@ RP_DEV void joint_finalize_store(const DevWorld &w, int j, JointRow *rows, const
 // joint of b3d_joint_grid): every loop unrolls, the rows stay in registers.  The run-time-indexed form above keeps its rows in scratch
 // memory (720 B per lane of the dataflow kernel), a memory round trip per access on a path that is rebuilt every substep.
 template <int LEN>
-RP_DEV void joint_finalize_store_static(const DevWorld &w, int j, JointRow (&rows)[LEN], V3 imsum, int substep_id) {
+RP_DEV void joint_finalize_static(const DevWorld &w, int j, JointRow (&rows)[LEN], V3 imsum, int substep_id) {
 #pragma unroll
     for (int a = 0; a < LEN; ++a) {
         JointRow &cj = rows[a];
@@ -153,11 +159,18 @@ RP_DEV void joint_finalize_store_static(const DevWorld &w, int j, JointRow (&row
     }
     const bool ws = w.prm.p.warmstart_joints != 0;
 #pragma unroll
-    for (int k = 0; k < LEN; ++k) {
+    for (int k = 0; k < LEN; ++k)
         if (ws) rows[k].impulse = (substep_id == 0 ? joint_seed_impulse(w, j, k) : jrow_impulse(w, j, k)) * w.prm.p.warmstart_coefficient;
-        jrow_store(w, j, k, rows[k]);
-    }
 }
+// where the rebuilt rows of a spherical joint go: to their planes (every launch path), or straight into the solve of the tile sweep that
+// rebuilt them (rp_tiles.hip: TileJointBuild keeps them in registers, the owner instance also stores them for the sweeps that follow)
+struct JointRowsToPlanes {
+    RP_DEV void take3(const DevWorld &w, int j, JointRow (&r3)[3], V3 im1, V3 im2) const {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) jrow_store(w, j, k, r3[k]);
+        JRP(JR_IM1, j) = f4(im1, 0.0f); JRP(JR_IM2, j) = f4(im2, 0.0f);
+    }
+};
 
 // How a joint reaches the solver bodies: plain HBM arrays on the per-stage launch path (PlainBodyIO), tagged write-through
 // records on the dataflow path (rp_flow.hip).  `side` = 0 / 1 for body1 / body2.
@@ -171,8 +184,10 @@ struct PlainBodyIO {
 };
 
 // JointConstraintBuilder::update for joint j (rows rebuilt from the solver poses s_rot / s_trans).
-template <class IO>
-RP_DEV void joint_update_one_t(const DevWorld &w, const IO &io, int j, int substep_id) {
+// ONLY_SPHERICAL: the caller knows that every joint it passes locks the three linear axes and nothing else (DevWorld::joints_spherical):
+// the run-time-indexed general form is compiled out
+template <class IO, class SINK = JointRowsToPlanes, bool ONLY_SPHERICAL = false>
+RP_DEV void joint_update_one_t(const DevWorld &w, const IO &io, int j, int substep_id, const SINK &sink = SINK()) {
     int b1 = w.j_b1[j], b2 = w.j_b2[j], locked = w.j_locked[j], limited = w.j_limited[j] & ~locked, motor = w.j_motor[j] & ~locked;
     Pose p1, p2; p1.r = q4(0, 0, 0, 1); p1.t = v3(0, 0, 0); p2 = p1;
     V3 im1 = v3(0, 0, 0), im2 = im1; Sym3 ii1 = {0, 0, 0, 0, 0, 0}, ii2 = ii1;
@@ -192,7 +207,7 @@ RP_DEV void joint_update_one_t(const DevWorld &w, const IO &io, int j, int subst
     V3 c1x = v3(0.0f, r1.z, -r1.y), c1y = v3(-r1.z, 0.0f, r1.x), c1z = v3(r1.y, -r1.x, 0.0f);
     V3 c2x = v3(0.0f, r2.z, -r2.y), c2y = v3(-r2.z, 0.0f, r2.x), c2z = v3(r2.y, -r2.x, 0.0f);
     V3 imsum = im1 + im2;
-    if (locked == 0x7 && !motor && !limited) { // three locked linear axes, nothing else (a spherical joint): rows in registers
+    if (ONLY_SPHERICAL || (locked == 0x7 && !motor && !limited)) { // three locked linear axes, nothing else (a spherical joint): rows in registers
         JointRow r3[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -208,10 +223,11 @@ RP_DEV void joint_update_one_t(const DevWorld &w, const IO &io, int j, int subst
             c.inv_lhs = 0.0f; c.cfm_coeff = w.prm.joint_cfm_coeff; c.cfm_gain = 0.0f; c.bmin = -JR_UNBOUNDED; c.bmax = JR_UNBOUNDED;
             c.rhs = rhs_wo_bias + rhs_bias; c.rhs_wo_bias = rhs_wo_bias;
         }
-        joint_finalize_store_static<3>(w, j, r3, imsum, substep_id);
-        JRP(JR_IM1, j) = f4(im1, 0.0f); JRP(JR_IM2, j) = f4(im2, 0.0f);
+        joint_finalize_static<3>(w, j, r3, imsum, substep_id);
+        sink.take3(w, j, r3, im1, im2);
         return;
     }
+    if (ONLY_SPHERICAL) return;
     JointRow rows[6];
     int dof[6] = {0, 0, 0, 0, 0, 0};
     int len = 0, base = 0;

@@ -814,6 +814,7 @@ __device__ __forceinline__ void pair_full_update(DevWorld &w, int s, int c1, int
 // settled scene the queue is empty and the heavy kernel exits at once instead of taxing every pair with its launch
 // footprint (29 us -> a few us per step on b3d_many_pyramids).
 __global__ void k_np_test(DevWorld w) {
+    if (collision_done(w)) return; // (rp_world.h "lean step graphs")
     int top = w.flags[FL_POOL_TOP];
     if (top > w.pool_cap) top = w.pool_cap;
     int stride = gridDim.x * blockDim.x;
@@ -841,6 +842,7 @@ __global__ void k_np_test(DevWorld w) {
 }
 __global__ void __launch_bounds__(NP_THREADS) k_np_update(DevWorld w) {
     __shared__ __align__(16) float np_lds[NP_THREADS * NP_LDS_DWORDS];
+    if (collision_done(w)) return; // (rp_world.h "lean step graphs")
     int count = w.flags[FL_NP_COUNT];
     if (count > w.pool_cap) count = w.pool_cap;
     int stride = gridDim.x * blockDim.x;
@@ -913,6 +915,9 @@ RP_DEV unsigned ld_u32(unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAX
 RP_DEV int ld_i32a(int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __global__ void __launch_bounds__(1024) k_color_pairs(DevWorld w) {
+    // first launch behind the collision stage, full graphs only: a dead lean step's resume (rp_world.h "lean step graphs") is past the
+    // kernels that skip on the marker
+    if (threadIdx.x == 0 && w.flags[FL_FAST_ABORT] == 2) w.flags[FL_FAST_ABORT] = 0;
     const int T = w.flags[FL_TODO_COUNT];
     if (T == 0) return;
     __shared__ int cursor, n_cur, n_next;
@@ -1069,9 +1074,15 @@ void rp_launch_sleep(const DevWorld &w, hipStream_t st);
 
 // `part`: 0 = contact determination (NarrowPhase::compute_contacts: test, update, deferred colouring, begin-touch wake-ups),
 // 1 = island construction in the reference's stage accounting (sleep decision, joint colouring, solver contact graph
-// buckets, contact islands), -1 = both (the step graphs).
+// buckets, contact islands), -1 = both (the step graphs), 2 = test + update alone (the lean step graph: rp_world.h).
 void rp_launch_narrowphase_part(const DevWorld &w, hipStream_t st, int part) {
     int blocks = (w.pool_cap + 255) / 256; if (blocks > 2048) blocks = 2048;
+    if (part == 2) {
+        if (w.n_colliders == 0) return;
+        hipLaunchKernelGGL(k_np_test, dim3(blocks), dim3(256), 0, st, w);
+        int nb = (w.pool_cap + NP_THREADS - 1) / NP_THREADS; hipLaunchKernelGGL(k_np_update, dim3(nb < 512 ? nb : 512), dim3(NP_THREADS), 0, st, w);
+        return;
+    }
     if (part != 1) {
         if (w.n_colliders > 0) {
             hipLaunchKernelGGL(k_np_test, dim3(blocks), dim3(256), 0, st, w);

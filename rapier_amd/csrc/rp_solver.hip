@@ -53,6 +53,7 @@ struct GenAccT : GlobalAccT<PRE> {
 template <bool COUL>
 __global__ void __launch_bounds__(256) k_begin_generate(DevWorld w) { // (FL_ANY_BOUNCY was reset by k_flow_ranks, the launch before)
     const int gid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    if (lean_dead(w)) return; // (a live lean step has FL_FLOW_DIRTY == 0 already: the store below changes nothing for the lanes still evaluating this)
     if (gid == 0) w.flags[FL_FLOW_DIRTY] = 0; // (the toucher ranks and the tiling were rebuilt by the launches before this one)
     for (int i = gid; i < w.n_bodies; i += stride) if (global_body(w, i)) g_body_begin(w, i);
     int M = w.flags[FL_N_CONS];
@@ -75,11 +76,13 @@ __global__ void __launch_bounds__(256) k_generate(DevWorld w) { // (256 threads:
 }
 __global__ void k_increment(DevWorld w) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lean_dead(w)) return;
     if (i >= w.n_bodies || !global_body(w, i)) return;
     g_body_increment(w, i);
 }
 __global__ void k_integrate(DevWorld w) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lean_dead(w)) return;
     if (i >= w.n_bodies || !global_body(w, i)) return;
     g_body_integrate(w, i);
 }
@@ -97,6 +100,7 @@ __global__ void k_integrate(DevWorld w) {
 // joint_substep >= 0: the launch also rebuilds the rows of every impulse joint from the current poses (k_joint_update folded in: both
 // are the pose-dependent, fully parallel preparation of a substep; jointed worlds on tiles save a launch per substep)
 __global__ void __launch_bounds__(256) k_ws_prepare(DevWorld w, float solved_dt, int joint_substep) {
+    if (lean_dead(w)) return;
     if (joint_substep >= 0) {
         const int jstride = gridDim.x * blockDim.x;
         for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < w.n_joints; j += jstride) if (joint_live(w, j)) joint_update_one(w, j, joint_substep);
@@ -108,6 +112,7 @@ __global__ void __launch_bounds__(256) k_ws_prepare(DevWorld w, float solved_dt,
 }
 __global__ void __launch_bounds__(256) k_increment_ws(DevWorld w) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lean_dead(w)) return;
     if (i >= w.n_bodies || !global_body(w, i)) return;
     V3 lin, ang;
     body_increment_ws(w, i, lin, ang);
@@ -132,6 +137,7 @@ __global__ void __launch_bounds__(1024) k_tail(DevWorld w, int first, int fricti
 }
 template <bool COUL>
 __global__ void k_writeback_impulses(DevWorld w) {
+    if (lean_dead(w)) return;
     int M = w.flags[FL_N_CONS];
     if (M > w.cons_cap) M = w.cons_cap;
     int stride = gridDim.x * blockDim.x;
@@ -141,6 +147,7 @@ __global__ void k_writeback_impulses(DevWorld w) {
 }
 __global__ void k_writeback_bodies(DevWorld w) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lean_dead(w)) return; // (the step did not happen: k_ccd counts the graph — FL_SEQ — and raises the marker)
     if (i == 0) { w.flags[FL_STEP] += 1; w.flags[FL_SEQ] += 1; }
     if (i >= w.n_bodies || !global_body(w, i)) return;
     g_body_writeback(w, i);
@@ -259,9 +266,12 @@ void rp_launch_global_single(const DevWorld &w, hipStream_t st, int has_restitut
 void rp_launch_flow_ranks(const DevWorld &w, hipStream_t st);
 void rp_launch_tiles_build(const DevWorld &w, hipStream_t st);
 void rp_launch_tile_sweep(const DevWorld &w, hipStream_t st, int mode, int grid, int friction_in_bias, float solved_dt, int fuse, int joint_warmstart);
-void rp_launch_solver_assembly(const DevWorld &w, hipStream_t st) {
-    rp_launch_flow_ranks(w, st); // the per-body toucher lists of the body-centric warm start (only rebuilt when the layout changed)
-    rp_launch_tiles_build(w, st); // ... and the LDS tiling of the big component (rp_tiles.hip; same gate)
+// lean: the graph runs only while FL_FLOW_DIRTY is clear (rp_world.h "lean step graphs") — both rebuilds would exit at once: left out
+void rp_launch_solver_assembly(const DevWorld &w, hipStream_t st, int lean) {
+    if (!lean) {
+        rp_launch_flow_ranks(w, st); // the per-body toucher lists of the body-centric warm start (only rebuilt when the layout changed)
+        rp_launch_tiles_build(w, st); // ... and the LDS tiling of the big component (rp_tiles.hip; same gate)
+    }
     const int blocks = std::max(body_blocks(w), cons_blocks(w)) > 2048 ? 2048 : std::max(body_blocks(w), cons_blocks(w));
     if (host_coulomb(w)) hipLaunchKernelGGL(k_begin_generate<true>, dim3(blocks), dim3(256), 0, st, w);
     else hipLaunchKernelGGL(k_begin_generate<false>, dim3(blocks), dim3(256), 0, st, w);
@@ -283,6 +293,9 @@ int rp_launch_solver_loop(const DevWorld &w0, hipStream_t st, int parallel_stage
     const bool can_fuse = tiles && p.num_internal_pgs_iterations >= 1;
     // (a world without contact manifolds — a hint: the folded form is correct either way — has no warm-start terms to gather: the
     // increment rides the sweep's prologue for free; with contacts the gather of every halo body costs more than the launch, measured)
+    // (worlds whose joints are all spherical: the first biased sweep of a substep rebuilds the joint rows itself — rp_tiles.hip, tile_joint_build)
+    static const bool joint_inline_ok = getenv("RP_NO_JOINT_INLINE") == nullptr;
+    const bool jinline = can_fuse && w.n_joints > 0 && w.joints_spherical && joint_inline_ok;
     const bool fuse_inc = can_fuse && ((fuse_mask & 1) || ((fuse_mask & 4) == 0 && no_contacts_hint)), fuse_int = can_fuse && (fuse_mask & 2);
 #define TILE_SWEEP(MODE, SDT, FUSE, JWS) do { const int fuse_ = (FUSE); rp_launch_tile_sweep(w, st, MODE, tile_grid, fib, SDT, fuse_, JWS); \
         std::swap(w.s_lin, w.t_lin); std::swap(w.s_ang, w.t_ang); w.c_par ^= 1; parity ^= 1; \
@@ -293,7 +306,7 @@ int rp_launch_solver_loop(const DevWorld &w0, hipStream_t st, int parallel_stage
     for (int s = 0; s < w.prm.num_substeps; ++s) {
         float solved_dt = (float)s * w.prm.dt_sub;
         if (!host_coulomb(w) && w.ws_terms) { // body-centric warm start: two launches instead of one per colour
-            hipLaunchKernelGGL(k_ws_prepare, dim3(cons_blocks(w)), dim3(256), 0, st, w, solved_dt, (tiles && w.n_joints > 0) ? s : -1);
+            hipLaunchKernelGGL(k_ws_prepare, dim3(cons_blocks(w)), dim3(256), 0, st, w, solved_dt, (tiles && w.n_joints > 0 && !jinline) ? s : -1);
             if (!fuse_inc) hipLaunchKernelGGL(k_increment_ws, dim3(nb), dim3(256), 0, st, w);
             if (!tiles) rp_launch_joint_update(w, st, s);
         } else {
@@ -303,7 +316,7 @@ int rp_launch_solver_loop(const DevWorld &w0, hipStream_t st, int parallel_stage
         }
         for (int it = 0; it < p.num_internal_pgs_iterations; ++it) {
             const int jws = (p.warmstart_joints && it == 0) ? 1 : 0;
-            if (tiles) TILE_SWEEP(MODE_BIAS, solved_dt, ((fuse_inc && it == 0) ? 1 : 0) | ((fuse_int && it == p.num_internal_pgs_iterations - 1) ? 2 : 0), jws);
+            if (tiles) TILE_SWEEP(MODE_BIAS, solved_dt, ((fuse_inc && it == 0) ? 1 : 0) | ((fuse_int && it == p.num_internal_pgs_iterations - 1) ? 2 : 0) | ((jinline && it == 0) ? (4 | (s << 8)) : 0), jws);
             else { rp_launch_joint_sweep(w, st, joint_stages, 0, jws); launch_sweep<MODE_BIAS>(w, st, plan, fib, solved_dt); } // all joints before any contact
         }
         if (!fuse_int) hipLaunchKernelGGL(k_integrate, dim3(nb), dim3(256), 0, st, w);

@@ -496,17 +496,44 @@ RP_DEV void tile_joint_fetch(const DevWorld &w, int j, TileJointPre &P) {
 #pragma unroll
     for (int q = 0; q < 3; ++q) jrow_load(w, j, q, P.R.c[q]);
 }
+// The first biased sweep of a substep in a world whose joints are all spherical (DevWorld::joints_spherical) rebuilds the rows itself:
+// JointConstraintBuilder::update straight from the poses (14 loads against the 20 of the built rows), the rows go from the registers
+// into the solve, the owner instance stores them for the sweeps that follow.  k_ws_prepare then has no joint work: in a world without
+// contacts (b3d_joint_grid) it becomes an empty launch.  (The words a sweep changes: the rebuilt impulse seeds the solve, whose result
+// goes to the other copy of jm as ever; the copy being read is NOT written — halo instances of other tiles still read it.)
+struct TilePoseIO { const DevWorld &w; RP_DEV void pose(int side, int b, Pose &p) const { p.r = q4(w.s_rot[b]); p.t = v3(w.s_trans[b]); } };
+struct TileJointBuild {
+    TileJointPre &P; bool own;
+    RP_DEV void take3(const DevWorld &w, int j, JointRow (&r3)[3], V3 im1, V3 im2) const {
+        P.im1 = im1; P.im2 = im2;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) P.R.c[k] = r3[k];
+        if (own) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) jrow_store_planes(w, j, k, r3[k]);
+            JRP(JR_IM1, j) = f4(im1, 0.0f); JRP(JR_IM2, j) = f4(im2, 0.0f);
+        }
+    }
+};
+RP_DEV void tile_joint_build(const DevWorld &w, const int4 e, int substep, TileJointPre &P) {
+    P.locked = 0x7; P.limited = 0; P.motor = 0;
+    const TilePoseIO io = {w};
+    const TileJointBuild sink = {P, e.w != 0};
+    joint_update_one_t<TilePoseIO, TileJointBuild, true>(w, io, -1 - e.x, substep, sink);
+}
 RP_DEV void tile_apply_joint(const DevWorld &w, const int4 e, TileJointPre &P, float4 *Ll, float4 *La, bool wo_bias, bool warmstart) {
     const TileJointIO io = {Ll, La, e.y, e.z, w.c_par ^ 1, e.w != 0};
     joint_solve_fetched<TileJointIO, 3>(w, io, -1 - e.x, joint_row_count(P.locked, P.limited, P.motor), P.im1, P.im2, P.R, wo_bias, warmstart);
 }
 
+// fuse bit 2: the sweep rebuilds the rows of its (spherical) joints itself — tile_joint_build; the substep index rides in fuse >> 8
 // fuse bit 0: the sweep starts the substep — every cone body is incremented and warm-started on its way into LDS (k_increment_ws folded
 //             in; halo bodies redundantly);  bit 1: the sweep ends the biased phase — owned bodies are integrated on their way out
 //             (k_integrate folded in): velocities AND poses then go to the other buffers (t_lin / t_ang / t_rot / t_trans).
 // LP: two lanes per manifold (tile_apply2) instead of one (tile_apply); RP_TILE_LANES=1 keeps the one-lane form
 template <int MODE, bool LP>
 __global__ void __launch_bounds__(RP_TILE_THREADS) k_tile_sweep(DevWorld w, int friction_in_bias, float solved_dt, int fuse, int joint_warmstart) {
+    if (lean_dead(w)) return; // (rp_world.h "lean step graphs")
     const int NT = w.flags[FL_N_TILES];
     const int t = threadIdx.x, nt = blockDim.x;
     const bool fib = friction_in_bias != 0;
@@ -515,6 +542,10 @@ __global__ void __launch_bounds__(RP_TILE_THREADS) k_tile_sweep(DevWorld w, int 
         if (blockIdx.x != 0) return;
         if (fuse & 1) {
             for (int i = t; i < w.n_bodies; i += nt) if (global_body(w, i)) { V3 lin, ang; body_increment_ws(w, i, lin, ang); w.s_lin[i] = f4(lin, 0.0f); w.s_ang[i] = f4(ang, 0.0f); }
+            __threadfence(); __syncthreads();
+        }
+        if (MODE == MODE_BIAS && (fuse & 4)) { // the rows this sweep was to rebuild on its tiles
+            for (int j = t; j < w.n_joints; j += nt) if (joint_live(w, j)) { const PlainBodyIO io = {w}; joint_update_one_t<PlainBodyIO, JointRowsToPlanes, true>(w, io, j, fuse >> 8); } // (all spherical: fuse bit 2)
             __threadfence(); __syncthreads();
         }
         if (MODE != MODE_RESTITUTION) joint_tail_sweep(w, 0, MODE == MODE_RELAX, joint_warmstart != 0); // every joint before any contact
@@ -582,7 +613,8 @@ __global__ void __launch_bounds__(RP_TILE_THREADS) k_tile_sweep(DevWorld w, int 
                 while (have) {
                     if (!odd) {
                         TileJointPre P;
-                        tile_joint_fetch(w, -1 - e.x, P);
+                        if (MODE == MODE_BIAS && (fuse & 4)) tile_joint_build(w, e, fuse >> 8, P);
+                        else tile_joint_fetch(w, -1 - e.x, P);
                         tile_apply_joint(w, e, P, Ll, La, MODE == MODE_RELAX, joint_warmstart != 0);
                     }
                     i += per; have = i < end;

@@ -200,6 +200,8 @@ struct DevWorld {
     int bp_incremental;    // the broad phase may update incrementally (0: RP_NO_BP_INCR=1, every pass is a full rebuild)
     int gbar_blocks;       // most workgroups (of 1024 threads) a grid-barrier kernel may use on this device: all of them resident at once (rp_gridbar.h)
     int has_sensors;       // some collider is a sensor: its pairs are intersection-tested every step (full step path)
+    int joints_spherical;  // every impulse joint locks the three linear axes and nothing else (no limit, no motor): tile sweeps may rebuild the rows themselves
+    int lean;              // 1 in the copy the LEAN step graph is captured with (rp_api.hip "lean graph"): its kernels check lean_dead / collision_done
     SimParams prm;
     int *flags;        // FL_* scalars
     unsigned *bar;     // [8] grid-barrier words of the fused rebuild kernels (rp_gridbar.h): {arrivals, base} per kernel
@@ -391,3 +393,24 @@ struct DevWorld {
     int *tl_bodies;             // [tile_cap][RP_TILE_BCAP] arena index of every cone body (owned + halo), index = tile-local id
     int4 *tl_cons;              // [tile_cap][RP_TILE_CCAP] cone constraints in stage order: position, local body 1, local body 2, owner?
 };
+// ---- lean step graphs (rp_api.hip "lean graph") ----------------------------------------------------------------------------------
+// A MULTI-mode world whose contact graph did not change this step needs none of the launches that rebuild the colouring, the joint
+// colouring, the layout, the toucher ranks or the tiling — nine early exits per step.  The LEAN graph leaves them out: collision
+// detection, then straight to the solver.  Whether that was right is known on the device once the narrow phase has run: the
+// solver kernels of a lean graph all evaluate the same condition (the flags below do not change after k_np_update in a lean graph)
+// and exit when work for the left-out launches turned up; the last kernel of the graph (k_ccd) then raises FL_FAST_ABORT = 2, which
+//   - makes every later lean graph a no-op (collision_done / lean_dead), and
+//   - makes the next FULL graph resume the step: its collision kernels skip (that stage already ran for this step, its results are
+//     in place), the rebuild launches run, the solver runs; k_color_pairs — first kernel behind the collision stage, full graphs
+//     only — clears the marker.
+// The host sees the marker in the hint buffer and stops enqueueing lean graphs; steps that died are replayed by settle() like
+// aborted fast steps.
+#if defined(__HIPCC__)
+__device__ __forceinline__ bool lean_dead(const DevWorld &w) {
+    if (!w.lean) return false;
+    return (w.flags[FL_FAST_ABORT] | w.flags[FL_TODO_COUNT] | w.flags[FL_LAYOUT_DIRTY] | w.flags[FL_FLOW_DIRTY] | (w.n_joints > 0 ? w.flags[FL_JOINT_DIRTY] : 0)) != 0;
+}
+// collision kernels: this step's collision stage already ran (a dead lean step waits for its resume), or an earlier lean step died
+__device__ __forceinline__ bool collision_done(const DevWorld &w) { const int a = w.flags[FL_FAST_ABORT]; return a == 2 || (w.lean && a != 0); }
+#endif
+

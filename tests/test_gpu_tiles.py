@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _world(scene, monkeypatch, **env):
-    for k in ("RP_NO_TILES", "RP_TILE_TARGET", "RP_TILE_MIN", "RP_FORCE_MULTI"):
+    for k in ("RP_NO_TILES", "RP_TILE_TARGET", "RP_TILE_MIN", "RP_FORCE_MULTI", "RP_NO_LEAN"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, str(v))
@@ -190,3 +190,41 @@ def test_sweep_counts_on_a_tiled_world_bit_exact(monkeypatch, override):
     for k, v in override.items():
         sc.params[k] = v
     _run(sc, [2, 12, 40], monkeypatch)
+
+
+# ---- lean step graphs: full steps without the rebuild launches, validated on the device (rp_world.h "lean step graphs") -------------
+def test_lean_steps_die_and_resume_bit_exact(monkeypatch):
+    """a tiled pyramid runs lean graphs once its contact graph stands still; an impulse then throws bodies off the top: pairs end and
+    begin steps later, on the device only — lean steps die behind their collision stage, the full graph resumes them, nothing differs
+    from the oracle; the same run with RP_NO_LEAN=1 enqueues no lean graph"""
+    monkeypatch.delenv("RP_NO_LEAN", raising=False)
+    sc = S.large_pyramid(60)
+    g, o = _world(sc, monkeypatch), OracleWorld(sc)
+    dyn = [i for i, b in enumerate(sc.bodies) if int(b["body_type"]) == S.BODY_DYNAMIC]
+    g.step(60); o.step(60)
+    _equal(g, o, "settling")
+    c0 = g.counters()
+    assert c0["lean_steps"] > 0, c0
+    for b in dyn[-3:]:
+        g.apply_impulse([b], impulse=(400.0, 900.0, 150.0)); o.apply_impulse(b, impulse=(400.0, 900.0, 150.0))
+    for n in (1, 30, 120, 200):
+        g.step(n); o.step(n)
+        _equal(g, o, f"after the impulse, +{n}")
+    c = g.counters()
+    assert c["overflow_flags"] == 0 and c["lean_steps"] > c0["lean_steps"] and c["replayed_steps"] > 0, c
+    h = _world(sc, monkeypatch, RP_NO_LEAN=1)
+    h.step(60)
+    for b in dyn[-3:]:
+        h.apply_impulse([b], impulse=(400.0, 900.0, 150.0))
+    h.step(351)
+    _equal(g, h, "lean vs full graphs")
+    assert h.counters()["lean_steps"] == 0
+
+
+def test_lean_steps_on_the_joint_grid_bit_exact(monkeypatch):
+    """b3d_joint_grid never has a contact: once tiled, every step is a lean graph; joint impulses included"""
+    monkeypatch.delenv("RP_NO_LEAN", raising=False)
+    g, o, c = _run(S.joint_grid(40), [5, 50, 200], monkeypatch)
+    assert c["lean_steps"] > 100, c
+    gc, gi = g.read_joints(); oc, oi = o.read_joints()
+    np.testing.assert_array_equal(gi, oi, err_msg="joint impulses")
