@@ -1135,7 +1135,6 @@ static int finalize(rp_world *w) {
     d.hash_cap = next_pow2(4LL * d.pool_cap);
     d.grid_cap = std::min(next_pow2(8LL * std::max(capc, 1)), 1 << 20);
     d.grid_cap = std::max(d.grid_cap, 1024);
-    d.entries_cap = 27 * capc + 64;
     d.large_cap = std::min(std::max(capc, 1), 4096);
     d.cons_cap = d.pool_cap;
     // grid cell size: 90th percentile of the collider bounding extents (+ fat margins)
@@ -1169,8 +1168,9 @@ static int finalize(rp_world *w) {
     DAC(d.c_mat, capc, DOM_COLL, 1, 1); DAC(d.c_rules, capc, DOM_COLL, 1, 1); DAC(d.c_groups, capc, DOM_COLL, 1, 1); DAC(d.c_fatmin, capc, DOM_COLL, 1, 1); DAC(d.c_fatmax, capc, DOM_COLL, 1, 1); DAC(d.c_events, capc, DOM_COLL, 1, 1);
     d.ev_cap = 65536;
     DAC(d.ev_col, d.ev_cap, DOM_FIXED, 1, 1); DAC(d.ev_force_meta, d.ev_cap, DOM_FIXED, 1, 1); DAC(d.ev_force_a, d.ev_cap, DOM_FIXED, 1, 1); DAC(d.ev_force_b, d.ev_cap, DOM_FIXED, 1, 1);
-    DA(d.cell_count, d.grid_cap); DA(d.cell_start, d.grid_cap + 1); DA(d.cell_fill, d.grid_cap); DA(d.scan_block, 1024 + 8); // + the scratch counters of a running broad-phase rebuild
-    DA(d.e_key, d.entries_cap); DA(d.e_col, d.entries_cap); DA(d.large_list, d.large_cap);
+    for (int k = 0; k < 2; ++k) { DA(d.bk_cnt[k], d.grid_cap); DA(d.bk_items[k], (size_t)d.grid_cap * RP_BP_BUCKET); } // the broad-phase grid: fixed-slot hash buckets, two copies (rp_broadphase.hip)
+    DA(d.scan_block, 1024 + 8); // the scratch counters of a running broad-phase rebuild
+    DA(d.large_list, d.large_cap);
     DA(d.c_chgstamp, capc); DA(d.c_stale, capc); DA(d.c_inlarge, capc); DA(d.bp_chg_list, capc); DA(d.bp_moved_list, RP_BP_MOVED_CAP); // incremental broad phase (scratch: rebuilt by the next full pass)
     DAF(d.h_key[0], d.hash_cap, 0xff); DAF(d.h_key[1], d.hash_cap, 0xff); DA(d.h_slot[0], d.hash_cap); DA(d.h_slot[1], d.hash_cap);
     DAC(d.free_stack, d.pool_cap, DOM_PAIR, 1, 1);

@@ -7,9 +7,9 @@
 //   * a pair exists exactly while the two fat AABBs intersect and it passes the filters of
 //     update.rs:334-396 (same parent, collision types, interaction groups);
 //   * AddPair creates an empty ContactPair, DeletePair frees its solver colour (pair_management.rs:382).
-// The tree is free to differ: here a hashed uniform grid built by counting sort (HBM-bound integer
+// The tree is free to differ: here a hashed uniform grid of fixed-slot buckets (HBM-bound integer
 // work, one thread per collider, wave-coalesced SoA loads) plus a brute-force list for colliders
-// spanning more than 3 cells.  Like the reference's change detection the whole pass is skipped
+// spanning more than 3 cells (and for the rare collider that met a full bucket).  Like the reference's change detection the whole pass is skipped
 // (every kernel early-exits on FL_BP_DIRTY == 0) while no fat AABB changed, and — like its refit of the changed
 // leaves only (update.rs:139-331, :448-601) — a pass in which FEW fat AABBs changed touches only those colliders:
 // the grid of the last full rebuild still describes every collider that has not moved since, so a changed collider
@@ -108,98 +108,45 @@ __global__ void k_fast_front(DevWorld w, int no_global_kernel) {
 }
 
 // ---- the rebuild, pass by pass (k_bp_rebuild below runs them behind grid barriers; gid / gstride span the whole launch) ----
-// (no clearing pass: a full rebuild leaves its scratch at rest — bp_finish_pairs empties the cell counters, the hash table that goes
-// out of service and the large-collider counter for the next rebuild; allocation provides the first rest state)
+// The grid: grid_cap hash buckets of RP_BP_BUCKET fixed slots, two copies.  A slot is ONE word — the collider and which of its (at
+// most 27) cells the entry stands for (bp_entry): 32 slots = one 128-byte line.  Cells that share a bucket are told apart without a
+// stored key: a reader at cell X accepts an entry only if the cell it stands for — recomputed from the partner's fat AABB, which the
+// overlap test loads anyway — is X (bp_entry_is_cell).  A rebuild fills the copy that is out
+// of service straight away — one atomic per (collider, cell) hands out the slot, no counting sort: three passes (build | pairs |
+// finish) where the counting sort took five (count | scan | add + fill | pairs | finish), and a pass of a rebuild is a grid barrier
+// plus a chain of cold misses whatever its work — ~10 us each on MI355X.  The copy in service (epoch parity, like the pair hash
+// tables) keeps serving until the rebuild closes; its counters are emptied by the finish pass, so the next rebuild finds its target at
+// rest (allocation provides the first rest state).  A collider that finds a bucket full joins the large list for this rebuild
+// (c_inlarge): everybody tests against that list anyway, its bucket entries are skipped — slower, never wrong.
 #define BP_LARGE_SCRATCH 1024 // scan_block[1024]: large colliders counted by the running rebuild (FL_N_LARGE keeps serving incremental passes until then)
-RP_DEV void bp_count(DevWorld &w, int gid, int gstride) {
+RP_DEV void bp_large_append(DevWorld &w, int i) {
+    int k = atomicAdd(&w.scan_block[BP_LARGE_SCRATCH], 1);
+    if (k < w.large_cap) w.large_list[k] = i; else atomicOr(&w.flags[FL_OVERFLOW], RP_OVF_LARGE);
+}
+RP_DEV int bp_entry(int collider, int ordinal) { return collider | (ordinal << 26); } // ordinal: x fastest inside the collider's cell range
+RP_DEV bool bp_entry_is_cell(const DevWorld &w, int entry, int x, int y, int z) {
+    const CellRange r = cell_range(w, entry & 0x3ffffff);
+    const int o = (int)((unsigned)entry >> 26), nx = r.hi[0] - r.lo[0] + 1, ny = r.hi[1] - r.lo[1] + 1;
+    return r.lo[0] + o % nx == x && r.lo[1] + (o / nx) % ny == y && r.lo[2] + o / (nx * ny) == z;
+}
+RP_DEV void bp_build(DevWorld &w, int gid, int gstride, int nxt) {
+    int *cnt = w.bk_cnt[nxt]; int *items = w.bk_items[nxt];
     for (int i = gid; i < w.n_colliders; i += gstride) {
         CellRange r = cell_range(w, i);
         w.c_inlarge[i] = r.large ? 1 : 0; w.c_stale[i] = 0; // the grid is being rebuilt: nobody is stale
-        if (r.large) {
-            int k = atomicAdd(&w.scan_block[BP_LARGE_SCRATCH], 1);
-            if (k < w.large_cap) w.large_list[k] = i; else atomicOr(&w.flags[FL_OVERFLOW], RP_OVF_LARGE);
-            continue;
-        }
+        if (r.large) { bp_large_append(w, i); continue; }
+        bool full = false;
+        int o = 0;
         for (int z = r.lo[2]; z <= r.hi[2]; ++z)
             for (int y = r.lo[1]; y <= r.hi[1]; ++y)
-                for (int x = r.lo[0]; x <= r.hi[0]; ++x) {
+                for (int x = r.lo[0]; x <= r.hi[0]; ++x, ++o) {
                     unsigned long long key = cell_key(x, y, z);
                     int h = (int)(rp_hash64(key) & (unsigned long long)(w.grid_cap - 1));
-                    atomicAdd(&w.cell_count[h], 1);
+                    int k = atomicAdd(&cnt[h], 1);
+                    if (k < RP_BP_BUCKET) items[(size_t)h * RP_BP_BUCKET + k] = bp_entry(i, o);
+                    else full = true;
                 }
-    }
-}
-// exclusive scan of cell_count -> cell_start: 1024-item chunks scanned in LDS; the workgroup that finishes last (a ticket) scans the
-// chunk sums, and the pass that fills the cells adds them back (bp_add_fill) — two barriers instead of four
-RP_DEV void bp_scan_sums(DevWorld &w, int *s) { // one workgroup; at most 1024 chunks (grid_cap <= 2^20)
-    const int nblocks = (w.grid_cap + 1023) / 1024;
-    int v = threadIdx.x < nblocks ? __hip_atomic_load(&w.scan_block[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0; // (written by other CUs in this launch)
-    s[threadIdx.x] = v;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        int t = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
-        __syncthreads();
-        s[threadIdx.x] += t;
-        __syncthreads();
-    }
-    if (threadIdx.x < nblocks) w.scan_block[threadIdx.x] = s[threadIdx.x] - v;
-    if (threadIdx.x == 1023) {
-        w.flags[FL_N_ENTRIES] = s[1023];
-        if (s[1023] > w.entries_cap) atomicOr(&w.flags[FL_OVERFLOW], RP_OVF_CELLS);
-        const int nl = __hip_atomic_load(&w.scan_block[BP_LARGE_SCRATCH], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        w.flags[FL_N_LARGE] = nl < w.large_cap ? nl : w.large_cap; // the count pass is complete: the new large list goes into service
-    }
-}
-RP_DEV void bp_scan_chunks(DevWorld &w, int *s) {
-    const int chunks = (w.grid_cap + 1023) / 1024;
-    for (int c = blockIdx.x; c < chunks; c += gridDim.x) {
-        int gid = c * 1024 + threadIdx.x;
-        int v = gid < w.grid_cap ? w.cell_count[gid] : 0;
-        s[threadIdx.x] = v;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            int t = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
-            __syncthreads();
-            s[threadIdx.x] += t;
-            __syncthreads();
-        }
-        if (gid < w.grid_cap) { w.cell_start[gid] = s[threadIdx.x] - v; w.cell_fill[gid] = s[threadIdx.x] - v; } // (cell_fill: the fill cursor starts at the chunk-local begin)
-        if (threadIdx.x == 1023) w.scan_block[c] = s[1023];
-        __syncthreads();
-    }
-    // (the hand-over of rp_gridbar.h: every wave drains its stores, the workgroup meets, ONE lane releases at agent scope and takes the
-    // ticket — a __threadfence() per thread made this pass 32 us)
-    __shared__ int last;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        last = __hip_atomic_fetch_add(&w.flags[FL_TICKET], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
-        if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-    if (last) {
-        bp_scan_sums(w, s);
-        if (threadIdx.x == 0) w.flags[FL_TICKET] = 0;
-    }
-}
-RP_DEV void bp_scan_add(DevWorld &w, int gid, int gstride) {
-    for (int i = gid; i < w.grid_cap; i += gstride) w.cell_start[i] += w.scan_block[i >> 10];
-    if (gid == 0) w.cell_start[w.grid_cap] = w.flags[FL_N_ENTRIES]; // the end of the last cell
-}
-RP_DEV void bp_fill(DevWorld &w, int gid, int gstride) {
-    for (int i = gid; i < w.n_colliders; i += gstride) {
-        CellRange r = cell_range(w, i);
-        if (r.large) continue;
-        for (int z = r.lo[2]; z <= r.hi[2]; ++z)
-            for (int y = r.lo[1]; y <= r.hi[1]; ++y)
-                for (int x = r.lo[0]; x <= r.hi[0]; ++x) {
-                    unsigned long long key = cell_key(x, y, z);
-                    int h = (int)(rp_hash64(key) & (unsigned long long)(w.grid_cap - 1));
-                    int pos = w.scan_block[h >> 10] + atomicAdd(&w.cell_fill[h], 1); // (cell_start is being finalised by bp_scan_add in this very pass: the cursor carries the chunk-local begin)
-                    if (pos < w.entries_cap) { w.e_key[pos] = key; w.e_col[pos] = i; }
-                }
+        if (full) { w.c_inlarge[i] = 1; bp_large_append(w, i); } // (only this thread writes c_inlarge[i] in this pass; readers sit behind the barrier)
     }
 }
 
@@ -284,35 +231,37 @@ __device__ void bp_insert_pair(DevWorld &w, int c1, int c2, bool incremental = f
 // chain of ~100 dependent L2 round trips, 150 us of the 213 us rebuild on b3d_large_pyramid (tools/pass_profile.py); a whole
 // wavefront per collider does not fit the resident grid of a barrier kernel (16 rounds: slower).
 #define BP_GROUP 8
-RP_DEV void bp_pairs(DevWorld &w) {
+RP_DEV void bp_pairs(DevWorld &w, int nxt) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, sub = tid & (BP_GROUP - 1), ngroups = (gridDim.x * blockDim.x) / BP_GROUP;
     const float ic = w.prm.inv_cell_size;
-    int nl = w.flags[FL_N_LARGE];
+    int nl = w.scan_block[BP_LARGE_SCRATCH]; // (the build pass is complete: geometric large colliders + the ones a full bucket sent here)
     if (nl > w.large_cap) nl = w.large_cap;
+    const int *cnt = w.bk_cnt[nxt]; const int *items = w.bk_items[nxt];
     for (int i = tid / BP_GROUP; i < w.n_colliders; i += ngroups) {
-        CellRange r = cell_range(w, i);
+        const bool ilarge = w.c_inlarge[i] != 0;
         for (int q = sub; q < nl; q += BP_GROUP) {
             int L = w.large_list[q];
-            if (L == i || (r.large && i > L)) continue; // large-large pairs reported from the lower index
+            if (L == i || (ilarge && i > L)) continue; // large-large pairs reported from the lower index
             V3 imin;
             if (!fat_overlap(w, i, L, imin) || !pair_allowed(w, i, L)) continue;
             bp_insert_pair(w, i < L ? i : L, i < L ? L : i);
         }
-        if (r.large) continue;
+        if (ilarge) continue;
+        CellRange r = cell_range(w, i);
         const int nx = r.hi[0] - r.lo[0] + 1, ny = r.hi[1] - r.lo[1] + 1, nz = r.hi[2] - r.lo[2] + 1;
         for (int c = sub; c < nx * ny * nz; c += BP_GROUP) {
             const int x = r.lo[0] + c % nx, y = r.lo[1] + (c / nx) % ny, z = r.lo[2] + c / (nx * ny);
             unsigned long long key = cell_key(x, y, z);
             int h = (int)(rp_hash64(key) & (unsigned long long)(w.grid_cap - 1));
-            int beg = w.cell_start[h], end = w.cell_start[h + 1]; // (cells are consecutive ranges of the entry array; cell_count is scratch of a rebuild)
-            if (end > w.entries_cap) end = w.entries_cap;
-            for (int e = beg; e < end; ++e) {
-                if (w.e_key[e] != key) continue;
-                int j = w.e_col[e];
+            int n = cnt[h]; if (n > RP_BP_BUCKET) n = RP_BP_BUCKET;
+            for (int e = 0; e < n; ++e) {
+                const int it = items[(size_t)h * RP_BP_BUCKET + e], j = it & 0x3ffffff;
                 if (j <= i) continue;
                 V3 imin;
                 if (!fat_overlap(w, i, j, imin)) continue;
                 if (cell_coord(imin.x, ic) != x || cell_coord(imin.y, ic) != y || cell_coord(imin.z, ic) != z) continue;
+                if (!bp_entry_is_cell(w, it, x, y, z)) continue; // (another cell of j that shares this bucket)
+                if (w.c_inlarge[j]) continue; // (a collider on the large list was met above; asked last: few entries get this far)
                 if (!pair_allowed(w, i, j)) continue;
                 bp_insert_pair(w, i, j);
             }
@@ -374,10 +323,14 @@ RP_DEV void bp_finish_pairs(DevWorld &w, int gid, int gstride) {
         if (w.p_stamp[s] == epoch + 1) continue;
         bp_delete_pair(w, s);
     }
-    // rest state for the next rebuild: empty cell counters, the table that goes out of service (it becomes the next rebuild's target)
-    for (int i = gid; i < w.grid_cap; i += gstride) w.cell_count[i] = 0;
+    // rest state for the next rebuild: the grid copy and the pair table that go out of service (they become the next rebuild's targets)
+    { int *old = w.bk_cnt[epoch & 1]; for (int i = gid; i < w.grid_cap; i += gstride) old[i] = 0; }
     { unsigned long long *old = w.h_key[epoch & 1]; for (int i = gid; i < w.hash_cap; i += gstride) old[i] = RP_EMPTY_KEY; }
-    if (gid == 0) w.scan_block[BP_LARGE_SCRATCH] = 0;
+    if (gid == 0) { // the new large list goes into service with the new grid
+        const int nl = w.scan_block[BP_LARGE_SCRATCH];
+        w.flags[FL_N_LARGE] = nl < w.large_cap ? nl : w.large_cap;
+        w.scan_block[BP_LARGE_SCRATCH] = 0;
+    }
 }
 
 // ---- incremental pass ------------------------------------------------------------------------------------------------------
@@ -418,15 +371,15 @@ RP_DEV void bp_incr_insert(DevWorld &w, int nchg, int nmoved) {
             const int x = r.lo[0] + lane % nx, y = r.lo[1] + (lane / nx) % ny, z = r.lo[2] + lane / (nx * ny);
             unsigned long long key = cell_key(x, y, z);
             int h = (int)(rp_hash64(key) & (unsigned long long)(w.grid_cap - 1));
-            int beg = w.cell_start[h], end = w.cell_start[h + 1]; // (cells are consecutive ranges of the entry array; cell_count is scratch of a rebuild)
-            if (end > w.entries_cap) end = w.entries_cap;
-            for (int e = beg; e < end; ++e) {
-                if (w.e_key[e] != key) continue;
-                int j = w.e_col[e];
-                if (j == i || w.c_stale[j] || w.c_chgstamp[j] == stamp) continue; // stale cells: covered by (b) / (c)
+            const int cur = w.flags[FL_BP_EPOCH] & 1; // the grid copy in service
+            int n = w.bk_cnt[cur][h]; if (n > RP_BP_BUCKET) n = RP_BP_BUCKET;
+            for (int e = 0; e < n; ++e) {
+                const int it = w.bk_items[cur][(size_t)h * RP_BP_BUCKET + e], j = it & 0x3ffffff;
+                if (j == i || w.c_stale[j] || w.c_chgstamp[j] == stamp || w.c_inlarge[j]) continue; // stale cells: covered by (b) / (c); the large list: by (a)
                 V3 imin;
                 if (!fat_overlap(w, i, j, imin)) continue;
                 if (cell_coord(imin.x, ic) != x || cell_coord(imin.y, ic) != y || cell_coord(imin.z, ic) != z) continue;
+                if (!bp_entry_is_cell(w, it, x, y, z)) continue; // (another cell of j that shares this bucket; j has not moved since the grid was built)
                 if (!pair_allowed(w, i, j)) continue;
                 bp_insert_pair(w, i < j ? i : j, i < j ? j : i, true);
             }
@@ -460,7 +413,6 @@ RP_DEV void bp_incr_delete(DevWorld &w, int gid, int gstride, int nchg) {
 __global__ void __launch_bounds__(1024) k_bp_rebuild(DevWorld w) {
     if (!w.flags[FL_BP_DIRTY]) return; // (cleared only after the last barrier: every workgroup reads the same value)
     if (collision_done(w)) return;     // (a dead lean step's collision stage is not repeated: rp_world.h "lean step graphs")
-    __shared__ int scan_lds[1024];
     const int gid = gbar_item(), gstride = gridDim.x * blockDim.x;
     // the mode is decided from scalars that only change behind a barrier of this launch (or at its very end)
     const int nchg = w.flags[FL_BP_NCHG] < w.n_colliders ? w.flags[FL_BP_NCHG] : w.n_colliders, nmoved = w.flags[FL_BP_NMOVED];
@@ -470,7 +422,7 @@ __global__ void __launch_bounds__(1024) k_bp_rebuild(DevWorld w) {
 #ifdef RP_PASS_PROFILE // why a pass was (not) incremental: dbg[240..] (tools/pass_profile.py)
     if (gid == 0) {
         w.dbg[240] += 1; w.dbg[241] += incremental ? 1 : 0; w.dbg[242] += w.flags[FL_BP_GRID_OK] ? 0 : 1; w.dbg[243] += (nchg > w.n_colliders / 4 + 16) ? 1 : 0;
-        w.dbg[244] += (nmoved + nchg > RP_BP_MOVED_CAP) ? 1 : 0; w.dbg[245] += (w.flags[FL_BP_TOMBS] >= w.hash_cap / 8) ? 1 : 0; w.dbg[246] += nchg; w.dbg[247] += nmoved;
+        w.dbg[244] += (nmoved + nchg > RP_BP_MOVED_CAP) ? 1 : 0; w.dbg[245] += (w.flags[FL_BP_TOMBS] >= w.hash_cap / 8) ? 1 : 0; w.dbg[246] += nchg; w.dbg[247] += nmoved; w.dbg[248] = w.flags[FL_N_LARGE];
     }
 #endif
     if (incremental) {
@@ -490,14 +442,9 @@ __global__ void __launch_bounds__(1024) k_bp_rebuild(DevWorld w) {
     }
     const int epoch = w.flags[FL_BP_EPOCH];
     RP_PASS_BEGIN();
-    bp_count(w, gid, gstride);
+    bp_build(w, gid, gstride, (epoch & 1) ^ 1);
     GBAR_SYNC(bar); RP_PASS_STAMP(w, 220);
-    bp_scan_chunks(w, scan_lds);
-    GBAR_SYNC(bar); RP_PASS_STAMP(w, 220);
-    bp_scan_add(w, gid, gstride);
-    bp_fill(w, gid, gstride);
-    GBAR_SYNC(bar); RP_PASS_STAMP(w, 220);
-    bp_pairs(w);
+    bp_pairs(w, (epoch & 1) ^ 1);
     GBAR_SYNC(bar); RP_PASS_STAMP(w, 220);
     bp_finish_pairs(w, gid, gstride);
     GBAR_SYNC(bar); RP_PASS_STAMP(w, 220);

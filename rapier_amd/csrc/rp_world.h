@@ -48,7 +48,8 @@
 // overflow / error flag bits (dev flags[FL_OVERFLOW])
 #define RP_OVF_POOL 0x1
 #define RP_OVF_HASH 0x2
-#define RP_OVF_CELLS 0x4
+#define RP_OVF_CELLS 0x4 // (unused since the grid has fixed-slot buckets: a full bucket sends the collider to the large list)
+#define RP_BP_BUCKET 32 // slots per hash bucket of the broad-phase grid (rp_broadphase.hip)
 #define RP_OVF_LARGE 0x8
 #define RP_OVF_CONS 0x10
 #define RP_OVF_GRID 0x20   // a workgroup of a fused rebuild kernel was not resident (rp_gridbar.h: its grid barrier timed out)
@@ -188,7 +189,6 @@ struct DevWorld {
     int pool_cap;      // pair slots
     int hash_cap;      // power of two
     int grid_cap;      // power of two (cell hash buckets)
-    int entries_cap;   // grid entries
     int large_cap;
     int cons_cap;      // solver manifolds
     int sleep_enabled; // some body may fall asleep (can_sleep dynamic bodies, any kinematic body): the sleep kernels run and pairs carry solver hints
@@ -270,8 +270,10 @@ struct DevWorld {
     float4 *ev_force_a, *ev_force_b; // total_force xyz + magnitude ; max_force_direction xyz + max magnitude
 
     // ---- broad phase ----
-    int *cell_count, *cell_start, *cell_fill, *scan_block;
-    unsigned long long *e_key; int *e_col;
+    int *bk_cnt[2];        // [grid_cap] entries handed out per hash bucket (may exceed RP_BP_BUCKET: the surplus went to the large list); two
+                           // copies: [FL_BP_EPOCH & 1] is in service, the other one rests at zero until the next rebuild fills it
+    int *bk_items[2];      // [grid_cap][RP_BP_BUCKET] collider | which of its cells << 26 (bp_entry)
+    int *scan_block;       // [1024 + 8] scratch counters of a running rebuild ([1024]: its large list)
     int *large_list;
     int *c_chgstamp, *c_stale, *c_inlarge; // per collider: pass (FL_BP_SEQ + 1) that already queued it on bp_chg_list; grid cells stale; on large_list
     int *bp_chg_list, *bp_moved_list;      // [colliders] fat AABBs rewritten since the last pass; [RP_BP_MOVED_CAP] stale colliders

@@ -38,15 +38,15 @@ L.rp_debug_read.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
 buf = np.zeros(64, np.int64)
 assert L.rp_debug_read(w._ptr, 200, 64, buf.ctypes.data) == 0
 lay = ["init+clear", "bucket count", "union", "isl_count", "isl_number", "isl_fill", "owner prefix + stage order", "scatter", "rank overflow"]
-bp = ["count", "scan (chunks + last-block sums)", "add + fill", "pairs", "finish + rest state"]
+bp = ["build (bucket slots)", "pairs", "finish + rest state"]
 for title, base, names in (("k_layout_rebuild", 0, lay), ("k_bp_rebuild (full pass)", 20, bp)):
     n = max(int(buf[base + 15]), 1)
     tot = sum(int(buf[base + k]) for k in range(len(names)))
     print(f"{name} {title}: {n} dirty launches, {tot / n / 100:.1f} us each:", " | ".join(f"{nm} {int(buf[base + k]) / n / 100:.1f}" for k, nm in enumerate(names)))
 print(w.counters())
 
-why = np.zeros(8, np.int64)
-assert L.rp_debug_read(w._ptr, 240, 8, why.ctypes.data) == 0
+why = np.zeros(9, np.int64)
+assert L.rp_debug_read(w._ptr, 240, 9, why.ctypes.data) == 0
 if why[0]:
     print(f"{name} broad-phase passes {why[0]}: incremental {why[1]}, not incremental because: grid not ok {why[2]}, too many changed {why[3]}, stale list full {why[4]}, tombstones {why[5]}; "
-          f"changed colliders per pass {why[6] / why[0]:.0f}, stale colliders {why[7] / why[0]:.0f}")
+          f"changed colliders per pass {why[6] / why[0]:.0f}, stale colliders {why[7] / why[0]:.0f}; large list {why[8]} (colliders spanning > 3 cells + those that met a full bucket)")
