@@ -182,6 +182,8 @@ typedef struct rp_counters {
     int32_t ccd_clamp_count;       /* (body, step) cases in which CCDSolver::solve_continuous clamped next_position to a time of impact */
     int32_t num_tiles;             /* LDS tiles the global solver path's big component is cut into (0 = colour stages run as launches) */
     int32_t tile_sweeps;           /* 1 = the last enqueued step ran its biased / relaxed sweeps as one launch over the tiles */
+    int32_t bp_large_list;         /* colliders the broad phase keeps on its brute-force list: those spanning more than 3 grid cells (ground slabs,
+                                    * half-spaces) and those that met a full hash bucket in the last full rebuild */
     int32_t lean_steps;            /* step graphs enqueued without the rebuild launches (colouring, layout, toucher ranks, tiling): worlds on the
                                     * per-stage / tile path whose contact graph stands still; validated on the device, a step whose narrow phase
                                     * found new work is resumed by the next full graph (counted in replayed_steps) */

@@ -375,10 +375,11 @@ RP_DEV void bp_incr_insert(DevWorld &w, int nchg, int nmoved) {
             int n = w.bk_cnt[cur][h]; if (n > RP_BP_BUCKET) n = RP_BP_BUCKET;
             for (int e = 0; e < n; ++e) {
                 const int it = w.bk_items[cur][(size_t)h * RP_BP_BUCKET + e], j = it & 0x3ffffff;
-                if (j == i || w.c_stale[j] || w.c_chgstamp[j] == stamp || w.c_inlarge[j]) continue; // stale cells: covered by (b) / (c); the large list: by (a)
+                if (j == i) continue;
                 V3 imin;
-                if (!fat_overlap(w, i, j, imin)) continue;
+                if (!fat_overlap(w, i, j, imin)) continue; // (geometry first: the three status words below are only fetched for the few entries that get past it)
                 if (cell_coord(imin.x, ic) != x || cell_coord(imin.y, ic) != y || cell_coord(imin.z, ic) != z) continue;
+                if (w.c_stale[j] || w.c_chgstamp[j] == stamp || w.c_inlarge[j]) continue; // stale cells: covered by (b) / (c); the large list: by (a)
                 if (!bp_entry_is_cell(w, it, x, y, z)) continue; // (another cell of j that shares this bucket; j has not moved since the grid was built)
                 if (!pair_allowed(w, i, j)) continue;
                 bp_insert_pair(w, i < j ? i : j, i < j ? j : i, true);

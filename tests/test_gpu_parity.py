@@ -193,6 +193,26 @@ def test_tumble_cuboids_only_second_seed():
     _compare(S.tumble(40, seed=21, balls=False), [20, 150])
 
 
+def test_crowded_grid_cell_goes_through_the_large_list():
+    """48 small balls dropped as one tight cluster among unit cubes: the broad phase's grid cell is as wide as the cubes, so the
+    cluster's fat AABBs fill one 32-slot hash bucket and the colliders that find it full are paired through the brute-force list
+    instead (rp_broadphase.hip, bp_build) — same pair set (update.rs:35-602: every pair of intersecting fat AABBs), same bits"""
+    s = S.Scene(name="crowded_cell", gravity=(0.0, -9.81, 0.0))
+    g = s.add_body(body_type=S.BODY_FIXED, translation=(0.0, -0.5, 0.0))
+    s.add_collider(g, half_extents=(12.0, 0.5, 12.0))
+    for ix in range(8):
+        for iz in range(8):
+            b = s.add_body(translation=(1.6 * (ix - 3.5), 0.5, 1.6 * (iz - 3.5)))
+            s.add_collider(b, half_extents=(0.5, 0.5, 0.5))
+    for k in range(48):
+        ix, iy, iz = k % 4, (k // 4) % 4, k // 16
+        b = s.add_body(translation=(0.8 + 0.11 * ix, 1.5 + 0.11 * iy, 0.8 + 0.11 * iz), linvel=(0.0, -1.0, 0.0))
+        s.add_collider(b, shape=S.SHAPE_BALL, half_extents=(0.05, 0, 0), friction=0.3)
+    gw, _ = _compare(s, [1, 5, 40, 150])
+    gw2 = PhysicsWorld.from_scene(s); gw2.step(1)
+    assert gw2.counters()["bp_large_list"] > 1, gw2.counters()  # the ground slab + the balls that met the full bucket
+
+
 @pytest.mark.parametrize("coeff", [1.0, 0.5, 0.0])
 def test_resting_impulse_kat_on_gpu(coeff):
     """total_contact_impulse.rs:13-75 through the C ABI."""
