@@ -228,3 +228,16 @@ def test_lean_steps_on_the_joint_grid_bit_exact(monkeypatch):
     assert c["lean_steps"] > 100, c
     gc, gi = g.read_joints(); oc, oi = o.read_joints()
     np.testing.assert_array_equal(gi, oi, err_msg="joint impulses")
+
+
+@pytest.mark.parametrize("seed", [3, 17])
+def test_lean_steps_in_a_churning_pile_bit_exact(monkeypatch, seed):
+    """1,300 tumbling cuboids and balls (restitution removed: worlds with a restitution sweep keep the full graph) settling in a pit:
+    pairs begin and end all the time, so lean graphs are tried whenever a few quiet steps went by and die often — the resume protocol
+    under stress, against the oracle bit for bit"""
+    monkeypatch.delenv("RP_NO_LEAN", raising=False)
+    sc = S.tumble(1300, seed=seed)
+    for c in sc.colliders:
+        c["restitution"] = 0.0
+    g, o, c = _run(sc, [1, 30, 120, 300, 500], monkeypatch, RP_TILE_MIN=256)
+    assert c["lean_steps"] > 0 and c["replayed_steps"] > 0, c
