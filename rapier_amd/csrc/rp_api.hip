@@ -1636,10 +1636,11 @@ static int step_once(rp_world *w, bool allow_fast) {
 static int settle(rp_world *w) {
     if (!w->finalized) return RP_OK;
     for (int guard = 0; guard < 64; ++guard) {
-        HIPCHK(w, hipStreamSynchronize(w->stream));
+        // the scalars ride the stream into the pinned hint buffer: ONE wait instead of a stream sync followed by a blocking copy
         int fl[FL_COUNT];
-        HIPCHK(w, hipMemcpy(fl, w->dw.flags, sizeof(fl), hipMemcpyDeviceToHost));
-        memcpy(w->pinned_flags, fl, sizeof(fl));
+        HIPCHK(w, hipMemcpyAsync(w->pinned_flags, w->dw.flags, sizeof(fl), hipMemcpyDeviceToHost, w->stream));
+        HIPCHK(w, hipStreamSynchronize(w->stream));
+        memcpy(fl, w->pinned_flags, sizeof(fl));
         if (fl[FL_GRID_TIMEOUT]) {
             // a fused fast step waited ~1 s for a workgroup that was not resident (another process or stream holds CUs): that step
             // aborted without writing anything and is replayed below; this world stops using the single-kernel fused step
