@@ -1097,7 +1097,8 @@ void rp_launch_narrowphase_part(const DevWorld &w, hipStream_t st, int part) {
     }
     if (part != 0) {
         rp_launch_sleep(w, st);   // sleep timers + the whole-island sleep decision (solve.rs:196-300, manager.rs:335-388); collider-less bodies too
-        if (w.n_colliders == 0) return;
+        // (a world without a single collider still has a solver layout: its bodies — under forces, on joints — sit on the global path;
+        // returning here left such worlds unsolved: test_pipeline_unit.py, the reference's collider-less pipeline tests)
         rp_launch_joint_coloring(w, st); // joints avoid this step's contact colours (init_joints, joints.rs:25-329)
         rp_launch_islands_build(w, st); // colour buckets, contact islands, stage layout, constraint positions: one launch (rp_islands.hip)
     }
