@@ -193,3 +193,175 @@ def test_world_without_colliders_still_moves(gpu, can_sleep):
     # point masses have no angular inertia (additional_mass adds none): they cannot turn, so the joints make the chain rigid — it must
     # hang where it was built, every link within the joints' softness of its place
     assert np.abs(p[1:7, :3] - start[1:7, :3]).max() < 2e-2, p
+
+
+def test_physics_world_builds_steps_and_queries_a_scene_oracle():
+    _bouncing_ball_check([_Oracle(_bouncing_ball())])
+
+
+@pytest.mark.gpu
+def test_physics_world_builds_steps_and_queries_a_scene_device():
+    _bouncing_ball_check(_worlds(_bouncing_ball(), True))
+
+
+def _bouncing_ball():
+    """crates/rapier3d/tests/issue_836_physics_world.rs: a ball (radius 0.5, restitution 0.7) dropped from y = 10 onto a thin ground slab
+    (half-height 0.1), 200 steps (the ray cast at the end of the reference test belongs to the query pipeline: out of scope)"""
+    s = S.Scene(name="issue_836", gravity=(0.0, -9.81, 0.0))
+    g = s.add_body(body_type=S.BODY_FIXED)
+    s.add_collider(g, half_extents=(100.0, 0.1, 100.0))
+    b = s.add_body(translation=(0.0, 10.0, 0.0), can_sleep=1)
+    s.add_collider(b, shape=S.SHAPE_BALL, half_extents=(0.5, 0, 0), restitution=0.7)
+    return s
+
+
+def _bouncing_ball_check(ws):
+    min_y = np.inf
+    for _ in range(200):
+        for w in ws:
+            w.step(1)
+        min_y = min(min_y, float(_same(ws, "bouncing ball")[0][1, 1]))
+    final_y = float(ws[0].read()[0][1, 1])
+    assert final_y < 9.0 and min_y > 0.4, (final_y, min_y)
+
+
+# ---- degenerate worlds (not reference scenes): whatever the world holds — or does not hold — a step must leave the device equal to the oracle ----
+def _degenerate(kind):
+    s = S.Scene(name=f"degenerate_{kind}", gravity=(0.0, -9.81, 0.0))
+    if kind == "empty":
+        pass
+    elif kind == "only_fixed":
+        for k in range(3):
+            f = s.add_body(body_type=S.BODY_FIXED, translation=(0.4 * k, 0.0, 0.0))
+            s.add_collider(f, half_extents=(0.5, 0.5, 0.5))
+    elif kind == "one_falling_ball":
+        b = s.add_body(translation=(0.0, 5.0, 0.0), angvel=(1.0, 2.0, 3.0))
+        s.add_collider(b, shape=S.SHAPE_BALL, half_extents=(0.5, 0, 0))
+    elif kind == "bare_bodies_and_a_fixed_collider":
+        g = s.add_body(body_type=S.BODY_FIXED, translation=(0.0, -0.5, 0.0))
+        s.add_collider(g, half_extents=(5.0, 0.5, 5.0))
+        for k in range(4):
+            s.add_body(translation=(float(k), 3.0, 0.0), additional_mass=1.0, linvel=(0.0, 1.0, 0.0))
+    elif kind == "dt0_stack":
+        s = S.box_stack(3)
+        s.params["dt"] = 0.0
+    elif kind == "no_gravity_at_rest":
+        s = S.box_stack(3)
+        s.gravity = (0.0, 0.0, 0.0)
+    elif kind == "far_from_the_origin":
+        g = s.add_body(body_type=S.BODY_FIXED, translation=(3.0e5, -0.5, -2.0e5))
+        s.add_collider(g, half_extents=(5.0, 0.5, 5.0))
+        for k in range(3):
+            b = s.add_body(translation=(3.0e5, 0.5 + 1.01 * k, -2.0e5))
+            s.add_collider(b, half_extents=(0.5, 0.5, 0.5))
+    elif kind == "massless":
+        g = s.add_body(body_type=S.BODY_FIXED, translation=(0.0, -0.5, 0.0))
+        s.add_collider(g, half_extents=(5.0, 0.5, 5.0))
+        b = s.add_body(translation=(0.0, 1.0, 0.0))
+        s.add_collider(b, half_extents=(0.5, 0.5, 0.5), density=0.0)       # zero mass: MassProperties with inv_mass 0 — nothing can move it
+        c = s.add_body(translation=(0.2, 2.2, 0.0))
+        s.add_collider(c, half_extents=(0.5, 0.5, 0.5))
+    elif kind == "one_iteration":
+        s = S.box_stack(4)
+        s.params["num_solver_iterations"] = 1
+    else:
+        raise ValueError(kind)
+    return s
+
+
+@pytest.mark.parametrize("gpu", GPU)
+@pytest.mark.parametrize("kind", ["empty", "only_fixed", "one_falling_ball", "bare_bodies_and_a_fixed_collider", "dt0_stack", "no_gravity_at_rest",
+                                  "far_from_the_origin", "massless", "one_iteration"])
+def test_degenerate_worlds(gpu, kind):
+    ws = _worlds(_degenerate(kind), gpu)
+    for n in (1, 2, 30, 120):
+        for w in ws:
+            w.step(n)
+        _same(ws, f"{kind}: {n} more steps")
+
+
+class _Script:
+    """the same edit script played on the oracle and on the device (handles = indices: rows are appended in insertion order on both)"""
+
+    def __init__(self, scene, gpu):
+        self.o = OracleWorld(scene)
+        self.g = _device(scene) if gpu else None
+
+    def step(self, n):
+        self.o.step(n)
+        if self.g is not None:
+            self.g.step(n)
+
+    def add_body(self, **kw):
+        b = self.o.add_body(**kw)
+        if self.g is not None:
+            hb = self.g.insert_body(S.body_desc(**kw))
+            assert int(hb) & 0xFFFFFFFF == b
+        return b
+
+    def add_collider(self, parent, **kw):
+        c = self.o.add_collider(parent, **kw)
+        if self.g is not None:
+            hc = self.g.insert_collider(S.collider_desc(**kw), parent)
+            assert int(hc) & 0xFFFFFFFF == c
+        return c
+
+    def remove_body(self, b):
+        self.o.remove_body(b)
+        if self.g is not None:
+            self.g.remove_body([b])
+
+    def remove_collider(self, c):
+        self.o.remove_collider(c)
+        if self.g is not None:
+            self.g.remove_collider([c])
+
+    def check(self, what, alive=None):
+        op, ov = self.o.read()
+        assert np.isfinite(op).all() and np.isfinite(ov).all(), what
+        if self.g is not None:
+            gp, gv = self.g.read_bodies()
+            rows = slice(None) if alive is None else alive
+            np.testing.assert_array_equal(gp[rows], op[rows], err_msg=what + " poses")
+            np.testing.assert_array_equal(gv[rows], ov[rows], err_msg=what + " velocities")
+            c = self.g.counters()
+            assert c["overflow_flags"] == 0, c
+        return op, ov
+
+
+@pytest.mark.parametrize("gpu", GPU)
+def test_a_world_that_starts_empty_and_is_edited_while_it_runs(gpu):
+    """not a reference scene: every edit lands on a world in an unusual state — no body at all, bodies but no collider, a body that gains
+    its first collider while it falls, the ground's collider removed under a resting body, the last dynamic body removed"""
+    w = _Script(S.Scene(name="starts_empty", gravity=(0.0, -9.81, 0.0)), gpu)
+    w.step(2)
+    w.check("an empty world")
+    ground = w.add_body(body_type=S.BODY_FIXED, translation=(0.0, -0.5, 0.0))
+    w.step(1)
+    gc = w.add_collider(ground, half_extents=(5.0, 0.5, 5.0))
+    w.step(1)
+    w.check("a fixed body and its collider")
+    box = w.add_body(translation=(0.0, 2.0, 0.0), additional_mass=1.0)
+    w.step(5)
+    p, _ = w.check("a collider-less body falls")
+    assert p[box, 1] < 2.0
+    w.add_collider(box, half_extents=(0.5, 0.5, 0.5))
+    w.step(60)
+    p, v = w.check("... gains a collider and lands")
+    assert 0.45 < p[box, 1] < 0.55 and abs(v[box, 1]) < 0.05, (p[box], v[box])
+    ball = w.add_body(translation=(0.2, 3.0, 0.1))
+    w.add_collider(ball, shape=S.SHAPE_BALL, half_extents=(0.3, 0, 0))
+    w.step(40)
+    w.check("a ball dropped onto the box")
+    w.remove_collider(gc)
+    w.step(20)
+    p, _ = w.check("the ground's collider removed: everything falls again")
+    assert p[box, 1] < 0.0
+    w.remove_body(box)
+    w.remove_body(ball)
+    w.step(3)
+    w.check("no dynamic body left", alive=[ground])
+    again = w.add_body(translation=(1.0, 1.0, 1.0), linvel=(1.0, 0.0, 0.0))
+    w.add_collider(again, half_extents=(0.2, 0.2, 0.2))
+    w.step(10)
+    w.check("and a new one inserted after that", alive=[ground, again])
