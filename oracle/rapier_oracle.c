@@ -290,6 +290,7 @@ ro_world *ro_world_new(const ro_params *params, const float gravity[3]) {
     w->pending_split = -1;
     return w;
 }
+void ro_set_params(ro_world *w, const ro_params *params) { w->params = *params; }
 void ro_world_free(ro_world *w) {
     if (!w) return;
     free(w->bodies); free(w->colliders); free(w->pairs); free(w->map_keys); free(w->map_vals);

@@ -105,6 +105,8 @@ typedef struct ro_world ro_world;
 
 void ro_default_params(ro_params *out);
 ro_world *ro_world_new(const ro_params *params, const float gravity[3]);
+/* the reference takes its IntegrationParameters per step (PhysicsPipeline::step(.., integration_parameters, ..)): they may change between any two steps */
+void ro_set_params(ro_world *w, const ro_params *params);
 void ro_world_free(ro_world *w);
 int32_t ro_add_body(ro_world *w, const ro_body_desc *d);
 int32_t ro_add_collider(ro_world *w, const ro_collider_desc *d, int32_t parent_body);

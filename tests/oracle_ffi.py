@@ -36,6 +36,7 @@ def lib():
         L.ro_world_new.restype = C.c_void_p
         L.ro_world_new.argtypes = [C.c_void_p, C.c_void_p]
         L.ro_world_free.argtypes = [C.c_void_p]
+        L.ro_set_params.argtypes = [C.c_void_p, C.c_void_p]
         L.ro_add_body.argtypes = [C.c_void_p, C.c_void_p]
         L.ro_add_collider.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         L.ro_add_joint.argtypes = [C.c_void_p, C.c_void_p]
@@ -115,6 +116,11 @@ class OracleWorld:
 
     def step(self, n: int = 1):
         lib().ro_step(self._w, n)
+
+    def set_params(self, params):
+        """the IntegrationParameters of the steps that follow (the reference takes them per step)"""
+        p = np.ascontiguousarray(params)
+        lib().ro_set_params(self._w, p.ctypes.data)
 
     def add_body(self, **kw) -> int:
         """RigidBodySet::insert into the (possibly already stepped) world."""

@@ -365,3 +365,34 @@ def test_a_world_that_starts_empty_and_is_edited_while_it_runs(gpu):
     w.add_collider(again, half_extents=(0.2, 0.2, 0.2))
     w.step(10)
     w.check("and a new one inserted after that", alive=[ground, again])
+
+
+@pytest.mark.parametrize("gpu", GPU)
+@pytest.mark.parametrize("scene", ["stack", "joints"])
+def test_integration_parameters_may_change_between_steps(gpu, scene):
+    """PhysicsPipeline::step takes its IntegrationParameters per call (physics_pipeline/mod.rs): a variable time step, another
+    iteration count or softer contacts from one step to the next are ordinary use.  rp_params_set on a live world = the next steps'
+    parameters; the device must follow the oracle bit for bit through every change"""
+    sc = S.box_stack(4) if scene == "stack" else S.jointed_pairs(2)
+    o = OracleWorld(sc)
+    g = _device(sc) if gpu else None
+    base = sc.params.copy()
+    changes = [dict(dt=1.0 / 120.0), dict(dt=1.0 / 30.0, num_solver_iterations=2), dict(dt=1.0 / 60.0, num_solver_iterations=6, num_internal_pgs_iterations=2),
+               dict(contact_natural_frequency=15.0, normalized_prediction_distance=0.05), dict(dt=0.0), dict(warmstart_coefficient=0.5, num_internal_stabilization_iterations=2), dict()]
+    for k, ch in enumerate(changes):
+        p = base.copy()
+        for name, val in ch.items():
+            p[name] = val
+        o.set_params(p)
+        if g is not None:
+            g.set_integration_parameters(p)
+        for n in (1, 7):
+            o.step(n)
+            if g is not None:
+                g.step(n)
+            op, ov = o.read()
+            assert np.isfinite(op).all() and np.isfinite(ov).all()
+            if g is not None:
+                gp, gv = g.read_bodies()
+                np.testing.assert_array_equal(gp, op, err_msg=f"change {k} {ch}: poses after {n}")
+                np.testing.assert_array_equal(gv, ov, err_msg=f"change {k} {ch}: velocities after {n}")
