@@ -306,8 +306,9 @@ int32_t rp_quarantine_read(rp_world *w, int32_t cap, uint64_t *handles_out);
  * whose total contact force exceeds the smaller of the two colliders' thresholds (solver_graph.rs:462-498).  With
  * out == NULL a call returns the number of queued events and consumes nothing.  Otherwise it writes the oldest
  * min(queued, cap) events (sorted by step, collider1, collider2), removes exactly those from the queue and returns how many
- * it wrote; the rest stays queued for the next call.  (A queue that overflowed its 65,536 slots between two reads has
- * dropped the newest events and says so in rp_last_error.) */
+ * it wrote; the rest stays queued for the next call.  (The queues hold max(65,536, pair slots) events — a step raises at most one
+ * collision and one force event per pair, so a queue that is read every step cannot overflow; one that did overflow between two reads
+ * has dropped the newest events and says so in rp_last_error.) */
 int32_t rp_collision_events_read(rp_world *w, int32_t cap, rp_collision_event *out);
 /* NarrowPhase::intersection_pairs (narrow_phase/queries.rs:150-190): every pair that involves a sensor collider, as triples
  * (collider1, collider2, intersecting 0|1) in triples3[3 * i ..]; returns the number of such pairs (may exceed cap). */

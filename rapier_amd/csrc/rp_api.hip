@@ -1166,7 +1166,7 @@ static int finalize(rp_world *w) {
     DAC(d.b_cmask, 4 * (size_t)capb, DOM_BODY, 1, 4); DAFC(d.b_min, capb, 0xff, DOM_BODY, 1, 1);
     DAC(d.c_parent, capc, DOM_COLL, 1, 1); DAC(d.c_ord, capc, DOM_COLL, 1, 1); DAC(d.c_shape, capc, DOM_COLL, 1, 1); DAC(d.c_lpos, capc, DOM_COLL, 1, 1); DAC(d.c_lrot, capc, DOM_COLL, 1, 1); DAC(d.c_pos, capc, DOM_COLL, 1, 1); DAC(d.c_rot, capc, DOM_COLL, 1, 1); DAC(d.c_he, capc, DOM_COLL, 1, 1);
     DAC(d.c_mat, capc, DOM_COLL, 1, 1); DAC(d.c_rules, capc, DOM_COLL, 1, 1); DAC(d.c_groups, capc, DOM_COLL, 1, 1); DAC(d.c_fatmin, capc, DOM_COLL, 1, 1); DAC(d.c_fatmax, capc, DOM_COLL, 1, 1); DAC(d.c_events, capc, DOM_COLL, 1, 1);
-    d.ev_cap = 65536;
+    d.ev_cap = std::max(65536, d.pool_cap); // a step raises at most one collision event and one force event per pair slot: a queue that is read every step cannot overflow
     DAC(d.ev_col, d.ev_cap, DOM_FIXED, 1, 1); DAC(d.ev_force_meta, d.ev_cap, DOM_FIXED, 1, 1); DAC(d.ev_force_a, d.ev_cap, DOM_FIXED, 1, 1); DAC(d.ev_force_b, d.ev_cap, DOM_FIXED, 1, 1);
     for (int k = 0; k < 2; ++k) { DA(d.bk_cnt[k], d.grid_cap); DA(d.bk_items[k], (size_t)d.grid_cap * RP_BP_BUCKET); } // the broad-phase grid: fixed-slot hash buckets, two copies (rp_broadphase.hip)
     DA(d.scan_block, 1024 + 8); // the scratch counters of a running broad-phase rebuild

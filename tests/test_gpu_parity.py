@@ -1039,6 +1039,24 @@ def test_collision_and_contact_force_events_bit_exact():
     assert g3.counters()["fast_steps"] > 0
 
 
+def test_event_queues_hold_every_pair_of_a_large_world():
+    """27 x 27 pyramids with collision events on every collider: ~106,000 pairs begin to touch within the first steps — more events than
+    the 65,536 slots the queues used to have.  The queues are sized by the pair pool (a step raises at most one event per pair): nothing
+    is dropped, the drained stream equals the oracle's"""
+    import oracle_ffi
+    sc = S.many_pyramids(rows=27, cols=27).enable_events(S.ACTIVE_EVENTS_COLLISION, 0.0)
+    oracle_ffi.set_threads(16)
+    try:
+        g, o = PhysicsWorld.from_scene(sc), OracleWorld(sc)
+        g.step(3); o.step(3)
+        ge, oe = g.collision_events(), o.collision_events()
+    finally:
+        oracle_ffi.set_threads(1)
+    assert len(oe) > 65536 and len(ge) == len(oe), (len(ge), len(oe))
+    key = lambda e: np.lexsort((e[:, 2], e[:, 1], e[:, 0], e[:, 4]))
+    np.testing.assert_array_equal(ge[key(ge)], oe[key(oe)])
+
+
 def test_contact_force_events_ride_the_fast_graph():
     """Worlds with ActiveEvents::CONTACT_FORCE_EVENTS take the two-kernel fast graph + k_force_events once they have settled; a kick
     in the middle aborts fast steps on the device (replayed on the full graph) without losing or duplicating a force event."""
