@@ -164,6 +164,7 @@ struct rp_world {
     float min_ccd_thickness = 3.402823466e+38f; // thinnest dynamic body (the fused single-kernel step needs it above the fat-AABB margin)
     bool compound = false;         // some dynamic body carries several colliders or an offset collider (no fused fast step)
     bool timed_ready[2] = {false, false};
+    int pairs_scale = 1;           // the pair pool holds RP_PAIRS_PER_COLLIDER x pairs_scale slots per collider row: doubled when the pool fills up (rp_step)
     int cur_fast = 0;              // mode the enqueue_* callbacks capture
     long long steps_requested = 0; // steps asked for since finalize (device FL_STEP counts the executed ones)
     long long seq_enqueued = 0;    // step graphs enqueued since finalize (device FL_SEQ counts the retired ones)
@@ -1131,11 +1132,11 @@ static int finalize(rp_world *w) {
     w->cap_bodies = capb; w->cap_colliders = capc;
     const char *env_pool = getenv("RP_PAIRS_PER_COLLIDER");
     int ppc = env_pool ? atoi(env_pool) : 8;
-    d.pool_cap = ppc * capc + 1024;
+    d.pool_cap = (int)std::min<long long>((long long)ppc * w->pairs_scale * capc + 1024, 1ll << 28);
     d.hash_cap = next_pow2(4LL * d.pool_cap);
     d.grid_cap = std::min(next_pow2(8LL * std::max(capc, 1)), 1 << 20);
     d.grid_cap = std::max(d.grid_cap, 1024);
-    d.large_cap = std::min(std::max(capc, 1), 4096);
+    d.large_cap = std::max(capc, 1); // (the brute-force list can hold every collider: a world of wildly mixed sizes gets slow, it does not fail)
     d.cons_cap = d.pool_cap;
     // grid cell size: 90th percentile of the collider bounding extents (+ fat margins)
     float pred = w->params.normalized_prediction_distance * w->params.length_unit;
@@ -1550,12 +1551,24 @@ static int step_once(rp_world *w, bool allow_fast) {
         // First step after (re)building the world: run collision detection eagerly and read the
         // colour layout once so the solver launch plan is right from the start.
         w->cur_fast = 0; w->cur_lean = 0;
-        enqueue_collision(w);
         int fl[FL_COUNT];
-        HIPCHK(w, hipMemcpyAsync(fl, w->dw.flags, sizeof(fl), hipMemcpyDeviceToHost, w->stream));
-        HIPCHK(w, hipStreamSynchronize(w->stream));
-        int r = check_overflow(w, fl);
-        if (r != RP_OK) return r;
+        for (int attempt = 0; ; ++attempt) {
+            enqueue_collision(w);
+            HIPCHK(w, hipMemcpyAsync(fl, w->dw.flags, sizeof(fl), hipMemcpyDeviceToHost, w->stream));
+            HIPCHK(w, hipStreamSynchronize(w->stream));
+            int r = check_overflow(w, fl);
+            if (r == RP_ERR_CAPACITY && fl[FL_OVERFLOW] == RP_OVF_POOL && w->seq_enqueued == 0 && attempt < 10) {
+                // the very first broad-phase pass of a freshly built world found more pairs than the pool holds (a dense pile: the pool
+                // starts at RP_PAIRS_PER_COLLIDER = 8 slots per collider row).  No step has run: build the device world again with twice
+                // the slots.  (A pool that fills up LATER grows ahead of time: rp_step.)
+                w->pairs_scale *= 2; w->err.clear();
+                free_device(w);
+                r = finalize(w); if (r != RP_OK) return r;
+                continue;
+            }
+            if (r != RP_OK) return r;
+            break;
+        }
         plan_from_hints(w, fl);
         memcpy(w->pinned_flags, fl, sizeof(fl));
         enqueue_solver(w); enqueue_finish(w);
@@ -1678,6 +1691,20 @@ extern "C" int32_t rp_step(rp_world *w, uint32_t nsteps) {
     HIPCHK(w, hipSetDevice(w->device));
     if (!w->finalized) { int r = finalize(w); if (r != RP_OK) return r; }
     for (uint32_t i = 0; i < nsteps; ++i) {
+        // the pair pool grows before it overflows: the hint buffer says how many slots the last retired step had in use; above 70 % the
+        // world moves to arrays with twice the slots per collider (grow_begin / carry_over: every pair keeps its manifold, impulses and
+        // colour — the state an insertion beyond the row capacity leaves behind).  Looked at every 16 steps: a pile has to gain 30 % more
+        // pairs within that many steps to still overflow (RP_ERR_CAPACITY, as before).
+        if ((i & 15) == 0 && w->hints_valid && !w->timers) {
+            const volatile int *pf = w->pinned_flags;
+            const int free_top = pf[FL_FREE_TOP];
+            const long long live = (long long)pf[FL_POOL_TOP] - (free_top > 0 ? free_top : 0);
+            if (live * 10 > (long long)w->dw.pool_cap * 7 && w->dw.pool_cap < (1 << 28)) {
+                w->pairs_scale *= 2;
+                int r = grow_begin(w); if (r != RP_OK) return r;
+                r = finalize(w); if (r != RP_OK) return r;
+            }
+        }
         w->steps_requested++;
         int r = step_once(w, true);
         if (r != RP_OK) return r;

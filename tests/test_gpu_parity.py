@@ -1039,6 +1039,22 @@ def test_collision_and_contact_force_events_bit_exact():
     assert g3.counters()["fast_steps"] > 0
 
 
+def test_pair_pool_grows_before_it_overflows(monkeypatch):
+    """1,300 tumbling bodies with ONE pair slot per collider row to start with (RP_PAIRS_PER_COLLIDER=1: 2,905 slots): the pile needs
+    several times that.  rp_step watches the pool through the hint buffer and moves the world to arrays with twice the slots whenever
+    70 % are in use — every pair keeps its manifold, impulses and colour (the growth carry-over) — so nothing overflows and nothing
+    differs from the oracle"""
+    monkeypatch.setenv("RP_PAIRS_PER_COLLIDER", "1")
+    sc = S.tumble(1300, seed=4)
+    g, o = PhysicsWorld.from_scene(sc), OracleWorld(sc)
+    for n in (1, 10, 10, 10, 10, 10, 10, 10, 10, 10, 10, 30, 60, 100):   # (rp_step per frame, like a game loop)
+        g.step(n); o.step(n)
+        _same_state(g, o, f"tumble with a growing pair pool, +{n}")
+    c = g.counters()
+    assert c["overflow_flags"] == 0 and c["num_pairs"] > 2905, c
+    assert c["num_pairs"] == o.stats()["num_pairs"]
+
+
 def test_event_queues_hold_every_pair_of_a_large_world():
     """27 x 27 pyramids with collision events on every collider: ~106,000 pairs begin to touch within the first steps — more events than
     the 65,536 slots the queues used to have.  The queues are sized by the pair pool (a step raises at most one event per pair): nothing
