@@ -99,9 +99,12 @@ __global__ void k_integrate(DevWorld w) {
 // (WS_TERMS, ws_put / ws_get, body_increment_ws: rp_global.h — shared with the tile sweeps of rp_tiles.hip)
 // joint_substep >= 0: the launch also rebuilds the rows of every impulse joint from the current poses (k_joint_update folded in: both
 // are the pose-dependent, fully parallel preparation of a substep; jointed worlds on tiles save a launch per substep)
+// (JOINTS = false: the contact half alone — the general joint update keeps its rows in scratch, 592 B per lane, and its registers would
+// set the occupancy of a launch that b3d_large_pyramid makes four times a step without a single joint)
+template <bool JOINTS>
 __global__ void __launch_bounds__(256) k_ws_prepare(DevWorld w, float solved_dt, int joint_substep) {
     if (lean_dead(w)) return;
-    if (joint_substep >= 0) {
+    if (JOINTS && joint_substep >= 0) {
         const int jstride = gridDim.x * blockDim.x;
         for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < w.n_joints; j += jstride) if (joint_live(w, j)) joint_update_one(w, j, joint_substep);
     }
@@ -306,7 +309,8 @@ int rp_launch_solver_loop(const DevWorld &w0, hipStream_t st, int parallel_stage
     for (int s = 0; s < w.prm.num_substeps; ++s) {
         float solved_dt = (float)s * w.prm.dt_sub;
         if (!host_coulomb(w) && w.ws_terms) { // body-centric warm start: two launches instead of one per colour
-            hipLaunchKernelGGL(k_ws_prepare, dim3(cons_blocks(w)), dim3(256), 0, st, w, solved_dt, (tiles && w.n_joints > 0 && !jinline) ? s : -1);
+            if (tiles && w.n_joints > 0 && !jinline) hipLaunchKernelGGL(k_ws_prepare<true>, dim3(cons_blocks(w)), dim3(256), 0, st, w, solved_dt, s);
+            else hipLaunchKernelGGL(k_ws_prepare<false>, dim3(cons_blocks(w)), dim3(256), 0, st, w, solved_dt, -1);
             if (!fuse_inc) hipLaunchKernelGGL(k_increment_ws, dim3(nb), dim3(256), 0, st, w);
             if (!tiles) rp_launch_joint_update(w, st, s);
         } else {
