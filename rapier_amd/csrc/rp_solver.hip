@@ -113,13 +113,19 @@ __global__ void __launch_bounds__(256) k_ws_prepare(DevWorld w, float solved_dt,
     const int stride = gridDim.x * blockDim.x;
     for (int pos = blockIdx.x * blockDim.x + threadIdx.x; pos < M; pos += stride) ws_prepare_one(w, GlobalAcc(w, pos), pos, solved_dt);
 }
+// The linear and the angular half of a body are independent chains (increment + five terms per toucher / gyroscopic increment + six
+// terms per toucher): the first half of the grid does the one, the second half the other — twice the wavefronts, about half the
+// dependent loads per lane (each half computes body_increment_ws and keeps one result: the other chain, its loads included, is dead
+// code the compiler removes).  The island kernel splits its bodies the same way (role_lin / role_ang).
 __global__ void __launch_bounds__(256) k_increment_ws(DevWorld w) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half_blocks = gridDim.x >> 1;
+    const bool angular = (int)blockIdx.x >= half_blocks;
+    const int i = ((int)blockIdx.x - (angular ? half_blocks : 0)) * blockDim.x + threadIdx.x;
     if (lean_dead(w)) return;
     if (i >= w.n_bodies || !global_body(w, i)) return;
     V3 lin, ang;
-    body_increment_ws(w, i, lin, ang);
-    w.s_lin[i] = f4(lin, 0.0f); w.s_ang[i] = f4(ang, 0.0f);
+    if (angular) { body_increment_ws(w, i, lin, ang); w.s_ang[i] = f4(ang, 0.0f); }
+    else { body_increment_ws(w, i, lin, ang); w.s_lin[i] = f4(lin, 0.0f); }
 }
 
 // One parallel colour stage: the reference's claim/steal chunk loop becomes a grid-stride loop.
@@ -311,7 +317,7 @@ int rp_launch_solver_loop(const DevWorld &w0, hipStream_t st, int parallel_stage
         if (!host_coulomb(w) && w.ws_terms) { // body-centric warm start: two launches instead of one per colour
             if (tiles && w.n_joints > 0 && !jinline) hipLaunchKernelGGL(k_ws_prepare<true>, dim3(cons_blocks(w)), dim3(256), 0, st, w, solved_dt, s);
             else hipLaunchKernelGGL(k_ws_prepare<false>, dim3(cons_blocks(w)), dim3(256), 0, st, w, solved_dt, -1);
-            if (!fuse_inc) hipLaunchKernelGGL(k_increment_ws, dim3(nb), dim3(256), 0, st, w);
+            if (!fuse_inc) hipLaunchKernelGGL(k_increment_ws, dim3(2 * nb), dim3(256), 0, st, w); // (linear halves, then angular halves)
             if (!tiles) rp_launch_joint_update(w, st, s);
         } else {
             hipLaunchKernelGGL(k_increment, dim3(nb), dim3(256), 0, st, w);
