@@ -164,6 +164,7 @@ struct rp_world {
     float min_ccd_thickness = 3.402823466e+38f; // thinnest dynamic body (the fused single-kernel step needs it above the fat-AABB margin)
     bool compound = false;         // some dynamic body carries several colliders or an offset collider (no fused fast step)
     bool timed_ready[2] = {false, false};
+    bool never_stepped = true;     // no step has retired and the device world was never rebuilt / grown: what the host mirrors hold is the whole state
     int pairs_scale = 1;           // the pair pool holds RP_PAIRS_PER_COLLIDER x pairs_scale slots per collider row: doubled when the pool fills up (rp_step)
     int cur_fast = 0;              // mode the enqueue_* callbacks capture
     long long steps_requested = 0; // steps asked for since finalize (device FL_STEP counts the executed ones)
@@ -1557,7 +1558,7 @@ static int step_once(rp_world *w, bool allow_fast) {
             HIPCHK(w, hipMemcpyAsync(fl, w->dw.flags, sizeof(fl), hipMemcpyDeviceToHost, w->stream));
             HIPCHK(w, hipStreamSynchronize(w->stream));
             int r = check_overflow(w, fl);
-            if (r == RP_ERR_CAPACITY && fl[FL_OVERFLOW] == RP_OVF_POOL && w->seq_enqueued == 0 && attempt < 10) {
+            if (r == RP_ERR_CAPACITY && fl[FL_OVERFLOW] == RP_OVF_POOL && w->never_stepped && w->seq_enqueued == 0 && attempt < 10) {
                 // the very first broad-phase pass of a freshly built world found more pairs than the pool holds (a dense pile: the pool
                 // starts at RP_PAIRS_PER_COLLIDER = 8 slots per collider row).  No step has run: build the device world again with twice
                 // the slots.  (A pool that fills up LATER grows ahead of time: rp_step.)
@@ -1573,6 +1574,7 @@ static int step_once(rp_world *w, bool allow_fast) {
         memcpy(w->pinned_flags, fl, sizeof(fl));
         enqueue_solver(w); enqueue_finish(w);
         w->seq_enqueued++; w->full_steps++;
+        w->never_stepped = false;
         w->hints_valid = true;
         w->full_until = w->steps_requested + 2;
         HIPCHK(w, hipGetLastError());
