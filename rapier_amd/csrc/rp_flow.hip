@@ -267,7 +267,7 @@ RP_DEV void flow_rank(DevWorld &w, int gid, int stride) {
 // the four passes as ONE launch behind grid barriers (rp_gridbar.h): a step whose layout did not change pays a single early exit
 __global__ void __launch_bounds__(1024) k_flow_ranks(DevWorld w) {
     if (blockIdx.x == 0 && threadIdx.x == 0) w.flags[FL_ANY_BOUNCY] = 0; // (the first launch of every solver assembly: k_begin_generate / k_flow_begin raise it)
-    if (!w.flags[FL_FLOW_DIRTY]) return; // (cleared by the kernel that starts the solve: k_flow_begin / k_solver_begin)
+    if (!w.flags[FL_FLOW_DIRTY]) return; // (cleared by the kernel that starts the solve: k_flow_begin / k_begin_generate)
     const int gid = gbar_item(), gstride = gridDim.x * blockDim.x;
     GridBar bar = gbar_begin(w, 3);
     flow_count(w, gid, gstride);
@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(1024) k_flow_ranks(DevWorld w) {
 
 // ---- the step ---------------------------------------------------------------------------------------
 RP_DEV unsigned flow_epoch(const DevWorld &w) { return (((unsigned)w.flags[FL_SEQ] % 1023u) + 1u) << FLOW_TICKET_BITS; }
-// S0 for every body of the global path (k_solver_begin's twin): records start at ticket 0 of this step's epoch
+// S0 for every body of the global path (the body half of k_begin_generate): records start at ticket 0 of this step's epoch
 __global__ void k_flow_begin(DevWorld w) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) { w.flags[FL_FLOW_DIRTY] = 0; w.flags[FL_FLOW_ABORT] = 0; w.flags[FL_ANY_BOUNCY] = 0; }

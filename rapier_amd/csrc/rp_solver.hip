@@ -24,15 +24,9 @@
 #include <algorithm>
 
 // ---- MULTI mode kernels ---------------------------------------------------------------------------
-__global__ void k_solver_begin(DevWorld w) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) { w.flags[FL_ANY_BOUNCY] = 0; w.flags[FL_FLOW_DIRTY] = 0; } // (the toucher ranks were rebuilt by the launches before this one)
-    if (i >= w.n_bodies || !global_body(w, i)) return;
-    g_body_begin(w, i);
-}
-// generate straight from the body arrays: the solver bodies k_solver_begin derives (lin / ang = the body velocities, solver pose =
-// (rotation, world centre of mass): the very expressions of body_begin) are recomputed per manifold side, so S0 and S1 need no kernel
-// boundary between them — one launch (k_begin_generate) instead of two
+// S0 + S1 in one launch: generate reads the solver bodies straight from the body arrays (lin / ang = the body velocities, solver pose =
+// (rotation, world centre of mass): the very expressions of g_body_begin, recomputed per manifold side), so the two need no kernel
+// boundary between them
 template <bool PRE>
 struct GenAccT : GlobalAccT<PRE> {
     RP_DEV GenAccT(const DevWorld &w_, int pos_) : GlobalAccT<PRE>(w_, pos_) {}
@@ -65,14 +59,6 @@ __global__ void __launch_bounds__(256) k_begin_generate(DevWorld w) { // (FL_ANY
         const bool bouncy = COUL ? coul_generate(w, GenAccT<true>(w, pos), s, id1, id2, id1, id2) : cons_generate(w, GenAccT<true>(w, pos), s, id1, id2, id1, id2);
         if (bouncy) w.flags[FL_ANY_BOUNCY] = 1;
     }
-}
-template <bool COUL>
-__global__ void __launch_bounds__(256) k_generate(DevWorld w) { // (256 threads: the whole register file, no spills)
-    int M = w.flags[FL_N_CONS];
-    if (M > w.cons_cap) M = w.cons_cap;
-    int stride = gridDim.x * blockDim.x;
-    for (int pos = blockIdx.x * blockDim.x + threadIdx.x; pos < M; pos += stride)
-        if (g_generate<COUL, true>(w, pos)) w.flags[FL_ANY_BOUNCY] = 1;
 }
 __global__ void k_increment(DevWorld w) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;

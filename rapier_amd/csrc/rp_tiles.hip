@@ -49,7 +49,7 @@ RP_DEV unsigned tile_hash(int g) { return ((unsigned)g * 2654435761u) >> 21; } /
 //     Positions inside a stage never matter for the result (a colour is body-disjoint), and any injective order is valid: bodies
 //     inserted after a sort keep b_order[i] = i, which lies above every rank handed out before.
 __global__ void __launch_bounds__(1024) k_tiles_sort(DevWorld w) {
-    if (!w.flags[FL_FLOW_DIRTY]) return; // (cleared by k_solver_begin, which runs after this kernel)
+    if (!w.flags[FL_FLOW_DIRTY]) return; // (cleared by k_begin_generate, which runs after this kernel)
     const int gid = gbar_item(), gstride = gridDim.x * blockDim.x, t = threadIdx.x;
     int M = w.flags[FL_N_CONS]; if (M > w.cons_cap) M = w.cons_cap;
     const int nst = w.flags[FL_N_STAGES], nb = w.n_bodies;
