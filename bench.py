@@ -184,6 +184,7 @@ def run(args, make_world=None, backend: str = "nccl", use_cuda: bool = True):
         if use_cuda:
             torch.cuda.synchronize()
 
+    w.step(0)   # builds the device world (allocation, uploads) — construction, not stepping: it must not land in the timed region when --warmup is 0
     w.step(args.warmup)
     w.sync()
     barrier()
