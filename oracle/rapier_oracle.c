@@ -1350,7 +1350,7 @@ static void narrow_phase_compute_contacts(ro_world *w) {
         uint32_t b = tr[i].body2 >= 0 ? (uint32_t)tr[i].body2 : RO_NO_BODY;
         uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
         todo[ntodo].key = ((uint64_t)lo << 32) | hi; todo[ntodo].pair = tr[i].pair;
-        { uint32_t o1 = (uint32_t)w->colliders[p->c1].ord, o2 = (uint32_t)w->colliders[p->c2].ord; todo[ntodo].tie = a < b ? (o1 << 12) | o2 : (o2 << 12) | o1; }
+        { uint32_t o1 = (uint32_t)w->colliders[p->c1].ord, o2 = (uint32_t)w->colliders[p->c2].ord; todo[ntodo].tie = a < b ? (o1 << 20) | o2 : (o2 << 20) | o1; } /* (lower body id: < 4,096 colliders; the higher one may be "no body": up to 2^20 parentless colliders) */
         todo[ntodo].b1 = tr[i].body1; todo[ntodo].b2 = tr[i].body2; ntodo++;
     }
     /* apply_deferred_solver_coloring — contacts.rs:369-385 */

@@ -100,6 +100,7 @@ struct HostBody {
     float max_extent = 0.0f, sleep_timer = 0.0f, sprev[7] = {0, 0, 0, 0, 0, 0, 1};
     float ccd_thickness = 3.402823466e+38f; // RigidBodyCcd::ccd_thickness: the thinnest attached shape (Real::MAX without colliders)
     int sleeping = 0, slabel = 0, next_ord = 0;
+    std::vector<int> cols;            // its colliders (removed ones included) in attachment order = ascending collider index
     int isl = -1;                     // RigidBodyIds::island_id (persistent islands, rp_sleep.hip), mirrored across device rebuilds
     bool has_next = false; float next[7] = {0, 0, 0, 0, 0, 0, 1}; // RigidBodyPosition::next_position of a kinematic body
     bool quarantined = false;         // disabled by the quarantine (quarantine.rs): inert like a removed body, handle still readable
@@ -170,6 +171,8 @@ struct rp_world {
     long long steps_requested = 0; // steps asked for since finalize (device FL_STEP counts the executed ones)
     long long seq_enqueued = 0;    // step graphs enqueued since finalize (device FL_SEQ counts the retired ones)
     long long full_until = 0;      // stay on the full graph until this many steps were requested
+    long long eager_until = 0;     // launch the kernels directly until this many steps were requested: a world that is being edited (bodies /
+                                   // colliders / joints coming and going every few steps) would re-capture its graphs — ~10 ms — after every edit
     long long fast_steps = 0, full_steps = 0, replayed_steps = 0;
     // timers
     bool timers = false;
@@ -194,7 +197,7 @@ static int settle(rp_world *w);
 static int upload_body_row(rp_world *w, int i);
 static int upload_body_row_mass(rp_world *w, int i);
 static int upload_collider_row(rp_world *w, int i);
-static int after_topology_edit(rp_world *w);
+static int after_topology_edit(rp_world *w, bool keep_grid = false);
 static bool world_sleep_enabled(const rp_world *w);
 static bool world_has_kinematic_pos(const rp_world *w);
 static bool world_has_force_events(const rp_world *w);
@@ -607,8 +610,8 @@ static void hmp_mp_add(hmp_mp *acc, const hmp_mp *o) {
 // sum of the attached colliders' mass properties at `density_override` (< 0: each collider's own density)
 static void sum_collider_mass_props(const rp_world *w, int body, float density_override, hmp_mp *acc) {
     memset(acc, 0, sizeof(*acc)); acc->frame[3] = 1.0f;
-    for (size_t i = 0; i < w->colliders.size(); ++i) {
-        if (w->collider_parent[i] != body || w->collider_removed[i]) continue;
+    for (int i : w->bodies[body].cols) { // (not a walk over every collider of the world: a million in b3d_large_world, per inserted body)
+        if (w->collider_removed[i]) continue;
         const rp_collider_desc &c = w->colliders[i];
         hmp_mp m; memset(&m, 0, sizeof(m)); m.frame[3] = 1.0f;
         shape_mass_props(c, density_override < 0.0f ? c.density : density_override, m.mass, m.pi, m.frame);
@@ -644,8 +647,8 @@ static void recompute_mass(rp_world *w, int body) {
     for (int q = 0; q < 4; ++q) b.pframe[q] = acc.frame[q];
     // recompute_max_extent (rigid_body_components.rs:491-515): bounding spheres of the attached shapes about the local CoM
     b.max_extent = 0.0f;
-    for (size_t i = 0; i < w->colliders.size(); ++i) {
-        if (w->collider_parent[i] != body || w->collider_removed[i]) continue;
+    for (int i : b.cols) {
+        if (w->collider_removed[i]) continue;
         const rp_collider_desc &c = w->colliders[i];
         float radius = shape_bounding_radius(c);
         float dx = c.translation[0] - b.lcom[0], dy = c.translation[1] - b.lcom[1], dz = c.translation[2] - b.lcom[2];
@@ -655,8 +658,8 @@ static void recompute_mass(rp_world *w, int body) {
     // RigidBodyCcd::ccd_thickness (rigid_body_components.rs:1227): min over the attached shapes of Shape::ccd_thickness
     // (ball: radius, cuboid: smallest half extent, capsule: radius)
     b.ccd_thickness = 3.402823466e+38f;
-    for (size_t i = 0; i < w->colliders.size(); ++i) {
-        if (w->collider_parent[i] != body || w->collider_removed[i]) continue;
+    for (int i : b.cols) {
+        if (w->collider_removed[i]) continue;
         const rp_collider_desc &c = w->colliders[i];
         if (c.shape == RP_SHAPE_HALFSPACE) continue; // Shape::ccd_thickness of a half-space is f32::MAX
         float th = c.shape == RP_SHAPE_BALL ? c.half_extents[0] : c.shape == RP_SHAPE_CAPSULE ? c.half_extents[1] : std::min(c.half_extents[0], std::min(c.half_extents[1], c.half_extents[2]));
@@ -793,7 +796,7 @@ extern "C" int32_t rp_bodies_insert(rp_world *w, int32_t n, const rp_body_desc *
         HIPCHK(w, hipStreamSynchronize(w->stream));
         { int r = upload_group_table(w); if (r != RP_OK) return r; }
         destroy_graphs(w); // kernel arguments (DevWorld by value) hold the body count
-        return after_topology_edit(w);
+        return after_topology_edit(w, true);
     }
     if (w->carry) return finalize(w); // the larger device world takes over the rows of the one it replaces
     return RP_OK;
@@ -826,10 +829,11 @@ extern "C" int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider
             if (parent < 0 || parent >= (int)w->bodies.size() || w->bodies[parent].removed || w->bodies[parent].quarantined) { w->err = "rp_colliders_insert: invalid parent handle (unknown, removed or quarantined body)"; return RP_ERR_INVALID; }
         }
         int &ord_counter = parent >= 0 ? w->bodies[parent].next_ord : w->next_free_ord;
-        if (ord_counter >= 4096) { w->err = "rp_colliders_insert: more than 4096 colliders on one body (or without a parent)"; return RP_ERR_CAPACITY; }
+        if (ord_counter >= (parent >= 0 ? 4096 : (1 << 20))) { w->err = "rp_colliders_insert: more than 4,096 colliders on one body (or 2^20 without a parent)"; return RP_ERR_CAPACITY; }
         w->collider_ord.push_back(ord_counter++);
         w->colliders.push_back(descs[i]);
         w->collider_parent.push_back(parent);
+        if (parent >= 0) w->bodies[parent].cols.push_back((int)w->collider_parent.size() - 1);
         w->collider_removed.push_back(0);
         if (parent >= 0) { w->bodies[parent].ncolliders++; recompute_mass(w, parent); }
         if (descs[i].restitution > 0.0f) w->has_restitution = true;
@@ -844,12 +848,23 @@ extern "C" int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider
     }
     if (in_place && n > 0) {
         w->dw.n_colliders = (int)w->colliders.size();
-        w->dw.has_force_events = world_has_force_events(w) ? 1 : 0;
-        w->dw.has_sensors = world_has_sensors(w) ? 1 : 0;
-        w->compound = world_has_compound_bodies(w); refresh_ccd_facts(w);
+        // the world-wide facts can only be switched ON by an insertion: looked up on the new rows alone (the full scans of
+        // world_has_* walk every collider — a million in b3d_large_world, per dropped sphere)
+        for (size_t ci = w->colliders.size() - (size_t)n; ci < w->colliders.size(); ++ci) {
+            const rp_collider_desc &c = w->colliders[ci];
+            const int p = w->collider_parent[ci];
+            if (c.active_events & RP_EVENTS_CONTACT_FORCE) w->dw.has_force_events = 1;
+            if (c.sensor) w->dw.has_sensors = 1;
+            if (p >= 0 && w->bodies[p].d.body_type == RP_BODY_DYNAMIC) {
+                const float *t = c.translation, *r = c.rotation;
+                const bool at_origin = t[0] == 0.0f && t[1] == 0.0f && t[2] == 0.0f && r[0] == 0.0f && r[1] == 0.0f && r[2] == 0.0f;
+                if (!at_origin || w->bodies[p].ncolliders > 1) w->compound = true; // (world_has_compound_bodies)
+            }
+        }
+        refresh_ccd_facts(w);
         HIPCHK(w, hipStreamSynchronize(w->stream));
         destroy_graphs(w);
-        return after_topology_edit(w);
+        return after_topology_edit(w, true);
     }
     if (w->carry) return finalize(w);
     return RP_OK;
@@ -1135,7 +1150,7 @@ static int finalize(rp_world *w) {
     int ppc = env_pool ? atoi(env_pool) : 8;
     d.pool_cap = (int)std::min<long long>((long long)ppc * w->pairs_scale * capc + 1024, 1ll << 28);
     d.hash_cap = next_pow2(4LL * d.pool_cap);
-    d.grid_cap = std::min(next_pow2(8LL * std::max(capc, 1)), 1 << 20);
+    d.grid_cap = std::min(next_pow2(8LL * std::max(capc, 1)), 1 << 23); // (a million colliders fill a million cells: with fewer buckets than cells the 32-slot buckets of colliding cells overflow)
     d.grid_cap = std::max(d.grid_cap, 1024);
     d.large_cap = std::max(capc, 1); // (the brute-force list can hold every collider: a world of wildly mixed sizes gets slow, it does not fail)
     d.cons_cap = d.pool_cap;
@@ -1534,7 +1549,7 @@ static int launch_step(rp_world *w, int fast) {
     }
     // a fused fast step is ONE kernel: launched directly (a one-node graph replay costs more than the launch)
     static const bool fused_eager = getenv("RP_FUSED_GRAPH") == nullptr;
-    if (!w->use_graph || (fast == 1 && w->plan_fused && fused_eager)) { enqueue_whole(w); HIPCHK(w, hipGetLastError()); return RP_OK; }
+    if (!w->use_graph || w->steps_requested <= w->eager_until || (fast == 1 && w->plan_fused && fused_eager)) { enqueue_whole(w); HIPCHK(w, hipGetLastError()); return RP_OK; }
     static const bool dbg = getenv("RP_DEBUG") != nullptr;
     if (!w->ge_whole[fast]) {
         if (dbg) fprintf(stderr, "RPDBG capture fast=%d seq=%lld stages=%d blocks=%d single=%d grid=%d jst=%d\n", fast, w->seq_enqueued, w->plan_stages, w->plan_blocks, w->plan_single, w->plan_island_grid, w->plan_joint_stages);
@@ -2096,13 +2111,18 @@ template <typename T> static int poke(rp_world *w, T *dst, const T &v) {
     return RP_OK;
 }
 static int set_flag(rp_world *w, int slot, int v) { return poke(w, w->dw.flags + slot, v); }
-static int after_topology_edit(rp_world *w) {
+// keep_grid: the edit only ADDED rows (bodies, colliders): the broad-phase grid still describes every collider it was built from, and a
+// new collider — its fat AABB starts inverted, so the next k_collider_update rewrites it and queues it like a collider that moved — finds
+// its partners in an incremental pass.  (b3d_large_world drops a sphere every five steps onto a million static boxes: a full rebuild
+// per drop was 25 ms.)
+static int after_topology_edit(rp_world *w, bool keep_grid) {
     if (!w->finalized) return RP_OK;
     int r;
-    if ((r = set_flag(w, FL_BP_GRID_OK, 0)) != RP_OK) return r; // colliders came, went or changed their filters: the next broad-phase pass is a full rebuild
+    if (!keep_grid && (r = set_flag(w, FL_BP_GRID_OK, 0)) != RP_OK) return r; // colliders went or changed their filters: the next broad-phase pass is a full rebuild
     if ((r = set_flag(w, FL_BP_DIRTY, 1)) != RP_OK || (r = set_flag(w, FL_LAYOUT_DIRTY, 1)) != RP_OK || (r = set_flag(w, FL_JOINT_DIRTY, 1)) != RP_OK || (r = set_flag(w, FL_FLOW_DIRTY, 1)) != RP_OK) return r;
     w->pinned_flags[FL_LAYOUT_DIRTY] = 1; // keeps the next steps on the full graph until the device reports a clean state
     w->full_until = w->steps_requested + 3;
+    w->eager_until = w->steps_requested + 8; // (graphs are captured again once eight steps went by without another edit)
     rp_launch_init_bodies(w->dw, w->stream);
     HIPCHK(w, hipStreamSynchronize(w->stream));
     return RP_OK;

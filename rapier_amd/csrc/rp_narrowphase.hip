@@ -800,10 +800,14 @@ __device__ __forceinline__ void pair_full_update(DevWorld &w, int s, int c1, int
             // same two bodies) by the colliders' attachment ordinals — the reference uses its edge creation order there
             unsigned a = rb1 >= 0 ? (unsigned)rb1 : 0xfffffu, b = rb2 >= 0 ? (unsigned)rb2 : 0xfffffu;
             unsigned lo = a < b ? a : b, hi = a < b ? b : a;
-            unsigned o1 = (unsigned)w.c_ord[c1] & 0xfffu, o2 = (unsigned)w.c_ord[c2] & 0xfffu;
-            unsigned tie = a < b ? (o1 << 12) | o2 : (o2 << 12) | o1;
+            // (the tie: ordinal on the lower body id — a real body: < 4,096 colliders — then the ordinal on the higher one, which may be
+            // "no body": parentless colliders count up to 2^20, b3d_large_world has a million.  Kept beside the key, in todo_tmp — scratch
+            // of k_layout_rebuild, which runs after the colouring)
+            const unsigned o1 = (unsigned)w.c_ord[c1], o2 = (unsigned)w.c_ord[c2];
+            const unsigned tie = a < b ? (o1 << 20) | o2 : (o2 << 20) | o1;
             w.todo_slot[t] = s;
-            w.todo_key[t] = ((unsigned long long)lo << 44) | ((unsigned long long)hi << 24) | (unsigned long long)tie;
+            w.todo_key[t] = ((unsigned long long)lo << 44) | ((unsigned long long)hi << 24);
+            w.todo_tmp[t] = (int)tie;
         }
     }
 }
@@ -964,12 +968,13 @@ __global__ void __launch_bounds__(1024) k_color_pairs(DevWorld w) {
     for (int t = tid; t < T; t += nt) {
         int4 r = w.col_rec[t];
         const unsigned long long key = w.todo_key[t];
+        const unsigned tie = (unsigned)w.todo_tmp[t];
         int2 rk = make_int2(-1, -1);
         for (int side = 0; side < 2; ++side) {
             int b = side ? r.y : r.x;
             if (b < 0) continue;
             int beg = ld_i32a(&w.col_begin[b]), n = ld_i32a(&w.col_cnt[b]), q = 0;
-            for (int k = 0; k < n; ++k) q += w.todo_key[ld_i32a(&w.col_list[beg + k])] < key;
+            for (int k = 0; k < n; ++k) { const int u = ld_i32a(&w.col_list[beg + k]); const unsigned long long ku = w.todo_key[u]; q += ku < key || (ku == key && (unsigned)w.todo_tmp[u] < tie); }
             w.col_sorted[beg + q] = t;
             if (side) rk.y = q; else rk.x = q;
         }

@@ -232,6 +232,41 @@ def _small_pyramid(scene: Scene, base_count: int, extent, center_x, base_z):
             scene.add_collider(b, half_extents=(extent, extent, extent), density=100.0)
 
 
+def large_world(grid: int = 1000, cell: float = 10.0) -> Scene:
+    """b3d_large_world.rs:20-41 — box3d's `large_world` benchmark: a grid x grid floor of PARENTLESS fixed cuboids (half extents
+    (cell / 2, 0.25, cell / 2); one million at the release settings) under gravity (0, -10, 0); the dynamic spheres are dropped while
+    the world runs (`large_world_drop`).  The descriptors are built as one array: a million Scene.add_collider calls take longer
+    than the benchmark."""
+    s = Scene(name=f"b3d_large_world_{grid}", gravity=(0.0, -10.0, 0.0))
+    half_span = _f(0.5) * _f(cell) * _f(grid)
+    k = np.arange(grid, dtype=np.float32)
+    xs = (-half_span + (k + _f(0.5)) * _f(cell)).astype(np.float32)      # x = -half_span + (i + 0.5) * cell, f32 like the reference
+    cols = np.zeros(grid * grid, dtype=COLLIDER_DTYPE)
+    cols[:] = collider_desc(half_extents=(0.5 * cell, 0.25, 0.5 * cell))
+    t = np.zeros((grid * grid, 3), np.float32)
+    t[:, 0] = np.repeat(xs, grid)                                       # i outer, j inner: the reference's insertion order
+    t[:, 2] = np.tile(xs, grid)
+    cols["translation"] = t
+    s.colliders = list(cols)
+    s.collider_parents = [-1] * (grid * grid)
+    return s
+
+
+def large_world_drop(idx: int, grid: int = 1000, cell: float = 10.0, spheres: int = 100):
+    """translation of the idx-th dropped sphere (b3d_large_world.rs:46-66: a coarse side x side grid over the inner 80 % of the floor,
+    y = 1.5; one sphere of radius 0.5 every 5 steps)"""
+    side = 1
+    while side * side < spheres:
+        side += 1
+    half_span = _f(0.5) * _f(cell) * _f(grid)
+    gi, gj = idx % side, idx // side
+    inset = _f(0.1) * _f(2.0) * half_span
+    usable = _f(2.0) * half_span - _f(2.0) * inset
+    x = -half_span + inset + (_f(gi) + _f(0.5)) * (usable / _f(side))
+    z = -half_span + inset + (_f(gj) + _f(0.5)) * (usable / _f(side))
+    return (float(x), 1.5, float(z))
+
+
 def many_pyramids(rows: int = 14, cols: int = 14, base_count: int = 10, col_range=None, pyramids=None) -> Scene:
     """b3d_many_pyramids.rs:36-64.  ``col_range=(lo, hi)`` keeps only pyramid columns lo..hi-1, ``pyramids`` (a boolean mask over
     the row-major pyramid index r * cols + c) only the selected islands: the multi-GPU island shards (the ground is replicated)."""

@@ -396,3 +396,24 @@ def test_integration_parameters_may_change_between_steps(gpu, scene):
                 gp, gv = g.read_bodies()
                 np.testing.assert_array_equal(gp, op, err_msg=f"change {k} {ch}: poses after {n}")
                 np.testing.assert_array_equal(gv, ov, err_msg=f"change {k} {ch}: velocities after {n}")
+
+
+@pytest.mark.parametrize("gpu", GPU)
+def test_b3d_large_world_at_reduced_size(gpu):
+    """examples3d/b3d_large_world.rs (box3d's `large_world` benchmark) with a 40 x 40 floor instead of 1000 x 1000 (the oracle's
+    sort-and-sweep broad phase takes seconds per pass over a million boxes): parentless fixed cuboids, a sphere dropped every 5 steps
+    into the running world; every sphere comes to rest on the floor (y = 0.25 + 0.5) and falls asleep; oracle = device bit for bit"""
+    grid, spheres = 40, 16
+    w = _Script(S.large_world(grid), gpu)
+    dropped, balls = 0, []
+    for step in range(260):
+        if dropped < spheres and step > 0 and step % 5 == 0:
+            b = w.add_body(translation=S.large_world_drop(dropped, grid, spheres=spheres), can_sleep=1)
+            w.add_collider(b, shape=S.SHAPE_BALL, half_extents=(0.5, 0, 0))
+            balls.append(b); dropped += 1
+        w.step(1)
+        if step % 20 == 0 or step == 259:
+            p, v = w.check(f"large_world step {step}")
+    assert dropped == spheres
+    np.testing.assert_allclose(p[balls, 1], 0.75, atol=0.01)
+    assert np.abs(v[balls]).max() < 1e-3
