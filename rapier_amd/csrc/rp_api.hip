@@ -1311,6 +1311,9 @@ static int finalize(rp_world *w) {
             DA(d.tl_soff, (size_t)d.tile_cap * (RP_TILE_STAGES + 1)); DA(d.tl_bodies, (size_t)d.tile_cap * RP_TILE_BCAP); DA(d.tl_cons, (size_t)d.tile_cap * RP_TILE_CCAP);
             const unsigned rest[16] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
             HIPCHK(w, hipMemcpy(d.tl_bbox, rest, sizeof(rest), hipMemcpyHostToDevice));
+            // test hook (RP_TILE_STALE_PLAN=1): the device never finds a tiling worth having while the host plans tile sweeps all the same —
+            // every sweep then takes the branch that normally only a stale hint reaches (k_tile_sweep with FL_N_TILES == 0)
+            if (getenv("RP_TILE_STALE_PLAN")) d.tile_min = 0x7fffffff;
         }
     }
 
@@ -1457,6 +1460,7 @@ static void plan_from_hints(rp_world *w, const int *fl) {
     w->plan_no_contacts = (fl[FL_N_CONS] == 0 && w->dw.tile_cap > 0) ? 1 : 0; // (tile sweeps: the increment folds into the sweep while no manifold exists)
     // (a valid tiling also replaces the dataflow launch of jointed worlds; forced flow — RP_FLOW=1 — keeps it)
     w->plan_tile_grid = (w->dw.tile_cap > 0 && !w->plan_single && !w->force_flow && fl[FL_N_TILES] > 0) ? ((fl[FL_N_TILES] + 15) / 16) * 16 : 0;
+    if (w->dw.tile_cap > 0 && w->dw.tile_min == 0x7fffffff && !w->plan_single && !w->force_flow) w->plan_tile_grid = 16; // (RP_TILE_STALE_PLAN: see finalize)
     if (w->plan_tile_grid > 0) { w->plan_stages = fl[FL_N_PARALLEL]; w->plan_joint_stages = fl[FL_NJ_STAGES]; w->plan_blocks = std::min(std::max(pow2_ceil((fl[FL_MAX_STAGE] + 255) / 256), 1), 4096); } // (the per-stage launches of the restitution sweep)
     // fused single-kernel fast step: every workgroup must be resident at once (in-launch arrival barrier)
     // (a grid of at most fused_grid workgroups; workgroups loop over islands beyond that)
