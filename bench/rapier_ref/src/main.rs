@@ -123,6 +123,34 @@ fn reference_pile() -> PhysicsWorld {
     world
 }
 
+/// examples3d/b3d_large_world.rs: `grid` x `grid` parentless fixed cuboids (half extents 5, 0.25, 5); the spheres are dropped by the
+/// timed loop (`large_world_drop`), one every five steps — tools/large_world.py runs the same script on the device
+fn large_world(grid: i32) -> PhysicsWorld {
+    let mut world = PhysicsWorld::new();
+    world.gravity = Vector::new(0.0, -10.0, 0.0);
+    let cell = 10.0f32;
+    let half_span = 0.5 * cell * grid as f32;
+    for i in 0..grid {
+        for j in 0..grid {
+            let at = Vector::new(-half_span + (i as f32 + 0.5) * cell, 0.0, -half_span + (j as f32 + 0.5) * cell);
+            world.insert_collider(ColliderBuilder::cuboid(0.5 * cell, 0.25, 0.5 * cell).translation(at), None);
+        }
+    }
+    world
+}
+fn large_world_drop(world: &mut PhysicsWorld, idx: i32, grid: i32, spheres: i32) {
+    let mut side = 1;
+    while side * side < spheres {
+        side += 1;
+    }
+    let half_span = 0.5 * 10.0 * grid as f32;
+    let inset = 0.1 * 2.0 * half_span;
+    let usable = 2.0 * half_span - 2.0 * inset;
+    let x = -half_span + inset + ((idx % side) as f32 + 0.5) * (usable / side as f32);
+    let z = -half_span + inset + ((idx / side) as f32 + 0.5) * (usable / side as f32);
+    world.insert(RigidBodyBuilder::dynamic().translation(Vector::new(x, 1.5, z)), ColliderBuilder::ball(0.5));
+}
+
 /// Per-step trace (see the file header); `steps` steps of `world`.
 fn trace(world: &mut PhysicsWorld, scene: &str, path: &std::path::Path, steps: u32) {
     use std::collections::BTreeSet;
@@ -213,6 +241,7 @@ fn main() {
         "large_pyramid" => large_pyramid(200),
         "joint_grid" => joint_grid(100),
         "reference_pile" => reference_pile(),
+        "large_world" => large_world(1000), // one million static shapes; `large_world [steps]` times the whole run, drops included
         other => panic!("unknown scene {other}"),
     };
     if args.get(2).map(String::as_str) == Some("--dump") {
@@ -232,6 +261,23 @@ fn main() {
         let path = std::path::PathBuf::from(args.get(3).expect("--trace <file> [steps]"));
         let steps: u32 = args.get(4).and_then(|s| s.parse().ok()).unwrap_or(120);
         trace(&mut world, scene, &path, steps);
+        return;
+    }
+    if scene == "large_world" {
+        // the benchmark IS the drop phase: no warm-up, a sphere every 5 steps up to 100 (tools/large_world.py: 699 steps after the first)
+        let steps: i32 = args.get(2).and_then(|s| s.parse().ok()).unwrap_or(700);
+        world.step();
+        let (mut dropped, t0) = (0, Instant::now());
+        for step in 1..steps {
+            if dropped < 100 && step % 5 == 0 {
+                large_world_drop(&mut world, dropped, 1000, 100);
+                dropped += 1;
+            }
+            world.step();
+        }
+        let dt = t0.elapsed().as_secs_f64();
+        println!("{{\"scene\": \"large_world\", \"threads\": {}, \"steps\": {}, \"steps_per_s\": {:.2}, \"ms_per_step\": {:.4}}}",
+                 rayon::current_num_threads(), steps - 1, (steps - 1) as f64 / dt, dt / (steps - 1) as f64 * 1e3);
         return;
     }
     let warmup: usize = args.get(2).and_then(|s| s.parse().ok()).unwrap_or(60);
