@@ -417,3 +417,35 @@ def test_b3d_large_world_at_reduced_size(gpu):
     assert dropped == spheres
     np.testing.assert_allclose(p[balls, 1], 0.75, atol=0.01)
     assert np.abs(v[balls]).max() < 1e-3
+
+
+def test_large_world_generator_matches_the_reference_formulas():
+    """examples3d/b3d_large_world.rs:27-41, :55-63 in closed form: floor box (i, j) at x = -half_span + (i + 0.5) * cell (f32 arithmetic),
+    i outer / j inner, no parent, half extents (5, 0.25, 5); sphere idx on a side x side grid (side = 10 for 100 spheres) over the
+    inner 80 % of the floor at y = 1.5"""
+    grid, cell = 30, np.float32(10.0)
+    s = S.large_world(grid)
+    assert len(s.bodies) == 0 and len(s.colliders) == grid * grid and set(s.collider_parents) == {-1}
+    half_span = np.float32(0.5) * cell * np.float32(grid)
+    for (i, j) in ((0, 0), (0, 1), (7, 19), (29, 29)):
+        c = s.colliders[i * grid + j]
+        want = (-half_span + (np.float32(i) + np.float32(0.5)) * cell, np.float32(0.0), -half_span + (np.float32(j) + np.float32(0.5)) * cell)
+        np.testing.assert_array_equal(np.asarray(c["translation"], np.float32), np.asarray(want, np.float32))
+        np.testing.assert_array_equal(np.asarray(c["half_extents"], np.float32), np.asarray((5.0, 0.25, 5.0), np.float32))
+        assert int(c["shape"]) == S.SHAPE_CUBOID
+    # spheres: side = 10; idx 0 -> cell (0, 0), idx 37 -> (7, 3)
+    inset = np.float32(0.1) * np.float32(2.0) * half_span
+    usable = np.float32(2.0) * half_span - np.float32(2.0) * inset
+    for idx, (gi, gj) in ((0, (0, 0)), (37, (7, 3)), (99, (9, 9))):
+        x = -half_span + inset + (np.float32(gi) + np.float32(0.5)) * (usable / np.float32(10))
+        z = -half_span + inset + (np.float32(gj) + np.float32(0.5)) * (usable / np.float32(10))
+        assert S.large_world_drop(idx, grid) == (float(x), 1.5, float(z))
+
+
+def test_gpu_tools_compile():
+    """the GPU-side tools of the round (they only run on the GPU box) at least parse"""
+    import os
+    import py_compile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name in ("large_world.py", "shard_dryrun.py", "tile_diag.py", "pass_profile.py", "lp_steady.py", "bench_configs.py"):
+        py_compile.compile(os.path.join(root, "tools", name), doraise=True)
