@@ -37,12 +37,18 @@
 // one process-wide lock; kernels, async copies on a world's own stream and stream / event waits stay outside it, so worlds still
 // overlap on the device.
 static std::mutex g_hip_unsafe_api;
-static inline hipError_t locked_hipMemcpy(void *dst, const void *src, size_t n, hipMemcpyKind k) { std::lock_guard<std::mutex> g(g_hip_unsafe_api); return hipMemcpy(dst, src, n, k); }
+// A "synchronous" copy of a world is a copy ON THE WORLD'S STREAM followed by a wait for that stream.  The stream is non-blocking, so the
+// legacy-stream hipMemcpy the first three rounds used here was not ordered against work still queued on it (the zero fills of
+// finalize(), kernels of an edit in progress): see the note at the b_order upload in finalize().
+static inline hipError_t stream_hipMemcpy(hipStream_t st, void *dst, const void *src, size_t n, hipMemcpyKind k) {
+    hipError_t e = hipMemcpyAsync(dst, src, n, k, st);
+    return e != hipSuccess ? e : hipStreamSynchronize(st);
+}
 static inline hipError_t locked_hipMallocBytes(void **p, size_t n) { std::lock_guard<std::mutex> g(g_hip_unsafe_api); return hipMalloc(p, n); }
 static inline hipError_t locked_hipFree(void *p) { std::lock_guard<std::mutex> g(g_hip_unsafe_api); return hipFree(p); }
 static inline hipError_t locked_hipHostMalloc(void **p, size_t n, unsigned flags) { std::lock_guard<std::mutex> g(g_hip_unsafe_api); return hipHostMalloc(p, n, flags); }
 static inline hipError_t locked_hipHostFree(void *p) { std::lock_guard<std::mutex> g(g_hip_unsafe_api); return hipHostFree(p); }
-#define hipMemcpy(dst, src, n, k) locked_hipMemcpy((void *)(dst), (const void *)(src), (n), (k))
+#define hipMemcpy(dst, src, n, k) stream_hipMemcpy(w->stream, (void *)(dst), (const void *)(src), (n), (k)) // (every caller has its world in scope as `w`)
 #define hipFree(p) locked_hipFree((void *)(p))
 #define hipHostFree(p) locked_hipHostFree((void *)(p))
 
@@ -902,6 +908,9 @@ static int dalloc(rp_world *w, T *&p, size_t count, int fill_byte = 0, int dom =
 }
 // DA / DAF: scratch or host-authoritative arrays; DAC / DAFC: persistent rows carried over when the world grows (domain, planes[, per])
 #define DA(ptr, count) do { int r_ = dalloc(w, ptr, (size_t)(count)); if (r_ != RP_OK) return r_; } while (0)
+// DAS: scratch that every reader finds written by an earlier kernel of the same step (no rest state).  RP_TEST_POISON=1 fills it with
+// 0xFF bytes (NaN / -1) instead of zeros: a kernel that reads such an array before it was written shows up in the parity tests
+#define DAS(ptr, count) do { static const int poison_ = (getenv("RP_TEST_POISON") && atoi(getenv("RP_TEST_POISON"))) ? 0xff : 0; int r_ = dalloc(w, ptr, (size_t)(count), poison_); if (r_ != RP_OK) return r_; } while (0)
 #define DAF(ptr, count, fill) do { int r_ = dalloc(w, ptr, (size_t)(count), fill); if (r_ != RP_OK) return r_; } while (0)
 #define DAC(ptr, count, ...) do { int r_ = dalloc(w, ptr, (size_t)(count), 0, __VA_ARGS__); if (r_ != RP_OK) return r_; } while (0)
 #define DAFC(ptr, count, fill, ...) do { int r_ = dalloc(w, ptr, (size_t)(count), fill, __VA_ARGS__); if (r_ != RP_OK) return r_; } while (0)
@@ -1274,7 +1283,7 @@ static int finalize(rp_world *w) {
     DA(d.j_stage_begin, RP_NUM_COLORS + 1); DA(d.j_stage_count, RP_NUM_COLORS + 1); DA(d.j_group, std::max(nj, 1));
     DA(d.jc_first, std::max(nj, 1)); DA(d.jc_list, 2 * (size_t)std::max(nj, 1)); DA(d.jc_sorted, 2 * (size_t)std::max(nj, 1)); DA(d.jc_deps, std::max(nj, 1)); DA(d.jc_q, 2 * (size_t)std::max(nj, 1)); DA(d.jc_rank, std::max(nj, 1)); DA(d.jc_succ, std::max(nj, 1));
     DAC(d.bj_cmask, 4 * (size_t)capb, DOM_BODY, 1, 4); DAFC(d.bj_min, capb, 0xff, DOM_BODY, 1, 1); DA(d.b_njoints, capb);
-    DA(d.JR, (size_t)RP_JR_COUNT * std::max(nj, 1)); // im1, im2 + 12 rows x 6 planes (rp_joints.h); planes of unused rows are never touched
+    DAS(d.JR, (size_t)RP_JR_COUNT * std::max(nj, 1)); // im1, im2 + 12 rows x 6 planes (rp_joints.h); planes of unused rows are never touched
     UP(d.j_b1, jb1); UP(d.j_b2, jb2); UP(d.j_f1t, jf1t); UP(d.j_f1r, jf1r); UP(d.j_f2t, jf2t); UP(d.j_f2r, jf2r);
     d.joints_spherical = nj > 0 ? 1 : 0;
     for (int k = 0; k < nj; ++k) if (!(jlocked[k] == 0x7 && (jlimited[k] & ~jlocked[k]) == 0 && (jmotor[k] & ~jlocked[k]) == 0)) d.joints_spherical = 0; // (joint_update_one_t's test)
@@ -1287,11 +1296,11 @@ static int finalize(rp_world *w) {
         UP(d.b_collider, bcol);
         HIPCHK(w, hipStreamSynchronize(w->stream));
     }
-    DA(d.k_b1, d.cons_cap); DA(d.k_b2, d.cons_cap); DA(d.k_n, d.cons_cap); DA(d.k_cid, d.cons_cap);
+    DAS(d.k_b1, d.cons_cap); DAS(d.k_b2, d.cons_cap); DAS(d.k_n, d.cons_cap); DAS(d.k_cid, d.cons_cap);
     // dataflow solver: toucher lists, rebuilt on the device whenever the layout changes (no carry-over needed)
     DA(d.f_rec, 2 * (size_t)capb); DA(d.fk_rank, d.cons_cap); DA(d.fj_rank, std::max(nj, 1)); DA(d.fb_deg, capb); DA(d.fb_begin, capb); DA(d.fb_fill, capb);
-    DA(d.f_adj, 2 * (size_t)d.cons_cap); DA(d.f_jadj, 2 * (size_t)std::max(nj, 1)); DA(d.f_sorted, 2 * (size_t)d.cons_cap); DA(d.f_other, 2 * (size_t)d.cons_cap);
-    if (w->params.friction_model != RP_FRICTION_COULOMB) DA(d.ws_terms, (size_t)11 * 2 * d.cons_cap);
+    DAS(d.f_adj, 2 * (size_t)d.cons_cap); DAS(d.f_jadj, 2 * (size_t)std::max(nj, 1)); DAS(d.f_sorted, 2 * (size_t)d.cons_cap); DAS(d.f_other, 2 * (size_t)d.cons_cap);
+    if (w->params.friction_model != RP_FRICTION_COULOMB) DAS(d.ws_terms, (size_t)11 * 2 * d.cons_cap);
     // LDS tiles of the global path (rp_tiles.hip): contact-only worlds under the twist model that are large enough to leave the single
     // workgroup; RP_NO_TILES=1 keeps the per-stage launches, RP_TILE_TARGET=<n> sets the number of tiles aimed at (default: one per CU)
     {
@@ -1301,16 +1310,26 @@ static int finalize(rp_world *w) {
         d.tile_cap = eligible ? capb / 64 + 2 : 0;
         d.tile_target = tt && atoi(tt) > 0 ? atoi(tt) : 240;
         // constraint planes: Coulomb: + 9 tangent planes per point (rp_coulomb.h); worlds that may tile: + the shadow copy of the mutable planes
-        DA(d.C, (size_t)(w->params.friction_model == RP_FRICTION_COULOMB ? CQ_COUNT : CP_COUNT + (d.tile_cap ? CP_SHADOW_COUNT : 0)) * d.cons_cap);
+        DAS(d.C, (size_t)(w->params.friction_model == RP_FRICTION_COULOMB ? CQ_COUNT : CP_COUNT + (d.tile_cap ? CP_SHADOW_COUNT : 0)) * d.cons_cap);
         if (d.tile_cap) {
-            DA(d.t_lin, capb); DA(d.t_ang, capb); DA(d.t_rot, capb); DA(d.t_trans, capb); DA(d.fk_ids, d.cons_cap); DA(d.tl_body_tile, capb); DA(d.tl_owned, capb);
-            DA(d.tl_hist, 2 * RP_TILE_CELLS); DA(d.tl_cellofs, 2 * RP_TILE_CELLS); DA(d.tl_bbox, 16); DA(d.tl_hdr, d.tile_cap);
-            DA(d.tl_cell, capb); DA(d.tl_sorted, capb); DA(d.b_order, capb);
-            if (nj > 0) { DA(d.jm, (size_t)2 * 12 * nj); DA(d.f_jsorted, 2 * (size_t)nj); DA(d.f_jother, 2 * (size_t)nj); } // joint stages on tiles: the sweeps' mutable row words (two copies), sorted joint toucher lists
-            { std::vector<int> iota(capb); for (int i = 0; i < capb; ++i) iota[i] = i; HIPCHK(w, hipMemcpy(d.b_order, iota.data(), (size_t)capb * sizeof(int), hipMemcpyHostToDevice)); }
-            DA(d.tl_soff, (size_t)d.tile_cap * (RP_TILE_STAGES + 1)); DA(d.tl_bodies, (size_t)d.tile_cap * RP_TILE_BCAP); DA(d.tl_cons, (size_t)d.tile_cap * RP_TILE_CCAP);
+            DAS(d.t_lin, capb); DAS(d.t_ang, capb); DAS(d.t_rot, capb); DAS(d.t_trans, capb); DAS(d.fk_ids, d.cons_cap); DAS(d.tl_body_tile, capb); DAS(d.tl_owned, capb);
+            DA(d.tl_hist, 2 * RP_TILE_CELLS); DAS(d.tl_cellofs, 2 * RP_TILE_CELLS); DA(d.tl_bbox, 16); DAS(d.tl_hdr, d.tile_cap);
+            DAS(d.tl_cell, capb); DAS(d.tl_sorted, capb); DA(d.b_order, capb);
+            if (nj > 0) { DAS(d.jm, (size_t)2 * 12 * nj); DAS(d.f_jsorted, 2 * (size_t)nj); DAS(d.f_jother, 2 * (size_t)nj); } // joint stages on tiles: the sweeps' mutable row words (two copies), sorted joint toucher lists
+            // (Both uploads below ride the world's stream behind the zero fills of DA: the stream is non-blocking, so a synchronous
+            // hipMemcpy — legacy stream — is NOT ordered against a fill that is still queued.  Round 3 used hipMemcpy here: a fill that
+            // ran late wiped b_order to all zeros — every manifold of a colour then ranked to the same position — or tl_bbox's rest
+            // state.  That was the intermittent gross mismatch of DESIGN.md section 4.10.)
+            { std::vector<int> iota(capb); for (int i = 0; i < capb; ++i) iota[i] = i; UP(d.b_order, iota); HIPCHK(w, hipStreamSynchronize(w->stream)); }
+            DAS(d.tl_soff, (size_t)d.tile_cap * (RP_TILE_STAGES + 1)); DAS(d.tl_bodies, (size_t)d.tile_cap * RP_TILE_BCAP); DAS(d.tl_cons, (size_t)d.tile_cap * RP_TILE_CCAP);
             const unsigned rest[16] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-            HIPCHK(w, hipMemcpy(d.tl_bbox, rest, sizeof(rest), hipMemcpyHostToDevice));
+            HIPCHK(w, hipMemcpyAsync(d.tl_bbox, rest, sizeof(rest), hipMemcpyHostToDevice, w->stream));
+            HIPCHK(w, hipStreamSynchronize(w->stream));
+            // test hook (tools/tile_race_stress.py --replay): what the round-3 race left behind when the fill lost it — 1: b_order wiped, 2: tl_bbox wiped
+            if (const char *lf = getenv("RP_TEST_LATE_FILL")) {
+                if (atoi(lf) & 1) HIPCHK(w, hipMemsetAsync(d.b_order, 0, (size_t)capb * sizeof(int), w->stream));
+                if (atoi(lf) & 2) HIPCHK(w, hipMemsetAsync(d.tl_bbox, 0, sizeof(rest), w->stream));
+            }
             // test hook (RP_TILE_STALE_PLAN=1): the device never finds a tiling worth having while the host plans tile sweeps all the same —
             // every sweep then takes the branch that normally only a stale hint reaches (k_tile_sweep with FL_N_TILES == 0)
             if (getenv("RP_TILE_STALE_PLAN")) d.tile_min = 0x7fffffff;

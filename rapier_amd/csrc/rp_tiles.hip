@@ -126,9 +126,7 @@ __global__ void __launch_bounds__(1024) k_tiles_sort(DevWorld w) {
         }
     }
     GBAR_SYNC(bar);
-    // pass 3: every body takes a slot of its cell's segment (tl_sorted: the input of the order pass in k_tiles_cones); a global-path body
-    // also takes its rank among the global-path bodies -> owner tile (the order inside a cell is whatever the atomics make it: a tiling
-    // only schedules the work, any partition gives the same bits)
+    // pass 3: every body takes a slot of its cell's segment (tl_sorted: the members of every cell, in whatever order the atomics make it)
     const int NG = (int)w.tl_bbox[6];
     int T = (NG + w.tile_target - 1) / w.tile_target; T = T < 64 ? 64 : (T > 256 ? 256 : T);
     const int NT = (NG + T - 1) / T;
@@ -136,8 +134,20 @@ __global__ void __launch_bounds__(1024) k_tiles_sort(DevWorld w) {
     for (int i = gid; i < nb; i += gstride) {
         const int cc = w.tl_cell[i], cell = cc >= 0 ? cc : -1 - cc;
         w.tl_sorted[w.tl_cellofs[cell] + atomicAdd(&w.tl_hist[cell], 1)] = i;
+    }
+    GBAR_SYNC(bar);
+    // pass 4: a global-path body's rank among the global-path bodies -> owner tile.  DETERMINISTIC: begin of its cell's segment + the
+    // global-path bodies of that cell with a smaller index (a cell holds a handful of bodies), so the same world always gets the same
+    // tiles and cones (round 3 ranked inside a cell by atomics: any partition gives the same bits, but a failure could not be replayed)
+    for (int i = gid; i < nb; i += gstride) {
+        const int cc = w.tl_cell[i];
         int tile = -1;
-        if (cc >= 0 && fits) { const int r = w.tl_cellofs[RP_TILE_CELLS + cell] + atomicAdd(&w.tl_hist[RP_TILE_CELLS + cell], 1); w.tl_owned[r] = i; tile = r / T; }
+        if (cc >= 0 && fits) {
+            const int beg = w.tl_cellofs[cc], end = cc + 1 < RP_TILE_CELLS ? w.tl_cellofs[cc + 1] : nb;
+            int r = w.tl_cellofs[RP_TILE_CELLS + cc];
+            for (int k = beg; k < end; ++k) { const int m = w.tl_sorted[k]; r += (m < i && w.tl_cell[m] >= 0) ? 1 : 0; }
+            w.tl_owned[r] = i; tile = r / T;
+        }
         w.tl_body_tile[i] = tile;
     }
     if (gid == 0) { // (dbg[900..]: statistics of the last tiling, tools/tile_diag.py)
