@@ -688,9 +688,14 @@ static bool world_has_compound_bodies(const rp_world *w) {
 // Bring the host mirrors up to date with the device (poses, velocities) before the device world is
 // rebuilt from them: inserting into a world that has been stepped continues from the current state
 // (contact warm-start data is not carried over a rebuild).
+static int download_rows(rp_world *w);
 static int download_state(rp_world *w) {
     if (!w->finalized) return RP_OK;
     { int r = settle(w); if (r != RP_OK) return r; }
+    return download_rows(w);
+}
+// (the copies alone: the caller knows the stream to be idle and the device world to hold every requested step)
+static int download_rows(rp_world *w) {
     int nb = w->dw.n_bodies;
     std::vector<float4> pos(nb), rot(nb), lv(nb), av(nb);
     HIPCHK(w, hipMemcpy(pos.data(), w->dw.b_pos, nb * sizeof(float4), hipMemcpyDeviceToHost));
@@ -1600,9 +1605,31 @@ static int step_once(rp_world *w, bool allow_fast) {
                 // the very first broad-phase pass of a freshly built world found more pairs than the pool holds (a dense pile: the pool
                 // starts at RP_PAIRS_PER_COLLIDER = 8 slots per collider row).  No step has run: build the device world again with twice
                 // the slots.  (A pool that fills up LATER grows ahead of time: rp_step.)
+                // What the host entry points wrote into device rows only since the world was built (rp_bodies_write, add_force,
+                // apply_impulse, wake_up, set_next_kinematic_position after a step(0) / an auto-finalize) comes along: the body rows
+                // return to the host mirrors, user forces and wake requests are put back after the rebuild.  finalize() starts the
+                // step counters afresh — but rp_step has already counted this step: they are put back too (a host one step behind the
+                // device's FL_STEP would take the first aborted fast step for a retired one and never replay it).
                 w->pairs_scale *= 2; w->err.clear();
+                const long long req = w->steps_requested, full_until = w->full_until;
+                const int nb0 = w->dw.n_bodies;
+                std::vector<float4> uf(nb0), ut(nb0); std::vector<int> wr(nb0);
+                if ((r = download_rows(w)) != RP_OK) return r;
+                if (nb0 > 0) {
+                    HIPCHK(w, hipMemcpy(uf.data(), w->dw.b_uforce, (size_t)nb0 * sizeof(float4), hipMemcpyDeviceToHost));
+                    HIPCHK(w, hipMemcpy(ut.data(), w->dw.b_utorque, (size_t)nb0 * sizeof(float4), hipMemcpyDeviceToHost));
+                    HIPCHK(w, hipMemcpy(wr.data(), w->dw.b_wake_req, (size_t)nb0 * sizeof(int), hipMemcpyDeviceToHost));
+                }
+                const int wake_pending = fl[FL_WAKE_PENDING];
                 free_device(w);
                 r = finalize(w); if (r != RP_OK) return r;
+                w->steps_requested = req; w->full_until = full_until;
+                if (nb0 > 0) {
+                    HIPCHK(w, hipMemcpy(w->dw.b_uforce, uf.data(), (size_t)nb0 * sizeof(float4), hipMemcpyHostToDevice));
+                    HIPCHK(w, hipMemcpy(w->dw.b_utorque, ut.data(), (size_t)nb0 * sizeof(float4), hipMemcpyHostToDevice));
+                    HIPCHK(w, hipMemcpy(w->dw.b_wake_req, wr.data(), (size_t)nb0 * sizeof(int), hipMemcpyHostToDevice));
+                    if (wake_pending) HIPCHK(w, hipMemcpy(w->dw.flags + FL_WAKE_PENDING, &wake_pending, sizeof(int), hipMemcpyHostToDevice));
+                }
                 continue;
             }
             if (r != RP_OK) return r;

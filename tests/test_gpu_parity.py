@@ -1055,6 +1055,42 @@ def test_pair_pool_grows_before_it_overflows(monkeypatch):
     assert c["num_pairs"] == o.stats()["num_pairs"]
 
 
+def test_first_step_pool_overflow_keeps_device_writes_and_step_count(monkeypatch):
+    """the very first broad-phase pass of a dense world overflows a pair pool of ONE slot per collider row, so step_once
+    rebuilds the device world with twice the slots and runs the step again.  (i) What the user wrote into device rows between the
+    auto-finalize (step(0)) and that step — an impulse, a force, a velocity — must survive the rebuild; (ii) the host's step counter
+    must not fall behind the device's: the first aborted fast step afterwards would otherwise be taken for a retired one and never be
+    replayed.  36 pyramids settle onto the fast path; a kick then makes fast steps abort."""
+    import os
+    import oracle_ffi
+    monkeypatch.setenv("RP_PAIRS_PER_COLLIDER", "1")
+    sc = S.many_pyramids(rows=6, cols=6)
+    oracle_ffi.set_threads(max(1, min(os.cpu_count() or 1, 16)))
+    try:
+        g, o = PhysicsWorld.from_scene(sc), OracleWorld(sc)
+        g.step(0)                                  # the device world exists; no step has run
+        dyn = [i for i, b in enumerate(sc.bodies) if int(b["body_type"]) == S.BODY_DYNAMIC]
+        a, b, c = dyn[5], dyn[300], dyn[-1]
+        g.apply_impulse([a], impulse=(40.0, 90.0, -15.0)); o.apply_impulse(a, impulse=(40.0, 90.0, -15.0))
+        g.add_force([b], force=(0.0, 500.0, 100.0)); o.add_force(b, force=(0.0, 500.0, 100.0))
+        kick = np.array([[1.0, 4.0, 0.5, 0.0, 2.0, 0.0]], np.float32)
+        g.write_bodies([c], vel6=kick); o.set_vel(c, kick[0, :3], kick[0, 3:])
+        for n in (1, 1, 30, 170):
+            g.step(n); o.step(n)
+            _same_state(g, o, f"first-step pool overflow, +{n}")
+        c0 = g.counters()
+        assert c0["overflow_flags"] == 0 and c0["num_pairs"] > len(sc.colliders) + 1024, c0   # more pairs than the first pool held
+        assert c0["fast_steps"] > 20, c0
+        g.write_bodies([c], vel6=kick); o.set_vel(c, kick[0, :3], kick[0, 3:])
+        for n in (1, 20, 100):
+            g.step(n); o.step(n)
+            _same_state(g, o, f"after the kick, +{n}")
+        c1 = g.counters()
+        assert c1["replayed_steps"] > 0 or c1["full_steps"] > c0["full_steps"], c1
+    finally:
+        oracle_ffi.set_threads(1)
+
+
 def test_event_queues_hold_every_pair_of_a_large_world():
     """27 x 27 pyramids with collision events on every collider: ~106,000 pairs begin to touch within the first steps — more events than
     the 65,536 slots the queues used to have.  The queues are sized by the pair pool (a step raises at most one event per pair): nothing
