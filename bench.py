@@ -32,35 +32,73 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 C3_CUBOIDS = 10780
 import glob
-_TRAFFIC = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_many_pyramids_hbm_traffic.json")))
-TRAFFIC_FILE = _TRAFFIC[-1] if _TRAFFIC else os.path.join(ROOT, "profiles", "r00_many_pyramids_hbm_traffic.json")  # the latest round's PMC record
-# sources whose change invalidates a recorded HBM-traffic measurement of the dominant kernel
-KERNEL_SOURCES = ["rapier_amd/csrc/rp_islands.hip", "rapier_amd/csrc/rp_constraint.h", "rapier_amd/csrc/rp_pairs.h", "rapier_amd/csrc/rp_world.h"]
+# the PMC record of a workload = the latest round's profiles/rNN_<scene>_hbm_traffic.json (tools/gpu_profile.sh + tools/pmc_summary.py)
+TRAFFIC_SCENE = {"c3": "many_pyramids", "large_pyramid": "large_pyramid", "joint_grid": "joint_grid"}
+# sources whose change invalidates a recorded HBM-traffic measurement: the island kernel's for the metric workload; the whole
+# global solver path (tiles, per-stage launches, joints) for the single-island / jointed scenes
+_ISLAND_SOURCES = ["rapier_amd/csrc/rp_islands.hip", "rapier_amd/csrc/rp_constraint.h", "rapier_amd/csrc/rp_pairs.h", "rapier_amd/csrc/rp_world.h"]
+_GLOBAL_SOURCES = _ISLAND_SOURCES[1:] + ["rapier_amd/csrc/rp_tiles.hip", "rapier_amd/csrc/rp_solver.hip", "rapier_amd/csrc/rp_global.h", "rapier_amd/csrc/rp_lanepair.h",
+                                       "rapier_amd/csrc/rp_joints.h", "rapier_amd/csrc/rp_joints.hip", "rapier_amd/csrc/rp_flow.hip"]
+KERNEL_SOURCES = {"c3": _ISLAND_SOURCES, "large_pyramid": _GLOBAL_SOURCES, "joint_grid": _GLOBAL_SOURCES}
+# kernels of the TGS loop on the global path (what `velocity_update_ms` brackets minus assembly / write-back): their PMC bytes per
+# step are summed into `solver_loop_hbm_bytes_per_step` by tools/pmc_summary.py
+SOLVER_LOOP_KERNELS = ("k_tile_sweep", "k_ws_prepare", "k_increment_ws", "k_increment", "k_integrate", "k_stage", "k_tail", "k_global_flow",
+                       "k_joint_update", "k_joint_sweep", "k_joint_tail")
 
 
-def algorithmic_bytes_per_step(M: int, N: int, substeps: int = 4) -> float:
-    """B_solve(step) = S * [ M * (1100 + 476 + 1008) + N * 224 ] bytes."""
-    return substeps * (M * (1100.0 + 476.0 + 1008.0) + N * 224.0)
+def algorithmic_bytes_per_step(M: int, N: int, substeps: int = 4, joint_rows: int = 0) -> float:
+    """B_solve(step) = S * [ M * (1100 + 476 + 1008) + R * 136 * 3 + N * 224 ] bytes — M solver manifolds, N solver bodies,
+    R joint constraint rows (one 136-byte JointConstraint per row: written by the rebuild, read by the biased and by the relaxed
+    sweep: b3d_joint_grid = 19,800 joints x 3 rows -> 24 MB per substep)."""
+    return substeps * (M * (1100.0 + 476.0 + 1008.0) + joint_rows * 136.0 * 3.0 + N * 224.0)
 
 
-def kernel_code_sha() -> str:
+def joint_rows_of(scene) -> int:
+    """constraint rows the scene's impulse joints build per substep: one per locked axis, per limited and per motorised free axis"""
+    pop = lambda x: bin(int(x) & 0x3f).count("1")  # noqa: E731
+    rows = 0
+    for j in scene.joints:
+        locked = int(j["locked_axes"])
+        rows += pop(locked) + pop(int(j["limit_axes"]) & ~locked) + pop(int(j["motor_axes"]) & ~locked)
+    return rows
+
+
+def kernel_code_sha(workload: str = "c3") -> str:
     h = hashlib.sha256()
-    for rel in KERNEL_SOURCES:
+    for rel in KERNEL_SOURCES.get(workload, _ISLAND_SOURCES):
         with open(os.path.join(ROOT, rel), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
 
 
-def recorded_traffic():
-    """HBM bytes per launch of the dominant kernel from the separate rocprofv3 --pmc passes (tools/gpu_profile.sh writes the file
-    with the hash of the kernel sources it measured).  A record taken on different kernel code is refused: traffic = null."""
-    if not os.path.exists(TRAFFIC_FILE):
-        return None, "no PMC record (profiles/rNN_many_pyramids_hbm_traffic.json)"
-    with open(TRAFFIC_FILE) as f:
+def recorded_traffic(workload: str = "c3"):
+    """HBM bytes of the dominant kernel (per launch; c3) / of the solver loop's kernels (per step; the global-path scenes) from the
+    separate rocprofv3 --pmc passes (tools/gpu_profile.sh writes the file with the hash of the kernel sources it measured).  A record
+    taken on different kernel code is refused: traffic = null."""
+    scene = TRAFFIC_SCENE.get(workload)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{scene}_hbm_traffic.json"))) if scene else []
+    if not files:
+        return None, f"no PMC record (profiles/rNN_{scene}_hbm_traffic.json)"
+    with open(files[-1]) as f:
         rec = json.load(f)
-    if rec.get("kernel_code_sha") != kernel_code_sha():
-        return None, f"stale PMC record refused (kernel sources changed since {rec.get('kernel_code_sha')})"
-    return rec.get("k_island_solve_hbm_bytes_per_launch"), "rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE per the guide), same kernel sources"
+    if rec.get("kernel_code_sha") != kernel_code_sha(workload):
+        return None, f"stale PMC record refused ({os.path.basename(files[-1])}: kernel sources changed since {rec.get('kernel_code_sha')})"
+    key = "k_island_solve_hbm_bytes_per_launch" if workload == "c3" else "solver_loop_hbm_bytes_per_step"
+    return rec.get(key), f"rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE per the guide), {os.path.basename(files[-1])}, same kernel sources"
+
+
+def recorded_c4_anchor():
+    """`--workload c4 --gpus 1` (all of C4 on ONE GPU) as last recorded under profiles/: the strong-scaling anchor quoted in the
+    config of an N > 1 line (an N > 1 run cannot measure it itself)."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_c4_160380_cuboids_1gpu.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            rec = json.loads(f.read().strip().splitlines()[-1])
+        return {"file": os.path.basename(files[-1]), "c4_world_steps_per_s_on_1_gpu": rec["config"]["sharded_world_steps_per_s"], "ms_per_step": rec["ms_per_step"]}
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def cpu_baseline(steps: int = 400, warmup: int = 60):
@@ -214,7 +252,9 @@ def run(args, make_world=None, backend: str = "nccl", use_cuda: bool = True):
         loop_ms, nmeas = w.solver_loop_time_ms()
         tc = w.counters()
         w.enable_timers(False)
-        bytes_step = algorithmic_bytes_per_step(M, Nd, int(scene.params["num_solver_iterations"]))
+        wkey = {"auto": "c3" if world == 1 else "c4"}.get(args.workload, args.workload)
+        jrows = joint_rows_of(scene)
+        bytes_step = algorithmic_bytes_per_step(M, Nd, int(scene.params["num_solver_iterations"]), jrows)
         kernel_name = ("k_island_solve (TGS velocity-solve loop: 4 substeps x [warmstart, biased, relaxed sweeps] of every LDS-resident island, "
                        "1 launch/step)")
         if tc["velocity_update_ms"] > tc["velocity_resolution_ms"]:
@@ -223,7 +263,7 @@ def run(args, make_world=None, backend: str = "nccl", use_cuda: bool = True):
             loop_ms = tc["velocity_update_ms"]
             kernel_name = "global solver path (TGS loop as per-colour-stage launches or one dataflow launch; hipEvents around the sequence)"
         achieved = bytes_step / (loop_ms * 1e-3) / 1e9 if loop_ms > 0 else 0.0
-        traffic, traffic_note = recorded_traffic() if (world == 1 and args.workload in ("auto", "c3")) else (None, "PMC record exists for the N = 1 metric workload only")
+        traffic, traffic_note = recorded_traffic(wkey) if (world == 1 and wkey in TRAFFIC_SCENE) else (None, "PMC records exist for the single-GPU workloads c3, large_pyramid, joint_grid")
         # `frac` prices the reference's ALGORITHMIC bytes against the HBM peak; `hbm_frac` is its twin for the bytes the
         # kernel really moved (PMC): the constraint set lives in registers / LDS, so the kernel is latency-bound, not bandwidth-bound
         hbm_frac = (traffic / (loop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and loop_ms > 0) else None
@@ -231,7 +271,7 @@ def run(args, make_world=None, backend: str = "nccl", use_cuda: bool = True):
                 "hbm_frac": hbm_frac,
                 "kernel": kernel_name,
                 "algorithmic_bytes_per_launch": bytes_step, "kernel_ms_per_launch": loop_ms, "measured_launches": nmeas,
-                "traffic_note": traffic_note, "kernel_code_sha": kernel_code_sha(),
+                "traffic_note": traffic_note, "kernel_code_sha": kernel_code_sha(wkey), "joint_rows": jrows,
                 "stage_ms": {k: tc[k] for k in ("collision_detection_ms", "velocity_resolution_ms", "velocity_update_ms")},
                 "path": {k: tc[k] for k in ("fast_steps", "full_steps", "replayed_steps")}}
 
@@ -247,10 +287,16 @@ def run(args, make_world=None, backend: str = "nccl", use_cuda: bool = True):
     out = None
     if rank == 0:
         is_metric_workload = world == 1 and args.workload in ("auto", "c3")
+        single_scene = {"large_pyramid": "b3d_large_pyramid", "joint_grid": "b3d_joint_grid"}.get(args.workload)  # one-GPU scenes quoted in their own unit
         value = (total_cuboids / C3_CUBOIDS) * args.steps / dt
+        if is_metric_workload or single_scene:
+            value_def = "steps / max-over-ranks time"
+        else:
+            value_def = ("C3-equivalent steps/s = (cuboids stepped by all ranks / 10,780) * steps / max-over-ranks time; sharded_world_steps_per_s = steps/s of "
+                         "the whole sharded world")
         out = {
-            "metric": "physics steps/sec (whole node), b3d_many_pyramids 3D f32",
-            "value": args.steps / dt if is_metric_workload else value,
+            "metric": f"physics steps/sec (whole node), {single_scene or 'b3d_many_pyramids'} 3D f32",
+            "value": args.steps / dt if (is_metric_workload or single_scene) else value,
             "unit": "steps/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -264,8 +310,10 @@ def run(args, make_world=None, backend: str = "nccl", use_cuda: bool = True):
             "config": {"workload": workload, "bodies_per_gpu": Nd, "solver_manifolds_per_gpu": M, "total_cuboids": total_cuboids,
                        "colors": counters["num_colors"], "pyramid_grid": list(grid) if grid else None,
                        "sharded_world_steps_per_s": args.steps / dt,
-                       "value_definition": "steps / max-over-ranks time" if is_metric_workload else
-                       "C3-equivalent steps/s = (cuboids stepped by all ranks / 10,780) * steps / max-over-ranks time; sharded_world_steps_per_s = steps/s of the whole sharded world"},
+                       "value_definition": value_def,
+                       # N > 1 steps BASELINE config C4's density (364.5 islands per GPU), N = 1 steps C3 (196 islands): the like-for-like
+                       # anchor of the N > 1 lines is all of C4 on ONE GPU (`--workload c4 --gpus 1`), quoted from its last record
+                       "strong_scaling_anchor": recorded_c4_anchor() if world > 1 else None},
             "roofline": roof,
             "finite": finite,
             "dist": None if dist is None else {"backend": backend, "world_size": world, "forced": bool(args.force_dist), "shard_source": shard_source,

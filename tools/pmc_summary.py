@@ -35,5 +35,17 @@ out["k_island_solve_hbm_bytes_per_launch"] = isl["hbm_bytes"] if isl else None
 # stamp: bench.py refuses this record once the kernel sources change (a stale traffic figure is worse than none)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
-out["kernel_code_sha"] = bench.kernel_code_sha()
+# argv[3] = the bench workload the passes ran (c3 | large_pyramid | joint_grid), argv[4] = steps the profiled run made (warm-up included):
+# the global-path scenes get the bytes of every solver-loop kernel summed per step
+workload = sys.argv[3] if len(sys.argv) > 3 else "c3"
+steps = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+if steps > 0:
+    tot = 0.0
+    for k, v in out["kernels"].items():
+        if k.startswith(bench.SOLVER_LOOP_KERNELS) or any(k.startswith("void " + p) for p in bench.SOLVER_LOOP_KERNELS):
+            tot += v["hbm_bytes"] * v["launches_fetch_pass"]
+    out["solver_loop_hbm_bytes_per_step"] = tot / steps
+    out["steps_profiled"] = steps
+out["workload"] = workload
+out["kernel_code_sha"] = bench.kernel_code_sha(workload)
 print(json.dumps(out, indent=1))
