@@ -150,12 +150,12 @@ struct rp_world {
     // shard guard (rp_world_set_shard_guard): host copy, re-uploaded whenever the device world is rebuilt
     std::vector<float4> guard_min, guard_max; std::vector<int> guard_start, guard_items; float guard_origin[3] = {0, 0, 0}, guard_cell = 0.0f; int guard_dims[3] = {0, 0, 0};
     // launch plan + graph
-    int plan_stages = 0, plan_blocks = 1, plan_single = 1, plan_island_grid = 1, plan_joint_stages = 0, plan_no_global = 0, plan_fused = 0, plan_tile_grid = 0, plan_no_contacts = 0;
+    int plan_stages = 0, plan_blocks = 1, plan_single = 1, plan_island_grid = 1, plan_joint_stages = 0, plan_no_global = 0, plan_fused = 0, plan_tile_grid = 0, plan_no_contacts = 0, plan_bare = 0;
     bool has_restitution = false;
     // [0] = full path, [1] = fast path, [2] = lean path; "whole" = one graph per step, col/loop/fin = timed thirds (full / fast only)
     hipGraph_t g_whole[3] = {nullptr, nullptr, nullptr}, g_col[3] = {nullptr, nullptr, nullptr}, g_loop[3] = {nullptr, nullptr, nullptr}, g_fin[3] = {nullptr, nullptr, nullptr};
     hipGraphExec_t ge_whole[3] = {nullptr, nullptr, nullptr}, ge_col[3] = {nullptr, nullptr, nullptr}, ge_loop[3] = {nullptr, nullptr, nullptr}, ge_fin[3] = {nullptr, nullptr, nullptr};
-    int graph_stages = -1, graph_blocks = -1, graph_single = -1, graph_island_grid = -1, graph_joint_stages = -1, graph_no_global = -1, graph_fused = -1, graph_tile_grid = -1, graph_no_contacts = -1;
+    int graph_stages = -1, graph_blocks = -1, graph_single = -1, graph_island_grid = -1, graph_joint_stages = -1, graph_no_global = -1, graph_fused = -1, graph_tile_grid = -1, graph_no_contacts = -1, graph_bare = -1;
     bool use_graph = true, use_fast = true, use_fused = true;
     bool use_lean = true;          // the lean step graph of MULTI-mode worlds (below: "lean graph"); RP_NO_LEAN=1: never
     int cur_lean = 0;              // the enqueue_* callbacks capture / launch the lean graph (with dw_lean)
@@ -411,7 +411,7 @@ static void destroy_graphs(rp_world *w) {
         for (auto e : ex) if (*e) { hipGraphExecDestroy(*e); *e = nullptr; }
         for (auto g : gr) if (*g) { hipGraphDestroy(*g); *g = nullptr; }
     }
-    w->graph_stages = -1; w->graph_blocks = -1; w->graph_single = -1; w->graph_island_grid = -1; w->graph_joint_stages = -1; w->graph_no_global = -1; w->graph_fused = -1; w->graph_tile_grid = -1; w->graph_no_contacts = -1;
+    w->graph_stages = -1; w->graph_blocks = -1; w->graph_single = -1; w->graph_island_grid = -1; w->graph_joint_stages = -1; w->graph_no_global = -1; w->graph_fused = -1; w->graph_tile_grid = -1; w->graph_no_contacts = -1; w->graph_bare = -1;
     w->timed_ready[0] = w->timed_ready[1] = false;
 }
 static void free_device(rp_world *w) {
@@ -1432,6 +1432,7 @@ static void enqueue_collision(rp_world *w) {
 static void enqueue_island_solver(rp_world *w) {
     // SINGLE mode: workgroup 0 of this launch retires the step (FL_SEQ / FL_STEP, hint publication)
     const int fused = (w->cur_fast && w->plan_fused) ? 1 : 0;
+    if (w->cur_lean && (w->dw_lean.lean & 2)) return; // a bare lean graph: no island exists (verified by lean_dead in every kernel of the graph)
     // every workgroup of the fused step must be resident at once: the grid is capped by what the device can hold (rp_fused_grid)
     rp_launch_island_solve(w->cur_lean ? w->dw_lean : w->dw, w->stream, fused ? std::min(w->plan_island_grid, w->fused_grid) : w->plan_island_grid,
                            w->has_restitution ? 1 : 0, w->cur_fast, w->plan_single, fused);
@@ -1482,6 +1483,10 @@ static void plan_from_hints(rp_world *w, const int *fl) {
     // LDS tiles (rp_tiles.hip): once the device has published a valid tiling of the global component, a sweep is one launch over the
     // tiles (grid rounded up to 16 so small changes of the tile count do not force a re-capture; the kernel loops over tiles beyond it)
     w->plan_no_contacts = (fl[FL_N_CONS] == 0 && w->dw.tile_cap > 0) ? 1 : 0; // (tile sweeps: the increment folds into the sweep while no manifold exists)
+    // a world without a single manifold and without an LDS island (b3d_joint_grid): its LEAN graphs also leave out the launches that
+    // only contacts and islands give work to — k_island_solve and the four k_ws_prepare of a step — and validate that on the device
+    // too (DevWorld::lean bit 1, lean_dead): ~25 us of launches that found nothing to do in a 0.27 ms step
+    w->plan_bare = (fl[FL_N_CONS] == 0 && fl[FL_N_ISLANDS] == 0 && fl[FL_N_CONS_ALL] == 0 && w->dw.tile_cap > 0) ? 1 : 0;
     // (a valid tiling also replaces the dataflow launch of jointed worlds; forced flow — RP_FLOW=1 — keeps it)
     w->plan_tile_grid = (w->dw.tile_cap > 0 && !w->plan_single && !w->force_flow && fl[FL_N_TILES] > 0) ? ((fl[FL_N_TILES] + 15) / 16) * 16 : 0;
     if (w->dw.tile_cap > 0 && w->dw.tile_min == 0x7fffffff && !w->plan_single && !w->force_flow) w->plan_tile_grid = 16; // (RP_TILE_STALE_PLAN: see finalize)
@@ -1532,7 +1537,7 @@ static int check_overflow(rp_world *w, const int *fl) {
 // graphs": a full step without the launches that rebuild colouring / layout / toucher ranks / tiling, self-validating on the device).
 static int launch_step(rp_world *w, int fast) {
     w->cur_lean = fast == 2 ? 1 : 0;
-    if (w->cur_lean) { w->dw_lean = w->dw; w->dw_lean.lean = 1; }
+    if (w->cur_lean) { w->dw_lean = w->dw; w->dw_lean.lean = 1 | (w->plan_bare ? 2 : 0); }
     w->cur_fast = fast == 1 ? 1 : 0;
     w->seq_enqueued++;
     if (fast == 1) w->fast_steps++; else if (fast == 2) w->lean_steps++; else w->full_steps++;
@@ -1656,11 +1661,11 @@ static int step_once(rp_world *w, bool allow_fast) {
         if (w->plan_island_grid < old_g && w->plan_island_grid * 2 >= old_g) w->plan_island_grid = old_g;
     }
     if (w->graph_stages != w->plan_stages || w->graph_blocks != w->plan_blocks || w->graph_single != w->plan_single ||
-        w->graph_island_grid != w->plan_island_grid || w->graph_joint_stages != w->plan_joint_stages || w->graph_no_global != w->plan_no_global || w->graph_fused != w->plan_fused || w->graph_tile_grid != w->plan_tile_grid || w->graph_no_contacts != w->plan_no_contacts) {
+        w->graph_island_grid != w->plan_island_grid || w->graph_joint_stages != w->plan_joint_stages || w->graph_no_global != w->plan_no_global || w->graph_fused != w->plan_fused || w->graph_tile_grid != w->plan_tile_grid || w->graph_no_contacts != w->plan_no_contacts || w->graph_bare != w->plan_bare) {
         if (w->ge_whole[0] || w->ge_whole[1] || w->timed_ready[0] || w->timed_ready[1]) HIPCHK(w, hipStreamSynchronize(w->stream)); // replays of the old graphs may still be in flight
         destroy_graphs(w);
         w->graph_stages = w->plan_stages; w->graph_blocks = w->plan_blocks; w->graph_single = w->plan_single; w->graph_island_grid = w->plan_island_grid;
-        w->graph_joint_stages = w->plan_joint_stages; w->graph_no_global = w->plan_no_global; w->graph_fused = w->plan_fused; w->graph_tile_grid = w->plan_tile_grid; w->graph_no_contacts = w->plan_no_contacts;
+        w->graph_joint_stages = w->plan_joint_stages; w->graph_no_global = w->plan_no_global; w->graph_fused = w->plan_fused; w->graph_tile_grid = w->plan_tile_grid; w->graph_no_contacts = w->plan_no_contacts; w->graph_bare = w->plan_bare;
     }
     // keep the host at most a few steps ahead of the device so the hints stay fresh (the device
     // never idles: several step graphs are always queued)

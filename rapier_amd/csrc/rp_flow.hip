@@ -492,7 +492,7 @@ __global__ void __launch_bounds__(256) k_global_flow(DevWorld w, int has_restitu
                 if (has) { nrows = joint_row_count(w.j_locked[j], w.j_limited[j], w.j_motor[j]); jim1 = v3(JRP(JR_IM1, j)); jim2 = v3(JRP(JR_IM2, j)); jrows_load<FLOW_JROWS>(w, j, 0, nrows, R0); }
                 FLOW_RUN(has, i1, e1, i2, e2, {
                     FlowJointIO io = {cx, {v1, v2}, {e1 + 1u, e2 + 1u}};
-                    joint_solve_fetched<FlowJointIO, FLOW_JROWS>(w, io, j, nrows, jim1, jim2, R0, false, prm.warmstart_joints && it == 0);
+                    joint_solve_fetched<FlowJointIO, FLOW_JROWS>(w, io, j, i1, i2, nrows, jim1, jim2, R0, false, prm.warmstart_joints && it == 0);
                 });
             }
             if (role == 2) for (int base = 0; base < M; base += T) {
@@ -539,7 +539,7 @@ __global__ void __launch_bounds__(256) k_global_flow(DevWorld w, int has_restitu
                 if (has) { nrows = joint_row_count(w.j_locked[j], w.j_limited[j], w.j_motor[j]); jim1 = v3(JRP(JR_IM1, j)); jim2 = v3(JRP(JR_IM2, j)); jrows_load<FLOW_JROWS>(w, j, 0, nrows, R0); }
                 FLOW_RUN(has, i1, e1, i2, e2, {
                     FlowJointIO io = {cx, {v1, v2}, {e1 + 1u, e2 + 1u}};
-                    joint_solve_fetched<FlowJointIO, FLOW_JROWS>(w, io, j, nrows, jim1, jim2, R0, true, false);
+                    joint_solve_fetched<FlowJointIO, FLOW_JROWS>(w, io, j, i1, i2, nrows, jim1, jim2, R0, true, false);
                 });
             }
             if (role == 2) for (int base = 0; base < M; base += T) {

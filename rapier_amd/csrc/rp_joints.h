@@ -454,9 +454,9 @@ RP_DEV void jrows_solve(const DevWorld &w, int j, int r0, int nrows, JointRowsT<
     }
 }
 // rows [0, CH) already fetched into R0 (with nrows, im1, im2) by the caller
+// (b1, b2: the joint's bodies, already known to the caller — a tile sweep fetches them with the rows, ahead of the stage loop)
 template <class IO, int CH>
-RP_DEV void joint_solve_fetched(const DevWorld &w, const IO &io, int j, int nrows, V3 im1, V3 im2, JointRowsT<CH> &R0, bool wo_bias, bool warmstart) {
-    int b1 = w.j_b1[j], b2 = w.j_b2[j];
+RP_DEV void joint_solve_fetched(const DevWorld &w, const IO &io, int j, int b1, int b2, int nrows, V3 im1, V3 im2, JointRowsT<CH> &R0, bool wo_bias, bool warmstart) {
     V3 l1 = v3(0, 0, 0), a1 = l1, l2 = l1, a2 = l1;
     if (b1 >= 0) io.load_vel(0, b1, l1, a1);
     if (b2 >= 0) io.load_vel(1, b2, l2, a2);
@@ -471,7 +471,7 @@ RP_DEV void joint_solve_one_t(const DevWorld &w, const IO &io, int j, bool wo_bi
     int nrows = joint_row_count(w.j_locked[j], w.j_limited[j], w.j_motor[j]);
     V3 im1 = v3(JRP(JR_IM1, j)), im2 = v3(JRP(JR_IM2, j));
     JointRowsT<CH> R0; jrows_load<CH>(w, j, 0, nrows, R0);
-    joint_solve_fetched<IO, CH>(w, io, j, nrows, im1, im2, R0, wo_bias, warmstart);
+    joint_solve_fetched<IO, CH>(w, io, j, w.j_b1[j], w.j_b2[j], nrows, im1, im2, R0, wo_bias, warmstart);
 }
 RP_DEV void joint_solve_one(const DevWorld &w, int j, bool wo_bias, bool warmstart) { PlainBodyIO io = {w}; joint_solve_one_t(w, io, j, wo_bias, warmstart); }
 

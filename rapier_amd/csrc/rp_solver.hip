@@ -302,7 +302,7 @@ int rp_launch_solver_loop(const DevWorld &w0, hipStream_t st, int parallel_stage
         float solved_dt = (float)s * w.prm.dt_sub;
         if (!host_coulomb(w) && w.ws_terms) { // body-centric warm start: two launches instead of one per colour
             if (tiles && w.n_joints > 0 && !jinline) hipLaunchKernelGGL(k_ws_prepare<true>, dim3(cons_blocks(w)), dim3(256), 0, st, w, solved_dt, s);
-            else hipLaunchKernelGGL(k_ws_prepare<false>, dim3(cons_blocks(w)), dim3(256), 0, st, w, solved_dt, -1);
+            else if (!(w.lean & 2)) hipLaunchKernelGGL(k_ws_prepare<false>, dim3(cons_blocks(w)), dim3(256), 0, st, w, solved_dt, -1); // (a bare lean graph holds no manifold: rp_world.h)
             if (!fuse_inc) hipLaunchKernelGGL(k_increment_ws, dim3(2 * nb), dim3(256), 0, st, w); // (linear halves, then angular halves)
             if (!tiles) rp_launch_joint_update(w, st, s);
         } else {

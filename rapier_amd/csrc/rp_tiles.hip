@@ -499,9 +499,9 @@ struct TileJointIO {
 // fetched in ONE round trip whatever the count turns out to be (every joint owns twelve row slots; a spherical joint — b3d_joint_grid —
 // has exactly three).  None of it changes during a sweep (the rows are rebuilt between sweeps, the sweep's own words go to the other
 // copy of DevWorld::jm), so the fetch of a thread's NEXT joint stage is issued a whole stage ahead.
-struct TileJointPre { int locked, limited, motor; V3 im1, im2; JointRowsT<3> R; };
+struct TileJointPre { int locked, limited, motor, b1, b2; V3 im1, im2; JointRowsT<3> R; };
 RP_DEV void tile_joint_fetch(const DevWorld &w, int j, TileJointPre &P) {
-    P.locked = w.j_locked[j]; P.limited = w.j_limited[j]; P.motor = w.j_motor[j];
+    P.locked = w.j_locked[j]; P.limited = w.j_limited[j]; P.motor = w.j_motor[j]; P.b1 = w.j_b1[j]; P.b2 = w.j_b2[j];
     P.im1 = v3(JRP(JR_IM1, j)); P.im2 = v3(JRP(JR_IM2, j));
 #pragma unroll
     for (int q = 0; q < 3; ++q) jrow_load(w, j, q, P.R.c[q]);
@@ -526,14 +526,14 @@ struct TileJointBuild {
     }
 };
 RP_DEV void tile_joint_build(const DevWorld &w, const int4 e, int substep, TileJointPre &P) {
-    P.locked = 0x7; P.limited = 0; P.motor = 0;
+    P.locked = 0x7; P.limited = 0; P.motor = 0; P.b1 = w.j_b1[-1 - e.x]; P.b2 = w.j_b2[-1 - e.x];
     const TilePoseIO io = {w};
     const TileJointBuild sink = {P, e.w != 0};
     joint_update_one_t<TilePoseIO, TileJointBuild, true>(w, io, -1 - e.x, substep, sink);
 }
 RP_DEV void tile_apply_joint(const DevWorld &w, const int4 e, TileJointPre &P, float4 *Ll, float4 *La, bool wo_bias, bool warmstart) {
     const TileJointIO io = {Ll, La, e.y, e.z, w.c_par ^ 1, e.w != 0};
-    joint_solve_fetched<TileJointIO, 3>(w, io, -1 - e.x, joint_row_count(P.locked, P.limited, P.motor), P.im1, P.im2, P.R, wo_bias, warmstart);
+    joint_solve_fetched<TileJointIO, 3>(w, io, -1 - e.x, P.b1, P.b2, joint_row_count(P.locked, P.limited, P.motor), P.im1, P.im2, P.R, wo_bias, warmstart);
 }
 
 // fuse bit 2: the sweep rebuilds the rows of its (spherical) joints itself — tile_joint_build; the substep index rides in fuse >> 8
@@ -610,35 +610,62 @@ __global__ void __launch_bounds__(RP_TILE_THREADS) k_tile_sweep(DevWorld w, int 
         // (Asking for the rows of stage s + 1 a stage ahead — one dword per row through global_load_lds into a junk LDS slot — was built
         // and measured: every stage got ~50 % SLOWER.  The sweeps already pull 2.3-4.6 TB/s from HBM (PMC FETCH_SIZE: 100 MB per relaxed
         // launch in 43 us): what bounds a stage is the traffic the tiling demands — rows x 1.95 instances — not the latency of one miss.)
-        int4 e_next; int n_next; bool have_next;
-        { const int i0 = Soff[0] + my; have_next = i0 < Soff[1]; e_next = cons[have_next ? i0 : 0]; n_next = w.k_n[e_next.x > 0 ? e_next.x : 0]; }
-        TP_STAMP(0);
-        for (int s = 0; s < nst; ++s) {
-            const int end = Soff[s + 1];
-            int i = Soff[s] + my;
-            int4 e = e_next; int n = n_next;
-            bool have = have_next;
-            { const int i1 = end + my; have_next = i1 < Soff[s + 2]; e_next = cons[have_next ? i1 : 0]; } // (Soff[nst + 1] = Soff[nst]: nothing behind the last stage)
-            if (s < njs) { // a joint stage (wave-uniform); one lane per joint (the even lane of a pair)
-                while (have) {
-                    if (!odd) {
+        // ---- the joint stages (they come first in a sweep) ----
+        // A cone that holds at most one joint per thread (b3d_joint_grid: ~200 per tile) hands thread k the k-th joint entry for the whole
+        // sweep: what a joint solve reads besides velocities — the rows, rebuilt from the poses by the first biased sweep of a substep
+        // (~600 dependent operations) or fetched (20 loads) — is independent of the sweep's velocities, so ALL of a tile's joints are
+        // prepared at once, before the first stage, by as many lanes as there are joints; a stage is then LDS velocities + three row
+        // solves.  (Round 3 prepared inside the stage: 45 busy lanes and a 2 us dependent chain in every one of the five stages.)
+        // Larger cones keep the per-stage form.
+        if (njs > 0) {
+            const int j0 = Soff[0], nje = Soff[njs] - j0;
+            if (nje <= nt) { // (tile-uniform)
+                int4 je = make_int4(0, 0, 0, 0); int jstage = -1; TileJointPre JP;
+                if (t < nje) {
+                    je = cons[j0 + t];
+                    jstage = 0; while (Soff[jstage + 1] - j0 <= t) ++jstage;
+                    if (MODE == MODE_BIAS && (fuse & 4)) tile_joint_build(w, je, fuse >> 8, JP);
+                    else tile_joint_fetch(w, -1 - je.x, JP);
+                }
+                TP_STAMP(0);
+                for (int s = 0; s < njs; ++s) {
+                    if (jstage == s) tile_apply_joint(w, je, JP, Ll, La, MODE == MODE_RELAX, joint_warmstart != 0);
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    TP_STAMP(4 + (s < 16 ? s : 16));
+                }
+            } else {
+                TP_STAMP(0);
+                for (int s = 0; s < njs; ++s) {
+                    const int end = Soff[s + 1];
+                    for (int i = Soff[s] + (LP ? (t >> 1) : t); i < end; i += (LP ? (nt >> 1) : nt)) {
+                        if (LP && (t & 1)) continue; // one lane per joint (the even lane of a pair)
+                        const int4 e = cons[i];
                         TileJointPre P;
                         if (MODE == MODE_BIAS && (fuse & 4)) tile_joint_build(w, e, fuse >> 8, P);
                         else tile_joint_fetch(w, -1 - e.x, P);
                         tile_apply_joint(w, e, P, Ll, La, MODE == MODE_RELAX, joint_warmstart != 0);
                     }
-                    i += per; have = i < end;
-                    if (have) e = cons[i];
-                }
-            } else {
-                while (have) {
-                    if (LP) tile_apply2<MODE>(w, e, n, odd, Lg, Ll, La, friction, solved_dt);
-                    else tile_apply<MODE>(w, e, n, Lg, Ll, La, fib, friction, solved_dt);
-                    i += per; have = i < end;
-                    if (have) { e = cons[i]; n = w.k_n[e.x]; }
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    TP_STAMP(4 + (s < 16 ? s : 16));
                 }
             }
-            n_next = w.k_n[e_next.x > 0 ? e_next.x : 0]; // (a joint entry carries a negative code: no point count)
+        } else TP_STAMP(0);
+        // ---- the contact stages ----
+        int4 e_next; int n_next; bool have_next;
+        { const int i0 = Soff[njs] + my; have_next = i0 < Soff[njs + 1]; e_next = cons[have_next ? i0 : 0]; n_next = w.k_n[e_next.x > 0 ? e_next.x : 0]; }
+        for (int s = njs; s < nst; ++s) {
+            const int end = Soff[s + 1];
+            int i = Soff[s] + my;
+            int4 e = e_next; int n = n_next;
+            bool have = have_next;
+            { const int i1 = end + my; have_next = i1 < Soff[s + 2]; e_next = cons[have_next ? i1 : 0]; } // (Soff[nst + 1] = Soff[nst]: nothing behind the last stage)
+            while (have) {
+                if (LP) tile_apply2<MODE>(w, e, n, odd, Lg, Ll, La, friction, solved_dt);
+                else tile_apply<MODE>(w, e, n, Lg, Ll, La, fib, friction, solved_dt);
+                i += per; have = i < end;
+                if (have) { e = cons[i]; n = w.k_n[e.x]; }
+            }
+            n_next = w.k_n[e_next.x > 0 ? e_next.x : 0];
             // the barrier orders the LDS velocities only: a thread's row stores may stay in flight (nothing reads them before the next kernel)
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             TP_STAMP(4 + (s < 16 ? s : 16));

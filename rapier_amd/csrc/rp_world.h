@@ -201,7 +201,7 @@ struct DevWorld {
     int gbar_blocks;       // most workgroups (of 1024 threads) a grid-barrier kernel may use on this device: all of them resident at once (rp_gridbar.h)
     int has_sensors;       // some collider is a sensor: its pairs are intersection-tested every step (full step path)
     int joints_spherical;  // every impulse joint locks the three linear axes and nothing else (no limit, no motor): tile sweeps may rebuild the rows themselves
-    int lean;              // 1 in the copy the LEAN step graph is captured with (rp_api.hip "lean graph"): its kernels check lean_dead / collision_done
+    int lean;              // bit 0 (bit 1: a bare lean graph, see lean_dead) set in the copy the LEAN step graph is captured with (rp_api.hip "lean graph"): its kernels check lean_dead / collision_done
     SimParams prm;
     int *flags;        // FL_* scalars
     unsigned *bar;     // [8] grid-barrier words of the fused rebuild kernels (rp_gridbar.h): {arrivals, base} per kernel
@@ -410,7 +410,10 @@ struct DevWorld {
 #if defined(__HIPCC__)
 __device__ __forceinline__ bool lean_dead(const DevWorld &w) {
     if (!w.lean) return false;
-    return (w.flags[FL_FAST_ABORT] | w.flags[FL_TODO_COUNT] | w.flags[FL_LAYOUT_DIRTY] | w.flags[FL_FLOW_DIRTY] | (w.n_joints > 0 ? w.flags[FL_JOINT_DIRTY] : 0)) != 0;
+    // (bit 1, a BARE lean graph: it also left out the launches that only manifolds and LDS islands give work to.  Both counts are
+    // results of the layout rebuild, which no lean graph runs: they cannot change while this graph executes)
+    const int bare_wrong = (w.lean & 2) ? (w.flags[FL_N_CONS_ALL] | w.flags[FL_N_ISLANDS]) : 0;
+    return (w.flags[FL_FAST_ABORT] | w.flags[FL_TODO_COUNT] | w.flags[FL_LAYOUT_DIRTY] | w.flags[FL_FLOW_DIRTY] | (w.n_joints > 0 ? w.flags[FL_JOINT_DIRTY] : 0) | bare_wrong) != 0;
 }
 // collision kernels: this step's collision stage already ran (a dead lean step waits for its resume), or an earlier lean step died
 __device__ __forceinline__ bool collision_done(const DevWorld &w) { const int a = w.flags[FL_FAST_ABORT]; return a == 2 || (w.lean && a != 0); }
