@@ -187,6 +187,7 @@ struct FlowAccT {
 };
 struct FlowJointIO {
     const FlowCtx &cx; Vel v[2]; unsigned t[2];
+    RP_DEV void bodies(const DevWorld &w_, int j, int &b1, int &b2) const { b1 = w_.j_b1[j]; b2 = w_.j_b2[j]; }
     RP_DEV void pose(int side, int b, Pose &p) const { p.r = flow_q4(flow_ld(cx.B.rot, b)); p.t = flow_v3(flow_ld(cx.B.trans, b)); }
     RP_DEV void load_vel(int side, int b, V3 &l, V3 &a) const { l = v[side].lin; a = v[side].ang; }
     RP_DEV void store_vel(int side, int b, V3 l, V3 a) const { flow_st_vel(cx.B, b, l, a, t[side]); }

@@ -176,6 +176,7 @@ struct JointRowsToPlanes {
 // records on the dataflow path (rp_flow.hip).  `side` = 0 / 1 for body1 / body2.
 struct PlainBodyIO {
     const DevWorld &w;
+    RP_DEV void bodies(const DevWorld &w_, int j, int &b1, int &b2) const { b1 = w_.j_b1[j]; b2 = w_.j_b2[j]; }
     RP_DEV void pose(int side, int b, Pose &p) const { p.r = q4(w.s_rot[b]); p.t = v3(w.s_trans[b]); }
     RP_DEV void load_vel(int side, int b, V3 &l, V3 &a) const { l = v3(w.s_lin[b]); a = v3(w.s_ang[b]); }
     RP_DEV void store_vel(int side, int b, V3 l, V3 a) const { w.s_lin[b] = f4(l, 0.0f); w.s_ang[b] = f4(a, 0.0f); }
@@ -188,7 +189,9 @@ struct PlainBodyIO {
 // the run-time-indexed general form is compiled out
 template <class IO, class SINK = JointRowsToPlanes, bool ONLY_SPHERICAL = false>
 RP_DEV void joint_update_one_t(const DevWorld &w, const IO &io, int j, int substep_id, const SINK &sink = SINK()) {
-    int b1 = w.j_b1[j], b2 = w.j_b2[j], locked = w.j_locked[j], limited = w.j_limited[j] & ~locked, motor = w.j_motor[j] & ~locked;
+    // (ONLY_SPHERICAL: the masks are known; an IO that already knows the joint's bodies — the tile sweeps: from the cone entry — says so)
+    int b1, b2; io.bodies(w, j, b1, b2);
+    const int locked = ONLY_SPHERICAL ? 0x7 : w.j_locked[j], limited = ONLY_SPHERICAL ? 0 : (w.j_limited[j] & ~locked), motor = ONLY_SPHERICAL ? 0 : (w.j_motor[j] & ~locked);
     Pose p1, p2; p1.r = q4(0, 0, 0, 1); p1.t = v3(0, 0, 0); p2 = p1;
     V3 im1 = v3(0, 0, 0), im2 = im1; Sym3 ii1 = {0, 0, 0, 0, 0, 0}, ii2 = ii1;
     if (b1 >= 0) { io.pose(0, b1, p1); im1 = v3(w.b_eim[b1]); float4 a = w.b_eii0[b1], b = w.b_eii1[b1]; ii1.m11 = a.x; ii1.m12 = a.y; ii1.m13 = a.z; ii1.m22 = a.w; ii1.m23 = b.x; ii1.m33 = b.y; }

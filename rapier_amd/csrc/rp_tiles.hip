@@ -500,8 +500,9 @@ struct TileJointIO {
 // has exactly three).  None of it changes during a sweep (the rows are rebuilt between sweeps, the sweep's own words go to the other
 // copy of DevWorld::jm), so the fetch of a thread's NEXT joint stage is issued a whole stage ahead.
 struct TileJointPre { int locked, limited, motor, b1, b2; V3 im1, im2; JointRowsT<3> R; };
-RP_DEV void tile_joint_fetch(const DevWorld &w, int j, TileJointPre &P) {
-    P.locked = w.j_locked[j]; P.limited = w.j_limited[j]; P.motor = w.j_motor[j]; P.b1 = w.j_b1[j]; P.b2 = w.j_b2[j];
+RP_DEV void tile_joint_fetch(const DevWorld &w, const int4 e, const int *Lg, TileJointPre &P) {
+    const int j = -1 - e.x;
+    P.locked = w.j_locked[j]; P.limited = w.j_limited[j]; P.motor = w.j_motor[j]; P.b1 = e.y >= 0 ? Lg[e.y] : -1; P.b2 = e.z >= 0 ? Lg[e.z] : -1;
     P.im1 = v3(JRP(JR_IM1, j)); P.im2 = v3(JRP(JR_IM2, j));
 #pragma unroll
     for (int q = 0; q < 3; ++q) jrow_load(w, j, q, P.R.c[q]);
@@ -511,7 +512,11 @@ RP_DEV void tile_joint_fetch(const DevWorld &w, int j, TileJointPre &P) {
 // into the solve, the owner instance stores them for the sweeps that follow.  k_ws_prepare then has no joint work: in a world without
 // contacts (b3d_joint_grid) it becomes an empty launch.  (The words a sweep changes: the rebuilt impulse seeds the solve, whose result
 // goes to the other copy of jm as ever; the copy being read is NOT written — halo instances of other tiles still read it.)
-struct TilePoseIO { const DevWorld &w; RP_DEV void pose(int side, int b, Pose &p) const { p.r = q4(w.s_rot[b]); p.t = v3(w.s_trans[b]); } };
+struct TilePoseIO {
+    const DevWorld &w; int b1, b2; // the joint's bodies (arena indices, -1 = world-attached side) from the cone entry's tile-local ids
+    RP_DEV void bodies(const DevWorld &, int, int &o1, int &o2) const { o1 = b1; o2 = b2; }
+    RP_DEV void pose(int side, int b, Pose &p) const { p.r = q4(w.s_rot[b]); p.t = v3(w.s_trans[b]); }
+};
 struct TileJointBuild {
     TileJointPre &P; bool own;
     RP_DEV void take3(const DevWorld &w, int j, JointRow (&r3)[3], V3 im1, V3 im2) const {
@@ -525,9 +530,9 @@ struct TileJointBuild {
         }
     }
 };
-RP_DEV void tile_joint_build(const DevWorld &w, const int4 e, int substep, TileJointPre &P) {
-    P.locked = 0x7; P.limited = 0; P.motor = 0; P.b1 = w.j_b1[-1 - e.x]; P.b2 = w.j_b2[-1 - e.x];
-    const TilePoseIO io = {w};
+RP_DEV void tile_joint_build(const DevWorld &w, const int4 e, const int *Lg, int substep, TileJointPre &P) {
+    P.locked = 0x7; P.limited = 0; P.motor = 0; P.b1 = e.y >= 0 ? Lg[e.y] : -1; P.b2 = e.z >= 0 ? Lg[e.z] : -1; // (no dependent load of j_b1 / j_b2)
+    const TilePoseIO io = {w, P.b1, P.b2};
     const TileJointBuild sink = {P, e.w != 0};
     joint_update_one_t<TilePoseIO, TileJointBuild, true>(w, io, -1 - e.x, substep, sink);
 }
@@ -591,16 +596,27 @@ __global__ void __launch_bounds__(RP_TILE_THREADS) k_tile_sweep(DevWorld w, int 
 #endif
     for (int tile = blockIdx.x; tile < NT; tile += gridDim.x) {
         __syncthreads();
-        const int nb = w.tl_hdr[tile].x;
-        for (int l = t; l < nb; l += nt) {
-            const int g = w.tl_bodies[(size_t)tile * RP_TILE_BCAP + l];
+        // one round trip for everything that only depends on the tile: the header, the body list (every thread asks for its
+        // RP_TILE_BCAP / 256 slots whatever the count turns out to be: the list is allocated in full), the stage offsets and — cones
+        // packed to the front of their list (k_tiles_cones: all but the very largest) — the thread's first list entry
+        const int4 *cons = w.tl_cons + (size_t)tile * RP_TILE_CCAP;
+        const int4 hdr = w.tl_hdr[tile];
+        int gl[RP_TILE_BCAP / RP_TILE_THREADS];
+#pragma unroll
+        for (int k = 0; k < RP_TILE_BCAP / RP_TILE_THREADS; ++k) gl[k] = w.tl_bodies[(size_t)tile * RP_TILE_BCAP + t + k * RP_TILE_THREADS];
+        const int4 e_first = cons[t];
+        for (int s = t; s <= nst + 3; s += nt) Soff[s] = w.tl_soff[(size_t)tile * (RP_TILE_STAGES + 1) + (s < nst ? s : nst)];
+        const int nb = hdr.x, n_owned = hdr.z; // (tile-local ids [0, n_owned) are the bodies the tile owns: k_tiles_cones inserts them first)
+#pragma unroll
+        for (int k = 0; k < RP_TILE_BCAP / RP_TILE_THREADS; ++k) {
+            const int l = t + k * RP_TILE_THREADS;
+            if (l >= nb) break;
+            const int g = gl[k];
             Lg[l] = g;
             if (fuse & 1) { V3 lin, ang; body_increment_ws(w, g, lin, ang); Ll[l] = f4(lin, 0.0f); La[l] = f4(ang, 0.0f); }
             else { Ll[l] = w.s_lin[g]; La[l] = w.s_ang[g]; }
         }
-        for (int s = t; s <= nst + 3; s += nt) Soff[s] = w.tl_soff[(size_t)tile * (RP_TILE_STAGES + 1) + (s < nst ? s : nst)];
         __syncthreads();
-        const int4 *cons = w.tl_cons + (size_t)tile * RP_TILE_CCAP;
         // the list entry (and point count) of a thread's next stage is fetched while it works on the current one: a stage then costs one
         // round trip (the rows) instead of two (branch-free: a load inside a conditional block is waited for at the end of the block).
         // (A deeper pipeline — entries two stages ahead, the rows of the next JOINT stage one ahead — was built and measured: the
@@ -621,13 +637,17 @@ __global__ void __launch_bounds__(RP_TILE_THREADS) k_tile_sweep(DevWorld w, int 
             const int j0 = Soff[0], nje = Soff[njs] - j0;
             if (nje <= nt) { // (tile-uniform)
                 int4 je = make_int4(0, 0, 0, 0); int jstage = -1; TileJointPre JP;
-                if (t < nje) {
-                    je = cons[j0 + t];
-                    jstage = 0; while (Soff[jstage + 1] - j0 <= t) ++jstage;
-                    if (MODE == MODE_BIAS && (fuse & 4)) tile_joint_build(w, je, fuse >> 8, JP);
-                    else tile_joint_fetch(w, -1 - je.x, JP);
-                }
                 TP_STAMP(0);
+                if (t < nje) {
+                    je = j0 == 0 ? e_first : cons[j0 + t];
+                    jstage = 0; while (Soff[jstage + 1] - j0 <= t) ++jstage;
+                    if (MODE == MODE_BIAS && (fuse & 4)) tile_joint_build(w, je, Lg, fuse >> 8, JP);
+                    else tile_joint_fetch(w, je, Lg, JP);
+                }
+#ifdef RP_TILE_PROFILE
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                TP_STAMP(3); // every joint of the cone prepared (rows rebuilt / fetched)
                 for (int s = 0; s < njs; ++s) {
                     if (jstage == s) tile_apply_joint(w, je, JP, Ll, La, MODE == MODE_RELAX, joint_warmstart != 0);
                     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -641,8 +661,8 @@ __global__ void __launch_bounds__(RP_TILE_THREADS) k_tile_sweep(DevWorld w, int 
                         if (LP && (t & 1)) continue; // one lane per joint (the even lane of a pair)
                         const int4 e = cons[i];
                         TileJointPre P;
-                        if (MODE == MODE_BIAS && (fuse & 4)) tile_joint_build(w, e, fuse >> 8, P);
-                        else tile_joint_fetch(w, -1 - e.x, P);
+                        if (MODE == MODE_BIAS && (fuse & 4)) tile_joint_build(w, e, Lg, fuse >> 8, P);
+                        else tile_joint_fetch(w, e, Lg, P);
                         tile_apply_joint(w, e, P, Ll, La, MODE == MODE_RELAX, joint_warmstart != 0);
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -670,9 +690,8 @@ __global__ void __launch_bounds__(RP_TILE_THREADS) k_tile_sweep(DevWorld w, int 
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             TP_STAMP(4 + (s < 16 ? s : 16));
         }
-        for (int l = t; l < nb; l += nt) {
+        for (int l = t; l < n_owned; l += nt) {
             const int g = Lg[l];
-            if (w.tl_body_tile[g] != tile) continue;
             if (fuse & 2) {
                 V3 lin = v3(Ll[l]), ang = v3(La[l]), trans = v3(w.s_trans[g]); Q4 rot = q4(w.s_rot[g]);
                 body_integrate(w, w.b_flags[g], lin, ang, rot, trans);

@@ -23,4 +23,4 @@ for mode, name in ((0, "biased"), (1, "relaxed")):
     r = prof[24 * mode: 24 * mode + 24]
     if r[2]:
         n = float(r[2])
-        print(f"tile 0 {name} sweep ({int(n)} launches): load {r[0] / n / 100:.2f} us, store {r[1] / n / 100:.2f} us, stages " + " ".join(f"{r[4 + k] / n / 100:.2f}" for k in range(17) if r[4 + k]))
+        print(f"tile 0 {name} sweep ({int(n)} launches): load {r[0] / n / 100:.2f} us, joint prepare {r[3] / n / 100:.2f} us, store {r[1] / n / 100:.2f} us, stages " + " ".join(f"{r[4 + k] / n / 100:.2f}" for k in range(17) if r[4 + k]))
