@@ -379,8 +379,12 @@ __global__ void __launch_bounds__(1024) k_layout_rebuild(DevWorld w) {
     GBAR_SYNC(bar); RP_PASS_STAMP(w, 200);
     lay_bucket_scatter(w, gid, gstride, lds_a, lds_b);
     GBAR_SYNC(bar); RP_PASS_STAMP(w, 200);
-    if (blockIdx.x == 0) lay_rank_overflow(w);
-    GBAR_SYNC(bar); RP_PASS_STAMP(w, 200);
+    // (the overflow colour is ranked by workgroup 0 behind one more barrier — which a world without a global-path manifold in that
+    // colour does not pay: FL_HAS_OVERFLOW_COLOR was written two barriers ago, every workgroup reads the same value)
+    if (ld_i32(&w.flags[FL_HAS_OVERFLOW_COLOR])) {
+        if (blockIdx.x == 0) lay_rank_overflow(w);
+        GBAR_SYNC(bar); RP_PASS_STAMP(w, 200);
+    }
     gbar_end(bar);
     if (gid == 0) { w.flags[FL_UF_NPAIRS] = 0; __hip_atomic_store(&w.flags[FL_LAYOUT_DIRTY], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 }

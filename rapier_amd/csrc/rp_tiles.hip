@@ -60,6 +60,26 @@ __global__ void __launch_bounds__(1024) k_tiles_sort(DevWorld w) {
         return;
     }
     GridBar bar = gbar_begin(w, 4);
+    // pass R: can the last partition stay?  A tiling only schedules the work — any partition of the global-path bodies gives the same
+    // bits — so the five passes of the sort are only needed when the SET of global-path bodies changed (or bodies came / went); a
+    // layout change of a settling pile (pairs begin / end to touch) leaves it alone.  One pass and one barrier: every body compares what
+    // it is now with what the last sort made of it.  Every 32nd time the sort runs anyway (bodies drift along the curve).
+    // tl_bbox[11]: scratch of this pass, [12]: tiles of the last sort that fitted, [13]: reuses in a row
+    const bool reusable = w.tl_bbox[8] != 0u && (int)w.tl_bbox[9] == nb && w.tl_bbox[12] != 0u && w.tl_bbox[13] < 32u; // (written behind the last barrier of a launch: uniform)
+    if (reusable) {
+        bool differs = false;
+        for (int i = gid; i < nb; i += gstride) differs |= (w.tl_body_tile[i] >= 0) != global_body(w, i);
+        if (__any(differs) && (t & 63) == 0) atomicOr(&w.tl_bbox[11], 1u);
+        for (int pos = gid; pos < M; pos += gstride) { int a, b; flow_ids(w, pos, a, b); w.fk_ids[pos] = make_int2(a, b); } // (what pass 0 of the sort would have done for the cones)
+        GBAR_SYNC(bar);
+        if (__hip_atomic_load(&w.tl_bbox[11], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            if (gid == 0) { w.flags[FL_N_TILES] = (int)w.tl_bbox[12]; w.tl_bbox[13] += 1u; w.dbg[909] += 1; w.dbg[905] = 0; w.dbg[906] = 0; w.dbg[907] = 0; w.dbg[908] = 0; }
+            gbar_end(bar);
+            return;
+        }
+        GBAR_SYNC(bar); // (every workgroup has read the verdict before it is cleared)
+        if (gid == 0) w.tl_bbox[11] = 0u;
+    }
     // pass 0: the solver bodies of every position; bounding box of the centres of mass (tl_bbox rests at min = ~0, max = 0)
     for (int pos = gid; pos < M; pos += gstride) { int a, b; flow_ids(w, pos, a, b); w.fk_ids[pos] = make_int2(a, b); }
     for (int i0 = gid - (t & 63); i0 < nb; i0 += gstride) { // (wave-uniform trip count: one atomic per wavefront and bound, not per body)
@@ -153,6 +173,7 @@ __global__ void __launch_bounds__(1024) k_tiles_sort(DevWorld w) {
     if (gid == 0) { // (dbg[900..]: statistics of the last tiling, tools/tile_diag.py)
         w.flags[FL_N_TILES] = fits ? NT : 0;
         w.tl_bbox[7] = (unsigned)T; w.tl_bbox[8] = 1u; w.tl_bbox[9] = (unsigned)nb; // [8]: the sort ran — k_tiles_cones derives b_order from it
+        w.tl_bbox[12] = fits ? (unsigned)NT : 0u; w.tl_bbox[13] = 0u;
         w.dbg[900] += 1; w.dbg[901] = fits ? 0 : 2; w.dbg[902] = NG; w.dbg[903] = NT; w.dbg[904] = T; w.dbg[905] = 0; w.dbg[906] = 0; w.dbg[907] = 0; w.dbg[908] = 0;
     }
     // the scratch of the sort goes back to its rest state once the ranks are out: by the cone kernel (next launch: a kernel boundary)
