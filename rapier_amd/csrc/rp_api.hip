@@ -62,7 +62,7 @@ void rp_launch_solver_assembly(const DevWorld &w, hipStream_t st, int lean);
 int rp_launch_solver_loop(const DevWorld &w, hipStream_t st, int parallel_stages, int stage_blocks, int has_restitution, int joint_stages, int tile_grid, int no_contacts_hint);
 void rp_launch_solver_writeback(const DevWorld &w, hipStream_t st, int parity, int publish);
 bool rp_ccd_launches(const DevWorld &w);
-void rp_launch_island_solve(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast, int retire, int fused);
+void rp_launch_island_solve(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast, int retire, int fused, int dense);
 void rp_launch_global_single(const DevWorld &w, hipStream_t st, int has_restitution, int fast);
 void rp_launch_fast_front(const DevWorld &w, hipStream_t st, int no_global_kernel);
 void rp_launch_wake(const DevWorld &w, hipStream_t st, int phase);
@@ -97,7 +97,7 @@ static int gbar_grid_for_device(int device) {
     if (device >= 0 && device < 64) cached[device] = g;
     return g;
 }
-int rp_fused_grid(int device);
+int rp_fused_grid(int device); int rp_fused_grid_dense(int device);
 
 struct HostBody {
     rp_body_desc d; float inv_mass; float inv_pi[3]; float lcom[3]; int ncolliders; bool removed;
@@ -157,6 +157,7 @@ struct rp_world {
     hipGraphExec_t ge_whole[3] = {nullptr, nullptr, nullptr}, ge_col[3] = {nullptr, nullptr, nullptr}, ge_loop[3] = {nullptr, nullptr, nullptr}, ge_fin[3] = {nullptr, nullptr, nullptr};
     int graph_stages = -1, graph_blocks = -1, graph_single = -1, graph_island_grid = -1, graph_joint_stages = -1, graph_no_global = -1, graph_fused = -1, graph_tile_grid = -1, graph_no_contacts = -1, graph_bare = -1;
     bool use_graph = true, use_fast = true, use_fused = true;
+    bool force_dense = false;      // RP_ISL_DENSE=1 (tests): the dense form of k_island_solve whatever the island count
     bool use_lean = true;          // the lean step graph of MULTI-mode worlds (below: "lean graph"); RP_NO_LEAN=1: never
     int cur_lean = 0;              // the enqueue_* callbacks capture / launch the lean graph (with dw_lean)
     DevWorld dw_lean;              // dw with lean = 1: the kernel argument of a lean graph's launches
@@ -167,6 +168,7 @@ struct rp_world {
     bool force_flow = false;
     int flow_grid = 0;             // workgroups of the dataflow launch (all resident at once), 0 = unavailable
     int fused_grid = 0;            // most workgroups a fused fast step may use (all resident at once), 0 = no fused step on this device
+    int fused_grid_dense = 0;      // the same for the dense form of k_island_solve (two islands per CU), 0 = that form is not used
     bool has_bullets = false;      // some dynamic body has ccd_enabled: the continuous-collision pass runs its second tier
     float min_ccd_thickness = 3.402823466e+38f; // thinnest dynamic body (the fused single-kernel step needs it above the fat-AABB margin)
     bool compound = false;         // some dynamic body carries several colliders or an offset collider (no fused fast step)
@@ -399,6 +401,7 @@ extern "C" int32_t rp_world_create(const rp_integration_params *params, const fl
     if (g && g[0] == '1') w->force_flow = true;
     if (w->use_flow) { w->flow_grid = rp_flow_grid(device); if (w->flow_grid <= 0) w->use_flow = false; }
     if (w->use_fused) { w->fused_grid = rp_fused_grid(device); if (w->fused_grid <= 0) w->use_fused = false; }
+    { const char *nd = getenv("RP_NO_ISL_DENSE"); w->fused_grid_dense = (nd && nd[0] == '1') ? 0 : rp_fused_grid_dense(device); if (const char *fd = getenv("RP_ISL_DENSE")) if (fd[0] == '1' && w->fused_grid_dense > 0) w->force_dense = true; }
     memset(&w->dw, 0, sizeof(w->dw));
     *out = w;
     return RP_OK;
@@ -1434,8 +1437,14 @@ static void enqueue_island_solver(rp_world *w) {
     const int fused = (w->cur_fast && w->plan_fused) ? 1 : 0;
     if (w->cur_lean && (w->dw_lean.lean & 2)) return; // a bare lean graph: no island exists (verified by lean_dead in every kernel of the graph)
     // every workgroup of the fused step must be resident at once: the grid is capped by what the device can hold (rp_fused_grid)
-    rp_launch_island_solve(w->cur_lean ? w->dw_lean : w->dw, w->stream, fused ? std::min(w->plan_island_grid, w->fused_grid) : w->plan_island_grid,
-                           w->has_restitution ? 1 : 0, w->cur_fast, w->plan_single, fused);
+    // the dense form of the kernel (two islands per CU, rp_islands.hip)
+    // (Opt-in, RP_ISL_DENSE=1: measured on MI355X in round 4 it LOSES — profiles/r04_island_dense_experiment.txt, DESIGN.md section 4.1:
+    // the 168-VGPR budget costs 528 B of scratch per lane and +50 % per island, and two such workgroups on one CU take twice the time of
+    // one.  It stays as the measured answer to "two islands per CU", not as a launch path the planner picks.)
+    const int dense = (w->fused_grid_dense > 0 && w->force_dense) ? 1 : 0;
+    const int cap = dense ? w->fused_grid_dense : w->fused_grid;
+    rp_launch_island_solve(w->cur_lean ? w->dw_lean : w->dw, w->stream, fused ? std::min(w->plan_island_grid, cap) : w->plan_island_grid,
+                           w->has_restitution ? 1 : 0, w->cur_fast, w->plan_single, fused, dense);
 }
 // MULTI mode of the global path, measured on MI355X: contact-only worlds under the twist model are fastest
 // with one launch per colour stage + the body-centric warm start (b3d_large_pyramid 0.81 ms against 0.94 ms); worlds with impulse

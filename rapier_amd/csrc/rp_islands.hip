@@ -557,7 +557,12 @@ RP_DEV void isl_pose_stage(const DevWorld &w, IslSide &h, const IslLds &L, int m
 // (isl_ws_terms) and the thread that owns a body adds them in exactly that order (isl_ws_accumulate):
 // 2 stages per substep instead of one per colour, same additions, same order, same bits.
 #define WS_SLOTS 11   // per lane: 4 x (lin, ang) point terms, tangent lin, tangent ang, twist ang
+#define WS_SLOTS_2PHASE 6 // the two-phase form (dense variant of the kernel): the linear terms (5 slots), then — same rows — the angular ones (6)
 #define WS_STRIDE (ISL_LANES + 2) // rows of one slot: every lane's row + two scratch rows for world-attached sides
+// PHASE 0: every term at once (11 slots).  PHASE 1 / 2: the update + the linear terms, then the angular terms into the SAME rows after
+// the owners of the linear halves have read theirs — 31 KB of LDS instead of 57 KB, which is what lets two islands share a CU.  Slot
+// map of the two-phase form: point k -> slot k, tangent -> slot 4 (.w = point count in both phases), twist -> slot 5.
+template <int PHASE>
 RP_DEV void isl_ws_terms(const DevWorld &w, IslSide &h, float4 *W, int t) { // t = this lane's row in W (its rank in its body's list)
     float wc = w.prm.p.warmstart_coefficient;
     bool ws = wc != 0.0f;
@@ -565,36 +570,48 @@ RP_DEV void isl_ws_terms(const DevWorld &w, IslSide &h, float4 *W, int t) { // t
     for (int k = 0; k < 4; ++k) {
         if (k >= h.n) break;
         SidePoint &p = h.P[k];
-        p.rhs = p.rhsB; p.cfm = p.cfmB;
-        p.acc += p.lam;
-        p.lam *= wc;
+        if (PHASE != 2) {
+            p.rhs = p.rhsB; p.cfm = p.cfmB;
+            p.acc += p.lam;
+            p.lam *= wc;
+        }
         if (ws) {
             float lam = dppf<DPP_FROM_EVEN>(p.lam);
-            W[(2 * k) * WS_STRIDE + t] = f4(h.sdim * lam, 0.0f);
-            W[(2 * k + 1) * WS_STRIDE + t] = f4(p.pc * lam, 0.0f);
+            if (PHASE == 0) { W[(2 * k) * WS_STRIDE + t] = f4(h.sdim * lam, 0.0f); W[(2 * k + 1) * WS_STRIDE + t] = f4(p.pc * lam, 0.0f); }
+            else if (PHASE == 1) W[k * WS_STRIDE + t] = f4(h.sdim * lam, 0.0f);
+            else W[k * WS_STRIDE + t] = f4(p.pc * lam, 0.0f);
         }
     }
-    h.t_rhs0 = h.rhs_wo0 + h.tb0; h.t_rhs1 = h.rhs_wo1 + h.tb1;
-    h.t_acc0 += h.t_imp0; h.t_acc1 += h.t_imp1;
-    h.t_imp0 *= wc; h.t_imp1 *= wc;
-    h.tw_acc += h.tw_imp;
-    h.tw_imp *= wc;
+    if (PHASE != 2) {
+        h.t_rhs0 = h.rhs_wo0 + h.tb0; h.t_rhs1 = h.rhs_wo1 + h.tb1;
+        h.t_acc0 += h.t_imp0; h.t_acc1 += h.t_imp1;
+        h.t_imp0 *= wc; h.t_imp1 *= wc;
+        h.tw_acc += h.tw_imp;
+        h.tw_imp *= wc;
+    }
     if (ws) {
         float i0 = dppf<DPP_FROM_EVEN>(h.t_imp0), i1 = dppf<DPP_FROM_EVEN>(h.t_imp1);
         float s0 = h.odd ? -i0 : i0, s1 = h.odd ? -i1 : i1;
-        W[8 * WS_STRIDE + t] = f4(cmul(h.t0 * s0 + h.t1 * s1, h.im), __int_as_float(h.n));
-        W[9 * WS_STRIDE + t] = f4(h.itd0 * i0 + h.itd1 * i1, 0.0f);
         float tw = dppf<DPP_FROM_EVEN>(h.tw_imp);
-        if (h.n > 1) W[10 * WS_STRIDE + t] = f4(h.stw * tw, 0.0f);
+        if (PHASE == 0) {
+            W[8 * WS_STRIDE + t] = f4(cmul(h.t0 * s0 + h.t1 * s1, h.im), __int_as_float(h.n));
+            W[9 * WS_STRIDE + t] = f4(h.itd0 * i0 + h.itd1 * i1, 0.0f);
+            if (h.n > 1) W[10 * WS_STRIDE + t] = f4(h.stw * tw, 0.0f);
+        } else if (PHASE == 1) W[4 * WS_STRIDE + t] = f4(cmul(h.t0 * s0 + h.t1 * s1, h.im), __int_as_float(h.n));
+        else {
+            W[4 * WS_STRIDE + t] = f4(h.itd0 * i0 + h.itd1 * i1, __int_as_float(h.n));
+            if (h.n > 1) W[5 * WS_STRIDE + t] = f4(h.stw * tw, 0.0f);
+        }
     }
 }
 // one thread adds the linear terms of a body, another one (64 lanes further) its angular terms
+template <bool TWO>
 RP_DEV void isl_ws_accumulate_lin(const float4 *W, int begin, int count, V3 &lin) {
 #pragma unroll 2
     for (int e = 0; e < count; ++e) {
         const int row = begin + e;
-        float4 tl = W[8 * WS_STRIDE + row];
-        float4 l0 = W[0 * WS_STRIDE + row], l1 = W[2 * WS_STRIDE + row], l2 = W[4 * WS_STRIDE + row], l3 = W[6 * WS_STRIDE + row];
+        float4 tl = W[(TWO ? 4 : 8) * WS_STRIDE + row];
+        float4 l0 = W[0 * WS_STRIDE + row], l1 = W[(TWO ? 1 : 2) * WS_STRIDE + row], l2 = W[(TWO ? 2 : 4) * WS_STRIDE + row], l3 = W[(TWO ? 3 : 6) * WS_STRIDE + row];
         const int n = __float_as_int(tl.w);
         lin = lin + v3(l0);
         if (n > 1) lin = lin + v3(l1);
@@ -603,12 +620,13 @@ RP_DEV void isl_ws_accumulate_lin(const float4 *W, int begin, int count, V3 &lin
         lin = lin + v3(tl);
     }
 }
+template <bool TWO>
 RP_DEV void isl_ws_accumulate_ang(const float4 *W, int begin, int count, V3 &ang) {
 #pragma unroll 2
     for (int e = 0; e < count; ++e) {
         const int row = begin + e;
-        float4 tl = W[8 * WS_STRIDE + row], ta = W[9 * WS_STRIDE + row], tw = W[10 * WS_STRIDE + row];
-        float4 a0 = W[1 * WS_STRIDE + row], a1 = W[3 * WS_STRIDE + row], a2 = W[5 * WS_STRIDE + row], a3 = W[7 * WS_STRIDE + row];
+        float4 tl = W[(TWO ? 4 : 8) * WS_STRIDE + row], ta = TWO ? tl : W[9 * WS_STRIDE + row], tw = W[(TWO ? 5 : 10) * WS_STRIDE + row];
+        float4 a0 = W[(TWO ? 0 : 1) * WS_STRIDE + row], a1 = W[(TWO ? 1 : 3) * WS_STRIDE + row], a2 = W[(TWO ? 2 : 5) * WS_STRIDE + row], a3 = W[(TWO ? 3 : 7) * WS_STRIDE + row];
         const int n = __float_as_int(tl.w);
         ang = ang + v3(a0);
         if (n > 1) ang = ang + v3(a1);
@@ -746,7 +764,15 @@ RP_DEV void island_sort(const DevWorld &w, int isl, int nc, int cb, int nst_glob
 // runs meanwhile; nothing is written back until every workgroup has arrived (~70 us later: the wait is
 // free) and no abort was raised.  An aborted launch leaves the world untouched and the host replays the
 // step on the full graph.  Needs every workgroup resident at once: the grid is capped below the CU count.
-__global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int has_restitution, int fast, int retire, int fused) {
+// DENSE = false: 512 threads, every warm-start term at once (57 KB of W), 256 VGPRs: ONE island per CU — the fastest form per island,
+//   chosen while the islands fit one pass of the resident grid (b3d_many_pyramids: 196 islands on 256 CUs).
+// DENSE = true: 320 threads (the 2 x 160 manifold lanes and nothing else), two-phase warm-start terms (31 KB of W), the register budget
+//   of three waves per SIMD: TWO islands per CU — each somewhat slower, the CU twice as busy; chosen when there are more islands than
+//   the resident grid of the other form holds (b3d_many_pyramids at C4's density: 365 islands per GPU, 2,916 on one GPU).  No idle
+//   wavefront is left to validate a fused step under cover of generate: every island of the workgroup is validated in the prologue.
+template <bool DENSE>
+__device__ __forceinline__ void island_solve_body(const DevWorld &w, int has_restitution, int fast, int retire, int fused) {
+    constexpr int THREADS = DENSE ? ISL_THREADS_DENSE : ISL_THREADS;
     const bool aborted = (fast && w.flags[FL_FAST_ABORT]) || lean_dead(w); // fast graph gave up on this step (rp_api.hip) / dead lean step (rp_world.h)
     if (retire && blockIdx.x == 0) {
         // SINGLE mode: workgroup 0 retires the step and publishes the scalars to the host hint buffer
@@ -773,7 +799,7 @@ __global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int ha
         }
         __syncthreads();
         bool bad = false;
-        for (int isl = blockIdx.x + gridDim.x; isl < n_islands; isl += gridDim.x) {
+        for (int isl = blockIdx.x + (DENSE ? 0 : gridDim.x); isl < n_islands; isl += gridDim.x) {
             const int nb = w.isl_nb[isl], nc = w.isl_nc[isl], ni = w.isl_ni[isl];
             const int bb = w.isl_body_begin[isl], cb = w.isl_cons_begin[isl], ib = w.isl_icons_begin[isl];
             for (int i = t; i < nb; i += blockDim.x) { int c = w.b_collider[w.isl_bodies[bb + i]]; if (c >= 0 && collider_left_fat_aabb(w, c)) bad = true; }
@@ -793,7 +819,7 @@ __global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int ha
     __shared__ float4 B_lin[RP_ISL_NB_MAX], B_ang[RP_ISL_NB_MAX], B_rot[RP_ISL_NB_MAX], B_trans[RP_ISL_NB_MAX];
     __shared__ float4 L_E[4 * RP_ISL_NC_MAX], L_F[4 * RP_ISL_NC_MAX], L_B0[RP_ISL_NC_MAX], L_B1[RP_ISL_NC_MAX];
     __shared__ int S_a[RP_ISL_NC_MAX], S_b[RP_ISL_NC_MAX], S_c[RP_ISL_NC_MAX], S_d[RP_ISL_NC_MAX];
-    __shared__ float4 W[WS_SLOTS * WS_STRIDE];
+    __shared__ float4 W[(DENSE ? WS_SLOTS_2PHASE : WS_SLOTS) * WS_STRIDE];
     __shared__ int any_bouncy;
 
     const int t = threadIdx.x, m = t >> 1;
@@ -853,11 +879,11 @@ __global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int ha
             if (isl_generate(w, h, L, m, slot, own_g, own_l, odd, pair_static) && !odd) any_bouncy = 1;
         }
         const int v_first = (2 * nc + 63) & ~63; // first wavefront without any manifold lane
-        if (fused && isl == (int)blockIdx.x && t >= v_first) {
+        if (!DENSE && fused && isl == (int)blockIdx.x && t >= v_first) {
             // the wavefronts without a manifold prove, under cover of generate (the longest interval of the
             // kernel), that this island needs neither broad nor narrow phase this step: one item (a body's
             // collider, an active pair, a pair without solver contacts) per lane and round
-            const int vt = t - v_first, vn = ISL_THREADS - v_first;
+            const int vt = t - v_first, vn = THREADS - v_first;
             const int ni = w.isl_ni[isl], ib = w.isl_icons_begin[isl];
             bool bad = false;
             for (int i = vt; i < nb + nc + ni; i += vn) {
@@ -872,22 +898,33 @@ __global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int ha
 
         for (int sub = 0; sub < w.prm.num_substeps; ++sub) {
             float solved_dt = (float)sub * w.prm.dt_sub;
-            if (live) isl_ws_terms(w, h, W, ws_row); // warm-start terms of every manifold, in parallel
+            if (live) isl_ws_terms<DENSE ? 1 : 0>(w, h, W, ws_row); // warm-start terms of every manifold, in parallel
             __syncthreads(); // + pose stage read rot/trans; relax sweep of the previous substep done
             if (fused && sub == 0 && isl == (int)blockIdx.x && t == 0) atomicAdd(&w.flags[FL_ARRIVE], 1 + (s_abort ? (1 << 16) : 0)); // this workgroup validated all of its islands
             ISL_STAMP(2); // warm-start terms
             // S2 increment (worker.rs:235-284), then the warm start of this body in sweep order
             if (role_lin) {
                 V3 lin = v3(B_lin[bt]) + b_incl;
-                if (prm.warmstart_coefficient != 0.0f) isl_ws_accumulate_lin(W, inc_begin, inc_cnt, lin);
+                if (prm.warmstart_coefficient != 0.0f) isl_ws_accumulate_lin<DENSE>(W, inc_begin, inc_cnt, lin);
                 B_lin[bt] = f4(lin, 0.0f);
-            } else if (role_ang) {
+            } else if (!DENSE && role_ang) {
                 V3 lin_unused = v3(0, 0, 0), ang = v3(B_ang[bt]);
                 body_increment(w, b_fl, lin_unused, ang, q4(B_rot[bt]), v3(0, 0, 0), b_inca, b_invpi, b_pframe);
-                if (prm.warmstart_coefficient != 0.0f) isl_ws_accumulate_ang(W, inc_begin, inc_cnt, ang);
+                if (prm.warmstart_coefficient != 0.0f) isl_ws_accumulate_ang<false>(W, inc_begin, inc_cnt, ang);
                 B_ang[bt] = f4(ang, 0.0f);
             }
             __syncthreads();
+            if (DENSE) { // second phase: the angular terms into the rows the linear halves have just been read from
+                if (live && prm.warmstart_coefficient != 0.0f) isl_ws_terms<2>(w, h, W, ws_row);
+                __syncthreads();
+                if (role_ang) {
+                    V3 lin_unused = v3(0, 0, 0), ang = v3(B_ang[bt]);
+                    body_increment(w, b_fl, lin_unused, ang, q4(B_rot[bt]), v3(0, 0, 0), b_inca, b_invpi, b_pframe);
+                    if (prm.warmstart_coefficient != 0.0f) isl_ws_accumulate_ang<true>(W, inc_begin, inc_cnt, ang);
+                    B_ang[bt] = f4(ang, 0.0f);
+                }
+                __syncthreads();
+            }
             ISL_STAMP(3); // increment + body-centric warm start
 #ifdef RP_ISL_EXTRA_EMPTY // overhead measurement only: one extra sweep of empty stages (velocity read/write + barrier)
             for (int q = 0; q < nls; ++q) { if (myq == q) { Vel v = isl_vel(L, h.id); isl_set_vel(L, h.id, v); } __syncthreads(); }
@@ -961,6 +998,10 @@ __global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int ha
         }
     }
 }
+
+__global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int has_restitution, int fast, int retire, int fused) { island_solve_body<false>(w, has_restitution, fast, retire, fused); }
+// (three waves per SIMD = 168 VGPRs: with 320-thread workgroups and 63 KB of LDS that is two islands per CU)
+__global__ void __launch_bounds__(ISL_THREADS_DENSE) __attribute__((amdgpu_waves_per_eu(3, 3))) k_island_solve_dense(DevWorld w, int has_restitution, int fast, int retire, int fused) { island_solve_body<true>(w, has_restitution, fast, retire, fused); }
 
 // ---- the generic island kernel ----------------------------------------------------------------------------------------------------
 // One workgroup = one island, like k_island_solve, but the constraint is the HBM-resident one of the global path (rp_constraint.h /
@@ -1089,11 +1130,25 @@ int rp_fused_grid(int device) {
     if (device >= 0 && device < 64) cached[device] = g;
     return g;
 }
-void rp_launch_island_solve(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast, int retire, int fused) {
+// the same for the dense form of the kernel (two islands per CU when the occupancy answer allows it; 0 = not better than the other form)
+int rp_fused_grid_dense(int device) {
+    static int cached[64] = {0};
+    if (device >= 0 && device < 64 && cached[device]) return cached[device] > 0 ? cached[device] : 0;
+    hipDeviceProp_t prop;
+    int per_cu = 0, cus = 0;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_island_solve_dense, ISL_THREADS_DENSE, 0) != hipSuccess) per_cu = 0;
+    int g = 0;
+    if (per_cu >= 2 && cus >= 1) { g = cus * 2 - (cus + 15) / 16; }
+    if (device >= 0 && device < 64) cached[device] = g > 0 ? g : -1;
+    return g;
+}
+void rp_launch_island_solve(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast, int retire, int fused, int dense) {
     if (grid < 1) grid = 1;
     if (w.prm.p.friction_model == RP_FRICTION_COULOMB) { hipLaunchKernelGGL(k_island_generic<true>, dim3(grid), dim3(ISL_THREADS), 0, st, w, has_restitution, fast, retire); return; }
     if (w.isl_generic) { hipLaunchKernelGGL(k_island_generic<false>, dim3(grid), dim3(ISL_THREADS), 0, st, w, has_restitution, fast, retire); return; } // RP_ISL_GENERIC=1: the twist model through the generic kernel (tests)
-    hipLaunchKernelGGL(k_island_solve, dim3(grid), dim3(ISL_THREADS), 0, st, w, has_restitution, fast, retire, fused);
+    if (dense) hipLaunchKernelGGL(k_island_solve_dense, dim3(grid), dim3(ISL_THREADS_DENSE), 0, st, w, has_restitution, fast, retire, fused);
+    else hipLaunchKernelGGL(k_island_solve, dim3(grid), dim3(ISL_THREADS), 0, st, w, has_restitution, fast, retire, fused);
 }
 
 // workgroups of k_layout_rebuild (1024 threads) one CU holds at once (0 = the query failed): input of DevWorld::gbar_blocks (rp_api.hip)

@@ -31,6 +31,7 @@ RP_DEV Xf isl_xf(const IslLds &L, int id) {
 // so the results stay bit-identical to the single-lane form and to the oracle.
 #define ISL_LANES (2 * RP_ISL_NC_MAX)   // lanes 2m, 2m+1 = manifold m
 #define ISL_THREADS 512                  // the lanes beyond an island's 2 * nc only validate the step (fused fast path)
+#define ISL_THREADS_DENSE ISL_LANES      // the dense form of k_island_solve (rp_islands.hip): the manifold lanes and nothing else
 #define DPP_FROM_ODD 0xF5   // quad_perm [1,1,3,3]: both lanes of a pair read the odd lane
 #define DPP_FROM_EVEN 0xA0  // quad_perm [0,0,2,2]: both lanes of a pair read the even lane
 template <int CTRL> RP_DEV float dppf(float x) {
