@@ -830,6 +830,7 @@ extern "C" int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider
         }
         if (cd.shape == RP_SHAPE_CAPSULE && (cd.half_extents[2] != 0.0f && cd.half_extents[2] != 1.0f && cd.half_extents[2] != 2.0f)) { w->err = "rp_colliders_insert: capsule half_extents = (half_height, radius, axis) with axis 0, 1 or 2"; return RP_ERR_INVALID; }
     }
+    if ((long long)w->colliders.size() + n >= (1ll << 24)) { w->err = "rp_colliders_insert: more than 2^24 - 1 colliders (the broad-phase grid's one-word entries)"; return RP_ERR_CAPACITY; }
     const bool in_place = w->finalized && (int)w->colliders.size() + n <= w->cap_colliders; // see rp_bodies_insert
     if (n > 0 && w->finalized) {
         HIPCHK(w, hipSetDevice(w->device));
@@ -1205,7 +1206,7 @@ static int finalize(rp_world *w) {
     for (int k = 0; k < 2; ++k) { DA(d.bk_cnt[k], d.grid_cap); DA(d.bk_items[k], (size_t)d.grid_cap * RP_BP_BUCKET); } // the broad-phase grid: fixed-slot hash buckets, two copies (rp_broadphase.hip)
     DA(d.scan_block, 1024 + 8); // the scratch counters of a running broad-phase rebuild
     DA(d.large_list, d.large_cap);
-    DA(d.c_chgstamp, capc); DA(d.c_stale, capc); DA(d.c_inlarge, capc); DA(d.bp_chg_list, capc); DA(d.bp_moved_list, RP_BP_MOVED_CAP); // incremental broad phase (scratch: rebuilt by the next full pass)
+    DA(d.c_chgstamp, capc); DA(d.c_stale, capc); DA(d.c_inlarge, capc); DA(d.c_rver, capc); DA(d.bp_chg_list, capc); DA(d.bp_moved_list, RP_BP_MOVED_CAP); // incremental broad phase (scratch: rebuilt by the next full pass)
     DAF(d.h_key[0], d.hash_cap, 0xff); DAF(d.h_key[1], d.hash_cap, 0xff); DA(d.h_slot[0], d.hash_cap); DA(d.h_slot[1], d.hash_cap);
     DAC(d.free_stack, d.pool_cap, DOM_PAIR, 1, 1);
     size_t P = (size_t)d.pool_cap;
@@ -1628,7 +1629,32 @@ static int step_once(rp_world *w, bool allow_fast) {
                 const long long req = w->steps_requested, full_until = w->full_until;
                 const int nb0 = w->dw.n_bodies;
                 std::vector<float4> uf(nb0), ut(nb0); std::vector<int> wr(nb0);
-                if ((r = download_rows(w)) != RP_OK) return r;
+                {   // only the rows the user wrote: a row that still holds what finalize() uploaded keeps its host mirror untouched (taking
+                    // it back would run the mirror's quaternion through pack_body's normalisation a second time: not the oracle's bits)
+                    std::vector<float4> pos(nb0), rot(nb0), lv(nb0), av(nb0), npos(nb0), nrot(nb0);
+                    if (nb0 > 0) {
+                        HIPCHK(w, hipMemcpy(pos.data(), w->dw.b_pos, (size_t)nb0 * sizeof(float4), hipMemcpyDeviceToHost));
+                        HIPCHK(w, hipMemcpy(rot.data(), w->dw.b_rot, (size_t)nb0 * sizeof(float4), hipMemcpyDeviceToHost));
+                        HIPCHK(w, hipMemcpy(lv.data(), w->dw.b_linvel, (size_t)nb0 * sizeof(float4), hipMemcpyDeviceToHost));
+                        HIPCHK(w, hipMemcpy(av.data(), w->dw.b_angvel, (size_t)nb0 * sizeof(float4), hipMemcpyDeviceToHost));
+                        HIPCHK(w, hipMemcpy(npos.data(), w->dw.b_next_pos, (size_t)nb0 * sizeof(float4), hipMemcpyDeviceToHost));
+                        HIPCHK(w, hipMemcpy(nrot.data(), w->dw.b_next_rot, (size_t)nb0 * sizeof(float4), hipMemcpyDeviceToHost));
+                    }
+                    auto same = [](const float4 &a, const float4 &b) { return memcmp(&a, &b, sizeof(float4)) == 0; };
+                    for (int i = 0; i < nb0; ++i) {
+                        HostBody &hb = w->bodies[i];
+                        const BodyRow up = pack_body(hb);
+                        rp_body_desc &d = hb.d;
+                        if (!same(pos[i], up.pos)) { d.translation[0] = pos[i].x; d.translation[1] = pos[i].y; d.translation[2] = pos[i].z; }
+                        if (!same(rot[i], up.rot)) { d.rotation[0] = rot[i].x; d.rotation[1] = rot[i].y; d.rotation[2] = rot[i].z; d.rotation[3] = rot[i].w; }
+                        if (!same(lv[i], up.lv)) { d.linvel[0] = lv[i].x; d.linvel[1] = lv[i].y; d.linvel[2] = lv[i].z; }
+                        if (!same(av[i], up.av)) { d.angvel[0] = av[i].x; d.angvel[1] = av[i].y; d.angvel[2] = av[i].z; }
+                        if (!same(npos[i], up.npos) || !same(nrot[i], up.nrot)) {
+                            hb.has_next = true; hb.next[0] = npos[i].x; hb.next[1] = npos[i].y; hb.next[2] = npos[i].z;
+                            hb.next[3] = nrot[i].x; hb.next[4] = nrot[i].y; hb.next[5] = nrot[i].z; hb.next[6] = nrot[i].w;
+                        }
+                    }
+                }
                 if (nb0 > 0) {
                     HIPCHK(w, hipMemcpy(uf.data(), w->dw.b_uforce, (size_t)nb0 * sizeof(float4), hipMemcpyDeviceToHost));
                     HIPCHK(w, hipMemcpy(ut.data(), w->dw.b_utorque, (size_t)nb0 * sizeof(float4), hipMemcpyDeviceToHost));

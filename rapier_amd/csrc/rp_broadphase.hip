@@ -11,13 +11,11 @@
 // work, one thread per collider, wave-coalesced SoA loads) plus a brute-force list for colliders
 // spanning more than 3 cells (and for the rare collider that met a full bucket).  Like the reference's change detection the whole pass is skipped
 // (every kernel early-exits on FL_BP_DIRTY == 0) while no fat AABB changed, and — like its refit of the changed
-// leaves only (update.rs:139-331, :448-601) — a pass in which FEW fat AABBs changed touches only those colliders:
-// the grid of the last full rebuild still describes every collider that has not moved since, so a changed collider
-// finds its new partners by walking the cells under its new AABB (unmoved partners), the short list of colliders
-// that moved since the rebuild (their cells are stale) and the large list, and the pairs it lost by one sweep over
-// the pair slots; deleted pairs leave a tombstone in the live hash table.  The pair SET equals the full rebuild's;
-// a full rebuild runs when many colliders moved, the stale list or the tombstones grew, a large collider moved or
-// the topology changed (FL_BP_GRID_OK).
+// leaves only (update.rs:139-331, :448-601) — a pass in which fat AABBs changed touches only those colliders: the grid in service
+// follows every collider whose fat AABB moves to other cells (bp_grid_follow, round 4), so a changed collider finds its new partners
+// by walking the cells under its new AABB and the large list, and the pairs it lost by one sweep over the pair slots; deleted pairs
+// leave a tombstone in the live hash table.  The pair SET equals the full rebuild's; a full rebuild runs when more than half of the
+// colliders changed, a bucket filled up, the tombstones grew, a large collider moved or the topology changed (FL_BP_GRID_OK).
 #include "rp_pairs.h"
 #include "rp_gridbar.h"
 
@@ -33,8 +31,9 @@ __device__ __forceinline__ unsigned long long cell_key(int cx, int cy, int cz) {
 __device__ __forceinline__ int cell_coord(float x, float inv_cell) { return (int)floorf(x * inv_cell); }
 
 struct CellRange { int lo[3], hi[3]; bool large; };
-__device__ __forceinline__ CellRange cell_range(const DevWorld &w, int i) {
-    float4 mn = w.c_fatmin[i], mx = w.c_fatmax[i];
+__device__ __forceinline__ CellRange cell_range_of(const DevWorld &w, float4 mn, float4 mx);
+__device__ __forceinline__ CellRange cell_range(const DevWorld &w, int i) { return cell_range_of(w, w.c_fatmin[i], w.c_fatmax[i]); }
+__device__ __forceinline__ CellRange cell_range_of(const DevWorld &w, float4 mn, float4 mx) {
     CellRange r;
     float ic = w.prm.inv_cell_size;
     r.lo[0] = cell_coord(mn.x, ic); r.lo[1] = cell_coord(mn.y, ic); r.lo[2] = cell_coord(mn.z, ic);
@@ -43,6 +42,50 @@ __device__ __forceinline__ CellRange cell_range(const DevWorld &w, int i) {
     const bool unbounded = (mx.x - mn.x) * ic > 1.0e6f || (mx.y - mn.y) * ic > 1.0e6f || (mx.z - mn.z) * ic > 1.0e6f;
     r.large = unbounded || (r.hi[0] - r.lo[0] > 2) || (r.hi[1] - r.lo[1] > 2) || (r.hi[2] - r.lo[2] > 2);
     return r;
+}
+
+// ---- the grid, and how it follows a collider whose fat AABB was rewritten ------------------------------------------------------------
+// The grid: grid_cap hash buckets of RP_BP_BUCKET fixed slots, two copies (the one in service: epoch parity).  A slot is ONE word:
+// collider (24 bits) | which of its at most 27 cells the entry stands for (5 bits, x fastest inside the collider's cell range) | the
+// collider's RANGE VERSION when the entry was written (3 bits).  Cells that share a bucket are told apart without a stored key: a
+// reader at cell X accepts an entry only if the cell it stands for — recomputed from the partner's fat AABB, which the overlap test
+// loads anyway — is X (bp_entry_is_cell).
+// Round 4: the grid in service FOLLOWS the colliders between full rebuilds.  A rewritten fat AABB that still covers the same cells needs
+// nothing (its entries decode to the same cells).  One that covers other cells bumps the collider's range version — which kills every
+// entry written before, wherever it sits — and appends an entry for every cell of the new range (k_collider_update / k_fast_front, the
+// kernel before the broad-phase pass).  So no collider is ever "stale": the incremental pass finds every partner through the grid, and
+// the stale list of round 3 (2,048 colliders, brute force, full rebuild when full: one pass in three on b3d_large_pyramid, five in
+// six on b3d_joint_grid) is gone.  A bucket that fills up, or a collider that changes cells for the 7th time since the last full
+// rebuild (3 version bits), clears FL_BP_GRID_OK: the next pass is a full rebuild, which starts every version from zero.
+RP_DEV int bp_entry(int collider, int ordinal, int version) { return collider | (ordinal << 24) | ((version & 7) << 29); }
+RP_DEV bool bp_entry_is_cell(const DevWorld &w, int entry, int x, int y, int z) {
+    const int j = entry & 0xffffff;
+    if ((int)((unsigned)entry >> 29) != (w.c_rver[j] & 7)) return false; // written for a cell range the collider has left since
+    const CellRange r = cell_range(w, j);
+    const int o = (entry >> 24) & 31, nx = r.hi[0] - r.lo[0] + 1, ny = r.hi[1] - r.lo[1] + 1;
+    return r.lo[0] + o % nx == x && r.lo[1] + (o / nx) % ny == y && r.lo[2] + o / (nx * ny) == z;
+}
+RP_DEV void bp_grid_follow(const DevWorld &w, int i, float4 omn, float4 omx) {
+    if (!w.bp_incremental || !w.flags[FL_BP_GRID_OK]) return; // no grid in service / a full rebuild is due anyway
+    if (w.c_inlarge[i]) return;                                // on the large list: the incremental pass leaves it to the full rebuild
+    const CellRange o = cell_range_of(w, omn, omx), r = cell_range(w, i);
+    if (r.large) return;                                       // (likewise)
+    const bool valid_before = omn.x <= omx.x && omn.y <= omx.y && omn.z <= omx.z; // (a freshly inserted collider has an empty box and no entry)
+    if (valid_before && !o.large && o.lo[0] == r.lo[0] && o.lo[1] == r.lo[1] && o.lo[2] == r.lo[2] && o.hi[0] == r.hi[0] && o.hi[1] == r.hi[1] && o.hi[2] == r.hi[2]) return;
+    const int ver = w.c_rver[i] + 1;
+    w.c_rver[i] = ver;
+    if (ver >= 8) { w.flags[FL_BP_GRID_OK] = 0; return; }      // the 3 version bits would wrap onto entries still in the buckets
+    const int cur = w.flags[FL_BP_EPOCH] & 1;
+    int *cnt = w.bk_cnt[cur]; int *items = w.bk_items[cur];
+    int ord = 0;
+    for (int z = r.lo[2]; z <= r.hi[2]; ++z)
+        for (int y = r.lo[1]; y <= r.hi[1]; ++y)
+            for (int x = r.lo[0]; x <= r.hi[0]; ++x, ++ord) {
+                const int h = (int)(rp_hash64(cell_key(x, y, z)) & (unsigned long long)(w.grid_cap - 1));
+                const int k = atomicAdd(&cnt[h], 1);
+                if (k < RP_BP_BUCKET) items[(size_t)h * RP_BP_BUCKET + k] = bp_entry(i, ord, ver);
+                else w.flags[FL_BP_GRID_OK] = 0;               // bucket full: rebuild
+            }
 }
 
 __global__ void k_collider_update(DevWorld w) {
@@ -55,7 +98,8 @@ __global__ void k_collider_update(DevWorld w) {
         w.flags[FL_FULL_UPDATES] = 0; w.flags[FL_TODO_COUNT] = 0; w.flags[FL_NP_COUNT] = 0; w.flags[FL_CCD_N] = 0;
     }
     if (i >= w.n_colliders) return;
-    collider_update_one(w, i);
+    const float4 omn = w.c_fatmin[i], omx = w.c_fatmax[i];
+    if (collider_update_one(w, i)) bp_grid_follow(w, i, omn, omx);
 }
 
 // Steady-state fast path, first kernel (see rp_api.hip "fast graph"): collider poses + fat-AABB checks
@@ -90,7 +134,8 @@ __global__ void k_fast_front(DevWorld w, int no_global_kernel) {
             if (motion > 0.25f * thickness) abort = true;
         }
     if (gid < w.n_colliders) {
-        abort |= collider_update_one(w, gid); // rewritten fat AABB => FL_BP_DIRTY
+        const float4 omn = w.c_fatmin[gid], omx = w.c_fatmax[gid];
+        if (collider_update_one(w, gid)) { abort = true; bp_grid_follow(w, gid, omn, omx); } // rewritten fat AABB => FL_BP_DIRTY (the replay on the full graph finds it rewritten: the grid follows here)
     }
     int top = w.flags[FL_POOL_TOP];
     if (top > w.pool_cap) top = w.pool_cap;
@@ -123,17 +168,11 @@ RP_DEV void bp_large_append(DevWorld &w, int i) {
     int k = atomicAdd(&w.scan_block[BP_LARGE_SCRATCH], 1);
     if (k < w.large_cap) w.large_list[k] = i; else atomicOr(&w.flags[FL_OVERFLOW], RP_OVF_LARGE);
 }
-RP_DEV int bp_entry(int collider, int ordinal) { return collider | (ordinal << 26); } // ordinal: x fastest inside the collider's cell range
-RP_DEV bool bp_entry_is_cell(const DevWorld &w, int entry, int x, int y, int z) {
-    const CellRange r = cell_range(w, entry & 0x3ffffff);
-    const int o = (int)((unsigned)entry >> 26), nx = r.hi[0] - r.lo[0] + 1, ny = r.hi[1] - r.lo[1] + 1;
-    return r.lo[0] + o % nx == x && r.lo[1] + (o / nx) % ny == y && r.lo[2] + o / (nx * ny) == z;
-}
 RP_DEV void bp_build(DevWorld &w, int gid, int gstride, int nxt) {
     int *cnt = w.bk_cnt[nxt]; int *items = w.bk_items[nxt];
     for (int i = gid; i < w.n_colliders; i += gstride) {
         CellRange r = cell_range(w, i);
-        w.c_inlarge[i] = r.large ? 1 : 0; w.c_stale[i] = 0; // the grid is being rebuilt: nobody is stale
+        w.c_inlarge[i] = r.large ? 1 : 0; w.c_rver[i] = 0; // the grid is being rebuilt: every range version starts from zero
         if (r.large) { bp_large_append(w, i); continue; }
         bool full = false;
         int o = 0;
@@ -143,7 +182,7 @@ RP_DEV void bp_build(DevWorld &w, int gid, int gstride, int nxt) {
                     unsigned long long key = cell_key(x, y, z);
                     int h = (int)(rp_hash64(key) & (unsigned long long)(w.grid_cap - 1));
                     int k = atomicAdd(&cnt[h], 1);
-                    if (k < RP_BP_BUCKET) items[(size_t)h * RP_BP_BUCKET + k] = bp_entry(i, o);
+                    if (k < RP_BP_BUCKET) items[(size_t)h * RP_BP_BUCKET + k] = bp_entry(i, o, 0);
                     else full = true;
                 }
         if (full) { w.c_inlarge[i] = 1; bp_large_append(w, i); } // (only this thread writes c_inlarge[i] in this pass; readers sit behind the barrier)
@@ -255,7 +294,7 @@ RP_DEV void bp_pairs(DevWorld &w, int nxt) {
             int h = (int)(rp_hash64(key) & (unsigned long long)(w.grid_cap - 1));
             int n = cnt[h]; if (n > RP_BP_BUCKET) n = RP_BP_BUCKET;
             for (int e = 0; e < n; ++e) {
-                const int it = items[(size_t)h * RP_BP_BUCKET + e], j = it & 0x3ffffff;
+                const int it = items[(size_t)h * RP_BP_BUCKET + e], j = it & 0xffffff;
                 if (j <= i) continue;
                 V3 imin;
                 if (!fat_overlap(w, i, j, imin)) continue;
@@ -349,7 +388,7 @@ __device__ __forceinline__ void bp_try_pair(DevWorld &w, int i, int j) {
     bp_insert_pair(w, i < j ? i : j, i < j ? j : i, true);
 }
 // new partners of the colliders on bp_chg_list: one wavefront per changed collider
-RP_DEV void bp_incr_insert(DevWorld &w, int nchg, int nmoved) {
+RP_DEV void bp_incr_insert(DevWorld &w, int nchg) {
     const int lane = threadIdx.x & 63, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
     const int stamp = w.flags[FL_BP_SEQ] + 1;
     const float ic = w.prm.inv_cell_size;
@@ -360,12 +399,9 @@ RP_DEV void bp_incr_insert(DevWorld &w, int nchg, int nmoved) {
         if (r.large || w.c_inlarge[i]) { if (lane == 0) w.flags[FL_BP_FORCE_FULL] = 1; continue; } // the large list is only rebuilt by a full pass
         // (a) the large colliders (ground slabs, walls: never stale)
         for (int q = lane; q < nl; q += 64) bp_try_pair(w, i, w.large_list[q]);
-        // (b) colliders that moved since the last full rebuild but not in this pass: their cells are stale, the list is short
-        for (int q = lane; q < nmoved; q += 64) { int j = w.bp_moved_list[q]; if (j != i && w.c_chgstamp[j] != stamp) bp_try_pair(w, i, j); }
-        // (c) colliders that changed in this pass too: reported from the smaller index
-        for (int q = lane; q < nchg; q += 64) { int j = w.bp_chg_list[q]; if (j > i) bp_try_pair(w, i, j); }
-        // (d) everybody else through the grid: one lane per cell of the new AABB (at most 27); a pair is reported from the cell that
-        // holds the min corner of the intersection, which lies in both cell ranges
+        // (b) everybody else through the grid, which follows every collider (bp_grid_follow): one lane per cell of the new AABB (at most
+        // 27); a pair is reported from the cell that holds the min corner of the intersection, which lies in both cell ranges; two
+        // colliders that both changed in this pass find each other — reported from the smaller index
         const int nx = r.hi[0] - r.lo[0] + 1, ny = r.hi[1] - r.lo[1] + 1, nz = r.hi[2] - r.lo[2] + 1;
         if (lane < nx * ny * nz) {
             const int x = r.lo[0] + lane % nx, y = r.lo[1] + (lane / nx) % ny, z = r.lo[2] + lane / (nx * ny);
@@ -374,20 +410,20 @@ RP_DEV void bp_incr_insert(DevWorld &w, int nchg, int nmoved) {
             const int cur = w.flags[FL_BP_EPOCH] & 1; // the grid copy in service
             int n = w.bk_cnt[cur][h]; if (n > RP_BP_BUCKET) n = RP_BP_BUCKET;
             for (int e = 0; e < n; ++e) {
-                const int it = w.bk_items[cur][(size_t)h * RP_BP_BUCKET + e], j = it & 0x3ffffff;
+                const int it = w.bk_items[cur][(size_t)h * RP_BP_BUCKET + e], j = it & 0xffffff;
                 if (j == i) continue;
                 V3 imin;
                 if (!fat_overlap(w, i, j, imin)) continue; // (geometry first: the three status words below are only fetched for the few entries that get past it)
                 if (cell_coord(imin.x, ic) != x || cell_coord(imin.y, ic) != y || cell_coord(imin.z, ic) != z) continue;
-                if (w.c_stale[j] || w.c_chgstamp[j] == stamp || w.c_inlarge[j]) continue; // stale cells: covered by (b) / (c); the large list: by (a)
-                if (!bp_entry_is_cell(w, it, x, y, z)) continue; // (another cell of j that shares this bucket; j has not moved since the grid was built)
+                if (w.c_inlarge[j] || (w.c_chgstamp[j] == stamp && j < i)) continue; // the large list: covered by (a)
+                if (!bp_entry_is_cell(w, it, x, y, z)) continue; // (another cell of j that shares this bucket, or an entry of a cell range j has left)
                 if (!pair_allowed(w, i, j)) continue;
                 bp_insert_pair(w, i < j ? i : j, i < j ? j : i, true);
             }
         }
     }
 }
-// lost partners: every pair with a changed collider whose fat AABBs no longer intersect; the changed colliders join the stale list
+// lost partners: every pair with a changed collider whose fat AABBs no longer intersect
 RP_DEV void bp_incr_delete(DevWorld &w, int gid, int gstride, int nchg) {
     const int stamp = w.flags[FL_BP_SEQ] + 1, cur = w.flags[FL_BP_EPOCH] & 1;
     int top = w.flags[FL_POOL_TOP];
@@ -403,10 +439,6 @@ RP_DEV void bp_incr_delete(DevWorld &w, int gid, int gstride, int nchg) {
         atomicAdd(&w.flags[FL_BP_TOMBS], 1);
         bp_delete_pair(w, s);
     }
-    for (int k = gid; k < nchg; k += gstride) {
-        const int i = w.bp_chg_list[k];
-        if (!w.c_stale[i]) { w.c_stale[i] = 1; int q = atomicAdd(&w.flags[FL_BP_NMOVED], 1); if (q < RP_BP_MOVED_CAP) w.bp_moved_list[q] = i; }
-    }
 }
 
 // The whole pass in ONE launch (see rp_gridbar.h): a clean step (no fat AABB changed) costs a single early exit, a step in which few
@@ -416,18 +448,19 @@ __global__ void __launch_bounds__(1024) k_bp_rebuild(DevWorld w) {
     if (collision_done(w)) return;     // (a dead lean step's collision stage is not repeated: rp_world.h "lean step graphs")
     const int gid = gbar_item(), gstride = gridDim.x * blockDim.x;
     // the mode is decided from scalars that only change behind a barrier of this launch (or at its very end)
-    const int nchg = w.flags[FL_BP_NCHG] < w.n_colliders ? w.flags[FL_BP_NCHG] : w.n_colliders, nmoved = w.flags[FL_BP_NMOVED];
-    const bool incremental = w.bp_incremental && w.flags[FL_BP_GRID_OK] && nchg > 0 && nchg <= w.n_colliders / 4 + 16 && nmoved + nchg <= RP_BP_MOVED_CAP &&
-                             w.flags[FL_BP_TOMBS] < w.hash_cap / 8;
+    // (an incremental pass spends a wavefront per changed collider, the full rebuild eight lanes per collider: beyond a quarter of the
+    // colliders the rebuild is the cheaper one — measured on b3d_joint_grid, where 3,559 of 10,000 change per pass: 36 us as a rebuild)
+    const int nchg = w.flags[FL_BP_NCHG] < w.n_colliders ? w.flags[FL_BP_NCHG] : w.n_colliders;
+    const bool incremental = w.bp_incremental && w.flags[FL_BP_GRID_OK] && nchg > 0 && nchg <= w.n_colliders / 4 + 16 && w.flags[FL_BP_TOMBS] < w.hash_cap / 8;
     GridBar bar = gbar_begin(w, 0);
 #ifdef RP_PASS_PROFILE // why a pass was (not) incremental: dbg[240..] (tools/pass_profile.py)
     if (gid == 0) {
         w.dbg[240] += 1; w.dbg[241] += incremental ? 1 : 0; w.dbg[242] += w.flags[FL_BP_GRID_OK] ? 0 : 1; w.dbg[243] += (nchg > w.n_colliders / 4 + 16) ? 1 : 0;
-        w.dbg[244] += (nmoved + nchg > RP_BP_MOVED_CAP) ? 1 : 0; w.dbg[245] += (w.flags[FL_BP_TOMBS] >= w.hash_cap / 8) ? 1 : 0; w.dbg[246] += nchg; w.dbg[247] += nmoved; w.dbg[248] = w.flags[FL_N_LARGE];
+        w.dbg[244] += 0; w.dbg[245] += (w.flags[FL_BP_TOMBS] >= w.hash_cap / 8) ? 1 : 0; w.dbg[246] += nchg; w.dbg[247] += 0; w.dbg[248] = w.flags[FL_N_LARGE];
     }
 #endif
     if (incremental) {
-        bp_incr_insert(w, nchg, nmoved);
+        bp_incr_insert(w, nchg);
         GBAR_SYNC(bar);
         if (!w.flags[FL_BP_FORCE_FULL]) {
             bp_incr_delete(w, gid, gstride, nchg);

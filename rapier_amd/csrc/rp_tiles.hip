@@ -557,6 +557,37 @@ RP_DEV void tile_joint_build(const DevWorld &w, const int4 e, const int *Lg, int
     const TileJointBuild sink = {P, e.w != 0};
     joint_update_one_t<TilePoseIO, TileJointBuild, true>(w, io, -1 - e.x, substep, sink);
 }
+// a prepared joint parked in LDS, one word per field and slot ([field][slot]: neighbouring threads, neighbouring banks)
+#define RP_TILE_JX 64
+#define TJP_WORDS (5 + 6 + 3 * 22)
+RP_DEV void tile_joint_park(float *Lj, int slot, const TileJointPre &P) {
+    int f = 0;
+#define TJ_PUT(x) Lj[(f++) * RP_TILE_JX + slot] = (x)
+    TJ_PUT(__int_as_float(P.locked)); TJ_PUT(__int_as_float(P.limited)); TJ_PUT(__int_as_float(P.motor)); TJ_PUT(__int_as_float(P.b1)); TJ_PUT(__int_as_float(P.b2));
+    TJ_PUT(P.im1.x); TJ_PUT(P.im1.y); TJ_PUT(P.im1.z); TJ_PUT(P.im2.x); TJ_PUT(P.im2.y); TJ_PUT(P.im2.z);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const JointRow &c = P.R.c[k];
+        TJ_PUT(c.lin_jac.x); TJ_PUT(c.lin_jac.y); TJ_PUT(c.lin_jac.z); TJ_PUT(c.ang_jac1.x); TJ_PUT(c.ang_jac1.y); TJ_PUT(c.ang_jac1.z);
+        TJ_PUT(c.ang_jac2.x); TJ_PUT(c.ang_jac2.y); TJ_PUT(c.ang_jac2.z); TJ_PUT(c.ii1.x); TJ_PUT(c.ii1.y); TJ_PUT(c.ii1.z); TJ_PUT(c.ii2.x); TJ_PUT(c.ii2.y); TJ_PUT(c.ii2.z);
+        TJ_PUT(c.impulse); TJ_PUT(c.inv_lhs); TJ_PUT(c.rhs); TJ_PUT(c.rhs_wo_bias); TJ_PUT(c.cfm_gain); TJ_PUT(c.bmin); TJ_PUT(c.bmax);
+    }
+#undef TJ_PUT
+}
+RP_DEV void tile_joint_unpark(const float *Lj, int slot, TileJointPre &P) {
+    int f = 0;
+#define TJ_GET() Lj[(f++) * RP_TILE_JX + slot]
+    P.locked = __float_as_int(TJ_GET()); P.limited = __float_as_int(TJ_GET()); P.motor = __float_as_int(TJ_GET()); P.b1 = __float_as_int(TJ_GET()); P.b2 = __float_as_int(TJ_GET());
+    P.im1.x = TJ_GET(); P.im1.y = TJ_GET(); P.im1.z = TJ_GET(); P.im2.x = TJ_GET(); P.im2.y = TJ_GET(); P.im2.z = TJ_GET();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        JointRow &c = P.R.c[k];
+        c.lin_jac.x = TJ_GET(); c.lin_jac.y = TJ_GET(); c.lin_jac.z = TJ_GET(); c.ang_jac1.x = TJ_GET(); c.ang_jac1.y = TJ_GET(); c.ang_jac1.z = TJ_GET();
+        c.ang_jac2.x = TJ_GET(); c.ang_jac2.y = TJ_GET(); c.ang_jac2.z = TJ_GET(); c.ii1.x = TJ_GET(); c.ii1.y = TJ_GET(); c.ii1.z = TJ_GET(); c.ii2.x = TJ_GET(); c.ii2.y = TJ_GET(); c.ii2.z = TJ_GET();
+        c.impulse = TJ_GET(); c.inv_lhs = TJ_GET(); c.rhs = TJ_GET(); c.rhs_wo_bias = TJ_GET(); c.cfm_gain = TJ_GET(); c.cfm_coeff = 0.0f; c.bmin = TJ_GET(); c.bmax = TJ_GET();
+    }
+#undef TJ_GET
+}
 RP_DEV void tile_apply_joint(const DevWorld &w, const int4 e, TileJointPre &P, float4 *Ll, float4 *La, bool wo_bias, bool warmstart) {
     const TileJointIO io = {Ll, La, e.y, e.z, w.c_par ^ 1, e.w != 0};
     joint_solve_fetched<TileJointIO, 3>(w, io, -1 - e.x, P.b1, P.b2, joint_row_count(P.locked, P.limited, P.motor), P.im1, P.im2, P.R, wo_bias, warmstart);
@@ -605,6 +636,7 @@ __global__ void __launch_bounds__(RP_TILE_THREADS) k_tile_sweep(DevWorld w, int 
     }
     __shared__ float4 Ll[RP_TILE_BCAP], La[RP_TILE_BCAP];
     __shared__ int Lg[RP_TILE_BCAP];
+    __shared__ float Lj[TJP_WORDS * RP_TILE_JX]; // the prepared second joints of the first RP_TILE_JX threads (tile_joint_park)
     __shared__ int Soff[RP_TILE_STAGES + 4];
     const int njs = tile_joint_stages(w); // joint stages come first in a sweep
     const int nst = njs + w.flags[FL_N_STAGES];
@@ -656,9 +688,20 @@ __global__ void __launch_bounds__(RP_TILE_THREADS) k_tile_sweep(DevWorld w, int 
         // Larger cones keep the per-stage form.
         if (njs > 0) {
             const int j0 = Soff[0], nje = Soff[njs] - j0;
-            if (nje <= nt) { // (tile-uniform)
-                int4 je = make_int4(0, 0, 0, 0); int jstage = -1; TileJointPre JP;
+            if (nje <= nt + RP_TILE_JX) { // (tile-uniform)
+                // (a cone of a few more joints than threads — b3d_joint_grid's tiles hold 200-270 — gives its first threads a second
+                // joint, prepared in a second round and parked in LDS until its stage: the cone sizes depend on where the Morton cuts
+                // fall, and a tile that dropped to the per-stage form cost the whole launch 5 us)
+                int4 je = make_int4(0, 0, 0, 0), je2 = je; int jstage = -1, jstage2 = -1; TileJointPre JP;
                 TP_STAMP(0);
+                if (t < nje - nt) {
+                    je2 = cons[j0 + nt + t];
+                    jstage2 = 0; while (Soff[jstage2 + 1] - j0 <= nt + t) ++jstage2;
+                    TileJointPre P2;
+                    if (MODE == MODE_BIAS && (fuse & 4)) tile_joint_build(w, je2, Lg, fuse >> 8, P2);
+                    else tile_joint_fetch(w, je2, Lg, P2);
+                    tile_joint_park(Lj, t, P2);
+                }
                 if (t < nje) {
                     je = j0 == 0 ? e_first : cons[j0 + t];
                     jstage = 0; while (Soff[jstage + 1] - j0 <= t) ++jstage;
@@ -671,6 +714,10 @@ __global__ void __launch_bounds__(RP_TILE_THREADS) k_tile_sweep(DevWorld w, int 
                 TP_STAMP(3); // every joint of the cone prepared (rows rebuilt / fetched)
                 for (int s = 0; s < njs; ++s) {
                     if (jstage == s) tile_apply_joint(w, je, JP, Ll, La, MODE == MODE_RELAX, joint_warmstart != 0);
+                    if (jstage2 == s) { // (a colour is body-disjoint: the thread's two joints of one stage do not share a body)
+                        TileJointPre P2; tile_joint_unpark(Lj, t, P2);
+                        tile_apply_joint(w, je2, P2, Ll, La, MODE == MODE_RELAX, joint_warmstart != 0);
+                    }
                     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                     TP_STAMP(4 + (s < 16 ? s : 16));
                 }

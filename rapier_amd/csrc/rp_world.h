@@ -272,10 +272,11 @@ struct DevWorld {
     // ---- broad phase ----
     int *bk_cnt[2];        // [grid_cap] entries handed out per hash bucket (may exceed RP_BP_BUCKET: the surplus went to the large list); two
                            // copies: [FL_BP_EPOCH & 1] is in service, the other one rests at zero until the next rebuild fills it
-    int *bk_items[2];      // [grid_cap][RP_BP_BUCKET] collider | which of its cells << 26 (bp_entry)
+    int *bk_items[2];      // [grid_cap][RP_BP_BUCKET] collider | which of its cells << 24 | range version << 29 (bp_entry)
     int *scan_block;       // [1024 + 8] scratch counters of a running rebuild ([1024]: its large list)
     int *large_list;
-    int *c_chgstamp, *c_stale, *c_inlarge; // per collider: pass (FL_BP_SEQ + 1) that already queued it on bp_chg_list; grid cells stale; on large_list
+    int *c_chgstamp, *c_stale, *c_inlarge; // per collider: pass (FL_BP_SEQ + 1) that already queued it on bp_chg_list; (unused since round 4); on large_list
+    int *c_rver;           // per collider: cell-range changes since the last full rebuild (the version its live grid entries carry: bp_grid_follow)
     int *bp_chg_list, *bp_moved_list;      // [colliders] fat AABBs rewritten since the last pass; [RP_BP_MOVED_CAP] stale colliders
     unsigned long long *h_key[2]; int *h_slot[2];
     int *free_stack;
