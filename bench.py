@@ -207,8 +207,19 @@ def run(args, make_world=None, backend: str = "nccl", use_cuda: bool = True):
                 shard_source = f"device proximity groups ({n_groups} groups of the whole scene, bin-packed; {len(guard[0])} foreign boxes guarded on rank {rank})"
                 workload += f"; shards from the device's proximity groups ({int((body_rank == rank).sum()) // 55} islands on rank {rank})"
                 del full
+                discovered = 1
             except Exception as e:  # noqa: BLE001 — the generator's shards are the fallback
-                shard_source = f"generator (device discovery failed: {type(e).__name__}: {e})"
+                shard_source = f"generator (device discovery failed on rank {rank}: {type(e).__name__}: {e})"
+                discovered = 0
+            # every rank must cut the world the same way: one rank that failed to discover the groups (out of memory while building the
+            # whole scene, say) sends ALL ranks to the generator's shards — mixed partitions would duplicate or lose bodies
+            if dist is not None:
+                ok = torch.tensor([discovered], dtype=torch.int64, device="cuda" if use_cuda else None)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 0 and discovered:
+                    shard_source = "generator (device discovery failed on another rank)"
+                discovered = int(ok.item())
+            if not discovered:
                 scene, workload, gids, n_global, grid = build_workload(wl, world, rank)
                 guard = None
     w = make_world(scene, local_rank)

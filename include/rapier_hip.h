@@ -286,6 +286,10 @@ int32_t rp_bodies_proximity_group(rp_world *w, int32_t n, const uint64_t *handle
  * group of the other shards, already inflated by whatever clearance the caller wants) that hold the bodies of OTHER shards.  When
  * the fat AABB of a non-fixed body of this world is rewritten so that it overlaps one of them, the shards are no longer independent
  * (the reference would have created the ColliderPair; a sharded run cannot): the next rp_sync / read returns RP_ERR_INVALID.
+ * LIMIT: the boxes are static — where the other shards' bodies WERE when the caller took them.  Two bodies of different shards
+ * that both leave their boxes and meet in between are not seen by either guard.  A caller that shards a world whose groups roam
+ * (not the pyramids of the benchmark scenes) must refresh the boxes periodically: gather the groups' current boxes over all
+ * ranks and call this function again (one all-gather of 6 floats per group).
  * n = 0 removes the guard. */
 int32_t rp_world_set_shard_guard(rp_world *w, int32_t n, const float *box_min3, const float *box_max3);
 int32_t rp_num_bodies(const rp_world *w);

@@ -198,25 +198,36 @@ __global__ void __launch_bounds__(256) k_ccd(DevWorld w, int tier, int publish) 
         const bool bullet = (fl1 & RP_BF_TYPE_MASK) == RP_BODY_DYNAMIC && (fl1 & RP_BF_CCD_ENABLED);
         __syncthreads();
         if ((bullet ? 1 : 0) != tier || (fl1 & RP_BF_SLEEPING)) continue; // (uniform over the workgroup)
-        if (threadIdx.x == 0) { best = __float_as_uint(1.0f); nfast = 0; }
+        if (threadIdx.x == 0) { best = __float_as_uint(1.0f); nfast = -1; }
         __syncthreads();
-        for (int c = threadIdx.x; c < w.n_colliders; c += blockDim.x) { // the body's own colliders (enabled, not sensors)
-            if (w.c_parent[c] != bi) continue;
-            uint2 g = w.c_groups[c];
-            if ((g.x == 0 && g.y == 0) || (__float_as_int(w.c_events[c].x) & RP_EVENTS_SENSOR_BIT)) continue;
-            int q = atomicAdd(&nfast, 1);
-            if (q < CCD_MAX_FAST_COLLIDERS) fast[q] = c;
-        }
+        // the body's own colliders (enabled, not sensors), CCD_MAX_FAST_COLLIDERS at a time by attachment ordinal (c_ord): every one of
+        // them is swept — a compound body of more than 64 colliders used to keep whichever 64 the atomics handed out — and
+        // the chunks are the same in every run.  nfast: the largest ordinal attached to the body
+        for (int c = threadIdx.x; c < w.n_colliders; c += blockDim.x) if (w.c_parent[c] == bi) atomicMax(&nfast, w.c_ord[c]);
         __syncthreads();
-        const int nf = nfast < CCD_MAX_FAST_COLLIDERS ? nfast : CCD_MAX_FAST_COLLIDERS;
+        const int max_ord = nfast;
         Pose start, end;
         start.t = v3(w.b_ccd0_pos[bi]); start.r = q4(w.b_ccd0_rot[bi]);
         end.t = v3(w.b_pos[bi]); end.r = q4(w.b_rot[bi]);
         const V3 lcom = v3(w.b_lcom_invm[bi]);
         const float max_extent = w.b_invpi[bi].w;
         const CcdSweep sw = ccd_sweep_from_poses(start, end, lcom);
-        for (int f = 0; f < nf; ++f) {
+        for (int base = 0; base <= max_ord; base += CCD_MAX_FAST_COLLIDERS) {
+          __syncthreads();
+          for (int q = threadIdx.x; q < CCD_MAX_FAST_COLLIDERS; q += blockDim.x) fast[q] = -1;
+          __syncthreads();
+          for (int c = threadIdx.x; c < w.n_colliders; c += blockDim.x) {
+              if (w.c_parent[c] != bi) continue;
+              const int o = w.c_ord[c] - base;
+              if (o < 0 || o >= CCD_MAX_FAST_COLLIDERS) continue;
+              uint2 g = w.c_groups[c];
+              if ((g.x == 0 && g.y == 0) || (__float_as_int(w.c_events[c].x) & RP_EVENTS_SENSOR_BIT)) continue;
+              fast[o] = c;
+          }
+          __syncthreads();
+          for (int f = 0; f < CCD_MAX_FAST_COLLIDERS; ++f) {
             const int c1 = fast[f];
+            if (c1 < 0) continue; // (uniform over the workgroup)
             const CcdShape s2 = ccd_shape_of(w.c_shape[c1], w.c_he[c1]);
             Pose pwp; pwp.t = v3(w.c_lpos[c1]); pwp.r = q4(w.c_lrot[c1]);
             const float rot_radius = ccd_rot_radius(s2, pwp, lcom);
@@ -240,6 +251,7 @@ __global__ void __launch_bounds__(256) k_ccd(DevWorld w, int tier, int publish) 
                 const float hit = ccd_cast_pair(s1, tp, s2, pwp, sw, rot_radius, cur, slop);
                 if (hit > 0.0f && hit < cur) atomicMin(&best, __float_as_uint(hit));
             }
+          }
         }
         __syncthreads();
         if (threadIdx.x == 0) {
