@@ -201,7 +201,7 @@ void rp_default_params(rp_integration_params *out);            /* IntegrationPar
 int32_t rp_params_get(const rp_world *w, rp_integration_params *out);
 int32_t rp_params_set(rp_world *w, const rp_integration_params *in);
 
-/* RigidBodySet::insert ×n; handles = generation<<32 | index (arena.rs:58-90). */
+/* RigidBodySet::insert ×n; handles = generation<<32 | index (arena.rs:58-90); removed slots are reused first, LIFO (arena.rs:260-290). */
 int32_t rp_bodies_insert(rp_world *w, int32_t n, const rp_body_desc *descs, uint64_t *handles_out);
 /* ColliderSet::insert_with_parent ×n (parent RP_INVALID_HANDLE = ColliderSet::insert).  Device path scope: cuboid / ball
  * shapes.  A body may carry any number of colliders at any pos_wrt_parent (compound bodies): its mass, centre of mass and
@@ -276,6 +276,12 @@ int32_t rp_bodies_is_sleeping(rp_world *w, int32_t n, const uint64_t *handles, i
  * and for every body of a world that holds no sleepable body (such a world keeps no islands; the first sleepable body bootstraps
  * them, persistent.rs:600-625).  As in the reference only EQUALITY of two ids is meaningful. */
 int32_t rp_bodies_persistent_island(rp_world *w, int32_t n, const uint64_t *handles, int32_t *island_out);
+/* RigidBodySet::iter / ColliderSet::iter as handles (Arena::iter, data/arena.rs:665-700): the handle of every arena row in index
+ * order — generation << 32 | index of the row's occupant (a free row: of the occupant removed last; only rp_bodies_read still accepts
+ * it).  Removed slots are handed out again LIFO with the arena's removal count as their generation (arena.rs:260-290, 353-380): a
+ * handle of an earlier occupant is stale and rejected with RP_ERR_INVALID everywhere.  Returns the row count, writes min(rows, cap). */
+int32_t rp_bodies_handles(const rp_world *w, int32_t cap, uint64_t *handles_out);
+int32_t rp_colliders_handles(const rp_world *w, int32_t cap, uint64_t *handles_out);
 /* Proximity groups: connected components of the non-fixed bodies over everything that can couple them within a step — every live
  * broad-phase pair (fat AABBs overlap: ColliderPair events of broad_phase_bvh/mod.rs:171-263) and every impulse joint.  Two bodies in
  * different groups cannot interact before one of them moves out of its fat AABB: the unit of island sharding over GPUs (SURVEY §8e;

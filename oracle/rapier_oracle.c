@@ -214,6 +214,11 @@ struct ro_world {
     int32_t pi_stats[RO_ISLAND_STATS];
     int32_t ccd_active_count, ccd_clamp_count; /* (body, step) cases of the fast-body criterion / of a clamped next_position */
     int nfree_colliders; /* colliders inserted without a parent */
+    /* Arena free lists (data/arena.rs:28-90, 260-380): a removed slot is handed out again, LIFO, before a fresh index is; the
+     * generation an Index carries is the arena's removal count at insertion time (ro_body_generation / ro_collider_generation). */
+    int *body_free; int nbody_free, cap_body_free; uint32_t body_arena_gen; uint32_t *body_gen; int cap_body_gen;
+    int *coll_free; int ncoll_free, cap_coll_free; uint32_t coll_arena_gen; uint32_t *coll_gen; int cap_coll_gen;
+    int dead_pairs;      /* colliders were removed since the last broad-phase pass: their pairs are still in the pair set */
     uint64_t *nc_keys; int n_nc, nc_dirty; /* sorted (min body, max body) keys of the joints with contacts_enabled = false */
     int32_t *col_events; int ncol_events, cap_col_events;       /* 5 ints per event */
     int32_t *force_meta; float *force_vals; int nforce_events, cap_force_events;
@@ -294,6 +299,7 @@ void ro_set_params(ro_world *w, const ro_params *params) { w->params = *params; 
 void ro_world_free(ro_world *w) {
     if (!w) return;
     free(w->bodies); free(w->colliders); free(w->pairs); free(w->map_keys); free(w->map_vals);
+    free(w->body_free); free(w->body_gen); free(w->coll_free); free(w->coll_gen);
     free(w->color_masks); free(w->vels); free(w->incr); free(w->poses); free(w->gyro); free(w->flags);
     free(w->dyn_bodies); free(w->cons); free(w->joints); free(w->active_joints); free(w->joint_order);
     free(w->joint_rows); free(w->joint_body_colors); free(w->uf); free(w->col_events); free(w->force_meta); free(w->force_vals); free(w->nc_keys); free(w->isl); free(w->isl_free); free(w->journal); free(w);
@@ -536,9 +542,18 @@ static int collider_enabled(const Collider *c) { return !(c->memberships == 0 &&
 /* sum of the attached colliders' mass properties at `density_override` (< 0: each collider's own density) */
 static void sum_collider_mass_props(const ro_world *w, int body, float density_override, ro_mp *acc) {
     memset(acc, 0, sizeof(*acc)); acc->frame[3] = 1.0f;
+    /* attachment order (rb.colliders(): ascending `ord`) — not index order: a collider may sit in a reused arena slot */
+    int cnt = 0, cap = 0, *list = NULL;
     for (int i = 0; i < w->ncolliders; ++i) {
         const Collider *c = &w->colliders[i];
         if (c->parent != body || !collider_enabled(c)) continue;
+        if (cnt == cap) { cap = cap ? 2 * cap : 8; list = (int *)realloc(list, sizeof(int) * cap); }
+        int k = cnt++;
+        while (k > 0 && w->colliders[list[k - 1]].ord > c->ord) { list[k] = list[k - 1]; --k; }
+        list[k] = i;
+    }
+    for (int q = 0; q < cnt; ++q) {
+        const Collider *c = &w->colliders[list[q]];
         ro_mp m; memset(&m, 0, sizeof(m)); m.frame[3] = 1.0f;
         v3 pi; shape_mass_props(c, density_override < 0.0f ? c->density : density_override, &m.mass, &pi, m.frame);
         m.pi[0] = pi.x; m.pi[1] = pi.y; m.pi[2] = pi.z;
@@ -547,6 +562,7 @@ static void sum_collider_mass_props(const ro_world *w, int body, float density_o
         ro_mp_transform(&m, t, q);
         ro_mp_add(acc, &m);
     }
+    free(list);
 }
 /* RigidBodyMassProps::recompute_mass_properties_from_colliders — rigid_body_components.rs:421-489: the attached
  * colliders' MassProperties (transformed by pos_wrt_parent) are summed in attachment order, then the additional mass. */
@@ -595,12 +611,36 @@ static void recompute_mass_properties(ro_world *w, Body *b) {
     update_world_mass_properties(b);
 }
 
+static void purge_dead_pairs(ro_world *w);
+static void gen_reserve(uint32_t **gen, int *cap, int n) {
+    if (n <= *cap) return;
+    int nc = *cap ? *cap : 1024; while (nc < n) nc *= 2;
+    *gen = (uint32_t *)realloc(*gen, sizeof(uint32_t) * nc);
+    memset(*gen + *cap, 0, sizeof(uint32_t) * (nc - *cap));
+    *cap = nc;
+}
+static void free_push(int **list, int *n, int *cap, int v) {
+    if (*n == *cap) { *cap = *cap ? *cap * 2 : 64; *list = (int *)realloc(*list, sizeof(int) * *cap); }
+    (*list)[(*n)++] = v;
+}
+uint32_t ro_body_generation(const ro_world *w, int32_t body) { return (body >= 0 && body < w->cap_body_gen) ? w->body_gen[body] : 0u; }
+uint32_t ro_collider_generation(const ro_world *w, int32_t collider) { return (collider >= 0 && collider < w->cap_coll_gen) ? w->coll_gen[collider] : 0u; }
 int32_t ro_add_body(ro_world *w, const ro_body_desc *d) {
-    if (w->nbodies == w->cap_bodies) {
+    /* Arena::insert (arena.rs:260-290): the head of the free list — the slot removed last — before any fresh index */
+    int idx = w->nbodies, reused = 0;
+    if (w->nbody_free > 0 && !getenv("RP_NO_ARENA_REUSE")) {
+        purge_dead_pairs(w);
+        idx = w->body_free[--w->nbody_free]; reused = 1;
+        /* the removed colliders of the slot's previous occupant no longer name it */
+        for (int i = 0; i < w->ncolliders; ++i) if (w->colliders[i].parent == idx && w->colliders[i].memberships == 0 && w->colliders[i].filter == 0) w->colliders[i].parent = -1;
+        if (idx < w->cap_masks) memset(&w->color_masks[idx], 0, sizeof(w->color_masks[idx]));
+    } else if (w->nbodies == w->cap_bodies) {
         w->cap_bodies = w->cap_bodies ? w->cap_bodies * 2 : 1024;
         w->bodies = (Body *)realloc(w->bodies, sizeof(Body) * w->cap_bodies);
     }
-    Body *b = &w->bodies[w->nbodies];
+    gen_reserve(&w->body_gen, &w->cap_body_gen, idx + 1);
+    w->body_gen[idx] = w->body_arena_gen;
+    Body *b = &w->bodies[idx];
     memset(b, 0, sizeof(*b));
     b->body_type = d->body_type;
     b->position.t = V3(d->translation[0], d->translation[1], d->translation[2]);
@@ -620,16 +660,21 @@ int32_t ro_add_body(ro_world *w, const ro_body_desc *d) {
     b->time_until_sleep = 0.5f; b->time_since_can_sleep = 0.0f; b->sleeping = 0;
     b->sleep_prev_pose = pose_ident(); b->island_id = -1; b->slept_at = 0;
     recompute_mass_properties(w, b);
-    pi_ensure_body(w, w->nbodies); /* IslandManager::rigid_body_updated -> PersistentIslands::ensure_body (manager.rs:303) */
-    return w->nbodies++;
+    if (!reused) w->nbodies++;
+    pi_ensure_body(w, idx); /* IslandManager::rigid_body_updated -> PersistentIslands::ensure_body (manager.rs:303) */
+    return idx;
 }
 
 int32_t ro_add_collider(ro_world *w, const ro_collider_desc *d, int32_t parent) {
-    if (w->ncolliders == w->cap_colliders) {
+    int idx = w->ncolliders, reused = 0;
+    if (w->ncoll_free > 0 && !getenv("RP_NO_ARENA_REUSE")) { purge_dead_pairs(w); idx = w->coll_free[--w->ncoll_free]; reused = 1; }
+    else if (w->ncolliders == w->cap_colliders) {
         w->cap_colliders = w->cap_colliders ? w->cap_colliders * 2 : 1024;
         w->colliders = (Collider *)realloc(w->colliders, sizeof(Collider) * w->cap_colliders);
     }
-    Collider *c = &w->colliders[w->ncolliders];
+    gen_reserve(&w->coll_gen, &w->cap_coll_gen, idx + 1);
+    w->coll_gen[idx] = w->coll_arena_gen;
+    Collider *c = &w->colliders[idx];
     memset(c, 0, sizeof(*c));
     c->parent = parent;
     c->shape = d->shape;
@@ -645,7 +690,7 @@ int32_t ro_add_collider(ro_world *w, const ro_collider_desc *d, int32_t parent) 
     c->ord = parent >= 0 ? w->bodies[parent].ncolliders++ : w->nfree_colliders++;
     if (parent >= 0) c->pos = pose_mul(w->bodies[parent].position, c->pos_wrt_parent);
     else c->pos = c->pos_wrt_parent;
-    int idx = w->ncolliders++;
+    if (!reused) w->ncolliders++;
     if (parent >= 0) recompute_mass_properties(w, &w->bodies[parent]);
     w->bp_dirty = 1;
     return idx;
@@ -911,6 +956,20 @@ static void apply_wakes(ro_world *w) {
     for (int i = 0; i < w->isl_next; ++i) if (w->isl[i].used && w->isl[i].sleeping == 2) w->isl[i].sleeping = 0;
 }
 
+static void clear_pair_solver_color(ro_world *w, Pair *p);
+static void delete_pair_effects(ro_world *w, Pair *p) {
+    const Collider *a = &w->colliders[p->c1], *b = &w->colliders[p->c2];
+    /* remove_pair wakes the bodies of a touching pair (pair_management.rs:541-552); remove_collider wakes
+     * every body that had a pair with the removed collider (:88-99) */
+    int gone = (a->memberships == 0 && a->filter == 0) || (b->memberships == 0 && b->filter == 0);
+    if (p->nsc > 0 || gone) { wake_request(w, a->parent, 1); wake_request(w, b->parent, 1); }
+    if (p->nsc > 0) pi_journal(w, a->parent, b->parent, 1, ((uint64_t)(uint32_t)p->c1 << 32) | (uint32_t)p->c2); /* unlink_contact (pair_management.rs:531) */
+    /* Stopped event of a touching pair: remove_pair (pair_management.rs:554-558), remove_collider (:101-110, REMOVED flag) */
+    if (p->nsc > 0 && ((a->active_events | b->active_events) & 1u)) push_collision_event(w, p->c1, p->c2, 0, gone ? 2 : 0);
+    if (p->intersecting && ((a->active_events | b->active_events) & 1u)) push_collision_event(w, p->c1, p->c2, 0, (gone ? 2 : 0) | 1); /* remove_pair / remove_collider on the intersection graph */
+    p->intersecting = 0;
+    clear_pair_solver_color(w, p);
+}
 static void broad_phase_update(ro_world *w) {
     for (int i = 0; i < w->ncolliders; ++i) if (!w->colliders[i].has_fat) bp_set_aabb(w, &w->colliders[i]);
     w->stats.bp_rebuilt = 0;
@@ -950,25 +1009,33 @@ static void broad_phase_update(ro_world *w) {
     /* DeletePair: NarrowPhase::remove_pair (pair_management.rs:382) frees the colour and drops the edge. */
     int out = 0, removed = 0;
     for (int i = 0; i < w->npairs; ++i) {
-        if (!w->pairs[i].alive) {
-            Pair *p = &w->pairs[i];
-            const Collider *a = &w->colliders[p->c1], *b = &w->colliders[p->c2];
-            /* remove_pair wakes the bodies of a touching pair (pair_management.rs:541-552); remove_collider wakes
-             * every body that had a pair with the removed collider (:88-99) */
-            int gone = (a->memberships == 0 && a->filter == 0) || (b->memberships == 0 && b->filter == 0);
-            if (p->nsc > 0 || gone) { wake_request(w, a->parent, 1); wake_request(w, b->parent, 1); }
-            if (p->nsc > 0) pi_journal(w, a->parent, b->parent, 1, ((uint64_t)(uint32_t)p->c1 << 32) | (uint32_t)p->c2); /* unlink_contact (pair_management.rs:531) */
-            /* Stopped event of a touching pair: remove_pair (pair_management.rs:554-558), remove_collider (:101-110, REMOVED flag) */
-            if (p->nsc > 0 && ((a->active_events | b->active_events) & 1u)) push_collision_event(w, p->c1, p->c2, 0, gone ? 2 : 0);
-            if (p->intersecting && ((a->active_events | b->active_events) & 1u)) push_collision_event(w, p->c1, p->c2, 0, (gone ? 2 : 0) | 1); /* remove_pair / remove_collider on the intersection graph */
-            p->intersecting = 0;
-            clear_pair_solver_color(w, p); removed = 1; continue;
-        }
+        if (!w->pairs[i].alive) { delete_pair_effects(w, &w->pairs[i]); removed = 1; continue; }
         if (out != i) w->pairs[out] = w->pairs[i];
         out++;
     }
     w->npairs = out;
     if (removed) map_rebuild(w);
+    w->dead_pairs = 0;
+}
+/* NarrowPhase::handle_user_changes for removed colliders (pair_management.rs:24-203) ahead of time: the pairs of every removed
+ * collider leave the pair set NOW, with the effects the next step's broad-phase pass would have had (events stamped with that step).
+ * Called before an arena slot is handed out again — the reference removes the pairs of a removed collider by HANDLE (index +
+ * generation) at the start of the next step; here a pair names its colliders by index alone, so it must not outlive the slot. */
+static void purge_dead_pairs(ro_world *w) {
+    if (!w->dead_pairs) return;
+    w->dead_pairs = 0;
+    w->step_seq++;
+    int out = 0, removed = 0;
+    for (int i = 0; i < w->npairs; ++i) {
+        Pair *p = &w->pairs[i];
+        const Collider *a = &w->colliders[p->c1], *b = &w->colliders[p->c2];
+        if ((a->memberships == 0 && a->filter == 0) || (b->memberships == 0 && b->filter == 0)) { delete_pair_effects(w, p); removed = 1; continue; }
+        if (out != i) w->pairs[out] = w->pairs[i];
+        out++;
+    }
+    w->npairs = out;
+    if (removed) map_rebuild(w);
+    w->step_seq--;
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -3151,6 +3218,9 @@ int32_t ro_remove_collider(ro_world *w, int32_t collider) {
     c->memberships = 0; c->filter = 0;
     w->bp_dirty = 1;
     if (c->parent >= 0) recompute_mass_properties(w, &w->bodies[c->parent]);
+    w->coll_arena_gen++; /* Arena::remove (arena.rs:353-380): the generation counts removals, the slot heads the free list */
+    free_push(&w->coll_free, &w->ncoll_free, &w->cap_coll_free, collider);
+    w->dead_pairs = 1;
     return 0;
 }
 /* RigidBodySet::remove with remove_attached_colliders = true (rigid_body_set.rs:121-170): attached
@@ -3158,13 +3228,24 @@ int32_t ro_remove_collider(ro_world *w, int32_t collider) {
 int32_t ro_remove_body(ro_world *w, int32_t body) {
     if (body < 0 || body >= w->nbodies) return -1;
     Body *b = &w->bodies[body];
-    for (int i = 0; i < w->ncolliders; ++i) if (w->colliders[i].parent == body) ro_remove_collider(w, i);
+    for (int k = 0; k < w->nbody_free; ++k) if (w->body_free[k] == body) return -1; /* a free slot: the handle is stale */
+    /* the attached colliders go in attachment order (rigid_body_set.rs:140-150 walks rb.colliders()): that is the order of the free list */
+    for (int ord = 0, left = 1; left; ++ord) {
+        left = 0;
+        for (int i = 0; i < w->ncolliders; ++i) {
+            const Collider *c = &w->colliders[i];
+            if (c->parent != body || (c->memberships == 0 && c->filter == 0)) continue;
+            if (c->ord == ord) ro_remove_collider(w, i); else if (c->ord > ord) left = 1;
+        }
+    }
     for (int i = 0; i < w->njoints; ++i) if (!w->joints[i].removed && (w->joints[i].body1 == body || w->joints[i].body2 == body)) ro_remove_joint(w, i);
     pi_remove_body(w, body); /* IslandManager::rigid_body_removed_or_disabled (manager.rs:62-78) */
     b->body_type = RO_BODY_FIXED;
     b->linvel = V3(0, 0, 0); b->angvel = V3(0, 0, 0);
     b->solver_id = RO_NO_BODY;
     update_world_mass_properties(b);
+    w->body_arena_gen++;
+    free_push(&w->body_free, &w->nbody_free, &w->cap_body_free, body);
     return 0;
 }
 int32_t ro_num_joints(const ro_world *w) { return w->njoints; }

@@ -112,6 +112,9 @@ int32_t ro_add_body(ro_world *w, const ro_body_desc *d);
 int32_t ro_add_collider(ro_world *w, const ro_collider_desc *d, int32_t parent_body);
 int32_t ro_add_joint(ro_world *w, const ro_joint_desc *d);
 int32_t ro_remove_body(ro_world *w, int32_t body);
+/* Index::generation of the occupant of an arena slot (data/arena.rs:58-90): the arena's removal count when it was inserted */
+uint32_t ro_body_generation(const ro_world *w, int32_t body);
+uint32_t ro_collider_generation(const ro_world *w, int32_t collider);
 int32_t ro_remove_collider(ro_world *w, int32_t collider);
 int32_t ro_remove_joint(ro_world *w, int32_t joint);
 /* GenericJoint::set_motor through ImpulseJointSet::get_mut(handle, wake_up = true): enables the axis' motor */

@@ -116,7 +116,7 @@ struct HostBody {
 // capacities (or receives a joint) can move to larger arrays and keep every persistent row: `per` contiguous elements per item,
 // `planes` planes of `stride` items each, items indexed by body / collider / pair slot / device joint.
 enum { DOM_NONE = 0, DOM_BODY, DOM_COLL, DOM_PAIR, DOM_JOINT, DOM_FIXED /* fixed-size array, carried whole */ };
-struct AllocRec { void *ptr; size_t off, elem, per, stride; int planes, dom; };
+struct AllocRec { void *ptr; size_t off, elem, per, stride; int planes, dom, fill; };
 
 struct rp_world {
     int device = 0;
@@ -127,6 +127,11 @@ struct rp_world {
     std::vector<rp_collider_desc> colliders;
     std::vector<int> collider_parent, collider_ord; // ord: ordinal among the colliders of the same parent (attachment order)
     int next_free_ord = 0;
+    // Arena slots (data/arena.rs:28-90, 260-380): a removed body / collider slot is handed out again, LIFO, before a fresh index is;
+    // a handle = generation << 32 | index, the generation being the arena's removal count at insertion time
+    std::vector<uint32_t> body_gen, coll_gen; uint32_t body_arena_gen = 0, coll_arena_gen = 0;
+    std::vector<int> body_free, coll_free;
+    bool dead_pairs_possible = false; // colliders were removed since the last step: their pairs are still in the device pair set
     std::vector<char> collider_removed, joint_removed;
     std::vector<rp_joint_desc> joints;
     std::vector<int> active_joint_ids; // device joint index -> index into `joints`
@@ -223,6 +228,10 @@ static int finalize(rp_world *w);
 static int quarantine_body_at(rp_world *w, int b);
 static bool all_finite(const float *v, int n);
 static int handle_index(uint64_t h);
+static int body_of(const rp_world *w, uint64_t h, bool allow_removed = false);
+static int collider_of(const rp_world *w, uint64_t h);
+static int reset_row(rp_world *w, int dom, int i);
+static int purge_dead_pairs(rp_world *w);
 template <typename T> static int poke(rp_world *w, T *dst, const T &v);
 template <typename T> static int poke(rp_world *w, T *dst, const T &v);
 
@@ -777,13 +786,22 @@ extern "C" int32_t rp_bodies_insert(rp_world *w, int32_t n, const rp_body_desc *
     // RigidBodySet::insert into a live world: rows are appended in place while the device arrays have
     // room (every pair keeps its warm-start data); otherwise the device world is rebuilt from the
     // current body states
-    const bool in_place = w->finalized && (int)w->bodies.size() + n <= w->cap_bodies;
+    // Arena::insert (arena.rs:260-290): removed slots first (LIFO), then fresh indices.  A batch that needs both is split: the reused
+    // slots are rewritten in place, the rest follows the append path (in place, or through the growth carry-over)
+    static const bool no_reuse = getenv("RP_NO_ARENA_REUSE") != nullptr; // (debug: append only, like rounds 1-3)
+    const int n_reuse = no_reuse ? 0 : std::min<int>(n, (int)w->body_free.size());
+    if (n_reuse > 0 && n_reuse < n) {
+        int r = rp_bodies_insert(w, n_reuse, descs, handles_out);
+        return r != RP_OK ? r : rp_bodies_insert(w, n - n_reuse, descs + n_reuse, handles_out ? handles_out + n_reuse : nullptr);
+    }
+    const bool reuse = n_reuse > 0;
+    const bool in_place = w->finalized && (reuse || (int)w->bodies.size() + n <= w->cap_bodies);
     if (n > 0 && w->finalized) {
         HIPCHK(w, hipSetDevice(w->device));
         int r = in_place ? settle(w) : grow_begin(w);
         if (r != RP_OK) return r;
     }
-    if ((long long)w->bodies.size() + n >= 0xfffff) { w->err = "rp_bodies_insert: more than 2^20 - 1 bodies"; return RP_ERR_CAPACITY; }
+    if (!reuse && (long long)w->bodies.size() + n >= 0xfffff) { w->err = "rp_bodies_insert: more than 2^20 - 1 bodies"; return RP_ERR_CAPACITY; }
     for (int i = 0; i < n; ++i) if (descs[i].body_type < RP_BODY_DYNAMIC || descs[i].body_type > RP_BODY_KINEMATIC_VELOCITY) { w->err = "rp_bodies_insert: unknown body_type"; return RP_ERR_INVALID; }
     for (int i = 0; i < n; ++i) if (descs[i].additional_solver_iterations < 0 || descs[i].additional_solver_iterations > 4096) { w->err = "rp_bodies_insert: additional_solver_iterations must be in [0, 4096]"; return RP_ERR_INVALID; }
     { // the distinct-count limit of the solve groups is checked on the prospective values, before host or device state changes
@@ -791,13 +809,32 @@ extern "C" int32_t rp_bodies_insert(rp_world *w, int32_t n, const rp_body_desc *
         for (int i = 0; i < n; ++i) if (descs[i].additional_solver_iterations > 0 && std::find(extras.begin(), extras.end(), descs[i].additional_solver_iterations) == extras.end()) extras.push_back(descs[i].additional_solver_iterations);
         if ((int)extras.size() > RP_MAX_GROUPS) { w->err = "more than 15 distinct positive additional_solver_iterations values in one world"; return RP_ERR_CAPACITY; }
     }
+    if (reuse && w->finalized) { int r = purge_dead_pairs(w); if (r != RP_OK) return r; } // no pair may still name the slots' previous occupants
+    int first_slot = -1;
     for (int i = 0; i < n; ++i) {
         HostBody b; b.d = descs[i]; b.ncolliders = 0; b.removed = false; b.inv_mass = 0; b.inv_pi[0] = b.inv_pi[1] = b.inv_pi[2] = 0; b.lcom[0] = b.lcom[1] = b.lcom[2] = 0;
-        b.slabel = (int)w->bodies.size();
-        w->bodies.push_back(b);
-        recompute_mass(w, (int)w->bodies.size() - 1);
-        if (handles_out) handles_out[i] = (uint64_t)(w->bodies.size() - 1);
-        if (in_place) { int r = upload_body_row(w, (int)w->bodies.size() - 1); if (r != RP_OK) return r; }
+        int slot;
+        if (reuse) {
+            slot = w->body_free.back(); w->body_free.pop_back();
+            // (the removed colliders of the slot's previous occupant no longer name it)
+            for (size_t c = 0; c < w->colliders.size(); ++c) if (w->collider_parent[c] == slot && w->collider_removed[c]) w->collider_parent[c] = -1;
+            b.slabel = slot;
+            w->bodies[(size_t)slot] = b;
+        } else {
+            slot = (int)w->bodies.size();
+            b.slabel = slot;
+            w->bodies.push_back(b); w->body_gen.push_back(0);
+        }
+        w->body_gen[(size_t)slot] = w->body_arena_gen;
+        if (first_slot < 0) first_slot = slot;
+        recompute_mass(w, slot);
+        if (handles_out) handles_out[i] = ((uint64_t)w->body_arena_gen << 32) | (uint64_t)(uint32_t)slot;
+        if (in_place) {
+            int r;
+            if (reuse && (r = reset_row(w, DOM_BODY, slot)) != RP_OK) return r;
+            if ((r = upload_body_row(w, slot)) != RP_OK) return r;
+            if (reuse && w->dw.sleep_enabled) rp_launch_pi_ensure(w->dw, w->stream, slot, 1, 0);
+        }
     }
     if (in_place && n > 0) {
         const int first_new = w->dw.n_bodies, was_sleep_enabled = w->dw.sleep_enabled;
@@ -805,7 +842,7 @@ extern "C" int32_t rp_bodies_insert(rp_world *w, int32_t n, const rp_body_desc *
         { int r = check_sleep_scope(w); if (r != RP_OK) return r; }
         w->dw.sleep_enabled = world_sleep_enabled(w) ? 1 : 0;
         // persistent islands: ensure_body for the new rows; a world that becomes sleep-enabled now bootstraps its islands
-        if (w->dw.sleep_enabled) rp_launch_pi_ensure(w->dw, w->stream, was_sleep_enabled ? first_new : 0, was_sleep_enabled ? n : w->dw.n_bodies, was_sleep_enabled ? 0 : 1);
+        if (w->dw.sleep_enabled && (!reuse || !was_sleep_enabled)) rp_launch_pi_ensure(w->dw, w->stream, was_sleep_enabled ? first_new : 0, was_sleep_enabled ? n : w->dw.n_bodies, was_sleep_enabled ? 0 : 1);
         w->dw.has_kinematic_pos = world_has_kinematic_pos(w) ? 1 : 0; refresh_ccd_facts(w);
         HIPCHK(w, hipStreamSynchronize(w->stream));
         { int r = upload_group_table(w); if (r != RP_OK) return r; }
@@ -824,40 +861,60 @@ extern "C" int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider
             const float *nn = cd.half_extents; const float l2 = nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2];
             if (!(std::fabs(l2 - 1.0f) <= 1.0e-3f)) { w->err = "rp_colliders_insert: a half-space's half_extents hold its unit outward normal"; return RP_ERR_INVALID; }
             if (parents && parents[i] != RP_INVALID_HANDLE) {
-                const int pb = handle_index(parents[i]);
+                const int pb = body_of(w, parents[i]);
                 if (pb >= 0 && pb < (int)w->bodies.size() && w->bodies[pb].d.body_type == RP_BODY_DYNAMIC) { w->err = "rp_colliders_insert: a half-space needs a fixed or kinematic parent (or none)"; return RP_ERR_INVALID; }
             }
         }
         if (cd.shape == RP_SHAPE_CAPSULE && (cd.half_extents[2] != 0.0f && cd.half_extents[2] != 1.0f && cd.half_extents[2] != 2.0f)) { w->err = "rp_colliders_insert: capsule half_extents = (half_height, radius, axis) with axis 0, 1 or 2"; return RP_ERR_INVALID; }
     }
     if ((long long)w->colliders.size() + n >= (1ll << 24)) { w->err = "rp_colliders_insert: more than 2^24 - 1 colliders (the broad-phase grid's one-word entries)"; return RP_ERR_CAPACITY; }
-    const bool in_place = w->finalized && (int)w->colliders.size() + n <= w->cap_colliders; // see rp_bodies_insert
+    static const bool no_reuse = getenv("RP_NO_ARENA_REUSE") != nullptr;
+    const int n_reuse = no_reuse ? 0 : std::min<int>(n, (int)w->coll_free.size()); // Arena::insert: removed slots first (see rp_bodies_insert)
+    if (n_reuse > 0 && n_reuse < n) {
+        int r = rp_colliders_insert(w, n_reuse, descs, parents, handles_out);
+        return r != RP_OK ? r : rp_colliders_insert(w, n - n_reuse, descs + n_reuse, parents ? parents + n_reuse : nullptr, handles_out ? handles_out + n_reuse : nullptr);
+    }
+    const bool reuse = n_reuse > 0;
+    const bool in_place = w->finalized && (reuse || (int)w->colliders.size() + n <= w->cap_colliders); // see rp_bodies_insert
     if (n > 0 && w->finalized) {
         HIPCHK(w, hipSetDevice(w->device));
         int r = in_place ? settle(w) : grow_begin(w);
         if (r != RP_OK) return r;
     }
+    for (int i = 0; i < n; ++i) if (parents && parents[i] != RP_INVALID_HANDLE) {
+        const int parent = body_of(w, parents[i]);
+        if (parent < 0 || w->bodies[parent].quarantined) { w->err = "rp_colliders_insert: invalid parent handle (unknown, stale, removed or quarantined body)"; return RP_ERR_INVALID; }
+    }
+    if (reuse && w->finalized) { int r = purge_dead_pairs(w); if (r != RP_OK) return r; } // no pair may still name the slots' previous occupants
+    std::vector<int> new_slots;
     for (int i = 0; i < n; ++i) {
-        int parent = -1;
-        if (parents && parents[i] != RP_INVALID_HANDLE) {
-            parent = handle_index(parents[i]);
-            if (parent < 0 || parent >= (int)w->bodies.size() || w->bodies[parent].removed || w->bodies[parent].quarantined) { w->err = "rp_colliders_insert: invalid parent handle (unknown, removed or quarantined body)"; return RP_ERR_INVALID; }
-        }
+        const int parent = (parents && parents[i] != RP_INVALID_HANDLE) ? body_of(w, parents[i]) : -1;
         int &ord_counter = parent >= 0 ? w->bodies[parent].next_ord : w->next_free_ord;
         if (ord_counter >= (parent >= 0 ? 4096 : (1 << 20))) { w->err = "rp_colliders_insert: more than 4,096 colliders on one body (or 2^20 without a parent)"; return RP_ERR_CAPACITY; }
-        w->collider_ord.push_back(ord_counter++);
-        w->colliders.push_back(descs[i]);
-        w->collider_parent.push_back(parent);
-        if (parent >= 0) w->bodies[parent].cols.push_back((int)w->collider_parent.size() - 1);
-        w->collider_removed.push_back(0);
+        int ci;
+        if (reuse) {
+            ci = w->coll_free.back(); w->coll_free.pop_back();
+            w->collider_ord[(size_t)ci] = ord_counter++; w->colliders[(size_t)ci] = descs[i]; w->collider_parent[(size_t)ci] = parent; w->collider_removed[(size_t)ci] = 0;
+        } else {
+            ci = (int)w->colliders.size();
+            w->collider_ord.push_back(ord_counter++); w->colliders.push_back(descs[i]); w->collider_parent.push_back(parent); w->collider_removed.push_back(0); w->coll_gen.push_back(0);
+        }
+        w->coll_gen[(size_t)ci] = w->coll_arena_gen;
+        new_slots.push_back(ci);
+        if (parent >= 0) w->bodies[parent].cols.push_back(ci);
         if (parent >= 0) { w->bodies[parent].ncolliders++; recompute_mass(w, parent); }
         if (descs[i].restitution > 0.0f) w->has_restitution = true;
-        if (handles_out) handles_out[i] = (uint64_t)(w->colliders.size() - 1);
+        if (handles_out) handles_out[i] = ((uint64_t)w->coll_arena_gen << 32) | (uint64_t)(uint32_t)ci;
         if (in_place) {
-            int r = upload_collider_row(w, (int)w->colliders.size() - 1);
+            int r = reuse ? reset_row(w, DOM_COLL, ci) : RP_OK;
+            if (r == RP_OK) r = upload_collider_row(w, ci);
             if (r == RP_OK && parent >= 0) r = upload_body_row_mass(w, parent);
             if (r == RP_OK && parent >= 0) r = refresh_joint_frames(w, parent); // the local centre of mass moved
-            if (r == RP_OK && parent >= 0 && w->bodies[parent].d.body_type == RP_BODY_DYNAMIC) { int ci = (int)w->colliders.size() - 1; HIPCHK(w, hipMemcpy(w->dw.b_collider + parent, &ci, sizeof(int), hipMemcpyHostToDevice)); }
+            if (r == RP_OK && parent >= 0 && w->bodies[parent].d.body_type == RP_BODY_DYNAMIC) {
+                // b_collider: the body's LAST live collider (the single-collider fast paths read it)
+                int last = -1; for (int q = 0; q < (int)w->colliders.size(); ++q) if (w->collider_parent[q] == parent && !w->collider_removed[q]) last = q;
+                HIPCHK(w, hipMemcpy(w->dw.b_collider + parent, &last, sizeof(int), hipMemcpyHostToDevice));
+            }
             if (r != RP_OK) return r;
         }
     }
@@ -865,7 +922,7 @@ extern "C" int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider
         w->dw.n_colliders = (int)w->colliders.size();
         // the world-wide facts can only be switched ON by an insertion: looked up on the new rows alone (the full scans of
         // world_has_* walk every collider — a million in b3d_large_world, per dropped sphere)
-        for (size_t ci = w->colliders.size() - (size_t)n; ci < w->colliders.size(); ++ci) {
+        for (size_t ci : new_slots) {
             const rp_collider_desc &c = w->colliders[ci];
             const int p = w->collider_parent[ci];
             if (c.active_events & RP_EVENTS_CONTACT_FORCE) w->dw.has_force_events = 1;
@@ -909,7 +966,7 @@ static int dalloc(rp_world *w, T *&p, size_t count, int fill_byte = 0, int dom =
     size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
     if (locked_hipMallocBytes((void **)&q, bytes) != hipSuccess) { w->err = "hipMalloc failed"; return RP_ERR_DEVICE; }
     if (hipMemsetAsync(q, fill_byte, bytes, w->stream) != hipSuccess) { w->err = "hipMemset failed"; return RP_ERR_DEVICE; }
-    AllocRec a; a.ptr = q; a.off = (size_t)((char *)&p - (char *)&w->dw); a.elem = sizeof(T); a.per = (size_t)per; a.planes = planes; a.dom = dom;
+    AllocRec a; a.ptr = q; a.off = (size_t)((char *)&p - (char *)&w->dw); a.elem = sizeof(T); a.per = (size_t)per; a.planes = planes; a.dom = dom; a.fill = fill_byte;
     a.stride = count / ((size_t)planes * (size_t)per);
     w->allocs.push_back(a);
     p = (T *)q;
@@ -1188,7 +1245,7 @@ static int finalize(rp_world *w) {
 
     DA(d.flags, FL_COUNT); DA(d.dbg, 1024); DA(d.bar, 16);
     DAC(d.b_pos, capb, DOM_BODY, 1, 1); DAC(d.b_rot, capb, DOM_BODY, 1, 1); DAC(d.b_linvel, capb, DOM_BODY, 1, 1); DAC(d.b_angvel, capb, DOM_BODY, 1, 1); DA(d.b_lcom_invm, capb); DA(d.b_invpi, capb);
-    DA(d.b_pframe, capb); DAC(d.b_wcom, capb, DOM_BODY, 1, 1); DAC(d.b_eim, capb, DOM_BODY, 1, 1); DAC(d.b_eii0, capb, DOM_BODY, 1, 1); DAC(d.b_eii1, capb, DOM_BODY, 1, 1); DAC(d.b_damp, capb, DOM_BODY, 1, 1);
+    DA(d.b_pframe, capb); DAC(d.b_wcom, capb, DOM_BODY, 1, 1); DAC(d.b_eim, capb, DOM_BODY, 1, 1); DAC(d.b_eii0, capb, DOM_BODY, 1, 1); DAC(d.b_eii1, capb, DOM_BODY, 1, 1); DA(d.b_damp, capb); /* host-authoritative (damping, gravity scale, ccd_thickness): NOT carried over a growth — the carried copy of a row whose body got a collider in the same call held the old thickness (found by the growth fuzz, round 4) */
     DAC(d.b_uforce, capb, DOM_BODY, 1, 1); DAC(d.b_utorque, capb, DOM_BODY, 1, 1); DAC(d.b_flags, capb, DOM_BODY, 1, 1); DAC(d.b_quar, capb, DOM_BODY, 1, 1); DAF(d.b_collider, capb, 0xff);
     DA(d.b_ccd0_pos, capb); DA(d.b_ccd0_rot, capb); DA(d.ccd_list, capb); // continuous-collision pass: scratch of one step
     DAC(d.b_sleep, capb, DOM_BODY, 1, 1); DA(d.b_sprev_t, capb); DAC(d.b_sprev_r, capb, DOM_BODY, 1, 1); DAC(d.b_slabel, capb, DOM_BODY, 1, 1); DAC(d.b_slept_at, capb, DOM_BODY, 1, 1); DA(d.b_sleep_stamp, capb); DAC(d.b_wake_req, capb, DOM_BODY, 1, 1);
@@ -1813,6 +1870,7 @@ extern "C" int32_t rp_step(rp_world *w, uint32_t nsteps) {
             }
         }
         w->steps_requested++;
+        w->dead_pairs_possible = false; // (this step's broad-phase pass deletes the pairs of every collider removed so far)
         int r = step_once(w, true);
         if (r != RP_OK) return r;
         if (w->timers) { r = settle(w); if (r != RP_OK) return r; } // timed steps are observed one by one
@@ -1841,7 +1899,7 @@ extern "C" int32_t rp_bodies_read(rp_world *w, int32_t n, const uint64_t *handle
     HIPCHK(w, hipStreamSynchronize(w->stream));
     int count = handles ? n : nb;
     for (int i = 0; i < count; ++i) {
-        int b = handles ? handle_index(handles[i]) : i;
+        int b = handles ? body_of(w, handles[i], true) : i;
         if (b < 0 || b >= nb) { w->err = "rp_bodies_read: invalid handle"; return RP_ERR_INVALID; }
         if (pos7_out) { float *p = pos7_out + 7 * i; p[0] = pos[b].x; p[1] = pos[b].y; p[2] = pos[b].z; p[3] = rot[b].x; p[4] = rot[b].y; p[5] = rot[b].z; p[6] = rot[b].w; }
         if (vel6_out) { float *v = vel6_out + 6 * i; v[0] = lv[b].x; v[1] = lv[b].y; v[2] = lv[b].z; v[3] = av[b].x; v[4] = av[b].y; v[5] = av[b].z; }
@@ -1856,7 +1914,7 @@ extern "C" int32_t rp_bodies_write(rp_world *w, int32_t n, const uint64_t *handl
     { int r = settle(w); if (r != RP_OK) return r; }
     bool quarantined_any = false;
     for (int i = 0; i < n; ++i) {
-        int b = handle_index(handles[i]);
+        int b = body_of(w, handles[i]);
         if (b < 0 || b >= w->dw.n_bodies || w->bodies[b].removed) { w->err = "rp_bodies_write: invalid handle"; return RP_ERR_INVALID; }
         if ((vel6 && !all_finite(vel6 + 6 * i, 6)) || (pos7 && !all_finite(pos7 + 7 * i, 7))) {
             // Quarantine::detect_user_changes (quarantine.rs:68-129): a non-finite user write never reaches the broad phase; the body
@@ -1906,7 +1964,7 @@ extern "C" int32_t rp_bodies_write(rp_world *w, int32_t n, const uint64_t *handl
         // set_linvel / set_position(.., wake_up = true): strong wake of the body (its whole island when asleep); a moved
         // body also wakes every body it has a pair with (pair_management.rs:236-258)
         for (int i = 0; i < n; ++i) {
-            int b = handle_index(handles[i]), lvl = pos7 ? 3 : 2;
+            int b = body_of(w, handles[i]), lvl = pos7 ? 3 : 2;
             { int r = queue_wake(w, b, lvl); if (r != RP_OK) return r; }
         }
         if (pos7) rp_launch_wake_partners(w->dw, w->stream);
@@ -1934,7 +1992,7 @@ extern "C" int32_t rp_bodies_set_additional_solver_iterations(rp_world *w, int32
     HIPCHK(w, hipSetDevice(w->device));
     if (w->finalized) { int r = settle(w); if (r != RP_OK) return r; }
     for (int i = 0; i < n; ++i) {
-        int b = handle_index(handles[i]);
+        int b = body_of(w, handles[i]);
         if (b < 0 || b >= (int)w->bodies.size() || w->bodies[b].removed) { w->err = "rp_bodies_set_additional_solver_iterations: invalid handle"; return RP_ERR_INVALID; }
         if (counts[i] < 0 || counts[i] > 4096) { w->err = "rp_bodies_set_additional_solver_iterations: count must be in [0, 4096]"; return RP_ERR_INVALID; }
     }
@@ -1944,13 +2002,13 @@ extern "C" int32_t rp_bodies_set_additional_solver_iterations(rp_world *w, int32
             const HostBody &hb = w->bodies[q];
             if (hb.removed || hb.quarantined) continue;
             int v = hb.d.additional_solver_iterations;
-            for (int i = 0; i < n; ++i) if (handle_index(handles[i]) == (int)q) v = counts[i];
+            for (int i = 0; i < n; ++i) if (body_of(w, handles[i]) == (int)q) v = counts[i];
             if (v > 0 && std::find(prospective.begin(), prospective.end(), v) == prospective.end()) prospective.push_back(v);
         }
         if ((int)prospective.size() + 1 > RP_MAX_GROUPS) { w->err = "more than 15 distinct positive additional_solver_iterations values in one world"; return RP_ERR_CAPACITY; }
     }
     for (int i = 0; i < n; ++i) {
-        int b = handle_index(handles[i]);
+        int b = body_of(w, handles[i]);
         w->bodies[b].d.additional_solver_iterations = counts[i];
         if (w->finalized) { int r = poke(w, w->dw.b_extra + b, (int)counts[i]); if (r != RP_OK) return r; }
     }
@@ -1967,8 +2025,8 @@ extern "C" int32_t rp_bodies_wake_up(rp_world *w, int32_t n, const uint64_t *han
     if (!w->finalized) { int r = finalize(w); if (r != RP_OK) return r; }
     { int r = settle(w); if (r != RP_OK) return r; }
     for (int i = 0; i < n; ++i) {
-        int b = (int)(handles[i] & 0xffffffffull);
-        if ((handles[i] >> 32) != 0 || b >= w->dw.n_bodies || w->bodies[b].removed) { w->err = "rp_bodies_wake_up: invalid handle"; return RP_ERR_INVALID; }
+        int b = body_of(w, handles[i]);
+        if (b < 0) { w->err = "rp_bodies_wake_up: invalid handle"; return RP_ERR_INVALID; }
         { int r = queue_wake(w, b, strong ? 2 : 1); if (r != RP_OK) return r; }
     }
     return RP_OK;
@@ -1980,8 +2038,8 @@ extern "C" int32_t rp_bodies_add_force(rp_world *w, int32_t n, const uint64_t *h
     if (!w->finalized) { int r = finalize(w); if (r != RP_OK) return r; }
     { int r = settle(w); if (r != RP_OK) return r; }
     for (int i = 0; i < n; ++i) {
-        int b = (int)(handles[i] & 0xffffffffull);
-        if ((handles[i] >> 32) != 0 || b >= w->dw.n_bodies || w->bodies[b].removed) { w->err = "rp_bodies_add_force: invalid handle"; return RP_ERR_INVALID; }
+        int b = body_of(w, handles[i]);
+        if (b < 0) { w->err = "rp_bodies_add_force: invalid handle"; return RP_ERR_INVALID; }
         float4 f, t; bool wake = false;
         HIPCHK(w, hipMemcpy(&f, w->dw.b_uforce + b, sizeof(f), hipMemcpyDeviceToHost));
         HIPCHK(w, hipMemcpy(&t, w->dw.b_utorque + b, sizeof(t), hipMemcpyDeviceToHost));
@@ -2007,8 +2065,8 @@ extern "C" int32_t rp_bodies_apply_impulse(rp_world *w, int32_t n, const uint64_
     if (!w->finalized) { int r = finalize(w); if (r != RP_OK) return r; }
     { int r = settle(w); if (r != RP_OK) return r; }
     for (int i = 0; i < n; ++i) {
-        int b = (int)(handles[i] & 0xffffffffull);
-        if ((handles[i] >> 32) != 0 || b >= w->dw.n_bodies || w->bodies[b].removed) { w->err = "rp_bodies_apply_impulse: invalid handle"; return RP_ERR_INVALID; }
+        int b = body_of(w, handles[i]);
+        if (b < 0) { w->err = "rp_bodies_apply_impulse: invalid handle"; return RP_ERR_INVALID; }
         if (w->bodies[b].d.body_type != RP_BODY_DYNAMIC) continue;
         const float *p = impulse3 ? impulse3 + 3 * i : nullptr, *q = torque_impulse3 ? torque_impulse3 + 3 * i : nullptr;
         bool wake = false;
@@ -2043,8 +2101,8 @@ extern "C" int32_t rp_bodies_set_next_kinematic_position(rp_world *w, int32_t n,
     { int r = settle(w); if (r != RP_OK) return r; }
     bool quarantined_any = false;
     for (int i = 0; i < n; ++i) {
-        int b = (int)(handles[i] & 0xffffffffull);
-        if ((handles[i] >> 32) != 0 || b >= w->dw.n_bodies || w->bodies[b].removed) { w->err = "rp_bodies_set_next_kinematic_position: invalid handle"; return RP_ERR_INVALID; }
+        int b = body_of(w, handles[i]);
+        if (b < 0) { w->err = "rp_bodies_set_next_kinematic_position: invalid handle"; return RP_ERR_INVALID; }
         int type = w->bodies[b].d.body_type;
         if (type != RP_BODY_KINEMATIC_POSITION && type != RP_BODY_KINEMATIC_VELOCITY) continue; // "if self.is_kinematic()"
         if (!all_finite(pos7 + 7 * i, 7)) { // only the kinematic target is invalid: the pose keeps its valid half (quarantine.rs:93-99)
@@ -2066,6 +2124,21 @@ extern "C" int32_t rp_bodies_set_next_kinematic_position(rp_world *w, int32_t n,
     return RP_OK;
 }
 // RigidBody::is_sleeping per handle (1 = asleep).
+// RigidBodySet::iter / ColliderSet::iter as handles (rigid_body_set.rs, collider_set.rs; Arena::iter, arena.rs:665-700): the handle of
+// every arena row in index order — generation << 32 | index of the occupant inserted last (free rows: of the occupant removed last,
+// which no entry point but rp_bodies_read accepts any more).  Returns the number of rows; writes min(rows, cap) handles.
+extern "C" int32_t rp_bodies_handles(const rp_world *w, int32_t cap, uint64_t *out) {
+    if (!w || cap < 0 || (cap > 0 && !out)) return RP_ERR_INVALID;
+    const int n = (int)w->bodies.size();
+    for (int i = 0; i < n && i < cap; ++i) out[i] = ((uint64_t)w->body_gen[(size_t)i] << 32) | (uint64_t)(uint32_t)i;
+    return n;
+}
+extern "C" int32_t rp_colliders_handles(const rp_world *w, int32_t cap, uint64_t *out) {
+    if (!w || cap < 0 || (cap > 0 && !out)) return RP_ERR_INVALID;
+    const int n = (int)w->colliders.size();
+    for (int i = 0; i < n && i < cap; ++i) out[i] = ((uint64_t)w->coll_gen[(size_t)i] << 32) | (uint64_t)(uint32_t)i;
+    return n;
+}
 extern "C" int32_t rp_bodies_is_sleeping(rp_world *w, int32_t n, const uint64_t *handles, int32_t *out) {
     if (!w || n < 0 || (n > 0 && (!handles || !out))) return RP_ERR_INVALID;
     HIPCHK(w, hipSetDevice(w->device));
@@ -2074,8 +2147,8 @@ extern "C" int32_t rp_bodies_is_sleeping(rp_world *w, int32_t n, const uint64_t 
     std::vector<int> fl(w->dw.n_bodies);
     if (!fl.empty()) HIPCHK(w, hipMemcpy(fl.data(), w->dw.b_flags, fl.size() * sizeof(int), hipMemcpyDeviceToHost));
     for (int i = 0; i < n; ++i) {
-        int b = (int)(handles[i] & 0xffffffffull);
-        if ((handles[i] >> 32) != 0 || b >= w->dw.n_bodies) { w->err = "rp_bodies_is_sleeping: invalid handle"; return RP_ERR_INVALID; }
+        int b = body_of(w, handles[i], true);
+        if (b < 0) { w->err = "rp_bodies_is_sleeping: invalid handle"; return RP_ERR_INVALID; }
         out[i] = ((fl[b] & RP_BF_TYPE_MASK) != RP_BODY_FIXED && (fl[b] & RP_BF_SLEEPING)) ? 1 : 0;
     }
     return RP_OK;
@@ -2091,7 +2164,7 @@ extern "C" int32_t rp_bodies_persistent_island(rp_world *w, int32_t n, const uin
     std::vector<int> isl(std::max(w->dw.n_bodies, 1), -1);
     if (w->dw.sleep_enabled && w->dw.n_bodies > 0) HIPCHK(w, hipMemcpy(isl.data(), w->dw.b_isl, (size_t)w->dw.n_bodies * sizeof(int), hipMemcpyDeviceToHost));
     for (int i = 0; i < n; ++i) {
-        int b = handle_index(handles[i]);
+        int b = body_of(w, handles[i], true);
         if (b < 0 || b >= w->dw.n_bodies) { w->err = "rp_bodies_persistent_island: invalid handle"; return RP_ERR_INVALID; }
         out[i] = w->bodies[b].removed ? -1 : isl[b];
     }
@@ -2120,7 +2193,7 @@ extern "C" int32_t rp_bodies_proximity_group(rp_world *w, int32_t n, const uint6
     }
     for (size_t j = 0; j < w->joints.size(); ++j) if (!w->joint_removed[j] && links((int)w->joints[j].body1) && links((int)w->joints[j].body2)) unite((int)w->joints[j].body1, (int)w->joints[j].body2);
     for (int i = 0; i < n; ++i) {
-        int b = handle_index(handles[i]);
+        int b = body_of(w, handles[i]);
         if (b < 0 || b >= nb) { w->err = "rp_bodies_proximity_group: invalid handle"; return RP_ERR_INVALID; }
         out[i] = links(b) ? find(b) : -1;
     }
@@ -2205,6 +2278,37 @@ static int set_flag(rp_world *w, int slot, int v) { return poke(w, w->dw.flags +
 // new collider — its fat AABB starts inverted, so the next k_collider_update rewrites it and queues it like a collider that moved — finds
 // its partners in an incremental pass.  (b3d_large_world drops a sphere every five steps onto a million static boxes: a full rebuild
 // per drop was 25 ms.)
+void rp_launch_purge_dead_pairs(const DevWorld &w, hipStream_t st);
+// NarrowPhase::handle_user_changes for removed colliders (pair_management.rs:24-203) ahead of time: the pairs of every removed collider
+// leave the device pair set NOW, with the effects the next broad-phase pass would have had (Stopped | REMOVED events stamped with the
+// coming step, wake-ups, freed colours).  The reference removes them by HANDLE at the start of the next step; here a pair names its
+// colliders by index, so it must not outlive the slot: called before an arena slot is handed out again.
+static int purge_dead_pairs(rp_world *w) {
+    if (!w->finalized || !w->dead_pairs_possible) return RP_OK;
+    rp_launch_purge_dead_pairs(w->dw, w->stream);
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    w->dead_pairs_possible = false;
+    return RP_OK;
+}
+// every persistent row of one body / collider back to the state finalize() gives a fresh row (the allocation's fill byte): the slot is
+// about to hold another occupant (colour masks, island ids, sleep state, warm-start words ... of the previous one must not leak)
+static int reset_row(rp_world *w, int dom, int i) {
+    // (tables that are merely SIZED like the body arrays — index = persistent-island id, sleep label, LDS-island id — are not rows of a
+    // body: the island table above all must survive; the others are rebuilt by the layout / label passes)
+    static const size_t not_rows[] = {offsetof(DevWorld, pi_used), offsetof(DevWorld, pi_nb), offsetof(DevWorld, pi_dirty), offsetof(DevWorld, pi_denied), offsetof(DevWorld, pi_sleeping),
+                                      offsetof(DevWorld, pi_free), offsetof(DevWorld, lab_wake), offsetof(DevWorld, lab_awake), offsetof(DevWorld, isl_body_begin), offsetof(DevWorld, isl_nb),
+                                      offsetof(DevWorld, isl_cons_begin), offsetof(DevWorld, isl_nc), offsetof(DevWorld, isl_fill_b), offsetof(DevWorld, isl_fill_c), offsetof(DevWorld, isl_bodies),
+                                      offsetof(DevWorld, isl_sorted), offsetof(DevWorld, isl_nstages), offsetof(DevWorld, isl_ni), offsetof(DevWorld, isl_icons_begin), offsetof(DevWorld, isl_fill_i),
+                                      offsetof(DevWorld, isl_inc_begin), offsetof(DevWorld, isl_inc_cnt), offsetof(DevWorld, r_nb), offsetof(DevWorld, r_nc), offsetof(DevWorld, r_ni), offsetof(DevWorld, r_island)};
+    for (const AllocRec &a : w->allocs) {
+        if (a.dom != dom) continue;
+        if (dom == DOM_BODY && std::find(std::begin(not_rows), std::end(not_rows), a.off) != std::end(not_rows)) continue;
+        for (int p = 0; p < a.planes; ++p)
+            HIPCHK(w, hipMemsetAsync((char *)a.ptr + ((size_t)p * a.stride + (size_t)i) * a.per * a.elem, a.fill, a.per * a.elem, w->stream));
+    }
+    HIPCHK(w, hipStreamSynchronize(w->stream)); // (the row uploads that follow are small copies from pageable memory: the fills have landed before any of them is issued)
+    return RP_OK;
+}
 static int after_topology_edit(rp_world *w, bool keep_grid) {
     if (!w->finalized) return RP_OK;
     int r;
@@ -2249,7 +2353,10 @@ static int remove_joint_at(rp_world *w, int j) {
 static int remove_collider_at(rp_world *w, int c) {
     if (w->collider_removed[c]) return RP_OK;
     w->collider_removed[c] = 1;
+    w->coll_arena_gen++; w->coll_free.push_back(c); // Arena::remove (arena.rs:353-380): the slot heads the free list, the generation counts removals
+    w->dead_pairs_possible = true;
     int parent = w->collider_parent[c];
+    if (parent >= 0) { std::vector<int> &cl = w->bodies[parent].cols; cl.erase(std::remove(cl.begin(), cl.end(), c), cl.end()); } // (the slot may soon belong to another body)
     if (parent >= 0) { w->bodies[parent].ncolliders--; recompute_mass(w, parent); }
     if (!w->finalized) return RP_OK;
     uint2 none; none.x = 0; none.y = 0;
@@ -2266,7 +2373,18 @@ static int remove_collider_at(rp_world *w, int c) {
     }
     return RP_OK;
 }
-static int handle_index(uint64_t h) { return (h >> 32) == 0 ? (int)(h & 0xffffffffull) : -1; }
+static int handle_index(uint64_t h) { return (h >> 32) == 0 ? (int)(h & 0xffffffffull) : -1; } // (impulse joints: dense indices)
+// body / collider handles: index + generation (Arena::get: the generations must match); -1 = unknown, stale, or — unless asked for — removed
+static int body_of(const rp_world *w, uint64_t h, bool allow_removed) {
+    const uint64_t i = h & 0xffffffffull;
+    if (i >= w->bodies.size() || (uint32_t)(h >> 32) != w->body_gen[(size_t)i]) return -1;
+    return (w->bodies[(size_t)i].removed && !allow_removed) ? -1 : (int)i;
+}
+static int collider_of(const rp_world *w, uint64_t h) {
+    const uint64_t i = h & 0xffffffffull;
+    if (i >= w->colliders.size() || (uint32_t)(h >> 32) != w->coll_gen[(size_t)i] || w->collider_removed[(size_t)i]) return -1;
+    return (int)i;
+}
 
 extern "C" int32_t rp_impulse_joints_remove(rp_world *w, int32_t n, const uint64_t *handles) {
     if (!w || n < 0 || (n > 0 && !handles)) return RP_ERR_INVALID;
@@ -2285,8 +2403,8 @@ extern "C" int32_t rp_colliders_remove(rp_world *w, int32_t n, const uint64_t *h
     HIPCHK(w, hipSetDevice(w->device));
     if (w->finalized) { int r = settle(w); if (r != RP_OK) return r; }
     for (int i = 0; i < n; ++i) {
-        int c = handle_index(handles[i]);
-        if (c < 0 || c >= (int)w->colliders.size() || w->collider_removed[c]) { w->err = "rp_colliders_remove: invalid handle"; return RP_ERR_INVALID; }
+        int c = collider_of(w, handles[i]);
+        if (c < 0) { w->err = "rp_colliders_remove: invalid handle"; return RP_ERR_INVALID; }
         int r = remove_collider_at(w, c);
         if (r != RP_OK) return r;
     }
@@ -2296,6 +2414,10 @@ extern "C" int32_t rp_colliders_remove(rp_world *w, int32_t n, const uint64_t *h
 // rp_bodies_remove (the handle dies) and the quarantine (RigidBody::set_enabled(false): the handle stays readable).
 static int detach_body_at(rp_world *w, int b) {
     int r;
+    { // the attached colliders go in attachment order (rigid_body_set.rs:140-150 walks rb.colliders()): the order of the free list
+        const std::vector<int> cols = w->bodies[b].cols;
+        for (int c : cols) if (c >= 0 && c < (int)w->colliders.size() && w->collider_parent[c] == b && (r = remove_collider_at(w, c)) != RP_OK) return r;
+    }
     for (size_t c = 0; c < w->colliders.size(); ++c) if (w->collider_parent[c] == b && (r = remove_collider_at(w, (int)c)) != RP_OK) return r;
     for (size_t j = 0; j < w->joints.size(); ++j) if ((w->joints[j].body1 == b || w->joints[j].body2 == b) && (r = remove_joint_at(w, (int)j)) != RP_OK) return r;
     HostBody &hb = w->bodies[b];
@@ -2315,11 +2437,12 @@ extern "C" int32_t rp_bodies_remove(rp_world *w, int32_t n, const uint64_t *hand
     HIPCHK(w, hipSetDevice(w->device));
     if (w->finalized) { int r = settle(w); if (r != RP_OK) return r; }
     for (int i = 0; i < n; ++i) {
-        int b = handle_index(handles[i]);
-        if (b < 0 || b >= (int)w->bodies.size() || w->bodies[b].removed) { w->err = "rp_bodies_remove: invalid handle"; return RP_ERR_INVALID; }
+        int b = body_of(w, handles[i]);
+        if (b < 0) { w->err = "rp_bodies_remove: invalid handle"; return RP_ERR_INVALID; }
         int r = detach_body_at(w, b);
         if (r != RP_OK) return r;
         w->bodies[b].removed = true;
+        w->body_arena_gen++; w->body_free.push_back(b);
     }
     return after_topology_edit(w);
 }

@@ -492,6 +492,29 @@ __global__ void __launch_bounds__(1024) k_bp_rebuild(DevWorld w) {
     }
 }
 
+// The pairs of removed colliders (groups zeroed: ColliderSet::remove) leave the pair set at once — what the next pass would do to
+// them — so that the collider's arena slot can be handed out again before a step has run (rp_api.hip purge_dead_pairs).
+__global__ void k_purge_dead_pairs(DevWorld w) {
+    const int cur = w.flags[FL_BP_EPOCH] & 1;
+    int top = w.flags[FL_POOL_TOP];
+    if (top > w.pool_cap) top = w.pool_cap;
+    const int stride = gridDim.x * blockDim.x;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < top; s += stride) {
+        const int c1 = w.p_c1[s];
+        if (c1 < 0) continue;
+        const int c2 = w.p_c2[s];
+        const uint2 g1 = w.c_groups[c1], g2 = w.c_groups[c2];
+        if (!((g1.x == 0 && g1.y == 0) || (g2.x == 0 && g2.y == 0))) continue;
+        hash_erase(w.h_key[cur], w.hash_cap, ((unsigned long long)(unsigned)c1 << 32) | (unsigned)c2);
+        atomicAdd(&w.flags[FL_BP_TOMBS], 1);
+        bp_delete_pair(w, s);
+    }
+}
+void rp_launch_purge_dead_pairs(const DevWorld &w, hipStream_t st) {
+    int blocks = (w.pool_cap + 255) / 256; if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_purge_dead_pairs, dim3(blocks), dim3(256), 0, st, w);
+}
+
 void rp_launch_collider_update(const DevWorld &w, hipStream_t st) {
     if (w.n_colliders == 0) return;
     hipLaunchKernelGGL(k_collider_update, dim3((w.n_colliders + 255) / 256), dim3(256), 0, st, w);

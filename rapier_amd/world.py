@@ -171,6 +171,38 @@ class PhysicsWorld:
         _check(self._ptr, self._lib.rp_params_set(self._ptr, ip.as_array().ctypes.data), "rp_params_set")
         self.integration_parameters = ip
 
+    # ---- handles ----
+    def body_handles(self) -> np.ndarray:
+        """RigidBodySet::iter as handles: generation << 32 | index of every arena row (rp_bodies_handles)."""
+        n = self._lib.rp_bodies_handles(self._ptr, 0, None)
+        out = np.zeros(max(n, 0), np.uint64)
+        if n > 0:
+            self._lib.rp_bodies_handles(self._ptr, n, out.ctypes.data)
+        return out
+
+    def collider_handles(self) -> np.ndarray:
+        n = self._lib.rp_colliders_handles(self._ptr, 0, None)
+        out = np.zeros(max(n, 0), np.uint64)
+        if n > 0:
+            self._lib.rp_colliders_handles(self._ptr, n, out.ctypes.data)
+        return out
+
+    def _bh(self, handles, table=None) -> np.ndarray:
+        """Body handles as the ABI wants them.  Callers may pass real handles (generation << 32 | index) or bare arena INDICES (values
+        below 2^32): an index addresses the slot's current occupant — RigidBodySet::get_unknown_gen (rigid_body_set.rs) — and is turned
+        into that occupant's handle here.  (A stale handle of generation 0 cannot be told from an index: staleness checks need a handle
+        whose generation is above zero.)"""
+        h = np.ascontiguousarray(np.atleast_1d(np.asarray(handles, dtype=np.uint64))).copy()
+        idx = h < np.uint64(1 << 32)
+        if idx.any():
+            cur = self.body_handles() if table is None else table
+            ok = idx & (h < np.uint64(len(cur)))
+            h[ok] = cur[h[ok].astype(np.int64)]
+        return h
+
+    def _ch(self, handles) -> np.ndarray:
+        return self._bh(handles, table=self.collider_handles())
+
     # ---- insertion (RigidBodySet::insert, ColliderSet::insert_with_parent, ...) ----
     def insert_bodies(self, descs: np.ndarray) -> np.ndarray:
         descs = np.ascontiguousarray(descs, dtype=S.BODY_DTYPE)
@@ -184,14 +216,14 @@ class PhysicsWorld:
 
     def insert_colliders(self, descs: np.ndarray, parents: np.ndarray) -> np.ndarray:
         descs = np.ascontiguousarray(descs, dtype=S.COLLIDER_DTYPE)
-        parents = np.ascontiguousarray(parents, dtype=np.uint64)
+        parents = self._bh(np.ascontiguousarray(parents, dtype=np.uint64)) if len(descs) else np.zeros(0, np.uint64)
         out = np.zeros(len(descs), np.uint64)
         _check(self._ptr, self._lib.rp_colliders_insert(self._ptr, len(descs), descs.ctypes.data, parents.ctypes.data, out.ctypes.data), "rp_colliders_insert")
         self.colliders._n += len(descs)
         return out
 
     def insert_collider(self, collider: np.ndarray, parent=None) -> ColliderHandle:
-        p = np.array([_ffi.RP_INVALID_HANDLE if parent is None else int(parent)], dtype=np.uint64)
+        p = np.array([_ffi.RP_INVALID_HANDLE if parent is None else int(self._bh([int(parent)])[0])], dtype=np.uint64)
         return ColliderHandle(int(self.insert_colliders(np.array([collider], dtype=S.COLLIDER_DTYPE), p)[0]))
 
     def insert(self, body: np.ndarray, collider: np.ndarray):
@@ -218,10 +250,10 @@ class PhysicsWorld:
 
     def remove_body(self, handles):
         """RigidBodySet::remove(handle, ..., remove_attached_colliders = true)."""
-        self._remove(self._lib.rp_bodies_remove, handles, "rp_bodies_remove")
+        self._remove(self._lib.rp_bodies_remove, self._bh(handles), "rp_bodies_remove")
 
     def remove_collider(self, handles):
-        self._remove(self._lib.rp_colliders_remove, handles, "rp_colliders_remove")
+        self._remove(self._lib.rp_colliders_remove, self._ch(handles), "rp_colliders_remove")
 
     def remove_impulse_joint(self, handles):
         self._remove(self._lib.rp_impulse_joints_remove, handles, "rp_impulse_joints_remove")
@@ -249,7 +281,7 @@ class PhysicsWorld:
             n = self._lib.rp_num_bodies(self._ptr)
             hp = None
         else:
-            h = np.ascontiguousarray(np.asarray(handles, dtype=np.uint64))
+            h = self._bh(handles)
             n, hp = len(h), h.ctypes.data
         pos = np.zeros((n, 7), np.float32)
         vel = np.zeros((n, 6), np.float32)
@@ -257,7 +289,7 @@ class PhysicsWorld:
         return pos, vel
 
     def write_bodies(self, handles, pos7=None, vel6=None):
-        h = np.ascontiguousarray(np.asarray(handles, dtype=np.uint64))
+        h = self._bh(handles)
         p = None if pos7 is None else np.ascontiguousarray(pos7, dtype=np.float32)
         v = None if vel6 is None else np.ascontiguousarray(vel6, dtype=np.float32)
         _check(self._ptr, self._lib.rp_bodies_write(self._ptr, len(h), h.ctypes.data, None if p is None else p.ctypes.data,
@@ -265,7 +297,7 @@ class PhysicsWorld:
 
     def add_force(self, handles, force=None, torque=None, reset: bool = False):
         """RigidBody::{reset_forces, reset_torques} (when ``reset``) then add_force / add_torque(.., wake_up=true)."""
-        h = np.ascontiguousarray(np.atleast_1d(np.asarray(handles, dtype=np.uint64)))
+        h = self._bh(handles)
         f = None if force is None else np.ascontiguousarray(np.asarray(force, np.float32).reshape(len(h), 3))
         t = None if torque is None else np.ascontiguousarray(np.asarray(torque, np.float32).reshape(len(h), 3))
         _check(self._ptr, self._lib.rp_bodies_add_force(self._ptr, len(h), h.ctypes.data, None if f is None else f.ctypes.data,
@@ -273,7 +305,7 @@ class PhysicsWorld:
 
     def apply_impulse(self, handles, impulse=None, torque_impulse=None):
         """RigidBody::{apply_impulse, apply_torque_impulse}(.., wake_up=true)."""
-        h = np.ascontiguousarray(np.atleast_1d(np.asarray(handles, dtype=np.uint64)))
+        h = self._bh(handles)
         f = None if impulse is None else np.ascontiguousarray(np.asarray(impulse, np.float32).reshape(len(h), 3))
         t = None if torque_impulse is None else np.ascontiguousarray(np.asarray(torque_impulse, np.float32).reshape(len(h), 3))
         _check(self._ptr, self._lib.rp_bodies_apply_impulse(self._ptr, len(h), h.ctypes.data, None if f is None else f.ctypes.data,
@@ -281,7 +313,7 @@ class PhysicsWorld:
 
     def set_next_kinematic_position(self, handles, pos7):
         """RigidBody::set_next_kinematic_position (rigid_body.rs:1085-1093) for kinematic bodies."""
-        h = np.ascontiguousarray(np.atleast_1d(np.asarray(handles, dtype=np.uint64)))
+        h = self._bh(handles)
         p = np.ascontiguousarray(np.asarray(pos7, dtype=np.float32).reshape(len(h), 7))
         _check(self._ptr, self._lib.rp_bodies_set_next_kinematic_position(self._ptr, len(h), h.ctypes.data, p.ctypes.data), "rp_bodies_set_next_kinematic_position")
 
@@ -333,20 +365,20 @@ class PhysicsWorld:
 
     def set_additional_solver_iterations(self, handles, counts):
         """RigidBody::set_additional_solver_iterations: extra TGS substeps for the whole connected component of each body."""
-        h = np.ascontiguousarray(np.atleast_1d(np.asarray(handles, dtype=np.uint64)))
+        h = self._bh(handles)
         c = np.ascontiguousarray(np.broadcast_to(np.asarray(counts, dtype=np.int32), h.shape))
         _check(self._ptr, self._lib.rp_bodies_set_additional_solver_iterations(self._ptr, len(h), h.ctypes.data, c.ctypes.data), "rp_bodies_set_additional_solver_iterations")
 
     def wake_up(self, handles, strong: bool = True):
         """IslandManager::wake_up (island_manager/sleep.rs:31) — effective at the next step, island-wide."""
-        h = np.ascontiguousarray(np.atleast_1d(np.asarray(handles, dtype=np.uint64)))
+        h = self._bh(handles)
         _check(self._ptr, self._lib.rp_bodies_wake_up(self._ptr, len(h), h.ctypes.data, 1 if strong else 0), "rp_bodies_wake_up")
 
     def sleeping(self, handles=None) -> np.ndarray:
         """RigidBody::is_sleeping for the given handles (default: every body, arena order)."""
         if handles is None:
-            handles = np.arange(self._lib.rp_num_bodies(self._ptr), dtype=np.uint64)
-        h = np.ascontiguousarray(np.atleast_1d(np.asarray(handles, dtype=np.uint64)))
+            handles = self.body_handles()
+        h = self._bh(handles)
         out = np.zeros(len(h), np.int32)
         _check(self._ptr, self._lib.rp_bodies_is_sleeping(self._ptr, len(h), h.ctypes.data, out.ctypes.data), "rp_bodies_is_sleeping")
         return out.astype(bool)
@@ -354,8 +386,8 @@ class PhysicsWorld:
     def island_labels(self, handles=None) -> np.ndarray:
         """IslandManager::persistent_island_of per body (-1: fixed / removed, or a world without sleepable bodies)."""
         if handles is None:
-            handles = np.arange(self._lib.rp_num_bodies(self._ptr), dtype=np.uint64)
-        h = np.ascontiguousarray(np.atleast_1d(np.asarray(handles, dtype=np.uint64)))
+            handles = self.body_handles()
+        h = self._bh(handles)
         out = np.zeros(len(h), np.int32)
         _check(self._ptr, self._lib.rp_bodies_persistent_island(self._ptr, len(h), h.ctypes.data, out.ctypes.data), "rp_bodies_persistent_island")
         return out
@@ -364,8 +396,8 @@ class PhysicsWorld:
         """Connected components of the non-fixed bodies over the live broad-phase pairs and the joints (rp_bodies_proximity_group): the
         unit of island sharding over GPUs.  -1: fixed / removed bodies.  Needs one step."""
         if handles is None:
-            handles = np.arange(self._lib.rp_num_bodies(self._ptr), dtype=np.uint64)
-        h = np.ascontiguousarray(np.atleast_1d(np.asarray(handles, dtype=np.uint64)))
+            handles = self.body_handles()
+        h = self._bh(handles)
         out = np.zeros(len(h), np.int32)
         _check(self._ptr, self._lib.rp_bodies_proximity_group(self._ptr, len(h), h.ctypes.data, out.ctypes.data), "rp_bodies_proximity_group")
         return out

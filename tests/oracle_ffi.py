@@ -61,6 +61,8 @@ def lib():
         L.ro_wake_up.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         L.ro_read_sleeping.argtypes = [C.c_void_p, C.c_void_p]
         L.ro_remove_body.argtypes = [C.c_void_p, C.c_int32]
+        L.ro_body_generation.argtypes = [C.c_void_p, C.c_int32]; L.ro_body_generation.restype = C.c_uint32
+        L.ro_collider_generation.argtypes = [C.c_void_p, C.c_int32]; L.ro_collider_generation.restype = C.c_uint32
         L.ro_remove_collider.argtypes = [C.c_void_p, C.c_int32]
         L.ro_remove_joint.argtypes = [C.c_void_p, C.c_int32]
         L.ro_num_joints.argtypes = [C.c_void_p]
@@ -116,6 +118,21 @@ class OracleWorld:
 
     def step(self, n: int = 1):
         lib().ro_step(self._w, n)
+
+    @property
+    def n(self) -> int:
+        """rows of the body arena (free slots included): ro_num_bodies — not a count of insertions, since removed slots are reused"""
+        return int(lib().ro_num_bodies(self._w))
+
+    @n.setter
+    def n(self, value):  # (callers that counted insertions themselves: `o.n += 1`)
+        pass
+
+    def body_generation(self, body: int) -> int:
+        return int(lib().ro_body_generation(self._w, int(body)))
+
+    def collider_generation(self, collider: int) -> int:
+        return int(lib().ro_collider_generation(self._w, int(collider)))
 
     def set_params(self, params):
         """the IntegrationParameters of the steps that follow (the reference takes them per step)"""

@@ -299,9 +299,9 @@ def _run(seed, steps=240, walls=False, params=False, world=None, extras=False, s
             g.set_next_kinematic_position([5], kp); o.set_next_kinematic_position(5, kp)
         if step % 7 == 0:                                         # a random user action
             act = int(rng.integers(0, 13))
-            log.append((step, act))
             live_dyn = [b for b in dyn if b in alive]
             b = int(rng.choice(live_dyn))
+            log.append((step, act, b))
             if act == 0:
                 imp = rng.uniform(-3, 3, size=3).astype(np.float32)
                 g.apply_impulse([b], impulse=[imp]); o.apply_impulse(b, impulse=imp)
@@ -365,6 +365,16 @@ def _run(seed, steps=240, walls=False, params=False, world=None, extras=False, s
                 axis = int(rng.integers(0, 6))
                 g.set_joint_motor(j, axis, **kw); o.set_joint_motor(j, axis, **kw)
         g.step(1); o.step(1)
+        if os.environ.get("RP_FUZZ_WATCH"):
+            wb, ws = (int(x) for x in os.environ["RP_FUZZ_WATCH"].split(":"))
+            if os.environ.get("RP_FUZZ_WATCH_ISL") and 180 <= step <= ws + 1:
+                gi_, oi_ = g.island_labels(), o.island_labels()
+                print(f"ISL step {step}: gpu {[int(gi_[x]) for x in (wb, 43, len(gi_) - 1)]} ora {[int(oi_[x]) for x in (wb, 43, len(oi_) - 1)]} stats gpu {g.island_stats()} ora {o.island_stats() if hasattr(o, 'island_stats') else None}")
+            if ws - 6 <= step <= ws + 1:
+                gp_, gv_ = g.read_bodies(); op_, ov_ = o.read()
+                print(f"POSE step {step} body {wb}: gpu v {np.round(gv_[wb], 3).tolist()} | ora v {np.round(ov_[wb], 3).tolist()} | others moved fast: {[(i_, np.round(ov_[i_][:3], 1).tolist(), np.round(gv_[i_][:3], 1).tolist()) for i_ in range(len(ov_)) if abs(ov_[i_][:3]).max() > 20]}")
+            if abs(step - ws) <= 1:
+                print(f"WATCH step {step} body {wb}: sleeping gpu {bool(g.sleeping()[wb])} ora {bool(o.sleeping()[wb])} pairs gpu {g.counters()['num_pairs']} ora {o.stats()['num_pairs']}")
         if step % 10 == 0 or step < 4 or TRACE:
             try:
                 _check(g, o, alive, f"seed {seed} step {step}")
@@ -372,7 +382,31 @@ def _run(seed, steps=240, walls=False, params=False, world=None, extras=False, s
                 if TRACE:
                     gp, gv = g.read_bodies(); op, ov = o.read()
                     bad = [b for b in alive if (gp[b] != op[b]).any() or (gv[b] != ov[b]).any()]
-                    print(f"TRACE seed {seed}: first divergence at step {step}, bodies {bad[:10]}, types {[int(sc.bodies[b]['body_type']) if b < len(sc.bodies) else 0 for b in bad[:10]]}; last actions {log[-6:]}")
+                    print(f"TRACE seed {seed}: first divergence at step {step}, bodies {bad[:10]}, types {[int(sc.bodies[b]['body_type']) if b < len(sc.bodies) else 0 for b in bad[:10]]}; last actions {log[-6:]}; edits {[a for a in log if a[1] in (4, 5, 6, 7, 10, 11)]}")
+                    gc_, os_ = g.counters(), o.stats()
+                    print("TRACE counters", {k: gc_[k] for k in ("num_pairs", "num_manifolds", "num_solver_contacts", "num_colors")}, os_)
+                    gm, gn, gi = g.contacts(); om, on, oi = o.manifolds()
+                    gk = {(a, b_): (c, n, tuple(i)) for (a, b_, c, n), i in zip(gm.tolist(), gi.tolist())}
+                    ok = {(a, b_): (c, n, tuple(i)) for (a, b_, c, n), i in zip(om.tolist(), oi.tolist())}
+                    for key in sorted(set(gk) | set(ok)):
+                        if gk.get(key) != ok.get(key):
+                            print(f"TRACE manifold {key}: gpu {gk.get(key)} ora {ok.get(key)}")
+                    gs_, os2_ = g.sleeping(), o.sleeping()
+                    print("TRACE sleeping differs for", [b_ for b_ in alive if gs_[b_] != os2_[b_]], "bad body sleeping gpu/ora", [(b_, bool(gs_[b_]), bool(os2_[b_])) for b_ in bad[:4]])
+                    for b_ in bad[:2]:
+                        print("TRACE body", b_, "gpu", gp[b_], gv[b_], "\nTRACE       ora", op[b_], ov[b_])
+                    try:
+                        print("TRACE islands gpu", g.island_labels()[bad[:3]].tolist(), "ora", o.island_labels()[bad[:3]].tolist())
+                    except Exception as e_:
+                        print("TRACE islands n/a", e_)
+                    gjc, gji = g.read_joints(); ojc, oji = o.read_joints()
+                    print("TRACE joints live", jb, "impulse rows that differ", [(j_, gji[j_].tolist(), oji[j_].tolist()) for j_ in range(len(gji)) if (gji[j_] != oji[j_]).any()][:6], "all joints of the scene touching the bad bodies", [(j_, int(sc.joints[j_]['body1']), int(sc.joints[j_]['body2'])) for j_ in range(len(sc.joints)) if int(sc.joints[j_]['body1']) in bad or int(sc.joints[j_]['body2']) in bad])
+                    print("TRACE manifold keys", sorted(gk))
+                    print("TRACE scene collider parents", list(enumerate(sc.collider_parents))[30:], "nb0", nb0, "joints", {j: bb for j, bb in jb.items() if 34 in bb or 43 in bb})
+                    from collections import Counter
+                    print("TRACE gpu manifold keys seen more than once:", [(k, v) for k, v in Counter((a, b_) for a, b_, c, n in gm.tolist()).items() if v > 1], "gpu manifolds", len(gm), "oracle", len(om))
+                    print("TRACE collider parents of the duplicated:", [(int(h) & 0xFFFFFFFF) for h in g.collider_handles() if int(h) >> 32], "col_parent tail", col_parent[-4:], "removed cols", sorted(removed_cols))
+                    print("TRACE handles", [hex(int(h)) for h in g.body_handles()[-6:]], [hex(int(h)) for h in g.collider_handles() if int(h) >> 32])
                 raise
     c = g.counters()
     assert c["overflow_flags"] == 0
