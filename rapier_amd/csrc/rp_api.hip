@@ -844,8 +844,9 @@ extern "C" int32_t rp_bodies_insert(rp_world *w, int32_t n, const rp_body_desc *
         // persistent islands: ensure_body for the new rows; a world that becomes sleep-enabled now bootstraps its islands
         if (w->dw.sleep_enabled && (!reuse || !was_sleep_enabled)) rp_launch_pi_ensure(w->dw, w->stream, was_sleep_enabled ? first_new : 0, was_sleep_enabled ? n : w->dw.n_bodies, was_sleep_enabled ? 0 : 1);
         w->dw.has_kinematic_pos = world_has_kinematic_pos(w) ? 1 : 0; refresh_ccd_facts(w);
-        HIPCHK(w, hipStreamSynchronize(w->stream));
-        { int r = upload_group_table(w); if (r != RP_OK) return r; }
+        bool extras = false; for (int i = 0; i < n; ++i) extras |= descs[i].additional_solver_iterations > 0;
+        if (extras) { int r = upload_group_table(w); if (r != RP_OK) return r; } // (a body without additional solver iterations leaves the group table alone)
+        HIPCHK(w, hipStreamSynchronize(w->stream)); // replays of the graphs destroyed below may still be in flight
         destroy_graphs(w); // kernel arguments (DevWorld by value) hold the body count
         return after_topology_edit(w, true);
     }
@@ -2309,16 +2310,17 @@ static int reset_row(rp_world *w, int dom, int i) {
     HIPCHK(w, hipStreamSynchronize(w->stream)); // (the row uploads that follow are small copies from pageable memory: the fills have landed before any of them is issued)
     return RP_OK;
 }
+void rp_launch_edit_flags(const DevWorld &w, hipStream_t st, int keep_grid);
 static int after_topology_edit(rp_world *w, bool keep_grid) {
     if (!w->finalized) return RP_OK;
-    int r;
-    if (!keep_grid && (r = set_flag(w, FL_BP_GRID_OK, 0)) != RP_OK) return r; // colliders went or changed their filters: the next broad-phase pass is a full rebuild
-    if ((r = set_flag(w, FL_BP_DIRTY, 1)) != RP_OK || (r = set_flag(w, FL_LAYOUT_DIRTY, 1)) != RP_OK || (r = set_flag(w, FL_JOINT_DIRTY, 1)) != RP_OK || (r = set_flag(w, FL_FLOW_DIRTY, 1)) != RP_OK) return r;
+    // the dirty flags of an edit in ONE launch behind whatever the edit queued (round 3: five blocking 4-byte copies + a stream wait —
+    // most of the 1.7 ms an insertion cost); nothing here waits: every entry point that reads the device settles the stream first
+    rp_launch_edit_flags(w->dw, w->stream, keep_grid ? 1 : 0); // (!keep_grid: colliders changed their filters: the next broad-phase pass is a full rebuild)
     w->pinned_flags[FL_LAYOUT_DIRTY] = 1; // keeps the next steps on the full graph until the device reports a clean state
     w->full_until = w->steps_requested + 3;
     w->eager_until = w->steps_requested + 8; // (graphs are captured again once eight steps went by without another edit)
     rp_launch_init_bodies(w->dw, w->stream);
-    HIPCHK(w, hipStreamSynchronize(w->stream));
+    HIPCHK(w, hipGetLastError());
     return RP_OK;
 }
 static int remove_joint_at(rp_world *w, int j) {
@@ -2408,7 +2410,8 @@ extern "C" int32_t rp_colliders_remove(rp_world *w, int32_t n, const uint64_t *h
         int r = remove_collider_at(w, c);
         if (r != RP_OK) return r;
     }
-    return after_topology_edit(w);
+    { int r = purge_dead_pairs(w); if (r != RP_OK) return r; } // (see rp_bodies_remove)
+    return after_topology_edit(w, true);
 }
 // A body leaves the simulation: its colliders and joints go, the device row becomes an inert fixed body.  Shared by
 // rp_bodies_remove (the handle dies) and the quarantine (RigidBody::set_enabled(false): the handle stays readable).
@@ -2444,7 +2447,10 @@ extern "C" int32_t rp_bodies_remove(rp_world *w, int32_t n, const uint64_t *hand
         w->bodies[b].removed = true;
         w->body_arena_gen++; w->body_free.push_back(b);
     }
-    return after_topology_edit(w);
+    // the pairs of the removed colliders leave the pair set now (what the next pass would do: purge_dead_pairs), so the broad-phase grid
+    // can stay in service — its entries of a dead collider pass no filter — and the next pass is incremental, not a rebuild
+    { int r = purge_dead_pairs(w); if (r != RP_OK) return r; }
+    return after_topology_edit(w, true);
 }
 // Quarantine::detect_user_changes / apply_end_step (quarantine.rs:68-195): the body keeps its last valid pose, its velocities and
 // user forces are zeroed and it is disabled (RigidBody::set_enabled(false): no colliders in the broad phase, no joints, not in

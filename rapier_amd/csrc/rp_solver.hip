@@ -245,6 +245,12 @@ static void launch_sweep(const DevWorld &w, hipStream_t st, const SolverLaunchPl
 static int body_blocks(const DevWorld &w) { int nb = (w.n_bodies + 255) / 256; return nb < 1 ? 1 : nb; }
 static int cons_blocks(const DevWorld &w) { int cb = (w.cons_cap + 255) / 256; if (cb > 2048) cb = 2048; return cb < 1 ? 1 : cb; }
 
+// the flags an edit of a live world raises (rp_api.hip after_topology_edit): one thread
+__global__ void k_edit_flags(DevWorld w, int keep_grid) {
+    if (!keep_grid) w.flags[FL_BP_GRID_OK] = 0;
+    w.flags[FL_BP_DIRTY] = 1; w.flags[FL_LAYOUT_DIRTY] = 1; w.flags[FL_JOINT_DIRTY] = 1; w.flags[FL_FLOW_DIRTY] = 1;
+}
+void rp_launch_edit_flags(const DevWorld &w, hipStream_t st, int keep_grid) { hipLaunchKernelGGL(k_edit_flags, dim3(1), dim3(1), 0, st, w, keep_grid); }
 void rp_launch_init_bodies(const DevWorld &w, hipStream_t st) {
     if (w.n_bodies == 0) return;
     hipLaunchKernelGGL(k_init_bodies, dim3(body_blocks(w)), dim3(256), 0, st, w);
