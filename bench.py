@@ -168,13 +168,21 @@ def run(args, make_world=None, backend: str = "nccl", use_cuda: bool = True):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29513")  # (--force-dist without a launcher: a one-rank group on this host)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if use_cuda:
+        backend = getattr(args, "backend", None) or backend
+        if use_cuda and getattr(args, "share_gpu", False):
+            # a development box with ONE GPU: the ranks share it (the sharded path runs for real — every rank a world of its own on the
+            # device — only the collective cannot be RCCL, which refuses two ranks on one device: --backend gloo)
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
+        if use_cuda and backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
+            if use_cuda:
+                torch.cuda.set_device(local_rank)
             dist.init_process_group(backend, rank=rank, world_size=world)
     elif use_cuda and torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
+    coll_on_device = use_cuda and backend == "nccl"   # the collectives' tensors: device memory for RCCL, host memory for gloo
 
     import numpy as np
     from rapier_amd import scenes as S, sharding
@@ -214,7 +222,7 @@ def run(args, make_world=None, backend: str = "nccl", use_cuda: bool = True):
             # every rank must cut the world the same way: one rank that failed to discover the groups (out of memory while building the
             # whole scene, say) sends ALL ranks to the generator's shards — mixed partitions would duplicate or lose bodies
             if dist is not None:
-                ok = torch.tensor([discovered], dtype=torch.int64, device="cuda" if use_cuda else None)
+                ok = torch.tensor([discovered], dtype=torch.int64, device="cuda" if coll_on_device else None)
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
                 if int(ok.item()) == 0 and discovered:
                     shard_source = "generator (device discovery failed on another rank)"
@@ -225,7 +233,7 @@ def run(args, make_world=None, backend: str = "nccl", use_cuda: bool = True):
     w = make_world(scene, local_rank)
     if guard is not None and len(guard[0]) and hasattr(w, "set_shard_guard"):
         w.set_shard_guard(*guard)
-    dev = "cuda" if use_cuda else None
+    dev = "cuda" if coll_on_device else None
 
     def barrier():
         if dist is not None:
@@ -351,6 +359,8 @@ def parse_args(argv=None):
     ap.add_argument("--roofline-steps", type=int, default=200)
     ap.add_argument("--shard-by", choices=("device", "generator"), default="device",
                     help="N > 1: shards from the device's proximity groups of the whole scene (default) or from the scene generator's pyramid list")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default=None, help="collective backend of the N > 1 leg (default: nccl = RCCL)")
+    ap.add_argument("--share-gpu", action="store_true", help="N ranks on a box with fewer GPUs: rank r uses device r mod (device count); needs --backend gloo")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N > 1 code path (init_process_group('nccl'), barrier, all-reduce, all-gather of body state) even with one rank")
     return ap.parse_args(argv)
