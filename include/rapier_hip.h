@@ -298,6 +298,11 @@ int32_t rp_bodies_proximity_group(rp_world *w, int32_t n, const uint64_t *handle
  * ranks and call this function again (one all-gather of 6 floats per group).
  * n = 0 removes the guard. */
 int32_t rp_world_set_shard_guard(rp_world *w, int32_t n, const float *box_min3, const float *box_max3);
+/* The bodies whose rewritten fat AABB overlapped a guard box since the last call (handles; returns their number, writes min(n, cap);
+ * call with cap >= n to consume them): the guard bit is cleared, rp_sync and the reads succeed again, and the world can go on — the
+ * caller moves the bodies' proximity group to the shard that owns the box they reached ("when an AddPair links bodies
+ * on different shards, migrate the smaller island": rapier_amd/sharding.py migrate_groups) and sets fresh guards on both sides. */
+int32_t rp_world_shard_guard_take_hits(rp_world *w, int32_t cap, uint64_t *bodies_out);
 int32_t rp_num_bodies(const rp_world *w);
 
 /* NarrowPhase::contact_pairs() analogue: for each active solver manifold: (collider1, collider2,

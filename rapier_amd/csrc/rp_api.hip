@@ -1255,6 +1255,7 @@ static int finalize(rp_world *w) {
     DAFC(d.b_isl, capb, 0xff, DOM_BODY, 1, 1); DAC(d.pi_used, capb, DOM_BODY, 1, 1); DAC(d.pi_nb, capb, DOM_BODY, 1, 1); DAC(d.pi_dirty, capb, DOM_BODY, 1, 1); DAC(d.pi_denied, capb, DOM_BODY, 1, 1);
     DAC(d.pi_sleeping, capb, DOM_BODY, 1, 1); DAC(d.pi_free, capb, DOM_BODY, 1, 1); DA(d.pi_uf, capb); DA(d.pi_new, capb); DA(d.pi_best, capb); DA(d.pi_csize, capb); DA(d.pi_cisl, capb); DA(d.pi_list, capb);
     DAC(d.pi_w64, 4, DOM_FIXED, 1, 1); DAC(d.pi_stats, 16, DOM_FIXED, 1, 1);
+    DA(d.sg_hit, capb);
     DAC(d.s_lin, capb, DOM_BODY, 1, 1); DAC(d.s_ang, capb, DOM_BODY, 1, 1); DAC(d.s_rot, capb, DOM_BODY, 1, 1); DAC(d.s_trans, capb, DOM_BODY, 1, 1); DAC(d.s_incl, capb, DOM_BODY, 1, 1); DAC(d.s_inca, capb, DOM_BODY, 1, 1);
     DAC(d.b_cmask, 4 * (size_t)capb, DOM_BODY, 1, 4); DAFC(d.b_min, capb, 0xff, DOM_BODY, 1, 1);
     DAC(d.c_parent, capc, DOM_COLL, 1, 1); DAC(d.c_ord, capc, DOM_COLL, 1, 1); DAC(d.c_shape, capc, DOM_COLL, 1, 1); DAC(d.c_lpos, capc, DOM_COLL, 1, 1); DAC(d.c_lrot, capc, DOM_COLL, 1, 1); DAC(d.c_pos, capc, DOM_COLL, 1, 1); DAC(d.c_rot, capc, DOM_COLL, 1, 1); DAC(d.c_he, capc, DOM_COLL, 1, 1);
@@ -2194,11 +2195,39 @@ extern "C" int32_t rp_bodies_proximity_group(rp_world *w, int32_t n, const uint6
     }
     for (size_t j = 0; j < w->joints.size(); ++j) if (!w->joint_removed[j] && links((int)w->joints[j].body1) && links((int)w->joints[j].body2)) unite((int)w->joints[j].body1, (int)w->joints[j].body2);
     for (int i = 0; i < n; ++i) {
-        int b = body_of(w, handles[i]);
+        int b = body_of(w, handles[i], true);
         if (b < 0 || b >= nb) { w->err = "rp_bodies_proximity_group: invalid handle"; return RP_ERR_INVALID; }
         out[i] = links(b) ? find(b) : -1;
     }
     return RP_OK;
+}
+// The bodies the shard guard caught since the last call, and the world goes on: the guard bit leaves FL_OVERFLOW, so rp_sync / reads
+// succeed again.  What the caller does with them is SURVEY section 8e's "migrate the smaller island": move the bodies' proximity group to
+// the shard whose box they reached (rapier_amd/sharding.py: migrate_groups), refresh the guards, continue.
+extern "C" int32_t rp_world_shard_guard_take_hits(rp_world *w, int32_t cap, uint64_t *bodies_out) {
+    if (!w || cap < 0 || (cap > 0 && !bodies_out)) return RP_ERR_INVALID;
+    if (!w->finalized) return 0;
+    HIPCHK(w, hipSetDevice(w->device));
+    {   // every requested step has run (an error return of settle() for the guard bit itself is what this call is for)
+        int r = settle(w);
+        if (r != RP_OK && !(r == RP_ERR_INVALID && w->err.find("shard guard") != std::string::npos)) return r;
+    }
+    int ovf = 0;
+    HIPCHK(w, hipMemcpy(&ovf, w->dw.flags + FL_OVERFLOW, sizeof(int), hipMemcpyDeviceToHost));
+    if (!(ovf & RP_OVF_SHARD)) return 0;
+    const int nb = w->dw.n_bodies;
+    std::vector<int> hit((size_t)std::max(nb, 1), 0);
+    if (nb > 0) HIPCHK(w, hipMemcpy(hit.data(), w->dw.sg_hit, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost));
+    int n = 0;
+    for (int b = 0; b < nb; ++b) if (hit[(size_t)b] && !w->bodies[(size_t)b].removed) { if (n < cap) bodies_out[n] = ((uint64_t)w->body_gen[(size_t)b] << 32) | (uint64_t)(uint32_t)b; ++n; }
+    if (n <= cap) { // everything was handed out: clear the marks and the bit (a short buffer leaves both for the next call)
+        if (nb > 0) HIPCHK(w, hipMemsetAsync(w->dw.sg_hit, 0, (size_t)nb * sizeof(int), w->stream));
+        ovf &= ~RP_OVF_SHARD;
+        HIPCHK(w, hipMemcpy(w->dw.flags + FL_OVERFLOW, &ovf, sizeof(int), hipMemcpyHostToDevice));
+        w->pinned_flags[FL_OVERFLOW] = ovf;
+        w->err.clear();
+    }
+    return n;
 }
 extern "C" int32_t rp_world_set_shard_guard(rp_world *w, int32_t n, const float *bmin, const float *bmax) {
     if (!w || n < 0 || (n > 0 && (!bmin || !bmax))) return RP_ERR_INVALID;

@@ -123,7 +123,7 @@ RP_DEV bool collider_update_one(const DevWorld &w, int i) { // true = the fat AA
                         foreign |= a[0] <= bmx.x && bmn.x <= b[0] && a[1] <= bmx.y && bmn.y <= b[1] && a[2] <= bmx.z && bmn.z <= b[2];
                     }
                 }
-            if (foreign) atomicOr(&w.flags[FL_OVERFLOW], RP_OVF_SHARD);
+            if (foreign) { atomicOr(&w.flags[FL_OVERFLOW], RP_OVF_SHARD); w.sg_hit[w.c_parent[i]] = 1; } // (which bodies: rp_world_shard_guard_take_hits)
         }
     }
     return !inside;

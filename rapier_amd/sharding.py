@@ -205,3 +205,197 @@ def proximity_groups_from_scene(scene: S.Scene, margin: float = 0.1) -> np.ndarr
             if a != b:
                 parent[max(a, b)] = min(a, b)
     return np.array([find(i) if dyn[i] else -1 for i in range(nb)], np.int32)
+
+
+# ---- migration: a body of one shard reaches a box of another ----------------------------------------------------------
+class ShardSet:
+    """The shards of ONE scene as a caller holds them when the guard of one of them fires: per rank a world, the sub-scene it was built
+    from and the global id of each of its rows.  `make_world(scene, rank)` builds a world (PhysicsWorld.from_scene on the device; the
+    CPU tests pass an oracle adapter).  Every rank may live in this process (one GPU, several worlds: tests, a single-process driver)
+    or one per process: then `exchange` is `torch.distributed.all_gather_object` over the job and `local_ranks` names the rank(s) held
+    here — the bookkeeping below is a pure function of what is exchanged, so every process ends up with the same tables.
+
+    step(n) steps every local world; when a guard fired, the bodies it caught are taken (rp_world_shard_guard_take_hits), their whole
+    proximity groups move to the rank whose group they reached — the smaller side moves, as the reference's note on cross-shard pairs
+    says — and every rank gets fresh guard boxes from the current poses.  A migrated body keeps pose and velocities; the contact
+    warm-start of its pairs is not carried (it has none with the shard it leaves by the time it reaches the clearance of another)."""
+
+    def __init__(self, scene: S.Scene, n_ranks: int, make_world, body_rank=None, groups=None, local_ranks=None, exchange=None, clearance: float = 0.25,
+                 check_every: int = 1):
+        self.scene, self.n_ranks, self.make_world, self.clearance = scene, n_ranks, make_world, clearance
+        self.check_every, self._since_check = max(1, int(check_every)), 0   # guard hits are looked at (one exchange) every so many steps
+        self.local_ranks = list(range(n_ranks)) if local_ranks is None else list(local_ranks)
+        self.exchange = exchange or (lambda obj: [obj])   # one process holds everything: nothing to exchange
+        if groups is None:
+            groups = proximity_groups_from_scene(scene)
+        if body_rank is None:
+            body_rank, _ = shards_from_groups(groups, n_ranks)
+        self.owner = np.asarray(body_rank, np.int32).copy()           # global body -> rank (-1: fixed, replicated)
+        self.desc = [b.copy() for b in scene.bodies]                  # global body -> descriptor (pose / velocities refreshed when it moves)
+        self.cols = [[] for _ in scene.bodies]                        # global body -> its collider descriptors
+        for c, p in zip(scene.colliders, scene.collider_parents):
+            if p >= 0:
+                self.cols[p].append(c.copy())
+        self.worlds, self.handle, self.gid_of_row = {}, {}, {}
+        for r in self.local_ranks:
+            sub, gids = partition_scene(scene, self.owner, r)
+            w = make_world(sub, r)
+            self.worlds[r] = w
+            self.gid_of_row[r] = [int(g) for g in gids]               # row of rank r's world -> global body
+            hs = w.body_handles() if hasattr(w, "body_handles") else np.arange(len(gids), dtype=np.uint64)
+            self.handle[r] = {int(g): int(h) for g, h in zip(gids, hs)}
+        self.migrations = 0
+        self._groups0 = np.asarray(groups)
+        self._refresh_guards(first=True)
+
+    # -- state of the locally held bodies, boxes of every group -------------------------------------------------------------------------
+    def _local_state(self):
+        """{global body: (pos7, vel6)} of every dynamic body held here"""
+        out = {}
+        for r, w in self.worlds.items():
+            pos, vel = w.read_bodies()
+            for row, g in enumerate(self.gid_of_row[r]):
+                if g >= 0 and self.owner[g] == r:
+                    out[g] = (pos[row].copy(), vel[row].copy())
+        return out
+
+    def _groups_and_boxes(self):
+        """current proximity groups of the locally held dynamic bodies and their boxes: [(rank, [global bodies], box min, box max)]"""
+        lo0, hi0 = body_boxes(self.scene)
+        half = np.where(np.isfinite(lo0), (hi0 - lo0) / 2.0, 0.0)
+        recs = []
+        for r, w in self.worlds.items():
+            pos, _ = w.read_bodies()
+            gr = w.proximity_groups() if hasattr(w, "proximity_groups") else None
+            rows = [row for row, g in enumerate(self.gid_of_row[r]) if g >= 0 and self.owner[g] == r]
+            if gr is None:                                                       # (oracle stand-in: every body its own group unless boxes overlap)
+                gr = np.arange(len(self.gid_of_row[r]))
+            by = {}
+            for row in rows:
+                by.setdefault(int(gr[row]) if int(gr[row]) >= 0 else -1 - row, []).append(row)
+            for rows_g in by.values():
+                gl = [self.gid_of_row[r][row] for row in rows_g]
+                c = np.array([pos[row][:3] for row in rows_g], np.float64)
+                h = np.array([half[g] for g in gl])
+                recs.append((r, gl, (c - h).min(0) - self.clearance, (c + h).max(0) + self.clearance))
+        return recs
+
+    def _initial_boxes(self):
+        """before the first step the device has no pair set yet: the groups the shards were cut from, boxed from the scene's poses"""
+        lo, hi = body_boxes(self.scene)
+        recs = []
+        for r in self.worlds:
+            mine = (self._groups0 >= 0) & (self.owner == r) & np.isfinite(lo[:, 0])
+            for k in np.unique(self._groups0[mine]):
+                m = mine & (self._groups0 == k)
+                recs.append((r, [int(g) for g in np.flatnonzero(m)], lo[m].min(0) - self.clearance, hi[m].max(0) + self.clearance))
+        return recs
+
+    def _refresh_guards(self, first=False):
+        mine = self._initial_boxes() if first else self._groups_and_boxes()
+        every = [x for part in self.exchange(mine) for x in part]
+        self._boxes = every
+        for r, w in self.worlds.items():
+            foreign = [(lo, hi) for (rr, _, lo, hi) in every if rr != r]
+            if hasattr(w, "set_shard_guard"):
+                if foreign:
+                    w.set_shard_guard(np.array([f[0] for f in foreign], np.float32), np.array([f[1] for f in foreign], np.float32))
+                else:
+                    w.set_shard_guard(None, None)
+
+    # -- stepping -----------------------------------------------------------------------------------------------------------------------
+    def step(self, n: int = 1):
+        for _ in range(n):
+            hits = {}
+            for r, w in self.worlds.items():
+                w.step(1)
+            self._since_check += 1
+            if self._since_check < self.check_every:
+                continue
+            self._since_check = 0
+            for r, w in self.worlds.items():
+                caught = w.take_shard_guard_hits() if hasattr(w, "take_shard_guard_hits") else np.zeros(0, np.uint64)
+                if len(caught):
+                    rev = {h: g for g, h in self.handle[r].items()}
+                    hits[r] = [rev[int(h)] for h in caught if int(h) in rev]
+            anyone = [x for part in self.exchange(hits) for x in ([part] if part else [])]
+            if anyone:
+                self._migrate({r: g for part in anyone for r, g in part.items()})
+
+    def _migrate(self, hits):
+        """hits = {rank: [global bodies its guard caught]}: plan from the exchanged boxes, so every process plans alike"""
+        boxes = [x for part in self.exchange(self._groups_and_boxes()) for x in part]
+        group_of = {}
+        for k, (r, gl, lo, hi) in enumerate(boxes):
+            for g in gl:
+                group_of[g] = k
+        moves = {}                                                              # group index -> destination rank
+        for r, bodies in sorted(hits.items()):
+            for g in bodies:
+                k = group_of.get(g)
+                if k is None or k in moves:
+                    continue
+                _, gl, lo, hi = boxes[k]
+                # the foreign group it reached: the nearest box of another rank that overlaps this group's (inflated) box
+                best = None
+                for k2, (r2, gl2, lo2, hi2) in enumerate(boxes):
+                    if r2 == r or k2 in moves:
+                        continue
+                    if np.all(lo <= hi2) and np.all(lo2 <= hi):
+                        d = float(np.linalg.norm((lo + hi) / 2 - (lo2 + hi2) / 2))
+                        if best is None or d < best[0]:
+                            best = (d, k2)
+                if best is None:
+                    continue
+                k2 = best[1]
+                if len(boxes[k2][1]) < len(gl):                                  # the smaller group moves
+                    moves[k2] = r
+                else:
+                    moves[k] = boxes[k2][0]
+        if not moves:
+            self._refresh_guards()
+            return
+        # the state of every moving body, from whoever holds it
+        local = self._local_state()
+        moving = {g for k in moves for g in boxes[k][1]}
+        state = {}
+        for part in self.exchange({g: local[g] for g in moving if g in local}):
+            state.update(part)
+        for k, dst in sorted(moves.items()):
+            src, gl = boxes[k][0], boxes[k][1]
+            for g in gl:
+                pos7, vel6 = state[g]
+                d = self.desc[g]
+                d["translation"], d["rotation"], d["linvel"], d["angvel"] = pos7[:3], pos7[3:], vel6[:3], vel6[3:]
+                if src in self.worlds:
+                    self.worlds[src].remove_body([self.handle[src].pop(g)])
+                    self.gid_of_row[src] = [(-1 if x == g else x) for x in self.gid_of_row[src]]
+                if dst in self.worlds:
+                    w = self.worlds[dst]
+                    hb = w.insert_body(d)
+                    for c in self.cols[g]:
+                        w.insert_collider(c, hb)
+                    row = int(hb) & 0xFFFFFFFF
+                    rows = self.gid_of_row[dst]
+                    if row < len(rows):
+                        rows[row] = g                                            # (a reused arena slot)
+                    else:
+                        rows.extend([-1] * (row - len(rows)) + [g])
+                    self.handle[dst][g] = int(hb)
+                self.owner[g] = dst
+            self.migrations += 1
+        self._refresh_guards()
+
+    # -- readback -----------------------------------------------------------------------------------------------------------------------
+    def read_bodies(self):
+        """(pos[n_global, 7], vel[n_global, 6]) assembled from every rank (fixed bodies from the scene)"""
+        n = len(self.scene.bodies)
+        pos = np.zeros((n, 7), np.float32); vel = np.zeros((n, 6), np.float32)
+        for g, b in enumerate(self.scene.bodies):
+            pos[g, :3], pos[g, 3:] = b["translation"], b["rotation"]
+        state = {}
+        for part in self.exchange(self._local_state()):
+            state.update(part)
+        for g, (p, v) in state.items():
+            pos[g], vel[g] = p, v
+        return pos, vel

@@ -413,6 +413,18 @@ class PhysicsWorld:
     ISLAND_STATS = ("merged", "multiway_groups", "removals", "connected", "detached", "hot", "over_budget", "sleeping_deferred", "global_splits",
                     "global_split_pieces", "bids", "bid_ties", "sleep_blocked", "order_dependent", "detach_size_ties", "split_keep_ties")
 
+    def take_shard_guard_hits(self) -> np.ndarray:
+        """Handles of the bodies the shard guard caught since the last call; clears the guard so the world can go on
+        (rp_world_shard_guard_take_hits)."""
+        n = self._lib.rp_world_shard_guard_take_hits(self._ptr, 0, None)
+        if n < 0:
+            _check(self._ptr, n, "rp_world_shard_guard_take_hits")
+        out = np.zeros(max(n, 1), np.uint64)
+        m = self._lib.rp_world_shard_guard_take_hits(self._ptr, len(out), out.ctypes.data)
+        if m < 0:
+            _check(self._ptr, m, "rp_world_shard_guard_take_hits")
+        return out[:max(m, 0)]
+
     def island_stats(self) -> dict:
         """debug aid: counters of the persistent-island machinery (the slots the device maintains; same names as the oracle's)"""
         out = np.zeros(16, np.int32)

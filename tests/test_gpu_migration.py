@@ -1,0 +1,45 @@
+"""Island migration between shards ("when an AddPair links bodies on different shards, migrate the smaller island"):
+two shards of one scene as two device worlds; a cube thrown from a pyramid of shard 0 towards a pyramid of shard 1 trips shard 0's
+guard, is taken (rp_world_shard_guard_take_hits), removed from shard 0 and inserted into shard 1 with its pose and velocities, both
+guards are refreshed and the run goes on — where round 3 ended it with RP_ERR_INVALID."""
+import numpy as np
+import pytest
+
+from rapier_amd import PhysicsWorld, scenes as S, sharding
+
+pytestmark = pytest.mark.gpu
+
+
+def test_a_thrown_cube_migrates_to_the_shard_it_reaches():
+    sc = S.many_pyramids(1, 2)
+    whole = PhysicsWorld.from_scene(sc)
+    groups = sharding.proximity_groups_from_scene(sc)
+    body_rank, ng = sharding.shards_from_groups(groups, 2)
+    assert ng == 2
+    shards = sharding.ShardSet(sc, 2, lambda sub, r: PhysicsWorld.from_scene(sub), body_rank=body_rank, groups=groups)
+    whole.step(5); shards.step(5)
+    # the top cube of rank 0's pyramid, thrown towards the other pyramid (11 m away along x)
+    top = max((i for i in range(len(sc.bodies)) if body_rank[i] == 0), key=lambda i: float(sc.bodies[i]["translation"][1]))
+    other_x = np.mean([float(sc.bodies[i]["translation"][0]) for i in range(len(sc.bodies)) if body_rank[i] == 1])
+    toward = float(np.sign(other_x - float(sc.bodies[top]["translation"][0])))
+    kick = np.array([[toward * 9.0, 6.0, 0.0, 0.0, 0.0, 0.0]], np.float32)
+    whole.write_bodies([top], vel6=kick)
+    shards.worlds[0].write_bodies([shards.handle[0][top]], vel6=kick)
+    moved_at = None
+    for step in range(1, 140):
+        whole.step(1); shards.step(1)
+        if moved_at is None and shards.migrations > 0:
+            moved_at = step
+            assert shards.owner[top] == 1 and top in shards.handle[1] and top not in shards.handle[0]
+            # in flight nothing touches the cube and the pyramids do not feel each other: the assembled shards ARE the whole world
+            gp, gv = shards.read_bodies(); wp, wv = whole.read_bodies()
+            np.testing.assert_array_equal(gp, wp); np.testing.assert_array_equal(gv, wv)
+    assert moved_at is not None and shards.migrations == 1, "the guard never fired: the cube did not reach the other shard"
+    gp, gv = shards.read_bodies(); wp, wv = whole.read_bodies()
+    assert np.isfinite(gp).all() and np.isfinite(gv).all()
+    # after the landing the cube sits in another row of another world (its index — hence the colour order of its contacts — differs from the
+    # whole world's): same physics, not the same bits
+    assert np.abs(gp[:, :3] - wp[:, :3]).max() < 0.05, float(np.abs(gp[:, :3] - wp[:, :3]).max())
+    assert abs(float(gp[top, 0]) - other_x) < 6.0                     # it is over there
+    for r in (0, 1):
+        assert shards.worlds[r].counters()["overflow_flags"] == 0
