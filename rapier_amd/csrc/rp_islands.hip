@@ -56,11 +56,21 @@ RP_DEV bool pair_active(const DevWorld &w, int s) { return pair_selected(w, s); 
 
 // Island discovery runs only when the set of active manifolds changed (FL_LAYOUT_DIRTY): passes of k_layout_rebuild below,
 // every pass one thread per body or per pair slot (gid / gstride span the whole launch).
-RP_DEV void lay_isl_init(DevWorld &w, int gid, int gstride) {
+// WARM START of the components (round 4).  The layout of a settling pile is rebuilt whenever a pair begins or ends to touch — 60 % of
+// the steps of b3d_large_pyramid's first seconds — and 80 of the 215 us of a rebuild went into finding, from singleton labels, the ONE
+// component the pile has been all along.  The labels of the last rebuild are a valid starting point whenever no body came, went or
+// changed its kind since (lay_state[0]; sleep-enabled worlds change the awake set: always cold): unions over the current edges then
+// only add what merged.  What a warm start cannot see is a SPLIT — so it is only taken while the global path holds a giant component
+// (>= 4,096 bodies: a piece that left it stays on the global path with it, which is where bodies without an island go anyway; any
+// partition into unions of components gives the same bits), and every 16th rebuild is cold so that pieces become islands again.
+RP_DEV bool lay_warm(const DevWorld &w) {
+    return !w.sleep_enabled && w.lay_state[0] == 1 && (w.lay_state[1] & 15) != 0 && w.lay_state[2] >= 4096; // ([2]: global-path bodies of the last rebuild — FL_N_GLOB_BODIES itself is reset by this launch)
+}
+RP_DEV void lay_isl_init(DevWorld &w, int gid, int gstride, bool warm) {
     const int i = gid;
     if (i == 0) { w.flags[FL_N_ISLANDS] = 0; w.flags[FL_N_GLOB_BODIES] = 0; w.flags[FL_ISL_BODY_CURSOR] = 0; w.flags[FL_ISL_CONS_CURSOR] = 0; w.flags[FL_ISL_ICONS_CURSOR] = 0; }
     for (size_t k = i, n = (size_t)128 * w.cb_words; k < n; k += (size_t)gstride) w.cb_bits[k] = 0u; // owner bitmaps of the colour stages
-    for (int b = gid; b < w.n_bodies; b += gstride) { w.b_label[b] = b; w.r_nb[b] = 0; w.r_nc[b] = 0; w.r_ni[b] = 0; w.r_island[b] = -1; w.b_island[b] = -1; w.b_local[b] = -1; }
+    for (int b = gid; b < w.n_bodies; b += gstride) { if (!warm) w.b_label[b] = b; w.r_nb[b] = 0; w.r_nc[b] = 0; w.r_ni[b] = 0; w.r_island[b] = -1; w.b_island[b] = -1; w.b_local[b] = -1; }
 }
 // the edges of the island graph, compacted (one atomic per wavefront): active pairs whose two sides are awake non-fixed bodies
 RP_DEV void lay_isl_edges(DevWorld &w, int gid, int gstride) {
@@ -90,8 +100,8 @@ RP_DEV int lds_find(int *label, int x) {
     while (p != x) { int gp = label[p]; if (gp != p) atomicCAS(&label[x], p, gp); x = p; p = gp; }
     return x;
 }
-RP_DEV void lay_isl_union_lds(DevWorld &w, int *label) { // workgroup 0
-    for (int b = threadIdx.x; b < w.n_bodies; b += blockDim.x) label[b] = b;
+RP_DEV void lay_isl_union_lds(DevWorld &w, int *label, bool warm) { // workgroup 0
+    for (int b = threadIdx.x; b < w.n_bodies; b += blockDim.x) label[b] = warm ? w.b_label[b] : b;
     __syncthreads();
     const int n = w.flags[FL_UF_NPAIRS];
     for (int k = threadIdx.x; k < n; k += blockDim.x) {
@@ -356,15 +366,16 @@ __global__ void __launch_bounds__(1024) k_layout_rebuild(DevWorld w) {
     const int gid = gbar_item(), gstride = gridDim.x * blockDim.x;
     GridBar bar = gbar_begin(w, 1);
     RP_PASS_BEGIN();
+    const bool warm = lay_warm(w); // (lay_state is only written behind the last barrier of a launch, or by an edit between steps: every workgroup reads the same)
     if (blockIdx.x == 0) lay_bucket_clear(w);
-    lay_isl_init(w, gid, gstride);
+    lay_isl_init(w, gid, gstride, warm);
     lay_isl_edges(w, gid, gstride);
     GBAR_SYNC(bar); RP_PASS_STAMP(w, 200);
     lay_bucket_count(w, gid, gstride, lds_a, lds_scalar);
 #ifdef RP_PASS_PROFILE
     GBAR_SYNC(bar); RP_PASS_STAMP(w, 200); // (profiling only: the bucket count apart from the union)
 #endif
-    if (w.n_bodies <= LAY_LDS_BODIES) { if (blockIdx.x == 0) lay_isl_union_lds(w, lds_uf); }
+    if (w.n_bodies <= LAY_LDS_BODIES) { if (blockIdx.x == 0) lay_isl_union_lds(w, lds_uf, warm); }
     else lay_isl_union(w, gid, gstride);
     GBAR_SYNC(bar); RP_PASS_STAMP(w, 200);
     lay_isl_count(w, gid, gstride);
@@ -386,7 +397,7 @@ __global__ void __launch_bounds__(1024) k_layout_rebuild(DevWorld w) {
         GBAR_SYNC(bar); RP_PASS_STAMP(w, 200);
     }
     gbar_end(bar);
-    if (gid == 0) { w.flags[FL_UF_NPAIRS] = 0; __hip_atomic_store(&w.flags[FL_LAYOUT_DIRTY], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    if (gid == 0) { w.flags[FL_UF_NPAIRS] = 0; w.lay_state[0] = 1; w.lay_state[1] += 1; w.lay_state[2] = w.flags[FL_N_GLOB_BODIES]; __hip_atomic_store(&w.flags[FL_LAYOUT_DIRTY], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 }
 
 // ---- register-resident constraint of one island thread ------------------------------------------

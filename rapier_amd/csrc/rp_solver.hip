@@ -248,6 +248,7 @@ static int cons_blocks(const DevWorld &w) { int cb = (w.cons_cap + 255) / 256; i
 // the flags an edit of a live world raises (rp_api.hip after_topology_edit): one thread
 __global__ void k_edit_flags(DevWorld w, int keep_grid) {
     if (!keep_grid) w.flags[FL_BP_GRID_OK] = 0;
+    w.lay_state[0] = 0; // bodies came, went or changed their kind: the next layout rebuild finds its components from scratch (rp_islands.hip)
     w.flags[FL_BP_DIRTY] = 1; w.flags[FL_LAYOUT_DIRTY] = 1; w.flags[FL_JOINT_DIRTY] = 1; w.flags[FL_FLOW_DIRTY] = 1;
 }
 void rp_launch_edit_flags(const DevWorld &w, hipStream_t st, int keep_grid) { hipLaunchKernelGGL(k_edit_flags, dim3(1), dim3(1), 0, st, w, keep_grid); }
