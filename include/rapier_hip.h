@@ -66,7 +66,11 @@ enum { RP_SHAPE_BALL = 0, RP_SHAPE_CUBOID = 1,
        RP_SHAPE_CAPSULE = 2 /* ColliderBuilder::capsule_x/y/z (collider.rs): half_extents = (half_height, radius, axis 0|1|2) */,
        RP_SHAPE_HALFSPACE = 3 /* ColliderBuilder::halfspace(outward_normal): half_extents = the unit normal in the collider's frame; the
                                  solid side is dot(normal, p) <= 0.  Parent: none, a fixed or a kinematic body (an unbounded shape
-                                 on a dynamic body is refused); weighs nothing (MassProperties::zero) */ };
+                                 on a dynamic body is refused); weighs nothing (MassProperties::zero) */,
+       RP_SHAPE_CYLINDER = 4 /* ColliderBuilder::cylinder(half_height, radius) (collider.rs:770): half_extents = (half_height, radius, -),
+                                axis Y */,
+       RP_SHAPE_CONE = 5 /* ColliderBuilder::cone(half_height, radius) (collider.rs:789): half_extents = (half_height, radius, -), base at
+                            -half_height, apex at +half_height; its centre of mass sits a quarter of the height above the base */ };
 enum { RP_RULE_AVERAGE = 0, RP_RULE_MIN, RP_RULE_MULTIPLY, RP_RULE_MAX, RP_RULE_CLAMPED_SUM, RP_RULE_GEOMETRIC_MEAN };
 
 /* RigidBodyBuilder — /root/reference/src/dynamics/rigid_body.rs:1560-1900 */

@@ -26,6 +26,7 @@
  */
 #include "rapier_oracle.h"
 #include "ro_shapes.h"
+#include "ro_convex.h"
 #include "ro_ccd.h"
 /* Optional OpenMP (bench.py's cpu_baseline leg): loops over items that touch pairwise-disjoint state
  * — the pairs of the narrow phase, the bodies, the constraints of one colour (the reference runs
@@ -385,9 +386,26 @@ static void update_world_mass_properties(Body *b) {
 
 /* parry Shape::mass_properties (cuboid / ball / capsule), SURVEY Appendix C.  `frame` = principal inertia local frame of the
  * shape (identity except for capsules along X / Z: MassProperties::from_capsule rotates Y onto the segment direction). */
-static void shape_mass_props(const Collider *c, float density, float *mass, v3 *principal_inertia, float frame[4]) {
+static void shape_mass_props(const Collider *c, float density, float *mass, v3 *principal_inertia, float frame[4], float com[3]) {
     frame[0] = 0.0f; frame[1] = 0.0f; frame[2] = 0.0f; frame[3] = 1.0f;
-    if (c->shape == RO_SHAPE_CUBOID) {
+    com[0] = com[1] = com[2] = 0.0f;
+    if (c->shape == RO_SHAPE_CYLINDER) { /* MassProperties::from_cylinder: cylinder_y_volume_unit_inertia */
+        float hh = c->he.y, r = c->radius;
+        float vol = hh * r * r * 3.14159265358979323846f * 2.0f;
+        float sq_radius = r * r, sq_height = hh * hh * 4.0f;
+        float off_principal = (sq_radius * 3.0f + sq_height) / 12.0f;
+        float m = vol * density;
+        *mass = m; *principal_inertia = V3(off_principal * m, sq_radius / 2.0f * m, off_principal * m);
+    } else if (c->shape == RO_SHAPE_CONE) { /* MassProperties::from_cone: cone_y_volume_unit_inertia, centre of mass a quarter of the height above the base */
+        float hh = c->he.y, r = c->radius;
+        float vol = r * r * 3.14159265358979323846f * hh * 2.0f / 3.0f;
+        float sq_radius = r * r, sq_height = hh * hh * 4.0f;
+        float off_principal = sq_radius * 3.0f / 20.0f + sq_height * 3.0f / 80.0f;
+        float principal = sq_radius * 3.0f / 10.0f;
+        float m = vol * density;
+        *mass = m; *principal_inertia = V3(off_principal * m, principal * m, off_principal * m);
+        com[1] = -hh / 2.0f;
+    } else if (c->shape == RO_SHAPE_CUBOID) {
         float vol = c->he.x * c->he.y * c->he.z * 8.0f;
         float m = vol * density;
         float ix = (c->he.y * c->he.y + c->he.z * c->he.z) / 3.0f;
@@ -426,6 +444,7 @@ static float shape_bounding_radius(const Collider *c) {
     if (c->shape == RO_SHAPE_CUBOID) return vlen(c->he);
     if (c->shape == RO_SHAPE_CAPSULE) return c->he.x + c->radius;
     if (c->shape == RO_SHAPE_HALFSPACE) return FLT_MAX;
+    if (c->shape == RO_SHAPE_CYLINDER || c->shape == RO_SHAPE_CONE) return sqrtf(c->radius * c->radius + c->he.y * c->he.y);
     return c->radius;
 }
 
@@ -555,7 +574,7 @@ static void sum_collider_mass_props(const ro_world *w, int body, float density_o
     for (int q = 0; q < cnt; ++q) {
         const Collider *c = &w->colliders[list[q]];
         ro_mp m; memset(&m, 0, sizeof(m)); m.frame[3] = 1.0f;
-        v3 pi; shape_mass_props(c, density_override < 0.0f ? c->density : density_override, &m.mass, &pi, m.frame);
+        v3 pi; shape_mass_props(c, density_override < 0.0f ? c->density : density_override, &m.mass, &pi, m.frame, m.com);
         m.pi[0] = pi.x; m.pi[1] = pi.y; m.pi[2] = pi.z;
         float t[3] = {c->pos_wrt_parent.t.x, c->pos_wrt_parent.t.y, c->pos_wrt_parent.t.z};
         float q[4] = {c->pos_wrt_parent.r.x, c->pos_wrt_parent.r.y, c->pos_wrt_parent.r.z, c->pos_wrt_parent.r.w};
@@ -681,6 +700,7 @@ int32_t ro_add_collider(ro_world *w, const ro_collider_desc *d, int32_t parent) 
     c->he = V3(d->half_extents[0], d->half_extents[1], d->half_extents[2]);
     c->radius = d->half_extents[0];
     if (c->shape == RO_SHAPE_CAPSULE) { c->radius = d->half_extents[1]; c->axis = (int)d->half_extents[2]; if (c->axis < 0 || c->axis > 2) c->axis = 1; }
+    if (c->shape == RO_SHAPE_CYLINDER || c->shape == RO_SHAPE_CONE) { c->radius = d->half_extents[1]; c->he = V3(c->radius, d->half_extents[0], c->radius); c->axis = 1; } /* he = the local AABB's half extents */
     c->pos_wrt_parent.t = V3(d->translation[0], d->translation[1], d->translation[2]);
     c->pos_wrt_parent.r = qnormalize(Q(d->rotation[0], d->rotation[1], d->rotation[2], d->rotation[3]));
     c->density = d->density; c->friction = d->friction; c->restitution = d->restitution;
@@ -816,7 +836,7 @@ void ro_read_sleeping(const ro_world *w, int32_t *sleeping) {
  * sort-and-sweep over fat AABBs, re-run only when some fat AABB changed. */
 static Aabb collider_collision_aabb(const Collider *c, float loosen) {
     Aabb a;
-    if (c->shape == RO_SHAPE_CUBOID) {
+    if (c->shape == RO_SHAPE_CUBOID || c->shape == RO_SHAPE_CYLINDER || c->shape == RO_SHAPE_CONE) { /* Cylinder / Cone::aabb = local_aabb().transform_by(pos) */
         float m[3][3]; quat_to_mat(c->pos.r, m);
         v3 h = V3(fabsf(m[0][0]) * c->he.x + fabsf(m[0][1]) * c->he.y + fabsf(m[0][2]) * c->he.z,
                   fabsf(m[1][0]) * c->he.x + fabsf(m[1][1]) * c->he.y + fabsf(m[1][2]) * c->he.z,
@@ -1095,7 +1115,7 @@ static float relative_pose_drift(pose base, pose cur, float max_extent) {
     return trans + chord;
 }
 static float collider_origin_radius(const Collider *c) {
-    if (c->shape == RO_SHAPE_CUBOID) return vlen(c->he); /* max(|mins|,|maxs|) of the local AABB */
+    if (c->shape == RO_SHAPE_CUBOID || c->shape == RO_SHAPE_CYLINDER || c->shape == RO_SHAPE_CONE) return vlen(c->he); /* max(|mins|,|maxs|) of the local AABB */
     if (c->shape == RO_SHAPE_CAPSULE) { v3 h = V3(c->radius, c->radius, c->radius); vset(&h, c->axis, c->he.x + c->radius); return vlen(h); }
     if (c->shape == RO_SHAPE_HALFSPACE) return INFINITY; /* |(MAX/2, MAX/2, MAX/2)| overflows: a pair with a half-space never recycles */
     return vlen(V3(c->radius, c->radius, c->radius));
@@ -1165,6 +1185,7 @@ static int joints_disable_contacts(const ro_world *w, int b1, int b2) {
  * separating axis among 3 + 3 face normals and 9 edge cross products), a ball against a convex shape (solid point projection),
  * capsule-capsule (segment distance).  Cuboid-capsule goes through GJK in parry; here the distance from the capsule's segment to
  * the box is minimised over the segment parameter (a convex function: ternary search, 48 fixed iterations). */
+static SmShape sm_shape_of(const Collider *c) { SmShape s; s.shape = c->shape; s.he = c->he; s.radius = c->radius; s.axis = c->axis; return s; }
 static float point_box_dist2(v3 p, v3 he) {
     float dx = ro_maxf(fabsf(p.x) - he.x, 0.0f), dy = ro_maxf(fabsf(p.y) - he.y, 0.0f), dz = ro_maxf(fabsf(p.z) - he.z, 0.0f);
     return dx * dx + dy * dy + dz * dz;
@@ -1172,6 +1193,12 @@ static float point_box_dist2(v3 p, v3 he) {
 static int shapes_intersect(const Collider *c1, const Collider *c2) {
     pose pos12 = pose_inv_mul(c1->pos, c2->pos);
     int s1 = c1->shape, s2 = c2->shape;
+    if (s1 >= RO_SHAPE_CYLINDER || s2 >= RO_SHAPE_CYLINDER) { /* cylinders, cones: GJK (intersection_test_support_map_support_map) */
+        SmShape a = sm_shape_of(c1), b = sm_shape_of(c2);
+        if (s1 == RO_SHAPE_HALFSPACE) return vdot(c1->he, pose_tp(pos12, sm_support(&b, qrot_inv(pos12.r, vneg(c1->he))))) <= 0.0f;
+        if (s2 == RO_SHAPE_HALFSPACE) { pose pos21 = pose_inv(pos12); return vdot(c2->he, pose_tp(pos21, sm_support(&a, qrot_inv(pos21.r, vneg(c2->he))))) <= 0.0f; }
+        return sm_intersects(&a, &b, pos12);
+    }
     if (s1 > s2) { /* order the pair: ball < cuboid < capsule < half-space */
         const Collider *t = c1; c1 = c2; c2 = t; pos12 = pose_inv(pos12); s1 = c1->shape; s2 = c2->shape;
     }
@@ -1271,7 +1298,15 @@ static int process_pair(ro_world *w, int pair_idx, Transition *tr_out) {
 
     /* :323-330 parry DefaultQueryDispatcher::contact_manifolds */
     int s1 = co1->shape, s2 = co2->shape;
-    if (s1 == RO_SHAPE_HALFSPACE || s2 == RO_SHAPE_HALFSPACE) {
+    if (s1 >= RO_SHAPE_CYLINDER || s2 >= RO_SHAPE_CYLINDER) { /* cylinders, cones (ro_convex.h): same dispatcher order — ball arms, half-space arms, pfm_pfm */
+        SmShape a = sm_shape_of(co1), b = sm_shape_of(co2);
+        if (s2 == RO_SHAPE_BALL) manifold_sm_ball(pos12, &a, co2->radius, eff_prediction, &p->m, 0);
+        else if (s1 == RO_SHAPE_BALL) manifold_sm_ball(pose_inv(pos12), &b, co1->radius, eff_prediction, &p->m, 1);
+        else if (s1 == RO_SHAPE_HALFSPACE) manifold_halfspace_sm(pos12, co1->he, &b, eff_prediction, &p->m, 0);
+        else if (s2 == RO_SHAPE_HALFSPACE) manifold_halfspace_sm(pose_inv(pos12), co2->he, &a, eff_prediction, &p->m, 1);
+        else manifold_pfm_pfm(pos12, &a, &b, eff_prediction, &p->m);
+    }
+    else if (s1 == RO_SHAPE_HALFSPACE || s2 == RO_SHAPE_HALFSPACE) {
         /* (_, Ball) | (Ball, _) -> convex_ball comes before (HalfSpace, pfm) | (pfm, HalfSpace) in the dispatcher */
         if (s1 == RO_SHAPE_HALFSPACE && s2 == RO_SHAPE_HALFSPACE) p->m.npoints = 0; /* Unsupported */
         else if (s1 == RO_SHAPE_HALFSPACE && s2 == RO_SHAPE_BALL) manifold_halfspace_ball(pos12, co1->he, co2->radius, eff_prediction, &p->m, 0);
@@ -2685,7 +2720,7 @@ static void solve_velocity_constraints(ro_world *w) {
  * that is not on a bullet, targets standing at their — possibly just clamped — next_position; the earliest solid impact clamps the
  * body's next_position (apply_clamps :325-339), velocities are untouched.  Sensors and colliders whose groups do not match never
  * stop a body (the paired intersection events of sensor crossings, :265-320, are not raised). */
-static CcdShape ccd_shape_of(const Collider *c) { CcdShape s; s.shape = c->shape; s.he = c->he; s.radius = c->radius; s.axis = c->axis; return s; }
+static CcdShape ccd_shape_of(const Collider *c) { return sm_shape_of(c); }
 static int ccd_is_bullet(const Body *b) { return b->body_type == RO_BODY_DYNAMIC && b->ccd_enabled; } /* sweeps.rs:29-31 */
 static void ccd_sweep_tier(ro_world *w, int bullets) {
     const float slop = w->params.normalized_allowed_linear_error * w->params.length_unit; /* IntegrationParameters::allowed_linear_error */
@@ -3255,4 +3290,40 @@ void ro_read_joints(const ro_world *w, int32_t *color, float *impulses3) {
         if (color) color[i] = w->joints[i].solver_color;
         if (impulses3) for (int k = 0; k < 3; ++k) impulses3[3 * i + k] = w->joints[i].impulses[k];
     }
+}
+
+/* ---- hooks for tests/test_convex_oracle.py: the support-mapped queries of ro_convex.h on two shapes given like collider descriptors
+ * (shape, half_extents) and the pose of shape 2 in the frame of shape 1 (translation xyz, rotation xyzw) ---- */
+static SmShape kat_shape(int32_t shape, const float he[3]) {
+    SmShape s; s.shape = shape; s.he = V3(he[0], he[1], he[2]); s.radius = he[0]; s.axis = 1;
+    if (shape == RO_SHAPE_CAPSULE) { s.radius = he[1]; s.axis = (int)he[2]; }
+    if (shape == RO_SHAPE_CYLINDER || shape == RO_SHAPE_CONE) { s.radius = he[1]; s.he = V3(he[1], he[0], he[1]); }
+    return s;
+}
+static pose kat_pose(const float p[7]) { pose r; r.t = V3(p[0], p[1], p[2]); r.r = qnormalize(Q(p[3], p[4], p[5], p[6])); return r; }
+/* out = hit, p1 xyz, p2 xyz (frame 1), normal xyz (1 -> 2) */
+void ro_kat_convex_contact(int32_t sh1, const float he1[3], int32_t sh2, const float he2[3], const float pos12[7], float prediction, float out[10]) {
+    SmShape a = kat_shape(sh1, he1), b = kat_shape(sh2, he2);
+    v3 p1 = V3(0, 0, 0), p2 = V3(0, 0, 0), n = V3(0, 0, 0);
+    int hit = sm_contact(&a, &b, kat_pose(pos12), prediction, V3(0, 0, 0), &p1, &p2, &n);
+    out[0] = (float)hit; out[1] = p1.x; out[2] = p1.y; out[3] = p1.z; out[4] = p2.x; out[5] = p2.y; out[6] = p2.z; out[7] = n.x; out[8] = n.y; out[9] = n.z;
+}
+/* the whole generator on an empty manifold: returns the number of points; pts = up to 8 x (local_p1 xyz, local_p2 xyz, dist, fid1, fid2), n1 = local_n1 */
+int32_t ro_kat_convex_manifold(int32_t sh1, const float he1[3], int32_t sh2, const float he2[3], const float pos12[7], float prediction, float *pts, float n1[3]) {
+    SmShape a = kat_shape(sh1, he1), b = kat_shape(sh2, he2);
+    Manifold m; memset(&m, 0, sizeof(m));
+    manifold_pfm_pfm(kat_pose(pos12), &a, &b, prediction, &m);
+    for (int i = 0; i < m.npoints; ++i) {
+        float *o = pts + 9 * i; const TrackedContact *c = &m.points[i];
+        o[0] = c->local_p1.x; o[1] = c->local_p1.y; o[2] = c->local_p1.z; o[3] = c->local_p2.x; o[4] = c->local_p2.y; o[5] = c->local_p2.z;
+        o[6] = c->dist; o[7] = (float)c->fid1; o[8] = (float)c->fid2;
+    }
+    n1[0] = m.local_n1.x; n1[1] = m.local_n1.y; n1[2] = m.local_n1.z;
+    return m.npoints;
+}
+/* the projection of a point on a cylinder / cone: out = proj xyz, inside */
+void ro_kat_convex_project(int32_t sh, const float he[3], const float pt[3], float out[4]) {
+    SmShape a = kat_shape(sh, he); int inside;
+    v3 q = sm_project_point(&a, V3(pt[0], pt[1], pt[2]), &inside);
+    out[0] = q.x; out[1] = q.y; out[2] = q.z; out[3] = (float)inside;
 }

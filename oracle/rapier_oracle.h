@@ -52,7 +52,9 @@ typedef struct ro_params {
 enum { RO_BODY_DYNAMIC = 0, RO_BODY_FIXED = 1, RO_BODY_KINEMATIC_POSITION = 2, RO_BODY_KINEMATIC_VELOCITY = 3 };
 enum { RO_FRICTION_SIMPLIFIED = 0, RO_FRICTION_COULOMB = 1 }; /* integration_parameters.rs:13-32 */
 enum { RO_SHAPE_BALL = 0, RO_SHAPE_CUBOID = 1, RO_SHAPE_CAPSULE = 2 /* half_extents = (half_height, radius, axis 0|1|2): ColliderBuilder::capsule_x/y/z */,
-       RO_SHAPE_HALFSPACE = 3 /* half_extents = the unit outward normal in the collider's frame: ColliderBuilder::halfspace */ };
+       RO_SHAPE_HALFSPACE = 3 /* half_extents = the unit outward normal in the collider's frame: ColliderBuilder::halfspace */,
+       RO_SHAPE_CYLINDER = 4 /* half_extents = (half_height, radius, -): ColliderBuilder::cylinder (collider.rs:770), axis Y */,
+       RO_SHAPE_CONE = 5 /* half_extents = (half_height, radius, -): ColliderBuilder::cone (collider.rs:789), apex at +Y */ };
 /* CoefficientCombineRule — coefficient_combine_rule.rs:37-57 */
 enum { RO_RULE_AVERAGE = 0, RO_RULE_MIN = 1, RO_RULE_MULTIPLY = 2, RO_RULE_MAX = 3,
        RO_RULE_CLAMPED_SUM = 4, RO_RULE_GEOMETRIC_MEAN = 5 };

@@ -53,7 +53,7 @@ static inline pose ccd_sweep_transform_at(const CcdSweep *s, float t) {
 
 /* a collider's shape as the CCD query sees it: kind, (cuboid half extents | capsule half height, radius, axis | ball radius in x |
  * half-space normal) */
-typedef struct { int shape; v3 he; float radius; int axis; } CcdShape;
+typedef SmShape CcdShape; /* ro_convex.h: the same record serves the support-mapped queries (cylinders, cones) */
 
 static inline v3 ccd_clamp_box(v3 p, v3 he) { return V3(ro_clampf(p.x, -he.x, he.x), ro_clampf(p.y, -he.y, he.y), ro_clampf(p.z, -he.z, he.z)); }
 /* separation of a point from a solid box (negative constant when inside) and the unit direction from the box to the point */
@@ -75,6 +75,14 @@ static inline float ccd_point_dir(v3 dv, v3 *dir) { /* |dv| and its direction; a
  * n1, in the frame of 1, from 1 towards 2, along which it was measured.  A value <= 0 means "touching or overlapping". */
 static inline float ccd_separation(const CcdShape *s1, const CcdShape *s2, pose pos12, v3 *n1) {
     const pose pos21 = pose_inv(pos12);
+    if (s1->shape >= RO_SHAPE_CYLINDER || s2->shape >= RO_SHAPE_CYLINDER) { /* cylinders, cones: the exact distance of the cores by GJK (ro_convex.h) */
+        if (s1->shape == RO_SHAPE_HALFSPACE) {
+            *n1 = s1->he;
+            return vdot(s1->he, pose_tp(pos12, sm_support(s2, qrot_inv(pos12.r, vneg(s1->he)))));
+        }
+        float d = sm_distance(s1, s2, pos12, n1);
+        return d < 0.0f ? d : d - sm_border_radius(s1) - sm_border_radius(s2);
+    }
     if (s1->shape == RO_SHAPE_HALFSPACE) {
         const v3 n = s1->he;
         *n1 = n;

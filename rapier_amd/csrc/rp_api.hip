@@ -476,11 +476,32 @@ static float shape_bounding_radius(const rp_collider_desc &c) { // Shape::comput
     if (c.shape == RP_SHAPE_CUBOID) return std::sqrt(c.half_extents[0] * c.half_extents[0] + c.half_extents[1] * c.half_extents[1] + c.half_extents[2] * c.half_extents[2]);
     if (c.shape == RP_SHAPE_CAPSULE) return c.half_extents[0] + c.half_extents[1];
     if (c.shape == RP_SHAPE_HALFSPACE) return 3.402823466e+38f;
+    if (c.shape == RP_SHAPE_CYLINDER || c.shape == RP_SHAPE_CONE) { volatile float rr = c.half_extents[1] * c.half_extents[1], hh2 = c.half_extents[0] * c.half_extents[0]; return std::sqrt(rr + hh2); }
     return c.half_extents[0];
 }
-static void shape_mass_props(const rp_collider_desc &c, float density, float &mass, float pi[3], float frame[4]) {
+static void shape_mass_props(const rp_collider_desc &c, float density, float &mass, float pi[3], float frame[4], float com[3]) {
     frame[0] = 0.0f; frame[1] = 0.0f; frame[2] = 0.0f; frame[3] = 1.0f;
-    if (c.shape == RP_SHAPE_CUBOID) {
+    com[0] = com[1] = com[2] = 0.0f;
+    if (c.shape == RP_SHAPE_CYLINDER) { // MassProperties::from_cylinder (cylinder_y_volume_unit_inertia)
+        float hh = c.half_extents[0], r = c.half_extents[1];
+        volatile float vol = hh * r * r * 3.14159265358979323846f * 2.0f;
+        volatile float sq_radius = r * r, sq_height = hh * hh * 4.0f;
+        volatile float off_principal = (sq_radius * 3.0f + sq_height) / 12.0f;
+        volatile float m = vol * density;
+        volatile float iy = sq_radius / 2.0f * m, ixz = off_principal * m;
+        mass = m; pi[0] = ixz; pi[1] = iy; pi[2] = ixz;
+    } else if (c.shape == RP_SHAPE_CONE) { // MassProperties::from_cone (cone_y_volume_unit_inertia): the centre of mass a quarter of the height above the base
+        float hh = c.half_extents[0], r = c.half_extents[1];
+        volatile float vol = r * r * 3.14159265358979323846f * hh * 2.0f / 3.0f;
+        volatile float sq_radius = r * r, sq_height = hh * hh * 4.0f;
+        volatile float t0 = sq_radius * 3.0f / 20.0f, t1 = sq_height * 3.0f / 80.0f;
+        volatile float off_principal = t0 + t1;
+        volatile float principal = sq_radius * 3.0f / 10.0f;
+        volatile float m = vol * density;
+        volatile float iy = principal * m, ixz = off_principal * m;
+        mass = m; pi[0] = ixz; pi[1] = iy; pi[2] = ixz;
+        com[1] = -hh / 2.0f;
+    } else if (c.shape == RP_SHAPE_CUBOID) {
         const float *he = c.half_extents;
         volatile float vol = he[0] * he[1] * he[2] * 8.0f;
         volatile float m = vol * density;
@@ -632,7 +653,7 @@ static void sum_collider_mass_props(const rp_world *w, int body, float density_o
         if (w->collider_removed[i]) continue;
         const rp_collider_desc &c = w->colliders[i];
         hmp_mp m; memset(&m, 0, sizeof(m)); m.frame[3] = 1.0f;
-        shape_mass_props(c, density_override < 0.0f ? c.density : density_override, m.mass, m.pi, m.frame);
+        shape_mass_props(c, density_override < 0.0f ? c.density : density_override, m.mass, m.pi, m.frame, m.com);
         float qn = std::sqrt(c.rotation[0] * c.rotation[0] + c.rotation[1] * c.rotation[1] + c.rotation[2] * c.rotation[2] + c.rotation[3] * c.rotation[3]);
         float qi = qn > 0.0f ? 1.0f / qn : 1.0f;
         float q[4] = {c.rotation[0] * qi, c.rotation[1] * qi, c.rotation[2] * qi, qn > 0.0f ? c.rotation[3] * qi : 1.0f};
@@ -680,7 +701,7 @@ static void recompute_mass(rp_world *w, int body) {
         if (w->collider_removed[i]) continue;
         const rp_collider_desc &c = w->colliders[i];
         if (c.shape == RP_SHAPE_HALFSPACE) continue; // Shape::ccd_thickness of a half-space is f32::MAX
-        float th = c.shape == RP_SHAPE_BALL ? c.half_extents[0] : c.shape == RP_SHAPE_CAPSULE ? c.half_extents[1] : std::min(c.half_extents[0], std::min(c.half_extents[1], c.half_extents[2]));
+        float th = c.shape == RP_SHAPE_BALL ? c.half_extents[0] : c.shape == RP_SHAPE_CAPSULE ? c.half_extents[1] : (c.shape == RP_SHAPE_CYLINDER || c.shape == RP_SHAPE_CONE) ? std::min(c.half_extents[0], c.half_extents[1]) : std::min(c.half_extents[0], std::min(c.half_extents[1], c.half_extents[2]));
         b.ccd_thickness = std::min(b.ccd_thickness, th);
     }
 }
@@ -857,7 +878,8 @@ extern "C" int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider
     if (!w || n < 0 || (n > 0 && !descs)) return RP_ERR_INVALID;
     for (int i = 0; i < n; ++i) {
         const rp_collider_desc &cd = descs[i];
-        if (cd.shape != RP_SHAPE_BALL && cd.shape != RP_SHAPE_CUBOID && cd.shape != RP_SHAPE_CAPSULE && cd.shape != RP_SHAPE_HALFSPACE) { w->err = "rp_colliders_insert: unknown shape (ball, cuboid, capsule and half-space are implemented)"; return RP_ERR_INVALID; }
+        if (cd.shape < RP_SHAPE_BALL || cd.shape > RP_SHAPE_CONE) { w->err = "rp_colliders_insert: unknown shape (ball, cuboid, capsule, half-space, cylinder and cone are implemented)"; return RP_ERR_INVALID; }
+        if ((cd.shape == RP_SHAPE_CYLINDER || cd.shape == RP_SHAPE_CONE) && !(cd.half_extents[0] > 0.0f && cd.half_extents[1] > 0.0f)) { w->err = "rp_colliders_insert: cylinder / cone half_extents = (half_height, radius, -), both positive"; return RP_ERR_INVALID; }
         if (cd.shape == RP_SHAPE_HALFSPACE) {
             const float *nn = cd.half_extents; const float l2 = nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2];
             if (!(std::fabs(l2 - 1.0f) <= 1.0e-3f)) { w->err = "rp_colliders_insert: a half-space's half_extents hold its unit outward normal"; return RP_ERR_INVALID; }
@@ -928,6 +950,7 @@ extern "C" int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider
             const int p = w->collider_parent[ci];
             if (c.active_events & RP_EVENTS_CONTACT_FORCE) w->dw.has_force_events = 1;
             if (c.sensor) w->dw.has_sensors = 1;
+            if (c.shape >= RP_SHAPE_CYLINDER) w->dw.has_convex = 1;
             if (p >= 0 && w->bodies[p].d.body_type == RP_BODY_DYNAMIC) {
                 const float *t = c.translation, *r = c.rotation;
                 const bool at_origin = t[0] == 0.0f && t[1] == 0.0f && t[2] == 0.0f && r[0] == 0.0f && r[1] == 0.0f && r[2] == 0.0f;
@@ -1046,6 +1069,7 @@ static ColliderRow pack_collider(const rp_world *w, int i) {
     o.lp = mk4(c.translation[0], c.translation[1], c.translation[2], 0);
     o.lr = mk4(c.rotation[0] * qi, c.rotation[1] * qi, c.rotation[2] * qi, qn > 0.0f ? c.rotation[3] * qi : 1.0f);
     o.he = mk4(c.half_extents[0], c.half_extents[1], c.half_extents[2], 0);
+    if (c.shape == RP_SHAPE_CYLINDER || c.shape == RP_SHAPE_CONE) o.he = mk4(c.half_extents[1], c.half_extents[0], c.half_extents[1], 0); // (radius, half_height, radius): the local AABB's half extents
     o.mat = mk4(c.friction, c.restitution, c.density, 0);
     o.rules.x = c.friction_rule; o.rules.y = c.restitution_rule;
     o.groups.x = w->collider_removed[i] ? 0u : c.collision_memberships; o.groups.y = w->collider_removed[i] ? 0u : c.collision_filter;
@@ -1111,6 +1135,10 @@ static void refresh_ccd_facts(rp_world *w) {
 }
 static bool world_has_sensors(const rp_world *w) {
     for (size_t i = 0; i < w->colliders.size(); ++i) if (!w->collider_removed[i] && w->colliders[i].sensor) return true;
+    return false;
+}
+static bool world_has_convex(const rp_world *w) {
+    for (size_t i = 0; i < w->colliders.size(); ++i) if (!w->collider_removed[i] && w->colliders[i].shape >= RP_SHAPE_CYLINDER) return true;
     return false;
 }
 static bool world_has_force_events(const rp_world *w) {
@@ -1210,6 +1238,7 @@ static int finalize(rp_world *w) {
     d.has_kinematic_pos = world_has_kinematic_pos(w) ? 1 : 0;
     d.has_force_events = world_has_force_events(w) ? 1 : 0;
     d.has_sensors = world_has_sensors(w) ? 1 : 0;
+    d.has_convex = world_has_convex(w) ? 1 : 0;
     d.gbar_blocks = gbar_grid_for_device(w->device);
     { const char *ni = getenv("RP_NO_BP_INCR"); d.bp_incremental = (ni && ni[0] == '1') ? 0 : 1; }
     { const char *ig = getenv("RP_ISL_GENERIC"); d.isl_generic = (ig && ig[0] == '1') ? 1 : 0; }

@@ -38,13 +38,8 @@ RP_DEV Pose ccd_sweep_transform_at(const CcdSweep &s, float t) {
 }
 // a collider's shape as the query sees it (c_shape / c_he of rp_world.h): he = cuboid half extents | half-space normal; capsule:
 // he.x = half height, radius, axis; ball: radius
-struct CcdShape { int shape; V3 he; float radius; int axis; };
-RP_DEV CcdShape ccd_shape_of(int sh, float4 he) {
-    CcdShape s; s.shape = sh; s.he = v3(he); s.axis = 1;
-    s.radius = sh == RP_SHAPE_CAPSULE ? he.y : he.x;
-    if (sh == RP_SHAPE_CAPSULE) s.axis = (int)he.z;
-    return s;
-}
+typedef SmShape CcdShape; // (rp_convex.h: the same record serves the support-mapped queries)
+RP_DEV CcdShape ccd_shape_of(int sh, float4 he) { return sm_shape_of(sh, he); }
 RP_DEV V3 ccd_clamp_box(V3 p, V3 he) { return v3(rp_clamp(p.x, -he.x, he.x), rp_clamp(p.y, -he.y, he.y), rp_clamp(p.z, -he.z, he.z)); }
 RP_DEV float ccd_point_dir(V3 dv, V3 &dir) {
     float dist = len(dv);
@@ -54,8 +49,18 @@ RP_DEV float ccd_point_dir(V3 dv, V3 &dir) {
 }
 RP_DEV float ccd_point_box(V3 p, V3 he, V3 &dir) { return ccd_point_dir(p - ccd_clamp_box(p, he), dir); }
 
-__device__ float ccd_separation(const CcdShape &s1, const CcdShape &s2, Pose pos12, V3 &n1) {
+template <bool CONVEX> __device__ float ccd_separation(const CcdShape &s1, const CcdShape &s2, Pose pos12, V3 &n1) {
     const Pose pos21 = pose_inv(pos12);
+    if constexpr (CONVEX) {
+        if (s1.shape >= RP_SHAPE_CYLINDER || s2.shape >= RP_SHAPE_CYLINDER) { // cylinders, cones: the exact distance of the cores by GJK
+            if (s1.shape == RP_SHAPE_HALFSPACE) {
+                n1 = s1.he;
+                return dot(s1.he, pose_tp(pos12, sm_support(s2, qrot_inv(pos12.r, -s1.he))));
+            }
+            float d = sm_distance(s1, s2, pos12, n1);
+            return d < 0.0f ? d : d - sm_border_radius(s1) - sm_border_radius(s2);
+        }
+    }
     if (s1.shape == RP_SHAPE_HALFSPACE) {
         const V3 n = s1.he;
         n1 = n;
@@ -135,7 +140,7 @@ RP_DEV float ccd_rot_radius(const CcdShape &s2, Pose pos_wrt_parent, V3 local_co
     }
     return len(c) + len(s2.he);
 }
-__device__ float ccd_cast_pair(const CcdShape &s1, Pose target_pose, const CcdShape &s2, Pose pos_wrt_parent, const CcdSweep &sw, float rot_radius,
+template <bool CONVEX> __device__ float ccd_cast_pair(const CcdShape &s1, Pose target_pose, const CcdShape &s2, Pose pos_wrt_parent, const CcdSweep &sw, float rot_radius,
                                float max_fraction, float slop) {
     const float total_radius = ((s1.shape == RP_SHAPE_BALL || s1.shape == RP_SHAPE_CAPSULE) ? s1.radius : 0.0f) + ((s2.shape == RP_SHAPE_BALL || s2.shape == RP_SHAPE_CAPSULE) ? s2.radius : 0.0f);
     const float target = rp_max(slop, total_radius - slop) - total_radius, tol = 0.25f * slop;
@@ -148,7 +153,7 @@ __device__ float ccd_cast_pair(const CcdShape &s1, Pose target_pose, const CcdSh
         Pose cp = pose_mul(ccd_sweep_transform_at(sw, t), pos_wrt_parent);
         Pose pos12 = pose_inv_mul(target_pose, cp);
         V3 n1;
-        float sep = ccd_separation(s1, s2, pos12, n1);
+        float sep = ccd_separation<CONVEX>(s1, s2, pos12, n1);
         if (sep < target + tol) return iter == 0 ? -1.0f : t;
         V3 nw = qrot(target_pose.r, n1);
         float approach = -dot(D, nw);
@@ -168,13 +173,14 @@ RP_DEV bool ccd_may_reach(V3 c0, V3 c1, float max_extent, V3 target_centre, floa
 RP_DEV float ccd_bounding_radius(int sh, float4 he) { // Shape::compute_local_bounding_sphere
     if (sh == RP_SHAPE_CUBOID) return len(v3(he));
     if (sh == RP_SHAPE_CAPSULE) return he.x + he.y;
+    if (sh >= RP_SHAPE_CYLINDER) return sqrtf(he.x * he.x + he.y * he.y);
     return he.x;
 }
 
 #define CCD_MAX_FAST_COLLIDERS 64
 // One workgroup per fast body of the list body_writeback filled this step (w.ccd_list, FL_CCD_N).  tier 0: non-bullets against fixed
 // targets; tier 1: bullets against everything that is not on a bullet.
-__global__ void __launch_bounds__(256) k_ccd(DevWorld w, int tier, int publish) {
+template <bool CONVEX> __global__ void __launch_bounds__(256) k_ccd(DevWorld w, int tier, int publish) {
     // (MULTI-mode steps: the hint buffer is published here, by the launch that follows the body write-back anyway — one launch less; the
     // two CCD counters reach the host's hints a step late, rp_counters_read reads the device)
     // (last kernel of a lean graph — rp_world.h "lean step graphs": a step that died is marked here for the graphs that follow and for
@@ -248,7 +254,7 @@ __global__ void __launch_bounds__(256) k_ccd(DevWorld w, int tier, int publish) 
                 if (sh2 != RP_SHAPE_HALFSPACE && !ccd_may_reach(sw.c0, sw.c1, max_extent, tp.t, ccd_bounding_radius(sh2, he2), 2.0f * slop)) continue;
                 const CcdShape s1 = ccd_shape_of(sh2, he2);
                 const float cur = __uint_as_float(__hip_atomic_load(&best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                const float hit = ccd_cast_pair(s1, tp, s2, pwp, sw, rot_radius, cur, slop);
+                const float hit = ccd_cast_pair<CONVEX>(s1, tp, s2, pwp, sw, rot_radius, cur, slop);
                 if (hit > 0.0f && hit < cur) atomicMin(&best, __float_as_uint(hit));
             }
           }
@@ -273,6 +279,11 @@ __global__ void __launch_bounds__(256) k_ccd(DevWorld w, int tier, int publish) 
 bool rp_ccd_launches(const DevWorld &w) { return !(w.prm.p.max_ccd_substeps == 0 || w.n_bodies == 0 || w.n_colliders == 0); }
 void rp_launch_ccd(const DevWorld &w, hipStream_t st, int has_bullets, int publish) {
     if (!rp_ccd_launches(w)) return;
-    hipLaunchKernelGGL(k_ccd, dim3(64), dim3(256), 0, st, w, 0, publish);
-    if (has_bullets) hipLaunchKernelGGL(k_ccd, dim3(64), dim3(256), 0, st, w, 1, 0);
+    if (w.has_convex) { // worlds with a cylinder / cone: the distance of such a pair is a GJK run (rp_convex.h)
+        hipLaunchKernelGGL(k_ccd<true>, dim3(64), dim3(256), 0, st, w, 0, publish);
+        if (has_bullets) hipLaunchKernelGGL(k_ccd<true>, dim3(64), dim3(256), 0, st, w, 1, 0);
+        return;
+    }
+    hipLaunchKernelGGL(k_ccd<false>, dim3(64), dim3(256), 0, st, w, 0, publish);
+    if (has_bullets) hipLaunchKernelGGL(k_ccd<false>, dim3(64), dim3(256), 0, st, w, 1, 0);
 }

@@ -515,6 +515,9 @@ __device__ void manifold_cuboid_capsule(Pose pos12, Pose upd, V3 he1, float4 c2,
 }
 #undef PERP
 
+// ---- cylinders, cones: GJK / EPA + polygonal feature maps (only instantiated in the CONVEX kernels) ----
+#include "rp_convex.h"
+
 // manifold_reduction::reduce_manifold_naive — geometry/manifold_reduction.rs:4-84
 __device__ void reduce_manifold(const LocalManifold &m, int sel[4], int &nsel, float prediction) {
     if (m.n <= 4) return;
@@ -544,7 +547,7 @@ __device__ void reduce_manifold(const LocalManifold &m, int sel[4], int &nsel, f
 
 // max(|mins|, |maxs|) of the shape's local AABB (the recycle extent of pair_update.rs:582-613)
 RP_DEV float shape_origin_radius(int sh, float4 he) {
-    if (sh == RP_SHAPE_CUBOID) return len(v3(he));
+    if (sh == RP_SHAPE_CUBOID || sh >= RP_SHAPE_CYLINDER) return len(v3(he)); // (cylinder / cone: he = the local AABB's half extents)
     if (sh == RP_SHAPE_CAPSULE) { int ax = (int)he.z; return len(v3(ax == 0 ? he.x + he.y : he.y, ax == 1 ? he.x + he.y : he.y, ax == 2 ? he.x + he.y : he.y)); }
     if (sh == RP_SHAPE_HALFSPACE) return INFINITY; // |(MAX/2, MAX/2, MAX/2)| overflows: a pair with a half-space never recycles
     return len(v3(he.x, he.x, he.x));
@@ -576,7 +579,15 @@ RP_DEV float point_box_dist2(V3 p, V3 he) {
     float dx = rp_max(fabsf(p.x) - he.x, 0.0f), dy = rp_max(fabsf(p.y) - he.y, 0.0f), dz = rp_max(fabsf(p.z) - he.z, 0.0f);
     return dx * dx + dy * dy + dz * dz;
 }
-__device__ __noinline__ bool shapes_intersect(int s1, float4 h1, int s2, float4 h2, Pose pos12) {
+template <bool CONVEX> __device__ __noinline__ bool shapes_intersect(int s1, float4 h1, int s2, float4 h2, Pose pos12) {
+    if constexpr (CONVEX) {
+        if (s1 >= RP_SHAPE_CYLINDER || s2 >= RP_SHAPE_CYLINDER) { // cylinders, cones: GJK (intersection_test_support_map_support_map)
+            const SmShape a = sm_shape_of(s1, h1), b = sm_shape_of(s2, h2);
+            if (s1 == RP_SHAPE_HALFSPACE) return dot(v3(h1), pose_tp(pos12, sm_support(b, qrot_inv(pos12.r, -v3(h1))))) <= 0.0f;
+            if (s2 == RP_SHAPE_HALFSPACE) { Pose pos21 = pose_inv(pos12); return dot(v3(h2), pose_tp(pos21, sm_support(a, qrot_inv(pos21.r, -v3(h2))))) <= 0.0f; }
+            return sm_intersects(a, b, pos12);
+        }
+    }
     if (s1 > s2) { int ts = s1; s1 = s2; s2 = ts; float4 th = h1; h1 = h2; h2 = th; pos12 = pose_inv(pos12); } // ball < cuboid < capsule < half-space
     if (s2 == RP_SHAPE_HALFSPACE) { // intersection_test_support_map_halfspace: the support point toward -normal lies in the solid side
         if (s1 == RP_SHAPE_HALFSPACE) return false;
@@ -627,11 +638,11 @@ __device__ __noinline__ bool shapes_intersect(int s1, float4 h1, int s2, float4 
 
 // A sensor pair lives in the intersection graph (narrow_phase/intersections.rs:17-175): no manifold, no solver contact, no colour, no
 // wake-up; it is re-tested while one of its bodies may have moved and raises Started / Stopped | SENSOR on a change.
-__device__ __forceinline__ void sensor_pair_update(DevWorld &w, int s, int c1, int c2, Pose pos12) {
+template <bool CONVEX> __device__ __forceinline__ void sensor_pair_update(DevWorld &w, int s, int c1, int c2, Pose pos12) {
     const int rb1 = w.c_parent[c1], rb2 = w.c_parent[c2];
     int pf = w.p_pflags[s] & ~RP_PF_RECYCLE;
     const bool had_i = (pf & RP_PF_INTERSECTING) != 0;
-    const bool now_i = (rb1 == rb2 && rb1 >= 0) ? false : shapes_intersect(w.c_shape[c1], w.c_he[c1], w.c_shape[c2], w.c_he[c2], pos12);
+    const bool now_i = (rb1 == rb2 && rb1 >= 0) ? false : shapes_intersect<CONVEX>(w.c_shape[c1], w.c_he[c1], w.c_shape[c2], w.c_he[c2], pos12);
     w.p_npts[s] = 0; w.p_nsc[s] = 0;
     if (now_i != had_i) {
         pf ^= RP_PF_INTERSECTING;
@@ -641,12 +652,12 @@ __device__ __forceinline__ void sensor_pair_update(DevWorld &w, int s, int c1, i
 }
 
 // The full narrow-phase update of one pair (pair_update.rs:173-613).
-__device__ __forceinline__ void pair_full_update(DevWorld &w, int s, int c1, int c2, Pose pc1, Pose pc2, Pose pos12, float *np_lds) {
+template <bool CONVEX> __device__ __forceinline__ void pair_full_update(DevWorld &w, int s, int c1, int c2, Pose pc1, Pose pc2, Pose pos12, float *np_lds) {
     const float prediction = w.prm.prediction;
     int rb1 = w.c_parent[c1], rb2 = w.c_parent[c2];
     int sh1 = w.c_shape[c1], sh2 = w.c_shape[c2];
     float4 he1 = w.c_he[c1], he2 = w.c_he[c2];
-    if (w.has_sensors && pair_is_sensor(w, c1, c2)) { sensor_pair_update(w, s, c1, c2, pos12); return; }
+    if (w.has_sensors && pair_is_sensor(w, c1, c2)) { sensor_pair_update<CONVEX>(w, s, c1, c2, pos12); return; }
     int had = w.p_nsc[s] > 0;
     const bool no_contact = joints_disable_contacts(w, rb1, rb2); // pair_update.rs:191-201: clear_filtered_pair
 
@@ -660,7 +671,20 @@ __device__ __forceinline__ void pair_full_update(DevWorld &w, int s, int c1, int
     }
     int nold = m.n;
     // pair_update.rs:323-330 -> parry DefaultQueryDispatcher::contact_manifolds
-    if (sh1 == RP_SHAPE_HALFSPACE || sh2 == RP_SHAPE_HALFSPACE) { // the ball arms come before (HalfSpace, pfm) | (pfm, HalfSpace) in the dispatcher
+    bool convex_pair = false;
+    if constexpr (CONVEX) { // cylinders, cones (rp_convex.h): the dispatcher's order — ball arms, half-space arms, pfm_pfm
+        convex_pair = sh1 >= RP_SHAPE_CYLINDER || sh2 >= RP_SHAPE_CYLINDER;
+        if (convex_pair) {
+            const SmShape a = sm_shape_of(sh1, he1), b = sm_shape_of(sh2, he2);
+            if (sh2 == RP_SHAPE_BALL) manifold_sm_ball(pos12, a, he2.x, prediction, m, false);
+            else if (sh1 == RP_SHAPE_BALL) manifold_sm_ball(pose_inv(pos12), b, he1.x, prediction, m, true);
+            else if (sh1 == RP_SHAPE_HALFSPACE) manifold_halfspace_sm(pos12, v3(he1), b, prediction, m, false);
+            else if (sh2 == RP_SHAPE_HALFSPACE) manifold_halfspace_sm(pose_inv(pos12), v3(he2), a, prediction, m, true);
+            else manifold_pfm_pfm(pos12, a, b, prediction, m);
+        }
+    }
+    if (convex_pair) {}
+    else if (sh1 == RP_SHAPE_HALFSPACE || sh2 == RP_SHAPE_HALFSPACE) { // the ball arms come before (HalfSpace, pfm) | (pfm, HalfSpace) in the dispatcher
         if (sh1 == sh2) m.n = 0; // unsupported pair
         else if (sh1 == RP_SHAPE_HALFSPACE && sh2 == RP_SHAPE_BALL) manifold_halfspace_ball(pos12, v3(he1), he2.x, prediction, m, false);
         else if (sh2 == RP_SHAPE_HALFSPACE && sh1 == RP_SHAPE_BALL) manifold_halfspace_ball(pose_inv(pos12), v3(he2), he1.x, prediction, m, true);
@@ -844,7 +868,7 @@ __global__ void k_np_test(DevWorld w) {
         w.np_list[atomicAdd(&w.flags[FL_NP_COUNT], 1)] = s;
     }
 }
-__global__ void __launch_bounds__(NP_THREADS) k_np_update(DevWorld w) {
+template <bool CONVEX> __global__ void __launch_bounds__(NP_THREADS) k_np_update(DevWorld w) {
     __shared__ __align__(16) float np_lds[NP_THREADS * NP_LDS_DWORDS];
     if (collision_done(w)) return; // (rp_world.h "lean step graphs")
     int count = w.flags[FL_NP_COUNT];
@@ -857,14 +881,14 @@ __global__ void __launch_bounds__(NP_THREADS) k_np_update(DevWorld w) {
         pc1.r = q4(w.c_rot[c1]); pc1.t = v3(w.c_pos[c1]);
         pc2.r = q4(w.c_rot[c2]); pc2.t = v3(w.c_pos[c2]);
         Pose pos12 = pose_inv_mul(pc1, pc2);
-        pair_full_update(w, s, c1, c2, pc1, pc2, pos12, np_lds);
+        pair_full_update<CONVEX>(w, s, c1, c2, pc1, pc2, pos12, np_lds);
     }
 }
 
 // Fast graph, worlds with sensors: k_fast_front leaves the sensor pairs alone (they hold no recycle state), this pass re-tests them
 // from the collider poses k_fast_front just refreshed — what the narrow phase of a full step would have done for them.  Runs only
 // once no later kernel of the graph can still abort the step.
-__global__ void k_sensor_pass(DevWorld w) {
+template <bool CONVEX> __global__ void k_sensor_pass(DevWorld w) {
     if (w.flags[FL_FAST_ABORT]) return;
     int top = w.flags[FL_POOL_TOP];
     if (top > w.pool_cap) top = w.pool_cap;
@@ -878,13 +902,14 @@ __global__ void k_sensor_pass(DevWorld w) {
         Pose pc1, pc2;
         pc1.r = q4(w.c_rot[c1]); pc1.t = v3(w.c_pos[c1]);
         pc2.r = q4(w.c_rot[c2]); pc2.t = v3(w.c_pos[c2]);
-        sensor_pair_update(w, s, c1, c2, pose_inv_mul(pc1, pc2));
+        sensor_pair_update<CONVEX>(w, s, c1, c2, pose_inv_mul(pc1, pc2));
     }
 }
 void rp_launch_sensor_fast(const DevWorld &w, hipStream_t st) {
     if (!w.has_sensors || w.n_colliders == 0) return;
     int blocks = (w.pool_cap + 255) / 256; if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(k_sensor_pass, dim3(blocks), dim3(256), 0, st, w);
+    if (w.has_convex) hipLaunchKernelGGL(k_sensor_pass<true>, dim3(blocks), dim3(256), 0, st, w);
+    else hipLaunchKernelGGL(k_sensor_pass<false>, dim3(blocks), dim3(256), 0, st, w);
 }
 
 // the set of contact-disabling joints changed: every filtered pair is evaluated again by the next narrow phase
@@ -1085,7 +1110,9 @@ void rp_launch_narrowphase_part(const DevWorld &w, hipStream_t st, int part) {
     if (part == 2) {
         if (w.n_colliders == 0) return;
         hipLaunchKernelGGL(k_np_test, dim3(blocks), dim3(256), 0, st, w);
-        int nb = (w.pool_cap + NP_THREADS - 1) / NP_THREADS; hipLaunchKernelGGL(k_np_update, dim3(nb < 512 ? nb : 512), dim3(NP_THREADS), 0, st, w);
+        int nb = (w.pool_cap + NP_THREADS - 1) / NP_THREADS;
+        if (w.has_convex) hipLaunchKernelGGL(k_np_update<true>, dim3(nb < 512 ? nb : 512), dim3(NP_THREADS), 0, st, w);
+        else hipLaunchKernelGGL(k_np_update<false>, dim3(nb < 512 ? nb : 512), dim3(NP_THREADS), 0, st, w);
         return;
     }
     if (part != 1) {
@@ -1095,7 +1122,9 @@ void rp_launch_narrowphase_part(const DevWorld &w, hipStream_t st, int part) {
             // even when the queue is empty (measured: 341 -> 256 workgroups = 140 -> 130 us per full step on b3d_many_pyramids)
             // (sizing this grid from the recent queue lengths was measured: 5-10 us per full step, paid for with a ~10 ms re-capture of
             // the step graphs whenever the size changed — not kept)
-            { int nb = (w.pool_cap + NP_THREADS - 1) / NP_THREADS; hipLaunchKernelGGL(k_np_update, dim3(nb < 512 ? nb : 512), dim3(NP_THREADS), 0, st, w); } // 2 workgroups per CU (70 KB of LDS each)
+            { int nb = (w.pool_cap + NP_THREADS - 1) / NP_THREADS;
+              if (w.has_convex) hipLaunchKernelGGL(k_np_update<true>, dim3(nb < 512 ? nb : 512), dim3(NP_THREADS), 0, st, w); // (worlds with a cylinder / cone: GJK / EPA compiled in, a polytope per lane in scratch)
+              else hipLaunchKernelGGL(k_np_update<false>, dim3(nb < 512 ? nb : 512), dim3(NP_THREADS), 0, st, w); } // 2 workgroups per CU (70 KB of LDS each)
             hipLaunchKernelGGL(k_color_pairs, dim3(1), dim3(1024), 0, st, w);
         }
         rp_launch_wake(w, st, 1); // begin-touch wake-ups (contacts.rs:333-351)

@@ -79,7 +79,7 @@ RP_DEV bool collider_update_one(const DevWorld &w, int i) { // true = the fat AA
     w.c_rot[i] = f4(pos.r);
     float4 he = w.c_he[i];
     V3 h;
-    if (w.c_shape[i] == RP_SHAPE_CUBOID) {
+    if (w.c_shape[i] == RP_SHAPE_CUBOID || w.c_shape[i] >= RP_SHAPE_CYLINDER) { // (Cylinder / Cone::aabb = local_aabb().transform_by(pos): he = (r, hh, r))
         float m[3][3]; quat_to_mat(pos.r, m);
         h = v3(fabsf(m[0][0]) * he.x + fabsf(m[0][1]) * he.y + fabsf(m[0][2]) * he.z,
                fabsf(m[1][0]) * he.x + fabsf(m[1][1]) * he.y + fabsf(m[1][2]) * he.z,
@@ -137,7 +137,7 @@ RP_DEV bool collider_left_fat_aabb(const DevWorld &w, int i) {
     if (!finite) return true;
     float4 he = w.c_he[i];
     V3 h;
-    if (w.c_shape[i] == RP_SHAPE_CUBOID) {
+    if (w.c_shape[i] == RP_SHAPE_CUBOID || w.c_shape[i] >= RP_SHAPE_CYLINDER) { // (Cylinder / Cone::aabb = local_aabb().transform_by(pos): he = (r, hh, r))
         float m[3][3]; quat_to_mat(pos.r, m);
         h = v3(fabsf(m[0][0]) * he.x + fabsf(m[0][1]) * he.y + fabsf(m[0][2]) * he.z,
                fabsf(m[1][0]) * he.x + fabsf(m[1][1]) * he.y + fabsf(m[1][2]) * he.z,

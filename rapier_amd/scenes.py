@@ -17,6 +17,7 @@ import numpy as np
 BODY_DYNAMIC, BODY_FIXED, BODY_KINEMATIC_POSITION, BODY_KINEMATIC_VELOCITY = 0, 1, 2, 3  # RigidBodyType
 SHAPE_BALL, SHAPE_CUBOID, SHAPE_CAPSULE = 0, 1, 2  # capsule: half_extents = (half_height, radius, axis 0|1|2) = ColliderBuilder::capsule_x/y/z
 SHAPE_HALFSPACE = 3  # half_extents = the unit outward normal in the collider frame = ColliderBuilder::halfspace (fixed or kinematic parents only)
+SHAPE_CYLINDER, SHAPE_CONE = 4, 5  # half_extents = (half_height, radius, -) = ColliderBuilder::cylinder / cone (axis Y, a cone's apex at +Y)
 RULE_AVERAGE, RULE_MIN, RULE_MULTIPLY, RULE_MAX, RULE_CLAMPED_SUM, RULE_GEOMETRIC_MEAN = range(6)
 
 # Field-for-field mirrors of rp_body_desc / rp_collider_desc / rp_joint_desc / rp_integration_params.
@@ -779,4 +780,73 @@ def halfspace_scene(n_side: int = 4) -> Scene:
             k += 1
     ramp = s.add_body(body_type=BODY_FIXED, translation=(3.0, 0.0, 0.0))
     s.add_collider(ramp, shape=SHAPE_HALFSPACE, half_extents=(-0.6, 0.8, 0.0), friction=0.2)
+    return s
+
+
+def convex_clutter(n: int = 40, seed: int = 3, ground: str = "cuboid", compound: bool = True) -> Scene:
+    """Seeded test scene (not a reference scene) for the support-mapped shapes: cylinders and cones (ColliderBuilder::cylinder / cone,
+    collider.rs:770, :789) tumbling among cuboids, balls and capsules on a slab (`ground` = "cuboid"), a wide fixed disc ("cylinder") or
+    a half-space ("halfspace") inside four walls — every pair the parry dispatcher sends through contact_manifold_pfm_pfm, the
+    ball and the half-space arms, plus one compound body carrying a cylinder and a cone."""
+    rng = np.random.default_rng(seed)
+    s = Scene(name=f"convex_clutter_{n}_{seed}_{ground}", gravity=(0.0, -9.81, 0.0))
+    g = s.add_body(body_type=BODY_FIXED, translation=(0.0, -0.5, 0.0))
+    if ground == "cylinder":
+        s.add_collider(g, shape=SHAPE_CYLINDER, half_extents=(0.5, 9.0, 0.0))
+    elif ground == "halfspace":
+        s.add_collider(g, shape=SHAPE_HALFSPACE, half_extents=(0.0, 1.0, 0.0), translation=(0.0, 0.5, 0.0))
+    else:
+        s.add_collider(g, half_extents=(9.0, 0.5, 9.0))
+    for sx, sz, hx, hz in ((4.5, 0.0, 0.25, 4.5), (-4.5, 0.0, 0.25, 4.5), (0.0, 4.5, 4.5, 0.25), (0.0, -4.5, 4.5, 0.25)):
+        wb = s.add_body(body_type=BODY_FIXED, translation=(sx, 1.0, sz))
+        s.add_collider(wb, half_extents=(hx, 1.0, hz))
+    pillar = s.add_body(body_type=BODY_FIXED, translation=(0.0, 0.6, 0.0))
+    s.add_collider(pillar, shape=SHAPE_CONE, half_extents=(0.6, 0.8, 0.0))
+    side = int(np.ceil(n ** (1.0 / 3.0)))
+    k = 0
+    for iy in range(side * 2):
+        for ix in range(side):
+            for iz in range(side):
+                if k >= n:
+                    break
+                q = rng.normal(size=4).astype(np.float32)
+                q /= np.linalg.norm(q)
+                pos = (np.float32(1.4 * (ix - side / 2) + 0.1 * rng.random()), np.float32(1.8 + 1.5 * iy),
+                       np.float32(1.4 * (iz - side / 2) + 0.1 * rng.random()))
+                lv = (rng.normal(size=3) * 1.0).astype(np.float32)
+                av = (rng.normal(size=3) * 2.0).astype(np.float32)
+                b = s.add_body(translation=pos, rotation=tuple(q), linvel=tuple(lv), angvel=tuple(av),
+                               angular_damping=0.2 if k % 4 == 0 else 0.0)
+                kind = k % 6
+                fr = np.float32(0.3 + 0.5 * rng.random())
+                if kind in (0, 3):
+                    s.add_collider(b, shape=SHAPE_CYLINDER, half_extents=(np.float32(0.2 + 0.3 * rng.random()), np.float32(0.2 + 0.3 * rng.random()), 0.0),
+                                   friction=fr, density=np.float32(0.5 + 1.5 * rng.random()))
+                elif kind == 1:
+                    s.add_collider(b, shape=SHAPE_CONE, half_extents=(np.float32(0.3 + 0.3 * rng.random()), np.float32(0.25 + 0.25 * rng.random()), 0.0),
+                                   friction=fr, restitution=0.2 if k % 2 == 0 else 0.0)
+                elif kind == 2:
+                    s.add_collider(b, half_extents=tuple((0.2 + 0.3 * rng.random(size=3)).astype(np.float32)), friction=fr)
+                elif kind == 4:
+                    s.add_collider(b, shape=SHAPE_BALL, half_extents=(np.float32(0.25 + 0.2 * rng.random()), 0, 0), friction=fr)
+                else:
+                    s.add_collider(b, shape=SHAPE_CAPSULE, half_extents=(np.float32(0.3 + 0.2 * rng.random()), np.float32(0.15 + 0.15 * rng.random()), float(k % 3)), friction=fr)
+                k += 1
+    if compound:  # a mallet: cylinder handle + cone head, off-centre
+        b = s.add_body(translation=(2.5, 3.0, -2.5), angvel=(0.5, 1.0, 0.0))
+        s.add_collider(b, shape=SHAPE_CYLINDER, half_extents=(0.6, 0.12, 0.0), density=0.8)
+        s.add_collider(b, shape=SHAPE_CONE, half_extents=(0.3, 0.35, 0.0), translation=(0.0, 0.85, 0.0), rotation=(0.0, 0.0, 0.70710678, 0.70710678), density=2.0)
+    return s
+
+
+def issue_810_disc() -> Scene:
+    """crates/rapier3d/tests/issue_810_cubes_thin_cylinder_tunnel.rs:61-95: twenty 0.1 m cubes dropped from y = 20 onto a thin fixed
+    cylinder disc (radius 10, half height 0.05), spread over it on a golden-angle spiral"""
+    s = Scene(name="issue_810", gravity=(0.0, -9.81, 0.0))
+    disc = s.add_body(body_type=BODY_FIXED, translation=(0.0, -2.0, 0.0))
+    s.add_collider(disc, shape=SHAPE_CYLINDER, half_extents=(0.05, 10.0, 0.0))
+    for k in range(20):
+        r, a = np.float32(k) * np.float32(0.45), np.float32(k) * np.float32(2.399)
+        b = s.add_body(translation=(float(r * np.cos(a)), 20.0, float(r * np.sin(a))))
+        s.add_collider(b, half_extents=(0.05, 0.05, 0.05))
     return s

@@ -41,7 +41,8 @@ def test_shape_and_body_enums_agree_across_header_python_and_oracle():
         return {m.group(1): int(m.group(2)) for m in re.finditer(prefix + r"_([A-Z_]+)\s*=\s*(\d+)", txt)}
     hdr = enum_values(os.path.join(ROOT, "include", "rapier_hip.h"), "RP_SHAPE")
     ora = enum_values(os.path.join(ROOT, "oracle", "rapier_oracle.h"), "RO_SHAPE")
-    assert hdr == ora == {"BALL": S.SHAPE_BALL, "CUBOID": S.SHAPE_CUBOID, "CAPSULE": S.SHAPE_CAPSULE, "HALFSPACE": S.SHAPE_HALFSPACE}
+    assert hdr == ora == {"BALL": S.SHAPE_BALL, "CUBOID": S.SHAPE_CUBOID, "CAPSULE": S.SHAPE_CAPSULE, "HALFSPACE": S.SHAPE_HALFSPACE,
+                          "CYLINDER": S.SHAPE_CYLINDER, "CONE": S.SHAPE_CONE}
     hb = enum_values(os.path.join(ROOT, "include", "rapier_hip.h"), "RP_BODY")
     ob = enum_values(os.path.join(ROOT, "oracle", "rapier_oracle.h"), "RO_BODY")
     assert hb == ob and hb["DYNAMIC"] == S.BODY_DYNAMIC and hb["FIXED"] == S.BODY_FIXED and hb["KINEMATIC_POSITION"] == S.BODY_KINEMATIC_POSITION
