@@ -248,6 +248,7 @@ __device__ void bp_insert_pair(DevWorld &w, int c1, int c2, bool incremental = f
         w.p_c1[slot] = c1; w.p_c2[slot] = c2; w.p_rb[slot] = make_int2(w.c_parent[c1], w.c_parent[c2]);
         w.p_color[slot] = RP_COLOR_UNCOLORED; w.p_nsc[slot] = 0; w.p_npts[slot] = 0; w.p_pflags[slot] = 0;
         w.p_reldom[slot] = 0; w.p_colorb[slot] = make_int2(-1, -1); w.p_conspos[slot] = -1; w.p_hint_seq[slot] = 0;
+        w.p_ln1[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); w.p_ln2[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // (a recycled slot: the last normal is GJK's first guess, rp_convex.h)
         // the lists of an LDS island also hold its pairs WITHOUT solver contacts (the fused step recycle-tests them): a new pair
         // changes the layout only when one of its bodies lives in such an island — not when both sit on the global path (the
         // creeping 20,100-body island of b3d_large_pyramid gains and loses near-miss pairs every step)

@@ -712,7 +712,7 @@ template <bool CONVEX> __device__ __forceinline__ void pair_full_update(DevWorld
         PT(w.pt_lp2f, k, s) = f4(m.lp2[k], __uint_as_float(m.fid[k]));
     }
     w.p_npts[s] = m.n;
-    w.p_ln1[s] = f4(m.ln1, 0.0f); w.p_ln2[s] = f4(m.ln2, 0.0f);
+    if (!no_contact) { w.p_ln1[s] = f4(m.ln1, 0.0f); w.p_ln2[s] = f4(m.ln2, 0.0f); } // (a filtered pair never reaches the generator in the reference: its cached normal stays)
 
     float4 mat1 = w.c_mat[c1], mat2 = w.c_mat[c2];
     int2 ru1 = w.c_rules[c1], ru2 = w.c_rules[c2];
