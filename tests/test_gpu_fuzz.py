@@ -21,14 +21,21 @@ def _rand_quat(rng):
     return tuple(float(x) for x in q)
 
 
+_CONVEX = [False]   # set by _scene(convex=True): cylinders and cones join the draw (the other variants keep their random streams)
+
+
 def _rand_collider(rng, scale=1.0):
-    kind = rng.integers(0, 3)
+    kind = rng.integers(0, 5 if _CONVEX[0] else 3)
     kw = dict(density=float(rng.uniform(0.5, 3.0)), friction=float(rng.choice([0.0, 0.3, 0.5, 1.0])),
               restitution=float(rng.choice([0.0, 0.0, 0.3, 0.8])), friction_rule=int(rng.integers(0, 6)), restitution_rule=int(rng.integers(0, 6)))
     if kind == 0:
         return dict(shape=S.SHAPE_BALL, half_extents=(float(rng.uniform(0.2, 0.5)) * scale, 0.0, 0.0), **kw)
     if kind == 1:
         return dict(shape=S.SHAPE_CUBOID, half_extents=tuple(float(x) * scale for x in rng.uniform(0.15, 0.6, size=3)), **kw)
+    if kind == 3:
+        return dict(shape=S.SHAPE_CYLINDER, half_extents=(float(rng.uniform(0.15, 0.5)) * scale, float(rng.uniform(0.15, 0.5)) * scale, 0.0), **kw)
+    if kind == 4:
+        return dict(shape=S.SHAPE_CONE, half_extents=(float(rng.uniform(0.2, 0.5)) * scale, float(rng.uniform(0.2, 0.45)) * scale, 0.0), **kw)
     return dict(shape=S.SHAPE_CAPSULE, half_extents=(float(rng.uniform(0.2, 0.6)) * scale, float(rng.uniform(0.15, 0.35)) * scale, float(rng.integers(0, 3))), **kw)
 
 
@@ -66,7 +73,8 @@ def _rand_joint(rng, sc, b1, b2, p1, p2):
     return sc.add_joint(b1, b2, a1, a2, locked_axes=locked, contacts_enabled=int(rng.random() < 0.7), basis1=basis, basis2=basis, limits=limits, motors=motors)
 
 
-def _scene(seed, n=40, spread=3.5, per_layer=4, calm=False):
+def _scene(seed, n=40, spread=3.5, per_layer=4, calm=False, convex=False):
+    _CONVEX[0] = bool(convex)
     rng = np.random.default_rng(seed)
     sc = S.Scene(name=f"fuzz{seed}", gravity=(0.0, -9.81, 0.0))
     sc.params["friction_model"] = S.FRICTION_COULOMB if seed % 4 == 3 else S.FRICTION_SIMPLIFIED
@@ -286,6 +294,14 @@ def _run(seed, steps=240, walls=False, params=False, world=None, extras=False, s
     alive = list(range(nb0))
     jb = {j: (int(sc.joints[j]["body1"]), int(sc.joints[j]["body2"])) for j in range(len(sc.joints))}   # live joints -> their bodies
     col_parent = list(sc.collider_parents); ncol = len(col_parent); removed_cols = set()
+
+    def note_collider(idx, parent):   # a new collider takes the slot removed last (arena reuse) or a fresh row
+        nonlocal ncol
+        if idx < ncol:
+            col_parent[idx] = parent; removed_cols.discard(idx)
+        else:
+            assert idx == ncol
+            col_parent.append(parent); ncol += 1
     log = []
     if extras:
         for b in dyn:
@@ -315,16 +331,17 @@ def _run(seed, steps=240, walls=False, params=False, world=None, extras=False, s
                 g.wake_up([b]); o.wake_up(b)
             elif act == 4 and len(live_dyn) > 10:
                 g.remove_body(b); o.remove_body(b); alive.remove(b)
+                removed_cols.update(c for c in range(ncol) if col_parent[c] == b)   # its colliders go with it
                 jb = {j: bb for j, bb in jb.items() if b not in bb}       # RigidBodySet::remove takes the attached joints along
             elif act == 5:
                 body = S.body_desc(translation=(float(rng.uniform(-2, 2)), float(rng.uniform(4, 7)), float(rng.uniform(-2, 2))), rotation=_rand_quat(rng), can_sleep=1)
                 col = S.collider_desc(**_rand_collider(rng))
-                hb = g.insert_body(body); g.insert_collider(col, hb)
+                hb = g.insert_body(body); hc = g.insert_collider(col, hb)
                 ob = lib().ro_add_body(o._w, np.array([body], S.BODY_DTYPE).ctypes.data); o.n += 1
-                lib().ro_add_collider(o._w, np.array([col], S.COLLIDER_DTYPE).ctypes.data, ob)
-                assert int(hb) & 0xFFFFFFFF == ob
+                oc = lib().ro_add_collider(o._w, np.array([col], S.COLLIDER_DTYPE).ctypes.data, ob)
+                assert int(hb) & 0xFFFFFFFF == ob and int(hc) & 0xFFFFFFFF == oc
                 alive.append(ob); dyn.append(ob)
-                col_parent.append(ob); ncol += 1
+                note_collider(oc, ob)
             elif act == 6 and jb:
                 j = int(rng.choice(sorted(jb)))
                 g.remove_impulse_joint(j); o.remove_joint(j); del jb[j]
@@ -355,7 +372,7 @@ def _run(seed, steps=240, walls=False, params=False, world=None, extras=False, s
                 hc = g.insert_collider(col, b)
                 oc = lib().ro_add_collider(o._w, np.array([col], S.COLLIDER_DTYPE).ctypes.data, b)
                 assert int(hc) & 0xFFFFFFFF == oc
-                col_parent.append(b); ncol += 1
+                note_collider(oc, b)
             elif act == 12:
                 tqi = rng.uniform(-0.5, 0.5, size=3).astype(np.float32)
                 g.apply_impulse([b], torque_impulse=[tqi]); o.apply_impulse(b, torque_impulse=tqi)
@@ -410,3 +427,22 @@ def _run(seed, steps=240, walls=False, params=False, world=None, extras=False, s
                 raise
     c = g.counters()
     assert c["overflow_flags"] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [40, 41, 42, 43, 2011])
+def test_fuzz_cylinders_and_cones_bit_exact(seed):
+    """the same scenes and actions with cylinders and cones in the draw (rp_convex.h: GJK / EPA manifolds under joints, both friction
+    models, events, sleeping, compound bodies, removals and insertions; seed 43 runs the Coulomb model)"""
+    try:
+        _run(seed, steps=200, params=seed >= 2000, convex=True)
+    finally:
+        _CONVEX[0] = False
+
+
+@pytest.mark.parametrize("seed", [40, 43])
+def test_fuzz_cylinders_and_cones_on_the_oracle_twin(seed):
+    try:
+        _run(seed, steps=120, world=OracleTwin, convex=True)
+    finally:
+        _CONVEX[0] = False
