@@ -70,7 +70,9 @@ enum { RP_SHAPE_BALL = 0, RP_SHAPE_CUBOID = 1,
        RP_SHAPE_CYLINDER = 4 /* ColliderBuilder::cylinder(half_height, radius) (collider.rs:770): half_extents = (half_height, radius, -),
                                 axis Y */,
        RP_SHAPE_CONE = 5 /* ColliderBuilder::cone(half_height, radius) (collider.rs:789): half_extents = (half_height, radius, -), base at
-                            -half_height, apex at +half_height; its centre of mass sits a quarter of the height above the base */ };
+                            -half_height, apex at +half_height; its centre of mass sits a quarter of the height above the base */,
+       RP_SHAPE_CONVEX_POLYHEDRON = 6 /* ColliderBuilder::convex_mesh / convex_hull (collider.rs:1039, :1070): half_extents[0] = the id
+                                         rp_convex_polyhedron_create returned (a whole number stored as a float) */ };
 enum { RP_RULE_AVERAGE = 0, RP_RULE_MIN, RP_RULE_MULTIPLY, RP_RULE_MAX, RP_RULE_CLAMPED_SUM, RP_RULE_GEOMETRIC_MEAN };
 
 /* RigidBodyBuilder — /root/reference/src/dynamics/rigid_body.rs:1560-1900 */
@@ -211,6 +213,20 @@ int32_t rp_bodies_insert(rp_world *w, int32_t n, const rp_body_desc *descs, uint
  * shapes.  A body may carry any number of colliders at any pos_wrt_parent (compound bodies): its mass, centre of mass and
  * principal inertia are the sum of the colliders' MassProperties (rigid_body_components.rs:421-489). */
 int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider_desc *descs, const uint64_t *parents, uint64_t *handles_out);
+/* SharedShape::convex_mesh(points, indices) — or SharedShape::convex_hull(points) when `indices` is NULL (ColliderBuilder::convex_mesh /
+ * convex_hull, /root/reference/src/geometry/collider.rs:1039, :1070): registers a convex polyhedron with the world and hands out the id
+ * colliders refer to (shape = RP_SHAPE_CONVEX_POLYHEDRON, half_extents[0] = id; any number of colliders may share one polyhedron).
+ * `indices` = n_triangles x 3 vertex indices of a closed triangle mesh wound counter-clockwise seen from outside; triangles with equal
+ * normals become one polygonal face.  RP_ERR_INVALID where the reference's builders return None (no volume, not closed) and for more
+ * than 256 hull vertices.  The polyhedron's centre of mass and inertia tensor follow MassProperties::from_convex_polyhedron. */
+int32_t rp_convex_polyhedron_create(rp_world *w, int32_t n_points, const float *points_xyz, int32_t n_triangles, const uint32_t *indices, int32_t *id_out);
+/* ConvexPolyhedron::points / faces / ... of a registered polyhedron as the library holds it (canonical form: DESIGN.md §4.4).
+ * counts = {vertices, faces, vertex-loop entries, edges}; then, each optional (NULL = skip): the vertices recentred on the centre of
+ * their bounding box, the unit face normals, per face the first entry and the length of its counter-clockwise vertex loop, the
+ * loops' vertices and edges, props = {box centre xyz, box half extents xyz, max |vertex|, bounding-sphere centre xyz and radius,
+ * volume, centre of mass xyz, inertia tensor about it at unit density: xx, yy, zz, xy, xz}. */
+int32_t rp_convex_polyhedron_read(const rp_world *w, int32_t id, int32_t counts[4], float *points_xyz, float *face_normals, int32_t *face_first, int32_t *face_count,
+                                  int32_t *loop_vertex, int32_t *loop_edge, float props[20]);
 /* ImpulseJointSet::insert ×n (impulse_joint_set.rs).  Device path scope: locked axes only — any JointAxesMask of locked
  * linear / angular axes (spherical 0x07, revolute 0x37, prismatic without limits 0x3e, fixed 0x3f; the free axis is the
  * local frame's X axis as in RevoluteJointBuilder / PrismaticJointBuilder); contacts_enabled = 0 filters the contact pairs between

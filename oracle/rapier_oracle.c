@@ -89,6 +89,7 @@ typedef struct { v3 mins, maxs; } Aabb;
 typedef struct {
     int parent; pose pos_wrt_parent, pos;
     int shape; v3 he; float radius; int axis; /* capsule: he.x = half height, radius, axis */
+    const RoPolyhedron *poly; /* RO_SHAPE_CONVEX_POLYHEDRON: the registered polyhedron (recentred; the centre is folded into pos_wrt_parent) */
     int sensor;         /* ColliderBuilder::sensor(true): intersection events only, no contacts (oracle only so far) */
     float density, friction, restitution; int friction_rule, restitution_rule;
     uint32_t memberships, filter;
@@ -189,6 +190,7 @@ struct ro_world {
     ro_params params; v3 gravity;
     Body *bodies; int nbodies, cap_bodies;
     Collider *colliders; int ncolliders, cap_colliders;
+    RoPolyhedron **polys; int npolys; /* ro_add_convex_polyhedron */
     Pair *pairs; int npairs, cap_pairs;
     /* open-addressing map (c1,c2) -> pair index */
     int64_t *map_keys; int *map_vals; int map_cap;
@@ -299,6 +301,8 @@ ro_world *ro_world_new(const ro_params *params, const float gravity[3]) {
 void ro_set_params(ro_world *w, const ro_params *params) { w->params = *params; }
 void ro_world_free(ro_world *w) {
     if (!w) return;
+    for (int i = 0; i < w->npolys; ++i) { ro_poly_free(w->polys[i]); free(w->polys[i]); }
+    free(w->polys);
     free(w->bodies); free(w->colliders); free(w->pairs); free(w->map_keys); free(w->map_vals);
     free(w->body_free); free(w->body_gen); free(w->coll_free); free(w->coll_gen);
     free(w->color_masks); free(w->vels); free(w->incr); free(w->poses); free(w->gyro); free(w->flags);
@@ -386,9 +390,19 @@ static void update_world_mass_properties(Body *b) {
 
 /* parry Shape::mass_properties (cuboid / ball / capsule), SURVEY Appendix C.  `frame` = principal inertia local frame of the
  * shape (identity except for capsules along X / Z: MassProperties::from_capsule rotates Y onto the segment direction). */
+static void ro_diagonalise(float a[3][3], float pi[3], float frame[4]);
 static void shape_mass_props(const Collider *c, float density, float *mass, v3 *principal_inertia, float frame[4], float com[3]) {
     frame[0] = 0.0f; frame[1] = 0.0f; frame[2] = 0.0f; frame[3] = 1.0f;
     com[0] = com[1] = com[2] = 0.0f;
+    if (c->shape == RO_SHAPE_CONVEX_POLYHEDRON) { /* MassProperties::from_convex_polyhedron -> with_inertia_matrix(com, volume * density, tensor * density) */
+        const RoPolyhedron *P = c->poly;
+        float a[3][3], pi[3];
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) a[i][j] = P->inertia[i][j] * density;
+        ro_diagonalise(a, pi, frame);
+        *mass = P->volume * density; *principal_inertia = V3(pi[0], pi[1], pi[2]);
+        com[0] = P->com.x - P->centre.x; com[1] = P->com.y - P->centre.y; com[2] = P->com.z - P->centre.z; /* (in the recentred collider frame) */
+        return;
+    }
     if (c->shape == RO_SHAPE_CYLINDER) { /* MassProperties::from_cylinder: cylinder_y_volume_unit_inertia */
         float hh = c->he.y, r = c->radius;
         float vol = hh * r * r * 3.14159265358979323846f * 2.0f;
@@ -445,6 +459,7 @@ static float shape_bounding_radius(const Collider *c) {
     if (c->shape == RO_SHAPE_CAPSULE) return c->he.x + c->radius;
     if (c->shape == RO_SHAPE_HALFSPACE) return FLT_MAX;
     if (c->shape == RO_SHAPE_CYLINDER || c->shape == RO_SHAPE_CONE) return sqrtf(c->radius * c->radius + c->he.y * c->he.y);
+    if (c->shape == RO_SHAPE_CONVEX_POLYHEDRON) return c->poly->origin_radius; /* about the collider origin (the CCD pre-filter); max_extent uses the point cloud's own sphere */
     return c->radius;
 }
 
@@ -612,7 +627,11 @@ static void recompute_mass_properties(ro_world *w, Body *b) {
         const Collider *c = &w->colliders[i];
         if (c->parent != body || !collider_enabled(c)) continue;
         float radius = shape_bounding_radius(c);
-        float extent = vlen(vsub(c->pos_wrt_parent.t, b->local_com)) + radius;
+        v3 centre = c->pos_wrt_parent.t;
+        if (c->shape == RO_SHAPE_CONVEX_POLYHEDRON) { /* point_cloud_bounding_sphere: centred on the mean of the points */
+            centre = pose_tp(c->pos_wrt_parent, vsub(c->poly->sphere_centre, c->poly->centre)); radius = c->poly->sphere_radius;
+        }
+        float extent = vlen(vsub(centre, b->local_com)) + radius;
         b->max_extent = ro_maxf(b->max_extent, extent);
     }
     /* RigidBodyCcd::ccd_thickness (rigid_body_components.rs:1227): the thinnest attached shape (Shape::ccd_thickness: ball radius,
@@ -701,8 +720,10 @@ int32_t ro_add_collider(ro_world *w, const ro_collider_desc *d, int32_t parent) 
     c->radius = d->half_extents[0];
     if (c->shape == RO_SHAPE_CAPSULE) { c->radius = d->half_extents[1]; c->axis = (int)d->half_extents[2]; if (c->axis < 0 || c->axis > 2) c->axis = 1; }
     if (c->shape == RO_SHAPE_CYLINDER || c->shape == RO_SHAPE_CONE) { c->radius = d->half_extents[1]; c->he = V3(c->radius, d->half_extents[0], c->radius); c->axis = 1; } /* he = the local AABB's half extents */
+    if (c->shape == RO_SHAPE_CONVEX_POLYHEDRON) { c->poly = w->polys[(int)d->half_extents[0]]; c->he = c->poly->half; c->radius = 0.0f; c->axis = 1; }
     c->pos_wrt_parent.t = V3(d->translation[0], d->translation[1], d->translation[2]);
     c->pos_wrt_parent.r = qnormalize(Q(d->rotation[0], d->rotation[1], d->rotation[2], d->rotation[3]));
+    if (c->shape == RO_SHAPE_CONVEX_POLYHEDRON) c->pos_wrt_parent.t = vadd(qrot(c->pos_wrt_parent.r, c->poly->centre), c->pos_wrt_parent.t); /* the recentring offset rides in the pose */
     c->density = d->density; c->friction = d->friction; c->restitution = d->restitution;
     c->friction_rule = d->friction_rule; c->restitution_rule = d->restitution_rule;
     c->memberships = d->collision_memberships; c->filter = d->collision_filter;
@@ -836,7 +857,7 @@ void ro_read_sleeping(const ro_world *w, int32_t *sleeping) {
  * sort-and-sweep over fat AABBs, re-run only when some fat AABB changed. */
 static Aabb collider_collision_aabb(const Collider *c, float loosen) {
     Aabb a;
-    if (c->shape == RO_SHAPE_CUBOID || c->shape == RO_SHAPE_CYLINDER || c->shape == RO_SHAPE_CONE) { /* Cylinder / Cone::aabb = local_aabb().transform_by(pos) */
+    if (c->shape == RO_SHAPE_CUBOID || c->shape >= RO_SHAPE_CYLINDER) { /* Cylinder / Cone::aabb = local_aabb().transform_by(pos); a polyhedron's local box likewise (ro_polyhedron.h) */
         float m[3][3]; quat_to_mat(c->pos.r, m);
         v3 h = V3(fabsf(m[0][0]) * c->he.x + fabsf(m[0][1]) * c->he.y + fabsf(m[0][2]) * c->he.z,
                   fabsf(m[1][0]) * c->he.x + fabsf(m[1][1]) * c->he.y + fabsf(m[1][2]) * c->he.z,
@@ -1115,7 +1136,7 @@ static float relative_pose_drift(pose base, pose cur, float max_extent) {
     return trans + chord;
 }
 static float collider_origin_radius(const Collider *c) {
-    if (c->shape == RO_SHAPE_CUBOID || c->shape == RO_SHAPE_CYLINDER || c->shape == RO_SHAPE_CONE) return vlen(c->he); /* max(|mins|,|maxs|) of the local AABB */
+    if (c->shape == RO_SHAPE_CUBOID || c->shape >= RO_SHAPE_CYLINDER) return vlen(c->he); /* max(|mins|,|maxs|) of the local AABB */
     if (c->shape == RO_SHAPE_CAPSULE) { v3 h = V3(c->radius, c->radius, c->radius); vset(&h, c->axis, c->he.x + c->radius); return vlen(h); }
     if (c->shape == RO_SHAPE_HALFSPACE) return INFINITY; /* |(MAX/2, MAX/2, MAX/2)| overflows: a pair with a half-space never recycles */
     return vlen(V3(c->radius, c->radius, c->radius));
@@ -1185,7 +1206,7 @@ static int joints_disable_contacts(const ro_world *w, int b1, int b2) {
  * separating axis among 3 + 3 face normals and 9 edge cross products), a ball against a convex shape (solid point projection),
  * capsule-capsule (segment distance).  Cuboid-capsule goes through GJK in parry; here the distance from the capsule's segment to
  * the box is minimised over the segment parameter (a convex function: ternary search, 48 fixed iterations). */
-static SmShape sm_shape_of(const Collider *c) { SmShape s; s.shape = c->shape; s.he = c->he; s.radius = c->radius; s.axis = c->axis; return s; }
+static SmShape sm_shape_of(const Collider *c) { SmShape s; s.shape = c->shape; s.he = c->he; s.radius = c->radius; s.axis = c->axis; s.poly = c->poly; return s; }
 static float point_box_dist2(v3 p, v3 he) {
     float dx = ro_maxf(fabsf(p.x) - he.x, 0.0f), dy = ro_maxf(fabsf(p.y) - he.y, 0.0f), dz = ro_maxf(fabsf(p.z) - he.z, 0.0f);
     return dx * dx + dy * dy + dz * dz;
@@ -3295,7 +3316,7 @@ void ro_read_joints(const ro_world *w, int32_t *color, float *impulses3) {
 /* ---- hooks for tests/test_convex_oracle.py: the support-mapped queries of ro_convex.h on two shapes given like collider descriptors
  * (shape, half_extents) and the pose of shape 2 in the frame of shape 1 (translation xyz, rotation xyzw) ---- */
 static SmShape kat_shape(int32_t shape, const float he[3]) {
-    SmShape s; s.shape = shape; s.he = V3(he[0], he[1], he[2]); s.radius = he[0]; s.axis = 1;
+    SmShape s; s.shape = shape; s.he = V3(he[0], he[1], he[2]); s.radius = he[0]; s.axis = 1; s.poly = NULL;
     if (shape == RO_SHAPE_CAPSULE) { s.radius = he[1]; s.axis = (int)he[2]; }
     if (shape == RO_SHAPE_CYLINDER || shape == RO_SHAPE_CONE) { s.radius = he[1]; s.he = V3(he[1], he[0], he[1]); }
     return s;
@@ -3326,4 +3347,29 @@ void ro_kat_convex_project(int32_t sh, const float he[3], const float pt[3], flo
     SmShape a = kat_shape(sh, he); int inside;
     v3 q = sm_project_point(&a, V3(pt[0], pt[1], pt[2]), &inside);
     out[0] = q.x; out[1] = q.y; out[2] = q.z; out[3] = (float)inside;
+}
+
+/* ---- convex polyhedra (ro_polyhedron.h) ---- */
+int32_t ro_add_convex_polyhedron(ro_world *w, int32_t n_points, const float *points_xyz, int32_t n_triangles, const uint32_t *indices) {
+    RoPolyhedron *P = (RoPolyhedron *)malloc(sizeof(RoPolyhedron));
+    if (ro_poly_build(P, n_points, points_xyz, n_triangles, indices) != 0) { free(P); return -1; }
+    w->polys = (RoPolyhedron **)realloc(w->polys, sizeof(RoPolyhedron *) * (w->npolys + 1));
+    w->polys[w->npolys] = P;
+    return w->npolys++;
+}
+void ro_read_convex_polyhedron(const ro_world *w, int32_t id, int32_t counts[4], float *points_xyz, float *face_normals, int32_t *face_first, int32_t *face_count,
+                               int32_t *loop_vertex, int32_t *loop_edge, float props[20]) {
+    const RoPolyhedron *P = w->polys[id];
+    counts[0] = P->nv; counts[1] = P->nf; counts[2] = P->nloop; counts[3] = P->ne;
+    if (points_xyz) for (int i = 0; i < P->nv; ++i) { points_xyz[3 * i] = P->pts[i].x; points_xyz[3 * i + 1] = P->pts[i].y; points_xyz[3 * i + 2] = P->pts[i].z; }
+    if (face_normals) for (int i = 0; i < P->nf; ++i) { face_normals[3 * i] = P->fnormal[i].x; face_normals[3 * i + 1] = P->fnormal[i].y; face_normals[3 * i + 2] = P->fnormal[i].z; }
+    if (face_first) for (int i = 0; i < P->nf; ++i) { face_first[i] = P->ffirst[i]; face_count[i] = P->fcount[i]; }
+    if (loop_vertex) for (int i = 0; i < P->nloop; ++i) { loop_vertex[i] = P->loop_v[i]; loop_edge[i] = P->loop_e[i]; }
+    if (props) {
+        float *o = props;
+        o[0] = P->centre.x; o[1] = P->centre.y; o[2] = P->centre.z; o[3] = P->half.x; o[4] = P->half.y; o[5] = P->half.z; o[6] = P->origin_radius;
+        o[7] = P->sphere_centre.x; o[8] = P->sphere_centre.y; o[9] = P->sphere_centre.z; o[10] = P->sphere_radius;
+        o[11] = P->volume; o[12] = P->com.x; o[13] = P->com.y; o[14] = P->com.z;
+        o[15] = P->inertia[0][0]; o[16] = P->inertia[1][1]; o[17] = P->inertia[2][2]; o[18] = P->inertia[0][1]; o[19] = P->inertia[0][2];
+    }
 }

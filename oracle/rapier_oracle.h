@@ -54,7 +54,8 @@ enum { RO_FRICTION_SIMPLIFIED = 0, RO_FRICTION_COULOMB = 1 }; /* integration_par
 enum { RO_SHAPE_BALL = 0, RO_SHAPE_CUBOID = 1, RO_SHAPE_CAPSULE = 2 /* half_extents = (half_height, radius, axis 0|1|2): ColliderBuilder::capsule_x/y/z */,
        RO_SHAPE_HALFSPACE = 3 /* half_extents = the unit outward normal in the collider's frame: ColliderBuilder::halfspace */,
        RO_SHAPE_CYLINDER = 4 /* half_extents = (half_height, radius, -): ColliderBuilder::cylinder (collider.rs:770), axis Y */,
-       RO_SHAPE_CONE = 5 /* half_extents = (half_height, radius, -): ColliderBuilder::cone (collider.rs:789), apex at +Y */ };
+       RO_SHAPE_CONE = 5 /* half_extents = (half_height, radius, -): ColliderBuilder::cone (collider.rs:789), apex at +Y */,
+       RO_SHAPE_CONVEX_POLYHEDRON = 6 /* half_extents[0] = the id ro_add_convex_polyhedron returned: ColliderBuilder::convex_mesh / convex_hull (collider.rs:1039, :1070) */ };
 /* CoefficientCombineRule — coefficient_combine_rule.rs:37-57 */
 enum { RO_RULE_AVERAGE = 0, RO_RULE_MIN = 1, RO_RULE_MULTIPLY = 2, RO_RULE_MAX = 3,
        RO_RULE_CLAMPED_SUM = 4, RO_RULE_GEOMETRIC_MEAN = 5 };
@@ -112,6 +113,10 @@ void ro_set_params(ro_world *w, const ro_params *params);
 void ro_world_free(ro_world *w);
 int32_t ro_add_body(ro_world *w, const ro_body_desc *d);
 int32_t ro_add_collider(ro_world *w, const ro_collider_desc *d, int32_t parent_body);
+/* SharedShape::convex_mesh(points, indices): registers a convex polyhedron (closed, outward-wound triangle mesh); returns its id or -1 */
+int32_t ro_add_convex_polyhedron(ro_world *w, int32_t n_points, const float *points_xyz, int32_t n_triangles, const uint32_t *indices);
+/* the canonical form it was given (ro_polyhedron.h): counts = {vertices, faces, loop entries, edges}; then the arrays (NULL = skip) */
+void ro_read_convex_polyhedron(const ro_world *w, int32_t id, int32_t counts[4], float *points_xyz, float *face_normals, int32_t *face_first, int32_t *face_count, int32_t *loop_vertex, int32_t *loop_edge, float props[20]);
 int32_t ro_add_joint(ro_world *w, const ro_joint_desc *d);
 int32_t ro_remove_body(ro_world *w, int32_t body);
 /* Index::generation of the occupant of an arena slot (data/arena.rs:58-90): the arena's removal count when it was inserted */

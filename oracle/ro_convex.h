@@ -24,10 +24,11 @@
 #ifndef RO_CONVEX_H
 #define RO_CONVEX_H
 #include "ro_shapes.h"
+#include "ro_polyhedron.h"
 
 /* he: cuboid half extents | capsule: he.x = half height, radius, axis | ball: radius | cylinder / cone (axis Y): he = (radius,
  * half_height, radius) — the half extents of the local AABB — and radius */
-typedef struct { int shape; v3 he; float radius; int axis; } SmShape;
+typedef struct { int shape; v3 he; float radius; int axis; const RoPolyhedron *poly; /* RO_SHAPE_CONVEX_POLYHEDRON: he = the local AABB's half extents */ } SmShape;
 
 #define RO_GJK_EPS_TOL 1.1920929e-6f          /* gjk::eps_tol() = 10 * f32::EPSILON */
 #define RO_EPA_EPS_TOL 1.1920929e-5f          /* 100 * f32::EPSILON */
@@ -61,6 +62,12 @@ static inline v3 sm_support(const SmShape *s, v3 d) {
         v3 r = V3(d.x / n * s->radius, -s->he.y, d.z / n * s->radius);
         if (vdot(d, r) < d.y * s->he.y) r = V3(0.0f, s->he.y, 0.0f);
         return r;
+    }
+    if (s->shape == RO_SHAPE_CONVEX_POLYHEDRON) { /* utils::point_cloud_support_point: the first vertex with the largest dot product */
+        const RoPolyhedron *P = s->poly;
+        int best = 0; float bd = vdot(P->pts[0], d);
+        for (int i = 1; i < P->nv; ++i) { float x = vdot(P->pts[i], d); if (x > bd) { bd = x; best = i; } }
+        return P->pts[best];
     }
     return V3(0, 0, 0); /* ball: its centre */
 }
@@ -430,6 +437,18 @@ static inline void sm_support_feature(const SmShape *s, v3 dir, v3 hint, PolyFea
         out->fid = 0; out->nv = 2;
         return;
     }
+    if (s->shape == RO_SHAPE_CONVEX_POLYHEDRON) { /* ConvexPolyhedron: the face whose normal is closest to dir (the first one), its first four vertices */
+        const RoPolyhedron *P = s->poly;
+        int best = 0; float bd = vdot(P->fnormal[0], dir);
+        for (int f = 1; f < P->nf; ++f) { float x = vdot(P->fnormal[f], dir); if (x > bd) { bd = x; best = f; } }
+        int cnt = P->fcount[best] < 4 ? P->fcount[best] : 4, first = P->ffirst[best];
+        for (int i = 0; i < 4; ++i) {
+            int k = first + (i < cnt ? i : cnt - 1);
+            out->v[i] = P->pts[P->loop_v[k]]; out->vid[i] = (uint32_t)P->loop_v[k]; out->eid[i] = RO_FID_EDGE | (uint32_t)P->loop_e[k];
+        }
+        out->fid = RO_FID_FACE | (uint32_t)best; out->nv = cnt;
+        return;
+    }
     float r = s->radius, hh = s->he.y;
     int curved = s->shape == RO_SHAPE_CYLINDER ? (fabsf(dir.y) < 0.5f) : (dir.y > 0.0f);
     if (curved) {
@@ -627,9 +646,27 @@ static inline v3 sm_project_point(const SmShape *s, v3 pt, int *inside) {
     }
     return proj;
 }
-/* contact_manifold_convex_ball with shape1 = a cylinder / cone; flipped = the ball is collider 1 */
+/* contact_manifold_convex_ball with shape1 = a cylinder / cone / convex polyhedron; flipped = the ball is collider 1 */
 static inline void manifold_sm_ball(pose pos12, const SmShape *s1, float r2, float prediction, Manifold *m, int flipped) {
     v3 pt = pos12.t;
+    if (s1->shape == RO_SHAPE_CONVEX_POLYHEDRON) {
+        /* ConvexPolyhedron::project_local_point = local_point_projection_on_support_map: GJK against the point, the polytope pass when
+         * the point is inside — the support-mapped contact query with the ball's centre as second shape */
+        SmShape centre; centre.shape = RO_SHAPE_BALL; centre.he = V3(0, 0, 0); centre.radius = 0.0f; centre.axis = 1; centre.poly = NULL;
+        v3 p1, p2, n1;
+        if (!sm_contact(s1, &centre, pos12, r2 + prediction, V3(0, 0, 0), &p1, &p2, &n1)) { m->npoints = 0; return; }
+        float dist = vdot(vsub(p2, p1), n1);
+        if (dist <= r2 + prediction) {
+            v3 n2 = qrot_inv(pos12.r, vneg(n1));
+            v3 q2 = vmul(n2, r2);
+            float d = dist - r2;
+            v3 a = flipped ? q2 : p1, b = flipped ? p1 : q2;
+            if (m->npoints != 1) { m->npoints = 0; manifold_push(m, a, b, RO_FID_UNKNOWN, RO_FID_UNKNOWN, d); }
+            else { m->points[0].local_p1 = a; m->points[0].local_p2 = b; m->points[0].dist = d; }
+            if (flipped) { m->local_n1 = n2; m->local_n2 = n1; } else { m->local_n1 = n1; m->local_n2 = n2; }
+        } else m->npoints = 0;
+        return;
+    }
     int inside;
     v3 proj = sm_project_point(s1, pt, &inside);
     v3 dpos = vsub(pt, proj);

@@ -22,6 +22,7 @@
 //     (settle()).  The physics is identical either way: the fast graph only skips work that the full
 //     graph would have found to be empty.
 #include "rp_world.h"
+#include "rp_polyhedron.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -133,6 +134,9 @@ struct rp_world {
     std::vector<int> body_free, coll_free;
     bool dead_pairs_possible = false; // colliders were removed since the last step: their pairs are still in the device pair set
     std::vector<char> collider_removed, joint_removed;
+    // convex polyhedra (rp_polyhedron.h): registered shapes, the polyhedron of every collider row (-1: another shape), their device tables
+    std::vector<HostPolyhedron> polys; std::vector<int> collider_poly; bool polys_uploaded = false;
+    void *cv_dev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<rp_joint_desc> joints;
     std::vector<int> active_joint_ids; // device joint index -> index into `joints`
     std::vector<int> quarantine_log;   // bodies disabled by the quarantine, in detection order
@@ -442,6 +446,7 @@ extern "C" int32_t rp_world_destroy(rp_world *w) {
     hipSetDevice(w->device);
     if (w->stream) hipStreamSynchronize(w->stream);
     free_device(w);
+    for (void *&b : w->cv_dev) if (b) { hipFree(b); b = nullptr; }
     for (auto &e : w->ev) if (e) hipEventDestroy(e);
     if (w->stream) hipStreamDestroy(w->stream);
     delete w;
@@ -472,16 +477,37 @@ extern "C" int32_t rp_num_bodies(const rp_world *w) { return w ? (int32_t)w->bod
 
 // parry Shape::mass_properties for cuboid / ball / capsule; frame = the shape's principal inertia local frame
 // (identity except for capsules along X / Z: MassProperties::from_capsule rotates Y onto the segment direction)
-static float shape_bounding_radius(const rp_collider_desc &c) { // Shape::compute_local_bounding_sphere
+// glam Quat::mul_vec3 (scalar path), the form the device and the checker use
+static void h_qrot(const float q[4], const float v[3], float out[3]) {
+    const float bx = q[0], by = q[1], bz = q[2], w = q[3];
+    const float b2 = bx * bx + by * by + bz * bz, vb = v[0] * bx + v[1] * by + v[2] * bz;
+    const float cx = by * v[2] - bz * v[1], cy = bz * v[0] - bx * v[2], cz = bx * v[1] - by * v[0];
+    const float k0 = w * w - b2, k1 = vb * 2.0f, k2 = w * 2.0f;
+    out[0] = v[0] * k0 + bx * k1 + cx * k2; out[1] = v[1] * k0 + by * k1 + cy * k2; out[2] = v[2] * k0 + bz * k1 + cz * k2;
+}
+static float shape_bounding_radius(const rp_world *w, int ci) { // Shape::compute_local_bounding_sphere (about the collider origin)
+    const rp_collider_desc &c = w->colliders[ci];
+    if (c.shape == RP_SHAPE_CONVEX_POLYHEDRON) return w->polys[w->collider_poly[ci]].origin_radius; // (the CCD pre-filter and the grid's cell size; max_extent uses the point cloud's own sphere)
     if (c.shape == RP_SHAPE_CUBOID) return std::sqrt(c.half_extents[0] * c.half_extents[0] + c.half_extents[1] * c.half_extents[1] + c.half_extents[2] * c.half_extents[2]);
     if (c.shape == RP_SHAPE_CAPSULE) return c.half_extents[0] + c.half_extents[1];
     if (c.shape == RP_SHAPE_HALFSPACE) return 3.402823466e+38f;
     if (c.shape == RP_SHAPE_CYLINDER || c.shape == RP_SHAPE_CONE) { volatile float rr = c.half_extents[1] * c.half_extents[1], hh2 = c.half_extents[0] * c.half_extents[0]; return std::sqrt(rr + hh2); }
     return c.half_extents[0];
 }
-static void shape_mass_props(const rp_collider_desc &c, float density, float &mass, float pi[3], float frame[4], float com[3]) {
+static void hmp_diagonalise(float a[3][3], float pi[3], float frame[4]);
+static void shape_mass_props(const rp_world *w, int ci, float density, float &mass, float pi[3], float frame[4], float com[3]) {
+    const rp_collider_desc &c = w->colliders[ci];
     frame[0] = 0.0f; frame[1] = 0.0f; frame[2] = 0.0f; frame[3] = 1.0f;
     com[0] = com[1] = com[2] = 0.0f;
+    if (c.shape == RP_SHAPE_CONVEX_POLYHEDRON) { // MassProperties::from_convex_polyhedron -> with_inertia_matrix(com, volume * density, tensor * density)
+        const HostPolyhedron &P = w->polys[w->collider_poly[ci]];
+        float a[3][3];
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) a[i][j] = P.inertia[i][j] * density;
+        hmp_diagonalise(a, pi, frame);
+        mass = P.volume * density;
+        com[0] = P.com[0] - P.centre[0]; com[1] = P.com[1] - P.centre[1]; com[2] = P.com[2] - P.centre[2]; // (in the recentred collider frame)
+        return;
+    }
     if (c.shape == RP_SHAPE_CYLINDER) { // MassProperties::from_cylinder (cylinder_y_volume_unit_inertia)
         float hh = c.half_extents[0], r = c.half_extents[1];
         volatile float vol = hh * r * r * 3.14159265358979323846f * 2.0f;
@@ -653,7 +679,7 @@ static void sum_collider_mass_props(const rp_world *w, int body, float density_o
         if (w->collider_removed[i]) continue;
         const rp_collider_desc &c = w->colliders[i];
         hmp_mp m; memset(&m, 0, sizeof(m)); m.frame[3] = 1.0f;
-        shape_mass_props(c, density_override < 0.0f ? c.density : density_override, m.mass, m.pi, m.frame, m.com);
+        shape_mass_props(w, i, density_override < 0.0f ? c.density : density_override, m.mass, m.pi, m.frame, m.com);
         float qn = std::sqrt(c.rotation[0] * c.rotation[0] + c.rotation[1] * c.rotation[1] + c.rotation[2] * c.rotation[2] + c.rotation[3] * c.rotation[3]);
         float qi = qn > 0.0f ? 1.0f / qn : 1.0f;
         float q[4] = {c.rotation[0] * qi, c.rotation[1] * qi, c.rotation[2] * qi, qn > 0.0f ? c.rotation[3] * qi : 1.0f};
@@ -689,8 +715,19 @@ static void recompute_mass(rp_world *w, int body) {
     for (int i : b.cols) {
         if (w->collider_removed[i]) continue;
         const rp_collider_desc &c = w->colliders[i];
-        float radius = shape_bounding_radius(c);
-        float dx = c.translation[0] - b.lcom[0], dy = c.translation[1] - b.lcom[1], dz = c.translation[2] - b.lcom[2];
+        float radius = shape_bounding_radius(w, i);
+        float ctr[3] = {c.translation[0], c.translation[1], c.translation[2]};
+        if (c.shape == RP_SHAPE_CONVEX_POLYHEDRON) { // point_cloud_bounding_sphere: centred on the mean of the points
+            const HostPolyhedron &P = w->polys[w->collider_poly[i]];
+            const float off[3] = {P.sphere_centre[0] - P.centre[0], P.sphere_centre[1] - P.centre[1], P.sphere_centre[2] - P.centre[2]};
+            float qn = std::sqrt(c.rotation[0] * c.rotation[0] + c.rotation[1] * c.rotation[1] + c.rotation[2] * c.rotation[2] + c.rotation[3] * c.rotation[3]);
+            float qi = qn > 0.0f ? 1.0f / qn : 1.0f;
+            const float q[4] = {c.rotation[0] * qi, c.rotation[1] * qi, c.rotation[2] * qi, qn > 0.0f ? c.rotation[3] * qi : 1.0f};
+            float r[3]; h_qrot(q, off, r);
+            ctr[0] = r[0] + c.translation[0]; ctr[1] = r[1] + c.translation[1]; ctr[2] = r[2] + c.translation[2];
+            radius = P.sphere_radius;
+        }
+        float dx = ctr[0] - b.lcom[0], dy = ctr[1] - b.lcom[1], dz = ctr[2] - b.lcom[2];
         float extent = std::sqrt(dx * dx + dy * dy + dz * dz) + radius;
         if (extent > b.max_extent) b.max_extent = extent;
     }
@@ -874,11 +911,78 @@ extern "C" int32_t rp_bodies_insert(rp_world *w, int32_t n, const rp_body_desc *
     if (w->carry) return finalize(w); // the larger device world takes over the rows of the one it replaces
     return RP_OK;
 }
+// the cv_* tables of the device world (rp_world.h): every registered polyhedron, flattened.  Own allocations (not rows of a growth domain):
+// replaced as a whole when a polyhedron is registered, referenced by pointer from DevWorld (the step graphs are captured again)
+static float4 mk4(float x, float y, float z, float w_);
+static int upload_polyhedra(rp_world *w) {
+    std::vector<int4> hdr; std::vector<float4> pts, fn; std::vector<int2> fl, loop;
+    for (const HostPolyhedron &P : w->polys) {
+        int4 h; h.x = (int)pts.size(); h.y = P.nv(); h.z = (int)fn.size(); h.w = P.nf();
+        hdr.push_back(h);
+        const int loop0 = (int)loop.size();
+        for (int i = 0; i < P.nv(); ++i) pts.push_back(mk4(P.pts[3 * i], P.pts[3 * i + 1], P.pts[3 * i + 2], P.origin_radius));
+        for (int f = 0; f < P.nf(); ++f) { fn.push_back(mk4(P.fnormal[3 * f], P.fnormal[3 * f + 1], P.fnormal[3 * f + 2], 0.0f)); int2 r; r.x = loop0 + P.ffirst[f]; r.y = P.fcount[f]; fl.push_back(r); }
+        for (size_t k = 0; k < P.loop_v.size(); ++k) { int2 r; r.x = P.loop_v[k]; r.y = P.loop_e[k]; loop.push_back(r); }
+    }
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    for (void *&b : w->cv_dev) if (b) { HIPCHK(w, hipFree(b)); b = nullptr; }
+    const void *src[5] = {hdr.data(), pts.data(), fn.data(), fl.data(), loop.data()};
+    const size_t bytes[5] = {hdr.size() * sizeof(int4), pts.size() * sizeof(float4), fn.size() * sizeof(float4), fl.size() * sizeof(int2), loop.size() * sizeof(int2)};
+    for (int k = 0; k < 5; ++k) {
+        if (bytes[k] == 0) continue;
+        HIPCHK(w, hipMalloc(&w->cv_dev[k], bytes[k]));
+        HIPCHK(w, hipMemcpyAsync(w->cv_dev[k], src[k], bytes[k], hipMemcpyHostToDevice, w->stream));
+    }
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    w->dw.cv_hdr = (int4 *)w->cv_dev[0]; w->dw.cv_pts = (float4 *)w->cv_dev[1]; w->dw.cv_fn = (float4 *)w->cv_dev[2]; w->dw.cv_fl = (int2 *)w->cv_dev[3]; w->dw.cv_loop = (int2 *)w->cv_dev[4];
+    w->polys_uploaded = true;
+    return RP_OK;
+}
+extern "C" int32_t rp_convex_polyhedron_create(rp_world *w, int32_t n_points, const float *points_xyz, int32_t n_triangles, const uint32_t *indices, int32_t *id_out) {
+    if (!w || !points_xyz || !id_out || n_points < 4 || (indices && n_triangles < 4)) { if (w) w->err = "rp_convex_polyhedron_create: at least four points (and four triangles)"; return RP_ERR_INVALID; }
+    std::vector<uint32_t> hull;
+    if (!indices) { // SharedShape::convex_hull
+        if (!rp_poly::convex_hull(n_points, points_xyz, hull)) { w->err = "rp_convex_polyhedron_create: the points have no volume (convex_hull returns None)"; return RP_ERR_INVALID; }
+        indices = hull.data(); n_triangles = (int32_t)(hull.size() / 3);
+    }
+    HostPolyhedron P;
+    if (!rp_poly::build(P, n_points, points_xyz, n_triangles, indices)) { w->err = "rp_convex_polyhedron_create: not a closed, outward-wound convex triangle mesh of 4..256 vertices"; return RP_ERR_INVALID; }
+    w->polys.push_back(std::move(P));
+    *id_out = (int32_t)w->polys.size() - 1;
+    if (w->finalized) { // the tables are replaced: no launch may still read the old ones, the graphs hold the old pointers
+        HIPCHK(w, hipSetDevice(w->device));
+        int r = settle(w); if (r != RP_OK) return r;
+        r = upload_polyhedra(w); if (r != RP_OK) return r;
+        destroy_graphs(w);
+    }
+    return RP_OK;
+}
+extern "C" int32_t rp_convex_polyhedron_read(const rp_world *w, int32_t id, int32_t counts[4], float *points_xyz, float *face_normals, int32_t *face_first, int32_t *face_count,
+                                             int32_t *loop_vertex, int32_t *loop_edge, float props[20]) {
+    if (!w || !counts || id < 0 || id >= (int32_t)w->polys.size()) return RP_ERR_INVALID;
+    const HostPolyhedron &P = w->polys[(size_t)id];
+    counts[0] = P.nv(); counts[1] = P.nf(); counts[2] = (int32_t)P.loop_v.size(); counts[3] = P.ne;
+    if (points_xyz) memcpy(points_xyz, P.pts.data(), P.pts.size() * sizeof(float));
+    if (face_normals) memcpy(face_normals, P.fnormal.data(), P.fnormal.size() * sizeof(float));
+    if (face_first) memcpy(face_first, P.ffirst.data(), P.ffirst.size() * sizeof(int));
+    if (face_count) memcpy(face_count, P.fcount.data(), P.fcount.size() * sizeof(int));
+    if (loop_vertex) memcpy(loop_vertex, P.loop_v.data(), P.loop_v.size() * sizeof(int));
+    if (loop_edge) memcpy(loop_edge, P.loop_e.data(), P.loop_e.size() * sizeof(int));
+    if (props) {
+        float *o = props;
+        o[0] = P.centre[0]; o[1] = P.centre[1]; o[2] = P.centre[2]; o[3] = P.half[0]; o[4] = P.half[1]; o[5] = P.half[2]; o[6] = P.origin_radius;
+        o[7] = P.sphere_centre[0]; o[8] = P.sphere_centre[1]; o[9] = P.sphere_centre[2]; o[10] = P.sphere_radius;
+        o[11] = P.volume; o[12] = P.com[0]; o[13] = P.com[1]; o[14] = P.com[2];
+        o[15] = P.inertia[0][0]; o[16] = P.inertia[1][1]; o[17] = P.inertia[2][2]; o[18] = P.inertia[0][1]; o[19] = P.inertia[0][2];
+    }
+    return RP_OK;
+}
 extern "C" int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider_desc *descs, const uint64_t *parents, uint64_t *handles_out) {
     if (!w || n < 0 || (n > 0 && !descs)) return RP_ERR_INVALID;
     for (int i = 0; i < n; ++i) {
         const rp_collider_desc &cd = descs[i];
-        if (cd.shape < RP_SHAPE_BALL || cd.shape > RP_SHAPE_CONE) { w->err = "rp_colliders_insert: unknown shape (ball, cuboid, capsule, half-space, cylinder and cone are implemented)"; return RP_ERR_INVALID; }
+        if (cd.shape < RP_SHAPE_BALL || cd.shape > RP_SHAPE_CONVEX_POLYHEDRON) { w->err = "rp_colliders_insert: unknown shape (ball, cuboid, capsule, half-space, cylinder, cone and convex polyhedron are implemented)"; return RP_ERR_INVALID; }
+        if (cd.shape == RP_SHAPE_CONVEX_POLYHEDRON && !(cd.half_extents[0] >= 0.0f && cd.half_extents[0] < (float)w->polys.size() && cd.half_extents[0] == std::floor(cd.half_extents[0]))) { w->err = "rp_colliders_insert: a convex polyhedron's half_extents[0] holds the id rp_convex_polyhedron_create returned"; return RP_ERR_INVALID; }
         if ((cd.shape == RP_SHAPE_CYLINDER || cd.shape == RP_SHAPE_CONE) && !(cd.half_extents[0] > 0.0f && cd.half_extents[1] > 0.0f)) { w->err = "rp_colliders_insert: cylinder / cone half_extents = (half_height, radius, -), both positive"; return RP_ERR_INVALID; }
         if (cd.shape == RP_SHAPE_HALFSPACE) {
             const float *nn = cd.half_extents; const float l2 = nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2];
@@ -915,12 +1019,24 @@ extern "C" int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider
         int &ord_counter = parent >= 0 ? w->bodies[parent].next_ord : w->next_free_ord;
         if (ord_counter >= (parent >= 0 ? 4096 : (1 << 20))) { w->err = "rp_colliders_insert: more than 4,096 colliders on one body (or 2^20 without a parent)"; return RP_ERR_CAPACITY; }
         int ci;
+        rp_collider_desc cd = descs[i];
+        int poly = -1;
+        if (cd.shape == RP_SHAPE_CONVEX_POLYHEDRON) { // stored recentred on its local AABB: the centre rides in the collider's pose, half_extents = the box (rp_polyhedron.h)
+            poly = (int)cd.half_extents[0];
+            const HostPolyhedron &P = w->polys[(size_t)poly];
+            float qn = std::sqrt(cd.rotation[0] * cd.rotation[0] + cd.rotation[1] * cd.rotation[1] + cd.rotation[2] * cd.rotation[2] + cd.rotation[3] * cd.rotation[3]);
+            float qi = qn > 0.0f ? 1.0f / qn : 1.0f;
+            const float q[4] = {cd.rotation[0] * qi, cd.rotation[1] * qi, cd.rotation[2] * qi, qn > 0.0f ? cd.rotation[3] * qi : 1.0f};
+            float r[3]; h_qrot(q, P.centre, r);
+            cd.translation[0] = r[0] + cd.translation[0]; cd.translation[1] = r[1] + cd.translation[1]; cd.translation[2] = r[2] + cd.translation[2];
+            cd.half_extents[0] = P.half[0]; cd.half_extents[1] = P.half[1]; cd.half_extents[2] = P.half[2];
+        }
         if (reuse) {
             ci = w->coll_free.back(); w->coll_free.pop_back();
-            w->collider_ord[(size_t)ci] = ord_counter++; w->colliders[(size_t)ci] = descs[i]; w->collider_parent[(size_t)ci] = parent; w->collider_removed[(size_t)ci] = 0;
+            w->collider_ord[(size_t)ci] = ord_counter++; w->colliders[(size_t)ci] = cd; w->collider_parent[(size_t)ci] = parent; w->collider_removed[(size_t)ci] = 0; w->collider_poly[(size_t)ci] = poly;
         } else {
             ci = (int)w->colliders.size();
-            w->collider_ord.push_back(ord_counter++); w->colliders.push_back(descs[i]); w->collider_parent.push_back(parent); w->collider_removed.push_back(0); w->coll_gen.push_back(0);
+            w->collider_ord.push_back(ord_counter++); w->colliders.push_back(cd); w->collider_parent.push_back(parent); w->collider_removed.push_back(0); w->coll_gen.push_back(0); w->collider_poly.push_back(poly);
         }
         w->coll_gen[(size_t)ci] = w->coll_arena_gen;
         new_slots.push_back(ci);
@@ -1070,6 +1186,7 @@ static ColliderRow pack_collider(const rp_world *w, int i) {
     o.lr = mk4(c.rotation[0] * qi, c.rotation[1] * qi, c.rotation[2] * qi, qn > 0.0f ? c.rotation[3] * qi : 1.0f);
     o.he = mk4(c.half_extents[0], c.half_extents[1], c.half_extents[2], 0);
     if (c.shape == RP_SHAPE_CYLINDER || c.shape == RP_SHAPE_CONE) o.he = mk4(c.half_extents[1], c.half_extents[0], c.half_extents[1], 0); // (radius, half_height, radius): the local AABB's half extents
+    if (c.shape == RP_SHAPE_CONVEX_POLYHEDRON) { int id = w->collider_poly[i]; memcpy(&o.he.w, &id, sizeof(int)); } // (half extents of the local box; w = the polyhedron's row in the cv_* tables, as bits)
     o.mat = mk4(c.friction, c.restitution, c.density, 0);
     o.rules.x = c.friction_rule; o.rules.y = c.restitution_rule;
     o.groups.x = w->collider_removed[i] ? 0u : c.collision_memberships; o.groups.y = w->collider_removed[i] ? 0u : c.collision_filter;
@@ -1239,6 +1356,7 @@ static int finalize(rp_world *w) {
     d.has_force_events = world_has_force_events(w) ? 1 : 0;
     d.has_sensors = world_has_sensors(w) ? 1 : 0;
     d.has_convex = world_has_convex(w) ? 1 : 0;
+    if (!w->polys.empty()) { int r = upload_polyhedra(w); if (r != RP_OK) return r; } // (after the memset above: the cv_* pointers)
     d.gbar_blocks = gbar_grid_for_device(w->device);
     { const char *ni = getenv("RP_NO_BP_INCR"); d.bp_incremental = (ni && ni[0] == '1') ? 0 : 1; }
     { const char *ig = getenv("RP_ISL_GENERIC"); d.isl_generic = (ig && ig[0] == '1') ? 1 : 0; }
@@ -1263,9 +1381,10 @@ static int finalize(rp_world *w) {
     float pred = w->params.normalized_prediction_distance * w->params.length_unit;
     float margin = 2.0f * (pred * 0.5f + 4.0e-2f * w->params.length_unit);
     std::vector<float> ext;
-    for (auto &c : w->colliders) {
+    for (int ci = 0; ci < (int)w->colliders.size(); ++ci) {
+        const rp_collider_desc &c = w->colliders[ci];
         if (c.shape == RP_SHAPE_HALFSPACE) continue; // unbounded: always on the broad phase's large list
-        float r = shape_bounding_radius(c);
+        float r = shape_bounding_radius(w, ci);
         ext.push_back(2.0f * r + margin);
     }
     float cell = 1.0f;

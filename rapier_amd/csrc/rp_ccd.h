@@ -39,7 +39,7 @@ RP_DEV Pose ccd_sweep_transform_at(const CcdSweep &s, float t) {
 // a collider's shape as the query sees it (c_shape / c_he of rp_world.h): he = cuboid half extents | half-space normal; capsule:
 // he.x = half height, radius, axis; ball: radius
 typedef SmShape CcdShape; // (rp_convex.h: the same record serves the support-mapped queries)
-RP_DEV CcdShape ccd_shape_of(int sh, float4 he) { return sm_shape_of(sh, he); }
+RP_DEV CcdShape ccd_shape_of(const DevWorld &w, int sh, float4 he) { return sm_shape_of(w, sh, he); }
 RP_DEV V3 ccd_clamp_box(V3 p, V3 he) { return v3(rp_clamp(p.x, -he.x, he.x), rp_clamp(p.y, -he.y, he.y), rp_clamp(p.z, -he.z, he.z)); }
 RP_DEV float ccd_point_dir(V3 dv, V3 &dir) {
     float dist = len(dv);
@@ -170,9 +170,10 @@ RP_DEV bool ccd_may_reach(V3 c0, V3 c1, float max_extent, V3 target_centre, floa
     float reach = (max_extent + target_radius) + margin;
     return len2(target_centre - p) <= reach * reach;
 }
-RP_DEV float ccd_bounding_radius(int sh, float4 he) { // Shape::compute_local_bounding_sphere
+RP_DEV float ccd_bounding_radius(const DevWorld &w, int sh, float4 he) { // Shape::compute_local_bounding_sphere
     if (sh == RP_SHAPE_CUBOID) return len(v3(he));
     if (sh == RP_SHAPE_CAPSULE) return he.x + he.y;
+    if (sh == RP_SHAPE_CONVEX_POLYHEDRON) return w.cv_pts[w.cv_hdr[__float_as_int(he.w)].x].w; // max |vertex| (every point row of the shape carries it)
     if (sh >= RP_SHAPE_CYLINDER) return sqrtf(he.x * he.x + he.y * he.y);
     return he.x;
 }
@@ -234,7 +235,7 @@ template <bool CONVEX> __global__ void __launch_bounds__(256) k_ccd(DevWorld w, 
           for (int f = 0; f < CCD_MAX_FAST_COLLIDERS; ++f) {
             const int c1 = fast[f];
             if (c1 < 0) continue; // (uniform over the workgroup)
-            const CcdShape s2 = ccd_shape_of(w.c_shape[c1], w.c_he[c1]);
+            const CcdShape s2 = ccd_shape_of(w, w.c_shape[c1], w.c_he[c1]);
             Pose pwp; pwp.t = v3(w.c_lpos[c1]); pwp.r = q4(w.c_lrot[c1]);
             const float rot_radius = ccd_rot_radius(s2, pwp, lcom);
             const uint2 g1 = w.c_groups[c1];
@@ -251,8 +252,8 @@ template <bool CONVEX> __global__ void __launch_bounds__(256) k_ccd(DevWorld w, 
                 Pose tp = collider_world_pose(w, c2); // target_collider_pose (:97-102): bodies already stand at their end-of-step pose
                 const int sh2 = w.c_shape[c2];
                 const float4 he2 = w.c_he[c2];
-                if (sh2 != RP_SHAPE_HALFSPACE && !ccd_may_reach(sw.c0, sw.c1, max_extent, tp.t, ccd_bounding_radius(sh2, he2), 2.0f * slop)) continue;
-                const CcdShape s1 = ccd_shape_of(sh2, he2);
+                if (sh2 != RP_SHAPE_HALFSPACE && !ccd_may_reach(sw.c0, sw.c1, max_extent, tp.t, ccd_bounding_radius(w, sh2, he2), 2.0f * slop)) continue;
+                const CcdShape s1 = ccd_shape_of(w, sh2, he2);
                 const float cur = __uint_as_float(__hip_atomic_load(&best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                 const float hit = ccd_cast_pair<CONVEX>(s1, tp, s2, pwp, sw, rot_radius, cur, slop);
                 if (hit > 0.0f && hit < cur) atomicMin(&best, __float_as_uint(hit));

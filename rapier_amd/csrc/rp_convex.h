@@ -27,11 +27,23 @@
 
 // c_shape / c_he of rp_world.h: cuboid half extents | capsule (half height, radius, axis) | ball radius | cylinder / cone (axis Y):
 // he = (radius, half_height, radius) = the half extents of the local AABB
-struct SmShape { int shape; V3 he; float radius; int axis; };
-RP_DEV SmShape sm_shape_of(int sh, float4 he) {
+// a convex polyhedron (c_he = its local box's half extents, w = its row in cv_hdr as bits): points, face normals, per face {first loop
+// entry, entries}, loop entries {vertex, edge} — pointers into the world's cv_* tables
+struct SmShape { int shape; V3 he; float radius; int axis; const float4 *pts; const float4 *fn; const int2 *fl; const int2 *loop; int npts, nfaces; };
+RP_DEV SmShape sm_shape_of(const DevWorld &w, int sh, float4 he) {
     SmShape s; s.shape = sh; s.he = v3(he); s.axis = 1;
     s.radius = sh == RP_SHAPE_CAPSULE ? he.y : he.x;
     if (sh == RP_SHAPE_CAPSULE) s.axis = (int)he.z;
+    s.pts = nullptr; s.fn = nullptr; s.fl = nullptr; s.loop = nullptr; s.npts = 0; s.nfaces = 0;
+    if (sh == RP_SHAPE_CONVEX_POLYHEDRON) {
+        const int4 h = w.cv_hdr[__float_as_int(he.w)];
+        s.pts = w.cv_pts + h.x; s.npts = h.y; s.fn = w.cv_fn + h.z; s.fl = w.cv_fl + h.z; s.nfaces = h.w; s.loop = w.cv_loop; s.radius = 0.0f;
+    }
+    return s;
+}
+RP_DEV SmShape sm_point_shape() { // a ball's centre as second shape of a query
+    SmShape s; s.shape = RP_SHAPE_BALL; s.he = v3(0, 0, 0); s.radius = 0.0f; s.axis = 1;
+    s.pts = nullptr; s.fn = nullptr; s.fl = nullptr; s.loop = nullptr; s.npts = 0; s.nfaces = 0;
     return s;
 }
 RP_DEV float sm_border_radius(const SmShape &s) { return (s.shape == RP_SHAPE_BALL || s.shape == RP_SHAPE_CAPSULE) ? s.radius : 0.0f; }
@@ -57,6 +69,11 @@ __device__ V3 sm_support(const SmShape &s, V3 d) {
         V3 r = v3(d.x / n * s.radius, -s.he.y, d.z / n * s.radius);
         if (dot(d, r) < d.y * s.he.y) r = v3(0.0f, s.he.y, 0.0f);
         return r;
+    }
+    if (s.shape == RP_SHAPE_CONVEX_POLYHEDRON) { // utils::point_cloud_support_point: the first vertex with the largest dot product
+        int best = 0; float bd = dot(v3(s.pts[0]), d);
+        for (int i = 1; i < s.npts; ++i) { float x = dot(v3(s.pts[i]), d); if (x > bd) { bd = x; best = i; } }
+        return v3(s.pts[best]);
     }
     return v3(0, 0, 0);
 }
@@ -403,6 +420,18 @@ __device__ void sm_support_feature(const SmShape &s, V3 dir, V3 hint, PolyFeat &
         out.fid = 0; out.nv = 2;
         return;
     }
+    if (s.shape == RP_SHAPE_CONVEX_POLYHEDRON) { // the face whose normal is closest to dir (the first one), its first four vertices
+        int best = 0; float bd = dot(v3(s.fn[0]), dir);
+        for (int f = 1; f < s.nfaces; ++f) { float x = dot(v3(s.fn[f]), dir); if (x > bd) { bd = x; best = f; } }
+        const int2 fl = s.fl[best];
+        const int cnt = fl.y < 4 ? fl.y : 4;
+        for (int i = 0; i < 4; ++i) {
+            const int2 le = s.loop[fl.x + (i < cnt ? i : cnt - 1)];
+            out.v[i] = v3(s.pts[le.x]); out.vid[i] = (unsigned)le.x; out.eid[i] = 0x4000u | (unsigned)le.y;
+        }
+        out.fid = 0x8000u | (unsigned)best; out.nv = cnt;
+        return;
+    }
     float r = s.radius, hh = s.he.y;
     bool curved = s.shape == RP_SHAPE_CYLINDER ? (fabsf(dir.y) < 0.5f) : (dir.y > 0.0f);
     if (curved) {
@@ -594,6 +623,23 @@ __device__ V3 sm_project_point(const SmShape &s, V3 pt, bool &inside) {
 // contact_manifold_convex_ball with shape1 = a cylinder / cone; flipped = the ball is collider 1
 __device__ void manifold_sm_ball(Pose pos12, const SmShape &s1, float r2, float prediction, LocalManifold &m, bool flipped) {
     V3 pt = pos12.t;
+    if (s1.shape == RP_SHAPE_CONVEX_POLYHEDRON) { // ConvexPolyhedron::project_local_point = GJK / polytope pass against the point
+        const SmShape centre = sm_point_shape();
+        V3 p1, p2, n1;
+        if (!sm_contact(s1, centre, pos12, r2 + prediction, v3(0, 0, 0), p1, p2, n1)) { m.n = 0; return; }
+        float dist = dot(p2 - p1, n1);
+        if (dist <= r2 + prediction) {
+            V3 n2 = qrot_inv(pos12.r, -n1);
+            V3 q2 = n2 * r2;
+            int keep = m.n == 1 ? 0 : -1;
+            m.n = 1;
+            m.lp1[0] = flipped ? q2 : p1; m.lp2[0] = flipped ? p1 : q2; m.dist[0] = dist - r2;
+            if (keep < 0) m.fid[0] = RP_FID_UNKNOWN | (RP_FID_UNKNOWN << 16);
+            m.src[0] = keep;
+            if (flipped) { m.ln1 = n2; m.ln2 = n1; } else { m.ln1 = n1; m.ln2 = n2; }
+        } else m.n = 0;
+        return;
+    }
     bool inside;
     V3 proj = sm_project_point(s1, pt, inside);
     convex_ball_finish(pos12, pt, proj, inside, r2, prediction, m, flipped);

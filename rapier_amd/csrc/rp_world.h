@@ -200,7 +200,10 @@ struct DevWorld {
     int bp_incremental;    // the broad phase may update incrementally (0: RP_NO_BP_INCR=1, every pass is a full rebuild)
     int gbar_blocks;       // most workgroups (of 1024 threads) a grid-barrier kernel may use on this device: all of them resident at once (rp_gridbar.h)
     int has_sensors;       // some collider is a sensor: its pairs are intersection-tested every step (full step path)
-    int has_convex;        // some collider is a cylinder / cone: the narrow-phase, sensor and CCD launches use their CONVEX instantiations (rp_convex.h)
+    int has_convex;        // some collider is a cylinder / cone / convex polyhedron: the narrow-phase, sensor and CCD launches use their CONVEX instantiations (rp_convex.h)
+    // convex polyhedra (rp_polyhedron.h), flattened: per shape {first point, points, first face, faces}; points (w: max |p|); face normals;
+    // per face {first loop entry, entries}; loop entries {vertex of the shape, edge of the shape}.  A collider's c_he.w holds its shape's row, as bits
+    int4 *cv_hdr; float4 *cv_pts; float4 *cv_fn; int2 *cv_fl; int2 *cv_loop;
     int joints_spherical;  // every impulse joint locks the three linear axes and nothing else (no limit, no motor): tile sweeps may rebuild the rows themselves
     int lean;              // bit 0 (bit 1: a bare lean graph, see lean_dead) set in the copy the LEAN step graph is captured with (rp_api.hip "lean graph"): its kernels check lean_dead / collision_done
     SimParams prm;

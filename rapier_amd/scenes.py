@@ -17,6 +17,7 @@ import numpy as np
 BODY_DYNAMIC, BODY_FIXED, BODY_KINEMATIC_POSITION, BODY_KINEMATIC_VELOCITY = 0, 1, 2, 3  # RigidBodyType
 SHAPE_BALL, SHAPE_CUBOID, SHAPE_CAPSULE = 0, 1, 2  # capsule: half_extents = (half_height, radius, axis 0|1|2) = ColliderBuilder::capsule_x/y/z
 SHAPE_HALFSPACE = 3  # half_extents = the unit outward normal in the collider frame = ColliderBuilder::halfspace (fixed or kinematic parents only)
+SHAPE_CONVEX = SHAPE_CONVEX_POLYHEDRON = 6  # half_extents[0] = the id Scene.add_convex_polyhedron returned = ColliderBuilder::convex_mesh / convex_hull (collider.rs:1039, :1070)
 SHAPE_CYLINDER, SHAPE_CONE = 4, 5  # half_extents = (half_height, radius, -) = ColliderBuilder::cylinder / cone (axis Y, a cone's apex at +Y)
 RULE_AVERAGE, RULE_MIN, RULE_MULTIPLY, RULE_MAX, RULE_CLAMPED_SUM, RULE_GEOMETRIC_MEAN = range(6)
 
@@ -155,6 +156,15 @@ class Scene:
     colliders: list = field(default_factory=list)
     collider_parents: list = field(default_factory=list)
     joints: list = field(default_factory=list)
+    polyhedra: list = field(default_factory=list)   # (points (n, 3) f32, triangles (m, 3) u32 or None = "take the convex hull")
+
+    def add_convex_polyhedron(self, points, triangles=None) -> int:
+        """SharedShape::convex_mesh(points, indices) — or convex_hull(points) when `triangles` is None; colliders use the returned id:
+        add_collider(b, shape=SHAPE_CONVEX, half_extents=(id, 0, 0))"""
+        pts = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
+        tris = None if triangles is None else np.ascontiguousarray(triangles, np.uint32).reshape(-1, 3)
+        self.polyhedra.append((pts, tris))
+        return len(self.polyhedra) - 1
 
     def add_body(self, **kw) -> int:
         self.bodies.append(body_desc(**kw))
@@ -849,4 +859,58 @@ def issue_810_disc() -> Scene:
         r, a = np.float32(k) * np.float32(0.45), np.float32(k) * np.float32(2.399)
         b = s.add_body(translation=(float(r * np.cos(a)), 20.0, float(r * np.sin(a))))
         s.add_collider(b, half_extents=(0.05, 0.05, 0.05))
+    return s
+
+
+def polyhedra_clutter(n: int = 24, seed: int = 2, hulls: bool = True) -> Scene:
+    """Seeded test scene (not a reference scene) for convex polyhedra (ColliderBuilder::convex_hull / convex_mesh, collider.rs:1039, :1070):
+    random point clouds, prisms, wedges and a box given as a polyhedron, tumbling with cuboids, balls, capsules, cylinders and cones on a
+    slab and a half-space ramp inside four walls; several bodies share one registered polyhedron, one compound body carries two, a
+    fixed polyhedron stands in the middle.  `hulls`: register the clouds as point sets (convex_hull) — the caller may replace them by
+    explicit triangle lists (convex_mesh)."""
+    rng = np.random.default_rng(seed)
+    s = Scene(name=f"polyhedra_clutter_{n}_{seed}", gravity=(0.0, -9.81, 0.0))
+    g = s.add_body(body_type=BODY_FIXED, translation=(0.0, -0.5, 0.0))
+    s.add_collider(g, half_extents=(9.0, 0.5, 9.0))
+    s.add_collider(g, shape=SHAPE_HALFSPACE, half_extents=(-0.5, 0.8660254, 0.0), translation=(3.0, 0.5, 0.0))     # a ramp along +x
+    for sx, sz, hx, hz in ((4.5, 0.0, 0.25, 4.5), (-4.5, 0.0, 0.25, 4.5), (0.0, 4.5, 4.5, 0.25), (0.0, -4.5, 4.5, 0.25)):
+        wb = s.add_body(body_type=BODY_FIXED, translation=(sx, 1.0, sz))
+        s.add_collider(wb, half_extents=(hx, 1.0, hz))
+    shapes = []
+    shapes.append(s.add_convex_polyhedron(np.array([[x, y, z] for x in (-.35, .35) for y in (-.25, .25) for z in (-.3, .3)], np.float32)))   # a box
+    shapes.append(s.add_convex_polyhedron(np.float32([[np.cos(a) * 0.35, h, np.sin(a) * 0.35] for h in (-0.3, 0.3) for a in np.linspace(0, 2 * np.pi, 6)[:-1]])))  # pentagonal prism
+    shapes.append(s.add_convex_polyhedron(np.float32([[-0.4, -0.2, -0.3], [0.4, -0.2, -0.3], [0.4, -0.2, 0.3], [-0.4, -0.2, 0.3], [-0.4, 0.3, -0.3], [-0.4, 0.3, 0.3]])))  # wedge
+    for k in range(3):
+        shapes.append(s.add_convex_polyhedron((rng.standard_normal((18 + 6 * k, 3)) * (0.22 + 0.04 * k)).astype(np.float32) + np.float32([0.1 * k, 0.0, 0.05])))       # clouds, off-centre
+    rock = s.add_body(body_type=BODY_FIXED, translation=(0.0, 0.45, 0.0), rotation=(0.1, 0.3, 0.0, 0.9486833))
+    s.add_collider(rock, shape=SHAPE_CONVEX, half_extents=(shapes[5], 0, 0))
+    side = int(np.ceil(n ** (1.0 / 3.0)))
+    k = 0
+    for iy in range(side * 2):
+        for ix in range(side):
+            for iz in range(side):
+                if k >= n:
+                    break
+                q = rng.normal(size=4).astype(np.float32)
+                q /= np.linalg.norm(q)
+                pos = (np.float32(1.4 * (ix - side / 2) + 0.1 * rng.random()), np.float32(2.0 + 1.5 * iy), np.float32(1.4 * (iz - side / 2) + 0.1 * rng.random()))
+                b = s.add_body(translation=pos, rotation=tuple(q), linvel=tuple((rng.normal(size=3) * 1.0).astype(np.float32)), angvel=tuple((rng.normal(size=3) * 2.0).astype(np.float32)),
+                               angular_damping=0.2 if k % 4 == 0 else 0.0)
+                fr = np.float32(0.3 + 0.5 * rng.random())
+                kind = k % 8
+                if kind in (0, 2, 4, 6):
+                    s.add_collider(b, shape=SHAPE_CONVEX, half_extents=(shapes[(k // 2) % len(shapes)], 0, 0), friction=fr, density=np.float32(0.8 + 1.5 * rng.random()),
+                                   restitution=0.2 if k % 6 == 0 else 0.0)
+                elif kind == 1:
+                    s.add_collider(b, half_extents=tuple((0.2 + 0.3 * rng.random(size=3)).astype(np.float32)), friction=fr)
+                elif kind == 3:
+                    s.add_collider(b, shape=SHAPE_BALL, half_extents=(np.float32(0.25 + 0.2 * rng.random()), 0, 0), friction=fr)
+                elif kind == 5:
+                    s.add_collider(b, shape=SHAPE_CAPSULE, half_extents=(np.float32(0.3 + 0.2 * rng.random()), np.float32(0.15 + 0.15 * rng.random()), float(k % 3)), friction=fr)
+                else:
+                    s.add_collider(b, shape=SHAPE_CYLINDER if k % 16 == 7 else SHAPE_CONE, half_extents=(np.float32(0.25 + 0.2 * rng.random()), np.float32(0.2 + 0.2 * rng.random()), 0.0), friction=fr)
+                k += 1
+    b = s.add_body(translation=(2.5, 3.5, -2.5), angvel=(0.5, 1.0, 0.0))                                              # a dumbbell of two polyhedra
+    s.add_collider(b, shape=SHAPE_CONVEX, half_extents=(shapes[1], 0, 0), translation=(-0.5, 0.0, 0.0), density=1.5)
+    s.add_collider(b, shape=SHAPE_CONVEX, half_extents=(shapes[3], 0, 0), translation=(0.5, 0.1, 0.0), rotation=(0.0, 0.3826834, 0.0, 0.9238795))
     return s

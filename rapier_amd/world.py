@@ -151,6 +151,8 @@ class PhysicsWorld:
     @classmethod
     def from_scene(cls, scene: S.Scene, device: int = 0) -> "PhysicsWorld":
         w = cls(gravity=scene.gravity, integration_parameters=IntegrationParameters(scene.params), device=device)
+        for pts, tris in getattr(scene, "polyhedra", []):
+            w.add_convex_polyhedron(pts, tris)
         bodies = scene.body_array()
         if len(bodies):
             w.insert_bodies(bodies)
@@ -170,6 +172,28 @@ class PhysicsWorld:
         ip = params if isinstance(params, IntegrationParameters) else IntegrationParameters(params)
         _check(self._ptr, self._lib.rp_params_set(self._ptr, ip.as_array().ctypes.data), "rp_params_set")
         self.integration_parameters = ip
+
+    # ---- convex polyhedra ----
+    def add_convex_polyhedron(self, points, triangles=None) -> int:
+        """SharedShape::convex_mesh(points, indices) — SharedShape::convex_hull(points) without `triangles` — registered with the world
+        (rp_convex_polyhedron_create); colliders use the id: collider_desc(shape=SHAPE_CONVEX, half_extents=(id, 0, 0))."""
+        pts = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
+        tris = None if triangles is None else np.ascontiguousarray(triangles, np.uint32).reshape(-1, 3)
+        out = np.zeros(1, np.int32)
+        _check(self._ptr, self._lib.rp_convex_polyhedron_create(self._ptr, len(pts), pts.ctypes.data, 0 if tris is None else len(tris),
+                                                                None if tris is None else tris.ctypes.data, out.ctypes.data), "rp_convex_polyhedron_create")
+        return int(out[0])
+
+    def read_convex_polyhedron(self, pid: int) -> dict:
+        """the polyhedron as the library holds it (rp_convex_polyhedron_read): recentred points, faces as vertex loops, mass properties"""
+        cnt = np.zeros(4, np.int32)
+        _check(self._ptr, self._lib.rp_convex_polyhedron_read(self._ptr, pid, cnt.ctypes.data, None, None, None, None, None, None, None), "rp_convex_polyhedron_read")
+        nv, nf, nl, ne = (int(x) for x in cnt)
+        pts, fn = np.zeros((nv, 3), np.float32), np.zeros((nf, 3), np.float32)
+        ff, fc, lv, le, props = np.zeros(nf, np.int32), np.zeros(nf, np.int32), np.zeros(nl, np.int32), np.zeros(nl, np.int32), np.zeros(20, np.float32)
+        _check(self._ptr, self._lib.rp_convex_polyhedron_read(self._ptr, pid, cnt.ctypes.data, pts.ctypes.data, fn.ctypes.data, ff.ctypes.data, fc.ctypes.data,
+                                                              lv.ctypes.data, le.ctypes.data, props.ctypes.data), "rp_convex_polyhedron_read")
+        return dict(points=pts, face_normals=fn, face_first=ff, face_count=fc, loop_vertex=lv, loop_edge=le, n_edges=ne, props=props)
 
     # ---- handles ----
     def body_handles(self) -> np.ndarray:

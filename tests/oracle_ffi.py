@@ -89,6 +89,20 @@ def set_threads(n: int):
     lib().ro_set_threads(int(n))
 
 
+def hull_triangles(points) -> np.ndarray:
+    """outward-wound triangles of the convex hull of `points` (scipy / Qhull): test-side stand-in for parry's convex_hull"""
+    from scipy.spatial import ConvexHull
+    pts = np.asarray(points, np.float64)
+    h = ConvexHull(pts)
+    tris = h.simplices.copy()
+    c = pts[h.vertices].mean(0)
+    for k, (a, b, cc) in enumerate(tris):
+        n = np.cross(pts[b] - pts[a], pts[cc] - pts[a])
+        if n @ (pts[a] - c) < 0:
+            tris[k] = (a, cc, b)
+    return np.ascontiguousarray(tris, np.uint32)
+
+
 class OracleWorld:
     """The oracle stepped through the same Scene descriptors as the product."""
 
@@ -104,6 +118,9 @@ class OracleWorld:
                 L.ro_set_additional_solver_iterations(self._w, bi, int(bodies["additional_solver_iterations"][i]))
             if int(bodies["ccd_enabled"][i]):
                 L.ro_set_ccd_enabled(self._w, bi, 1)
+        for pts, tris in getattr(scene, "polyhedra", []):
+            if self.add_convex_polyhedron(pts, tris) < 0:
+                raise ValueError("oracle: not a closed convex triangle mesh")
         cols = scene.collider_array()
         parents = scene.parent_array()
         for i in range(len(cols)):
@@ -115,6 +132,26 @@ class OracleWorld:
             if L.ro_add_joint(self._w, joints[i:i + 1].ctypes.data) < 0:
                 raise ValueError("oracle: unsupported joint")
         self.n = len(bodies)
+
+    def add_convex_polyhedron(self, points, triangles=None) -> int:
+        """ro_add_convex_polyhedron; without triangles the hull comes from scipy (Qhull), wound outwards — the oracle has no hull code"""
+        pts = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
+        tris = hull_triangles(pts) if triangles is None else np.ascontiguousarray(triangles, np.uint32).reshape(-1, 3)
+        L = lib()
+        L.ro_add_convex_polyhedron.restype = C.c_int32
+        return int(L.ro_add_convex_polyhedron(C.c_void_p(self._w), C.c_int32(len(pts)), C.c_void_p(pts.ctypes.data), C.c_int32(len(tris)), C.c_void_p(tris.ctypes.data)))
+
+    def read_convex_polyhedron(self, pid: int) -> dict:
+        """the canonical form the oracle built (ro_polyhedron.h)"""
+        L = lib()
+        cnt = np.zeros(4, np.int32)
+        L.ro_read_convex_polyhedron(C.c_void_p(self._w), C.c_int32(pid), C.c_void_p(cnt.ctypes.data), None, None, None, None, None, None, None)
+        nv, nf, nl, ne = (int(x) for x in cnt)
+        pts, fn = np.zeros((nv, 3), np.float32), np.zeros((nf, 3), np.float32)
+        ff, fc, lv, le, props = np.zeros(nf, np.int32), np.zeros(nf, np.int32), np.zeros(nl, np.int32), np.zeros(nl, np.int32), np.zeros(20, np.float32)
+        L.ro_read_convex_polyhedron(C.c_void_p(self._w), C.c_int32(pid), C.c_void_p(cnt.ctypes.data), C.c_void_p(pts.ctypes.data), C.c_void_p(fn.ctypes.data),
+                                    C.c_void_p(ff.ctypes.data), C.c_void_p(fc.ctypes.data), C.c_void_p(lv.ctypes.data), C.c_void_p(le.ctypes.data), C.c_void_p(props.ctypes.data))
+        return dict(points=pts, face_normals=fn, face_first=ff, face_count=fc, loop_vertex=lv, loop_edge=le, n_edges=ne, props=props)
 
     def step(self, n: int = 1):
         lib().ro_step(self._w, n)

@@ -42,7 +42,7 @@ def test_shape_and_body_enums_agree_across_header_python_and_oracle():
     hdr = enum_values(os.path.join(ROOT, "include", "rapier_hip.h"), "RP_SHAPE")
     ora = enum_values(os.path.join(ROOT, "oracle", "rapier_oracle.h"), "RO_SHAPE")
     assert hdr == ora == {"BALL": S.SHAPE_BALL, "CUBOID": S.SHAPE_CUBOID, "CAPSULE": S.SHAPE_CAPSULE, "HALFSPACE": S.SHAPE_HALFSPACE,
-                          "CYLINDER": S.SHAPE_CYLINDER, "CONE": S.SHAPE_CONE}
+                          "CYLINDER": S.SHAPE_CYLINDER, "CONE": S.SHAPE_CONE, "CONVEX_POLYHEDRON": S.SHAPE_CONVEX_POLYHEDRON}
     hb = enum_values(os.path.join(ROOT, "include", "rapier_hip.h"), "RP_BODY")
     ob = enum_values(os.path.join(ROOT, "oracle", "rapier_oracle.h"), "RO_BODY")
     assert hb == ob and hb["DYNAMIC"] == S.BODY_DYNAMIC and hb["FIXED"] == S.BODY_FIXED and hb["KINEMATIC_POSITION"] == S.BODY_KINEMATIC_POSITION

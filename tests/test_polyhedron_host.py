@@ -1,0 +1,177 @@
+"""Convex polyhedra without a GPU: the product's host-side construction (rapier_amd/csrc/rp_polyhedron.h, compiled into a test shim with
+g++) against the oracle's (oracle/ro_polyhedron.h) and against Qhull (scipy) —
+
+  * convex_hull: same vertex set and volume as Qhull's hull, outward winding, closed;
+  * the canonical form (vertices, faces as loops, edges, normals, box, spheres, volume, centre of mass, inertia tensor): BIT-EQUAL between
+    product and oracle, and independent of how the faces were triangulated;
+  * closed forms: a box's volume / inertia, a tetrahedron's, Euler's formula;
+  * meshes the reference's builders refuse (flat, open, wound inwards) are refused;
+  * the oracle stepping worlds of polyhedra: rest heights, a box-shaped polyhedron behaves like the cuboid it is (same rest pose within
+    the solver's tolerance), everything stays on the ground."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from rapier_amd import scenes as S
+from oracle_ffi import OracleWorld, hull_triangles
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_SHIM = None
+
+
+def shim():
+    global _SHIM
+    if _SHIM is None:
+        out = os.path.join(ROOT, "tests", "_build", "libpoly_shim.so")
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        src = os.path.join(ROOT, "tests", "poly_shim.cpp")
+        hdr = os.path.join(ROOT, "rapier_amd", "csrc", "rp_polyhedron.h")
+        if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+            subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", out, src], check=True)
+        _SHIM = C.CDLL(out)
+    return _SHIM
+
+
+def product_hull(points):
+    pts = np.ascontiguousarray(points, np.float32)
+    out = np.zeros((4096, 3), np.uint32)
+    n = shim().shim_hull(C.c_int(len(pts)), C.c_void_p(pts.ctypes.data), C.c_void_p(out.ctypes.data), C.c_int(out.size))
+    return None if n < 0 else out[:n].copy()
+
+
+def product_build(points, tris):
+    pts = np.ascontiguousarray(points, np.float32); tris = np.ascontiguousarray(tris, np.uint32)
+    cnt = np.zeros(4, np.int32)
+    P, fn = np.zeros((256, 3), np.float32), np.zeros((2048, 3), np.float32)
+    ff, fc, lv, le, props = np.zeros(2048, np.int32), np.zeros(2048, np.int32), np.zeros(8192, np.int32), np.zeros(8192, np.int32), np.zeros(20, np.float32)
+    r = shim().shim_build(C.c_int(len(pts)), C.c_void_p(pts.ctypes.data), C.c_int(len(tris)), C.c_void_p(tris.ctypes.data), C.c_void_p(cnt.ctypes.data),
+                          *(C.c_void_p(a.ctypes.data) for a in (P, fn, ff, fc, lv, le, props)))
+    if r != 0:
+        return None
+    nv, nf, nl, ne = (int(x) for x in cnt)
+    return dict(points=P[:nv], face_normals=fn[:nf], face_first=ff[:nf], face_count=fc[:nf], loop_vertex=lv[:nl], loop_edge=le[:nl], n_edges=ne, props=props)
+
+
+def oracle_build(points, tris):
+    sc = S.Scene(name="poly")
+    o = OracleWorld(sc)
+    pid = o.add_convex_polyhedron(points, tris)
+    return None if pid < 0 else o.read_convex_polyhedron(pid)
+
+
+def _same(a, b):
+    assert a["n_edges"] == b["n_edges"]
+    for k in ("points", "face_normals", "face_first", "face_count", "loop_vertex", "loop_edge", "props"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
+BOX = np.array([[x, y, z] for x in (-.5, .5) for y in (-.3, .3) for z in (-.4, .4)], np.float32)
+
+
+def _clouds():
+    rng = np.random.default_rng(7)
+    yield "box", BOX + np.float32([0.2, 0.1, 0.0])
+    yield "tetra", np.float32([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]])
+    yield "prism", np.float32([[np.cos(a), h, np.sin(a)] for h in (-0.4, 0.6) for a in np.linspace(0, 2 * np.pi, 7)[:-1]])
+    yield "blob", (rng.standard_normal((40, 3)) * 0.4).astype(np.float32)
+    yield "blob_with_inner_points", np.concatenate([(rng.standard_normal((25, 3)) * 0.5).astype(np.float32), np.zeros((5, 3), np.float32) + np.float32([[0.01 * k, 0, 0] for k in range(5)])])
+    yield "sphere64", np.float32([[np.sin(t) * np.cos(p), np.cos(t), np.sin(t) * np.sin(p)] for t in np.linspace(0.3, np.pi - 0.3, 8) for p in np.linspace(0, 2 * np.pi, 9)[:-1]])
+
+
+@pytest.mark.parametrize("name,pts", list(_clouds()), ids=[n for n, _ in _clouds()])
+def test_product_hull_is_qhulls_hull(name, pts):
+    from scipy.spatial import ConvexHull
+    tris = product_hull(pts)
+    assert tris is not None
+    q = ConvexHull(pts.astype(np.float64))
+    assert set(np.unique(tris).tolist()) == set(q.vertices.tolist())              # the same extreme points
+    p = pts.astype(np.float64)
+    vol = sum(np.dot(p[a], np.cross(p[b], p[c])) for a, b, c in tris) / 6.0          # outward winding: a positive signed volume ...
+    assert abs(vol - q.volume) < 1e-6 * max(1.0, q.volume)                         # ... equal to the hull's
+    edges = {}
+    for a, b, c in tris.tolist():
+        for e in ((a, b), (b, c), (c, a)):
+            assert e not in edges
+            edges[e] = 1
+    assert all((b, a) in edges for (a, b) in edges)                               # closed: every directed edge has its twin
+
+
+@pytest.mark.parametrize("name,pts", list(_clouds()), ids=[n for n, _ in _clouds()])
+def test_canonical_form_equal_on_both_sides_and_independent_of_the_triangulation(name, pts):
+    t_product, t_qhull = product_hull(pts), hull_triangles(pts)
+    a, b = product_build(pts, t_product), oracle_build(pts, t_product)
+    assert a is not None and b is not None
+    _same(a, b)                                                                    # product == oracle, bit for bit
+    _same(a, product_build(pts, t_qhull))                                          # whichever way the faces were cut into triangles
+    _same(a, oracle_build(pts, t_qhull))
+    nv, nf, ne = len(a["points"]), len(a["face_normals"]), a["n_edges"]
+    assert nv - ne + nf == 2                                                       # Euler
+    for f in range(nf):                                                            # every loop is planar, convex and counter-clockwise about its normal
+        loop = a["loop_vertex"][a["face_first"][f]: a["face_first"][f] + a["face_count"][f]]
+        assert loop[0] == loop.min()
+        P = a["points"][loop].astype(np.float64); n = a["face_normals"][f].astype(np.float64)
+        assert np.abs((P - P[0]) @ n).max() < 1e-4
+        for k in range(len(loop)):
+            e0, e1 = P[(k + 1) % len(loop)] - P[k], P[(k + 2) % len(loop)] - P[(k + 1) % len(loop)]
+            assert np.cross(e0, e1) @ n > -1e-6
+        assert np.all(a["points"].astype(np.float64) @ n <= P[0] @ n + 1e-4)       # a supporting plane of the whole polyhedron
+
+
+def test_box_and_tetrahedron_closed_forms():
+    a = product_build(BOX + np.float32([0.2, 0.1, 0.0]), product_hull(BOX))
+    assert len(a["face_normals"]) == 6 and list(a["face_count"]) == [4] * 6 and a["n_edges"] == 12
+    p = a["props"]
+    np.testing.assert_allclose(p[0:3], (0.2, 0.1, 0.0), atol=1e-7); np.testing.assert_allclose(p[3:6], (0.5, 0.3, 0.4), atol=1e-7)
+    np.testing.assert_allclose(p[11], 1.0 * 0.6 * 0.8, rtol=1e-6); np.testing.assert_allclose(p[12:15], (0.2, 0.1, 0.0), atol=1e-6)
+    m = 0.48
+    np.testing.assert_allclose(p[15:18], (m * (0.6 ** 2 + 0.8 ** 2) / 12, m * (1.0 + 0.8 ** 2) / 12, m * (1.0 + 0.6 ** 2) / 12), rtol=1e-5)
+    np.testing.assert_allclose(p[18:20], 0.0, atol=1e-7)
+    t = product_build(np.float32([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]]), np.uint32([[0, 2, 1], [0, 1, 3], [0, 3, 2], [1, 2, 3]]))
+    np.testing.assert_allclose(t["props"][11], 1 / 6, rtol=1e-6); np.testing.assert_allclose(t["props"][12:15], 0.25, rtol=1e-6)
+    np.testing.assert_allclose(t["props"][15], 1 / 80, rtol=1e-5)                     # Ixx of the unit corner tetrahedron about its centroid (unit density): 3/80 * ... = 1/80
+    np.testing.assert_allclose(t["props"][18], 1 / 480, rtol=1e-4)                    # Ixy = -(-1/480)
+
+
+def test_meshes_the_builders_refuse():
+    flat = np.float32([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0], [0.3, 0.3, 0]])
+    assert product_hull(flat) is None                                              # no volume: convex_hull returns None
+    tet = np.float32([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]])
+    good = np.uint32([[0, 2, 1], [0, 1, 3], [0, 3, 2], [1, 2, 3]])
+    assert product_build(tet, good) is not None and oracle_build(tet, good) is not None
+    assert product_build(tet, good[:3]) is None and oracle_build(tet, good[:3]) is None          # open
+    assert product_build(tet, good[:, ::-1]) is None and oracle_build(tet, good[:, ::-1].copy()) is None   # wound inwards
+    assert product_build(tet, np.uint32([[0, 2, 1], [0, 1, 3], [0, 3, 2], [1, 2, 7]])) is None      # an index out of range
+
+
+def _ground(sc):
+    g = sc.add_body(body_type=S.BODY_FIXED, translation=(0, -0.5, 0)); sc.add_collider(g, half_extents=(10, 0.5, 10))
+
+
+def test_a_box_shaped_polyhedron_rests_like_the_cuboid_it_is():
+    sc = S.Scene(name="polybox", gravity=(0.0, -9.81, 0.0)); _ground(sc)
+    pid = sc.add_convex_polyhedron(BOX)
+    a = sc.add_body(translation=(-1.5, 1.0, 0.0), rotation=(0.0, 0.2, 0.0, 0.9797959)); sc.add_collider(a, shape=S.SHAPE_CONVEX, half_extents=(pid, 0, 0), density=2.0)
+    b = sc.add_body(translation=(1.5, 1.0, 0.0), rotation=(0.0, 0.2, 0.0, 0.9797959)); sc.add_collider(b, half_extents=(0.5, 0.3, 0.4), density=2.0)
+    o = OracleWorld(sc)
+    o.step(1)
+    _, v = o.read()
+    np.testing.assert_allclose(v[a], v[b], atol=1e-6)                               # same mass properties: same free fall
+    o.step(300)
+    p, v = o.read()
+    assert abs(p[a][1] - 0.3) < 2.5e-3 and abs(p[b][1] - 0.3) < 2.5e-3 and abs(v[a][1]) < 1e-2
+    o.apply_impulse(a, impulse=(0.0, 0.0, 0.0), torque_impulse=(0.0, 0.3, 0.0)); o.apply_impulse(b, impulse=(0.0, 0.0, 0.0), torque_impulse=(0.0, 0.3, 0.0))
+    _, v = o.read()
+    np.testing.assert_allclose(v[a][3:], v[b][3:], rtol=1e-4, atol=1e-6)            # same inertia about the vertical axis
+
+
+def test_clutter_of_polyhedra_settles_on_the_oracle():
+    sc = S.polyhedra_clutter(24, 2)
+    a, b = OracleWorld(sc), OracleWorld(sc)
+    a.step(400); b.step(400)
+    pa, va = a.read(); pb, _ = b.read()
+    np.testing.assert_array_equal(pa, pb)
+    dyn = [i for i, d in enumerate(sc.bodies) if int(d["body_type"]) == S.BODY_DYNAMIC]
+    assert np.isfinite(pa).all() and pa[dyn, 1].min() > 0.0 and pa[dyn, 1].max() < 3.5 and np.abs(pa[dyn][:, [0, 2]]).max() < 4.5

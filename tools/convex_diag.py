@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 from rapier_amd import PhysicsWorld, scenes as S  # noqa: E402
 from oracle_ffi import OracleWorld  # noqa: E402
 
-NAMES = {0: "ball", 1: "cuboid", 2: "capsule", 3: "halfspace", 4: "cylinder", 5: "cone"}
+NAMES = {0: "ball", 1: "cuboid", 2: "capsule", 3: "halfspace", 4: "cylinder", 5: "cone", 6: "polyhedron"}
 
 
 def rand_shape(rng, kind):
@@ -21,20 +21,26 @@ def rand_shape(rng, kind):
         he = tuple(float(x) for x in rng.uniform(.2, .7, 3)); return he, float(np.linalg.norm(he))
     if kind == S.SHAPE_CAPSULE:
         hh, r = float(rng.uniform(.2, .6)), float(rng.uniform(.1, .3)); return (hh, r, float(rng.integers(0, 3))), hh + r
+    if kind == S.SHAPE_CONVEX:
+        return None, 0.6       # (a fresh point cloud, registered by the caller)
     hh, r = float(rng.uniform(.2, .7)), float(rng.uniform(.15, .6)); return (hh, r, 0.0), float(np.hypot(hh, r))
 
 
 def micro(n_cases, seed):
     rng = np.random.default_rng(seed)
-    kinds = [S.SHAPE_BALL, S.SHAPE_CUBOID, S.SHAPE_CAPSULE, S.SHAPE_CYLINDER, S.SHAPE_CONE]
+    kinds = [S.SHAPE_BALL, S.SHAPE_CUBOID, S.SHAPE_CAPSULE, S.SHAPE_CYLINDER, S.SHAPE_CONE, S.SHAPE_CONVEX]
     stats = {}
     shown = 0
     for case in range(n_cases):
-        ka, kb = kinds[rng.integers(0, 5)], kinds[rng.integers(0, 5)]
+        ka, kb = kinds[rng.integers(0, 6)], kinds[rng.integers(0, 6)]
         if ka < S.SHAPE_CYLINDER and kb < S.SHAPE_CYLINDER:
             continue
         (hea, ra), (heb, rb) = rand_shape(rng, ka), rand_shape(rng, kb)
         sc = S.Scene(name="micro", gravity=(0.0, -2.0, 0.0))
+        if hea is None:
+            hea = (sc.add_convex_polyhedron((rng.standard_normal((int(rng.integers(6, 30)), 3)) * 0.3).astype(np.float32) + np.float32(rng.uniform(-0.1, 0.1, 3))), 0.0, 0.0)
+        if heb is None:
+            heb = (sc.add_convex_polyhedron((rng.standard_normal((int(rng.integers(6, 30)), 3)) * 0.3).astype(np.float32)), 0.0, 0.0)
         qa = rng.standard_normal(4); qa /= np.linalg.norm(qa)
         qb = rng.standard_normal(4); qb /= np.linalg.norm(qb)
         a = sc.add_body(body_type=S.BODY_FIXED if case % 3 else S.BODY_DYNAMIC, translation=(0.0, 0.0, 0.0), rotation=tuple(float(x) for x in qa))
@@ -72,7 +78,7 @@ def micro(n_cases, seed):
 
 
 def clutter(ground, steps):
-    sc = S.convex_clutter(40, 3, ground)
+    sc = S.polyhedra_clutter(28, 2) if ground == "polyhedra" else S.convex_clutter(40, 3, ground)
     g, o = PhysicsWorld.from_scene(sc), OracleWorld(sc)
     for step in range(steps):
         g.step(1); o.step(1)
@@ -97,4 +103,5 @@ if __name__ == "__main__":
     bad = micro(int(sys.argv[1]) if len(sys.argv) > 1 else 400, 1)
     for gr in ("cuboid", "cylinder", "halfspace"):
         bad += clutter(gr, 300)
+    bad += clutter("polyhedra", 300)
     print("TOTAL MISMATCHES", bad)
