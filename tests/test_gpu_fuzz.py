@@ -25,7 +25,7 @@ _CONVEX = [False]   # set by _scene(convex=True): cylinders and cones join the d
 
 
 def _rand_collider(rng, scale=1.0):
-    kind = rng.integers(0, 5 if _CONVEX[0] else 3)
+    kind = rng.integers(0, (5 + (1 if _CONVEX[0] > 1 else 0)) if _CONVEX[0] else 3)
     kw = dict(density=float(rng.uniform(0.5, 3.0)), friction=float(rng.choice([0.0, 0.3, 0.5, 1.0])),
               restitution=float(rng.choice([0.0, 0.0, 0.3, 0.8])), friction_rule=int(rng.integers(0, 6)), restitution_rule=int(rng.integers(0, 6)))
     if kind == 0:
@@ -34,6 +34,8 @@ def _rand_collider(rng, scale=1.0):
         return dict(shape=S.SHAPE_CUBOID, half_extents=tuple(float(x) * scale for x in rng.uniform(0.15, 0.6, size=3)), **kw)
     if kind == 3:
         return dict(shape=S.SHAPE_CYLINDER, half_extents=(float(rng.uniform(0.15, 0.5)) * scale, float(rng.uniform(0.15, 0.5)) * scale, 0.0), **kw)
+    if kind == 5:       # one of the polyhedra _scene registered (scaled shapes are not: a polyhedron has the size it was registered with)
+        return dict(shape=S.SHAPE_CONVEX, half_extents=(float(rng.integers(0, _CONVEX[0] - 1)), 0.0, 0.0), **kw)
     if kind == 4:
         return dict(shape=S.SHAPE_CONE, half_extents=(float(rng.uniform(0.2, 0.5)) * scale, float(rng.uniform(0.2, 0.45)) * scale, 0.0), **kw)
     return dict(shape=S.SHAPE_CAPSULE, half_extents=(float(rng.uniform(0.2, 0.6)) * scale, float(rng.uniform(0.15, 0.35)) * scale, float(rng.integers(0, 3))), **kw)
@@ -74,9 +76,11 @@ def _rand_joint(rng, sc, b1, b2, p1, p2):
 
 
 def _scene(seed, n=40, spread=3.5, per_layer=4, calm=False, convex=False):
-    _CONVEX[0] = bool(convex)
+    _CONVEX[0] = int(convex)       # 0: the three basic shapes, 1: + cylinders and cones, n > 1: + n - 1 registered convex polyhedra
     rng = np.random.default_rng(seed)
     sc = S.Scene(name=f"fuzz{seed}", gravity=(0.0, -9.81, 0.0))
+    for k in range(max(0, int(convex) - 1)):
+        sc.add_convex_polyhedron((np.random.default_rng(900 + k).standard_normal((10 + 6 * k, 3)) * (0.2 + 0.05 * k)).astype(np.float32) + np.float32([0.05 * k, 0.0, 0.0]))
     sc.params["friction_model"] = S.FRICTION_COULOMB if seed % 4 == 3 else S.FRICTION_SIMPLIFIED
     sc.params["warmstart_joints"] = int(seed % 3 == 1)
     g = sc.add_body(body_type=S.BODY_FIXED, translation=(0.0, -0.5, 0.0))
@@ -444,5 +448,24 @@ def test_fuzz_cylinders_and_cones_bit_exact(seed):
 def test_fuzz_cylinders_and_cones_on_the_oracle_twin(seed):
     try:
         _run(seed, steps=120, world=OracleTwin, convex=True)
+    finally:
+        _CONVEX[0] = False
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [50, 51, 52, 2013])
+def test_fuzz_convex_polyhedra_bit_exact(seed):
+    """... and with four registered convex polyhedra in the draw (shared between bodies, parts of compound bodies, attached to and
+    removed from live bodies)"""
+    try:
+        _run(seed, steps=200, params=seed >= 2000, convex=5)
+    finally:
+        _CONVEX[0] = False
+
+
+@pytest.mark.parametrize("seed", [50])
+def test_fuzz_convex_polyhedra_on_the_oracle_twin(seed):
+    try:
+        _run(seed, steps=120, world=OracleTwin, convex=5)
     finally:
         _CONVEX[0] = False
