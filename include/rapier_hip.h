@@ -72,7 +72,11 @@ enum { RP_SHAPE_BALL = 0, RP_SHAPE_CUBOID = 1,
        RP_SHAPE_CONE = 5 /* ColliderBuilder::cone(half_height, radius) (collider.rs:789): half_extents = (half_height, radius, -), base at
                             -half_height, apex at +half_height; its centre of mass sits a quarter of the height above the base */,
        RP_SHAPE_CONVEX_POLYHEDRON = 6 /* ColliderBuilder::convex_mesh / convex_hull (collider.rs:1039, :1070): half_extents[0] = the id
-                                         rp_convex_polyhedron_create returned (a whole number stored as a float) */ };
+                                         rp_convex_polyhedron_create returned (a whole number stored as a float) */,
+       /* ColliderBuilder::round_cuboid / round_cylinder / round_cone / round_convex_hull / round_convex_mesh (collider.rs:700-1090): the
+        * shape above dilated by a sphere of radius rp_collider_desc.border_radius (parry RoundShape<S>); half_extents as for the inner
+        * shape; mass properties are the inner shape's (RoundShape::mass_properties) */
+       RP_SHAPE_ROUND_CUBOID = 7, RP_SHAPE_ROUND_CYLINDER = 8, RP_SHAPE_ROUND_CONE = 9, RP_SHAPE_ROUND_CONVEX_POLYHEDRON = 10 };
 enum { RP_RULE_AVERAGE = 0, RP_RULE_MIN, RP_RULE_MULTIPLY, RP_RULE_MAX, RP_RULE_CLAMPED_SUM, RP_RULE_GEOMETRIC_MEAN };
 
 /* RigidBodyBuilder — /root/reference/src/dynamics/rigid_body.rs:1560-1900 */
@@ -111,6 +115,7 @@ typedef struct rp_collider_desc {
     int32_t sensor;                      /* ColliderBuilder::sensor(true) (collider.rs): the collider's pairs live in the intersection graph
                                           * (narrow_phase/intersections.rs:17-175): no contacts, no forces, no wake-ups, only Started / Stopped
                                           * collision events flagged RP_COLLISION_EVENT_SENSOR and rp_intersection_pairs_read */
+    float border_radius;                 /* RP_SHAPE_ROUND_*: RoundShape::border_radius (> 0); ignored for the other shapes */
 } rp_collider_desc;
 
 enum { RP_EVENTS_COLLISION = 1, RP_EVENTS_CONTACT_FORCE = 2 };

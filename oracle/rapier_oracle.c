@@ -89,6 +89,7 @@ typedef struct { v3 mins, maxs; } Aabb;
 typedef struct {
     int parent; pose pos_wrt_parent, pos;
     int shape; v3 he; float radius; int axis; /* capsule: he.x = half height, radius, axis */
+    float border;       /* round shapes (RO_SHAPE_ROUND_*): RoundShape::border_radius; 0 otherwise */
     const RoPolyhedron *poly; /* RO_SHAPE_CONVEX_POLYHEDRON: the registered polyhedron (recentred; the centre is folded into pos_wrt_parent) */
     int sensor;         /* ColliderBuilder::sensor(true): intersection events only, no contacts (oracle only so far) */
     float density, friction, restitution; int friction_rule, restitution_rule;
@@ -391,6 +392,8 @@ static void update_world_mass_properties(Body *b) {
 /* parry Shape::mass_properties (cuboid / ball / capsule), SURVEY Appendix C.  `frame` = principal inertia local frame of the
  * shape (identity except for capsules along X / Z: MassProperties::from_capsule rotates Y onto the segment direction). */
 static void ro_diagonalise(float a[3][3], float pi[3], float frame[4]);
+/* the inner shape of a round one (parry RoundShape<S>::inner_shape) */
+static int ro_core_shape(int shape) { return shape >= RO_SHAPE_ROUND_CUBOID ? (shape == RO_SHAPE_ROUND_CUBOID ? RO_SHAPE_CUBOID : shape - RO_SHAPE_ROUND_CYLINDER + RO_SHAPE_CYLINDER) : shape; }
 static void shape_mass_props(const Collider *c, float density, float *mass, v3 *principal_inertia, float frame[4], float com[3]) {
     frame[0] = 0.0f; frame[1] = 0.0f; frame[2] = 0.0f; frame[3] = 1.0f;
     com[0] = com[1] = com[2] = 0.0f;
@@ -454,7 +457,9 @@ static void shape_mass_props(const Collider *c, float density, float *mass, v3 *
     }
 }
 /* radius of the shape's local bounding sphere (centred on the collider origin) — Shape::compute_local_bounding_sphere */
-static float shape_bounding_radius(const Collider *c) {
+static float shape_bounding_radius_core(const Collider *c);
+static float shape_bounding_radius(const Collider *c) { float r = shape_bounding_radius_core(c); return c->border > 0.0f ? r + c->border : r; } /* RoundShape: the inner sphere + the border */
+static float shape_bounding_radius_core(const Collider *c) {
     if (c->shape == RO_SHAPE_CUBOID) return vlen(c->he);
     if (c->shape == RO_SHAPE_CAPSULE) return c->he.x + c->radius;
     if (c->shape == RO_SHAPE_HALFSPACE) return FLT_MAX;
@@ -629,7 +634,7 @@ static void recompute_mass_properties(ro_world *w, Body *b) {
         float radius = shape_bounding_radius(c);
         v3 centre = c->pos_wrt_parent.t;
         if (c->shape == RO_SHAPE_CONVEX_POLYHEDRON) { /* point_cloud_bounding_sphere: centred on the mean of the points */
-            centre = pose_tp(c->pos_wrt_parent, vsub(c->poly->sphere_centre, c->poly->centre)); radius = c->poly->sphere_radius;
+            centre = pose_tp(c->pos_wrt_parent, vsub(c->poly->sphere_centre, c->poly->centre)); radius = c->border > 0.0f ? c->poly->sphere_radius + c->border : c->poly->sphere_radius;
         }
         float extent = vlen(vsub(centre, b->local_com)) + radius;
         b->max_extent = ro_maxf(b->max_extent, extent);
@@ -641,6 +646,7 @@ static void recompute_mass_properties(ro_world *w, Body *b) {
         const Collider *c = &w->colliders[i];
         if (c->parent != body || !collider_enabled(c) || c->shape == RO_SHAPE_HALFSPACE) continue;
         float th = c->shape == RO_SHAPE_BALL ? c->radius : c->shape == RO_SHAPE_CAPSULE ? c->radius : ro_minf(c->he.x, ro_minf(c->he.y, c->he.z));
+        if (c->border > 0.0f) th = th + c->border; /* RoundShape::ccd_thickness = inner + border */
         b->ccd_thickness = ro_minf(b->ccd_thickness, th);
     }
     b->inv_mass = ro_inv(acc.mass);
@@ -715,7 +721,7 @@ int32_t ro_add_collider(ro_world *w, const ro_collider_desc *d, int32_t parent) 
     Collider *c = &w->colliders[idx];
     memset(c, 0, sizeof(*c));
     c->parent = parent;
-    c->shape = d->shape;
+    c->shape = ro_core_shape(d->shape); c->border = d->shape >= RO_SHAPE_ROUND_CUBOID ? d->border_radius : 0.0f; /* a round shape = its inner shape + a border radius */
     c->he = V3(d->half_extents[0], d->half_extents[1], d->half_extents[2]);
     c->radius = d->half_extents[0];
     if (c->shape == RO_SHAPE_CAPSULE) { c->radius = d->half_extents[1]; c->axis = (int)d->half_extents[2]; if (c->axis < 0 || c->axis > 2) c->axis = 1; }
@@ -878,6 +884,7 @@ static Aabb collider_collision_aabb(const Collider *c, float loosen) {
         v3 h = V3(c->radius, c->radius, c->radius);
         a.mins = vsub(c->pos.t, h); a.maxs = vadd(c->pos.t, h);
     }
+    if (c->border > 0.0f) { v3 bb = V3(c->border, c->border, c->border); a.mins = vsub(a.mins, bb); a.maxs = vadd(a.maxs, bb); } /* RoundShape::aabb = inner.aabb(pos).loosened(border_radius) */
     v3 l = V3(loosen, loosen, loosen);
     a.mins = vsub(a.mins, l); a.maxs = vadd(a.maxs, l);
     return a;
@@ -1136,6 +1143,7 @@ static float relative_pose_drift(pose base, pose cur, float max_extent) {
     return trans + chord;
 }
 static float collider_origin_radius(const Collider *c) {
+    if (c->border > 0.0f) return vlen(V3(c->he.x + c->border, c->he.y + c->border, c->he.z + c->border)); /* the inner local box loosened by the border */
     if (c->shape == RO_SHAPE_CUBOID || c->shape >= RO_SHAPE_CYLINDER) return vlen(c->he); /* max(|mins|,|maxs|) of the local AABB */
     if (c->shape == RO_SHAPE_CAPSULE) { v3 h = V3(c->radius, c->radius, c->radius); vset(&h, c->axis, c->he.x + c->radius); return vlen(h); }
     if (c->shape == RO_SHAPE_HALFSPACE) return INFINITY; /* |(MAX/2, MAX/2, MAX/2)| overflows: a pair with a half-space never recycles */
@@ -1206,7 +1214,7 @@ static int joints_disable_contacts(const ro_world *w, int b1, int b2) {
  * separating axis among 3 + 3 face normals and 9 edge cross products), a ball against a convex shape (solid point projection),
  * capsule-capsule (segment distance).  Cuboid-capsule goes through GJK in parry; here the distance from the capsule's segment to
  * the box is minimised over the segment parameter (a convex function: ternary search, 48 fixed iterations). */
-static SmShape sm_shape_of(const Collider *c) { SmShape s; s.shape = c->shape; s.he = c->he; s.radius = c->radius; s.axis = c->axis; s.poly = c->poly; return s; }
+static SmShape sm_shape_of(const Collider *c) { SmShape s; s.shape = c->shape; s.he = c->he; s.radius = c->radius; s.axis = c->axis; s.poly = c->poly; s.border = c->border; return s; }
 static float point_box_dist2(v3 p, v3 he) {
     float dx = ro_maxf(fabsf(p.x) - he.x, 0.0f), dy = ro_maxf(fabsf(p.y) - he.y, 0.0f), dz = ro_maxf(fabsf(p.z) - he.z, 0.0f);
     return dx * dx + dy * dy + dz * dz;
@@ -1214,10 +1222,10 @@ static float point_box_dist2(v3 p, v3 he) {
 static int shapes_intersect(const Collider *c1, const Collider *c2) {
     pose pos12 = pose_inv_mul(c1->pos, c2->pos);
     int s1 = c1->shape, s2 = c2->shape;
-    if (s1 >= RO_SHAPE_CYLINDER || s2 >= RO_SHAPE_CYLINDER) { /* cylinders, cones: GJK (intersection_test_support_map_support_map) */
+    if (s1 >= RO_SHAPE_CYLINDER || s2 >= RO_SHAPE_CYLINDER || c1->border > 0.0f || c2->border > 0.0f) { /* cylinders, cones, polyhedra, round shapes: GJK (intersection_test_support_map_support_map) */
         SmShape a = sm_shape_of(c1), b = sm_shape_of(c2);
-        if (s1 == RO_SHAPE_HALFSPACE) return vdot(c1->he, pose_tp(pos12, sm_support(&b, qrot_inv(pos12.r, vneg(c1->he))))) <= 0.0f;
-        if (s2 == RO_SHAPE_HALFSPACE) { pose pos21 = pose_inv(pos12); return vdot(c2->he, pose_tp(pos21, sm_support(&a, qrot_inv(pos21.r, vneg(c2->he))))) <= 0.0f; }
+        if (s1 == RO_SHAPE_HALFSPACE) return vdot(c1->he, pose_tp(pos12, sm_support(&b, qrot_inv(pos12.r, vneg(c1->he))))) - b.border <= 0.0f;
+        if (s2 == RO_SHAPE_HALFSPACE) { pose pos21 = pose_inv(pos12); return vdot(c2->he, pose_tp(pos21, sm_support(&a, qrot_inv(pos21.r, vneg(c2->he))))) - a.border <= 0.0f; }
         return sm_intersects(&a, &b, pos12);
     }
     if (s1 > s2) { /* order the pair: ball < cuboid < capsule < half-space */
@@ -1319,7 +1327,7 @@ static int process_pair(ro_world *w, int pair_idx, Transition *tr_out) {
 
     /* :323-330 parry DefaultQueryDispatcher::contact_manifolds */
     int s1 = co1->shape, s2 = co2->shape;
-    if (s1 >= RO_SHAPE_CYLINDER || s2 >= RO_SHAPE_CYLINDER) { /* cylinders, cones (ro_convex.h): same dispatcher order — ball arms, half-space arms, pfm_pfm */
+    if (s1 >= RO_SHAPE_CYLINDER || s2 >= RO_SHAPE_CYLINDER || co1->border > 0.0f || co2->border > 0.0f) { /* cylinders, cones, polyhedra, round shapes (ro_convex.h): same dispatcher order — ball arms, half-space arms, pfm_pfm */
         SmShape a = sm_shape_of(co1), b = sm_shape_of(co2);
         if (s2 == RO_SHAPE_BALL) manifold_sm_ball(pos12, &a, co2->radius, eff_prediction, &p->m, 0);
         else if (s1 == RO_SHAPE_BALL) manifold_sm_ball(pose_inv(pos12), &b, co1->radius, eff_prediction, &p->m, 1);
@@ -3316,7 +3324,7 @@ void ro_read_joints(const ro_world *w, int32_t *color, float *impulses3) {
 /* ---- hooks for tests/test_convex_oracle.py: the support-mapped queries of ro_convex.h on two shapes given like collider descriptors
  * (shape, half_extents) and the pose of shape 2 in the frame of shape 1 (translation xyz, rotation xyzw) ---- */
 static SmShape kat_shape(int32_t shape, const float he[3]) {
-    SmShape s; s.shape = shape; s.he = V3(he[0], he[1], he[2]); s.radius = he[0]; s.axis = 1; s.poly = NULL;
+    SmShape s; s.shape = shape; s.he = V3(he[0], he[1], he[2]); s.radius = he[0]; s.axis = 1; s.poly = NULL; s.border = 0.0f;
     if (shape == RO_SHAPE_CAPSULE) { s.radius = he[1]; s.axis = (int)he[2]; }
     if (shape == RO_SHAPE_CYLINDER || shape == RO_SHAPE_CONE) { s.radius = he[1]; s.he = V3(he[1], he[0], he[1]); }
     return s;

@@ -55,7 +55,10 @@ enum { RO_SHAPE_BALL = 0, RO_SHAPE_CUBOID = 1, RO_SHAPE_CAPSULE = 2 /* half_exte
        RO_SHAPE_HALFSPACE = 3 /* half_extents = the unit outward normal in the collider's frame: ColliderBuilder::halfspace */,
        RO_SHAPE_CYLINDER = 4 /* half_extents = (half_height, radius, -): ColliderBuilder::cylinder (collider.rs:770), axis Y */,
        RO_SHAPE_CONE = 5 /* half_extents = (half_height, radius, -): ColliderBuilder::cone (collider.rs:789), apex at +Y */,
-       RO_SHAPE_CONVEX_POLYHEDRON = 6 /* half_extents[0] = the id ro_add_convex_polyhedron returned: ColliderBuilder::convex_mesh / convex_hull (collider.rs:1039, :1070) */ };
+       RO_SHAPE_CONVEX_POLYHEDRON = 6 /* half_extents[0] = the id ro_add_convex_polyhedron returned: ColliderBuilder::convex_mesh / convex_hull (collider.rs:1039, :1070) */,
+       /* ColliderBuilder::round_cuboid / round_cylinder / round_cone / round_convex_hull (collider.rs:778-1080): the shape above dilated by a
+        * sphere of radius ro_collider_desc.border_radius (parry RoundShape<S>); half_extents as for the inner shape */
+       RO_SHAPE_ROUND_CUBOID = 7, RO_SHAPE_ROUND_CYLINDER = 8, RO_SHAPE_ROUND_CONE = 9, RO_SHAPE_ROUND_CONVEX_POLYHEDRON = 10 };
 /* CoefficientCombineRule — coefficient_combine_rule.rs:37-57 */
 enum { RO_RULE_AVERAGE = 0, RO_RULE_MIN = 1, RO_RULE_MULTIPLY = 2, RO_RULE_MAX = 3,
        RO_RULE_CLAMPED_SUM = 4, RO_RULE_GEOMETRIC_MEAN = 5 };
@@ -85,6 +88,8 @@ typedef struct ro_collider_desc {
     uint32_t collision_memberships, collision_filter; /* InteractionGroups */
     uint32_t active_events;                /* ActiveEvents: bit0 COLLISION_EVENTS, bit1 CONTACT_FORCE_EVENTS */
     float contact_force_event_threshold;   /* ColliderBuilder::contact_force_event_threshold */
+    int32_t sensor;                        /* (set through ro_set_collider_sensor; the field keeps the product's layout) */
+    float border_radius;                   /* round shapes: RoundShape::border_radius */
 } ro_collider_desc;
 
 /* JointMotor (dynamics/joint/generic_joint.rs:200-232); model: 0 = MotorModel::AccelerationBased, 1 = ForceBased */

@@ -75,10 +75,10 @@ static inline float ccd_point_dir(v3 dv, v3 *dir) { /* |dv| and its direction; a
  * n1, in the frame of 1, from 1 towards 2, along which it was measured.  A value <= 0 means "touching or overlapping". */
 static inline float ccd_separation(const CcdShape *s1, const CcdShape *s2, pose pos12, v3 *n1) {
     const pose pos21 = pose_inv(pos12);
-    if (s1->shape >= RO_SHAPE_CYLINDER || s2->shape >= RO_SHAPE_CYLINDER) { /* cylinders, cones: the exact distance of the cores by GJK (ro_convex.h) */
+    if (s1->shape >= RO_SHAPE_CYLINDER || s2->shape >= RO_SHAPE_CYLINDER || s1->border > 0.0f || s2->border > 0.0f) { /* cylinders, cones, polyhedra, round shapes: the exact distance of the cores by GJK (ro_convex.h) */
         if (s1->shape == RO_SHAPE_HALFSPACE) {
             *n1 = s1->he;
-            return vdot(s1->he, pose_tp(pos12, sm_support(s2, qrot_inv(pos12.r, vneg(s1->he)))));
+            return vdot(s1->he, pose_tp(pos12, sm_support(s2, qrot_inv(pos12.r, vneg(s1->he))))) - s2->border;
         }
         float d = sm_distance(s1, s2, pos12, n1);
         return d < 0.0f ? d : d - sm_border_radius(s1) - sm_border_radius(s2);
@@ -165,12 +165,12 @@ static inline float ccd_rot_radius(const CcdShape *s2, pose pos_wrt_parent, v3 l
         v3 e = qrot(pos_wrt_parent.r, vmul(capsule_axis_dir(s2->axis), s2->he.x));
         return ro_maxf(vlen(vsub(c, e)), vlen(vadd(c, e)));
     }
-    return vlen(c) + vlen(s2->he);
+    return (vlen(c) + vlen(s2->he)) + s2->border;
 }
 static inline float ccd_cast_pair(const CcdShape *s1, pose target_pose, const CcdShape *s2, pose pos_wrt_parent, const CcdSweep *sw,
                                   float rot_radius, float max_fraction, float slop) {
     /* the impact distance of the surfaces: max(slop, total_radius - slop) between the cores, minus the radii */
-    const float total_radius = ((s1->shape == RO_SHAPE_BALL || s1->shape == RO_SHAPE_CAPSULE) ? s1->radius : 0.0f) + ((s2->shape == RO_SHAPE_BALL || s2->shape == RO_SHAPE_CAPSULE) ? s2->radius : 0.0f);
+    const float total_radius = sm_border_radius(s1) + sm_border_radius(s2); /* balls, capsules, round shapes */
     const float target = ro_maxf(slop, total_radius - slop) - total_radius, tol = 0.25f * slop;
     const v3 D = vsub(sw->c1, sw->c0);
     const quat dq = qmul(sw->q1, qconj(sw->q0));

@@ -28,7 +28,8 @@
 
 /* he: cuboid half extents | capsule: he.x = half height, radius, axis | ball: radius | cylinder / cone (axis Y): he = (radius,
  * half_height, radius) — the half extents of the local AABB — and radius */
-typedef struct { int shape; v3 he; float radius; int axis; const RoPolyhedron *poly; /* RO_SHAPE_CONVEX_POLYHEDRON: he = the local AABB's half extents */ } SmShape;
+typedef struct { int shape; v3 he; float radius; int axis; const RoPolyhedron *poly; /* RO_SHAPE_CONVEX_POLYHEDRON: he = the local AABB's half extents */
+                 float border; /* a round shape (parry RoundShape<S>): `shape` is its inner shape, this its border radius */ } SmShape;
 
 #define RO_GJK_EPS_TOL 1.1920929e-6f          /* gjk::eps_tol() = 10 * f32::EPSILON */
 #define RO_EPA_EPS_TOL 1.1920929e-5f          /* 100 * f32::EPSILON */
@@ -39,7 +40,7 @@ typedef struct { int shape; v3 he; float radius; int axis; const RoPolyhedron *p
 #define RO_EPA_MAXE 48
 
 /* the part of a round shape that goes through GJK is its core (a ball's centre, a capsule's segment) */
-static inline float sm_border_radius(const SmShape *s) { return (s->shape == RO_SHAPE_BALL || s->shape == RO_SHAPE_CAPSULE) ? s->radius : 0.0f; }
+static inline float sm_border_radius(const SmShape *s) { return (s->shape == RO_SHAPE_BALL || s->shape == RO_SHAPE_CAPSULE) ? s->radius : s->border; }
 
 /* SupportMap::local_support_point of the core shape */
 static inline v3 sm_support(const SmShape *s, v3 d) {
@@ -649,13 +650,16 @@ static inline v3 sm_project_point(const SmShape *s, v3 pt, int *inside) {
 /* contact_manifold_convex_ball with shape1 = a cylinder / cone / convex polyhedron; flipped = the ball is collider 1 */
 static inline void manifold_sm_ball(pose pos12, const SmShape *s1, float r2, float prediction, Manifold *m, int flipped) {
     v3 pt = pos12.t;
-    if (s1->shape == RO_SHAPE_CONVEX_POLYHEDRON) {
-        /* ConvexPolyhedron::project_local_point = local_point_projection_on_support_map: GJK against the point, the polytope pass when
-         * the point is inside — the support-mapped contact query with the ball's centre as second shape */
-        SmShape centre; centre.shape = RO_SHAPE_BALL; centre.he = V3(0, 0, 0); centre.radius = 0.0f; centre.axis = 1; centre.poly = NULL;
+    if (s1->shape == RO_SHAPE_CONVEX_POLYHEDRON || s1->border > 0.0f) {
+        /* ConvexPolyhedron / RoundShape::project_local_point = local_point_projection_on_support_map: GJK against the point, the polytope
+         * pass when the point is inside — the support-mapped contact query with the ball's centre as second shape; a round shape's
+         * border moves the projection out along the normal */
+        SmShape centre; centre.shape = RO_SHAPE_BALL; centre.he = V3(0, 0, 0); centre.radius = 0.0f; centre.axis = 1; centre.poly = NULL; centre.border = 0.0f;
+        const float b1 = s1->border;
         v3 p1, p2, n1;
-        if (!sm_contact(s1, &centre, pos12, r2 + prediction, V3(0, 0, 0), &p1, &p2, &n1)) { m->npoints = 0; return; }
+        if (!sm_contact(s1, &centre, pos12, (r2 + prediction) + b1, V3(0, 0, 0), &p1, &p2, &n1)) { m->npoints = 0; return; }
         float dist = vdot(vsub(p2, p1), n1);
+        if (b1 != 0.0f) { p1 = vadd(p1, vmul(n1, b1)); dist = dist - b1; }
         if (dist <= r2 + prediction) {
             v3 n2 = qrot_inv(pos12.r, vneg(n1));
             v3 q2 = vmul(n2, r2);
@@ -689,16 +693,18 @@ static inline void manifold_halfspace_sm(pose pos12, v3 normal1, const SmShape *
     v3 normal1_2 = qrot_inv(pos12.r, normal1);
     PolyFeat f;
     sm_support_feature(s2, vneg(normal1_2), V3(0, 0, 0), &f);
+    const float border = s2->border;
     TrackedContact old[RO_MAX_MANIFOLD_PTS]; int nold = m->npoints;
     memcpy(old, m->points, sizeof(old));
     m->npoints = 0;
     for (int i = 0; i < f.nv; ++i) {
         v3 vtx2_1 = pose_tp(pos12, f.v[i]);
         float dist_to_plane = vdot(vtx2_1, normal1);
-        if (dist_to_plane <= prediction) {
+        if (dist_to_plane - border <= prediction) {
             v3 p1 = vsub(vtx2_1, vmul(normal1, dist_to_plane));
-            if (flipped) manifold_push(m, f.v[i], p1, f.vid[i], 0u, dist_to_plane);
-            else manifold_push(m, p1, f.v[i], 0u, f.vid[i], dist_to_plane);
+            v3 p2 = border != 0.0f ? vsub(f.v[i], vmul(normal1_2, border)) : f.v[i];
+            if (flipped) manifold_push(m, p2, p1, f.vid[i], 0u, dist_to_plane - border);
+            else manifold_push(m, p1, p2, 0u, f.vid[i], dist_to_plane - border);
         }
     }
     if (flipped) { m->local_n1 = vneg(normal1_2); m->local_n2 = normal1; }

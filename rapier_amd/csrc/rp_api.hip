@@ -477,6 +477,9 @@ extern "C" int32_t rp_num_bodies(const rp_world *w) { return w ? (int32_t)w->bod
 
 // parry Shape::mass_properties for cuboid / ball / capsule; frame = the shape's principal inertia local frame
 // (identity except for capsules along X / Z: MassProperties::from_capsule rotates Y onto the segment direction)
+// the inner shape of a round one (parry RoundShape<S>::inner_shape) and its border radius
+static int core_shape(int shape) { return shape >= RP_SHAPE_ROUND_CUBOID ? (shape == RP_SHAPE_ROUND_CUBOID ? RP_SHAPE_CUBOID : shape - RP_SHAPE_ROUND_CYLINDER + RP_SHAPE_CYLINDER) : shape; }
+static float shape_border(const rp_collider_desc &c) { return c.shape >= RP_SHAPE_ROUND_CUBOID ? c.border_radius : 0.0f; }
 // glam Quat::mul_vec3 (scalar path), the form the device and the checker use
 static void h_qrot(const float q[4], const float v[3], float out[3]) {
     const float bx = q[0], by = q[1], bz = q[2], w = q[3];
@@ -485,8 +488,13 @@ static void h_qrot(const float q[4], const float v[3], float out[3]) {
     const float k0 = w * w - b2, k1 = vb * 2.0f, k2 = w * 2.0f;
     out[0] = v[0] * k0 + bx * k1 + cx * k2; out[1] = v[1] * k0 + by * k1 + cy * k2; out[2] = v[2] * k0 + bz * k1 + cz * k2;
 }
-static float shape_bounding_radius(const rp_world *w, int ci) { // Shape::compute_local_bounding_sphere (about the collider origin)
-    const rp_collider_desc &c = w->colliders[ci];
+static float shape_bounding_radius_core(const rp_world *w, int ci);
+static float shape_bounding_radius(const rp_world *w, int ci) { // RoundShape: the inner sphere + the border
+    const float r = shape_bounding_radius_core(w, ci), b = shape_border(w->colliders[ci]);
+    return b > 0.0f ? r + b : r;
+}
+static float shape_bounding_radius_core(const rp_world *w, int ci) { // Shape::compute_local_bounding_sphere (about the collider origin)
+    rp_collider_desc c = w->colliders[ci]; c.shape = core_shape(c.shape);
     if (c.shape == RP_SHAPE_CONVEX_POLYHEDRON) return w->polys[w->collider_poly[ci]].origin_radius; // (the CCD pre-filter and the grid's cell size; max_extent uses the point cloud's own sphere)
     if (c.shape == RP_SHAPE_CUBOID) return std::sqrt(c.half_extents[0] * c.half_extents[0] + c.half_extents[1] * c.half_extents[1] + c.half_extents[2] * c.half_extents[2]);
     if (c.shape == RP_SHAPE_CAPSULE) return c.half_extents[0] + c.half_extents[1];
@@ -496,7 +504,7 @@ static float shape_bounding_radius(const rp_world *w, int ci) { // Shape::comput
 }
 static void hmp_diagonalise(float a[3][3], float pi[3], float frame[4]);
 static void shape_mass_props(const rp_world *w, int ci, float density, float &mass, float pi[3], float frame[4], float com[3]) {
-    const rp_collider_desc &c = w->colliders[ci];
+    rp_collider_desc c = w->colliders[ci]; c.shape = core_shape(c.shape); // (RoundShape::mass_properties = the inner shape's)
     frame[0] = 0.0f; frame[1] = 0.0f; frame[2] = 0.0f; frame[3] = 1.0f;
     com[0] = com[1] = com[2] = 0.0f;
     if (c.shape == RP_SHAPE_CONVEX_POLYHEDRON) { // MassProperties::from_convex_polyhedron -> with_inertia_matrix(com, volume * density, tensor * density)
@@ -717,7 +725,7 @@ static void recompute_mass(rp_world *w, int body) {
         const rp_collider_desc &c = w->colliders[i];
         float radius = shape_bounding_radius(w, i);
         float ctr[3] = {c.translation[0], c.translation[1], c.translation[2]};
-        if (c.shape == RP_SHAPE_CONVEX_POLYHEDRON) { // point_cloud_bounding_sphere: centred on the mean of the points
+        if (core_shape(c.shape) == RP_SHAPE_CONVEX_POLYHEDRON) { // point_cloud_bounding_sphere: centred on the mean of the points
             const HostPolyhedron &P = w->polys[w->collider_poly[i]];
             const float off[3] = {P.sphere_centre[0] - P.centre[0], P.sphere_centre[1] - P.centre[1], P.sphere_centre[2] - P.centre[2]};
             float qn = std::sqrt(c.rotation[0] * c.rotation[0] + c.rotation[1] * c.rotation[1] + c.rotation[2] * c.rotation[2] + c.rotation[3] * c.rotation[3]);
@@ -725,7 +733,7 @@ static void recompute_mass(rp_world *w, int body) {
             const float q[4] = {c.rotation[0] * qi, c.rotation[1] * qi, c.rotation[2] * qi, qn > 0.0f ? c.rotation[3] * qi : 1.0f};
             float r[3]; h_qrot(q, off, r);
             ctr[0] = r[0] + c.translation[0]; ctr[1] = r[1] + c.translation[1]; ctr[2] = r[2] + c.translation[2];
-            radius = P.sphere_radius;
+            radius = shape_border(c) > 0.0f ? P.sphere_radius + shape_border(c) : P.sphere_radius;
         }
         float dx = ctr[0] - b.lcom[0], dy = ctr[1] - b.lcom[1], dz = ctr[2] - b.lcom[2];
         float extent = std::sqrt(dx * dx + dy * dy + dz * dz) + radius;
@@ -738,7 +746,9 @@ static void recompute_mass(rp_world *w, int body) {
         if (w->collider_removed[i]) continue;
         const rp_collider_desc &c = w->colliders[i];
         if (c.shape == RP_SHAPE_HALFSPACE) continue; // Shape::ccd_thickness of a half-space is f32::MAX
-        float th = c.shape == RP_SHAPE_BALL ? c.half_extents[0] : c.shape == RP_SHAPE_CAPSULE ? c.half_extents[1] : (c.shape == RP_SHAPE_CYLINDER || c.shape == RP_SHAPE_CONE) ? std::min(c.half_extents[0], c.half_extents[1]) : std::min(c.half_extents[0], std::min(c.half_extents[1], c.half_extents[2]));
+        const int ck = core_shape(c.shape);
+        float th = ck == RP_SHAPE_BALL ? c.half_extents[0] : ck == RP_SHAPE_CAPSULE ? c.half_extents[1] : (ck == RP_SHAPE_CYLINDER || ck == RP_SHAPE_CONE) ? std::min(c.half_extents[0], c.half_extents[1]) : std::min(c.half_extents[0], std::min(c.half_extents[1], c.half_extents[2]));
+        if (shape_border(c) > 0.0f) th = th + shape_border(c); // RoundShape::ccd_thickness = inner + border
         b.ccd_thickness = std::min(b.ccd_thickness, th);
     }
 }
@@ -981,9 +991,10 @@ extern "C" int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider
     if (!w || n < 0 || (n > 0 && !descs)) return RP_ERR_INVALID;
     for (int i = 0; i < n; ++i) {
         const rp_collider_desc &cd = descs[i];
-        if (cd.shape < RP_SHAPE_BALL || cd.shape > RP_SHAPE_CONVEX_POLYHEDRON) { w->err = "rp_colliders_insert: unknown shape (ball, cuboid, capsule, half-space, cylinder, cone and convex polyhedron are implemented)"; return RP_ERR_INVALID; }
-        if (cd.shape == RP_SHAPE_CONVEX_POLYHEDRON && !(cd.half_extents[0] >= 0.0f && cd.half_extents[0] < (float)w->polys.size() && cd.half_extents[0] == std::floor(cd.half_extents[0]))) { w->err = "rp_colliders_insert: a convex polyhedron's half_extents[0] holds the id rp_convex_polyhedron_create returned"; return RP_ERR_INVALID; }
-        if ((cd.shape == RP_SHAPE_CYLINDER || cd.shape == RP_SHAPE_CONE) && !(cd.half_extents[0] > 0.0f && cd.half_extents[1] > 0.0f)) { w->err = "rp_colliders_insert: cylinder / cone half_extents = (half_height, radius, -), both positive"; return RP_ERR_INVALID; }
+        if (cd.shape < RP_SHAPE_BALL || cd.shape > RP_SHAPE_ROUND_CONVEX_POLYHEDRON) { w->err = "rp_colliders_insert: unknown shape (ball, cuboid, capsule, half-space, cylinder, cone, convex polyhedron and their round variants are implemented)"; return RP_ERR_INVALID; }
+        if (cd.shape >= RP_SHAPE_ROUND_CUBOID && !(cd.border_radius > 0.0f)) { w->err = "rp_colliders_insert: a round shape needs a positive border_radius"; return RP_ERR_INVALID; }
+        if (core_shape(cd.shape) == RP_SHAPE_CONVEX_POLYHEDRON && !(cd.half_extents[0] >= 0.0f && cd.half_extents[0] < (float)w->polys.size() && cd.half_extents[0] == std::floor(cd.half_extents[0]))) { w->err = "rp_colliders_insert: a convex polyhedron's half_extents[0] holds the id rp_convex_polyhedron_create returned"; return RP_ERR_INVALID; }
+        if ((core_shape(cd.shape) == RP_SHAPE_CYLINDER || core_shape(cd.shape) == RP_SHAPE_CONE) && !(cd.half_extents[0] > 0.0f && cd.half_extents[1] > 0.0f)) { w->err = "rp_colliders_insert: cylinder / cone half_extents = (half_height, radius, -), both positive"; return RP_ERR_INVALID; }
         if (cd.shape == RP_SHAPE_HALFSPACE) {
             const float *nn = cd.half_extents; const float l2 = nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2];
             if (!(std::fabs(l2 - 1.0f) <= 1.0e-3f)) { w->err = "rp_colliders_insert: a half-space's half_extents hold its unit outward normal"; return RP_ERR_INVALID; }
@@ -1021,7 +1032,7 @@ extern "C" int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider
         int ci;
         rp_collider_desc cd = descs[i];
         int poly = -1;
-        if (cd.shape == RP_SHAPE_CONVEX_POLYHEDRON) { // stored recentred on its local AABB: the centre rides in the collider's pose, half_extents = the box (rp_polyhedron.h)
+        if (core_shape(cd.shape) == RP_SHAPE_CONVEX_POLYHEDRON) { // stored recentred on its local AABB: the centre rides in the collider's pose, half_extents = the box (rp_polyhedron.h)
             poly = (int)cd.half_extents[0];
             const HostPolyhedron &P = w->polys[(size_t)poly];
             float qn = std::sqrt(cd.rotation[0] * cd.rotation[0] + cd.rotation[1] * cd.rotation[1] + cd.rotation[2] * cd.rotation[2] + cd.rotation[3] * cd.rotation[3]);
@@ -1185,9 +1196,9 @@ static ColliderRow pack_collider(const rp_world *w, int i) {
     o.lp = mk4(c.translation[0], c.translation[1], c.translation[2], 0);
     o.lr = mk4(c.rotation[0] * qi, c.rotation[1] * qi, c.rotation[2] * qi, qn > 0.0f ? c.rotation[3] * qi : 1.0f);
     o.he = mk4(c.half_extents[0], c.half_extents[1], c.half_extents[2], 0);
-    if (c.shape == RP_SHAPE_CYLINDER || c.shape == RP_SHAPE_CONE) o.he = mk4(c.half_extents[1], c.half_extents[0], c.half_extents[1], 0); // (radius, half_height, radius): the local AABB's half extents
-    if (c.shape == RP_SHAPE_CONVEX_POLYHEDRON) { int id = w->collider_poly[i]; memcpy(&o.he.w, &id, sizeof(int)); } // (half extents of the local box; w = the polyhedron's row in the cv_* tables, as bits)
-    o.mat = mk4(c.friction, c.restitution, c.density, 0);
+    if (core_shape(c.shape) == RP_SHAPE_CYLINDER || core_shape(c.shape) == RP_SHAPE_CONE) o.he = mk4(c.half_extents[1], c.half_extents[0], c.half_extents[1], 0); // (radius, half_height, radius): the local AABB's half extents
+    if (core_shape(c.shape) == RP_SHAPE_CONVEX_POLYHEDRON) { int id = w->collider_poly[i]; memcpy(&o.he.w, &id, sizeof(int)); } // (half extents of the local box; w = the polyhedron's row in the cv_* tables, as bits)
+    o.mat = mk4(c.friction, c.restitution, c.density, shape_border(c)); // (w: a round shape's border radius)
     o.rules.x = c.friction_rule; o.rules.y = c.restitution_rule;
     o.groups.x = w->collider_removed[i] ? 0u : c.collision_memberships; o.groups.y = w->collider_removed[i] ? 0u : c.collision_filter;
     // an "inverted" AABB: the first k_collider_update always rewrites it (and flags the broad phase)
@@ -1359,6 +1370,7 @@ static int finalize(rp_world *w) {
     if (!w->polys.empty()) { int r = upload_polyhedra(w); if (r != RP_OK) return r; } // (after the memset above: the cv_* pointers)
     d.gbar_blocks = gbar_grid_for_device(w->device);
     { const char *ni = getenv("RP_NO_BP_INCR"); d.bp_incremental = (ni && ni[0] == '1') ? 0 : 1; }
+    { const char *ab = getenv("RP_BP_ALWAYS_BUILD"); d.bp_always_build = (ab && ab[0] == '1') ? 1 : 0; }
     { const char *ig = getenv("RP_ISL_GENERIC"); d.isl_generic = (ig && ig[0] == '1') ? 1 : 0; }
     w->compound = world_has_compound_bodies(w); refresh_ccd_facts(w);
     int nb = (int)w->bodies.size(), nc = (int)w->colliders.size();

@@ -57,6 +57,9 @@ __device__ __forceinline__ CellRange cell_range_of(const DevWorld &w, float4 mn,
 // the stale list of round 3 (2,048 colliders, brute force, full rebuild when full: one pass in three on b3d_large_pyramid, five in
 // six on b3d_joint_grid) is gone.  A bucket that fills up, or a collider that changes cells for the 7th time since the last full
 // rebuild (3 version bits), clears FL_BP_GRID_OK: the next pass is a full rebuild, which starts every version from zero.
+// Which grid copy is in service: its own parity (lay_state[8]), not the pair tables' epoch — a full rebuild that finds the grid in order
+// (it follows the colliders, see above) keeps it and skips the build pass; lay_state[9] counts such rebuilds since the last build.
+#define BP_GPAR(w) ((w).lay_state[8] & 1)
 RP_DEV int bp_entry(int collider, int ordinal, int version) { return collider | (ordinal << 24) | ((version & 7) << 29); }
 RP_DEV bool bp_entry_is_cell(const DevWorld &w, int entry, int x, int y, int z) {
     const int j = entry & 0xffffff;
@@ -67,15 +70,15 @@ RP_DEV bool bp_entry_is_cell(const DevWorld &w, int entry, int x, int y, int z) 
 }
 RP_DEV void bp_grid_follow(const DevWorld &w, int i, float4 omn, float4 omx) {
     if (!w.bp_incremental || !w.flags[FL_BP_GRID_OK]) return; // no grid in service / a full rebuild is due anyway
-    if (w.c_inlarge[i]) return;                                // on the large list: the incremental pass leaves it to the full rebuild
+    if (w.c_inlarge[i]) { w.flags[FL_BP_FORCE_FULL] = 1; return; } // on the large list: only a rebuild WITH its build pass renews that list
     const CellRange o = cell_range_of(w, omn, omx), r = cell_range(w, i);
-    if (r.large) return;                                       // (likewise)
+    if (r.large) { w.flags[FL_BP_FORCE_FULL] = 1; return; }        // (likewise)
     const bool valid_before = omn.x <= omx.x && omn.y <= omx.y && omn.z <= omx.z; // (a freshly inserted collider has an empty box and no entry)
     if (valid_before && !o.large && o.lo[0] == r.lo[0] && o.lo[1] == r.lo[1] && o.lo[2] == r.lo[2] && o.hi[0] == r.hi[0] && o.hi[1] == r.hi[1] && o.hi[2] == r.hi[2]) return;
     const int ver = w.c_rver[i] + 1;
     w.c_rver[i] = ver;
     if (ver >= 8) { w.flags[FL_BP_GRID_OK] = 0; return; }      // the 3 version bits would wrap onto entries still in the buckets
-    const int cur = w.flags[FL_BP_EPOCH] & 1;
+    const int cur = BP_GPAR(w);
     int *cnt = w.bk_cnt[cur]; int *items = w.bk_items[cur];
     int ord = 0;
     for (int z = r.lo[2]; z <= r.hi[2]; ++z)
@@ -271,10 +274,9 @@ __device__ void bp_insert_pair(DevWorld &w, int c1, int c2, bool incremental = f
 // chain of ~100 dependent L2 round trips, 150 us of the 213 us rebuild on b3d_large_pyramid (tools/pass_profile.py); a whole
 // wavefront per collider does not fit the resident grid of a barrier kernel (16 rounds: slower).
 #define BP_GROUP 8
-RP_DEV void bp_pairs(DevWorld &w, int nxt) {
+RP_DEV void bp_pairs(DevWorld &w, int nxt, int nl) { // nl: the large list that goes with grid copy `nxt` (just built: scan_block's count; kept: FL_N_LARGE)
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, sub = tid & (BP_GROUP - 1), ngroups = (gridDim.x * blockDim.x) / BP_GROUP;
     const float ic = w.prm.inv_cell_size;
-    int nl = w.scan_block[BP_LARGE_SCRATCH]; // (the build pass is complete: geometric large colliders + the ones a full bucket sent here)
     if (nl > w.large_cap) nl = w.large_cap;
     const int *cnt = w.bk_cnt[nxt]; const int *items = w.bk_items[nxt];
     for (int i = tid / BP_GROUP; i < w.n_colliders; i += ngroups) {
@@ -354,7 +356,7 @@ RP_DEV void bp_delete_pair(DevWorld &w, int s) {
 }
 
 // DeletePair of a rebuild: slots not re-stamped by it are dead.
-RP_DEV void bp_finish_pairs(DevWorld &w, int gid, int gstride) {
+RP_DEV void bp_finish_pairs(DevWorld &w, int gid, int gstride, bool keep_grid, int gcur) {
     int epoch = w.flags[FL_BP_EPOCH];
     int top = w.flags[FL_POOL_TOP];
     if (top > w.pool_cap) top = w.pool_cap;
@@ -364,9 +366,9 @@ RP_DEV void bp_finish_pairs(DevWorld &w, int gid, int gstride) {
         bp_delete_pair(w, s);
     }
     // rest state for the next rebuild: the grid copy and the pair table that go out of service (they become the next rebuild's targets)
-    { int *old = w.bk_cnt[epoch & 1]; for (int i = gid; i < w.grid_cap; i += gstride) old[i] = 0; }
+    if (!keep_grid) { int *old = w.bk_cnt[gcur]; for (int i = gid; i < w.grid_cap; i += gstride) old[i] = 0; }
     { unsigned long long *old = w.h_key[epoch & 1]; for (int i = gid; i < w.hash_cap; i += gstride) old[i] = RP_EMPTY_KEY; }
-    if (gid == 0) { // the new large list goes into service with the new grid
+    if (gid == 0 && !keep_grid) { // the new large list goes into service with the new grid
         const int nl = w.scan_block[BP_LARGE_SCRATCH];
         w.flags[FL_N_LARGE] = nl < w.large_cap ? nl : w.large_cap;
         w.scan_block[BP_LARGE_SCRATCH] = 0;
@@ -408,7 +410,7 @@ RP_DEV void bp_incr_insert(DevWorld &w, int nchg) {
             const int x = r.lo[0] + lane % nx, y = r.lo[1] + (lane / nx) % ny, z = r.lo[2] + lane / (nx * ny);
             unsigned long long key = cell_key(x, y, z);
             int h = (int)(rp_hash64(key) & (unsigned long long)(w.grid_cap - 1));
-            const int cur = w.flags[FL_BP_EPOCH] & 1; // the grid copy in service
+            const int cur = BP_GPAR(w); // the grid copy in service
             int n = w.bk_cnt[cur][h]; if (n > RP_BP_BUCKET) n = RP_BP_BUCKET;
             for (int e = 0; e < n; ++e) {
                 const int it = w.bk_items[cur][(size_t)h * RP_BP_BUCKET + e], j = it & 0xffffff;
@@ -452,7 +454,7 @@ __global__ void __launch_bounds__(1024) k_bp_rebuild(DevWorld w) {
     // (an incremental pass spends a wavefront per changed collider, the full rebuild eight lanes per collider: beyond a quarter of the
     // colliders the rebuild is the cheaper one — measured on b3d_joint_grid, where 3,559 of 10,000 change per pass: 36 us as a rebuild)
     const int nchg = w.flags[FL_BP_NCHG] < w.n_colliders ? w.flags[FL_BP_NCHG] : w.n_colliders;
-    const bool incremental = w.bp_incremental && w.flags[FL_BP_GRID_OK] && nchg > 0 && nchg <= w.n_colliders / 4 + 16 && w.flags[FL_BP_TOMBS] < w.hash_cap / 8;
+    const bool incremental = w.bp_incremental && w.flags[FL_BP_GRID_OK] && !w.flags[FL_BP_FORCE_FULL] && nchg > 0 && nchg <= w.n_colliders / 4 + 16 && w.flags[FL_BP_TOMBS] < w.hash_cap / 8;
     GridBar bar = gbar_begin(w, 0);
 #ifdef RP_PASS_PROFILE // why a pass was (not) incremental: dbg[240..] (tools/pass_profile.py)
     if (gid == 0) {
@@ -476,19 +478,30 @@ __global__ void __launch_bounds__(1024) k_bp_rebuild(DevWorld w) {
         // a large collider moved: the pairs inserted so far are found again (and re-stamped) by the rebuild below
     }
     const int epoch = w.flags[FL_BP_EPOCH];
+    // Round 4: the grid in service follows every collider (bp_grid_follow), so a rebuild of the PAIR SET — what a step needs when many fat
+    // AABBs were rewritten — can read it as it stands: build | pairs | finish becomes pairs | finish.  The build pass (which also renews
+    // the large list and compacts the buckets: entries of left cell ranges die with it) runs when the grid is not in order, when a
+    // large collider moved, and every 32nd rebuild.  (Scalars read here only change behind this launch's barriers or in the launch before.)
+    const int gcur = BP_GPAR(w);
+    const bool keep_grid = w.bp_incremental && w.flags[FL_BP_GRID_OK] && !w.flags[FL_BP_FORCE_FULL] && w.lay_state[9] < 32 && !w.bp_always_build;
     RP_PASS_BEGIN();
-    bp_build(w, gid, gstride, (epoch & 1) ^ 1);
+    if (!keep_grid) { bp_build(w, gid, gstride, gcur ^ 1); GBAR_SYNC(bar); }
+    RP_PASS_STAMP(w, 220);
+    bp_pairs(w, keep_grid ? gcur : gcur ^ 1, keep_grid ? w.flags[FL_N_LARGE] : w.scan_block[BP_LARGE_SCRATCH]);
     GBAR_SYNC(bar); RP_PASS_STAMP(w, 220);
-    bp_pairs(w, (epoch & 1) ^ 1);
-    GBAR_SYNC(bar); RP_PASS_STAMP(w, 220);
-    bp_finish_pairs(w, gid, gstride);
+    bp_finish_pairs(w, gid, gstride, keep_grid, gcur);
     GBAR_SYNC(bar); RP_PASS_STAMP(w, 220);
     gbar_end(bar);
     if (gid == 0) { // the rebuild is closed: epoch flip, dirty flag; the grid is valid and nobody is stale
         w.flags[FL_BP_EPOCH] = epoch + 1;
         w.flags[FL_BP_REBUILDS] += 1;
-        w.flags[FL_BP_NCHG] = 0; w.flags[FL_BP_NMOVED] = 0; w.flags[FL_BP_TOMBS] = 0; w.flags[FL_BP_FORCE_FULL] = 0; w.flags[FL_BP_SEQ] += 1;
-        w.flags[FL_BP_GRID_OK] = (w.flags[FL_OVERFLOW] & (RP_OVF_CELLS | RP_OVF_LARGE)) ? 0 : 1;
+        w.flags[FL_BP_NCHG] = 0; w.flags[FL_BP_TOMBS] = 0; w.flags[FL_BP_FORCE_FULL] = 0; w.flags[FL_BP_SEQ] += 1;
+        if (keep_grid) w.lay_state[9] += 1;
+        else {
+            w.lay_state[8] = gcur ^ 1; w.lay_state[9] = 0;
+            w.flags[FL_BP_NMOVED] = 0;
+            w.flags[FL_BP_GRID_OK] = (w.flags[FL_OVERFLOW] & (RP_OVF_CELLS | RP_OVF_LARGE)) ? 0 : 1;
+        }
         __hip_atomic_store(&w.flags[FL_BP_DIRTY], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }

@@ -39,7 +39,12 @@ RP_DEV Pose ccd_sweep_transform_at(const CcdSweep &s, float t) {
 // a collider's shape as the query sees it (c_shape / c_he of rp_world.h): he = cuboid half extents | half-space normal; capsule:
 // he.x = half height, radius, axis; ball: radius
 typedef SmShape CcdShape; // (rp_convex.h: the same record serves the support-mapped queries)
-RP_DEV CcdShape ccd_shape_of(const DevWorld &w, int sh, float4 he) { return sm_shape_of(w, sh, he); }
+template <bool CONVEX> RP_DEV CcdShape ccd_shape_of(const DevWorld &w, int c) { // collider c as the query sees it (round shapes only exist in CONVEX worlds)
+    const int sh = w.c_shape[c];
+    float border = 0.0f;
+    if constexpr (CONVEX) { if (sh >= RP_SHAPE_ROUND_CUBOID) border = w.c_mat[c].w; }
+    return sm_shape_of(w, sh, w.c_he[c], border);
+}
 RP_DEV V3 ccd_clamp_box(V3 p, V3 he) { return v3(rp_clamp(p.x, -he.x, he.x), rp_clamp(p.y, -he.y, he.y), rp_clamp(p.z, -he.z, he.z)); }
 RP_DEV float ccd_point_dir(V3 dv, V3 &dir) {
     float dist = len(dv);
@@ -52,10 +57,10 @@ RP_DEV float ccd_point_box(V3 p, V3 he, V3 &dir) { return ccd_point_dir(p - ccd_
 template <bool CONVEX> __device__ float ccd_separation(const CcdShape &s1, const CcdShape &s2, Pose pos12, V3 &n1) {
     const Pose pos21 = pose_inv(pos12);
     if constexpr (CONVEX) {
-        if (s1.shape >= RP_SHAPE_CYLINDER || s2.shape >= RP_SHAPE_CYLINDER) { // cylinders, cones: the exact distance of the cores by GJK
+        if (s1.shape >= RP_SHAPE_CYLINDER || s2.shape >= RP_SHAPE_CYLINDER || s1.border > 0.0f || s2.border > 0.0f) { // cylinders, cones, polyhedra, round shapes: the exact distance of the cores by GJK
             if (s1.shape == RP_SHAPE_HALFSPACE) {
                 n1 = s1.he;
-                return dot(s1.he, pose_tp(pos12, sm_support(s2, qrot_inv(pos12.r, -s1.he))));
+                return dot(s1.he, pose_tp(pos12, sm_support(s2, qrot_inv(pos12.r, -s1.he)))) - s2.border;
             }
             float d = sm_distance(s1, s2, pos12, n1);
             return d < 0.0f ? d : d - sm_border_radius(s1) - sm_border_radius(s2);
@@ -138,11 +143,11 @@ RP_DEV float ccd_rot_radius(const CcdShape &s2, Pose pos_wrt_parent, V3 local_co
         V3 e = qrot(pos_wrt_parent.r, capsule_axis_dir(s2.axis) * s2.he.x);
         return rp_max(len(c - e), len(c + e));
     }
-    return len(c) + len(s2.he);
+    return (len(c) + len(s2.he)) + s2.border;
 }
 template <bool CONVEX> __device__ float ccd_cast_pair(const CcdShape &s1, Pose target_pose, const CcdShape &s2, Pose pos_wrt_parent, const CcdSweep &sw, float rot_radius,
                                float max_fraction, float slop) {
-    const float total_radius = ((s1.shape == RP_SHAPE_BALL || s1.shape == RP_SHAPE_CAPSULE) ? s1.radius : 0.0f) + ((s2.shape == RP_SHAPE_BALL || s2.shape == RP_SHAPE_CAPSULE) ? s2.radius : 0.0f);
+    const float total_radius = sm_border_radius(s1) + sm_border_radius(s2); // balls, capsules, round shapes
     const float target = rp_max(slop, total_radius - slop) - total_radius, tol = 0.25f * slop;
     const V3 D = sw.c1 - sw.c0;
     const Q4 dq = qmul(sw.q1, qconj(sw.q0));
@@ -170,7 +175,13 @@ RP_DEV bool ccd_may_reach(V3 c0, V3 c1, float max_extent, V3 target_centre, floa
     float reach = (max_extent + target_radius) + margin;
     return len2(target_centre - p) <= reach * reach;
 }
-RP_DEV float ccd_bounding_radius(const DevWorld &w, int sh, float4 he) { // Shape::compute_local_bounding_sphere
+RP_DEV float ccd_bounding_radius_core(const DevWorld &w, int sh, float4 he);
+RP_DEV float ccd_bounding_radius(const DevWorld &w, int c) { // Shape::compute_local_bounding_sphere of collider c (RoundShape: the inner sphere + the border)
+    const int sh = w.c_shape[c];
+    const float r = ccd_bounding_radius_core(w, sm_core_shape(sh), w.c_he[c]);
+    return sh >= RP_SHAPE_ROUND_CUBOID ? r + w.c_mat[c].w : r;
+}
+RP_DEV float ccd_bounding_radius_core(const DevWorld &w, int sh, float4 he) {
     if (sh == RP_SHAPE_CUBOID) return len(v3(he));
     if (sh == RP_SHAPE_CAPSULE) return he.x + he.y;
     if (sh == RP_SHAPE_CONVEX_POLYHEDRON) return w.cv_pts[w.cv_hdr[__float_as_int(he.w)].x].w; // max |vertex| (every point row of the shape carries it)
@@ -235,7 +246,7 @@ template <bool CONVEX> __global__ void __launch_bounds__(256) k_ccd(DevWorld w, 
           for (int f = 0; f < CCD_MAX_FAST_COLLIDERS; ++f) {
             const int c1 = fast[f];
             if (c1 < 0) continue; // (uniform over the workgroup)
-            const CcdShape s2 = ccd_shape_of(w, w.c_shape[c1], w.c_he[c1]);
+            const CcdShape s2 = ccd_shape_of<CONVEX>(w, c1);
             Pose pwp; pwp.t = v3(w.c_lpos[c1]); pwp.r = q4(w.c_lrot[c1]);
             const float rot_radius = ccd_rot_radius(s2, pwp, lcom);
             const uint2 g1 = w.c_groups[c1];
@@ -252,8 +263,8 @@ template <bool CONVEX> __global__ void __launch_bounds__(256) k_ccd(DevWorld w, 
                 Pose tp = collider_world_pose(w, c2); // target_collider_pose (:97-102): bodies already stand at their end-of-step pose
                 const int sh2 = w.c_shape[c2];
                 const float4 he2 = w.c_he[c2];
-                if (sh2 != RP_SHAPE_HALFSPACE && !ccd_may_reach(sw.c0, sw.c1, max_extent, tp.t, ccd_bounding_radius(w, sh2, he2), 2.0f * slop)) continue;
-                const CcdShape s1 = ccd_shape_of(w, sh2, he2);
+                if (sh2 != RP_SHAPE_HALFSPACE && !ccd_may_reach(sw.c0, sw.c1, max_extent, tp.t, ccd_bounding_radius(w, c2), 2.0f * slop)) continue;
+                const CcdShape s1 = ccd_shape_of<CONVEX>(w, c2);
                 const float cur = __uint_as_float(__hip_atomic_load(&best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                 const float hit = ccd_cast_pair<CONVEX>(s1, tp, s2, pwp, sw, rot_radius, cur, slop);
                 if (hit > 0.0f && hit < cur) atomicMin(&best, __float_as_uint(hit));

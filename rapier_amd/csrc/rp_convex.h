@@ -29,9 +29,12 @@
 // he = (radius, half_height, radius) = the half extents of the local AABB
 // a convex polyhedron (c_he = its local box's half extents, w = its row in cv_hdr as bits): points, face normals, per face {first loop
 // entry, entries}, loop entries {vertex, edge} — pointers into the world's cv_* tables
-struct SmShape { int shape; V3 he; float radius; int axis; const float4 *pts; const float4 *fn; const int2 *fl; const int2 *loop; int npts, nfaces; };
-RP_DEV SmShape sm_shape_of(const DevWorld &w, int sh, float4 he) {
-    SmShape s; s.shape = sh; s.he = v3(he); s.axis = 1;
+// a round shape (RP_SHAPE_ROUND_*, parry RoundShape<S>): `shape` is its inner shape, `border` its border radius (c_mat.w)
+struct SmShape { int shape; V3 he; float radius; int axis; const float4 *pts; const float4 *fn; const int2 *fl; const int2 *loop; int npts, nfaces; float border; };
+RP_DEV int sm_core_shape(int sh) { return sh >= RP_SHAPE_ROUND_CUBOID ? (sh == RP_SHAPE_ROUND_CUBOID ? RP_SHAPE_CUBOID : sh - RP_SHAPE_ROUND_CYLINDER + RP_SHAPE_CYLINDER) : sh; }
+RP_DEV SmShape sm_shape_of(const DevWorld &w, int sh_in, float4 he, float border_in) {
+    const int sh = sm_core_shape(sh_in);
+    SmShape s; s.shape = sh; s.he = v3(he); s.axis = 1; s.border = sh_in >= RP_SHAPE_ROUND_CUBOID ? border_in : 0.0f;
     s.radius = sh == RP_SHAPE_CAPSULE ? he.y : he.x;
     if (sh == RP_SHAPE_CAPSULE) s.axis = (int)he.z;
     s.pts = nullptr; s.fn = nullptr; s.fl = nullptr; s.loop = nullptr; s.npts = 0; s.nfaces = 0;
@@ -43,10 +46,10 @@ RP_DEV SmShape sm_shape_of(const DevWorld &w, int sh, float4 he) {
 }
 RP_DEV SmShape sm_point_shape() { // a ball's centre as second shape of a query
     SmShape s; s.shape = RP_SHAPE_BALL; s.he = v3(0, 0, 0); s.radius = 0.0f; s.axis = 1;
-    s.pts = nullptr; s.fn = nullptr; s.fl = nullptr; s.loop = nullptr; s.npts = 0; s.nfaces = 0;
+    s.pts = nullptr; s.fn = nullptr; s.fl = nullptr; s.loop = nullptr; s.npts = 0; s.nfaces = 0; s.border = 0.0f;
     return s;
 }
-RP_DEV float sm_border_radius(const SmShape &s) { return (s.shape == RP_SHAPE_BALL || s.shape == RP_SHAPE_CAPSULE) ? s.radius : 0.0f; }
+RP_DEV float sm_border_radius(const SmShape &s) { return (s.shape == RP_SHAPE_BALL || s.shape == RP_SHAPE_CAPSULE) ? s.radius : s.border; }
 
 // SupportMap::local_support_point of the core shape (a ball's centre, a capsule's segment)
 __device__ V3 sm_support(const SmShape &s, V3 d) {
@@ -623,11 +626,13 @@ __device__ V3 sm_project_point(const SmShape &s, V3 pt, bool &inside) {
 // contact_manifold_convex_ball with shape1 = a cylinder / cone; flipped = the ball is collider 1
 __device__ void manifold_sm_ball(Pose pos12, const SmShape &s1, float r2, float prediction, LocalManifold &m, bool flipped) {
     V3 pt = pos12.t;
-    if (s1.shape == RP_SHAPE_CONVEX_POLYHEDRON) { // ConvexPolyhedron::project_local_point = GJK / polytope pass against the point
+    if (s1.shape == RP_SHAPE_CONVEX_POLYHEDRON || s1.border > 0.0f) { // ConvexPolyhedron / RoundShape::project_local_point = GJK / polytope pass against the point
         const SmShape centre = sm_point_shape();
+        const float b1 = s1.border;
         V3 p1, p2, n1;
-        if (!sm_contact(s1, centre, pos12, r2 + prediction, v3(0, 0, 0), p1, p2, n1)) { m.n = 0; return; }
+        if (!sm_contact(s1, centre, pos12, (r2 + prediction) + b1, v3(0, 0, 0), p1, p2, n1)) { m.n = 0; return; }
         float dist = dot(p2 - p1, n1);
+        if (b1 != 0.0f) { p1 = p1 + n1 * b1; dist = dist - b1; }
         if (dist <= r2 + prediction) {
             V3 n2 = qrot_inv(pos12.r, -n1);
             V3 q2 = n2 * r2;
@@ -649,16 +654,18 @@ __device__ void manifold_halfspace_sm(Pose pos12, V3 normal1, const SmShape &s2,
     V3 normal1_2 = qrot_inv(pos12.r, normal1);
     PolyFeat f;
     sm_support_feature(s2, -normal1_2, v3(0, 0, 0), f);
+    const float border = s2.border;
     int nold = m.n;
     for (int i = 0; i < nold; ++i) m.old_fid_set(i, m.fid[i]);
     m.n = 0;
     for (int i = 0; i < f.nv; ++i) {
         V3 vtx2_1 = pose_tp(pos12, f.v[i]);
         float dist_to_plane = dot(vtx2_1, normal1);
-        if (dist_to_plane <= prediction) {
+        if (dist_to_plane - border <= prediction) {
             V3 q1 = vtx2_1 - normal1 * dist_to_plane;
-            if (flipped) lm_push(m, f.v[i], q1, f.vid[i], 0u, dist_to_plane);
-            else lm_push(m, q1, f.v[i], 0u, f.vid[i], dist_to_plane);
+            V3 q2 = border != 0.0f ? f.v[i] - normal1_2 * border : f.v[i];
+            if (flipped) lm_push(m, q2, q1, f.vid[i], 0u, dist_to_plane - border);
+            else lm_push(m, q1, q2, 0u, f.vid[i], dist_to_plane - border);
         }
     }
     if (flipped) { m.ln1 = -normal1_2; m.ln2 = normal1; } else { m.ln1 = normal1; m.ln2 = -normal1_2; }

@@ -546,7 +546,8 @@ __device__ void reduce_manifold(const LocalManifold &m, int sel[4], int &nsel, f
 }
 
 // max(|mins|, |maxs|) of the shape's local AABB (the recycle extent of pair_update.rs:582-613)
-RP_DEV float shape_origin_radius(int sh, float4 he) {
+RP_DEV float shape_origin_radius(int sh, float4 he, float border = 0.0f) {
+    if (sh >= RP_SHAPE_ROUND_CUBOID) return len(v3(he.x + border, he.y + border, he.z + border)); // the inner local box loosened by the border
     if (sh == RP_SHAPE_CUBOID || sh >= RP_SHAPE_CYLINDER) return len(v3(he)); // (cylinder / cone: he = the local AABB's half extents)
     if (sh == RP_SHAPE_CAPSULE) { int ax = (int)he.z; return len(v3(ax == 0 ? he.x + he.y : he.y, ax == 1 ? he.x + he.y : he.y, ax == 2 ? he.x + he.y : he.y)); }
     if (sh == RP_SHAPE_HALFSPACE) return INFINITY; // |(MAX/2, MAX/2, MAX/2)| overflows: a pair with a half-space never recycles
@@ -579,12 +580,12 @@ RP_DEV float point_box_dist2(V3 p, V3 he) {
     float dx = rp_max(fabsf(p.x) - he.x, 0.0f), dy = rp_max(fabsf(p.y) - he.y, 0.0f), dz = rp_max(fabsf(p.z) - he.z, 0.0f);
     return dx * dx + dy * dy + dz * dz;
 }
-template <bool CONVEX> __device__ __noinline__ bool shapes_intersect(const DevWorld &w, int s1, float4 h1, int s2, float4 h2, Pose pos12) {
+template <bool CONVEX> __device__ __noinline__ bool shapes_intersect(const DevWorld &w, int s1, float4 h1, int s2, float4 h2, Pose pos12, float border1, float border2) {
     if constexpr (CONVEX) {
         if (s1 >= RP_SHAPE_CYLINDER || s2 >= RP_SHAPE_CYLINDER) { // cylinders, cones: GJK (intersection_test_support_map_support_map)
-            const SmShape a = sm_shape_of(w, s1, h1), b = sm_shape_of(w, s2, h2);
-            if (s1 == RP_SHAPE_HALFSPACE) return dot(v3(h1), pose_tp(pos12, sm_support(b, qrot_inv(pos12.r, -v3(h1))))) <= 0.0f;
-            if (s2 == RP_SHAPE_HALFSPACE) { Pose pos21 = pose_inv(pos12); return dot(v3(h2), pose_tp(pos21, sm_support(a, qrot_inv(pos21.r, -v3(h2))))) <= 0.0f; }
+            const SmShape a = sm_shape_of(w, s1, h1, border1), b = sm_shape_of(w, s2, h2, border2);
+            if (s1 == RP_SHAPE_HALFSPACE) return dot(v3(h1), pose_tp(pos12, sm_support(b, qrot_inv(pos12.r, -v3(h1))))) - b.border <= 0.0f;
+            if (s2 == RP_SHAPE_HALFSPACE) { Pose pos21 = pose_inv(pos12); return dot(v3(h2), pose_tp(pos21, sm_support(a, qrot_inv(pos21.r, -v3(h2))))) - a.border <= 0.0f; }
             return sm_intersects(a, b, pos12);
         }
     }
@@ -642,7 +643,7 @@ template <bool CONVEX> __device__ __forceinline__ void sensor_pair_update(DevWor
     const int rb1 = w.c_parent[c1], rb2 = w.c_parent[c2];
     int pf = w.p_pflags[s] & ~RP_PF_RECYCLE;
     const bool had_i = (pf & RP_PF_INTERSECTING) != 0;
-    const bool now_i = (rb1 == rb2 && rb1 >= 0) ? false : shapes_intersect<CONVEX>(w, w.c_shape[c1], w.c_he[c1], w.c_shape[c2], w.c_he[c2], pos12);
+    const bool now_i = (rb1 == rb2 && rb1 >= 0) ? false : shapes_intersect<CONVEX>(w, w.c_shape[c1], w.c_he[c1], w.c_shape[c2], w.c_he[c2], pos12, CONVEX ? w.c_mat[c1].w : 0.0f, CONVEX ? w.c_mat[c2].w : 0.0f);
     w.p_npts[s] = 0; w.p_nsc[s] = 0;
     if (now_i != had_i) {
         pf ^= RP_PF_INTERSECTING;
@@ -675,7 +676,7 @@ template <bool CONVEX> __device__ __forceinline__ void pair_full_update(DevWorld
     if constexpr (CONVEX) { // cylinders, cones (rp_convex.h): the dispatcher's order — ball arms, half-space arms, pfm_pfm
         convex_pair = sh1 >= RP_SHAPE_CYLINDER || sh2 >= RP_SHAPE_CYLINDER;
         if (convex_pair) {
-            const SmShape a = sm_shape_of(w, sh1, he1), b = sm_shape_of(w, sh2, he2);
+            const SmShape a = sm_shape_of(w, sh1, he1, w.c_mat[c1].w), b = sm_shape_of(w, sh2, he2, w.c_mat[c2].w);
             if (sh2 == RP_SHAPE_BALL) manifold_sm_ball(pos12, a, he2.x, prediction, m, false);
             else if (sh1 == RP_SHAPE_BALL) manifold_sm_ball(pose_inv(pos12), b, he1.x, prediction, m, true);
             else if (sh1 == RP_SHAPE_HALFSPACE) manifold_halfspace_sm(pos12, v3(he1), b, prediction, m, false);
@@ -782,7 +783,7 @@ template <bool CONVEX> __device__ __forceinline__ void pair_full_update(DevWorld
         float max_extent;
         if (w.p_pflags[s] & RP_PF_RECYCLE) max_extent = w.p_misc[s].y;
         else {
-            float e1 = shape_origin_radius(sh1, he1), e2 = shape_origin_radius(sh2, he2);
+            float e1 = shape_origin_radius(sh1, he1, mat1.w), e2 = shape_origin_radius(sh2, he2, mat2.w);
             max_extent = rp_max(e1, e2);
         }
         float max_drift = nsc > 0 ? recycle : rp_min(recycle, prediction);

@@ -87,6 +87,7 @@ RP_DEV bool collider_update_one(const DevWorld &w, int i) { // true = the fat AA
     } else {
         h = v3(he.x, he.x, he.x);
     }
+    if (w.c_shape[i] >= RP_SHAPE_ROUND_CUBOID) { const float b = w.c_mat[i].w; h = h + v3(b, b, b); } // RoundShape::aabb = inner.aabb(pos).loosened(border_radius)
     float loosen = w.prm.prediction / 2.0f;
     V3 mn = pos.t - h - v3(loosen, loosen, loosen);
     V3 mx = pos.t + h + v3(loosen, loosen, loosen);
@@ -101,7 +102,15 @@ RP_DEV bool collider_update_one(const DevWorld &w, int i) { // true = the fat AA
         w.flags[FL_BP_DIRTY] = 1;
         // queued once per broad-phase pass for the incremental update (rp_broadphase.hip)
         const int stamp = w.flags[FL_BP_SEQ] + 1;
-        if (w.c_chgstamp[i] != stamp) { w.c_chgstamp[i] = stamp; int k = atomicAdd(&w.flags[FL_BP_NCHG], 1); if (k < w.n_colliders) w.bp_chg_list[k] = i; }
+        if (w.c_chgstamp[i] != stamp) { // ONE atomic per wavefront on the list's counter (a third of b3d_joint_grid's 10,000 colliders queue every pass: 3,559 same-address atomics)
+            w.c_chgstamp[i] = stamp;
+            const unsigned long long m = __ballot(1);
+            const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+            int k = 0;
+            if (lane == leader) k = atomicAdd(&w.flags[FL_BP_NCHG], __popcll(m));
+            k = __shfl(k, leader, 64) + __popcll(m & ((1ull << lane) - 1ull));
+            if (k < w.n_colliders) w.bp_chg_list[k] = i;
+        }
         // shard guard: islands are sharded over GPUs without any exchange, which is only sound while no body of this shard comes near
         // a body of another one — a rewritten fat AABB that overlaps a box another shard occupies ends the run with an error
         if (w.sg_bmin && w.c_parent[i] >= 0 && (w.b_flags[w.c_parent[i]] & RP_BF_TYPE_MASK) != RP_BODY_FIXED && w.c_shape[i] != RP_SHAPE_HALFSPACE) {
@@ -145,6 +154,7 @@ RP_DEV bool collider_left_fat_aabb(const DevWorld &w, int i) {
     } else {
         h = v3(he.x, he.x, he.x);
     }
+    if (w.c_shape[i] >= RP_SHAPE_ROUND_CUBOID) { const float b = w.c_mat[i].w; h = h + v3(b, b, b); } // RoundShape::aabb = inner.aabb(pos).loosened(border_radius)
     float loosen = w.prm.prediction / 2.0f;
     V3 mn = pos.t - h - v3(loosen, loosen, loosen);
     V3 mx = pos.t + h + v3(loosen, loosen, loosen);

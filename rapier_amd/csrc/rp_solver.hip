@@ -144,6 +144,9 @@ __global__ void k_writeback_bodies(DevWorld w) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (lean_dead(w)) return; // (the step did not happen: k_ccd counts the graph — FL_SEQ — and raises the marker)
     if (i == 0) { w.flags[FL_STEP] += 1; w.flags[FL_SEQ] += 1; }
+    // a bare lean graph (no manifold in the world: rp_world.h) has no contact impulse to write back: the joints' impulses — what is left
+    // of k_writeback_impulses — ride this launch (one launch less per step on b3d_joint_grid)
+    if (w.lean & 2) { const int stride = gridDim.x * blockDim.x; for (int j = i; j < w.n_joints; j += stride) if (joint_live(w, j)) joint_writeback_one(w, j); }
     if (i >= w.n_bodies || !global_body(w, i)) return;
     g_body_writeback(w, i);
 }
@@ -336,7 +339,8 @@ void rp_launch_solver_writeback(const DevWorld &w0, hipStream_t st, int parity, 
     DevWorld w = w0;
     if (parity & 1) { std::swap(w.s_lin, w.t_lin); std::swap(w.s_ang, w.t_ang); w.c_par = 1; } // the tile sweeps left the velocities (and the mutable constraint planes) in the other copy
     if (parity & 2) { std::swap(w.s_rot, w.t_rot); std::swap(w.s_trans, w.t_trans); } // ... and the poses
-    if (host_coulomb(w)) hipLaunchKernelGGL(k_writeback_impulses<true>, dim3(cons_blocks(w)), dim3(256), 0, st, w);
+    if (w.lean & 2) {} // (bare lean graph: the joints' write-back rides k_writeback_bodies)
+    else if (host_coulomb(w)) hipLaunchKernelGGL(k_writeback_impulses<true>, dim3(cons_blocks(w)), dim3(256), 0, st, w);
     else hipLaunchKernelGGL(k_writeback_impulses<false>, dim3(cons_blocks(w)), dim3(256), 0, st, w);
     hipLaunchKernelGGL(k_writeback_bodies, dim3(body_blocks(w)), dim3(256), 0, st, w);
     if (publish) hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, w); // hint buffer (MULTI mode: after the step; else k_ccd carries it)

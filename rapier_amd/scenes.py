@@ -17,6 +17,8 @@ import numpy as np
 BODY_DYNAMIC, BODY_FIXED, BODY_KINEMATIC_POSITION, BODY_KINEMATIC_VELOCITY = 0, 1, 2, 3  # RigidBodyType
 SHAPE_BALL, SHAPE_CUBOID, SHAPE_CAPSULE = 0, 1, 2  # capsule: half_extents = (half_height, radius, axis 0|1|2) = ColliderBuilder::capsule_x/y/z
 SHAPE_HALFSPACE = 3  # half_extents = the unit outward normal in the collider frame = ColliderBuilder::halfspace (fixed or kinematic parents only)
+# ColliderBuilder::round_cuboid / round_cylinder / round_cone / round_convex_hull: the inner shape's half_extents + collider_desc(border_radius=...)
+SHAPE_ROUND_CUBOID, SHAPE_ROUND_CYLINDER, SHAPE_ROUND_CONE, SHAPE_ROUND_CONVEX_POLYHEDRON = 7, 8, 9, 10
 SHAPE_CONVEX = SHAPE_CONVEX_POLYHEDRON = 6  # half_extents[0] = the id Scene.add_convex_polyhedron returned = ColliderBuilder::convex_mesh / convex_hull (collider.rs:1039, :1070)
 SHAPE_CYLINDER, SHAPE_CONE = 4, 5  # half_extents = (half_height, radius, -) = ColliderBuilder::cylinder / cone (axis Y, a cone's apex at +Y)
 RULE_AVERAGE, RULE_MIN, RULE_MULTIPLY, RULE_MAX, RULE_CLAMPED_SUM, RULE_GEOMETRIC_MEAN = range(6)
@@ -34,7 +36,7 @@ COLLIDER_DTYPE = np.dtype([
     ("density", "<f4"), ("friction", "<f4"), ("restitution", "<f4"),
     ("friction_rule", "<i4"), ("restitution_rule", "<i4"),
     ("collision_memberships", "<u4"), ("collision_filter", "<u4"),
-    ("active_events", "<u4"), ("contact_force_event_threshold", "<f4"), ("sensor", "<i4"),
+    ("active_events", "<u4"), ("contact_force_event_threshold", "<f4"), ("sensor", "<i4"), ("border_radius", "<f4"),
 ], align=False)
 
 ACTIVE_EVENTS_COLLISION, ACTIVE_EVENTS_CONTACT_FORCE = 1, 2  # ActiveEvents bits
@@ -130,7 +132,7 @@ def body_desc(body_type=BODY_DYNAMIC, translation=(0, 0, 0), rotation=(0, 0, 0, 
 def collider_desc(shape=SHAPE_CUBOID, half_extents=(0.5, 0.5, 0.5), translation=(0, 0, 0),
                   rotation=(0, 0, 0, 1), density=1.0, friction=0.5, restitution=0.0,
                   friction_rule=RULE_AVERAGE, restitution_rule=RULE_AVERAGE,
-                  memberships=0xFFFFFFFF, filter=0xFFFFFFFF, active_events=0, contact_force_event_threshold=0.0, sensor=0) -> np.ndarray:
+                  memberships=0xFFFFFFFF, filter=0xFFFFFFFF, active_events=0, contact_force_event_threshold=0.0, sensor=0, border_radius=0.0) -> np.ndarray:
     """ColliderBuilder defaults — /root/reference/src/geometry/collider.rs:1125-1127 (friction 0.5,
     restitution 0, density 1, rule Average)."""
     c = np.zeros((), dtype=COLLIDER_DTYPE)
@@ -144,6 +146,7 @@ def collider_desc(shape=SHAPE_CUBOID, half_extents=(0.5, 0.5, 0.5), translation=
     c["collision_memberships"], c["collision_filter"] = memberships, filter
     c["active_events"], c["contact_force_event_threshold"] = active_events, contact_force_event_threshold
     c["sensor"] = sensor  # ColliderBuilder::sensor(true): intersection events only
+    c["border_radius"] = border_radius  # round shapes (SHAPE_ROUND_*): RoundShape::border_radius
     return c
 
 
@@ -913,4 +916,54 @@ def polyhedra_clutter(n: int = 24, seed: int = 2, hulls: bool = True) -> Scene:
     b = s.add_body(translation=(2.5, 3.5, -2.5), angvel=(0.5, 1.0, 0.0))                                              # a dumbbell of two polyhedra
     s.add_collider(b, shape=SHAPE_CONVEX, half_extents=(shapes[1], 0, 0), translation=(-0.5, 0.0, 0.0), density=1.5)
     s.add_collider(b, shape=SHAPE_CONVEX, half_extents=(shapes[3], 0, 0), translation=(0.5, 0.1, 0.0), rotation=(0.0, 0.3826834, 0.0, 0.9238795))
+    return s
+
+
+def round_clutter(n: int = 30, seed: int = 6) -> Scene:
+    """Seeded test scene (not a reference scene) for the round shapes (ColliderBuilder::round_cuboid / round_cylinder / round_cone /
+    round_convex_hull, collider.rs:700-1090: parry RoundShape<S> = the inner shape dilated by a border radius): they tumble with plain
+    cuboids, balls, capsules and cylinders on a round-cuboid slab and a half-space ramp inside four walls; a fixed round cone stands in
+    the middle."""
+    rng = np.random.default_rng(seed)
+    s = Scene(name=f"round_clutter_{n}_{seed}", gravity=(0.0, -9.81, 0.0))
+    g = s.add_body(body_type=BODY_FIXED, translation=(0.0, -0.5, 0.0))
+    s.add_collider(g, shape=SHAPE_ROUND_CUBOID, half_extents=(9.0, 0.4, 9.0), border_radius=0.1)
+    s.add_collider(g, shape=SHAPE_HALFSPACE, half_extents=(-0.5, 0.8660254, 0.0), translation=(3.0, 0.5, 0.0))
+    for sx, sz, hx, hz in ((4.5, 0.0, 0.25, 4.5), (-4.5, 0.0, 0.25, 4.5), (0.0, 4.5, 4.5, 0.25), (0.0, -4.5, 4.5, 0.25)):
+        wb = s.add_body(body_type=BODY_FIXED, translation=(sx, 1.0, sz))
+        s.add_collider(wb, half_extents=(hx, 1.0, hz))
+    pid = s.add_convex_polyhedron((rng.standard_normal((20, 3)) * 0.25).astype(np.float32))
+    pillar = s.add_body(body_type=BODY_FIXED, translation=(0.0, 0.65, 0.0))
+    s.add_collider(pillar, shape=SHAPE_ROUND_CONE, half_extents=(0.5, 0.6, 0.0), border_radius=0.08)
+    side = int(np.ceil(n ** (1.0 / 3.0)))
+    k = 0
+    for iy in range(side * 2):
+        for ix in range(side):
+            for iz in range(side):
+                if k >= n:
+                    break
+                q = rng.normal(size=4).astype(np.float32)
+                q /= np.linalg.norm(q)
+                pos = (np.float32(1.4 * (ix - side / 2) + 0.1 * rng.random()), np.float32(2.0 + 1.5 * iy), np.float32(1.4 * (iz - side / 2) + 0.1 * rng.random()))
+                b = s.add_body(translation=pos, rotation=tuple(q), linvel=tuple((rng.normal(size=3) * 1.0).astype(np.float32)), angvel=tuple((rng.normal(size=3) * 2.0).astype(np.float32)),
+                               angular_damping=0.2 if k % 4 == 0 else 0.0)
+                fr, br = np.float32(0.3 + 0.5 * rng.random()), np.float32(0.03 + 0.09 * rng.random())
+                kind = k % 8
+                if kind == 0:
+                    s.add_collider(b, shape=SHAPE_ROUND_CUBOID, half_extents=tuple((0.15 + 0.25 * rng.random(size=3)).astype(np.float32)), border_radius=br, friction=fr)
+                elif kind == 1:
+                    s.add_collider(b, shape=SHAPE_ROUND_CYLINDER, half_extents=(np.float32(0.2 + 0.2 * rng.random()), np.float32(0.2 + 0.2 * rng.random()), 0.0), border_radius=br, friction=fr)
+                elif kind == 2:
+                    s.add_collider(b, shape=SHAPE_ROUND_CONE, half_extents=(np.float32(0.25 + 0.2 * rng.random()), np.float32(0.2 + 0.2 * rng.random()), 0.0), border_radius=br, friction=fr)
+                elif kind == 3:
+                    s.add_collider(b, shape=SHAPE_ROUND_CONVEX_POLYHEDRON, half_extents=(pid, 0, 0), border_radius=br, friction=fr, density=1.5)
+                elif kind == 4:
+                    s.add_collider(b, half_extents=tuple((0.2 + 0.3 * rng.random(size=3)).astype(np.float32)), friction=fr)
+                elif kind == 5:
+                    s.add_collider(b, shape=SHAPE_BALL, half_extents=(np.float32(0.25 + 0.2 * rng.random()), 0, 0), friction=fr)
+                elif kind == 6:
+                    s.add_collider(b, shape=SHAPE_CAPSULE, half_extents=(np.float32(0.3 + 0.2 * rng.random()), np.float32(0.15 + 0.15 * rng.random()), float(k % 3)), friction=fr)
+                else:
+                    s.add_collider(b, shape=SHAPE_CYLINDER, half_extents=(np.float32(0.25 + 0.2 * rng.random()), np.float32(0.2 + 0.2 * rng.random()), 0.0), friction=fr)
+                k += 1
     return s

@@ -270,3 +270,43 @@ def test_clutter_settles_and_is_reproducible(ground):
     dyn = [i for i, d in enumerate(sc.bodies) if int(d["body_type"]) == S.BODY_DYNAMIC]
     assert np.isfinite(pa).all() and pa[dyn, 1].min() > 0.1 and pa[dyn, 1].max() < 3.0       # nothing fell through, nothing was launched
     assert np.abs(pa[dyn][:, [0, 2]]).max() < 4.5                                             # everything is still inside the walls
+
+
+@pytest.mark.parametrize("ground", ["cuboid", "halfspace", "round_cuboid"])
+def test_round_shapes_rest_on_their_border(ground):
+    """parry RoundShape<S>: the inner shape dilated by border_radius — ColliderBuilder::round_cuboid / round_cylinder / round_cone"""
+    sc = S.Scene(name="round_rest", gravity=(0.0, -9.81, 0.0))
+    g = sc.add_body(body_type=S.BODY_FIXED, translation=(0, -0.5, 0))
+    if ground == "cuboid":
+        sc.add_collider(g, half_extents=(20, 0.5, 5))
+    elif ground == "round_cuboid":
+        sc.add_collider(g, shape=S.SHAPE_ROUND_CUBOID, half_extents=(20, 0.4, 5), border_radius=0.1)
+    else:
+        sc.add_collider(g, shape=S.SHAPE_HALFSPACE, half_extents=(0, 1, 0), translation=(0, 0.5, 0))
+    want = []
+    for k, (sh, he, rot, rest) in enumerate([(S.SHAPE_ROUND_CUBOID, (0.3, 0.2, 0.25), (0, 0, 0, 1), 0.25), (S.SHAPE_ROUND_CYLINDER, (0.4, 0.3, 0), (0, 0, 0, 1), 0.45),
+                                             (S.SHAPE_ROUND_CYLINDER, (0.4, 0.3, 0), (0, 0, _S2, _S2), 0.35), (S.SHAPE_ROUND_CONE, (0.4, 0.3, 0), (0, 0, 0, 1), 0.45),
+                                             (S.SHAPE_BALL, (0.3, 0, 0), (0, 0, 0, 1), 0.3)]):
+        b = sc.add_body(translation=(3.0 * k - 6, 1.2, 0), rotation=rot)
+        sc.add_collider(b, shape=sh, half_extents=he, border_radius=0.05 if sh >= S.SHAPE_ROUND_CUBOID else 0.0)
+        want.append((b, rest))
+    o = OracleWorld(sc)
+    o.step(1)
+    _, v = o.read()
+    o2 = OracleWorld(_lone_body(S.SHAPE_CUBOID, (0.3, 0.2, 0.25)))        # RoundShape::mass_properties = the inner shape's
+    o2.apply_impulse(0, impulse=(1.0, 0.0, 0.0)); o.apply_impulse(want[0][0], impulse=(1.0, 0.0, 0.0))
+    assert abs(o2.read()[1][0][0] - (o.read()[1][want[0][0]][0] - v[want[0][0]][0])) < 1e-5
+    o.step(300)
+    p, v = o.read()
+    for b, rest in want:
+        assert abs(p[b][1] - rest) < 2.5e-3 and abs(v[b][1]) < 1e-2, (b, p[b], rest)
+
+
+def test_round_clutter_settles_and_is_reproducible():
+    sc = S.round_clutter(30, 6)
+    a, b = OracleWorld(sc), OracleWorld(sc)
+    a.step(400); b.step(400)
+    pa, _ = a.read(); pb, _ = b.read()
+    np.testing.assert_array_equal(pa, pb)
+    dyn = [i for i, d in enumerate(sc.bodies) if int(d["body_type"]) == S.BODY_DYNAMIC]
+    assert np.isfinite(pa).all() and pa[dyn, 1].min() > 0.1 and pa[dyn, 1].max() < 3.0 and np.abs(pa[dyn][:, [0, 2]]).max() < 4.5

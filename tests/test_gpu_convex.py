@@ -156,3 +156,71 @@ def test_unknown_shape_and_bad_dimensions_are_refused():
         g.insert_collider(S.collider_desc(shape=6, half_extents=(0.5, 0.5, 0.5)), hb)
     with pytest.raises(RapierHipError):
         g.insert_collider(S.collider_desc(shape=S.SHAPE_CONE, half_extents=(0.5, 0.0, 0.0)), hb)
+
+
+def test_round_clutter_bit_exact():
+    """ColliderBuilder::round_cuboid / round_cylinder / round_cone / round_convex_hull (parry RoundShape<S>): the inner shapes' GJK / EPA
+    manifolds with border radii, against every other shape, a round-cuboid ground and a half-space ramp"""
+    sc = S.round_clutter(30, 6)
+    for step, g, o, ev in _lockstep(sc, 400, every=4):
+        pass
+    c = g.counters()
+    assert c["num_manifolds"] == o.stats()["num_active_manifolds"] and c["num_manifolds"] > 30
+    pos, _ = g.read_bodies()
+    dyn = [i for i, b in enumerate(sc.bodies) if int(b["body_type"]) == S.BODY_DYNAMIC]
+    assert pos[dyn, 1].min() > 0.1
+
+
+def test_round_shapes_sleeping_sensors_and_ccd():
+    sc = S.Scene(name="round_misc", gravity=(0.0, -9.81, 0.0))
+    fl = sc.add_body(body_type=S.BODY_FIXED, translation=(0.0, -0.25, 0.0)); sc.add_collider(fl, half_extents=(60.0, 0.25, 60.0))
+    z = sc.add_body(body_type=S.BODY_FIXED, translation=(0.0, 2.0, 0.0))
+    sc.add_collider(z, shape=S.SHAPE_ROUND_CUBOID, half_extents=(1.5, 0.5, 1.5), border_radius=0.3, sensor=1, active_events=S.ACTIVE_EVENTS_COLLISION)
+    for k, (shape, he) in enumerate([(S.SHAPE_BALL, (0.3, 0, 0)), (S.SHAPE_ROUND_CUBOID, (0.2, 0.15, 0.2)), (S.SHAPE_ROUND_CONE, (0.3, 0.25, 0.0)), (S.SHAPE_CAPSULE, (0.3, 0.15, 0.0))]):
+        b = sc.add_body(translation=(-1.2 + 0.8 * k, 5.0 + 0.8 * k, 0.2 * k), rotation=(0.2, 0.1, 0.3, 0.9273618), angvel=(1.0, 0.0, 2.0), can_sleep=1)
+        sc.add_collider(b, shape=shape, half_extents=he, border_radius=0.06 if shape >= S.SHAPE_ROUND_CUBOID else 0.0, active_events=S.ACTIVE_EVENTS_COLLISION)
+    fast = []
+    for k in range(2):
+        b = sc.add_body(translation=(6.0 + 1.5 * k, 7.0 + k, 0.1 * k), linvel=(0.0, -60.0 - 10.0 * k, 0.0), rotation=(0.3, 0.0, 0.2, 0.9327379), ccd_enabled=k)
+        sc.add_collider(b, shape=S.SHAPE_ROUND_CYLINDER, half_extents=(0.06, 0.08, 0.0), border_radius=0.02, density=4.0)
+        fast.append(b)
+    n_sensor = 0
+    for step, g, o, ev in _lockstep(sc, 600, every=2, sleeping=True):
+        n_sensor += sum(1 for e in ev if e[3] & 1)
+    assert n_sensor >= 6 and g.sleeping().any()
+    pos, _ = g.read_bodies()
+    assert pos[fast, 1].min() > 0.0 and g.counters()["ccd_clamp_count"] >= 1
+
+
+def test_fountain_churn_with_the_references_shapes_in_lockstep():
+    """solver_graph_stale_refs.rs:24-79 on the device: a round cylinder, a cone or a cuboid spawned every step, the outermost bodies
+    removed beyond 120 (arena slots reused) — 400 steps, every state compared with the oracle's"""
+    sc = S.Scene(name="fountain", gravity=(0.0, -9.81, 0.0))
+    gnd = sc.add_body(body_type=S.BODY_FIXED, translation=(0.0, -2.1, 0.0)); sc.add_collider(gnd, half_extents=(40.0, 2.1, 40.0))
+    g, o = PhysicsWorld.from_scene(sc), OracleWorld(sc)
+    alive, rad = [], 0.5          # (device handle, oracle index)
+    for step_id in range(1, 400):
+        g.step(1); o.step(1)
+        body = S.body_desc(translation=(0.0, 10.0, 0.0), can_sleep=1)
+        if step_id % 3 == 0:
+            col = S.collider_desc(shape=S.SHAPE_ROUND_CYLINDER, half_extents=(rad, rad, 0.0), border_radius=rad / 10.0)
+        elif step_id % 3 == 1:
+            col = S.collider_desc(shape=S.SHAPE_CONE, half_extents=(rad, rad, 0.0))
+        else:
+            col = S.collider_desc(half_extents=(rad, rad, rad))
+        hb = g.insert_body(body); g.insert_collider(col, hb)
+        ob = lib().ro_add_body(o._w, np.array([body], S.BODY_DTYPE).ctypes.data)
+        lib().ro_add_collider(o._w, np.array([col], S.COLLIDER_DTYPE).ctypes.data, ob)
+        assert int(hb) & 0xFFFFFFFF == ob
+        alive.append((hb, ob))
+        if len(alive) + 1 > 120:
+            pos, _ = o.read()
+            order = sorted(alive, key=lambda h: -(abs(pos[h[1], 0]) + abs(pos[h[1], 2])))
+            for h in order[:len(alive) + 1 - 120]:
+                g.remove_body([h[0]]); o.remove_body(h[1]); alive.remove(h)
+        if step_id % 10 == 0 or step_id > 380:
+            gp, gv = g.read_bodies([h for h, _ in alive]); op, ov = o.read()
+            idx = [b for _, b in alive]
+            np.testing.assert_array_equal(gp, op[idx], err_msg=f"step {step_id}"); np.testing.assert_array_equal(gv, ov[idx], err_msg=f"step {step_id}")
+    g.step(1); o.step(1)          # (the pairs of the bodies removed last leave the oracle's pair set with its next broad-phase pass)
+    assert g.counters()["overflow_flags"] == 0 and g.counters()["num_pairs"] == o.stats()["num_pairs"]

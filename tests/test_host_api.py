@@ -25,7 +25,7 @@ def test_descriptor_layouts_match_header():
     # sizes implied by include/rapier_hip.h (all 4-byte fields, no padding)
     assert S.PARAMS_DTYPE.itemsize == 14 * 4 + 8 * 4
     assert S.BODY_DTYPE.itemsize == 4 + 12 + 16 + 12 + 12 + 4 * 4 + 5 * 4 + 4 + 4  # ... + additional_solver_iterations + ccd_enabled
-    assert S.COLLIDER_DTYPE.itemsize == 4 + 12 + 12 + 16 + 12 + 8 + 8 + 8 + 4
+    assert S.COLLIDER_DTYPE.itemsize == 4 + 12 + 12 + 16 + 12 + 8 + 8 + 8 + 4 + 4  # ... + sensor + border_radius
     assert S.JOINT_DTYPE.itemsize == 8 + 24 + 32 + 8 + 4 + 48 + 4 + 6 * 24
     assert C.sizeof(_ffi.Counters) == 9 * 4 + 20 * 4  # ... + num_tiles, tile_sweeps, bp_large_list, lean_steps
     p = S.default_params()
@@ -42,7 +42,8 @@ def test_shape_and_body_enums_agree_across_header_python_and_oracle():
     hdr = enum_values(os.path.join(ROOT, "include", "rapier_hip.h"), "RP_SHAPE")
     ora = enum_values(os.path.join(ROOT, "oracle", "rapier_oracle.h"), "RO_SHAPE")
     assert hdr == ora == {"BALL": S.SHAPE_BALL, "CUBOID": S.SHAPE_CUBOID, "CAPSULE": S.SHAPE_CAPSULE, "HALFSPACE": S.SHAPE_HALFSPACE,
-                          "CYLINDER": S.SHAPE_CYLINDER, "CONE": S.SHAPE_CONE, "CONVEX_POLYHEDRON": S.SHAPE_CONVEX_POLYHEDRON}
+                          "CYLINDER": S.SHAPE_CYLINDER, "CONE": S.SHAPE_CONE, "CONVEX_POLYHEDRON": S.SHAPE_CONVEX_POLYHEDRON, "ROUND_CUBOID": S.SHAPE_ROUND_CUBOID,
+                          "ROUND_CYLINDER": S.SHAPE_ROUND_CYLINDER, "ROUND_CONE": S.SHAPE_ROUND_CONE, "ROUND_CONVEX_POLYHEDRON": S.SHAPE_ROUND_CONVEX_POLYHEDRON}
     hb = enum_values(os.path.join(ROOT, "include", "rapier_hip.h"), "RP_BODY")
     ob = enum_values(os.path.join(ROOT, "oracle", "rapier_oracle.h"), "RO_BODY")
     assert hb == ob and hb["DYNAMIC"] == S.BODY_DYNAMIC and hb["FIXED"] == S.BODY_FIXED and hb["KINEMATIC_POSITION"] == S.BODY_KINEMATIC_POSITION

@@ -863,6 +863,37 @@ def test_miri_scenes():
 
 
 # ---- solver_graph_stale_refs.rs ------------------------------------------------------------------------------------------
+def test_body_churn_with_the_references_own_shapes():
+    """solver_graph_stale_refs.rs:24-79 as written: ColliderBuilder::round_cylinder(rad, rad, rad / 10), cone(rad, rad), cuboid(rad, rad,
+    rad) in turn, one body per step, the outermost dynamic ones removed once more than 120 exist (800 of the reference's 1,500 steps)"""
+    sc = world()
+    g = sc.add_body(body_type=S.BODY_FIXED, translation=(0.0, -2.1, 0.0))
+    sc.add_collider(g, half_extents=(40.0, 2.1, 40.0))
+    w = OracleWorld(sc)
+    alive, rad = [], 0.5
+    for step_id in range(1, 800):
+        w.step(1)
+        b = w.add_body(translation=(0.0, 10.0, 0.0), can_sleep=1)
+        if step_id % 3 == 0:
+            w.add_collider(b, shape=S.SHAPE_ROUND_CYLINDER, half_extents=(rad, rad, 0.0), border_radius=rad / 10.0)
+        elif step_id % 3 == 1:
+            w.add_collider(b, shape=S.SHAPE_CONE, half_extents=(rad, rad, 0.0))
+        else:
+            w.add_collider(b, half_extents=(rad, rad, rad))
+        alive.append(b)
+        if len(alive) + 1 > 120:
+            pos = w.read()[0]
+            order = sorted(alive, key=lambda h: -(abs(pos[h, 0]) + abs(pos[h, 2])))
+            for h in order[:len(alive) + 1 - 120]:
+                w.remove_body(h); alive.remove(h)
+        if step_id % 50 == 0:
+            pos, vel = w.read()
+            assert np.isfinite(pos[alive]).all() and np.isfinite(vel[alive]).all()
+            assert pos[alive, 1].min() > -0.5
+            meta, _, _ = w.manifolds()
+            assert len(meta) > 0
+
+
 def test_body_churn_keeps_the_world_sane():
     """solver_graph_stale_refs.rs:24-79 with cuboids / balls in place of the cylinder / cone: a body spawned every step, the
     outermost dynamic ones removed once more than 120 exist; collider removal and pair removal in the same step, sleep / wake
