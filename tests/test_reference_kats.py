@@ -384,11 +384,11 @@ def test_joint_get_mut_wakes_sleeping_bodies():
 
 
 def test_motor_position_with_rotating_base_stays_finite():
-    """issue_856 (the base is a cuboid here instead of a cylinder): a stiff position motor whose base body is re-oriented by
-    the user every frame keeps every body finite."""
+    """issue_856: a stiff position motor whose base body — ColliderBuilder::cylinder(0.2, 1.0) — is re-oriented by the user every frame
+    keeps every body finite."""
     sc = world()
     base = sc.add_body(translation=(0.0, 3.0, 0.0))
-    sc.add_collider(base, half_extents=(1.0, 0.2, 1.0))
+    sc.add_collider(base, shape=S.SHAPE_CYLINDER, half_extents=(0.2, 1.0, 0.0))
     hammer = sc.add_body(translation=(2.0, 3.0, 0.0))
     sc.add_collider(hammer, half_extents=(0.5, 0.1, 0.1))
     sc.add_joint(base, hammer, (1.0, 0.0, 0.0), (-1.0, 0.0, 0.0), locked_axes=S.LOCK_REVOLUTE, basis1=S.AXIS_Z_BASIS, basis2=S.AXIS_Z_BASIS,
@@ -983,8 +983,10 @@ def separate_colliders_scene():
             pos = (i - 10.0, 0.0, j - 10.0)
             if n % 3 == 2:
                 sc.add_collider(g, shape=S.SHAPE_CAPSULE, half_extents=(0.3, 0.4, 1.0), translation=pos)
-            else:                                               # the reference alternates cuboids and cylinders here
-                sc.add_collider(g, half_extents=(0.5, 0.5, 0.5) if n % 3 == 0 else (0.4, 0.5, 0.4), translation=pos)
+            elif n % 3 == 1:
+                sc.add_collider(g, shape=S.SHAPE_CYLINDER, half_extents=(0.5, 0.4, 0.0), translation=pos)      # ColliderBuilder::cylinder(0.5, 0.4)
+            else:
+                sc.add_collider(g, half_extents=(0.5, 0.5, 0.5), translation=pos)
             n += 1
     balls = []
     for k in range(500):
