@@ -967,3 +967,50 @@ def round_clutter(n: int = 30, seed: int = 6) -> Scene:
                     s.add_collider(b, shape=SHAPE_CYLINDER, half_extents=(np.float32(0.25 + 0.2 * rng.random()), np.float32(0.2 + 0.2 * rng.random()), 0.0), friction=fr)
                 k += 1
     return s
+
+
+def shapes_rain(n: int = 8000, seed: int = 1, spacing: float = 1.6) -> Scene:
+    """Measurement scene (not a reference scene) for the support-mapped shapes at scale: `n` bodies — cuboids, balls, capsules, cylinders,
+    cones, convex polyhedra (eight registered clouds, shared) and the round variants in equal parts — in three layers over a large slab,
+    random orientations and spins, falling into a loose carpet: thousands of GJK / EPA manifolds per step while it lands."""
+    rng = np.random.default_rng(seed)
+    s = Scene(name=f"shapes_rain_{n}_{seed}", gravity=(0.0, -9.81, 0.0))
+    side = int(np.ceil(np.sqrt(n / 3.0)))
+    half = 0.5 * spacing * side + 2.0
+    g = s.add_body(body_type=BODY_FIXED, translation=(0.0, -0.5, 0.0))
+    s.add_collider(g, half_extents=(half, 0.5, half))
+    polys = [s.add_convex_polyhedron((rng.standard_normal((12 + 4 * k, 3)) * 0.22).astype(np.float32)) for k in range(8)]
+    k = 0
+    for layer in range(3):
+        for ix in range(side):
+            for iz in range(side):
+                if k >= n:
+                    break
+                q = rng.normal(size=4).astype(np.float32)
+                q /= np.linalg.norm(q)
+                pos = (np.float32(spacing * (ix - side / 2) + 0.2 * rng.random()), np.float32(1.0 + 1.3 * layer + 0.2 * rng.random()), np.float32(spacing * (iz - side / 2) + 0.2 * rng.random()))
+                b = s.add_body(translation=pos, rotation=tuple(q), angvel=tuple((rng.normal(size=3) * 1.5).astype(np.float32)))
+                kind, br = k % 10, np.float32(0.04 + 0.04 * rng.random())
+                a, c = np.float32(0.2 + 0.15 * rng.random()), np.float32(0.2 + 0.15 * rng.random())
+                if kind == 0:
+                    s.add_collider(b, half_extents=(a, c, np.float32(0.2 + 0.15 * rng.random())))
+                elif kind == 1:
+                    s.add_collider(b, shape=SHAPE_BALL, half_extents=(a, 0, 0))
+                elif kind == 2:
+                    s.add_collider(b, shape=SHAPE_CAPSULE, half_extents=(a, np.float32(0.5 * c), float(k % 3)))
+                elif kind == 3:
+                    s.add_collider(b, shape=SHAPE_CYLINDER, half_extents=(a, c, 0.0))
+                elif kind == 4:
+                    s.add_collider(b, shape=SHAPE_CONE, half_extents=(a, c, 0.0))
+                elif kind == 5:
+                    s.add_collider(b, shape=SHAPE_CONVEX, half_extents=(polys[(k // 10) % 8], 0, 0))
+                elif kind == 6:
+                    s.add_collider(b, shape=SHAPE_ROUND_CUBOID, half_extents=(a, c, a), border_radius=br)
+                elif kind == 7:
+                    s.add_collider(b, shape=SHAPE_ROUND_CYLINDER, half_extents=(a, c, 0.0), border_radius=br)
+                elif kind == 8:
+                    s.add_collider(b, shape=SHAPE_ROUND_CONE, half_extents=(a, c, 0.0), border_radius=br)
+                else:
+                    s.add_collider(b, shape=SHAPE_ROUND_CONVEX_POLYHEDRON, half_extents=(polys[(k // 10) % 8], 0, 0), border_radius=br)
+                k += 1
+    return s
