@@ -18,6 +18,7 @@
 // (collider of the body, target collider) candidates, the earliest fraction is an atomicMin over positive float bits, so the result
 // does not depend on the visiting order.  Every function mirrors the checker's restatement operation for operation.
 #pragma once
+#include "rp_grid.h"
 
 #define RP_CCD_MAX_ITERS 48
 
@@ -210,6 +211,9 @@ template <bool CONVEX> __global__ void __launch_bounds__(256) k_ccd(DevWorld w, 
     __shared__ unsigned best;
     __shared__ int nfast, fast[CCD_MAX_FAST_COLLIDERS];
     const float slop = w.prm.p.normalized_allowed_linear_error * w.prm.p.length_unit; // IntegrationParameters::allowed_linear_error
+    // the grid describes every collider (it follows them, and nothing edited the world since its last pass); only tier 0's FIXED targets stand where their fat AABBs say
+    const bool grid_ok = tier == 0 && w.bp_incremental && w.flags[FL_BP_GRID_OK] != 0 && !w.flags[FL_BP_DIRTY] && !w.bp_always_build; // (RP_BP_ALWAYS_BUILD=1: the round-3 forms, incl. the walk over every collider here)
+    int n_large = w.flags[FL_N_LARGE]; if (n_large > w.large_cap) n_large = w.large_cap;
     for (int k = blockIdx.x; k < n; k += gridDim.x) {
         const int bi = w.ccd_list[k];
         const int fl1 = w.b_flags[bi];
@@ -230,6 +234,16 @@ template <bool CONVEX> __global__ void __launch_bounds__(256) k_ccd(DevWorld w, 
         const V3 lcom = v3(w.b_lcom_invm[bi]);
         const float max_extent = w.b_invpi[bi].w;
         const CcdSweep sw = ccd_sweep_from_poses(start, end, lcom);
+        // tier 0, grid in service: the cells under the swept volume's box (see try_target below); too many cells: the plain walk
+        const float ic = w.prm.inv_cell_size;
+        const float reach = max_extent + 2.0f * slop;
+        const V3 qmn = v3(fminf(sw.c0.x, sw.c1.x) - reach, fminf(sw.c0.y, sw.c1.y) - reach, fminf(sw.c0.z, sw.c1.z) - reach);
+        const V3 qmx = v3(fmaxf(sw.c0.x, sw.c1.x) + reach, fmaxf(sw.c0.y, sw.c1.y) + reach, fmaxf(sw.c0.z, sw.c1.z) + reach);
+        const int qlo[3] = {cell_coord(qmn.x, ic), cell_coord(qmn.y, ic), cell_coord(qmn.z, ic)};
+        const int qnx = cell_coord(qmx.x, ic) - qlo[0] + 1, qny = cell_coord(qmx.y, ic) - qlo[1] + 1, qnz = cell_coord(qmx.z, ic) - qlo[2] + 1;
+        const bool few_cells = qnx > 0 && qny > 0 && qnz > 0 && qnx <= 64 && qny <= 64 && qnz <= 64 && qnx * qny * qnz <= 2048;
+        const int ncell = few_cells ? qnx * qny * qnz : 0;
+        const bool use_grid = grid_ok && few_cells; // (uniform over the workgroup)
         for (int base = 0; base <= max_ord; base += CCD_MAX_FAST_COLLIDERS) {
           __syncthreads();
           for (int q = threadIdx.x; q < CCD_MAX_FAST_COLLIDERS; q += blockDim.x) fast[q] = -1;
@@ -250,24 +264,48 @@ template <bool CONVEX> __global__ void __launch_bounds__(256) k_ccd(DevWorld w, 
             Pose pwp; pwp.t = v3(w.c_lpos[c1]); pwp.r = q4(w.c_lrot[c1]);
             const float rot_radius = ccd_rot_radius(s2, pwp, lcom);
             const uint2 g1 = w.c_groups[c1];
-            for (int c2 = threadIdx.x; c2 < w.n_colliders; c2 += blockDim.x) {
+            // one candidate target: the filters of sweep_fast_body, the reach pre-filter, the cast
+            auto try_target = [&](int c2) {
                 const int p2 = w.c_parent[c2];
-                if (c2 == c1 || p2 == bi) continue;
+                if (c2 == c1 || p2 == bi) return;
                 const uint2 g2 = w.c_groups[c2];
-                if ((g2.x == 0 && g2.y == 0) || (__float_as_int(w.c_events[c2].x) & RP_EVENTS_SENSOR_BIT)) continue;
+                if ((g2.x == 0 && g2.y == 0) || (__float_as_int(w.c_events[c2].x) & RP_EVENTS_SENSOR_BIT)) return;
                 const int fl2 = p2 >= 0 ? w.b_flags[p2] : RP_BODY_FIXED;
                 const bool fixed2 = (fl2 & RP_BF_TYPE_MASK) == RP_BODY_FIXED;
                 // tier_allows (sweeps.rs:35-41)
-                if (tier) { if ((fl2 & RP_BF_TYPE_MASK) == RP_BODY_DYNAMIC && (fl2 & RP_BF_CCD_ENABLED)) continue; } else if (!fixed2) continue;
-                if (!((g1.x & g2.y) != 0 && (g2.x & g1.y) != 0)) continue; // collision_groups.test
+                if (tier) { if ((fl2 & RP_BF_TYPE_MASK) == RP_BODY_DYNAMIC && (fl2 & RP_BF_CCD_ENABLED)) return; } else if (!fixed2) return;
+                if (!((g1.x & g2.y) != 0 && (g2.x & g1.y) != 0)) return; // collision_groups.test
                 Pose tp = collider_world_pose(w, c2); // target_collider_pose (:97-102): bodies already stand at their end-of-step pose
                 const int sh2 = w.c_shape[c2];
-                const float4 he2 = w.c_he[c2];
-                if (sh2 != RP_SHAPE_HALFSPACE && !ccd_may_reach(sw.c0, sw.c1, max_extent, tp.t, ccd_bounding_radius(w, c2), 2.0f * slop)) continue;
+                if (sh2 != RP_SHAPE_HALFSPACE && !ccd_may_reach(sw.c0, sw.c1, max_extent, tp.t, ccd_bounding_radius(w, c2), 2.0f * slop)) return;
                 const CcdShape s1 = ccd_shape_of<CONVEX>(w, c2);
                 const float cur = __uint_as_float(__hip_atomic_load(&best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                 const float hit = ccd_cast_pair<CONVEX>(s1, tp, s2, pwp, sw, rot_radius, cur, slop);
                 if (hit > 0.0f && hit < cur) atomicMin(&best, __float_as_uint(hit));
+            };
+            if (use_grid) {
+                // tier 0 sweeps FIXED colliders: their fat AABBs are where they stand, and the broad phase's grid (which follows every
+                // collider: rp_grid.h) finds the ones whose box meets the swept volume's box — the centre-of-mass segment inflated by
+                // max_extent + 2 slop, what ccd_may_reach measures against — instead of a walk over every collider of the world per fast
+                // body (23 % of a step in which thousands of small shapes land: profiles/r04_shapes_rain_kernel_stats.txt).  The large
+                // list (slabs, walls, half-spaces) is walked whole; a collider met through several cells is taken from the cell that
+                // holds the min corner of (its box ∩ the query box).  The earliest fraction is an atomicMin: no order dependence.
+                for (int q = threadIdx.x; q < n_large; q += blockDim.x) try_target(w.large_list[q]);
+                const int gcur = BP_GPAR(w);
+                for (int idx = threadIdx.x; idx < ncell * RP_BP_BUCKET; idx += blockDim.x) {
+                    const int cell = idx / RP_BP_BUCKET, e = idx % RP_BP_BUCKET;
+                    const int x = qlo[0] + cell % qnx, y = qlo[1] + (cell / qnx) % qny, z = qlo[2] + cell / (qnx * qny);
+                    const int h = (int)(rp_hash64(cell_key(x, y, z)) & (unsigned long long)(w.grid_cap - 1));
+                    int nb = w.bk_cnt[gcur][h]; if (nb > RP_BP_BUCKET) nb = RP_BP_BUCKET;
+                    if (e >= nb) continue;
+                    const int it = w.bk_items[gcur][(size_t)h * RP_BP_BUCKET + e], j = it & 0xffffff;
+                    if (w.c_inlarge[j] || !bp_entry_is_cell(w, it, x, y, z)) continue;
+                    const float4 jmn = w.c_fatmin[j];
+                    if (cell_coord(fmaxf(jmn.x, qmn.x), ic) != x || cell_coord(fmaxf(jmn.y, qmn.y), ic) != y || cell_coord(fmaxf(jmn.z, qmn.z), ic) != z) continue;
+                    try_target(j);
+                }
+            } else {
+                for (int c2 = threadIdx.x; c2 < w.n_colliders; c2 += blockDim.x) try_target(c2);
             }
           }
         }
@@ -292,7 +330,7 @@ bool rp_ccd_launches(const DevWorld &w) { return !(w.prm.p.max_ccd_substeps == 0
 void rp_launch_ccd(const DevWorld &w, hipStream_t st, int has_bullets, int publish) {
     if (!rp_ccd_launches(w)) return;
     if (w.has_convex) { // worlds with a cylinder / cone: the distance of such a pair is a GJK run (rp_convex.h)
-        hipLaunchKernelGGL(k_ccd<true>, dim3(64), dim3(256), 0, st, w, 0, publish);
+        hipLaunchKernelGGL(k_ccd<true>, dim3(240), dim3(256), 0, st, w, 0, publish);
         if (has_bullets) hipLaunchKernelGGL(k_ccd<true>, dim3(64), dim3(256), 0, st, w, 1, 0);
         return;
     }
