@@ -1371,6 +1371,7 @@ static int finalize(rp_world *w) {
     d.gbar_blocks = gbar_grid_for_device(w->device);
     { const char *ni = getenv("RP_NO_BP_INCR"); d.bp_incremental = (ni && ni[0] == '1') ? 0 : 1; }
     { const char *ab = getenv("RP_BP_ALWAYS_BUILD"); d.bp_always_build = (ab && ab[0] == '1') ? 1 : 0; }
+    { const char *nt = getenv("RP_NO_TINY_ROUTING"); d.isl_route_tiny = (nt && nt[0] == '1') ? 0 : 1; }
     { const char *ig = getenv("RP_ISL_GENERIC"); d.isl_generic = (ig && ig[0] == '1') ? 1 : 0; }
     w->compound = world_has_compound_bodies(w); refresh_ccd_facts(w);
     int nb = (int)w->bodies.size(), nc = (int)w->colliders.size();

@@ -68,7 +68,7 @@ RP_DEV bool lay_warm(const DevWorld &w) {
 }
 RP_DEV void lay_isl_init(DevWorld &w, int gid, int gstride, bool warm) {
     const int i = gid;
-    if (i == 0) { w.flags[FL_N_ISLANDS] = 0; w.flags[FL_N_GLOB_BODIES] = 0; w.flags[FL_ISL_BODY_CURSOR] = 0; w.flags[FL_ISL_CONS_CURSOR] = 0; w.flags[FL_ISL_ICONS_CURSOR] = 0; }
+    if (i == 0) { w.flags[FL_N_ISLANDS] = 0; w.flags[FL_N_GLOB_BODIES] = 0; w.flags[FL_ISL_BODY_CURSOR] = 0; w.flags[FL_ISL_CONS_CURSOR] = 0; w.flags[FL_ISL_ICONS_CURSOR] = 0; w.lay_state[4] = 0; }
     for (size_t k = i, n = (size_t)128 * w.cb_words; k < n; k += (size_t)gstride) w.cb_bits[k] = 0u; // owner bitmaps of the colour stages
     for (int b = gid; b < w.n_bodies; b += gstride) { if (!warm) w.b_label[b] = b; w.r_nb[b] = 0; w.r_nc[b] = 0; w.r_ni[b] = 0; w.r_island[b] = -1; w.b_island[b] = -1; w.b_local[b] = -1; }
 }
@@ -179,11 +179,21 @@ RP_DEV void lay_isl_count(DevWorld &w, int gid, int stride) {
     }
 }
 // number the islands that fit one workgroup (registers + LDS)
+// Round 4: k_island_solve gives an island a whole workgroup (512 lanes for up to 145 manifolds) and runs 240 of them at a time — right
+// for piles, wasteful for debris: 4,400 islands of one to five bodies (thousands of small shapes on a floor) are 18 passes, 1.35 ms.
+// When the previous rebuild counted more than RP_ISL_MANY candidates, components of at most RP_ISL_TINY_NC manifolds stay on the global
+// path, whose colour stages / LDS tiles take them all at once (either path gives the same bits: a routing decision, not a result).
+// lay_state[3] = candidates of the last rebuild (written behind its last barrier), [4] = this rebuild's count.
+#define RP_ISL_MANY 960
+#define RP_ISL_TINY_NC 8
 RP_DEV void lay_isl_number(DevWorld &w, int gid, int gstride) {
+  const bool route_tiny = w.isl_route_tiny && w.lay_state[3] > RP_ISL_MANY;
   for (int b = gid; b < w.n_bodies; b += gstride) {
     if (!is_dyn(w, b) || w.b_label[b] != b) continue;
     int cnb = w.r_nb[b], cnc = w.r_nc[b];
-    if (cnc > 0 && cnb <= RP_ISL_NB_MAX && cnc <= RP_ISL_NC_MAX) {
+    const bool candidate = cnc > 0 && cnb <= RP_ISL_NB_MAX && cnc <= RP_ISL_NC_MAX;
+    if (candidate) atomicAdd(&w.lay_state[4], 1);
+    if (candidate && !(route_tiny && cnc <= RP_ISL_TINY_NC)) {
         int id = atomicAdd(&w.flags[FL_N_ISLANDS], 1);
         w.isl_body_begin[id] = atomicAdd(&w.flags[FL_ISL_BODY_CURSOR], cnb);
         w.isl_cons_begin[id] = atomicAdd(&w.flags[FL_ISL_CONS_CURSOR], cnc);
@@ -397,7 +407,7 @@ __global__ void __launch_bounds__(1024) k_layout_rebuild(DevWorld w) {
         GBAR_SYNC(bar); RP_PASS_STAMP(w, 200);
     }
     gbar_end(bar);
-    if (gid == 0) { w.flags[FL_UF_NPAIRS] = 0; w.lay_state[0] = 1; w.lay_state[1] += 1; w.lay_state[2] = w.flags[FL_N_GLOB_BODIES]; __hip_atomic_store(&w.flags[FL_LAYOUT_DIRTY], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    if (gid == 0) { w.flags[FL_UF_NPAIRS] = 0; w.lay_state[0] = 1; w.lay_state[1] += 1; w.lay_state[2] = w.flags[FL_N_GLOB_BODIES]; w.lay_state[3] = w.lay_state[4]; __hip_atomic_store(&w.flags[FL_LAYOUT_DIRTY], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 }
 
 // ---- register-resident constraint of one island thread ------------------------------------------

@@ -200,6 +200,7 @@ struct DevWorld {
     int bp_incremental;    // the broad phase may update incrementally (0: RP_NO_BP_INCR=1, every pass is a full rebuild)
     int gbar_blocks;       // most workgroups (of 1024 threads) a grid-barrier kernel may use on this device: all of them resident at once (rp_gridbar.h)
     int has_sensors;       // some collider is a sensor: its pairs are intersection-tested every step (full step path)
+    int isl_route_tiny;    // 1 (RP_NO_TINY_ROUTING=1: 0): worlds with thousands of tiny islands solve them on the global path (rp_islands.hip, lay_isl_number)
     int bp_always_build;   // RP_BP_ALWAYS_BUILD=1: every full broad-phase rebuild runs its build pass (A/B switch for the kept-grid rebuild, rp_broadphase.hip)
     int has_convex;        // some collider is a cylinder / cone / convex polyhedron: the narrow-phase, sensor and CCD launches use their CONVEX instantiations (rp_convex.h)
     // convex polyhedra (rp_polyhedron.h), flattened: per shape {first point, points, first face, faces}; points (w: max |p|); face normals;
@@ -378,7 +379,7 @@ struct DevWorld {
     // ---- shard guard (multi-GPU island sharding: this world holds one shard, the cells below belong to the others) ----
     float4 *sg_bmin, *sg_bmax;  // [boxes] AABBs that hold the bodies of OTHER shards (one per foreign proximity group); null = no guard
     int *sg_cell_start, *sg_cell_items; // coarse uniform grid over the boxes: CSR lists of the boxes touching each cell (x fastest)
-    int *lay_state;             // [16] layout-rebuild state that survives between rebuilds: [0] the flat component labels of the last rebuild are still valid (cleared by every edit of the world), [1] rebuilds so far, [2] global-path bodies the last rebuild counted; the broad phase keeps [8] the parity of the grid copy in service and [9] the rebuilds that kept the grid since its last build pass (rp_broadphase.hip)
+    int *lay_state;             // [16] layout-rebuild state that survives between rebuilds: [0] the flat component labels of the last rebuild are still valid (cleared by every edit of the world), [1] rebuilds so far, [2] global-path bodies the last rebuild counted; the broad phase keeps [8] the parity of the grid copy in service and [9] the rebuilds that kept the grid since its last build pass (rp_broadphase.hip); [3] / [4] island candidates of the last / the running layout rebuild (rp_islands.hip)
     int *sg_hit;                // [bodies] 1 = a rewritten fat AABB of the body overlapped a foreign box (read and cleared by rp_world_shard_guard_take_hits)
     float sg_origin[3], sg_inv_cell; int sg_dims[3];
     int c_par;                  // which copy of the MUTABLE constraint planes (impulses, accumulators, rhs: NP_M x 4, CP_HM0, CP_HM1) is current:
