@@ -224,3 +224,22 @@ def test_fountain_churn_with_the_references_shapes_in_lockstep():
             np.testing.assert_array_equal(gp, op[idx], err_msg=f"step {step_id}"); np.testing.assert_array_equal(gv, ov[idx], err_msg=f"step {step_id}")
     g.step(1); o.step(1)          # (the pairs of the bodies removed last leave the oracle's pair set with its next broad-phase pass)
     assert g.counters()["overflow_flags"] == 0 and g.counters()["num_pairs"] == o.stats()["num_pairs"]
+
+
+def test_thousands_of_tiny_islands_take_the_global_path_bit_exact(monkeypatch):
+    """S.shapes_rain: 3,000 bodies of all ten shape kinds landing on a slab = far more than 960 islands of a few bodies each, which the
+    layout rebuild then leaves on the global path (rp_islands.hip, lay_isl_number); the oracle, and the same world with
+    RP_NO_TINY_ROUTING=1 (every island its own workgroup), must agree bit for bit"""
+    sc = S.shapes_rain(3000)
+    g, o = PhysicsWorld.from_scene(sc), OracleWorld(sc)
+    monkeypatch.setenv("RP_NO_TINY_ROUTING", "1")
+    h = PhysicsWorld.from_scene(sc)
+    monkeypatch.delenv("RP_NO_TINY_ROUTING")
+    for cp in (20, 60, 120, 200):
+        n = cp - (0 if cp == 20 else {60: 20, 120: 60, 200: 120}[cp])
+        g.step(n); o.step(n); h.step(n)
+        gp, gv = g.read_bodies(); op, ov = o.read(); hp, hv = h.read_bodies()
+        np.testing.assert_array_equal(gp, op, err_msg=f"step {cp}"); np.testing.assert_array_equal(gv, ov, err_msg=f"step {cp}")
+        np.testing.assert_array_equal(gp, hp, err_msg=f"step {cp} (routing)"); np.testing.assert_array_equal(gv, hv, err_msg=f"step {cp} (routing)")
+    c = g.counters()
+    assert c["overflow_flags"] == 0 and c["num_manifolds"] == o.stats()["num_active_manifolds"] > 2000
