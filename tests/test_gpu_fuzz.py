@@ -25,7 +25,7 @@ _CONVEX = [False]   # set by _scene(convex=True): cylinders and cones join the d
 
 
 def _rand_collider(rng, scale=1.0):
-    kind = rng.integers(0, (5 + (1 if _CONVEX[0] > 1 else 0)) if _CONVEX[0] else 3)
+    kind = rng.integers(0, (5 + (1 if _CONVEX[0] > 1 else 0) + (3 if _CONVEX[0] > 5 else 0)) if _CONVEX[0] else 3)   # (> 5: the round variants join)
     kw = dict(density=float(rng.uniform(0.5, 3.0)), friction=float(rng.choice([0.0, 0.3, 0.5, 1.0])),
               restitution=float(rng.choice([0.0, 0.0, 0.3, 0.8])), friction_rule=int(rng.integers(0, 6)), restitution_rule=int(rng.integers(0, 6)))
     if kind == 0:
@@ -34,6 +34,11 @@ def _rand_collider(rng, scale=1.0):
         return dict(shape=S.SHAPE_CUBOID, half_extents=tuple(float(x) * scale for x in rng.uniform(0.15, 0.6, size=3)), **kw)
     if kind == 3:
         return dict(shape=S.SHAPE_CYLINDER, half_extents=(float(rng.uniform(0.15, 0.5)) * scale, float(rng.uniform(0.15, 0.5)) * scale, 0.0), **kw)
+    if kind >= 6:       # RoundShape<S>: round cuboid / cylinder / cone
+        br = float(rng.uniform(0.03, 0.1)) * scale
+        if kind == 6:
+            return dict(shape=S.SHAPE_ROUND_CUBOID, half_extents=tuple(float(x) * scale for x in rng.uniform(0.12, 0.45, size=3)), border_radius=br, **kw)
+        return dict(shape=S.SHAPE_ROUND_CYLINDER if kind == 7 else S.SHAPE_ROUND_CONE, half_extents=(float(rng.uniform(0.15, 0.4)) * scale, float(rng.uniform(0.15, 0.4)) * scale, 0.0), border_radius=br, **kw)
     if kind == 5:       # one of the polyhedra _scene registered (scaled shapes are not: a polyhedron has the size it was registered with)
         return dict(shape=S.SHAPE_CONVEX, half_extents=(float(rng.integers(0, _CONVEX[0] - 1)), 0.0, 0.0), **kw)
     if kind == 4:
@@ -478,3 +483,22 @@ def test_fuzz_with_the_round3_broad_phase_forms(seed, monkeypatch):
     (the forms before the kept-grid rebuild and the grid look-up of round 4) — the A/B switch must not change a bit"""
     monkeypatch.setenv("RP_BP_ALWAYS_BUILD", "1")
     _run(seed, steps=200, params=seed >= 2000)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [60, 61, 62, 2019])
+def test_fuzz_round_shapes_bit_exact(seed):
+    """... and with the round variants (RoundShape<S>: border radii through the same GJK / EPA path) in the draw, next to five registered
+    polyhedra, cylinders and cones"""
+    try:
+        _run(seed, steps=200, params=seed >= 2000, convex=6)
+    finally:
+        _CONVEX[0] = False
+
+
+@pytest.mark.parametrize("seed", [60])
+def test_fuzz_round_shapes_on_the_oracle_twin(seed):
+    try:
+        _run(seed, steps=120, world=OracleTwin, convex=6)
+    finally:
+        _CONVEX[0] = False

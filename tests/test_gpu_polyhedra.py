@@ -132,3 +132,25 @@ def test_bad_polyhedra_are_refused():
     g.insert_collider(S.collider_desc(shape=S.SHAPE_CONVEX, half_extents=(pid, 0, 0)), hb)
     with pytest.raises(RapierHipError):
         g.insert_collider(S.collider_desc(shape=S.SHAPE_CONVEX, half_extents=(pid + 1, 0, 0)), hb)                # no such polyhedron
+
+
+def test_a_polyhedron_of_256_vertices_and_one_too_many():
+    """the vertex limit of a registered polyhedron (RP_POLY_MAX_VERTS): a 256-vertex geodesic-like hull works (support scans over all of
+    them), 257 hull vertices are refused"""
+    def sphere(n):
+        i = np.arange(n) + 0.5
+        phi, th = np.arccos(1 - 2 * i / n), np.pi * (1 + 5 ** 0.5) * i
+        return np.stack([np.cos(th) * np.sin(phi), np.cos(phi), np.sin(th) * np.sin(phi)], 1).astype(np.float32) * np.float32(0.5)
+    sc = S.Scene(name="poly256", gravity=(0.0, -9.81, 0.0))
+    gnd = sc.add_body(body_type=S.BODY_FIXED, translation=(0, -0.5, 0)); sc.add_collider(gnd, half_extents=(10, 0.5, 10))
+    pid = sc.add_convex_polyhedron(sphere(256))
+    for k in range(3):
+        b = sc.add_body(translation=(0.2 * k, 1.0 + 1.2 * k, 0.1 * k), angvel=(1.0, 0.0, 0.5))
+        sc.add_collider(b, shape=S.SHAPE_CONVEX, half_extents=(pid, 0, 0))
+    for step, g, o, ev in _lockstep(sc, 240, every=8):
+        pass
+    assert len(g.read_convex_polyhedron(pid)["points"]) == 256
+    pos, _ = g.read_bodies()
+    assert pos[1:4, 1].min() > 0.45                                       # three 256-vertex "balls" of radius 0.5: on the ground (or on each other), not in it
+    with pytest.raises(RapierHipError):
+        g.add_convex_polyhedron(sphere(257))
