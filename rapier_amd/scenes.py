@@ -1014,3 +1014,117 @@ def shapes_rain(n: int = 8000, seed: int = 1, spacing: float = 1.6) -> Scene:
                     s.add_collider(b, shape=SHAPE_ROUND_CONVEX_POLYHEDRON, half_extents=(polys[(k // 10) % 8], 0, 0), border_radius=br)
                 k += 1
     return s
+
+
+# ---- the reference's box3d ports that need convex hulls (examples3d/b3d_junkyard.rs, b3d_washer.rs; not BASELINE configs) ----
+def _b3_rock(radius: float = 1.5) -> np.ndarray:
+    """b3d_junkyard.rs:102-124 (box3d b3CreateRock): 10 points of a Fibonacci lattice on a sphere, the angle advanced by the rotation
+    recurrence of the original, in f32"""
+    f = np.float32
+    n = 10
+    phi = (f(1.0) + np.sqrt(f(5.0))) / f(2.0)
+    theta = f(2.0) * f(np.pi) / phi
+    ds, dc = np.sin(theta, dtype=np.float32), np.cos(theta, dtype=np.float32)
+    c, s = f(1.0), f(0.0)
+    pts = []
+    for i in range(n):
+        z = f(1.0) - (f(2.0) * f(i) + f(1.0)) / f(n)
+        rxy = np.sqrt(f(1.0) - z * z)
+        pts.append((f(radius) * rxy * c, f(radius) * rxy * s, f(radius) * z))
+        c, s = dc * c - ds * s, ds * c + dc * s
+    return np.array(pts, np.float32)
+
+
+def _b3_cylinder(height: float, radius: float, y_offset: float, sides: int) -> np.ndarray:
+    """b3d_junkyard.rs:84-100 (box3d b3CreateCylinder): 2 * sides points of a Y cylinder with its base at y_offset"""
+    f = np.float32
+    da, a, pts = f(2.0) * f(np.pi) / f(sides), f(0.0), []
+    for _ in range(sides):
+        sa, ca = np.sin(a, dtype=np.float32), np.cos(a, dtype=np.float32)
+        pts.append((f(radius) * ca, f(y_offset), f(radius) * sa))
+        pts.append((f(radius) * ca, f(y_offset) + f(height), f(radius) * sa))
+        a = a + da
+    return np.array(pts, np.float32)
+
+
+def junkyard(layers: int = 24, nx: int = 21, nz: int = 21) -> Scene:
+    """examples3d/b3d_junkyard.rs:10-81 (box3d `junkyard`): a walled arena (one fixed body, five cuboids), `layers` x 21 x 21 convex
+    "rocks" that share ONE hull (SharedShape::convex_hull(&create_rock(1.5))), and an orbiting kinematic position-based pusher — a
+    32-point cylinder hull — driven every step through junkyard_pusher_target.  Full size: 10,584 rocks."""
+    s = Scene(name=f"b3d_junkyard_{layers}x{nx}x{nz}", gravity=(0.0, -10.0, 0.0))
+    g = s.add_body(body_type=BODY_FIXED, translation=(0.0, -1.0, 0.0))
+    s.add_collider(g, half_extents=(120.0, 1.0, 120.0))
+    for hx, hy, hz, off in ((1.0, 8.0, 50.0, (-50.0, 8.0, 0.0)), (1.0, 8.0, 50.0, (50.0, 8.0, 0.0)), (50.0, 8.0, 1.0, (0.0, 8.0, -50.0)), (50.0, 8.0, 1.0, (0.0, 8.0, 50.0))):
+        s.add_collider(g, half_extents=(hx, hy, hz), translation=off)
+    rock = s.add_convex_polyhedron(_b3_rock(1.5))
+    height = np.float32(24.0)
+    for y in range(layers):
+        for x in range(nx):
+            for z in range(nz):
+                pos = (np.float32(-40.0) + np.float32(4.0) * np.float32(x), np.float32(4.0) * np.float32(y) + height + np.float32(1.0), np.float32(-40.0) + np.float32(4.0) * np.float32(z))
+                b = s.add_body(translation=tuple(float(v) for v in pos))
+                s.add_collider(b, shape=SHAPE_CONVEX, half_extents=(rock, 0, 0))
+    pusher = s.add_body(body_type=BODY_KINEMATIC_POSITION, translation=(35.0, 0.0, 0.0))
+    s.add_collider(pusher, shape=SHAPE_CONVEX, half_extents=(s.add_convex_polyhedron(_b3_cylinder(24.0, 4.0, 0.0, 16)), 0, 0))
+    s.pusher = pusher
+    return s
+
+
+def junkyard_pusher_target(step: int) -> np.ndarray:
+    """b3d_junkyard.rs:69-78: the pusher's next_kinematic_translation before step `step` (1-based): 35 m from the axis, -6 degrees per second"""
+    f = np.float32
+    degrees = f(0.0)
+    for _ in range(step):
+        degrees = degrees + f(-6.0) * (f(1.0) / f(60.0))
+    rad = degrees * f(np.pi) / f(180.0)
+    return np.array([f(35.0) * np.cos(rad, dtype=np.float32), 0.0, f(35.0) * np.sin(rad, dtype=np.float32), 0.0, 0.0, 0.0, 1.0], np.float32)
+
+
+def _qrot_f32(q, v):
+    """glam Quat * Vec3 in f32"""
+    f = np.float32
+    b = np.array(q[:3], np.float32); w = f(q[3]); v = np.array(v, np.float32)
+    b2 = b @ b
+    return (v * (w * w - b2) + b * ((v @ b) * f(2.0)) + np.cross(b, v).astype(np.float32) * (w * f(2.0))).astype(np.float32)
+
+
+def washer(grid: int = 20) -> Scene:
+    """examples3d/b3d_washer.rs:10-100 (box3d `washer`): a kinematic velocity-based ring — 36 outer segments + 4 paddles, each its own
+    8-point convex hull, on ONE body that turns at 25 degrees per second — tumbling a grid^3 block of 0.4 m cubes of density 1000.
+    Full size: 8,000 cubes."""
+    f = np.float32
+    s = Scene(name=f"b3d_washer_{grid}", gravity=(0.0, -10.0, 0.0))
+    g = s.add_body(body_type=BODY_FIXED, translation=(0.0, -1.0, 0.0))
+    s.add_collider(g, half_extents=(60.0, 1.0, 60.0))
+    ring = s.add_body(body_type=BODY_KINEMATIC_VELOCITY, translation=(0.0, 21.0, 0.0), angvel=(0.0, 0.0, float(f(np.pi) / f(180.0) * f(25.0))), linvel=(0.001, -0.002, 0.0))
+    r0, r1, r2 = f(14.0), f(16.0), f(18.0)
+    neg_d, pos_d = np.array([0, 0, -10], np.float32), np.array([0, 0, 10], np.float32)
+    angle = f(np.pi) / f(18.0)
+
+    def axis_z(a):
+        return (0.0, 0.0, float(np.sin(a * f(0.5), dtype=np.float32)), float(np.cos(a * f(0.5), dtype=np.float32)))
+    q, qo = axis_z(angle), axis_z(f(0.1) * angle)
+    qo_inv = (-qo[0], -qo[1], -qo[2], qo[3])
+    u1 = np.array([1, 0, 0], np.float32)
+    for i in range(36):
+        u2 = np.array([1, 0, 0], np.float32) if i == 35 else _qrot_f32(q, u1)
+        a1, a2 = _qrot_f32(qo_inv, u1), _qrot_f32(qo, u2)
+        pts = [neg_d + r1 * a1, neg_d + r2 * a1, neg_d + r1 * a2, neg_d + r2 * a2, pos_d + r1 * a1, pos_d + r2 * a1, pos_d + r1 * a2, pos_d + r2 * a2]
+        s.add_collider(ring, shape=SHAPE_CONVEX, half_extents=(s.add_convex_polyhedron(np.array(pts, np.float32)), 0, 0))
+        if i % 9 == 0:
+            pts = [neg_d + r0 * u1, neg_d + r1 * u1, neg_d + r0 * u2, neg_d + r1 * u2, pos_d + r0 * u1, pos_d + r1 * u1, pos_d + r0 * u2, pos_d + r1 * u2]
+            s.add_collider(ring, shape=SHAPE_CONVEX, half_extents=(s.add_convex_polyhedron(np.array(pts, np.float32)), 0, 0))
+        u1 = u2
+    a = f(0.2)
+    x = f(-2.0) * a * f(grid)
+    for _ in range(grid):
+        y = f(-2.0) * a * f(grid) + f(21.0)
+        for _ in range(grid):
+            z = f(-2.0) * a * f(grid)
+            for _ in range(grid):
+                b = s.add_body(translation=(float(x), float(y), float(z)))
+                s.add_collider(b, half_extents=(float(a), float(a), float(a)), density=1000.0)
+                z = z + f(4.0) * a
+            y = y + f(4.0) * a
+        x = x + f(4.0) * a
+    return s
