@@ -1416,7 +1416,7 @@ static int finalize(rp_world *w) {
     DAFC(d.b_isl, capb, 0xff, DOM_BODY, 1, 1); DAC(d.pi_used, capb, DOM_BODY, 1, 1); DAC(d.pi_nb, capb, DOM_BODY, 1, 1); DAC(d.pi_dirty, capb, DOM_BODY, 1, 1); DAC(d.pi_denied, capb, DOM_BODY, 1, 1);
     DAC(d.pi_sleeping, capb, DOM_BODY, 1, 1); DAC(d.pi_free, capb, DOM_BODY, 1, 1); DA(d.pi_uf, capb); DA(d.pi_new, capb); DA(d.pi_best, capb); DA(d.pi_csize, capb); DA(d.pi_cisl, capb); DA(d.pi_list, capb);
     DAC(d.pi_w64, 4, DOM_FIXED, 1, 1); DAC(d.pi_stats, 16, DOM_FIXED, 1, 1);
-    DA(d.sg_hit, capb); DA(d.lay_state, 16);
+    DA(d.sg_hit, capb); DA(d.lay_state, 16); DA(d.ov_owner, d.cons_cap);
     DAC(d.s_lin, capb, DOM_BODY, 1, 1); DAC(d.s_ang, capb, DOM_BODY, 1, 1); DAC(d.s_rot, capb, DOM_BODY, 1, 1); DAC(d.s_trans, capb, DOM_BODY, 1, 1); DAC(d.s_incl, capb, DOM_BODY, 1, 1); DAC(d.s_inca, capb, DOM_BODY, 1, 1);
     DAC(d.b_cmask, 4 * (size_t)capb, DOM_BODY, 1, 4); DAFC(d.b_min, capb, 0xff, DOM_BODY, 1, 1);
     DAC(d.c_parent, capc, DOM_COLL, 1, 1); DAC(d.c_ord, capc, DOM_COLL, 1, 1); DAC(d.c_shape, capc, DOM_COLL, 1, 1); DAC(d.c_lpos, capc, DOM_COLL, 1, 1); DAC(d.c_lrot, capc, DOM_COLL, 1, 1); DAC(d.c_pos, capc, DOM_COLL, 1, 1); DAC(d.c_rot, capc, DOM_COLL, 1, 1); DAC(d.c_he, capc, DOM_COLL, 1, 1);

@@ -200,8 +200,13 @@ RP_DEV void tail_sweep(const DevWorld &w, int first, bool fib, float solved_dt) 
         __syncthreads();
     }
     if (w.flags[FL_HAS_OVERFLOW_COLOR]) {
-        if (threadIdx.x == 0) {
-            int beg = w.stage_begin[nst], cnt = w.stage_count[nst];
+        const int beg = w.stage_begin[nst], cnt = w.stage_count[nst];
+        if (w.lay_state[5] && cnt > 8) {
+            // every overflow manifold has one dynamic side (lay_rank_overflow, rp_islands.hip): each thread sweeps, in key order, the
+            // manifolds of the bodies it owns — what the serial sweep computes, since manifolds of different owners share no written side
+            const unsigned nt = blockDim.x;
+            for (int i = 0; i < cnt; ++i) if ((unsigned)w.ov_owner[i] % nt == threadIdx.x) cons_apply_model<COUL>(w, GlobalAccT<PRE>(w, beg + i), MODE, fib, solved_dt);
+        } else if (threadIdx.x == 0) {
             for (int i = 0; i < cnt; ++i) { cons_apply_model<COUL>(w, GlobalAccT<PRE>(w, beg + i), MODE, fib, solved_dt); __threadfence(); }
         }
         __threadfence();

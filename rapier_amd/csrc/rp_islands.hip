@@ -365,6 +365,20 @@ RP_DEV void lay_rank_overflow(DevWorld &w) { // workgroup 0, after a grid barrie
         }
         __threadfence(); __syncthreads();
     }
+    // Who may sweep the overflow colour in parallel (tail_sweep, rp_global.h): a manifold with ONE dynamic side — its other side a
+    // kinematic body whose 120 colours ran out: b3d_washer's ring holds thousands of contacts — only shares a side nobody writes, so
+    // manifolds of different owners commute bit for bit.  ov_owner[i] = that dynamic body; lay_state[5] = every overflow manifold has one
+    if (on >= 1 && ob + on <= w.cons_cap) {
+        if (threadIdx.x == 0) w.lay_state[5] = 1;
+        __threadfence(); __syncthreads();
+        for (int i = threadIdx.x; i < on; i += blockDim.x) {
+            const int2 rb = w.p_rb[ld_i32(&w.cons_pair[ob + i])];
+            const bool d1 = rb.x >= 0 && (w.b_flags[rb.x] & RP_BF_TYPE_MASK) == RP_BODY_DYNAMIC, d2 = rb.y >= 0 && (w.b_flags[rb.y] & RP_BF_TYPE_MASK) == RP_BODY_DYNAMIC;
+            w.ov_owner[i] = d1 && d2 ? -1 : (d1 ? rb.x : (d2 ? rb.y : 0));
+            if (d1 && d2) w.lay_state[5] = 0; // (two dynamic sides: the serial order is part of the result)
+        }
+        __threadfence(); __syncthreads();
+    }
 }
 
 // The whole layout rebuild in ONE launch (rp_gridbar.h): colour buckets (maintain_solver_contact_graph, solver_graph.rs:129-361),

@@ -379,7 +379,8 @@ struct DevWorld {
     // ---- shard guard (multi-GPU island sharding: this world holds one shard, the cells below belong to the others) ----
     float4 *sg_bmin, *sg_bmax;  // [boxes] AABBs that hold the bodies of OTHER shards (one per foreign proximity group); null = no guard
     int *sg_cell_start, *sg_cell_items; // coarse uniform grid over the boxes: CSR lists of the boxes touching each cell (x fastest)
-    int *lay_state;             // [16] layout-rebuild state that survives between rebuilds: [0] the flat component labels of the last rebuild are still valid (cleared by every edit of the world), [1] rebuilds so far, [2] global-path bodies the last rebuild counted; the broad phase keeps [8] the parity of the grid copy in service and [9] the rebuilds that kept the grid since its last build pass (rp_broadphase.hip); [3] / [4] island candidates of the last / the running layout rebuild (rp_islands.hip)
+    int *ov_owner;              // [cons_cap] per manifold of the overflow colour (in sweep order): the dynamic body that owns it, -1 = two dynamic sides (lay_rank_overflow)
+    int *lay_state;             // [16] layout-rebuild state that survives between rebuilds: [0] the flat component labels of the last rebuild are still valid (cleared by every edit of the world), [1] rebuilds so far, [2] global-path bodies the last rebuild counted; the broad phase keeps [8] the parity of the grid copy in service and [9] the rebuilds that kept the grid since its last build pass (rp_broadphase.hip); [3] / [4] island candidates of the last / the running layout rebuild, [5] the overflow colour may be swept owner-parallel (rp_islands.hip)
     int *sg_hit;                // [bodies] 1 = a rewritten fat AABB of the body overlapped a foreign box (read and cleared by rp_world_shard_guard_take_hits)
     float sg_origin[3], sg_inv_cell; int sg_dims[3];
     int c_par;                  // which copy of the MUTABLE constraint planes (impulses, accumulators, rhs: NP_M x 4, CP_HM0, CP_HM1) is current:

@@ -15,6 +15,7 @@ variants = {
     "many_pyramids_sleep": lambda: S.many_pyramids().enable_sleep(),
     "many_pyramids_coulomb": lambda: _with(S.many_pyramids(), "friction_model", S.FRICTION_COULOMB),
     "many_pyramids_events": lambda: S.many_pyramids().enable_events(3, 100.0),
+    "washer": S.washer, "junkyard": S.junkyard,   # the reference's box3d ports (tools/b3d_ports.py; the junkyard's pusher stands still here)
     "shapes_rain": lambda: S.shapes_rain(8000),   # all ten shape kinds landing on a slab (tools/shapes_bench.py)
 }
 
