@@ -175,3 +175,37 @@ def test_clutter_of_polyhedra_settles_on_the_oracle():
     np.testing.assert_array_equal(pa, pb)
     dyn = [i for i, d in enumerate(sc.bodies) if int(d["body_type"]) == S.BODY_DYNAMIC]
     assert np.isfinite(pa).all() and pa[dyn, 1].min() > 0.0 and pa[dyn, 1].max() < 3.5 and np.abs(pa[dyn][:, [0, 2]]).max() < 4.5
+
+
+def test_hull_fuzz_against_qhull():
+    """120 clouds — gaussian, uniform, with duplicated points, box corners plus points on its faces, points on a sphere, clouds far from
+    the origin; 4..200 points, scales 1e-3..1e3: the library's hull has Qhull's volume and builds into a canonical polyhedron"""
+    from scipy.spatial import ConvexHull
+    rng = np.random.default_rng(0)
+    for k in range(120):
+        n, scale, kind = int(rng.integers(4, 200)), 10.0 ** rng.uniform(-3, 3), k % 6
+        if kind == 0:
+            pts = rng.standard_normal((n, 3))
+        elif kind == 1:
+            pts = rng.uniform(-1, 1, (n, 3))
+        elif kind == 2:
+            base = rng.standard_normal((max(4, n // 3), 3))
+            pts = np.concatenate([base, base[rng.integers(0, len(base), n)]])
+        elif kind == 3:
+            on = rng.uniform(-1, 1, (n, 3))
+            on[np.arange(n), rng.integers(0, 3, n)] = rng.choice([-1, 1], n)
+            pts = np.concatenate([np.array([[x, y, z] for x in (-1, 1) for y in (-1, 1) for z in (-1, 1)], float), on])
+        elif kind == 4:
+            v = rng.standard_normal((n, 3))
+            pts = v / np.linalg.norm(v, axis=1)[:, None]
+        else:
+            pts = rng.standard_normal((n, 3)) + np.array([50.0, -30.0, 20.0])
+        pts = np.ascontiguousarray(pts * scale, np.float32)
+        tris = product_hull(pts)
+        assert tris is not None, (k, kind, n, scale)
+        p = pts.astype(np.float64)
+        vol = sum(np.dot(p[a], np.cross(p[b], p[c])) for a, b, c in tris) / 6.0
+        qv = ConvexHull(p).volume
+        assert abs(vol - qv) <= 1e-5 * qv, (k, kind, n, scale, vol, qv)
+        if len(np.unique(tris)) <= 256:
+            assert product_build(pts, tris) is not None, (k, kind, n, scale)
