@@ -858,6 +858,15 @@ extern "C" int32_t rp_bodies_insert(rp_world *w, int32_t n, const rp_body_desc *
     // slots are rewritten in place, the rest follows the append path (in place, or through the growth carry-over)
     static const bool no_reuse = getenv("RP_NO_ARENA_REUSE") != nullptr; // (debug: append only, like rounds 1-3)
     const int n_reuse = no_reuse ? 0 : std::min<int>(n, (int)w->body_free.size());
+    // the WHOLE batch is validated before anything changes (and before the split below: a batch is inserted entirely or not at all)
+    if ((long long)w->bodies.size() + (n - n_reuse) >= 0xfffff) { w->err = "rp_bodies_insert: more than 2^20 - 1 bodies"; return RP_ERR_CAPACITY; }
+    for (int i = 0; i < n; ++i) if (descs[i].body_type < RP_BODY_DYNAMIC || descs[i].body_type > RP_BODY_KINEMATIC_VELOCITY) { w->err = "rp_bodies_insert: unknown body_type"; return RP_ERR_INVALID; }
+    for (int i = 0; i < n; ++i) if (descs[i].additional_solver_iterations < 0 || descs[i].additional_solver_iterations > 4096) { w->err = "rp_bodies_insert: additional_solver_iterations must be in [0, 4096]"; return RP_ERR_INVALID; }
+    { // the distinct-count limit of the solve groups is checked on the prospective values, before host or device state changes
+        std::vector<int> extras; group_table(w, extras);
+        for (int i = 0; i < n; ++i) if (descs[i].additional_solver_iterations > 0 && std::find(extras.begin(), extras.end(), descs[i].additional_solver_iterations) == extras.end()) extras.push_back(descs[i].additional_solver_iterations);
+        if ((int)extras.size() > RP_MAX_GROUPS) { w->err = "more than 15 distinct positive additional_solver_iterations values in one world"; return RP_ERR_CAPACITY; }
+    }
     if (n_reuse > 0 && n_reuse < n) {
         int r = rp_bodies_insert(w, n_reuse, descs, handles_out);
         return r != RP_OK ? r : rp_bodies_insert(w, n - n_reuse, descs + n_reuse, handles_out ? handles_out + n_reuse : nullptr);
@@ -868,14 +877,6 @@ extern "C" int32_t rp_bodies_insert(rp_world *w, int32_t n, const rp_body_desc *
         HIPCHK(w, hipSetDevice(w->device));
         int r = in_place ? settle(w) : grow_begin(w);
         if (r != RP_OK) return r;
-    }
-    if (!reuse && (long long)w->bodies.size() + n >= 0xfffff) { w->err = "rp_bodies_insert: more than 2^20 - 1 bodies"; return RP_ERR_CAPACITY; }
-    for (int i = 0; i < n; ++i) if (descs[i].body_type < RP_BODY_DYNAMIC || descs[i].body_type > RP_BODY_KINEMATIC_VELOCITY) { w->err = "rp_bodies_insert: unknown body_type"; return RP_ERR_INVALID; }
-    for (int i = 0; i < n; ++i) if (descs[i].additional_solver_iterations < 0 || descs[i].additional_solver_iterations > 4096) { w->err = "rp_bodies_insert: additional_solver_iterations must be in [0, 4096]"; return RP_ERR_INVALID; }
-    { // the distinct-count limit of the solve groups is checked on the prospective values, before host or device state changes
-        std::vector<int> extras; group_table(w, extras);
-        for (int i = 0; i < n; ++i) if (descs[i].additional_solver_iterations > 0 && std::find(extras.begin(), extras.end(), descs[i].additional_solver_iterations) == extras.end()) extras.push_back(descs[i].additional_solver_iterations);
-        if ((int)extras.size() > RP_MAX_GROUPS) { w->err = "more than 15 distinct positive additional_solver_iterations values in one world"; return RP_ERR_CAPACITY; }
     }
     if (reuse && w->finalized) { int r = purge_dead_pairs(w); if (r != RP_OK) return r; } // no pair may still name the slots' previous occupants
     int first_slot = -1;
@@ -1008,6 +1009,20 @@ extern "C" int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider
     if ((long long)w->colliders.size() + n >= (1ll << 24)) { w->err = "rp_colliders_insert: more than 2^24 - 1 colliders (the broad-phase grid's one-word entries)"; return RP_ERR_CAPACITY; }
     static const bool no_reuse = getenv("RP_NO_ARENA_REUSE") != nullptr;
     const int n_reuse = no_reuse ? 0 : std::min<int>(n, (int)w->coll_free.size()); // Arena::insert: removed slots first (see rp_bodies_insert)
+    { // parents and per-body collider counts of the WHOLE batch, before anything changes and before the split below
+        std::vector<std::pair<int, int>> added; int added_free = 0; // (parent, colliders this batch gives it)
+        for (int i = 0; i < n; ++i) {
+            int parent = -1;
+            if (parents && parents[i] != RP_INVALID_HANDLE) {
+                parent = body_of(w, parents[i]);
+                if (parent < 0 || w->bodies[parent].quarantined) { w->err = "rp_colliders_insert: invalid parent handle (unknown, stale, removed or quarantined body)"; return RP_ERR_INVALID; }
+            }
+            int count = 0;
+            if (parent < 0) count = ++added_free;
+            else { auto it = std::find_if(added.begin(), added.end(), [&](const std::pair<int, int> &e) { return e.first == parent; }); if (it == added.end()) { added.push_back({parent, 1}); count = 1; } else count = ++it->second; }
+            if ((parent >= 0 ? w->bodies[parent].next_ord : w->next_free_ord) + count > (parent >= 0 ? 4096 : (1 << 20))) { w->err = "rp_colliders_insert: more than 4,096 colliders on one body (or 2^20 without a parent)"; return RP_ERR_CAPACITY; }
+        }
+    }
     if (n_reuse > 0 && n_reuse < n) {
         int r = rp_colliders_insert(w, n_reuse, descs, parents, handles_out);
         return r != RP_OK ? r : rp_colliders_insert(w, n - n_reuse, descs + n_reuse, parents ? parents + n_reuse : nullptr, handles_out ? handles_out + n_reuse : nullptr);
@@ -1097,6 +1112,7 @@ extern "C" int32_t rp_impulse_joints_insert(rp_world *w, int32_t n, const rp_joi
     for (int i = 0; i < n; ++i) {
         const rp_joint_desc &j = descs[i];
         if (j.body1 < 0 || j.body2 < 0 || j.body1 >= (int)w->bodies.size() || j.body2 >= (int)w->bodies.size()) { w->err = "rp_impulse_joints_insert: invalid body index"; return RP_ERR_INVALID; }
+        if (w->bodies[(size_t)j.body1].removed || w->bodies[(size_t)j.body2].removed) { w->err = "rp_impulse_joints_insert: a joint names a removed body (a free arena slot)"; return RP_ERR_INVALID; }
         if ((j.locked_axes & ~0x3fu) != 0 || (j.limit_axes & ~0x3fu) != 0 || (j.motor_axes & ~0x3fu) != 0) { w->err = "rp_impulse_joints_insert: locked_axes / limit_axes / motor_axes must be JointAxesMasks (coupled axes are not implemented on the device path)"; return RP_ERR_INVALID; }
         for (int a = 0; a < 6; ++a) if (j.motors[a].model != RP_MOTOR_ACCELERATION_BASED && j.motors[a].model != RP_MOTOR_FORCE_BASED) { w->err = "rp_impulse_joints_insert: unknown motor model"; return RP_ERR_INVALID; }
     }
@@ -2750,7 +2766,7 @@ extern "C" int32_t rp_quarantine_read(rp_world *w, int32_t cap, uint64_t *handle
     int nb = w->dw.n_bodies, m = 0;
     std::vector<int> q(std::max(nb, 1));
     if (nb > 0) HIPCHK(w, hipMemcpy(q.data(), w->dw.b_quar, nb * sizeof(int), hipMemcpyDeviceToHost));
-    for (int i = 0; i < nb; ++i) if (q[i]) { if (handles_out && m < cap) handles_out[m] = (uint64_t)i; m++; }
+    for (int i = 0; i < nb; ++i) if (q[i]) { if (handles_out && m < cap) handles_out[m] = ((uint64_t)w->body_gen[(size_t)i] << 32) | (uint64_t)(uint32_t)i; m++; }
     return m;
 }
 

@@ -30,9 +30,12 @@ def partition_scene(scene: S.Scene, body_rank: np.ndarray, rank: int):
     """Sub-scene of `rank`: its dynamic bodies + every fixed body (replicated), with colliders.
     Returns (sub_scene, global_index_of_local_body)."""
     sub = S.Scene(name=f"{scene.name}@{rank}", gravity=scene.gravity, params=scene.params.copy())
+    sub.polyhedra = list(scene.polyhedra)   # registered point clouds keep their ids in every shard (SHAPE_CONVEX half_extents[0])
     local_of = {}
     global_ids = []
     for gi, b in enumerate(scene.bodies):
+        if int(b["body_type"]) == S.BODY_DYNAMIC and int(body_rank[gi]) < 0:
+            raise ValueError(f"dynamic body {gi} belongs to no shard (no collider gives it a box, or its group was not ranked)")
         if int(b["body_type"]) != S.BODY_DYNAMIC or int(body_rank[gi]) == rank:
             local_of[gi] = len(sub.bodies)
             sub.bodies.append(b)
@@ -157,10 +160,17 @@ def body_boxes(scene: S.Scene):
             r = he[0]
         elif shape == S.SHAPE_CAPSULE:
             r = he[0] + he[1]
-        elif shape == S.SHAPE_CUBOID:
+        elif shape in (S.SHAPE_CUBOID, S.SHAPE_ROUND_CUBOID):
             r = float(np.linalg.norm(he))
+        elif shape in (S.SHAPE_CYLINDER, S.SHAPE_CONE, S.SHAPE_ROUND_CYLINDER, S.SHAPE_ROUND_CONE):
+            r = float(np.hypot(he[0], he[1]))   # (half height, radius): the rim is the farthest point from the centre
+        elif shape in (S.SHAPE_CONVEX_POLYHEDRON, S.SHAPE_ROUND_CONVEX_POLYHEDRON):
+            r = float(np.linalg.norm(np.asarray(scene.polyhedra[int(he[0])][0], np.float64), axis=1).max())
+        elif shape == S.SHAPE_HALFSPACE:
+            continue  # (half-spaces sit on fixed or kinematic bodies and have no finite box)
         else:
-            continue  # (half-spaces sit on fixed bodies: never boxed)
+            raise ValueError(f"body_boxes: unknown shape {shape}")
+        r += float(c["border_radius"]) if "border_radius" in c.dtype.names else 0.0
         r += float(np.linalg.norm(np.asarray(c["translation"], np.float64)))  # the collider's offset from the body, whatever the rotation
         lo[p] = np.minimum(lo[p], pos[p] - r); hi[p] = np.maximum(hi[p], pos[p] + r)
     return lo, hi
@@ -236,6 +246,7 @@ class ShardSet:
         for c, p in zip(scene.colliders, scene.collider_parents):
             if p >= 0:
                 self.cols[p].append(c.copy())
+        self.joints = [j.copy() for j in scene.joints]                # impulse joints by GLOBAL body id: re-inserted where their bodies go
         self.worlds, self.handle, self.gid_of_row = {}, {}, {}
         for r in self.local_ranks:
             sub, gids = partition_scene(scene, self.owner, r)
@@ -363,6 +374,8 @@ class ShardSet:
             state.update(part)
         for k, dst in sorted(moves.items()):
             src, gl = boxes[k][0], boxes[k][1]
+            # replicated bodies (fixed, kinematic) already live on every rank: only the group's dynamic bodies change hands
+            gl = [g for g in gl if int(self.desc[g]["body_type"]) == S.BODY_DYNAMIC]
             for g in gl:
                 pos7, vel6 = state[g]
                 d = self.desc[g]
@@ -383,6 +396,21 @@ class ShardSet:
                         rows.extend([-1] * (row - len(rows)) + [g])
                     self.handle[dst][g] = int(hb)
                 self.owner[g] = dst
+            # the group's impulse joints: removing a body dropped them at the source (RigidBodySet::remove removes attached joints);
+            # the destination gets them back once both ends live there (the other end: a body of the group or a replicated one)
+            if dst in self.worlds and self.joints:
+                moved, w = set(gl), self.worlds[dst]
+                row_of = {g: int(h) & 0xFFFFFFFF for g, h in self.handle[dst].items()}
+                back = []
+                for j in self.joints:
+                    b1, b2 = int(j["body1"]), int(j["body2"])
+                    if (b1 in moved or b2 in moved) and b1 in row_of and b2 in row_of:
+                        jj = j.copy(); jj["body1"], jj["body2"] = row_of[b1], row_of[b2]
+                        back.append(jj)
+                if back:
+                    if not hasattr(w, "insert_impulse_joints"):
+                        raise NotImplementedError("this world type cannot re-insert the joints of a migrating group")
+                    w.insert_impulse_joints(np.array(back, dtype=S.JOINT_DTYPE))
             self.migrations += 1
         self._refresh_guards()
 

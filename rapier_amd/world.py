@@ -211,21 +211,29 @@ class PhysicsWorld:
             self._lib.rp_colliders_handles(self._ptr, n, out.ctypes.data)
         return out
 
-    def _bh(self, handles, table=None) -> np.ndarray:
-        """Body handles as the ABI wants them.  Callers may pass real handles (generation << 32 | index) or bare arena INDICES (values
-        below 2^32): an index addresses the slot's current occupant — RigidBodySet::get_unknown_gen (rigid_body_set.rs) — and is turned
-        into that occupant's handle here.  (A stale handle of generation 0 cannot be told from an index: staleness checks need a handle
-        whose generation is above zero.)"""
-        h = np.ascontiguousarray(np.atleast_1d(np.asarray(handles, dtype=np.uint64))).copy()
-        idx = h < np.uint64(1 << 32)
-        if idx.any():
-            cur = self.body_handles() if table is None else table
-            ok = idx & (h < np.uint64(len(cur)))
-            h[ok] = cur[h[ok].astype(np.int64)]
-        return h
+    def _bh(self, handles) -> np.ndarray:
+        """Body (or collider) handles as the ABI wants them: generation << 32 | index, passed through UNCHANGED.  A handle issued before
+        the first removal has generation 0 and therefore equals its arena index; once the slot has been reused its occupant carries a
+        higher generation and the old value is refused by the library (RP_ERR_INVALID), exactly as Arena::get returns None for a stale
+        handle (data/arena.rs).  Addressing a slot's CURRENT occupant by index is a separate, explicit operation: `body_handles_at` /
+        `collider_handles_at` (RigidBodySet::get_unknown_gen)."""
+        return np.ascontiguousarray(np.atleast_1d(np.asarray(handles, dtype=np.uint64))).copy()
 
-    def _ch(self, handles) -> np.ndarray:
-        return self._bh(handles, table=self.collider_handles())
+    _ch = _bh
+
+    def body_handles_at(self, indices) -> np.ndarray:
+        """RigidBodySet::get_unknown_gen: the handles of the bodies that occupy these arena slots NOW."""
+        return self._handles_at(indices, self.body_handles(), "body")
+
+    def collider_handles_at(self, indices) -> np.ndarray:
+        return self._handles_at(indices, self.collider_handles(), "collider")
+
+    @staticmethod
+    def _handles_at(indices, table, what) -> np.ndarray:
+        i = np.atleast_1d(np.asarray(indices, dtype=np.int64))
+        if len(i) and (i.min() < 0 or i.max() >= len(table)):
+            raise IndexError(f"{what} index out of range")
+        return table[i].copy()  # (a free row yields the handle of its last occupant, which every entry point but rp_bodies_read refuses)
 
     # ---- insertion (RigidBodySet::insert, ColliderSet::insert_with_parent, ...) ----
     def insert_bodies(self, descs: np.ndarray) -> np.ndarray:
