@@ -159,13 +159,14 @@ struct rp_world {
     // shard guard (rp_world_set_shard_guard): host copy, re-uploaded whenever the device world is rebuilt
     std::vector<float4> guard_min, guard_max; std::vector<int> guard_start, guard_items; float guard_origin[3] = {0, 0, 0}, guard_cell = 0.0f; int guard_dims[3] = {0, 0, 0};
     // launch plan + graph
-    int plan_stages = 0, plan_blocks = 1, plan_single = 1, plan_island_grid = 1, plan_joint_stages = 0, plan_no_global = 0, plan_fused = 0, plan_tile_grid = 0, plan_no_contacts = 0, plan_bare = 0;
+    int plan_stages = 0, plan_blocks = 1, plan_single = 1, plan_island_grid = 1, plan_joint_stages = 0, plan_no_global = 0, plan_fused = 0, plan_tile_grid = 0, plan_no_contacts = 0, plan_bare = 0, plan_dense = 0;
     bool has_restitution = false;
     // [0] = full path, [1] = fast path, [2] = lean path; "whole" = one graph per step, col/loop/fin = timed thirds (full / fast only)
     hipGraph_t g_whole[3] = {nullptr, nullptr, nullptr}, g_col[3] = {nullptr, nullptr, nullptr}, g_loop[3] = {nullptr, nullptr, nullptr}, g_fin[3] = {nullptr, nullptr, nullptr};
     hipGraphExec_t ge_whole[3] = {nullptr, nullptr, nullptr}, ge_col[3] = {nullptr, nullptr, nullptr}, ge_loop[3] = {nullptr, nullptr, nullptr}, ge_fin[3] = {nullptr, nullptr, nullptr};
-    int graph_stages = -1, graph_blocks = -1, graph_single = -1, graph_island_grid = -1, graph_joint_stages = -1, graph_no_global = -1, graph_fused = -1, graph_tile_grid = -1, graph_no_contacts = -1, graph_bare = -1;
+    int graph_stages = -1, graph_blocks = -1, graph_single = -1, graph_island_grid = -1, graph_dense = -1, graph_joint_stages = -1, graph_no_global = -1, graph_fused = -1, graph_tile_grid = -1, graph_no_contacts = -1, graph_bare = -1;
     bool use_graph = true, use_fast = true, use_fused = true;
+    bool auto_dense = true;        // RP_ISL_DENSE=0: never
     bool force_dense = false;      // RP_ISL_DENSE=1 (tests): the dense form of k_island_solve whatever the island count
     bool use_lean = true;          // the lean step graph of MULTI-mode worlds (below: "lean graph"); RP_NO_LEAN=1: never
     int cur_lean = 0;              // the enqueue_* callbacks capture / launch the lean graph (with dw_lean)
@@ -414,7 +415,7 @@ extern "C" int32_t rp_world_create(const rp_integration_params *params, const fl
     if (g && g[0] == '1') w->force_flow = true;
     if (w->use_flow) { w->flow_grid = rp_flow_grid(device); if (w->flow_grid <= 0) w->use_flow = false; }
     if (w->use_fused) { w->fused_grid = rp_fused_grid(device); if (w->fused_grid <= 0) w->use_fused = false; }
-    { const char *nd = getenv("RP_NO_ISL_DENSE"); w->fused_grid_dense = (nd && nd[0] == '1') ? 0 : rp_fused_grid_dense(device); if (const char *fd = getenv("RP_ISL_DENSE")) if (fd[0] == '1' && w->fused_grid_dense > 0) w->force_dense = true; }
+    { const char *nd = getenv("RP_NO_ISL_DENSE"); w->fused_grid_dense = (nd && nd[0] == '1') ? 0 : rp_fused_grid_dense(device); if (const char *fd = getenv("RP_ISL_DENSE")) { if (fd[0] == '1' && w->fused_grid_dense > 0) w->force_dense = true; if (fd[0] == '0') w->auto_dense = false; } }
     memset(&w->dw, 0, sizeof(w->dw));
     *out = w;
     return RP_OK;
@@ -427,7 +428,7 @@ static void destroy_graphs(rp_world *w) {
         for (auto e : ex) if (*e) { hipGraphExecDestroy(*e); *e = nullptr; }
         for (auto g : gr) if (*g) { hipGraphDestroy(*g); *g = nullptr; }
     }
-    w->graph_stages = -1; w->graph_blocks = -1; w->graph_single = -1; w->graph_island_grid = -1; w->graph_joint_stages = -1; w->graph_no_global = -1; w->graph_fused = -1; w->graph_tile_grid = -1; w->graph_no_contacts = -1; w->graph_bare = -1;
+    w->graph_stages = -1; w->graph_blocks = -1; w->graph_single = -1; w->graph_island_grid = -1; w->graph_dense = -1; w->graph_joint_stages = -1; w->graph_no_global = -1; w->graph_fused = -1; w->graph_tile_grid = -1; w->graph_no_contacts = -1; w->graph_bare = -1;
     w->timed_ready[0] = w->timed_ready[1] = false;
 }
 static void free_device(rp_world *w) {
@@ -1674,13 +1675,12 @@ static void enqueue_island_solver(rp_world *w) {
     const int fused = (w->cur_fast && w->plan_fused) ? 1 : 0;
     if (w->cur_lean && (w->dw_lean.lean & 2)) return; // a bare lean graph: no island exists (verified by lean_dead in every kernel of the graph)
     // every workgroup of the fused step must be resident at once: the grid is capped by what the device can hold (rp_fused_grid)
-    // the dense form of the kernel (two islands per CU, rp_islands.hip)
-    // (Opt-in, RP_ISL_DENSE=1: measured on MI355X in round 4 it LOSES — profiles/r04_island_dense_experiment.txt, DESIGN.md section 4.1:
-    // the 168-VGPR budget costs 528 B of scratch per lane and +50 % per island, and two such workgroups on one CU take twice the time of
-    // one.  It stays as the measured answer to "two islands per CU", not as a launch path the planner picks.)
-    const int dense = (w->fused_grid_dense > 0 && w->force_dense) ? 1 : 0;
+    // the register-lean form of the kernel (rp_islands_lean.h: one 640-thread workgroup = TWO islands per CU) is the planner's choice
+    // when the world has more islands than one pass of the classic form holds (plan_dense); a workgroup takes two islands per round
+    const int dense = w->plan_dense;
     const int cap = dense ? w->fused_grid_dense : w->fused_grid;
-    rp_launch_island_solve(w->cur_lean ? w->dw_lean : w->dw, w->stream, fused ? std::min(w->plan_island_grid, cap) : w->plan_island_grid,
+    const int want = dense ? (w->plan_island_grid + 1) / 2 : w->plan_island_grid;
+    rp_launch_island_solve(w->cur_lean ? w->dw_lean : w->dw, w->stream, fused ? std::min(want, cap) : want,
                            w->has_restitution ? 1 : 0, w->cur_fast, w->plan_single, fused, dense);
 }
 // MULTI mode of the global path, measured on MI355X: contact-only worlds under the twist model are fastest
@@ -1726,6 +1726,20 @@ static void plan_from_hints(rp_world *w, const int *fl) {
     // round up to a power of two so small changes of the stage size do not force a re-capture
     w->plan_blocks = flow_now(w) ? 1 : std::min(std::max(pow2_ceil((fl[FL_MAX_STAGE] + 255) / 256), 1), 4096);
     w->plan_island_grid = std::min(std::max(pow2_ceil(fl[FL_N_ISLANDS]), 1), 8192);
+    // more islands than one resident pass of k_island_solve holds: the lean form puts two on a CU.  Cost model from the island-count sweep
+    // on MI355X (profiles/r05_island_count_sweep.txt): a pass of the classic form (<= fused_grid islands) takes ~71 us, a pass of the
+    // lean form (<= 2 x fused_grid_dense islands) ~118 us — the lean form wins when it saves enough passes (361 islands: 118 against
+    // 141 us; 484: 235 against 209, so the classic form keeps those; 2,916: 830 against 936).
+    {
+        const int n_isl = fl[FL_N_ISLANDS];
+        bool lean_wins = false;
+        if (w->fused_grid_dense > 0 && w->fused_grid > 0 && n_isl > w->fused_grid) {
+            const long long classic = (long long)((n_isl + w->fused_grid - 1) / w->fused_grid) * 71;
+            const long long lean = (long long)((n_isl + 2 * w->fused_grid_dense - 1) / (2 * w->fused_grid_dense)) * 118;
+            lean_wins = lean < classic;
+        }
+        w->plan_dense = (w->fused_grid_dense > 0 && (w->force_dense || (w->auto_dense && lean_wins))) ? 1 : 0;
+    }
     // LDS tiles (rp_tiles.hip): once the device has published a valid tiling of the global component, a sweep is one launch over the
     // tiles (grid rounded up to 16 so small changes of the tile count do not force a re-capture; the kernel loops over tiles beyond it)
     w->plan_no_contacts = (fl[FL_N_CONS] == 0 && w->dw.tile_cap > 0) ? 1 : 0; // (tile sweeps: the increment folds into the sweep while no manifold exists)
@@ -1932,10 +1946,10 @@ static int step_once(rp_world *w, bool allow_fast) {
         if (w->plan_island_grid < old_g && w->plan_island_grid * 2 >= old_g) w->plan_island_grid = old_g;
     }
     if (w->graph_stages != w->plan_stages || w->graph_blocks != w->plan_blocks || w->graph_single != w->plan_single ||
-        w->graph_island_grid != w->plan_island_grid || w->graph_joint_stages != w->plan_joint_stages || w->graph_no_global != w->plan_no_global || w->graph_fused != w->plan_fused || w->graph_tile_grid != w->plan_tile_grid || w->graph_no_contacts != w->plan_no_contacts || w->graph_bare != w->plan_bare) {
+        w->graph_island_grid != w->plan_island_grid || w->graph_dense != w->plan_dense || w->graph_joint_stages != w->plan_joint_stages || w->graph_no_global != w->plan_no_global || w->graph_fused != w->plan_fused || w->graph_tile_grid != w->plan_tile_grid || w->graph_no_contacts != w->plan_no_contacts || w->graph_bare != w->plan_bare) {
         if (w->ge_whole[0] || w->ge_whole[1] || w->timed_ready[0] || w->timed_ready[1]) HIPCHK(w, hipStreamSynchronize(w->stream)); // replays of the old graphs may still be in flight
         destroy_graphs(w);
-        w->graph_stages = w->plan_stages; w->graph_blocks = w->plan_blocks; w->graph_single = w->plan_single; w->graph_island_grid = w->plan_island_grid;
+        w->graph_stages = w->plan_stages; w->graph_blocks = w->plan_blocks; w->graph_single = w->plan_single; w->graph_island_grid = w->plan_island_grid; w->graph_dense = w->plan_dense;
         w->graph_joint_stages = w->plan_joint_stages; w->graph_no_global = w->plan_no_global; w->graph_fused = w->plan_fused; w->graph_tile_grid = w->plan_tile_grid; w->graph_no_contacts = w->plan_no_contacts; w->graph_bare = w->plan_bare;
     }
     // keep the host at most a few steps ahead of the device so the hints stay fresh (the device

@@ -344,8 +344,24 @@ RP_DEV void lean_writeback(const DevWorld &w, const IslPk &h, int s) {
     }
 }
 
-// One workgroup = one island, 320 threads: lanes 2m, 2m+1 = manifold m; threads [0, nb) also own the linear half of body t, threads
-// [64, 64 + nb) the angular half of body t - 64.  Stage order and fused-step protocol: island_solve_body (rp_islands.hip).
+// One workgroup = TWO islands, 640 manifold lanes (+ 128 validating lanes: twelve wavefronts, three per SIMD at 168 VGPRs — the layout the CU actually
+// accepts: the waves of a workgroup are spread so that a SIMD holds ceil(waves / 4) of them and two workgroups never interleave, so
+// two separate 5-wave workgroups would need 4 x 168 registers on one SIMD and are NOT co-resident, whatever the occupancy API answers;
+// measured with tools/ubench/coresident.hip, profiles/r05_ubench_coresident_*.txt).  Threads [0, 320) hold the island of the
+// workgroup's even slot, [320, 640) the one of its odd slot; inside a half: lanes 2m, 2m+1 = manifold m, threads [0, nb) also own
+// the linear half of body t, threads [64, 64 + nb) the angular half of body t - 64.  The two islands share every barrier (a stage of
+// the sweep is a stage of both).  Stage order and fused-step protocol: island_solve_body (rp_islands.hip).
+#define LEAN_HALF ISL_THREADS_DENSE        // threads per island
+#define LEAN_VALIDATORS 128                // two more wavefronts (twelve = three per SIMD, the same register budget): they hold no manifold and
+                                           // prove, under cover of generate, that the fused step needs neither broad nor narrow phase
+#define LEAN_THREADS (2 * LEAN_HALF + LEAN_VALIDATORS)
+struct LeanLds { // per island
+    float4 B_lin[RP_ISL_NB_MAX], B_ang[RP_ISL_NB_MAX], B_rot[RP_ISL_NB_MAX], B_trans[RP_ISL_NB_MAX];
+    float4 O_incl[RP_ISL_NB_MAX], O_inca[RP_ISL_NB_MAX], O_invpi[RP_ISL_NB_MAX], O_pframe[RP_ISL_NB_MAX]; // owner constants: .w of incl = first row, of inca = row count, of invpi = body flags
+    float4 L_E[4 * RP_ISL_NC_MAX], L_F[4 * RP_ISL_NC_MAX], L_B0[RP_ISL_NC_MAX], L_B1[RP_ISL_NC_MAX];
+    float4 W[WS_SLOTS_2PHASE * WS_STRIDE];
+    int any_bouncy, nls;
+};
 __device__ __forceinline__ void island_solve_lean(const DevWorld &w, int has_restitution, int fast, int retire, int fused) {
     const bool aborted = (fast && w.flags[FL_FAST_ABORT]) || lean_dead(w);
     if (retire && blockIdx.x == 0) {
@@ -355,62 +371,70 @@ __device__ __forceinline__ void island_solve_lean(const DevWorld &w, int has_res
     }
     if (aborted) return;
     __shared__ int s_abort, s_go;
+    __shared__ LeanLds LD[2];
+    __shared__ int S_a[RP_ISL_NC_MAX], S_b[RP_ISL_NC_MAX], S_c[RP_ISL_NC_MAX], S_d[RP_ISL_NC_MAX];
+    const int n_islands = w.flags[FL_N_ISLANDS];
 #ifdef RP_ISL_PROFILE
     long long t_fused0 = (long long)__builtin_readcyclecounter();
 #endif
     if (fused) {
-        // no idle wavefront is left to validate under cover of generate: every island of this workgroup is validated up front
+        // the islands of this workgroup BEYOND its first two are validated up front; the first two by the validator wavefronts under
+        // cover of generate (below).  FL_ARRIVE counts arrivals in its low 16 bits and aborting workgroups above.
         const int t = threadIdx.x;
-        const int n_islands = w.flags[FL_N_ISLANDS];
         if (t == 0) {
             s_abort = 0;
             if (blockIdx.x == 0 && (w.flags[FL_BP_DIRTY] || w.flags[FL_N_CONS] > 0 || w.flags[FL_N_GLOB_BODIES] > 0 || w.n_joints > 0)) s_abort = 1;
         }
         __syncthreads();
         bool bad = false;
-        for (int isl = blockIdx.x; isl < n_islands; isl += gridDim.x) {
-            const int nb = w.isl_nb[isl], nc = w.isl_nc[isl], ni = w.isl_ni[isl];
-            const int bb = w.isl_body_begin[isl], cb = w.isl_cons_begin[isl], ib = w.isl_icons_begin[isl];
-            for (int i = t; i < nb + nc + ni; i += blockDim.x) {
-                if (i < nb) { int c = w.b_collider[w.isl_bodies[bb + i]]; if (c >= 0 && collider_left_fat_aabb(w, c)) bad = true; }
-                else if (i < nb + nc) { if (pair_needs_narrow_phase(w, w.isl_cons[cb + i - nb])) bad = true; }
-                else if (pair_needs_narrow_phase(w, w.isl_icons[ib + i - nb - nc])) bad = true;
+        for (int base = 2 * (blockIdx.x + gridDim.x); base < n_islands; base += 2 * gridDim.x) {
+            for (int isl = base; isl < base + 2 && isl < n_islands; ++isl) {
+                const int nb = w.isl_nb[isl], nc = w.isl_nc[isl], ni = w.isl_ni[isl];
+                const int bb = w.isl_body_begin[isl], cb = w.isl_cons_begin[isl], ib = w.isl_icons_begin[isl];
+                for (int i = t; i < nb + nc + ni; i += blockDim.x) {
+                    if (i < nb) { int c = w.b_collider[w.isl_bodies[bb + i]]; if (c >= 0 && collider_left_fat_aabb(w, c)) bad = true; }
+                    else if (i < nb + nc) { if (pair_needs_narrow_phase(w, w.isl_cons[cb + i - nb])) bad = true; }
+                    else if (pair_needs_narrow_phase(w, w.isl_icons[ib + i - nb - nc])) bad = true;
+                }
             }
         }
         if (bad) s_abort = 1;
-        __syncthreads();
-        if (t == 0) atomicAdd(&w.flags[FL_ARRIVE], 1 + (s_abort ? (1 << 16) : 0));
+        if (2 * (int)blockIdx.x >= n_islands) { // no island at all: arrive now
+            __syncthreads();
+            if (t == 0) atomicAdd(&w.flags[FL_ARRIVE], 1 + (s_abort ? (1 << 16) : 0));
+        }
 #ifdef RP_ISL_PROFILE
         if (blockIdx.x == 0 && threadIdx.x == 0) w.dbg[10] += (long long)__builtin_readcyclecounter() - t_fused0;
 #endif
     }
     bool decided = !fused, go = true;
-    __shared__ float4 B_lin[RP_ISL_NB_MAX], B_ang[RP_ISL_NB_MAX], B_rot[RP_ISL_NB_MAX], B_trans[RP_ISL_NB_MAX];
-    __shared__ float4 O_incl[RP_ISL_NB_MAX], O_inca[RP_ISL_NB_MAX], O_invpi[RP_ISL_NB_MAX], O_pframe[RP_ISL_NB_MAX]; // owner constants: .w of incl = first row, of inca = row count, of invpi = body flags
-    __shared__ float4 L_E[4 * RP_ISL_NC_MAX], L_F[4 * RP_ISL_NC_MAX], L_B0[RP_ISL_NC_MAX], L_B1[RP_ISL_NC_MAX];
-    __shared__ int S_a[RP_ISL_NC_MAX], S_b[RP_ISL_NC_MAX], S_c[RP_ISL_NC_MAX], S_d[RP_ISL_NC_MAX];
-    __shared__ float4 W[WS_SLOTS_2PHASE * WS_STRIDE];
-    __shared__ int any_bouncy;
-
-    const int t0 = threadIdx.x;
-    const int n_islands = w.flags[FL_N_ISLANDS];
+    const bool validator = threadIdx.x >= 2 * LEAN_HALF;  // wave-uniform, like `half`: LEAN_HALF is five wavefronts
+    const int half = (!validator && threadIdx.x >= LEAN_HALF) ? 1 : 0;
+    const int t0 = validator ? LEAN_HALF : (int)threadIdx.x - half * LEAN_HALF; // (a validator's lane index lies beyond every manifold and body)
     const int nst_global = w.flags[FL_N_STAGES];
     const rp_integration_params &prm = w.prm.p;
     const bool fib = prm.friction_in_bias_pass || prm.num_internal_stabilization_iterations == 0;
     const bool wsc = prm.warmstart_coefficient != 0.0f;
-    IslLds L;
-    L.lin = B_lin; L.ang = B_ang; L.rot = B_rot; L.trans = B_trans; L.E = L_E; L.F = L_F; L.B0 = L_B0; L.B1 = L_B1;
 
-    for (int isl = blockIdx.x; isl < n_islands; isl += gridDim.x) {
-        const int nb = w.isl_nb[isl], nc = w.isl_nc[isl];
-        const int bb = w.isl_body_begin[isl], cb = w.isl_cons_begin[isl];
-        const int t = pk_opaque(t0), m = t >> 1;
-        const bool odd = (t & 1) != 0;
-        __syncthreads();
+    for (int base = 2 * blockIdx.x; base < n_islands; base += 2 * gridDim.x) {
+        __syncthreads(); // the previous islands of this workgroup are fully written back
 #ifdef RP_ISL_PROFILE
         long long t_prev = (long long)__builtin_readcyclecounter();
 #endif
-        if (!w.isl_sorted[isl]) island_sort(w, isl, nc, cb, nst_global, S_a, S_b, S_c, S_d);
+        // (the stage sort of an island runs once per layout change, on the whole workgroup, one island after the other)
+        for (int k = 0; k < 2; ++k) {
+            const int i2 = base + k;
+            if (i2 < n_islands && !w.isl_sorted[i2]) island_sort(w, i2, w.isl_nc[i2], w.isl_cons_begin[i2], nst_global, S_a, S_b, S_c, S_d);
+        }
+        const int isl = base + half;
+        const bool have = isl < n_islands;              // an odd island count leaves the last workgroup's second half idle (it still meets every barrier)
+        const int nb = have ? w.isl_nb[isl] : 0, nc = have ? w.isl_nc[isl] : 0;
+        const int bb = have ? w.isl_body_begin[isl] : 0, cb = have ? w.isl_cons_begin[isl] : 0;
+        const int t = pk_opaque(t0), m = t >> 1;
+        const bool odd = (t & 1) != 0;
+        LeanLds &D = LD[half];
+        IslLds L;
+        L.lin = D.B_lin; L.ang = D.B_ang; L.rot = D.B_rot; L.trans = D.B_trans; L.E = D.L_E; L.F = D.L_F; L.B0 = D.L_B0; L.B1 = D.L_B1;
         const int bt = t & (RP_ISL_NB_MAX - 1);
         const bool role_lin = t < nb, role_ang = t >= RP_ISL_NB_MAX && t < RP_ISL_NB_MAX + nb;
         if (role_lin || role_ang) {
@@ -418,17 +442,16 @@ __device__ __forceinline__ void island_solve_lean(const DevWorld &w, int has_res
             V3 lin, ang, trans, incl, inca; Q4 rot;
             body_begin(w, g, lin, ang, rot, trans, incl, inca);
             if (role_lin) {
-                B_lin[bt] = f4(lin, 0.0f); B_rot[bt] = f4(rot); B_trans[bt] = f4(trans, 0.0f);
-                O_incl[bt] = f4(incl, __int_as_float(w.isl_inc_begin[bb + bt]));
+                D.B_lin[bt] = f4(lin, 0.0f); D.B_rot[bt] = f4(rot); D.B_trans[bt] = f4(trans, 0.0f);
+                D.O_incl[bt] = f4(incl, __int_as_float(w.isl_inc_begin[bb + bt]));
             } else {
-                B_ang[bt] = f4(ang, 0.0f);
-                O_inca[bt] = f4(inca, __int_as_float(w.isl_inc_cnt[bb + bt]));
-                O_invpi[bt] = f4(v3(w.b_invpi[g]), __int_as_float(w.b_flags[g]));
-                O_pframe[bt] = w.b_pframe[g];
+                D.B_ang[bt] = f4(ang, 0.0f);
+                D.O_inca[bt] = f4(inca, __int_as_float(w.isl_inc_cnt[bb + bt]));
+                D.O_invpi[bt] = f4(v3(w.b_invpi[g]), __int_as_float(w.b_flags[g]));
+                D.O_pframe[bt] = w.b_pframe[g];
             }
         }
-        if (t == 0) any_bouncy = 0;
-        const int nls = w.isl_nstages[isl];
+        if (t == 0) { D.any_bouncy = 0; D.nls = have ? w.isl_nstages[isl] : 0; }
         const bool live = m < nc;
         int myq = -1, own_g = -1, own_l = -1, ws_row0 = 0, slot = -1;
         bool pair_static = false;
@@ -440,37 +463,54 @@ __device__ __forceinline__ void island_solve_lean(const DevWorld &w, int has_res
             ws_row0 = w.isl_inc_pos[2 * cb + t];
         }
         __syncthreads();
+        const int nls = LD[0].nls > LD[1].nls ? LD[0].nls : LD[1].nls; // the stages of the longer island: the shorter one idles through the rest
         ISL_STAMP(0);
         IslPk h;
         h.n = 0; h.id = -1; h.odd = odd;
         if (live) {
-            if (lean_generate(w, h, L, W + t, m, slot, own_g, own_l, odd, pair_static) && !odd) any_bouncy = 1;
+            if (lean_generate(w, h, L, D.W + t, m, slot, own_g, own_l, odd, pair_static) && !odd) D.any_bouncy = 1;
             lean_pose_stage(w, h, L, m, 0.0f);
+        }
+        if (validator && fused && base == 2 * (int)blockIdx.x) {
+            // one item (a body's collider, an active pair, a pair without solver contacts) per lane and round, over both islands
+            const int vt = threadIdx.x - 2 * LEAN_HALF;
+            bool bad = false;
+            for (int i2 = base; i2 < base + 2 && i2 < n_islands; ++i2) {
+                const int vnb = w.isl_nb[i2], vnc = w.isl_nc[i2], vni = w.isl_ni[i2];
+                const int vbb = w.isl_body_begin[i2], vcb = w.isl_cons_begin[i2], vib = w.isl_icons_begin[i2];
+                for (int i = vt; i < vnb + vnc + vni; i += LEAN_VALIDATORS) {
+                    if (i < vnb) { int c = w.b_collider[w.isl_bodies[vbb + i]]; if (c >= 0 && collider_left_fat_aabb(w, c)) bad = true; }
+                    else if (i < vnb + vnc) { if (pair_needs_narrow_phase(w, w.isl_cons[vcb + i - vnb])) bad = true; }
+                    else if (pair_needs_narrow_phase(w, w.isl_icons[vib + i - vnb - vnc])) bad = true;
+                }
+            }
+            if (bad) s_abort = 1;
         }
         ISL_STAMP(1);
 
         for (int sub = 0; sub < w.prm.num_substeps; ++sub) {
             const float solved_dt = (float)sub * w.prm.dt_sub;
             const int t = pk_opaque(t0), bt = t & (RP_ISL_NB_MAX - 1), m = t >> 1, ws_row = pk_opaque(ws_row0);
-            __syncthreads(); // generate's rows of W / the previous substep's angular rows have been read; relax sweep of the previous substep done
-            if (live) lean_ws_terms<1>(w, h, W, ws_row);
+            if (sub == 0) __syncthreads(); // generate's rows of W have been read back by their lanes
+            if (live) lean_ws_terms<1>(w, h, D.W, ws_row);
             __syncthreads();
+            if (fused && sub == 0 && base == 2 * (int)blockIdx.x && threadIdx.x == 0) atomicAdd(&w.flags[FL_ARRIVE], 1 + (s_abort ? (1 << 16) : 0)); // this workgroup validated all of its islands
             ISL_STAMP(2);
             if (role_lin) { // S2 increment (worker.rs:235-284), then the warm start of this body in sweep order
-                const float4 oi = O_incl[bt];
-                V3 lin = v3(B_lin[bt]) + v3(oi);
-                if (wsc) isl_ws_accumulate_lin<true>(W, __float_as_int(oi.w), __float_as_int(O_inca[bt].w), lin);
-                B_lin[bt] = f4(lin, 0.0f);
+                const float4 oi = D.O_incl[bt];
+                V3 lin = v3(D.B_lin[bt]) + v3(oi);
+                if (wsc) isl_ws_accumulate_lin<true>(D.W, __float_as_int(oi.w), __float_as_int(D.O_inca[bt].w), lin);
+                D.B_lin[bt] = f4(lin, 0.0f);
             }
             __syncthreads();
-            if (live && wsc) lean_ws_terms<2>(w, h, W, ws_row);
+            if (live && wsc) lean_ws_terms<2>(w, h, D.W, ws_row);
             __syncthreads();
             if (role_ang) {
-                const float4 oa = O_inca[bt], op = O_invpi[bt];
-                V3 lin_unused = v3(0, 0, 0), ang = v3(B_ang[bt]);
-                body_increment(w, __float_as_int(op.w), lin_unused, ang, q4(B_rot[bt]), v3(0, 0, 0), v3(oa), v3(op), q4(O_pframe[bt]));
-                if (wsc) isl_ws_accumulate_ang<true>(W, __float_as_int(O_incl[bt].w), __float_as_int(oa.w), ang);
-                B_ang[bt] = f4(ang, 0.0f);
+                const float4 oa = D.O_inca[bt], op = D.O_invpi[bt];
+                V3 lin_unused = v3(0, 0, 0), ang = v3(D.B_ang[bt]);
+                body_increment(w, __float_as_int(op.w), lin_unused, ang, q4(D.B_rot[bt]), v3(0, 0, 0), v3(oa), v3(op), q4(D.O_pframe[bt]));
+                if (wsc) isl_ws_accumulate_ang<true>(D.W, __float_as_int(D.O_incl[bt].w), __float_as_int(oa.w), ang);
+                D.B_ang[bt] = f4(ang, 0.0f);
             }
             __syncthreads();
             ISL_STAMP(3);
@@ -478,9 +518,9 @@ __device__ __forceinline__ void island_solve_lean(const DevWorld &w, int has_res
                 for (int q = 0; q < nls; ++q) { if (myq == q) lean_solve(h, L, fib); __syncthreads(); }
             ISL_STAMP(4);
             if (t < nb) { // S6
-                V3 lin = v3(B_lin[t]), ang = v3(B_ang[t]), trans = v3(B_trans[t]); Q4 rot = q4(B_rot[t]);
-                body_integrate(w, __float_as_int(O_invpi[t].w), lin, ang, rot, trans);
-                B_lin[t] = f4(lin, 0.0f); B_ang[t] = f4(ang, 0.0f); B_rot[t] = f4(rot); B_trans[t] = f4(trans, 0.0f);
+                V3 lin = v3(D.B_lin[t]), ang = v3(D.B_ang[t]), trans = v3(D.B_trans[t]); Q4 rot = q4(D.B_rot[t]);
+                body_integrate(w, __float_as_int(D.O_invpi[t].w), lin, ang, rot, trans);
+                D.B_lin[t] = f4(lin, 0.0f); D.B_ang[t] = f4(ang, 0.0f); D.B_rot[t] = f4(rot); D.B_trans[t] = f4(trans, 0.0f);
             }
             __syncthreads();
             ISL_STAMP(5);
@@ -490,13 +530,13 @@ __device__ __forceinline__ void island_solve_lean(const DevWorld &w, int has_res
                 for (int q = 0; q < nls; ++q) { if (myq == q) lean_solve(h, L, true); __syncthreads(); }
             ISL_STAMP(7);
         }
-        if (has_restitution && any_bouncy)
-            for (int q = 0; q < nls; ++q) { if (myq == q) lean_restitution(h, L); __syncthreads(); }
+        if (has_restitution && (LD[0].any_bouncy | LD[1].any_bouncy))
+            for (int q = 0; q < nls; ++q) { if (myq == q && D.any_bouncy) lean_restitution(h, L); __syncthreads(); }
         if (!decided) { // fused: nothing leaves the workgroup before every workgroup validated its islands
 #ifdef RP_ISL_PROFILE
             long long t_w0 = (long long)__builtin_readcyclecounter();
 #endif
-            if (t == 0) {
+            if (threadIdx.x == 0) {
                 int spins = 0, v;
                 while (((v = __hip_atomic_load(&w.flags[FL_ARRIVE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffff) < (int)gridDim.x) {
                     __builtin_amdgcn_s_sleep(8);
@@ -518,10 +558,10 @@ __device__ __forceinline__ void island_solve_lean(const DevWorld &w, int has_res
         }
         if (!go) break;
         if (live) lean_writeback(w, h, slot);
-        if (t < nb) body_writeback(w, w.isl_bodies[bb + t], v3(B_lin[t]), v3(B_ang[t]), q4(B_rot[t]), v3(B_trans[t]));
+        if (t < nb) body_writeback(w, w.isl_bodies[bb + t], v3(D.B_lin[t]), v3(D.B_ang[t]), q4(D.B_rot[t]), v3(D.B_trans[t]));
         ISL_STAMP(8);
 #ifdef RP_ISL_PROFILE
-        if (blockIdx.x == 0 && threadIdx.x == 0) w.dbg[63] += 1;
+        if (blockIdx.x == 0 && threadIdx.x == 0) w.dbg[63] += (base + 1 < n_islands) ? 2 : 1;
 #endif
     }
     if (fused) { // the last workgroup to leave retires the step (or not, when aborted) and re-arms the counters

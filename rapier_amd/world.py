@@ -9,6 +9,7 @@ downloads it.  Errors from the device library raise `RapierHipError` (the refere
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -133,7 +134,12 @@ class PhysicsPipeline:
 class PhysicsWorld:
     """PhysicsWorld::new() on device `device` (physics_world.rs:61-157)."""
 
-    def __init__(self, gravity=(0.0, -9.81, 0.0), integration_parameters: IntegrationParameters | None = None, device: int = 0):
+    def __init__(self, gravity=(0.0, -9.81, 0.0), integration_parameters: IntegrationParameters | None = None, device: int = 0,
+                 index_addressing: bool | None = None):
+        # index_addressing: values below 2^32 passed where a handle is expected name an arena SLOT (its current occupant,
+        # RigidBodySet::get_unknown_gen) instead of a generation-0 handle.  Off by default — a stale handle must be refused, not
+        # silently retargeted; the oracle-lockstep tests, which keep the oracle's plain indices, switch it on (RP_INDEX_ADDRESSING=1).
+        self.index_addressing = (os.environ.get("RP_INDEX_ADDRESSING") == "1") if index_addressing is None else bool(index_addressing)
         self._lib = _ffi.lib()
         self.integration_parameters = integration_parameters or IntegrationParameters()
         self.gravity = tuple(float(g) for g in gravity)
@@ -149,8 +155,8 @@ class PhysicsWorld:
         self.physics_pipeline = PhysicsPipeline(self)
 
     @classmethod
-    def from_scene(cls, scene: S.Scene, device: int = 0) -> "PhysicsWorld":
-        w = cls(gravity=scene.gravity, integration_parameters=IntegrationParameters(scene.params), device=device)
+    def from_scene(cls, scene: S.Scene, device: int = 0, index_addressing: bool | None = None) -> "PhysicsWorld":
+        w = cls(gravity=scene.gravity, integration_parameters=IntegrationParameters(scene.params), device=device, index_addressing=index_addressing)
         for pts, tris in getattr(scene, "polyhedra", []):
             w.add_convex_polyhedron(pts, tris)
         bodies = scene.body_array()
@@ -211,15 +217,24 @@ class PhysicsWorld:
             self._lib.rp_colliders_handles(self._ptr, n, out.ctypes.data)
         return out
 
-    def _bh(self, handles) -> np.ndarray:
+    def _bh(self, handles, table=None) -> np.ndarray:
         """Body (or collider) handles as the ABI wants them: generation << 32 | index, passed through UNCHANGED.  A handle issued before
         the first removal has generation 0 and therefore equals its arena index; once the slot has been reused its occupant carries a
         higher generation and the old value is refused by the library (RP_ERR_INVALID), exactly as Arena::get returns None for a stale
         handle (data/arena.rs).  Addressing a slot's CURRENT occupant by index is a separate, explicit operation: `body_handles_at` /
-        `collider_handles_at` (RigidBodySet::get_unknown_gen)."""
-        return np.ascontiguousarray(np.atleast_1d(np.asarray(handles, dtype=np.uint64))).copy()
+        `collider_handles_at` (RigidBodySet::get_unknown_gen) — or, for callers that keep plain indices throughout, a world created
+        with index_addressing=True, where every value below 2^32 is such an index."""
+        h = np.ascontiguousarray(np.atleast_1d(np.asarray(handles, dtype=np.uint64))).copy()
+        if self.index_addressing:
+            idx = h < np.uint64(1 << 32)
+            if idx.any():
+                cur = self.body_handles() if table is None else table
+                ok = idx & (h < np.uint64(len(cur)))
+                h[ok] = cur[h[ok].astype(np.int64)]
+        return h
 
-    _ch = _bh
+    def _ch(self, handles) -> np.ndarray:
+        return self._bh(handles, table=self.collider_handles() if self.index_addressing else None)
 
     def body_handles_at(self, indices) -> np.ndarray:
         """RigidBodySet::get_unknown_gen: the handles of the bodies that occupy these arena slots NOW."""

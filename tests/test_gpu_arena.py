@@ -166,3 +166,25 @@ def test_ccd_clamps_a_fast_body_that_lives_in_a_reused_slot(monkeypatch, spare):
         gp, gv = g.read_bodies(); op, ov = o.read()
         np.testing.assert_array_equal(gp, op, err_msg=f"+{n} poses"); np.testing.assert_array_equal(gv, ov, err_msg=f"+{n} velocities")
     assert g.counters()["ccd_clamp_count"] > 0
+
+
+def test_a_stale_generation_zero_handle_is_refused_not_retargeted():
+    """a handle of the initial scene has generation 0 and equals its index; after its slot was reused it must be REFUSED by
+    the Python wrapper too (Arena::get -> None, data/arena.rs), not rewritten to the slot's new occupant."""
+    sc = S.Scene(name="stale0", gravity=(0.0, -9.81, 0.0))
+    gb = sc.add_body(body_type=S.BODY_FIXED, translation=(0.0, -1.0, 0.0)); sc.add_collider(gb, half_extents=(10.0, 1.0, 10.0))
+    a = sc.add_body(translation=(0.0, 0.5, 0.0)); sc.add_collider(a)
+    g = PhysicsWorld.from_scene(sc, index_addressing=False)
+    g.step(2)
+    old = int(g.body_handles()[a])
+    assert old == a                                              # generation 0: the handle IS the index
+    g.remove_body([old])
+    new = int(g.insert_body(S.body_desc(translation=(3.0, 0.5, 0.0))))
+    assert new & 0xFFFFFFFF == a and new >> 32 > 0               # the slot is reused under a higher generation
+    for call in (lambda: g.read_bodies([old]), lambda: g.remove_body([old]), lambda: g.write_bodies([old], vel6=np.zeros((1, 6), np.float32)),
+                 lambda: g.apply_impulse([old], impulse=(1.0, 0.0, 0.0))):
+        with pytest.raises(RapierHipError):
+            call()
+    assert int(g.body_handles_at([a])[0]) == new                 # explicit index addressing names the current occupant
+    pos, _ = g.read_bodies([new])
+    assert abs(float(pos[0, 0]) - 3.0) < 1e-6

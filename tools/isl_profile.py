@@ -9,7 +9,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from rapier_amd import PhysicsWorld, scenes as S, _ffi  # noqa: E402
 
-w = PhysicsWorld.from_scene(S.many_pyramids())
+rows, cols = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (14, 14)
+w = PhysicsWorld.from_scene(S.many_pyramids(rows=rows, cols=cols))
+print(f"{rows * cols} islands, RP_ISL_DENSE={os.environ.get('RP_ISL_DENSE')}")
 w.step(200); w.sync()
 buf = np.zeros(64, np.int64)
 L = _ffi.lib()
