@@ -91,6 +91,8 @@ typedef struct {
     int shape; v3 he; float radius; int axis; /* capsule: he.x = half height, radius, axis */
     float border;       /* round shapes (RO_SHAPE_ROUND_*): RoundShape::border_radius; 0 otherwise */
     const RoPolyhedron *poly; /* RO_SHAPE_CONVEX_POLYHEDRON: the registered polyhedron (recentred; the centre is folded into pos_wrt_parent) */
+    const struct RoComposite *comp; /* RO_SHAPE_COMPOUND / RO_SHAPE_TRIMESH: the registered composite (recentred on its local AABB like a polyhedron; he = that box) */
+    v3 tri[3];          /* RO_SHAPE_TRIANGLE (a mesh triangle handed to the shape dispatcher): its vertices */
     int sensor;         /* ColliderBuilder::sensor(true): intersection events only, no contacts (oracle only so far) */
     float density, friction, restitution; int friction_rule, restitution_rule;
     uint32_t memberships, filter;
@@ -116,7 +118,26 @@ typedef struct {
     uint8_t color; uint32_t color_bodies[2];
     int force_emitted;  /* PairEventStatus::INITIAL_FORCE_THRESHOLD_EVENT_EMITTED */
     int hint_seq;       /* step at which pair_solver_hints[edge] was last computed (pair_update.rs:141-161,636-650) */
+    /* Composite pairs (ro_composite.h).  The fields above (m, normal, sc, nsc) are SOLVER MANIFOLD 0 of the pair: the plain manifold of the
+     * one candidate sub-shape pair, or — when contact clustering applies (pair_update.rs:350) — cluster 0; ex[k - 1] = cluster k.  The
+     * clusters with solver contacts come first (stable), so nsc > 0 still means has_any_active_contact. */
+    int ncl;            /* 0 = plain manifold (or none); >= 1 = that many clusters (ContactPair::solver_clusters) */
+    int plain_sub[2];   /* the sub-shapes manifold 0 belongs to while ncl == 0 (-1: the collider itself) */
+    struct ExtraCluster *ex; /* [RO_MAX_CLUSTERS - 1], allocated on first use */
 } Pair;
+#define RO_MAX_CLUSTERS 4      /* solver manifolds per pair (the reference: unbounded; a 5th normal direction joins the closest cluster) */
+#define RO_CLUSTER_PTS 64      /* points of one cluster while it is built (the reference: 255) */
+#define RO_MAX_SUBPAIRS 96     /* candidate sub-shape pairs of one collider pair per step (in index order; the rest is ignored and counted) */
+typedef struct ExtraCluster { Manifold m; v3 normal; SolverContact sc[4]; int nsc; } ExtraCluster;
+/* solver manifold k of a pair */
+static inline Manifold *sm_m(Pair *p, int k) { return k == 0 ? &p->m : &p->ex[k - 1].m; }
+static inline SolverContact *sm_sc(Pair *p, int k) { return k == 0 ? p->sc : p->ex[k - 1].sc; }
+static inline int *sm_nsc(Pair *p, int k) { return k == 0 ? &p->nsc : &p->ex[k - 1].nsc; }
+static inline v3 *sm_normal(Pair *p, int k) { return k == 0 ? &p->normal : &p->ex[k - 1].normal; }
+static inline int pair_num_sm(const Pair *p) { return p->ncl > 1 ? p->ncl : 1; }
+#define RO_SM_SHIFT 28          /* solver-manifold reference = pair index | k << 28 */
+#define RO_SM_PAIR(x) ((x) & ((1 << RO_SM_SHIFT) - 1))
+#define RO_SM_K(x) ((int)((unsigned)(x) >> RO_SM_SHIFT))
 
 /* ContactWithTwistFriction + builder, one lane — contact_with_twist_friction.rs:18-55,600-630 */
 typedef struct {
@@ -192,6 +213,8 @@ struct ro_world {
     Body *bodies; int nbodies, cap_bodies;
     Collider *colliders; int ncolliders, cap_colliders;
     RoPolyhedron **polys; int npolys; /* ro_add_convex_polyhedron */
+    struct RoComposite **comps; int ncomps; /* ro_add_compound / ro_add_trimesh / ro_add_heightfield */
+    int subpair_overflows; /* collider pairs that met more than RO_MAX_SUBPAIRS candidate sub-shape pairs (cumulative) */
     Pair *pairs; int npairs, cap_pairs;
     /* open-addressing map (c1,c2) -> pair index */
     int64_t *map_keys; int *map_vals; int map_cap;
@@ -393,7 +416,7 @@ static void update_world_mass_properties(Body *b) {
  * shape (identity except for capsules along X / Z: MassProperties::from_capsule rotates Y onto the segment direction). */
 static void ro_diagonalise(float a[3][3], float pi[3], float frame[4]);
 /* the inner shape of a round one (parry RoundShape<S>::inner_shape) */
-static int ro_core_shape(int shape) { return shape >= RO_SHAPE_ROUND_CUBOID ? (shape == RO_SHAPE_ROUND_CUBOID ? RO_SHAPE_CUBOID : shape - RO_SHAPE_ROUND_CYLINDER + RO_SHAPE_CYLINDER) : shape; }
+static int ro_core_shape(int shape) { return (shape >= RO_SHAPE_ROUND_CUBOID && shape <= RO_SHAPE_ROUND_CONVEX_POLYHEDRON) ? (shape == RO_SHAPE_ROUND_CUBOID ? RO_SHAPE_CUBOID : shape - RO_SHAPE_ROUND_CYLINDER + RO_SHAPE_CYLINDER) : shape; }
 static void shape_mass_props(const Collider *c, float density, float *mass, v3 *principal_inertia, float frame[4], float com[3]) {
     frame[0] = 0.0f; frame[1] = 0.0f; frame[2] = 0.0f; frame[3] = 1.0f;
     com[0] = com[1] = com[2] = 0.0f;
@@ -579,6 +602,7 @@ static void ro_mp_add(ro_mp *acc, const ro_mp *o) {
 
 static int collider_enabled(const Collider *c) { return !(c->memberships == 0 && c->filter == 0); }
 /* sum of the attached colliders' mass properties at `density_override` (< 0: each collider's own density) */
+static void comp_mass_props(const Collider *c, float density, ro_mp *out); /* ro_composite.h */
 static void sum_collider_mass_props(const ro_world *w, int body, float density_override, ro_mp *acc) {
     memset(acc, 0, sizeof(*acc)); acc->frame[3] = 1.0f;
     /* attachment order (rb.colliders(): ascending `ord`) — not index order: a collider may sit in a reused arena slot */
@@ -594,8 +618,11 @@ static void sum_collider_mass_props(const ro_world *w, int body, float density_o
     for (int q = 0; q < cnt; ++q) {
         const Collider *c = &w->colliders[list[q]];
         ro_mp m; memset(&m, 0, sizeof(m)); m.frame[3] = 1.0f;
+        if (c->shape == RO_SHAPE_COMPOUND || c->shape == RO_SHAPE_TRIMESH) comp_mass_props(c, density_override < 0.0f ? c->density : density_override, &m);
+        else {
         v3 pi; shape_mass_props(c, density_override < 0.0f ? c->density : density_override, &m.mass, &pi, m.frame, m.com);
         m.pi[0] = pi.x; m.pi[1] = pi.y; m.pi[2] = pi.z;
+        }
         float t[3] = {c->pos_wrt_parent.t.x, c->pos_wrt_parent.t.y, c->pos_wrt_parent.t.z};
         float q[4] = {c->pos_wrt_parent.r.x, c->pos_wrt_parent.r.y, c->pos_wrt_parent.r.z, c->pos_wrt_parent.r.w};
         ro_mp_transform(&m, t, q);
@@ -709,6 +736,7 @@ int32_t ro_add_body(ro_world *w, const ro_body_desc *d) {
     return idx;
 }
 
+struct RoComposite; static v3 comp_half(const struct RoComposite *C); static v3 comp_centre(const struct RoComposite *C); /* ro_composite.h */
 int32_t ro_add_collider(ro_world *w, const ro_collider_desc *d, int32_t parent) {
     int idx = w->ncolliders, reused = 0;
     if (w->ncoll_free > 0 && !getenv("RP_NO_ARENA_REUSE")) { purge_dead_pairs(w); idx = w->coll_free[--w->ncoll_free]; reused = 1; }
@@ -721,15 +749,17 @@ int32_t ro_add_collider(ro_world *w, const ro_collider_desc *d, int32_t parent) 
     Collider *c = &w->colliders[idx];
     memset(c, 0, sizeof(*c));
     c->parent = parent;
-    c->shape = ro_core_shape(d->shape); c->border = d->shape >= RO_SHAPE_ROUND_CUBOID ? d->border_radius : 0.0f; /* a round shape = its inner shape + a border radius */
+    c->shape = ro_core_shape(d->shape); c->border = (d->shape >= RO_SHAPE_ROUND_CUBOID && d->shape <= RO_SHAPE_ROUND_CONVEX_POLYHEDRON) ? d->border_radius : 0.0f; /* a round shape = its inner shape + a border radius */
     c->he = V3(d->half_extents[0], d->half_extents[1], d->half_extents[2]);
     c->radius = d->half_extents[0];
     if (c->shape == RO_SHAPE_CAPSULE) { c->radius = d->half_extents[1]; c->axis = (int)d->half_extents[2]; if (c->axis < 0 || c->axis > 2) c->axis = 1; }
     if (c->shape == RO_SHAPE_CYLINDER || c->shape == RO_SHAPE_CONE) { c->radius = d->half_extents[1]; c->he = V3(c->radius, d->half_extents[0], c->radius); c->axis = 1; } /* he = the local AABB's half extents */
     if (c->shape == RO_SHAPE_CONVEX_POLYHEDRON) { c->poly = w->polys[(int)d->half_extents[0]]; c->he = c->poly->half; c->radius = 0.0f; c->axis = 1; }
+    if (d->shape == RO_SHAPE_COMPOUND || d->shape == RO_SHAPE_TRIMESH) { c->shape = d->shape; c->border = 0.0f; c->comp = w->comps[(int)d->half_extents[0]]; c->he = comp_half(c->comp); c->radius = 0.0f; c->axis = 1; }
     c->pos_wrt_parent.t = V3(d->translation[0], d->translation[1], d->translation[2]);
     c->pos_wrt_parent.r = qnormalize(Q(d->rotation[0], d->rotation[1], d->rotation[2], d->rotation[3]));
     if (c->shape == RO_SHAPE_CONVEX_POLYHEDRON) c->pos_wrt_parent.t = vadd(qrot(c->pos_wrt_parent.r, c->poly->centre), c->pos_wrt_parent.t); /* the recentring offset rides in the pose */
+    if (c->comp) c->pos_wrt_parent.t = vadd(qrot(c->pos_wrt_parent.r, comp_centre(c->comp)), c->pos_wrt_parent.t); /* likewise: a composite is stored recentred on its local AABB */
     c->density = d->density; c->friction = d->friction; c->restitution = d->restitution;
     c->friction_rule = d->friction_rule; c->restitution_rule = d->restitution_rule;
     c->memberships = d->collision_memberships; c->filter = d->collision_filter;
@@ -1151,26 +1181,26 @@ static float collider_origin_radius(const Collider *c) {
 }
 
 /* manifold_reduction::reduce_manifold_naive — geometry/manifold_reduction.rs:4-84 */
-static void reduce_manifold_naive(const Manifold *m, int selected[4], int *num_selected, float prediction) {
-    if (m->npoints <= 4) return;
+static void reduce_points_naive(const TrackedContact *points, int npoints, v3 local_n1, int selected[4], int *num_selected, float prediction) {
+    if (npoints <= 4) return;
     selected[0] = selected[1] = selected[2] = selected[3] = -1;
     float deepest = FLT_MAX;
-    for (int i = 0; i < m->npoints; ++i) if (m->points[i].dist < deepest) { deepest = m->points[i].dist; selected[0] = i; }
+    for (int i = 0; i < npoints; ++i) if (points[i].dist < deepest) { deepest = points[i].dist; selected[0] = i; }
     if (selected[0] < 0) { *num_selected = 0; return; }
-    v3 a = m->points[selected[0]].local_p1;
+    v3 a = points[selected[0]].local_p1;
     float furthest = -FLT_MAX;
-    for (int i = 0; i < m->npoints; ++i) {
-        float d = vlen2(vsub(m->points[i].local_p1, a));
-        if (i != selected[0] && m->points[i].dist <= prediction && d > furthest) { furthest = d; selected[1] = i; }
+    for (int i = 0; i < npoints; ++i) {
+        float d = vlen2(vsub(points[i].local_p1, a));
+        if (i != selected[0] && points[i].dist <= prediction && d > furthest) { furthest = d; selected[1] = i; }
     }
     if (selected[1] < 0) { *num_selected = 1; return; }
-    v3 b = m->points[selected[1]].local_p1;
+    v3 b = points[selected[1]].local_p1;
     if (a.x == b.x && a.y == b.y && a.z == b.z) { *num_selected = 1; return; }
-    v3 tangent = vcross(vsub(b, a), m->local_n1);
+    v3 tangent = vcross(vsub(b, a), local_n1);
     float min_dot = FLT_MAX, max_dot = -FLT_MAX;
-    for (int i = 0; i < m->npoints; ++i) {
-        if (i == selected[0] || i == selected[1] || m->points[i].dist > prediction) continue;
-        float dot = vdot(vsub(m->points[i].local_p1, a), tangent);
+    for (int i = 0; i < npoints; ++i) {
+        if (i == selected[0] || i == selected[1] || points[i].dist > prediction) continue;
+        float dot = vdot(vsub(points[i].local_p1, a), tangent);
         if (dot < min_dot) { min_dot = dot; selected[2] = i; }
         if (dot > max_dot) { max_dot = dot; selected[3] = i; }
     }
@@ -1214,7 +1244,7 @@ static int joints_disable_contacts(const ro_world *w, int b1, int b2) {
  * separating axis among 3 + 3 face normals and 9 edge cross products), a ball against a convex shape (solid point projection),
  * capsule-capsule (segment distance).  Cuboid-capsule goes through GJK in parry; here the distance from the capsule's segment to
  * the box is minimised over the segment parameter (a convex function: ternary search, 48 fixed iterations). */
-static SmShape sm_shape_of(const Collider *c) { SmShape s; s.shape = c->shape; s.he = c->he; s.radius = c->radius; s.axis = c->axis; s.poly = c->poly; s.border = c->border; return s; }
+static SmShape sm_shape_of(const Collider *c) { SmShape s; s.shape = c->shape; s.he = c->he; s.radius = c->radius; s.axis = c->axis; s.poly = c->poly; s.border = c->border; s.tri[0] = c->tri[0]; s.tri[1] = c->tri[1]; s.tri[2] = c->tri[2]; return s; }
 static float point_box_dist2(v3 p, v3 he) {
     float dx = ro_maxf(fabsf(p.x) - he.x, 0.0f), dy = ro_maxf(fabsf(p.y) - he.y, 0.0f), dz = ro_maxf(fabsf(p.z) - he.z, 0.0f);
     return dx * dx + dy * dy + dz * dz;
@@ -1281,6 +1311,109 @@ static int shapes_intersect(const Collider *c1, const Collider *c2) {
         return vdot(d, d) <= r * r;
     }
 }
+/* pair_update.rs:404-577 for ONE solver manifold (a pair's plain manifold or a cluster): manifold reduction, the lexicographic sort in
+ * the contact plane, the solver contacts that pass the distance / approach test, anchors localised and lever arms frozen.
+ * pts[npts] / local_n1: the manifold (points local to wp1 / wp2 = collider pose x subshape pose); `normal` = wp1.rotation * local_n1 */
+static void build_solver_contacts(const ro_world *w, int rb1, int rb2, int rel_dom, v3 normal, v3 local_n1, TrackedContact *pts, int npts,
+                                  pose wp1, pose wp2, float prediction, SolverContact *scs, int *nsc_out) {
+    const ro_params *prm = &w->params;
+    int nsc = 0;
+    if (npts > 0) {
+        int selected[4] = {0, 1, 2, 3};
+        int num_selected = npts < 4 ? npts : 4;
+        reduce_points_naive(pts, npts, local_n1, selected, &num_selected, prediction);
+        /* :430-457 lexicographic sort in the contact plane */
+        if (num_selected > 1) {
+            v3 basis[2]; orthonormal_basis(local_n1, basis);
+            float k0[4], k1[4]; int ks[4];
+            for (int i = 0; i < num_selected; ++i) {
+                v3 lp = pts[selected[i]].local_p1;
+                k0[i] = vdot(lp, basis[0]); k1[i] = vdot(lp, basis[1]); ks[i] = selected[i];
+            }
+            for (int i = 1; i < num_selected; ++i) {
+                float a0 = k0[i], a1 = k1[i]; int as = ks[i]; int j = i;
+                while (j > 0 && (k0[j - 1] > a0 || (k0[j - 1] == a0 && k1[j - 1] > a1))) {
+                    k0[j] = k0[j - 1]; k1[j] = k1[j - 1]; ks[j] = ks[j - 1]; j--;
+                }
+                k0[j] = a0; k1[j] = a1; ks[j] = as;
+            }
+            for (int i = 0; i < num_selected; ++i) selected[i] = ks[i];
+        }
+        /* :459-498 solver contacts */
+        for (int s = 0; s < num_selected; ++s) {
+            int cid = selected[s];
+            TrackedContact *c = &pts[cid];
+            float eff_dist = c->dist; /* - skins (0) */
+            v3 world_pt1 = pose_tp(wp1, c->local_p1);
+            v3 world_pt2 = pose_tp(wp2, c->local_p2);
+            int keep = eff_dist < prediction;
+            if (!keep) {
+                v3 vel1 = V3(0, 0, 0), vel2 = V3(0, 0, 0);
+                if (rb1 >= 0) { const Body *b = &w->bodies[rb1]; vel1 = vadd(b->linvel, vcross(b->angvel, vsub(world_pt1, b->world_com))); }
+                if (rb2 >= 0) { const Body *b = &w->bodies[rb2]; vel2 = vadd(b->linvel, vcross(b->angvel, vsub(world_pt2, b->world_com))); }
+                keep = eff_dist + vdot(vsub(vel2, vel1), normal) * prm->dt < prediction;
+            }
+            if (keep) {
+                SolverContact *sc = &scs[nsc++];
+                sc->anchor1 = world_pt1; sc->anchor2 = world_pt2; sc->dist = eff_dist;
+                sc->tangent_velocity = V3(0, 0, 0); sc->cid = cid;
+            }
+        }
+        /* :536-577 localise anchors and freeze the solver lever arms */
+        {
+            int has1 = rb1 >= 0 && rel_dom <= 0, has2 = rb2 >= 0 && rel_dom >= 0;
+            pose com1 = pose_ident(), com2 = pose_ident();
+            if (has1) { const Body *b = &w->bodies[rb1]; com1.r = b->position.r; com1.t = pose_tp(b->position, b->local_com); }
+            if (has2) { const Body *b = &w->bodies[rb2]; com2.r = b->position.r; com2.t = pose_tp(b->position, b->local_com); }
+            for (int s = 0; s < nsc; ++s) {
+                SolverContact *sc = &scs[s];
+                float shift = vdot(vsub(sc->anchor2, sc->anchor1), normal) - sc->dist;
+                v3 p1 = vadd(sc->anchor1, vmul(normal, shift));
+                v3 point = vmul(vadd(p1, sc->anchor2), 0.5f);
+                ContactData *pd = &pts[sc->cid].data;
+                pd->solver_dp1 = has1 ? vsub(point, com1.t) : point;
+                pd->solver_dp2 = has2 ? vsub(point, com2.t) : point;
+                sc->anchor1 = has1 ? pose_itp(com1, p1) : p1;
+                if (has2) sc->anchor2 = pose_itp(com2, sc->anchor2);
+            }
+        }
+    }
+    *nsc_out = nsc;
+}
+/* parry DefaultQueryDispatcher::contact_manifold_convex_convex (pair_update.rs:323-330 reaches it through contact_manifolds): co1 / co2
+ * name SHAPES here (a collider, a part of a compound, a mesh triangle) — only their shape fields are read */
+static void dispatch_manifold(const Collider *co1, const Collider *co2, pose pos12, float prediction, Manifold *m) {
+    int s1 = co1->shape, s2 = co2->shape;
+    if (s1 >= RO_SHAPE_CYLINDER || s2 >= RO_SHAPE_CYLINDER || co1->border > 0.0f || co2->border > 0.0f) { /* cylinders, cones, polyhedra, round shapes (ro_convex.h): same dispatcher order — ball arms, half-space arms, pfm_pfm */
+        SmShape a = sm_shape_of(co1), b = sm_shape_of(co2);
+        if (s2 == RO_SHAPE_BALL) manifold_sm_ball(pos12, &a, co2->radius, prediction, m, 0);
+        else if (s1 == RO_SHAPE_BALL) manifold_sm_ball(pose_inv(pos12), &b, co1->radius, prediction, m, 1);
+        else if (s1 == RO_SHAPE_HALFSPACE) manifold_halfspace_sm(pos12, co1->he, &b, prediction, m, 0);
+        else if (s2 == RO_SHAPE_HALFSPACE) manifold_halfspace_sm(pose_inv(pos12), co2->he, &a, prediction, m, 1);
+        else manifold_pfm_pfm(pos12, &a, &b, prediction, m);
+    }
+    else if (s1 == RO_SHAPE_HALFSPACE || s2 == RO_SHAPE_HALFSPACE) {
+        /* (_, Ball) | (Ball, _) -> convex_ball comes before (HalfSpace, pfm) | (pfm, HalfSpace) in the dispatcher */
+        if (s1 == RO_SHAPE_HALFSPACE && s2 == RO_SHAPE_HALFSPACE) m->npoints = 0; /* Unsupported */
+        else if (s1 == RO_SHAPE_HALFSPACE && s2 == RO_SHAPE_BALL) manifold_halfspace_ball(pos12, co1->he, co2->radius, prediction, m, 0);
+        else if (s2 == RO_SHAPE_HALFSPACE && s1 == RO_SHAPE_BALL) manifold_halfspace_ball(pose_inv(pos12), co2->he, co1->radius, prediction, m, 1);
+        else if (s1 == RO_SHAPE_HALFSPACE) manifold_halfspace_pfm(pos12, co1->he, s2 == RO_SHAPE_CAPSULE, co2->he, co2->he.x, co2->radius, co2->axis, prediction, m, 0);
+        else manifold_halfspace_pfm(pose_inv(pos12), co2->he, s1 == RO_SHAPE_CAPSULE, co1->he, co1->he.x, co1->radius, co1->axis, prediction, m, 1);
+    }
+    else if (s1 == RO_SHAPE_CUBOID && s2 == RO_SHAPE_CUBOID) manifold_cuboid_cuboid(pos12, co1->he, co2->he, prediction, m);
+    else if (s1 == RO_SHAPE_BALL && s2 == RO_SHAPE_BALL) manifold_ball_ball(pos12, co1->radius, co2->radius, prediction, m);
+    else if (s1 == RO_SHAPE_CAPSULE && s2 == RO_SHAPE_CAPSULE) manifold_capsule_capsule(pos12, co1->he.x, co1->radius, co1->axis, co2->he.x, co2->radius, co2->axis, prediction, m);
+    else if (s1 == RO_SHAPE_CUBOID && s2 == RO_SHAPE_CAPSULE) manifold_cuboid_capsule(pos12, pos12, co1->he, co2->he.x, co2->radius, co2->axis, prediction, m, 0);
+    else if (s1 == RO_SHAPE_CAPSULE && s2 == RO_SHAPE_CUBOID) manifold_cuboid_capsule(pose_inv(pos12), pos12, co2->he, co1->he.x, co1->radius, co1->axis, prediction, m, 1);
+    else if (s1 == RO_SHAPE_CAPSULE && s2 == RO_SHAPE_BALL) manifold_capsule_ball(pos12, co1->he.x, co1->radius, co1->axis, co2->radius, prediction, m, 0);
+    else if (s1 == RO_SHAPE_BALL && s2 == RO_SHAPE_CAPSULE) manifold_capsule_ball(pose_inv(pos12), co2->he.x, co2->radius, co2->axis, co1->radius, prediction, m, 1);
+    else if (s1 == RO_SHAPE_CUBOID) manifold_cuboid_ball(pos12, co1->he, co2->radius, prediction, m, 0);
+    else manifold_cuboid_ball(pose_inv(pos12), co2->he, co1->radius, prediction, m, 1);
+
+}
+#include "ro_composite.h"
+static int process_composite_pair(ro_world *w, int pair_idx, Transition *tr_out, pose pos12, float prediction, float recycle_dist, int had);
+static int composite_shapes_intersect(const Collider *co1, const Collider *co2, float prediction);
 static int process_pair(ro_world *w, int pair_idx, Transition *tr_out) {
     tr_out->pair = -1;
     Pair *p = &w->pairs[pair_idx];
@@ -1297,7 +1430,7 @@ static int process_pair(ro_world *w, int pair_idx, Transition *tr_out) {
     if (co1->sensor || co2->sensor) {
         int had_i = p->intersecting;
         p->m.npoints = 0; p->nsc = 0; p->has_recycle = 0;
-        p->intersecting = co1->parent == co2->parent && co1->parent >= 0 ? 0 : shapes_intersect(co1, co2);
+        p->intersecting = co1->parent == co2->parent && co1->parent >= 0 ? 0 : ((co_is_composite(co1) || co_is_composite(co2)) ? composite_shapes_intersect(co1, co2, prediction) : shapes_intersect(co1, co2));
         if (had_i != p->intersecting) { tr_out->pair = pair_idx; tr_out->body1 = co1->parent; tr_out->body2 = co2->parent; tr_out->touching = p->intersecting; tr_out->sensor = 1; }
         return 2;
     }
@@ -1324,103 +1457,16 @@ static int process_pair(ro_world *w, int pair_idx, Transition *tr_out) {
     /* the other filters (:203-252) were applied when the pair was created (static in this scope) */
     pose pos12 = pose_inv_mul(co1->pos, co2->pos);
     float eff_prediction = prediction; /* contact_skin = 0, no soft-ccd */
+    if (co_is_composite(co1) || co_is_composite(co2)) return process_composite_pair(w, pair_idx, tr_out, pos12, prediction, recycle_dist, had);
 
     /* :323-330 parry DefaultQueryDispatcher::contact_manifolds */
-    int s1 = co1->shape, s2 = co2->shape;
-    if (s1 >= RO_SHAPE_CYLINDER || s2 >= RO_SHAPE_CYLINDER || co1->border > 0.0f || co2->border > 0.0f) { /* cylinders, cones, polyhedra, round shapes (ro_convex.h): same dispatcher order — ball arms, half-space arms, pfm_pfm */
-        SmShape a = sm_shape_of(co1), b = sm_shape_of(co2);
-        if (s2 == RO_SHAPE_BALL) manifold_sm_ball(pos12, &a, co2->radius, eff_prediction, &p->m, 0);
-        else if (s1 == RO_SHAPE_BALL) manifold_sm_ball(pose_inv(pos12), &b, co1->radius, eff_prediction, &p->m, 1);
-        else if (s1 == RO_SHAPE_HALFSPACE) manifold_halfspace_sm(pos12, co1->he, &b, eff_prediction, &p->m, 0);
-        else if (s2 == RO_SHAPE_HALFSPACE) manifold_halfspace_sm(pose_inv(pos12), co2->he, &a, eff_prediction, &p->m, 1);
-        else manifold_pfm_pfm(pos12, &a, &b, eff_prediction, &p->m);
-    }
-    else if (s1 == RO_SHAPE_HALFSPACE || s2 == RO_SHAPE_HALFSPACE) {
-        /* (_, Ball) | (Ball, _) -> convex_ball comes before (HalfSpace, pfm) | (pfm, HalfSpace) in the dispatcher */
-        if (s1 == RO_SHAPE_HALFSPACE && s2 == RO_SHAPE_HALFSPACE) p->m.npoints = 0; /* Unsupported */
-        else if (s1 == RO_SHAPE_HALFSPACE && s2 == RO_SHAPE_BALL) manifold_halfspace_ball(pos12, co1->he, co2->radius, eff_prediction, &p->m, 0);
-        else if (s2 == RO_SHAPE_HALFSPACE && s1 == RO_SHAPE_BALL) manifold_halfspace_ball(pose_inv(pos12), co2->he, co1->radius, eff_prediction, &p->m, 1);
-        else if (s1 == RO_SHAPE_HALFSPACE) manifold_halfspace_pfm(pos12, co1->he, s2 == RO_SHAPE_CAPSULE, co2->he, co2->he.x, co2->radius, co2->axis, eff_prediction, &p->m, 0);
-        else manifold_halfspace_pfm(pose_inv(pos12), co2->he, s1 == RO_SHAPE_CAPSULE, co1->he, co1->he.x, co1->radius, co1->axis, eff_prediction, &p->m, 1);
-    }
-    else if (s1 == RO_SHAPE_CUBOID && s2 == RO_SHAPE_CUBOID) manifold_cuboid_cuboid(pos12, co1->he, co2->he, eff_prediction, &p->m);
-    else if (s1 == RO_SHAPE_BALL && s2 == RO_SHAPE_BALL) manifold_ball_ball(pos12, co1->radius, co2->radius, eff_prediction, &p->m);
-    else if (s1 == RO_SHAPE_CAPSULE && s2 == RO_SHAPE_CAPSULE) manifold_capsule_capsule(pos12, co1->he.x, co1->radius, co1->axis, co2->he.x, co2->radius, co2->axis, eff_prediction, &p->m);
-    else if (s1 == RO_SHAPE_CUBOID && s2 == RO_SHAPE_CAPSULE) manifold_cuboid_capsule(pos12, pos12, co1->he, co2->he.x, co2->radius, co2->axis, eff_prediction, &p->m, 0);
-    else if (s1 == RO_SHAPE_CAPSULE && s2 == RO_SHAPE_CUBOID) manifold_cuboid_capsule(pose_inv(pos12), pos12, co2->he, co1->he.x, co1->radius, co1->axis, eff_prediction, &p->m, 1);
-    else if (s1 == RO_SHAPE_CAPSULE && s2 == RO_SHAPE_BALL) manifold_capsule_ball(pos12, co1->he.x, co1->radius, co1->axis, co2->radius, eff_prediction, &p->m, 0);
-    else if (s1 == RO_SHAPE_BALL && s2 == RO_SHAPE_CAPSULE) manifold_capsule_ball(pose_inv(pos12), co2->he.x, co2->radius, co2->axis, co1->radius, eff_prediction, &p->m, 1);
-    else if (s1 == RO_SHAPE_CUBOID) manifold_cuboid_ball(pos12, co1->he, co2->radius, eff_prediction, &p->m, 0);
-    else manifold_cuboid_ball(pose_inv(pos12), co2->he, co1->radius, eff_prediction, &p->m, 1);
+    dispatch_manifold(co1, co2, pos12, eff_prediction, &p->m);
 
     p->friction = ro_combine_coefficient(co1->friction, co2->friction, co1->friction_rule, co2->friction_rule);
     p->restitution = ro_combine_coefficient(co1->restitution, co2->restitution, co1->restitution_rule, co2->restitution_rule);
     p->relative_dominance = effective_dominance_group(w, rb1) - effective_dominance_group(w, rb2);
     p->normal = qrot(co1->pos.r, p->m.local_n1);
-    p->nsc = 0;
-
-    Manifold *m = &p->m;
-    if (m->npoints > 0) {
-        int selected[4] = {0, 1, 2, 3};
-        int num_selected = m->npoints < 4 ? m->npoints : 4;
-        reduce_manifold_naive(m, selected, &num_selected, prediction);
-        /* :430-457 lexicographic sort in the contact plane */
-        if (num_selected > 1) {
-            v3 basis[2]; orthonormal_basis(m->local_n1, basis);
-            float k0[4], k1[4]; int ks[4];
-            for (int i = 0; i < num_selected; ++i) {
-                v3 lp = m->points[selected[i]].local_p1;
-                k0[i] = vdot(lp, basis[0]); k1[i] = vdot(lp, basis[1]); ks[i] = selected[i];
-            }
-            for (int i = 1; i < num_selected; ++i) {
-                float a0 = k0[i], a1 = k1[i]; int as = ks[i]; int j = i;
-                while (j > 0 && (k0[j - 1] > a0 || (k0[j - 1] == a0 && k1[j - 1] > a1))) {
-                    k0[j] = k0[j - 1]; k1[j] = k1[j - 1]; ks[j] = ks[j - 1]; j--;
-                }
-                k0[j] = a0; k1[j] = a1; ks[j] = as;
-            }
-            for (int i = 0; i < num_selected; ++i) selected[i] = ks[i];
-        }
-        /* :459-498 solver contacts */
-        for (int s = 0; s < num_selected; ++s) {
-            int cid = selected[s];
-            TrackedContact *c = &m->points[cid];
-            float eff_dist = c->dist; /* - skins (0) */
-            v3 world_pt1 = pose_tp(co1->pos, c->local_p1);
-            v3 world_pt2 = pose_tp(co2->pos, c->local_p2);
-            int keep = eff_dist < prediction;
-            if (!keep) {
-                v3 vel1 = V3(0, 0, 0), vel2 = V3(0, 0, 0);
-                if (rb1 >= 0) { const Body *b = &w->bodies[rb1]; vel1 = vadd(b->linvel, vcross(b->angvel, vsub(world_pt1, b->world_com))); }
-                if (rb2 >= 0) { const Body *b = &w->bodies[rb2]; vel2 = vadd(b->linvel, vcross(b->angvel, vsub(world_pt2, b->world_com))); }
-                keep = eff_dist + vdot(vsub(vel2, vel1), p->normal) * prm->dt < prediction;
-            }
-            if (keep) {
-                SolverContact *sc = &p->sc[p->nsc++];
-                sc->anchor1 = world_pt1; sc->anchor2 = world_pt2; sc->dist = eff_dist;
-                sc->tangent_velocity = V3(0, 0, 0); sc->cid = cid;
-            }
-        }
-        /* :536-577 localise anchors and freeze the solver lever arms */
-        {
-            v3 normal = p->normal; int rel_dom = p->relative_dominance;
-            int has1 = rb1 >= 0 && rel_dom <= 0, has2 = rb2 >= 0 && rel_dom >= 0;
-            pose com1 = pose_ident(), com2 = pose_ident();
-            if (has1) { const Body *b = &w->bodies[rb1]; com1.r = b->position.r; com1.t = pose_tp(b->position, b->local_com); }
-            if (has2) { const Body *b = &w->bodies[rb2]; com2.r = b->position.r; com2.t = pose_tp(b->position, b->local_com); }
-            for (int s = 0; s < p->nsc; ++s) {
-                SolverContact *sc = &p->sc[s];
-                float shift = vdot(vsub(sc->anchor2, sc->anchor1), normal) - sc->dist;
-                v3 p1 = vadd(sc->anchor1, vmul(normal, shift));
-                v3 point = vmul(vadd(p1, sc->anchor2), 0.5f);
-                ContactData *pd = &m->points[sc->cid].data;
-                pd->solver_dp1 = has1 ? vsub(point, com1.t) : point;
-                pd->solver_dp2 = has2 ? vsub(point, com2.t) : point;
-                sc->anchor1 = has1 ? pose_itp(com1, p1) : p1;
-                if (has2) sc->anchor2 = pose_itp(com2, sc->anchor2);
-            }
-        }
-    }
+    build_solver_contacts(w, rb1, rb2, p->relative_dominance, p->normal, p->m.local_n1, p->m.points, p->m.npoints, co1->pos, co2->pos, prediction, p->sc, &p->nsc);
     /* :582-613 recycle state */
     if (recycle_dist > 0.0f) {
         float max_extent = p->has_recycle ? p->rec_max_extent : ro_maxf(collider_origin_radius(co1), collider_origin_radius(co2));
@@ -1435,6 +1481,125 @@ static int process_pair(ro_world *w, int pair_idx, Transition *tr_out) {
         Transition *t = tr_out;
         t->pair = pair_idx; t->body1 = rb1; t->body2 = rb2; t->touching = has;
     }
+    return 1;
+}
+
+/* intersection test of a sensor pair with a composite side: any candidate sub-shape pair intersects (intersection_test_composite_shape_shape) */
+static int composite_shapes_intersect(const Collider *co1, const Collider *co2, float prediction) {
+    (void)prediction;
+    pose pos12 = pose_inv_mul(co1->pos, co2->pos);
+    int cand[RO_MAX_SUBPAIRS][2], ovf;
+    int n = comp_candidates(co1, co2, pos12, 0.0f, cand, RO_MAX_SUBPAIRS, &ovf);
+    for (int q = 0; q < n; ++q) {
+        Collider a, b; pose pa, pb; int ha, hb;
+        co_sub(co1, cand[q][0] < 0 ? 0 : cand[q][0], &a, &pa, &ha); co_sub(co2, cand[q][1] < 0 ? 0 : cand[q][1], &b, &pb, &hb);
+        a.pos = ha ? pose_mul(co1->pos, pa) : co1->pos; b.pos = hb ? pose_mul(co2->pos, pb) : co2->pos;
+        if (shapes_intersect(&a, &b)) return 1;
+    }
+    return 0;
+}
+/* The full update of a pair with a composite collider (pair_update.rs:323-577 with several manifolds): sub-manifolds of the candidate
+ * sub-shape pairs, then either the plain manifold (one candidate) or the solver clusters (contact_clustering.rs), solver contacts per
+ * solver manifold, clusters with solver contacts first.  Called from process_pair behind its early outs; `had` = touched before. */
+static int process_composite_pair(ro_world *w, int pair_idx, Transition *tr_out, pose pos12, float prediction, float recycle_dist, int had) {
+    Pair *p = &w->pairs[pair_idx];
+    const Collider *co1 = &w->colliders[p->c1], *co2 = &w->colliders[p->c2];
+    const int rb1 = co1->parent, rb2 = co2->parent;
+    int cand[RO_MAX_SUBPAIRS][2], ovf = 0;
+    const int ncand = comp_candidates(co1, co2, pos12, prediction, cand, RO_MAX_SUBPAIRS, &ovf);
+    if (ovf) {
+#pragma omp atomic
+        w->subpair_overflows += 1;
+    }
+    p->friction = ro_combine_coefficient(co1->friction, co2->friction, co1->friction_rule, co2->friction_rule);
+    p->restitution = ro_combine_coefficient(co1->restitution, co2->restitution, co1->restitution_rule, co2->restitution_rule);
+    p->relative_dominance = effective_dominance_group(w, rb1) - effective_dominance_group(w, rb2);
+    if (!p->ex && ncand > 1) p->ex = (ExtraCluster *)calloc(RO_MAX_CLUSTERS - 1, sizeof(ExtraCluster));
+    /* the solver manifolds of the previous step: the warm-start source of this step's clusters (pair_update.rs:360-369) */
+    const int prev_ncl = p->ncl;
+    Manifold prev_m[RO_MAX_CLUSTERS]; const Manifold *prev[RO_MAX_CLUSTERS];
+    for (int k = 0; k < prev_ncl; ++k) { prev_m[k] = *sm_m(p, k); prev[k] = &prev_m[k]; }
+
+    if (ncand <= 1) {
+        /* ---- one manifold: the plain path (pair_update.rs:385-396, :398-403) ---- */
+        const int s1 = ncand ? cand[0][0] : -1, s2 = ncand ? cand[0][1] : -1;
+        Manifold *m = &p->m;
+        if (prev_ncl > 0 || p->plain_sub[0] != s1 || p->plain_sub[1] != s2 || ncand == 0) { m->npoints = 0; m->local_n1 = V3(0, 0, 0); m->local_n2 = V3(0, 0, 0); } /* another sub-shape pair: another (new) manifold */
+        p->plain_sub[0] = s1; p->plain_sub[1] = s2; p->ncl = 0;
+        for (int k = 1; k < RO_MAX_CLUSTERS && p->ex; ++k) { p->ex[k - 1].nsc = 0; p->ex[k - 1].m.npoints = 0; }
+        pose wp1 = co1->pos, wp2 = co2->pos;
+        p->nsc = 0;
+        if (ncand == 1) {
+            Collider a, b; pose pa, pb; int ha, hb;
+            co_sub(co1, s1 < 0 ? 0 : s1, &a, &pa, &ha); co_sub(co2, s2 < 0 ? 0 : s2, &b, &pb, &hb);
+            pose rel = ha ? pose_inv_mul(pa, pos12) : pos12;
+            if (hb) rel = pose_mul(rel, pb);
+            dispatch_manifold(&a, &b, rel, prediction, m);
+            if (prev_ncl > 0) { /* clustering stopped applying: carry the warm-start data back into the plain manifold once (:385-396) */
+                v3 tn1 = m->local_n1; TrackedContact *tp = m->points; int tnp = m->npoints; const pose *tpos = ha ? &pa : NULL;
+                carry_warmstart(prev, prev_ncl, &tn1, &tp, &tnp, &tpos, 1, prediction);
+            }
+            if (ha) wp1 = pose_mul(co1->pos, pa);
+            if (hb) wp2 = pose_mul(co2->pos, pb);
+            p->normal = qrot(wp1.r, m->local_n1);
+            build_solver_contacts(w, rb1, rb2, p->relative_dominance, p->normal, m->local_n1, m->points, m->npoints, wp1, wp2, prediction, p->sc, &p->nsc);
+        }
+    } else {
+        /* ---- several manifolds: solver clusters (contact_clustering.rs:33-122) ---- */
+        static _Thread_local ClusterTmp cl[RO_MAX_CLUSTERS];
+        int ncl = 0;
+        const float dedup_eps = prediction * 0.25f, dedup_eps_sq = dedup_eps * dedup_eps;
+        for (int q = 0; q < ncand; ++q) {
+            Collider a, b; pose pa, pb; int ha, hb;
+            co_sub(co1, cand[q][0] < 0 ? 0 : cand[q][0], &a, &pa, &ha); co_sub(co2, cand[q][1] < 0 ? 0 : cand[q][1], &b, &pb, &hb);
+            pose rel = ha ? pose_inv_mul(pa, pos12) : pos12;
+            if (hb) rel = pose_mul(rel, pb);
+            Manifold sub; memset(&sub, 0, sizeof(sub));
+            dispatch_manifold(&a, &b, rel, prediction, &sub);
+            if (sub.npoints == 0) continue;
+            const v3 n1 = ha ? qrot(pa.r, sub.local_n1) : sub.local_n1, n2 = hb ? qrot(pb.r, sub.local_n2) : sub.local_n2;
+            cluster_add_manifold(cl, &ncl, &sub, n1, n2, ha ? &pa : NULL, hb ? &pb : NULL, dedup_eps_sq);
+        }
+        { /* carry_warmstart_data(prev clusters -> new clusters) :124 */
+            v3 tn1[RO_MAX_CLUSTERS]; TrackedContact *tp[RO_MAX_CLUSTERS]; int tnp[RO_MAX_CLUSTERS]; const pose *tpos[RO_MAX_CLUSTERS];
+            for (int c = 0; c < ncl; ++c) { tn1[c] = cl[c].n1; tp[c] = cl[c].pts; tnp[c] = cl[c].np; tpos[c] = NULL; }
+            carry_warmstart(prev, prev_ncl, tn1, tp, tnp, tpos, ncl, prediction);
+        }
+        /* solver contacts of every cluster (pair_update.rs:404-577 with subshape_pos = None), then the clusters with solver contacts first */
+        SolverContact scs[RO_MAX_CLUSTERS][4]; int nscs[RO_MAX_CLUSTERS]; v3 normals[RO_MAX_CLUSTERS];
+        for (int c = 0; c < ncl; ++c) {
+            normals[c] = qrot(co1->pos.r, cl[c].n1);
+            build_solver_contacts(w, rb1, rb2, p->relative_dominance, normals[c], cl[c].n1, cl[c].pts, cl[c].np, co1->pos, co2->pos, prediction, scs[c], &nscs[c]);
+        }
+        int order[RO_MAX_CLUSTERS], no = 0;
+        for (int c = 0; c < ncl; ++c) if (nscs[c] > 0) order[no++] = c;
+        for (int c = 0; c < ncl; ++c) if (nscs[c] == 0) order[no++] = c;
+        for (int k = 0; k < RO_MAX_CLUSTERS; ++k) {
+            Manifold *m = sm_m(p, k); SolverContact *sc = sm_sc(p, k); int *nsc = sm_nsc(p, k);
+            *nsc = 0; m->npoints = 0;
+            if (k >= ncl) continue;
+            const ClusterTmp *C = &cl[order[k]];
+            m->local_n1 = C->n1; m->local_n2 = C->n2; *sm_normal(p, k) = normals[order[k]];
+            /* kept: the points the solver contacts name (in that order: contact id = position), then the other points that carry
+             * warm-start data (a later step may hand it on), as many as the manifold holds */
+            int remap[RO_CLUSTER_PTS]; for (int i = 0; i < C->np; ++i) remap[i] = -1;
+            for (int j = 0; j < nscs[order[k]]; ++j) { const int cid = scs[order[k]][j].cid; remap[cid] = m->npoints; m->points[m->npoints++] = C->pts[cid]; }
+            for (int i = 0; i < C->np && m->npoints < RO_MAX_MANIFOLD_PTS; ++i) if (remap[i] < 0 && data_has_warmstart(&C->pts[i].data)) m->points[m->npoints++] = C->pts[i];
+            for (int j = 0; j < nscs[order[k]]; ++j) { sc[j] = scs[order[k]][j]; sc[j].cid = remap[sc[j].cid]; }
+            *nsc = nscs[order[k]];
+        }
+        p->ncl = ncl; p->plain_sub[0] = p->plain_sub[1] = -2;
+    }
+    /* :582-613 recycle state */
+    if (recycle_dist > 0.0f) {
+        float max_extent = p->has_recycle ? p->rec_max_extent : ro_maxf(collider_origin_radius(co1), collider_origin_radius(co2));
+        p->rec_max_drift = p->nsc > 0 ? recycle_dist : ro_minf(recycle_dist, prediction);
+        p->rec_pos12 = pos12; p->rec_rot1 = co1->pos.r; p->rec_rot2 = co2->pos.r; p->rec_max_extent = max_extent;
+        p->has_recycle = 1;
+    }
+    p->hint_seq = w->step_seq;
+    const int has = p->nsc > 0;
+    if (has != had) { tr_out->pair = pair_idx; tr_out->body1 = rb1; tr_out->body2 = rb2; tr_out->touching = has; }
     return 1;
 }
 

@@ -58,7 +58,12 @@ enum { RO_SHAPE_BALL = 0, RO_SHAPE_CUBOID = 1, RO_SHAPE_CAPSULE = 2 /* half_exte
        RO_SHAPE_CONVEX_POLYHEDRON = 6 /* half_extents[0] = the id ro_add_convex_polyhedron returned: ColliderBuilder::convex_mesh / convex_hull (collider.rs:1039, :1070) */,
        /* ColliderBuilder::round_cuboid / round_cylinder / round_cone / round_convex_hull (collider.rs:778-1080): the shape above dilated by a
         * sphere of radius ro_collider_desc.border_radius (parry RoundShape<S>); half_extents as for the inner shape */
-       RO_SHAPE_ROUND_CUBOID = 7, RO_SHAPE_ROUND_CYLINDER = 8, RO_SHAPE_ROUND_CONE = 9, RO_SHAPE_ROUND_CONVEX_POLYHEDRON = 10 };
+       RO_SHAPE_ROUND_CUBOID = 7, RO_SHAPE_ROUND_CYLINDER = 8, RO_SHAPE_ROUND_CONE = 9, RO_SHAPE_ROUND_CONVEX_POLYHEDRON = 10,
+       /* composite shapes as ONE collider (half_extents[0] = the id ro_add_compound / ro_add_trimesh / ro_add_heightfield returned):
+        * ColliderBuilder::compound (collider.rs:711), ::trimesh (:944), ::heightfield (:1089).  Several manifolds per pair ->
+        * contact clustering (contact_clustering.rs:33).  A triangle mesh / height field needs a fixed or kinematic parent (or none). */
+       RO_SHAPE_COMPOUND = 11, RO_SHAPE_TRIMESH = 12,
+       RO_SHAPE_TRIANGLE = 13 /* internal: one triangle of a mesh as a support-mapped shape (never a collider's own shape) */ };
 /* CoefficientCombineRule — coefficient_combine_rule.rs:37-57 */
 enum { RO_RULE_AVERAGE = 0, RO_RULE_MIN = 1, RO_RULE_MULTIPLY = 2, RO_RULE_MAX = 3,
        RO_RULE_CLAMPED_SUM = 4, RO_RULE_GEOMETRIC_MEAN = 5 };
@@ -120,6 +125,16 @@ int32_t ro_add_body(ro_world *w, const ro_body_desc *d);
 int32_t ro_add_collider(ro_world *w, const ro_collider_desc *d, int32_t parent_body);
 /* SharedShape::convex_mesh(points, indices): registers a convex polyhedron (closed, outward-wound triangle mesh); returns its id or -1 */
 int32_t ro_add_convex_polyhedron(ro_world *w, int32_t n_points, const float *points_xyz, int32_t n_triangles, const uint32_t *indices);
+/* Composite shapes (registered once, shared by colliders; -1 = invalid input).  Compound: `parts` are collider descriptors of which only
+ * shape (a primitive or round primitive), half_extents, translation, rotation and border_radius are read (SharedShape::compound).
+ * TriMesh: vertices + triangle index triples (TriMesh::new, no flags).  HeightField: an nrows x ncols grid of heights (row-major
+ * heights[r * ncols + c], r along z, c along x) scaled by `scale` — served by the triangle-mesh machinery with parry's cell
+ * triangulation (two triangles per cell, heightfield3.rs). */
+int32_t ro_add_compound(ro_world *w, int32_t n_parts, const struct ro_collider_desc *parts);
+int32_t ro_add_trimesh(ro_world *w, int32_t n_vertices, const float *vertices_xyz, int32_t n_triangles, const uint32_t *indices);
+int32_t ro_add_heightfield(ro_world *w, int32_t nrows, int32_t ncols, const float *heights, const float scale[3]);
+/* solver manifolds (clusters) of pair (c1, c2): count, and per cluster the solver-contact count (cap entries) — test / diagnostics */
+int32_t ro_pair_clusters(const ro_world *w, int32_t c1, int32_t c2, int32_t cap, int32_t *nsc_out);
 /* the canonical form it was given (ro_polyhedron.h): counts = {vertices, faces, loop entries, edges}; then the arrays (NULL = skip) */
 void ro_read_convex_polyhedron(const ro_world *w, int32_t id, int32_t counts[4], float *points_xyz, float *face_normals, int32_t *face_first, int32_t *face_count, int32_t *loop_vertex, int32_t *loop_edge, float props[20]);
 int32_t ro_add_joint(ro_world *w, const ro_joint_desc *d);

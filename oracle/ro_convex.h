@@ -29,7 +29,8 @@
 /* he: cuboid half extents | capsule: he.x = half height, radius, axis | ball: radius | cylinder / cone (axis Y): he = (radius,
  * half_height, radius) — the half extents of the local AABB — and radius */
 typedef struct { int shape; v3 he; float radius; int axis; const RoPolyhedron *poly; /* RO_SHAPE_CONVEX_POLYHEDRON: he = the local AABB's half extents */
-                 float border; /* a round shape (parry RoundShape<S>): `shape` is its inner shape, this its border radius */ } SmShape;
+                 float border; /* a round shape (parry RoundShape<S>): `shape` is its inner shape, this its border radius */
+                 v3 tri[3];    /* RO_SHAPE_TRIANGLE (a triangle of a TriMesh / HeightField, ro_composite): its vertices */ } SmShape;
 
 #define RO_GJK_EPS_TOL 1.1920929e-6f          /* gjk::eps_tol() = 10 * f32::EPSILON */
 #define RO_EPA_EPS_TOL 1.1920929e-5f          /* 100 * f32::EPSILON */
@@ -63,6 +64,11 @@ static inline v3 sm_support(const SmShape *s, v3 d) {
         v3 r = V3(d.x / n * s->radius, -s->he.y, d.z / n * s->radius);
         if (vdot(d, r) < d.y * s->he.y) r = V3(0.0f, s->he.y, 0.0f);
         return r;
+    }
+    if (s->shape == RO_SHAPE_TRIANGLE) { /* Triangle::local_support_point: the first vertex with the largest dot product */
+        float da = vdot(s->tri[0], d), db = vdot(s->tri[1], d), dc = vdot(s->tri[2], d);
+        if (da > db) return da > dc ? s->tri[0] : s->tri[2];
+        return db > dc ? s->tri[1] : s->tri[2];
     }
     if (s->shape == RO_SHAPE_CONVEX_POLYHEDRON) { /* utils::point_cloud_support_point: the first vertex with the largest dot product */
         const RoPolyhedron *P = s->poly;
@@ -438,6 +444,11 @@ static inline void sm_support_feature(const SmShape *s, v3 dir, v3 hint, PolyFea
         out->fid = 0; out->nv = 2;
         return;
     }
+    if (s->shape == RO_SHAPE_TRIANGLE) { /* Triangle: PolygonalFeature::from(triangle) — the face itself whatever the direction (vertex ids 0, 2, 4, edge ids 1, 3, 5) */
+        for (int i = 0; i < 4; ++i) { int k = i < 3 ? i : 2; out->v[i] = s->tri[k]; out->vid[i] = 2u * (uint32_t)k; out->eid[i] = 2u * (uint32_t)k + 1u; }
+        out->fid = 0; out->nv = 3;
+        return;
+    }
     if (s->shape == RO_SHAPE_CONVEX_POLYHEDRON) { /* ConvexPolyhedron: the face whose normal is closest to dir (the first one), its first four vertices */
         const RoPolyhedron *P = s->poly;
         int best = 0; float bd = vdot(P->fnormal[0], dir);
@@ -650,8 +661,8 @@ static inline v3 sm_project_point(const SmShape *s, v3 pt, int *inside) {
 /* contact_manifold_convex_ball with shape1 = a cylinder / cone / convex polyhedron; flipped = the ball is collider 1 */
 static inline void manifold_sm_ball(pose pos12, const SmShape *s1, float r2, float prediction, Manifold *m, int flipped) {
     v3 pt = pos12.t;
-    if (s1->shape == RO_SHAPE_CONVEX_POLYHEDRON || s1->border > 0.0f) {
-        /* ConvexPolyhedron / RoundShape::project_local_point = local_point_projection_on_support_map: GJK against the point, the polytope
+    if (s1->shape == RO_SHAPE_CONVEX_POLYHEDRON || s1->shape == RO_SHAPE_TRIANGLE || s1->border > 0.0f) {
+        /* ConvexPolyhedron / Triangle / RoundShape::project_local_point = local_point_projection_on_support_map: GJK against the point, the polytope
          * pass when the point is inside — the support-mapped contact query with the ball's centre as second shape; a round shape's
          * border moves the projection out along the normal */
         SmShape centre; centre.shape = RO_SHAPE_BALL; centre.he = V3(0, 0, 0); centre.radius = 0.0f; centre.axis = 1; centre.poly = NULL; centre.border = 0.0f;

@@ -1349,7 +1349,7 @@ static int carry_over(rp_world *w) {
     rp_launch_bp_rehash(d, w->stream); // the live pairs enter the (larger) current-epoch table
     int one = 1;
     for (int f : {FL_BP_DIRTY, FL_LAYOUT_DIRTY, FL_JOINT_DIRTY, FL_FLOW_DIRTY}) HIPCHK(w, hipMemcpyAsync(d.flags + f, &one, sizeof(int), hipMemcpyHostToDevice, w->stream));
-    { int zero = 0; for (int f : {FL_BP_GRID_OK, FL_BP_NCHG, FL_BP_NMOVED, FL_BP_TOMBS, FL_BP_FORCE_FULL}) HIPCHK(w, hipMemcpyAsync(d.flags + f, &zero, sizeof(int), hipMemcpyHostToDevice, w->stream)); } // the grid and the change lists are scratch of the old world
+    { int zero = 0; for (int f : {FL_BP_GRID_OK, FL_BP_NCHG, FL_BP_NFREED, FL_BP_TOMBS, FL_BP_FORCE_FULL}) HIPCHK(w, hipMemcpyAsync(d.flags + f, &zero, sizeof(int), hipMemcpyHostToDevice, w->stream)); } // the grid and the change lists are scratch of the old world
     HIPCHK(w, hipStreamSynchronize(w->stream));
     w->pinned_flags[FL_LAYOUT_DIRTY] = 1; // next steps stay on the full graph until the device reports a clean state
     w->full_until = w->steps_requested + 3;
@@ -1387,6 +1387,7 @@ static int finalize(rp_world *w) {
     if (!w->polys.empty()) { int r = upload_polyhedra(w); if (r != RP_OK) return r; } // (after the memset above: the cv_* pointers)
     d.gbar_blocks = gbar_grid_for_device(w->device);
     { const char *ni = getenv("RP_NO_BP_INCR"); d.bp_incremental = (ni && ni[0] == '1') ? 0 : 1; }
+    { const char *dv = getenv("RP_BP_INCR_DIV"); d.bp_incr_div = dv ? std::max(1, atoi(dv)) : 1; }
     { const char *ab = getenv("RP_BP_ALWAYS_BUILD"); d.bp_always_build = (ab && ab[0] == '1') ? 1 : 0; }
     { const char *nt = getenv("RP_NO_TINY_ROUTING"); d.isl_route_tiny = (nt && nt[0] == '1') ? 0 : 1; }
     { const char *ig = getenv("RP_ISL_GENERIC"); d.isl_generic = (ig && ig[0] == '1') ? 1 : 0; }
@@ -1443,7 +1444,7 @@ static int finalize(rp_world *w) {
     for (int k = 0; k < 2; ++k) { DA(d.bk_cnt[k], d.grid_cap); DA(d.bk_items[k], (size_t)d.grid_cap * RP_BP_BUCKET); } // the broad-phase grid: fixed-slot hash buckets, two copies (rp_broadphase.hip)
     DA(d.scan_block, 1024 + 8); // the scratch counters of a running broad-phase rebuild
     DA(d.large_list, d.large_cap);
-    DA(d.c_chgstamp, capc); DA(d.c_stale, capc); DA(d.c_inlarge, capc); DA(d.c_rver, capc); DA(d.bp_chg_list, capc); DA(d.bp_moved_list, RP_BP_MOVED_CAP); // incremental broad phase (scratch: rebuilt by the next full pass)
+    DA(d.c_chgstamp, capc); DA(d.c_stale, capc); DA(d.c_inlarge, capc); DA(d.c_rver, capc); DA(d.bp_chg_list, capc); DA(d.free_pending, d.pool_cap); // incremental broad phase (scratch: rebuilt by the next full pass)
     DAF(d.h_key[0], d.hash_cap, 0xff); DAF(d.h_key[1], d.hash_cap, 0xff); DA(d.h_slot[0], d.hash_cap); DA(d.h_slot[1], d.hash_cap);
     DAC(d.free_stack, d.pool_cap, DOM_PAIR, 1, 1);
     size_t P = (size_t)d.pool_cap;

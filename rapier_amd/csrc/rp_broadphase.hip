@@ -265,7 +265,9 @@ RP_DEV void bp_pairs(DevWorld &w, int nxt, int nl) { // nl: the large list that 
 
 // DeletePair (NarrowPhase::remove_pair, pair_management.rs:382) of pair slot s: free the colour, raise the events and wake-ups,
 // journal the unlink, recycle the slot.
-RP_DEV void bp_delete_pair(DevWorld &w, int s) {
+// (`deferred`: the slot is parked in free_pending instead of going onto the free stack — an incremental pass inserts and deletes in
+// ONE pass, and its inserts pop that stack meanwhile; the pass's last workgroup moves the parked slots over)
+RP_DEV void bp_delete_pair(DevWorld &w, int s, bool deferred = false) {
     int color = w.p_color[s];
     if (color < RP_COLOR_OVERFLOW) {
         int2 cb = w.p_colorb[s];
@@ -303,6 +305,7 @@ RP_DEV void bp_delete_pair(DevWorld &w, int s) {
         if (w.p_nsc[s] > 0) pi_journal(w, rb.x, rb.y, 1, c1, c2); // unlink_contact of a removed touching pair (pair_management.rs:531)
     }
     w.p_c1[s] = -1; w.p_nsc[s] = 0; w.p_npts[s] = 0; w.p_color[s] = RP_COLOR_UNCOLORED;
+    if (deferred) { int t = atomicAdd(&w.flags[FL_BP_NFREED], 1); w.free_pending[t] = s; return; }
     int t = atomicAdd(&w.flags[FL_FREE_TOP], 1);
     w.free_stack[t] = s;
 }
@@ -342,30 +345,33 @@ __device__ __forceinline__ void bp_try_pair(DevWorld &w, int i, int j) {
     if (!fat_overlap(w, i, j, imin) || !pair_allowed(w, i, j)) return;
     bp_insert_pair(w, i < j ? i : j, i < j ? j : i, true);
 }
-// new partners of the colliders on bp_chg_list: one wavefront per changed collider
+// new partners of the colliders on bp_chg_list: EIGHT lanes per changed collider, like the pair pass of a full rebuild (round 5: a
+// whole wavefront per collider — round 3, when an incremental pass served a few dozen colliders — left 56 of 64 lanes idle on the
+// 2 x 2 x 2 cell range of a ball and made a pass over b3d_joint_grid's 3,559 rewritten AABBs slower than the full rebuild)
 RP_DEV void bp_incr_insert(DevWorld &w, int nchg) {
-    const int lane = threadIdx.x & 63, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, sub = tid & (BP_GROUP - 1), ngroups = (gridDim.x * blockDim.x) / BP_GROUP;
     const int stamp = w.flags[FL_BP_SEQ] + 1;
     const float ic = w.prm.inv_cell_size;
     int nl = w.flags[FL_N_LARGE]; if (nl > w.large_cap) nl = w.large_cap;
-    for (int k = wave; k < nchg; k += nwaves) {
+    const int cur = BP_GPAR(w); // the grid copy in service
+    const int *cnt = w.bk_cnt[cur]; const int *items = w.bk_items[cur];
+    for (int k = tid / BP_GROUP; k < nchg; k += ngroups) {
         const int i = w.bp_chg_list[k];
         CellRange r = cell_range(w, i);
-        if (r.large || w.c_inlarge[i]) { if (lane == 0) w.flags[FL_BP_FORCE_FULL] = 1; continue; } // the large list is only rebuilt by a full pass
+        if (r.large || w.c_inlarge[i]) continue; // (never here: bp_grid_follow raised FL_BP_FORCE_FULL when it rewrote that AABB, and this launch chose the full rebuild)
         // (a) the large colliders (ground slabs, walls: never stale)
-        for (int q = lane; q < nl; q += 64) bp_try_pair(w, i, w.large_list[q]);
-        // (b) everybody else through the grid, which follows every collider (bp_grid_follow): one lane per cell of the new AABB (at most
-        // 27); a pair is reported from the cell that holds the min corner of the intersection, which lies in both cell ranges; two
-        // colliders that both changed in this pass find each other — reported from the smaller index
+        for (int q = sub; q < nl; q += BP_GROUP) bp_try_pair(w, i, w.large_list[q]);
+        // (b) everybody else through the grid, which follows every collider (bp_grid_follow): the cells of the new AABB (at most 27)
+        // over the eight lanes; a pair is reported from the cell that holds the min corner of the intersection, which lies in both
+        // cell ranges; two colliders that both changed in this pass find each other — reported from the smaller index
         const int nx = r.hi[0] - r.lo[0] + 1, ny = r.hi[1] - r.lo[1] + 1, nz = r.hi[2] - r.lo[2] + 1;
-        if (lane < nx * ny * nz) {
-            const int x = r.lo[0] + lane % nx, y = r.lo[1] + (lane / nx) % ny, z = r.lo[2] + lane / (nx * ny);
+        for (int c = sub; c < nx * ny * nz; c += BP_GROUP) {
+            const int x = r.lo[0] + c % nx, y = r.lo[1] + (c / nx) % ny, z = r.lo[2] + c / (nx * ny);
             unsigned long long key = cell_key(x, y, z);
             int h = (int)(rp_hash64(key) & (unsigned long long)(w.grid_cap - 1));
-            const int cur = BP_GPAR(w); // the grid copy in service
-            int n = w.bk_cnt[cur][h]; if (n > RP_BP_BUCKET) n = RP_BP_BUCKET;
+            int n = cnt[h]; if (n > RP_BP_BUCKET) n = RP_BP_BUCKET;
             for (int e = 0; e < n; ++e) {
-                const int it = w.bk_items[cur][(size_t)h * RP_BP_BUCKET + e], j = it & 0xffffff;
+                const int it = items[(size_t)h * RP_BP_BUCKET + e], j = it & 0xffffff;
                 if (j == i) continue;
                 V3 imin;
                 if (!fat_overlap(w, i, j, imin)) continue; // (geometry first: the three status words below are only fetched for the few entries that get past it)
@@ -392,7 +398,7 @@ RP_DEV void bp_incr_delete(DevWorld &w, int gid, int gstride, int nchg) {
         if (fat_overlap(w, c1, c2, imin)) continue;
         hash_erase(w.h_key[cur], w.hash_cap, ((unsigned long long)(unsigned)c1 << 32) | (unsigned)c2);
         atomicAdd(&w.flags[FL_BP_TOMBS], 1);
-        bp_delete_pair(w, s);
+        bp_delete_pair(w, s, true);
     }
 }
 
@@ -406,28 +412,43 @@ __global__ void __launch_bounds__(1024) k_bp_rebuild(DevWorld w) {
     // (an incremental pass spends a wavefront per changed collider, the full rebuild eight lanes per collider: beyond a quarter of the
     // colliders the rebuild is the cheaper one — measured on b3d_joint_grid, where 3,559 of 10,000 change per pass: 36 us as a rebuild)
     const int nchg = w.flags[FL_BP_NCHG] < w.n_colliders ? w.flags[FL_BP_NCHG] : w.n_colliders;
-    const bool incremental = w.bp_incremental && w.flags[FL_BP_GRID_OK] && !w.flags[FL_BP_FORCE_FULL] && nchg > 0 && nchg <= w.n_colliders / 4 + 16 && w.flags[FL_BP_TOMBS] < w.hash_cap / 8;
+    const bool incremental = w.bp_incremental && w.flags[FL_BP_GRID_OK] && !w.flags[FL_BP_FORCE_FULL] && nchg > 0 && nchg <= w.n_colliders / w.bp_incr_div + 16 && w.flags[FL_BP_TOMBS] < w.hash_cap / 8;
     GridBar bar = gbar_begin(w, 0);
 #ifdef RP_PASS_PROFILE // why a pass was (not) incremental: dbg[240..] (tools/pass_profile.py)
     if (gid == 0) {
-        w.dbg[240] += 1; w.dbg[241] += incremental ? 1 : 0; w.dbg[242] += w.flags[FL_BP_GRID_OK] ? 0 : 1; w.dbg[243] += (nchg > w.n_colliders / 4 + 16) ? 1 : 0;
+        w.dbg[240] += 1; w.dbg[241] += incremental ? 1 : 0; w.dbg[242] += w.flags[FL_BP_GRID_OK] ? 0 : 1; w.dbg[243] += (nchg > w.n_colliders / w.bp_incr_div + 16) ? 1 : 0;
         w.dbg[244] += 0; w.dbg[245] += (w.flags[FL_BP_TOMBS] >= w.hash_cap / 8) ? 1 : 0; w.dbg[246] += nchg; w.dbg[247] += 0; w.dbg[248] = w.flags[FL_N_LARGE];
     }
 #endif
     if (incremental) {
+        // ONE pass, no grid barrier (round 5): new partners of the changed colliders and the pairs they lost are independent of each
+        // other — a pair is in exactly one of the two sets — the hash table takes CAS inserts and tombstones side by side, and freed
+        // slots are parked (bp_delete_pair deferred) while the inserts pop the free stack.  The last workgroup to finish (ticket)
+        // moves the parked slots onto the stack and closes the pass.  b3d_joint_grid, 3,559 of 10,000 fat AABBs rewritten per pass:
+        // 28 us (pairs | finish behind two barriers) -> see profiles/r05_joint_grid_kernel_stats.txt.
         bp_incr_insert(w, nchg);
-        GBAR_SYNC(bar);
-        if (!w.flags[FL_BP_FORCE_FULL]) {
-            bp_incr_delete(w, gid, gstride, nchg);
-            GBAR_SYNC(bar);
-            gbar_end(bar);
-            if (gid == 0) {
-                w.flags[FL_BP_NCHG] = 0; w.flags[FL_BP_SEQ] += 1; w.flags[FL_BP_REBUILDS] += 1;
-                __hip_atomic_store(&w.flags[FL_BP_DIRTY], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            return;
+        bp_incr_delete(w, gid, gstride, nchg);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every wave: its stores have left the CU (one releasing lane per workgroup, like gbar_sync:
+        __syncthreads();                                   // a fence per thread cost such a pass 32 us in round 3)
+        __shared__ int s_last;
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            s_last = (__hip_atomic_fetch_add(&w.flags[FL_TICKET], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) ? 1 : 0;
+            if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
-        // a large collider moved: the pairs inserted so far are found again (and re-stamped) by the rebuild below
+        __syncthreads();
+        if (!s_last) return;
+        const int nfreed = __hip_atomic_load(&w.flags[FL_BP_NFREED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int ftop = __hip_atomic_load(&w.flags[FL_FREE_TOP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = threadIdx.x; k < nfreed; k += blockDim.x) w.free_stack[ftop + k] = w.free_pending[k];
+        __threadfence(); __syncthreads();
+        if (threadIdx.x == 0) {
+            w.flags[FL_FREE_TOP] = ftop + nfreed; w.flags[FL_BP_NFREED] = 0; w.flags[FL_TICKET] = 0;
+            w.flags[FL_BP_NCHG] = 0; w.flags[FL_BP_SEQ] += 1; w.flags[FL_BP_REBUILDS] += 1;
+            __hip_atomic_store(&w.flags[FL_BP_DIRTY], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
     }
     const int epoch = w.flags[FL_BP_EPOCH];
     // Round 4: the grid in service follows every collider (bp_grid_follow), so a rebuild of the PAIR SET — what a step needs when many fat
@@ -451,7 +472,6 @@ __global__ void __launch_bounds__(1024) k_bp_rebuild(DevWorld w) {
         if (keep_grid) w.lay_state[9] += 1;
         else {
             w.lay_state[8] = gcur ^ 1; w.lay_state[9] = 0;
-            w.flags[FL_BP_NMOVED] = 0;
             w.flags[FL_BP_GRID_OK] = (w.flags[FL_OVERFLOW] & (RP_OVF_CELLS | RP_OVF_LARGE)) ? 0 : 1;
         }
         __hip_atomic_store(&w.flags[FL_BP_DIRTY], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -110,7 +110,7 @@ enum {
     FL_PI_JLINK,        // first device joint whose ImpulseJointIslandEvent::Link is not applied yet, + 1 (0 = none)
     // incremental broad phase (rp_broadphase.hip)
     FL_BP_NCHG,         // colliders whose fat AABB was rewritten since the last broad-phase pass (bp_chg_list)
-    FL_BP_NMOVED,       // colliders whose grid cells are stale since the last FULL rebuild (bp_moved_list)
+    FL_BP_NFREED,       // pair slots freed by the running incremental pass, waiting in free_pending for its epilogue (rp_broadphase.hip)
     FL_BP_GRID_OK,      // the grid describes every collider that is not on bp_moved_list (cleared by topology edits)
     FL_BP_SEQ,          // broad-phase passes run so far (stamps c_chgstamp)
     FL_BP_FORCE_FULL,   // scratch of one pass: the incremental update met a case it leaves to the full rebuild
@@ -198,6 +198,7 @@ struct DevWorld {
     int isl_generic;       // RP_ISL_GENERIC=1: islands through k_island_generic even under the twist model (tests of that kernel)
     int n_groups;          // distinct additional_solver_iterations counts in the world (1 = no elevated body: the plain paths)
     int bp_incremental;    // the broad phase may update incrementally (0: RP_NO_BP_INCR=1, every pass is a full rebuild)
+    int bp_incr_div;       // an incremental pass serves up to n_colliders / bp_incr_div (+ 16) rewritten fat AABBs (1; RP_BP_INCR_DIV: A/B)
     int gbar_blocks;       // most workgroups (of 1024 threads) a grid-barrier kernel may use on this device: all of them resident at once (rp_gridbar.h)
     int has_sensors;       // some collider is a sensor: its pairs are intersection-tested every step (full step path)
     int isl_route_tiny;    // 1 (RP_NO_TINY_ROUTING=1: 0): worlds with thousands of tiny islands solve them on the global path (rp_islands.hip, lay_isl_number)
@@ -283,7 +284,7 @@ struct DevWorld {
     int *large_list;
     int *c_chgstamp, *c_stale, *c_inlarge; // per collider: pass (FL_BP_SEQ + 1) that already queued it on bp_chg_list; (unused since round 4); on large_list
     int *c_rver;           // per collider: cell-range changes since the last full rebuild (the version its live grid entries carry: bp_grid_follow)
-    int *bp_chg_list, *bp_moved_list;      // [colliders] fat AABBs rewritten since the last pass; [RP_BP_MOVED_CAP] stale colliders
+    int *bp_chg_list, *free_pending;       // [colliders] fat AABBs rewritten since the last pass; [pool_cap] slots freed by a running incremental pass
     unsigned long long *h_key[2]; int *h_slot[2];
     int *free_stack;
 
