@@ -135,6 +135,7 @@ static inline SolverContact *sm_sc(Pair *p, int k) { return k == 0 ? p->sc : p->
 static inline int *sm_nsc(Pair *p, int k) { return k == 0 ? &p->nsc : &p->ex[k - 1].nsc; }
 static inline v3 *sm_normal(Pair *p, int k) { return k == 0 ? &p->normal : &p->ex[k - 1].normal; }
 static inline int pair_num_sm(const Pair *p) { return p->ncl > 1 ? p->ncl : 1; }
+static inline void pair_clear_clusters(Pair *p) { p->ncl = 0; p->plain_sub[0] = p->plain_sub[1] = -1; if (p->ex) for (int k = 0; k < RO_MAX_CLUSTERS - 1; ++k) { p->ex[k].nsc = 0; p->ex[k].m.npoints = 0; } }
 #define RO_SM_SHIFT 28          /* solver-manifold reference = pair index | k << 28 */
 #define RO_SM_PAIR(x) ((x) & ((1 << RO_SM_SHIFT) - 1))
 #define RO_SM_K(x) ((int)((unsigned)(x) >> RO_SM_SHIFT))
@@ -323,7 +324,9 @@ ro_world *ro_world_new(const ro_params *params, const float gravity[3]) {
     return w;
 }
 void ro_set_params(ro_world *w, const ro_params *params) { w->params = *params; }
+struct RoComposite; static void comp_free_fwd(struct RoComposite *C);
 void ro_world_free(ro_world *w) {
+    if (w) { for (int i = 0; i < w->npairs; ++i) free(w->pairs[i].ex); for (int i = 0; i < w->ncomps; ++i) comp_free_fwd(w->comps[i]); free(w->comps); }
     if (!w) return;
     for (int i = 0; i < w->npolys; ++i) { ro_poly_free(w->polys[i]); free(w->polys[i]); }
     free(w->polys);
@@ -1075,7 +1078,7 @@ static void broad_phase_update(ro_world *w) {
             }
             Pair *p = &w->pairs[w->npairs];
             memset(p, 0, sizeof(*p));
-            p->c1 = c1; p->c2 = c2; p->alive = 1; p->color = RO_COLOR_UNCOLORED;
+            p->c1 = c1; p->c2 = c2; p->alive = 1; p->color = RO_COLOR_UNCOLORED; p->plain_sub[0] = p->plain_sub[1] = -1;
             p->color_bodies[0] = p->color_bodies[1] = RO_NO_BODY;
             p->solver_body_ids[0] = p->solver_body_ids[1] = RO_NO_BODY;
             w->npairs++;
@@ -1087,7 +1090,7 @@ static void broad_phase_update(ro_world *w) {
     /* DeletePair: NarrowPhase::remove_pair (pair_management.rs:382) frees the colour and drops the edge. */
     int out = 0, removed = 0;
     for (int i = 0; i < w->npairs; ++i) {
-        if (!w->pairs[i].alive) { delete_pair_effects(w, &w->pairs[i]); removed = 1; continue; }
+        if (!w->pairs[i].alive) { delete_pair_effects(w, &w->pairs[i]); free(w->pairs[i].ex); w->pairs[i].ex = NULL; removed = 1; continue; }
         if (out != i) w->pairs[out] = w->pairs[i];
         out++;
     }
@@ -1107,7 +1110,7 @@ static void purge_dead_pairs(ro_world *w) {
     for (int i = 0; i < w->npairs; ++i) {
         Pair *p = &w->pairs[i];
         const Collider *a = &w->colliders[p->c1], *b = &w->colliders[p->c2];
-        if ((a->memberships == 0 && a->filter == 0) || (b->memberships == 0 && b->filter == 0)) { delete_pair_effects(w, p); removed = 1; continue; }
+        if ((a->memberships == 0 && a->filter == 0) || (b->memberships == 0 && b->filter == 0)) { delete_pair_effects(w, p); free(p->ex); p->ex = NULL; removed = 1; continue; }
         if (out != i) w->pairs[out] = w->pairs[i];
         out++;
     }
@@ -1429,7 +1432,7 @@ static int process_pair(ro_world *w, int pair_idx, Transition *tr_out) {
      * pair is re-tested while one of its bodies may have moved, Started / Stopped (CollisionEventFlags::SENSOR) on a change */
     if (co1->sensor || co2->sensor) {
         int had_i = p->intersecting;
-        p->m.npoints = 0; p->nsc = 0; p->has_recycle = 0;
+        p->m.npoints = 0; p->nsc = 0; p->has_recycle = 0; pair_clear_clusters(p);
         p->intersecting = co1->parent == co2->parent && co1->parent >= 0 ? 0 : ((co_is_composite(co1) || co_is_composite(co2)) ? composite_shapes_intersect(co1, co2, prediction) : shapes_intersect(co1, co2));
         if (had_i != p->intersecting) { tr_out->pair = pair_idx; tr_out->body1 = co1->parent; tr_out->body2 = co2->parent; tr_out->touching = p->intersecting; tr_out->sensor = 1; }
         return 2;
@@ -1449,7 +1452,7 @@ static int process_pair(ro_world *w, int pair_idx, Transition *tr_out) {
     int rb1 = co1->parent, rb2 = co2->parent;
     /* :191-201 contacts disabled between two bodies attached by a joint: clear_filtered_pair */
     if (rb1 >= 0 && rb2 >= 0 && joints_disable_contacts(w, rb1, rb2)) {
-        p->m.npoints = 0; p->nsc = 0; p->has_recycle = 0; /* ContactPair::clear */
+        p->m.npoints = 0; p->nsc = 0; p->has_recycle = 0; pair_clear_clusters(p); /* ContactPair::clear */
         p->hint_seq = w->step_seq;
         if (had) { tr_out->pair = pair_idx; tr_out->body1 = rb1; tr_out->body2 = rb2; tr_out->touching = 0; }
         return 1;
@@ -1680,7 +1683,9 @@ static v3 spose_itp(const SolverPose *p, v3 x) { return qrot_inv(p->rotation, vs
 
 /* ContactWithTwistFrictionBuilder::generate — contact_with_twist_friction.rs:58-424 (one lane) */
 static void constraint_generate(ro_world *w, int pair_idx, Constraint *c) {
-    const Pair *p = &w->pairs[pair_idx];
+    const int sm_k = RO_SM_K(pair_idx); /* solver-manifold reference: pair | k << 28 */
+    Pair *p = &w->pairs[RO_SM_PAIR(pair_idx)];
+    const v3 sm_normal_v = *sm_normal(p, sm_k); const int sm_nsc_v = *sm_nsc(p, sm_k); const SolverContact *sm_sc_v = sm_sc(p, sm_k); const Manifold *sm_m_v = sm_m(p, sm_k);
     memset(c, 0, sizeof(*c));
     uint32_t ids1 = p->relative_dominance <= 0 ? p->solver_body_ids[0] : RO_NO_BODY;
     uint32_t ids2 = p->relative_dominance >= 0 ? p->solver_body_ids[1] : RO_NO_BODY;
@@ -1688,8 +1693,8 @@ static void constraint_generate(ro_world *w, int pair_idx, Constraint *c) {
     gather_vel(w, ids1, &vels1); gather_vel(w, ids2, &vels2);
     gather_pose(w, ids1, &poses1); gather_pose(w, ids2, &poses2);
     v3 world_com1 = poses1.translation, world_com2 = poses2.translation;
-    v3 force_dir1 = vneg(p->normal);
-    int count = p->nsc < 4 ? p->nsc : 4;
+    v3 force_dir1 = vneg(sm_normal_v);
+    int count = sm_nsc_v < 4 ? sm_nsc_v : 4;
     v3 tangents1[2];
     tangents1[0] = orthonormal_vector(force_dir1);           /* contact_constraint/mod.rs:27-46 */
     tangents1[1] = vcross(force_dir1, tangents1[0]);
@@ -1707,8 +1712,8 @@ static void constraint_generate(ro_world *w, int pair_idx, Constraint *c) {
     v3 points[4];
     for (int k = 0; k < count; ++k) {
         float weight = inv_num_points;
-        const SolverContact *sc = &p->sc[k];
-        const ContactData *pd = &p->m.points[sc->cid].data;
+        const SolverContact *sc = &sm_sc_v[k];
+        const ContactData *pd = &sm_m_v->points[sc->cid].data;
         float warmstart_impulse = pd->warmstart_impulse;
         v3 wt = pd->warmstart_tangent_world;
         float wti[2] = {vdot(wt, tangents1[0]), vdot(wt, tangents1[1])};
@@ -1954,13 +1959,14 @@ static void constraint_apply_restitution(ro_world *w, Constraint *c) {
 
 /* writeback_impulses — contact_with_twist_friction.rs:783-829 */
 static void constraint_writeback(ro_world *w, const Constraint *c) {
-    Pair *p = &w->pairs[c->pair];
+    Pair *p = &w->pairs[RO_SM_PAIR(c->pair)];
+    Manifold *sm_m_v = sm_m(p, RO_SM_K(c->pair));
     v3 tangent2 = vcross(c->dir1, c->tangent1);
     /* the stored impulses go through utils::canonicalize_zero (x + 0.0: -0.0 becomes +0.0; utils/mod.rs:80-102, enabled by the
      * reference's enhanced-determinism feature, a bit-level no-op for every other value) */
     v3 wtw = vcanon(vadd(vmul(c->tangent1, canon0(c->tangent_part.impulse[0])), vmul(tangent2, canon0(c->tangent_part.impulse[1]))));
     for (int k = 0; k < c->num_contacts; ++k) {
-        ContactData *pd = &p->m.points[c->contact_id[k]].data;
+        ContactData *pd = &sm_m_v->points[c->contact_id[k]].data;
         pd->warmstart_impulse = canon0(c->normal_part[k].impulse);
         pd->impulse = canon0(c->normal_part[k].impulse_accumulator + c->normal_part[k].impulse);
         pd->warmstart_tangent_world = wtw;
@@ -1973,7 +1979,9 @@ static void constraint_writeback(ro_world *w, const Constraint *c) {
  * One Coulomb friction constraint per contact point (exact coupled 2x2 solve, limit mu * lambda_k) instead of the
  * friction-centre tangent + twist pair.  The normal parts are the twist model's. */
 static void coulomb_generate(ro_world *w, int pair_idx, Constraint *c) {
-    const Pair *p = &w->pairs[pair_idx];
+    const int sm_k = RO_SM_K(pair_idx); /* solver-manifold reference: pair | k << 28 */
+    Pair *p = &w->pairs[RO_SM_PAIR(pair_idx)];
+    const v3 sm_normal_v = *sm_normal(p, sm_k); const int sm_nsc_v = *sm_nsc(p, sm_k); const SolverContact *sm_sc_v = sm_sc(p, sm_k); const Manifold *sm_m_v = sm_m(p, sm_k);
     memset(c, 0, sizeof(*c));
     uint32_t ids1 = p->relative_dominance <= 0 ? p->solver_body_ids[0] : RO_NO_BODY;
     uint32_t ids2 = p->relative_dominance >= 0 ? p->solver_body_ids[1] : RO_NO_BODY;
@@ -1981,8 +1989,8 @@ static void coulomb_generate(ro_world *w, int pair_idx, Constraint *c) {
     gather_vel(w, ids1, &vels1); gather_vel(w, ids2, &vels2);
     gather_pose(w, ids1, &poses1); gather_pose(w, ids2, &poses2);
     v3 world_com1 = poses1.translation, world_com2 = poses2.translation;
-    v3 force_dir1 = vneg(p->normal);
-    int count = p->nsc < 4 ? p->nsc : 4;
+    v3 force_dir1 = vneg(sm_normal_v);
+    int count = sm_nsc_v < 4 ? sm_nsc_v : 4;
     v3 tangents1[2];
     tangents1[0] = orthonormal_vector(force_dir1);           /* compute_tangent_contact_directions, mod.rs:27-46 */
     tangents1[1] = vcross(force_dir1, tangents1[0]);
@@ -1994,8 +2002,8 @@ static void coulomb_generate(ro_world *w, int pair_idx, Constraint *c) {
     c->limit = p->friction;
     v3 imsum = vadd(poses1.im, poses2.im);
     for (int k = 0; k < count; ++k) {
-        const SolverContact *sc = &p->sc[k];
-        const ContactData *pd = &p->m.points[sc->cid].data;
+        const SolverContact *sc = &sm_sc_v[k];
+        const ContactData *pd = &sm_m_v->points[sc->cid].data;
         float warmstart_impulse = pd->warmstart_impulse;
         v3 wt = pd->warmstart_tangent_world;
         float wti[2] = {vdot(wt, tangents1[0]), vdot(wt, tangents1[1])};
@@ -2155,10 +2163,11 @@ static void coulomb_solve(ro_world *w, Constraint *c, int solve_friction) {
 }
 /* writeback_impulses :692-760: per-point world-space friction impulse; the twist warm start is left untouched */
 static void coulomb_writeback(ro_world *w, const Constraint *c) {
-    Pair *p = &w->pairs[c->pair];
+    Pair *p = &w->pairs[RO_SM_PAIR(c->pair)];
+    Manifold *sm_m_v = sm_m(p, RO_SM_K(c->pair));
     v3 tangent2 = vcross(c->dir1, c->tangent1);
     for (int k = 0; k < c->num_contacts; ++k) {
-        ContactData *pd = &p->m.points[c->contact_id[k]].data;
+        ContactData *pd = &sm_m_v->points[c->contact_id[k]].data;
         pd->warmstart_impulse = canon0(c->normal_part[k].impulse);
         pd->impulse = canon0(c->normal_part[k].impulse_accumulator + c->normal_part[k].impulse);
         pd->warmstart_tangent_world = vcanon(vadd(vmul(c->tangent1, canon0(c->ctangent[k].impulse[0])), vmul(tangent2, canon0(c->ctangent[k].impulse[1]))));
@@ -2630,6 +2639,8 @@ static void solve_velocity_constraints(ro_world *w) {
         Pair *p = &w->pairs[i];
         if (!pair_selected(w, p)) continue;
         counts[p->color]++; M++; nsc += p->nsc;
+        /* the pair's further solver manifolds (clusters 2+ with solver contacts) go to the overflow colour (solver_graph.rs:534-547) */
+        for (int k = 1; k < p->ncl; ++k) if (p->ex[k - 1].nsc > 0) { counts[RO_COLOR_OVERFLOW]++; M++; nsc += p->ex[k - 1].nsc; }
     }
     solver_reserve(w, nd, M);
     nd = 0;
@@ -2650,6 +2661,7 @@ static void solve_velocity_constraints(ro_world *w) {
         p->solver_body_ids[0] = b1 >= 0 ? w->bodies[b1].solver_id : RO_NO_BODY;
         p->solver_body_ids[1] = b2 >= 0 ? w->bodies[b2].solver_id : RO_NO_BODY;
         order[cursor[p->color]++] = i;
+        for (int k = 1; k < p->ncl; ++k) if (p->ex[k - 1].nsc > 0) order[cursor[RO_COLOR_OVERFLOW]++] = i | (k << RO_SM_SHIFT);
     }
     /* The overflow colour is swept serially and is not body-disjoint, so its order is part of the result.  The reference orders it
      * by its body-mask regrouping of contact-graph edge ids (interaction_groups.rs:240-355), which depend on the BVH's pair creation
@@ -2657,14 +2669,14 @@ static void solve_velocity_constraints(ro_world *w) {
      * can change (deliberate deviations). */
     if (counts[RO_COLOR_OVERFLOW] > 1) {
         int ob = w->bucket_begin[RO_COLOR_OVERFLOW], on = counts[RO_COLOR_OVERFLOW];
-        for (int a = 1; a < on; ++a) { /* insertion sort: the bucket is nearly sorted (pairs are created in sweep order) */
-            int v = order[ob + a]; const Pair *pv = &w->pairs[v];
-            uint64_t kv = ((uint64_t)(uint32_t)pv->c1 << 32) | (uint32_t)pv->c2;
+        for (int a = 1; a < on; ++a) { /* insertion sort: the bucket is nearly sorted (pairs are created in sweep order); key (collider1, collider2, cluster) */
+            int v = order[ob + a]; const Pair *pv = &w->pairs[RO_SM_PAIR(v)];
+            uint64_t kv = ((uint64_t)(uint32_t)pv->c1 << 32) | (uint32_t)pv->c2; int cv = RO_SM_K(v);
             int b = a - 1;
             while (b >= 0) {
-                const Pair *pb = &w->pairs[order[ob + b]];
-                uint64_t kb = ((uint64_t)(uint32_t)pb->c1 << 32) | (uint32_t)pb->c2;
-                if (kb <= kv) break;
+                const Pair *pb = &w->pairs[RO_SM_PAIR(order[ob + b])];
+                uint64_t kb = ((uint64_t)(uint32_t)pb->c1 << 32) | (uint32_t)pb->c2; int cb = RO_SM_K(order[ob + b]);
+                if (kb < kv || (kb == kv && cb <= cv)) break;
                 order[ob + b + 1] = order[ob + b]; --b;
             }
             order[ob + b + 1] = v;
@@ -2690,7 +2702,7 @@ static void solve_velocity_constraints(ro_world *w) {
     for (int i = 0; i < w->nbodies; ++i) w->bodies[i].last_group_extra = -1;
     for (int i = 0; i < nd; ++i) w->bodies[w->dyn_bodies[i]].last_group_extra = g_extra[grp_body[i]];
     for (int i = 0; i < M; ++i) {
-        const Pair *p = &w->pairs[order[i]];
+        const Pair *p = &w->pairs[RO_SM_PAIR(order[i])];
         int g = 0;
         for (int k = 0; k < 2; ++k) if (p->solver_body_ids[k] != RO_NO_BODY && grp_body[p->solver_body_ids[k]] > g) g = grp_body[p->solver_body_ids[k]];
         grp_cons[i] = g;
@@ -2926,11 +2938,12 @@ static void ccd_sweep_tier(ro_world *w, int bullets) {
         for (int f = 0; f < w->ncolliders; ++f) {
             const Collider *co1 = &w->colliders[f];
             if (co1->parent != bi || !collider_enabled(co1) || co1->sensor) continue;
+            if (co_is_composite(co1)) continue; /* (composite colliders take no part in the continuous-collision pass of this restatement: DESIGN.md section 8) */
             CcdShape s2 = ccd_shape_of(co1);
             const float rot_radius = ccd_rot_radius(&s2, co1->pos_wrt_parent, rb1->local_com);
             for (int t = 0; t < w->ncolliders; ++t) {
                 const Collider *co2 = &w->colliders[t];
-                if (t == f || co2->parent == bi || !collider_enabled(co2) || co2->sensor) continue;
+                if (t == f || co2->parent == bi || !collider_enabled(co2) || co2->sensor || co_is_composite(co2)) continue;
                 const Body *rb2 = co2->parent >= 0 ? &w->bodies[co2->parent] : NULL;
                 /* tier_allows (sweeps.rs:35-41): a non-bullet only meets fixed targets, a bullet everything but bullets */
                 if (bullets) { if (rb2 && ccd_is_bullet(rb2)) continue; } else if (rb2 && rb2->body_type != RO_BODY_FIXED) continue;
@@ -3246,8 +3259,8 @@ static void emit_contact_force_events(ro_world *w) {
         float ta = (a->active_events & 2u) ? a->force_threshold : FLT_MAX, tb = (b->active_events & 2u) ? b->force_threshold : FLT_MAX;
         float threshold = ta < tb ? ta : tb;
         if (!(threshold < FLT_MAX) || !pair_selected(w, p)) continue; /* force_event_pairs: solver-active pairs with force events enabled */
-        float total = 0.0f;
-        for (int k = 0; k < p->m.npoints; ++k) total += p->m.points[k].data.impulse;
+        float total = 0.0f; /* over every solver manifold of the pair (ContactPair::solver_manifolds: the plain manifold or its clusters) */
+        for (int q = 0; q < pair_num_sm(p); ++q) { const Manifold *mq = sm_m(p, q); for (int k = 0; k < mq->npoints; ++k) total += mq->points[k].data.impulse; }
         float total_magnitude = (0.0f + total) * inv_dt;
         if (total_magnitude > threshold) {
             if (w->nforce_events == w->cap_force_events) {
@@ -3257,13 +3270,18 @@ static void emit_contact_force_events(ro_world *w) {
             }
             int32_t *m = w->force_meta + 4 * w->nforce_events; float *v = w->force_vals + 8 * w->nforce_events; w->nforce_events++;
             m[0] = p->c1; m[1] = p->c2; m[2] = w->step_seq; m[3] = !p->force_emitted;
-            float max_mag = 0.0f; v3 max_dir = V3(0, 0, 0); float tmi = 0.0f;
-            for (int k = 0; k < p->m.npoints; ++k) {
-                float imp = p->m.points[k].data.impulse;
-                tmi += imp;
-                if (imp > max_mag) { max_mag = imp; max_dir = p->normal; }
+            float max_mag = 0.0f; v3 max_dir = V3(0, 0, 0); v3 total_force = V3(0, 0, 0);
+            for (int q = 0; q < pair_num_sm(p); ++q) {
+                const Manifold *mq = sm_m(p, q); const v3 nq = *sm_normal(p, q);
+                float tmi = 0.0f;
+                for (int k = 0; k < mq->npoints; ++k) {
+                    float imp = mq->points[k].data.impulse;
+                    tmi += imp;
+                    if (imp > max_mag) { max_mag = imp; max_dir = nq; }
+                }
+                total_force = vadd(total_force, vmul(nq, tmi));
             }
-            v3 total_force = vmul(vadd(V3(0, 0, 0), vmul(p->normal, tmi)), inv_dt);
+            total_force = vmul(total_force, inv_dt);
             v[0] = total_force.x; v[1] = total_force.y; v[2] = total_force.z; v[3] = total_magnitude;
             v[4] = max_dir.x; v[5] = max_dir.y; v[6] = max_dir.z; v[7] = max_mag * inv_dt;
             p->force_emitted = 1;
@@ -3348,7 +3366,7 @@ float ro_total_contact_impulse(const ro_world *w) {
     for (int i = 0; i < w->npairs; ++i) {
         const Pair *p = &w->pairs[i];
         float s = 0.0f;
-        for (int k = 0; k < p->m.npoints; ++k) s += p->m.points[k].data.impulse;
+        for (int q = 0; q < pair_num_sm((Pair *)p); ++q) { const Manifold *mq = sm_m((Pair *)p, q); for (int k = 0; k < mq->npoints; ++k) s += mq->points[k].data.impulse; }
         total += s;
     }
     return total;
@@ -3356,14 +3374,19 @@ float ro_total_contact_impulse(const ro_world *w) {
 int32_t ro_dump_manifolds(const ro_world *w, int32_t cap, int32_t *meta, float *normal3, float *impulses4) {
     int n = 0;
     for (int i = 0; i < w->npairs; ++i) {
-        const Pair *p = &w->pairs[i];
+        Pair *p = (Pair *)&w->pairs[i];
         if (p->nsc == 0) continue;
-        if (n < cap) {
-            if (meta) { meta[4 * n] = p->c1; meta[4 * n + 1] = p->c2; meta[4 * n + 2] = p->color; meta[4 * n + 3] = p->nsc; }
-            if (normal3) { normal3[3 * n] = p->normal.x; normal3[3 * n + 1] = p->normal.y; normal3[3 * n + 2] = p->normal.z; }
-            if (impulses4) for (int k = 0; k < 4; ++k) impulses4[4 * n + k] = k < p->nsc ? p->m.points[p->sc[k].cid].data.impulse : 0.0f;
+        for (int q = 0; q < pair_num_sm(p); ++q) { /* every solver manifold of the pair: the first in the pair's colour, the others in the overflow colour */
+            const int nsc = *sm_nsc(p, q);
+            if (nsc == 0) continue;
+            if (n < cap) {
+                const Manifold *m = sm_m(p, q); const SolverContact *sc = sm_sc(p, q); const v3 nq = *sm_normal(p, q);
+                if (meta) { meta[4 * n] = p->c1; meta[4 * n + 1] = p->c2; meta[4 * n + 2] = q == 0 ? p->color : RO_COLOR_OVERFLOW; meta[4 * n + 3] = nsc; }
+                if (normal3) { normal3[3 * n] = nq.x; normal3[3 * n + 1] = nq.y; normal3[3 * n + 2] = nq.z; }
+                if (impulses4) for (int k = 0; k < 4; ++k) impulses4[4 * n + k] = k < nsc ? m->points[sc[k].cid].data.impulse : 0.0f;
+            }
+            n++;
         }
-        n++;
     }
     return n;
 }
@@ -3545,4 +3568,17 @@ void ro_read_convex_polyhedron(const ro_world *w, int32_t id, int32_t counts[4],
         o[11] = P->volume; o[12] = P->com.x; o[13] = P->com.y; o[14] = P->com.z;
         o[15] = P->inertia[0][0]; o[16] = P->inertia[1][1]; o[17] = P->inertia[2][2]; o[18] = P->inertia[0][1]; o[19] = P->inertia[0][2];
     }
+}
+
+static void comp_free_fwd(struct RoComposite *C) { comp_free(C); }
+/* solver manifolds of pair (c1, c2): returns the number of clusters (0 = the pair takes the plain path), -1 = no such pair;
+ * nsc_out[k] = solver contacts of solver manifold k (k = 0 is also filled on the plain path) */
+int32_t ro_pair_clusters(const ro_world *w, int32_t c1, int32_t c2, int32_t cap, int32_t *nsc_out) {
+    const int64_t key = ((int64_t)(c1 < c2 ? c1 : c2) << 32) | (uint32_t)(c1 < c2 ? c2 : c1);
+    const int pi = map_find(w, key);
+    if (pi < 0) return -1;
+    Pair *p = (Pair *)&w->pairs[pi];
+    const int n = p->ncl > 0 ? p->ncl : 1;
+    for (int k = 0; k < n && k < cap; ++k) nsc_out[k] = *sm_nsc(p, k);
+    return p->ncl;
 }

@@ -20,6 +20,10 @@ SHAPE_HALFSPACE = 3  # half_extents = the unit outward normal in the collider fr
 # ColliderBuilder::round_cuboid / round_cylinder / round_cone / round_convex_hull: the inner shape's half_extents + collider_desc(border_radius=...)
 SHAPE_ROUND_CUBOID, SHAPE_ROUND_CYLINDER, SHAPE_ROUND_CONE, SHAPE_ROUND_CONVEX_POLYHEDRON = 7, 8, 9, 10
 SHAPE_CONVEX = SHAPE_CONVEX_POLYHEDRON = 6  # half_extents[0] = the id Scene.add_convex_polyhedron returned = ColliderBuilder::convex_mesh / convex_hull (collider.rs:1039, :1070)
+# Composite shapes as ONE collider: half_extents[0] = the id Scene.add_compound / add_trimesh / add_heightfield returned (ColliderBuilder::compound,
+# ::trimesh, ::heightfield — collider.rs:711, :944, :1089); a triangle mesh / height field needs a fixed or kinematic parent (or none)
+SHAPE_COMPOUND, SHAPE_TRIMESH = 11, 12
+SHAPE_TRIANGLE = 13  # internal to the shape dispatchers (one triangle of a mesh); never a collider's shape
 SHAPE_CYLINDER, SHAPE_CONE = 4, 5  # half_extents = (half_height, radius, -) = ColliderBuilder::cylinder / cone (axis Y, a cone's apex at +Y)
 RULE_AVERAGE, RULE_MIN, RULE_MULTIPLY, RULE_MAX, RULE_CLAMPED_SUM, RULE_GEOMETRIC_MEAN = range(6)
 
@@ -160,6 +164,24 @@ class Scene:
     collider_parents: list = field(default_factory=list)
     joints: list = field(default_factory=list)
     polyhedra: list = field(default_factory=list)   # (points (n, 3) f32, triangles (m, 3) u32 or None = "take the convex hull")
+    composites: list = field(default_factory=list)  # ("compound", parts: COLLIDER_DTYPE array) | ("trimesh", vertices (n, 3) f32, triangles (m, 3) u32) | ("heightfield", heights (r, c) f32, scale (3,))
+
+    def add_compound(self, parts) -> int:
+        """SharedShape::compound(parts): `parts` = collider descriptors (collider_desc(...)) of which shape, half_extents, translation,
+        rotation and border_radius are read.  Colliders use the returned id: add_collider(b, shape=SHAPE_COMPOUND, half_extents=(id, 0, 0))"""
+        self.composites.append(("compound", np.array(list(parts), dtype=COLLIDER_DTYPE)))
+        return len(self.composites) - 1
+
+    def add_trimesh(self, vertices, triangles) -> int:
+        """SharedShape::trimesh(vertices, indices): add_collider(b, shape=SHAPE_TRIMESH, half_extents=(id, 0, 0))"""
+        self.composites.append(("trimesh", np.ascontiguousarray(vertices, np.float32).reshape(-1, 3), np.ascontiguousarray(triangles, np.uint32).reshape(-1, 3)))
+        return len(self.composites) - 1
+
+    def add_heightfield(self, heights, scale) -> int:
+        """SharedShape::heightfield(heights, scale): heights[r, c] (r along z, c along x) over the unit square scaled by `scale`; used
+        like a triangle mesh: add_collider(b, shape=SHAPE_TRIMESH, half_extents=(id, 0, 0))"""
+        self.composites.append(("heightfield", np.ascontiguousarray(heights, np.float32), np.asarray(scale, np.float32).reshape(3)))
+        return len(self.composites) - 1
 
     def add_convex_polyhedron(self, points, triangles=None) -> int:
         """SharedShape::convex_mesh(points, indices) — or convex_hull(points) when `triangles` is None; colliders use the returned id:

@@ -121,6 +121,9 @@ class OracleWorld:
         for pts, tris in getattr(scene, "polyhedra", []):
             if self.add_convex_polyhedron(pts, tris) < 0:
                 raise ValueError("oracle: not a closed convex triangle mesh")
+        for comp in getattr(scene, "composites", []):
+            if self.add_composite(comp) < 0:
+                raise ValueError("oracle: invalid composite shape")
         cols = scene.collider_array()
         parents = scene.parent_array()
         for i in range(len(cols)):
@@ -132,6 +135,27 @@ class OracleWorld:
             if L.ro_add_joint(self._w, joints[i:i + 1].ctypes.data) < 0:
                 raise ValueError("oracle: unsupported joint")
         self.n = len(bodies)
+
+    def add_composite(self, comp) -> int:
+        """ro_add_compound / ro_add_trimesh / ro_add_heightfield from a Scene.composites entry"""
+        L = lib()
+        for f in (L.ro_add_compound, L.ro_add_trimesh, L.ro_add_heightfield):
+            f.restype = C.c_int32
+        if comp[0] == "compound":
+            parts = np.ascontiguousarray(comp[1], S.COLLIDER_DTYPE)
+            return int(L.ro_add_compound(C.c_void_p(self._w), C.c_int32(len(parts)), C.c_void_p(parts.ctypes.data)))
+        if comp[0] == "trimesh":
+            v, t = np.ascontiguousarray(comp[1], np.float32), np.ascontiguousarray(comp[2], np.uint32)
+            return int(L.ro_add_trimesh(C.c_void_p(self._w), C.c_int32(len(v)), C.c_void_p(v.ctypes.data), C.c_int32(len(t)), C.c_void_p(t.ctypes.data)))
+        h, sc = np.ascontiguousarray(comp[1], np.float32), np.ascontiguousarray(comp[2], np.float32)
+        return int(L.ro_add_heightfield(C.c_void_p(self._w), C.c_int32(h.shape[0]), C.c_int32(h.shape[1]), C.c_void_p(h.ctypes.data), C.c_void_p(sc.ctypes.data)))
+
+    def pair_clusters(self, c1: int, c2: int):
+        """(number of clusters: 0 = plain path, -1 = no such pair; solver contacts per solver manifold)"""
+        L = lib(); L.ro_pair_clusters.restype = C.c_int32
+        out = np.zeros(4, np.int32)
+        n = int(L.ro_pair_clusters(C.c_void_p(self._w), C.c_int32(c1), C.c_int32(c2), C.c_int32(4), C.c_void_p(out.ctypes.data)))
+        return n, out[:max(n, 1)].tolist()
 
     def add_convex_polyhedron(self, points, triangles=None) -> int:
         """ro_add_convex_polyhedron; without triangles the hull comes from scipy (Qhull), wound outwards — the oracle has no hull code"""
