@@ -76,7 +76,14 @@ enum { RP_SHAPE_BALL = 0, RP_SHAPE_CUBOID = 1,
        /* ColliderBuilder::round_cuboid / round_cylinder / round_cone / round_convex_hull / round_convex_mesh (collider.rs:700-1090): the
         * shape above dilated by a sphere of radius rp_collider_desc.border_radius (parry RoundShape<S>); half_extents as for the inner
         * shape; mass properties are the inner shape's (RoundShape::mass_properties) */
-       RP_SHAPE_ROUND_CUBOID = 7, RP_SHAPE_ROUND_CYLINDER = 8, RP_SHAPE_ROUND_CONE = 9, RP_SHAPE_ROUND_CONVEX_POLYHEDRON = 10 };
+       RP_SHAPE_ROUND_CUBOID = 7, RP_SHAPE_ROUND_CYLINDER = 8, RP_SHAPE_ROUND_CONE = 9, RP_SHAPE_ROUND_CONVEX_POLYHEDRON = 10,
+       /* Composite shapes as ONE collider — ColliderBuilder::compound (collider.rs:711), ::trimesh (:944), ::heightfield (:1089):
+        * half_extents[0] = the id rp_compound_create / rp_trimesh_create / rp_heightfield_create returned.  A pair with such a collider
+        * holds one manifold per sub-shape pair in reach; several manifolds are merged into solver clusters by normal
+        * (contact_clustering.rs:33), whose warm-start data is carried by position (:129).  A triangle mesh / height field needs a fixed
+        * or kinematic parent (or none) and weighs nothing; a compound's mass properties are the sum of its parts'. */
+       RP_SHAPE_COMPOUND = 11, RP_SHAPE_TRIMESH = 12,
+       RP_SHAPE_TRIANGLE = 13 /* internal to the shape dispatchers: one triangle of a mesh; never a collider's shape */ };
 enum { RP_RULE_AVERAGE = 0, RP_RULE_MIN, RP_RULE_MULTIPLY, RP_RULE_MAX, RP_RULE_CLAMPED_SUM, RP_RULE_GEOMETRIC_MEAN };
 
 /* RigidBodyBuilder — /root/reference/src/dynamics/rigid_body.rs:1560-1900 */
@@ -225,6 +232,17 @@ int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider_desc *desc
  * normals become one polygonal face.  RP_ERR_INVALID where the reference's builders return None (no volume, not closed) and for more
  * than 256 hull vertices.  The polyhedron's centre of mass and inertia tensor follow MassProperties::from_convex_polyhedron. */
 int32_t rp_convex_polyhedron_create(rp_world *w, int32_t n_points, const float *points_xyz, int32_t n_triangles, const uint32_t *indices, int32_t *id_out);
+/* SharedShape::compound(parts) (ColliderBuilder::compound, collider.rs:711): registers a compound shape; of every part descriptor only
+ * shape (a primitive or round primitive: no half-space, no composite), half_extents, translation, rotation and border_radius are
+ * read.  Colliders refer to it with shape = RP_SHAPE_COMPOUND, half_extents[0] = id. */
+int32_t rp_compound_create(rp_world *w, int32_t n_parts, const rp_collider_desc *parts, int32_t *id_out);
+/* SharedShape::trimesh(vertices, indices) (ColliderBuilder::trimesh, collider.rs:944; no TriMeshFlags): n_triangles x 3 vertex indices.
+ * Colliders: shape = RP_SHAPE_TRIMESH, half_extents[0] = id, on a fixed or kinematic body (or none). */
+int32_t rp_trimesh_create(rp_world *w, int32_t n_vertices, const float *vertices_xyz, int32_t n_triangles, const uint32_t *indices, int32_t *id_out);
+/* SharedShape::heightfield(heights, scale) (ColliderBuilder::heightfield, collider.rs:1089): heights[r * ncols + c] over the unit square
+ * (r along z, c along x) scaled by `scale`; every cell is cut into two triangles along its (r, c) -> (r + 1, c + 1) diagonal and the
+ * field is served by the triangle-mesh path: colliders use shape = RP_SHAPE_TRIMESH with the id returned here. */
+int32_t rp_heightfield_create(rp_world *w, int32_t nrows, int32_t ncols, const float *heights, const float scale[3], int32_t *id_out);
 /* ConvexPolyhedron::points / faces / ... of a registered polyhedron as the library holds it (canonical form: DESIGN.md §4.4).
  * counts = {vertices, faces, vertex-loop entries, edges}; then, each optional (NULL = skip): the vertices recentred on the centre of
  * their bounding box, the unit face normals, per face the first entry and the length of its counter-clockwise vertex loop, the

@@ -126,8 +126,8 @@ typedef struct {
     struct ExtraCluster *ex; /* [RO_MAX_CLUSTERS - 1], allocated on first use */
 } Pair;
 #define RO_MAX_CLUSTERS 4      /* solver manifolds per pair (the reference: unbounded; a 5th normal direction joins the closest cluster) */
-#define RO_CLUSTER_PTS 64      /* points of one cluster while it is built (the reference: 255) */
-#define RO_MAX_SUBPAIRS 96     /* candidate sub-shape pairs of one collider pair per step (in index order; the rest is ignored and counted) */
+#define RO_CLUSTER_PTS 32      /* points of one cluster while it is built (the reference: 255) */
+#define RO_MAX_SUBPAIRS 64     /* candidate sub-shape pairs of one collider pair per step (in index order; the rest is ignored and counted) */
 typedef struct ExtraCluster { Manifold m; v3 normal; SolverContact sc[4]; int nsc; } ExtraCluster;
 /* solver manifold k of a pair */
 static inline Manifold *sm_m(Pair *p, int k) { return k == 0 ? &p->m : &p->ex[k - 1].m; }
@@ -486,7 +486,7 @@ static void shape_mass_props(const Collider *c, float density, float *mass, v3 *
 static float shape_bounding_radius_core(const Collider *c);
 static float shape_bounding_radius(const Collider *c) { float r = shape_bounding_radius_core(c); return c->border > 0.0f ? r + c->border : r; } /* RoundShape: the inner sphere + the border */
 static float shape_bounding_radius_core(const Collider *c) {
-    if (c->shape == RO_SHAPE_CUBOID) return vlen(c->he);
+    if (c->shape == RO_SHAPE_CUBOID || c->shape == RO_SHAPE_COMPOUND || c->shape == RO_SHAPE_TRIMESH) return vlen(c->he); /* (a composite: the sphere about its local box) */
     if (c->shape == RO_SHAPE_CAPSULE) return c->he.x + c->radius;
     if (c->shape == RO_SHAPE_HALFSPACE) return FLT_MAX;
     if (c->shape == RO_SHAPE_CYLINDER || c->shape == RO_SHAPE_CONE) return sqrtf(c->radius * c->radius + c->he.y * c->he.y);
@@ -3581,4 +3581,22 @@ int32_t ro_pair_clusters(const ro_world *w, int32_t c1, int32_t c2, int32_t cap,
     const int n = p->ncl > 0 ? p->ncl : 1;
     for (int k = 0; k < n && k < cap; ++k) nsc_out[k] = *sm_nsc(p, k);
     return p->ncl;
+}
+
+/* debug aid (tools/composite_diag.py): the same record as the device's rp_debug_pair_points */
+int32_t ro_debug_pair_points(const ro_world *w, int32_t c1, int32_t c2, int32_t cap, float *out) {
+    const int64_t key = ((int64_t)c1 << 32) | (uint32_t)c2;
+    const int pi = map_find(w, key);
+    if (pi < 0) return 0;
+    Pair *p = (Pair *)&w->pairs[pi];
+    int n = 0;
+#define RO_PUT(v) do { if (n < cap) out[n] = (float)(v); ++n; } while (0)
+    RO_PUT(p->ncl); RO_PUT(p->plain_sub[0]); RO_PUT(p->plain_sub[1]);
+    for (int k = 0; k < pair_num_sm(p); ++k) {
+        const Manifold *m = sm_m(p, k);
+        RO_PUT(k); RO_PUT(m->npoints); RO_PUT(*sm_nsc(p, k));
+        for (int i = 0; i < m->npoints; ++i) { RO_PUT(m->points[i].local_p1.x); RO_PUT(m->points[i].local_p1.y); RO_PUT(m->points[i].local_p1.z); RO_PUT(m->points[i].dist); RO_PUT(m->points[i].data.impulse); RO_PUT(m->points[i].data.warmstart_impulse); }
+    }
+#undef RO_PUT
+    return n;
 }

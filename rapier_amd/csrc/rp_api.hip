@@ -136,6 +136,17 @@ struct rp_world {
     std::vector<char> collider_removed, joint_removed;
     // convex polyhedra (rp_polyhedron.h): registered shapes, the polyhedron of every collider row (-1: another shape), their device tables
     std::vector<HostPolyhedron> polys; std::vector<int> collider_poly; bool polys_uploaded = false;
+    // composite shapes (rp_compound_create / rp_trimesh_create / rp_heightfield_create; device twin: rp_composite.h)
+    struct HostComposite {
+        int kind = 0;                                   // RP_SHAPE_COMPOUND | RP_SHAPE_TRIMESH
+        std::vector<rp_collider_desc> parts; std::vector<int> part_poly; // compound: the part descriptors (translation recentred, quaternion normalised)
+        std::vector<float> tri;                         // mesh: 9 floats per triangle (vertices recentred)
+        std::vector<float> smin, smax;                  // 3 floats per sub-shape: its AABB in the composite frame
+        float centre[3] = {0, 0, 0}, half[3] = {0, 0, 0};
+        int count() const { return kind == RP_SHAPE_COMPOUND ? (int)parts.size() : (int)(tri.size() / 9); }
+    };
+    std::vector<HostComposite> comps; std::vector<int> collider_comp;
+    void *cm_dev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     void *cv_dev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<rp_joint_desc> joints;
     std::vector<int> active_joint_ids; // device joint index -> index into `joints`
@@ -448,6 +459,7 @@ extern "C" int32_t rp_world_destroy(rp_world *w) {
     if (w->stream) hipStreamSynchronize(w->stream);
     free_device(w);
     for (void *&b : w->cv_dev) if (b) { hipFree(b); b = nullptr; }
+    for (void *&b : w->cm_dev) if (b) { hipFree(b); b = nullptr; }
     for (auto &e : w->ev) if (e) hipEventDestroy(e);
     if (w->stream) hipStreamDestroy(w->stream);
     delete w;
@@ -479,8 +491,9 @@ extern "C" int32_t rp_num_bodies(const rp_world *w) { return w ? (int32_t)w->bod
 // parry Shape::mass_properties for cuboid / ball / capsule; frame = the shape's principal inertia local frame
 // (identity except for capsules along X / Z: MassProperties::from_capsule rotates Y onto the segment direction)
 // the inner shape of a round one (parry RoundShape<S>::inner_shape) and its border radius
-static int core_shape(int shape) { return shape >= RP_SHAPE_ROUND_CUBOID ? (shape == RP_SHAPE_ROUND_CUBOID ? RP_SHAPE_CUBOID : shape - RP_SHAPE_ROUND_CYLINDER + RP_SHAPE_CYLINDER) : shape; }
-static float shape_border(const rp_collider_desc &c) { return c.shape >= RP_SHAPE_ROUND_CUBOID ? c.border_radius : 0.0f; }
+static int core_shape(int shape) { return (shape >= RP_SHAPE_ROUND_CUBOID && shape <= RP_SHAPE_ROUND_CONVEX_POLYHEDRON) ? (shape == RP_SHAPE_ROUND_CUBOID ? RP_SHAPE_CUBOID : shape - RP_SHAPE_ROUND_CYLINDER + RP_SHAPE_CYLINDER) : shape; }
+static float shape_border(const rp_collider_desc &c) { return (c.shape >= RP_SHAPE_ROUND_CUBOID && c.shape <= RP_SHAPE_ROUND_CONVEX_POLYHEDRON) ? c.border_radius : 0.0f; }
+static bool shape_composite(int shape) { return shape == RP_SHAPE_COMPOUND || shape == RP_SHAPE_TRIMESH; }
 // glam Quat::mul_vec3 (scalar path), the form the device and the checker use
 static void h_qrot(const float q[4], const float v[3], float out[3]) {
     const float bx = q[0], by = q[1], bz = q[2], w = q[3];
@@ -497,19 +510,26 @@ static float shape_bounding_radius(const rp_world *w, int ci) { // RoundShape: t
 static float shape_bounding_radius_core(const rp_world *w, int ci) { // Shape::compute_local_bounding_sphere (about the collider origin)
     rp_collider_desc c = w->colliders[ci]; c.shape = core_shape(c.shape);
     if (c.shape == RP_SHAPE_CONVEX_POLYHEDRON) return w->polys[w->collider_poly[ci]].origin_radius; // (the CCD pre-filter and the grid's cell size; max_extent uses the point cloud's own sphere)
-    if (c.shape == RP_SHAPE_CUBOID) return std::sqrt(c.half_extents[0] * c.half_extents[0] + c.half_extents[1] * c.half_extents[1] + c.half_extents[2] * c.half_extents[2]);
+    if (c.shape == RP_SHAPE_CUBOID || shape_composite(c.shape)) // (a composite: the sphere about its local box)
+        return std::sqrt(c.half_extents[0] * c.half_extents[0] + c.half_extents[1] * c.half_extents[1] + c.half_extents[2] * c.half_extents[2]);
+    if (false) return std::sqrt(c.half_extents[0] * c.half_extents[0] + c.half_extents[1] * c.half_extents[1] + c.half_extents[2] * c.half_extents[2]);
     if (c.shape == RP_SHAPE_CAPSULE) return c.half_extents[0] + c.half_extents[1];
     if (c.shape == RP_SHAPE_HALFSPACE) return 3.402823466e+38f;
     if (c.shape == RP_SHAPE_CYLINDER || c.shape == RP_SHAPE_CONE) { volatile float rr = c.half_extents[1] * c.half_extents[1], hh2 = c.half_extents[0] * c.half_extents[0]; return std::sqrt(rr + hh2); }
     return c.half_extents[0];
 }
 static void hmp_diagonalise(float a[3][3], float pi[3], float frame[4]);
+static void shape_mass_props_desc(const rp_world *w, rp_collider_desc c, int poly_id, float density, float &mass, float pi[3], float frame[4], float com[3]);
 static void shape_mass_props(const rp_world *w, int ci, float density, float &mass, float pi[3], float frame[4], float com[3]) {
-    rp_collider_desc c = w->colliders[ci]; c.shape = core_shape(c.shape); // (RoundShape::mass_properties = the inner shape's)
+    shape_mass_props_desc(w, w->colliders[ci], w->collider_poly[ci], density, mass, pi, frame, com);
+}
+// (by descriptor: a collider, or a part of a compound shape)
+static void shape_mass_props_desc(const rp_world *w, rp_collider_desc c, int poly_id, float density, float &mass, float pi[3], float frame[4], float com[3]) {
+    c.shape = core_shape(c.shape); // (RoundShape::mass_properties = the inner shape's)
     frame[0] = 0.0f; frame[1] = 0.0f; frame[2] = 0.0f; frame[3] = 1.0f;
     com[0] = com[1] = com[2] = 0.0f;
     if (c.shape == RP_SHAPE_CONVEX_POLYHEDRON) { // MassProperties::from_convex_polyhedron -> with_inertia_matrix(com, volume * density, tensor * density)
-        const HostPolyhedron &P = w->polys[w->collider_poly[ci]];
+        const HostPolyhedron &P = w->polys[(size_t)poly_id];
         float a[3][3];
         for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) a[i][j] = P.inertia[i][j] * density;
         hmp_diagonalise(a, pi, frame);
@@ -688,6 +708,18 @@ static void sum_collider_mass_props(const rp_world *w, int body, float density_o
         if (w->collider_removed[i]) continue;
         const rp_collider_desc &c = w->colliders[i];
         hmp_mp m; memset(&m, 0, sizeof(m)); m.frame[3] = 1.0f;
+        if (shape_composite(c.shape)) { // MassProperties::from_compound: the sum of the parts' (a triangle mesh on a fixed body weighs nothing)
+            if (c.shape == RP_SHAPE_COMPOUND) {
+                const rp_world::HostComposite &C = w->comps[(size_t)w->collider_comp[i]];
+                for (size_t k = 0; k < C.parts.size(); ++k) {
+                    const rp_collider_desc &pd = C.parts[k];
+                    hmp_mp pm; memset(&pm, 0, sizeof(pm)); pm.frame[3] = 1.0f;
+                    shape_mass_props_desc(w, pd, C.part_poly[k], density_override < 0.0f ? c.density : density_override, pm.mass, pm.pi, pm.frame, pm.com);
+                    hmp_mp_transform(&pm, pd.translation, pd.rotation);
+                    if (k == 0) m = pm; else hmp_mp_add(&m, &pm);
+                }
+            }
+        } else
         shape_mass_props(w, i, density_override < 0.0f ? c.density : density_override, m.mass, m.pi, m.frame, m.com);
         float qn = std::sqrt(c.rotation[0] * c.rotation[0] + c.rotation[1] * c.rotation[1] + c.rotation[2] * c.rotation[2] + c.rotation[3] * c.rotation[3]);
         float qi = qn > 0.0f ? 1.0f / qn : 1.0f;
@@ -926,6 +958,7 @@ extern "C" int32_t rp_bodies_insert(rp_world *w, int32_t n, const rp_body_desc *
 // the cv_* tables of the device world (rp_world.h): every registered polyhedron, flattened.  Own allocations (not rows of a growth domain):
 // replaced as a whole when a polyhedron is registered, referenced by pointer from DevWorld (the step graphs are captured again)
 static float4 mk4(float x, float y, float z, float w_);
+#define RP_CM_WS_F4_HOST (4 * 32 * 4 + 64 / 2) // = RP_CM_WS_F4 of rp_composite.h (clusters x points x 4 planes + the candidate list)
 static int upload_polyhedra(rp_world *w) {
     std::vector<int4> hdr; std::vector<float4> pts, fn; std::vector<int2> fl, loop;
     for (const HostPolyhedron &P : w->polys) {
@@ -989,10 +1022,178 @@ extern "C" int32_t rp_convex_polyhedron_read(const rp_world *w, int32_t id, int3
     }
     return RP_OK;
 }
+// ---- composite shapes (include/rapier_hip.h: rp_compound_create / rp_trimesh_create / rp_heightfield_create) -------------------------
+// Shape::compute_aabb(pos) of a part, in the words of the device's prim_aabb_at (rp_composite.h) and the oracle's (ro_composite.h):
+// he in the c_he layout (cylinder / cone: radius, half height, radius; capsule: half height, radius, axis; polyhedron: its box)
+static void h_prim_aabb_at(int core, const float he[3], float border, Pose at, V3 &mn, V3 &mx) {
+    if (core == RP_SHAPE_CUBOID || core >= RP_SHAPE_CYLINDER) {
+        float m[3][3]; quat_to_mat(at.r, m);
+        V3 h = v3(fabsf(m[0][0]) * he[0] + fabsf(m[0][1]) * he[1] + fabsf(m[0][2]) * he[2],
+                  fabsf(m[1][0]) * he[0] + fabsf(m[1][1]) * he[1] + fabsf(m[1][2]) * he[2],
+                  fabsf(m[2][0]) * he[0] + fabsf(m[2][1]) * he[1] + fabsf(m[2][2]) * he[2]);
+        mn = at.t - h; mx = at.t + h;
+    } else if (core == RP_SHAPE_CAPSULE) {
+        const int axis = (int)he[2];
+        V3 e = v3(axis == 0 ? 1.0f : 0.0f, axis == 1 ? 1.0f : 0.0f, axis == 2 ? 1.0f : 0.0f);
+        V3 pa = pose_tp(at, e * -he[0]), pb = pose_tp(at, e * he[0]);
+        V3 r = v3(he[1], he[1], he[1]);
+        mn = v3(rp_min(pa.x, pb.x), rp_min(pa.y, pb.y), rp_min(pa.z, pb.z)) - r;
+        mx = v3(rp_max(pa.x, pb.x), rp_max(pa.y, pb.y), rp_max(pa.z, pb.z)) + r;
+    } else {
+        V3 h = v3(he[0], he[0], he[0]);
+        mn = at.t - h; mx = at.t + h;
+    }
+    if (border > 0.0f) { V3 b = v3(border, border, border); mn = mn - b; mx = mx + b; }
+}
+// the part's half extents in the c_he layout (pack_collider's rule)
+static void part_che(const rp_world *w, const rp_collider_desc &c, int poly, float he[3]) {
+    const int core = core_shape(c.shape);
+    he[0] = c.half_extents[0]; he[1] = c.half_extents[1]; he[2] = c.half_extents[2];
+    if (core == RP_SHAPE_CYLINDER || core == RP_SHAPE_CONE) { he[0] = c.half_extents[1]; he[1] = c.half_extents[0]; he[2] = c.half_extents[1]; }
+    if (core == RP_SHAPE_CONVEX_POLYHEDRON) { const HostPolyhedron &P = w->polys[(size_t)poly]; he[0] = P.half[0]; he[1] = P.half[1]; he[2] = P.half[2]; }
+}
+static Pose part_pose(const rp_collider_desc &c) {
+    Pose p; p.t = v3(c.translation[0], c.translation[1], c.translation[2]); p.r = q4(c.rotation[0], c.rotation[1], c.rotation[2], c.rotation[3]);
+    return p;
+}
+static int upload_composites(rp_world *w) {
+    std::vector<int4> hdr; std::vector<float4> mn, mx, a, b, c; std::vector<float> border;
+    for (const rp_world::HostComposite &C : w->comps) {
+        int4 h; h.x = C.kind; h.y = (int)mn.size(); h.z = C.count(); h.w = 0;
+        hdr.push_back(h);
+        for (int i = 0; i < C.count(); ++i) {
+            mn.push_back(mk4(C.smin[3 * i], C.smin[3 * i + 1], C.smin[3 * i + 2], 0.0f)); mx.push_back(mk4(C.smax[3 * i], C.smax[3 * i + 1], C.smax[3 * i + 2], 0.0f));
+            if (C.kind == RP_SHAPE_COMPOUND) {
+                const rp_collider_desc &d = C.parts[(size_t)i];
+                float he[3]; part_che(w, d, C.part_poly[(size_t)i], he);
+                float4 ra = mk4(he[0], he[1], he[2], 0.0f);
+                if (core_shape(d.shape) == RP_SHAPE_CONVEX_POLYHEDRON) { int id = C.part_poly[(size_t)i]; memcpy(&ra.w, &id, sizeof(int)); }
+                float4 rb = mk4(d.translation[0], d.translation[1], d.translation[2], 0.0f); int sh = d.shape; memcpy(&rb.w, &sh, sizeof(int));
+                a.push_back(ra); b.push_back(rb); c.push_back(mk4(d.rotation[0], d.rotation[1], d.rotation[2], d.rotation[3])); border.push_back(shape_border(d));
+            } else {
+                const float *t = &C.tri[9 * (size_t)i];
+                a.push_back(mk4(t[0], t[1], t[2], 0.0f)); b.push_back(mk4(t[3], t[4], t[5], 0.0f)); c.push_back(mk4(t[6], t[7], t[8], 0.0f)); border.push_back(0.0f);
+            }
+        }
+    }
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    for (int k = 0; k < 7; ++k) if (w->cm_dev[k]) { HIPCHK(w, hipFree(w->cm_dev[k])); w->cm_dev[k] = nullptr; }
+    const void *src[7] = {hdr.data(), mn.data(), mx.data(), a.data(), b.data(), c.data(), border.data()};
+    const size_t bytes[7] = {hdr.size() * sizeof(int4), mn.size() * sizeof(float4), mx.size() * sizeof(float4), a.size() * sizeof(float4), b.size() * sizeof(float4), c.size() * sizeof(float4), border.size() * sizeof(float)};
+    for (int k = 0; k < 7; ++k) {
+        if (bytes[k] == 0) continue;
+        HIPCHK(w, hipMalloc(&w->cm_dev[k], bytes[k]));
+        HIPCHK(w, hipMemcpyAsync(w->cm_dev[k], src[k], bytes[k], hipMemcpyHostToDevice, w->stream));
+    }
+    if (!w->cm_dev[7]) { // the cluster workspace of k_np_composite: RP_CM_WS_F4 float4 per thread
+        w->dw.cm_ws_threads = 32 * 128;
+        HIPCHK(w, hipMalloc(&w->cm_dev[7], (size_t)w->dw.cm_ws_threads * RP_CM_WS_F4_HOST * sizeof(float4)));
+    }
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    w->dw.cm_hdr = (int4 *)w->cm_dev[0]; w->dw.cm_min = (float4 *)w->cm_dev[1]; w->dw.cm_max = (float4 *)w->cm_dev[2];
+    w->dw.cm_a = (float4 *)w->cm_dev[3]; w->dw.cm_b = (float4 *)w->cm_dev[4]; w->dw.cm_c = (float4 *)w->cm_dev[5]; w->dw.cm_border = (float *)w->cm_dev[6];
+    w->dw.cm_ws = (float4 *)w->cm_dev[7]; w->dw.cm_ws_threads = 32 * 128;
+    return RP_OK;
+}
+static int composite_registered(rp_world *w, rp_world::HostComposite &&C, int32_t *id_out) {
+    w->comps.push_back(std::move(C));
+    *id_out = (int32_t)w->comps.size() - 1;
+    if (w->finalized) { // the tables are replaced: no launch may still read the old ones, the graphs hold the old pointers
+        HIPCHK(w, hipSetDevice(w->device));
+        int r = settle(w); if (r != RP_OK) return r;
+        r = upload_composites(w); if (r != RP_OK) return r;
+        destroy_graphs(w);
+    }
+    return RP_OK;
+}
+extern "C" int32_t rp_compound_create(rp_world *w, int32_t n_parts, const rp_collider_desc *parts, int32_t *id_out) {
+    if (!w || !parts || !id_out || n_parts < 1) { if (w) w->err = "rp_compound_create: at least one part"; return RP_ERR_INVALID; }
+    rp_world::HostComposite C; C.kind = RP_SHAPE_COMPOUND;
+    for (int i = 0; i < n_parts; ++i) {
+        rp_collider_desc d = parts[i];
+        if (d.shape < RP_SHAPE_BALL || d.shape > RP_SHAPE_ROUND_CONVEX_POLYHEDRON || d.shape == RP_SHAPE_HALFSPACE) { w->err = "rp_compound_create: a part is a primitive or round primitive (no half-space, no composite)"; return RP_ERR_INVALID; }
+        int poly = -1;
+        if (core_shape(d.shape) == RP_SHAPE_CONVEX_POLYHEDRON) {
+            if (!(d.half_extents[0] >= 0.0f && d.half_extents[0] < (float)w->polys.size() && d.half_extents[0] == std::floor(d.half_extents[0]))) { w->err = "rp_compound_create: a polyhedron part's half_extents[0] holds the id rp_convex_polyhedron_create returned"; return RP_ERR_INVALID; }
+            poly = (int)d.half_extents[0];
+        }
+        const float qn = std::sqrt(d.rotation[0] * d.rotation[0] + d.rotation[1] * d.rotation[1] + d.rotation[2] * d.rotation[2] + d.rotation[3] * d.rotation[3]);
+        const float qi = qn > 0.0f ? 1.0f / qn : 1.0f;
+        d.rotation[0] *= qi; d.rotation[1] *= qi; d.rotation[2] *= qi; d.rotation[3] = qn > 0.0f ? d.rotation[3] * qi : 1.0f;
+        if (poly >= 0) { // a polyhedron is stored recentred: the offset rides in the part's pose
+            float r[3]; h_qrot(d.rotation, w->polys[(size_t)poly].centre, r);
+            d.translation[0] = r[0] + d.translation[0]; d.translation[1] = r[1] + d.translation[1]; d.translation[2] = r[2] + d.translation[2];
+        }
+        C.parts.push_back(d); C.part_poly.push_back(poly);
+    }
+    V3 bmn = v3(0, 0, 0), bmx = bmn;
+    for (int i = 0; i < n_parts; ++i) {
+        float he[3]; part_che(w, C.parts[(size_t)i], C.part_poly[(size_t)i], he);
+        V3 mn, mx; h_prim_aabb_at(core_shape(C.parts[(size_t)i].shape), he, shape_border(C.parts[(size_t)i]), part_pose(C.parts[(size_t)i]), mn, mx);
+        if (i == 0) { bmn = mn; bmx = mx; }
+        else { bmn = v3(rp_min(bmn.x, mn.x), rp_min(bmn.y, mn.y), rp_min(bmn.z, mn.z)); bmx = v3(rp_max(bmx.x, mx.x), rp_max(bmx.y, mx.y), rp_max(bmx.z, mx.z)); }
+    }
+    const V3 centre = (bmn + bmx) * 0.5f, half = (bmx - bmn) * 0.5f;
+    C.centre[0] = centre.x; C.centre[1] = centre.y; C.centre[2] = centre.z; C.half[0] = half.x; C.half[1] = half.y; C.half[2] = half.z;
+    for (int i = 0; i < n_parts; ++i) { // recentred on the local AABB (the centre is folded into the collider's pose, like a polyhedron's)
+        rp_collider_desc &d = C.parts[(size_t)i];
+        const V3 t = v3(d.translation[0], d.translation[1], d.translation[2]) - centre;
+        d.translation[0] = t.x; d.translation[1] = t.y; d.translation[2] = t.z;
+        float he[3]; part_che(w, d, C.part_poly[(size_t)i], he);
+        V3 mn, mx; h_prim_aabb_at(core_shape(d.shape), he, shape_border(d), part_pose(d), mn, mx);
+        C.smin.push_back(mn.x); C.smin.push_back(mn.y); C.smin.push_back(mn.z); C.smax.push_back(mx.x); C.smax.push_back(mx.y); C.smax.push_back(mx.z);
+    }
+    return composite_registered(w, std::move(C), id_out);
+}
+extern "C" int32_t rp_trimesh_create(rp_world *w, int32_t nv, const float *xyz, int32_t nt, const uint32_t *idx, int32_t *id_out) {
+    if (!w || !xyz || !idx || !id_out || nv < 3 || nt < 1) { if (w) w->err = "rp_trimesh_create: at least three vertices and one triangle"; return RP_ERR_INVALID; }
+    for (int i = 0; i < 3 * nt; ++i) if (idx[i] >= (uint32_t)nv) { w->err = "rp_trimesh_create: a triangle names a vertex that does not exist"; return RP_ERR_INVALID; }
+    rp_world::HostComposite C; C.kind = RP_SHAPE_TRIMESH;
+    V3 bmn = v3(xyz[0], xyz[1], xyz[2]), bmx = bmn;
+    for (int i = 1; i < nv; ++i) {
+        const V3 p = v3(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+        bmn = v3(rp_min(bmn.x, p.x), rp_min(bmn.y, p.y), rp_min(bmn.z, p.z)); bmx = v3(rp_max(bmx.x, p.x), rp_max(bmx.y, p.y), rp_max(bmx.z, p.z));
+    }
+    const V3 centre = (bmn + bmx) * 0.5f, half = (bmx - bmn) * 0.5f;
+    C.centre[0] = centre.x; C.centre[1] = centre.y; C.centre[2] = centre.z; C.half[0] = half.x; C.half[1] = half.y; C.half[2] = half.z;
+    for (int t = 0; t < nt; ++t) {
+        V3 q[3];
+        for (int k = 0; k < 3; ++k) { const uint32_t vi = idx[3 * t + k]; q[k] = v3(xyz[3 * vi], xyz[3 * vi + 1], xyz[3 * vi + 2]) - centre; C.tri.push_back(q[k].x); C.tri.push_back(q[k].y); C.tri.push_back(q[k].z); }
+        V3 mn = q[0], mx = q[0];
+        for (int k = 1; k < 3; ++k) { mn = v3(rp_min(mn.x, q[k].x), rp_min(mn.y, q[k].y), rp_min(mn.z, q[k].z)); mx = v3(rp_max(mx.x, q[k].x), rp_max(mx.y, q[k].y), rp_max(mx.z, q[k].z)); }
+        C.smin.push_back(mn.x); C.smin.push_back(mn.y); C.smin.push_back(mn.z); C.smax.push_back(mx.x); C.smax.push_back(mx.y); C.smax.push_back(mx.z);
+    }
+    return composite_registered(w, std::move(C), id_out);
+}
+extern "C" int32_t rp_heightfield_create(rp_world *w, int32_t nrows, int32_t ncols, const float *heights, const float scale[3], int32_t *id_out) {
+    if (!w || !heights || !scale || !id_out || nrows < 2 || ncols < 2) { if (w) w->err = "rp_heightfield_create: at least 2 x 2 heights"; return RP_ERR_INVALID; }
+    const int nv = nrows * ncols, nt = 2 * (nrows - 1) * (ncols - 1);
+    std::vector<float> xyz((size_t)3 * nv); std::vector<uint32_t> idx((size_t)3 * nt);
+    for (int r = 0; r < nrows; ++r) for (int c = 0; c < ncols; ++c) {
+        const int i = r * ncols + c;
+        xyz[3 * (size_t)i] = ((float)c / (float)(ncols - 1) - 0.5f) * scale[0]; xyz[3 * (size_t)i + 1] = heights[i] * scale[1]; xyz[3 * (size_t)i + 2] = ((float)r / (float)(nrows - 1) - 0.5f) * scale[2];
+    }
+    size_t t = 0;
+    for (int r = 0; r + 1 < nrows; ++r) for (int c = 0; c + 1 < ncols; ++c) { // heightfield3.rs: two triangles per cell, cut along (r, c) -> (r + 1, c + 1)
+        const uint32_t p00 = (uint32_t)(r * ncols + c), p01 = p00 + 1, p10 = p00 + (uint32_t)ncols, p11 = p10 + 1;
+        idx[3 * t] = p00; idx[3 * t + 1] = p10; idx[3 * t + 2] = p11; ++t;
+        idx[3 * t] = p00; idx[3 * t + 1] = p11; idx[3 * t + 2] = p01; ++t;
+    }
+    return rp_trimesh_create(w, nv, xyz.data(), nt, idx.data(), id_out);
+}
 extern "C" int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider_desc *descs, const uint64_t *parents, uint64_t *handles_out) {
     if (!w || n < 0 || (n > 0 && !descs)) return RP_ERR_INVALID;
     for (int i = 0; i < n; ++i) {
         const rp_collider_desc &cd = descs[i];
+        if (shape_composite(cd.shape)) {
+            if (!(cd.half_extents[0] >= 0.0f && cd.half_extents[0] < (float)w->comps.size() && cd.half_extents[0] == std::floor(cd.half_extents[0])) ||
+                w->comps[(size_t)cd.half_extents[0]].kind != cd.shape) { w->err = "rp_colliders_insert: a composite collider's half_extents[0] holds the id rp_compound_create / rp_trimesh_create / rp_heightfield_create returned (for that shape)"; return RP_ERR_INVALID; }
+            if (cd.shape == RP_SHAPE_TRIMESH && parents && parents[i] != RP_INVALID_HANDLE) {
+                const int pb = body_of(w, parents[i]);
+                if (pb >= 0 && pb < (int)w->bodies.size() && w->bodies[pb].d.body_type == RP_BODY_DYNAMIC) { w->err = "rp_colliders_insert: a triangle mesh / height field needs a fixed or kinematic parent (or none)"; return RP_ERR_INVALID; }
+            }
+            continue;
+        }
         if (cd.shape < RP_SHAPE_BALL || cd.shape > RP_SHAPE_ROUND_CONVEX_POLYHEDRON) { w->err = "rp_colliders_insert: unknown shape (ball, cuboid, capsule, half-space, cylinder, cone, convex polyhedron and their round variants are implemented)"; return RP_ERR_INVALID; }
         if (cd.shape >= RP_SHAPE_ROUND_CUBOID && !(cd.border_radius > 0.0f)) { w->err = "rp_colliders_insert: a round shape needs a positive border_radius"; return RP_ERR_INVALID; }
         if (core_shape(cd.shape) == RP_SHAPE_CONVEX_POLYHEDRON && !(cd.half_extents[0] >= 0.0f && cd.half_extents[0] < (float)w->polys.size() && cd.half_extents[0] == std::floor(cd.half_extents[0]))) { w->err = "rp_colliders_insert: a convex polyhedron's half_extents[0] holds the id rp_convex_polyhedron_create returned"; return RP_ERR_INVALID; }
@@ -1047,7 +1248,18 @@ extern "C" int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider
         if (ord_counter >= (parent >= 0 ? 4096 : (1 << 20))) { w->err = "rp_colliders_insert: more than 4,096 colliders on one body (or 2^20 without a parent)"; return RP_ERR_CAPACITY; }
         int ci;
         rp_collider_desc cd = descs[i];
-        int poly = -1;
+        int poly = -1, comp = -1;
+        if (shape_composite(cd.shape)) { // stored recentred on its local AABB, like a polyhedron: the centre rides in the collider's pose, half_extents = the box
+            comp = (int)cd.half_extents[0];
+            const rp_world::HostComposite &C = w->comps[(size_t)comp];
+            float qn = std::sqrt(cd.rotation[0] * cd.rotation[0] + cd.rotation[1] * cd.rotation[1] + cd.rotation[2] * cd.rotation[2] + cd.rotation[3] * cd.rotation[3]);
+            float qi = qn > 0.0f ? 1.0f / qn : 1.0f;
+            const float q[4] = {cd.rotation[0] * qi, cd.rotation[1] * qi, cd.rotation[2] * qi, qn > 0.0f ? cd.rotation[3] * qi : 1.0f};
+            float r[3]; h_qrot(q, C.centre, r);
+            cd.translation[0] = r[0] + cd.translation[0]; cd.translation[1] = r[1] + cd.translation[1]; cd.translation[2] = r[2] + cd.translation[2];
+            cd.half_extents[0] = C.half[0]; cd.half_extents[1] = C.half[1]; cd.half_extents[2] = C.half[2];
+            cd.border_radius = 0.0f;
+        }
         if (core_shape(cd.shape) == RP_SHAPE_CONVEX_POLYHEDRON) { // stored recentred on its local AABB: the centre rides in the collider's pose, half_extents = the box (rp_polyhedron.h)
             poly = (int)cd.half_extents[0];
             const HostPolyhedron &P = w->polys[(size_t)poly];
@@ -1060,10 +1272,10 @@ extern "C" int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider
         }
         if (reuse) {
             ci = w->coll_free.back(); w->coll_free.pop_back();
-            w->collider_ord[(size_t)ci] = ord_counter++; w->colliders[(size_t)ci] = cd; w->collider_parent[(size_t)ci] = parent; w->collider_removed[(size_t)ci] = 0; w->collider_poly[(size_t)ci] = poly;
+            w->collider_ord[(size_t)ci] = ord_counter++; w->colliders[(size_t)ci] = cd; w->collider_parent[(size_t)ci] = parent; w->collider_removed[(size_t)ci] = 0; w->collider_poly[(size_t)ci] = poly; w->collider_comp[(size_t)ci] = comp;
         } else {
             ci = (int)w->colliders.size();
-            w->collider_ord.push_back(ord_counter++); w->colliders.push_back(cd); w->collider_parent.push_back(parent); w->collider_removed.push_back(0); w->coll_gen.push_back(0); w->collider_poly.push_back(poly);
+            w->collider_ord.push_back(ord_counter++); w->colliders.push_back(cd); w->collider_parent.push_back(parent); w->collider_removed.push_back(0); w->coll_gen.push_back(0); w->collider_poly.push_back(poly); w->collider_comp.push_back(comp);
         }
         w->coll_gen[(size_t)ci] = w->coll_arena_gen;
         new_slots.push_back(ci);
@@ -1094,6 +1306,7 @@ extern "C" int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider
             if (c.active_events & RP_EVENTS_CONTACT_FORCE) w->dw.has_force_events = 1;
             if (c.sensor) w->dw.has_sensors = 1;
             if (c.shape >= RP_SHAPE_CYLINDER) w->dw.has_convex = 1;
+            if (shape_composite(c.shape)) w->dw.has_composite = 1;
             if (p >= 0 && w->bodies[p].d.body_type == RP_BODY_DYNAMIC) {
                 const float *t = c.translation, *r = c.rotation;
                 const bool at_origin = t[0] == 0.0f && t[1] == 0.0f && t[2] == 0.0f && r[0] == 0.0f && r[1] == 0.0f && r[2] == 0.0f;
@@ -1215,6 +1428,7 @@ static ColliderRow pack_collider(const rp_world *w, int i) {
     o.he = mk4(c.half_extents[0], c.half_extents[1], c.half_extents[2], 0);
     if (core_shape(c.shape) == RP_SHAPE_CYLINDER || core_shape(c.shape) == RP_SHAPE_CONE) o.he = mk4(c.half_extents[1], c.half_extents[0], c.half_extents[1], 0); // (radius, half_height, radius): the local AABB's half extents
     if (core_shape(c.shape) == RP_SHAPE_CONVEX_POLYHEDRON) { int id = w->collider_poly[i]; memcpy(&o.he.w, &id, sizeof(int)); } // (half extents of the local box; w = the polyhedron's row in the cv_* tables, as bits)
+    if (shape_composite(c.shape)) { int id = w->collider_comp[i]; memcpy(&o.he.w, &id, sizeof(int)); } // (likewise: the composite's row in cm_hdr)
     o.mat = mk4(c.friction, c.restitution, c.density, shape_border(c)); // (w: a round shape's border radius)
     o.rules.x = c.friction_rule; o.rules.y = c.restitution_rule;
     o.groups.x = w->collider_removed[i] ? 0u : c.collision_memberships; o.groups.y = w->collider_removed[i] ? 0u : c.collision_filter;
@@ -1385,6 +1599,8 @@ static int finalize(rp_world *w) {
     d.has_sensors = world_has_sensors(w) ? 1 : 0;
     d.has_convex = world_has_convex(w) ? 1 : 0;
     if (!w->polys.empty()) { int r = upload_polyhedra(w); if (r != RP_OK) return r; } // (after the memset above: the cv_* pointers)
+    if (!w->comps.empty()) { int r = upload_composites(w); if (r != RP_OK) return r; }
+    d.has_composite = 0; for (size_t i = 0; i < w->colliders.size(); ++i) if (!w->collider_removed[i] && shape_composite(w->colliders[i].shape)) d.has_composite = 1;
     d.gbar_blocks = gbar_grid_for_device(w->device);
     { const char *ni = getenv("RP_NO_BP_INCR"); d.bp_incremental = (ni && ni[0] == '1') ? 0 : 1; }
     { const char *dv = getenv("RP_BP_INCR_DIV"); d.bp_incr_div = dv ? std::max(1, atoi(dv)) : 1; }
@@ -1449,6 +1665,7 @@ static int finalize(rp_world *w) {
     DAC(d.free_stack, d.pool_cap, DOM_PAIR, 1, 1);
     size_t P = (size_t)d.pool_cap;
     DAFC(d.p_c1, P, 0xff, DOM_PAIR, 1, 1); DAC(d.p_c2, P, DOM_PAIR, 1, 1); DAC(d.p_stamp, P, DOM_PAIR, 1, 1); DAC(d.p_color, P, DOM_PAIR, 1, 1); DAC(d.p_nsc, P, DOM_PAIR, 1, 1); DAC(d.p_npts, P, DOM_PAIR, 1, 1); DAC(d.p_pflags, P, DOM_PAIR, 1, 1); DAC(d.p_reldom, P, DOM_PAIR, 1, 1);
+    DAFC(d.p_aux, P, 0xff, DOM_PAIR, 1, 1); DAFC(d.p_sub, P, 0xff, DOM_PAIR, 1, 1); // (composite pairs: no aux slot, no sub-shape yet = -1; the cluster count is set by bp_insert_pair)
     DAC(d.p_hint_seq, P, DOM_PAIR, 1, 1); DAC(d.p_colorb, P, DOM_PAIR, 1, 1); DAC(d.p_rb, P, DOM_PAIR, 1, 1); DAC(d.p_ln1, P, DOM_PAIR, 1, 1); DAC(d.p_ln2, P, DOM_PAIR, 1, 1); DAC(d.p_normal, P, DOM_PAIR, 1, 1); DAC(d.p_misc, P, DOM_PAIR, 1, 1);
     DAC(d.r_t, P, DOM_PAIR, 1, 1); DAC(d.r_r, P, DOM_PAIR, 1, 1); DAC(d.r_rot1, P, DOM_PAIR, 1, 1); DAC(d.r_rot2, P, DOM_PAIR, 1, 1);
     DAC(d.pt_lp1d, RP_MAX_PTS * P, DOM_PAIR, RP_MAX_PTS, 1); DAC(d.pt_lp2f, RP_MAX_PTS * P, DOM_PAIR, RP_MAX_PTS, 1); DAC(d.pt_imp, RP_MAX_PTS * P, DOM_PAIR, RP_MAX_PTS, 1); DAC(d.pt_wst, RP_MAX_PTS * P, DOM_PAIR, RP_MAX_PTS, 1);
@@ -2941,6 +3158,11 @@ extern "C" int32_t rp_counters_read(rp_world *w, rp_counters *out) {
     {
         int top = std::min(fl[FL_POOL_TOP], w->dw.pool_cap);
         live = top - fl[FL_FREE_TOP];
+        if (w->dw.has_composite && top > 0) { // (clusters of composite pairs hold pool slots but are not pairs)
+            std::vector<int> pc1((size_t)top), pfl((size_t)top);
+            HIPCHK(w, hipMemcpy(pc1.data(), w->dw.p_c1, (size_t)top * sizeof(int), hipMemcpyDeviceToHost)); HIPCHK(w, hipMemcpy(pfl.data(), w->dw.p_pflags, (size_t)top * sizeof(int), hipMemcpyDeviceToHost));
+            for (int q = 0; q < top; ++q) if (pc1[(size_t)q] >= 0 && (pfl[(size_t)q] & RP_PF_AUX)) --live;
+        }
     }
     out->num_pairs = live;
     out->num_manifolds = fl[FL_N_CONS_ALL];
@@ -2990,4 +3212,38 @@ extern "C" int32_t rp_solver_loop_time_ms(rp_world *w, float *avg, int32_t *step
     if (steps) *steps = w->loop_steps_since_read;
     w->loop_ms_since_read = 0.0; w->loop_steps_since_read = 0;
     return RP_OK;
+}
+
+// debug aid (not in the header; tools/composite_diag.py): the solver manifolds of pair (c1, c2) as the device holds them.
+// out: [0] = cluster count (p_aux.w), [1..2] = p_sub, then per solver manifold k < max(1, count): slot, npts, nsc, then npts x (lp1.xyz, dist, impulse, warmstart_impulse)
+extern "C" int32_t rp_debug_pair_points(rp_world *w, int32_t c1, int32_t c2, int32_t cap, float *out) {
+    if (!w || !w->finalized) return RP_ERR_INVALID;
+    HIPCHK(w, hipSetDevice(w->device));
+    { int r = settle(w); if (r != RP_OK) return r; }
+    int fl[FL_COUNT]; HIPCHK(w, hipMemcpy(fl, w->dw.flags, sizeof(fl), hipMemcpyDeviceToHost));
+    const int top = std::min(fl[FL_POOL_TOP], w->dw.pool_cap); const size_t P = (size_t)w->dw.pool_cap;
+    std::vector<int> pc1((size_t)top), pc2((size_t)top), pfl((size_t)top);
+    HIPCHK(w, hipMemcpy(pc1.data(), w->dw.p_c1, (size_t)top * sizeof(int), hipMemcpyDeviceToHost)); HIPCHK(w, hipMemcpy(pc2.data(), w->dw.p_c2, (size_t)top * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(w, hipMemcpy(pfl.data(), w->dw.p_pflags, (size_t)top * sizeof(int), hipMemcpyDeviceToHost));
+    int s = -1;
+    for (int q = 0; q < top; ++q) if (pc1[(size_t)q] == c1 && pc2[(size_t)q] == c2 && !(pfl[(size_t)q] & RP_PF_AUX)) { s = q; break; }
+    if (s < 0) return 0;
+    int4 aux; int2 sub;
+    HIPCHK(w, hipMemcpy(&aux, w->dw.p_aux + s, sizeof(int4), hipMemcpyDeviceToHost)); HIPCHK(w, hipMemcpy(&sub, w->dw.p_sub + s, sizeof(int2), hipMemcpyDeviceToHost));
+    int n = 0;
+    auto put = [&](float v) { if (n < cap) out[n] = v; ++n; };
+    put((float)aux.w); put((float)sub.x); put((float)sub.y);
+    const int nsm = aux.w > 1 ? aux.w : 1;
+    for (int k = 0; k < nsm; ++k) {
+        const int slot = k == 0 ? s : (k == 1 ? aux.x : (k == 2 ? aux.y : aux.z));
+        int npts = 0, nsc = 0;
+        if (slot >= 0) { HIPCHK(w, hipMemcpy(&npts, w->dw.p_npts + slot, sizeof(int), hipMemcpyDeviceToHost)); HIPCHK(w, hipMemcpy(&nsc, w->dw.p_nsc + slot, sizeof(int), hipMemcpyDeviceToHost)); }
+        put((float)slot); put((float)npts); put((float)nsc);
+        for (int i = 0; i < npts; ++i) {
+            float4 a, im;
+            HIPCHK(w, hipMemcpy(&a, w->dw.pt_lp1d + (size_t)i * P + slot, sizeof(float4), hipMemcpyDeviceToHost)); HIPCHK(w, hipMemcpy(&im, w->dw.pt_imp + (size_t)i * P + slot, sizeof(float4), hipMemcpyDeviceToHost));
+            put(a.x); put(a.y); put(a.z); put(a.w); put(im.x); put(im.y);
+        }
+    }
+    return n;
 }

@@ -96,6 +96,7 @@ __global__ void k_fast_front(DevWorld w, int no_global_kernel) {
     if (top > w.pool_cap) top = w.pool_cap;
     int stride = gridDim.x * blockDim.x;
     for (int s = gid; s < top; s += stride) {
+        if (w.has_composite && w.p_c1[s] >= 0 && pair_is_aux(w, s)) continue; // (a cluster of a composite pair: its parent slot is the pair)
         if (w.sleep_enabled) {
             if (w.p_c1[s] < 0) continue;
             int2 rb = w.p_rb[s];
@@ -203,6 +204,7 @@ __device__ void bp_insert_pair(DevWorld &w, int c1, int c2, bool incremental = f
         w.p_c1[slot] = c1; w.p_c2[slot] = c2; w.p_rb[slot] = make_int2(w.c_parent[c1], w.c_parent[c2]);
         w.p_color[slot] = RP_COLOR_UNCOLORED; w.p_nsc[slot] = 0; w.p_npts[slot] = 0; w.p_pflags[slot] = 0;
         w.p_reldom[slot] = 0; w.p_colorb[slot] = make_int2(-1, -1); w.p_conspos[slot] = -1; w.p_hint_seq[slot] = 0;
+        w.p_aux[slot] = make_int4(-1, -1, -1, 0); w.p_sub[slot] = make_int2(-1, -1);
         w.p_ln1[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); w.p_ln2[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // (a recycled slot: the last normal is GJK's first guess, rp_convex.h)
         // the lists of an LDS island also hold its pairs WITHOUT solver contacts (the fused step recycle-tests them): a new pair
         // changes the layout only when one of its bodies lives in such an island — not when both sit on the global path (the
@@ -304,6 +306,7 @@ RP_DEV void bp_delete_pair(DevWorld &w, int s, bool deferred = false) {
         }
         if (w.p_nsc[s] > 0) pi_journal(w, rb.x, rb.y, 1, c1, c2); // unlink_contact of a removed touching pair (pair_management.rs:531)
     }
+    if (w.has_composite) aux_free_all(w, s, deferred); // the clusters of a composite pair go with it
     w.p_c1[s] = -1; w.p_nsc[s] = 0; w.p_npts[s] = 0; w.p_color[s] = RP_COLOR_UNCOLORED;
     if (deferred) { int t = atomicAdd(&w.flags[FL_BP_NFREED], 1); w.free_pending[t] = s; return; }
     int t = atomicAdd(&w.flags[FL_FREE_TOP], 1);
@@ -317,6 +320,7 @@ RP_DEV void bp_finish_pairs(DevWorld &w, int gid, int gstride, bool keep_grid, i
     if (top > w.pool_cap) top = w.pool_cap;
     for (int s = gid; s < top; s += gstride) {
         if (w.p_c1[s] < 0) continue;
+        if (w.has_composite && pair_is_aux(w, s)) continue; // (a cluster of a composite pair: deleted with its parent)
         if (w.p_stamp[s] == epoch + 1) continue;
         bp_delete_pair(w, s);
     }
@@ -392,6 +396,7 @@ RP_DEV void bp_incr_delete(DevWorld &w, int gid, int gstride, int nchg) {
     for (int s = gid; s < top; s += gstride) {
         const int c1 = w.p_c1[s];
         if (c1 < 0) continue;
+        if (w.has_composite && pair_is_aux(w, s)) continue;
         const int c2 = w.p_c2[s];
         if (w.c_chgstamp[c1] != stamp && w.c_chgstamp[c2] != stamp) continue;
         V3 imin;
@@ -488,6 +493,7 @@ __global__ void k_purge_dead_pairs(DevWorld w) {
     for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < top; s += stride) {
         const int c1 = w.p_c1[s];
         if (c1 < 0) continue;
+        if (w.has_composite && pair_is_aux(w, s)) continue; // (a cluster of a composite pair: its parent frees it)
         const int c2 = w.p_c2[s];
         const uint2 g1 = w.c_groups[c1], g2 = w.c_groups[c2];
         if (!((g1.x == 0 && g1.y == 0) || (g2.x == 0 && g2.y == 0))) continue;

@@ -254,6 +254,7 @@ template <bool CONVEX> __global__ void __launch_bounds__(256) k_ccd(DevWorld w, 
               if (o < 0 || o >= CCD_MAX_FAST_COLLIDERS) continue;
               uint2 g = w.c_groups[c];
               if ((g.x == 0 && g.y == 0) || (__float_as_int(w.c_events[c].x) & RP_EVENTS_SENSOR_BIT)) continue;
+              if (shape_is_composite(w.c_shape[c])) continue; // (composite colliders take no part in the continuous-collision pass: DESIGN.md section 8)
               fast[o] = c;
           }
           __syncthreads();
@@ -268,6 +269,7 @@ template <bool CONVEX> __global__ void __launch_bounds__(256) k_ccd(DevWorld w, 
             auto try_target = [&](int c2) {
                 const int p2 = w.c_parent[c2];
                 if (c2 == c1 || p2 == bi) return;
+                if (shape_is_composite(w.c_shape[c2])) return; // (likewise as targets)
                 const uint2 g2 = w.c_groups[c2];
                 if ((g2.x == 0 && g2.y == 0) || (__float_as_int(w.c_events[c2].x) & RP_EVENTS_SENSOR_BIT)) return;
                 const int fl2 = p2 >= 0 ? w.b_flags[p2] : RP_BODY_FIXED;

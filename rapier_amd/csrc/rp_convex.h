@@ -30,11 +30,13 @@
 // a convex polyhedron (c_he = its local box's half extents, w = its row in cv_hdr as bits): points, face normals, per face {first loop
 // entry, entries}, loop entries {vertex, edge} — pointers into the world's cv_* tables
 // a round shape (RP_SHAPE_ROUND_*, parry RoundShape<S>): `shape` is its inner shape, `border` its border radius (c_mat.w)
-struct SmShape { int shape; V3 he; float radius; int axis; const float4 *pts; const float4 *fn; const int2 *fl; const int2 *loop; int npts, nfaces; float border; };
-RP_DEV int sm_core_shape(int sh) { return sh >= RP_SHAPE_ROUND_CUBOID ? (sh == RP_SHAPE_ROUND_CUBOID ? RP_SHAPE_CUBOID : sh - RP_SHAPE_ROUND_CYLINDER + RP_SHAPE_CYLINDER) : sh; }
+struct SmShape { int shape; V3 he; float radius; int axis; const float4 *pts; const float4 *fn; const int2 *fl; const int2 *loop; int npts, nfaces; float border;
+                 V3 tri[3]; }; // tri: RP_SHAPE_TRIANGLE (a triangle of a mesh collider, rp_composite.h): its vertices
+RP_DEV int sm_core_shape(int sh) { return (sh >= RP_SHAPE_ROUND_CUBOID && sh <= RP_SHAPE_ROUND_CONVEX_POLYHEDRON) ? (sh == RP_SHAPE_ROUND_CUBOID ? RP_SHAPE_CUBOID : sh - RP_SHAPE_ROUND_CYLINDER + RP_SHAPE_CYLINDER) : sh; }
 RP_DEV SmShape sm_shape_of(const DevWorld &w, int sh_in, float4 he, float border_in) {
     const int sh = sm_core_shape(sh_in);
-    SmShape s; s.shape = sh; s.he = v3(he); s.axis = 1; s.border = sh_in >= RP_SHAPE_ROUND_CUBOID ? border_in : 0.0f;
+    SmShape s; s.shape = sh; s.he = v3(he); s.axis = 1; s.border = (sh_in >= RP_SHAPE_ROUND_CUBOID && sh_in <= RP_SHAPE_ROUND_CONVEX_POLYHEDRON) ? border_in : 0.0f;
+    s.tri[0] = v3(0, 0, 0); s.tri[1] = s.tri[0]; s.tri[2] = s.tri[0];
     s.radius = sh == RP_SHAPE_CAPSULE ? he.y : he.x;
     if (sh == RP_SHAPE_CAPSULE) s.axis = (int)he.z;
     s.pts = nullptr; s.fn = nullptr; s.fl = nullptr; s.loop = nullptr; s.npts = 0; s.nfaces = 0;
@@ -47,6 +49,7 @@ RP_DEV SmShape sm_shape_of(const DevWorld &w, int sh_in, float4 he, float border
 RP_DEV SmShape sm_point_shape() { // a ball's centre as second shape of a query
     SmShape s; s.shape = RP_SHAPE_BALL; s.he = v3(0, 0, 0); s.radius = 0.0f; s.axis = 1;
     s.pts = nullptr; s.fn = nullptr; s.fl = nullptr; s.loop = nullptr; s.npts = 0; s.nfaces = 0; s.border = 0.0f;
+    s.tri[0] = v3(0, 0, 0); s.tri[1] = s.tri[0]; s.tri[2] = s.tri[0];
     return s;
 }
 RP_DEV float sm_border_radius(const SmShape &s) { return (s.shape == RP_SHAPE_BALL || s.shape == RP_SHAPE_CAPSULE) ? s.radius : s.border; }
@@ -72,6 +75,11 @@ __device__ V3 sm_support(const SmShape &s, V3 d) {
         V3 r = v3(d.x / n * s.radius, -s.he.y, d.z / n * s.radius);
         if (dot(d, r) < d.y * s.he.y) r = v3(0.0f, s.he.y, 0.0f);
         return r;
+    }
+    if (s.shape == RP_SHAPE_TRIANGLE) { // Triangle::local_support_point: the first vertex with the largest dot product
+        float da = dot(s.tri[0], d), db = dot(s.tri[1], d), dc = dot(s.tri[2], d);
+        if (da > db) return da > dc ? s.tri[0] : s.tri[2];
+        return db > dc ? s.tri[1] : s.tri[2];
     }
     if (s.shape == RP_SHAPE_CONVEX_POLYHEDRON) { // utils::point_cloud_support_point: the first vertex with the largest dot product
         int best = 0; float bd = dot(v3(s.pts[0]), d);
@@ -423,6 +431,11 @@ __device__ void sm_support_feature(const SmShape &s, V3 dir, V3 hint, PolyFeat &
         out.fid = 0; out.nv = 2;
         return;
     }
+    if (s.shape == RP_SHAPE_TRIANGLE) { // Triangle: PolygonalFeature::from(triangle) — the face itself whatever the direction (vertex ids 0, 2, 4, edge ids 1, 3, 5)
+        for (int i = 0; i < 4; ++i) { const int k = i < 3 ? i : 2; out.v[i] = s.tri[k]; out.vid[i] = 2u * (unsigned)k; out.eid[i] = 2u * (unsigned)k + 1u; }
+        out.fid = 0; out.nv = 3;
+        return;
+    }
     if (s.shape == RP_SHAPE_CONVEX_POLYHEDRON) { // the face whose normal is closest to dir (the first one), its first four vertices
         int best = 0; float bd = dot(v3(s.fn[0]), dir);
         for (int f = 1; f < s.nfaces; ++f) { float x = dot(v3(s.fn[f]), dir); if (x > bd) { bd = x; best = f; } }
@@ -626,7 +639,7 @@ __device__ V3 sm_project_point(const SmShape &s, V3 pt, bool &inside) {
 // contact_manifold_convex_ball with shape1 = a cylinder / cone; flipped = the ball is collider 1
 __device__ void manifold_sm_ball(Pose pos12, const SmShape &s1, float r2, float prediction, LocalManifold &m, bool flipped) {
     V3 pt = pos12.t;
-    if (s1.shape == RP_SHAPE_CONVEX_POLYHEDRON || s1.border > 0.0f) { // ConvexPolyhedron / RoundShape::project_local_point = GJK / polytope pass against the point
+    if (s1.shape == RP_SHAPE_CONVEX_POLYHEDRON || s1.shape == RP_SHAPE_TRIANGLE || s1.border > 0.0f) { // ConvexPolyhedron / Triangle / RoundShape::project_local_point = GJK / polytope pass against the point
         const SmShape centre = sm_point_shape();
         const float b1 = s1.border;
         V3 p1, p2, n1;

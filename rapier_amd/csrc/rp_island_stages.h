@@ -302,11 +302,11 @@ RP_DEV void island_sort(const DevWorld &w, int isl, int nc, int cb, int nst_glob
         int r = T_rank[t], s = T_slot[t], posn = 0;
         // ties broken by the (collider1, collider2) key so the serial overflow order depends neither on atomics nor on the order in
         // which the broad phase handed out the pair slots (the oracle sweeps its overflow colour in the same order)
-        const unsigned long long key = ((unsigned long long)(unsigned)w.p_c1[s] << 32) | (unsigned)w.p_c2[s];
+        const unsigned long long key = pair_order_key(w, s);
         for (int j = 0; j < nc; ++j) {
             int rj = T_rank[j];
             if (rj < r) posn++;
-            else if (rj == r && j != t) { int sj = T_slot[j]; unsigned long long kj = ((unsigned long long)(unsigned)w.p_c1[sj] << 32) | (unsigned)w.p_c2[sj]; posn += kj < key; }
+            else if (rj == r && j != t) { int sj = T_slot[j]; unsigned long long kj = pair_order_key(w, sj); posn += kj < key; }
         }
         K_slot[posn] = s; K_rank[posn] = r;
     }

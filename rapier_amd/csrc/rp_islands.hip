@@ -358,9 +358,9 @@ RP_DEV void lay_rank_overflow(DevWorld &w) { // workgroup 0, after a grid barrie
         __threadfence(); __syncthreads();
         for (int i = threadIdx.x; i < on; i += blockDim.x) {
             int si = ld_i32(&w.todo_tmp[i]);
-            unsigned long long ki = ((unsigned long long)(unsigned)w.p_c1[si] << 32) | (unsigned)w.p_c2[si];
+            unsigned long long ki = pair_order_key(w, si);
             int rank = 0;
-            for (int j = 0; j < on; ++j) { int sj = ld_i32(&w.todo_tmp[j]); unsigned long long kj = ((unsigned long long)(unsigned)w.p_c1[sj] << 32) | (unsigned)w.p_c2[sj]; rank += kj < ki; }
+            for (int j = 0; j < on; ++j) { int sj = ld_i32(&w.todo_tmp[j]); unsigned long long kj = pair_order_key(w, sj); rank += kj < ki; }
             w.cons_pair[ob + rank] = si; w.p_conspos[si] = ob + rank;
         }
         __threadfence(); __syncthreads();

@@ -653,30 +653,17 @@ template <bool CONVEX> __device__ __forceinline__ void sensor_pair_update(DevWor
 }
 
 // The full narrow-phase update of one pair (pair_update.rs:173-613).
-template <bool CONVEX> __device__ __forceinline__ void pair_full_update(DevWorld &w, int s, int c1, int c2, Pose pc1, Pose pc2, Pose pos12, float *np_lds) {
-    const float prediction = w.prm.prediction;
-    int rb1 = w.c_parent[c1], rb2 = w.c_parent[c2];
-    int sh1 = w.c_shape[c1], sh2 = w.c_shape[c2];
-    float4 he1 = w.c_he[c1], he2 = w.c_he[c2];
-    if (w.has_sensors && pair_is_sensor(w, c1, c2)) { sensor_pair_update<CONVEX>(w, s, c1, c2, pos12); return; }
-    int had = w.p_nsc[s] > 0;
-    const bool no_contact = joints_disable_contacts(w, rb1, rb2); // pair_update.rs:191-201: clear_filtered_pair
-
-    LocalManifold m;
-    m.bind(np_lds);
-    m.n = w.p_npts[s];
-    m.ln1 = v3(w.p_ln1[s]); m.ln2 = v3(w.p_ln2[s]);
-    for (int k = 0; k < m.n; ++k) {
-        float4 a = PT(w.pt_lp1d, k, s), b = PT(w.pt_lp2f, k, s);
-        m.lp1[k] = v3(a); m.dist[k] = a.w; m.lp2[k] = v3(b); m.fid[k] = __float_as_uint(b.w); m.src[k] = k;
-    }
-    int nold = m.n;
-    // pair_update.rs:323-330 -> parry DefaultQueryDispatcher::contact_manifolds
+// parry DefaultQueryDispatcher::contact_manifold_convex_convex (pair_update.rs:323-330 reaches it through contact_manifolds) for two
+// primitive SHAPES in the c_he layout (a collider, a part of a compound, a mesh triangle: tri1 / tri2), shape 2 at pos12 in shape 1's frame
+template <bool CONVEX> __device__ __forceinline__ void dispatch_manifold(const DevWorld &w, int sh1, float4 he1, float bd1, const V3 *tri1, int sh2, float4 he2, float bd2, const V3 *tri2,
+                                                                         Pose pos12, float prediction, LocalManifold &m) {
     bool convex_pair = false;
     if constexpr (CONVEX) { // cylinders, cones (rp_convex.h): the dispatcher's order — ball arms, half-space arms, pfm_pfm
         convex_pair = sh1 >= RP_SHAPE_CYLINDER || sh2 >= RP_SHAPE_CYLINDER;
         if (convex_pair) {
-            const SmShape a = sm_shape_of(w, sh1, he1, w.c_mat[c1].w), b = sm_shape_of(w, sh2, he2, w.c_mat[c2].w);
+            SmShape a = sm_shape_of(w, sh1, he1, bd1), b = sm_shape_of(w, sh2, he2, bd2);
+            if (tri1) { a.tri[0] = tri1[0]; a.tri[1] = tri1[1]; a.tri[2] = tri1[2]; }
+            if (tri2) { b.tri[0] = tri2[0]; b.tri[1] = tri2[1]; b.tri[2] = tri2[2]; }
             if (sh2 == RP_SHAPE_BALL) manifold_sm_ball(pos12, a, he2.x, prediction, m, false);
             else if (sh1 == RP_SHAPE_BALL) manifold_sm_ball(pose_inv(pos12), b, he1.x, prediction, m, true);
             else if (sh1 == RP_SHAPE_HALFSPACE) manifold_halfspace_sm(pos12, v3(he1), b, prediction, m, false);
@@ -701,78 +688,14 @@ template <bool CONVEX> __device__ __forceinline__ void pair_full_update(DevWorld
     else if (sh1 == RP_SHAPE_BALL && sh2 == RP_SHAPE_CAPSULE) manifold_capsule_ball(pose_inv(pos12), he2, he1.x, prediction, m, true);
     else if (sh1 == RP_SHAPE_CUBOID) manifold_cuboid_ball(pos12, v3(he1), he2.x, prediction, m, false);
     else manifold_cuboid_ball(pose_inv(pos12), v3(he2), he1.x, prediction, m, true);
+}
 
-    // carry ContactData (impulse, warm starts) to the new point order
-    for (int k = 0; k < nold; ++k) { m.b_set4(4 * k, PT(w.pt_imp, k, s)); m.b_set4(32 + 4 * k, PT(w.pt_wst, k, s)); }
-    for (int k = 0; k < m.n; ++k) {
-        int j = m.src[k];
-        float4 im = j >= 0 ? m.b_get4(4 * j) : make_float4(0, 0, 0, 0);
-        float4 ws = j >= 0 ? m.b_get4(32 + 4 * j) : make_float4(0, 0, 0, 0);
-        PT(w.pt_imp, k, s) = im; PT(w.pt_wst, k, s) = ws;
-        PT(w.pt_lp1d, k, s) = f4(m.lp1[k], m.dist[k]);
-        PT(w.pt_lp2f, k, s) = f4(m.lp2[k], __uint_as_float(m.fid[k]));
-    }
-    w.p_npts[s] = m.n;
-    if (!no_contact) { w.p_ln1[s] = f4(m.ln1, 0.0f); w.p_ln2[s] = f4(m.ln2, 0.0f); } // (a filtered pair never reaches the generator in the reference: its cached normal stays)
-
-    float4 mat1 = w.c_mat[c1], mat2 = w.c_mat[c2];
-    int2 ru1 = w.c_rules[c1], ru2 = w.c_rules[c2];
-    float friction = combine_coeff(mat1.x, mat2.x, ru1.x, ru2.x);
-    float restitution = combine_coeff(mat1.y, mat2.y, ru1.y, ru2.y);
-    int rel_dom = effective_dominance(w, rb1) - effective_dominance(w, rb2);
-    V3 normal = qrot(pc1.r, m.ln1);
-    w.p_normal[s] = f4(normal, friction);
-    w.p_reldom[s] = rel_dom;
-
-    int nsc = 0;
-    if (no_contact) { m.n = 0; w.p_npts[s] = 0; }
-    if (m.n > 0) {
-        int sel[4] = {0, 1, 2, 3};
-        int nsel = m.n < 4 ? m.n : 4;
-        reduce_manifold(m, sel, nsel, prediction);
-        if (nsel > 1) { // pair_update.rs:430-457
-            V3 b0, b1; orthonormal_basis(m.ln1, b0, b1);
-            float k0[4], k1[4]; int ks[4];
-            for (int i = 0; i < nsel; ++i) { V3 lp = m.lp1[sel[i]]; k0[i] = dot(lp, b0); k1[i] = dot(lp, b1); ks[i] = sel[i]; }
-            for (int i = 1; i < nsel; ++i) {
-                float a0 = k0[i], a1 = k1[i]; int as = ks[i]; int j = i;
-                while (j > 0 && (k0[j - 1] > a0 || (k0[j - 1] == a0 && k1[j - 1] > a1))) { k0[j] = k0[j - 1]; k1[j] = k1[j - 1]; ks[j] = ks[j - 1]; j--; }
-                k0[j] = a0; k1[j] = a1; ks[j] = as;
-            }
-            for (int i = 0; i < nsel; ++i) sel[i] = ks[i];
-        }
-        bool has1 = rb1 >= 0 && rel_dom <= 0, has2 = rb2 >= 0 && rel_dom >= 0;
-        Pose com1, com2;
-        com1.r = q4(0, 0, 0, 1); com1.t = v3(0, 0, 0); com2 = com1;
-        V3 lv1 = v3(0, 0, 0), av1 = lv1, wc1 = lv1, lv2 = lv1, av2 = lv1, wc2 = lv1;
-        if (rb1 >= 0) { lv1 = v3(w.b_linvel[rb1]); av1 = v3(w.b_angvel[rb1]); wc1 = v3(w.b_wcom[rb1]); }
-        if (rb2 >= 0) { lv2 = v3(w.b_linvel[rb2]); av2 = v3(w.b_angvel[rb2]); wc2 = v3(w.b_wcom[rb2]); }
-        if (has1) { Pose bp; bp.r = q4(w.b_rot[rb1]); bp.t = v3(w.b_pos[rb1]); com1.r = bp.r; com1.t = pose_tp(bp, v3(w.b_lcom_invm[rb1])); }
-        if (has2) { Pose bp; bp.r = q4(w.b_rot[rb2]); bp.t = v3(w.b_pos[rb2]); com2.r = bp.r; com2.t = pose_tp(bp, v3(w.b_lcom_invm[rb2])); }
-        for (int q = 0; q < nsel; ++q) { // pair_update.rs:459-498 + :536-577
-            int cid = sel[q];
-            float eff_dist = m.dist[cid];
-            V3 wp1 = pose_tp(pc1, m.lp1[cid]);
-            V3 wp2 = pose_tp(pc2, m.lp2[cid]);
-            bool keep = eff_dist < prediction;
-            if (!keep) {
-                V3 vel1 = rb1 >= 0 ? lv1 + cross(av1, wp1 - wc1) : v3(0, 0, 0);
-                V3 vel2 = rb2 >= 0 ? lv2 + cross(av2, wp2 - wc2) : v3(0, 0, 0);
-                keep = eff_dist + dot(vel2 - vel1, normal) * w.prm.p.dt < prediction;
-            }
-            if (!keep) continue;
-            float shift = dot(wp2 - wp1, normal) - eff_dist;
-            V3 p1 = wp1 + normal * shift;
-            V3 point = (p1 + wp2) * 0.5f;
-            PT(w.pt_dp1, cid, s) = f4(has1 ? point - com1.t : point, 0.0f);
-            PT(w.pt_dp2, cid, s) = f4(has2 ? point - com2.t : point, 0.0f);
-            V3 a1 = has1 ? pose_itp(com1, p1) : p1;
-            V3 a2 = has2 ? pose_itp(com2, wp2) : wp2;
-            PT(w.sc_a1, nsc, s) = f4(a1, eff_dist);
-            PT(w.sc_a2, nsc, s) = f4(a2, __int_as_float(cid));
-            nsc++;
-        }
-    }
+// The pair-level tail of a full update (pair_update.rs:582-650, contacts.rs:300-364): solver-contact count of the pair's manifold 0,
+// recycle state, hint, begin / end-touch transition (events, colour, journal, the colouring queue).  Shared by pair_full_update and
+// the composite pairs' cluster path (rp_composite.h).  sh / he / border: the COLLIDERS' shapes.
+__device__ __forceinline__ void pair_update_finish(DevWorld &w, int s, int c1, int c2, int rb1, int rb2, int csh1, float4 che1, int csh2, float4 che2, float cbd1, float cbd2,
+                                                    Pose pc1, Pose pc2, Pose cpos12, int nsc, int had, bool no_contact, float restitution) {
+    const float prediction = w.prm.prediction;
     w.p_nsc[s] = nsc;
     // recycle state — pair_update.rs:582-613
     float recycle = w.prm.recycle_distance;
@@ -783,12 +706,12 @@ template <bool CONVEX> __device__ __forceinline__ void pair_full_update(DevWorld
         float max_extent;
         if (w.p_pflags[s] & RP_PF_RECYCLE) max_extent = w.p_misc[s].y;
         else {
-            float e1 = shape_origin_radius(sh1, he1, mat1.w), e2 = shape_origin_radius(sh2, he2, mat2.w);
+            float e1 = shape_origin_radius(csh1, che1, cbd1), e2 = shape_origin_radius(csh2, che2, cbd2);
             max_extent = rp_max(e1, e2);
         }
         float max_drift = nsc > 0 ? recycle : rp_min(recycle, prediction);
         w.p_misc[s] = make_float4(restitution, max_extent, max_drift, 0.0f);
-        w.r_t[s] = f4(pos12.t, 0.0f); w.r_r[s] = f4(pos12.r); w.r_rot1[s] = f4(pc1.r); w.r_rot2[s] = f4(pc2.r);
+        w.r_t[s] = f4(cpos12.t, 0.0f); w.r_r[s] = f4(cpos12.r); w.r_rot1[s] = f4(pc1.r); w.r_rot2[s] = f4(pc2.r);
         w.p_pflags[s] |= RP_PF_RECYCLE;
     } else {
         w.p_misc[s] = make_float4(restitution, 0.0f, 0.0f, 0.0f);
@@ -837,6 +760,126 @@ template <bool CONVEX> __device__ __forceinline__ void pair_full_update(DevWorld
     }
 }
 
+// A composite pair on its PLAIN path (rp_composite.h): the ONE candidate sub-shape pair the pair's manifold belongs to this step.
+struct SubSel {
+    int sh1, sh2; float4 he1, he2; float bd1, bd2; V3 tri1[3], tri2[3];
+    Pose wp1, wp2;            // world poses the manifold's points are local to (collider pose x part pose)
+    Pose rel;                 // sub-shape 2 in sub-shape 1's frame
+    bool has_pos1; Pose pos1; // side 1's part pose (carry_warmstart_data's subshape_pos1)
+    bool fresh;               // the stored manifold belongs to another sub-shape pair (or the pair held clusters): start from an empty one
+    bool none;                // no candidate at all: no manifold
+    int prev_ncl;             // solver clusters of the previous step: the warm-start source when clustering stops applying
+};
+__device__ void composite_carry_to_plain(DevWorld &w, int s, const LocalManifold &m, const SubSel &sub, float4 *cimp, float4 *cwst); // rp_composite.h
+template <bool CONVEX> __device__ __forceinline__ void pair_full_update(DevWorld &w, int s, int c1, int c2, Pose pc1, Pose pc2, Pose pos12, float *np_lds, const SubSel *sub = nullptr) {
+    const float prediction = w.prm.prediction;
+    int rb1 = w.c_parent[c1], rb2 = w.c_parent[c2];
+    int sh1 = w.c_shape[c1], sh2 = w.c_shape[c2];
+    float4 he1 = w.c_he[c1], he2 = w.c_he[c2];
+    if (w.has_sensors && pair_is_sensor(w, c1, c2)) { sensor_pair_update<CONVEX>(w, s, c1, c2, pos12); return; }
+    int had = w.p_nsc[s] > 0;
+    const bool no_contact = joints_disable_contacts(w, rb1, rb2); // pair_update.rs:191-201: clear_filtered_pair
+
+    LocalManifold m;
+    m.bind(np_lds);
+    m.n = w.p_npts[s];
+    m.ln1 = v3(w.p_ln1[s]); m.ln2 = v3(w.p_ln2[s]);
+    for (int k = 0; k < m.n; ++k) {
+        float4 a = PT(w.pt_lp1d, k, s), b = PT(w.pt_lp2f, k, s);
+        m.lp1[k] = v3(a); m.dist[k] = a.w; m.lp2[k] = v3(b); m.fid[k] = __float_as_uint(b.w); m.src[k] = k;
+    }
+    if (sub && sub->fresh) { m.n = 0; m.ln1 = v3(0, 0, 0); m.ln2 = v3(0, 0, 0); }
+    int nold = m.n;
+    // (a composite pair: the shapes that meet are the candidate sub-shapes, in the sub-shapes' relative pose; the collider-level values
+    // above keep serving the recycle state)
+    const int csh1 = sh1, csh2 = sh2; const float4 che1 = he1, che2 = he2; const Pose cpos12 = pos12;
+    float bd1 = w.c_mat[c1].w, bd2 = w.c_mat[c2].w;
+    const Pose wp1 = sub ? sub->wp1 : pc1, wp2 = sub ? sub->wp2 : pc2;
+    if (sub) { sh1 = sub->sh1; sh2 = sub->sh2; he1 = sub->he1; he2 = sub->he2; bd1 = sub->bd1; bd2 = sub->bd2; pos12 = sub->rel; }
+    // pair_update.rs:323-330 -> parry DefaultQueryDispatcher::contact_manifolds
+    if (sub && sub->none) m.n = 0;
+    else dispatch_manifold<CONVEX>(w, sh1, he1, bd1, sub ? sub->tri1 : nullptr, sh2, he2, bd2, sub ? sub->tri2 : nullptr, pos12, prediction, m);
+
+    // carry ContactData (impulse, warm starts) to the new point order
+    float4 cimp[RP_MAX_PTS], cwst[RP_MAX_PTS];
+    const bool from_clusters = sub && sub->prev_ncl > 0; // clustering stopped applying: the warm-start data comes back from the clusters, by position (pair_update.rs:385-396)
+    if (from_clusters) composite_carry_to_plain(w, s, m, *sub, cimp, cwst);
+    for (int k = 0; k < nold; ++k) { m.b_set4(4 * k, PT(w.pt_imp, k, s)); m.b_set4(32 + 4 * k, PT(w.pt_wst, k, s)); }
+    for (int k = 0; k < m.n; ++k) {
+        int j = m.src[k];
+        float4 im = j >= 0 ? m.b_get4(4 * j) : make_float4(0, 0, 0, 0);
+        float4 ws = j >= 0 ? m.b_get4(32 + 4 * j) : make_float4(0, 0, 0, 0);
+        if (from_clusters) { im = cimp[k]; ws = cwst[k]; }
+        PT(w.pt_imp, k, s) = im; PT(w.pt_wst, k, s) = ws;
+        PT(w.pt_lp1d, k, s) = f4(m.lp1[k], m.dist[k]);
+        PT(w.pt_lp2f, k, s) = f4(m.lp2[k], __uint_as_float(m.fid[k]));
+    }
+    w.p_npts[s] = m.n;
+    if (!no_contact) { w.p_ln1[s] = f4(m.ln1, 0.0f); w.p_ln2[s] = f4(m.ln2, 0.0f); } // (a filtered pair never reaches the generator in the reference: its cached normal stays)
+
+    float4 mat1 = w.c_mat[c1], mat2 = w.c_mat[c2];
+    int2 ru1 = w.c_rules[c1], ru2 = w.c_rules[c2];
+    float friction = combine_coeff(mat1.x, mat2.x, ru1.x, ru2.x);
+    float restitution = combine_coeff(mat1.y, mat2.y, ru1.y, ru2.y);
+    int rel_dom = effective_dominance(w, rb1) - effective_dominance(w, rb2);
+    V3 normal = qrot(wp1.r, m.ln1);
+    w.p_normal[s] = f4(normal, friction);
+    w.p_reldom[s] = rel_dom;
+
+    int nsc = 0;
+    if (no_contact) { m.n = 0; w.p_npts[s] = 0; }
+    if (m.n > 0) {
+        int sel[4] = {0, 1, 2, 3};
+        int nsel = m.n < 4 ? m.n : 4;
+        reduce_manifold(m, sel, nsel, prediction);
+        if (nsel > 1) { // pair_update.rs:430-457
+            V3 b0, b1; orthonormal_basis(m.ln1, b0, b1);
+            float k0[4], k1[4]; int ks[4];
+            for (int i = 0; i < nsel; ++i) { V3 lp = m.lp1[sel[i]]; k0[i] = dot(lp, b0); k1[i] = dot(lp, b1); ks[i] = sel[i]; }
+            for (int i = 1; i < nsel; ++i) {
+                float a0 = k0[i], a1 = k1[i]; int as = ks[i]; int j = i;
+                while (j > 0 && (k0[j - 1] > a0 || (k0[j - 1] == a0 && k1[j - 1] > a1))) { k0[j] = k0[j - 1]; k1[j] = k1[j - 1]; ks[j] = ks[j - 1]; j--; }
+                k0[j] = a0; k1[j] = a1; ks[j] = as;
+            }
+            for (int i = 0; i < nsel; ++i) sel[i] = ks[i];
+        }
+        bool has1 = rb1 >= 0 && rel_dom <= 0, has2 = rb2 >= 0 && rel_dom >= 0;
+        Pose com1, com2;
+        com1.r = q4(0, 0, 0, 1); com1.t = v3(0, 0, 0); com2 = com1;
+        V3 lv1 = v3(0, 0, 0), av1 = lv1, wc1 = lv1, lv2 = lv1, av2 = lv1, wc2 = lv1;
+        if (rb1 >= 0) { lv1 = v3(w.b_linvel[rb1]); av1 = v3(w.b_angvel[rb1]); wc1 = v3(w.b_wcom[rb1]); }
+        if (rb2 >= 0) { lv2 = v3(w.b_linvel[rb2]); av2 = v3(w.b_angvel[rb2]); wc2 = v3(w.b_wcom[rb2]); }
+        if (has1) { Pose bp; bp.r = q4(w.b_rot[rb1]); bp.t = v3(w.b_pos[rb1]); com1.r = bp.r; com1.t = pose_tp(bp, v3(w.b_lcom_invm[rb1])); }
+        if (has2) { Pose bp; bp.r = q4(w.b_rot[rb2]); bp.t = v3(w.b_pos[rb2]); com2.r = bp.r; com2.t = pose_tp(bp, v3(w.b_lcom_invm[rb2])); }
+        for (int q = 0; q < nsel; ++q) { // pair_update.rs:459-498 + :536-577
+            int cid = sel[q];
+            float eff_dist = m.dist[cid];
+            V3 wpt1 = pose_tp(wp1, m.lp1[cid]);
+            V3 wpt2 = pose_tp(wp2, m.lp2[cid]);
+            bool keep = eff_dist < prediction;
+            if (!keep) {
+                V3 vel1 = rb1 >= 0 ? lv1 + cross(av1, wpt1 - wc1) : v3(0, 0, 0);
+                V3 vel2 = rb2 >= 0 ? lv2 + cross(av2, wpt2 - wc2) : v3(0, 0, 0);
+                keep = eff_dist + dot(vel2 - vel1, normal) * w.prm.p.dt < prediction;
+            }
+            if (!keep) continue;
+            float shift = dot(wpt2 - wpt1, normal) - eff_dist;
+            V3 p1 = wpt1 + normal * shift;
+            V3 point = (p1 + wpt2) * 0.5f;
+            PT(w.pt_dp1, cid, s) = f4(has1 ? point - com1.t : point, 0.0f);
+            PT(w.pt_dp2, cid, s) = f4(has2 ? point - com2.t : point, 0.0f);
+            V3 a1 = has1 ? pose_itp(com1, p1) : p1;
+            V3 a2 = has2 ? pose_itp(com2, wpt2) : wpt2;
+            PT(w.sc_a1, nsc, s) = f4(a1, eff_dist);
+            PT(w.sc_a2, nsc, s) = f4(a2, __int_as_float(cid));
+            nsc++;
+        }
+    }
+    pair_update_finish(w, s, c1, c2, rb1, rb2, csh1, che1, csh2, che2, mat1.w, mat2.w, pc1, pc2, cpos12, nsc, had, no_contact, restitution);
+}
+
+#include "rp_composite.h"
+
 // The narrow phase runs as two kernels: k_np_test (one thread per pair slot, a few dozen flops: who is awake, the
 // contact-recycling test of pair_update.rs:111-171) queues the pairs that need contact determination, k_np_update runs
 // the full update (parry manifolds, reduction, solver contacts: ~2.7 KB of scratch per lane) over that queue only.  On a
@@ -850,6 +893,7 @@ __global__ void k_np_test(DevWorld w) {
     for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < top; s += stride) {
         int c1 = w.p_c1[s];
         if (c1 < 0) continue;
+        if (w.has_composite && pair_is_aux(w, s)) continue; // (a cluster of a composite pair: its parent slot is the pair)
         int c2 = w.p_c2[s];
         if (w.n_nc && (w.p_pflags[s] & RP_PF_NO_CONTACT)) continue; // filtered by a contact-disabling joint (cleared below)
         Pose pc1, pc2;
@@ -878,6 +922,7 @@ template <bool CONVEX> __global__ void __launch_bounds__(NP_THREADS) k_np_update
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
         int s = w.np_list[i];
         int c1 = w.p_c1[s], c2 = w.p_c2[s];
+        if (w.has_composite && (shape_is_composite(w.c_shape[c1]) || shape_is_composite(w.c_shape[c2]))) continue; // k_np_composite takes it
         Pose pc1, pc2;
         pc1.r = q4(w.c_rot[c1]); pc1.t = v3(w.c_pos[c1]);
         pc2.r = q4(w.c_rot[c2]); pc2.t = v3(w.c_pos[c2]);
@@ -1106,6 +1151,12 @@ void rp_launch_sleep(const DevWorld &w, hipStream_t st);
 // `part`: 0 = contact determination (NarrowPhase::compute_contacts: test, update, deferred colouring, begin-touch wake-ups),
 // 1 = island construction in the reference's stage accounting (sleep decision, joint colouring, solver contact graph
 // buckets, contact islands), -1 = both (the step graphs), 2 = test + update alone (the lean step graph: rp_world.h).
+// composite pairs of this step's queue (worlds with a compound / mesh collider only): one thread per pair, cm_ws_threads threads
+static void rp_launch_np_composite(const DevWorld &w, hipStream_t st) {
+    if (!w.has_composite || w.cm_ws_threads <= 0) return;
+    hipLaunchKernelGGL(k_np_composite<true>, dim3(w.cm_ws_threads / NP_THREADS), dim3(NP_THREADS), 0, st, w);
+    hipLaunchKernelGGL(k_cm_finish, dim3(1), dim3(256), 0, st, w);
+}
 void rp_launch_narrowphase_part(const DevWorld &w, hipStream_t st, int part) {
     int blocks = (w.pool_cap + 255) / 256; if (blocks > 2048) blocks = 2048;
     if (part == 2) {
@@ -1114,6 +1165,7 @@ void rp_launch_narrowphase_part(const DevWorld &w, hipStream_t st, int part) {
         int nb = (w.pool_cap + NP_THREADS - 1) / NP_THREADS;
         if (w.has_convex) hipLaunchKernelGGL(k_np_update<true>, dim3(nb < 512 ? nb : 512), dim3(NP_THREADS), 0, st, w);
         else hipLaunchKernelGGL(k_np_update<false>, dim3(nb < 512 ? nb : 512), dim3(NP_THREADS), 0, st, w);
+        rp_launch_np_composite(w, st);
         return;
     }
     if (part != 1) {
@@ -1126,6 +1178,7 @@ void rp_launch_narrowphase_part(const DevWorld &w, hipStream_t st, int part) {
             { int nb = (w.pool_cap + NP_THREADS - 1) / NP_THREADS;
               if (w.has_convex) hipLaunchKernelGGL(k_np_update<true>, dim3(nb < 512 ? nb : 512), dim3(NP_THREADS), 0, st, w); // (worlds with a cylinder / cone: GJK / EPA compiled in, a polytope per lane in scratch)
               else hipLaunchKernelGGL(k_np_update<false>, dim3(nb < 512 ? nb : 512), dim3(NP_THREADS), 0, st, w); } // 2 workgroups per CU (70 KB of LDS each)
+            rp_launch_np_composite(w, st); // composite pairs (rp_composite.h)
             hipLaunchKernelGGL(k_color_pairs, dim3(1), dim3(1024), 0, st, w);
         }
         rp_launch_wake(w, st, 1); // begin-touch wake-ups (contacts.rs:333-351)

@@ -21,7 +21,7 @@ RP_DEV bool pair_selected(const DevWorld &w, int s) {
     if (w.p_c1[s] < 0 || w.p_nsc[s] == 0) return false;
     if (!w.sleep_enabled) return true;
     int2 rb = w.p_rb[s];
-    if (pair_hint_cleared(w, s, rb)) return false;
+    if (pair_hint_cleared(w, (w.p_pflags[s] & RP_PF_AUX) ? w.p_aux[s].x : s, rb)) return false; // (a cluster of a composite pair: the PAIR's hint)
     return body_dyn_awake(w, rb.x) || body_dyn_awake(w, rb.y); // PAIR_HINT_DYN_BIT: at least one awake DYNAMIC body
 }
 
@@ -195,6 +195,7 @@ RP_DEV Pose collider_world_pose_of(const DevWorld &w, int i, int parent) { // pa
 RP_DEV bool pair_needs_narrow_phase(const DevWorld &w, int s) {
     int c1 = w.p_c1[s];
     if (c1 < 0) return false;
+    if (w.has_composite && (w.p_pflags[s] & RP_PF_AUX)) return false; // a cluster of a composite pair: the parent slot answers for the pair
     if (w.n_nc && (w.p_pflags[s] & RP_PF_NO_CONTACT)) return false; // filtered by a contact-disabling joint: nothing to compute
     int c2 = w.p_c2[s];
     if (w.has_sensors && pair_is_sensor(w, c1, c2)) return false; // intersection-tested by k_sensor_pass on the fast graph
@@ -202,4 +203,33 @@ RP_DEV bool pair_needs_narrow_phase(const DevWorld &w, int s) {
     Pose pc1 = collider_world_pose_of(w, c1, rb.x), pc2 = collider_world_pose_of(w, c2, rb.y);
     Pose pos12 = pose_inv_mul(pc1, pc2);
     return !pair_recycle_ok(w, s, pc1, pc2, pos12);
+}
+
+// ---- composite pairs: auxiliary pair slots (rp_composite.h) ---------------------------------------------------------------------------
+RP_DEV bool shape_is_composite(int sh) { return sh == RP_SHAPE_COMPOUND || sh == RP_SHAPE_TRIMESH; }
+RP_DEV bool pair_is_aux(const DevWorld &w, int s) { return (w.p_pflags[s] & RP_PF_AUX) != 0; }
+// the serial order of the overflow colour: ascending (collider1, collider2), then the cluster index of a composite pair's further solver
+// manifolds (collider indices are below 2^24: rp_colliders_insert) — the order the oracle sweeps it in
+RP_DEV unsigned long long pair_order_key(const DevWorld &w, int s) {
+    const unsigned long long k = (w.p_pflags[s] & RP_PF_AUX) ? (unsigned long long)(unsigned)w.p_aux[s].y : 0ull;
+    return ((unsigned long long)(unsigned)w.p_c1[s] << 34) | ((unsigned long long)(unsigned)w.p_c2[s] << 2) | k;
+}
+// solver-manifold slot k of pair slot s (k = 0: s itself)
+RP_DEV int sm_slot(const DevWorld &w, int s, int k) { const int4 a = w.p_aux[s]; return k == 0 ? s : (k == 1 ? a.x : (k == 2 ? a.y : a.z)); }
+
+// an aux slot leaves the pool (its parent's cluster count shrank, the pair left the plain path's way, or the pair is deleted)
+RP_DEV void aux_slot_free(DevWorld &w, int a, bool deferred) {
+    if (w.p_nsc[a] > 0) w.flags[FL_LAYOUT_DIRTY] = 1;
+    w.p_c1[a] = -1; w.p_nsc[a] = 0; w.p_npts[a] = 0; w.p_color[a] = RP_COLOR_UNCOLORED; w.p_pflags[a] = 0;
+    if (deferred) { int t = atomicAdd(&w.flags[FL_BP_NFREED], 1); w.free_pending[t] = a; return; }
+    int t = atomicAdd(&w.flags[FL_FREE_TOP], 1);
+    w.free_stack[t] = a;
+}
+// every aux slot of parent slot s (pair deletion, ContactPair::clear)
+RP_DEV void aux_free_all(DevWorld &w, int s, bool deferred) {
+    const int4 a = w.p_aux[s];
+    if (a.x >= 0) aux_slot_free(w, a.x, deferred);
+    if (a.y >= 0) aux_slot_free(w, a.y, deferred);
+    if (a.z >= 0) aux_slot_free(w, a.z, deferred);
+    w.p_aux[s] = make_int4(-1, -1, -1, 0);
 }

@@ -168,21 +168,30 @@ __global__ void k_force_events(DevWorld w, int fast) {
         float ta = (__float_as_int(e1.x) & RP_EVENTS_CONTACT_FORCE) ? e1.y : 3.402823466e+38f;
         float tb = (__float_as_int(e2.x) & RP_EVENTS_CONTACT_FORCE) ? e2.y : 3.402823466e+38f;
         float threshold = ta < tb ? ta : tb;
+        if (w.has_composite && pair_is_aux(w, s)) continue; // (a cluster of a composite pair: summed with its parent below)
         if (!(threshold < 3.402823466e+38f) || !pair_selected(w, s)) continue;
-        int npts = w.p_npts[s];
+        // every solver manifold of the pair (ContactPair::solver_manifolds: the plain manifold, or the clusters: this slot + its aux slots)
+        const int nsm = (w.has_composite && w.p_aux[s].w > 1) ? w.p_aux[s].w : 1;
         float total = 0.0f;
-        for (int k = 0; k < npts; ++k) total += PT(w.pt_imp, k, s).x; // every tracked point, like ContactManifoldExt::total_impulse
+        for (int q = 0; q < nsm; ++q) { const int sq = sm_slot(w, s, q); if (sq < 0) continue; const int npts = w.p_npts[sq]; for (int k = 0; k < npts; ++k) total += PT(w.pt_imp, k, sq).x; } // every tracked point, like ContactManifoldExt::total_impulse
         float total_magnitude = (0.0f + total) * inv_dt;
         int pf = w.p_pflags[s];
         if (total_magnitude > threshold) {
-            V3 normal = v3(w.p_normal[s]);
-            float max_mag = 0.0f, tmi = 0.0f; V3 max_dir = v3(0, 0, 0);
-            for (int k = 0; k < npts; ++k) {
-                float imp = PT(w.pt_imp, k, s).x;
-                tmi += imp;
-                if (imp > max_mag) { max_mag = imp; max_dir = normal; }
+            float max_mag = 0.0f; V3 max_dir = v3(0, 0, 0), total_force = v3(0, 0, 0);
+            for (int q = 0; q < nsm; ++q) {
+                const int sq = sm_slot(w, s, q);
+                if (sq < 0) continue;
+                const V3 normal = v3(w.p_normal[sq]);
+                const int npts = w.p_npts[sq];
+                float tmi = 0.0f;
+                for (int k = 0; k < npts; ++k) {
+                    float imp = PT(w.pt_imp, k, sq).x;
+                    tmi += imp;
+                    if (imp > max_mag) { max_mag = imp; max_dir = normal; }
+                }
+                total_force = total_force + normal * tmi;
             }
-            V3 total_force = (v3(0, 0, 0) + normal * tmi) * inv_dt;
+            total_force = total_force * inv_dt;
             int k = atomicAdd(&w.flags[FL_EV_FORCE], 1);
             if (k < w.ev_cap) {
                 w.ev_force_meta[k] = make_int4(c1, c2, step, (pf & RP_PF_FORCE_EMITTED) ? 0 : 1);

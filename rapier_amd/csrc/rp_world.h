@@ -39,6 +39,7 @@
 #define RP_BF_LOCK_SHIFT 16           // LockedAxes (6 bits): translation x,y,z then rotation x,y,z
 
 // pair flag bits
+#define RP_PF_AUX 0x10                 // an auxiliary slot: solver manifold (cluster) 2+ of a composite pair (p_aux)
 #define RP_PF_RECYCLE 0x1
 #define RP_PF_FORCE_EMITTED 0x2
 #define RP_PF_INTERSECTING 0x8       // IntersectionPair::intersecting of a sensor pair (narrow_phase/intersections.rs)
@@ -207,6 +208,14 @@ struct DevWorld {
     // convex polyhedra (rp_polyhedron.h), flattened: per shape {first point, points, first face, faces}; points (w: max |p|); face normals;
     // per face {first loop entry, entries}; loop entries {vertex of the shape, edge of the shape}.  A collider's c_he.w holds its shape's row, as bits
     int4 *cv_hdr; float4 *cv_pts; float4 *cv_fn; int2 *cv_fl; int2 *cv_loop;
+    // composite shapes (rp_composite.h; RP_SHAPE_COMPOUND / RP_SHAPE_TRIMESH: c_he.w = the shape's row in cm_hdr, as bits)
+    int has_composite;     // some collider is a composite shape: k_np_composite runs behind k_np_update
+    int4 *cm_hdr;          // per composite: kind (RP_SHAPE_COMPOUND | RP_SHAPE_TRIMESH), first sub-shape row, sub-shape count, -
+    float4 *cm_min, *cm_max; // per sub-shape: its AABB in the composite's (recentred) frame
+    float4 *cm_a, *cm_b, *cm_c; // compound part: a = c_he of the part (w: polyhedron row bits), b = pose translation (w: shape bits), c = pose rotation;
+                           // mesh triangle: a, b, c = its vertices
+    float *cm_border;      // compound part: border radius of a round part (0 otherwise)
+    float4 *cm_ws; int cm_ws_threads; // k_np_composite's per-thread workspace: clusters while they are built (RP_CM_WS_F4 float4 per thread)
     int joints_spherical;  // every impulse joint locks the three linear axes and nothing else (no limit, no motor): tile sweeps may rebuild the rows themselves
     int lean;              // bit 0 (bit 1: a bare lean graph, see lean_dead) set in the copy the LEAN step graph is captured with (rp_api.hip "lean graph"): its kernels check lean_dead / collision_done
     SimParams prm;
@@ -293,6 +302,10 @@ struct DevWorld {
     int2 *p_colorb;
     int *p_hint_seq;            // step at which the pair's solver hint was last computed (pair_update.rs:141-161,636-650)
     int2 *p_rb;                 // parent bodies of the two colliders (c_parent is static), saves a dependent load
+    int4 *p_aux;                // composite pairs: x, y, z = the AUX slots of solver manifolds (clusters) 2..4 or -1, w = cluster count (0 = plain manifold);
+                                // an aux slot (RP_PF_AUX): x = its parent slot, y = its cluster index.  An aux slot holds ONE solver manifold of its
+                                // parent's pair and is a pair slot to the solver only: no hash entry, skipped by the broad and narrow phase
+    int2 *p_sub;                // composite pairs: the sub-shapes manifold 0 belongs to while the pair takes the plain path (-1: the collider itself)
     float4 *p_ln1, *p_ln2;      // manifold local normals
     float4 *p_normal;           // world normal xyz, friction
     float4 *p_misc;             // restitution, recycle max_extent, recycle max_drift, -

@@ -159,6 +159,13 @@ class PhysicsWorld:
         w = cls(gravity=scene.gravity, integration_parameters=IntegrationParameters(scene.params), device=device, index_addressing=index_addressing)
         for pts, tris in getattr(scene, "polyhedra", []):
             w.add_convex_polyhedron(pts, tris)
+        for comp in getattr(scene, "composites", []):
+            if comp[0] == "compound":
+                w.add_compound(comp[1])
+            elif comp[0] == "trimesh":
+                w.add_trimesh(comp[1], comp[2])
+            else:
+                w.add_heightfield(comp[1], comp[2])
         bodies = scene.body_array()
         if len(bodies):
             w.insert_bodies(bodies)
@@ -188,6 +195,28 @@ class PhysicsWorld:
         out = np.zeros(1, np.int32)
         _check(self._ptr, self._lib.rp_convex_polyhedron_create(self._ptr, len(pts), pts.ctypes.data, 0 if tris is None else len(tris),
                                                                 None if tris is None else tris.ctypes.data, out.ctypes.data), "rp_convex_polyhedron_create")
+        return int(out[0])
+
+    def add_compound(self, parts) -> int:
+        """SharedShape::compound(parts) (rp_compound_create): `parts` = collider descriptors; colliders use the id:
+        collider_desc(shape=SHAPE_COMPOUND, half_extents=(id, 0, 0))."""
+        parts = np.ascontiguousarray(np.array(list(parts), dtype=S.COLLIDER_DTYPE))
+        out = np.zeros(1, np.int32)
+        _check(self._ptr, self._lib.rp_compound_create(self._ptr, len(parts), parts.ctypes.data, out.ctypes.data), "rp_compound_create")
+        return int(out[0])
+
+    def add_trimesh(self, vertices, triangles) -> int:
+        """SharedShape::trimesh(vertices, indices) (rp_trimesh_create): collider_desc(shape=SHAPE_TRIMESH, half_extents=(id, 0, 0))."""
+        v = np.ascontiguousarray(vertices, np.float32).reshape(-1, 3); t = np.ascontiguousarray(triangles, np.uint32).reshape(-1, 3)
+        out = np.zeros(1, np.int32)
+        _check(self._ptr, self._lib.rp_trimesh_create(self._ptr, len(v), v.ctypes.data, len(t), t.ctypes.data, out.ctypes.data), "rp_trimesh_create")
+        return int(out[0])
+
+    def add_heightfield(self, heights, scale) -> int:
+        """SharedShape::heightfield(heights, scale) (rp_heightfield_create): used like a triangle mesh (shape=SHAPE_TRIMESH)."""
+        h = np.ascontiguousarray(heights, np.float32); sc = np.ascontiguousarray(np.asarray(scale, np.float32).reshape(3))
+        out = np.zeros(1, np.int32)
+        _check(self._ptr, self._lib.rp_heightfield_create(self._ptr, h.shape[0], h.shape[1], h.ctypes.data, sc.ctypes.data, out.ctypes.data), "rp_heightfield_create")
         return int(out[0])
 
     def read_convex_polyhedron(self, pid: int) -> dict:

@@ -43,7 +43,8 @@ def test_shape_and_body_enums_agree_across_header_python_and_oracle():
     ora = enum_values(os.path.join(ROOT, "oracle", "rapier_oracle.h"), "RO_SHAPE")
     assert hdr == ora == {"BALL": S.SHAPE_BALL, "CUBOID": S.SHAPE_CUBOID, "CAPSULE": S.SHAPE_CAPSULE, "HALFSPACE": S.SHAPE_HALFSPACE,
                           "CYLINDER": S.SHAPE_CYLINDER, "CONE": S.SHAPE_CONE, "CONVEX_POLYHEDRON": S.SHAPE_CONVEX_POLYHEDRON, "ROUND_CUBOID": S.SHAPE_ROUND_CUBOID,
-                          "ROUND_CYLINDER": S.SHAPE_ROUND_CYLINDER, "ROUND_CONE": S.SHAPE_ROUND_CONE, "ROUND_CONVEX_POLYHEDRON": S.SHAPE_ROUND_CONVEX_POLYHEDRON}
+                          "ROUND_CYLINDER": S.SHAPE_ROUND_CYLINDER, "ROUND_CONE": S.SHAPE_ROUND_CONE, "ROUND_CONVEX_POLYHEDRON": S.SHAPE_ROUND_CONVEX_POLYHEDRON,
+                          "COMPOUND": S.SHAPE_COMPOUND, "TRIMESH": S.SHAPE_TRIMESH, "TRIANGLE": S.SHAPE_TRIANGLE}
     hb = enum_values(os.path.join(ROOT, "include", "rapier_hip.h"), "RP_BODY")
     ob = enum_values(os.path.join(ROOT, "oracle", "rapier_oracle.h"), "RO_BODY")
     assert hb == ob and hb["DYNAMIC"] == S.BODY_DYNAMIC and hb["FIXED"] == S.BODY_FIXED and hb["KINEMATIC_POSITION"] == S.BODY_KINEMATIC_POSITION
