@@ -1664,7 +1664,7 @@ static int finalize(rp_world *w) {
     DAF(d.h_key[0], d.hash_cap, 0xff); DAF(d.h_key[1], d.hash_cap, 0xff); DA(d.h_slot[0], d.hash_cap); DA(d.h_slot[1], d.hash_cap);
     DAC(d.free_stack, d.pool_cap, DOM_PAIR, 1, 1);
     size_t P = (size_t)d.pool_cap;
-    DAFC(d.p_c1, P, 0xff, DOM_PAIR, 1, 1); DAC(d.p_c2, P, DOM_PAIR, 1, 1); DAC(d.p_stamp, P, DOM_PAIR, 1, 1); DAC(d.p_color, P, DOM_PAIR, 1, 1); DAC(d.p_nsc, P, DOM_PAIR, 1, 1); DAC(d.p_npts, P, DOM_PAIR, 1, 1); DAC(d.p_pflags, P, DOM_PAIR, 1, 1); DAC(d.p_reldom, P, DOM_PAIR, 1, 1);
+    DAFC(d.p_c1, P, 0xff, DOM_PAIR, 1, 1); DAFC(d.p_c2, P, 0xff, DOM_PAIR, 1, 1); DAC(d.p_stamp, P, DOM_PAIR, 1, 1); DAC(d.p_color, P, DOM_PAIR, 1, 1); DAC(d.p_nsc, P, DOM_PAIR, 1, 1); DAC(d.p_npts, P, DOM_PAIR, 1, 1); DAC(d.p_pflags, P, DOM_PAIR, 1, 1); DAC(d.p_reldom, P, DOM_PAIR, 1, 1);
     DAFC(d.p_aux, P, 0xff, DOM_PAIR, 1, 1); DAFC(d.p_sub, P, 0xff, DOM_PAIR, 1, 1); // (composite pairs: no aux slot, no sub-shape yet = -1; the cluster count is set by bp_insert_pair)
     DAC(d.p_hint_seq, P, DOM_PAIR, 1, 1); DAC(d.p_colorb, P, DOM_PAIR, 1, 1); DAC(d.p_rb, P, DOM_PAIR, 1, 1); DAC(d.p_ln1, P, DOM_PAIR, 1, 1); DAC(d.p_ln2, P, DOM_PAIR, 1, 1); DAC(d.p_normal, P, DOM_PAIR, 1, 1); DAC(d.p_misc, P, DOM_PAIR, 1, 1);
     DAC(d.r_t, P, DOM_PAIR, 1, 1); DAC(d.r_r, P, DOM_PAIR, 1, 1); DAC(d.r_rot1, P, DOM_PAIR, 1, 1); DAC(d.r_rot2, P, DOM_PAIR, 1, 1);

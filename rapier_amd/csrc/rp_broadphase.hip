@@ -307,7 +307,9 @@ RP_DEV void bp_delete_pair(DevWorld &w, int s, bool deferred = false) {
         if (w.p_nsc[s] > 0) pi_journal(w, rb.x, rb.y, 1, c1, c2); // unlink_contact of a removed touching pair (pair_management.rs:531)
     }
     if (w.has_composite) aux_free_all(w, s, deferred); // the clusters of a composite pair go with it
-    w.p_c1[s] = -1; w.p_nsc[s] = 0; w.p_npts[s] = 0; w.p_color[s] = RP_COLOR_UNCOLORED;
+    // (BOTH collider fields are scrubbed: an incremental pass inserts and deletes in one pass, and its delete sweep may look at a slot
+    // that an insert is filling at that moment — with -1 in whichever field has not landed yet the sweep skips it, see bp_incr_delete)
+    w.p_c1[s] = -1; w.p_c2[s] = -1; w.p_nsc[s] = 0; w.p_npts[s] = 0; w.p_color[s] = RP_COLOR_UNCOLORED;
     if (deferred) { int t = atomicAdd(&w.flags[FL_BP_NFREED], 1); w.free_pending[t] = s; return; }
     int t = atomicAdd(&w.flags[FL_FREE_TOP], 1);
     w.free_stack[t] = s;
@@ -396,8 +398,9 @@ RP_DEV void bp_incr_delete(DevWorld &w, int gid, int gstride, int nchg) {
     for (int s = gid; s < top; s += gstride) {
         const int c1 = w.p_c1[s];
         if (c1 < 0) continue;
-        if (w.has_composite && pair_is_aux(w, s)) continue;
         const int c2 = w.p_c2[s];
+        if (c2 < 0) continue; // (a recycled slot that an insert of this very pass is filling: half written — a new pair, nothing to delete)
+        if (w.has_composite && pair_is_aux(w, s)) continue;
         if (w.c_chgstamp[c1] != stamp && w.c_chgstamp[c2] != stamp) continue;
         V3 imin;
         if (fat_overlap(w, c1, c2, imin)) continue;

@@ -220,7 +220,7 @@ RP_DEV int sm_slot(const DevWorld &w, int s, int k) { const int4 a = w.p_aux[s];
 // an aux slot leaves the pool (its parent's cluster count shrank, the pair left the plain path's way, or the pair is deleted)
 RP_DEV void aux_slot_free(DevWorld &w, int a, bool deferred) {
     if (w.p_nsc[a] > 0) w.flags[FL_LAYOUT_DIRTY] = 1;
-    w.p_c1[a] = -1; w.p_nsc[a] = 0; w.p_npts[a] = 0; w.p_color[a] = RP_COLOR_UNCOLORED; w.p_pflags[a] = 0;
+    w.p_c1[a] = -1; w.p_c2[a] = -1; w.p_nsc[a] = 0; w.p_npts[a] = 0; w.p_color[a] = RP_COLOR_UNCOLORED; w.p_pflags[a] = 0;
     if (deferred) { int t = atomicAdd(&w.flags[FL_BP_NFREED], 1); w.free_pending[t] = a; return; }
     int t = atomicAdd(&w.flags[FL_FREE_TOP], 1);
     w.free_stack[t] = a;
