@@ -36,8 +36,8 @@ import glob
 TRAFFIC_SCENE = {"c3": "many_pyramids", "large_pyramid": "large_pyramid", "joint_grid": "joint_grid"}
 # sources whose change invalidates a recorded HBM-traffic measurement: the island kernel's for the metric workload; the whole
 # global solver path (tiles, per-stage launches, joints) for the single-island / jointed scenes
-_ISLAND_SOURCES = ["rapier_amd/csrc/rp_islands.hip", "rapier_amd/csrc/rp_constraint.h", "rapier_amd/csrc/rp_pairs.h", "rapier_amd/csrc/rp_world.h"]
-_GLOBAL_SOURCES = _ISLAND_SOURCES[1:] + ["rapier_amd/csrc/rp_tiles.hip", "rapier_amd/csrc/rp_solver.hip", "rapier_amd/csrc/rp_global.h", "rapier_amd/csrc/rp_lanepair.h",
+_ISLAND_SOURCES = ["rapier_amd/csrc/rp_islands.hip", "rapier_amd/csrc/rp_island_stages.h", "rapier_amd/csrc/rp_lanepair.h", "rapier_amd/csrc/rp_constraint.h", "rapier_amd/csrc/rp_pairs.h", "rapier_amd/csrc/rp_world.h"]
+_GLOBAL_SOURCES = _ISLAND_SOURCES[3:] + ["rapier_amd/csrc/rp_tiles.hip", "rapier_amd/csrc/rp_solver.hip", "rapier_amd/csrc/rp_global.h", "rapier_amd/csrc/rp_lanepair.h",
                                        "rapier_amd/csrc/rp_joints.h", "rapier_amd/csrc/rp_joints.hip", "rapier_amd/csrc/rp_flow.hip"]
 KERNEL_SOURCES = {"c3": _ISLAND_SOURCES, "large_pyramid": _GLOBAL_SOURCES, "joint_grid": _GLOBAL_SOURCES}
 # kernels of the TGS loop on the global path (what `velocity_update_ms` brackets minus assembly / write-back): their PMC bytes per
@@ -104,23 +104,30 @@ def recorded_c4_anchor():
 def cpu_baseline(steps: int = 400, warmup: int = 60):
     """The C oracle (a scalar port of the reference algorithm, OpenMP over the same body-disjoint colour
     stages the reference hands to its rayon pool) timed on the host cores on a bounded sample of the
-    same workload.  `value` = the multi-threaded rate; the single-thread rate is reported beside it."""
+    same workload.  `value` = the best multi-threaded rate of a short sweep over thread counts (threads pinned to cores, one per
+    core: OMP_PLACES=cores, OMP_PROC_BIND=close — set before the OpenMP runtime starts); the single-thread rate is reported beside it."""
+    os.environ.setdefault("OMP_PLACES", "cores"); os.environ.setdefault("OMP_PROC_BIND", "close"); os.environ.setdefault("OMP_WAIT_POLICY", "active")
     import oracle_ffi
     from rapier_amd import scenes as S
-    cores = max(1, min(os.cpu_count() or 1, 32))
+    ncpu = os.cpu_count() or 1
+    counts = sorted({c for c in (8, 16, 32, 64) if c <= ncpu} | {min(ncpu, 32)})
+    w = oracle_ffi.OracleWorld(S.many_pyramids())
+    oracle_ffi.set_threads(min(ncpu, 32))
+    w.step(warmup)
     out = {}
-    for threads in (1, cores):
+    for threads in [1] + counts:
         oracle_ffi.set_threads(threads)
-        w = oracle_ffi.OracleWorld(S.many_pyramids())
-        w.step(warmup)
-        n = steps if threads > 1 else steps // 4
+        n = steps // 4
+        w.step(4)   # (the team of this size is up and its pages are touched before the clock starts)
         t = time.perf_counter()
         w.step(n)
         out[threads] = n / (time.perf_counter() - t)
     oracle_ffi.set_threads(1)
-    return {"value": out[cores], "unit": "steps/s", "cores": cores, "kind": "port", "single_thread_value": out[1],
-            "sample": f"{steps} steps of b3d_many_pyramids (10,780 cuboids) after {warmup} warm-up steps, oracle/librapier_oracle.so "
-                      f"(C restatement, OpenMP, {cores} threads; {steps // 4} steps on 1 thread)"}
+    best = max(counts, key=lambda c: out[c])
+    return {"value": out[best], "unit": "steps/s", "cores": best, "kind": "port", "single_thread_value": out[1],
+            "thread_sweep": {str(c): round(out[c], 2) for c in counts},
+            "sample": f"{steps // 4} steps of b3d_many_pyramids (10,780 cuboids) per thread count after {warmup} warm-up steps, oracle/librapier_oracle.so "
+                      f"(C restatement, OpenMP, threads pinned one per core; best of {counts} threads = {best}; {steps // 4} steps on 1 thread)"}
 
 
 def build_workload(name: str, world: int, rank: int):
@@ -200,33 +207,43 @@ def run(args, make_world=None, backend: str = "nccl", use_cuda: bool = True):
         if args.shard_by == "device" and grid is not None:
             # the shards come from the device's own proximity groups of the WHOLE scene (built once per rank, stepped once, dropped):
             # whole groups are bin-packed over the ranks, and every rank's world is guarded against the boxes of the other ranks' groups
-            try:
-                full = S.many_pyramids(grid[0], grid[1])
-                wf = make_world(full, local_rank)
-                wf.step(1)
-                groups = wf.proximity_groups() if hasattr(wf, "proximity_groups") else sharding.proximity_groups_from_scene(full)
-                if hasattr(wf, "close"):
-                    wf.close()
-                del wf
+            # RANK 0 discovers (it builds and steps the whole world once, ~10 s for the 160,380 cuboids of C4) and BROADCASTS the group of
+            # every body (4 B each); the other ranks only generate the closed-form scene on the host and cut their shard out of it.  One
+            # whole-world build per job instead of one per rank; every rank cuts the world from the same array.  
+            full = S.many_pyramids(grid[0], grid[1])
+            groups, discovered, err = None, 0, ""
+            if rank == 0 or dist is None:
+                try:
+                    wf = make_world(full, local_rank)
+                    wf.step(1)
+                    groups = np.ascontiguousarray(wf.proximity_groups() if hasattr(wf, "proximity_groups") else sharding.proximity_groups_from_scene(full), np.int32)
+                    if hasattr(wf, "close"):
+                        wf.close()
+                    del wf
+                    discovered = int(len(groups) == len(full.bodies))
+                except Exception as e:  # noqa: BLE001 — the generator's shards are the fallback
+                    err = f"{type(e).__name__}: {e}"
+            if dist is not None:
+                # every rank must cut the world the same way: a failed discovery sends ALL ranks to the generator's shards
+                ok = torch.tensor([discovered], dtype=torch.int64, device="cuda" if coll_on_device else None)
+                dist.broadcast(ok, src=0)
+                discovered = int(ok.item())
+                if discovered:
+                    gt = torch.from_numpy(groups if rank == 0 else np.zeros(len(full.bodies), np.int32))
+                    if coll_on_device:
+                        gt = gt.cuda()
+                    dist.broadcast(gt, src=0)
+                    groups = gt.cpu().numpy()
+            if discovered:
                 body_rank, n_groups = sharding.shards_from_groups(groups, world)
                 scene, gids = sharding.partition_scene(full, body_rank, rank)
                 n_global = len(full.bodies)
                 guard = sharding.guard_boxes(full, groups, body_rank, rank)
-                shard_source = f"device proximity groups ({n_groups} groups of the whole scene, bin-packed; {len(guard[0])} foreign boxes guarded on rank {rank})"
+                shard_source = f"device proximity groups discovered on rank 0 and broadcast ({n_groups} groups of the whole scene, bin-packed; {len(guard[0])} foreign boxes guarded on rank {rank})"
                 workload += f"; shards from the device's proximity groups ({int((body_rank == rank).sum()) // 55} islands on rank {rank})"
-                del full
-                discovered = 1
-            except Exception as e:  # noqa: BLE001 — the generator's shards are the fallback
-                shard_source = f"generator (device discovery failed on rank {rank}: {type(e).__name__}: {e})"
-                discovered = 0
-            # every rank must cut the world the same way: one rank that failed to discover the groups (out of memory while building the
-            # whole scene, say) sends ALL ranks to the generator's shards — mixed partitions would duplicate or lose bodies
-            if dist is not None:
-                ok = torch.tensor([discovered], dtype=torch.int64, device="cuda" if coll_on_device else None)
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-                if int(ok.item()) == 0 and discovered:
-                    shard_source = "generator (device discovery failed on another rank)"
-                discovered = int(ok.item())
+            else:
+                shard_source = f"generator (device discovery failed on rank 0{': ' + err if err else ''})"
+            del full
             if not discovered:
                 scene, workload, gids, n_global, grid = build_workload(wl, world, rank)
                 guard = None
@@ -303,6 +320,12 @@ def run(args, make_world=None, backend: str = "nccl", use_cuda: bool = True):
         gathered = sharding.all_gather_bodies(pos, vel, gids, n_global, dyn, device=dev)
         finite = finite and bool(np.isfinite(gathered[0]).all())
 
+    per_rank_paths = None
+    if dist is not None: # which way every rank's steps went (fused fast steps / full steps / aborted-and-replayed ones): one small all-gather
+        mine = torch.tensor([counters.get("fast_steps", 0), counters.get("full_steps", 0), counters.get("replayed_steps", 0)], dtype=torch.int64, device=dev)
+        allp = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allp, mine)
+        per_rank_paths = [{"fast": int(t[0]), "full": int(t[1]), "replayed": int(t[2])} for t in (x.cpu() for x in allp)]
     out = None
     if rank == 0:
         is_metric_workload = world == 1 and args.workload in ("auto", "c3")
@@ -336,7 +359,8 @@ def run(args, make_world=None, backend: str = "nccl", use_cuda: bool = True):
             "roofline": roof,
             "finite": finite,
             "dist": None if dist is None else {"backend": backend, "world_size": world, "forced": bool(args.force_dist), "shard_source": shard_source,
-                                               "gathered_bodies": None if gathered is None else int(gathered[0].shape[0])},
+                                               "gathered_bodies": None if gathered is None else int(gathered[0].shape[0]),
+                                               "per_rank_step_paths": per_rank_paths},
         }
         if not args.no_cpu_baseline and is_metric_workload:
             out["cpu_baseline"] = cpu_baseline()

@@ -3306,15 +3306,30 @@ void ro_read_island_stats(const ro_world *w, int32_t *out) { memcpy(out, w->pi_s
 void ro_read_slept_at(const ro_world *w, int32_t *out) { for (int i = 0; i < w->nbodies; ++i) out[i] = w->bodies[i].slept_at; }
 
 /* PhysicsPipeline::step_inner — pipeline/physics_pipeline/substep.rs:267-581 */
+/* RO_PROFILE=1: wall time per phase of a step, accumulated (printed by ro_profile_dump; tools only) */
+#include <time.h>
+static double ro_prof_t[16]; static int ro_prof_on = -1;
+static double ro_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+#define RO_PROF(k) do { if (ro_prof_on > 0) { double n_ = ro_now(); ro_prof_t[k] += n_ - t_prof; t_prof = n_; } } while (0)
+void ro_profile_dump(void) {
+    static const char *nm[] = {"wakes+joint links", "broad phase", "narrow phase", "merge links+kinematic", "sleep", "forces", "solve", "force events+ccd", "advance+aabbs"};
+    for (int k = 0; k < 9; ++k) fprintf(stderr, "  %-24s %9.3f ms\n", nm[k], ro_prof_t[k] * 1e3);
+    for (int k = 0; k < 16; ++k) ro_prof_t[k] = 0.0;
+}
 static void step_once(ro_world *w) {
+    if (ro_prof_on < 0) ro_prof_on = getenv("RO_PROFILE") ? 1 : 0;
+    double t_prof = ro_prof_on > 0 ? ro_now() : 0.0;
     w->step_seq++;
     apply_wakes(w);     /* user wake-ups precede the joint edits (substep.rs:288-300) */
     pi_link_joints(w);
+    RO_PROF(0);
     /* detect_collisions — solve.rs:45-157 (user-requested wake-ups and pair deletions take effect before the
      * narrow phase reads the awake mask) */
     broad_phase_update(w);
+    RO_PROF(1);
     apply_wakes(w);
     narrow_phase_compute_contacts(w);
+    RO_PROF(2);
     apply_wakes(w);
     pi_merge_links(w); /* link_contact of this step's begin-touch transitions */
     /* interpolate_kinematic_velocities — substep.rs:242-264, RigidBodyPosition::interpolate_velocity
@@ -3329,8 +3344,10 @@ static void step_once(ro_world *w) {
         b->linvel = vmul(dpos.t, inv_dt);
         b->angvel = vmul(quat_to_scaled_axis(dpos.r), inv_dt);
     }
+    RO_PROF(3);
     /* fused body pass — solve.rs:234-291: sleep timers, then the island sleep decision (update_islands) */
     update_sleep(w);
+    RO_PROF(4);
     /* compute_effective_force_and_torque rigid_body_components.rs:1030-1033 */
     for (int i = 0; i < w->nbodies; ++i) {
         Body *b = &w->bodies[i];
@@ -3339,10 +3356,13 @@ static void step_once(ro_world *w) {
         b->force = vadd(b->user_force, vmul(vcmul(w->gravity, mass), b->gravity_scale));
         b->torque = b->user_torque;
     }
+    RO_PROF(5);
     solve_velocity_constraints(w);
+    RO_PROF(6);
     emit_contact_force_events(w);
     /* run_ccd_motion_clamping (substep.rs:54-82, :496-519): only when some body moved fast */
     if (w->params.max_ccd_substeps != 0) ccd_solve_continuous(w);
+    RO_PROF(7);
     /* advance_to_final_positions — substep.rs:84-224; refresh_moved_collider_aabbs :229-240 */
     for (int i = 0; i < w->nbodies; ++i) {
         Body *b = &w->bodies[i];
@@ -3356,6 +3376,7 @@ static void step_once(ro_world *w) {
         c->pos = pose_mul(w->bodies[c->parent].position, c->pos_wrt_parent);
         bp_set_aabb(w, c);
     }
+    RO_PROF(8);
 }
 
 void ro_step(ro_world *w, int32_t nsteps) { for (int i = 0; i < nsteps; ++i) step_once(w); }

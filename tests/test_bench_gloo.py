@@ -24,9 +24,12 @@ def _free_port():
 class OracleAdapter:
     """The slice of PhysicsWorld's interface bench.run uses, over the oracle."""
 
+    built = []          # body counts of the worlds this process built (the whole-world discovery build happens on rank 0 only)
+
     def __init__(self, scene, device):
         from oracle_ffi import OracleWorld
         from rapier_amd import scenes as S
+        OracleAdapter.built.append(len(scene.bodies))
         self._w = OracleWorld(scene)
         self._nd = sum(1 for b in scene.bodies if int(b["body_type"]) == S.BODY_DYNAMIC)
 
@@ -41,7 +44,8 @@ class OracleAdapter:
 
     def counters(self):
         st = self._w.stats()
-        return {"num_manifolds": st["num_active_manifolds"], "num_dynamic_bodies": self._nd, "num_colors": st["num_colors_used"]}
+        return {"num_manifolds": st["num_active_manifolds"], "num_dynamic_bodies": self._nd, "num_colors": st["num_colors_used"],
+                "fast_steps": 0, "full_steps": st.get("steps", 0), "replayed_steps": 0}
 
 
 def _worker(rank, world, port, out_dir):
@@ -51,6 +55,8 @@ def _worker(rank, world, port, out_dir):
     import bench
     args = bench.parse_args(["--gpus", str(world), "--steps", "6", "--warmup", "3", "--workload", "grid:2x3", "--no-cpu-baseline"])
     out, gathered = bench.run(args, make_world=OracleAdapter, backend="gloo", use_cuda=False)
+    with open(os.path.join(out_dir, f"built{rank}.json"), "w") as f:
+        json.dump(OracleAdapter.built, f)
     if rank == 0:
         np.savez(os.path.join(out_dir, "gathered.npz"), pos=gathered[0], vel=gathered[1])
         with open(os.path.join(out_dir, "line.json"), "w") as f:
@@ -73,6 +79,11 @@ def test_bench_control_flow_two_ranks(tmp_path):
     assert line["config"]["total_cuboids"] == 6 * 55 and line["config"]["bodies_per_gpu"] == 3 * 55 and line["finite"]
     # whole-job value: C3-equivalent steps/s of all ranks, consistent with the reported time
     assert abs(line["value"] - (330 / 10780) * 6 / (line["ms_per_step"] * 6e-3)) <= 1e-6 * line["value"]
+    # discovery: rank 0 alone built the whole world (1 + 6*55 bodies), the groups reached rank 1 by broadcast; both ranks then built their shard
+    built = [json.load(open(os.path.join(str(tmp_path), f"built{r}.json"))) for r in range(2)]
+    assert built[0] == [331, 1 + 3 * 55] and built[1] == [1 + 3 * 55]
+    assert line["dist"]["shard_source"].startswith("device proximity groups discovered on rank 0 and broadcast (6 groups")
+    assert [set(p) for p in line["dist"]["per_rank_step_paths"]] == [{"fast", "full", "replayed"}] * 2
     assert abs(line["config"]["sharded_world_steps_per_s"] - 1e3 / line["ms_per_step"]) <= 1e-6 * line["config"]["sharded_world_steps_per_s"]
 
 
@@ -93,7 +104,7 @@ def test_force_dist_runs_the_collective_leg_on_one_rank(tmp_path):
     mp.spawn(_worker_forced, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
     rec = json.load(open(os.path.join(str(tmp_path), "forced.json")))
     d = rec["line"]["dist"]
-    assert d["shard_source"].startswith("device proximity groups (4 groups")   # shards derived from the (stand-in) device's groups
+    assert d["shard_source"].startswith("device proximity groups discovered on rank 0 and broadcast (4 groups")   # shards derived from the (stand-in) device's groups
     assert {k: d[k] for k in ("backend", "world_size", "forced", "gathered_bodies")} == {"backend": "gloo", "world_size": 1, "forced": True, "gathered_bodies": 1 + 4 * 55}
     assert rec["line"]["n_gpus"] == 1 and rec["n"] == 221 and rec["line"]["finite"]
 
