@@ -346,6 +346,14 @@ int32_t rp_world_set_shard_guard(rp_world *w, int32_t n, const float *box_min3, 
  * caller moves the bodies' proximity group to the shard that owns the box they reached ("when an AddPair links bodies
  * on different shards, migrate the smaller island": rapier_amd/sharding.py migrate_groups) and sets fresh guards on both sides. */
 int32_t rp_world_shard_guard_take_hits(rp_world *w, int32_t cap, uint64_t *bodies_out);
+/* How long a hit may wait for the caller, in seconds (steps between two rp_world_shard_guard_take_hits x dt; default 0): the device
+ * tests every rewritten fat AABB inflated by |linvel of its body| x seconds, so a fast body is caught that much earlier while slow
+ * neighbours of a foreign box are left alone.  The boxes themselves should carry the same allowance for THEIR group's speed. */
+int32_t rp_world_set_shard_guard_horizon(rp_world *w, float seconds);
+/* max |linvel| over the non-fixed bodies (device reduction, one 4-byte read-back; pending steps run first).  A caller that consumes the
+ * guard's hits every k steps inflates the boxes by 2 * speed * dt * k so that no body crosses a box between two looks
+ * (no reference counterpart: the reference has one address space). */
+int32_t rp_world_max_linear_speed(rp_world *w, float *out);
 int32_t rp_num_bodies(const rp_world *w);
 
 /* NarrowPhase::contact_pairs() analogue: for each active solver manifold: (collider1, collider2,

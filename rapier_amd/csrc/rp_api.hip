@@ -167,6 +167,8 @@ struct rp_world {
     DevWorld old_dw;
     int *old_pinned = nullptr;
     std::vector<int> old_active_joint_ids;
+    unsigned *d_speed = nullptr; // rp_world_max_linear_speed's reduction cell
+    float guard_horizon = 0.0f;  // rp_world_set_shard_guard_horizon
     // shard guard (rp_world_set_shard_guard): host copy, re-uploaded whenever the device world is rebuilt
     std::vector<float4> guard_min, guard_max; std::vector<int> guard_start, guard_items; float guard_origin[3] = {0, 0, 0}, guard_cell = 0.0f; int guard_dims[3] = {0, 0, 0};
     // launch plan + graph
@@ -460,6 +462,7 @@ extern "C" int32_t rp_world_destroy(rp_world *w) {
     free_device(w);
     for (void *&b : w->cv_dev) if (b) { hipFree(b); b = nullptr; }
     for (void *&b : w->cm_dev) if (b) { hipFree(b); b = nullptr; }
+    if (w->d_speed) { hipFree(w->d_speed); w->d_speed = nullptr; }
     for (auto &e : w->ev) if (e) hipEventDestroy(e);
     if (w->stream) hipStreamDestroy(w->stream);
     delete w;
@@ -1583,6 +1586,7 @@ static int upload_shard_guard(rp_world *w) {
     UP(d.sg_bmin, w->guard_min); UP(d.sg_bmax, w->guard_max); UP(d.sg_cell_start, w->guard_start); UP(d.sg_cell_items, w->guard_items);
     for (int k = 0; k < 3; ++k) { d.sg_origin[k] = w->guard_origin[k]; d.sg_dims[k] = w->guard_dims[k]; }
     d.sg_inv_cell = 1.0f / w->guard_cell;
+    d.sg_horizon = w->guard_horizon;
     HIPCHK(w, hipStreamSynchronize(w->stream));
     return RP_OK;
 }
@@ -2638,6 +2642,36 @@ extern "C" int32_t rp_world_shard_guard_take_hits(rp_world *w, int32_t cap, uint
     }
     return n;
 }
+// max |linvel| over the non-fixed bodies, reduced on the device (non-negative floats order like their bit patterns)
+__global__ void k_max_linear_speed(DevWorld w, unsigned *out) {
+    float m = 0.0f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < w.n_bodies; i += gridDim.x * blockDim.x) {
+        if ((w.b_flags[i] & RP_BF_TYPE_MASK) == RP_BODY_FIXED) continue;
+        const float4 v = w.b_linvel[i];
+        const float s = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+        if (s == s) m = fmaxf(m, s);
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(out, __float_as_uint(m));
+}
+// How far the fastest body of this shard travels per step: what a caller that looks at the guard every k steps adds to the clearance of
+// the boxes it hands to rp_world_set_shard_guard (2 * speed * dt * k: both sides may move) — rapier_amd/sharding.py: ShardSet.
+extern "C" int32_t rp_world_max_linear_speed(rp_world *w, float *out) {
+    if (!w || !out) return RP_ERR_INVALID;
+    *out = 0.0f;
+    if (!w->finalized || w->dw.n_bodies == 0) return RP_OK;
+    HIPCHK(w, hipSetDevice(w->device));
+    if (!w->d_speed) HIPCHK(w, hipMalloc((void **)&w->d_speed, sizeof(unsigned)));
+    HIPCHK(w, hipMemsetAsync(w->d_speed, 0, sizeof(unsigned), w->stream));
+    const int nb = w->dw.n_bodies;
+    hipLaunchKernelGGL(k_max_linear_speed, dim3(std::min((nb + 255) / 256, 1024)), dim3(256), 0, w->stream, w->dw, w->d_speed);
+    HIPCHK(w, hipGetLastError());
+    unsigned bits = 0;
+    HIPCHK(w, hipMemcpyAsync(&bits, w->d_speed, sizeof(unsigned), hipMemcpyDeviceToHost, w->stream));
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    memcpy(out, &bits, sizeof(float));
+    return RP_OK;
+}
 extern "C" int32_t rp_world_set_shard_guard(rp_world *w, int32_t n, const float *bmin, const float *bmax) {
     if (!w || n < 0 || (n > 0 && (!bmin || !bmax))) return RP_ERR_INVALID;
     HIPCHK(w, hipSetDevice(w->device));
@@ -2679,6 +2713,20 @@ extern "C" int32_t rp_world_set_shard_guard(rp_world *w, int32_t n, const float 
     if (!w->finalized) return RP_OK; // uploaded when the device world is built
     { int r = settle(w); if (r != RP_OK) return r; }
     { int r = upload_shard_guard(w); if (r != RP_OK) return r; }
+    destroy_graphs(w); // the captured launches hold the old DevWorld
+    return RP_OK;
+}
+// The time a guard hit may wait for the caller (the steps between two rp_world_shard_guard_take_hits x dt): the device tests every
+// rewritten fat AABB INFLATED by |linvel of its body| x horizon, so a body is caught that many steps before it reaches a foreign box —
+// per body, not one world-wide clearance that would merge shards which merely stand close (rapier_amd/sharding.py: ShardSet).
+extern "C" int32_t rp_world_set_shard_guard_horizon(rp_world *w, float seconds) {
+    if (!w || !(seconds >= 0.0f) || !std::isfinite(seconds)) return RP_ERR_INVALID;
+    if (seconds == w->guard_horizon) return RP_OK;
+    w->guard_horizon = seconds;
+    if (!w->finalized) return RP_OK;
+    HIPCHK(w, hipSetDevice(w->device));
+    { int r = settle(w); if (r != RP_OK) return r; }
+    w->dw.sg_horizon = seconds;
     destroy_graphs(w); // the captured launches hold the old DevWorld
     return RP_OK;
 }

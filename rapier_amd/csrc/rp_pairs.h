@@ -115,7 +115,9 @@ RP_DEV bool collider_update_one(const DevWorld &w, int i) { // true = the fat AA
         // a body of another one — a rewritten fat AABB that overlaps a box another shard occupies ends the run with an error
         if (w.sg_bmin && w.c_parent[i] >= 0 && (w.b_flags[w.c_parent[i]] & RP_BF_TYPE_MASK) != RP_BODY_FIXED && w.c_shape[i] != RP_SHAPE_HALFSPACE) {
             int lo[3], hi[3];
-            const float a[3] = {mn.x - s, mn.y - s, mn.z - s}, b[3] = {mx.x + s, mx.y + s, mx.z + s};
+            float g = s;                                      // + the way the body travels before the caller looks at the hits
+            if (w.sg_horizon > 0.0f) { const float4 lv = w.b_linvel[w.c_parent[i]]; g += w.sg_horizon * sqrtf(lv.x * lv.x + lv.y * lv.y + lv.z * lv.z); }
+            const float a[3] = {mn.x - g, mn.y - g, mn.z - g}, b[3] = {mx.x + g, mx.y + g, mx.z + g};
             bool outside = false;
             for (int k = 0; k < 3; ++k) {
                 lo[k] = (int)floorf((a[k] - w.sg_origin[k]) * w.sg_inv_cell); hi[k] = (int)floorf((b[k] - w.sg_origin[k]) * w.sg_inv_cell);

@@ -397,6 +397,7 @@ struct DevWorld {
     int *lay_state;             // [16] layout-rebuild state that survives between rebuilds: [0] the flat component labels of the last rebuild are still valid (cleared by every edit of the world), [1] rebuilds so far, [2] global-path bodies the last rebuild counted; the broad phase keeps [8] the parity of the grid copy in service and [9] the rebuilds that kept the grid since its last build pass (rp_broadphase.hip); [3] / [4] island candidates of the last / the running layout rebuild, [5] the overflow colour may be swept owner-parallel (rp_islands.hip)
     int *sg_hit;                // [bodies] 1 = a rewritten fat AABB of the body overlapped a foreign box (read and cleared by rp_world_shard_guard_take_hits)
     float sg_origin[3], sg_inv_cell; int sg_dims[3];
+    float sg_horizon;           // seconds a hit may wait for the caller: the tested box grows by |linvel| x horizon (rp_world_set_shard_guard_horizon)
     int c_par;                  // which copy of the MUTABLE constraint planes (impulses, accumulators, rhs: NP_M x 4, CP_HM0, CP_HM1) is current:
                                 // 0 = in place, 1 = the shadow planes behind CP_COUNT.  A tile sweep reads one copy and its owner instances write
                                 // the other (a halo instance must not see the owner's result of the same sweep); every other kernel works in

@@ -232,7 +232,14 @@ class ShardSet:
 
     def __init__(self, scene: S.Scene, n_ranks: int, make_world, body_rank=None, groups=None, local_ranks=None, exchange=None, clearance: float = 0.25,
                  check_every: int = 1):
-        self.scene, self.n_ranks, self.make_world, self.clearance = scene, n_ranks, make_world, clearance
+        self.scene, self.n_ranks, self.make_world = scene, n_ranks, make_world
+        # A guard hit waits at most `check_every` steps for us.  Three allowances make that sound without one world-wide clearance (which
+        # would merge shards that merely stand close): the DEVICE inflates every tested body box by |linvel| x horizon
+        # (rp_world_set_shard_guard_horizon, horizon = dt x check_every); every group's box carries base + ITS top speed x horizon; and the
+        # boxes are refreshed once the fastest body of the job (rp_world_max_linear_speed, exchanged with the hits) may have drifted
+        # half the base clearance away from where the boxes were taken.
+        self.clearance = float(clearance)
+        self._dt = float(scene.params["dt"])
         self.check_every, self._since_check = max(1, int(check_every)), 0   # guard hits are looked at (one exchange) every so many steps
         self.local_ranks = list(range(n_ranks)) if local_ranks is None else list(local_ranks)
         self.exchange = exchange or (lambda obj: [obj])   # one process holds everything: nothing to exchange
@@ -257,7 +264,24 @@ class ShardSet:
             self.handle[r] = {int(g): int(h) for g, h in zip(gids, hs)}
         self.migrations = 0
         self._groups0 = np.asarray(groups)
+        self._horizon = self._dt * self.check_every
+        for w in self.worlds.values():
+            if hasattr(w, "set_shard_guard_horizon"):
+                w.set_shard_guard_horizon(self._horizon)
+        self._drift, self.guard_refreshes = 0.0, 0
         self._refresh_guards(first=True)
+
+    def _local_max_speed(self) -> float:
+        out = 0.0
+        for r, w in self.worlds.items():
+            if hasattr(w, "max_linear_speed"):
+                out = max(out, float(w.max_linear_speed()))
+            else:                                                     # (the oracle stand-in of the CPU tests)
+                _, vel = w.read_bodies()
+                rows = [row for row, g in enumerate(self.gid_of_row[r]) if g >= 0 and self.owner[g] == r]
+                if rows:
+                    out = max(out, float(np.linalg.norm(np.asarray(vel)[rows, :3].astype(np.float64), axis=1).max()))
+        return out
 
     # -- state of the locally held bodies, boxes of every group -------------------------------------------------------------------------
     def _local_state(self):
@@ -276,7 +300,7 @@ class ShardSet:
         half = np.where(np.isfinite(lo0), (hi0 - lo0) / 2.0, 0.0)
         recs = []
         for r, w in self.worlds.items():
-            pos, _ = w.read_bodies()
+            pos, vel = w.read_bodies()
             gr = w.proximity_groups() if hasattr(w, "proximity_groups") else None
             rows = [row for row, g in enumerate(self.gid_of_row[r]) if g >= 0 and self.owner[g] == r]
             if gr is None:                                                       # (oracle stand-in: every body its own group unless boxes overlap)
@@ -288,7 +312,8 @@ class ShardSet:
                 gl = [self.gid_of_row[r][row] for row in rows_g]
                 c = np.array([pos[row][:3] for row in rows_g], np.float64)
                 h = np.array([half[g] for g in gl])
-                recs.append((r, gl, (c - h).min(0) - self.clearance, (c + h).max(0) + self.clearance))
+                allow = self.clearance + self._horizon * float(np.linalg.norm(np.array([vel[row][:3] for row in rows_g], np.float64), axis=1).max())
+                recs.append((r, gl, (c - h).min(0) - allow, (c + h).max(0) + allow))
         return recs
 
     def _initial_boxes(self):
@@ -299,13 +324,16 @@ class ShardSet:
             mine = (self._groups0 >= 0) & (self.owner == r) & np.isfinite(lo[:, 0])
             for k in np.unique(self._groups0[mine]):
                 m = mine & (self._groups0 == k)
-                recs.append((r, [int(g) for g in np.flatnonzero(m)], lo[m].min(0) - self.clearance, hi[m].max(0) + self.clearance))
+                allow = self.clearance + self._horizon * max(float(np.linalg.norm(np.asarray(self.scene.bodies[g]["linvel"], np.float64))) for g in np.flatnonzero(m))
+                recs.append((r, [int(g) for g in np.flatnonzero(m)], lo[m].min(0) - allow, hi[m].max(0) + allow))
         return recs
 
     def _refresh_guards(self, first=False):
         mine = self._initial_boxes() if first else self._groups_and_boxes()
         every = [x for part in self.exchange(mine) for x in part]
         self._boxes = every
+        self._drift = 0.0
+        self.guard_refreshes += 0 if first else 1
         for r, w in self.worlds.items():
             foreign = [(lo, hi) for (rr, _, lo, hi) in every if rr != r]
             if hasattr(w, "set_shard_guard"):
@@ -329,9 +357,13 @@ class ShardSet:
                 if len(caught):
                     rev = {h: g for g, h in self.handle[r].items()}
                     hits[r] = [rev[int(h)] for h in caught if int(h) in rev]
-            anyone = [x for part in self.exchange(hits) for x in ([part] if part else [])]
+            parts = self.exchange((hits, self._local_max_speed()))   # ONE exchange per look: the hits and every rank's top speed
+            anyone = [h for h, _ in parts if h]
+            self._drift += max(v for _, v in parts) * self._horizon     # how far a body may be from where the boxes were taken
             if anyone:
                 self._migrate({r: g for part in anyone for r, g in part.items()})
+            elif self._drift > 0.5 * self.clearance:
+                self._refresh_guards()
 
     def _migrate(self, hits):
         """hits = {rank: [global bodies its guard caught]}: plan from the exchanged boxes, so every process plans alike"""

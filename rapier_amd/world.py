@@ -489,6 +489,16 @@ class PhysicsWorld:
     ISLAND_STATS = ("merged", "multiway_groups", "removals", "connected", "detached", "hot", "over_budget", "sleeping_deferred", "global_splits",
                     "global_split_pieces", "bids", "bid_ties", "sleep_blocked", "order_dependent", "detach_size_ties", "split_keep_ties")
 
+    def set_shard_guard_horizon(self, seconds: float):
+        """how long a guard hit may wait for take_shard_guard_hits (rp_world_set_shard_guard_horizon)"""
+        _check(self._ptr, self._lib.rp_world_set_shard_guard_horizon(self._ptr, float(seconds)), "rp_world_set_shard_guard_horizon")
+
+    def max_linear_speed(self) -> float:
+        """max |linvel| over the non-fixed bodies, reduced on the device (rp_world_max_linear_speed)"""
+        out = C.c_float(0.0)
+        _check(self._ptr, self._lib.rp_world_max_linear_speed(self._ptr, C.byref(out)), "rp_world_max_linear_speed")
+        return float(out.value)
+
     def take_shard_guard_hits(self) -> np.ndarray:
         """Handles of the bodies the shard guard caught since the last call; clears the guard so the world can go on
         (rp_world_shard_guard_take_hits)."""

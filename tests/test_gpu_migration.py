@@ -43,3 +43,35 @@ def test_a_thrown_cube_migrates_to_the_shard_it_reaches():
     assert abs(float(gp[top, 0]) - other_x) < 6.0                     # it is over there
     for r in (0, 1):
         assert shards.worlds[r].counters()["overflow_flags"] == 0
+
+
+def test_hits_looked_at_every_fourth_step_still_catch_the_cube_in_time():
+    """check_every = 4: the device tests every body box inflated by |linvel| x 4 dt (rp_world_set_shard_guard_horizon), so the cube
+    is handed over while it is still in flight; the job-wide top speed (rp_world_max_linear_speed) drives the refresh of the boxes"""
+    sc = S.many_pyramids(1, 2)
+    whole = PhysicsWorld.from_scene(sc)
+    groups = sharding.proximity_groups_from_scene(sc)
+    body_rank, _ = sharding.shards_from_groups(groups, 2)
+    shards = sharding.ShardSet(sc, 2, lambda sub, r: PhysicsWorld.from_scene(sub), body_rank=body_rank, groups=groups, check_every=4)
+    whole.step(4); shards.step(4)
+    assert shards.guard_refreshes == 0                                   # a pyramid that settles does not move its box
+    top = max((i for i in range(len(sc.bodies)) if body_rank[i] == 0), key=lambda i: float(sc.bodies[i]["translation"][1]))
+    other_x = np.mean([float(sc.bodies[i]["translation"][0]) for i in range(len(sc.bodies)) if body_rank[i] == 1])
+    toward = float(np.sign(other_x - float(sc.bodies[top]["translation"][0])))
+    kick = np.array([[toward * 9.0, 6.0, 0.0, 0.0, 0.0, 0.0]], np.float32)
+    whole.write_bodies([top], vel6=kick)
+    shards.worlds[0].write_bodies([shards.handle[0][top]], vel6=kick)
+    assert abs(shards.worlds[0].max_linear_speed() - float(np.linalg.norm(kick[0, :3]))) < 1e-5
+    moved_at = None
+    for look in range(1, 36):
+        whole.step(4); shards.step(4)
+        if moved_at is None and shards.migrations > 0:
+            moved_at = look
+            gp, gv = shards.read_bodies(); wp, wv = whole.read_bodies()
+            np.testing.assert_array_equal(gp, wp); np.testing.assert_array_equal(gv, wv)   # caught in flight: nothing was missed
+    assert moved_at is not None and shards.migrations == 1 and shards.owner[top] == 1
+    assert shards.guard_refreshes > 0                                    # the flying cube dragged its box along
+    gp, _ = shards.read_bodies(); wp, _ = whole.read_bodies()
+    assert np.isfinite(gp).all() and np.abs(gp[:, :3] - wp[:, :3]).max() < 0.05
+    for r in (0, 1):
+        assert shards.worlds[r].counters()["overflow_flags"] == 0
