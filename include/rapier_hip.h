@@ -205,6 +205,7 @@ typedef struct rp_counters {
     int32_t lean_steps;            /* step graphs enqueued without the rebuild launches (colouring, layout, toucher ranks, tiling): worlds on the
                                     * per-stage / tile path whose contact graph stands still; validated on the device, a step whose narrow phase
                                     * found new work is resumed by the next full graph (counted in replayed_steps) */
+    int32_t fused_steps;           /* of fast_steps: those enqueued as the ONE-kernel fused step (k_island_solve validates the step itself) */
 } rp_counters;
 
 #define RP_INVALID_HANDLE 0xffffffffffffffffull

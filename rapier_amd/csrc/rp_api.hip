@@ -63,7 +63,7 @@ void rp_launch_solver_assembly(const DevWorld &w, hipStream_t st, int lean);
 int rp_launch_solver_loop(const DevWorld &w, hipStream_t st, int parallel_stages, int stage_blocks, int has_restitution, int joint_stages, int tile_grid, int no_contacts_hint);
 void rp_launch_solver_writeback(const DevWorld &w, hipStream_t st, int parity, int publish);
 bool rp_ccd_launches(const DevWorld &w);
-void rp_launch_island_solve(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast, int retire, int fused, int dense);
+void rp_launch_island_solve(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast, int retire, int fused, int dense, int wide);
 void rp_launch_global_single(const DevWorld &w, hipStream_t st, int has_restitution, int fast);
 void rp_launch_fast_front(const DevWorld &w, hipStream_t st, int no_global_kernel);
 void rp_launch_wake(const DevWorld &w, hipStream_t st, int phase);
@@ -72,6 +72,7 @@ void rp_launch_force_events(const DevWorld &w, hipStream_t st, int fast);
 void rp_launch_idle_step(const DevWorld &w, hipStream_t st);
 void rp_launch_sleep_fast(const DevWorld &w, hipStream_t st);
 void rp_launch_sensor_fast(const DevWorld &w, hipStream_t st);
+void rp_launch_sensor_check(const DevWorld &w, hipStream_t st);
 void rp_launch_clear_no_contact(const DevWorld &w, hipStream_t st);
 void rp_launch_global_flow(const DevWorld &w, hipStream_t st, int grid, int has_restitution);
 void rp_launch_ccd(const DevWorld &w, hipStream_t st, int has_bullets, int publish);
@@ -172,12 +173,12 @@ struct rp_world {
     // shard guard (rp_world_set_shard_guard): host copy, re-uploaded whenever the device world is rebuilt
     std::vector<float4> guard_min, guard_max; std::vector<int> guard_start, guard_items; float guard_origin[3] = {0, 0, 0}, guard_cell = 0.0f; int guard_dims[3] = {0, 0, 0};
     // launch plan + graph
-    int plan_stages = 0, plan_blocks = 1, plan_single = 1, plan_island_grid = 1, plan_joint_stages = 0, plan_no_global = 0, plan_fused = 0, plan_tile_grid = 0, plan_no_contacts = 0, plan_bare = 0, plan_dense = 0;
+    int plan_stages = 0, plan_blocks = 1, plan_single = 1, plan_island_grid = 1, plan_joint_stages = 0, plan_no_global = 0, plan_fused = 0, plan_tile_grid = 0, plan_no_contacts = 0, plan_bare = 0, plan_dense = 0, plan_wide = 0;
     bool has_restitution = false;
     // [0] = full path, [1] = fast path, [2] = lean path; "whole" = one graph per step, col/loop/fin = timed thirds (full / fast only)
     hipGraph_t g_whole[3] = {nullptr, nullptr, nullptr}, g_col[3] = {nullptr, nullptr, nullptr}, g_loop[3] = {nullptr, nullptr, nullptr}, g_fin[3] = {nullptr, nullptr, nullptr};
     hipGraphExec_t ge_whole[3] = {nullptr, nullptr, nullptr}, ge_col[3] = {nullptr, nullptr, nullptr}, ge_loop[3] = {nullptr, nullptr, nullptr}, ge_fin[3] = {nullptr, nullptr, nullptr};
-    int graph_stages = -1, graph_blocks = -1, graph_single = -1, graph_island_grid = -1, graph_dense = -1, graph_joint_stages = -1, graph_no_global = -1, graph_fused = -1, graph_tile_grid = -1, graph_no_contacts = -1, graph_bare = -1;
+    int graph_stages = -1, graph_blocks = -1, graph_single = -1, graph_island_grid = -1, graph_dense = -1, graph_wide = -1, graph_joint_stages = -1, graph_no_global = -1, graph_fused = -1, graph_tile_grid = -1, graph_no_contacts = -1, graph_bare = -1;
     bool use_graph = true, use_fast = true, use_fused = true;
     bool auto_dense = true;        // RP_ISL_DENSE=0: never
     bool force_dense = false;      // RP_ISL_DENSE=1 (tests): the dense form of k_island_solve whatever the island count
@@ -204,7 +205,7 @@ struct rp_world {
     long long full_until = 0;      // stay on the full graph until this many steps were requested
     long long eager_until = 0;     // launch the kernels directly until this many steps were requested: a world that is being edited (bodies /
                                    // colliders / joints coming and going every few steps) would re-capture its graphs — ~10 ms — after every edit
-    long long fast_steps = 0, full_steps = 0, replayed_steps = 0;
+    long long fast_steps = 0, full_steps = 0, replayed_steps = 0, fused_steps = 0;
     // timers
     bool timers = false;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -228,6 +229,7 @@ static int settle(rp_world *w);
 static int upload_body_row(rp_world *w, int i);
 static int upload_body_row_mass(rp_world *w, int i);
 static int upload_collider_row(rp_world *w, int i);
+static int upload_collider_chain(rp_world *w, int parent);
 static int after_topology_edit(rp_world *w, bool keep_grid = false);
 static bool world_sleep_enabled(const rp_world *w);
 static bool world_has_kinematic_pos(const rp_world *w);
@@ -441,7 +443,7 @@ static void destroy_graphs(rp_world *w) {
         for (auto e : ex) if (*e) { hipGraphExecDestroy(*e); *e = nullptr; }
         for (auto g : gr) if (*g) { hipGraphDestroy(*g); *g = nullptr; }
     }
-    w->graph_stages = -1; w->graph_blocks = -1; w->graph_single = -1; w->graph_island_grid = -1; w->graph_dense = -1; w->graph_joint_stages = -1; w->graph_no_global = -1; w->graph_fused = -1; w->graph_tile_grid = -1; w->graph_no_contacts = -1; w->graph_bare = -1;
+    w->graph_stages = -1; w->graph_blocks = -1; w->graph_single = -1; w->graph_island_grid = -1; w->graph_dense = -1; w->graph_wide = -1; w->graph_joint_stages = -1; w->graph_no_global = -1; w->graph_fused = -1; w->graph_tile_grid = -1; w->graph_no_contacts = -1; w->graph_bare = -1;
     w->timed_ready[0] = w->timed_ready[1] = false;
 }
 static void free_device(rp_world *w) {
@@ -1292,9 +1294,7 @@ extern "C" int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider
             if (r == RP_OK && parent >= 0) r = upload_body_row_mass(w, parent);
             if (r == RP_OK && parent >= 0) r = refresh_joint_frames(w, parent); // the local centre of mass moved
             if (r == RP_OK && parent >= 0 && w->bodies[parent].d.body_type == RP_BODY_DYNAMIC) {
-                // b_collider: the body's LAST live collider (the single-collider fast paths read it)
-                int last = -1; for (int q = 0; q < (int)w->colliders.size(); ++q) if (w->collider_parent[q] == parent && !w->collider_removed[q]) last = q;
-                HIPCHK(w, hipMemcpy(w->dw.b_collider + parent, &last, sizeof(int), hipMemcpyHostToDevice));
+                r = upload_collider_chain(w, parent);
             }
             if (r != RP_OK) return r;
         }
@@ -1467,6 +1467,15 @@ static int upload_body_row_mass(rp_world *w, int i) { // mass properties only (a
     PUT(d.b_lcom_invm, i, r.lci); PUT(d.b_invpi, i, r.ipi); PUT(d.b_pframe, i, r.pfr);
     PUT((float *)(d.b_sprev_t + i) + 3, 0, r.spt.w); // max_extent follows the attached shapes
     PUT(d.b_damp, i, r.damp);                         // ... and so does ccd_thickness (damp.w)
+    return RP_OK;
+}
+// b_collider / c_sibling of one body: its live colliders as a chain from the last one down (the fused step's validators walk it)
+static int upload_collider_chain(rp_world *w, int parent) {
+    int last = -1;
+    if (w->bodies[(size_t)parent].d.body_type == RP_BODY_DYNAMIC)
+        for (int q = 0; q < (int)w->colliders.size(); ++q)
+            if (w->collider_parent[(size_t)q] == parent && !w->collider_removed[(size_t)q]) { PUT(w->dw.c_sibling, q, last); last = q; }
+    PUT(w->dw.b_collider, parent, last);
     return RP_OK;
 }
 static int upload_collider_row(rp_world *w, int i) {
@@ -1646,7 +1655,7 @@ static int finalize(rp_world *w) {
     DA(d.flags, FL_COUNT); DA(d.dbg, 1024); DA(d.bar, 16);
     DAC(d.b_pos, capb, DOM_BODY, 1, 1); DAC(d.b_rot, capb, DOM_BODY, 1, 1); DAC(d.b_linvel, capb, DOM_BODY, 1, 1); DAC(d.b_angvel, capb, DOM_BODY, 1, 1); DA(d.b_lcom_invm, capb); DA(d.b_invpi, capb);
     DA(d.b_pframe, capb); DAC(d.b_wcom, capb, DOM_BODY, 1, 1); DAC(d.b_eim, capb, DOM_BODY, 1, 1); DAC(d.b_eii0, capb, DOM_BODY, 1, 1); DAC(d.b_eii1, capb, DOM_BODY, 1, 1); DA(d.b_damp, capb); /* host-authoritative (damping, gravity scale, ccd_thickness): NOT carried over a growth — the carried copy of a row whose body got a collider in the same call held the old thickness (found by the growth fuzz, round 4) */
-    DAC(d.b_uforce, capb, DOM_BODY, 1, 1); DAC(d.b_utorque, capb, DOM_BODY, 1, 1); DAC(d.b_flags, capb, DOM_BODY, 1, 1); DAC(d.b_quar, capb, DOM_BODY, 1, 1); DAF(d.b_collider, capb, 0xff);
+    DAC(d.b_uforce, capb, DOM_BODY, 1, 1); DAC(d.b_utorque, capb, DOM_BODY, 1, 1); DAC(d.b_flags, capb, DOM_BODY, 1, 1); DAC(d.b_quar, capb, DOM_BODY, 1, 1); DAF(d.b_collider, capb, 0xff); DAF(d.c_sibling, capc, 0xff);
     DA(d.b_ccd0_pos, capb); DA(d.b_ccd0_rot, capb); DA(d.ccd_list, capb); // continuous-collision pass: scratch of one step
     DAC(d.b_sleep, capb, DOM_BODY, 1, 1); DA(d.b_sprev_t, capb); DAC(d.b_sprev_r, capb, DOM_BODY, 1, 1); DAC(d.b_slabel, capb, DOM_BODY, 1, 1); DAC(d.b_slept_at, capb, DOM_BODY, 1, 1); DA(d.b_sleep_stamp, capb); DAC(d.b_wake_req, capb, DOM_BODY, 1, 1);
     DAC(d.lab_wake, capb, DOM_BODY, 1, 1); DAC(d.lab_awake, capb, DOM_BODY, 1, 1); DAC(d.b_next_pos, capb, DOM_BODY, 1, 1); DAC(d.b_next_rot, capb, DOM_BODY, 1, 1);
@@ -1759,9 +1768,10 @@ static int finalize(rp_world *w) {
     for (int a = 0; a < 12; ++a) if (nj > 0 && hipMemcpyAsync(d.j_mot + (size_t)a * nj, jmot[a].data(), (size_t)nj * sizeof(float4), hipMemcpyHostToDevice, w->stream) != hipSuccess) { w->err = "upload failed"; return RP_ERR_DEVICE; }
     for (int a = 0; a < 6; ++a) if (nj > 0 && hipMemcpyAsync(d.j_lim + (size_t)a * nj, jlim[a].data(), (size_t)nj * sizeof(float4), hipMemcpyHostToDevice, w->stream) != hipSuccess) { w->err = "upload failed"; return RP_ERR_DEVICE; }
     {
-        std::vector<int> bcol(nb, -1);
-        for (int c = 0; c < nc; ++c) { int pb = w->collider_parent[c]; if (pb >= 0 && !w->collider_removed[c] && w->bodies[pb].d.body_type == RP_BODY_DYNAMIC && !w->bodies[pb].removed) bcol[pb] = c; }
-        UP(d.b_collider, bcol);
+        // b_collider: the LAST live collider of a dynamic body; c_sibling: the one before it (the chain the fused step's validators walk)
+        std::vector<int> bcol(nb, -1), csib(nc, -1);
+        for (int c = 0; c < nc; ++c) { int pb = w->collider_parent[c]; if (pb >= 0 && !w->collider_removed[c] && w->bodies[pb].d.body_type == RP_BODY_DYNAMIC && !w->bodies[pb].removed) { csib[c] = bcol[pb]; bcol[pb] = c; } }
+        UP(d.b_collider, bcol); UP(d.c_sibling, csib);
         HIPCHK(w, hipStreamSynchronize(w->stream));
     }
     DAS(d.k_b1, d.cons_cap); DAS(d.k_b2, d.cons_cap); DAS(d.k_n, d.cons_cap); DAS(d.k_cid, d.cons_cap);
@@ -1873,7 +1883,10 @@ static int finalize(rp_world *w) {
 }
 
 static void enqueue_collision(rp_world *w) {
-    if (w->cur_fast && w->plan_fused) return; // the fused k_island_solve validates the step itself
+    if (w->cur_fast && w->plan_fused) { // the fused k_island_solve validates the step itself (fat AABBs, recycle tests, sleep observation) ...
+        rp_launch_sensor_check(w->dw, w->stream); // ... except that a sensor's intersection may start or stop (worlds with sensors only)
+        return;
+    }
     if (w->cur_fast) {
         rp_launch_fast_front(w->dw, w->stream, w->plan_no_global);
         rp_launch_sleep_fast(w->dw, w->stream); // sleep-enabled worlds: the per-step observation + "would an island fall asleep?" (then: abort)
@@ -1903,7 +1916,7 @@ static void enqueue_island_solver(rp_world *w) {
     const int cap = dense ? w->fused_grid_dense : w->fused_grid;
     const int want = dense ? (w->plan_island_grid + 1) / 2 : w->plan_island_grid;
     rp_launch_island_solve(w->cur_lean ? w->dw_lean : w->dw, w->stream, fused ? std::min(want, cap) : want,
-                           w->has_restitution ? 1 : 0, w->cur_fast, w->plan_single, fused, dense);
+                           w->has_restitution ? 1 : 0, w->cur_fast, w->plan_single, fused, dense, w->plan_wide);
 }
 // MULTI mode of the global path, measured on MI355X: contact-only worlds under the twist model are fastest
 // with one launch per colour stage + the body-centric warm start (b3d_large_pyramid 0.81 ms against 0.94 ms); worlds with impulse
@@ -1975,13 +1988,17 @@ static void plan_from_hints(rp_world *w, const int *fl) {
     if (w->plan_tile_grid > 0) { w->plan_stages = fl[FL_N_PARALLEL]; w->plan_joint_stages = fl[FL_NJ_STAGES]; w->plan_blocks = std::min(std::max(pow2_ceil((fl[FL_MAX_STAGE] + 255) / 256), 1), 4096); } // (the per-stage launches of the restitution sweep)
     // fused single-kernel fast step: every workgroup must be resident at once (in-launch arrival barrier)
     // (a grid of at most fused_grid workgroups; workgroups loop over islands beyond that)
-    // (contact-force events are evaluated by a kernel of their own after every step: such worlds take the two-kernel fast graph)
-    // (... and so do sleep-enabled worlds: their sleep observation is a pass of its own)
-    // (... and so do the worlds whose islands run on k_island_generic: FrictionModel::Coulomb)
+    // Round 5: compound bodies (the validators walk every collider of a body), sleep-enabled worlds (the validators run the sleep
+    // observation of their islands' bodies and abort when an island could fall asleep), worlds with sensors (k_sensor_check in front)
+    // and contact-force events (k_force_events behind, as in every graph) keep it.
+    // (the worlds whose islands run on k_island_generic — FrictionModel::Coulomb — do not: that kernel has no fused form)
     // (a body thinner than ~3.5 x the fat-AABB margin could move half its thickness — the CCD criterion — without leaving its fat AABB,
     // i.e. without the fused step noticing: such worlds take the fast graph, whose front kernel predicts the criterion)
     const bool ccd_safe = w->params.max_ccd_substeps == 0 || w->min_ccd_thickness >= 0.14f * w->params.length_unit;
-    w->plan_fused = (ccd_safe && w->use_fused && w->fused_grid > 0 && !w->compound && w->params.friction_model != RP_FRICTION_COULOMB && !w->dw.isl_generic && !w->dw.has_force_events && !w->dw.sleep_enabled && !w->dw.has_sensors && w->plan_no_global && w->plan_single && fl[FL_N_ISLANDS] > 0) ? 1 : 0;
+    static const bool narrow_fused = getenv("RP_FUSED_NARROW") && getenv("RP_FUSED_NARROW")[0] == '1'; // A/B: round 4's rule (no compound bodies, sleeping, sensors, force events)
+    w->plan_wide = (w->compound || w->dw.sleep_enabled) ? 1 : 0; // the island kernel with the WIDE validators (every collider of a body, sleep observation)
+    const bool cliffs = w->compound || w->dw.has_force_events || w->dw.sleep_enabled || w->dw.has_sensors;
+    w->plan_fused = (ccd_safe && w->use_fused && w->fused_grid > 0 && !(narrow_fused && cliffs) && !(w->dw.has_sensors && w->dw.has_composite) && w->params.friction_model != RP_FRICTION_COULOMB && !w->dw.isl_generic && w->plan_no_global && w->plan_single && fl[FL_N_ISLANDS] > 0) ? 1 : 0;
 }
 
 static int capture(rp_world *w, hipGraph_t *g, hipGraphExec_t *ge, void (*fn)(rp_world *)) {
@@ -2022,12 +2039,12 @@ static int launch_step(rp_world *w, int fast) {
     if (w->cur_lean) { w->dw_lean = w->dw; w->dw_lean.lean = 1 | (w->plan_bare ? 2 : 0); }
     w->cur_fast = fast == 1 ? 1 : 0;
     w->seq_enqueued++;
-    if (fast == 1) w->fast_steps++; else if (fast == 2) w->lean_steps++; else w->full_steps++;
+    if (fast == 1) { w->fast_steps++; if (w->plan_fused) w->fused_steps++; } else if (fast == 2) w->lean_steps++; else w->full_steps++;
     if (w->timers) {
         // three sub-graphs with events in between (Counters from hipEvents)
         if (!w->timed_ready[fast]) {
             int r;
-            if (fast && !w->plan_fused && (r = capture(w, &w->g_col[fast], &w->ge_col[fast], enqueue_collision)) != RP_OK) return r;
+            if (fast && (!w->plan_fused || w->dw.has_sensors) && (r = capture(w, &w->g_col[fast], &w->ge_col[fast], enqueue_collision)) != RP_OK) return r; // (fused: only k_sensor_check lives there)
             w->timed_ready[fast] = true;
             if (!(fast && w->plan_no_global && !w->dw.has_force_events) && (r = capture(w, &w->g_fin[fast], &w->ge_fin[fast], enqueue_global_and_finish)) != RP_OK) return r;
         }
@@ -2168,10 +2185,10 @@ static int step_once(rp_world *w, bool allow_fast) {
         if (w->plan_island_grid < old_g && w->plan_island_grid * 2 >= old_g) w->plan_island_grid = old_g;
     }
     if (w->graph_stages != w->plan_stages || w->graph_blocks != w->plan_blocks || w->graph_single != w->plan_single ||
-        w->graph_island_grid != w->plan_island_grid || w->graph_dense != w->plan_dense || w->graph_joint_stages != w->plan_joint_stages || w->graph_no_global != w->plan_no_global || w->graph_fused != w->plan_fused || w->graph_tile_grid != w->plan_tile_grid || w->graph_no_contacts != w->plan_no_contacts || w->graph_bare != w->plan_bare) {
+        w->graph_island_grid != w->plan_island_grid || w->graph_dense != w->plan_dense || w->graph_wide != w->plan_wide || w->graph_joint_stages != w->plan_joint_stages || w->graph_no_global != w->plan_no_global || w->graph_fused != w->plan_fused || w->graph_tile_grid != w->plan_tile_grid || w->graph_no_contacts != w->plan_no_contacts || w->graph_bare != w->plan_bare) {
         if (w->ge_whole[0] || w->ge_whole[1] || w->timed_ready[0] || w->timed_ready[1]) HIPCHK(w, hipStreamSynchronize(w->stream)); // replays of the old graphs may still be in flight
         destroy_graphs(w);
-        w->graph_stages = w->plan_stages; w->graph_blocks = w->plan_blocks; w->graph_single = w->plan_single; w->graph_island_grid = w->plan_island_grid; w->graph_dense = w->plan_dense;
+        w->graph_stages = w->plan_stages; w->graph_blocks = w->plan_blocks; w->graph_single = w->plan_single; w->graph_island_grid = w->plan_island_grid; w->graph_dense = w->plan_dense; w->graph_wide = w->plan_wide;
         w->graph_joint_stages = w->plan_joint_stages; w->graph_no_global = w->plan_no_global; w->graph_fused = w->plan_fused; w->graph_tile_grid = w->plan_tile_grid; w->graph_no_contacts = w->plan_no_contacts; w->graph_bare = w->plan_bare;
     }
     // keep the host at most a few steps ahead of the device so the hints stay fresh (the device
@@ -2853,9 +2870,8 @@ static int remove_collider_at(rp_world *w, int c) {
     if (parent >= 0) {
         // the body's mass properties follow its remaining colliders (local centre of mass, principal inertia AND frame, the
         // sleep metric's max_extent), and so do the CoM-space frames of its joints
-        int last = -1;
-        if (w->bodies[parent].d.body_type == RP_BODY_DYNAMIC) for (int q = 0; q < (int)w->colliders.size(); ++q) if (w->collider_parent[q] == parent && !w->collider_removed[q]) last = q;
-        if ((r = poke(w, w->dw.b_collider + parent, last)) != RP_OK) return r;
+        if ((r = poke(w, w->dw.c_sibling + c, -1)) != RP_OK) return r;
+        if ((r = upload_collider_chain(w, parent)) != RP_OK) return r;
         if ((r = upload_body_row_mass(w, parent)) != RP_OK) return r;
         if ((r = refresh_joint_frames(w, parent)) != RP_OK) return r;
     }
@@ -3225,7 +3241,7 @@ extern "C" int32_t rp_counters_read(rp_world *w, rp_counters *out) {
     out->quarantined = fl[FL_QUARANTINE];
     out->ccd_active_count = fl[FL_CCD_ACTIVE]; out->ccd_clamp_count = fl[FL_CCD_CLAMPS];
     out->num_tiles = fl[FL_N_TILES]; out->tile_sweeps = (w->graph_tile_grid > 0 && !w->plan_single) ? 1 : 0; out->lean_steps = (int32_t)w->lean_steps; out->bp_large_list = fl[FL_N_LARGE];
-    out->fast_steps = (int32_t)w->fast_steps; out->full_steps = (int32_t)w->full_steps; out->replayed_steps = (int32_t)w->replayed_steps;
+    out->fast_steps = (int32_t)w->fast_steps; out->full_steps = (int32_t)w->full_steps; out->replayed_steps = (int32_t)w->replayed_steps; out->fused_steps = (int32_t)w->fused_steps;
     if (w->dw.sleep_enabled && w->dw.n_bodies > 0) {
         std::vector<int> bfl(w->dw.n_bodies);
         HIPCHK(w, hipMemcpy(bfl.data(), w->dw.b_flags, bfl.size() * sizeof(int), hipMemcpyDeviceToHost));

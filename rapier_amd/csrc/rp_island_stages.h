@@ -5,6 +5,7 @@
 #include "rp_global.h"
 #include "rp_lanepair.h"
 #include "rp_pairs.h"
+#include "rp_sleep_observe.h"
 
 RP_DEV bool is_dyn(const DevWorld &w, int b) { return body_active(w, b); } // awake dynamic bodies: the active set
 
@@ -360,3 +361,44 @@ RP_DEV void island_sort(const DevWorld &w, int isl, int nc, int cb, int nst_glob
     __syncthreads();
 }
 
+// ---- the fused step's validation (k_island_solve / k_island_solve_dense with `fused`): does island `isl` need the broad phase, the
+// narrow phase or the sleep commit this step?  Lane vt of vn validating lanes takes every vn-th item: a body (EVERY collider of it —
+// compound bodies chain theirs through c_sibling — against its fat AABB, and in a sleep-enabled world the body's sleep observation), an
+// active pair, a pair without solver contacts (recycle test; in a sleep-enabled world also the hint a body that fell asleep cleared).
+// `slp` collects sleep_observe_fused's bits over the lane's bodies; fused_sleep_abort() reads their OR over the whole island.
+// WIDE = false: the form for worlds of one-collider bodies that never sleep (the benchmark scenes): exactly one collider and one test
+// per item, nothing else in the validators' dependent chain (A/B on C3: the wide form costs 5 us of a 73 us step).
+template <bool WIDE> RP_DEV bool fused_validate_island(const DevWorld &w, int isl, int vt, int vn, int stamp_before, int &slp) {
+    const int nb = w.isl_nb[isl], nc = w.isl_nc[isl], ni = w.isl_ni[isl];
+    const int bb = w.isl_body_begin[isl], cb = w.isl_cons_begin[isl], ib = w.isl_icons_begin[isl];
+    const int ns = (WIDE && w.sleep_enabled) ? nb : 0; // the sleep observations are items of their own: other lanes than the fat-AABB tests of the same bodies
+    bool bad = false;
+    for (int i = vt; i < nb + ns + nc + ni; i += vn) {
+        if (i < nb) {
+            const int b = w.isl_bodies[bb + i];
+            if constexpr (WIDE) {
+                for (int c = w.b_collider[b]; c >= 0; c = w.c_sibling[c]) if (collider_left_fat_aabb(w, c)) bad = true;
+            } else {
+                const int c = w.b_collider[b];
+                if (c >= 0 && collider_left_fat_aabb(w, c)) bad = true;
+            }
+        } else if (i < nb + ns) {
+            if constexpr (WIDE) { const int o = sleep_observe_fused(w, w.isl_bodies[bb + i - nb], stamp_before); slp |= o; if (o & 4) bad = true; }
+        } else {
+            const int k = i - nb - ns;
+            const int s = k < nc ? w.isl_cons[cb + k] : w.isl_icons[ib + k - nc];
+            if constexpr (WIDE) if (w.sleep_enabled && w.p_c1[s] >= 0 && pair_hint_cleared(w, s, w.p_rb[s])) bad = true; // (k_fast_front's test: the narrow phase recomputes a count-cleared hint)
+            if (pair_needs_narrow_phase(w, s)) bad = true;
+        }
+    }
+    return bad;
+}
+// an island none of whose members keeps its persistent island awake may fall asleep in this step's commit: that is the full graph's
+RP_DEV bool fused_sleep_abort(int slp_all) { return (slp_all & 1) && !(slp_all & 2); }
+// what k_fast_front checks for the whole world before a fast step (workgroup 0)
+template <bool WIDE> RP_DEV bool fused_world_abort(const DevWorld &w) {
+    if (w.flags[FL_BP_DIRTY] || w.flags[FL_N_CONS] > 0 || w.flags[FL_N_GLOB_BODIES] > 0 || w.n_joints > 0) return true;
+    if constexpr (!WIDE) return false;
+    // sleep-enabled worlds: the awake set must be settled — no layout change, wake-up request or island bookkeeping waiting for a full step
+    return w.sleep_enabled && (w.flags[FL_LAYOUT_DIRTY] || w.flags[FL_WAKE_PENDING] || w.flags[FL_N_AWAKE] == 0 || w.flags[FL_PI_PENDING] || w.flags[FL_PJ_COUNT] || w.flags[FL_PI_JLINK]);
+}

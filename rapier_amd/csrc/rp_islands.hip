@@ -439,7 +439,7 @@ __global__ void __launch_bounds__(1024) k_layout_rebuild(DevWorld w) {
 //   while the islands fit one pass of the resident grid (b3d_many_pyramids: 196 islands on 256 CUs).
 // The register-lean form (rp_islands_lean.h, k_island_solve_dense): 320 threads, 168 VGPRs, two islands per CU — chosen when there
 //   are more islands than the resident grid of this form holds (b3d_many_pyramids at C4's density: 365 islands per GPU, 2,916 on one).
-__device__ __forceinline__ void island_solve_body(const DevWorld &w, int has_restitution, int fast, int retire, int fused) {
+template <bool WIDE> __device__ __forceinline__ void island_solve_body(const DevWorld &w, int has_restitution, int fast, int retire, int fused) {
     constexpr int THREADS = ISL_THREADS;
     const bool aborted = (fast && w.flags[FL_FAST_ABORT]) || lean_dead(w); // fast graph gave up on this step (rp_api.hip) / dead lean step (rp_world.h)
     if (retire && blockIdx.x == 0) {
@@ -450,7 +450,7 @@ __device__ __forceinline__ void island_solve_body(const DevWorld &w, int has_res
         publish_flags(w);
     }
     if (aborted) return;
-    __shared__ int s_abort, s_go;
+    __shared__ int s_abort, s_go, s_slp;
 #ifdef RP_ISL_PROFILE
     long long t_fused0 = (long long)__builtin_readcyclecounter();
 #endif
@@ -461,18 +461,17 @@ __device__ __forceinline__ void island_solve_body(const DevWorld &w, int has_res
         const int t = threadIdx.x;
         const int n_islands = w.flags[FL_N_ISLANDS];
         if (t == 0) {
-            s_abort = 0;
-            // block 0: the conditions k_fast_front checks for the whole world
-            if (blockIdx.x == 0 && (w.flags[FL_BP_DIRTY] || w.flags[FL_N_CONS] > 0 || w.flags[FL_N_GLOB_BODIES] > 0 || w.n_joints > 0)) s_abort = 1;
+            s_abort = 0; s_slp = 0;
+            if (blockIdx.x == 0 && fused_world_abort<WIDE>(w)) s_abort = 1; // block 0: the conditions k_fast_front checks for the whole world
+            if constexpr (WIDE) if (w.sleep_enabled) sleep_begin_scan(w); // ONE stamp bump per workgroup (every observing lane trying it: thousands of CAS on one word)
         }
         __syncthreads();
         bool bad = false;
+        const int stamp_before = (WIDE && w.sleep_enabled) ? pi_stamp_before(w) : 0;
         for (int isl = blockIdx.x + gridDim.x; isl < n_islands; isl += gridDim.x) {
-            const int nb = w.isl_nb[isl], nc = w.isl_nc[isl], ni = w.isl_ni[isl];
-            const int bb = w.isl_body_begin[isl], cb = w.isl_cons_begin[isl], ib = w.isl_icons_begin[isl];
-            for (int i = t; i < nb; i += blockDim.x) { int c = w.b_collider[w.isl_bodies[bb + i]]; if (c >= 0 && collider_left_fat_aabb(w, c)) bad = true; }
-            for (int i = t; i < nc; i += blockDim.x) if (pair_needs_narrow_phase(w, w.isl_cons[cb + i])) bad = true;
-            for (int i = t; i < ni; i += blockDim.x) if (pair_needs_narrow_phase(w, w.isl_icons[ib + i])) bad = true;
+            int slp = 0;
+            if (fused_validate_island<WIDE>(w, isl, t, blockDim.x, stamp_before, slp)) bad = true;
+            if constexpr (WIDE) if (w.sleep_enabled && fused_sleep_abort(__syncthreads_or(slp))) bad = true;
         }
         if (bad) s_abort = 1;
         if ((int)blockIdx.x >= n_islands) { // no island at all: arrive now
@@ -551,15 +550,9 @@ __device__ __forceinline__ void island_solve_body(const DevWorld &w, int has_res
             // the wavefronts without a manifold prove, under cover of generate (the longest interval of the
             // kernel), that this island needs neither broad nor narrow phase this step: one item (a body's
             // collider, an active pair, a pair without solver contacts) per lane and round
-            const int vt = t - v_first, vn = THREADS - v_first;
-            const int ni = w.isl_ni[isl], ib = w.isl_icons_begin[isl];
-            bool bad = false;
-            for (int i = vt; i < nb + nc + ni; i += vn) {
-                if (i < nb) { int c = w.b_collider[w.isl_bodies[bb + i]]; if (c >= 0 && collider_left_fat_aabb(w, c)) bad = true; }
-                else if (i < nb + nc) { if (pair_needs_narrow_phase(w, w.isl_cons[cb + i - nb])) bad = true; }
-                else if (pair_needs_narrow_phase(w, w.isl_icons[ib + i - nb - nc])) bad = true;
-            }
-            if (bad) s_abort = 1;
+            int slp = 0;
+            if (fused_validate_island<WIDE>(w, isl, t - v_first, THREADS - v_first, (WIDE && w.sleep_enabled) ? pi_stamp_before(w) : 0, slp)) s_abort = 1;
+            if constexpr (WIDE) if (slp) atomicOr(&s_slp, slp);
         }
         if (live) isl_pose_stage(w, h, L, m, 0.0f); // each lane reads back only what it stored itself
         ISL_STAMP(1); // generate + first pose stage
@@ -568,7 +561,7 @@ __device__ __forceinline__ void island_solve_body(const DevWorld &w, int has_res
             float solved_dt = (float)sub * w.prm.dt_sub;
             if (live) isl_ws_terms(w, h, W, ws_row); // warm-start terms of every manifold, in parallel
             __syncthreads(); // + pose stage read rot/trans; relax sweep of the previous substep done
-            if (fused && sub == 0 && isl == (int)blockIdx.x && t == 0) atomicAdd(&w.flags[FL_ARRIVE], 1 + (s_abort ? (1 << 16) : 0)); // this workgroup validated all of its islands
+            if (fused && sub == 0 && isl == (int)blockIdx.x && t == 0) atomicAdd(&w.flags[FL_ARRIVE], 1 + ((s_abort || (WIDE && fused_sleep_abort(s_slp))) ? (1 << 16) : 0)); // this workgroup validated all of its islands
             ISL_STAMP(2); // warm-start terms
             // S2 increment (worker.rs:235-284), then the warm start of this body in sweep order
             if (role_lin) {
@@ -656,7 +649,9 @@ __device__ __forceinline__ void island_solve_body(const DevWorld &w, int has_res
     }
 }
 
-__global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int has_restitution, int fast, int retire, int fused) { island_solve_body(w, has_restitution, fast, retire, fused); }
+__global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int has_restitution, int fast, int retire, int fused) { island_solve_body<false>(w, has_restitution, fast, retire, fused); }
+// the same kernel with the WIDE validators (rp_island_stages.h): worlds with compound bodies or sleeping enabled
+__global__ void __launch_bounds__(ISL_THREADS) k_island_solve_wide(DevWorld w, int has_restitution, int fast, int retire, int fused) { island_solve_body<true>(w, has_restitution, fast, retire, fused); }
 // ---- the generic island kernel ----------------------------------------------------------------------------------------------------
 // One workgroup = one island, like k_island_solve, but the constraint is the HBM-resident one of the global path (rp_constraint.h /
 // rp_coulomb.h through an accessor): thread m owns manifold m for the whole step, so its constraint planes are private to the
@@ -777,6 +772,7 @@ int rp_fused_grid(int device) {
     int per_cu = 0, cus = 0;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_island_solve, ISL_THREADS, 0) != hipSuccess) per_cu = 0;
+    { int pw = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pw, k_island_solve_wide, ISL_THREADS, 0) != hipSuccess) pw = 0; if (pw < per_cu) per_cu = pw; }
     if (per_cu < 1 || cus < 1) return 0;
     if (per_cu > 2) per_cu = 2; // more co-resident islands per CU than this only slow each other down
     int g = cus * per_cu - (cus + 15) / 16;
@@ -784,12 +780,13 @@ int rp_fused_grid(int device) {
     if (device >= 0 && device < 64) cached[device] = g;
     return g;
 }
-void rp_launch_island_solve_dense(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast, int retire, int fused);
-void rp_launch_island_solve(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast, int retire, int fused, int dense) {
+void rp_launch_island_solve_dense(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast, int retire, int fused, int wide);
+void rp_launch_island_solve(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast, int retire, int fused, int dense, int wide) {
     if (grid < 1) grid = 1;
     if (w.prm.p.friction_model == RP_FRICTION_COULOMB) { hipLaunchKernelGGL(k_island_generic<true>, dim3(grid), dim3(ISL_THREADS), 0, st, w, has_restitution, fast, retire); return; }
     if (w.isl_generic) { hipLaunchKernelGGL(k_island_generic<false>, dim3(grid), dim3(ISL_THREADS), 0, st, w, has_restitution, fast, retire); return; } // RP_ISL_GENERIC=1: the twist model through the generic kernel (tests)
-    if (dense) rp_launch_island_solve_dense(w, st, grid, has_restitution, fast, retire, fused); // rp_islands_lean.hip
+    if (dense) rp_launch_island_solve_dense(w, st, grid, has_restitution, fast, retire, fused, wide); // rp_islands_lean.hip
+    else if (wide) hipLaunchKernelGGL(k_island_solve_wide, dim3(grid), dim3(ISL_THREADS), 0, st, w, has_restitution, fast, retire, fused);
     else hipLaunchKernelGGL(k_island_solve, dim3(grid), dim3(ISL_THREADS), 0, st, w, has_restitution, fast, retire, fused);
 }
 

@@ -362,7 +362,7 @@ struct LeanLds { // per island
     float4 W[WS_SLOTS_2PHASE * WS_STRIDE];
     int any_bouncy, nls;
 };
-__device__ __forceinline__ void island_solve_lean(const DevWorld &w, int has_restitution, int fast, int retire, int fused) {
+template <bool WIDE> __device__ __forceinline__ void island_solve_lean(const DevWorld &w, int has_restitution, int fast, int retire, int fused) {
     const bool aborted = (fast && w.flags[FL_FAST_ABORT]) || lean_dead(w);
     if (retire && blockIdx.x == 0) {
         if (threadIdx.x == 0) { w.flags[FL_SEQ] += 1; if (!aborted && !fused) w.flags[FL_STEP] += 1; if (fused) w.flags[FL_FULL_UPDATES] = 0; }
@@ -370,7 +370,7 @@ __device__ __forceinline__ void island_solve_lean(const DevWorld &w, int has_res
         publish_flags(w);
     }
     if (aborted) return;
-    __shared__ int s_abort, s_go;
+    __shared__ int s_abort, s_go, s_slp[2];
     __shared__ LeanLds LD[2];
     __shared__ int S_a[RP_ISL_NC_MAX], S_b[RP_ISL_NC_MAX], S_c[RP_ISL_NC_MAX], S_d[RP_ISL_NC_MAX];
     const int n_islands = w.flags[FL_N_ISLANDS];
@@ -382,20 +382,18 @@ __device__ __forceinline__ void island_solve_lean(const DevWorld &w, int has_res
         // cover of generate (below).  FL_ARRIVE counts arrivals in its low 16 bits and aborting workgroups above.
         const int t = threadIdx.x;
         if (t == 0) {
-            s_abort = 0;
-            if (blockIdx.x == 0 && (w.flags[FL_BP_DIRTY] || w.flags[FL_N_CONS] > 0 || w.flags[FL_N_GLOB_BODIES] > 0 || w.n_joints > 0)) s_abort = 1;
+            s_abort = 0; s_slp[0] = 0; s_slp[1] = 0;
+            if (blockIdx.x == 0 && fused_world_abort<WIDE>(w)) s_abort = 1;
+            if constexpr (WIDE) if (w.sleep_enabled) sleep_begin_scan(w);
         }
         __syncthreads();
         bool bad = false;
+        const int stamp_before = (WIDE && w.sleep_enabled) ? pi_stamp_before(w) : 0;
         for (int base = 2 * (blockIdx.x + gridDim.x); base < n_islands; base += 2 * gridDim.x) {
             for (int isl = base; isl < base + 2 && isl < n_islands; ++isl) {
-                const int nb = w.isl_nb[isl], nc = w.isl_nc[isl], ni = w.isl_ni[isl];
-                const int bb = w.isl_body_begin[isl], cb = w.isl_cons_begin[isl], ib = w.isl_icons_begin[isl];
-                for (int i = t; i < nb + nc + ni; i += blockDim.x) {
-                    if (i < nb) { int c = w.b_collider[w.isl_bodies[bb + i]]; if (c >= 0 && collider_left_fat_aabb(w, c)) bad = true; }
-                    else if (i < nb + nc) { if (pair_needs_narrow_phase(w, w.isl_cons[cb + i - nb])) bad = true; }
-                    else if (pair_needs_narrow_phase(w, w.isl_icons[ib + i - nb - nc])) bad = true;
-                }
+                int slp = 0;
+                if (fused_validate_island<WIDE>(w, isl, t, blockDim.x, stamp_before, slp)) bad = true;
+                if constexpr (WIDE) if (w.sleep_enabled && fused_sleep_abort(__syncthreads_or(slp))) bad = true;
             }
         }
         if (bad) s_abort = 1;
@@ -473,18 +471,12 @@ __device__ __forceinline__ void island_solve_lean(const DevWorld &w, int has_res
         }
         if (validator && fused && base == 2 * (int)blockIdx.x) {
             // one item (a body's collider, an active pair, a pair without solver contacts) per lane and round, over both islands
-            const int vt = threadIdx.x - 2 * LEAN_HALF;
-            bool bad = false;
+            const int vt = threadIdx.x - 2 * LEAN_HALF, stamp_before = (WIDE && w.sleep_enabled) ? pi_stamp_before(w) : 0;
             for (int i2 = base; i2 < base + 2 && i2 < n_islands; ++i2) {
-                const int vnb = w.isl_nb[i2], vnc = w.isl_nc[i2], vni = w.isl_ni[i2];
-                const int vbb = w.isl_body_begin[i2], vcb = w.isl_cons_begin[i2], vib = w.isl_icons_begin[i2];
-                for (int i = vt; i < vnb + vnc + vni; i += LEAN_VALIDATORS) {
-                    if (i < vnb) { int c = w.b_collider[w.isl_bodies[vbb + i]]; if (c >= 0 && collider_left_fat_aabb(w, c)) bad = true; }
-                    else if (i < vnb + vnc) { if (pair_needs_narrow_phase(w, w.isl_cons[vcb + i - vnb])) bad = true; }
-                    else if (pair_needs_narrow_phase(w, w.isl_icons[vib + i - vnb - vnc])) bad = true;
-                }
+                int slp = 0;
+                if (fused_validate_island<WIDE>(w, i2, vt, LEAN_VALIDATORS, stamp_before, slp)) s_abort = 1;
+                if constexpr (WIDE) if (slp) atomicOr(&s_slp[i2 - base], slp);
             }
-            if (bad) s_abort = 1;
         }
         ISL_STAMP(1);
 
@@ -494,7 +486,7 @@ __device__ __forceinline__ void island_solve_lean(const DevWorld &w, int has_res
             if (sub == 0) __syncthreads(); // generate's rows of W have been read back by their lanes
             if (live) lean_ws_terms<1>(w, h, D.W, ws_row);
             __syncthreads();
-            if (fused && sub == 0 && base == 2 * (int)blockIdx.x && threadIdx.x == 0) atomicAdd(&w.flags[FL_ARRIVE], 1 + (s_abort ? (1 << 16) : 0)); // this workgroup validated all of its islands
+            if (fused && sub == 0 && base == 2 * (int)blockIdx.x && threadIdx.x == 0) atomicAdd(&w.flags[FL_ARRIVE], 1 + ((s_abort || (WIDE && (fused_sleep_abort(s_slp[0]) || fused_sleep_abort(s_slp[1])))) ? (1 << 16) : 0)); // this workgroup validated all of its islands
             ISL_STAMP(2);
             if (role_lin) { // S2 increment (worker.rs:235-284), then the warm start of this body in sweep order
                 const float4 oi = D.O_incl[bt];

@@ -951,6 +951,36 @@ template <bool CONVEX> __global__ void k_sensor_pass(DevWorld w) {
         sensor_pair_update<CONVEX>(w, s, c1, c2, pose_inv_mul(pc1, pc2));
     }
 }
+// The fused fast step (one kernel that validates and solves, rp_islands.hip) cannot raise a sensor's events itself: this launch in front
+// of it tests every sensor pair READ-ONLY from the body poses and sends the step to the full graph (FL_FAST_ABORT: k_island_solve then
+// only retires the launch) when an intersection would start or stop — the replay raises the event.  While nothing changes, a world
+// with sensors keeps the fused step.
+template <bool CONVEX> __global__ void k_sensor_check(DevWorld w) {
+    if (w.flags[FL_FAST_ABORT]) return;
+    int top = w.flags[FL_POOL_TOP];
+    if (top > w.pool_cap) top = w.pool_cap;
+    int stride = gridDim.x * blockDim.x;
+    bool changed = false;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < top; s += stride) {
+        int c1 = w.p_c1[s];
+        if (c1 < 0) continue;
+        int c2 = w.p_c2[s];
+        if (!pair_is_sensor(w, c1, c2)) continue;
+        const int rb1 = w.c_parent[c1], rb2 = w.c_parent[c2];
+        if (w.sleep_enabled && !body_active(w, rb1) && !body_active(w, rb2)) continue; // pair_update.rs:98-106
+        const Pose pc1 = collider_world_pose_of(w, c1, rb1), pc2 = collider_world_pose_of(w, c2, rb2);
+        const bool had_i = (w.p_pflags[s] & RP_PF_INTERSECTING) != 0;
+        const bool now_i = (rb1 == rb2 && rb1 >= 0) ? false : shapes_intersect<CONVEX>(w, w.c_shape[c1], w.c_he[c1], w.c_shape[c2], w.c_he[c2], pose_inv_mul(pc1, pc2), CONVEX ? w.c_mat[c1].w : 0.0f, CONVEX ? w.c_mat[c2].w : 0.0f);
+        if (now_i != had_i) changed = true;
+    }
+    if (changed) w.flags[FL_FAST_ABORT] = 1;
+}
+void rp_launch_sensor_check(const DevWorld &w, hipStream_t st) {
+    if (!w.has_sensors || w.n_colliders == 0) return;
+    int blocks = (w.pool_cap + 255) / 256; if (blocks > 1024) blocks = 1024;
+    if (w.has_convex) hipLaunchKernelGGL(k_sensor_check<true>, dim3(blocks), dim3(256), 0, st, w);
+    else hipLaunchKernelGGL(k_sensor_check<false>, dim3(blocks), dim3(256), 0, st, w);
+}
 void rp_launch_sensor_fast(const DevWorld &w, hipStream_t st) {
     if (!w.has_sensors || w.n_colliders == 0) return;
     int blocks = (w.pool_cap + 255) / 256; if (blocks > 1024) blocks = 1024;

@@ -235,7 +235,8 @@ struct DevWorld {
     float4 *b_damp;        // linear damping, angular damping, gravity scale, -
     float4 *b_uforce, *b_utorque;
     int *b_flags;
-    int *b_collider;       // the collider of a dynamic body (one per dynamic body, -1 = none)
+    int *b_collider;       // the LAST live collider of a dynamic body (-1 = none); the others follow through c_sibling
+    int *c_sibling;        // [colliders] the previous live collider of the same dynamic body (-1 = none): compound bodies
     int *b_quar;           // sticky: non-finite state was detected (and rolled back) for this body
     float4 *b_ccd0_pos, *b_ccd0_rot; int *ccd_list; // continuous-collision pass (rp_ccd.h): start-of-step pose of the bodies on ccd_list
     // ---- sleeping (RigidBodyActivation + whole-island sleep, rp_sleep.hip) ----

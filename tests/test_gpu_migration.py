@@ -63,15 +63,18 @@ def test_hits_looked_at_every_fourth_step_still_catch_the_cube_in_time():
     shards.worlds[0].write_bodies([shards.handle[0][top]], vel6=kick)
     assert abs(shards.worlds[0].max_linear_speed() - float(np.linalg.norm(kick[0, :3]))) < 1e-5
     moved_at = None
-    for look in range(1, 36):
+    for look in range(1, 17):                                            # 64 steps: the cube is in the air all the time
         whole.step(4); shards.step(4)
         if moved_at is None and shards.migrations > 0:
             moved_at = look
-            gp, gv = shards.read_bodies(); wp, wv = whole.read_bodies()
-            np.testing.assert_array_equal(gp, wp); np.testing.assert_array_equal(gv, wv)   # caught in flight: nothing was missed
+        # before AND after the hand-over nothing was missed: the assembled shards are the whole world, bit for bit
+        gp, gv = shards.read_bodies(); wp, wv = whole.read_bodies()
+        np.testing.assert_array_equal(gp, wp); np.testing.assert_array_equal(gv, wv)
     assert moved_at is not None and shards.migrations == 1 and shards.owner[top] == 1
     assert shards.guard_refreshes > 0                                    # the flying cube dragged its box along
+    whole.step(12); shards.step(12)                                      # the landing: in shard 1 the cube sits in another row (colour order differs)
     gp, _ = shards.read_bodies(); wp, _ = whole.read_bodies()
-    assert np.isfinite(gp).all() and np.abs(gp[:, :3] - wp[:, :3]).max() < 0.05
+    assert np.isfinite(gp).all() and np.abs(gp[:, :3] - wp[:, :3]).max() < 0.1
+    assert abs(float(gp[top, 0]) - other_x) < 6.0                        # it is over there
     for r in (0, 1):
         assert shards.worlds[r].counters()["overflow_flags"] == 0
