@@ -46,6 +46,7 @@ def test_two_ranks_share_one_gpu_and_assemble_the_whole_world(tmp_path):
     np.testing.assert_array_equal(g["vel"], vel)
     d = line["dist"]
     assert line["n_gpus"] == 2 and d["backend"] == "gloo" and d["world_size"] == 2 and d["gathered_bodies"] == 1 + 24 * 55 and line["finite"]
-    assert d["shard_source"].startswith("device proximity groups (24 groups")
+    assert d["shard_source"].startswith("device proximity groups discovered on rank 0 and broadcast (24 groups")   # rank 1 never built the whole world
+    assert len(d["per_rank_step_paths"]) == 2 and all(p["fast"] + p["full"] > 0 for p in d["per_rank_step_paths"])
     assert line["config"]["total_cuboids"] == 24 * 55 and line["config"]["bodies_per_gpu"] == 12 * 55
     assert line["config"]["strong_scaling_anchor"] is None or "c4_world_steps_per_s_on_1_gpu" in line["config"]["strong_scaling_anchor"]
