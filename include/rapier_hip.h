@@ -355,6 +355,15 @@ int32_t rp_world_set_shard_guard_horizon(rp_world *w, float seconds);
  * guard's hits every k steps inflates the boxes by 2 * speed * dt * k so that no body crosses a box between two looks
  * (no reference counterpart: the reference has one address space). */
 int32_t rp_world_max_linear_speed(rp_world *w, float *out);
+/* Batches of small worlds (no reference counterpart: the reference steps one World per call; the closest reference construct is ONE
+ * World whose PhysicsHooks::filter_contact_pair, physics_hooks.rs:203, rejects pairs across the groups).  Everything inserted after
+ * rp_world_begin_subworld belongs to a new sub-world (returns its index; the bodies / colliders inserted before the first call are
+ * sub-world 0); colliders of different sub-worlds never pair, so sub-worlds may overlap in space; they share the integration
+ * parameters and every launch of rp_step.  The result is that of the one reference world described above — for n copies of one scene,
+ * bit for bit the result of stepping each copy alone (colour populations then agree; tests/test_gpu_subworlds.py). */
+int32_t rp_world_begin_subworld(rp_world *w);
+/* rp_step(worlds[i], steps) for every i, enqueued back to back on the worlds' own streams before anything is waited for. */
+int32_t rp_step_many(rp_world *const *worlds, int32_t n, int32_t steps);
 int32_t rp_num_bodies(const rp_world *w);
 
 /* NarrowPhase::contact_pairs() analogue: for each active solver manifold: (collider1, collider2,

@@ -99,6 +99,7 @@ typedef struct {
     uint32_t active_events; float force_threshold;
     int ord;            /* ordinal among the colliders attached to the same parent (attachment order) */
     Aabb fat; int has_fat;
+    int sub;            /* sub-world (ro_begin_subworld): colliders of different sub-worlds never pair */
 } Collider;
 
 /* SolverContact — contact_pair.rs:617-629 */
@@ -213,6 +214,7 @@ struct ro_world {
     ro_params params; v3 gravity;
     Body *bodies; int nbodies, cap_bodies;
     Collider *colliders; int ncolliders, cap_colliders;
+    int cur_sub, n_sub; /* ro_begin_subworld */
     RoPolyhedron **polys; int npolys; /* ro_add_convex_polyhedron */
     struct RoComposite **comps; int ncomps; /* ro_add_compound / ro_add_trimesh / ro_add_heightfield */
     int subpair_overflows; /* collider pairs that met more than RO_MAX_SUBPAIRS candidate sub-shape pairs (cumulative) */
@@ -313,6 +315,7 @@ float ro_combine_coefficient(float a, float b, int32_t ra, int32_t rb) {
 
 ro_world *ro_world_new(const ro_params *params, const float gravity[3]) {
     ro_world *w = (ro_world *)calloc(1, sizeof(ro_world));
+    w->n_sub = 1;
     w->params = *params;
     w->gravity = V3(gravity[0], gravity[1], gravity[2]);
     w->map_cap = 1 << 12;
@@ -751,7 +754,7 @@ int32_t ro_add_collider(ro_world *w, const ro_collider_desc *d, int32_t parent) 
     w->coll_gen[idx] = w->coll_arena_gen;
     Collider *c = &w->colliders[idx];
     memset(c, 0, sizeof(*c));
-    c->parent = parent;
+    c->parent = parent; c->sub = w->cur_sub;
     c->shape = ro_core_shape(d->shape); c->border = (d->shape >= RO_SHAPE_ROUND_CUBOID && d->shape <= RO_SHAPE_ROUND_CONVEX_POLYHEDRON) ? d->border_radius : 0.0f; /* a round shape = its inner shape + a border radius */
     c->he = V3(d->half_extents[0], d->half_extents[1], d->half_extents[2]);
     c->radius = d->half_extents[0];
@@ -776,6 +779,8 @@ int32_t ro_add_collider(ro_world *w, const ro_collider_desc *d, int32_t parent) 
     return idx;
 }
 
+/* everything added from now on belongs to a new sub-world (the twin of rp_world_begin_subworld) */
+int32_t ro_begin_subworld(ro_world *w) { if (w->ncolliders == 0 && w->nbodies == 0 && w->n_sub == 1) return 0; w->cur_sub = w->n_sub++; return w->cur_sub; }
 int32_t ro_num_bodies(const ro_world *w) { return w->nbodies; }
 void ro_read_bodies(const ro_world *w, float *pos7, float *vel6) {
     for (int i = 0; i < w->nbodies; ++i) {
@@ -987,6 +992,7 @@ static int pair_selected(const ro_world *w, const Pair *p) {
 
 /* update.rs:334-396 pair filter (same parent, collision types, groups) */
 static int bp_pair_allowed(const ro_world *w, const Collider *a, const Collider *b) {
+    if (a->sub != b->sub) return 0; /* batched small worlds (rapier_hip.h rp_world_begin_subworld): as a filter_contact_pair hook would */
     if (a->parent >= 0 && a->parent == b->parent) return 0;
     if (!body_is_dynamic(w, a->parent) && !body_is_dynamic(w, b->parent)) return 0; /* ActiveCollisionTypes::default */
     if (!((a->memberships & b->filter) != 0 && (b->memberships & a->filter) != 0)) return 0;
@@ -2943,7 +2949,7 @@ static void ccd_sweep_tier(ro_world *w, int bullets) {
             const float rot_radius = ccd_rot_radius(&s2, co1->pos_wrt_parent, rb1->local_com);
             for (int t = 0; t < w->ncolliders; ++t) {
                 const Collider *co2 = &w->colliders[t];
-                if (t == f || co2->parent == bi || !collider_enabled(co2) || co2->sensor || co_is_composite(co2)) continue;
+                if (t == f || co2->parent == bi || !collider_enabled(co2) || co2->sensor || co_is_composite(co2) || co2->sub != co1->sub) continue;
                 const Body *rb2 = co2->parent >= 0 ? &w->bodies[co2->parent] : NULL;
                 /* tier_allows (sweeps.rs:35-41): a non-bullet only meets fixed targets, a bullet everything but bullets */
                 if (bullets) { if (rb2 && ccd_is_bullet(rb2)) continue; } else if (rb2 && rb2->body_type != RO_BODY_FIXED) continue;

@@ -123,6 +123,8 @@ void ro_set_params(ro_world *w, const ro_params *params);
 void ro_world_free(ro_world *w);
 int32_t ro_add_body(ro_world *w, const ro_body_desc *d);
 int32_t ro_add_collider(ro_world *w, const ro_collider_desc *d, int32_t parent_body);
+/* twin of rp_world_begin_subworld (include/rapier_hip.h): what is added from now on belongs to a new sub-world; returns its index */
+int32_t ro_begin_subworld(ro_world *w);
 /* SharedShape::convex_mesh(points, indices): registers a convex polyhedron (closed, outward-wound triangle mesh); returns its id or -1 */
 int32_t ro_add_convex_polyhedron(ro_world *w, int32_t n_points, const float *points_xyz, int32_t n_triangles, const uint32_t *indices);
 /* Composite shapes (registered once, shared by colliders; -1 = invalid input).  Compound: `parts` are collider descriptors of which only

@@ -128,6 +128,7 @@ struct rp_world {
     std::vector<HostBody> bodies;
     std::vector<rp_collider_desc> colliders;
     std::vector<int> collider_parent, collider_ord; // ord: ordinal among the colliders of the same parent (attachment order)
+    std::vector<int> collider_sub; int cur_sub = 0, n_sub = 1; // sub-worlds (rp_world_begin_subworld): the one every collider was inserted into
     int next_free_ord = 0;
     // Arena slots (data/arena.rs:28-90, 260-380): a removed body / collider slot is handed out again, LIFO, before a fresh index is;
     // a handle = generation << 32 | index, the generation being the arena's removal count at insertion time
@@ -1277,10 +1278,10 @@ extern "C" int32_t rp_colliders_insert(rp_world *w, int32_t n, const rp_collider
         }
         if (reuse) {
             ci = w->coll_free.back(); w->coll_free.pop_back();
-            w->collider_ord[(size_t)ci] = ord_counter++; w->colliders[(size_t)ci] = cd; w->collider_parent[(size_t)ci] = parent; w->collider_removed[(size_t)ci] = 0; w->collider_poly[(size_t)ci] = poly; w->collider_comp[(size_t)ci] = comp;
+            w->collider_ord[(size_t)ci] = ord_counter++; w->colliders[(size_t)ci] = cd; w->collider_parent[(size_t)ci] = parent; w->collider_removed[(size_t)ci] = 0; w->collider_poly[(size_t)ci] = poly; w->collider_comp[(size_t)ci] = comp; w->collider_sub[(size_t)ci] = w->cur_sub;
         } else {
             ci = (int)w->colliders.size();
-            w->collider_ord.push_back(ord_counter++); w->colliders.push_back(cd); w->collider_parent.push_back(parent); w->collider_removed.push_back(0); w->coll_gen.push_back(0); w->collider_poly.push_back(poly); w->collider_comp.push_back(comp);
+            w->collider_ord.push_back(ord_counter++); w->colliders.push_back(cd); w->collider_parent.push_back(parent); w->collider_removed.push_back(0); w->coll_gen.push_back(0); w->collider_poly.push_back(poly); w->collider_comp.push_back(comp); w->collider_sub.push_back(w->cur_sub);
         }
         w->coll_gen[(size_t)ci] = w->coll_arena_gen;
         new_slots.push_back(ci);
@@ -1481,6 +1482,7 @@ static int upload_collider_chain(rp_world *w, int parent) {
 static int upload_collider_row(rp_world *w, int i) {
     const DevWorld &d = w->dw;
     ColliderRow r = pack_collider(w, i);
+    PUT(d.c_sub, i, w->collider_sub[(size_t)i]);
     PUT(d.c_parent, i, r.parent); PUT(d.c_ord, i, r.ord); PUT(d.c_shape, i, r.shape); PUT(d.c_lpos, i, r.lp); PUT(d.c_lrot, i, r.lr); PUT(d.c_he, i, r.he); PUT(d.c_mat, i, r.mat);
     PUT(d.c_rules, i, r.rules); PUT(d.c_groups, i, r.groups); PUT(d.c_fatmin, i, r.fmn); PUT(d.c_fatmax, i, r.fmx); PUT(d.c_events, i, r.events);
     return RP_OK;
@@ -1619,6 +1621,7 @@ static int finalize(rp_world *w) {
     { const char *dv = getenv("RP_BP_INCR_DIV"); d.bp_incr_div = dv ? std::max(1, atoi(dv)) : 1; }
     { const char *ab = getenv("RP_BP_ALWAYS_BUILD"); d.bp_always_build = (ab && ab[0] == '1') ? 1 : 0; }
     { const char *nt = getenv("RP_NO_TINY_ROUTING"); d.isl_route_tiny = (nt && nt[0] == '1') ? 0 : 1; }
+    { const char *im = getenv("RP_ISL_MANY"); d.isl_many = im ? std::max(1, atoi(im)) : (w->fused_grid > 0 ? w->fused_grid : 240); } // (more candidates than ONE resident pass of k_island_solve: round 5, a batch of 64 capsule worlds — 320 islands of 4 manifolds — 414 -> 230 us per step; round 4 waited for 960)
     { const char *ig = getenv("RP_ISL_GENERIC"); d.isl_generic = (ig && ig[0] == '1') ? 1 : 0; }
     w->compound = world_has_compound_bodies(w); refresh_ccd_facts(w);
     int nb = (int)w->bodies.size(), nc = (int)w->colliders.size();
@@ -1666,13 +1669,15 @@ static int finalize(rp_world *w) {
     DA(d.sg_hit, capb); DA(d.lay_state, 16); DA(d.ov_owner, d.cons_cap);
     DAC(d.s_lin, capb, DOM_BODY, 1, 1); DAC(d.s_ang, capb, DOM_BODY, 1, 1); DAC(d.s_rot, capb, DOM_BODY, 1, 1); DAC(d.s_trans, capb, DOM_BODY, 1, 1); DAC(d.s_incl, capb, DOM_BODY, 1, 1); DAC(d.s_inca, capb, DOM_BODY, 1, 1);
     DAC(d.b_cmask, 4 * (size_t)capb, DOM_BODY, 1, 4); DAFC(d.b_min, capb, 0xff, DOM_BODY, 1, 1);
-    DAC(d.c_parent, capc, DOM_COLL, 1, 1); DAC(d.c_ord, capc, DOM_COLL, 1, 1); DAC(d.c_shape, capc, DOM_COLL, 1, 1); DAC(d.c_lpos, capc, DOM_COLL, 1, 1); DAC(d.c_lrot, capc, DOM_COLL, 1, 1); DAC(d.c_pos, capc, DOM_COLL, 1, 1); DAC(d.c_rot, capc, DOM_COLL, 1, 1); DAC(d.c_he, capc, DOM_COLL, 1, 1);
+    DAC(d.c_parent, capc, DOM_COLL, 1, 1); DAC(d.c_sub, capc, DOM_COLL, 1, 1); DAC(d.c_ord, capc, DOM_COLL, 1, 1); DAC(d.c_shape, capc, DOM_COLL, 1, 1); DAC(d.c_lpos, capc, DOM_COLL, 1, 1); DAC(d.c_lrot, capc, DOM_COLL, 1, 1); DAC(d.c_pos, capc, DOM_COLL, 1, 1); DAC(d.c_rot, capc, DOM_COLL, 1, 1); DAC(d.c_he, capc, DOM_COLL, 1, 1);
     DAC(d.c_mat, capc, DOM_COLL, 1, 1); DAC(d.c_rules, capc, DOM_COLL, 1, 1); DAC(d.c_groups, capc, DOM_COLL, 1, 1); DAC(d.c_fatmin, capc, DOM_COLL, 1, 1); DAC(d.c_fatmax, capc, DOM_COLL, 1, 1); DAC(d.c_events, capc, DOM_COLL, 1, 1);
     d.ev_cap = std::max(65536, d.pool_cap); // a step raises at most one collision event and one force event per pair slot: a queue that is read every step cannot overflow
     DAC(d.ev_col, d.ev_cap, DOM_FIXED, 1, 1); DAC(d.ev_force_meta, d.ev_cap, DOM_FIXED, 1, 1); DAC(d.ev_force_a, d.ev_cap, DOM_FIXED, 1, 1); DAC(d.ev_force_b, d.ev_cap, DOM_FIXED, 1, 1);
     for (int k = 0; k < 2; ++k) { DA(d.bk_cnt[k], d.grid_cap); DA(d.bk_items[k], (size_t)d.grid_cap * RP_BP_BUCKET); } // the broad-phase grid: fixed-slot hash buckets, two copies (rp_broadphase.hip)
     DA(d.scan_block, 1024 + 8); // the scratch counters of a running broad-phase rebuild
     DA(d.large_list, d.large_cap);
+    d.sub_cap = std::max(1024, 2 * w->n_sub);
+    DA(d.large_sub_begin, (size_t)d.sub_cap + 2); DA(d.large_sub_cur, (size_t)d.sub_cap + 2); DA(d.large_tmp, d.large_cap);
     DA(d.c_chgstamp, capc); DA(d.c_stale, capc); DA(d.c_inlarge, capc); DA(d.c_rver, capc); DA(d.bp_chg_list, capc); DA(d.free_pending, d.pool_cap); // incremental broad phase (scratch: rebuilt by the next full pass)
     DAF(d.h_key[0], d.hash_cap, 0xff); DAF(d.h_key[1], d.hash_cap, 0xff); DA(d.h_slot[0], d.hash_cap); DA(d.h_slot[1], d.hash_cap);
     DAC(d.free_stack, d.pool_cap, DOM_PAIR, 1, 1);
@@ -1838,6 +1843,7 @@ static int finalize(rp_world *w) {
             ColliderRow r = pack_collider(w, i);
             cpar[i] = r.parent; cord[i] = r.ord; csh[i] = r.shape; clp[i] = r.lp; clr[i] = r.lr; che[i] = r.he; cmat[i] = r.mat; crul[i] = r.rules; cgrp[i] = r.groups; fmn[i] = r.fmn; fmx[i] = r.fmx; cev[i] = r.events;
         }
+        UP(d.c_sub, w->collider_sub); d.n_sub = w->n_sub;
         UP(d.c_parent, cpar); UP(d.c_ord, cord); UP(d.c_shape, csh); UP(d.c_lpos, clp); UP(d.c_lrot, clr); UP(d.c_he, che); UP(d.c_mat, cmat);
         UP(d.c_rules, crul); UP(d.c_groups, cgrp); UP(d.c_fatmin, fmn); UP(d.c_fatmax, fmx); UP(d.c_events, cev);
         HIPCHK(w, hipStreamSynchronize(w->stream)); // the staging vectors die here
@@ -1968,7 +1974,10 @@ static void plan_from_hints(rp_world *w, const int *fl) {
     {
         const int n_isl = fl[FL_N_ISLANDS];
         bool lean_wins = false;
-        if (w->fused_grid_dense > 0 && w->fused_grid > 0 && n_isl > w->fused_grid) {
+        // (the model is the pyramids' — 145 manifolds per island; islands of a few bodies finish a pass of the classic form long before
+        // 71 us and gain nothing from sharing a CU: a batch of 64 capsule worlds, 320 islands of 4 manifolds, took 136 us per lean launch)
+        const bool sizable = (long long)fl[FL_N_CONS_ALL] - fl[FL_N_CONS] >= 48ll * n_isl;
+        if (w->fused_grid_dense > 0 && w->fused_grid > 0 && n_isl > w->fused_grid && sizable) {
             const long long classic = (long long)((n_isl + w->fused_grid - 1) / w->fused_grid) * 71;
             const long long lean = (long long)((n_isl + 2 * w->fused_grid_dense - 1) / (2 * w->fused_grid_dense)) * 118;
             lean_wins = lean < classic;
@@ -2736,6 +2745,37 @@ extern "C" int32_t rp_world_set_shard_guard(rp_world *w, int32_t n, const float 
 // The time a guard hit may wait for the caller (the steps between two rp_world_shard_guard_take_hits x dt): the device tests every
 // rewritten fat AABB INFLATED by |linvel of its body| x horizon, so a body is caught that many steps before it reaches a foreign box —
 // per body, not one world-wide clearance that would merge shards which merely stand close (rapier_amd/sharding.py: ShardSet).
+// A batch of small, independent worlds in ONE device world: everything inserted after this call belongs to a new
+// sub-world; colliders of different sub-worlds never form a pair (the broad phase keys its cells with the sub-world, pair_allowed
+// rejects what still meets), so the sub-worlds may occupy the same space.  They share the integration parameters, the step counter and
+// every launch: a step of the batch costs what a step of one world with that many islands costs, not n small launches sequences.
+// In reference terms: one World whose PhysicsHooks::filter_contact_pair rejects pairs across sub-worlds.
+extern "C" int32_t rp_world_begin_subworld(rp_world *w) {
+    if (!w) return RP_ERR_INVALID;
+    if (w->colliders.empty() && w->bodies.empty() && w->n_sub == 1) return 0; // the implicit first sub-world is still empty
+    w->cur_sub = w->n_sub++;
+    if (w->finalized) { // kernels take n_sub from the DevWorld they are launched with
+        HIPCHK(w, hipSetDevice(w->device));
+        int r = settle(w); if (r != RP_OK) return r;
+        if (w->n_sub > w->dw.sub_cap) { r = rebuild_begin(w); if (r != RP_OK) return r; } // the per-sub-world tables are full: the next step rebuilds the device world from the current state
+        else {
+            w->dw.n_sub = w->n_sub;
+            destroy_graphs(w);
+            // the broad phase's large list is segmented by sub-world: the next pass builds it afresh (and finds the newcomers)
+            int one = 1; HIPCHK(w, hipMemcpyAsync(w->dw.flags + FL_BP_FORCE_FULL, &one, sizeof(int), hipMemcpyHostToDevice, w->stream)); HIPCHK(w, hipStreamSynchronize(w->stream));
+        }
+    }
+    return w->cur_sub;
+}
+// rp_step for several worlds from one host thread: every world's steps are enqueued on its own stream before any of them is waited for,
+// so worlds that do not fill the device overlap.  (Small worlds of ONE parameter set are better served as sub-worlds of one world.)
+extern "C" int32_t rp_step_many(rp_world *const *worlds, int32_t n, int32_t steps) {
+    if (!worlds || n < 0 || steps < 0) return RP_ERR_INVALID;
+    for (int32_t i = 0; i < n; ++i) if (!worlds[i]) return RP_ERR_INVALID;
+    for (int32_t s = 0; s < steps; ++s) // step-major: the worlds advance together and their launches interleave on the device
+        for (int32_t i = 0; i < n; ++i) { int r = rp_step(worlds[i], 1); if (r != RP_OK) return r; }
+    return RP_OK;
+}
 extern "C" int32_t rp_world_set_shard_guard_horizon(rp_world *w, float seconds) {
     if (!w || !(seconds >= 0.0f) || !std::isfinite(seconds)) return RP_ERR_INVALID;
     if (seconds == w->guard_horizon) return RP_OK;

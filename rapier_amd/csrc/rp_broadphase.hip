@@ -36,7 +36,7 @@ RP_DEV void bp_grid_follow(const DevWorld &w, int i, float4 omn, float4 omx) {
     for (int z = r.lo[2]; z <= r.hi[2]; ++z)
         for (int y = r.lo[1]; y <= r.hi[1]; ++y)
             for (int x = r.lo[0]; x <= r.hi[0]; ++x, ++ord) {
-                const int h = (int)(rp_hash64(cell_key(x, y, z)) & (unsigned long long)(w.grid_cap - 1));
+                const int h = (int)(rp_hash64(cell_key_of(w, i, x, y, z)) & (unsigned long long)(w.grid_cap - 1));
                 const int k = atomicAdd(&cnt[h], 1);
                 if (k < RP_BP_BUCKET) items[(size_t)h * RP_BP_BUCKET + k] = bp_entry(i, ord, ver);
                 else w.flags[FL_BP_GRID_OK] = 0;               // bucket full: rebuild
@@ -124,6 +124,28 @@ RP_DEV void bp_large_append(DevWorld &w, int i) {
     int k = atomicAdd(&w.scan_block[BP_LARGE_SCRATCH], 1);
     if (k < w.large_cap) w.large_list[k] = i; else atomicOr(&w.flags[FL_OVERFLOW], RP_OVF_LARGE);
 }
+// Batches of small worlds (n_sub > 1): the large list just built, counting-sorted by sub-world; large_sub_begin[s] .. [s + 1] is
+// sub-world s's segment (large_range_of).  ONE workgroup (the list holds a slab or two per sub-world), behind the build pass's barrier.
+RP_DEV void bp_large_by_sub(DevWorld &w, int nl) {
+    __shared__ int part[1024];
+    const int t = threadIdx.x, n = w.n_sub + 1; // entries [0, n_sub]: counts shifted by one, then their inclusive prefix = the begins
+    if (nl > w.large_cap) nl = w.large_cap;
+    for (int s = t; s <= w.n_sub + 1 && s <= w.sub_cap + 1; s += blockDim.x) w.large_sub_begin[s] = 0;
+    __threadfence(); __syncthreads();
+    for (int q = t; q < nl; q += blockDim.x) { const int L = w.large_list[q]; w.large_tmp[q] = L; atomicAdd(&w.large_sub_begin[w.c_sub[L] + 1], 1); }
+    __threadfence(); __syncthreads();
+    const int per = (n + (int)blockDim.x - 1) / (int)blockDim.x, lo = t * per, hi = lo + per < n ? lo + per : n;
+    int sum = 0;
+    for (int s = lo; s < hi; ++s) sum += __hip_atomic_load(&w.large_sub_begin[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    part[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < (int)blockDim.x; off <<= 1) { int v = t >= off ? part[t - off] : 0; __syncthreads(); part[t] += v; __syncthreads(); }
+    int run = part[t] - sum;
+    for (int s = lo; s < hi; ++s) { run += __hip_atomic_load(&w.large_sub_begin[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); w.large_sub_begin[s] = run; w.large_sub_cur[s] = run; }
+    __threadfence(); __syncthreads();
+    // (entry s now holds the END of sub-world s - 1 = the begin of sub-world s; entry 0 = 0)
+    for (int q = t; q < nl; q += blockDim.x) { const int L = w.large_tmp[q]; const int pos = atomicAdd(&w.large_sub_cur[w.c_sub[L]], 1); w.large_list[pos] = L; }
+}
 RP_DEV void bp_build(DevWorld &w, int gid, int gstride, int nxt) {
     int *cnt = w.bk_cnt[nxt]; int *items = w.bk_items[nxt];
     for (int i = gid; i < w.n_colliders; i += gstride) {
@@ -135,7 +157,7 @@ RP_DEV void bp_build(DevWorld &w, int gid, int gstride, int nxt) {
         for (int z = r.lo[2]; z <= r.hi[2]; ++z)
             for (int y = r.lo[1]; y <= r.hi[1]; ++y)
                 for (int x = r.lo[0]; x <= r.hi[0]; ++x, ++o) {
-                    unsigned long long key = cell_key(x, y, z);
+                    unsigned long long key = cell_key_of(w, i, x, y, z);
                     int h = (int)(rp_hash64(key) & (unsigned long long)(w.grid_cap - 1));
                     int k = atomicAdd(&cnt[h], 1);
                     if (k < RP_BP_BUCKET) items[(size_t)h * RP_BP_BUCKET + k] = bp_entry(i, o, 0);
@@ -153,6 +175,7 @@ __device__ __forceinline__ bool fat_overlap(const DevWorld &w, int a, int b, V3 
 }
 // update.rs:334-396: same parent / ActiveCollisionTypes::default() / InteractionGroups::test
 __device__ __forceinline__ bool pair_allowed(const DevWorld &w, int a, int b) {
+    if (w.n_sub > 1 && w.c_sub[a] != w.c_sub[b]) return false; // colliders of different sub-worlds never meet (rp_world_begin_subworld)
     int pa = w.c_parent[a], pb = w.c_parent[b];
     if (pa >= 0 && pa == pb) return false;
     bool da = pa >= 0 && (w.b_flags[pa] & RP_BF_TYPE_MASK) == RP_BODY_DYNAMIC;
@@ -235,7 +258,8 @@ RP_DEV void bp_pairs(DevWorld &w, int nxt, int nl) { // nl: the large list that 
     const int *cnt = w.bk_cnt[nxt]; const int *items = w.bk_items[nxt];
     for (int i = tid / BP_GROUP; i < w.n_colliders; i += ngroups) {
         const bool ilarge = w.c_inlarge[i] != 0;
-        for (int q = sub; q < nl; q += BP_GROUP) {
+        int q0, q1; large_range_of(w, i, nl, q0, q1);
+        for (int q = q0 + sub; q < q1; q += BP_GROUP) {
             int L = w.large_list[q];
             if (L == i || (ilarge && i > L)) continue; // large-large pairs reported from the lower index
             V3 imin;
@@ -247,7 +271,7 @@ RP_DEV void bp_pairs(DevWorld &w, int nxt, int nl) { // nl: the large list that 
         const int nx = r.hi[0] - r.lo[0] + 1, ny = r.hi[1] - r.lo[1] + 1, nz = r.hi[2] - r.lo[2] + 1;
         for (int c = sub; c < nx * ny * nz; c += BP_GROUP) {
             const int x = r.lo[0] + c % nx, y = r.lo[1] + (c / nx) % ny, z = r.lo[2] + c / (nx * ny);
-            unsigned long long key = cell_key(x, y, z);
+            unsigned long long key = cell_key_of(w, i, x, y, z);
             int h = (int)(rp_hash64(key) & (unsigned long long)(w.grid_cap - 1));
             int n = cnt[h]; if (n > RP_BP_BUCKET) n = RP_BP_BUCKET;
             for (int e = 0; e < n; ++e) {
@@ -366,14 +390,14 @@ RP_DEV void bp_incr_insert(DevWorld &w, int nchg) {
         CellRange r = cell_range(w, i);
         if (r.large || w.c_inlarge[i]) continue; // (never here: bp_grid_follow raised FL_BP_FORCE_FULL when it rewrote that AABB, and this launch chose the full rebuild)
         // (a) the large colliders (ground slabs, walls: never stale)
-        for (int q = sub; q < nl; q += BP_GROUP) bp_try_pair(w, i, w.large_list[q]);
+        { int q0, q1; large_range_of(w, i, nl, q0, q1); for (int q = q0 + sub; q < q1; q += BP_GROUP) bp_try_pair(w, i, w.large_list[q]); }
         // (b) everybody else through the grid, which follows every collider (bp_grid_follow): the cells of the new AABB (at most 27)
         // over the eight lanes; a pair is reported from the cell that holds the min corner of the intersection, which lies in both
         // cell ranges; two colliders that both changed in this pass find each other — reported from the smaller index
         const int nx = r.hi[0] - r.lo[0] + 1, ny = r.hi[1] - r.lo[1] + 1, nz = r.hi[2] - r.lo[2] + 1;
         for (int c = sub; c < nx * ny * nz; c += BP_GROUP) {
             const int x = r.lo[0] + c % nx, y = r.lo[1] + (c / nx) % ny, z = r.lo[2] + c / (nx * ny);
-            unsigned long long key = cell_key(x, y, z);
+            unsigned long long key = cell_key_of(w, i, x, y, z);
             int h = (int)(rp_hash64(key) & (unsigned long long)(w.grid_cap - 1));
             int n = cnt[h]; if (n > RP_BP_BUCKET) n = RP_BP_BUCKET;
             for (int e = 0; e < n; ++e) {
@@ -466,7 +490,10 @@ __global__ void __launch_bounds__(1024) k_bp_rebuild(DevWorld w) {
     const int gcur = BP_GPAR(w);
     const bool keep_grid = w.bp_incremental && w.flags[FL_BP_GRID_OK] && !w.flags[FL_BP_FORCE_FULL] && w.lay_state[9] < 32 && !w.bp_always_build;
     RP_PASS_BEGIN();
-    if (!keep_grid) { bp_build(w, gid, gstride, gcur ^ 1); GBAR_SYNC(bar); }
+    if (!keep_grid) {
+        bp_build(w, gid, gstride, gcur ^ 1); GBAR_SYNC(bar);
+        if (w.n_sub > 1) { if (blockIdx.x == 0) bp_large_by_sub(w, w.scan_block[BP_LARGE_SCRATCH]); GBAR_SYNC(bar); } // (n_sub: the same for every workgroup)
+    }
     RP_PASS_STAMP(w, 220);
     bp_pairs(w, keep_grid ? gcur : gcur ^ 1, keep_grid ? w.flags[FL_N_LARGE] : w.scan_block[BP_LARGE_SCRATCH]);
     GBAR_SYNC(bar); RP_PASS_STAMP(w, 220);

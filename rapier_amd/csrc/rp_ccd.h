@@ -269,6 +269,7 @@ template <bool CONVEX> __global__ void __launch_bounds__(256) k_ccd(DevWorld w, 
             auto try_target = [&](int c2) {
                 const int p2 = w.c_parent[c2];
                 if (c2 == c1 || p2 == bi) return;
+                if (w.n_sub > 1 && w.c_sub[c2] != w.c_sub[c1]) return; // another sub-world (rp_world_begin_subworld)
                 if (shape_is_composite(w.c_shape[c2])) return; // (likewise as targets)
                 const uint2 g2 = w.c_groups[c2];
                 if ((g2.x == 0 && g2.y == 0) || (__float_as_int(w.c_events[c2].x) & RP_EVENTS_SENSOR_BIT)) return;
@@ -292,12 +293,12 @@ template <bool CONVEX> __global__ void __launch_bounds__(256) k_ccd(DevWorld w, 
                 // body (23 % of a step in which thousands of small shapes land: profiles/r04_shapes_rain_kernel_stats.txt).  The large
                 // list (slabs, walls, half-spaces) is walked whole; a collider met through several cells is taken from the cell that
                 // holds the min corner of (its box ∩ the query box).  The earliest fraction is an atomicMin: no order dependence.
-                for (int q = threadIdx.x; q < n_large; q += blockDim.x) try_target(w.large_list[q]);
+                { int q0, q1; large_range_of(w, c1, n_large, q0, q1); for (int q = q0 + threadIdx.x; q < q1; q += blockDim.x) try_target(w.large_list[q]); }
                 const int gcur = BP_GPAR(w);
                 for (int idx = threadIdx.x; idx < ncell * RP_BP_BUCKET; idx += blockDim.x) {
                     const int cell = idx / RP_BP_BUCKET, e = idx % RP_BP_BUCKET;
                     const int x = qlo[0] + cell % qnx, y = qlo[1] + (cell / qnx) % qny, z = qlo[2] + cell / (qnx * qny);
-                    const int h = (int)(rp_hash64(cell_key(x, y, z)) & (unsigned long long)(w.grid_cap - 1));
+                    const int h = (int)(rp_hash64(cell_key_of(w, c1, x, y, z)) & (unsigned long long)(w.grid_cap - 1));
                     int nb = w.bk_cnt[gcur][h]; if (nb > RP_BP_BUCKET) nb = RP_BP_BUCKET;
                     if (e >= nb) continue;
                     const int it = w.bk_items[gcur][(size_t)h * RP_BP_BUCKET + e], j = it & 0xffffff;

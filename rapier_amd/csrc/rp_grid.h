@@ -12,6 +12,24 @@ __device__ __forceinline__ unsigned long long cell_key(int cx, int cy, int cz) {
     return ((unsigned long long)((cx + off) & 0x1fffff)) | ((unsigned long long)((cy + off) & 0x1fffff) << 21) |
            ((unsigned long long)((cz + off) & 0x1fffff) << 42);
 }
+// Sub-worlds (rp_world_begin_subworld: a batch of small worlds in one device world) may overlap in space: a collider's cells are keyed
+// with its sub-world, so every sub-world fills buckets of its own (what still collides in the hash is told apart by pair_allowed).
+__device__ __forceinline__ unsigned long long cell_key_of(const DevWorld &w, int collider, int cx, int cy, int cz) {
+    unsigned long long k = cell_key(cx, cy, cz);
+    if (w.n_sub > 1) k ^= (unsigned long long)(unsigned)w.c_sub[collider] * 0x9E3779B97F4A7C15ull;
+    return k;
+}
+// ... and the brute-force list of large colliders (ground slabs: one per sub-world in a batch of small worlds) is kept SORTED by
+// sub-world (bp_large_by_sub, after every build pass): a collider walks its own sub-world's segment, not n slabs it can never meet.
+__device__ __forceinline__ void large_range_of(const DevWorld &w, int collider, int nl, int &q0, int &q1) {
+    q0 = 0; q1 = nl;
+    if (w.n_sub > 1) {
+        const int s = w.c_sub[collider];
+        q0 = w.large_sub_begin[s]; q1 = w.large_sub_begin[s + 1];
+        if (q0 > nl) q0 = nl;
+        if (q1 > nl) q1 = nl;
+    }
+}
 __device__ __forceinline__ int cell_coord(float x, float inv_cell) { return (int)floorf(x * inv_cell); }
 
 struct CellRange { int lo[3], hi[3]; bool large; };

@@ -203,6 +203,7 @@ struct DevWorld {
     int gbar_blocks;       // most workgroups (of 1024 threads) a grid-barrier kernel may use on this device: all of them resident at once (rp_gridbar.h)
     int has_sensors;       // some collider is a sensor: its pairs are intersection-tested every step (full step path)
     int isl_route_tiny;    // 1 (RP_NO_TINY_ROUTING=1: 0): worlds with thousands of tiny islands solve them on the global path (rp_islands.hip, lay_isl_number)
+    int isl_many;          // ... "thousands" = more island candidates than this in the previous rebuild (960; RP_ISL_MANY overrides it)
     int bp_always_build;   // RP_BP_ALWAYS_BUILD=1: every full broad-phase rebuild runs its build pass (A/B switch for the kept-grid rebuild, rp_broadphase.hip)
     int has_convex;        // some collider is a cylinder / cone / convex polyhedron: the narrow-phase, sensor and CCD launches use their CONVEX instantiations (rp_convex.h)
     // convex polyhedra (rp_polyhedron.h), flattened: per shape {first point, points, first face, faces}; points (w: max |p|); face normals;
@@ -274,6 +275,7 @@ struct DevWorld {
 
     // ---- colliders ----
     int *c_parent, *c_shape;
+    int *c_sub; int n_sub;  // sub-world of every collider (rp_world_begin_subworld; n_sub <= 1: one world, c_sub is not read)
     int *c_ord;            // ordinal of the collider among the colliders of its parent (attachment order, < 4096)
     float4 *c_lpos, *c_lrot, *c_pos, *c_rot, *c_he;
     float4 *c_mat;         // friction, restitution, density, -
@@ -292,6 +294,7 @@ struct DevWorld {
     int *bk_items[2];      // [grid_cap][RP_BP_BUCKET] collider | which of its cells << 24 | range version << 29 (bp_entry)
     int *scan_block;       // [1024 + 8] scratch counters of a running rebuild ([1024]: its large list)
     int *large_list;
+    int *large_sub_begin, *large_sub_cur, *large_tmp; int sub_cap; // the large list by sub-world (rp_grid.h large_range_of): begins [sub_cap + 2], scratch
     int *c_chgstamp, *c_stale, *c_inlarge; // per collider: pass (FL_BP_SEQ + 1) that already queued it on bp_chg_list; (unused since round 4); on large_list
     int *c_rver;           // per collider: cell-range changes since the last full rebuild (the version its live grid entries carry: bp_grid_follow)
     int *bp_chg_list, *free_pending;       // [colliders] fat AABBs rewritten since the last pass; [pool_cap] slots freed by a running incremental pass

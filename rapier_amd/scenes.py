@@ -164,6 +164,7 @@ class Scene:
     collider_parents: list = field(default_factory=list)
     joints: list = field(default_factory=list)
     polyhedra: list = field(default_factory=list)   # (points (n, 3) f32, triangles (m, 3) u32 or None = "take the convex hull")
+    subworlds: list = field(default_factory=list)   # batch(): [(first body, first collider, first joint)] of every sub-world (empty: one world)
     composites: list = field(default_factory=list)  # ("compound", parts: COLLIDER_DTYPE array) | ("trimesh", vertices (n, 3) f32, triangles (m, 3) u32) | ("heightfield", heights (r, c) f32, scale (3,))
 
     def add_compound(self, parts) -> int:
@@ -252,6 +253,28 @@ class Scene:
     def num_dynamic(self) -> int:
         return int(sum(int(b["body_type"]) == BODY_DYNAMIC for b in self.bodies))
 
+
+def batch(scenes, name: str | None = None) -> Scene:
+    """Several small scenes as the SUB-WORLDS of one scene (rp_world_begin_subworld): bodies, colliders and joints concatenated (indices
+    shifted), `subworlds` = where each one begins.  Colliders of different sub-worlds never pair, so the scenes may overlap in space;
+    they must agree on gravity and integration parameters (one world steps them).  Convex polyhedra / composite shapes: not batched."""
+    scenes = list(scenes)
+    first = scenes[0]
+    out = Scene(name=name or f"batch_{len(scenes)}x_{first.name}", gravity=tuple(first.gravity), params=first.params.copy())
+    for sc in scenes:
+        if tuple(sc.gravity) != tuple(first.gravity) or sc.params.tobytes() != first.params.tobytes():
+            raise ValueError("batch: the sub-worlds of a batch share gravity and integration parameters")
+        if sc.polyhedra or sc.composites or sc.subworlds:
+            raise ValueError("batch: plain scenes only")
+        nb = len(out.bodies)
+        out.subworlds.append((nb, len(out.colliders), len(out.joints)))
+        out.bodies += [b.copy() for b in sc.bodies]
+        out.colliders += [c.copy() for c in sc.colliders]
+        out.collider_parents += [(p + nb if p >= 0 else p) for p in sc.collider_parents]
+        for j in sc.joints:
+            jj = j.copy(); jj["body1"], jj["body2"] = int(j["body1"]) + nb, int(j["body2"]) + nb
+            out.joints.append(jj)
+    return out
 
 def _f(x):
     return np.float32(x)

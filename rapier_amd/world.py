@@ -166,15 +166,20 @@ class PhysicsWorld:
                 w.add_trimesh(comp[1], comp[2])
             else:
                 w.add_heightfield(comp[1], comp[2])
-        bodies = scene.body_array()
-        if len(bodies):
-            w.insert_bodies(bodies)
-        cols = scene.collider_array()
-        if len(cols):
-            parents = scene.parent_array().astype(np.int64)
-            ph = np.where(parents < 0, np.uint64(_ffi.RP_INVALID_HANDLE), parents.astype(np.uint64)).astype(np.uint64)
-            w.insert_colliders(cols, ph)
-        joints = scene.joint_array()
+        bodies, cols, joints = scene.body_array(), scene.collider_array(), scene.joint_array()
+        parents = scene.parent_array().astype(np.int64) if len(cols) else np.zeros(0, np.int64)
+        ph = np.where(parents < 0, np.uint64(_ffi.RP_INVALID_HANDLE), parents.astype(np.uint64)).astype(np.uint64)
+        # a batch (scenes.batch): every sub-world's bodies and colliders go in behind its own rp_world_begin_subworld
+        starts = list(getattr(scene, "subworlds", None) or [(0, 0, 0)]) + [(len(bodies), len(cols), len(joints))]
+        for k in range(len(starts) - 1):
+            (b0, c0, _), (b1, c1, _) = starts[k], starts[k + 1]
+            if k:
+                w.begin_subworld()
+            if b1 > b0:
+                w.insert_bodies(bodies[b0:b1])
+            if c1 > c0:
+                w.insert_colliders(cols[c0:c1], ph[c0:c1])
+        w.subworlds = [(starts[k][0], starts[k + 1][0]) for k in range(len(starts) - 1)]   # body rows [first, end) of every sub-world
         if len(joints):
             w.insert_impulse_joints(joints)
         return w
@@ -489,6 +494,14 @@ class PhysicsWorld:
     ISLAND_STATS = ("merged", "multiway_groups", "removals", "connected", "detached", "hot", "over_budget", "sleeping_deferred", "global_splits",
                     "global_split_pieces", "bids", "bid_ties", "sleep_blocked", "order_dependent", "detach_size_ties", "split_keep_ties")
 
+    def begin_subworld(self) -> int:
+        """everything inserted from now on belongs to a new sub-world (rp_world_begin_subworld): a batch of small worlds in one device
+        world, stepped by the same launches; colliders of different sub-worlds never pair"""
+        r = self._lib.rp_world_begin_subworld(self._ptr)
+        if r < 0:
+            _check(self._ptr, r, "rp_world_begin_subworld")
+        return int(r)
+
     def set_shard_guard_horizon(self, seconds: float):
         """how long a guard hit may wait for take_shard_guard_hits (rp_world_set_shard_guard_horizon)"""
         _check(self._ptr, self._lib.rp_world_set_shard_guard_horizon(self._ptr, float(seconds)), "rp_world_set_shard_guard_horizon")
@@ -591,3 +604,16 @@ class PhysicsWorld:
             self.close()
         except Exception:
             pass
+
+
+def step_many(worlds, steps: int = 1):
+    """rp_step_many: `steps` steps of every world, enqueued back to back on the worlds' own streams before anything is waited for
+    (small worlds that share ONE parameter set are better served as the sub-worlds of one world: scenes.batch)."""
+    worlds = list(worlds)
+    if not worlds:
+        return
+    arr = (C.c_void_p * len(worlds))(*[w._ptr for w in worlds])
+    r = worlds[0]._lib.rp_step_many(arr, len(worlds), int(steps))
+    if r != 0:
+        for w in worlds:
+            _check(w._ptr, r, "rp_step_many")

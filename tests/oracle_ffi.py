@@ -40,6 +40,7 @@ def lib():
         L.ro_add_body.argtypes = [C.c_void_p, C.c_void_p]
         L.ro_add_collider.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         L.ro_add_joint.argtypes = [C.c_void_p, C.c_void_p]
+        L.ro_begin_subworld.argtypes = [C.c_void_p]; L.ro_begin_subworld.restype = C.c_int32
         L.ro_step.argtypes = [C.c_void_p, C.c_int32]
         L.ro_num_bodies.argtypes = [C.c_void_p]
         L.ro_read_bodies.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -112,12 +113,6 @@ class OracleWorld:
         grav = np.asarray(scene.gravity, dtype=np.float32)
         self._w = L.ro_world_new(params.ctypes.data, grav.ctypes.data)
         bodies = scene.body_array()
-        for i in range(len(bodies)):
-            bi = L.ro_add_body(self._w, bodies[i:i + 1].ctypes.data)
-            if int(bodies["additional_solver_iterations"][i]):  # trailing descriptor field (the oracle's struct ends before it)
-                L.ro_set_additional_solver_iterations(self._w, bi, int(bodies["additional_solver_iterations"][i]))
-            if int(bodies["ccd_enabled"][i]):
-                L.ro_set_ccd_enabled(self._w, bi, 1)
         for pts, tris in getattr(scene, "polyhedra", []):
             if self.add_convex_polyhedron(pts, tris) < 0:
                 raise ValueError("oracle: not a closed convex triangle mesh")
@@ -126,10 +121,22 @@ class OracleWorld:
                 raise ValueError("oracle: invalid composite shape")
         cols = scene.collider_array()
         parents = scene.parent_array()
-        for i in range(len(cols)):
-            ci = L.ro_add_collider(self._w, cols[i:i + 1].ctypes.data, int(parents[i]))
-            if int(cols["sensor"][i]):  # the descriptor's trailing `sensor` field (the oracle's struct ends before it)
-                L.ro_set_collider_sensor(self._w, ci, 1)
+        # a batch (scenes.batch): every sub-world's bodies and colliders go in behind its own ro_begin_subworld, like PhysicsWorld.from_scene
+        starts = list(getattr(scene, "subworlds", None) or [(0, 0, 0)]) + [(len(bodies), len(cols), 0)]
+        for k in range(len(starts) - 1):
+            (b0, c0, _), (b1, c1, _) = starts[k], starts[k + 1]
+            if k:
+                L.ro_begin_subworld(self._w)
+            for i in range(b0, b1):
+                bi = L.ro_add_body(self._w, bodies[i:i + 1].ctypes.data)
+                if int(bodies["additional_solver_iterations"][i]):  # trailing descriptor field (the oracle's struct ends before it)
+                    L.ro_set_additional_solver_iterations(self._w, bi, int(bodies["additional_solver_iterations"][i]))
+                if int(bodies["ccd_enabled"][i]):
+                    L.ro_set_ccd_enabled(self._w, bi, 1)
+            for i in range(c0, c1):
+                ci = L.ro_add_collider(self._w, cols[i:i + 1].ctypes.data, int(parents[i]))
+                if int(cols["sensor"][i]):  # the descriptor's trailing `sensor` field (the oracle's struct ends before it)
+                    L.ro_set_collider_sensor(self._w, ci, 1)
         joints = scene.joint_array()
         for i in range(len(joints)):
             if L.ro_add_joint(self._w, joints[i:i + 1].ctypes.data) < 0:

@@ -16,6 +16,7 @@ variants = {
     "many_pyramids_coulomb": lambda: _with(S.many_pyramids(), "friction_model", S.FRICTION_COULOMB),
     "many_pyramids_events": lambda: S.many_pyramids().enable_events(3, 100.0),
     "washer": S.washer, "junkyard": S.junkyard,   # the reference's box3d ports (tools/b3d_ports.py; the junkyard's pusher stands still here)
+    "batch_capsules": lambda: S.batch([S.capsules(6) for _ in range(int(os.environ.get("RP_BATCH_N", "256")))]),   # 256 small worlds as sub-worlds of one (tools/subworld_rate.py)
     "shapes_rain": lambda: S.shapes_rain(8000),   # all ten shape kinds landing on a slab (tools/shapes_bench.py)
 }
 
@@ -27,7 +28,7 @@ def _with(scene, key, value):
 
 scene = variants[name]()
 w = PhysicsWorld.from_scene(scene)
-w.step(60); w.sync()
+w.step(300 if name == "batch_capsules" else 60); w.sync()
 t = time.time(); w.step(steps); w.sync(); dt = time.time() - t
 print(f"{name}: {steps / dt:.1f} steps/s  {dt / steps * 1e3:.3f} ms/step", w.counters())
 try:  # hand-off statistics of the dataflow launch (rp_flow.hip), accumulated since world creation
