@@ -1361,7 +1361,11 @@ static int dalloc(rp_world *w, T *&p, size_t count, int fill_byte = 0, int dom =
 #define DA(ptr, count) do { int r_ = dalloc(w, ptr, (size_t)(count)); if (r_ != RP_OK) return r_; } while (0)
 // DAS: scratch that every reader finds written by an earlier kernel of the same step (no rest state).  RP_TEST_POISON=1 fills it with
 // 0xFF bytes (NaN / -1) instead of zeros: a kernel that reads such an array before it was written shows up in the parity tests
+#ifdef RP_TESTING // (the testing build, `make testing` -> librapier_hip_testing.so: the product library carries no test hook)
 #define DAS(ptr, count) do { static const int poison_ = (getenv("RP_TEST_POISON") && atoi(getenv("RP_TEST_POISON"))) ? 0xff : 0; int r_ = dalloc(w, ptr, (size_t)(count), poison_); if (r_ != RP_OK) return r_; } while (0)
+#else
+#define DAS(ptr, count) DA(ptr, count)
+#endif
 #define DAF(ptr, count, fill) do { int r_ = dalloc(w, ptr, (size_t)(count), fill); if (r_ != RP_OK) return r_; } while (0)
 #define DAC(ptr, count, ...) do { int r_ = dalloc(w, ptr, (size_t)(count), 0, __VA_ARGS__); if (r_ != RP_OK) return r_; } while (0)
 #define DAFC(ptr, count, fill, ...) do { int r_ = dalloc(w, ptr, (size_t)(count), fill, __VA_ARGS__); if (r_ != RP_OK) return r_; } while (0)
@@ -1808,6 +1812,7 @@ static int finalize(rp_world *w) {
             const unsigned rest[16] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
             HIPCHK(w, hipMemcpyAsync(d.tl_bbox, rest, sizeof(rest), hipMemcpyHostToDevice, w->stream));
             HIPCHK(w, hipStreamSynchronize(w->stream));
+#ifdef RP_TESTING
             // test hook (tools/tile_race_stress.py --replay): what the round-3 race left behind when the fill lost it — 1: b_order wiped, 2: tl_bbox wiped
             if (const char *lf = getenv("RP_TEST_LATE_FILL")) {
                 if (atoi(lf) & 1) HIPCHK(w, hipMemsetAsync(d.b_order, 0, (size_t)capb * sizeof(int), w->stream));
@@ -1816,6 +1821,7 @@ static int finalize(rp_world *w) {
             // test hook (RP_TILE_STALE_PLAN=1): the device never finds a tiling worth having while the host plans tile sweeps all the same —
             // every sweep then takes the branch that normally only a stale hint reaches (k_tile_sweep with FL_N_TILES == 0)
             if (getenv("RP_TILE_STALE_PLAN")) d.tile_min = 0x7fffffff;
+#endif
         }
     }
 

@@ -21,6 +21,27 @@ def _world(scene, monkeypatch, **env):
     return w
 
 
+def _in_testing_build(fn_name: str, *args, **env):
+    """run `test_gpu_tiles.<fn_name>(*args)` in a child process whose rapier_amd loads the TESTING build (librapier_hip_testing.so: the
+    product library compiles the test hooks out, `make testing` keeps them) with the hook's switches set"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "rapier_amd", "librapier_hip_testing.so")
+    assert os.path.exists(lib), "build the testing library: make -C rapier_amd/csrc testing"
+    e = dict(os.environ, RP_HIP_LIB=lib, **{k: str(v) for k, v in env.items()})
+    code = f"import sys; sys.path[:0] = [{root!r}, {os.path.join(root, 'tests')!r}]; import test_gpu_tiles as t; t.{fn_name}(*{args!r})"
+    r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+class _Env:
+    """monkeypatch's two methods over os.environ, for the bodies that run in a child process"""
+    def setenv(self, k, v):
+        import os; os.environ[k] = v
+    def delenv(self, k, raising=False):
+        import os; os.environ.pop(k, None)
+
+
 def _equal(g, o, msg):
     gp, gv = g.read_bodies()
     op, ov = o.read() if isinstance(o, OracleWorld) else o.read_bodies()
@@ -79,17 +100,30 @@ def test_any_tile_size_gives_the_same_bits(monkeypatch, target, checkpoints):
     _run(S.large_pyramid(60), checkpoints, monkeypatch, RP_TILE_TARGET=target)
 
 
-def test_a_late_zero_fill_is_what_the_round3_failure_was(monkeypatch):
-    """the replay hook of finalize() (RP_TEST_LATE_FILL=3: the zero fill of b_order and tl_bbox re-issued behind their uploads, which is
-    what the unordered hipMemcpy of round 3 amounted to when the fill ran late) reproduces the failure's fingerprint exactly — and shows
-    that this file's comparisons catch such a state.  Without the hook the same world is bit-exact (the tests around this one)."""
+def _late_fill_body():
     sc = S.large_pyramid(60)
-    g, o = _world(sc, monkeypatch, RP_TILE_TARGET=3, RP_TEST_LATE_FILL=3), OracleWorld(sc)
+    g, o = _world(sc, _Env(), RP_TILE_TARGET=3, RP_TEST_LATE_FILL=3), OracleWorld(sc)
     g.step(2); o.step(2)
     gp, _ = g.read_bodies(); op, _ = o.read()
     # (colliding constraint positions race with each other, so the wreck is not the same to the last element every time: 9478 elements
     # / 0.44956553 m — the round-3 log's numbers — in two of three runs on record, 9484 in the third: profiles/r04_tile_race_replay.txt)
     assert gp.size == 12817 and int((gp != op).sum()) > 9000 and 0.2 < float(np.abs(gp - op).max()) < 1.0
+
+
+def test_a_late_zero_fill_is_what_the_round3_failure_was():
+    """the replay hook of finalize() (RP_TEST_LATE_FILL=3: the zero fill of b_order and tl_bbox re-issued behind their uploads, which is
+    what the unordered hipMemcpy of round 3 amounted to when the fill ran late) reproduces the failure's fingerprint exactly — and shows
+    that this file's comparisons catch such a state.  Without the hook the same world is bit-exact (the tests around this one).  The
+    hook only exists in the testing build (round 5: -DRP_TESTING)."""
+    _in_testing_build("_late_fill_body")
+
+
+def test_the_product_library_ignores_the_test_hooks(monkeypatch):
+    """RP_TEST_LATE_FILL in the environment of the PRODUCT library changes nothing: the hooks are compiled out"""
+    sc = S.large_pyramid(60)
+    g, o = _world(sc, monkeypatch, RP_TILE_TARGET=3, RP_TEST_LATE_FILL=3), OracleWorld(sc)
+    g.step(2); o.step(2)
+    _equal(g, o, "product library with RP_TEST_LATE_FILL set")
 
 
 def _churn(monkeypatch, k):
@@ -314,11 +348,15 @@ def test_lean_steps_in_a_churning_pile_bit_exact(monkeypatch, seed):
     assert c["lean_steps"] > 0 and c["replayed_steps"] > 0, c
 
 
+def _stale_plan_body(scene):
+    sc = S.large_pyramid(60) if scene == "pyramid" else S.joint_net(36)
+    g, o, c = _run(sc, [1, 2, 3, 10, 40], _Env(), want_tiles=False, RP_TILE_STALE_PLAN=1, RP_TILE_MIN=256)
+    assert c["num_tiles"] == 0 and c["tile_sweeps"] == 1, c
+
+
 @pytest.mark.parametrize("scene", ["pyramid", "joint_net"])
-def test_a_stale_tile_plan_falls_back_bit_exact(monkeypatch, scene):
+def test_a_stale_tile_plan_falls_back_bit_exact(scene):
     """the host plans tile sweeps from a hint; when the device has meanwhile decided against tiling (the hint was stale: a layout change
     made a cone outgrow its LDS budget) every sweep kernel runs the whole sweep in workgroup 0 and moves the result to the other
-    buffers.  A timing accident in normal runs — RP_TILE_STALE_PLAN=1 makes it every sweep of every step"""
-    sc = S.large_pyramid(60) if scene == "pyramid" else S.joint_net(36)
-    g, o, c = _run(sc, [1, 2, 3, 10, 40], monkeypatch, want_tiles=False, RP_TILE_STALE_PLAN=1, RP_TILE_MIN=256)
-    assert c["num_tiles"] == 0 and c["tile_sweeps"] == 1, c
+    buffers.  A timing accident in normal runs — RP_TILE_STALE_PLAN=1 (a hook of the testing build) makes it every sweep of every step"""
+    _in_testing_build("_stale_plan_body", scene)

@@ -17,6 +17,8 @@ import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+# the --replay hook (RP_TEST_LATE_FILL) only exists in the testing build of the library (make -C rapier_amd/csrc testing)
+os.environ.setdefault("RP_HIP_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "rapier_amd", "librapier_hip_testing.so"))
 
 from rapier_amd import PhysicsWorld, scenes as S   # noqa: E402
 from oracle_ffi import OracleWorld                 # noqa: E402
