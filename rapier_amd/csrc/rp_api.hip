@@ -73,6 +73,7 @@ void rp_launch_idle_step(const DevWorld &w, hipStream_t st);
 void rp_launch_sleep_fast(const DevWorld &w, hipStream_t st);
 void rp_launch_sensor_fast(const DevWorld &w, hipStream_t st);
 void rp_launch_sensor_check(const DevWorld &w, hipStream_t st);
+void rp_launch_rebase_stamps(const DevWorld &w, hipStream_t st, int delta);
 void rp_launch_clear_no_contact(const DevWorld &w, hipStream_t st);
 void rp_launch_global_flow(const DevWorld &w, hipStream_t st, int grid, int has_restitution);
 void rp_launch_ccd(const DevWorld &w, hipStream_t st, int has_bullets, int publish);
@@ -202,6 +203,8 @@ struct rp_world {
     int pairs_scale = 1;           // the pair pool holds RP_PAIRS_PER_COLLIDER x pairs_scale slots per collider row: doubled when the pool fills up (rp_step)
     int cur_fast = 0;              // mode the enqueue_* callbacks capture
     long long steps_requested = 0; // steps asked for since finalize (device FL_STEP counts the executed ones)
+    int rebase_at = 1 << 30;       // FL_STEP beyond which the device's 32-bit step stamps move back (k_rebase_stamps)
+    long long rebases = 0;
     long long seq_enqueued = 0;    // step graphs enqueued since finalize (device FL_SEQ counts the retired ones)
     long long full_until = 0;      // stay on the full graph until this many steps were requested
     long long eager_until = 0;     // launch the kernels directly until this many steps were requested: a world that is being edited (bodies /
@@ -431,6 +434,9 @@ extern "C" int32_t rp_world_create(const rp_integration_params *params, const fl
     if (g && g[0] == '1') w->force_flow = true;
     if (w->use_flow) { w->flow_grid = rp_flow_grid(device); if (w->flow_grid <= 0) w->use_flow = false; }
     if (w->use_fused) { w->fused_grid = rp_fused_grid(device); if (w->fused_grid <= 0) w->use_fused = false; }
+#ifdef RP_TESTING
+    if (const char *ra = getenv("RP_TEST_REBASE_AT")) w->rebase_at = std::max(8, atoi(ra)); // (test hook: the stamps move back every few steps)
+#endif
     { const char *nd = getenv("RP_NO_ISL_DENSE"); w->fused_grid_dense = (nd && nd[0] == '1') ? 0 : rp_fused_grid_dense(device); if (const char *fd = getenv("RP_ISL_DENSE")) { if (fd[0] == '1' && w->fused_grid_dense > 0) w->force_dense = true; if (fd[0] == '0') w->auto_dense = false; } }
     memset(&w->dw, 0, sizeof(w->dw));
     *out = w;
@@ -2287,6 +2293,17 @@ static int settle(rp_world *w) {
                 for (int b = 0; b < nb; ++b) if (q[b] && !w->bodies[b].quarantined && !w->bodies[b].removed) { int r = quarantine_body_at(w, b); if (r != RP_OK) return r; any = true; }
                 if (any) { int r = after_topology_edit(w); if (r != RP_OK) return r; }
             }
+            if (fl[FL_STEP] > w->rebase_at && !fl[FL_OVERFLOW]) {
+                // 32-bit step stamps: move them back before they can wrap (the stream is idle, every requested step has retired);
+                // the host's own step counters move with them
+                const int delta = w->rebase_at;
+                rp_launch_rebase_stamps(w->dw, w->stream, delta);
+                HIPCHK(w, hipGetLastError());
+                HIPCHK(w, hipStreamSynchronize(w->stream));
+                w->steps_requested -= delta; w->full_until -= delta; w->eager_until -= delta;
+                w->pinned_flags[FL_STEP] = fl[FL_STEP] - delta;
+                w->rebases++;
+            }
             return check_overflow(w, fl);
         }
         w->full_until = w->steps_requested + 3;
@@ -2316,6 +2333,7 @@ extern "C" int32_t rp_step(rp_world *w, uint32_t nsteps) {
                 r = finalize(w); if (r != RP_OK) return r;
             }
         }
+        if ((w->steps_requested & 0xfffff) == 0xfffff) { int r = settle(w); if (r != RP_OK) return r; } // (every 2^20 steps: the step stamps' rebase lives in settle)
         w->steps_requested++;
         w->dead_pairs_possible = false; // (this step's broad-phase pass deletes the pairs of every collider removed so far)
         int r = step_once(w, true);
@@ -2793,6 +2811,8 @@ extern "C" int32_t rp_world_set_shard_guard_horizon(rp_world *w, float seconds) 
     destroy_graphs(w); // the captured launches hold the old DevWorld
     return RP_OK;
 }
+// Debug aid (not part of include/rapier_hip.h): how often the step stamps moved back (k_rebase_stamps)
+extern "C" int64_t rp_debug_rebases(const rp_world *w) { return w ? (int64_t)w->rebases : -1; }
 // Debug aid (not part of include/rapier_hip.h): the island machinery's counters (slots of the oracle's RO_IS_*), the scan stamp, the
 // pending split (-1 = none) and, for `island` >= 0, its table row (in use, bodies, dirty, denied-until, sleeping).
 extern "C" int32_t rp_debug_islands(rp_world *w, int32_t *stats16, int32_t *stamp_pending2, int32_t island, int32_t *row5) {

@@ -263,6 +263,38 @@ __global__ void k_edit_flags(DevWorld w, int keep_grid) {
     w.lay_state[0] = 0; // bodies came, went or changed their kind: the next layout rebuild finds its components from scratch (rp_islands.hip)
     w.flags[FL_BP_DIRTY] = 1; w.flags[FL_LAYOUT_DIRTY] = 1; w.flags[FL_JOINT_DIRTY] = 1; w.flags[FL_FLOW_DIRTY] = 1;
 }
+// The device's step stamps are 32-bit (FL_STEP and everything stamped with cur_step): long before they could wrap — the host asks for
+// it once FL_STEP passes 2^30, ~21 h at the headline rate — every stamp moves back by `delta` steps.  Stamps that are only compared for
+// EQUALITY with the step in progress (sleep observation, island marks) and lie more than delta steps back become 0 = never; the two
+// that are ORDERED against each other (a body's last fall-asleep step against the step a pair's solver hint was computed in) keep
+// their order across the line (older ones collapse onto 1: at worst a hint is recomputed once).  The sleep-scan stamp (one per step)
+// and the islands' split cooldowns move with it.  Runs between steps, on an idle stream.
+__global__ void k_rebase_stamps(DevWorld w, int delta) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    auto eq = [&](int v) { return v > delta ? v - delta : 0; };
+    auto ord = [&](int v) { return v > delta ? v - delta : (v > 0 ? 1 : 0); };
+    const unsigned long long scan = w.pi_w64[0];
+    const int scan_stamp = (int)(unsigned)(scan & 0xffffffffull), scan_step = (int)(scan >> 32);
+    const bool move_scan = scan_stamp > delta;
+    for (int i = gid; i < w.n_bodies; i += stride) {
+        w.b_sleep_stamp[i] = eq(w.b_sleep_stamp[i]); w.lab_wake[i] = eq(w.lab_wake[i]); w.lab_awake[i] = eq(w.lab_awake[i]);
+        w.b_slept_at[i] = ord(w.b_slept_at[i]);
+        if (move_scan) { const int d = w.pi_denied[i]; w.pi_denied[i] = d > delta ? d - delta : 0; }
+    }
+    int top = w.flags[FL_POOL_TOP];
+    if (top > w.pool_cap) top = w.pool_cap;
+    for (int s = gid; s < top; s += stride) w.p_hint_seq[s] = ord(w.p_hint_seq[s]);
+    if (gid == 0) {
+        w.flags[FL_STEP] -= delta; w.flags[FL_WAKE_STAMP] = 0;
+        w.pi_w64[0] = ((unsigned long long)(unsigned)eq(scan_step) << 32) | (unsigned)(move_scan ? scan_stamp - delta : scan_stamp);
+    }
+}
+void rp_launch_rebase_stamps(const DevWorld &w, hipStream_t st, int delta) {
+    int n = w.n_bodies > w.pool_cap ? w.n_bodies : w.pool_cap, blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_rebase_stamps, dim3(blocks), dim3(256), 0, st, w, delta);
+}
 void rp_launch_edit_flags(const DevWorld &w, hipStream_t st, int keep_grid) { hipLaunchKernelGGL(k_edit_flags, dim3(1), dim3(1), 0, st, w, keep_grid); }
 void rp_launch_init_bodies(const DevWorld &w, hipStream_t st) {
     if (w.n_bodies == 0) return;

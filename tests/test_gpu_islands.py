@@ -170,3 +170,33 @@ def test_churn_with_sleeping_many_pyramids_islands():
         p.run(10)
     st = p.g.island_stats()
     assert st["removals"] > 0 and st["global_splits"] + st["detached"] > 0
+
+
+# ---- 32-bit step stamps move back long before they can wrap (k_rebase_stamps; round 5) ------------------------------------------------
+def _rebase_body():
+    """sleeping, waking, island splits and solver hints across many rebases of the step stamps: every few steps the device's FL_STEP
+    and everything stamped with it moves back by RP_TEST_REBASE_AT steps — the world must not notice"""
+    import ctypes as C
+    for sc, steps in ((S.sleep_impact(), 720), (S.many_pyramids(rows=1, cols=2).enable_sleep(), 300)):
+        g, o = PhysicsWorld.from_scene(sc), OracleWorld(sc)
+        for k in range(steps // 6):
+            g.step(6); o.step(6)
+            gp, gv = g.read_bodies(); op, ov = o.read()
+            np.testing.assert_array_equal(gp, op, err_msg=f"{sc.name} +{6 * (k + 1)}"); np.testing.assert_array_equal(gv, ov)
+            np.testing.assert_array_equal(g.sleeping(), o.sleeping(), err_msg=f"{sc.name} sleep states +{6 * (k + 1)}")
+            if sc.name.startswith("many") and k == 30:   # wake one pyramid up long after everything fell asleep
+                v = np.array([[1.0, 2.0, 0.0, 0.0, 0.0, 0.0]], np.float32)
+                g.write_bodies([55], vel6=v); o.set_vel(55, v[0, :3], v[0, 3:]); g.wake_up([55]); o.wake_up(55)
+        assert g.sleeping().any() and g.counters()["overflow_flags"] == 0
+        L = g._lib; L.rp_debug_rebases.restype = C.c_int64; L.rp_debug_rebases.argtypes = [C.c_void_p]
+        assert L.rp_debug_rebases(g._ptr) > steps // 40, L.rp_debug_rebases(g._ptr)
+
+
+def test_step_stamps_move_back_without_a_trace():
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "rapier_amd", "librapier_hip_testing.so")
+    assert os.path.exists(lib), "build the testing library: make -C rapier_amd/csrc testing"
+    code = f"import sys; sys.path[:0] = [{root!r}, {os.path.join(root, 'tests')!r}]; import test_gpu_islands as t; t._rebase_body()"
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RP_HIP_LIB=lib, RP_TEST_REBASE_AT="16"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
