@@ -36,8 +36,8 @@ import glob
 TRAFFIC_SCENE = {"c3": "many_pyramids", "large_pyramid": "large_pyramid", "joint_grid": "joint_grid"}
 # sources whose change invalidates a recorded HBM-traffic measurement: the island kernel's for the metric workload; the whole
 # global solver path (tiles, per-stage launches, joints) for the single-island / jointed scenes
-_ISLAND_SOURCES = ["rapier_amd/csrc/rp_islands.hip", "rapier_amd/csrc/rp_island_stages.h", "rapier_amd/csrc/rp_lanepair.h", "rapier_amd/csrc/rp_constraint.h", "rapier_amd/csrc/rp_pairs.h", "rapier_amd/csrc/rp_world.h"]
-_GLOBAL_SOURCES = _ISLAND_SOURCES[3:] + ["rapier_amd/csrc/rp_tiles.hip", "rapier_amd/csrc/rp_solver.hip", "rapier_amd/csrc/rp_global.h", "rapier_amd/csrc/rp_lanepair.h",
+_ISLAND_SOURCES = ["rapier_amd/csrc/rp_islands.hip", "rapier_amd/csrc/rp_island_stages.h", "rapier_amd/csrc/rp_sleep_observe.h", "rapier_amd/csrc/rp_lanepair.h", "rapier_amd/csrc/rp_constraint.h", "rapier_amd/csrc/rp_pairs.h", "rapier_amd/csrc/rp_world.h"]
+_GLOBAL_SOURCES = _ISLAND_SOURCES[4:] + ["rapier_amd/csrc/rp_tiles.hip", "rapier_amd/csrc/rp_solver.hip", "rapier_amd/csrc/rp_global.h", "rapier_amd/csrc/rp_lanepair.h",
                                        "rapier_amd/csrc/rp_joints.h", "rapier_amd/csrc/rp_joints.hip", "rapier_amd/csrc/rp_flow.hip"]
 KERNEL_SOURCES = {"c3": _ISLAND_SOURCES, "large_pyramid": _GLOBAL_SOURCES, "joint_grid": _GLOBAL_SOURCES}
 # kernels of the TGS loop on the global path (what `velocity_update_ms` brackets minus assembly / write-back): their PMC bytes per
