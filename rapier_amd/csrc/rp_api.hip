@@ -2228,8 +2228,9 @@ static int step_once(rp_world *w, bool allow_fast) {
     const bool sleep_fast_ok = !w->dw.sleep_enabled || (!w->dw.has_kinematic_pos && pf[FL_N_AWAKE] > 0 && !pf[FL_WAKE_PENDING]);
     bool fast = allow_fast && w->use_fast && sleep_fast_ok && w->plan_single && w->dw.n_colliders > 0 && w->steps_requested >= w->full_until;
     if (fast && (pf[FL_FAST_ABORT] || pf[FL_FULL_UPDATES] || pf[FL_LAYOUT_DIRTY] || pf[FL_TODO_COUNT] || pf[FL_PI_PENDING] || pf[FL_PJ_COUNT] || pf[FL_PI_JLINK])) {
+        static const int full_after = getenv("RP_FULL_AFTER_ABORT") ? std::max(0, atoi(getenv("RP_FULL_AFTER_ABORT"))) : 3;
         fast = false;
-        w->full_until = w->steps_requested + 3;
+        w->full_until = w->steps_requested + full_after;
     }
     // idle steps: the whole world sleeps (FL_N_AWAKE == 0 as of the last retired step) and nothing is pending; the
     // device re-checks and aborts otherwise (k_idle_step), the host then replays through the full graph

@@ -2,7 +2,7 @@
 groups come from the device, whole groups are bin-packed over 8 ranks, and every rank's guarded sub-world is stepped and timed in
 turn.  Nothing here is a multi-GPU measurement: it shows that every rank's shard builds, steps with a quiet guard, and how long the
 slowest one takes — bench.py's `value` at N = 8 is (cuboids of all ranks / 10,780) * steps / that time when the ranks run side by side.
-    python tools/shard_dryrun.py [world=8] [steps=300] [warmup=120]"""
+    python tools/shard_dryrun.py [world=8] [steps=300] [warmup=120] [ranks to run: all]"""
 import os
 import sys
 import time
@@ -15,6 +15,7 @@ from rapier_amd import PhysicsWorld, scenes as S, sharding  # noqa: E402
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 warmup = int(sys.argv[3]) if len(sys.argv) > 3 else 120
+only = int(sys.argv[4]) if len(sys.argv) > 4 else world   # (a quick look: the first few ranks only)
 rows, cols = sharding.C4_GRIDS.get(world, (54, 54))
 t = time.perf_counter()
 full = S.many_pyramids(rows, cols)
@@ -25,7 +26,7 @@ wf.close()
 body_rank, n_groups = sharding.shards_from_groups(groups, world)
 print(f"{rows}x{cols} pyramids = {rows * cols * 55:,} cuboids: {n_groups} proximity groups from the device in {time.perf_counter() - t:.1f} s")
 worst, total = 0.0, 0
-for rank in range(world):
+for rank in range(min(world, only)):
     scene, gids = sharding.partition_scene(full, body_rank, rank)
     guard = sharding.guard_boxes(full, groups, body_rank, rank)
     w = PhysicsWorld.from_scene(scene, 0)
