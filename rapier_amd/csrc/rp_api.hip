@@ -1688,6 +1688,7 @@ static int finalize(rp_world *w) {
     DA(d.large_list, d.large_cap);
     d.sub_cap = std::max(1024, 2 * w->n_sub);
     DA(d.large_sub_begin, (size_t)d.sub_cap + 2); DA(d.large_sub_cur, (size_t)d.sub_cap + 2); DA(d.large_tmp, d.large_cap);
+    DA(d.c_fatold_min, capc); DA(d.c_fatold_max, capc);
     DA(d.c_chgstamp, capc); DA(d.c_stale, capc); DA(d.c_inlarge, capc); DA(d.c_rver, capc); DA(d.bp_chg_list, capc); DA(d.free_pending, d.pool_cap); // incremental broad phase (scratch: rebuilt by the next full pass)
     DAF(d.h_key[0], d.hash_cap, 0xff); DAF(d.h_key[1], d.hash_cap, 0xff); DA(d.h_slot[0], d.hash_cap); DA(d.h_slot[1], d.hash_cap);
     DAC(d.free_stack, d.pool_cap, DOM_PAIR, 1, 1);

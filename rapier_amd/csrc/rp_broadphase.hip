@@ -370,43 +370,65 @@ __device__ __forceinline__ void hash_erase(unsigned long long *keys, int cap, un
         h = (h + 1) & (cap - 1);
     }
 }
-__device__ __forceinline__ void bp_try_pair(DevWorld &w, int i, int j) {
-    V3 imin;
-    if (!fat_overlap(w, i, j, imin) || !pair_allowed(w, i, j)) return;
+// Did the pair (i, j) exist after the LAST pass?  The pair set of a pass is exactly the allowed pairs of overlapping fat AABBs, so it
+// did iff the boxes the two colliders had then overlap: a collider queued in this pass keeps that box in c_fatold (collider_update_one),
+// everybody else still has it.  The incremental pass skips such partners before any of the status words, the filter and the hash probe
+// are fetched — on b3d_joint_grid (a third of the fat AABBs rewritten per pass) nearly every candidate is an existing pair.
+struct BpOld { float4 mn, mx; bool valid; };
+RP_DEV bool box_valid(float4 mn, float4 mx) { return mn.x <= mx.x && mn.y <= mx.y && mn.z <= mx.z; }
+RP_DEV bool box_overlap(float4 amn, float4 amx, float4 bmn, float4 bmx) { return amn.x <= bmx.x && bmn.x <= amx.x && amn.y <= bmx.y && bmn.y <= amx.y && amn.z <= bmx.z && bmn.z <= amx.z; }
+RP_DEV bool bp_pair_existed(const DevWorld &w, const BpOld &oi, int j, bool jchg, float4 jmn, float4 jmx) {
+    if (!oi.valid) return false;
+    if (jchg) { jmn = w.c_fatold_min[j]; jmx = w.c_fatold_max[j]; if (!box_valid(jmn, jmx)) return false; }
+    return box_overlap(oi.mn, oi.mx, jmn, jmx);
+}
+__device__ __forceinline__ void bp_try_pair(DevWorld &w, int i, int j, const BpOld &oi, int stamp) {
+    const float4 imn = w.c_fatmin[i], imx = w.c_fatmax[i], jmn = w.c_fatmin[j], jmx = w.c_fatmax[j];
+    if (!box_overlap(imn, imx, jmn, jmx)) return;
+    if (bp_pair_existed(w, oi, j, w.c_chgstamp[j] == stamp, jmn, jmx)) return;
+    if (!pair_allowed(w, i, j)) return;
     bp_insert_pair(w, i < j ? i : j, i < j ? j : i, true);
 }
-// new partners of the colliders on bp_chg_list: EIGHT lanes per changed collider, like the pair pass of a full rebuild (round 5: a
-// whole wavefront per collider — round 3, when an incremental pass served a few dozen colliders — left 56 of 64 lanes idle on the
-// 2 x 2 x 2 cell range of a ball and made a pass over b3d_joint_grid's 3,559 rewritten AABBs slower than the full rebuild)
+// new partners of the colliders on bp_chg_list.  Round 5, third form: a WAVEFRONT per changed collider, its 64 lanes spread over
+// (cell, bucket slot) — eight cells at a time, eight lanes per cell, lane s of a cell takes the bucket entries s, s + 8, ... — so a
+// lane's dependent chain is one or two entries long (bucket count -> entry -> the partner's box -> its stamp), not the whole bucket of
+// its cell (the eight-lanes-per-collider form: a cell per lane, its 4-12 entries one after the other: ~25 dependent loads).  Consecutive
+// list entries go to DIFFERENT workgroups: a few thousand changed colliders are a wavefront or two on every CU, not sixteen wavefronts of
+// scattered 16-byte loads on the first thirty CUs.  (Round 3's wavefront form gave a lane a whole CELL: 56 of 64 lanes idle on a ball.)
 RP_DEV void bp_incr_insert(DevWorld &w, int nchg) {
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x, sub = tid & (BP_GROUP - 1), ngroups = (gridDim.x * blockDim.x) / BP_GROUP;
+    const int lane = threadIdx.x & 63, cl = lane >> 3, sl = lane & 7;
     const int stamp = w.flags[FL_BP_SEQ] + 1;
     const float ic = w.prm.inv_cell_size;
     int nl = w.flags[FL_N_LARGE]; if (nl > w.large_cap) nl = w.large_cap;
     const int cur = BP_GPAR(w); // the grid copy in service
     const int *cnt = w.bk_cnt[cur]; const int *items = w.bk_items[cur];
-    for (int k = tid / BP_GROUP; k < nchg; k += ngroups) {
+    const int waves_per_block = (int)blockDim.x >> 6;
+    for (int k = (int)(threadIdx.x >> 6) * (int)gridDim.x + (int)blockIdx.x; k < nchg; k += waves_per_block * (int)gridDim.x) {
         const int i = w.bp_chg_list[k];
         CellRange r = cell_range(w, i);
         if (r.large || w.c_inlarge[i]) continue; // (never here: bp_grid_follow raised FL_BP_FORCE_FULL when it rewrote that AABB, and this launch chose the full rebuild)
         // (a) the large colliders (ground slabs, walls: never stale)
-        { int q0, q1; large_range_of(w, i, nl, q0, q1); for (int q = q0 + sub; q < q1; q += BP_GROUP) bp_try_pair(w, i, w.large_list[q]); }
-        // (b) everybody else through the grid, which follows every collider (bp_grid_follow): the cells of the new AABB (at most 27)
-        // over the eight lanes; a pair is reported from the cell that holds the min corner of the intersection, which lies in both
-        // cell ranges; two colliders that both changed in this pass find each other — reported from the smaller index
+        BpOld oi; oi.mn = w.c_fatold_min[i]; oi.mx = w.c_fatold_max[i]; oi.valid = box_valid(oi.mn, oi.mx); // (queued in this pass: c_fatold holds the box of the last pass)
+        { int q0, q1; large_range_of(w, i, nl, q0, q1); for (int q = q0 + lane; q < q1; q += 64) bp_try_pair(w, i, w.large_list[q], oi, stamp); }
+        // (b) everybody else through the grid, which follows every collider (bp_grid_follow): a pair is reported from the cell that
+        // holds the min corner of the intersection, which lies in both cell ranges; two colliders that both changed in this pass find
+        // each other — reported from the smaller index
         const int nx = r.hi[0] - r.lo[0] + 1, ny = r.hi[1] - r.lo[1] + 1, nz = r.hi[2] - r.lo[2] + 1;
-        for (int c = sub; c < nx * ny * nz; c += BP_GROUP) {
+        const float4 imn = w.c_fatmin[i], imx = w.c_fatmax[i];
+        for (int c = cl; c < nx * ny * nz; c += 8) {
             const int x = r.lo[0] + c % nx, y = r.lo[1] + (c / nx) % ny, z = r.lo[2] + c / (nx * ny);
             unsigned long long key = cell_key_of(w, i, x, y, z);
             int h = (int)(rp_hash64(key) & (unsigned long long)(w.grid_cap - 1));
             int n = cnt[h]; if (n > RP_BP_BUCKET) n = RP_BP_BUCKET;
-            for (int e = 0; e < n; ++e) {
+            for (int e = sl; e < n; e += 8) {
                 const int it = items[(size_t)h * RP_BP_BUCKET + e], j = it & 0xffffff;
                 if (j == i) continue;
-                V3 imin;
-                if (!fat_overlap(w, i, j, imin)) continue; // (geometry first: the three status words below are only fetched for the few entries that get past it)
-                if (cell_coord(imin.x, ic) != x || cell_coord(imin.y, ic) != y || cell_coord(imin.z, ic) != z) continue;
-                if (w.c_inlarge[j] || (w.c_chgstamp[j] == stamp && j < i)) continue; // the large list: covered by (a)
+                const float4 jmn = w.c_fatmin[j], jmx = w.c_fatmax[j];
+                if (!box_overlap(imn, imx, jmn, jmx)) continue; // (geometry first: the status words below are only fetched for the few entries that get past it)
+                const bool jchg = w.c_chgstamp[j] == stamp;
+                if (bp_pair_existed(w, oi, j, jchg, jmn, jmx)) continue; // an existing pair: nothing to insert (the common case by far)
+                if (cell_coord(fmaxf(imn.x, jmn.x), ic) != x || cell_coord(fmaxf(imn.y, jmn.y), ic) != y || cell_coord(fmaxf(imn.z, jmn.z), ic) != z) continue;
+                if (w.c_inlarge[j] || (jchg && j < i)) continue; // the large list: covered by (a)
                 if (!bp_entry_is_cell(w, it, x, y, z)) continue; // (another cell of j that shares this bucket, or an entry of a cell range j has left)
                 if (!pair_allowed(w, i, j)) continue;
                 bp_insert_pair(w, i < j ? i : j, i < j ? j : i, true);
@@ -455,31 +477,14 @@ __global__ void __launch_bounds__(1024) k_bp_rebuild(DevWorld w) {
     if (incremental) {
         // ONE pass, no grid barrier (round 5): new partners of the changed colliders and the pairs they lost are independent of each
         // other — a pair is in exactly one of the two sets — the hash table takes CAS inserts and tombstones side by side, and freed
-        // slots are parked (bp_delete_pair deferred) while the inserts pop the free stack.  The last workgroup to finish (ticket)
-        // moves the parked slots onto the stack and closes the pass.  b3d_joint_grid, 3,559 of 10,000 fat AABBs rewritten per pass:
-        // 28 us (pairs | finish behind two barriers) -> see profiles/r05_joint_grid_kernel_stats.txt.
+        // slots are parked (bp_delete_pair deferred) while the inserts pop the free stack.
         bp_incr_insert(w, nchg);
         bp_incr_delete(w, gid, gstride, nchg);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every wave: its stores have left the CU (one releasing lane per workgroup, like gbar_sync:
-        __syncthreads();                                   // a fence per thread cost such a pass 32 us in round 3)
-        __shared__ int s_last;
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            s_last = (__hip_atomic_fetch_add(&w.flags[FL_TICKET], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) ? 1 : 0;
-            if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        __syncthreads();
-        if (!s_last) return;
-        const int nfreed = __hip_atomic_load(&w.flags[FL_BP_NFREED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int ftop = __hip_atomic_load(&w.flags[FL_FREE_TOP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int k = threadIdx.x; k < nfreed; k += blockDim.x) w.free_stack[ftop + k] = w.free_pending[k];
-        __threadfence(); __syncthreads();
-        if (threadIdx.x == 0) {
-            w.flags[FL_FREE_TOP] = ftop + nfreed; w.flags[FL_BP_NFREED] = 0; w.flags[FL_TICKET] = 0;
-            w.flags[FL_BP_NCHG] = 0; w.flags[FL_BP_SEQ] += 1; w.flags[FL_BP_REBUILDS] += 1;
-            __hip_atomic_store(&w.flags[FL_BP_DIRTY], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        // The pass is CLOSED by the next kernel of the step (bp_close_incremental, workgroup 0 of k_np_test: parked slots onto the free
+        // stack, counters, the dirty flag): behind a kernel boundary, not behind a last-workgroup ticket — the agent-scope release fence
+        // every workgroup paid for that ticket was most of a pass that found nothing to do (b3d_joint_grid: not one pair, ~4,000 fat
+        // AABBs rewritten per pass: 19 us).
+        if (gid == 0) w.flags[FL_BP_CLOSE] = 1;
         return;
     }
     const int epoch = w.flags[FL_BP_EPOCH];
@@ -579,6 +584,8 @@ void rp_launch_broadphase(const DevWorld &w, hipStream_t st) {
     if (w.n_colliders == 0) return;
     // every workgroup must be resident (grid barriers): at most DevWorld::gbar_blocks workgroups of 1024 threads (rp_gridbar.h)
     int blocks = (w.n_colliders + 127) / 128; // the pair pass gives every collider 8 lanes (BP_GROUP): one round when the grid allows
+    { static const int wide = getenv("RP_BP_GRID_DIV") ? atoi(getenv("RP_BP_GRID_DIV")) : 32; // (the incremental pass: a wavefront per changed collider, 16 per workgroup)
+      if (wide > 0) { const int b2 = (w.n_colliders + wide - 1) / wide; if (b2 > blocks) blocks = b2; } }
     if (blocks < 8) blocks = 8;    // the clears and the pair-slot sweep are sized by capacities, not by the collider count
     if (blocks > w.gbar_blocks) blocks = w.gbar_blocks;
     hipLaunchKernelGGL(k_bp_rebuild, dim3(blocks), dim3(1024), 0, st, w);

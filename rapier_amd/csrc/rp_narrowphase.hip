@@ -886,6 +886,7 @@ template <bool CONVEX> __device__ __forceinline__ void pair_full_update(DevWorld
 // settled scene the queue is empty and the heavy kernel exits at once instead of taxing every pair with its launch
 // footprint (29 us -> a few us per step on b3d_many_pyramids).
 __global__ void k_np_test(DevWorld w) {
+    if (blockIdx.x == 0) bp_close_incremental(w); // (the broad-phase pass in front of this kernel, if it was an incremental one)
     if (collision_done(w)) return; // (rp_world.h "lean step graphs")
     int top = w.flags[FL_POOL_TOP];
     if (top > w.pool_cap) top = w.pool_cap;

@@ -104,6 +104,7 @@ RP_DEV bool collider_update_one(const DevWorld &w, int i) { // true = the fat AA
         const int stamp = w.flags[FL_BP_SEQ] + 1;
         if (w.c_chgstamp[i] != stamp) { // ONE atomic per wavefront on the list's counter (a third of b3d_joint_grid's 10,000 colliders queue every pass: 3,559 same-address atomics)
             w.c_chgstamp[i] = stamp;
+            w.c_fatold_min[i] = fmn; w.c_fatold_max[i] = fmx; // what the pair set of the last pass was computed from (bp_incr_insert: pairs that already exist)
             const unsigned long long m = __ballot(1);
             const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
             int k = 0;
@@ -234,4 +235,19 @@ RP_DEV void aux_free_all(DevWorld &w, int s, bool deferred) {
     if (a.y >= 0) aux_slot_free(w, a.y, deferred);
     if (a.z >= 0) aux_slot_free(w, a.z, deferred);
     w.p_aux[s] = make_int4(-1, -1, -1, 0);
+}
+
+// Closes the incremental broad-phase pass of this step (k_bp_rebuild leaves FL_BP_CLOSE behind): the slots its deletions parked go onto
+// the free stack, the pass counters advance, the dirty flag falls.  ONE workgroup, first thing in the kernel that follows the pass
+// (k_np_test): nothing between the two reads the free stack, FL_BP_DIRTY or the change list.
+RP_DEV void bp_close_incremental(const DevWorld &w) {
+    if (!w.flags[FL_BP_CLOSE]) return; // (uniform)
+    const int nfreed = w.flags[FL_BP_NFREED], ftop = w.flags[FL_FREE_TOP];
+    for (int k = threadIdx.x; k < nfreed; k += blockDim.x) w.free_stack[ftop + k] = w.free_pending[k];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        w.flags[FL_FREE_TOP] = ftop + nfreed; w.flags[FL_BP_NFREED] = 0;
+        w.flags[FL_BP_NCHG] = 0; w.flags[FL_BP_SEQ] += 1; w.flags[FL_BP_REBUILDS] += 1;
+        w.flags[FL_BP_DIRTY] = 0; w.flags[FL_BP_CLOSE] = 0;
+    }
 }

@@ -89,7 +89,7 @@ enum {
     FL_NJ_STAGES, FL_NJ_OVF_BEGIN, FL_NJ_OVF_COUNT, // joint stage layout: parallel colours, serial overflow range in j_order
     FL_ARRIVE, FL_DEPART, // fused fast step: workgroups that validated their islands / that finished (reset by the last one)
     FL_ISL_ICONS_CURSOR,
-    FL_TICKET,          // last-workgroup-done ticket (one user at a time: kernels of a step are serialised)
+    FL_BP_CLOSE,        // an incremental broad-phase pass waits to be closed by the next kernel (rp_pairs.h bp_close_incremental)
     FL_FAST_ABORT,      // steady-state fast path found work it cannot do (see rp_api.hip); sticky until a full step
     FL_EV_COL, FL_EV_FORCE, // events appended to the collision / contact-force queues (may exceed the queue capacity)
     FL_N_AWAKE,         // awake non-fixed bodies after the last sleep pass (0 = the whole world sleeps: idle steps, rp_sleep.hip)
@@ -295,6 +295,7 @@ struct DevWorld {
     int *scan_block;       // [1024 + 8] scratch counters of a running rebuild ([1024]: its large list)
     int *large_list;
     int *large_sub_begin, *large_sub_cur, *large_tmp; int sub_cap; // the large list by sub-world (rp_grid.h large_range_of): begins [sub_cap + 2], scratch
+    float4 *c_fatold_min, *c_fatold_max; // the fat AABB a collider queued in this pass had at the LAST pass (valid while c_chgstamp == the pass's stamp): rp_broadphase.hip bp_incr_insert
     int *c_chgstamp, *c_stale, *c_inlarge; // per collider: pass (FL_BP_SEQ + 1) that already queued it on bp_chg_list; (unused since round 4); on large_list
     int *c_rver;           // per collider: cell-range changes since the last full rebuild (the version its live grid entries carry: bp_grid_follow)
     int *bp_chg_list, *free_pending;       // [colliders] fat AABBs rewritten since the last pass; [pool_cap] slots freed by a running incremental pass

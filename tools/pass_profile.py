@@ -13,7 +13,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "build":
     subprocess.run(["make", "-s", "-C", src], check=True)
     flags = "-O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -DRP_PASS_PROFILE".split()
     objs = []
-    for f in ("rp_api", "rp_broadphase", "rp_narrowphase", "rp_solver", "rp_islands", "rp_joints", "rp_sleep", "rp_flow", "rp_tiles"):
+    for f in ("rp_api", "rp_broadphase", "rp_narrowphase", "rp_solver", "rp_islands", "rp_islands_lean", "rp_joints", "rp_sleep", "rp_flow", "rp_tiles"):
         if f in ("rp_islands", "rp_broadphase"):
             o = f"/tmp/{f}_pp.o"
             subprocess.run(["/opt/rocm/bin/hipcc", *flags, "-c", os.path.join(src, f + ".hip"), "-o", o], check=True)
