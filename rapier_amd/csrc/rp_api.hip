@@ -1631,6 +1631,7 @@ static int finalize(rp_world *w) {
     { const char *dv = getenv("RP_BP_INCR_DIV"); d.bp_incr_div = dv ? std::max(1, atoi(dv)) : 1; }
     { const char *ab = getenv("RP_BP_ALWAYS_BUILD"); d.bp_always_build = (ab && ab[0] == '1') ? 1 : 0; }
     { const char *nt = getenv("RP_NO_TINY_ROUTING"); d.isl_route_tiny = (nt && nt[0] == '1') ? 0 : 1; }
+    { const char *tn = getenv("RP_ISL_TINY_NC"); d.isl_tiny_nc = tn ? std::max(0, atoi(tn)) : 8; }
     { const char *im = getenv("RP_ISL_MANY"); d.isl_many = im ? std::max(1, atoi(im)) : (w->fused_grid > 0 ? w->fused_grid : 240); } // (more candidates than ONE resident pass of k_island_solve: round 5, a batch of 64 capsule worlds — 320 islands of 4 manifolds — 414 -> 230 us per step; round 4 waited for 960)
     { const char *ig = getenv("RP_ISL_GENERIC"); d.isl_generic = (ig && ig[0] == '1') ? 1 : 0; }
     w->compound = world_has_compound_bodies(w); refresh_ccd_facts(w);

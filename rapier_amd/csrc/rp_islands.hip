@@ -181,10 +181,9 @@ RP_DEV void lay_isl_count(DevWorld &w, int gid, int stride) {
 // number the islands that fit one workgroup (registers + LDS)
 // Round 4: k_island_solve gives an island a whole workgroup (512 lanes for up to 145 manifolds) and runs 240 of them at a time — right
 // for piles, wasteful for debris: 4,400 islands of one to five bodies (thousands of small shapes on a floor) are 18 passes, 1.35 ms.
-// When the previous rebuild counted more candidates than DevWorld::isl_many (one resident pass of k_island_solve: 240 on MI355X), components of at most RP_ISL_TINY_NC manifolds stay on the global
+// When the previous rebuild counted more candidates than DevWorld::isl_many (one resident pass of k_island_solve: 240 on MI355X), components of at most DevWorld::isl_tiny_nc (8) manifolds stay on the global
 // path, whose colour stages / LDS tiles take them all at once (either path gives the same bits: a routing decision, not a result).
 // lay_state[3] = candidates of the last rebuild (written behind its last barrier), [4] = this rebuild's count.
-#define RP_ISL_TINY_NC 8
 RP_DEV void lay_isl_number(DevWorld &w, int gid, int gstride) {
   const bool route_tiny = w.isl_route_tiny && w.lay_state[3] > w.isl_many;
   for (int b = gid; b < w.n_bodies; b += gstride) {
@@ -192,7 +191,7 @@ RP_DEV void lay_isl_number(DevWorld &w, int gid, int gstride) {
     int cnb = w.r_nb[b], cnc = w.r_nc[b];
     const bool candidate = cnc > 0 && cnb <= RP_ISL_NB_MAX && cnc <= RP_ISL_NC_MAX;
     if (candidate) atomicAdd(&w.lay_state[4], 1);
-    if (candidate && !(route_tiny && cnc <= RP_ISL_TINY_NC)) {
+    if (candidate && !(route_tiny && cnc <= w.isl_tiny_nc)) {
         int id = atomicAdd(&w.flags[FL_N_ISLANDS], 1);
         w.isl_body_begin[id] = atomicAdd(&w.flags[FL_ISL_BODY_CURSOR], cnb);
         w.isl_cons_begin[id] = atomicAdd(&w.flags[FL_ISL_CONS_CURSOR], cnc);

@@ -203,6 +203,7 @@ struct DevWorld {
     int gbar_blocks;       // most workgroups (of 1024 threads) a grid-barrier kernel may use on this device: all of them resident at once (rp_gridbar.h)
     int has_sensors;       // some collider is a sensor: its pairs are intersection-tested every step (full step path)
     int isl_route_tiny;    // 1 (RP_NO_TINY_ROUTING=1: 0): worlds with thousands of tiny islands solve them on the global path (rp_islands.hip, lay_isl_number)
+    int isl_tiny_nc;       // ... and "tiny" = at most this many manifolds (8; RP_ISL_TINY_NC)
     int isl_many;          // ... "thousands" = more island candidates than this in the previous rebuild (960; RP_ISL_MANY overrides it)
     int bp_always_build;   // RP_BP_ALWAYS_BUILD=1: every full broad-phase rebuild runs its build pass (A/B switch for the kept-grid rebuild, rp_broadphase.hip)
     int has_convex;        // some collider is a cylinder / cone / convex polyhedron: the narrow-phase, sensor and CCD launches use their CONVEX instantiations (rp_convex.h)

@@ -262,6 +262,14 @@ def test_fuzz_solve_groups_bit_exact(seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", [60, 61, 62, 63, 2003, 2012])
+def test_fuzz_in_a_batch_of_sub_worlds_bit_exact(seed):
+    """the driver's scene and actions inside a batch of three overlapping sub-worlds (rp_world_begin_subworld): removals, insertions,
+    sleeping, joints, events, CCD and both friction models with two other worlds in the same place"""
+    _run(seed, params=seed >= 2000, batch=True)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", [20, 21, 22, 23, 2005])
 def test_fuzz_sensors_bit_exact(seed):
     """the same scenes and actions with sensor colliders: a trigger volume in the middle of the pile, sensor obstacles, sensor
@@ -277,7 +285,7 @@ def test_fuzz_halfspace_ground_bit_exact(seed):
     _run(seed, steps=200, params=seed >= 2000, halfspace=True)
 
 
-def _run(seed, steps=240, walls=False, params=False, world=None, extras=False, sensors=False, halfspace=False, **kw):
+def _run(seed, steps=240, walls=False, params=False, world=None, extras=False, sensors=False, halfspace=False, batch=False, **kw):
     sc, rng = _scene(seed, **kw)
     if halfspace:
         c0 = sc.colliders[0]                                       # the ground slab (top face at y = 0) becomes the plane y = 0
@@ -297,9 +305,16 @@ def _run(seed, steps=240, walls=False, params=False, world=None, extras=False, s
     if walls:
         for k, (x, z, hx, hz) in enumerate(((3.2, 0, 0.3, 3.5), (-3.2, 0, 0.3, 3.5), (0, 3.2, 3.5, 0.3), (0, -3.2, 3.5, 0.3))):
             sc.add_collider(0, half_extents=(hx, 6.0, hz), translation=(x, 6.5, z))
+    dyn = [i for i, b in enumerate(sc.bodies) if int(b["body_type"]) == S.BODY_DYNAMIC]
+    if batch:
+        # the fuzzed scene as sub-world 0 of a BATCH (rp_world_begin_subworld): two more random scenes occupy the same space as
+        # sub-worlds 1 and 2 — they never meet the fuzzed one — and everything the driver inserts later lands in sub-world 2
+        others = [_scene(seed + 500 + k, **kw)[0] for k in range(2)]
+        for other in others:
+            other.gravity, other.params = sc.gravity, sc.params.copy()
+        sc = S.batch([sc] + others)
     g, o = (world(sc) if world else PhysicsWorld.from_scene(sc)), OracleWorld(sc)
     nb0 = len(sc.bodies)
-    dyn = [i for i, b in enumerate(sc.bodies) if int(b["body_type"]) == S.BODY_DYNAMIC]
     alive = list(range(nb0))
     jb = {j: (int(sc.joints[j]["body1"]), int(sc.joints[j]["body2"])) for j in range(len(sc.joints))}   # live joints -> their bodies
     col_parent = list(sc.collider_parents); ncol = len(col_parent); removed_cols = set()
