@@ -155,8 +155,8 @@ typedef struct rp_joint_motor {
     int32_t model;
 } rp_joint_motor;
 
-/* GenericJoint without coupled axes — /root/reference/src/dynamics/joint/generic_joint.rs:341-355; the local frames
- * are (local_anchor, local_basis) like GenericJoint::local_frame1/2 */
+/* GenericJoint — /root/reference/src/dynamics/joint/generic_joint.rs:255-355; the local frames are (local_anchor, local_basis) like
+ * GenericJoint::local_frame1/2 */
 typedef struct rp_joint_desc {
     int32_t body1, body2; /* dense body indices (handle low 32 bits) */
     float local_anchor1[3], local_anchor2[3];
@@ -167,6 +167,10 @@ typedef struct rp_joint_desc {
     float limits[6][2];   /* JointLimits::{min, max} per axis (GenericJoint::limits, generic_joint.rs:230-245): metres / radians */
     uint32_t motor_axes;  /* GenericJoint::motor_axes: JointAxesMask of the motorised (free) axes */
     rp_joint_motor motors[6]; /* GenericJoint::motors */
+    uint32_t coupled_axes;    /* GenericJoint::coupled_axes (generic_joint.rs:285): the linear axes in the mask share ONE limit row (max distance:
+                               * RopeJoint, rope_joint.rs:31-38) and ONE motor row (SpringJoint, spring_joint.rs:31-40) along their combined
+                               * error — limits and motor are those of the first coupled axis; exactly two angular axes in the mask share one
+                               * limit row (joint_constraint_helper.rs:725-790); a motor on coupled angular axes does nothing, as in the reference */
 } rp_joint_desc;
 
 /* Counters mirror (ms, from hipEvents) — /root/reference/src/counters/{mod,stages_counters,

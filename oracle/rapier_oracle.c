@@ -172,6 +172,7 @@ typedef struct {
     int body1, body2;
     pose local_frame1, local_frame2;      /* GenericJoint::local_frame1/2 (body space) */
     uint32_t locked_axes; int contacts_enabled;
+    uint32_t coupled_axes; /* GenericJoint::coupled_axes */
     uint32_t limit_axes; float limits[6][2];   /* GenericJoint::{limit_axes, limits} */
     float ang_limit_center[3][2], ang_limit_half_range[3]; /* AngularLimitParams (joint_constraint_helper.rs:34-72) */
     float limit_impulses[6];                    /* JointLimits::impulse */
@@ -2258,9 +2259,16 @@ static void joints_color(ro_world *w) {
 }
 /* JointConstraintBuilder::generate — joint_constraint_builder.rs:34-60 +
  * GenericJoint::transform_to_solver_body_space — generic_joint.rs:624-636 */
+static int ro_ctz(uint32_t x) { int n = 0; while (!(x & 1u)) { x >>= 1; ++n; } return n; } /* trailing_zeros of a non-zero mask */
 static int joint_num_rows(const Joint *j) {
+    /* joint_velocity_constraint.rs:159-352: per-axis rows skip the coupled axes; the coupled linear axes add one motor row and one
+     * limit row (carried by the first coupled axis), two coupled angular axes one limit row; a coupled angular motor is a no-op */
+    const uint32_t locked = j->locked_axes & 0x3fu, coupled = j->coupled_axes, motor = j->motor_axes & ~locked, limit = j->limit_axes & ~locked;
     int n = 0;
-    for (int i = 0; i < 6; ++i) { if ((j->locked_axes | j->limit_axes) & (1u << i)) n++; if ((j->motor_axes & ~j->locked_axes) & (1u << i)) n++; }
+    for (int i = 0; i < 6; ++i) { if (locked & (1u << i)) n++; if ((limit & ~coupled) & (1u << i)) n++; if ((motor & ~coupled) & (1u << i)) n++; }
+    if ((motor & coupled) & 7u) n++;
+    if ((coupled & 0x38u) && (limit & (1u << ro_ctz(coupled & 0x38u)))) n++;
+    if ((coupled & 7u) && (limit & (1u << ro_ctz(coupled & 7u)))) n++;
     return n;
 }
 static void joint_builder_generate(ro_world *w, Joint *j, int *num_rows) {
@@ -2342,8 +2350,9 @@ static int joint_update_rows(const ro_world *w, const Joint *j, float dt, JointR
     int len = 0, start = 0;
     /* motor rows first, finalised as a block of their own (joint_velocity_constraint.rs:186-246): motor_angular
      * (joint_constraint_helper.rs:566-625) for the angular axes, then motor_linear (:285-331) */
-    uint32_t motor_axes = j->motor_axes & ~j->locked_axes;
-    if (motor_axes) {
+    const uint32_t coupled = j->coupled_axes;
+    const uint32_t motor_all = j->motor_axes & ~j->locked_axes, motor_axes = motor_all & ~coupled; /* (motor_axes & !coupled_axes, :190-221) */
+    if (motor_all) {
         quat q1m = frame1.r, q2m = frame2.r;
         float sgnm = copysignf(1.0f, qdot(q1m, q2m));
         quat ang_errm = qmul(qconj(q1m), q2m);
@@ -2388,6 +2397,36 @@ static int joint_update_rows(const ro_world *w, const Joint *j, float dt, JointR
             rhs_wo_bias += -target_vel;
             c->inv_lhs = 0.0f; c->cfm_coeff = mp.cfm_coeff; c->cfm_gain = mp.cfm_gain;
             c->rhs = rhs_wo_bias; c->rhs_wo_bias = rhs_wo_bias; c->dof = 12 + i;
+        }
+        /* (a coupled ANGULAR motor is a no-op: "TODO: coupled angular motor constraint", :223-225) */
+        if ((motor_all & coupled) & 7u) {
+            /* motor_linear_coupled (joint_constraint_helper.rs:333-408): ONE row along the combined error of the coupled linear axes;
+             * motor and limits are those of the first coupled linear axis (SpringJoint: LinX) */
+            const int fa = ro_ctz(coupled & 7u);
+            MotorParams mp = motor_params(&j->motors[fa], dt);
+            v3 lin_jac = V3(0, 0, 0), aj1 = V3(0, 0, 0), aj2 = V3(0, 0, 0);
+            for (int i = 0; i < 3; ++i) {
+                if (!(coupled & (1u << i))) continue;
+                float coeff = vdot(col[i], lin_err);
+                lin_jac = vadd(lin_jac, vmul(col[i], coeff));
+                aj1 = vadd(aj1, vmul(vadd(vadd(vmul(c1x, col[i].x), vmul(c1y, col[i].y)), vmul(c1z, col[i].z)), coeff));
+                aj2 = vadd(aj2, vmul(vadd(vadd(vmul(c2x, col[i].x), vmul(c2y, col[i].y)), vmul(c2z, col[i].z)), coeff));
+            }
+            float dist = sqrtf(vdot(lin_jac, lin_jac)), inv_dist = ro_inv(dist);
+            lin_jac = vmul(lin_jac, inv_dist); aj1 = vmul(aj1, inv_dist); aj2 = vmul(aj2, inv_dist);
+            float rhs_wo_bias = 0.0f;
+            if (mp.erp_inv_dt != 0.0f) rhs_wo_bias += (dist - mp.target_pos) * mp.erp_inv_dt;
+            float target_vel = mp.target_vel;
+            if ((j->limit_axes & ~j->locked_axes) & (1u << fa)) { float inv_dt = ro_inv(dt); target_vel = ro_clampf(target_vel, (j->limits[fa][0] - dist) * inv_dt, (j->limits[fa][1] - dist) * inv_dt); }
+            rhs_wo_bias += -target_vel;
+            JointRow *c = &out[len++];
+            c->solver_vel1 = j->solver_body_ids[0]; c->solver_vel2 = j->solver_body_ids[1];
+            c->im1 = rb1.im; c->im2 = rb2.im;
+            c->impulse = 0.0f; c->impulse_bounds[0] = -mp.max_impulse; c->impulse_bounds[1] = mp.max_impulse;
+            c->lin_jac = lin_jac; c->ang_jac1 = aj1; c->ang_jac2 = aj2;
+            c->ii_ang_jac1 = sym3_mul(rb1.ii, aj1); c->ii_ang_jac2 = sym3_mul(rb2.ii, aj2);
+            c->inv_lhs = 0.0f; c->cfm_coeff = mp.cfm_coeff; c->cfm_gain = mp.cfm_gain;
+            c->rhs = rhs_wo_bias; c->rhs_wo_bias = rhs_wo_bias; c->dof = 12 + fa;
         }
         joint_finalize_rows(out, len);
         start = len;
@@ -2451,7 +2490,7 @@ static int joint_update_rows(const ro_world *w, const Joint *j, float dt, JointR
         c->rhs = rhs_wo_bias + rhs_bias; c->rhs_wo_bias = rhs_wo_bias; c->dof = i;
     }
     /* limited (free) axes — scalar update order: limit_angular rows, then limit_linear rows (joint_velocity_constraint.rs:285-314) */
-    uint32_t limit_axes = j->limit_axes & ~j->locked_axes;
+    const uint32_t limit_all = j->limit_axes & ~j->locked_axes, limit_axes = limit_all & ~coupled; /* (limit_axes & !coupled_axes, :285-314) */
     float max_bias = w->params.normalized_max_corrective_velocity * w->params.length_unit;
     if (limit_axes & 0x38u) {
         /* limit_angular (joint_constraint_helper.rs:503-564) with recentered_angle (:468-501) */
@@ -2504,6 +2543,73 @@ static int joint_update_rows(const ro_world *w, const Joint *j, float dt, JointR
         c->inv_lhs = 0.0f; c->cfm_coeff = cfm_coeff; c->cfm_gain = 0.0f;
         c->rhs = rhs_wo_bias + rhs_bias; c->rhs_wo_bias = rhs_wo_bias; c->dof = 6 + i;
         c->impulse_bounds[0] = min_enabled ? -INFINITY : 0.0f; c->impulse_bounds[1] = max_enabled ? INFINITY : 0.0f;
+    }
+    if ((coupled & 0x38u) && (limit_all & (1u << ro_ctz(coupled & 0x38u)))) {
+        /* limit_angular_coupled (joint_constraint_helper.rs:725-790): exactly two coupled angular axes; the angle between the two
+         * frames' copies of the THIRD axis is limited — glam 0.33 Quat::from_rotation_arc + to_axis_angle restated (the crate is not
+         * under /root/reference: its published algorithm) */
+        const int fa = ro_ctz(coupled & 0x38u);
+        const uint32_t ca = (coupled >> 3) & 7u;
+        int nc = 0; while (ca & (1u << nc)) ++nc; /* trailing_ones: the index of the angular axis that is NOT coupled */
+        float m2[3][3]; quat_to_mat(frame2.r, m2);
+        v3 axis1 = col[nc], axis2 = V3(m2[0][nc], m2[1][nc], m2[2][nc]);
+        quat rot; float d = vdot(axis1, axis2);
+        const float one_minus_eps = 1.0f - 2.0f * 1.1920929e-7f;
+        if (d > one_minus_eps) rot = Q(0.0f, 0.0f, 0.0f, 1.0f);
+        else if (d < -one_minus_eps) { /* from_axis_angle(from.any_orthonormal_vector(), PI) */
+            float sign = copysignf(1.0f, axis1.z), a = -1.0f / (sign + axis1.z), b = axis1.x * axis1.y * a;
+            v3 o = V3(b, sign + axis1.y * axis1.y * a, -axis1.y);
+            rot = Q(o.x * 1.0f, o.y * 1.0f, o.z * 1.0f, -4.371139e-08f); /* sin, cos of PI / 2 in f32 */
+        } else {
+            v3 cr = vcross(axis1, axis2);
+            quat q = Q(cr.x, cr.y, cr.z, 1.0f + d);
+            float inv = 1.0f / sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+            rot = Q(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
+        }
+        v3 rv = V3(rot.x, rot.y, rot.z), ang_jac; float angle;
+        float rl = sqrtf(vdot(rv, rv));
+        if (rl >= 1.0e-8f) { angle = 2.0f * ro_atan2_portable(rl, rot.w); ang_jac = vmul(rv, 1.0f / rl); } else { ang_jac = V3(1.0f, 0.0f, 0.0f); angle = 0.0f; }
+        if (angle == 0.0f) { /* axis1.orthonormal_basis()[0] (utils/orthonormal_basis.rs:37-50) */
+            float sign = copysignf(1.0f, axis1.z), a = -1.0f / (sign + axis1.z), b = axis1.x * axis1.y * a;
+            ang_jac = V3(1.0f + sign * axis1.x * axis1.x * a, sign * b, -sign * axis1.x);
+        }
+        float lmin = j->limits[fa][0], lmax = j->limits[fa][1];
+        int min_enabled = angle <= lmin, max_enabled = lmax <= angle;
+        JointRow *c = &out[len++];
+        c->solver_vel1 = j->solver_body_ids[0]; c->solver_vel2 = j->solver_body_ids[1];
+        c->im1 = rb1.im; c->im2 = rb2.im;
+        c->impulse = 0.0f; c->impulse_bounds[0] = min_enabled ? -INFINITY : 0.0f; c->impulse_bounds[1] = max_enabled ? INFINITY : 0.0f;
+        c->lin_jac = V3(0, 0, 0); c->ang_jac1 = ang_jac; c->ang_jac2 = ang_jac;
+        float rhs_bias = ro_clampf((ro_maxf(angle - lmax, 0.0f) - ro_maxf(lmin - angle, 0.0f)) * erp_inv_dt, -max_bias, max_bias);
+        c->ii_ang_jac1 = sym3_mul(rb1.ii, ang_jac); c->ii_ang_jac2 = sym3_mul(rb2.ii, ang_jac);
+        c->inv_lhs = 0.0f; c->cfm_coeff = cfm_coeff; c->cfm_gain = 0.0f;
+        c->rhs = 0.0f + rhs_bias; c->rhs_wo_bias = 0.0f; c->dof = 6 + fa;
+    }
+    if ((coupled & 7u) && (limit_all & (1u << ro_ctz(coupled & 7u)))) {
+        /* limit_linear_coupled (joint_constraint_helper.rs:210-283): the distance along the combined error of the coupled linear
+         * axes against the MAX limit of the first coupled axis (RopeJoint; "FIXME: handle min limit too") */
+        const int fa = ro_ctz(coupled & 7u);
+        v3 lin_jac = V3(0, 0, 0), aj1 = V3(0, 0, 0), aj2 = V3(0, 0, 0);
+        for (int i = 0; i < 3; ++i) {
+            if (!(coupled & (1u << i))) continue;
+            float coeff = vdot(col[i], lin_err);
+            lin_jac = vadd(lin_jac, vmul(col[i], coeff));
+            aj1 = vadd(aj1, vmul(vadd(vadd(vmul(c1x, col[i].x), vmul(c1y, col[i].y)), vmul(c1z, col[i].z)), coeff));
+            aj2 = vadd(aj2, vmul(vadd(vadd(vmul(c2x, col[i].x), vmul(c2y, col[i].y)), vmul(c2z, col[i].z)), coeff));
+        }
+        float dist = sqrtf(vdot(lin_jac, lin_jac)), inv_dist = ro_inv(dist);
+        lin_jac = vmul(lin_jac, inv_dist); aj1 = vmul(aj1, inv_dist); aj2 = vmul(aj2, inv_dist);
+        float lmax = j->limits[fa][1];
+        float rhs_wo_bias = ro_minf(dist - lmax, 0.0f) * ro_inv(dt);
+        float rhs_bias = ro_clampf(ro_maxf(dist - lmax, 0.0f) * erp_inv_dt, -max_bias, max_bias);
+        JointRow *c = &out[len++];
+        c->solver_vel1 = j->solver_body_ids[0]; c->solver_vel2 = j->solver_body_ids[1];
+        c->im1 = rb1.im; c->im2 = rb2.im;
+        c->impulse = 0.0f; c->impulse_bounds[0] = 0.0f; c->impulse_bounds[1] = INFINITY;
+        c->lin_jac = lin_jac; c->ang_jac1 = aj1; c->ang_jac2 = aj2;
+        c->ii_ang_jac1 = sym3_mul(rb1.ii, aj1); c->ii_ang_jac2 = sym3_mul(rb2.ii, aj2);
+        c->inv_lhs = 0.0f; c->cfm_coeff = cfm_coeff; c->cfm_gain = 0.0f;
+        c->rhs = rhs_wo_bias + rhs_bias; c->rhs_wo_bias = rhs_wo_bias; c->dof = 6 + fa;
     }
     joint_finalize_rows(out + start, len - start);
     return len;
@@ -3421,7 +3527,8 @@ int32_t ro_dump_manifolds(const ro_world *w, int32_t cap, int32_t *meta, float *
  * contacts between the two bodies enabled. */
 int32_t ro_add_joint(ro_world *w, const ro_joint_desc *d) {
     if (d->body1 < 0 || d->body2 < 0 || d->body1 >= w->nbodies || d->body2 >= w->nbodies) return -1;
-    if ((d->locked_axes & ~0x3fu) != 0 || (d->limit_axes & ~0x3fu) != 0 || (d->motor_axes & ~0x3fu) != 0) return -1;
+    if ((d->locked_axes & ~0x3fu) != 0 || (d->limit_axes & ~0x3fu) != 0 || (d->motor_axes & ~0x3fu) != 0 || (d->coupled_axes & ~0x3fu) != 0) return -1;
+    { uint32_t ca = (d->coupled_axes >> 3) & 7u; if (ca != 0 && ca != 3 && ca != 5 && ca != 6) return -1; } /* limit_angular_coupled: exactly two coupled angular axes (joint_constraint_helper.rs:737-739) */
     if (w->njoints == w->cap_joints) {
         w->cap_joints = w->cap_joints ? w->cap_joints * 2 : 1024;
         w->joints = (Joint *)realloc(w->joints, sizeof(Joint) * w->cap_joints);
@@ -3436,6 +3543,7 @@ int32_t ro_add_joint(ro_world *w, const ro_joint_desc *d) {
     j->local_frame1.r = qnormalize(Q(d->local_basis1[0], d->local_basis1[1], d->local_basis1[2], d->local_basis1[3]));
     j->local_frame2.r = qnormalize(Q(d->local_basis2[0], d->local_basis2[1], d->local_basis2[2], d->local_basis2[3]));
     j->locked_axes = d->locked_axes; j->contacts_enabled = d->contacts_enabled;
+    j->coupled_axes = d->coupled_axes & 0x3fu;
     j->limit_axes = d->limit_axes & 0x3fu;
     for (int i = 0; i < 6; ++i) { j->limits[i][0] = d->limits[i][0]; j->limits[i][1] = d->limits[i][1]; }
     for (int a = 0; a < 3; ++a) { /* AngularLimitParams::new(min, max) */

@@ -100,7 +100,7 @@ typedef struct ro_collider_desc {
 /* JointMotor (dynamics/joint/generic_joint.rs:200-232); model: 0 = MotorModel::AccelerationBased, 1 = ForceBased */
 typedef struct ro_joint_motor { float target_vel, target_pos, stiffness, damping, max_force; int32_t model; } ro_joint_motor;
 
-/* GenericJoint: locked axes, limits and motors of the free axes (no coupled axes). */
+/* GenericJoint: locked axes, limits and motors of the free axes, coupled axes (RopeJoint / SpringJoint couple the linear axes). */
 typedef struct ro_joint_desc {
     int32_t body1, body2;
     float local_anchor1[3], local_anchor2[3];
@@ -111,6 +111,8 @@ typedef struct ro_joint_desc {
     float limits[6][2];   /* JointLimits::{min, max} per axis (metres for the linear axes, radians for the angular ones) */
     uint32_t motor_axes;  /* JointAxesMask of the motorised (free) axes — GenericJoint::motor_axes */
     ro_joint_motor motors[6];
+    uint32_t coupled_axes; /* GenericJoint::coupled_axes (generic_joint.rs:285): the linear axes in it share ONE limit / motor row along their
+                            * combined error, exactly two angular axes in it one limit row; the first coupled axis carries limits and motor */
 } ro_joint_desc;
 
 #define RO_ISLAND_STATS_MAX 16

@@ -65,19 +65,37 @@ RP_DEV void jrow_store_planes(const DevWorld &w, int j, int r, const JointRow &c
 }
 // rows of a joint: the motors of its free axes (GenericJoint::motor_axes & !locked_axes), its locked axes, then the limits of
 // its free axes (limit_axes & !locked_axes)
+// (GenericJoint::coupled_axes rides in bits 8..13 of the `limited` word — j_limited — so that every caller that hands the three masks on
+// hands it on too: JR_COUPLED(limited).)  Per-axis rows skip the coupled axes; the coupled linear axes add ONE motor row and ONE limit
+// row (carried by the first coupled axis), two coupled angular axes one limit row (joint_velocity_constraint.rs:159-352).
+#define JR_COUPLED(limited_word) (((limited_word) >> 8) & 0x3f)
 RP_DEV int joint_row_count(int locked, int limited, int motor) {
-    return __popc(((unsigned)locked | (unsigned)limited) & 0x3fu) + __popc((unsigned)motor & ~(unsigned)locked & 0x3fu);
+    const int coupled = JR_COUPLED(limited);
+    locked &= 0x3f; limited &= 0x3f & ~locked; motor &= 0x3f & ~locked;
+    int n = __popc((unsigned)locked) + __popc((unsigned)(limited & ~coupled)) + __popc((unsigned)(motor & ~coupled));
+    if (coupled) {
+        if (motor & coupled & 7) n++;
+        if ((coupled & 0x38) && (limited & (1 << (__ffs(coupled & 0x38) - 1)))) n++;
+        if ((coupled & 7) && (limited & (1 << (__ffs(coupled & 7) - 1)))) n++;
+    }
+    return n;
 }
-// WritebackId of row k (scalar update order, joint_velocity_constraint.rs:186-314): Motor(3 + a), Motor(i), Dof(3 + a) for the locked
-// angular axes, Dof(i) for the locked linear ones, then Limit(3 + a) and Limit(i); Dof = axis, Limit = 6 + axis, Motor = 12 + axis
+// WritebackId of row k (scalar update order, joint_velocity_constraint.rs:186-352): Motor(3 + a), Motor(i), the coupled linear motor,
+// Dof(3 + a) for the locked angular axes, Dof(i) for the locked linear ones, then Limit(3 + a), Limit(i), the coupled angular limit, the
+// coupled linear limit; Dof = axis, Limit = 6 + axis, Motor = 12 + axis
 RP_DEV int joint_row_dof(int locked, int limited, int motor, int k) {
-    limited &= ~locked; motor &= ~locked;
-    for (int a = 0; a < 3; ++a) if (motor & (8 << a)) { if (k == 0) return 12 + 3 + a; --k; }
-    for (int i = 0; i < 3; ++i) if (motor & (1 << i)) { if (k == 0) return 12 + i; --k; }
+    const int coupled = JR_COUPLED(limited);
+    locked &= 0x3f; limited &= 0x3f & ~locked; motor &= 0x3f & ~locked;
+    const int lim1 = limited & ~coupled, mot1 = motor & ~coupled;
+    for (int a = 0; a < 3; ++a) if (mot1 & (8 << a)) { if (k == 0) return 12 + 3 + a; --k; }
+    for (int i = 0; i < 3; ++i) if (mot1 & (1 << i)) { if (k == 0) return 12 + i; --k; }
+    if (motor & coupled & 7) { if (k == 0) return 12 + __ffs(coupled & 7) - 1; --k; }
     for (int a = 0; a < 3; ++a) if (locked & (8 << a)) { if (k == 0) return 3 + a; --k; }
     for (int i = 0; i < 3; ++i) if (locked & (1 << i)) { if (k == 0) return i; --k; }
-    for (int a = 0; a < 3; ++a) if (limited & (8 << a)) { if (k == 0) return 6 + 3 + a; --k; }
-    for (int i = 0; i < 3; ++i) if (limited & (1 << i)) { if (k == 0) return 6 + i; --k; }
+    for (int a = 0; a < 3; ++a) if (lim1 & (8 << a)) { if (k == 0) return 6 + 3 + a; --k; }
+    for (int i = 0; i < 3; ++i) if (lim1 & (1 << i)) { if (k == 0) return 6 + i; --k; }
+    if ((coupled & 0x38) && (limited & (1 << (__ffs(coupled & 0x38) - 1)))) { if (k == 0) return 6 + __ffs(coupled & 0x38) - 1; --k; }
+    if ((coupled & 7) && (limited & (1 << (__ffs(coupled & 7) - 1)))) { if (k == 0) return 6 + __ffs(coupled & 7) - 1; --k; }
     return 0;
 }
 // impulse written back by the last step for a WritebackId (warm start of substep 0)
@@ -191,7 +209,10 @@ template <class IO, class SINK = JointRowsToPlanes, bool ONLY_SPHERICAL = false>
 RP_DEV void joint_update_one_t(const DevWorld &w, const IO &io, int j, int substep_id, const SINK &sink = SINK()) {
     // (ONLY_SPHERICAL: the masks are known; an IO that already knows the joint's bodies — the tile sweeps: from the cone entry — says so)
     int b1, b2; io.bodies(w, j, b1, b2);
-    const int locked = ONLY_SPHERICAL ? 0x7 : w.j_locked[j], limited = ONLY_SPHERICAL ? 0 : (w.j_limited[j] & ~locked), motor = ONLY_SPHERICAL ? 0 : (w.j_motor[j] & ~locked);
+    const int locked = ONLY_SPHERICAL ? 0x7 : w.j_locked[j], limited_word = ONLY_SPHERICAL ? 0 : w.j_limited[j];
+    const int coupled = ONLY_SPHERICAL ? 0 : JR_COUPLED(limited_word);   // GenericJoint::coupled_axes
+    const int limited_all = limited_word & 0x3f & ~locked, motor_all = ONLY_SPHERICAL ? 0 : (w.j_motor[j] & 0x3f & ~locked);
+    const int limited = limited_all & ~coupled, motor = motor_all & ~coupled; // the per-axis rows skip the coupled axes
     Pose p1, p2; p1.r = q4(0, 0, 0, 1); p1.t = v3(0, 0, 0); p2 = p1;
     V3 im1 = v3(0, 0, 0), im2 = im1; Sym3 ii1 = {0, 0, 0, 0, 0, 0}, ii2 = ii1;
     if (b1 >= 0) { io.pose(0, b1, p1); im1 = v3(w.b_eim[b1]); float4 a = w.b_eii0[b1], b = w.b_eii1[b1]; ii1.m11 = a.x; ii1.m12 = a.y; ii1.m13 = a.z; ii1.m22 = a.w; ii1.m23 = b.x; ii1.m33 = b.y; }
@@ -210,7 +231,7 @@ RP_DEV void joint_update_one_t(const DevWorld &w, const IO &io, int j, int subst
     V3 c1x = v3(0.0f, r1.z, -r1.y), c1y = v3(-r1.z, 0.0f, r1.x), c1z = v3(r1.y, -r1.x, 0.0f);
     V3 c2x = v3(0.0f, r2.z, -r2.y), c2y = v3(-r2.z, 0.0f, r2.x), c2z = v3(r2.y, -r2.x, 0.0f);
     V3 imsum = im1 + im2;
-    if (ONLY_SPHERICAL || (locked == 0x7 && !motor && !limited)) { // three locked linear axes, nothing else (a spherical joint): rows in registers
+    if (ONLY_SPHERICAL || (locked == 0x7 && !motor_all && !limited_all && !coupled)) { // three locked linear axes, nothing else (a spherical joint): rows in registers
         JointRow r3[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -234,7 +255,7 @@ RP_DEV void joint_update_one_t(const DevWorld &w, const IO &io, int j, int subst
     JointRow rows[6];
     int dof[6] = {0, 0, 0, 0, 0, 0};
     int len = 0, base = 0;
-    if (motor) {
+    if (motor_all) {
         // motor rows come first and are finalised as a block of their own (joint_velocity_constraint.rs:186-246): motor_angular for
         // the angular axes (joint_constraint_helper.rs:566-625), then motor_linear (:285-331)
         const float dt = w.prm.dt_sub;
@@ -286,6 +307,37 @@ RP_DEV void joint_update_one_t(const DevWorld &w, const IO &io, int j, int subst
             c.inv_lhs = 0.0f; c.cfm_coeff = mp.cfm_coeff; c.cfm_gain = mp.cfm_gain;
             c.rhs = rhs_wo_bias; c.rhs_wo_bias = rhs_wo_bias;
             dof[len] = 12 + i;
+            len++;
+        }
+        // (a coupled ANGULAR motor is a no-op in the reference: "TODO: coupled angular motor constraint")
+        if (motor_all & coupled & 7) {
+            // motor_linear_coupled (joint_constraint_helper.rs:333-408): ONE row along the combined error of the coupled linear axes; the
+            // motor and limits of the first coupled linear axis (SpringJoint: LinX)
+            const int fa = __ffs(coupled & 7) - 1;
+            MotorParams mp = joint_motor_params(w, j, fa, dt);
+            V3 lj = v3(0, 0, 0), aj1 = lj, aj2 = lj;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                if (!(coupled & (1 << i))) continue;
+                const float coeff = dot(col[i], lin_err);
+                lj = lj + col[i] * coeff;
+                aj1 = aj1 + (c1x * col[i].x + c1y * col[i].y + c1z * col[i].z) * coeff;
+                aj2 = aj2 + (c2x * col[i].x + c2y * col[i].y + c2z * col[i].z) * coeff;
+            }
+            const float dist = sqrtf(dot(lj, lj)), inv_dist = rp_inv(dist);
+            lj = lj * inv_dist; aj1 = aj1 * inv_dist; aj2 = aj2 * inv_dist;
+            float rhs_wo_bias = 0.0f;
+            if (mp.erp_inv_dt != 0.0f) rhs_wo_bias += (dist - mp.target_pos) * mp.erp_inv_dt;
+            float target_vel = mp.target_vel;
+            if (limited_all & (1 << fa)) { float4 lp = w.j_lim[(size_t)fa * w.n_joints + j]; float inv_dt = rp_inv(dt); target_vel = rp_clamp(target_vel, (lp.x - dist) * inv_dt, (lp.y - dist) * inv_dt); }
+            rhs_wo_bias += -target_vel;
+            JointRow &c = rows[len];
+            c.impulse = 0.0f; c.bmin = -mp.max_impulse; c.bmax = mp.max_impulse;
+            c.lin_jac = lj; c.ang_jac1 = aj1; c.ang_jac2 = aj2;
+            c.ii1 = sym_mul(ii1, aj1); c.ii2 = sym_mul(ii2, aj2);
+            c.inv_lhs = 0.0f; c.cfm_coeff = mp.cfm_coeff; c.cfm_gain = mp.cfm_gain;
+            c.rhs = rhs_wo_bias; c.rhs_wo_bias = rhs_wo_bias;
+            dof[len] = 12 + fa;
             len++;
         }
         joint_finalize_store(w, j, rows, dof, len, 0, imsum, substep_id);
@@ -349,8 +401,8 @@ RP_DEV void joint_update_one_t(const DevWorld &w, const IO &io, int j, int subst
         dof[len] = i;
         len++;
     }
-    if (limited) {
-        // limited (free) axes: limit_angular rows, then limit_linear rows (joint_constraint_helper.rs:166-208, 468-564)
+    if (limited_all) {
+        // limited (free) axes: limit_angular rows, then limit_linear rows, then the coupled ones (joint_constraint_helper.rs:166-208, 468-564)
         const float maxcv = w.prm.max_corrective_velocity, erp = w.prm.joint_erp_inv_dt;
         const float inf = __int_as_float(0x7f800000);
         if (limited & 0x38) {
@@ -403,6 +455,74 @@ RP_DEV void joint_update_one_t(const DevWorld &w, const IO &io, int j, int subst
             c.rhs = rhs_wo_bias + rhs_bias; c.rhs_wo_bias = rhs_wo_bias;
             c.bmin = min_enabled ? -inf : 0.0f; c.bmax = max_enabled ? inf : 0.0f;
             dof[len] = 6 + i;
+            len++;
+        }
+        if ((coupled & 0x38) && (limited_all & (1 << (__ffs(coupled & 0x38) - 1)))) {
+            // limit_angular_coupled (joint_constraint_helper.rs:725-790): exactly two coupled angular axes; the angle between the two
+            // frames' copies of the THIRD axis is limited (glam Quat::from_rotation_arc + to_axis_angle restated, as in the oracle)
+            const int fa = __ffs(coupled & 0x38) - 1, ca = (coupled >> 3) & 7;
+            const int nc = (ca & 1) ? ((ca & 2) ? 2 : 1) : 0;                       // trailing_ones: the angular axis that is NOT coupled
+            float m2[3][3]; quat_to_mat(frame2.r, m2);
+            const V3 axis1 = nc == 0 ? col[0] : nc == 1 ? col[1] : col[2];
+            const V3 axis2 = nc == 0 ? v3(m2[0][0], m2[1][0], m2[2][0]) : nc == 1 ? v3(m2[0][1], m2[1][1], m2[2][1]) : v3(m2[0][2], m2[1][2], m2[2][2]);
+            Q4 rot; const float d = dot(axis1, axis2);
+            const float one_minus_eps = 1.0f - 2.0f * 1.1920929e-7f;
+            if (d > one_minus_eps) rot = q4(0.0f, 0.0f, 0.0f, 1.0f);
+            else if (d < -one_minus_eps) { // from_axis_angle(from.any_orthonormal_vector(), PI)
+                const float sign = copysignf(1.0f, axis1.z), a = -1.0f / (sign + axis1.z), b = axis1.x * axis1.y * a;
+                const V3 o = v3(b, sign + axis1.y * axis1.y * a, -axis1.y);
+                rot = q4(o.x * 1.0f, o.y * 1.0f, o.z * 1.0f, -4.371139e-08f);
+            } else {
+                const V3 cr = cross(axis1, axis2);
+                const Q4 q = q4(cr.x, cr.y, cr.z, 1.0f + d);
+                const float inv = 1.0f / sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+                rot = q4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
+            }
+            const V3 rv = v3(rot.x, rot.y, rot.z);
+            V3 ang_jac; float angle;
+            const float rl = sqrtf(dot(rv, rv));
+            if (rl >= 1.0e-8f) { angle = 2.0f * rp_atan2_portable(rl, rot.w); ang_jac = rv * (1.0f / rl); } else { ang_jac = v3(1.0f, 0.0f, 0.0f); angle = 0.0f; }
+            if (angle == 0.0f) { // axis1.orthonormal_basis()[0] (utils/orthonormal_basis.rs:37-50)
+                const float sign = copysignf(1.0f, axis1.z), a = -1.0f / (sign + axis1.z), b = axis1.x * axis1.y * a;
+                ang_jac = v3(1.0f + sign * axis1.x * axis1.x * a, sign * b, -sign * axis1.x);
+            }
+            const float4 lm = w.j_lim[(size_t)fa * w.n_joints + j]; // (min, max): a COUPLED angular axis keeps its raw limits there (no per-axis row ever reads the recentred form)
+            const bool min_enabled = angle <= lm.x, max_enabled = lm.y <= angle;
+            JointRow &c = rows[len];
+            c.impulse = 0.0f; c.bmin = min_enabled ? -inf : 0.0f; c.bmax = max_enabled ? inf : 0.0f;
+            c.lin_jac = v3(0, 0, 0); c.ang_jac1 = ang_jac; c.ang_jac2 = ang_jac;
+            const float rhs_bias = rp_clamp((rp_max(angle - lm.y, 0.0f) - rp_max(lm.x - angle, 0.0f)) * erp, -maxcv, maxcv);
+            c.ii1 = sym_mul(ii1, ang_jac); c.ii2 = sym_mul(ii2, ang_jac);
+            c.inv_lhs = 0.0f; c.cfm_coeff = w.prm.joint_cfm_coeff; c.cfm_gain = 0.0f;
+            c.rhs = 0.0f + rhs_bias; c.rhs_wo_bias = 0.0f;
+            dof[len] = 6 + fa;
+            len++;
+        }
+        if ((coupled & 7) && (limited_all & (1 << (__ffs(coupled & 7) - 1)))) {
+            // limit_linear_coupled (joint_constraint_helper.rs:210-283): the distance along the combined error of the coupled linear
+            // axes against the MAX limit of the first coupled axis (RopeJoint; the reference: "FIXME: handle min limit too")
+            const int fa = __ffs(coupled & 7) - 1;
+            V3 lj = v3(0, 0, 0), aj1 = lj, aj2 = lj;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                if (!(coupled & (1 << i))) continue;
+                const float coeff = dot(col[i], lin_err);
+                lj = lj + col[i] * coeff;
+                aj1 = aj1 + (c1x * col[i].x + c1y * col[i].y + c1z * col[i].z) * coeff;
+                aj2 = aj2 + (c2x * col[i].x + c2y * col[i].y + c2z * col[i].z) * coeff;
+            }
+            const float dist = sqrtf(dot(lj, lj)), inv_dist = rp_inv(dist);
+            lj = lj * inv_dist; aj1 = aj1 * inv_dist; aj2 = aj2 * inv_dist;
+            const float lmax = w.j_lim[(size_t)fa * w.n_joints + j].y;
+            const float rhs_wo_bias = rp_min(dist - lmax, 0.0f) * rp_inv(w.prm.dt_sub);
+            const float rhs_bias = rp_clamp(rp_max(dist - lmax, 0.0f) * erp, -maxcv, maxcv);
+            JointRow &c = rows[len];
+            c.impulse = 0.0f; c.bmin = 0.0f; c.bmax = inf;
+            c.lin_jac = lj; c.ang_jac1 = aj1; c.ang_jac2 = aj2;
+            c.ii1 = sym_mul(ii1, aj1); c.ii2 = sym_mul(ii2, aj2);
+            c.inv_lhs = 0.0f; c.cfm_coeff = w.prm.joint_cfm_coeff; c.cfm_gain = 0.0f;
+            c.rhs = rhs_wo_bias + rhs_bias; c.rhs_wo_bias = rhs_wo_bias;
+            dof[len] = 6 + fa;
             len++;
         }
     }

@@ -53,7 +53,7 @@ JOINT_DTYPE = np.dtype([
     ("body1", "<i4"), ("body2", "<i4"), ("local_anchor1", "<f4", 3), ("local_anchor2", "<f4", 3),
     ("local_basis1", "<f4", 4), ("local_basis2", "<f4", 4), ("locked_axes", "<u4"),
     ("contacts_enabled", "<i4"), ("limit_axes", "<u4"), ("limits", "<f4", (6, 2)),
-    ("motor_axes", "<u4"), ("motors", MOTOR_DTYPE, 6),
+    ("motor_axes", "<u4"), ("motors", MOTOR_DTYPE, 6), ("coupled_axes", "<u4"),
 ], align=False)
 
 
@@ -215,7 +215,7 @@ class Scene:
         return len(self.colliders) - 1
 
     def add_joint(self, body1, body2, anchor1, anchor2, locked_axes=LOCK_LIN, contacts_enabled=1,
-                  basis1=(0, 0, 0, 1), basis2=(0, 0, 0, 1), limits=None, motors=None) -> int:
+                  basis1=(0, 0, 0, 1), basis2=(0, 0, 0, 1), limits=None, motors=None, coupled_axes=0) -> int:
         """``limits`` = {axis: (min, max)} with axis 0..2 = translation along the frame's X/Y/Z (metres), 3..5 = rotation about
         them (radians): GenericJoint::set_limits.  ``motors`` = {axis: motor_desc(...) or its keyword dict}:
         GenericJoint::set_motor / set_motor_velocity / set_motor_position / set_motor_max_force / set_motor_model."""
@@ -225,6 +225,7 @@ class Scene:
         j["local_basis1"] = basis1
         j["local_basis2"] = basis2
         j["locked_axes"], j["contacts_enabled"] = locked_axes, contacts_enabled
+        j["coupled_axes"] = coupled_axes   # GenericJoint::coupled_axes (RopeJoint / SpringJoint: the three linear axes)
         for axis, (lo, hi) in (limits or {}).items():
             j["limit_axes"] |= np.uint32(1 << axis)
             j["limits"][axis] = (lo, hi)
@@ -235,6 +236,16 @@ class Scene:
             j["motors"][axis] = motor_desc(**m) if isinstance(m, dict) else m
         self.joints.append(j)
         return len(self.joints) - 1
+
+    def add_rope_joint(self, body1, body2, anchor1, anchor2, max_dist: float, contacts_enabled=1) -> int:
+        """RopeJoint::new(max_dist) (rope_joint.rs:31-38, set_max_distance :124-127): the three linear axes coupled, limited to [0, max_dist]"""
+        return self.add_joint(body1, body2, anchor1, anchor2, locked_axes=0, contacts_enabled=contacts_enabled, limits={0: (0.0, max_dist)}, coupled_axes=LOCK_LIN)
+
+    def add_spring_joint(self, body1, body2, anchor1, anchor2, rest_length: float, stiffness: float, damping: float, contacts_enabled=1) -> int:
+        """SpringJoint::new(rest_length, stiffness, damping) (spring_joint.rs:31-40): the three linear axes coupled, a force-based position
+        motor on LinX towards the rest length"""
+        return self.add_joint(body1, body2, anchor1, anchor2, locked_axes=0, contacts_enabled=contacts_enabled, coupled_axes=LOCK_LIN,
+                              motors={0: dict(target_pos=rest_length, stiffness=stiffness, damping=damping, model=MOTOR_FORCE_BASED)})
 
     # Packed arrays ---------------------------------------------------------------------
     def body_array(self) -> np.ndarray:

@@ -270,6 +270,19 @@ def test_fuzz_in_a_batch_of_sub_worlds_bit_exact(seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", [70, 71, 72, 73, 74, 2006, 2010])
+def test_fuzz_coupled_joints_bit_exact(seed):
+    """ropes, springs and coupled angular axes (GenericJoint::coupled_axes) under the driver's actions — motor changes on coupled axes,
+    removals, sleeping, both friction models, joint warm start"""
+    _run(seed, params=seed >= 2000, coupled=True)
+
+
+@pytest.mark.parametrize("seed", [70, 2006])
+def test_fuzz_coupled_joints_on_the_oracle_twin(seed):
+    _run(seed, params=seed >= 2000, coupled=True, world=OracleTwin)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", [20, 21, 22, 23, 2005])
 def test_fuzz_sensors_bit_exact(seed):
     """the same scenes and actions with sensor colliders: a trigger volume in the middle of the pile, sensor obstacles, sensor
@@ -285,8 +298,34 @@ def test_fuzz_halfspace_ground_bit_exact(seed):
     _run(seed, steps=200, params=seed >= 2000, halfspace=True)
 
 
-def _run(seed, steps=240, walls=False, params=False, world=None, extras=False, sensors=False, halfspace=False, batch=False, **kw):
+def _couple_some_joints(sc, rng):
+    """GenericJoint::coupled_axes on about two thirds of the scene's joints (their own random stream: the other variants keep theirs):
+    ropes and springs (the three linear axes coupled, whatever the angular axes do) and pairs of coupled angular axes with a cone limit"""
+    for j in sc.joints:
+        r = rng.random()
+        locked = int(j["locked_axes"])
+        if r < 0.25:        # RopeJoint on top of the joint's angular locks
+            j["locked_axes"] = locked & 0x38; j["coupled_axes"] = 7
+            j["limit_axes"] = (int(j["limit_axes"]) & 0x38) | 1; j["limits"][0] = (0.0, float(rng.uniform(0.3, 1.2)))
+            j["motor_axes"] = int(j["motor_axes"]) & 0x38
+        elif r < 0.5:       # SpringJoint, sometimes with a travel limit on top
+            j["locked_axes"] = locked & 0x38; j["coupled_axes"] = 7
+            j["limit_axes"] = int(j["limit_axes"]) & 0x38
+            if rng.random() < 0.4:
+                j["limit_axes"] = int(j["limit_axes"]) | 1; j["limits"][0] = (0.0, float(rng.uniform(0.6, 1.5)))
+            j["motor_axes"] = (int(j["motor_axes"]) & 0x38) | 1
+            j["motors"][0] = S.motor_desc(target_pos=float(rng.uniform(0.2, 0.8)), stiffness=float(rng.uniform(50.0, 400.0)), damping=float(rng.uniform(1.0, 10.0)), model=int(rng.integers(0, 2)))
+        elif r < 0.67 and (locked & 0x38) == 0:   # two coupled angular axes: a cone limit on the third axis' swing (+ a no-op motor on one of them)
+            pair = [(3, 4), (3, 5), (4, 5)][int(rng.integers(0, 3))]
+            j["coupled_axes"] = (1 << pair[0]) | (1 << pair[1])
+            j["limit_axes"] = (int(j["limit_axes"]) & 7) | (1 << pair[0]); j["limits"][pair[0]] = (0.0, float(rng.uniform(0.2, 0.9)))
+            j["motor_axes"] = (int(j["motor_axes"]) & 7) | ((1 << pair[1]) if rng.random() < 0.5 else 0)
+
+
+def _run(seed, steps=240, walls=False, params=False, world=None, extras=False, sensors=False, halfspace=False, batch=False, coupled=False, **kw):
     sc, rng = _scene(seed, **kw)
+    if coupled:
+        _couple_some_joints(sc, np.random.default_rng(seed + 777))
     if halfspace:
         c0 = sc.colliders[0]                                       # the ground slab (top face at y = 0) becomes the plane y = 0
         c0["shape"] = S.SHAPE_HALFSPACE; c0["half_extents"] = (0.0, 1.0, 0.0); c0["translation"] = (0.0, 0.5, 0.0)

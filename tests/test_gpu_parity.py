@@ -1252,3 +1252,24 @@ def test_full_size_properties_many_pyramids():
         b = np.concatenate([parents[sel[:, 0]], parents[sel[:, 1]]])
         b = b[b > 0]  # body 0 is the fixed ground
         assert len(np.unique(b)) == len(b)
+
+
+# ---- GenericJoint::coupled_axes: rope, spring, two coupled angular axes (oracle side: tests/test_coupled_joints_oracle.py) ----
+def test_rope_spring_and_coupled_angular_limits_bit_exact():
+    from test_coupled_joints_oracle import rope_scene, spring_scene, cone_scene
+    for sc, cps in ((rope_scene(2.0), [1, 2, 30, 200, 600]), (spring_scene(), [1, 2, 50, 400, 1200]), (cone_scene()[0], [1, 2, 20, 100, 300])):
+        g, o = _compare(sc, cps)
+        gj = g.joint_impulses() if hasattr(g, "joint_impulses") else None
+    # a mixed world: a chain of ropes and springs between stacked boxes, next to ordinary joints (row counts 1 .. 6 in one joint set)
+    sc = S.joint_chain(4, with_boxes=True)
+    a = sc.add_body(body_type=S.BODY_FIXED, translation=(6.0, 6.0, 0.0))
+    prev = a
+    for k in range(5):
+        b = sc.add_body(translation=(6.0 + 0.4 * (k + 1), 6.0 - 0.5 * (k + 1), 0.1 * k))
+        sc.add_collider(b, half_extents=(0.2, 0.2, 0.2))
+        if k % 2 == 0:
+            sc.add_rope_joint(prev, b, (0.0, -0.2, 0.0), (0.0, 0.2, 0.0), 0.6)
+        else:
+            sc.add_spring_joint(prev, b, (0.0, -0.2, 0.0), (0.0, 0.2, 0.0), 0.4, 300.0, 3.0)
+        prev = b
+    _compare(sc, [1, 5, 60, 240, 480])

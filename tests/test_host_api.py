@@ -26,7 +26,7 @@ def test_descriptor_layouts_match_header():
     assert S.PARAMS_DTYPE.itemsize == 14 * 4 + 8 * 4
     assert S.BODY_DTYPE.itemsize == 4 + 12 + 16 + 12 + 12 + 4 * 4 + 5 * 4 + 4 + 4  # ... + additional_solver_iterations + ccd_enabled
     assert S.COLLIDER_DTYPE.itemsize == 4 + 12 + 12 + 16 + 12 + 8 + 8 + 8 + 4 + 4  # ... + sensor + border_radius
-    assert S.JOINT_DTYPE.itemsize == 8 + 24 + 32 + 8 + 4 + 48 + 4 + 6 * 24
+    assert S.JOINT_DTYPE.itemsize == 8 + 24 + 32 + 8 + 4 + 48 + 4 + 6 * 24 + 4  # ... + coupled_axes
     assert C.sizeof(_ffi.Counters) == 9 * 4 + 21 * 4  # ... + num_tiles, tile_sweeps, bp_large_list, lean_steps, fused_steps
     p = S.default_params()
     q = np.zeros((), S.PARAMS_DTYPE)
