@@ -268,19 +268,37 @@ class Scene:
 def batch(scenes, name: str | None = None) -> Scene:
     """Several small scenes as the SUB-WORLDS of one scene (rp_world_begin_subworld): bodies, colliders and joints concatenated (indices
     shifted), `subworlds` = where each one begins.  Colliders of different sub-worlds never pair, so the scenes may overlap in space;
-    they must agree on gravity and integration parameters (one world steps them).  Convex polyhedra / composite shapes: not batched."""
+    they must agree on gravity and integration parameters (one world steps them)."""
     scenes = list(scenes)
     first = scenes[0]
     out = Scene(name=name or f"batch_{len(scenes)}x_{first.name}", gravity=tuple(first.gravity), params=first.params.copy())
     for sc in scenes:
         if tuple(sc.gravity) != tuple(first.gravity) or sc.params.tobytes() != first.params.tobytes():
             raise ValueError("batch: the sub-worlds of a batch share gravity and integration parameters")
-        if sc.polyhedra or sc.composites or sc.subworlds:
-            raise ValueError("batch: plain scenes only")
-        nb = len(out.bodies)
+        if sc.subworlds:
+            raise ValueError("batch: a batch of batches is not supported")
+        nb, npoly, ncomp = len(out.bodies), len(out.polyhedra), len(out.composites)
         out.subworlds.append((nb, len(out.colliders), len(out.joints)))
         out.bodies += [b.copy() for b in sc.bodies]
-        out.colliders += [c.copy() for c in sc.colliders]
+        # registered shapes (convex polyhedra, compounds / meshes / height fields) are world-wide tables: the ids a collider — or a
+        # compound's part — names move behind the ones already registered
+        out.polyhedra += list(sc.polyhedra)
+        for comp in sc.composites:
+            if comp[0] == "compound":
+                parts = comp[1].copy()
+                for part in parts:
+                    if int(part["shape"]) in (SHAPE_CONVEX_POLYHEDRON, SHAPE_ROUND_CONVEX_POLYHEDRON):
+                        part["half_extents"][0] += npoly
+                out.composites.append(("compound", parts))
+            else:
+                out.composites.append(comp)
+        for c in sc.colliders:
+            cc = c.copy()
+            if int(cc["shape"]) in (SHAPE_CONVEX_POLYHEDRON, SHAPE_ROUND_CONVEX_POLYHEDRON):
+                cc["half_extents"][0] += npoly
+            elif int(cc["shape"]) in (SHAPE_COMPOUND, SHAPE_TRIMESH):
+                cc["half_extents"][0] += ncomp
+            out.colliders.append(cc)
         out.collider_parents += [(p + nb if p >= 0 else p) for p in sc.collider_parents]
         for j in sc.joints:
             jj = j.copy(); jj["body1"], jj["body2"] = int(j["body1"]) + nb, int(j["body2"]) + nb

@@ -113,3 +113,18 @@ def test_step_many_advances_separate_worlds_together():
             o.step(25)
         for g, o, sc in zip(gs, os_, scenes):
             _same(g, o, f"{sc.name} via rp_step_many +{25 * (k + 1)}")
+
+
+def test_batch_with_polyhedra_and_a_mesh_world_bit_exact():
+    """registered shapes travel with their sub-world (scenes.batch moves the ids): hull clutter twice and a box on a triangle mesh"""
+    from test_composite_oracle import _box_on_mesh
+    mesh_world, _ = _box_on_mesh()
+    parts = [S.polyhedra_clutter(6, 2), mesh_world, S.polyhedra_clutter(6, 2), S.capsules(4)]
+    for p in parts:
+        p.gravity, p.params = parts[0].gravity, parts[0].params.copy()
+    b = S.batch(parts)
+    g, o = PhysicsWorld.from_scene(b), OracleWorld(b)
+    done = 0
+    for cp in (1, 3, 40, 160):
+        g.step(cp - done); o.step(cp - done); done = cp
+        _same(g, o, f"batch with registered shapes @ {cp}")

@@ -51,3 +51,25 @@ def test_batch_refuses_mismatched_parameters():
     except ValueError:
         return
     raise AssertionError("a batch of scenes with different dt must be refused")
+
+
+def test_a_batch_carries_registered_shapes_with_their_ids_moved():
+    """convex polyhedra and composite shapes are world-wide tables: in a batch the ids a collider names move behind the ones the
+    earlier sub-worlds registered — every sub-world still evolves like its scene alone (4 copies + a mesh world: no colour crosses the
+    >= 32-chunk line)"""
+    from test_composite_oracle import _box_on_mesh
+    mesh_world, _ = _box_on_mesh()
+    clutter = S.polyhedra_clutter(6, 2)
+    parts = [clutter, mesh_world, S.polyhedra_clutter(6, 2)]
+    for p in parts:
+        p.gravity, p.params = parts[0].gravity, parts[0].params.copy()
+    b = S.batch(parts)
+    assert len(b.polyhedra) == 2 * len(clutter.polyhedra) and len(b.composites) == 1
+    w = OracleWorld(b); w.step(120)
+    bp, bv = w.read()
+    off = 0
+    for p in parts:
+        o = OracleWorld(p); o.step(120)
+        pos, vel = o.read()
+        np.testing.assert_array_equal(bp[off:off + len(pos)], pos, err_msg=p.name); np.testing.assert_array_equal(bv[off:off + len(pos)], vel)
+        off += len(pos)
