@@ -171,6 +171,7 @@ struct rp_world {
     int *old_pinned = nullptr;
     std::vector<int> old_active_joint_ids;
     unsigned *d_speed = nullptr; // rp_world_max_linear_speed's reduction cell
+    void *d_puts = nullptr;      // PutBatch's record buffer (rp_api_device.inc)
     float guard_horizon = 0.0f;  // rp_world_set_shard_guard_horizon
     // shard guard (rp_world_set_shard_guard): host copy, re-uploaded whenever the device world is rebuilt
     std::vector<float4> guard_min, guard_max; std::vector<int> guard_start, guard_items; float guard_origin[3] = {0, 0, 0}, guard_cell = 0.0f; int guard_dims[3] = {0, 0, 0};
@@ -472,6 +473,7 @@ extern "C" int32_t rp_world_destroy(rp_world *w) {
     for (void *&b : w->cv_dev) if (b) { hipFree(b); b = nullptr; }
     for (void *&b : w->cm_dev) if (b) { hipFree(b); b = nullptr; }
     if (w->d_speed) { hipFree(w->d_speed); w->d_speed = nullptr; }
+    if (w->d_puts) { hipFree(w->d_puts); w->d_puts = nullptr; }
     for (auto &e : w->ev) if (e) hipEventDestroy(e);
     if (w->stream) hipStreamDestroy(w->stream);
     delete w;
