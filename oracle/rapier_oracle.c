@@ -610,6 +610,7 @@ static void ro_mp_add(ro_mp *acc, const ro_mp *o) {
 static int collider_enabled(const Collider *c) { return !(c->memberships == 0 && c->filter == 0); }
 /* sum of the attached colliders' mass properties at `density_override` (< 0: each collider's own density) */
 static void comp_mass_props(const Collider *c, float density, ro_mp *out); /* ro_composite.h */
+static float comp_ccd_thickness(const Collider *c);                           /* ro_composite.h */
 static void sum_collider_mass_props(const ro_world *w, int body, float density_override, ro_mp *acc) {
     memset(acc, 0, sizeof(*acc)); acc->frame[3] = 1.0f;
     /* attachment order (rb.colliders(): ascending `ord`) — not index order: a collider may sit in a reused arena slot */
@@ -679,6 +680,8 @@ static void recompute_mass_properties(ro_world *w, Body *b) {
     for (int i = 0; i < w->ncolliders; ++i) {
         const Collider *c = &w->colliders[i];
         if (c->parent != body || !collider_enabled(c) || c->shape == RO_SHAPE_HALFSPACE) continue;
+        if (c->shape == RO_SHAPE_TRIMESH) continue; /* a mesh is never swept and stays out of ccd_thickness (sweeps.rs:86-97: shape_never_ccd_swept) */
+        if (c->shape == RO_SHAPE_COMPOUND) { b->ccd_thickness = ro_minf(b->ccd_thickness, comp_ccd_thickness(c)); continue; } /* Compound::ccd_thickness: the thinnest part */
         float th = c->shape == RO_SHAPE_BALL ? c->radius : c->shape == RO_SHAPE_CAPSULE ? c->radius : ro_minf(c->he.x, ro_minf(c->he.y, c->he.z));
         if (c->border > 0.0f) th = th + c->border; /* RoundShape::ccd_thickness = inner + border */
         b->ccd_thickness = ro_minf(b->ccd_thickness, th);
@@ -3050,22 +3053,54 @@ static void ccd_sweep_tier(ro_world *w, int bullets) {
         for (int f = 0; f < w->ncolliders; ++f) {
             const Collider *co1 = &w->colliders[f];
             if (co1->parent != bi || !collider_enabled(co1) || co1->sensor) continue;
-            if (co_is_composite(co1)) continue; /* (composite colliders take no part in the continuous-collision pass of this restatement: DESIGN.md section 8) */
-            CcdShape s2 = ccd_shape_of(co1);
-            const float rot_radius = ccd_rot_radius(&s2, co1->pos_wrt_parent, rb1->local_com);
+            if (co1->shape == RO_SHAPE_TRIMESH) continue; /* a mesh is never the fast shape (sweeps.rs:86-97) */
+            /* a compound is swept child by child (FastShapeKind::Compound, sweeps.rs:337-345): each part with the part's own pose on the body */
+            const int nparts1 = co_is_composite(co1) ? co_num_subs(co1) : 1;
+            for (int part = 0; part < nparts1; ++part) {
+            Collider prim1 = *co1; pose pwp1 = co1->pos_wrt_parent;
+            if (co_is_composite(co1)) { pose pp; int hp; co_sub(co1, part, &prim1, &pp, &hp); pwp1 = pose_mul(co1->pos_wrt_parent, pp); }
+            CcdShape s2 = ccd_shape_of(&prim1);
+            const float rot_radius = ccd_rot_radius(&s2, pwp1, rb1->local_com);
             for (int t = 0; t < w->ncolliders; ++t) {
                 const Collider *co2 = &w->colliders[t];
-                if (t == f || co2->parent == bi || !collider_enabled(co2) || co2->sensor || co_is_composite(co2) || co2->sub != co1->sub) continue;
+                if (t == f || co2->parent == bi || !collider_enabled(co2) || co2->sensor || co2->sub != co1->sub) continue;
                 const Body *rb2 = co2->parent >= 0 ? &w->bodies[co2->parent] : NULL;
                 /* tier_allows (sweeps.rs:35-41): a non-bullet only meets fixed targets, a bullet everything but bullets */
                 if (bullets) { if (rb2 && ccd_is_bullet(rb2)) continue; } else if (rb2 && rb2->body_type != RO_BODY_FIXED) continue;
                 if (!((co1->memberships & co2->filter) != 0 && (co2->memberships & co1->filter) != 0)) continue; /* collision_groups.test */
                 /* target_collider_pose (:97-102): stationary at its end-of-step pose */
                 pose tp = (rb2 && rb2->body_type != RO_BODY_FIXED) ? pose_mul(rb2->next_position, co2->pos_wrt_parent) : co2->pos;
+                if (co_is_composite(co2)) {
+                    /* a composite target (sweeps.rs:255-262, :384-400: sweep_time_of_impact_composite): every sub-shape whose box meets the
+                     * swept volume's box — the centre-of-mass segment inflated by max_extent + 2 slop, taken into the composite's frame —
+                     * is a target of its own; the earliest fraction wins (round 5: composites used to be skipped) */
+                    const float reach = rb1->max_extent + 2.0f * slop;
+                    v3 qmn = V3(fminf(sw.c0.x, sw.c1.x) - reach, fminf(sw.c0.y, sw.c1.y) - reach, fminf(sw.c0.z, sw.c1.z) - reach);
+                    v3 qmx = V3(fmaxf(sw.c0.x, sw.c1.x) + reach, fmaxf(sw.c0.y, sw.c1.y) + reach, fmaxf(sw.c0.z, sw.c1.z) + reach);
+                    v3 qc = vmul(vadd(qmn, qmx), 0.5f), qh = vmul(vsub(qmx, qmn), 0.5f);
+                    v3 lc = pose_itp(tp, qc);
+                    float m[3][3]; quat_to_mat(tp.r, m);
+                    v3 lh = V3(fabsf(m[0][0]) * qh.x + fabsf(m[1][0]) * qh.y + fabsf(m[2][0]) * qh.z,
+                               fabsf(m[0][1]) * qh.x + fabsf(m[1][1]) * qh.y + fabsf(m[2][1]) * qh.z,
+                               fabsf(m[0][2]) * qh.x + fabsf(m[1][2]) * qh.y + fabsf(m[2][2]) * qh.z);
+                    const int nsub = co_num_subs(co2);
+                    for (int i = 0; i < nsub; ++i) {
+                        const Aabb a = co_sub_aabb(co2, i);
+                        if (a.mins.x > lc.x + lh.x || a.maxs.x < lc.x - lh.x || a.mins.y > lc.y + lh.y || a.maxs.y < lc.y - lh.y || a.mins.z > lc.z + lh.z || a.maxs.z < lc.z - lh.z) continue;
+                        Collider prim; pose pp; int hp; co_sub(co2, i, &prim, &pp, &hp);
+                        pose tpose = hp ? pose_mul(tp, pp) : tp;
+                        if (hp && !ccd_may_reach(sw.c0, sw.c1, rb1->max_extent, tpose.t, shape_bounding_radius(&prim), 2.0f * slop)) continue;
+                        CcdShape s1 = ccd_shape_of(&prim);
+                        float hit = ccd_cast_pair(&s1, tpose, &s2, pwp1, &sw, rot_radius, fraction, slop);
+                        if (hit > 0.0f && hit < fraction) fraction = hit;
+                    }
+                    continue;
+                }
                 if (co2->shape != RO_SHAPE_HALFSPACE && !ccd_may_reach(sw.c0, sw.c1, rb1->max_extent, tp.t, shape_bounding_radius(co2), 2.0f * slop)) continue;
                 CcdShape s1 = ccd_shape_of(co2);
-                float hit = ccd_cast_pair(&s1, tp, &s2, co1->pos_wrt_parent, &sw, rot_radius, fraction, slop);
+                float hit = ccd_cast_pair(&s1, tp, &s2, pwp1, &sw, rot_radius, fraction, slop);
                 if (hit > 0.0f && hit < fraction) fraction = hit;
+            }
             }
         }
         if (fraction < 1.0f) { rb1->next_position = ccd_sweep_transform_at(&sw, fraction); w->ccd_clamp_count++; }

@@ -156,6 +156,17 @@ static void co_sub(const Collider *c, int i, Collider *prim, pose *pos, int *has
         for (int k = 0; k < 3; ++k) prim->tri[k] = C->verts[C->tris[3 * i + k]];
     } else *prim = *c;
 }
+/* Compound::ccd_thickness (parry): the thinnest part's (Shape::ccd_thickness: ball / capsule radius, smallest half extent; + a round part's border) */
+static float comp_ccd_thickness(const Collider *c) {
+    float th = FLT_MAX;
+    for (int k = 0; k < c->comp->n; ++k) {
+        const Collider *q = &c->comp->parts[k].prim;
+        float tq = q->shape == RO_SHAPE_BALL ? q->radius : q->shape == RO_SHAPE_CAPSULE ? q->radius : ro_minf(q->he.x, ro_minf(q->he.y, q->he.z));
+        if (q->border > 0.0f) tq = tq + q->border;
+        th = ro_minf(th, tq);
+    }
+    return th;
+}
 /* MassProperties of a compound = the sum of its parts' (MassProperties::from_compound); a triangle mesh on a fixed body weighs nothing */
 static void comp_mass_props(const Collider *c, float density, ro_mp *out) {
     memset(out, 0, sizeof(*out)); out->frame[3] = 1.0f;

@@ -254,15 +254,20 @@ template <bool CONVEX> __global__ void __launch_bounds__(256) k_ccd(DevWorld w, 
               if (o < 0 || o >= CCD_MAX_FAST_COLLIDERS) continue;
               uint2 g = w.c_groups[c];
               if ((g.x == 0 && g.y == 0) || (__float_as_int(w.c_events[c].x) & RP_EVENTS_SENSOR_BIT)) continue;
-              if (shape_is_composite(w.c_shape[c])) continue; // (composite colliders take no part in the continuous-collision pass: DESIGN.md section 8)
+              if (w.c_shape[c] == RP_SHAPE_TRIMESH) continue; // a mesh is never the fast shape (sweeps.rs:86-97: shape_never_ccd_swept)
               fast[o] = c;
           }
           __syncthreads();
           for (int f = 0; f < CCD_MAX_FAST_COLLIDERS; ++f) {
             const int c1 = fast[f];
             if (c1 < 0) continue; // (uniform over the workgroup)
-            const CcdShape s2 = ccd_shape_of<CONVEX>(w, c1);
+            // a compound is swept child by child (FastShapeKind::Compound, sweeps.rs:337-345): each part with its own pose on the body
+            const bool comp1 = shape_is_composite(w.c_shape[c1]);
+            const int nparts1 = comp1 ? co_num_subs(w, c1) : 1; // (uniform over the workgroup)
+            for (int part = 0; part < nparts1; ++part) {
+            CcdShape s2 = ccd_shape_of<CONVEX>(w, c1);
             Pose pwp; pwp.t = v3(w.c_lpos[c1]); pwp.r = q4(w.c_lrot[c1]);
+            if (comp1) { const SubShape a = co_sub(w, c1, part); s2 = sm_shape_of(w, a.sh, a.he, a.bd); pwp = pose_mul(pwp, a.pos); }
             const float rot_radius = ccd_rot_radius(s2, pwp, lcom);
             const uint2 g1 = w.c_groups[c1];
             // one candidate target: the filters of sweep_fast_body, the reach pre-filter, the cast
@@ -270,7 +275,6 @@ template <bool CONVEX> __global__ void __launch_bounds__(256) k_ccd(DevWorld w, 
                 const int p2 = w.c_parent[c2];
                 if (c2 == c1 || p2 == bi) return;
                 if (w.n_sub > 1 && w.c_sub[c2] != w.c_sub[c1]) return; // another sub-world (rp_world_begin_subworld)
-                if (shape_is_composite(w.c_shape[c2])) return; // (likewise as targets)
                 const uint2 g2 = w.c_groups[c2];
                 if ((g2.x == 0 && g2.y == 0) || (__float_as_int(w.c_events[c2].x) & RP_EVENTS_SENSOR_BIT)) return;
                 const int fl2 = p2 >= 0 ? w.b_flags[p2] : RP_BODY_FIXED;
@@ -280,6 +284,33 @@ template <bool CONVEX> __global__ void __launch_bounds__(256) k_ccd(DevWorld w, 
                 if (!((g1.x & g2.y) != 0 && (g2.x & g1.y) != 0)) return; // collision_groups.test
                 Pose tp = collider_world_pose(w, c2); // target_collider_pose (:97-102): bodies already stand at their end-of-step pose
                 const int sh2 = w.c_shape[c2];
+                if (shape_is_composite(sh2)) {
+                    // a composite target (sweeps.rs:255-262, :384-400: sweep_time_of_impact_composite): every sub-shape whose box meets the
+                    // swept volume's box, taken into the composite's frame, is a target of its own; the earliest fraction wins (an atomicMin:
+                    // no order dependence).  One lane walks the sub-shapes of ITS target (round 5: composites used to be skipped)
+                    if constexpr (CONVEX) {
+                        const V3 qc = (qmn + qmx) * 0.5f, qh = (qmx - qmn) * 0.5f;
+                        const V3 lc = pose_itp(tp, qc);
+                        float m[3][3]; quat_to_mat(tp.r, m);
+                        const V3 lh = v3(fabsf(m[0][0]) * qh.x + fabsf(m[1][0]) * qh.y + fabsf(m[2][0]) * qh.z,
+                                         fabsf(m[0][1]) * qh.x + fabsf(m[1][1]) * qh.y + fabsf(m[2][1]) * qh.z,
+                                         fabsf(m[0][2]) * qh.x + fabsf(m[1][2]) * qh.y + fabsf(m[2][2]) * qh.z);
+                        const int first = co_first_sub(w, c2), nsub = co_num_subs(w, c2);
+                        for (int i = 0; i < nsub; ++i) {
+                            const float4 amn = w.cm_min[first + i], amx = w.cm_max[first + i];
+                            if (amn.x > lc.x + lh.x || amx.x < lc.x - lh.x || amn.y > lc.y + lh.y || amx.y < lc.y - lh.y || amn.z > lc.z + lh.z || amx.z < lc.z - lh.z) continue;
+                            const SubShape b = co_sub(w, c2, i);
+                            const Pose tpose = b.has_pose ? pose_mul(tp, b.pos) : tp;
+                            if (b.has_pose && !ccd_may_reach(sw.c0, sw.c1, max_extent, tpose.t, ccd_bounding_radius_core(w, sm_core_shape(b.sh), b.he) + b.bd, 2.0f * slop)) continue;
+                            CcdShape s1 = sm_shape_of(w, b.sh, b.he, b.bd);
+                            s1.tri[0] = b.tri[0]; s1.tri[1] = b.tri[1]; s1.tri[2] = b.tri[2];
+                            const float cur = __uint_as_float(__hip_atomic_load(&best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                            const float hit = ccd_cast_pair<CONVEX>(s1, tpose, s2, pwp, sw, rot_radius, cur, slop);
+                            if (hit > 0.0f && hit < cur) atomicMin(&best, __float_as_uint(hit));
+                        }
+                    }
+                    return;
+                }
                 if (sh2 != RP_SHAPE_HALFSPACE && !ccd_may_reach(sw.c0, sw.c1, max_extent, tp.t, ccd_bounding_radius(w, c2), 2.0f * slop)) return;
                 const CcdShape s1 = ccd_shape_of<CONVEX>(w, c2);
                 const float cur = __uint_as_float(__hip_atomic_load(&best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
@@ -310,6 +341,7 @@ template <bool CONVEX> __global__ void __launch_bounds__(256) k_ccd(DevWorld w, 
             } else {
                 for (int c2 = threadIdx.x; c2 < w.n_colliders; c2 += blockDim.x) try_target(c2);
             }
+            } // (the parts of a compound fast collider)
           }
         }
         __syncthreads();

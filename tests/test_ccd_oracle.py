@@ -193,3 +193,81 @@ def test_slow_bodies_never_enter_the_pass():
     w = OracleWorld(S.pyramid10())
     w.step(120)
     assert w.ccd_counts() == (0, 0)
+
+
+# ---- composite targets (sweeps.rs:255-262, :384-400: sweep_time_of_impact_composite) — round 5 --------------------------------------
+def mesh_wall_scene(kind="trimesh", ccd=False, vx=200.0):
+    """a thin wall in the Y-Z plane at x = 0 as ONE composite collider: a two-layer triangle mesh (a 0.1 m slab's two faces), a compound
+    of four thin cuboid panels, or a height field stood on its side; a fast cube flies at it"""
+    sc = harness()
+    wall = sc.add_body(body_type=S.BODY_FIXED)
+    if kind == "trimesh":
+        n, size = 4, 10.0
+        ys = np.linspace(-size / 2, size / 2, n + 1)
+        v, t = [], []
+        for x in (-0.05, 0.05):
+            base = len(v)
+            v += [[x, y, z] for z in ys for y in ys]
+            for r in range(n):
+                for c in range(n):
+                    a = base + r * (n + 1) + c
+                    t += [[a, a + n + 1, a + n + 2], [a, a + n + 2, a + 1]]
+        mid = sc.add_trimesh(np.array(v, np.float32), np.array(t, np.uint32))
+        sc.add_collider(wall, shape=S.SHAPE_TRIMESH, half_extents=(mid, 0, 0))
+    elif kind == "compound":
+        parts = [S.collider_desc(half_extents=(0.05, 2.5, 2.5), translation=(0.0, 2.5 * sy, 2.5 * sz)) for sy in (-1, 1) for sz in (-1, 1)]
+        cid = sc.add_compound(parts)
+        sc.add_collider(wall, shape=S.SHAPE_COMPOUND, half_extents=(cid, 0, 0))
+    else:   # a flat height field rotated so that its up axis points along -x
+        hid = sc.add_heightfield(np.zeros((5, 5), np.float32), (10.0, 1.0, 10.0))
+        sc.add_collider(wall, shape=S.SHAPE_TRIMESH, half_extents=(hid, 0, 0), rotation=(0.0, 0.0, 0.70710678, 0.70710678))
+    return sc, fast_dynamic(sc, ccd, vx=vx)
+
+
+@pytest.mark.parametrize("kind", ["trimesh", "compound", "heightfield"])
+def test_fast_body_is_stopped_by_a_composite_wall(kind):
+    """3.3 m per step against a wall 0.1 m thick (or a one-triangle-thick sheet): without the continuous pass the cube is on the far side
+    after one step; with it — composite targets are swept sub-shape by sub-shape — it is stopped on the near side, like the cuboid wall of
+    ccd_default_vs_fixed.rs"""
+    sc, body = mesh_wall_scene(kind)
+    w = OracleWorld(sc); w.step(120)
+    pos, _ = w.read()
+    assert np.isfinite(pos).all() and pos[body, 0] < 0.0, (kind, pos[body])
+    active, clamps = w.ccd_counts()
+    assert active >= 1 and clamps >= 1
+    sc2, body2 = mesh_wall_scene(kind)
+    sc2.params["max_ccd_substeps"] = 0                       # the pass switched off: it tunnels
+    w2 = OracleWorld(sc2); w2.step(120)
+    assert w2.read()[0][body2, 0] > 1.0
+
+
+def test_a_bullet_is_stopped_by_a_dynamic_compound():
+    """tier 1 (ccd_enabled): targets on dynamic bodies too — a compound dumbbell floating in zero gravity"""
+    sc = harness()
+    d = sc.add_body(translation=(0.0, 0.0, 0.0))
+    cid = sc.add_compound([S.collider_desc(half_extents=(0.05, 1.0, 1.0)), S.collider_desc(shape=S.SHAPE_BALL, half_extents=(0.3, 0.0, 0.0), translation=(0.0, 1.2, 0.0))])
+    sc.add_collider(d, shape=S.SHAPE_COMPOUND, half_extents=(cid, 0, 0), density=50.0)
+    b = fast_dynamic(sc, True)
+    w = OracleWorld(sc); w.step(3)
+    pos, vel = w.read()
+    assert pos[b, 0] < 0.2 and w.ccd_counts()[1] >= 1        # it did not pass through the plate
+    assert vel[d, 0] > 0.0                                    # ... and pushed it
+
+
+def fast_compound_scene(ccd=False):
+    """a dumbbell (a plate + a ball, one compound collider) thrown at the thin fixed wall at 200 m/s: a compound is swept child by
+    child (sweeps.rs:337-345); its ccd_thickness is its thinnest part's"""
+    sc = harness()
+    thin_fixed_wall(sc)
+    b = sc.add_body(translation=(-3.0, 0.0, 0.0), linvel=(200.0, 0.0, 0.0), angvel=(0.0, 0.5, 0.0), ccd_enabled=1 if ccd else 0)
+    cid = sc.add_compound([S.collider_desc(half_extents=(0.12, 0.3, 0.3)), S.collider_desc(shape=S.SHAPE_BALL, half_extents=(0.12, 0.0, 0.0), translation=(0.0, 0.45, 0.0))])
+    sc.add_collider(b, shape=S.SHAPE_COMPOUND, half_extents=(cid, 0, 0))
+    return sc, b
+
+
+def test_a_fast_compound_is_swept_part_by_part():
+    sc, b = fast_compound_scene()
+    w = OracleWorld(sc); w.step(60)
+    pos, _ = w.read()
+    assert np.isfinite(pos).all() and pos[b, 0] < 0.0, pos[b]
+    assert w.ccd_counts()[1] >= 1

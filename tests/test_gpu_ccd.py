@@ -79,3 +79,41 @@ def test_scenes_with_falling_bodies_bit_exact():
     for sc, steps in ((S.tumble(40, seed=11), 90), (S.capsules(6), 100), (S.halfspace_scene(), 120), (S.compound_bodies(6), 100)):
         g, o = _twin(sc, steps, every=10)
         assert g.counters()["ccd_clamp_count"] > 0
+
+
+# ---- composite targets (round 5): a mesh / compound / height-field wall, a dynamic compound hit by a bullet ------------------------------
+@pytest.mark.parametrize("kind", ["trimesh", "compound", "heightfield"])
+def test_composite_wall_stops_the_fast_body_bit_exact(kind):
+    sc, body = T.mesh_wall_scene(kind)
+    g, o = _twin(sc, 120, every=4)
+    assert g.read_bodies()[0][body, 0] < 0.0 and g.counters()["ccd_clamp_count"] >= 1
+
+
+def test_bullets_rain_on_a_mesh_ground_and_a_dynamic_compound_bit_exact():
+    """every shape kind shot at a triangle-mesh floor at 120 m/s under gravity (tier 0 against the fixed mesh), and a bullet against a
+    floating compound plate (tier 1)"""
+    from test_composite_oracle import _grid_mesh
+    sc = T.harness(gravity=(0.0, -9.81, 0.0))
+    g0 = sc.add_body(body_type=S.BODY_FIXED)
+    v, t = _grid_mesh(8, 24.0)
+    sc.add_collider(g0, shape=S.SHAPE_TRIMESH, half_extents=(sc.add_trimesh(v, t), 0, 0))
+    kinds = [(S.SHAPE_BALL, (0.15, 0.0, 0.0)), (S.SHAPE_CUBOID, (0.12, 0.1, 0.15)), (S.SHAPE_CAPSULE, (0.2, 0.08, 1.0)), (S.SHAPE_CYLINDER, (0.15, 0.1, 0.0)), (S.SHAPE_CONE, (0.15, 0.12, 0.0))]
+    for k, (sh, he) in enumerate(kinds):
+        b = sc.add_body(translation=(-4.0 + 2.0 * k, 3.0, -2.0 + 0.9 * k), linvel=(0.3, -120.0, 0.1), angvel=(2.0, 0.5, -1.0), ccd_enabled=k % 2)
+        sc.add_collider(b, shape=sh, half_extents=he)
+    gp, o = _twin(sc, 90, every=3)
+    assert (gp.read_bodies()[0][1:, 1] > -0.5).all()        # nobody fell through the mesh (it is 24 m wide: nobody reaches its edge either)
+    sc2 = T.harness()
+    d = sc2.add_body(translation=(0.0, 0.0, 0.0))
+    cid = sc2.add_compound([S.collider_desc(half_extents=(0.05, 1.0, 1.0)), S.collider_desc(shape=S.SHAPE_BALL, half_extents=(0.3, 0.0, 0.0), translation=(0.0, 1.2, 0.0))])
+    sc2.add_collider(d, shape=S.SHAPE_COMPOUND, half_extents=(cid, 0, 0), density=50.0)
+    T.fast_dynamic(sc2, True)
+    _twin(sc2, 30)
+
+
+def test_fast_compound_body_swept_part_by_part_bit_exact():
+    sc, b = T.fast_compound_scene()
+    g, o = _twin(sc, 60, every=2)
+    assert g.read_bodies()[0][b, 0] < 0.0 and g.counters()["ccd_clamp_count"] >= 1
+    sc2, b2 = T.fast_compound_scene(ccd=True)            # ... as a bullet too
+    _twin(sc2, 30)
