@@ -661,14 +661,29 @@ __global__ void __launch_bounds__(ISL_THREADS) k_island_solve_wide(DevWorld w, i
 struct IslGenAcc {
     static constexpr bool PRELOAD = false; // a fused kernel: the preloaded rows would live in scratch (measured: 0.57 -> 1.67 ms)
     const DevWorld &w; int pos; const IslLds &L;
-    RP_DEV IslGenAcc(const DevWorld &w_, int pos_, const IslLds &L_) : w(w_), pos(pos_), L(L_) {}
-    RP_DEV float4 ld(int plane) const { return w.C[(size_t)plane * w.cons_cap + pos]; }
-    RP_DEV void st(int plane, float4 v) const { w.C[(size_t)plane * w.cons_cap + pos] = v; }
-    RP_DEV int id1() const { return w.k_b1[pos]; }
-    RP_DEV int id2() const { return w.k_b2[pos]; }
-    RP_DEV int n() const { return w.k_n[pos]; }
-    RP_DEV int cids() const { return w.k_cid[pos]; }
-    RP_DEV void set_meta(int a, int b, int cnt, int cid) const { w.k_b1[pos] = a; w.k_b2[pos] = b; w.k_n[pos] = cnt; w.k_cid[pos] = cid; }
+    // The thread owns ONE manifold from generate to write-back: what every stage asks for FIRST — the two solver bodies, the point
+    // count, the direction / inverse-mass / tangent header planes — stays in registers once generate has stored it (round 5: those
+    // seven L2 round trips sat at the head of every stage's dependent chain: C3 under FrictionModel::Coulomb 581 -> 495 us per step).
+    // The planes still go to memory (write-back reads them through the same accessor; nothing else reads an island's rows).
+    // (Also measured in round 5: the 56 per-point planes of a sweep in LDS instead of L2 — 147 KB of dynamic LDS — 516 us: a stage is
+    // bound by the ~2,500 dependent instructions of its four normal + four tangent solves on one wavefront per SIMD, not by its loads.)
+    mutable int m_id1, m_id2, m_n, m_cid; mutable float4 m_h0, m_h1, m_h2, m_h6;
+    RP_DEV IslGenAcc(const DevWorld &w_, int pos_, const IslLds &L_) : w(w_), pos(pos_), L(L_), m_id1(-1), m_id2(-1), m_n(0), m_cid(0) {
+        m_h0 = make_float4(0, 0, 0, 0); m_h1 = m_h0; m_h2 = m_h0; m_h6 = m_h0;
+    }
+    RP_DEV float4 ld(int plane) const {
+        if (plane <= CP_H6) { if (plane == CP_H0) return m_h0; if (plane == CP_H1) return m_h1; if (plane == CP_H2) return m_h2; if (plane == CP_H6) return m_h6; }
+        return w.C[(size_t)plane * w.cons_cap + pos];
+    }
+    RP_DEV void st(int plane, float4 v) const {
+        w.C[(size_t)plane * w.cons_cap + pos] = v;
+        if (plane <= CP_H6) { if (plane == CP_H0) m_h0 = v; else if (plane == CP_H1) m_h1 = v; else if (plane == CP_H2) m_h2 = v; else if (plane == CP_H6) m_h6 = v; }
+    }
+    RP_DEV int id1() const { return m_id1; }
+    RP_DEV int id2() const { return m_id2; }
+    RP_DEV int n() const { return m_n; }
+    RP_DEV int cids() const { return m_cid; }
+    RP_DEV void set_meta(int a, int b, int cnt, int cid) const { w.k_b1[pos] = a; w.k_b2[pos] = b; w.k_n[pos] = cnt; w.k_cid[pos] = cid; m_id1 = a; m_id2 = b; m_n = cnt; m_cid = cid; }
     RP_DEV Vel vel(int id) const { return isl_vel(L, id); }
     RP_DEV void set_vel(int id, const Vel &v) const { isl_set_vel(L, id, v); }
     RP_DEV Xf xf(int id) const { return isl_xf(L, id); }
