@@ -3092,6 +3092,10 @@ static void ccd_sweep_tier(ro_world *w, int bullets) {
                         if (hp && !ccd_may_reach(sw.c0, sw.c1, rb1->max_extent, tpose.t, shape_bounding_radius(&prim), 2.0f * slop)) continue;
                         CcdShape s1 = ccd_shape_of(&prim);
                         float hit = ccd_cast_pair(&s1, tpose, &s2, pwp1, &sw, rot_radius, fraction, slop);
+                        if (hit == -2.0f) { /* starts on this sub-shape: the core ball's turn (ro_ccd.h: ccd_core_of) */
+                            CcdShape core = ccd_core_of(&s2);
+                            hit = ccd_cast_pair(&s1, tpose, &core, pwp1, &sw, ccd_rot_radius(&core, pwp1, rb1->local_com), fraction, slop);
+                        }
                         if (hit > 0.0f && hit < fraction) fraction = hit;
                     }
                     continue;

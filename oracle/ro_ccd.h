@@ -156,8 +156,9 @@ static inline float ccd_separation(const CcdShape *s1, const CcdShape *s2, pose 
 }
 
 /* One pair: the fraction in (0, max_fraction) at which the fast collider (shape s2 at sweep(t) * pos_wrt_parent) comes within
- * target + tolerance of the stationary target (shape s1 at target_pose), or -1.  An initial overlap / touch (fraction 0) is
- * "no impact" for a solid pair in 3D (sweeps.rs:268-275, :409-411). */
+ * target + tolerance of the stationary target (shape s1 at target_pose), -1 for a miss, -2 for an initial overlap / touch (fraction 0),
+ * which is "no impact" for a solid pair in 3D (sweeps.rs:268-275, :409-411) — except that a sub-shape of a composite target is then
+ * tried again with the fast piece's core ball (ccd_core_of below). */
 static inline float ccd_rot_radius(const CcdShape *s2, pose pos_wrt_parent, v3 local_com) { /* see the header: what rotation about the centre of mass can move */
     v3 c = vsub(pos_wrt_parent.t, local_com);
     if (s2->shape == RO_SHAPE_BALL) return vlen(c);
@@ -182,7 +183,7 @@ static inline float ccd_cast_pair(const CcdShape *s1, pose target_pose, const Cc
         pose pos12 = pose_inv_mul(target_pose, cp);
         v3 n1;
         float sep = ccd_separation(s1, s2, pos12, &n1);
-        if (sep < target + tol) return iter == 0 ? -1.0f : t;
+        if (sep < target + tol) return iter == 0 ? -2.0f : t; /* -2: touching or overlapping at the start */
         v3 nw = qrot(target_pose.r, n1);
         float approach = -vdot(D, nw);
         if (approach < 0.0f) approach = 0.0f;
@@ -192,6 +193,22 @@ static inline float ccd_cast_pair(const CcdShape *s1, pose target_pose, const Cc
         if (!(t < max_fraction)) return -1.0f;
     }
     return -1.0f;
+}
+
+/* The core of a fast piece (sweeps.rs:166-173 FastSubShape::local_centroid / min_extent, handed to the composite sweep at
+ * :386-391): a ball of CORE_FRACTION x the piece's smallest extent about its centre.  A piece that starts a step touching or
+ * overlapping one triangle / cell / part of a composite target (a thin slab lying across a mesh that has no inside) is swept
+ * again as this ball, so that its centre can never cross the sheet within a step (sweeps.rs:421-440 shows the retry for the 2D
+ * proxies).  CORE_FRACTION is a parry constant (sweep_toi.rs, not under /root/reference): 0.25, the value of the Box2D v3
+ * continuous pass this design follows — unpinned like the rest of the time-of-impact query.  The smallest extent is the shape's
+ * ccd_thickness; the centre is the origin of the shape's own frame. */
+#define RO_CCD_CORE_FRACTION 0.25f
+static inline CcdShape ccd_core_of(const CcdShape *s2) {
+    float th = s2->shape == RO_SHAPE_BALL ? s2->radius : s2->shape == RO_SHAPE_CAPSULE ? s2->radius : ro_minf(s2->he.x, ro_minf(s2->he.y, s2->he.z));
+    if (s2->border > 0.0f) th = th + s2->border;
+    CcdShape c = *s2;
+    c.shape = RO_SHAPE_BALL; c.radius = RO_CCD_CORE_FRACTION * th; c.border = 0.0f; c.poly = NULL; c.he = V3(c.radius, 0.0f, 0.0f);
+    return c;
 }
 
 /* conservative pre-filter: the whole swept volume of the fast BODY lies within max_extent of its centre-of-mass segment */

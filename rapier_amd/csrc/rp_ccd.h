@@ -160,7 +160,7 @@ template <bool CONVEX> __device__ float ccd_cast_pair(const CcdShape &s1, Pose t
         Pose pos12 = pose_inv_mul(target_pose, cp);
         V3 n1;
         float sep = ccd_separation<CONVEX>(s1, s2, pos12, n1);
-        if (sep < target + tol) return iter == 0 ? -1.0f : t;
+        if (sep < target + tol) return iter == 0 ? -2.0f : t; // -2: touching or overlapping at the start
         V3 nw = qrot(target_pose.r, n1);
         float approach = -dot(D, nw);
         if (approach < 0.0f) approach = 0.0f;
@@ -170,6 +170,20 @@ template <bool CONVEX> __device__ float ccd_cast_pair(const CcdShape &s1, Pose t
         if (!(t < max_fraction)) return -1.0f;
     }
     return -1.0f;
+}
+// The core of a fast piece (sweeps.rs:166-173 FastSubShape::local_centroid / min_extent, handed to the composite sweep at :386-391):
+// a ball of CORE_FRACTION x the piece's smallest extent (its ccd_thickness) about the origin of its own frame.  A piece that starts
+// a step touching or overlapping one sub-shape of a composite target — a thin slab lying across a mesh that has no inside — is
+// swept again as this ball, so that its centre never crosses the sheet within a step (the reference's issue 524).  CORE_FRACTION
+// is a parry constant that cannot be read here: 0.25, Box2D v3's (oracle/ro_ccd.h has the note).
+#define RP_CCD_CORE_FRACTION 0.25f
+RP_DEV CcdShape ccd_core_of(const CcdShape &s2) {
+    float th = s2.shape == RP_SHAPE_BALL ? s2.radius : s2.shape == RP_SHAPE_CAPSULE ? s2.radius : rp_min(s2.he.x, rp_min(s2.he.y, s2.he.z));
+    if (s2.border > 0.0f) th = th + s2.border;
+    CcdShape c = s2;
+    c.shape = RP_SHAPE_BALL; c.radius = RP_CCD_CORE_FRACTION * th; c.border = 0.0f; c.he = v3(c.radius, 0.0f, 0.0f);
+    c.pts = nullptr; c.fn = nullptr; c.fl = nullptr; c.loop = nullptr; c.npts = 0; c.nfaces = 0;
+    return c;
 }
 RP_DEV bool ccd_may_reach(V3 c0, V3 c1, float max_extent, V3 target_centre, float target_radius, float margin) {
     V3 p = segment_project_point(c0, c1, target_centre);
@@ -305,7 +319,11 @@ template <bool CONVEX> __global__ void __launch_bounds__(256) k_ccd(DevWorld w, 
                             CcdShape s1 = sm_shape_of(w, b.sh, b.he, b.bd);
                             s1.tri[0] = b.tri[0]; s1.tri[1] = b.tri[1]; s1.tri[2] = b.tri[2];
                             const float cur = __uint_as_float(__hip_atomic_load(&best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                            const float hit = ccd_cast_pair<CONVEX>(s1, tpose, s2, pwp, sw, rot_radius, cur, slop);
+                            float hit = ccd_cast_pair<CONVEX>(s1, tpose, s2, pwp, sw, rot_radius, cur, slop);
+                            if (hit == -2.0f) { // starts on this sub-shape: the core ball's turn
+                                const CcdShape core = ccd_core_of(s2);
+                                hit = ccd_cast_pair<CONVEX>(s1, tpose, core, pwp, sw, ccd_rot_radius(core, pwp, lcom), cur, slop);
+                            }
                             if (hit > 0.0f && hit < cur) atomicMin(&best, __float_as_uint(hit));
                         }
                     }

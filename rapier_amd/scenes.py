@@ -1202,3 +1202,91 @@ def washer(grid: int = 20) -> Scene:
             y = y + f(4.0) * a
         x = x + f(4.0) * a
     return s
+
+
+def compound3(num: int = 8, numy: int = 15) -> Scene:
+    """examples3d/compound3.rs:8-80: U-shaped bodies raining on a slab — the lower half of the layers as THREE colliders on one body,
+    the upper half as ONE compound collider of the same three cuboids.  Full size: 8 x 15 x 8 = 960 bodies."""
+    f = np.float32
+    s = Scene(name=f"compound3_{num}x{numy}")
+    g = s.add_body(body_type=BODY_FIXED, translation=(0.0, -0.1, 0.0))
+    s.add_collider(g, half_extents=(50.0, 0.1, 50.0))
+    rad = f(0.2)
+    shift = rad * f(4.0) + rad
+    cx, cy = shift * f(num // 2), shift / f(2.0)
+    offset = -f(num) * (rad * f(2.0) + rad) * f(0.5)
+    arm = float(rad * f(10.0))
+    for j in range(numy):
+        for i in range(num):
+            for k in range(num):
+                x = f(i) * shift * f(5.0) - cx + offset
+                y = f(j) * (shift * f(5.0)) + cy + f(3.0)
+                z = f(k) * shift * f(2.0) - cx + offset
+                b = s.add_body(translation=(float(x), float(y), float(z)), can_sleep=1)
+                if j < numy // 2:
+                    s.add_collider(b, half_extents=(arm, float(rad), float(rad)))
+                    s.add_collider(b, half_extents=(float(rad), arm, float(rad)), translation=(arm, arm, 0.0))
+                    s.add_collider(b, half_extents=(float(rad), arm, float(rad)), translation=(-arm, arm, 0.0))
+                else:
+                    cid = s.add_compound([collider_desc(half_extents=(arm, float(rad), float(rad))),
+                                          collider_desc(half_extents=(float(rad), arm, float(rad)), translation=(arm, arm, 0.0)),
+                                          collider_desc(half_extents=(float(rad), arm, float(rad)), translation=(-arm, arm, 0.0))])
+                    s.add_collider(b, shape=SHAPE_COMPOUND, half_extents=(cid, 0, 0))
+        offset -= f(0.05) * rad * (f(num) - f(1.0))
+    return s
+
+
+def heightfield3(num: int = 8, layers: int = 20, nsubdivs: int = 20, mesh: bool = False) -> Scene:
+    """examples3d/heightfield3.rs:8-100 (mesh=False) and trimesh3.rs:8-100 (mesh=True: the same terrain through
+    HeightField::to_trimesh, here the height field's own two triangles per cell handed to SharedShape::trimesh): cuboids, balls,
+    round cylinders, cones, capsules and three-cuboid compounds, layer by layer, on a rolling 100 x 100 terrain with raised borders.
+    Full size: 8 x 20 x 8 = 1,280 bodies."""
+    f = np.float32
+    s = Scene(name=f"{'trimesh3' if mesh else 'heightfield3'}_{num}x{layers}")
+    i, j = np.meshgrid(np.arange(nsubdivs + 1), np.arange(nsubdivs + 1), indexing="ij")
+    x = i.astype(np.float32) * f(100.0) / f(nsubdivs)
+    z = j.astype(np.float32) * f(100.0) / f(nsubdivs)
+    h = (np.sin(x, dtype=np.float32) + np.cos(z, dtype=np.float32)).astype(np.float32)
+    h[0, :] = h[nsubdivs, :] = 10.0
+    h[:, 0] = h[:, nsubdivs] = 10.0
+    g = s.add_body(body_type=BODY_FIXED)
+    if mesh:
+        # HeightField::to_trimesh: vertex (r, c) at ((c / n - 0.5) sx, h[r, c] sy, (r / n - 0.5) sz), two triangles per cell
+        n = nsubdivs
+        verts = np.zeros(((n + 1) * (n + 1), 3), np.float32)
+        for r in range(n + 1):
+            for c in range(n + 1):
+                verts[r * (n + 1) + c] = ((f(c) / f(n) - f(0.5)) * f(100.0), h[r, c], (f(r) / f(n) - f(0.5)) * f(100.0))
+        tris = []
+        for r in range(n):
+            for c in range(n):
+                p00, p10, p01, p11 = r * (n + 1) + c, (r + 1) * (n + 1) + c, r * (n + 1) + c + 1, (r + 1) * (n + 1) + c + 1
+                tris += [(p00, p10, p11), (p00, p11, p01)]
+        s.add_collider(g, shape=SHAPE_TRIMESH, half_extents=(s.add_trimesh(verts, np.array(tris, np.uint32)), 0, 0))
+    else:
+        s.add_collider(g, shape=SHAPE_TRIMESH, half_extents=(s.add_heightfield(h, (100.0, 1.0, 100.0)), 0, 0))
+    rad = f(1.0)
+    shift = rad * f(2.0) + rad
+    cx, cy = shift * f(num // 2), shift / f(2.0)
+    r = float(rad)
+    for jj in range(layers):
+        for ii in range(num):
+            for kk in range(num):
+                b = s.add_body(translation=(float(f(ii) * shift - cx), float(f(jj) * shift + cy + f(3.0)), float(f(kk) * shift - cx)), can_sleep=1)
+                kind = jj % 6
+                if kind == 0:
+                    s.add_collider(b, half_extents=(r, r, r))
+                elif kind == 1:
+                    s.add_collider(b, shape=SHAPE_BALL, half_extents=(r, 0.0, 0.0))
+                elif kind == 2:
+                    s.add_collider(b, shape=SHAPE_ROUND_CYLINDER, half_extents=(r, r, 0.0), border_radius=r / 10.0)
+                elif kind == 3:
+                    s.add_collider(b, shape=SHAPE_CONE, half_extents=(r, r, 0.0))
+                elif kind == 4:
+                    s.add_collider(b, shape=SHAPE_CAPSULE, half_extents=(r, r, 1.0))
+                else:
+                    cid = s.add_compound([collider_desc(half_extents=(r, r / 2.0, r / 2.0)),
+                                          collider_desc(half_extents=(r / 2.0, r, r / 2.0), translation=(r, 0.0, 0.0)),
+                                          collider_desc(half_extents=(r / 2.0, r, r / 2.0), translation=(-r, 0.0, 0.0))])
+                    s.add_collider(b, shape=SHAPE_COMPOUND, half_extents=(cid, 0, 0))
+    return s

@@ -153,3 +153,17 @@ def test_invalid_composites_are_refused():
     assert o.add_composite(("compound", np.array([S.collider_desc(shape=S.SHAPE_HALFSPACE, half_extents=(0, 1, 0))], S.COLLIDER_DTYPE))) < 0
     assert o.add_composite(("trimesh", np.zeros((3, 3), np.float32), np.array([[0, 1, 7]], np.uint32))) < 0
     assert o.add_composite(("heightfield", np.zeros((1, 4), np.float32), np.ones(3, np.float32))) < 0
+
+
+def test_the_references_composite_demos_run_sanely():
+    """examples3d/compound3.rs, heightfield3.rs, trimesh3.rs restated (rapier_amd/scenes.py) at a reduced count: everything stays
+    finite and on top of its ground; the terrain as a height field and as the mesh HeightField::to_trimesh gives are the same world"""
+    s = S.compound3(4, 6)
+    w = OracleWorld(s); w.step(240)
+    pos, vel = w.read()
+    assert np.isfinite(pos).all() and np.isfinite(vel).all() and pos[1:, 1].min() > 0.15 and np.abs(vel[:, :3]).max() < 40.0
+    a, b = OracleWorld(S.heightfield3(4, 12)), OracleWorld(S.heightfield3(4, 12, mesh=True))
+    a.step(240); b.step(240)
+    pa, pb = a.read()[0], b.read()[0]
+    np.testing.assert_array_equal(pa, pb)
+    assert np.isfinite(pa).all() and pa[1:, 1].min() > -2.5 and np.abs(pa[1:, [0, 2]]).max() < 50.0

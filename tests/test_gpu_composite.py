@@ -136,9 +136,24 @@ def test_invalid_composites_are_refused_by_the_library():
         w.add_compound([S.collider_desc(shape=S.SHAPE_HALFSPACE, half_extents=(0, 1, 0))])
     with pytest.raises(RapierHipError):
         w.add_trimesh(np.zeros((3, 3), np.float32), np.array([[0, 1, 7]], np.uint32))
+    # issue_717_trimesh_result.rs:14-25: invalid mesh input is an error, not a crash; the unit triangle is accepted
+    unit = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    for verts, tris in ((np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint32)), (unit, np.zeros((0, 3), np.uint32))):
+        with pytest.raises(RapierHipError):
+            w.add_trimesh(verts, tris)
+    assert w.add_trimesh(unit, np.array([[0, 1, 2]], np.uint32)) >= 0
     tid = w.add_trimesh(np.array([[0, 0, 0], [1, 0, 0], [0, 0, 1]], np.float32), np.array([[0, 2, 1]], np.uint32))
     b = w.insert_body(S.body_desc(translation=(0, 1, 0)))
     with pytest.raises(RapierHipError):
         w.insert_collider(S.collider_desc(shape=S.SHAPE_TRIMESH, half_extents=(tid, 0, 0)), b)   # a mesh on a dynamic body
     with pytest.raises(RapierHipError):
         w.insert_collider(S.collider_desc(shape=S.SHAPE_COMPOUND, half_extents=(tid, 0, 0)), b)  # the id names a mesh, not a compound
+
+
+@pytest.mark.parametrize("scene", [lambda: S.compound3(4, 6), lambda: S.heightfield3(4, 12), lambda: S.heightfield3(3, 6, mesh=True)],
+                         ids=["compound3", "heightfield3", "trimesh3"])
+def test_the_references_composite_demos_bit_exact(scene):
+    """examples3d/compound3.rs, heightfield3.rs, trimesh3.rs (rapier_amd/scenes.py: compound3, heightfield3) at a reduced count: U-shaped
+    multi-collider bodies and compounds raining on a slab; six kinds of shapes (cuboid, ball, round cylinder, cone, capsule, compound)
+    on a rolling terrain — impacts fast enough for the automatic sweeps, clusters, sleeping allowed"""
+    _lockstep(scene(), [1, 30, 90, 150, 240])

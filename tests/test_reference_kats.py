@@ -1348,3 +1348,161 @@ def test_joint_contact_solve_order_heavy_cubes_rest_on_sprung_balls():
     assert np.isfinite(pos).all()
     for i, (ball, cube) in enumerate(pairs):
         assert pos[cube, 1] > pos[ball, 1], f"cube {i} tunnelled through its sprung ball (cube y = {pos[cube, 1]:.3f}, ball y = {pos[ball, 1]:.3f})"
+
+
+def test_joint_contact_solve_order_with_the_references_spring_joints():
+    """crates/rapier3d/tests/joint_contact_solve_order.rs:29-82 as written: SpringJointBuilder::new(0.0, stiffness, damping) with
+    local_anchor1 three metres under each ball (GenericJoint::coupled_axes, round 5)."""
+    sc = world()
+    g = sc.add_body(body_type=S.BODY_FIXED)
+    num, radius = 30, 0.5
+    mass = 4.0 / 3.0 * np.pi * radius ** 3
+    stiffness = 1.0e3
+    critical = 2.0 * np.sqrt(stiffness * mass)
+    pairs = []
+    for i in range(num + 1):
+        x = -6.0 + 1.5 * i
+        ball = sc.add_body(translation=(x, 4.5, 0.0))
+        sc.add_collider(ball, shape=S.SHAPE_BALL, half_extents=(radius, 0.0, 0.0))
+        sc.add_spring_joint(g, ball, (x, 1.5, 0.0), (0.0, 0.0, 0.0), 0.0, stiffness, float((i / (num / 2.0)) * critical))
+        cube = sc.add_body(translation=(x, 9.5, 0.0), can_sleep=1)
+        sc.add_collider(cube, half_extents=(radius, radius, radius), density=100.0)
+        pairs.append((ball, cube))
+    w = OracleWorld(sc)
+    w.step(300)
+    pos, _ = w.read()
+    assert np.isfinite(pos).all()
+    for i, (ball, cube) in enumerate(pairs):
+        assert pos[cube, 1] > pos[ball, 1], f"cube {i} tunnelled through its spring-jointed ball (cube y = {pos[cube, 1]:.3f}, ball y = {pos[ball, 1]:.3f})"
+
+
+# ---- the reference's tests on meshes and height fields (composite shapes, round 5) ---------------------------------------
+def two_triangle_ground(sc, parent=-1, half=20.0, winding=((0, 2, 1), (0, 3, 2))):
+    """the flat two-triangle mesh of issues 372 and 524"""
+    v = np.array([[-half, 0, -half], [half, 0, -half], [half, 0, half], [-half, 0, half]], np.float32)
+    return sc.add_collider(parent, shape=S.SHAPE_TRIMESH, half_extents=(sc.add_trimesh(v, np.array(winding, np.uint32)), 0, 0))
+
+
+@pytest.mark.parametrize("tilt", [(0.1, 0.0, 0.0), (0.0, 0.0, 0.12), (0.15, 0.0, 0.1), (-0.12, 0.0, 0.08)], ids=["x", "z", "xz", "neg"])
+def test_thin_slab_dropped_tilted_settles_on_a_trimesh(tilt):
+    """issue_524_thin_slab_trimesh_tunnel.rs:61-128: a 2 x 0.06 x 2 slab dropped tilted from 5 m on a two-triangle mesh, default
+    parameters (no explicit CCD): the automatic fast-body-against-fixed sweep must keep it above the sheet (y > -0.1 throughout)
+    and it must lie still on it after 600 steps.  The `neg` tilt lands across the shared diagonal, is turned flat by its first
+    corner contact while its centre keeps falling, and passes only because a piece that starts a step touching a triangle is swept
+    again as its core ball (oracle/ro_ccd.h: ccd_core_of)."""
+    sc = world()
+    fixed = sc.add_body(body_type=S.BODY_FIXED)
+    two_triangle_ground(sc, fixed)
+    slab = sc.add_body(translation=(0.0, 5.0, 0.0), rotation=quat_from_scaled_axis(tilt), can_sleep=1)
+    sc.add_collider(slab, half_extents=(1.0, 0.03, 1.0))
+    w = OracleWorld(sc)
+    for i in range(600):
+        w.step(1)
+        y = float(w.read()[0][slab, 1])
+        assert y > -0.1, f"slab tunnelled through the mesh at step {i} (tilt {tilt}, y = {y})"
+    pos, vel = w.read()
+    assert 0.0 < pos[slab, 1] < 0.2, f"slab did not settle on the mesh (y = {pos[slab, 1]})"
+    assert np.linalg.norm(vel[slab, :3]) < 0.05
+
+
+@pytest.mark.parametrize("what", ["ball", "capsule"])
+def test_bodies_on_a_trimesh_fall_asleep(what):
+    """issue_372_trimesh_sleep.rs:81-111: a ball (linvel 0.03) / a lying capsule (linvel 0.012) dropped on a parentless two-triangle
+    mesh must fall asleep within 2000 steps"""
+    sc = world()
+    two_triangle_ground(sc)
+    if what == "ball":
+        b = sc.add_body(translation=(-5.0, 1.0, 5.0), linvel=(0.03, 0.0, 0.0), can_sleep=1)
+        sc.add_collider(b, shape=S.SHAPE_BALL, half_extents=(0.5, 0.0, 0.0))
+    else:
+        b = sc.add_body(translation=(-5.0, 1.0, 5.0), rotation=quat_from_scaled_axis((np.pi / 2, 0.0, 0.0)), linvel=(0.012, 0.0, 0.0), can_sleep=1)
+        sc.add_collider(b, shape=S.SHAPE_CAPSULE, half_extents=(0.4, 0.3, 1.0))
+    w = OracleWorld(sc)
+    for _ in range(2000):
+        w.step(1)
+        if w.sleeping()[b]:
+            break
+    else:
+        pytest.fail(f"{what} never fell asleep on the mesh (velocity {w.read()[1][b]})")
+
+
+def test_capsule_crosses_flush_heightfield_seam_without_sinking():
+    """issue_182_heightfield_seam.rs:55-119: two flat 16 x 16 height fields side by side; a frictionless upright capsule with locked
+    rotations settles at y = 0.6, is driven at 2 m/s across the seam at x = 8 and must neither sink (y > rest - 0.05 at every step)
+    nor stop (x > 12 after 480 steps)."""
+    sc = world()
+    for x in (0.0, 16.0):
+        hf = sc.add_heightfield(np.zeros((17, 17), np.float32), (16.0, 1.0, 16.0))
+        sc.add_collider(-1, shape=S.SHAPE_TRIMESH, half_extents=(hf, 0, 0), translation=(x, 0.0, 0.0))
+    ch = sc.add_body(translation=(0.0, 0.7, 0.0), locked_axes=8 | 16 | 32, can_sleep=1)
+    sc.add_collider(ch, shape=S.SHAPE_CAPSULE, half_extents=(0.3, 0.3, 1.0), friction=0.0)
+    w = OracleWorld(sc)
+    w.step(120)
+    rest_y = float(w.read()[0][ch, 1])
+    assert abs(rest_y - 0.6) < 0.1
+    for i in range(480):
+        vel = w.read()[1]
+        w.set_vel(ch, (2.0, float(vel[ch, 1]), 0.0), tuple(float(c) for c in vel[ch, 3:]))
+        w.step(1)
+        pos = w.read()[0]
+        assert pos[ch, 1] > rest_y - 0.05, f"capsule sank at the seam at step {i}: x = {pos[ch, 0]}, y = {pos[ch, 1]}"
+    assert pos[ch, 0] > 12.0 and abs(pos[ch, 1] - rest_y) < 0.05
+
+
+def test_heightfield_stress_stays_consistent():
+    """heightfield_solver_graph.rs:5-62: 2048 cubes and balls poured on a 50 x 50 rolling height field with raised borders, 200
+    steps; the reference asserts that the solver's graph bookkeeping survives (no panic) — here: finite, and nothing under the
+    terrain's lowest point."""
+    sc = world()
+    n = 50
+    i, j = np.meshgrid(np.arange(n + 1), np.arange(n + 1), indexing="ij")
+    x = i.astype(np.float32) * np.float32(50.0) / np.float32(n)
+    z = j.astype(np.float32) * np.float32(50.0) / np.float32(n)
+    h = ((np.cos(x) + np.sin(z)) * np.float32(1.5)).astype(np.float32)
+    h[0, :] = h[n, :] = 8.0
+    h[:, 0] = h[:, n] = 8.0
+    g = sc.add_body(body_type=S.BODY_FIXED)
+    sc.add_collider(g, shape=S.SHAPE_TRIMESH, half_extents=(sc.add_heightfield(h, (50.0, 1.0, 50.0)), 0, 0))
+    num, rad = 8, 0.5
+    shift = rad * 2.5
+    cx, cy = shift * (num // 2), shift / 2.0
+    for a in range(num):
+        for b in range(num * 4):
+            for c in range(num):
+                bd = sc.add_body(translation=(a * shift - cx, b * shift + cy + 3.0, c * shift - cx), can_sleep=1)
+                if (a + b + c) % 2 == 0:
+                    sc.add_collider(bd, half_extents=(rad, rad, rad))
+                else:
+                    sc.add_collider(bd, shape=S.SHAPE_BALL, half_extents=(rad, 0.0, 0.0))
+    w = OracleWorld(sc)
+    for _ in range(4):
+        w.step(50)
+        pos, vel = w.read()
+        assert np.isfinite(pos).all() and np.isfinite(vel).all()
+    assert pos[1:, 1].min() > -3.0
+
+
+def test_contact_force_event_is_populated_under_contact_clustering():
+    """contact_force_event_clustering.rs:44-127: a cube resting on a two-triangle mesh (several manifolds, one solver cluster) with
+    CONTACT_FORCE_EVENTS and threshold 0: the last event of 60 steps carries a positive total and max force, a unit direction, and
+    max <= total."""
+    sc = world()
+    fixed = sc.add_body(body_type=S.BODY_FIXED)
+    gc = two_triangle_ground(sc, fixed, half=2.0, winding=((0, 1, 2), (0, 2, 3)))
+    box = sc.add_body(translation=(0.0, 0.55, 0.0))
+    bc = sc.add_collider(box, half_extents=(0.5, 0.5, 0.5), active_events=S.ACTIVE_EVENTS_CONTACT_FORCE, contact_force_event_threshold=0.0)
+    w = OracleWorld(sc)
+    last = None
+    for _ in range(60):
+        w.step(1)
+        meta, vals = w.force_events()
+        for m, v in zip(meta, vals):
+            assert {int(m[0]), int(m[1])} == {gc, bc}
+            last = v
+    nclusters, per_cluster = w.pair_clusters(gc, bc)
+    assert nclusters >= 1 and 1 <= per_cluster[0] <= 4          # contact clustering applied to the pair
+    assert last is not None, "no contact force event was emitted"
+    total, total_mag, direction, max_mag = last[:3], last[3], last[4:7], last[7]
+    assert total_mag > 0.0 and max_mag > 0.0 and np.linalg.norm(total) > 0.0
+    assert abs(np.linalg.norm(direction) - 1.0) < 1.0e-4
+    assert max_mag <= total_mag * 1.001
