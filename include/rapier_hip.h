@@ -210,6 +210,8 @@ typedef struct rp_counters {
                                     * per-stage / tile path whose contact graph stands still; validated on the device, a step whose narrow phase
                                     * found new work is resumed by the next full graph (counted in replayed_steps) */
     int32_t fused_steps;           /* of fast_steps: those enqueued as the ONE-kernel fused step (k_island_solve validates the step itself) */
+    int32_t num_islands;           /* contact islands the last layout rebuild handed to the LDS-resident island kernel (a bundle of tiny islands counts once) */
+    int32_t num_global_bodies;     /* awake dynamic bodies it left to the global solver path (components too large for an island, bodies with joints, free bodies) */
 } rp_counters;
 
 #define RP_INVALID_HANDLE 0xffffffffffffffffull

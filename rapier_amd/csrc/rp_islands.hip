@@ -68,9 +68,9 @@ RP_DEV bool lay_warm(const DevWorld &w) {
 }
 RP_DEV void lay_isl_init(DevWorld &w, int gid, int gstride, bool warm) {
     const int i = gid;
-    if (i == 0) { w.flags[FL_N_ISLANDS] = 0; w.flags[FL_N_GLOB_BODIES] = 0; w.flags[FL_ISL_BODY_CURSOR] = 0; w.flags[FL_ISL_CONS_CURSOR] = 0; w.flags[FL_ISL_ICONS_CURSOR] = 0; w.lay_state[4] = 0; }
+    if (i == 0) { w.flags[FL_N_ISLANDS] = 0; w.flags[FL_N_GLOB_BODIES] = 0; w.flags[FL_ISL_BODY_CURSOR] = 0; w.flags[FL_ISL_CONS_CURSOR] = 0; w.flags[FL_ISL_ICONS_CURSOR] = 0; w.lay_state[4] = 0; w.lay_state[6] = 0; }
     for (size_t k = i, n = (size_t)128 * w.cb_words; k < n; k += (size_t)gstride) w.cb_bits[k] = 0u; // owner bitmaps of the colour stages
-    for (int b = gid; b < w.n_bodies; b += gstride) { if (!warm) w.b_label[b] = b; w.r_nb[b] = 0; w.r_nc[b] = 0; w.r_ni[b] = 0; w.r_island[b] = -1; w.b_island[b] = -1; w.b_local[b] = -1; }
+    for (int b = gid; b < w.n_bodies; b += gstride) { if (!warm) w.b_label[b] = b; w.r_nb[b] = 0; w.r_nc[b] = 0; w.r_ni[b] = 0; w.r_island[b] = -1; w.b_island[b] = -1; w.b_local[b] = -1; w.bun_nb[b] = 0; w.bun_nc[b] = 0; w.bun_ni[b] = 0; w.bun_id[b] = -1; }
 }
 // the edges of the island graph, compacted (one atomic per wavefront): active pairs whose two sides are awake non-fixed bodies
 RP_DEV void lay_isl_edges(DevWorld &w, int gid, int gstride) {
@@ -184,13 +184,34 @@ RP_DEV void lay_isl_count(DevWorld &w, int gid, int stride) {
 // When the previous rebuild counted more candidates than DevWorld::isl_many (one resident pass of k_island_solve: 240 on MI355X), components of at most DevWorld::isl_tiny_nc (8) manifolds stay on the global
 // path, whose colour stages / LDS tiles take them all at once (either path gives the same bits: a routing decision, not a result).
 // lay_state[3] = candidates of the last rebuild (written behind its last barrier), [4] = this rebuild's count.
+//
+// Round 5, BUNDLES: in a world whose bodies never sleep the tiny components do not go to the global path either — several of them
+// share ONE island of the kernel.  An island is solved colour stage by colour stage in the world's stage order and a constraint only
+// touches its own two bodies, so a union of components that share no body gives every one of them the bits it gets alone (the same
+// argument as for the routing).  A component of cnb bodies and cnc manifolds weighs max(cnb, ceil(2 cnc / 5)) (an island holds 64
+// bodies and 160 manifolds); a running sum of the weights (lay_state[6]) is cut every lay_bundle_span() units, a component belongs to
+// the bundle its first unit falls into, which therefore holds at most span - 1 + (isl_tiny_nc + 1) = 64 units.  The totals of a bundle
+// are only known once every component has been seen: lay_isl_bundles(), one grid barrier later, numbers the bundles as islands.
+// 256 sub-worlds of 18 bodies (rolling capsules: piles of a few bodies + singles): the tile sweeps, their preparation and the
+// dataflow ranks leave the step.  Worlds with sleeping keep the routing: the fused step's "may this island fall asleep" test
+// (fused_sleep_abort) speaks about ONE persistent island per kernel island.
+RP_DEV int lay_bundle_span(const DevWorld &w) { return RP_ISL_NB_MAX - w.isl_tiny_nc; }
+RP_DEV bool lay_bundling(const DevWorld &w) { return w.isl_bundle_tiny && !w.sleep_enabled && w.isl_tiny_nc >= 1 && w.isl_tiny_nc <= 32; }
 RP_DEV void lay_isl_number(DevWorld &w, int gid, int gstride) {
   const bool route_tiny = w.isl_route_tiny && w.lay_state[3] > w.isl_many;
+  const bool bundle = route_tiny && lay_bundling(w);
   for (int b = gid; b < w.n_bodies; b += gstride) {
     if (!is_dyn(w, b) || w.b_label[b] != b) continue;
     int cnb = w.r_nb[b], cnc = w.r_nc[b];
     const bool candidate = cnc > 0 && cnb <= RP_ISL_NB_MAX && cnc <= RP_ISL_NC_MAX;
     if (candidate) atomicAdd(&w.lay_state[4], 1);
+    if (candidate && bundle && cnc <= w.isl_tiny_nc && cnb <= w.isl_tiny_nc + 1) {
+        const int wc = (2 * cnc + 4) / 5, wgt = cnb > wc ? cnb : wc;
+        const int k = atomicAdd(&w.lay_state[6], wgt) / lay_bundle_span(w);
+        atomicAdd(&w.bun_nb[k], cnb); atomicAdd(&w.bun_nc[k], cnc); atomicAdd(&w.bun_ni[k], w.r_ni[b]);
+        w.r_island[b] = -2 - k; // (lay_isl_fill reads the island id through bun_id)
+        continue;
+    }
     if (candidate && !(route_tiny && cnc <= w.isl_tiny_nc)) {
         int id = atomicAdd(&w.flags[FL_N_ISLANDS], 1);
         w.isl_body_begin[id] = atomicAdd(&w.flags[FL_ISL_BODY_CURSOR], cnb);
@@ -202,6 +223,21 @@ RP_DEV void lay_isl_number(DevWorld &w, int gid, int gstride) {
     }
   }
 }
+// the bundles of tiny components become islands (their totals are complete: one barrier behind lay_isl_number)
+RP_DEV void lay_isl_bundles(DevWorld &w, int gid, int gstride) {
+    const int span = lay_bundle_span(w), nbun = (w.lay_state[6] + span - 1) / span;
+    for (int k = gid; k < nbun; k += gstride) {
+        const int cnb = w.bun_nb[k], cnc = w.bun_nc[k], cni = w.bun_ni[k];
+        if (cnc == 0) continue;
+        const int id = atomicAdd(&w.flags[FL_N_ISLANDS], 1);
+        w.isl_body_begin[id] = atomicAdd(&w.flags[FL_ISL_BODY_CURSOR], cnb);
+        w.isl_cons_begin[id] = atomicAdd(&w.flags[FL_ISL_CONS_CURSOR], cnc);
+        w.isl_nb[id] = cnb; w.isl_nc[id] = cnc; w.isl_fill_b[id] = 0; w.isl_fill_c[id] = 0; w.isl_sorted[id] = 0; w.isl_nstages[id] = 0;
+        w.isl_ni[id] = cni; w.isl_fill_i[id] = 0; w.isl_icons_begin[id] = atomicAdd(&w.flags[FL_ISL_ICONS_CURSOR], cni);
+        w.bun_id[k] = id;
+    }
+}
+RP_DEV int lay_island_of_root(const DevWorld &w, int root) { const int id = w.r_island[root]; return id <= -2 ? w.bun_id[-2 - id] : id; }
 // fill the island lists; count the global-path manifolds per colour
 RP_DEV void lay_isl_fill(DevWorld &w, int gid, int stride, int *hist, int &n_glob) {
     for (int c = threadIdx.x; c < RP_NUM_COLORS; c += blockDim.x) hist[c] = 0;
@@ -211,7 +247,7 @@ RP_DEV void lay_isl_fill(DevWorld &w, int gid, int stride, int *hist, int &n_glo
     if (top > w.pool_cap) top = w.pool_cap;
     for (int b = gid; b < w.n_bodies; b += stride) {
         if (!is_dyn(w, b)) continue;
-        int id = w.r_island[w.b_label[b]];
+        int id = lay_island_of_root(w, w.b_label[b]);
         if (id >= 0) {
             int k = atomicAdd(&w.isl_fill_b[id], 1);
             w.isl_bodies[w.isl_body_begin[id] + k] = b;
@@ -222,7 +258,7 @@ RP_DEV void lay_isl_fill(DevWorld &w, int gid, int stride, int *hist, int &n_glo
         if (w.p_c1[s] < 0) { w.p_island[s] = -1; continue; }
         int b1 = w.c_parent[w.p_c1[s]], b2 = w.c_parent[w.p_c2[s]];
         int b = is_dyn(w, b1) ? b1 : b2;
-        int id = is_dyn(w, b) ? w.r_island[w.b_label[b]] : -1;
+        int id = is_dyn(w, b) ? lay_island_of_root(w, w.b_label[b]) : -1;
         if (!pair_active(w, s)) { // owned by the island of its first dynamic body (recycle-tested there)
             w.p_island[s] = -1;
             if (id >= 0) { int k = atomicAdd(&w.isl_fill_i[id], 1); w.isl_icons[w.isl_icons_begin[id] + k] = s; }
@@ -406,6 +442,8 @@ __global__ void __launch_bounds__(1024) k_layout_rebuild(DevWorld w) {
     GBAR_SYNC(bar); RP_PASS_STAMP(w, 200);
     lay_isl_number(w, gid, gstride);
     GBAR_SYNC(bar); RP_PASS_STAMP(w, 200);
+    // (worlds that bundle pay one more barrier — DevWorld is a kernel argument: every workgroup takes the same branch)
+    if (lay_bundling(w)) { lay_isl_bundles(w, gid, gstride); GBAR_SYNC(bar); RP_PASS_STAMP(w, 200); }
     __syncthreads();
     lay_isl_fill(w, gid, gstride, lds_a, lds_scalar);
     GBAR_SYNC(bar); RP_PASS_STAMP(w, 200);

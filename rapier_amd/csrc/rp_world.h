@@ -203,6 +203,7 @@ struct DevWorld {
     int gbar_blocks;       // most workgroups (of 1024 threads) a grid-barrier kernel may use on this device: all of them resident at once (rp_gridbar.h)
     int has_sensors;       // some collider is a sensor: its pairs are intersection-tested every step (full step path)
     int isl_route_tiny;    // 1 (RP_NO_TINY_ROUTING=1: 0): worlds with thousands of tiny islands solve them on the global path (rp_islands.hip, lay_isl_number)
+    int isl_bundle_tiny;   // 1 (RP_NO_TINY_BUNDLES=1: 0): worlds without sleeping pack the tiny islands into shared islands instead (lay_isl_number)
     int isl_tiny_nc;       // ... and "tiny" = at most this many manifolds (8; RP_ISL_TINY_NC)
     int isl_many;          // ... "thousands" = more island candidates than this in the previous rebuild (960; RP_ISL_MANY overrides it)
     int bp_always_build;   // RP_BP_ALWAYS_BUILD=1: every full broad-phase rebuild runs its build pass (A/B switch for the kept-grid rebuild, rp_broadphase.hip)
@@ -350,7 +351,8 @@ struct DevWorld {
     int *b_label;               // union-find labels
     int2 *uf_pairs;             // [pool] scratch: the two bodies of every active pair that links two awake non-fixed bodies
     int *b_island, *b_local;    // island id (>= 0: LDS island path, -1: global path), index inside the island
-    int *r_nb, *r_nc, *r_island; // per-root scratch: body count, manifold count, island id
+    int *r_nb, *r_nc, *r_island; // per-root scratch: body count, manifold count, island id (<= -2: -2 - the bundle of tiny components it joined)
+    int *bun_nb, *bun_nc, *bun_ni, *bun_id; // per bundle of tiny components (rp_islands.hip, lay_isl_number): totals, the island it became
     int *p_island;              // pair slot -> island id or -1
     int *isl_body_begin, *isl_nb, *isl_cons_begin, *isl_nc, *isl_fill_b, *isl_fill_c;
     int *isl_bodies, *isl_cons;

@@ -233,7 +233,7 @@ def test_thousands_of_tiny_islands_take_the_global_path_bit_exact(monkeypatch):
     sc = S.shapes_rain(3000)
     g, o = PhysicsWorld.from_scene(sc), OracleWorld(sc)
     monkeypatch.setenv("RP_NO_TINY_ROUTING", "1")
-    h = PhysicsWorld.from_scene(sc)
+    h = PhysicsWorld.from_scene(sc); h.read_bodies()            # (the device world — and with it the switch — is built by the first call that needs it)
     monkeypatch.delenv("RP_NO_TINY_ROUTING")
     for cp in (20, 60, 120, 200):
         n = cp - (0 if cp == 20 else {60: 20, 120: 60, 200: 120}[cp])

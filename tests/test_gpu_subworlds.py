@@ -128,3 +128,30 @@ def test_batch_with_polyhedra_and_a_mesh_world_bit_exact():
     for cp in (1, 3, 40, 160):
         g.step(cp - done); o.step(cp - done); done = cp
         _same(g, o, f"batch with registered shapes @ {cp}")
+
+
+def test_tiny_islands_share_bundles_bit_exact(monkeypatch):
+    """rp_islands.hip, lay_isl_number (round 5): once a world holds more island candidates than one resident pass of the island kernel,
+    the components of at most 8 manifolds of a world WITHOUT sleeping are packed into shared islands ("bundles": a union of components
+    that share no body gives each the bits it gets alone) instead of going to the global path.  RP_ISL_MANY=4 makes a batch of 24
+    capsule worlds such a world: the bundled world, the same world with RP_NO_TINY_BUNDLES=1 (tiny islands on the global path, round 4's
+    routing) and the oracle must agree bit for bit — and the bundled one must leave nothing but free-flying bodies to the global path."""
+    b = S.batch([S.capsules(6) for _ in range(24)] + [S.tumble(24, seed=5)])
+    monkeypatch.setenv("RP_ISL_MANY", "4")
+    g = PhysicsWorld.from_scene(b); g.read_bodies()             # (the device world — and with it the switches — is built by the first call that needs it)
+    monkeypatch.setenv("RP_NO_TINY_BUNDLES", "1")
+    h = PhysicsWorld.from_scene(b); h.read_bodies()
+    monkeypatch.delenv("RP_NO_TINY_BUNDLES"); monkeypatch.delenv("RP_ISL_MANY")
+    o = OracleWorld(b)
+    done, fewer = 0, 0
+    for cp in (1, 2, 3, 10, 40, 120, 300, 450):
+        d, done = cp - done, cp
+        g.step(d); h.step(d); o.step(d)
+        _same(g, o, f"bundled @ {cp}")
+        gp, gv = g.read_bodies(); hp, hv = h.read_bodies()
+        np.testing.assert_array_equal(gp, hp, err_msg=f"bundles vs routing @ {cp}"); np.testing.assert_array_equal(gv, hv)
+        cg, ch = g.counters(), h.counters()
+        assert cg["num_manifolds"] == ch["num_manifolds"]
+        fewer += cg["num_global_bodies"] < ch["num_global_bodies"]
+        assert cg["num_global_bodies"] <= ch["num_global_bodies"]
+    assert fewer >= 3, "the bundles never took a tiny island off the global path"

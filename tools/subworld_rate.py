@@ -21,5 +21,5 @@ for n in ns:
     sc = S.capsules(6) if n == 1 else S.batch([S.capsules(6) for _ in range(n)])
     w = PhysicsWorld.from_scene(sc)
     r, c = rate(w, 600)
-    print(f"{n:7d} {len(sc.bodies):8d} {r:14.0f} {r * n:14.0f} {1e6 / r:14.1f}  {c['fused_steps']} / {c['fast_steps']} / {c['full_steps']} / {c['replayed_steps']}  islands? manifolds {c['num_manifolds']}")
+    print(f"{n:7d} {len(sc.bodies):8d} {r:14.0f} {r * n:14.0f} {1e6 / r:14.1f}  {c['fused_steps']} / {c['fast_steps']} / {c['full_steps']} / {c['replayed_steps']}  islands {c['num_islands']} global bodies {c['num_global_bodies']} manifolds {c['num_manifolds']}")
     w.close() if hasattr(w, "close") else None
