@@ -196,10 +196,12 @@ RP_DEV void lay_isl_count(DevWorld &w, int gid, int stride) {
 // dataflow ranks leave the step.  Worlds with sleeping keep the routing: the fused step's "may this island fall asleep" test
 // (fused_sleep_abort) speaks about ONE persistent island per kernel island.
 RP_DEV int lay_bundle_span(const DevWorld &w) { return RP_ISL_NB_MAX - w.isl_tiny_nc; }
-RP_DEV bool lay_bundling(const DevWorld &w) { return w.isl_bundle_tiny && !w.sleep_enabled && w.isl_tiny_nc >= 1 && w.isl_tiny_nc <= 32; }
+RP_DEV bool lay_route_tiny(const DevWorld &w) { return w.isl_route_tiny && w.lay_state[3] > w.isl_many; }
+// (lay_state[3] is only written behind the last barrier of a rebuild: every workgroup of a launch gets the same answer)
+RP_DEV bool lay_bundling(const DevWorld &w) { return lay_route_tiny(w) && w.isl_bundle_tiny && !w.sleep_enabled && w.isl_tiny_nc >= 1 && w.isl_tiny_nc <= 32; }
 RP_DEV void lay_isl_number(DevWorld &w, int gid, int gstride) {
-  const bool route_tiny = w.isl_route_tiny && w.lay_state[3] > w.isl_many;
-  const bool bundle = route_tiny && lay_bundling(w);
+  const bool route_tiny = lay_route_tiny(w);
+  const bool bundle = lay_bundling(w);
   for (int b = gid; b < w.n_bodies; b += gstride) {
     if (!is_dyn(w, b) || w.b_label[b] != b) continue;
     int cnb = w.r_nb[b], cnc = w.r_nc[b];
@@ -442,7 +444,7 @@ __global__ void __launch_bounds__(1024) k_layout_rebuild(DevWorld w) {
     GBAR_SYNC(bar); RP_PASS_STAMP(w, 200);
     lay_isl_number(w, gid, gstride);
     GBAR_SYNC(bar); RP_PASS_STAMP(w, 200);
-    // (worlds that bundle pay one more barrier — DevWorld is a kernel argument: every workgroup takes the same branch)
+    // (a rebuild that bundles pays one more barrier; every workgroup takes the same branch: see lay_bundling)
     if (lay_bundling(w)) { lay_isl_bundles(w, gid, gstride); GBAR_SYNC(bar); RP_PASS_STAMP(w, 200); }
     __syncthreads();
     lay_isl_fill(w, gid, gstride, lds_a, lds_scalar);
