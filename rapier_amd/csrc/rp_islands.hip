@@ -461,7 +461,15 @@ __global__ void __launch_bounds__(1024) k_layout_rebuild(DevWorld w) {
         GBAR_SYNC(bar); RP_PASS_STAMP(w, 200);
     }
     gbar_end(bar);
-    if (gid == 0) { w.flags[FL_UF_NPAIRS] = 0; w.lay_state[0] = 1; w.lay_state[1] += 1; w.lay_state[2] = w.flags[FL_N_GLOB_BODIES]; w.lay_state[3] = w.lay_state[4]; __hip_atomic_store(&w.flags[FL_LAYOUT_DIRTY], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    if (gid == 0) {
+        // The routing of tiny islands went by the candidates of the LAST rebuild; a world that settles at once (debris dropped on a
+        // floor: one rebuild, then nothing changes any more) would keep thousands of one-manifold islands in workgroups of their own
+        // for good.  When this rebuild's count answers the routing question differently, the layout stays dirty: the next step
+        // rebuilds it with the right answer (a routing decision, never a result; the host keeps the full graph while it is dirty).
+        const int again = (w.isl_route_tiny && (w.lay_state[4] > w.isl_many) != (w.lay_state[3] > w.isl_many)) ? 1 : 0;
+        w.flags[FL_UF_NPAIRS] = 0; w.lay_state[0] = 1; w.lay_state[1] += 1; w.lay_state[2] = w.flags[FL_N_GLOB_BODIES]; w.lay_state[3] = w.lay_state[4];
+        __hip_atomic_store(&w.flags[FL_LAYOUT_DIRTY], again, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // One workgroup = one island; lanes 2m, 2m+1 = manifold m (sorted by sweep stage), threads < nb also own a body.

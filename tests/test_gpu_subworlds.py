@@ -155,3 +155,30 @@ def test_tiny_islands_share_bundles_bit_exact(monkeypatch):
         fewer += cg["num_global_bodies"] < ch["num_global_bodies"]
         assert cg["num_global_bodies"] <= ch["num_global_bodies"]
     assert fewer >= 3, "the bundles never took a tiny island off the global path"
+
+
+def test_bundled_debris_at_rest_takes_fused_steps_bit_exact(monkeypatch):
+    """400 separate boxes dropped a little above a slab, sleeping off: 400 islands of one manifold = bundles of 56 (the rebuild that first
+    counts them leaves the layout dirty, the next one bundles: rp_islands.hip, k_layout_rebuild); once they lie still the world runs on
+    the ONE-kernel fused step, whose validators then walk the bodies and pairs of bundles — same bits as the oracle
+    and as the world with every island in a workgroup of its own (RP_NO_TINY_ROUTING=1), and fused steps must have been taken."""
+    side = 20
+    sc = S.Scene(name="debris", gravity=(0.0, -9.81, 0.0))
+    g0 = sc.add_body(body_type=S.BODY_FIXED, translation=(0.0, -0.5, 0.0)); sc.add_collider(g0, half_extents=(2.0 * side, 0.5, 2.0 * side))
+    for i in range(side * side):
+        b = sc.add_body(translation=(2.0 * (i % side) - side, 0.5 + 0.002 * (i % 7), 2.0 * (i // side) - side)); sc.add_collider(b, half_extents=(0.5, 0.5, 0.5))
+    g = PhysicsWorld.from_scene(sc); g.read_bodies()
+    monkeypatch.setenv("RP_NO_TINY_ROUTING", "1")
+    h = PhysicsWorld.from_scene(sc); h.read_bodies()
+    monkeypatch.delenv("RP_NO_TINY_ROUTING")
+    o = OracleWorld(sc)
+    done = 0
+    for cp in (1, 2, 30, 120, 400):
+        d, done = cp - done, cp
+        g.step(d); h.step(d); o.step(d)
+        _same(g, o, f"debris @ {cp}")
+        gp, gv = g.read_bodies(); hp, hv = h.read_bodies()
+        np.testing.assert_array_equal(gp, hp, err_msg=f"bundles vs one island each @ {cp}"); np.testing.assert_array_equal(gv, hv)
+    cg, ch = g.counters(), h.counters()
+    assert cg["num_global_bodies"] == 0 and 0 < cg["num_islands"] <= 10 and ch["num_islands"] == side * side, (cg, ch)
+    assert cg["fused_steps"] > 100, cg
