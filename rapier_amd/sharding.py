@@ -31,6 +31,7 @@ def partition_scene(scene: S.Scene, body_rank: np.ndarray, rank: int):
     Returns (sub_scene, global_index_of_local_body)."""
     sub = S.Scene(name=f"{scene.name}@{rank}", gravity=scene.gravity, params=scene.params.copy())
     sub.polyhedra = list(scene.polyhedra)   # registered point clouds keep their ids in every shard (SHAPE_CONVEX half_extents[0])
+    sub.composites = list(scene.composites)  # ... and so do compounds, triangle meshes and height fields (SHAPE_COMPOUND / SHAPE_TRIMESH half_extents[0])
     local_of = {}
     global_ids = []
     for gi, b in enumerate(scene.bodies):
@@ -148,14 +149,9 @@ def shards_from_groups(groups: np.ndarray, world_size: int):
 
 def body_boxes(scene: S.Scene):
     """Conservative world AABB of every body (centre of every collider +- its bounding radius): (min[n, 3], max[n, 3])."""
-    nb = len(scene.bodies)
-    lo = np.full((nb, 3), np.inf, np.float64); hi = np.full((nb, 3), -np.inf, np.float64)
-    pos = np.array([b["translation"] for b in scene.bodies], np.float64).reshape(nb, 3)
-    for c, p in zip(scene.colliders, scene.collider_parents):
-        if p < 0:
-            continue
-        he = np.asarray(c["half_extents"], np.float64)
-        shape = int(c["shape"])
+    def radius(shape, he, border):
+        """bounding radius of a shape about the origin of its own frame"""
+        he = np.asarray(he, np.float64)
         if shape == S.SHAPE_BALL:
             r = he[0]
         elif shape == S.SHAPE_CAPSULE:
@@ -166,11 +162,28 @@ def body_boxes(scene: S.Scene):
             r = float(np.hypot(he[0], he[1]))   # (half height, radius): the rim is the farthest point from the centre
         elif shape in (S.SHAPE_CONVEX_POLYHEDRON, S.SHAPE_ROUND_CONVEX_POLYHEDRON):
             r = float(np.linalg.norm(np.asarray(scene.polyhedra[int(he[0])][0], np.float64), axis=1).max())
-        elif shape == S.SHAPE_HALFSPACE:
-            continue  # (half-spaces sit on fixed or kinematic bodies and have no finite box)
+        elif shape in (S.SHAPE_COMPOUND, S.SHAPE_TRIMESH):
+            comp = scene.composites[int(he[0])]
+            if comp[0] == "compound":      # the farthest part: its offset in the compound's frame + its own radius
+                r = max(float(np.linalg.norm(np.asarray(q["translation"], np.float64))) + radius(int(q["shape"]), q["half_extents"], float(q["border_radius"])) for q in comp[1])
+            elif comp[0] == "trimesh":
+                r = float(np.linalg.norm(np.asarray(comp[1], np.float64), axis=1).max())
+            else:                          # height field: the unit square scaled by (sx, sy, sz), centred on the origin
+                h, sc = np.asarray(comp[1], np.float64), np.asarray(comp[2], np.float64)
+                r = float(np.linalg.norm([0.5 * sc[0], np.abs(h).max() * sc[1], 0.5 * sc[2]]))
         else:
             raise ValueError(f"body_boxes: unknown shape {shape}")
-        r += float(c["border_radius"]) if "border_radius" in c.dtype.names else 0.0
+        return r + border
+    nb = len(scene.bodies)
+    lo = np.full((nb, 3), np.inf, np.float64); hi = np.full((nb, 3), -np.inf, np.float64)
+    pos = np.array([b["translation"] for b in scene.bodies], np.float64).reshape(nb, 3)
+    for c, p in zip(scene.colliders, scene.collider_parents):
+        if p < 0:
+            continue
+        shape = int(c["shape"])
+        if shape == S.SHAPE_HALFSPACE:
+            continue  # (half-spaces sit on fixed or kinematic bodies and have no finite box)
+        r = radius(shape, c["half_extents"], float(c["border_radius"]) if "border_radius" in c.dtype.names else 0.0)
         r += float(np.linalg.norm(np.asarray(c["translation"], np.float64)))  # the collider's offset from the body, whatever the rotation
         lo[p] = np.minimum(lo[p], pos[p] - r); hi[p] = np.maximum(hi[p], pos[p] + r)
     return lo, hi

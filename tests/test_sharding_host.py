@@ -65,3 +65,38 @@ def test_a_dynamic_body_without_a_shard_is_an_error():
     body_rank[ids[2]] = -1
     with pytest.raises(ValueError):
         sharding.partition_scene(s, body_rank, 0)
+
+
+def test_shards_carry_composite_shapes_and_step_like_the_whole_world():
+    """compounds, a triangle mesh and a height field (one collider each, round 5): every shard keeps the registered composites under
+    their ids, compound bodies get finite boxes (the farthest part), and each shard evolves bit for bit like its bodies in the whole world"""
+    from oracle_ffi import OracleWorld
+    s = S.Scene(name="two_piles_composite", gravity=(0.0, -9.81, 0.0))
+    g = s.add_body(body_type=S.BODY_FIXED)
+    v = np.array([[-30, 0, -4], [0, 0, -4], [0, 0, 4], [-30, 0, 4]], np.float32)
+    s.add_collider(g, shape=S.SHAPE_TRIMESH, half_extents=(s.add_trimesh(v, np.array([[0, 2, 1], [0, 3, 2]], np.uint32)), 0, 0))
+    g2 = s.add_body(body_type=S.BODY_FIXED, translation=(15.0, 0.0, 0.0))
+    s.add_collider(g2, shape=S.SHAPE_TRIMESH, half_extents=(s.add_heightfield(np.zeros((5, 5), np.float32), (30.0, 1.0, 8.0)), 0, 0))
+    ids = []
+    for x0 in (-20.0, 20.0):
+        for k in range(3):
+            cid = s.add_compound([S.collider_desc(half_extents=(0.4, 0.1, 0.1)), S.collider_desc(half_extents=(0.1, 0.4, 0.1), translation=(0.4, 0.4, 0.0)),
+                                  S.collider_desc(shape=S.SHAPE_BALL, half_extents=(0.15, 0, 0), translation=(-0.4, 0.3, 0.0))])
+            b = s.add_body(translation=(x0 + 1.2 * k, 0.8 + 0.3 * k, 0.1 * k), can_sleep=1)
+            s.add_collider(b, shape=S.SHAPE_COMPOUND, half_extents=(cid, 0, 0))
+            ids.append(b)
+    lo, hi = sharding.body_boxes(s)
+    assert np.all(np.isfinite(lo[ids])) and np.all(np.isfinite(hi[ids]))
+    assert np.all(hi[ids, 0] - lo[ids, 0] >= 2 * (np.hypot(0.4, 0.4) + np.sqrt(0.1 ** 2 + 0.4 ** 2 + 0.1 ** 2)) - 1e-6)   # the farthest part, its own radius included
+    assert hi[g][0] - lo[g][0] >= 60.0 and hi[g2][0] - lo[g2][0] >= 30.0                                                       # the mesh and the height field
+    groups = sharding.proximity_groups_from_scene(s)
+    body_rank, n_groups = sharding.shards_from_groups(groups, 2)
+    assert body_rank[ids[0]] != body_rank[ids[3]]
+    whole = OracleWorld(s); whole.step(60)
+    wp, wv = whole.read()
+    for rank in (0, 1):
+        sub, gids = sharding.partition_scene(s, body_rank, rank)
+        assert len(sub.composites) == len(s.composites)
+        w = OracleWorld(sub); w.step(60)
+        p, v6 = w.read()
+        assert np.array_equal(p, wp[gids]) and np.array_equal(v6, wv[gids])
