@@ -29,6 +29,8 @@ def bin_pack(sizes, world_size: int) -> np.ndarray:
 def partition_scene(scene: S.Scene, body_rank: np.ndarray, rank: int):
     """Sub-scene of `rank`: its dynamic bodies + every fixed body (replicated), with colliders.
     Returns (sub_scene, global_index_of_local_body)."""
+    if scene.subworlds:
+        raise ValueError("partition_scene: a batch of sub-worlds (scenes.batch) cannot be cut by body rank — its sub-worlds overlap in space and a shard would lose their boundaries; give whole sub-worlds to each rank instead")
     sub = S.Scene(name=f"{scene.name}@{rank}", gravity=scene.gravity, params=scene.params.copy())
     sub.polyhedra = list(scene.polyhedra)   # registered point clouds keep their ids in every shard (SHAPE_CONVEX half_extents[0])
     sub.composites = list(scene.composites)  # ... and so do compounds, triangle meshes and height fields (SHAPE_COMPOUND / SHAPE_TRIMESH half_extents[0])

@@ -100,3 +100,9 @@ def test_shards_carry_composite_shapes_and_step_like_the_whole_world():
         w = OracleWorld(sub); w.step(60)
         p, v6 = w.read()
         assert np.array_equal(p, wp[gids]) and np.array_equal(v6, wv[gids])
+
+
+def test_a_batch_of_sub_worlds_is_not_cut_by_body_rank():
+    b = S.batch([S.capsules(2), S.capsules(2)])
+    with pytest.raises(ValueError, match="sub-worlds"):
+        sharding.partition_scene(b, np.zeros(len(b.bodies), np.int32), 0)
