@@ -127,7 +127,7 @@ def cpu_baseline(steps: int = 400, warmup: int = 60):
     return {"value": out[best], "unit": "steps/s", "cores": best, "kind": "port", "single_thread_value": out[1],
             "thread_sweep": {str(c): round(out[c], 2) for c in counts},
             "sample": f"{steps // 4} steps of b3d_many_pyramids (10,780 cuboids) per thread count after {warmup} warm-up steps, oracle/librapier_oracle.so "
-                      f"(C restatement, OpenMP, threads pinned one per core; best of {counts} threads = {best}; {steps // 4} steps on 1 thread)"}
+                      f"(C restatement, gcc -O3 -march=x86-64-v3 -ffp-contract=off, OpenMP, threads pinned one per core; best of {counts} threads = {best}; {steps // 4} steps on 1 thread)"}
 
 
 def build_workload(name: str, world: int, rank: int):

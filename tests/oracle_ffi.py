@@ -29,8 +29,8 @@ def lib():
     global _LIB
     if _LIB is None:
         path = os.path.join(_ORACLE_DIR, "librapier_oracle.so")
-        src = os.path.join(_ORACLE_DIR, "rapier_oracle.c")
-        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+        srcs = [os.path.join(_ORACLE_DIR, f) for f in os.listdir(_ORACLE_DIR) if f.endswith((".c", ".h")) or f == "Makefile"]
+        if not os.path.exists(path) or os.path.getmtime(path) < max(os.path.getmtime(f) for f in srcs):
             build_oracle()
         L = C.CDLL(path)
         L.ro_world_new.restype = C.c_void_p
