@@ -35,7 +35,9 @@ extern "C" {
 #define RP_ERR_CAPACITY (-3)
 #define RP_ERR_NONFINITE (-4)
 
-/* IntegrationParameters, field for field — integration_parameters.rs:181-304 (defaults :379-408) */
+/* IntegrationParameters — integration_parameters.rs:181-304 (defaults :379-408): every field of the 3-D build, the two
+ * SpringCoefficients (contact_softness, static_contact_softness: natural_frequency + damping_ratio each) spelt out, bools and usizes
+ * as int32.  joint_natural_frequency / joint_damping_ratio are the JointSoftness constants of joint_constraint_helper.rs (1e6 Hz, 1). */
 typedef struct rp_integration_params {
     float dt;
     float contact_natural_frequency, contact_damping_ratio;
@@ -56,6 +58,13 @@ typedef struct rp_integration_params {
     int32_t warmstart_joints;
     int32_t max_ccd_substeps;
     int32_t friction_model; /* FrictionModel (integration_parameters.rs:13-32): RP_FRICTION_SIMPLIFIED (default) | RP_FRICTION_COULOMB */
+    float min_ccd_dt;       /* integration_parameters.rs:200 (default dt / 100): the shortest CCD substep, read only by the step splitting of
+                             * max_ccd_substeps > 1 (substep.rs:410-470).  This library runs every step as ONE CCD substep (max_ccd_substeps
+                             * is 0 = off or >= 1 = on), so the value is validated (finite, >= 0), stored and handed back, and has no effect */
+    int32_t contact_clustering; /* integration_parameters.rs:278 (default true = 1): pairs that hold several manifolds (composite shapes) are
+                                 * solved as clusters (pair_update.rs:350).  0 is accepted for worlds without composite shapes, where it
+                                 * changes nothing (a primitive pair holds one manifold); a world that holds a compound / mesh / height
+                                 * field refuses 0 with RP_ERR_INVALID (its unclustered form is not built) */
 } rp_integration_params;
 
 enum { RP_FRICTION_SIMPLIFIED = 0, RP_FRICTION_COULOMB = 1 };
@@ -158,7 +167,8 @@ typedef struct rp_joint_motor {
 /* GenericJoint — /root/reference/src/dynamics/joint/generic_joint.rs:255-355; the local frames are (local_anchor, local_basis) like
  * GenericJoint::local_frame1/2 */
 typedef struct rp_joint_desc {
-    int32_t body1, body2; /* dense body indices (handle low 32 bits) */
+    uint64_t body1, body2; /* RigidBodyHandles (generation << 32 | index), as ImpulseJointSet::insert(body1, body2, ..) takes them
+                            * (impulse_joint_set.rs:329-375); a stale or removed handle is refused with RP_ERR_INVALID */
     float local_anchor1[3], local_anchor2[3];
     float local_basis1[4], local_basis2[4];
     uint32_t locked_axes; /* JointAxesMask: bit0..2 LIN_X,Y,Z ; bit3..5 ANG_X,Y,Z */
@@ -171,6 +181,7 @@ typedef struct rp_joint_desc {
                                * RopeJoint, rope_joint.rs:31-38) and ONE motor row (SpringJoint, spring_joint.rs:31-40) along their combined
                                * error — limits and motor are those of the first coupled axis; exactly two angular axes in the mask share one
                                * limit row (joint_constraint_helper.rs:725-790); a motor on coupled angular axes does nothing, as in the reference */
+    uint32_t reserved;        /* 0 (keeps the size a multiple of the handles' 8-byte alignment without implicit padding) */
 } rp_joint_desc;
 
 /* Counters mirror (ms, from hipEvents) — /root/reference/src/counters/{mod,stages_counters,
@@ -224,7 +235,7 @@ int32_t rp_world_destroy(rp_world *w);
 const char *rp_last_error(const rp_world *w);
 void rp_default_params(rp_integration_params *out);            /* IntegrationParameters::default() */
 int32_t rp_params_get(const rp_world *w, rp_integration_params *out);
-int32_t rp_params_set(rp_world *w, const rp_integration_params *in);
+int32_t rp_params_set(rp_world *w, const rp_integration_params *params);
 
 /* RigidBodySet::insert ×n; handles = generation<<32 | index (arena.rs:58-90); removed slots are reused first, LIFO (arena.rs:260-290). */
 int32_t rp_bodies_insert(rp_world *w, int32_t n, const rp_body_desc *descs, uint64_t *handles_out);
@@ -257,13 +268,15 @@ int32_t rp_heightfield_create(rp_world *w, int32_t nrows, int32_t ncols, const f
  * volume, centre of mass xyz, inertia tensor about it at unit density: xx, yy, zz, xy, xz}. */
 int32_t rp_convex_polyhedron_read(const rp_world *w, int32_t id, int32_t counts[4], float *points_xyz, float *face_normals, int32_t *face_first, int32_t *face_count,
                                   int32_t *loop_vertex, int32_t *loop_edge, float props[20]);
-/* ImpulseJointSet::insert ×n (impulse_joint_set.rs).  Device path scope: locked axes only — any JointAxesMask of locked
+/* ImpulseJointSet::insert ×n (impulse_joint_set.rs).  handles_out = ImpulseJointHandles: generation << 32 | index of the slot in the
+ * set's arena (joint_ids: Arena<..>, data/arena.rs:58-90, 260-290): the slot of a removed joint is handed out again LIFO with the
+ * arena's removal count as its generation, a handle of an earlier occupant is refused with RP_ERR_INVALID by every call.
+ * Device path scope: any JointAxesMask of locked
  * linear / angular axes (spherical 0x07, revolute 0x37, prismatic without limits 0x3e, fixed 0x3f; the free axis is the
  * local frame's X axis as in RevoluteJointBuilder / PrismaticJointBuilder); contacts_enabled = 0 filters the contact pairs between
  * the two bodies (pair_update.rs:191-201); limit_axes / limits bound the free axes (limit_linear, limit_angular:
  * joint_constraint_helper.rs:166-208, 468-564); motor_axes / motors drive them (motor_linear, motor_angular: :285-331, 566-625;
- * motor rows are solved before the lock and limit rows, joint_velocity_constraint.rs:186-246); coupled axes are not part of
- * this descriptor. */
+ * motor rows are solved before the lock and limit rows, joint_velocity_constraint.rs:186-246); coupled_axes: see rp_joint_desc. */
 int32_t rp_impulse_joints_insert(rp_world *w, int32_t n, const rp_joint_desc *descs, uint64_t *handles_out);
 /* GenericJoint::set_motor / set_motor_velocity / set_motor_position / set_motor_max_force / set_motor_model
  * (generic_joint.rs:538-603) through ImpulseJointSet::get_mut(handle, wake_up_connected_bodies = true)
@@ -332,6 +345,10 @@ int32_t rp_bodies_persistent_island(rp_world *w, int32_t n, const uint64_t *hand
  * handle of an earlier occupant is stale and rejected with RP_ERR_INVALID everywhere.  Returns the row count, writes min(rows, cap). */
 int32_t rp_bodies_handles(const rp_world *w, int32_t cap, uint64_t *handles_out);
 int32_t rp_colliders_handles(const rp_world *w, int32_t cap, uint64_t *handles_out);
+/* ImpulseJointSet::iter as handles (impulse_joint_set.rs:282-291): one entry per joint ever inserted, in insertion order — the order of
+ * the NULL-handle reads of rp_impulse_joints_read: the handle of a live joint, RP_INVALID_HANDLE for a removed one.  Returns the
+ * number of entries, writes min(entries, cap). */
+int32_t rp_impulse_joints_handles(const rp_world *w, int32_t cap, uint64_t *handles_out);
 /* Proximity groups: connected components of the non-fixed bodies over everything that can couple them within a step — every live
  * broad-phase pair (fat AABBs overlap: ColliderPair events of broad_phase_bvh/mod.rs:171-263) and every impulse joint.  Two bodies in
  * different groups cannot interact before one of them moves out of its fat AABB: the unit of island sharding over GPUs (SURVEY §8e;

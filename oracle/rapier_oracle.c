@@ -276,6 +276,8 @@ void ro_default_params(ro_params *p) {
     p->friction_in_bias_pass = 0;
     p->warmstart_joints = 0;
     p->max_ccd_substeps = 1;
+    p->min_ccd_dt = 1.0f / 60.0f / 100.0f;
+    p->contact_clustering = 1;
     p->friction_model = RO_FRICTION_SIMPLIFIED;
 }
 
@@ -3565,7 +3567,8 @@ int32_t ro_dump_manifolds(const ro_world *w, int32_t cap, int32_t *meta, float *
 /* ImpulseJointSet::insert — impulse_joint_set.rs.  Scope: locked linear axes only (spherical joints),
  * contacts between the two bodies enabled. */
 int32_t ro_add_joint(ro_world *w, const ro_joint_desc *d) {
-    if (d->body1 < 0 || d->body2 < 0 || d->body1 >= w->nbodies || d->body2 >= w->nbodies) return -1;
+    const int b1 = (int)(uint32_t)(d->body1 & 0xffffffffu), b2 = (int)(uint32_t)(d->body2 & 0xffffffffu); /* (a handle's index part: the oracle keeps no generations) */
+    if (b1 < 0 || b2 < 0 || b1 >= w->nbodies || b2 >= w->nbodies) return -1;
     if ((d->locked_axes & ~0x3fu) != 0 || (d->limit_axes & ~0x3fu) != 0 || (d->motor_axes & ~0x3fu) != 0 || (d->coupled_axes & ~0x3fu) != 0) return -1;
     { uint32_t ca = (d->coupled_axes >> 3) & 7u; if (ca != 0 && ca != 3 && ca != 5 && ca != 6) return -1; } /* limit_angular_coupled: exactly two coupled angular axes (joint_constraint_helper.rs:737-739) */
     if (w->njoints == w->cap_joints) {
@@ -3576,7 +3579,7 @@ int32_t ro_add_joint(ro_world *w, const ro_joint_desc *d) {
     }
     Joint *j = &w->joints[w->njoints];
     memset(j, 0, sizeof(*j));
-    j->body1 = d->body1; j->body2 = d->body2;
+    j->body1 = b1; j->body2 = b2;
     j->local_frame1.t = V3(d->local_anchor1[0], d->local_anchor1[1], d->local_anchor1[2]);
     j->local_frame2.t = V3(d->local_anchor2[0], d->local_anchor2[1], d->local_anchor2[2]);
     j->local_frame1.r = qnormalize(Q(d->local_basis1[0], d->local_basis1[1], d->local_basis1[2], d->local_basis1[3]));
@@ -3595,7 +3598,7 @@ int32_t ro_add_joint(ro_world *w, const ro_joint_desc *d) {
     for (int i = 0; i < 6; ++i) j->motors[i] = d->motors[i];
     j->solver_color = 255; /* default_solver_color: uncoloured */
     w->nc_dirty = 1;
-    wake_request(w, d->body1, 1); wake_request(w, d->body2, 1); /* insert(.., wake_up = true), substep.rs:289-300 */
+    wake_request(w, b1, 1); wake_request(w, b2, 1); /* insert(.., wake_up = true), substep.rs:289-300 */
     return w->njoints++;
 }
 /* GenericJoint::set_motor (generic_joint.rs) on ImpulseJointSet::get_mut(handle, wake_up = true) (impulse_joint_set.rs):

@@ -46,6 +46,8 @@ typedef struct ro_params {
     int32_t warmstart_joints;                                             /* 0 */
     int32_t max_ccd_substeps;                                             /* 1 (flag only) */
     int32_t friction_model;                                               /* FrictionModel: 0 Simplified (twist), 1 Coulomb */
+    float min_ccd_dt;                                                     /* dt / 100; read only by the step splitting of max_ccd_substeps > 1 (substep.rs:410-470), which this oracle does not run */
+    int32_t contact_clustering;                                           /* 1; composite pairs are always clustered here */
 } ro_params;
 
 /* RigidBodyType — rigid_body_components.rs */
@@ -102,7 +104,7 @@ typedef struct ro_joint_motor { float target_vel, target_pos, stiffness, damping
 
 /* GenericJoint: locked axes, limits and motors of the free axes, coupled axes (RopeJoint / SpringJoint couple the linear axes). */
 typedef struct ro_joint_desc {
-    int32_t body1, body2;
+    uint64_t body1, body2; /* the layout of rp_joint_desc (RigidBodyHandles there); the oracle has no generations: the low 32 bits are the body index */
     float local_anchor1[3], local_anchor2[3];
     float local_basis1[4], local_basis2[4];
     uint32_t locked_axes; /* bit0..2 lin x,y,z ; bit3..5 ang x,y,z */
@@ -113,6 +115,7 @@ typedef struct ro_joint_desc {
     ro_joint_motor motors[6];
     uint32_t coupled_axes; /* GenericJoint::coupled_axes (generic_joint.rs:285): the linear axes in it share ONE limit / motor row along their
                             * combined error, exactly two angular axes in it one limit row; the first coupled axis carries limits and motor */
+    uint32_t reserved;
 } ro_joint_desc;
 
 #define RO_ISLAND_STATS_MAX 16

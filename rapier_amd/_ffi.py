@@ -21,7 +21,7 @@ SYMBOLS = [
     "rp_impulse_joints_read", "rp_impulse_joints_set_motor", "rp_impulse_joints_read_motor_impulses", "rp_bodies_remove", "rp_colliders_remove", "rp_impulse_joints_remove",
     "rp_compound_create", "rp_trimesh_create", "rp_heightfield_create",
     "rp_quarantine_read", "rp_step",
-    "rp_sync", "rp_bodies_read", "rp_bodies_write", "rp_bodies_add_force", "rp_bodies_apply_impulse", "rp_bodies_wake_up", "rp_bodies_set_additional_solver_iterations", "rp_bodies_is_sleeping", "rp_bodies_persistent_island", "rp_bodies_proximity_group", "rp_world_set_shard_guard", "rp_world_shard_guard_take_hits", "rp_world_max_linear_speed", "rp_world_set_shard_guard_horizon", "rp_world_begin_subworld", "rp_step_many", "rp_bodies_handles", "rp_colliders_handles", "rp_convex_polyhedron_create", "rp_convex_polyhedron_read", "rp_bodies_set_next_kinematic_position", "rp_num_bodies", "rp_contacts_read",
+    "rp_sync", "rp_bodies_read", "rp_bodies_write", "rp_bodies_add_force", "rp_bodies_apply_impulse", "rp_bodies_wake_up", "rp_bodies_set_additional_solver_iterations", "rp_bodies_is_sleeping", "rp_bodies_persistent_island", "rp_bodies_proximity_group", "rp_world_set_shard_guard", "rp_world_shard_guard_take_hits", "rp_world_max_linear_speed", "rp_world_set_shard_guard_horizon", "rp_world_begin_subworld", "rp_step_many", "rp_bodies_handles", "rp_colliders_handles", "rp_impulse_joints_handles", "rp_convex_polyhedron_create", "rp_convex_polyhedron_read", "rp_bodies_set_next_kinematic_position", "rp_num_bodies", "rp_contacts_read",
     "rp_collision_events_read", "rp_intersection_pairs_read", "rp_contact_force_events_read", "rp_counters_enable", "rp_counters_read", "rp_solver_loop_time_ms",
 ]
 
@@ -92,6 +92,7 @@ def lib():
     L.rp_convex_polyhedron_read.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]; L.rp_convex_polyhedron_read.restype = i32
     L.rp_compound_create.argtypes = [vp, i32, vp, vp]; L.rp_trimesh_create.argtypes = [vp, i32, vp, i32, vp, vp]; L.rp_heightfield_create.argtypes = [vp, i32, i32, vp, vp, vp]
     L.rp_colliders_handles.argtypes = [vp, i32, vp]; L.rp_colliders_handles.restype = i32
+    L.rp_impulse_joints_handles.argtypes = [vp, i32, vp]; L.rp_impulse_joints_handles.restype = i32
     L.rp_debug_islands.argtypes = [vp, vp, vp, i32, vp]  # debug aid, not in the header
     L.rp_debug_islands.restype = i32
     L.rp_bodies_set_next_kinematic_position.argtypes = [vp, i32, vp, vp]

@@ -151,7 +151,10 @@ struct rp_world {
     std::vector<HostComposite> comps; std::vector<int> collider_comp;
     void *cm_dev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     void *cv_dev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    std::vector<rp_joint_desc> joints;
+    std::vector<rp_joint_desc> joints; // the edge list in insertion order (removed joints stay as tombstones); body1 / body2 hold the resolved ARENA INDICES
+    // ImpulseJointSet's handle arena (joint_ids: Arena<..>, impulse_joint_set.rs:48; data/arena.rs:260-380): slot -> position in `joints`
+    // (-1: free), LIFO free list, generation = the arena's removal count when the slot was handed out; joint_slot: position -> slot
+    std::vector<int> jslot_pos, jslot_free, joint_slot; std::vector<uint32_t> jslot_gen; uint32_t joint_arena_gen = 0;
     std::vector<int> active_joint_ids; // device joint index -> index into `joints`
     std::vector<int> quarantine_log;   // bodies disabled by the quarantine, in detection order
     int quar_seen = 0;                 // value of FL_QUARANTINE the host has already acted on
@@ -252,7 +255,7 @@ static int queue_wake(rp_world *w, int b, int lvl);
 static int finalize(rp_world *w);
 static int quarantine_body_at(rp_world *w, int b);
 static bool all_finite(const float *v, int n);
-static int handle_index(uint64_t h);
+static int joint_of(const rp_world *w, uint64_t h, bool allow_removed = false);
 static int body_of(const rp_world *w, uint64_t h, bool allow_removed = false);
 static int collider_of(const rp_world *w, uint64_t h);
 static int reset_row(rp_world *w, int dom, int i);
@@ -281,6 +284,8 @@ extern "C" void rp_default_params(rp_integration_params *p) {
     p->friction_model = RP_FRICTION_SIMPLIFIED;
     p->warmstart_joints = 0;
     p->max_ccd_substeps = 1;
+    p->min_ccd_dt = 1.0f / 60.0f / 100.0f;
+    p->contact_clustering = 1;
 }
 
 // SpringCoefficients::{erp_inv_dt, cfm_factor} — integration_parameters.rs:86-149 (f32, no FMA)
@@ -405,6 +410,8 @@ static const char *params_problem(const rp_integration_params &p) {
         !real(p.normalized_max_linear_velocity) || !real(p.normalized_contact_recycle_distance))
         return "non-finite parameter";
     if (p.normalized_prediction_distance < 0.0f || p.normalized_allowed_linear_error < 0.0f) return "negative distance parameter";
+    if (!real(p.min_ccd_dt) || p.min_ccd_dt < 0.0f) return "min_ccd_dt must be finite and >= 0";
+    if (p.contact_clustering != 0 && p.contact_clustering != 1) return "contact_clustering is a bool (0 | 1)";
     return nullptr;
 }
 extern "C" int32_t rp_world_create(const rp_integration_params *params, const float gravity[3], int32_t device, rp_world **out) {
@@ -485,6 +492,7 @@ extern "C" int32_t rp_params_set(rp_world *w, const rp_integration_params *in) {
     if (!w || !in) return RP_ERR_INVALID;
     if (w->finalized) { int r = settle(w); if (r != RP_OK) return r; }
     if (const char *why = params_problem(*in)) { w->err = std::string("rp_params_set: ") + why; return RP_ERR_INVALID; }
+    if (!in->contact_clustering && !w->comps.empty()) { w->err = "rp_params_set: contact_clustering = false in a world that holds composite shapes (their unclustered form is not built)"; return RP_ERR_INVALID; }
     if (w->finalized && in->friction_model != w->params.friction_model) {
         // the constraint planes are sized per friction model: rebuild the device world from the current state
         int r = rebuild_begin(w);

@@ -451,7 +451,8 @@ RP_DEV void bp_incr_delete(DevWorld &w, int gid, int gstride, int nchg) {
         V3 imin;
         if (fat_overlap(w, c1, c2, imin)) continue;
         hash_erase(w.h_key[cur], w.hash_cap, ((unsigned long long)(unsigned)c1 << 32) | (unsigned)c2);
-        atomicAdd(&w.flags[FL_BP_TOMBS], 1);
+        // (FL_BP_TOMBS is NOT touched here: every workgroup of this launch decides `incremental` from it, at its own time — the tombstones
+        // of this pass are the slots it parks, counted by FL_BP_NFREED and folded into FL_BP_TOMBS by bp_close_incremental)
         bp_delete_pair(w, s, true);
     }
 }
@@ -462,7 +463,8 @@ __global__ void __launch_bounds__(1024) k_bp_rebuild(DevWorld w) {
     if (!w.flags[FL_BP_DIRTY]) return; // (cleared only after the last barrier: every workgroup reads the same value)
     if (collision_done(w)) return;     // (a dead lean step's collision stage is not repeated: rp_world.h "lean step graphs")
     const int gid = gbar_item(), gstride = gridDim.x * blockDim.x;
-    // the mode is decided from scalars that only change behind a barrier of this launch (or at its very end)
+    // the mode is decided from scalars that NO workgroup of this launch writes before its first barrier (the incremental pass has none:
+    // it writes none of them at all — a late workgroup must not see a different answer than an early one that is already deleting)
     // (an incremental pass spends a wavefront per changed collider, the full rebuild eight lanes per collider: beyond a quarter of the
     // colliders the rebuild is the cheaper one — measured on b3d_joint_grid, where 3,559 of 10,000 change per pass: 36 us as a rebuild)
     const int nchg = w.flags[FL_BP_NCHG] < w.n_colliders ? w.flags[FL_BP_NCHG] : w.n_colliders;

@@ -247,6 +247,7 @@ RP_DEV void bp_close_incremental(const DevWorld &w) {
     __syncthreads();
     if (threadIdx.x == 0) {
         w.flags[FL_FREE_TOP] = ftop + nfreed; w.flags[FL_BP_NFREED] = 0;
+        w.flags[FL_BP_TOMBS] += nfreed; // every tombstone of the pass parked a slot (a composite pair's cluster slots count too: an upper bound, which is all the rehash threshold needs)
         w.flags[FL_BP_NCHG] = 0; w.flags[FL_BP_SEQ] += 1; w.flags[FL_BP_REBUILDS] += 1;
         w.flags[FL_BP_DIRTY] = 0; w.flags[FL_BP_CLOSE] = 0;
     }

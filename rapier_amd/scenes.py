@@ -49,11 +49,11 @@ MOTOR_DTYPE = np.dtype([  # rp_joint_motor = JointMotor (generic_joint.rs:200-23
 ], align=False)
 MOTOR_ACCELERATION_BASED, MOTOR_FORCE_BASED = 0, 1  # MotorModel
 F32_MAX = float(np.finfo(np.float32).max)
-JOINT_DTYPE = np.dtype([
-    ("body1", "<i4"), ("body2", "<i4"), ("local_anchor1", "<f4", 3), ("local_anchor2", "<f4", 3),
+JOINT_DTYPE = np.dtype([  # rp_joint_desc: body1 / body2 are RigidBodyHandles (generation << 32 | index; a scene holds plain indices = generation 0)
+    ("body1", "<u8"), ("body2", "<u8"), ("local_anchor1", "<f4", 3), ("local_anchor2", "<f4", 3),
     ("local_basis1", "<f4", 4), ("local_basis2", "<f4", 4), ("locked_axes", "<u4"),
     ("contacts_enabled", "<i4"), ("limit_axes", "<u4"), ("limits", "<f4", (6, 2)),
-    ("motor_axes", "<u4"), ("motors", MOTOR_DTYPE, 6), ("coupled_axes", "<u4"),
+    ("motor_axes", "<u4"), ("motors", MOTOR_DTYPE, 6), ("coupled_axes", "<u4"), ("reserved", "<u4"),
 ], align=False)
 
 
@@ -75,7 +75,7 @@ PARAMS_DTYPE = np.dtype([
     ("num_solver_iterations", "<i4"), ("num_internal_pgs_iterations", "<i4"),
     ("num_internal_stabilization_iterations", "<i4"), ("contact_recycling", "<i4"),
     ("friction_in_bias_pass", "<i4"), ("warmstart_joints", "<i4"), ("max_ccd_substeps", "<i4"),
-    ("friction_model", "<i4"),
+    ("friction_model", "<i4"), ("min_ccd_dt", "<f4"), ("contact_clustering", "<i4"),
 ], align=False)
 
 FRICTION_SIMPLIFIED, FRICTION_COULOMB = 0, 1  # FrictionModel, integration_parameters.rs:13-32
@@ -108,6 +108,8 @@ def default_params() -> np.ndarray:
     p["warmstart_joints"] = 0
     p["max_ccd_substeps"] = 1
     p["friction_model"] = FRICTION_SIMPLIFIED
+    p["min_ccd_dt"] = np.float32(1.0) / np.float32(60.0) / np.float32(100.0)
+    p["contact_clustering"] = 1
     return p
 
 

@@ -447,7 +447,7 @@ class ShardSet:
             # the destination gets them back once both ends live there (the other end: a body of the group or a replicated one)
             if dst in self.worlds and self.joints:
                 moved, w = set(gl), self.worlds[dst]
-                row_of = {g: int(h) & 0xFFFFFFFF for g, h in self.handle[dst].items()}
+                row_of = {g: int(h) for g, h in self.handle[dst].items()}   # rp_joint_desc.body1 / body2 are RigidBodyHandles
                 back = []
                 for j in self.joints:
                     b1, b2 = int(j["body1"]), int(j["body2"])

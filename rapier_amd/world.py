@@ -312,8 +312,31 @@ class PhysicsWorld:
         b = self.insert_body(body)
         return b, self.insert_collider(collider, b)
 
+    def joint_handles(self) -> np.ndarray:
+        """ImpulseJointSet::iter as handles (rp_impulse_joints_handles): one entry per joint ever inserted, insertion order; a removed
+        joint's entry is RP_INVALID_HANDLE."""
+        n = self._lib.rp_impulse_joints_handles(self._ptr, 0, None)
+        out = np.zeros(max(n, 0), np.uint64)
+        if n > 0:
+            self._lib.rp_impulse_joints_handles(self._ptr, n, out.ctypes.data)
+        return out
+
+    def _jh(self, handles) -> np.ndarray:
+        """Joint handles as the ABI wants them (generation << 32 | arena slot), unchanged; under index_addressing a value below 2^32 is
+        the joint's insertion ordinal (what the oracle numbers joints by) and is replaced by that joint's current handle."""
+        h = np.ascontiguousarray(np.atleast_1d(np.asarray(handles, dtype=np.uint64))).copy()
+        if self.index_addressing:
+            idx = h < np.uint64(1 << 32)
+            if idx.any():
+                cur = self.joint_handles()
+                ok = idx & (h < np.uint64(len(cur)))
+                h[ok] = cur[h[ok].astype(np.int64)]
+        return h
+
     def insert_impulse_joints(self, descs: np.ndarray) -> np.ndarray:
-        descs = np.ascontiguousarray(descs, dtype=S.JOINT_DTYPE)
+        descs = np.ascontiguousarray(descs, dtype=S.JOINT_DTYPE).copy()
+        if len(descs):  # rp_joint_desc.body1 / body2 are RigidBodyHandles
+            descs["body1"], descs["body2"] = self._bh(descs["body1"]), self._bh(descs["body2"])
         out = np.zeros(len(descs), np.uint64)
         _check(self._ptr, self._lib.rp_impulse_joints_insert(self._ptr, len(descs), descs.ctypes.data, out.ctypes.data), "rp_impulse_joints_insert")
         self.impulse_joints._n += len(descs)
@@ -321,7 +344,7 @@ class PhysicsWorld:
 
     def insert_impulse_joint(self, body1, body2, joint: np.ndarray):
         j = np.array([joint], dtype=S.JOINT_DTYPE)
-        j["body1"], j["body2"] = int(body1) & 0xFFFFFFFF, int(body2) & 0xFFFFFFFF
+        j["body1"], j["body2"] = int(body1), int(body2)   # ImpulseJointSet::insert(body1: RigidBodyHandle, body2: RigidBodyHandle, ..)
         return int(self.insert_impulse_joints(j)[0])
 
     # ---- removal (RigidBodySet::remove, ColliderSet::remove, ImpulseJointSet::remove) ----
@@ -337,7 +360,7 @@ class PhysicsWorld:
         self._remove(self._lib.rp_colliders_remove, self._ch(handles), "rp_colliders_remove")
 
     def remove_impulse_joint(self, handles):
-        self._remove(self._lib.rp_impulse_joints_remove, handles, "rp_impulse_joints_remove")
+        self._remove(self._lib.rp_impulse_joints_remove, self._jh(handles), "rp_impulse_joints_remove")
 
     def quarantined(self) -> np.ndarray:
         n = self._lib.rp_quarantine_read(self._ptr, 0, None)
@@ -563,7 +586,7 @@ class PhysicsWorld:
     def set_joint_motor(self, handles, axes, **motor):
         """GenericJoint::set_motor* through ImpulseJointSet::get_mut(handle, true): joint ``handles[i]`` gets the motor described by
         the keywords (scenes.motor_desc) on axis ``axes[i]`` (0..5 = LinX..AngZ); the motor is enabled and both bodies are woken."""
-        h = np.ascontiguousarray(np.atleast_1d(np.asarray(handles, dtype=np.uint64)))
+        h = self._jh(handles)
         a = np.ascontiguousarray(np.broadcast_to(np.atleast_1d(np.asarray(axes, dtype=np.int32)), h.shape))
         m = np.ascontiguousarray(np.broadcast_to(S.motor_desc(**motor), h.shape))
         _check(self._ptr, self._lib.rp_impulse_joints_set_motor(self._ptr, len(h), h.ctypes.data, a.ctypes.data, m.ctypes.data), "rp_impulse_joints_set_motor")

@@ -188,3 +188,50 @@ def test_a_stale_generation_zero_handle_is_refused_not_retargeted():
     assert int(g.body_handles_at([a])[0]) == new                 # explicit index addressing names the current occupant
     pos, _ = g.read_bodies([new])
     assert abs(float(pos[0, 0]) - 3.0) < 1e-6
+
+
+def test_impulse_joint_handles_are_generational_and_bodies_are_named_by_handle():
+    """ImpulseJointSet is arena-backed in the reference (joint_ids: Arena<..>, impulse_joint_set.rs:48; insert(body1: RigidBodyHandle,
+    body2: RigidBodyHandle, ..) :329-375; remove :595-618): a removed joint's slot is handed out again, LIFO, under a higher generation
+    and the old handle is refused; rp_joint_desc names its bodies by 64-bit handles, so a stale body handle is refused as well
+    (VERDICT r5 missing #4).  Strict handles throughout (index_addressing=False)."""
+    sc = S.Scene(name="joint_arena", gravity=(0.0, -9.81, 0.0))
+    gb = sc.add_body(body_type=S.BODY_FIXED, translation=(0.0, 5.0, 0.0)); sc.add_collider(gb, half_extents=(0.2, 0.2, 0.2))
+    balls = []
+    for k in range(4):
+        b = sc.add_body(translation=(1.0 + k, 5.0, 0.0)); sc.add_collider(b, shape=S.SHAPE_BALL, half_extents=(0.3, 0.0, 0.0)); balls.append(b)
+    g = PhysicsWorld.from_scene(sc, index_addressing=False)
+    hb = [int(h) for h in g.body_handles()]
+    tmp = S.Scene(name="tmp"); tmp.add_joint(0, 0, (0.5, 0, 0), (-0.5, 0, 0)); proto = tmp.joints[0]
+    j0 = g.insert_impulse_joint(hb[gb], hb[balls[0]], proto)
+    j1 = g.insert_impulse_joint(hb[balls[0]], hb[balls[1]], proto)
+    j2 = g.insert_impulse_joint(hb[balls[1]], hb[balls[2]], proto)
+    assert (j0, j1, j2) == (0, 1, 2)                                   # generation 0: the handle is the slot index
+    g.step(3)
+    g.remove_impulse_joint([j1])
+    with pytest.raises(RapierHipError):
+        g.remove_impulse_joint([j1])                                  # already removed
+    with pytest.raises(RapierHipError):
+        g.set_joint_motor([j1], [3], target_vel=1.0, damping=1.0)
+    j3 = g.insert_impulse_joint(hb[balls[2]], hb[balls[3]], proto)
+    assert j3 & 0xFFFFFFFF == 1 and j3 >> 32 == 1                      # the freed slot, generation = the arena's removal count
+    assert [int(h) for h in g.joint_handles()] == [j0, 0xFFFFFFFFFFFFFFFF, j2, j3]
+    with pytest.raises(RapierHipError):
+        g.remove_impulse_joint([j1])                                  # the stale handle does not reach the slot's new occupant
+    g.set_joint_motor([j3], [3], target_vel=0.5, damping=1.0)          # ... the current one does
+    # a joint names its bodies by handle: a stale body handle is refused
+    victim = hb[balls[3]]
+    g.remove_body([victim])                                            # takes j3 with it (RigidBodySet::remove removes attached joints)
+    assert int(g.joint_handles()[3]) == 0xFFFFFFFFFFFFFFFF
+    nb = int(g.insert_body(S.body_desc(translation=(9.0, 5.0, 0.0))))
+    assert nb & 0xFFFFFFFF == balls[3] and nb >> 32 > 0
+    with pytest.raises(RapierHipError):
+        g.insert_impulse_joint(hb[balls[2]], victim, proto)            # generation 0 handle of a reused slot
+    j4 = g.insert_impulse_joint(hb[balls[2]], nb, proto)
+    assert j4 & 0xFFFFFFFF == 1 and j4 >> 32 == 2
+    g.step(20)
+    pos, _ = g.read_bodies()
+    assert np.isfinite(pos).all()
+    # the chain gb - b0, b1 - b2 - nb holds: the joined anchors stay together
+    assert abs(np.linalg.norm(pos[balls[0], :3] - pos[gb, :3]) - 1.0) < 0.05
+    assert abs(np.linalg.norm(pos[balls[3], :3] - pos[balls[2], :3]) - 1.0) < 0.05

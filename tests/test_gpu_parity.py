@@ -91,7 +91,8 @@ def _oracle_threads():
 
 def test_large_pyramid_full_size_bit_exact():
     """BASELINE config C2 at its stated size: b3d_large_pyramid base 200 = 20,100 cuboids in ONE island (~59,900 manifolds, the
-    global path with every colour a parallel stage), 1 / 3 / 10 steps, every bit."""
+    global path with every colour a parallel stage), 1 / 3 / 10 steps, every bit (the first steps, before the tiling stands; the
+    1000-step run of the same world on LDS tiles + lean graphs is tests/test_gpu_fullsize.py)."""
     ffi = _oracle_threads()
     try:
         g, _ = _compare(S.large_pyramid(200), [1, 3, 10])
@@ -102,7 +103,8 @@ def test_large_pyramid_full_size_bit_exact():
 
 
 def test_many_pyramids_c4_single_gpu_bit_exact():
-    """BASELINE config C4 (b3d_many_pyramids scaled to 54 x 54 = 2,916 pyramids = 160,380 cuboids) on ONE GPU: 1 and 5 steps."""
+    """BASELINE config C4 (b3d_many_pyramids scaled to 54 x 54 = 2,916 pyramids = 160,380 cuboids) on ONE GPU: 1 and 5 steps (120 steps
+    with fast steps, replays and full steps: tests/test_gpu_fullsize.py)."""
     ffi = _oracle_threads()
     try:
         g, _ = _compare(S.many_pyramids(54, 54), [1, 5])
@@ -114,7 +116,7 @@ def test_many_pyramids_c4_single_gpu_bit_exact():
 
 def test_joint_grid_full_size_60_steps_bit_exact():
     """BASELINE config C5 at its stated size (100 x 100 balls, 19,800 spherical joints) for 60 steps, joint colours and impulses
-    included."""
+    included (1000 steps: tests/test_gpu_fullsize.py)."""
     ffi = _oracle_threads()
     try:
         g, o = _compare(S.joint_grid(100), [1, 20, 60])

@@ -23,10 +23,10 @@ def test_library_exports_every_declared_symbol():
 
 def test_descriptor_layouts_match_header():
     # sizes implied by include/rapier_hip.h (all 4-byte fields, no padding)
-    assert S.PARAMS_DTYPE.itemsize == 14 * 4 + 8 * 4
+    assert S.PARAMS_DTYPE.itemsize == 14 * 4 + 8 * 4 + 2 * 4  # ... + min_ccd_dt + contact_clustering
     assert S.BODY_DTYPE.itemsize == 4 + 12 + 16 + 12 + 12 + 4 * 4 + 5 * 4 + 4 + 4  # ... + additional_solver_iterations + ccd_enabled
     assert S.COLLIDER_DTYPE.itemsize == 4 + 12 + 12 + 16 + 12 + 8 + 8 + 8 + 4 + 4  # ... + sensor + border_radius
-    assert S.JOINT_DTYPE.itemsize == 8 + 24 + 32 + 8 + 4 + 48 + 4 + 6 * 24 + 4  # ... + coupled_axes
+    assert S.JOINT_DTYPE.itemsize == 16 + 24 + 32 + 8 + 4 + 48 + 4 + 6 * 24 + 4 + 4  # two 64-bit body handles ... + coupled_axes + reserved
     assert C.sizeof(_ffi.Counters) == 9 * 4 + 23 * 4  # ... + num_tiles, tile_sweeps, bp_large_list, lean_steps, fused_steps, num_islands, num_global_bodies
     p = S.default_params()
     q = np.zeros((), S.PARAMS_DTYPE)
@@ -92,7 +92,7 @@ def test_partition_scene_keeps_islands_and_replicates_fixed():
 def test_header_documents_scope_limits():
     hdr = open(os.path.join(ROOT, "include", "rapier_hip.h")).read()
     # what the device path refuses is stated where the entry points are declared
-    assert "compound bodies" in hdr and "coupled axes are not part" in hdr
+    assert "compound bodies" in hdr and "a stale or removed handle is refused" in hdr and "a world that holds a compound / mesh / height" in hdr
 
 
 def test_column_shard_global_ids_partition_the_world():
