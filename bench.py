@@ -314,10 +314,27 @@ def run(args, make_world=None, backend: str = "nccl", use_cuda: bool = True):
     # readback (not timed): assemble the world state with one all-gather over RCCL/xGMI
     pos, vel = w.read_bodies()
     finite = bool(np.isfinite(pos).all())
-    gathered = None
+    gathered, readback = None, None
     if dist is not None:
         dyn = np.array([int(b["body_type"]) == S.BODY_DYNAMIC for b in scene.bodies])
-        gathered = sharding.all_gather_bodies(pos, vel, gids, n_global, dyn, device=dev)
+        readback = "torch.distributed all_gather of host-packed rows (gloo leg / worlds without the native collective)"
+        if backend == "nccl" and coll_on_device and hasattr(w, "shard_all_gather"):
+            # the library's own collective: k_pack_bodies -> ncclAllGather on the world's stream -> D2H of the gathered rows;
+            # torch.distributed only carries the 128-byte ncclUniqueId and the agreed row count
+            from rapier_amd import ShardComm
+            idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                idt = torch.frombuffer(bytearray(ShardComm.unique_id()), dtype=torch.uint8).to(dev)
+            dist.broadcast(idt, src=0)
+            comm = ShardComm(bytes(idt.cpu().numpy().tobytes()), world, rank, local_rank)
+            rows = torch.tensor([int(dyn.sum())], dtype=torch.int64, device=dev)
+            dist.all_reduce(rows, op=dist.ReduceOp.MAX)
+            gp, gv, per = sharding.all_gather_bodies_native(w, comm, pos, vel, gids, n_global, dyn, max(1, int(rows.item())))
+            gathered = (gp, gv)
+            readback = f"rp_shard_all_gather: k_pack_bodies -> ncclAllGather (librccl, world stream) -> one D2H; rows per rank {per.tolist()}"
+            comm.close()
+        else:
+            gathered = sharding.all_gather_bodies(pos, vel, gids, n_global, dyn, device=dev)
         finite = finite and bool(np.isfinite(gathered[0]).all())
 
     per_rank_paths = None
@@ -359,7 +376,7 @@ def run(args, make_world=None, backend: str = "nccl", use_cuda: bool = True):
             "roofline": roof,
             "finite": finite,
             "dist": None if dist is None else {"backend": backend, "world_size": world, "forced": bool(args.force_dist), "shard_source": shard_source,
-                                               "gathered_bodies": None if gathered is None else int(gathered[0].shape[0]),
+                                               "gathered_bodies": None if gathered is None else int(gathered[0].shape[0]), "readback": readback,
                                                "per_rank_step_paths": per_rank_paths},
         }
         if not args.no_cpu_baseline and is_metric_workload:

@@ -389,6 +389,32 @@ int32_t rp_world_begin_subworld(rp_world *w);
 int32_t rp_step_many(rp_world *const *worlds, int32_t n, int32_t steps);
 int32_t rp_num_bodies(const rp_world *w);
 
+/* ---- The collective of a sharded world (no reference counterpart: the reference is one address space) ----------
+ * Islands shard over the GPUs of a node, one process and one rp_world per GPU, with no collective in a step.  What crosses xGMI is ONE
+ * RCCL all-gather of packed body state when a caller wants the whole world back.  RCCL (librccl.so.1) is bound at run time when the
+ * first communicator is asked for; the library has no link-time dependency on it. */
+typedef struct rp_comm rp_comm;
+typedef struct rp_comm_id { char internal[128]; } rp_comm_id; /* ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128) */
+/* ncclGetUniqueId: called by ONE rank; the 128 bytes travel to the other ranks by any host channel (MPI, a file, torch.distributed). */
+int32_t rp_comm_unique_id(rp_comm_id *id_out);
+/* ncclCommInitRank on `device` (collective: every rank of the job calls it with the same id and world_size). */
+int32_t rp_comm_create(const rp_comm_id *id, int32_t world_size, int32_t rank, int32_t device, rp_comm **out);
+int32_t rp_comm_destroy(rp_comm *c);
+const char *rp_comm_last_error(const rp_comm *c); /* c == NULL: the calling thread's last rp_comm_unique_id / rp_comm_create failure */
+/* The global id of every arena row of this shard (ids[i] for body index i; rows beyond n, and a world that never calls this, use the
+ * arena index): what the packed rows carry so that a gather can be scattered into the order of the unsharded world. */
+int32_t rp_world_set_global_ids(rp_world *w, int32_t n, const int64_t *ids);
+/* Packs the state of the world's live non-fixed bodies ON THE DEVICE (pending steps run first): one 64-byte row per body =
+ * { int64 global id, translation xyz, rotation xyzw, linvel xyz, angvel xyz, 0 } (16 words), rows in no particular order.  Hands out
+ * the device pointer (owned by the world, valid until the next pack / gather / destroy) and the row count. */
+int32_t rp_world_pack_bodies(rp_world *w, const void **dev_rows_out, int32_t *n_rows_out);
+/* The readback collective: packs this shard's bodies (as above, padded with id -1 rows to rows_per_rank — a value every rank agrees on,
+ * >= the largest shard's body count), ncclAllGather on the world's stream (device to device over xGMI; no host copy in front of it),
+ * one D2H of the gathered rows, and a scatter by global id into pos7_out[7 * n_global] / vel6_out[6 * n_global] (either may be NULL;
+ * rows nobody owns — the replicated fixed bodies — are left as the caller initialised them).  rows_of_rank_out (optional,
+ * world_size ints) = the bodies each rank contributed.  RP_ERR_CAPACITY when this rank owns more than rows_per_rank bodies. */
+int32_t rp_shard_all_gather(rp_world *w, rp_comm *c, int32_t rows_per_rank, int64_t n_global, float *pos7_out, float *vel6_out, int32_t *rows_of_rank_out);
+
 /* NarrowPhase::contact_pairs() analogue: for each active solver manifold: (collider1, collider2,
  * colour, num solver contacts), world normal, total normal impulse per solver contact.
  * Returns the number of active manifolds (may exceed cap; only cap are written). */

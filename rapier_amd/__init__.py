@@ -2,5 +2,5 @@
 from . import scenes  # noqa: F401
 from .world import (  # noqa: F401
     ColliderHandle, ColliderSet, ImpulseJointSet, IntegrationParameters, PhysicsPipeline, PhysicsWorld,
-    RapierHipError, RigidBodyHandle, RigidBodySet, step_many,
+    RapierHipError, RigidBodyHandle, RigidBodySet, ShardComm, step_many,
 )

@@ -23,6 +23,7 @@ SYMBOLS = [
     "rp_quarantine_read", "rp_step",
     "rp_sync", "rp_bodies_read", "rp_bodies_write", "rp_bodies_add_force", "rp_bodies_apply_impulse", "rp_bodies_wake_up", "rp_bodies_set_additional_solver_iterations", "rp_bodies_is_sleeping", "rp_bodies_persistent_island", "rp_bodies_proximity_group", "rp_world_set_shard_guard", "rp_world_shard_guard_take_hits", "rp_world_max_linear_speed", "rp_world_set_shard_guard_horizon", "rp_world_begin_subworld", "rp_step_many", "rp_bodies_handles", "rp_colliders_handles", "rp_impulse_joints_handles", "rp_convex_polyhedron_create", "rp_convex_polyhedron_read", "rp_bodies_set_next_kinematic_position", "rp_num_bodies", "rp_contacts_read",
     "rp_collision_events_read", "rp_intersection_pairs_read", "rp_contact_force_events_read", "rp_counters_enable", "rp_counters_read", "rp_solver_loop_time_ms",
+    "rp_comm_unique_id", "rp_comm_create", "rp_comm_destroy", "rp_comm_last_error", "rp_world_set_global_ids", "rp_world_pack_bodies", "rp_shard_all_gather",
 ]
 
 
@@ -104,9 +105,16 @@ def lib():
     L.rp_counters_enable.argtypes = [vp, i32]
     L.rp_counters_read.argtypes = [vp, vp]
     L.rp_solver_loop_time_ms.argtypes = [vp, C.POINTER(f32), C.POINTER(i32)]
+    L.rp_comm_unique_id.argtypes = [vp]
+    L.rp_comm_create.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
+    L.rp_comm_destroy.argtypes = [vp]
+    L.rp_comm_last_error.argtypes = [vp]; L.rp_comm_last_error.restype = C.c_char_p
+    L.rp_world_set_global_ids.argtypes = [vp, i32, vp]
+    L.rp_world_pack_bodies.argtypes = [vp, C.POINTER(vp), C.POINTER(i32)]
+    L.rp_shard_all_gather.argtypes = [vp, vp, i32, C.c_int64, vp, vp, vp]
     for name in SYMBOLS:
         fn = getattr(L, name)
-        if name not in ("rp_last_error", "rp_default_params"):
+        if name not in ("rp_last_error", "rp_default_params", "rp_comm_last_error"):
             fn.restype = i32
     _LIB = L
     return L

@@ -174,6 +174,11 @@ struct rp_world {
     int *old_pinned = nullptr;
     std::vector<int> old_active_joint_ids;
     unsigned *d_speed = nullptr; // rp_world_max_linear_speed's reduction cell
+    // rp_world_pack_bodies / rp_shard_all_gather (rp_api_comm.inc): global body ids (host, per arena row; empty = the arena index), their
+    // device copy + the free-slot mask, the packed rows of this shard, the gathered rows of every rank
+    std::vector<int64_t> global_ids; bool global_ids_dirty = true;
+    void *d_gid = nullptr, *d_skip = nullptr, *d_pack = nullptr, *d_gather = nullptr; int *d_pack_count = nullptr;
+    int pack_cap = 0, pack_tables_rows = -1; uint32_t pack_tables_edit = 0; size_t gather_cap = 0;
     void *d_puts = nullptr;      // PutBatch's record buffer (rp_api_device.inc)
     float guard_horizon = 0.0f;  // rp_world_set_shard_guard_horizon
     // shard guard (rp_world_set_shard_guard): host copy, re-uploaded whenever the device world is rebuilt
@@ -480,6 +485,7 @@ extern "C" int32_t rp_world_destroy(rp_world *w) {
     for (void *&b : w->cv_dev) if (b) { hipFree(b); b = nullptr; }
     for (void *&b : w->cm_dev) if (b) { hipFree(b); b = nullptr; }
     if (w->d_speed) { hipFree(w->d_speed); w->d_speed = nullptr; }
+    for (void **b : {&w->d_gid, &w->d_skip, &w->d_pack, &w->d_gather, (void **)&w->d_pack_count}) if (*b) { hipFree(*b); *b = nullptr; }
     if (w->d_puts) { hipFree(w->d_puts); w->d_puts = nullptr; }
     for (auto &e : w->ev) if (e) hipEventDestroy(e);
     if (w->stream) hipStreamDestroy(w->stream);
@@ -517,3 +523,4 @@ extern "C" int32_t rp_num_bodies(const rp_world *w) { return w ? (int32_t)w->bod
 #include "rp_api_access.inc"
 #include "rp_api_edits.inc"
 #include "rp_api_readback.inc"
+#include "rp_api_comm.inc"

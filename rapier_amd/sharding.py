@@ -110,6 +110,22 @@ def all_gather_bodies(local_pos: np.ndarray, local_vel: np.ndarray, global_ids: 
     return pos, vel
 
 
+def all_gather_bodies_native(world_obj, comm, local_pos: np.ndarray, local_vel: np.ndarray, global_ids: np.ndarray, n_global: int,
+                             dynamic_mask_local: np.ndarray, rows_per_rank: int):
+    """The same read-back through the library's own collective (include/rapier_hip.h: rp_shard_all_gather): the shard's bodies are packed
+    ON THE DEVICE, one ncclAllGather on the world's stream moves them between the GPUs, one D2H of the gathered rows follows the RCCL
+    kernel — no body state touches the host before the collective.  `comm` = rapier_amd.ShardComm over the job's ranks,
+    rows_per_rank = a value every rank agrees on, >= the largest shard's dynamic-body count.  Returns (pos, vel, rows_per_rank_seen)."""
+    world_obj.set_global_ids(np.ascontiguousarray(global_ids, np.int64))
+    pos = np.zeros((n_global, 7), np.float32)
+    vel = np.zeros((n_global, 6), np.float32)
+    fixed = ~dynamic_mask_local.astype(bool)   # fixed bodies are replicated: take them from the local copy
+    pos[global_ids[fixed]] = local_pos[fixed]
+    vel[global_ids[fixed]] = local_vel[fixed]
+    per = world_obj.shard_all_gather(comm, rows_per_rank, pos, vel)
+    return pos, vel, per
+
+
 def column_shard_global_ids(rows: int, cols_per_rank: int, base_count: int, world_size: int, rank: int) -> np.ndarray:
     """Global body ids of rank `rank`'s bodies when a rows x (cols_per_rank * world_size) many_pyramids world is sharded by
     pyramid columns (bench.py --gpus N): local body 0 is the replicated ground (global 0); the generator emits pyramids row by

@@ -617,9 +617,67 @@ class PhysicsWorld:
         self._lib.rp_solver_loop_time_ms(self._ptr, C.byref(avg), C.byref(n))
         return float(avg.value), int(n.value)
 
+    # ---- the collective of a sharded world (include/rapier_hip.h: rp_world_set_global_ids / rp_world_pack_bodies / rp_shard_all_gather) ----
+    def set_global_ids(self, ids):
+        """ids[i] = the id body row i carries in a packed / gathered row (its index in the unsharded world)"""
+        a = np.ascontiguousarray(ids, dtype=np.int64)
+        _check(self._ptr, self._lib.rp_world_set_global_ids(self._ptr, len(a), a.ctypes.data), "rp_world_set_global_ids")
+
+    def pack_bodies(self):
+        """(device pointer, rows): this shard's live non-fixed bodies packed on the device, one 64-byte row each"""
+        import ctypes as C
+        ptr, n = C.c_void_p(), C.c_int32()
+        _check(self._ptr, self._lib.rp_world_pack_bodies(self._ptr, C.byref(ptr), C.byref(n)), "rp_world_pack_bodies")
+        return ptr.value, int(n.value)
+
+    def shard_all_gather(self, comm: "ShardComm", rows_per_rank: int, pos: np.ndarray, vel: np.ndarray):
+        """pack -> ncclAllGather on the world's stream -> scatter by global id into pos[n_global, 7] / vel[n_global, 6] (in place; rows no
+        rank owns keep their values).  Returns the number of bodies every rank contributed."""
+        assert pos.dtype == np.float32 and vel.dtype == np.float32 and pos.flags.c_contiguous and vel.flags.c_contiguous and len(pos) == len(vel)
+        per = np.zeros(comm.world_size, np.int32)
+        _check(self._ptr, self._lib.rp_shard_all_gather(self._ptr, comm._ptr, int(rows_per_rank), len(pos), pos.ctypes.data, vel.ctypes.data, per.ctypes.data), "rp_shard_all_gather")
+        return per
+
     def close(self):
         if getattr(self, "_ptr", None):
             self._lib.rp_world_destroy(self._ptr)
+            self._ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ShardComm:
+    """rp_comm: one RCCL communicator over the ranks of a job (ncclCommInitRank), bound by the library at run time.  Rank 0 calls
+    ShardComm.unique_id() and hands the 128 bytes to the other ranks by any host channel; then every rank constructs its ShardComm."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+        buf = (C.c_char * 128)()
+        rc = _ffi.lib().rp_comm_unique_id(C.byref(buf))
+        if rc != 0:
+            raise RapierHipError(f"rp_comm_unique_id failed ({rc}): {_ffi.lib().rp_comm_last_error(None).decode()}")
+        return bytes(buf)
+
+    def __init__(self, unique_id: bytes, world_size: int, rank: int, device: int = 0):
+        import ctypes as C
+        assert len(unique_id) == 128
+        self._lib = _ffi.lib()
+        self.world_size, self.rank, self.device = int(world_size), int(rank), int(device)
+        buf = (C.c_char * 128).from_buffer_copy(unique_id)
+        p = C.c_void_p()
+        rc = self._lib.rp_comm_create(C.byref(buf), self.world_size, self.rank, self.device, C.byref(p))
+        if rc != 0 or not p.value:
+            raise RapierHipError(f"rp_comm_create failed ({rc}): {self._lib.rp_comm_last_error(None).decode()}")
+        self._ptr = p
+
+    def close(self):
+        if getattr(self, "_ptr", None):
+            self._lib.rp_comm_destroy(self._ptr)
             self._ptr = None
 
     def __del__(self):

@@ -26,7 +26,7 @@ def test_rust_shim_structs_and_exports_equal_the_header():
 def test_every_header_struct_and_export_is_bound_by_the_shim():
     hs, hf = abi_parse.parse_header()
     rs, rf = abi_parse.parse_rust(abi_parse.rust_block())
-    assert len(hs) == 8 and set(abi_parse.RUST_NAME[c] for c in hs) <= set(rs)   # params, body, collider, 2 events, motor, joint, counters
+    assert len(hs) == 9 and set(abi_parse.RUST_NAME[c] for c in hs) <= set(rs)   # params, body, collider, 2 events, motor, joint, counters, comm id
     assert set(hf) == set(rf) == set(_ffi.SYMBOLS) and len(hf) >= 50
     # the fields whose loss VERDICT r5 reported, by name
     assert ("ccd_enabled", "i32", 1) in rs["BodyDesc"]

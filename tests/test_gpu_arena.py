@@ -232,6 +232,11 @@ def test_impulse_joint_handles_are_generational_and_bodies_are_named_by_handle()
     g.step(20)
     pos, _ = g.read_bodies()
     assert np.isfinite(pos).all()
-    # the chain gb - b0, b1 - b2 - nb holds: the joined anchors stay together
-    assert abs(np.linalg.norm(pos[balls[0], :3] - pos[gb, :3]) - 1.0) < 0.05
-    assert abs(np.linalg.norm(pos[balls[3], :3] - pos[balls[2], :3]) - 1.0) < 0.05
+    # the chain gb - b0, b1 - b2 - nb holds: the two anchors of every live joint coincide in world space
+    def anchor(b, local):
+        t, (x, y, z, w_) = pos[b, :3].astype(np.float64), pos[b, 3:].astype(np.float64)
+        u = np.array([x, y, z]); v = np.asarray(local, np.float64)
+        return t + v + 2.0 * np.cross(u, np.cross(u, v) + w_ * v)
+    for b1, b2 in ((gb, balls[0]), (balls[1], balls[2]), (balls[2], balls[3])):
+        assert np.linalg.norm(anchor(b1, (0.5, 0, 0)) - anchor(b2, (-0.5, 0, 0))) < 0.02, (b1, b2)
+    assert np.linalg.norm(anchor(balls[0], (0.5, 0, 0)) - anchor(balls[1], (-0.5, 0, 0))) > 0.05   # the removed joint holds nothing

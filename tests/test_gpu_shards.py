@@ -71,3 +71,28 @@ def test_guard_fires_when_a_body_reaches_another_shards_box():
     w2.write_bodies([local_top], vel6=[[toward * 40.0, 5.0, 0.0, 0.0, 0.0, 0.0]])
     w2.step(40)
     w2.read_bodies()
+
+
+def test_native_collective_packs_on_the_device_and_gathers_through_rccl():
+    """SURVEY 8(e)'s one collective through the library itself (rp_world_pack_bodies / rp_shard_all_gather): a one-rank RCCL communicator
+    (ncclCommInitRank bound at run time from librccl.so.1), the shard's bodies packed by a kernel, ncclAllGather on the world's stream,
+    scatter by global id.  The gathered rows equal rp_bodies_read of the shard, the rows of the other shard stay untouched."""
+    from rapier_amd import ShardComm
+    full = S.many_pyramids(rows=2, cols=4)
+    body_rank = sharding.many_pyramids_body_ranks(2, 4, 10, 2)
+    sub, gids = sharding.partition_scene(full, body_rank, 0)
+    g = PhysicsWorld.from_scene(sub)
+    g.step(7)
+    pos, vel = g.read_bodies()
+    dyn = np.array([int(b["body_type"]) == S.BODY_DYNAMIC for b in sub.bodies])
+    ptr, n = g.pack_bodies()
+    assert ptr and n == int(dyn.sum()) == 4 * 55
+    comm = ShardComm(ShardComm.unique_id(), 1, 0, 0)
+    gp, gv, per = sharding.all_gather_bodies_native(g, comm, pos, vel, gids, len(full.bodies), dyn, rows_per_rank=n + 13)
+    assert per.tolist() == [n]
+    np.testing.assert_array_equal(gp[gids], pos); np.testing.assert_array_equal(gv[gids], vel)
+    others = np.setdiff1d(np.arange(len(full.bodies)), gids)
+    assert len(others) == 4 * 55 and not gp[others].any() and not gv[others].any()
+    with pytest.raises(Exception):   # a row budget below the shard's size is refused, not truncated
+        sharding.all_gather_bodies_native(g, comm, pos, vel, gids, len(full.bodies), dyn, rows_per_rank=n - 1)
+    comm.close()

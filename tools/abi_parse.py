@@ -16,11 +16,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "rapier_hip.h")
 INTEGRATION = os.path.join(ROOT, "INTEGRATION.md")
 
-SCALARS = {"int32_t": ("i32", 4), "uint32_t": ("u32", 4), "uint64_t": ("u64", 8), "float": ("f32", 4), "char": ("c_char", 1), "void": ("c_void", 0)}
+SCALARS = {"int32_t": ("i32", 4), "uint32_t": ("u32", 4), "uint64_t": ("u64", 8), "int64_t": ("i64", 8), "float": ("f32", 4), "char": ("c_char", 1), "void": ("c_void", 0)}
 # the reference-side names of the ABI's structs (what a rapier maintainer would call them)
 RUST_NAME = {"rp_integration_params": "IntegrationParameters", "rp_body_desc": "BodyDesc", "rp_collider_desc": "ColliderDesc",
              "rp_collision_event": "CollisionEventRaw", "rp_contact_force_event": "ContactForceEventRaw", "rp_joint_motor": "JointMotor",
-             "rp_joint_desc": "GenericJoint", "rp_counters": "Counters", "rp_world": "RpWorld"}
+             "rp_joint_desc": "GenericJoint", "rp_counters": "Counters", "rp_world": "RpWorld", "rp_comm": "RpComm", "rp_comm_id": "CommId"}
 
 
 def _strip_c_comments(txt: str) -> str:
@@ -167,7 +167,7 @@ def compare(header=HEADER, integration=INTEGRATION):
 def generate() -> str:
     """the FFI layer of the Rust shim, generated from the header"""
     hs, hf = parse_header()
-    lines = ["use std::os::raw::c_char;", ""]
+    lines = ["use std::os::raw::{c_char, c_void};", ""]
     for cname, fields in hs.items():
         rname = RUST_NAME[cname]
         derive = "#[repr(C)] #[derive(Clone, Copy)]"
@@ -178,7 +178,7 @@ def generate() -> str:
                 rt = f"[{rt}; {d}]"
             lines.append(f"    pub {f}: {rt},")
         lines.append("}")
-    lines += ["#[repr(C)] pub struct RpWorld { _private: [u8; 0] }", "", '#[link(name = "rapier_hip")]', 'extern "C" {']
+    lines += ["#[repr(C)] pub struct RpWorld { _private: [u8; 0] }", "#[repr(C)] pub struct RpComm { _private: [u8; 0] }", "", '#[link(name = "rapier_hip")]', 'extern "C" {']
     txt = _strip_c_comments(open(HEADER).read())
     for name, (ret, args) in hf.items():
         m = re.search(r"\b" + name + r"\s*\(([^;{]*?)\)\s*;", txt, flags=re.S)
