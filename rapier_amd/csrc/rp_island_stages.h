@@ -181,12 +181,20 @@ RP_DEV void isl_pose_stage(const DevWorld &w, IslSide &h, const IslLds &L, int m
 #define WS_STRIDE (ISL_LANES + 2) // rows of one slot: every lane's row + two scratch rows for world-attached sides
 // every term at once (11 slots); the register-lean form of the kernel writes the linear and the angular terms in two phases into 6 slots
 // (lean_ws_terms, rp_islands_lean.h: 31 KB of LDS instead of 57 KB, which is what lets two islands share a CU)
+// DENSE: every one of the 11 rows is written — the rows of points a manifold does not have (and the twist row of a one-point manifold)
+// hold -0.0, the one float whose addition changes no bit of any accumulator (x + -0.0 == x for every x, +0.0 and -0.0 included) — so
+// that the body threads add a toucher's rows without reading its point count: no compare / select on their dependent chain
+// (isl_ws_accumulate_*_dense; round 6).
+template <bool DENSE = false>
 RP_DEV void isl_ws_terms(const DevWorld &w, IslSide &h, float4 *W, int t) { // t = this lane's row in W (its rank in its body's list)
     float wc = w.prm.p.warmstart_coefficient;
     bool ws = wc != 0.0f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if (k >= h.n) break;
+        if (k >= h.n) {
+            if constexpr (DENSE) { if (ws) { const float4 z = make_float4(-0.0f, -0.0f, -0.0f, 0.0f); for (int j = k; j < 4; ++j) { W[(2 * j) * WS_STRIDE + t] = z; W[(2 * j + 1) * WS_STRIDE + t] = z; } } }
+            break;
+        }
         SidePoint &p = h.P[k];
         p.rhs = p.rhsB; p.cfm = p.cfmB;
         p.acc += p.lam;
@@ -208,6 +216,24 @@ RP_DEV void isl_ws_terms(const DevWorld &w, IslSide &h, float4 *W, int t) { // t
         W[8 * WS_STRIDE + t] = f4(cmul(h.t0 * s0 + h.t1 * s1, h.im), __int_as_float(h.n));
         W[9 * WS_STRIDE + t] = f4(h.itd0 * i0 + h.itd1 * i1, 0.0f);
         if (h.n > 1) W[10 * WS_STRIDE + t] = f4(h.stw * tw, 0.0f);
+        else if constexpr (DENSE) W[10 * WS_STRIDE + t] = make_float4(-0.0f, -0.0f, -0.0f, 0.0f);
+    }
+}
+// the body threads' side of the dense rows: the same additions in the same order, minus the ones of -0.0 rows that change nothing
+RP_DEV void isl_ws_accumulate_lin_dense(const float4 *W, int begin, int count, V3 &lin) {
+#pragma unroll 2
+    for (int e = 0; e < count; ++e) {
+        const int row = begin + e;
+        const float4 l0 = W[0 * WS_STRIDE + row], l1 = W[2 * WS_STRIDE + row], l2 = W[4 * WS_STRIDE + row], l3 = W[6 * WS_STRIDE + row], tl = W[8 * WS_STRIDE + row];
+        lin = lin + v3(l0); lin = lin + v3(l1); lin = lin + v3(l2); lin = lin + v3(l3); lin = lin + v3(tl);
+    }
+}
+RP_DEV void isl_ws_accumulate_ang_dense(const float4 *W, int begin, int count, V3 &ang) {
+#pragma unroll 2
+    for (int e = 0; e < count; ++e) {
+        const int row = begin + e;
+        const float4 a0 = W[1 * WS_STRIDE + row], a1 = W[3 * WS_STRIDE + row], a2 = W[5 * WS_STRIDE + row], a3 = W[7 * WS_STRIDE + row], ta = W[9 * WS_STRIDE + row], tw = W[10 * WS_STRIDE + row];
+        ang = ang + v3(a0); ang = ang + v3(a1); ang = ang + v3(a2); ang = ang + v3(a3); ang = ang + v3(ta); ang = ang + v3(tw);
     }
 }
 // one thread adds the linear terms of a body, another one (64 lanes further) its angular terms
@@ -368,12 +394,31 @@ RP_DEV void island_sort(const DevWorld &w, int isl, int nc, int cb, int nst_glob
 // `slp` collects sleep_observe_fused's bits over the lane's bodies; fused_sleep_abort() reads their OR over the whole island.
 // WIDE = false: the form for worlds of one-collider bodies that never sleep (the benchmark scenes): exactly one collider and one test
 // per item, nothing else in the validators' dependent chain (A/B on C3: the wide form costs 5 us of a 73 us step).
-template <bool WIDE> RP_DEV bool fused_validate_island(const DevWorld &w, int isl, int vt, int vn, int stamp_before, int &slp) {
+// `part`: 0 = every item; 1 / 2 = the two halves of a split at `total - tail` items: part 1 the items in front of it, part 2 the last `tail`
+// ones (k_island_solve, round 6: the wavefronts that also hold the body roles take one item per lane behind their body loads, the
+// wavefronts that only validate take the rest and start with the kernel).
+template <bool WIDE> RP_DEV bool fused_validate_island(const DevWorld &w, int isl, int vt, int vn, int stamp_before, int &slp, int part = 0, int tail = 0) {
     const int nb = w.isl_nb[isl], nc = w.isl_nc[isl], ni = w.isl_ni[isl];
     const int bb = w.isl_body_begin[isl], cb = w.isl_cons_begin[isl], ib = w.isl_icons_begin[isl];
     const int ns = (WIDE && w.sleep_enabled) ? nb : 0; // the sleep observations are items of their own: other lanes than the fat-AABB tests of the same bodies
     bool bad = false;
-    for (int i = vt; i < nb + ns + nc + ni; i += vn) {
+    const int total = nb + ns + nc + ni, split = total > tail ? total - tail : 0;
+    const int i_begin = part == 2 ? split : 0, i_end = part == 1 ? split : total;
+    if constexpr (!WIDE) {
+        // the benchmark form: pairs first, bodies behind them (a lane that gets two items gets the cheaper kind second), flat loads
+        for (int i = i_begin + vt; i < i_end; i += vn) {
+            if (i < nc + ni) {
+                const int s = i < nc ? w.isl_cons[cb + i] : w.isl_icons[ib + i - nc];
+                if (pair_needs_narrow_phase_flat(w, s)) bad = true;
+            } else {
+                const int b = w.isl_bodies[bb + i - nc - ni];
+                const int c = w.b_collider[b];
+                if (c >= 0 && collider_left_fat_aabb_flat(w, c, b)) bad = true;
+            }
+        }
+        return bad;
+    }
+    for (int i = i_begin + vt; i < i_end; i += vn) {
         if (i < nb) {
             const int b = w.isl_bodies[bb + i];
             if constexpr (WIDE) {

@@ -529,7 +529,7 @@ template <bool WIDE> __device__ __forceinline__ void island_solve_body(const Dev
 #endif
     }
     bool decided = !fused, go = true;
-    __shared__ float4 B_lin[RP_ISL_NB_MAX], B_ang[RP_ISL_NB_MAX], B_rot[RP_ISL_NB_MAX], B_trans[RP_ISL_NB_MAX];
+    __shared__ float4 B_lin[RP_ISL_NB_MAX], B_ang[RP_ISL_NB_MAX], B_rot[RP_ISL_NB_MAX], B_trans[RP_ISL_NB_MAX], B_axes[RP_ISL_NB_MAX];
     __shared__ float4 L_E[4 * RP_ISL_NC_MAX], L_F[4 * RP_ISL_NC_MAX], L_B0[RP_ISL_NC_MAX], L_B1[RP_ISL_NC_MAX];
     __shared__ int S_a[RP_ISL_NC_MAX], S_b[RP_ISL_NC_MAX], S_c[RP_ISL_NC_MAX], S_d[RP_ISL_NC_MAX];
     __shared__ float4 W[WS_SLOTS * WS_STRIDE];
@@ -552,22 +552,30 @@ template <bool WIDE> __device__ __forceinline__ void island_solve_body(const Dev
         long long t_prev = (long long)__builtin_readcyclecounter();
 #endif
         if (!w.isl_sorted[isl]) island_sort(w, isl, nc, cb, nst_global, S_a, S_b, S_c, S_d);
+        const int v_first = (2 * nc + 63) & ~63; // first wavefront without any manifold lane
         // ---- bodies -> LDS (+ per-body constants in the owning thread's registers) (S0) ----
-        // threads [0, nb) own the linear half of body t (and integrate / write it back), threads
-        // [64, 64 + nb) the angular half of body t - 64: the two halves of the increment and of the
-        // body-centric warm start are independent chains
+        // The body roles live in the wavefronts that hold NO manifold lane (round 6): threads [320, 320 + nb) own the linear half of
+        // body t - 320 (and integrate / write it back), threads [384, 384 + nb) the angular half: the two halves of the increment and of
+        // the body-centric warm start are independent chains, and on wavefronts of their own the increment (the gyroscopic term is a
+        // ~200-instruction dependent chain) runs WHILE the manifold lanes write their warm-start terms instead of behind them.
+        constexpr int ROLE_LIN0 = ISL_LANES, ROLE_ANG0 = ISL_LANES + RP_ISL_NB_MAX;
+        static_assert(ROLE_ANG0 + RP_ISL_NB_MAX <= THREADS, "the body roles need two wavefronts beyond the manifold lanes");
         const int bt = t & (RP_ISL_NB_MAX - 1);
-        const bool role_lin = t < nb, role_ang = t >= RP_ISL_NB_MAX && t < RP_ISL_NB_MAX + nb;
+        const bool role_lin = t >= ROLE_LIN0 && t < ROLE_LIN0 + nb, role_ang = t >= ROLE_ANG0 && t < ROLE_ANG0 + nb;
         int b_gid = -1, b_fl = 0;
-        V3 b_incl = v3(0, 0, 0), b_inca = b_incl, b_invpi = b_incl; Q4 b_pframe = q4(0, 0, 0, 1);
+        V3 b_inc = v3(0, 0, 0) /* the linear increment on a body's linear thread, the angular one on its angular thread */, b_invpi = b_inc, b_pi = b_inc; Q4 b_pframe = q4(0, 0, 0, 1);
         if (role_lin || role_ang) {
             int g = w.isl_bodies[bb + bt];
             V3 lin, ang, trans; Q4 rot;
-            body_begin(w, g, lin, ang, rot, trans, b_incl, b_inca);
+            V3 incl, inca;
+            body_begin(w, g, lin, ang, rot, trans, incl, inca);
             b_gid = g; b_fl = w.b_flags[g];
-            if (role_lin) { B_lin[bt] = f4(lin, 0.0f); B_rot[bt] = f4(rot); B_trans[bt] = f4(trans, 0.0f); }
-            else B_ang[bt] = f4(ang, 0.0f);
+            if (role_lin) { B_lin[bt] = f4(lin, 0.0f); B_rot[bt] = f4(rot); B_trans[bt] = f4(trans, 0.0f); b_inc = incl; }
+            else { B_ang[bt] = f4(ang, 0.0f); b_inc = inca; }
             b_invpi = v3(w.b_invpi[g]); b_pframe = q4(w.b_pframe[g]);
+            // what body_increment's gyroscopic term derives from constants / from the pose alone, once instead of on every substep's
+            // critical path: the principal inertia (three IEEE divisions) and the principal axes in world space (updated behind integrate)
+            if (role_ang && (b_fl & RP_BF_GYRO)) { b_pi = v3(rp_inv(b_invpi.x), rp_inv(b_invpi.y), rp_inv(b_invpi.z)); B_axes[bt] = f4(qmul(rot, b_pframe)); } // (each thread reads back only what it stored itself)
         }
         if (t == 0) any_bouncy = 0;
         const int nls = w.isl_nstages[isl];
@@ -591,34 +599,45 @@ template <bool WIDE> __device__ __forceinline__ void island_solve_body(const Dev
         if (live) {
             if (isl_generate(w, h, L, m, slot, own_g, own_l, odd, pair_static) && !odd) any_bouncy = 1;
         }
-        const int v_first = (2 * nc + 63) & ~63; // first wavefront without any manifold lane
         if (fused && isl == (int)blockIdx.x && t >= v_first) {
             // the wavefronts without a manifold prove, under cover of generate (the longest interval of the
             // kernel), that this island needs neither broad nor narrow phase this step: one item (a body's
             // collider, an active pair, a pair without solver contacts) per lane and round
+#ifdef RP_ISL_PROFILE
+            long long tv0 = (long long)__builtin_readcyclecounter();
+#endif
             int slp = 0;
+#ifndef RP_ISL_NOVAL
             if (fused_validate_island<WIDE>(w, isl, t - v_first, THREADS - v_first, (WIDE && w.sleep_enabled) ? pi_stamp_before(w) : 0, slp)) s_abort = 1;
+#endif
             if constexpr (WIDE) if (slp) atomicOr(&s_slp, slp);
+#ifdef RP_ISL_PROFILE
+            if (blockIdx.x == 0 && (t == v_first || t == THREADS - 1)) w.dbg[t == v_first ? 13 : 14] += (long long)__builtin_readcyclecounter() - tv0;
+#endif
         }
         if (live) isl_pose_stage(w, h, L, m, 0.0f); // each lane reads back only what it stored itself
         ISL_STAMP(1); // generate + first pose stage
 
         for (int sub = 0; sub < w.prm.num_substeps; ++sub) {
             float solved_dt = (float)sub * w.prm.dt_sub;
-            if (live) isl_ws_terms(w, h, W, ws_row); // warm-start terms of every manifold, in parallel
+            // S2 increment (worker.rs:235-284) by the body threads, side by side with the warm-start terms of every manifold ...
+            V3 inc_v = v3(0, 0, 0);
+            if (live) isl_ws_terms<true>(w, h, W, ws_row);
+            else if (role_lin) inc_v = v3(B_lin[bt]) + b_inc;
+            else if (role_ang) { // (body_increment's angular half: ang + inca, then gyroscopic_corrected_angvel with the hoisted operands)
+                inc_v = v3(B_ang[bt]) + b_inc;
+                if (b_fl & RP_BF_GYRO) inc_v = gyro_corrected(inc_v, q4(B_axes[bt]), b_pi, b_invpi, w.prm.dt_sub);
+            }
             __syncthreads(); // + pose stage read rot/trans; relax sweep of the previous substep done
             if (fused && sub == 0 && isl == (int)blockIdx.x && t == 0) atomicAdd(&w.flags[FL_ARRIVE], 1 + ((s_abort || (WIDE && fused_sleep_abort(s_slp))) ? (1 << 16) : 0)); // this workgroup validated all of its islands
-            ISL_STAMP(2); // warm-start terms
-            // S2 increment (worker.rs:235-284), then the warm start of this body in sweep order
+            ISL_STAMP(sub == 0 ? 12 : 2); // warm-start terms + increment (substep 0: + whatever the validating wavefronts still have to do)
+            // ... then the warm start of this body in sweep order
             if (role_lin) {
-                V3 lin = v3(B_lin[bt]) + b_incl;
-                if (prm.warmstart_coefficient != 0.0f) isl_ws_accumulate_lin<false>(W, inc_begin, inc_cnt, lin);
-                B_lin[bt] = f4(lin, 0.0f);
+                if (prm.warmstart_coefficient != 0.0f) isl_ws_accumulate_lin_dense(W, inc_begin, inc_cnt, inc_v);
+                B_lin[bt] = f4(inc_v, 0.0f);
             } else if (role_ang) {
-                V3 lin_unused = v3(0, 0, 0), ang = v3(B_ang[bt]);
-                body_increment(w, b_fl, lin_unused, ang, q4(B_rot[bt]), v3(0, 0, 0), b_inca, b_invpi, b_pframe);
-                if (prm.warmstart_coefficient != 0.0f) isl_ws_accumulate_ang<false>(W, inc_begin, inc_cnt, ang);
-                B_ang[bt] = f4(ang, 0.0f);
+                if (prm.warmstart_coefficient != 0.0f) isl_ws_accumulate_ang_dense(W, inc_begin, inc_cnt, inc_v);
+                B_ang[bt] = f4(inc_v, 0.0f);
             }
             __syncthreads();
             ISL_STAMP(3); // increment + body-centric warm start
@@ -629,14 +648,15 @@ template <bool WIDE> __device__ __forceinline__ void island_solve_body(const Dev
             for (int it = 0; it < prm.num_internal_pgs_iterations; ++it)
                 for (int q = 0; q < nls; ++q) { if (myq == q) isl_solve(h, L, false, fib); __syncthreads(); }
             ISL_STAMP(4); // biased sweep
-            if (t < nb) { // S6
-                V3 lin = v3(B_lin[t]), ang = v3(B_ang[t]), trans = v3(B_trans[t]); Q4 rot = q4(B_rot[t]);
+            if (role_lin) { // S6
+                V3 lin = v3(B_lin[bt]), ang = v3(B_ang[bt]), trans = v3(B_trans[bt]); Q4 rot = q4(B_rot[bt]);
                 body_integrate(w, b_fl, lin, ang, rot, trans);
-                B_lin[t] = f4(lin, 0.0f); B_ang[t] = f4(ang, 0.0f); B_rot[t] = f4(rot); B_trans[t] = f4(trans, 0.0f);
+                B_lin[bt] = f4(lin, 0.0f); B_ang[bt] = f4(ang, 0.0f); B_rot[bt] = f4(rot); B_trans[bt] = f4(trans, 0.0f);
             }
             __syncthreads();
             ISL_STAMP(5); // integrate
             if (live) isl_pose_stage(w, h, L, m, solved_dt + w.prm.dt_sub);
+            else if (role_ang && (b_fl & RP_BF_GYRO)) B_axes[bt] = f4(qmul(q4(B_rot[bt]), b_pframe)); // (the next substep's increment; rot stands until the next integrate)
             ISL_STAMP(6); // pose stage
             for (int it = 0; it < prm.num_internal_stabilization_iterations; ++it)
                 for (int q = 0; q < nls; ++q) { if (myq == q) isl_solve(h, L, true, true); __syncthreads(); }
@@ -674,7 +694,7 @@ template <bool WIDE> __device__ __forceinline__ void island_solve_body(const Dev
         }
         if (!go) break;
         if (live && !odd) isl_writeback(w, h, slot);
-        if (t < nb) body_writeback(w, b_gid, v3(B_lin[t]), v3(B_ang[t]), q4(B_rot[t]), v3(B_trans[t]));
+        if (role_lin) body_writeback(w, b_gid, v3(B_lin[bt]), v3(B_ang[bt]), q4(B_rot[bt]), v3(B_trans[bt]));
         ISL_STAMP(8); // write-back
 #ifdef RP_ISL_PROFILE
         if (blockIdx.x == 0 && threadIdx.x == 0) w.dbg[63] += 1;

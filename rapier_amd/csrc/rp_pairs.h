@@ -195,6 +195,63 @@ RP_DEV Pose collider_world_pose_of(const DevWorld &w, int i, int parent) { // pa
     Pose bp; bp.r = q4(w.b_rot[parent]); bp.t = v3(w.b_pos[parent]);
     return pose_mul(bp, lp);
 }
+// The two tests of the fused step's validators (rp_island_stages.h) in FLAT form: every load that depends on the same index is issued
+// at once and nothing is decided before the last one is back — the validating lanes walk 3 levels of dependent loads per item instead
+// of 6 (they share their SIMD with an issue-bound generate wavefront: 10.6k cycles per item before, profiles/r06_island_stage_cycles.txt).
+// Same answers as pair_needs_narrow_phase / collider_left_fat_aabb for every input (a freed slot reads row 0 and answers "no").
+RP_DEV bool pair_needs_narrow_phase_flat(const DevWorld &w, int s) {
+    const int c1 = w.p_c1[s], c2 = w.p_c2[s], pf = w.p_pflags[s];
+    const int2 rb = w.p_rb[s];
+    const float4 rt = w.r_t[s], rr = w.r_r[s], misc = w.p_misc[s], q1 = w.r_rot1[s], q2 = w.r_rot2[s];
+    const int a = c1 < 0 ? 0 : c1, b = c2 < 0 ? 0 : c2, pa = rb.x < 0 ? 0 : rb.x, pb = rb.y < 0 ? 0 : rb.y;
+    const float4 l1r = w.c_lrot[a], l1t = w.c_lpos[a], l2r = w.c_lrot[b], l2t = w.c_lpos[b];
+    const float4 b1r = w.b_rot[pa], b1t = w.b_pos[pa], b2r = w.b_rot[pb], b2t = w.b_pos[pb];
+    if (c1 < 0) return false;
+    if (w.has_composite && (pf & RP_PF_AUX)) return false;
+    if (w.n_nc && (pf & RP_PF_NO_CONTACT)) return false;
+    if (w.has_sensors && pair_is_sensor(w, c1, c2)) return false;
+    Pose pc1, pc2; pc1.r = q4(l1r); pc1.t = v3(l1t); pc2.r = q4(l2r); pc2.t = v3(l2t);
+    if (rb.x >= 0) { Pose bp; bp.r = q4(b1r); bp.t = v3(b1t); pc1 = pose_mul(bp, pc1); }
+    if (rb.y >= 0) { Pose bp; bp.r = q4(b2r); bp.t = v3(b2t); pc2 = pose_mul(bp, pc2); }
+    const Pose pos12 = pose_inv_mul(pc1, pc2);
+    // pair_recycle_ok on the operands fetched above
+    if (!(w.prm.recycle_distance > 0.0f) || !(pf & RP_PF_RECYCLE)) return true;
+    Pose base; base.t = v3(rt); base.r = q4(rr);
+    float trans = len(pos12.t - base.t);
+    Q4 d = qmul(pos12.r, qconj(base.r));
+    float drift = trans + 2.0f * len(v3(d.x, d.y, d.z)) * misc.y;
+    float ca = qdot(q4(q1), pc1.r), cb = qdot(q4(q2), pc2.r);
+    float rot_cos = rp_min(2.0f * ca * ca - 1.0f, 2.0f * cb * cb - 1.0f);
+    return !(drift <= misc.z && rot_cos > 0.98f);
+}
+// collider_left_fat_aabb for a collider whose parent is known (the body item of a validator: c = b_collider[parent]); cuboids and balls
+// only are decided here, every other shape goes to the general form
+RP_DEV bool collider_left_fat_aabb_flat(const DevWorld &w, int i, int parent) {
+    const float4 lr = w.c_lrot[i], lt = w.c_lpos[i], he = w.c_he[i], fmn = w.c_fatmin[i], fmx = w.c_fatmax[i];
+    const int shape = w.c_shape[i];
+    const float4 br = w.b_rot[parent], bt = w.b_pos[parent];
+    if (shape != RP_SHAPE_CUBOID && shape != RP_SHAPE_BALL) return collider_left_fat_aabb(w, i);
+    Pose lp; lp.r = q4(lr); lp.t = v3(lt);
+    Pose bp; bp.r = q4(br); bp.t = v3(bt);
+    const Pose pos = pose_mul(bp, lp);
+    bool finite = isfinite(pos.t.x) && isfinite(pos.t.y) && isfinite(pos.t.z) && isfinite(pos.r.x) && isfinite(pos.r.y) &&
+                  isfinite(pos.r.z) && isfinite(pos.r.w);
+    if (!finite) return true;
+    V3 h;
+    if (shape == RP_SHAPE_CUBOID) {
+        float m[3][3]; quat_to_mat(pos.r, m);
+        h = v3(fabsf(m[0][0]) * he.x + fabsf(m[0][1]) * he.y + fabsf(m[0][2]) * he.z,
+               fabsf(m[1][0]) * he.x + fabsf(m[1][1]) * he.y + fabsf(m[1][2]) * he.z,
+               fabsf(m[2][0]) * he.x + fabsf(m[2][1]) * he.y + fabsf(m[2][2]) * he.z);
+    } else {
+        h = v3(he.x, he.x, he.x);
+    }
+    float loosen = w.prm.prediction / 2.0f;
+    V3 mn = pos.t - h - v3(loosen, loosen, loosen);
+    V3 mx = pos.t + h + v3(loosen, loosen, loosen);
+    bool inside = fmn.x <= mn.x && fmn.y <= mn.y && fmn.z <= mn.z && fmx.x >= mx.x && fmx.y >= mx.y && fmx.z >= mx.z;
+    return !inside;
+}
 RP_DEV bool pair_needs_narrow_phase(const DevWorld &w, int s) {
     int c1 = w.p_c1[s];
     if (c1 < 0) return false;

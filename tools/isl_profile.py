@@ -18,8 +18,10 @@ L = _ffi.lib()
 L.rp_debug_cycles.argtypes = [C.c_void_p, C.c_void_p]
 L.rp_debug_cycles(w._ptr, buf.ctypes.data)
 n = max(int(buf[63]), 1)
-names = ["load", "generate+pose0", "ws terms", "incr+ws accumulate", "biased sweep", "integrate", "pose stage", "relax sweep", "writeback", "extra empty sweep", "fused: validate+arrive", "fused: wait for arrivals"]
-tot = buf[:12].sum() / n
+names = ["load", "generate+pose0", "ws terms + increment (substeps 1..)", "ws accumulate", "biased sweep", "integrate", "pose stage", "relax sweep", "writeback", "extra empty sweep", "fused: validate+arrive", "fused: wait for arrivals",
+         "ws terms + increment (substep 0: incl. the wait for the validating wavefronts)"]
+print(f"validation as its own wavefronts see it: first validating lane {buf[13] / n:.0f} cycles, last lane {buf[14] / n:.0f} cycles (both start at the barrier behind the body loads)")
+tot = buf[:13].sum() / n
 for k, nm in enumerate(names):
-    print(f"{nm:18s} {buf[k] / n:10.0f} cycles/step  {100.0 * buf[k] / n / tot:5.1f}%")
+    print(f"{nm:38s} {buf[k] / n:10.0f} cycles/step  {100.0 * buf[k] / n / tot:5.1f}%")
 print(f"total {tot:.0f} cycles/step over {n} steps")
