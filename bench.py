@@ -307,6 +307,13 @@ def run(args, make_world=None, backend: str = "nccl", use_cuda: bool = True):
                 "hbm_frac": hbm_frac,
                 "kernel": kernel_name,
                 "algorithmic_bytes_per_launch": bytes_step, "kernel_ms_per_launch": loop_ms, "measured_launches": nmeas,
+                # what `kernel_ms_per_launch` was measured on (rp_api_step.inc launch_step with timers on): C3 / C4 = the SAME one-kernel fused
+                # step the timed region runs (k_island_solve validating the step itself), launched directly between two hipEvents on the
+                # world's stream; every timed step is waited for before the next is enqueued, so — unlike in the timed region — no launch
+                # overlaps the tail of its predecessor (ms_per_step can therefore be a little BELOW kernel_ms_per_launch)
+                "timed_form": ("one-kernel fused step (k_island_solve / k_island_solve_dense), launched directly between two hipEvents, one step at a time"
+                               if tc["velocity_update_ms"] <= tc["velocity_resolution_ms"] else
+                               "the solver-loop launches of a full / lean step (tile sweeps or colour-stage launches) between two hipEvents, one step at a time"),
                 "traffic_note": traffic_note, "kernel_code_sha": kernel_code_sha(wkey), "joint_rows": jrows,
                 "stage_ms": {k: tc[k] for k in ("collision_detection_ms", "velocity_resolution_ms", "velocity_update_ms")},
                 "path": {k: tc[k] for k in ("fast_steps", "full_steps", "replayed_steps")}}

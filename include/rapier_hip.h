@@ -223,6 +223,9 @@ typedef struct rp_counters {
     int32_t fused_steps;           /* of fast_steps: those enqueued as the ONE-kernel fused step (k_island_solve validates the step itself) */
     int32_t num_islands;           /* contact islands the last layout rebuild handed to the LDS-resident island kernel (a bundle of tiny islands counts once) */
     int32_t num_global_bodies;     /* awake dynamic bodies it left to the global solver path (components too large for an island, bodies with joints, free bodies) */
+    int32_t fused_disabled;        /* how often a fused step waited ~1 s for a workgroup that never became resident (another process or stream
+                                    * holds CUs): that step was aborted and replayed, and from the first such event on this world no longer
+                                    * uses the one-kernel fused step (it keeps the two-kernel fast graph) — nonzero = the world lost its fastest path */
 } rp_counters;
 
 #define RP_INVALID_HANDLE 0xffffffffffffffffull

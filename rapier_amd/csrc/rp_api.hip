@@ -212,13 +212,14 @@ struct rp_world {
     int pairs_scale = 1;           // the pair pool holds RP_PAIRS_PER_COLLIDER x pairs_scale slots per collider row: doubled when the pool fills up (rp_step)
     int cur_fast = 0;              // mode the enqueue_* callbacks capture
     long long steps_requested = 0; // steps asked for since finalize (device FL_STEP counts the executed ones)
-    int rebase_at = 1 << 30;       // FL_STEP beyond which the device's 32-bit step stamps move back (k_rebase_stamps)
+    int rebase_at = 1 << 29;       // FL_STEP beyond which the device's 32-bit step stamps move back (k_rebase_stamps); the wake stamp is 2 * step + phase and
+                                   // settles that look at the counter may be 2^20 steps apart: 2 * (2^29 + 2^20) stays inside an int
     long long rebases = 0;
     long long seq_enqueued = 0;    // step graphs enqueued since finalize (device FL_SEQ counts the retired ones)
     long long full_until = 0;      // stay on the full graph until this many steps were requested
     long long eager_until = 0;     // launch the kernels directly until this many steps were requested: a world that is being edited (bodies /
                                    // colliders / joints coming and going every few steps) would re-capture its graphs — ~10 ms — after every edit
-    long long fast_steps = 0, full_steps = 0, replayed_steps = 0, fused_steps = 0;
+    long long fast_steps = 0, full_steps = 0, replayed_steps = 0, fused_steps = 0; int fused_disabled = 0;
     // timers
     bool timers = false;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

@@ -495,7 +495,7 @@ __global__ void __launch_bounds__(1024) k_bp_rebuild(DevWorld w) {
     // the large list and compacts the buckets: entries of left cell ranges die with it) runs when the grid is not in order, when a
     // large collider moved, and every 32nd rebuild.  (Scalars read here only change behind this launch's barriers or in the launch before.)
     const int gcur = BP_GPAR(w);
-    const bool keep_grid = w.bp_incremental && w.flags[FL_BP_GRID_OK] && !w.flags[FL_BP_FORCE_FULL] && w.lay_state[9] < 32 && !w.bp_always_build;
+    const bool keep_grid = w.bp_incremental && w.flags[FL_BP_GRID_OK] && !w.flags[FL_BP_FORCE_FULL] && w.lay_state[9] < 32;
     RP_PASS_BEGIN();
     if (!keep_grid) {
         bp_build(w, gid, gstride, gcur ^ 1); GBAR_SYNC(bar);
@@ -586,8 +586,8 @@ void rp_launch_broadphase(const DevWorld &w, hipStream_t st) {
     if (w.n_colliders == 0) return;
     // every workgroup must be resident (grid barriers): at most DevWorld::gbar_blocks workgroups of 1024 threads (rp_gridbar.h)
     int blocks = (w.n_colliders + 127) / 128; // the pair pass gives every collider 8 lanes (BP_GROUP): one round when the grid allows
-    { static const int wide = getenv("RP_BP_GRID_DIV") ? atoi(getenv("RP_BP_GRID_DIV")) : 32; // (the incremental pass: a wavefront per changed collider, 16 per workgroup)
-      if (wide > 0) { const int b2 = (w.n_colliders + wide - 1) / wide; if (b2 > blocks) blocks = b2; } }
+    { const int wide = 32; // (the incremental pass: a wavefront per changed collider, 16 per workgroup)
+      const int b2 = (w.n_colliders + wide - 1) / wide; if (b2 > blocks) blocks = b2; }
     if (blocks < 8) blocks = 8;    // the clears and the pair-slot sweep are sized by capacities, not by the collider count
     if (blocks > w.gbar_blocks) blocks = w.gbar_blocks;
     hipLaunchKernelGGL(k_bp_rebuild, dim3(blocks), dim3(1024), 0, st, w);

@@ -226,7 +226,7 @@ template <bool CONVEX> __global__ void __launch_bounds__(256) k_ccd(DevWorld w, 
     __shared__ int nfast, fast[CCD_MAX_FAST_COLLIDERS];
     const float slop = w.prm.p.normalized_allowed_linear_error * w.prm.p.length_unit; // IntegrationParameters::allowed_linear_error
     // the grid describes every collider (it follows them, and nothing edited the world since its last pass); only tier 0's FIXED targets stand where their fat AABBs say
-    const bool grid_ok = tier == 0 && w.bp_incremental && w.flags[FL_BP_GRID_OK] != 0 && !w.flags[FL_BP_DIRTY] && !w.bp_always_build; // (RP_BP_ALWAYS_BUILD=1: the round-3 forms, incl. the walk over every collider here)
+    const bool grid_ok = tier == 0 && w.bp_incremental && w.flags[FL_BP_GRID_OK] != 0 && !w.flags[FL_BP_DIRTY];
     int n_large = w.flags[FL_N_LARGE]; if (n_large > w.large_cap) n_large = w.large_cap;
     for (int k = blockIdx.x; k < n; k += gridDim.x) {
         const int bi = w.ccd_list[k];

@@ -625,9 +625,7 @@ int rp_flow_grid(int device) {
     int per_cu2 = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, k_global_flow<false, true>, 256, 0) != hipSuccess) per_cu2 = 0;
     if (per_cu2 < per_cu) per_cu = per_cu2;
-    int want = 1; // workgroups per CU (RP_FLOW_WG_PER_CU); stays well below the occupancy answer: the hardware may admit one fewer
-    const char *e = getenv("RP_FLOW_WG_PER_CU");
-    if (e && atoi(e) > 0) want = atoi(e);
+    int want = 1; // workgroups per CU; stays well below the occupancy answer: the hardware may admit one fewer
     if (want > per_cu - 1 && per_cu > 4) want = per_cu - 1; // near the hardware's own limit the occupancy answer can be one too many
     if (per_cu < 1 || cus < 1) return 0;
     if (want > per_cu) want = per_cu;

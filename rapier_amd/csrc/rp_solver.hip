@@ -335,7 +335,7 @@ int rp_launch_solver_loop(const DevWorld &w0, hipStream_t st, int parallel_stage
     const rp_integration_params &p = w.prm.p;
     int fib = (p.friction_in_bias_pass || p.num_internal_stabilization_iterations == 0) ? 1 : 0;
     // with tiles the first biased sweep of a substep also increments + warm-starts the bodies, the last one also integrates them
-    static const int fuse_mask = getenv("RP_TILE_FUSE") ? atoi(getenv("RP_TILE_FUSE")) : 2; // (experiments: 0 = k_increment_ws / k_integrate stay launches)
+    const int fuse_mask = 2; // (bit 0, the increment folded into the sweep's prologue, measured slower on worlds with contacts: every halo body pays the gather again)
     const bool can_fuse = tiles && p.num_internal_pgs_iterations >= 1;
     // (a world without contact manifolds — a hint: the folded form is correct either way — has no warm-start terms to gather: the
     // increment rides the sweep's prologue for free; with contacts the gather of every halo body costs more than the launch, measured)

@@ -199,14 +199,13 @@ struct DevWorld {
     int isl_generic;       // RP_ISL_GENERIC=1: islands through k_island_generic even under the twist model (tests of that kernel)
     int n_groups;          // distinct additional_solver_iterations counts in the world (1 = no elevated body: the plain paths)
     int bp_incremental;    // the broad phase may update incrementally (0: RP_NO_BP_INCR=1, every pass is a full rebuild)
-    int bp_incr_div;       // an incremental pass serves up to n_colliders / bp_incr_div (+ 16) rewritten fat AABBs (1; RP_BP_INCR_DIV: A/B)
+    int bp_incr_div;       // an incremental pass serves up to n_colliders / bp_incr_div (+ 16) rewritten fat AABBs (1: A/B)
     int gbar_blocks;       // most workgroups (of 1024 threads) a grid-barrier kernel may use on this device: all of them resident at once (rp_gridbar.h)
     int has_sensors;       // some collider is a sensor: its pairs are intersection-tested every step (full step path)
     int isl_route_tiny;    // 1 (RP_NO_TINY_ROUTING=1: 0): worlds with thousands of tiny islands solve them on the global path (rp_islands.hip, lay_isl_number)
     int isl_bundle_tiny;   // 1 (RP_NO_TINY_BUNDLES=1: 0): worlds without sleeping pack the tiny islands into shared islands instead (lay_isl_number)
-    int isl_tiny_nc;       // ... and "tiny" = at most this many manifolds (8; RP_ISL_TINY_NC)
+    int isl_tiny_nc;       // ... and "tiny" = at most this many manifolds (8)
     int isl_many;          // ... "thousands" = more island candidates than this in the previous rebuild (960; RP_ISL_MANY overrides it)
-    int bp_always_build;   // RP_BP_ALWAYS_BUILD=1: every full broad-phase rebuild runs its build pass (A/B switch for the kept-grid rebuild, rp_broadphase.hip)
     int has_convex;        // some collider is a cylinder / cone / convex polyhedron: the narrow-phase, sensor and CCD launches use their CONVEX instantiations (rp_convex.h)
     // convex polyhedra (rp_polyhedron.h), flattened: per shape {first point, points, first face, faces}; points (w: max |p|); face normals;
     // per face {first loop entry, entries}; loop entries {vertex of the shape, edge of the shape}.  A collider's c_he.w holds its shape's row, as bits

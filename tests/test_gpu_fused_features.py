@@ -1,7 +1,7 @@
 """The single-kernel fused step (k_island_solve validates the step itself, rp_api.hip plan_fused) in the worlds that used to fall off
 it: bodies with several / offset colliders, sleep-enabled worlds whose bodies are awake, worlds with sensors,
 worlds that raise contact-force events.  Each world runs in lockstep with the oracle — poses, velocities, events, sleep states bit for
-bit — and must have taken fused steps (rp_counters::fused_steps).  (`RP_FUSED_NARROW=1` restores round 4's rule for A/B timing.)"""
+bit — and must have taken fused steps (rp_counters::fused_steps)."""
 import numpy as np
 import pytest
 

@@ -531,15 +531,6 @@ def test_fuzz_convex_polyhedra_on_the_oracle_twin(seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", [3, 9, 2003])
-def test_fuzz_with_the_round3_broad_phase_forms(seed, monkeypatch):
-    """RP_BP_ALWAYS_BUILD=1: every full broad-phase rebuild runs its grid-build pass and the continuous-collision pass walks every collider
-    (the forms before the kept-grid rebuild and the grid look-up of round 4) — the A/B switch must not change a bit"""
-    monkeypatch.setenv("RP_BP_ALWAYS_BUILD", "1")
-    _run(seed, steps=200, params=seed >= 2000)
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize("seed", [60, 61, 62, 2019])
 def test_fuzz_round_shapes_bit_exact(seed):
     """... and with the round variants (RoundShape<S>: border radii through the same GJK / EPA path) in the draw, next to five registered

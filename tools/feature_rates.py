@@ -1,5 +1,5 @@
 """What a feature costs on the headline scene (b3d_many_pyramids, 10,780 cuboids): settled steps/s with the feature on, and which way
-the steps went (VERDICT r4 weak #5 "feature cliffs off the fused step").  RP_FUSED_NARROW=1 = round 4's rule for the fused step."""
+the steps went (VERDICT r4 weak #5 "feature cliffs off the fused step")."""
 import os
 import sys
 import time

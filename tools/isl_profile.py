@@ -10,8 +10,9 @@ sys.path.insert(0, ROOT)
 from rapier_amd import PhysicsWorld, scenes as S, _ffi  # noqa: E402
 
 rows, cols = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (14, 14)
-w = PhysicsWorld.from_scene(S.many_pyramids(rows=rows, cols=cols))
-print(f"{rows * cols} islands, RP_ISL_DENSE={os.environ.get('RP_ISL_DENSE')}")
+base = int(sys.argv[3]) if len(sys.argv) > 3 else 10   # cubes in a pyramid's bottom row (10: b3d_many_pyramids; 9: 117 manifolds = 4 wavefronts of lanes)
+w = PhysicsWorld.from_scene(S.many_pyramids(rows=rows, cols=cols, base_count=base))
+print(f"{rows * cols} islands of base {base}, RP_ISL_DENSE={os.environ.get('RP_ISL_DENSE')}")
 w.step(200); w.sync()
 buf = np.zeros(64, np.int64)
 L = _ffi.lib()

@@ -1,6 +1,6 @@
 """Cost of a step of a sleep-enabled world while its bodies are still awake (b3d_many_pyramids with can_sleep(true): every
 pyramid falls asleep after ~36 steps, so 20 steps between step 10 and step 30 are timed, over several fresh worlds; the counters
-say which way those steps went — fused single-kernel steps since round 5, `RP_FUSED_NARROW=1` = round 4's two-kernel fast graph)."""
+say which way those steps went — fused single-kernel steps since round 5)."""
 import os
 import sys
 import time
