@@ -226,6 +226,9 @@ typedef struct rp_counters {
     int32_t fused_disabled;        /* how often a fused step waited ~1 s for a workgroup that never became resident (another process or stream
                                     * holds CUs): that step was aborted and replayed, and from the first such event on this world no longer
                                     * uses the one-kernel fused step (it keeps the two-kernel fast graph) — nonzero = the world lost its fastest path */
+    int32_t fused_launches;        /* launches that carried the fused_steps: a world whose islands fit one island per workgroup takes up to 32 fused
+                                    * steps per launch (k_island_solve_steps: a step boundary inside the launch is a workgroup barrier and the
+                                    * next step reads what this one wrote from the CU's own caches); fused_steps / fused_launches = steps per launch */
 } rp_counters;
 
 #define RP_INVALID_HANDLE 0xffffffffffffffffull

@@ -64,6 +64,7 @@ int rp_launch_solver_loop(const DevWorld &w, hipStream_t st, int parallel_stages
 void rp_launch_solver_writeback(const DevWorld &w, hipStream_t st, int parity, int publish);
 bool rp_ccd_launches(const DevWorld &w);
 void rp_launch_island_solve(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast, int retire, int fused, int dense, int wide);
+void rp_launch_island_solve_steps(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int nsteps);
 void rp_launch_global_single(const DevWorld &w, hipStream_t st, int has_restitution, int fast);
 void rp_launch_fast_front(const DevWorld &w, hipStream_t st, int no_global_kernel);
 void rp_launch_wake(const DevWorld &w, hipStream_t st, int phase);
@@ -191,6 +192,8 @@ struct rp_world {
     hipGraphExec_t ge_whole[3] = {nullptr, nullptr, nullptr}, ge_col[3] = {nullptr, nullptr, nullptr}, ge_loop[3] = {nullptr, nullptr, nullptr}, ge_fin[3] = {nullptr, nullptr, nullptr};
     int graph_stages = -1, graph_blocks = -1, graph_single = -1, graph_island_grid = -1, graph_dense = -1, graph_wide = -1, graph_joint_stages = -1, graph_no_global = -1, graph_fused = -1, graph_tile_grid = -1, graph_no_contacts = -1, graph_bare = -1;
     bool use_graph = true, use_fast = true, use_fused = true;
+    long long last_periodic_settle = 0;
+    bool use_multi = true; int cur_multi = 1; long long multi_launches = 0, fused_launches = 0; // launches of several fused steps (k_island_solve_steps): allowed / steps of the launch being enqueued
     bool auto_dense = true;        // RP_ISL_DENSE=0: never
     bool force_dense = false;      // RP_ISL_DENSE=1 (tests): the dense form of k_island_solve whatever the island count
     bool use_lean = true;          // the lean step graph of MULTI-mode worlds (below: "lean graph"); RP_NO_LEAN=1: never
@@ -440,6 +443,7 @@ extern "C" int32_t rp_world_create(const rp_integration_params *params, const fl
     if (g && g[0] == '1') w->use_fast = false;
     g = getenv("RP_NO_FUSED");
     if (g && g[0] == '1') w->use_fused = false;
+    { const char *m = getenv("RP_NO_MULTI_STEP"); if (m && m[0] == '1') w->use_multi = false; }
     g = getenv("RP_NO_LEAN");
     if (g && g[0] == '1') w->use_lean = false;
     g = getenv("RP_NO_FLOW");

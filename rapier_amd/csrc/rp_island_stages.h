@@ -397,7 +397,9 @@ RP_DEV void island_sort(const DevWorld &w, int isl, int nc, int cb, int nst_glob
 // `part`: 0 = every item; 1 / 2 = the two halves of a split at `total - tail` items: part 1 the items in front of it, part 2 the last `tail`
 // ones (k_island_solve, round 6: the wavefronts that also hold the body roles take one item per lane behind their body loads, the
 // wavefronts that only validate take the rest and start with the kernel).
-template <bool WIDE> RP_DEV bool fused_validate_island(const DevWorld &w, int isl, int vt, int vn, int stamp_before, int &slp, int part = 0, int tail = 0) {
+// `cross` (a launch of several steps, narrow form): set when an item names a body of ANOTHER island (a pair without solver contacts is
+// listed with the island of its first dynamic body): such an island may not take a second step inside the launch.
+template <bool WIDE> RP_DEV bool fused_validate_island(const DevWorld &w, int isl, int vt, int vn, int stamp_before, int &slp, int part = 0, int tail = 0, bool *cross = nullptr) {
     const int nb = w.isl_nb[isl], nc = w.isl_nc[isl], ni = w.isl_ni[isl];
     const int bb = w.isl_body_begin[isl], cb = w.isl_cons_begin[isl], ib = w.isl_icons_begin[isl];
     const int ns = (WIDE && w.sleep_enabled) ? nb : 0; // the sleep observations are items of their own: other lanes than the fat-AABB tests of the same bodies
@@ -409,7 +411,7 @@ template <bool WIDE> RP_DEV bool fused_validate_island(const DevWorld &w, int is
         for (int i = i_begin + vt; i < i_end; i += vn) {
             if (i < nc + ni) {
                 const int s = i < nc ? w.isl_cons[cb + i] : w.isl_icons[ib + i - nc];
-                if (pair_needs_narrow_phase_flat(w, s)) bad = true;
+                if (pair_needs_narrow_phase_flat(w, s, cross ? isl : -1, cross)) bad = true;
             } else {
                 const int b = w.isl_bodies[bb + i - nc - ni];
                 const int c = w.b_collider[b];

@@ -485,18 +485,26 @@ __global__ void __launch_bounds__(1024) k_layout_rebuild(DevWorld w) {
 //   while the islands fit one pass of the resident grid (b3d_many_pyramids: 196 islands on 256 CUs).
 // The register-lean form (rp_islands_lean.h, k_island_solve_dense): 320 threads, 168 VGPRs, two islands per CU — chosen when there
 //   are more islands than the resident grid of this form holds (b3d_many_pyramids at C4's density: 365 islands per GPU, 2,916 on one).
-template <bool WIDE> __device__ __forceinline__ void island_solve_body(const DevWorld &w, int has_restitution, int fast, int retire, int fused) {
+// `nsteps` (fused launches only; round 6): SEVERAL steps in one launch.  A step boundary inside the launch is a workgroup barrier, not a
+// kernel boundary: what a step wrote back (bodies, impulses) is read by the next one from this CU's own caches instead of from a cold L2
+// — every launch used to open with all workgroups pulling ~100 KB each through the fabric at once — and every step keeps the fused
+// step's protocol (validate, arrive, solve, commit only when every workgroup arrived and none aborted): FL_ARRIVE counts (step + 1) x
+// grid arrivals, the first aborted step ends the launch for every workgroup at the same step, FL_STEP advances by the steps committed
+// and the host replays the rest on the full graph.  Needs one island per workgroup at most, and islands whose pairs name no body of
+// ANOTHER island (a workgroup may read another one's bodies only across a kernel boundary): otherwise the launch runs one step.
+template <bool WIDE> __device__ __forceinline__ void island_solve_body(const DevWorld &w, int has_restitution, int fast, int retire, int fused, int nsteps = 1) {
     constexpr int THREADS = ISL_THREADS;
     const bool aborted = (fast && w.flags[FL_FAST_ABORT]) || lean_dead(w); // fast graph gave up on this step (rp_api.hip) / dead lean step (rp_world.h)
     if (retire && blockIdx.x == 0) {
         // SINGLE mode: workgroup 0 retires the step and publishes the scalars to the host hint buffer
         // up front, so the PCIe writes overlap the solve instead of ending the step
-        if (threadIdx.x == 0) { w.flags[FL_SEQ] += 1; if (!aborted && !fused) w.flags[FL_STEP] += 1; if (fused) w.flags[FL_FULL_UPDATES] = 0; }
+        if (threadIdx.x == 0) { w.flags[FL_SEQ] += (fused && nsteps > 1) ? nsteps : 1; if (!aborted && !fused) w.flags[FL_STEP] += 1; if (fused) w.flags[FL_FULL_UPDATES] = 0; }
         __threadfence(); __syncthreads();
         publish_flags(w);
     }
     if (aborted) return;
-    __shared__ int s_abort, s_go, s_slp;
+    __shared__ int s_abort, s_go, s_slp, s_cross;
+    if (threadIdx.x == 0) s_cross = 0;
 #ifdef RP_ISL_PROFILE
     long long t_fused0 = (long long)__builtin_readcyclecounter();
 #endif
@@ -520,7 +528,7 @@ template <bool WIDE> __device__ __forceinline__ void island_solve_body(const Dev
             if constexpr (WIDE) if (w.sleep_enabled && fused_sleep_abort(__syncthreads_or(slp))) bad = true;
         }
         if (bad) s_abort = 1;
-        if ((int)blockIdx.x >= n_islands) { // no island at all: arrive now
+        if ((int)blockIdx.x >= n_islands && !(nsteps > 1 && n_islands <= (int)gridDim.x)) { // no island at all: arrive now (a launch of several steps: once per step, below)
             __syncthreads();
             if (t == 0) atomicAdd(&w.flags[FL_ARRIVE], 1 + (s_abort ? (1 << 16) : 0));
         }
@@ -544,6 +552,28 @@ template <bool WIDE> __device__ __forceinline__ void island_solve_body(const Dev
     IslLds L;
     L.lin = B_lin; L.ang = B_ang; L.rot = B_rot; L.trans = B_trans; L.E = L_E; L.F = L_F; L.B0 = L_B0; L.B1 = L_B1;
 
+    const int ns = (fused && nsteps > 1 && n_islands <= (int)gridDim.x) ? nsteps : 1; // (more islands than workgroups: one step, islands in rounds)
+    for (int step = 0; step < ns; ++step) {
+    // FL_ARRIVE: arrivals in the low 16 bits (cumulative over the steps of the launch), aborting workgroups above them in TWO 8-bit fields
+    // by the parity of the step they abort: workgroups are at most one step apart, and an abort raised by a faster one for step s + 1 must
+    // not undo step s for a slower one that is still waiting for the verdict on s (every workgroup commits a step or none does)
+    const int arrive_target = (step + 1) * (int)gridDim.x, ab_shift = 16 + 8 * (step & 1);
+    const unsigned ab_one = 1u << ab_shift;
+    if (step > 0) { // the next step of this launch: fresh verdicts (the barrier at the end of the last step ordered its write-back before this)
+        decided = false;
+        if (t == 0) { s_abort = s_cross; s_slp = 0; } // (an island with a pair into another island takes no second step: see fused_validate_island)
+        __syncthreads();
+    }
+    if (ns > 1 && (int)blockIdx.x >= n_islands) { // a workgroup without an island follows the protocol of every step: arrive, wait for the verdict
+        if (t == 0) {
+            atomicAdd((unsigned *)&w.flags[FL_ARRIVE], 1u + (s_abort ? ab_one : 0u));
+            unsigned v; int spins = 0;
+            while (((v = __hip_atomic_load((unsigned *)&w.flags[FL_ARRIVE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffffu) < (unsigned)arrive_target && ((v >> ab_shift) & 0xffu) == 0 && ++spins < (1 << 23)) __builtin_amdgcn_s_sleep(8);
+            s_go = (v & 0xffffu) >= (unsigned)arrive_target && ((v >> ab_shift) & 0xffu) == 0; // (a timeout is raised by the workgroups that hold islands)
+        }
+        __syncthreads();
+        go = s_go != 0;
+    }
     for (int isl = blockIdx.x; isl < n_islands; isl += gridDim.x) {
         const int nb = w.isl_nb[isl], nc = w.isl_nc[isl];
         const int bb = w.isl_body_begin[isl], cb = w.isl_cons_begin[isl];
@@ -608,7 +638,9 @@ template <bool WIDE> __device__ __forceinline__ void island_solve_body(const Dev
 #endif
             int slp = 0;
 #ifndef RP_ISL_NOVAL
-            if (fused_validate_island<WIDE>(w, isl, t - v_first, THREADS - v_first, (WIDE && w.sleep_enabled) ? pi_stamp_before(w) : 0, slp)) s_abort = 1;
+            bool cross = false;
+            if (fused_validate_island<WIDE>(w, isl, t - v_first, THREADS - v_first, (WIDE && w.sleep_enabled) ? pi_stamp_before(w) : 0, slp, 0, 0, ns > 1 ? &cross : nullptr)) s_abort = 1;
+            if (cross) { s_cross = 1; if (w.flags[FL_GRID_TIMEOUT] == 0) w.flags[FL_GRID_TIMEOUT] = 2; } // (2: "no launches of several steps for this world", read by settle())
 #endif
             if constexpr (WIDE) if (slp) atomicOr(&s_slp, slp);
 #ifdef RP_ISL_PROFILE
@@ -629,7 +661,7 @@ template <bool WIDE> __device__ __forceinline__ void island_solve_body(const Dev
                 if (b_fl & RP_BF_GYRO) inc_v = gyro_corrected(inc_v, q4(B_axes[bt]), b_pi, b_invpi, w.prm.dt_sub);
             }
             __syncthreads(); // + pose stage read rot/trans; relax sweep of the previous substep done
-            if (fused && sub == 0 && isl == (int)blockIdx.x && t == 0) atomicAdd(&w.flags[FL_ARRIVE], 1 + ((s_abort || (WIDE && fused_sleep_abort(s_slp))) ? (1 << 16) : 0)); // this workgroup validated all of its islands
+            if (fused && sub == 0 && isl == (int)blockIdx.x && t == 0) atomicAdd((unsigned *)&w.flags[FL_ARRIVE], 1u + ((s_abort || (WIDE && fused_sleep_abort(s_slp))) ? ab_one : 0u)); // this workgroup validated all of its islands (for this step)
             ISL_STAMP(sub == 0 ? 12 : 2); // warm-start terms + increment (substep 0: + whatever the validating wavefronts still have to do)
             // ... then the warm start of this body in sweep order
             if (role_lin) {
@@ -670,21 +702,22 @@ template <bool WIDE> __device__ __forceinline__ void island_solve_body(const Dev
             long long t_w0 = (long long)__builtin_readcyclecounter();
 #endif
             if (t == 0) {
-                int spins = 0, v;
-                while (((v = __hip_atomic_load(&w.flags[FL_ARRIVE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffff) < (int)gridDim.x) {
+                int spins = 0; unsigned v;
+                while (((v = __hip_atomic_load((unsigned *)&w.flags[FL_ARRIVE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffffu) < (unsigned)arrive_target) {
+                    if (ns > 1 && ((v >> ab_shift) & 0xffu) != 0) break; // (a launch of several steps: an abort of THIS step is final, its arrivals need not be waited for)
                     __builtin_amdgcn_s_sleep(8);
                     if (++spins > (1 << 22)) {
                         // ~1 s: a workgroup never became resident (the GPU is shared).  Turn the wait into an abort of the whole launch:
                         // the abort count is added only while the arrival count is still short (CAS), so a workgroup that later
                         // finds the count complete also finds the abort — either every workgroup writes back or none does.
-                        int seen = v;
-                        while ((seen & 0xffff) < (int)gridDim.x &&
-                               !__hip_atomic_compare_exchange_strong(&w.flags[FL_ARRIVE], &seen, seen + (1 << 16), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { }
-                        if ((seen & 0xffff) < (int)gridDim.x) { v = seen + (1 << 16); __hip_atomic_store(&w.flags[FL_GRID_TIMEOUT], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                        unsigned seen = v;
+                        while ((seen & 0xffffu) < (unsigned)arrive_target &&
+                               !__hip_atomic_compare_exchange_strong((unsigned *)&w.flags[FL_ARRIVE], &seen, seen + ab_one, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { }
+                        if ((seen & 0xffffu) < (unsigned)arrive_target) { v = seen + ab_one; __hip_atomic_store(&w.flags[FL_GRID_TIMEOUT], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                         v = seen; break; // the last arrival came in meanwhile: decide from the complete count
                     }
                 }
-                s_go = (v & 0xffff) >= (int)gridDim.x && (v >> 16) == 0;
+                s_go = (v & 0xffffu) >= (unsigned)arrive_target && ((v >> ab_shift) & 0xffu) == 0;
             }
             __syncthreads();
             go = s_go != 0; decided = true;
@@ -694,20 +727,28 @@ template <bool WIDE> __device__ __forceinline__ void island_solve_body(const Dev
         }
         if (!go) break;
         if (live && !odd) isl_writeback(w, h, slot);
-        if (role_lin) body_writeback(w, b_gid, v3(B_lin[bt]), v3(B_ang[bt]), q4(B_rot[bt]), v3(B_trans[bt]));
+        if (role_lin) {
+            body_writeback(w, b_gid, v3(B_lin[bt]), v3(B_ang[bt]), q4(B_rot[bt]), v3(B_trans[bt]));
+            if (ns > 1 && w.b_quar[b_gid]) s_cross = 1; // a body went non-finite and was stopped: the host disables it before the next step (no further step here)
+        }
         ISL_STAMP(8); // write-back
 #ifdef RP_ISL_PROFILE
         if (blockIdx.x == 0 && threadIdx.x == 0) w.dbg[63] += 1;
 #endif
     }
+    if (!go) break;
+    __syncthreads(); // this step's write-back (global memory, written by this workgroup) is visible to all of it before the next step reads it
+    } // steps of this launch
     if (fused) { // the last workgroup to leave retires the step (or not, when aborted) and re-arms the counters
         __syncthreads();
         if (threadIdx.x == 0) {
             if (atomicAdd(&w.flags[FL_DEPART], 1) == (int)gridDim.x - 1) {
                 // every workgroup has arrived by now (each one arrives before it can reach this point)
-                int v = __hip_atomic_load(&w.flags[FL_ARRIVE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((v >> 16) == 0) w.flags[FL_STEP] += 1;
-                else w.flags[FL_FAST_ABORT] = 1; // sticky: later fast launches exit until a full step ran
+                const unsigned v = __hip_atomic_load((unsigned *)&w.flags[FL_ARRIVE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // the steps every workgroup committed: all of them, or — the launch ended at its first aborted step j, for which every
+                // workgroup that left had arrived — the full rounds of arrivals in front of that step
+                w.flags[FL_STEP] += (v >> 16) == 0 ? ns : (int)(((v & 0xffffu) - 1u) / gridDim.x);
+                if ((v >> 16) != 0) w.flags[FL_FAST_ABORT] = 1; // sticky: later fast launches exit until a full step ran
                 __hip_atomic_store(&w.flags[FL_ARRIVE], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&w.flags[FL_DEPART], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -716,6 +757,8 @@ template <bool WIDE> __device__ __forceinline__ void island_solve_body(const Dev
 }
 
 __global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int has_restitution, int fast, int retire, int fused) { island_solve_body<false>(w, has_restitution, fast, retire, fused); }
+// ... and as a launch of `nsteps` fused steps (see island_solve_body)
+__global__ void __launch_bounds__(ISL_THREADS) k_island_solve_steps(DevWorld w, int has_restitution, int nsteps) { island_solve_body<false>(w, has_restitution, 1, 1, 1, nsteps); }
 // the same kernel with the WIDE validators (rp_island_stages.h): worlds with compound bodies or sleeping enabled
 __global__ void __launch_bounds__(ISL_THREADS) k_island_solve_wide(DevWorld w, int has_restitution, int fast, int retire, int fused) { island_solve_body<true>(w, has_restitution, fast, retire, fused); }
 // ---- the generic island kernel ----------------------------------------------------------------------------------------------------
@@ -862,6 +905,9 @@ int rp_fused_grid(int device) {
     return g;
 }
 void rp_launch_island_solve_dense(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast, int retire, int fused, int wide);
+void rp_launch_island_solve_steps(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int nsteps) {
+    hipLaunchKernelGGL(k_island_solve_steps, dim3(grid < 1 ? 1 : grid), dim3(ISL_THREADS), 0, st, w, has_restitution, nsteps);
+}
 void rp_launch_island_solve(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast, int retire, int fused, int dense, int wide) {
     if (grid < 1) grid = 1;
     if (w.prm.p.friction_model == RP_FRICTION_COULOMB) { hipLaunchKernelGGL(k_island_generic<true>, dim3(grid), dim3(ISL_THREADS), 0, st, w, has_restitution, fast, retire); return; }

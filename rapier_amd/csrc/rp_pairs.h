@@ -199,13 +199,17 @@ RP_DEV Pose collider_world_pose_of(const DevWorld &w, int i, int parent) { // pa
 // at once and nothing is decided before the last one is back — the validating lanes walk 3 levels of dependent loads per item instead
 // of 6 (they share their SIMD with an issue-bound generate wavefront: 10.6k cycles per item before, profiles/r06_island_stage_cycles.txt).
 // Same answers as pair_needs_narrow_phase / collider_left_fat_aabb for every input (a freed slot reads row 0 and answers "no").
-RP_DEV bool pair_needs_narrow_phase_flat(const DevWorld &w, int s) {
+RP_DEV bool pair_needs_narrow_phase_flat(const DevWorld &w, int s, int guard_isl = -1, bool *cross = nullptr) {
     const int c1 = w.p_c1[s], c2 = w.p_c2[s], pf = w.p_pflags[s];
     const int2 rb = w.p_rb[s];
     const float4 rt = w.r_t[s], rr = w.r_r[s], misc = w.p_misc[s], q1 = w.r_rot1[s], q2 = w.r_rot2[s];
     const int a = c1 < 0 ? 0 : c1, b = c2 < 0 ? 0 : c2, pa = rb.x < 0 ? 0 : rb.x, pb = rb.y < 0 ? 0 : rb.y;
     const float4 l1r = w.c_lrot[a], l1t = w.c_lpos[a], l2r = w.c_lrot[b], l2t = w.c_lpos[b];
     const float4 b1r = w.b_rot[pa], b1t = w.b_pos[pa], b2r = w.b_rot[pb], b2t = w.b_pos[pb];
+    if (cross && c1 >= 0) { // a body that lives in another island of the LDS path (fixed bodies and the bodies of this island: -1 / guard_isl)
+        const int i1 = rb.x >= 0 ? w.b_island[pa] : -1, i2 = rb.y >= 0 ? w.b_island[pb] : -1;
+        if ((i1 >= 0 && i1 != guard_isl) || (i2 >= 0 && i2 != guard_isl)) *cross = true;
+    }
     if (c1 < 0) return false;
     if (w.has_composite && (pf & RP_PF_AUX)) return false;
     if (w.n_nc && (pf & RP_PF_NO_CONTACT)) return false;

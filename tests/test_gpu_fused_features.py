@@ -108,3 +108,47 @@ def test_contact_force_events_on_the_fused_step():
         assert len(gm) > 0
     assert g.counters()["fused_steps"] > 60
 
+
+
+def test_several_fused_steps_per_launch_commit_and_abort_step_by_step():
+    """Round 6: a world whose islands fit one per workgroup takes up to 32 fused steps in ONE launch (k_island_solve_steps) — every step
+    still validates itself, arrives, and commits only when every workgroup did; the first aborted step ends the launch for all of them
+    and the host replays the rest.  (a) a settled field of pyramids: launches of many steps, bit for bit the oracle; (b) a kick in the
+    middle of a long batch: the launch stops at the step the kicked cube leaves its fat AABB, the steps behind it are replayed."""
+    sc = S.many_pyramids(3, 3)
+    g, o = PhysicsWorld.from_scene(sc), OracleWorld(sc)
+    g.step(90); o.step(90)
+    c0 = g.counters()
+    g.step(200); o.step(200)
+    gp, gv = g.read_bodies(); op, ov = o.read()
+    np.testing.assert_array_equal(gp, op); np.testing.assert_array_equal(gv, ov)
+    c1 = g.counters()
+    steps, launches = c1["fused_steps"] - c0["fused_steps"], c1["fused_launches"] - c0["fused_launches"]
+    assert steps >= 150 and launches * 8 <= steps, (c0, c1)          # (many steps per launch)
+    top = 55                                                           # the top cube of the first pyramid
+    vel = np.zeros((1, 6), np.float32); vel[0, :3] = (3.0, 4.0, 0.5)
+    g.write_bodies([top], vel6=vel); o.set_vel(top, vel[0, :3], vel[0, 3:])
+    for n in (64, 1, 200):
+        g.step(n); o.step(n)
+        gp, gv = g.read_bodies(); op, ov = o.read()
+        np.testing.assert_array_equal(gp, op, err_msg=f"kick +{n}"); np.testing.assert_array_equal(gv, ov, err_msg=f"kick +{n}")
+    assert g.counters()["replayed_steps"] > c1["replayed_steps"]
+
+
+def test_an_island_with_a_pair_into_another_island_takes_one_step_per_launch():
+    """A pair without solver contacts is listed with the island of its first dynamic body; when its other body lives in ANOTHER island the
+    validating workgroup reads a pose another workgroup writes — sound across a kernel boundary only.  Two stacks 0.05 apart (inside each
+    other's fat AABBs, outside the contact prediction): the device finds the pair, the world goes back to one fused step per launch."""
+    sc = S.Scene(name="near_stacks", gravity=(0.0, -9.81, 0.0))
+    gb = sc.add_body(body_type=S.BODY_FIXED, translation=(0.0, -1.0, 0.0)); sc.add_collider(gb, half_extents=(20.0, 1.0, 20.0))
+    for x in (-0.525, 0.525):
+        for k in range(3):
+            b = sc.add_body(translation=(x, 0.5 + k, 0.0)); sc.add_collider(b, half_extents=(0.5, 0.5, 0.5), density=100.0)
+    g, o = PhysicsWorld.from_scene(sc), OracleWorld(sc)
+    for n in (80, 100, 150):
+        g.step(n); o.step(n)
+        gp, gv = g.read_bodies(); op, ov = o.read()
+        np.testing.assert_array_equal(gp, op, err_msg=f"+{n}"); np.testing.assert_array_equal(gv, ov, err_msg=f"+{n}")
+    c = g.counters()
+    assert c["num_islands"] == 2 and c["num_pairs"] > c["num_manifolds"], c         # two islands, pairs without solver contacts between them
+    assert c["fused_steps"] > 100 and c["fused_launches"] * 2 > c["fused_steps"], c  # fused, but (after the first long launch was cut short) one step per launch
