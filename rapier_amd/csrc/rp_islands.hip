@@ -553,6 +553,17 @@ template <bool WIDE> __device__ __forceinline__ void island_solve_body(const Dev
     L.lin = B_lin; L.ang = B_ang; L.rot = B_rot; L.trans = B_trans; L.E = L_E; L.F = L_F; L.B0 = L_B0; L.B1 = L_B1;
 
     const int ns = (fused && nsteps > 1 && n_islands <= (int)gridDim.x) ? nsteps : 1; // (more islands than workgroups: one step, islands in rounds)
+    // what a workgroup knows about its island once and for all steps of a launch (loaded by the first step; a launch of one step visits
+    // its islands in rounds and loads them per island): the island's lists, each lane's manifold, each body thread's constants
+    constexpr int ROLE_LIN0 = ISL_LANES, ROLE_ANG0 = ISL_LANES + RP_ISL_NB_MAX;
+    static_assert(ROLE_ANG0 + RP_ISL_NB_MAX <= THREADS, "the body roles need two wavefronts beyond the manifold lanes");
+    const int bt = t & (RP_ISL_NB_MAX - 1);
+    int nb = 0, nc = 0, bb = 0, cb = 0, nls = 0, v_first = 0;
+    bool role_lin = false, role_ang = false, live = false, pair_static = false;
+    int b_gid = -1, b_fl = 0, slot = -1, myq = -1, own_g = -1, own_l = -1, ws_row = 0, inc_begin = 0, inc_cnt = 0;
+    V3 b_inc = v3(0, 0, 0) /* the linear increment on a body's linear thread, the angular one on its angular thread */, b_invpi = b_inc, b_pi = b_inc;
+    V3 b_aux = b_inc; // (launches of several steps) linear thread: the local centre of mass; angular thread: the user torque — what the per-step reload needs besides the state
+    Q4 b_pframe = q4(0, 0, 0, 1);
     for (int step = 0; step < ns; ++step) {
     // FL_ARRIVE: arrivals in the low 16 bits (cumulative over the steps of the launch), aborting workgroups above them in TWO 8-bit fields
     // by the parity of the step they abort: workgroups are at most one step apart, and an abort raised by a faster one for step s + 1 must
@@ -575,52 +586,61 @@ template <bool WIDE> __device__ __forceinline__ void island_solve_body(const Dev
         go = s_go != 0;
     }
     for (int isl = blockIdx.x; isl < n_islands; isl += gridDim.x) {
-        const int nb = w.isl_nb[isl], nc = w.isl_nc[isl];
-        const int bb = w.isl_body_begin[isl], cb = w.isl_cons_begin[isl];
+        if (step == 0) { nb = w.isl_nb[isl]; nc = w.isl_nc[isl]; bb = w.isl_body_begin[isl]; cb = w.isl_cons_begin[isl]; }
         __syncthreads(); // previous island of this workgroup fully written back
 #ifdef RP_ISL_PROFILE
         long long t_prev = (long long)__builtin_readcyclecounter();
 #endif
-        if (!w.isl_sorted[isl]) island_sort(w, isl, nc, cb, nst_global, S_a, S_b, S_c, S_d);
-        const int v_first = (2 * nc + 63) & ~63; // first wavefront without any manifold lane
+        if (step == 0 && !w.isl_sorted[isl]) island_sort(w, isl, nc, cb, nst_global, S_a, S_b, S_c, S_d);
         // ---- bodies -> LDS (+ per-body constants in the owning thread's registers) (S0) ----
         // The body roles live in the wavefronts that hold NO manifold lane (round 6): threads [320, 320 + nb) own the linear half of
         // body t - 320 (and integrate / write it back), threads [384, 384 + nb) the angular half: the two halves of the increment and of
         // the body-centric warm start are independent chains, and on wavefronts of their own the increment (the gyroscopic term is a
         // ~200-instruction dependent chain) runs WHILE the manifold lanes write their warm-start terms instead of behind them.
-        constexpr int ROLE_LIN0 = ISL_LANES, ROLE_ANG0 = ISL_LANES + RP_ISL_NB_MAX;
-        static_assert(ROLE_ANG0 + RP_ISL_NB_MAX <= THREADS, "the body roles need two wavefronts beyond the manifold lanes");
-        const int bt = t & (RP_ISL_NB_MAX - 1);
-        const bool role_lin = t >= ROLE_LIN0 && t < ROLE_LIN0 + nb, role_ang = t >= ROLE_ANG0 && t < ROLE_ANG0 + nb;
-        int b_gid = -1, b_fl = 0;
-        V3 b_inc = v3(0, 0, 0) /* the linear increment on a body's linear thread, the angular one on its angular thread */, b_invpi = b_inc, b_pi = b_inc; Q4 b_pframe = q4(0, 0, 0, 1);
-        if (role_lin || role_ang) {
-            int g = w.isl_bodies[bb + bt];
-            V3 lin, ang, trans; Q4 rot;
-            V3 incl, inca;
-            body_begin(w, g, lin, ang, rot, trans, incl, inca);
-            b_gid = g; b_fl = w.b_flags[g];
-            if (role_lin) { B_lin[bt] = f4(lin, 0.0f); B_rot[bt] = f4(rot); B_trans[bt] = f4(trans, 0.0f); b_inc = incl; }
-            else { B_ang[bt] = f4(ang, 0.0f); b_inc = inca; }
-            b_invpi = v3(w.b_invpi[g]); b_pframe = q4(w.b_pframe[g]);
-            // what body_increment's gyroscopic term derives from constants / from the pose alone, once instead of on every substep's
-            // critical path: the principal inertia (three IEEE divisions) and the principal axes in world space (updated behind integrate)
-            if (role_ang && (b_fl & RP_BF_GYRO)) { b_pi = v3(rp_inv(b_invpi.x), rp_inv(b_invpi.y), rp_inv(b_invpi.z)); B_axes[bt] = f4(qmul(rot, b_pframe)); } // (each thread reads back only what it stored itself)
+        if (step == 0) {
+            v_first = (2 * nc + 63) & ~63; // first wavefront without any manifold lane
+            role_lin = t >= ROLE_LIN0 && t < ROLE_LIN0 + nb; role_ang = t >= ROLE_ANG0 && t < ROLE_ANG0 + nb;
+            b_gid = -1; b_fl = 0;
+            if (role_lin || role_ang) {
+                int g = w.isl_bodies[bb + bt];
+                V3 lin, ang, trans; Q4 rot;
+                V3 incl, inca;
+                body_begin(w, g, lin, ang, rot, trans, incl, inca);
+                b_gid = g; b_fl = w.b_flags[g];
+                if (role_lin) { B_lin[bt] = f4(lin, 0.0f); B_rot[bt] = f4(rot); B_trans[bt] = f4(trans, 0.0f); b_inc = incl; }
+                else { B_ang[bt] = f4(ang, 0.0f); b_inc = inca; }
+                b_invpi = v3(w.b_invpi[g]); b_pframe = q4(w.b_pframe[g]);
+                if (ns > 1) b_aux = role_lin ? v3(w.b_lcom_invm[g]) : v3(w.b_utorque[g]);
+                // what body_increment's gyroscopic term derives from constants / from the pose alone, once instead of on every substep's
+                // critical path: the principal inertia (three IEEE divisions) and the principal axes in world space (updated behind integrate)
+                if (role_ang && (b_fl & RP_BF_GYRO)) { b_pi = v3(rp_inv(b_invpi.x), rp_inv(b_invpi.y), rp_inv(b_invpi.z)); B_axes[bt] = f4(qmul(rot, b_pframe)); } // (each thread reads back only what it stored itself)
+            }
+            nls = w.isl_nstages[isl];
+            live = m < nc;
+            slot = -1; myq = -1; own_g = -1; own_l = -1; ws_row = 0; pair_static = false;
+            if (live) {
+                slot = w.isl_cons[cb + m]; myq = w.isl_cstage[cb + m];
+                const int l1 = w.isl_cl1[cb + m], l2 = w.isl_cl2[cb + m];
+                own_g = (odd ? w.isl_cg2 : w.isl_cg1)[cb + m]; own_l = odd ? l2 : l1;
+                pair_static = l1 < 0 || l2 < 0;
+                ws_row = w.isl_inc_pos[2 * cb + t];
+            }
+            inc_begin = 0; inc_cnt = 0;
+            if (role_lin || role_ang) { inc_begin = w.isl_inc_begin[bb + bt]; inc_cnt = w.isl_inc_cnt[bb + bt]; }
+        } else if (role_lin) {
+            // a further step of the launch: the state the last step wrote back (by this very thread; the barrier behind the write-back made
+            // it visible), through body_begin's own expressions — what does not change within a launch stayed in registers
+            const V3 lin = v3(w.b_linvel[b_gid]); const Q4 rot = q4(w.b_rot[b_gid]);
+            const V3 trans = qrot(rot, b_aux) + v3(w.b_pos[b_gid]);
+            B_lin[bt] = f4(lin, 0.0f); B_rot[bt] = f4(rot); B_trans[bt] = f4(trans, 0.0f);
+        } else if (role_ang) {
+            const V3 ang = v3(w.b_angvel[b_gid]);
+            const Sym3 ii = load_ii(w, b_gid);
+            b_inc = sym_mul(ii, b_aux) * w.prm.dt_sub; // (inca: the world inverse inertia turned with the body)
+            B_ang[bt] = f4(ang, 0.0f);
+            if (b_fl & RP_BF_GYRO) B_axes[bt] = f4(qmul(q4(w.b_rot[b_gid]), b_pframe));
         }
         if (t == 0) any_bouncy = 0;
-        const int nls = w.isl_nstages[isl];
-        const bool live = m < nc;
-        int slot = -1, myq = -1, own_g = -1, own_l = -1, ws_row = 0;
-        bool pair_static = false;
-        if (live) {
-            slot = w.isl_cons[cb + m]; myq = w.isl_cstage[cb + m];
-            const int l1 = w.isl_cl1[cb + m], l2 = w.isl_cl2[cb + m];
-            own_g = (odd ? w.isl_cg2 : w.isl_cg1)[cb + m]; own_l = odd ? l2 : l1;
-            pair_static = l1 < 0 || l2 < 0;
-            ws_row = w.isl_inc_pos[2 * cb + t];
-        }
-        int inc_begin = 0, inc_cnt = 0;
-        if (role_lin || role_ang) { inc_begin = w.isl_inc_begin[bb + bt]; inc_cnt = w.isl_inc_cnt[bb + bt]; }
         __syncthreads();
         ISL_STAMP(0); // body load + list
         IslSide h;
