@@ -30,8 +30,15 @@ for k in sorted(set(fetch) | set(write)):
     f = fetch[k][0] / max(fetch[k][1], 1) if k in fetch else 0.0
     w = write[k][0] / max(write[k][1], 1) if k in write else 0.0
     out["kernels"][k] = {"launches_fetch_pass": fetch[k][1] if k in fetch else 0, "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "hbm_bytes": (2.0 * f + w) * 1024.0}
+# the island kernel: one fused step per launch (k_island_solve) or up to 32 (k_island_solve_steps, round 6) — bytes per STEP from the
+# fused steps the profiled run counted (argv[5]: the counters tools/prof_run.py wrote), bytes per launch of the 32-step form beside it
+isl_total = sum(out["kernels"][k]["hbm_bytes"] * out["kernels"][k]["launches_fetch_pass"] for k in ("k_island_solve", "k_island_solve_steps") if k in out["kernels"])
+counters = json.load(open(sys.argv[5])) if len(sys.argv) > 5 and os.path.exists(sys.argv[5]) else {}
+fused_steps = int(counters.get("fused_steps", 0))
+out["run_counters"] = {k: counters.get(k) for k in ("fused_steps", "fused_launches", "fast_steps", "full_steps", "replayed_steps")}
+out["k_island_solve_hbm_bytes_per_step"] = isl_total / fused_steps if fused_steps > 0 else None
 isl = out["kernels"].get("k_island_solve")
-out["k_island_solve_hbm_bytes_per_launch"] = isl["hbm_bytes"] if isl else None
+out["k_island_solve_hbm_bytes_per_launch"] = isl["hbm_bytes"] if isl else None   # (the single-step launches of the run: warm-up tails)
 # stamp: bench.py refuses this record once the kernel sources change (a stale traffic figure is worse than none)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402

@@ -31,6 +31,10 @@ w = PhysicsWorld.from_scene(scene)
 w.step(300 if name == "batch_capsules" else 60); w.sync()
 t = time.time(); w.step(steps); w.sync(); dt = time.time() - t
 print(f"{name}: {steps / dt:.1f} steps/s  {dt / steps * 1e3:.3f} ms/step", w.counters())
+if os.environ.get("RP_PROF_COUNTERS"):  # (tools/gpu_profile.sh: pmc_summary.py turns bytes per LAUNCH into bytes per STEP with the fused steps / launches of this run)
+    import json
+    with open(os.environ["RP_PROF_COUNTERS"], "w") as f:
+        json.dump({k: int(v) if isinstance(v, (int,)) else float(v) for k, v in w.counters().items()}, f)
 try:  # hand-off statistics of the dataflow launch (rp_flow.hip), accumulated since world creation
     import ctypes as C
     import numpy as np
