@@ -64,7 +64,7 @@ int rp_launch_solver_loop(const DevWorld &w, hipStream_t st, int parallel_stages
 void rp_launch_solver_writeback(const DevWorld &w, hipStream_t st, int parity, int publish);
 bool rp_ccd_launches(const DevWorld &w);
 void rp_launch_island_solve(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast, int retire, int fused, int dense, int wide);
-void rp_launch_island_solve_steps(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int nsteps);
+void rp_launch_island_solve_steps(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int nsteps, int dense);
 void rp_launch_global_single(const DevWorld &w, hipStream_t st, int has_restitution, int fast);
 void rp_launch_fast_front(const DevWorld &w, hipStream_t st, int no_global_kernel);
 void rp_launch_wake(const DevWorld &w, hipStream_t st, int phase);

@@ -925,7 +925,9 @@ int rp_fused_grid(int device) {
     return g;
 }
 void rp_launch_island_solve_dense(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast, int retire, int fused, int wide);
-void rp_launch_island_solve_steps(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int nsteps) {
+void rp_launch_island_solve_dense_steps(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int nsteps); // rp_islands_lean.hip
+void rp_launch_island_solve_steps(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int nsteps, int dense) {
+    if (dense) { rp_launch_island_solve_dense_steps(w, st, grid, has_restitution, nsteps); return; }
     hipLaunchKernelGGL(k_island_solve_steps, dim3(grid < 1 ? 1 : grid), dim3(ISL_THREADS), 0, st, w, has_restitution, nsteps);
 }
 void rp_launch_island_solve(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast, int retire, int fused, int dense, int wide) {

@@ -362,15 +362,18 @@ struct LeanLds { // per island
     float4 W[WS_SLOTS_2PHASE * WS_STRIDE];
     int any_bouncy, nls;
 };
-template <bool WIDE> __device__ __forceinline__ void island_solve_lean(const DevWorld &w, int has_restitution, int fast, int retire, int fused) {
+// `nsteps`: several fused steps in one launch, exactly as in island_solve_body (rp_islands.hip: per-step validate / arrive / commit on
+// cumulative counts, abort fields by step parity, one island PAIR per workgroup at most, no pair into another island).
+template <bool WIDE> __device__ __forceinline__ void island_solve_lean(const DevWorld &w, int has_restitution, int fast, int retire, int fused, int nsteps = 1) {
     const bool aborted = (fast && w.flags[FL_FAST_ABORT]) || lean_dead(w);
     if (retire && blockIdx.x == 0) {
-        if (threadIdx.x == 0) { w.flags[FL_SEQ] += 1; if (!aborted && !fused) w.flags[FL_STEP] += 1; if (fused) w.flags[FL_FULL_UPDATES] = 0; }
+        if (threadIdx.x == 0) { w.flags[FL_SEQ] += (fused && nsteps > 1) ? nsteps : 1; if (!aborted && !fused) w.flags[FL_STEP] += 1; if (fused) w.flags[FL_FULL_UPDATES] = 0; }
         __threadfence(); __syncthreads();
         publish_flags(w);
     }
     if (aborted) return;
-    __shared__ int s_abort, s_go, s_slp[2];
+    __shared__ int s_abort, s_go, s_slp[2], s_cross;
+    if (threadIdx.x == 0) s_cross = 0;
     __shared__ LeanLds LD[2];
     __shared__ int S_a[RP_ISL_NC_MAX], S_b[RP_ISL_NC_MAX], S_c[RP_ISL_NC_MAX], S_d[RP_ISL_NC_MAX];
     const int n_islands = w.flags[FL_N_ISLANDS];
@@ -397,7 +400,7 @@ template <bool WIDE> __device__ __forceinline__ void island_solve_lean(const Dev
             }
         }
         if (bad) s_abort = 1;
-        if (2 * (int)blockIdx.x >= n_islands) { // no island at all: arrive now
+        if (2 * (int)blockIdx.x >= n_islands && !(nsteps > 1 && n_islands <= 2 * (int)gridDim.x)) { // no island at all: arrive now (a launch of several steps: once per step, below)
             __syncthreads();
             if (t == 0) atomicAdd(&w.flags[FL_ARRIVE], 1 + (s_abort ? (1 << 16) : 0));
         }
@@ -414,6 +417,25 @@ template <bool WIDE> __device__ __forceinline__ void island_solve_lean(const Dev
     const bool fib = prm.friction_in_bias_pass || prm.num_internal_stabilization_iterations == 0;
     const bool wsc = prm.warmstart_coefficient != 0.0f;
 
+    const int ns = (fused && nsteps > 1 && n_islands <= 2 * (int)gridDim.x) ? nsteps : 1; // (more island pairs than workgroups: one step, pairs in rounds)
+    for (int step = 0; step < ns; ++step) {
+    const int arrive_target = (step + 1) * (int)gridDim.x, ab_shift = 16 + 8 * (step & 1); // (see island_solve_body)
+    const unsigned ab_one = 1u << ab_shift;
+    if (step > 0) {
+        decided = false;
+        if (threadIdx.x == 0) { s_abort = s_cross; s_slp[0] = 0; s_slp[1] = 0; }
+        __syncthreads();
+    }
+    if (ns > 1 && 2 * (int)blockIdx.x >= n_islands) { // a workgroup without an island follows the protocol of every step
+        if (threadIdx.x == 0) {
+            atomicAdd((unsigned *)&w.flags[FL_ARRIVE], 1u + (s_abort ? ab_one : 0u));
+            unsigned v; int spins = 0;
+            while (((v = __hip_atomic_load((unsigned *)&w.flags[FL_ARRIVE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffffu) < (unsigned)arrive_target && ((v >> ab_shift) & 0xffu) == 0 && ++spins < (1 << 23)) __builtin_amdgcn_s_sleep(8);
+            s_go = (v & 0xffffu) >= (unsigned)arrive_target && ((v >> ab_shift) & 0xffu) == 0;
+        }
+        __syncthreads();
+        go = s_go != 0;
+    }
     for (int base = 2 * blockIdx.x; base < n_islands; base += 2 * gridDim.x) {
         __syncthreads(); // the previous islands of this workgroup are fully written back
 #ifdef RP_ISL_PROFILE
@@ -474,7 +496,9 @@ template <bool WIDE> __device__ __forceinline__ void island_solve_lean(const Dev
             const int vt = threadIdx.x - 2 * LEAN_HALF, stamp_before = (WIDE && w.sleep_enabled) ? pi_stamp_before(w) : 0;
             for (int i2 = base; i2 < base + 2 && i2 < n_islands; ++i2) {
                 int slp = 0;
-                if (fused_validate_island<WIDE>(w, i2, vt, LEAN_VALIDATORS, stamp_before, slp)) s_abort = 1;
+                bool cross = false;
+                if (fused_validate_island<WIDE>(w, i2, vt, LEAN_VALIDATORS, stamp_before, slp, 0, 0, ns > 1 ? &cross : nullptr)) s_abort = 1;
+                if (cross) { s_cross = 1; if (w.flags[FL_GRID_TIMEOUT] == 0) w.flags[FL_GRID_TIMEOUT] = 2; }
                 if constexpr (WIDE) if (slp) atomicOr(&s_slp[i2 - base], slp);
             }
         }
@@ -486,7 +510,7 @@ template <bool WIDE> __device__ __forceinline__ void island_solve_lean(const Dev
             if (sub == 0) __syncthreads(); // generate's rows of W have been read back by their lanes
             if (live) lean_ws_terms<1>(w, h, D.W, ws_row);
             __syncthreads();
-            if (fused && sub == 0 && base == 2 * (int)blockIdx.x && threadIdx.x == 0) atomicAdd(&w.flags[FL_ARRIVE], 1 + ((s_abort || (WIDE && (fused_sleep_abort(s_slp[0]) || fused_sleep_abort(s_slp[1])))) ? (1 << 16) : 0)); // this workgroup validated all of its islands
+            if (fused && sub == 0 && base == 2 * (int)blockIdx.x && threadIdx.x == 0) atomicAdd((unsigned *)&w.flags[FL_ARRIVE], 1u + ((s_abort || (WIDE && (fused_sleep_abort(s_slp[0]) || fused_sleep_abort(s_slp[1])))) ? ab_one : 0u)); // this workgroup validated all of its islands
             ISL_STAMP(2);
             if (role_lin) { // S2 increment (worker.rs:235-284), then the warm start of this body in sweep order
                 const float4 oi = D.O_incl[bt];
@@ -529,18 +553,19 @@ template <bool WIDE> __device__ __forceinline__ void island_solve_lean(const Dev
             long long t_w0 = (long long)__builtin_readcyclecounter();
 #endif
             if (threadIdx.x == 0) {
-                int spins = 0, v;
-                while (((v = __hip_atomic_load(&w.flags[FL_ARRIVE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffff) < (int)gridDim.x) {
+                int spins = 0; unsigned v;
+                while (((v = __hip_atomic_load((unsigned *)&w.flags[FL_ARRIVE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffffu) < (unsigned)arrive_target) {
+                    if (ns > 1 && ((v >> ab_shift) & 0xffu) != 0) break; // an abort of THIS step is final
                     __builtin_amdgcn_s_sleep(8);
                     if (++spins > (1 << 22)) { // ~1 s: a workgroup never became resident — turn the wait into an abort of the whole launch (see island_solve_body)
-                        int seen = v;
-                        while ((seen & 0xffff) < (int)gridDim.x &&
-                               !__hip_atomic_compare_exchange_strong(&w.flags[FL_ARRIVE], &seen, seen + (1 << 16), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { }
-                        if ((seen & 0xffff) < (int)gridDim.x) { v = seen + (1 << 16); __hip_atomic_store(&w.flags[FL_GRID_TIMEOUT], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                        unsigned seen = v;
+                        while ((seen & 0xffffu) < (unsigned)arrive_target &&
+                               !__hip_atomic_compare_exchange_strong((unsigned *)&w.flags[FL_ARRIVE], &seen, seen + ab_one, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { }
+                        if ((seen & 0xffffu) < (unsigned)arrive_target) { v = seen + ab_one; __hip_atomic_store(&w.flags[FL_GRID_TIMEOUT], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                         v = seen; break;
                     }
                 }
-                s_go = (v & 0xffff) >= (int)gridDim.x && (v >> 16) == 0;
+                s_go = (v & 0xffffu) >= (unsigned)arrive_target && ((v >> ab_shift) & 0xffu) == 0;
             }
             __syncthreads();
             go = s_go != 0; decided = true;
@@ -550,19 +575,26 @@ template <bool WIDE> __device__ __forceinline__ void island_solve_lean(const Dev
         }
         if (!go) break;
         if (live) lean_writeback(w, h, slot);
-        if (t < nb) body_writeback(w, w.isl_bodies[bb + t], v3(D.B_lin[t]), v3(D.B_ang[t]), q4(D.B_rot[t]), v3(D.B_trans[t]));
+        if (t < nb) {
+            const int g = w.isl_bodies[bb + t];
+            body_writeback(w, g, v3(D.B_lin[t]), v3(D.B_ang[t]), q4(D.B_rot[t]), v3(D.B_trans[t]));
+            if (ns > 1 && w.b_quar[g]) s_cross = 1; // a body went non-finite: no further step in this launch
+        }
         ISL_STAMP(8);
 #ifdef RP_ISL_PROFILE
         if (blockIdx.x == 0 && threadIdx.x == 0) w.dbg[63] += (base + 1 < n_islands) ? 2 : 1;
 #endif
     }
+    if (!go) break;
+    __syncthreads(); // this step's write-back is visible to the whole workgroup before the next step reads it
+    } // steps of this launch
     if (fused) { // the last workgroup to leave retires the step (or not, when aborted) and re-arms the counters
         __syncthreads();
         if (threadIdx.x == 0) {
             if (atomicAdd(&w.flags[FL_DEPART], 1) == (int)gridDim.x - 1) {
-                int v = __hip_atomic_load(&w.flags[FL_ARRIVE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((v >> 16) == 0) w.flags[FL_STEP] += 1;
-                else w.flags[FL_FAST_ABORT] = 1;
+                const unsigned v = __hip_atomic_load((unsigned *)&w.flags[FL_ARRIVE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                w.flags[FL_STEP] += (v >> 16) == 0 ? ns : (int)(((v & 0xffffu) - 1u) / gridDim.x); // (the steps every workgroup committed: island_solve_body)
+                if ((v >> 16) != 0) w.flags[FL_FAST_ABORT] = 1;
                 __hip_atomic_store(&w.flags[FL_ARRIVE], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&w.flags[FL_DEPART], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }

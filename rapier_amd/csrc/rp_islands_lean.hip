@@ -6,6 +6,8 @@
 
 // (twelve wavefronts = three per SIMD at 168 VGPRs: ONE 768-thread workgroup per CU that holds TWO islands, 135 KB of LDS)
 __global__ void __launch_bounds__(LEAN_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) k_island_solve_dense(DevWorld w, int has_restitution, int fast, int retire, int fused) { island_solve_lean<false>(w, has_restitution, fast, retire, fused); }
+// ... as a launch of `nsteps` fused steps (island_solve_body, rp_islands.hip)
+__global__ void __launch_bounds__(LEAN_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) k_island_solve_dense_steps(DevWorld w, int has_restitution, int nsteps) { island_solve_lean<false>(w, has_restitution, 1, 1, 1, nsteps); }
 // (the WIDE validators of rp_island_stages.h: worlds with compound bodies or sleeping enabled)
 __global__ void __launch_bounds__(LEAN_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) k_island_solve_dense_wide(DevWorld w, int has_restitution, int fast, int retire, int fused) { island_solve_lean<true>(w, has_restitution, fast, retire, fused); }
 
@@ -23,6 +25,9 @@ int rp_fused_grid_dense(int device) {
     if (per_cu >= 1 && cus >= 1) { g = cus - (cus + 15) / 16; if (g < 1) g = 1; }
     if (device >= 0 && device < 64) cached[device] = g > 0 ? g : -1;
     return g;
+}
+void rp_launch_island_solve_dense_steps(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int nsteps) {
+    hipLaunchKernelGGL(k_island_solve_dense_steps, dim3(grid < 1 ? 1 : grid), dim3(LEAN_THREADS), 0, st, w, has_restitution, nsteps);
 }
 // `grid` = workgroups (each takes islands 2b and 2b + 1, then strides by 2 x grid)
 void rp_launch_island_solve_dense(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast, int retire, int fused, int wide) {
