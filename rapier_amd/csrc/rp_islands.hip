@@ -503,8 +503,8 @@ template <bool WIDE> __device__ __forceinline__ void island_solve_body(const Dev
         publish_flags(w);
     }
     if (aborted) return;
-    __shared__ int s_abort, s_go, s_slp, s_cross;
-    if (threadIdx.x == 0) s_cross = 0;
+    __shared__ int s_abort, s_go, s_slp, s_cross, s_early;
+    if (threadIdx.x == 0) { s_cross = 0; s_early = 0; }
 #ifdef RP_ISL_PROFILE
     long long t_fused0 = (long long)__builtin_readcyclecounter();
 #endif
@@ -572,7 +572,7 @@ template <bool WIDE> __device__ __forceinline__ void island_solve_body(const Dev
     const unsigned ab_one = 1u << ab_shift;
     if (step > 0) { // the next step of this launch: fresh verdicts (the barrier at the end of the last step ordered its write-back before this)
         decided = false;
-        if (t == 0) { s_abort = s_cross; s_slp = 0; } // (an island with a pair into another island takes no second step: see fused_validate_island)
+        if (t == 0) { s_abort = s_cross; s_slp = 0; s_early = 0; } // (an island with a pair into another island takes no second step: see fused_validate_island)
         __syncthreads();
     }
     if (ns > 1 && (int)blockIdx.x >= n_islands) { // a workgroup without an island follows the protocol of every step: arrive, wait for the verdict
@@ -709,6 +709,12 @@ template <bool WIDE> __device__ __forceinline__ void island_solve_body(const Dev
             ISL_STAMP(5); // integrate
             if (live) isl_pose_stage(w, h, L, m, solved_dt + w.prm.dt_sub);
             else if (role_ang && (b_fl & RP_BF_GYRO)) B_axes[bt] = f4(qmul(q4(B_rot[bt]), b_pframe)); // (the next substep's increment; rot stands until the next integrate)
+            else if (fused && !decided && t == THREADS - 1 && sub == w.prm.num_substeps - 1 && isl == (int)blockIdx.x) {
+                // the verdict on this step, asked for EARLY by a lane that has nothing else to do: every workgroup arrived long ago (it does
+                // so in substep 0), so the one L2 round trip of the commit poll hides behind the last relaxed sweep instead of following it
+                const unsigned v = __hip_atomic_load((unsigned *)&w.flags[FL_ARRIVE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((v & 0xffffu) >= (unsigned)arrive_target) s_early = ((v >> ab_shift) & 0xffu) == 0 ? 1 : 2; // complete: final either way
+            }
             ISL_STAMP(6); // pose stage
             for (int it = 0; it < prm.num_internal_stabilization_iterations; ++it)
                 for (int q = 0; q < nls; ++q) { if (myq == q) isl_solve(h, L, true, true); __syncthreads(); }
@@ -721,7 +727,8 @@ template <bool WIDE> __device__ __forceinline__ void island_solve_body(const Dev
 #ifdef RP_ISL_PROFILE
             long long t_w0 = (long long)__builtin_readcyclecounter();
 #endif
-            if (t == 0) {
+            if (t == 0 && s_early) s_go = s_early == 1; // (the early answer: see the last pose stage)
+            else if (t == 0) {
                 int spins = 0; unsigned v;
                 while (((v = __hip_atomic_load((unsigned *)&w.flags[FL_ARRIVE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffffu) < (unsigned)arrive_target) {
                     if (ns > 1 && ((v >> ab_shift) & 0xffu) != 0) break; // (a launch of several steps: an abort of THIS step is final, its arrivals need not be waited for)

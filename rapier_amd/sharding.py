@@ -460,14 +460,21 @@ class ShardSet:
                     self.handle[dst][g] = int(hb)
                 self.owner[g] = dst
             # the group's impulse joints: removing a body dropped them at the source (RigidBodySet::remove removes attached joints);
-            # the destination gets them back once both ends live there (the other end: a body of the group or a replicated one)
+            # the destination gets them back once both ends live there (the other end: a body of the group or a replicated one).
+            # LIMIT: they are re-created from the scene's descriptors — motor changes made at run time (rp_impulse_joints_set_motor) and
+            # the joints' warm-start impulses do not travel (the ABI hands out impulses, not descriptors): a caller that edits motors
+            # of a sharded world must re-apply them after a migration (ShardSet.migrations counts them)
             if dst in self.worlds and self.joints:
                 moved, w = set(gl), self.worlds[dst]
                 row_of = {g: int(h) for g, h in self.handle[dst].items()}   # rp_joint_desc.body1 / body2 are RigidBodyHandles
                 back = []
                 for j in self.joints:
                     b1, b2 = int(j["body1"]), int(j["body2"])
-                    if (b1 in moved or b2 in moved) and b1 in row_of and b2 in row_of:
+                    if b1 in moved or b2 in moved:
+                        if b1 not in row_of or b2 not in row_of:
+                            # (a joint links the proximity groups of its bodies, so both ends travel together or are replicated: an end that
+                            # is missing here means the shards and the scene disagree — do not continue with a world that lost a joint)
+                            raise RuntimeError(f"migration: joint ({b1}, {b2}) of a moved body cannot be re-created on rank {dst}: body {b1 if b1 not in row_of else b2} is not there")
                         jj = j.copy(); jj["body1"], jj["body2"] = row_of[b1], row_of[b2]
                         back.append(jj)
                 if back:

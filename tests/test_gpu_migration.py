@@ -16,7 +16,7 @@ def test_a_thrown_cube_migrates_to_the_shard_it_reaches():
     groups = sharding.proximity_groups_from_scene(sc)
     body_rank, ng = sharding.shards_from_groups(groups, 2)
     assert ng == 2
-    shards = sharding.ShardSet(sc, 2, lambda sub, r: PhysicsWorld.from_scene(sub), body_rank=body_rank, groups=groups)
+    shards = sharding.ShardSet(sc, 2, lambda sub, r: PhysicsWorld.from_scene(sub, index_addressing=False), body_rank=body_rank, groups=groups)  # strict handles: the product default
     whole.step(5); shards.step(5)
     # the top cube of rank 0's pyramid, thrown towards the other pyramid (11 m away along x)
     top = max((i for i in range(len(sc.bodies)) if body_rank[i] == 0), key=lambda i: float(sc.bodies[i]["translation"][1]))
@@ -52,7 +52,7 @@ def test_hits_looked_at_every_fourth_step_still_catch_the_cube_in_time():
     whole = PhysicsWorld.from_scene(sc)
     groups = sharding.proximity_groups_from_scene(sc)
     body_rank, _ = sharding.shards_from_groups(groups, 2)
-    shards = sharding.ShardSet(sc, 2, lambda sub, r: PhysicsWorld.from_scene(sub), body_rank=body_rank, groups=groups, check_every=4)
+    shards = sharding.ShardSet(sc, 2, lambda sub, r: PhysicsWorld.from_scene(sub, index_addressing=False), body_rank=body_rank, groups=groups, check_every=4)
     whole.step(4); shards.step(4)
     assert shards.guard_refreshes == 0                                   # a pyramid that settles does not move its box
     top = max((i for i in range(len(sc.bodies)) if body_rank[i] == 0), key=lambda i: float(sc.bodies[i]["translation"][1]))
