@@ -229,6 +229,8 @@ typedef struct rp_counters {
     int32_t fused_launches;        /* launches that carried the fused_steps: a world whose islands fit one island per workgroup takes up to 32 fused
                                     * steps per launch (k_island_solve_steps: a step boundary inside the launch is a workgroup barrier and the
                                     * next step reads what this one wrote from the CU's own caches); fused_steps / fused_launches = steps per launch */
+    int32_t joint_net_steps;       /* of lean_steps: those whose whole TGS loop was ONE launch that keeps every tile's joints in registers
+                                    * (k_joint_net_step: worlds of spherical impulse joints without a single contact manifold — b3d_joint_grid) */
 } rp_counters;
 
 #define RP_INVALID_HANDLE 0xffffffffffffffffull

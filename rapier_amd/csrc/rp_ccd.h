@@ -217,7 +217,7 @@ template <bool CONVEX> __global__ void __launch_bounds__(256) k_ccd(DevWorld w, 
         if (threadIdx.x == 0) { w.flags[FL_FAST_ABORT] = 2; w.flags[FL_SEQ] += 1; }
         __threadfence(); __syncthreads();
     }
-    if (publish && blockIdx.x == 0) { if (threadIdx.x < FL_COUNT) { int v = __hip_atomic_load(&w.flags[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&w.host_flags[threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } }
+    if (publish && blockIdx.x == 0) { for (int k = threadIdx.x; k < FL_COUNT; k += blockDim.x) { int v = __hip_atomic_load(&w.flags[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&w.host_flags[k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } }
     if (dead) return;
     int n = w.flags[FL_CCD_N];
     if (n <= 0) return;

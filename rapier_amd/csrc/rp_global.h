@@ -218,9 +218,9 @@ RP_DEV void tail_sweep(const DevWorld &w, int first, bool fib, float solved_dt) 
 // Publish the device scalars to the host-mapped hint buffer (posted PCIe writes; the host only ever
 // uses them as hints, or re-reads them after a stream sync).
 RP_DEV void publish_flags(const DevWorld &w) {
-    if (threadIdx.x < FL_COUNT) {
-        int v = __hip_atomic_load(&w.flags[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&w.host_flags[threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int k = threadIdx.x; k < FL_COUNT; k += blockDim.x) {
+        int v = __hip_atomic_load(&w.flags[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&w.host_flags[k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 template <bool COUL>

@@ -506,9 +506,9 @@ __global__ void k_idle_step(DevWorld w) {
     }
     __threadfence();
     __syncthreads();
-    if (threadIdx.x < FL_COUNT) {
-        int v = __hip_atomic_load(&w.flags[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&w.host_flags[threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int k = threadIdx.x; k < FL_COUNT; k += blockDim.x) {
+        int v = __hip_atomic_load(&w.flags[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&w.host_flags[k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 void rp_launch_idle_step(const DevWorld &w, hipStream_t st) { hipLaunchKernelGGL(k_idle_step, dim3(1), dim3(64), 0, st, w); }

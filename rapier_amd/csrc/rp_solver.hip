@@ -312,6 +312,7 @@ void rp_launch_global_single(const DevWorld &w, hipStream_t st, int has_restitut
 void rp_launch_flow_ranks(const DevWorld &w, hipStream_t st);
 void rp_launch_tiles_build(const DevWorld &w, hipStream_t st);
 void rp_launch_tile_sweep(const DevWorld &w, hipStream_t st, int mode, int grid, int friction_in_bias, float solved_dt, int fuse, int joint_warmstart);
+void rp_launch_joint_net_step(const DevWorld &w, hipStream_t st, int grid, int joint_warmstart);
 // lean: the graph runs only while FL_FLOW_DIRTY is clear (rp_world.h "lean step graphs") — both rebuilds would exit at once: left out
 void rp_launch_solver_assembly(const DevWorld &w, hipStream_t st, int lean) {
     if (!lean) {
@@ -343,6 +344,12 @@ int rp_launch_solver_loop(const DevWorld &w0, hipStream_t st, int parallel_stage
     static const bool joint_inline_ok = getenv("RP_NO_JOINT_INLINE") == nullptr;
     const bool jinline = can_fuse && w.n_joints > 0 && w.joints_spherical && joint_inline_ok;
     const bool fuse_inc = can_fuse && ((fuse_mask & 1) || ((fuse_mask & 4) == 0 && no_contacts_hint)), fuse_int = can_fuse && (fuse_mask & 2);
+    // a bare lean graph in the joint-net form (DevWorld::lean bit 2, planned by the host, verified by lean_dead): the whole loop is ONE
+    // launch that keeps every tile's joints in registers (k_joint_net_step, rp_tiles.hip) — b3d_joint_grid
+    if (w.lean & 4) {
+        rp_launch_joint_net_step(w, st, w.lean >> 8, p.warmstart_joints ? 1 : 0);
+        return (w.prm.num_substeps & 1) ? 2 : 0; // (velocities where they began, poses in the other copy after an odd number of substeps)
+    }
 #define TILE_SWEEP(MODE, SDT, FUSE, JWS) do { const int fuse_ = (FUSE); rp_launch_tile_sweep(w, st, MODE, tile_grid, fib, SDT, fuse_, JWS); \
         std::swap(w.s_lin, w.t_lin); std::swap(w.s_ang, w.t_ang); w.c_par ^= 1; parity ^= 1; \
         if (fuse_ & 2) { std::swap(w.s_rot, w.t_rot); std::swap(w.s_trans, w.t_trans); parity ^= 2; } } while (0)

@@ -51,6 +51,7 @@ RP_DEV unsigned tile_hash(int g) { return ((unsigned)g * 2654435761u) >> 21; } /
 __global__ void __launch_bounds__(1024) k_tiles_sort(DevWorld w) {
     if (!w.flags[FL_FLOW_DIRTY]) return; // (cleared by k_begin_generate, which runs after this kernel)
     const int gid = gbar_item(), gstride = gridDim.x * blockDim.x, t = threadIdx.x;
+    if (gid == 0) w.flags[FL_TILE_JMAX] = 0; // (k_tiles_cones, the next launch, takes the maximum over the cones it builds)
     int M = w.flags[FL_N_CONS]; if (M > w.cons_cap) M = w.cons_cap;
     const int nst = w.flags[FL_N_STAGES], nb = w.n_bodies;
     const int njl = w.n_joints > 0 ? w.flags[FL_NJ_OVF_BEGIN] + w.flags[FL_NJ_OVF_COUNT] : 0, njs = tile_joint_stages(w); // live joints, their colour stages (small colours included)
@@ -310,6 +311,7 @@ __global__ void __launch_bounds__(RP_CONE_THREADS) k_tiles_cones(DevWorld w) {
             if (t == 0) { soff[S] = RP_TILE_CCAP - (ncons < RP_TILE_CCAP ? ncons : RP_TILE_CCAP); nsnap = nloc; } // the list is filled from its end: ascending stages once read forwards
             __syncthreads();
         }
+        if (t == 0 && njs > 0) atomicMax(&w.flags[FL_TILE_JMAX], soff[njs] - soff[0]); // the most joints one cone holds (k_joint_net_step: one per thread)
         if (t == 0) { // statistics of the tiling (tools/tile_diag.py)
             atomicMax((unsigned long long *)&w.dbg[905], (unsigned long long)nloc); atomicMax((unsigned long long *)&w.dbg[906], (unsigned long long)ncons);
             atomicAdd((unsigned long long *)&w.dbg[907], (unsigned long long)nloc); atomicAdd((unsigned long long *)&w.dbg[908], (unsigned long long)ncons);
@@ -644,6 +646,7 @@ __global__ void __launch_bounds__(RP_TILE_THREADS) k_tile_sweep(DevWorld w, int 
 #ifdef RP_TILE_PROFILE // thread 0 of tile 0 accumulates wall-clock ticks (10 ns) per phase into dbg[920 + 24 * MODE ..] (tools/tile_diag.py)
 #define TP_STAMP(k) do { if (blockIdx.x == 0 && t == 0) { const long long n_ = (long long)wall_clock64(); w.dbg[920 + 24 * MODE + (k)] += n_ - tp_; tp_ = n_; } } while (0)
     long long tp_ = (long long)wall_clock64();
+    const long long tp0_ = tp_;
 #else
 #define TP_STAMP(k) do { } while (0)
 #endif
@@ -770,9 +773,142 @@ __global__ void __launch_bounds__(RP_TILE_THREADS) k_tile_sweep(DevWorld w, int 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         TP_STAMP(1);
         if (blockIdx.x == 0 && t == 0) w.dbg[920 + 24 * MODE + 2] += 1;
+        if (t == 0 && tile < 256) { w.dbg[(MODE == MODE_BIAS ? 300 : 560) + tile] += (long long)wall_clock64() - tp0_; if (MODE == MODE_BIAS && tile < 70) w.dbg[830 + tile] = Soff[njs] - Soff[0]; } // every tile: its whole sweep (tools/tile_diag.py)
 #endif
     }
 #undef TP_STAMP
+}
+
+// ---- b3d_joint_grid: the TGS loop of a net of spherical joints as ONE launch, the joints in registers from the first substep to the last
+// Measured on the sweeps above (tools/tile_diag.py, every tile stamped): of the 12.4 / 10.5 us a tile spends in a biased / relaxed
+// sweep only 4.5 are its colour stages — the rest is fetching what the previous launch of the same tile already held (its lists, its
+// bodies, its joints' rows and impulses), and the launch itself takes 22.6 / 16.6 us.  Here a workgroup keeps its tile for the whole
+// step: the lists are read once, every cone joint lives in ONE thread's registers (rows rebuilt from the poses at the head of a substep,
+// impulses carried from sweep to sweep: a cone joint is solved on correct inputs in every sweep, so every instance holds the owner's
+// impulse), and between two sweeps only what another tile may need crosses memory — the owned bodies' velocities (poses behind the
+// biased sweep) go out, a grid barrier (rp_gridbar.h), the cone bodies' come in.  The arithmetic is the sweeps': body_increment,
+// joint_update_one_t, joint_solve_fetched, body_integrate on the same operands in the same order.  Row planes are not written (nothing
+// reads them before the next rebuild); the impulses and right-hand sides go to DevWorld::jm once, at the end, for the write-back.
+// Where it runs: bare lean graphs (DevWorld::lean bits 1 and 2; lean_dead verifies no manifold, no LDS island, a valid tiling that fits
+// the grid, no contact stage, no cone above RP_JN_THREADS joints), all joints spherical, one PGS and one stabilisation iteration.
+struct JnPoseIO {
+    const float4 *rot, *trans; int b1, b2;
+    RP_DEV void bodies(const DevWorld &, int, int &o1, int &o2) const { o1 = b1; o2 = b2; }
+    RP_DEV void pose(int side, int b, Pose &p) const { p.r = q4(rot[b]); p.t = v3(trans[b]); }
+};
+struct JnSink {
+    TileJointPre &P;
+    RP_DEV void take3(const DevWorld &, int, JointRow (&r3)[3], V3 im1, V3 im2) const {
+        P.im1 = im1; P.im2 = im2;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) P.R.c[k] = r3[k];
+    }
+};
+struct JnVelIO { // LDS velocities; the sweep's words stay in the registers (no store)
+    float4 *Ll, *La; int l1, l2;
+    RP_DEV void load_vel(int side, int b, V3 &l, V3 &a) const { const int lid = side ? l2 : l1; l = v3(Ll[lid]); a = v3(La[lid]); }
+    RP_DEV void store_vel(int side, int b, V3 l, V3 a) const { const int lid = side ? l2 : l1; Ll[lid] = f4(l, 0.0f); La[lid] = f4(a, 0.0f); }
+    RP_DEV int jm_out(const DevWorld &w) const { return w.c_par; }
+    RP_DEV bool jm_store() const { return false; }
+};
+__global__ void __launch_bounds__(RP_JN_THREADS) k_joint_net_step(DevWorld w, int joint_warmstart) {
+    if (lean_dead(w)) return; // (the same answer in every workgroup: nothing it reads changes while a lean graph runs)
+    __shared__ float4 Ll[RP_TILE_BCAP], La[RP_TILE_BCAP];
+    __shared__ int Lg[RP_TILE_BCAP];
+    __shared__ int Soff[RP_TILE_STAGES + 2];
+    const int t = threadIdx.x, nt = blockDim.x, tile = blockIdx.x;
+    const int njs = tile_joint_stages(w), substeps = w.prm.num_substeps;
+    const bool have = tile < w.flags[FL_N_TILES]; // (workgroups beyond the tiling only keep the barriers company)
+    GridBar bar = gbar_begin(w, 5);
+    int nb = 0, n_owned = 0;
+    if (have) {
+        const int4 hdr = w.tl_hdr[tile];
+        nb = hdr.x; n_owned = hdr.z;
+        for (int s = t; s <= njs; s += nt) Soff[s] = w.tl_soff[(size_t)tile * (RP_TILE_STAGES + 1) + s];
+        for (int l = t; l < nb; l += nt) Lg[l] = w.tl_bodies[(size_t)tile * RP_TILE_BCAP + l];
+    }
+    __syncthreads();
+    int4 je = make_int4(0, -1, -1, 0); int jstage = -1; bool mine = false;
+    TileJointPre JP;
+    if (have) {
+        const int j0 = Soff[0], nje = Soff[njs] - j0;
+        if (t < nje) {
+            mine = true;
+            je = w.tl_cons[(size_t)tile * RP_TILE_CCAP + j0 + t];
+            jstage = 0; while (Soff[jstage + 1] - j0 <= t) ++jstage;
+        }
+    }
+    JP.locked = 0x7; JP.limited = 0; JP.motor = 0; JP.b1 = (mine && je.y >= 0) ? Lg[je.y] : -1; JP.b2 = (mine && je.z >= 0) ? Lg[je.z] : -1;
+    const int j = -1 - je.x;
+    float4 *vs = w.s_lin, *as = w.s_ang, *vt = w.t_lin, *at = w.t_ang, *rs = w.s_rot, *ts = w.s_trans, *rt = w.t_rot, *tt = w.t_trans;
+    const bool ws = w.prm.p.warmstart_joints != 0;
+    const float ws_coeff = w.prm.p.warmstart_coefficient;
+    for (int s = 0; s < substeps; ++s) {
+        // S2: every cone body is incremented on its way into LDS (halo bodies redundantly, on the same operands)
+        for (int l = t; l < nb; l += nt) {
+            const int g = Lg[l];
+            V3 lin = v3(vs[g]), ang = v3(as[g]);
+            body_increment(w, w.b_flags[g], lin, ang, q4(rs[g]), v3(w.s_incl[g]), v3(w.s_inca[g]), v3(w.b_invpi[g]), q4(w.b_pframe[g]));
+            Ll[l] = f4(lin, 0.0f); La[l] = f4(ang, 0.0f);
+        }
+        // the rows of this substep from the poses (JointConstraintBuilder::update); the impulse of the last sweep seeds the next
+        if (mine) {
+            const float i0 = JP.R.c[0].impulse, i1 = JP.R.c[1].impulse, i2 = JP.R.c[2].impulse;
+            const JnPoseIO io = {rs, ts, JP.b1, JP.b2};
+            const JnSink sink = {JP};
+            joint_update_one_t<JnPoseIO, JnSink, true>(w, io, j, 0, sink); // (substep 0: seeded from the joint's stored impulses)
+            if (s > 0 && ws) { JP.R.c[0].impulse = i0 * ws_coeff; JP.R.c[1].impulse = i1 * ws_coeff; JP.R.c[2].impulse = i2 * ws_coeff; }
+        }
+        __syncthreads();
+        const JnVelIO vio = {Ll, La, je.y, je.z};
+        for (int st = 0; st < njs; ++st) {
+            if (jstage == st) joint_solve_fetched<JnVelIO, 3>(w, vio, j, JP.b1, JP.b2, 3, JP.im1, JP.im2, JP.R, false, joint_warmstart != 0);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        // S6: the owned bodies are integrated on their way out (velocities AND poses to the other copies)
+        for (int l = t; l < n_owned; l += nt) {
+            const int g = Lg[l];
+            V3 lin = v3(Ll[l]), ang = v3(La[l]), trans = v3(ts[g]); Q4 rot = q4(rs[g]);
+            body_integrate(w, w.b_flags[g], lin, ang, rot, trans);
+            vt[g] = f4(lin, 0.0f); at[g] = f4(ang, 0.0f); rt[g] = f4(rot); tt[g] = f4(trans, 0.0f);
+        }
+        { float4 *a = vs; vs = vt; vt = a; a = as; as = at; at = a; a = rs; rs = rt; rt = a; a = ts; ts = tt; tt = a; }
+        GBAR_SYNC(bar);
+        for (int l = t; l < nb; l += nt) { const int g = Lg[l]; Ll[l] = vs[g]; La[l] = as[g]; }
+        __syncthreads();
+        for (int st = 0; st < njs; ++st) {
+            if (jstage == st) joint_solve_fetched<JnVelIO, 3>(w, vio, j, JP.b1, JP.b2, 3, JP.im1, JP.im2, JP.R, true, false);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        for (int l = t; l < n_owned; l += nt) { const int g = Lg[l]; vt[g] = Ll[l]; at[g] = La[l]; }
+        { float4 *a = vs; vs = vt; vt = a; a = as; as = at; at = a; }
+        if (s + 1 < substeps) GBAR_SYNC(bar);
+    }
+    // what the write-back reads: the owner instance's impulses (and right-hand sides, as the sweeps leave them) in the current copy of jm
+    if (mine && je.w != 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) jm_put(w, j, k, w.c_par, JP.R.c[k].impulse, JP.R.c[k].rhs);
+    }
+    gbar_end(bar);
+}
+void rp_launch_joint_net_step(const DevWorld &w, hipStream_t st, int grid, int joint_warmstart) {
+    hipLaunchKernelGGL(k_joint_net_step, dim3(grid < 1 ? 1 : grid), dim3(RP_JN_THREADS), 0, st, w, joint_warmstart);
+}
+// most workgroups a k_joint_net_step launch may use on the current device (all of them resident at once: grid barriers), 0 = none
+int rp_joint_net_cap(void) {
+    static int cached[64] = {0};
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return 0;
+    if (device >= 0 && device < 64 && cached[device]) return cached[device] > 0 ? cached[device] : 0;
+    hipDeviceProp_t prop;
+    int per_cu = 0, cus = 0;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_joint_net_step, RP_JN_THREADS, 0) != hipSuccess) per_cu = 0;
+    if (per_cu > 1) per_cu = 1;
+    int g = cus * per_cu - (cus + 15) / 16; // (a sixteenth left free, like the fused island step)
+    if (g < 1) g = -1;
+    if (device >= 0 && device < 64) cached[device] = g;
+    return g > 0 ? g : 0;
 }
 
 void rp_launch_tiles_build(const DevWorld &w, hipStream_t st) {

@@ -25,6 +25,7 @@
 #define RP_FID_UNKNOWN 0xffffu
 #define RP_TILE_BCAP 1024            // cone bodies (owned + halo) of one LDS tile (rp_tiles.hip)
 #define RP_TILE_CCAP 3072            // cone constraints of one tile
+#define RP_JN_THREADS 512            // threads of k_joint_net_step: one cone joint each (rp_tiles.hip)
 #define RP_TILE_STAGES 127           // sweep stages a tiling handles (every colour but the overflow one)
 #define RP_TILE_CELLS 4096           // cells of the Morton counting sort that orders bodies into tiles (12 bits)
 #define RP_TILE_MIN_BODIES 1024      // global-path bodies below which the colour stages stay launches
@@ -120,7 +121,8 @@ enum {
     FL_CCD_CLAMPS,      // (body, step) cases in which k_ccd clamped a pose to a time of impact
     FL_UF_NPAIRS,       // scratch of a layout rebuild: active dynamic-dynamic pairs listed for the island union-find (uf_pairs)
     FL_N_TILES,         // LDS tiles the global path's big component is cut into (rp_tiles.hip); 0 = no valid tiling: colour stages as launches
-    FL_COUNT = 64       // <= 64: publish_flags copies one slot per lane of a wavefront
+    FL_TILE_JMAX,       // joints of the largest cone of the current tiling (k_tiles_cones): k_joint_net_step holds one per thread
+    FL_COUNT = 72       // (publish_flags copies the slots in strides of the workgroup)
 };
 
 // constraint float4 planes (per solver manifold) — restates ContactWithTwistFriction +
@@ -445,7 +447,12 @@ __device__ __forceinline__ bool lean_dead(const DevWorld &w) {
     // (bit 1, a BARE lean graph: it also left out the launches that only manifolds and LDS islands give work to.  Both counts are
     // results of the layout rebuild, which no lean graph runs: they cannot change while this graph executes)
     const int bare_wrong = (w.lean & 2) ? (w.flags[FL_N_CONS_ALL] | w.flags[FL_N_ISLANDS]) : 0;
-    return (w.flags[FL_FAST_ABORT] | w.flags[FL_TODO_COUNT] | w.flags[FL_LAYOUT_DIRTY] | w.flags[FL_FLOW_DIRTY] | (w.n_joints > 0 ? w.flags[FL_JOINT_DIRTY] : 0) | bare_wrong) != 0;
+    // (bit 2, a bare lean graph whose TGS loop is ONE launch — k_joint_net_step, rp_tiles.hip —, its grid in bits 8 and up: a valid
+    // tiling of at most that many tiles, no contact stage, no cone with more joints than the kernel has threads.  All four are results
+    // of the layout rebuild / the tiling, which no lean graph runs)
+    int jn_wrong = 0;
+    if (w.lean & 4) { const int nt = w.flags[FL_N_TILES], jmax = w.flags[FL_TILE_JMAX]; jn_wrong = (nt <= 0 || nt > (w.lean >> 8) || w.flags[FL_N_STAGES] != 0 || jmax <= 0 || jmax > RP_JN_THREADS) ? 1 : 0; }
+    return (w.flags[FL_FAST_ABORT] | w.flags[FL_TODO_COUNT] | w.flags[FL_LAYOUT_DIRTY] | w.flags[FL_FLOW_DIRTY] | (w.n_joints > 0 ? w.flags[FL_JOINT_DIRTY] : 0) | bare_wrong | jn_wrong) != 0;
 }
 // collision kernels: this step's collision stage already ran (a dead lean step waits for its resume), or an earlier lean step died
 __device__ __forceinline__ bool collision_done(const DevWorld &w) { const int a = w.flags[FL_FAST_ABORT]; return a == 2 || (w.lean && a != 0); }

@@ -69,7 +69,7 @@ def test_c5_joint_grid_full_size_1000_steps_on_tiles_and_lean_graphs():
     finally:
         oracle_ffi.set_threads(1)
     assert c["overflow_flags"] == 0 and c["num_tiles"] > 100 and c["tile_sweeps"] == 1, c
-    assert c["lean_steps"] > 700, c
+    assert c["lean_steps"] > 700 and c["joint_net_steps"] > 700, c  # (round 6: the lean graphs of this world are the joint-net launch, k_joint_net_step)
 
 
 def test_c4_one_shard_of_eight_guarded_120_steps():

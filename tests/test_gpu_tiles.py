@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _world(scene, monkeypatch, **env):
-    for k in ("RP_NO_TILES", "RP_TILE_TARGET", "RP_TILE_MIN", "RP_FORCE_MULTI", "RP_NO_LEAN", "RP_TILE_STALE_PLAN", "RP_TEST_LATE_FILL"):
+    for k in ("RP_NO_TILES", "RP_TILE_TARGET", "RP_TILE_MIN", "RP_FORCE_MULTI", "RP_NO_LEAN", "RP_TILE_STALE_PLAN", "RP_TEST_LATE_FILL", "RP_NO_JOINT_NET"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, str(v))
@@ -333,6 +333,74 @@ def test_lean_steps_on_the_joint_grid_bit_exact(monkeypatch):
     assert c["lean_steps"] > 100, c
     gc, gi = g.read_joints(); oc, oi = o.read_joints()
     np.testing.assert_array_equal(gi, oi, err_msg="joint impulses")
+
+
+# ---- the joint-net form of a bare lean graph: the TGS loop of a step as ONE launch, every tile's joints in registers (k_joint_net_step) -
+def _joint_impulses_equal(g, o, msg):
+    gc, gi = g.read_joints(); oc, oi = o.read_joints()
+    np.testing.assert_array_equal(gc, oc, err_msg=msg + ": joint colours"); np.testing.assert_array_equal(gi, oi, err_msg=msg + ": joint impulses")
+
+
+@pytest.mark.parametrize("case", ["grid", "net_warmstart", "three_substeps", "one_substep", "no_warmstart_coefficient", "small_tiles", "large_tiles", "oversized_cones"])
+def test_joint_net_step_bit_exact(monkeypatch, case):
+    """worlds of spherical joints without a contact: once tiled, every step is a lean graph whose whole TGS loop is one launch — rows
+    rebuilt from the poses at the head of every substep, impulses carried in registers from sweep to sweep, grid barriers where the
+    launch boundaries were.  Odd substep counts leave the poses in the other copy; fixed bodies are world-attached sides; the tile
+    size changes cones and halos, never the bits.  The same run with RP_NO_JOINT_NET=1 keeps the eight sweep launches."""
+    env = {}
+    if case == "net_warmstart":
+        sc = S.joint_net(36); sc.params["warmstart_joints"] = 1
+    else:
+        sc = S.joint_grid(40)
+    if case == "three_substeps": sc.params["num_solver_iterations"] = 3
+    if case == "one_substep": sc.params["num_solver_iterations"] = 1
+    if case == "no_warmstart_coefficient": sc.params["warmstart_coefficient"] = 0.0; sc.params["warmstart_joints"] = 1
+    if case == "small_tiles": env["RP_TILE_TARGET"] = 200
+    if case == "large_tiles": env["RP_TILE_TARGET"] = 16
+    if case == "oversized_cones": env["RP_TILE_TARGET"] = 8   # cones of more joints than the launch has threads: the sweeps stay launches
+    g, o, c = _run(sc, [1, 6, 40, 150], monkeypatch, **env)
+    if case == "oversized_cones":
+        assert c["joint_net_steps"] == 0 and c["lean_steps"] > 100, c
+        return
+    assert c["joint_net_steps"] > 100 and c["joint_net_steps"] <= c["lean_steps"], c
+    _joint_impulses_equal(g, o, case)
+    h = _world(sc, monkeypatch, RP_NO_JOINT_NET=1, **env)
+    h.step(150)
+    _equal(g, h, "joint-net launch vs sweep launches")
+    ch = h.counters()
+    assert ch["joint_net_steps"] == 0 and ch["lean_steps"] > 100, ch
+
+
+def test_joint_net_step_dies_and_resumes_bit_exact(monkeypatch):
+    """the joint-net launch validates itself like every lean graph: kicked balls, a removed joint (the joint colouring is rebuilt, the
+    tiling with it) and a ball dropped INTO the net (the first contact manifold: the bare form is wrong from then on) are all found
+    on the device; the steps that died are resumed by the full graph and nothing differs from the oracle"""
+    sc = S.joint_net(36)
+    g, o = _world(sc, monkeypatch), OracleWorld(sc)
+    g.step(40); o.step(40)
+    _equal(g, o, "hanging")
+    c0 = g.counters()
+    assert c0["joint_net_steps"] > 0, c0
+    for b in (700, 701, 900):
+        g.apply_impulse([b], impulse=(3.0, 2.0, 9.0)); o.apply_impulse(b, impulse=(3.0, 2.0, 9.0))
+    g.step(25); o.step(25)
+    _equal(g, o, "kicked")
+    jh = g.joint_handles()
+    g.remove_impulse_joint([jh[1000]]); o.remove_joint(1000)
+    for n in (1, 2, 30):
+        g.step(n); o.step(n)
+        _equal(g, o, f"joint removed, +{n}")
+    c1 = g.counters()
+    assert c1["joint_net_steps"] > c0["joint_net_steps"] + 20, (c0, c1)
+    _joint_impulses_equal(g, o, "after the removal")
+    # a ball lands on the net: contacts from here on
+    _drop_boxes(g, o, [(16.0, 1.0, 0.0)])   # (above a pinned ball of the top row)
+    seen = 0
+    for n in (1, 3, 6, 20, 60, 120):
+        g.step(n); o.step(n)
+        _equal(g, o, f"a box on the net, +{n}")
+        seen = max(seen, g.counters()["num_manifolds"])
+    assert seen > 0 and g.counters()["overflow_flags"] == 0
 
 
 @pytest.mark.parametrize("seed", [3, 17])

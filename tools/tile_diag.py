@@ -24,3 +24,16 @@ for mode, name in ((0, "biased"), (1, "relaxed")):
     if r[2]:
         n = float(r[2])
         print(f"tile 0 {name} sweep ({int(n)} launches): load {r[0] / n / 100:.2f} us, joint prepare {r[3] / n / 100:.2f} us, store {r[1] / n / 100:.2f} us, stages " + " ".join(f"{r[4 + k] / n / 100:.2f}" for k in range(17) if r[4 + k]))
+
+# every tile's whole sweep (thread 0 of the tile, kernel entry to its last store)
+per = np.zeros(520, np.int64)
+L.rp_debug_read(w._ptr, 300, 520, per.ctypes.data)
+nj = np.zeros(70, np.int64)
+L.rp_debug_read(w._ptr, 830, 70, nj.ctypes.data)
+for name, off, n in (("biased", 0, float(prof[2])), ("relaxed", 260, float(prof[26]))):
+    v = per[off: off + 256].astype(float)
+    v = v[v > 0]
+    if n and len(v):
+        v = v / n / 100
+        print(f"{name}: {len(v)} tiles, whole sweep per tile: min {v.min():.2f} median {np.median(v):.2f} mean {v.mean():.2f} p90 {np.percentile(v, 90):.2f} max {v.max():.2f} us (argmax {int(v.argmax())})")
+        if off == 0: print("  first tiles (us, joints):", " ".join(f"{v[k]:.1f}/{int(nj[k])}" for k in range(min(70, len(v)))))
