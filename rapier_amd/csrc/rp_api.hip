@@ -214,7 +214,7 @@ struct rp_world {
     bool has_bullets = false;      // some dynamic body has ccd_enabled: the continuous-collision pass runs its second tier
     float min_ccd_thickness = 3.402823466e+38f; // thinnest dynamic body (the fused single-kernel step needs it above the fat-AABB margin)
     bool compound = false;         // some dynamic body carries several colliders or an offset collider (no fused fast step)
-    bool timed_ready[2] = {false, false};
+    bool timed_ready[3] = {false, false, false};
     bool never_stepped = true;     // no step has retired and the device world was never rebuilt / grown: what the host mirrors hold is the whole state
     int pairs_scale = 1;           // the pair pool holds RP_PAIRS_PER_COLLIDER x pairs_scale slots per collider row: doubled when the pool fills up (rp_step)
     int cur_fast = 0;              // mode the enqueue_* callbacks capture
@@ -475,7 +475,7 @@ static void destroy_graphs(rp_world *w) {
         for (auto g : gr) if (*g) { hipGraphDestroy(*g); *g = nullptr; }
     }
     w->graph_stages = -1; w->graph_blocks = -1; w->graph_single = -1; w->graph_island_grid = -1; w->graph_dense = -1; w->graph_wide = -1; w->graph_joint_stages = -1; w->graph_no_global = -1; w->graph_fused = -1; w->graph_tile_grid = -1; w->graph_no_contacts = -1; w->graph_bare = -1;
-    w->timed_ready[0] = w->timed_ready[1] = false;
+    w->timed_ready[0] = w->timed_ready[1] = w->timed_ready[2] = false; w->graph_jn = -1;
 }
 static void free_device(rp_world *w) {
     destroy_graphs(w);

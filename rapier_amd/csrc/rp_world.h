@@ -428,7 +428,11 @@ struct DevWorld {
     int *tl_soff;               // [tile_cap][RP_TILE_STAGES + 1] begin of every sweep stage inside the tile's constraint list
     int *tl_bodies;             // [tile_cap][RP_TILE_BCAP] arena index of every cone body (owned + halo), index = tile-local id
     int4 *tl_cons;              // [tile_cap][RP_TILE_CCAP] cone constraints in stage order: position, local body 1, local body 2, owner?
+    unsigned *tl_nbr;           // [tile_cap][RP_TILE_NBR_WORDS(tile_cap)] bit B of row A: tiles A and B exchange bodies between sweeps (one holds a body the
+                                // other owns; symmetric) — whom a tile of k_joint_net_step waits for (rebuilt with the cones)
+    unsigned *tl_flag;          // [tile_cap][32] (one 128-byte line each) the sweep a tile has published: 16 x FL_SEQ of the launch + sweeps done
 };
+#define RP_TILE_NBR_WORDS(tile_cap) (((tile_cap) + 31) / 32)
 // ---- lean step graphs (rp_api.hip "lean graph") ----------------------------------------------------------------------------------
 // A MULTI-mode world whose contact graph did not change this step needs none of the launches that rebuild the colouring, the joint
 // colouring, the layout, the toucher ranks or the tiling — nine early exits per step.  The LEAN graph leaves them out: collision
@@ -451,7 +455,7 @@ __device__ __forceinline__ bool lean_dead(const DevWorld &w) {
     // tiling of at most that many tiles, no contact stage, no cone with more joints than the kernel has threads.  All four are results
     // of the layout rebuild / the tiling, which no lean graph runs)
     int jn_wrong = 0;
-    if (w.lean & 4) { const int nt = w.flags[FL_N_TILES], jmax = w.flags[FL_TILE_JMAX]; jn_wrong = (nt <= 0 || nt > (w.lean >> 8) || w.flags[FL_N_STAGES] != 0 || jmax <= 0 || jmax > RP_JN_THREADS) ? 1 : 0; }
+    if (w.lean & 4) { const int nt = w.flags[FL_N_TILES], jmax = w.flags[FL_TILE_JMAX]; jn_wrong = (nt <= 0 || nt > (w.lean >> 8) || nt > RP_JN_THREADS || w.prm.num_substeps > 8 || w.flags[FL_N_STAGES] != 0 || jmax <= 0 || jmax > RP_JN_THREADS) ? 1 : 0; }
     return (w.flags[FL_FAST_ABORT] | w.flags[FL_TODO_COUNT] | w.flags[FL_LAYOUT_DIRTY] | w.flags[FL_FLOW_DIRTY] | (w.n_joints > 0 ? w.flags[FL_JOINT_DIRTY] : 0) | bare_wrong | jn_wrong) != 0;
 }
 // collision kernels: this step's collision stage already ran (a dead lean step waits for its resume), or an earlier lean step died

@@ -37,3 +37,11 @@ for name, off, n in (("biased", 0, float(prof[2])), ("relaxed", 260, float(prof[
         v = v / n / 100
         print(f"{name}: {len(v)} tiles, whole sweep per tile: min {v.min():.2f} median {np.median(v):.2f} mean {v.mean():.2f} p90 {np.percentile(v, 90):.2f} max {v.max():.2f} us (argmax {int(v.argmax())})")
         if off == 0: print("  first tiles (us, joints):", " ".join(f"{v[k]:.1f}/{int(nj[k])}" for k in range(min(70, len(v)))))
+
+# the joint-net launch (k_joint_net_step), workgroup 0: ticks per phase, summed over the substeps of a launch
+jn = np.zeros(12, np.int64)
+L.rp_debug_read(w._ptr, 260, 12, jn.ctypes.data)
+if jn[11]:
+    n = float(jn[11]) * 100
+    names = ("prologue (lists, first entry)", "increment into LDS", "rows from poses", "biased stages", "integrate + publish", "grid barrier 1", "halo reload", "relaxed stages", "publish", "grid barrier 2", "impulses out")
+    print(f"k_joint_net_step, workgroup 0, {int(jn[11])} launches, us per launch: " + "; ".join(f"{names[k]} {jn[k] / n:.2f}" for k in range(11)) + f"; total {jn[:11].sum() / n:.1f}")
