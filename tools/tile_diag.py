@@ -43,5 +43,5 @@ jn = np.zeros(12, np.int64)
 L.rp_debug_read(w._ptr, 260, 12, jn.ctypes.data)
 if jn[11]:
     n = float(jn[11]) * 100
-    names = ("prologue (lists, first entry)", "increment into LDS", "rows from poses", "biased stages", "integrate + publish", "grid barrier 1", "halo reload", "relaxed stages", "publish", "grid barrier 2", "impulses out")
+    names = ("prologue (lists, first entry)", "increment into LDS", "rows from poses", "biased stages", "integrate + publish", "wait for the neighbouring tiles 1", "halo reload", "relaxed stages", "publish", "wait for the neighbouring tiles 2", "impulses out")
     print(f"k_joint_net_step, workgroup 0, {int(jn[11])} launches, us per launch: " + "; ".join(f"{names[k]} {jn[k] / n:.2f}" for k in range(11)) + f"; total {jn[:11].sum() / n:.1f}")
