@@ -235,6 +235,11 @@ RP_DEV int tile_cursor_below(const int *list, int begin, int n, int shift, int l
     return c;
 }
 #define RP_CONE_THREADS 512
+#ifdef RP_CONES_CHECK // diagnosis build: an index outside its array is recorded (dbg[890] = site, dbg[891] = index, dbg[892] = bound) and skipped
+#define CCHK(site, idx, bound) (((long long)(idx) >= 0 && (long long)(idx) < (long long)(bound)) ? true : (atomicMax((unsigned long long *)&w.dbg[890], (unsigned long long)(site)), w.dbg[891] = (long long)(idx), w.dbg[892] = (long long)(bound), false))
+#else
+#define CCHK(site, idx, bound) true
+#endif
 __global__ void __launch_bounds__(RP_CONE_THREADS) k_tiles_cones(DevWorld w) {
     if (!w.flags[FL_FLOW_DIRTY]) return;
     const int t = threadIdx.x, nt = blockDim.x, gid = blockIdx.x * nt + t, gstride = gridDim.x * nt;
@@ -245,8 +250,11 @@ __global__ void __launch_bounds__(RP_CONE_THREADS) k_tiles_cones(DevWorld w) {
         // slots inside a segment were handed out by atomics; a cell holds a handful of bodies)
         const int nb = (int)w.tl_bbox[9]; // bodies the sort covered
         for (int i = gid; i < nb; i += gstride) {
+            if (!CCHK(1, i, w.n_bodies)) continue;
             const int cc = w.tl_cell[i], cell = cc >= 0 ? cc : -1 - cc;
+            if (!CCHK(2, cell, RP_TILE_CELLS)) continue;
             const int beg = w.tl_cellofs[cell], end = cell + 1 < RP_TILE_CELLS ? w.tl_cellofs[cell + 1] : nb;
+            if (!CCHK(3, beg, w.n_bodies + 1) || !CCHK(4, end, w.n_bodies + 1)) continue;
             int r = 0;
             for (int k = beg; k < end; ++k) r += w.tl_sorted[k] < i;
             w.b_order[i] = beg + r;
@@ -254,7 +262,13 @@ __global__ void __launch_bounds__(RP_CONE_THREADS) k_tiles_cones(DevWorld w) {
         // the first sort of a world: its layout was still built in arena-index order — have the next step rebuild it along the curve
         if (gid == 0) { if (w.tl_bbox[10] == 0u) w.flags[FL_LAYOUT_DIRTY] = 1; w.tl_bbox[10] += 1u; }
     }
-    const int NT = w.flags[FL_N_TILES];
+    // ONE read of the tile count per workgroup: a workgroup whose cone does not fit zeroes FL_N_TILES while others are still starting, and
+    // waves of one workgroup that read different counts would leave the loop (and its barriers) at different tiles — the waves that
+    // stay then walk hash slots the others never initialised (found in round 6 on a collapsing pyramid of base 400: a memory fault)
+    __shared__ int nt_sh;
+    if (t == 0) nt_sh = __hip_atomic_load(&w.flags[FL_N_TILES], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int NT = nt_sh;
     if (NT <= 0) return;
     const int nst = w.flags[FL_N_STAGES], NG = (int)w.tl_bbox[6], T = (int)w.tl_bbox[7];
     const int njs = tile_joint_stages(w), nall = njs + nst; // a sweep = every joint stage, then every contact stage (solve.rs:89-92)
@@ -268,7 +282,7 @@ __global__ void __launch_bounds__(RP_CONE_THREADS) k_tiles_cones(DevWorld w) {
         if (t == 0) { nloc = 0; ncons = 0; bad = 0; }
         __syncthreads();
         const int ob = tile * T, oc = (NG - ob) < T ? (NG - ob) : T;
-        for (int k = t; k < oc; k += nt) { const int g = w.tl_owned[ob + k]; const int2 d = w.fb_deg[g], bg = w.fb_begin[g]; tile_insert(Tb, g, nall, d.x, bg.x, njs ? d.y : 0, bg.y); }
+        for (int k = t; k < oc; k += nt) { if (!CCHK(5, ob + k, w.n_bodies)) continue; const int g = w.tl_owned[ob + k]; if (!CCHK(6, g, w.n_bodies)) continue; const int2 d = w.fb_deg[g], bg = w.fb_begin[g]; tile_insert(Tb, g, nall, d.x, bg.x, njs ? d.y : 0, bg.y); }
         int4 *cons = w.tl_cons + (size_t)tile * RP_TILE_CCAP;
         int *soff = w.tl_soff + (size_t)tile * (RP_TILE_STAGES + 1);
         __syncthreads();
@@ -291,7 +305,15 @@ __global__ void __launch_bounds__(RP_CONE_THREADS) k_tiles_cones(DevWorld w) {
                 const int c = jst ? hj[h] : TW_CUR(wd);
                 if (c <= 0) continue;
                 const int at = (jst ? hjbeg[h] : hbeg[h]) + c - 1;
+                if (!CCHK(7, at, 2 * (size_t)w.cons_cap)) {
+#ifdef RP_CONES_CHECK
+                    if (atomicCAS((unsigned long long *)&w.dbg[888], 0ull, 1ull) == 0ull) {
+                    w.dbg[893] = hbeg[h]; w.dbg[894] = c; w.dbg[895] = h; w.dbg[896] = lid; w.dbg[897] = a; w.dbg[898] = wd; w.dbg[899] = (long long)S * 100000 + n0; w.dbg[889] = (long long)nloc * 100000 + tile; w.dbg[887] = (long long)nsnap * 100000 + oc; w.dbg[886] = (long long)bad * 100000 + ncons; }
+#endif
+                    continue;
+                }
                 const int item = jst ? w.f_jsorted[at] : (w.f_sorted[at] >> 1), b = jst ? w.f_jother[at] : w.f_other[at];
+                if (b >= 0 && !CCHK(8, b, w.n_bodies)) continue;
                 if (item < beg) continue; // this body has no item of stage S
                 if (jst) hj[h] = c - 1; else hw[h] = wd - (1 << 11);
                 if (b >= 0) {
@@ -347,9 +369,11 @@ __global__ void __launch_bounds__(RP_CONE_THREADS) k_tiles_cones(DevWorld w) {
                 dst = ssoff[sg] + r;
             }
             int2 ab; int code;
+            if (item >= 0 && !CCHK(9, item, w.cons_cap)) continue;
             if (item >= 0) { ab = w.fk_ids[item]; code = item; }
             else { const int j = w.j_order[-1 - item]; ab = make_int2(w.j_b1[j], w.j_b2[j]); code = -1 - j; } // (the sweep wants the joint itself)
             const int first = ab.x >= 0 ? ab.x : ab.y;
+            if (!CCHK(10, first, w.n_bodies)) continue;
             const int own = w.tl_body_tile[first] == tile ? 1 : 0;
             const int l1 = ab.x >= 0 ? TW_LID(hw[tile_find(Tb, ab.x)]) : -1, l2 = ab.y >= 0 ? TW_LID(hw[tile_find(Tb, ab.y)]) : -1;
             cons[dst] = make_int4(code, l1, l2, own);

@@ -428,3 +428,20 @@ def test_a_stale_tile_plan_falls_back_bit_exact(scene):
     made a cone outgrow its LDS budget) every sweep kernel runs the whole sweep in workgroup 0 and moves the result to the other
     buffers.  A timing accident in normal runs — RP_TILE_STALE_PLAN=1 (a hook of the testing build) makes it every sweep of every step"""
     _in_testing_build("_stale_plan_body", scene)
+
+
+def test_a_pile_whose_cones_outgrow_the_budget_abandons_its_tiling_without_a_fault():
+    """b3d_large_pyramid at base 400 (80,200 cuboids) collapses while it settles; around step 450 some cones no longer fit the LDS budget
+    and the tiling is abandoned (FL_N_TILES = 0) by the workgroup that finds out — while other workgroups of k_tiles_cones are still
+    starting.  Until round 6 the waves of one workgroup could read different tile counts there, leave the tile loop at different tiles
+    and walk hash slots nobody had initialised: a GPU memory fault around step 470 (every run).  In a child process: a fault would
+    take the interpreter with it."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RP_NO_TILES", "RP_TILE_TARGET", "RP_TILE_MIN", "RP_NO_LEAN")}
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "lp_big_diag.py"), "400", "550"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("400 ")]
+    assert len(lines) == 11, r.stdout[-1500:]
+    assert any("'num_tiles': 0" in ln for ln in lines[6:]) and any("'tile_sweeps': 1" in ln for ln in lines[:6]), r.stdout[-1500:]   # tiled first, abandoned later
+    assert all("'overflow_flags': 0" in ln for ln in lines)
