@@ -231,6 +231,9 @@ typedef struct rp_counters {
                                     * next step reads what this one wrote from the CU's own caches); fused_steps / fused_launches = steps per launch */
     int32_t joint_net_steps;       /* of lean_steps: those whose whole TGS loop was ONE launch that keeps every tile's joints in registers
                                     * (k_joint_net_step: worlds of spherical impulse joints without a single contact manifold — b3d_joint_grid) */
+    int32_t joint_net_disabled;    /* how often a tile of that launch waited ~2 s for a neighbouring tile whose workgroup never became resident (another
+                                    * process or stream holds CUs): the step died without writing anything and was resumed by the full graph, and the
+                                    * world takes the sweep launches from then on — nonzero = the world lost this path */
 } rp_counters;
 
 #define RP_INVALID_HANDLE 0xffffffffffffffffull

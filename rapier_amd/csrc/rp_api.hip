@@ -126,6 +126,8 @@ struct AllocRec { void *ptr; size_t off, elem, per, stride; int planes, dom, fil
 struct rp_world {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;           // the solver branch of a joint-net lean step (enqueue_whole): runs beside the collision stage
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     rp_integration_params params;
     float gravity[3];
     std::vector<HostBody> bodies;
@@ -226,7 +228,7 @@ struct rp_world {
     long long full_until = 0;      // stay on the full graph until this many steps were requested
     long long eager_until = 0;     // launch the kernels directly until this many steps were requested: a world that is being edited (bodies /
                                    // colliders / joints coming and going every few steps) would re-capture its graphs — ~10 ms — after every edit
-    long long fast_steps = 0, full_steps = 0, replayed_steps = 0, fused_steps = 0; int fused_disabled = 0;
+    long long fast_steps = 0, full_steps = 0, replayed_steps = 0, fused_steps = 0; int fused_disabled = 0, jn_disabled = 0;
     // timers
     bool timers = false;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -452,6 +454,11 @@ extern "C" int32_t rp_world_create(const rp_integration_params *params, const fl
     if (g && g[0] == '1') w->use_lean = false;
     g = getenv("RP_NO_JOINT_NET");
     if (g && g[0] == '1') w->use_jn = false;
+    g = getenv("RP_NO_JOINT_NET_FORK");
+    if (!(g && g[0] == '1') && w->use_jn) { // (the fork is an optimisation: a world without it runs the lean step in one line)
+        if (hipStreamCreateWithFlags(&w->stream2, hipStreamNonBlocking) != hipSuccess) w->stream2 = nullptr;
+        if (w->stream2 && (hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming) != hipSuccess)) { hipStreamDestroy(w->stream2); w->stream2 = nullptr; }
+    }
     g = getenv("RP_NO_FLOW");
     if (g && g[0] == '1') w->use_flow = false;
     g = getenv("RP_FLOW");
@@ -459,6 +466,7 @@ extern "C" int32_t rp_world_create(const rp_integration_params *params, const fl
     if (w->use_flow) { w->flow_grid = rp_flow_grid(device); if (w->flow_grid <= 0) w->use_flow = false; }
     if (w->use_fused) { w->fused_grid = rp_fused_grid(device); if (w->fused_grid <= 0) w->use_fused = false; }
 #ifdef RP_TESTING
+    { extern int rp_test_jn_stall_tile; const char *js = getenv("RP_TEST_JN_STALL"); rp_test_jn_stall_tile = js ? atoi(js) : -1; } // (test hook: that workgroup of k_joint_net_step never arrives)
     if (const char *ra = getenv("RP_TEST_REBASE_AT")) w->rebase_at = std::max(8, atoi(ra)); // (test hook: the stamps move back every few steps)
 #endif
     { const char *nd = getenv("RP_NO_ISL_DENSE"); w->fused_grid_dense = (nd && nd[0] == '1') ? 0 : rp_fused_grid_dense(device); if (const char *fd = getenv("RP_ISL_DENSE")) { if (fd[0] == '1' && w->fused_grid_dense > 0) w->force_dense = true; if (fd[0] == '0') w->auto_dense = false; } }
@@ -499,6 +507,9 @@ extern "C" int32_t rp_world_destroy(rp_world *w) {
     for (void **b : {&w->d_gid, &w->d_skip, &w->d_pack, &w->d_gather, (void **)&w->d_pack_count}) if (*b) { hipFree(*b); *b = nullptr; }
     if (w->d_puts) { hipFree(w->d_puts); w->d_puts = nullptr; }
     for (auto &e : w->ev) if (e) hipEventDestroy(e);
+    if (w->ev_fork) hipEventDestroy(w->ev_fork);
+    if (w->ev_join) hipEventDestroy(w->ev_join);
+    if (w->stream2) hipStreamDestroy(w->stream2);
     if (w->stream) hipStreamDestroy(w->stream);
     delete w;
     return RP_OK;

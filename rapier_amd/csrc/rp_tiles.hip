@@ -859,7 +859,9 @@ RP_DEV void jn_store_sc1(float4 *p, float4 v) {
 // ahead of a neighbour — the other copy of the double buffers is safe to overwrite).  handoff-flag of the MI355X guide (sc1 payload,
 // every storing wave drains, one lane stores the flag; relaxed polls, ONE agent acquire) in place of a grid barrier: ~7 us -> ~2 us
 // per sweep boundary, and a slow tile only holds up its neighbours.
-// true = the launch is dead (a neighbour never arrived: not resident — RP_OVF_GRID, as gbar_sync)
+// true = the launch is dead: a neighbour never arrived (a workgroup that is not resident — another process or stream holds CUs).  Nothing
+// is committed by this kernel (the write-back is a launch of its own and looks at lean_dead): FL_JN_TIMEOUT makes the step die like any
+// lean step, the full graph resumes it, and settle() stops planning the joint-net form for this world (rp_counters.joint_net_disabled)
 RP_DEV bool jn_sync(const DevWorld &w, int tile, unsigned epoch, const int *Lnbr, int nn) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every wave: its write-through stores have completed
     __syncthreads();
@@ -870,16 +872,17 @@ RP_DEV bool jn_sync(const DevWorld &w, int tile, unsigned epoch, const int *Lnbr
         unsigned spins = 0;
         while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 21)) { atomicOr(&w.flags[FL_OVERFLOW], RP_OVF_GRID); dead = 1; break; }
-            if ((spins & 1023u) == 0 && (__hip_atomic_load(&w.flags[FL_OVERFLOW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & RP_OVF_GRID)) { dead = 1; break; }
+            if (++spins > (1u << 21)) { __hip_atomic_store(&w.flags[FL_JN_TIMEOUT], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); dead = 1; break; }
+            if ((spins & 1023u) == 0 && __hip_atomic_load(&w.flags[FL_JN_TIMEOUT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { dead = 1; break; } // (some tile gave up: so does this one)
         }
     }
     __syncthreads();
     if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     return __syncthreads_or(dead) != 0;
 }
-__global__ void __launch_bounds__(RP_JN_THREADS) k_joint_net_step(DevWorld w, int joint_warmstart) {
+__global__ void __launch_bounds__(RP_JN_THREADS) k_joint_net_step(DevWorld w, int joint_warmstart, int stall_tile) {
     if (lean_dead(w)) return; // (the same answer in every workgroup: nothing it reads changes while a lean graph runs)
+    if ((int)blockIdx.x == stall_tile) return; // (test hook, testing build only: a workgroup that never becomes resident)
     __shared__ float4 Ll[RP_TILE_BCAP], La[RP_TILE_BCAP];
     __shared__ int Lg[RP_TILE_BCAP];
     __shared__ int Soff[RP_TILE_STAGES + 2];
@@ -985,8 +988,9 @@ __global__ void __launch_bounds__(RP_JN_THREADS) k_joint_net_step(DevWorld w, in
 #endif
 #undef JN_STAMP
 }
+int rp_test_jn_stall_tile = -1; // (RP_TEST_JN_STALL=<tile>, testing build only: rp_api.hip)
 void rp_launch_joint_net_step(const DevWorld &w, hipStream_t st, int grid, int joint_warmstart) {
-    hipLaunchKernelGGL(k_joint_net_step, dim3(grid < 1 ? 1 : grid), dim3(RP_JN_THREADS), 0, st, w, joint_warmstart);
+    hipLaunchKernelGGL(k_joint_net_step, dim3(grid < 1 ? 1 : grid), dim3(RP_JN_THREADS), 0, st, w, joint_warmstart, rp_test_jn_stall_tile);
 }
 // most workgroups a k_joint_net_step launch may use on the current device (all of them resident at once: grid barriers), 0 = none
 int rp_joint_net_cap(void) {

@@ -121,6 +121,8 @@ enum {
     FL_CCD_CLAMPS,      // (body, step) cases in which k_ccd clamped a pose to a time of impact
     FL_UF_NPAIRS,       // scratch of a layout rebuild: active dynamic-dynamic pairs listed for the island union-find (uf_pairs)
     FL_N_TILES,         // LDS tiles the global path's big component is cut into (rp_tiles.hip); 0 = no valid tiling: colour stages as launches
+    FL_JN_TIMEOUT,      // a tile of k_joint_net_step gave up waiting for a neighbouring tile (~2 s: a workgroup of the launch was not resident): the
+                        // step died like any lean step (nothing committed, resumed by the full graph); settle() takes the joint-net form from this world
     FL_TILE_JMAX,       // joints of the largest cone of the current tiling (k_tiles_cones): k_joint_net_step holds one per thread
     FL_COUNT = 72       // (publish_flags copies the slots in strides of the workgroup)
 };
@@ -455,7 +457,7 @@ __device__ __forceinline__ bool lean_dead(const DevWorld &w) {
     // tiling of at most that many tiles, no contact stage, no cone with more joints than the kernel has threads.  All four are results
     // of the layout rebuild / the tiling, which no lean graph runs)
     int jn_wrong = 0;
-    if (w.lean & 4) { const int nt = w.flags[FL_N_TILES], jmax = w.flags[FL_TILE_JMAX]; jn_wrong = (nt <= 0 || nt > (w.lean >> 8) || nt > RP_JN_THREADS || w.prm.num_substeps > 8 || w.flags[FL_N_STAGES] != 0 || jmax <= 0 || jmax > RP_JN_THREADS) ? 1 : 0; }
+    if (w.lean & 4) { const int nt = w.flags[FL_N_TILES], jmax = w.flags[FL_TILE_JMAX]; jn_wrong = (w.flags[FL_JN_TIMEOUT] != 0 || nt <= 0 || nt > (w.lean >> 8) || nt > RP_JN_THREADS || w.prm.num_substeps > 8 || w.flags[FL_N_STAGES] != 0 || jmax <= 0 || jmax > RP_JN_THREADS) ? 1 : 0; }
     return (w.flags[FL_FAST_ABORT] | w.flags[FL_TODO_COUNT] | w.flags[FL_LAYOUT_DIRTY] | w.flags[FL_FLOW_DIRTY] | (w.n_joints > 0 ? w.flags[FL_JOINT_DIRTY] : 0) | bare_wrong | jn_wrong) != 0;
 }
 // collision kernels: this step's collision stage already ran (a dead lean step waits for its resume), or an earlier lean step died

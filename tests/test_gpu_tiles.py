@@ -403,6 +403,28 @@ def test_joint_net_step_dies_and_resumes_bit_exact(monkeypatch):
     assert seen > 0 and g.counters()["overflow_flags"] == 0
 
 
+def test_joint_net_step_meets_its_first_contact_on_the_device_bit_exact(monkeypatch):
+    """a free ball flies into the hanging net: the first contact manifold of the world appears on the DEVICE, in the narrow phase of a
+    lean step whose solver branch (k_begin_generate + k_joint_net_step, forked beside the collision stage) started on "alive" — the
+    write-back behind the join finds the step dead, nothing is committed, the full graph resumes it; contacts come and go while the
+    ball bounces through, joint-net launches return when the last one has ended"""
+    sc = S.joint_net(36)
+    b = sc.add_body(body_type=S.BODY_DYNAMIC, translation=(17.4, -10.0, 7.0), linvel=(0.3, 0.0, -9.0))
+    sc.add_collider(b, shape=S.SHAPE_BALL, half_extents=(0.45, 0.0, 0.0), density=3.0)
+    g, o = _world(sc, monkeypatch), OracleWorld(sc)
+    seen, jn = 0, []
+    for cp in (20, 40, 50, 60, 70, 80, 100, 140, 200, 300):
+        g.step(cp - (jn[-1][0] if jn else 0)); o.step(cp - (jn[-1][0] if jn else 0))
+        _equal(g, o, f"ball into the net @ {cp}")
+        c = g.counters()
+        seen = max(seen, c["num_manifolds"]); jn.append((cp, c["joint_net_steps"], c["replayed_steps"]))
+    _joint_impulses_equal(g, o, "ball into the net")
+    assert seen > 0, jn                          # the ball met the net
+    assert jn[1][1] > 20, jn                     # joint-net launches before the impact ...
+    assert c["replayed_steps"] > 0, jn           # ... a lean step died on the device and was resumed
+    assert c["overflow_flags"] == 0
+
+
 @pytest.mark.parametrize("seed", [3, 17])
 def test_lean_steps_in_a_churning_pile_bit_exact(monkeypatch, seed):
     """1,300 tumbling cuboids and balls (restitution removed: worlds with a restitution sweep keep the full graph) settling in a pit:
@@ -428,6 +450,23 @@ def test_a_stale_tile_plan_falls_back_bit_exact(scene):
     made a cone outgrow its LDS budget) every sweep kernel runs the whole sweep in workgroup 0 and moves the result to the other
     buffers.  A timing accident in normal runs — RP_TILE_STALE_PLAN=1 (a hook of the testing build) makes it every sweep of every step"""
     _in_testing_build("_stale_plan_body", scene)
+
+
+def _jn_stall_body():
+    sc = S.joint_grid(40)
+    g, o, c = _run(sc, [1, 6, 40, 80], _Env(), RP_TEST_JN_STALL=3)
+    assert c["joint_net_disabled"] == 1 and c["joint_net_steps"] >= 1 and c["replayed_steps"] >= 1 and c["overflow_flags"] == 0, c
+    assert c["lean_steps"] > c["joint_net_steps"] + 20, c          # lean graphs went on, on the sweep launches
+    gc, gi = g.read_joints(); oc, oi = o.read_joints()
+    np.testing.assert_array_equal(gi, oi, err_msg="joint impulses")
+
+
+def test_a_joint_net_launch_whose_workgroup_never_arrives_dies_without_writing():
+    """every workgroup of k_joint_net_step must be resident (a tile waits for its neighbours' flags); on a shared device one may not be.
+    RP_TEST_JN_STALL=3 (testing build) makes workgroup 3 of every such launch leave at once: its neighbours give up after ~2 s
+    (FL_JN_TIMEOUT), every other tile follows, the write-back behind the launch finds the step dead — nothing was committed —, the
+    full graph resumes it and the world takes the sweep launches from then on (rp_counters.joint_net_disabled); bit for bit the oracle"""
+    _in_testing_build("_jn_stall_body")
 
 
 def test_a_pile_whose_cones_outgrow_the_budget_abandons_its_tiling_without_a_fault():
