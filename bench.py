@@ -42,7 +42,7 @@ _GLOBAL_SOURCES = _ISLAND_SOURCES[4:] + ["rapier_amd/csrc/rp_tiles.hip", "rapier
 KERNEL_SOURCES = {"c3": _ISLAND_SOURCES, "large_pyramid": _GLOBAL_SOURCES, "joint_grid": _GLOBAL_SOURCES}
 # kernels of the TGS loop on the global path (what `velocity_update_ms` brackets minus assembly / write-back): their PMC bytes per
 # step are summed into `solver_loop_hbm_bytes_per_step` by tools/pmc_summary.py
-SOLVER_LOOP_KERNELS = ("k_tile_sweep", "k_ws_prepare", "k_increment_ws", "k_increment", "k_integrate", "k_stage", "k_tail", "k_global_flow",
+SOLVER_LOOP_KERNELS = ("k_joint_net_step", "k_tile_sweep", "k_ws_prepare", "k_increment_ws", "k_increment", "k_integrate", "k_stage", "k_tail", "k_global_flow",
                        "k_joint_update", "k_joint_sweep", "k_joint_tail")
 
 
