@@ -375,6 +375,57 @@ def test_joint_net_step_bit_exact(monkeypatch, case):
     assert ch["joint_net_steps"] == 0 and ch["lean_steps"] > 100, ch
 
 
+def _random_net(seed: int, n: int = 36):
+    """an n x n net of balls on spherical joints with holes, diagonals, random pins, random ball sizes and gravity: irregular cones, joint
+    colours and halos for the joint-net launch"""
+    rng = np.random.default_rng(seed)
+    g = rng.uniform(-1.0, 1.0, 3) * (2.0, 9.81, 2.0)
+    sc = S.Scene(name=f"random_net_{seed}", gravity=(float(g[0]), float(-abs(g[1])), float(g[2])))
+    h = [[-1] * n for _ in range(n)]
+    for i in range(n):
+        for j in range(n):
+            fixed = (i == 0 and rng.random() < 0.3) or rng.random() < 0.01
+            b = sc.add_body(body_type=S.BODY_FIXED if fixed else S.BODY_DYNAMIC, translation=(float(j), -float(i), 0.0))
+            sc.add_collider(b, shape=S.SHAPE_BALL, half_extents=(float(rng.uniform(0.12, 0.3)), 0.0, 0.0), density=float(rng.uniform(0.5, 3.0)))
+            h[i][j] = b
+    for i in range(n):
+        for j in range(n):
+            if i > 0 and rng.random() < 0.92: sc.add_joint(h[i - 1][j], h[i][j], (0.0, -0.5, 0.0), (0.0, 0.5, 0.0))
+            if j > 0 and rng.random() < 0.92: sc.add_joint(h[i][j - 1], h[i][j], (0.5, 0.0, 0.0), (-0.5, 0.0, 0.0))
+            if i > 0 and j > 0 and rng.random() < 0.15: sc.add_joint(h[i - 1][j - 1], h[i][j], (0.5, -0.5, 0.0), (-0.5, 0.5, 0.0))
+    sc.params["warmstart_joints"] = int(rng.integers(0, 2))
+    return sc, rng
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_fuzz_random_spherical_nets_bit_exact(monkeypatch, seed):
+    """random nets with random kicks and a removed joint between checkpoints: whatever launch form a step takes (joint-net, sweep launches,
+    full steps after an edit or a contact) the bodies and the joint impulses are the oracle's"""
+    import os
+    import oracle_ffi
+    sc, rng = _random_net(seed)
+    oracle_ffi.set_threads(max(1, min(os.cpu_count() or 1, 16)))
+    try:
+        g, o = _world(sc, monkeypatch), OracleWorld(sc)
+        dyn = [i for i, b in enumerate(sc.bodies) if int(b["body_type"]) == S.BODY_DYNAMIC]
+        done = 0
+        for k, cp in enumerate((3, 30, 60, 61, 90, 150, 220)):
+            g.step(cp - done); o.step(cp - done); done = cp
+            _equal(g, o, f"{sc.name} @ {cp}")
+            if k in (1, 3, 5):
+                for b in rng.choice(dyn, 6, replace=False):
+                    imp = tuple(float(x) for x in rng.uniform(-2.0, 2.0, 3))
+                    g.apply_impulse([int(b)], impulse=imp); o.apply_impulse(int(b), impulse=imp)
+            if k == 2:
+                j = int(rng.integers(0, len(sc.joints)))
+                g.remove_impulse_joint([g.joint_handles()[j]]); o.remove_joint(j)
+        c = g.counters()
+    finally:
+        oracle_ffi.set_threads(1)
+    _joint_impulses_equal(g, o, sc.name)
+    assert c["overflow_flags"] == 0 and c["joint_net_steps"] > 10, c   # (kicked balls that meet the CCD criterion take full steps)
+
+
 def test_joint_net_step_dies_and_resumes_bit_exact(monkeypatch):
     """the joint-net launch validates itself like every lean graph: kicked balls, a removed joint (the joint colouring is rebuilt, the
     tiling with it) and a ball dropped INTO the net (the first contact manifold: the bare form is wrong from then on) are all found
