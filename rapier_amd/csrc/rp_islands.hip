@@ -796,8 +796,14 @@ __global__ void __launch_bounds__(ISL_THREADS) k_island_solve_wide(DevWorld w, i
 // whose constraint model k_island_solve does not hold in registers (FrictionModel::Coulomb): their islands used to be poisoned
 // onto the global path, where every colour stage costs a cross-CU hand-off (~8 us) instead of a barrier.
 // Same stage order as global_single_block (rp_global.h), so the result is bit-identical to the global path and the oracle.
-struct IslGenAcc {
-    static constexpr bool PRELOAD = false; // a fused kernel: the preloaded rows would live in scratch (measured: 0.57 -> 1.67 ms)
+#define ISL_GEN_THREADS 256 // k_island_generic: one thread per manifold (<= RP_ISL_NC_MAX = 160), FOUR wavefronts = one per SIMD, so a lane may hold up to
+                            // 512 registers — room for the rows a stage reads (Acc::PRELOAD below)
+template <bool PRE>
+struct IslGenAccT {
+    // PRELOAD: a stage fetches every row it reads in ONE round trip before its first store instead of one round trip per contact point
+    // and part (rolled loops: 8 dependent trips of ~0.7 us per stage = what a stage cost).  At 512 threads per workgroup the preloaded
+    // rows lived in scratch (256 registers per lane: 0.57 -> 1.67 ms per step, round 2); at 256 threads they fit the register file.
+    static constexpr bool PRELOAD = PRE;
     const DevWorld &w; int pos; const IslLds &L;
     // The thread owns ONE manifold from generate to write-back: what every stage asks for FIRST — the two solver bodies, the point
     // count, the direction / inverse-mass / tangent header planes — stays in registers once generate has stored it (round 5: those
@@ -806,7 +812,7 @@ struct IslGenAcc {
     // (Also measured in round 5: the 56 per-point planes of a sweep in LDS instead of L2 — 147 KB of dynamic LDS — 516 us: a stage is
     // bound by the ~2,500 dependent instructions of its four normal + four tangent solves on one wavefront per SIMD, not by its loads.)
     mutable int m_id1, m_id2, m_n, m_cid; mutable float4 m_h0, m_h1, m_h2, m_h6;
-    RP_DEV IslGenAcc(const DevWorld &w_, int pos_, const IslLds &L_) : w(w_), pos(pos_), L(L_), m_id1(-1), m_id2(-1), m_n(0), m_cid(0) {
+    RP_DEV IslGenAccT(const DevWorld &w_, int pos_, const IslLds &L_) : w(w_), pos(pos_), L(L_), m_id1(-1), m_id2(-1), m_n(0), m_cid(0) {
         m_h0 = make_float4(0, 0, 0, 0); m_h1 = m_h0; m_h2 = m_h0; m_h6 = m_h0;
     }
     RP_DEV float4 ld(int plane) const {
@@ -826,8 +832,9 @@ struct IslGenAcc {
     RP_DEV void set_vel(int id, const Vel &v) const { isl_set_vel(L, id, v); }
     RP_DEV Xf xf(int id) const { return isl_xf(L, id); }
 };
+typedef IslGenAccT<true> IslGenAcc;
 template <bool COUL>
-__global__ void __launch_bounds__(ISL_THREADS) k_island_generic(DevWorld w, int has_restitution, int fast, int retire) {
+__global__ void __launch_bounds__(ISL_GEN_THREADS) k_island_generic(DevWorld w, int has_restitution, int fast, int retire) {
     const bool aborted = fast && w.flags[FL_FAST_ABORT];
     if (retire && blockIdx.x == 0) { // SINGLE mode: workgroup 0 retires the step and publishes the scalars (as k_island_solve does)
         if (threadIdx.x == 0) { w.flags[FL_SEQ] += 1; if (!aborted) w.flags[FL_STEP] += 1; }
@@ -939,8 +946,8 @@ void rp_launch_island_solve_steps(const DevWorld &w, hipStream_t st, int grid, i
 }
 void rp_launch_island_solve(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast, int retire, int fused, int dense, int wide) {
     if (grid < 1) grid = 1;
-    if (w.prm.p.friction_model == RP_FRICTION_COULOMB) { hipLaunchKernelGGL(k_island_generic<true>, dim3(grid), dim3(ISL_THREADS), 0, st, w, has_restitution, fast, retire); return; }
-    if (w.isl_generic) { hipLaunchKernelGGL(k_island_generic<false>, dim3(grid), dim3(ISL_THREADS), 0, st, w, has_restitution, fast, retire); return; } // RP_ISL_GENERIC=1: the twist model through the generic kernel (tests)
+    if (w.prm.p.friction_model == RP_FRICTION_COULOMB) { hipLaunchKernelGGL(k_island_generic<true>, dim3(grid), dim3(ISL_GEN_THREADS), 0, st, w, has_restitution, fast, retire); return; }
+    if (w.isl_generic) { hipLaunchKernelGGL(k_island_generic<false>, dim3(grid), dim3(ISL_GEN_THREADS), 0, st, w, has_restitution, fast, retire); return; } // RP_ISL_GENERIC=1: the twist model through the generic kernel (tests)
     if (dense) rp_launch_island_solve_dense(w, st, grid, has_restitution, fast, retire, fused, wide); // rp_islands_lean.hip
     else if (wide) hipLaunchKernelGGL(k_island_solve_wide, dim3(grid), dim3(ISL_THREADS), 0, st, w, has_restitution, fast, retire, fused);
     else hipLaunchKernelGGL(k_island_solve, dim3(grid), dim3(ISL_THREADS), 0, st, w, has_restitution, fast, retire, fused);
