@@ -233,7 +233,10 @@ typedef struct rp_counters {
                                     * (k_joint_net_step: worlds of spherical impulse joints without a single contact manifold — b3d_joint_grid) */
     int32_t joint_net_disabled;    /* how often a tile of that launch waited ~2 s for a neighbouring tile whose workgroup never became resident (another
                                     * process or stream holds CUs): the step died without writing anything and was resumed by the full graph, and the
-                                    * world takes the sweep launches from then on — nonzero = the world lost this path */
+                                    * world takes the sweep launches from then on — nonzero = the world lost this path (tile_step_steps' launch counts here too) */
+    int32_t tile_step_steps;       /* of lean_steps: those whose whole TGS loop was ONE launch over the LDS tiles of a contact world (k_tile_step: the
+                                    * prepare / increment / biased / relaxed launches of every substep as phases of one kernel, a tile waits for its
+                                    * neighbouring tiles' flags instead of a kernel boundary — b3d_large_pyramid) */
 } rp_counters;
 
 #define RP_INVALID_HANDLE 0xffffffffffffffffull

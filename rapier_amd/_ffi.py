@@ -35,7 +35,7 @@ class Counters(C.Structure):
         "velocity_update_ms")] + [(n, C.c_int32) for n in (
         "num_pairs", "num_manifolds", "num_solver_contacts", "num_colors", "num_parallel_stages",
         "num_dynamic_bodies", "bp_rebuilds", "full_updates", "overflow_flags", "quarantined",
-        "fast_steps", "full_steps", "replayed_steps", "num_sleeping_bodies", "ccd_active_count", "ccd_clamp_count", "num_tiles", "tile_sweeps", "bp_large_list", "lean_steps", "fused_steps", "num_islands", "num_global_bodies", "fused_disabled", "fused_launches", "joint_net_steps", "joint_net_disabled")]
+        "fast_steps", "full_steps", "replayed_steps", "num_sleeping_bodies", "ccd_active_count", "ccd_clamp_count", "num_tiles", "tile_sweeps", "bp_large_list", "lean_steps", "fused_steps", "num_islands", "num_global_bodies", "fused_disabled", "fused_launches", "joint_net_steps", "joint_net_disabled", "tile_step_steps")]
 
 
 _LIB = None

@@ -103,6 +103,7 @@ static int gbar_grid_for_device(int device) {
 }
 int rp_fused_grid(int device); int rp_fused_grid_dense(int device);
 int rp_joint_net_cap(void); // rp_tiles.hip
+int rp_tile_step_cap(void);  // rp_tiles.hip
 
 struct HostBody {
     rp_body_desc d; float inv_mass; float inv_pi[3]; float lcom[3]; int ncolliders; bool removed;
@@ -188,22 +189,26 @@ struct rp_world {
     // shard guard (rp_world_set_shard_guard): host copy, re-uploaded whenever the device world is rebuilt
     std::vector<float4> guard_min, guard_max; std::vector<int> guard_start, guard_items; float guard_origin[3] = {0, 0, 0}, guard_cell = 0.0f; int guard_dims[3] = {0, 0, 0};
     // launch plan + graph
-    int plan_stages = 0, plan_blocks = 1, plan_single = 1, plan_island_grid = 1, plan_joint_stages = 0, plan_no_global = 0, plan_fused = 0, plan_tile_grid = 0, plan_no_contacts = 0, plan_bare = 0, plan_jn = 0, plan_dense = 0, plan_wide = 0;
+    int plan_stages = 0, plan_blocks = 1, plan_single = 1, plan_island_grid = 1, plan_joint_stages = 0, plan_no_global = 0, plan_fused = 0, plan_tile_grid = 0, plan_no_contacts = 0, plan_bare = 0, plan_jn = 0, plan_ts = 0, plan_dense = 0, plan_wide = 0;
     bool has_restitution = false;
     // [0] = full path, [1] = fast path, [2] = lean path; "whole" = one graph per step, col/loop/fin = timed thirds (full / fast only)
     hipGraph_t g_whole[3] = {nullptr, nullptr, nullptr}, g_col[3] = {nullptr, nullptr, nullptr}, g_loop[3] = {nullptr, nullptr, nullptr}, g_fin[3] = {nullptr, nullptr, nullptr};
     hipGraphExec_t ge_whole[3] = {nullptr, nullptr, nullptr}, ge_col[3] = {nullptr, nullptr, nullptr}, ge_loop[3] = {nullptr, nullptr, nullptr}, ge_fin[3] = {nullptr, nullptr, nullptr};
-    int graph_stages = -1, graph_blocks = -1, graph_single = -1, graph_island_grid = -1, graph_dense = -1, graph_wide = -1, graph_joint_stages = -1, graph_no_global = -1, graph_fused = -1, graph_tile_grid = -1, graph_no_contacts = -1, graph_bare = -1, graph_jn = -1;
+    int graph_stages = -1, graph_blocks = -1, graph_single = -1, graph_island_grid = -1, graph_dense = -1, graph_wide = -1, graph_joint_stages = -1, graph_no_global = -1, graph_fused = -1, graph_tile_grid = -1, graph_no_contacts = -1, graph_bare = -1, graph_jn = -1, graph_ts = -1;
     bool use_graph = true, use_fast = true, use_fused = true;
     long long last_periodic_settle = 0;
     long long clean_fast_steps = 0; // fast steps enqueued since the host last saw an aborted one (step_once: how many steps a launch may carry)
     bool replaying = false;         // settle() is replaying steps that were requested before: step_once must not count them again
-    bool use_multi = true; int cur_multi = 1; long long multi_launches = 0, fused_launches = 0, jn_steps = 0; // launches of several fused steps (k_island_solve_steps): allowed / steps of the launch being enqueued
+    bool use_multi = true; int cur_multi = 1; long long multi_launches = 0, fused_launches = 0, jn_steps = 0, ts_steps = 0; // launches of several fused steps (k_island_solve_steps): allowed / steps of the launch being enqueued
     bool auto_dense = true;        // RP_ISL_DENSE=0: never
     bool force_dense = false;      // RP_ISL_DENSE=1 (tests): the dense form of k_island_solve whatever the island count
     bool use_jn = true;            // the joint-net form of a bare lean graph (k_joint_net_step, rp_tiles.hip); RP_NO_JOINT_NET=1: never
+    bool use_ts = true;            // the one-launch form of a tiled contact world's lean graph (k_tile_step, rp_tiles.hip); RP_NO_TILE_STEP=1: never
     bool use_lean = true;          // the lean step graph of MULTI-mode worlds (below: "lean graph"); RP_NO_LEAN=1: never
     int cur_lean = 0;              // the enqueue_* callbacks capture / launch the lean graph (with dw_lean)
+    bool ts_world_ok = false;      // step_once: nothing in this world (sleeping, events, sensors, ...) that a step dying behind its solver launch would have touched
+    int cur_ts = 0;                // ... a FULL graph whose TGS loop is the one-launch form (k_tile_step): its solver, write-back and k_ccd launches get dw_ts
+    DevWorld dw_ts;                // dw with lean = 8 | grid << 8 (no bit 0: the graph is a full one; lean_dead then only speaks about the launch itself)
     DevWorld dw_lean;              // dw with lean = 1: the kernel argument of a lean graph's launches
     long long lean_steps = 0;      // lean graphs enqueued
     long long lean_backoff = 3;    // full steps after a lean step died (doubles per death up to 256, back to 3 after 64 clean lean steps)
@@ -454,6 +459,8 @@ extern "C" int32_t rp_world_create(const rp_integration_params *params, const fl
     if (g && g[0] == '1') w->use_lean = false;
     g = getenv("RP_NO_JOINT_NET");
     if (g && g[0] == '1') w->use_jn = false;
+    g = getenv("RP_NO_TILE_STEP");
+    if (g && g[0] == '1') w->use_ts = false;
     g = getenv("RP_NO_JOINT_NET_FORK");
     if (!(g && g[0] == '1') && w->use_jn) { // (the fork is an optimisation: a world without it runs the lean step in one line)
         if (hipStreamCreateWithFlags(&w->stream2, hipStreamNonBlocking) != hipSuccess) w->stream2 = nullptr;
@@ -466,6 +473,7 @@ extern "C" int32_t rp_world_create(const rp_integration_params *params, const fl
     if (w->use_flow) { w->flow_grid = rp_flow_grid(device); if (w->flow_grid <= 0) w->use_flow = false; }
     if (w->use_fused) { w->fused_grid = rp_fused_grid(device); if (w->fused_grid <= 0) w->use_fused = false; }
 #ifdef RP_TESTING
+    { extern int rp_test_ts_stall_tile; const char *js = getenv("RP_TEST_TS_STALL"); rp_test_ts_stall_tile = js ? atoi(js) : -1; } // (... of k_tile_step)
     { extern int rp_test_jn_stall_tile; const char *js = getenv("RP_TEST_JN_STALL"); rp_test_jn_stall_tile = js ? atoi(js) : -1; } // (test hook: that workgroup of k_joint_net_step never arrives)
     if (const char *ra = getenv("RP_TEST_REBASE_AT")) w->rebase_at = std::max(8, atoi(ra)); // (test hook: the stamps move back every few steps)
 #endif
@@ -483,7 +491,7 @@ static void destroy_graphs(rp_world *w) {
         for (auto g : gr) if (*g) { hipGraphDestroy(*g); *g = nullptr; }
     }
     w->graph_stages = -1; w->graph_blocks = -1; w->graph_single = -1; w->graph_island_grid = -1; w->graph_dense = -1; w->graph_wide = -1; w->graph_joint_stages = -1; w->graph_no_global = -1; w->graph_fused = -1; w->graph_tile_grid = -1; w->graph_no_contacts = -1; w->graph_bare = -1;
-    w->timed_ready[0] = w->timed_ready[1] = w->timed_ready[2] = false; w->graph_jn = -1;
+    w->timed_ready[0] = w->timed_ready[1] = w->timed_ready[2] = false; w->graph_jn = -1; w->graph_ts = -1;
 }
 static void free_device(rp_world *w) {
     destroy_graphs(w);

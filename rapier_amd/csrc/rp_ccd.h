@@ -214,7 +214,9 @@ template <bool CONVEX> __global__ void __launch_bounds__(256) k_ccd(DevWorld w, 
     // the host; the graph still counts in FL_SEQ.  The flags of lean_dead only ever stay or become non-zero here: every workgroup decides alike)
     const bool dead = lean_dead(w);
     if (dead && publish && blockIdx.x == 0) {
-        if (threadIdx.x == 0) { w.flags[FL_FAST_ABORT] = 2; w.flags[FL_SEQ] += 1; }
+        // (a FULL graph in the one-launch form — DevWorld::lean without bit 0 — that died in its solver launch has already coloured this step's
+        // begin-touch pairs: the resume must not colour them again; every other rebuild is gated by a flag its first run cleared)
+        if (threadIdx.x == 0) { w.flags[FL_FAST_ABORT] = 2; w.flags[FL_SEQ] += 1; if (!(w.lean & 1)) w.flags[FL_TODO_COUNT] = 0; }
         __threadfence(); __syncthreads();
     }
     if (publish && blockIdx.x == 0) { for (int k = threadIdx.x; k < FL_COUNT; k += blockDim.x) { int v = __hip_atomic_load(&w.flags[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&w.host_flags[k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } }

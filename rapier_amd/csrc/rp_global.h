@@ -82,13 +82,21 @@ RP_DEV void flow_ids(const DevWorld &w, int pos, int &id1, int &id2) {
 // per-body layout, one contiguous run of terms per body, was measured: the scattered 176-byte writes doubled k_ws_prepare and
 // bought the accumulation nothing).  `row` = 2 * pos + side, -1 for a world-attached side.
 RP_DEV void ws_put(const DevWorld &w, int slot, int row, V3 v) { if (row >= 0) w.ws_terms[(size_t)slot * (2 * (size_t)w.cons_cap) + row] = f4(v, 0.0f); }
+// (SC1: the write-through store of a launch that hands the terms to other workgroups behind a flag instead of a kernel boundary — k_tile_step)
+template <bool SC1>
+RP_DEV void ws_put_t(const DevWorld &w, int slot, int row, V3 v) {
+    if (row < 0) return;
+    float4 *p = &w.ws_terms[(size_t)slot * (2 * (size_t)w.cons_cap) + row];
+    if (SC1) { typedef float ws_v4f __attribute__((ext_vector_type(4))); const ws_v4f x = {v.x, v.y, v.z, 0.0f}; asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(x) : "memory"); }
+    else *p = f4(v, 0.0f);
+}
 RP_DEV V3 ws_get(const DevWorld &w, int slot, int row) { return v3(w.ws_terms[(size_t)slot * (2 * (size_t)w.cons_cap) + row]); }
 // update (contact_with_twist_friction.rs:426-522) of one manifold + the velocity terms its warm start adds to either body, for the
 // body-centric warm start: the right-hand sides and cfm of the coming substep from the current poses, the banked impulses, the 11 terms
 // of either side into ws_terms (row 2 * pos + side).  Called by k_ws_prepare for every manifold, and by the owner instance of a
 // manifold at the end of its RELAXED solve on LDS tiles (rp_tiles.hip): its rows are in registers there and the poses are the ones the
 // next substep's prepare would read — three launches and a pass over every row saved per step.
-template <class Acc>
+template <class Acc, bool SC1 = false>
 RP_DEV void ws_prepare_one(const DevWorld &w, const Acc &A, int pos, float solved_dt) {
     const int id1 = A.id1(), id2 = A.id2(), n = A.n();
     const bool is_static = id1 < 0 || id2 < 0;
@@ -119,8 +127,8 @@ RP_DEV void ws_prepare_one(const DevWorld &w, const Acc &A, int pos, float solve
         m.z *= wc;
         A.st(NPL(k, NP_M), m);
         if (ws) { // ContactConstraintNormalPartSlim::warmstart, contact_constraint_element.rs:465-478
-            ws_put(w, k, s1, cmul(dir1, im1) * m.z); ws_put(w, 5 + k, s1, v3(c) * m.z);
-            ws_put(w, k, s2, cmul(dir1, im2) * (-m.z)); ws_put(w, 5 + k, s2, v3(d) * m.z);
+            ws_put_t<SC1>(w, k, s1, cmul(dir1, im1) * m.z); ws_put_t<SC1>(w, 5 + k, s1, v3(c) * m.z);
+            ws_put_t<SC1>(w, k, s2, cmul(dir1, im2) * (-m.z)); ws_put_t<SC1>(w, 5 + k, s2, v3(d) * m.z);
         }
     }
     float4 hm0 = A.ld(CP_HM0), hm1 = A.ld(CP_HM1), h7 = A.ld(CP_H7);
@@ -137,13 +145,13 @@ RP_DEV void ws_prepare_one(const DevWorld &w, const Acc &A, int pos, float solve
     A.st(CP_HM0, hm0); A.st(CP_HM1, hm1);
     if (ws) {
         const float i0 = hm0.z, i1 = hm0.w;
-        ws_put(w, 4, s1, cmul(t0 * i0 + t1 * i1, im1)); ws_put(w, 9, s1, v3(A.ld(CP_T4)) * i0 + v3(A.ld(CP_T5)) * i1);
-        ws_put(w, 4, s2, cmul(t0 * (-i0) + t1 * (-i1), im2)); ws_put(w, 9, s2, v3(A.ld(CP_T6)) * i0 + v3(A.ld(CP_T7)) * i1);
+        ws_put_t<SC1>(w, 4, s1, cmul(t0 * i0 + t1 * i1, im1)); ws_put_t<SC1>(w, 9, s1, v3(A.ld(CP_T4)) * i0 + v3(A.ld(CP_T5)) * i1);
+        ws_put_t<SC1>(w, 4, s2, cmul(t0 * (-i0) + t1 * (-i1), im2)); ws_put_t<SC1>(w, 9, s2, v3(A.ld(CP_T6)) * i0 + v3(A.ld(CP_T7)) * i1);
         if (n > 1) {
             float4 h3 = A.ld(CP_H3), h4 = A.ld(CP_H4), h5 = A.ld(CP_H5);
             Sym3 ii1 = {h3.x, h3.y, h3.z, h3.w, h4.x, h4.y}, ii2 = {h4.z, h4.w, h5.x, h5.y, h5.z, h5.w};
-            ws_put(w, 10, s1, sym_mul(ii1, dir1) * hm0.x);
-            ws_put(w, 10, s2, -(sym_mul(ii2, dir1) * hm0.x)); // v2.ang - y == v2.ang + (-y), exactly
+            ws_put_t<SC1>(w, 10, s1, sym_mul(ii1, dir1) * hm0.x);
+            ws_put_t<SC1>(w, 10, s2, -(sym_mul(ii2, dir1) * hm0.x)); // v2.ang - y == v2.ang + (-y), exactly
         }
     }
 }
@@ -164,10 +172,11 @@ RP_DEV void ws_accumulate(V3 &lin, V3 &ang, const float4 (&tm)[WS_TERMS], int n)
     ang = ang + v3(tm[9]);
     if (n > 1) ang = ang + v3(tm[10]);
 }
-RP_DEV void body_increment_ws(const DevWorld &w, int i, V3 &lin, V3 &ang) {
-    lin = v3(w.s_lin[i]); ang = v3(w.s_ang[i]);
+// (vs / as / rs: the copies of the solver velocities and rotations that are current — the tile launches alternate between two)
+RP_DEV void body_increment_ws_at(const DevWorld &w, int i, const float4 *vs, const float4 *as, const float4 *rs, V3 &lin, V3 &ang) {
+    lin = v3(vs[i]); ang = v3(as[i]);
     const int2 beg2 = w.fb_begin[i], deg2 = w.fb_deg[i];
-    body_increment(w, w.b_flags[i], lin, ang, q4(w.s_rot[i]), v3(w.s_incl[i]), v3(w.s_inca[i]), v3(w.b_invpi[i]), q4(w.b_pframe[i]));
+    body_increment(w, w.b_flags[i], lin, ang, q4(rs[i]), v3(w.s_incl[i]), v3(w.s_inca[i]), v3(w.b_invpi[i]), q4(w.b_pframe[i]));
     if (w.prm.p.warmstart_coefficient == 0.0f) return;
     const int beg = beg2.x, deg = deg2.x;
     for (int r0 = 0; r0 < deg; r0 += 8) { // this body's constraints in sweep order, eight at a time
@@ -187,6 +196,7 @@ RP_DEV void body_increment_ws(const DevWorld &w, int i, V3 &lin, V3 &ang) {
         }
     }
 }
+RP_DEV void body_increment_ws(const DevWorld &w, int i, V3 &lin, V3 &ang) { body_increment_ws_at(w, i, w.s_lin, w.s_ang, w.s_rot, lin, ang); }
 
 // Serial tail of one sweep (worker 0 of the reference): stages [first, n_stages) one after the other
 // inside one workgroup, then the overflow colour on lane 0.

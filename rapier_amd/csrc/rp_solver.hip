@@ -313,6 +313,7 @@ void rp_launch_flow_ranks(const DevWorld &w, hipStream_t st);
 void rp_launch_tiles_build(const DevWorld &w, hipStream_t st);
 void rp_launch_tile_sweep(const DevWorld &w, hipStream_t st, int mode, int grid, int friction_in_bias, float solved_dt, int fuse, int joint_warmstart);
 void rp_launch_joint_net_step(const DevWorld &w, hipStream_t st, int grid, int joint_warmstart);
+void rp_launch_tile_step(const DevWorld &w, hipStream_t st, int grid, int friction_in_bias);
 // lean: the graph runs only while FL_FLOW_DIRTY is clear (rp_world.h "lean step graphs") — both rebuilds would exit at once: left out
 void rp_launch_solver_assembly(const DevWorld &w, hipStream_t st, int lean) {
     if (!lean) {
@@ -349,6 +350,12 @@ int rp_launch_solver_loop(const DevWorld &w0, hipStream_t st, int parallel_stage
     if (w.lean & 4) {
         rp_launch_joint_net_step(w, st, w.lean >> 8, p.warmstart_joints ? 1 : 0);
         return (w.prm.num_substeps & 1) ? 2 : 0; // (velocities where they began, poses in the other copy after an odd number of substeps)
+    }
+    // a lean graph of a tiled contact world in the one-launch form (DevWorld::lean bit 3, planned by the host, verified by lean_dead): the
+    // four launches of every substep are phases of k_tile_step (rp_tiles.hip) — b3d_large_pyramid
+    if (w.lean & 8) {
+        rp_launch_tile_step(w, st, w.lean >> 8, fib);
+        return (w.prm.num_substeps & 1) ? 2 : 0; // (velocities and mutable planes where they began, poses in the other copy after an odd number of substeps)
     }
 #define TILE_SWEEP(MODE, SDT, FUSE, JWS) do { const int fuse_ = (FUSE); rp_launch_tile_sweep(w, st, MODE, tile_grid, fib, SDT, fuse_, JWS); \
         std::swap(w.s_lin, w.t_lin); std::swap(w.s_ang, w.t_ang); w.c_par ^= 1; parity ^= 1; \

@@ -469,12 +469,19 @@ RP_DEV void tile_apply(const DevWorld &w, const int4 e, const int n, const int *
 // bound by the instruction issue of its one wavefront per SIMD (~2,000 instructions for a relaxed 4-point solve in the one-lane form):
 // the pair halves the stream and the row loads per lane.  Same operations on the same operands as cons_solve (the island kernel is
 // compared with the oracle bit for bit over the same rows): identical results.
-template <int MODE>
-RP_DEV void tile_apply2(const DevWorld &w, const int4 e, const int n, const bool odd, const int *Lg, float4 *Ll, float4 *La, bool friction, float solved_dt) {
+// (SC1, cpar, rot, trans: k_tile_step — the copy of the mutable planes and of the poses that is current inside a launch that runs many
+// sweeps, and write-through stores for what other tiles read behind a flag instead of a kernel boundary)
+RP_DEV void tl_store_sc1(float4 *p, float4 v) {
+    typedef float tl_v4f __attribute__((ext_vector_type(4)));
+    const tl_v4f x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(x) : "memory");
+}
+template <int MODE, bool SC1 = false>
+RP_DEV void tile_apply2(const DevWorld &w, const int4 e, const int n, const bool odd, const int *Lg, float4 *Ll, float4 *La, bool friction, float solved_dt, const int cpar, const float4 *rot, const float4 *trans) {
     const int pos = e.x;
     const size_t cap = w.cons_cap;
 #define TL2(pe, po) w.C[(size_t)(odd ? (po) : (pe)) * cap + pos]   // an immutable plane per lane parity
-#define TLM(p) w.C[(size_t)cplane(p, w.c_par) * cap + pos]          // a mutable plane (even lane's business; both lanes fetch it)
+#define TLM(p) w.C[(size_t)cplane(p, cpar) * cap + pos]             // a mutable plane (even lane's business; both lanes fetch it)
     float4 h0 = TL2(CP_H0, CP_H0), h6 = TL2(CP_H6, CP_H6), imr = TL2(CP_H1, CP_H2), h2 = TL2(CP_H2, CP_H2), hm0 = TLM(CP_HM0), hm1 = TLM(CP_HM1);
     float4 pa[4], pc[4], pm[4], lp[4];
 #pragma unroll
@@ -488,7 +495,7 @@ RP_DEV void tile_apply2(const DevWorld &w, const int4 e, const int n, const bool
         h7 = TL2(CP_H7, CP_H7); h8 = TL2(CP_H8, CP_H8);
     }
     const int lid = odd ? e.z : e.y;
-    if (MODE == MODE_RELAX) { b2 = TL2(CP_B2, CP_B2); const int g = Lg[lid >= 0 ? lid : 0]; xr = w.s_rot[g]; xt = w.s_trans[g]; }
+    if (MODE == MODE_RELAX) { b2 = TL2(CP_B2, CP_B2); const int g = Lg[lid >= 0 ? lid : 0]; xr = rot[g]; xt = trans[g]; }
 #undef TL2
 #undef TLM
     __builtin_amdgcn_sched_group_barrier(0x020, 48, 0); // every VMEM read above as one group
@@ -534,11 +541,13 @@ RP_DEV void tile_apply2(const DevWorld &w, const int4 e, const int n, const bool
     IslLds L; L.lin = Ll; L.ang = La; L.rot = nullptr; L.trans = nullptr; L.E = nullptr; L.F = nullptr; L.B0 = nullptr; L.B1 = nullptr;
     isl_solve(h, L, MODE == MODE_RELAX, friction);
     if (!odd && e.w != 0) { // the owner's even lane stores the manifold's mutable planes into the other copy (all of them: see tile_apply)
-        const int par = w.c_par ^ 1;
+        const int par = cpar ^ 1;
+#define TLS(p, v) do { float4 *d_ = &w.C[(size_t)cplane(p, par) * cap + pos]; if (SC1) tl_store_sc1(d_, v); else *d_ = v; } while (0)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { if (k >= n) break; const SidePoint &q = h.P[k]; w.C[(size_t)cplane(NPL(k, NP_M), par) * cap + pos] = make_float4(q.rhs, q.cfm, q.lam, q.acc); }
-        w.C[(size_t)cplane(CP_HM0, par) * cap + pos] = make_float4(h.tw_imp, h.tw_acc, h.t_imp0, h.t_imp1);
-        w.C[(size_t)cplane(CP_HM1, par) * cap + pos] = make_float4(h.t_acc0, h.t_acc1, h.t_rhs0, h.t_rhs1);
+        for (int k = 0; k < 4; ++k) { if (k >= n) break; const SidePoint &q = h.P[k]; TLS(NPL(k, NP_M), make_float4(q.rhs, q.cfm, q.lam, q.acc)); }
+        TLS(CP_HM0, make_float4(h.tw_imp, h.tw_acc, h.t_imp0, h.t_imp1));
+        TLS(CP_HM1, make_float4(h.t_acc0, h.t_acc1, h.t_rhs0, h.t_rhs1));
+#undef TLS
     }
 }
 
@@ -784,7 +793,7 @@ __global__ void __launch_bounds__(RP_TILE_THREADS) k_tile_sweep(DevWorld w, int 
             bool have = have_next;
             { const int i1 = end + my; have_next = i1 < Soff[s + 2]; e_next = cons[have_next ? i1 : 0]; } // (Soff[nst + 1] = Soff[nst]: nothing behind the last stage)
             while (have) {
-                if (LP) tile_apply2<MODE>(w, e, n, odd, Lg, Ll, La, friction, solved_dt);
+                if (LP) tile_apply2<MODE>(w, e, n, odd, Lg, Ll, La, friction, solved_dt, w.c_par, w.s_rot, w.s_trans);
                 else tile_apply<MODE>(w, e, n, Lg, Ll, La, fib, friction, solved_dt);
                 i += per; have = i < end;
                 if (have) { e = cons[i]; n = w.k_n[e.x]; }
@@ -1002,6 +1011,199 @@ int rp_joint_net_cap(void) {
     int per_cu = 0, cus = 0;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_joint_net_step, RP_JN_THREADS, 0) != hipSuccess) per_cu = 0;
+    if (per_cu > 1) per_cu = 1;
+    int g = cus * per_cu - (cus + 15) / 16; // (a sixteenth left free, like the fused island step)
+    if (g < 1) g = -1;
+    if (device >= 0 && device < 64) cached[device] = g;
+    return g > 0 ? g : 0;
+}
+
+// ---- b3d_large_pyramid: the TGS loop of a tiled contact world as ONE launch (round 6) ------------------------------------
+// Measured on the sweep launches (rocprofv3, 1,060 steps of b3d_large_pyramid): a substep is k_ws_prepare 12.9 us + k_increment_ws 12.2 us
+// + biased sweep 27.6 us + relaxed sweep 38.2 us, while a tile is busy for 19.3 / 28.8 us of a sweep and the two preparation launches are
+// one or two round trips each: a third of the solver loop is launch, prologue and the wait for the slowest of 240 tiles — sixteen times a
+// step.  Here a workgroup keeps its tile for the whole step (the joint-net recipe, k_joint_net_step, without its register residency: a
+// tile's ~480 manifold instances x 816 B are streamed every sweep as before) and the four launches of a substep become four phases:
+//   A  update + warm-start terms of the manifolds the tile OWNS (ws_prepare_one, k_ws_prepare's body)            -> flag
+//   B  increment + body-centric warm start of the bodies it owns (body_increment_ws, k_increment_ws's body)      -> flag
+//   C  biased sweep over the cone (tile_apply2), owned bodies integrated on their way out                        -> flag
+//   D  relaxed sweep over the cone
+// What another tile reads next — terms, owned bodies' velocities and poses, the owner's copy of the six mutable planes — is stored
+// write-through (sc1), a tile waits for the flags of the tiles it exchanges bodies with (jn_sync: a constraint instance in another cone
+// puts one of my bodies there, a toucher of my body owned elsewhere puts my body into its owner's cone: both are neighbours in tl_nbr),
+// and the double buffers of the sweeps keep a tile that is one phase ahead from overwriting what a neighbour still reads: D reads the
+// copies C wrote and writes the ones A / B / C read, and between my next C and a neighbour's D lie two flags it has to have passed.
+// Same device functions on the same operands in the same order as the launches: the same bits.  Where it runs: lean graphs
+// (DevWorld::lean bit 3, the grid in bits 8 and up; lean_dead verifies a valid tiling that fits the grid), no impulse joints, one PGS
+// and one stabilisation iteration, at most five substeps (a launch owns 16 flag values).  A tile that waits in vain raises
+// FL_JN_TIMEOUT: nothing is committed by this kernel, the step dies like any lean step and the world keeps the sweep launches.
+struct TsPrepAcc { // ws_prepare_one's view of one owned manifold: rows (of the current copy) in registers, write-through stores, poses fetched with the rows
+    static constexpr bool PRELOAD = false;
+    const DevWorld &w; const float4 *v; int pos, par, b1, b2, nn; Xf X1, X2;
+    RP_DEV float4 ld(int plane) const { return v[plane]; }
+    RP_DEV void st(int plane, float4 x) const { tl_store_sc1(&w.C[(size_t)cplane(plane, par) * w.cons_cap + pos], x); }
+    RP_DEV int id1() const { return b1; }
+    RP_DEV int id2() const { return b2; }
+    RP_DEV int n() const { return nn; }
+    RP_DEV Xf xf(int id) const {
+        if (id < 0) { Xf x; x.r = q4(0, 0, 0, 1); x.t = v3(0, 0, 0); return x; }
+        return id == b1 ? X1 : X2;
+    }
+};
+// phase A for one owned manifold: everything ws_prepare_one reads comes in with ONE round trip (k_ws_prepare hides its dependent loads
+// behind thousands of wavefronts; a tile has four)
+RP_DEV void ts_prepare(const DevWorld &w, const int pos, const int b1, const int b2, const int n, const int par, const float4 *rot, const float4 *trans, const float solved_dt) {
+    float4 v[CP_COUNT];
+#define TP_LD(p) v[p] = w.C[(size_t)cplane(p, par) * w.cons_cap + pos]
+    TP_LD(CP_H0); TP_LD(CP_H1); TP_LD(CP_H2); TP_LD(CP_H3); TP_LD(CP_H4); TP_LD(CP_H5); TP_LD(CP_H6); TP_LD(CP_H7); TP_LD(CP_HM0); TP_LD(CP_HM1);
+    TP_LD(CP_T4); TP_LD(CP_T5); TP_LD(CP_T6); TP_LD(CP_T7); TP_LD(CP_B0); TP_LD(CP_B1); TP_LD(CP_B2);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { TP_LD(NPL(k, NP_M)); TP_LD(NPL(k, NP_C)); TP_LD(NPL(k, NP_D)); TP_LD(NPL(k, NP_E)); TP_LD(NPL(k, NP_F)); }
+#undef TP_LD
+    const int g1 = b1 >= 0 ? b1 : 0, g2 = b2 >= 0 ? b2 : 0;
+    float4 r1 = rot[g1], t1 = trans[g1], r2 = rot[g2], t2 = trans[g2];
+    __builtin_amdgcn_sched_group_barrier(0x020, 48, 0); // every VMEM read above as one group
+#define TP_PIN(r_) asm volatile("" : "+v"((r_).x), "+v"((r_).y), "+v"((r_).z), "+v"((r_).w))
+    TP_PIN(v[CP_H0]); TP_PIN(v[CP_H1]); TP_PIN(v[CP_H2]); TP_PIN(v[CP_H3]); TP_PIN(v[CP_H4]); TP_PIN(v[CP_H5]); TP_PIN(v[CP_H6]); TP_PIN(v[CP_H7]); TP_PIN(v[CP_HM0]); TP_PIN(v[CP_HM1]);
+    TP_PIN(v[CP_T4]); TP_PIN(v[CP_T5]); TP_PIN(v[CP_T6]); TP_PIN(v[CP_T7]); TP_PIN(v[CP_B0]); TP_PIN(v[CP_B1]); TP_PIN(v[CP_B2]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { TP_PIN(v[NPL(k, NP_M)]); TP_PIN(v[NPL(k, NP_C)]); TP_PIN(v[NPL(k, NP_D)]); TP_PIN(v[NPL(k, NP_E)]); TP_PIN(v[NPL(k, NP_F)]); }
+    TP_PIN(r1); TP_PIN(t1); TP_PIN(r2); TP_PIN(t2);
+#undef TP_PIN
+    Xf X1, X2; X1.r = q4(r1); X1.t = v3(t1); X2.r = q4(r2); X2.t = v3(t2);
+    const TsPrepAcc A = {w, v, pos, par, b1, b2, n, X1, X2};
+    ws_prepare_one<TsPrepAcc, true>(w, A, pos, solved_dt);
+}
+// the contact stages of one sweep over the cone (the stage loop of k_tile_sweep: the list entry and point count of a thread's next
+// stage are fetched while it works on the current one)
+template <int MODE>
+RP_DEV void ts_stages(const DevWorld &w, const int4 *cons, const int *Soff, const int nst, const int my, const int per, const bool odd, const int *Lg, float4 *Ll, float4 *La,
+                      const bool friction, const float solved_dt, const int cpar, const float4 *rot, const float4 *trans) {
+    int4 e_next; int n_next; bool have_next;
+    { const int i0 = Soff[0] + my; have_next = i0 < Soff[1]; e_next = cons[have_next ? i0 : 0]; n_next = w.k_n[e_next.x > 0 ? e_next.x : 0]; }
+    for (int s = 0; s < nst; ++s) {
+        const int end = Soff[s + 1];
+        int i = Soff[s] + my;
+        int4 e = e_next; int n = n_next;
+        bool have = have_next;
+        { const int i1 = end + my; have_next = i1 < Soff[s + 2]; e_next = cons[have_next ? i1 : 0]; } // (Soff[nst + 1] = Soff[nst]: nothing behind the last stage)
+        while (have) {
+            tile_apply2<MODE, true>(w, e, n, odd, Lg, Ll, La, friction, solved_dt, cpar, rot, trans);
+            i += per; have = i < end;
+            if (have) { e = cons[i]; n = w.k_n[e.x]; }
+        }
+        n_next = w.k_n[e_next.x > 0 ? e_next.x : 0];
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // (orders the LDS velocities only: the row stores stay in flight until the next flag)
+    }
+}
+#define RP_TS_THREADS 256 // (512 threads — every owned manifold of phase A in one round — was measured: 256 registers per lane put the preloaded rows into scratch, phase A 10 -> 30 us)
+__global__ void __launch_bounds__(RP_TS_THREADS) k_tile_step(DevWorld w, int friction_in_bias, int stall_tile) {
+    if (lean_dead(w)) return; // (the same answer in every workgroup: nothing it reads changes while a lean graph runs)
+    if ((int)blockIdx.x == stall_tile) return; // (test hook, testing build only: a workgroup that never becomes resident)
+    __shared__ float4 Ll[RP_TILE_BCAP], La[RP_TILE_BCAP];
+    __shared__ int Lg[RP_TILE_BCAP];
+    __shared__ int Soff[RP_TILE_STAGES + 4];
+    __shared__ int Lnbr[RP_TS_THREADS];
+    __shared__ int Lown[RP_TILE_CCAP]; // positions of the manifolds this tile owns
+    __shared__ int nn_sh, nown_sh;
+    const int t = threadIdx.x, nt = blockDim.x, tile = blockIdx.x;
+#ifdef RP_TILE_PROFILE // thread 0 of a tile in the middle of the curve accumulates wall-clock ticks (10 ns) per phase into dbg[272 ..] (tools/tile_diag.py)
+#define TS_STAMP(k) do { if (blockIdx.x == 100 && t == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const long long n_ = (long long)wall_clock64(); w.dbg[272 + (k)] += n_ - tsp_; tsp_ = n_; } } while (0)
+    long long tsp_ = (long long)wall_clock64();
+#else
+#define TS_STAMP(k) do { } while (0)
+#endif
+    if (tile >= w.flags[FL_N_TILES]) return; // (workgroups beyond the tiling: nobody waits for them)
+    const int nst = w.flags[FL_N_STAGES], substeps = w.prm.num_substeps;
+    const bool fib = friction_in_bias != 0;
+    if (t == 0) { nn_sh = 0; nown_sh = 0; }
+    const unsigned e0 = 16u * (unsigned)w.flags[FL_SEQ]; // (FL_SEQ moves once per step graph, behind this launch: the same in every workgroup)
+    __syncthreads();
+    for (int a = t; a < w.tile_cap; a += nt)
+        if ((w.tl_nbr[(size_t)tile * RP_TILE_NBR_WORDS(w.tile_cap) + (a >> 5)] >> (a & 31)) & 1u) { const int k = atomicAdd(&nn_sh, 1); if (k < RP_TS_THREADS) Lnbr[k] = a; }
+    const int4 *cons = w.tl_cons + (size_t)tile * RP_TILE_CCAP;
+    const int4 hdr = w.tl_hdr[tile];
+    const int nb = hdr.x, nc = hdr.y, n_owned = hdr.z;
+    for (int i = t; i < nc; i += nt) { const int4 e = cons[i]; if (e.w != 0 && e.x >= 0) Lown[atomicAdd(&nown_sh, 1)] = e.x; }
+    for (int s = t; s <= nst + 3; s += nt) Soff[s] = w.tl_soff[(size_t)tile * (RP_TILE_STAGES + 1) + (s < nst ? s : nst)];
+    for (int l = t; l < nb; l += nt) Lg[l] = w.tl_bodies[(size_t)tile * RP_TILE_BCAP + l];
+    __syncthreads();
+    const int nn = nn_sh < RP_TS_THREADS ? nn_sh : RP_TS_THREADS;
+    const int n_own = nown_sh;
+    // a thread's first owned manifold stays in its registers for the whole step (position, solver bodies, point count: what phase A asks for first)
+    const int own_pos = t < n_own ? Lown[t] : -1;
+    const int own_b1 = own_pos >= 0 ? w.k_b1[own_pos] : -1, own_b2 = own_pos >= 0 ? w.k_b2[own_pos] : -1, own_n = own_pos >= 0 ? w.k_n[own_pos] : 0;
+    float4 *vs = w.s_lin, *as = w.s_ang, *vt = w.t_lin, *at = w.t_ang, *rs = w.s_rot, *ts = w.s_trans, *rt = w.t_rot, *tt = w.t_trans;
+    const int par = w.c_par;
+    const int my = t >> 1, per = nt >> 1;
+    const bool odd = (t & 1) != 0;
+    const int half = nt >> 1; // phase B: the first half of the workgroup adds the linear chains, the second the angular ones (as k_increment_ws's two grid halves)
+    TS_STAMP(0);
+    for (int s = 0; s < substeps; ++s) {
+        const float solved_dt = (float)s * w.prm.dt_sub;
+        // A: the manifolds this tile owns
+        if (own_pos >= 0) ts_prepare(w, own_pos, own_b1, own_b2, own_n, par, rs, ts, solved_dt);
+        for (int k = t + nt; k < n_own; k += nt) { const int pos = Lown[k]; ts_prepare(w, pos, w.k_b1[pos], w.k_b2[pos], w.k_n[pos], par, rs, ts, solved_dt); }
+        TS_STAMP(1);
+        if (jn_sync(w, tile, e0 + 3u * (unsigned)s + 1u, Lnbr, nn)) return;
+        TS_STAMP(2);
+        // B: the bodies this tile owns
+        if (t < half) {
+            for (int l = t; l < n_owned; l += half) { const int g = Lg[l]; V3 lin, ang; body_increment_ws_at(w, g, vs, as, rs, lin, ang); Ll[l] = f4(lin, 0.0f); tl_store_sc1(vs + g, f4(lin, 0.0f)); }
+        } else {
+            for (int l = t - half; l < n_owned; l += half) { const int g = Lg[l]; V3 lin, ang; body_increment_ws_at(w, g, vs, as, rs, lin, ang); La[l] = f4(ang, 0.0f); tl_store_sc1(as + g, f4(ang, 0.0f)); }
+        }
+        TS_STAMP(3);
+        if (jn_sync(w, tile, e0 + 3u * (unsigned)s + 2u, Lnbr, nn)) return;
+        TS_STAMP(4);
+        // C: biased sweep; the halo bodies come in, the owned ones leave integrated (velocities AND poses to the other copies)
+        for (int l = n_owned + t; l < nb; l += nt) { const int g = Lg[l]; Ll[l] = vs[g]; La[l] = as[g]; }
+        __syncthreads();
+        TS_STAMP(5);
+        ts_stages<MODE_BIAS>(w, cons, Soff, nst, my, per, odd, Lg, Ll, La, fib, solved_dt, par, rs, ts);
+        TS_STAMP(6);
+        for (int l = t; l < n_owned; l += nt) {
+            const int g = Lg[l];
+            V3 lin = v3(Ll[l]), ang = v3(La[l]), trans = v3(ts[g]); Q4 rot = q4(rs[g]);
+            body_integrate(w, w.b_flags[g], lin, ang, rot, trans);
+            Ll[l] = f4(lin, 0.0f); La[l] = f4(ang, 0.0f);
+            tl_store_sc1(vt + g, f4(lin, 0.0f)); tl_store_sc1(at + g, f4(ang, 0.0f)); tl_store_sc1(rt + g, f4(rot)); tl_store_sc1(tt + g, f4(trans, 0.0f));
+        }
+        { float4 *a = vs; vs = vt; vt = a; a = as; as = at; at = a; a = rs; rs = rt; rt = a; a = ts; ts = tt; tt = a; }
+        TS_STAMP(7);
+        if (jn_sync(w, tile, e0 + 3u * (unsigned)s + 3u, Lnbr, nn)) return;
+        TS_STAMP(8);
+        // D: relaxed sweep (the other copy of the mutable planes, the new poses)
+        for (int l = n_owned + t; l < nb; l += nt) { const int g = Lg[l]; Ll[l] = vs[g]; La[l] = as[g]; }
+        __syncthreads();
+        TS_STAMP(9);
+        ts_stages<MODE_RELAX>(w, cons, Soff, nst, my, per, odd, Lg, Ll, La, true, solved_dt + w.prm.dt_sub, par ^ 1, rs, ts);
+        TS_STAMP(10);
+        for (int l = t; l < n_owned; l += nt) { const int g = Lg[l]; tl_store_sc1(vt + g, Ll[l]); tl_store_sc1(at + g, La[l]); }
+        { float4 *a = vs; vs = vt; vt = a; a = as; as = at; at = a; }
+        __syncthreads(); // (every store of this phase has completed: phase A reads the rows this tile just wrote, phase B its own bodies)
+        TS_STAMP(11);
+    }
+#ifdef RP_TILE_PROFILE
+    if (blockIdx.x == 100 && t == 0) w.dbg[272 + 12] += 1;
+#endif
+#undef TS_STAMP
+}
+int rp_test_ts_stall_tile = -1; // (RP_TEST_TS_STALL=<tile>, testing build only: rp_api.hip)
+// returns the parity for rp_launch_solver_writeback (velocities and mutable planes where they began, poses in the other copy after an odd number of substeps)
+void rp_launch_tile_step(const DevWorld &w, hipStream_t st, int grid, int friction_in_bias) {
+    hipLaunchKernelGGL(k_tile_step, dim3(grid < 1 ? 1 : grid), dim3(RP_TS_THREADS), 0, st, w, friction_in_bias, rp_test_ts_stall_tile);
+}
+// most workgroups a k_tile_step launch may use on the current device (all of them resident at once), 0 = none
+int rp_tile_step_cap(void) {
+    static int cached[64] = {0};
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return 0;
+    if (device >= 0 && device < 64 && cached[device]) return cached[device] > 0 ? cached[device] : 0;
+    hipDeviceProp_t prop;
+    int per_cu = 0, cus = 0;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_tile_step, RP_TS_THREADS, 0) != hipSuccess) per_cu = 0;
     if (per_cu > 1) per_cu = 1;
     int g = cus * per_cu - (cus + 15) / 16; // (a sixteenth left free, like the fused island step)
     if (g < 1) g = -1;

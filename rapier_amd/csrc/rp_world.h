@@ -458,6 +458,12 @@ __device__ __forceinline__ bool lean_dead(const DevWorld &w) {
     // of the layout rebuild / the tiling, which no lean graph runs)
     int jn_wrong = 0;
     if (w.lean & 4) { const int nt = w.flags[FL_N_TILES], jmax = w.flags[FL_TILE_JMAX]; jn_wrong = (w.flags[FL_JN_TIMEOUT] != 0 || nt <= 0 || nt > (w.lean >> 8) || nt > RP_JN_THREADS || w.prm.num_substeps > 8 || w.flags[FL_N_STAGES] != 0 || jmax <= 0 || jmax > RP_JN_THREADS) ? 1 : 0; }
+    // (bit 3, a lean graph of a tiled contact world whose TGS loop is ONE launch — k_tile_step, rp_tiles.hip —, its grid in bits 8 and up: a
+    // valid tiling of at most that many tiles, at most five substeps — a launch owns sixteen values of a tile's flag, three per substep)
+    if (w.lean & 8) { const int nt = w.flags[FL_N_TILES]; jn_wrong = (w.flags[FL_JN_TIMEOUT] != 0 || nt <= 0 || nt > (w.lean >> 8) || w.prm.num_substeps > 5 || w.n_joints > 0 || w.flags[FL_N_ISLANDS] != 0) ? 1 : 0; } // (no LDS island: k_island_solve commits its bodies before this launch could give up)
+    // (no bit 0: a FULL graph in the one-launch form — every rebuild ran, the flags below speak about work a lean graph leaves out (FL_TODO_COUNT
+    // stays up behind the colouring until the next step's first kernel); only the launch itself can fail)
+    if (!(w.lean & 1)) return jn_wrong != 0;
     return (w.flags[FL_FAST_ABORT] | w.flags[FL_TODO_COUNT] | w.flags[FL_LAYOUT_DIRTY] | w.flags[FL_FLOW_DIRTY] | (w.n_joints > 0 ? w.flags[FL_JOINT_DIRTY] : 0) | bare_wrong | jn_wrong) != 0;
 }
 // collision kernels: this step's collision stage already ran (a dead lean step waits for its resume), or an earlier lean step died

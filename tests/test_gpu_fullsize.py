@@ -47,8 +47,9 @@ def test_c2_large_pyramid_full_size_1000_steps_on_tiles_and_lean_graphs():
     assert c["overflow_flags"] == 0 and c["quarantined"] == 0 and c["num_dynamic_bodies"] == 20100, c
     assert tiled == 6 and c["num_tiles"] >= 200, c                      # every checkpoint saw the sweeps on tiles
     assert lean_seen > 0, c                                             # lean graphs were enqueued ...
+    assert c["tile_step_steps"] > 900 and c["tile_step_steps"] <= c["lean_steps"] + c["full_steps"] and c["joint_net_disabled"] == 0, c   # ... lean and full graphs in the one-launch form (k_tile_step)
     assert c["num_manifolds"] == o.stats()["num_active_manifolds"]
-    print("C2 counters:", {k: c[k] for k in ("num_tiles", "lean_steps", "replayed_steps", "full_steps", "fast_steps")})
+    print("C2 counters:", {k: c[k] for k in ("num_tiles", "lean_steps", "tile_step_steps", "replayed_steps", "full_steps", "fast_steps")})
 
 
 def test_c5_joint_grid_full_size_1000_steps_on_tiles_and_lean_graphs():

@@ -27,7 +27,7 @@ def test_descriptor_layouts_match_header():
     assert S.BODY_DTYPE.itemsize == 4 + 12 + 16 + 12 + 12 + 4 * 4 + 5 * 4 + 4 + 4  # ... + additional_solver_iterations + ccd_enabled
     assert S.COLLIDER_DTYPE.itemsize == 4 + 12 + 12 + 16 + 12 + 8 + 8 + 8 + 4 + 4  # ... + sensor + border_radius
     assert S.JOINT_DTYPE.itemsize == 16 + 24 + 32 + 8 + 4 + 48 + 4 + 6 * 24 + 4 + 4  # two 64-bit body handles ... + coupled_axes + reserved
-    assert C.sizeof(_ffi.Counters) == 9 * 4 + 27 * 4  # ... + num_tiles, tile_sweeps, bp_large_list, lean_steps, fused_steps, num_islands, num_global_bodies, fused_disabled, fused_launches, joint_net_steps, joint_net_disabled
+    assert C.sizeof(_ffi.Counters) == 9 * 4 + 28 * 4  # ... + num_tiles, tile_sweeps, bp_large_list, lean_steps, fused_steps, num_islands, num_global_bodies, fused_disabled, fused_launches, joint_net_steps, joint_net_disabled
     p = S.default_params()
     q = np.zeros((), S.PARAMS_DTYPE)
     _ffi.lib().rp_default_params(q.ctypes.data)

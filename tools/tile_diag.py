@@ -5,10 +5,10 @@ from rapier_amd import PhysicsWorld, scenes as S
 sc = {"lp": lambda: S.large_pyramid(200), "jg": lambda: S.joint_grid(100)}.get(sys.argv[1] if len(sys.argv) > 1 else "", lambda: S.reference_pile(14, 5, 14, chain=False, sleep=False))()
 w = PhysicsWorld.from_scene(sc)
 done = 0
-for cp in (1, 5, 20, 40, 60, 80, 120):
+for cp in (1, 5, 20, 40, 60, 80, 120) + ((int(sys.argv[2]),) if len(sys.argv) > 2 else ()):
     w.step(cp - done); done = cp
     c = w.counters()
-    print(cp, {k: c[k] for k in ("num_manifolds", "num_colors", "num_parallel_stages", "num_tiles", "tile_sweeps", "overflow_flags", "num_pairs", "full_updates")})
+    print(cp, {k: c[k] for k in ("num_manifolds", "num_colors", "num_parallel_stages", "num_tiles", "tile_sweeps", "overflow_flags", "num_pairs", "full_updates", "lean_steps", "tile_step_steps")})
 import ctypes as C, numpy as np
 from rapier_amd import _ffi
 L = _ffi.lib()
@@ -45,3 +45,12 @@ if jn[11]:
     n = float(jn[11]) * 100
     names = ("prologue (lists, first entry)", "increment into LDS", "rows from poses", "biased stages", "integrate + publish", "wait for the neighbouring tiles 1", "halo reload", "relaxed stages", "publish", "wait for the neighbouring tiles 2", "impulses out")
     print(f"k_joint_net_step, workgroup 0, {int(jn[11])} launches, us per launch: " + "; ".join(f"{names[k]} {jn[k] / n:.2f}" for k in range(11)) + f"; total {jn[:11].sum() / n:.1f}")
+
+# the one-launch TGS loop of a tiled contact world (k_tile_step), workgroup 100: ticks per phase, summed over the substeps of a launch
+ts = np.zeros(13, np.int64)
+L.rp_debug_read(w._ptr, 272, 13, ts.ctypes.data)
+if ts[12]:
+    n = float(ts[12]) * 100
+    names = ("prologue (lists)", "A update + terms of the owned manifolds", "flag A", "B increment + warm start of the owned bodies", "flag B", "halo in (C)", "biased stages", "integrate + publish", "flag C",
+             "halo in (D)", "relaxed stages", "publish")
+    print(f"k_tile_step, workgroup 100, {int(ts[12])} launches, us per launch: " + "; ".join(f"{names[k]} {ts[k] / n:.2f}" for k in range(12)) + f"; total {ts[:12].sum() / n:.1f}")
