@@ -284,6 +284,28 @@ RP_DEV void lay_isl_fill(DevWorld &w, int gid, int stride, int *hist, int &n_glo
 }
 
 
+// The same pass for a world that holds NO island: every pair belongs to the global path (k_layout_rebuild's all-global form)
+RP_DEV void lay_glob_fill(DevWorld &w, int gid, int stride, int *hist) {
+    for (int c = threadIdx.x; c < RP_NUM_COLORS; c += blockDim.x) hist[c] = 0;
+    __syncthreads();
+    int top = w.flags[FL_POOL_TOP];
+    if (top > w.pool_cap) top = w.pool_cap;
+    for (int s = gid; s < top; s += stride) {
+        w.p_island[s] = -1;
+        if (w.p_c1[s] < 0 || !pair_active(w, s)) continue;
+        const int b1 = w.c_parent[w.p_c1[s]], b2 = w.c_parent[w.p_c2[s]];
+        const int color = w.p_color[s];
+        if (color <= RP_COLOR_OVERFLOW) atomicAdd(&hist[color], 1);
+        if (color < RP_COLOR_OVERFLOW) {
+            int owner = body_dyn_awake(w, b1) ? b1 : b2;
+            if (w.b_order) owner = w.b_order[owner];
+            atomicOr(&w.cb_bits[(size_t)color * w.cb_words + (owner >> 5)], 1u << (owner & 31));
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < RP_NUM_COLORS; c += blockDim.x) if (hist[c]) atomicAdd(&w.color_count_glob[c], hist[c]);
+}
+
 // ---- solver contact graph buckets + stage layout (were rp_narrowphase.hip kernels) ----
 RP_DEV void lay_bucket_clear(DevWorld &w) { // workgroup 0
     if (threadIdx.x < RP_NUM_COLORS) { w.color_count[threadIdx.x] = 0; w.color_count_glob[threadIdx.x] = 0; }
@@ -429,6 +451,32 @@ __global__ void __launch_bounds__(1024) k_layout_rebuild(DevWorld w) {
     GridBar bar = gbar_begin(w, 1);
     RP_PASS_BEGIN();
     const bool warm = lay_warm(w); // (lay_state is only written behind the last barrier of a launch, or by an edit between steps: every workgroup reads the same)
+    // ALL-GLOBAL form (round 6).  A settling pile rebuilds its layout on a third of its steps (b3d_large_pyramid: ~300 of the first 1,060)
+    // and each time the island passes — edges, union-find, counts, numbering, fill: five of the eight grid barriers and 140 of the 200 us —
+    // find what the warm start already assumes: one giant component, no island.  While the labels are warm and the last rebuild left no
+    // island (lay_state[7]), a body that leaves the pile stays on the global path anyway (lay_warm: a routing decision, never a result), so
+    // only the colour buckets, the stage order and the constraint positions are rebuilt; every 16th rebuild is cold and looks again.
+    if (warm && w.lay_state[7] == 1) {
+        if (blockIdx.x == 0) lay_bucket_clear(w);
+        for (size_t k = gid, n = (size_t)128 * w.cb_words; k < n; k += (size_t)gstride) w.cb_bits[k] = 0u;
+        GBAR_SYNC(bar); RP_PASS_STAMP(w, 200);
+        lay_bucket_count(w, gid, gstride, lds_a, lds_scalar);
+        __syncthreads();
+        lay_glob_fill(w, gid, gstride, lds_a);
+        GBAR_SYNC(bar); RP_PASS_STAMP(w, 200);
+        lay_owner_prefix(w);
+        if (blockIdx.x == 0) lay_bucket_layout(w);
+        GBAR_SYNC(bar); RP_PASS_STAMP(w, 200);
+        lay_bucket_scatter(w, gid, gstride, lds_a, lds_b);
+        GBAR_SYNC(bar); RP_PASS_STAMP(w, 200);
+        if (ld_i32(&w.flags[FL_HAS_OVERFLOW_COLOR])) {
+            if (blockIdx.x == 0) lay_rank_overflow(w);
+            GBAR_SYNC(bar); RP_PASS_STAMP(w, 200);
+        }
+        gbar_end(bar);
+        if (gid == 0) { w.lay_state[1] += 1; __hip_atomic_store(&w.flags[FL_LAYOUT_DIRTY], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        return;
+    }
     if (blockIdx.x == 0) lay_bucket_clear(w);
     lay_isl_init(w, gid, gstride, warm);
     lay_isl_edges(w, gid, gstride);
@@ -468,6 +516,7 @@ __global__ void __launch_bounds__(1024) k_layout_rebuild(DevWorld w) {
         // rebuilds it with the right answer (a routing decision, never a result; the host keeps the full graph while it is dirty).
         const int again = (w.isl_route_tiny && (w.lay_state[4] > w.isl_many) != (w.lay_state[3] > w.isl_many)) ? 1 : 0;
         w.flags[FL_UF_NPAIRS] = 0; w.lay_state[0] = 1; w.lay_state[1] += 1; w.lay_state[2] = w.flags[FL_N_GLOB_BODIES]; w.lay_state[3] = w.lay_state[4];
+        w.lay_state[7] = w.flags[FL_N_ISLANDS] == 0 ? 1 : 0; // (no island, no bundle: the next warm rebuilds take the all-global form)
         __hip_atomic_store(&w.flags[FL_LAYOUT_DIRTY], again, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }

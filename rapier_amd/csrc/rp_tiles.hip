@@ -1133,6 +1133,9 @@ __global__ void __launch_bounds__(RP_TS_THREADS) k_tile_step(DevWorld w, int fri
     // a thread's first owned manifold stays in its registers for the whole step (position, solver bodies, point count: what phase A asks for first)
     const int own_pos = t < n_own ? Lown[t] : -1;
     const int own_b1 = own_pos >= 0 ? w.k_b1[own_pos] : -1, own_b2 = own_pos >= 0 ? w.k_b2[own_pos] : -1, own_n = own_pos >= 0 ? w.k_n[own_pos] : 0;
+    // (... and its second one: a tile of b3d_large_pyramid owns ~250 manifolds, some tiles a few more than the workgroup has threads)
+    const int own2_pos = t + nt < n_own ? Lown[t + nt] : -1;
+    const int own2_b1 = own2_pos >= 0 ? w.k_b1[own2_pos] : -1, own2_b2 = own2_pos >= 0 ? w.k_b2[own2_pos] : -1, own2_n = own2_pos >= 0 ? w.k_n[own2_pos] : 0;
     float4 *vs = w.s_lin, *as = w.s_ang, *vt = w.t_lin, *at = w.t_ang, *rs = w.s_rot, *ts = w.s_trans, *rt = w.t_rot, *tt = w.t_trans;
     const int par = w.c_par;
     const int my = t >> 1, per = nt >> 1;
@@ -1143,7 +1146,8 @@ __global__ void __launch_bounds__(RP_TS_THREADS) k_tile_step(DevWorld w, int fri
         const float solved_dt = (float)s * w.prm.dt_sub;
         // A: the manifolds this tile owns
         if (own_pos >= 0) ts_prepare(w, own_pos, own_b1, own_b2, own_n, par, rs, ts, solved_dt);
-        for (int k = t + nt; k < n_own; k += nt) { const int pos = Lown[k]; ts_prepare(w, pos, w.k_b1[pos], w.k_b2[pos], w.k_n[pos], par, rs, ts, solved_dt); }
+        if (own2_pos >= 0) ts_prepare(w, own2_pos, own2_b1, own2_b2, own2_n, par, rs, ts, solved_dt);
+        for (int k = t + 2 * nt; k < n_own; k += nt) { const int pos = Lown[k]; ts_prepare(w, pos, w.k_b1[pos], w.k_b2[pos], w.k_n[pos], par, rs, ts, solved_dt); }
         TS_STAMP(1);
         if (jn_sync(w, tile, e0 + 3u * (unsigned)s + 1u, Lnbr, nn)) return;
         TS_STAMP(2);
