@@ -42,7 +42,7 @@ _GLOBAL_SOURCES = _ISLAND_SOURCES[4:] + ["rapier_amd/csrc/rp_tiles.hip", "rapier
 KERNEL_SOURCES = {"c3": _ISLAND_SOURCES, "large_pyramid": _GLOBAL_SOURCES, "joint_grid": _GLOBAL_SOURCES}
 # kernels of the TGS loop on the global path (what `velocity_update_ms` brackets minus assembly / write-back): their PMC bytes per
 # step are summed into `solver_loop_hbm_bytes_per_step` by tools/pmc_summary.py
-SOLVER_LOOP_KERNELS = ("k_joint_net_step", "k_tile_sweep", "k_ws_prepare", "k_increment_ws", "k_increment", "k_integrate", "k_stage", "k_tail", "k_global_flow",
+SOLVER_LOOP_KERNELS = ("k_joint_net_step", "k_tile_step", "k_tile_sweep", "k_ws_prepare", "k_increment_ws", "k_increment", "k_integrate", "k_stage", "k_tail", "k_global_flow",
                        "k_joint_update", "k_joint_sweep", "k_joint_tail")
 
 
@@ -307,6 +307,12 @@ def run(args, make_world=None, backend: str = "nccl", use_cuda: bool = True):
             kernel_name = "global solver path (TGS loop as per-colour-stage launches or one dataflow launch; hipEvents around the sequence)"
             # round 6: a net of spherical joints without contacts runs its whole TGS loop as ONE launch (k_joint_net_step) on lean graphs,
             # and those graphs are what the events bracket here too (solver sequence of the lean graph: that launch, the write-back, k_ccd)
+            # round 6: a tiled contact world (b3d_large_pyramid) runs its whole TGS loop as ONE launch too (k_tile_step, lean and full graphs);
+            # the events bracket k_begin_generate, that launch, the write-back and k_ccd
+            d_ts = tc.get("tile_step_steps", 0) - c_before.get("tile_step_steps", 0)
+            if d_ts > 0:
+                kernel_name = (f"k_begin_generate + k_tile_step (the TGS loop of a step as one launch over the LDS tiles: prepare / increment / biased / relaxed sweeps of "
+                               f"every substep as phases, neighbouring tiles' flags between them) + k_writeback + k_ccd; {d_ts} of {args.roofline_steps} timed steps took it")
             d_jn = tc.get("joint_net_steps", 0) - c_before.get("joint_net_steps", 0)
             if d_jn > 0:
                 kernel_name = (f"k_joint_net_step (the TGS loop of a step as one launch: every tile's joints in registers, grid barriers between sweeps) "
@@ -332,10 +338,12 @@ def run(args, make_world=None, backend: str = "nccl", use_cuda: bool = True):
                                if tc["velocity_update_ms"] <= tc["velocity_resolution_ms"] else
                                ("the solver sequence of the lean step graph the timed region runs (k_joint_net_step, write-back, k_ccd) between two hipEvents, one step at a time"
                                 if (tc.get("joint_net_steps", 0) - c_before.get("joint_net_steps", 0)) > 0 else
+                                "the solver sequence of the step graphs the timed region runs (k_begin_generate, k_tile_step, k_writeback, k_ccd) between two hipEvents, one step at a time"
+                                if (tc.get("tile_step_steps", 0) - c_before.get("tile_step_steps", 0)) > 0 else
                                 "the solver-loop launches of a full / lean step (tile sweeps or colour-stage launches) between two hipEvents, one step at a time")),
                 "traffic_note": traffic_note, "kernel_code_sha": kernel_code_sha(wkey), "joint_rows": jrows,
                 "stage_ms": {k: tc[k] for k in ("collision_detection_ms", "velocity_resolution_ms", "velocity_update_ms")},
-                "path": {k: tc[k] for k in ("fast_steps", "full_steps", "replayed_steps", "lean_steps", "joint_net_steps") if k in tc}}
+                "path": {k: tc[k] for k in ("fast_steps", "full_steps", "replayed_steps", "lean_steps", "joint_net_steps", "tile_step_steps") if k in tc}}
 
     # readback (not timed): assemble the world state with one all-gather over RCCL/xGMI
     pos, vel = w.read_bodies()

@@ -78,6 +78,25 @@ RP_DEV void flow_ids(const DevWorld &w, int pos, int &id1, int &id2) {
 
 // ---- body-centric warm start (rp_solver.hip: k_ws_prepare writes the terms, k_increment_ws / the tile sweeps add them) ----
 #define WS_TERMS 11
+// A 16-byte load that reads past this XCD's L2 (sc1): the reader's half of "sc1 stores AND sc1 loads" (MI355X guide, inter-workgroup
+// visibility) — what another workgroup of the SAME launch stored write-through is read from the memory side without an agent-scope
+// acquire, i.e. without invalidating the L2 every tile of the XCD shares (k_tile_step, rp_tiles.hip).  A buffer load, so that the compiler
+// counts it (a hand-issued global_load is invisible to its waitcnt pass); `base` is wave-uniform, `idx` per lane.
+RP_DEV float4 ld16_sc1(const float4 *base, unsigned idx) {
+    typedef unsigned ld_v4u __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0xffffffff, 0x00027000);
+    const ld_v4u x = __builtin_amdgcn_raw_buffer_load_b128(r, idx * 16u, 0, 16); // (aux bit 4 = sc1 on gfx94x / gfx950)
+    return make_float4(__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w));
+}
+template <bool SC1LD> RP_DEV float4 ld16_t(const float4 *base, unsigned idx) { return SC1LD ? ld16_sc1(base, idx) : base[idx]; }
+// ... and the writer's half: a 16-byte write-through store (sc1: nothing of it stays dirty in the XCD's L2), as a buffer store the
+// compiler schedules and counts (the hand-issued form — asm volatile + "memory" — kept every store in program order between the loads)
+RP_DEV void st16_sc1(float4 *base, unsigned idx, float4 v) {
+    typedef unsigned st_v4u __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0xffffffff, 0x00027000);
+    const st_v4u x = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(x, r, idx * 16u, 0, 16);
+}
 // ws_terms = [11][2 * cons_cap] planes indexed by 2 * position + side: the writes of k_ws_prepare are coalesced plane by plane (a
 // per-body layout, one contiguous run of terms per body, was measured: the scattered 176-byte writes doubled k_ws_prepare and
 // bought the accumulation nothing).  `row` = 2 * pos + side, -1 for a world-attached side.
@@ -86,9 +105,8 @@ RP_DEV void ws_put(const DevWorld &w, int slot, int row, V3 v) { if (row >= 0) w
 template <bool SC1>
 RP_DEV void ws_put_t(const DevWorld &w, int slot, int row, V3 v) {
     if (row < 0) return;
-    float4 *p = &w.ws_terms[(size_t)slot * (2 * (size_t)w.cons_cap) + row];
-    if (SC1) { typedef float ws_v4f __attribute__((ext_vector_type(4))); const ws_v4f x = {v.x, v.y, v.z, 0.0f}; asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(x) : "memory"); }
-    else *p = f4(v, 0.0f);
+    if (SC1) st16_sc1(w.ws_terms + (size_t)slot * (2 * (size_t)w.cons_cap), (unsigned)row, f4(v, 0.0f));
+    else w.ws_terms[(size_t)slot * (2 * (size_t)w.cons_cap) + row] = f4(v, 0.0f);
 }
 RP_DEV V3 ws_get(const DevWorld &w, int slot, int row) { return v3(w.ws_terms[(size_t)slot * (2 * (size_t)w.cons_cap) + row]); }
 // update (contact_with_twist_friction.rs:426-522) of one manifold + the velocity terms its warm start adds to either body, for the
@@ -161,9 +179,10 @@ RP_DEV void ws_prepare_one(const DevWorld &w, const Acc &A, int pos, float solve
 // per accumulator).  The loads are batched — every row index of up to eight touchers, then their point counts and the terms two
 // touchers at a time (all eleven terms of a side: the slots of unused points hold stale values that are fetched and ignored) — so the
 // chain is ~5 round trips instead of three per toucher (measured as the prologue of the tile sweeps: 24 us before).
+template <bool SC1LD = false>
 RP_DEV void ws_fetch(const DevWorld &w, int row, float4 (&tm)[WS_TERMS]) {
 #pragma unroll
-    for (int s = 0; s < WS_TERMS; ++s) tm[s] = w.ws_terms[(size_t)s * (2 * (size_t)w.cons_cap) + row];
+    for (int s = 0; s < WS_TERMS; ++s) tm[s] = ld16_t<SC1LD>(w.ws_terms + (size_t)s * (2 * (size_t)w.cons_cap), (unsigned)row);
 }
 RP_DEV void ws_accumulate(V3 &lin, V3 &ang, const float4 (&tm)[WS_TERMS], int n) {
 #pragma unroll
@@ -173,10 +192,11 @@ RP_DEV void ws_accumulate(V3 &lin, V3 &ang, const float4 (&tm)[WS_TERMS], int n)
     if (n > 1) ang = ang + v3(tm[10]);
 }
 // (vs / as / rs: the copies of the solver velocities and rotations that are current — the tile launches alternate between two)
+template <bool SC1LD = false>
 RP_DEV void body_increment_ws_at(const DevWorld &w, int i, const float4 *vs, const float4 *as, const float4 *rs, V3 &lin, V3 &ang) {
-    lin = v3(vs[i]); ang = v3(as[i]);
+    lin = v3(ld16_t<SC1LD>(vs, (unsigned)i)); ang = v3(ld16_t<SC1LD>(as, (unsigned)i));
     const int2 beg2 = w.fb_begin[i], deg2 = w.fb_deg[i];
-    body_increment(w, w.b_flags[i], lin, ang, q4(rs[i]), v3(w.s_incl[i]), v3(w.s_inca[i]), v3(w.b_invpi[i]), q4(w.b_pframe[i]));
+    body_increment(w, w.b_flags[i], lin, ang, q4(ld16_t<SC1LD>(rs, (unsigned)i)), v3(w.s_incl[i]), v3(w.s_inca[i]), v3(w.b_invpi[i]), q4(w.b_pframe[i]));
     if (w.prm.p.warmstart_coefficient == 0.0f) return;
     const int beg = beg2.x, deg = deg2.x;
     for (int r0 = 0; r0 < deg; r0 += 8) { // this body's constraints in sweep order, eight at a time
@@ -189,8 +209,8 @@ RP_DEV void body_increment_ws_at(const DevWorld &w, int i, const float4 *vs, con
         for (int j = 0; j < 8; j += 2) {
             if (rows[j] < 0) break;
             float4 ta[WS_TERMS], tb[WS_TERMS];
-            ws_fetch(w, rows[j], ta);
-            if (rows[j + 1] >= 0) ws_fetch(w, rows[j + 1], tb);
+            ws_fetch<SC1LD>(w, rows[j], ta);
+            if (rows[j + 1] >= 0) ws_fetch<SC1LD>(w, rows[j + 1], tb);
             ws_accumulate(lin, ang, ta, ns[j]);
             if (rows[j + 1] >= 0) ws_accumulate(lin, ang, tb, ns[j + 1]);
         }

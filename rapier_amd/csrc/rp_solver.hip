@@ -151,6 +151,26 @@ __global__ void k_writeback_bodies(DevWorld w) {
     g_body_writeback(w, i);
 }
 
+// The two write-backs as ONE launch (round 6): they share no word — the first body_blocks workgroups write the bodies back, the rest the
+// impulses (grid-stride, as k_writeback_impulses) — so a step of a contact world pays one launch and the longer of the two instead of
+// two launches end to end (b3d_large_pyramid: 8.6 + 6.5 us + a gap)
+template <bool COUL>
+__global__ void k_writeback(DevWorld w, int body_blocks) {
+    if (lean_dead(w)) return; // (the step did not happen: k_ccd counts the graph — FL_SEQ — and raises the marker)
+    if ((int)blockIdx.x < body_blocks) {
+        const int i = blockIdx.x * blockDim.x + threadIdx.x;
+        if (i == 0) { w.flags[FL_STEP] += 1; w.flags[FL_SEQ] += 1; }
+        if (i >= w.n_bodies || !global_body(w, i)) return;
+        g_body_writeback(w, i);
+        return;
+    }
+    int M = w.flags[FL_N_CONS];
+    if (M > w.cons_cap) M = w.cons_cap;
+    const int stride = ((int)gridDim.x - body_blocks) * blockDim.x, first = ((int)blockIdx.x - body_blocks) * blockDim.x + threadIdx.x;
+    for (int pos = first; pos < M; pos += stride) { if (COUL) coul_writeback(w, GlobalAcc(w, pos), w.cons_pair[pos]); else cons_writeback(w, GlobalAcc(w, pos), w.cons_pair[pos]); }
+    for (int j = first; j < w.n_joints; j += stride) if (joint_live(w, j)) joint_writeback_one(w, j);
+}
+
 // NarrowPhase::emit_contact_force_events (solver_graph.rs:462-498) + ContactForceEvent::from_contact_pair
 // (geometry/mod.rs:223-258): one thread per pair slot, after the impulses of the step were written back.
 __global__ void k_force_events(DevWorld w, int fast) {
@@ -394,9 +414,8 @@ void rp_launch_solver_writeback(const DevWorld &w0, hipStream_t st, int parity, 
     DevWorld w = w0;
     if (parity & 1) { std::swap(w.s_lin, w.t_lin); std::swap(w.s_ang, w.t_ang); w.c_par = 1; } // the tile sweeps left the velocities (and the mutable constraint planes) in the other copy
     if (parity & 2) { std::swap(w.s_rot, w.t_rot); std::swap(w.s_trans, w.t_trans); } // ... and the poses
-    if (w.lean & 2) {} // (bare lean graph: the joints' write-back rides k_writeback_bodies)
-    else if (host_coulomb(w)) hipLaunchKernelGGL(k_writeback_impulses<true>, dim3(cons_blocks(w)), dim3(256), 0, st, w);
-    else hipLaunchKernelGGL(k_writeback_impulses<false>, dim3(cons_blocks(w)), dim3(256), 0, st, w);
-    hipLaunchKernelGGL(k_writeback_bodies, dim3(body_blocks(w)), dim3(256), 0, st, w);
+    if (w.lean & 2) hipLaunchKernelGGL(k_writeback_bodies, dim3(body_blocks(w)), dim3(256), 0, st, w); // (bare lean graph: the joints' write-back rides k_writeback_bodies)
+    else if (host_coulomb(w)) hipLaunchKernelGGL(k_writeback<true>, dim3(body_blocks(w) + cons_blocks(w)), dim3(256), 0, st, w, body_blocks(w));
+    else hipLaunchKernelGGL(k_writeback<false>, dim3(body_blocks(w) + cons_blocks(w)), dim3(256), 0, st, w, body_blocks(w));
     if (publish) hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, w); // hint buffer (MULTI mode: after the step; else k_ccd carries it)
 }

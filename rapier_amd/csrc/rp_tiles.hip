@@ -471,17 +471,12 @@ RP_DEV void tile_apply(const DevWorld &w, const int4 e, const int n, const int *
 // compared with the oracle bit for bit over the same rows): identical results.
 // (SC1, cpar, rot, trans: k_tile_step — the copy of the mutable planes and of the poses that is current inside a launch that runs many
 // sweeps, and write-through stores for what other tiles read behind a flag instead of a kernel boundary)
-RP_DEV void tl_store_sc1(float4 *p, float4 v) {
-    typedef float tl_v4f __attribute__((ext_vector_type(4)));
-    const tl_v4f x = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(x) : "memory");
-}
-template <int MODE, bool SC1 = false>
+template <int MODE, bool SC1 = false, bool SC1LD = false>
 RP_DEV void tile_apply2(const DevWorld &w, const int4 e, const int n, const bool odd, const int *Lg, float4 *Ll, float4 *La, bool friction, float solved_dt, const int cpar, const float4 *rot, const float4 *trans) {
     const int pos = e.x;
     const size_t cap = w.cons_cap;
 #define TL2(pe, po) w.C[(size_t)(odd ? (po) : (pe)) * cap + pos]   // an immutable plane per lane parity
-#define TLM(p) w.C[(size_t)cplane(p, cpar) * cap + pos]             // a mutable plane (even lane's business; both lanes fetch it)
+#define TLM(p) ld16_t<SC1LD>(w.C + (size_t)cplane(p, cpar) * cap, (unsigned)pos) // a mutable plane (even lane's business; both lanes fetch it)
     float4 h0 = TL2(CP_H0, CP_H0), h6 = TL2(CP_H6, CP_H6), imr = TL2(CP_H1, CP_H2), h2 = TL2(CP_H2, CP_H2), hm0 = TLM(CP_HM0), hm1 = TLM(CP_HM1);
     float4 pa[4], pc[4], pm[4], lp[4];
 #pragma unroll
@@ -495,7 +490,7 @@ RP_DEV void tile_apply2(const DevWorld &w, const int4 e, const int n, const bool
         h7 = TL2(CP_H7, CP_H7); h8 = TL2(CP_H8, CP_H8);
     }
     const int lid = odd ? e.z : e.y;
-    if (MODE == MODE_RELAX) { b2 = TL2(CP_B2, CP_B2); const int g = Lg[lid >= 0 ? lid : 0]; xr = rot[g]; xt = trans[g]; }
+    if (MODE == MODE_RELAX) { b2 = TL2(CP_B2, CP_B2); const int g = Lg[lid >= 0 ? lid : 0]; xr = ld16_t<SC1LD>(rot, (unsigned)g); xt = ld16_t<SC1LD>(trans, (unsigned)g); }
 #undef TL2
 #undef TLM
     __builtin_amdgcn_sched_group_barrier(0x020, 48, 0); // every VMEM read above as one group
@@ -542,7 +537,7 @@ RP_DEV void tile_apply2(const DevWorld &w, const int4 e, const int n, const bool
     isl_solve(h, L, MODE == MODE_RELAX, friction);
     if (!odd && e.w != 0) { // the owner's even lane stores the manifold's mutable planes into the other copy (all of them: see tile_apply)
         const int par = cpar ^ 1;
-#define TLS(p, v) do { float4 *d_ = &w.C[(size_t)cplane(p, par) * cap + pos]; if (SC1) tl_store_sc1(d_, v); else *d_ = v; } while (0)
+#define TLS(p, v) do { if (SC1) st16_sc1(w.C + (size_t)cplane(p, par) * cap, (unsigned)pos, v); else w.C[(size_t)cplane(p, par) * cap + pos] = v; } while (0)
 #pragma unroll
         for (int k = 0; k < 4; ++k) { if (k >= n) break; const SidePoint &q = h.P[k]; TLS(NPL(k, NP_M), make_float4(q.rhs, q.cfm, q.lam, q.acc)); }
         TLS(CP_HM0, make_float4(h.tw_imp, h.tw_acc, h.t_imp0, h.t_imp1));
@@ -876,6 +871,7 @@ RP_DEV void jn_store_sc1(float4 *p, float4 v) {
 // true = the launch is dead: a neighbour never arrived (a workgroup that is not resident — another process or stream holds CUs).  Nothing
 // is committed by this kernel (the write-back is a launch of its own and looks at lean_dead): FL_JN_TIMEOUT makes the step die like any
 // lean step, the full graph resumes it, and settle() stops planning the joint-net form for this world (rp_counters.joint_net_disabled)
+template <bool ACQ = true>
 RP_DEV bool jn_sync(const DevWorld &w, int tile, unsigned epoch, const int *Lnbr, int nn) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every wave: its write-through stores have completed
     __syncthreads();
@@ -891,7 +887,7 @@ RP_DEV bool jn_sync(const DevWorld &w, int tile, unsigned epoch, const int *Lnbr
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (ACQ && threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // (!ACQ: the caller reads what its neighbours published with sc1 loads)
     return __syncthreads_or(dead) != 0;
 }
 __global__ void __launch_bounds__(RP_JN_THREADS) k_joint_net_step(DevWorld w, int joint_warmstart, int stall_tile) {
@@ -1047,11 +1043,14 @@ int rp_joint_net_cap(void) {
 // (DevWorld::lean bit 3, the grid in bits 8 and up; lean_dead verifies a valid tiling that fits the grid), no impulse joints, one PGS
 // and one stabilisation iteration, at most five substeps (a launch owns 16 flag values).  A tile that waits in vain raises
 // FL_JN_TIMEOUT: nothing is committed by this kernel, the step dies like any lean step and the world keeps the sweep launches.
+#ifndef RP_TS_SC1LD
+#define RP_TS_SC1LD true // what another tile stored in this launch is read past the L2 (sc1 loads) and a flag is not followed by an agent-scope acquire: the L2 the XCD's tiles share keeps their rows
+#endif
 struct TsPrepAcc { // ws_prepare_one's view of one owned manifold: rows (of the current copy) in registers, write-through stores, poses fetched with the rows
     static constexpr bool PRELOAD = false;
     const DevWorld &w; const float4 *v; int pos, par, b1, b2, nn; Xf X1, X2;
     RP_DEV float4 ld(int plane) const { return v[plane]; }
-    RP_DEV void st(int plane, float4 x) const { tl_store_sc1(&w.C[(size_t)cplane(plane, par) * w.cons_cap + pos], x); }
+    RP_DEV void st(int plane, float4 x) const { st16_sc1(w.C + (size_t)cplane(plane, par) * w.cons_cap, (unsigned)pos, x); }
     RP_DEV int id1() const { return b1; }
     RP_DEV int id2() const { return b2; }
     RP_DEV int n() const { return nn; }
@@ -1064,14 +1063,14 @@ struct TsPrepAcc { // ws_prepare_one's view of one owned manifold: rows (of the 
 // behind thousands of wavefronts; a tile has four)
 RP_DEV void ts_prepare(const DevWorld &w, const int pos, const int b1, const int b2, const int n, const int par, const float4 *rot, const float4 *trans, const float solved_dt) {
     float4 v[CP_COUNT];
-#define TP_LD(p) v[p] = w.C[(size_t)cplane(p, par) * w.cons_cap + pos]
+#define TP_LD(p) v[p] = (RP_TS_SC1LD && cplane_mut_index(p) >= 0) ? ld16_sc1(w.C + (size_t)cplane(p, par) * w.cons_cap, (unsigned)pos) : w.C[(size_t)cplane(p, par) * w.cons_cap + pos]
     TP_LD(CP_H0); TP_LD(CP_H1); TP_LD(CP_H2); TP_LD(CP_H3); TP_LD(CP_H4); TP_LD(CP_H5); TP_LD(CP_H6); TP_LD(CP_H7); TP_LD(CP_HM0); TP_LD(CP_HM1);
     TP_LD(CP_T4); TP_LD(CP_T5); TP_LD(CP_T6); TP_LD(CP_T7); TP_LD(CP_B0); TP_LD(CP_B1); TP_LD(CP_B2);
 #pragma unroll
     for (int k = 0; k < 4; ++k) { TP_LD(NPL(k, NP_M)); TP_LD(NPL(k, NP_C)); TP_LD(NPL(k, NP_D)); TP_LD(NPL(k, NP_E)); TP_LD(NPL(k, NP_F)); }
 #undef TP_LD
     const int g1 = b1 >= 0 ? b1 : 0, g2 = b2 >= 0 ? b2 : 0;
-    float4 r1 = rot[g1], t1 = trans[g1], r2 = rot[g2], t2 = trans[g2];
+    float4 r1 = ld16_t<RP_TS_SC1LD>(rot, (unsigned)g1), t1 = ld16_t<RP_TS_SC1LD>(trans, (unsigned)g1), r2 = ld16_t<RP_TS_SC1LD>(rot, (unsigned)g2), t2 = ld16_t<RP_TS_SC1LD>(trans, (unsigned)g2);
     __builtin_amdgcn_sched_group_barrier(0x020, 48, 0); // every VMEM read above as one group
 #define TP_PIN(r_) asm volatile("" : "+v"((r_).x), "+v"((r_).y), "+v"((r_).z), "+v"((r_).w))
     TP_PIN(v[CP_H0]); TP_PIN(v[CP_H1]); TP_PIN(v[CP_H2]); TP_PIN(v[CP_H3]); TP_PIN(v[CP_H4]); TP_PIN(v[CP_H5]); TP_PIN(v[CP_H6]); TP_PIN(v[CP_H7]); TP_PIN(v[CP_HM0]); TP_PIN(v[CP_HM1]);
@@ -1124,7 +1123,7 @@ RP_DEV void ts_stages(const DevWorld &w, const int4 *cons, const int *Soff, cons
         bool have = have_next;
         { const int i1 = end + my; have_next = i1 < Soff[s + 2]; e_next = cons[have_next ? i1 : 0]; } // (Soff[nst + 1] = Soff[nst]: nothing behind the last stage)
         while (have) {
-            tile_apply2<MODE, true>(w, e, n, odd, Lg, Ll, La, friction, solved_dt, cpar, rot, trans);
+            tile_apply2<MODE, true, RP_TS_SC1LD>(w, e, n, odd, Lg, Ll, La, friction, solved_dt, cpar, rot, trans);
             i += per; have = i < end;
             if (have) { e = cons[i]; n = w.k_n[e.x]; }
         }
@@ -1199,41 +1198,41 @@ __global__ void __launch_bounds__(RP_TS_THREADS) k_tile_step(DevWorld w, int fri
         if (own2_pos >= 0) ts_prepare(w, own2_pos, own2_b1, own2_b2, own2_n, par, rs, ts, solved_dt);
         for (int k = t + 2 * nt; k < n_own; k += nt) { const int pos = Lown[k]; ts_prepare(w, pos, w.k_b1[pos], w.k_b2[pos], w.k_n[pos], par, rs, ts, solved_dt); }
         TS_STAMP(1);
-        if (jn_sync(w, tile, e0 + 3u * (unsigned)s + 1u, Lnbr, nn)) return;
+        if (jn_sync<!RP_TS_SC1LD>(w, tile, e0 + 3u * (unsigned)s + 1u, Lnbr, nn)) return;
         TS_STAMP(2);
         // B: the bodies this tile owns
         if (t < half) {
-            for (int l = t; l < n_owned; l += half) { const int g = Lg[l]; V3 lin, ang; body_increment_ws_at(w, g, vs, as, rs, lin, ang); Ll[l] = f4(lin, 0.0f); tl_store_sc1(vs + g, f4(lin, 0.0f)); }
+            for (int l = t; l < n_owned; l += half) { const int g = Lg[l]; V3 lin, ang; body_increment_ws_at<RP_TS_SC1LD>(w, g, vs, as, rs, lin, ang); Ll[l] = f4(lin, 0.0f); st16_sc1(vs, (unsigned)g, f4(lin, 0.0f)); }
         } else {
-            for (int l = t - half; l < n_owned; l += half) { const int g = Lg[l]; V3 lin, ang; body_increment_ws_at(w, g, vs, as, rs, lin, ang); La[l] = f4(ang, 0.0f); tl_store_sc1(as + g, f4(ang, 0.0f)); }
+            for (int l = t - half; l < n_owned; l += half) { const int g = Lg[l]; V3 lin, ang; body_increment_ws_at<RP_TS_SC1LD>(w, g, vs, as, rs, lin, ang); La[l] = f4(ang, 0.0f); st16_sc1(as, (unsigned)g, f4(ang, 0.0f)); }
         }
         TS_STAMP(3);
-        if (jn_sync(w, tile, e0 + 3u * (unsigned)s + 2u, Lnbr, nn)) return;
+        if (jn_sync<!RP_TS_SC1LD>(w, tile, e0 + 3u * (unsigned)s + 2u, Lnbr, nn)) return;
         TS_STAMP(4);
         // C: biased sweep; the halo bodies come in, the owned ones leave integrated (velocities AND poses to the other copies)
-        for (int l = n_owned + t; l < nb; l += nt) { const int g = Lg[l]; Ll[l] = vs[g]; La[l] = as[g]; }
+        for (int l = n_owned + t; l < nb; l += nt) { const int g = Lg[l]; Ll[l] = ld16_t<RP_TS_SC1LD>(vs, (unsigned)g); La[l] = ld16_t<RP_TS_SC1LD>(as, (unsigned)g); }
         __syncthreads();
         TS_STAMP(5);
         ts_stages<MODE_BIAS, RP_TS_PREFETCH>(w, cons, Soff, nst, my, per, odd, Lg, Ll, La, fib, solved_dt, par, rs, ts);
         TS_STAMP(6);
         for (int l = t; l < n_owned; l += nt) {
             const int g = Lg[l];
-            V3 lin = v3(Ll[l]), ang = v3(La[l]), trans = v3(ts[g]); Q4 rot = q4(rs[g]);
+            V3 lin = v3(Ll[l]), ang = v3(La[l]), trans = v3(ld16_t<RP_TS_SC1LD>(ts, (unsigned)g)); Q4 rot = q4(ld16_t<RP_TS_SC1LD>(rs, (unsigned)g));
             body_integrate(w, w.b_flags[g], lin, ang, rot, trans);
             Ll[l] = f4(lin, 0.0f); La[l] = f4(ang, 0.0f);
-            tl_store_sc1(vt + g, f4(lin, 0.0f)); tl_store_sc1(at + g, f4(ang, 0.0f)); tl_store_sc1(rt + g, f4(rot)); tl_store_sc1(tt + g, f4(trans, 0.0f));
+            st16_sc1(vt, (unsigned)g, f4(lin, 0.0f)); st16_sc1(at, (unsigned)g, f4(ang, 0.0f)); st16_sc1(rt, (unsigned)g, f4(rot)); st16_sc1(tt, (unsigned)g, f4(trans, 0.0f));
         }
         { float4 *a = vs; vs = vt; vt = a; a = as; as = at; at = a; a = rs; rs = rt; rt = a; a = ts; ts = tt; tt = a; }
         TS_STAMP(7);
-        if (jn_sync(w, tile, e0 + 3u * (unsigned)s + 3u, Lnbr, nn)) return;
+        if (jn_sync<!RP_TS_SC1LD>(w, tile, e0 + 3u * (unsigned)s + 3u, Lnbr, nn)) return;
         TS_STAMP(8);
         // D: relaxed sweep (the other copy of the mutable planes, the new poses)
-        for (int l = n_owned + t; l < nb; l += nt) { const int g = Lg[l]; Ll[l] = vs[g]; La[l] = as[g]; }
+        for (int l = n_owned + t; l < nb; l += nt) { const int g = Lg[l]; Ll[l] = ld16_t<RP_TS_SC1LD>(vs, (unsigned)g); La[l] = ld16_t<RP_TS_SC1LD>(as, (unsigned)g); }
         __syncthreads();
         TS_STAMP(9);
         ts_stages<MODE_RELAX, RP_TS_PREFETCH>(w, cons, Soff, nst, my, per, odd, Lg, Ll, La, true, solved_dt + w.prm.dt_sub, par ^ 1, rs, ts);
         TS_STAMP(10);
-        for (int l = t; l < n_owned; l += nt) { const int g = Lg[l]; tl_store_sc1(vt + g, Ll[l]); tl_store_sc1(at + g, La[l]); }
+        for (int l = t; l < n_owned; l += nt) { const int g = Lg[l]; st16_sc1(vt, (unsigned)g, Ll[l]); st16_sc1(at, (unsigned)g, La[l]); }
         { float4 *a = vs; vs = vt; vt = a; a = as; as = at; at = a; }
         __syncthreads(); // (every store of this phase has completed: phase A reads the rows this tile just wrote, phase B its own bodies)
         TS_STAMP(11);

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _world(scene, monkeypatch, **env):
-    for k in ("RP_NO_TILES", "RP_TILE_TARGET", "RP_TILE_MIN", "RP_FORCE_MULTI", "RP_NO_LEAN", "RP_TILE_STALE_PLAN", "RP_TEST_LATE_FILL", "RP_NO_JOINT_NET"):
+    for k in ("RP_NO_TILES", "RP_TILE_TARGET", "RP_TILE_MIN", "RP_FORCE_MULTI", "RP_NO_LEAN", "RP_TILE_STALE_PLAN", "RP_TEST_LATE_FILL", "RP_NO_JOINT_NET", "RP_NO_TILE_STEP"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, str(v))
@@ -522,6 +522,68 @@ def test_a_joint_net_launch_whose_workgroup_never_arrives_dies_without_writing()
     (FL_JN_TIMEOUT), every other tile follows, the write-back behind the launch finds the step dead — nothing was committed —, the
     full graph resumes it and the world takes the sweep launches from then on (rp_counters.joint_net_disabled); bit for bit the oracle"""
     _in_testing_build("_jn_stall_body")
+
+
+# ---- k_tile_step: the TGS loop of a tiled contact world as ONE launch (rp_tiles.hip, round 6) -------------------------------------------
+def test_tile_step_launch_equals_the_sweep_launches_and_the_oracle(monkeypatch):
+    """a tiled pyramid with the one-launch TGS loop (k_tile_step: prepare / increment / biased / relaxed sweeps of every substep as phases
+    of one kernel, neighbouring tiles' flags instead of kernel boundaries) on its lean AND its full graphs, the same world on the sweep
+    launches (RP_NO_TILE_STEP=1), and the oracle: identical bits at every checkpoint, an impulse in between included (pairs end and
+    begin: full graphs, layout rebuilds, lean graphs dying behind their collision stage)"""
+    monkeypatch.delenv("RP_NO_LEAN", raising=False)
+    sc = S.large_pyramid(60)
+    a, o = _world(sc, monkeypatch), OracleWorld(sc)
+    b = _world(sc, monkeypatch, RP_NO_TILE_STEP=1)
+    dyn = [i for i, bd in enumerate(sc.bodies) if int(bd["body_type"]) == S.BODY_DYNAMIC]
+    done = 0
+    for cp in (1, 12, 60, 120, 121, 140, 220):
+        if cp == 121:
+            for bd in dyn[-3:]:
+                a.apply_impulse([bd], impulse=(400.0, 900.0, 150.0)); b.apply_impulse([bd], impulse=(400.0, 900.0, 150.0)); o.apply_impulse(bd, impulse=(400.0, 900.0, 150.0))
+        a.step(cp - done); b.step(cp - done); o.step(cp - done); done = cp
+        _equal(a, o, f"k_tile_step @ {cp}"); _equal(b, o, f"sweep launches @ {cp}")
+    ca, cb = a.counters(), b.counters()
+    assert ca["tile_step_steps"] > 80 and ca["tile_step_steps"] <= ca["lean_steps"] + ca["full_steps"] and ca["joint_net_disabled"] == 0, ca
+    assert ca["lean_steps"] > 20 and ca["full_steps"] >= 3, ca          # both graph kinds were enqueued
+    assert cb["tile_step_steps"] == 0 and cb["tile_sweeps"] == 1, cb
+
+
+@pytest.mark.parametrize("override", [{"num_solver_iterations": 5}, {"num_solver_iterations": 1}, {"warmstart_coefficient": 0.0}, {"num_solver_iterations": 6}])
+def test_tile_step_launch_substep_counts(monkeypatch, override):
+    """one to five substeps run the one-launch form (a launch owns sixteen values of a tile's flag, three per substep); six keep the sweep
+    launches; without a warm start phase A still updates the right-hand sides"""
+    sc = S.large_pyramid(60)
+    for k, v in override.items():
+        sc.params[k] = v
+    g, o, c = _run(sc, [2, 12, 40, 90], monkeypatch)
+    if override.get("num_solver_iterations", 4) <= 5: assert c["tile_step_steps"] > 40, c
+    else: assert c["tile_step_steps"] == 0, c
+
+
+def test_tile_step_launch_in_a_churning_pile_with_islands_coming_and_going(monkeypatch):
+    """tumbling cuboids and balls: debris leaves the pile and forms islands of its own (k_tile_step runs in worlds without an LDS island:
+    a step planned on a stale hint dies before it commits anything and is resumed on the sweep launches), pairs begin and end all the time"""
+    sc = S.tumble(1300, seed=5)
+    for c in sc.colliders:
+        c["restitution"] = 0.0
+    g, o, c = _run(sc, [1, 30, 120, 300, 500], monkeypatch, RP_TILE_MIN=256)
+    print("tumble counters:", {k: c[k] for k in ("tile_step_steps", "lean_steps", "full_steps", "replayed_steps", "num_islands")})
+
+
+def _ts_stall_body():
+    sc = S.large_pyramid(60)
+    g, o, c = _run(sc, [1, 6, 40, 80], _Env(), RP_TEST_TS_STALL=3)
+    assert c["joint_net_disabled"] == 1 and c["tile_step_steps"] >= 1 and c["replayed_steps"] >= 1 and c["overflow_flags"] == 0, c
+    assert c["lean_steps"] + c["full_steps"] > c["tile_step_steps"] + 40, c          # the world went on, on the sweep launches
+
+
+def test_a_tile_step_launch_whose_workgroup_never_arrives_dies_without_writing():
+    """every workgroup of k_tile_step must be resident (a tile waits for its neighbours' flags); on a shared device one may not be.
+    RP_TEST_TS_STALL=3 (testing build) makes workgroup 3 of every such launch leave at once: its neighbours give up after ~2 s
+    (FL_JN_TIMEOUT), every other tile follows, the write-back behind the launch finds the step dead — nothing was committed, on a FULL
+    graph too (whose resume does not colour the step's new pairs a second time) —, the sweep launches resume it and the world keeps them
+    from then on (rp_counters.joint_net_disabled); bit for bit the oracle"""
+    _in_testing_build("_ts_stall_body")
 
 
 def test_a_pile_whose_cones_outgrow_the_budget_abandons_its_tiling_without_a_fault():
