@@ -236,7 +236,7 @@ struct rp_world {
     long long fast_steps = 0, full_steps = 0, replayed_steps = 0, fused_steps = 0; int fused_disabled = 0, jn_disabled = 0;
     // timers
     bool timers = false;
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // ([6], [7]: around the one-launch TGS loop of a timed step)
     double acc_isl_ms = 0.0, acc_glob_ms = 0.0, acc_col_ms = 0.0, acc_step_ms = 0.0;
     double acc_bp_ms = 0.0, acc_np_ms = 0.0, acc_islc_ms = 0.0; int acc_full_steps = 0; // full steps only: broad phase, narrow phase, island construction
     int acc_steps = 0;
