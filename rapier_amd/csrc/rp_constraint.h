@@ -106,6 +106,7 @@ RP_DEV bool cons_generate(const DevWorld &w, const Acc &A, int s, int gid1, int 
             in_imp[k] = PT(w.pt_imp, cid, s); in_wst[k] = PT(w.pt_wst, cid, s); in_dp1[k] = PT(w.pt_dp1, cid, s); in_dp2[k] = PT(w.pt_dp2, cid, s);
         }
     }
+    float d0s0 = 0.0f, d0s1 = 0.0f, d0s2 = 0.0f, d0s3 = 0.0f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (k >= count) break;
@@ -142,6 +143,7 @@ RP_DEV bool cons_generate(const DevWorld &w, const Acc &A, int s, int gid1, int 
         float restitution_seed = is_bouncy * restitution * projected_velocity;
         bouncy_seed |= restitution_seed < 0.0f;
         float info_dist = dist - dot(point - (world_com2 + dp2), force_dir1);
+        if (k == 0) d0s0 = info_dist; else if (k == 1) d0s1 = info_dist; else if (k == 2) d0s2 = info_dist; else d0s3 = info_dist;
         A.st(NPL(k, NP_M), make_float4(0.0f, 1.0f, warmstart_impulse, -warmstart_impulse));
         A.st(NPL(k, NP_A), f4(torque_dir1, projected_mass));
         A.st(NPL(k, NP_B), f4(torque_dir2, restitution_seed));
@@ -181,17 +183,19 @@ RP_DEV bool cons_generate(const DevWorld &w, const Acc &A, int s, int gid1, int 
     A.st(CP_H4, make_float4(ii1.m23, ii1.m33, ii2.m11, ii2.m12));
     A.st(CP_H5, make_float4(ii2.m13, ii2.m22, ii2.m23, ii2.m33));
     A.st(CP_H6, f4(t0, rhs_wo[0]));
-    A.st(CP_H7, make_float4(rhs_wo[1], r[0], r[1], 0.0f));
+    // (the spare words of T0, T1, B2 and H7 carry a second copy of the points' builder distances: the tile sweeps recompute the
+    // ii_torque_dir rows from the inertia instead of fetching them — rp_tiles.hip, tile_apply2 — and NP_C, which holds the distance, is one of them)
+    A.st(CP_H7, make_float4(rhs_wo[1], r[0], r[1], d0s3));
     A.st(CP_H8, tdists);
     A.st(CP_HM0, make_float4(twist_imp, -twist_imp, tw0, tw1));
     A.st(CP_HM1, make_float4(-tw0, -tw1, rhs_wo[0], rhs_wo[1]));
-    A.st(CP_T0, f4(td1[0], 0.0f)); A.st(CP_T1, f4(td1[1], 0.0f));
+    A.st(CP_T0, f4(td1[0], d0s0)); A.st(CP_T1, f4(td1[1], d0s1));
     A.st(CP_T2, f4(td2[0], 0.0f)); A.st(CP_T3, f4(td2[1], 0.0f));
     A.st(CP_T4, f4(itd1[0], 0.0f)); A.st(CP_T5, f4(itd1[1], 0.0f));
     A.st(CP_T6, f4(itd2[0], 0.0f)); A.st(CP_T7, f4(itd2[1], 0.0f));
     A.st(CP_B0, f4(xf_itp(poses1, friction_center), 0.0f));
     A.st(CP_B1, f4(xf_itp(poses2, friction_center2), 0.0f));
-    A.st(CP_B2, f4(tangent_vel, 0.0f));
+    A.st(CP_B2, f4(tangent_vel, d0s2));
     A.set_meta(id1, id2, count, cids);
     return bouncy_seed;
 }

@@ -471,6 +471,9 @@ RP_DEV void tile_apply(const DevWorld &w, const int4 e, const int n, const int *
 // compared with the oracle bit for bit over the same rows): identical results.
 // (SC1, cpar, rot, trans: k_tile_step — the copy of the mutable planes and of the poses that is current inside a launch that runs many
 // sweeps, and write-through stores for what other tiles read behind a flag instead of a kernel boundary)
+#ifndef RP_TILE_RECOMP
+#define RP_TILE_RECOMP true
+#endif
 template <int MODE, bool SC1 = false, bool SC1LD = false>
 RP_DEV void tile_apply2(const DevWorld &w, const int4 e, const int n, const bool odd, const int *Lg, float4 *Ll, float4 *La, bool friction, float solved_dt, const int cpar, const float4 *rot, const float4 *trans) {
     const int pos = e.x;
@@ -481,12 +484,15 @@ RP_DEV void tile_apply2(const DevWorld &w, const int4 e, const int n, const bool
     float4 pa[4], pc[4], pm[4], lp[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { // (all four points: no load waits for the point count)
-        pa[k] = TL2(NPL(k, NP_A), NPL(k, NP_B)); pc[k] = TL2(NPL(k, NP_C), NPL(k, NP_D)); pm[k] = TLM(NPL(k, NP_M));
+        pa[k] = TL2(NPL(k, NP_A), NPL(k, NP_B)); pm[k] = TLM(NPL(k, NP_M));
+        if (!RP_TILE_RECOMP) pc[k] = TL2(NPL(k, NP_C), NPL(k, NP_D));
         if (MODE == MODE_RELAX) lp[k] = TL2(NPL(k, NP_E), NPL(k, NP_F));
     }
     float4 iiA = h0, iiB = h0, td0 = h0, td1 = h0, itd0 = h0, itd1 = h0, h7 = h0, h8 = h0, b2 = h0, xr = h0, xt = h0;
+    if (friction || RP_TILE_RECOMP) { iiA = TL2(CP_H3, CP_H5); iiB = TL2(CP_H4, CP_H4); }
     if (friction) {
-        iiA = TL2(CP_H3, CP_H5); iiB = TL2(CP_H4, CP_H4); td0 = TL2(CP_T0, CP_T2); td1 = TL2(CP_T1, CP_T3); itd0 = TL2(CP_T4, CP_T6); itd1 = TL2(CP_T5, CP_T7);
+        td0 = TL2(CP_T0, CP_T2); td1 = TL2(CP_T1, CP_T3);
+        if (!RP_TILE_RECOMP) { itd0 = TL2(CP_T4, CP_T6); itd1 = TL2(CP_T5, CP_T7); }
         h7 = TL2(CP_H7, CP_H7); h8 = TL2(CP_H8, CP_H8);
     }
     const int lid = odd ? e.z : e.y;
@@ -497,8 +503,9 @@ RP_DEV void tile_apply2(const DevWorld &w, const int4 e, const int n, const bool
 #define P4(r_) asm volatile("" : "+v"((r_).x), "+v"((r_).y), "+v"((r_).z), "+v"((r_).w))
     P4(h0); P4(h6); P4(imr); P4(h2); P4(hm0); P4(hm1);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { P4(pa[k]); P4(pc[k]); P4(pm[k]); if (MODE == MODE_RELAX) P4(lp[k]); }
-    if (friction) { P4(iiA); P4(iiB); P4(td0); P4(td1); P4(itd0); P4(itd1); P4(h7); P4(h8); }
+    for (int k = 0; k < 4; ++k) { P4(pa[k]); if (!RP_TILE_RECOMP) P4(pc[k]); P4(pm[k]); if (MODE == MODE_RELAX) P4(lp[k]); }
+    if (friction || RP_TILE_RECOMP) { P4(iiA); P4(iiB); }
+    if (friction) { P4(td0); P4(td1); if (!RP_TILE_RECOMP) { P4(itd0); P4(itd1); } P4(h7); P4(h8); }
     if (MODE == MODE_RELAX) { P4(b2); P4(xr); P4(xt); }
 #undef P4
     IslSide h;
@@ -506,12 +513,17 @@ RP_DEV void tile_apply2(const DevWorld &w, const int4 e, const int n, const bool
     h.dir = v3(h0); h.t0 = v3(h6); h.t1 = cross(h.dir, h.t0);
     h.im = v3(imr);
     { const V3 dim = cmul(h.dir, h.im); h.sdim = odd ? -dim : dim; }
+    // RP_TILE_RECOMP: the ii_torque_dir rows (NP_C / NP_D of every point, T4 .. T7) are not fetched — sym_mul of the inertia (H3 .. H5, fetched
+    // for the twist row anyway) with the torque_dir rows is what cons_generate stored there, operand for operand (rp_constraint.h:138-172):
+    // 6 of a lane's 33 row loads in a relaxed stage, 4 of 18 (+ the two inertia rows) in a biased one, for ~90 multiply-adds.  The builder
+    // distance NP_C carried in its spare word comes from the copies cons_generate leaves in T0.w, T1.w, B2.w, H7.w.
+    const Sym3 ii = odd ? Sym3{iiB.z, iiB.w, iiA.x, iiA.y, iiA.z, iiA.w} : Sym3{iiA.x, iiA.y, iiA.z, iiA.w, iiB.x, iiB.y};
     {
-        const Sym3 ii = odd ? Sym3{iiB.z, iiB.w, iiA.x, iiA.y, iiA.z, iiA.w} : Sym3{iiA.x, iiA.y, iiA.z, iiA.w, iiB.x, iiB.y};
         const V3 tw = sym_mul(ii, h.dir);
         h.stw = odd ? -tw : tw;
     }
-    h.td0 = v3(td0); h.td1 = v3(td1); h.itd0 = v3(itd0); h.itd1 = v3(itd1);
+    h.td0 = v3(td0); h.td1 = v3(td1);
+    if (RP_TILE_RECOMP) { h.itd0 = sym_mul(ii, h.td0); h.itd1 = sym_mul(ii, h.td1); } else { h.itd0 = v3(itd0); h.itd1 = v3(itd1); }
     h.mu = h0.w; h.twist_r = imr.w; h.rhs_wo0 = h6.w; h.rhs_wo1 = h7.x; h.k11 = h7.y; h.k22 = h7.z; h.k12 = h2.w * 0.5f;
     h.inv_det = rp_inv(h.k11 * h.k22 - h.k12 * h.k12);
     h.td[0] = h8.x; h.td[1] = h8.y; h.td[2] = h8.z; h.td[3] = h8.w;
@@ -523,7 +535,9 @@ RP_DEV void tile_apply2(const DevWorld &w, const int4 e, const int n, const bool
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         SidePoint &q = h.P[k];
-        q.pa = v3(pa[k]); q.r = pa[k].w; q.pc = v3(pc[k]); q.d0 = pc[k].w; q.seed = 0.0f;
+        q.pa = v3(pa[k]); q.r = pa[k].w; q.seed = 0.0f;
+        if (RP_TILE_RECOMP) { q.pc = sym_mul(ii, q.pa); q.d0 = k == 0 ? td0.w : (k == 1 ? td1.w : (k == 2 ? b2.w : h7.w)); } // (d0: read by the relaxed form only, whose even lane holds T0 / T1)
+        else { q.pc = v3(pc[k]); q.d0 = pc[k].w; }
         q.rhs = pm[k].x; q.cfm = pm[k].y; q.lam = pm[k].z; q.acc = pm[k].w; q.rhsR = 0.0f; q.rhsB = 0.0f; q.cfmB = 1.0f;
         if (MODE == MODE_RELAX) { // refresh_rhs_wo_bias (:529-554): p1 = T1 lp1 + delta on the even lane, p2 = T2 lp2 on the odd one
             V3 pw = xf_tp(x, v3(lp[k]));
