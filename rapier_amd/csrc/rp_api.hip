@@ -189,7 +189,7 @@ struct rp_world {
     // shard guard (rp_world_set_shard_guard): host copy, re-uploaded whenever the device world is rebuilt
     std::vector<float4> guard_min, guard_max; std::vector<int> guard_start, guard_items; float guard_origin[3] = {0, 0, 0}, guard_cell = 0.0f; int guard_dims[3] = {0, 0, 0};
     // launch plan + graph
-    int plan_stages = 0, plan_blocks = 1, plan_single = 1, plan_island_grid = 1, plan_joint_stages = 0, plan_no_global = 0, plan_fused = 0, plan_tile_grid = 0, plan_no_contacts = 0, plan_bare = 0, plan_jn = 0, plan_ts = 0, plan_dense = 0, plan_wide = 0;
+    int plan_stages = 0, plan_blocks = 1, plan_single = 1, plan_island_grid = 1, plan_joint_stages = 0, plan_no_global = 0, plan_fused = 0, plan_tile_grid = 0, plan_no_contacts = 0, plan_bare = 0, plan_jn = 0, plan_ts = 0, plan_dense = 0, plan_wide = 0, plan_islands_hint = 0;
     bool has_restitution = false;
     // [0] = full path, [1] = fast path, [2] = lean path; "whole" = one graph per step, col/loop/fin = timed thirds (full / fast only)
     hipGraph_t g_whole[3] = {nullptr, nullptr, nullptr}, g_col[3] = {nullptr, nullptr, nullptr}, g_loop[3] = {nullptr, nullptr, nullptr}, g_fin[3] = {nullptr, nullptr, nullptr};

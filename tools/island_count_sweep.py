@@ -11,7 +11,7 @@ from rapier_amd import PhysicsWorld, scenes as S  # noqa: E402
 print("islands  cuboids   us/step  steps/s   us/step per pass of 240")
 grids = ((7, 7), (10, 10), (14, 14), (15, 16), (16, 16), (19, 19), (20, 24), (22, 22), (27, 27), (38, 38), (54, 54))
 if len(sys.argv) > 1 and sys.argv[1] == "short":
-    grids = ((14, 14), (16, 16), (19, 19), (20, 24), (22, 22), (27, 27), (54, 54))
+    grids = ((14, 14), (16, 16), (19, 19), (20, 24), (22, 22), (27, 27), (27, 54), (54, 54))
 print("RP_NO_ISL_DENSE =", os.environ.get("RP_NO_ISL_DENSE"), " RP_ISL_DENSE =", os.environ.get("RP_ISL_DENSE"))
 for r, c in grids:
     w = PhysicsWorld.from_scene(S.many_pyramids(rows=r, cols=c))
