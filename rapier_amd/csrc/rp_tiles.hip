@@ -913,11 +913,7 @@ __global__ void __launch_bounds__(RP_JN_THREADS) k_joint_net_step(DevWorld w, in
     const int t = threadIdx.x, nt = blockDim.x;
     // (XCD-aware placement: workgroup b runs on XCD b % 8; every XCD takes a contiguous run of the curve — the tiles a tile exchanges bodies with sit behind the same L2)
     const int ntiles_ = w.flags[FL_N_TILES], per_xcd_ = (ntiles_ + 7) >> 3;
-#ifdef RP_JN_NO_XMAP
-    const bool xmap_ = false;
-#else
-    const bool xmap_ = 8 * per_xcd_ <= (int)gridDim.x;
-#endif
+    const bool xmap_ = 8 * per_xcd_ <= (int)gridDim.x; // (A/B on one box, 3,000 steps of b3d_joint_grid twice: 10,993 / 11,045 steps/s with the map, 10,841 / 10,770 without)
     if (xmap_ && ((int)blockIdx.x >> 3) >= per_xcd_) return; // (workgroups beyond the map)
     const int tile = xmap_ ? ((int)blockIdx.x & 7) * per_xcd_ + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
     const int njs = tile_joint_stages(w), substeps = w.prm.num_substeps;
