@@ -1099,36 +1099,15 @@ RP_DEV void ts_prepare(const DevWorld &w, const int pos, const int b1, const int
 }
 // the contact stages of one sweep over the cone (the stage loop of k_tile_sweep: the list entry and point count of a thread's next
 // stage are fetched while it works on the current one)
-// Rows of the NEXT stage asked for by the lanes that hold no manifold of the current one (a stage of b3d_large_pyramid keeps ~53 lane
-// pairs of 128 busy: two of the four wavefronts idle): one dword per row and manifold, the result dropped — the line is on its way
-// into the XCD's L2 while the busy wavefronts solve, so their own row loads a stage later find it there instead of going out to the fabric
-// (84 % of a sweep's row requests miss the L2: profiles/r06_large_pyramid_l2_counters.txt).  The launches' experiment with this — the
-// SAME lanes asking a stage ahead through global_load_lds — made every stage slower: the loads sat in front of the stage's own in the
-// wavefront's return queue.  Here they queue in wavefronts that have nothing else to wait for.
-// (the destination register of a hand-issued load is invisible to the compiler while the load is in flight: every touch names the SAME
-// live variable — `sink`, read-write operand — which the caller keeps alive until a vmcnt(0) wait of its own; only wavefronts without a
-// single busy lane touch, so that wait never holds up a solve)
-RP_DEV void tl_touch(const float4 *p, float &sink) { asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(p) : "memory"); }
+// (Measured and removed, round 6: the wavefronts of a stage that hold no manifold — a stage of b3d_large_pyramid keeps ~53 of 128 lane
+// pairs busy — touching the NEXT stage's rows, one dword per row and manifold through a live sink register, so that the busy wavefronts
+// would find them in the L2 a stage later.  Every stage got 2.2x SLOWER (biased 60 -> 132, relaxed 103 -> 224 us per launch): a stage is
+// bound by the row traffic it already causes, not by the latency of its first miss — the verdict of round 3's global_load_lds experiment
+// with the SAME lanes asking ahead, now confirmed with the loads in wavefronts that have nothing else to wait for.)
 template <int MODE>
-RP_DEV void ts_prefetch(const DevWorld &w, const int4 *cons, const int beg, const int cnt, const int q, const int nq, const bool friction, const int cpar, float &sink) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the touches of the stage before: long since back)
-    const bool all = MODE == MODE_RELAX || friction;
-    const int npl = all ? 48 : 26, total = cnt * npl;
-    for (int k = q; k < total; k += nq) {
-        const int pk = k / cnt, ent = k - pk * cnt; // (consecutive lanes: consecutive entries = neighbouring positions of one plane: a few lines per wavefront request)
-        int plane;
-        if (all) plane = pk < 19 ? pk : (pk == 19 ? (int)CP_B2 : (int)CP_N0 + (pk - 20)); // H0 .. T7, B2, every per-point plane
-        else if (pk < 6) plane = pk < 3 ? pk : (pk == 3 ? (int)CP_H6 : (pk == 4 ? (int)CP_HM0 : (int)CP_HM1));
-        else { const int kk = pk - 6, pt = kk / 5; plane = NPL(pt, kk - 5 * pt); } // M, A, B, C, D of every point
-        const int pos = cons[beg + ent].x;
-        tl_touch(&w.C[(size_t)cplane(plane, cpar) * w.cons_cap + pos], sink);
-    }
-}
-template <int MODE, bool PF>
 RP_DEV void ts_stages(const DevWorld &w, const int4 *cons, const int *Soff, const int nst, const int my, const int per, const bool odd, const int *Lg, float4 *Ll, float4 *La,
                       const bool friction, const float solved_dt, const int cpar, const float4 *rot, const float4 *trans) {
     int4 e_next; int n_next; bool have_next;
-    float sink = 0.0f;
     { const int i0 = Soff[0] + my; have_next = i0 < Soff[1]; e_next = cons[have_next ? i0 : 0]; n_next = w.k_n[e_next.x > 0 ? e_next.x : 0]; }
     for (int s = 0; s < nst; ++s) {
         const int end = Soff[s + 1];
@@ -1141,18 +1120,10 @@ RP_DEV void ts_stages(const DevWorld &w, const int4 *cons, const int *Soff, cons
             i += per; have = i < end;
             if (have) { e = cons[i]; n = w.k_n[e.x]; }
         }
-        if (PF) { // (wave-uniform: the wavefronts past the last busy lane)
-            const int busy = ((2 * (end - Soff[s])) + 63) & ~63, nt_ = 2 * per, t_ = 2 * my + (odd ? 1 : 0);
-            if ((t_ & ~63) >= busy) ts_prefetch<MODE>(w, cons, end, Soff[s + 2] - end, t_ - busy, nt_ - busy, friction, cpar, sink);
-        }
         n_next = w.k_n[e_next.x > 0 ? e_next.x : 0];
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // (orders the LDS velocities only: the row stores stay in flight until the next flag)
     }
-    if (PF) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); asm volatile("" :: "v"(sink)); } // (the last touches have landed: `sink` may go)
 }
-#ifndef RP_TS_PREFETCH
-#define RP_TS_PREFETCH false // (measured: the idle wavefronts touching the next stage's rows made the stages 2.2x SLOWER — 60 -> 132 / 103 -> 224 us per launch: a stage is bound by the row traffic itself, ~5.7 TB/s while the stages run, not by the latency of its first miss)
-#endif
 #define RP_TS_THREADS 256 // (512 threads — every owned manifold of phase A in one round — was measured: 256 registers per lane put the preloaded rows into scratch, phase A 10 -> 30 us)
 __global__ void __launch_bounds__(RP_TS_THREADS) k_tile_step(DevWorld w, int friction_in_bias, int stall_tile) {
     if (lean_dead(w)) return; // (the same answer in every workgroup: nothing it reads changes while a lean graph runs)
@@ -1227,7 +1198,7 @@ __global__ void __launch_bounds__(RP_TS_THREADS) k_tile_step(DevWorld w, int fri
         for (int l = n_owned + t; l < nb; l += nt) { const int g = Lg[l]; Ll[l] = ld16_t<RP_TS_SC1LD>(vs, (unsigned)g); La[l] = ld16_t<RP_TS_SC1LD>(as, (unsigned)g); }
         __syncthreads();
         TS_STAMP(5);
-        ts_stages<MODE_BIAS, RP_TS_PREFETCH>(w, cons, Soff, nst, my, per, odd, Lg, Ll, La, fib, solved_dt, par, rs, ts);
+        ts_stages<MODE_BIAS>(w, cons, Soff, nst, my, per, odd, Lg, Ll, La, fib, solved_dt, par, rs, ts);
         TS_STAMP(6);
         for (int l = t; l < n_owned; l += nt) {
             const int g = Lg[l];
@@ -1244,7 +1215,7 @@ __global__ void __launch_bounds__(RP_TS_THREADS) k_tile_step(DevWorld w, int fri
         for (int l = n_owned + t; l < nb; l += nt) { const int g = Lg[l]; Ll[l] = ld16_t<RP_TS_SC1LD>(vs, (unsigned)g); La[l] = ld16_t<RP_TS_SC1LD>(as, (unsigned)g); }
         __syncthreads();
         TS_STAMP(9);
-        ts_stages<MODE_RELAX, RP_TS_PREFETCH>(w, cons, Soff, nst, my, per, odd, Lg, Ll, La, true, solved_dt + w.prm.dt_sub, par ^ 1, rs, ts);
+        ts_stages<MODE_RELAX>(w, cons, Soff, nst, my, per, odd, Lg, Ll, La, true, solved_dt + w.prm.dt_sub, par ^ 1, rs, ts);
         TS_STAMP(10);
         for (int l = t; l < n_owned; l += nt) { const int g = Lg[l]; st16_sc1(vt, (unsigned)g, Ll[l]); st16_sc1(at, (unsigned)g, La[l]); }
         { float4 *a = vs; vs = vt; vt = a; a = as; as = at; at = a; }
