@@ -560,6 +560,14 @@ def test_tile_step_launch_substep_counts(monkeypatch, override):
     else: assert c["tile_step_steps"] == 0, c
 
 
+@pytest.mark.parametrize("target", [3, 4000])
+def test_tile_step_launch_on_the_largest_and_the_smallest_tiles(monkeypatch, target):
+    """8 tiles of 256 bodies (every tile owns ~750 manifolds: three rounds of phase A, two rounds of phase B per half) and the smallest
+    tiles the builder makes (64 bodies: many neighbours per tile)"""
+    g, o, c = _run(S.large_pyramid(60), [2, 12, 60, 110], monkeypatch, RP_TILE_TARGET=target)
+    assert c["tile_step_steps"] > 60, c
+
+
 def test_tile_step_launch_in_a_churning_pile_with_islands_coming_and_going(monkeypatch):
     """tumbling cuboids and balls: debris leaves the pile and forms islands of its own (k_tile_step runs in worlds without an LDS island:
     a step planned on a stale hint dies before it commits anything and is resumed on the sweep launches), pairs begin and end all the time"""
