@@ -179,6 +179,7 @@ RP_DEV void isl_pose_stage(const DevWorld &w, IslSide &h, const IslLds &L, int m
 #define WS_SLOTS 11   // per lane: 4 x (lin, ang) point terms, tangent lin, tangent ang, twist ang
 #define WS_SLOTS_2PHASE 6 // the two-phase form (dense variant of the kernel): the linear terms (5 slots), then — same rows — the angular ones (6)
 #define WS_STRIDE (ISL_LANES + 2) // rows of one slot: every lane's row + two scratch rows for world-attached sides
+#include "rp_coulomb_pair.h"      // FrictionModel::Coulomb by the lane pair: 16 dense rows (its own generate / pose stage / terms / solve / write-back)
 // every term at once (11 slots); the register-lean form of the kernel writes the linear and the angular terms in two phases into 6 slots
 // (lean_ws_terms, rp_islands_lean.h: 31 KB of LDS instead of 57 KB, which is what lets two islands share a CU)
 // DENSE: every one of the 11 rows is written — the rows of points a manifold does not have (and the twist row of a one-point manifold)
@@ -269,8 +270,8 @@ RP_DEV void isl_ws_accumulate_ang(const float4 *W, int begin, int count, V3 &ang
     }
 }
 
-// apply_restitution (:568-597)
-RP_DEV void isl_restitution(IslSide &h, const IslLds &L) {
+// apply_restitution (:568-597; the Coulomb model's is the same sweep over its normal parts, contact_with_coulomb_friction.rs:520-559)
+template <class Side> RP_DEV void isl_restitution(Side &h, const IslLds &L) {
     bool any = false;
 #pragma unroll
     for (int k = 0; k < 4; ++k) { if (k >= h.n) break; any |= dppf<DPP_FROM_EVEN>(h.P[k].seed) < 0.0f; }
@@ -279,7 +280,7 @@ RP_DEV void isl_restitution(IslSide &h, const IslLds &L) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (k >= h.n) break;
-        SidePoint &p = h.P[k];
+        auto &p = h.P[k];
         float X = dot(h.dir, v.lin), Y = dot(p.pa, v.ang);
         float S = X + Y;
         float dvel = S - dppf<DPP_FROM_ODD>(X) + dppf<DPP_FROM_ODD>(Y) + p.seed;

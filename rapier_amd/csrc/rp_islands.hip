@@ -541,7 +541,7 @@ __global__ void __launch_bounds__(1024) k_layout_rebuild(DevWorld w) {
 // grid arrivals, the first aborted step ends the launch for every workgroup at the same step, FL_STEP advances by the steps committed
 // and the host replays the rest on the full graph.  Needs one island per workgroup at most, and islands whose pairs name no body of
 // ANOTHER island (a workgroup may read another one's bodies only across a kernel boundary): otherwise the launch runs one step.
-template <bool WIDE> __device__ __forceinline__ void island_solve_body(const DevWorld &w, int has_restitution, int fast, int retire, int fused, int nsteps = 1) {
+template <bool WIDE, bool COUL = false> __device__ __forceinline__ void island_solve_body(const DevWorld &w, int has_restitution, int fast, int retire, int fused, int nsteps = 1) {
     constexpr int THREADS = ISL_THREADS;
     const bool aborted = (fast && w.flags[FL_FAST_ABORT]) || lean_dead(w); // fast graph gave up on this step (rp_api.hip) / dead lean step (rp_world.h)
     if (retire && blockIdx.x == 0) {
@@ -587,9 +587,9 @@ template <bool WIDE> __device__ __forceinline__ void island_solve_body(const Dev
     }
     bool decided = !fused, go = true;
     __shared__ float4 B_lin[RP_ISL_NB_MAX], B_ang[RP_ISL_NB_MAX], B_rot[RP_ISL_NB_MAX], B_trans[RP_ISL_NB_MAX], B_axes[RP_ISL_NB_MAX];
-    __shared__ float4 L_E[4 * RP_ISL_NC_MAX], L_F[4 * RP_ISL_NC_MAX], L_B0[RP_ISL_NC_MAX], L_B1[RP_ISL_NC_MAX];
+    __shared__ float4 L_E[4 * RP_ISL_NC_MAX], L_F[4 * RP_ISL_NC_MAX], L_B0[COUL ? 1 : RP_ISL_NC_MAX], L_B1[COUL ? 1 : RP_ISL_NC_MAX]; // (the Coulomb model has no friction centre)
     __shared__ int S_a[RP_ISL_NC_MAX], S_b[RP_ISL_NC_MAX], S_c[RP_ISL_NC_MAX], S_d[RP_ISL_NC_MAX];
-    __shared__ float4 W[WS_SLOTS * WS_STRIDE];
+    __shared__ float4 W[(COUL ? WS_SLOTS_COUL : WS_SLOTS) * WS_STRIDE];
     __shared__ int any_bouncy;
 
     const int t = threadIdx.x, m = t >> 1;
@@ -692,7 +692,7 @@ template <bool WIDE> __device__ __forceinline__ void island_solve_body(const Dev
         if (t == 0) any_bouncy = 0;
         __syncthreads();
         ISL_STAMP(0); // body load + list
-        IslSide h;
+        typename std::conditional<COUL, IslSideC, IslSide>::type h; // the lane's half of its manifold: rp_lanepair.h (twist model) / rp_coulomb_pair.h
         h.n = 0; h.id = -1; h.odd = odd; h.cids = 0;
         // ---- generate (S1) by the lane pair, pose stage for the initial poses ----
         if (live) {
@@ -723,7 +723,7 @@ template <bool WIDE> __device__ __forceinline__ void island_solve_body(const Dev
             float solved_dt = (float)sub * w.prm.dt_sub;
             // S2 increment (worker.rs:235-284) by the body threads, side by side with the warm-start terms of every manifold ...
             V3 inc_v = v3(0, 0, 0);
-            if (live) isl_ws_terms<true>(w, h, W, ws_row);
+            if (live) { if constexpr (COUL) isl_ws_terms_coul(w, h, W, ws_row); else isl_ws_terms<true>(w, h, W, ws_row); }
             else if (role_lin) inc_v = v3(B_lin[bt]) + b_inc;
             else if (role_ang) { // (body_increment's angular half: ang + inca, then gyroscopic_corrected_angvel with the hoisted operands)
                 inc_v = v3(B_ang[bt]) + b_inc;
@@ -734,10 +734,10 @@ template <bool WIDE> __device__ __forceinline__ void island_solve_body(const Dev
             ISL_STAMP(sub == 0 ? 12 : 2); // warm-start terms + increment (substep 0: + whatever the validating wavefronts still have to do)
             // ... then the warm start of this body in sweep order
             if (role_lin) {
-                if (prm.warmstart_coefficient != 0.0f) isl_ws_accumulate_lin_dense(W, inc_begin, inc_cnt, inc_v);
+                if (prm.warmstart_coefficient != 0.0f) { if constexpr (COUL) isl_ws_accumulate_lin_coul(W, inc_begin, inc_cnt, inc_v); else isl_ws_accumulate_lin_dense(W, inc_begin, inc_cnt, inc_v); }
                 B_lin[bt] = f4(inc_v, 0.0f);
             } else if (role_ang) {
-                if (prm.warmstart_coefficient != 0.0f) isl_ws_accumulate_ang_dense(W, inc_begin, inc_cnt, inc_v);
+                if (prm.warmstart_coefficient != 0.0f) { if constexpr (COUL) isl_ws_accumulate_ang_coul(W, inc_begin, inc_cnt, inc_v); else isl_ws_accumulate_ang_dense(W, inc_begin, inc_cnt, inc_v); }
                 B_ang[bt] = f4(inc_v, 0.0f);
             }
             __syncthreads();
@@ -837,6 +837,11 @@ __global__ void __launch_bounds__(ISL_THREADS) k_island_solve(DevWorld w, int ha
 __global__ void __launch_bounds__(ISL_THREADS) k_island_solve_steps(DevWorld w, int has_restitution, int nsteps) { island_solve_body<false>(w, has_restitution, 1, 1, 1, nsteps); }
 // the same kernel with the WIDE validators (rp_island_stages.h): worlds with compound bodies or sleeping enabled
 __global__ void __launch_bounds__(ISL_THREADS) k_island_solve_wide(DevWorld w, int has_restitution, int fast, int retire, int fused) { island_solve_body<true>(w, has_restitution, fast, retire, fused); }
+// FrictionModel::Coulomb in the same kernel (round 6): the lane pair holds ContactWithCoulombFriction (rp_coulomb_pair.h) in registers
+// — 16 warm-start rows per lane instead of 11 (82 KB of W), one island per CU like the twist form, the same fused / several-steps protocol
+__global__ void __launch_bounds__(ISL_THREADS) k_island_solve_coul(DevWorld w, int has_restitution, int fast, int retire, int fused) { island_solve_body<false, true>(w, has_restitution, fast, retire, fused); }
+__global__ void __launch_bounds__(ISL_THREADS) k_island_solve_coul_steps(DevWorld w, int has_restitution, int nsteps) { island_solve_body<false, true>(w, has_restitution, 1, 1, 1, nsteps); }
+__global__ void __launch_bounds__(ISL_THREADS) k_island_solve_coul_wide(DevWorld w, int has_restitution, int fast, int retire, int fused) { island_solve_body<true, true>(w, has_restitution, fast, retire, fused); }
 // ---- the generic island kernel ----------------------------------------------------------------------------------------------------
 // One workgroup = one island, like k_island_solve, but the constraint is the HBM-resident one of the global path (rp_constraint.h /
 // rp_coulomb.h through an accessor): thread m owns manifold m for the whole step, so its constraint planes are private to the
@@ -980,6 +985,7 @@ int rp_fused_grid(int device) {
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_island_solve, ISL_THREADS, 0) != hipSuccess) per_cu = 0;
     { int pw = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pw, k_island_solve_wide, ISL_THREADS, 0) != hipSuccess) pw = 0; if (pw < per_cu) per_cu = pw; }
+    { int pc = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, k_island_solve_coul_wide, ISL_THREADS, 0) != hipSuccess) pc = 0; if (pc < per_cu) per_cu = pc; } // (111 KB of LDS: one per CU, like the twist forms)
     if (per_cu < 1 || cus < 1) return 0;
     if (per_cu > 2) per_cu = 2; // more co-resident islands per CU than this only slow each other down
     int g = cus * per_cu - (cus + 15) / 16;
@@ -990,12 +996,18 @@ int rp_fused_grid(int device) {
 void rp_launch_island_solve_dense(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast, int retire, int fused, int wide);
 void rp_launch_island_solve_dense_steps(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int nsteps); // rp_islands_lean.hip
 void rp_launch_island_solve_steps(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int nsteps, int dense) {
+    if (w.prm.p.friction_model == RP_FRICTION_COULOMB) { hipLaunchKernelGGL(k_island_solve_coul_steps, dim3(grid < 1 ? 1 : grid), dim3(ISL_THREADS), 0, st, w, has_restitution, nsteps); return; }
     if (dense) { rp_launch_island_solve_dense_steps(w, st, grid, has_restitution, nsteps); return; }
     hipLaunchKernelGGL(k_island_solve_steps, dim3(grid < 1 ? 1 : grid), dim3(ISL_THREADS), 0, st, w, has_restitution, nsteps);
 }
 void rp_launch_island_solve(const DevWorld &w, hipStream_t st, int grid, int has_restitution, int fast, int retire, int fused, int dense, int wide) {
     if (grid < 1) grid = 1;
-    if (w.prm.p.friction_model == RP_FRICTION_COULOMB) { hipLaunchKernelGGL(k_island_generic<true>, dim3(grid), dim3(ISL_GEN_THREADS), 0, st, w, has_restitution, fast, retire); return; }
+    if (w.prm.p.friction_model == RP_FRICTION_COULOMB) { // (no register-lean form of the Coulomb pair: `dense` is never planned for this model, rp_api_step.inc)
+        if (w.isl_generic) hipLaunchKernelGGL(k_island_generic<true>, dim3(grid), dim3(ISL_GEN_THREADS), 0, st, w, has_restitution, fast, retire); // RP_ISL_GENERIC=1: rows in HBM, one lane per manifold (A/B, tests)
+        else if (wide) hipLaunchKernelGGL(k_island_solve_coul_wide, dim3(grid), dim3(ISL_THREADS), 0, st, w, has_restitution, fast, retire, fused);
+        else hipLaunchKernelGGL(k_island_solve_coul, dim3(grid), dim3(ISL_THREADS), 0, st, w, has_restitution, fast, retire, fused);
+        return;
+    }
     if (w.isl_generic) { hipLaunchKernelGGL(k_island_generic<false>, dim3(grid), dim3(ISL_GEN_THREADS), 0, st, w, has_restitution, fast, retire); return; } // RP_ISL_GENERIC=1: the twist model through the generic kernel (tests)
     if (dense) rp_launch_island_solve_dense(w, st, grid, has_restitution, fast, retire, fused, wide); // rp_islands_lean.hip
     else if (wide) hipLaunchKernelGGL(k_island_solve_wide, dim3(grid), dim3(ISL_THREADS), 0, st, w, has_restitution, fast, retire, fused);

@@ -892,7 +892,8 @@ def test_revolute_and_fixed_joints_bit_exact():
     assert np.linalg.norm(pos[w2, :3] - pos[w1, :3]) == pytest.approx(1.2, abs=2e-3)                       # the weld holds
 
 
-# ---- FrictionModel::Coulomb (SURVEY §8a SV1 twin): rp_coulomb.h on the global path vs the oracle ----
+# ---- FrictionModel::Coulomb (SURVEY §8a SV1 twin): rp_coulomb_pair.h in k_island_solve_coul (islands), rp_coulomb.h on the global path and
+# in k_island_generic (RP_ISL_GENERIC=1) vs the oracle ----
 def _coulomb(scene):
     scene.params["friction_model"] = S.FRICTION_COULOMB
     return scene
@@ -912,9 +913,15 @@ def test_coulomb_friction_bit_exact():
 
 
 def test_coulomb_multi_mode_and_model_switch():
-    """Full-size b3d_many_pyramids under Coulomb friction: 196 islands on k_island_generic (one workgroup per island)."""
-    g, o = _compare(_coulomb(S.many_pyramids()), [1, 5, 30])
-    assert g.counters()["num_manifolds"] == 28420
+    """Full-size b3d_many_pyramids under Coulomb friction: 196 islands on k_island_solve_coul (one workgroup per island, the lane pair
+    of rp_coulomb_pair.h), fused steps and launches of several steps included; 300 steps against the 16-thread oracle."""
+    of = _oracle_threads()
+    try:
+        g, o = _compare(_coulomb(S.many_pyramids()), [1, 5, 30, 300])
+    finally:
+        of.set_threads(1)
+    c = g.counters()
+    assert c["num_manifolds"] == 28420 and c["fused_steps"] > 200 and c["replayed_steps"] == 0, c
     # switching the model on a live world rebuilds the device world from the current state and keeps simulating
     sc = S.pyramid10()
     w = PhysicsWorld.from_scene(sc)
@@ -937,6 +944,16 @@ def test_coulomb_islands_next_to_a_global_component():
             sc.add_collider(b, half_extents=(0.5, 0.5, 0.5))
     g, o = _compare(sc, [1, 10, 60, 150])
     assert g.counters()["num_manifolds"] > 580 + 400
+
+
+def test_coulomb_model_through_the_generic_island_kernel(monkeypatch):
+    """RP_ISL_GENERIC=1: the Coulomb islands on k_island_generic<true> (rows in HBM, one lane per manifold — the form of rounds 2-5, kept
+    as the A/B of the lane pair): same bits."""
+    monkeypatch.setenv("RP_ISL_GENERIC", "1")
+    g, o = _compare(_coulomb(S.pyramid10()), [1, 10, 100])
+    assert g.counters()["fused_steps"] == 0
+    _compare(_coulomb(S.many_pyramids(rows=2, cols=2)), [1, 5, 40])
+    _compare(_coulomb(S.tumble(40, seed=11)), [1, 30, 90])
 
 
 def test_twist_model_through_the_generic_island_kernel(monkeypatch):
