@@ -231,6 +231,7 @@ struct rp_world {
     long long rebases = 0;
     long long seq_enqueued = 0;    // step graphs enqueued since finalize (device FL_SEQ counts the retired ones)
     long long full_until = 0;      // stay on the full graph until this many steps were requested
+    long long hints_from_seq = 0; bool hints_from_seq_valid = false; // hints published by launches before this sequence number are stale (step_once)
     long long eager_until = 0;     // launch the kernels directly until this many steps were requested: a world that is being edited (bodies /
                                    // colliders / joints coming and going every few steps) would re-capture its graphs — ~10 ms — after every edit
     long long fast_steps = 0, full_steps = 0, replayed_steps = 0, fused_steps = 0; int fused_disabled = 0, jn_disabled = 0;

@@ -543,6 +543,11 @@ __global__ void __launch_bounds__(1024) k_layout_rebuild(DevWorld w) {
 // ANOTHER island (a workgroup may read another one's bodies only across a kernel boundary): otherwise the launch runs one step.
 template <bool WIDE, bool COUL = false> __device__ __forceinline__ void island_solve_body(const DevWorld &w, int has_restitution, int fast, int retire, int fused, int nsteps = 1) {
     constexpr int THREADS = ISL_THREADS;
+    // `fused` bit 1 / `nsteps` bit 16 (the host sets them while aborts are recent, step_once): ask for the verdict on a step EARLY — a lane
+    // without work polls FL_ARRIVE in substep 0's pose stage, and a step some workgroup has aborted ends at the top of substep 1 instead of
+    // behind its last relaxed sweep: a doomed step then costs a third of a step (a shard of C4 aborts every third step: its pyramids creep)
+    const bool early_poll = ((fused & 2) != 0) || ((nsteps & (1 << 16)) != 0);
+    fused &= 1; nsteps &= 0xffff;
     const bool aborted = (fast && w.flags[FL_FAST_ABORT]) || lean_dead(w); // fast graph gave up on this step (rp_api.hip) / dead lean step (rp_world.h)
     if (retire && blockIdx.x == 0) {
         // SINGLE mode: workgroup 0 retires the step and publishes the scalars to the host hint buffer
@@ -730,6 +735,7 @@ template <bool WIDE, bool COUL = false> __device__ __forceinline__ void island_s
                 if (b_fl & RP_BF_GYRO) inc_v = gyro_corrected(inc_v, q4(B_axes[bt]), b_pi, b_invpi, w.prm.dt_sub);
             }
             __syncthreads(); // + pose stage read rot/trans; relax sweep of the previous substep done
+            if (early_poll && sub == 1 && !decided && s_early == 2) { go = false; decided = true; break; } // (written in substep 0's pose stage, barriers ago; uniform)
             if (fused && sub == 0 && isl == (int)blockIdx.x && t == 0) atomicAdd((unsigned *)&w.flags[FL_ARRIVE], 1u + ((s_abort || (WIDE && fused_sleep_abort(s_slp))) ? ab_one : 0u)); // this workgroup validated all of its islands (for this step)
             ISL_STAMP(sub == 0 ? 12 : 2); // warm-start terms + increment (substep 0: + whatever the validating wavefronts still have to do)
             // ... then the warm start of this body in sweep order
@@ -758,18 +764,20 @@ template <bool WIDE, bool COUL = false> __device__ __forceinline__ void island_s
             ISL_STAMP(5); // integrate
             if (live) isl_pose_stage(w, h, L, m, solved_dt + w.prm.dt_sub);
             else if (role_ang && (b_fl & RP_BF_GYRO)) B_axes[bt] = f4(qmul(q4(B_rot[bt]), b_pframe)); // (the next substep's increment; rot stands until the next integrate)
-            else if (fused && !decided && t == THREADS - 1 && sub == w.prm.num_substeps - 1 && isl == (int)blockIdx.x) {
+            else if (fused && !decided && t == THREADS - 1 && (sub == w.prm.num_substeps - 1 || (early_poll && sub == 0)) && isl == (int)blockIdx.x && s_early == 0) {
                 // the verdict on this step, asked for EARLY by a lane that has nothing else to do: every workgroup arrived long ago (it does
                 // so in substep 0), so the one L2 round trip of the commit poll hides behind the last relaxed sweep instead of following it
+                // (early_poll: also in substep 0 — an abort standing by then is final whatever the count, and ends the step at the top of substep 1)
                 const unsigned v = __hip_atomic_load((unsigned *)&w.flags[FL_ARRIVE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((v & 0xffffu) >= (unsigned)arrive_target) s_early = ((v >> ab_shift) & 0xffu) == 0 ? 1 : 2; // complete: final either way
+                if (((v >> ab_shift) & 0xffu) != 0) s_early = 2;                        // an abort of THIS step: final
+                else if ((v & 0xffffu) >= (unsigned)arrive_target) s_early = 1;         // complete and clean: final
             }
             ISL_STAMP(6); // pose stage
             for (int it = 0; it < prm.num_internal_stabilization_iterations; ++it)
                 for (int q = 0; q < nls; ++q) { if (myq == q) isl_solve(h, L, true, true); __syncthreads(); }
             ISL_STAMP(7); // relax sweep
         }
-        if (has_restitution && any_bouncy)
+        if (go && has_restitution && any_bouncy)
             for (int q = 0; q < nls; ++q) { if (myq == q) isl_restitution(h, L); __syncthreads(); }
         // ---- write-back (S9, S10, advance_to_final_positions) ----
         if (!decided) { // fused: nothing leaves the workgroup before every workgroup validated its islands

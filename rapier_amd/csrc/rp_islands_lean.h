@@ -365,6 +365,8 @@ struct LeanLds { // per island
 // `nsteps`: several fused steps in one launch, exactly as in island_solve_body (rp_islands.hip: per-step validate / arrive / commit on
 // cumulative counts, abort fields by step parity, one island PAIR per workgroup at most, no pair into another island).
 template <bool WIDE> __device__ __forceinline__ void island_solve_lean(const DevWorld &w, int has_restitution, int fast, int retire, int fused, int nsteps = 1) {
+    const bool early_poll = ((fused & 2) != 0) || ((nsteps & (1 << 16)) != 0); // the verdict on a step asked for in substep 0 already (island_solve_body, rp_islands.hip)
+    fused &= 1; nsteps &= 0xffff;
     const bool aborted = (fast && w.flags[FL_FAST_ABORT]) || lean_dead(w);
     if (retire && blockIdx.x == 0) {
         if (threadIdx.x == 0) { w.flags[FL_SEQ] += (fused && nsteps > 1) ? nsteps : 1; if (!aborted && !fused) w.flags[FL_STEP] += 1; if (fused) w.flags[FL_FULL_UPDATES] = 0; }
@@ -372,8 +374,8 @@ template <bool WIDE> __device__ __forceinline__ void island_solve_lean(const Dev
         publish_flags(w);
     }
     if (aborted) return;
-    __shared__ int s_abort, s_go, s_slp[2], s_cross;
-    if (threadIdx.x == 0) s_cross = 0;
+    __shared__ int s_abort, s_go, s_slp[2], s_cross, s_early;
+    if (threadIdx.x == 0) { s_cross = 0; s_early = 0; }
     __shared__ LeanLds LD[2];
     __shared__ int S_a[RP_ISL_NC_MAX], S_b[RP_ISL_NC_MAX], S_c[RP_ISL_NC_MAX], S_d[RP_ISL_NC_MAX];
     const int n_islands = w.flags[FL_N_ISLANDS];
@@ -423,7 +425,7 @@ template <bool WIDE> __device__ __forceinline__ void island_solve_lean(const Dev
     const unsigned ab_one = 1u << ab_shift;
     if (step > 0) {
         decided = false;
-        if (threadIdx.x == 0) { s_abort = s_cross; s_slp[0] = 0; s_slp[1] = 0; }
+        if (threadIdx.x == 0) { s_abort = s_cross; s_slp[0] = 0; s_slp[1] = 0; s_early = 0; }
         __syncthreads();
     }
     if (ns > 1 && 2 * (int)blockIdx.x >= n_islands) { // a workgroup without an island follows the protocol of every step
@@ -510,6 +512,7 @@ template <bool WIDE> __device__ __forceinline__ void island_solve_lean(const Dev
             if (sub == 0) __syncthreads(); // generate's rows of W have been read back by their lanes
             if (live) lean_ws_terms<1>(w, h, D.W, ws_row);
             __syncthreads();
+            if (early_poll && sub == 1 && !decided && s_early == 2) { go = false; decided = true; break; } // (an abort seen in substep 0's pose stage: uniform, barriers ago)
             if (fused && sub == 0 && base == 2 * (int)blockIdx.x && threadIdx.x == 0) atomicAdd((unsigned *)&w.flags[FL_ARRIVE], 1u + ((s_abort || (WIDE && (fused_sleep_abort(s_slp[0]) || fused_sleep_abort(s_slp[1])))) ? ab_one : 0u)); // this workgroup validated all of its islands
             ISL_STAMP(2);
             if (role_lin) { // S2 increment (worker.rs:235-284), then the warm start of this body in sweep order
@@ -541,12 +544,17 @@ template <bool WIDE> __device__ __forceinline__ void island_solve_lean(const Dev
             __syncthreads();
             ISL_STAMP(5);
             if (live) lean_pose_stage(w, h, L, m, solved_dt + w.prm.dt_sub);
+            else if (early_poll && fused && !decided && sub == 0 && threadIdx.x == LEAN_THREADS - 1 && base == 2 * (int)blockIdx.x) {
+                // (a validating lane, idle by now: is an abort of this step standing?  Then the step ends at the top of substep 1)
+                const unsigned v = __hip_atomic_load((unsigned *)&w.flags[FL_ARRIVE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (((v >> ab_shift) & 0xffu) != 0) s_early = 2;
+            }
             ISL_STAMP(6);
             for (int it = 0; it < prm.num_internal_stabilization_iterations; ++it)
                 for (int q = 0; q < nls; ++q) { if (myq == q) lean_solve(h, L, true); __syncthreads(); }
             ISL_STAMP(7);
         }
-        if (has_restitution && (LD[0].any_bouncy | LD[1].any_bouncy))
+        if (go && has_restitution && (LD[0].any_bouncy | LD[1].any_bouncy))
             for (int q = 0; q < nls; ++q) { if (myq == q && D.any_bouncy) lean_restitution(h, L); __syncthreads(); }
         if (!decided) { // fused: nothing leaves the workgroup before every workgroup validated its islands
 #ifdef RP_ISL_PROFILE
