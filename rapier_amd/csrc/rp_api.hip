@@ -228,7 +228,7 @@ struct rp_world {
     long long steps_requested = 0; // steps asked for since finalize (device FL_STEP counts the executed ones)
     int rebase_at = 1 << 29;       // FL_STEP beyond which the device's 32-bit step stamps move back (k_rebase_stamps); the wake stamp is 2 * step + phase and
                                    // settles that look at the counter may be 2^20 steps apart: 2 * (2^29 + 2^20) stays inside an int
-    long long rebases = 0;
+    long long rebases = 0, rebased_steps = 0; // (rebased_steps: what the stamps moved back so far — events are handed out with it added back)
     long long seq_enqueued = 0;    // step graphs enqueued since finalize (device FL_SEQ counts the retired ones)
     long long full_until = 0;      // stay on the full graph until this many steps were requested
     long long hints_from_seq = 0; bool hints_from_seq_valid = false; // hints published by launches before this sequence number are stale (step_once)

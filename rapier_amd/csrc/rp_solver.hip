@@ -284,7 +284,7 @@ __global__ void k_edit_flags(DevWorld w, int keep_grid) {
     w.flags[FL_BP_DIRTY] = 1; w.flags[FL_LAYOUT_DIRTY] = 1; w.flags[FL_JOINT_DIRTY] = 1; w.flags[FL_FLOW_DIRTY] = 1;
 }
 // The device's step stamps are 32-bit (FL_STEP and everything stamped with cur_step): long before they could wrap — the host asks for
-// it once FL_STEP passes 2^30, ~21 h at the headline rate — every stamp moves back by `delta` steps.  Stamps that are only compared for
+// it once FL_STEP passes 2^29, ~9 h at the headline rate — every stamp moves back by `delta` steps.  Stamps that are only compared for
 // EQUALITY with the step in progress (sleep observation, island marks) and lie more than delta steps back become 0 = never; the two
 // that are ORDERED against each other (a body's last fall-asleep step against the step a pair's solver hint was computed in) keep
 // their order across the line (older ones collapse onto 1: at worst a hint is recomputed once).  The sleep-scan stamp (one per step)
@@ -304,6 +304,10 @@ __global__ void k_rebase_stamps(DevWorld w, int delta) {
     int top = w.flags[FL_POOL_TOP];
     if (top > w.pool_cap) top = w.pool_cap;
     for (int s = gid; s < top; s += stride) w.p_hint_seq[s] = ord(w.p_hint_seq[s]);
+    // events still queued keep their ORDER against the ones to come: their stamps move by delta as they are (signed: an event from before
+    // the line gets a stamp <= 0; the host adds the steps moved so far when it hands events out, rp_collision_events_read)
+    if (w.ev_col) { int n = w.flags[FL_EV_COL]; if (n > w.ev_cap) n = w.ev_cap; for (int k = gid; k < n; k += stride) w.ev_col[k].w -= delta; }
+    if (w.ev_force_meta) { int n = w.flags[FL_EV_FORCE]; if (n > w.ev_cap) n = w.ev_cap; for (int k = gid; k < n; k += stride) w.ev_force_meta[k].z -= delta; }
     if (gid == 0) {
         w.flags[FL_STEP] -= delta; w.flags[FL_WAKE_STAMP] = 0;
         w.pi_w64[0] = ((unsigned long long)(unsigned)eq(scan_step) << 32) | (unsigned)(move_scan ? scan_stamp - delta : scan_stamp);

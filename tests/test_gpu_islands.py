@@ -190,6 +190,20 @@ def _rebase_body():
         assert g.sleeping().any() and g.counters()["overflow_flags"] == 0
         L = g._lib; L.rp_debug_rebases.restype = C.c_int64; L.rp_debug_rebases.argtypes = [C.c_void_p]
         assert L.rp_debug_rebases(g._ptr) > steps // 40, L.rp_debug_rebases(g._ptr)
+    # events queued ACROSS rebases keep their order and their step numbers (the queue is re-stamped with the rest, the host
+    # adds back what the stamps moved): drained only every 60 steps, compared with the oracle's list, steps included
+    sc = S.tumble(40, seed=11).enable_events(S.ACTIVE_EVENTS_COLLISION | S.ACTIVE_EVENTS_CONTACT_FORCE, 2.0)
+    g, o = PhysicsWorld.from_scene(sc), OracleWorld(sc)
+    for k in range(4):
+        for _ in range(10):
+            g.step(6); o.step(6); g.sync()                      # (the stamps move back inside settle(): let it run between batches)
+        ge = [tuple(int(x) for x in e) for e in g.collision_events()]; oe = sorted(tuple(int(x) for x in e) for e in o.collision_events())
+        assert sorted(ge) == oe and len(ge) > 0, (k, ge[:4], oe[:4])
+        assert [e[4] for e in ge] == sorted(e[4] for e in ge), "events are handed out oldest first"
+        gm, gv = g.contact_force_events(); om, ov = o.force_events()
+        go = np.lexsort((gm[:, 1], gm[:, 0], gm[:, 2])); oo = np.lexsort((om[:, 1], om[:, 0], om[:, 2]))
+        np.testing.assert_array_equal(gm[go], om[oo]); np.testing.assert_array_equal(gv[go], ov[oo])
+    assert L.rp_debug_rebases(g._ptr) > 4
 
 
 def test_step_stamps_move_back_without_a_trace():
