@@ -297,6 +297,9 @@ int32_t rp_impulse_joints_insert(rp_world *w, int32_t n, const rp_joint_desc *de
  * (impulse_joint_set.rs:235-250): axes[i] (0..5 = LinX..AngZ) of joint handles[i] gets motors[i], its motor is enabled,
  * and both bodies of the joint are woken. */
 int32_t rp_impulse_joints_set_motor(rp_world *w, int32_t n, const uint64_t *handles, const int32_t *axes, const rp_joint_motor *motors);
+/* ImpulseJointSet::get(handle) (impulse_joint_set.rs:222-233): the live descriptors of n joints — as inserted, with every
+ * rp_impulse_joints_set_motor edit since; body1 / body2 are RigidBodyHandles.  A stale or removed handle: RP_ERR_INVALID. */
+int32_t rp_impulse_joints_get(const rp_world *w, int32_t n, const uint64_t *handles, rp_joint_desc *descs_out);
 /* JointMotor::impulse of the six axes of n joints (NULL handles = all, insertion order), as written back by the last step. */
 int32_t rp_impulse_joints_read_motor_impulses(rp_world *w, int32_t n, const uint64_t *handles, float *impulse6_out);
 /* ImpulseJoint::impulses (per locked linear dof, as written back by the last step) and the persistent

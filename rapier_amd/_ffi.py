@@ -18,7 +18,7 @@ RP_INVALID_HANDLE = 0xFFFFFFFFFFFFFFFF
 SYMBOLS = [
     "rp_world_create", "rp_world_destroy", "rp_last_error", "rp_default_params", "rp_params_get",
     "rp_params_set", "rp_bodies_insert", "rp_colliders_insert", "rp_impulse_joints_insert",
-    "rp_impulse_joints_read", "rp_impulse_joints_set_motor", "rp_impulse_joints_read_motor_impulses", "rp_bodies_remove", "rp_colliders_remove", "rp_impulse_joints_remove",
+    "rp_impulse_joints_read", "rp_impulse_joints_get", "rp_impulse_joints_set_motor", "rp_impulse_joints_read_motor_impulses", "rp_bodies_remove", "rp_colliders_remove", "rp_impulse_joints_remove",
     "rp_compound_create", "rp_trimesh_create", "rp_heightfield_create",
     "rp_quarantine_read", "rp_step",
     "rp_sync", "rp_bodies_read", "rp_bodies_write", "rp_bodies_add_force", "rp_bodies_apply_impulse", "rp_bodies_wake_up", "rp_bodies_set_additional_solver_iterations", "rp_bodies_is_sleeping", "rp_bodies_persistent_island", "rp_bodies_proximity_group", "rp_world_set_shard_guard", "rp_world_shard_guard_take_hits", "rp_world_max_linear_speed", "rp_world_set_shard_guard_horizon", "rp_world_begin_subworld", "rp_step_many", "rp_bodies_handles", "rp_colliders_handles", "rp_impulse_joints_handles", "rp_convex_polyhedron_create", "rp_convex_polyhedron_read", "rp_bodies_set_next_kinematic_position", "rp_num_bodies", "rp_contacts_read",
@@ -66,6 +66,7 @@ def lib():
     L.rp_impulse_joints_insert.argtypes = [vp, i32, vp, vp]
     L.rp_impulse_joints_read.argtypes = [vp, i32, vp, vp, vp]
     L.rp_impulse_joints_set_motor.argtypes = [vp, i32, vp, vp, vp]
+    L.rp_impulse_joints_get.argtypes = [vp, i32, vp, vp]
     L.rp_impulse_joints_read_motor_impulses.argtypes = [vp, i32, vp, vp]
     L.rp_bodies_remove.argtypes = [vp, i32, vp]
     L.rp_colliders_remove.argtypes = [vp, i32, vp]

@@ -435,6 +435,33 @@ class ShardSet:
         state = {}
         for part in self.exchange({g: local[g] for g in moving if g in local}):
             state.update(part)
+        # ... and the LIVE descriptors of the impulse joints that travel with them (ImpulseJointSet::get = rp_impulse_joints_get: what was
+        # inserted plus every rp_impulse_joints_set_motor edit since; a joint the caller removed is not listed and stays removed), from
+        # the source world before its bodies — and with them their joints — are removed.  Keyed by the GLOBAL ids of the two ends; several
+        # joints between one pair keep their insertion order.  A world type without the read (the CPU oracle in the gloo tests) is not
+        # listed: its joints are re-created from the descriptors this set holds.
+        mine = {}
+        for r, w in self.worlds.items():
+            if not self.joints or not hasattr(w, "impulse_joint_descs"):
+                continue
+            rev = {int(h): g for g, h in self.handle[r].items()}
+            hs = w.joint_handles(); hs = hs[hs != np.uint64(0xFFFFFFFFFFFFFFFF)]
+            table = {}
+            for d in w.impulse_joint_descs(hs):
+                g1, g2 = rev.get(int(d["body1"])), rev.get(int(d["body2"]))
+                if g1 in moving or g2 in moving:
+                    dd = d.copy(); dd["body1"], dd["body2"] = g1, g2
+                    table.setdefault((g1, g2), []).append(dd)
+            mine[r] = table
+        live = {}
+        for part in self.exchange(mine):
+            live.update(part)
+        # a destination's guard still holds the box the arriving group had on its old rank — the group sits INSIDE it — and an insertion
+        # may run collision detection there (a world that is rebuilt around new joints does): its guard is off while the group is handed
+        # over, _refresh_guards below sets the new boxes before the next step
+        for dst in set(moves.values()):
+            if dst in self.worlds and hasattr(self.worlds[dst], "set_shard_guard"):
+                self.worlds[dst].set_shard_guard(None, None)
         for k, dst in sorted(moves.items()):
             src, gl = boxes[k][0], boxes[k][1]
             # replicated bodies (fixed, kinematic) already live on every rank: only the group's dynamic bodies change hands
@@ -461,11 +488,23 @@ class ShardSet:
                 self.owner[g] = dst
             # the group's impulse joints: removing a body dropped them at the source (RigidBodySet::remove removes attached joints);
             # the destination gets them back once both ends live there (the other end: a body of the group or a replicated one).
-            # LIMIT: they are re-created from the scene's descriptors — motor changes made at run time (rp_impulse_joints_set_motor) and
-            # the joints' warm-start impulses do not travel (the ABI hands out impulses, not descriptors): a caller that edits motors
-            # of a sharded world must re-apply them after a migration (ShardSet.migrations counts them)
+            # The descriptors are the source world's live ones (above) and replace the ones this set held, on every process alike; the
+            # joints' warm-start impulses do not travel (nor do the contacts': §7) — the first step at the destination solves them cold.
+            if self.joints:
+                moved = set(gl)
+                table = live.get(src)                                        # None: the source world cannot hand out descriptors
+                taken, kept = {}, []
+                for j in self.joints:
+                    b1, b2 = int(j["body1"]), int(j["body2"])
+                    if (b1 in moved or b2 in moved) and table is not None:
+                        i = taken.get((b1, b2), 0); taken[(b1, b2)] = i + 1
+                        if i >= len(table.get((b1, b2), [])):
+                            continue                                         # removed at run time (ImpulseJointSet::remove): it stays removed
+                        j = table[(b1, b2)][i]
+                    kept.append(j)
+                self.joints = kept
             if dst in self.worlds and self.joints:
-                moved, w = set(gl), self.worlds[dst]
+                w = self.worlds[dst]
                 row_of = {g: int(h) for g, h in self.handle[dst].items()}   # rp_joint_desc.body1 / body2 are RigidBodyHandles
                 back = []
                 for j in self.joints:

@@ -342,6 +342,15 @@ class PhysicsWorld:
         self.impulse_joints._n += len(descs)
         return out
 
+    def impulse_joint_descs(self, handles) -> np.ndarray:
+        """ImpulseJointSet::get(handle) (rp_impulse_joints_get): the live descriptors — as inserted plus every motor edit since —,
+        body1 / body2 as RigidBodyHandles."""
+        h = self._jh(handles)
+        out = np.zeros(len(h), dtype=S.JOINT_DTYPE)
+        if len(h):
+            _check(self._ptr, self._lib.rp_impulse_joints_get(self._ptr, len(h), h.ctypes.data, out.ctypes.data), "rp_impulse_joints_get")
+        return out
+
     def insert_impulse_joint(self, body1, body2, joint: np.ndarray):
         j = np.array([joint], dtype=S.JOINT_DTYPE)
         j["body1"], j["body2"] = int(body1), int(body2)   # ImpulseJointSet::insert(body1: RigidBodyHandle, body2: RigidBodyHandle, ..)
