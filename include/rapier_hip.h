@@ -224,8 +224,10 @@ typedef struct rp_counters {
     int32_t num_islands;           /* contact islands the last layout rebuild handed to the LDS-resident island kernel (a bundle of tiny islands counts once) */
     int32_t num_global_bodies;     /* awake dynamic bodies it left to the global solver path (components too large for an island, bodies with joints, free bodies) */
     int32_t fused_disabled;        /* how often a fused step waited ~1 s for a workgroup that never became resident (another process or stream
-                                    * holds CUs): that step was aborted and replayed, and from the first such event on this world no longer
-                                    * uses the one-kernel fused step (it keeps the two-kernel fast graph) — nonzero = the world lost its fastest path */
+                                    * holds CUs): that step was aborted and replayed, and this world
+                                    * holds back from the one-kernel fused step (it keeps the two-kernel fast graph) and tries it again 4,096 steps
+                                    * later, four times as many after every further loss (RP_ONE_LAUNCH_RETRY=<steps>, 0 = never) — a count that
+                                    * keeps rising = the GPU stays shared */
     int32_t fused_launches;        /* launches that carried the fused_steps: a world whose islands fit one island per workgroup takes up to 32 fused
                                     * steps per launch (k_island_solve_steps: a step boundary inside the launch is a workgroup barrier and the
                                     * next step reads what this one wrote from the CU's own caches); fused_steps / fused_launches = steps per launch */
@@ -233,7 +235,7 @@ typedef struct rp_counters {
                                     * (k_joint_net_step: worlds of spherical impulse joints without a single contact manifold — b3d_joint_grid) */
     int32_t joint_net_disabled;    /* how often a tile of that launch waited ~2 s for a neighbouring tile whose workgroup never became resident (another
                                     * process or stream holds CUs): the step died without writing anything and was resumed by the full graph, and the
-                                    * world takes the sweep launches from then on — nonzero = the world lost this path (tile_step_steps' launch counts here too) */
+                                    * world takes the sweep launches until the same retry rule brings the launch back (tile_step_steps' launch counts here too) */
     int32_t tile_step_steps;       /* of lean_steps: those whose whole TGS loop was ONE launch over the LDS tiles of a contact world (k_tile_step: the
                                     * prepare / increment / biased / relaxed launches of every substep as phases of one kernel, a tile waits for its
                                     * neighbouring tiles' flags instead of a kernel boundary — b3d_large_pyramid) */

@@ -235,6 +235,10 @@ struct rp_world {
     long long eager_until = 0;     // launch the kernels directly until this many steps were requested: a world that is being edited (bodies /
                                    // colliders / joints coming and going every few steps) would re-capture its graphs — ~10 ms — after every edit
     long long fast_steps = 0, full_steps = 0, replayed_steps = 0, fused_steps = 0; int fused_disabled = 0, jn_disabled = 0;
+    // a one-launch form lost to a workgroup that never became resident (FL_GRID_TIMEOUT / FL_JN_TIMEOUT: the GPU was shared at that moment) is
+    // tried again once this many steps were requested (-1: not waiting); every loss in a row waits four times as long (4,096 steps ... 2^22)
+    long long fused_retry_at = -1, jn_retry_at = -1, fused_backoff = 4096, jn_backoff = 4096; // (RP_ONE_LAUNCH_RETRY=<steps>: the first wait; 0 = a lost form stays lost)
+    bool retry_jn = false, retry_ts = false; // what the joint-net / tile-step loss took away (a form switched off by the environment stays off)
     // timers
     bool timers = false;
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // ([6], [7]: around the one-launch TGS loop of a timed step)
@@ -473,6 +477,7 @@ extern "C" int32_t rp_world_create(const rp_integration_params *params, const fl
     if (g && g[0] == '1') w->force_flow = true;
     if (w->use_flow) { w->flow_grid = rp_flow_grid(device); if (w->flow_grid <= 0) w->use_flow = false; }
     if (w->use_fused) { w->fused_grid = rp_fused_grid(device); if (w->fused_grid <= 0) w->use_fused = false; }
+    { const char *rs = getenv("RP_ONE_LAUNCH_RETRY"); if (rs) w->fused_backoff = w->jn_backoff = std::max(0ll, atoll(rs)); }
 #ifdef RP_TESTING
     { extern int rp_test_ts_stall_tile; const char *js = getenv("RP_TEST_TS_STALL"); rp_test_ts_stall_tile = js ? atoi(js) : -1; } // (... of k_tile_step)
     { extern int rp_test_jn_stall_tile; const char *js = getenv("RP_TEST_JN_STALL"); rp_test_jn_stall_tile = js ? atoi(js) : -1; } // (test hook: that workgroup of k_joint_net_step never arrives)

@@ -524,6 +524,23 @@ def test_a_joint_net_launch_whose_workgroup_never_arrives_dies_without_writing()
     _in_testing_build("_jn_stall_body")
 
 
+def _jn_stall_retry_body():
+    sc = S.joint_grid(40)
+    g, o, c = _run(sc, [1, 6, 40, 80], _Env(), RP_TEST_JN_STALL=3, RP_ONE_LAUNCH_RETRY=24)
+    # lost at its first launch, tried again 24 steps later (the hook stalls that launch too), the next try would come 96 steps after that
+    assert c["joint_net_disabled"] == 2 and c["replayed_steps"] >= 2 and c["overflow_flags"] == 0, c
+    assert c["lean_steps"] > c["joint_net_steps"] + 20, c
+    gc, gi = g.read_joints(); oc, oi = o.read_joints()
+    np.testing.assert_array_equal(gi, oi, err_msg="joint impulses")
+
+
+def test_a_lost_one_launch_form_is_tried_again_after_a_while():
+    """a world that lost a one-launch form to a workgroup that was not resident (the GPU was shared at that moment)
+    used to lose it for good.  Now the planner tries the form again after a number of steps (4,096; RP_ONE_LAUNCH_RETRY), four times as
+    many after every further loss; with the stall hook still on, the second try dies like the first and the run stays bit-exact"""
+    _in_testing_build("_jn_stall_retry_body")
+
+
 # ---- k_tile_step: the TGS loop of a tiled contact world as ONE launch (rp_tiles.hip, round 6) -------------------------------------------
 def test_tile_step_launch_equals_the_sweep_launches_and_the_oracle(monkeypatch):
     """a tiled pyramid with the one-launch TGS loop (k_tile_step: prepare / increment / biased / relaxed sweeps of every substep as phases
