@@ -197,7 +197,8 @@ struct rp_world {
     int graph_stages = -1, graph_blocks = -1, graph_single = -1, graph_island_grid = -1, graph_dense = -1, graph_wide = -1, graph_joint_stages = -1, graph_no_global = -1, graph_fused = -1, graph_tile_grid = -1, graph_no_contacts = -1, graph_bare = -1, graph_jn = -1, graph_ts = -1;
     bool use_graph = true, use_fast = true, use_fused = true;
     long long last_periodic_settle = 0;
-    long long clean_fast_steps = 0; // fast steps enqueued since the host last saw an aborted one (step_once: how many steps a launch may carry)
+    long long clean_fast_steps = 64; // fast steps enqueued since the host last saw an aborted one (step_once: how many steps a launch may carry); a world that has
+                                     // not aborted yet counts as clean (a 20-step call of a settled world is ONE launch, not a ramp of seven)
     bool replaying = false;         // settle() is replaying steps that were requested before: step_once must not count them again
     bool use_multi = true; int cur_multi = 1; long long multi_launches = 0, fused_launches = 0, jn_steps = 0, ts_steps = 0; // launches of several fused steps (k_island_solve_steps): allowed / steps of the launch being enqueued
     bool auto_dense = true;        // RP_ISL_DENSE=0: never
