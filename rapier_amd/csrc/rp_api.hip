@@ -197,8 +197,10 @@ struct rp_world {
     int graph_stages = -1, graph_blocks = -1, graph_single = -1, graph_island_grid = -1, graph_dense = -1, graph_wide = -1, graph_joint_stages = -1, graph_no_global = -1, graph_fused = -1, graph_tile_grid = -1, graph_no_contacts = -1, graph_bare = -1, graph_jn = -1, graph_ts = -1;
     bool use_graph = true, use_fast = true, use_fused = true;
     long long last_periodic_settle = 0;
-    long long clean_fast_steps = 64; // fast steps enqueued since the host last saw an aborted one (step_once: how many steps a launch may carry); a world that has
-                                     // not aborted yet counts as clean (a 20-step call of a settled world is ONE launch, not a ramp of seven)
+    bool dense_seen = false;         // the register-lean island kernel was planned at least once (step_once: such a world starts wary)
+    bool abort_seen = false;         // a fast step aborted and fewer than 1,024 clean fast steps went by since (step_once)
+    long long clean_fast_steps = 40; // fast steps enqueued since the host last saw an aborted one (step_once: how many steps a launch may carry); a world that has
+                                     // not aborted yet counts as fairly clean (40: a 20-step call of a settled world is ONE launch, not a ramp of seven)
     bool replaying = false;         // settle() is replaying steps that were requested before: step_once must not count them again
     bool use_multi = true; int cur_multi = 1; long long multi_launches = 0, fused_launches = 0, jn_steps = 0, ts_steps = 0; // launches of several fused steps (k_island_solve_steps): allowed / steps of the launch being enqueued
     bool auto_dense = true;        // RP_ISL_DENSE=0: never
@@ -477,6 +479,7 @@ extern "C" int32_t rp_world_create(const rp_integration_params *params, const fl
     g = getenv("RP_FLOW");
     if (g && g[0] == '1') w->force_flow = true;
     if (w->use_flow) { w->flow_grid = rp_flow_grid(device); if (w->flow_grid <= 0) w->use_flow = false; }
+    if (getenv("RP_LAUNCH_RAMP")) w->clean_fast_steps = 0;
     if (w->use_fused) { w->fused_grid = rp_fused_grid(device); if (w->fused_grid <= 0) w->use_fused = false; }
     { const char *rs = getenv("RP_ONE_LAUNCH_RETRY"); if (rs) w->fused_backoff = w->jn_backoff = std::max(0ll, atoll(rs)); }
 #ifdef RP_TESTING
